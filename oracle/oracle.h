@@ -1,0 +1,30 @@
+/* oracle/oracle.h -- TEST INFRASTRUCTURE ONLY: C interface of the CPU restatement of the
+ * reference's hot path (see each .c file for the reference file:line it follows). */
+#ifndef DIAMOND_ORACLE_H
+#define DIAMOND_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ORACLE_OK = 0, ORACLE_ERR_ARG = -1, ORACLE_ERR_TRACEBACK = -2, ORACLE_ERR_CAP = -3 };
+enum { ORACLE_SCORE_ONLY = 0, ORACLE_COORDS = 1, ORACLE_TRACEBACK = 2, ORACLE_STATS_FWD = 3, ORACLE_STATS_BWD = 4 };
+
+typedef struct {
+	int32_t score, max_col, max_band_row, cols;
+	int32_t q_begin, q_end, s_begin, s_end;
+	int32_t length, identities, mismatches, positives, gap_openings, gaps;
+	int32_t transcript_len;
+} oracle_hsp;
+
+int oracle_banded_cols(int qlen, int tlen, int d_begin, int d_end);
+
+int oracle_banded_swipe(const int8_t* query, int qlen, const int8_t* cbs,
+	const int8_t* target, int tlen, int d_begin, int d_end,
+	const int8_t* matrix8, int gap_open, int gap_extend, int mode,
+	oracle_hsp* out, uint8_t* transcript, int transcript_cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
