@@ -1,0 +1,62 @@
+"""ctypes binding of the deterministic synthetic workload generator (csrc/synth.c)."""
+import ctypes
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class _Cfg(ctypes.Structure):
+    _fields_ = [("seed", ctypes.c_uint64), ("families", ctypes.c_int64), ("members", ctypes.c_int),
+                ("queries", ctypes.c_int64), ("decoy_frac", ctypes.c_double),
+                ("len_mean", ctypes.c_double), ("len_sd", ctypes.c_double),
+                ("len_min", ctypes.c_int), ("len_max", ctypes.c_int),
+                ("sub_lo", ctypes.c_double), ("sub_hi", ctypes.c_double),
+                ("q_lo", ctypes.c_double), ("q_hi", ctypes.c_double), ("indel", ctypes.c_double)]
+
+
+def _lib():
+    path = os.path.join(_HERE, "libdmnd_synth.so")
+    if not os.path.exists(path):
+        raise RuntimeError("libdmnd_synth.so missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = ctypes.CDLL(path)
+    lib.synth_generate.restype = ctypes.c_int
+    lib.synth_write_fasta.restype = ctypes.c_int
+    return lib
+
+
+def generate(families, members=10, queries=1000, seed=20260923, decoy_frac=0.05, len_mean=300.0, len_sd=80.0,
+             len_min=50, len_max=2000, sub=(0.1, 0.6), qsub=(0.2, 0.5), indel=0.02):
+    """Returns (db_letters int8[], db_offsets int64[n+1], q_letters, q_offsets)."""
+    lib = _lib()
+    cfg = _Cfg(seed, families, members, queries, decoy_frac, len_mean, len_sd, len_min, len_max,
+               sub[0], sub[1], qsub[0], qsub[1], indel)
+    dd = ctypes.POINTER(ctypes.c_int8)()
+    do = ctypes.POINTER(ctypes.c_int64)()
+    qd = ctypes.POINTER(ctypes.c_int8)()
+    qo = ctypes.POINTER(ctypes.c_int64)()
+    dn = ctypes.c_int64()
+    qn = ctypes.c_int64()
+    rc = lib.synth_generate(ctypes.byref(cfg), ctypes.byref(dd), ctypes.byref(do), ctypes.byref(dn),
+                            ctypes.byref(qd), ctypes.byref(qo), ctypes.byref(qn))
+    if rc != 0:
+        raise MemoryError("synth_generate failed")
+    try:
+        db_off = np.ctypeslib.as_array(do, shape=(dn.value + 1,)).copy()
+        q_off = np.ctypeslib.as_array(qo, shape=(qn.value + 1,)).copy()
+        db = np.ctypeslib.as_array(dd, shape=(int(db_off[-1]),)).copy()
+        q = np.ctypeslib.as_array(qd, shape=(int(q_off[-1]),)).copy()
+    finally:
+        for p in (dd, do, qd, qo):
+            lib.synth_free(p)
+    return db, db_off, q, q_off
+
+
+def write_fasta(path, prefix, data, off):
+    lib = _lib()
+    data = np.ascontiguousarray(data, dtype=np.int8)
+    off = np.ascontiguousarray(off, dtype=np.int64)
+    rc = lib.synth_write_fasta(path.encode(), prefix.encode(), data.ctypes.data_as(ctypes.POINTER(ctypes.c_int8)),
+                               off.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), ctypes.c_int64(len(off) - 1))
+    if rc != 0:
+        raise OSError("cannot write " + path)

@@ -241,3 +241,48 @@ int oracle_banded_swipe(const int8_t* query, int qlen, const int8_t* cbs,
 	free(hgap); free(score); free(sa); free(sb); free(ha); free(hb); free(trace);
 	return rc;
 }
+
+/* The "stats without traceback" path: forward pass with ForwardCell, then
+ * recompute_reversed() -- src/dp/swipe/swipe_wrapper.cpp:364-444 -- a second banded sweep over the
+ * reversed query and the reversed target prefix [0, s_end) with BackwardCell, whose end point gives
+ * the start coordinates (carry-over branch of traceback(), banded_swipe.h:107-117).
+ * hsp_values is the reference's HspValues bit set (basic/match.h); it selects the cell types as
+ * dispatch_swipe() does (swipe_wrapper.cpp:196-215). */
+int oracle_swipe_stats(const int8_t* query, int qlen, const int8_t* cbs,
+	const int8_t* target, int tlen, int d_begin, int d_end,
+	const int8_t* matrix8, int gap_open, int gap_extend, unsigned hsp_values, oracle_hsp* out)
+{
+	enum { IDENT = 1 << 5, LENGTH = 1 << 6, MISMATCHES = 1 << 7, GAP_OPENINGS = 1 << 8, QUERY_START = 1 << 1, TARGET_START = 1 << 3 };
+	oracle_hsp f, b;
+	const int mode_f = (hsp_values & (IDENT | LENGTH)) ? ORACLE_STATS_FWD : ORACLE_COORDS;
+	int rc = oracle_banded_swipe(query, qlen, cbs, target, tlen, d_begin, d_end, matrix8, gap_open, gap_extend, mode_f, &f, NULL, 0);
+	if (rc != ORACLE_OK)
+		return rc;
+	*out = f;
+	if (f.score <= 0 || !(hsp_values & (QUERY_START | TARGET_START | MISMATCHES | GAP_OPENINGS)))   /* reversed(), :115-118 */
+		return ORACLE_OK;
+	const int tl = f.s_end;                                            /* :378,382 */
+	int8_t* rq = (int8_t*)malloc((size_t)qlen);
+	int8_t* rt = (int8_t*)malloc((size_t)tl);
+	int8_t* rc_ = cbs ? (int8_t*)malloc((size_t)qlen) : NULL;
+	for (int i = 0; i < qlen; ++i) {
+		rq[i] = query[qlen - 1 - i];
+		if (cbs) rc_[i] = cbs[qlen - 1 - i];
+	}
+	for (int i = 0; i < tl; ++i)
+		rt[i] = target[tl - 1 - i];
+	const int rd0 = -(d_end - 1) + qlen - tl;                          /* Geo::rev_diag, util/geo/geo.h:37 */
+	const int rd1 = -d_begin + qlen - tl + 1;
+	const int mode_b = (hsp_values & (MISMATCHES | GAP_OPENINGS)) ? ORACLE_STATS_BWD : ORACLE_COORDS;
+	rc = oracle_banded_swipe(rq, qlen, rc_, rt, tl, rd0, rd1, matrix8, gap_open, gap_extend, mode_b, &b, NULL, 0);
+	free(rq); free(rt); free(rc_);
+	if (rc != ORACLE_OK)
+		return rc;
+	out->score = b.score;
+	out->q_begin = qlen - b.q_end;                                     /* banded_swipe.h:114-115 */
+	out->s_begin = tl - b.s_end;
+	out->mismatches = b.mismatches;
+	out->gap_openings = b.gap_openings;
+	out->gaps = out->length - out->identities - out->mismatches;       /* assign_stats, stat_cell.h:216-220 */
+	return ORACLE_OK;
+}

@@ -24,6 +24,21 @@ int oracle_banded_swipe(const int8_t* query, int qlen, const int8_t* cbs,
 	const int8_t* matrix8, int gap_open, int gap_extend, int mode,
 	oracle_hsp* out, uint8_t* transcript, int transcript_cap);
 
+int oracle_swipe_stats(const int8_t* query, int qlen, const int8_t* cbs,
+	const int8_t* target, int tlen, int d_begin, int d_end,
+	const int8_t* matrix8, int gap_open, int gap_extend, unsigned hsp_values, oracle_hsp* out);
+
+typedef struct {
+	double lambda, K, a_I, b_I, a_J, b_J, alpha_I, beta_I, alpha_J, beta_J, sigma, tau;
+	double vi_y_thr, vj_y_thr, c_y_thr, db_letters, ln_k;
+} oracle_evaluer;
+
+void oracle_evalue_init(oracle_evaluer* e, double lambda, double K, double alpha, double alpha_v, double sigma,
+	double u_alpha, double u_alpha_v, int gap_open, int gap_extend, double db_letters);
+double oracle_area(const oracle_evaluer* e, double y, double seqlen1, double seqlen2);
+double oracle_evalue(const oracle_evaluer* e, int raw_score, unsigned query_len, unsigned subject_len);
+double oracle_bitscore(const oracle_evaluer* e, double raw_score);
+
 #ifdef __cplusplus
 }
 #endif

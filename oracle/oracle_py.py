@@ -1,0 +1,95 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes view of the CPU restatement (oracle/*.c -> oracle/_ref/libswipe_oracle.so).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module."""
+import ctypes
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_ref", "libswipe_oracle.so")
+
+SCORE_ONLY, COORDS, TRACEBACK, STATS_FWD, STATS_BWD = range(5)
+
+# BLOSUM62, gap open 11 / extend 1: gapped and ungapped Gumbel constants
+# (/root/reference/src/stats/matrices/blosum62.h rows {11,1} and 0; the published NCBI values)
+BLOSUM62_11_1 = dict(lambda_=0.267, K=0.041, alpha=1.9, alpha_v=42.6028, sigma=43.6362, u_alpha=0.7916, u_alpha_v=4.96466)
+
+
+class Hsp(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in
+                "score max_col max_band_row cols q_begin q_end s_begin s_end length identities mismatches "
+                "positives gap_openings gaps transcript_len".split()]
+
+    def asdict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class Evaluer(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_double) for n in
+                "lambda_ K a_I b_I a_J b_J alpha_I beta_I alpha_J beta_J sigma tau vi_y_thr vj_y_thr c_y_thr db_letters ln_k".split()]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+        if not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
+            subprocess.check_call(["make", "-s", "-C", _HERE, "restatement"])
+        _lib = ctypes.CDLL(_SO)
+        _lib.oracle_evalue.restype = ctypes.c_double
+        _lib.oracle_bitscore.restype = ctypes.c_double
+        _lib.oracle_area.restype = ctypes.c_double
+    return _lib
+
+
+def _p8(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_int8)) if a is not None else None
+
+
+def banded_swipe(query, cbs, target, d_begin, d_end, matrix8, gap_open, gap_extend, mode, transcript_cap=1 << 17):
+    """One target through the restated banded sweep; returns (rc, Hsp dict, transcript uint8[])."""
+    q = np.ascontiguousarray(query, dtype=np.int8)
+    t = np.ascontiguousarray(target, dtype=np.int8)
+    c = np.ascontiguousarray(cbs, dtype=np.int8) if cbs is not None else None
+    m = np.ascontiguousarray(matrix8, dtype=np.int8)
+    out = Hsp()
+    tr = np.zeros(transcript_cap if mode == TRACEBACK else 1, np.uint8)
+    rc = lib().oracle_banded_swipe(_p8(q), len(q), _p8(c), _p8(t), len(t), int(d_begin), int(d_end), _p8(m),
+                                   int(gap_open), int(gap_extend), int(mode), ctypes.byref(out),
+                                   tr.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), len(tr))
+    return rc, out.asdict(), tr[:out.transcript_len].copy()
+
+
+def swipe_stats(query, cbs, target, d_begin, d_end, matrix8, gap_open, gap_extend, hsp_values):
+    q = np.ascontiguousarray(query, dtype=np.int8)
+    t = np.ascontiguousarray(target, dtype=np.int8)
+    c = np.ascontiguousarray(cbs, dtype=np.int8) if cbs is not None else None
+    m = np.ascontiguousarray(matrix8, dtype=np.int8)
+    out = Hsp()
+    rc = lib().oracle_swipe_stats(_p8(q), len(q), _p8(c), _p8(t), len(t), int(d_begin), int(d_end), _p8(m),
+                                  int(gap_open), int(gap_extend), ctypes.c_uint(hsp_values), ctypes.byref(out))
+    return rc, out.asdict()
+
+
+def banded_cols(qlen, tlen, d_begin, d_end):
+    return lib().oracle_banded_cols(int(qlen), int(tlen), int(d_begin), int(d_end))
+
+
+def evaluer(db_letters, gap_open=11, gap_extend=1, consts=BLOSUM62_11_1):
+    e = Evaluer()
+    d = ctypes.c_double
+    lib().oracle_evalue_init(ctypes.byref(e), d(consts["lambda_"]), d(consts["K"]), d(consts["alpha"]),
+                             d(consts["alpha_v"]), d(consts["sigma"]), d(consts["u_alpha"]), d(consts["u_alpha_v"]),
+                             int(gap_open), int(gap_extend), d(db_letters))
+    return e
+
+
+def evalue(e, score, qlen, slen):
+    return lib().oracle_evalue(ctypes.byref(e), int(score), ctypes.c_uint(qlen), ctypes.c_uint(slen))
+
+
+def bitscore(e, score):
+    return lib().oracle_bitscore(ctypes.byref(e), ctypes.c_double(score))

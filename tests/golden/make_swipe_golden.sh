@@ -1,0 +1,41 @@
+#!/bin/bash
+# Mints the kernel-level known answers under tests/golden/ from the GENUINE reference
+# (oracle/_ref/diamond_tap = /root/reference compiled in place + the --wrap tap of oracle/ref_tap.cpp).
+# Run in the build container only (needs /root/reference); the .tap fixtures are committed.
+set -euo pipefail
+HERE="$(cd "$(dirname "$0")" && pwd)"
+ROOT="$(cd "$HERE/../.." && pwd)"
+REFTEST=/root/reference/src/test
+TAP="$ROOT/oracle/_ref/diamond_tap"
+TMP="$(mktemp -d)"
+make -C "$ROOT/oracle" ref >/dev/null
+
+# 1. default sensitivity on the reference's own 389-domain SCOP fixture (ctest diamond-test-blastp-default,
+#    CMakeLists.txt:553): first 120 queries, round 1 (score only) + round 2 (traceback) calls
+DIAMOND_TAP_FILE="$HERE/swipe_default.tap" DIAMOND_TAP_MAX_CALLS=240 \
+  "$TAP" blastp -q "$REFTEST/data.faa" -d "$REFTEST/data.faa" -o "$TMP/default.out" -p1 2>/dev/null
+diff -q "$TMP/default.out" "$REFTEST/diamond-test-blastp-default.out"   # the tap must not change results
+
+# 2. --fast (BASELINE configs C1/C2) on the same fixture
+DIAMOND_TAP_FILE="$HERE/swipe_fast.tap" DIAMOND_TAP_MAX_CALLS=200 \
+  "$TAP" blastp --fast -q "$REFTEST/data.faa" -d "$REFTEST/data.faa" -o "$TMP/fast.out" -p1 2>/dev/null
+
+# 3. long synthetic proteins: DP size > max_swipe_dp (1e6 cells, basic/config.cpp:595) forces the
+#    statistics-without-traceback path (ForwardCell + recompute_reversed with BackwardCell)
+DMND_ROOT="$ROOT" python3 - "$TMP" <<'PY'
+import os, sys
+sys.path.insert(0, os.environ["DMND_ROOT"])
+from diamond_amd import synth
+db, do, q, qo = synth.generate(3, members=2, queries=3, len_mean=9000, len_sd=500, len_min=8000, len_max=10000,
+                               seed=7, decoy_frac=0.0)
+synth.write_fasta(sys.argv[1] + "/long_db.faa", "t", db, do)
+synth.write_fasta(sys.argv[1] + "/long_q.faa", "q", q, qo)
+PY
+DIAMOND_TAP_FILE="$HERE/swipe_long.tap" \
+  "$TAP" blastp -q "$TMP/long_q.faa" -d "$TMP/long_db.faa" -o "$TMP/long.out" -p1 2>/dev/null
+
+# 4. blastx (6 query contexts, frames) on the reference's galaxy fixture (ctest galaxy_7)
+DIAMOND_TAP_FILE="$HERE/swipe_blastx.tap" \
+  "$TAP" blastx -q "$REFTEST/galaxy/nucleotide.fasta" -d "$REFTEST/galaxy/db.dmnd" -o "$TMP/bx.out" -p1 2>/dev/null || true
+ls -la "$HERE"/*.tap
+rm -rf "$TMP"

@@ -1,0 +1,70 @@
+"""Pins the CPU restatement (oracle/banded_swipe.c, oracle/evalue.c) against known answers minted from
+the genuine reference at its own dispatch seam (tests/golden/make_swipe_golden.sh ->
+DP::BandedSwipe::swipe, /root/reference/src/dp/dp.h:287).  CPU only."""
+import os
+import numpy as np
+import pytest
+
+import oracle_py as orc
+from tapfile import read_tap
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TAPS = ["swipe_default.tap", "swipe_fast.tap", "swipe_long.tap", "swipe_blastx.tap"]
+COORD_KEYS = "q_begin q_end s_begin s_end length identities mismatches gap_openings gaps".split()
+
+
+def _targets_with_hsps(rec):
+    by_t = {}
+    for h in rec["hsps"]:
+        by_t.setdefault((h["swipe_target"], h["d_begin"], h["d_end"]), []).append(h)
+    for t in rec["targets"]:
+        yield t, by_t.get((t["target_idx"], t["d_begin"], t["d_end"]), [])
+
+
+@pytest.mark.parametrize("tap", TAPS)
+def test_restated_swipe_matches_reference(tap):
+    hdr, recs = read_tap(os.path.join(GOLDEN, tap))
+    M, go, ge = hdr["matrix8"], hdr["gap_open"], hdr["gap_extend"]
+    ev = orc.evaluer(hdr["db_letters"], go, ge)
+    n_hsp = n_silent = 0
+    for rec in recs:
+        q, cbs, v = rec["query"], rec["cbs"], rec["hsp_values"]
+        for t, hsps in _targets_with_hsps(rec):
+            assert orc.banded_cols(len(q), len(t["seq"]), t["d_begin"], t["d_end"]) == t["cols"]
+            if not hsps:
+                # the reference dropped it: score <= 0 or e-value above the report cutoff (banded_swipe.h:334-336)
+                rc, o, _ = orc.banded_swipe(q, cbs, t["seq"], t["d_begin"], t["d_end"], M, go, ge, orc.SCORE_ONLY)
+                assert rc == 0
+                assert o["score"] <= 0 or orc.evalue(ev, o["score"], len(q), t["true_target_len"]) > hdr["max_evalue"]
+                n_silent += 1
+                continue
+            assert len(hsps) == 1
+            h = hsps[0]
+            if v == 0:
+                rc, o, _ = orc.banded_swipe(q, cbs, t["seq"], t["d_begin"], t["d_end"], M, go, ge, orc.SCORE_ONLY)
+                assert rc == 0 and o["score"] == h["score"]
+            elif h["swipe_bin"] < 3:        # traceback bins (swipe_wrapper.cpp:191-194)
+                rc, o, tr = orc.banded_swipe(q, cbs, t["seq"], t["d_begin"], t["d_end"], M, go, ge, orc.TRACEBACK)
+                assert rc == 0 and o["score"] == h["score"]
+                for k in COORD_KEYS + ["positives"]:
+                    assert o[k] == h[k], (k, o, h)
+                assert h["transcript"][-1] == 0 and np.array_equal(h["transcript"][:-1], tr)
+            else:                            # statistics without traceback + reversed pass (:364-444)
+                rc, o = orc.swipe_stats(q, cbs, t["seq"], t["d_begin"], t["d_end"], M, go, ge, v)
+                assert rc == 0 and o["score"] == h["score"]
+                for k in COORD_KEYS:
+                    assert o[k] == h[k], (k, o, h)
+            assert orc.evalue(ev, h["score"], len(q), t["true_target_len"]) == pytest.approx(h["evalue"], rel=1e-12, abs=0)
+            assert orc.bitscore(ev, h["score"]) == pytest.approx(h["bit_score"], rel=1e-12)
+            n_hsp += 1
+    assert n_hsp > 0
+
+
+def test_golden_covers_all_modes():
+    seen = set()
+    for tap in TAPS:
+        _, recs = read_tap(os.path.join(GOLDEN, tap))
+        for rec in recs:
+            for h in rec["hsps"]:
+                seen.add((rec["hsp_values"] != 0, h["swipe_bin"] >= 3))
+    assert {(False, False), (True, False), (True, True)} <= seen
