@@ -1,0 +1,31 @@
+# Builds the product libraries in-tree (they travel to the GPU box with the gpurun snapshot):
+#   diamond_amd/libdiamond_hip.so   HIP kernels + C ABI (include/diamond_hip.h), gfx950 only
+#   diamond_amd/libdmnd_synth.so    deterministic synthetic workload generator (plain C)
+# and the test-only helpers: oracle/_ref/* (CPU restatement + reference build), tests/emu/libswipe_emu.so
+HIPCC   ?= /opt/rocm/bin/hipcc
+CSRC    := diamond_amd/csrc
+HIPSRC  := $(CSRC)/api.hip $(CSRC)/swipe_kernels.hip
+HIPHDR  := $(wildcard $(CSRC)/*.h) include/diamond_hip.h
+HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function
+
+.PHONY: all product oracle emu clean
+all: product oracle emu
+
+product: diamond_amd/libdiamond_hip.so diamond_amd/libdmnd_synth.so
+
+diamond_amd/libdiamond_hip.so: $(HIPSRC) $(HIPHDR)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIPSRC)
+
+diamond_amd/libdmnd_synth.so: $(CSRC)/synth.c
+	gcc -O2 -fPIC -shared -std=c11 -Wall -o $@ $< -lm
+
+oracle:
+	$(MAKE) -C oracle all
+
+emu: tests/emu/libswipe_emu.so
+tests/emu/libswipe_emu.so: tests/emu/swipe_emu.cpp $(CSRC)/swipe_core.h
+	g++ -O2 -std=c++17 -fPIC -shared -w -o $@ $<
+
+clean:
+	rm -f diamond_amd/*.so tests/emu/*.so
+	$(MAKE) -C oracle clean

@@ -1,0 +1,465 @@
+// api.hip -- the C ABI of libdiamond_hip.so (include/diamond_hip.h): context, HBM residency of the
+// sequence blocks, batching of DpTargets into wavefront launches, result collection.
+//
+// Host-side restatement of the binning/ordering work of the reference's swipe wrapper
+// (/root/reference/src/dp/swipe/swipe_wrapper.cpp:317-362 swipe_bin, :446-470 swipe) re-thought for
+// the GPU: instead of 8/16/32-bit score bins with overflow escalation, items are classed by band
+// width (P = diagonals-per-lane class) and ordered longest-first so the 256 CUs drain evenly.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+#include "../../include/diamond_hip.h"
+#include "swipe_core.h"
+#include "swipe_kernels.h"
+#include "evalue.h"
+#include "blosum62.h"
+
+using namespace dmnd;
+
+static thread_local std::string g_last_error;
+
+static int fail(int code, const std::string& msg)
+{
+	g_last_error = msg;
+	return code;
+}
+
+#define HIP_TRY(expr)                                                                                     \
+	do {                                                                                                  \
+		hipError_t e_ = (expr);                                                                           \
+		if (e_ != hipSuccess)                                                                             \
+			return fail(DMND_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));                \
+	} while (0)
+
+struct DevBuf {
+	void* p = nullptr;
+	size_t cap = 0;
+	int ensure(size_t bytes)
+	{
+		if (bytes <= cap)
+			return DMND_OK;
+		if (p) (void)hipFree(p);
+		p = nullptr; cap = 0;
+		const size_t want = bytes + bytes / 4 + 256;
+		if (hipMalloc(&p, want) != hipSuccess) {
+			p = nullptr;
+			return fail(DMND_E_NOMEM, "hipMalloc of " + std::to_string(want) + " bytes failed");
+		}
+		cap = want;
+		return DMND_OK;
+	}
+	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+	template<typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct dmnd_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+	dmnd_params params;
+	Evaluer evaluer;
+	DevBuf block[2], cbs, matrix;
+	int64_t block_len[2] = { 0, 0 }, cbs_len = 0;
+	std::vector<int64_t> limits[2];
+	// work buffers
+	DevBuf items, order, p_of_slot, trace_off, transcript_off, ends, hsps, trace, transcript, status;
+	DevBuf host_q, host_t, host_cbs;      // staging for dmnd_banded_swipe_host
+	double swipe_ms = 0.0, traceback_ms = 0.0;
+	size_t trace_arena_max = (size_t)8 << 30;
+};
+
+extern "C" int dmnd_abi_version(void) { return DMND_ABI_VERSION; }
+
+extern "C" const char* dmnd_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int dmnd_default_params(dmnd_params* p)
+{
+	// BLOSUM62, gap open 11 / extend 1 (the reference's defaults, src/stats/score_matrix.cpp:51-52),
+	// Gumbel constants of the published NCBI table for that matrix and penalty pair.
+	if (!p) return fail(DMND_E_ARG, "params is NULL");
+	blosum62_matrix8(p->matrix8);
+	p->gap_open = 11; p->gap_extend = 1;
+	p->lambda = 0.267; p->K = 0.041; p->alpha = 1.9; p->alpha_v = 42.6028; p->sigma = 43.6362;
+	p->u_alpha = 0.7916; p->u_alpha_v = 4.96466;
+	p->db_letters = 0.0;
+	p->max_evalue = 0.001;      // config.max_evalue default, src/basic/config.cpp
+	return DMND_OK;
+}
+
+extern "C" dmnd_ctx* dmnd_create(int device, const dmnd_params* params)
+{
+	if (!params) { fail(DMND_E_ARG, "dmnd_create: params is NULL"); return nullptr; }
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess || count == 0) {
+		fail(DMND_E_DEVICE, "dmnd_create: no HIP device visible (this library has no CPU fallback)");
+		return nullptr;
+	}
+	if (device < 0) {
+		if (hipGetDevice(&device) != hipSuccess) { fail(DMND_E_DEVICE, "hipGetDevice failed"); return nullptr; }
+	}
+	if (device >= count) { fail(DMND_E_ARG, "dmnd_create: device index out of range"); return nullptr; }
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) != hipSuccess) { fail(DMND_E_DEVICE, "hipGetDeviceProperties failed"); return nullptr; }
+	if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+		fail(DMND_E_DEVICE, std::string("dmnd_create: device is ") + prop.gcnArchName + ", kernels are built for gfx950 (MI355X) only");
+		return nullptr;
+	}
+	if (hipSetDevice(device) != hipSuccess) { fail(DMND_E_DEVICE, "hipSetDevice failed"); return nullptr; }
+	dmnd_ctx* c = new dmnd_ctx();
+	c->device = device;
+	c->params = *params;
+	c->evaluer.init(*params);
+	if (const char* mb = getenv("DMND_TRACE_ARENA_MB"))
+		c->trace_arena_max = (size_t)std::max(64L, atol(mb)) << 20;
+	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess
+		|| hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev2) != hipSuccess
+		|| c->matrix.ensure(32 * 32) != DMND_OK
+		|| hipMemcpy(c->matrix.p, params->matrix8, 32 * 32, hipMemcpyHostToDevice) != hipSuccess) {
+		fail(DMND_E_DEVICE, "dmnd_create: stream/event/matrix setup failed");
+		dmnd_destroy(c);
+		return nullptr;
+	}
+	return c;
+}
+
+extern "C" void dmnd_destroy(dmnd_ctx* c)
+{
+	if (!c) return;
+	(void)hipSetDevice(c->device);
+	if (c->stream) (void)hipStreamSynchronize(c->stream);
+	for (DevBuf* b : { &c->block[0], &c->block[1], &c->cbs, &c->matrix, &c->items, &c->order, &c->p_of_slot, &c->trace_off,
+		&c->transcript_off, &c->ends, &c->hsps, &c->trace, &c->transcript, &c->status, &c->host_q, &c->host_t, &c->host_cbs })
+		b->release();
+	if (c->ev0) (void)hipEventDestroy(c->ev0);
+	if (c->ev1) (void)hipEventDestroy(c->ev1);
+	if (c->ev2) (void)hipEventDestroy(c->ev2);
+	if (c->stream) (void)hipStreamDestroy(c->stream);
+	delete c;
+}
+
+extern "C" int dmnd_set_db_letters(dmnd_ctx* c, double db_letters)
+{
+	if (!c) return fail(DMND_E_ARG, "ctx is NULL");
+	c->params.db_letters = db_letters;
+	c->evaluer.db_letters = db_letters;
+	return DMND_OK;
+}
+
+extern "C" int dmnd_upload_block(dmnd_ctx* c, int which, const int8_t* data, int64_t data_len, const int64_t* limits, int64_t n_seqs)
+{
+	if (!c || (which != DMND_QUERY && which != DMND_TARGET) || !data || data_len <= 0 || n_seqs < 0)
+		return fail(DMND_E_ARG, "dmnd_upload_block: bad argument");
+	HIP_TRY(hipSetDevice(c->device));
+	if (int rc = c->block[which].ensure((size_t)data_len + 64)) return rc;
+	HIP_TRY(hipMemcpyAsync(c->block[which].p, data, (size_t)data_len, hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	c->block_len[which] = data_len;
+	c->limits[which].clear();
+	if (limits)
+		c->limits[which].assign(limits, limits + n_seqs + 1);
+	return DMND_OK;
+}
+
+extern "C" int dmnd_upload_cbs(dmnd_ctx* c, const int8_t* cbs, int64_t len)
+{
+	if (!c || len < 0 || (len > 0 && !cbs))
+		return fail(DMND_E_ARG, "dmnd_upload_cbs: bad argument");
+	HIP_TRY(hipSetDevice(c->device));
+	c->cbs_len = len;
+	if (len == 0)
+		return DMND_OK;
+	if (int rc = c->cbs.ensure((size_t)len + 64)) return rc;
+	HIP_TRY(hipMemcpyAsync(c->cbs.p, cbs, (size_t)len, hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return DMND_OK;
+}
+
+extern "C" int32_t dmnd_banded_cols(int32_t qlen, int32_t tlen, int32_t d_begin, int32_t d_end)
+{
+	// DpTarget::banded_cols, src/dp/dp.h:47-52
+	const int32_t pos = std::max(d_end - 1, 0) - (d_end - 1);
+	const int32_t j1 = std::min(qlen - 1 - d_begin, tlen - 1) + 1;
+	return j1 - pos;
+}
+
+extern "C" double dmnd_evalue(const dmnd_ctx* c, int32_t raw_score, uint32_t query_len, uint32_t subject_len)
+{
+	return c ? c->evaluer.evalue(raw_score, query_len, subject_len) : 0.0;
+}
+
+extern "C" double dmnd_evalue_p(const dmnd_params* p, int32_t raw_score, uint32_t query_len, uint32_t subject_len)
+{
+	if (!p) return 0.0;
+	Evaluer e;
+	e.init(*p);
+	return e.evalue(raw_score, query_len, subject_len);
+}
+
+extern "C" int dmnd_evalue_batch(const dmnd_params* p, const int32_t* raw_score, const int32_t* query_len, const int32_t* subject_len,
+	int64_t n, double* out)
+{
+	if (!p || !raw_score || !query_len || !subject_len || !out || n < 0) return fail(DMND_E_ARG, "dmnd_evalue_batch: bad argument");
+	Evaluer e;
+	e.init(*p);
+	for (int64_t i = 0; i < n; ++i)
+		out[i] = e.evalue(raw_score[i], (unsigned)query_len[i], (unsigned)subject_len[i]);
+	return DMND_OK;
+}
+
+extern "C" double dmnd_bitscore_p(const dmnd_params* p, double raw_score)
+{
+	if (!p) return 0.0;
+	Evaluer e;
+	e.init(*p);
+	return e.bitscore(raw_score);
+}
+
+extern "C" double dmnd_bitscore(const dmnd_ctx* c, double raw_score)
+{
+	return c ? c->evaluer.bitscore(raw_score) : 0.0;
+}
+
+extern "C" int dmnd_last_kernel_ms(const dmnd_ctx* c, double* swipe_ms, double* traceback_ms)
+{
+	if (!c) return fail(DMND_E_ARG, "ctx is NULL");
+	if (swipe_ms) *swipe_ms = c->swipe_ms;
+	if (traceback_ms) *traceback_ms = c->traceback_ms;
+	return DMND_OK;
+}
+
+namespace {
+
+struct Bases {
+	const int8_t* q; int64_t q_len;
+	const int8_t* t; int64_t t_len;
+	const int8_t* cbs; int64_t cbs_len;
+};
+
+struct Slot { int32_t item; int32_t P; int64_t steps; };
+
+// Runs one chunk of items [begin, end) (indices into `items`), all modes.
+int run_chunk(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, const dmnd_dp_target* d_items, const std::vector<Slot>& slots,
+	int kmode, dmnd_hsp* out, std::vector<uint8_t>* chunk_transcripts, std::vector<int64_t>* chunk_tr_off)
+{
+	const int64_t n = (int64_t)slots.size();
+	if (n == 0) return DMND_OK;
+	const bool trace = kmode == 2;
+	std::vector<int32_t> order(n), p_of(n);
+	std::vector<int64_t> trace_off(n + 1, 0), tr_off(n + 1, 0);
+	for (int64_t s = 0; s < n; ++s) {
+		order[s] = slots[s].item;
+		p_of[s] = slots[s].P;
+		if (trace) {
+			const dmnd_dp_target& it = items[slots[s].item];
+			const Geom g = make_geom(it.query_len, it.target_len, it.d_begin, it.d_end);
+			trace_off[s + 1] = trace_off[s] + trace_rows(g) * 64 * slots[s].P;
+			tr_off[s + 1] = tr_off[s] + (int64_t)it.query_len + it.target_len + 2;
+		}
+	}
+	if (int rc = c->order.ensure(n * sizeof(int32_t))) return rc;
+	HIP_TRY(hipMemcpyAsync(c->order.p, order.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+	if (trace) {
+		if (int rc = c->p_of_slot.ensure(n * sizeof(int32_t))) return rc;
+		if (int rc = c->trace_off.ensure((n + 1) * sizeof(int64_t))) return rc;
+		if (int rc = c->transcript_off.ensure((n + 1) * sizeof(int64_t))) return rc;
+		if (int rc = c->trace.ensure((size_t)trace_off[n] + 64)) return rc;
+		if (int rc = c->transcript.ensure((size_t)tr_off[n] + 64)) return rc;
+		if (int rc = c->status.ensure(sizeof(int32_t))) return rc;
+		HIP_TRY(hipMemcpyAsync(c->p_of_slot.p, p_of.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(hipMemcpyAsync(c->trace_off.p, trace_off.data(), (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(hipMemcpyAsync(c->transcript_off.p, tr_off.data(), (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(hipMemsetAsync(c->status.p, 0, sizeof(int32_t), c->stream));
+	}
+
+	HIP_TRY(hipEventRecord(c->ev0, c->stream));
+	// slots are grouped by P (ascending) by the caller: one launch per class
+	for (int64_t s0 = 0; s0 < n;) {
+		int64_t s1 = s0;
+		while (s1 < n && slots[s1].P == slots[s0].P) ++s1;
+		SwipeArgs a;
+		a.qblock = b.q; a.tblock = b.t; a.cbs = b.cbs; a.matrix = c->matrix.as<int8_t>();
+		a.items = d_items;
+		a.order = c->order.as<int32_t>() + s0;
+		a.trace_off = trace ? c->trace_off.as<int64_t>() + s0 : nullptr;
+		a.trace = trace ? c->trace.as<uint8_t>() : nullptr;
+		a.ends = c->ends.as<SwipeEnd>();
+		a.n = s1 - s0;
+		a.gap_open = c->params.gap_open; a.gap_extend = c->params.gap_extend;
+		HIP_TRY(launch_banded_swipe(slots[s0].P, kmode, a, c->stream));
+		s0 = s1;
+	}
+	HIP_TRY(hipEventRecord(c->ev1, c->stream));
+	if (trace) {
+		TracebackArgs t;
+		t.qblock = b.q; t.tblock = b.t; t.cbs = b.cbs; t.matrix = c->matrix.as<int8_t>();
+		t.items = d_items; t.order = c->order.as<int32_t>(); t.p_of_slot = c->p_of_slot.as<int32_t>();
+		t.trace_off = c->trace_off.as<int64_t>(); t.transcript_off = c->transcript_off.as<int64_t>();
+		t.trace = c->trace.as<uint8_t>(); t.transcript = c->transcript.as<uint8_t>();
+		t.ends = c->ends.as<SwipeEnd>(); t.hsps = c->hsps.as<dmnd_hsp>(); t.status = c->status.as<int32_t>();
+		t.n = n; t.gap_open = c->params.gap_open; t.gap_extend = c->params.gap_extend;
+		HIP_TRY(launch_traceback(t, c->stream));
+		HIP_TRY(hipEventRecord(c->ev2, c->stream));
+		chunk_transcripts->resize((size_t)tr_off[n]);
+		HIP_TRY(hipMemcpyAsync(chunk_transcripts->data(), c->transcript.p, (size_t)tr_off[n], hipMemcpyDeviceToHost, c->stream));
+		*chunk_tr_off = tr_off;
+	}
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	float ms = 0.f;
+	HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+	c->swipe_ms += ms;
+	if (trace) {
+		HIP_TRY(hipEventElapsedTime(&ms, c->ev1, c->ev2));
+		c->traceback_ms += ms;
+		int32_t st = 0;
+		HIP_TRY(hipMemcpy(&st, c->status.p, sizeof(st), hipMemcpyDeviceToHost));
+		if (st != 0)
+			return fail(st, st == DMND_E_TRACEBACK ? "Traceback error." : "transcript slot too small");
+	}
+	(void)out;
+	return DMND_OK;
+}
+
+int swipe_impl(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, int64_t n, int mode, uint32_t hsp_values,
+	dmnd_hsp* out, uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used)
+{
+	(void)hsp_values;
+	if (transcript_used) *transcript_used = 0;
+	if (n == 0) return DMND_OK;
+	if (!items || !out || n < 0) return fail(DMND_E_ARG, "dmnd_banded_swipe: NULL items/out");
+	if (n > 0x7fffffff) return fail(DMND_E_ARG, "dmnd_banded_swipe: more than 2^31-1 items in one call");
+	int kmode;
+	switch (mode) {
+	case DMND_SWIPE_SCORE: kmode = 0; break;
+	case DMND_SWIPE_COORDS: kmode = 1; break;
+	case DMND_SWIPE_TRACEBACK: kmode = 2; break;
+	default: return fail(DMND_E_ARG, "dmnd_banded_swipe: mode not supported (DMND_SWIPE_STATS not implemented yet)");
+	}
+	if (kmode == 2 && (!transcript || transcript_cap <= 0))
+		return fail(DMND_E_ARG, "dmnd_banded_swipe: TRACEBACK needs a transcript arena");
+	if (!b.q || !b.t) return fail(DMND_E_ARG, "dmnd_banded_swipe: sequence blocks not uploaded");
+	HIP_TRY(hipSetDevice(c->device));
+
+	std::vector<Slot> slots((size_t)n);
+	for (int64_t i = 0; i < n; ++i) {
+		const dmnd_dp_target& it = items[i];
+		const int band = it.d_end - it.d_begin;
+		if (band <= 0 || it.query_len <= 0 || it.target_len <= 0 || it.query_off < 0 || it.target_off < 0
+			|| it.query_off + it.query_len > b.q_len || it.target_off + it.target_len > b.t_len
+			|| (it.cbs_off >= 0 && (!b.cbs || it.cbs_off + it.query_len > b.cbs_len)))
+			return fail(DMND_E_ARG, "dmnd_banded_swipe: item " + std::to_string(i) + " out of range");
+		const int P = band_class(band);
+		if (P > 32)
+			return fail(DMND_E_BAND, "Band size exceeds the supported maximum (" + std::to_string(DMND_MAX_BAND) + ")");
+		const Geom g = make_geom(it.query_len, it.target_len, it.d_begin, it.d_end);
+		slots[i] = Slot{ (int32_t)i, P, n_steps(g) };
+	}
+	if (int rc = c->items.ensure(n * sizeof(dmnd_dp_target))) return rc;
+	if (int rc = c->ends.ensure(n * sizeof(SwipeEnd))) return rc;
+	if (kmode == 2) { if (int rc = c->hsps.ensure(n * sizeof(dmnd_hsp))) return rc; }
+	HIP_TRY(hipMemcpyAsync(c->items.p, items, n * sizeof(dmnd_dp_target), hipMemcpyHostToDevice, c->stream));
+	c->swipe_ms = c->traceback_ms = 0.0;
+
+	std::vector<SwipeEnd> ends((size_t)n);
+	std::vector<dmnd_hsp> hsps;
+	auto by_class = [](const Slot& x, const Slot& y) { return x.P < y.P || (x.P == y.P && x.steps > y.steps); };
+	if (kmode != 2) {
+		std::sort(slots.begin(), slots.end(), by_class);
+		if (int rc = run_chunk(c, b, items, c->items.as<dmnd_dp_target>(), slots, kmode, out, nullptr, nullptr)) return rc;
+		HIP_TRY(hipMemcpy(ends.data(), c->ends.p, n * sizeof(SwipeEnd), hipMemcpyDeviceToHost));
+		for (int64_t i = 0; i < n; ++i) {
+			dmnd_hsp h;
+			std::memset(&h, 0, sizeof(h));
+			h.score = ends[i].score;
+			if (kmode == 1 && h.score > 0) { h.q_end = ends[i].end_i + 1; h.s_end = ends[i].end_j + 1; }
+			out[i] = h;
+		}
+		return DMND_OK;
+	}
+
+	// TRACEBACK: chunk by trace arena size, keep input order across chunks
+	hsps.resize((size_t)n);
+	int64_t used = 0;
+	for (int64_t c0 = 0; c0 < n;) {
+		int64_t c1 = c0;
+		size_t bytes = 0;
+		while (c1 < n) {
+			const dmnd_dp_target& it = items[c1];
+			const Geom g = make_geom(it.query_len, it.target_len, it.d_begin, it.d_end);
+			const size_t need = (size_t)trace_rows(g) * 64 * slots[c1].P;
+			if (c1 > c0 && bytes + need > c->trace_arena_max) break;
+			bytes += need;
+			++c1;
+		}
+		std::vector<Slot> chunk(slots.begin() + c0, slots.begin() + c1);
+		std::sort(chunk.begin(), chunk.end(), by_class);
+		std::vector<uint8_t> tr;
+		std::vector<int64_t> tr_off;
+		if (int rc = run_chunk(c, b, items, c->items.as<dmnd_dp_target>(), chunk, kmode, out, &tr, &tr_off)) return rc;
+		HIP_TRY(hipMemcpy(hsps.data() + c0, c->hsps.as<dmnd_hsp>() + c0, (size_t)(c1 - c0) * sizeof(dmnd_hsp), hipMemcpyDeviceToHost));
+		// pack the transcripts tightly into the caller's arena, in input order
+		std::vector<int64_t> slot_of((size_t)(c1 - c0));
+		for (size_t s = 0; s < chunk.size(); ++s) slot_of[(size_t)(chunk[s].item - c0)] = (int64_t)s;
+		for (int64_t i = c0; i < c1; ++i) {
+			dmnd_hsp h = hsps[i];
+			const int64_t s = slot_of[(size_t)(i - c0)];
+			const int64_t len = h.transcript_len + 1;
+			if (used + len > transcript_cap)
+				return fail(DMND_E_CAP, "dmnd_banded_swipe: transcript arena too small");
+			std::memcpy(transcript + used, tr.data() + tr_off[s], (size_t)len);
+			h.transcript_off = used;
+			used += len;
+			out[i] = h;
+		}
+		c0 = c1;
+	}
+	if (transcript_used) *transcript_used = used;
+	return DMND_OK;
+}
+
+}  // namespace
+
+extern "C" int dmnd_banded_swipe(dmnd_ctx* c, const dmnd_dp_target* items, int64_t n, int mode, uint32_t hsp_values,
+	dmnd_hsp* out, uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used)
+{
+	if (!c) return fail(DMND_E_ARG, "ctx is NULL");
+	const Bases b{ c->block[DMND_QUERY].as<int8_t>(), c->block_len[DMND_QUERY], c->block[DMND_TARGET].as<int8_t>(), c->block_len[DMND_TARGET],
+		c->cbs_len > 0 ? c->cbs.as<int8_t>() : nullptr, c->cbs_len };
+	return swipe_impl(c, b, items, n, mode, hsp_values, out, transcript, transcript_cap, transcript_used);
+}
+
+extern "C" int dmnd_banded_swipe_host(dmnd_ctx* c, const int8_t* query, int32_t query_len, const int8_t* cbs,
+	const dmnd_host_target* targets, int64_t n, int mode, uint32_t hsp_values,
+	dmnd_hsp* out, uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used)
+{
+	if (!c) return fail(DMND_E_ARG, "ctx is NULL");
+	if (transcript_used) *transcript_used = 0;
+	if (n == 0) return DMND_OK;
+	if (!query || query_len <= 0 || !targets || n < 0) return fail(DMND_E_ARG, "dmnd_banded_swipe_host: bad argument");
+	HIP_TRY(hipSetDevice(c->device));
+	std::vector<dmnd_dp_target> items((size_t)n);
+	int64_t total = 0;
+	for (int64_t i = 0; i < n; ++i) {
+		if (!targets[i].seq || targets[i].len <= 0) return fail(DMND_E_ARG, "dmnd_banded_swipe_host: empty target");
+		items[i] = dmnd_dp_target{ 0, total, cbs ? 0 : -1, query_len, targets[i].len, targets[i].d_begin, targets[i].d_end };
+		total += targets[i].len;
+	}
+	std::vector<int8_t> tbuf((size_t)total);
+	for (int64_t i = 0; i < n; ++i)
+		std::memcpy(tbuf.data() + items[i].target_off, targets[i].seq, (size_t)targets[i].len);
+	if (int rc = c->host_q.ensure((size_t)query_len + 64)) return rc;
+	if (int rc = c->host_t.ensure((size_t)total + 64)) return rc;
+	HIP_TRY(hipMemcpyAsync(c->host_q.p, query, (size_t)query_len, hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(hipMemcpyAsync(c->host_t.p, tbuf.data(), (size_t)total, hipMemcpyHostToDevice, c->stream));
+	if (cbs) {
+		if (int rc = c->host_cbs.ensure((size_t)query_len + 64)) return rc;
+		HIP_TRY(hipMemcpyAsync(c->host_cbs.p, cbs, (size_t)query_len, hipMemcpyHostToDevice, c->stream));
+	}
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	const Bases b{ c->host_q.as<int8_t>(), query_len, c->host_t.as<int8_t>(), total, cbs ? c->host_cbs.as<int8_t>() : nullptr, cbs ? query_len : 0 };
+	return swipe_impl(c, b, items.data(), n, mode, hsp_values, out, transcript, transcript_cap, transcript_used);
+}

@@ -1,0 +1,257 @@
+// swipe_core.h -- per-lane arithmetic of the MI355X banded Smith-Waterman kernels.
+//
+// What it computes: the reference's banded SWIPE (DP::BandedSwipe::swipe,
+// /root/reference/src/dp/swipe/banded_swipe.h:189-351; cell update cell_update.h:103-140) for one
+// target per 64-lane wavefront -- NOT as the reference's column sweep with one target per SIMD
+// channel, but as an anti-diagonal wavefront sweep: step a handles all cells with i + j = a.
+// Inside the diagonal band [d_begin, d_end) only every other diagonal has a cell on a given
+// anti-diagonal, so lane l owns 2*P consecutive diagonals (k = 2*P*l .. 2*P*l + 2*P - 1,
+// k = i - j - d_begin) and computes P cells per step, alternating between its even and odd
+// diagonals. A cell on diagonal k needs
+//     H(i-1,j-1)   same diagonal, two steps ago         -> register
+//     E(i,j-1)     diagonal k+1, previous step          -> register, or lane l+1 (one DPP/shuffle)
+//     F(i-1,j)     diagonal k-1, previous step          -> register, or lane l-1 (one DPP/shuffle)
+// so the whole DP state lives in VGPRs; no LDS or HBM traffic for H/E/F.
+//
+// Semantics (bit-exact with the reference, see oracle/banded_swipe.c): values are clamped below at 0
+// like the reference's saturating score vectors; cells outside the band or the matrix read as 0;
+// the end cell is, among all cells with the best score, the one with the smallest column j and
+// then the largest row i (column-major scan with `col_best > best` and VectorRowCounter keeping the
+// last row equal to the column maximum: banded_swipe.h:312-318, cell_update.h:44-47).
+//
+// The functions here are plain inline C++ shared by the HIP kernels (swipe_kernels.hip) and by the
+// CPU lane-emulator used in the CPU test-suite (tests/emu) so the index arithmetic, tie-breaking and
+// traceback walk are tested without a GPU.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define DMND_HD __host__ __device__ __forceinline__
+#else
+#define DMND_HD inline
+#endif
+
+namespace dmnd {
+
+enum { LETTER_MASK = 31 };
+enum { TB_GAP_V = 1, TB_GAP_H = 2, TB_OPEN_V = 4, TB_OPEN_H = 8 };
+enum { OP_MATCH = 0, OP_INSERTION = 1, OP_DELETION = 2, OP_SUBSTITUTION = 3, OP_COUNT_BITS = 6, OP_MAX_COUNT = 63 };
+
+DMND_HD int imax(int a, int b) { return a > b ? a : b; }
+DMND_HD int imin(int a, int b) { return a < b ? a : b; }
+
+// Geometry of one work item shared by all lanes of the wave.
+struct Geom {
+	int qlen, tlen, d_begin, band;   // band = d_end - d_begin
+	int a_first, a_last;             // first / last anti-diagonal that holds a cell (a_first has the parity of d_begin)
+};
+
+DMND_HD Geom make_geom(int qlen, int tlen, int d_begin, int d_end)
+{
+	Geom g;
+	g.qlen = qlen; g.tlen = tlen; g.d_begin = d_begin; g.band = d_end - d_begin;
+	// first anti-diagonal with a cell inside band x matrix
+	int a0;
+	if (d_begin > 0) a0 = d_begin;              // cell (d_begin, 0)
+	else if (d_end <= 0) a0 = -(d_end - 1);     // cell (0, -(d_end-1))
+	else a0 = 0;                                // cell (0, 0)
+	// last: a = 2*min(qlen-1, tlen-1+d) - d is maximal at d* = clamp(qlen - tlen, d_begin, d_end-1)
+	const int ds = imin(imax(qlen - tlen, d_begin), d_end - 1);
+	g.a_last = 2 * imin(qlen - 1, tlen - 1 + ds) - ds;
+	if ((a0 + d_begin) & 1) --a0;                // loop is unrolled by parity: start on an even (a + d_begin)
+	g.a_first = a0;
+	return g;
+}
+
+// Number of anti-diagonal steps and trace bytes of one item (trace: one byte per (step, diagonal pair)).
+DMND_HD int64_t n_steps(const Geom& g) { return g.a_last >= g.a_first ? (int64_t)(g.a_last - g.a_first + 1) : 0; }
+// The kernel runs steps in (even, odd) pairs, so the trace holds an even number of rows.
+DMND_HD int64_t trace_rows(const Geom& g) { return (n_steps(g) + 1) / 2 * 2; }
+// lanes own 2*P diagonals each: smallest power of two with 128*P >= band
+DMND_HD int band_class(int band) { int P = 1; while (128 * P < band) P *= 2; return P; }
+
+// validity window of diagonal k (global index) on anti-diagonal a:  a_lo <= a <= a_hi
+//   i >= 0 <=> a >= -d ; j >= 0 <=> a >= d ; i < qlen <=> a <= 2*qlen-2-d ; j < tlen <=> a <= 2*tlen-2+d
+DMND_HD void diag_window(const Geom& g, int k, int& a_lo, int& a_span)
+{
+	const int d = g.d_begin + k;
+	a_lo = d < 0 ? -d : d;
+	const int a_hi = imin(2 * g.qlen - 2 - d, 2 * g.tlen - 2 + d);
+	a_span = a_hi - a_lo;
+	if (k >= g.band || a_span < 0) {              // never valid: (unsigned)(a - a_lo) is huge for every a
+		a_lo = 0x3fffffff;
+		a_span = 0;
+	}
+}
+
+// "x is a better end cell than the current best" -- see header comment
+DMND_HD bool better_end(int s, int j, int i, int bs, int bj, int bi)
+{
+	return s > bs || (s == bs && (j < bj || (j == bj && i > bi)));
+}
+
+template<int P, bool COORDS>
+struct Lane {
+	int H[2 * P], E[2 * P], F[2 * P];
+	int a_lo[2 * P], a_span[2 * P];
+	int best, best_i, best_j;
+
+	DMND_HD void init(const Geom& g, int lane)
+	{
+#pragma unroll
+		for (int k = 0; k < 2 * P; ++k) {
+			H[k] = E[k] = F[k] = 0;
+			diag_window(g, 2 * P * lane + k, a_lo[k], a_span[k]);
+		}
+		best = 0; best_i = 0; best_j = 0x7fffffff;
+	}
+};
+
+// One cell. Returns the 4 trace bits when TRACE.  (cell_update.h:103-140 with values clamped at 0.)
+template<bool TRACE>
+DMND_HD int cell_update(int Hd, int s, int E_in, int F_in, int go, int ge, int& cur, int& E_out, int& F_out)
+{
+	int c = Hd + s;
+	c = imax(c, E_in);
+	c = imax(c, F_in);
+	c = imax(c, 0);
+	const int open = imax(c - go, 0);
+	E_out = imax(imax(E_in - ge, 0), open);
+	F_out = imax(imax(F_in - ge, 0), open);
+	cur = c;
+	if (TRACE)
+		return (c == F_in ? TB_GAP_V : 0) | (c == E_in ? TB_GAP_H : 0) | (F_out == open ? TB_OPEN_V : 0) | (E_out == open ? TB_OPEN_H : 0);
+	return 0;
+}
+
+// Sequence/matrix access policy used by the step: q/t are letter pointers, cbs may be null,
+// M is the 32x32 int8 matrix (in LDS on the device).
+struct SeqView {
+	const int8_t* q;
+	const int8_t* t;
+	const int8_t* cbs;
+	const int8_t* M;
+};
+
+DMND_HD int match_score(const SeqView& v, int i, int j)
+{
+	const int ql = v.q[i] & LETTER_MASK, tl = v.t[j] & LETTER_MASK;
+	int s = v.M[tl * 32 + ql];
+	if (v.cbs) s += v.cbs[i];
+	return s;
+}
+
+// One anti-diagonal step of one lane. PAR = parity of (a + d_begin): 0 -> the lane's even local
+// diagonals are active and nb is F_out of lane-1's top diagonal; 1 -> odd diagonals, nb is E_out of
+// lane+1's bottom diagonal. trace (if TRACE) points at this lane's P bytes of the step's trace row.
+template<int P, bool COORDS, bool TRACE, int PAR>
+DMND_HD void lane_step(Lane<P, COORDS>& st, const Geom& g, const SeqView& v, int lane, int a, int nb, int go, int ge, uint8_t* trace)
+{
+#pragma unroll
+	for (int p = 0; p < P; ++p) {
+		const int k = 2 * p + PAR;
+		int E_in, F_in;
+		if (PAR == 0) {
+			E_in = st.E[k + 1];
+			F_in = p == 0 ? nb : st.F[k - 1];
+		}
+		else {
+			E_in = p == P - 1 ? nb : st.E[k + 1];
+			F_in = st.F[k - 1];
+		}
+		const bool valid = (unsigned)(a - st.a_lo[k]) <= (unsigned)st.a_span[k];
+		int cur = 0, E_out = 0, F_out = 0, tb = 0;
+		if (valid) {
+			const int d = g.d_begin + 2 * P * lane + k;
+			const int i = (a + d) >> 1, j = (a - d) >> 1;
+			const int s = match_score(v, i, j);
+			tb = cell_update<TRACE>(st.H[k], s, E_in, F_in, go, ge, cur, E_out, F_out);
+			if (COORDS) {
+				if (better_end(cur, j, i, st.best, st.best_j, st.best_i)) { st.best = cur; st.best_j = j; st.best_i = i; }
+			}
+			else
+				st.best = imax(st.best, cur);
+		}
+		st.H[k] = cur; st.E[k] = E_out; st.F[k] = F_out;
+		if (TRACE)
+			trace[p] = (uint8_t)tb;
+	}
+}
+
+// ---- traceback walk over the anti-diagonal trace (one thread per item) -------------------------
+// Follows banded_swipe.h:128-183 + TracebackVectorMatrix::TracebackIterator (banded_matrix.h:359-408)
+// and the accounting of Hsp::push_match / push_gap (basic/hssp.cpp:260-290).
+// trace layout: byte [(a - a_first) * W + (k >> 1)], W = 64*P (row stride), k = i - j - d_begin.
+struct WalkResult {
+	int q_begin, s_begin, length, identities, mismatches, positives, gap_openings, gaps, transcript_len, status;
+};
+
+DMND_HD uint8_t trace_at(const uint8_t* trace, const Geom& g, int W, int i, int j)
+{
+	const int a = i + j, k = i - j - g.d_begin;
+	if (k < 0 || k >= g.band || a < g.a_first)       // cannot happen on a valid path; keeps the walk memory-safe
+		return TB_OPEN_V | TB_OPEN_H;
+	return trace[(int64_t)(a - g.a_first) * W + (k >> 1)];
+}
+
+// transcript receives the packed operations in forward order followed by a 0 terminator;
+// cap is the number of bytes available (including the terminator).
+DMND_HD WalkResult traceback_walk(const uint8_t* trace, const Geom& g, int W, const SeqView& v, int gap_open, int gap_extend,
+	int best, int end_i, int end_j, uint8_t* transcript, int cap)
+{
+	WalkResult r;
+	r.length = r.identities = r.mismatches = r.positives = r.gap_openings = r.gaps = 0;
+	r.status = 0;
+	int i = end_i, j = end_j, sc = 0, n = 0;
+	// written backwards from the end of the slot, then moved to the front
+	while (i >= 0 && j >= 0 && sc < best) {
+		const uint8_t m = trace_at(trace, g, W, i, j);
+		if ((m & (TB_GAP_V | TB_GAP_H)) == 0) {
+			const int ql = v.q[i] & LETTER_MASK, tl = v.t[j] & LETTER_MASK;
+			int s = v.M[tl * 32 + ql];
+			const bool positive = s > 0;
+			if (v.cbs) s += v.cbs[i];
+			sc += s;
+			if (n < cap - 1) transcript[cap - 2 - n] = (uint8_t)(ql == tl ? (OP_MATCH << OP_COUNT_BITS) | 1 : (OP_SUBSTITUTION << OP_COUNT_BITS) | tl);
+			++n;
+			if (ql == tl) { ++r.identities; ++r.positives; }
+			else { ++r.mismatches; if (positive) ++r.positives; }
+			++r.length;
+			--i; --j;
+		}
+		else {
+			int l = 0;
+			if (m & TB_GAP_V) {
+				do { ++l; --i; } while (i > 0 && (trace_at(trace, g, W, i, j) & TB_OPEN_V) == 0);
+				// reference loop: do { ++l; --i; --mask; } while (!(mask->open & v) && i > 0)
+				int c = l;
+				while (c > 0) {
+					const int kk = imin(c, (int)OP_MAX_COUNT);
+					if (n < cap - 1) transcript[cap - 2 - n] = (uint8_t)((OP_INSERTION << OP_COUNT_BITS) | kk);
+					++n; c -= kk;
+				}
+			}
+			else {
+				const int j_before = j;
+				do { ++l; --j; } while (j > 0 && (trace_at(trace, g, W, i, j) & TB_OPEN_H) == 0);
+				for (int x = 0; x < l; ++x) {
+					if (n < cap - 1) transcript[cap - 2 - n] = (uint8_t)((OP_DELETION << OP_COUNT_BITS) | (v.t[j_before - x] & LETTER_MASK));
+					++n;
+				}
+			}
+			++r.gap_openings;
+			r.length += l;
+			r.gaps += l;
+			sc -= gap_open + l * gap_extend;
+		}
+	}
+	if (sc != best) r.status = -6;           // DMND_E_TRACEBACK
+	if (n > cap - 1) { r.status = -5; n = 0; }    // DMND_E_CAP
+	// move to the front of the slot (already in forward order because it was written from the back)
+	for (int x = 0; x < n; ++x) transcript[x] = transcript[cap - 1 - n + x];
+	if (cap > 0) transcript[n] = 0;
+	r.q_begin = i + 1; r.s_begin = j + 1; r.transcript_len = n;
+	return r;
+}
+
+}  // namespace dmnd

@@ -1,0 +1,51 @@
+// swipe_kernels.h -- launch interface between the host API (api.hip) and swipe_kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/diamond_hip.h"
+
+namespace dmnd {
+
+enum { WAVES_PER_BLOCK = 4 };
+
+struct SwipeEnd {            // per item: best score and its end cell (row i, column j)
+	int32_t score, end_i, end_j, pad;
+};
+
+struct SwipeArgs {
+	const int8_t* qblock;        // DMND_QUERY block letters (HBM)
+	const int8_t* tblock;        // DMND_TARGET block letters (HBM)
+	const int8_t* cbs;           // concatenated composition-bias vectors or nullptr
+	const int8_t* matrix;        // 32x32 int8 (HBM; staged to LDS per workgroup)
+	const dmnd_dp_target* items; // all items of the call (HBM)
+	const int32_t* order;        // slot -> item index, this launch's items (one P class)
+	const int64_t* trace_off;    // slot -> byte offset into trace (TRACEBACK only)
+	uint8_t* trace;
+	SwipeEnd* ends;              // indexed by item
+	int64_t n;                   // slots in this launch
+	int32_t gap_open, gap_extend;
+};
+
+struct TracebackArgs {
+	const int8_t* qblock;
+	const int8_t* tblock;
+	const int8_t* cbs;
+	const int8_t* matrix;
+	const dmnd_dp_target* items;
+	const int32_t* order;        // slot -> item index (all TRACEBACK slots of the chunk)
+	const int32_t* p_of_slot;    // slot -> P (trace row stride = 64*P)
+	const int64_t* trace_off;    // slot -> trace byte offset
+	const int64_t* transcript_off; // slot -> transcript byte offset, n+1 entries
+	const uint8_t* trace;
+	uint8_t* transcript;
+	const SwipeEnd* ends;
+	dmnd_hsp* hsps;              // indexed by item
+	int32_t* status;             // min over items of the walk status (0 = ok)
+	int64_t n;
+	int32_t gap_open, gap_extend;
+};
+
+hipError_t launch_banded_swipe(int P, int mode, const SwipeArgs& a, hipStream_t stream);
+hipError_t launch_traceback(const TracebackArgs& a, hipStream_t stream);
+
+}  // namespace dmnd

@@ -1,0 +1,150 @@
+// swipe_kernels.hip -- gfx950 (MI355X) kernels for the banded Smith-Waterman extension.
+//
+// Replaces the reference's SIMD kernels behind DP::BandedSwipe::swipe
+// (/root/reference/src/dp/swipe/banded_swipe.h:189-351, swipe_wrapper.cpp:446-470).
+// Design (see swipe_core.h for the per-lane arithmetic and DESIGN.md for the numbers):
+//   * one 64-lane wavefront per work item (DpTarget), anti-diagonal sweep; lane l owns 2*P
+//     consecutive band diagonals, P chosen per item so that 128*P >= band;
+//   * H/E/F live in VGPRs; the only cross-lane traffic is ONE DPP wave shift per step
+//     (v_mov_b32_dpp wave_shr:1 / wave_shl:1 -- no LDS, no ds_bpermute);
+//   * the 32x32 int8 substitution matrix is staged in LDS once per workgroup;
+//   * letters are read from the HBM-resident blocks through L1/L2 (adjacent lanes read adjacent
+//     bytes: lane l+1 reads query i+P, target j-P);
+//   * TRACEBACK mode streams one trace byte per cell, one coalesced 64*P-byte row per step, to an
+//     HBM arena; a second kernel walks it with one thread per item.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "swipe_core.h"
+#include "swipe_kernels.h"
+
+namespace dmnd {
+
+// wave_shr:1 -> lane l reads lane l-1, lane 0 keeps `old` (0);  wave_shl:1 -> lane l reads lane l+1, lane 63 gets 0
+__device__ __forceinline__ int wave_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int wave_shl1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }
+
+template<int P, bool COORDS, bool TRACE>
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64)
+void banded_swipe_kernel(SwipeArgs args)
+{
+	__shared__ int8_t matrix[32 * 32];
+	for (int x = threadIdx.x; x < 32 * 32 / 4; x += blockDim.x)
+		reinterpret_cast<int32_t*>(matrix)[x] = reinterpret_cast<const int32_t*>(args.matrix)[x];
+	__syncthreads();
+
+	const int lane = threadIdx.x & 63;
+	const int64_t slot = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+	if (slot >= args.n)
+		return;
+	const int32_t item_idx = args.order[slot];
+	const dmnd_dp_target it = args.items[item_idx];
+	const Geom g = make_geom(it.query_len, it.target_len, it.d_begin, it.d_end);
+	const SeqView v{ args.qblock + it.query_off, args.tblock + it.target_off,
+		it.cbs_off >= 0 ? args.cbs + it.cbs_off : nullptr, matrix };
+	const int go = args.gap_open + args.gap_extend, ge = args.gap_extend;
+
+	Lane<P, COORDS> st;
+	st.init(g, lane);
+	uint8_t* row = nullptr;
+	if (TRACE)
+		row = args.trace + args.trace_off[slot] + lane * P;
+	constexpr int W = 64 * P;
+
+	for (int a = g.a_first; a <= g.a_last; a += 2) {
+		int nb = wave_shr1(st.F[2 * P - 1]);
+		lane_step<P, COORDS, TRACE, 0>(st, g, v, lane, a, nb, go, ge, row);
+		if (TRACE) row += W;
+		// the odd step may lie past a_last: all its cells are then invalid, and its trace row is allocated
+		nb = wave_shl1(st.E[0]);
+		lane_step<P, COORDS, TRACE, 1>(st, g, v, lane, a + 1, nb, go, ge, row);
+		if (TRACE) row += W;
+	}
+
+	// wave reduction of the end cell
+	int bs = st.best, bi = st.best_i, bj = st.best_j;
+#pragma unroll
+	for (int off = 32; off >= 1; off >>= 1) {
+		const int os = __shfl_xor(bs, off), oi = __shfl_xor(bi, off), oj = __shfl_xor(bj, off);
+		if (COORDS ? better_end(os, oj, oi, bs, bj, bi) : os > bs) { bs = os; bi = oi; bj = oj; }
+	}
+	if (lane == 0) {
+		SwipeEnd e;
+		e.score = bs; e.end_i = bi; e.end_j = bj; e.pad = 0;
+		args.ends[item_idx] = e;
+	}
+}
+
+// One thread per item: walks the trace, writes the transcript slot and the alignment statistics.
+__global__ void traceback_kernel(TracebackArgs args)
+{
+	__shared__ int8_t matrix[32 * 32];
+	for (int x = threadIdx.x; x < 32 * 32 / 4; x += blockDim.x)
+		reinterpret_cast<int32_t*>(matrix)[x] = reinterpret_cast<const int32_t*>(args.matrix)[x];
+	__syncthreads();
+	const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (slot >= args.n)
+		return;
+	const int32_t item_idx = args.order[slot];
+	const dmnd_dp_target it = args.items[item_idx];
+	const SwipeEnd e = args.ends[item_idx];
+	dmnd_hsp h;
+	h.score = e.score;
+	h.q_begin = h.q_end = h.s_begin = h.s_end = 0;
+	h.length = h.identities = h.mismatches = h.positives = h.gap_openings = h.gaps = 0;
+	h.transcript_len = 0;
+	h.transcript_off = args.transcript_off[slot];
+	if (e.score > 0) {
+		const Geom g = make_geom(it.query_len, it.target_len, it.d_begin, it.d_end);
+		const SeqView v{ args.qblock + it.query_off, args.tblock + it.target_off,
+			it.cbs_off >= 0 ? args.cbs + it.cbs_off : nullptr, matrix };
+		const int W = 64 * args.p_of_slot[slot];
+		const int cap = (int)(args.transcript_off[slot + 1] - args.transcript_off[slot]);
+		const WalkResult r = traceback_walk(args.trace + args.trace_off[slot], g, W, v, args.gap_open, args.gap_extend,
+			e.score, e.end_i, e.end_j, args.transcript + args.transcript_off[slot], cap);
+		h.q_begin = r.q_begin; h.s_begin = r.s_begin; h.q_end = e.end_i + 1; h.s_end = e.end_j + 1;
+		h.length = r.length; h.identities = r.identities; h.mismatches = r.mismatches; h.positives = r.positives;
+		h.gap_openings = r.gap_openings; h.gaps = r.gaps; h.transcript_len = r.transcript_len;
+		if (r.status != 0)
+			atomicMin(args.status, r.status);
+	}
+	else if (args.transcript_off[slot + 1] > args.transcript_off[slot])
+		args.transcript[args.transcript_off[slot]] = 0;
+	args.hsps[item_idx] = h;
+}
+
+template<int P>
+static hipError_t launch_p(int mode, const SwipeArgs& a, hipStream_t stream)
+{
+	const unsigned blocks = (unsigned)((a.n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+	if (blocks == 0)
+		return hipSuccess;
+	const dim3 grid(blocks), block(WAVES_PER_BLOCK * 64);
+	if (mode == 0) hipLaunchKernelGGL((banded_swipe_kernel<P, false, false>), grid, block, 0, stream, a);
+	else if (mode == 1) hipLaunchKernelGGL((banded_swipe_kernel<P, true, false>), grid, block, 0, stream, a);
+	else hipLaunchKernelGGL((banded_swipe_kernel<P, true, true>), grid, block, 0, stream, a);
+	return hipGetLastError();
+}
+
+hipError_t launch_banded_swipe(int P, int mode, const SwipeArgs& a, hipStream_t stream)
+{
+	switch (P) {
+	case 1: return launch_p<1>(mode, a, stream);
+	case 2: return launch_p<2>(mode, a, stream);
+	case 4: return launch_p<4>(mode, a, stream);
+	case 8: return launch_p<8>(mode, a, stream);
+	case 16: return launch_p<16>(mode, a, stream);
+	case 32: return launch_p<32>(mode, a, stream);
+	default: return hipErrorInvalidValue;
+	}
+}
+
+hipError_t launch_traceback(const TracebackArgs& a, hipStream_t stream)
+{
+	if (a.n == 0)
+		return hipSuccess;
+	const unsigned threads = 64, blocks = (unsigned)((a.n + threads - 1) / threads);
+	hipLaunchKernelGGL(traceback_kernel, dim3(blocks), dim3(threads), 0, stream, a);
+	return hipGetLastError();
+}
+
+}  // namespace dmnd

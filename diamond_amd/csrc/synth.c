@@ -8,6 +8,8 @@
  * indels (rate indel_rate per site, geometric length p=0.5). Queries are fresh mutants of uniformly
  * chosen ancestors (rate U(q_lo,q_hi)) with a fraction of pure-random decoys.
  *
+ * q_family[q] = index of the family a query was derived from (its members are database sequences
+ * family*members .. family*members+members-1), or -1 for a decoy.
  * Output is letters in the reference's amino-acid code (0..19 = "ARNDCQEGHILKMFPSTWYV",
  * src/basic/value.h:53) in one flat buffer + offsets, or FASTA text for the reference CLI.
  * Plain C, no dependencies: used by bench.py / tests through ctypes and by the C++ host driver.
@@ -94,7 +96,7 @@ typedef struct {
 /* Generates database and queries into caller-visible malloc'ed buffers.
  * db_data/q_data: letters back to back (no delimiters); *_off: n+1 int64 offsets. Free with synth_free. */
 int synth_generate(const synth_cfg* c, int8_t** db_data, int64_t** db_off, int64_t* db_n,
-	int8_t** q_data, int64_t** q_off, int64_t* q_n)
+	int8_t** q_data, int64_t** q_off, int64_t* q_n, int64_t** q_family)
 {
 	init_cdf();
 	rng_t r; rng_seed(&r, c->seed);
@@ -130,18 +132,21 @@ int synth_generate(const synth_cfg* c, int8_t** db_data, int64_t** db_off, int64
 	int64_t qcap = (int64_t)((double)c->queries * (c->len_mean + 16) * 1.1) + 1024, qpos = 0;
 	int8_t* qd = (int8_t*)malloc((size_t)qcap);
 	int64_t* qoff = (int64_t*)malloc(sizeof(int64_t) * (size_t)(c->queries + 1));
-	if (!qd || !qoff) return -1;
+	int64_t* qfam = (int64_t*)malloc(sizeof(int64_t) * (size_t)(c->queries + 1));
+	if (!qd || !qoff || !qfam) return -1;
 	qoff[0] = 0;
 	for (int64_t q = 0; q < c->queries; ++q) {
 		int l;
 		if (rng_u(&r) < c->decoy_frac) {
 			l = rand_len(&r, c->len_mean, c->len_sd, c->len_min, c->len_max);
 			for (int i = 0; i < l; ++i) tmp[i] = rand_letter(&r);
+			qfam[q] = -1;
 		}
 		else {
 			const int64_t f = (int64_t)(rng_u(&r) * (double)c->families) % c->families;
 			const double sub = c->q_lo + (c->q_hi - c->q_lo) * rng_u(&r);
 			l = mutate(&r, anc_all + f * c->len_max, anc_len[f], sub, c->indel, tmp, cap);
+			qfam[q] = f;
 		}
 		if (qpos + l > qcap) {
 			qcap = qcap * 3 / 2 + l;
@@ -155,6 +160,7 @@ int synth_generate(const synth_cfg* c, int8_t** db_data, int64_t** db_off, int64
 	free(anc_all); free(anc_len); free(tmp);
 	*db_data = dd; *db_off = doff; *db_n = n_db;
 	*q_data = qd; *q_off = qoff; *q_n = c->queries;
+	if (q_family) *q_family = qfam; else free(qfam);
 	return 0;
 }
 

@@ -1,0 +1,187 @@
+"""ctypes host mirror of the C ABI in include/diamond_hip.h (libdiamond_hip.so).
+
+This is plumbing only: it loads the in-tree HIP library and marshals numpy arrays. There is no CPU
+fallback -- if the library is missing or no gfx950 device is visible, calls raise DiamondHipError.
+The method names mirror the reference's operator interface: `banded_swipe` is
+DP::BandedSwipe::swipe (/root/reference/src/dp/dp.h:287)."""
+import ctypes
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdiamond_hip.so")
+
+SWIPE_SCORE, SWIPE_COORDS, SWIPE_TRACEBACK, SWIPE_STATS = 0, 1, 2, 3
+QUERY, TARGET = 0, 1
+
+
+class DiamondHipError(RuntimeError):
+    pass
+
+
+class Params(ctypes.Structure):
+    _fields_ = [("matrix8", ctypes.c_int8 * 1024), ("gap_open", ctypes.c_int32), ("gap_extend", ctypes.c_int32),
+                ("lambda_", ctypes.c_double), ("K", ctypes.c_double), ("alpha", ctypes.c_double),
+                ("alpha_v", ctypes.c_double), ("sigma", ctypes.c_double), ("u_alpha", ctypes.c_double),
+                ("u_alpha_v", ctypes.c_double), ("db_letters", ctypes.c_double), ("max_evalue", ctypes.c_double)]
+
+
+DP_TARGET_DTYPE = np.dtype([("query_off", "<i8"), ("target_off", "<i8"), ("cbs_off", "<i8"), ("query_len", "<i4"),
+                            ("target_len", "<i4"), ("d_begin", "<i4"), ("d_end", "<i4")], align=True)
+HSP_DTYPE = np.dtype([("score", "<i4"), ("q_begin", "<i4"), ("q_end", "<i4"), ("s_begin", "<i4"), ("s_end", "<i4"),
+                      ("length", "<i4"), ("identities", "<i4"), ("mismatches", "<i4"), ("positives", "<i4"),
+                      ("gap_openings", "<i4"), ("gaps", "<i4"), ("transcript_len", "<i4"), ("transcript_off", "<i8")],
+                     align=True)
+HOST_TARGET_DTYPE = np.dtype([("seq", "<u8"), ("len", "<i4"), ("d_begin", "<i4"), ("d_end", "<i4")], align=True)
+assert DP_TARGET_DTYPE.itemsize == 40 and HSP_DTYPE.itemsize == 56 and HOST_TARGET_DTYPE.itemsize == 24
+
+_lib = None
+
+EXPORTS = ["dmnd_abi_version", "dmnd_last_error", "dmnd_default_params", "dmnd_create", "dmnd_destroy",
+           "dmnd_set_db_letters", "dmnd_upload_block", "dmnd_upload_cbs", "dmnd_banded_swipe",
+           "dmnd_banded_swipe_host", "dmnd_banded_cols", "dmnd_evalue", "dmnd_bitscore", "dmnd_evalue_p",
+           "dmnd_bitscore_p", "dmnd_evalue_batch", "dmnd_last_kernel_ms"]
+
+
+def load():
+    """Loads libdiamond_hip.so (fails loudly if it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DiamondHipError("libdiamond_hip.so is not built: run `make product` (needs hipcc)")
+        lib = ctypes.CDLL(LIB_PATH)
+        lib.dmnd_last_error.restype = ctypes.c_char_p
+        lib.dmnd_create.restype = ctypes.c_void_p
+        lib.dmnd_create.argtypes = [ctypes.c_int, ctypes.POINTER(Params)]
+        lib.dmnd_destroy.argtypes = [ctypes.c_void_p]
+        lib.dmnd_set_db_letters.argtypes = [ctypes.c_void_p, ctypes.c_double]
+        lib.dmnd_upload_block.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]
+        lib.dmnd_upload_cbs.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
+        lib.dmnd_banded_swipe.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_uint32,
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
+        lib.dmnd_banded_swipe_host.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_int64, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
+        lib.dmnd_banded_cols.restype = ctypes.c_int32
+        lib.dmnd_evalue.restype = ctypes.c_double
+        lib.dmnd_evalue.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32, ctypes.c_uint32]
+        lib.dmnd_bitscore.restype = ctypes.c_double
+        lib.dmnd_bitscore.argtypes = [ctypes.c_void_p, ctypes.c_double]
+        lib.dmnd_evalue_p.restype = ctypes.c_double
+        lib.dmnd_evalue_p.argtypes = [ctypes.POINTER(Params), ctypes.c_int32, ctypes.c_uint32, ctypes.c_uint32]
+        lib.dmnd_bitscore_p.restype = ctypes.c_double
+        lib.dmnd_bitscore_p.argtypes = [ctypes.POINTER(Params), ctypes.c_double]
+        lib.dmnd_last_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+        _lib = lib
+    return _lib
+
+
+def default_params():
+    p = Params()
+    rc = load().dmnd_default_params(ctypes.byref(p))
+    if rc != 0:
+        raise DiamondHipError(load().dmnd_last_error().decode())
+    return p
+
+
+def evalue_batch(p, score, qlen, slen):
+    """ScoreMatrix::evalue for arrays (host double precision)."""
+    score = np.ascontiguousarray(score, dtype=np.int32)
+    qlen = np.ascontiguousarray(qlen, dtype=np.int32)
+    slen = np.ascontiguousarray(slen, dtype=np.int32)
+    out = np.zeros(score.size, np.float64)
+    lib = load()
+    rc = lib.dmnd_evalue_batch(ctypes.byref(p), score.ctypes.data_as(ctypes.c_void_p), qlen.ctypes.data_as(ctypes.c_void_p),
+                               slen.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(score.size), out.ctypes.data_as(ctypes.c_void_p))
+    if rc != 0:
+        raise DiamondHipError(lib.dmnd_last_error().decode())
+    return out
+
+
+def matrix_of(p):
+    return np.frombuffer(bytes(p.matrix8), dtype=np.int8).reshape(32, 32).copy()
+
+
+class Context:
+    """One dmnd_ctx = one MI355X."""
+
+    def __init__(self, device=-1, params=None):
+        self.lib = load()
+        self.params = params if params is not None else default_params()
+        self.h = self.lib.dmnd_create(device, ctypes.byref(self.params))
+        if not self.h:
+            raise DiamondHipError(self.lib.dmnd_last_error().decode())
+
+    def close(self):
+        if self.h:
+            self.lib.dmnd_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise DiamondHipError("error %d: %s" % (rc, self.lib.dmnd_last_error().decode()))
+
+    def set_db_letters(self, n):
+        self._check(self.lib.dmnd_set_db_letters(self.h, float(n)))
+
+    def upload_block(self, which, data, limits=None):
+        data = np.ascontiguousarray(data, dtype=np.int8)
+        lim = np.ascontiguousarray(limits, dtype=np.int64) if limits is not None else None
+        self._check(self.lib.dmnd_upload_block(self.h, which, data.ctypes.data, data.size,
+                                               lim.ctypes.data if lim is not None else None,
+                                               (lim.size - 1) if lim is not None else 0))
+
+    def upload_cbs(self, cbs):
+        cbs = np.ascontiguousarray(cbs, dtype=np.int8)
+        self._check(self.lib.dmnd_upload_cbs(self.h, cbs.ctypes.data if cbs.size else None, cbs.size))
+
+    def banded_swipe(self, items, mode, hsp_values=0, transcript_cap=None):
+        """items: structured array of DP_TARGET_DTYPE. Returns (hsps[HSP_DTYPE], transcript bytes or None)."""
+        items = np.ascontiguousarray(items, dtype=DP_TARGET_DTYPE)
+        out = np.zeros(items.size, dtype=HSP_DTYPE)
+        tr = None
+        used = ctypes.c_int64(0)
+        if mode == SWIPE_TRACEBACK:
+            if transcript_cap is None:
+                transcript_cap = int((items["query_len"].astype(np.int64) + items["target_len"] + 2).sum()) + 16
+            tr = np.zeros(transcript_cap, np.uint8)
+        self._check(self.lib.dmnd_banded_swipe(self.h, items.ctypes.data, items.size, mode, hsp_values, out.ctypes.data,
+                                               tr.ctypes.data if tr is not None else None,
+                                               tr.size if tr is not None else 0, ctypes.byref(used)))
+        return out, (tr[:used.value] if tr is not None else None)
+
+    def banded_swipe_host(self, query, cbs, targets, mode, hsp_values=0):
+        """targets: list of (seq int8[], d_begin, d_end): the literal reference call shape (one query)."""
+        q = np.ascontiguousarray(query, dtype=np.int8)
+        c = np.ascontiguousarray(cbs, dtype=np.int8) if cbs is not None else None
+        seqs = [np.ascontiguousarray(t[0], dtype=np.int8) for t in targets]
+        ht = np.zeros(len(targets), dtype=HOST_TARGET_DTYPE)
+        for k, (s, t) in enumerate(zip(seqs, targets)):
+            ht[k] = (s.ctypes.data, s.size, t[1], t[2])
+        out = np.zeros(len(targets), dtype=HSP_DTYPE)
+        tr = None
+        used = ctypes.c_int64(0)
+        if mode == SWIPE_TRACEBACK:
+            tr = np.zeros(sum(s.size + q.size + 2 for s in seqs) + 16, np.uint8)
+        self._check(self.lib.dmnd_banded_swipe_host(self.h, q.ctypes.data, q.size, c.ctypes.data if c is not None else None,
+                                                    ht.ctypes.data, len(targets), mode, hsp_values, out.ctypes.data,
+                                                    tr.ctypes.data if tr is not None else None,
+                                                    tr.size if tr is not None else 0, ctypes.byref(used)))
+        return out, (tr[:used.value] if tr is not None else None)
+
+    def last_kernel_ms(self):
+        a, b = ctypes.c_double(0), ctypes.c_double(0)
+        self._check(self.lib.dmnd_last_kernel_ms(self.h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
+    def evalue(self, score, qlen, slen):
+        return self.lib.dmnd_evalue(self.h, int(score), int(qlen), int(slen))
+
+    def bitscore(self, score):
+        return self.lib.dmnd_bitscore(self.h, float(score))

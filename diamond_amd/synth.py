@@ -26,8 +26,9 @@ def _lib():
 
 
 def generate(families, members=10, queries=1000, seed=20260923, decoy_frac=0.05, len_mean=300.0, len_sd=80.0,
-             len_min=50, len_max=2000, sub=(0.1, 0.6), qsub=(0.2, 0.5), indel=0.02):
-    """Returns (db_letters int8[], db_offsets int64[n+1], q_letters, q_offsets)."""
+             len_min=50, len_max=2000, sub=(0.1, 0.6), qsub=(0.2, 0.5), indel=0.02, family=False):
+    """Returns (db_letters int8[], db_offsets int64[n+1], q_letters, q_offsets); with family=True also the
+    family index each query was derived from (-1 = decoy)."""
     lib = _lib()
     cfg = _Cfg(seed, families, members, queries, decoy_frac, len_mean, len_sd, len_min, len_max,
                sub[0], sub[1], qsub[0], qsub[1], indel)
@@ -35,10 +36,11 @@ def generate(families, members=10, queries=1000, seed=20260923, decoy_frac=0.05,
     do = ctypes.POINTER(ctypes.c_int64)()
     qd = ctypes.POINTER(ctypes.c_int8)()
     qo = ctypes.POINTER(ctypes.c_int64)()
+    qf = ctypes.POINTER(ctypes.c_int64)()
     dn = ctypes.c_int64()
     qn = ctypes.c_int64()
     rc = lib.synth_generate(ctypes.byref(cfg), ctypes.byref(dd), ctypes.byref(do), ctypes.byref(dn),
-                            ctypes.byref(qd), ctypes.byref(qo), ctypes.byref(qn))
+                            ctypes.byref(qd), ctypes.byref(qo), ctypes.byref(qn), ctypes.byref(qf))
     if rc != 0:
         raise MemoryError("synth_generate failed")
     try:
@@ -46,9 +48,12 @@ def generate(families, members=10, queries=1000, seed=20260923, decoy_frac=0.05,
         q_off = np.ctypeslib.as_array(qo, shape=(qn.value + 1,)).copy()
         db = np.ctypeslib.as_array(dd, shape=(int(db_off[-1]),)).copy()
         q = np.ctypeslib.as_array(qd, shape=(int(q_off[-1]),)).copy()
+        fam = np.ctypeslib.as_array(qf, shape=(qn.value,)).copy()
     finally:
-        for p in (dd, do, qd, qo):
+        for p in (dd, do, qd, qo, qf):
             lib.synth_free(p)
+    if family:
+        return db, db_off, q, q_off, fam
     return db, db_off, q, q_off
 
 

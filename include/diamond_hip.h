@@ -1,0 +1,162 @@
+/* diamond_hip.h -- C ABI of libdiamond_hip.so: the MI355X (gfx950) back end for DIAMOND's
+ * seed-and-extend hot path.
+ *
+ * This is the drop-in boundary.  The reference's own operator seam is its
+ * DISPATCH_ARCH switch (/root/reference/src/util/simd/dispatch.h:45-228): the functions below are
+ * what one more case of that switch binds.  Every entry point cites the reference interface it
+ * replaces.  POD only (plain pointers + sizes), no STL, no torch types.
+ *
+ * Conventions
+ *   - return value: 0 = ok, negative = error (DMND_E_*); dmnd_last_error() gives the text
+ *     (the reference throws std::runtime_error across this seam, src/run/main.cpp:211-232).
+ *   - a dmnd_ctx owns one HIP device, its streams and all device buffers; calls on one ctx are
+ *     serialised by the caller (one ctx per host thread / per GPU); distinct ctxs are independent.
+ *   - letters are the reference's Letter codes (int8; 0..19 amino acids, 20-22 BJZ, 23 X/mask,
+ *     24 '*', 25 super-hard mask, 31 delimiter; bit 7 = SEED_MASK; src/basic/value.h:53-65).
+ *   - there is NO CPU fallback: if no gfx950 device is usable every call fails with DMND_E_DEVICE.
+ */
+#ifndef DIAMOND_HIP_H
+#define DIAMOND_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DMND_ABI_VERSION 1
+
+enum {
+	DMND_OK = 0,
+	DMND_E_ARG = -1,        /* bad argument */
+	DMND_E_DEVICE = -2,     /* no usable gfx950 device / HIP error */
+	DMND_E_NOMEM = -3,      /* device or host allocation failed */
+	DMND_E_BAND = -4,       /* band wider than DMND_MAX_BAND ("Band size exceeds row counter maximum", banded_swipe.h:204) */
+	DMND_E_CAP = -5,        /* caller-provided output arena too small */
+	DMND_E_TRACEBACK = -6   /* "Traceback error." (banded_swipe.h:168) */
+};
+
+#define DMND_MAX_BAND 4096
+
+/* which sequence block (reference: Search::Config::query / ::target Blocks, src/run/config.h) */
+enum { DMND_QUERY = 0, DMND_TARGET = 1 };
+
+/* HspValues bit set, identical to the reference's enum (src/basic/match.h: HspValues) */
+enum {
+	DMND_HSP_NONE = 0, DMND_HSP_TRANSCRIPT = 1, DMND_HSP_QUERY_START = 1 << 1, DMND_HSP_QUERY_END = 1 << 2,
+	DMND_HSP_TARGET_START = 1 << 3, DMND_HSP_TARGET_END = 1 << 4, DMND_HSP_IDENT = 1 << 5, DMND_HSP_LENGTH = 1 << 6,
+	DMND_HSP_MISMATCHES = 1 << 7, DMND_HSP_GAP_OPENINGS = 1 << 8,
+	DMND_HSP_COORDS = (1 << 1) | (1 << 2) | (1 << 3) | (1 << 4)
+};
+
+/* how one target is to be computed; mirrors the Cfg chosen by dispatch_swipe()
+ * (src/dp/swipe/swipe_wrapper.cpp:183-217) */
+enum {
+	DMND_SWIPE_SCORE = 0,      /* score only                         (HspValues::NONE)                 */
+	DMND_SWIPE_COORDS = 1,     /* + end coordinates                  (VectorRowCounter)                */
+	DMND_SWIPE_TRACEBACK = 2,  /* + start coords, transcript, stats  (bins 0-2, TracebackVectorMatrix) */
+	DMND_SWIPE_STATS = 3       /* statistics without traceback: ForwardCell pass + reversed BackwardCell
+	                              pass (bins 3-5, recompute_reversed, swipe_wrapper.cpp:364-444)      */
+};
+
+typedef struct dmnd_ctx dmnd_ctx;
+
+/* Scoring + statistics parameters: the globals the reference reads across the seam
+ * (`score_matrix`, `config`; SURVEY.md 8b "Global state read across the seam"). */
+typedef struct {
+	int8_t matrix8[32 * 32];   /* ScoreMatrix::matrix8(), src/stats/score_matrix.h:69 (row = letter, 32 columns) */
+	int32_t gap_open;          /* ScoreMatrix::gap_open()   (BLOSUM62 default 11) */
+	int32_t gap_extend;        /* ScoreMatrix::gap_extend() (default 1) */
+	/* Gumbel constants for ScoreMatrix::evalue (src/stats/score_matrix.cpp:43-47,217): gapped row and ungapped row */
+	double lambda, K, alpha, alpha_v, sigma, u_alpha, u_alpha_v;
+	double db_letters;         /* ScoreMatrix::db_letters() */
+	double max_evalue;         /* config.max_evalue (report_cutoff, score_matrix.cpp:234) */
+} dmnd_params;
+
+/* One banded-DP work item = one DpTarget of the reference (src/dp/dp.h:34-157) together with the
+ * query it is aligned against (DP::Params::query / composition_bias, src/dp/dp.h:171-184).
+ * Offsets address letters inside the blocks uploaded with dmnd_upload_block(). */
+typedef struct {
+	int64_t query_off;    /* first query letter, offset into the DMND_QUERY block data */
+	int64_t target_off;   /* first target letter, offset into the DMND_TARGET block data */
+	int64_t cbs_off;      /* offset of the query's int8 composition bias inside the uploaded bias buffer, or -1 (NoCBS) */
+	int32_t query_len;
+	int32_t target_len;   /* DpTarget::seq.length() (a prefix length in reversed passes) */
+	int32_t d_begin;      /* diagonal band [d_begin, d_end), diagonal = i - j */
+	int32_t d_end;
+} dmnd_dp_target;
+
+/* Result of one work item = the fields of Hsp the swipe fills (src/basic/match.h:45-330,
+ * banded_swipe.h:88-183).  Fields a mode does not compute are 0. */
+typedef struct {
+	int32_t score;
+	int32_t q_begin, q_end, s_begin, s_end;     /* query_range / subject_range, end exclusive */
+	int32_t length, identities, mismatches, positives, gap_openings, gaps;
+	int32_t transcript_len;                     /* PackedOperation bytes, without the terminator */
+	int64_t transcript_off;                     /* offset into the transcript arena */
+} dmnd_hsp;
+
+/* -- lifecycle ---------------------------------------------------------------------------------- */
+int dmnd_abi_version(void);
+const char* dmnd_last_error(void);
+/* Fills params with the reference's defaults: BLOSUM62, gap open 11 / extend 1
+ * (ScoreMatrix ctor, src/stats/score_matrix.cpp:49-72), max_evalue 0.001. */
+int dmnd_default_params(dmnd_params* params);
+/* device < 0: use the current HIP device. Fails (NULL) when no gfx950 device is present. */
+dmnd_ctx* dmnd_create(int device, const dmnd_params* params);
+void dmnd_destroy(dmnd_ctx* ctx);
+/* ScoreMatrix::set_db_letters (src/run/double_indexed.cpp:900) */
+int dmnd_set_db_letters(dmnd_ctx* ctx, double db_letters);
+
+/* -- data: SequenceSet / Block residency (src/data/string_set.h:27-318, sequence_set.h:25) ------- */
+/* Uploads the flat letter store of a block (the reference's data_ vector, padding and 0x1F
+ * delimiters included, exactly as laid out in host memory) and keeps it resident in HBM.
+ * limits may be NULL when only the DP entry points are used. */
+int dmnd_upload_block(dmnd_ctx* ctx, int which, const int8_t* data, int64_t data_len,
+	const int64_t* limits, int64_t n_seqs);
+/* Uploads the per-query Hauser composition-bias vectors (HauserCorrection::int8,
+ * src/stats/hauser_correction.cpp:107), concatenated; dmnd_dp_target::cbs_off indexes this buffer. */
+int dmnd_upload_cbs(dmnd_ctx* ctx, const int8_t* cbs, int64_t len);
+
+/* -- banded Smith-Waterman: replaces DP::BandedSwipe::swipe (src/dp/dp.h:287;
+ *    dispatcher src/dp/swipe/swipe_wrapper.cpp:446-470,487) -------------------------------------- */
+/* Computes n work items in one batched launch (any mix of queries).  mode is DMND_SWIPE_*;
+ * hsp_values (DMND_HSP_* bits) selects the cell types of DMND_SWIPE_STATS as dispatch_swipe() does.
+ * out[n] receives one dmnd_hsp per item (input order).  transcript (may be NULL unless mode is
+ * TRACEBACK) is a caller-owned host arena of transcript_cap bytes receiving the packed edit
+ * transcripts (PackedOperation codes, src/basic/packed_transcript.h:30-90), each followed by a 0
+ * terminator; *transcript_used returns the bytes written.
+ * Unlike the SIMD reference there is no 8/16/32-bit escalation: scores are exact int32. */
+int dmnd_banded_swipe(dmnd_ctx* ctx, const dmnd_dp_target* items, int64_t n, int mode, uint32_t hsp_values,
+	dmnd_hsp* out, uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used);
+
+/* Same computation on caller-owned HOST sequences -- the literal shape of the reference call
+ * (one query, its DpTargets as pointer+length): stages the letters into HBM, then runs the batch. */
+typedef struct {
+	const int8_t* seq;     /* DpTarget::seq.data() */
+	int32_t len;           /* DpTarget::seq.length() */
+	int32_t d_begin, d_end;
+} dmnd_host_target;
+int dmnd_banded_swipe_host(dmnd_ctx* ctx, const int8_t* query, int32_t query_len, const int8_t* cbs,
+	const dmnd_host_target* targets, int64_t n, int mode, uint32_t hsp_values,
+	dmnd_hsp* out, uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used);
+
+/* DpTarget::banded_cols (src/dp/dp.h:47-52) and DpTarget::cells (:121-124): the cell count the
+ * GCUPS metric is defined on. */
+int32_t dmnd_banded_cols(int32_t qlen, int32_t tlen, int32_t d_begin, int32_t d_end);
+
+/* ScoreMatrix::evalue / bitscore (src/stats/score_matrix.cpp:217,250), host double precision. */
+double dmnd_evalue(const dmnd_ctx* ctx, int32_t raw_score, uint32_t query_len, uint32_t subject_len);
+double dmnd_bitscore(const dmnd_ctx* ctx, double raw_score);
+/* context-free forms (pure host arithmetic on a parameter block) */
+double dmnd_evalue_p(const dmnd_params* params, int32_t raw_score, uint32_t query_len, uint32_t subject_len);
+double dmnd_bitscore_p(const dmnd_params* params, double raw_score);
+int dmnd_evalue_batch(const dmnd_params* params, const int32_t* raw_score, const int32_t* query_len,
+	const int32_t* subject_len, int64_t n, double* out);
+
+/* -- timing hooks for bench.py: device time of the DP kernels of the last dmnd_banded_swipe call,
+ *    measured with HIP events on the stream the kernels ran on ------------------------------------ */
+int dmnd_last_kernel_ms(const dmnd_ctx* ctx, double* swipe_ms, double* traceback_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,77 @@
+// tests/emu/swipe_emu.cpp -- TEST INFRASTRUCTURE ONLY.
+// CPU lane-emulator of the wavefront schedule in diamond_amd/csrc/swipe_kernels.hip: runs the SAME
+// per-lane code (diamond_amd/csrc/swipe_core.h) for 64 emulated lanes in lock-step, with the DPP
+// wave shifts replaced by array indexing. Lets the CPU test-suite check the anti-diagonal index
+// arithmetic, tie-breaking and the traceback walk against oracle/ without a GPU. Never used by the
+// product (the product path is the HIP library and fails loudly without a GPU).
+#include <vector>
+#include <cstring>
+#include "../../diamond_amd/csrc/swipe_core.h"
+
+using namespace dmnd;
+
+struct EmuOut {
+	int32_t score, q_begin, q_end, s_begin, s_end, length, identities, mismatches, positives, gap_openings, gaps, transcript_len, status;
+};
+
+template<int P, bool COORDS, bool TRACE>
+static void run(const SeqView& v, int qlen, int tlen, int d_begin, int d_end, int gap_open, int gap_extend, EmuOut* out, uint8_t* transcript, int cap)
+{
+	const Geom g = make_geom(qlen, tlen, d_begin, d_end);
+	const int go = gap_open + gap_extend, ge = gap_extend, W = 64 * P;
+	std::vector<Lane<P, COORDS>> st(64);
+	for (int l = 0; l < 64; ++l) st[l].init(g, l);
+	std::vector<uint8_t> trace;
+	if (TRACE) trace.assign((size_t)n_steps(g) * W + 1, 0xee);
+	int nb[64];
+	for (int a = g.a_first; a <= g.a_last; a += 2) {
+		uint8_t* row = TRACE ? trace.data() + (size_t)(a - g.a_first) * W : nullptr;
+		for (int l = 0; l < 64; ++l) nb[l] = l == 0 ? 0 : st[l - 1].F[2 * P - 1];       // wave_shr:1, lane 0 reads 0
+		for (int l = 0; l < 64; ++l) lane_step<P, COORDS, TRACE, 0>(st[l], g, v, l, a, nb[l], go, ge, row ? row + l * P : nullptr);
+		if (a + 1 > g.a_last) break;
+		row = TRACE ? trace.data() + (size_t)(a + 1 - g.a_first) * W : nullptr;
+		for (int l = 0; l < 64; ++l) nb[l] = l == 63 ? 0 : st[l + 1].E[0];               // wave_shl:1, lane 63 reads 0
+		for (int l = 0; l < 64; ++l) lane_step<P, COORDS, TRACE, 1>(st[l], g, v, l, a + 1, nb[l], go, ge, row ? row + l * P : nullptr);
+	}
+	int bs = 0, bi = 0, bj = 0x7fffffff;
+	for (int l = 0; l < 64; ++l) {
+		if (COORDS ? better_end(st[l].best, st[l].best_j, st[l].best_i, bs, bj, bi) : st[l].best > bs) {
+			bs = st[l].best; bi = st[l].best_i; bj = st[l].best_j;
+		}
+	}
+	memset(out, 0, sizeof(*out));
+	out->score = bs;
+	if (COORDS && bs > 0) { out->q_end = bi + 1; out->s_end = bj + 1; }
+	if (TRACE && bs > 0) {
+		const WalkResult r = traceback_walk(trace.data(), g, W, v, gap_open, gap_extend, bs, bi, bj, transcript, cap);
+		out->q_begin = r.q_begin; out->s_begin = r.s_begin; out->length = r.length; out->identities = r.identities;
+		out->mismatches = r.mismatches; out->positives = r.positives; out->gap_openings = r.gap_openings; out->gaps = r.gaps;
+		out->transcript_len = r.transcript_len; out->status = r.status;
+	}
+}
+
+template<int P>
+static void run_mode(int mode, const SeqView& v, int qlen, int tlen, int d_begin, int d_end, int go, int ge, EmuOut* out, uint8_t* tr, int cap)
+{
+	if (mode == 0) run<P, false, false>(v, qlen, tlen, d_begin, d_end, go, ge, out, tr, cap);
+	else if (mode == 1) run<P, true, false>(v, qlen, tlen, d_begin, d_end, go, ge, out, tr, cap);
+	else run<P, true, true>(v, qlen, tlen, d_begin, d_end, go, ge, out, tr, cap);
+}
+
+extern "C" int emu_banded_swipe(const int8_t* q, int qlen, const int8_t* cbs, const int8_t* t, int tlen, int d_begin, int d_end,
+	const int8_t* M, int gap_open, int gap_extend, int mode, int force_p, EmuOut* out, uint8_t* transcript, int cap)
+{
+	const int band = d_end - d_begin;
+	int P = 1;
+	while (128 * P < band) P *= 2;
+	if (force_p > P) P = force_p;
+	const SeqView v{ q, t, cbs, M };
+	switch (P) {
+	case 1: run_mode<1>(mode, v, qlen, tlen, d_begin, d_end, gap_open, gap_extend, out, transcript, cap); break;
+	case 2: run_mode<2>(mode, v, qlen, tlen, d_begin, d_end, gap_open, gap_extend, out, transcript, cap); break;
+	case 4: run_mode<4>(mode, v, qlen, tlen, d_begin, d_end, gap_open, gap_extend, out, transcript, cap); break;
+	case 8: run_mode<8>(mode, v, qlen, tlen, d_begin, d_end, gap_open, gap_extend, out, transcript, cap); break;
+	default: return -4;
+	}
+	return 0;
+}

@@ -1,0 +1,239 @@
+"""-m gpu parity tests of the HIP banded Smith-Waterman, called through the C ABI
+(dmnd_banded_swipe / dmnd_banded_swipe_host in include/diamond_hip.h):
+  * against the committed golden vectors minted from the genuine reference (tests/golden/*.tap),
+  * against the CPU oracle on seeded random inputs incl. the edge geometries the reference's
+    band logic allows (bands leaving the matrix, 1-letter sequences, wide bands -> every P class),
+  * at BASELINE-config scale through size-independent properties (mode agreement, transcript
+    re-scoring, batch-order independence)."""
+import os
+import numpy as np
+import pytest
+import torch
+
+import oracle_py as orc
+from tapfile import read_tap
+from diamond_amd import hip, synth
+from gpu_util import pack_records
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+KEYS = "score q_begin q_end s_begin s_end length identities mismatches positives gap_openings gaps".split()
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    c = hip.Context()
+    yield c
+    c.close()
+
+
+def _transcript(tr, h):
+    return tr[h["transcript_off"]: h["transcript_off"] + h["transcript_len"]]
+
+
+@pytest.mark.parametrize("tap", ["swipe_default.tap", "swipe_fast.tap", "swipe_blastx.tap"])
+def test_golden_reference_calls(ctx, tap):
+    hdr, recs = read_tap(os.path.join(GOLDEN, tap))
+    for v, mode in ((0, hip.SWIPE_SCORE), (510, hip.SWIPE_TRACEBACK)):
+        sel = [r for r in recs if r["hsp_values"] == v]
+        if not sel:
+            continue
+        qb, tb, cbs, items, meta = pack_records(sel)
+        ctx.upload_block(hip.QUERY, qb)
+        ctx.upload_block(hip.TARGET, tb)
+        ctx.upload_cbs(cbs)
+        out, tr = ctx.banded_swipe(items, mode, v)
+        p = hip.default_params()
+        p.db_letters = hdr["db_letters"]
+        n_checked = 0
+        for k, (rec, t) in enumerate(meta):
+            hs = [h for h in rec["hsps"] if (h["swipe_target"], h["d_begin"], h["d_end"]) == (t["target_idx"], t["d_begin"], t["d_end"])]
+            o = out[k]
+            if not hs:
+                ev = ctx.lib.dmnd_evalue_p(p, int(o["score"]), len(rec["query"]), t["true_target_len"]) if o["score"] > 0 else 1e9
+                assert o["score"] <= 0 or ev > hdr["max_evalue"]
+                continue
+            h = hs[0]
+            assert o["score"] == h["score"]
+            if mode == hip.SWIPE_TRACEBACK and h["swipe_bin"] < 3:
+                for key in KEYS:
+                    assert o[key] == h[key], (key, k)
+                assert np.array_equal(_transcript(tr, o), h["transcript"][:-1])
+                assert tr[o["transcript_off"] + o["transcript_len"]] == 0
+            n_checked += 1
+        assert n_checked > 0
+
+
+def _random_items(rng, n, M, wide=False):
+    recs = []
+    for it in range(n):
+        qlen = int(rng.integers(1, 400 if not wide else 1500))
+        q = rng.integers(0, 25, qlen).astype(np.int8)
+        if it % 2 == 0:
+            t = q.copy()
+            mut = rng.random(qlen) < 0.35
+            t[mut] = rng.integers(0, 20, int(mut.sum()))
+            cut = int(rng.integers(0, qlen))
+            t = np.concatenate([t[:cut], rng.integers(0, 20, int(rng.integers(0, 8))).astype(np.int8), t[cut + int(rng.integers(0, 5)):]])
+            if len(t) == 0:
+                t = q[:1].copy()
+        else:
+            t = rng.integers(0, 25, int(rng.integers(1, 400))).astype(np.int8)
+        tlen = len(t)
+        if it % 5 == 0:
+            q[rng.integers(0, qlen)] |= -128
+        d0 = int(rng.integers(-(tlen - 1) - 5, qlen + 3))
+        width = int(rng.integers(1, 140)) if not wide else int(rng.integers(100, 1100))
+        d1 = d0 + width
+        if d1 <= -(tlen - 1) or d0 >= qlen:
+            d0, d1 = -3, 4
+        cbs = rng.integers(-3, 2, qlen).astype(np.int8) if it % 3 else None
+        recs.append({"query": q, "cbs": cbs, "targets": [{"seq": t, "d_begin": d0, "d_end": d1}]})
+    return recs
+
+
+@pytest.mark.parametrize("wide", [False, True])
+def test_random_geometry_against_oracle(ctx, wide):
+    M = hip.matrix_of(ctx.params)
+    rng = np.random.default_rng(11 + wide)
+    recs = _random_items(rng, 400 if not wide else 120, M, wide)
+    qb, tb, cbs, items, meta = pack_records(recs)
+    ctx.upload_block(hip.QUERY, qb)
+    ctx.upload_block(hip.TARGET, tb)
+    ctx.upload_cbs(cbs)
+    res = {}
+    for mode in (hip.SWIPE_SCORE, hip.SWIPE_COORDS, hip.SWIPE_TRACEBACK):
+        res[mode] = ctx.banded_swipe(items, mode)
+    for k, (rec, t) in enumerate(meta):
+        rc, o, otr = orc.banded_swipe(rec["query"], rec["cbs"], t["seq"], t["d_begin"], t["d_end"], M, 11, 1, orc.TRACEBACK)
+        assert rc == 0
+        assert res[hip.SWIPE_SCORE][0][k]["score"] == o["score"]
+        c = res[hip.SWIPE_COORDS][0][k]
+        assert c["score"] == o["score"]
+        if o["score"] > 0:
+            assert (c["q_end"], c["s_end"]) == (o["q_end"], o["s_end"])
+            g, tr = res[hip.SWIPE_TRACEBACK][0][k], res[hip.SWIPE_TRACEBACK][1]
+            for key in KEYS:
+                assert g[key] == o[key], (key, k)
+            assert np.array_equal(_transcript(tr, g), otr)
+
+
+def test_host_call_shape_equals_batched_call(ctx):
+    """dmnd_banded_swipe_host is the literal DP::BandedSwipe::swipe call shape (one query + its targets)."""
+    hdr, recs = read_tap(os.path.join(GOLDEN, "swipe_fast.tap"), max_records=40)
+    M = hip.matrix_of(ctx.params)
+    for rec in recs[:40:4]:
+        mode = hip.SWIPE_SCORE if rec["hsp_values"] == 0 else hip.SWIPE_TRACEBACK
+        out, tr = ctx.banded_swipe_host(rec["query"], rec["cbs"], [(t["seq"], t["d_begin"], t["d_end"]) for t in rec["targets"]], mode)
+        for o, t in zip(out, rec["targets"]):
+            rc, ref, rtr = orc.banded_swipe(rec["query"], rec["cbs"], t["seq"], t["d_begin"], t["d_end"], M, 11, 1,
+                                            orc.SCORE_ONLY if mode == hip.SWIPE_SCORE else orc.TRACEBACK)
+            assert o["score"] == ref["score"]
+            if mode == hip.SWIPE_TRACEBACK and ref["score"] > 0:
+                assert np.array_equal(_transcript(tr, o), rtr)
+
+
+def test_trace_arena_chunking_is_transparent(ctx):
+    """Small trace arena -> many chunks; results must not change."""
+    M = hip.matrix_of(ctx.params)
+    recs = _random_items(np.random.default_rng(3), 300, M)
+    qb, tb, cbs, items, _ = pack_records(recs)
+    ctx.upload_block(hip.QUERY, qb)
+    ctx.upload_block(hip.TARGET, tb)
+    ctx.upload_cbs(cbs)
+    a, atr = ctx.banded_swipe(items, hip.SWIPE_TRACEBACK)
+    os.environ["DMND_TRACE_ARENA_MB"] = "64"
+    c2 = hip.Context()
+    del os.environ["DMND_TRACE_ARENA_MB"]
+    c2.upload_block(hip.QUERY, qb)
+    c2.upload_block(hip.TARGET, tb)
+    c2.upload_cbs(cbs)
+    b, btr = c2.banded_swipe(items, hip.SWIPE_TRACEBACK)
+    c2.close()
+    assert np.array_equal(a, b) and np.array_equal(atr, btr)
+
+
+def _rescore(q, cbs, t, h, tr, M):
+    """Re-scores a packed transcript (PackedOperation codes) -> (score, q_end, s_end)."""
+    i, j, s = int(h["q_begin"]), int(h["s_begin"]), 0
+    k = 0
+    ops = tr[h["transcript_off"]: h["transcript_off"] + h["transcript_len"]]
+    while k < len(ops):
+        op, cnt = ops[k] >> 6, ops[k] & 63
+        if op == 0 or op == 3:
+            n = cnt if op == 0 else 1
+            for _ in range(n):
+                s += int(M[t[j] & 31, q[i] & 31]) + (int(cbs[i]) if cbs is not None else 0)
+                i += 1
+                j += 1
+            k += 1
+        elif op == 1:
+            run = 0
+            while k < len(ops) and ops[k] >> 6 == 1:
+                run += ops[k] & 63
+                k += 1
+            s -= 11 + run
+            i += run
+        else:
+            run = 0
+            while k < len(ops) and ops[k] >> 6 == 2:
+                run += 1
+                k += 1
+            s -= 11 + run
+            j += run
+    return s, i, j
+
+
+def test_baseline_scale_properties(ctx):
+    """C1-shaped synthetic workload (1k queries x 10k-seq DB, SURVEY.md 8d generator), ~20k DpTargets:
+    size-independent invariants instead of a per-item oracle."""
+    db, doff, q, qoff = synth.generate(1000, members=10, queries=1000, seed=1)
+    rng = np.random.default_rng(2)
+    # every query against 20 members: its own family is unknown here, so pair with random targets plus
+    # a self-derived band around the main diagonal; half the items get narrow bands, half wide
+    nq = len(qoff) - 1
+    qi = np.repeat(np.arange(nq), 20)
+    ti = rng.integers(0, len(doff) - 1, qi.size)
+    ql = (qoff[qi + 1] - qoff[qi]).astype(np.int32)
+    tl = (doff[ti + 1] - doff[ti]).astype(np.int32)
+    centre = rng.integers(-20, 20, qi.size)
+    half = rng.choice([12, 30, 40, 64, 150], qi.size)
+    items = np.zeros(qi.size, dtype=hip.DP_TARGET_DTYPE)
+    items["query_off"] = qoff[qi]
+    items["target_off"] = doff[ti]
+    items["cbs_off"] = -1
+    items["query_len"] = ql
+    items["target_len"] = tl
+    items["d_begin"] = np.maximum(centre - half, -(tl - 1))
+    items["d_end"] = np.minimum(centre + half + 1, ql)
+    ctx.upload_block(hip.QUERY, q)
+    ctx.upload_block(hip.TARGET, db)
+    ctx.upload_cbs(np.zeros(0, np.int8))
+    s0, _ = ctx.banded_swipe(items, hip.SWIPE_SCORE)
+    s1, _ = ctx.banded_swipe(items, hip.SWIPE_COORDS)
+    s2, tr = ctx.banded_swipe(items, hip.SWIPE_TRACEBACK)
+    assert np.array_equal(s0["score"], s1["score"]) and np.array_equal(s0["score"], s2["score"])
+    pos = s0["score"] > 0
+    assert pos.sum() > 1000
+    assert np.array_equal(s1["q_end"][pos], s2["q_end"][pos]) and np.array_equal(s1["s_end"][pos], s2["s_end"][pos])
+    # batch-order independence
+    perm = rng.permutation(items.size)
+    sp, _ = ctx.banded_swipe(items[perm], hip.SWIPE_SCORE)
+    assert np.array_equal(sp["score"], s0["score"][perm])
+    # transcripts re-score to the reported score and coordinates; spot-check against the oracle
+    M = hip.matrix_of(ctx.params)
+    for k in rng.choice(np.nonzero(pos)[0], 300, replace=False):
+        it = items[k]
+        qs = q[it["query_off"]: it["query_off"] + it["query_len"]]
+        ts = db[it["target_off"]: it["target_off"] + it["target_len"]]
+        sc, qe, se = _rescore(qs, None, ts, s2[k], tr, M)
+        assert (sc, qe, se) == (s2[k]["score"], s2[k]["q_end"], s2[k]["s_end"])
+        assert s2[k]["length"] == s2[k]["identities"] + s2[k]["mismatches"] + s2[k]["gaps"]
+    for k in rng.choice(items.size, 200, replace=False):
+        it = items[k]
+        qs = q[it["query_off"]: it["query_off"] + it["query_len"]]
+        ts = db[it["target_off"]: it["target_off"] + it["target_len"]]
+        rc, o, _ = orc.banded_swipe(qs, None, ts, it["d_begin"], it["d_end"], M, 11, 1, orc.SCORE_ONLY)
+        assert o["score"] == s0[k]["score"]
