@@ -161,7 +161,7 @@ def _rescore(q, cbs, t, h, tr, M):
     k = 0
     ops = tr[h["transcript_off"]: h["transcript_off"] + h["transcript_len"]]
     while k < len(ops):
-        op, cnt = ops[k] >> 6, ops[k] & 63
+        op, cnt = int(ops[k]) >> 6, int(ops[k]) & 63
         if op == 0 or op == 3:
             n = cnt if op == 0 else 1
             for _ in range(n):
@@ -171,14 +171,14 @@ def _rescore(q, cbs, t, h, tr, M):
             k += 1
         elif op == 1:
             run = 0
-            while k < len(ops) and ops[k] >> 6 == 1:
-                run += ops[k] & 63
+            while k < len(ops) and int(ops[k]) >> 6 == 1:
+                run += int(ops[k]) & 63
                 k += 1
             s -= 11 + run
             i += run
         else:
             run = 0
-            while k < len(ops) and ops[k] >> 6 == 2:
+            while k < len(ops) and int(ops[k]) >> 6 == 2:
                 run += 1
                 k += 1
             s -= 11 + run
