@@ -112,13 +112,20 @@ def main():
     state = {}
 
     def step():
+        t_a = time.perf_counter()
         r1, _ = ctx.banded_swipe(w.items, hip.SWIPE_SCORE)
+        t_b = time.perf_counter()
         ms1 = ctx.last_kernel_ms()[0]
         sel = w.select_round2(params, r1["score"])
+        t_c = time.perf_counter()
         r2, tr = ctx.banded_swipe(w.items[sel], hip.SWIPE_TRACEBACK, 510)
+        t_d = time.perf_counter()
         ms2, mstb = ctx.last_kernel_ms()
         aligned = gather_topk(w, params, r2, sel, world, rank, device)
-        state.update(sel=sel, ms1=ms1, ms2=ms2, mstb=mstb, aligned=aligned, n2=sel.size)
+        t_e = time.perf_counter()
+        state.update(sel=sel, ms1=ms1, ms2=ms2, mstb=mstb, aligned=aligned, n2=sel.size,
+                     wall_ms={"round1_call": (t_b - t_a) * 1e3, "culling": (t_c - t_b) * 1e3, "round2_call": (t_d - t_c) * 1e3,
+                              "topk_gather": (t_e - t_d) * 1e3})
 
     def sync():
         torch.cuda.synchronize()
@@ -169,6 +176,7 @@ def main():
                          "kernel_gcups": cells1 / (k_ms * 1e-3) / 1e9,
                          "note": "integer DP held in VGPRs: VALU-issue bound, not HBM-bound (SURVEY.md 8d); HBM fraction reported as the contract asks"},
             "kernel_ms": {"round1_swipe": state["ms1"], "round2_swipe": state["ms2"], "round2_traceback": state["mstb"]},
+            "wall_ms_last_step": state["wall_ms"],
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, params, args.cpu_items)

@@ -248,7 +248,7 @@ int run_chunk(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, const dm
 {
 	const int64_t n = (int64_t)slots.size();
 	if (n == 0) return DMND_OK;
-	const bool trace = kmode == 2;
+	const bool trace = kmode == K_TRACE;
 	std::vector<int32_t> order(n), p_of(n);
 	std::vector<int64_t> trace_off(n + 1, 0), tr_off(n + 1, 0);
 	for (int64_t s = 0; s < n; ++s) {
@@ -334,12 +334,13 @@ int swipe_impl(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, int64_t
 	if (n > 0x7fffffff) return fail(DMND_E_ARG, "dmnd_banded_swipe: more than 2^31-1 items in one call");
 	int kmode;
 	switch (mode) {
-	case DMND_SWIPE_SCORE: kmode = 0; break;
-	case DMND_SWIPE_COORDS: kmode = 1; break;
-	case DMND_SWIPE_TRACEBACK: kmode = 2; break;
-	default: return fail(DMND_E_ARG, "dmnd_banded_swipe: mode not supported (DMND_SWIPE_STATS not implemented yet)");
+	case DMND_SWIPE_SCORE: kmode = K_SCORE; break;
+	case DMND_SWIPE_COORDS: kmode = K_COORDS; break;
+	case DMND_SWIPE_TRACEBACK: kmode = K_TRACE; break;
+	case DMND_SWIPE_STATS: kmode = K_STATS_FWD; break;
+	default: return fail(DMND_E_ARG, "dmnd_banded_swipe: unknown mode");
 	}
-	if (kmode == 2 && (!transcript || transcript_cap <= 0))
+	if (kmode == K_TRACE && (!transcript || transcript_cap <= 0))
 		return fail(DMND_E_ARG, "dmnd_banded_swipe: TRACEBACK needs a transcript arena");
 	if (!b.q || !b.t) return fail(DMND_E_ARG, "dmnd_banded_swipe: sequence blocks not uploaded");
 	HIP_TRY(hipSetDevice(c->device));
@@ -353,21 +354,21 @@ int swipe_impl(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, int64_t
 			|| (it.cbs_off >= 0 && (!b.cbs || it.cbs_off + it.query_len > b.cbs_len)))
 			return fail(DMND_E_ARG, "dmnd_banded_swipe: item " + std::to_string(i) + " out of range");
 		const int P = band_class(band);
-		if (P > 32)
-			return fail(DMND_E_BAND, "Band size exceeds the supported maximum (" + std::to_string(DMND_MAX_BAND) + ")");
+		if (P > 32 || (kmode == K_STATS_FWD && P > 16))
+			return fail(DMND_E_BAND, "Band size exceeds the supported maximum (" + std::to_string(kmode == K_STATS_FWD ? DMND_MAX_BAND / 2 : DMND_MAX_BAND) + ")");
 		const Geom g = make_geom(it.query_len, it.target_len, it.d_begin, it.d_end);
 		slots[i] = Slot{ (int32_t)i, P, n_steps(g) };
 	}
 	if (int rc = c->items.ensure(n * sizeof(dmnd_dp_target))) return rc;
 	if (int rc = c->ends.ensure(n * sizeof(SwipeEnd))) return rc;
-	if (kmode == 2) { if (int rc = c->hsps.ensure(n * sizeof(dmnd_hsp))) return rc; }
+	if (kmode == K_TRACE) { if (int rc = c->hsps.ensure(n * sizeof(dmnd_hsp))) return rc; }
 	HIP_TRY(hipMemcpyAsync(c->items.p, items, n * sizeof(dmnd_dp_target), hipMemcpyHostToDevice, c->stream));
 	c->swipe_ms = c->traceback_ms = 0.0;
 
 	std::vector<SwipeEnd> ends((size_t)n);
 	std::vector<dmnd_hsp> hsps;
 	auto by_class = [](const Slot& x, const Slot& y) { return x.P < y.P || (x.P == y.P && x.steps > y.steps); };
-	if (kmode != 2) {
+	if (kmode != K_TRACE) {
 		std::sort(slots.begin(), slots.end(), by_class);
 		if (int rc = run_chunk(c, b, items, c->items.as<dmnd_dp_target>(), slots, kmode, out, nullptr, nullptr)) return rc;
 		HIP_TRY(hipMemcpy(ends.data(), c->ends.p, n * sizeof(SwipeEnd), hipMemcpyDeviceToHost));
@@ -375,8 +376,49 @@ int swipe_impl(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, int64_t
 			dmnd_hsp h;
 			std::memset(&h, 0, sizeof(h));
 			h.score = ends[i].score;
-			if (kmode == 1 && h.score > 0) { h.q_end = ends[i].end_i + 1; h.s_end = ends[i].end_j + 1; }
+			if (kmode != K_SCORE && h.score > 0) { h.q_end = ends[i].end_i + 1; h.s_end = ends[i].end_j + 1; }
+			if (kmode == K_STATS_FWD && h.score > 0) { h.identities = ends[i].stat_a; h.length = ends[i].stat_b; }
 			out[i] = h;
+		}
+		if (kmode != K_STATS_FWD)
+			return DMND_OK;
+		// statistics without traceback: second, reversed pass over the target prefix [0, s_end)
+		// (recompute_reversed, swipe_wrapper.cpp:364-444); only if a start coordinate or a backward statistic is wanted
+		const uint32_t need_rev = DMND_HSP_QUERY_START | DMND_HSP_TARGET_START | DMND_HSP_MISMATCHES | DMND_HSP_GAP_OPENINGS;
+		if (hsp_values != 0 && !(hsp_values & need_rev))
+			return DMND_OK;
+		std::vector<dmnd_dp_target> rev;
+		std::vector<int64_t> src;
+		for (int64_t i = 0; i < n; ++i) {
+			if (out[i].score <= 0) continue;
+			dmnd_dp_target r = items[i];
+			int rt, rd0, rd1;
+			reversed_band(r.query_len, out[i].s_end, r.d_begin, r.d_end, rt, rd0, rd1);
+			r.target_len = rt; r.d_begin = rd0; r.d_end = rd1;
+			rev.push_back(r);
+			src.push_back(i);
+		}
+		const int64_t m = (int64_t)rev.size();
+		if (m == 0) return DMND_OK;
+		std::vector<Slot> rslots((size_t)m);
+		for (int64_t k = 0; k < m; ++k) {
+			const Geom g = make_geom(rev[k].query_len, rev[k].target_len, rev[k].d_begin, rev[k].d_end);
+			rslots[k] = Slot{ (int32_t)k, band_class(rev[k].d_end - rev[k].d_begin), n_steps(g) };
+		}
+		std::sort(rslots.begin(), rslots.end(), by_class);
+		HIP_TRY(hipMemcpyAsync(c->items.p, rev.data(), m * sizeof(dmnd_dp_target), hipMemcpyHostToDevice, c->stream));
+		const double ms_fwd = c->swipe_ms;
+		if (int rc = run_chunk(c, b, rev.data(), c->items.as<dmnd_dp_target>(), rslots, K_STATS_BWD_REV, out, nullptr, nullptr)) return rc;
+		(void)ms_fwd;
+		HIP_TRY(hipMemcpy(ends.data(), c->ends.p, m * sizeof(SwipeEnd), hipMemcpyDeviceToHost));
+		for (int64_t k = 0; k < m; ++k) {
+			dmnd_hsp& h = out[src[k]];
+			h.score = ends[k].score;                                          // the reversed pass' score is what the reference reports
+			h.q_begin = rev[k].query_len - (ends[k].end_i + 1);              // banded_swipe.h:114-115
+			h.s_begin = rev[k].target_len - (ends[k].end_j + 1);
+			h.mismatches = ends[k].stat_a;
+			h.gap_openings = ends[k].stat_b;
+			h.gaps = h.length - h.identities - h.mismatches;                  // assign_stats, stat_cell.h:216-220
 		}
 		return DMND_OK;
 	}
@@ -399,7 +441,7 @@ int swipe_impl(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, int64_t
 		std::sort(chunk.begin(), chunk.end(), by_class);
 		std::vector<uint8_t> tr;
 		std::vector<int64_t> tr_off;
-		if (int rc = run_chunk(c, b, items, c->items.as<dmnd_dp_target>(), chunk, kmode, out, &tr, &tr_off)) return rc;
+		if (int rc = run_chunk(c, b, items, c->items.as<dmnd_dp_target>(), chunk, K_TRACE, out, &tr, &tr_off)) return rc;
 		HIP_TRY(hipMemcpy(hsps.data() + c0, c->hsps.as<dmnd_hsp>() + c0, (size_t)(c1 - c0) * sizeof(dmnd_hsp), hipMemcpyDeviceToHost));
 		// pack the transcripts tightly into the caller's arena, in input order
 		std::vector<int64_t> slot_of((size_t)(c1 - c0));

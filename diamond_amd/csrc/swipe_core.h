@@ -90,11 +90,19 @@ DMND_HD bool better_end(int s, int j, int i, int bs, int bj, int bi)
 	return s > bs || (s == bs && (j < bj || (j == bj && i > bi)));
 }
 
-template<int P, bool COORDS>
+// STAT: 0 = none, 1 = ForwardCell (a = identities, b = length), 2 = BackwardCell (a = mismatches,
+// b = gap openings) -- the statistics carried along the arg-max path, stat_cell.h:47-279.
+enum { STAT_NONE = 0, STAT_FWD = 1, STAT_BWD = 2 };
+
+template<int N, bool ON> struct StatRegs { int Ha[N], Hb[N], Ea[N], Eb[N], Fa[N], Fb[N]; };
+template<int N> struct StatRegs<N, false> {};
+
+template<int P, bool COORDS, int STAT = STAT_NONE>
 struct Lane {
 	int H[2 * P], E[2 * P], F[2 * P];
 	int a_lo[2 * P], a_span[2 * P];
-	int best, best_i, best_j;
+	int best, best_i, best_j, best_a, best_b;
+	StatRegs<2 * P, STAT != STAT_NONE> st;
 
 	DMND_HD void init(const Geom& g, int lane)
 	{
@@ -102,10 +110,35 @@ struct Lane {
 		for (int k = 0; k < 2 * P; ++k) {
 			H[k] = E[k] = F[k] = 0;
 			diag_window(g, 2 * P * lane + k, a_lo[k], a_span[k]);
+			if constexpr (STAT != STAT_NONE) { st.Ha[k] = st.Hb[k] = st.Ea[k] = st.Eb[k] = st.Fa[k] = st.Fb[k] = 0; }
 		}
-		best = 0; best_i = 0; best_j = 0x7fffffff;
+		best = 0; best_i = 0; best_j = 0x7fffffff; best_a = 0; best_b = 0;
 	}
 };
+
+// One cell with statistics (oracle/banded_swipe.c is the line-by-line restatement of stat_cell.h):
+// set_max ties take the argument's statistics (E before F), the reset on a zero cell applies to the
+// stored H statistics but not to the copy that opens a gap.
+template<int STAT>
+DMND_HD void cell_update_stats(int Hd, int s, bool ident, int E_in, int F_in, int go, int ge,
+	int Hda, int Hdb, int Ea, int Eb, int Fa, int Fb,
+	int& cur, int& E_out, int& F_out, int& ca, int& cb, int& ea, int& eb, int& fa, int& fb)
+{
+	int c = Hd + s, xa, xb;
+	if (STAT == STAT_FWD) { xa = Hda + (ident ? 1 : 0); xb = Hdb + 1; Eb += 1; Fb += 1; }
+	else { xa = Hda + (ident ? 0 : 1); xb = Hdb; }
+	if (E_in >= c) { c = E_in; xa = Ea; xb = Eb; }
+	if (F_in >= c) { c = F_in; xa = Fa; xb = Fb; }
+	if (c < 0) c = 0;
+	const int open = imax(c - go, 0);
+	int oa = xa, ob = xb;
+	if (STAT == STAT_BWD) ob += 1;
+	if (c == 0) { xa = 0; xb = 0; }
+	int e = imax(E_in - ge, 0), f = imax(F_in - ge, 0);
+	if (open >= e) { e = open; Ea = oa; Eb = ob; }
+	if (open >= f) { f = open; Fa = oa; Fb = ob; }
+	cur = c; E_out = e; F_out = f; ca = xa; cb = xb; ea = Ea; eb = Eb; fa = Fa; fb = Fb;
+}
 
 // One cell. Returns the 4 trace bits when TRACE.  (cell_update.h:103-140 with values clamped at 0.)
 template<bool TRACE>
@@ -126,11 +159,14 @@ DMND_HD int cell_update(int Hd, int s, int E_in, int F_in, int go, int ge, int& 
 
 // Sequence/matrix access policy used by the step: q/t are letter pointers, cbs may be null,
 // M is the 32x32 int8 matrix (in LDS on the device).
+// rev_q / rev_t >= 0 make the view read the sequences back to front (index x -> rev - x): the reversed
+// pass of recompute_reversed() (swipe_wrapper.cpp:364-444) without materialising reversed copies.
 struct SeqView {
 	const int8_t* q;
 	const int8_t* t;
 	const int8_t* cbs;
 	const int8_t* M;
+	int rev_q = -1, rev_t = -1;      // qlen-1 / tlen-1 when reversed
 };
 
 DMND_HD int match_score(const SeqView& v, int i, int j)
@@ -141,41 +177,85 @@ DMND_HD int match_score(const SeqView& v, int i, int j)
 	return s;
 }
 
+DMND_HD int match_score_stats(const SeqView& v, int i, int j, bool& ident)
+{
+	const int ii = v.rev_q >= 0 ? v.rev_q - i : i, jj = v.rev_t >= 0 ? v.rev_t - j : j;
+	const int ql = v.q[ii] & LETTER_MASK, traw = v.t[jj], tl = traw & LETTER_MASK;
+	int s = v.M[tl * 32 + ql];
+	if (v.cbs) s += v.cbs[ii];
+	ident = ql == traw;                 // VectorIdMask compares the masked query letter with the RAW target byte (stat_cell.h:41-44)
+	return s;
+}
+
 // One anti-diagonal step of one lane. PAR = parity of (a + d_begin): 0 -> the lane's even local
 // diagonals are active and nb is F_out of lane-1's top diagonal; 1 -> odd diagonals, nb is E_out of
 // lane+1's bottom diagonal. trace (if TRACE) points at this lane's P bytes of the step's trace row.
-template<int P, bool COORDS, bool TRACE, int PAR>
-DMND_HD void lane_step(Lane<P, COORDS>& st, const Geom& g, const SeqView& v, int lane, int a, int nb, int go, int ge, uint8_t* trace)
+template<int P, bool COORDS, bool TRACE, int PAR, int STAT = STAT_NONE>
+DMND_HD void lane_step(Lane<P, COORDS, STAT>& st, const Geom& g, const SeqView& v, int lane, int a, int nb, int go, int ge, uint8_t* trace,
+	int nb_a = 0, int nb_b = 0)
 {
 #pragma unroll
 	for (int p = 0; p < P; ++p) {
 		const int k = 2 * p + PAR;
-		int E_in, F_in;
+		int E_in, F_in, Ea = 0, Eb = 0, Fa = 0, Fb = 0;
 		if (PAR == 0) {
 			E_in = st.E[k + 1];
 			F_in = p == 0 ? nb : st.F[k - 1];
+			if constexpr (STAT != STAT_NONE) {
+				Ea = st.st.Ea[k + 1]; Eb = st.st.Eb[k + 1];
+				Fa = p == 0 ? nb_a : st.st.Fa[k - 1]; Fb = p == 0 ? nb_b : st.st.Fb[k - 1];
+			}
 		}
 		else {
 			E_in = p == P - 1 ? nb : st.E[k + 1];
 			F_in = st.F[k - 1];
+			if constexpr (STAT != STAT_NONE) {
+				Ea = p == P - 1 ? nb_a : st.st.Ea[k + 1]; Eb = p == P - 1 ? nb_b : st.st.Eb[k + 1];
+				Fa = st.st.Fa[k - 1]; Fb = st.st.Fb[k - 1];
+			}
 		}
 		const bool valid = (unsigned)(a - st.a_lo[k]) <= (unsigned)st.a_span[k];
 		int cur = 0, E_out = 0, F_out = 0, tb = 0;
+		int ca = 0, cb = 0, ea = 0, eb = 0, fa = 0, fb = 0;
 		if (valid) {
 			const int d = g.d_begin + 2 * P * lane + k;
 			const int i = (a + d) >> 1, j = (a - d) >> 1;
-			const int s = match_score(v, i, j);
-			tb = cell_update<TRACE>(st.H[k], s, E_in, F_in, go, ge, cur, E_out, F_out);
+			if constexpr (STAT != STAT_NONE) {
+				bool ident;
+				const int s = match_score_stats(v, i, j, ident);
+				cell_update_stats<STAT>(st.H[k], s, ident, E_in, F_in, go, ge, st.st.Ha[k], st.st.Hb[k], Ea, Eb, Fa, Fb,
+					cur, E_out, F_out, ca, cb, ea, eb, fa, fb);
+			}
+			else {
+				const int s = match_score(v, i, j);
+				tb = cell_update<TRACE>(st.H[k], s, E_in, F_in, go, ge, cur, E_out, F_out);
+			}
 			if (COORDS) {
-				if (better_end(cur, j, i, st.best, st.best_j, st.best_i)) { st.best = cur; st.best_j = j; st.best_i = i; }
+				if (better_end(cur, j, i, st.best, st.best_j, st.best_i)) {
+					st.best = cur; st.best_j = j; st.best_i = i;
+					if constexpr (STAT != STAT_NONE) { st.best_a = ca; st.best_b = cb; }
+				}
 			}
 			else
 				st.best = imax(st.best, cur);
 		}
 		st.H[k] = cur; st.E[k] = E_out; st.F[k] = F_out;
+		if constexpr (STAT != STAT_NONE) {
+			st.st.Ha[k] = ca; st.st.Hb[k] = cb; st.st.Ea[k] = ea; st.st.Eb[k] = eb; st.st.Fa[k] = fa; st.st.Fb[k] = fb;
+		}
 		if (TRACE)
 			trace[p] = (uint8_t)tb;
 	}
+}
+
+// Geometry of the reversed pass of recompute_reversed() (swipe_wrapper.cpp:378-391): the target is the
+// prefix [0, s_end) of the forward target, both sequences are read back to front, the band is mirrored
+// with Geo::rev_diag (util/geo/geo.h:37).
+DMND_HD void reversed_band(int qlen, int s_end, int d_begin, int d_end, int& r_tlen, int& r_d_begin, int& r_d_end)
+{
+	r_tlen = s_end;
+	r_d_begin = -(d_end - 1) + qlen - s_end;
+	r_d_end = -d_begin + qlen - s_end + 1;
 }
 
 // ---- traceback walk over the anti-diagonal trace (one thread per item) -------------------------

@@ -8,9 +8,12 @@ namespace dmnd {
 
 enum { WAVES_PER_BLOCK = 4 };
 
-struct SwipeEnd {            // per item: best score and its end cell (row i, column j)
-	int32_t score, end_i, end_j, pad;
+struct SwipeEnd {            // per item: best score, its end cell (row i, column j) and the carried statistics
+	int32_t score, end_i, end_j, stat_a, stat_b, pad[3];
 };
+
+// kernel variants (launch_banded_swipe's kmode)
+enum { K_SCORE = 0, K_COORDS = 1, K_TRACE = 2, K_STATS_FWD = 3, K_STATS_BWD_REV = 4 };
 
 struct SwipeArgs {
 	const int8_t* qblock;        // DMND_QUERY block letters (HBM)

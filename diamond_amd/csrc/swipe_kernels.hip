@@ -23,7 +23,7 @@ namespace dmnd {
 __device__ __forceinline__ int wave_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
 __device__ __forceinline__ int wave_shl1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }
 
-template<int P, bool COORDS, bool TRACE>
+template<int P, bool COORDS, bool TRACE, int STAT = STAT_NONE, bool REV = false>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * 64)
 void banded_swipe_kernel(SwipeArgs args)
 {
@@ -39,11 +39,12 @@ void banded_swipe_kernel(SwipeArgs args)
 	const int32_t item_idx = args.order[slot];
 	const dmnd_dp_target it = args.items[item_idx];
 	const Geom g = make_geom(it.query_len, it.target_len, it.d_begin, it.d_end);
-	const SeqView v{ args.qblock + it.query_off, args.tblock + it.target_off,
+	SeqView v{ args.qblock + it.query_off, args.tblock + it.target_off,
 		it.cbs_off >= 0 ? args.cbs + it.cbs_off : nullptr, matrix };
+	if (REV) { v.rev_q = it.query_len - 1; v.rev_t = it.target_len - 1; }
 	const int go = args.gap_open + args.gap_extend, ge = args.gap_extend;
 
-	Lane<P, COORDS> st;
+	Lane<P, COORDS, STAT> st;
 	st.init(g, lane);
 	uint8_t* row = nullptr;
 	if (TRACE)
@@ -51,25 +52,29 @@ void banded_swipe_kernel(SwipeArgs args)
 	constexpr int W = 64 * P;
 
 	for (int a = g.a_first; a <= g.a_last; a += 2) {
-		int nb = wave_shr1(st.F[2 * P - 1]);
-		lane_step<P, COORDS, TRACE, 0>(st, g, v, lane, a, nb, go, ge, row);
+		int nb = wave_shr1(st.F[2 * P - 1]), na = 0, nbb = 0;
+		if constexpr (STAT != STAT_NONE) { na = wave_shr1(st.st.Fa[2 * P - 1]); nbb = wave_shr1(st.st.Fb[2 * P - 1]); }
+		lane_step<P, COORDS, TRACE, 0, STAT>(st, g, v, lane, a, nb, go, ge, row, na, nbb);
 		if (TRACE) row += W;
 		// the odd step may lie past a_last: all its cells are then invalid, and its trace row is allocated
 		nb = wave_shl1(st.E[0]);
-		lane_step<P, COORDS, TRACE, 1>(st, g, v, lane, a + 1, nb, go, ge, row);
+		if constexpr (STAT != STAT_NONE) { na = wave_shl1(st.st.Ea[0]); nbb = wave_shl1(st.st.Eb[0]); }
+		lane_step<P, COORDS, TRACE, 1, STAT>(st, g, v, lane, a + 1, nb, go, ge, row, na, nbb);
 		if (TRACE) row += W;
 	}
 
 	// wave reduction of the end cell
-	int bs = st.best, bi = st.best_i, bj = st.best_j;
+	int bs = st.best, bi = st.best_i, bj = st.best_j, ba = st.best_a, bb = st.best_b;
 #pragma unroll
 	for (int off = 32; off >= 1; off >>= 1) {
 		const int os = __shfl_xor(bs, off), oi = __shfl_xor(bi, off), oj = __shfl_xor(bj, off);
-		if (COORDS ? better_end(os, oj, oi, bs, bj, bi) : os > bs) { bs = os; bi = oi; bj = oj; }
+		int oa = 0, ob = 0;
+		if constexpr (STAT != STAT_NONE) { oa = __shfl_xor(ba, off); ob = __shfl_xor(bb, off); }
+		if (COORDS ? better_end(os, oj, oi, bs, bj, bi) : os > bs) { bs = os; bi = oi; bj = oj; ba = oa; bb = ob; }
 	}
 	if (lane == 0) {
 		SwipeEnd e;
-		e.score = bs; e.end_i = bi; e.end_j = bj; e.pad = 0;
+		e.score = bs; e.end_i = bi; e.end_j = bj; e.stat_a = ba; e.stat_b = bb; e.pad[0] = e.pad[1] = e.pad[2] = 0;
 		args.ends[item_idx] = e;
 	}
 }
@@ -119,9 +124,20 @@ static hipError_t launch_p(int mode, const SwipeArgs& a, hipStream_t stream)
 	if (blocks == 0)
 		return hipSuccess;
 	const dim3 grid(blocks), block(WAVES_PER_BLOCK * 64);
-	if (mode == 0) hipLaunchKernelGGL((banded_swipe_kernel<P, false, false>), grid, block, 0, stream, a);
-	else if (mode == 1) hipLaunchKernelGGL((banded_swipe_kernel<P, true, false>), grid, block, 0, stream, a);
-	else hipLaunchKernelGGL((banded_swipe_kernel<P, true, true>), grid, block, 0, stream, a);
+	switch (mode) {
+	case K_SCORE: hipLaunchKernelGGL((banded_swipe_kernel<P, false, false>), grid, block, 0, stream, a); break;
+	case K_COORDS: hipLaunchKernelGGL((banded_swipe_kernel<P, true, false>), grid, block, 0, stream, a); break;
+	case K_TRACE: hipLaunchKernelGGL((banded_swipe_kernel<P, true, true>), grid, block, 0, stream, a); break;
+	case K_STATS_FWD:
+		if constexpr (P <= 16) hipLaunchKernelGGL((banded_swipe_kernel<P, true, false, STAT_FWD, false>), grid, block, 0, stream, a);
+		else return hipErrorInvalidValue;
+		break;
+	case K_STATS_BWD_REV:
+		if constexpr (P <= 16) hipLaunchKernelGGL((banded_swipe_kernel<P, true, false, STAT_BWD, true>), grid, block, 0, stream, a);
+		else return hipErrorInvalidValue;
+		break;
+	default: return hipErrorInvalidValue;
+	}
 	return hipGetLastError();
 }
 
@@ -133,7 +149,7 @@ hipError_t launch_banded_swipe(int P, int mode, const SwipeArgs& a, hipStream_t 
 	case 4: return launch_p<4>(mode, a, stream);
 	case 8: return launch_p<8>(mode, a, stream);
 	case 16: return launch_p<16>(mode, a, stream);
-	case 32: return launch_p<32>(mode, a, stream);
+	case 32: return launch_p<32>(mode, a, stream);   // statistics variants exist up to P = 16 (band <= 2048) only
 	default: return hipErrorInvalidValue;
 	}
 }

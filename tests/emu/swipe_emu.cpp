@@ -50,6 +50,73 @@ static void run(const SeqView& v, int qlen, int tlen, int d_begin, int d_end, in
 	}
 }
 
+// one statistics pass (STAT_FWD forward, STAT_BWD on the reversed views); returns score, end cell, (a, b)
+template<int P, int STAT>
+static void run_stats(const SeqView& v, int qlen, int tlen, int d_begin, int d_end, int gap_open, int gap_extend, int* res)
+{
+	const Geom g = make_geom(qlen, tlen, d_begin, d_end);
+	const int go = gap_open + gap_extend, ge = gap_extend;
+	std::vector<Lane<P, true, STAT>> st(64);
+	for (int l = 0; l < 64; ++l) st[l].init(g, l);
+	int nb[64], na[64], nbb[64];
+	for (int a = g.a_first; a <= g.a_last; a += 2) {
+		for (int l = 0; l < 64; ++l) {
+			nb[l] = l == 0 ? 0 : st[l - 1].F[2 * P - 1];
+			na[l] = l == 0 ? 0 : st[l - 1].st.Fa[2 * P - 1];
+			nbb[l] = l == 0 ? 0 : st[l - 1].st.Fb[2 * P - 1];
+		}
+		for (int l = 0; l < 64; ++l) lane_step<P, true, false, 0, STAT>(st[l], g, v, l, a, nb[l], go, ge, nullptr, na[l], nbb[l]);
+		for (int l = 0; l < 64; ++l) {
+			nb[l] = l == 63 ? 0 : st[l + 1].E[0];
+			na[l] = l == 63 ? 0 : st[l + 1].st.Ea[0];
+			nbb[l] = l == 63 ? 0 : st[l + 1].st.Eb[0];
+		}
+		for (int l = 0; l < 64; ++l) lane_step<P, true, false, 1, STAT>(st[l], g, v, l, a + 1, nb[l], go, ge, nullptr, na[l], nbb[l]);
+	}
+	int bs = 0, bi = 0, bj = 0x7fffffff, ba = 0, bb = 0;
+	for (int l = 0; l < 64; ++l)
+		if (better_end(st[l].best, st[l].best_j, st[l].best_i, bs, bj, bi)) {
+			bs = st[l].best; bi = st[l].best_i; bj = st[l].best_j; ba = st[l].best_a; bb = st[l].best_b;
+		}
+	res[0] = bs; res[1] = bi; res[2] = bj; res[3] = ba; res[4] = bb;
+}
+
+template<int P>
+static void stats_p(const int8_t* q, int qlen, const int8_t* cbs, const int8_t* t, int tlen, int d_begin, int d_end,
+	const int8_t* M, int gap_open, int gap_extend, EmuOut* out)
+{
+	int f[5], b[5];
+	SeqView v{ q, t, cbs, M };
+	run_stats<P, STAT_FWD>(v, qlen, tlen, d_begin, d_end, gap_open, gap_extend, f);
+	memset(out, 0, sizeof(*out));
+	out->score = f[0];
+	if (f[0] <= 0) return;
+	out->q_end = f[1] + 1; out->s_end = f[2] + 1; out->identities = f[3]; out->length = f[4];
+	int rt, rd0, rd1;
+	reversed_band(qlen, out->s_end, d_begin, d_end, rt, rd0, rd1);
+	SeqView r{ q, t, cbs, M };
+	r.rev_q = qlen - 1; r.rev_t = rt - 1;
+	run_stats<P, STAT_BWD>(r, qlen, rt, rd0, rd1, gap_open, gap_extend, b);
+	out->score = b[0];
+	out->q_begin = qlen - (b[1] + 1); out->s_begin = rt - (b[2] + 1);
+	out->mismatches = b[3]; out->gap_openings = b[4];
+	out->gaps = out->length - out->identities - out->mismatches;
+}
+
+extern "C" int emu_swipe_stats(const int8_t* q, int qlen, const int8_t* cbs, const int8_t* t, int tlen, int d_begin, int d_end,
+	const int8_t* M, int gap_open, int gap_extend, EmuOut* out)
+{
+	int P = 1;
+	while (128 * P < d_end - d_begin) P *= 2;
+	switch (P) {
+	case 1: stats_p<1>(q, qlen, cbs, t, tlen, d_begin, d_end, M, gap_open, gap_extend, out); break;
+	case 2: stats_p<2>(q, qlen, cbs, t, tlen, d_begin, d_end, M, gap_open, gap_extend, out); break;
+	case 4: stats_p<4>(q, qlen, cbs, t, tlen, d_begin, d_end, M, gap_open, gap_extend, out); break;
+	default: return -4;
+	}
+	return 0;
+}
+
 template<int P>
 static void run_mode(int mode, const SeqView& v, int qlen, int tlen, int d_begin, int d_end, int go, int ge, EmuOut* out, uint8_t* tr, int cap)
 {

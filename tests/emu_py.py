@@ -43,3 +43,16 @@ def banded_swipe(query, cbs, target, d_begin, d_end, matrix8, gap_open, gap_exte
                                 tr.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), cap)
     o = {n: getattr(out, n) for n, _ in EmuOut._fields_}
     return rc, o, tr[:o["transcript_len"]].copy()
+
+
+def swipe_stats(query, cbs, target, d_begin, d_end, matrix8, gap_open, gap_extend):
+    p8 = ctypes.POINTER(ctypes.c_int8)
+    q = np.ascontiguousarray(query, dtype=np.int8)
+    t = np.ascontiguousarray(target, dtype=np.int8)
+    c = np.ascontiguousarray(cbs, dtype=np.int8) if cbs is not None else None
+    m = np.ascontiguousarray(matrix8, dtype=np.int8)
+    out = EmuOut()
+    rc = lib().emu_swipe_stats(q.ctypes.data_as(p8), len(q), c.ctypes.data_as(p8) if c is not None else None,
+                               t.ctypes.data_as(p8), len(t), int(d_begin), int(d_end), m.ctypes.data_as(p8),
+                               int(gap_open), int(gap_extend), ctypes.byref(out))
+    return rc, {n: getattr(out, n) for n, _ in EmuOut._fields_}

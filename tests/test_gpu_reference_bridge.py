@@ -1,0 +1,49 @@
+"""-m gpu A/B test at the reference's own operator seam: oracle/_ref/diamond_hip is the GENUINE reference
+(compiled in place from /root/reference by oracle/Makefile) whose DP::BandedSwipe::swipe is answered by our
+C ABI on the MI355X (oracle/ref_hip_bridge.cpp). Its output must be byte-identical to the unmodified
+reference binary on the same inputs -- hit sets, scores, coordinates, identities, CIGARs, e-values."""
+import os
+import subprocess
+import numpy as np
+import pytest
+
+from diamond_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref", "diamond")
+BRIDGE = os.path.join(ROOT, "oracle", "_ref", "diamond_hip")
+
+
+@pytest.fixture(scope="module")
+def data(tmp_path_factory):
+    if not (os.path.exists(REF) and os.path.exists(BRIDGE)):
+        pytest.skip("oracle/_ref binaries not built (need /root/reference at build time)")
+    d = tmp_path_factory.mktemp("bridge")
+    db, doff, q, qoff = synth.generate(300, members=10, queries=300, seed=11)
+    synth.write_fasta(str(d / "db.faa"), "t", db, doff)
+    synth.write_fasta(str(d / "q.faa"), "q", q, qoff)
+    return d
+
+
+def _run(binary, d, name, extra):
+    env = dict(os.environ, DMND_HIP_LIB=os.path.join(ROOT, "diamond_amd", "libdiamond_hip.so"))
+    out = d / name
+    cmd = [binary, "blastp", "-q", str(d / "q.faa"), "-d", str(d / "db.faa"), "-o", str(out), "-p", "4", "--algo", "0"] + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return open(out).read()
+
+
+@pytest.mark.parametrize("name,extra", [
+    ("fast", ["--fast"]),
+    ("fast_cigar", ["--fast", "-f", "6", "qseqid", "sseqid", "score", "qstart", "qend", "sstart", "send", "cigar", "evalue", "bitscore"]),
+    ("default", []),
+    ("sensitive_k5", ["--sensitive", "-k", "5"]),
+])
+def test_reference_with_hip_swipe_is_byte_identical(data, name, extra):
+    ref = _run(REF, data, name + ".ref.tsv", extra)
+    got = _run(BRIDGE, data, name + ".hip.tsv", extra)
+    assert len(ref.splitlines()) > 200
+    assert got == ref

@@ -237,3 +237,39 @@ def test_baseline_scale_properties(ctx):
         ts = db[it["target_off"]: it["target_off"] + it["target_len"]]
         rc, o, _ = orc.banded_swipe(qs, None, ts, it["d_begin"], it["d_end"], M, 11, 1, orc.SCORE_ONLY)
         assert o["score"] == s0[k]["score"]
+
+
+STAT_KEYS = "score q_begin q_end s_begin s_end length identities mismatches gap_openings gaps".split()
+
+
+def test_stats_without_traceback_golden_and_oracle(ctx):
+    """DMND_SWIPE_STATS = ForwardCell pass + reversed BackwardCell pass (swipe_wrapper.cpp:364-444): the long-protein
+    golden calls (DP size > max_swipe_dp) and a seeded sample against the oracle."""
+    hdr, recs = read_tap(os.path.join(GOLDEN, "swipe_long.tap"))
+    sel = [r for r in recs if r["hsp_values"] != 0]
+    qb, tb, cbs, items, meta = pack_records(sel)
+    ctx.upload_block(hip.QUERY, qb)
+    ctx.upload_block(hip.TARGET, tb)
+    ctx.upload_cbs(cbs)
+    out, _ = ctx.banded_swipe(items, hip.SWIPE_STATS, 510)
+    n = 0
+    for k, (rec, t) in enumerate(meta):
+        hs = [h for h in rec["hsps"] if (h["swipe_target"], h["d_begin"], h["d_end"]) == (t["target_idx"], t["d_begin"], t["d_end"])]
+        if hs and hs[0]["swipe_bin"] >= 3:
+            for key in STAT_KEYS:
+                assert out[k][key] == hs[0][key], (key, k)
+            n += 1
+    assert n >= 5
+    M = hip.matrix_of(ctx.params)
+    recs = _random_items(np.random.default_rng(21), 300, M)
+    qb, tb, cbs, items, meta = pack_records(recs)
+    ctx.upload_block(hip.QUERY, qb)
+    ctx.upload_block(hip.TARGET, tb)
+    ctx.upload_cbs(cbs)
+    out, _ = ctx.banded_swipe(items, hip.SWIPE_STATS, 510)
+    for k, (rec, t) in enumerate(meta):
+        rc, o = orc.swipe_stats(rec["query"], rec["cbs"], t["seq"], t["d_begin"], t["d_end"], M, 11, 1, 510)
+        assert rc == 0 and out[k]["score"] == o["score"]
+        if o["score"] > 0:          # a zero score never becomes an HSP; its coordinates are don't-care
+            for key in STAT_KEYS:
+                assert out[k][key] == o[key], (key, k, out[k], o)

@@ -69,3 +69,30 @@ def test_emulated_wavefront_random_geometry():
             continue
         cbs = rng.integers(-3, 2, qlen).astype(np.int8) if it % 3 else None
         _compare(q, cbs, t, d0, d1, M, 11, 1, force_p=(2 if it % 11 == 0 else 0))
+
+
+STAT_KEYS = "score q_begin q_end s_begin s_end length identities mismatches gap_openings gaps".split()
+
+
+def test_emulated_stats_passes_match_oracle_and_reference():
+    """Statistics-without-traceback path (ForwardCell + reversed BackwardCell pass)."""
+    hdr, recs = read_tap(os.path.join(GOLDEN, "swipe_long.tap"))
+    n = 0
+    for rec in recs:
+        if rec["hsp_values"] == 0:
+            continue
+        for t in rec["targets"][:2]:
+            rc, o = orc.swipe_stats(rec["query"], rec["cbs"], t["seq"], t["d_begin"], t["d_end"], hdr["matrix8"], 11, 1, 510)
+            rc2, e = emu.swipe_stats(rec["query"], rec["cbs"], t["seq"], t["d_begin"], t["d_end"], hdr["matrix8"], 11, 1)
+            assert rc == 0 and rc2 == 0
+            for k in STAT_KEYS:
+                assert e[k] == o[k], (k, e, o)
+            n += 1
+    assert n >= 2
+    hdr, recs = read_tap(os.path.join(GOLDEN, "swipe_fast.tap"), max_records=60)
+    for rec in recs[::5]:
+        for t in rec["targets"]:
+            rc, o = orc.swipe_stats(rec["query"], rec["cbs"], t["seq"], t["d_begin"], t["d_end"], hdr["matrix8"], 11, 1, 510)
+            rc2, e = emu.swipe_stats(rec["query"], rec["cbs"], t["seq"], t["d_begin"], t["d_end"], hdr["matrix8"], 11, 1)
+            for k in STAT_KEYS:
+                assert e[k] == o[k], (k, e, o)
