@@ -28,33 +28,62 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-from diamond_amd import hip, workload  # noqa: E402
+from diamond_amd import hip, multigpu, workload  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
 def gather_topk(w, params, hsps, sel, world, rank, device):
-    """Per-query top-k records (evalue, -score, target oid), ordered as JoinRecord::cmp_evalue
-    (output/join_blocks.cpp:129-137) orders them, gathered from all ranks with ONE all_gather of a
-    fixed-size tensor. Returns the number of aligned queries of the whole job."""
-    k = workload.MAX_TARGET_SEQS
-    nq = w.n_queries
-    rec = torch.full((nq, k, 3), float("inf"), dtype=torch.float64)
-    if sel.size:
-        ev = hip.evalue_batch(params, hsps["score"], w.items["query_len"][sel], w.items["target_len"][sel])
-        q = w.qi[sel]
-        start = np.r_[0, np.nonzero(np.diff(q))[0] + 1]
-        rank_in_q = np.arange(sel.size) - np.repeat(start, np.diff(np.r_[start, sel.size]))
-        r = rec.numpy()
-        r[q, rank_in_q, 0] = ev
-        r[q, rank_in_q, 1] = -hsps["score"].astype(np.float64)
-        r[q, rank_in_q, 2] = w.ti[sel].astype(np.float64) + rank * 1e9      # global oid = shard offset + local id
-    if world == 1:
-        return int((rec[:, 0, 0] < float("inf")).sum())
-    rec_d = rec.to(device)
-    gathered = torch.empty((world,) + tuple(rec.shape), dtype=torch.float64, device=device)
-    dist.all_gather_into_tensor(gathered, rec_d)
-    return int((gathered[:, :, 0, 0] < float("inf")).sum().item())
+    """Per-query top-k records of this rank's query slice, gathered from all ranks with ONE all_gather of a
+    fixed-size tensor (diamond_amd/multigpu.py). Returns the number of aligned queries of the whole job."""
+    ev = hip.evalue_batch(params, hsps["score"], w.items["query_len"][sel], w.items["target_len"][sel]) if sel.size else np.zeros(0)
+    rec = multigpu.topk_records(w.n_queries, w.qi[sel], ev, hsps["score"], w.ti[sel])
+    return multigpu.aligned_queries(multigpu.gather_records(rec, device))
+
+
+def cpu_baseline_reference(args):
+    """The GENUINE reference (oracle/_ref/diamond_tap: /root/reference compiled in place; the tap only counts
+    DP cells) timed on this box's host cores on a bounded sample of the same synthetic workload:
+    `blastp --fast --algo 0` on frac x (queries, database). Returns None if the prebuilt binary is absent."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    from diamond_amd import synth
+    exe = os.path.join(ROOT, "oracle", "_ref", "diamond_tap")
+    if not os.path.exists(exe):
+        return None
+    frac = args.cpu_sample_frac
+    nq, nf = max(int(args.queries * frac), 100), max(int(args.families * frac), 1000)
+    cores = os.cpu_count() or 1
+    tmp = tempfile.mkdtemp(prefix="dmnd_cpu_")
+    try:
+        db, doff, q, qoff = synth.generate(nf, members=10, queries=nq, seed=20260923)
+        synth.write_fasta(os.path.join(tmp, "db.faa"), "t", db, doff)
+        synth.write_fasta(os.path.join(tmp, "q.faa"), "q", q, qoff)
+        subprocess.run([exe, "makedb", "--in", os.path.join(tmp, "db.faa"), "-d", os.path.join(tmp, "db")],
+                       check=True, capture_output=True, timeout=600)
+        env = dict(os.environ, DIAMOND_TAP_CELLS=os.path.join(tmp, "cells.json"))
+        t0 = time.perf_counter()
+        r = subprocess.run([exe, "blastp", "--fast", "--algo", "0", "-q", os.path.join(tmp, "q.faa"), "-d", os.path.join(tmp, "db"),
+                            "-o", os.path.join(tmp, "out.tsv"), "-p", str(cores), "--log"], check=True, capture_output=True,
+                           text=True, env=env, timeout=1200)
+        wall = time.perf_counter() - t0
+        cells = json.load(open(os.path.join(tmp, "cells.json")))
+        log = r.stdout + r.stderr
+        sw = re.search(r"Time \(Smith Waterman\)\s*= ([0-9.eE+-]+)s", log)
+        aligned = re.search(r"(\d+) queries aligned", log)
+        sw_s = float(sw.group(1)) if sw else float("nan")
+        model = open("/proc/cpuinfo").read().split("model name")[1].split("\n")[0].strip(": \t") if os.path.exists("/proc/cpuinfo") else "?"
+        return {"value": cells["cells"] / wall / 1e9, "unit": "GCUPS", "cores": cores, "kind": "reference",
+                "sample": "reference diamond v2.2.2 `blastp --fast --algo 0 -p %d` on %d queries x %d seqs (%.0f%% of the workload), CPU %s: "
+                          "%.2f s wall end-to-end, %d DpTargets / %d cells (both rounds), %s queries aligned, %.1f aligned queries/s; "
+                          "SW stage alone: %.3f CPU-s => %.2f GCUPS per core"
+                          % (cores, nq, nf * 10, frac * 100, model, wall, cells["targets"], cells["cells"],
+                             aligned.group(1) if aligned else "?", (int(aligned.group(1)) / wall) if aligned else float("nan"),
+                             sw_s, cells["cells"] / sw_s / 1e9)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def cpu_baseline(w, params, n_items):
@@ -85,6 +114,7 @@ def main():
     ap.add_argument("--queries", type=int, default=10_000)
     ap.add_argument("--families", type=int, default=100_000)
     ap.add_argument("--cpu-items", type=int, default=6000)
+    ap.add_argument("--cpu-sample-frac", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -155,6 +185,12 @@ def main():
 
     if rank == 0:
         alg_bytes = workload.Workload.algorithmic_bytes(w.items)
+        # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of this same
+        # command, summarised by tools/ into profiles/); only valid for the default workload size
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tpath) and args.queries == 10_000 and args.families == 100_000:
+            traffic = json.load(open(tpath))["round1_score_kernels"]["traffic_bytes_fetch_x2"]
         k_ms = ms1_sum / args.steps
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         out = {
@@ -171,7 +207,7 @@ def main():
                        "cells_per_step": cells_step, "parallelism": "query-shard x%d + RCCL all_gather of top-k records" % world if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "banded_swipe_kernel<P,score-only> (round 1)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None,
+                         "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_ms,
                          "kernel_gcups": cells1 / (k_ms * 1e-3) / 1e9,
                          "note": "integer DP held in VGPRs: VALU-issue bound, not HBM-bound (SURVEY.md 8d); HBM fraction reported as the contract asks"},
@@ -179,7 +215,10 @@ def main():
             "wall_ms_last_step": state["wall_ms"],
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(w, params, args.cpu_items)
+            ref = cpu_baseline_reference(args)
+            port = cpu_baseline(w, params, args.cpu_items)
+            out["cpu_baseline"] = ref if ref is not None else port
+            out["cpu_baseline_port"] = port
         print(json.dumps(out))
     ctx.close()
     if world > 1:

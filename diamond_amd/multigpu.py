@@ -1,0 +1,60 @@
+"""Multi-GPU plumbing (one process per GPU, torch.distributed; backend "nccl" is RCCL on ROCm).
+
+The hot path shards by query (SURVEY.md 8e option 1): every rank extends its own query slice against the
+database block resident in its HBM, so there is NO collective on the data path. The only exchange is the
+final gather of fixed-size per-query top-k records, ordered as the reference's cross-block merge orders
+them (JoinRecord::cmp_evalue: evalue asc, score desc, target oid asc; output/join_blocks.cpp:129-137)."""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+TOPK = 25       # max_target_seqs default, basic/config.h:55
+
+
+def shard_range(n, world, rank):
+    """Contiguous query slice of rank (so that concatenating rank outputs preserves query order)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def topk_records(n_queries, query_idx, evalue, score, target_oid, k=TOPK):
+    """Packs per-query top-k (evalue, -score, oid) records into a dense [n_queries, k, 3] float64 tensor
+    (+inf padded). Inputs must already be culled to <= k rows per query; rows of a query keep input order."""
+    rec = np.full((n_queries, k, 3), np.inf)
+    if len(query_idx):
+        order = np.lexsort((target_oid, -np.asarray(score, np.int64), evalue, query_idx))
+        q = np.asarray(query_idx)[order]
+        start = np.r_[0, np.nonzero(np.diff(q))[0] + 1]
+        rank_in_q = np.arange(q.size) - np.repeat(start, np.diff(np.r_[start, q.size]))
+        keep = rank_in_q < k
+        rec[q[keep], rank_in_q[keep], 0] = np.asarray(evalue)[order][keep]
+        rec[q[keep], rank_in_q[keep], 1] = -np.asarray(score, np.float64)[order][keep]
+        rec[q[keep], rank_in_q[keep], 2] = np.asarray(target_oid, np.float64)[order][keep]
+    return torch.from_numpy(rec)
+
+
+def gather_records(rec, device):
+    """ONE all_gather of the fixed-size record tensor; returns [world, n_queries, k, 3] on `device`."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return rec.unsqueeze(0)
+    world = dist.get_world_size()
+    rec_d = rec.to(device).contiguous()
+    out = torch.empty((world * rec.shape[0],) + tuple(rec.shape[1:]), dtype=rec.dtype, device=device)
+    dist.all_gather_into_tensor(out, rec_d)          # concatenation along dim 0 (accepted by RCCL and gloo)
+    return out.view((world,) + tuple(rec.shape))
+
+
+def merge_topk(gathered, k=TOPK):
+    """Database-sharded variant (SURVEY.md 8e option 2): every rank saw ALL queries against its own shard;
+    merges [world, nq, k, 3] into the global per-query top-k with the reference's ordering."""
+    world, nq, kk, _ = gathered.shape
+    allrec = gathered.permute(1, 0, 2, 3).reshape(nq, world * kk, 3)
+    for key in (2, 1, 0):       # stable sorts, least significant key first
+        order = torch.sort(allrec[:, :, key], dim=1, stable=True).indices
+        allrec = torch.gather(allrec, 1, order.unsqueeze(-1).expand(-1, -1, 3))
+    return allrec[:, :k]
+
+
+def aligned_queries(gathered):
+    return int((gathered[..., 0, 0] < float("inf")).sum().item())

@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
+#include <atomic>
 #include <vector>
 #include <list>
 #include "dp/dp.h"
@@ -46,6 +47,18 @@ long tap_limit() {
 	}
 	return lim;
 }
+// Cell counting mode ($DIAMOND_TAP_CELLS=file): no record dump, only the number of swipe() calls, DpTargets and
+// DP cells (sum of DpTarget::cells(), dp/dp.h:121-124 = the reference's NET_DP_CELLS definition; its own
+// -DDP_STAT counters do not compile in this revision) -- written at exit. Used for the GCUPS cpu_baseline.
+std::atomic<long long> g_cells(0), g_targets(0), g_calls(0);
+void write_cells() {
+	const char* p = getenv("DIAMOND_TAP_CELLS");
+	if (!p) return;
+	if (FILE* f = fopen(p, "w")) {
+		fprintf(f, "{\"calls\": %lld, \"targets\": %lld, \"cells\": %lld}\n", g_calls.load(), g_targets.load(), g_cells.load());
+		fclose(f);
+	}
+}
 struct Buf {
 	std::vector<char> d;
 	void i32(int32_t v) { d.insert(d.end(), (char*)&v, (char*)&v + 4); }
@@ -61,6 +74,15 @@ std::list<Hsp> wrap_swipe(const DP::Targets& targets, DP::Params& params) asm("_
 std::list<Hsp> wrap_swipe(const DP::Targets& targets, DP::Params& params)
 {
 	static long calls = 0;
+	static const bool count_cells = getenv("DIAMOND_TAP_CELLS") != nullptr;
+	if (count_cells) {
+		static std::once_flag once;
+		std::call_once(once, [] { atexit(write_cells); });
+		long long c = 0, n = 0;
+		for (int bin = 0; bin < DP::BINS; ++bin)
+			for (const DpTarget& t : targets[bin]) { c += t.cells(params.flags, params.query.length()); ++n; }
+		g_cells += c; g_targets += n; ++g_calls;
+	}
 	Buf b;
 	FILE* f = tap_file();
 	if (f) {
