@@ -39,6 +39,22 @@ double oracle_area(const oracle_evaluer* e, double y, double seqlen1, double seq
 double oracle_evalue(const oracle_evaluer* e, int raw_score, unsigned query_len, unsigned subject_len);
 double oracle_bitscore(const oracle_evaluer* e, double raw_score);
 
+/* ---- seed stage (oracle/seed_search.c) ---- */
+typedef struct {
+	int32_t seedp_bits, index_chunks, hamming_filter_id, n_shapes;
+	int32_t shape_len[16], shape_weight[16];
+	uint32_t shape_mask[16];
+	int32_t shape_pos[16][32];
+	int32_t reduction[32], reduction_size;
+	int32_t ungapped_window, left_most_interval;     /* config.ungapped_window (48), config.left_most_interval (32) */
+	double seed_complexity_cut;
+} oracle_seed_cfg;
+
+typedef struct { uint32_t query; int32_t seed_offset; int64_t subject; int32_t score; int32_t pad; } oracle_hit;
+
+int64_t oracle_seed_search(const oracle_seed_cfg* c, int8_t* qdata, const int64_t* qlimits, int64_t nq,
+	const int8_t* tdata, const int64_t* tlimits, int64_t nt, oracle_hit* hits, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -93,3 +93,49 @@ def evalue(e, score, qlen, slen):
 
 def bitscore(e, score):
     return lib().oracle_bitscore(ctypes.byref(e), ctypes.c_double(score))
+
+
+# ---- seed stage -------------------------------------------------------------------------------------------------
+class SeedCfg(ctypes.Structure):
+    _fields_ = [("seedp_bits", ctypes.c_int32), ("index_chunks", ctypes.c_int32), ("hamming_filter_id", ctypes.c_int32),
+                ("n_shapes", ctypes.c_int32), ("shape_len", ctypes.c_int32 * 16), ("shape_weight", ctypes.c_int32 * 16),
+                ("shape_mask", ctypes.c_uint32 * 16), ("shape_pos", (ctypes.c_int32 * 32) * 16),
+                ("reduction", ctypes.c_int32 * 32), ("reduction_size", ctypes.c_int32),
+                ("ungapped_window", ctypes.c_int32), ("left_most_interval", ctypes.c_int32),
+                ("seed_complexity_cut", ctypes.c_double)]
+
+
+HIT_DTYPE = np.dtype([("query", "<u4"), ("seed_offset", "<i4"), ("subject", "<i8"), ("score", "<i4"), ("pad", "<i4")])
+
+
+def seed_cfg_from_tap(cfg):
+    """Builds the oracle's configuration from the 'BLK1' header of an extend tap (tapfile.read_ext_tap)."""
+    c = SeedCfg()
+    c.seedp_bits, c.index_chunks, c.hamming_filter_id = cfg["seedp_bits"], cfg["index_chunks"], cfg["hamming_filter_id"]
+    c.n_shapes = len(cfg["shapes"])
+    for i, sh in enumerate(cfg["shapes"]):
+        c.shape_len[i], c.shape_weight[i], c.shape_mask[i] = sh["length"], sh["weight"], sh["mask"]
+        for k, p in enumerate(sh["positions"]):
+            c.shape_pos[i][k] = p
+    for i in range(32):
+        c.reduction[i] = int(cfg["reduction"][i])
+    c.reduction_size = int(max(cfg["reduction"][:20])) + 1
+    c.ungapped_window, c.left_most_interval = 48, 32
+    c.seed_complexity_cut = cfg["seed_complexity_cut"]
+    return c
+
+
+def seed_search(c, qdata, qlimits, tdata, tlimits, cap=1 << 22):
+    qd = np.ascontiguousarray(qdata, dtype=np.int8).copy()
+    td = np.ascontiguousarray(tdata, dtype=np.int8)
+    ql = np.ascontiguousarray(qlimits, dtype=np.int64)
+    tl = np.ascontiguousarray(tlimits, dtype=np.int64)
+    hits = np.zeros(cap, dtype=HIT_DTYPE)
+    f = lib().oracle_seed_search
+    f.restype = ctypes.c_int64
+    n = f(ctypes.byref(c), qd.ctypes.data_as(ctypes.c_void_p), ql.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(len(ql) - 1),
+          td.ctypes.data_as(ctypes.c_void_p), tl.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(len(tl) - 1),
+          hits.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(cap))
+    if n < 0:
+        raise RuntimeError("hit buffer too small")
+    return hits[:n].copy()

@@ -26,6 +26,12 @@
 #include <list>
 #include "dp/dp.h"
 #include "stats/score_matrix.h"
+#include "align/extend.h"
+#include "search/hit.h"
+#include "run/config.h"
+#include "data/block/block.h"
+#include "basic/shape_config.h"
+#include "basic/reduction.h"
 
 namespace {
 std::mutex tap_mtx;
@@ -162,6 +168,101 @@ std::list<Hsp> wrap_swipe(const DP::Targets& targets, DP::Params& params)
 			fflush(f);
 		}
 		++calls;
+	}
+	return out;
+}
+
+
+// ---- second seam: Extension::extend(query_id, Hit* begin, Hit* end, cfg, ...) (align/extend.cpp:346), called per
+// query from align_worker (align/align.cpp:157). Its input is the query's stage-2 seed hits (the output of the whole
+// seed stage, all shapes and index chunks), its output the query's final Match list. $DIAMOND_TAP_EXT=file:
+//   first record 'BLK1': seed-stage configuration + both sequence blocks (letters as they are at extension time):
+//     seedp_bits index_chunks hamming_filter_id n_shapes | per shape: length weight mask positions[weight]
+//     | reduction map[32] (int32) | f64 seed_complexity_cut | f64 ungapped_evalue | f64 gapped_filter_evalue
+//     | query_contexts | per block (query, target): n_seqs, i64 raw_len, data[raw_len], i64 limits[n_seqs+1]
+//   then per call 'EXT1': query_id n_hits | n_hits x { u32 query, i64 subject, i32 seed_offset, i32 score }
+//     | n_matches x { target_block_id filter_score f64 filter_evalue ungapped_score n_hsp | hsp records as above }
+namespace {
+FILE* ext_file() {
+	static FILE* f = nullptr;
+	static bool init = false;
+	if (!init) {
+		init = true;
+		const char* p = getenv("DIAMOND_TAP_EXT");
+		if (p) f = fopen(p, "wb");
+	}
+	return f;
+}
+void i64(Buf& b, int64_t v) { b.bytes(&v, 8); }
+void dump_block(Buf& b, const SequenceSet& s) {
+	const int64_t n = s.size();
+	b.i32((int32_t)n);
+	const int64_t raw = s.position(n - 1, 0) + s.length(n - 1) + 1 + 256;     // last delimiter + perimeter padding
+	i64(b, raw);
+	b.bytes(s.data(0), (size_t)raw);
+	for (int64_t i = 0; i < n; ++i) i64(b, s.position(i, 0));
+	i64(b, s.position(n - 1, 0) + s.length(n - 1) + 1);
+}
+void dump_hsp(Buf& b, const Hsp& h) {
+	b.i32(h.swipe_target); b.i32(h.swipe_bin); b.i32(h.score); b.i32(h.frame); b.i32(h.d_begin); b.i32(h.d_end);
+	b.i32(h.query_range.begin_); b.i32(h.query_range.end_); b.i32(h.subject_range.begin_); b.i32(h.subject_range.end_);
+	b.i32(h.length); b.i32(h.identities); b.i32(h.mismatches); b.i32(h.positives); b.i32(h.gap_openings); b.i32(h.gaps);
+	b.i32(h.backtraced ? 1 : 0); b.f64(h.evalue); b.f64(h.bit_score);
+	const auto& tr = h.transcript.data();
+	b.i32((int32_t)tr.size());
+	for (const PackedOperation& op : tr) { const uint8_t c = op.code; b.bytes(&c, 1); }
+}
+}
+
+std::vector<Extension::Match> real_extend(BlockId query_id, Search::Hit* begin, Search::Hit* end, const Search::Config& cfg, Statistics& stat, DP::Flags flags, std::pmr::monotonic_buffer_resource& pool)
+	asm("__real__ZN9Extension6extendEjPN6Search3HitES2_RKNS0_6ConfigER10StatisticsN2DP5FlagsERNSt3pmr25monotonic_buffer_resourceE");
+std::vector<Extension::Match> wrap_extend(BlockId query_id, Search::Hit* begin, Search::Hit* end, const Search::Config& cfg, Statistics& stat, DP::Flags flags, std::pmr::monotonic_buffer_resource& pool)
+	asm("__wrap__ZN9Extension6extendEjPN6Search3HitES2_RKNS0_6ConfigER10StatisticsN2DP5FlagsERNSt3pmr25monotonic_buffer_resourceE");
+
+std::vector<Extension::Match> wrap_extend(BlockId query_id, Search::Hit* begin, Search::Hit* end, const Search::Config& cfg, Statistics& stat, DP::Flags flags, std::pmr::monotonic_buffer_resource& pool)
+{
+	FILE* f = ext_file();
+	Buf b;
+	if (f) {
+		b.i32(0x31545845);
+		b.i32((int32_t)query_id);
+		b.i32((int32_t)(end - begin));
+		for (const Search::Hit* h = begin; h < end; ++h) {
+			b.i32((int32_t)h->query_);
+			i64(b, (int64_t)(uint64_t)h->subject_);
+			b.i32((int32_t)h->seed_offset_);
+			b.i32((int32_t)h->score_);
+		}
+	}
+	std::vector<Extension::Match> out = real_extend(query_id, begin, end, cfg, stat, flags, pool);
+	if (f) {
+		b.i32((int32_t)out.size());
+		for (const Extension::Match& m : out) {
+			b.i32((int32_t)m.target_block_id); b.i32(m.filter_score); b.f64(m.filter_evalue); b.i32(m.ungapped_score);
+			b.i32((int32_t)m.hsp.size());
+			for (const Hsp& h : m.hsp) dump_hsp(b, h);
+		}
+		static std::mutex mtx;
+		static bool header = false;
+		std::lock_guard<std::mutex> lock(mtx);
+		if (!header) {
+			header = true;
+			Buf h;
+			h.i32(0x314b4c42);
+			h.i32(cfg.seedp_bits); h.i32((int32_t)cfg.index_chunks); h.i32((int32_t)cfg.hamming_filter_id); h.i32(shapes.count());
+			for (int i = 0; i < shapes.count(); ++i) {
+				h.i32(shapes[i].length_); h.i32(shapes[i].weight_); h.i32((int32_t)shapes[i].mask_);
+				for (int k = 0; k < shapes[i].weight_; ++k) h.i32(shapes[i].positions_[k]);
+			}
+			for (int i = 0; i < 32; ++i) h.i32((int32_t)Reduction::get_reduction()((size_t)i));
+			h.f64(cfg.seed_complexity_cut); h.f64(cfg.ungapped_evalue); h.f64(cfg.gapped_filter_evalue);
+			h.i32(align_mode.query_contexts);
+			dump_block(h, cfg.query->seqs());
+			dump_block(h, cfg.target->seqs());
+			fwrite(h.d.data(), 1, h.d.size(), f);
+		}
+		fwrite(b.d.data(), 1, b.d.size(), f);
+		fflush(f);
 	}
 	return out;
 }

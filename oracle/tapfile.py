@@ -67,3 +67,82 @@ def read_tap(path, max_records=None):
         rec["hsps"] = hsps
         out.append(rec)
     return header, out
+
+
+MAGIC_BLK = 0x314B4C42
+MAGIC_EXT = 0x31545845
+
+
+def read_ext_tap(path, max_records=None):
+    """Reader for $DIAMOND_TAP_EXT files (oracle/ref_tap.cpp, second seam: Extension::extend).
+    Returns (cfg, records): cfg holds the seed-stage configuration and both sequence blocks;
+    records[i] = {query_id, hits (structured array), matches}."""
+    buf = open(path, "rb").read()
+    pos = 0
+
+    def i32():
+        nonlocal pos
+        v = struct.unpack_from("<i", buf, pos)[0]
+        pos += 4
+        return v
+
+    def i64():
+        nonlocal pos
+        v = struct.unpack_from("<q", buf, pos)[0]
+        pos += 8
+        return v
+
+    def f64():
+        nonlocal pos
+        v = struct.unpack_from("<d", buf, pos)[0]
+        pos += 8
+        return v
+
+    def raw(n, dtype):
+        nonlocal pos
+        a = np.frombuffer(buf, dtype=dtype, count=n, offset=pos).copy()
+        pos += n * np.dtype(dtype).itemsize
+        return a
+
+    hit_dtype = np.dtype([("query", "<u4"), ("subject", "<i8"), ("seed_offset", "<i4"), ("score", "<i4")])
+    cfg, out = None, []
+    while pos < len(buf) and (max_records is None or len(out) < max_records):
+        magic = i32()
+        if magic == MAGIC_BLK:
+            cfg = {"seedp_bits": i32(), "index_chunks": i32(), "hamming_filter_id": i32()}
+            shapes = []
+            for _ in range(i32()):
+                sh = {"length": i32(), "weight": i32(), "mask": i32()}
+                sh["positions"] = [i32() for _ in range(sh["weight"])]
+                shapes.append(sh)
+            cfg["shapes"] = shapes
+            cfg["reduction"] = np.array([i32() for _ in range(32)], dtype=np.int32)
+            cfg["seed_complexity_cut"], cfg["ungapped_evalue"], cfg["gapped_filter_evalue"] = f64(), f64(), f64()
+            cfg["query_contexts"] = i32()
+            for name in ("query", "target"):
+                n = i32()
+                raw_len = i64()
+                data = raw(raw_len, np.int8)
+                limits = raw(n + 1, np.int64)
+                cfg[name] = {"n": n, "data": data, "limits": limits}
+            continue
+        assert magic == MAGIC_EXT, "bad ext tap magic at %d" % (pos - 4)
+        rec = {"query_id": i32()}
+        nh = i32()
+        rec["hits"] = np.frombuffer(buf, dtype=hit_dtype, count=nh, offset=pos).copy()
+        pos += nh * hit_dtype.itemsize
+        matches = []
+        for _ in range(i32()):
+            m = {"target_block_id": i32(), "filter_score": i32(), "filter_evalue": f64(), "ungapped_score": i32()}
+            hsps = []
+            for _ in range(i32()):
+                h = {k: i32() for k in HSP_FIELDS}
+                h["evalue"] = f64()
+                h["bit_score"] = f64()
+                h["transcript"] = raw(i32(), np.uint8)
+                hsps.append(h)
+            m["hsps"] = hsps
+            matches.append(m)
+        rec["matches"] = matches
+        out.append(rec)
+    return cfg, out

@@ -37,5 +37,20 @@ DIAMOND_TAP_FILE="$HERE/swipe_long.tap" \
 # 4. blastx (6 query contexts, frames) on the reference's galaxy fixture (ctest galaxy_7)
 DIAMOND_TAP_FILE="$HERE/swipe_blastx.tap" \
   "$TAP" blastx -q "$REFTEST/galaxy/nucleotide.fasta" -d "$REFTEST/galaxy/db.dmnd" -o "$TMP/bx.out" -p1 2>/dev/null || true
+# 5. seed stage + extension stage known answers, tapped at Extension::extend (align/extend.cpp:346): per query the
+#    stage-2 seed hits it receives and the Match list it returns; header = both sequence blocks + seed configuration.
+#    Masking is host pre-processing outside the path: run with --masking 0 --motif-masking 0.
+DIAMOND_TAP_EXT="$HERE/ext_fast.tap" \
+  "$TAP" blastp --fast --masking 0 --motif-masking 0 --algo 0 -q "$REFTEST/data.faa" -d "$REFTEST/data.faa" -o "$TMP/e1.out" -p1 2>/dev/null
+DMND_ROOT="$ROOT" python3 - "$TMP" <<'PY'
+import os, sys
+sys.path.insert(0, os.environ["DMND_ROOT"])
+from diamond_amd import synth
+db, do, q, qo = synth.generate(250, members=10, queries=300, seed=1)
+synth.write_fasta(sys.argv[1] + "/s_db.faa", "t", db, do)
+synth.write_fasta(sys.argv[1] + "/s_q.faa", "q", q, qo)
+PY
+DIAMOND_TAP_EXT="$HERE/ext_fast_synth.tap" \
+  "$TAP" blastp --fast --masking 0 --motif-masking 0 --algo 0 -q "$TMP/s_q.faa" -d "$TMP/s_db.faa" -o "$TMP/e2.out" -p4 2>/dev/null
 ls -la "$HERE"/*.tap
 rm -rf "$TMP"
