@@ -16,62 +16,33 @@
 #include "../../include/diamond_hip.h"
 #include "swipe_core.h"
 #include "swipe_kernels.h"
-#include "evalue.h"
+#include "ctx.h"
 #include "blosum62.h"
 
 using namespace dmnd;
 
 static thread_local std::string g_last_error;
 
-static int fail(int code, const std::string& msg)
+int dmnd::fail(int code, const std::string& msg)
 {
 	g_last_error = msg;
 	return code;
 }
 
-#define HIP_TRY(expr)                                                                                     \
-	do {                                                                                                  \
-		hipError_t e_ = (expr);                                                                           \
-		if (e_ != hipSuccess)                                                                             \
-			return fail(DMND_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));                \
-	} while (0)
-
-struct DevBuf {
-	void* p = nullptr;
-	size_t cap = 0;
-	int ensure(size_t bytes)
-	{
-		if (bytes <= cap)
-			return DMND_OK;
-		if (p) (void)hipFree(p);
-		p = nullptr; cap = 0;
-		const size_t want = bytes + bytes / 4 + 256;
-		if (hipMalloc(&p, want) != hipSuccess) {
-			p = nullptr;
-			return fail(DMND_E_NOMEM, "hipMalloc of " + std::to_string(want) + " bytes failed");
-		}
-		cap = want;
+int dmnd::DevBuf::ensure(size_t bytes)
+{
+	if (bytes <= cap)
 		return DMND_OK;
+	if (p) (void)hipFree(p);
+	p = nullptr; cap = 0;
+	const size_t want = bytes + bytes / 4 + 256;
+	if (hipMalloc(&p, want) != hipSuccess) {
+		p = nullptr;
+		return fail(DMND_E_NOMEM, "hipMalloc of " + std::to_string(want) + " bytes failed");
 	}
-	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-	template<typename T> T* as() const { return reinterpret_cast<T*>(p); }
-};
-
-struct dmnd_ctx {
-	int device = 0;
-	hipStream_t stream = nullptr;
-	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
-	dmnd_params params;
-	Evaluer evaluer;
-	DevBuf block[2], cbs, matrix;
-	int64_t block_len[2] = { 0, 0 }, cbs_len = 0;
-	std::vector<int64_t> limits[2];
-	// work buffers
-	DevBuf items, order, p_of_slot, trace_off, transcript_off, ends, hsps, trace, transcript, status;
-	DevBuf host_q, host_t, host_cbs;      // staging for dmnd_banded_swipe_host
-	double swipe_ms = 0.0, traceback_ms = 0.0;
-	size_t trace_arena_max = (size_t)8 << 30;
-};
+	cap = want;
+	return DMND_OK;
+}
 
 extern "C" int dmnd_abi_version(void) { return DMND_ABI_VERSION; }
 
@@ -133,7 +104,9 @@ extern "C" void dmnd_destroy(dmnd_ctx* c)
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	for (DevBuf* b : { &c->block[0], &c->block[1], &c->cbs, &c->matrix, &c->items, &c->order, &c->p_of_slot, &c->trace_off,
-		&c->transcript_off, &c->ends, &c->hsps, &c->trace, &c->transcript, &c->status, &c->host_q, &c->host_t, &c->host_cbs })
+		&c->transcript_off, &c->ends, &c->hsps, &c->trace, &c->transcript, &c->status, &c->host_q, &c->host_t, &c->host_cbs,
+		&c->d_limits[0], &c->d_limits[1], &c->qid_of, &c->mask_time, &c->seed_keys, &c->seed_heads, &c->seed_next, &c->seed_flags,
+		&c->matched_slot, &c->matched_loc, &c->counters, &c->seed_hits })
 		b->release();
 	if (c->ev0) (void)hipEventDestroy(c->ev0);
 	if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -160,8 +133,12 @@ extern "C" int dmnd_upload_block(dmnd_ctx* c, int which, const int8_t* data, int
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	c->block_len[which] = data_len;
 	c->limits[which].clear();
-	if (limits)
+	if (limits) {
 		c->limits[which].assign(limits, limits + n_seqs + 1);
+		if (limits[n_seqs] > data_len) return fail(DMND_E_ARG, "dmnd_upload_block: limits exceed data_len");
+		if (int rc = c->d_limits[which].ensure((size_t)(n_seqs + 1) * sizeof(int64_t))) return rc;
+		HIP_TRY(hipMemcpy(c->d_limits[which].p, limits, (size_t)(n_seqs + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+	}
 	return DMND_OK;
 }
 

@@ -1,0 +1,50 @@
+// ctx.h -- shared internals of libdiamond_hip.so: error plumbing, device buffers, the context object.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/diamond_hip.h"
+#include "evalue.h"
+
+namespace dmnd {
+
+int fail(int code, const std::string& msg);      // sets dmnd_last_error(), returns code
+
+#define HIP_TRY(expr)                                                                                     \
+	do {                                                                                                  \
+		hipError_t e_ = (expr);                                                                           \
+		if (e_ != hipSuccess)                                                                             \
+			return ::dmnd::fail(DMND_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));        \
+	} while (0)
+
+struct DevBuf {
+	void* p = nullptr;
+	size_t cap = 0;
+	int ensure(size_t bytes);
+	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+	template<typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+}  // namespace dmnd
+
+struct dmnd_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+	dmnd_params params;
+	dmnd::Evaluer evaluer;
+	dmnd::DevBuf block[2], cbs, matrix;
+	int64_t block_len[2] = { 0, 0 }, cbs_len = 0;
+	std::vector<int64_t> limits[2];
+	dmnd::DevBuf d_limits[2];
+	// banded-swipe work buffers
+	dmnd::DevBuf items, order, p_of_slot, trace_off, transcript_off, ends, hsps, trace, transcript, status;
+	dmnd::DevBuf host_q, host_t, host_cbs;      // staging for dmnd_banded_swipe_host
+	double swipe_ms = 0.0, traceback_ms = 0.0;
+	size_t trace_arena_max = (size_t)8 << 30;
+	// seed-stage buffers (seed_api.hip)
+	dmnd::DevBuf qid_of, mask_time, seed_keys, seed_heads, seed_next, seed_flags, matched_slot, matched_loc, counters, seed_hits;
+	int64_t n_seed_hits = 0;
+	double seed_ms[5] = { 0, 0, 0, 0, 0 };
+};

@@ -1,0 +1,205 @@
+// seed_api.hip -- host side of the seed stage (include/diamond_hip.h: dmnd_seed_search / dmnd_seed_hits).
+// Orchestrates seed_kernels.hip per shape: index queries -> stream the reference -> complexity masks (all shapes
+// first, because a pair's left-most test needs the mask times of every earlier shape/chunk), then the pair filter
+// per shape. Replaces the control flow of Search::search_shape (/root/reference/src/search/stage0.cpp:101-217).
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "ctx.h"
+#include "seed_core.h"
+#include "seed_kernels.h"
+
+using namespace dmnd;
+
+static_assert(sizeof(dmnd_seed_params) == sizeof(SeedParams), "dmnd_seed_params must mirror dmnd::SeedParams");
+static_assert(sizeof(dmnd_seed_hit) == 24, "dmnd_seed_hit layout");
+
+extern "C" int dmnd_seed_params_fast(dmnd_seed_params* p, int threads)
+{
+	if (!p || threads < 1) return fail(DMND_E_ARG, "dmnd_seed_params_fast: bad argument");
+	std::memset(p, 0, sizeof(*p));
+	const char* code = "1101110101101111";                 // shape_codes[FAST], search/setup.cpp:211-212
+	p->n_shapes = 1;
+	int w = 0, len = (int)std::strlen(code);
+	for (int i = 0; i < len; ++i)
+		if (code[i] == '1') { p->shape_pos[0][w++] = (int8_t)i; p->shape_mask[0] |= 1u << i; }
+	p->shape_len[0] = len; p->shape_weight[0] = w;
+	// murphy10 "A KR EDNQ C G H ILVM FYW P ST" over ARNDCQEGHILKMFPSTWYV (stats/stats.cpp:48, basic/value.h:53);
+	// X and '*' reduce to the mask letter, every other code to class 0 (Reduction ctor, basic.cpp:267-297)
+	static const int8_t murphy10[32] = { 0, 1, 2, 2, 3, 2, 2, 4, 5, 6, 6, 1, 6, 7, 8, 9, 9, 7, 7, 6, 0, 0, 0, 23, 23, 0, 0, 0, 0, 0, 0, 0 };
+	std::memcpy(p->reduction, murphy10, 32);
+	p->reduction_size = 10;
+	p->index_chunks = 4;                                    // sensitivity_traits[FAST].index_chunks
+	p->hamming_filter_id = 11;
+	// seedp_bits(): max(bit_length(size^weight - 1) - 32, bit_length(threads*4*chunks - 1), 8), setup.cpp:306-309
+	auto bit_length = [](uint64_t x) { int b = 0; while (x) { ++b; x >>= 1; } return b; };
+	uint64_t space = 1;
+	for (int i = 0; i < w; ++i) space *= 10;
+	p->seedp_bits = std::max(std::max(bit_length(space - 1) - 32, bit_length((uint64_t)threads * 4 * p->index_chunks - 1)), 8);
+	p->ungapped_window = 48;
+	p->left_most_interval = 32;
+	p->seed_complexity_cut = 0.9 * 0.69314718055994530942 * w;      // seed_cut * log(2) * weight, setup.cpp:369-370
+	return DMND_OK;
+}
+
+extern "C" int dmnd_seed_kernel_ms(const dmnd_ctx* c, double ms[5])
+{
+	if (!c || !ms) return fail(DMND_E_ARG, "dmnd_seed_kernel_ms: bad argument");
+	for (int i = 0; i < 5; ++i) ms[i] = c->seed_ms[i];
+	return DMND_OK;
+}
+
+namespace {
+
+struct Timer {
+	hipEvent_t a, b;
+	hipStream_t st;
+	Timer(hipStream_t s) : st(s) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); }
+	~Timer() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
+	void start() { (void)hipEventRecord(a, st); }
+	double stop() { (void)hipEventRecord(b, st); (void)hipEventSynchronize(b); float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms; }
+};
+
+}
+
+extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int64_t* n_hits)
+{
+	if (!c || !params || !n_hits) return fail(DMND_E_ARG, "dmnd_seed_search: NULL argument");
+	*n_hits = 0;
+	const std::vector<int64_t>& ql = c->limits[DMND_QUERY];
+	const std::vector<int64_t>& tl = c->limits[DMND_TARGET];
+	if (ql.size() < 2 || tl.size() < 2) return fail(DMND_E_ARG, "dmnd_seed_search: both blocks must be uploaded with limits");
+	SeedParams sp;
+	std::memcpy(&sp, params, sizeof(sp));
+	if (sp.n_shapes < 1 || sp.n_shapes > SEED_MAX_SHAPES || sp.index_chunks < 1 || sp.seedp_bits < 1 || sp.seedp_bits > 24
+		|| sp.n_shapes * sp.index_chunks >= SEED_NEVER || sp.ungapped_window < 1 || sp.ungapped_window > 128 || sp.reduction_size < 2)
+		return fail(DMND_E_ARG, "dmnd_seed_search: unsupported seed configuration");
+	for (int i = 0; i < sp.n_shapes; ++i)
+		if (sp.shape_len[i] < 1 || sp.shape_len[i] > 32 || sp.shape_weight[i] < 1 || sp.shape_weight[i] > SEED_MAX_WEIGHT)
+			return fail(DMND_E_ARG, "dmnd_seed_search: bad shape");
+	HIP_TRY(hipSetDevice(c->device));
+	hipStream_t st = c->stream;
+	const int64_t q_begin = ql.front(), q_end = ql.back(), t_begin = tl.front(), t_end = tl.back();
+	const int64_t nq_pos = q_end - q_begin;
+	if (nq_pos <= 0 || t_end <= t_begin) return DMND_OK;
+	if (nq_pos >= 0xffffffffLL) return fail(DMND_E_ARG, "dmnd_seed_search: query block larger than 4G letters");
+	const int S = sp.n_shapes;
+	uint64_t slots = 1024;
+	while (slots < (uint64_t)nq_pos * 2) slots <<= 1;
+
+	if (int rc = c->qid_of.ensure((size_t)q_end * sizeof(uint32_t))) return rc;
+	if (int rc = c->mask_time.ensure((size_t)c->block_len[DMND_QUERY] + 256)) return rc;
+	if (int rc = c->seed_keys.ensure((size_t)S * slots * sizeof(uint64_t))) return rc;
+	if (int rc = c->seed_heads.ensure((size_t)S * slots * sizeof(uint32_t))) return rc;
+	if (int rc = c->seed_flags.ensure((size_t)S * slots)) return rc;
+	if (int rc = c->seed_next.ensure((size_t)S * nq_pos * sizeof(uint32_t))) return rc;
+	if (int rc = c->counters.ensure((size_t)(S + 1) * sizeof(unsigned long long))) return rc;
+	HIP_TRY(hipMemsetAsync(c->mask_time.p, SEED_NEVER, (size_t)c->block_len[DMND_QUERY] + 256, st));
+	HIP_TRY(hipMemsetAsync(c->seed_keys.p, 0xff, (size_t)S * slots * sizeof(uint64_t), st));
+	HIP_TRY(hipMemsetAsync(c->seed_heads.p, 0xff, (size_t)S * slots * sizeof(uint32_t), st));
+	HIP_TRY(hipMemsetAsync(c->seed_flags.p, 0, (size_t)S * slots, st));
+	HIP_TRY(launch_seed_qid(c->d_limits[DMND_QUERY].as<int64_t>(), (int64_t)ql.size() - 1, c->qid_of.as<uint32_t>(), st));
+
+	auto args_for = [&](int sid, int64_t matched_cap, int64_t matched_off) {
+		SeedArgs a;
+		a.params = sp;
+		a.qdata = c->block[DMND_QUERY].as<int8_t>(); a.tdata = c->block[DMND_TARGET].as<int8_t>();
+		a.qlimits = c->d_limits[DMND_QUERY].as<int64_t>();
+		a.q_begin = q_begin; a.q_end = q_end; a.t_begin = t_begin; a.t_end = t_end;
+		a.qid_of = c->qid_of.as<uint32_t>(); a.mask_time = c->mask_time.as<uint8_t>();
+		a.keys = c->seed_keys.as<uint64_t>() + (size_t)sid * slots;
+		a.heads = c->seed_heads.as<uint32_t>() + (size_t)sid * slots;
+		a.flags = c->seed_flags.as<uint8_t>() + (size_t)sid * slots;
+		a.next = c->seed_next.as<uint32_t>() + (size_t)sid * nq_pos;
+		a.slot_mask = slots - 1;
+		a.matched_slot = c->matched_slot.as<uint32_t>() + matched_off;
+		a.matched_loc = c->matched_loc.as<int64_t>() + matched_off;
+		a.matched_count = c->counters.as<unsigned long long>() + sid;
+		a.matched_cap = matched_cap;
+		a.hits = c->seed_hits.as<dmnd_seed_hit>(); a.hit_count = c->counters.as<unsigned long long>() + S; a.hit_cap = 0;
+		return a;
+	};
+
+	Timer tm(st);
+	for (int i = 0; i < 5; ++i) c->seed_ms[i] = 0;
+	// phase 1: index + stream + mask, every shape. The joined-position lists of all shapes share one buffer.
+	std::vector<unsigned long long> counts((size_t)S + 1, 0);
+	std::vector<int64_t> m_off((size_t)S + 1, 0);
+	int64_t cap_total = std::max<int64_t>((int64_t)1 << 22, 4 * nq_pos);
+	for (int attempt = 0;; ++attempt) {
+		if (int rc = c->matched_slot.ensure((size_t)cap_total * sizeof(uint32_t))) return rc;
+		if (int rc = c->matched_loc.ensure((size_t)cap_total * sizeof(int64_t))) return rc;
+		HIP_TRY(hipMemsetAsync(c->counters.p, 0, (size_t)(S + 1) * sizeof(unsigned long long), st));
+		if (attempt > 0) {
+			HIP_TRY(hipMemsetAsync(c->seed_keys.p, 0xff, (size_t)S * slots * sizeof(uint64_t), st));
+			HIP_TRY(hipMemsetAsync(c->seed_heads.p, 0xff, (size_t)S * slots * sizeof(uint32_t), st));
+			HIP_TRY(hipMemsetAsync(c->seed_flags.p, 0, (size_t)S * slots, st));
+		}
+		bool overflow = false;
+		int64_t off = 0;
+		for (int sid = 0; sid < S; ++sid) {
+			m_off[sid] = off;
+			SeedArgs a = args_for(sid, cap_total - off, off);
+			tm.start();
+			HIP_TRY(launch_seed_index(a, sid, st));
+			c->seed_ms[0] += tm.stop();
+			tm.start();
+			HIP_TRY(launch_seed_stream(a, sid, st));
+			c->seed_ms[1] += tm.stop();
+			HIP_TRY(hipMemcpy(&counts[sid], a.matched_count, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+			if ((int64_t)counts[sid] > cap_total - off) { overflow = true; off += (int64_t)counts[sid]; continue; }
+			off += (int64_t)counts[sid];
+		}
+		m_off[S] = off;
+		if (!overflow) break;
+		if (attempt >= 2) return fail(DMND_E_NOMEM, "dmnd_seed_search: joined-position buffer overflow");
+		cap_total = off + off / 8 + 1024;
+	}
+	for (int sid = 0; sid < S; ++sid) {
+		SeedArgs a = args_for(sid, (int64_t)counts[sid], m_off[sid]);
+		tm.start();
+		HIP_TRY(launch_seed_mask(a, sid, st));
+		c->seed_ms[2] += tm.stop();
+	}
+	// phase 2: pair filter per shape; hit buffer grows on overflow
+	int64_t hit_cap = std::max<int64_t>((int64_t)1 << 20, m_off[S]);
+	for (int attempt = 0;; ++attempt) {
+		if (int rc = c->seed_hits.ensure((size_t)hit_cap * sizeof(dmnd_seed_hit))) return rc;
+		HIP_TRY(hipMemsetAsync(c->counters.as<unsigned long long>() + S, 0, sizeof(unsigned long long), st));
+		double ms = 0;
+		for (int sid = 0; sid < S; ++sid) {
+			SeedArgs a = args_for(sid, (int64_t)counts[sid], m_off[sid]);
+			a.hits = c->seed_hits.as<dmnd_seed_hit>();
+			a.hit_cap = hit_cap;
+			tm.start();
+			HIP_TRY(launch_seed_pairs(a, sid, (int64_t)counts[sid], st));
+			ms += tm.stop();
+		}
+		unsigned long long nh = 0;
+		HIP_TRY(hipMemcpy(&nh, c->counters.as<unsigned long long>() + S, sizeof(nh), hipMemcpyDeviceToHost));
+		c->seed_ms[3] = ms;
+		if ((int64_t)nh <= hit_cap) { c->n_seed_hits = (int64_t)nh; break; }
+		if (attempt >= 2) return fail(DMND_E_NOMEM, "dmnd_seed_search: hit buffer overflow");
+		hit_cap = (int64_t)nh + 1024;
+	}
+	c->seed_ms[4] = c->seed_ms[0] + c->seed_ms[1] + c->seed_ms[2] + c->seed_ms[3];
+	*n_hits = c->n_seed_hits;
+	return DMND_OK;
+}
+
+extern "C" int dmnd_seed_hits(dmnd_ctx* c, dmnd_seed_hit* out, int64_t cap)
+{
+	if (!c || (!out && c->n_seed_hits > 0)) return fail(DMND_E_ARG, "dmnd_seed_hits: NULL argument");
+	if (cap < c->n_seed_hits) return fail(DMND_E_CAP, "dmnd_seed_hits: buffer too small");
+	if (c->n_seed_hits == 0) return DMND_OK;
+	HIP_TRY(hipSetDevice(c->device));
+	HIP_TRY(hipMemcpy(out, c->seed_hits.p, (size_t)c->n_seed_hits * sizeof(dmnd_seed_hit), hipMemcpyDeviceToHost));
+	std::sort(out, out + c->n_seed_hits, [](const dmnd_seed_hit& a, const dmnd_seed_hit& b) {
+		if (a.query != b.query) return a.query < b.query;
+		if (a.subject != b.subject) return a.subject < b.subject;
+		return a.seed_offset < b.seed_offset;
+	});
+	return DMND_OK;
+}

@@ -1,0 +1,251 @@
+// seed_core.h -- per-thread arithmetic of the MI355X seed stage.
+//
+// What the stage computes (reference: Search::search_shape, /root/reference/src/search/stage0.cpp:101-217):
+// all (query position, reference position) pairs whose spaced seeds are equal (the double-indexed seed-hit
+// join), minus low-complexity seeds (seed_complexity.cpp:37-120), filtered by the 48-byte Hamming fingerprint
+// (hamming/finger_print.h:59-96, kernel.h:29-75) and by the left-most-seed rule (left_most.h:30-108), emitted
+// as Search::Hit records (hit.h:30-47).
+//
+// GPU-first formulation -- NOT the reference's two partitioned seed arrays + radix/hash
+// join: the small side (queries) is indexed in an open-addressing table with per-seed linked lists of query
+// positions; the large side (reference block) is streamed once, every position's seed is computed in registers
+// and probed. Because every (q, s) decision depends only on the two sequence windows, the seed's index chunk
+// and the time at which query letters were masked, all pairs are independent; the reference's sequential
+// "index chunk" order is reproduced by comparing chunk ids (chunk of the seed's partition) and by storing,
+// per query letter, the (shape, chunk) time at which mask_seeds set its SEED_MASK bit.
+//
+// These functions are shared by the HIP kernels (seed_kernels.hip) and the CPU emulator in tests/emu.
+#pragma once
+#include <stdint.h>
+#include "swipe_core.h"      // DMND_HD, LETTER_MASK, imin/imax
+
+namespace dmnd {
+
+enum { SEED_MAX_SHAPES = 16, SEED_MAX_WEIGHT = 32, L_MASK = 23, L_STOP = 24, L_DELIM = 31, SEED_NEVER = 255 };
+
+// Seed-stage configuration: the globals the reference reads across the seam (shapes, Reduction::instance,
+// config.*, Search::Config), SURVEY 8b.
+struct SeedParams {
+	int32_t n_shapes;
+	int32_t shape_len[SEED_MAX_SHAPES], shape_weight[SEED_MAX_SHAPES];
+	uint32_t shape_mask[SEED_MAX_SHAPES];                    // Shape::mask_ (bit i = care position i)
+	int8_t shape_pos[SEED_MAX_SHAPES][SEED_MAX_WEIGHT];      // Shape::positions_
+	int8_t reduction[32];                                    // Reduction::map_ on masked letters (23 = invalid)
+	int32_t reduction_size;
+	int32_t seedp_bits, index_chunks, hamming_filter_id;
+	int32_t ungapped_window, left_most_interval;             // config.ungapped_window (48), config.left_most_interval (32)
+	double seed_complexity_cut;
+};
+
+DMND_HD bool is_amino_acid(int l) { return l != L_MASK && l != L_DELIM && l != L_STOP; }
+
+// Seed of the window starting at p (Shape::set_seed_reduced on reduced letters, shape.h:114-152): base-`size`
+// Horner polynomial; invalid if a care position is X or '*', or if the window [p, p+len) leaves its sequence
+// (contains a delimiter/padding byte) -- the reference only enumerates j <= L - len (seed_iterator.h:30-33).
+DMND_HD bool seed_at(const SeedParams& c, int sid, const int8_t* p, uint64_t& out)
+{
+	uint64_t s = 0;
+	const int len = c.shape_len[sid];
+	for (int i = 0; i < len; ++i)
+		if ((p[i] & LETTER_MASK) == L_DELIM) return false;
+	for (int k = 0; k < c.shape_weight[sid]; ++k) {
+		const int r = c.reduction[p[c.shape_pos[sid][k]] & LETTER_MASK];
+		if (r == L_MASK) return false;
+		s = s * (uint64_t)c.reduction_size + (uint64_t)r;
+	}
+	out = s;
+	return true;
+}
+
+// Shape::set_seed on unreduced letters (shape.h:72-96), used by verify_hit
+DMND_HD bool seed_unreduced(const SeedParams& c, int sid, const int8_t* p, uint64_t& out)
+{
+	uint64_t s = 0;
+	for (int k = 0; k < c.shape_weight[sid]; ++k) {
+		const int l = p[c.shape_pos[sid][k]] & LETTER_MASK;
+		if (!is_amino_acid(l)) return false;
+		s = s * (uint64_t)c.reduction_size + (uint64_t)c.reduction[l];
+	}
+	out = s;
+	return true;
+}
+
+// Index chunk of a seed: Partition<SeedPartition>(2^seedp_bits, index_chunks) over seed & mask
+// (basic/seed.h:35-51, util/algo/partition.h:25-55, stage0.cpp:104-121)
+DMND_HD int seed_chunk(const SeedParams& c, uint64_t seed)
+{
+	const int parts = 1 << c.seedp_bits, chunks = c.index_chunks < parts ? c.index_chunks : parts;
+	const int part = (int)(seed & (uint64_t)(parts - 1));
+	const int size = parts / chunks, rem = parts % chunks;
+	const int big = rem * (size + 1);
+	return part < big ? part / (size + 1) : rem + (part - big) / size;
+}
+
+DMND_HD void chunk_range(const SeedParams& c, int chunk, int& lo, int& hi)
+{
+	const int parts = 1 << c.seedp_bits, chunks = c.index_chunks < parts ? c.index_chunks : parts;
+	const int size = parts / chunks, rem = parts % chunks, b = chunk < rem ? chunk : rem;
+	lo = b * (size + 1) + (chunk - b) * size;
+	hi = lo + (chunk < rem ? size + 1 : size);
+}
+
+// seed_is_complex (seed_complexity.cpp:37-52); lnfact = ln(k!) rounded to 6 decimals (lib/blast/blast_seg.cpp:54)
+DMND_HD bool seed_is_complex(const SeedParams& c, int sid, const int8_t* p)
+{
+	const double LNFACT[20] = { 0.000000, 0.000000, 0.693147, 1.791759, 3.178054, 4.787492, 6.579251, 8.525161, 10.604603,
+		12.801827, 15.104413, 17.502308, 19.987214, 22.552164, 25.191221, 27.899271, 30.671860, 33.505073, 36.395445, 39.339884 };
+	int count[20];
+	for (int i = 0; i < 20; ++i) count[i] = 0;
+	for (int k = 0; k < c.shape_weight[sid]; ++k) {
+		const int l = p[c.shape_pos[sid][k]] & LETTER_MASK;
+		if (l >= 20) return false;
+		++count[c.reduction[l]];
+	}
+	double entropy = LNFACT[c.shape_weight[sid] < 20 ? c.shape_weight[sid] : 19];
+	for (int i = 0; i < c.reduction_size; ++i) entropy -= LNFACT[count[i]];
+	return entropy >= c.seed_complexity_cut;
+}
+
+// FingerPrint::match over [loc-16, loc+32) of masked letters
+DMND_HD int fingerprint_id(const int8_t* q, const int8_t* s)
+{
+	int n = 0;
+	for (int i = -16; i < 32; ++i)
+		n += (q[i] & LETTER_MASK) == (s[i] & LETTER_MASK);
+	return n;
+}
+
+// Util::Seq::clip (util/sequence/sequence.h:30-40): delimiter-free stretch of [seq, seq+len) around seq+anchor
+DMND_HD void clip_window(const int8_t* seq, int len, int anchor, int& begin, int& end)
+{
+	int b = 0, e = len;
+	for (int i = 0; i < len; ++i)
+		if (seq[i] == L_DELIM) {              // raw byte compare, as memchr does
+			if (i >= anchor) { e = i; break; }
+			b = i + 1;
+		}
+	begin = b; end = e;
+}
+
+// reduced_match (sse_dist.h:104-153) with Reduction::map8 / map8b (basic.cpp:267-297)
+DMND_HD uint64_t reduced_match(const SeedParams& c, const int8_t* q, const int8_t* s, int len)
+{
+	uint64_t m = 0;
+	for (int i = 0; i < len && i < 64; ++i) {
+		const int lq = q[i] & LETTER_MASK, ls = s[i] & LETTER_MASK;
+		const bool bq = lq == L_MASK || lq == L_STOP || lq == L_DELIM, bs = ls == L_MASK || ls == L_STOP || ls == L_DELIM;
+		if (!bq && !bs && c.reduction[lq] == c.reduction[ls]) m |= 1ull << i;
+	}
+	return m;
+}
+
+// PatternMatcher::hit over the shape masks [0, n_patterns) (util/algo/pattern_matcher.h:23-63)
+DMND_HD uint32_t pattern_hit(const SeedParams& c, int n_patterns, uint32_t h, uint32_t len)
+{
+	if (n_patterns == 0) return 0;
+	uint32_t min_len = 32, max_len = 0;
+	for (int i = 0; i < n_patterns; ++i) {
+		const uint32_t l = (uint32_t)c.shape_len[i];          // = 32 - clz(mask): a shape code starts and ends with '1'
+		if (l < min_len) min_len = l;
+		if (l > max_len) max_len = l;
+	}
+	if (len < min_len) return 0;
+	const uint32_t suffix_mask = max_len >= 32 ? 0xffffffffu : ((1u << max_len) - 1), end = len - min_len + 1;
+	uint32_t r = 0;
+	for (uint32_t i = 0; i < end && i < 32; ++i) {
+		const uint32_t w = h & suffix_mask;
+		for (int p = 0; p < n_patterns; ++p)
+			if ((w & c.shape_mask[p]) == c.shape_mask[p]) { r |= 1u << i; break; }
+		h >>= 1;
+	}
+	return r;
+}
+
+DMND_HD bool verify_hit(const SeedParams& c, const int8_t* q, const int8_t* s, bool left, uint32_t match_mask, int sid, bool chunked, int lo, int hi)
+{
+	if (chunked && (c.shape_mask[sid] & match_mask) == c.shape_mask[sid]) {
+		uint64_t seed;
+		if (!seed_unreduced(c, sid, s, seed)) return false;
+		const int part = (int)(seed & (uint64_t)((1 << c.seedp_bits) - 1));
+		if (left && !(part < hi)) return false;          // current_range.lower_or_equal
+		if (!left && !(part < lo)) return false;         // current_range.lower
+	}
+	return fingerprint_id(q, s) >= c.hamming_filter_id;
+}
+
+DMND_HD bool verify_hits(const SeedParams& c, uint32_t mask, const int8_t* q, const int8_t* s, bool left, uint32_t match_mask, int sid, bool chunked, int lo, int hi)
+{
+	for (int pos = 0; mask != 0 && pos < 32; ++pos) {
+		if ((mask & 1u) && verify_hit(c, q + pos, s + pos, left, match_mask >> pos, sid, chunked, lo, hi)) return true;
+		mask >>= 1;
+	}
+	return false;
+}
+
+// Query letters that carry the SEED_MASK bit at "time" t_now = sid * index_chunks + chunk: mask_time[] holds the
+// earliest (shape, chunk) at which mask_seeds set the bit on that letter (SEED_NEVER = never).
+DMND_HD uint64_t seed_mask_bits(const uint8_t* mask_time, int len, int t_now)
+{
+	uint64_t m = 0;
+	for (int i = 0; i < len && i < 64; ++i)
+		if (mask_time[i] <= t_now) m |= 1ull << i;
+	return m;
+}
+
+// search_query_offset + left_most_filter for one (query position, reference position) pair that passed the
+// Hamming filter (stage2.h:74-154, left_most.h:62-108). q/s point at the seed positions inside the blocks,
+// qmt at the query position's entry of mask_time[]. Returns true if the pair is kept (it is the left-most
+// seed hit of its diagonal in index-chunk order).
+DMND_HD bool left_most_pair(const SeedParams& c, const int8_t* q, const uint8_t* qmt, const int8_t* s, int seed_offset, int sid, int chunk)
+{
+	const int window = c.ungapped_window;
+	int cb, ce;
+	clip_window(q - window, 2 * window, window, cb, ce);           // query_clipped, stage2.h:94
+	const int window_left0 = window - cb, clipped_len = ce - cb;
+	const int interval_mod = c.left_most_interval > 0 ? seed_offset % c.left_most_interval : window_left0;
+	const int overhang = imax(window_left0 - interval_mod, 0);
+	// left_most_filter(query_clipped + overhang, subject + overhang, window_left - overhang, ...)
+	const int8_t* qd = q - window_left0 + overhang;                 // query.data()
+	const uint8_t* md = qmt - window_left0 + overhang;
+	const int8_t* sd = s - window_left0 + overhang;                 // subject
+	const int qlen = clipped_len - overhang;
+	const int so = window_left0 - overhang;                         // seed_offset inside the clipped window
+	const int seed_len = c.shape_len[sid];
+	const bool chunked = c.index_chunks > 1, first_shape = sid == 0;
+	int lo, hi;
+	chunk_range(c, chunk, lo, hi);
+	const int t_now = sid * c.index_chunks + chunk;
+
+	int d = imax(so - 16, 0), window_left = imin(16, so);
+	const int8_t *qq = qd + d, *ss = sd + d;
+	const uint8_t* mm = md + d;
+	int w = imin(qlen - d, window_left + 1 + 32);
+	int sb, se;
+	clip_window(ss, w, window_left, sb, se);                         // subject_clipped
+	w -= w - se;
+	qq += sb; ss += sb; mm += sb; window_left -= sb; w -= sb;
+
+	const uint64_t match_mask = reduced_match(c, qq, ss, w), query_seed_mask = ~seed_mask_bits(mm, w, t_now);
+	const uint32_t len_left = (uint32_t)(window_left + seed_len - 1);
+	const uint32_t match_mask_left = (uint32_t)(((1ull << len_left) - 1) & match_mask),
+		query_mask_left = (uint32_t)(((1ull << len_left) - 1) & query_seed_mask);
+	const uint32_t left_hit = pattern_hit(c, sid + 1, match_mask_left, len_left) & query_mask_left;
+	if (first_shape && !chunked)
+		return left_hit == 0 || !verify_hits(c, left_hit, qq, ss, true, match_mask_left, sid, chunked, lo, hi);
+	const uint32_t len_right = (uint32_t)(w - window_left - 1),
+		match_mask_right = (uint32_t)(match_mask >> (window_left + 1)), query_mask_right = (uint32_t)(query_seed_mask >> (window_left + 1));
+	const uint32_t right_hit = pattern_hit(c, chunked ? sid + 1 : sid, match_mask_right, len_right) & query_mask_right;
+	return (left_hit == 0 || !verify_hits(c, left_hit, qq, ss, true, match_mask_left, sid, chunked, lo, hi))
+		&& (right_hit == 0 || !verify_hits(c, right_hit, qq + window_left + 1, ss + window_left + 1, false, match_mask_right, sid, chunked, lo, hi));
+}
+
+// 64-bit mixer for the open-addressing table (splitmix64 finaliser)
+DMND_HD uint64_t seed_hash(uint64_t x)
+{
+	x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ULL;
+	x ^= x >> 27; x *= 0x94d049bb133111ebULL;
+	x ^= x >> 31;
+	return x;
+}
+
+}  // namespace dmnd

@@ -1,0 +1,36 @@
+// seed_kernels.h -- launch interface between seed_api.hip and seed_kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/diamond_hip.h"
+#include "seed_core.h"
+
+namespace dmnd {
+
+static const uint64_t SEED_EMPTY = ~0ull;
+static const uint32_t LIST_END = 0xffffffffu;
+enum { SLOT_FREE = 0, SLOT_JOINED = 1, SLOT_ERASED = 2 };
+
+struct SeedArgs {
+	SeedParams params;
+	const int8_t* qdata; const int8_t* tdata;     // block letters (HBM)
+	const int64_t* qlimits;                       // query block limits (HBM)
+	int64_t q_begin, q_end, t_begin, t_end;       // letter ranges [limits[0], limits[n])
+	const uint32_t* qid_of;                       // query position -> query id
+	uint8_t* mask_time;                           // per query letter: (shape, chunk) time of its SEED_MASK bit
+	// per-shape query seed table
+	uint64_t* keys; uint32_t* heads; uint32_t* next; uint8_t* flags;
+	uint64_t slot_mask;
+	// joined reference positions of this shape
+	uint32_t* matched_slot; int64_t* matched_loc; unsigned long long* matched_count; int64_t matched_cap;
+	// output
+	dmnd_seed_hit* hits; unsigned long long* hit_count; int64_t hit_cap;
+};
+
+hipError_t launch_seed_qid(const int64_t* limits, int64_t n_seqs, uint32_t* qid_of, hipStream_t st);
+hipError_t launch_seed_index(const SeedArgs& a, int sid, hipStream_t st);
+hipError_t launch_seed_stream(const SeedArgs& a, int sid, hipStream_t st);
+hipError_t launch_seed_mask(const SeedArgs& a, int sid, hipStream_t st);
+hipError_t launch_seed_pairs(const SeedArgs& a, int sid, int64_t n_matched, hipStream_t st);
+
+}  // namespace dmnd

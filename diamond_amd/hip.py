@@ -26,6 +26,18 @@ class Params(ctypes.Structure):
                 ("u_alpha_v", ctypes.c_double), ("db_letters", ctypes.c_double), ("max_evalue", ctypes.c_double)]
 
 
+class SeedParams(ctypes.Structure):
+    """dmnd_seed_params (include/diamond_hip.h)."""
+    _fields_ = [("n_shapes", ctypes.c_int32), ("shape_len", ctypes.c_int32 * 16), ("shape_weight", ctypes.c_int32 * 16),
+                ("shape_mask", ctypes.c_uint32 * 16), ("shape_pos", (ctypes.c_int8 * 32) * 16),
+                ("reduction", ctypes.c_int8 * 32), ("reduction_size", ctypes.c_int32),
+                ("seedp_bits", ctypes.c_int32), ("index_chunks", ctypes.c_int32), ("hamming_filter_id", ctypes.c_int32),
+                ("ungapped_window", ctypes.c_int32), ("left_most_interval", ctypes.c_int32),
+                ("seed_complexity_cut", ctypes.c_double)]
+
+
+SEED_HIT_DTYPE = np.dtype([("query", "<u4"), ("seed_offset", "<i4"), ("subject", "<i8"), ("score", "<i4"), ("pad", "<i4")])
+
 DP_TARGET_DTYPE = np.dtype([("query_off", "<i8"), ("target_off", "<i8"), ("cbs_off", "<i8"), ("query_len", "<i4"),
                             ("target_len", "<i4"), ("d_begin", "<i4"), ("d_end", "<i4")], align=True)
 HSP_DTYPE = np.dtype([("score", "<i4"), ("q_begin", "<i4"), ("q_end", "<i4"), ("s_begin", "<i4"), ("s_end", "<i4"),
@@ -40,7 +52,8 @@ _lib = None
 EXPORTS = ["dmnd_abi_version", "dmnd_last_error", "dmnd_default_params", "dmnd_create", "dmnd_destroy",
            "dmnd_set_db_letters", "dmnd_upload_block", "dmnd_upload_cbs", "dmnd_banded_swipe",
            "dmnd_banded_swipe_host", "dmnd_banded_cols", "dmnd_evalue", "dmnd_bitscore", "dmnd_evalue_p",
-           "dmnd_bitscore_p", "dmnd_evalue_batch", "dmnd_last_kernel_ms"]
+           "dmnd_bitscore_p", "dmnd_evalue_batch", "dmnd_last_kernel_ms", "dmnd_seed_params_fast", "dmnd_seed_search",
+           "dmnd_seed_hits", "dmnd_seed_kernel_ms"]
 
 
 def load():
@@ -71,6 +84,10 @@ def load():
         lib.dmnd_evalue_p.argtypes = [ctypes.POINTER(Params), ctypes.c_int32, ctypes.c_uint32, ctypes.c_uint32]
         lib.dmnd_bitscore_p.restype = ctypes.c_double
         lib.dmnd_bitscore_p.argtypes = [ctypes.POINTER(Params), ctypes.c_double]
+        lib.dmnd_seed_params_fast.argtypes = [ctypes.POINTER(SeedParams), ctypes.c_int]
+        lib.dmnd_seed_search.argtypes = [ctypes.c_void_p, ctypes.POINTER(SeedParams), ctypes.POINTER(ctypes.c_int64)]
+        lib.dmnd_seed_hits.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
+        lib.dmnd_seed_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
         lib.dmnd_last_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
         _lib = lib
     return _lib
@@ -96,6 +113,15 @@ def evalue_batch(p, score, qlen, slen):
     if rc != 0:
         raise DiamondHipError(lib.dmnd_last_error().decode())
     return out
+
+
+def seed_params_fast(threads=1):
+    """--fast seed configuration as the reference sets it up for `threads` threads (search/setup.cpp)."""
+    p = SeedParams()
+    rc = load().dmnd_seed_params_fast(ctypes.byref(p), int(threads))
+    if rc != 0:
+        raise DiamondHipError(load().dmnd_last_error().decode())
+    return p
 
 
 def matrix_of(p):
@@ -174,6 +200,19 @@ class Context:
                                                     tr.ctypes.data if tr is not None else None,
                                                     tr.size if tr is not None else 0, ctypes.byref(used)))
         return out, (tr[:used.value] if tr is not None else None)
+
+    def seed_search(self, seed_params):
+        """Search::search_shape for all shapes/chunks on the uploaded blocks. Returns hits sorted by (query, subject, seed_offset)."""
+        n = ctypes.c_int64(0)
+        self._check(self.lib.dmnd_seed_search(self.h, ctypes.byref(seed_params), ctypes.byref(n)))
+        hits = np.zeros(n.value, dtype=SEED_HIT_DTYPE)
+        self._check(self.lib.dmnd_seed_hits(self.h, hits.ctypes.data if n.value else None, n.value))
+        return hits
+
+    def seed_kernel_ms(self):
+        ms = (ctypes.c_double * 5)()
+        self._check(self.lib.dmnd_seed_kernel_ms(self.h, ms))
+        return list(ms)
 
     def last_kernel_ms(self):
         a, b = ctypes.c_double(0), ctypes.c_double(0)

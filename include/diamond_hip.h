@@ -152,6 +152,50 @@ double dmnd_bitscore_p(const dmnd_params* params, double raw_score);
 int dmnd_evalue_batch(const dmnd_params* params, const int32_t* raw_score, const int32_t* query_len,
 	const int32_t* subject_len, int64_t n, double* out);
 
+/* -- seed stage: replaces Search::search_shape for all shapes and index chunks of one (query block, reference
+ *    block) pair (src/search/search.h:83, src/search/stage0.cpp:101-228) -------------------------------------- */
+#define DMND_MAX_SHAPES 16
+#define DMND_MAX_SHAPE_WEIGHT 32
+/* The globals the reference reads across the seam: `shapes` (basic/shape_config.h), Reduction::instance
+ * (basic/reduction.h), Search::Config::{seedp_bits,index_chunks,hamming_filter_id,seed_complexity_cut}
+ * (run/config.h:102-115), config.ungapped_window / left_most_interval (basic/config.cpp:558,582). */
+typedef struct {
+	int32_t n_shapes;
+	int32_t shape_len[DMND_MAX_SHAPES], shape_weight[DMND_MAX_SHAPES];
+	uint32_t shape_mask[DMND_MAX_SHAPES];                         /* Shape::mask_ */
+	int8_t shape_pos[DMND_MAX_SHAPES][DMND_MAX_SHAPE_WEIGHT];     /* Shape::positions_ */
+	int8_t reduction[32];                                         /* Reduction::map_ for letters 0..31 (23 = mask) */
+	int32_t reduction_size;
+	int32_t seedp_bits, index_chunks, hamming_filter_id;
+	int32_t ungapped_window, left_most_interval;
+	double seed_complexity_cut;
+} dmnd_seed_params;
+
+/* One stage-2 seed hit = Search::Hit (src/search/hit.h:30-47): query context index, reference location
+ * (offset into the DMND_TARGET block data), seed offset inside the query, stage-1 score
+ * (0xFFFF when the ungapped filter is off, as the reference writes: stage2.h:86,112,139). */
+typedef struct {
+	uint32_t query;
+	int32_t seed_offset;
+	int64_t subject;
+	int32_t score;
+	int32_t pad;
+} dmnd_seed_hit;
+
+/* Fills the --fast configuration (one shape 1101110101101111, murphy10 reduction, Hamming id 11, seed cut 0.9,
+ * 4 index chunks; search/setup.cpp:43,211-212) for `threads` reference threads (seedp_bits depends on it,
+ * setup.cpp:306-309). */
+int dmnd_seed_params_fast(dmnd_seed_params* p, int threads);
+/* Runs the whole seed stage on the uploaded blocks (both must have been uploaded WITH limits). Supported:
+ * spaced seeds, ungapped e-value filter off (the --fast family). Hits stay in device memory;
+ * *n_hits returns their number. */
+int dmnd_seed_search(dmnd_ctx* ctx, const dmnd_seed_params* params, int64_t* n_hits);
+/* Copies the hits of the last dmnd_seed_search to the caller, sorted by (query, subject, seed_offset)
+ * (the reference sorts by query before extension, align/align.cpp:233). cap < n -> DMND_E_CAP. */
+int dmnd_seed_hits(dmnd_ctx* ctx, dmnd_seed_hit* out, int64_t cap);
+/* device milliseconds of the last dmnd_seed_search: [0] index queries [1] stream reference [2] mask [3] pair filter [4] total */
+int dmnd_seed_kernel_ms(const dmnd_ctx* ctx, double ms[5]);
+
 /* -- timing hooks for bench.py: device time of the DP kernels of the last dmnd_banded_swipe call,
  *    measured with HIP events on the stream the kernels ran on ------------------------------------ */
 int dmnd_last_kernel_ms(const dmnd_ctx* ctx, double* swipe_ms, double* traceback_ms);

@@ -1,0 +1,70 @@
+// tests/emu/seed_emu.cpp -- TEST INFRASTRUCTURE ONLY.
+// CPU emulation of the GPU seed-stage data flow (diamond_amd/csrc/seed_kernels.hip) built from the SAME per-thread
+// code (diamond_amd/csrc/seed_core.h): index the query seeds, stream the reference once, mark joined seeds, derive the
+// per-letter mask times, then filter every (query, reference) pair independently. Checks on the CPU that the
+// order-free formulation reproduces the reference's sequential index-chunk semantics. Never used by the product.
+#include <algorithm>
+#include <unordered_map>
+#include <vector>
+#include "../../diamond_amd/csrc/seed_core.h"
+
+using namespace dmnd;
+
+struct EmuHit { uint32_t query; int32_t seed_offset; int64_t subject; int32_t score; int32_t pad; };
+
+extern "C" int64_t emu_seed_search(const SeedParams* cp, const int8_t* qdata, const int64_t* qlimits, int64_t nq,
+	const int8_t* tdata, const int64_t* tlimits, int64_t nt, EmuHit* hits, int64_t cap)
+{
+	const SeedParams& c = *cp;
+	const int64_t qraw = qlimits[nq], traw = tlimits[nt];
+	std::vector<uint8_t> mask_time((size_t)qraw + 256, SEED_NEVER);
+	std::vector<uint32_t> qid_of((size_t)qraw, 0);
+	for (int64_t i = 0; i < nq; ++i)
+		for (int64_t p = qlimits[i]; p < qlimits[i + 1]; ++p) qid_of[(size_t)p] = (uint32_t)i;
+	struct Group { std::vector<int64_t> q; bool present = false, erased = false; };
+	std::vector<std::unordered_map<uint64_t, Group>> tables(c.n_shapes);
+	std::vector<std::vector<std::pair<uint64_t, int64_t>>> matched(c.n_shapes);
+	// phase 1: index queries, stream the reference, complexity masks -- for every shape
+	for (int sid = 0; sid < c.n_shapes; ++sid) {
+		auto& tab = tables[sid];
+		for (int64_t p = qlimits[0]; p < qraw; ++p) {
+			uint64_t s;
+			if (seed_at(c, sid, qdata + p, s)) tab[s].q.push_back(p);
+		}
+		for (int64_t p = tlimits[0]; p < traw; ++p) {
+			uint64_t s;
+			if (!seed_at(c, sid, tdata + p, s)) continue;
+			auto it = tab.find(s);
+			if (it == tab.end()) continue;
+			it->second.present = true;
+			matched[sid].push_back({ s, p });
+		}
+		for (auto& kv : tab) {
+			Group& g = kv.second;
+			if (!g.present) continue;
+			const int64_t first = *std::min_element(g.q.begin(), g.q.end());
+			if (!seed_is_complex(c, sid, qdata + first)) {
+				g.erased = true;
+				const int t = sid * c.index_chunks + seed_chunk(c, kv.first);
+				for (int64_t p : g.q) mask_time[(size_t)p] = (uint8_t)std::min<int>(mask_time[(size_t)p], t);
+			}
+		}
+	}
+	// phase 2: every joined pair independently
+	int64_t n = 0;
+	for (int sid = 0; sid < c.n_shapes; ++sid)
+		for (const auto& m : matched[sid]) {
+			const Group& g = tables[sid][m.first];
+			if (g.erased) continue;
+			const int chunk = seed_chunk(c, m.first);
+			for (int64_t qp : g.q) {
+				if (fingerprint_id(qdata + qp, tdata + m.second) < c.hamming_filter_id) continue;
+				const uint32_t qid = qid_of[(size_t)qp];
+				const int seed_offset = (int)(qp - qlimits[qid]);
+				if (!left_most_pair(c, qdata + qp, mask_time.data() + qp, tdata + m.second, seed_offset, sid, chunk)) continue;
+				if (n >= cap) return -1;
+				hits[n++] = EmuHit{ qid, seed_offset, m.second, 0xFFFF, 0 };
+			}
+		}
+	return n;
+}

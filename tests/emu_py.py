@@ -7,7 +7,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SRC = os.path.join(_HERE, "emu", "swipe_emu.cpp")
+_SRC2 = os.path.join(_HERE, "emu", "seed_emu.cpp")
 _CORE = os.path.join(_HERE, "..", "diamond_amd", "csrc", "swipe_core.h")
+_CORE2 = os.path.join(_HERE, "..", "diamond_amd", "csrc", "seed_core.h")
 _SO = os.path.join(_HERE, "emu", "libswipe_emu.so")
 
 
@@ -23,8 +25,8 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_SO) or max(os.path.getmtime(_SRC), os.path.getmtime(_CORE)) > os.path.getmtime(_SO):
-            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-o", _SO, _SRC])
+        if not os.path.exists(_SO) or max(os.path.getmtime(f) for f in (_SRC, _SRC2, _CORE, _CORE2)) > os.path.getmtime(_SO):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-o", _SO, _SRC, _SRC2])
         _lib = ctypes.CDLL(_SO)
     return _lib
 
@@ -56,3 +58,48 @@ def swipe_stats(query, cbs, target, d_begin, d_end, matrix8, gap_open, gap_exten
                                t.ctypes.data_as(p8), len(t), int(d_begin), int(d_end), m.ctypes.data_as(p8),
                                int(gap_open), int(gap_extend), ctypes.byref(out))
     return rc, {n: getattr(out, n) for n, _ in EmuOut._fields_}
+
+
+# ---- seed stage ---------------------------------------------------------------------------------------------------
+class SeedParams(ctypes.Structure):
+    """Mirror of dmnd::SeedParams (diamond_amd/csrc/seed_core.h) = dmnd_seed_params (include/diamond_hip.h)."""
+    _fields_ = [("n_shapes", ctypes.c_int32), ("shape_len", ctypes.c_int32 * 16), ("shape_weight", ctypes.c_int32 * 16),
+                ("shape_mask", ctypes.c_uint32 * 16), ("shape_pos", (ctypes.c_int8 * 32) * 16),
+                ("reduction", ctypes.c_int8 * 32), ("reduction_size", ctypes.c_int32),
+                ("seedp_bits", ctypes.c_int32), ("index_chunks", ctypes.c_int32), ("hamming_filter_id", ctypes.c_int32),
+                ("ungapped_window", ctypes.c_int32), ("left_most_interval", ctypes.c_int32),
+                ("seed_complexity_cut", ctypes.c_double)]
+
+
+HIT_DTYPE = np.dtype([("query", "<u4"), ("seed_offset", "<i4"), ("subject", "<i8"), ("score", "<i4"), ("pad", "<i4")])
+
+
+def seed_params_from_tap(cfg):
+    c = SeedParams()
+    c.n_shapes = len(cfg["shapes"])
+    for i, sh in enumerate(cfg["shapes"]):
+        c.shape_len[i], c.shape_weight[i], c.shape_mask[i] = sh["length"], sh["weight"], sh["mask"]
+        for k, p in enumerate(sh["positions"]):
+            c.shape_pos[i][k] = p
+    for i in range(32):
+        c.reduction[i] = int(cfg["reduction"][i])
+    c.reduction_size = int(max(cfg["reduction"][:20])) + 1
+    c.seedp_bits, c.index_chunks, c.hamming_filter_id = cfg["seedp_bits"], cfg["index_chunks"], cfg["hamming_filter_id"]
+    c.ungapped_window, c.left_most_interval = 48, 32
+    c.seed_complexity_cut = cfg["seed_complexity_cut"]
+    return c
+
+
+def seed_search(c, qdata, qlimits, tdata, tlimits, cap=1 << 22):
+    qd = np.ascontiguousarray(qdata, dtype=np.int8)
+    td = np.ascontiguousarray(tdata, dtype=np.int8)
+    ql = np.ascontiguousarray(qlimits, dtype=np.int64)
+    tl = np.ascontiguousarray(tlimits, dtype=np.int64)
+    hits = np.zeros(cap, dtype=HIT_DTYPE)
+    f = lib().emu_seed_search
+    f.restype = ctypes.c_int64
+    n = f(ctypes.byref(c), qd.ctypes.data_as(ctypes.c_void_p), ql.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(len(ql) - 1),
+          td.ctypes.data_as(ctypes.c_void_p), tl.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(len(tl) - 1),
+          hits.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(cap))
+    assert n >= 0
+    return hits[:n].copy()

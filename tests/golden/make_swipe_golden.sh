@@ -42,6 +42,9 @@ DIAMOND_TAP_FILE="$HERE/swipe_blastx.tap" \
 #    Masking is host pre-processing outside the path: run with --masking 0 --motif-masking 0.
 DIAMOND_TAP_EXT="$HERE/ext_fast.tap" \
   "$TAP" blastp --fast --masking 0 --motif-masking 0 --algo 0 -q "$REFTEST/data.faa" -d "$REFTEST/data.faa" -o "$TMP/e1.out" -p1 2>/dev/null
+# six shapes of weight 10 (still no ungapped filter): exercises the cross-shape left-most rule and mask times
+DIAMOND_TAP_EXT="$HERE/ext_6x10.tap" \
+  "$TAP" blastp --shapes-6x10 --masking 0 --motif-masking 0 --algo 0 -q "$REFTEST/data.faa" -d "$REFTEST/data.faa" -o "$TMP/e6.out" -p4 2>/dev/null
 DMND_ROOT="$ROOT" python3 - "$TMP" <<'PY'
 import os, sys
 sys.path.insert(0, os.environ["DMND_ROOT"])
