@@ -4,6 +4,7 @@
 // per shape. Replaces the control flow of Search::search_shape (/root/reference/src/search/stage0.cpp:101-217).
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -89,6 +90,17 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	uint64_t slots = 1024;
 	while (slots < (uint64_t)nq_pos * 2) slots <<= 1;
 
+	// bitmap: >= 16 bits per query position, at most 2^27 bits (16 MB); word mask for 32-bit words
+	uint64_t bm_words = 1 << 15;
+	while (bm_words * 32 < (uint64_t)nq_pos * 16 && bm_words < ((uint64_t)1 << 22)) bm_words <<= 1;
+	// level-1 bitmap: 2^24 bits = 2 MB by default (half an XCD's L2), never larger than level 2
+	int bm1_log2 = 24;
+	if (const char* e = getenv("DMND_SEED_BITMAP1_LOG2")) bm1_log2 = std::min(30, std::max(15, atoi(e)));
+	uint64_t bm1_words = ((uint64_t)1 << bm1_log2) / 32;
+	if (bm1_words > bm_words) bm1_words = bm_words;
+	const size_t bm_total = (size_t)S * (bm_words + bm1_words) * sizeof(uint32_t);
+	if (int rc = c->seed_bitmap.ensure(bm_total)) return rc;
+	HIP_TRY(hipMemsetAsync(c->seed_bitmap.p, 0, bm_total, st));
 	if (int rc = c->qid_of.ensure((size_t)q_end * sizeof(uint32_t))) return rc;
 	if (int rc = c->mask_time.ensure((size_t)c->block_len[DMND_QUERY] + 256)) return rc;
 	if (int rc = c->seed_keys.ensure((size_t)S * slots * sizeof(uint64_t))) return rc;
@@ -114,6 +126,10 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		a.flags = c->seed_flags.as<uint8_t>() + (size_t)sid * slots;
 		a.next = c->seed_next.as<uint32_t>() + (size_t)sid * nq_pos;
 		a.slot_mask = slots - 1;
+		a.bitmap = c->seed_bitmap.as<uint32_t>() + (size_t)sid * (bm_words + bm1_words);
+		a.bitmap_mask = (uint32_t)(bm_words - 1);
+		a.bitmap1 = a.bitmap + bm_words;
+		a.bitmap1_mask = (uint32_t)(bm1_words - 1);
 		a.matched_slot = c->matched_slot.as<uint32_t>() + matched_off;
 		a.matched_loc = c->matched_loc.as<int64_t>() + matched_off;
 		a.matched_count = c->counters.as<unsigned long long>() + sid;
@@ -136,6 +152,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 			HIP_TRY(hipMemsetAsync(c->seed_keys.p, 0xff, (size_t)S * slots * sizeof(uint64_t), st));
 			HIP_TRY(hipMemsetAsync(c->seed_heads.p, 0xff, (size_t)S * slots * sizeof(uint32_t), st));
 			HIP_TRY(hipMemsetAsync(c->seed_flags.p, 0, (size_t)S * slots, st));
+			HIP_TRY(hipMemsetAsync(c->seed_bitmap.p, 0, bm_total, st));
 		}
 		bool overflow = false;
 		int64_t off = 0;

@@ -239,13 +239,16 @@ DMND_HD bool left_most_pair(const SeedParams& c, const int8_t* q, const uint8_t*
 		&& (right_hit == 0 || !verify_hits(c, right_hit, qq + window_left + 1, ss + window_left + 1, false, match_mask_right, sid, chunked, lo, hi));
 }
 
-// 64-bit mixer for the open-addressing table (splitmix64 finaliser)
+// Hash of a seed for the query seed table: two 32-bit mixes (murmur3-style finalisers on 32-bit lanes, cheap on
+// the VALU) packed as (bitmap hash << 32) | slot hash.
 DMND_HD uint64_t seed_hash(uint64_t x)
 {
-	x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ULL;
-	x ^= x >> 27; x *= 0x94d049bb133111ebULL;
-	x ^= x >> 31;
-	return x;
+	const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+	uint32_t a = lo * 0x9E3779B1u + hi * 0x85EBCA6Bu;
+	a ^= a >> 15; a *= 0x2C1B3C6Du; a ^= a >> 12; a *= 0x297A2D39u; a ^= a >> 15;
+	uint32_t b = (lo ^ 0x68E31DA4u) * 0xCC9E2D51u + (hi + 0x1B873593u) * 0x27D4EB2Fu;
+	b ^= b >> 16; b *= 0x85EBCA6Bu; b ^= b >> 13;
+	return ((uint64_t)b << 32) | a;
 }
 
 }  // namespace dmnd

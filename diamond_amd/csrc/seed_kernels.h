@@ -21,6 +21,11 @@ struct SeedArgs {
 	// per-shape query seed table
 	uint64_t* keys; uint32_t* heads; uint32_t* next; uint8_t* flags;
 	uint64_t slot_mask;
+	// two one-hash bitmaps of the query seeds: level 1 is sized to stay resident in every XCD's 4 MB L2 (the reference
+	// stream probes it once per position), level 2 (>= 16 bits per query seed) filters level-1 false positives before
+	// the open-addressing table is touched
+	uint32_t* bitmap1; uint32_t bitmap1_mask;
+	uint32_t* bitmap; uint32_t bitmap_mask;
 	// joined reference positions of this shape
 	uint32_t* matched_slot; int64_t* matched_loc; unsigned long long* matched_count; int64_t matched_cap;
 	// output

@@ -37,7 +37,10 @@ __global__ void seed_index_kernel(SeedArgs a, int sid)
 	if (p >= a.q_end) return;
 	uint64_t seed;
 	if (!seed_at(a.params, sid, a.qdata + p, seed)) return;
-	uint64_t slot = seed_hash(seed) & a.slot_mask;
+	const uint64_t h = seed_hash(seed);
+	atomicOr(&a.bitmap[(h >> 32) & a.bitmap_mask], 1u << (h >> 59));
+	atomicOr(&a.bitmap1[(uint32_t)(h >> 10) & a.bitmap1_mask], (1u << (h & 31)) | (1u << ((h >> 5) & 31)));   // 2 bits, one word
+	uint64_t slot = h & a.slot_mask;
 	for (;;) {
 		const unsigned long long old = atomicCAS((unsigned long long*)&a.keys[slot], (unsigned long long)SEED_EMPTY, (unsigned long long)seed);
 		if (old == SEED_EMPTY || old == seed) break;
@@ -65,6 +68,111 @@ __global__ void seed_stream_kernel(SeedArgs a, int sid)
 	if (idx < (unsigned long long)a.matched_cap) {
 		a.matched_slot[idx] = (uint32_t)slot;
 		a.matched_loc[idx] = p;
+	}
+}
+
+// ---- fast reference stream: 16 positions per thread -------------------------------------------------------------
+// Each thread loads 32 consecutive letters with two aligned 16-byte loads (coalesced: a wavefront reads 1 KiB + a
+// 16-byte halo that hits L1), reduces them to 4-bit classes packed in two 64-bit registers, and evaluates the seed
+// polynomial of its 16 window starts with bit-field extracts at the shape's (wave-uniform) care positions -- no LDS,
+// no per-position byte loads. A 2^k-bit Bloom-style bitmap of the query seeds (built by seed_index_kernel, resident
+// in every XCD's L2) rejects most reference seeds before the open-addressing table in HBM/Infinity Cache is touched.
+// Preconditions (checked by the host): shape length <= 16, reduction size <= 15.
+__device__ __forceinline__ uint32_t reduce4(uint32_t letter, uint64_t map_lo, uint64_t map_hi)
+{
+	const uint64_t m = (letter & 16) ? map_hi : map_lo;
+	return (uint32_t)(m >> ((letter & 15) * 4)) & 15u;
+}
+template<bool RADIX10>
+__global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int sid, uint64_t map_lo, uint64_t map_hi, int64_t base, int lo_digits, uint32_t lo_scale)
+{
+	const int64_t p0 = base + ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+	if (p0 >= a.t_end) return;
+	const uint4 v0 = *reinterpret_cast<const uint4*>(a.tdata + p0);
+	const uint4 v1 = *reinterpret_cast<const uint4*>(a.tdata + p0 + 16);
+	const uint32_t w[8] = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };
+	uint64_t codes[2] = { 0, 0 };
+	uint32_t delim = 0, bad = 0;
+#pragma unroll
+	for (int j = 0; j < 32; ++j) {
+		const uint32_t l = (w[j >> 2] >> ((j & 3) * 8)) & LETTER_MASK;
+		const uint32_t c = reduce4(l, map_lo, map_hi);
+		codes[j >> 4] |= (uint64_t)c << ((j & 15) * 4);
+		delim |= (l == L_DELIM ? 1u : 0u) << j;
+		bad |= (c == 15u ? 1u : 0u) << j;
+	}
+	const int len = a.params.shape_len[sid], weight = a.params.shape_weight[sid];
+	const uint32_t care = a.params.shape_mask[sid], span = (1u << len) - 1;      // len <= 16
+	const uint32_t radix = (uint32_t)a.params.reduction_size;
+
+	// The 16 window starts are handled as two batches of 8 (register pressure). Per batch: outer loop over the
+	// (wave-uniform) care positions, inner loop unrolled over the window starts; the seed is kept as
+	// hi * radix^lo_digits + lo in 32-bit accumulators; then the 8 bitmap probes are issued back to back.
+	const int hi_digits = weight - lo_digits;
+	const int64_t first = a.t_begin - p0, last = a.t_end - p0;                 // valid window starts: first <= i < last
+#pragma unroll 1
+	for (int half = 0; half < 2; ++half) {
+		uint32_t hi[8], lo[8];
+#pragma unroll
+		for (int i = 0; i < 8; ++i) { hi[i] = 0; lo[i] = 0; }
+		for (int k = 0; k < weight; ++k) {
+			const int sh = (a.params.shape_pos[sid][k] + 8 * half) * 4;          // uniform, 0..92
+			// low 32 bits of (codes128 >> sh): nibble i = class at window start (8*half + i), care position k
+			const uint32_t win = sh == 0 ? (uint32_t)codes[0]
+				: sh < 64 ? (uint32_t)((codes[0] >> sh) | (codes[1] << (64 - sh))) : (uint32_t)(codes[1] >> (sh - 64));
+			if (k < hi_digits) {
+#pragma unroll
+				for (int i = 0; i < 8; ++i) {
+					const uint32_t c = (win >> (i * 4)) & 15u;
+					hi[i] = RADIX10 ? ((hi[i] << 2) + hi[i]) * 2 + c : hi[i] * radix + c;
+				}
+			}
+			else {
+#pragma unroll
+				for (int i = 0; i < 8; ++i) {
+					const uint32_t c = (win >> (i * 4)) & 15u;
+					lo[i] = RADIX10 ? ((lo[i] << 2) + lo[i]) * 2 + c : lo[i] * radix + c;
+				}
+			}
+		}
+		uint32_t pos_mask = 0;
+		uint32_t word[8];
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {
+			const int w0 = 8 * half + i;
+			const bool ok = w0 >= first && w0 < last && (((delim >> w0) & span) | ((bad >> w0) & care)) == 0;
+			const uint64_t h = seed_hash((uint64_t)hi[i] * lo_scale + lo[i]);
+			const uint32_t bw = ok ? a.bitmap1[(uint32_t)(h >> 10) & a.bitmap1_mask] : 0u;
+			word[i] = (bw >> ((uint32_t)h & 31)) & (bw >> ((uint32_t)(h >> 5) & 31));
+		}
+#pragma unroll
+		for (int i = 0; i < 8; ++i) pos_mask |= (word[i] & 1u) << i;
+		// rare path: level-1 positives -> level-2 bitmap -> table
+		while (pos_mask) {
+			const int i = __builtin_ctz(pos_mask);
+			pos_mask &= pos_mask - 1;
+			uint32_t h_i = 0, l_i = 0;
+#pragma unroll
+			for (int x = 0; x < 8; ++x) if (x == i) { h_i = hi[x]; l_i = lo[x]; }
+			const uint64_t seed = (uint64_t)h_i * lo_scale + l_i;
+			const uint64_t hh = seed_hash(seed);
+			if (!((a.bitmap[(uint32_t)(hh >> 32) & a.bitmap_mask] >> (uint32_t)(hh >> 59)) & 1u)) continue;
+			uint64_t slot = hh & a.slot_mask;
+			bool found = false;
+			for (;;) {
+				const uint64_t kk = a.keys[slot];
+				if (kk == SEED_EMPTY) break;
+				if (kk == seed) { found = true; break; }
+				slot = (slot + 1) & a.slot_mask;
+			}
+			if (!found) continue;
+			a.flags[slot] = SLOT_JOINED;
+			const unsigned long long idx = atomicAdd(a.matched_count, 1ull);
+			if (idx < (unsigned long long)a.matched_cap) {
+				a.matched_slot[idx] = (uint32_t)slot;
+				a.matched_loc[idx] = p0 + 8 * half + i;
+			}
+		}
 	}
 }
 
@@ -128,6 +236,28 @@ hipError_t launch_seed_index(const SeedArgs& a, int sid, hipStream_t st)
 
 hipError_t launch_seed_stream(const SeedArgs& a, int sid, hipStream_t st)
 {
+	const SeedParams& c = a.params;
+	// the seed is accumulated as hi * radix^lo_digits + lo in 32-bit registers
+	int lo_digits = 0;
+	uint64_t scale = 1;
+	while (scale * (uint64_t)c.reduction_size <= 0xffffffffull && lo_digits < c.shape_weight[sid]) { scale *= (uint64_t)c.reduction_size; ++lo_digits; }
+	uint64_t hi_max = 1;
+	for (int i = 0; i < c.shape_weight[sid] - lo_digits; ++i) hi_max *= (uint64_t)c.reduction_size;
+	if (c.shape_len[sid] <= 16 && c.reduction_size <= 15 && hi_max <= 0xffffffffull) {
+		// 4-bit class map: 15 = invalid (X, '*'); every other letter code -> its reduced class
+		uint64_t lo = 0, hi = 0;
+		for (int l = 0; l < 32; ++l) {
+			const uint64_t code = c.reduction[l] == L_MASK ? 15u : (uint64_t)c.reduction[l];
+			(l < 16 ? lo : hi) |= code << ((l & 15) * 4);
+		}
+		const int64_t base = a.t_begin & ~(int64_t)15;
+		const int64_t threads = (a.t_end - base + 15) / 16;
+		if (c.reduction_size == 10)
+			hipLaunchKernelGGL(seed_stream_fast_kernel<true>, dim3(blocks_for(threads, 256)), dim3(256), 0, st, a, sid, lo, hi, base, lo_digits, (uint32_t)scale);
+		else
+			hipLaunchKernelGGL(seed_stream_fast_kernel<false>, dim3(blocks_for(threads, 256)), dim3(256), 0, st, a, sid, lo, hi, base, lo_digits, (uint32_t)scale);
+		return hipGetLastError();
+	}
 	hipLaunchKernelGGL(seed_stream_kernel, dim3(blocks_for(a.t_end - a.t_begin, 256)), dim3(256), 0, st, a, sid);
 	return hipGetLastError();
 }
