@@ -4,7 +4,7 @@
 # and the test-only helpers: oracle/_ref/* (CPU restatement + reference build), tests/emu/libswipe_emu.so
 HIPCC   ?= /opt/rocm/bin/hipcc
 CSRC    := diamond_amd/csrc
-HIPSRC  := $(CSRC)/api.hip $(CSRC)/swipe_kernels.hip $(CSRC)/seed_api.hip $(CSRC)/seed_kernels.hip
+HIPSRC  := $(CSRC)/api.hip $(CSRC)/swipe_kernels.hip $(CSRC)/seed_api.hip $(CSRC)/seed_kernels.hip $(CSRC)/extend_host.hip
 HIPHDR  := $(wildcard $(CSRC)/*.h) include/diamond_hip.h
 HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function
 

@@ -38,6 +38,15 @@ class SeedParams(ctypes.Structure):
 
 SEED_HIT_DTYPE = np.dtype([("query", "<u4"), ("seed_offset", "<i4"), ("subject", "<i8"), ("score", "<i4"), ("pad", "<i4")])
 
+MATCH_DTYPE = np.dtype([("query", "<u4"), ("target", "<u4"), ("ungapped_score", "<i4"), ("d_begin", "<i4"), ("d_end", "<i4"),
+                        ("pad", "<i4"), ("evalue", "<f8"), ("bit_score", "<f8"),
+                        ("hsp", [("score", "<i4"), ("q_begin", "<i4"), ("q_end", "<i4"), ("s_begin", "<i4"), ("s_end", "<i4"),
+                                 ("length", "<i4"), ("identities", "<i4"), ("mismatches", "<i4"), ("positives", "<i4"),
+                                 ("gap_openings", "<i4"), ("gaps", "<i4"), ("transcript_len", "<i4"), ("transcript_off", "<i8")])])
+assert MATCH_DTYPE.itemsize == 96
+
+PLAN_DTYPE = np.dtype([("query", "<u4"), ("target", "<u4"), ("d_begin", "<i4"), ("d_end", "<i4"), ("ungapped_score", "<i4")])
+
 DP_TARGET_DTYPE = np.dtype([("query_off", "<i8"), ("target_off", "<i8"), ("cbs_off", "<i8"), ("query_len", "<i4"),
                             ("target_len", "<i4"), ("d_begin", "<i4"), ("d_end", "<i4")], align=True)
 HSP_DTYPE = np.dtype([("score", "<i4"), ("q_begin", "<i4"), ("q_end", "<i4"), ("s_begin", "<i4"), ("s_end", "<i4"),
@@ -53,7 +62,7 @@ EXPORTS = ["dmnd_abi_version", "dmnd_last_error", "dmnd_default_params", "dmnd_c
            "dmnd_set_db_letters", "dmnd_upload_block", "dmnd_upload_cbs", "dmnd_banded_swipe",
            "dmnd_banded_swipe_host", "dmnd_banded_cols", "dmnd_evalue", "dmnd_bitscore", "dmnd_evalue_p",
            "dmnd_bitscore_p", "dmnd_evalue_batch", "dmnd_last_kernel_ms", "dmnd_seed_params_fast", "dmnd_seed_search",
-           "dmnd_seed_hits", "dmnd_seed_kernel_ms"]
+           "dmnd_seed_hits", "dmnd_seed_kernel_ms", "dmnd_extend_plan", "dmnd_extend", "dmnd_format_tab"]
 
 
 def load():
@@ -88,6 +97,7 @@ def load():
         lib.dmnd_seed_search.argtypes = [ctypes.c_void_p, ctypes.POINTER(SeedParams), ctypes.POINTER(ctypes.c_int64)]
         lib.dmnd_seed_hits.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
         lib.dmnd_seed_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
+        lib.dmnd_format_tab.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int64]
         lib.dmnd_last_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
         _lib = lib
     return _lib
@@ -122,6 +132,42 @@ def seed_params_fast(threads=1):
     if rc != 0:
         raise DiamondHipError(load().dmnd_last_error().decode())
     return p
+
+
+def extend_plan(params, qdata, qlimits, tdata, tlimits, hits, threads=1):
+    """Host-only: (Hauser int8 bias parallel to qdata, round-1 DpTargets) for seed hits sorted by query."""
+    lib = load()
+    qd = np.ascontiguousarray(qdata, dtype=np.int8)
+    td = np.ascontiguousarray(tdata, dtype=np.int8)
+    ql = np.ascontiguousarray(qlimits, dtype=np.int64)
+    tl = np.ascontiguousarray(tlimits, dtype=np.int64)
+    hits = np.ascontiguousarray(hits, dtype=SEED_HIT_DTYPE)
+    cbs = np.zeros(qd.size, np.int8)
+    cap = max(1024, 4 * hits.size)
+    out = np.zeros(cap, dtype=PLAN_DTYPE)
+    n = ctypes.c_int64(0)
+    v = ctypes.c_void_p
+    rc = lib.dmnd_extend_plan(ctypes.byref(params), qd.ctypes.data_as(v), ql.ctypes.data_as(v), ctypes.c_int64(ql.size - 1),
+                              td.ctypes.data_as(v), tl.ctypes.data_as(v), ctypes.c_int64(tl.size - 1),
+                              hits.ctypes.data_as(v), ctypes.c_int64(hits.size), int(threads), cbs.ctypes.data_as(v),
+                              out.ctypes.data_as(v), ctypes.c_int64(cap), ctypes.byref(n))
+    if rc != 0:
+        raise DiamondHipError(lib.dmnd_last_error().decode())
+    return cbs, out[:n.value].copy()
+
+
+def format_tab(matches, qids, tids):
+    """BLAST tabular text (-f 6 default columns) of match records, as the reference prints it."""
+    lib = load()
+    buf = ctypes.create_string_buffer(4096)
+    out = []
+    for m in matches:
+        rec = np.ascontiguousarray(m)
+        n = lib.dmnd_format_tab(rec.ctypes.data_as(ctypes.c_void_p), qids[int(m["query"])].encode(), tids[int(m["target"])].encode(), buf, 4096)
+        if n < 0:
+            raise DiamondHipError(lib.dmnd_last_error().decode())
+        out.append(buf.raw[:n].decode())
+    return "".join(out)
 
 
 def matrix_of(p):
@@ -213,6 +259,23 @@ class Context:
         ms = (ctypes.c_double * 5)()
         self._check(self.lib.dmnd_seed_kernel_ms(self.h, ms))
         return list(ms)
+
+    def extend(self, qdata, tdata, hits, threads=8, hsp_values=510, with_transcripts=False):
+        """Extension::extend for every query of the block (hits sorted by query). Returns (matches, transcripts|None)."""
+        qd = np.ascontiguousarray(qdata, dtype=np.int8)
+        td = np.ascontiguousarray(tdata, dtype=np.int8)
+        hits = np.ascontiguousarray(hits, dtype=SEED_HIT_DTYPE)
+        cap = max(1024, hits.size)
+        out = np.zeros(cap, dtype=MATCH_DTYPE)
+        n, used = ctypes.c_int64(0), ctypes.c_int64(0)
+        tr = np.zeros(max(1 << 20, 64 * hits.size) if with_transcripts else 0, np.uint8)
+        v = ctypes.c_void_p
+        self._check(self.lib.dmnd_extend(self.h, qd.ctypes.data_as(v), td.ctypes.data_as(v), hits.ctypes.data_as(v),
+                                         ctypes.c_int64(hits.size), int(threads), ctypes.c_uint32(hsp_values),
+                                         out.ctypes.data_as(v), ctypes.c_int64(cap), ctypes.byref(n),
+                                         tr.ctypes.data_as(v) if with_transcripts else None, ctypes.c_int64(tr.size),
+                                         ctypes.byref(used)))
+        return out[:n.value].copy(), (tr[:used.value] if with_transcripts else None)
 
     def last_kernel_ms(self):
         a, b = ctypes.c_double(0), ctypes.c_double(0)

@@ -196,6 +196,38 @@ int dmnd_seed_hits(dmnd_ctx* ctx, dmnd_seed_hit* out, int64_t cap);
 /* device milliseconds of the last dmnd_seed_search: [0] index queries [1] stream reference [2] mask [3] pair filter [4] total */
 int dmnd_seed_kernel_ms(const dmnd_ctx* ctx, double ms[5]);
 
+/* -- extension stage: replaces Extension::extend for every query of a block (src/align/extend.cpp:226-420;
+ *    called per query from align_worker, src/align/align.cpp:157) as one block-wide batch ---------------------- */
+/* One round-1 DpTarget as the extension stage builds it from seed hits (x-drop ungapped extension, chaining,
+ * Extension::band, add_dp_targets: src/align/ungapped.cpp:62, chaining/greedy_align.cpp:482, align/gapped_score.cpp:107) */
+typedef struct {
+	uint32_t query, target;       /* block ids */
+	int32_t d_begin, d_end;
+	int32_t ungapped_score;       /* WorkTarget::ungapped_score = max stage-1 score of the target's seed hits */
+} dmnd_plan_target;
+
+/* One reported alignment = Extension::Match with its single Hsp (max_hsps = 1), src/align/extend.h:34-66 */
+typedef struct {
+	uint32_t query, target;       /* block ids */
+	int32_t ungapped_score, d_begin, d_end, pad;
+	double evalue, bit_score;
+	dmnd_hsp hsp;
+} dmnd_match;
+
+/* Host-only part (no GPU needed): per-query Hauser composition bias (cbs_out: int8 array parallel to qdata, may be
+ * NULL) and the round-1 DpTargets for seed hits sorted by query. */
+int dmnd_extend_plan(const dmnd_params* params, const int8_t* qdata, const int64_t* qlimits, int64_t nq,
+	const int8_t* tdata, const int64_t* tlimits, int64_t nt, const dmnd_seed_hit* hits, int64_t n_hits, int threads,
+	int8_t* cbs_out, dmnd_plan_target* out, int64_t cap, int64_t* n_out);
+/* Whole extension stage on the uploaded blocks (qdata/tdata: the caller's host copies of the same blocks). hits must be
+ * sorted by query. Matches come out ordered by query, then as the reference orders them (e-value, score, target).
+ * transcript may be NULL (then dmnd_hsp::transcript_off = -1). Blastp defaults: max_target_seqs 25, max_hsps 1. */
+int dmnd_extend(dmnd_ctx* ctx, const int8_t* qdata, const int8_t* tdata, const dmnd_seed_hit* hits, int64_t n_hits,
+	int threads, uint32_t hsp_values, dmnd_match* out, int64_t cap, int64_t* n_out,
+	uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used);
+/* BLAST tabular (-f 6 default fields) line of one match, as the reference prints it; returns the length written. */
+int dmnd_format_tab(const dmnd_match* m, const char* qseqid, const char* sseqid, char* buf, int64_t cap);
+
 /* -- timing hooks for bench.py: device time of the DP kernels of the last dmnd_banded_swipe call,
  *    measured with HIP events on the stream the kernels ran on ------------------------------------ */
 int dmnd_last_kernel_ms(const dmnd_ctx* ctx, double* swipe_ms, double* traceback_ms);

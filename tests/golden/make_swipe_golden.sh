@@ -53,7 +53,9 @@ db, do, q, qo = synth.generate(250, members=10, queries=300, seed=1)
 synth.write_fasta(sys.argv[1] + "/s_db.faa", "t", db, do)
 synth.write_fasta(sys.argv[1] + "/s_q.faa", "q", q, qo)
 PY
-DIAMOND_TAP_EXT="$HERE/ext_fast_synth.tap" \
-  "$TAP" blastp --fast --masking 0 --motif-masking 0 --algo 0 -q "$TMP/s_q.faa" -d "$TMP/s_db.faa" -o "$TMP/e2.out" -p4 2>/dev/null
+# both seams in one run: the same queries' seed hits, DpTargets (= band geometry from chaining) and Match lists;
+# the reference's TSV output is kept as the end-to-end golden
+DIAMOND_TAP_EXT="$HERE/ext_fast_synth.tap" DIAMOND_TAP_FILE="$HERE/swipe_fast_synth.tap" \
+  "$TAP" blastp --fast --masking 0 --motif-masking 0 --algo 0 -q "$TMP/s_q.faa" -d "$TMP/s_db.faa" -o "$HERE/fast_synth.tsv" -p4 2>/dev/null
 ls -la "$HERE"/*.tap
 rm -rf "$TMP"
