@@ -97,6 +97,9 @@ def load():
         lib.dmnd_seed_search.argtypes = [ctypes.c_void_p, ctypes.POINTER(SeedParams), ctypes.POINTER(ctypes.c_int64)]
         lib.dmnd_seed_hits.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
         lib.dmnd_seed_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
+        v = ctypes.c_void_p
+        lib.dmnd_extend.argtypes = [v, v, v, v, ctypes.c_int64, ctypes.c_int, ctypes.c_uint32, v, ctypes.c_int64,
+                                    ctypes.POINTER(ctypes.c_int64), v, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
         lib.dmnd_format_tab.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int64]
         lib.dmnd_last_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
         _lib = lib

@@ -41,7 +41,7 @@ def test_matches_equal_reference_extend(ctx, tap):
     m = _run(ctx, cfg, db_letters)
     pos = 0
     n = 0
-    for r in recs:
+    for r in sorted(recs, key=lambda x: x["query_id"]):          # tap records are in call order of the reference's worker threads
         for ref in r["matches"]:
             assert pos < len(m)
             got = m[pos]
