@@ -47,4 +47,6 @@ struct dmnd_ctx {
 	dmnd::DevBuf qid_of, mask_time, seed_keys, seed_heads, seed_next, seed_flags, matched_slot, matched_loc, counters, seed_hits, seed_bitmap;
 	int64_t n_seed_hits = 0;
 	double seed_ms[5] = { 0, 0, 0, 0, 0 };
+	// extension-stage statistics of the last dmnd_extend (extend_host.hip)
+	double ext_stats[12] = { 0 };
 };

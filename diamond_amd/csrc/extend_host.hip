@@ -20,6 +20,7 @@
 // no id/coverage filters, single ranking chunk (a query with more targets than the ranking chunk fails loudly).
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -283,13 +284,24 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	make_cfg(c, h);
 	h.ref_letters = (double)(tl.back() - tl.front() - ((int64_t)tl.size() - 1));
 	if (hsp_values == 0) hsp_values = 510;
+	for (double& x : c->ext_stats) x = 0;
+	auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	auto cells_of = [](const std::vector<dmnd_dp_target>& v) {
+		double s = 0;
+		for (const auto& d : v) s += (double)dmnd_banded_cols(d.query_len, d.target_len, d.d_begin, d.d_end) * (double)(d.d_end - d.d_begin);
+		return s;
+	};
+	const double t0 = now();
 	// 1. Hauser bias for every query, resident next to the query block
 	std::vector<int8_t> cbs;
 	all_hauser(h, threads, qdata, ql, cbs);
 	if (int rc = dmnd_upload_cbs(c, cbs.data(), ql.back())) return rc;
+	const double t1 = now();
 	// 2. plan
 	std::vector<PlanTarget> plan;
 	if (int rc = plan_all(h, threads, hits, n_hits, qdata, ql, tdata, tl, cbs.data(), plan)) return rc;
+	const double t2 = now();
+	c->ext_stats[4] = t1 - t0; c->ext_stats[5] = t2 - t1;
 	if (plan.empty()) return DMND_OK;
 	// 3. round 1: score only
 	std::vector<dmnd_dp_target> items(plan.size());
@@ -301,6 +313,8 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	std::vector<dmnd_hsp> r1(plan.size());
 	if (int rc = dmnd_banded_swipe(c, items.data(), (int64_t)items.size(), DMND_SWIPE_SCORE, 0, r1.data(), nullptr, 0, nullptr)) return rc;
 	const double sw1 = c->swipe_ms;
+	const double t3 = now();
+	c->ext_stats[0] = (double)items.size(); c->ext_stats[2] = cells_of(items); c->ext_stats[6] = t3 - t2; c->ext_stats[9] = sw1;
 	// 4. per query: report cutoff, best HSP per target (Target::add_hit + inner_culling with max_hsps = 1), top-k culling
 	std::vector<Cand> survivors;
 	std::vector<uint32_t> surv_query;
@@ -332,6 +346,8 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 		for (const Cand& k : cands) { survivors.push_back(k); surv_query.push_back(plan[i].query); }
 		i = j;
 	}
+	const double t4 = now();
+	c->ext_stats[7] = t4 - t3;
 	if (survivors.empty()) return DMND_OK;
 	// 5. round 2: traceback for DP sizes <= max_swipe_dp, statistics passes above (DP::BandedSwipe::bin)
 	std::vector<dmnd_dp_target> it_tb, it_st;
@@ -370,6 +386,9 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 		sw2 += c->swipe_ms;
 	}
 	c->swipe_ms = sw1 + sw2; c->traceback_ms = tb2;
+	const double t5 = now();
+	c->ext_stats[1] = (double)survivors.size(); c->ext_stats[3] = cells_of(it_tb) + cells_of(it_st); c->ext_stats[8] = t5 - t4;
+	c->ext_stats[10] = sw2; c->ext_stats[11] = tb2;
 	if (transcript_used) *transcript_used = transcript ? used : 0;
 	// 6. final per-query culling (Match::cmp_evalue + output_range) -> records
 	int64_t n = 0;
@@ -405,6 +424,16 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	}
 	*n_out = n;
 	if (n > cap) return fail(DMND_E_CAP, "dmnd_extend: match buffer too small");
+	return DMND_OK;
+}
+
+// [0] round-1 DpTargets [1] round-2 DpTargets [2] round-1 cells [3] round-2 cells (DpTarget::cells, dp/dp.h:121-124)
+// host wall ms: [4] Hauser+upload [5] chaining/plan [6] round-1 call [7] culling [8] round-2 call
+// device ms: [9] round-1 swipe kernels [10] round-2 swipe kernels [11] traceback kernel
+extern "C" int dmnd_extend_stats(const dmnd_ctx* c, double out[12])
+{
+	if (!c || !out) return fail(DMND_E_ARG, "dmnd_extend_stats: NULL argument");
+	for (int i = 0; i < 12; ++i) out[i] = c->ext_stats[i];
 	return DMND_OK;
 }
 

@@ -62,7 +62,7 @@ EXPORTS = ["dmnd_abi_version", "dmnd_last_error", "dmnd_default_params", "dmnd_c
            "dmnd_set_db_letters", "dmnd_upload_block", "dmnd_upload_cbs", "dmnd_banded_swipe",
            "dmnd_banded_swipe_host", "dmnd_banded_cols", "dmnd_evalue", "dmnd_bitscore", "dmnd_evalue_p",
            "dmnd_bitscore_p", "dmnd_evalue_batch", "dmnd_last_kernel_ms", "dmnd_seed_params_fast", "dmnd_seed_search",
-           "dmnd_seed_hits", "dmnd_seed_kernel_ms", "dmnd_extend_plan", "dmnd_extend", "dmnd_format_tab"]
+           "dmnd_seed_hits", "dmnd_seed_kernel_ms", "dmnd_extend_plan", "dmnd_extend", "dmnd_extend_stats", "dmnd_format_tab"]
 
 
 def load():
@@ -279,6 +279,15 @@ class Context:
                                          tr.ctypes.data_as(v) if with_transcripts else None, ctypes.c_int64(tr.size),
                                          ctypes.byref(used)))
         return out[:n.value].copy(), (tr[:used.value] if with_transcripts else None)
+
+    def extend_stats(self):
+        st = (ctypes.c_double * 12)()
+        self.lib.dmnd_extend_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
+        self._check(self.lib.dmnd_extend_stats(self.h, st))
+        keys = ["round1_targets", "round2_targets", "round1_cells", "round2_cells", "host_hauser_ms", "host_chaining_ms",
+                "round1_call_ms", "host_culling_ms", "round2_call_ms", "round1_swipe_kernel_ms", "round2_swipe_kernel_ms",
+                "traceback_kernel_ms"]
+        return dict(zip(keys, list(st)))
 
     def last_kernel_ms(self):
         a, b = ctypes.c_double(0), ctypes.c_double(0)

@@ -225,6 +225,10 @@ int dmnd_extend_plan(const dmnd_params* params, const int8_t* qdata, const int64
 int dmnd_extend(dmnd_ctx* ctx, const int8_t* qdata, const int8_t* tdata, const dmnd_seed_hit* hits, int64_t n_hits,
 	int threads, uint32_t hsp_values, dmnd_match* out, int64_t cap, int64_t* n_out,
 	uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used);
+/* Statistics of the last dmnd_extend: [0] round-1 DpTargets [1] round-2 DpTargets [2] round-1 cells [3] round-2 cells
+ * (DpTarget::cells, src/dp/dp.h:121-124: the GCUPS denominator); host wall ms [4] Hauser+upload [5] chaining [6] round-1
+ * call [7] culling [8] round-2 call; device ms [9] round-1 swipe [10] round-2 swipe [11] traceback. */
+int dmnd_extend_stats(const dmnd_ctx* ctx, double out[12]);
 /* BLAST tabular (-f 6 default fields) line of one match, as the reference prints it; returns the length written. */
 int dmnd_format_tab(const dmnd_match* m, const char* qseqid, const char* sseqid, char* buf, int64_t cap);
 
