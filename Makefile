@@ -11,10 +11,14 @@ HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-functio
 .PHONY: all product oracle emu clean
 all: product oracle emu
 
-product: diamond_amd/libdiamond_hip.so diamond_amd/libdmnd_synth.so
+product: diamond_amd/libdiamond_hip.so diamond_amd/libdmnd_synth.so diamond_amd/diamond-hip
 
 diamond_amd/libdiamond_hip.so: $(HIPSRC) $(HIPHDR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIPSRC)
+
+# the CLI (makedb / blastp) over the C ABI; finds the library next to itself
+diamond_amd/diamond-hip: $(CSRC)/cli.cpp include/diamond_hip.h diamond_amd/libdiamond_hip.so
+	g++ -O2 -std=c++17 -Wall -o $@ $(CSRC)/cli.cpp -Ldiamond_amd -ldiamond_hip -Wl,-rpath,'$$ORIGIN'
 
 diamond_amd/libdmnd_synth.so: $(CSRC)/synth.c
 	gcc -O2 -fPIC -shared -std=c11 -Wall -o $@ $< -lm
@@ -27,5 +31,5 @@ tests/emu/libswipe_emu.so: tests/emu/swipe_emu.cpp tests/emu/seed_emu.cpp $(CSRC
 	g++ -O2 -std=c++17 -fPIC -shared -w -o $@ tests/emu/swipe_emu.cpp tests/emu/seed_emu.cpp
 
 clean:
-	rm -f diamond_amd/*.so tests/emu/*.so
+	rm -f diamond_amd/*.so diamond_amd/diamond-hip tests/emu/*.so
 	$(MAKE) -C oracle clean

@@ -1,0 +1,302 @@
+// cli.cpp -- `diamond-hip`: the reference's command line for the hot path (makedb / blastp) on top of the C ABI in
+// include/diamond_hip.h. Host I/O only (FASTA and .dmnd in, BLAST tabular out); every alignment step runs through
+// libdiamond_hip.so on the MI355X.
+// Mirrors: option names of src/basic/config.cpp:217-345, the FASTA reader's letter mapping (src/basic/value.cpp:25-47,
+// amino-acid alphabet "ARNDCQEGHILKMFPSTWYVBJZX*_", U/O/- -> X), the .dmnd layout (src/legacy/dmnd/dmnd.cpp:50-117,224-340:
+// ReferenceHeader 40 bytes, ReferenceHeader2 as a size-prefixed record, per sequence 0xFF letters 0xFF id 0, trailer of
+// (pos u64, len u32, pad u32) records), SequenceSet layout (src/data/string_set.h:27-60), tabular output
+// (src/output/blast_tab_format.cpp, sequence ids cut at the first blank).
+// Supported: blastp --fast with masking off (tantan/SEG/motif masking are host pre-processing that is not restated yet:
+// the tool insists on --masking 0 semantics and says so), -e, -k, -p, -f 6 default columns.
+#include <algorithm>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../../include/diamond_hip.h"
+
+namespace {
+
+struct SeqBlock {
+	std::vector<int8_t> data;        // SequenceSet layout
+	std::vector<int64_t> limits;
+	std::vector<std::string> ids;
+	int64_t letters = 0;
+	void begin() { data.assign(256, 31); limits.assign(1, 256); }
+	void push(const std::vector<int8_t>& s, const std::string& id)
+	{
+		data.insert(data.end(), s.begin(), s.end());
+		data.push_back(31);
+		limits.push_back((int64_t)data.size());
+		ids.push_back(id);
+		letters += (int64_t)s.size();
+	}
+	void finish() { data.insert(data.end(), 256, 31); }
+};
+
+int8_t letter_of(char c)
+{
+	static int8_t map[256];
+	static bool init = false;
+	if (!init) {
+		std::memset(map, -1, sizeof map);
+		const char* alpha = "ARNDCQEGHILKMFPSTWYVBJZX*_";
+		for (int i = 0; alpha[i]; ++i) { map[(unsigned char)alpha[i]] = (int8_t)i; map[(unsigned char)std::tolower(alpha[i])] = (int8_t)i; }
+		for (const char* m = "UO-"; *m; ++m) { map[(unsigned char)*m] = 23; map[(unsigned char)std::tolower(*m)] = 23; }
+		init = true;
+	}
+	return map[(unsigned char)c];
+}
+
+std::string short_id(const std::string& title)
+{
+	const size_t e = title.find_first_of(" \t");
+	return e == std::string::npos ? title : title.substr(0, e);
+}
+
+void read_fasta(const std::string& path, SeqBlock& b)
+{
+	std::ifstream f(path);
+	if (!f) throw std::runtime_error("Error opening file " + path);
+	b.begin();
+	std::string line, id;
+	std::vector<int8_t> seq;
+	bool have = false;
+	auto flush = [&] {
+		if (!have) return;
+		if (seq.empty()) throw std::runtime_error("File format error: sequence of length 0");
+		b.push(seq, id);
+		seq.clear();
+	};
+	while (std::getline(f, line)) {
+		if (!line.empty() && line.back() == '\r') line.pop_back();
+		if (line.empty()) continue;
+		if (line[0] == '>') { flush(); id = line.substr(1); have = true; continue; }
+		if (!have) throw std::runtime_error("FASTA format error: missing '>' in " + path);
+		for (char c : line) {
+			if (c == ' ' || c == '\t') continue;
+			const int8_t l = letter_of(c);
+			if (l < 0) throw std::runtime_error(std::string("Invalid character (") + c + ") in sequence " + id);
+			seq.push_back(l);
+		}
+	}
+	flush();
+	b.finish();
+}
+
+const uint64_t DMND_MAGIC = 0x24af8a415ee186dULL;
+
+bool is_dmnd(const std::string& path)
+{
+	std::ifstream f(path, std::ios::binary);
+	uint64_t m = 0;
+	f.read((char*)&m, 8);
+	return f && m == DMND_MAGIC;
+}
+
+void read_dmnd(const std::string& path, SeqBlock& b)
+{
+	std::ifstream f(path, std::ios::binary);
+	if (!f) throw std::runtime_error("Error opening file " + path);
+	uint64_t magic, sequences, letters, pos_array_offset; uint32_t build, version;
+	f.read((char*)&magic, 8); f.read((char*)&build, 4); f.read((char*)&version, 4);
+	f.read((char*)&sequences, 8); f.read((char*)&letters, 8); f.read((char*)&pos_array_offset, 8);
+	if (!f || magic != DMND_MAGIC) throw std::runtime_error("Database file is not a DIAMOND database.");
+	if (version < 2 || version > 3) throw std::runtime_error("Unsupported DIAMOND database version (protein databases of format 2-3 only).");
+	std::vector<uint64_t> pos(sequences + 1);
+	std::vector<uint32_t> len(sequences + 1);
+	f.seekg((std::streamoff)pos_array_offset);
+	for (uint64_t i = 0; i <= sequences; ++i) { uint32_t pad; f.read((char*)&pos[i], 8); f.read((char*)&len[i], 4); f.read((char*)&pad, 4); }
+	if (!f) throw std::runtime_error("Truncated DIAMOND database.");
+	b.begin();
+	std::vector<int8_t> seq;
+	std::string rec;
+	for (uint64_t i = 0; i < sequences; ++i) {
+		const uint64_t n = pos[i + 1] - pos[i];
+		rec.resize(n);
+		f.seekg((std::streamoff)pos[i]);
+		f.read(&rec[0], (std::streamsize)n);
+		// 0xFF letters 0xFF id 0
+		seq.assign(rec.begin() + 1, rec.begin() + 1 + len[i]);
+		// the reference's makedb stores its SEG soft mask in bit 7 (src/legacy/dmnd/dmnd.cpp:262-265); with masking off
+		// the search ignores it (Sequence::operator[] & LETTER_MASK), so it is dropped at load time
+		for (int8_t& l : seq) l &= 31;
+		const char* id = rec.data() + len[i] + 2;
+		b.push(seq, std::string(id));
+	}
+	b.finish();
+}
+
+void write_dmnd(const std::string& path, const SeqBlock& b)
+{
+	std::string out = path;
+	if (out.size() < 5 || out.substr(out.size() - 5) != ".dmnd") out += ".dmnd";
+	std::ofstream f(out, std::ios::binary);
+	if (!f) throw std::runtime_error("Error opening file " + out);
+	const uint64_t n = b.ids.size();
+	uint64_t magic = DMND_MAGIC, sequences = n, letters = (uint64_t)b.letters, pos_array_offset = 0;
+	uint32_t build = 182, version = 3;
+	auto header = [&] {
+		f.seekp(0);
+		f.write((char*)&magic, 8); f.write((char*)&build, 4); f.write((char*)&version, 4);
+		f.write((char*)&sequences, 8); f.write((char*)&letters, 8); f.write((char*)&pos_array_offset, 8);
+	};
+	header();
+	const uint64_t h2size = 48, zero = 0;
+	f.write((char*)&h2size, 8);
+	char hash[16] = { 0 };
+	f.write(hash, 16);
+	for (int i = 0; i < 4; ++i) f.write((char*)&zero, 8);
+	uint64_t offset = (uint64_t)f.tellp();
+	std::vector<uint64_t> pos;
+	const char ff = (char)0xff;
+	for (uint64_t i = 0; i < n; ++i) {
+		const int64_t len = b.limits[i + 1] - b.limits[i] - 1;
+		pos.push_back(offset);
+		f.write(&ff, 1);
+		f.write((const char*)b.data.data() + b.limits[i], len);
+		f.write(&ff, 1);
+		f.write(b.ids[i].c_str(), (std::streamsize)b.ids[i].size() + 1);
+		offset += (uint64_t)len + b.ids[i].size() + 3;
+	}
+	pos_array_offset = offset;
+	pos.push_back(offset);
+	for (uint64_t i = 0; i <= n; ++i) {
+		const uint32_t len = i < n ? (uint32_t)(b.limits[i + 1] - b.limits[i] - 1) : 0, pad = 0;
+		f.write((char*)&pos[i], 8); f.write((char*)&len, 4); f.write((char*)&pad, 4);
+	}
+	header();
+	std::cerr << "Database sequences  " << n << "\nDatabase letters  " << b.letters << "\n";
+}
+
+struct Options {
+	std::string command, query, db, out, in;
+	int threads = 0, k = 25;
+	double evalue = 0.001;
+	bool fast = false;
+	std::string masking = "", motif_masking = "", sens = "";
+};
+
+Options parse(int argc, char** argv)
+{
+	Options o;
+	if (argc < 2) { o.command = "help"; return o; }
+	o.command = argv[1];
+	auto need = [&](int& i) -> std::string { if (i + 1 >= argc) throw std::runtime_error(std::string("Missing parameter for option ") + argv[i]); return argv[++i]; };
+	for (int i = 2; i < argc; ++i) {
+		const std::string a = argv[i];
+		if (a == "-q" || a == "--query") o.query = need(i);
+		else if (a == "-d" || a == "--db") o.db = need(i);
+		else if (a == "-o" || a == "--out") o.out = need(i);
+		else if (a == "--in") o.in = need(i);
+		else if (a == "-p" || a == "--threads") o.threads = std::atoi(need(i).c_str());
+		else if (a == "-k" || a == "--max-target-seqs") o.k = std::atoi(need(i).c_str());
+		else if (a == "-e" || a == "--evalue") o.evalue = std::atof(need(i).c_str());
+		else if (a == "--fast") o.fast = true;
+		else if (a == "--masking") o.masking = need(i);
+		else if (a == "--motif-masking") o.motif_masking = need(i);
+		else if (a == "--algo") { if (need(i) != "0") throw std::runtime_error("Only --algo 0 (double-indexed) is implemented."); }
+		else if (a == "-f" || a == "--outfmt") { if (need(i) != "6") throw std::runtime_error("Only output format 6 (BLAST tabular, default columns) is implemented."); }
+		else if (a == "--faster" || a == "--mid-sensitive" || a == "--sensitive" || a == "--more-sensitive" || a == "--very-sensitive" || a == "--ultra-sensitive")
+			o.sens = a;
+		else if (a == "--quiet" || a == "--log" || a == "-v" || a == "--verbose") {}
+		else throw std::runtime_error("Invalid option: " + a);
+	}
+	return o;
+}
+
+double ms_since(std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); }
+
+int run_blastp(const Options& o)
+{
+	if (o.query.empty() || o.db.empty()) throw std::runtime_error("Missing parameter: query (--query/-q) and database (--db/-d) are required.");
+	if (!o.fast || !o.sens.empty())
+		throw std::runtime_error("This build implements the --fast sensitivity only (default/sensitive modes need the ungapped and gapped filters, SURVEY.md 8 rows a7/a11).");
+	if (o.masking != "0" || (o.motif_masking != "0" && !o.motif_masking.empty()))
+		std::cerr << "Warning: repeat masking (tantan / motif) is not implemented; running as --masking 0 --motif-masking 0.\n";
+	const auto t_all = std::chrono::steady_clock::now();
+	SeqBlock q, t;
+	auto t0 = std::chrono::steady_clock::now();
+	read_fasta(o.query, q);
+	std::string dbpath = o.db;
+	if (!std::ifstream(dbpath).good() && std::ifstream(dbpath + ".dmnd").good()) dbpath += ".dmnd";
+	if (is_dmnd(dbpath)) read_dmnd(dbpath, t); else read_fasta(dbpath, t);
+	std::cerr << "Loading sequences...  [" << ms_since(t0) / 1e3 << "s]  queries=" << q.ids.size() << " targets=" << t.ids.size() << " letters=" << t.letters << "\n";
+	dmnd_params p;
+	dmnd_default_params(&p);
+	p.db_letters = (double)t.letters;
+	p.max_evalue = o.evalue;
+	dmnd_ctx* ctx = dmnd_create(-1, &p);
+	if (!ctx) throw std::runtime_error(dmnd_last_error());
+	auto chk = [&](int rc) { if (rc != DMND_OK) throw std::runtime_error(dmnd_last_error()); };
+	chk(dmnd_set_max_target_seqs(ctx, o.k));
+	t0 = std::chrono::steady_clock::now();
+	chk(dmnd_upload_block(ctx, DMND_QUERY, q.data.data(), (int64_t)q.data.size(), q.limits.data(), (int64_t)q.ids.size()));
+	chk(dmnd_upload_block(ctx, DMND_TARGET, t.data.data(), (int64_t)t.data.size(), t.limits.data(), (int64_t)t.ids.size()));
+	std::cerr << "Uploading blocks to HBM...  [" << ms_since(t0) / 1e3 << "s]\n";
+	const int threads = o.threads > 0 ? o.threads : 8;
+	dmnd_seed_params sp;
+	chk(dmnd_seed_params_fast(&sp, threads));
+	t0 = std::chrono::steady_clock::now();
+	int64_t n_hits = 0;
+	chk(dmnd_seed_search(ctx, &sp, &n_hits));
+	std::vector<dmnd_seed_hit> hits((size_t)n_hits);
+	chk(dmnd_seed_hits(ctx, hits.data(), n_hits));
+	std::cerr << "Searching alignments (seed stage)...  [" << ms_since(t0) / 1e3 << "s]  hits=" << n_hits << "\n";
+	t0 = std::chrono::steady_clock::now();
+	std::vector<dmnd_match> matches((size_t)std::max<int64_t>(n_hits, 1));
+	int64_t n_matches = 0;
+	chk(dmnd_extend(ctx, q.data.data(), t.data.data(), hits.data(), n_hits, threads, 0, matches.data(), (int64_t)matches.size(), &n_matches, nullptr, 0, nullptr));
+	std::cerr << "Computing alignments (extension stage)...  [" << ms_since(t0) / 1e3 << "s]\n";
+	FILE* out = o.out.empty() ? stdout : std::fopen(o.out.c_str(), "w");
+	if (!out) throw std::runtime_error("Error opening file " + o.out);
+	std::vector<std::string> qid(q.ids.size()), tid(t.ids.size());
+	for (size_t i = 0; i < qid.size(); ++i) qid[i] = short_id(q.ids[i]);
+	for (size_t i = 0; i < tid.size(); ++i) tid[i] = short_id(t.ids[i]);
+	char line[8192];
+	int64_t aligned = 0;
+	for (int64_t i = 0; i < n_matches; ++i) {
+		const int w = dmnd_format_tab(&matches[(size_t)i], qid[matches[(size_t)i].query].c_str(), tid[matches[(size_t)i].target].c_str(), line, sizeof line);
+		if (w < 0) throw std::runtime_error(dmnd_last_error());
+		std::fwrite(line, 1, (size_t)w, out);
+		if (i == 0 || matches[(size_t)i].query != matches[(size_t)i - 1].query) ++aligned;
+	}
+	if (out != stdout) std::fclose(out);
+	dmnd_destroy(ctx);
+	std::cerr << "Total time = " << ms_since(t_all) / 1e3 << "s\nReported " << n_matches << " pairwise alignments, " << n_matches << " HSPs.\n" << aligned << " queries aligned.\n";
+	return 0;
+}
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+	try {
+		const Options o = parse(argc, argv);
+		if (o.command == "version") { std::cout << "diamond-hip (MI355X back end of DIAMOND's seed-and-extend path), ABI " << dmnd_abi_version() << "\n"; return 0; }
+		if (o.command == "help" || o.command == "--help") {
+			std::cout << "Syntax: diamond-hip COMMAND [OPTIONS]\n  makedb --in FASTA -d DB        build a .dmnd database (no masking)\n"
+				"  blastp --fast -q FASTA -d DB(.dmnd|FASTA) -o OUT [--masking 0] [-e EVALUE] [-k N] [-p THREADS]\n  version\n";
+			return 0;
+		}
+		if (o.command == "makedb") {
+			if (o.in.empty() || o.db.empty()) throw std::runtime_error("makedb needs --in and -d");
+			SeqBlock b;
+			read_fasta(o.in, b);
+			write_dmnd(o.db, b);
+			return 0;
+		}
+		if (o.command == "blastp") return run_blastp(o);
+		throw std::runtime_error("Invalid command: " + o.command + " (blastx and the other workflows are not part of this build)");
+	}
+	catch (const std::exception& e) {
+		std::cerr << "Error: " << e.what() << std::endl;          // main.cpp:211-232
+		return 1;
+	}
+}

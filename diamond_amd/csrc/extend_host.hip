@@ -282,6 +282,7 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	if (ql.size() < 2 || tl.size() < 2) return fail(DMND_E_ARG, "dmnd_extend: blocks must be uploaded with limits");
 	HostCfg h;
 	make_cfg(c, h);
+	h.max_target_seqs = c->max_target_seqs;
 	h.ref_letters = (double)(tl.back() - tl.front() - ((int64_t)tl.size() - 1));
 	if (hsp_values == 0) hsp_values = 510;
 	for (double& x : c->ext_stats) x = 0;
@@ -424,6 +425,13 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	}
 	*n_out = n;
 	if (n > cap) return fail(DMND_E_CAP, "dmnd_extend: match buffer too small");
+	return DMND_OK;
+}
+
+extern "C" int dmnd_set_max_target_seqs(dmnd_ctx* c, int k)
+{
+	if (!c || k < 1) return fail(DMND_E_ARG, "dmnd_set_max_target_seqs: bad argument");
+	c->max_target_seqs = k;
 	return DMND_OK;
 }
 

@@ -225,6 +225,8 @@ int dmnd_extend_plan(const dmnd_params* params, const int8_t* qdata, const int64
 int dmnd_extend(dmnd_ctx* ctx, const int8_t* qdata, const int8_t* tdata, const dmnd_seed_hit* hits, int64_t n_hits,
 	int threads, uint32_t hsp_values, dmnd_match* out, int64_t cap, int64_t* n_out,
 	uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used);
+/* -k / --max-target-seqs (default 25, src/basic/config.h:55) */
+int dmnd_set_max_target_seqs(dmnd_ctx* ctx, int k);
 /* Statistics of the last dmnd_extend: [0] round-1 DpTargets [1] round-2 DpTargets [2] round-1 cells [3] round-2 cells
  * (DpTarget::cells, src/dp/dp.h:121-124: the GCUPS denominator); host wall ms [4] Hauser+upload [5] chaining [6] round-1
  * call [7] culling [8] round-2 call; device ms [9] round-1 swipe [10] round-2 swipe [11] traceback. */
