@@ -98,44 +98,63 @@ int64_t ranking_chunk_size(double ref_letters, int max_target_seqs)       // ext
 
 struct PlanTarget { uint32_t query, target; int32_t d_begin, d_end, ungapped_score; };
 
-struct QueryPlan {
-	std::vector<PlanTarget> dp;          // round-1 DpTargets of one query, reference order
+// One query's seed hits grouped by target (SeedHitList of load_hits) + its ranking state (extend.cpp:226-344)
+struct TargetGroup { uint32_t target; size_t begin, end; int score; };
+
+struct QueryWork {
+	uint32_t query = 0;
+	std::vector<HostSeedHit> sh;            // seed hits, grouped by target
+	std::vector<TargetGroup> groups;        // in load order (ascending target)
+	std::vector<uint32_t> order;            // ranking order: indices into groups (l.target_scores)
+	int64_t chunk_size = 0;
+	size_t i0 = 0, i1 = 0;                  // current ranking chunk [i0, i1) of `order`
 };
 
-// hits of ONE query -> its round-1 DpTargets
-int plan_query(const HostCfg& h, ChainWorkspace& ws, uint32_t query, const dmnd_seed_hit* hb, const dmnd_seed_hit* he,
-	const int8_t* qdata, const int64_t* ql, const int8_t* tdata, const int64_t* tl, int64_t nt, const int8_t* cbs_all,
-	std::vector<PlanTarget>& out, std::string& err)
+// load_hits (load_hits.h:44-127) + the target ranking of extend() (extend.cpp:403-414)
+void load_query(const HostCfg& h, QueryWork& w, uint32_t query, const dmnd_seed_hit* hb, const dmnd_seed_hit* he, const int64_t* tl, int64_t nt)
 {
 	std::vector<dmnd_seed_hit> hits(hb, he);
 	std::sort(hits.begin(), hits.end(), [](const dmnd_seed_hit& a, const dmnd_seed_hit& b) {       // Hit::CmpSubject
 		return a.subject < b.subject || (a.subject == b.subject && (a.query < b.query || (a.query == b.query && a.seed_offset < b.seed_offset)));
 	});
-	const SeqRef q{ qdata + ql[query], (int)(ql[query + 1] - ql[query] - 1) };
-	const int8_t* cbs = cbs_all ? cbs_all + ql[query] : nullptr;
-	// group by target (load_hits)
-	struct TG { uint32_t target; size_t begin, end; int score; };
-	std::vector<TG> groups;
-	std::vector<HostSeedHit> sh(hits.size());
+	w.query = query;
+	w.sh.resize(hits.size());
+	w.groups.clear();
 	const int64_t* it = tl;
 	for (size_t x = 0; x < hits.size(); ++x) {
 		const int64_t s = hits[x].subject;
 		it = std::upper_bound(it, tl + nt + 1, s);
 		const uint32_t t = (uint32_t)(it - tl) - 1;
 		--it;
-		if (groups.empty() || groups.back().target != t) groups.push_back(TG{ t, x, x, 0 });
-		sh[x] = HostSeedHit{ hits[x].seed_offset, (int)(s - tl[t]), hits[x].score };
-		groups.back().end = x + 1;
-		groups.back().score = std::max(groups.back().score, (int)(uint16_t)hits[x].score);
+		if (w.groups.empty() || w.groups.back().target != t) w.groups.push_back(TargetGroup{ t, x, x, 0 });
+		w.sh[x] = HostSeedHit{ hits[x].seed_offset, (int)(s - tl[t]), hits[x].score };
+		w.groups.back().end = x + 1;
+		w.groups.back().score = std::max(w.groups.back().score, (int)(uint16_t)hits[x].score);
 	}
-	if ((int64_t)groups.size() > ranking_chunk_size(h.ref_letters, h.max_target_seqs)) {
-		err = "query " + std::to_string(query) + " has " + std::to_string(groups.size()) + " seed-hit targets: ranking chunks are not implemented";
-		return DMND_E_ARG;
-	}
+	w.order.resize(w.groups.size());
+	for (size_t i = 0; i < w.order.size(); ++i) w.order[i] = (uint32_t)i;
+	w.chunk_size = ranking_chunk_size(h.ref_letters, h.max_target_seqs);
+	if (w.chunk_size < (int64_t)w.groups.size())      // TargetScore::operator<: score desc, target index asc (target.h:146-158)
+		std::sort(w.order.begin(), w.order.end(), [&](uint32_t a, uint32_t b) {
+			return w.groups[a].score > w.groups[b].score || (w.groups[a].score == w.groups[b].score && a < b);
+		});
+	w.i0 = 0;
+	w.i1 = std::min((size_t)w.chunk_size, w.order.size());
+}
+
+// ungapped_stage + chaining + add_dp_targets for the targets order[g0, g1) of one query
+void plan_groups(const HostCfg& h, ChainWorkspace& ws, QueryWork& w, size_t g0, size_t g1,
+	const int8_t* qdata, const int64_t* ql, const int8_t* tdata, const int64_t* tl, const int8_t* cbs_all, std::vector<PlanTarget>& out)
+{
+	const uint32_t query = w.query;
+	const SeqRef q{ qdata + ql[query], (int)(ql[query + 1] - ql[query] - 1) };
+	const int8_t* cbs = cbs_all ? cbs_all + ql[query] : nullptr;
 	std::vector<Seg> segs;
 	std::vector<Chain> chains;
+	std::vector<HostSeedHit>& sh = w.sh;
 	const int base_band = band_for(q.len, h.band_mode_fast != 0);
-	for (const TG& g : groups) {
+	for (size_t gi = g0; gi < g1; ++gi) {
+		const TargetGroup& g = w.groups[w.order[gi]];
 		const SeqRef t{ tdata + tl[g.target], (int)(tl[g.target + 1] - tl[g.target] - 1) };
 		std::sort(sh.begin() + (ptrdiff_t)g.begin, sh.begin() + (ptrdiff_t)g.end, [](const HostSeedHit& a, const HostSeedHit& b) {
 			const int d1 = a.i - a.j, d2 = b.i - b.j;
@@ -160,8 +179,8 @@ int plan_query(const HostCfg& h, ChainWorkspace& ws, uint32_t query, const dmnd_
 			const int lo = std::max(d0, b0), hi = std::min(d1, b1);
 			const double overlap = hi > lo ? hi - lo : 0;
 			// (d1 - d0) wraps for the initial (INT_MAX, INT_MIN) pair exactly as in the reference: the first chain never merges
-			const double w = (double)(int)((unsigned)d1 - (unsigned)d0);
-			if (overlap / w > 0.0 || overlap / (b1 - b0) > 0.0) { d0 = std::min(d0, b0); d1 = std::max(d1, b1); }
+			const double wd = (double)(int)((unsigned)d1 - (unsigned)d0);
+			if (overlap / wd > 0.0 || overlap / (b1 - b0) > 0.0) { d0 = std::min(d0, b0); d1 = std::max(d1, b1); }
 			else {
 				if (d0 != INT_MAX) out.push_back(PlanTarget{ query, g.target, d0, d1, ungapped });
 				d0 = b0; d1 = b1;
@@ -169,7 +188,6 @@ int plan_query(const HostCfg& h, ChainWorkspace& ws, uint32_t query, const dmnd_
 		}
 		if (d0 != INT_MAX) out.push_back(PlanTarget{ query, g.target, d0, d1, ungapped });
 	}
-	return DMND_OK;
 }
 
 struct Range { size_t b, e; };
@@ -198,6 +216,7 @@ void parallel_for(size_t n, int threads, F f)
 	for (auto& x : th) x.join();
 }
 
+// all queries: load + plan every target (used by the CPU-checkable dmnd_extend_plan)
 int plan_all(const HostCfg& h, int threads, const dmnd_seed_hit* hits, int64_t n_hits,
 	const int8_t* qdata, const std::vector<int64_t>& ql, const int8_t* tdata, const std::vector<int64_t>& tl,
 	const int8_t* cbs_all, std::vector<PlanTarget>& out)
@@ -206,14 +225,11 @@ int plan_all(const HostCfg& h, int threads, const dmnd_seed_hit* hits, int64_t n
 	std::vector<std::vector<PlanTarget>> per(qr.size());
 	threads = std::max(1, threads);
 	std::vector<ChainWorkspace> ws((size_t)threads);
-	std::vector<std::string> errs((size_t)threads);
-	std::vector<int> rcs((size_t)threads, 0);
 	parallel_for(qr.size(), threads, [&](size_t i, int t) {
-		const int rc = plan_query(h, ws[(size_t)t], hits[qr[i].b].query, hits + qr[i].b, hits + qr[i].e, qdata, ql.data(), tdata, tl.data(),
-			(int64_t)tl.size() - 1, cbs_all, per[i], errs[(size_t)t]);
-		if (rc) rcs[(size_t)t] = rc;
+		QueryWork w;
+		load_query(h, w, hits[qr[i].b].query, hits + qr[i].b, hits + qr[i].e, tl.data(), (int64_t)tl.size() - 1);
+		plan_groups(h, ws[(size_t)t], w, 0, w.order.size(), qdata, ql.data(), tdata, tl.data(), cbs_all, per[i]);
 	});
-	for (size_t t = 0; t < rcs.size(); ++t) if (rcs[t]) return fail(rcs[t], errs[t]);
 	size_t total = 0;
 	for (auto& v : per) total += v.size();
 	out.clear(); out.reserve(total);
@@ -267,9 +283,55 @@ struct Cand {              // one target of one query after round 1 (Extension::
 	double evalue;
 };
 
+bool cand_less(const Cand& a, const Cand& b)                 // Target::comp_evalue, target.h:123-129
+{
+	return a.evalue < b.evalue || (a.evalue == b.evalue && (a.score > b.score || (a.score == b.score && a.target < b.target)));
 }
 
-// The whole extension stage for one (query block, reference block) pair on the uploaded blocks.
+bool match_less(const dmnd_match& a, const dmnd_match& b)    // Match::cmp_evalue, extend.h:51-56
+{
+	return a.evalue < b.evalue || (a.evalue == b.evalue && (a.hsp.score > b.hsp.score || (a.hsp.score == b.hsp.score && a.target < b.target)));
+}
+
+// culling(targets, sort_only, cfg) for first-round targets (culling.cpp:189-193, output_range :97-113)
+void cull(std::vector<Cand>& t, bool sort_only, int k)
+{
+	std::sort(t.begin(), t.end(), cand_less);
+	if (!sort_only && (int)t.size() > k) t.resize((size_t)k);
+}
+
+// append_hits(targets, begin, end, with_culling = true, cfg), culling.cpp:115-145
+bool append_hits(std::vector<Cand>& targets, const std::vector<Cand>& v, int k)
+{
+	if (v.empty()) return false;
+	bool new_hits = (int)targets.size() < k;
+	bool append = new_hits;
+	cull(targets, append, k);
+	double min_evalue = DBL_MAX;
+	for (const Cand& c : v) min_evalue = std::min(min_evalue, c.evalue);
+	const size_t range_end = std::min(targets.size(), (size_t)k);
+	if (targets.empty() || min_evalue <= targets[range_end - 1].evalue) { append = true; new_hits = true; }
+	if (append) targets.insert(targets.end(), v.begin(), v.end());
+	return new_hits;
+}
+
+// Per-query ranking state of Extension::extend (extend.cpp:226-344)
+struct QueryState {
+	QueryWork w;
+	std::vector<Cand> aligned;          // aligned_targets of the current outer iteration
+	std::vector<dmnd_match> matches;
+	int tail_score = 0, previous_tail_score = 0;
+	bool new_hits_ev = false;
+	bool in_inner = true, done = false;
+	std::vector<PlanTarget> plan;       // DpTargets of the current chunk
+	size_t item_begin = 0, item_end = 0;
+};
+
+}
+
+// The whole extension stage for one (query block, reference block) pair on the uploaded blocks. The reference's per-query
+// loop over ranking chunks (extend.cpp:289-336) becomes a batch-synchronous state machine: every pass plans the current
+// chunk of all still-active queries on the host threads and scores all of them in ONE GPU launch.
 extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata, const dmnd_seed_hit* hits, int64_t n_hits,
 	int threads, uint32_t hsp_values, dmnd_match* out, int64_t cap, int64_t* n_out,
 	uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used)
@@ -285,6 +347,8 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	h.max_target_seqs = c->max_target_seqs;
 	h.ref_letters = (double)(tl.back() - tl.front() - ((int64_t)tl.size() - 1));
 	if (hsp_values == 0) hsp_values = 510;
+	const int K = h.max_target_seqs;
+	threads = std::max(1, threads);
 	for (double& x : c->ext_stats) x = 0;
 	auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	auto cells_of = [](const std::vector<dmnd_dp_target>& v) {
@@ -292,136 +356,178 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 		for (const auto& d : v) s += (double)dmnd_banded_cols(d.query_len, d.target_len, d.d_begin, d.d_end) * (double)(d.d_end - d.d_begin);
 		return s;
 	};
-	const double t0 = now();
+	double t_mark = now();
+	auto lap = [&](int slot) { const double t = now(); c->ext_stats[slot] += t - t_mark; t_mark = t; };
 	// 1. Hauser bias for every query, resident next to the query block
 	std::vector<int8_t> cbs;
 	all_hauser(h, threads, qdata, ql, cbs);
 	if (int rc = dmnd_upload_cbs(c, cbs.data(), ql.back())) return rc;
-	const double t1 = now();
-	// 2. plan
-	std::vector<PlanTarget> plan;
-	if (int rc = plan_all(h, threads, hits, n_hits, qdata, ql, tdata, tl, cbs.data(), plan)) return rc;
-	const double t2 = now();
-	c->ext_stats[4] = t1 - t0; c->ext_stats[5] = t2 - t1;
-	if (plan.empty()) return DMND_OK;
-	// 3. round 1: score only
-	std::vector<dmnd_dp_target> items(plan.size());
-	for (size_t i = 0; i < plan.size(); ++i) {
-		const PlanTarget& p = plan[i];
-		items[i] = dmnd_dp_target{ ql[p.query], tl[p.target], ql[p.query], (int32_t)(ql[p.query + 1] - ql[p.query] - 1),
-			(int32_t)(tl[p.target + 1] - tl[p.target] - 1), p.d_begin, p.d_end };
-	}
-	std::vector<dmnd_hsp> r1(plan.size());
-	if (int rc = dmnd_banded_swipe(c, items.data(), (int64_t)items.size(), DMND_SWIPE_SCORE, 0, r1.data(), nullptr, 0, nullptr)) return rc;
-	const double sw1 = c->swipe_ms;
-	const double t3 = now();
-	c->ext_stats[0] = (double)items.size(); c->ext_stats[2] = cells_of(items); c->ext_stats[6] = t3 - t2; c->ext_stats[9] = sw1;
-	// 4. per query: report cutoff, best HSP per target (Target::add_hit + inner_culling with max_hsps = 1), top-k culling
-	std::vector<Cand> survivors;
-	std::vector<uint32_t> surv_query;
-	for (size_t i = 0; i < plan.size();) {
-		size_t j = i;
-		std::vector<Cand> cands;
-		while (j < plan.size() && plan[j].query == plan[i].query) {
-			const PlanTarget& p = plan[j];
-			const int score = r1[j].score;
-			const int qlen = items[j].query_len, tlen = items[j].target_len;
-			if (score > 0) {
-				const double ev = c->evaluer.evalue(score, (unsigned)qlen, (unsigned)tlen);
-				if (ev <= c->params.max_evalue) {
-					// add_hit: a later HSP of the same target replaces the filter values only with a strictly higher score;
-					// inner_culling keeps the best HSP by (score desc, d_begin asc) (Hsp::operator<, basic/match.h:199)
-					if (!cands.empty() && cands.back().target == p.target) {
-						Cand& k = cands.back();
-						if (score > k.score || (score == k.score && p.d_begin < k.d_begin)) { k.score = score; k.evalue = ev; k.d_begin = p.d_begin; k.d_end = p.d_end; }
-					}
-					else cands.push_back(Cand{ p.target, score, p.d_begin, p.d_end, p.ungapped_score, ev });
-				}
-			}
-			++j;
-		}
-		std::sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) {        // Target::comp_evalue
-			return a.evalue < b.evalue || (a.evalue == b.evalue && (a.score > b.score || (a.score == b.score && a.target < b.target)));
-		});
-		if ((int)cands.size() > h.max_target_seqs) cands.resize((size_t)h.max_target_seqs);
-		for (const Cand& k : cands) { survivors.push_back(k); surv_query.push_back(plan[i].query); }
-		i = j;
-	}
-	const double t4 = now();
-	c->ext_stats[7] = t4 - t3;
-	if (survivors.empty()) return DMND_OK;
-	// 5. round 2: traceback for DP sizes <= max_swipe_dp, statistics passes above (DP::BandedSwipe::bin)
-	std::vector<dmnd_dp_target> it_tb, it_st;
-	std::vector<size_t> idx_tb, idx_st;
-	for (size_t i = 0; i < survivors.size(); ++i) {
-		const Cand& k = survivors[i];
-		const uint32_t q = surv_query[i];
-		dmnd_dp_target d{ ql[q], tl[k.target], ql[q], (int32_t)(ql[q + 1] - ql[q] - 1), (int32_t)(tl[k.target + 1] - tl[k.target] - 1), k.d_begin, k.d_end };
-		const int64_t dp_size = (int64_t)dmnd_banded_cols(d.query_len, d.target_len, d.d_begin, d.d_end) * (int64_t)(d.d_end - d.d_begin);
-		if (dp_size > h.max_swipe_dp) { it_st.push_back(d); idx_st.push_back(i); }
-		else { it_tb.push_back(d); idx_tb.push_back(i); }
-	}
-	std::vector<dmnd_hsp> r2(survivors.size());
-	std::vector<dmnd_hsp> tmp;
+	lap(4);
+	// 2. load_hits for every query
+	const std::vector<Range> qr = split_by_query(hits, n_hits);
+	std::vector<QueryState> qs(qr.size());
+	parallel_for(qr.size(), threads, [&](size_t i, int) {
+		load_query(h, qs[i].w, hits[qr[i].b].query, hits + qr[i].b, hits + qr[i].e, tl.data(), (int64_t)tl.size() - 1);
+		if (qs[i].w.order.empty()) qs[i].done = true;
+	});
+	std::vector<ChainWorkspace> ws((size_t)threads);
+	lap(5);
+	auto item_of = [&](uint32_t q, uint32_t t, int d0, int d1) {
+		return dmnd_dp_target{ ql[q], tl[t], ql[q], (int32_t)(ql[q + 1] - ql[q] - 1), (int32_t)(tl[t + 1] - tl[t] - 1), d0, d1 };
+	};
+	double sw1 = 0, sw2 = 0, tb2 = 0;
 	int64_t used = 0;
 	std::vector<uint8_t> own_arena;
-	uint8_t* arena = transcript;
-	int64_t arena_cap = transcript_cap;
-	if (!arena) {
-		int64_t need = 16;
-		for (const auto& d : it_tb) need += (int64_t)d.query_len + d.target_len + 2;
-		own_arena.resize((size_t)need);
-		arena = own_arena.data(); arena_cap = need;
-	}
-	double sw2 = 0, tb2 = 0;
-	if (!it_tb.empty()) {
-		tmp.resize(it_tb.size());
-		if (int rc = dmnd_banded_swipe(c, it_tb.data(), (int64_t)it_tb.size(), DMND_SWIPE_TRACEBACK, hsp_values, tmp.data(), arena, arena_cap, &used)) return rc;
-		for (size_t x = 0; x < idx_tb.size(); ++x) r2[idx_tb[x]] = tmp[x];
-		sw2 += c->swipe_ms; tb2 += c->traceback_ms;
-	}
-	if (!it_st.empty()) {
-		tmp.resize(it_st.size());
-		if (int rc = dmnd_banded_swipe(c, it_st.data(), (int64_t)it_st.size(), DMND_SWIPE_STATS, hsp_values, tmp.data(), nullptr, 0, nullptr)) return rc;
-		for (size_t x = 0; x < idx_st.size(); ++x) { r2[idx_st[x]] = tmp[x]; r2[idx_st[x]].transcript_len = 0; r2[idx_st[x]].transcript_off = -1; }
-		sw2 += c->swipe_ms;
+	std::vector<dmnd_dp_target> items;
+	std::vector<dmnd_hsp> res;
+	for (;;) {
+		// ---- inner loop: ranking chunks, round 1 (score only) ----
+		for (;;) {
+			std::vector<size_t> active;
+			for (size_t i = 0; i < qs.size(); ++i) if (!qs[i].done && qs[i].in_inner) active.push_back(i);
+			if (active.empty()) break;
+			parallel_for(active.size(), threads, [&](size_t a, int t) {
+				QueryState& s = qs[active[a]];
+				s.plan.clear();
+				plan_groups(h, ws[(size_t)t], s.w, s.w.i0, s.w.i1, qdata, ql.data(), tdata, tl.data(), cbs.data(), s.plan);
+			});
+			items.clear();
+			for (size_t i : active) {
+				QueryState& s = qs[i];
+				s.item_begin = items.size();
+				for (const PlanTarget& p : s.plan) items.push_back(item_of(p.query, p.target, p.d_begin, p.d_end));
+				s.item_end = items.size();
+			}
+			lap(5);
+			res.assign(items.size(), dmnd_hsp());
+			if (!items.empty()) {
+				if (int rc = dmnd_banded_swipe(c, items.data(), (int64_t)items.size(), DMND_SWIPE_SCORE, 0, res.data(), nullptr, 0, nullptr)) return rc;
+				sw1 += c->swipe_ms;
+				c->ext_stats[0] += (double)items.size(); c->ext_stats[2] += cells_of(items);
+			}
+			lap(6);
+			for (size_t i : active) {
+				QueryState& s = qs[i];
+				// extend_chunk -> align (gapped_score.cpp:182-268): report cutoff, best HSP per target
+				std::vector<Cand> v;
+				for (size_t x = s.item_begin; x < s.item_end; ++x) {
+					const PlanTarget& p = s.plan[x - s.item_begin];
+					const int score = res[x].score;
+					if (score <= 0) continue;
+					const double ev = c->evaluer.evalue(score, (unsigned)items[x].query_len, (unsigned)items[x].target_len);
+					if (ev > c->params.max_evalue) continue;
+					if (!v.empty() && v.back().target == p.target) {
+						Cand& k = v.back();     // inner_culling keeps the best HSP by (score desc, d_begin asc) (Hsp::operator<, match.h:199)
+						if (score > k.score || (score == k.score && p.d_begin < k.d_begin)) { k.score = score; k.evalue = ev; k.d_begin = p.d_begin; k.d_end = p.d_end; }
+					}
+					else v.push_back(Cand{ p.target, score, p.d_begin, p.d_end, p.ungapped_score, ev });
+				}
+				const bool multi_chunk = (s.w.i1 - s.w.i0) < s.w.order.size();
+				bool new_hits = s.new_hits_ev = !v.empty();
+				if (multi_chunk) new_hits = append_hits(s.aligned, v, K);
+				else s.aligned = v;
+				// advance the chunk window (extend.cpp:325-329)
+				s.w.i0 = s.w.i1;
+				s.w.i1 += std::min((size_t)s.w.chunk_size, s.w.order.size() - s.w.i1);
+				s.previous_tail_score = s.tail_score;
+				const int next_tail = s.w.groups[s.w.order[s.w.i1 - 1]].score;
+				if (new_hits) s.tail_score = next_tail;
+				// ranking_terminate (extend.cpp:111-119) with default options
+				const bool terminate = !new_hits && (s.previous_tail_score == 0
+					|| (double)next_tail / (double)s.previous_tail_score <= 0.95
+					|| c->evaluer.bitscore(next_tail) < 25.0);
+				if (!(s.w.i0 < s.w.order.size() && !terminate)) s.in_inner = false;
+			}
+			lap(7);
+		}
+		// ---- round 2 for every query that just left the inner loop ----
+		std::vector<size_t> batch;
+		for (size_t i = 0; i < qs.size(); ++i) if (!qs[i].done && !qs[i].in_inner) batch.push_back(i);
+		if (batch.empty()) break;
+		std::vector<dmnd_dp_target> it_tb, it_st;
+		struct Ref { size_t q, k; };
+		std::vector<Ref> ref_tb, ref_st;
+		for (size_t i : batch) {
+			QueryState& s = qs[i];
+			cull(s.aligned, false, K);                                          // extend.cpp:331
+			for (size_t k = 0; k < s.aligned.size(); ++k) {
+				const Cand& cd = s.aligned[k];
+				const dmnd_dp_target d = item_of(s.w.query, cd.target, cd.d_begin, cd.d_end);
+				const int64_t dp_size = (int64_t)dmnd_banded_cols(d.query_len, d.target_len, d.d_begin, d.d_end) * (int64_t)(d.d_end - d.d_begin);
+				if (dp_size > h.max_swipe_dp) { it_st.push_back(d); ref_st.push_back(Ref{ i, k }); }      // DP::BandedSwipe::bin
+				else { it_tb.push_back(d); ref_tb.push_back(Ref{ i, k }); }
+			}
+		}
+		lap(7);
+		std::vector<std::vector<dmnd_hsp>> r2(qs.size());
+		for (size_t i : batch) r2[i].assign(qs[i].aligned.size(), dmnd_hsp());
+		if (!it_tb.empty()) {
+			uint8_t* arena = transcript ? transcript + used : nullptr;
+			int64_t arena_cap = transcript ? transcript_cap - used : 0;
+			if (!transcript) {
+				int64_t need = 16;
+				for (const auto& d : it_tb) need += (int64_t)d.query_len + d.target_len + 2;
+				own_arena.resize((size_t)need);
+				arena = own_arena.data(); arena_cap = need;
+			}
+			res.assign(it_tb.size(), dmnd_hsp());
+			int64_t u = 0;
+			if (int rc = dmnd_banded_swipe(c, it_tb.data(), (int64_t)it_tb.size(), DMND_SWIPE_TRACEBACK, hsp_values, res.data(), arena, arena_cap, &u)) return rc;
+			for (size_t x = 0; x < ref_tb.size(); ++x) {
+				r2[ref_tb[x].q][ref_tb[x].k] = res[x];
+				if (transcript) r2[ref_tb[x].q][ref_tb[x].k].transcript_off += used; else r2[ref_tb[x].q][ref_tb[x].k].transcript_off = -1;
+			}
+			if (transcript) used += u;
+			sw2 += c->swipe_ms; tb2 += c->traceback_ms;
+		}
+		if (!it_st.empty()) {
+			res.assign(it_st.size(), dmnd_hsp());
+			if (int rc = dmnd_banded_swipe(c, it_st.data(), (int64_t)it_st.size(), DMND_SWIPE_STATS, hsp_values, res.data(), nullptr, 0, nullptr)) return rc;
+			for (size_t x = 0; x < ref_st.size(); ++x) { r2[ref_st[x].q][ref_st[x].k] = res[x]; r2[ref_st[x].q][ref_st[x].k].transcript_len = 0; r2[ref_st[x].q][ref_st[x].k].transcript_off = -1; }
+			sw2 += c->swipe_ms;
+		}
+		c->ext_stats[1] += (double)(it_tb.size() + it_st.size()); c->ext_stats[3] += cells_of(it_tb) + cells_of(it_st);
+		lap(8);
+		for (size_t i : batch) {
+			QueryState& s = qs[i];
+			// align() round 2 (gapped_final.cpp:80-160): report cutoff again, culling of this round's matches
+			std::vector<dmnd_match> round;
+			const uint32_t q = s.w.query;
+			const int qlen = (int)(ql[q + 1] - ql[q] - 1);
+			for (size_t k = 0; k < s.aligned.size(); ++k) {
+				const Cand& cd = s.aligned[k];
+				const dmnd_hsp& hsp = r2[i][k];
+				if (hsp.score <= 0) continue;
+				const int tlen = (int)(tl[cd.target + 1] - tl[cd.target] - 1);
+				const double ev = c->evaluer.evalue(hsp.score, (unsigned)qlen, (unsigned)tlen);
+				if (ev > c->params.max_evalue) continue;
+				dmnd_match m;
+				m.query = q; m.target = cd.target; m.evalue = ev; m.bit_score = c->evaluer.bitscore(hsp.score);
+				m.ungapped_score = cd.ungapped; m.d_begin = cd.d_begin; m.d_end = cd.d_end; m.pad = 0; m.hsp = hsp;
+				round.push_back(m);
+			}
+			std::sort(round.begin(), round.end(), match_less);
+			if ((int)round.size() > K) round.resize((size_t)K);
+			s.matches.insert(s.matches.end(), round.begin(), round.end());
+			s.aligned.clear();
+			// outer loop condition (extend.cpp:336)
+			if ((int)s.matches.size() < K && s.w.i0 < s.w.order.size() && s.new_hits_ev) s.in_inner = true;
+			else s.done = true;
+		}
+		lap(7);
 	}
 	c->swipe_ms = sw1 + sw2; c->traceback_ms = tb2;
-	const double t5 = now();
-	c->ext_stats[1] = (double)survivors.size(); c->ext_stats[3] = cells_of(it_tb) + cells_of(it_st); c->ext_stats[8] = t5 - t4;
-	c->ext_stats[10] = sw2; c->ext_stats[11] = tb2;
+	c->ext_stats[9] = sw1; c->ext_stats[10] = sw2; c->ext_stats[11] = tb2;
 	if (transcript_used) *transcript_used = transcript ? used : 0;
-	// 6. final per-query culling (Match::cmp_evalue + output_range) -> records
+	// final culling(matches, cfg) per query (extend.cpp:341) -> records in query order
 	int64_t n = 0;
-	for (size_t i = 0; i < survivors.size();) {
-		size_t j = i;
-		std::vector<dmnd_match> ms;
-		while (j < survivors.size() && surv_query[j] == surv_query[i]) {
-			const Cand& k = survivors[j];
-			const dmnd_hsp& hsp = r2[j];
-			const uint32_t q = surv_query[j];
-			const int qlen = (int)(ql[q + 1] - ql[q] - 1), tlen = (int)(tl[k.target + 1] - tl[k.target] - 1);
-			if (hsp.score > 0) {
-				const double ev = c->evaluer.evalue(hsp.score, (unsigned)qlen, (unsigned)tlen);
-				if (ev <= c->params.max_evalue) {
-					dmnd_match m;
-					m.query = q; m.target = k.target; m.evalue = ev; m.bit_score = c->evaluer.bitscore(hsp.score);
-					m.ungapped_score = k.ungapped; m.d_begin = k.d_begin; m.d_end = k.d_end; m.hsp = hsp;
-					if (!transcript) m.hsp.transcript_off = -1;
-					ms.push_back(m);
-				}
-			}
-			++j;
-		}
-		std::sort(ms.begin(), ms.end(), [](const dmnd_match& a, const dmnd_match& b) {     // Match::cmp_evalue
-			return a.evalue < b.evalue || (a.evalue == b.evalue && (a.hsp.score > b.hsp.score || (a.hsp.score == b.hsp.score && a.target < b.target)));
-		});
-		if ((int)ms.size() > h.max_target_seqs) ms.resize((size_t)h.max_target_seqs);
-		for (const dmnd_match& m : ms) {
+	for (QueryState& s : qs) {
+		std::sort(s.matches.begin(), s.matches.end(), match_less);
+		if ((int)s.matches.size() > K) s.matches.resize((size_t)K);
+		for (const dmnd_match& m : s.matches) {
 			if (n < cap && out) out[n] = m;
 			++n;
 		}
-		i = j;
 	}
 	*n_out = n;
 	if (n > cap) return fail(DMND_E_CAP, "dmnd_extend: match buffer too small");

@@ -57,5 +57,17 @@ PY
 # the reference's TSV output is kept as the end-to-end golden
 DIAMOND_TAP_EXT="$HERE/ext_fast_synth.tap" DIAMOND_TAP_FILE="$HERE/swipe_fast_synth.tap" \
   "$TAP" blastp --fast --masking 0 --motif-masking 0 --algo 0 -q "$TMP/s_q.faa" -d "$TMP/s_db.faa" -o "$HERE/fast_synth.tsv" -p4 2>/dev/null
+# 6. ranking chunks: a few large, well-conserved families so that every query has far more than 128 seed-hit targets
+#    (ranking_chunk_size, extend.cpp:79-92): exercises the chunked target ranking / early termination loop
+DMND_ROOT="$ROOT" python3 - "$TMP" <<'PY'
+import os, sys
+sys.path.insert(0, os.environ["DMND_ROOT"])
+from diamond_amd import synth
+db, do, q, qo = synth.generate(3, members=400, queries=24, seed=9, sub=(0.05, 0.5), qsub=(0.05, 0.3), decoy_frac=0.0)
+synth.write_fasta(sys.argv[1] + "/r_db.faa", "t", db, do)
+synth.write_fasta(sys.argv[1] + "/r_q.faa", "q", q, qo)
+PY
+DIAMOND_TAP_EXT="$HERE/ext_rank.tap" \
+  "$TAP" blastp --fast --masking 0 --motif-masking 0 --algo 0 -q "$TMP/r_q.faa" -d "$TMP/r_db.faa" -o "$HERE/rank.tsv" -p1 2>/dev/null
 ls -la "$HERE"/*.tap
 rm -rf "$TMP"

@@ -33,7 +33,7 @@ def _run(ctx, cfg, db_letters):
     return ctx.extend(qd, td, hits, threads=4)[0]
 
 
-@pytest.mark.parametrize("tap", ["ext_fast_synth.tap", "ext_fast.tap", "ext_6x10.tap"])
+@pytest.mark.parametrize("tap", ["ext_fast_synth.tap", "ext_fast.tap", "ext_6x10.tap", "ext_rank.tap"])
 def test_matches_equal_reference_extend(ctx, tap):
     cfg, recs = read_ext_tap(os.path.join(GOLDEN, tap))
     tl = cfg["target"]["limits"]
@@ -58,13 +58,14 @@ def test_matches_equal_reference_extend(ctx, tap):
     assert pos == len(m) and n > 300
 
 
-def test_tabular_output_is_byte_identical_to_reference(ctx):
-    cfg, recs = read_ext_tap(os.path.join(GOLDEN, "ext_fast_synth.tap"))
+@pytest.mark.parametrize("tap,tsv", [("ext_fast_synth.tap", "fast_synth.tsv"), ("ext_rank.tap", "rank.tsv")])
+def test_tabular_output_is_byte_identical_to_reference(ctx, tap, tsv):
+    cfg, recs = read_ext_tap(os.path.join(GOLDEN, tap))
     tl = cfg["target"]["limits"]
     m = _run(ctx, cfg, float(tl[-1] - tl[0] - (len(tl) - 1)))
     qids = ["q%d" % i for i in range(cfg["query"]["n"])]
     tids = ["t%d" % i for i in range(cfg["target"]["n"])]
     text = hip.format_tab(m, qids, tids)
-    ref = open(os.path.join(GOLDEN, "fast_synth.tsv")).read()
+    ref = open(os.path.join(GOLDEN, tsv)).read()
     assert len(ref.splitlines()) > 300
     assert text == ref

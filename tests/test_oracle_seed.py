@@ -14,7 +14,7 @@ def hit_set(h):
     return set(zip(h["query"].tolist(), h["subject"].tolist(), h["seed_offset"].tolist(), h["score"].tolist()))
 
 
-@pytest.mark.parametrize("tap", ["ext_fast.tap", "ext_fast_synth.tap", "ext_6x10.tap"])
+@pytest.mark.parametrize("tap", ["ext_fast.tap", "ext_fast_synth.tap", "ext_6x10.tap", "ext_rank.tap"])
 def test_seed_stage_hit_multiset_equals_reference(tap):
     cfg, recs = read_ext_tap(os.path.join(GOLDEN, tap))
     assert cfg["ungapped_evalue"] == 0.0 and cfg["index_chunks"] == 4
