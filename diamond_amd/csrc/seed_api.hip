@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -42,6 +43,36 @@ extern "C" int dmnd_seed_params_fast(dmnd_seed_params* p, int threads)
 	p->ungapped_window = 48;
 	p->left_most_interval = 32;
 	p->seed_complexity_cut = 0.9 * 0.69314718055994530942 * w;      // seed_cut * log(2) * weight, setup.cpp:369-370
+	p->use_ungapped = 0; p->short_query_max_len = 60; p->tile_size = 1024; p->simd_lanes = 32;
+	return DMND_OK;
+}
+
+extern "C" int dmnd_seed_params_default(dmnd_seed_params* p, int threads, const dmnd_params* sc)
+{
+	if (!p || !sc || threads < 1) return fail(DMND_E_ARG, "dmnd_seed_params_default: bad argument");
+	if (int rc = dmnd_seed_params_fast(p, threads)) return rc;
+	const char* codes[2] = { "111101110111", "111011010010111" };          // shape_codes[DEFAULT], search/setup.cpp:82-84
+	p->n_shapes = 2;
+	for (int sid = 0; sid < 2; ++sid) {
+		int w = 0;
+		const int len = (int)std::strlen(codes[sid]);
+		p->shape_mask[sid] = 0;
+		std::memset(p->shape_pos[sid], 0, sizeof(p->shape_pos[sid]));
+		for (int i = 0; i < len; ++i)
+			if (codes[sid][i] == '1') { p->shape_pos[sid][w++] = (int8_t)i; p->shape_mask[sid] |= 1u << i; }
+		p->shape_len[sid] = len; p->shape_weight[sid] = w;
+	}
+	auto bit_length = [](uint64_t x) { int b = 0; while (x) { ++b; x >>= 1; } return b; };
+	p->seedp_bits = std::max(std::max(bit_length(10000000000ull - 1) - 32, bit_length((uint64_t)threads * 4 * p->index_chunks - 1)), 8);
+	p->seed_complexity_cut = 0.8 * 0.69314718055994530942 * 10;
+	// ungapped e-value 10000: CutoffTable + short-query cutoff (cutoff_table.h:30-35, score_matrix.h:130-151, config.cpp:431)
+	const double LN2 = 0.69314718055994530941723212145818, ln_k = std::log(sc->K);
+	auto raw = [&](double bits) { return (int32_t)std::ceil((bits * LN2 + ln_k) / sc->lambda); };
+	p->use_ungapped = 1;
+	p->short_query_cutoff = raw(25.0);
+	p->cutoff_table[0] = 0;
+	for (int b = 1; b < 32; ++b)
+		p->cutoff_table[b] = raw(-std::log(10000.0 / 1e9 / (double)(1u << (b - 1))) / std::log(2.0));
 	return DMND_OK;
 }
 
@@ -108,6 +139,8 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	if (int rc = c->seed_flags.ensure((size_t)S * slots)) return rc;
 	if (int rc = c->seed_next.ensure((size_t)S * nq_pos * sizeof(uint32_t))) return rc;
 	if (int rc = c->counters.ensure((size_t)(S + 1) * sizeof(unsigned long long))) return rc;
+	if (int rc = c->seed_sheads.ensure((size_t)S * slots * sizeof(uint32_t))) return rc;
+	HIP_TRY(hipMemsetAsync(c->seed_sheads.p, 0xff, (size_t)S * slots * sizeof(uint32_t), st));
 	HIP_TRY(hipMemsetAsync(c->mask_time.p, SEED_NEVER, (size_t)c->block_len[DMND_QUERY] + 256, st));
 	HIP_TRY(hipMemsetAsync(c->seed_keys.p, 0xff, (size_t)S * slots * sizeof(uint64_t), st));
 	HIP_TRY(hipMemsetAsync(c->seed_heads.p, 0xff, (size_t)S * slots * sizeof(uint32_t), st));
@@ -134,6 +167,9 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		a.matched_loc = c->matched_loc.as<int64_t>() + matched_off;
 		a.matched_count = c->counters.as<unsigned long long>() + sid;
 		a.matched_cap = matched_cap;
+		a.s_heads = c->seed_sheads.as<uint32_t>() + (size_t)sid * slots;
+		a.s_next = c->seed_snext.as<uint32_t>() + matched_off;
+		a.matrix = c->matrix.as<int8_t>();
 		a.hits = c->seed_hits.as<dmnd_seed_hit>(); a.hit_count = c->counters.as<unsigned long long>() + S; a.hit_cap = 0;
 		return a;
 	};
@@ -147,12 +183,14 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	for (int attempt = 0;; ++attempt) {
 		if (int rc = c->matched_slot.ensure((size_t)cap_total * sizeof(uint32_t))) return rc;
 		if (int rc = c->matched_loc.ensure((size_t)cap_total * sizeof(int64_t))) return rc;
+		if (int rc = c->seed_snext.ensure((size_t)cap_total * sizeof(uint32_t))) return rc;
 		HIP_TRY(hipMemsetAsync(c->counters.p, 0, (size_t)(S + 1) * sizeof(unsigned long long), st));
 		if (attempt > 0) {
 			HIP_TRY(hipMemsetAsync(c->seed_keys.p, 0xff, (size_t)S * slots * sizeof(uint64_t), st));
 			HIP_TRY(hipMemsetAsync(c->seed_heads.p, 0xff, (size_t)S * slots * sizeof(uint32_t), st));
 			HIP_TRY(hipMemsetAsync(c->seed_flags.p, 0, (size_t)S * slots, st));
 			HIP_TRY(hipMemsetAsync(c->seed_bitmap.p, 0, bm_total, st));
+			HIP_TRY(hipMemsetAsync(c->seed_sheads.p, 0xff, (size_t)S * slots * sizeof(uint32_t), st));
 		}
 		bool overflow = false;
 		int64_t off = 0;

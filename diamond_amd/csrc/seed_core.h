@@ -35,6 +35,10 @@ struct SeedParams {
 	int32_t seedp_bits, index_chunks, hamming_filter_id;
 	int32_t ungapped_window, left_most_interval;             // config.ungapped_window (48), config.left_most_interval (32)
 	double seed_complexity_cut;
+	// stage-2 ungapped window filter (stage2.h:43-63,107-113); use_ungapped = 0 <=> ungapped_evalue == 0
+	int32_t use_ungapped, short_query_max_len, short_query_cutoff;
+	int32_t cutoff_table[32];                                // CutoffTable::data_[bit_length(query_len)]
+	int32_t tile_size, simd_lanes;                           // config.tile_size (1024); int8 lanes of the reference build (AVX2: 32)
 };
 
 DMND_HD bool is_amino_acid(int l) { return l != L_MASK && l != L_DELIM && l != L_STOP; }
@@ -237,6 +241,72 @@ DMND_HD bool left_most_pair(const SeedParams& c, const int8_t* q, const uint8_t*
 	const uint32_t right_hit = pattern_hit(c, chunked ? sid + 1 : sid, match_mask_right, len_right) & query_mask_right;
 	return (left_hit == 0 || !verify_hits(c, left_hit, qq, ss, true, match_mask_left, sid, chunked, lo, hi))
 		&& (right_hit == 0 || !verify_hits(c, right_hit, qq + window_left + 1, ss + window_left + 1, false, match_mask_right, sid, chunked, lo, hi));
+}
+
+// Stage-2 ungapped window score: best running local score over `window` aligned letters
+// (window_ungapped_best / ungapped_window, src/dp/ungapped_simd.cpp:32-87, dp/ungapped_align.cpp:244-258).
+DMND_HD int ungapped_window_score(const int8_t* M, const int8_t* q, const int8_t* s, int window)
+{
+	int score = 0, st = 0;
+	for (int n = 0; n < window; ++n) {
+		st += M[(q[n] & LETTER_MASK) * 32 + (s[n] & LETTER_MASK)];
+		st = imax(st, 0);
+		score = imax(score, st);
+	}
+	return score;
+}
+
+// ungapped_cutoff (stage2.h:43-63): short queries use a fixed bit-score cutoff, others CutoffTable[bit_length(len)]
+// (util/scores/cutoff_table.h:26-47). 0 <=> filter off.
+DMND_HD int ungapped_cutoff(const SeedParams& c, int query_len)
+{
+	if (!c.use_ungapped) return 0;
+	if (query_len <= c.short_query_max_len) return c.short_query_cutoff;
+	int b = 0;
+	for (uint32_t x = (uint32_t)query_len; x; x >>= 1) ++b;
+	return c.cutoff_table[b];
+}
+
+// Linked list of the reference positions joined to one query seed (entries of the stream kernel's match arrays)
+struct SList { const int64_t* loc; const uint32_t* next; uint32_t head; };
+
+// The reference scores Hamming survivors in SIMD batches (search_query_offset, stage2.h:74-154): per subject tile
+// of `tile_size` joined positions (ascending position order), survivors are taken `simd_lanes` at a time, and a
+// batch of >= 4 runs the int8 kernel whose scores saturate at 255 (ungapped_simd.cpp:69-87) while smaller batches
+// run the scalar one. Returns the size of the batch the pair (q, sloc) lands in. Order-free restatement: the tile
+// is found by rank of sloc among the seed's joined positions, the batch by rank among the tile's survivors.
+// Only needed when the exact score exceeds 255 (rare), so the O(list) walks are off the common path.
+DMND_HD int simd_batch_size(const SeedParams& c, const SList& l, const int8_t* tdata, const int8_t* q, int64_t sloc)
+{
+	int64_t n_all = 0, rank = 0;
+	for (uint32_t i = l.head; i != 0xffffffffu; i = l.next[i]) { ++n_all; rank += l.loc[i] < sloc; }
+	int64_t lo_loc = INT64_MIN, hi_loc = INT64_MAX;              // tile = joined positions with lo_loc <= loc < hi_loc
+	const int64_t T = c.tile_size;
+	if (T > 0 && n_all > T) {
+		const int64_t t_lo = rank / T * T, t_hi = t_lo + T;
+		// loc of the element with rank `want` (exactly `want` smaller elements): bisect on the value
+		for (int k = 0; k < 2; ++k) {
+			const int64_t want = k == 0 ? t_lo : t_hi;
+			if (want <= 0 || want >= n_all) continue;
+			int64_t a = 0, b = INT64_MAX;                            // smallest x with count(loc <= x) >= want + 1
+			while (a < b) {
+				const int64_t mid = a + (b - a) / 2;
+				int64_t cnt = 0;
+				for (uint32_t i = l.head; i != 0xffffffffu; i = l.next[i]) cnt += l.loc[i] <= mid;
+				if (cnt >= want + 1) b = mid; else a = mid + 1;
+			}
+			if (k == 0) lo_loc = a; else hi_loc = a;
+		}
+	}
+	int64_t L = 0, r = 0;
+	for (uint32_t i = l.head; i != 0xffffffffu; i = l.next[i]) {
+		const int64_t x = l.loc[i];
+		if (x < lo_loc || x >= hi_loc) continue;
+		if (fingerprint_id(q, tdata + x) < c.hamming_filter_id) continue;
+		++L; r += x < sloc;
+	}
+	const int64_t lanes = c.simd_lanes, left = L - r / lanes * lanes;
+	return (int)(left < lanes ? left : lanes);
 }
 
 // Hash of a seed for the query seed table: two 32-bit mixes (murmur3-style finalisers on 32-bit lanes, cheap on

@@ -28,6 +28,8 @@ struct SeedArgs {
 	uint32_t* bitmap; uint32_t bitmap_mask;
 	// joined reference positions of this shape
 	uint32_t* matched_slot; int64_t* matched_loc; unsigned long long* matched_count; int64_t matched_cap;
+	uint32_t* s_heads; uint32_t* s_next;          // per slot: linked list of its joined reference positions (entries of matched_*)
+	const int8_t* matrix;                         // 32x32 int8 substitution matrix (HBM) for the stage-2 ungapped window score
 	// output
 	dmnd_seed_hit* hits; unsigned long long* hit_count; int64_t hit_cap;
 };

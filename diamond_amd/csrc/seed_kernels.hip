@@ -68,6 +68,7 @@ __global__ void seed_stream_kernel(SeedArgs a, int sid)
 	if (idx < (unsigned long long)a.matched_cap) {
 		a.matched_slot[idx] = (uint32_t)slot;
 		a.matched_loc[idx] = p;
+		a.s_next[idx] = atomicExch(&a.s_heads[slot], (uint32_t)idx);
 	}
 }
 
@@ -171,6 +172,7 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 			if (idx < (unsigned long long)a.matched_cap) {
 				a.matched_slot[idx] = (uint32_t)slot;
 				a.matched_loc[idx] = p0 + 8 * half + i;
+				a.s_next[idx] = atomicExch(&a.s_heads[slot], (uint32_t)idx);
 			}
 		}
 	}
@@ -209,11 +211,28 @@ __global__ void seed_pair_kernel(SeedArgs a, int sid, int64_t n_matched)
 		if (fingerprint_id(q, s) < a.params.hamming_filter_id) continue;
 		const uint32_t qid = a.qid_of[qp];
 		const int seed_offset = (int)(qp - a.qlimits[qid]);
+		int score = 0xFFFF;
+		if (a.params.use_ungapped) {
+			// stage-2 ungapped window score over the query window clipped at its sequence ends (stage2.h:92-113)
+			const int cutoff = ungapped_cutoff(a.params, (int)(a.qlimits[qid + 1] - a.qlimits[qid] - 1));
+			if (cutoff) {
+				const int window = a.params.ungapped_window;
+				int cb, ce;
+				clip_window(q - window, 2 * window, window, cb, ce);
+				const int window_left = window - cb;
+				score = ungapped_window_score(a.matrix, q - window_left, s - window_left, ce - cb);
+				if (score > 255) {
+					const SList l{ a.matched_loc, a.s_next, a.s_heads[slot] };
+					if (simd_batch_size(a.params, l, a.tdata, q, sloc) >= 4) score = 255;
+				}
+				if (score <= cutoff) continue;
+			}
+		}
 		if (!left_most_pair(a.params, q, a.mask_time + qp, s, seed_offset, sid, chunk)) continue;
 		const unsigned long long idx = atomicAdd(a.hit_count, 1ull);
 		if (idx < (unsigned long long)a.hit_cap) {
 			dmnd_seed_hit h;
-			h.query = qid; h.seed_offset = seed_offset; h.subject = sloc; h.score = 0xFFFF; h.pad = 0;
+			h.query = qid; h.seed_offset = seed_offset; h.subject = sloc; h.score = score; h.pad = 0;
 			a.hits[idx] = h;
 		}
 	}

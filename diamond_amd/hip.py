@@ -33,7 +33,9 @@ class SeedParams(ctypes.Structure):
                 ("reduction", ctypes.c_int8 * 32), ("reduction_size", ctypes.c_int32),
                 ("seedp_bits", ctypes.c_int32), ("index_chunks", ctypes.c_int32), ("hamming_filter_id", ctypes.c_int32),
                 ("ungapped_window", ctypes.c_int32), ("left_most_interval", ctypes.c_int32),
-                ("seed_complexity_cut", ctypes.c_double)]
+                ("seed_complexity_cut", ctypes.c_double),
+                ("use_ungapped", ctypes.c_int32), ("short_query_max_len", ctypes.c_int32), ("short_query_cutoff", ctypes.c_int32),
+                ("cutoff_table", ctypes.c_int32 * 32), ("tile_size", ctypes.c_int32), ("simd_lanes", ctypes.c_int32)]
 
 
 SEED_HIT_DTYPE = np.dtype([("query", "<u4"), ("seed_offset", "<i4"), ("subject", "<i8"), ("score", "<i4"), ("pad", "<i4")])
@@ -61,7 +63,7 @@ _lib = None
 EXPORTS = ["dmnd_abi_version", "dmnd_last_error", "dmnd_default_params", "dmnd_create", "dmnd_destroy",
            "dmnd_set_db_letters", "dmnd_upload_block", "dmnd_upload_cbs", "dmnd_banded_swipe",
            "dmnd_banded_swipe_host", "dmnd_banded_cols", "dmnd_evalue", "dmnd_bitscore", "dmnd_evalue_p",
-           "dmnd_bitscore_p", "dmnd_evalue_batch", "dmnd_last_kernel_ms", "dmnd_seed_params_fast", "dmnd_seed_search",
+           "dmnd_bitscore_p", "dmnd_evalue_batch", "dmnd_last_kernel_ms", "dmnd_seed_params_fast", "dmnd_seed_params_default", "dmnd_seed_search",
            "dmnd_seed_hits", "dmnd_seed_kernel_ms", "dmnd_extend_plan", "dmnd_extend", "dmnd_extend_stats", "dmnd_format_tab", "dmnd_set_max_target_seqs"]
 
 
@@ -94,6 +96,7 @@ def load():
         lib.dmnd_bitscore_p.restype = ctypes.c_double
         lib.dmnd_bitscore_p.argtypes = [ctypes.POINTER(Params), ctypes.c_double]
         lib.dmnd_seed_params_fast.argtypes = [ctypes.POINTER(SeedParams), ctypes.c_int]
+        lib.dmnd_seed_params_default.argtypes = [ctypes.POINTER(SeedParams), ctypes.c_int, ctypes.POINTER(Params)]
         lib.dmnd_seed_search.argtypes = [ctypes.c_void_p, ctypes.POINTER(SeedParams), ctypes.POINTER(ctypes.c_int64)]
         lib.dmnd_seed_hits.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
         lib.dmnd_seed_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
@@ -171,6 +174,15 @@ def format_tab(matches, qids, tids):
             raise DiamondHipError(lib.dmnd_last_error().decode())
         out.append(buf.raw[:n].decode())
     return "".join(out)
+
+
+def seed_params_default(scoring, threads=1):
+    """Default-sensitivity seed configuration (2 shapes of weight 10, ungapped e-value filter 10000)."""
+    p = SeedParams()
+    rc = load().dmnd_seed_params_default(ctypes.byref(p), int(threads), ctypes.byref(scoring))
+    if rc != 0:
+        raise DiamondHipError(load().dmnd_last_error().decode())
+    return p
 
 
 def matrix_of(p):

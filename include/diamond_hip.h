@@ -169,6 +169,11 @@ typedef struct {
 	int32_t seedp_bits, index_chunks, hamming_filter_id;
 	int32_t ungapped_window, left_most_interval;
 	double seed_complexity_cut;
+	/* stage-2 ungapped window filter (src/search/stage2.h:43-63,107-113); use_ungapped = 0 <=> ungapped e-value 0 (--fast) */
+	int32_t use_ungapped, short_query_max_len, short_query_cutoff;
+	int32_t cutoff_table[32];     /* CutoffTable::data_ (src/util/scores/cutoff_table.h:26-47), index = bit length of the query length */
+	int32_t tile_size, simd_lanes; /* config.tile_size (1024); int8 lanes of the reference's SIMD build (32 = AVX2): the batch rule
+	                                  that decides whether a stage-2 score saturates at 255 (src/dp/ungapped_simd.cpp:69-87) */
 } dmnd_seed_params;
 
 /* One stage-2 seed hit = Search::Hit (src/search/hit.h:30-47): query context index, reference location
@@ -186,6 +191,9 @@ typedef struct {
  * 4 index chunks; search/setup.cpp:43,211-212) for `threads` reference threads (seedp_bits depends on it,
  * setup.cpp:306-309). */
 int dmnd_seed_params_fast(dmnd_seed_params* p, int threads);
+/* Default sensitivity (two shapes of weight 10: 111101110111, 111011010010111; ungapped e-value 10000, seed cut 0.8;
+ * search/setup.cpp:46,82-84); the cutoff table is derived from the scoring parameters (lambda, K). */
+int dmnd_seed_params_default(dmnd_seed_params* p, int threads, const dmnd_params* scoring);
 /* Runs the whole seed stage on the uploaded blocks (both must have been uploaded WITH limits). Supported:
  * spaced seeds, ungapped e-value filter off (the --fast family). Hits stay in device memory;
  * *n_hits returns their number. */

@@ -48,6 +48,11 @@ typedef struct {
 	int32_t reduction[32], reduction_size;
 	int32_t ungapped_window, left_most_interval;     /* config.ungapped_window (48), config.left_most_interval (32) */
 	double seed_complexity_cut;
+	/* stage-2 ungapped window filter (stage2.h:43-63, 107-113); use_ungapped = 0 when ungapped_evalue == 0 */
+	int32_t use_ungapped, short_query_max_len, short_query_cutoff;
+	int32_t cutoff_table[32];        /* CutoffTable::data_[bit_length(query_len)], util/scores/cutoff_table.h:26-47 */
+	int32_t tile_size, simd_lanes;   /* config.tile_size (1024), int8 lanes of the reference's SIMD build (32 for AVX2) */
+	int8_t matrix[32 * 32];          /* ScoreMatrix::matrix8 (= matrix32 values) for ungapped_window */
 } oracle_seed_cfg;
 
 typedef struct { uint32_t query; int32_t seed_offset; int64_t subject; int32_t score; int32_t pad; } oracle_hit;

@@ -102,13 +102,30 @@ class SeedCfg(ctypes.Structure):
                 ("shape_mask", ctypes.c_uint32 * 16), ("shape_pos", (ctypes.c_int32 * 32) * 16),
                 ("reduction", ctypes.c_int32 * 32), ("reduction_size", ctypes.c_int32),
                 ("ungapped_window", ctypes.c_int32), ("left_most_interval", ctypes.c_int32),
-                ("seed_complexity_cut", ctypes.c_double)]
+                ("seed_complexity_cut", ctypes.c_double),
+                ("use_ungapped", ctypes.c_int32), ("short_query_max_len", ctypes.c_int32), ("short_query_cutoff", ctypes.c_int32),
+                ("cutoff_table", ctypes.c_int32 * 32), ("tile_size", ctypes.c_int32), ("simd_lanes", ctypes.c_int32),
+                ("matrix", ctypes.c_int8 * 1024)]
+
+
+def ungapped_cutoffs(ungapped_evalue, lambda_=0.267, K=0.041, short_bits=25.0):
+    """(short-query cutoff, CutoffTable): rawscore(bits) = ceil((bits*ln2 + ln K)/lambda) (stats/score_matrix.h:130-134),
+    CutoffTable[b] = rawscore(-log(evalue / 1e9 / 2^(b-1)) / log 2) (util/scores/cutoff_table.h:30-35)."""
+    import math
+
+    def raw(bits):
+        return int(math.ceil((bits * 0.69314718055994530941723212145818 + math.log(K)) / lambda_))
+    table = [0] * 32
+    if ungapped_evalue > 0:
+        for b in range(1, 32):
+            table[b] = raw(-math.log(ungapped_evalue / 1e9 / (1 << (b - 1))) / math.log(2))
+    return raw(short_bits), table
 
 
 HIT_DTYPE = np.dtype([("query", "<u4"), ("seed_offset", "<i4"), ("subject", "<i8"), ("score", "<i4"), ("pad", "<i4")])
 
 
-def seed_cfg_from_tap(cfg):
+def seed_cfg_from_tap(cfg, matrix8=None):
     """Builds the oracle's configuration from the 'BLK1' header of an extend tap (tapfile.read_ext_tap)."""
     c = SeedCfg()
     c.seedp_bits, c.index_chunks, c.hamming_filter_id = cfg["seedp_bits"], cfg["index_chunks"], cfg["hamming_filter_id"]
@@ -122,6 +139,17 @@ def seed_cfg_from_tap(cfg):
     c.reduction_size = int(max(cfg["reduction"][:20])) + 1
     c.ungapped_window, c.left_most_interval = 48, 32
     c.seed_complexity_cut = cfg["seed_complexity_cut"]
+    c.use_ungapped = 1 if cfg["ungapped_evalue"] > 0 else 0
+    c.short_query_max_len = 60
+    short, table = ungapped_cutoffs(cfg["ungapped_evalue"])
+    c.short_query_cutoff = short
+    for i in range(32):
+        c.cutoff_table[i] = table[i]
+    c.tile_size, c.simd_lanes = 1024, 32
+    if matrix8 is not None:
+        m = np.ascontiguousarray(matrix8, dtype=np.int8).ravel()
+        for i in range(1024):
+            c.matrix[i] = int(m[i])
     return c
 
 

@@ -14,9 +14,14 @@
  *   reduced_match / seed_mask                                  src/search/sse_dist.h:104-200
  *   PatternMatcher::hit                                        src/util/algo/pattern_matcher.h:23-63
  *   Util::Seq::clip                                            src/util/sequence/sequence.h:30-40
- * Covered configuration: ungapped_evalue == 0 (the --fast family: no window scoring, Hit::score_ = 0xFFFF because
- * the reference leaves `scores[]` at INT_MAX, stage2.h:86,112), no self mode, no soft masking (run the reference
- * with --masking 0 --motif-masking 0).  Shapes and index chunks are processed in the reference's order so the
+ *   window_ungapped_best / ungapped_window (stage-2 score)      src/dp/ungapped_simd.cpp:32-87, dp/ungapped_align.cpp:244-258
+ *   ungapped_cutoff, CutoffTable                                src/search/stage2.h:43-63, util/scores/cutoff_table.h:26-47
+ * Covered: with ungapped_evalue == 0 (the --fast family) no window scoring happens and Hit::score_ = 0xFFFF because the
+ * reference leaves `scores[]` at INT_MAX (stage2.h:86,112); with ungapped_evalue > 0 (default, sensitive ...) the score
+ * is the best local ungapped score of the clipped +-48 window, EXACT when fewer than 4 subjects share the SIMD batch and
+ * saturated at 255 otherwise (batches = consecutive groups of `simd_lanes` Hamming survivors of one query position
+ * inside one 1024x1024 tile, subjects in ascending location order) -- the AVX2 behaviour SURVEY.md section 7 fixes as canonical.
+ * No self mode, no soft masking (run the reference with --masking 0 --motif-masking 0), no translated-query short rules.  Shapes and index chunks are processed in the reference's order so the
  * SEED_MASK bits written by mask_seeds are visible to later chunks exactly as in the reference.
  * Pinned by tests/test_oracle_seed.py against tests/golden/ext_*.tap (hits tapped at Extension::extend).
  */
@@ -204,6 +209,27 @@ static int left_most_filter(const oracle_seed_cfg* c, const int8_t* qdata, int q
 		&& (right_hit == 0 || !verify_hits(c, right_hit, q + window_left + 1, s + window_left + 1, 0, match_mask_right, sid, chunked, r));
 }
 
+/* ungapped_window: best local ungapped score over `window` aligned letters */
+static int ungapped_window(const oracle_seed_cfg* c, const int8_t* q, const int8_t* s, int window)
+{
+	int score = 0, st = 0;
+	for (int n = 0; n < window; ++n) {
+		st += c->matrix[(q[n] & LETTER_MASK) * 32 + (s[n] & LETTER_MASK)];
+		if (st < 0) st = 0;
+		if (st > score) score = st;
+	}
+	return score;
+}
+
+static int ungapped_cutoff(const oracle_seed_cfg* c, int query_len)
+{
+	if (!c->use_ungapped) return 0;
+	if (query_len <= c->short_query_max_len) return c->short_query_cutoff;
+	int b = 0;
+	for (unsigned x = (unsigned)query_len; x; x >>= 1) ++b;
+	return c->cutoff_table[b];
+}
+
 static int64_t enumerate(const oracle_seed_cfg* c, int sid, const int8_t* data, const int64_t* limits, int64_t n, range_t r, entry_t* out)
 {
 	int64_t m = 0;
@@ -272,16 +298,36 @@ int64_t oracle_seed_search(const oracle_seed_cfg* c, int8_t* qdata, const int64_
 							const int window_left = (int)((qdata + qloc) - cb), window_clipped = (int)(ce - cb);
 							const int interval_mod = c->left_most_interval > 0 ? seed_offset % c->left_most_interval : window_left;
 							const int overhang = window_left - interval_mod > 0 ? window_left - interval_mod : 0;
-							for (int64_t y = j; y < j1; ++y) {
-								const int64_t sloc = te[y].loc;
-								if (fingerprint_id(qdata + qloc, tdata + sloc) < c->hamming_filter_id) continue;
-								const int8_t* subject = tdata + sloc - window_left;
-								if (!left_most_filter(c, cb + overhang, window_clipped - overhang, subject + overhang, window_left - overhang, sid, chunked, r))
-									continue;
-								if (n_hits >= cap) { n_hits = -1; break; }
-								hits[n_hits].query = (uint32_t)query_id; hits[n_hits].subject = sloc;
-								hits[n_hits].seed_offset = seed_offset; hits[n_hits].score = 0xFFFF;
-								++n_hits;
+							const int query_len = (int)(qlimits[query_id + 1] - qlimits[query_id] - 1);
+							const int cutoff = ungapped_cutoff(c, query_len);
+							/* search_tile / search_query_offset: per S tile, Hamming survivors in batches of simd_lanes */
+							const int64_t tile = c->tile_size > 0 ? c->tile_size : (j1 - j);
+							for (int64_t tj = j; tj < j1 && n_hits >= 0; tj += tile) {
+								const int64_t tj1 = tj + tile < j1 ? tj + tile : j1;
+								int64_t* surv = (int64_t*)malloc(sizeof(int64_t) * (size_t)(tj1 - tj));
+								int64_t ns = 0;
+								for (int64_t y = tj; y < tj1; ++y)
+									if (fingerprint_id(qdata + qloc, tdata + te[y].loc) >= c->hamming_filter_id) surv[ns++] = te[y].loc;
+								for (int64_t b0 = 0; b0 < ns && n_hits >= 0; b0 += c->simd_lanes) {
+									const int64_t nb = ns - b0 < c->simd_lanes ? ns - b0 : c->simd_lanes;
+									for (int64_t y = b0; y < b0 + nb; ++y) {
+										const int64_t sloc = surv[y];
+										const int8_t* subject = tdata + sloc - window_left;
+										int score = 0xFFFF;
+										if (cutoff) {
+											score = ungapped_window(c, cb, subject, window_clipped);
+											if (nb >= 4 && score > 255) score = 255;
+											if (score <= cutoff) continue;
+										}
+										if (!left_most_filter(c, cb + overhang, window_clipped - overhang, subject + overhang, window_left - overhang, sid, chunked, r))
+											continue;
+										if (n_hits >= cap) { n_hits = -1; break; }
+										hits[n_hits].query = (uint32_t)query_id; hits[n_hits].subject = sloc;
+										hits[n_hits].seed_offset = seed_offset; hits[n_hits].score = score;
+										++n_hits;
+									}
+								}
+								free(surv);
 							}
 						}
 					}

@@ -12,7 +12,7 @@ using namespace dmnd;
 
 struct EmuHit { uint32_t query; int32_t seed_offset; int64_t subject; int32_t score; int32_t pad; };
 
-extern "C" int64_t emu_seed_search(const SeedParams* cp, const int8_t* qdata, const int64_t* qlimits, int64_t nq,
+extern "C" int64_t emu_seed_search(const SeedParams* cp, const int8_t* matrix, const int8_t* qdata, const int64_t* qlimits, int64_t nq,
 	const int8_t* tdata, const int64_t* tlimits, int64_t nt, EmuHit* hits, int64_t cap)
 {
 	const SeedParams& c = *cp;
@@ -21,7 +21,9 @@ extern "C" int64_t emu_seed_search(const SeedParams* cp, const int8_t* qdata, co
 	std::vector<uint32_t> qid_of((size_t)qraw, 0);
 	for (int64_t i = 0; i < nq; ++i)
 		for (int64_t p = qlimits[i]; p < qlimits[i + 1]; ++p) qid_of[(size_t)p] = (uint32_t)i;
-	struct Group { std::vector<int64_t> q; bool present = false, erased = false; };
+	struct Group { std::vector<int64_t> q; bool present = false, erased = false; uint32_t s_head = 0xffffffffu; };
+	std::vector<std::vector<int64_t>> m_loc(c.n_shapes);       // matched_loc / s_next exactly as the stream kernel builds them
+	std::vector<std::vector<uint32_t>> m_next(c.n_shapes);
 	std::vector<std::unordered_map<uint64_t, Group>> tables(c.n_shapes);
 	std::vector<std::vector<std::pair<uint64_t, int64_t>>> matched(c.n_shapes);
 	// phase 1: index queries, stream the reference, complexity masks -- for every shape
@@ -38,6 +40,9 @@ extern "C" int64_t emu_seed_search(const SeedParams* cp, const int8_t* qdata, co
 			if (it == tab.end()) continue;
 			it->second.present = true;
 			matched[sid].push_back({ s, p });
+			m_loc[sid].push_back(p);
+			m_next[sid].push_back(it->second.s_head);            // atomicExch(&s_heads[slot], idx)
+			it->second.s_head = (uint32_t)(m_loc[sid].size() - 1);
 		}
 		for (auto& kv : tab) {
 			Group& g = kv.second;
@@ -61,9 +66,25 @@ extern "C" int64_t emu_seed_search(const SeedParams* cp, const int8_t* qdata, co
 				if (fingerprint_id(qdata + qp, tdata + m.second) < c.hamming_filter_id) continue;
 				const uint32_t qid = qid_of[(size_t)qp];
 				const int seed_offset = (int)(qp - qlimits[qid]);
+				int score = 0xFFFF;
+				if (c.use_ungapped) {
+					const int cutoff = ungapped_cutoff(c, (int)(qlimits[qid + 1] - qlimits[qid] - 1));
+					if (cutoff) {
+						const int window = c.ungapped_window;
+						int cb, ce;
+						clip_window(qdata + qp - window, 2 * window, window, cb, ce);
+						const int window_left = window - cb;
+						score = ungapped_window_score(matrix, qdata + qp - window_left, tdata + m.second - window_left, ce - cb);
+						if (score > 255) {
+							const SList l{ m_loc[sid].data(), m_next[sid].data(), g.s_head };
+							if (simd_batch_size(c, l, tdata, qdata + qp, m.second) >= 4) score = 255;
+						}
+						if (score <= cutoff) continue;
+					}
+				}
 				if (!left_most_pair(c, qdata + qp, mask_time.data() + qp, tdata + m.second, seed_offset, sid, chunk)) continue;
 				if (n >= cap) return -1;
-				hits[n++] = EmuHit{ qid, seed_offset, m.second, 0xFFFF, 0 };
+				hits[n++] = EmuHit{ qid, seed_offset, m.second, score, 0 };
 			}
 		}
 	return n;

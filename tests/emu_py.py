@@ -68,7 +68,9 @@ class SeedParams(ctypes.Structure):
                 ("reduction", ctypes.c_int8 * 32), ("reduction_size", ctypes.c_int32),
                 ("seedp_bits", ctypes.c_int32), ("index_chunks", ctypes.c_int32), ("hamming_filter_id", ctypes.c_int32),
                 ("ungapped_window", ctypes.c_int32), ("left_most_interval", ctypes.c_int32),
-                ("seed_complexity_cut", ctypes.c_double)]
+                ("seed_complexity_cut", ctypes.c_double),
+                ("use_ungapped", ctypes.c_int32), ("short_query_max_len", ctypes.c_int32), ("short_query_cutoff", ctypes.c_int32),
+                ("cutoff_table", ctypes.c_int32 * 32), ("tile_size", ctypes.c_int32), ("simd_lanes", ctypes.c_int32)]
 
 
 HIT_DTYPE = np.dtype([("query", "<u4"), ("seed_offset", "<i4"), ("subject", "<i8"), ("score", "<i4"), ("pad", "<i4")])
@@ -87,10 +89,17 @@ def seed_params_from_tap(cfg):
     c.seedp_bits, c.index_chunks, c.hamming_filter_id = cfg["seedp_bits"], cfg["index_chunks"], cfg["hamming_filter_id"]
     c.ungapped_window, c.left_most_interval = 48, 32
     c.seed_complexity_cut = cfg["seed_complexity_cut"]
+    import oracle_py
+    short, table = oracle_py.ungapped_cutoffs(cfg["ungapped_evalue"])
+    c.use_ungapped = 1 if cfg["ungapped_evalue"] > 0 else 0
+    c.short_query_max_len, c.short_query_cutoff = 60, short
+    for i in range(32):
+        c.cutoff_table[i] = table[i]
+    c.tile_size, c.simd_lanes = 1024, 32
     return c
 
 
-def seed_search(c, qdata, qlimits, tdata, tlimits, cap=1 << 22):
+def seed_search(c, qdata, qlimits, tdata, tlimits, cap=1 << 22, matrix8=None):
     qd = np.ascontiguousarray(qdata, dtype=np.int8)
     td = np.ascontiguousarray(tdata, dtype=np.int8)
     ql = np.ascontiguousarray(qlimits, dtype=np.int64)
@@ -98,8 +107,9 @@ def seed_search(c, qdata, qlimits, tdata, tlimits, cap=1 << 22):
     hits = np.zeros(cap, dtype=HIT_DTYPE)
     f = lib().emu_seed_search
     f.restype = ctypes.c_int64
-    n = f(ctypes.byref(c), qd.ctypes.data_as(ctypes.c_void_p), ql.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(len(ql) - 1),
-          td.ctypes.data_as(ctypes.c_void_p), tl.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(len(tl) - 1),
+    m = np.ascontiguousarray(matrix8 if matrix8 is not None else np.zeros(1024), dtype=np.int8)
+    n = f(ctypes.byref(c), m.ctypes.data_as(ctypes.c_void_p), qd.ctypes.data_as(ctypes.c_void_p), ql.ctypes.data_as(ctypes.c_void_p),
+          ctypes.c_int64(len(ql) - 1), td.ctypes.data_as(ctypes.c_void_p), tl.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(len(tl) - 1),
           hits.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(cap))
     assert n >= 0
     return hits[:n].copy()

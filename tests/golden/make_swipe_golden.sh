@@ -69,5 +69,11 @@ synth.write_fasta(sys.argv[1] + "/r_q.faa", "q", q, qo)
 PY
 DIAMOND_TAP_EXT="$HERE/ext_rank.tap" \
   "$TAP" blastp --fast --masking 0 --motif-masking 0 --algo 0 -q "$TMP/r_q.faa" -d "$TMP/r_db.faa" -o "$HERE/rank.tsv" -p1 2>/dev/null
+# 7. default sensitivity (two weight-10 shapes + the stage-2 ungapped e-value filter): the reference's
+#    own fixture, and the synthetic block (whose conserved families push window scores past 255 -> int8 saturation rule)
+DIAMOND_TAP_EXT="$HERE/ext_default.tap" \
+  "$TAP" blastp --masking 0 --motif-masking 0 --algo 0 -q "$REFTEST/data.faa" -d "$REFTEST/data.faa" -o "$HERE/default.tsv" -p1 2>/dev/null
+DIAMOND_TAP_EXT="$HERE/ext_default_synth.tap" \
+  "$TAP" blastp --masking 0 --motif-masking 0 --algo 0 -q "$TMP/s_q.faa" -d "$TMP/s_db.faa" -o "$HERE/default_synth.tsv" -p4 2>/dev/null
 ls -la "$HERE"/*.tap
 rm -rf "$TMP"

@@ -75,3 +75,23 @@ def test_banded_cols_matches_oracle():
 def test_no_cpu_fallback_without_gpu():
     with pytest.raises(hip.DiamondHipError):
         hip.Context()
+
+
+def test_seed_parameter_presets_equal_the_reference_configuration():
+    """dmnd_seed_params_fast / _default (host-only, no GPU call) must reproduce the configuration the genuine reference
+    ran with, as tapped into the golden headers (shapes, partition bits, Hamming id, complexity cut, cutoff table)."""
+    import ctypes, os
+    import emu_py as emu
+    from tapfile import read_ext_tap
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for tap, make in (("ext_fast.tap", lambda: hip.seed_params_fast(1)),
+                      ("ext_default.tap", lambda: hip.seed_params_default(hip.default_params(), 1))):
+        cfg, _ = read_ext_tap(os.path.join(golden, tap), max_records=1)
+        want, got = emu.seed_params_from_tap(cfg), make()
+        for name, _t in hip.SeedParams._fields_:
+            a, b = getattr(got, name), getattr(want, name)
+            if hasattr(a, "_length_"):
+                a, b = bytes(a), bytes(b)
+            if tap == "ext_fast.tap" and name in ("short_query_cutoff", "cutoff_table"):
+                continue                                             # unused when use_ungapped == 0
+            assert a == b, (tap, name)

@@ -33,7 +33,7 @@ def _run(ctx, cfg, db_letters):
     return ctx.extend(qd, td, hits, threads=4)[0]
 
 
-@pytest.mark.parametrize("tap", ["ext_fast_synth.tap", "ext_fast.tap", "ext_6x10.tap", "ext_rank.tap"])
+@pytest.mark.parametrize("tap", ["ext_fast_synth.tap", "ext_fast.tap", "ext_6x10.tap", "ext_rank.tap", "ext_default.tap", "ext_default_synth.tap"])
 def test_matches_equal_reference_extend(ctx, tap):
     cfg, recs = read_ext_tap(os.path.join(GOLDEN, tap))
     tl = cfg["target"]["limits"]
@@ -58,13 +58,17 @@ def test_matches_equal_reference_extend(ctx, tap):
     assert pos == len(m) and n > 300
 
 
-@pytest.mark.parametrize("tap,tsv", [("ext_fast_synth.tap", "fast_synth.tsv"), ("ext_rank.tap", "rank.tsv")])
+@pytest.mark.parametrize("tap,tsv", [("ext_fast_synth.tap", "fast_synth.tsv"), ("ext_rank.tap", "rank.tsv"),
+                                     ("ext_default_synth.tap", "default_synth.tsv"), ("ext_default.tap", "default.tsv")])
 def test_tabular_output_is_byte_identical_to_reference(ctx, tap, tsv):
     cfg, recs = read_ext_tap(os.path.join(GOLDEN, tap))
     tl = cfg["target"]["limits"]
     m = _run(ctx, cfg, float(tl[-1] - tl[0] - (len(tl) - 1)))
-    qids = ["q%d" % i for i in range(cfg["query"]["n"])]
-    tids = ["t%d" % i for i in range(cfg["target"]["n"])]
+    if tsv == "default.tsv":                                       # the reference's own fixture (src/test/data.faa) against itself
+        qids = tids = open(os.path.join(GOLDEN, "data_ids.txt")).read().split()
+    else:
+        qids = ["q%d" % i for i in range(cfg["query"]["n"])]
+        tids = ["t%d" % i for i in range(cfg["target"]["n"])]
     text = hip.format_tab(m, qids, tids)
     ref = open(os.path.join(GOLDEN, tsv)).read()
     assert len(ref.splitlines()) > 300
