@@ -308,8 +308,9 @@ int64_t oracle_seed_search(const oracle_seed_cfg* c, int8_t* qdata, const int64_
 								int64_t ns = 0;
 								for (int64_t y = tj; y < tj1; ++y)
 									if (fingerprint_id(qdata + qloc, tdata + te[y].loc) >= c->hamming_filter_id) surv[ns++] = te[y].loc;
-								for (int64_t b0 = 0; b0 < ns && n_hits >= 0; b0 += c->simd_lanes) {
-									const int64_t nb = ns - b0 < c->simd_lanes ? ns - b0 : c->simd_lanes;
+								const int64_t lanes = c->simd_lanes > 0 ? c->simd_lanes : 32;
+								for (int64_t b0 = 0; b0 < ns && n_hits >= 0; b0 += lanes) {
+									const int64_t nb = ns - b0 < lanes ? ns - b0 : lanes;
 									for (int64_t y = b0; y < b0 + nb; ++y) {
 										const int64_t sloc = surv[y];
 										const int8_t* subject = tdata + sloc - window_left;

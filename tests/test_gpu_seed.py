@@ -88,6 +88,7 @@ def test_seed_stage_c1_scale_against_oracle_and_properties(ctx):
     for i in range(32):
         oc.reduction[i] = p.reduction[i]
     oc.reduction_size, oc.ungapped_window, oc.left_most_interval, oc.seed_complexity_cut = 10, 48, 32, p.seed_complexity_cut
+    oc.tile_size, oc.simd_lanes = p.tile_size, p.simd_lanes
     a = orc.seed_search(oc, qd, ql, td, tl)
     assert len(hits) == len(a) > 1000 and hit_set(hits) == hit_set(a)
     # properties: every hit is a true seed match inside its sequences, deterministic across runs
