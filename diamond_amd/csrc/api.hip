@@ -106,7 +106,7 @@ extern "C" void dmnd_destroy(dmnd_ctx* c)
 	for (DevBuf* b : { &c->block[0], &c->block[1], &c->cbs, &c->matrix, &c->items, &c->order, &c->p_of_slot, &c->trace_off,
 		&c->transcript_off, &c->ends, &c->hsps, &c->trace, &c->transcript, &c->status, &c->host_q, &c->host_t, &c->host_cbs,
 		&c->d_limits[0], &c->d_limits[1], &c->qid_of, &c->mask_time, &c->seed_keys, &c->seed_heads, &c->seed_next, &c->seed_flags,
-		&c->matched_slot, &c->matched_loc, &c->counters, &c->seed_hits, &c->seed_bitmap, &c->seed_sheads, &c->seed_snext })
+		&c->matched_slot, &c->matched_loc, &c->counters, &c->seed_hits, &c->seed_bitmap, &c->seed_sheads, &c->seed_snext, &c->gf_tables, &c->gf_hits, &c->gf_flags, &c->gf_scores })
 		b->release();
 	if (c->ev0) (void)hipEventDestroy(c->ev0);
 	if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -150,7 +150,7 @@ extern "C" int dmnd_upload_cbs(dmnd_ctx* c, const int8_t* cbs, int64_t len)
 	c->cbs_len = len;
 	if (len == 0)
 		return DMND_OK;
-	if (int rc = c->cbs.ensure((size_t)len + 64)) return rc;
+	if (int rc = c->cbs.ensure((size_t)len + 256)) return rc;      // slack: the gapped filter reads up to 130 bytes past a query (values unused)
 	HIP_TRY(hipMemcpyAsync(c->cbs.p, cbs, (size_t)len, hipMemcpyHostToDevice, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	return DMND_OK;

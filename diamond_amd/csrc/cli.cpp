@@ -6,7 +6,7 @@
 // ReferenceHeader 40 bytes, ReferenceHeader2 as a size-prefixed record, per sequence 0xFF letters 0xFF id 0, trailer of
 // (pos u64, len u32, pad u32) records), SequenceSet layout (src/data/string_set.h:27-60), tabular output
 // (src/output/blast_tab_format.cpp, sequence ids cut at the first blank).
-// Supported: blastp --fast with masking off (tantan/SEG/motif masking are host pre-processing that is not restated yet:
+// Supported: blastp (--fast, default sensitivity, --sensitive) with masking off (tantan/SEG/motif masking are host pre-processing that is not restated yet:
 // the tool insists on --masking 0 semantics and says so), -e, -k, -p, -f 6 default columns.
 #include <algorithm>
 #include <chrono>
@@ -216,8 +216,9 @@ double ms_since(std::chrono::steady_clock::time_point t) { return std::chrono::d
 int run_blastp(const Options& o)
 {
 	if (o.query.empty() || o.db.empty()) throw std::runtime_error("Missing parameter: query (--query/-q) and database (--db/-d) are required.");
-	if (!o.fast || !o.sens.empty())
-		throw std::runtime_error("This build implements the --fast sensitivity only (default/sensitive modes need the ungapped and gapped filters, SURVEY.md 8 rows a7/a11).");
+	if (!o.sens.empty() && o.sens != "--sensitive")
+		throw std::runtime_error("This build implements the --fast, default and --sensitive modes only (" + o.sens + " is not available).");
+	if (o.fast && !o.sens.empty()) throw std::runtime_error("Conflicting sensitivity options.");
 	if (o.masking != "0" || (o.motif_masking != "0" && !o.motif_masking.empty()))
 		std::cerr << "Warning: repeat masking (tantan / motif) is not implemented; running as --masking 0 --motif-masking 0.\n";
 	const auto t_all = std::chrono::steady_clock::now();
@@ -242,7 +243,9 @@ int run_blastp(const Options& o)
 	std::cerr << "Uploading blocks to HBM...  [" << ms_since(t0) / 1e3 << "s]\n";
 	const int threads = o.threads > 0 ? o.threads : 8;
 	dmnd_seed_params sp;
-	chk(dmnd_seed_params_fast(&sp, threads));
+	if (o.fast) chk(dmnd_seed_params_fast(&sp, threads));
+	else if (o.sens == "--sensitive") { chk(dmnd_seed_params_sensitive(&sp, threads, &p)); chk(dmnd_set_gapped_filter(ctx, 1.0)); }
+	else chk(dmnd_seed_params_default(&sp, threads, &p));
 	t0 = std::chrono::steady_clock::now();
 	int64_t n_hits = 0;
 	chk(dmnd_seed_search(ctx, &sp, &n_hits));
@@ -282,7 +285,7 @@ int main(int argc, char** argv)
 		if (o.command == "version") { std::cout << "diamond-hip (MI355X back end of DIAMOND's seed-and-extend path), ABI " << dmnd_abi_version() << "\n"; return 0; }
 		if (o.command == "help" || o.command == "--help") {
 			std::cout << "Syntax: diamond-hip COMMAND [OPTIONS]\n  makedb --in FASTA -d DB        build a .dmnd database (no masking)\n"
-				"  blastp --fast -q FASTA -d DB(.dmnd|FASTA) -o OUT [--masking 0] [-e EVALUE] [-k N] [-p THREADS]\n  version\n";
+				"  blastp [--fast|--sensitive] -q FASTA -d DB(.dmnd|FASTA) -o OUT [--masking 0] [-e EVALUE] [-k N] [-p THREADS]\n  version\n";
 			return 0;
 		}
 		if (o.command == "makedb") {

@@ -46,6 +46,9 @@ struct dmnd_ctx {
 	// seed-stage buffers (seed_api.hip)
 	dmnd::DevBuf qid_of, mask_time, seed_keys, seed_heads, seed_next, seed_flags, matched_slot, matched_loc, counters, seed_hits, seed_bitmap, seed_sheads, seed_snext;
 	int64_t n_seed_hits = 0;
+	// gapped filter (gapped_api.hip)
+	dmnd::DevBuf gf_tables, gf_hits, gf_flags, gf_scores;
+	double gapped_filter_evalue = 0.0, gf_ms = 0.0;
 	double seed_ms[5] = { 0, 0, 0, 0, 0 };
 	// extension-stage statistics of the last dmnd_extend (extend_host.hip)
 	double ext_stats[12] = { 0 };

@@ -99,7 +99,7 @@ int64_t ranking_chunk_size(double ref_letters, int max_target_seqs)       // ext
 struct PlanTarget { uint32_t query, target; int32_t d_begin, d_end, ungapped_score; };
 
 // One query's seed hits grouped by target (SeedHitList of load_hits) + its ranking state (extend.cpp:226-344)
-struct TargetGroup { uint32_t target; size_t begin, end; int score; };
+struct TargetGroup { uint32_t target; size_t begin, end; int score; bool pass; };      // pass: survives the gapped filter (any hit flagged)
 
 struct QueryWork {
 	uint32_t query = 0;
@@ -111,9 +111,11 @@ struct QueryWork {
 };
 
 // load_hits (load_hits.h:44-127) + the target ranking of extend() (extend.cpp:403-414)
-void load_query(const HostCfg& h, QueryWork& w, uint32_t query, const dmnd_seed_hit* hb, const dmnd_seed_hit* he, const int64_t* tl, int64_t nt)
+void load_query(const HostCfg& h, QueryWork& w, uint32_t query, const dmnd_seed_hit* hb, const dmnd_seed_hit* he, const uint8_t* gf_flags,
+	const int64_t* tl, int64_t nt)
 {
 	std::vector<dmnd_seed_hit> hits(hb, he);
+	for (size_t x = 0; x < hits.size(); ++x) hits[x].pad = gf_flags ? gf_flags[x] : 1;      // carried through the sort below
 	std::sort(hits.begin(), hits.end(), [](const dmnd_seed_hit& a, const dmnd_seed_hit& b) {       // Hit::CmpSubject
 		return a.subject < b.subject || (a.subject == b.subject && (a.query < b.query || (a.query == b.query && a.seed_offset < b.seed_offset)));
 	});
@@ -126,10 +128,11 @@ void load_query(const HostCfg& h, QueryWork& w, uint32_t query, const dmnd_seed_
 		it = std::upper_bound(it, tl + nt + 1, s);
 		const uint32_t t = (uint32_t)(it - tl) - 1;
 		--it;
-		if (w.groups.empty() || w.groups.back().target != t) w.groups.push_back(TargetGroup{ t, x, x, 0 });
+		if (w.groups.empty() || w.groups.back().target != t) w.groups.push_back(TargetGroup{ t, x, x, 0, false });
 		w.sh[x] = HostSeedHit{ hits[x].seed_offset, (int)(s - tl[t]), hits[x].score };
 		w.groups.back().end = x + 1;
 		w.groups.back().score = std::max(w.groups.back().score, (int)(uint16_t)hits[x].score);
+		w.groups.back().pass |= hits[x].pad != 0;        // gapped-filter flag of the hit (1 everywhere when the filter is off)
 	}
 	w.order.resize(w.groups.size());
 	for (size_t i = 0; i < w.order.size(); ++i) w.order[i] = (uint32_t)i;
@@ -155,6 +158,7 @@ void plan_groups(const HostCfg& h, ChainWorkspace& ws, QueryWork& w, size_t g0, 
 	const int base_band = band_for(q.len, h.band_mode_fast != 0);
 	for (size_t gi = g0; gi < g1; ++gi) {
 		const TargetGroup& g = w.groups[w.order[gi]];
+		if (!g.pass) continue;                               // gapped filter (extend.cpp:205-213): dropped before chaining
 		const SeqRef t{ tdata + tl[g.target], (int)(tl[g.target + 1] - tl[g.target] - 1) };
 		std::sort(sh.begin() + (ptrdiff_t)g.begin, sh.begin() + (ptrdiff_t)g.end, [](const HostSeedHit& a, const HostSeedHit& b) {
 			const int d1 = a.i - a.j, d2 = b.i - b.j;
@@ -227,7 +231,7 @@ int plan_all(const HostCfg& h, int threads, const dmnd_seed_hit* hits, int64_t n
 	std::vector<ChainWorkspace> ws((size_t)threads);
 	parallel_for(qr.size(), threads, [&](size_t i, int t) {
 		QueryWork w;
-		load_query(h, w, hits[qr[i].b].query, hits + qr[i].b, hits + qr[i].e, tl.data(), (int64_t)tl.size() - 1);
+		load_query(h, w, hits[qr[i].b].query, hits + qr[i].b, hits + qr[i].e, nullptr, tl.data(), (int64_t)tl.size() - 1);
 		plan_groups(h, ws[(size_t)t], w, 0, w.order.size(), qdata, ql.data(), tdata, tl.data(), cbs_all, per[i]);
 	});
 	size_t total = 0;
@@ -363,11 +367,19 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	all_hauser(h, threads, qdata, ql, cbs);
 	if (int rc = dmnd_upload_cbs(c, cbs.data(), ql.back())) return rc;
 	lap(4);
+	// 1b. gapped filter of every seed hit in one launch (only --sensitive and above; extend.cpp:205-213)
+	std::vector<uint8_t> gf;
+	c->gf_ms = 0;
+	if (c->gapped_filter_evalue > 0.0 && n_hits > 0) {
+		gf.resize((size_t)n_hits);
+		if (int rc = dmnd_gapped_filter(c, hits, n_hits, 1, gf.data(), nullptr)) return rc;
+	}
+	lap(4);
 	// 2. load_hits for every query
 	const std::vector<Range> qr = split_by_query(hits, n_hits);
 	std::vector<QueryState> qs(qr.size());
 	parallel_for(qr.size(), threads, [&](size_t i, int) {
-		load_query(h, qs[i].w, hits[qr[i].b].query, hits + qr[i].b, hits + qr[i].e, tl.data(), (int64_t)tl.size() - 1);
+		load_query(h, qs[i].w, hits[qr[i].b].query, hits + qr[i].b, hits + qr[i].e, gf.empty() ? nullptr : gf.data() + qr[i].b, tl.data(), (int64_t)tl.size() - 1);
 		if (qs[i].w.order.empty()) qs[i].done = true;
 	});
 	std::vector<ChainWorkspace> ws((size_t)threads);

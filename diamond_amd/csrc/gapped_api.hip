@@ -1,0 +1,87 @@
+// gapped_api.hip -- C ABI of the gapped filter: dmnd_set_gapped_filter, dmnd_gapped_filter.
+// Replaces Extension::gapped_filter (src/align/gapped_filter.cpp:80-109) for a whole batch of seed hits.
+#include <cmath>
+#include <vector>
+#include "ctx.h"
+#include "gapped_kernels.h"
+
+using namespace dmnd;
+
+namespace {
+
+// CutoffTable2D(evalue) (util/scores/cutoff_table.h:50-83) over ScoreMatrix::evalue_norm (score_matrix.cpp:222-225):
+// smallest raw score in [10, 1000) whose e-value, normalised to a database of 1e9 letters, is <= evalue
+void cutoff_table2d(const dmnd_ctx* c, double evalue, int32_t* table)
+{
+	Evaluer e = c->evaluer;
+	e.db_letters = 1e9;
+	for (int i = 0; i < 32 * 32; ++i) table[i] = 0;
+	for (int b1 = 1; b1 <= 31; ++b1)
+		for (int b2 = 1; b2 <= 31; ++b2) {
+			int r = 1000;
+			for (int i = 10; i < 1000; ++i)
+				if (e.evalue(i, 1u << (b1 - 1), 1u << (b2 - 1)) <= evalue) { r = i; break; }
+			table[b1 * 32 + b2] = r;
+		}
+}
+
+}
+
+extern "C" int dmnd_set_gapped_filter(dmnd_ctx* c, double evalue)
+{
+	if (!c || !(evalue >= 0.0)) return fail(DMND_E_ARG, "dmnd_set_gapped_filter: bad argument");
+	HIP_TRY(hipSetDevice(c->device));
+	c->gapped_filter_evalue = evalue;
+	if (evalue == 0.0) return DMND_OK;
+	std::vector<int32_t> t(2 * 32 * 32);
+	cutoff_table2d(c, 2000.0, t.data());                    // config.gapped_filter_evalue1, basic/config.cpp:567
+	cutoff_table2d(c, evalue, t.data() + 32 * 32);          // Search::Config::gapped_filter_evalue, run/double_indexed.cpp:301-305
+	if (int rc = c->gf_tables.ensure(t.size() * sizeof(int32_t))) return rc;
+	HIP_TRY(hipMemcpy(c->gf_tables.p, t.data(), t.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+	return DMND_OK;
+}
+
+extern "C" int dmnd_gapped_filter(dmnd_ctx* c, const dmnd_seed_hit* hits, int64_t n_hits, int use_cbs_flag, uint8_t* flags, int32_t* scores)
+{
+	if (!c || (!hits && n_hits) || (!flags && n_hits)) return fail(DMND_E_ARG, "dmnd_gapped_filter: NULL argument");
+	if (n_hits < 0) return fail(DMND_E_ARG, "dmnd_gapped_filter: negative count");
+	if (c->gapped_filter_evalue <= 0.0) return fail(DMND_E_ARG, "dmnd_gapped_filter: filter is off (dmnd_set_gapped_filter)");
+	if (!c->block[DMND_QUERY].p || !c->block[DMND_TARGET].p || c->limits[DMND_QUERY].size() < 2 || c->limits[DMND_TARGET].size() < 2)
+		return fail(DMND_E_ARG, "dmnd_gapped_filter: blocks must be uploaded with limits");
+	const bool use_cbs = use_cbs_flag != 0;
+	if (use_cbs && c->cbs_len < c->limits[DMND_QUERY].back()) return fail(DMND_E_ARG, "dmnd_gapped_filter: query bias not uploaded (dmnd_upload_cbs)");
+	c->gf_ms = 0;
+	if (n_hits == 0) return DMND_OK;
+	HIP_TRY(hipSetDevice(c->device));
+	hipStream_t st = c->stream;
+	if (int rc = c->gf_hits.ensure((size_t)n_hits * sizeof(dmnd_seed_hit))) return rc;
+	if (int rc = c->gf_flags.ensure((size_t)n_hits)) return rc;
+	if (scores) if (int rc = c->gf_scores.ensure((size_t)n_hits * 2 * sizeof(int32_t))) return rc;
+	HIP_TRY(hipMemcpyAsync(c->gf_hits.p, hits, (size_t)n_hits * sizeof(dmnd_seed_hit), hipMemcpyHostToDevice, st));
+	GfArgs a;
+	const double LN2 = 0.69314718055994530941723212145818;
+	a.p.diag_score = (int32_t)std::ceil((12.0 * LN2 + std::log(c->params.K)) / c->params.lambda);    // rawscore(gapped_filter_diag_bit_score), setup.cpp:368
+	a.p.gap_open = c->params.gap_open; a.p.gap_extend = c->params.gap_extend;
+	a.p.window2 = 200;                                                                               // config.gapped_filter_window
+	a.p.use_cbs = use_cbs ? 1 : 0;
+	a.qdata = c->block[DMND_QUERY].as<int8_t>(); a.tdata = c->block[DMND_TARGET].as<int8_t>(); a.cbs = c->cbs.as<int8_t>();
+	a.qlimits = c->d_limits[DMND_QUERY].as<int64_t>(); a.tlimits = c->d_limits[DMND_TARGET].as<int64_t>();
+	a.n_targets = (int64_t)c->limits[DMND_TARGET].size() - 1;
+	a.matrix = c->matrix.as<int8_t>();
+	a.cutoff1 = c->gf_tables.as<int32_t>(); a.cutoff2 = a.cutoff1 + 32 * 32;
+	a.hits = c->gf_hits.as<dmnd_seed_hit>(); a.n_hits = n_hits;
+	a.flags = c->gf_flags.as<uint8_t>();
+	a.scores = scores ? c->gf_scores.as<int32_t>() : nullptr;
+	HIP_TRY(hipEventRecord(c->ev0, st));
+	HIP_TRY(launch_gapped_filter(a, st));
+	HIP_TRY(hipEventRecord(c->ev1, st));
+	HIP_TRY(hipMemcpyAsync(flags, c->gf_flags.p, (size_t)n_hits, hipMemcpyDeviceToHost, st));
+	if (scores) HIP_TRY(hipMemcpyAsync(scores, c->gf_scores.p, (size_t)n_hits * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	float ms = 0;
+	HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+	c->gf_ms = ms;
+	return DMND_OK;
+}
+
+extern "C" double dmnd_gapped_filter_ms(const dmnd_ctx* c) { return c ? c->gf_ms : 0.0; }

@@ -47,13 +47,15 @@ extern "C" int dmnd_seed_params_fast(dmnd_seed_params* p, int threads)
 	return DMND_OK;
 }
 
-extern "C" int dmnd_seed_params_default(dmnd_seed_params* p, int threads, const dmnd_params* sc)
+namespace {
+
+// shapes + the stage-2 ungapped e-value filter (10000) shared by the default and sensitive presets
+int spaced_preset(dmnd_seed_params* p, int threads, const dmnd_params* sc, const char* const* codes, int n, double seed_cut)
 {
-	if (!p || !sc || threads < 1) return fail(DMND_E_ARG, "dmnd_seed_params_default: bad argument");
 	if (int rc = dmnd_seed_params_fast(p, threads)) return rc;
-	const char* codes[2] = { "111101110111", "111011010010111" };          // shape_codes[DEFAULT], search/setup.cpp:82-84
-	p->n_shapes = 2;
-	for (int sid = 0; sid < 2; ++sid) {
+	p->n_shapes = n;
+	int weight = 0;
+	for (int sid = 0; sid < n; ++sid) {
 		int w = 0;
 		const int len = (int)std::strlen(codes[sid]);
 		p->shape_mask[sid] = 0;
@@ -61,10 +63,11 @@ extern "C" int dmnd_seed_params_default(dmnd_seed_params* p, int threads, const 
 		for (int i = 0; i < len; ++i)
 			if (codes[sid][i] == '1') { p->shape_pos[sid][w++] = (int8_t)i; p->shape_mask[sid] |= 1u << i; }
 		p->shape_len[sid] = len; p->shape_weight[sid] = w;
+		weight = w;
 	}
 	auto bit_length = [](uint64_t x) { int b = 0; while (x) { ++b; x >>= 1; } return b; };
 	p->seedp_bits = std::max(std::max(bit_length(10000000000ull - 1) - 32, bit_length((uint64_t)threads * 4 * p->index_chunks - 1)), 8);
-	p->seed_complexity_cut = 0.8 * 0.69314718055994530942 * 10;
+	p->seed_complexity_cut = seed_cut * 0.69314718055994530942 * weight;       // setup.cpp:369-370
 	// ungapped e-value 10000: CutoffTable + short-query cutoff (cutoff_table.h:30-35, score_matrix.h:130-151, config.cpp:431)
 	const double LN2 = 0.69314718055994530941723212145818, ln_k = std::log(sc->K);
 	auto raw = [&](double bits) { return (int32_t)std::ceil((bits * LN2 + ln_k) / sc->lambda); };
@@ -74,6 +77,25 @@ extern "C" int dmnd_seed_params_default(dmnd_seed_params* p, int threads, const 
 	for (int b = 1; b < 32; ++b)
 		p->cutoff_table[b] = raw(-std::log(10000.0 / 1e9 / (double)(1u << (b - 1))) / std::log(2.0));
 	return DMND_OK;
+}
+
+}
+
+extern "C" int dmnd_seed_params_default(dmnd_seed_params* p, int threads, const dmnd_params* sc)
+{
+	if (!p || !sc || threads < 1) return fail(DMND_E_ARG, "dmnd_seed_params_default: bad argument");
+	static const char* const codes[2] = { "111101110111", "111011010010111" };          // shape_codes[DEFAULT], search/setup.cpp:82-84
+	return spaced_preset(p, threads, sc, codes, 2, 0.8);
+}
+
+extern "C" int dmnd_seed_params_sensitive(dmnd_seed_params* p, int threads, const dmnd_params* sc)
+{
+	if (!p || !sc || threads < 1) return fail(DMND_E_ARG, "dmnd_seed_params_sensitive: bad argument");
+	static const char* const codes[16] = {                                               // shape_codes[SENSITIVE], search/setup.cpp:86-102
+		"1011110111", "110100100010111", "11001011111", "101110001111", "11011101100001", "1111010010101", "111001001001011",
+		"10101001101011", "111101010011", "1111000010000111", "1100011011011", "1101010000011011", "1110001010101001",
+		"110011000110011", "11011010001101", "1101001100010011" };
+	return spaced_preset(p, threads, sc, codes, 16, 1.0);
 }
 
 extern "C" int dmnd_seed_kernel_ms(const dmnd_ctx* c, double ms[5])

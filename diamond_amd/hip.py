@@ -64,7 +64,8 @@ EXPORTS = ["dmnd_abi_version", "dmnd_last_error", "dmnd_default_params", "dmnd_c
            "dmnd_set_db_letters", "dmnd_upload_block", "dmnd_upload_cbs", "dmnd_banded_swipe",
            "dmnd_banded_swipe_host", "dmnd_banded_cols", "dmnd_evalue", "dmnd_bitscore", "dmnd_evalue_p",
            "dmnd_bitscore_p", "dmnd_evalue_batch", "dmnd_last_kernel_ms", "dmnd_seed_params_fast", "dmnd_seed_params_default", "dmnd_seed_search",
-           "dmnd_seed_hits", "dmnd_seed_kernel_ms", "dmnd_extend_plan", "dmnd_extend", "dmnd_extend_stats", "dmnd_format_tab", "dmnd_set_max_target_seqs"]
+           "dmnd_seed_hits", "dmnd_seed_kernel_ms", "dmnd_extend_plan", "dmnd_extend", "dmnd_extend_stats", "dmnd_format_tab", "dmnd_set_max_target_seqs",
+           "dmnd_seed_params_sensitive", "dmnd_set_gapped_filter", "dmnd_gapped_filter", "dmnd_gapped_filter_ms"]
 
 
 def load():
@@ -97,6 +98,11 @@ def load():
         lib.dmnd_bitscore_p.argtypes = [ctypes.POINTER(Params), ctypes.c_double]
         lib.dmnd_seed_params_fast.argtypes = [ctypes.POINTER(SeedParams), ctypes.c_int]
         lib.dmnd_seed_params_default.argtypes = [ctypes.POINTER(SeedParams), ctypes.c_int, ctypes.POINTER(Params)]
+        lib.dmnd_seed_params_sensitive.argtypes = [ctypes.POINTER(SeedParams), ctypes.c_int, ctypes.POINTER(Params)]
+        lib.dmnd_set_gapped_filter.argtypes = [ctypes.c_void_p, ctypes.c_double]
+        lib.dmnd_gapped_filter.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        lib.dmnd_gapped_filter_ms.argtypes = [ctypes.c_void_p]
+        lib.dmnd_gapped_filter_ms.restype = ctypes.c_double
         lib.dmnd_seed_search.argtypes = [ctypes.c_void_p, ctypes.POINTER(SeedParams), ctypes.POINTER(ctypes.c_int64)]
         lib.dmnd_seed_hits.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
         lib.dmnd_seed_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
@@ -180,6 +186,15 @@ def seed_params_default(scoring, threads=1):
     """Default-sensitivity seed configuration (2 shapes of weight 10, ungapped e-value filter 10000)."""
     p = SeedParams()
     rc = load().dmnd_seed_params_default(ctypes.byref(p), int(threads), ctypes.byref(scoring))
+    if rc != 0:
+        raise DiamondHipError(load().dmnd_last_error().decode())
+    return p
+
+
+def seed_params_sensitive(scoring, threads=1):
+    """--sensitive seed configuration (16 shapes of weight 8, ungapped e-value filter 10000); pair with set_gapped_filter(1.0)."""
+    p = SeedParams()
+    rc = load().dmnd_seed_params_sensitive(ctypes.byref(p), int(threads), ctypes.byref(scoring))
     if rc != 0:
         raise DiamondHipError(load().dmnd_last_error().decode())
     return p
@@ -269,6 +284,23 @@ class Context:
         hits = np.zeros(n.value, dtype=SEED_HIT_DTYPE)
         self._check(self.lib.dmnd_seed_hits(self.h, hits.ctypes.data if n.value else None, n.value))
         return hits
+
+    def set_gapped_filter(self, evalue):
+        """Search::Config::gapped_filter_evalue (1.0 for --sensitive; 0 switches the filter off)."""
+        self._check(self.lib.dmnd_set_gapped_filter(self.h, float(evalue)))
+
+    def gapped_filter(self, hits, use_cbs=True, with_scores=False):
+        """Per seed hit: 1 if it passes both gapped-filter stages. Returns flags (uint8) [, scores (n x 2 int32: f1, f2)]."""
+        hits = np.ascontiguousarray(hits, dtype=SEED_HIT_DTYPE)
+        flags = np.zeros(hits.size, np.uint8)
+        scores = np.zeros((hits.size, 2), np.int32) if with_scores else None
+        self._check(self.lib.dmnd_gapped_filter(self.h, hits.ctypes.data if hits.size else None, hits.size, 1 if use_cbs else 0,
+                                                flags.ctypes.data if hits.size else None,
+                                                scores.ctypes.data if with_scores and hits.size else None))
+        return (flags, scores) if with_scores else flags
+
+    def gapped_filter_ms(self):
+        return float(self.lib.dmnd_gapped_filter_ms(self.h))
 
     def seed_kernel_ms(self):
         ms = (ctypes.c_double * 5)()

@@ -233,6 +233,22 @@ int dmnd_extend_plan(const dmnd_params* params, const int8_t* qdata, const int64
 int dmnd_extend(dmnd_ctx* ctx, const int8_t* qdata, const int8_t* tdata, const dmnd_seed_hit* hits, int64_t n_hits,
 	int threads, uint32_t hsp_values, dmnd_match* out, int64_t cap, int64_t* n_out,
 	uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used);
+/* Gapped filter (replaces Extension::gapped_filter, src/align/gapped_filter.cpp:80-109, with
+ * scan_diags64/128 + diag_alignment, src/dp/scan_diags.cpp:30,128,277, and make_profile8, src/dp/score_profile.cpp:33).
+ * dmnd_set_gapped_filter: Search::Config::gapped_filter_evalue (1.0 for --sensitive and above, 0 = off = default and
+ * --fast; search/setup.cpp:40-53); builds the two CutoffTable2D tables (evalue1 = 2000 and this one).
+ * dmnd_gapped_filter: per seed hit (any order) flags[h] = 1 iff the hit passes stage 1 (64 diagonals, +-100 columns)
+ * and stage 2 (128 diagonals, +-200 columns) against the cutoffs of its (query length, target length); a target
+ * survives iff any of its hits is flagged. scores (optional, 2 per hit) receives the two filter values (f2 = -1 when
+ * stage 2 did not run). use_cbs: add the uploaded Hauser bias (dmnd_upload_cbs) to the profile, as the reference does
+ * with composition based statistics on. Blocks must be uploaded with limits. dmnd_extend applies it by itself. */
+int dmnd_set_gapped_filter(dmnd_ctx* ctx, double gapped_filter_evalue);
+int dmnd_gapped_filter(dmnd_ctx* ctx, const dmnd_seed_hit* hits, int64_t n_hits, int use_cbs, uint8_t* flags, int32_t* scores);
+/* device time (ms) of the gapped filter kernel of the last dmnd_gapped_filter / dmnd_extend */
+double dmnd_gapped_filter_ms(const dmnd_ctx* ctx);
+/* Sensitive mode seed configuration (16 shapes of weight 8, search/setup.cpp:86-102; ungapped e-value 10000, seed cut 1.0) */
+int dmnd_seed_params_sensitive(dmnd_seed_params* p, int threads, const dmnd_params* scoring);
+
 /* -k / --max-target-seqs (default 25, src/basic/config.h:55) */
 int dmnd_set_max_target_seqs(dmnd_ctx* ctx, int k);
 /* Statistics of the last dmnd_extend: [0] round-1 DpTargets [1] round-2 DpTargets [2] round-1 cells [3] round-2 cells

@@ -39,6 +39,16 @@ double oracle_area(const oracle_evaluer* e, double y, double seqlen1, double seq
 double oracle_evalue(const oracle_evaluer* e, int raw_score, unsigned query_len, unsigned subject_len);
 double oracle_bitscore(const oracle_evaluer* e, double raw_score);
 
+/* gapped filter (gapped_filter.c) */
+void oracle_scan_diags(const int8_t* matrix8, const int8_t* query, int qlen, const int8_t* cbs, const int8_t* target,
+	int d_begin, int j_begin, int j_end, int band, int* out);
+int oracle_diag_alignment(const int* s, int count, int diag_score, int gap_open, int gap_extend);
+int oracle_gapped_filter_hit(const int8_t* matrix8, const int8_t* query, int qlen, const int8_t* cbs, const int8_t* target, int slen,
+	int hit_i, int hit_j, int band, int window, int diag_score, int gap_open, int gap_extend);
+int oracle_gapped_filter_target(const int8_t* matrix8, const int8_t* query, int qlen, const int8_t* cbs, const int8_t* target, int slen,
+	const int32_t* hit_i, const int32_t* hit_j, int n_hits, int cutoff1, int cutoff2, int window2, int diag_score, int gap_open, int gap_extend);
+void oracle_cutoff_table2d(const oracle_evaluer* e, double evalue, int32_t* table);
+
 /* ---- seed stage (oracle/seed_search.c) ---- */
 typedef struct {
 	int32_t seedp_bits, index_chunks, hamming_filter_id, n_shapes;

@@ -167,3 +167,36 @@ def seed_search(c, qdata, qlimits, tdata, tlimits, cap=1 << 22):
     if n < 0:
         raise RuntimeError("hit buffer too small")
     return hits[:n].copy()
+
+
+# ---- gapped filter ----------------------------------------------------------------------------------------------
+def cutoff_table2d(evalue_threshold, gap_open=11, gap_extend=1):
+    """CutoffTable2D(evalue) as a 32x32 int32 array indexed [bit_length(qlen)][bit_length(slen)]."""
+    e = evaluer(1e9, gap_open, gap_extend)
+    t = np.zeros(32 * 32, np.int32)
+    lib().oracle_cutoff_table2d(ctypes.byref(e), ctypes.c_double(evalue_threshold), t.ctypes.data_as(ctypes.c_void_p))
+    return t.reshape(32, 32)
+
+
+def gapped_filter_target(matrix8, query, cbs, target, hits_ij, cutoff1, cutoff2, window2=200, diag_score=None, gap_open=11, gap_extend=1):
+    """True if the target survives the gapped filter for this query (any seed hit passes both stages)."""
+    m = np.ascontiguousarray(matrix8, np.int8)
+    q = np.ascontiguousarray(query, np.int8)
+    t = np.ascontiguousarray(target, np.int8)
+    c = None if cbs is None else np.ascontiguousarray(cbs, np.int8)
+    hi = np.ascontiguousarray(hits_ij[:, 0], np.int32)
+    hj = np.ascontiguousarray(hits_ij[:, 1], np.int32)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+    return bool(lib().oracle_gapped_filter_target(p(m), p(q), len(q), p(c), p(t), len(t), p(hi), p(hj), len(hi), int(cutoff1), int(cutoff2),
+                                                  int(window2), int(diag_score), int(gap_open), int(gap_extend)))
+
+
+def gapped_filter_hit(matrix8, query, cbs, target, hit_i, hit_j, band, window, diag_score, gap_open=11, gap_extend=1):
+    """diag_alignment(scan_diags<band>(...)) of one seed hit (gapped_filter.cpp:33-41)."""
+    m = np.ascontiguousarray(matrix8, np.int8)
+    q = np.ascontiguousarray(query, np.int8)
+    t = np.ascontiguousarray(target, np.int8)
+    c = None if cbs is None else np.ascontiguousarray(cbs, np.int8)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+    return int(lib().oracle_gapped_filter_hit(p(m), p(q), len(q), p(c), p(t), len(t), int(hit_i), int(hit_j), int(band), int(window),
+                                              int(diag_score), int(gap_open), int(gap_extend)))

@@ -266,3 +266,55 @@ std::vector<Extension::Match> wrap_extend(BlockId query_id, Search::Hit* begin, 
 	}
 	return out;
 }
+
+// ---- third seam: the gapped filter (align/gapped_filter.cpp:80; called from Extension::extend, align/extend.cpp:206,
+// only when gapped_filter_evalue > 0, i.e. --sensitive and above). $DIAMOND_TAP_GF=file, per call one 'GFL1' record:
+//   f64 gapped_filter_evalue | f64 gapped_filter_evalue1 | i32 diag_score window gap_open gap_extend
+//   | i64 query offset inside the query block | i32 qlen | i32 has_cbs | int8 cbs[qlen]
+//   | i32 n_targets x { u32 block_id, i32 cutoff1, i32 cutoff2, i32 n_hits x { i32 i j score frame } }
+//   | i32 n_out x u32 surviving block ids
+#include "align/target.h"
+#include "stats/hauser_correction.h"
+#define GF_SYM "_ZN9Extension13gapped_filterEPK8SequencePK16HauserCorrectionN9FlatArrayINS_7SeedHitEmE8IteratorES9_N9__gnu_cxx17__normal_iteratorIPKjSt6vectorIjSaIjEEEER10StatisticsN2DP5FlagsERKN6Search6ConfigE"
+using GfResult = std::pair<FlatArray<Extension::SeedHit>, std::vector<uint32_t>>;
+GfResult real_gf(const Sequence* query, const HauserCorrection* query_cbs, FlatArray<Extension::SeedHit>::Iterator seed_hits, FlatArray<Extension::SeedHit>::Iterator seed_hits_end,
+	std::vector<uint32_t>::const_iterator target_block_ids, Statistics& stat, DP::Flags flags, const Search::Config& params) asm("__real_" GF_SYM);
+GfResult wrap_gf(const Sequence* query, const HauserCorrection* query_cbs, FlatArray<Extension::SeedHit>::Iterator seed_hits, FlatArray<Extension::SeedHit>::Iterator seed_hits_end,
+	std::vector<uint32_t>::const_iterator target_block_ids, Statistics& stat, DP::Flags flags, const Search::Config& params) asm("__wrap_" GF_SYM);
+
+GfResult wrap_gf(const Sequence* query, const HauserCorrection* query_cbs, FlatArray<Extension::SeedHit>::Iterator seed_hits, FlatArray<Extension::SeedHit>::Iterator seed_hits_end,
+	std::vector<uint32_t>::const_iterator target_block_ids, Statistics& stat, DP::Flags flags, const Search::Config& params)
+{
+	static FILE* f = getenv("DIAMOND_TAP_GF") ? fopen(getenv("DIAMOND_TAP_GF"), "wb") : nullptr;
+	Buf b;
+	if (f) {
+		const int64_t n = seed_hits_end - seed_hits;
+		const int qlen = (int)query[0].length();
+		b.i32(0x314c4647);
+		b.f64(params.gapped_filter_evalue); b.f64(config.gapped_filter_evalue1);
+		b.i32(config.gapped_filter_diag_score); b.i32(config.gapped_filter_window); b.i32(score_matrix.gap_open()); b.i32(score_matrix.gap_extend());
+		i64(b, (int64_t)(query[0].data() - params.query->seqs().data(0)));
+		b.i32(qlen);
+		const bool has_cbs = Stats::CBS::hauser(config.comp_based_stats);
+		b.i32(has_cbs ? 1 : 0);
+		if (has_cbs) b.bytes(query_cbs[0].int8.data(), (size_t)qlen);
+		b.i32((int32_t)n);
+		for (int64_t t = 0; t < n; ++t) {
+			const uint32_t id = target_block_ids[t];
+			const int slen = (int)params.target->seqs()[id].length();
+			b.i32((int32_t)id); b.i32(params.cutoff_gapped1_new(qlen, slen)); b.i32(params.cutoff_gapped2_new(qlen, slen));
+			b.i32((int32_t)(seed_hits.end(t) - seed_hits.begin(t)));
+			for (auto h = seed_hits.begin(t); h < seed_hits.end(t); ++h) { b.i32(h->i); b.i32(h->j); b.i32(h->score); b.i32((int32_t)h->frame); }
+		}
+	}
+	GfResult out = real_gf(query, query_cbs, seed_hits, seed_hits_end, target_block_ids, stat, flags, params);
+	if (f) {
+		b.i32((int32_t)out.second.size());
+		for (uint32_t id : out.second) b.i32((int32_t)id);
+		static std::mutex mtx;
+		std::lock_guard<std::mutex> lock(mtx);
+		fwrite(b.d.data(), 1, b.d.size(), f);
+		fflush(f);
+	}
+	return out;
+}

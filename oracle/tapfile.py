@@ -146,3 +146,36 @@ def read_ext_tap(path, max_records=None):
         rec["matches"] = matches
         out.append(rec)
     return cfg, out
+
+
+def read_gf_tap(path, max_records=None):
+    """Reader for $DIAMOND_TAP_GF files (oracle/ref_tap.cpp, third seam: Extension::gapped_filter).
+    records[i] = {gapped_filter_evalue, gapped_filter_evalue1, diag_score, window, gap_open, gap_extend, query_offset,
+    qlen, cbs (int8 array or None), targets: [{block_id, cutoff1, cutoff2, hits (n x 4 int32: i j score frame)}], out}."""
+    buf = open(path, "rb").read()
+    pos, recs = 0, []
+    while pos < len(buf) and (max_records is None or len(recs) < max_records):
+        magic, = struct.unpack_from("<i", buf, pos)
+        assert magic == 0x314c4647, hex(magic)
+        ev, ev1, diag, window, go, ge, qoff, qlen, has_cbs = struct.unpack_from("<ddiiiiqii", buf, pos + 4)
+        pos += 4 + struct.calcsize("<ddiiiiqii")
+        cbs = None
+        if has_cbs:
+            cbs = np.frombuffer(buf, np.int8, qlen, pos).copy()
+            pos += qlen
+        n, = struct.unpack_from("<i", buf, pos)
+        pos += 4
+        targets = []
+        for _ in range(n):
+            bid, c1, c2, nh = struct.unpack_from("<iiii", buf, pos)
+            pos += 16
+            hits = np.frombuffer(buf, "<i4", nh * 4, pos).reshape(nh, 4).copy()
+            pos += nh * 16
+            targets.append(dict(block_id=bid, cutoff1=c1, cutoff2=c2, hits=hits))
+        n_out, = struct.unpack_from("<i", buf, pos)
+        pos += 4
+        out = np.frombuffer(buf, "<i4", n_out, pos).copy()
+        pos += 4 * n_out
+        recs.append(dict(gapped_filter_evalue=ev, gapped_filter_evalue1=ev1, diag_score=diag, window=window, gap_open=go,
+                         gap_extend=ge, query_offset=qoff, qlen=qlen, cbs=cbs, targets=targets, out=out))
+    return recs

@@ -10,6 +10,8 @@ _SRC = os.path.join(_HERE, "emu", "swipe_emu.cpp")
 _SRC2 = os.path.join(_HERE, "emu", "seed_emu.cpp")
 _CORE = os.path.join(_HERE, "..", "diamond_amd", "csrc", "swipe_core.h")
 _CORE2 = os.path.join(_HERE, "..", "diamond_amd", "csrc", "seed_core.h")
+_SRC3 = os.path.join(_HERE, "emu", "gapped_emu.cpp")
+_CORE3 = os.path.join(_HERE, "..", "diamond_amd", "csrc", "gapped_core.h")
 _SO = os.path.join(_HERE, "emu", "libswipe_emu.so")
 
 
@@ -25,8 +27,8 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_SO) or max(os.path.getmtime(f) for f in (_SRC, _SRC2, _CORE, _CORE2)) > os.path.getmtime(_SO):
-            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-o", _SO, _SRC, _SRC2])
+        if not os.path.exists(_SO) or max(os.path.getmtime(f) for f in (_SRC, _SRC2, _SRC3, _CORE, _CORE2, _CORE3)) > os.path.getmtime(_SO):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-o", _SO, _SRC, _SRC2, _SRC3])
         _lib = ctypes.CDLL(_SO)
     return _lib
 
@@ -113,3 +115,22 @@ def seed_search(c, qdata, qlimits, tdata, tlimits, cap=1 << 22, matrix8=None):
           hits.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(cap))
     assert n >= 0
     return hits[:n].copy()
+
+
+# ---- gapped filter ----------------------------------------------------------------------------------------------
+class GfParams(ctypes.Structure):
+    _fields_ = [("diag_score", ctypes.c_int32), ("gap_open", ctypes.c_int32), ("gap_extend", ctypes.c_int32),
+                ("window2", ctypes.c_int32), ("use_cbs", ctypes.c_int32)]
+
+
+def gapped_filter_hit(p, matrix8, query, cbs, target, hit_i, hit_j, cutoff1, cutoff2):
+    """(flag, f1, f2) of one seed hit through the emulated kernel code."""
+    m = np.ascontiguousarray(matrix8, np.int8)
+    q = np.ascontiguousarray(query, np.int8)
+    t = np.ascontiguousarray(target, np.int8)
+    c = np.ascontiguousarray(cbs if cbs is not None else np.zeros(len(q)), np.int8)
+    f = (ctypes.c_int * 2)()
+    v = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    flag = lib().emu_gapped_filter_hit(ctypes.byref(p), v(m), v(q), len(q), v(c), v(t), len(t), int(hit_i), int(hit_j),
+                                       int(cutoff1), int(cutoff2), f)
+    return flag, f[0], f[1]

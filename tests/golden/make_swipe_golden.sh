@@ -75,5 +75,9 @@ DIAMOND_TAP_EXT="$HERE/ext_default.tap" \
   "$TAP" blastp --masking 0 --motif-masking 0 --algo 0 -q "$REFTEST/data.faa" -d "$REFTEST/data.faa" -o "$HERE/default.tsv" -p1 2>/dev/null
 DIAMOND_TAP_EXT="$HERE/ext_default_synth.tap" \
   "$TAP" blastp --masking 0 --motif-masking 0 --algo 0 -q "$TMP/s_q.faa" -d "$TMP/s_db.faa" -o "$HERE/default_synth.tsv" -p4 2>/dev/null
+# 8. --sensitive (16 shapes of weight 8 + the gapped filter): third seam = Extension::gapped_filter
+#    (per query: Hauser bias, the seed hits of every target of the ranking chunk, both cutoffs, the surviving targets)
+DIAMOND_TAP_EXT="$HERE/ext_sensitive.tap" DIAMOND_TAP_GF="$HERE/gf_sensitive.tap" \
+  "$TAP" blastp --sensitive --masking 0 --motif-masking 0 --algo 0 -q "$REFTEST/data.faa" -d "$REFTEST/data.faa" -o "$HERE/sensitive.tsv" -p1 2>/dev/null
 ls -la "$HERE"/*.tap
 rm -rf "$TMP"

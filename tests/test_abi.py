@@ -85,7 +85,8 @@ def test_seed_parameter_presets_equal_the_reference_configuration():
     from tapfile import read_ext_tap
     golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     for tap, make in (("ext_fast.tap", lambda: hip.seed_params_fast(1)),
-                      ("ext_default.tap", lambda: hip.seed_params_default(hip.default_params(), 1))):
+                      ("ext_default.tap", lambda: hip.seed_params_default(hip.default_params(), 1)),
+                      ("ext_sensitive.tap", lambda: hip.seed_params_sensitive(hip.default_params(), 1))):
         cfg, _ = read_ext_tap(os.path.join(golden, tap), max_records=1)
         want, got = emu.seed_params_from_tap(cfg), make()
         for name, _t in hip.SeedParams._fields_:

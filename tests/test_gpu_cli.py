@@ -36,8 +36,20 @@ def test_cli_makedb_blastp_matches_reference(tmp_path):
     assert len(ref.splitlines()) > 300
     assert open(tmp_path / "hip.tsv").read() == ref
     assert open(tmp_path / "hip2.tsv").read() == open(tmp_path / "ref2.tsv").read()
+    # default sensitivity (two shapes + stage-2 ungapped e-value filter)
+    _run([REF] + [a for a in ref_args if a != "--fast"] + ["-d", str(tmp_path / "db.dmnd"), "-o", str(tmp_path / "ref3.tsv")])
+    _run([CLI, "blastp", "--masking", "0", "-q", str(tmp_path / "q.faa"), "-d", str(tmp_path / "db.dmnd"), "-o", str(tmp_path / "hip3.tsv"), "-p", "4"])
+    ref3 = open(tmp_path / "ref3.tsv").read()
+    assert len(ref3.splitlines()) >= len(ref.splitlines())
+    assert open(tmp_path / "hip3.tsv").read() == ref3
+    # --sensitive (16 shapes, ungapped + gapped filters)
+    _run([REF] + [a if a != "--fast" else "--sensitive" for a in ref_args] + ["-d", str(tmp_path / "db.dmnd"), "-o", str(tmp_path / "ref4.tsv")])
+    _run([CLI, "blastp", "--sensitive", "--masking", "0", "-q", str(tmp_path / "q.faa"), "-d", str(tmp_path / "db.dmnd"), "-o", str(tmp_path / "hip4.tsv"), "-p", "4"])
+    ref4 = open(tmp_path / "ref4.tsv").read()
+    assert len(ref4.splitlines()) >= len(ref3.splitlines())
+    assert open(tmp_path / "hip4.tsv").read() == ref4
 
 
 def test_cli_refuses_unimplemented_modes(tmp_path):
-    r = subprocess.run([CLI, "blastp", "--sensitive", "-q", "x", "-d", "y"], capture_output=True, text=True)
-    assert r.returncode != 0 and "--fast" in r.stderr
+    r = subprocess.run([CLI, "blastp", "--very-sensitive", "-q", "x", "-d", "y"], capture_output=True, text=True)
+    assert r.returncode != 0 and "not available" in r.stderr

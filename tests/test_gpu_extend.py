@@ -29,11 +29,12 @@ def _run(ctx, cfg, db_letters):
     ctx.upload_block(hip.QUERY, qd, ql)
     ctx.upload_block(hip.TARGET, td, tl)
     ctx.set_db_letters(db_letters)
+    ctx.set_gapped_filter(cfg["gapped_filter_evalue"])          # 0 except --sensitive (1.0)
     hits = ctx.seed_search(to_hip_params(cfg))
     return ctx.extend(qd, td, hits, threads=4)[0]
 
 
-@pytest.mark.parametrize("tap", ["ext_fast_synth.tap", "ext_fast.tap", "ext_6x10.tap", "ext_rank.tap", "ext_default.tap", "ext_default_synth.tap"])
+@pytest.mark.parametrize("tap", ["ext_fast_synth.tap", "ext_fast.tap", "ext_6x10.tap", "ext_rank.tap", "ext_default.tap", "ext_default_synth.tap", "ext_sensitive.tap"])
 def test_matches_equal_reference_extend(ctx, tap):
     cfg, recs = read_ext_tap(os.path.join(GOLDEN, tap))
     tl = cfg["target"]["limits"]
@@ -59,12 +60,13 @@ def test_matches_equal_reference_extend(ctx, tap):
 
 
 @pytest.mark.parametrize("tap,tsv", [("ext_fast_synth.tap", "fast_synth.tsv"), ("ext_rank.tap", "rank.tsv"),
-                                     ("ext_default_synth.tap", "default_synth.tsv"), ("ext_default.tap", "default.tsv")])
+                                     ("ext_default_synth.tap", "default_synth.tsv"), ("ext_default.tap", "default.tsv"),
+                                     ("ext_sensitive.tap", "sensitive.tsv")])
 def test_tabular_output_is_byte_identical_to_reference(ctx, tap, tsv):
     cfg, recs = read_ext_tap(os.path.join(GOLDEN, tap))
     tl = cfg["target"]["limits"]
     m = _run(ctx, cfg, float(tl[-1] - tl[0] - (len(tl) - 1)))
-    if tsv == "default.tsv":                                       # the reference's own fixture (src/test/data.faa) against itself
+    if tsv in ("default.tsv", "sensitive.tsv"):                                       # the reference's own fixture (src/test/data.faa) against itself
         qids = tids = open(os.path.join(GOLDEN, "data_ids.txt")).read().split()
     else:
         qids = ["q%d" % i for i in range(cfg["query"]["n"])]
