@@ -39,7 +39,7 @@ HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 def gather_topk(n_queries, matches, device):
     """Per-query top-k records of this rank's query slice, gathered from all ranks with ONE all_gather of a
     fixed-size tensor (diamond_amd/multigpu.py). Returns the number of aligned queries of the whole job."""
-    rec = multigpu.topk_records(n_queries, matches["query"], matches["evalue"], matches["hsp"]["score"], matches["target"])
+    rec = multigpu.topk_records(n_queries, matches["query"], matches["evalue"], matches["hsp"]["score"], matches["target"], presorted=True)
     return multigpu.aligned_queries(multigpu.gather_records(rec, device))
 
 

@@ -27,6 +27,9 @@
 #include <string>
 #include <atomic>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <functional>
 #include <vector>
 #include "ctx.h"
 #include "chain_host.h"
@@ -208,16 +211,82 @@ std::vector<Range> split_by_query(const dmnd_seed_hit* hits, int64_t n)
 	return r;
 }
 
+// Persistent worker pool: dmnd_extend issues a handful of short parallel loops per call, and thread start-up would
+// cost more than the loops themselves. Workers sleep on a condition variable between loops; the caller is worker 0.
+class WorkerPool {
+public:
+	~WorkerPool()
+	{
+		{ std::lock_guard<std::mutex> g(m_); stop_ = true; }
+		cv_.notify_all();
+		for (auto& t : th_) t.join();
+	}
+	template<typename F>
+	void run(size_t n, int threads, F& f)
+	{
+		std::unique_lock<std::mutex> own(busy_, std::try_to_lock);
+		if (!own.owns_lock()) {                              // another context is using the pool: plain threads for this loop
+			std::vector<std::thread> th;
+			std::atomic<size_t> next(0);
+			for (int t = 0; t < threads; ++t) th.emplace_back([&, t] { size_t i; while ((i = next.fetch_add(1)) < n) f(i, t); });
+			for (auto& x : th) x.join();
+			return;
+		}
+		grow(threads - 1);
+		std::function<void(size_t, int)> fn = [&f](size_t i, int t) { f(i, t); };
+		{
+			std::lock_guard<std::mutex> g(m_);
+			fn_ = &fn; n_ = n; next_.store(0); want_ = threads - 1; running_ = threads - 1; ++gen_;
+		}
+		cv_.notify_all();
+		size_t i;
+		while ((i = next_.fetch_add(1)) < n) f(i, 0);
+		std::unique_lock<std::mutex> g(m_);
+		done_.wait(g, [&] { return running_ == 0; });
+		fn_ = nullptr;
+	}
+private:
+	void grow(int workers)
+	{
+		while ((int)th_.size() < workers) {
+			const int id = (int)th_.size() + 1;
+			th_.emplace_back([this, id] {
+				uint64_t seen = 0;
+				for (;;) {
+					std::unique_lock<std::mutex> g(m_);
+					cv_.wait(g, [&] { return stop_ || (gen_ != seen && id <= want_); });
+					if (stop_) return;
+					seen = gen_;
+					const std::function<void(size_t, int)>* fn = fn_;
+					const size_t n = n_;
+					g.unlock();
+					size_t i;
+					while ((i = next_.fetch_add(1)) < n) (*fn)(i, id);
+					g.lock();
+					if (--running_ == 0) done_.notify_one();
+				}
+			});
+		}
+	}
+	std::vector<std::thread> th_;
+	std::mutex m_, busy_;
+	std::condition_variable cv_, done_;
+	const std::function<void(size_t, int)>* fn_ = nullptr;
+	size_t n_ = 0;
+	std::atomic<size_t> next_{ 0 };
+	int want_ = 0, running_ = 0;
+	uint64_t gen_ = 0;
+	bool stop_ = false;
+};
+
+WorkerPool& pool() { static WorkerPool p; return p; }
+
 template<typename F>
 void parallel_for(size_t n, int threads, F f)
 {
 	threads = std::max(1, std::min<int>(threads, (int)n));
 	if (threads == 1) { for (size_t i = 0; i < n; ++i) f(i, 0); return; }
-	std::vector<std::thread> th;
-	std::atomic<size_t> next(0);
-	for (int t = 0; t < threads; ++t)
-		th.emplace_back([&, t] { size_t i; while ((i = next.fetch_add(1)) < n) f(i, t); });
-	for (auto& x : th) x.join();
+	pool().run(n, threads, f);
 }
 
 // all queries: load + plan every target (used by the CPU-checkable dmnd_extend_plan)
@@ -363,8 +432,13 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	double t_mark = now();
 	auto lap = [&](int slot) { const double t = now(); c->ext_stats[slot] += t - t_mark; t_mark = t; };
 	// 1. Hauser bias for every query, resident next to the query block
-	std::vector<int8_t> cbs;
-	all_hauser(h, threads, qdata, ql, cbs);
+	const std::vector<Range> qr = split_by_query(hits, n_hits);
+	std::vector<int8_t> cbs((size_t)ql.back() + 64, 0);            // only queries with seed hits are ever aligned
+	parallel_for(qr.size(), threads, [&](size_t i, int) {
+		const uint32_t q = hits[qr[i].b].query;
+		const SeqRef s{ qdata + ql[q], (int)(ql[q + 1] - ql[q] - 1) };
+		if (s.len > 0) hauser_int8(h, s, cbs.data() + ql[q]);
+	});
 	if (int rc = dmnd_upload_cbs(c, cbs.data(), ql.back())) return rc;
 	lap(4);
 	// 1b. gapped filter of every seed hit in one launch (only --sensitive and above; extend.cpp:205-213)
@@ -376,7 +450,6 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	}
 	lap(4);
 	// 2. load_hits for every query
-	const std::vector<Range> qr = split_by_query(hits, n_hits);
 	std::vector<QueryState> qs(qr.size());
 	parallel_for(qr.size(), threads, [&](size_t i, int) {
 		load_query(h, qs[i].w, hits[qr[i].b].query, hits + qr[i].b, hits + qr[i].e, gf.empty() ? nullptr : gf.data() + qr[i].b, tl.data(), (int64_t)tl.size() - 1);

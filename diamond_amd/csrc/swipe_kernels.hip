@@ -11,7 +11,7 @@
 //   * letters are read from the HBM-resident blocks through L1/L2 (adjacent lanes read adjacent
 //     bytes: lane l+1 reads query i+P, target j-P);
 //   * TRACEBACK mode streams one trace byte per cell, one coalesced 64*P-byte row per step, to an
-//     HBM arena; a second kernel walks it with one thread per item.
+//     HBM arena; a second kernel walks it with one wavefront per item (64 columns per round trip).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "swipe_core.h"
@@ -79,14 +79,109 @@ void banded_swipe_kernel(SwipeArgs args)
 	}
 }
 
-// One thread per item: walks the trace, writes the transcript slot and the alignment statistics.
-__global__ void traceback_kernel(TracebackArgs args)
+// ---- traceback: one WAVEFRONT per item ---------------------------------------------------------------------------
+// The serial walk (traceback_walk, swipe_core.h) is one dependent HBM/L2 load per alignment column. Alignments are
+// mostly runs of (mis)matches along one diagonal, so the wave speculates: lane L loads the trace byte and scores the
+// cell L diagonal steps back from the current cell; a ballot finds the length of the leading match run, a wave prefix
+// sum of the cell scores finds the step at which the running score reaches the alignment score (the walk's stop
+// condition, banded_swipe.h:128-183), and up to 64 columns are consumed per round trip. Gaps (rare, short) are walked
+// serially by the whole wave in lockstep. Same outputs as traceback_walk, byte for byte.
+__device__ __forceinline__ int wave_prefix_sum(int x, int lane)
+{
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		const int y = __shfl_up(x, d);
+		if (lane >= d) x += y;
+	}
+	return x;
+}
+
+__device__ __forceinline__ int popc64(unsigned long long x) { return __popcll(x); }
+
+__device__ WalkResult traceback_walk_wave(const uint8_t* trace, const Geom& g, int W, const SeqView& v, int gap_open, int gap_extend,
+	int best, int end_i, int end_j, uint8_t* transcript, int cap, int lane)
+{
+	WalkResult r;
+	r.length = r.identities = r.mismatches = r.positives = r.gap_openings = r.gaps = 0;
+	r.status = 0;
+	int i = end_i, j = end_j, sc = 0, n = 0;                  // wave-uniform
+	while (i >= 0 && j >= 0 && sc < best) {
+		const int ii = i - lane, jj = j - lane;
+		const bool valid = ii >= 0 && jj >= 0;
+		const uint8_t m = valid ? trace_at(trace, g, W, ii, jj) : (uint8_t)TB_GAP_V;
+		const bool is_match = valid && (m & (TB_GAP_V | TB_GAP_H)) == 0;
+		int s = 0, ql = 0, tl = 1;
+		bool positive = false;
+		if (is_match) {
+			ql = v.q[ii] & LETTER_MASK; tl = v.t[jj] & LETTER_MASK;
+			s = v.M[tl * 32 + ql];
+			positive = s > 0;
+			if (v.cbs) s += v.cbs[ii];
+		}
+		const unsigned long long mm = __ballot(is_match);
+		const int run = ~mm ? __builtin_ctzll(~mm) : 64;
+		if (run > 0) {
+			const int ps = wave_prefix_sum(lane < run ? s : 0, lane);
+			// the walk tests `sc < best` before every column: column L is consumed iff the score before it is still below best
+			const unsigned long long sm = __ballot(lane < run && sc + (ps - s) >= best);
+			const int steps = sm ? imin(run, __builtin_ctzll(sm)) : run;       // >= 1: lane 0 sees sc < best
+			const bool mine = lane < steps;
+			if (mine && n + lane < cap - 1)
+				transcript[cap - 2 - (n + lane)] = (uint8_t)(ql == tl ? (OP_MATCH << OP_COUNT_BITS) | 1 : (OP_SUBSTITUTION << OP_COUNT_BITS) | tl);
+			const int ident = popc64(__ballot(mine && ql == tl)), pos_mm = popc64(__ballot(mine && ql != tl && positive));
+			r.identities += ident; r.positives += ident + pos_mm; r.mismatches += steps - ident;
+			r.length += steps;
+			sc += __shfl(ps, steps - 1);
+			n += steps; i -= steps; j -= steps;
+			continue;
+		}
+		// gap at (i, j): lane 0's byte, walked by all lanes in lockstep (wave-uniform addresses)
+		const uint8_t m0 = (uint8_t)__shfl((int)m, 0);
+		int l = 0;
+		if (m0 & TB_GAP_V) {
+			do { ++l; --i; } while (i > 0 && (trace_at(trace, g, W, i, j) & TB_OPEN_V) == 0);
+			int c = l;
+			while (c > 0) {
+				const int kk = imin(c, (int)OP_MAX_COUNT);
+				if (lane == 0 && n < cap - 1) transcript[cap - 2 - n] = (uint8_t)((OP_INSERTION << OP_COUNT_BITS) | kk);
+				++n; c -= kk;
+			}
+		}
+		else {
+			const int j_before = j;
+			do { ++l; --j; } while (j > 0 && (trace_at(trace, g, W, i, j) & TB_OPEN_H) == 0);
+			for (int x = lane; x < l; x += 64)
+				if (n + x < cap - 1) transcript[cap - 2 - (n + x)] = (uint8_t)((OP_DELETION << OP_COUNT_BITS) | (v.t[j_before - x] & LETTER_MASK));
+			n += l;
+		}
+		++r.gap_openings;
+		r.length += l;
+		r.gaps += l;
+		sc -= gap_open + l * gap_extend;
+	}
+	if (sc != best) r.status = -6;           // DMND_E_TRACEBACK
+	if (n > cap - 1) { r.status = -5; n = 0; }    // DMND_E_CAP
+	// move to the front of the slot: 64 bytes per pass, every pass reads before it writes, destinations trail sources
+	for (int x0 = 0; x0 < n; x0 += 64) {
+		const int x = x0 + lane;
+		uint8_t b = 0;
+		if (x < n) b = transcript[cap - 1 - n + x];
+		__builtin_amdgcn_wave_barrier();
+		if (x < n) transcript[x] = b;
+	}
+	if (cap > 0 && lane == 0) transcript[n] = 0;
+	r.q_begin = i + 1; r.s_begin = j + 1; r.transcript_len = n;
+	return r;
+}
+
+__global__ __launch_bounds__(256) void traceback_kernel(TracebackArgs args)
 {
 	__shared__ int8_t matrix[32 * 32];
 	for (int x = threadIdx.x; x < 32 * 32 / 4; x += blockDim.x)
 		reinterpret_cast<int32_t*>(matrix)[x] = reinterpret_cast<const int32_t*>(args.matrix)[x];
 	__syncthreads();
-	const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const int lane = threadIdx.x & 63;
+	const int64_t slot = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
 	if (slot >= args.n)
 		return;
 	const int32_t item_idx = args.order[slot];
@@ -104,17 +199,17 @@ __global__ void traceback_kernel(TracebackArgs args)
 			it.cbs_off >= 0 ? args.cbs + it.cbs_off : nullptr, matrix };
 		const int W = 64 * args.p_of_slot[slot];
 		const int cap = (int)(args.transcript_off[slot + 1] - args.transcript_off[slot]);
-		const WalkResult r = traceback_walk(args.trace + args.trace_off[slot], g, W, v, args.gap_open, args.gap_extend,
-			e.score, e.end_i, e.end_j, args.transcript + args.transcript_off[slot], cap);
+		const WalkResult r = traceback_walk_wave(args.trace + args.trace_off[slot], g, W, v, args.gap_open, args.gap_extend,
+			e.score, e.end_i, e.end_j, args.transcript + args.transcript_off[slot], cap, lane);
 		h.q_begin = r.q_begin; h.s_begin = r.s_begin; h.q_end = e.end_i + 1; h.s_end = e.end_j + 1;
 		h.length = r.length; h.identities = r.identities; h.mismatches = r.mismatches; h.positives = r.positives;
 		h.gap_openings = r.gap_openings; h.gaps = r.gaps; h.transcript_len = r.transcript_len;
-		if (r.status != 0)
+		if (r.status != 0 && lane == 0)
 			atomicMin(args.status, r.status);
 	}
-	else if (args.transcript_off[slot + 1] > args.transcript_off[slot])
+	else if (lane == 0 && args.transcript_off[slot + 1] > args.transcript_off[slot])
 		args.transcript[args.transcript_off[slot]] = 0;
-	args.hsps[item_idx] = h;
+	if (lane == 0) args.hsps[item_idx] = h;
 }
 
 template<int P>
@@ -158,8 +253,8 @@ hipError_t launch_traceback(const TracebackArgs& a, hipStream_t stream)
 {
 	if (a.n == 0)
 		return hipSuccess;
-	const unsigned threads = 64, blocks = (unsigned)((a.n + threads - 1) / threads);
-	hipLaunchKernelGGL(traceback_kernel, dim3(blocks), dim3(threads), 0, stream, a);
+	const unsigned waves = 4, blocks = (unsigned)((a.n + waves - 1) / waves);
+	hipLaunchKernelGGL(traceback_kernel, dim3(blocks), dim3(waves * 64), 0, stream, a);
 	return hipGetLastError();
 }
 

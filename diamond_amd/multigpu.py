@@ -18,12 +18,16 @@ def shard_range(n, world, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def topk_records(n_queries, query_idx, evalue, score, target_oid, k=TOPK):
+def topk_records(n_queries, query_idx, evalue, score, target_oid, k=TOPK, presorted=False):
     """Packs per-query top-k (evalue, -score, oid) records into a dense [n_queries, k, 3] float64 tensor
-    (+inf padded). Inputs must already be culled to <= k rows per query; rows of a query keep input order."""
+    (+inf padded). Inputs must already be culled to <= k rows per query; rows of a query keep input order.
+    presorted: rows are already in (query, evalue, -score, oid) order, as dmnd_extend returns them."""
     rec = np.full((n_queries, k, 3), np.inf)
     if len(query_idx):
-        order = np.lexsort((target_oid, -np.asarray(score, np.int64), evalue, query_idx))
+        if presorted:
+            order = slice(None)
+        else:
+            order = np.lexsort((target_oid, -np.asarray(score, np.int64), evalue, query_idx))
         q = np.asarray(query_idx)[order]
         start = np.r_[0, np.nonzero(np.diff(q))[0] + 1]
         rank_in_q = np.arange(q.size) - np.repeat(start, np.diff(np.r_[start, q.size]))
