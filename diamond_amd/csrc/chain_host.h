@@ -52,7 +52,7 @@ struct Chain {                     // the fields of ApproxHsp the extension read
 	int q0, q1, s0, s1;            // query_range / subject_range
 };
 
-struct HostSeedHit { int i, j, score; };
+struct HostSeedHit { int i, j, score, frame; };
 
 // chaining constants = the reference's config defaults (basic/config.cpp:549-603)
 struct ChainCfg {

@@ -90,6 +90,53 @@ void read_fasta(const std::string& path, SeqBlock& b)
 	b.finish();
 }
 
+// blastx query file: DNA reads -> six translated frames per read, consecutive in the block (Block::push_back,
+// data/block/block.cpp:82-100). source_len keeps the read lengths for the DNA coordinates of the output.
+void read_dna_fasta_translated(const std::string& path, SeqBlock& b, std::vector<int32_t>& source_len, std::vector<std::string>& read_ids)
+{
+	std::ifstream f(path);
+	if (!f) throw std::runtime_error("Error opening file " + path);
+	static int8_t map[256];
+	static bool init = false;
+	if (!init) {                                                     // nucleotide_traits("ACGTN", 4, "MRWSYKVHDBX"), stats/stats.cpp:42
+		std::memset(map, -1, sizeof map);
+		const char* alpha = "ACGTN";
+		for (int i = 0; alpha[i]; ++i) { map[(unsigned char)alpha[i]] = (int8_t)i; map[(unsigned char)std::tolower(alpha[i])] = (int8_t)i; }
+		for (const char* m = "MRWSYKVHDBX"; *m; ++m) { map[(unsigned char)*m] = 4; map[(unsigned char)std::tolower(*m)] = 4; }
+		init = true;
+	}
+	b.begin();
+	std::string line, id;
+	std::vector<int8_t> seq, frames[6];
+	bool have = false;
+	auto flush = [&] {
+		if (!have) return;
+		if (seq.empty()) throw std::runtime_error("File format error: sequence of length 0");
+		int8_t* out[6];
+		int32_t lens[6];
+		for (int k = 0; k < 6; ++k) { frames[k].assign(seq.size() / 3 + 1, 0); out[k] = frames[k].data(); }
+		if (dmnd_translate(seq.data(), (int32_t)seq.size(), out, lens) != DMND_OK) throw std::runtime_error(dmnd_last_error());
+		for (int k = 0; k < 6; ++k) { frames[k].resize((size_t)lens[k]); b.push(frames[k], id); }
+		source_len.push_back((int32_t)seq.size());
+		read_ids.push_back(id);
+		seq.clear();
+	};
+	while (std::getline(f, line)) {
+		if (!line.empty() && line.back() == '\r') line.pop_back();
+		if (line.empty()) continue;
+		if (line[0] == '>') { flush(); id = line.substr(1); have = true; continue; }
+		if (!have) throw std::runtime_error("FASTA format error: missing '>' in " + path);
+		for (char c : line) {
+			if (c == ' ' || c == '\t') continue;
+			const int8_t l = map[(unsigned char)c];
+			if (l < 0) throw std::runtime_error(std::string("Invalid character (") + c + ") in sequence " + id);
+			seq.push_back(l);
+		}
+	}
+	flush();
+	b.finish();
+}
+
 const uint64_t DMND_MAGIC = 0x24af8a415ee186dULL;
 
 bool is_dmnd(const std::string& path)
@@ -223,12 +270,16 @@ int run_blastp(const Options& o)
 		std::cerr << "Warning: repeat masking (tantan / motif) is not implemented; running as --masking 0 --motif-masking 0.\n";
 	const auto t_all = std::chrono::steady_clock::now();
 	SeqBlock q, t;
+	const bool blastx = o.command == "blastx";
+	std::vector<int32_t> source_len;
+	std::vector<std::string> read_ids;
 	auto t0 = std::chrono::steady_clock::now();
-	read_fasta(o.query, q);
+	if (blastx) read_dna_fasta_translated(o.query, q, source_len, read_ids);
+	else read_fasta(o.query, q);
 	std::string dbpath = o.db;
 	if (!std::ifstream(dbpath).good() && std::ifstream(dbpath + ".dmnd").good()) dbpath += ".dmnd";
 	if (is_dmnd(dbpath)) read_dmnd(dbpath, t); else read_fasta(dbpath, t);
-	std::cerr << "Loading sequences...  [" << ms_since(t0) / 1e3 << "s]  queries=" << q.ids.size() << " targets=" << t.ids.size() << " letters=" << t.letters << "\n";
+	std::cerr << "Loading sequences...  [" << ms_since(t0) / 1e3 << "s]  queries=" << (blastx ? read_ids.size() : q.ids.size()) << " targets=" << t.ids.size() << " letters=" << t.letters << "\n";
 	dmnd_params p;
 	dmnd_default_params(&p);
 	p.db_letters = (double)t.letters;
@@ -237,6 +288,7 @@ int run_blastp(const Options& o)
 	if (!ctx) throw std::runtime_error(dmnd_last_error());
 	auto chk = [&](int rc) { if (rc != DMND_OK) throw std::runtime_error(dmnd_last_error()); };
 	chk(dmnd_set_max_target_seqs(ctx, o.k));
+	chk(dmnd_set_query_contexts(ctx, blastx ? 6 : 1));
 	t0 = std::chrono::steady_clock::now();
 	chk(dmnd_upload_block(ctx, DMND_QUERY, q.data.data(), (int64_t)q.data.size(), q.limits.data(), (int64_t)q.ids.size()));
 	chk(dmnd_upload_block(ctx, DMND_TARGET, t.data.data(), (int64_t)t.data.size(), t.limits.data(), (int64_t)t.ids.size()));
@@ -246,6 +298,7 @@ int run_blastp(const Options& o)
 	if (o.fast) chk(dmnd_seed_params_fast(&sp, threads));
 	else if (o.sens == "--sensitive") { chk(dmnd_seed_params_sensitive(&sp, threads, &p)); chk(dmnd_set_gapped_filter(ctx, 1.0)); }
 	else chk(dmnd_seed_params_default(&sp, threads, &p));
+	sp.query_translated = blastx ? 1 : 0;
 	t0 = std::chrono::steady_clock::now();
 	int64_t n_hits = 0;
 	chk(dmnd_seed_search(ctx, &sp, &n_hits));
@@ -259,13 +312,16 @@ int run_blastp(const Options& o)
 	std::cerr << "Computing alignments (extension stage)...  [" << ms_since(t0) / 1e3 << "s]\n";
 	FILE* out = o.out.empty() ? stdout : std::fopen(o.out.c_str(), "w");
 	if (!out) throw std::runtime_error("Error opening file " + o.out);
-	std::vector<std::string> qid(q.ids.size()), tid(t.ids.size());
-	for (size_t i = 0; i < qid.size(); ++i) qid[i] = short_id(q.ids[i]);
+	const std::vector<std::string>& qtitles = blastx ? read_ids : q.ids;
+	std::vector<std::string> qid(qtitles.size()), tid(t.ids.size());
+	for (size_t i = 0; i < qid.size(); ++i) qid[i] = short_id(qtitles[i]);
 	for (size_t i = 0; i < tid.size(); ++i) tid[i] = short_id(t.ids[i]);
 	char line[8192];
 	int64_t aligned = 0;
 	for (int64_t i = 0; i < n_matches; ++i) {
-		const int w = dmnd_format_tab(&matches[(size_t)i], qid[matches[(size_t)i].query].c_str(), tid[matches[(size_t)i].target].c_str(), line, sizeof line);
+		const dmnd_match& m = matches[(size_t)i];
+		const int w = blastx ? dmnd_format_tab_translated(&m, qid[m.query].c_str(), tid[m.target].c_str(), source_len[m.query], line, sizeof line)
+			: dmnd_format_tab(&m, qid[m.query].c_str(), tid[m.target].c_str(), line, sizeof line);
 		if (w < 0) throw std::runtime_error(dmnd_last_error());
 		std::fwrite(line, 1, (size_t)w, out);
 		if (i == 0 || matches[(size_t)i].query != matches[(size_t)i - 1].query) ++aligned;
@@ -285,7 +341,8 @@ int main(int argc, char** argv)
 		if (o.command == "version") { std::cout << "diamond-hip (MI355X back end of DIAMOND's seed-and-extend path), ABI " << dmnd_abi_version() << "\n"; return 0; }
 		if (o.command == "help" || o.command == "--help") {
 			std::cout << "Syntax: diamond-hip COMMAND [OPTIONS]\n  makedb --in FASTA -d DB        build a .dmnd database (no masking)\n"
-				"  blastp [--fast|--sensitive] -q FASTA -d DB(.dmnd|FASTA) -o OUT [--masking 0] [-e EVALUE] [-k N] [-p THREADS]\n  version\n";
+				"  blastp [--fast|--sensitive] -q FASTA -d DB(.dmnd|FASTA) -o OUT [--masking 0] [-e EVALUE] [-k N] [-p THREADS]\n"
+				"  blastx [--fast|--sensitive] -q DNA_FASTA -d DB ...   (six-frame translation, standard genetic code)\n  version\n";
 			return 0;
 		}
 		if (o.command == "makedb") {
@@ -295,8 +352,8 @@ int main(int argc, char** argv)
 			write_dmnd(o.db, b);
 			return 0;
 		}
-		if (o.command == "blastp") return run_blastp(o);
-		throw std::runtime_error("Invalid command: " + o.command + " (blastx and the other workflows are not part of this build)");
+		if (o.command == "blastp" || o.command == "blastx") return run_blastp(o);
+		throw std::runtime_error("Invalid command: " + o.command + " (only makedb, blastp and blastx are part of this build)");
 	}
 	catch (const std::exception& e) {
 		std::cerr << "Error: " << e.what() << std::endl;          // main.cpp:211-232

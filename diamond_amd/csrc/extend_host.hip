@@ -54,6 +54,7 @@ struct HostCfg {
 	int64_t max_swipe_dp = 1000000;      // config.max_swipe_dp
 	int band_mode_fast = 1;              // Extension::Mode::BANDED_FAST for every sensitivity up to --sensitive
 	double ref_letters = 0;
+	int contexts = 1;                    // align_mode.query_contexts: 1 (blastp) or 6 (blastx: the block holds 6 frames per read)
 };
 
 void make_cfg(const dmnd_ctx* c, HostCfg& h)
@@ -99,7 +100,7 @@ int64_t ranking_chunk_size(double ref_letters, int max_target_seqs)       // ext
 	return std::max((int64_t)128, std::min(m32, (int64_t)400)) * block_mult;
 }
 
-struct PlanTarget { uint32_t query, target; int32_t d_begin, d_end, ungapped_score; };
+struct PlanTarget { uint32_t query, target; int32_t d_begin, d_end, ungapped_score; };      // query = block sequence id = query id * contexts + frame
 
 // One query's seed hits grouped by target (SeedHitList of load_hits) + its ranking state (extend.cpp:226-344)
 struct TargetGroup { uint32_t target; size_t begin, end; int score; bool pass; };      // pass: survives the gapped filter (any hit flagged)
@@ -132,7 +133,7 @@ void load_query(const HostCfg& h, QueryWork& w, uint32_t query, const dmnd_seed_
 		const uint32_t t = (uint32_t)(it - tl) - 1;
 		--it;
 		if (w.groups.empty() || w.groups.back().target != t) w.groups.push_back(TargetGroup{ t, x, x, 0, false });
-		w.sh[x] = HostSeedHit{ hits[x].seed_offset, (int)(s - tl[t]), hits[x].score };
+		w.sh[x] = HostSeedHit{ hits[x].seed_offset, (int)(s - tl[t]), hits[x].score, (int)(hits[x].query % (uint32_t)h.contexts) };
 		w.groups.back().end = x + 1;
 		w.groups.back().score = std::max(w.groups.back().score, (int)(uint16_t)hits[x].score);
 		w.groups.back().pass |= hits[x].pad != 0;        // gapped-filter flag of the hit (1 everywhere when the filter is off)
@@ -148,63 +149,87 @@ void load_query(const HostCfg& h, QueryWork& w, uint32_t query, const dmnd_seed_
 	w.i1 = std::min((size_t)w.chunk_size, w.order.size());
 }
 
-// ungapped_stage + chaining + add_dp_targets for the targets order[g0, g1) of one query
+// ungapped_stage + chaining + add_dp_targets for the targets order[g0, g1) of one query (all its contexts)
 void plan_groups(const HostCfg& h, ChainWorkspace& ws, QueryWork& w, size_t g0, size_t g1,
 	const int8_t* qdata, const int64_t* ql, const int8_t* tdata, const int64_t* tl, const int8_t* cbs_all, std::vector<PlanTarget>& out)
 {
-	const uint32_t query = w.query;
-	const SeqRef q{ qdata + ql[query], (int)(ql[query + 1] - ql[query] - 1) };
-	const int8_t* cbs = cbs_all ? cbs_all + ql[query] : nullptr;
-	std::vector<Seg> segs;
+	const int C = h.contexts;
+	const uint32_t q0 = w.query * (uint32_t)C;                  // block id of context 0
+	SeqRef q[6];
+	const int8_t* cbs[6];
+	for (int f = 0; f < C; ++f) {
+		q[f] = SeqRef{ qdata + ql[q0 + f], (int)(ql[q0 + f + 1] - ql[q0 + f] - 1) };
+		cbs[f] = cbs_all ? cbs_all + ql[q0 + f] : nullptr;
+	}
+	std::vector<Seg> segs[6];
 	std::vector<Chain> chains;
 	std::vector<HostSeedHit>& sh = w.sh;
-	const int base_band = band_for(q.len, h.band_mode_fast != 0);
+	const int base_band = band_for(q[0].len, h.band_mode_fast != 0);       // Extension::band(query_seq->length(), mode): context 0
 	for (size_t gi = g0; gi < g1; ++gi) {
 		const TargetGroup& g = w.groups[w.order[gi]];
 		if (!g.pass) continue;                               // gapped filter (extend.cpp:205-213): dropped before chaining
 		const SeqRef t{ tdata + tl[g.target], (int)(tl[g.target + 1] - tl[g.target] - 1) };
-		std::sort(sh.begin() + (ptrdiff_t)g.begin, sh.begin() + (ptrdiff_t)g.end, [](const HostSeedHit& a, const HostSeedHit& b) {
-			const int d1 = a.i - a.j, d2 = b.i - b.j;
-			return d1 < d2 || (d1 == d2 && a.j < b.j);
-		});
-		segs.clear();
-		int ungapped = 0;
-		for (size_t x = g.begin; x < g.end; ++x) {
-			ungapped = std::max(ungapped, sh[x].score);
-			if (!segs.empty() && segs.back().diag() == sh[x].i - sh[x].j && segs.back().j_end() >= sh[x].j) continue;
-			const Seg d = xdrop_ungapped(h.S, q, cbs, t, sh[x].i, sh[x].j, ws.cfg.xdrop);
-			if (d.score > 0) segs.push_back(d);
+		int ungapped[6] = { 0, 0, 0, 0, 0, 0 };
+		for (int f = 0; f < C; ++f) segs[f].clear();
+		const bool single_translated = C > 1 && g.end - g.begin == 1;      // ungapped.cpp:76-80: one seed hit of a translated query
+		if (single_translated) {                                           // becomes a one-diagonal ApproxHsp without extension
+			const HostSeedHit& x = sh[g.begin];
+			ungapped[x.frame] = x.score;
 		}
-		if (segs.empty()) continue;
-		std::stable_sort(segs.begin(), segs.end(), [](const Seg& a, const Seg& b) { return a.diag() < b.diag() || (a.diag() == b.diag() && a.j < b.j); });
-		ws.run(h.S, q, t, segs, chains);
-		std::stable_sort(chains.begin(), chains.end(), [](const Chain& a, const Chain& b) { return a.d_min < b.d_min; });
-		// add_dp_targets: merge overlapping bands of the target's chains
-		int d0 = INT_MAX, d1 = INT_MIN;
-		for (const Chain& c : chains) {
-			const int b0 = std::max(c.d_min - base_band, -(t.len - 1)), b1 = std::min(c.d_max + 1 + base_band, q.len);
-			const int lo = std::max(d0, b0), hi = std::min(d1, b1);
-			const double overlap = hi > lo ? hi - lo : 0;
-			// (d1 - d0) wraps for the initial (INT_MAX, INT_MIN) pair exactly as in the reference: the first chain never merges
-			const double wd = (double)(int)((unsigned)d1 - (unsigned)d0);
-			if (overlap / wd > 0.0 || overlap / (b1 - b0) > 0.0) { d0 = std::min(d0, b0); d1 = std::max(d1, b1); }
-			else {
-				if (d0 != INT_MAX) out.push_back(PlanTarget{ query, g.target, d0, d1, ungapped });
-				d0 = b0; d1 = b1;
+		else {
+			std::sort(sh.begin() + (ptrdiff_t)g.begin, sh.begin() + (ptrdiff_t)g.end, [](const HostSeedHit& a, const HostSeedHit& b) {
+				const int d1 = a.i - a.j, d2 = b.i - b.j;
+				return d1 < d2 || (d1 == d2 && a.j < b.j);
+			});
+			for (size_t x = g.begin; x < g.end; ++x) {
+				const int f = sh[x].frame;
+				ungapped[f] = std::max(ungapped[f], sh[x].score);
+				if (!segs[f].empty() && segs[f].back().diag() == sh[x].i - sh[x].j && segs[f].back().j_end() >= sh[x].j) continue;
+				const Seg d = xdrop_ungapped(h.S, q[f], cbs[f], t, sh[x].i, sh[x].j, ws.cfg.xdrop);
+				if (d.score > 0) segs[f].push_back(d);
 			}
 		}
-		if (d0 != INT_MAX) out.push_back(PlanTarget{ query, g.target, d0, d1, ungapped });
+		for (int f = 0; f < C; ++f) {
+			if (single_translated) {
+				const HostSeedHit& x = sh[g.begin];
+				if (x.frame != f) continue;
+				chains.clear();
+				chains.push_back(Chain{ x.i - x.j, x.i - x.j, x.score, x.i, x.i + 1, x.j, x.j + 1 });
+			}
+			else {
+				if (segs[f].empty()) continue;
+				std::stable_sort(segs[f].begin(), segs[f].end(), [](const Seg& a, const Seg& b) { return a.diag() < b.diag() || (a.diag() == b.diag() && a.j < b.j); });
+				ws.run(h.S, q[f], t, segs[f], chains);
+				std::stable_sort(chains.begin(), chains.end(), [](const Chain& a, const Chain& b) { return a.d_min < b.d_min; });
+			}
+			// add_dp_targets (gapped_score.cpp:107-180): merge overlapping bands of the context's chains
+			int d0 = INT_MAX, d1 = INT_MIN;
+			for (const Chain& c : chains) {
+				const int b0 = std::max(c.d_min - base_band, -(t.len - 1)), b1 = std::min(c.d_max + 1 + base_band, q[f].len);
+				const int lo = std::max(d0, b0), hi = std::min(d1, b1);
+				const double overlap = hi > lo ? hi - lo : 0;
+				// (d1 - d0) wraps for the initial (INT_MAX, INT_MIN) pair exactly as in the reference: the first chain never merges
+				const double wd = (double)(int)((unsigned)d1 - (unsigned)d0);
+				if (overlap / wd > 0.0 || overlap / (b1 - b0) > 0.0) { d0 = std::min(d0, b0); d1 = std::max(d1, b1); }
+				else {
+					if (d0 != INT_MAX) out.push_back(PlanTarget{ q0 + (uint32_t)f, g.target, d0, d1, ungapped[0] });
+					d0 = b0; d1 = b1;
+				}
+			}
+			if (d0 != INT_MAX) out.push_back(PlanTarget{ q0 + (uint32_t)f, g.target, d0, d1, ungapped[0] });
+		}
 	}
 }
 
 struct Range { size_t b, e; };
 
-std::vector<Range> split_by_query(const dmnd_seed_hit* hits, int64_t n)
+std::vector<Range> split_by_query(const dmnd_seed_hit* hits, int64_t n, int contexts)
 {
 	std::vector<Range> r;
+	const uint32_t C = (uint32_t)contexts;
 	for (int64_t i = 0; i < n;) {
 		int64_t j = i;
-		while (j < n && hits[j].query == hits[i].query) ++j;
+		while (j < n && hits[j].query / C == hits[i].query / C) ++j;
 		r.push_back(Range{ (size_t)i, (size_t)j });
 		i = j;
 	}
@@ -294,13 +319,13 @@ int plan_all(const HostCfg& h, int threads, const dmnd_seed_hit* hits, int64_t n
 	const int8_t* qdata, const std::vector<int64_t>& ql, const int8_t* tdata, const std::vector<int64_t>& tl,
 	const int8_t* cbs_all, std::vector<PlanTarget>& out)
 {
-	const std::vector<Range> qr = split_by_query(hits, n_hits);
+	const std::vector<Range> qr = split_by_query(hits, n_hits, h.contexts);
 	std::vector<std::vector<PlanTarget>> per(qr.size());
 	threads = std::max(1, threads);
 	std::vector<ChainWorkspace> ws((size_t)threads);
 	parallel_for(qr.size(), threads, [&](size_t i, int t) {
 		QueryWork w;
-		load_query(h, w, hits[qr[i].b].query, hits + qr[i].b, hits + qr[i].e, nullptr, tl.data(), (int64_t)tl.size() - 1);
+		load_query(h, w, hits[qr[i].b].query / (uint32_t)h.contexts, hits + qr[i].b, hits + qr[i].e, nullptr, tl.data(), (int64_t)tl.size() - 1);
 		plan_groups(h, ws[(size_t)t], w, 0, w.order.size(), qdata, ql.data(), tdata, tl.data(), cbs_all, per[i]);
 	});
 	size_t total = 0;
@@ -326,15 +351,17 @@ void all_hauser(const HostCfg& h, int threads, const int8_t* qdata, const std::v
 // Pure host part (no device needed): the Hauser bias of every query and the round-1 DpTargets the extension stage
 // would send to the swipe. Exposed so that the band construction can be checked on a CPU-only box.
 extern "C" int dmnd_extend_plan(const dmnd_params* params, const int8_t* qdata, const int64_t* qlimits, int64_t nq,
-	const int8_t* tdata, const int64_t* tlimits, int64_t nt, const dmnd_seed_hit* hits, int64_t n_hits, int threads,
+	const int8_t* tdata, const int64_t* tlimits, int64_t nt, const dmnd_seed_hit* hits, int64_t n_hits, int threads, int query_contexts,
 	int8_t* cbs_out, dmnd_plan_target* out, int64_t cap, int64_t* n_out)
 {
 	if (!params || !qdata || !qlimits || !tdata || !tlimits || (!hits && n_hits) || !n_out) return fail(DMND_E_ARG, "dmnd_extend_plan: NULL argument");
+	if ((query_contexts != 1 && query_contexts != 6) || nq % query_contexts != 0) return fail(DMND_E_ARG, "dmnd_extend_plan: query_contexts must be 1 or 6 and divide the block size");
 	dmnd_ctx tmp;
 	tmp.params = *params;
 	HostCfg h;
 	make_cfg(&tmp, h);
 	h.ref_letters = (double)(tlimits[nt] - tlimits[0] - nt);
+	h.contexts = query_contexts;
 	const std::vector<int64_t> ql(qlimits, qlimits + nq + 1), tl(tlimits, tlimits + nt + 1);
 	std::vector<int8_t> cbs;
 	all_hauser(h, threads, qdata, ql, cbs);
@@ -352,7 +379,7 @@ namespace {
 
 struct Cand {              // one target of one query after round 1 (Extension::Target with max_hsps = 1)
 	uint32_t target;
-	int score, d_begin, d_end, ungapped;
+	int score, d_begin, d_end, ungapped, frame;
 	double evalue;
 };
 
@@ -418,6 +445,9 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	HostCfg h;
 	make_cfg(c, h);
 	h.max_target_seqs = c->max_target_seqs;
+	h.contexts = c->query_contexts;
+	const uint32_t C = (uint32_t)h.contexts;
+	if ((ql.size() - 1) % C != 0) return fail(DMND_E_ARG, "dmnd_extend: query block size is not a multiple of the query contexts");
 	h.ref_letters = (double)(tl.back() - tl.front() - ((int64_t)tl.size() - 1));
 	if (hsp_values == 0) hsp_values = 510;
 	const int K = h.max_target_seqs;
@@ -432,12 +462,14 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	double t_mark = now();
 	auto lap = [&](int slot) { const double t = now(); c->ext_stats[slot] += t - t_mark; t_mark = t; };
 	// 1. Hauser bias for every query, resident next to the query block
-	const std::vector<Range> qr = split_by_query(hits, n_hits);
+	const std::vector<Range> qr = split_by_query(hits, n_hits, h.contexts);
 	std::vector<int8_t> cbs((size_t)ql.back() + 64, 0);            // only queries with seed hits are ever aligned
 	parallel_for(qr.size(), threads, [&](size_t i, int) {
-		const uint32_t q = hits[qr[i].b].query;
-		const SeqRef s{ qdata + ql[q], (int)(ql[q + 1] - ql[q] - 1) };
-		if (s.len > 0) hauser_int8(h, s, cbs.data() + ql[q]);
+		const uint32_t q0 = hits[qr[i].b].query / C * C;
+		for (uint32_t q = q0; q < q0 + C; ++q) {
+			const SeqRef s{ qdata + ql[q], (int)(ql[q + 1] - ql[q] - 1) };
+			if (s.len > 0) hauser_int8(h, s, cbs.data() + ql[q]);
+		}
 	});
 	if (int rc = dmnd_upload_cbs(c, cbs.data(), ql.back())) return rc;
 	lap(4);
@@ -452,7 +484,7 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	// 2. load_hits for every query
 	std::vector<QueryState> qs(qr.size());
 	parallel_for(qr.size(), threads, [&](size_t i, int) {
-		load_query(h, qs[i].w, hits[qr[i].b].query, hits + qr[i].b, hits + qr[i].e, gf.empty() ? nullptr : gf.data() + qr[i].b, tl.data(), (int64_t)tl.size() - 1);
+		load_query(h, qs[i].w, hits[qr[i].b].query / (uint32_t)h.contexts, hits + qr[i].b, hits + qr[i].e, gf.empty() ? nullptr : gf.data() + qr[i].b, tl.data(), (int64_t)tl.size() - 1);
 		if (qs[i].w.order.empty()) qs[i].done = true;
 	});
 	std::vector<ChainWorkspace> ws((size_t)threads);
@@ -491,8 +523,8 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 				c->ext_stats[0] += (double)items.size(); c->ext_stats[2] += cells_of(items);
 			}
 			lap(6);
-			for (size_t i : active) {
-				QueryState& s = qs[i];
+			parallel_for(active.size(), threads, [&](size_t ai, int) {
+				QueryState& s = qs[active[ai]];
 				// extend_chunk -> align (gapped_score.cpp:182-268): report cutoff, best HSP per target
 				std::vector<Cand> v;
 				for (size_t x = s.item_begin; x < s.item_end; ++x) {
@@ -501,11 +533,17 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 					if (score <= 0) continue;
 					const double ev = c->evaluer.evalue(score, (unsigned)items[x].query_len, (unsigned)items[x].target_len);
 					if (ev > c->params.max_evalue) continue;
+					const int frame = (int)(p.query % C);
 					if (!v.empty() && v.back().target == p.target) {
-						Cand& k = v.back();     // inner_culling keeps the best HSP by (score desc, d_begin asc) (Hsp::operator<, match.h:199)
-						if (score > k.score || (score == k.score && p.d_begin < k.d_begin)) { k.score = score; k.evalue = ev; k.d_begin = p.d_begin; k.d_end = p.d_end; }
+						// Target::add_hit(list, it) (target.h:105-113): the best context is the first one (contexts ascending) that
+						// reaches the maximum score; inner_culling then keeps that context's best HSP by (score desc, d_begin asc)
+						// (Hsp::operator<, match.h:199)
+						Cand& k = v.back();
+						if (score > k.score || (score == k.score && frame == k.frame && p.d_begin < k.d_begin)) {
+							k.score = score; k.evalue = ev; k.d_begin = p.d_begin; k.d_end = p.d_end; k.frame = frame;
+						}
 					}
-					else v.push_back(Cand{ p.target, score, p.d_begin, p.d_end, p.ungapped_score, ev });
+					else v.push_back(Cand{ p.target, score, p.d_begin, p.d_end, p.ungapped_score, frame, ev });
 				}
 				const bool multi_chunk = (s.w.i1 - s.w.i0) < s.w.order.size();
 				bool new_hits = s.new_hits_ev = !v.empty();
@@ -522,7 +560,7 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 					|| (double)next_tail / (double)s.previous_tail_score <= 0.95
 					|| c->evaluer.bitscore(next_tail) < 25.0);
 				if (!(s.w.i0 < s.w.order.size() && !terminate)) s.in_inner = false;
-			}
+			});
 			lap(7);
 		}
 		// ---- round 2 for every query that just left the inner loop ----
@@ -537,7 +575,7 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 			cull(s.aligned, false, K);                                          // extend.cpp:331
 			for (size_t k = 0; k < s.aligned.size(); ++k) {
 				const Cand& cd = s.aligned[k];
-				const dmnd_dp_target d = item_of(s.w.query, cd.target, cd.d_begin, cd.d_end);
+				const dmnd_dp_target d = item_of(s.w.query * C + (uint32_t)cd.frame, cd.target, cd.d_begin, cd.d_end);
 				const int64_t dp_size = (int64_t)dmnd_banded_cols(d.query_len, d.target_len, d.d_begin, d.d_end) * (int64_t)(d.d_end - d.d_begin);
 				if (dp_size > h.max_swipe_dp) { it_st.push_back(d); ref_st.push_back(Ref{ i, k }); }      // DP::BandedSwipe::bin
 				else { it_tb.push_back(d); ref_tb.push_back(Ref{ i, k }); }
@@ -573,22 +611,24 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 		}
 		c->ext_stats[1] += (double)(it_tb.size() + it_st.size()); c->ext_stats[3] += cells_of(it_tb) + cells_of(it_st);
 		lap(8);
-		for (size_t i : batch) {
+		parallel_for(batch.size(), threads, [&](size_t bi, int) {
+			const size_t i = batch[bi];
 			QueryState& s = qs[i];
 			// align() round 2 (gapped_final.cpp:80-160): report cutoff again, culling of this round's matches
 			std::vector<dmnd_match> round;
 			const uint32_t q = s.w.query;
-			const int qlen = (int)(ql[q + 1] - ql[q] - 1);
 			for (size_t k = 0; k < s.aligned.size(); ++k) {
 				const Cand& cd = s.aligned[k];
 				const dmnd_hsp& hsp = r2[i][k];
 				if (hsp.score <= 0) continue;
 				const int tlen = (int)(tl[cd.target + 1] - tl[cd.target] - 1);
+				const uint32_t qc = q * C + (uint32_t)cd.frame;
+				const int qlen = (int)(ql[qc + 1] - ql[qc] - 1);
 				const double ev = c->evaluer.evalue(hsp.score, (unsigned)qlen, (unsigned)tlen);
 				if (ev > c->params.max_evalue) continue;
 				dmnd_match m;
 				m.query = q; m.target = cd.target; m.evalue = ev; m.bit_score = c->evaluer.bitscore(hsp.score);
-				m.ungapped_score = cd.ungapped; m.d_begin = cd.d_begin; m.d_end = cd.d_end; m.pad = 0; m.hsp = hsp;
+				m.ungapped_score = cd.ungapped; m.d_begin = cd.d_begin; m.d_end = cd.d_end; m.frame = cd.frame; m.hsp = hsp;
 				round.push_back(m);
 			}
 			std::sort(round.begin(), round.end(), match_less);
@@ -598,7 +638,7 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 			// outer loop condition (extend.cpp:336)
 			if ((int)s.matches.size() < K && s.w.i0 < s.w.order.size() && s.new_hits_ev) s.in_inner = true;
 			else s.done = true;
-		}
+		});
 		lap(7);
 	}
 	c->swipe_ms = sw1 + sw2; c->traceback_ms = tb2;
@@ -638,9 +678,10 @@ extern "C" int dmnd_extend_stats(const dmnd_ctx* c, double out[12])
 
 // BLAST tabular line of one match (qseqid sseqid pident length mismatch gapopen qstart qend sstart send evalue bitscore),
 // formatted as the reference prints it (src/output/blast_tab_format.cpp; util/text_buffer.h:238-260).
-extern "C" int dmnd_format_tab(const dmnd_match* m, const char* qseqid, const char* sseqid, char* buf, int64_t cap)
+namespace {
+
+int format_tab_impl(const dmnd_match* m, const char* qseqid, const char* sseqid, int qstart, int qend, char* buf, int64_t cap)
 {
-	if (!m || !qseqid || !sseqid || !buf) return fail(DMND_E_ARG, "dmnd_format_tab: NULL argument");
 	const dmnd_hsp& h = m->hsp;
 	// Util::String::format_double (util/string/string.h:87-92): >= 100 -> floor, else one rounded decimal
 	auto fd = [](double x, char* p, size_t n) {
@@ -653,6 +694,100 @@ extern "C" int dmnd_format_tab(const dmnd_match* m, const char* qseqid, const ch
 	else std::snprintf(ev, sizeof ev, "%.2e", m->evalue);
 	fd(m->bit_score, bs, sizeof bs);
 	const int w = std::snprintf(buf, (size_t)cap, "%s\t%s\t%s\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%s\t%s\n", qseqid, sseqid, pid, h.length,
-		h.mismatches, h.gap_openings, h.q_begin + 1, h.q_end, h.s_begin + 1, h.s_end, ev, bs);
+		h.mismatches, h.gap_openings, qstart, qend, h.s_begin + 1, h.s_end, ev, bs);
 	return w < cap ? w : DMND_E_CAP;
+}
+
+}
+
+extern "C" int dmnd_format_tab(const dmnd_match* m, const char* qseqid, const char* sseqid, char* buf, int64_t cap)
+{
+	if (!m || !qseqid || !sseqid || !buf) return fail(DMND_E_ARG, "dmnd_format_tab: NULL argument");
+	return format_tab_impl(m, qseqid, sseqid, m->hsp.q_begin + 1, m->hsp.q_end, buf, cap);
+}
+
+// Hsp::oriented_query_range over query_source_range (basic/match.h:168-174; TranslatedPosition::absolute_interval,
+// basic/translated_position.h:131-137): forward frame f reads DNA [f + 3 b, f + 3 e), reverse frames count from the 3' end
+extern "C" int dmnd_format_tab_translated(const dmnd_match* m, const char* qseqid, const char* sseqid, int32_t source_len, char* buf, int64_t cap)
+{
+	if (!m || !qseqid || !sseqid || !buf) return fail(DMND_E_ARG, "dmnd_format_tab_translated: NULL argument");
+	if (m->frame < 0 || m->frame > 5) return fail(DMND_E_ARG, "dmnd_format_tab_translated: frame out of range");
+	const int b = m->hsp.q_begin, e = m->hsp.q_end;
+	int qstart, qend;
+	if (m->frame < 3) { qstart = m->frame + 3 * b + 1; qend = m->frame + 3 * e; }
+	else { const int off = m->frame - 3; qstart = source_len - off - 3 * b; qend = source_len - off - 3 * e + 1; }
+	return format_tab_impl(m, qseqid, sseqid, qstart, qend, buf, cap);
+}
+
+extern "C" int dmnd_set_query_contexts(dmnd_ctx* c, int contexts)
+{
+	if (!c || (contexts != 1 && contexts != 6)) return fail(DMND_E_ARG, "dmnd_set_query_contexts: contexts must be 1 (blastp) or 6 (blastx)");
+	c->query_contexts = contexts;
+	return DMND_OK;
+}
+
+// ---- six-frame translation (blastx query loading) ---------------------------------------------------------------------
+namespace {
+
+struct CodonTable {
+	int8_t fwd[5][5][5], rev[5][5][5];
+	CodonTable()
+	{
+		// Translator::init(1) (basic/basic.cpp:116-139): NCBI table 1, base order TCAG; DNA letters A C G T N = 0..4
+		static const char* code = "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";
+		static const char* aa = "ARNDCQEGHILKMFPSTWYVBJZX*_";
+		static const int idx[4] = { 2, 1, 3, 0 }, comp[5] = { 3, 2, 1, 0, 4 };
+		auto letter = [&](char ch) { return (int8_t)(std::strchr(aa, ch) - aa); };
+		for (int i = 0; i < 5; ++i)
+			for (int j = 0; j < 5; ++j)
+				for (int k = 0; k < 5; ++k) {
+					if (i == 4 || j == 4 || k == 4) { fwd[i][j][k] = rev[i][j][k] = 23; continue; }
+					fwd[i][j][k] = letter(code[idx[i] * 16 + idx[j] * 4 + idx[k]]);
+					rev[i][j][k] = letter(code[idx[comp[i]] * 16 + idx[comp[j]] * 4 + idx[comp[k]]]);
+				}
+		for (int i = 0; i < 4; ++i)            // an N in the wobble position that cannot change the amino acid
+			for (int j = 0; j < 4; ++j) {
+				bool f = true, r = true;
+				for (int k = 1; k < 4; ++k) { f &= fwd[i][j][k] == fwd[i][j][0]; r &= rev[i][j][k] == rev[i][j][0]; }
+				if (f) fwd[i][j][4] = fwd[i][j][0];
+				if (r) rev[i][j][4] = rev[i][j][0];
+			}
+	}
+};
+
+// Util::Seq::find_orfs (util/sequence/sequence.cpp:180-197): stretches between stop codons shorter than min_len -> X
+void mask_short_orfs(int8_t* s, int n, int min_len)
+{
+	int begin = 0;
+	for (int i = 0; i <= n; ++i)
+		if (i == n || s[i] == 24) {
+			if (i - begin < min_len) for (int x = begin; x < i; ++x) s[x] = 23;
+			begin = i + 1;
+		}
+}
+
+}
+
+extern "C" int dmnd_translate(const int8_t* dna, int32_t len, int8_t* out[6], int32_t lens[6])
+{
+	if (!dna || !out || !lens || len < 0) return fail(DMND_E_ARG, "dmnd_translate: bad argument");
+	static const CodonTable T;
+	for (int f = 0; f < 6; ++f) lens[f] = 0;
+	if (len < 3) return DMND_OK;
+	for (int32_t i = 0; i < len; ++i)
+		if (dna[i] < 0 || dna[i] > 4) return fail(DMND_E_ARG, "dmnd_translate: DNA letters must be 0-4 (ACGTN)");
+	for (int f = 0; f < 3; ++f) {
+		const int n = (len - f) / 3;
+		lens[f] = lens[f + 3] = n;
+		for (int i = 0; i < n; ++i) {
+			const int p = 3 * i + f;                                    // Translator::getAminoAcid
+			out[f][i] = T.fwd[dna[p]][dna[p + 1]][dna[p + 2]];
+			const int r = len - 3 - f - 3 * i;                           // Translator::getAminoAcidReverse(dna, r): letters r+2, r+1, r
+			out[f + 3][i] = T.rev[dna[r + 2]][dna[r + 1]][dna[r]];
+		}
+	}
+	// config.min_orf_len(frame 0 length) with the default run_len 0 (basic/config.h:413-424)
+	const int l0 = lens[0], min_len = l0 < 30 ? 1 : l0 < 100 ? 20 : 40;
+	for (int f = 0; f < 6; ++f) mask_short_orfs(out[f], lens[f], min_len);
+	return DMND_OK;
 }

@@ -64,6 +64,7 @@ extern "C" int dmnd_gapped_filter(dmnd_ctx* c, const dmnd_seed_hit* hits, int64_
 	a.p.gap_open = c->params.gap_open; a.p.gap_extend = c->params.gap_extend;
 	a.p.window2 = 200;                                                                               // config.gapped_filter_window
 	a.p.use_cbs = use_cbs ? 1 : 0;
+	a.p.contexts = c->query_contexts;
 	a.qdata = c->block[DMND_QUERY].as<int8_t>(); a.tdata = c->block[DMND_TARGET].as<int8_t>(); a.cbs = c->cbs.as<int8_t>();
 	a.qlimits = c->d_limits[DMND_QUERY].as<int64_t>(); a.tlimits = c->d_limits[DMND_TARGET].as<int64_t>();
 	a.n_targets = (int64_t)c->limits[DMND_TARGET].size() - 1;

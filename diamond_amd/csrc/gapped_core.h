@@ -18,6 +18,7 @@ struct GfParams {
 	int32_t gap_open, gap_extend;
 	int32_t window2;             // config.gapped_filter_window (200)
 	int32_t use_cbs;
+	int32_t contexts;            // align_mode.query_contexts; > 1 = translated queries (rules of extend.cpp:206, gapped_filter.cpp:43,54)
 };
 
 // Column range the scan runs over, equal for all diagonals of the band (out-of-query cells score the padding value -1)

@@ -83,7 +83,17 @@ __global__ __launch_bounds__(256) void gapped_filter_kernel(const GfArgs a)
 		const int hit_j = (int)(subject - t0);
 		const int8_t* q = a.qdata + q0; const int8_t* t = a.tdata + t0;
 		const int8_t* cbs = a.p.use_cbs ? a.cbs + q0 : nullptr;
-		const int b1 = bit_length32((uint32_t)qlen), b2 = bit_length32((uint32_t)slen);
+		// cutoffs use the length of the query's context 0 (gapped_filter.cpp:43: query_profile->length())
+		int qlen0 = qlen;
+		if (a.p.contexts > 1) {
+			const uint32_t c0 = query / (uint32_t)a.p.contexts * (uint32_t)a.p.contexts;
+			qlen0 = (int)(a.qlimits[c0 + 1] - a.qlimits[c0] - 1);
+			if (qlen0 < 85) {                                     // GAPPED_FILTER_MIN_QLEN, extend.cpp:195,206: filter not applied
+				if (lane == 0) { a.flags[h] = 1; if (a.scores) { a.scores[2 * h] = -1; a.scores[2 * h + 1] = -1; } }
+				continue;
+			}
+		}
+		const int b1 = bit_length32((uint32_t)qlen0), b2 = bit_length32((uint32_t)slen);
 		int d, jb, je, j0, j1;
 		hit_window(hit_i, hit_j, slen, 64, 100, d, jb, je);
 		scan_range(qlen, d, 64, jb, je, j0, j1);
@@ -94,7 +104,8 @@ __global__ __launch_bounds__(256) void gapped_filter_kernel(const GfArgs a)
 		for (int i = 0; i < 64; ++i) al.step(a.p, sread(s1, i), i);
 		const int f1 = al.best;
 		int f2 = -1;
-		if (f1 > a.cutoff1[b1 * 32 + b2]) {
+		const bool stage1_only = a.p.contexts > 1 && qlen0 < 100;       // MIN_STAGE2_QLEN, gapped_filter.cpp:44,54
+		if (f1 > a.cutoff1[b1 * 32 + b2] && !stage1_only) {
 			hit_window(hit_i, hit_j, slen, 128, a.p.window2, d, jb, je);
 			scan_range(qlen, d, 128, jb, je, j0, j1);
 			scan_diags_lds<2>(M, q, qlen, cbs, t, d + lane, j0, j1, sa, sb);
@@ -104,7 +115,7 @@ __global__ __launch_bounds__(256) void gapped_filter_kernel(const GfArgs a)
 			f2 = al.best;
 		}
 		if (lane == 0) {
-			a.flags[h] = (uint8_t)(f2 >= 0 && f2 > a.cutoff2[b1 * 32 + b2]);
+			a.flags[h] = (uint8_t)(stage1_only ? f1 > a.cutoff1[b1 * 32 + b2] : (f2 >= 0 && f2 > a.cutoff2[b1 * 32 + b2]));
 			if (a.scores) { a.scores[2 * h] = f1; a.scores[2 * h + 1] = f2; }
 		}
 	}

@@ -39,6 +39,8 @@ struct SeedParams {
 	int32_t use_ungapped, short_query_max_len, short_query_cutoff;
 	int32_t cutoff_table[32];                                // CutoffTable::data_[bit_length(query_len)]
 	int32_t tile_size, simd_lanes;                           // config.tile_size (1024); int8 lanes of the reference build (AVX2: 32)
+	int32_t query_translated;                                // align_mode.query_translated (blastx): short-frame rules of stage2.h:51,58-63
+	int32_t pad_;
 };
 
 DMND_HD bool is_amino_acid(int l) { return l != L_MASK && l != L_DELIM && l != L_STOP; }
@@ -196,13 +198,19 @@ DMND_HD uint64_t seed_mask_bits(const uint8_t* mask_time, int len, int t_now)
 	return m;
 }
 
+// ungapped_window(query_len) (stage2.h:58-63): frames of translated reads no longer than 85 use their whole length
+DMND_HD int stage2_window(const SeedParams& c, int query_len)
+{
+	return (c.query_translated && query_len <= 85) ? query_len : c.ungapped_window;
+}
+
 // search_query_offset + left_most_filter for one (query position, reference position) pair that passed the
 // Hamming filter (stage2.h:74-154, left_most.h:62-108). q/s point at the seed positions inside the blocks,
 // qmt at the query position's entry of mask_time[]. Returns true if the pair is kept (it is the left-most
 // seed hit of its diagonal in index-chunk order).
-DMND_HD bool left_most_pair(const SeedParams& c, const int8_t* q, const uint8_t* qmt, const int8_t* s, int seed_offset, int sid, int chunk)
+DMND_HD bool left_most_pair(const SeedParams& c, const int8_t* q, const uint8_t* qmt, const int8_t* s, int seed_offset, int sid, int chunk, int query_len)
 {
-	const int window = c.ungapped_window;
+	const int window = stage2_window(c, query_len);
 	int cb, ce;
 	clip_window(q - window, 2 * window, window, cb, ce);           // query_clipped, stage2.h:94
 	const int window_left0 = window - cb, clipped_len = ce - cb;
@@ -262,6 +270,8 @@ DMND_HD int ungapped_cutoff(const SeedParams& c, int query_len)
 {
 	if (!c.use_ungapped) return 0;
 	if (query_len <= c.short_query_max_len) return c.short_query_cutoff;
+	// 60 < len <= 85 of a translated query: cutoff_table_short = CutoffTable(ungapped_evalue_short), the same table for every
+	// sensitivity this library presets (ungapped_evalue_short == ungapped_evalue, setup.cpp:40-53)
 	int b = 0;
 	for (uint32_t x = (uint32_t)query_len; x; x >>= 1) ++b;
 	return c.cutoff_table[b];

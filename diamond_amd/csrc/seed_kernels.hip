@@ -212,11 +212,12 @@ __global__ void seed_pair_kernel(SeedArgs a, int sid, int64_t n_matched)
 		const uint32_t qid = a.qid_of[qp];
 		const int seed_offset = (int)(qp - a.qlimits[qid]);
 		int score = 0xFFFF;
+		const int query_len = (int)(a.qlimits[qid + 1] - a.qlimits[qid] - 1);
 		if (a.params.use_ungapped) {
 			// stage-2 ungapped window score over the query window clipped at its sequence ends (stage2.h:92-113)
-			const int cutoff = ungapped_cutoff(a.params, (int)(a.qlimits[qid + 1] - a.qlimits[qid] - 1));
+			const int cutoff = ungapped_cutoff(a.params, query_len);
 			if (cutoff) {
-				const int window = a.params.ungapped_window;
+				const int window = stage2_window(a.params, query_len);
 				int cb, ce;
 				clip_window(q - window, 2 * window, window, cb, ce);
 				const int window_left = window - cb;
@@ -228,7 +229,7 @@ __global__ void seed_pair_kernel(SeedArgs a, int sid, int64_t n_matched)
 				if (score <= cutoff) continue;
 			}
 		}
-		if (!left_most_pair(a.params, q, a.mask_time + qp, s, seed_offset, sid, chunk)) continue;
+		if (!left_most_pair(a.params, q, a.mask_time + qp, s, seed_offset, sid, chunk, query_len)) continue;
 		const unsigned long long idx = atomicAdd(a.hit_count, 1ull);
 		if (idx < (unsigned long long)a.hit_cap) {
 			dmnd_seed_hit h;

@@ -35,13 +35,14 @@ class SeedParams(ctypes.Structure):
                 ("ungapped_window", ctypes.c_int32), ("left_most_interval", ctypes.c_int32),
                 ("seed_complexity_cut", ctypes.c_double),
                 ("use_ungapped", ctypes.c_int32), ("short_query_max_len", ctypes.c_int32), ("short_query_cutoff", ctypes.c_int32),
-                ("cutoff_table", ctypes.c_int32 * 32), ("tile_size", ctypes.c_int32), ("simd_lanes", ctypes.c_int32)]
+                ("cutoff_table", ctypes.c_int32 * 32), ("tile_size", ctypes.c_int32), ("simd_lanes", ctypes.c_int32),
+                ("query_translated", ctypes.c_int32), ("pad_", ctypes.c_int32)]
 
 
 SEED_HIT_DTYPE = np.dtype([("query", "<u4"), ("seed_offset", "<i4"), ("subject", "<i8"), ("score", "<i4"), ("pad", "<i4")])
 
 MATCH_DTYPE = np.dtype([("query", "<u4"), ("target", "<u4"), ("ungapped_score", "<i4"), ("d_begin", "<i4"), ("d_end", "<i4"),
-                        ("pad", "<i4"), ("evalue", "<f8"), ("bit_score", "<f8"),
+                        ("frame", "<i4"), ("evalue", "<f8"), ("bit_score", "<f8"),
                         ("hsp", [("score", "<i4"), ("q_begin", "<i4"), ("q_end", "<i4"), ("s_begin", "<i4"), ("s_end", "<i4"),
                                  ("length", "<i4"), ("identities", "<i4"), ("mismatches", "<i4"), ("positives", "<i4"),
                                  ("gap_openings", "<i4"), ("gaps", "<i4"), ("transcript_len", "<i4"), ("transcript_off", "<i8")])])
@@ -65,7 +66,8 @@ EXPORTS = ["dmnd_abi_version", "dmnd_last_error", "dmnd_default_params", "dmnd_c
            "dmnd_banded_swipe_host", "dmnd_banded_cols", "dmnd_evalue", "dmnd_bitscore", "dmnd_evalue_p",
            "dmnd_bitscore_p", "dmnd_evalue_batch", "dmnd_last_kernel_ms", "dmnd_seed_params_fast", "dmnd_seed_params_default", "dmnd_seed_search",
            "dmnd_seed_hits", "dmnd_seed_kernel_ms", "dmnd_extend_plan", "dmnd_extend", "dmnd_extend_stats", "dmnd_format_tab", "dmnd_set_max_target_seqs",
-           "dmnd_seed_params_sensitive", "dmnd_set_gapped_filter", "dmnd_gapped_filter", "dmnd_gapped_filter_ms"]
+           "dmnd_seed_params_sensitive", "dmnd_set_gapped_filter", "dmnd_gapped_filter", "dmnd_gapped_filter_ms",
+           "dmnd_set_query_contexts", "dmnd_translate", "dmnd_format_tab_translated"]
 
 
 def load():
@@ -110,6 +112,9 @@ def load():
         lib.dmnd_extend.argtypes = [v, v, v, v, ctypes.c_int64, ctypes.c_int, ctypes.c_uint32, v, ctypes.c_int64,
                                     ctypes.POINTER(ctypes.c_int64), v, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
         lib.dmnd_format_tab.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int64]
+        lib.dmnd_format_tab_translated.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int32, ctypes.c_char_p, ctypes.c_int64]
+        lib.dmnd_set_query_contexts.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        lib.dmnd_translate.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
         lib.dmnd_last_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
         _lib = lib
     return _lib
@@ -146,8 +151,9 @@ def seed_params_fast(threads=1):
     return p
 
 
-def extend_plan(params, qdata, qlimits, tdata, tlimits, hits, threads=1):
-    """Host-only: (Hauser int8 bias parallel to qdata, round-1 DpTargets) for seed hits sorted by query."""
+def extend_plan(params, qdata, qlimits, tdata, tlimits, hits, threads=1, query_contexts=1):
+    """Host-only: (Hauser int8 bias parallel to qdata, round-1 DpTargets) for seed hits sorted by query.
+    query_contexts = 6 for a translated (blastx) query block; PLAN records then carry the frame's block sequence id."""
     lib = load()
     qd = np.ascontiguousarray(qdata, dtype=np.int8)
     td = np.ascontiguousarray(tdata, dtype=np.int8)
@@ -161,21 +167,26 @@ def extend_plan(params, qdata, qlimits, tdata, tlimits, hits, threads=1):
     v = ctypes.c_void_p
     rc = lib.dmnd_extend_plan(ctypes.byref(params), qd.ctypes.data_as(v), ql.ctypes.data_as(v), ctypes.c_int64(ql.size - 1),
                               td.ctypes.data_as(v), tl.ctypes.data_as(v), ctypes.c_int64(tl.size - 1),
-                              hits.ctypes.data_as(v), ctypes.c_int64(hits.size), int(threads), cbs.ctypes.data_as(v),
+                              hits.ctypes.data_as(v), ctypes.c_int64(hits.size), int(threads), int(query_contexts), cbs.ctypes.data_as(v),
                               out.ctypes.data_as(v), ctypes.c_int64(cap), ctypes.byref(n))
     if rc != 0:
         raise DiamondHipError(lib.dmnd_last_error().decode())
     return cbs, out[:n.value].copy()
 
 
-def format_tab(matches, qids, tids):
-    """BLAST tabular text (-f 6 default columns) of match records, as the reference prints it."""
+def format_tab(matches, qids, tids, source_lens=None):
+    """BLAST tabular text (-f 6 default columns) of match records, as the reference prints it.
+    source_lens: DNA read lengths for translated (blastx) matches -> qstart/qend in read coordinates."""
     lib = load()
     buf = ctypes.create_string_buffer(4096)
     out = []
     for m in matches:
         rec = np.ascontiguousarray(m)
-        n = lib.dmnd_format_tab(rec.ctypes.data_as(ctypes.c_void_p), qids[int(m["query"])].encode(), tids[int(m["target"])].encode(), buf, 4096)
+        if source_lens is not None:
+            n = lib.dmnd_format_tab_translated(rec.ctypes.data_as(ctypes.c_void_p), qids[int(m["query"])].encode(), tids[int(m["target"])].encode(),
+                                               int(source_lens[int(m["query"])]), buf, 4096)
+        else:
+            n = lib.dmnd_format_tab(rec.ctypes.data_as(ctypes.c_void_p), qids[int(m["query"])].encode(), tids[int(m["target"])].encode(), buf, 4096)
         if n < 0:
             raise DiamondHipError(lib.dmnd_last_error().decode())
         out.append(buf.raw[:n].decode())
@@ -198,6 +209,33 @@ def seed_params_sensitive(scoring, threads=1):
     if rc != 0:
         raise DiamondHipError(load().dmnd_last_error().decode())
     return p
+
+
+def translate(dna):
+    """Six-frame translation of one DNA read (int8 letters 0-4 = ACGTN) as the reference loads a blastx query.
+    Returns a list of six int8 arrays (frames 0-2 forward, 3-5 reverse)."""
+    lib = load()
+    dna = np.ascontiguousarray(dna, dtype=np.int8)
+    n = dna.size // 3
+    bufs = [np.zeros(max(n, 1), np.int8) for _ in range(6)]
+    ptrs = (ctypes.c_void_p * 6)(*[b.ctypes.data for b in bufs])
+    lens = (ctypes.c_int32 * 6)()
+    rc = lib.dmnd_translate(dna.ctypes.data_as(ctypes.c_void_p), ctypes.c_int32(dna.size), ptrs, lens)
+    if rc != 0:
+        raise DiamondHipError(lib.dmnd_last_error().decode())
+    return [bufs[f][:lens[f]].copy() for f in range(6)]
+
+
+def translated_block(dna, off):
+    """SequenceSet block (data, limits) of the six frames of every read, in the reference's order (read-major)."""
+    from . import workload
+    frames = []
+    for i in range(len(off) - 1):
+        frames.extend(translate(dna[off[i]:off[i + 1]]))
+    lens = np.array([len(f) for f in frames], np.int64)
+    o = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    data = np.concatenate(frames) if frames else np.zeros(0, np.int8)
+    return workload.sequence_set(data, o)
 
 
 def matrix_of(p):
@@ -284,6 +322,10 @@ class Context:
         hits = np.zeros(n.value, dtype=SEED_HIT_DTYPE)
         self._check(self.lib.dmnd_seed_hits(self.h, hits.ctypes.data if n.value else None, n.value))
         return hits
+
+    def set_query_contexts(self, contexts):
+        """1 = blastp, 6 = blastx (the query block holds the six frames of every read consecutively)."""
+        self._check(self.lib.dmnd_set_query_contexts(self.h, int(contexts)))
 
     def set_gapped_filter(self, evalue):
         """Search::Config::gapped_filter_evalue (1.0 for --sensitive; 0 switches the filter off)."""

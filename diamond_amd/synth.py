@@ -65,3 +65,55 @@ def write_fasta(path, prefix, data, off):
                                off.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), ctypes.c_int64(len(off) - 1))
     if rc != 0:
         raise OSError("cannot write " + path)
+
+
+# ---- DNA reads for blastx (BASELINE config C4) ------------------------------------------------------------------------
+_AA = "ARNDCQEGHILKMFPSTWYVBJZX*_"
+_STD_CODE = "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG"      # NCBI table 1, base order TCAG
+_NT = "ACGTN"
+
+
+def back_translate(q, q_off, seed=1, flank=(0, 60), reverse_frac=0.5):
+    """Synthetic DNA reads: every protein query is written with uniformly chosen synonymous codons (standard code),
+    wrapped in random flanks (so that the coding frame varies) and reverse-complemented with probability reverse_frac.
+    Returns (dna int8[] in ACGTN = 0..4 coding, offsets int64[n+1])."""
+    rng = np.random.default_rng(seed)
+    base = {"T": 3, "C": 1, "A": 0, "G": 2}
+    order = "TCAG"
+    codons = [[] for _ in range(20)]
+    for i, aa in enumerate(_STD_CODE):
+        if aa != "*":
+            codons[_AA.index(aa)].append((base[order[i // 16]], base[order[(i // 4) % 4]], base[order[i % 4]]))
+    n_cod = np.array([len(c) for c in codons])
+    table = np.zeros((20, 6, 3), np.int8)
+    for a, cs in enumerate(codons):
+        for k, c in enumerate(cs):
+            table[a, k] = c
+    q = np.asarray(q)
+    aa = np.where(q < 20, q, 0).astype(np.int64)                 # ambiguity letters do not occur in the generator's output
+    pick = (rng.random(aa.size) * n_cod[aa]).astype(np.int64)
+    coding = table[aa, pick].reshape(-1)                          # 3 nt per residue, concatenated over all queries
+    n = len(q_off) - 1
+    left = rng.integers(flank[0], flank[1] + 1, n)
+    right = rng.integers(flank[0], flank[1] + 1, n)
+    rev = rng.random(n) < reverse_frac
+    lens = 3 * np.diff(q_off) + left + right
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    out = rng.integers(0, 4, int(off[-1])).astype(np.int8)        # flanks = random bases
+    for i in range(n):
+        a, b = 3 * int(q_off[i]), 3 * int(q_off[i + 1])
+        s = int(off[i]) + int(left[i])
+        out[s:s + (b - a)] = coding[a:b]
+        if rev[i]:
+            r = out[off[i]:off[i + 1]][::-1]
+            out[off[i]:off[i + 1]] = np.where(r < 4, 3 - r, r)
+    return out, off
+
+
+def write_dna_fasta(path, prefix, dna, off):
+    lut = np.frombuffer(_NT.encode(), np.uint8)
+    with open(path, "wb") as f:
+        for i in range(len(off) - 1):
+            f.write((">%s%d\n" % (prefix, i)).encode())
+            f.write(lut[dna[off[i]:off[i + 1]]].tobytes())
+            f.write(b"\n")

@@ -174,6 +174,9 @@ typedef struct {
 	int32_t cutoff_table[32];     /* CutoffTable::data_ (src/util/scores/cutoff_table.h:26-47), index = bit length of the query length */
 	int32_t tile_size, simd_lanes; /* config.tile_size (1024); int8 lanes of the reference's SIMD build (32 = AVX2): the batch rule
 	                                  that decides whether a stage-2 score saturates at 255 (src/dp/ungapped_simd.cpp:69-87) */
+	int32_t query_translated;      /* align_mode.query_translated: 1 for blastx blocks (six frames per read); enables the short-frame
+	                                  rules of src/search/stage2.h:51,58-63 (window = frame length for frames of <= 85 letters) */
+	int32_t pad_;
 } dmnd_seed_params;
 
 /* One stage-2 seed hit = Search::Hit (src/search/hit.h:30-47): query context index, reference location
@@ -209,15 +212,16 @@ int dmnd_seed_kernel_ms(const dmnd_ctx* ctx, double ms[5]);
 /* One round-1 DpTarget as the extension stage builds it from seed hits (x-drop ungapped extension, chaining,
  * Extension::band, add_dp_targets: src/align/ungapped.cpp:62, chaining/greedy_align.cpp:482, align/gapped_score.cpp:107) */
 typedef struct {
-	uint32_t query, target;       /* block ids */
+	uint32_t query, target;       /* block sequence ids; query = query id * query_contexts + frame */
 	int32_t d_begin, d_end;
 	int32_t ungapped_score;       /* WorkTarget::ungapped_score = max stage-1 score of the target's seed hits */
 } dmnd_plan_target;
 
 /* One reported alignment = Extension::Match with its single Hsp (max_hsps = 1), src/align/extend.h:34-66 */
 typedef struct {
-	uint32_t query, target;       /* block ids */
-	int32_t ungapped_score, d_begin, d_end, pad;
+	uint32_t query, target;       /* query id (= block sequence id / query_contexts), target block id */
+	int32_t ungapped_score, d_begin, d_end;
+	int32_t frame;                /* query context of the HSP: 0 for blastp; 0-2 forward, 3-5 reverse frames for blastx (Hsp::frame) */
 	double evalue, bit_score;
 	dmnd_hsp hsp;
 } dmnd_match;
@@ -225,7 +229,7 @@ typedef struct {
 /* Host-only part (no GPU needed): per-query Hauser composition bias (cbs_out: int8 array parallel to qdata, may be
  * NULL) and the round-1 DpTargets for seed hits sorted by query. */
 int dmnd_extend_plan(const dmnd_params* params, const int8_t* qdata, const int64_t* qlimits, int64_t nq,
-	const int8_t* tdata, const int64_t* tlimits, int64_t nt, const dmnd_seed_hit* hits, int64_t n_hits, int threads,
+	const int8_t* tdata, const int64_t* tlimits, int64_t nt, const dmnd_seed_hit* hits, int64_t n_hits, int threads, int query_contexts,
 	int8_t* cbs_out, dmnd_plan_target* out, int64_t cap, int64_t* n_out);
 /* Whole extension stage on the uploaded blocks (qdata/tdata: the caller's host copies of the same blocks). hits must be
  * sorted by query. Matches come out ordered by query, then as the reference orders them (e-value, score, target).
@@ -248,6 +252,18 @@ int dmnd_gapped_filter(dmnd_ctx* ctx, const dmnd_seed_hit* hits, int64_t n_hits,
 double dmnd_gapped_filter_ms(const dmnd_ctx* ctx);
 /* Sensitive mode seed configuration (16 shapes of weight 8, search/setup.cpp:86-102; ungapped e-value 10000, seed cut 1.0) */
 int dmnd_seed_params_sensitive(dmnd_seed_params* p, int threads, const dmnd_params* scoring);
+
+/* align_mode.query_contexts (src/basic/basic.cpp:40-60): 1 = blastp; 6 = blastx, the DMND_QUERY block then holds the six
+ * translated frames of every read consecutively (Block::push_back, src/data/block/block.cpp:82-100; frame order of
+ * Translator::translate, src/util/sequence/translate.h:62-108) and seed hits carry the frame's block sequence id. */
+int dmnd_set_query_contexts(dmnd_ctx* ctx, int contexts);
+/* Six-frame translation of one DNA read (letters 0-4 = ACGTN) exactly as the reference loads a blastx query:
+ * standard genetic code, stop codons = letter 24, ORFs shorter than config.min_orf_len masked to 23 (find_orfs,
+ * src/util/sequence/sequence.cpp:180-197). out[f] must hold len/3 letters each; lens[f] receives the frame lengths. */
+int dmnd_translate(const int8_t* dna, int32_t len, int8_t* out[6], int32_t lens[6]);
+/* BLAST tabular line of a translated match: qstart/qend in DNA coordinates of the read (TranslatedPosition,
+ * src/basic/translated_position.h:125-175; reverse frames print qstart > qend). */
+int dmnd_format_tab_translated(const dmnd_match* m, const char* qseqid, const char* sseqid, int32_t source_len, char* buf, int64_t cap);
 
 /* -k / --max-target-seqs (default 25, src/basic/config.h:55) */
 int dmnd_set_max_target_seqs(dmnd_ctx* ctx, int k);

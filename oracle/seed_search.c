@@ -292,13 +292,14 @@ int64_t oracle_seed_search(const oracle_seed_cfg* c, int8_t* qdata, const int64_
 							while (hi - lo > 1) { const int64_t mid = (lo + hi) / 2; if (qlimits[mid] <= qloc) lo = mid; else hi = mid; }
 							const int64_t query_id = lo;
 							const int seed_offset = (int)(qloc - qlimits[query_id]);
-							const int window = c->ungapped_window;
+							const int query_len = (int)(qlimits[query_id + 1] - qlimits[query_id] - 1);
+							/* ungapped_window(query_len), stage2.h:58-63 */
+							const int window = (c->query_translated && query_len <= 85) ? query_len : c->ungapped_window;
 							const int8_t *cb, *ce;
 							clip(qdata + qloc - window, window * 2, window, &cb, &ce);
 							const int window_left = (int)((qdata + qloc) - cb), window_clipped = (int)(ce - cb);
 							const int interval_mod = c->left_most_interval > 0 ? seed_offset % c->left_most_interval : window_left;
 							const int overhang = window_left - interval_mod > 0 ? window_left - interval_mod : 0;
-							const int query_len = (int)(qlimits[query_id + 1] - qlimits[query_id] - 1);
 							const int cutoff = ungapped_cutoff(c, query_len);
 							/* search_tile / search_query_offset: per S tile, Hamming survivors in batches of simd_lanes */
 							const int64_t tile = c->tile_size > 0 ? c->tile_size : (j1 - j);

@@ -67,10 +67,11 @@ extern "C" int64_t emu_seed_search(const SeedParams* cp, const int8_t* matrix, c
 				const uint32_t qid = qid_of[(size_t)qp];
 				const int seed_offset = (int)(qp - qlimits[qid]);
 				int score = 0xFFFF;
+				const int query_len = (int)(qlimits[qid + 1] - qlimits[qid] - 1);
 				if (c.use_ungapped) {
-					const int cutoff = ungapped_cutoff(c, (int)(qlimits[qid + 1] - qlimits[qid] - 1));
+					const int cutoff = ungapped_cutoff(c, query_len);
 					if (cutoff) {
-						const int window = c.ungapped_window;
+						const int window = stage2_window(c, query_len);
 						int cb, ce;
 						clip_window(qdata + qp - window, 2 * window, window, cb, ce);
 						const int window_left = window - cb;
@@ -82,7 +83,7 @@ extern "C" int64_t emu_seed_search(const SeedParams* cp, const int8_t* matrix, c
 						if (score <= cutoff) continue;
 					}
 				}
-				if (!left_most_pair(c, qdata + qp, mask_time.data() + qp, tdata + m.second, seed_offset, sid, chunk)) continue;
+				if (!left_most_pair(c, qdata + qp, mask_time.data() + qp, tdata + m.second, seed_offset, sid, chunk, query_len)) continue;
 				if (n >= cap) return -1;
 				hits[n++] = EmuHit{ qid, seed_offset, m.second, score, 0 };
 			}

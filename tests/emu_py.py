@@ -72,7 +72,8 @@ class SeedParams(ctypes.Structure):
                 ("ungapped_window", ctypes.c_int32), ("left_most_interval", ctypes.c_int32),
                 ("seed_complexity_cut", ctypes.c_double),
                 ("use_ungapped", ctypes.c_int32), ("short_query_max_len", ctypes.c_int32), ("short_query_cutoff", ctypes.c_int32),
-                ("cutoff_table", ctypes.c_int32 * 32), ("tile_size", ctypes.c_int32), ("simd_lanes", ctypes.c_int32)]
+                ("cutoff_table", ctypes.c_int32 * 32), ("tile_size", ctypes.c_int32), ("simd_lanes", ctypes.c_int32),
+                ("query_translated", ctypes.c_int32), ("pad_", ctypes.c_int32)]
 
 
 HIT_DTYPE = np.dtype([("query", "<u4"), ("seed_offset", "<i4"), ("subject", "<i8"), ("score", "<i4"), ("pad", "<i4")])
@@ -98,6 +99,7 @@ def seed_params_from_tap(cfg):
     for i in range(32):
         c.cutoff_table[i] = table[i]
     c.tile_size, c.simd_lanes = 1024, 32
+    c.query_translated = 1 if cfg.get("query_contexts", 1) > 1 else 0
     return c
 
 
@@ -120,7 +122,7 @@ def seed_search(c, qdata, qlimits, tdata, tlimits, cap=1 << 22, matrix8=None):
 # ---- gapped filter ----------------------------------------------------------------------------------------------
 class GfParams(ctypes.Structure):
     _fields_ = [("diag_score", ctypes.c_int32), ("gap_open", ctypes.c_int32), ("gap_extend", ctypes.c_int32),
-                ("window2", ctypes.c_int32), ("use_cbs", ctypes.c_int32)]
+                ("window2", ctypes.c_int32), ("use_cbs", ctypes.c_int32), ("contexts", ctypes.c_int32)]
 
 
 def gapped_filter_hit(p, matrix8, query, cbs, target, hit_i, hit_j, cutoff1, cutoff2):

@@ -79,5 +79,19 @@ DIAMOND_TAP_EXT="$HERE/ext_default_synth.tap" \
 #    (per query: Hauser bias, the seed hits of every target of the ranking chunk, both cutoffs, the surviving targets)
 DIAMOND_TAP_EXT="$HERE/ext_sensitive.tap" DIAMOND_TAP_GF="$HERE/gf_sensitive.tap" \
   "$TAP" blastp --sensitive --masking 0 --motif-masking 0 --algo 0 -q "$REFTEST/data.faa" -d "$REFTEST/data.faa" -o "$HERE/sensitive.tsv" -p1 2>/dev/null
+# 9. blastx: synthetic DNA reads (back-translated protein queries with random codons, flanks and strand) against a
+#    protein DB; the tap header holds the TRANSLATED query block (6 frames per read, short ORFs masked), so the golden also
+#    pins dmnd_translate. The reads are kept as blastx_reads.fna (source lengths for the DNA coordinates of the output).
+DMND_ROOT="$ROOT" python3 - "$TMP" "$HERE" <<'PY'
+import os, sys
+sys.path.insert(0, os.environ["DMND_ROOT"])
+from diamond_amd import synth
+db, do, q, qo = synth.generate(150, members=10, queries=120, seed=3)
+dna, off = synth.back_translate(q, qo, seed=4)
+synth.write_fasta(sys.argv[1] + "/x_db.faa", "t", db, do)
+synth.write_dna_fasta(sys.argv[2] + "/blastx_reads.fna", "r", dna, off)
+PY
+DIAMOND_TAP_EXT="$HERE/ext_blastx.tap" \
+  "$TAP" blastx --masking 0 --motif-masking 0 --algo 0 -q "$HERE/blastx_reads.fna" -d "$TMP/x_db.faa" -o "$HERE/blastx.tsv" -p1 2>/dev/null
 ls -la "$HERE"/*.tap
 rm -rf "$TMP"

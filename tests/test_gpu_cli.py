@@ -50,6 +50,24 @@ def test_cli_makedb_blastp_matches_reference(tmp_path):
     assert open(tmp_path / "hip4.tsv").read() == ref4
 
 
+def test_cli_blastx_matches_reference(tmp_path):
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/diamond not built")
+    db, doff, q, qoff = synth.generate(300, members=10, queries=250, seed=11)
+    dna, off = synth.back_translate(q, qoff, seed=12)
+    synth.write_fasta(str(tmp_path / "db.faa"), "t", db, doff)
+    synth.write_dna_fasta(str(tmp_path / "reads.fna"), "r", dna, off)
+    for mode in ([], ["--fast"], ["--sensitive"]):
+        tag = (mode or ["default"])[0].strip("-")
+        _run([REF, "blastx"] + mode + ["--algo", "0", "--masking", "0", "--motif-masking", "0", "-q", str(tmp_path / "reads.fna"),
+                                        "-d", str(tmp_path / "db.faa"), "-o", str(tmp_path / ("ref_%s.tsv" % tag)), "-p", "4"])
+        _run([CLI, "blastx"] + mode + ["--masking", "0", "-q", str(tmp_path / "reads.fna"), "-d", str(tmp_path / "db.faa"),
+                                        "-o", str(tmp_path / ("hip_%s.tsv" % tag)), "-p", "4"])
+        ref = open(tmp_path / ("ref_%s.tsv" % tag)).read()
+        assert len(ref.splitlines()) > 300
+        assert open(tmp_path / ("hip_%s.tsv" % tag)).read() == ref, tag
+
+
 def test_cli_refuses_unimplemented_modes(tmp_path):
     r = subprocess.run([CLI, "blastp", "--very-sensitive", "-q", "x", "-d", "y"], capture_output=True, text=True)
     assert r.returncode != 0 and "not available" in r.stderr

@@ -30,11 +30,12 @@ def _run(ctx, cfg, db_letters):
     ctx.upload_block(hip.TARGET, td, tl)
     ctx.set_db_letters(db_letters)
     ctx.set_gapped_filter(cfg["gapped_filter_evalue"])          # 0 except --sensitive (1.0)
+    ctx.set_query_contexts(cfg["query_contexts"])               # 6 for the blastx golden
     hits = ctx.seed_search(to_hip_params(cfg))
     return ctx.extend(qd, td, hits, threads=4)[0]
 
 
-@pytest.mark.parametrize("tap", ["ext_fast_synth.tap", "ext_fast.tap", "ext_6x10.tap", "ext_rank.tap", "ext_default.tap", "ext_default_synth.tap", "ext_sensitive.tap"])
+@pytest.mark.parametrize("tap", ["ext_fast_synth.tap", "ext_fast.tap", "ext_6x10.tap", "ext_rank.tap", "ext_default.tap", "ext_default_synth.tap", "ext_sensitive.tap", "ext_blastx.tap"])
 def test_matches_equal_reference_extend(ctx, tap):
     cfg, recs = read_ext_tap(os.path.join(GOLDEN, tap))
     tl = cfg["target"]["limits"]
@@ -52,6 +53,7 @@ def test_matches_equal_reference_extend(ctx, tap):
             assert len(ref["hsps"]) == 1
             for k in HSP_KEYS:
                 assert got["hsp"][k] == h[k], (k, r["query_id"], ref["target_block_id"])
+            assert got["frame"] == h["frame"]
             assert got["evalue"] == pytest.approx(h["evalue"], rel=1e-6, abs=0)      # north_star tolerance
             assert got["bit_score"] == pytest.approx(h["bit_score"], rel=1e-12)
             assert got["ungapped_score"] == ref["ungapped_score"]
@@ -61,7 +63,7 @@ def test_matches_equal_reference_extend(ctx, tap):
 
 @pytest.mark.parametrize("tap,tsv", [("ext_fast_synth.tap", "fast_synth.tsv"), ("ext_rank.tap", "rank.tsv"),
                                      ("ext_default_synth.tap", "default_synth.tsv"), ("ext_default.tap", "default.tsv"),
-                                     ("ext_sensitive.tap", "sensitive.tsv")])
+                                     ("ext_sensitive.tap", "sensitive.tsv"), ("ext_blastx.tap", "blastx.tsv")])
 def test_tabular_output_is_byte_identical_to_reference(ctx, tap, tsv):
     cfg, recs = read_ext_tap(os.path.join(GOLDEN, tap))
     tl = cfg["target"]["limits"]
@@ -71,7 +73,13 @@ def test_tabular_output_is_byte_identical_to_reference(ctx, tap, tsv):
     else:
         qids = ["q%d" % i for i in range(cfg["query"]["n"])]
         tids = ["t%d" % i for i in range(cfg["target"]["n"])]
-    text = hip.format_tab(m, qids, tids)
+    source_lens = None
+    if tsv == "blastx.tsv":                                        # DNA coordinates need the read lengths
+        reads = [l.strip() for l in open(os.path.join(GOLDEN, "blastx_reads.fna")) if not l.startswith(">")]
+        source_lens = [len(x) for x in reads]
+        qids = ["r%d" % i for i in range(len(reads))]
+        assert len(reads) * 6 == cfg["query"]["n"]
+    text = hip.format_tab(m, qids, tids, source_lens)
     ref = open(os.path.join(GOLDEN, tsv)).read()
     assert len(ref.splitlines()) > 300
     assert text == ref

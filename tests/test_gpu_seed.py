@@ -37,7 +37,7 @@ def to_hip_params(cfg):
     return p
 
 
-@pytest.mark.parametrize("tap", ["ext_fast.tap", "ext_fast_synth.tap", "ext_6x10.tap", "ext_default.tap", "ext_default_synth.tap", "ext_sensitive.tap"])
+@pytest.mark.parametrize("tap", ["ext_fast.tap", "ext_fast_synth.tap", "ext_6x10.tap", "ext_default.tap", "ext_default_synth.tap", "ext_sensitive.tap", "ext_blastx.tap"])
 def test_seed_hits_equal_reference(ctx, tap):
     cfg, recs = read_ext_tap(os.path.join(GOLDEN, tap))
     ctx.upload_block(hip.QUERY, cfg["query"]["data"], cfg["query"]["limits"])

@@ -47,7 +47,7 @@ def test_surviving_targets_and_cutoffs_equal_reference(tap):
 
 def test_emulated_kernel_equals_oracle_per_hit(tap):
     recs, cfg, m8 = tap
-    p = emu.GfParams(diag_score=20, gap_open=11, gap_extend=1, window2=200, use_cbs=1)
+    p = emu.GfParams(diag_score=20, gap_open=11, gap_extend=1, window2=200, use_cbs=1, contexts=1)
     n = stage2 = 0
     for r in recs[::3]:
         for t in r["targets"]:
@@ -70,7 +70,7 @@ def test_scan_edge_geometry_against_oracle():
     """Hits near sequence ends, short sequences, bias saturation: band/window clipping and profile padding."""
     rng = np.random.default_rng(5)
     m8 = blosum62_matrix8()
-    p = emu.GfParams(diag_score=20, gap_open=11, gap_extend=1, window2=200, use_cbs=1)
+    p = emu.GfParams(diag_score=20, gap_open=11, gap_extend=1, window2=200, use_cbs=1, contexts=1)
     for _ in range(300):
         qlen, slen = int(rng.integers(1, 400)), int(rng.integers(1, 400))
         q = rng.integers(0, 20, qlen).astype(np.int8)

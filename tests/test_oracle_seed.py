@@ -25,10 +25,10 @@ def blosum62_matrix8():
     return read_tap(os.path.join(GOLDEN, "swipe_fast.tap"), max_records=1)[0]["matrix8"]
 
 
-@pytest.mark.parametrize("tap", ["ext_fast.tap", "ext_fast_synth.tap", "ext_6x10.tap", "ext_rank.tap", "ext_default.tap", "ext_default_synth.tap", "ext_sensitive.tap"])
+@pytest.mark.parametrize("tap", ["ext_fast.tap", "ext_fast_synth.tap", "ext_6x10.tap", "ext_rank.tap", "ext_default.tap", "ext_default_synth.tap", "ext_sensitive.tap", "ext_blastx.tap"])
 def test_seed_stage_hit_multiset_equals_reference(tap):
     cfg, recs = read_ext_tap(os.path.join(GOLDEN, tap))
-    assert cfg["ungapped_evalue"] == (10000.0 if "default" in tap or "sensitive" in tap else 0.0) and cfg["index_chunks"] == 4
+    assert cfg["ungapped_evalue"] == (10000.0 if "default" in tap or "sensitive" in tap or "blastx" in tap else 0.0) and cfg["index_chunks"] == 4
     c = orc.seed_cfg_from_tap(cfg, blosum62_matrix8())
     hits = orc.seed_search(c, cfg["query"]["data"], cfg["query"]["limits"], cfg["target"]["data"], cfg["target"]["limits"])
     ref = np.concatenate([r["hits"] for r in recs])
@@ -37,7 +37,7 @@ def test_seed_stage_hit_multiset_equals_reference(tap):
     if "sensitive" not in tap:
         assert len(ref) == len(hit_set(ref))                      # few shapes: a multiset without duplicates
     assert hit_multiset(hits) == hit_multiset(ref)
-    if "default" in tap:                                          # both batch rules occur: scalar (> 255 kept) and int8 (saturated)
+    if "default" in tap:                                        # both batch rules occur: scalar (> 255 kept) and int8 (saturated)
         assert (ref["score"] == 255).any() and (ref["score"] > 255).any() and (ref["score"] < 0xFFFF).all()
     for r in recs:                                                # extend() is called once per query with its own hits only
-        assert (r["hits"]["query"] == r["query_id"]).all()
+        assert (r["hits"]["query"] // cfg["query_contexts"] == r["query_id"]).all()

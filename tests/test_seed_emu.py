@@ -17,7 +17,7 @@ def hit_set(h):
     return set(zip(h["query"].tolist(), h["subject"].tolist(), h["seed_offset"].tolist(), h["score"].tolist()))
 
 
-@pytest.mark.parametrize("tap", ["ext_fast.tap", "ext_fast_synth.tap", "ext_6x10.tap", "ext_rank.tap", "ext_default.tap", "ext_default_synth.tap", "ext_sensitive.tap"])
+@pytest.mark.parametrize("tap", ["ext_fast.tap", "ext_fast_synth.tap", "ext_6x10.tap", "ext_rank.tap", "ext_default.tap", "ext_default_synth.tap", "ext_sensitive.tap", "ext_blastx.tap"])
 def test_emulated_seed_stage_equals_reference_hits(tap):
     cfg, recs = read_ext_tap(os.path.join(GOLDEN, tap))
     c = emu.seed_params_from_tap(cfg)
