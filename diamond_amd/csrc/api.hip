@@ -7,6 +7,7 @@
 // width (P = diagonals-per-lane class) and ordered longest-first so the 256 CUs drain evenly.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -245,7 +246,7 @@ int run_chunk(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, const dm
 		if (int rc = c->trace_off.ensure((n + 1) * sizeof(int64_t))) return rc;
 		if (int rc = c->transcript_off.ensure((n + 1) * sizeof(int64_t))) return rc;
 		if (int rc = c->trace.ensure((size_t)trace_off[n] + 64)) return rc;
-		if (int rc = c->transcript.ensure((size_t)tr_off[n] + 64)) return rc;
+		if (chunk_transcripts) if (int rc = c->transcript.ensure((size_t)tr_off[n] + 64)) return rc;
 		if (int rc = c->status.ensure(sizeof(int32_t))) return rc;
 		HIP_TRY(hipMemcpyAsync(c->p_of_slot.p, p_of.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
 		HIP_TRY(hipMemcpyAsync(c->trace_off.p, trace_off.data(), (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
@@ -276,14 +277,16 @@ int run_chunk(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, const dm
 		t.qblock = b.q; t.tblock = b.t; t.cbs = b.cbs; t.matrix = c->matrix.as<int8_t>();
 		t.items = d_items; t.order = c->order.as<int32_t>(); t.p_of_slot = c->p_of_slot.as<int32_t>();
 		t.trace_off = c->trace_off.as<int64_t>(); t.transcript_off = c->transcript_off.as<int64_t>();
-		t.trace = c->trace.as<uint8_t>(); t.transcript = c->transcript.as<uint8_t>();
+		t.trace = c->trace.as<uint8_t>(); t.transcript = chunk_transcripts ? c->transcript.as<uint8_t>() : nullptr;
 		t.ends = c->ends.as<SwipeEnd>(); t.hsps = c->hsps.as<dmnd_hsp>(); t.status = c->status.as<int32_t>();
 		t.n = n; t.gap_open = c->params.gap_open; t.gap_extend = c->params.gap_extend;
 		HIP_TRY(launch_traceback(t, c->stream));
 		HIP_TRY(hipEventRecord(c->ev2, c->stream));
-		chunk_transcripts->resize((size_t)tr_off[n]);
-		HIP_TRY(hipMemcpyAsync(chunk_transcripts->data(), c->transcript.p, (size_t)tr_off[n], hipMemcpyDeviceToHost, c->stream));
-		*chunk_tr_off = tr_off;
+		if (chunk_transcripts) {
+			chunk_transcripts->resize((size_t)tr_off[n]);
+			HIP_TRY(hipMemcpyAsync(chunk_transcripts->data(), c->transcript.p, (size_t)tr_off[n], hipMemcpyDeviceToHost, c->stream));
+			*chunk_tr_off = tr_off;
+		}
 	}
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	float ms = 0.f;
@@ -317,10 +320,12 @@ int swipe_impl(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, int64_t
 	case DMND_SWIPE_STATS: kmode = K_STATS_FWD; break;
 	default: return fail(DMND_E_ARG, "dmnd_banded_swipe: unknown mode");
 	}
-	if (kmode == K_TRACE && (!transcript || transcript_cap <= 0))
-		return fail(DMND_E_ARG, "dmnd_banded_swipe: TRACEBACK needs a transcript arena");
+	// TRACEBACK with transcript == NULL: coordinates and statistics from the traceback walk, transcripts not returned
 	if (!b.q || !b.t) return fail(DMND_E_ARG, "dmnd_banded_swipe: sequence blocks not uploaded");
 	HIP_TRY(hipSetDevice(c->device));
+	auto wall = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	double t_mark = wall();
+	auto lap = [&](int slot) { const double t = wall(); c->host_ms[slot] += t - t_mark; t_mark = t; };
 
 	std::vector<Slot> slots((size_t)n);
 	for (int64_t i = 0; i < n; ++i) {
@@ -347,7 +352,9 @@ int swipe_impl(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, int64_t
 	auto by_class = [](const Slot& x, const Slot& y) { return x.P < y.P || (x.P == y.P && x.steps > y.steps); };
 	if (kmode != K_TRACE) {
 		std::sort(slots.begin(), slots.end(), by_class);
+		lap(0);
 		if (int rc = run_chunk(c, b, items, c->items.as<dmnd_dp_target>(), slots, kmode, out, nullptr, nullptr)) return rc;
+		lap(1);
 		HIP_TRY(hipMemcpy(ends.data(), c->ends.p, n * sizeof(SwipeEnd), hipMemcpyDeviceToHost));
 		for (int64_t i = 0; i < n; ++i) {
 			dmnd_hsp h;
@@ -357,6 +364,7 @@ int swipe_impl(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, int64_t
 			if (kmode == K_STATS_FWD && h.score > 0) { h.identities = ends[i].stat_a; h.length = ends[i].stat_b; }
 			out[i] = h;
 		}
+		lap(2);
 		if (kmode != K_STATS_FWD)
 			return DMND_OK;
 		// statistics without traceback: second, reversed pass over the target prefix [0, s_end)
@@ -418,8 +426,15 @@ int swipe_impl(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, int64_t
 		std::sort(chunk.begin(), chunk.end(), by_class);
 		std::vector<uint8_t> tr;
 		std::vector<int64_t> tr_off;
-		if (int rc = run_chunk(c, b, items, c->items.as<dmnd_dp_target>(), chunk, K_TRACE, out, &tr, &tr_off)) return rc;
+		lap(0);
+		if (int rc = run_chunk(c, b, items, c->items.as<dmnd_dp_target>(), chunk, K_TRACE, out, transcript ? &tr : nullptr, transcript ? &tr_off : nullptr)) return rc;
+		lap(1);
 		HIP_TRY(hipMemcpy(hsps.data() + c0, c->hsps.as<dmnd_hsp>() + c0, (size_t)(c1 - c0) * sizeof(dmnd_hsp), hipMemcpyDeviceToHost));
+		if (!transcript) {
+			for (int64_t i = c0; i < c1; ++i) { out[i] = hsps[i]; out[i].transcript_off = -1; }
+			c0 = c1;
+			continue;
+		}
 		// pack the transcripts tightly into the caller's arena, in input order
 		std::vector<int64_t> slot_of((size_t)(c1 - c0));
 		for (size_t s = 0; s < chunk.size(); ++s) slot_of[(size_t)(chunk[s].item - c0)] = (int64_t)s;
@@ -437,6 +452,7 @@ int swipe_impl(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, int64_t
 		c0 = c1;
 	}
 	if (transcript_used) *transcript_used = used;
+	lap(2);
 	return DMND_OK;
 }
 

@@ -52,6 +52,7 @@ struct dmnd_ctx {
 	double seed_ms[5] = { 0, 0, 0, 0, 0 };
 	// extension-stage statistics of the last dmnd_extend (extend_host.hip)
 	double ext_stats[12] = { 0 };
+	double host_ms[3] = { 0, 0, 0 };           // host wall time inside dmnd_banded_swipe: prepare, launch+wait, unpack (DMND_TRACE)
 	int query_contexts = 1;                    // align_mode.query_contexts: 6 for blastx (basic/basic.cpp:40-60)
 	int max_target_seqs = 25;                  // config.max_target_seqs (-k), basic/config.h:55
 };

@@ -23,6 +23,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <atomic>
@@ -453,6 +454,7 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	const int K = h.max_target_seqs;
 	threads = std::max(1, threads);
 	for (double& x : c->ext_stats) x = 0;
+	for (double& x : c->host_ms) x = 0;
 	auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	auto cells_of = [](const std::vector<dmnd_dp_target>& v) {
 		double s = 0;
@@ -460,7 +462,8 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 		return s;
 	};
 	double t_mark = now();
-	auto lap = [&](int slot) { const double t = now(); c->ext_stats[slot] += t - t_mark; t_mark = t; };
+	double fine[16] = { 0 };          // DMND_TRACE=1: finer host timeline on stderr
+	auto lap = [&](int slot, int f = -1) { const double t = now(); c->ext_stats[slot] += t - t_mark; if (f >= 0) fine[f] += t - t_mark; t_mark = t; };
 	// 1. Hauser bias for every query, resident next to the query block
 	const std::vector<Range> qr = split_by_query(hits, n_hits, h.contexts);
 	std::vector<int8_t> cbs((size_t)ql.back() + 64, 0);            // only queries with seed hits are ever aligned
@@ -472,7 +475,7 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 		}
 	});
 	if (int rc = dmnd_upload_cbs(c, cbs.data(), ql.back())) return rc;
-	lap(4);
+	lap(4, 1);
 	// 1b. gapped filter of every seed hit in one launch (only --sensitive and above; extend.cpp:205-213)
 	std::vector<uint8_t> gf;
 	c->gf_ms = 0;
@@ -480,7 +483,7 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 		gf.resize((size_t)n_hits);
 		if (int rc = dmnd_gapped_filter(c, hits, n_hits, 1, gf.data(), nullptr)) return rc;
 	}
-	lap(4);
+	lap(4, 2);
 	// 2. load_hits for every query
 	std::vector<QueryState> qs(qr.size());
 	parallel_for(qr.size(), threads, [&](size_t i, int) {
@@ -488,13 +491,12 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 		if (qs[i].w.order.empty()) qs[i].done = true;
 	});
 	std::vector<ChainWorkspace> ws((size_t)threads);
-	lap(5);
+	lap(5, 3);
 	auto item_of = [&](uint32_t q, uint32_t t, int d0, int d1) {
 		return dmnd_dp_target{ ql[q], tl[t], ql[q], (int32_t)(ql[q + 1] - ql[q] - 1), (int32_t)(tl[t + 1] - tl[t] - 1), d0, d1 };
 	};
 	double sw1 = 0, sw2 = 0, tb2 = 0;
 	int64_t used = 0;
-	std::vector<uint8_t> own_arena;
 	std::vector<dmnd_dp_target> items;
 	std::vector<dmnd_hsp> res;
 	for (;;) {
@@ -515,14 +517,14 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 				for (const PlanTarget& p : s.plan) items.push_back(item_of(p.query, p.target, p.d_begin, p.d_end));
 				s.item_end = items.size();
 			}
-			lap(5);
+			lap(5, 4);
 			res.assign(items.size(), dmnd_hsp());
 			if (!items.empty()) {
 				if (int rc = dmnd_banded_swipe(c, items.data(), (int64_t)items.size(), DMND_SWIPE_SCORE, 0, res.data(), nullptr, 0, nullptr)) return rc;
 				sw1 += c->swipe_ms;
 				c->ext_stats[0] += (double)items.size(); c->ext_stats[2] += cells_of(items);
 			}
-			lap(6);
+			lap(6, 5);
 			parallel_for(active.size(), threads, [&](size_t ai, int) {
 				QueryState& s = qs[active[ai]];
 				// extend_chunk -> align (gapped_score.cpp:182-268): report cutoff, best HSP per target
@@ -561,7 +563,7 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 					|| c->evaluer.bitscore(next_tail) < 25.0);
 				if (!(s.w.i0 < s.w.order.size() && !terminate)) s.in_inner = false;
 			});
-			lap(7);
+			lap(7, 6);
 		}
 		// ---- round 2 for every query that just left the inner loop ----
 		std::vector<size_t> batch;
@@ -581,18 +583,12 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 				else { it_tb.push_back(d); ref_tb.push_back(Ref{ i, k }); }
 			}
 		}
-		lap(7);
+		lap(7, 7);
 		std::vector<std::vector<dmnd_hsp>> r2(qs.size());
 		for (size_t i : batch) r2[i].assign(qs[i].aligned.size(), dmnd_hsp());
 		if (!it_tb.empty()) {
-			uint8_t* arena = transcript ? transcript + used : nullptr;
+			uint8_t* arena = transcript ? transcript + used : nullptr;           // NULL: statistics only, no transcripts copied back
 			int64_t arena_cap = transcript ? transcript_cap - used : 0;
-			if (!transcript) {
-				int64_t need = 16;
-				for (const auto& d : it_tb) need += (int64_t)d.query_len + d.target_len + 2;
-				own_arena.resize((size_t)need);
-				arena = own_arena.data(); arena_cap = need;
-			}
 			res.assign(it_tb.size(), dmnd_hsp());
 			int64_t u = 0;
 			if (int rc = dmnd_banded_swipe(c, it_tb.data(), (int64_t)it_tb.size(), DMND_SWIPE_TRACEBACK, hsp_values, res.data(), arena, arena_cap, &u)) return rc;
@@ -610,7 +606,7 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 			sw2 += c->swipe_ms;
 		}
 		c->ext_stats[1] += (double)(it_tb.size() + it_st.size()); c->ext_stats[3] += cells_of(it_tb) + cells_of(it_st);
-		lap(8);
+		lap(8, 8);
 		parallel_for(batch.size(), threads, [&](size_t bi, int) {
 			const size_t i = batch[bi];
 			QueryState& s = qs[i];
@@ -639,7 +635,7 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 			if ((int)s.matches.size() < K && s.w.i0 < s.w.order.size() && s.new_hits_ev) s.in_inner = true;
 			else s.done = true;
 		});
-		lap(7);
+		lap(7, 9);
 	}
 	c->swipe_ms = sw1 + sw2; c->traceback_ms = tb2;
 	c->ext_stats[9] = sw1; c->ext_stats[10] = sw2; c->ext_stats[11] = tb2;
@@ -655,6 +651,10 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 		}
 	}
 	*n_out = n;
+	lap(7, 10);
+	if (std::getenv("DMND_TRACE"))
+		std::fprintf(stderr, "dmnd_extend ms: hauser+upload %.2f gapped_filter %.2f load %.2f plan %.2f swipe1 %.2f post1 %.2f build2 %.2f swipe2 %.2f post2 %.2f final %.2f | swipe host: prep %.2f run %.2f post %.2f\n",
+			fine[1], fine[2], fine[3], fine[4], fine[5], fine[6], fine[7], fine[8], fine[9], fine[10], c->host_ms[0], c->host_ms[1], c->host_ms[2]);
 	if (n > cap) return fail(DMND_E_CAP, "dmnd_extend: match buffer too small");
 	return DMND_OK;
 }

@@ -126,7 +126,7 @@ __device__ WalkResult traceback_walk_wave(const uint8_t* trace, const Geom& g, i
 			const unsigned long long sm = __ballot(lane < run && sc + (ps - s) >= best);
 			const int steps = sm ? imin(run, __builtin_ctzll(sm)) : run;       // >= 1: lane 0 sees sc < best
 			const bool mine = lane < steps;
-			if (mine && n + lane < cap - 1)
+			if (transcript && mine && n + lane < cap - 1)
 				transcript[cap - 2 - (n + lane)] = (uint8_t)(ql == tl ? (OP_MATCH << OP_COUNT_BITS) | 1 : (OP_SUBSTITUTION << OP_COUNT_BITS) | tl);
 			const int ident = popc64(__ballot(mine && ql == tl)), pos_mm = popc64(__ballot(mine && ql != tl && positive));
 			r.identities += ident; r.positives += ident + pos_mm; r.mismatches += steps - ident;
@@ -143,14 +143,14 @@ __device__ WalkResult traceback_walk_wave(const uint8_t* trace, const Geom& g, i
 			int c = l;
 			while (c > 0) {
 				const int kk = imin(c, (int)OP_MAX_COUNT);
-				if (lane == 0 && n < cap - 1) transcript[cap - 2 - n] = (uint8_t)((OP_INSERTION << OP_COUNT_BITS) | kk);
+				if (transcript && lane == 0 && n < cap - 1) transcript[cap - 2 - n] = (uint8_t)((OP_INSERTION << OP_COUNT_BITS) | kk);
 				++n; c -= kk;
 			}
 		}
 		else {
 			const int j_before = j;
 			do { ++l; --j; } while (j > 0 && (trace_at(trace, g, W, i, j) & TB_OPEN_H) == 0);
-			for (int x = lane; x < l; x += 64)
+			for (int x = lane; transcript && x < l; x += 64)
 				if (n + x < cap - 1) transcript[cap - 2 - (n + x)] = (uint8_t)((OP_DELETION << OP_COUNT_BITS) | (v.t[j_before - x] & LETTER_MASK));
 			n += l;
 		}
@@ -160,6 +160,8 @@ __device__ WalkResult traceback_walk_wave(const uint8_t* trace, const Geom& g, i
 		sc -= gap_open + l * gap_extend;
 	}
 	if (sc != best) r.status = -6;           // DMND_E_TRACEBACK
+	r.q_begin = i + 1; r.s_begin = j + 1; r.transcript_len = n;
+	if (!transcript) return r;               // statistics only (the caller did not ask for transcripts)
 	if (n > cap - 1) { r.status = -5; n = 0; }    // DMND_E_CAP
 	// move to the front of the slot: 64 bytes per pass, every pass reads before it writes, destinations trail sources
 	for (int x0 = 0; x0 < n; x0 += 64) {
@@ -200,14 +202,14 @@ __global__ __launch_bounds__(256) void traceback_kernel(TracebackArgs args)
 		const int W = 64 * args.p_of_slot[slot];
 		const int cap = (int)(args.transcript_off[slot + 1] - args.transcript_off[slot]);
 		const WalkResult r = traceback_walk_wave(args.trace + args.trace_off[slot], g, W, v, args.gap_open, args.gap_extend,
-			e.score, e.end_i, e.end_j, args.transcript + args.transcript_off[slot], cap, lane);
+			e.score, e.end_i, e.end_j, args.transcript ? args.transcript + args.transcript_off[slot] : nullptr, cap, lane);
 		h.q_begin = r.q_begin; h.s_begin = r.s_begin; h.q_end = e.end_i + 1; h.s_end = e.end_j + 1;
 		h.length = r.length; h.identities = r.identities; h.mismatches = r.mismatches; h.positives = r.positives;
 		h.gap_openings = r.gap_openings; h.gaps = r.gaps; h.transcript_len = r.transcript_len;
 		if (r.status != 0 && lane == 0)
 			atomicMin(args.status, r.status);
 	}
-	else if (lane == 0 && args.transcript_off[slot + 1] > args.transcript_off[slot])
+	else if (args.transcript && lane == 0 && args.transcript_off[slot + 1] > args.transcript_off[slot])
 		args.transcript[args.transcript_off[slot]] = 0;
 	if (lane == 0) args.hsps[item_idx] = h;
 }

@@ -120,10 +120,11 @@ int dmnd_upload_cbs(dmnd_ctx* ctx, const int8_t* cbs, int64_t len);
  *    dispatcher src/dp/swipe/swipe_wrapper.cpp:446-470,487) -------------------------------------- */
 /* Computes n work items in one batched launch (any mix of queries).  mode is DMND_SWIPE_*;
  * hsp_values (DMND_HSP_* bits) selects the cell types of DMND_SWIPE_STATS as dispatch_swipe() does.
- * out[n] receives one dmnd_hsp per item (input order).  transcript (may be NULL unless mode is
- * TRACEBACK) is a caller-owned host arena of transcript_cap bytes receiving the packed edit
- * transcripts (PackedOperation codes, src/basic/packed_transcript.h:30-90), each followed by a 0
- * terminator; *transcript_used returns the bytes written.
+ * out[n] receives one dmnd_hsp per item (input order).  transcript is a caller-owned host arena of
+ * transcript_cap bytes receiving the packed edit transcripts of mode TRACEBACK (PackedOperation codes,
+ * src/basic/packed_transcript.h:30-90), each followed by a 0 terminator; *transcript_used returns the
+ * bytes written. With transcript == NULL, TRACEBACK still reports coordinates and statistics from the
+ * traceback walk (transcript_len set, transcript_off = -1) but returns no transcript bytes.
  * Unlike the SIMD reference there is no 8/16/32-bit escalation: scores are exact int32. */
 int dmnd_banded_swipe(dmnd_ctx* ctx, const dmnd_dp_target* items, int64_t n, int mode, uint32_t hsp_values,
 	dmnd_hsp* out, uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used);

@@ -1,0 +1,81 @@
+"""-m gpu: the whole hot path at BASELINE config C2 size (blastp --fast, 10k queries x 1M-sequence / 3.0e8-letter DB)
+through the C ABI, checked with size-independent properties (no per-item oracle is feasible at this size):
+determinism, ordering and top-k bounds of the reported records, ground truth of the synthetic families, and a sampled
+re-derivation of reported alignments by the CPU oracle on the same band and composition bias."""
+import numpy as np
+import pytest
+import torch
+
+import oracle_py as orc
+from diamond_amd import hip, synth, workload
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
+KEYS = "score q_begin q_end s_begin s_end length identities mismatches gap_openings gaps".split()
+
+
+def test_c2_full_path_properties():
+    assert torch.cuda.is_available()
+    members = 10
+    db, doff, q, qoff, fam = synth.generate(100_000, members=members, queries=10_000, seed=20260923, family=True)
+    qd, ql = workload.sequence_set(q, qoff)
+    td, tl = workload.sequence_set(db, doff)
+    params = hip.default_params()
+    params.db_letters = float(doff[-1])
+    ctx = hip.Context(params=params)
+    try:
+        ctx.upload_block(hip.QUERY, qd, ql)
+        ctx.upload_block(hip.TARGET, td, tl)
+        sp = hip.seed_params_fast(threads=8)
+        hits = ctx.seed_search(sp)
+        m, _ = ctx.extend(qd, td, hits, threads=16)
+        # determinism of the whole path
+        hits2 = ctx.seed_search(sp)
+        m2, _ = ctx.extend(qd, td, hits2, threads=7)                  # a different host thread count must not matter
+        assert np.array_equal(hits, hits2) and np.array_equal(m, m2)
+    finally:
+        ctx.close()
+    assert len(hits) > 15_000 and len(m) > 8_000
+    # every hit is a seed match between its two sequences (positions inside the sequences, same reduced letters)
+    pos = np.array([sp.shape_pos[0][k] for k in range(sp.shape_weight[0])])
+    red = np.array([sp.reduction[i] for i in range(32)])
+    qloc = ql[hits["query"]] + hits["seed_offset"]
+    assert (red[qd[qloc[:, None] + pos[None, :]] & 31] == red[td[hits["subject"][:, None] + pos[None, :]] & 31]).all()
+    # records: grouped by query ascending, <= 25 per query, ordered by (evalue asc, score desc, target asc), below the e-value cutoff
+    qv = m["query"].astype(np.int64)
+    assert (np.diff(qv) >= 0).all()
+    _, counts = np.unique(qv, return_counts=True)
+    assert counts.max() <= 25
+    same = qv[1:] == qv[:-1]
+    ev, sc, tg = m["evalue"], m["hsp"]["score"], m["target"].astype(np.int64)
+    ordered = (ev[1:] > ev[:-1]) | ((ev[1:] == ev[:-1]) & ((sc[1:] < sc[:-1]) | ((sc[1:] == sc[:-1]) & (tg[1:] > tg[:-1]))))
+    assert ordered[same].all()
+    assert (ev <= 0.001).all() and (sc > 0).all()
+    # every reported target received at least one seed hit of that query
+    tid = np.searchsorted(tl, hits["subject"], side="right") - 1
+    pairs = set(zip(hits["query"].tolist(), tid.tolist()))
+    assert all((int(a), int(b)) in pairs for a, b in zip(m["query"], m["target"]))
+    # ground truth of the generator: the best hit of a query derived from family f is a member of f (decoys align to nothing much)
+    first = np.r_[True, qv[1:] != qv[:-1]]
+    top_q, top_t = qv[first], tg[first]
+    derived = fam[top_q] >= 0
+    assert derived.sum() > 4000
+    assert ((top_t[derived] // members) == fam[top_q[derived]]).mean() > 0.99
+    # sampled parity: oracle on the same band + bias reproduces score, coordinates and statistics; e-value within 1e-6
+    rng = np.random.default_rng(3)
+    sample = rng.choice(len(m), 150, replace=False)
+    e = orc.evaluer(float(doff[-1]))
+    M = hip.matrix_of(params)
+    cbs_cache = {}
+    for k in sample:
+        r = m[k]
+        qi, ti = int(r["query"]), int(r["target"])
+        qs, ts = qd[ql[qi]:ql[qi + 1] - 1], td[tl[ti]:tl[ti + 1] - 1]
+        if qi not in cbs_cache:
+            one_ql = np.array([256, 256 + len(qs) + 1], np.int64)
+            one_qd = np.concatenate([np.full(256, 31, np.int8), qs, np.full(257, 31, np.int8)])
+            cbs_cache[qi] = hip.extend_plan(params, one_qd, one_ql, one_qd, one_ql, np.zeros(0, hip.SEED_HIT_DTYPE))[0][256:256 + len(qs)]
+        rc, o, _ = orc.banded_swipe(qs, cbs_cache[qi], ts, int(r["d_begin"]), int(r["d_end"]), M, 11, 1, orc.TRACEBACK)
+        assert rc == 0
+        for key in KEYS:
+            assert o[key] == r["hsp"][key], (key, qi, ti)
+        assert r["evalue"] == pytest.approx(orc.evalue(e, o["score"], len(qs), len(ts)), rel=1e-6, abs=0)
