@@ -6,8 +6,8 @@
 // ReferenceHeader 40 bytes, ReferenceHeader2 as a size-prefixed record, per sequence 0xFF letters 0xFF id 0, trailer of
 // (pos u64, len u32, pad u32) records), SequenceSet layout (src/data/string_set.h:27-60), tabular output
 // (src/output/blast_tab_format.cpp, sequence ids cut at the first blank).
-// Supported: blastp (--fast, default sensitivity, --sensitive) with masking off (tantan/SEG/motif masking are host pre-processing that is not restated yet:
-// the tool insists on --masking 0 semantics and says so), -e, -k, -p, -f 6 default columns.
+// Supported: blastp / blastx (--fast, default sensitivity, --sensitive), tantan masking on the GPU (default) or --masking 0
+// (SEG and motif masking are not part of this build: --motif-masking 0 semantics, and the tool says so), -e, -k, -p, -f 6 default columns.
 #include <algorithm>
 #include <chrono>
 #include <cstdint>
@@ -266,8 +266,12 @@ int run_blastp(const Options& o)
 	if (!o.sens.empty() && o.sens != "--sensitive")
 		throw std::runtime_error("This build implements the --fast, default and --sensitive modes only (" + o.sens + " is not available).");
 	if (o.fast && !o.sens.empty()) throw std::runtime_error("Conflicting sensitivity options.");
-	if (o.masking != "0" || (o.motif_masking != "0" && !o.motif_masking.empty()))
-		std::cerr << "Warning: repeat masking (tantan / motif) is not implemented; running as --masking 0 --motif-masking 0.\n";
+	// --masking: tantan = default (run/config.cpp:124-135); seg is not part of this build
+	const bool tantan = o.masking.empty() || o.masking == "1" || o.masking == "tantan";
+	if (!tantan && o.masking != "0" && o.masking != "none")
+		throw std::runtime_error("Only --masking tantan (default) and --masking 0 are implemented.");
+	if (o.motif_masking != "0")
+		std::cerr << "Warning: motif masking is not implemented; running as --motif-masking 0.\n";
 	const auto t_all = std::chrono::steady_clock::now();
 	SeqBlock q, t;
 	const bool blastx = o.command == "blastx";
@@ -293,6 +297,13 @@ int run_blastp(const Options& o)
 	chk(dmnd_upload_block(ctx, DMND_QUERY, q.data.data(), (int64_t)q.data.size(), q.limits.data(), (int64_t)q.ids.size()));
 	chk(dmnd_upload_block(ctx, DMND_TARGET, t.data.data(), (int64_t)t.data.size(), t.limits.data(), (int64_t)t.ids.size()));
 	std::cerr << "Uploading blocks to HBM...  [" << ms_since(t0) / 1e3 << "s]\n";
+	if (tantan) {
+		t0 = std::chrono::steady_clock::now();
+		int64_t mq = 0, mt = 0;
+		chk(dmnd_mask_block(ctx, DMND_QUERY, q.data.data(), &mq));        // the host copies get the masked letters too
+		chk(dmnd_mask_block(ctx, DMND_TARGET, t.data.data(), &mt));
+		std::cerr << "Masking queries and reference (tantan)...  [" << ms_since(t0) / 1e3 << "s]  masked letters: " << mq << " + " << mt << "\n";
+	}
 	const int threads = o.threads > 0 ? o.threads : 8;
 	dmnd_seed_params sp;
 	if (o.fast) chk(dmnd_seed_params_fast(&sp, threads));

@@ -49,6 +49,9 @@ struct dmnd_ctx {
 	// gapped filter (gapped_api.hip)
 	dmnd::DevBuf gf_tables, gf_hits, gf_flags, gf_scores;
 	double gapped_filter_evalue = 0.0, gf_ms = 0.0;
+	// tantan masking (mask_api.hip)
+	dmnd::DevBuf mask_lr, mask_pb, mask_scale;
+	double mask_ms = 0.0;
 	double seed_ms[5] = { 0, 0, 0, 0, 0 };
 	// extension-stage statistics of the last dmnd_extend (extend_host.hip)
 	double ext_stats[12] = { 0 };

@@ -1,0 +1,108 @@
+// mask_api.hip -- C ABI of tantan repeat masking: dmnd_mask_block.
+// Replaces mask_seqs(seqs, Masking::get(), true, MaskingAlgo::TANTAN) (src/masking/masking.cpp:225-251) as the reference
+// applies it to the reference block (run/double_indexed.cpp:122-127) and to the query block (:737-740).
+#pragma clang fp contract(off)
+#include <cmath>
+#include <vector>
+#include "ctx.h"
+#include "mask_kernels.h"
+
+using namespace dmnd;
+
+namespace {
+
+// f(lambda) = sum(inverse(exp(lambda * S))) - 1 over the 20 standard residues (cbrc::LambdaCalculator, masking/lambda.cpp)
+bool inv_sum(const int8_t* m8, double lambda, double& f)
+{
+	const int n = 20;
+	double A[20][40];
+	for (int i = 0; i < n; ++i)
+		for (int j = 0; j < n; ++j) { A[i][j] = std::exp(lambda * (double)m8[i * 32 + j]); A[i][n + j] = i == j ? 1.0 : 0.0; }
+	for (int k = 0; k < n; ++k) {
+		int p = k;
+		for (int i = k + 1; i < n; ++i) if (std::fabs(A[i][k]) > std::fabs(A[p][k])) p = i;
+		if (std::fabs(A[p][k]) < 1e-12) return false;
+		if (p != k) for (int j = 0; j < 2 * n; ++j) std::swap(A[k][j], A[p][j]);
+		const double piv = A[k][k];
+		for (int j = 0; j < 2 * n; ++j) A[k][j] /= piv;
+		for (int i = 0; i < n; ++i) {
+			if (i == k) continue;
+			const double m = A[i][k];
+			if (m != 0.0) for (int j = 0; j < 2 * n; ++j) A[i][j] -= m * A[k][j];
+		}
+	}
+	long double acc = 0;
+	for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) acc += A[i][n + j];
+	f = (double)(acc - 1.0L);
+	return true;
+}
+
+bool likelihood_ratios(const int8_t* m8, float* lr)
+{
+	double lo = 1e-3, hi = 1.0, flo, fhi, fm;
+	if (!inv_sum(m8, lo, flo) || !inv_sum(m8, hi, fhi) || flo * fhi > 0) return false;
+	for (int it = 0; it < 200 && hi - lo >= 1e-15; ++it) {
+		const double mid = 0.5 * (lo + hi);
+		if (!inv_sum(m8, mid, fm)) return false;
+		if ((fm < 0) == (flo < 0)) { lo = mid; flo = fm; } else { hi = mid; fhi = fm; }
+	}
+	const double lambda = 0.5 * (lo + hi);
+	for (int i = 0; i < 32; ++i)
+		for (int j = 0; j < 32; ++j)      // Masking::Masking, masking.cpp:147-153: the 26 alphabet letters, 0 elsewhere
+			lr[i * 32 + j] = (i < 26 && j < 26) ? (float)std::exp(lambda * (double)m8[i * 32 + j]) : 0.0f;
+	return true;
+}
+
+}
+
+extern "C" int dmnd_mask_block(dmnd_ctx* c, int which, int8_t* host_data, int64_t* n_masked)
+{
+	if (!c || (which != DMND_QUERY && which != DMND_TARGET)) return fail(DMND_E_ARG, "dmnd_mask_block: bad argument");
+	if (!c->block[which].p || c->limits[which].size() < 2) return fail(DMND_E_ARG, "dmnd_mask_block: block must be uploaded with limits");
+	HIP_TRY(hipSetDevice(c->device));
+	hipStream_t st = c->stream;
+	const std::vector<int64_t>& lim = c->limits[which];
+	const int64_t n = (int64_t)lim.size() - 1, raw = c->block_len[which];
+	std::vector<float> lr(32 * 32);
+	if (!likelihood_ratios(c->params.matrix8, lr.data())) return fail(DMND_E_ARG, "dmnd_mask_block: no lambda for this scoring matrix");
+	TantanArgs a;
+	// Masking::operator() (masking.cpp:176): p_repeat 0.005, p_repeat_end 0.05, growth 1/0.9, minMaskProb 0.9 (config.cpp:402)
+	const float p_repeat = 0.005f, p_repeat_end = 0.05f, growth = 1.0f / 0.9f;
+	a.p.p_repeat_end = p_repeat_end;
+	a.p.b2b = 1.0f - p_repeat;
+	a.p.f2f = 1.0f - p_repeat_end;
+	a.p.p_mask = (float)0.9;
+	const float b2f0 = p_repeat * (1.0f - growth) / (1.0f - std::pow(growth, (float)TANTAN_WINDOW));     // tantan.cpp:130-136
+	a.p.d[TANTAN_WINDOW - 1] = b2f0;
+	for (int i = TANTAN_WINDOW - 2; i >= 0; --i) a.p.d[i] = a.p.d[i + 1] * growth;
+	if (int rc = c->mask_lr.ensure(lr.size() * sizeof(float))) return rc;
+	if (int rc = c->mask_pb.ensure((size_t)raw * sizeof(float))) return rc;
+	if (int rc = c->mask_scale.ensure((size_t)(raw / 16 + n + 16) * sizeof(float))) return rc;
+	if (int rc = c->counters.ensure(64 * sizeof(unsigned long long))) return rc;
+	HIP_TRY(hipMemcpyAsync(c->mask_lr.p, lr.data(), lr.size() * sizeof(float), hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(unsigned long long), st));
+	a.data = c->block[which].as<int8_t>();
+	a.limits = c->d_limits[which].as<int64_t>();
+	a.n_seqs = n;
+	a.lr = c->mask_lr.as<float>();
+	a.pb = c->mask_pb.as<float>();
+	a.scale = c->mask_scale.as<float>();
+	a.n_masked = c->counters.as<unsigned long long>();
+	HIP_TRY(hipEventRecord(c->ev0, st));
+	HIP_TRY(launch_tantan(a, st));
+	HIP_TRY(hipEventRecord(c->ev1, st));
+	unsigned long long nm = 0;
+	HIP_TRY(hipMemcpyAsync(&nm, c->counters.p, sizeof(nm), hipMemcpyDeviceToHost, st));
+	if (host_data) HIP_TRY(hipMemcpyAsync(host_data, c->block[which].p, (size_t)raw, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	float ms = 0;
+	HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+	c->mask_ms = ms;
+	if (n_masked) *n_masked = (int64_t)nm;
+	// the scratch (4 B per letter) is only needed during the call
+	c->mask_pb.release();
+	c->mask_scale.release();
+	return DMND_OK;
+}
+
+extern "C" double dmnd_mask_kernel_ms(const dmnd_ctx* c) { return c ? c->mask_ms : 0.0; }

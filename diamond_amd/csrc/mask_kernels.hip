@@ -1,0 +1,143 @@
+// mask_kernels.hip -- tantan repeat masking on the MI355X: one 64-lane wavefront per sequence, lane k owns repeat
+// offset k (50 of 64 lanes). The forward and backward recurrences run over the sequence positions; per position the
+// lanes read their history letter (position i-1-k: consecutive lanes, consecutive bytes), look the likelihood ratio up
+// in a 4 KB LDS table, update their state in registers and combine through three ds_swizzle butterflies + ordered
+// scalar adds. The background probabilities of the forward pass go to an HBM scratch (4 B per letter), written and read
+// back 64 positions at a time. Float operation order = the reference's (mask_core.h); no contraction in this file.
+#pragma clang fp contract(off)      // before every definition of this translation unit, mask_core.h included
+#include "mask_kernels.h"
+
+namespace dmnd {
+
+namespace {
+
+__device__ __forceinline__ float swz(float v, int mask)
+{
+	// ds_swizzle bit-mask mode: and 0x1f, or 0, xor mask (lanes exchange inside their half-wave)
+	int x = __float_as_int(v);
+	switch (mask) {
+	case 1: x = __builtin_amdgcn_ds_swizzle(x, 0x041f); break;
+	case 2: x = __builtin_amdgcn_ds_swizzle(x, 0x081f); break;
+	default: x = __builtin_amdgcn_ds_swizzle(x, 0x101f); break;
+	}
+	return __int_as_float(x);
+}
+
+__device__ __forceinline__ float lane_of(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+
+// ordered total of the 50 per-offset values: six groups of 8, then offsets 48 and 49 (forward_step / backward_step)
+__device__ __forceinline__ float ordered_sum(float v)
+{
+	const float g = tantan_group_sum(v, [](float x, int m) { return swz(x, m); });
+	float s = 0.0f;
+#pragma unroll
+	for (int k = 0; k < 6; ++k) s = s + lane_of(g, 8 * k);
+	s = s + lane_of(v, 48);
+	s = s + lane_of(v, 49);
+	return s;
+}
+
+__global__ __launch_bounds__(256) void tantan_kernel(const TantanArgs a)
+{
+	__shared__ float L[32 * 32];
+	for (int i = threadIdx.x; i < 1024; i += blockDim.x) L[i] = a.lr[i];
+	__syncthreads();
+	const int lane = threadIdx.x & 63;
+	const int64_t seq_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	if (seq_id >= a.n_seqs) return;
+	const int64_t base = a.limits[seq_id];
+	const int len = (int)(a.limits[seq_id + 1] - base - 1);
+	if (len <= 0) return;
+	int8_t* seq = a.data + base;
+	float* pb = a.pb + base;
+	float* scale = a.scale + base / 16 + seq_id;
+	const bool own = lane < TANTAN_WINDOW;
+	const float d = own ? a.p.d[lane] : 0.0f;
+	const float f2f = a.p.f2f, b2b = a.p.b2b, pre = a.p.p_repeat_end;
+
+	// ---- forward ----
+	float f = 0.0f, b = 1.0f, f_sum = 0.0f, pbv = 0.0f;
+	int chunk = 0;                                     // letters [i0, i0 + 64) of the sequence, one per lane
+	for (int i = 0; i < len; ++i) {
+		if ((i & 63) == 0) chunk = (i + lane < len) ? (seq[i + lane] & 31) : 0;
+		const int ltr = __builtin_amdgcn_readlane(chunk, i & 63);
+		const int hp = i - 1 - lane;
+		const float e = (own && hp >= 0) ? L[ltr * 32 + (seq[hp] & 31)] : 0.0f;
+		const float b_old = b;
+		f = tantan_fwd_cell(f, f2f, b_old, d, e);
+		const float f_sum_new = ordered_sum(f);
+		{ const float t1 = b_old * b2b, t2 = f_sum * pre; b = t1 + t2; }
+		f_sum = f_sum_new;
+		if ((i & 15) == 15) {
+			const float s = __fdiv_rn(1.0f, b);
+			if (lane == 0) scale[i >> 4] = s;
+			b = b * s;
+			f = f * s;
+			f_sum = f_sum * s;
+		}
+		if (lane == (i & 63)) pbv = b;
+		if ((i & 63) == 63 || i == len - 1) {
+			const int i0 = i & ~63;
+			if (i0 + lane <= i) pb[i0 + lane] = pbv;
+		}
+	}
+	// z = b * b2b + sum(f, 50) * p_repeat_end   (SIMD::sum: lane-wise accumulation of the six groups, then hsum, then 48, 49)
+	float acc = 0.0f;
+#pragma unroll
+	for (int g = 0; g < 6; ++g) acc = acc + __shfl(f, (lane & 7) + 8 * g);
+	float total = tantan_group_sum(acc, [](float x, int m) { return swz(x, m); });
+	total = lane_of(total, 0);
+	total = total + lane_of(f, 48);
+	total = total + lane_of(f, 49);
+	float z;
+	{ const float t1 = b * b2b, t2 = total * pre; z = t1 + t2; }
+	const float zinv = __fdiv_rn(1.0f, z);
+
+	// ---- backward ----
+	b = b2b;
+	f = own ? pre : 0.0f;
+	int n_masked = 0;
+	bool mask_me = false;
+	for (int i = len - 1; i >= 0; --i) {
+		if ((i & 63) == 63 || i == len - 1) {
+			const int i0 = i & ~63;
+			pbv = (i0 + lane <= i) ? pb[i0 + lane] : 0.0f;
+			chunk = (i0 + lane <= i) ? (seq[i0 + lane] & 31) : 0;
+			mask_me = false;
+		}
+		const float pbi = lane_of(pbv, i & 63);
+		float pf;
+		{ const float t = pbi * b; const float u = t * zinv; pf = 1.0f - u; }
+		if ((i & 15) == 15) {
+			const float s = scale[i >> 4];
+			b = b * s;
+			f = f * s;
+		}
+		const int ltr = __builtin_amdgcn_readlane(chunk, i & 63);
+		const int hp = i - 1 - lane;
+		const float e = (own && hp >= 0) ? L[ltr * 32 + (seq[hp] & 31)] : 0.0f;
+		const float C = pre * b;
+		float vt;
+		f = tantan_bwd_cell(f, e, d, f2f, C, vt);
+		if (!own) { f = 0.0f; vt = 0.0f; }
+		const float tsum = ordered_sum(vt);
+		{ const float t1 = b2b * b; b = t1 + tsum; }
+		if (pf >= a.p.p_mask) { if (lane == (i & 63)) mask_me = true; ++n_masked; }
+		if ((i & 63) == 0) {                                   // positions [i, i + 64) are final: no later step reads them
+			if (mask_me) seq[i + lane] = 23;
+		}
+	}
+	if (lane == 0 && n_masked) atomicAdd(a.n_masked, (unsigned long long)n_masked);
+}
+
+}  // namespace
+
+hipError_t launch_tantan(const TantanArgs& a, hipStream_t st)
+{
+	if (a.n_seqs <= 0) return hipSuccess;
+	const int64_t blocks = (a.n_seqs + 3) / 4;
+	tantan_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(a);
+	return hipGetLastError();
+}
+
+}  // namespace dmnd

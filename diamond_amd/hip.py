@@ -67,7 +67,7 @@ EXPORTS = ["dmnd_abi_version", "dmnd_last_error", "dmnd_default_params", "dmnd_c
            "dmnd_bitscore_p", "dmnd_evalue_batch", "dmnd_last_kernel_ms", "dmnd_seed_params_fast", "dmnd_seed_params_default", "dmnd_seed_search",
            "dmnd_seed_hits", "dmnd_seed_kernel_ms", "dmnd_extend_plan", "dmnd_extend", "dmnd_extend_stats", "dmnd_format_tab", "dmnd_set_max_target_seqs",
            "dmnd_seed_params_sensitive", "dmnd_set_gapped_filter", "dmnd_gapped_filter", "dmnd_gapped_filter_ms",
-           "dmnd_set_query_contexts", "dmnd_translate", "dmnd_format_tab_translated"]
+           "dmnd_set_query_contexts", "dmnd_translate", "dmnd_format_tab_translated", "dmnd_mask_block", "dmnd_mask_kernel_ms"]
 
 
 def load():
@@ -114,6 +114,9 @@ def load():
         lib.dmnd_format_tab.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int64]
         lib.dmnd_format_tab_translated.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int32, ctypes.c_char_p, ctypes.c_int64]
         lib.dmnd_set_query_contexts.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        lib.dmnd_mask_block.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)]
+        lib.dmnd_mask_kernel_ms.argtypes = [ctypes.c_void_p]
+        lib.dmnd_mask_kernel_ms.restype = ctypes.c_double
         lib.dmnd_translate.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
         lib.dmnd_last_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
         _lib = lib
@@ -322,6 +325,20 @@ class Context:
         hits = np.zeros(n.value, dtype=SEED_HIT_DTYPE)
         self._check(self.lib.dmnd_seed_hits(self.h, hits.ctypes.data if n.value else None, n.value))
         return hits
+
+    def mask_block(self, which, host_data=None):
+        """tantan repeat masking of the uploaded block in HBM (hard mask, letter 23). host_data: the int8 array the block was
+        uploaded from (C-contiguous); it receives the masked letters. Returns the number of masked positions."""
+        n = ctypes.c_int64(0)
+        ptr = None
+        if host_data is not None:
+            assert host_data.dtype == np.int8 and host_data.flags["C_CONTIGUOUS"]
+            ptr = host_data.ctypes.data
+        self._check(self.lib.dmnd_mask_block(self.h, int(which), ptr, ctypes.byref(n)))
+        return n.value
+
+    def mask_kernel_ms(self):
+        return float(self.lib.dmnd_mask_kernel_ms(self.h))
 
     def set_query_contexts(self, contexts):
         """1 = blastp, 6 = blastx (the query block holds the six frames of every read consecutively)."""

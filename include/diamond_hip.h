@@ -266,6 +266,15 @@ int dmnd_translate(const int8_t* dna, int32_t len, int8_t* out[6], int32_t lens[
  * src/basic/translated_position.h:125-175; reverse frames print qstart > qend). */
 int dmnd_format_tab_translated(const dmnd_match* m, const char* qseqid, const char* sseqid, int32_t source_len, char* buf, int64_t cap);
 
+/* tantan repeat masking of an uploaded block, in place in HBM (hard mask: letter 23), as the reference masks the
+ * reference block and the query block with its default --masking tantan (mask_seqs, src/masking/masking.cpp:225-251;
+ * Util::tantan::mask, src/masking/tantan.cpp:112; likelihood ratios exp(lambda * score), masking.cpp:134-155).
+ * Results are bit-identical to the reference's AVX2 build (float operation order restated, see csrc/mask_core.h).
+ * host_data (may be NULL) receives the masked block letters (block raw length bytes): the extension stage's host part
+ * reads the same letters. *n_masked (may be NULL) = number of positions at or above the mask probability. */
+int dmnd_mask_block(dmnd_ctx* ctx, int which, int8_t* host_data, int64_t* n_masked);
+double dmnd_mask_kernel_ms(const dmnd_ctx* ctx);
+
 /* -k / --max-target-seqs (default 25, src/basic/config.h:55) */
 int dmnd_set_max_target_seqs(dmnd_ctx* ctx, int k);
 /* Statistics of the last dmnd_extend: [0] round-1 DpTargets [1] round-2 DpTargets [2] round-1 cells [3] round-2 cells

@@ -49,6 +49,11 @@ int oracle_gapped_filter_target(const int8_t* matrix8, const int8_t* query, int 
 	const int32_t* hit_i, const int32_t* hit_j, int n_hits, int cutoff1, int cutoff2, int window2, int diag_score, int gap_open, int gap_extend);
 void oracle_cutoff_table2d(const oracle_evaluer* e, double evalue, int32_t* table);
 
+/* tantan repeat masking (tantan.c) */
+int oracle_tantan_mask(int8_t* seq, int len, const float* lr, float p_repeat, float p_repeat_end, float repeat_growth, float p_mask);
+double oracle_tantan_lambda(const int8_t* matrix8);
+void oracle_tantan_matrix(const int8_t* matrix8, float* lr);
+
 /* ---- seed stage (oracle/seed_search.c) ---- */
 typedef struct {
 	int32_t seedp_bits, index_chunks, hamming_filter_id, n_shapes;

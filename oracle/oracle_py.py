@@ -201,3 +201,28 @@ def gapped_filter_hit(matrix8, query, cbs, target, hit_i, hit_j, band, window, d
     p = lambda a: a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
     return int(lib().oracle_gapped_filter_hit(p(m), p(q), len(q), p(c), p(t), len(t), int(hit_i), int(hit_j), int(band), int(window),
                                               int(diag_score), int(gap_open), int(gap_extend)))
+
+
+# ---- tantan masking ---------------------------------------------------------------------------------------------
+def tantan_matrix(matrix8):
+    """32x32 float32 likelihood-ratio matrix exp(lambda * score) as Masking::Masking builds it."""
+    m = np.ascontiguousarray(matrix8, np.int8)
+    lr = np.zeros(1024, np.float32)
+    lib().oracle_tantan_matrix(m.ctypes.data_as(ctypes.c_void_p), lr.ctypes.data_as(ctypes.c_void_p))
+    return lr.reshape(32, 32)
+
+
+def tantan_lambda(matrix8):
+    m = np.ascontiguousarray(matrix8, np.int8)
+    lib().oracle_tantan_lambda.restype = ctypes.c_double
+    return lib().oracle_tantan_lambda(m.ctypes.data_as(ctypes.c_void_p))
+
+
+def tantan_mask(seq, lr, p_repeat=0.005, p_repeat_end=0.05, repeat_growth=1.0 / 0.9, p_mask=0.9):
+    """Hard-masks a copy of seq; returns (masked int8[], number of masked letters)."""
+    s = np.ascontiguousarray(seq, np.int8).copy()
+    m = np.ascontiguousarray(lr, np.float32)
+    f = ctypes.c_float
+    n = lib().oracle_tantan_mask(s.ctypes.data_as(ctypes.c_void_p), len(s), m.ctypes.data_as(ctypes.c_void_p),
+                                 f(p_repeat), f(p_repeat_end), f(repeat_growth), f(p_mask))
+    return s, n

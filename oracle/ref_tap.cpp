@@ -318,3 +318,43 @@ GfResult wrap_gf(const Sequence* query, const HauserCorrection* query_cbs, FlatA
 	}
 	return out;
 }
+
+// ---- fourth seam: tantan repeat masking (masking/tantan.cpp:112, dispatcher Util::tantan::mask; called per sequence from
+// Masking::operator(), masking/masking.cpp:176, for the query and the reference block when --masking is tantan = default).
+// $DIAMOND_TAP_TANTAN=file: header 'TANH' + 32x32 float likelihood-ratio matrix + p_repeat p_repeat_end repeat_growth p_mask
+// (floats), then per call 'TAN1': len | letters before | letters after (mask_mode as passed).
+#include "masking/def.h"
+#define TANTAN_SYM "_ZN4Util6tantan4maskEPaiPPKfffffi"
+namespace Util { namespace tantan { } }
+Mask::Ranges real_tantan(Letter* seq, int len, const float** lr, float p_repeat, float p_repeat_end, float repeat_growth, float p_mask, int mask_mode) asm("__real_" TANTAN_SYM);
+Mask::Ranges wrap_tantan(Letter* seq, int len, const float** lr, float p_repeat, float p_repeat_end, float repeat_growth, float p_mask, int mask_mode) asm("__wrap_" TANTAN_SYM);
+
+Mask::Ranges wrap_tantan(Letter* seq, int len, const float** lr, float p_repeat, float p_repeat_end, float repeat_growth, float p_mask, int mask_mode)
+{
+	static FILE* f = getenv("DIAMOND_TAP_TANTAN") ? fopen(getenv("DIAMOND_TAP_TANTAN"), "wb") : nullptr;
+	static std::mutex mtx;
+	static bool header = false;
+	static std::atomic<int64_t> budget(getenv("DIAMOND_TAP_TANTAN_MAX") ? atoll(getenv("DIAMOND_TAP_TANTAN_MAX")) : (int64_t)1 << 62);
+	if (!f || budget.fetch_sub(1) <= 0)
+		return real_tantan(seq, len, lr, p_repeat, p_repeat_end, repeat_growth, p_mask, mask_mode);
+	Buf b;
+	b.i32(0x314e4154); b.i32(len); b.i32(mask_mode);
+	b.bytes(seq, (size_t)len);
+	Mask::Ranges r = real_tantan(seq, len, lr, p_repeat, p_repeat_end, repeat_growth, p_mask, mask_mode);
+	b.bytes(seq, (size_t)len);
+	b.i32((int32_t)r.size());
+	for (const auto& x : r) { b.i32(x.first); b.i32(x.second); }
+	std::lock_guard<std::mutex> lock(mtx);
+	if (!header) {
+		header = true;
+		Buf h;
+		h.i32(0x484e4154);
+		for (int i = 0; i < 32; ++i) h.bytes(i < AMINO_ACID_COUNT ? lr[i] : lr[0], 32 * sizeof(float));
+		const float p[4] = { p_repeat, p_repeat_end, repeat_growth, p_mask };
+		h.bytes(p, sizeof p);
+		fwrite(h.d.data(), 1, h.d.size(), f);
+	}
+	fwrite(b.d.data(), 1, b.d.size(), f);
+	fflush(f);
+	return r;
+}

@@ -179,3 +179,29 @@ def read_gf_tap(path, max_records=None):
         recs.append(dict(gapped_filter_evalue=ev, gapped_filter_evalue1=ev1, diag_score=diag, window=window, gap_open=go,
                          gap_extend=ge, query_offset=qoff, qlen=qlen, cbs=cbs, targets=targets, out=out))
     return recs
+
+
+def read_tantan_tap(path, max_records=None):
+    """Reader for $DIAMOND_TAP_TANTAN files (oracle/ref_tap.cpp, fourth seam: Util::tantan::mask).
+    Returns (hdr, records): hdr = {lr (32x32 float32), p_repeat, p_repeat_end, repeat_growth, p_mask};
+    records[i] = {mask_mode, before (int8[]), after (int8[]), ranges (n x 2 int32)}."""
+    buf = open(path, "rb").read()
+    magic, = struct.unpack_from("<i", buf, 0)
+    assert magic == 0x484e4154, hex(magic)
+    lr = np.frombuffer(buf, "<f4", 1024, 4).reshape(32, 32).copy()
+    p = np.frombuffer(buf, "<f4", 4, 4 + 4096)
+    hdr = dict(lr=lr, p_repeat=p[0], p_repeat_end=p[1], repeat_growth=p[2], p_mask=p[3])
+    pos, recs = 4 + 4096 + 16, []
+    while pos < len(buf) and (max_records is None or len(recs) < max_records):
+        magic, n, mode = struct.unpack_from("<iii", buf, pos)
+        assert magic == 0x314e4154, hex(magic)
+        pos += 12
+        before = np.frombuffer(buf, np.int8, n, pos).copy()
+        after = np.frombuffer(buf, np.int8, n, pos + n).copy()
+        pos += 2 * n
+        nr, = struct.unpack_from("<i", buf, pos)
+        pos += 4
+        ranges = np.frombuffer(buf, "<i4", 2 * nr, pos).reshape(nr, 2).copy()
+        pos += 8 * nr
+        recs.append(dict(mask_mode=mode, before=before, after=after, ranges=ranges))
+    return hdr, recs

@@ -12,6 +12,8 @@ _CORE = os.path.join(_HERE, "..", "diamond_amd", "csrc", "swipe_core.h")
 _CORE2 = os.path.join(_HERE, "..", "diamond_amd", "csrc", "seed_core.h")
 _SRC3 = os.path.join(_HERE, "emu", "gapped_emu.cpp")
 _CORE3 = os.path.join(_HERE, "..", "diamond_amd", "csrc", "gapped_core.h")
+_SRC4 = os.path.join(_HERE, "emu", "mask_emu.cpp")
+_CORE4 = os.path.join(_HERE, "..", "diamond_amd", "csrc", "mask_core.h")
 _SO = os.path.join(_HERE, "emu", "libswipe_emu.so")
 
 
@@ -27,8 +29,8 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_SO) or max(os.path.getmtime(f) for f in (_SRC, _SRC2, _SRC3, _CORE, _CORE2, _CORE3)) > os.path.getmtime(_SO):
-            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-o", _SO, _SRC, _SRC2, _SRC3])
+        if not os.path.exists(_SO) or max(os.path.getmtime(f) for f in (_SRC, _SRC2, _SRC3, _SRC4, _CORE, _CORE2, _CORE3, _CORE4)) > os.path.getmtime(_SO):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-w", "-o", _SO, _SRC, _SRC2, _SRC3, _SRC4])
         _lib = ctypes.CDLL(_SO)
     return _lib
 
@@ -136,3 +138,35 @@ def gapped_filter_hit(p, matrix8, query, cbs, target, hit_i, hit_j, cutoff1, cut
     flag = lib().emu_gapped_filter_hit(ctypes.byref(p), v(m), v(q), len(q), v(c), v(t), len(t), int(hit_i), int(hit_j),
                                        int(cutoff1), int(cutoff2), f)
     return flag, f[0], f[1]
+
+
+# ---- tantan masking ---------------------------------------------------------------------------------------------
+class TantanParams(ctypes.Structure):
+    _fields_ = [("p_repeat_end", ctypes.c_float), ("b2b", ctypes.c_float), ("f2f", ctypes.c_float), ("p_mask", ctypes.c_float),
+                ("d", ctypes.c_float * 50)]
+
+
+def tantan_params(p_repeat=0.005, p_repeat_end=0.05, growth=1.0 / 0.9, p_mask=0.9):
+    f32 = np.float32
+    p = TantanParams()
+    p.p_repeat_end = p_repeat_end
+    p.b2b = float(f32(1.0) - f32(p_repeat))
+    p.f2f = float(f32(1.0) - f32(p_repeat_end))
+    p.p_mask = p_mask
+    g = f32(growth)
+    b2f0 = f32(p_repeat) * (f32(1.0) - g) / (f32(1.0) - f32(np.power(g, f32(50.0), dtype=np.float32)))
+    d = np.zeros(50, np.float32)
+    d[49] = b2f0
+    for i in range(48, -1, -1):
+        d[i] = d[i + 1] * g
+    for i in range(50):
+        p.d[i] = float(d[i])
+    return p
+
+
+def tantan_mask(p, lr, seq):
+    """Masked copy of seq through the emulated kernel, and the number of masked positions."""
+    s = np.ascontiguousarray(seq, np.int8).copy()
+    m = np.ascontiguousarray(lr, np.float32)
+    n = lib().emu_tantan_mask(ctypes.byref(p), m.ctypes.data_as(ctypes.c_void_p), s.ctypes.data_as(ctypes.c_void_p), len(s))
+    return s, n

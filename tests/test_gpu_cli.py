@@ -3,6 +3,7 @@ all alignment work on the MI355X) against the unmodified reference binary on the
 makedb must be readable by the reference, and the tabular outputs must be byte-identical."""
 import os
 import subprocess
+import numpy as np
 import pytest
 
 from diamond_amd import synth
@@ -66,6 +67,48 @@ def test_cli_blastx_matches_reference(tmp_path):
         ref = open(tmp_path / ("ref_%s.tsv" % tag)).read()
         assert len(ref.splitlines()) > 150
         assert open(tmp_path / ("hip_%s.tsv" % tag)).read() == ref, tag
+
+
+def _plant_repeats(data, off, rng, frac=0.3):
+    """Low-complexity stretches (tandem repeats with a few substitutions) inside a fraction of the sequences."""
+    data = data.copy()
+    for i in range(len(off) - 1):
+        n = int(off[i + 1] - off[i])
+        if n < 80 or rng.random() > frac:
+            continue
+        unit = rng.integers(0, 20, int(rng.integers(1, 7))).astype(data.dtype)
+        a = int(rng.integers(0, n - 60))
+        L = int(rng.integers(25, 60))
+        seg = np.resize(unit, L)
+        flip = rng.random(L) < 0.05
+        seg[flip] = rng.integers(0, 20, int(flip.sum()))
+        data[off[i] + a: off[i] + a + L] = seg
+    return data
+
+
+def test_cli_default_masking_matches_reference(tmp_path):
+    """Default --masking (tantan on both blocks, on the GPU) against the reference's default masking; motif masking off."""
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/diamond not built")
+    rng = np.random.default_rng(21)
+    db, doff, q, qoff = synth.generate(300, members=10, queries=400, seed=21)
+    db, q = _plant_repeats(db, doff, rng), _plant_repeats(q, qoff, rng)
+    synth.write_fasta(str(tmp_path / "db.faa"), "t", db, doff)
+    synth.write_fasta(str(tmp_path / "q.faa"), "q", q, qoff)
+    for mode in ([], ["--fast"], ["--sensitive"]):
+        tag = (mode or ["default"])[0].strip("-")
+        _run([REF, "blastp"] + mode + ["--algo", "0", "--motif-masking", "0", "-q", str(tmp_path / "q.faa"), "-d", str(tmp_path / "db.faa"),
+                                        "-o", str(tmp_path / ("ref_%s.tsv" % tag)), "-p", "4"])
+        r = _run([CLI, "blastp"] + mode + ["--motif-masking", "0", "-q", str(tmp_path / "q.faa"), "-d", str(tmp_path / "db.faa"),
+                                            "-o", str(tmp_path / ("hip_%s.tsv" % tag)), "-p", "4"])
+        assert "masked letters" in r.stderr
+        ref = open(tmp_path / ("ref_%s.tsv" % tag)).read()
+        assert len(ref.splitlines()) > 300
+        assert open(tmp_path / ("hip_%s.tsv" % tag)).read() == ref, tag
+    # masking really changes this workload: the unmasked run differs
+    _run([REF, "blastp", "--algo", "0", "--masking", "0", "--motif-masking", "0", "-q", str(tmp_path / "q.faa"), "-d", str(tmp_path / "db.faa"),
+          "-o", str(tmp_path / "ref_nomask.tsv"), "-p", "4"])
+    assert open(tmp_path / "ref_nomask.tsv").read() != open(tmp_path / "ref_default.tsv").read()
 
 
 def test_cli_refuses_unimplemented_modes(tmp_path):
