@@ -98,6 +98,30 @@ extern "C" int dmnd_seed_params_sensitive(dmnd_seed_params* p, int threads, cons
 	return spaced_preset(p, threads, sc, codes, 16, 1.0);
 }
 
+// One entry for every sensitivity this library presets: shape set, seed cut and the gapped-filter e-value that goes with it
+// (sensitivity_traits + shape_codes, search/setup.cpp:40-53,80-215)
+extern "C" int dmnd_seed_params_preset(dmnd_seed_params* p, int sensitivity, int threads, const dmnd_params* sc, double* gapped_filter_evalue)
+{
+	if (!p || threads < 1) return fail(DMND_E_ARG, "dmnd_seed_params_preset: bad argument");
+	if (gapped_filter_evalue) *gapped_filter_evalue = 0.0;
+	switch (sensitivity) {
+	case DMND_SENS_FAST: return dmnd_seed_params_fast(p, threads);
+	case DMND_SENS_DEFAULT: return dmnd_seed_params_default(p, threads, sc);
+	case DMND_SENS_MID_SENSITIVE: {
+		if (!sc) return fail(DMND_E_ARG, "dmnd_seed_params_preset: scoring parameters needed");
+		static const char* const codes[8] = { "11110110111", "1101100111101", "1110010101111", "11010101100111", "11101110001011",
+			"1110100100010111", "1101000011010111", "1110011000011011" };                   // 8x9, setup.cpp:196-205
+		return spaced_preset(p, threads, sc, codes, 8, 1.0);
+	}
+	case DMND_SENS_SENSITIVE:
+	case DMND_SENS_MORE_SENSITIVE:       // same shapes and filters; differs only in freq_sd / motif masking, which this library does not apply
+		if (gapped_filter_evalue) *gapped_filter_evalue = 1.0;
+		return dmnd_seed_params_sensitive(p, threads, sc);
+	default:
+		return fail(DMND_E_ARG, "dmnd_seed_params_preset: unknown sensitivity");
+	}
+}
+
 extern "C" int dmnd_seed_kernel_ms(const dmnd_ctx* c, double ms[5])
 {
 	if (!c || !ms) return fail(DMND_E_ARG, "dmnd_seed_kernel_ms: bad argument");

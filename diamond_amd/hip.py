@@ -67,7 +67,7 @@ EXPORTS = ["dmnd_abi_version", "dmnd_last_error", "dmnd_default_params", "dmnd_c
            "dmnd_bitscore_p", "dmnd_evalue_batch", "dmnd_last_kernel_ms", "dmnd_seed_params_fast", "dmnd_seed_params_default", "dmnd_seed_search",
            "dmnd_seed_hits", "dmnd_seed_kernel_ms", "dmnd_extend_plan", "dmnd_extend", "dmnd_extend_stats", "dmnd_format_tab", "dmnd_set_max_target_seqs",
            "dmnd_seed_params_sensitive", "dmnd_set_gapped_filter", "dmnd_gapped_filter", "dmnd_gapped_filter_ms",
-           "dmnd_set_query_contexts", "dmnd_translate", "dmnd_format_tab_translated", "dmnd_mask_block", "dmnd_mask_kernel_ms"]
+           "dmnd_set_query_contexts", "dmnd_translate", "dmnd_format_tab_translated", "dmnd_mask_block", "dmnd_mask_kernel_ms", "dmnd_seed_params_preset"]
 
 
 def load():
@@ -203,6 +203,21 @@ def seed_params_default(scoring, threads=1):
     if rc != 0:
         raise DiamondHipError(load().dmnd_last_error().decode())
     return p
+
+
+SENS = {"fast": 0, "default": 1, "mid-sensitive": 2, "sensitive": 3, "more-sensitive": 4}
+
+
+def seed_params_preset(name, scoring, threads=1):
+    """(SeedParams, gapped_filter_evalue) of a sensitivity preset: fast, default, mid-sensitive, sensitive, more-sensitive."""
+    p = SeedParams()
+    gf = ctypes.c_double(0)
+    lib = load()
+    lib.dmnd_seed_params_preset.argtypes = [ctypes.POINTER(SeedParams), ctypes.c_int, ctypes.c_int, ctypes.POINTER(Params), ctypes.POINTER(ctypes.c_double)]
+    rc = lib.dmnd_seed_params_preset(ctypes.byref(p), SENS[name], int(threads), ctypes.byref(scoring), ctypes.byref(gf))
+    if rc != 0:
+        raise DiamondHipError(lib.dmnd_last_error().decode())
+    return p, gf.value
 
 
 def seed_params_sensitive(scoring, threads=1):

@@ -251,6 +251,10 @@ int dmnd_set_gapped_filter(dmnd_ctx* ctx, double gapped_filter_evalue);
 int dmnd_gapped_filter(dmnd_ctx* ctx, const dmnd_seed_hit* hits, int64_t n_hits, int use_cbs, uint8_t* flags, int32_t* scores);
 /* device time (ms) of the gapped filter kernel of the last dmnd_gapped_filter / dmnd_extend */
 double dmnd_gapped_filter_ms(const dmnd_ctx* ctx);
+/* Sensitivity presets (Sensitivity enum + sensitivity_traits, src/search/setup.cpp:40-53): shapes, seed cut, ungapped
+ * e-value, and through *gapped_filter_evalue (may be NULL) the value to pass to dmnd_set_gapped_filter. */
+enum { DMND_SENS_FAST = 0, DMND_SENS_DEFAULT = 1, DMND_SENS_MID_SENSITIVE = 2, DMND_SENS_SENSITIVE = 3, DMND_SENS_MORE_SENSITIVE = 4 };
+int dmnd_seed_params_preset(dmnd_seed_params* p, int sensitivity, int threads, const dmnd_params* scoring, double* gapped_filter_evalue);
 /* Sensitive mode seed configuration (16 shapes of weight 8, search/setup.cpp:86-102; ungapped e-value 10000, seed cut 1.0) */
 int dmnd_seed_params_sensitive(dmnd_seed_params* p, int threads, const dmnd_params* scoring);
 

@@ -95,7 +95,7 @@ def test_cli_default_masking_matches_reference(tmp_path):
     db, q = _plant_repeats(db, doff, rng), _plant_repeats(q, qoff, rng)
     synth.write_fasta(str(tmp_path / "db.faa"), "t", db, doff)
     synth.write_fasta(str(tmp_path / "q.faa"), "q", q, qoff)
-    for mode in ([], ["--fast"], ["--sensitive"]):
+    for mode in ([], ["--fast"], ["--mid-sensitive"], ["--sensitive"], ["--more-sensitive"]):
         tag = (mode or ["default"])[0].strip("-")
         _run([REF, "blastp"] + mode + ["--algo", "0", "--motif-masking", "0", "-q", str(tmp_path / "q.faa"), "-d", str(tmp_path / "db.faa"),
                                         "-o", str(tmp_path / ("ref_%s.tsv" % tag)), "-p", "4"])
