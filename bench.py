@@ -168,9 +168,13 @@ def main():
         alg_bytes = int(tl[-1] - tl[0])
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_seed_stream_pmc.json")
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")      # rocprofv3 --pmc passes of this command (tools/profile_round.sh)
         if os.path.exists(tpath) and args.queries == 10_000 and args.families == 100_000:
-            traffic = json.load(open(tpath))["traffic_bytes_fetch_x2"]
+            pmc = json.load(open(tpath))
+            k = [v for name, v in pmc.items() if "seed_stream_fast_kernel" in name]
+            if k:
+                # HBM-side bytes per launch: FETCH_SIZE (x2: gfx950 under-reports wide reads, upper bound) + WRITE_SIZE
+                traffic = k[0]["FETCH_SIZE_x2_bytes_per_launch"] + k[0]["WRITE_SIZE_bytes_per_launch"]
         out = {
             "metric": "GCUPS + aligned queries/s, blastp --fast 10k queries vs 1M-seq DB (seed stage + banded SW extension)",
             "value": gcups, "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
