@@ -79,3 +79,75 @@ def test_c2_full_path_properties():
         for key in KEYS:
             assert o[key] == r["hsp"][key], (key, qi, ti)
         assert r["evalue"] == pytest.approx(orc.evalue(e, o["score"], len(qs), len(ts)), rel=1e-6, abs=0)
+
+
+def _family_truth(m, fam, members, min_frac):
+    qv, tg = m["query"].astype(np.int64), m["target"].astype(np.int64)
+    first = np.r_[True, qv[1:] != qv[:-1]]
+    top_q, top_t = qv[first], tg[first]
+    derived = fam[top_q] >= 0
+    assert derived.sum() > 1000
+    assert ((top_t[derived] // members) == fam[top_q[derived]]).mean() > min_frac
+    _, counts = np.unique(qv, return_counts=True)
+    assert counts.max() <= 25 and (m["evalue"] <= 0.001).all()
+
+
+def test_c3_sensitive_and_c4_blastx_at_scale(capsys):
+    """BASELINE configs C3 (blastp --sensitive, 10k x 1M) and C4 (blastx, 5k reads of ~1 kb x 1M): the same database block,
+    ground truth of the synthetic families, bounds on the records, and that more sensitive modes find a superset of aligned
+    queries. Timings are printed for DESIGN.md (not a bench line)."""
+    import time
+    assert torch.cuda.is_available()
+    members = 10
+    db, doff, q, qoff, fam = synth.generate(100_000, members=members, queries=10_000, seed=20260923, family=True)
+    qd, ql = workload.sequence_set(q, qoff)
+    td, tl = workload.sequence_set(db, doff)
+    params = hip.default_params()
+    params.db_letters = float(doff[-1])
+    ctx = hip.Context(params=params)
+    out = {}
+    try:
+        ctx.upload_block(hip.TARGET, td, tl)
+        ctx.upload_block(hip.QUERY, qd, ql)
+        aligned = {}
+        for name in ("fast", "default", "sensitive"):
+            sp, gf = hip.seed_params_preset(name, params, threads=8)
+            ctx.set_gapped_filter(gf)
+            t0 = time.perf_counter()
+            hits = ctx.seed_search(sp)
+            t1 = time.perf_counter()
+            m, _ = ctx.extend(qd, td, hits, threads=16)
+            t2 = time.perf_counter()
+            _family_truth(m, fam, members, 0.99)
+            aligned[name] = set(m["query"].tolist())
+            out[name] = dict(hits=int(len(hits)), matches=int(len(m)), aligned=len(aligned[name]), seed_ms=(t1 - t0) * 1e3,
+                             seed_kernel_ms=ctx.seed_kernel_ms()[4], extend_ms=(t2 - t1) * 1e3, gapped_filter_ms=ctx.gapped_filter_ms())
+        assert len(aligned["fast"] - aligned["default"]) <= 0.002 * len(aligned["fast"])
+        assert len(aligned["default"] - aligned["sensitive"]) <= 0.002 * len(aligned["default"])
+        assert len(aligned["sensitive"]) > len(aligned["fast"])
+        # C4: 5k reads back-translated from the first 5k queries, six frames each
+        n_reads = 5000
+        dna, off = synth.back_translate(q[:qoff[n_reads]], qoff[:n_reads + 1], seed=5)
+        t0 = time.perf_counter()
+        xd, xl = hip.translated_block(dna, off)
+        t1 = time.perf_counter()
+        ctx.upload_block(hip.QUERY, xd, xl)
+        ctx.set_query_contexts(6)
+        sp, gf = hip.seed_params_preset("default", params, threads=8)
+        sp.query_translated = 1
+        ctx.set_gapped_filter(gf)
+        hits = ctx.seed_search(sp)
+        t2 = time.perf_counter()
+        m, _ = ctx.extend(xd, td, hits, threads=16)
+        t3 = time.perf_counter()
+        _family_truth(m, fam[:n_reads], members, 0.99)
+        assert set(np.unique(m["frame"]).tolist()) <= set(range(6)) and len(np.unique(m["frame"])) == 6      # both strands, all offsets
+        out["blastx"] = dict(reads=n_reads, hits=int(len(hits)), matches=int(len(m)), aligned=len(set(m["query"].tolist())),
+                             translate_host_ms=(t1 - t0) * 1e3, seed_ms=(t2 - t1) * 1e3, seed_kernel_ms=ctx.seed_kernel_ms()[4], extend_ms=(t3 - t2) * 1e3)
+        # the same reads as proteins align to the same top target in (almost) every case
+        assert len(set(m["query"].tolist()) ^ set(x for x in aligned["default"] if x < n_reads)) < 0.05 * n_reads
+    finally:
+        ctx.close()
+    with capsys.disabled():
+        import json
+        print("\\nSCALE_TIMINGS " + json.dumps(out))
