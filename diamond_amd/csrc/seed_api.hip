@@ -226,6 +226,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	std::vector<unsigned long long> counts((size_t)S + 1, 0);
 	std::vector<int64_t> m_off((size_t)S + 1, 0);
 	int64_t cap_total = std::max<int64_t>((int64_t)1 << 22, 4 * nq_pos);
+	if (const char* e = getenv("DMND_SEED_MATCHED_CAP")) cap_total = std::max<int64_t>(1, atoll(e));      // tests: force the overflow/retry path
 	for (int attempt = 0;; ++attempt) {
 		if (int rc = c->matched_slot.ensure((size_t)cap_total * sizeof(uint32_t))) return rc;
 		if (int rc = c->matched_loc.ensure((size_t)cap_total * sizeof(int64_t))) return rc;
@@ -242,7 +243,8 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		int64_t off = 0;
 		for (int sid = 0; sid < S; ++sid) {
 			m_off[sid] = off;
-			SeedArgs a = args_for(sid, cap_total - off, off);
+			// after an overflow the remaining shapes only count (capacity 0): a negative capacity would pass the kernels' unsigned bound test
+			SeedArgs a = args_for(sid, std::max<int64_t>(cap_total - off, 0), std::min(off, cap_total));
 			tm.start();
 			HIP_TRY(launch_seed_index(a, sid, st));
 			c->seed_ms[0] += tm.stop();
@@ -266,6 +268,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	}
 	// phase 2: pair filter per shape; hit buffer grows on overflow
 	int64_t hit_cap = std::max<int64_t>((int64_t)1 << 20, m_off[S]);
+	if (const char* e = getenv("DMND_SEED_HIT_CAP")) hit_cap = std::max<int64_t>(1, atoll(e));
 	for (int attempt = 0;; ++attempt) {
 		if (int rc = c->seed_hits.ensure((size_t)hit_cap * sizeof(dmnd_seed_hit))) return rc;
 		HIP_TRY(hipMemsetAsync(c->counters.as<unsigned long long>() + S, 0, sizeof(unsigned long long), st));

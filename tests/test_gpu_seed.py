@@ -49,6 +49,24 @@ def test_seed_hits_equal_reference(ctx, tap):
     assert (np.diff(hits["query"].astype(np.int64)) >= 0).all()
 
 
+def test_buffer_overflow_retry_paths_are_transparent(ctx, monkeypatch):
+    """Joined-position and hit buffers that are too small (forced through the test hooks) must grow and give the same hits;
+    with several shapes the shapes after the overflowing one run with zero remaining capacity."""
+    cfg, recs = read_ext_tap(os.path.join(GOLDEN, "ext_6x10.tap"))
+    ctx.upload_block(hip.QUERY, cfg["query"]["data"], cfg["query"]["limits"])
+    ctx.upload_block(hip.TARGET, cfg["target"]["data"], cfg["target"]["limits"])
+    want = ctx.seed_search(to_hip_params(cfg))
+    for mcap, hcap in ((1, None), (5000, None), (None, 10), (3000, 100)):
+        if mcap is not None:
+            monkeypatch.setenv("DMND_SEED_MATCHED_CAP", str(mcap))
+        if hcap is not None:
+            monkeypatch.setenv("DMND_SEED_HIT_CAP", str(hcap))
+        got = ctx.seed_search(to_hip_params(cfg))
+        monkeypatch.delenv("DMND_SEED_MATCHED_CAP", raising=False)
+        monkeypatch.delenv("DMND_SEED_HIT_CAP", raising=False)
+        assert np.array_equal(got, want)
+
+
 @pytest.mark.parametrize("chunks,bits", [(1, 8), (3, 9), (7, 10)])
 def test_seed_hits_equal_oracle_other_partitionings(ctx, chunks, bits):
     cfg, _ = read_ext_tap(os.path.join(GOLDEN, "ext_fast_synth.tap"), max_records=1)
