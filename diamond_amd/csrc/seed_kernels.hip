@@ -50,21 +50,37 @@ __global__ void seed_index_kernel(SeedArgs a, int sid)
 	a.next[p - a.q_begin] = prev;
 }
 
+// Wave-aggregated append: the lanes of the wavefront that have an element reserve their slots with ONE atomic on the
+// shared counter (a per-element atomicAdd on one address serialises at the L2 atomic unit: with tens of millions of joined
+// positions per shape that was > 90 % of the seed stage in the sensitive modes). Must be called by every active lane.
+__device__ __forceinline__ unsigned long long wave_append(unsigned long long* counter, bool have)
+{
+	const unsigned long long mask = __ballot(have);
+	if (mask == 0) return 0;
+	const int lane = threadIdx.x & 63, leader = __builtin_ctzll(mask);
+	unsigned long long base = 0;
+	if (lane == leader) base = atomicAdd(counter, (unsigned long long)__builtin_popcountll(mask));
+	base = (unsigned long long)__shfl((long long)base, leader);
+	return base + (unsigned long long)__builtin_popcountll(mask & ((1ull << lane) - 1));
+}
+
 __global__ void seed_stream_kernel(SeedArgs a, int sid)
 {
 	const int64_t p = a.t_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (p >= a.t_end) return;
-	uint64_t seed;
-	if (!seed_at(a.params, sid, a.tdata + p, seed)) return;
-	uint64_t slot = seed_hash(seed) & a.slot_mask;
-	for (;;) {
-		const uint64_t k = a.keys[slot];
-		if (k == SEED_EMPTY) return;
-		if (k == seed) break;
-		slot = (slot + 1) & a.slot_mask;
+	uint64_t seed = 0, slot = 0;
+	bool found = false;
+	if (p < a.t_end && seed_at(a.params, sid, a.tdata + p, seed)) {
+		slot = seed_hash(seed) & a.slot_mask;
+		for (;;) {
+			const uint64_t k = a.keys[slot];
+			if (k == SEED_EMPTY) break;
+			if (k == seed) { found = true; break; }
+			slot = (slot + 1) & a.slot_mask;
+		}
 	}
+	const unsigned long long idx = wave_append(a.matched_count, found);
+	if (!found) return;
 	a.flags[slot] = SLOT_JOINED;                       // benign race: every writer stores the same value
-	const unsigned long long idx = atomicAdd(a.matched_count, 1ull);
 	if (idx < (unsigned long long)a.matched_cap) {
 		a.matched_slot[idx] = (uint32_t)slot;
 		a.matched_loc[idx] = p;
@@ -157,18 +173,19 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 			for (int x = 0; x < 8; ++x) if (x == i) { h_i = hi[x]; l_i = lo[x]; }
 			const uint64_t seed = (uint64_t)h_i * lo_scale + l_i;
 			const uint64_t hh = seed_hash(seed);
-			if (!((a.bitmap[(uint32_t)(hh >> 32) & a.bitmap_mask] >> (uint32_t)(hh >> 59)) & 1u)) continue;
 			uint64_t slot = hh & a.slot_mask;
 			bool found = false;
-			for (;;) {
-				const uint64_t kk = a.keys[slot];
-				if (kk == SEED_EMPTY) break;
-				if (kk == seed) { found = true; break; }
-				slot = (slot + 1) & a.slot_mask;
-			}
+			if ((a.bitmap[(uint32_t)(hh >> 32) & a.bitmap_mask] >> (uint32_t)(hh >> 59)) & 1u)
+				for (;;) {
+					const uint64_t kk = a.keys[slot];
+					if (kk == SEED_EMPTY) break;
+					if (kk == seed) { found = true; break; }
+					slot = (slot + 1) & a.slot_mask;
+				}
+			// the lanes that are in this iteration of the loop reserve their output slots together
+			const unsigned long long idx = wave_append(a.matched_count, found);
 			if (!found) continue;
 			a.flags[slot] = SLOT_JOINED;
-			const unsigned long long idx = atomicAdd(a.matched_count, 1ull);
 			if (idx < (unsigned long long)a.matched_cap) {
 				a.matched_slot[idx] = (uint32_t)slot;
 				a.matched_loc[idx] = p0 + 8 * half + i;
