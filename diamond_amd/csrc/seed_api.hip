@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -289,6 +290,11 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		hit_cap = (int64_t)nh + 1024;
 	}
 	c->seed_ms[4] = c->seed_ms[0] + c->seed_ms[1] + c->seed_ms[2] + c->seed_ms[3];
+	if (getenv("DMND_TRACE")) {
+		std::fprintf(stderr, "dmnd_seed_search: %d shapes, %lld query positions, joined reference positions per shape:", S, (long long)nq_pos);
+		for (int sid = 0; sid < S; ++sid) std::fprintf(stderr, " %llu", counts[sid]);
+		std::fprintf(stderr, " | hits %lld | ms index %.2f stream %.2f mask %.2f pairs %.2f\n", (long long)c->n_seed_hits, c->seed_ms[0], c->seed_ms[1], c->seed_ms[2], c->seed_ms[3]);
+	}
 	*n_hits = c->n_seed_hits;
 	return DMND_OK;
 }
