@@ -185,9 +185,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	if (int rc = c->seed_heads.ensure((size_t)S * slots * sizeof(uint32_t))) return rc;
 	if (int rc = c->seed_flags.ensure((size_t)S * slots)) return rc;
 	if (int rc = c->seed_next.ensure((size_t)S * nq_pos * sizeof(uint32_t))) return rc;
-	if (int rc = c->counters.ensure((size_t)(S + 1) * sizeof(unsigned long long))) return rc;
-	if (int rc = c->seed_sheads.ensure((size_t)S * slots * sizeof(uint32_t))) return rc;
-	HIP_TRY(hipMemsetAsync(c->seed_sheads.p, 0xff, (size_t)S * slots * sizeof(uint32_t), st));
+	if (int rc = c->counters.ensure((size_t)(S + 3) * sizeof(unsigned long long))) return rc;      // [S] hits, [S+1] deferred pairs, [S+2] collected positions
 	HIP_TRY(hipMemsetAsync(c->mask_time.p, SEED_NEVER, (size_t)c->block_len[DMND_QUERY] + 256, st));
 	HIP_TRY(hipMemsetAsync(c->seed_keys.p, 0xff, (size_t)S * slots * sizeof(uint64_t), st));
 	HIP_TRY(hipMemsetAsync(c->seed_heads.p, 0xff, (size_t)S * slots * sizeof(uint32_t), st));
@@ -214,8 +212,8 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		a.matched_loc = c->matched_loc.as<int64_t>() + matched_off;
 		a.matched_count = c->counters.as<unsigned long long>() + sid;
 		a.matched_cap = matched_cap;
-		a.s_heads = c->seed_sheads.as<uint32_t>() + (size_t)sid * slots;
-		a.s_next = c->seed_snext.as<uint32_t>() + matched_off;
+		a.deferred = nullptr; a.deferred_count = c->counters.as<unsigned long long>() + S + 1; a.deferred_cap = 0;
+		a.e_slot = nullptr; a.e_loc = nullptr; a.e_count = c->counters.as<unsigned long long>() + S + 2; a.e_n = 0;
 		a.matrix = c->matrix.as<int8_t>();
 		a.hits = c->seed_hits.as<dmnd_seed_hit>(); a.hit_count = c->counters.as<unsigned long long>() + S; a.hit_cap = 0;
 		return a;
@@ -231,14 +229,12 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	for (int attempt = 0;; ++attempt) {
 		if (int rc = c->matched_slot.ensure((size_t)cap_total * sizeof(uint32_t))) return rc;
 		if (int rc = c->matched_loc.ensure((size_t)cap_total * sizeof(int64_t))) return rc;
-		if (int rc = c->seed_snext.ensure((size_t)cap_total * sizeof(uint32_t))) return rc;
-		HIP_TRY(hipMemsetAsync(c->counters.p, 0, (size_t)(S + 1) * sizeof(unsigned long long), st));
+		HIP_TRY(hipMemsetAsync(c->counters.p, 0, (size_t)(S + 3) * sizeof(unsigned long long), st));
 		if (attempt > 0) {
 			HIP_TRY(hipMemsetAsync(c->seed_keys.p, 0xff, (size_t)S * slots * sizeof(uint64_t), st));
 			HIP_TRY(hipMemsetAsync(c->seed_heads.p, 0xff, (size_t)S * slots * sizeof(uint32_t), st));
 			HIP_TRY(hipMemsetAsync(c->seed_flags.p, 0, (size_t)S * slots, st));
 			HIP_TRY(hipMemsetAsync(c->seed_bitmap.p, 0, bm_total, st));
-			HIP_TRY(hipMemsetAsync(c->seed_sheads.p, 0xff, (size_t)S * slots * sizeof(uint32_t), st));
 		}
 		bool overflow = false;
 		int64_t off = 0;
@@ -267,27 +263,70 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		HIP_TRY(launch_seed_mask(a, sid, st));
 		c->seed_ms[2] += tm.stop();
 	}
-	// phase 2: pair filter per shape; hit buffer grows on overflow
+	// phase 2: pair filter per shape; hit and deferred-pair buffers grow on overflow
 	int64_t hit_cap = std::max<int64_t>((int64_t)1 << 20, m_off[S]);
 	if (const char* e = getenv("DMND_SEED_HIT_CAP")) hit_cap = std::max<int64_t>(1, atoll(e));
+	int64_t def_cap = (int64_t)1 << 18;
+	if (const char* e = getenv("DMND_SEED_DEFERRED_CAP")) def_cap = std::max<int64_t>(1, atoll(e));
+	std::vector<SeedDeferred> h_def;
+	std::vector<uint32_t> h_eslot, perm_slot;
+	std::vector<int64_t> h_eloc, perm_loc;
+	std::vector<int64_t> order;
 	for (int attempt = 0;; ++attempt) {
 		if (int rc = c->seed_hits.ensure((size_t)hit_cap * sizeof(dmnd_seed_hit))) return rc;
+		if (int rc = c->seed_deferred.ensure((size_t)def_cap * sizeof(SeedDeferred))) return rc;
 		HIP_TRY(hipMemsetAsync(c->counters.as<unsigned long long>() + S, 0, sizeof(unsigned long long), st));
 		double ms = 0;
+		bool def_overflow = false;
+		unsigned long long def_max = 0;
 		for (int sid = 0; sid < S; ++sid) {
 			SeedArgs a = args_for(sid, (int64_t)counts[sid], m_off[sid]);
 			a.hits = c->seed_hits.as<dmnd_seed_hit>();
 			a.hit_cap = hit_cap;
+			a.deferred = c->seed_deferred.as<SeedDeferred>(); a.deferred_cap = def_cap;
+			HIP_TRY(hipMemsetAsync(a.deferred_count, 0, 2 * sizeof(unsigned long long), st));
 			tm.start();
 			HIP_TRY(launch_seed_pairs(a, sid, (int64_t)counts[sid], st));
+			ms += tm.stop();
+			if (!sp.use_ungapped) continue;
+			// pairs scoring above 255 (rare): resolve the reference's SIMD-batch saturation rule in a second pass
+			unsigned long long nd = 0;
+			HIP_TRY(hipMemcpy(&nd, a.deferred_count, sizeof(nd), hipMemcpyDeviceToHost));
+			if (nd == 0) continue;
+			def_max = std::max(def_max, nd);
+			if ((int64_t)nd > def_cap) { def_overflow = true; continue; }
+			if (int rc = c->seed_eslot.ensure((size_t)counts[sid] * sizeof(uint32_t))) return rc;
+			if (int rc = c->seed_eloc.ensure((size_t)counts[sid] * sizeof(int64_t))) return rc;
+			a.e_slot = c->seed_eslot.as<uint32_t>(); a.e_loc = c->seed_eloc.as<int64_t>();
+			tm.start();
+			HIP_TRY(launch_seed_collect(a, (int64_t)counts[sid], st));
+			ms += tm.stop();
+			unsigned long long ne = 0;
+			HIP_TRY(hipMemcpy(&ne, a.e_count, sizeof(ne), hipMemcpyDeviceToHost));
+			h_eslot.resize((size_t)ne); h_eloc.resize((size_t)ne);
+			HIP_TRY(hipMemcpy(h_eslot.data(), a.e_slot, (size_t)ne * sizeof(uint32_t), hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(h_eloc.data(), a.e_loc, (size_t)ne * sizeof(int64_t), hipMemcpyDeviceToHost));
+			order.resize((size_t)ne);
+			for (size_t i = 0; i < order.size(); ++i) order[i] = (int64_t)i;
+			std::sort(order.begin(), order.end(), [&](int64_t x, int64_t y) {
+				return h_eslot[(size_t)x] < h_eslot[(size_t)y] || (h_eslot[(size_t)x] == h_eslot[(size_t)y] && h_eloc[(size_t)x] < h_eloc[(size_t)y]);
+			});
+			perm_slot.resize((size_t)ne); perm_loc.resize((size_t)ne);
+			for (size_t i = 0; i < order.size(); ++i) { perm_slot[i] = h_eslot[(size_t)order[i]]; perm_loc[i] = h_eloc[(size_t)order[i]]; }
+			HIP_TRY(hipMemcpy(a.e_slot, perm_slot.data(), (size_t)ne * sizeof(uint32_t), hipMemcpyHostToDevice));
+			HIP_TRY(hipMemcpy(a.e_loc, perm_loc.data(), (size_t)ne * sizeof(int64_t), hipMemcpyHostToDevice));
+			a.e_n = (int64_t)ne;
+			tm.start();
+			HIP_TRY(launch_seed_deferred(a, sid, (int64_t)nd, st));
 			ms += tm.stop();
 		}
 		unsigned long long nh = 0;
 		HIP_TRY(hipMemcpy(&nh, c->counters.as<unsigned long long>() + S, sizeof(nh), hipMemcpyDeviceToHost));
 		c->seed_ms[3] = ms;
-		if ((int64_t)nh <= hit_cap) { c->n_seed_hits = (int64_t)nh; break; }
-		if (attempt >= 2) return fail(DMND_E_NOMEM, "dmnd_seed_search: hit buffer overflow");
-		hit_cap = (int64_t)nh + 1024;
+		if ((int64_t)nh <= hit_cap && !def_overflow) { c->n_seed_hits = (int64_t)nh; break; }
+		if (attempt >= 3) return fail(DMND_E_NOMEM, "dmnd_seed_search: hit buffer overflow");
+		if ((int64_t)nh > hit_cap) hit_cap = (int64_t)nh + 1024;
+		if (def_overflow) def_cap = (int64_t)def_max + 1024;
 	}
 	c->seed_ms[4] = c->seed_ms[0] + c->seed_ms[1] + c->seed_ms[2] + c->seed_ms[3];
 	if (getenv("DMND_TRACE")) {

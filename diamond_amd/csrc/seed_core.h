@@ -277,43 +277,24 @@ DMND_HD int ungapped_cutoff(const SeedParams& c, int query_len)
 	return c.cutoff_table[b];
 }
 
-// Linked list of the reference positions joined to one query seed (entries of the stream kernel's match arrays)
-struct SList { const int64_t* loc; const uint32_t* next; uint32_t head; };
-
 // The reference scores Hamming survivors in SIMD batches (search_query_offset, stage2.h:74-154): per subject tile
 // of `tile_size` joined positions (ascending position order), survivors are taken `simd_lanes` at a time, and a
 // batch of >= 4 runs the int8 kernel whose scores saturate at 255 (ungapped_simd.cpp:69-87) while smaller batches
-// run the scalar one. Returns the size of the batch the pair (q, sloc) lands in. Order-free restatement: the tile
-// is found by rank of sloc among the seed's joined positions, the batch by rank among the tile's survivors.
-// Only needed when the exact score exceeds 255 (rare), so the O(list) walks are off the common path.
-DMND_HD int simd_batch_size(const SeedParams& c, const SList& l, const int8_t* tdata, const int8_t* q, int64_t sloc)
+// run the scalar one. Returns the size of the batch the pair (q, sloc) lands in. Order-free restatement over the seed's
+// joined reference positions in ascending order (locs[0..n)): the tile is found by the rank of sloc, the batch by the
+// rank among the tile's Hamming survivors. Only needed when the exact score exceeds 255 (rare): such pairs are deferred
+// by the pair kernel and resolved in a second pass over a sorted copy of the joined positions of the seeds concerned.
+DMND_HD int simd_batch_size_sorted(const SeedParams& c, const int64_t* locs, int64_t n, const int8_t* tdata, const int8_t* q, int64_t sloc)
 {
-	int64_t n_all = 0, rank = 0;
-	for (uint32_t i = l.head; i != 0xffffffffu; i = l.next[i]) { ++n_all; rank += l.loc[i] < sloc; }
-	int64_t lo_loc = INT64_MIN, hi_loc = INT64_MAX;              // tile = joined positions with lo_loc <= loc < hi_loc
-	const int64_t T = c.tile_size;
-	if (T > 0 && n_all > T) {
-		const int64_t t_lo = rank / T * T, t_hi = t_lo + T;
-		// loc of the element with rank `want` (exactly `want` smaller elements): bisect on the value
-		for (int k = 0; k < 2; ++k) {
-			const int64_t want = k == 0 ? t_lo : t_hi;
-			if (want <= 0 || want >= n_all) continue;
-			int64_t a = 0, b = INT64_MAX;                            // smallest x with count(loc <= x) >= want + 1
-			while (a < b) {
-				const int64_t mid = a + (b - a) / 2;
-				int64_t cnt = 0;
-				for (uint32_t i = l.head; i != 0xffffffffu; i = l.next[i]) cnt += l.loc[i] <= mid;
-				if (cnt >= want + 1) b = mid; else a = mid + 1;
-			}
-			if (k == 0) lo_loc = a; else hi_loc = a;
-		}
-	}
+	int64_t lo = 0, hi = n;                                       // rank = number of positions < sloc
+	while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (locs[mid] < sloc) lo = mid + 1; else hi = mid; }
+	const int64_t rank = lo, T = c.tile_size;
+	int64_t t_lo = 0, t_hi = n;
+	if (T > 0 && n > T) { t_lo = rank / T * T; t_hi = t_lo + T < n ? t_lo + T : n; }
 	int64_t L = 0, r = 0;
-	for (uint32_t i = l.head; i != 0xffffffffu; i = l.next[i]) {
-		const int64_t x = l.loc[i];
-		if (x < lo_loc || x >= hi_loc) continue;
-		if (fingerprint_id(q, tdata + x) < c.hamming_filter_id) continue;
-		++L; r += x < sloc;
+	for (int64_t k = t_lo; k < t_hi; ++k) {
+		if (fingerprint_id(q, tdata + locs[k]) < c.hamming_filter_id) continue;
+		++L; r += k < rank;
 	}
 	const int64_t lanes = c.simd_lanes, left = L - r / lanes * lanes;
 	return (int)(left < lanes ? left : lanes);

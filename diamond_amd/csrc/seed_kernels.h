@@ -9,7 +9,11 @@ namespace dmnd {
 
 static const uint64_t SEED_EMPTY = ~0ull;
 static const uint32_t LIST_END = 0xffffffffu;
-enum { SLOT_FREE = 0, SLOT_JOINED = 1, SLOT_ERASED = 2 };
+enum { SLOT_FREE = 0, SLOT_JOINED = 1, SLOT_ERASED = 2, SLOT_NEED = 4 };      // NEED: the seed has a deferred pair (score > 255)
+
+// A (joined reference position, query position) pair whose stage-2 score exceeds 255: whether it saturates depends on the
+// reference's SIMD batch it would have been scored in (simd_batch_size_sorted), resolved in a second pass.
+struct SeedDeferred { int64_t m; uint32_t x; int32_t score; };
 
 struct SeedArgs {
 	SeedParams params;
@@ -28,7 +32,9 @@ struct SeedArgs {
 	uint32_t* bitmap; uint32_t bitmap_mask;
 	// joined reference positions of this shape
 	uint32_t* matched_slot; int64_t* matched_loc; unsigned long long* matched_count; int64_t matched_cap;
-	uint32_t* s_heads; uint32_t* s_next;          // per slot: linked list of its joined reference positions (entries of matched_*)
+	SeedDeferred* deferred; unsigned long long* deferred_count; int64_t deferred_cap;
+	// joined positions of the seeds flagged SLOT_NEED, sorted by (slot, position) for the second pass
+	uint32_t* e_slot; int64_t* e_loc; unsigned long long* e_count; int64_t e_n;
 	const int8_t* matrix;                         // 32x32 int8 substitution matrix (HBM) for the stage-2 ungapped window score
 	// output
 	dmnd_seed_hit* hits; unsigned long long* hit_count; int64_t hit_cap;
@@ -39,5 +45,7 @@ hipError_t launch_seed_index(const SeedArgs& a, int sid, hipStream_t st);
 hipError_t launch_seed_stream(const SeedArgs& a, int sid, hipStream_t st);
 hipError_t launch_seed_mask(const SeedArgs& a, int sid, hipStream_t st);
 hipError_t launch_seed_pairs(const SeedArgs& a, int sid, int64_t n_matched, hipStream_t st);
+hipError_t launch_seed_collect(const SeedArgs& a, int64_t n_matched, hipStream_t st);
+hipError_t launch_seed_deferred(const SeedArgs& a, int sid, int64_t n_deferred, hipStream_t st);
 
 }  // namespace dmnd

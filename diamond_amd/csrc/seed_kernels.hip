@@ -84,7 +84,6 @@ __global__ void seed_stream_kernel(SeedArgs a, int sid)
 	if (idx < (unsigned long long)a.matched_cap) {
 		a.matched_slot[idx] = (uint32_t)slot;
 		a.matched_loc[idx] = p;
-		a.s_next[idx] = atomicExch(&a.s_heads[slot], (uint32_t)idx);
 	}
 }
 
@@ -189,8 +188,7 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 			if (idx < (unsigned long long)a.matched_cap) {
 				a.matched_slot[idx] = (uint32_t)slot;
 				a.matched_loc[idx] = p0 + 8 * half + i;
-				a.s_next[idx] = atomicExch(&a.s_heads[slot], (uint32_t)idx);
-			}
+					}
 		}
 	}
 }
@@ -213,12 +211,25 @@ __global__ void seed_mask_kernel(SeedArgs a, int sid)
 	}
 }
 
+// left-most rule + emission of one pair that passed the Hamming and ungapped-score filters
+__device__ __forceinline__ void finish_pair(const SeedArgs& a, int sid, int chunk, int64_t qp, const int8_t* q, const int8_t* s,
+	uint32_t qid, int seed_offset, int query_len, int64_t sloc, int score)
+{
+	if (!left_most_pair(a.params, q, a.mask_time + qp, s, seed_offset, sid, chunk, query_len)) return;
+	const unsigned long long idx = atomicAdd(a.hit_count, 1ull);
+	if (idx < (unsigned long long)a.hit_cap) {
+		dmnd_seed_hit h;
+		h.query = qid; h.seed_offset = seed_offset; h.subject = sloc; h.score = score; h.pad = 0;
+		a.hits[idx] = h;
+	}
+}
+
 __global__ void seed_pair_kernel(SeedArgs a, int sid, int64_t n_matched)
 {
 	const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (m >= n_matched) return;
 	const uint32_t slot = a.matched_slot[m];
-	if (a.flags[slot] == SLOT_ERASED) return;
+	if (a.flags[slot] & SLOT_ERASED) return;
 	const int64_t sloc = a.matched_loc[m];
 	const int chunk = seed_chunk(a.params, a.keys[slot]);
 	const int8_t* s = a.tdata + sloc;
@@ -240,20 +251,52 @@ __global__ void seed_pair_kernel(SeedArgs a, int sid, int64_t n_matched)
 				const int window_left = window - cb;
 				score = ungapped_window_score(a.matrix, q - window_left, s - window_left, ce - cb);
 				if (score > 255) {
-					const SList l{ a.matched_loc, a.s_next, a.s_heads[slot] };
-					if (simd_batch_size(a.params, l, a.tdata, q, sloc) >= 4) score = 255;
+					// saturation depends on the SIMD batch of the reference: second pass (seed_deferred_kernel)
+					const unsigned long long d = atomicAdd(a.deferred_count, 1ull);
+					if (d < (unsigned long long)a.deferred_cap) a.deferred[d] = SeedDeferred{ m, x, score };
+					a.flags[slot] = SLOT_JOINED | SLOT_NEED;          // benign race: every writer stores the same value
+					continue;
 				}
 				if (score <= cutoff) continue;
 			}
 		}
-		if (!left_most_pair(a.params, q, a.mask_time + qp, s, seed_offset, sid, chunk, query_len)) continue;
-		const unsigned long long idx = atomicAdd(a.hit_count, 1ull);
-		if (idx < (unsigned long long)a.hit_cap) {
-			dmnd_seed_hit h;
-			h.query = qid; h.seed_offset = seed_offset; h.subject = sloc; h.score = score; h.pad = 0;
-			a.hits[idx] = h;
-		}
+		finish_pair(a, sid, chunk, qp, q, s, qid, seed_offset, query_len, sloc, score);
 	}
+}
+
+// copies the joined positions of the seeds that have deferred pairs (unsorted; the host sorts by (slot, position))
+__global__ void seed_collect_kernel(SeedArgs a, int64_t n_matched)
+{
+	const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	bool have = false;
+	uint32_t slot = 0;
+	if (m < n_matched) { slot = a.matched_slot[m]; have = (a.flags[slot] & SLOT_NEED) != 0; }
+	const unsigned long long idx = wave_append(a.e_count, have);
+	if (have) { a.e_slot[idx] = slot; a.e_loc[idx] = a.matched_loc[m]; }
+}
+
+__global__ void seed_deferred_kernel(SeedArgs a, int sid, int64_t n_deferred)
+{
+	const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (d >= n_deferred) return;
+	const SeedDeferred r = a.deferred[d];
+	const uint32_t slot = a.matched_slot[r.m];
+	const int64_t sloc = a.matched_loc[r.m];
+	// the seed's joined positions: range of `slot` in the sorted copy
+	int64_t lo = 0, hi = a.e_n;
+	while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (a.e_slot[mid] < slot) lo = mid + 1; else hi = mid; }
+	const int64_t b = lo;
+	hi = a.e_n;
+	while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (a.e_slot[mid] <= slot) lo = mid + 1; else hi = mid; }
+	const int64_t qp = a.q_begin + r.x;
+	const int8_t* q = a.qdata + qp;
+	const int8_t* s = a.tdata + sloc;
+	int score = r.score;
+	if (simd_batch_size_sorted(a.params, a.e_loc + b, lo - b, a.tdata, q, sloc) >= 4) score = 255;
+	const uint32_t qid = a.qid_of[qp];
+	const int query_len = (int)(a.qlimits[qid + 1] - a.qlimits[qid] - 1);
+	if (score <= ungapped_cutoff(a.params, query_len)) return;
+	finish_pair(a, sid, seed_chunk(a.params, a.keys[slot]), qp, q, s, qid, (int)(qp - a.qlimits[qid]), query_len, sloc, score);
 }
 
 static unsigned blocks_for(int64_t n, int threads) { return (unsigned)((n + threads - 1) / threads); }
@@ -309,6 +352,20 @@ hipError_t launch_seed_pairs(const SeedArgs& a, int sid, int64_t n_matched, hipS
 {
 	if (n_matched == 0) return hipSuccess;
 	hipLaunchKernelGGL(seed_pair_kernel, dim3(blocks_for(n_matched, 128)), dim3(128), 0, st, a, sid, n_matched);
+	return hipGetLastError();
+}
+
+hipError_t launch_seed_collect(const SeedArgs& a, int64_t n_matched, hipStream_t st)
+{
+	if (n_matched == 0) return hipSuccess;
+	hipLaunchKernelGGL(seed_collect_kernel, dim3(blocks_for(n_matched, 256)), dim3(256), 0, st, a, n_matched);
+	return hipGetLastError();
+}
+
+hipError_t launch_seed_deferred(const SeedArgs& a, int sid, int64_t n_deferred, hipStream_t st)
+{
+	if (n_deferred == 0) return hipSuccess;
+	hipLaunchKernelGGL(seed_deferred_kernel, dim3(blocks_for(n_deferred, 64)), dim3(64), 0, st, a, sid, n_deferred);
 	return hipGetLastError();
 }
 

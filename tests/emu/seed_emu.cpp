@@ -4,6 +4,8 @@
 // per-letter mask times, then filter every (query, reference) pair independently. Checks on the CPU that the
 // order-free formulation reproduces the reference's sequential index-chunk semantics. Never used by the product.
 #include <algorithm>
+#include <climits>
+#include <cstdint>
 #include <unordered_map>
 #include <vector>
 #include "../../diamond_amd/csrc/seed_core.h"
@@ -21,9 +23,7 @@ extern "C" int64_t emu_seed_search(const SeedParams* cp, const int8_t* matrix, c
 	std::vector<uint32_t> qid_of((size_t)qraw, 0);
 	for (int64_t i = 0; i < nq; ++i)
 		for (int64_t p = qlimits[i]; p < qlimits[i + 1]; ++p) qid_of[(size_t)p] = (uint32_t)i;
-	struct Group { std::vector<int64_t> q; bool present = false, erased = false; uint32_t s_head = 0xffffffffu; };
-	std::vector<std::vector<int64_t>> m_loc(c.n_shapes);       // matched_loc / s_next exactly as the stream kernel builds them
-	std::vector<std::vector<uint32_t>> m_next(c.n_shapes);
+	struct Group { std::vector<int64_t> q; bool present = false, erased = false, need = false; };
 	std::vector<std::unordered_map<uint64_t, Group>> tables(c.n_shapes);
 	std::vector<std::vector<std::pair<uint64_t, int64_t>>> matched(c.n_shapes);
 	// phase 1: index queries, stream the reference, complexity masks -- for every shape
@@ -40,9 +40,6 @@ extern "C" int64_t emu_seed_search(const SeedParams* cp, const int8_t* matrix, c
 			if (it == tab.end()) continue;
 			it->second.present = true;
 			matched[sid].push_back({ s, p });
-			m_loc[sid].push_back(p);
-			m_next[sid].push_back(it->second.s_head);            // atomicExch(&s_heads[slot], idx)
-			it->second.s_head = (uint32_t)(m_loc[sid].size() - 1);
 		}
 		for (auto& kv : tab) {
 			Group& g = kv.second;
@@ -55,11 +52,14 @@ extern "C" int64_t emu_seed_search(const SeedParams* cp, const int8_t* matrix, c
 			}
 		}
 	}
-	// phase 2: every joined pair independently
+	// phase 2: every joined pair independently; pairs scoring above 255 are deferred (seed_pair_kernel)
+	struct Deferred { size_t m; int64_t qp; int score; };
 	int64_t n = 0;
-	for (int sid = 0; sid < c.n_shapes; ++sid)
-		for (const auto& m : matched[sid]) {
-			const Group& g = tables[sid][m.first];
+	for (int sid = 0; sid < c.n_shapes; ++sid) {
+		std::vector<Deferred> deferred;
+		for (size_t mi = 0; mi < matched[sid].size(); ++mi) {
+			const auto& m = matched[sid][mi];
+			Group& g = tables[sid][m.first];
 			if (g.erased) continue;
 			const int chunk = seed_chunk(c, m.first);
 			for (int64_t qp : g.q) {
@@ -76,10 +76,7 @@ extern "C" int64_t emu_seed_search(const SeedParams* cp, const int8_t* matrix, c
 						clip_window(qdata + qp - window, 2 * window, window, cb, ce);
 						const int window_left = window - cb;
 						score = ungapped_window_score(matrix, qdata + qp - window_left, tdata + m.second - window_left, ce - cb);
-						if (score > 255) {
-							const SList l{ m_loc[sid].data(), m_next[sid].data(), g.s_head };
-							if (simd_batch_size(c, l, tdata, qdata + qp, m.second) >= 4) score = 255;
-						}
+						if (score > 255) { deferred.push_back(Deferred{ mi, qp, score }); g.need = true; continue; }
 						if (score <= cutoff) continue;
 					}
 				}
@@ -88,5 +85,28 @@ extern "C" int64_t emu_seed_search(const SeedParams* cp, const int8_t* matrix, c
 				hits[n++] = EmuHit{ qid, seed_offset, m.second, score, 0 };
 			}
 		}
+		if (deferred.empty()) continue;
+		// seed_collect_kernel + host sort: joined positions of the flagged seeds, ordered by (seed, position)
+		std::vector<std::pair<uint64_t, int64_t>> e;
+		for (const auto& m : matched[sid]) if (tables[sid][m.first].need) e.push_back(m);
+		std::sort(e.begin(), e.end());
+		std::vector<int64_t> e_loc(e.size());
+		for (size_t i = 0; i < e.size(); ++i) e_loc[i] = e[i].second;
+		// seed_deferred_kernel
+		for (const Deferred& d : deferred) {
+			const auto& m = matched[sid][d.m];
+			const size_t b = (size_t)(std::lower_bound(e.begin(), e.end(), std::make_pair(m.first, (int64_t)INT64_MIN)) - e.begin());
+			const size_t en = (size_t)(std::upper_bound(e.begin(), e.end(), std::make_pair(m.first, (int64_t)INT64_MAX)) - e.begin());
+			int score = d.score;
+			if (simd_batch_size_sorted(c, e_loc.data() + b, (int64_t)(en - b), tdata, qdata + d.qp, m.second) >= 4) score = 255;
+			const uint32_t qid = qid_of[(size_t)d.qp];
+			const int seed_offset = (int)(d.qp - qlimits[qid]);
+			const int query_len = (int)(qlimits[qid + 1] - qlimits[qid] - 1);
+			if (score <= ungapped_cutoff(c, query_len)) continue;
+			if (!left_most_pair(c, qdata + d.qp, mask_time.data() + d.qp, tdata + m.second, seed_offset, sid, seed_chunk(c, m.first), query_len)) continue;
+			if (n >= cap) return -1;
+			hits[n++] = EmuHit{ qid, seed_offset, m.second, score, 0 };
+		}
+	}
 	return n;
 }

@@ -65,6 +65,18 @@ def test_buffer_overflow_retry_paths_are_transparent(ctx, monkeypatch):
         monkeypatch.delenv("DMND_SEED_MATCHED_CAP", raising=False)
         monkeypatch.delenv("DMND_SEED_HIT_CAP", raising=False)
         assert np.array_equal(got, want)
+    # default sensitivity: the buffer of deferred pairs (stage-2 scores above 255, resolved in a second pass) overflows too
+    cfg, recs = read_ext_tap(os.path.join(GOLDEN, "ext_default.tap"))
+    ctx.upload_block(hip.QUERY, cfg["query"]["data"], cfg["query"]["limits"])
+    ctx.upload_block(hip.TARGET, cfg["target"]["data"], cfg["target"]["limits"])
+    want = ctx.seed_search(to_hip_params(cfg))
+    assert (want["score"] > 255).any() and (want["score"] == 255).any()
+    monkeypatch.setenv("DMND_SEED_DEFERRED_CAP", "7")
+    monkeypatch.setenv("DMND_SEED_HIT_CAP", "50")
+    got = ctx.seed_search(to_hip_params(cfg))
+    monkeypatch.delenv("DMND_SEED_DEFERRED_CAP")
+    monkeypatch.delenv("DMND_SEED_HIT_CAP")
+    assert np.array_equal(got, want)
 
 
 @pytest.mark.parametrize("chunks,bits", [(1, 8), (3, 9), (7, 10)])
