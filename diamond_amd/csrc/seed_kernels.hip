@@ -102,8 +102,19 @@ __device__ __forceinline__ uint32_t reduce4(uint32_t letter, uint64_t map_lo, ui
 template<bool RADIX10>
 __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int sid, uint64_t map_lo, uint64_t map_hi, int64_t base, int lo_digits, uint32_t lo_scale)
 {
+	// Joined positions are staged in LDS and flushed with ONE atomic on the shared counter per workgroup: an atomicAdd per
+	// match on a single address serialises at ~4.5 ns each (measured: 3.3 M matches = 14.8 ms per shape in default mode,
+	// 22 M = 98 ms per shape in --sensitive), which dwarfed the 1.6 ms stream itself.
+	constexpr unsigned STAGE = 1024;
+	__shared__ uint32_t st_slot[STAGE];
+	__shared__ int64_t st_loc[STAGE];
+	__shared__ unsigned st_n;
+	__shared__ unsigned long long st_base;
+	if (threadIdx.x == 0) st_n = 0;
+	__syncthreads();
 	const int64_t p0 = base + ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
-	if (p0 >= a.t_end) return;
+	const bool in_range = p0 < a.t_end;
+	if (in_range) {
 	const uint4 v0 = *reinterpret_cast<const uint4*>(a.tdata + p0);
 	const uint4 v1 = *reinterpret_cast<const uint4*>(a.tdata + p0 + 16);
 	const uint32_t w[8] = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };
@@ -181,15 +192,25 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 					if (kk == seed) { found = true; break; }
 					slot = (slot + 1) & a.slot_mask;
 				}
-			// the lanes that are in this iteration of the loop reserve their output slots together
-			const unsigned long long idx = wave_append(a.matched_count, found);
 			if (!found) continue;
 			a.flags[slot] = SLOT_JOINED;
-			if (idx < (unsigned long long)a.matched_cap) {
-				a.matched_slot[idx] = (uint32_t)slot;
-				a.matched_loc[idx] = p0 + 8 * half + i;
-					}
+			const unsigned k = atomicAdd(&st_n, 1u);                 // LDS atomic
+			if (k < STAGE) { st_slot[k] = (uint32_t)slot; st_loc[k] = p0 + 8 * half + i; }
+			else {                                                    // staging area full (dense matches): direct append
+				const unsigned long long idx = atomicAdd(a.matched_count, 1ull);
+				if (idx < (unsigned long long)a.matched_cap) { a.matched_slot[idx] = (uint32_t)slot; a.matched_loc[idx] = p0 + 8 * half + i; }
+			}
 		}
+	}
+	}
+	__syncthreads();
+	const unsigned n_staged = st_n < STAGE ? st_n : STAGE;
+	if (n_staged == 0) return;
+	if (threadIdx.x == 0) st_base = atomicAdd(a.matched_count, (unsigned long long)n_staged);
+	__syncthreads();
+	for (unsigned k = threadIdx.x; k < n_staged; k += blockDim.x) {
+		const unsigned long long idx = st_base + k;
+		if (idx < (unsigned long long)a.matched_cap) { a.matched_slot[idx] = st_slot[k]; a.matched_loc[idx] = st_loc[k]; }
 	}
 }
 
