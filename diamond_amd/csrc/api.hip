@@ -101,6 +101,7 @@ extern "C" dmnd_ctx* dmnd_create(int device, const dmnd_params* params)
 
 extern "C" void dmnd_destroy(dmnd_ctx* c)
 {
+	if (c && c->sort_tmp) { (void)hipFree(c->sort_tmp); c->sort_tmp = nullptr; c->sort_tmp_bytes = 0; }
 	if (!c) return;
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);

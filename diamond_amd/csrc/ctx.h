@@ -45,6 +45,7 @@ struct dmnd_ctx {
 	size_t trace_arena_max = (size_t)8 << 30;
 	// seed-stage buffers (seed_api.hip)
 	dmnd::DevBuf qid_of, mask_time, seed_keys, seed_heads, seed_next, seed_flags, matched_slot, matched_loc, counters, seed_hits, seed_bitmap, seed_deferred, seed_eslot, seed_eloc;
+	void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0;      // rocPRIM radix sort scratch
 	int64_t n_seed_hits = 0;
 	// gapped filter (gapped_api.hip)
 	dmnd::DevBuf gf_tables, gf_hits, gf_flags, gf_scores;

@@ -213,7 +213,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		a.matched_count = c->counters.as<unsigned long long>() + sid;
 		a.matched_cap = matched_cap;
 		a.deferred = nullptr; a.deferred_count = c->counters.as<unsigned long long>() + S + 1; a.deferred_cap = 0;
-		a.e_slot = nullptr; a.e_loc = nullptr; a.e_count = c->counters.as<unsigned long long>() + S + 2; a.e_n = 0;
+		a.e_key = nullptr; a.e_count = c->counters.as<unsigned long long>() + S + 2; a.e_n = 0;
 		a.matrix = c->matrix.as<int8_t>();
 		a.hits = c->seed_hits.as<dmnd_seed_hit>(); a.hit_count = c->counters.as<unsigned long long>() + S; a.hit_cap = 0;
 		return a;
@@ -268,10 +268,6 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	if (const char* e = getenv("DMND_SEED_HIT_CAP")) hit_cap = std::max<int64_t>(1, atoll(e));
 	int64_t def_cap = (int64_t)1 << 18;
 	if (const char* e = getenv("DMND_SEED_DEFERRED_CAP")) def_cap = std::max<int64_t>(1, atoll(e));
-	std::vector<SeedDeferred> h_def;
-	std::vector<uint32_t> h_eslot, perm_slot;
-	std::vector<int64_t> h_eloc, perm_loc;
-	std::vector<int64_t> order;
 	for (int attempt = 0;; ++attempt) {
 		if (int rc = c->seed_hits.ensure((size_t)hit_cap * sizeof(dmnd_seed_hit))) return rc;
 		if (int rc = c->seed_deferred.ensure((size_t)def_cap * sizeof(SeedDeferred))) return rc;
@@ -295,28 +291,17 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 			if (nd == 0) continue;
 			def_max = std::max(def_max, nd);
 			if ((int64_t)nd > def_cap) { def_overflow = true; continue; }
-			if (int rc = c->seed_eslot.ensure((size_t)counts[sid] * sizeof(uint32_t))) return rc;
-			if (int rc = c->seed_eloc.ensure((size_t)counts[sid] * sizeof(int64_t))) return rc;
-			a.e_slot = c->seed_eslot.as<uint32_t>(); a.e_loc = c->seed_eloc.as<int64_t>();
+			if (int rc = c->seed_eslot.ensure((size_t)counts[sid] * sizeof(uint64_t))) return rc;      // unsorted keys
+			if (int rc = c->seed_eloc.ensure((size_t)counts[sid] * sizeof(uint64_t))) return rc;       // sorted keys
+			a.e_key = c->seed_eslot.as<uint64_t>();
 			tm.start();
 			HIP_TRY(launch_seed_collect(a, (int64_t)counts[sid], st));
-			ms += tm.stop();
 			unsigned long long ne = 0;
-			HIP_TRY(hipMemcpy(&ne, a.e_count, sizeof(ne), hipMemcpyDeviceToHost));
-			h_eslot.resize((size_t)ne); h_eloc.resize((size_t)ne);
-			HIP_TRY(hipMemcpy(h_eslot.data(), a.e_slot, (size_t)ne * sizeof(uint32_t), hipMemcpyDeviceToHost));
-			HIP_TRY(hipMemcpy(h_eloc.data(), a.e_loc, (size_t)ne * sizeof(int64_t), hipMemcpyDeviceToHost));
-			order.resize((size_t)ne);
-			for (size_t i = 0; i < order.size(); ++i) order[i] = (int64_t)i;
-			std::sort(order.begin(), order.end(), [&](int64_t x, int64_t y) {
-				return h_eslot[(size_t)x] < h_eslot[(size_t)y] || (h_eslot[(size_t)x] == h_eslot[(size_t)y] && h_eloc[(size_t)x] < h_eloc[(size_t)y]);
-			});
-			perm_slot.resize((size_t)ne); perm_loc.resize((size_t)ne);
-			for (size_t i = 0; i < order.size(); ++i) { perm_slot[i] = h_eslot[(size_t)order[i]]; perm_loc[i] = h_eloc[(size_t)order[i]]; }
-			HIP_TRY(hipMemcpy(a.e_slot, perm_slot.data(), (size_t)ne * sizeof(uint32_t), hipMemcpyHostToDevice));
-			HIP_TRY(hipMemcpy(a.e_loc, perm_loc.data(), (size_t)ne * sizeof(int64_t), hipMemcpyHostToDevice));
+			HIP_TRY(hipMemcpyAsync(&ne, a.e_count, sizeof(ne), hipMemcpyDeviceToHost, st));
+			HIP_TRY(hipStreamSynchronize(st));
+			HIP_TRY(sort_keys_u64(c->seed_eslot.as<uint64_t>(), c->seed_eloc.as<uint64_t>(), (int64_t)ne, &c->sort_tmp, &c->sort_tmp_bytes, st));
+			a.e_key = c->seed_eloc.as<uint64_t>();
 			a.e_n = (int64_t)ne;
-			tm.start();
 			HIP_TRY(launch_seed_deferred(a, sid, (int64_t)nd, st));
 			ms += tm.stop();
 		}

@@ -284,16 +284,18 @@ DMND_HD int ungapped_cutoff(const SeedParams& c, int query_len)
 // joined reference positions in ascending order (locs[0..n)): the tile is found by the rank of sloc, the batch by the
 // rank among the tile's Hamming survivors. Only needed when the exact score exceeds 255 (rare): such pairs are deferred
 // by the pair kernel and resolved in a second pass over a sorted copy of the joined positions of the seeds concerned.
-DMND_HD int simd_batch_size_sorted(const SeedParams& c, const int64_t* locs, int64_t n, const int8_t* tdata, const int8_t* q, int64_t sloc)
+// locs[k] holds the position in its low 40 bits (the sort key of the second pass is seed slot << 40 | position).
+DMND_HD int simd_batch_size_sorted(const SeedParams& c, const uint64_t* locs, int64_t n, const int8_t* tdata, const int8_t* q, int64_t sloc)
 {
+	const uint64_t LOC = ((uint64_t)1 << 40) - 1;
 	int64_t lo = 0, hi = n;                                       // rank = number of positions < sloc
-	while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (locs[mid] < sloc) lo = mid + 1; else hi = mid; }
+	while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((int64_t)(locs[mid] & LOC) < sloc) lo = mid + 1; else hi = mid; }
 	const int64_t rank = lo, T = c.tile_size;
 	int64_t t_lo = 0, t_hi = n;
 	if (T > 0 && n > T) { t_lo = rank / T * T; t_hi = t_lo + T < n ? t_lo + T : n; }
 	int64_t L = 0, r = 0;
 	for (int64_t k = t_lo; k < t_hi; ++k) {
-		if (fingerprint_id(q, tdata + locs[k]) < c.hamming_filter_id) continue;
+		if (fingerprint_id(q, tdata + (int64_t)(locs[k] & LOC)) < c.hamming_filter_id) continue;
 		++L; r += k < rank;
 	}
 	const int64_t lanes = c.simd_lanes, left = L - r / lanes * lanes;

@@ -34,7 +34,7 @@ struct SeedArgs {
 	uint32_t* matched_slot; int64_t* matched_loc; unsigned long long* matched_count; int64_t matched_cap;
 	SeedDeferred* deferred; unsigned long long* deferred_count; int64_t deferred_cap;
 	// joined positions of the seeds flagged SLOT_NEED, sorted by (slot, position) for the second pass
-	uint32_t* e_slot; int64_t* e_loc; unsigned long long* e_count; int64_t e_n;
+	uint64_t* e_key; unsigned long long* e_count; int64_t e_n;     // key = slot << 40 | position
 	const int8_t* matrix;                         // 32x32 int8 substitution matrix (HBM) for the stage-2 ungapped window score
 	// output
 	dmnd_seed_hit* hits; unsigned long long* hit_count; int64_t hit_cap;
@@ -47,5 +47,7 @@ hipError_t launch_seed_mask(const SeedArgs& a, int sid, hipStream_t st);
 hipError_t launch_seed_pairs(const SeedArgs& a, int sid, int64_t n_matched, hipStream_t st);
 hipError_t launch_seed_collect(const SeedArgs& a, int64_t n_matched, hipStream_t st);
 hipError_t launch_seed_deferred(const SeedArgs& a, int sid, int64_t n_deferred, hipStream_t st);
+// ascending device sort of n 64-bit keys (rocPRIM radix sort); tmp is grown as needed
+hipError_t sort_keys_u64(const uint64_t* in, uint64_t* out, int64_t n, void** tmp, size_t* tmp_bytes, hipStream_t st);
 
 }  // namespace dmnd

@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "seed_core.h"
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
 #include "seed_kernels.h"
 
 namespace dmnd {
@@ -285,7 +287,7 @@ __global__ void seed_pair_kernel(SeedArgs a, int sid, int64_t n_matched)
 	}
 }
 
-// copies the joined positions of the seeds that have deferred pairs (unsorted; the host sorts by (slot, position))
+// copies the joined positions of the seeds that have deferred pairs as sort keys slot << 40 | position
 __global__ void seed_collect_kernel(SeedArgs a, int64_t n_matched)
 {
 	const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -293,7 +295,7 @@ __global__ void seed_collect_kernel(SeedArgs a, int64_t n_matched)
 	uint32_t slot = 0;
 	if (m < n_matched) { slot = a.matched_slot[m]; have = (a.flags[slot] & SLOT_NEED) != 0; }
 	const unsigned long long idx = wave_append(a.e_count, have);
-	if (have) { a.e_slot[idx] = slot; a.e_loc[idx] = a.matched_loc[m]; }
+	if (have) a.e_key[idx] = ((uint64_t)slot << 40) | (uint64_t)a.matched_loc[m];
 }
 
 __global__ void seed_deferred_kernel(SeedArgs a, int sid, int64_t n_deferred)
@@ -305,15 +307,15 @@ __global__ void seed_deferred_kernel(SeedArgs a, int sid, int64_t n_deferred)
 	const int64_t sloc = a.matched_loc[r.m];
 	// the seed's joined positions: range of `slot` in the sorted copy
 	int64_t lo = 0, hi = a.e_n;
-	while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (a.e_slot[mid] < slot) lo = mid + 1; else hi = mid; }
+	while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((uint32_t)(a.e_key[mid] >> 40) < slot) lo = mid + 1; else hi = mid; }
 	const int64_t b = lo;
 	hi = a.e_n;
-	while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (a.e_slot[mid] <= slot) lo = mid + 1; else hi = mid; }
+	while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((uint32_t)(a.e_key[mid] >> 40) <= slot) lo = mid + 1; else hi = mid; }
 	const int64_t qp = a.q_begin + r.x;
 	const int8_t* q = a.qdata + qp;
 	const int8_t* s = a.tdata + sloc;
 	int score = r.score;
-	if (simd_batch_size_sorted(a.params, a.e_loc + b, lo - b, a.tdata, q, sloc) >= 4) score = 255;
+	if (simd_batch_size_sorted(a.params, a.e_key + b, lo - b, a.tdata, q, sloc) >= 4) score = 255;
 	const uint32_t qid = a.qid_of[qp];
 	const int query_len = (int)(a.qlimits[qid + 1] - a.qlimits[qid] - 1);
 	if (score <= ungapped_cutoff(a.params, query_len)) return;
@@ -381,6 +383,21 @@ hipError_t launch_seed_collect(const SeedArgs& a, int64_t n_matched, hipStream_t
 	if (n_matched == 0) return hipSuccess;
 	hipLaunchKernelGGL(seed_collect_kernel, dim3(blocks_for(n_matched, 256)), dim3(256), 0, st, a, n_matched);
 	return hipGetLastError();
+}
+
+hipError_t sort_keys_u64(const uint64_t* in, uint64_t* out, int64_t n, void** tmp, size_t* tmp_bytes, hipStream_t st)
+{
+	size_t need = 0;
+	hipError_t e = rocprim::radix_sort_keys(nullptr, need, in, out, (size_t)n, 0, 64, st);
+	if (e != hipSuccess) return e;
+	if (need > *tmp_bytes) {
+		if (*tmp) (void)hipFree(*tmp);
+		*tmp = nullptr; *tmp_bytes = 0;
+		e = hipMalloc(tmp, need);
+		if (e != hipSuccess) return e;
+		*tmp_bytes = need;
+	}
+	return rocprim::radix_sort_keys(*tmp, need, in, out, (size_t)n, 0, 64, st);
 }
 
 hipError_t launch_seed_deferred(const SeedArgs& a, int sid, int64_t n_deferred, hipStream_t st)

@@ -90,8 +90,8 @@ extern "C" int64_t emu_seed_search(const SeedParams* cp, const int8_t* matrix, c
 		std::vector<std::pair<uint64_t, int64_t>> e;
 		for (const auto& m : matched[sid]) if (tables[sid][m.first].need) e.push_back(m);
 		std::sort(e.begin(), e.end());
-		std::vector<int64_t> e_loc(e.size());
-		for (size_t i = 0; i < e.size(); ++i) e_loc[i] = e[i].second;
+		std::vector<uint64_t> e_loc(e.size());                     // low 40 bits = position, as in the device sort key
+		for (size_t i = 0; i < e.size(); ++i) e_loc[i] = (uint64_t)e[i].second;
 		// seed_deferred_kernel
 		for (const Deferred& d : deferred) {
 			const auto& m = matched[sid][d.m];
