@@ -224,7 +224,8 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	// phase 1: index + stream + mask, every shape. The joined-position lists of all shapes share one buffer.
 	std::vector<unsigned long long> counts((size_t)S + 1, 0);
 	std::vector<int64_t> m_off((size_t)S + 1, 0);
-	int64_t cap_total = std::max<int64_t>((int64_t)1 << 22, 4 * nq_pos);
+	// start from what earlier calls already grew the buffers to: a repeated search of the same scale never takes the overflow path
+	int64_t cap_total = std::max<int64_t>(std::max<int64_t>((int64_t)1 << 22, 4 * nq_pos), (int64_t)std::min(c->matched_loc.cap / sizeof(int64_t), c->matched_slot.cap / sizeof(uint32_t)));
 	if (const char* e = getenv("DMND_SEED_MATCHED_CAP")) cap_total = std::max<int64_t>(1, atoll(e));      // tests: force the overflow/retry path
 	for (int attempt = 0;; ++attempt) {
 		if (int rc = c->matched_slot.ensure((size_t)cap_total * sizeof(uint32_t))) return rc;
@@ -264,9 +265,9 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		c->seed_ms[2] += tm.stop();
 	}
 	// phase 2: pair filter per shape; hit and deferred-pair buffers grow on overflow
-	int64_t hit_cap = std::max<int64_t>((int64_t)1 << 20, m_off[S]);
+	int64_t hit_cap = std::max<int64_t>(std::max<int64_t>((int64_t)1 << 20, m_off[S] / 8), (int64_t)(c->seed_hits.cap / sizeof(dmnd_seed_hit)));
 	if (const char* e = getenv("DMND_SEED_HIT_CAP")) hit_cap = std::max<int64_t>(1, atoll(e));
-	int64_t def_cap = (int64_t)1 << 18;
+	int64_t def_cap = std::max<int64_t>((int64_t)1 << 18, (int64_t)(c->seed_deferred.cap / sizeof(SeedDeferred)));
 	if (const char* e = getenv("DMND_SEED_DEFERRED_CAP")) def_cap = std::max<int64_t>(1, atoll(e));
 	for (int attempt = 0;; ++attempt) {
 		if (int rc = c->seed_hits.ensure((size_t)hit_cap * sizeof(dmnd_seed_hit))) return rc;
