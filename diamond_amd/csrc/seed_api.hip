@@ -314,6 +314,21 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		if ((int64_t)nh > hit_cap) hit_cap = (int64_t)nh + 1024;
 		if (def_overflow) def_cap = (int64_t)def_max + 1024;
 	}
+	// order the hits by (query, subject, seed_offset, score) on the device: what align_queries needs (hits grouped by query),
+	// made deterministic (the append order of the kernels is not)
+	if (c->n_seed_hits > 0) {
+		const int64_t n = c->n_seed_hits;
+		if (n > 0xffffffffLL) return fail(DMND_E_CAP, "dmnd_seed_search: more than 2^32 seed hits in one block pair");
+		if (int rc = c->seed_hits_sorted.ensure((size_t)n * sizeof(dmnd_seed_hit))) return rc;
+		if (int rc = c->sort_keys[0].ensure((size_t)n * sizeof(uint64_t))) return rc;
+		if (int rc = c->sort_keys[1].ensure((size_t)n * sizeof(uint64_t))) return rc;
+		if (int rc = c->sort_idx[0].ensure((size_t)n * sizeof(uint32_t))) return rc;
+		if (int rc = c->sort_idx[1].ensure((size_t)n * sizeof(uint32_t))) return rc;
+		uint64_t* keys[2] = { c->sort_keys[0].as<uint64_t>(), c->sort_keys[1].as<uint64_t>() };
+		uint32_t* idx[2] = { c->sort_idx[0].as<uint32_t>(), c->sort_idx[1].as<uint32_t>() };
+		HIP_TRY(sort_seed_hits(c->seed_hits.as<dmnd_seed_hit>(), c->seed_hits_sorted.as<dmnd_seed_hit>(), n, keys, idx, &c->sort_tmp, &c->sort_tmp_bytes, st));
+		HIP_TRY(hipStreamSynchronize(st));
+	}
 	c->seed_ms[4] = c->seed_ms[0] + c->seed_ms[1] + c->seed_ms[2] + c->seed_ms[3];
 	if (getenv("DMND_TRACE")) {
 		std::fprintf(stderr, "dmnd_seed_search: %d shapes, %lld query positions, joined reference positions per shape:", S, (long long)nq_pos);
@@ -330,11 +345,6 @@ extern "C" int dmnd_seed_hits(dmnd_ctx* c, dmnd_seed_hit* out, int64_t cap)
 	if (cap < c->n_seed_hits) return fail(DMND_E_CAP, "dmnd_seed_hits: buffer too small");
 	if (c->n_seed_hits == 0) return DMND_OK;
 	HIP_TRY(hipSetDevice(c->device));
-	HIP_TRY(hipMemcpy(out, c->seed_hits.p, (size_t)c->n_seed_hits * sizeof(dmnd_seed_hit), hipMemcpyDeviceToHost));
-	std::sort(out, out + c->n_seed_hits, [](const dmnd_seed_hit& a, const dmnd_seed_hit& b) {
-		if (a.query != b.query) return a.query < b.query;
-		if (a.subject != b.subject) return a.subject < b.subject;
-		return a.seed_offset < b.seed_offset;
-	});
+	HIP_TRY(hipMemcpy(out, c->seed_hits_sorted.p, (size_t)c->n_seed_hits * sizeof(dmnd_seed_hit), hipMemcpyDeviceToHost));      // sorted by dmnd_seed_search
 	return DMND_OK;
 }

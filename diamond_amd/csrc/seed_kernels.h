@@ -49,5 +49,9 @@ hipError_t launch_seed_collect(const SeedArgs& a, int64_t n_matched, hipStream_t
 hipError_t launch_seed_deferred(const SeedArgs& a, int sid, int64_t n_deferred, hipStream_t st);
 // ascending device sort of n 64-bit keys (rocPRIM radix sort); tmp is grown as needed
 hipError_t sort_keys_u64(const uint64_t* in, uint64_t* out, int64_t n, void** tmp, size_t* tmp_bytes, hipStream_t st);
+// Orders the n seed hits by (query, subject, seed_offset, score) on the device: three stable radix-sort passes over an index
+// permutation (keys/idx: two buffers of n uint64 / uint32 each), then one gather into `out`.
+hipError_t sort_seed_hits(const dmnd_seed_hit* hits, dmnd_seed_hit* out, int64_t n, uint64_t* keys[2], uint32_t* idx[2],
+	void** tmp, size_t* tmp_bytes, hipStream_t st);
 
 }  // namespace dmnd

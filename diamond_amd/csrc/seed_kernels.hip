@@ -400,6 +400,59 @@ hipError_t sort_keys_u64(const uint64_t* in, uint64_t* out, int64_t n, void** tm
 	return rocprim::radix_sort_keys(*tmp, need, in, out, (size_t)n, 0, 64, st);
 }
 
+namespace {
+
+// pass 0: key = score, identity permutation; pass 1: key = subject << 24 | seed_offset; pass 2: key = query
+__global__ void hit_keys_kernel(const dmnd_seed_hit* hits, const uint32_t* perm, int64_t n, int pass, uint64_t* keys, uint32_t* idx_out)
+{
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t src = perm ? perm[i] : (uint32_t)i;
+	const dmnd_seed_hit h = hits[src];
+	keys[i] = pass == 0 ? (uint64_t)(uint32_t)h.score : pass == 1 ? ((uint64_t)h.subject << 24) | ((uint64_t)h.seed_offset & 0xffffffu) : (uint64_t)h.query;
+	if (idx_out) idx_out[i] = src;
+}
+
+__global__ void hit_gather_kernel(const dmnd_seed_hit* hits, const uint32_t* perm, int64_t n, dmnd_seed_hit* out)
+{
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) out[i] = hits[perm[i]];
+}
+
+hipError_t sort_pairs(const uint64_t* kin, uint64_t* kout, const uint32_t* vin, uint32_t* vout, int64_t n, int bits, void** tmp, size_t* tmp_bytes, hipStream_t st)
+{
+	size_t need = 0;
+	hipError_t e = rocprim::radix_sort_pairs(nullptr, need, kin, kout, vin, vout, (size_t)n, 0, bits, st);
+	if (e != hipSuccess) return e;
+	if (need > *tmp_bytes) {
+		if (*tmp) (void)hipFree(*tmp);
+		*tmp = nullptr; *tmp_bytes = 0;
+		e = hipMalloc(tmp, need);
+		if (e != hipSuccess) return e;
+		*tmp_bytes = need;
+	}
+	return rocprim::radix_sort_pairs(*tmp, need, kin, kout, vin, vout, (size_t)n, 0, bits, st);
+}
+
+}  // namespace
+
+hipError_t sort_seed_hits(const dmnd_seed_hit* hits, dmnd_seed_hit* out, int64_t n, uint64_t* keys[2], uint32_t* idx[2],
+	void** tmp, size_t* tmp_bytes, hipStream_t st)
+{
+	if (n <= 0) return hipSuccess;
+	const dim3 grid(blocks_for(n, 256)), block(256);
+	hipError_t e;
+	// least significant criterion first; every pass is stable
+	hipLaunchKernelGGL(hit_keys_kernel, grid, block, 0, st, hits, (const uint32_t*)nullptr, n, 0, keys[0], idx[0]);
+	if ((e = sort_pairs(keys[0], keys[1], idx[0], idx[1], n, 32, tmp, tmp_bytes, st)) != hipSuccess) return e;
+	hipLaunchKernelGGL(hit_keys_kernel, grid, block, 0, st, hits, (const uint32_t*)idx[1], n, 1, keys[0], (uint32_t*)nullptr);
+	if ((e = sort_pairs(keys[0], keys[1], idx[1], idx[0], n, 64, tmp, tmp_bytes, st)) != hipSuccess) return e;
+	hipLaunchKernelGGL(hit_keys_kernel, grid, block, 0, st, hits, (const uint32_t*)idx[0], n, 2, keys[0], (uint32_t*)nullptr);
+	if ((e = sort_pairs(keys[0], keys[1], idx[0], idx[1], n, 32, tmp, tmp_bytes, st)) != hipSuccess) return e;
+	hipLaunchKernelGGL(hit_gather_kernel, grid, block, 0, st, hits, (const uint32_t*)idx[1], n, out);
+	return hipGetLastError();
+}
+
 hipError_t launch_seed_deferred(const SeedArgs& a, int sid, int64_t n_deferred, hipStream_t st)
 {
 	if (n_deferred == 0) return hipSuccess;
