@@ -263,8 +263,8 @@ double ms_since(std::chrono::steady_clock::time_point t) { return std::chrono::d
 int run_blastp(const Options& o)
 {
 	if (o.query.empty() || o.db.empty()) throw std::runtime_error("Missing parameter: query (--query/-q) and database (--db/-d) are required.");
-	if (!o.sens.empty() && o.sens != "--sensitive" && o.sens != "--mid-sensitive" && o.sens != "--more-sensitive")
-		throw std::runtime_error("This build implements --fast, default, --mid-sensitive, --sensitive and --more-sensitive (" + o.sens + " is not available).");
+	if (!o.sens.empty() && o.sens != "--sensitive" && o.sens != "--mid-sensitive" && o.sens != "--more-sensitive" && o.sens != "--very-sensitive")
+		throw std::runtime_error("This build implements --fast, default, --mid-sensitive, --sensitive, --more-sensitive and --very-sensitive (" + o.sens + " is not available).");
 	if (o.fast && !o.sens.empty()) throw std::runtime_error("Conflicting sensitivity options.");
 	// --masking: tantan = default (run/config.cpp:124-135); seg is not part of this build
 	const bool tantan = o.masking.empty() || o.masking == "1" || o.masking == "tantan";
@@ -307,7 +307,7 @@ int run_blastp(const Options& o)
 	const int threads = o.threads > 0 ? o.threads : 8;
 	dmnd_seed_params sp;
 	const int sens = o.fast ? DMND_SENS_FAST : o.sens == "--mid-sensitive" ? DMND_SENS_MID_SENSITIVE : o.sens == "--sensitive" ? DMND_SENS_SENSITIVE
-		: o.sens == "--more-sensitive" ? DMND_SENS_MORE_SENSITIVE : DMND_SENS_DEFAULT;
+		: o.sens == "--more-sensitive" ? DMND_SENS_MORE_SENSITIVE : o.sens == "--very-sensitive" ? DMND_SENS_VERY_SENSITIVE : DMND_SENS_DEFAULT;
 	double gf_evalue = 0.0;
 	chk(dmnd_seed_params_preset(&sp, sens, threads, &p, &gf_evalue));
 	chk(dmnd_set_gapped_filter(ctx, gf_evalue));
@@ -354,7 +354,7 @@ int main(int argc, char** argv)
 		if (o.command == "version") { std::cout << "diamond-hip (MI355X back end of DIAMOND's seed-and-extend path), ABI " << dmnd_abi_version() << "\n"; return 0; }
 		if (o.command == "help" || o.command == "--help") {
 			std::cout << "Syntax: diamond-hip COMMAND [OPTIONS]\n  makedb --in FASTA -d DB        build a .dmnd database (no masking)\n"
-				"  blastp [--fast|--mid-sensitive|--sensitive|--more-sensitive] -q FASTA -d DB(.dmnd|FASTA) -o OUT [--masking 0] [-e EVALUE] [-k N] [-p THREADS]\n"
+				"  blastp [--fast|--mid-sensitive|--sensitive|--more-sensitive|--very-sensitive] -q FASTA -d DB(.dmnd|FASTA) -o OUT [--masking 0] [-e EVALUE] [-k N] [-p THREADS]\n"
 				"  blastx [--fast|--sensitive] -q DNA_FASTA -d DB ...   (six-frame translation, standard genetic code)\n  version\n";
 			return 0;
 		}

@@ -51,10 +51,13 @@ extern "C" int dmnd_seed_params_fast(dmnd_seed_params* p, int threads)
 namespace {
 
 // shapes + the stage-2 ungapped e-value filter (10000) shared by the default and sensitive presets
-int spaced_preset(dmnd_seed_params* p, int threads, const dmnd_params* sc, const char* const* codes, int n, double seed_cut)
+int spaced_preset(dmnd_seed_params* p, int threads, const dmnd_params* sc, const char* const* codes, int n, double seed_cut,
+	double ungapped_evalue = 10000.0, double ungapped_evalue_short = 10000.0, int hamming_id = 11, int index_chunks = 4)
 {
 	if (int rc = dmnd_seed_params_fast(p, threads)) return rc;
 	p->n_shapes = n;
+	p->hamming_filter_id = hamming_id;
+	p->index_chunks = index_chunks;
 	int weight = 0;
 	for (int sid = 0; sid < n; ++sid) {
 		int w = 0;
@@ -67,7 +70,9 @@ int spaced_preset(dmnd_seed_params* p, int threads, const dmnd_params* sc, const
 		weight = w;
 	}
 	auto bit_length = [](uint64_t x) { int b = 0; while (x) { ++b; x >>= 1; } return b; };
-	p->seedp_bits = std::max(std::max(bit_length(10000000000ull - 1) - 32, bit_length((uint64_t)threads * 4 * p->index_chunks - 1)), 8);
+	uint64_t space = 1;
+	for (int i = 0; i < weight; ++i) space *= (uint64_t)p->reduction_size;
+	p->seedp_bits = std::max(std::max(bit_length(space - 1) - 32, bit_length((uint64_t)threads * 4 * p->index_chunks - 1)), 8);      // setup.cpp:306-309
 	p->seed_complexity_cut = seed_cut * 0.69314718055994530942 * weight;       // setup.cpp:369-370
 	// ungapped e-value 10000: CutoffTable + short-query cutoff (cutoff_table.h:30-35, score_matrix.h:130-151, config.cpp:431)
 	const double LN2 = 0.69314718055994530941723212145818, ln_k = std::log(sc->K);
@@ -75,8 +80,11 @@ int spaced_preset(dmnd_seed_params* p, int threads, const dmnd_params* sc, const
 	p->use_ungapped = 1;
 	p->short_query_cutoff = raw(25.0);
 	p->cutoff_table[0] = 0;
-	for (int b = 1; b < 32; ++b)
-		p->cutoff_table[b] = raw(-std::log(10000.0 / 1e9 / (double)(1u << (b - 1))) / std::log(2.0));
+	p->cutoff_table_short[0] = 0;
+	for (int b = 1; b < 32; ++b) {
+		p->cutoff_table[b] = raw(-std::log(ungapped_evalue / 1e9 / (double)(1u << (b - 1))) / std::log(2.0));
+		p->cutoff_table_short[b] = raw(-std::log(ungapped_evalue_short / 1e9 / (double)(1u << (b - 1))) / std::log(2.0));
+	}
 	return DMND_OK;
 }
 
@@ -118,6 +126,14 @@ extern "C" int dmnd_seed_params_preset(dmnd_seed_params* p, int sensitivity, int
 	case DMND_SENS_MORE_SENSITIVE:       // same shapes and filters; differs only in freq_sd / motif masking, which this library does not apply
 		if (gapped_filter_evalue) *gapped_filter_evalue = 1.0;
 		return dmnd_seed_params_sensitive(p, threads, sc);
+	case DMND_SENS_VERY_SENSITIVE: {
+		if (!sc) return fail(DMND_E_ARG, "dmnd_seed_params_preset: scoring parameters needed");
+		static const char* const codes[14] = { "11101111", "110110111", "111111001", "1010111011", "11110001011", "110100101011", "110110001101",
+			"1010101000111", "1100101001011", "1101010101001", "1110010010011", "110110000010011", "111001000100011", "1101000100010011" };   // 14x7, setup.cpp:118-133
+		if (gapped_filter_evalue) *gapped_filter_evalue = 1.0;
+		// sensitivity_traits: min id 9, ungapped e-values 100000 / 30000 (short), one index chunk (setup.cpp:51)
+		return spaced_preset(p, threads, sc, codes, 14, 1.0, 100000.0, 30000.0, 9, 1);
+	}
 	default:
 		return fail(DMND_E_ARG, "dmnd_seed_params_preset: unknown sensitivity");
 	}

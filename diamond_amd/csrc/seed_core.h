@@ -41,6 +41,7 @@ struct SeedParams {
 	int32_t tile_size, simd_lanes;                           // config.tile_size (1024); int8 lanes of the reference build (AVX2: 32)
 	int32_t query_translated;                                // align_mode.query_translated (blastx): short-frame rules of stage2.h:51,58-63
 	int32_t pad_;
+	int32_t cutoff_table_short[32];                          // CutoffTable(ungapped_evalue_short): translated frames of 61..85 letters (stage2.h:51)
 };
 
 DMND_HD bool is_amino_acid(int l) { return l != L_MASK && l != L_DELIM && l != L_STOP; }
@@ -270,11 +271,10 @@ DMND_HD int ungapped_cutoff(const SeedParams& c, int query_len)
 {
 	if (!c.use_ungapped) return 0;
 	if (query_len <= c.short_query_max_len) return c.short_query_cutoff;
-	// 60 < len <= 85 of a translated query: cutoff_table_short = CutoffTable(ungapped_evalue_short), the same table for every
-	// sensitivity this library presets (ungapped_evalue_short == ungapped_evalue, setup.cpp:40-53)
 	int b = 0;
 	for (uint32_t x = (uint32_t)query_len; x; x >>= 1) ++b;
-	return c.cutoff_table[b];
+	// 60 < len <= 85 of a translated query: CutoffTable(ungapped_evalue_short) (differs from the main table from --very-sensitive up)
+	return (c.query_translated && query_len <= 85) ? c.cutoff_table_short[b] : c.cutoff_table[b];
 }
 
 // The reference scores Hamming survivors in SIMD batches (search_query_offset, stage2.h:74-154): per subject tile

@@ -178,6 +178,7 @@ typedef struct {
 	int32_t query_translated;      /* align_mode.query_translated: 1 for blastx blocks (six frames per read); enables the short-frame
 	                                  rules of src/search/stage2.h:51,58-63 (window = frame length for frames of <= 85 letters) */
 	int32_t pad_;
+	int32_t cutoff_table_short[32]; /* CutoffTable(ungapped_evalue_short), used for translated frames of 61..85 letters (stage2.h:51) */
 } dmnd_seed_params;
 
 /* One stage-2 seed hit = Search::Hit (src/search/hit.h:30-47): query context index, reference location
@@ -253,7 +254,8 @@ int dmnd_gapped_filter(dmnd_ctx* ctx, const dmnd_seed_hit* hits, int64_t n_hits,
 double dmnd_gapped_filter_ms(const dmnd_ctx* ctx);
 /* Sensitivity presets (Sensitivity enum + sensitivity_traits, src/search/setup.cpp:40-53): shapes, seed cut, ungapped
  * e-value, and through *gapped_filter_evalue (may be NULL) the value to pass to dmnd_set_gapped_filter. */
-enum { DMND_SENS_FAST = 0, DMND_SENS_DEFAULT = 1, DMND_SENS_MID_SENSITIVE = 2, DMND_SENS_SENSITIVE = 3, DMND_SENS_MORE_SENSITIVE = 4 };
+enum { DMND_SENS_FAST = 0, DMND_SENS_DEFAULT = 1, DMND_SENS_MID_SENSITIVE = 2, DMND_SENS_SENSITIVE = 3, DMND_SENS_MORE_SENSITIVE = 4,
+       DMND_SENS_VERY_SENSITIVE = 5 };
 int dmnd_seed_params_preset(dmnd_seed_params* p, int sensitivity, int threads, const dmnd_params* scoring, double* gapped_filter_evalue);
 /* Sensitive mode seed configuration (16 shapes of weight 8, search/setup.cpp:86-102; ungapped e-value 10000, seed cut 1.0) */
 int dmnd_seed_params_sensitive(dmnd_seed_params* p, int threads, const dmnd_params* scoring);

@@ -105,7 +105,7 @@ class SeedCfg(ctypes.Structure):
                 ("seed_complexity_cut", ctypes.c_double),
                 ("use_ungapped", ctypes.c_int32), ("short_query_max_len", ctypes.c_int32), ("short_query_cutoff", ctypes.c_int32),
                 ("cutoff_table", ctypes.c_int32 * 32), ("tile_size", ctypes.c_int32), ("simd_lanes", ctypes.c_int32),
-                ("matrix", ctypes.c_int8 * 1024), ("query_translated", ctypes.c_int32)]
+                ("matrix", ctypes.c_int8 * 1024), ("query_translated", ctypes.c_int32), ("cutoff_table_short", ctypes.c_int32 * 32)]
 
 
 def ungapped_cutoffs(ungapped_evalue, lambda_=0.267, K=0.041, short_bits=25.0):
@@ -145,6 +145,7 @@ def seed_cfg_from_tap(cfg, matrix8=None):
     c.short_query_cutoff = short
     for i in range(32):
         c.cutoff_table[i] = table[i]
+        c.cutoff_table_short[i] = table[i]
     c.tile_size, c.simd_lanes = 1024, 32
     c.query_translated = 1 if cfg.get("query_contexts", 1) > 1 else 0
     if matrix8 is not None:

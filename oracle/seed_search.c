@@ -227,7 +227,7 @@ static int ungapped_cutoff(const oracle_seed_cfg* c, int query_len)
 	if (query_len <= c->short_query_max_len) return c->short_query_cutoff;
 	int b = 0;
 	for (unsigned x = (unsigned)query_len; x; x >>= 1) ++b;
-	return c->cutoff_table[b];
+	return (c->query_translated && query_len <= 85) ? c->cutoff_table_short[b] : c->cutoff_table[b];
 }
 
 static int64_t enumerate(const oracle_seed_cfg* c, int sid, const int8_t* data, const int64_t* limits, int64_t n, range_t r, entry_t* out)

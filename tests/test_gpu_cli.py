@@ -95,7 +95,7 @@ def test_cli_default_masking_matches_reference(tmp_path):
     db, q = _plant_repeats(db, doff, rng), _plant_repeats(q, qoff, rng)
     synth.write_fasta(str(tmp_path / "db.faa"), "t", db, doff)
     synth.write_fasta(str(tmp_path / "q.faa"), "q", q, qoff)
-    for mode in ([], ["--fast"], ["--mid-sensitive"], ["--sensitive"], ["--more-sensitive"]):
+    for mode in ([], ["--fast"], ["--mid-sensitive"], ["--sensitive"], ["--more-sensitive"], ["--very-sensitive"]):
         tag = (mode or ["default"])[0].strip("-")
         _run([REF, "blastp"] + mode + ["--algo", "0", "--motif-masking", "0", "-q", str(tmp_path / "q.faa"), "-d", str(tmp_path / "db.faa"),
                                         "-o", str(tmp_path / ("ref_%s.tsv" % tag)), "-p", "4"])
@@ -112,5 +112,5 @@ def test_cli_default_masking_matches_reference(tmp_path):
 
 
 def test_cli_refuses_unimplemented_modes(tmp_path):
-    r = subprocess.run([CLI, "blastp", "--very-sensitive", "-q", "x", "-d", "y"], capture_output=True, text=True)
+    r = subprocess.run([CLI, "blastp", "--ultra-sensitive", "-q", "x", "-d", "y"], capture_output=True, text=True)
     assert r.returncode != 0 and "not available" in r.stderr
