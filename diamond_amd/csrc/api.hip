@@ -134,6 +134,7 @@ extern "C" int dmnd_upload_block(dmnd_ctx* c, int which, const int8_t* data, int
 	HIP_TRY(hipMemcpyAsync(c->block[which].p, data, (size_t)data_len, hipMemcpyHostToDevice, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	c->block_len[which] = data_len;
+	if (which == DMND_QUERY) c->host_cbs_buf.clear();          // bias cache of the previous query block
 	c->limits[which].clear();
 	if (limits) {
 		c->limits[which].assign(limits, limits + n_seqs + 1);

@@ -55,6 +55,7 @@ struct dmnd_ctx {
 	double mask_ms = 0.0;
 	double seed_ms[5] = { 0, 0, 0, 0, 0 };
 	// extension-stage statistics of the last dmnd_extend (extend_host.hip)
+	std::vector<int8_t> host_cbs_buf;          // Hauser bias of the query block (host copy, parallel to the block letters)
 	double ext_stats[12] = { 0 };
 	double host_ms[3] = { 0, 0, 0 };           // host wall time inside dmnd_banded_swipe: prepare, launch+wait, unpack (DMND_TRACE)
 	int query_contexts = 1;                    // align_mode.query_contexts: 6 for blastx (basic/basic.cpp:40-60)

@@ -470,7 +470,10 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	auto lap = [&](int slot, int f = -1) { const double t = now(); c->ext_stats[slot] += t - t_mark; if (f >= 0) fine[f] += t - t_mark; t_mark = t; };
 	// 1. Hauser bias for every query, resident next to the query block
 	const std::vector<Range> qr = split_by_query(hits, n_hits, h.contexts);
-	std::vector<int8_t> cbs((size_t)ql.back() + 64, 0);            // only queries with seed hits are ever aligned
+	// only queries with seed hits are ever aligned, and only their bias is ever read: the buffer lives in the context, so
+	// neither its allocation nor a 3 MB clear is paid per call (stale values of other queries are never touched)
+	std::vector<int8_t>& cbs = c->host_cbs_buf;
+	if (cbs.size() < (size_t)ql.back() + 64) cbs.assign((size_t)ql.back() + 64, 0);
 	parallel_for(qr.size(), threads, [&](size_t i, int) {
 		const uint32_t q0 = hits[qr[i].b].query / C * C;
 		for (uint32_t q = q0; q < q0 + C; ++q) {
@@ -644,24 +647,31 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	c->swipe_ms = sw1 + sw2; c->traceback_ms = tb2;
 	c->ext_stats[9] = sw1; c->ext_stats[10] = sw2; c->ext_stats[11] = tb2;
 	if (transcript_used) *transcript_used = transcript ? used : 0;
-	// final culling(matches, cfg) per query (extend.cpp:341) -> records in query order
-	int64_t n = 0;
-	for (QueryState& s : qs) {
-		std::sort(s.matches.begin(), s.matches.end(), match_less);
-		if ((int)s.matches.size() > K) s.matches.resize((size_t)K);
-		for (const dmnd_match& m : s.matches) {
-			if (n < cap && out) out[n] = m;
-			++n;
-		}
-	}
-	*n_out = n;
-	// release the per-query state on the worker threads (tens of thousands of small blocks; serial frees cost ~3 ms on C2)
+	// final culling(matches, cfg) per query (extend.cpp:341) -> records in query order; sorting, copying out and releasing the
+	// per-query state (tens of thousands of small blocks: serial frees cost ~3 ms on C2) all run on the worker threads
+	std::vector<int64_t> out_off(qs.size() + 1, 0);
 	{
 		const size_t chunk = 64, n_chunks = (qs.size() + chunk - 1) / chunk;
 		parallel_for(n_chunks, threads, [&](size_t ci, int) {
-			for (size_t i = ci * chunk; i < std::min(qs.size(), (ci + 1) * chunk); ++i) { QueryState empty; std::swap(qs[i], empty); }
+			for (size_t i = ci * chunk; i < std::min(qs.size(), (ci + 1) * chunk); ++i) {
+				QueryState& s = qs[i];
+				std::sort(s.matches.begin(), s.matches.end(), match_less);
+				if ((int)s.matches.size() > K) s.matches.resize((size_t)K);
+				out_off[i + 1] = (int64_t)s.matches.size();
+			}
+		});
+		for (size_t i = 0; i < qs.size(); ++i) out_off[i + 1] += out_off[i];
+		const int64_t total = out_off[qs.size()];
+		parallel_for(n_chunks, threads, [&](size_t ci, int) {
+			for (size_t i = ci * chunk; i < std::min(qs.size(), (ci + 1) * chunk); ++i) {
+				if (out && total <= cap) std::copy(qs[i].matches.begin(), qs[i].matches.end(), out + out_off[i]);
+				QueryState empty;
+				std::swap(qs[i], empty);
+			}
 		});
 	}
+	const int64_t n = out_off[qs.size()];
+	*n_out = n;
 	lap(7, 10);
 	if (std::getenv("DMND_TRACE"))
 		std::fprintf(stderr, "dmnd_extend ms: hauser+upload %.2f gapped_filter %.2f load %.2f plan %.2f swipe1 %.2f post1 %.2f build2 %.2f swipe2 %.2f post2 %.2f final %.2f | swipe host: prep %.2f run %.2f post %.2f\n",
