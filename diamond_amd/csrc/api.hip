@@ -7,6 +7,7 @@
 // width (P = diagonals-per-lane class) and ordered longest-first so the 256 CUs drain evenly.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -16,6 +17,7 @@
 #include <vector>
 #include "../../include/diamond_hip.h"
 #include "swipe_core.h"
+#include "host_pool.h"
 #include "swipe_kernels.h"
 #include "ctx.h"
 #include "blosum62.h"
@@ -330,19 +332,25 @@ int swipe_impl(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, int64_t
 	auto lap = [&](int slot) { const double t = wall(); c->host_ms[slot] += t - t_mark; t_mark = t; };
 
 	std::vector<Slot> slots((size_t)n);
-	for (int64_t i = 0; i < n; ++i) {
-		const dmnd_dp_target& it = items[i];
-		const int band = it.d_end - it.d_begin;
-		if (band <= 0 || it.query_len <= 0 || it.target_len <= 0 || it.query_off < 0 || it.target_off < 0
-			|| it.query_off + it.query_len > b.q_len || it.target_off + it.target_len > b.t_len
-			|| (it.cbs_off >= 0 && (!b.cbs || it.cbs_off + it.query_len > b.cbs_len)))
-			return fail(DMND_E_ARG, "dmnd_banded_swipe: item " + std::to_string(i) + " out of range");
-		const int P = band_class(band);
-		if (P > 32 || (kmode == K_STATS_FWD && P > 16))
-			return fail(DMND_E_BAND, "Band size exceeds the supported maximum (" + std::to_string(kmode == K_STATS_FWD ? DMND_MAX_BAND / 2 : DMND_MAX_BAND) + ")");
-		const Geom g = make_geom(it.query_len, it.target_len, it.d_begin, it.d_end);
-		slots[i] = Slot{ (int32_t)i, P, n_steps(g) };
-	}
+	std::atomic<int64_t> bad_item(-1), bad_band(-1);
+	const int host_threads = n >= 4096 ? 8 : 1;
+	const int64_t chunk = 2048, n_chunks = (n + chunk - 1) / chunk;
+	parallel_for((size_t)n_chunks, host_threads, [&](size_t ci, int) {
+		for (int64_t i = (int64_t)ci * chunk; i < std::min(n, ((int64_t)ci + 1) * chunk); ++i) {
+			const dmnd_dp_target& it = items[i];
+			const int band = it.d_end - it.d_begin;
+			if (band <= 0 || it.query_len <= 0 || it.target_len <= 0 || it.query_off < 0 || it.target_off < 0
+				|| it.query_off + it.query_len > b.q_len || it.target_off + it.target_len > b.t_len
+				|| (it.cbs_off >= 0 && (!b.cbs || it.cbs_off + it.query_len > b.cbs_len))) { bad_item.store(i); slots[i] = Slot{ (int32_t)i, 1, 0 }; continue; }
+			const int P = band_class(band);
+			if (P > 32 || (kmode == K_STATS_FWD && P > 16)) { bad_band.store(i); slots[i] = Slot{ (int32_t)i, 1, 0 }; continue; }
+			const Geom g = make_geom(it.query_len, it.target_len, it.d_begin, it.d_end);
+			slots[i] = Slot{ (int32_t)i, P, n_steps(g) };
+		}
+	});
+	if (bad_item.load() >= 0) return fail(DMND_E_ARG, "dmnd_banded_swipe: item " + std::to_string(bad_item.load()) + " out of range");
+	if (bad_band.load() >= 0)
+		return fail(DMND_E_BAND, "Band size exceeds the supported maximum (" + std::to_string(kmode == K_STATS_FWD ? DMND_MAX_BAND / 2 : DMND_MAX_BAND) + ")");
 	if (int rc = c->items.ensure(n * sizeof(dmnd_dp_target))) return rc;
 	if (int rc = c->ends.ensure(n * sizeof(SwipeEnd))) return rc;
 	if (kmode == K_TRACE) { if (int rc = c->hsps.ensure(n * sizeof(dmnd_hsp))) return rc; }

@@ -1,0 +1,95 @@
+// host_pool.h -- persistent host worker pool shared by the host parts of libdiamond_hip.so (extension stage, swipe call
+// preparation). One pool per process; a loop that finds it busy falls back to plain threads.
+#pragma once
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstddef>
+#include <cstdint>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace dmnd {
+
+// Persistent worker pool: dmnd_extend issues a handful of short parallel loops per call, and thread start-up would
+// cost more than the loops themselves. Workers sleep on a condition variable between loops; the caller is worker 0.
+class WorkerPool {
+public:
+	~WorkerPool()
+	{
+		{ std::lock_guard<std::mutex> g(m_); stop_ = true; }
+		cv_.notify_all();
+		for (auto& t : th_) t.join();
+	}
+	template<typename F>
+	void run(size_t n, int threads, F& f)
+	{
+		std::unique_lock<std::mutex> own(busy_, std::try_to_lock);
+		if (!own.owns_lock()) {                              // another context is using the pool: plain threads for this loop
+			std::vector<std::thread> th;
+			std::atomic<size_t> next(0);
+			for (int t = 0; t < threads; ++t) th.emplace_back([&, t] { size_t i; while ((i = next.fetch_add(1)) < n) f(i, t); });
+			for (auto& x : th) x.join();
+			return;
+		}
+		grow(threads - 1);
+		std::function<void(size_t, int)> fn = [&f](size_t i, int t) { f(i, t); };
+		{
+			std::lock_guard<std::mutex> g(m_);
+			fn_ = &fn; n_ = n; next_.store(0); want_ = threads - 1; running_ = threads - 1; ++gen_;
+		}
+		cv_.notify_all();
+		size_t i;
+		while ((i = next_.fetch_add(1)) < n) f(i, 0);
+		std::unique_lock<std::mutex> g(m_);
+		done_.wait(g, [&] { return running_ == 0; });
+		fn_ = nullptr;
+	}
+private:
+	void grow(int workers)
+	{
+		while ((int)th_.size() < workers) {
+			const int id = (int)th_.size() + 1;
+			th_.emplace_back([this, id] {
+				uint64_t seen = 0;
+				for (;;) {
+					std::unique_lock<std::mutex> g(m_);
+					cv_.wait(g, [&] { return stop_ || (gen_ != seen && id <= want_); });
+					if (stop_) return;
+					seen = gen_;
+					const std::function<void(size_t, int)>* fn = fn_;
+					const size_t n = n_;
+					g.unlock();
+					size_t i;
+					while ((i = next_.fetch_add(1)) < n) (*fn)(i, id);
+					g.lock();
+					if (--running_ == 0) done_.notify_one();
+				}
+			});
+		}
+	}
+	std::vector<std::thread> th_;
+	std::mutex m_, busy_;
+	std::condition_variable cv_, done_;
+	const std::function<void(size_t, int)>* fn_ = nullptr;
+	size_t n_ = 0;
+	std::atomic<size_t> next_{ 0 };
+	int want_ = 0, running_ = 0;
+	uint64_t gen_ = 0;
+	bool stop_ = false;
+};
+
+WorkerPool& pool();      // defined once, in extend_host.hip
+
+template<typename F>
+void parallel_for(size_t n, int threads, F f)
+{
+	threads = std::max(1, std::min<int>(threads, (int)n));
+	if (threads == 1) { for (size_t i = 0; i < n; ++i) f(i, 0); return; }
+	pool().run(n, threads, f);
+}
+
+
+}  // namespace dmnd
