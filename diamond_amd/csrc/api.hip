@@ -360,8 +360,21 @@ int swipe_impl(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, int64_t
 	std::vector<SwipeEnd> ends((size_t)n);
 	std::vector<dmnd_hsp> hsps;
 	auto by_class = [](const Slot& x, const Slot& y) { return x.P < y.P || (x.P == y.P && x.steps > y.steps); };
+	// launch order: classes ascending, inside a class longest items first (load balance). A bucket sort on (P, steps / 16) is
+	// enough for that and is O(n); exact order inside a bucket does not matter (results are written by item index).
+	auto order_slots = [&](std::vector<Slot>& v) {
+		if (v.size() < 2048) { std::sort(v.begin(), v.end(), by_class); return; }
+		const int NB = 1024;
+		std::vector<uint32_t> count((size_t)33 * NB + 1, 0);
+		auto bucket = [&](const Slot& x) { return (size_t)x.P * NB + (size_t)(NB - 1 - std::min<int64_t>(x.steps >> 4, NB - 1)); };
+		for (const Slot& x : v) ++count[bucket(x) + 1];
+		for (size_t i = 1; i < count.size(); ++i) count[i] += count[i - 1];
+		std::vector<Slot> out(v.size());
+		for (const Slot& x : v) out[count[bucket(x)]++] = x;
+		v.swap(out);
+	};
 	if (kmode != K_TRACE) {
-		std::sort(slots.begin(), slots.end(), by_class);
+		order_slots(slots);
 		lap(0);
 		if (int rc = run_chunk(c, b, items, c->items.as<dmnd_dp_target>(), slots, kmode, out, nullptr, nullptr)) return rc;
 		lap(1);
@@ -433,7 +446,7 @@ int swipe_impl(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, int64_t
 			++c1;
 		}
 		std::vector<Slot> chunk(slots.begin() + c0, slots.begin() + c1);
-		std::sort(chunk.begin(), chunk.end(), by_class);
+		order_slots(chunk);
 		std::vector<uint8_t> tr;
 		std::vector<int64_t> tr_off;
 		lap(0);
