@@ -103,8 +103,10 @@ extern "C" dmnd_ctx* dmnd_create(int device, const dmnd_params* params)
 
 extern "C" void dmnd_destroy(dmnd_ctx* c)
 {
-	if (c && c->sort_tmp) { (void)hipFree(c->sort_tmp); c->sort_tmp = nullptr; c->sort_tmp_bytes = 0; }
 	if (!c) return;
+	if (c->sort_tmp) { (void)hipFree(c->sort_tmp); c->sort_tmp = nullptr; c->sort_tmp_bytes = 0; }
+	for (dmnd_ctx* a : c->aux) dmnd_destroy(a);
+	c->aux.clear();
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	for (DevBuf* b : { &c->block[0], &c->block[1], &c->cbs, &c->matrix, &c->items, &c->order, &c->p_of_slot, &c->trace_off,
@@ -481,13 +483,38 @@ int swipe_impl(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, int64_t
 
 }  // namespace
 
+int dmnd_swipe_shared(dmnd_ctx* work, const dmnd_ctx* c, const dmnd_dp_target* items, int64_t n, int mode, uint32_t hsp_values,
+	dmnd_hsp* out, uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used)
+{
+	if (!c || !work) return fail(DMND_E_ARG, "ctx is NULL");
+	const Bases b{ c->block[DMND_QUERY].as<int8_t>(), c->block_len[DMND_QUERY], c->block[DMND_TARGET].as<int8_t>(), c->block_len[DMND_TARGET],
+		c->cbs_len > 0 ? c->cbs.as<int8_t>() : nullptr, c->cbs_len };
+	if (work != c) {                                       // scoring state of the owner, by reference
+		work->matrix.p = c->matrix.p; work->matrix.cap = c->matrix.cap; work->matrix.own = false;
+		work->params = c->params; work->evaluer = c->evaluer;
+	}
+	return swipe_impl(work, b, items, n, mode, hsp_values, out, transcript, transcript_cap, transcript_used);
+}
+
+dmnd_ctx* aux_context(dmnd_ctx* c, int k, int split)
+{
+	if (!c || k < 0) return nullptr;
+	while ((int)c->aux.size() <= k) {
+		dmnd_ctx* a = new dmnd_ctx();
+		a->device = c->device;
+		if (hipSetDevice(c->device) != hipSuccess || hipStreamCreate(&a->stream) != hipSuccess || hipEventCreate(&a->ev0) != hipSuccess
+			|| hipEventCreate(&a->ev1) != hipSuccess || hipEventCreate(&a->ev2) != hipSuccess) { delete a; return nullptr; }
+		c->aux.push_back(a);
+	}
+	dmnd_ctx* a = c->aux[(size_t)k];
+	a->trace_arena_max = std::max<size_t>(c->trace_arena_max / (size_t)std::max(split, 1), (size_t)256 << 20);
+	return a;
+}
+
 extern "C" int dmnd_banded_swipe(dmnd_ctx* c, const dmnd_dp_target* items, int64_t n, int mode, uint32_t hsp_values,
 	dmnd_hsp* out, uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used)
 {
-	if (!c) return fail(DMND_E_ARG, "ctx is NULL");
-	const Bases b{ c->block[DMND_QUERY].as<int8_t>(), c->block_len[DMND_QUERY], c->block[DMND_TARGET].as<int8_t>(), c->block_len[DMND_TARGET],
-		c->cbs_len > 0 ? c->cbs.as<int8_t>() : nullptr, c->cbs_len };
-	return swipe_impl(c, b, items, n, mode, hsp_values, out, transcript, transcript_cap, transcript_used);
+	return dmnd_swipe_shared(c, c, items, n, mode, hsp_values, out, transcript, transcript_cap, transcript_used);
 }
 
 extern "C" int dmnd_banded_swipe_host(dmnd_ctx* c, const int8_t* query, int32_t query_len, const int8_t* cbs,

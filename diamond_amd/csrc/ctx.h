@@ -22,7 +22,8 @@ struct DevBuf {
 	void* p = nullptr;
 	size_t cap = 0;
 	int ensure(size_t bytes);
-	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+	bool own = true;                       // false: alias of another context's buffer (auxiliary contexts)
+	void release() { if (p && own) (void)hipFree(p); p = nullptr; cap = 0; own = true; }
 	template<typename T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
@@ -55,9 +56,17 @@ struct dmnd_ctx {
 	double mask_ms = 0.0;
 	double seed_ms[5] = { 0, 0, 0, 0, 0 };
 	// extension-stage statistics of the last dmnd_extend (extend_host.hip)
+	std::vector<dmnd_ctx*> aux;                // auxiliary contexts (own stream + work buffers) for concurrent sub-batches of dmnd_extend
 	std::vector<int8_t> host_cbs_buf;          // Hauser bias of the query block (host copy, parallel to the block letters)
 	double ext_stats[12] = { 0 };
 	double host_ms[3] = { 0, 0, 0 };           // host wall time inside dmnd_banded_swipe: prepare, launch+wait, unpack (DMND_TRACE)
 	int query_contexts = 1;                    // align_mode.query_contexts: 6 for blastx (basic/basic.cpp:40-60)
 	int max_target_seqs = 25;                  // config.max_target_seqs (-k), basic/config.h:55
 };
+
+// internal (not part of the C ABI)
+// banded swipe on the work buffers / stream of `work` over the blocks, bias and scoring matrix resident in `blocks`
+int dmnd_swipe_shared(dmnd_ctx* work, const dmnd_ctx* blocks, const dmnd_dp_target* items, int64_t n, int mode, uint32_t hsp_values,
+	dmnd_hsp* out, uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used);
+// k-th of `split` auxiliary contexts of c (created on first use; owned and destroyed by c)
+dmnd_ctx* aux_context(dmnd_ctx* c, int k, int split);

@@ -36,7 +36,15 @@
 #include "chain_host.h"
 #include "host_pool.h"
 
-namespace dmnd { WorkerPool& pool() { static WorkerPool p; return p; } }
+namespace dmnd {
+static thread_local int tls_pool = -1;
+void set_thread_pool(int k) { tls_pool = k; }
+WorkerPool& pool()
+{
+	static WorkerPool pools[MAX_POOLS + 1];
+	return pools[tls_pool >= 0 && tls_pool < MAX_POOLS ? tls_pool + 1 : 0];
+}
+}
 
 using namespace dmnd;
 
@@ -355,35 +363,20 @@ struct QueryState {
 
 }
 
-// The whole extension stage for one (query block, reference block) pair on the uploaded blocks. The reference's per-query
-// loop over ranking chunks (extend.cpp:289-336) becomes a batch-synchronous state machine: every pass plans the current
-// chunk of all still-active queries on the host threads and scores all of them in ONE GPU launch.
-extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata, const dmnd_seed_hit* hits, int64_t n_hits,
-	int threads, uint32_t hsp_values, dmnd_match* out, int64_t cap, int64_t* n_out,
+// Steps 2.. of the extension stage for the queries qr[qr_begin, qr_end): c = the context that owns the blocks, limits, bias
+// and statistics parameters (read only), w = the context whose stream, device work buffers and counters this range uses
+// (w == c, or one of c's auxiliary contexts when the block is processed as concurrent sub-batches).
+static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const std::vector<Range>& qr, size_t qr_begin, size_t qr_end,
+	const dmnd_seed_hit* hits, const std::vector<uint8_t>& gf, const int8_t* qdata, const int8_t* tdata, const std::vector<int8_t>& cbs,
+	int threads, uint32_t hsp_values, std::vector<dmnd_match>& out_matches,
 	uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used)
 {
-	if (!c || !qdata || !tdata || (!hits && n_hits) || !n_out) return fail(DMND_E_ARG, "dmnd_extend: NULL argument");
-	struct Total {                     // declared first = destroyed last: covers the release of all per-call state
-		std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-		~Total() { if (std::getenv("DMND_TRACE")) std::fprintf(stderr, "dmnd_extend total %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); }
-	} total_clock;
-	*n_out = 0;
-	if (transcript_used) *transcript_used = 0;
 	const std::vector<int64_t>& ql = c->limits[DMND_QUERY];
 	const std::vector<int64_t>& tl = c->limits[DMND_TARGET];
-	if (ql.size() < 2 || tl.size() < 2) return fail(DMND_E_ARG, "dmnd_extend: blocks must be uploaded with limits");
-	HostCfg h;
-	make_cfg(c, h);
-	h.max_target_seqs = c->max_target_seqs;
-	h.contexts = c->query_contexts;
 	const uint32_t C = (uint32_t)h.contexts;
-	if ((ql.size() - 1) % C != 0) return fail(DMND_E_ARG, "dmnd_extend: query block size is not a multiple of the query contexts");
-	h.ref_letters = (double)(tl.back() - tl.front() - ((int64_t)tl.size() - 1));
-	if (hsp_values == 0) hsp_values = 510;
 	const int K = h.max_target_seqs;
-	threads = std::max(1, threads);
-	for (double& x : c->ext_stats) x = 0;
-	for (double& x : c->host_ms) x = 0;
+	for (int i = 0; i < 12; ++i) if (i != 4) w->ext_stats[i] = 0;      // [4] (bias + upload) belongs to the caller
+	for (double& x : w->host_ms) x = 0;
 	auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	auto cells_of = [](const std::vector<dmnd_dp_target>& v) {
 		double s = 0;
@@ -392,34 +385,12 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	};
 	double t_mark = now();
 	double fine[16] = { 0 };          // DMND_TRACE=1: finer host timeline on stderr
-	auto lap = [&](int slot, int f = -1) { const double t = now(); c->ext_stats[slot] += t - t_mark; if (f >= 0) fine[f] += t - t_mark; t_mark = t; };
-	// 1. Hauser bias for every query, resident next to the query block
-	const std::vector<Range> qr = split_by_query(hits, n_hits, h.contexts);
-	// only queries with seed hits are ever aligned, and only their bias is ever read: the buffer lives in the context, so
-	// neither its allocation nor a 3 MB clear is paid per call (stale values of other queries are never touched)
-	std::vector<int8_t>& cbs = c->host_cbs_buf;
-	if (cbs.size() < (size_t)ql.back() + 64) cbs.assign((size_t)ql.back() + 64, 0);
-	parallel_for(qr.size(), threads, [&](size_t i, int) {
-		const uint32_t q0 = hits[qr[i].b].query / C * C;
-		for (uint32_t q = q0; q < q0 + C; ++q) {
-			const SeqRef s{ qdata + ql[q], (int)(ql[q + 1] - ql[q] - 1) };
-			if (s.len > 0) hauser_int8(h, s, cbs.data() + ql[q]);
-		}
-	});
-	if (int rc = dmnd_upload_cbs(c, cbs.data(), ql.back())) return rc;
-	lap(4, 1);
-	// 1b. gapped filter of every seed hit in one launch (only --sensitive and above; extend.cpp:205-213)
-	std::vector<uint8_t> gf;
-	c->gf_ms = 0;
-	if (c->gapped_filter_evalue > 0.0 && n_hits > 0) {
-		gf.resize((size_t)n_hits);
-		if (int rc = dmnd_gapped_filter(c, hits, n_hits, 1, gf.data(), nullptr)) return rc;
-	}
-	lap(4, 2);
+	auto lap = [&](int slot, int f = -1) { const double t = now(); w->ext_stats[slot] += t - t_mark; if (f >= 0) fine[f] += t - t_mark; t_mark = t; };
 	// 2. load_hits for every query
-	std::vector<QueryState> qs(qr.size());
-	parallel_for(qr.size(), threads, [&](size_t i, int) {
-		load_query(h, qs[i].w, hits[qr[i].b].query / (uint32_t)h.contexts, hits + qr[i].b, hits + qr[i].e, gf.empty() ? nullptr : gf.data() + qr[i].b, tl.data(), (int64_t)tl.size() - 1);
+	std::vector<QueryState> qs(qr_end - qr_begin);
+	parallel_for(qs.size(), threads, [&](size_t i, int) {
+		const Range& r = qr[qr_begin + i];
+		load_query(h, qs[i].w, hits[r.b].query / (uint32_t)h.contexts, hits + r.b, hits + r.e, gf.empty() ? nullptr : gf.data() + r.b, tl.data(), (int64_t)tl.size() - 1);
 		if (qs[i].w.order.empty()) qs[i].done = true;
 	});
 	std::vector<ChainWorkspace> ws((size_t)threads);
@@ -452,9 +423,9 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 			lap(5, 4);
 			res.assign(items.size(), dmnd_hsp());
 			if (!items.empty()) {
-				if (int rc = dmnd_banded_swipe(c, items.data(), (int64_t)items.size(), DMND_SWIPE_SCORE, 0, res.data(), nullptr, 0, nullptr)) return rc;
-				sw1 += c->swipe_ms;
-				c->ext_stats[0] += (double)items.size(); c->ext_stats[2] += cells_of(items);
+				if (int rc = dmnd_swipe_shared(w, c, items.data(), (int64_t)items.size(), DMND_SWIPE_SCORE, 0, res.data(), nullptr, 0, nullptr)) return rc;
+				sw1 += w->swipe_ms;
+				w->ext_stats[0] += (double)items.size(); w->ext_stats[2] += cells_of(items);
 			}
 			lap(6, 5);
 			parallel_for(active.size(), threads, [&](size_t ai, int) {
@@ -523,21 +494,21 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 			int64_t arena_cap = transcript ? transcript_cap - used : 0;
 			res.assign(it_tb.size(), dmnd_hsp());
 			int64_t u = 0;
-			if (int rc = dmnd_banded_swipe(c, it_tb.data(), (int64_t)it_tb.size(), DMND_SWIPE_TRACEBACK, hsp_values, res.data(), arena, arena_cap, &u)) return rc;
+			if (int rc = dmnd_swipe_shared(w, c, it_tb.data(), (int64_t)it_tb.size(), DMND_SWIPE_TRACEBACK, hsp_values, res.data(), arena, arena_cap, &u)) return rc;
 			for (size_t x = 0; x < ref_tb.size(); ++x) {
 				r2[ref_tb[x].q][ref_tb[x].k] = res[x];
 				if (transcript) r2[ref_tb[x].q][ref_tb[x].k].transcript_off += used; else r2[ref_tb[x].q][ref_tb[x].k].transcript_off = -1;
 			}
 			if (transcript) used += u;
-			sw2 += c->swipe_ms; tb2 += c->traceback_ms;
+			sw2 += w->swipe_ms; tb2 += w->traceback_ms;
 		}
 		if (!it_st.empty()) {
 			res.assign(it_st.size(), dmnd_hsp());
-			if (int rc = dmnd_banded_swipe(c, it_st.data(), (int64_t)it_st.size(), DMND_SWIPE_STATS, hsp_values, res.data(), nullptr, 0, nullptr)) return rc;
+			if (int rc = dmnd_swipe_shared(w, c, it_st.data(), (int64_t)it_st.size(), DMND_SWIPE_STATS, hsp_values, res.data(), nullptr, 0, nullptr)) return rc;
 			for (size_t x = 0; x < ref_st.size(); ++x) { r2[ref_st[x].q][ref_st[x].k] = res[x]; r2[ref_st[x].q][ref_st[x].k].transcript_len = 0; r2[ref_st[x].q][ref_st[x].k].transcript_off = -1; }
-			sw2 += c->swipe_ms;
+			sw2 += w->swipe_ms;
 		}
-		c->ext_stats[1] += (double)(it_tb.size() + it_st.size()); c->ext_stats[3] += cells_of(it_tb) + cells_of(it_st);
+		w->ext_stats[1] += (double)(it_tb.size() + it_st.size()); w->ext_stats[3] += cells_of(it_tb) + cells_of(it_st);
 		lap(8, 8);
 		parallel_for(batch.size(), threads, [&](size_t bi, int) {
 			const size_t i = batch[bi];
@@ -569,8 +540,8 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 		});
 		lap(7, 9);
 	}
-	c->swipe_ms = sw1 + sw2; c->traceback_ms = tb2;
-	c->ext_stats[9] = sw1; c->ext_stats[10] = sw2; c->ext_stats[11] = tb2;
+	w->swipe_ms = sw1 + sw2; w->traceback_ms = tb2;
+	w->ext_stats[9] = sw1; w->ext_stats[10] = sw2; w->ext_stats[11] = tb2;
 	if (transcript_used) *transcript_used = transcript ? used : 0;
 	// final culling(matches, cfg) per query (extend.cpp:341) -> records in query order; sorting, copying out and releasing the
 	// per-query state (tens of thousands of small blocks: serial frees cost ~3 ms on C2) all run on the worker threads
@@ -586,22 +557,130 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 			}
 		});
 		for (size_t i = 0; i < qs.size(); ++i) out_off[i + 1] += out_off[i];
-		const int64_t total = out_off[qs.size()];
+		out_matches.resize((size_t)out_off[qs.size()]);
 		parallel_for(n_chunks, threads, [&](size_t ci, int) {
 			for (size_t i = ci * chunk; i < std::min(qs.size(), (ci + 1) * chunk); ++i) {
-				if (out && total <= cap) std::copy(qs[i].matches.begin(), qs[i].matches.end(), out + out_off[i]);
+				std::copy(qs[i].matches.begin(), qs[i].matches.end(), out_matches.begin() + out_off[i]);
 				QueryState empty;
 				std::swap(qs[i], empty);
 			}
 		});
 	}
-	const int64_t n = out_off[qs.size()];
-	*n_out = n;
 	lap(7, 10);
 	if (std::getenv("DMND_TRACE"))
-		std::fprintf(stderr, "dmnd_extend ms: hauser+upload %.2f gapped_filter %.2f load %.2f plan %.2f swipe1 %.2f post1 %.2f build2 %.2f swipe2 %.2f post2 %.2f final %.2f | swipe host: prep %.2f run %.2f post %.2f\n",
-			fine[1], fine[2], fine[3], fine[4], fine[5], fine[6], fine[7], fine[8], fine[9], fine[10], c->host_ms[0], c->host_ms[1], c->host_ms[2]);
+		std::fprintf(stderr, "dmnd_extend[%zu queries] ms: load %.2f plan %.2f swipe1 %.2f post1 %.2f build2 %.2f swipe2 %.2f post2 %.2f final %.2f | swipe host: prep %.2f run %.2f post %.2f\n",
+			qs.size(), fine[3], fine[4], fine[5], fine[6], fine[7], fine[8], fine[9], fine[10], w->host_ms[0], w->host_ms[1], w->host_ms[2]);
+	return DMND_OK;
+}
+
+// The whole extension stage for one (query block, reference block) pair on the uploaded blocks. The reference's per-query
+// loop over ranking chunks (extend.cpp:289-336) becomes a batch-synchronous state machine: every pass plans the current
+// chunk of all still-active queries on the host threads and scores all of them in ONE GPU launch.
+extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata, const dmnd_seed_hit* hits, int64_t n_hits,
+	int threads, uint32_t hsp_values, dmnd_match* out, int64_t cap, int64_t* n_out,
+	uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used)
+{
+	if (!c || !qdata || !tdata || (!hits && n_hits) || !n_out) return fail(DMND_E_ARG, "dmnd_extend: NULL argument");
+	struct Total {                     // declared first = destroyed last: covers the release of all per-call state
+		std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+		~Total() { if (std::getenv("DMND_TRACE")) std::fprintf(stderr, "dmnd_extend total %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); }
+	} total_clock;
+	*n_out = 0;
+	if (transcript_used) *transcript_used = 0;
+	const std::vector<int64_t>& ql = c->limits[DMND_QUERY];
+	const std::vector<int64_t>& tl = c->limits[DMND_TARGET];
+	if (ql.size() < 2 || tl.size() < 2) return fail(DMND_E_ARG, "dmnd_extend: blocks must be uploaded with limits");
+	HostCfg h;
+	make_cfg(c, h);
+	h.max_target_seqs = c->max_target_seqs;
+	h.contexts = c->query_contexts;
+	const uint32_t C = (uint32_t)h.contexts;
+	if ((ql.size() - 1) % C != 0) return fail(DMND_E_ARG, "dmnd_extend: query block size is not a multiple of the query contexts");
+	h.ref_letters = (double)(tl.back() - tl.front() - ((int64_t)tl.size() - 1));
+	if (hsp_values == 0) hsp_values = 510;
+	threads = std::max(1, threads);
+	for (double& x : c->ext_stats) x = 0;
+	for (double& x : c->host_ms) x = 0;
+	auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	double t_mark = now();
+	double fine[16] = { 0 };          // DMND_TRACE=1: finer host timeline on stderr
+	auto lap = [&](int slot, int f = -1) { const double t = now(); c->ext_stats[slot] += t - t_mark; if (f >= 0) fine[f] += t - t_mark; t_mark = t; };
+	// 1. Hauser bias for every query, resident next to the query block
+	const std::vector<Range> qr = split_by_query(hits, n_hits, h.contexts);
+	// only queries with seed hits are ever aligned, and only their bias is ever read: the buffer lives in the context, so
+	// neither its allocation nor a 3 MB clear is paid per call (stale values of other queries are never touched)
+	std::vector<int8_t>& cbs = c->host_cbs_buf;
+	if (cbs.size() < (size_t)ql.back() + 64) cbs.assign((size_t)ql.back() + 64, 0);
+	parallel_for(qr.size(), threads, [&](size_t i, int) {
+		const uint32_t q0 = hits[qr[i].b].query / C * C;
+		for (uint32_t q = q0; q < q0 + C; ++q) {
+			const SeqRef s{ qdata + ql[q], (int)(ql[q + 1] - ql[q] - 1) };
+			if (s.len > 0) hauser_int8(h, s, cbs.data() + ql[q]);
+		}
+	});
+	if (int rc = dmnd_upload_cbs(c, cbs.data(), ql.back())) return rc;
+	lap(4, 1);
+	// 1b. gapped filter of every seed hit in one launch (only --sensitive and above; extend.cpp:205-213)
+	std::vector<uint8_t> gf;
+	c->gf_ms = 0;
+	if (c->gapped_filter_evalue > 0.0 && n_hits > 0) {
+		gf.resize((size_t)n_hits);
+		if (int rc = dmnd_gapped_filter(c, hits, n_hits, 1, gf.data(), nullptr)) return rc;
+	}
+	lap(4, 2);
+	if (std::getenv("DMND_TRACE")) std::fprintf(stderr, "dmnd_extend ms: hauser+upload %.2f gapped_filter %.2f\n", fine[1], fine[2]);
+	// 2.. : the queries are processed as `split` concurrent sub-batches, each on its own host thread, HIP stream and device work
+	// buffers (auxiliary contexts): while one sub-batch waits for its swipe kernels the others chain, cull and pack on the
+	// host. Results are concatenated in query order, so the output does not depend on the split.
+	int split = 1;
+	if (!transcript && qr.size() >= 2048) split = 2;
+	if (const char* e = std::getenv("DMND_EXTEND_SPLIT")) split = std::max(1, std::min((int)MAX_POOLS, std::atoi(e)));
+	if (transcript || qr.size() < (size_t)split * 2) split = 1;
+	std::vector<std::vector<dmnd_match>> parts((size_t)split);
+	std::vector<int> rcs((size_t)split, DMND_OK);
+	std::vector<std::string> errs((size_t)split);
+	if (split == 1) {
+		rcs[0] = extend_range(c, c, h, qr, 0, qr.size(), hits, gf, qdata, tdata, cbs, threads, hsp_values, parts[0], transcript, transcript_cap, transcript_used);
+	}
+	else {
+		const double stats4 = c->ext_stats[4];
+		std::vector<dmnd_ctx*> work((size_t)split);
+		for (int k = 0; k < split; ++k) {
+			work[(size_t)k] = aux_context(c, k, split);
+			if (!work[(size_t)k]) return fail(DMND_E_DEVICE, "dmnd_extend: cannot create an auxiliary context");
+		}
+		std::vector<std::thread> th;
+		const int sub_threads = std::max(1, threads / split);
+		for (int k = 0; k < split; ++k)
+			th.emplace_back([&, k] {
+				set_thread_pool(k);
+				(void)hipSetDevice(c->device);
+				const size_t b = qr.size() * (size_t)k / (size_t)split, e = qr.size() * (size_t)(k + 1) / (size_t)split;
+				rcs[(size_t)k] = extend_range(c, work[(size_t)k], h, qr, b, e, hits, gf, qdata, tdata, cbs, sub_threads, hsp_values, parts[(size_t)k], nullptr, 0, nullptr);
+				if (rcs[(size_t)k] != DMND_OK) errs[(size_t)k] = dmnd_last_error();
+				set_thread_pool(-1);
+			});
+		for (auto& t : th) t.join();
+		// statistics of the call: counts and device times add up, host wall times are those of the slowest sub-batch
+		for (double& x : c->ext_stats) x = 0;
+		c->ext_stats[4] = stats4;
+		for (int k = 0; k < split; ++k) {
+			const dmnd_ctx* w = work[(size_t)k];
+			for (int i : { 0, 1, 2, 3, 9, 10, 11 }) c->ext_stats[i] += w->ext_stats[i];
+			for (int i : { 5, 6, 7, 8 }) c->ext_stats[i] = std::max(c->ext_stats[i], w->ext_stats[i]);
+		}
+		c->swipe_ms = c->ext_stats[9] + c->ext_stats[10]; c->traceback_ms = c->ext_stats[11];
+	}
+	for (int k = 0; k < split; ++k)
+		if (rcs[(size_t)k] != DMND_OK) return split == 1 ? rcs[0] : fail(rcs[(size_t)k], errs[(size_t)k]);
+	int64_t n = 0;
+	for (const auto& v : parts) n += (int64_t)v.size();
+	*n_out = n;
 	if (n > cap) return fail(DMND_E_CAP, "dmnd_extend: match buffer too small");
+	if (out) {
+		int64_t off = 0;
+		for (const auto& v : parts) { std::copy(v.begin(), v.end(), out + off); off += (int64_t)v.size(); }
+	}
 	return DMND_OK;
 }
 

@@ -81,7 +81,11 @@ private:
 	bool stop_ = false;
 };
 
-WorkerPool& pool();      // defined once, in extend_host.hip
+enum { MAX_POOLS = 4 };
+// pool(): the worker pool of the calling thread. Threads that drive one of the concurrent sub-batches of dmnd_extend select
+// their own pool with set_thread_pool(k) (k < MAX_POOLS); every other thread shares the default pool. Defined in extend_host.hip.
+WorkerPool& pool();
+void set_thread_pool(int k);
 
 template<typename F>
 void parallel_for(size_t n, int threads, F f)
