@@ -367,7 +367,7 @@ struct QueryState {
 // and statistics parameters (read only), w = the context whose stream, device work buffers and counters this range uses
 // (w == c, or one of c's auxiliary contexts when the block is processed as concurrent sub-batches).
 static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const std::vector<Range>& qr, size_t qr_begin, size_t qr_end,
-	const dmnd_seed_hit* hits, const std::vector<uint8_t>& gf, const int8_t* qdata, const int8_t* tdata, const std::vector<int8_t>& cbs,
+	const dmnd_seed_hit* hits, const std::vector<uint8_t>& gf, const int8_t* qdata, const int8_t* tdata, std::vector<int8_t>& cbs, bool compute_bias,
 	int threads, uint32_t hsp_values, std::vector<dmnd_match>& out_matches,
 	uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used)
 {
@@ -375,7 +375,7 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 	const std::vector<int64_t>& tl = c->limits[DMND_TARGET];
 	const uint32_t C = (uint32_t)h.contexts;
 	const int K = h.max_target_seqs;
-	for (int i = 0; i < 12; ++i) if (i != 4) w->ext_stats[i] = 0;      // [4] (bias + upload) belongs to the caller
+	for (int i = 0; i < 12; ++i) if (i != 4 || w != c) w->ext_stats[i] = 0;      // [4] (bias + upload) of the caller's prelude is kept
 	for (double& x : w->host_ms) x = 0;
 	auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	auto cells_of = [](const std::vector<dmnd_dp_target>& v) {
@@ -386,6 +386,20 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 	double t_mark = now();
 	double fine[16] = { 0 };          // DMND_TRACE=1: finer host timeline on stderr
 	auto lap = [&](int slot, int f = -1) { const double t = now(); w->ext_stats[slot] += t - t_mark; if (f >= 0) fine[f] += t - t_mark; t_mark = t; };
+	// 1. (unless done by the caller) Hauser bias of this range's queries + upload of their slice of the bias buffer
+	if (compute_bias && qr_end > qr_begin) {
+		parallel_for(qr_end - qr_begin, threads, [&](size_t i, int) {
+			const uint32_t q0 = hits[qr[qr_begin + i].b].query / C * C;
+			for (uint32_t q = q0; q < q0 + C; ++q) {
+				const SeqRef s{ qdata + ql[q], (int)(ql[q + 1] - ql[q] - 1) };
+				if (s.len > 0) hauser_int8(h, s, cbs.data() + ql[q]);
+			}
+		});
+		const uint32_t qa = hits[qr[qr_begin].b].query / C * C, qb = hits[qr[qr_end - 1].b].query / C * C + C;      // contiguous in the block
+		HIP_TRY(hipMemcpyAsync(c->cbs.as<int8_t>() + ql[qa], cbs.data() + ql[qa], (size_t)(ql[qb] - ql[qa]), hipMemcpyHostToDevice, w->stream));
+		HIP_TRY(hipStreamSynchronize(w->stream));
+	}
+	lap(4, 1);
 	// 2. load_hits for every query
 	std::vector<QueryState> qs(qr_end - qr_begin);
 	parallel_for(qs.size(), threads, [&](size_t i, int) {
@@ -568,8 +582,8 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 	}
 	lap(7, 10);
 	if (std::getenv("DMND_TRACE"))
-		std::fprintf(stderr, "dmnd_extend[%zu queries] ms: load %.2f plan %.2f swipe1 %.2f post1 %.2f build2 %.2f swipe2 %.2f post2 %.2f final %.2f | swipe host: prep %.2f run %.2f post %.2f\n",
-			qs.size(), fine[3], fine[4], fine[5], fine[6], fine[7], fine[8], fine[9], fine[10], w->host_ms[0], w->host_ms[1], w->host_ms[2]);
+		std::fprintf(stderr, "dmnd_extend[%zu queries] ms: bias %.2f load %.2f plan %.2f swipe1 %.2f post1 %.2f build2 %.2f swipe2 %.2f post2 %.2f final %.2f | swipe host: prep %.2f run %.2f post %.2f\n",
+			qs.size(), fine[1], fine[3], fine[4], fine[5], fine[6], fine[7], fine[8], fine[9], fine[10], w->host_ms[0], w->host_ms[1], w->host_ms[2]);
 	return DMND_OK;
 }
 
@@ -611,14 +625,24 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	// neither its allocation nor a 3 MB clear is paid per call (stale values of other queries are never touched)
 	std::vector<int8_t>& cbs = c->host_cbs_buf;
 	if (cbs.size() < (size_t)ql.back() + 64) cbs.assign((size_t)ql.back() + 64, 0);
-	parallel_for(qr.size(), threads, [&](size_t i, int) {
-		const uint32_t q0 = hits[qr[i].b].query / C * C;
-		for (uint32_t q = q0; q < q0 + C; ++q) {
-			const SeqRef s{ qdata + ql[q], (int)(ql[q + 1] - ql[q] - 1) };
-			if (s.len > 0) hauser_int8(h, s, cbs.data() + ql[q]);
-		}
-	});
-	if (int rc = dmnd_upload_cbs(c, cbs.data(), ql.back())) return rc;
+	// With the gapped filter on, the bias of every query is needed before the sub-batches start; otherwise every sub-batch
+	// computes and uploads the slice of its own queries (on its own stream), overlapped with the other sub-batches.
+	const bool bias_in_prelude = c->gapped_filter_evalue > 0.0;
+	if (bias_in_prelude) {
+		parallel_for(qr.size(), threads, [&](size_t i, int) {
+			const uint32_t q0 = hits[qr[i].b].query / C * C;
+			for (uint32_t q = q0; q < q0 + C; ++q) {
+				const SeqRef s{ qdata + ql[q], (int)(ql[q + 1] - ql[q] - 1) };
+				if (s.len > 0) hauser_int8(h, s, cbs.data() + ql[q]);
+			}
+		});
+		if (int rc = dmnd_upload_cbs(c, cbs.data(), ql.back())) return rc;
+	}
+	else {
+		HIP_TRY(hipSetDevice(c->device));
+		if (int rc = c->cbs.ensure((size_t)ql.back() + 256)) return rc;
+		c->cbs_len = ql.back();
+	}
 	lap(4, 1);
 	// 1b. gapped filter of every seed hit in one launch (only --sensitive and above; extend.cpp:205-213)
 	std::vector<uint8_t> gf;
@@ -640,7 +664,7 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	std::vector<int> rcs((size_t)split, DMND_OK);
 	std::vector<std::string> errs((size_t)split);
 	if (split == 1) {
-		rcs[0] = extend_range(c, c, h, qr, 0, qr.size(), hits, gf, qdata, tdata, cbs, threads, hsp_values, parts[0], transcript, transcript_cap, transcript_used);
+		rcs[0] = extend_range(c, c, h, qr, 0, qr.size(), hits, gf, qdata, tdata, cbs, !bias_in_prelude, threads, hsp_values, parts[0], transcript, transcript_cap, transcript_used);
 	}
 	else {
 		const double stats4 = c->ext_stats[4];
@@ -656,7 +680,7 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 				set_thread_pool(k);
 				(void)hipSetDevice(c->device);
 				const size_t b = qr.size() * (size_t)k / (size_t)split, e = qr.size() * (size_t)(k + 1) / (size_t)split;
-				rcs[(size_t)k] = extend_range(c, work[(size_t)k], h, qr, b, e, hits, gf, qdata, tdata, cbs, sub_threads, hsp_values, parts[(size_t)k], nullptr, 0, nullptr);
+				rcs[(size_t)k] = extend_range(c, work[(size_t)k], h, qr, b, e, hits, gf, qdata, tdata, cbs, !bias_in_prelude, sub_threads, hsp_values, parts[(size_t)k], nullptr, 0, nullptr);
 				if (rcs[(size_t)k] != DMND_OK) errs[(size_t)k] = dmnd_last_error();
 				set_thread_pool(-1);
 			});
@@ -668,6 +692,7 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 			const dmnd_ctx* w = work[(size_t)k];
 			for (int i : { 0, 1, 2, 3, 9, 10, 11 }) c->ext_stats[i] += w->ext_stats[i];
 			for (int i : { 5, 6, 7, 8 }) c->ext_stats[i] = std::max(c->ext_stats[i], w->ext_stats[i]);
+			c->ext_stats[4] = std::max(c->ext_stats[4], stats4 + w->ext_stats[4]);
 		}
 		c->swipe_ms = c->ext_stats[9] + c->ext_stats[10]; c->traceback_ms = c->ext_stats[11];
 	}
