@@ -61,6 +61,7 @@ const double BLOSUM62_BG[20] = { 7.4216205067993410e-02, 5.1614486141284638e-02,
 struct HostCfg {
 	ScoreTable S;
 	double background_scores[20];
+	alignas(32) int16_t rows[32][24];    // score matrix rows (row = letter, 20 residue columns padded to 24) for the vectorised window sums
 	int cbs_window = 40;                 // config.cbs_window
 	int max_target_seqs = 25;
 	int64_t max_swipe_dp = 1000000;      // config.max_swipe_dp
@@ -71,7 +72,7 @@ struct HostCfg {
 
 void make_cfg(const dmnd_ctx* c, HostCfg& h)
 {
-	for (int i = 0; i < 32 * 32; ++i) h.S.m[i] = c->params.matrix8[i];
+	for (int i = 0; i < 32 * 32; ++i) { h.S.m[i] = c->params.matrix8[i]; if ((i & 31) < 24) h.rows[i >> 5][i & 31] = (i & 31) < 20 ? c->params.matrix8[i] : 0; }
 	h.S.gap_open = c->params.gap_open; h.S.gap_extend = c->params.gap_extend;
 	for (int i = 0; i < 20; ++i) {                     // ScoreMatrix::init_background_scores, score_matrix.cpp:241-248
 		h.background_scores[i] = 0;
@@ -80,23 +81,27 @@ void make_cfg(const dmnd_ctx* c, HostCfg& h)
 }
 
 // HauserCorrection(seq): sliding-window expected-score bias per query position, rounded to int8
+// (stats/hauser_correction.cpp:28-107). The window sums of all 20 residue scores are kept as one int16[24] vector and
+// updated with the matrix row of the letter entering / leaving the window (vectorised by the compiler).
 void hauser_int8(const HostCfg& h, const SeqRef& seq, int8_t* out)
 {
 	const unsigned l = (unsigned)seq.len, window = (unsigned)h.cbs_window, window_half = std::min(window / 2, l - 1);
-	std::vector<float> f(l, 0.0f);
-	int scores[20] = { 0 };
-	auto add = [&](int letter, int sign) { for (int i = 0; i < 20; ++i) scores[i] += sign * h.S.at(letter, i); };
+	// 16-bit sums are exact: at most 41 window letters x |score| <= 15
+	alignas(32) int16_t scores[24] = { 0 };
+	auto add = [&](int letter) { const int16_t* r = h.rows[letter]; for (int i = 0; i < 24; ++i) scores[i] = (int16_t)(scores[i] + r[i]); };
+	auto sub = [&](int letter) { const int16_t* r = h.rows[letter]; for (int i = 0; i < 24; ++i) scores[i] = (int16_t)(scores[i] - r[i]); };
 	auto emit = [&](unsigned m, unsigned n) {
 		const int r = seq[(int)m];
-		if (r < 20) f[m] = (float)h.background_scores[r] - float(scores[r] - h.S.at(r, r)) / (n - 1);
+		float f = 0.0f;
+		if (r < 20) f = (float)h.background_scores[r] - float((int)scores[r] - (int)h.rows[r][r]) / (n - 1);
+		out[m] = (int8_t)(f < 0.0f ? f - 0.5f : f + 0.5f);
 	};
 	unsigned n = 0, hh = 0, m = 0, t = 0;
-	while (n < window_half && hh < l) { ++n; add(seq[(int)hh], 1); ++hh; }
-	while (n < window + 1 && hh < l) { ++n; add(seq[(int)hh], 1); emit(m, n); ++hh; ++m; }
-	while (hh < l) { add(seq[(int)hh], 1); add(seq[(int)t], -1); emit(m, n); ++hh; ++t; ++m; }
-	while (m < l && n > window_half + 1) { --n; add(seq[(int)t], -1); emit(m, n); ++t; ++m; }
+	while (n < window_half && hh < l) { ++n; add(seq[(int)hh]); ++hh; }
+	while (n < window + 1 && hh < l) { ++n; add(seq[(int)hh]); emit(m, n); ++hh; ++m; }
+	while (hh < l) { add(seq[(int)hh]); sub(seq[(int)t]); emit(m, n); ++hh; ++t; ++m; }
+	while (m < l && n > window_half + 1) { --n; sub(seq[(int)t]); emit(m, n); ++t; ++m; }
 	while (m < l) { emit(m, n); ++m; }
-	for (unsigned i = 0; i < l; ++i) out[i] = (int8_t)(f[i] < 0.0f ? f[i] - 0.5f : f[i] + 0.5f);
 }
 
 int band_for(int len, bool fast)                            // Extension::band, gapped_score.cpp:41-73
