@@ -199,7 +199,7 @@ def main():
                                    "round2": ext["round2_cells"] / max(ext["round2_swipe_kernel_ms"], 1e-9) / 1e6},
             "wall_ms_last_step": state["wall_ms"],
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # reported on rank 0 at N=1 only
             ref = cpu_baseline_reference(args)
             if ref is not None:
                 out["cpu_baseline"] = ref
