@@ -64,6 +64,39 @@ DMND_HD bool seed_at(const SeedParams& c, int sid, const int8_t* p, uint64_t& ou
 	return true;
 }
 
+// Table key of a seed on the GPU. For shapes of length <= 16 over an alphabet of <= 15 classes the key is the window's
+// class nibbles at the care positions (nibble i = class of letter i, 0 elsewhere): the reference stream obtains it with one
+// funnel shift and one AND per window instead of a Horner polynomial over the care positions. It is an injective function
+// of the seed, which is all the join needs; the seed VALUE (its low bits select the seed partition / index chunk) is
+// recovered with seed_of_key where it matters (mask and pair kernels). Other shapes use the seed value itself as the key.
+DMND_HD bool seed_nibble_mode(const SeedParams& c, int sid) { return c.shape_len[sid] <= 16 && c.reduction_size <= 15; }
+
+DMND_HD bool seed_key_at(const SeedParams& c, int sid, const int8_t* p, uint64_t& out)
+{
+	if (!seed_nibble_mode(c, sid)) return seed_at(c, sid, p, out);
+	const int len = c.shape_len[sid];
+	for (int i = 0; i < len; ++i)
+		if ((p[i] & LETTER_MASK) == L_DELIM) return false;
+	uint64_t k = 0;
+	for (int j = 0; j < c.shape_weight[sid]; ++j) {
+		const int pos = c.shape_pos[sid][j];
+		const int r = c.reduction[p[pos] & LETTER_MASK];
+		if (r == L_MASK) return false;
+		k |= (uint64_t)r << (4 * pos);
+	}
+	out = k;
+	return true;
+}
+
+DMND_HD uint64_t seed_of_key(const SeedParams& c, int sid, uint64_t key)
+{
+	if (!seed_nibble_mode(c, sid)) return key;
+	uint64_t s = 0;
+	for (int j = 0; j < c.shape_weight[sid]; ++j)
+		s = s * (uint64_t)c.reduction_size + ((key >> (4 * c.shape_pos[sid][j])) & 15u);
+	return s;
+}
+
 // Shape::set_seed on unreduced letters (shape.h:72-96), used by verify_hit
 DMND_HD bool seed_unreduced(const SeedParams& c, int sid, const int8_t* p, uint64_t& out)
 {

@@ -37,8 +37,8 @@ __global__ void seed_index_kernel(SeedArgs a, int sid)
 {
 	const int64_t p = a.q_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (p >= a.q_end) return;
-	uint64_t seed;
-	if (!seed_at(a.params, sid, a.qdata + p, seed)) return;
+	uint64_t seed;                                     // table key (seed_key_at)
+	if (!seed_key_at(a.params, sid, a.qdata + p, seed)) return;
 	const uint64_t h = seed_hash(seed);
 	atomicOr(&a.bitmap[(h >> 32) & a.bitmap_mask], 1u << (h >> 59));
 	atomicOr(&a.bitmap1[(uint32_t)(h >> 10) & a.bitmap1_mask], (1u << (h & 31)) | (1u << ((h >> 5) & 31)));   // 2 bits, one word
@@ -71,7 +71,7 @@ __global__ void seed_stream_kernel(SeedArgs a, int sid)
 	const int64_t p = a.t_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	uint64_t seed = 0, slot = 0;
 	bool found = false;
-	if (p < a.t_end && seed_at(a.params, sid, a.tdata + p, seed)) {
+	if (p < a.t_end && seed_key_at(a.params, sid, a.tdata + p, seed)) {
 		slot = seed_hash(seed) & a.slot_mask;
 		for (;;) {
 			const uint64_t k = a.keys[slot];
@@ -91,9 +91,9 @@ __global__ void seed_stream_kernel(SeedArgs a, int sid)
 
 // ---- fast reference stream: 16 positions per thread -------------------------------------------------------------
 // Each thread loads 32 consecutive letters with two aligned 16-byte loads (coalesced: a wavefront reads 1 KiB + a
-// 16-byte halo that hits L1), reduces them to 4-bit classes packed in two 64-bit registers, and evaluates the seed
-// polynomial of its 16 window starts with bit-field extracts at the shape's (wave-uniform) care positions -- no LDS,
-// no per-position byte loads. A 2^k-bit Bloom-style bitmap of the query seeds (built by seed_index_kernel, resident
+// 16-byte halo that hits L1), reduces them to 4-bit classes packed in two 64-bit registers, and forms the table key
+// of each of its 16 window starts as (class nibbles >> 4 * start) & care-position mask (seed_key_at) -- no LDS, no
+// per-position byte loads, no polynomial. A 2^k-bit Bloom-style bitmap of the query seeds (built by seed_index_kernel, resident
 // in every XCD's L2) rejects most reference seeds before the open-addressing table in HBM/Infinity Cache is touched.
 // Preconditions (checked by the host): shape length <= 16, reduction size <= 15.
 __device__ __forceinline__ uint32_t reduce4(uint32_t letter, uint64_t map_lo, uint64_t map_hi)
@@ -101,8 +101,7 @@ __device__ __forceinline__ uint32_t reduce4(uint32_t letter, uint64_t map_lo, ui
 	const uint64_t m = (letter & 16) ? map_hi : map_lo;
 	return (uint32_t)(m >> ((letter & 15) * 4)) & 15u;
 }
-template<bool RADIX10>
-__global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int sid, uint64_t map_lo, uint64_t map_hi, int64_t base, int lo_digits, uint32_t lo_scale)
+__global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int sid, uint64_t map_lo, uint64_t map_hi, int64_t base, uint64_t care64)
 {
 	// Joined positions are staged in LDS and flushed with ONE atomic on the shared counter per workgroup: an atomicAdd per
 	// match on a single address serialises at ~4.5 ns each (measured: 3.3 M matches = 14.8 ms per shape in default mode,
@@ -130,39 +129,19 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 		delim |= (l == L_DELIM ? 1u : 0u) << j;
 		bad |= (c == 15u ? 1u : 0u) << j;
 	}
-	const int len = a.params.shape_len[sid], weight = a.params.shape_weight[sid];
+	const int len = a.params.shape_len[sid];
 	const uint32_t care = a.params.shape_mask[sid], span = (1u << len) - 1;      // len <= 16
-	const uint32_t radix = (uint32_t)a.params.reduction_size;
 
-	// The 16 window starts are handled as two batches of 8 (register pressure). Per batch: outer loop over the
-	// (wave-uniform) care positions, inner loop unrolled over the window starts; the seed is kept as
-	// hi * radix^lo_digits + lo in 32-bit accumulators; then the 8 bitmap probes are issued back to back.
-	const int hi_digits = weight - lo_digits;
+	// The 16 window starts are handled as two batches of 8 (register pressure). The table key of a window is its 16
+	// class nibbles ANDed with the care-position mask (seed_key_at): one funnel shift + one AND per window.
 	const int64_t first = a.t_begin - p0, last = a.t_end - p0;                 // valid window starts: first <= i < last
 #pragma unroll 1
 	for (int half = 0; half < 2; ++half) {
-		uint32_t hi[8], lo[8];
+		uint64_t key[8];
 #pragma unroll
-		for (int i = 0; i < 8; ++i) { hi[i] = 0; lo[i] = 0; }
-		for (int k = 0; k < weight; ++k) {
-			const int sh = (a.params.shape_pos[sid][k] + 8 * half) * 4;          // uniform, 0..92
-			// low 32 bits of (codes128 >> sh): nibble i = class at window start (8*half + i), care position k
-			const uint32_t win = sh == 0 ? (uint32_t)codes[0]
-				: sh < 64 ? (uint32_t)((codes[0] >> sh) | (codes[1] << (64 - sh))) : (uint32_t)(codes[1] >> (sh - 64));
-			if (k < hi_digits) {
-#pragma unroll
-				for (int i = 0; i < 8; ++i) {
-					const uint32_t c = (win >> (i * 4)) & 15u;
-					hi[i] = RADIX10 ? ((hi[i] << 2) + hi[i]) * 2 + c : hi[i] * radix + c;
-				}
-			}
-			else {
-#pragma unroll
-				for (int i = 0; i < 8; ++i) {
-					const uint32_t c = (win >> (i * 4)) & 15u;
-					lo[i] = RADIX10 ? ((lo[i] << 2) + lo[i]) * 2 + c : lo[i] * radix + c;
-				}
-			}
+		for (int i = 0; i < 8; ++i) {
+			const int sh = (8 * half + i) * 4;                                   // 0..60
+			key[i] = (sh == 0 ? codes[0] : (codes[0] >> sh) | (codes[1] << (64 - sh))) & care64;
 		}
 		uint32_t pos_mask = 0;
 		uint32_t word[8];
@@ -170,7 +149,7 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 		for (int i = 0; i < 8; ++i) {
 			const int w0 = 8 * half + i;
 			const bool ok = w0 >= first && w0 < last && (((delim >> w0) & span) | ((bad >> w0) & care)) == 0;
-			const uint64_t h = seed_hash((uint64_t)hi[i] * lo_scale + lo[i]);
+			const uint64_t h = seed_hash(key[i]);
 			const uint32_t bw = ok ? a.bitmap1[(uint32_t)(h >> 10) & a.bitmap1_mask] : 0u;
 			word[i] = (bw >> ((uint32_t)h & 31)) & (bw >> ((uint32_t)(h >> 5) & 31));
 		}
@@ -180,10 +159,9 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 		while (pos_mask) {
 			const int i = __builtin_ctz(pos_mask);
 			pos_mask &= pos_mask - 1;
-			uint32_t h_i = 0, l_i = 0;
+			uint64_t seed = 0;
 #pragma unroll
-			for (int x = 0; x < 8; ++x) if (x == i) { h_i = hi[x]; l_i = lo[x]; }
-			const uint64_t seed = (uint64_t)h_i * lo_scale + l_i;
+			for (int x = 0; x < 8; ++x) if (x == i) seed = key[x];
 			const uint64_t hh = seed_hash(seed);
 			uint64_t slot = hh & a.slot_mask;
 			bool found = false;
@@ -227,7 +205,7 @@ __global__ void seed_mask_kernel(SeedArgs a, int sid)
 		first = x < first ? x : first;
 	if (seed_is_complex(a.params, sid, a.qdata + a.q_begin + first)) return;
 	a.flags[slot] = SLOT_ERASED;
-	const int t = sid * a.params.index_chunks + seed_chunk(a.params, a.keys[slot]);
+	const int t = sid * a.params.index_chunks + seed_chunk(a.params, seed_of_key(a.params, sid, a.keys[slot]));
 	for (uint32_t x = a.heads[slot]; x != LIST_END; x = a.next[x]) {
 		const uint8_t old = a.mask_time[a.q_begin + x];
 		if (t < old) a.mask_time[a.q_begin + x] = (uint8_t)t;       // one group per position and shape: no race within a launch
@@ -254,7 +232,7 @@ __global__ void seed_pair_kernel(SeedArgs a, int sid, int64_t n_matched)
 	const uint32_t slot = a.matched_slot[m];
 	if (a.flags[slot] & SLOT_ERASED) return;
 	const int64_t sloc = a.matched_loc[m];
-	const int chunk = seed_chunk(a.params, a.keys[slot]);
+	const int chunk = seed_chunk(a.params, seed_of_key(a.params, sid, a.keys[slot]));
 	const int8_t* s = a.tdata + sloc;
 	for (uint32_t x = a.heads[slot]; x != LIST_END; x = a.next[x]) {
 		const int64_t qp = a.q_begin + x;
@@ -319,7 +297,7 @@ __global__ void seed_deferred_kernel(SeedArgs a, int sid, int64_t n_deferred)
 	const uint32_t qid = a.qid_of[qp];
 	const int query_len = (int)(a.qlimits[qid + 1] - a.qlimits[qid] - 1);
 	if (score <= ungapped_cutoff(a.params, query_len)) return;
-	finish_pair(a, sid, seed_chunk(a.params, a.keys[slot]), qp, q, s, qid, (int)(qp - a.qlimits[qid]), query_len, sloc, score);
+	finish_pair(a, sid, seed_chunk(a.params, seed_of_key(a.params, sid, a.keys[slot])), qp, q, s, qid, (int)(qp - a.qlimits[qid]), query_len, sloc, score);
 }
 
 static unsigned blocks_for(int64_t n, int threads) { return (unsigned)((n + threads - 1) / threads); }
@@ -340,13 +318,7 @@ hipError_t launch_seed_index(const SeedArgs& a, int sid, hipStream_t st)
 hipError_t launch_seed_stream(const SeedArgs& a, int sid, hipStream_t st)
 {
 	const SeedParams& c = a.params;
-	// the seed is accumulated as hi * radix^lo_digits + lo in 32-bit registers
-	int lo_digits = 0;
-	uint64_t scale = 1;
-	while (scale * (uint64_t)c.reduction_size <= 0xffffffffull && lo_digits < c.shape_weight[sid]) { scale *= (uint64_t)c.reduction_size; ++lo_digits; }
-	uint64_t hi_max = 1;
-	for (int i = 0; i < c.shape_weight[sid] - lo_digits; ++i) hi_max *= (uint64_t)c.reduction_size;
-	if (c.shape_len[sid] <= 16 && c.reduction_size <= 15 && hi_max <= 0xffffffffull) {
+	if (seed_nibble_mode(c, sid)) {
 		// 4-bit class map: 15 = invalid (X, '*'); every other letter code -> its reduced class
 		uint64_t lo = 0, hi = 0;
 		for (int l = 0; l < 32; ++l) {
@@ -355,10 +327,9 @@ hipError_t launch_seed_stream(const SeedArgs& a, int sid, hipStream_t st)
 		}
 		const int64_t base = a.t_begin & ~(int64_t)15;
 		const int64_t threads = (a.t_end - base + 15) / 16;
-		if (c.reduction_size == 10)
-			hipLaunchKernelGGL(seed_stream_fast_kernel<true>, dim3(blocks_for(threads, 256)), dim3(256), 0, st, a, sid, lo, hi, base, lo_digits, (uint32_t)scale);
-		else
-			hipLaunchKernelGGL(seed_stream_fast_kernel<false>, dim3(blocks_for(threads, 256)), dim3(256), 0, st, a, sid, lo, hi, base, lo_digits, (uint32_t)scale);
+		uint64_t care64 = 0;
+		for (int k = 0; k < c.shape_weight[sid]; ++k) care64 |= (uint64_t)15 << (4 * c.shape_pos[sid][k]);
+		hipLaunchKernelGGL(seed_stream_fast_kernel, dim3(blocks_for(threads, 256)), dim3(256), 0, st, a, sid, lo, hi, base, care64);
 		return hipGetLastError();
 	}
 	hipLaunchKernelGGL(seed_stream_kernel, dim3(blocks_for(a.t_end - a.t_begin, 256)), dim3(256), 0, st, a, sid);
