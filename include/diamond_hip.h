@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DMND_ABI_VERSION 1
+#define DMND_ABI_VERSION 2      /* 2: dmnd_match.frame, seed parameters (ungapped filter, translated queries), dmnd_extend_plan(query_contexts) */
 
 enum {
 	DMND_OK = 0,
