@@ -197,15 +197,11 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	HIP_TRY(hipMemsetAsync(c->seed_bitmap.p, 0, bm_total, st));
 	if (int rc = c->qid_of.ensure((size_t)q_end * sizeof(uint32_t))) return rc;
 	if (int rc = c->mask_time.ensure((size_t)c->block_len[DMND_QUERY] + 256)) return rc;
-	if (int rc = c->seed_keys.ensure((size_t)S * slots * sizeof(uint64_t))) return rc;
-	if (int rc = c->seed_heads.ensure((size_t)S * slots * sizeof(uint32_t))) return rc;
-	if (int rc = c->seed_flags.ensure((size_t)S * slots)) return rc;
+	if (int rc = c->seed_keys.ensure((size_t)S * slots * sizeof(SeedSlot))) return rc;
 	if (int rc = c->seed_next.ensure((size_t)S * nq_pos * sizeof(uint32_t))) return rc;
 	if (int rc = c->counters.ensure((size_t)(S + 3) * sizeof(unsigned long long))) return rc;      // [S] hits, [S+1] deferred pairs, [S+2] collected positions
 	HIP_TRY(hipMemsetAsync(c->mask_time.p, SEED_NEVER, (size_t)c->block_len[DMND_QUERY] + 256, st));
-	HIP_TRY(hipMemsetAsync(c->seed_keys.p, 0xff, (size_t)S * slots * sizeof(uint64_t), st));
-	HIP_TRY(hipMemsetAsync(c->seed_heads.p, 0xff, (size_t)S * slots * sizeof(uint32_t), st));
-	HIP_TRY(hipMemsetAsync(c->seed_flags.p, 0, (size_t)S * slots, st));
+	HIP_TRY(hipMemsetAsync(c->seed_keys.p, 0xff, (size_t)S * slots * sizeof(SeedSlot), st));
 	HIP_TRY(launch_seed_qid(c->d_limits[DMND_QUERY].as<int64_t>(), (int64_t)ql.size() - 1, c->qid_of.as<uint32_t>(), st));
 
 	auto args_for = [&](int sid, int64_t matched_cap, int64_t matched_off) {
@@ -215,9 +211,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		a.qlimits = c->d_limits[DMND_QUERY].as<int64_t>();
 		a.q_begin = q_begin; a.q_end = q_end; a.t_begin = t_begin; a.t_end = t_end;
 		a.qid_of = c->qid_of.as<uint32_t>(); a.mask_time = c->mask_time.as<uint8_t>();
-		a.keys = c->seed_keys.as<uint64_t>() + (size_t)sid * slots;
-		a.heads = c->seed_heads.as<uint32_t>() + (size_t)sid * slots;
-		a.flags = c->seed_flags.as<uint8_t>() + (size_t)sid * slots;
+		a.slots = c->seed_keys.as<SeedSlot>() + (size_t)sid * slots;
 		a.next = c->seed_next.as<uint32_t>() + (size_t)sid * nq_pos;
 		a.slot_mask = slots - 1;
 		a.bitmap = c->seed_bitmap.as<uint32_t>() + (size_t)sid * (bm_words + bm1_words);
@@ -248,9 +242,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		if (int rc = c->matched_loc.ensure((size_t)cap_total * sizeof(int64_t))) return rc;
 		HIP_TRY(hipMemsetAsync(c->counters.p, 0, (size_t)(S + 3) * sizeof(unsigned long long), st));
 		if (attempt > 0) {
-			HIP_TRY(hipMemsetAsync(c->seed_keys.p, 0xff, (size_t)S * slots * sizeof(uint64_t), st));
-			HIP_TRY(hipMemsetAsync(c->seed_heads.p, 0xff, (size_t)S * slots * sizeof(uint32_t), st));
-			HIP_TRY(hipMemsetAsync(c->seed_flags.p, 0, (size_t)S * slots, st));
+			HIP_TRY(hipMemsetAsync(c->seed_keys.p, 0xff, (size_t)S * slots * sizeof(SeedSlot), st));
 			HIP_TRY(hipMemsetAsync(c->seed_bitmap.p, 0, bm_total, st));
 		}
 		bool overflow = false;

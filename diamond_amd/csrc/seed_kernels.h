@@ -9,7 +9,13 @@ namespace dmnd {
 
 static const uint64_t SEED_EMPTY = ~0ull;
 static const uint32_t LIST_END = 0xffffffffu;
-enum { SLOT_FREE = 0, SLOT_JOINED = 1, SLOT_ERASED = 2, SLOT_NEED = 4 };      // NEED: the seed has a deferred pair (score > 255)
+// A free slot is all ones (one memset initialises the table); the state of an occupied slot is written explicitly, and no
+// kernel bit-tests the state of a free slot.
+enum : uint32_t { SLOT_JOINED = 1, SLOT_ERASED = 2, SLOT_NEED = 4 };
+
+// One entry of the open-addressing query seed table: key, head of the list of query positions, join state -- 16 bytes, so
+// that the probe of the reference stream and the pair filter touch ONE cache line per seed instead of three arrays.
+struct SeedSlot { uint64_t key; uint32_t head; uint32_t flags; };      // NEED: the seed has a deferred pair (score > 255)
 
 // A (joined reference position, query position) pair whose stage-2 score exceeds 255: whether it saturates depends on the
 // reference's SIMD batch it would have been scored in (simd_batch_size_sorted), resolved in a second pass.
@@ -23,7 +29,7 @@ struct SeedArgs {
 	const uint32_t* qid_of;                       // query position -> query id
 	uint8_t* mask_time;                           // per query letter: (shape, chunk) time of its SEED_MASK bit
 	// per-shape query seed table
-	uint64_t* keys; uint32_t* heads; uint32_t* next; uint8_t* flags;
+	SeedSlot* slots; uint32_t* next;
 	uint64_t slot_mask;
 	// two one-hash bitmaps of the query seeds: level 1 is sized to stay resident in every XCD's 4 MB L2 (the reference
 	// stream probes it once per position), level 2 (>= 16 bits per query seed) filters level-1 false positives before

@@ -44,11 +44,11 @@ __global__ void seed_index_kernel(SeedArgs a, int sid)
 	atomicOr(&a.bitmap1[(uint32_t)(h >> 10) & a.bitmap1_mask], (1u << (h & 31)) | (1u << ((h >> 5) & 31)));   // 2 bits, one word
 	uint64_t slot = h & a.slot_mask;
 	for (;;) {
-		const unsigned long long old = atomicCAS((unsigned long long*)&a.keys[slot], (unsigned long long)SEED_EMPTY, (unsigned long long)seed);
+		const unsigned long long old = atomicCAS((unsigned long long*)&a.slots[slot].key, (unsigned long long)SEED_EMPTY, (unsigned long long)seed);
 		if (old == SEED_EMPTY || old == seed) break;
 		slot = (slot + 1) & a.slot_mask;
 	}
-	const uint32_t prev = atomicExch(&a.heads[slot], (uint32_t)(p - a.q_begin));
+	const uint32_t prev = atomicExch(&a.slots[slot].head, (uint32_t)(p - a.q_begin));
 	a.next[p - a.q_begin] = prev;
 }
 
@@ -74,7 +74,7 @@ __global__ void seed_stream_kernel(SeedArgs a, int sid)
 	if (p < a.t_end && seed_key_at(a.params, sid, a.tdata + p, seed)) {
 		slot = seed_hash(seed) & a.slot_mask;
 		for (;;) {
-			const uint64_t k = a.keys[slot];
+			const uint64_t k = a.slots[slot].key;
 			if (k == SEED_EMPTY) break;
 			if (k == seed) { found = true; break; }
 			slot = (slot + 1) & a.slot_mask;
@@ -82,7 +82,7 @@ __global__ void seed_stream_kernel(SeedArgs a, int sid)
 	}
 	const unsigned long long idx = wave_append(a.matched_count, found);
 	if (!found) return;
-	a.flags[slot] = SLOT_JOINED;                       // benign race: every writer stores the same value
+	a.slots[slot].flags = SLOT_JOINED;                 // benign race: every writer stores the same value
 	if (idx < (unsigned long long)a.matched_cap) {
 		a.matched_slot[idx] = (uint32_t)slot;
 		a.matched_loc[idx] = p;
@@ -167,13 +167,13 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 			bool found = false;
 			if ((a.bitmap[(uint32_t)(hh >> 32) & a.bitmap_mask] >> (uint32_t)(hh >> 59)) & 1u)
 				for (;;) {
-					const uint64_t kk = a.keys[slot];
+					const uint64_t kk = a.slots[slot].key;
 					if (kk == SEED_EMPTY) break;
 					if (kk == seed) { found = true; break; }
 					slot = (slot + 1) & a.slot_mask;
 				}
 			if (!found) continue;
-			a.flags[slot] = SLOT_JOINED;
+			a.slots[slot].flags = SLOT_JOINED;
 			const unsigned k = atomicAdd(&st_n, 1u);                 // LDS atomic
 			if (k < STAGE) { st_slot[k] = (uint32_t)slot; st_loc[k] = p0 + 8 * half + i; }
 			else {                                                    // staging area full (dense matches): direct append
@@ -197,16 +197,16 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 __global__ void seed_mask_kernel(SeedArgs a, int sid)
 {
 	const uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (slot > a.slot_mask || a.flags[slot] != SLOT_JOINED) return;
+	if (slot > a.slot_mask || a.slots[slot].flags != SLOT_JOINED) return;
 	// Search::mask_seeds evaluates the first query position of the joined group (seed_complexity.cpp:97-99);
 	// "first" = smallest position here (and in the oracle)
 	uint32_t first = 0xffffffffu;
-	for (uint32_t x = a.heads[slot]; x != LIST_END; x = a.next[x])
+	for (uint32_t x = a.slots[slot].head; x != LIST_END; x = a.next[x])
 		first = x < first ? x : first;
 	if (seed_is_complex(a.params, sid, a.qdata + a.q_begin + first)) return;
-	a.flags[slot] = SLOT_ERASED;
-	const int t = sid * a.params.index_chunks + seed_chunk(a.params, seed_of_key(a.params, sid, a.keys[slot]));
-	for (uint32_t x = a.heads[slot]; x != LIST_END; x = a.next[x]) {
+	a.slots[slot].flags = SLOT_ERASED;
+	const int t = sid * a.params.index_chunks + seed_chunk(a.params, seed_of_key(a.params, sid, a.slots[slot].key));
+	for (uint32_t x = a.slots[slot].head; x != LIST_END; x = a.next[x]) {
 		const uint8_t old = a.mask_time[a.q_begin + x];
 		if (t < old) a.mask_time[a.q_begin + x] = (uint8_t)t;       // one group per position and shape: no race within a launch
 	}
@@ -230,11 +230,12 @@ __global__ void seed_pair_kernel(SeedArgs a, int sid, int64_t n_matched)
 	const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (m >= n_matched) return;
 	const uint32_t slot = a.matched_slot[m];
-	if (a.flags[slot] & SLOT_ERASED) return;
+	const SeedSlot sl = a.slots[slot];                 // key, list head and state of the seed in one 16-byte read
+	if (sl.flags & SLOT_ERASED) return;
 	const int64_t sloc = a.matched_loc[m];
-	const int chunk = seed_chunk(a.params, seed_of_key(a.params, sid, a.keys[slot]));
+	const int chunk = seed_chunk(a.params, seed_of_key(a.params, sid, sl.key));
 	const int8_t* s = a.tdata + sloc;
-	for (uint32_t x = a.heads[slot]; x != LIST_END; x = a.next[x]) {
+	for (uint32_t x = sl.head; x != LIST_END; x = a.next[x]) {
 		const int64_t qp = a.q_begin + x;
 		const int8_t* q = a.qdata + qp;
 		if (fingerprint_id(q, s) < a.params.hamming_filter_id) continue;
@@ -255,7 +256,7 @@ __global__ void seed_pair_kernel(SeedArgs a, int sid, int64_t n_matched)
 					// saturation depends on the SIMD batch of the reference: second pass (seed_deferred_kernel)
 					const unsigned long long d = atomicAdd(a.deferred_count, 1ull);
 					if (d < (unsigned long long)a.deferred_cap) a.deferred[d] = SeedDeferred{ m, x, score };
-					a.flags[slot] = SLOT_JOINED | SLOT_NEED;          // benign race: every writer stores the same value
+					a.slots[slot].flags = SLOT_JOINED | SLOT_NEED;          // benign race: every writer stores the same value
 					continue;
 				}
 				if (score <= cutoff) continue;
@@ -271,7 +272,7 @@ __global__ void seed_collect_kernel(SeedArgs a, int64_t n_matched)
 	const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	bool have = false;
 	uint32_t slot = 0;
-	if (m < n_matched) { slot = a.matched_slot[m]; have = (a.flags[slot] & SLOT_NEED) != 0; }
+	if (m < n_matched) { slot = a.matched_slot[m]; have = (a.slots[slot].flags & SLOT_NEED) != 0; }
 	const unsigned long long idx = wave_append(a.e_count, have);
 	if (have) a.e_key[idx] = ((uint64_t)slot << 40) | (uint64_t)a.matched_loc[m];
 }
@@ -297,7 +298,7 @@ __global__ void seed_deferred_kernel(SeedArgs a, int sid, int64_t n_deferred)
 	const uint32_t qid = a.qid_of[qp];
 	const int query_len = (int)(a.qlimits[qid + 1] - a.qlimits[qid] - 1);
 	if (score <= ungapped_cutoff(a.params, query_len)) return;
-	finish_pair(a, sid, seed_chunk(a.params, seed_of_key(a.params, sid, a.keys[slot])), qp, q, s, qid, (int)(qp - a.qlimits[qid]), query_len, sloc, score);
+	finish_pair(a, sid, seed_chunk(a.params, seed_of_key(a.params, sid, a.slots[slot].key)), qp, q, s, qid, (int)(qp - a.qlimits[qid]), query_len, sloc, score);
 }
 
 static unsigned blocks_for(int64_t n, int threads) { return (unsigned)((n + threads - 1) / threads); }
