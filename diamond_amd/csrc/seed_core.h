@@ -146,13 +146,33 @@ DMND_HD bool seed_is_complex(const SeedParams& c, int sid, const int8_t* p)
 	return entropy >= c.seed_complexity_cut;
 }
 
-// FingerPrint::match over [loc-16, loc+32) of masked letters
+// FingerPrint::match over [loc-16, loc+32) of masked letters (search/hamming/finger_print.h:59-96): number of equal letters.
+// On the device the two 48-byte windows are read with three unaligned 16-byte loads each and compared four letters per
+// 32-bit operation: this filter sees every joined (query, reference) position pair -- 1.3e9 of them per --sensitive block
+// pair -- and 96 byte-granular gather loads per pair made the pair kernel bound by load issue.
 DMND_HD int fingerprint_id(const int8_t* q, const int8_t* s)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+	int n = 0;
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+		uint32_t a[4], b[4];
+		__builtin_memcpy(a, q - 16 + 16 * k, 16);
+		__builtin_memcpy(b, s - 16 + 16 * k, 16);
+#pragma unroll
+		for (int w = 0; w < 4; ++w) {
+			const uint32_t d = (a[w] ^ b[w]) & 0x1f1f1f1fu;               // letter = low 5 bits of every byte
+			const uint32_t nz = (d + 0x7f7f7f7fu) & 0x80808080u;         // bit 7 of a byte set <=> the letters differ (no carries: d bytes <= 0x1f)
+			n += 4 - __builtin_popcount(nz);
+		}
+	}
+	return n;
+#else
 	int n = 0;
 	for (int i = -16; i < 32; ++i)
 		n += (q[i] & LETTER_MASK) == (s[i] & LETTER_MASK);
 	return n;
+#endif
 }
 
 // Util::Seq::clip (util/sequence/sequence.h:30-40): delimiter-free stretch of [seq, seq+len) around seq+anchor
