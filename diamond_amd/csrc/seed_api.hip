@@ -198,7 +198,10 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	if (int rc = c->qid_of.ensure((size_t)q_end * sizeof(uint32_t))) return rc;
 	if (int rc = c->mask_time.ensure((size_t)c->block_len[DMND_QUERY] + 256)) return rc;
 	if (int rc = c->seed_keys.ensure((size_t)S * slots * sizeof(SeedSlot))) return rc;
-	if (int rc = c->seed_next.ensure((size_t)S * nq_pos * sizeof(uint32_t))) return rc;
+	if (int rc = c->seed_next.ensure((size_t)S * nq_pos * sizeof(uint32_t))) return rc;        // qslot
+	if (int rc = c->seed_qlist.ensure((size_t)S * nq_pos * sizeof(uint32_t))) return rc;
+	if (int rc = c->seed_qkeys.ensure((size_t)nq_pos * sizeof(uint32_t))) return rc;
+	HIP_TRY(hipMemsetAsync(c->seed_next.p, 0xff, (size_t)S * nq_pos * sizeof(uint32_t), st));
 	if (int rc = c->counters.ensure((size_t)(S + 3) * sizeof(unsigned long long))) return rc;      // [S] hits, [S+1] deferred pairs, [S+2] collected positions
 	HIP_TRY(hipMemsetAsync(c->mask_time.p, SEED_NEVER, (size_t)c->block_len[DMND_QUERY] + 256, st));
 	HIP_TRY(hipMemsetAsync(c->seed_keys.p, 0xff, (size_t)S * slots * sizeof(SeedSlot), st));
@@ -212,7 +215,8 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		a.q_begin = q_begin; a.q_end = q_end; a.t_begin = t_begin; a.t_end = t_end;
 		a.qid_of = c->qid_of.as<uint32_t>(); a.mask_time = c->mask_time.as<uint8_t>();
 		a.slots = c->seed_keys.as<SeedSlot>() + (size_t)sid * slots;
-		a.next = c->seed_next.as<uint32_t>() + (size_t)sid * nq_pos;
+		a.qslot = c->seed_next.as<uint32_t>() + (size_t)sid * nq_pos;
+		a.qlist = c->seed_qlist.as<uint32_t>() + (size_t)sid * nq_pos;
 		a.slot_mask = slots - 1;
 		a.bitmap = c->seed_bitmap.as<uint32_t>() + (size_t)sid * (bm_words + bm1_words);
 		a.bitmap_mask = (uint32_t)(bm_words - 1);
@@ -244,6 +248,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		if (attempt > 0) {
 			HIP_TRY(hipMemsetAsync(c->seed_keys.p, 0xff, (size_t)S * slots * sizeof(SeedSlot), st));
 			HIP_TRY(hipMemsetAsync(c->seed_bitmap.p, 0, bm_total, st));
+			HIP_TRY(hipMemsetAsync(c->seed_next.p, 0xff, (size_t)S * nq_pos * sizeof(uint32_t), st));
 		}
 		bool overflow = false;
 		int64_t off = 0;
@@ -253,6 +258,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 			SeedArgs a = args_for(sid, std::max<int64_t>(cap_total - off, 0), std::min(off, cap_total));
 			tm.start();
 			HIP_TRY(launch_seed_index(a, sid, st));
+			HIP_TRY(launch_seed_lists(a, c->seed_qkeys.as<uint32_t>(), c->seed_qlist.as<uint32_t>() + (size_t)sid * nq_pos, 32, &c->sort_tmp, &c->sort_tmp_bytes, st));
 			c->seed_ms[0] += tm.stop();
 			tm.start();
 			HIP_TRY(launch_seed_stream(a, sid, st));

@@ -9,6 +9,7 @@ namespace dmnd {
 
 static const uint64_t SEED_EMPTY = ~0ull;
 static const uint32_t LIST_END = 0xffffffffu;
+// head = start of the seed's query-position list in SeedArgs::qlist, flags = state (low byte) | list size << 8.
 // A free slot is all ones (one memset initialises the table); the state of an occupied slot is written explicitly, and no
 // kernel bit-tests the state of a free slot.
 enum : uint32_t { SLOT_JOINED = 1, SLOT_ERASED = 2, SLOT_NEED = 4 };
@@ -29,7 +30,9 @@ struct SeedArgs {
 	const uint32_t* qid_of;                       // query position -> query id
 	uint8_t* mask_time;                           // per query letter: (shape, chunk) time of its SEED_MASK bit
 	// per-shape query seed table
-	SeedSlot* slots; uint32_t* next;
+	SeedSlot* slots;
+	uint32_t* qslot;                              // per query position: slot of its seed (LIST_END: no seed); input of the list sort
+	const uint32_t* qlist;                        // query positions grouped by slot (SeedSlot::head = start, count in flags >> 8)
 	uint64_t slot_mask;
 	// two one-hash bitmaps of the query seeds: level 1 is sized to stay resident in every XCD's 4 MB L2 (the reference
 	// stream probes it once per position), level 2 (>= 16 bits per query seed) filters level-1 false positives before
@@ -48,6 +51,9 @@ struct SeedArgs {
 
 hipError_t launch_seed_qid(const int64_t* limits, int64_t n_seqs, uint32_t* qid_of, hipStream_t st);
 hipError_t launch_seed_index(const SeedArgs& a, int sid, hipStream_t st);
+// groups the query positions by slot: stable radix sort of (qslot, position) into (sorted_slot, qlist_out), then the list
+// start/size of every occupied slot is written into the table
+hipError_t launch_seed_lists(const SeedArgs& a, uint32_t* sorted_slot, uint32_t* qlist_out, int slot_bits, void** tmp, size_t* tmp_bytes, hipStream_t st);
 hipError_t launch_seed_stream(const SeedArgs& a, int sid, hipStream_t st);
 hipError_t launch_seed_mask(const SeedArgs& a, int sid, hipStream_t st);
 hipError_t launch_seed_pairs(const SeedArgs& a, int sid, int64_t n_matched, hipStream_t st);

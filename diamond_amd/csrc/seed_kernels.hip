@@ -18,6 +18,7 @@
 #include "seed_core.h"
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 #include "seed_kernels.h"
 
 namespace dmnd {
@@ -48,8 +49,21 @@ __global__ void seed_index_kernel(SeedArgs a, int sid)
 		if (old == SEED_EMPTY || old == seed) break;
 		slot = (slot + 1) & a.slot_mask;
 	}
-	const uint32_t prev = atomicExch(&a.slots[slot].head, (uint32_t)(p - a.q_begin));
-	a.next[p - a.q_begin] = prev;
+	a.qslot[p - a.q_begin] = (uint32_t)slot;            // the per-seed position lists are built by a sort on this (seed_lists_kernel)
+}
+
+// After the query positions have been sorted by slot (stable: ascending position inside a seed): the first element of every
+// group writes the group's start and size into its slot. state = 0 (occupied, not joined), count in bits 8..31.
+__global__ void seed_lists_kernel(SeedArgs a, const uint32_t* sorted_slot, int64_t n)
+{
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t k = sorted_slot[i];
+	if (k == LIST_END || (i > 0 && sorted_slot[i - 1] == k)) return;
+	int64_t e = i + 1;
+	while (e < n && sorted_slot[e] == k) ++e;
+	a.slots[k].head = (uint32_t)i;
+	a.slots[k].flags = (uint32_t)(e - i) << 8;
 }
 
 // Wave-aggregated append: the lanes of the wavefront that have an element reserve their slots with ONE atomic on the
@@ -70,19 +84,20 @@ __global__ void seed_stream_kernel(SeedArgs a, int sid)
 {
 	const int64_t p = a.t_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	uint64_t seed = 0, slot = 0;
+	uint32_t fl = 0;
 	bool found = false;
 	if (p < a.t_end && seed_key_at(a.params, sid, a.tdata + p, seed)) {
 		slot = seed_hash(seed) & a.slot_mask;
 		for (;;) {
-			const uint64_t k = a.slots[slot].key;
-			if (k == SEED_EMPTY) break;
-			if (k == seed) { found = true; break; }
+			const SeedSlot sl = a.slots[slot];
+			if (sl.key == SEED_EMPTY) break;
+			if (sl.key == seed) { found = true; fl = sl.flags; break; }
 			slot = (slot + 1) & a.slot_mask;
 		}
 	}
 	const unsigned long long idx = wave_append(a.matched_count, found);
 	if (!found) return;
-	a.slots[slot].flags = SLOT_JOINED;                 // benign race: every writer stores the same value
+	if ((fl & 0xffu) != SLOT_JOINED) a.slots[slot].flags = (fl & ~0xffu) | SLOT_JOINED;      // benign race: every writer stores the same value
 	if (idx < (unsigned long long)a.matched_cap) {
 		a.matched_slot[idx] = (uint32_t)slot;
 		a.matched_loc[idx] = p;
@@ -165,15 +180,16 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 			const uint64_t hh = seed_hash(seed);
 			uint64_t slot = hh & a.slot_mask;
 			bool found = false;
+			uint32_t fl = 0;
 			if ((a.bitmap[(uint32_t)(hh >> 32) & a.bitmap_mask] >> (uint32_t)(hh >> 59)) & 1u)
 				for (;;) {
-					const uint64_t kk = a.slots[slot].key;
-					if (kk == SEED_EMPTY) break;
-					if (kk == seed) { found = true; break; }
+					const SeedSlot sl = a.slots[slot];
+					if (sl.key == SEED_EMPTY) break;
+					if (sl.key == seed) { found = true; fl = sl.flags; break; }
 					slot = (slot + 1) & a.slot_mask;
 				}
 			if (!found) continue;
-			a.slots[slot].flags = SLOT_JOINED;
+			if ((fl & 0xffu) != SLOT_JOINED) a.slots[slot].flags = (fl & ~0xffu) | SLOT_JOINED;
 			const unsigned k = atomicAdd(&st_n, 1u);                 // LDS atomic
 			if (k < STAGE) { st_slot[k] = (uint32_t)slot; st_loc[k] = p0 + 8 * half + i; }
 			else {                                                    // staging area full (dense matches): direct append
@@ -197,16 +213,17 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 __global__ void seed_mask_kernel(SeedArgs a, int sid)
 {
 	const uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (slot > a.slot_mask || a.slots[slot].flags != SLOT_JOINED) return;
+	if (slot > a.slot_mask) return;
+	const SeedSlot sl = a.slots[slot];
+	if ((sl.flags & 0xffu) != SLOT_JOINED) return;
 	// Search::mask_seeds evaluates the first query position of the joined group (seed_complexity.cpp:97-99);
-	// "first" = smallest position here (and in the oracle)
-	uint32_t first = 0xffffffffu;
-	for (uint32_t x = a.slots[slot].head; x != LIST_END; x = a.next[x])
-		first = x < first ? x : first;
-	if (seed_is_complex(a.params, sid, a.qdata + a.q_begin + first)) return;
-	a.slots[slot].flags = SLOT_ERASED;
-	const int t = sid * a.params.index_chunks + seed_chunk(a.params, seed_of_key(a.params, sid, a.slots[slot].key));
-	for (uint32_t x = a.slots[slot].head; x != LIST_END; x = a.next[x]) {
+	// "first" = smallest position here (and in the oracle): the lists are sorted by position
+	const uint32_t count = sl.flags >> 8;
+	if (seed_is_complex(a.params, sid, a.qdata + a.q_begin + a.qlist[sl.head])) return;
+	a.slots[slot].flags = (sl.flags & ~0xffu) | SLOT_ERASED;
+	const int t = sid * a.params.index_chunks + seed_chunk(a.params, seed_of_key(a.params, sid, sl.key));
+	for (uint32_t i = 0; i < count; ++i) {
+		const uint32_t x = a.qlist[sl.head + i];
 		const uint8_t old = a.mask_time[a.q_begin + x];
 		if (t < old) a.mask_time[a.q_begin + x] = (uint8_t)t;       // one group per position and shape: no race within a launch
 	}
@@ -225,44 +242,71 @@ __device__ __forceinline__ void finish_pair(const SeedArgs& a, int sid, int chun
 	}
 }
 
+// Hamming + stage-2 score filters and emission for one (joined reference position m, query position x) pair
+__device__ __forceinline__ void filter_pair(const SeedArgs& a, int sid, int64_t m, uint32_t slot, uint32_t slot_flags, int chunk, int64_t sloc, uint32_t x)
+{
+	const int8_t* s = a.tdata + sloc;
+	const int64_t qp = a.q_begin + x;
+	const int8_t* q = a.qdata + qp;
+	if (fingerprint_id(q, s) < a.params.hamming_filter_id) return;
+	const uint32_t qid = a.qid_of[qp];
+	const int seed_offset = (int)(qp - a.qlimits[qid]);
+	int score = 0xFFFF;
+	const int query_len = (int)(a.qlimits[qid + 1] - a.qlimits[qid] - 1);
+	if (a.params.use_ungapped) {
+		// stage-2 ungapped window score over the query window clipped at its sequence ends (stage2.h:92-113)
+		const int cutoff = ungapped_cutoff(a.params, query_len);
+		if (cutoff) {
+			const int window = stage2_window(a.params, query_len);
+			int cb, ce;
+			clip_window(q - window, 2 * window, window, cb, ce);
+			const int window_left = window - cb;
+			score = ungapped_window_score(a.matrix, q - window_left, s - window_left, ce - cb);
+			if (score > 255) {
+				// saturation depends on the SIMD batch of the reference: second pass (seed_deferred_kernel)
+				const unsigned long long d = atomicAdd(a.deferred_count, 1ull);
+				if (d < (unsigned long long)a.deferred_cap) a.deferred[d] = SeedDeferred{ m, x, score };
+				a.slots[slot].flags = (slot_flags & ~0xffu) | SLOT_JOINED | SLOT_NEED;      // benign race: every writer stores the same value
+				return;
+			}
+			if (score <= cutoff) return;
+		}
+	}
+	finish_pair(a, sid, chunk, qp, q, s, qid, seed_offset, query_len, sloc, score);
+}
+
+// One thread per joined reference position; the seed's query positions are a contiguous list. Work per position is the
+// list length, which is heavily skewed (a frequent seed has thousands of query positions and thousands of joined reference
+// positions): lists longer than LIGHT are processed by the whole wavefront, 64 query positions at a time, so that no lane
+// runs a 10^4-iteration loop while the rest of the machine idles.
 __global__ void seed_pair_kernel(SeedArgs a, int sid, int64_t n_matched)
 {
+	constexpr uint32_t LIGHT = 8;
+	const int lane = threadIdx.x & 63;
 	const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (m >= n_matched) return;
-	const uint32_t slot = a.matched_slot[m];
-	const SeedSlot sl = a.slots[slot];                 // key, list head and state of the seed in one 16-byte read
-	if (sl.flags & SLOT_ERASED) return;
-	const int64_t sloc = a.matched_loc[m];
-	const int chunk = seed_chunk(a.params, seed_of_key(a.params, sid, sl.key));
-	const int8_t* s = a.tdata + sloc;
-	for (uint32_t x = sl.head; x != LIST_END; x = a.next[x]) {
-		const int64_t qp = a.q_begin + x;
-		const int8_t* q = a.qdata + qp;
-		if (fingerprint_id(q, s) < a.params.hamming_filter_id) continue;
-		const uint32_t qid = a.qid_of[qp];
-		const int seed_offset = (int)(qp - a.qlimits[qid]);
-		int score = 0xFFFF;
-		const int query_len = (int)(a.qlimits[qid + 1] - a.qlimits[qid] - 1);
-		if (a.params.use_ungapped) {
-			// stage-2 ungapped window score over the query window clipped at its sequence ends (stage2.h:92-113)
-			const int cutoff = ungapped_cutoff(a.params, query_len);
-			if (cutoff) {
-				const int window = stage2_window(a.params, query_len);
-				int cb, ce;
-				clip_window(q - window, 2 * window, window, cb, ce);
-				const int window_left = window - cb;
-				score = ungapped_window_score(a.matrix, q - window_left, s - window_left, ce - cb);
-				if (score > 255) {
-					// saturation depends on the SIMD batch of the reference: second pass (seed_deferred_kernel)
-					const unsigned long long d = atomicAdd(a.deferred_count, 1ull);
-					if (d < (unsigned long long)a.deferred_cap) a.deferred[d] = SeedDeferred{ m, x, score };
-					a.slots[slot].flags = SLOT_JOINED | SLOT_NEED;          // benign race: every writer stores the same value
-					continue;
-				}
-				if (score <= cutoff) continue;
-			}
+	uint32_t slot = 0, head = 0, count = 0, flags = 0;
+	int64_t sloc = 0;
+	int chunk = 0;
+	if (m < n_matched) {
+		slot = a.matched_slot[m];
+		const SeedSlot sl = a.slots[slot];                // key, list start, size and state of the seed in one 16-byte read
+		if (!(sl.flags & SLOT_ERASED)) {
+			head = sl.head; count = sl.flags >> 8; flags = sl.flags;
+			sloc = a.matched_loc[m];
+			chunk = seed_chunk(a.params, seed_of_key(a.params, sid, sl.key));
 		}
-		finish_pair(a, sid, chunk, qp, q, s, qid, seed_offset, query_len, sloc, score);
+	}
+	if (count <= LIGHT)
+		for (uint32_t i = 0; i < count; ++i) filter_pair(a, sid, m, slot, flags, chunk, sloc, a.qlist[head + i]);
+	unsigned long long heavy = __ballot(count > LIGHT);
+	while (heavy) {
+		const int src = __builtin_ctzll(heavy);
+		heavy &= heavy - 1;
+		const uint32_t h_slot = (uint32_t)__shfl((int)slot, src), h_head = (uint32_t)__shfl((int)head, src), h_count = (uint32_t)__shfl((int)count, src),
+			h_flags = (uint32_t)__shfl((int)flags, src);
+		const int h_chunk = __shfl(chunk, src);
+		const int64_t h_sloc = (int64_t)__shfl((long long)sloc, src), h_m = (int64_t)__shfl((long long)m, src);
+		for (uint32_t i = (uint32_t)lane; i < h_count; i += 64) filter_pair(a, sid, h_m, h_slot, h_flags, h_chunk, h_sloc, a.qlist[h_head + i]);
 	}
 }
 
@@ -313,6 +357,28 @@ hipError_t launch_seed_qid(const int64_t* limits, int64_t n_seqs, uint32_t* qid_
 hipError_t launch_seed_index(const SeedArgs& a, int sid, hipStream_t st)
 {
 	hipLaunchKernelGGL(seed_index_kernel, dim3(blocks_for(a.q_end - a.q_begin, 256)), dim3(256), 0, st, a, sid);
+	return hipGetLastError();
+}
+
+hipError_t launch_seed_lists(const SeedArgs& a, uint32_t* sorted_slot, uint32_t* qlist_out, int slot_bits, void** tmp, size_t* tmp_bytes, hipStream_t st)
+{
+	const int64_t n = a.q_end - a.q_begin;
+	if (n <= 0) return hipSuccess;
+	(void)slot_bits;                                      // LIST_END (all ones) must sort last: all 32 key bits
+	size_t need = 0;
+	rocprim::counting_iterator<uint32_t> iota(0);
+	hipError_t e = rocprim::radix_sort_pairs(nullptr, need, a.qslot, sorted_slot, iota, qlist_out, (size_t)n, 0, 32, st);
+	if (e != hipSuccess) return e;
+	if (need > *tmp_bytes) {
+		if (*tmp) (void)hipFree(*tmp);
+		*tmp = nullptr; *tmp_bytes = 0;
+		e = hipMalloc(tmp, need);
+		if (e != hipSuccess) return e;
+		*tmp_bytes = need;
+	}
+	e = rocprim::radix_sort_pairs(*tmp, need, a.qslot, sorted_slot, iota, qlist_out, (size_t)n, 0, 32, st);
+	if (e != hipSuccess) return e;
+	hipLaunchKernelGGL(seed_lists_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, a, (const uint32_t*)sorted_slot, n);
 	return hipGetLastError();
 }
 
