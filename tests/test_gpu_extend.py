@@ -83,3 +83,32 @@ def test_tabular_output_is_byte_identical_to_reference(ctx, tap, tsv):
     ref = open(os.path.join(GOLDEN, tsv)).read()
     assert len(ref.splitlines()) > 300
     assert text == ref
+
+
+def test_transcripts_equal_reference(ctx):
+    """dmnd_extend with a transcript arena (the unsplit path): the packed edit transcript of every reported alignment equals
+    the reference's (PackedOperation bytes, basic/packed_transcript.h)."""
+    cfg, recs = read_ext_tap(os.path.join(GOLDEN, "ext_fast_synth.tap"))
+    qd, ql, td, tl = cfg["query"]["data"], cfg["query"]["limits"], cfg["target"]["data"], cfg["target"]["limits"]
+    ctx.upload_block(hip.QUERY, qd, ql)
+    ctx.upload_block(hip.TARGET, td, tl)
+    ctx.set_db_letters(float(tl[-1] - tl[0] - (len(tl) - 1)))
+    ctx.set_gapped_filter(0.0)
+    ctx.set_query_contexts(1)
+    hits = ctx.seed_search(to_hip_params(cfg))
+    m, tr = ctx.extend(qd, td, hits, threads=4, with_transcripts=True)
+    m0 = ctx.extend(qd, td, hits, threads=4)[0]
+    for k in HSP_KEYS:
+        assert np.array_equal(m["hsp"][k], m0["hsp"][k])                         # same alignments with and without transcripts
+    pos = 0
+    for r in sorted(recs, key=lambda x: x["query_id"]):
+        for ref in r["matches"]:
+            got = m[pos]
+            pos += 1
+            h = ref["hsps"][0]
+            want = np.asarray(h["transcript"], np.uint8)
+            want = want[:-1] if len(want) and want[-1] == 0 else want
+            off, n = int(got["hsp"]["transcript_off"]), int(got["hsp"]["transcript_len"])
+            assert off >= 0 and n == len(want) and np.array_equal(tr[off:off + n], want)
+            assert tr[off + n] == 0
+    assert pos == len(m) > 300
