@@ -211,6 +211,8 @@ def main():
             "extension": ext,
             "swipe_kernel_gcups": {"round1": ext["round1_cells"] / max(ext["round1_swipe_kernel_ms"], 1e-9) / 1e6,
                                    "round2": ext["round2_cells"] / max(ext["round2_swipe_kernel_ms"], 1e-9) / 1e6},
+            # seed-stage Gletters/s = (L_q + L_r) x shapes / seed-stage seconds (device time of its kernels)
+            "seed_stage_gletters_per_s": (int(ql[-1] - ql[0]) + int(tl[-1] - tl[0])) * seed_params.n_shapes / max(state["seed_ms"][4], 1e-9) / 1e6,
             "wall_ms_last_step": state["wall_ms"],
             # not part of `value`: one-time PCIe upload of both blocks, and the rate if it were paid on every step
             "block_upload_ms": upload_ms,
