@@ -183,6 +183,17 @@ def main():
             if k:
                 # HBM-side bytes per launch: FETCH_SIZE (x2: gfx950 under-reports wide reads, upper bound) + WRITE_SIZE
                 traffic = k[0]["FETCH_SIZE_x2_bytes_per_launch"] + k[0]["WRITE_SIZE_bytes_per_launch"]
+        # achievable HBM bandwidth on this device: device-to-device copy of 1 GiB (bytes read + written per second)
+        buf_a = torch.empty(1 << 30, dtype=torch.uint8, device=device)
+        buf_b = torch.empty_like(buf_a)
+        buf_b.copy_(buf_a)
+        torch.cuda.synchronize()
+        t_c = time.perf_counter()
+        for _ in range(5):
+            buf_b.copy_(buf_a)
+        torch.cuda.synchronize()
+        copy_gbs = 5 * 2 * (1 << 30) / (time.perf_counter() - t_c) / 1e9
+        del buf_a, buf_b
         out = {
             "metric": "GCUPS + aligned queries/s, blastp --fast 10k queries vs 1M-seq DB (seed stage + banded SW extension)",
             "value": gcups, "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -198,6 +209,7 @@ def main():
                        "parallelism": "query-shard x%d + RCCL all_gather of top-k records" % world if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "seed_stream_fast_kernel (reference block streamed once against the query seed table)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "measured_copy_gbs": copy_gbs,
                          "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_unit": 17, "units_per_launch": ref_letters,
                          "kernel_ms": k_ms,
                          "design_bytes_per_launch": design_bytes, "achieved_design_bytes": achieved_design,
