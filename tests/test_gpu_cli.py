@@ -105,6 +105,9 @@ def test_cli_default_masking_matches_reference(tmp_path):
         ref = open(tmp_path / ("ref_%s.tsv" % tag)).read()
         assert len(ref.splitlines()) > 300
         assert open(tmp_path / ("hip_%s.tsv" % tag)).read() == ref, tag
+    # the reference's own choice of seed-index algorithm (AUTO picks the query-indexed path at these sizes) gives the same text
+    _run([REF, "blastp", "--motif-masking", "0", "-q", str(tmp_path / "q.faa"), "-d", str(tmp_path / "db.faa"), "-o", str(tmp_path / "ref_auto.tsv"), "-p", "4"])
+    assert open(tmp_path / "ref_auto.tsv").read() == open(tmp_path / "hip_default.tsv").read()
     # masking really changes this workload: the unmasked run differs
     _run([REF, "blastp", "--algo", "0", "--masking", "0", "--motif-masking", "0", "-q", str(tmp_path / "q.faa"), "-d", str(tmp_path / "db.faa"),
           "-o", str(tmp_path / "ref_nomask.tsv"), "-p", "4"])
