@@ -297,7 +297,21 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 			a.deferred = c->seed_deferred.as<SeedDeferred>(); a.deferred_cap = def_cap;
 			HIP_TRY(hipMemsetAsync(a.deferred_count, 0, 2 * sizeof(unsigned long long), st));
 			tm.start();
-			HIP_TRY(launch_seed_pairs(a, sid, (int64_t)counts[sid], st));
+			// many joined positions (short seeds): sort them by seed and run the LDS-tiled filter; otherwise one thread per position
+			bool tiled = (int64_t)counts[sid] >= ((int64_t)1 << 22);
+			if (const char* e = getenv("DMND_SEED_TILED")) tiled = atoi(e) != 0;
+			if (tiled) {
+				if (int rc = c->seed_slot2.ensure((size_t)counts[sid] * sizeof(uint32_t))) return rc;
+				if (int rc = c->seed_loc2.ensure((size_t)counts[sid] * sizeof(int64_t))) return rc;
+				int slot_bits = 1;
+				while (((uint64_t)1 << slot_bits) < slots) ++slot_bits;
+				HIP_TRY(sort_matched_by_slot(a.matched_slot, c->seed_slot2.as<uint32_t>(), a.matched_loc, c->seed_loc2.as<int64_t>(), (int64_t)counts[sid], slot_bits,
+					&c->sort_tmp, &c->sort_tmp_bytes, st));
+				a.matched_slot = c->seed_slot2.as<uint32_t>(); a.matched_loc = c->seed_loc2.as<int64_t>();      // also for the deferred pass below
+				HIP_TRY(launch_seed_pairs_tiled(a, sid, (int64_t)counts[sid], st));
+			}
+			else
+				HIP_TRY(launch_seed_pairs(a, sid, (int64_t)counts[sid], st));
 			ms += tm.stop();
 			if (!sp.use_ungapped) continue;
 			// pairs scoring above 255 (rare): resolve the reference's SIMD-batch saturation rule in a second pass

@@ -57,6 +57,9 @@ hipError_t launch_seed_lists(const SeedArgs& a, uint32_t* sorted_slot, uint32_t*
 hipError_t launch_seed_stream(const SeedArgs& a, int sid, hipStream_t st);
 hipError_t launch_seed_mask(const SeedArgs& a, int sid, hipStream_t st);
 hipError_t launch_seed_pairs(const SeedArgs& a, int sid, int64_t n_matched, hipStream_t st);
+hipError_t launch_seed_pairs_tiled(const SeedArgs& a, int sid, int64_t n_matched, hipStream_t st);      // a.matched_* sorted by slot
+hipError_t sort_matched_by_slot(const uint32_t* slot_in, uint32_t* slot_out, const int64_t* loc_in, int64_t* loc_out, int64_t n, int slot_bits,
+	void** tmp, size_t* tmp_bytes, hipStream_t st);
 hipError_t launch_seed_collect(const SeedArgs& a, int64_t n_matched, hipStream_t st);
 hipError_t launch_seed_deferred(const SeedArgs& a, int sid, int64_t n_deferred, hipStream_t st);
 // ascending device sort of n 64-bit keys (rocPRIM radix sort); tmp is grown as needed

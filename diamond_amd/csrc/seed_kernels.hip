@@ -243,12 +243,12 @@ __device__ __forceinline__ void finish_pair(const SeedArgs& a, int sid, int chun
 }
 
 // Hamming + stage-2 score filters and emission for one (joined reference position m, query position x) pair
-__device__ __forceinline__ void filter_pair(const SeedArgs& a, int sid, int64_t m, uint32_t slot, uint32_t slot_flags, int chunk, int64_t sloc, uint32_t x)
+// everything after the Hamming filter for one (joined reference position m, query position x) pair
+__device__ __forceinline__ void post_hamming(const SeedArgs& a, int sid, int64_t m, uint32_t slot, uint32_t slot_flags, int chunk, int64_t sloc, uint32_t x)
 {
 	const int8_t* s = a.tdata + sloc;
 	const int64_t qp = a.q_begin + x;
 	const int8_t* q = a.qdata + qp;
-	if (fingerprint_id(q, s) < a.params.hamming_filter_id) return;
 	const uint32_t qid = a.qid_of[qp];
 	const int seed_offset = (int)(qp - a.qlimits[qid]);
 	int score = 0xFFFF;
@@ -273,6 +273,12 @@ __device__ __forceinline__ void filter_pair(const SeedArgs& a, int sid, int64_t 
 		}
 	}
 	finish_pair(a, sid, chunk, qp, q, s, qid, seed_offset, query_len, sloc, score);
+}
+
+__device__ __forceinline__ void filter_pair(const SeedArgs& a, int sid, int64_t m, uint32_t slot, uint32_t slot_flags, int chunk, int64_t sloc, uint32_t x)
+{
+	if (fingerprint_id(a.qdata + a.q_begin + x, a.tdata + sloc) < a.params.hamming_filter_id) return;
+	post_hamming(a, sid, m, slot, slot_flags, chunk, sloc, x);
 }
 
 // One thread per joined reference position; the seed's query positions are a contiguous list. Work per position is the
@@ -307,6 +313,81 @@ __global__ void seed_pair_kernel(SeedArgs a, int sid, int64_t n_matched)
 		const int h_chunk = __shfl(chunk, src);
 		const int64_t h_sloc = (int64_t)__shfl((long long)sloc, src), h_m = (int64_t)__shfl((long long)m, src);
 		for (uint32_t i = (uint32_t)lane; i < h_count; i += 64) filter_pair(a, sid, h_m, h_slot, h_flags, h_chunk, h_sloc, a.qlist[h_head + i]);
+	}
+}
+
+// ---- tiled pair filter for the sensitive modes -------------------------------------------------------------------------
+// With short seeds a third of the reference positions join and the Hamming filter sees ~3e9 (query, reference) window pairs
+// per shape. The joined positions are first sorted by seed slot (radix sort), so that the 256 entries of a workgroup belong to
+// a few seeds; per seed with a long query list the workgroup stages the 48-byte query windows in LDS, TQ at a time, and every
+// thread compares them (broadcast LDS reads) with its own reference window held in 12 registers: the query windows are read
+// from the cache hierarchy once per workgroup instead of once per pair.
+__device__ __forceinline__ int window_identity(const uint32_t* a, const uint32_t* b)
+{
+	int n = 0;
+#pragma unroll
+	for (int w = 0; w < 12; ++w) {
+		const uint32_t d = (a[w] ^ b[w]) & 0x1f1f1f1fu;
+		n += 4 - __builtin_popcount((d + 0x7f7f7f7fu) & 0x80808080u);
+	}
+	return n;
+}
+
+__global__ __launch_bounds__(256) void seed_pair_tiled_kernel(SeedArgs a, int sid, int64_t n_matched)
+{
+	constexpr uint32_t LIGHT = 8;
+	constexpr int TQ = 64;
+	__shared__ uint32_t q_tile[TQ * 12];
+	__shared__ uint32_t q_x[TQ];
+	__shared__ uint32_t sh_slot[256], sh_head[256], sh_count[256], run_of[256];
+	__shared__ int n_runs;
+	const int tid = threadIdx.x;
+	const int64_t m = (int64_t)blockIdx.x * 256 + tid;
+	uint32_t slot = LIST_END, head = 0, count = 0, flags = 0;
+	int64_t sloc = 0;
+	int chunk = 0;
+	uint32_t sw[12];
+#pragma unroll
+	for (int w = 0; w < 12; ++w) sw[w] = 0;
+	if (m < n_matched) {
+		slot = a.matched_slot[m];
+		const SeedSlot sl = a.slots[slot];
+		if (!(sl.flags & SLOT_ERASED)) {
+			head = sl.head; count = sl.flags >> 8; flags = sl.flags;
+			sloc = a.matched_loc[m];
+			chunk = seed_chunk(a.params, seed_of_key(a.params, sid, sl.key));
+			__builtin_memcpy(sw, a.tdata + sloc - 16, 48);
+		}
+	}
+	if (count > 0 && count <= LIGHT)
+		for (uint32_t i = 0; i < count; ++i) filter_pair(a, sid, m, slot, flags, chunk, sloc, a.qlist[head + i]);
+	const bool heavy = count > LIGHT;
+	sh_slot[tid] = heavy ? slot : LIST_END;
+	sh_head[tid] = head; sh_count[tid] = count;
+	if (tid == 0) n_runs = 0;
+	__syncthreads();
+	if (heavy && (tid == 0 || sh_slot[tid - 1] != slot)) run_of[atomicAdd(&n_runs, 1)] = (uint32_t)tid;      // first entry of a run of equal slots
+	__syncthreads();
+	const int runs = n_runs;
+	for (int r = 0; r < runs; ++r) {
+		const uint32_t lt = run_of[r], r_slot = sh_slot[lt], r_head = sh_head[lt], r_count = sh_count[lt];
+		for (uint32_t base = 0; base < r_count; base += TQ) {
+			const int nt = (int)(r_count - base < (uint32_t)TQ ? r_count - base : (uint32_t)TQ);
+			for (int idx = tid; idx < nt * 12; idx += 256) {
+				const int w = idx / 12, d = idx - 12 * w;
+				const uint32_t x = a.qlist[r_head + base + w];
+				uint32_t v;
+				__builtin_memcpy(&v, a.qdata + a.q_begin + x - 16 + 4 * d, 4);
+				q_tile[idx] = v;
+				if (d == 0) q_x[w] = x;
+			}
+			__syncthreads();
+			if (heavy && slot == r_slot)
+				for (int w = 0; w < nt; ++w)
+					if (window_identity(sw, q_tile + 12 * w) >= a.params.hamming_filter_id)
+						post_hamming(a, sid, m, slot, flags, chunk, sloc, q_x[w]);
+			__syncthreads();
+		}
 	}
 }
 
@@ -414,6 +495,31 @@ hipError_t launch_seed_pairs(const SeedArgs& a, int sid, int64_t n_matched, hipS
 	if (n_matched == 0) return hipSuccess;
 	hipLaunchKernelGGL(seed_pair_kernel, dim3(blocks_for(n_matched, 128)), dim3(128), 0, st, a, sid, n_matched);
 	return hipGetLastError();
+}
+
+hipError_t launch_seed_pairs_tiled(const SeedArgs& a, int sid, int64_t n_matched, hipStream_t st)
+{
+	if (n_matched == 0) return hipSuccess;
+	hipLaunchKernelGGL(seed_pair_tiled_kernel, dim3(blocks_for(n_matched, 256)), dim3(256), 0, st, a, sid, n_matched);
+	return hipGetLastError();
+}
+
+// stable sort of the joined positions by slot: (slot_in, loc_in) -> (slot_out, loc_out)
+hipError_t sort_matched_by_slot(const uint32_t* slot_in, uint32_t* slot_out, const int64_t* loc_in, int64_t* loc_out, int64_t n, int slot_bits,
+	void** tmp, size_t* tmp_bytes, hipStream_t st)
+{
+	if (n <= 0) return hipSuccess;
+	size_t need = 0;
+	hipError_t e = rocprim::radix_sort_pairs(nullptr, need, slot_in, slot_out, loc_in, loc_out, (size_t)n, 0, slot_bits, st);
+	if (e != hipSuccess) return e;
+	if (need > *tmp_bytes) {
+		if (*tmp) (void)hipFree(*tmp);
+		*tmp = nullptr; *tmp_bytes = 0;
+		e = hipMalloc(tmp, need);
+		if (e != hipSuccess) return e;
+		*tmp_bytes = need;
+	}
+	return rocprim::radix_sort_pairs(*tmp, need, slot_in, slot_out, loc_in, loc_out, (size_t)n, 0, slot_bits, st);
 }
 
 hipError_t launch_seed_collect(const SeedArgs& a, int64_t n_matched, hipStream_t st)

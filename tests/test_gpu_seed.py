@@ -79,6 +79,23 @@ def test_buffer_overflow_retry_paths_are_transparent(ctx, monkeypatch):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("tap", ["ext_fast_synth.tap", "ext_default.tap", "ext_sensitive.tap", "ext_blastx.tap", "ext_rank.tap"])
+def test_tiled_pair_filter_equals_reference(ctx, tap, monkeypatch):
+    """The LDS-tiled pair filter (joined positions sorted by seed; normally chosen for >= 4 M joined positions per shape)
+    forced on the goldens: same hit multiset as the reference."""
+    cfg, recs = read_ext_tap(os.path.join(GOLDEN, tap))
+    ctx.upload_block(hip.QUERY, cfg["query"]["data"], cfg["query"]["limits"])
+    ctx.upload_block(hip.TARGET, cfg["target"]["data"], cfg["target"]["limits"])
+    monkeypatch.setenv("DMND_SEED_TILED", "1")
+    hits = ctx.seed_search(to_hip_params(cfg))
+    monkeypatch.setenv("DMND_SEED_TILED", "0")
+    plain = ctx.seed_search(to_hip_params(cfg))
+    monkeypatch.delenv("DMND_SEED_TILED")
+    ref = np.concatenate([r["hits"] for r in recs])
+    assert len(hits) == len(ref) and hit_multiset(hits) == hit_multiset(ref)
+    assert np.array_equal(hits, plain)
+
+
 @pytest.mark.parametrize("chunks,bits", [(1, 8), (3, 9), (7, 10)])
 def test_seed_hits_equal_oracle_other_partitionings(ctx, chunks, bits):
     cfg, _ = read_ext_tap(os.path.join(GOLDEN, "ext_fast_synth.tap"), max_records=1)
