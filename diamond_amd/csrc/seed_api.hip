@@ -202,7 +202,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	if (int rc = c->seed_qlist.ensure((size_t)S * nq_pos * sizeof(uint32_t))) return rc;
 	if (int rc = c->seed_qkeys.ensure((size_t)nq_pos * sizeof(uint32_t))) return rc;
 	HIP_TRY(hipMemsetAsync(c->seed_next.p, 0xff, (size_t)S * nq_pos * sizeof(uint32_t), st));
-	if (int rc = c->counters.ensure((size_t)(S + 3) * sizeof(unsigned long long))) return rc;      // [S] hits, [S+1] deferred pairs, [S+2] collected positions
+	if (int rc = c->counters.ensure((size_t)(S + 4) * sizeof(unsigned long long))) return rc;      // [S] hits, [S+1] deferred pairs, [S+2] collected positions, [S+3] Hamming survivors
 	HIP_TRY(hipMemsetAsync(c->mask_time.p, SEED_NEVER, (size_t)c->block_len[DMND_QUERY] + 256, st));
 	HIP_TRY(hipMemsetAsync(c->seed_keys.p, 0xff, (size_t)S * slots * sizeof(SeedSlot), st));
 	HIP_TRY(launch_seed_qid(c->d_limits[DMND_QUERY].as<int64_t>(), (int64_t)ql.size() - 1, c->qid_of.as<uint32_t>(), st));
@@ -227,6 +227,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		a.matched_count = c->counters.as<unsigned long long>() + sid;
 		a.matched_cap = matched_cap;
 		a.deferred = nullptr; a.deferred_count = c->counters.as<unsigned long long>() + S + 1; a.deferred_cap = 0;
+		a.survivors = nullptr; a.survivor_count = c->counters.as<unsigned long long>() + S + 3; a.survivor_cap = 0;
 		a.e_key = nullptr; a.e_count = c->counters.as<unsigned long long>() + S + 2; a.e_n = 0;
 		a.matrix = c->matrix.as<int8_t>();
 		a.hits = c->seed_hits.as<dmnd_seed_hit>(); a.hit_count = c->counters.as<unsigned long long>() + S; a.hit_cap = 0;
@@ -244,7 +245,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	for (int attempt = 0;; ++attempt) {
 		if (int rc = c->matched_slot.ensure((size_t)cap_total * sizeof(uint32_t))) return rc;
 		if (int rc = c->matched_loc.ensure((size_t)cap_total * sizeof(int64_t))) return rc;
-		HIP_TRY(hipMemsetAsync(c->counters.p, 0, (size_t)(S + 3) * sizeof(unsigned long long), st));
+		HIP_TRY(hipMemsetAsync(c->counters.p, 0, (size_t)(S + 4) * sizeof(unsigned long long), st));
 		if (attempt > 0) {
 			HIP_TRY(hipMemsetAsync(c->seed_keys.p, 0xff, (size_t)S * slots * sizeof(SeedSlot), st));
 			HIP_TRY(hipMemsetAsync(c->seed_bitmap.p, 0, bm_total, st));
@@ -308,7 +309,21 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 				HIP_TRY(sort_matched_by_slot(a.matched_slot, c->seed_slot2.as<uint32_t>(), a.matched_loc, c->seed_loc2.as<int64_t>(), (int64_t)counts[sid], slot_bits,
 					&c->sort_tmp, &c->sort_tmp_bytes, st));
 				a.matched_slot = c->seed_slot2.as<uint32_t>(); a.matched_loc = c->seed_loc2.as<int64_t>();      // also for the deferred pass below
-				HIP_TRY(launch_seed_pairs_tiled(a, sid, (int64_t)counts[sid], st));
+				int64_t surv_cap = std::max<int64_t>(std::max<int64_t>((int64_t)1 << 22, 2 * (int64_t)counts[sid]), (int64_t)(c->seed_survivors.cap / sizeof(SeedSurvivor)));
+				if (const char* e = getenv("DMND_SEED_SURVIVOR_CAP")) surv_cap = std::max<int64_t>(1, atoll(e));
+				unsigned long long ns = 0;
+				for (int pass = 0;; ++pass) {
+					if (int rc = c->seed_survivors.ensure((size_t)surv_cap * sizeof(SeedSurvivor))) return rc;
+					a.survivors = c->seed_survivors.as<SeedSurvivor>(); a.survivor_cap = surv_cap;
+					HIP_TRY(hipMemsetAsync(a.survivor_count, 0, sizeof(unsigned long long), st));
+					HIP_TRY(launch_seed_pairs_tiled(a, sid, (int64_t)counts[sid], st));
+					HIP_TRY(hipMemcpyAsync(&ns, a.survivor_count, sizeof(ns), hipMemcpyDeviceToHost, st));
+					HIP_TRY(hipStreamSynchronize(st));
+					if ((int64_t)ns <= surv_cap) break;
+					if (pass >= 2) return fail(DMND_E_NOMEM, "dmnd_seed_search: survivor buffer overflow");
+					surv_cap = (int64_t)ns + 1024;
+				}
+				HIP_TRY(launch_seed_post(a, sid, (int64_t)ns, st));
 			}
 			else
 				HIP_TRY(launch_seed_pairs(a, sid, (int64_t)counts[sid], st));

@@ -22,6 +22,9 @@ struct SeedSlot { uint64_t key; uint32_t head; uint32_t flags; };      // NEED: 
 // reference's SIMD batch it would have been scored in (simd_batch_size_sorted), resolved in a second pass.
 struct SeedDeferred { int64_t m; uint32_t x; int32_t score; };
 
+// A (joined reference position m, query position x) pair that passed the Hamming filter of the tiled pair kernel
+struct SeedSurvivor { uint32_t m, x; };
+
 struct SeedArgs {
 	SeedParams params;
 	const int8_t* qdata; const int8_t* tdata;     // block letters (HBM)
@@ -42,6 +45,7 @@ struct SeedArgs {
 	// joined reference positions of this shape
 	uint32_t* matched_slot; int64_t* matched_loc; unsigned long long* matched_count; int64_t matched_cap;
 	SeedDeferred* deferred; unsigned long long* deferred_count; int64_t deferred_cap;
+	SeedSurvivor* survivors; unsigned long long* survivor_count; int64_t survivor_cap;
 	// joined positions of the seeds flagged SLOT_NEED, sorted by (slot, position) for the second pass
 	uint64_t* e_key; unsigned long long* e_count; int64_t e_n;     // key = slot << 40 | position
 	const int8_t* matrix;                         // 32x32 int8 substitution matrix (HBM) for the stage-2 ungapped window score
@@ -57,7 +61,8 @@ hipError_t launch_seed_lists(const SeedArgs& a, uint32_t* sorted_slot, uint32_t*
 hipError_t launch_seed_stream(const SeedArgs& a, int sid, hipStream_t st);
 hipError_t launch_seed_mask(const SeedArgs& a, int sid, hipStream_t st);
 hipError_t launch_seed_pairs(const SeedArgs& a, int sid, int64_t n_matched, hipStream_t st);
-hipError_t launch_seed_pairs_tiled(const SeedArgs& a, int sid, int64_t n_matched, hipStream_t st);      // a.matched_* sorted by slot
+hipError_t launch_seed_pairs_tiled(const SeedArgs& a, int sid, int64_t n_matched, hipStream_t st);      // a.matched_* sorted by slot; fills a.survivors
+hipError_t launch_seed_post(const SeedArgs& a, int sid, int64_t n_survivors, hipStream_t st);
 hipError_t sort_matched_by_slot(const uint32_t* slot_in, uint32_t* slot_out, const int64_t* loc_in, int64_t* loc_out, int64_t n, int slot_bits,
 	void** tmp, size_t* tmp_bytes, hipStream_t st);
 hipError_t launch_seed_collect(const SeedArgs& a, int64_t n_matched, hipStream_t st);

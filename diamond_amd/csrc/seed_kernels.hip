@@ -242,7 +242,6 @@ __device__ __forceinline__ void finish_pair(const SeedArgs& a, int sid, int chun
 	}
 }
 
-// Hamming + stage-2 score filters and emission for one (joined reference position m, query position x) pair
 // everything after the Hamming filter for one (joined reference position m, query position x) pair
 __device__ __forceinline__ void post_hamming(const SeedArgs& a, int sid, int64_t m, uint32_t slot, uint32_t slot_flags, int chunk, int64_t sloc, uint32_t x)
 {
@@ -333,19 +332,24 @@ __device__ __forceinline__ int window_identity(const uint32_t* a, const uint32_t
 	return n;
 }
 
+// Pairs that pass the Hamming filter are NOT scored in place: in a wavefront only the ~10 % passing lanes would run the long
+// stage-2 code while the others wait (measured: 3/4 of the kernel's time). They are staged in LDS, flushed to a compact
+// survivor list with one global atomic per flush, and scored by seed_post_kernel with all lanes busy.
 __global__ __launch_bounds__(256) void seed_pair_tiled_kernel(SeedArgs a, int sid, int64_t n_matched)
 {
 	constexpr uint32_t LIGHT = 8;
 	constexpr int TQ = 64;
+	constexpr unsigned STAGE = 2048;
 	__shared__ uint32_t q_tile[TQ * 12];
 	__shared__ uint32_t q_x[TQ];
 	__shared__ uint32_t sh_slot[256], sh_head[256], sh_count[256], run_of[256];
+	__shared__ SeedSurvivor stage[STAGE];
+	__shared__ unsigned st_n;
+	__shared__ unsigned long long st_base;
 	__shared__ int n_runs;
 	const int tid = threadIdx.x;
 	const int64_t m = (int64_t)blockIdx.x * 256 + tid;
-	uint32_t slot = LIST_END, head = 0, count = 0, flags = 0;
-	int64_t sloc = 0;
-	int chunk = 0;
+	uint32_t slot = LIST_END, head = 0, count = 0;
 	uint32_t sw[12];
 #pragma unroll
 	for (int w = 0; w < 12; ++w) sw[w] = 0;
@@ -353,21 +357,47 @@ __global__ __launch_bounds__(256) void seed_pair_tiled_kernel(SeedArgs a, int si
 		slot = a.matched_slot[m];
 		const SeedSlot sl = a.slots[slot];
 		if (!(sl.flags & SLOT_ERASED)) {
-			head = sl.head; count = sl.flags >> 8; flags = sl.flags;
-			sloc = a.matched_loc[m];
-			chunk = seed_chunk(a.params, seed_of_key(a.params, sid, sl.key));
-			__builtin_memcpy(sw, a.tdata + sloc - 16, 48);
+			head = sl.head; count = sl.flags >> 8;
+			__builtin_memcpy(sw, a.tdata + a.matched_loc[m] - 16, 48);
 		}
 	}
-	if (count > 0 && count <= LIGHT)
-		for (uint32_t i = 0; i < count; ++i) filter_pair(a, sid, m, slot, flags, chunk, sloc, a.qlist[head + i]);
+	auto survive = [&](uint32_t x) {
+		const unsigned k = atomicAdd(&st_n, 1u);
+		if (k < STAGE) stage[k] = SeedSurvivor{ (uint32_t)m, x };
+		else {                                             // staging area full between two flushes: direct append
+			const unsigned long long idx = atomicAdd(a.survivor_count, 1ull);
+			if (idx < (unsigned long long)a.survivor_cap) a.survivors[idx] = SeedSurvivor{ (uint32_t)m, x };
+		}
+	};
+	auto flush = [&]() {                                   // block-uniform
+		__syncthreads();
+		const unsigned n = st_n < STAGE ? st_n : STAGE;
+		if (n) {
+			if (tid == 0) st_base = atomicAdd(a.survivor_count, (unsigned long long)n);
+			__syncthreads();
+			for (unsigned k = (unsigned)tid; k < n; k += 256) {
+				const unsigned long long idx = st_base + k;
+				if (idx < (unsigned long long)a.survivor_cap) a.survivors[idx] = stage[k];
+			}
+		}
+		__syncthreads();
+		if (tid == 0) st_n = 0;
+		__syncthreads();
+	};
 	const bool heavy = count > LIGHT;
 	sh_slot[tid] = heavy ? slot : LIST_END;
 	sh_head[tid] = head; sh_count[tid] = count;
-	if (tid == 0) n_runs = 0;
+	if (tid == 0) { n_runs = 0; st_n = 0; }
 	__syncthreads();
 	if (heavy && (tid == 0 || sh_slot[tid - 1] != slot)) run_of[atomicAdd(&n_runs, 1)] = (uint32_t)tid;      // first entry of a run of equal slots
-	__syncthreads();
+	if (count > 0 && count <= LIGHT)
+		for (uint32_t i = 0; i < count; ++i) {
+			const uint32_t x = a.qlist[head + i];
+			uint32_t qw[12];
+			__builtin_memcpy(qw, a.qdata + a.q_begin + x - 16, 48);
+			if (window_identity(sw, qw) >= a.params.hamming_filter_id) survive(x);
+		}
+	flush();
 	const int runs = n_runs;
 	for (int r = 0; r < runs; ++r) {
 		const uint32_t lt = run_of[r], r_slot = sh_slot[lt], r_head = sh_head[lt], r_count = sh_count[lt];
@@ -384,11 +414,25 @@ __global__ __launch_bounds__(256) void seed_pair_tiled_kernel(SeedArgs a, int si
 			__syncthreads();
 			if (heavy && slot == r_slot)
 				for (int w = 0; w < nt; ++w)
-					if (window_identity(sw, q_tile + 12 * w) >= a.params.hamming_filter_id)
-						post_hamming(a, sid, m, slot, flags, chunk, sloc, q_x[w]);
-			__syncthreads();
+					if (window_identity(sw, q_tile + 12 * w) >= a.params.hamming_filter_id) survive(q_x[w]);
+			flush();
 		}
 	}
+}
+
+// stage-2 scoring, left-most rule and emission for the compact list of pairs that passed the Hamming filter
+__global__ __launch_bounds__(256) void seed_post_kernel(SeedArgs a, int sid, int64_t n_survivors)
+{
+	__shared__ int8_t matrix[32 * 32];
+	for (int i = threadIdx.x; i < 1024; i += blockDim.x) matrix[i] = a.matrix[i];
+	__syncthreads();
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_survivors) return;
+	a.matrix = matrix;                                    // flat pointer into LDS
+	const SeedSurvivor sv = a.survivors[i];
+	const uint32_t slot = a.matched_slot[sv.m];
+	const SeedSlot sl = a.slots[slot];
+	post_hamming(a, sid, (int64_t)sv.m, slot, sl.flags, seed_chunk(a.params, seed_of_key(a.params, sid, sl.key)), a.matched_loc[sv.m], sv.x);
 }
 
 // copies the joined positions of the seeds that have deferred pairs as sort keys slot << 40 | position
@@ -501,6 +545,13 @@ hipError_t launch_seed_pairs_tiled(const SeedArgs& a, int sid, int64_t n_matched
 {
 	if (n_matched == 0) return hipSuccess;
 	hipLaunchKernelGGL(seed_pair_tiled_kernel, dim3(blocks_for(n_matched, 256)), dim3(256), 0, st, a, sid, n_matched);
+	return hipGetLastError();
+}
+
+hipError_t launch_seed_post(const SeedArgs& a, int sid, int64_t n_survivors, hipStream_t st)
+{
+	if (n_survivors == 0) return hipSuccess;
+	hipLaunchKernelGGL(seed_post_kernel, dim3(blocks_for(n_survivors, 256)), dim3(256), 0, st, a, sid, n_survivors);
 	return hipGetLastError();
 }
 

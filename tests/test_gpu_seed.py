@@ -88,6 +88,9 @@ def test_tiled_pair_filter_equals_reference(ctx, tap, monkeypatch):
     ctx.upload_block(hip.TARGET, cfg["target"]["data"], cfg["target"]["limits"])
     monkeypatch.setenv("DMND_SEED_TILED", "1")
     hits = ctx.seed_search(to_hip_params(cfg))
+    monkeypatch.setenv("DMND_SEED_SURVIVOR_CAP", "5")          # survivor list too small: grows and reruns
+    assert np.array_equal(ctx.seed_search(to_hip_params(cfg)), hits)
+    monkeypatch.delenv("DMND_SEED_SURVIVOR_CAP")
     monkeypatch.setenv("DMND_SEED_TILED", "0")
     plain = ctx.seed_search(to_hip_params(cfg))
     monkeypatch.delenv("DMND_SEED_TILED")
