@@ -116,6 +116,9 @@ __device__ __forceinline__ uint32_t reduce4(uint32_t letter, uint64_t map_lo, ui
 	const uint64_t m = (letter & 16) ? map_hi : map_lo;
 	return (uint32_t)(m >> ((letter & 15) * 4)) & 15u;
 }
+// LEVEL2: consult the level-2 bitmap before the table. It pays when most level-1 positives are false (long seeds: --fast,
+// default); with short seeds (weight <= 9: a third of the reference positions really join) it is a wasted random access.
+template<bool LEVEL2>
 __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int sid, uint64_t map_lo, uint64_t map_hi, int64_t base, uint64_t care64)
 {
 	// Joined positions are staged in LDS and flushed with ONE atomic on the shared counter per workgroup: an atomicAdd per
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 			uint64_t slot = hh & a.slot_mask;
 			bool found = false;
 			uint32_t fl = 0;
-			if ((a.bitmap[(uint32_t)(hh >> 32) & a.bitmap_mask] >> (uint32_t)(hh >> 59)) & 1u)
+			if (!LEVEL2 || ((a.bitmap[(uint32_t)(hh >> 32) & a.bitmap_mask] >> (uint32_t)(hh >> 59)) & 1u))
 				for (;;) {
 					const SeedSlot sl = a.slots[slot];
 					if (sl.key == SEED_EMPTY) break;
@@ -521,7 +524,10 @@ hipError_t launch_seed_stream(const SeedArgs& a, int sid, hipStream_t st)
 		const int64_t threads = (a.t_end - base + 15) / 16;
 		uint64_t care64 = 0;
 		for (int k = 0; k < c.shape_weight[sid]; ++k) care64 |= (uint64_t)15 << (4 * c.shape_pos[sid][k]);
-		hipLaunchKernelGGL(seed_stream_fast_kernel, dim3(blocks_for(threads, 256)), dim3(256), 0, st, a, sid, lo, hi, base, care64);
+		if (c.shape_weight[sid] >= 10)
+			hipLaunchKernelGGL(seed_stream_fast_kernel<true>, dim3(blocks_for(threads, 256)), dim3(256), 0, st, a, sid, lo, hi, base, care64);
+		else
+			hipLaunchKernelGGL(seed_stream_fast_kernel<false>, dim3(blocks_for(threads, 256)), dim3(256), 0, st, a, sid, lo, hi, base, care64);
 		return hipGetLastError();
 	}
 	hipLaunchKernelGGL(seed_stream_kernel, dim3(blocks_for(a.t_end - a.t_begin, 256)), dim3(256), 0, st, a, sid);
