@@ -104,11 +104,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    # test hook: several ranks on ONE GPU (RCCL refuses that), used to exercise the multi-rank code path on a 1-GPU box:
+    # DMND_BENCH_SHARE_GPU=1 maps every rank to cuda:0 and gathers the top-k records over gloo instead of RCCL
+    share_gpu = os.environ.get("DMND_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    coll_device = torch.device("cpu") if share_gpu else device
     assert world == args.gpus or world == 1
     threads = args.host_threads or max(1, min(32, (os.cpu_count() or 8) // max(world, 1)))
 
@@ -133,7 +142,7 @@ def main():
         t_b = time.perf_counter()
         matches, _ = ctx.extend(qd, td, hits, threads=threads)
         t_c = time.perf_counter()
-        aligned = gather_topk(args.queries, matches, device)
+        aligned = gather_topk(args.queries, matches, coll_device)
         t_d = time.perf_counter()
         state.update(hits=int(hits.size), matches=int(matches.size), aligned=aligned, seed_ms=ctx.seed_kernel_ms(), ext=ctx.extend_stats(),
                      wall_ms={"seed_stage_call": (t_b - t_a) * 1e3, "extension_call": (t_c - t_b) * 1e3, "topk_gather": (t_d - t_c) * 1e3})
@@ -155,7 +164,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
