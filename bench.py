@@ -119,7 +119,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     coll_device = torch.device("cpu") if share_gpu else device
     assert world == args.gpus or world == 1
-    threads = args.host_threads or max(1, min(32, (os.cpu_count() or 8) // max(world, 1)))
+    threads = args.host_threads or max(1, min(64, (os.cpu_count() or 8) // max(world, 1)))
 
     # every rank: its own seeded query slice + database block (weak scaling: per-GPU work is fixed)
     db, doff, q, qoff = synth.generate(args.families, members=10, queries=args.queries, seed=20260923 + 1000 * rank)
