@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Cost split of the seed stage's pair filter on the C2 blocks (first two --sensitive shapes): normal run, Hamming threshold
+set above 48 (nothing passes: the pure all-pairs stage), and the same with the untiled kernel (DMND_SEED_TILED=0)."""
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from diamond_amd import hip, synth, workload
