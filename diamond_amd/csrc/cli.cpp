@@ -224,7 +224,7 @@ void write_dmnd(const std::string& path, const SeqBlock& b)
 
 struct Options {
 	std::string command, query, db, out, in;
-	int threads = 0, k = 25;
+	int threads = 0, k = 25, cbs = 1;
 	double evalue = 0.001;
 	bool fast = false;
 	std::string masking = "", motif_masking = "", sens = "";
@@ -246,6 +246,7 @@ Options parse(int argc, char** argv)
 		else if (a == "-k" || a == "--max-target-seqs") o.k = std::atoi(need(i).c_str());
 		else if (a == "-e" || a == "--evalue") o.evalue = std::atof(need(i).c_str());
 		else if (a == "--fast") o.fast = true;
+		else if (a == "--comp-based-stats") { o.cbs = std::atoi(need(i).c_str()); if (o.cbs != 0 && o.cbs != 1) throw std::runtime_error("Only --comp-based-stats 0 and 1 are implemented."); }
 		else if (a == "--masking") o.masking = need(i);
 		else if (a == "--motif-masking") o.motif_masking = need(i);
 		else if (a == "--algo") { if (need(i) != "0") throw std::runtime_error("Only --algo 0 (double-indexed) is implemented."); }
@@ -292,6 +293,7 @@ int run_blastp(const Options& o)
 	if (!ctx) throw std::runtime_error(dmnd_last_error());
 	auto chk = [&](int rc) { if (rc != DMND_OK) throw std::runtime_error(dmnd_last_error()); };
 	chk(dmnd_set_max_target_seqs(ctx, o.k));
+	chk(dmnd_set_comp_based_stats(ctx, o.cbs));
 	chk(dmnd_set_query_contexts(ctx, blastx ? 6 : 1));
 	t0 = std::chrono::steady_clock::now();
 	chk(dmnd_upload_block(ctx, DMND_QUERY, q.data.data(), (int64_t)q.data.size(), q.limits.data(), (int64_t)q.ids.size()));

@@ -60,6 +60,7 @@ struct dmnd_ctx {
 	std::vector<int8_t> host_cbs_buf;          // Hauser bias of the query block (host copy, parallel to the block letters)
 	double ext_stats[12] = { 0 };
 	double host_ms[3] = { 0, 0, 0 };           // host wall time inside dmnd_banded_swipe: prepare, launch+wait, unpack (DMND_TRACE)
+	int comp_based_stats = 1;                  // config.comp_based_stats: 1 = Hauser bias (default), 0 = off
 	int query_contexts = 1;                    // align_mode.query_contexts: 6 for blastx (basic/basic.cpp:40-60)
 	int max_target_seqs = 25;                  // config.max_target_seqs (-k), basic/config.h:55
 };

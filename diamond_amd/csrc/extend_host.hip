@@ -67,6 +67,7 @@ struct HostCfg {
 	int64_t max_swipe_dp = 1000000;      // config.max_swipe_dp
 	int band_mode_fast = 1;              // Extension::Mode::BANDED_FAST for every sensitivity up to --sensitive
 	double ref_letters = 0;
+	bool use_cbs = true;                 // config.comp_based_stats == 1 (Hauser bias); 0 = no composition correction
 	int contexts = 1;                    // align_mode.query_contexts: 1 (blastp) or 6 (blastx: the block holds 6 frames per read)
 };
 
@@ -415,7 +416,7 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 	std::vector<ChainWorkspace> ws((size_t)threads);
 	lap(5, 3);
 	auto item_of = [&](uint32_t q, uint32_t t, int d0, int d1) {
-		return dmnd_dp_target{ ql[q], tl[t], ql[q], (int32_t)(ql[q + 1] - ql[q] - 1), (int32_t)(tl[t + 1] - tl[t] - 1), d0, d1 };
+		return dmnd_dp_target{ ql[q], tl[t], h.use_cbs ? ql[q] : (int64_t)-1, (int32_t)(ql[q + 1] - ql[q] - 1), (int32_t)(tl[t + 1] - tl[t] - 1), d0, d1 };
 	};
 	double sw1 = 0, sw2 = 0, tb2 = 0;
 	int64_t used = 0;
@@ -430,7 +431,7 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 			parallel_for(active.size(), threads, [&](size_t a, int t) {
 				QueryState& s = qs[active[a]];
 				s.plan.clear();
-				plan_groups(h, ws[(size_t)t], s.w, s.w.i0, s.w.i1, qdata, ql.data(), tdata, tl.data(), cbs.data(), s.plan);
+				plan_groups(h, ws[(size_t)t], s.w, s.w.i0, s.w.i1, qdata, ql.data(), tdata, tl.data(), h.use_cbs ? cbs.data() : nullptr, s.plan);
 			});
 			items.clear();
 			for (size_t i : active) {
@@ -613,6 +614,7 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	make_cfg(c, h);
 	h.max_target_seqs = c->max_target_seqs;
 	h.contexts = c->query_contexts;
+	h.use_cbs = c->comp_based_stats != 0;
 	const uint32_t C = (uint32_t)h.contexts;
 	if ((ql.size() - 1) % C != 0) return fail(DMND_E_ARG, "dmnd_extend: query block size is not a multiple of the query contexts");
 	h.ref_letters = (double)(tl.back() - tl.front() - ((int64_t)tl.size() - 1));
@@ -632,8 +634,11 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	if (cbs.size() < (size_t)ql.back() + 64) cbs.assign((size_t)ql.back() + 64, 0);
 	// With the gapped filter on, the bias of every query is needed before the sub-batches start; otherwise every sub-batch
 	// computes and uploads the slice of its own queries (on its own stream), overlapped with the other sub-batches.
-	const bool bias_in_prelude = c->gapped_filter_evalue > 0.0;
-	if (bias_in_prelude) {
+	const bool bias_in_prelude = c->gapped_filter_evalue > 0.0 || !h.use_cbs;
+	if (!h.use_cbs) {
+		c->cbs_len = 0;                                     // --comp-based-stats 0: no bias anywhere on the path
+	}
+	else if (bias_in_prelude) {
 		parallel_for(qr.size(), threads, [&](size_t i, int) {
 			const uint32_t q0 = hits[qr[i].b].query / C * C;
 			for (uint32_t q = q0; q < q0 + C; ++q) {
@@ -654,7 +659,7 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	c->gf_ms = 0;
 	if (c->gapped_filter_evalue > 0.0 && n_hits > 0) {
 		gf.resize((size_t)n_hits);
-		if (int rc = dmnd_gapped_filter(c, hits, n_hits, 1, gf.data(), nullptr)) return rc;
+		if (int rc = dmnd_gapped_filter(c, hits, n_hits, h.use_cbs ? 1 : 0, gf.data(), nullptr)) return rc;
 	}
 	lap(4, 2);
 	if (std::getenv("DMND_TRACE")) std::fprintf(stderr, "dmnd_extend ms: hauser+upload %.2f gapped_filter %.2f\n", fine[1], fine[2]);
@@ -711,6 +716,13 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 		int64_t off = 0;
 		for (const auto& v : parts) { std::copy(v.begin(), v.end(), out + off); off += (int64_t)v.size(); }
 	}
+	return DMND_OK;
+}
+
+extern "C" int dmnd_set_comp_based_stats(dmnd_ctx* c, int mode)
+{
+	if (!c || (mode != 0 && mode != 1)) return fail(DMND_E_ARG, "dmnd_set_comp_based_stats: only modes 0 (off) and 1 (Hauser, the default) are implemented");
+	c->comp_based_stats = mode;
 	return DMND_OK;
 }
 

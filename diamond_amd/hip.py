@@ -67,7 +67,7 @@ EXPORTS = ["dmnd_abi_version", "dmnd_last_error", "dmnd_default_params", "dmnd_c
            "dmnd_bitscore_p", "dmnd_evalue_batch", "dmnd_last_kernel_ms", "dmnd_seed_params_fast", "dmnd_seed_params_default", "dmnd_seed_search",
            "dmnd_seed_hits", "dmnd_seed_kernel_ms", "dmnd_extend_plan", "dmnd_extend", "dmnd_extend_stats", "dmnd_format_tab", "dmnd_set_max_target_seqs",
            "dmnd_seed_params_sensitive", "dmnd_set_gapped_filter", "dmnd_gapped_filter", "dmnd_gapped_filter_ms",
-           "dmnd_set_query_contexts", "dmnd_translate", "dmnd_format_tab_translated", "dmnd_mask_block", "dmnd_mask_kernel_ms", "dmnd_seed_params_preset"]
+           "dmnd_set_query_contexts", "dmnd_translate", "dmnd_format_tab_translated", "dmnd_mask_block", "dmnd_mask_kernel_ms", "dmnd_seed_params_preset", "dmnd_set_comp_based_stats"]
 
 
 def load():
@@ -354,6 +354,11 @@ class Context:
 
     def mask_kernel_ms(self):
         return float(self.lib.dmnd_mask_kernel_ms(self.h))
+
+    def set_comp_based_stats(self, mode):
+        """1 = Hauser composition bias (default), 0 = none."""
+        self.lib.dmnd_set_comp_based_stats.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        self._check(self.lib.dmnd_set_comp_based_stats(self.h, int(mode)))
 
     def set_query_contexts(self, contexts):
         """1 = blastp, 6 = blastx (the query block holds the six frames of every read consecutively)."""

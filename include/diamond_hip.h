@@ -281,6 +281,9 @@ int dmnd_format_tab_translated(const dmnd_match* m, const char* qseqid, const ch
 int dmnd_mask_block(dmnd_ctx* ctx, int which, int8_t* host_data, int64_t* n_masked);
 double dmnd_mask_kernel_ms(const dmnd_ctx* ctx);
 
+/* --comp-based-stats: 1 = Hauser composition bias (default; HauserCorrection, stats/hauser_correction.cpp), 0 = none.
+ * The matrix-adjust modes 2-4 (stats/cbs.cpp) are not implemented. */
+int dmnd_set_comp_based_stats(dmnd_ctx* ctx, int mode);
 /* -k / --max-target-seqs (default 25, src/basic/config.h:55) */
 int dmnd_set_max_target_seqs(dmnd_ctx* ctx, int k);
 /* Statistics of the last dmnd_extend: [0] round-1 DpTargets [1] round-2 DpTargets [2] round-1 cells [3] round-2 cells

@@ -37,6 +37,10 @@ def test_cli_makedb_blastp_matches_reference(tmp_path):
     assert len(ref.splitlines()) > 300
     assert open(tmp_path / "hip.tsv").read() == ref
     assert open(tmp_path / "hip2.tsv").read() == open(tmp_path / "ref2.tsv").read()
+    # no composition based statistics (reference ctest diamond-test-blastp-comp-based-stats-0)
+    _run([REF] + [a for a in ref_args if a != "--fast"] + ["--comp-based-stats", "0", "-d", str(tmp_path / "db.dmnd"), "-o", str(tmp_path / "ref5.tsv")])
+    _run([CLI, "blastp", "--masking", "0", "--comp-based-stats", "0", "-q", str(tmp_path / "q.faa"), "-d", str(tmp_path / "db.dmnd"), "-o", str(tmp_path / "hip5.tsv"), "-p", "4"])
+    assert open(tmp_path / "hip5.tsv").read() == open(tmp_path / "ref5.tsv").read()
     # default sensitivity (two shapes + stage-2 ungapped e-value filter)
     _run([REF] + [a for a in ref_args if a != "--fast"] + ["-d", str(tmp_path / "db.dmnd"), "-o", str(tmp_path / "ref3.tsv")])
     _run([CLI, "blastp", "--masking", "0", "-q", str(tmp_path / "q.faa"), "-d", str(tmp_path / "db.dmnd"), "-o", str(tmp_path / "hip3.tsv"), "-p", "4"])
