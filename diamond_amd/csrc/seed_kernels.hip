@@ -277,58 +277,44 @@ __device__ __forceinline__ void post_hamming(const SeedArgs& a, int sid, int64_t
 	finish_pair(a, sid, chunk, qp, q, s, qid, seed_offset, query_len, sloc, score);
 }
 
-// Pairs that pass the Hamming filter are NOT scored in place by the pair kernels: in a wavefront only the ~10 % passing lanes
-// would run the long stage-2 code while the others wait (measured on --sensitive: 3/4 of the kernel's time). They are staged in
-// LDS, flushed to a compact survivor list with one global atomic per flush, and scored by seed_post_kernel with all lanes busy.
+__device__ __forceinline__ void filter_pair(const SeedArgs& a, int sid, int64_t m, uint32_t slot, uint32_t slot_flags, int chunk, int64_t sloc, uint32_t x)
+{
+	if (fingerprint_id(a.qdata + a.q_begin + x, a.tdata + sloc) < a.params.hamming_filter_id) return;
+	post_hamming(a, sid, m, slot, slot_flags, chunk, sloc, x);
+}
 
 // One thread per joined reference position; the seed's query positions are a contiguous list. Work per position is the
 // list length, which is heavily skewed (a frequent seed has thousands of query positions and thousands of joined reference
 // positions): lists longer than LIGHT are processed by the whole wavefront, 64 query positions at a time, so that no lane
 // runs a 10^4-iteration loop while the rest of the machine idles.
-__global__ __launch_bounds__(128) void seed_pair_kernel(SeedArgs a, int sid, int64_t n_matched)
+__global__ void seed_pair_kernel(SeedArgs a, int sid, int64_t n_matched)
 {
 	constexpr uint32_t LIGHT = 8;
-	constexpr unsigned STAGE = 1024;
-	__shared__ SeedSurvivor stage[STAGE];
-	__shared__ unsigned st_n;
-	__shared__ unsigned long long st_base;
-	if (threadIdx.x == 0) st_n = 0;
-	__syncthreads();
 	const int lane = threadIdx.x & 63;
 	const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	uint32_t head = 0, count = 0;
+	uint32_t slot = 0, head = 0, count = 0, flags = 0;
 	int64_t sloc = 0;
+	int chunk = 0;
 	if (m < n_matched) {
-		const SeedSlot sl = a.slots[a.matched_slot[m]];   // list start, size and state of the seed in one 16-byte read
-		if (!(sl.flags & SLOT_ERASED)) { head = sl.head; count = sl.flags >> 8; sloc = a.matched_loc[m]; }
-	}
-	auto test = [&](int64_t mm, int64_t s_loc, uint32_t x) {
-		if (fingerprint_id(a.qdata + a.q_begin + x, a.tdata + s_loc) < a.params.hamming_filter_id) return;
-		const unsigned k = atomicAdd(&st_n, 1u);
-		if (k < STAGE) stage[k] = SeedSurvivor{ (uint32_t)mm, x };
-		else {                                             // staging area full: direct append
-			const unsigned long long idx = atomicAdd(a.survivor_count, 1ull);
-			if (idx < (unsigned long long)a.survivor_cap) a.survivors[idx] = SeedSurvivor{ (uint32_t)mm, x };
+		slot = a.matched_slot[m];
+		const SeedSlot sl = a.slots[slot];                // key, list start, size and state of the seed in one 16-byte read
+		if (!(sl.flags & SLOT_ERASED)) {
+			head = sl.head; count = sl.flags >> 8; flags = sl.flags;
+			sloc = a.matched_loc[m];
+			chunk = seed_chunk(a.params, seed_of_key(a.params, sid, sl.key));
 		}
-	};
+	}
 	if (count <= LIGHT)
-		for (uint32_t i = 0; i < count; ++i) test(m, sloc, a.qlist[head + i]);
+		for (uint32_t i = 0; i < count; ++i) filter_pair(a, sid, m, slot, flags, chunk, sloc, a.qlist[head + i]);
 	unsigned long long heavy = __ballot(count > LIGHT);
 	while (heavy) {
 		const int src = __builtin_ctzll(heavy);
 		heavy &= heavy - 1;
-		const uint32_t h_head = (uint32_t)__shfl((int)head, src), h_count = (uint32_t)__shfl((int)count, src);
+		const uint32_t h_slot = (uint32_t)__shfl((int)slot, src), h_head = (uint32_t)__shfl((int)head, src), h_count = (uint32_t)__shfl((int)count, src),
+			h_flags = (uint32_t)__shfl((int)flags, src);
+		const int h_chunk = __shfl(chunk, src);
 		const int64_t h_sloc = (int64_t)__shfl((long long)sloc, src), h_m = (int64_t)__shfl((long long)m, src);
-		for (uint32_t i = (uint32_t)lane; i < h_count; i += 64) test(h_m, h_sloc, a.qlist[h_head + i]);
-	}
-	__syncthreads();
-	const unsigned n = st_n < STAGE ? st_n : STAGE;
-	if (n == 0) return;
-	if (threadIdx.x == 0) st_base = atomicAdd(a.survivor_count, (unsigned long long)n);
-	__syncthreads();
-	for (unsigned k = threadIdx.x; k < n; k += blockDim.x) {
-		const unsigned long long idx = st_base + k;
-		if (idx < (unsigned long long)a.survivor_cap) a.survivors[idx] = stage[k];
+		for (uint32_t i = (uint32_t)lane; i < h_count; i += 64) filter_pair(a, sid, h_m, h_slot, h_flags, h_chunk, h_sloc, a.qlist[h_head + i]);
 	}
 }
 
@@ -349,6 +335,9 @@ __device__ __forceinline__ int window_identity(const uint32_t* a, const uint32_t
 	return n;
 }
 
+// Pairs that pass the Hamming filter are NOT scored in place: in a wavefront only the ~10 % passing lanes would run the long
+// stage-2 code while the others wait (measured: 3/4 of the kernel's time). They are staged in LDS, flushed to a compact
+// survivor list with one global atomic per flush, and scored by seed_post_kernel with all lanes busy.
 __global__ __launch_bounds__(256) void seed_pair_tiled_kernel(SeedArgs a, int sid, int64_t n_matched)
 {
 	constexpr uint32_t LIGHT = 8;
