@@ -93,5 +93,8 @@ synth.write_dna_fasta(sys.argv[2] + "/blastx_reads.fna", "r", dna, off)
 PY
 DIAMOND_TAP_EXT="$HERE/ext_blastx.tap" \
   "$TAP" blastx --masking 0 --motif-masking 0 --algo 0 -q "$HERE/blastx_reads.fna" -d "$TMP/x_db.faa" -o "$HERE/blastx.tsv" -p1 2>/dev/null
+# 10. the long proteins of step 3 end to end (round 2 takes the statistics-without-traceback path: DP size > 1e6 cells)
+DIAMOND_TAP_EXT="$HERE/ext_long.tap" \
+  "$TAP" blastp --masking 0 --motif-masking 0 --algo 0 -q "$TMP/long_q.faa" -d "$TMP/long_db.faa" -o "$HERE/long.tsv" -p1 2>/dev/null
 ls -la "$HERE"/*.tap
 rm -rf "$TMP"

@@ -35,7 +35,7 @@ def _run(ctx, cfg, db_letters):
     return ctx.extend(qd, td, hits, threads=4)[0]
 
 
-@pytest.mark.parametrize("tap", ["ext_fast_synth.tap", "ext_fast.tap", "ext_6x10.tap", "ext_rank.tap", "ext_default.tap", "ext_default_synth.tap", "ext_sensitive.tap", "ext_blastx.tap"])
+@pytest.mark.parametrize("tap", ["ext_fast_synth.tap", "ext_fast.tap", "ext_6x10.tap", "ext_rank.tap", "ext_default.tap", "ext_default_synth.tap", "ext_sensitive.tap", "ext_blastx.tap", "ext_long.tap"])
 def test_matches_equal_reference_extend(ctx, tap):
     cfg, recs = read_ext_tap(os.path.join(GOLDEN, tap))
     tl = cfg["target"]["limits"]
@@ -58,12 +58,12 @@ def test_matches_equal_reference_extend(ctx, tap):
             assert got["bit_score"] == pytest.approx(h["bit_score"], rel=1e-12)
             assert got["ungapped_score"] == ref["ungapped_score"]
             n += 1
-    assert pos == len(m) and n > 300
+    assert pos == len(m) and n > (300 if tap != "ext_long.tap" else 4)      # ext_long: 9 kb proteins, DP > 1e6 cells -> statistics-without-traceback path
 
 
 @pytest.mark.parametrize("tap,tsv", [("ext_fast_synth.tap", "fast_synth.tsv"), ("ext_rank.tap", "rank.tsv"),
                                      ("ext_default_synth.tap", "default_synth.tsv"), ("ext_default.tap", "default.tsv"),
-                                     ("ext_sensitive.tap", "sensitive.tsv"), ("ext_blastx.tap", "blastx.tsv")])
+                                     ("ext_sensitive.tap", "sensitive.tsv"), ("ext_blastx.tap", "blastx.tsv"), ("ext_long.tap", "long.tsv")])
 def test_tabular_output_is_byte_identical_to_reference(ctx, tap, tsv):
     cfg, recs = read_ext_tap(os.path.join(GOLDEN, tap))
     tl = cfg["target"]["limits"]
@@ -81,7 +81,7 @@ def test_tabular_output_is_byte_identical_to_reference(ctx, tap, tsv):
         assert len(reads) * 6 == cfg["query"]["n"]
     text = hip.format_tab(m, qids, tids, source_lens)
     ref = open(os.path.join(GOLDEN, tsv)).read()
-    assert len(ref.splitlines()) > 300
+    assert len(ref.splitlines()) > (300 if tsv != "long.tsv" else 4)
     assert text == ref
 
 
