@@ -151,3 +151,41 @@ def test_c3_sensitive_and_c4_blastx_at_scale(capsys):
     with capsys.disabled():
         import json
         print("\\nSCALE_TIMINGS " + json.dumps(out))
+
+
+def test_c2_tantan_masking_at_scale(capsys):
+    """tantan over the 3.0e8-letter C2 reference block in one call: sampled sequences equal the oracle bit for bit, untouched
+    delimiters, and the kernel time is printed for DESIGN.md."""
+    import json
+    from test_oracle_seed import blosum62_matrix8
+    assert torch.cuda.is_available()
+    db, doff, q, qoff = synth.generate(100_000, members=10, queries=10_000, seed=20260923)
+    rng = np.random.default_rng(5)
+    db = db.copy()
+    for i in rng.choice(len(doff) - 1, 20_000, replace=False):                    # plant repeats in 2 % of the sequences
+        n = int(doff[i + 1] - doff[i])
+        if n < 90:
+            continue
+        a, L = int(rng.integers(0, n - 70)), int(rng.integers(25, 70))
+        db[doff[i] + a: doff[i] + a + L] = np.resize(rng.integers(0, 20, int(rng.integers(1, 6))).astype(np.int8), L)
+    td, tl = workload.sequence_set(db, doff)
+    ctx = hip.Context()
+    try:
+        ctx.upload_block(hip.TARGET, td, tl)
+        masked = td.copy()
+        n = ctx.mask_block(hip.TARGET, masked)
+        ms = ctx.mask_kernel_ms()
+    finally:
+        ctx.close()
+    assert n > 300_000
+    assert (masked[tl[1:] - 1] == 31).all() and (masked[:256] == 31).all()
+    changed = masked != td
+    assert (masked[changed] == 23).all()
+    lr = orc.tantan_matrix(blosum62_matrix8())
+    planted = np.nonzero(np.add.reduceat(changed.astype(np.int64), tl[:-1]) > 0)[0]
+    sample = np.concatenate([rng.choice(planted, 150, replace=False), rng.choice(len(tl) - 1, 150, replace=False)])
+    for i in sample:
+        a, b = int(tl[i]), int(tl[i + 1]) - 1
+        assert np.array_equal(masked[a:b], orc.tantan_mask(td[a:b], lr)[0]), int(i)
+    with capsys.disabled():
+        print("\nMASK_TIMING " + json.dumps(dict(letters=int(doff[-1]), masked=int(n), kernel_ms=ms)))
