@@ -662,7 +662,11 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 		if (int rc = dmnd_gapped_filter(c, hits, n_hits, h.use_cbs ? 1 : 0, gf.data(), nullptr)) return rc;
 	}
 	lap(4, 2);
-	if (std::getenv("DMND_TRACE")) std::fprintf(stderr, "dmnd_extend ms: hauser+upload %.2f gapped_filter %.2f\n", fine[1], fine[2]);
+	if (std::getenv("DMND_TRACE")) {
+		const double t0 = now();
+		for (int i = 0; i < 20; ++i) parallel_for((size_t)threads, threads, [](size_t, int) {});
+		std::fprintf(stderr, "dmnd_extend ms: hauser+upload %.2f gapped_filter %.2f | empty parallel loop over %d threads: %.3f ms\n", fine[1], fine[2], threads, (now() - t0) / 20);
+	}
 	// 2.. : the queries are processed as `split` concurrent sub-batches, each on its own host thread, HIP stream and device work
 	// buffers (auxiliary contexts): while one sub-batch waits for its swipe kernels the others chain, cull and pack on the
 	// host. Results are concatenated in query order, so the output does not depend on the split.

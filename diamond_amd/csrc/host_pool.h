@@ -15,11 +15,20 @@ namespace dmnd {
 
 // Persistent worker pool: dmnd_extend issues a handful of short parallel loops per call, and thread start-up would
 // cost more than the loops themselves. Workers sleep on a condition variable between loops; the caller is worker 0.
+inline void cpu_relax()
+{
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+	__builtin_ia32_pause();
+#endif
+}
+
+// Workers first spin on an atomic generation counter for a few tens of microseconds (dmnd_extend issues its short parallel
+// loops back to back: a sleeping worker costs ~0.1 ms of wake-up per loop with 64 threads), then sleep on a condition variable.
 class WorkerPool {
 public:
 	~WorkerPool()
 	{
-		{ std::lock_guard<std::mutex> g(m_); stop_ = true; }
+		{ std::lock_guard<std::mutex> g(m_); stop_ = true; stop_a_.store(true); }
 		cv_.notify_all();
 		for (auto& t : th_) t.join();
 	}
@@ -38,16 +47,23 @@ public:
 		std::function<void(size_t, int)> fn = [&f](size_t i, int t) { f(i, t); };
 		{
 			std::lock_guard<std::mutex> g(m_);
-			fn_ = &fn; n_ = n; next_.store(0); want_ = threads - 1; running_ = threads - 1; ++gen_;
+			fn_ = &fn; n_ = n; next_.store(0); want_ = threads - 1; want_a_.store(threads - 1);
+			running_.store(threads - 1);
+			++gen_;
+			gen_a_.store(gen_, std::memory_order_release);      // publishes the job to the spinning workers
 		}
 		cv_.notify_all();
 		size_t i;
 		while ((i = next_.fetch_add(1)) < n) f(i, 0);
-		std::unique_lock<std::mutex> g(m_);
-		done_.wait(g, [&] { return running_ == 0; });
+		for (int s = 0; s < SPINS && running_.load(std::memory_order_acquire) != 0; ++s) cpu_relax();
+		if (running_.load(std::memory_order_acquire) != 0) {
+			std::unique_lock<std::mutex> g(m_);
+			done_.wait(g, [&] { return running_.load(std::memory_order_acquire) == 0; });
+		}
 		fn_ = nullptr;
 	}
 private:
+	enum { SPINS = 4000 };
 	void grow(int workers)
 	{
 		while ((int)th_.size() < workers) {
@@ -55,17 +71,27 @@ private:
 			th_.emplace_back([this, id] {
 				uint64_t seen = 0;
 				for (;;) {
-					std::unique_lock<std::mutex> g(m_);
-					cv_.wait(g, [&] { return stop_ || (gen_ != seen && id <= want_); });
-					if (stop_) return;
-					seen = gen_;
+					bool got = false;
+					for (int s = 0; s < SPINS; ++s) {
+						if (stop_a_.load(std::memory_order_relaxed)) return;
+						if (gen_a_.load(std::memory_order_acquire) != seen && id <= want_a_.load(std::memory_order_relaxed)) { got = true; break; }
+						cpu_relax();
+					}
+					if (!got) {
+						std::unique_lock<std::mutex> g(m_);
+						cv_.wait(g, [&] { return stop_ || (gen_ != seen && id <= want_); });
+						if (stop_) return;
+					}
+					// the job fields were written before gen_a_ was released (and under m_)
+					seen = gen_a_.load(std::memory_order_acquire);
 					const std::function<void(size_t, int)>* fn = fn_;
 					const size_t n = n_;
-					g.unlock();
 					size_t i;
 					while ((i = next_.fetch_add(1)) < n) (*fn)(i, id);
-					g.lock();
-					if (--running_ == 0) done_.notify_one();
+					if (running_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+						std::lock_guard<std::mutex> g(m_);           // pairs with the predicate check of the waiting caller
+						done_.notify_one();
+					}
 				}
 			});
 		}
@@ -76,9 +102,12 @@ private:
 	const std::function<void(size_t, int)>* fn_ = nullptr;
 	size_t n_ = 0;
 	std::atomic<size_t> next_{ 0 };
-	int want_ = 0, running_ = 0;
+	int want_ = 0;
+	std::atomic<int> want_a_{ 0 }, running_{ 0 };
 	uint64_t gen_ = 0;
+	std::atomic<uint64_t> gen_a_{ 0 };
 	bool stop_ = false;
+	std::atomic<bool> stop_a_{ false };
 };
 
 enum { MAX_POOLS = 4 };
