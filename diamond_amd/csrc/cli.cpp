@@ -7,7 +7,9 @@
 // (pos u64, len u32, pad u32) records), SequenceSet layout (src/data/string_set.h:27-60), tabular output
 // (src/output/blast_tab_format.cpp, sequence ids cut at the first blank).
 // Supported: blastp / blastx (--fast, default sensitivity, --sensitive), tantan masking on the GPU (default) or --masking 0
-// (SEG and motif masking are not part of this build: --motif-masking 0 semantics, and the tool says so), -e, -k, -p, -f 6 default columns.
+// (SEG and motif masking are not part of this build: --motif-masking 0 semantics, and the tool says so), -e, -k, -p, -f 6 default columns,
+// -b / -c: query and reference blocks cut as load_seqs cuts them, records of a query block merged over the reference blocks as
+// join_blocks does (output/join_blocks.cpp) -> same text as the reference run with the same -b.
 #include <algorithm>
 #include <chrono>
 #include <cstdint>
@@ -227,6 +229,8 @@ struct Options {
 	int threads = 0, k = 25, cbs = 1;
 	double evalue = 0.001;
 	bool fast = false;
+	double block_size = 0.0;        // -b, billions of letters (0 = the reference's default for the sensitivity)
+	int index_chunks = 0;           // -c (0 = the sensitivity's default)
 	std::string masking = "", motif_masking = "", sens = "";
 };
 
@@ -246,6 +250,8 @@ Options parse(int argc, char** argv)
 		else if (a == "-k" || a == "--max-target-seqs") o.k = std::atoi(need(i).c_str());
 		else if (a == "-e" || a == "--evalue") o.evalue = std::atof(need(i).c_str());
 		else if (a == "--fast") o.fast = true;
+		else if (a == "-b" || a == "--block-size" || (a.size() > 2 && a.compare(0, 2, "-b") == 0)) { o.block_size = std::atof(a.size() > 2 && a[1] == 'b' ? a.c_str() + 2 : need(i).c_str()); if (o.block_size <= 0.0) throw std::runtime_error("Invalid block size."); }
+		else if (a == "-c" || a == "--index-chunks" || (a.size() > 2 && a.compare(0, 2, "-c") == 0)) { o.index_chunks = std::atoi(a.size() > 2 && a[1] == 'c' ? a.c_str() + 2 : need(i).c_str()); if (o.index_chunks < 1) throw std::runtime_error("Invalid number of index chunks."); }
 		else if (a == "--comp-based-stats") { o.cbs = std::atoi(need(i).c_str()); if (o.cbs != 0 && o.cbs != 1) throw std::runtime_error("Only --comp-based-stats 0 and 1 are implemented."); }
 		else if (a == "--masking") o.masking = need(i);
 		else if (a == "--motif-masking") o.motif_masking = need(i);
@@ -261,6 +267,37 @@ Options parse(int argc, char** argv)
 
 double ms_since(std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); }
 
+// Block boundaries of SequenceFile::load_seqs (src/data/sequence_file.cpp:215-222 for a .dmnd, :311-330 for FASTA):
+// units (sequences, or reads with their six frames) are added while letters < max_letters, so a block ends with the unit
+// that reaches the limit.
+struct Range { size_t begin, end; };
+
+std::vector<Range> split_blocks(const std::vector<int64_t>& unit_letters, int64_t max_letters)
+{
+	std::vector<Range> r;
+	size_t i = 0;
+	while (i < unit_letters.size()) {
+		Range b{ i, i };
+		int64_t letters = 0;
+		do { letters += unit_letters[b.end++]; } while (b.end < unit_letters.size() && letters < max_letters);
+		r.push_back(b);
+		i = b.end;
+	}
+	return r;
+}
+
+// sequences [begin, end) of a loaded file as a block of their own (SequenceSet layout with its padding)
+SeqBlock slice(const SeqBlock& all, size_t begin, size_t end)
+{
+	SeqBlock b;
+	b.begin();
+	b.data.insert(b.data.end(), all.data.begin() + all.limits[begin], all.data.begin() + all.limits[end]);
+	for (size_t i = begin; i < end; ++i) b.limits.push_back(all.limits[i + 1] - all.limits[begin] + 256);
+	b.letters = (all.limits[end] - all.limits[begin]) - (int64_t)(end - begin);
+	b.finish();
+	return b;
+}
+
 int run_blastp(const Options& o)
 {
 	if (o.query.empty() || o.db.empty()) throw std::runtime_error("Missing parameter: query (--query/-q) and database (--db/-d) are required.");
@@ -274,20 +311,46 @@ int run_blastp(const Options& o)
 	if (o.motif_masking != "0")
 		std::cerr << "Warning: motif masking is not implemented; running as --motif-masking 0.\n";
 	const auto t_all = std::chrono::steady_clock::now();
-	SeqBlock q, t;
+	SeqBlock q_all, t_all_seqs;
 	const bool blastx = o.command == "blastx";
+	const size_t C = blastx ? 6 : 1;
 	std::vector<int32_t> source_len;
 	std::vector<std::string> read_ids;
 	auto t0 = std::chrono::steady_clock::now();
-	if (blastx) read_dna_fasta_translated(o.query, q, source_len, read_ids);
-	else read_fasta(o.query, q);
+	if (blastx) read_dna_fasta_translated(o.query, q_all, source_len, read_ids);
+	else read_fasta(o.query, q_all);
 	std::string dbpath = o.db;
 	if (!std::ifstream(dbpath).good() && std::ifstream(dbpath + ".dmnd").good()) dbpath += ".dmnd";
-	if (is_dmnd(dbpath)) read_dmnd(dbpath, t); else read_fasta(dbpath, t);
-	std::cerr << "Loading sequences...  [" << ms_since(t0) / 1e3 << "s]  queries=" << (blastx ? read_ids.size() : q.ids.size()) << " targets=" << t.ids.size() << " letters=" << t.letters << "\n";
+	if (is_dmnd(dbpath)) read_dmnd(dbpath, t_all_seqs); else read_fasta(dbpath, t_all_seqs);
+	const size_t n_queries = q_all.ids.size() / C, n_targets = t_all_seqs.ids.size();
+	std::cerr << "Loading sequences...  [" << ms_since(t0) / 1e3 << "s]  queries=" << n_queries << " targets=" << n_targets << " letters=" << t_all_seqs.letters << "\n";
+	const int sens = o.fast ? DMND_SENS_FAST : o.sens == "--mid-sensitive" ? DMND_SENS_MID_SENSITIVE : o.sens == "--sensitive" ? DMND_SENS_SENSITIVE
+		: o.sens == "--more-sensitive" ? DMND_SENS_MORE_SENSITIVE : o.sens == "--very-sensitive" ? DMND_SENS_VERY_SENSITIVE : DMND_SENS_DEFAULT;
+	// -b: 2.0 billion letters, 0.4 from --very-sensitive up (run/double_indexed.cpp:792-795); basic/config.h:434
+	const double b_opt = o.block_size > 0.0 ? o.block_size : (sens >= DMND_SENS_VERY_SENSITIVE ? 0.4 : 2.0);
+	const int64_t max_letters = (int64_t)(b_opt * 1e9);
+	std::vector<int64_t> q_units(n_queries), t_units(n_targets);
+	for (size_t i = 0; i < n_targets; ++i) t_units[i] = t_all_seqs.limits[i + 1] - t_all_seqs.limits[i] - 1;
+	for (size_t i = 0; i < n_queries; ++i) {
+		if (!blastx) { q_units[i] = q_all.limits[i + 1] - q_all.limits[i] - 1; continue; }
+		// Block::push_back counts the letters of the ORFs that survive find_orfs (data/block/block.cpp:88-100)
+		const int l0 = (int)(q_all.limits[i * 6 + 1] - q_all.limits[i * 6] - 1), min_len = l0 < 30 ? 1 : l0 < 100 ? 20 : 40;
+		int64_t n = 0;
+		for (size_t f = 0; f < 6; ++f) {
+			const int8_t* s = q_all.data.data() + q_all.limits[i * 6 + f];
+			const int len = (int)(q_all.limits[i * 6 + f + 1] - q_all.limits[i * 6 + f] - 1);
+			for (int x = 0, begin = 0; x <= len; ++x)
+				if (x == len || s[x] == 24) { if (x - begin >= min_len) n += x - begin; begin = x + 1; }
+		}
+		q_units[i] = n;
+	}
+	const std::vector<Range> q_blocks = split_blocks(q_units, max_letters), t_blocks = split_blocks(t_units, max_letters);
+	if (q_blocks.size() > 1 || t_blocks.size() > 1)
+		std::cerr << "Block size = " << max_letters << "  query blocks=" << q_blocks.size() << " reference blocks=" << t_blocks.size() << "\n";
+
 	dmnd_params p;
 	dmnd_default_params(&p);
-	p.db_letters = (double)t.letters;
+	p.db_letters = (double)t_all_seqs.letters;
 	p.max_evalue = o.evalue;
 	dmnd_ctx* ctx = dmnd_create(-1, &p);
 	if (!ctx) throw std::runtime_error(dmnd_last_error());
@@ -295,55 +358,90 @@ int run_blastp(const Options& o)
 	chk(dmnd_set_max_target_seqs(ctx, o.k));
 	chk(dmnd_set_comp_based_stats(ctx, o.cbs));
 	chk(dmnd_set_query_contexts(ctx, blastx ? 6 : 1));
-	t0 = std::chrono::steady_clock::now();
-	chk(dmnd_upload_block(ctx, DMND_QUERY, q.data.data(), (int64_t)q.data.size(), q.limits.data(), (int64_t)q.ids.size()));
-	chk(dmnd_upload_block(ctx, DMND_TARGET, t.data.data(), (int64_t)t.data.size(), t.limits.data(), (int64_t)t.ids.size()));
-	std::cerr << "Uploading blocks to HBM...  [" << ms_since(t0) / 1e3 << "s]\n";
-	if (tantan) {
-		t0 = std::chrono::steady_clock::now();
-		int64_t mq = 0, mt = 0;
-		chk(dmnd_mask_block(ctx, DMND_QUERY, q.data.data(), &mq));        // the host copies get the masked letters too
-		chk(dmnd_mask_block(ctx, DMND_TARGET, t.data.data(), &mt));
-		std::cerr << "Masking queries and reference (tantan)...  [" << ms_since(t0) / 1e3 << "s]  masked letters: " << mq << " + " << mt << "\n";
-	}
+	chk(dmnd_set_sensitivity(ctx, sens));
 	const int threads = o.threads > 0 ? o.threads : 8;
 	dmnd_seed_params sp;
-	const int sens = o.fast ? DMND_SENS_FAST : o.sens == "--mid-sensitive" ? DMND_SENS_MID_SENSITIVE : o.sens == "--sensitive" ? DMND_SENS_SENSITIVE
-		: o.sens == "--more-sensitive" ? DMND_SENS_MORE_SENSITIVE : o.sens == "--very-sensitive" ? DMND_SENS_VERY_SENSITIVE : DMND_SENS_DEFAULT;
 	double gf_evalue = 0.0;
 	chk(dmnd_seed_params_preset(&sp, sens, threads, &p, &gf_evalue));
+	if (o.index_chunks > 0) chk(dmnd_seed_params_set_index_chunks(&sp, o.index_chunks, threads));
 	chk(dmnd_set_gapped_filter(ctx, gf_evalue));
 	sp.query_translated = blastx ? 1 : 0;
-	t0 = std::chrono::steady_clock::now();
-	int64_t n_hits = 0;
-	chk(dmnd_seed_search(ctx, &sp, &n_hits));
-	std::vector<dmnd_seed_hit> hits((size_t)n_hits);
-	chk(dmnd_seed_hits(ctx, hits.data(), n_hits));
-	std::cerr << "Searching alignments (seed stage)...  [" << ms_since(t0) / 1e3 << "s]  hits=" << n_hits << "\n";
-	t0 = std::chrono::steady_clock::now();
-	std::vector<dmnd_match> matches((size_t)std::max<int64_t>(n_hits, 1));
-	int64_t n_matches = 0;
-	chk(dmnd_extend(ctx, q.data.data(), t.data.data(), hits.data(), n_hits, threads, 0, matches.data(), (int64_t)matches.size(), &n_matches, nullptr, 0, nullptr));
-	std::cerr << "Computing alignments (extension stage)...  [" << ms_since(t0) / 1e3 << "s]\n";
+
 	FILE* out = o.out.empty() ? stdout : std::fopen(o.out.c_str(), "w");
 	if (!out) throw std::runtime_error("Error opening file " + o.out);
-	const std::vector<std::string>& qtitles = blastx ? read_ids : q.ids;
-	std::vector<std::string> qid(qtitles.size()), tid(t.ids.size());
+	const std::vector<std::string>& qtitles = blastx ? read_ids : q_all.ids;
+	std::vector<std::string> qid(qtitles.size()), tid(n_targets);
 	for (size_t i = 0; i < qid.size(); ++i) qid[i] = short_id(qtitles[i]);
-	for (size_t i = 0; i < tid.size(); ++i) tid[i] = short_id(t.ids[i]);
+	for (size_t i = 0; i < tid.size(); ++i) tid[i] = short_id(t_all_seqs.ids[i]);
+	double ms_upload = 0, ms_mask = 0, ms_seed = 0, ms_ext = 0;
+	int64_t total_hits = 0, total_matches = 0, aligned = 0, mq_total = 0, mt_total = 0;
 	char line[8192];
-	int64_t aligned = 0;
-	for (int64_t i = 0; i < n_matches; ++i) {
-		const dmnd_match& m = matches[(size_t)i];
-		const int w = blastx ? dmnd_format_tab_translated(&m, qid[m.query].c_str(), tid[m.target].c_str(), source_len[m.query], line, sizeof line)
-			: dmnd_format_tab(&m, qid[m.query].c_str(), tid[m.target].c_str(), line, sizeof line);
-		if (w < 0) throw std::runtime_error(dmnd_last_error());
-		std::fwrite(line, 1, (size_t)w, out);
-		if (i == 0 || matches[(size_t)i].query != matches[(size_t)i - 1].query) ++aligned;
+	for (const Range& qr : q_blocks) {
+		SeqBlock q_own;
+		if (q_blocks.size() > 1) q_own = slice(q_all, qr.begin * C, qr.end * C);
+		SeqBlock& q = q_blocks.size() > 1 ? q_own : q_all;
+		const int64_t nq = (int64_t)((qr.end - qr.begin) * C);
+		t0 = std::chrono::steady_clock::now();
+		chk(dmnd_upload_block(ctx, DMND_QUERY, q.data.data(), (int64_t)q.data.size(), q.limits.data(), nq));
+		ms_upload += ms_since(t0);
+		if (tantan) {
+			t0 = std::chrono::steady_clock::now();
+			int64_t mq = 0;
+			chk(dmnd_mask_block(ctx, DMND_QUERY, q.data.data(), &mq));        // the host copy gets the masked letters too
+			mq_total += mq;
+			ms_mask += ms_since(t0);
+		}
+		std::vector<dmnd_match> joined;                       // the query block's records against all reference blocks
+		for (const Range& tr : t_blocks) {
+			// the reference re-reads and re-masks every reference block for every query block (run/double_indexed.cpp:404-470)
+			SeqBlock t_own;
+			if (t_blocks.size() > 1) t_own = slice(t_all_seqs, tr.begin, tr.end);
+			SeqBlock& t = t_blocks.size() > 1 ? t_own : t_all_seqs;
+			t0 = std::chrono::steady_clock::now();
+			chk(dmnd_upload_block(ctx, DMND_TARGET, t.data.data(), (int64_t)t.data.size(), t.limits.data(), (int64_t)(tr.end - tr.begin)));
+			ms_upload += ms_since(t0);
+			if (tantan && (t_blocks.size() > 1 || &qr == &q_blocks.front())) {     // a single reference block is masked once
+				t0 = std::chrono::steady_clock::now();
+				int64_t mt = 0;
+				chk(dmnd_mask_block(ctx, DMND_TARGET, t.data.data(), &mt));
+				if (&qr == &q_blocks.front()) mt_total += mt;
+				ms_mask += ms_since(t0);
+			}
+			t0 = std::chrono::steady_clock::now();
+			int64_t n_hits = 0;
+			chk(dmnd_seed_search(ctx, &sp, &n_hits));
+			std::vector<dmnd_seed_hit> hits((size_t)n_hits);
+			chk(dmnd_seed_hits(ctx, hits.data(), n_hits));
+			ms_seed += ms_since(t0);
+			total_hits += n_hits;
+			t0 = std::chrono::steady_clock::now();
+			const size_t base = joined.size();
+			joined.resize(base + (size_t)std::max<int64_t>(n_hits, 1));
+			int64_t n_matches = 0;
+			chk(dmnd_extend(ctx, q.data.data(), t.data.data(), hits.data(), n_hits, threads, 0, joined.data() + base, (int64_t)(joined.size() - base), &n_matches, nullptr, 0, nullptr));
+			joined.resize(base + (size_t)n_matches);
+			for (size_t i = base; i < joined.size(); ++i) { joined[i].query += (uint32_t)qr.begin; joined[i].target += (uint32_t)tr.begin; }   // block ids -> file ordinals
+			ms_ext += ms_since(t0);
+		}
+		int64_t n_matches = (int64_t)joined.size();
+		if (t_blocks.size() > 1) chk(dmnd_join_blocks(joined.data(), (int64_t)joined.size(), o.k, &n_matches));
+		for (int64_t i = 0; i < n_matches; ++i) {
+			const dmnd_match& m = joined[(size_t)i];
+			const int w = blastx ? dmnd_format_tab_translated(&m, qid[m.query].c_str(), tid[m.target].c_str(), source_len[m.query], line, sizeof line)
+				: dmnd_format_tab(&m, qid[m.query].c_str(), tid[m.target].c_str(), line, sizeof line);
+			if (w < 0) throw std::runtime_error(dmnd_last_error());
+			std::fwrite(line, 1, (size_t)w, out);
+			if (i == 0 || joined[(size_t)i].query != joined[(size_t)i - 1].query) ++aligned;
+		}
+		total_matches += n_matches;
 	}
 	if (out != stdout) std::fclose(out);
 	dmnd_destroy(ctx);
-	std::cerr << "Total time = " << ms_since(t_all) / 1e3 << "s\nReported " << n_matches << " pairwise alignments, " << n_matches << " HSPs.\n" << aligned << " queries aligned.\n";
+	std::cerr << "Uploading blocks to HBM...  [" << ms_upload / 1e3 << "s]\n";
+	if (tantan) std::cerr << "Masking queries and reference (tantan)...  [" << ms_mask / 1e3 << "s]  masked letters: " << mq_total << " + " << mt_total << "\n";
+	std::cerr << "Searching alignments (seed stage)...  [" << ms_seed / 1e3 << "s]  hits=" << total_hits << "\n";
+	std::cerr << "Computing alignments (extension stage)...  [" << ms_ext / 1e3 << "s]\n";
+	std::cerr << "Total time = " << ms_since(t_all) / 1e3 << "s\nReported " << total_matches << " pairwise alignments, " << total_matches << " HSPs.\n" << aligned << " queries aligned.\n";
 	return 0;
 }
 
@@ -356,7 +454,7 @@ int main(int argc, char** argv)
 		if (o.command == "version") { std::cout << "diamond-hip (MI355X back end of DIAMOND's seed-and-extend path), ABI " << dmnd_abi_version() << "\n"; return 0; }
 		if (o.command == "help" || o.command == "--help") {
 			std::cout << "Syntax: diamond-hip COMMAND [OPTIONS]\n  makedb --in FASTA -d DB        build a .dmnd database (no masking)\n"
-				"  blastp [--fast|--mid-sensitive|--sensitive|--more-sensitive|--very-sensitive] -q FASTA -d DB(.dmnd|FASTA) -o OUT [--masking 0] [-e EVALUE] [-k N] [-p THREADS]\n"
+				"  blastp [--fast|--mid-sensitive|--sensitive|--more-sensitive|--very-sensitive] -q FASTA -d DB(.dmnd|FASTA) -o OUT [--masking 0] [-e EVALUE] [-k N] [-p THREADS] [-b BLOCK_SIZE] [-c INDEX_CHUNKS]\n"
 				"  blastx [--fast|--sensitive] -q DNA_FASTA -d DB ...   (six-frame translation, standard genetic code)\n  version\n";
 			return 0;
 		}

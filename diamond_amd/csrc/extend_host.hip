@@ -67,6 +67,7 @@ struct HostCfg {
 	int64_t max_swipe_dp = 1000000;      // config.max_swipe_dp
 	int band_mode_fast = 1;              // Extension::Mode::BANDED_FAST for every sensitivity up to --sensitive
 	double ref_letters = 0;
+	double ranking_block_letters = 2e9;
 	bool use_cbs = true;                 // config.comp_based_stats == 1 (Hauser bias); 0 = no composition correction
 	int contexts = 1;                    // align_mode.query_contexts: 1 (blastp) or 6 (blastx: the block holds 6 frames per read)
 };
@@ -111,9 +112,9 @@ int band_for(int len, bool fast)                            // Extension::band, 
 	return len < 50 ? 15 : len < 100 ? 20 : len < 150 ? 30 : len < 200 ? 50 : len < 250 ? 60 : len < 350 ? 100 : len < 500 ? 120 : 150;
 }
 
-int64_t ranking_chunk_size(double ref_letters, int max_target_seqs)       // extend.cpp:79-92, default options
+int64_t ranking_chunk_size(double ref_letters, int max_target_seqs, double default_letters)       // extend.cpp:79-92, default options
 {
-	const int64_t block_mult = std::max((int64_t)std::llround(ref_letters / 2e9), (int64_t)1);
+	const int64_t block_mult = std::max((int64_t)std::llround(ref_letters / default_letters), (int64_t)1);
 	const int64_t m32 = ((int64_t)max_target_seqs + 31) / 32 * 32;
 	return std::max((int64_t)128, std::min(m32, (int64_t)400)) * block_mult;
 }
@@ -158,7 +159,7 @@ void load_query(const HostCfg& h, QueryWork& w, uint32_t query, const dmnd_seed_
 	}
 	w.order.resize(w.groups.size());
 	for (size_t i = 0; i < w.order.size(); ++i) w.order[i] = (uint32_t)i;
-	w.chunk_size = ranking_chunk_size(h.ref_letters, h.max_target_seqs);
+	w.chunk_size = ranking_chunk_size(h.ref_letters, h.max_target_seqs, h.ranking_block_letters);
 	if (w.chunk_size < (int64_t)w.groups.size())      // TargetScore::operator<: score desc, target index asc (target.h:146-158)
 		std::sort(w.order.begin(), w.order.end(), [&](uint32_t a, uint32_t b) {
 			return w.groups[a].score > w.groups[b].score || (w.groups[a].score == w.groups[b].score && a < b);
@@ -613,6 +614,7 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	HostCfg h;
 	make_cfg(c, h);
 	h.max_target_seqs = c->max_target_seqs;
+	h.ranking_block_letters = c->ranking_block_letters;
 	h.contexts = c->query_contexts;
 	h.use_cbs = c->comp_based_stats != 0;
 	const uint32_t C = (uint32_t)h.contexts;
@@ -730,10 +732,33 @@ extern "C" int dmnd_set_comp_based_stats(dmnd_ctx* c, int mode)
 	return DMND_OK;
 }
 
+extern "C" int dmnd_set_sensitivity(dmnd_ctx* c, int sensitivity)
+{
+	if (!c || sensitivity < DMND_SENS_FAST || sensitivity > DMND_SENS_VERY_SENSITIVE) return fail(DMND_E_ARG, "dmnd_set_sensitivity: bad argument");
+	c->ranking_block_letters = sensitivity >= DMND_SENS_VERY_SENSITIVE ? 800e6 : 2e9;      // extend.cpp:87
+	return DMND_OK;
+}
+
 extern "C" int dmnd_set_max_target_seqs(dmnd_ctx* c, int k)
 {
 	if (!c || k < 1) return fail(DMND_E_ARG, "dmnd_set_max_target_seqs: bad argument");
 	c->max_target_seqs = k;
+	return DMND_OK;
+}
+
+// join_query over the records of several reference blocks (output/join_blocks.cpp:180-256): every block's list of a query is
+// already in match_less order, so the reference's heap merge by JoinRecord::cmp_evalue (join_blocks.cpp:129-142) is the sort of
+// the union by (e-value, score descending, target ordinal); GlobalCulling keeps the first max_target_seqs (target_culling.h:70-88).
+extern "C" int dmnd_join_blocks(dmnd_match* r, int64_t n, int max_target_seqs, int64_t* n_out)
+{
+	if (!r || n < 0 || max_target_seqs < 1 || !n_out) return fail(DMND_E_ARG, "dmnd_join_blocks: bad argument");
+	std::stable_sort(r, r + n, [](const dmnd_match& a, const dmnd_match& b) { return a.query < b.query || (a.query == b.query && match_less(a, b)); });
+	int64_t w = 0, run = 0;
+	for (int64_t i = 0; i < n; ++i) {
+		run = (i > 0 && r[i].query == r[i - 1].query) ? run + 1 : 0;
+		if (run < max_target_seqs) { if (w != i) r[w] = r[i]; ++w; }
+	}
+	*n_out = w;
 	return DMND_OK;
 }
 

@@ -139,6 +139,17 @@ extern "C" int dmnd_seed_params_preset(dmnd_seed_params* p, int sensitivity, int
 	}
 }
 
+extern "C" int dmnd_seed_params_set_index_chunks(dmnd_seed_params* p, int index_chunks, int threads)
+{
+	if (!p || index_chunks < 1 || threads < 1 || p->n_shapes < 1) return fail(DMND_E_ARG, "dmnd_seed_params_set_index_chunks: bad argument");
+	auto bit_length = [](uint64_t x) { int b = 0; while (x) { ++b; x >>= 1; } return b; };
+	uint64_t space = 1;
+	for (int i = 0; i < p->shape_weight[0]; ++i) space *= (uint64_t)p->reduction_size;
+	p->index_chunks = index_chunks;
+	p->seedp_bits = std::max(std::max(bit_length(space - 1) - 32, bit_length((uint64_t)threads * 4 * index_chunks - 1)), 8);      // setup.cpp:306-309
+	return DMND_OK;
+}
+
 extern "C" int dmnd_seed_kernel_ms(const dmnd_ctx* c, double ms[5])
 {
 	if (!c || !ms) return fail(DMND_E_ARG, "dmnd_seed_kernel_ms: bad argument");

@@ -67,7 +67,8 @@ EXPORTS = ["dmnd_abi_version", "dmnd_last_error", "dmnd_default_params", "dmnd_c
            "dmnd_bitscore_p", "dmnd_evalue_batch", "dmnd_last_kernel_ms", "dmnd_seed_params_fast", "dmnd_seed_params_default", "dmnd_seed_search",
            "dmnd_seed_hits", "dmnd_seed_kernel_ms", "dmnd_extend_plan", "dmnd_extend", "dmnd_extend_stats", "dmnd_format_tab", "dmnd_set_max_target_seqs",
            "dmnd_seed_params_sensitive", "dmnd_set_gapped_filter", "dmnd_gapped_filter", "dmnd_gapped_filter_ms",
-           "dmnd_set_query_contexts", "dmnd_translate", "dmnd_format_tab_translated", "dmnd_mask_block", "dmnd_mask_kernel_ms", "dmnd_seed_params_preset", "dmnd_set_comp_based_stats"]
+           "dmnd_set_query_contexts", "dmnd_translate", "dmnd_format_tab_translated", "dmnd_mask_block", "dmnd_mask_kernel_ms", "dmnd_seed_params_preset", "dmnd_set_comp_based_stats",
+           "dmnd_seed_params_set_index_chunks", "dmnd_join_blocks", "dmnd_set_sensitivity"]
 
 
 def load():
@@ -218,6 +219,27 @@ def seed_params_preset(name, scoring, threads=1):
     if rc != 0:
         raise DiamondHipError(lib.dmnd_last_error().decode())
     return p, gf.value
+
+
+def set_index_chunks(p, index_chunks, threads=1):
+    """-c / --index-chunks on a SeedParams preset (recomputes seedp_bits as the reference does)."""
+    lib = load()
+    lib.dmnd_seed_params_set_index_chunks.argtypes = [ctypes.POINTER(SeedParams), ctypes.c_int, ctypes.c_int]
+    if lib.dmnd_seed_params_set_index_chunks(ctypes.byref(p), int(index_chunks), int(threads)) != 0:
+        raise DiamondHipError(lib.dmnd_last_error().decode())
+    return p
+
+
+def join_blocks(records, max_target_seqs=25):
+    """Merge of one query block's records against several reference blocks (dmnd_join_blocks: join_query of the reference):
+    `records` = concatenation of the per-block MATCH_DTYPE arrays with database-wide target ordinals."""
+    lib = load()
+    r = np.ascontiguousarray(records, dtype=MATCH_DTYPE).copy()
+    n = ctypes.c_int64(0)
+    lib.dmnd_join_blocks.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_int64)]
+    if lib.dmnd_join_blocks(r.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(r.size), int(max_target_seqs), ctypes.byref(n)) != 0:
+        raise DiamondHipError(lib.dmnd_last_error().decode())
+    return r[:n.value]
 
 
 def seed_params_sensitive(scoring, threads=1):

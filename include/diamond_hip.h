@@ -257,6 +257,10 @@ double dmnd_gapped_filter_ms(const dmnd_ctx* ctx);
 enum { DMND_SENS_FAST = 0, DMND_SENS_DEFAULT = 1, DMND_SENS_MID_SENSITIVE = 2, DMND_SENS_SENSITIVE = 3, DMND_SENS_MORE_SENSITIVE = 4,
        DMND_SENS_VERY_SENSITIVE = 5 };
 int dmnd_seed_params_preset(dmnd_seed_params* p, int sensitivity, int threads, const dmnd_params* scoring, double* gapped_filter_evalue);
+/* -c / --index-chunks on a preset (config.lowmem_, src/run/double_indexed.cpp:297): sets index_chunks and recomputes
+ * seedp_bits as Search::seedp_bits does (src/search/setup.cpp:306-309). The chunk of a seed decides which shape/chunk
+ * pass sees it first, i.e. the left-most filter, so results depend on it exactly as in the reference. */
+int dmnd_seed_params_set_index_chunks(dmnd_seed_params* p, int index_chunks, int threads);
 /* Sensitive mode seed configuration (16 shapes of weight 8, search/setup.cpp:86-102; ungapped e-value 10000, seed cut 1.0) */
 int dmnd_seed_params_sensitive(dmnd_seed_params* p, int threads, const dmnd_params* scoring);
 
@@ -284,8 +288,18 @@ double dmnd_mask_kernel_ms(const dmnd_ctx* ctx);
 /* --comp-based-stats: 1 = Hauser composition bias (default; HauserCorrection, stats/hauser_correction.cpp), 0 = none.
  * The matrix-adjust modes 2-4 (stats/cbs.cpp) are not implemented. */
 int dmnd_set_comp_based_stats(dmnd_ctx* ctx, int mode);
+/* The part of the sensitivity that the extension stage reads: ranking_chunk_size counts reference-block letters in units of
+ * 2e9, or of 8e8 from --very-sensitive up (src/align/extend.cpp:79-92). Only matters for reference blocks above 1.2e9 letters. */
+int dmnd_set_sensitivity(dmnd_ctx* ctx, int sensitivity);
 /* -k / --max-target-seqs (default 25, src/basic/config.h:55) */
 int dmnd_set_max_target_seqs(dmnd_ctx* ctx, int k);
+/* Multi-block databases (-b / --block-size): the records of one query block against several reference
+ * blocks (dmnd_match::target already offset to database ordinals by the caller, blocks in any order) are merged per query
+ * the way join_query does it: ascending by (e-value, score descending, target ordinal) = JoinRecord::cmp_evalue
+ * (src/output/join_blocks.cpp:129-142), then the first max_target_seqs of every query are kept (GlobalCulling,
+ * src/output/target_culling.h:70-88). In place; records stay grouped by ascending query. The outcome equals the
+ * reference run with the same block boundaries, not the single-block run (ranking and culling happen per block). */
+int dmnd_join_blocks(dmnd_match* records, int64_t n, int max_target_seqs, int64_t* n_out);
 /* Statistics of the last dmnd_extend: [0] round-1 DpTargets [1] round-2 DpTargets [2] round-1 cells [3] round-2 cells
  * (DpTarget::cells, src/dp/dp.h:121-124: the GCUPS denominator); host wall ms [4] Hauser+upload [5] chaining [6] round-1
  * call [7] culling [8] round-2 call; device ms [9] round-1 swipe [10] round-2 swipe [11] traceback. */

@@ -227,3 +227,29 @@ def tantan_mask(seq, lr, p_repeat=0.005, p_repeat_end=0.05, repeat_growth=1.0 / 
     n = lib().oracle_tantan_mask(s.ctypes.data_as(ctypes.c_void_p), len(s), m.ctypes.data_as(ctypes.c_void_p),
                                  f(p_repeat), f(p_repeat_end), f(repeat_growth), f(p_mask))
     return s, n
+
+
+def join_blocks(per_block, max_target_seqs=25):
+    """join_query of the reference for one query (output/join_blocks.cpp:180-256): `per_block` = one list per reference block
+    of (evalue, score, target_oid) in that block's output order. BlockJoiner keeps one cursor per block and a heap of the
+    cursors' heads ordered by JoinRecord::cmp_evalue (:129-137: e-value ascending, score descending, target ordinal
+    ascending); GlobalCulling stops after max_target_seqs targets (target_culling.h:70-88). Returns the joined list."""
+    import functools
+
+    def heap_less(a, b):                      # cmp_evalue(lhs, rhs): true when lhs must sink below rhs
+        (ea, sa, ta), (eb, sb, tb) = a[0], b[0]
+        return ea > eb or (ea == eb and (sa < sb or (sa == sb and tb < ta)))
+
+    heads = [[blk[0], bi, 0] for bi, blk in enumerate(per_block) if len(blk)]
+    out = []
+    while heads and len(out) < max_target_seqs:
+        top = heads[0]
+        for h in heads[1:]:                   # top of a max-heap under heap_less = the element no other one sinks
+            if heap_less(top, h):
+                top = h
+        out.append(top[0])
+        bi, pos = top[1], top[2] + 1
+        heads.remove(top)
+        if pos < len(per_block[bi]):
+            heads.append([per_block[bi][pos], bi, pos])
+    return out

@@ -121,3 +121,42 @@ def test_cli_default_masking_matches_reference(tmp_path):
 def test_cli_refuses_unimplemented_modes(tmp_path):
     r = subprocess.run([CLI, "blastp", "--ultra-sensitive", "-q", "x", "-d", "y"], capture_output=True, text=True)
     assert r.returncode != 0 and "not available" in r.stderr
+
+
+def test_cli_blocked_matches_reference(tmp_path):
+    """-b: several query and reference blocks (reference ctest diamond-test-blastp-blocked: -c1 -b0.00002), joined as
+    join_blocks does. Same text as the reference with the same block size."""
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/diamond not built")
+    rng = np.random.default_rng(33)
+    db, doff, q, qoff = synth.generate(400, members=10, queries=500, seed=33)
+    db, q = _plant_repeats(db, doff, rng), _plant_repeats(q, qoff, rng)
+    synth.write_fasta(str(tmp_path / "db.faa"), "t", db, doff)
+    synth.write_fasta(str(tmp_path / "q.faa"), "q", q, qoff)
+    _run([CLI, "makedb", "--in", str(tmp_path / "db.faa"), "-d", str(tmp_path / "db")])
+    common = ["--motif-masking", "0", "-q", str(tmp_path / "q.faa"), "-p", "4"]
+    cases = [("fast_fasta", ["--fast", "-b0.0001", "-c1"], "db.faa"), ("default_dmnd", ["-b", "0.00015", "-c1"], "db.dmnd"),
+             ("default_c4", ["-b0.0003"], "db.dmnd"), ("fast_k3", ["--fast", "-b0.0001", "-c1", "-k", "3"], "db.dmnd"), ("sensitive", ["--sensitive", "-b0.0002", "-c1"], "db.faa")]
+    for tag, mode, dbfile in cases:
+        _run([REF, "blastp", "--algo", "0"] + mode + common + ["-d", str(tmp_path / dbfile), "-o", str(tmp_path / ("ref_%s.tsv" % tag))])
+        r = _run([CLI, "blastp"] + mode + common + ["-d", str(tmp_path / dbfile), "-o", str(tmp_path / ("hip_%s.tsv" % tag))])
+        assert "reference blocks=" in r.stderr
+        ref = open(tmp_path / ("ref_%s.tsv" % tag)).read()
+        assert len(ref.splitlines()) > 300
+        assert open(tmp_path / ("hip_%s.tsv" % tag)).read() == ref, tag
+    assert max(np.unique([l.split("\t")[0] for l in open(tmp_path / "hip_fast_k3.tsv")], return_counts=True)[1]) == 3      # the join's cap
+    _run([CLI, "blastp", "-c1"] + common + ["-d", str(tmp_path / "db.dmnd"), "-o", str(tmp_path / "hip_single.tsv")])
+    _run([REF, "blastp", "--algo", "0", "-c1"] + common + ["-d", str(tmp_path / "db.dmnd"), "-o", str(tmp_path / "ref_single.tsv")])
+    single = open(tmp_path / "hip_single.tsv").read()
+    assert single == open(tmp_path / "ref_single.tsv").read()
+    # (with <= 25 detectable targets per query the blocked and the single-block text coincide here; in general they need not)
+    assert sorted(single.splitlines()) == sorted(open(tmp_path / "hip_default_dmnd.tsv").read().splitlines())
+    # blastx: reads are cut into blocks by the letters of their surviving ORFs
+    dna, off = synth.back_translate(q[:qoff[250]], qoff[:251], seed=12)
+    synth.write_dna_fasta(str(tmp_path / "reads.fna"), "r", dna, off)
+    xargs = ["-b0.0001", "-c1", "--masking", "0", "--motif-masking", "0", "-q", str(tmp_path / "reads.fna"), "-d", str(tmp_path / "db.faa"), "-p", "4"]
+    _run([REF, "blastx", "--algo", "0"] + xargs + ["-o", str(tmp_path / "ref_x.tsv")])
+    _run([CLI, "blastx"] + xargs + ["-o", str(tmp_path / "hip_x.tsv")])
+    ref = open(tmp_path / "ref_x.tsv").read()
+    assert len(ref.splitlines()) > 150
+    assert open(tmp_path / "hip_x.tsv").read() == ref
