@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--host-threads", type=int, default=0)
     ap.add_argument("--cpu-sample-frac", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="run seed stage and extension stage of a batch back to back on one context")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -135,6 +136,15 @@ def main():
     upload_ms = (time.perf_counter() - t_up) * 1e3          # outside the timed region: inputs are resident when a step starts
     seed_params = hip.seed_params_fast(threads=8)
     state = {}
+    # Batch pipeline (default): a second context holds the same two blocks and runs the seed stage of batch s+1 on its own
+    # stream while this one extends batch s -- what a run over many query blocks does (every batch still passes through the
+    # whole path inside the timed region; the blocks of both contexts are resident before it starts).
+    pipeline = not args.no_pipeline
+    ctx_seed = ctx
+    if pipeline:
+        ctx_seed = hip.Context(device=local_rank, params=params)
+        ctx_seed.upload_block(hip.QUERY, qd, ql)
+        ctx_seed.upload_block(hip.TARGET, td, tl)
 
     def step():
         t_a = time.perf_counter()
@@ -153,16 +163,60 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def seed_stage():
+        torch.cuda.set_device(local_rank)
+        hits = ctx_seed.seed_search(seed_params)
+        return hits, ctx_seed.seed_kernel_ms()
+
+    def run_pipelined(n_steps):
+        """n_steps batches; the seed stage of batch s+1 runs on a worker thread (ctypes releases the GIL) during the extension of batch s"""
+        stream = 0.0
+        fut = seed_pool.submit(seed_stage)
+        wall = [0.0, 0.0, 0.0]
+        for s in range(n_steps):
+            t_a = time.perf_counter()
+            hits, seed_ms = fut.result()
+            stream += seed_ms[1]
+            if s + 1 < n_steps:
+                fut = seed_pool.submit(seed_stage)
+            t_b = time.perf_counter()
+            matches, _ = ctx.extend(qd, td, hits, threads=threads)
+            t_c = time.perf_counter()
+            aligned = gather_topk(args.queries, matches, coll_device)
+            t_d = time.perf_counter()
+            for i, x in enumerate((t_b - t_a, t_c - t_b, t_d - t_c)):
+                wall[i] += x * 1e3 / n_steps
+            state.update(hits=int(hits.size), matches=int(matches.size), aligned=aligned, seed_ms=seed_ms, ext=ctx.extend_stats(),
+                         pipe_wall_ms={"wait_for_seed_stage": wall[0], "extension_call": wall[1], "topk_gather": wall[2]})
+        return stream
+
+    if pipeline:
+        import concurrent.futures
+        seed_pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
     for _ in range(args.warmup):
         step()
+    if pipeline and args.warmup:
+        run_pipelined(2)
     sync()
     t0 = time.perf_counter()
     stream_ms = 0.0
-    for _ in range(args.steps):
-        step()
-        stream_ms += state["seed_ms"][1]
+    if pipeline:
+        stream_ms = run_pipelined(args.steps)
+    else:
+        for _ in range(args.steps):
+            step()
+            stream_ms += state["seed_ms"][1]
     sync()
     dt = time.perf_counter() - t0
+    if pipeline:                                             # stage latencies of one batch on an otherwise idle GPU, after the timed region
+        state["pipe_ext"] = dict(state["ext"])
+        serial = []
+        for _ in range(3):
+            t_s = time.perf_counter()
+            step()
+            serial.append((time.perf_counter() - t_s) * 1e3)
+        state["serial_ms"] = min(serial)
+        state["serial_stream_ms"] = state["seed_ms"][1]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -235,6 +289,10 @@ def main():
             # seed-stage Gletters/s = (L_q + L_r) x shapes / seed-stage seconds (device time of its kernels)
             "seed_stage_gletters_per_s": (int(ql[-1] - ql[0]) + int(tl[-1] - tl[0])) * seed_params.n_shapes / max(state["seed_ms"][4], 1e-9) / 1e6,
             "wall_ms_last_step": state["wall_ms"],
+            "pipeline": ("seed stage of batch s+1 (second context, own stream) overlaps the extension stage of batch s; latency of one batch alone "
+                         "%.2f ms, its stream kernel alone %.3f ms" % (state["serial_ms"], state["serial_stream_ms"])) if pipeline else "off",
+            "pipeline_wall_ms_per_step": state.get("pipe_wall_ms"),
+            "pipeline_extension_last_step": state.get("pipe_ext"),
             # not part of `value`: one-time PCIe upload of both blocks, and the rate if it were paid on every step
             "block_upload_ms": upload_ms,
             "pcie_inclusive_gcups": cells_step * world / ((dt / args.steps + upload_ms * 1e-3)) / 1e9,

@@ -90,7 +90,14 @@ extern "C" dmnd_ctx* dmnd_create(int device, const dmnd_params* params)
 	c->evaluer.init(*params);
 	if (const char* mb = getenv("DMND_TRACE_ARENA_MB"))
 		c->trace_arena_max = (size_t)std::max(64L, atol(mb)) << 20;
-	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess
+	// The context's own stream (seed stage, masking, uploads) runs at the lowest priority and the streams of the extension
+	// stage's runners (aux_context) at the highest: when a driver overlaps the seed stage of the next batch with the extension
+	// of the current one, the swipe kernels -- which sit on the extension's critical path between host phases -- get the CUs
+	// first and the seed kernels fill the gaps.
+	int prio_least = 0, prio_greatest = 0;
+	(void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+	if (std::getenv("DMND_NO_STREAM_PRIORITY")) prio_least = prio_greatest = 0;
+	if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_least) != hipSuccess
 		|| hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev2) != hipSuccess
 		|| c->matrix.ensure(32 * 32) != DMND_OK
 		|| hipMemcpy(c->matrix.p, params->matrix8, 32 * 32, hipMemcpyHostToDevice) != hipSuccess) {
@@ -144,7 +151,7 @@ extern "C" int dmnd_upload_block(dmnd_ctx* c, int which, const int8_t* data, int
 		c->limits[which].assign(limits, limits + n_seqs + 1);
 		if (limits[n_seqs] > data_len) return fail(DMND_E_ARG, "dmnd_upload_block: limits exceed data_len");
 		if (int rc = c->d_limits[which].ensure((size_t)(n_seqs + 1) * sizeof(int64_t))) return rc;
-		HIP_TRY(hipMemcpy(c->d_limits[which].p, limits, (size_t)(n_seqs + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+		HIP_TRY(copy_now(c->stream, c->d_limits[which].p, limits, (size_t)(n_seqs + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
 	}
 	return DMND_OK;
 }
@@ -302,7 +309,7 @@ int run_chunk(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, const dm
 		HIP_TRY(hipEventElapsedTime(&ms, c->ev1, c->ev2));
 		c->traceback_ms += ms;
 		int32_t st = 0;
-		HIP_TRY(hipMemcpy(&st, c->status.p, sizeof(st), hipMemcpyDeviceToHost));
+		HIP_TRY(copy_now(c->stream, &st, c->status.p, sizeof(st), hipMemcpyDeviceToHost));
 		if (st != 0)
 			return fail(st, st == DMND_E_TRACEBACK ? "Traceback error." : "transcript slot too small");
 	}
@@ -380,7 +387,7 @@ int swipe_impl(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, int64_t
 		lap(0);
 		if (int rc = run_chunk(c, b, items, c->items.as<dmnd_dp_target>(), slots, kmode, out, nullptr, nullptr)) return rc;
 		lap(1);
-		HIP_TRY(hipMemcpy(ends.data(), c->ends.p, n * sizeof(SwipeEnd), hipMemcpyDeviceToHost));
+		HIP_TRY(copy_now(c->stream, ends.data(), c->ends.p, n * sizeof(SwipeEnd), hipMemcpyDeviceToHost));
 		for (int64_t i = 0; i < n; ++i) {
 			dmnd_hsp h;
 			std::memset(&h, 0, sizeof(h));
@@ -420,7 +427,7 @@ int swipe_impl(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, int64_t
 		const double ms_fwd = c->swipe_ms;
 		if (int rc = run_chunk(c, b, rev.data(), c->items.as<dmnd_dp_target>(), rslots, K_STATS_BWD_REV, out, nullptr, nullptr)) return rc;
 		(void)ms_fwd;
-		HIP_TRY(hipMemcpy(ends.data(), c->ends.p, m * sizeof(SwipeEnd), hipMemcpyDeviceToHost));
+		HIP_TRY(copy_now(c->stream, ends.data(), c->ends.p, m * sizeof(SwipeEnd), hipMemcpyDeviceToHost));
 		for (int64_t k = 0; k < m; ++k) {
 			dmnd_hsp& h = out[src[k]];
 			h.score = ends[k].score;                                          // the reversed pass' score is what the reference reports
@@ -454,7 +461,7 @@ int swipe_impl(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, int64_t
 		lap(0);
 		if (int rc = run_chunk(c, b, items, c->items.as<dmnd_dp_target>(), chunk, K_TRACE, out, transcript ? &tr : nullptr, transcript ? &tr_off : nullptr)) return rc;
 		lap(1);
-		HIP_TRY(hipMemcpy(hsps.data() + c0, c->hsps.as<dmnd_hsp>() + c0, (size_t)(c1 - c0) * sizeof(dmnd_hsp), hipMemcpyDeviceToHost));
+		HIP_TRY(copy_now(c->stream, hsps.data() + c0, c->hsps.as<dmnd_hsp>() + c0, (size_t)(c1 - c0) * sizeof(dmnd_hsp), hipMemcpyDeviceToHost));
 		if (!transcript) {
 			for (int64_t i = c0; i < c1; ++i) { out[i] = hsps[i]; out[i].transcript_off = -1; }
 			c0 = c1;
@@ -496,13 +503,20 @@ int dmnd_swipe_shared(dmnd_ctx* work, const dmnd_ctx* c, const dmnd_dp_target* i
 	return swipe_impl(work, b, items, n, mode, hsp_values, out, transcript, transcript_cap, transcript_used);
 }
 
+static int aux_priority()
+{
+	int least = 0, greatest = 0;
+	(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+	return std::getenv("DMND_NO_STREAM_PRIORITY") ? 0 : greatest;
+}
+
 dmnd_ctx* aux_context(dmnd_ctx* c, int k, int split)
 {
 	if (!c || k < 0) return nullptr;
 	while ((int)c->aux.size() <= k) {
 		dmnd_ctx* a = new dmnd_ctx();
 		a->device = c->device;
-		if (hipSetDevice(c->device) != hipSuccess || hipStreamCreate(&a->stream) != hipSuccess || hipEventCreate(&a->ev0) != hipSuccess
+		if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithPriority(&a->stream, hipStreamNonBlocking, aux_priority()) != hipSuccess || hipEventCreate(&a->ev0) != hipSuccess
 			|| hipEventCreate(&a->ev1) != hipSuccess || hipEventCreate(&a->ev2) != hipSuccess) { delete a; return nullptr; }
 		c->aux.push_back(a);
 	}

@@ -18,6 +18,14 @@ int fail(int code, const std::string& msg);      // sets dmnd_last_error(), retu
 			return ::dmnd::fail(DMND_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));        \
 	} while (0)
 
+// Blocking copy on the context's own stream. A plain hipMemcpy runs on the null stream, which waits for (and stalls) every
+// blocking stream of the process: the concurrent sub-batches of dmnd_extend and independent contexts would serialise on it.
+inline hipError_t copy_now(hipStream_t s, void* dst, const void* src, size_t bytes, hipMemcpyKind kind)
+{
+	const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, s);
+	return e != hipSuccess ? e : hipStreamSynchronize(s);
+}
+
 struct DevBuf {
 	void* p = nullptr;
 	size_t cap = 0;

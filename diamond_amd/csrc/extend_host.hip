@@ -19,6 +19,7 @@
 // Scope: blastp, one query context, max_hsps = 1, Hauser composition bias (comp-based-stats 1), no gapped filter,
 // no id/coverage filters, single ranking chunk (a query with more targets than the ranking chunk fails loudly).
 #include <algorithm>
+#include <array>
 #include <cfloat>
 #include <chrono>
 #include <cmath>
@@ -669,13 +670,17 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 		for (int i = 0; i < 20; ++i) parallel_for((size_t)threads, threads, [](size_t, int) {});
 		std::fprintf(stderr, "dmnd_extend ms: hauser+upload %.2f gapped_filter %.2f | empty parallel loop over %d threads: %.3f ms\n", fine[1], fine[2], threads, (now() - t0) / 20);
 	}
-	// 2.. : the queries are processed as `split` concurrent sub-batches, each on its own host thread, HIP stream and device work
-	// buffers (auxiliary contexts): while one sub-batch waits for its swipe kernels the others chain, cull and pack on the
-	// host. Results are concatenated in query order, so the output does not depend on the split.
-	int split = 1;
-	if (!transcript && qr.size() >= 2048) split = 2;
-	if (const char* e = std::getenv("DMND_EXTEND_SPLIT")) split = std::max(1, std::min((int)MAX_POOLS, std::atoi(e)));
+	// 2.. : the queries are cut into `split` sub-batches that `runners` host threads pull from a queue, each runner with its own
+	// HIP stream, device work buffers (auxiliary context) and share of the worker threads. While one runner waits for its swipe
+	// kernels the others chain, cull and pack on the host; the GPU serialises the runners' launches, which staggers them after
+	// the first round, so with more sub-batches than runners host and device phases overlap like a pipeline. Results are
+	// concatenated in query order, so the output does not depend on the split.
+	int split = 1, runners = 1;
+	if (!transcript && qr.size() >= 2048) { split = 4; runners = 4; }
+	if (const char* e = std::getenv("DMND_EXTEND_SPLIT")) split = std::max(1, std::min(64, std::atoi(e)));
+	if (const char* e = std::getenv("DMND_EXTEND_RUNNERS")) runners = std::max(1, std::atoi(e));
 	if (transcript || qr.size() < (size_t)split * 2) split = 1;
+	runners = std::min(std::min(runners, split), (int)MAX_POOLS);
 	std::vector<std::vector<dmnd_match>> parts((size_t)split);
 	std::vector<int> rcs((size_t)split, DMND_OK);
 	std::vector<std::string> errs((size_t)split);
@@ -684,31 +689,38 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	}
 	else {
 		const double stats4 = c->ext_stats[4];
-		std::vector<dmnd_ctx*> work((size_t)split);
-		for (int k = 0; k < split; ++k) {
-			work[(size_t)k] = aux_context(c, k, split);
-			if (!work[(size_t)k]) return fail(DMND_E_DEVICE, "dmnd_extend: cannot create an auxiliary context");
+		std::vector<dmnd_ctx*> work((size_t)runners);
+		for (int r = 0; r < runners; ++r) {
+			work[(size_t)r] = aux_context(c, r, runners);
+			if (!work[(size_t)r]) return fail(DMND_E_DEVICE, "dmnd_extend: cannot create an auxiliary context");
 		}
 		std::vector<std::thread> th;
-		const int sub_threads = std::max(1, threads / split);
-		for (int k = 0; k < split; ++k)
-			th.emplace_back([&, k] {
-				set_thread_pool(k);
+		const int sub_threads = std::max(1, threads / runners);
+		std::atomic<int> next_sub(0);
+		std::vector<std::array<double, 12>> acc((size_t)runners);
+		for (auto& x : acc) x.fill(0.0);
+		for (int r = 0; r < runners; ++r)
+			th.emplace_back([&, r] {
+				set_thread_pool(r);
 				(void)hipSetDevice(c->device);
-				const size_t b = qr.size() * (size_t)k / (size_t)split, e = qr.size() * (size_t)(k + 1) / (size_t)split;
-				rcs[(size_t)k] = extend_range(c, work[(size_t)k], h, qr, b, e, hits, gf, qdata, tdata, cbs, !bias_in_prelude, sub_threads, hsp_values, parts[(size_t)k], nullptr, 0, nullptr);
-				if (rcs[(size_t)k] != DMND_OK) errs[(size_t)k] = dmnd_last_error();
+				dmnd_ctx* w = work[(size_t)r];
+				for (int k; (k = next_sub.fetch_add(1)) < split;) {
+					const size_t b = qr.size() * (size_t)k / (size_t)split, e = qr.size() * (size_t)(k + 1) / (size_t)split;
+					rcs[(size_t)k] = extend_range(c, w, h, qr, b, e, hits, gf, qdata, tdata, cbs, !bias_in_prelude, sub_threads, hsp_values, parts[(size_t)k], nullptr, 0, nullptr);
+					if (rcs[(size_t)k] != DMND_OK) { errs[(size_t)k] = dmnd_last_error(); break; }
+					for (int i = 0; i < 12; ++i) acc[(size_t)r][(size_t)i] += w->ext_stats[i];
+				}
 				set_thread_pool(-1);
 			});
 		for (auto& t : th) t.join();
-		// statistics of the call: counts and device times add up, host wall times are those of the slowest sub-batch
+		// statistics of the call: counts and device times add up, host wall times are those of the busiest runner
 		for (double& x : c->ext_stats) x = 0;
 		c->ext_stats[4] = stats4;
-		for (int k = 0; k < split; ++k) {
-			const dmnd_ctx* w = work[(size_t)k];
-			for (int i : { 0, 1, 2, 3, 9, 10, 11 }) c->ext_stats[i] += w->ext_stats[i];
-			for (int i : { 5, 6, 7, 8 }) c->ext_stats[i] = std::max(c->ext_stats[i], w->ext_stats[i]);
-			c->ext_stats[4] = std::max(c->ext_stats[4], stats4 + w->ext_stats[4]);
+		for (int r = 0; r < runners; ++r) {
+			const std::array<double, 12>& w = acc[(size_t)r];
+			for (int i : { 0, 1, 2, 3, 9, 10, 11 }) c->ext_stats[i] += w[(size_t)i];
+			for (int i : { 5, 6, 7, 8 }) c->ext_stats[i] = std::max(c->ext_stats[i], w[(size_t)i]);
+			c->ext_stats[4] = std::max(c->ext_stats[4], stats4 + w[4]);
 		}
 		c->swipe_ms = c->ext_stats[9] + c->ext_stats[10]; c->traceback_ms = c->ext_stats[11];
 	}

@@ -37,7 +37,7 @@ extern "C" int dmnd_set_gapped_filter(dmnd_ctx* c, double evalue)
 	cutoff_table2d(c, 2000.0, t.data());                    // config.gapped_filter_evalue1, basic/config.cpp:567
 	cutoff_table2d(c, evalue, t.data() + 32 * 32);          // Search::Config::gapped_filter_evalue, run/double_indexed.cpp:301-305
 	if (int rc = c->gf_tables.ensure(t.size() * sizeof(int32_t))) return rc;
-	HIP_TRY(hipMemcpy(c->gf_tables.p, t.data(), t.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+	HIP_TRY(copy_now(c->stream, c->gf_tables.p, t.data(), t.size() * sizeof(int32_t), hipMemcpyHostToDevice));
 	return DMND_OK;
 }
 

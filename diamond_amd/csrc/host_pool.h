@@ -110,7 +110,7 @@ private:
 	std::atomic<bool> stop_a_{ false };
 };
 
-enum { MAX_POOLS = 4 };
+enum { MAX_POOLS = 8 };
 // pool(): the worker pool of the calling thread. Threads that drive one of the concurrent sub-batches of dmnd_extend select
 // their own pool with set_thread_pool(k) (k < MAX_POOLS); every other thread shares the default pool. Defined in extend_host.hip.
 WorkerPool& pool();

@@ -275,7 +275,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 			tm.start();
 			HIP_TRY(launch_seed_stream(a, sid, st));
 			c->seed_ms[1] += tm.stop();
-			HIP_TRY(hipMemcpy(&counts[sid], a.matched_count, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+			HIP_TRY(copy_now(c->stream, &counts[sid], a.matched_count, sizeof(unsigned long long), hipMemcpyDeviceToHost));
 			if ((int64_t)counts[sid] > cap_total - off) { overflow = true; off += (int64_t)counts[sid]; continue; }
 			off += (int64_t)counts[sid];
 		}
@@ -342,7 +342,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 			if (!sp.use_ungapped) continue;
 			// pairs scoring above 255 (rare): resolve the reference's SIMD-batch saturation rule in a second pass
 			unsigned long long nd = 0;
-			HIP_TRY(hipMemcpy(&nd, a.deferred_count, sizeof(nd), hipMemcpyDeviceToHost));
+			HIP_TRY(copy_now(c->stream, &nd, a.deferred_count, sizeof(nd), hipMemcpyDeviceToHost));
 			if (nd == 0) continue;
 			def_max = std::max(def_max, nd);
 			if ((int64_t)nd > def_cap) { def_overflow = true; continue; }
@@ -361,7 +361,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 			ms += tm.stop();
 		}
 		unsigned long long nh = 0;
-		HIP_TRY(hipMemcpy(&nh, c->counters.as<unsigned long long>() + S, sizeof(nh), hipMemcpyDeviceToHost));
+		HIP_TRY(copy_now(c->stream, &nh, c->counters.as<unsigned long long>() + S, sizeof(nh), hipMemcpyDeviceToHost));
 		c->seed_ms[3] = ms;
 		if ((int64_t)nh <= hit_cap && !def_overflow) { c->n_seed_hits = (int64_t)nh; break; }
 		if (attempt >= 3) return fail(DMND_E_NOMEM, "dmnd_seed_search: hit buffer overflow");
@@ -399,6 +399,6 @@ extern "C" int dmnd_seed_hits(dmnd_ctx* c, dmnd_seed_hit* out, int64_t cap)
 	if (cap < c->n_seed_hits) return fail(DMND_E_CAP, "dmnd_seed_hits: buffer too small");
 	if (c->n_seed_hits == 0) return DMND_OK;
 	HIP_TRY(hipSetDevice(c->device));
-	HIP_TRY(hipMemcpy(out, c->seed_hits_sorted.p, (size_t)c->n_seed_hits * sizeof(dmnd_seed_hit), hipMemcpyDeviceToHost));      // sorted by dmnd_seed_search
+	HIP_TRY(copy_now(c->stream, out, c->seed_hits_sorted.p, (size_t)c->n_seed_hits * sizeof(dmnd_seed_hit), hipMemcpyDeviceToHost));      // sorted by dmnd_seed_search
 	return DMND_OK;
 }

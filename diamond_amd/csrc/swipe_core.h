@@ -248,6 +248,136 @@ DMND_HD void lane_step(Lane<P, COORDS, STAT>& st, const Geom& g, const SeqView& 
 	}
 }
 
+// ---- register-window lane (score-only / coordinates / traceback kernels) -----------------------------------------
+// The lane's cells of one (even, odd) step pair sit on diagonals d0 .. d0 + 2P - 1 (d0 = d_begin + 2P * lane). With
+// I0 = (a + d0) / 2 and J0 = (a - d0) / 2 for the even anti-diagonal a of the pair,
+//     even cell p : (I0 + p,     J0 - p)         odd cell p : (I0 + p + 1, J0 - p)
+// and the next pair is the same picture one row and one column further (I0 + 1, J0 + 1). So the lane keeps a window of
+// P + 1 query letters (with their composition bias) and P target letters in registers and fetches exactly ONE new query
+// letter, ONE bias byte and ONE target letter per step pair, a whole pair ahead of their first use -- instead of loading
+// both letters and the bias of every cell at the cell (2P of each per pair, each load on the cell's critical path).
+// Cells are computed branch-free: an invalid cell (outside the matrix or the band) computes on whatever letters the
+// clamped window holds and is then forced to H = E = F = 0, which is what lane_step's skipped cells read as.
+template<int P, bool COORDS>
+struct WinLane {
+	int H[2 * P], E[2 * P], F[2 * P];
+	int rel[2 * P];                 // (anti-diagonal of diagonal k's next cell) - a_lo[k]; valid iff (unsigned)rel <= span
+	int span[2 * P];
+	int Q[P + 1], C[P + 1];         // query letters (masked) and bias at rows I0 .. I0 + P
+	int T[P];                       // (target letter << 5) at columns J0 - p: the matrix row offset
+	int iq, jt;                     // row / column of the next letters to fetch (I0 + P + 1, J0 + 1)
+	int best, best_i, best_j;
+	// COORDS, P <= WIN_DIAG_BEST_MAX_P: best score of every diagonal and the anti-diagonal of its FIRST occurrence. Along one
+	// diagonal the column grows with the anti-diagonal, so "first" is the reference's tie-break (smallest column) and no
+	// coordinates are needed per cell; win_finish picks the lane's end cell from these. Wider classes keep one end cell per lane.
+	int bk[COORDS && P <= 4 ? 2 * P : 1], ba[COORDS && P <= 4 ? 2 * P : 1];
+};
+enum { WIN_DIAG_BEST_MAX_P = 4 };
+
+// index into a sequence of hi + 1 letters, any x: rows / columns outside the sequence belong to invalid cells only, which
+// may read any letter (a negative x wraps to a huge unsigned value and lands on hi)
+DMND_HD int clampi(int x, int hi) { return (int)((unsigned)x < (unsigned)hi ? (unsigned)x : (unsigned)hi); }
+
+template<int P, bool COORDS>
+DMND_HD void win_init(WinLane<P, COORDS>& st, const Geom& g, const SeqView& v, int lane)
+{
+#pragma unroll
+	for (int k = 0; k < 2 * P; ++k) {
+		st.H[k] = st.E[k] = st.F[k] = 0;
+		int a_lo, a_span;
+		diag_window(g, 2 * P * lane + k, a_lo, a_span);
+		st.rel[k] = g.a_first + (k & 1) - a_lo;       // never-valid diagonals: a_lo = 0x3fffffff keeps this negative for the whole sweep
+		st.span[k] = a_span;
+	}
+	const int d0 = g.d_begin + 2 * P * lane;
+	const int I0 = (g.a_first + d0) >> 1, J0 = (g.a_first - d0) >> 1;
+#pragma unroll
+	for (int x = 0; x <= P; ++x) {
+		const int i = clampi(I0 + x, g.qlen - 1);
+		st.Q[x] = v.q[i] & LETTER_MASK;
+		st.C[x] = v.cbs ? v.cbs[i] : 0;
+	}
+#pragma unroll
+	for (int p = 0; p < P; ++p)
+		st.T[p] = (v.t[clampi(J0 - p, g.tlen - 1)] & LETTER_MASK) << 5;
+	st.iq = I0 + P + 1; st.jt = J0 + 1;
+	st.best = 0; st.best_i = 0; st.best_j = 0x7fffffff;
+	if (COORDS && P <= WIN_DIAG_BEST_MAX_P) {
+#pragma unroll
+		for (int k = 0; k < 2 * P; ++k) { st.bk[k] = 0; st.ba[k] = 0; }
+	}
+}
+
+// after the sweep: the lane's end cell (best, best_i, best_j) from the per-diagonal records
+template<int P, bool COORDS>
+DMND_HD void win_finish(WinLane<P, COORDS>& st, int d0)
+{
+	if (COORDS && P <= WIN_DIAG_BEST_MAX_P) {
+#pragma unroll
+		for (int k = 0; k < 2 * P; ++k) {
+			const int d = d0 + k, i = (st.ba[k] + d) >> 1, j = (st.ba[k] - d) >> 1;
+			if (st.bk[k] > 0 && better_end(st.bk[k], j, i, st.best, st.best_j, st.best_i)) { st.best = st.bk[k]; st.best_j = j; st.best_i = i; }
+		}
+	}
+}
+
+// One anti-diagonal step (PAR as in lane_step; `a` = its anti-diagonal, d0 = the lane's first diagonal: only read when a new
+// end cell is recorded). trace: this lane's P bytes of the step's trace row (aligned to min(P, 4): written as one 1-, 2- or 4-byte store per up to 4 cells).
+template<int P, bool COORDS, bool TRACE, int PAR>
+DMND_HD void win_step(WinLane<P, COORDS>& st, const int8_t* M, int nb, int go, int ge, int a, int d0, uint8_t* trace)
+{
+	uint32_t packed = 0;
+#pragma unroll
+	for (int p = 0; p < P; ++p) {
+		const int k = 2 * p + PAR;
+		int E_in, F_in;
+		if (PAR == 0) { E_in = st.E[k + 1]; F_in = p == 0 ? nb : st.F[k - 1]; }
+		else { E_in = p == P - 1 ? nb : st.E[k + 1]; F_in = st.F[k - 1]; }
+		const bool valid = (unsigned)st.rel[k] <= (unsigned)st.span[k];
+		st.rel[k] += 2;
+		const int s = M[st.T[p] | st.Q[p + PAR]] + st.C[p + PAR];
+		int c = imax(imax(st.H[k] + s, E_in), imax(F_in, 0));
+		const int open = imax(c - go, 0);
+		const int e = imax(E_in - ge, open), f = imax(F_in - ge, open);        // open >= 0 already clamps them
+		if (TRACE) {
+			const uint32_t tb = (c == F_in ? TB_GAP_V : 0) | (c == E_in ? TB_GAP_H : 0) | (f == open ? TB_OPEN_V : 0) | (e == open ? TB_OPEN_H : 0);
+			packed |= tb << (8 * (p & 3));
+			if (P >= 4 && (p & 3) == 3) { *reinterpret_cast<uint32_t*>(trace + p - 3) = packed; packed = 0; }
+		}
+		c = valid ? c : 0;
+		st.H[k] = c; st.E[k] = valid ? e : 0; st.F[k] = valid ? f : 0;
+		if (COORDS && P <= WIN_DIAG_BEST_MAX_P) {
+			const bool up = c > st.bk[k];                // invalid cells carry c = 0 and never improve a record
+			st.ba[k] = up ? a : st.ba[k];
+			st.bk[k] = imax(st.bk[k], c);
+		}
+		else if (COORDS) {
+			if (valid && c >= st.best) {
+				const int d = d0 + k, i = (a + d) >> 1, j = (a - d) >> 1;
+				if (better_end(c, j, i, st.best, st.best_j, st.best_i)) { st.best = c; st.best_j = j; st.best_i = i; }
+			}
+		}
+		else
+			st.best = imax(st.best, c);
+	}
+	if (TRACE && P == 1) trace[0] = (uint8_t)packed;
+	if (TRACE && P == 2) *reinterpret_cast<uint16_t*>(trace) = (uint16_t)packed;
+}
+
+// end of a step pair: the window moves one row down and one column right; nq / nc / nt are the letters of row st.iq and
+// column st.jt (clamped into the sequences by the caller, which fetched them before the pair's two steps)
+template<int P, bool COORDS>
+DMND_HD void win_advance(WinLane<P, COORDS>& st, int nq, int nc, int nt)
+{
+#pragma unroll
+	for (int x = 0; x < P; ++x) { st.Q[x] = st.Q[x + 1]; st.C[x] = st.C[x + 1]; }
+	st.Q[P] = nq & LETTER_MASK; st.C[P] = nc;
+#pragma unroll
+	for (int p = P - 1; p > 0; --p) st.T[p] = st.T[p - 1];
+	st.T[0] = (nt & LETTER_MASK) << 5;
+	++st.iq; ++st.jt;
+}
+
 // Geometry of the reversed pass of recompute_reversed() (swipe_wrapper.cpp:378-391): the target is the
 // prefix [0, s_end) of the forward target, both sequences are read back to front, the band is mirrored
 // with Geo::rev_diag (util/geo/geo.h:37).

@@ -20,8 +20,14 @@
 namespace dmnd {
 
 // wave_shr:1 -> lane l reads lane l-1, lane 0 keeps `old` (0);  wave_shl:1 -> lane l reads lane l+1, lane 63 gets 0
-__device__ __forceinline__ int wave_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
-__device__ __forceinline__ int wave_shl1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ int wave_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true); }
+__device__ __forceinline__ int wave_shl1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true); }
+
+__device__ __forceinline__ int64_t uniform64(int64_t x)
+{
+	const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)x >> 32));
+	return (int64_t)(((uint64_t)hi << 32) | lo);
+}
 
 template<int P, bool COORDS, bool TRACE, int STAT = STAT_NONE, bool REV = false>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * 64)
@@ -39,32 +45,52 @@ void banded_swipe_kernel(SwipeArgs args)
 	const int32_t item_idx = args.order[slot];
 	const dmnd_dp_target it = args.items[item_idx];
 	const Geom g = make_geom(it.query_len, it.target_len, it.d_begin, it.d_end);
-	SeqView v{ args.qblock + it.query_off, args.tblock + it.target_off,
-		it.cbs_off >= 0 ? args.cbs + it.cbs_off : nullptr, matrix };
+	// the item is the same for all 64 lanes: keeping its offsets in SGPRs lets the letter loads use scalar base + lane offset
+	const int64_t q_off = uniform64(it.query_off), t_off = uniform64(it.target_off), c_off = uniform64(it.cbs_off);
+	SeqView v{ args.qblock + q_off, args.tblock + t_off, c_off >= 0 ? args.cbs + c_off : nullptr, matrix };
 	if (REV) { v.rev_q = it.query_len - 1; v.rev_t = it.target_len - 1; }
 	const int go = args.gap_open + args.gap_extend, ge = args.gap_extend;
 
-	Lane<P, COORDS, STAT> st;
-	st.init(g, lane);
-	uint8_t* row = nullptr;
-	if (TRACE)
-		row = args.trace + args.trace_off[slot] + lane * P;
-	constexpr int W = 64 * P;
-
-	for (int a = g.a_first; a <= g.a_last; a += 2) {
-		int nb = wave_shr1(st.F[2 * P - 1]), na = 0, nbb = 0;
-		if constexpr (STAT != STAT_NONE) { na = wave_shr1(st.st.Fa[2 * P - 1]); nbb = wave_shr1(st.st.Fb[2 * P - 1]); }
-		lane_step<P, COORDS, TRACE, 0, STAT>(st, g, v, lane, a, nb, go, ge, row, na, nbb);
-		if (TRACE) row += W;
-		// the odd step may lie past a_last: all its cells are then invalid, and its trace row is allocated
-		nb = wave_shl1(st.E[0]);
-		if constexpr (STAT != STAT_NONE) { na = wave_shl1(st.st.Ea[0]); nbb = wave_shl1(st.st.Eb[0]); }
-		lane_step<P, COORDS, TRACE, 1, STAT>(st, g, v, lane, a + 1, nb, go, ge, row, na, nbb);
-		if (TRACE) row += W;
+	int bs, bi, bj, ba = 0, bb = 0;
+	if constexpr (STAT == STAT_NONE) {
+		// register-window sweep (swipe_core.h): per step pair one query letter, one bias byte and one target letter are
+		// fetched, a pair ahead of their use; the cells themselves touch only VGPRs and the matrix in LDS
+		WinLane<P, COORDS> st;
+		win_init(st, g, v, lane);
+		const int d0 = g.d_begin + 2 * P * lane;
+		uint8_t* row = nullptr;
+		if (TRACE)
+			row = args.trace + args.trace_off[slot] + lane * P;
+		constexpr int W = 64 * P;
+		const bool has_cbs = v.cbs != nullptr;
+		for (int a = g.a_first; a <= g.a_last; a += 2) {
+			const uint32_t xi = (uint32_t)clampi(st.iq, g.qlen - 1), xj = (uint32_t)clampi(st.jt, g.tlen - 1);
+			const int nq = v.q[xi], nt = v.t[xj], nc = has_cbs ? v.cbs[xi] : 0;      // consumed by win_advance at the end of the pair
+			int nb = wave_shr1(st.F[2 * P - 1]);
+			win_step<P, COORDS, TRACE, 0>(st, matrix, nb, go, ge, a, d0, row);
+			if (TRACE) row += W;
+			// the odd step may lie past a_last: all its cells are then invalid, and its trace row is allocated
+			nb = wave_shl1(st.E[0]);
+			win_step<P, COORDS, TRACE, 1>(st, matrix, nb, go, ge, a + 1, d0, row);
+			if (TRACE) row += W;
+			win_advance(st, nq, nc, nt);
+		}
+		win_finish(st, d0);
+		bs = st.best; bi = st.best_i; bj = st.best_j;
+	}
+	else {
+		Lane<P, COORDS, STAT> st;
+		st.init(g, lane);
+		for (int a = g.a_first; a <= g.a_last; a += 2) {
+			int nb = wave_shr1(st.F[2 * P - 1]), na = wave_shr1(st.st.Fa[2 * P - 1]), nbb = wave_shr1(st.st.Fb[2 * P - 1]);
+			lane_step<P, COORDS, false, 0, STAT>(st, g, v, lane, a, nb, go, ge, nullptr, na, nbb);
+			nb = wave_shl1(st.E[0]); na = wave_shl1(st.st.Ea[0]); nbb = wave_shl1(st.st.Eb[0]);
+			lane_step<P, COORDS, false, 1, STAT>(st, g, v, lane, a + 1, nb, go, ge, nullptr, na, nbb);
+		}
+		bs = st.best; bi = st.best_i; bj = st.best_j; ba = st.best_a; bb = st.best_b;
 	}
 
 	// wave reduction of the end cell
-	int bs = st.best, bi = st.best_i, bj = st.best_j, ba = st.best_a, bb = st.best_b;
 #pragma unroll
 	for (int off = 32; off >= 1; off >>= 1) {
 		const int os = __shfl_xor(bs, off), oi = __shfl_xor(bi, off), oj = __shfl_xor(bj, off);

@@ -19,20 +19,27 @@ static void run(const SeqView& v, int qlen, int tlen, int d_begin, int d_end, in
 {
 	const Geom g = make_geom(qlen, tlen, d_begin, d_end);
 	const int go = gap_open + gap_extend, ge = gap_extend, W = 64 * P;
-	std::vector<Lane<P, COORDS>> st(64);
-	for (int l = 0; l < 64; ++l) st[l].init(g, l);
+	// the register-window lanes of the score / coordinates / traceback kernels (WinLane, swipe_core.h), driven exactly as
+	// banded_swipe_kernel drives them: fetch the pair's new letters, even step, odd step, advance the windows
+	std::vector<WinLane<P, COORDS>> st(64);
+	for (int l = 0; l < 64; ++l) win_init(st[l], g, v, l);
 	std::vector<uint8_t> trace;
-	if (TRACE) trace.assign((size_t)n_steps(g) * W + 1, 0xee);
-	int nb[64];
+	if (TRACE) trace.assign((size_t)trace_rows(g) * W + 8, 0xee);
+	int nb[64], nq[64], nc[64], nt[64];
 	for (int a = g.a_first; a <= g.a_last; a += 2) {
+		for (int l = 0; l < 64; ++l) {
+			const int xi = clampi(st[l].iq, g.qlen - 1), xj = clampi(st[l].jt, g.tlen - 1);
+			nq[l] = v.q[xi]; nt[l] = v.t[xj]; nc[l] = v.cbs ? v.cbs[xi] : 0;
+		}
 		uint8_t* row = TRACE ? trace.data() + (size_t)(a - g.a_first) * W : nullptr;
 		for (int l = 0; l < 64; ++l) nb[l] = l == 0 ? 0 : st[l - 1].F[2 * P - 1];       // wave_shr:1, lane 0 reads 0
-		for (int l = 0; l < 64; ++l) lane_step<P, COORDS, TRACE, 0>(st[l], g, v, l, a, nb[l], go, ge, row ? row + l * P : nullptr);
-		if (a + 1 > g.a_last) break;
+		for (int l = 0; l < 64; ++l) win_step<P, COORDS, TRACE, 0>(st[l], v.M, nb[l], go, ge, a, g.d_begin + 2 * P * l, row ? row + l * P : nullptr);
 		row = TRACE ? trace.data() + (size_t)(a + 1 - g.a_first) * W : nullptr;
 		for (int l = 0; l < 64; ++l) nb[l] = l == 63 ? 0 : st[l + 1].E[0];               // wave_shl:1, lane 63 reads 0
-		for (int l = 0; l < 64; ++l) lane_step<P, COORDS, TRACE, 1>(st[l], g, v, l, a + 1, nb[l], go, ge, row ? row + l * P : nullptr);
+		for (int l = 0; l < 64; ++l) win_step<P, COORDS, TRACE, 1>(st[l], v.M, nb[l], go, ge, a + 1, g.d_begin + 2 * P * l, row ? row + l * P : nullptr);
+		for (int l = 0; l < 64; ++l) win_advance(st[l], nq[l], nc[l], nt[l]);
 	}
+	for (int l = 0; l < 64; ++l) win_finish(st[l], g.d_begin + 2 * P * l);
 	int bs = 0, bi = 0, bj = 0x7fffffff;
 	for (int l = 0; l < 64; ++l) {
 		if (COORDS ? better_end(st[l].best, st[l].best_j, st[l].best_i, bs, bj, bi) : st[l].best > bs) {
