@@ -147,15 +147,16 @@ def main():
         ctx_seed.upload_block(hip.TARGET, td, tl)
 
     def step():
-        t_a = time.perf_counter()
+        t_a, c_a = time.perf_counter(), time.process_time()
         hits = ctx.seed_search(seed_params)
-        t_b = time.perf_counter()
+        t_b, c_b = time.perf_counter(), time.process_time()
         matches, _ = ctx.extend(qd, td, hits, threads=threads)
-        t_c = time.perf_counter()
+        t_c, c_c = time.perf_counter(), time.process_time()
         aligned = gather_topk(args.queries, matches, coll_device)
-        t_d = time.perf_counter()
+        t_d, c_d = time.perf_counter(), time.process_time()
         state.update(hits=int(hits.size), matches=int(matches.size), aligned=aligned, seed_ms=ctx.seed_kernel_ms(), ext=ctx.extend_stats(),
-                     wall_ms={"seed_stage_call": (t_b - t_a) * 1e3, "extension_call": (t_c - t_b) * 1e3, "topk_gather": (t_d - t_c) * 1e3})
+                     wall_ms={"seed_stage_call": (t_b - t_a) * 1e3, "extension_call": (t_c - t_b) * 1e3, "topk_gather": (t_d - t_c) * 1e3},
+                     cpu_ms={"seed_stage_call": (c_b - c_a) * 1e3, "extension_call": (c_c - c_b) * 1e3, "topk_gather": (c_d - c_c) * 1e3})
 
     def sync():
         torch.cuda.synchronize()
@@ -173,6 +174,8 @@ def main():
         stream = 0.0
         fut = seed_pool.submit(seed_stage)
         wall = [0.0, 0.0, 0.0]
+        each = state.setdefault("each_ms", [])
+        del each[:]
         for s in range(n_steps):
             t_a = time.perf_counter()
             hits, seed_ms = fut.result()
@@ -186,6 +189,7 @@ def main():
             t_d = time.perf_counter()
             for i, x in enumerate((t_b - t_a, t_c - t_b, t_d - t_c)):
                 wall[i] += x * 1e3 / n_steps
+            each.append(round((t_d - t_a) * 1e3, 2))
             state.update(hits=int(hits.size), matches=int(matches.size), aligned=aligned, seed_ms=seed_ms, ext=ctx.extend_stats(),
                          pipe_wall_ms={"wait_for_seed_stage": wall[0], "extension_call": wall[1], "topk_gather": wall[2]})
         return stream
@@ -199,6 +203,7 @@ def main():
         run_pipelined(2)
     sync()
     t0 = time.perf_counter()
+    cpu0 = time.process_time()
     stream_ms = 0.0
     if pipeline:
         stream_ms = run_pipelined(args.steps)
@@ -208,6 +213,7 @@ def main():
             stream_ms += state["seed_ms"][1]
     sync()
     dt = time.perf_counter() - t0
+    cpu_ms_per_step = (time.process_time() - cpu0) * 1e3 / args.steps      # CPU time of all threads of this process
     if pipeline:                                             # stage latencies of one batch on an otherwise idle GPU, after the timed region
         state["pipe_ext"] = dict(state["ext"])
         serial = []
@@ -275,6 +281,10 @@ def main():
                          "measured_copy_gbs": copy_gbs,
                          "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_unit": 17, "units_per_launch": ref_letters,
                          "kernel_ms": k_ms,
+                         # with the batch pipeline the low-priority stream kernel shares the CUs with the previous batch's swipe kernels
+                         # inside the timed region; alone (the serial steps after it) it takes kernel_ms_alone
+                         "kernel_ms_alone": state.get("serial_stream_ms"),
+                         "frac_alone": (alg_bytes / (state["serial_stream_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if state.get("serial_stream_ms") else None,
                          "design_bytes_per_launch": design_bytes, "achieved_design_bytes": achieved_design,
                          "frac_design_bytes": achieved_design / HBM_PEAK_GBS,
                          "note": "achieved = SURVEY 8(d) algorithmic bytes of the join's reference side (17 B per reference letter: residue + "
@@ -289,10 +299,13 @@ def main():
             # seed-stage Gletters/s = (L_q + L_r) x shapes / seed-stage seconds (device time of its kernels)
             "seed_stage_gletters_per_s": (int(ql[-1] - ql[0]) + int(tl[-1] - tl[0])) * seed_params.n_shapes / max(state["seed_ms"][4], 1e-9) / 1e6,
             "wall_ms_last_step": state["wall_ms"],
+            "host_cpu_ms_last_step": state.get("cpu_ms"),
             "pipeline": ("seed stage of batch s+1 (second context, own stream) overlaps the extension stage of batch s; latency of one batch alone "
                          "%.2f ms, its stream kernel alone %.3f ms" % (state["serial_ms"], state["serial_stream_ms"])) if pipeline else "off",
             "pipeline_wall_ms_per_step": state.get("pipe_wall_ms"),
             "pipeline_extension_last_step": state.get("pipe_ext"),
+            "ms_each_step": state.get("each_ms"),
+            "host_cpu_ms_per_step": cpu_ms_per_step,
             # not part of `value`: one-time PCIe upload of both blocks, and the rate if it were paid on every step
             "block_upload_ms": upload_ms,
             "pcie_inclusive_gcups": cells_step * world / ((dt / args.steps + upload_ms * 1e-3)) / 1e9,

@@ -112,6 +112,7 @@ extern "C" void dmnd_destroy(dmnd_ctx* c)
 {
 	if (!c) return;
 	if (c->sort_tmp) { (void)hipFree(c->sort_tmp); c->sort_tmp = nullptr; c->sort_tmp_bytes = 0; }
+	if (c->pinned_cbs) (void)hipHostFree(c->pinned_cbs);
 	for (dmnd_ctx* a : c->aux) dmnd_destroy(a);
 	c->aux.clear();
 	(void)hipSetDevice(c->device);
@@ -143,12 +144,19 @@ extern "C" int dmnd_upload_block(dmnd_ctx* c, int which, const int8_t* data, int
 	HIP_TRY(hipSetDevice(c->device));
 	if (int rc = c->block[which].ensure((size_t)data_len + 64)) return rc;
 	HIP_TRY(hipMemcpyAsync(c->block[which].p, data, (size_t)data_len, hipMemcpyHostToDevice, c->stream));
-	HIP_TRY(hipStreamSynchronize(c->stream));
+	HIP_TRY(sync_stream(c->stream));
 	c->block_len[which] = data_len;
-	if (which == DMND_QUERY) c->host_cbs_buf.clear();          // bias cache of the previous query block
 	c->limits[which].clear();
 	if (limits) {
 		c->limits[which].assign(limits, limits + n_seqs + 1);
+		std::vector<uint32_t>& co = c->coarse[which];
+		co.assign((size_t)(limits[n_seqs] >> dmnd_ctx::COARSE_SHIFT) + 2, 0);
+		int64_t sidx = 0;
+		for (size_t b = 0; b < co.size(); ++b) {
+			const int64_t pos = (int64_t)b << dmnd_ctx::COARSE_SHIFT;
+			while (sidx + 1 <= n_seqs && limits[sidx + 1] <= pos) ++sidx;
+			co[b] = (uint32_t)std::min<int64_t>(sidx, n_seqs - 1);
+		}
 		if (limits[n_seqs] > data_len) return fail(DMND_E_ARG, "dmnd_upload_block: limits exceed data_len");
 		if (int rc = c->d_limits[which].ensure((size_t)(n_seqs + 1) * sizeof(int64_t))) return rc;
 		HIP_TRY(copy_now(c->stream, c->d_limits[which].p, limits, (size_t)(n_seqs + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
@@ -166,7 +174,7 @@ extern "C" int dmnd_upload_cbs(dmnd_ctx* c, const int8_t* cbs, int64_t len)
 		return DMND_OK;
 	if (int rc = c->cbs.ensure((size_t)len + 256)) return rc;      // slack: the gapped filter reads up to 130 bytes past a query (values unused)
 	HIP_TRY(hipMemcpyAsync(c->cbs.p, cbs, (size_t)len, hipMemcpyHostToDevice, c->stream));
-	HIP_TRY(hipStreamSynchronize(c->stream));
+	HIP_TRY(sync_stream(c->stream));
 	return DMND_OK;
 }
 
@@ -301,7 +309,7 @@ int run_chunk(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, const dm
 			*chunk_tr_off = tr_off;
 		}
 	}
-	HIP_TRY(hipStreamSynchronize(c->stream));
+	HIP_TRY(sync_stream(c->stream));
 	float ms = 0.f;
 	HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
 	c->swipe_ms += ms;
@@ -558,7 +566,7 @@ extern "C" int dmnd_banded_swipe_host(dmnd_ctx* c, const int8_t* query, int32_t 
 		if (int rc = c->host_cbs.ensure((size_t)query_len + 64)) return rc;
 		HIP_TRY(hipMemcpyAsync(c->host_cbs.p, cbs, (size_t)query_len, hipMemcpyHostToDevice, c->stream));
 	}
-	HIP_TRY(hipStreamSynchronize(c->stream));
+	HIP_TRY(sync_stream(c->stream));
 	const Bases b{ c->host_q.as<int8_t>(), query_len, c->host_t.as<int8_t>(), total, cbs ? c->host_cbs.as<int8_t>() : nullptr, cbs ? query_len : 0 };
 	return swipe_impl(c, b, items.data(), n, mode, hsp_values, out, transcript, transcript_cap, transcript_used);
 }

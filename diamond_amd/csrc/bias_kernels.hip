@@ -1,0 +1,38 @@
+// bias_kernels.hip -- Hauser composition bias of a whole query block on the GPU.
+// Replaces HauserCorrection (/root/reference/src/stats/hauser_correction.cpp:28-107) as called per query by
+// Extension::extend (src/align/extend.cpp:252-262). One workgroup per sequence, one thread per position: the position's
+// window is known in closed form (bias_core.h), so no running sums are carried along the sequence -- every thread sums
+// the <= W + 1 matrix entries of its own window (letters through L1, matrix in LDS). 3.0e6 query letters of the C2
+// block are ~1.2e8 LDS reads: tens of microseconds, against ~11 ms of host CPU time for the running-sum loop.
+#include <hip/hip_runtime.h>
+#include "bias_core.h"
+#include "bias_kernels.h"
+
+namespace dmnd {
+
+__global__ __launch_bounds__(256) void hauser_bias_kernel(BiasArgs a)
+{
+	__shared__ int8_t M[32 * 32];
+	__shared__ float bg[20];
+	for (int x = threadIdx.x; x < 32 * 32 / 4; x += blockDim.x)
+		reinterpret_cast<int32_t*>(M)[x] = reinterpret_cast<const int32_t*>(a.matrix)[x];
+	if (threadIdx.x < 20) bg[threadIdx.x] = a.bg[threadIdx.x];
+	__syncthreads();
+	for (int64_t s = blockIdx.x; s < a.n_seqs; s += gridDim.x) {
+		const int64_t begin = a.limits[s];
+		const int l = (int)(a.limits[s + 1] - begin - 1);
+		const int8_t* seq = a.block + begin;
+		for (int m = threadIdx.x; m < l; m += blockDim.x)
+			a.out[begin + m] = hauser_at(seq, l, m, M, bg, a.window);
+	}
+}
+
+hipError_t launch_hauser_bias(const BiasArgs& a, hipStream_t st)
+{
+	if (a.n_seqs <= 0) return hipSuccess;
+	const unsigned blocks = (unsigned)(a.n_seqs < 65536 ? a.n_seqs : 65536);
+	hipLaunchKernelGGL(hauser_bias_kernel, dim3(blocks), dim3(256), 0, st, a);
+	return hipGetLastError();
+}
+
+}  // namespace dmnd

@@ -1,6 +1,7 @@
 // ctx.h -- shared internals of libdiamond_hip.so: error plumbing, device buffers, the context object.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 #include <string>
 #include <vector>
@@ -20,10 +21,39 @@ int fail(int code, const std::string& msg);      // sets dmnd_last_error(), retu
 
 // Blocking copy on the context's own stream. A plain hipMemcpy runs on the null stream, which waits for (and stalls) every
 // blocking stream of the process: the concurrent sub-batches of dmnd_extend and independent contexts would serialise on it.
+// Host wait for a stream. hipStreamSynchronize spins on the completion signal: a runner of dmnd_extend or the seed stage's
+// thread then burns a whole core for as long as the GPU works, which is what a CPU-quota'd container (cgroup cpu.max; the
+// MI355X boxes of this project give 16 CPUs to 256 hardware threads) can least afford -- the quota runs out and every thread
+// of the process is frozen for the rest of the 100 ms period. So by default the wait is an interrupt-driven one on a
+// hipEventBlockingSync event (one per thread); DMND_SPIN_SYNC=1 restores the spinning wait (lowest latency on an idle host).
+inline bool spin_sync()
+{
+	static const bool v = [] { const char* e = std::getenv("DMND_SPIN_SYNC"); return e && e[0] == '1'; }();
+	return v;
+}
+
+inline hipError_t sync_stream(hipStream_t s)
+{
+	if (spin_sync()) return hipStreamSynchronize(s);
+	static thread_local hipEvent_t ev = nullptr;
+	static thread_local int ev_device = -1;
+	int dev = 0;
+	hipError_t e = hipGetDevice(&dev);
+	if (e != hipSuccess) return e;
+	if (!ev || ev_device != dev) {
+		if (ev) (void)hipEventDestroy(ev);
+		e = hipEventCreateWithFlags(&ev, hipEventBlockingSync | hipEventDisableTiming);
+		if (e != hipSuccess) { ev = nullptr; return e; }
+		ev_device = dev;
+	}
+	e = hipEventRecord(ev, s);
+	return e != hipSuccess ? e : hipEventSynchronize(ev);
+}
+
 inline hipError_t copy_now(hipStream_t s, void* dst, const void* src, size_t bytes, hipMemcpyKind kind)
 {
 	const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, s);
-	return e != hipSuccess ? e : hipStreamSynchronize(s);
+	return e != hipSuccess ? e : sync_stream(s);
 }
 
 struct DevBuf {
@@ -46,6 +76,11 @@ struct dmnd_ctx {
 	dmnd::DevBuf block[2], cbs, matrix;
 	int64_t block_len[2] = { 0, 0 }, cbs_len = 0;
 	std::vector<int64_t> limits[2];
+	// coarse[which][p >> COARSE_SHIFT] = index of the last sequence starting at or before block offset (p >> COARSE_SHIFT) << COARSE_SHIFT:
+	// the host's "which sequence holds this block offset" lookups (one per seed hit in load_hits) become one read of this
+	// L2-sized table plus a search over the few sequences of a 4 KiB stretch, instead of a binary search over all limits
+	std::vector<uint32_t> coarse[2];
+	enum { COARSE_SHIFT = 12 };
 	dmnd::DevBuf d_limits[2];
 	// banded-swipe work buffers
 	dmnd::DevBuf items, order, p_of_slot, trace_off, transcript_off, ends, hsps, trace, transcript, status;
@@ -65,7 +100,7 @@ struct dmnd_ctx {
 	double seed_ms[5] = { 0, 0, 0, 0, 0 };
 	// extension-stage statistics of the last dmnd_extend (extend_host.hip)
 	std::vector<dmnd_ctx*> aux;                // auxiliary contexts (own stream + work buffers) for concurrent sub-batches of dmnd_extend
-	std::vector<int8_t> host_cbs_buf;          // Hauser bias of the query block (host copy, parallel to the block letters)
+	int8_t* pinned_cbs = nullptr; size_t pinned_cbs_cap = 0;      // Hauser bias of the query block, pinned host copy (parallel to the block letters)
 	double ext_stats[12] = { 0 };
 	double host_ms[3] = { 0, 0, 0 };           // host wall time inside dmnd_banded_swipe: prepare, launch+wait, unpack (DMND_TRACE)
 	int comp_based_stats = 1;                  // config.comp_based_stats: 1 = Hauser bias (default), 0 = off

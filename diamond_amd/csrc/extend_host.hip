@@ -36,9 +36,11 @@
 #include "ctx.h"
 #include "chain_host.h"
 #include "host_pool.h"
+#include "bias_kernels.h"
 
 namespace dmnd {
 static thread_local int tls_pool = -1;
+static double g_extend_t0 = 0;           // DMND_TRACE=2: start of the current dmnd_extend (absolute timeline of the runners)
 void set_thread_pool(int k) { tls_pool = k; }
 WorkerPool& pool()
 {
@@ -136,7 +138,7 @@ struct QueryWork {
 
 // load_hits (load_hits.h:44-127) + the target ranking of extend() (extend.cpp:403-414)
 void load_query(const HostCfg& h, QueryWork& w, uint32_t query, const dmnd_seed_hit* hb, const dmnd_seed_hit* he, const uint8_t* gf_flags,
-	const int64_t* tl, int64_t nt)
+	const int64_t* tl, int64_t nt, const uint32_t* coarse = nullptr)
 {
 	std::vector<dmnd_seed_hit> hits(hb, he);
 	for (size_t x = 0; x < hits.size(); ++x) hits[x].pad = gf_flags ? gf_flags[x] : 1;      // carried through the sort below
@@ -149,7 +151,14 @@ void load_query(const HostCfg& h, QueryWork& w, uint32_t query, const dmnd_seed_
 	const int64_t* it = tl;
 	for (size_t x = 0; x < hits.size(); ++x) {
 		const int64_t s = hits[x].subject;
-		it = std::upper_bound(it, tl + nt + 1, s);
+		if (coarse) {                                        // sequences starting inside the hit's 4 KiB stretch, from the table's entry on
+			const int64_t* lo = tl + coarse[s >> dmnd_ctx::COARSE_SHIFT];
+			if (lo > it) it = lo;
+			while (it + 1 <= tl + nt && it[1] <= s) ++it;
+			++it;
+		}
+		else
+			it = std::upper_bound(it, tl + nt + 1, s);
 		const uint32_t t = (uint32_t)(it - tl) - 1;
 		--it;
 		if (w.groups.empty() || w.groups.back().target != t) w.groups.push_back(TargetGroup{ t, x, x, 0, false });
@@ -375,7 +384,7 @@ struct QueryState {
 // and statistics parameters (read only), w = the context whose stream, device work buffers and counters this range uses
 // (w == c, or one of c's auxiliary contexts when the block is processed as concurrent sub-batches).
 static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const std::vector<Range>& qr, size_t qr_begin, size_t qr_end,
-	const dmnd_seed_hit* hits, const std::vector<uint8_t>& gf, const int8_t* qdata, const int8_t* tdata, std::vector<int8_t>& cbs, bool compute_bias,
+	const dmnd_seed_hit* hits, const std::vector<uint8_t>& gf, const int8_t* qdata, const int8_t* tdata, const int8_t* cbs,
 	int threads, uint32_t hsp_values, std::vector<dmnd_match>& out_matches,
 	uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used)
 {
@@ -392,27 +401,15 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 		return s;
 	};
 	double t_mark = now();
-	double fine[16] = { 0 };          // DMND_TRACE=1: finer host timeline on stderr
-	auto lap = [&](int slot, int f = -1) { const double t = now(); w->ext_stats[slot] += t - t_mark; if (f >= 0) fine[f] += t - t_mark; t_mark = t; };
-	// 1. (unless done by the caller) Hauser bias of this range's queries + upload of their slice of the bias buffer
-	if (compute_bias && qr_end > qr_begin) {
-		parallel_for(qr_end - qr_begin, threads, [&](size_t i, int) {
-			const uint32_t q0 = hits[qr[qr_begin + i].b].query / C * C;
-			for (uint32_t q = q0; q < q0 + C; ++q) {
-				const SeqRef s{ qdata + ql[q], (int)(ql[q + 1] - ql[q] - 1) };
-				if (s.len > 0) hauser_int8(h, s, cbs.data() + ql[q]);
-			}
-		});
-		const uint32_t qa = hits[qr[qr_begin].b].query / C * C, qb = hits[qr[qr_end - 1].b].query / C * C + C;      // contiguous in the block
-		HIP_TRY(hipMemcpyAsync(c->cbs.as<int8_t>() + ql[qa], cbs.data() + ql[qa], (size_t)(ql[qb] - ql[qa]), hipMemcpyHostToDevice, w->stream));
-		HIP_TRY(hipStreamSynchronize(w->stream));
-	}
+	const double t_enter = t_mark;
+	double fine[16] = { 0 }, at[16] = { 0 };          // DMND_TRACE=1: finer host timeline on stderr (at[]: end of each phase since dmnd_extend began, first pass)
+	auto lap = [&](int slot, int f = -1) { const double t = now(); w->ext_stats[slot] += t - t_mark; if (f >= 0) { fine[f] += t - t_mark; if (at[f] == 0) at[f] = t - g_extend_t0; } t_mark = t; };
 	lap(4, 1);
 	// 2. load_hits for every query
 	std::vector<QueryState> qs(qr_end - qr_begin);
 	parallel_for(qs.size(), threads, [&](size_t i, int) {
 		const Range& r = qr[qr_begin + i];
-		load_query(h, qs[i].w, hits[r.b].query / (uint32_t)h.contexts, hits + r.b, hits + r.e, gf.empty() ? nullptr : gf.data() + r.b, tl.data(), (int64_t)tl.size() - 1);
+		load_query(h, qs[i].w, hits[r.b].query / (uint32_t)h.contexts, hits + r.b, hits + r.e, gf.empty() ? nullptr : gf.data() + r.b, tl.data(), (int64_t)tl.size() - 1, c->coarse[DMND_TARGET].empty() ? nullptr : c->coarse[DMND_TARGET].data());
 		if (qs[i].w.order.empty()) qs[i].done = true;
 	});
 	std::vector<ChainWorkspace> ws((size_t)threads);
@@ -433,7 +430,7 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 			parallel_for(active.size(), threads, [&](size_t a, int t) {
 				QueryState& s = qs[active[a]];
 				s.plan.clear();
-				plan_groups(h, ws[(size_t)t], s.w, s.w.i0, s.w.i1, qdata, ql.data(), tdata, tl.data(), h.use_cbs ? cbs.data() : nullptr, s.plan);
+				plan_groups(h, ws[(size_t)t], s.w, s.w.i0, s.w.i1, qdata, ql.data(), tdata, tl.data(), h.use_cbs ? cbs : nullptr, s.plan);
 			});
 			items.clear();
 			for (size_t i : active) {
@@ -589,6 +586,9 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 		});
 	}
 	lap(7, 10);
+	if (const char* tr = std::getenv("DMND_TRACE")) if (tr[0] == '2')
+		std::fprintf(stderr, "  timeline[%zu queries] enter %.2f | bias %.2f load %.2f plan %.2f swipe1 %.2f post1 %.2f build2 %.2f swipe2 %.2f post2 %.2f final %.2f\n",
+			qs.size(), t_enter - g_extend_t0, at[1], at[3], at[4], at[5], at[6], at[7], at[8], at[9], at[10]);
 	if (std::getenv("DMND_TRACE"))
 		std::fprintf(stderr, "dmnd_extend[%zu queries] ms: bias %.2f load %.2f plan %.2f swipe1 %.2f post1 %.2f build2 %.2f swipe2 %.2f post2 %.2f final %.2f | swipe host: prep %.2f run %.2f post %.2f\n",
 			qs.size(), fine[1], fine[3], fine[4], fine[5], fine[6], fine[7], fine[8], fine[9], fine[10], w->host_ms[0], w->host_ms[1], w->host_ms[2]);
@@ -627,34 +627,35 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	for (double& x : c->host_ms) x = 0;
 	auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	double t_mark = now();
+	g_extend_t0 = t_mark;
 	double fine[16] = { 0 };          // DMND_TRACE=1: finer host timeline on stderr
 	auto lap = [&](int slot, int f = -1) { const double t = now(); c->ext_stats[slot] += t - t_mark; if (f >= 0) fine[f] += t - t_mark; t_mark = t; };
 	// 1. Hauser bias for every query, resident next to the query block
 	const std::vector<Range> qr = split_by_query(hits, n_hits, h.contexts);
-	// only queries with seed hits are ever aligned, and only their bias is ever read: the buffer lives in the context, so
-	// neither its allocation nor a 3 MB clear is paid per call (stale values of other queries are never touched)
-	std::vector<int8_t>& cbs = c->host_cbs_buf;
-	if (cbs.size() < (size_t)ql.back() + 64) cbs.assign((size_t)ql.back() + 64, 0);
-	// With the gapped filter on, the bias of every query is needed before the sub-batches start; otherwise every sub-batch
-	// computes and uploads the slice of its own queries (on its own stream), overlapped with the other sub-batches.
-	const bool bias_in_prelude = c->gapped_filter_evalue > 0.0 || !h.use_cbs;
+	// One launch over the whole query block (bias_kernels.hip: closed-form window per position), result kept in HBM next to
+	// the block for the swipe kernels and the gapped filter, and copied into a pinned host buffer for the host's x-drop stage.
+	const int8_t* cbs = nullptr;
 	if (!h.use_cbs) {
 		c->cbs_len = 0;                                     // --comp-based-stats 0: no bias anywhere on the path
-	}
-	else if (bias_in_prelude) {
-		parallel_for(qr.size(), threads, [&](size_t i, int) {
-			const uint32_t q0 = hits[qr[i].b].query / C * C;
-			for (uint32_t q = q0; q < q0 + C; ++q) {
-				const SeqRef s{ qdata + ql[q], (int)(ql[q + 1] - ql[q] - 1) };
-				if (s.len > 0) hauser_int8(h, s, cbs.data() + ql[q]);
-			}
-		});
-		if (int rc = dmnd_upload_cbs(c, cbs.data(), ql.back())) return rc;
 	}
 	else {
 		HIP_TRY(hipSetDevice(c->device));
 		if (int rc = c->cbs.ensure((size_t)ql.back() + 256)) return rc;
+		if (c->pinned_cbs_cap < (size_t)ql.back() + 64) {
+			if (c->pinned_cbs) (void)hipHostFree(c->pinned_cbs);
+			c->pinned_cbs = nullptr; c->pinned_cbs_cap = 0;
+			HIP_TRY(hipHostMalloc((void**)&c->pinned_cbs, (size_t)ql.back() + 64, hipHostMallocDefault));
+			c->pinned_cbs_cap = (size_t)ql.back() + 64;
+		}
+		BiasArgs ba;
+		ba.block = c->block[DMND_QUERY].as<int8_t>(); ba.limits = c->d_limits[DMND_QUERY].as<int64_t>(); ba.n_seqs = (int64_t)ql.size() - 1;
+		ba.matrix = c->matrix.as<int8_t>(); ba.window = h.cbs_window; ba.out = c->cbs.as<int8_t>();
+		for (int i = 0; i < 20; ++i) ba.bg[i] = (float)h.background_scores[i];
+		HIP_TRY(launch_hauser_bias(ba, c->stream));
+		HIP_TRY(hipMemcpyAsync(c->pinned_cbs, c->cbs.p, (size_t)ql.back(), hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(sync_stream(c->stream));
 		c->cbs_len = ql.back();
+		cbs = c->pinned_cbs;
 	}
 	lap(4, 1);
 	// 1b. gapped filter of every seed hit in one launch (only --sensitive and above; extend.cpp:205-213)
@@ -665,7 +666,7 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 		if (int rc = dmnd_gapped_filter(c, hits, n_hits, h.use_cbs ? 1 : 0, gf.data(), nullptr)) return rc;
 	}
 	lap(4, 2);
-	if (std::getenv("DMND_TRACE")) {
+	if (const char* tr = std::getenv("DMND_TRACE")) if (tr[0] == '3') {
 		const double t0 = now();
 		for (int i = 0; i < 20; ++i) parallel_for((size_t)threads, threads, [](size_t, int) {});
 		std::fprintf(stderr, "dmnd_extend ms: hauser+upload %.2f gapped_filter %.2f | empty parallel loop over %d threads: %.3f ms\n", fine[1], fine[2], threads, (now() - t0) / 20);
@@ -675,8 +676,12 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	// kernels the others chain, cull and pack on the host; the GPU serialises the runners' launches, which staggers them after
 	// the first round, so with more sub-batches than runners host and device phases overlap like a pipeline. Results are
 	// concatenated in query order, so the output does not depend on the split.
+	// How many: measured on C2 (20k seed hits, 6.7k queries with hits) eight single-threaded runners beat every combination with
+	// worker threads under them -- the host phases of a sub-batch are a few hundred microseconds, less than it costs to wake a
+	// pool -- and use a quarter of the CPU time, which matters on CPU-quota'd hosts. Worker threads are added per runner only
+	// when a runner's share of the seed hits is large enough to pay for them (--sensitive: 1.2e6 hits per block).
 	int split = 1, runners = 1;
-	if (!transcript && qr.size() >= 2048) { split = 4; runners = 4; }
+	if (!transcript && qr.size() >= 2048) { runners = std::max(1, std::min(8, threads)); split = runners; }
 	if (const char* e = std::getenv("DMND_EXTEND_SPLIT")) split = std::max(1, std::min(64, std::atoi(e)));
 	if (const char* e = std::getenv("DMND_EXTEND_RUNNERS")) runners = std::max(1, std::atoi(e));
 	if (transcript || qr.size() < (size_t)split * 2) split = 1;
@@ -685,7 +690,7 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	std::vector<int> rcs((size_t)split, DMND_OK);
 	std::vector<std::string> errs((size_t)split);
 	if (split == 1) {
-		rcs[0] = extend_range(c, c, h, qr, 0, qr.size(), hits, gf, qdata, tdata, cbs, !bias_in_prelude, threads, hsp_values, parts[0], transcript, transcript_cap, transcript_used);
+		rcs[0] = extend_range(c, c, h, qr, 0, qr.size(), hits, gf, qdata, tdata, cbs, threads, hsp_values, parts[0], transcript, transcript_cap, transcript_used);
 	}
 	else {
 		const double stats4 = c->ext_stats[4];
@@ -695,7 +700,8 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 			if (!work[(size_t)r]) return fail(DMND_E_DEVICE, "dmnd_extend: cannot create an auxiliary context");
 		}
 		std::vector<std::thread> th;
-		const int sub_threads = std::max(1, threads / runners);
+		int sub_threads = std::max(1, std::min(threads / runners, (int)(n_hits / runners / 8192)));
+		if (const char* e = std::getenv("DMND_EXTEND_SUB_THREADS")) sub_threads = std::max(1, std::atoi(e));
 		std::atomic<int> next_sub(0);
 		std::vector<std::array<double, 12>> acc((size_t)runners);
 		for (auto& x : acc) x.fill(0.0);
@@ -706,7 +712,7 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 				dmnd_ctx* w = work[(size_t)r];
 				for (int k; (k = next_sub.fetch_add(1)) < split;) {
 					const size_t b = qr.size() * (size_t)k / (size_t)split, e = qr.size() * (size_t)(k + 1) / (size_t)split;
-					rcs[(size_t)k] = extend_range(c, w, h, qr, b, e, hits, gf, qdata, tdata, cbs, !bias_in_prelude, sub_threads, hsp_values, parts[(size_t)k], nullptr, 0, nullptr);
+					rcs[(size_t)k] = extend_range(c, w, h, qr, b, e, hits, gf, qdata, tdata, cbs, sub_threads, hsp_values, parts[(size_t)k], nullptr, 0, nullptr);
 					if (rcs[(size_t)k] != DMND_OK) { errs[(size_t)k] = dmnd_last_error(); break; }
 					for (int i = 0; i < 12; ++i) acc[(size_t)r][(size_t)i] += w->ext_stats[i];
 				}

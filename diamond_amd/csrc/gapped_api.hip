@@ -78,7 +78,7 @@ extern "C" int dmnd_gapped_filter(dmnd_ctx* c, const dmnd_seed_hit* hits, int64_
 	HIP_TRY(hipEventRecord(c->ev1, st));
 	HIP_TRY(hipMemcpyAsync(flags, c->gf_flags.p, (size_t)n_hits, hipMemcpyDeviceToHost, st));
 	if (scores) HIP_TRY(hipMemcpyAsync(scores, c->gf_scores.p, (size_t)n_hits * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipStreamSynchronize(st));
+	HIP_TRY(sync_stream(st));
 	float ms = 0;
 	HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
 	c->gf_ms = ms;

@@ -6,6 +6,7 @@
 #include <condition_variable>
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -55,7 +56,7 @@ public:
 		cv_.notify_all();
 		size_t i;
 		while ((i = next_.fetch_add(1)) < n) f(i, 0);
-		for (int s = 0; s < SPINS && running_.load(std::memory_order_acquire) != 0; ++s) cpu_relax();
+		for (int s = 0, n = spins() * 8; s < n && running_.load(std::memory_order_acquire) != 0; ++s) cpu_relax();
 		if (running_.load(std::memory_order_acquire) != 0) {
 			std::unique_lock<std::mutex> g(m_);
 			done_.wait(g, [&] { return running_.load(std::memory_order_acquire) == 0; });
@@ -63,7 +64,13 @@ public:
 		fn_ = nullptr;
 	}
 private:
-	enum { SPINS = 4000 };
+	// iterations of the spin phase (a pause instruction each, ~25 ns): long enough to catch the next of a run of back-to-back
+	// loops, short enough not to eat a CPU quota with dozens of idle spinning workers (DMND_POOL_SPINS overrides)
+	static int spins()
+	{
+		static const int v = [] { const char* e = std::getenv("DMND_POOL_SPINS"); return e ? std::max(0, std::atoi(e)) : 600; }();
+		return v;
+	}
 	void grow(int workers)
 	{
 		while ((int)th_.size() < workers) {
@@ -72,7 +79,7 @@ private:
 				uint64_t seen = 0;
 				for (;;) {
 					bool got = false;
-					for (int s = 0; s < SPINS; ++s) {
+					for (int s = 0, n = spins(); s < n; ++s) {
 						if (stop_a_.load(std::memory_order_relaxed)) return;
 						if (gen_a_.load(std::memory_order_acquire) != seen && id <= want_a_.load(std::memory_order_relaxed)) { got = true; break; }
 						cpu_relax();
@@ -110,7 +117,7 @@ private:
 	std::atomic<bool> stop_a_{ false };
 };
 
-enum { MAX_POOLS = 8 };
+enum { MAX_POOLS = 16 };
 // pool(): the worker pool of the calling thread. Threads that drive one of the concurrent sub-batches of dmnd_extend select
 // their own pool with set_thread_pool(k) (k < MAX_POOLS); every other thread shares the default pool. Defined in extend_host.hip.
 WorkerPool& pool();

@@ -94,7 +94,7 @@ extern "C" int dmnd_mask_block(dmnd_ctx* c, int which, int8_t* host_data, int64_
 	unsigned long long nm = 0;
 	HIP_TRY(hipMemcpyAsync(&nm, c->counters.p, sizeof(nm), hipMemcpyDeviceToHost, st));
 	if (host_data) HIP_TRY(hipMemcpyAsync(host_data, c->block[which].p, (size_t)raw, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipStreamSynchronize(st));
+	HIP_TRY(sync_stream(st));
 	float ms = 0;
 	HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
 	c->mask_ms = ms;

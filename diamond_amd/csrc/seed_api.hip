@@ -162,7 +162,7 @@ namespace {
 struct Timer {
 	hipEvent_t a, b;
 	hipStream_t st;
-	Timer(hipStream_t s) : st(s) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); }
+	Timer(hipStream_t s) : st(s) { (void)hipEventCreate(&a); (void)hipEventCreateWithFlags(&b, spin_sync() ? hipEventDefault : hipEventBlockingSync); }
 	~Timer() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
 	void start() { (void)hipEventRecord(a, st); }
 	double stop() { (void)hipEventRecord(b, st); (void)hipEventSynchronize(b); float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms; }
@@ -329,7 +329,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 					HIP_TRY(hipMemsetAsync(a.survivor_count, 0, sizeof(unsigned long long), st));
 					HIP_TRY(launch_seed_pairs_tiled(a, sid, (int64_t)counts[sid], st));
 					HIP_TRY(hipMemcpyAsync(&ns, a.survivor_count, sizeof(ns), hipMemcpyDeviceToHost, st));
-					HIP_TRY(hipStreamSynchronize(st));
+					HIP_TRY(sync_stream(st));
 					if ((int64_t)ns <= surv_cap) break;
 					if (pass >= 2) return fail(DMND_E_NOMEM, "dmnd_seed_search: survivor buffer overflow");
 					surv_cap = (int64_t)ns + 1024;
@@ -353,7 +353,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 			HIP_TRY(launch_seed_collect(a, (int64_t)counts[sid], st));
 			unsigned long long ne = 0;
 			HIP_TRY(hipMemcpyAsync(&ne, a.e_count, sizeof(ne), hipMemcpyDeviceToHost, st));
-			HIP_TRY(hipStreamSynchronize(st));
+			HIP_TRY(sync_stream(st));
 			HIP_TRY(sort_keys_u64(c->seed_eslot.as<uint64_t>(), c->seed_eloc.as<uint64_t>(), (int64_t)ne, &c->sort_tmp, &c->sort_tmp_bytes, st));
 			a.e_key = c->seed_eloc.as<uint64_t>();
 			a.e_n = (int64_t)ne;
@@ -381,7 +381,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		uint64_t* keys[2] = { c->sort_keys[0].as<uint64_t>(), c->sort_keys[1].as<uint64_t>() };
 		uint32_t* idx[2] = { c->sort_idx[0].as<uint32_t>(), c->sort_idx[1].as<uint32_t>() };
 		HIP_TRY(sort_seed_hits(c->seed_hits.as<dmnd_seed_hit>(), c->seed_hits_sorted.as<dmnd_seed_hit>(), n, keys, idx, &c->sort_tmp, &c->sort_tmp_bytes, st));
-		HIP_TRY(hipStreamSynchronize(st));
+		HIP_TRY(sync_stream(st));
 	}
 	c->seed_ms[4] = c->seed_ms[0] + c->seed_ms[1] + c->seed_ms[2] + c->seed_ms[3];
 	if (getenv("DMND_TRACE")) {

@@ -8,8 +8,11 @@
 //   * H/E/F live in VGPRs; the only cross-lane traffic is ONE DPP wave shift per step
 //     (v_mov_b32_dpp wave_shr:1 / wave_shl:1 -- no LDS, no ds_bpermute);
 //   * the 32x32 int8 substitution matrix is staged in LDS once per workgroup;
-//   * letters are read from the HBM-resident blocks through L1/L2 (adjacent lanes read adjacent
-//     bytes: lane l+1 reads query i+P, target j-P);
+//   * letters: a lane's cells of one (even, odd) step pair need P + 1 consecutive query letters and P consecutive target
+//     letters, and the next pair the same windows moved by one, so the windows live in VGPRs and every pair fetches ONE
+//     query letter, ONE bias byte and ONE target letter per lane (scalar base + lane offset, adjacent lanes adjacent bytes),
+//     issued a whole pair before their first use; cells are branch-free (invalid cells are zeroed by v_cndmask), the end
+//     cell is kept as one (best score, first anti-diagonal) record per diagonal and turned into coordinates after the sweep;
 //   * TRACEBACK mode streams one trace byte per cell, one coalesced 64*P-byte row per step, to an
 //     HBM arena; a second kernel walks it with one wavefront per item (64 columns per round trip).
 #include <hip/hip_runtime.h>

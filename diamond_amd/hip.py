@@ -359,7 +359,7 @@ class Context:
         """Search::search_shape for all shapes/chunks on the uploaded blocks. Returns hits sorted by (query, subject, seed_offset)."""
         n = ctypes.c_int64(0)
         self._check(self.lib.dmnd_seed_search(self.h, ctypes.byref(seed_params), ctypes.byref(n)))
-        hits = np.zeros(n.value, dtype=SEED_HIT_DTYPE)
+        hits = np.empty(n.value, dtype=SEED_HIT_DTYPE)
         self._check(self.lib.dmnd_seed_hits(self.h, hits.ctypes.data if n.value else None, n.value))
         return hits
 
@@ -414,7 +414,7 @@ class Context:
         td = np.ascontiguousarray(tdata, dtype=np.int8)
         hits = np.ascontiguousarray(hits, dtype=SEED_HIT_DTYPE)
         cap = max(1024, hits.size)
-        out = np.zeros(cap, dtype=MATCH_DTYPE)
+        out = np.empty(cap, dtype=MATCH_DTYPE)
         n, used = ctypes.c_int64(0), ctypes.c_int64(0)
         tr = np.zeros(max(1 << 20, 64 * hits.size) if with_transcripts else 0, np.uint8)
         v = ctypes.c_void_p
@@ -423,7 +423,7 @@ class Context:
                                          out.ctypes.data_as(v), ctypes.c_int64(cap), ctypes.byref(n),
                                          tr.ctypes.data_as(v) if with_transcripts else None, ctypes.c_int64(tr.size),
                                          ctypes.byref(used)))
-        return out[:n.value].copy(), (tr[:used.value] if with_transcripts else None)
+        return out[:n.value], (tr[:used.value] if with_transcripts else None)
 
     def extend_stats(self):
         st = (ctypes.c_double * 12)()

@@ -171,3 +171,15 @@ def tantan_mask(p, lr, seq):
     m = np.ascontiguousarray(lr, np.float32)
     n = lib().emu_tantan_mask(ctypes.byref(p), m.ctypes.data_as(ctypes.c_void_p), s.ctypes.data_as(ctypes.c_void_p), len(s))
     return s, n
+
+
+def hauser_bias(seq, matrix8, bg, window=40):
+    """Closed-form Hauser bias of one sequence (bias_core.h: the per-position code of hauser_bias_kernel)."""
+    s = np.ascontiguousarray(seq, dtype=np.int8)
+    m = np.ascontiguousarray(matrix8, dtype=np.int8)
+    b = np.ascontiguousarray(bg, dtype=np.float32)
+    out = np.zeros(len(s), np.int8)
+    lib().emu_hauser_bias.restype = None
+    lib().emu_hauser_bias(s.ctypes.data_as(ctypes.c_void_p), len(s), m.ctypes.data_as(ctypes.c_void_p), b.ctypes.data_as(ctypes.c_void_p),
+                          int(window), out.ctypes.data_as(ctypes.c_void_p))
+    return out
