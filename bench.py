@@ -176,6 +176,12 @@ def main():
         wall = [0.0, 0.0, 0.0]
         each = state.setdefault("each_ms", [])
         del each[:]
+        gathered = None                                   # the record gather of batch s-1 runs on its own thread during batch s
+
+        def gather_stage(matches):
+            torch.cuda.set_device(local_rank)
+            return gather_topk(args.queries, matches, coll_device)
+
         for s in range(n_steps):
             t_a = time.perf_counter()
             hits, seed_ms = fut.result()
@@ -185,18 +191,22 @@ def main():
             t_b = time.perf_counter()
             matches, _ = ctx.extend(qd, td, hits, threads=threads)
             t_c = time.perf_counter()
-            aligned = gather_topk(args.queries, matches, coll_device)
+            if gathered is not None:
+                state["aligned"] = gathered.result()
+            gathered = gather_pool.submit(gather_stage, matches)
             t_d = time.perf_counter()
             for i, x in enumerate((t_b - t_a, t_c - t_b, t_d - t_c)):
                 wall[i] += x * 1e3 / n_steps
             each.append(round((t_d - t_a) * 1e3, 2))
-            state.update(hits=int(hits.size), matches=int(matches.size), aligned=aligned, seed_ms=seed_ms, ext=ctx.extend_stats(),
-                         pipe_wall_ms={"wait_for_seed_stage": wall[0], "extension_call": wall[1], "topk_gather": wall[2]})
+            state.update(hits=int(hits.size), matches=int(matches.size), seed_ms=seed_ms, ext=ctx.extend_stats(),
+                         pipe_wall_ms={"wait_for_seed_stage": wall[0], "extension_call": wall[1], "wait_for_previous_gather": wall[2]})
+        state["aligned"] = gathered.result()              # the last batch's records are gathered inside the timed region too
         return stream
 
     if pipeline:
         import concurrent.futures
         seed_pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
+        gather_pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
     for _ in range(args.warmup):
         step()
     if pipeline and args.warmup:
@@ -300,7 +310,7 @@ def main():
             "seed_stage_gletters_per_s": (int(ql[-1] - ql[0]) + int(tl[-1] - tl[0])) * seed_params.n_shapes / max(state["seed_ms"][4], 1e-9) / 1e6,
             "wall_ms_last_step": state["wall_ms"],
             "host_cpu_ms_last_step": state.get("cpu_ms"),
-            "pipeline": ("seed stage of batch s+1 (second context, own stream) overlaps the extension stage of batch s; latency of one batch alone "
+            "pipeline": ("seed stage of batch s+1 (second context, own stream) and the record gather of batch s-1 overlap the extension stage of batch s; latency of one batch alone "
                          "%.2f ms, its stream kernel alone %.3f ms" % (state["serial_ms"], state["serial_stream_ms"])) if pipeline else "off",
             "pipeline_wall_ms_per_step": state.get("pipe_wall_ms"),
             "pipeline_extension_last_step": state.get("pipe_ext"),

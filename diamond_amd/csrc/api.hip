@@ -113,6 +113,7 @@ extern "C" void dmnd_destroy(dmnd_ctx* c)
 	if (!c) return;
 	if (c->sort_tmp) { (void)hipFree(c->sort_tmp); c->sort_tmp = nullptr; c->sort_tmp_bytes = 0; }
 	if (c->pinned_cbs) (void)hipHostFree(c->pinned_cbs);
+	for (DevBuf& kb : c->keep_trace) kb.release();
 	for (dmnd_ctx* a : c->aux) dmnd_destroy(a);
 	c->aux.clear();
 	(void)hipSetDevice(c->device);
@@ -509,6 +510,158 @@ int dmnd_swipe_shared(dmnd_ctx* work, const dmnd_ctx* c, const dmnd_dp_target* i
 		work->params = c->params; work->evaluer = c->evaluer;
 	}
 	return swipe_impl(work, b, items, n, mode, hsp_values, out, transcript, transcript_cap, transcript_used);
+}
+
+int dmnd_swipe_keep(dmnd_ctx* work, const dmnd_ctx* c, const dmnd_dp_target* items, int64_t n, int arena, dmnd_hsp* out, KeptTrace& kt)
+{
+	kt = KeptTrace();
+	kt.arena = arena;
+	if (!c || !work) return fail(DMND_E_ARG, "ctx is NULL");
+	if (n == 0) return DMND_OK;
+	// trace bytes of the whole call; past the budget (or with an unusable item) the plain score-only call does the job and reports errors
+	int64_t total = 0;
+	bool usable = arena >= 0 && arena < 16 && n <= 0x7fffffff;
+	std::vector<Slot> slots((size_t)n);
+	for (int64_t i = 0; i < n && usable; ++i) {
+		const dmnd_dp_target& it = items[i];
+		const int band = it.d_end - it.d_begin;
+		if (band <= 0 || it.query_len <= 0 || it.target_len <= 0 || band_class(band) > 32) { usable = false; break; }
+		const Geom g = make_geom(it.query_len, it.target_len, it.d_begin, it.d_end);
+		slots[(size_t)i] = Slot{ (int32_t)i, band_class(band), n_steps(g) };
+		total += trace_rows(g) * 64 * slots[(size_t)i].P;
+	}
+	if (!usable || (size_t)total > work->trace_arena_max)
+		return dmnd_swipe_shared(work, c, items, n, DMND_SWIPE_SCORE, 0, out, nullptr, 0, nullptr);
+	const Bases b{ c->block[DMND_QUERY].as<int8_t>(), c->block_len[DMND_QUERY], c->block[DMND_TARGET].as<int8_t>(), c->block_len[DMND_TARGET],
+		c->cbs_len > 0 ? c->cbs.as<int8_t>() : nullptr, c->cbs_len };
+	for (int64_t i = 0; i < n; ++i) {
+		const dmnd_dp_target& it = items[i];
+		if (it.query_off < 0 || it.target_off < 0 || it.query_off + it.query_len > b.q_len || it.target_off + it.target_len > b.t_len
+			|| (it.cbs_off >= 0 && (!b.cbs || it.cbs_off + it.query_len > b.cbs_len)))
+			return fail(DMND_E_ARG, "dmnd_swipe_keep: item " + std::to_string(i) + " out of range");
+	}
+	if (work != c) {
+		work->matrix.p = c->matrix.p; work->matrix.cap = c->matrix.cap; work->matrix.own = false;
+		work->params = c->params; work->evaluer = c->evaluer;
+	}
+	HIP_TRY(hipSetDevice(work->device));
+	auto wall = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	const double t0 = wall();
+	// classes ascending, longest first inside a class (as swipe_impl orders them)
+	std::sort(slots.begin(), slots.end(), [](const Slot& x, const Slot& y) { return x.P < y.P || (x.P == y.P && x.steps > y.steps); });
+	std::vector<int32_t> order((size_t)n);
+	std::vector<int64_t> trace_off((size_t)n + 1, 0);
+	kt.trace_off.assign((size_t)n, 0); kt.P.assign((size_t)n, 0);
+	for (int64_t s = 0; s < n; ++s) {
+		const dmnd_dp_target& it = items[slots[(size_t)s].item];
+		const Geom g = make_geom(it.query_len, it.target_len, it.d_begin, it.d_end);
+		order[(size_t)s] = slots[(size_t)s].item;
+		trace_off[(size_t)s + 1] = trace_off[(size_t)s] + trace_rows(g) * 64 * slots[(size_t)s].P;
+		kt.trace_off[(size_t)slots[(size_t)s].item] = trace_off[(size_t)s];
+		kt.P[(size_t)slots[(size_t)s].item] = slots[(size_t)s].P;
+	}
+	if ((int)work->keep_trace.size() <= arena) work->keep_trace.resize((size_t)arena + 1);
+	DevBuf& tr = work->keep_trace[(size_t)arena];
+	if (int rc = tr.ensure((size_t)total + 64)) return rc;
+	if (int rc = work->items.ensure(n * sizeof(dmnd_dp_target))) return rc;
+	if (int rc = work->ends.ensure(n * sizeof(SwipeEnd))) return rc;
+	if (int rc = work->order.ensure(n * sizeof(int32_t))) return rc;
+	if (int rc = work->trace_off.ensure((n + 1) * sizeof(int64_t))) return rc;
+	HIP_TRY(hipMemcpyAsync(work->items.p, items, n * sizeof(dmnd_dp_target), hipMemcpyHostToDevice, work->stream));
+	HIP_TRY(hipMemcpyAsync(work->order.p, order.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, work->stream));
+	HIP_TRY(hipMemcpyAsync(work->trace_off.p, trace_off.data(), (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, work->stream));
+	work->host_ms[0] += wall() - t0;
+	const double t1 = wall();
+	HIP_TRY(hipEventRecord(work->ev0, work->stream));
+	for (int64_t s0 = 0; s0 < n;) {
+		int64_t s1 = s0;
+		while (s1 < n && slots[(size_t)s1].P == slots[(size_t)s0].P) ++s1;
+		SwipeArgs a;
+		a.qblock = b.q; a.tblock = b.t; a.cbs = b.cbs; a.matrix = work->matrix.as<int8_t>();
+		a.items = work->items.as<dmnd_dp_target>();
+		a.order = work->order.as<int32_t>() + s0;
+		a.trace_off = work->trace_off.as<int64_t>() + s0;
+		a.trace = tr.as<uint8_t>();
+		a.ends = work->ends.as<SwipeEnd>();
+		a.n = s1 - s0;
+		a.gap_open = work->params.gap_open; a.gap_extend = work->params.gap_extend;
+		HIP_TRY(launch_banded_swipe(slots[(size_t)s0].P, K_TRACE, a, work->stream));
+		s0 = s1;
+	}
+	HIP_TRY(hipEventRecord(work->ev1, work->stream));
+	std::vector<SwipeEnd> ends((size_t)n);
+	HIP_TRY(copy_now(work->stream, ends.data(), work->ends.p, n * sizeof(SwipeEnd), hipMemcpyDeviceToHost));
+	float ms = 0.f;
+	HIP_TRY(hipEventElapsedTime(&ms, work->ev0, work->ev1));
+	work->swipe_ms = ms; work->traceback_ms = 0.0;
+	work->host_ms[1] += wall() - t1;
+	kt.score.resize((size_t)n); kt.end_i.resize((size_t)n); kt.end_j.resize((size_t)n);
+	for (int64_t i = 0; i < n; ++i) {
+		dmnd_hsp h;
+		std::memset(&h, 0, sizeof(h));
+		h.score = ends[(size_t)i].score;
+		if (h.score > 0) { h.q_end = ends[(size_t)i].end_i + 1; h.s_end = ends[(size_t)i].end_j + 1; }
+		h.transcript_off = -1;
+		out[i] = h;
+		kt.score[(size_t)i] = ends[(size_t)i].score; kt.end_i[(size_t)i] = ends[(size_t)i].end_i; kt.end_j[(size_t)i] = ends[(size_t)i].end_j;
+	}
+	kt.kept = true;
+	return DMND_OK;
+}
+
+int dmnd_traceback_kept(dmnd_ctx* work, const dmnd_ctx* c, const dmnd_dp_target* items, const KeptTrace& kt, const int64_t* src, int64_t n, dmnd_hsp* out)
+{
+	if (!c || !work || !kt.kept || kt.arena < 0 || kt.arena >= (int)work->keep_trace.size()) return fail(DMND_E_ARG, "dmnd_traceback_kept: no kept trace");
+	if (n == 0) return DMND_OK;
+	const Bases b{ c->block[DMND_QUERY].as<int8_t>(), c->block_len[DMND_QUERY], c->block[DMND_TARGET].as<int8_t>(), c->block_len[DMND_TARGET],
+		c->cbs_len > 0 ? c->cbs.as<int8_t>() : nullptr, c->cbs_len };
+	HIP_TRY(hipSetDevice(work->device));
+	std::vector<int32_t> order((size_t)n), p_of((size_t)n);
+	std::vector<int64_t> trace_off((size_t)n), tr_zero((size_t)n + 1, 0);
+	std::vector<SwipeEnd> ends((size_t)n);
+	for (int64_t k = 0; k < n; ++k) {
+		const int64_t x = src[k];
+		if (x < 0 || x >= (int64_t)kt.P.size()) return fail(DMND_E_ARG, "dmnd_traceback_kept: item index out of range");
+		order[(size_t)k] = (int32_t)k; p_of[(size_t)k] = kt.P[(size_t)x]; trace_off[(size_t)k] = kt.trace_off[(size_t)x];
+		SwipeEnd e;
+		std::memset(&e, 0, sizeof(e));
+		e.score = kt.score[(size_t)x]; e.end_i = kt.end_i[(size_t)x]; e.end_j = kt.end_j[(size_t)x];
+		ends[(size_t)k] = e;
+	}
+	if (int rc = work->items.ensure(n * sizeof(dmnd_dp_target))) return rc;
+	if (int rc = work->ends.ensure(n * sizeof(SwipeEnd))) return rc;
+	if (int rc = work->hsps.ensure(n * sizeof(dmnd_hsp))) return rc;
+	if (int rc = work->order.ensure(n * sizeof(int32_t))) return rc;
+	if (int rc = work->p_of_slot.ensure(n * sizeof(int32_t))) return rc;
+	if (int rc = work->trace_off.ensure((n + 1) * sizeof(int64_t))) return rc;
+	if (int rc = work->transcript_off.ensure((n + 1) * sizeof(int64_t))) return rc;
+	if (int rc = work->status.ensure(sizeof(int32_t))) return rc;
+	HIP_TRY(hipMemcpyAsync(work->items.p, items, n * sizeof(dmnd_dp_target), hipMemcpyHostToDevice, work->stream));
+	HIP_TRY(hipMemcpyAsync(work->ends.p, ends.data(), n * sizeof(SwipeEnd), hipMemcpyHostToDevice, work->stream));
+	HIP_TRY(hipMemcpyAsync(work->order.p, order.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, work->stream));
+	HIP_TRY(hipMemcpyAsync(work->p_of_slot.p, p_of.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, work->stream));
+	HIP_TRY(hipMemcpyAsync(work->trace_off.p, trace_off.data(), n * sizeof(int64_t), hipMemcpyHostToDevice, work->stream));
+	HIP_TRY(hipMemcpyAsync(work->transcript_off.p, tr_zero.data(), (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, work->stream));
+	HIP_TRY(hipMemsetAsync(work->status.p, 0, sizeof(int32_t), work->stream));
+	HIP_TRY(hipEventRecord(work->ev1, work->stream));
+	TracebackArgs t;
+	t.qblock = b.q; t.tblock = b.t; t.cbs = b.cbs; t.matrix = work->matrix.as<int8_t>();
+	t.items = work->items.as<dmnd_dp_target>(); t.order = work->order.as<int32_t>(); t.p_of_slot = work->p_of_slot.as<int32_t>();
+	t.trace_off = work->trace_off.as<int64_t>(); t.transcript_off = work->transcript_off.as<int64_t>();
+	t.trace = work->keep_trace[(size_t)kt.arena].as<uint8_t>(); t.transcript = nullptr;
+	t.ends = work->ends.as<SwipeEnd>(); t.hsps = work->hsps.as<dmnd_hsp>(); t.status = work->status.as<int32_t>();
+	t.n = n; t.gap_open = work->params.gap_open; t.gap_extend = work->params.gap_extend;
+	HIP_TRY(launch_traceback(t, work->stream));
+	HIP_TRY(hipEventRecord(work->ev2, work->stream));
+	HIP_TRY(copy_now(work->stream, out, work->hsps.p, n * sizeof(dmnd_hsp), hipMemcpyDeviceToHost));
+	float ms = 0.f;
+	HIP_TRY(hipEventElapsedTime(&ms, work->ev1, work->ev2));
+	work->swipe_ms = 0.0; work->traceback_ms = ms;
+	int32_t st = 0;
+	HIP_TRY(copy_now(work->stream, &st, work->status.p, sizeof(st), hipMemcpyDeviceToHost));
+	if (st != 0) return fail(st, st == DMND_E_TRACEBACK ? "Traceback error." : "transcript slot too small");
+	for (int64_t k = 0; k < n; ++k) out[k].transcript_off = -1;
+	return DMND_OK;
 }
 
 static int aux_priority()

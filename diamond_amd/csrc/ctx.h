@@ -99,6 +99,7 @@ struct dmnd_ctx {
 	double mask_ms = 0.0;
 	double seed_ms[5] = { 0, 0, 0, 0, 0 };
 	// extension-stage statistics of the last dmnd_extend (extend_host.hip)
+	std::vector<dmnd::DevBuf> keep_trace;      // trace arenas of dmnd_swipe_keep (one per ranking-chunk iteration of a pass)
 	std::vector<dmnd_ctx*> aux;                // auxiliary contexts (own stream + work buffers) for concurrent sub-batches of dmnd_extend
 	int8_t* pinned_cbs = nullptr; size_t pinned_cbs_cap = 0;      // Hauser bias of the query block, pinned host copy (parallel to the block letters)
 	double ext_stats[12] = { 0 };
@@ -111,6 +112,21 @@ struct dmnd_ctx {
 
 // internal (not part of the C ABI)
 // banded swipe on the work buffers / stream of `work` over the blocks, bias and scoring matrix resident in `blocks`
+// Round-1 sweep that keeps its trace (api.hip): the extension stage's second round re-runs the same DpTargets with traceback
+// (gapped_final.cpp), so the first sweep already writes the trace rows and the end cells of every target whose matrix fits the
+// traceback path, and round 2 only walks the kept traces of the targets that survive culling (dmnd_traceback_kept).
+// A KeptTrace describes one such sweep: per item the offset of its trace in arena `arena` of the work context, its band class
+// and its end cell. kept = false: the arena would exceed the context's trace budget, the call ran score-only instead.
+struct KeptTrace {
+	int arena = -1;
+	bool kept = false;
+	std::vector<int64_t> trace_off;
+	std::vector<int32_t> P;
+	std::vector<int32_t> score, end_i, end_j;
+};
+int dmnd_swipe_keep(dmnd_ctx* work, const dmnd_ctx* blocks, const dmnd_dp_target* items, int64_t n, int arena, dmnd_hsp* out, KeptTrace& kt);
+// items[k] with its KeptTrace entry src[k] (index into kt's vectors): statistics and coordinates from the kept trace, no transcripts
+int dmnd_traceback_kept(dmnd_ctx* work, const dmnd_ctx* blocks, const dmnd_dp_target* items, const KeptTrace& kt, const int64_t* src, int64_t n, dmnd_hsp* out);
 int dmnd_swipe_shared(dmnd_ctx* work, const dmnd_ctx* blocks, const dmnd_dp_target* items, int64_t n, int mode, uint32_t hsp_values,
 	dmnd_hsp* out, uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used);
 // k-th of `split` auxiliary contexts of c (created on first use; owned and destroyed by c)

@@ -332,6 +332,8 @@ struct Cand {              // one target of one query after round 1 (Extension::
 	uint32_t target;
 	int score, d_begin, d_end, ungapped, frame;
 	double evalue;
+	int arena = -1;            // >= 0: the round-1 sweep kept this DpTarget's trace (KeptTrace kts[arena], entry `item`)
+	int64_t item = -1;
 };
 
 bool cand_less(const Cand& a, const Cand& b)                 // Target::comp_evalue, target.h:123-129
@@ -421,8 +423,15 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 	int64_t used = 0;
 	std::vector<dmnd_dp_target> items;
 	std::vector<dmnd_hsp> res;
+	// Round 2 re-runs the DpTargets that survive culling with traceback -- the same targets, bands and bias as round 1. So
+	// round 1 already sweeps in traceback mode and keeps the trace rows (one arena per ranking-chunk iteration of a pass), and
+	// round 2 only walks the kept traces. Not used when the caller wants transcripts, when a chunk holds a matrix too large for
+	// the traceback path (those go through the statistics kernels), or past the context's trace budget: then round 2 sweeps again.
+	static const bool keep_traces = [] { const char* e = std::getenv("DMND_EXTEND_KEEP_TRACE"); return !e || e[0] != '0'; }();
+	std::vector<KeptTrace> kts(8);
 	for (;;) {
-		// ---- inner loop: ranking chunks, round 1 (score only) ----
+		int arena_iter = 0;
+		// ---- inner loop: ranking chunks, round 1 (score only, or traceback mode with kept traces) ----
 		for (;;) {
 			std::vector<size_t> active;
 			for (size_t i = 0; i < qs.size(); ++i) if (!qs[i].done && qs[i].in_inner) active.push_back(i);
@@ -441,8 +450,19 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 			}
 			lap(5, 4);
 			res.assign(items.size(), dmnd_hsp());
+			int arena = -1;
 			if (!items.empty()) {
-				if (int rc = dmnd_swipe_shared(w, c, items.data(), (int64_t)items.size(), DMND_SWIPE_SCORE, 0, res.data(), nullptr, 0, nullptr)) return rc;
+				bool keep = keep_traces && !transcript && arena_iter < (int)kts.size();
+				for (size_t x = 0; x < items.size() && keep; ++x) {
+					const dmnd_dp_target& d = items[x];
+					keep = (int64_t)dmnd_banded_cols(d.query_len, d.target_len, d.d_begin, d.d_end) * (int64_t)(d.d_end - d.d_begin) <= h.max_swipe_dp;
+				}
+				if (keep) {
+					if (int rc = dmnd_swipe_keep(w, c, items.data(), (int64_t)items.size(), arena_iter, res.data(), kts[(size_t)arena_iter])) return rc;
+					if (kts[(size_t)arena_iter].kept) arena = arena_iter;
+					++arena_iter;
+				}
+				else if (int rc = dmnd_swipe_shared(w, c, items.data(), (int64_t)items.size(), DMND_SWIPE_SCORE, 0, res.data(), nullptr, 0, nullptr)) return rc;
 				sw1 += w->swipe_ms;
 				w->ext_stats[0] += (double)items.size(); w->ext_stats[2] += cells_of(items);
 			}
@@ -464,10 +484,10 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 						// (Hsp::operator<, match.h:199)
 						Cand& k = v.back();
 						if (score > k.score || (score == k.score && frame == k.frame && p.d_begin < k.d_begin)) {
-							k.score = score; k.evalue = ev; k.d_begin = p.d_begin; k.d_end = p.d_end; k.frame = frame;
+							k.score = score; k.evalue = ev; k.d_begin = p.d_begin; k.d_end = p.d_end; k.frame = frame; k.arena = arena; k.item = (int64_t)x;
 						}
 					}
-					else v.push_back(Cand{ p.target, score, p.d_begin, p.d_end, p.ungapped_score, frame, ev });
+					else v.push_back(Cand{ p.target, score, p.d_begin, p.d_end, p.ungapped_score, frame, ev, arena, (int64_t)x });
 				}
 				const bool multi_chunk = (s.w.i1 - s.w.i0) < s.w.order.size();
 				bool new_hits = s.new_hits_ev = !v.empty();
@@ -494,6 +514,8 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 		std::vector<dmnd_dp_target> it_tb, it_st;
 		struct Ref { size_t q, k; };
 		std::vector<Ref> ref_tb, ref_st;
+		struct KeptGroup { std::vector<dmnd_dp_target> items; std::vector<int64_t> src; std::vector<Ref> ref; };
+		std::vector<KeptGroup> kept(kts.size());
 		for (size_t i : batch) {
 			QueryState& s = qs[i];
 			cull(s.aligned, false, K);                                          // extend.cpp:331
@@ -502,12 +524,22 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 				const dmnd_dp_target d = item_of(s.w.query * C + (uint32_t)cd.frame, cd.target, cd.d_begin, cd.d_end);
 				const int64_t dp_size = (int64_t)dmnd_banded_cols(d.query_len, d.target_len, d.d_begin, d.d_end) * (int64_t)(d.d_end - d.d_begin);
 				if (dp_size > h.max_swipe_dp) { it_st.push_back(d); ref_st.push_back(Ref{ i, k }); }      // DP::BandedSwipe::bin
+				else if (cd.arena >= 0) { KeptGroup& g = kept[(size_t)cd.arena]; g.items.push_back(d); g.src.push_back(cd.item); g.ref.push_back(Ref{ i, k }); }
 				else { it_tb.push_back(d); ref_tb.push_back(Ref{ i, k }); }
 			}
 		}
 		lap(7, 7);
 		std::vector<std::vector<dmnd_hsp>> r2(qs.size());
 		for (size_t i : batch) r2[i].assign(qs[i].aligned.size(), dmnd_hsp());
+		for (size_t a = 0; a < kept.size(); ++a) {                               // walks over the traces kept by round 1
+			KeptGroup& g = kept[a];
+			if (g.items.empty()) continue;
+			res.assign(g.items.size(), dmnd_hsp());
+			if (int rc = dmnd_traceback_kept(w, c, g.items.data(), kts[a], g.src.data(), (int64_t)g.items.size(), res.data())) return rc;
+			for (size_t x = 0; x < g.ref.size(); ++x) r2[g.ref[x].q][g.ref[x].k] = res[x];
+			tb2 += w->traceback_ms;
+			w->ext_stats[1] += (double)g.items.size(); w->ext_stats[3] += cells_of(g.items);      // the reference's round-2 targets and cells
+		}
 		if (!it_tb.empty()) {
 			uint8_t* arena = transcript ? transcript + used : nullptr;           // NULL: statistics only, no transcripts copied back
 			int64_t arena_cap = transcript ? transcript_cap - used : 0;
