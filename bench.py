@@ -4,14 +4,19 @@
 
 A "step" = one full pass of the hot path over the query block and the reference block, both resident in HBM before
 the timed region: seed stage on the GPU (dmnd_seed_search: query seed table, one stream over the reference block,
-complexity masks, Hamming + left-most filters -> stage-2 hits) and extension stage (dmnd_extend: host x-drop/chaining,
-round-1 score-only banded Smith-Waterman on the GPU, e-value cutoff + top-25 culling, round-2 banded Smith-Waterman
-with traceback on the GPU, final culling -> match records). It is the work `diamond blastp --fast --algo 0
---masking 0 --motif-masking 0` does between "Building reference seed array" and the output writer; results are
-byte-identical to the reference's (tests/test_gpu_extend.py).
+complexity masks, Hamming + left-most filters -> stage-2 hits) and extension stage (dmnd_extend: Hauser bias on the GPU,
+host x-drop/chaining, round-1 banded Smith-Waterman on the GPU in traceback mode with kept trace rows, e-value cutoff +
+top-25 culling, round-2 walk of the kept traces on the GPU, final culling -> match records). It is the work `diamond
+blastp --fast --algo 0 --masking 0 --motif-masking 0` does between "Building reference seed array" and the output
+writer; results are byte-identical to the reference's (tests/test_gpu_extend.py).
 
-metric  = GCUPS: DP cells per the reference's definition (DpTarget::cells, dp/dp.h:121-124, both swipe rounds)
-          / wall seconds of the K timed steps; aligned queries/s is reported beside it.
+Batches are pipelined (default; --no-pipeline runs them back to back): the seed stage of batch s+1 runs on a second
+context (own low-priority stream) and the record gather of batch s-1 on a third thread while batch s is extended --
+every batch still passes through the whole path inside the timed region.
+
+metric  = GCUPS: DP cells per the reference's definition (DpTarget::cells, dp/dp.h:121-124, both swipe rounds of the
+          reference on this workload -- the same count cpu_baseline uses) / wall seconds of the K timed steps; the cells
+          the device actually sweeps (round-2 targets once, not twice) and aligned queries/s are reported beside it.
 N > 1   : query sharding (SURVEY.md 8e option 1, bit-identical to one GPU): every rank holds a database block in HBM
           and processes its own 10k-query slice; no collective on the data path, one RCCL all_gather of the fixed-size
           per-query top-k records at the end of each step -> weak scaling.
@@ -169,10 +174,15 @@ def main():
         hits = ctx_seed.seed_search(seed_params)
         return hits, ctx_seed.seed_kernel_ms()
 
-    def run_pipelined(n_steps):
-        """n_steps batches; the seed stage of batch s+1 runs on a worker thread (ctypes releases the GIL) during the extension of batch s"""
+    def run_pipelined(n_steps, primed=None):
+        """n_steps batches in steady state: every step takes the seed hits of its batch (primed: computed by the previous step, or by
+        the warm-up for the first timed step), starts the seed stage of the NEXT batch on a worker thread (ctypes releases the GIL),
+        extends its own batch and hands the records of the batch to the gather thread. So a run of n steps executes n seed stages,
+        n extensions and n gathers; the seed stage started by the last step is awaited before the clock stops.
+        Returns (stream kernel ms summed over the seed stages started here, the outstanding seed stage)."""
         stream = 0.0
-        fut = seed_pool.submit(seed_stage)
+        fut = primed if primed is not None else seed_pool.submit(seed_stage)
+        started = 0 if primed is not None else 1
         wall = [0.0, 0.0, 0.0]
         each = state.setdefault("each_ms", [])
         del each[:]
@@ -185,9 +195,13 @@ def main():
         for s in range(n_steps):
             t_a = time.perf_counter()
             hits, seed_ms = fut.result()
-            stream += seed_ms[1]
-            if s + 1 < n_steps:
+            if not (s == 0 and primed is not None):
+                stream += seed_ms[1]                      # a seed stage that ran inside this call
+            if started < n_steps:
                 fut = seed_pool.submit(seed_stage)
+                started += 1
+            else:
+                fut = None
             t_b = time.perf_counter()
             matches, _ = ctx.extend(qd, td, hits, threads=threads)
             t_c = time.perf_counter()
@@ -198,10 +212,14 @@ def main():
             for i, x in enumerate((t_b - t_a, t_c - t_b, t_d - t_c)):
                 wall[i] += x * 1e3 / n_steps
             each.append(round((t_d - t_a) * 1e3, 2))
+            if s == 0:
+                state["first_step_ms"] = {"wait_for_seed_stage": (t_b - t_a) * 1e3, "extension_call": (t_c - t_b) * 1e3, "wait_for_previous_gather": (t_d - t_c) * 1e3}
             state.update(hits=int(hits.size), matches=int(matches.size), seed_ms=seed_ms, ext=ctx.extend_stats(),
                          pipe_wall_ms={"wait_for_seed_stage": wall[0], "extension_call": wall[1], "wait_for_previous_gather": wall[2]})
         state["aligned"] = gathered.result()              # the last batch's records are gathered inside the timed region too
-        return stream
+        if fut is not None:
+            stream += fut.result()[1][1]                  # ... and so is the seed stage the last step started
+        return stream, fut
 
     if pipeline:
         import concurrent.futures
@@ -209,14 +227,22 @@ def main():
         gather_pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
     for _ in range(args.warmup):
         step()
+    primed = None
     if pipeline and args.warmup:
         run_pipelined(2)
+        primed = seed_pool.submit(seed_stage)                # fills the pipeline: the first timed step finds its seed hits ready,
+        primed.result()                                      # computed before the clock starts (the last timed step computes a batch ahead)
     sync()
+    # hipDeviceSynchronize lets the runtime release the hardware queues of idle streams; re-acquiring those of the extension
+    # runners would cost the first timed step ~6.5 ms (measured; a streaming caller never synchronizes the whole device)
+    ctx.touch_streams()
+    if pipeline:
+        ctx_seed.touch_streams()
     t0 = time.perf_counter()
     cpu0 = time.process_time()
     stream_ms = 0.0
     if pipeline:
-        stream_ms = run_pipelined(args.steps)
+        stream_ms, _ = run_pipelined(args.steps, primed)
     else:
         for _ in range(args.steps):
             step()
@@ -239,7 +265,11 @@ def main():
         dt = float(t.item())
 
     ext = state["ext"]
+    # GCUPS numerator = the DP cells of the reference's two swipe rounds on this workload (DpTarget::cells of every round-1 and
+    # round-2 target: what the reference computes and what cpu_baseline counts). The device sweeps the round-2 targets only once:
+    # round 1 keeps its trace rows and round 2 walks them (round2_swipe_kernel_ms == 0), reported as cells_swept_per_step.
     cells_step = ext["round1_cells"] + ext["round2_cells"]
+    cells_swept = ext["round1_cells"] + (ext["round2_cells"] if ext["round2_swipe_kernel_ms"] > 0 else 0.0)
     gcups = cells_step * world * args.steps / dt / 1e9      # every rank runs a slice of the same shape (weak scaling)
 
     if rank == 0:
@@ -284,6 +314,9 @@ def main():
                                    % (args.queries, args.families * 10, int(doff[-1]), " per GPU" if world > 1 else "", state["hits"],
                                       int(ext["round1_targets"]), int(ext["round2_targets"]), state["matches"], state["aligned"] // world),
                        "queries": args.queries, "db_seqs": args.families * 10, "db_letters": int(doff[-1]), "cells_per_step": cells_step,
+                       "cells_swept_per_step": cells_swept, "gcups_on_cells_swept": cells_swept * world * args.steps / dt / 1e9,
+                       "cells_note": "value counts the DP cells of the reference's round 1 + round 2 (same definition as cpu_baseline); the device "
+                                     "sweeps round-2 targets once (round 1 keeps the trace, round 2 walks it), cells_swept_per_step is what it computes",
                        "host_threads": threads,
                        "parallelism": "query-shard x%d + RCCL all_gather of top-k records" % world if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "seed_stream_fast_kernel (reference block streamed once against the query seed table)",
@@ -304,8 +337,9 @@ def main():
                                  "reference position (PMC: ~1 TCC request per letter), not by HBM bytes; see DESIGN.md 5"},
             "seed_kernel_ms": dict(zip(["index_queries", "stream_reference", "mask_groups", "pair_filter", "total"], state["seed_ms"])),
             "extension": ext,
+            # device time summed over the concurrent runners' launches (they overlap on the GPU: a lower bound of the kernel rate)
             "swipe_kernel_gcups": {"round1": ext["round1_cells"] / max(ext["round1_swipe_kernel_ms"], 1e-9) / 1e6,
-                                   "round2": ext["round2_cells"] / max(ext["round2_swipe_kernel_ms"], 1e-9) / 1e6},
+                                   "round2": (ext["round2_cells"] / ext["round2_swipe_kernel_ms"] / 1e6) if ext["round2_swipe_kernel_ms"] > 0 else None},
             # seed-stage Gletters/s = (L_q + L_r) x shapes / seed-stage seconds (device time of its kernels)
             "seed_stage_gletters_per_s": (int(ql[-1] - ql[0]) + int(tl[-1] - tl[0])) * seed_params.n_shapes / max(state["seed_ms"][4], 1e-9) / 1e6,
             "wall_ms_last_step": state["wall_ms"],
@@ -315,6 +349,7 @@ def main():
             "pipeline_wall_ms_per_step": state.get("pipe_wall_ms"),
             "pipeline_extension_last_step": state.get("pipe_ext"),
             "ms_each_step": state.get("each_ms"),
+            "first_step_ms": state.get("first_step_ms"),
             "host_cpu_ms_per_step": cpu_ms_per_step,
             # not part of `value`: one-time PCIe upload of both blocks, and the rate if it were paid on every step
             "block_upload_ms": upload_ms,

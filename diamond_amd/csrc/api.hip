@@ -664,6 +664,28 @@ int dmnd_traceback_kept(dmnd_ctx* work, const dmnd_ctx* c, const dmnd_dp_target*
 	return DMND_OK;
 }
 
+__global__ void touch_kernel() {}
+
+extern "C" int dmnd_touch_streams(dmnd_ctx* c)
+{
+	if (!c) return fail(DMND_E_ARG, "ctx is NULL");
+	HIP_TRY(hipSetDevice(c->device));
+	// a marker kernel plus one small pageable copy in each direction: the runtime's staging buffers for pageable copies
+	// are among the things it lets go of at a device-wide synchronize
+	std::vector<dmnd_ctx*> all(1, c);
+	all.insert(all.end(), c->aux.begin(), c->aux.end());
+	std::vector<char> host((size_t)256 << 10, 0);
+	for (dmnd_ctx* a : all) {
+		if (int rc = a->items.ensure(host.size())) return rc;
+		hipLaunchKernelGGL(touch_kernel, dim3(1), dim3(64), 0, a->stream);
+		HIP_TRY(hipMemcpyAsync(a->items.p, host.data(), host.size(), hipMemcpyHostToDevice, a->stream));
+		HIP_TRY(hipMemcpyAsync(host.data(), a->items.p, host.size(), hipMemcpyDeviceToHost, a->stream));
+	}
+	HIP_TRY(hipGetLastError());
+	for (dmnd_ctx* a : all) HIP_TRY(sync_stream(a->stream));
+	return DMND_OK;
+}
+
 static int aux_priority()
 {
 	int least = 0, greatest = 0;

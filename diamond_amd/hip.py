@@ -68,7 +68,7 @@ EXPORTS = ["dmnd_abi_version", "dmnd_last_error", "dmnd_default_params", "dmnd_c
            "dmnd_seed_hits", "dmnd_seed_kernel_ms", "dmnd_extend_plan", "dmnd_extend", "dmnd_extend_stats", "dmnd_format_tab", "dmnd_set_max_target_seqs",
            "dmnd_seed_params_sensitive", "dmnd_set_gapped_filter", "dmnd_gapped_filter", "dmnd_gapped_filter_ms",
            "dmnd_set_query_contexts", "dmnd_translate", "dmnd_format_tab_translated", "dmnd_mask_block", "dmnd_mask_kernel_ms", "dmnd_seed_params_preset", "dmnd_set_comp_based_stats",
-           "dmnd_seed_params_set_index_chunks", "dmnd_join_blocks", "dmnd_set_sensitivity"]
+           "dmnd_seed_params_set_index_chunks", "dmnd_join_blocks", "dmnd_set_sensitivity", "dmnd_touch_streams"]
 
 
 def load():
@@ -105,6 +105,7 @@ def load():
         lib.dmnd_set_gapped_filter.argtypes = [ctypes.c_void_p, ctypes.c_double]
         lib.dmnd_gapped_filter.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         lib.dmnd_gapped_filter_ms.argtypes = [ctypes.c_void_p]
+        lib.dmnd_touch_streams.argtypes = [ctypes.c_void_p]
         lib.dmnd_gapped_filter_ms.restype = ctypes.c_double
         lib.dmnd_seed_search.argtypes = [ctypes.c_void_p, ctypes.POINTER(SeedParams), ctypes.POINTER(ctypes.c_int64)]
         lib.dmnd_seed_hits.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
@@ -424,6 +425,10 @@ class Context:
                                          tr.ctypes.data_as(v) if with_transcripts else None, ctypes.c_int64(tr.size),
                                          ctypes.byref(used)))
         return out[:n.value], (tr[:used.value] if with_transcripts else None)
+
+    def touch_streams(self):
+        """Re-acquires the hardware queues of the context's streams after a device-wide synchronize (see diamond_hip.h)."""
+        self._check(self.lib.dmnd_touch_streams(self.h))
 
     def extend_stats(self):
         st = (ctypes.c_double * 12)()

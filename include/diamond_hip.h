@@ -300,6 +300,11 @@ int dmnd_set_max_target_seqs(dmnd_ctx* ctx, int k);
  * src/output/target_culling.h:70-88). In place; records stay grouped by ascending query. The outcome equals the
  * reference run with the same block boundaries, not the single-block run (ranking and culling happen per block). */
 int dmnd_join_blocks(dmnd_match* records, int64_t n, int max_target_seqs, int64_t* n_out);
+/* Touches every HIP stream the context owns (its own and those of the extension stage's runners) with an empty marker and
+ * waits for them. A driver that calls hipDeviceSynchronize between batches (bench.py must, by its timing contract) lets the
+ * runtime release idle hardware queues; re-acquiring them costs the next dmnd_extend several milliseconds (measured: +6.5 ms
+ * for eight runner streams). Not needed by callers that only use the library's own stream-scoped waits. */
+int dmnd_touch_streams(dmnd_ctx* ctx);
 /* Statistics of the last dmnd_extend: [0] round-1 DpTargets [1] round-2 DpTargets [2] round-1 cells [3] round-2 cells
  * (DpTarget::cells, src/dp/dp.h:121-124: the GCUPS denominator); host wall ms [4] Hauser+upload [5] chaining [6] round-1
  * call [7] culling [8] round-2 call; device ms [9] round-1 swipe [10] round-2 swipe [11] traceback. */
