@@ -62,3 +62,36 @@ def merge_topk(gathered, k=TOPK):
 
 def aligned_queries(gathered):
     return int((gathered[..., 0, 0] < float("inf")).sum().item())
+
+
+def gather_matches(matches, device, target_base=0):
+    """Database sharding (SURVEY.md 8e option 2, BASELINE config C5): this rank extended ALL queries against its own shard of
+    the database. Gathers the ranks' match records (variable length: one all_gather of the counts, one of the zero-padded
+    byte tensors) and returns their concatenation with `target_base` (ordinal of the shard's first sequence) added to the
+    targets -- the input of `hip.join_blocks`, which merges them exactly as the reference joins the blocks of a `-b` run."""
+    from . import hip
+    rec = np.ascontiguousarray(matches, dtype=hip.MATCH_DTYPE).copy()
+    rec["target"] += np.uint32(target_base)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return rec
+    world = dist.get_world_size()
+    n = torch.tensor([rec.size], dtype=torch.int64, device=device)
+    counts = torch.zeros(world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(counts, n)
+    counts = counts.cpu().numpy()
+    cap = int(counts.max())
+    item = hip.MATCH_DTYPE.itemsize
+    buf = np.zeros(cap * item, np.uint8)
+    buf[: rec.size * item] = rec.view(np.uint8).reshape(-1)
+    mine = torch.from_numpy(buf).to(device)
+    out = torch.empty(world * cap * item, dtype=torch.uint8, device=device)
+    dist.all_gather_into_tensor(out, mine)
+    out = out.cpu().numpy().reshape(world, cap * item)
+    parts = [out[r, : int(counts[r]) * item].view(hip.MATCH_DTYPE) for r in range(world)]
+    return np.concatenate(parts) if parts else rec
+
+
+def db_shard_join(matches, device, target_base=0, k=TOPK):
+    """gather_matches + the reference's block join: every rank returns the same joined records (grouped by query)."""
+    from . import hip
+    return hip.join_blocks(gather_matches(matches, device, target_base), k)

@@ -1,0 +1,80 @@
+"""-m gpu: database sharding (SURVEY.md 8e option 2 / BASELINE config C5) end to end with two ranks on ONE GPU (gloo for the
+record exchange, as bench.py's DMND_BENCH_SHARE_GPU hook does): every rank searches ALL queries against its own shard on
+the MI355X, the ranks gather their match records and join them as the reference joins the blocks of a `-b` run. Must equal
+the same two blocks processed one after the other in a single process (whose text tests/test_gpu_cli.py pins against the
+reference binary run with the same block boundaries)."""
+import os
+import sys
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(300)]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _blocks():
+    from diamond_amd import synth, workload
+    db, doff, q, qoff = synth.generate(400, members=10, queries=500, seed=77)
+    qd, ql = workload.sequence_set(q, qoff)
+    half = (len(doff) - 1) // 2
+    shards = []
+    for a, b in ((0, half), (half, len(doff) - 1)):
+        td, tl = workload.sequence_set(db[doff[a]:doff[b]], doff[a:b + 1] - doff[a])
+        shards.append((a, td, tl))
+    return qd, ql, shards, float(doff[-1])
+
+
+def _search(ctx, hip, qd, ql, td, tl, sp):
+    ctx.upload_block(hip.QUERY, qd, ql)
+    ctx.upload_block(hip.TARGET, td, tl)
+    hits = ctx.seed_search(sp)
+    m, _ = ctx.extend(qd, td, hits, threads=4)
+    return m
+
+
+def _rank(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    from diamond_amd import hip, multigpu
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    qd, ql, shards, letters = _blocks()
+    params = hip.default_params()
+    params.db_letters = letters                                   # e-values against the WHOLE database on every rank
+    ctx = hip.Context(device=0, params=params)
+    try:
+        base, td, tl = shards[rank]
+        m = _search(ctx, hip, qd, ql, td, tl, hip.seed_params_fast(threads=4))
+        joined = multigpu.db_shard_join(m, torch.device("cpu"), target_base=base, k=25)
+    finally:
+        ctx.close()
+    ret[rank] = joined.tobytes()
+    dist.destroy_process_group()
+
+
+def test_two_rank_database_shards_equal_sequential_blocks():
+    assert torch.cuda.is_available()
+    sys.path.insert(0, ROOT)
+    from diamond_amd import hip
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_rank, args=(world, 29541, ret), nprocs=world, join=True)
+    qd, ql, shards, letters = _blocks()
+    params = hip.default_params()
+    params.db_letters = letters
+    ctx = hip.Context(params=params)
+    try:
+        parts = []
+        for base, td, tl in shards:
+            m = _search(ctx, hip, qd, ql, td, tl, hip.seed_params_fast(threads=4)).copy()
+            m["target"] += np.uint32(base)
+            parts.append(m)
+    finally:
+        ctx.close()
+    want = hip.join_blocks(np.concatenate(parts), 25)
+    assert len(want) > 300 and len(set(want["target"].tolist())) > 300
+    assert ret[0] == ret[1] == want.tobytes()

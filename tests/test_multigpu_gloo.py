@@ -62,3 +62,35 @@ def test_two_rank_gather_and_merge():
         got = [tuple(x) for x in m0[qi] if np.isfinite(x[0])]
         assert got == want
         assert len(mine) >= len(got)
+
+
+def _shard_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from diamond_amd import multigpu
+    from test_join_blocks import _block_records
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    blocks = _block_records(np.random.default_rng(5), 40, world, 300)          # every rank draws the same set and keeps its own shard
+    mine = blocks[rank].copy()
+    mine["target"] -= np.uint32(rank * 300)                                     # shard-local target ids, as dmnd_extend returns them
+    joined = multigpu.db_shard_join(mine, torch.device("cpu"), target_base=rank * 300, k=25)
+    ret[rank] = joined.tobytes()
+    dist.destroy_process_group()
+
+
+def test_two_rank_database_shard_join_equals_block_join():
+    """Database sharding (SURVEY.md 8e option 2): two ranks, one shard each, all queries; the gathered + joined records equal
+    the sequential join of the same two blocks (dmnd_join_blocks, pinned on the reference's heap merge in test_join_blocks)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from diamond_amd import hip
+    from test_join_blocks import _block_records
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_shard_worker, args=(world, 29519, ret), nprocs=world, join=True)
+    blocks = _block_records(np.random.default_rng(5), 40, world, 300)
+    want = hip.join_blocks(np.concatenate(blocks), 25)
+    assert ret[0] == ret[1] == want.tobytes()
+    assert len(want) > 500
