@@ -122,3 +122,43 @@ def test_misuse_is_reported_not_crashed():
             c.set_query_contexts(3)
     finally:
         c.close()
+
+
+def test_extension_without_kept_traces_gives_the_same_records(monkeypatch):
+    """Round 1 normally sweeps in traceback mode and keeps its trace rows (dmnd_swipe_keep). When the rows of a call do not fit
+    the context's trace budget the call falls back to a score-only sweep and round 2 sweeps again: same records either way
+    (the budget is read from DMND_TRACE_ARENA_MB when the context is created; 64 MB is less than this batch needs)."""
+    from diamond_amd import synth, workload
+    db, doff, q, qoff = synth.generate(300, members=10, queries=1500, seed=4)
+    qd, ql = workload.sequence_set(q, qoff)
+    td, tl = workload.sequence_set(db, doff)
+    params = hip.default_params()
+    params.db_letters = float(doff[-1])
+    out = []
+    for mb in (None, "64"):
+        if mb is None:
+            monkeypatch.delenv("DMND_TRACE_ARENA_MB", raising=False)
+        else:
+            monkeypatch.setenv("DMND_TRACE_ARENA_MB", mb)
+        ctx = hip.Context(params=params)
+        try:
+            ctx.upload_block(hip.QUERY, qd, ql)
+            ctx.upload_block(hip.TARGET, td, tl)
+            hits = ctx.seed_search(hip.seed_params_fast(threads=4))
+            m, _ = ctx.extend(qd, td, hits, threads=4)
+            st = ctx.extend_stats()
+        finally:
+            ctx.close()
+        out.append((m.copy(), st))
+    (m_keep, st_keep), (m_again, st_again) = out
+    assert len(m_keep) > 500 and len(m_keep) == len(m_again), (len(m_keep), len(m_again))
+    for name in m_keep.dtype.names:
+        if name == "hsp":
+            for f in m_keep["hsp"].dtype.names:
+                bad = np.nonzero(m_keep["hsp"][f] != m_again["hsp"][f])[0]
+                assert bad.size == 0, ("hsp." + f, bad[:5], m_keep["hsp"][f][bad[:5]], m_again["hsp"][f][bad[:5]])
+        else:
+            bad = np.nonzero(m_keep[name] != m_again[name])[0]
+            assert bad.size == 0, (name, bad[:5], m_keep[name][bad[:5]], m_again[name][bad[:5]])
+    assert st_keep["round2_swipe_kernel_ms"] == 0.0 and st_again["round2_swipe_kernel_ms"] > 0.0      # the two paths really differ
+    assert st_keep["round1_targets"] * 40_000 > 64 << 20                                                 # ... because the trace rows exceed 64 MB
