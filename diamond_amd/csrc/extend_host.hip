@@ -1,23 +1,31 @@
 // extend_host.hip -- the extension stage above the GPU Smith-Waterman: what Extension::extend does per query
-// (/root/reference/src/align/extend.cpp:226-420), re-organised for the GPU as a block-wide batch:
-//   all queries:  load_hits -> x-drop ungapped -> chaining -> band construction        (host threads)
-//   ONE launch :  round-1 score-only banded swipe over every DpTarget of the block     (GPU)
-//   all queries:  e-value cutoff, per-target best HSP, top-k culling                   (host)
-//   ONE launch :  round-2 banded swipe with traceback / statistics                     (GPU)
-//   all queries:  final culling -> match records -> BLAST tabular text                 (host)
-// instead of the reference's per-query calls of DP::BandedSwipe::swipe from a thread pool.
+// (/root/reference/src/align/extend.cpp:226-420), re-organised for the GPU as block-wide batches. The queries with seed hits are
+// cut into sub-batches that a few single-threaded runners (own HIP stream and device buffers each) pull from a queue; a runner
+// takes its sub-batch through
+//   prelude     :  Hauser bias of the whole query block                              (GPU, bias_kernels.hip; once per call)
+//                  gapped filter of every seed hit, --sensitive and above             (GPU, gapped_kernels.hip; once per call)
+//   all queries :  load_hits -> x-drop ungapped -> chaining -> band construction      (host)
+//   ONE call    :  round-1 banded swipe over every DpTarget of the ranking chunk, in traceback mode with kept trace rows
+//                  (score-only when the caller wants transcripts or the rows exceed the trace budget)      (GPU)
+//   all queries :  e-value cutoff, per-target best HSP, ranking-chunk logic, top-k culling                 (host)
+//   ONE call    :  round 2 = traceback walk over the kept traces of the surviving targets (or a second sweep with traceback;
+//                  statistics kernels for matrices above max_swipe_dp)                                     (GPU)
+//   all queries :  final culling -> match records                                                          (host)
+// instead of the reference's per-query calls of DP::BandedSwipe::swipe from a thread pool. While one runner waits for the GPU
+// the others work on the host, and the GPU serialises their launches.
 // Reference pieces restated here (chaining itself is in chain_host.h):
-//   HauserCorrection                        src/stats/hauser_correction.cpp:53-109
+//   HauserCorrection                        src/stats/hauser_correction.cpp:53-109   (host copy: dmnd_extend_plan; GPU: bias_core.h)
 //   load_hits                               src/align/load_hits.h:44-127
-//   ranking_chunk_size                      src/align/extend.cpp:79-92
+//   ranking_chunk_size, ranking loop        src/align/extend.cpp:79-119, 289-336
 //   ungapped_stage                          src/align/ungapped.cpp:62-126
 //   Extension::band, add_dp_targets         src/align/gapped_score.cpp:41-180
 //   DP::BandedSwipe::bin                    src/dp/swipe/swipe_wrapper.cpp:75-102
 //   Target::add_hit / inner_culling, culling, output_range   src/align/target.h:97-113, culling.cpp:37-113,189-203
 //   round-2 add_dp_targets / align          src/align/gapped_final.cpp:66-160
-//   blast tab fields                        src/output/blast_tab_format.cpp
-// Scope: blastp, one query context, max_hsps = 1, Hauser composition bias (comp-based-stats 1), no gapped filter,
-// no id/coverage filters, single ranking chunk (a query with more targets than the ranking chunk fails loudly).
+//   join of reference blocks                src/output/join_blocks.cpp:129-256
+//   six-frame translation, blast tab fields src/util/sequence/translate.h, src/output/blast_tab_format.cpp
+// Scope: blastp and blastx (1 or 6 query contexts), max_hsps = 1, comp-based-stats 0 / 1, gapped filter, ranking chunks;
+// no id/coverage filters, no frameshift alignment.
 #include <algorithm>
 #include <array>
 #include <cfloat>

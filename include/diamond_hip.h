@@ -235,7 +235,10 @@ int dmnd_extend_plan(const dmnd_params* params, const int8_t* qdata, const int64
 	int8_t* cbs_out, dmnd_plan_target* out, int64_t cap, int64_t* n_out);
 /* Whole extension stage on the uploaded blocks (qdata/tdata: the caller's host copies of the same blocks). hits must be
  * sorted by query. Matches come out ordered by query, then as the reference orders them (e-value, score, target).
- * transcript may be NULL (then dmnd_hsp::transcript_off = -1). Blastp defaults: max_target_seqs 25, max_hsps 1. */
+ * transcript may be NULL (then dmnd_hsp::transcript_off = -1). Blastp defaults: max_target_seqs 25, max_hsps 1.
+ * threads bounds the host threads: blocks with >= 2048 queries run as up to 8 runners (own HIP stream each), worker threads
+ * under a runner only when its share of the seed hits is large. Without transcripts round 1 keeps its trace rows in HBM and
+ * round 2 only walks them (dmnd_extend_stats[10] = 0 then); the records are the same either way. */
 int dmnd_extend(dmnd_ctx* ctx, const int8_t* qdata, const int8_t* tdata, const dmnd_seed_hit* hits, int64_t n_hits,
 	int threads, uint32_t hsp_values, dmnd_match* out, int64_t cap, int64_t* n_out,
 	uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used);
