@@ -96,3 +96,26 @@ def test_emulated_stats_passes_match_oracle_and_reference():
             rc2, e = emu.swipe_stats(rec["query"], rec["cbs"], t["seq"], t["d_begin"], t["d_end"], hdr["matrix8"], 11, 1)
             for k in STAT_KEYS:
                 assert e[k] == o[k], (k, e, o)
+
+
+def test_emulated_wavefront_wide_classes_and_ties():
+    """Every band class the register-window lanes are built for (P = 1, 2, 4 with one end-cell record per diagonal; P = 8 with
+    one per lane), on score ties: repeats of one short motif give many cells with the best score, so the end cell is decided
+    by the reference's tie rule (smallest column, then largest row) across diagonals, lanes and step parities."""
+    hdr, _ = read_tap(os.path.join(GOLDEN, "swipe_fast.tap"), max_records=1)
+    M = hdr["matrix8"]
+    rng = np.random.default_rng(12)
+    for it in range(120):
+        motif = rng.integers(0, 20, int(rng.integers(2, 6))).astype(np.int8)
+        q = np.resize(motif, int(rng.integers(5, 120)))
+        t = np.resize(motif, int(rng.integers(5, 160)))
+        if it % 3 == 0:                                   # break the repeat here and there: several disjoint equal-score segments
+            q = q.copy(); t = t.copy()
+            q[rng.integers(0, len(q), 2)] = 23
+            t[rng.integers(0, len(t), 3)] = 23
+        d0 = int(rng.integers(-(len(t) - 1), len(q) - 1))
+        d1 = d0 + int(rng.integers(1, 200))
+        if d1 <= -(len(t) - 1) or d0 >= len(q):
+            continue
+        cbs = rng.integers(-2, 2, len(q)).astype(np.int8) if it % 2 else None
+        _compare(q, cbs, t, d0, d1, M, 11, 1, force_p=(1, 2, 4, 8)[it % 4])
