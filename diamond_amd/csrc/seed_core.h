@@ -355,16 +355,26 @@ DMND_HD int simd_batch_size_sorted(const SeedParams& c, const uint64_t* locs, in
 	return (int)(left < lanes ? left : lanes);
 }
 
-// Hash of a seed for the query seed table: two 32-bit mixes (murmur3-style finalisers on 32-bit lanes, cheap on
-// the VALU) packed as (bitmap hash << 32) | slot hash.
-DMND_HD uint64_t seed_hash(uint64_t x)
+// Hash of a seed for the query seed table: two independent 32-bit mixes (murmur3-style finalisers on 32-bit lanes).
+// a: table slot and level-1 bitmap bits -- evaluated for EVERY reference position by the stream kernel, so it is kept to
+// three 32-bit multiplies (v_mul_lo_u32 issues at a quarter of the VALU rate); b: level-2 bitmap, only evaluated for the
+// positions that pass level 1. seed_hash = (b << 32) | a.
+DMND_HD uint32_t seed_hash_a(uint64_t x)
 {
 	const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
 	uint32_t a = lo * 0x9E3779B1u + hi * 0x85EBCA6Bu;
-	a ^= a >> 15; a *= 0x2C1B3C6Du; a ^= a >> 12; a *= 0x297A2D39u; a ^= a >> 15;
+	a ^= a >> 15; a *= 0x2C1B3C6Du; a ^= a >> 13;
+	return a;
+}
+
+DMND_HD uint32_t seed_hash_b(uint64_t x)
+{
+	const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
 	uint32_t b = (lo ^ 0x68E31DA4u) * 0xCC9E2D51u + (hi + 0x1B873593u) * 0x27D4EB2Fu;
 	b ^= b >> 16; b *= 0x85EBCA6Bu; b ^= b >> 13;
-	return ((uint64_t)b << 32) | a;
+	return b;
 }
+
+DMND_HD uint64_t seed_hash(uint64_t x) { return ((uint64_t)seed_hash_b(x) << 32) | seed_hash_a(x); }
 
 }  // namespace dmnd

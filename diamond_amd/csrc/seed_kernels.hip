@@ -42,7 +42,7 @@ __global__ void seed_index_kernel(SeedArgs a, int sid)
 	if (!seed_key_at(a.params, sid, a.qdata + p, seed)) return;
 	const uint64_t h = seed_hash(seed);
 	atomicOr(&a.bitmap[(h >> 32) & a.bitmap_mask], 1u << (h >> 59));
-	atomicOr(&a.bitmap1[(uint32_t)(h >> 10) & a.bitmap1_mask], (1u << (h & 31)) | (1u << ((h >> 5) & 31)));   // 2 bits, one word
+	atomicOr(&a.bitmap1[((uint32_t)h >> 10) & a.bitmap1_mask], (1u << (h & 31)) | (1u << ((h >> 5) & 31)));   // 2 bits, one word; bits of hash a only
 	uint64_t slot = h & a.slot_mask;
 	for (;;) {
 		const unsigned long long old = atomicCAS((unsigned long long*)&a.slots[slot].key, (unsigned long long)SEED_EMPTY, (unsigned long long)seed);
@@ -167,9 +167,9 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 		for (int i = 0; i < 8; ++i) {
 			const int w0 = 8 * half + i;
 			const bool ok = w0 >= first && w0 < last && (((delim >> w0) & span) | ((bad >> w0) & care)) == 0;
-			const uint64_t h = seed_hash(key[i]);
-			const uint32_t bw = ok ? a.bitmap1[(uint32_t)(h >> 10) & a.bitmap1_mask] : 0u;
-			word[i] = (bw >> ((uint32_t)h & 31)) & (bw >> ((uint32_t)(h >> 5) & 31));
+			const uint32_t h = seed_hash_a(key[i]);                              // hash b is only needed past level 1
+			const uint32_t bw = ok ? a.bitmap1[(h >> 10) & a.bitmap1_mask] : 0u;
+			word[i] = (bw >> (h & 31)) & (bw >> ((h >> 5) & 31));
 		}
 #pragma unroll
 		for (int i = 0; i < 8; ++i) pos_mask |= (word[i] & 1u) << i;
