@@ -24,13 +24,11 @@ N > 1   : query sharding (SURVEY.md 8e option 1, bit-identical to one GPU): ever
 Prints ONE JSON line on rank 0.
 """
 import argparse
-import ctypes
 import json
 import os
 import sys
 import time
 
-import numpy as np
 import torch
 import torch.distributed as dist
 

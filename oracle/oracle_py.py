@@ -234,7 +234,6 @@ def join_blocks(per_block, max_target_seqs=25):
     of (evalue, score, target_oid) in that block's output order. BlockJoiner keeps one cursor per block and a heap of the
     cursors' heads ordered by JoinRecord::cmp_evalue (:129-137: e-value ascending, score descending, target ordinal
     ascending); GlobalCulling stops after max_target_seqs targets (target_culling.h:70-88). Returns the joined list."""
-    import functools
 
     def heap_less(a, b):                      # cmp_evalue(lhs, rhs): true when lhs must sink below rhs
         (ea, sa, ta), (eb, sb, tb) = a[0], b[0]

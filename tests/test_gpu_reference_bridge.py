@@ -4,7 +4,6 @@ C ABI on the MI355X (oracle/ref_hip_bridge.cpp). Its output must be byte-identic
 reference binary on the same inputs -- hit sets, scores, coordinates, identities, CIGARs, e-values."""
 import os
 import subprocess
-import numpy as np
 import pytest
 
 from diamond_amd import synth
