@@ -4,7 +4,7 @@
 # and the test-only helpers: oracle/_ref/* (CPU restatement + reference build), tests/emu/libswipe_emu.so
 HIPCC   ?= /opt/rocm/bin/hipcc
 CSRC    := diamond_amd/csrc
-HIPSRC  := $(CSRC)/api.hip $(CSRC)/swipe_kernels.hip $(CSRC)/seed_api.hip $(CSRC)/seed_kernels.hip $(CSRC)/extend_host.hip $(CSRC)/gapped_api.hip $(CSRC)/gapped_kernels.hip $(CSRC)/mask_api.hip $(CSRC)/mask_kernels.hip $(CSRC)/bias_kernels.hip
+HIPSRC  := $(CSRC)/api.hip $(CSRC)/swipe_kernels.hip $(CSRC)/swipe16_kernels.hip $(CSRC)/seed_api.hip $(CSRC)/seed_kernels.hip $(CSRC)/extend_host.hip $(CSRC)/gapped_api.hip $(CSRC)/gapped_kernels.hip $(CSRC)/mask_api.hip $(CSRC)/mask_kernels.hip $(CSRC)/bias_kernels.hip
 HIPHDR  := $(wildcard $(CSRC)/*.h) include/diamond_hip.h
 HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function
 
@@ -27,8 +27,8 @@ oracle:
 	$(MAKE) -C oracle all
 
 emu: tests/emu/libswipe_emu.so
-tests/emu/libswipe_emu.so: tests/emu/swipe_emu.cpp tests/emu/seed_emu.cpp tests/emu/gapped_emu.cpp tests/emu/mask_emu.cpp tests/emu/bias_emu.cpp $(CSRC)/swipe_core.h $(CSRC)/seed_core.h $(CSRC)/gapped_core.h $(CSRC)/mask_core.h $(CSRC)/bias_core.h
-	g++ -O2 -std=c++17 -ffp-contract=off -fPIC -shared -w -o $@ tests/emu/swipe_emu.cpp tests/emu/seed_emu.cpp tests/emu/gapped_emu.cpp tests/emu/mask_emu.cpp tests/emu/bias_emu.cpp
+tests/emu/libswipe_emu.so: $(wildcard tests/emu/*.cpp) $(wildcard $(CSRC)/*_core.h)
+	g++ -O2 -std=c++17 -ffp-contract=off -fPIC -shared -w -o $@ $(wildcard tests/emu/*.cpp)
 
 clean:
 	rm -f diamond_amd/*.so diamond_amd/diamond-hip tests/emu/*.so

@@ -17,6 +17,7 @@
 #include <vector>
 #include "../../include/diamond_hip.h"
 #include "swipe_core.h"
+#include "swipe16_core.h"
 #include "host_pool.h"
 #include "swipe_kernels.h"
 #include "ctx.h"
@@ -119,7 +120,7 @@ extern "C" void dmnd_destroy(dmnd_ctx* c)
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	for (DevBuf* b : { &c->block[0], &c->block[1], &c->cbs, &c->matrix, &c->items, &c->order, &c->p_of_slot, &c->trace_off,
-		&c->transcript_off, &c->ends, &c->hsps, &c->trace, &c->transcript, &c->status, &c->host_q, &c->host_t, &c->host_cbs,
+		&c->transcript_off, &c->ends, &c->hsps, &c->trace, &c->transcript, &c->status, &c->pairs, &c->trace_off_item, &c->host_q, &c->host_t, &c->host_cbs,
 		&c->d_limits[0], &c->d_limits[1], &c->qid_of, &c->mask_time, &c->seed_keys, &c->seed_next, &c->seed_qlist, &c->seed_qkeys, &c->seed_slot2, &c->seed_loc2, &c->seed_survivors,
 		&c->matched_slot, &c->matched_loc, &c->counters, &c->seed_hits, &c->seed_bitmap, &c->seed_deferred, &c->seed_eslot, &c->seed_eloc, &c->seed_hits_sorted, &c->sort_keys[0], &c->sort_keys[1], &c->sort_idx[0], &c->sort_idx[1], &c->gf_tables, &c->gf_hits, &c->gf_flags, &c->gf_scores, &c->mask_lr, &c->mask_pb, &c->mask_scale })
 		b->release();
@@ -242,9 +243,86 @@ struct Bases {
 
 struct Slot { int32_t item; int32_t P; int64_t steps; };
 
+// DMND_SWIPE32=1: every sweep in the 32-bit kernels (A/B runs; the packed 16-bit kernels are the default for band classes
+// up to SW16_MAX_P)
+bool force_swipe32()
+{
+	static const bool v = [] { const char* e = std::getenv("DMND_SWIPE32"); return e && e[0] == '1'; }();
+	return v;
+}
+
+// Launches the sweep of `slots` (grouped by class P ascending, longest first inside a class) on work's stream: per class
+// the packed-int16 kernel with two items per wavefront (neighbours in launch order = similar lengths) when the class is
+// eligible, else the 32-bit kernel with one item per wavefront. kmode: K_SCORE / K_COORDS / K_TRACE.
+// order_dev: slot -> item (device, as uploaded by the caller); trace_off_slot_dev: slot-indexed offsets for the 32-bit kernel;
+// trace_off_slot: the same on the host. force32: re-run of items that saturated 16 bits.
+int launch_sweeps(dmnd_ctx* work, const Bases& b, const dmnd_dp_target* d_items, int64_t n_items_total, const std::vector<Slot>& slots,
+	const int32_t* order_dev, const int64_t* trace_off_slot_dev, const std::vector<int64_t>* trace_off_slot, uint8_t* trace_dev, int kmode, bool force32)
+{
+	const int64_t n = (int64_t)slots.size();
+	const bool trace = kmode == K_TRACE;
+	// which classes go through the 16-bit kernel
+	std::vector<int32_t>& pairs = work->h_pairs;
+	pairs.clear();
+	struct Launch { int64_t s0, s1; bool k16; int64_t pair0; };
+	std::vector<Launch> launches;
+	for (int64_t s0 = 0; s0 < n;) {
+		int64_t s1 = s0, max_steps = 0;
+		while (s1 < n && slots[(size_t)s1].P == slots[(size_t)s0].P) { max_steps = std::max(max_steps, slots[(size_t)s1].steps); ++s1; }
+		const bool k16 = !force32 && !force_swipe32() && kmode <= K_TRACE && slots[(size_t)s0].P <= SW16_MAX_P && max_steps <= 2 * (int64_t)SW16_MAX_PAIRS;
+		launches.push_back(Launch{ s0, s1, k16, (int64_t)pairs.size() / 2 });
+		if (k16)
+			for (int64_t s = s0; s < s1; s += 2) {
+				pairs.push_back(slots[(size_t)s].item);
+				pairs.push_back(s + 1 < s1 ? slots[(size_t)s + 1].item : -1);
+			}
+		s0 = s1;
+	}
+	if (!pairs.empty()) {
+		if (int rc = work->pairs.ensure(pairs.size() * sizeof(int32_t))) return rc;
+		HIP_TRY(hipMemcpyAsync(work->pairs.p, pairs.data(), pairs.size() * sizeof(int32_t), hipMemcpyHostToDevice, work->stream));
+		if (trace) {
+			// the 16-bit kernel addresses trace rows by item index
+			std::vector<int64_t>& by_item = work->h_trace_off_item;
+			by_item.assign((size_t)n_items_total, 0);
+			for (int64_t s = 0; s < n; ++s) by_item[(size_t)slots[(size_t)s].item] = (*trace_off_slot)[(size_t)s];
+			if (int rc = work->trace_off_item.ensure(by_item.size() * sizeof(int64_t))) return rc;
+			HIP_TRY(hipMemcpyAsync(work->trace_off_item.p, by_item.data(), by_item.size() * sizeof(int64_t), hipMemcpyHostToDevice, work->stream));
+		}
+	}
+	for (const Launch& l : launches) {
+		const int P = slots[(size_t)l.s0].P;
+		if (l.k16) {
+			Swipe16Args a;
+			a.qblock = b.q; a.tblock = b.t; a.cbs = b.cbs; a.matrix = work->matrix.as<int8_t>();
+			a.items = d_items;
+			a.pairs = work->pairs.as<int32_t>() + 2 * l.pair0;
+			a.trace_off = trace ? work->trace_off_item.as<int64_t>() : nullptr;
+			a.trace = trace ? trace_dev : nullptr;
+			a.ends = work->ends.as<SwipeEnd>();
+			a.n_pairs = (l.s1 - l.s0 + 1) / 2;
+			a.gap_open = work->params.gap_open; a.gap_extend = work->params.gap_extend;
+			HIP_TRY(launch_banded_swipe16(P, trace, a, work->stream));
+		}
+		else {
+			SwipeArgs a;
+			a.qblock = b.q; a.tblock = b.t; a.cbs = b.cbs; a.matrix = work->matrix.as<int8_t>();
+			a.items = d_items;
+			a.order = order_dev + l.s0;
+			a.trace_off = trace ? trace_off_slot_dev + l.s0 : nullptr;
+			a.trace = trace ? trace_dev : nullptr;
+			a.ends = work->ends.as<SwipeEnd>();
+			a.n = l.s1 - l.s0;
+			a.gap_open = work->params.gap_open; a.gap_extend = work->params.gap_extend;
+			HIP_TRY(launch_banded_swipe(P, kmode, a, work->stream));
+		}
+	}
+	return DMND_OK;
+}
+
 // Runs one chunk of items [begin, end) (indices into `items`), all modes.
-int run_chunk(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, const dmnd_dp_target* d_items, const std::vector<Slot>& slots,
-	int kmode, dmnd_hsp* out, std::vector<uint8_t>* chunk_transcripts, std::vector<int64_t>* chunk_tr_off)
+int run_chunk(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, int64_t n_items_total, const dmnd_dp_target* d_items, const std::vector<Slot>& slots,
+	int kmode, dmnd_hsp* out, std::vector<uint8_t>* chunk_transcripts, std::vector<int64_t>* chunk_tr_off, bool force32 = false)
 {
 	const int64_t n = (int64_t)slots.size();
 	if (n == 0) return DMND_OK;
@@ -278,21 +356,8 @@ int run_chunk(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, const dm
 
 	HIP_TRY(hipEventRecord(c->ev0, c->stream));
 	// slots are grouped by P (ascending) by the caller: one launch per class
-	for (int64_t s0 = 0; s0 < n;) {
-		int64_t s1 = s0;
-		while (s1 < n && slots[s1].P == slots[s0].P) ++s1;
-		SwipeArgs a;
-		a.qblock = b.q; a.tblock = b.t; a.cbs = b.cbs; a.matrix = c->matrix.as<int8_t>();
-		a.items = d_items;
-		a.order = c->order.as<int32_t>() + s0;
-		a.trace_off = trace ? c->trace_off.as<int64_t>() + s0 : nullptr;
-		a.trace = trace ? c->trace.as<uint8_t>() : nullptr;
-		a.ends = c->ends.as<SwipeEnd>();
-		a.n = s1 - s0;
-		a.gap_open = c->params.gap_open; a.gap_extend = c->params.gap_extend;
-		HIP_TRY(launch_banded_swipe(slots[s0].P, kmode, a, c->stream));
-		s0 = s1;
-	}
+	if (int rc = launch_sweeps(c, b, d_items, n_items_total, slots, c->order.as<int32_t>(), trace ? c->trace_off.as<int64_t>() : nullptr, &trace_off,
+		trace ? c->trace.as<uint8_t>() : nullptr, kmode, force32)) return rc;
 	HIP_TRY(hipEventRecord(c->ev1, c->stream));
 	if (trace) {
 		TracebackArgs t;
@@ -394,9 +459,19 @@ int swipe_impl(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, int64_t
 	if (kmode != K_TRACE) {
 		order_slots(slots);
 		lap(0);
-		if (int rc = run_chunk(c, b, items, c->items.as<dmnd_dp_target>(), slots, kmode, out, nullptr, nullptr)) return rc;
+		if (int rc = run_chunk(c, b, items, n, c->items.as<dmnd_dp_target>(), slots, kmode, out, nullptr, nullptr)) return rc;
 		lap(1);
 		HIP_TRY(copy_now(c->stream, ends.data(), c->ends.p, n * sizeof(SwipeEnd), hipMemcpyDeviceToHost));
+		{
+			// items that saturated the 16-bit sweep (score >= 32767): once more in the 32-bit kernels, as the reference escalates
+			// its score vectors (swipe_wrapper.cpp:317-360)
+			std::vector<Slot> again;
+			for (const Slot& x : slots) if (ends[(size_t)x.item].pad[0]) again.push_back(x);
+			if (!again.empty()) {
+				if (int rc = run_chunk(c, b, items, n, c->items.as<dmnd_dp_target>(), again, kmode, out, nullptr, nullptr, true)) return rc;
+				HIP_TRY(copy_now(c->stream, ends.data(), c->ends.p, n * sizeof(SwipeEnd), hipMemcpyDeviceToHost));
+			}
+		}
 		for (int64_t i = 0; i < n; ++i) {
 			dmnd_hsp h;
 			std::memset(&h, 0, sizeof(h));
@@ -434,7 +509,7 @@ int swipe_impl(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, int64_t
 		std::sort(rslots.begin(), rslots.end(), by_class);
 		HIP_TRY(hipMemcpyAsync(c->items.p, rev.data(), m * sizeof(dmnd_dp_target), hipMemcpyHostToDevice, c->stream));
 		const double ms_fwd = c->swipe_ms;
-		if (int rc = run_chunk(c, b, rev.data(), c->items.as<dmnd_dp_target>(), rslots, K_STATS_BWD_REV, out, nullptr, nullptr)) return rc;
+		if (int rc = run_chunk(c, b, rev.data(), m, c->items.as<dmnd_dp_target>(), rslots, K_STATS_BWD_REV, out, nullptr, nullptr)) return rc;
 		(void)ms_fwd;
 		HIP_TRY(copy_now(c->stream, ends.data(), c->ends.p, m * sizeof(SwipeEnd), hipMemcpyDeviceToHost));
 		for (int64_t k = 0; k < m; ++k) {
@@ -468,24 +543,36 @@ int swipe_impl(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, int64_t
 		std::vector<uint8_t> tr;
 		std::vector<int64_t> tr_off;
 		lap(0);
-		if (int rc = run_chunk(c, b, items, c->items.as<dmnd_dp_target>(), chunk, K_TRACE, out, transcript ? &tr : nullptr, transcript ? &tr_off : nullptr)) return rc;
+		if (int rc = run_chunk(c, b, items, n, c->items.as<dmnd_dp_target>(), chunk, K_TRACE, out, transcript ? &tr : nullptr, transcript ? &tr_off : nullptr)) return rc;
 		lap(1);
 		HIP_TRY(copy_now(c->stream, hsps.data() + c0, c->hsps.as<dmnd_hsp>() + c0, (size_t)(c1 - c0) * sizeof(dmnd_hsp), hipMemcpyDeviceToHost));
+		// items that saturated the 16-bit sweep (the walk skipped them: transcript_len < 0): sweep + walk again in 32 bits
+		std::vector<Slot> again;
+		std::vector<uint8_t> tr2;
+		std::vector<int64_t> tr_off2;
+		for (const Slot& x : chunk) if (hsps[(size_t)x.item].transcript_len < 0) again.push_back(x);
+		if (!again.empty()) {
+			if (int rc = run_chunk(c, b, items, n, c->items.as<dmnd_dp_target>(), again, K_TRACE, out, transcript ? &tr2 : nullptr, transcript ? &tr_off2 : nullptr, true)) return rc;
+			for (const Slot& x : again)
+				HIP_TRY(copy_now(c->stream, &hsps[(size_t)x.item], c->hsps.as<dmnd_hsp>() + x.item, sizeof(dmnd_hsp), hipMemcpyDeviceToHost));
+		}
 		if (!transcript) {
 			for (int64_t i = c0; i < c1; ++i) { out[i] = hsps[i]; out[i].transcript_off = -1; }
 			c0 = c1;
 			continue;
 		}
 		// pack the transcripts tightly into the caller's arena, in input order
-		std::vector<int64_t> slot_of((size_t)(c1 - c0));
+		std::vector<int64_t> slot_of((size_t)(c1 - c0)), slot2_of((size_t)(c1 - c0), -1);
 		for (size_t s = 0; s < chunk.size(); ++s) slot_of[(size_t)(chunk[s].item - c0)] = (int64_t)s;
+		for (size_t s = 0; s < again.size(); ++s) slot2_of[(size_t)(again[s].item - c0)] = (int64_t)s;
 		for (int64_t i = c0; i < c1; ++i) {
 			dmnd_hsp h = hsps[i];
-			const int64_t s = slot_of[(size_t)(i - c0)];
+			const int64_t s2 = slot2_of[(size_t)(i - c0)], s = slot_of[(size_t)(i - c0)];
+			const uint8_t* src = s2 >= 0 ? tr2.data() + tr_off2[(size_t)s2] : tr.data() + tr_off[(size_t)s];
 			const int64_t len = h.transcript_len + 1;
 			if (used + len > transcript_cap)
 				return fail(DMND_E_CAP, "dmnd_banded_swipe: transcript arena too small");
-			std::memcpy(transcript + used, tr.data() + tr_off[s], (size_t)len);
+			std::memcpy(transcript + used, src, (size_t)len);
 			h.transcript_off = used;
 			used += len;
 			out[i] = h;
@@ -573,24 +660,26 @@ int dmnd_swipe_keep(dmnd_ctx* work, const dmnd_ctx* c, const dmnd_dp_target* ite
 	work->host_ms[0] += wall() - t0;
 	const double t1 = wall();
 	HIP_TRY(hipEventRecord(work->ev0, work->stream));
-	for (int64_t s0 = 0; s0 < n;) {
-		int64_t s1 = s0;
-		while (s1 < n && slots[(size_t)s1].P == slots[(size_t)s0].P) ++s1;
-		SwipeArgs a;
-		a.qblock = b.q; a.tblock = b.t; a.cbs = b.cbs; a.matrix = work->matrix.as<int8_t>();
-		a.items = work->items.as<dmnd_dp_target>();
-		a.order = work->order.as<int32_t>() + s0;
-		a.trace_off = work->trace_off.as<int64_t>() + s0;
-		a.trace = tr.as<uint8_t>();
-		a.ends = work->ends.as<SwipeEnd>();
-		a.n = s1 - s0;
-		a.gap_open = work->params.gap_open; a.gap_extend = work->params.gap_extend;
-		HIP_TRY(launch_banded_swipe(slots[(size_t)s0].P, K_TRACE, a, work->stream));
-		s0 = s1;
-	}
+	if (int rc = launch_sweeps(work, b, work->items.as<dmnd_dp_target>(), n, slots, work->order.as<int32_t>(), work->trace_off.as<int64_t>(), &trace_off,
+		tr.as<uint8_t>(), K_TRACE, false)) return rc;
 	HIP_TRY(hipEventRecord(work->ev1, work->stream));
 	std::vector<SwipeEnd> ends((size_t)n);
 	HIP_TRY(copy_now(work->stream, ends.data(), work->ends.p, n * sizeof(SwipeEnd), hipMemcpyDeviceToHost));
+	{
+		// items that saturated the 16-bit sweep: once more in the 32-bit kernel, into the same trace rows
+		std::vector<Slot> again;
+		for (const Slot& x : slots) if (ends[(size_t)x.item].pad[0]) again.push_back(x);
+		if (!again.empty()) {
+			std::vector<int32_t> order2(again.size());
+			std::vector<int64_t> off2(again.size());
+			for (size_t k = 0; k < again.size(); ++k) { order2[k] = again[k].item; off2[k] = kt.trace_off[(size_t)again[k].item]; }
+			HIP_TRY(hipMemcpyAsync(work->order.p, order2.data(), order2.size() * sizeof(int32_t), hipMemcpyHostToDevice, work->stream));
+			HIP_TRY(hipMemcpyAsync(work->trace_off.p, off2.data(), off2.size() * sizeof(int64_t), hipMemcpyHostToDevice, work->stream));
+			if (int rc = launch_sweeps(work, b, work->items.as<dmnd_dp_target>(), n, again, work->order.as<int32_t>(), work->trace_off.as<int64_t>(), &off2,
+				tr.as<uint8_t>(), K_TRACE, true)) return rc;
+			HIP_TRY(copy_now(work->stream, ends.data(), work->ends.p, n * sizeof(SwipeEnd), hipMemcpyDeviceToHost));
+		}
+	}
 	float ms = 0.f;
 	HIP_TRY(hipEventElapsedTime(&ms, work->ev0, work->ev1));
 	work->swipe_ms = ms; work->traceback_ms = 0.0;

@@ -84,6 +84,9 @@ struct dmnd_ctx {
 	dmnd::DevBuf d_limits[2];
 	// banded-swipe work buffers
 	dmnd::DevBuf items, order, p_of_slot, trace_off, transcript_off, ends, hsps, trace, transcript, status;
+	dmnd::DevBuf pairs, trace_off_item;        // packed-int16 sweep: item pairs per wavefront, trace offset by item index
+	std::vector<int32_t> h_pairs;              // their host staging (outlive the asynchronous copies of a call)
+	std::vector<int64_t> h_trace_off_item;
 	dmnd::DevBuf host_q, host_t, host_cbs;      // staging for dmnd_banded_swipe_host
 	double swipe_ms = 0.0, traceback_ms = 0.0;
 	size_t trace_arena_max = (size_t)8 << 30;

@@ -1,0 +1,203 @@
+// swipe16_kernels.hip -- gfx950 (MI355X) banded Smith-Waterman sweep on the packed 16-bit VALU, two work items per wavefront.
+//
+// Replaces, for bands of up to 128 * SW16_MAX_P diagonals, the 32-bit kernels of swipe_kernels.hip behind
+// DP::BandedSwipe::swipe (/root/reference/src/dp/swipe/banded_swipe.h:189-351; the reference's 16-bit vectors with overflow
+// escalation: score_vector_int16.h, swipe_wrapper.cpp:317-360). Per-lane arithmetic and its correctness argument:
+// swipe16_core.h. What this file adds is the wavefront schedule:
+//   * one wavefront per PAIR of work items (low / high halves of every DP register), 4 wavefronts per workgroup;
+//   * per pair-step one DPP shift each for F (even step) and E (odd step), and three for the packed letter windows (query
+//     letters, their bias, target letters of both items) -- only lane 63 / lane 0 take new letters, from an edge record that
+//     the wavefront prepared in LDS for the next 256 pair-steps (one broadcast ds_read_b128 per pair-step, issued a whole
+//     pair-step before use; the inner loop has no global loads and next to no scalar-unit work);
+//   * the scores of pair-step t + 1 are looked up in LDS (32x32 table of 16-bit entries with the sentinel's row and column
+//     at -128) BEFORE the cells of pair-step t are computed, so LDS latency hides behind ~40 packed VALU instructions
+//     instead of stalling the first cell of every step;
+//   * trace rows (TRACE) in the layout of the 32-bit kernel -- one byte per cell, 64*P bytes per step and item -- so the
+//     wave-cooperative walk of swipe_kernels.hip (traceback_kernel) decodes them unchanged.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+#include "swipe16_core.h"
+#include "swipe_kernels.h"
+
+namespace dmnd {
+
+// wave_shr:1 -> lane l reads lane l-1, wave_shl:1 -> lane l reads lane l+1. *_z: the edge lane gets 0; *_in: it keeps `edge`.
+__device__ __forceinline__ uint32_t shr1_z(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true); }
+__device__ __forceinline__ uint32_t shl1_z(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true); }
+__device__ __forceinline__ uint32_t shr1_in(uint32_t edge, uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ uint32_t shl1_in(uint32_t edge, uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x130, 0xf, 0xf, false); }
+
+__device__ __forceinline__ int rfl(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ int64_t rfl64(int64_t x)
+{
+	const uint32_t lo = (uint32_t)rfl((int)(uint32_t)x), hi = (uint32_t)rfl((int)(uint32_t)((uint64_t)x >> 32));
+	return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+// one work item of the pair with every field in scalar registers (it is the same for all 64 lanes)
+struct Item16 {
+	Geom g;
+	SeqView v;
+	int pairs;                      // pair-steps
+};
+
+__device__ __forceinline__ Item16 load_item(const dmnd_dp_target* items, int idx, const int8_t* qblock, const int8_t* tblock, const int8_t* cbs)
+{
+	const dmnd_dp_target it = items[idx];
+	Item16 r;
+	r.g = make_geom(rfl(it.query_len), rfl(it.target_len), rfl(it.d_begin), rfl(it.d_end));
+	const int64_t c = rfl64(it.cbs_off);
+	r.v = SeqView{ qblock + rfl64(it.query_off), tblock + rfl64(it.target_off), c >= 0 ? cbs + c : nullptr, nullptr };
+	r.pairs = sw16_pairs(r.g);
+	return r;
+}
+
+// the P trace bytes of one lane, step and item (item B: the high halves)
+template<int P, bool SECOND>
+__device__ __forceinline__ void store_trace(uint8_t* row, const pk16* tb)
+{
+	const int sh = SECOND ? 16 : 0;
+	if (P == 1) row[0] = (uint8_t)(tb[0] >> sh);
+	else if (P == 2) *reinterpret_cast<uint16_t*>(row) = (uint16_t)(((tb[0] >> sh) & 0xffu) | (((tb[1] >> sh) & 0xffu) << 8));
+	else {
+#pragma unroll
+		for (int p = 0; p < P; p += 4)
+			*reinterpret_cast<uint32_t*>(row + p) = ((tb[p] >> sh) & 0xffu) | (((tb[p + 1] >> sh) & 0xffu) << 8) | (((tb[p + 2] >> sh) & 0xffu) << 16) | (((tb[p + 3] >> sh) & 0xffu) << 24);
+	}
+}
+
+enum { EDGE_CHUNK = 256 };            // pair-steps per refill of a wavefront's edge records (4 records per lane)
+
+template<int P, bool TRACE>
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64)
+void banded_swipe16_kernel(const int8_t* __restrict__ qblock, const int8_t* __restrict__ tblock, const int8_t* __restrict__ cbs,
+	const int8_t* __restrict__ matrix, const dmnd_dp_target* __restrict__ items, const int32_t* __restrict__ pairs,
+	const int64_t* __restrict__ trace_off, uint8_t* __restrict__ trace, SwipeEnd* __restrict__ ends, int64_t n_pairs, int gap_open, int gap_extend)
+{
+	__shared__ uint16_t table[32 * 32];
+	__shared__ uint4 edges[WAVES_PER_BLOCK][EDGE_CHUNK];      // per wavefront: Edge16 (qq, tt, cc) of the next EDGE_CHUNK pair-steps
+	for (int x = threadIdx.x; x < 32 * 32; x += blockDim.x)
+		table[x] = sw16_table_entry(matrix, x);
+	__syncthreads();
+
+	const int lane = threadIdx.x & 63, wave = rfl((int)(threadIdx.x >> 6));
+	const int64_t slot = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
+	if (slot >= n_pairs)
+		return;
+	const int idxA = rfl(pairs[2 * slot]), idxB_raw = rfl(pairs[2 * slot + 1]);
+	const bool hasB = idxB_raw >= 0;                   // the odd item of a class shares its wavefront with a copy of itself
+	const int idxB = hasB ? idxB_raw : idxA;
+	const Item16 A = load_item(items, idxA, qblock, tblock, cbs), B = load_item(items, idxB, qblock, tblock, cbs);
+	const pk16 go = pk_both(gap_open + gap_extend), ge = pk_both(gap_extend);
+	const int nA = A.pairs, nB = hasB ? B.pairs : 0;
+
+	Lane16<P> st;
+	lane16_init(st, A.g, A.v, B.g, B.v, lane);
+	constexpr int W = 64 * P;
+	uint8_t *baseA = nullptr, *baseB = nullptr;
+	if (TRACE) {
+		baseA = trace + rfl64(trace_off[idxA]);
+		baseB = trace + rfl64(trace_off[idxB]);
+	}
+	const uint32_t lane_off = (uint32_t)(lane * P);
+	uint4* const my_edges = edges[wave];
+
+	pk16 S0[P], S1[P];
+	lane16_scores(st, table, S0, S1);
+	Edge16 e = sw16_edge(A.g, A.v, B.g, B.v, P, 0);        // enters at the end of pair-step 0
+
+	// pair-steps [t0, t1): SA / SB = item A / B still has trace rows to write there
+	auto sweep = [&](auto sa, auto sb, int t0, int t1) {
+		constexpr bool SA = decltype(sa)::value, SB = decltype(sb)::value;
+		auto pair_step = [&](int t, int tc) {
+			// edge record of the NEXT pair-step (LDS broadcast read, in flight during this one)
+			const uint4 nx = my_edges[t - tc];
+			// windows of pair-step t + 1 and its scores: the LDS reads are in flight while the cells of pair-step t are computed
+			lane16_advance(st, shl1_in(e.qq, st.QQ[1]), shl1_in(e.cc, st.CC[1]), shr1_in(e.tt, st.TT[P - 1]));
+			pk16 N0[P], N1[P];
+			lane16_scores(st, table, N0, N1);
+			const uint32_t revt = 0xffffu - (uint32_t)t;
+			const uint32_t row = lane_off + (uint32_t)t * (2 * W);
+			pk16 tb[P];
+			lane16_step<P, TRACE, 0>(st, S0, shr1_z(st.F[2 * P - 1]), go, ge, revt, tb);
+			if (TRACE && SA) store_trace<P, false>(baseA + row, tb);
+			if (TRACE && SB) store_trace<P, true>(baseB + row, tb);
+			lane16_step<P, TRACE, 1>(st, S1, shl1_z(st.E[0]), go, ge, revt, tb);
+			if (TRACE && SA) store_trace<P, false>(baseA + row + W, tb);
+			if (TRACE && SB) store_trace<P, true>(baseB + row + W, tb);
+#pragma unroll
+			for (int p = 0; p < P; ++p) { S0[p] = N0[p]; S1[p] = N1[p]; }
+			e.qq = nx.x; e.tt = nx.y; e.cc = nx.z;
+		};
+		for (int tc = t0; tc < t1; tc += EDGE_CHUNK) {
+			// records of pair-steps tc + 1 .. tc + EDGE_CHUNK (slot r holds pair-step tc + 1 + r), built by the lanes in parallel
+			// (adjacent lanes read adjacent letters); only this wavefront reads them back, so a wave-level barrier orders the
+			// writes before the reads
+			__builtin_amdgcn_wave_barrier();
+#pragma unroll
+			for (int r = lane; r < EDGE_CHUNK; r += 64) {
+				const Edge16 x = sw16_edge(A.g, A.v, B.g, B.v, P, tc + 1 + r);
+				my_edges[r] = make_uint4(x.qq, x.tt, x.cc, 0u);
+			}
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			const int te = tc + EDGE_CHUNK < t1 ? tc + EDGE_CHUNK : t1;
+			// two pair-steps per trip: the window registers rotate with period P + 1 (2 at P = 1) and the score registers with
+			// period 2, so the copies at the end of a pair-step become renames (the DPP moves are convergent operations, which
+			// keeps the compiler from unrolling a loop with a run-time trip count by itself)
+			int t = tc;
+			for (; t + 1 < te; t += 2) { pair_step(t, tc); pair_step(t + 1, tc); }
+			if (t < te) pair_step(t, tc);
+		}
+	};
+	const int n_both = nA < nB ? nA : nB;
+	sweep(std::true_type(), std::true_type(), 0, n_both);
+	if (nA > n_both) sweep(std::true_type(), std::false_type(), n_both, nA);
+	if (nB > n_both) sweep(std::false_type(), std::true_type(), n_both, nB);
+
+	// end cells of both items: per lane from its diagonal keys, then a wave reduction
+#pragma unroll
+	for (int item = 0; item < 2; ++item) {
+		if (item == 1 && !hasB) break;
+		int bs, bi, bj;
+		lane16_finish(st, item ? B.g : A.g, item == 1, lane, bs, bi, bj);
+#pragma unroll
+		for (int off = 32; off >= 1; off >>= 1) {
+			const int os = __shfl_xor(bs, off), oi = __shfl_xor(bi, off), oj = __shfl_xor(bj, off);
+			if (better_end(os, oj, oi, bs, bj, bi)) { bs = os; bi = oi; bj = oj; }
+		}
+		if (lane == 0) {
+			SwipeEnd x;
+			x.score = bs; x.end_i = bi; x.end_j = bj; x.stat_a = 0; x.stat_b = 0;
+			x.pad[0] = bs >= SW16_MAX_SCORE ? 1 : 0;      // saturated: the host re-runs the item in the 32-bit kernel
+			x.pad[1] = x.pad[2] = 0;
+			ends[item ? idxB : idxA] = x;
+		}
+	}
+}
+
+template<int P>
+static hipError_t launch16_p(bool trace, const Swipe16Args& a, hipStream_t stream)
+{
+	const unsigned blocks = (unsigned)((a.n_pairs + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+	if (blocks == 0)
+		return hipSuccess;
+	const dim3 grid(blocks), block(WAVES_PER_BLOCK * 64);
+	if (trace) hipLaunchKernelGGL((banded_swipe16_kernel<P, true>), grid, block, 0, stream, a.qblock, a.tblock, a.cbs, a.matrix, a.items, a.pairs, a.trace_off, a.trace, a.ends, a.n_pairs, a.gap_open, a.gap_extend);
+	else hipLaunchKernelGGL((banded_swipe16_kernel<P, false>), grid, block, 0, stream, a.qblock, a.tblock, a.cbs, a.matrix, a.items, a.pairs, a.trace_off, a.trace, a.ends, a.n_pairs, a.gap_open, a.gap_extend);
+	return hipGetLastError();
+}
+
+hipError_t launch_banded_swipe16(int P, bool trace, const Swipe16Args& a, hipStream_t stream)
+{
+	switch (P) {
+	case 1: return launch16_p<1>(trace, a, stream);
+	case 2: return launch16_p<2>(trace, a, stream);
+	case 4: return launch16_p<4>(trace, a, stream);
+	default: return hipErrorInvalidValue;
+	}
+}
+
+}  // namespace dmnd

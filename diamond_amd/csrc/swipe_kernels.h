@@ -8,7 +8,8 @@ namespace dmnd {
 
 enum { WAVES_PER_BLOCK = 4 };
 
-struct SwipeEnd {            // per item: best score, its end cell (row i, column j) and the carried statistics
+struct SwipeEnd {            // per item: best score, its end cell (row i, column j) and the carried statistics;
+	                             // pad[0] = 1: the packed 16-bit sweep saturated, the item must be re-run in 32 bits
 	int32_t score, end_i, end_j, stat_a, stat_b, pad[3];
 };
 
@@ -48,7 +49,23 @@ struct TracebackArgs {
 	int32_t gap_open, gap_extend;
 };
 
+// packed-int16 sweep, two items per wavefront (swipe16_kernels.hip): band classes P <= 4, at most 65535 pair-steps per item
+struct Swipe16Args {
+	const int8_t* qblock;
+	const int8_t* tblock;
+	const int8_t* cbs;
+	const int8_t* matrix;
+	const dmnd_dp_target* items;
+	const int32_t* pairs;        // 2 item indices per wavefront of this launch (one P class); second = -1: single item
+	const int64_t* trace_off;    // item index -> byte offset into trace (traceback mode)
+	uint8_t* trace;
+	SwipeEnd* ends;              // indexed by item; score == 32767: saturated, to be re-run in the 32-bit kernel
+	int64_t n_pairs;
+	int32_t gap_open, gap_extend;
+};
+
 hipError_t launch_banded_swipe(int P, int mode, const SwipeArgs& a, hipStream_t stream);
+hipError_t launch_banded_swipe16(int P, bool trace, const Swipe16Args& a, hipStream_t stream);
 hipError_t launch_traceback(const TracebackArgs& a, hipStream_t stream);
 
 }  // namespace dmnd

@@ -224,7 +224,8 @@ __global__ __launch_bounds__(256) void traceback_kernel(TracebackArgs args)
 	h.length = h.identities = h.mismatches = h.positives = h.gap_openings = h.gaps = 0;
 	h.transcript_len = 0;
 	h.transcript_off = args.transcript_off[slot];
-	if (e.score > 0) {
+	if (e.pad[0]) h.transcript_len = -1;          // saturated 16-bit sweep: nothing to walk, the host re-runs the item
+	if (e.score > 0 && !e.pad[0]) {
 		const Geom g = make_geom(it.query_len, it.target_len, it.d_begin, it.d_end);
 		const SeqView v{ args.qblock + it.query_off, args.tblock + it.target_off,
 			it.cbs_off >= 0 ? args.cbs + it.cbs_off : nullptr, matrix };

@@ -1,0 +1,98 @@
+// tests/emu/swipe16_emu.cpp -- TEST INFRASTRUCTURE ONLY.
+// CPU lane-emulator of the packed-int16 two-items-per-wavefront sweep (diamond_amd/csrc/swipe16_kernels.hip): runs the SAME
+// per-lane code (diamond_amd/csrc/swipe16_core.h) for 64 emulated lanes in lock-step, DPP shifts replaced by array indexing,
+// including the systolic letter flow (rows come down from lane l+1, columns from lane l-1, edge lanes read memory). The trace
+// it writes has the layout of the 32-bit kernel, so the reference walk (traceback_walk, swipe_core.h) decodes it.
+#include <vector>
+#include <cstring>
+#include "../../diamond_amd/csrc/swipe16_core.h"
+
+using namespace dmnd;
+
+struct Emu16Out {
+	int32_t score, q_begin, q_end, s_begin, s_end, length, identities, mismatches, positives, gap_openings, gaps, transcript_len, status;
+};
+
+struct Emu16Item {
+	const int8_t* q; int32_t qlen; const int8_t* cbs; const int8_t* t; int32_t tlen; int32_t d_begin, d_end;
+};
+
+template<int P, bool TRACE>
+static void run16(const Emu16Item& A, const Emu16Item& B, const int8_t* M, int gap_open, int gap_extend, Emu16Out* outA, Emu16Out* outB,
+	uint8_t* trA, uint8_t* trB, int cap)
+{
+	uint16_t table[1024];
+	for (int x = 0; x < 1024; ++x) table[x] = sw16_table_entry(M, x);
+	const Geom gA = make_geom(A.qlen, A.tlen, A.d_begin, A.d_end), gB = make_geom(B.qlen, B.tlen, B.d_begin, B.d_end);
+	const SeqView vA{ A.q, A.t, A.cbs, M }, vB{ B.q, B.t, B.cbs, M };
+	const int nA = sw16_pairs(gA), nB = sw16_pairs(gB), T = nA > nB ? nA : nB, W = 64 * P;
+	const pk16 go = pk_both(gap_open + gap_extend), ge = pk_both(gap_extend);
+	std::vector<Lane16<P>> st(64);
+	for (int l = 0; l < 64; ++l) lane16_init(st[l], gA, vA, gB, vB, l);
+	std::vector<uint8_t> traceA, traceB;
+	if (TRACE) { traceA.assign((size_t)2 * nA * W + 8, 0xee); traceB.assign((size_t)2 * nB * W + 8, 0xee); }
+	pk16 S0[64][P], S1[64][P], tb[64][P], nb[64];
+	for (int t = 0; t < T; ++t) {
+		const uint32_t revt = 0xffffu - (uint32_t)t;
+		for (int l = 0; l < 64; ++l) lane16_scores(st[l], table, S0[l], S1[l]);
+		for (int par = 0; par < 2; ++par) {
+			if (par == 0) for (int l = 0; l < 64; ++l) nb[l] = l == 0 ? 0 : st[l - 1].F[2 * P - 1];
+			else for (int l = 0; l < 64; ++l) nb[l] = l == 63 ? 0 : st[l + 1].E[0];
+			for (int l = 0; l < 64; ++l) {
+				if (par == 0) lane16_step<P, TRACE, 0>(st[l], S0[l], nb[l], go, ge, revt, tb[l]);
+				else lane16_step<P, TRACE, 1>(st[l], S1[l], nb[l], go, ge, revt, tb[l]);
+			}
+			if (TRACE)
+				for (int l = 0; l < 64; ++l)
+					for (int p = 0; p < P; ++p) {
+						if (t < nA) traceA[(size_t)(2 * t + par) * W + l * P + p] = (uint8_t)(tb[l][p] & 0xff);
+						if (t < nB) traceB[(size_t)(2 * t + par) * W + l * P + p] = (uint8_t)((tb[l][p] >> 16) & 0xff);
+					}
+		}
+		// systolic letter flow
+		const Edge16 e = sw16_edge(gA, vA, gB, vB, P, t);
+		pk16 nqq[64], ncc[64], ntt[64];
+		for (int l = 0; l < 64; ++l) {
+			nqq[l] = l < 63 ? st[l + 1].QQ[1] : e.qq;
+			ncc[l] = l < 63 ? st[l + 1].CC[1] : e.cc;
+			ntt[l] = l > 0 ? st[l - 1].TT[P - 1] : e.tt;
+		}
+		for (int l = 0; l < 64; ++l) lane16_advance(st[l], nqq[l], ncc[l], ntt[l]);
+	}
+	for (int item = 0; item < 2; ++item) {
+		const Geom& g = item ? gB : gA;
+		const SeqView& v = item ? vB : vA;
+		Emu16Out* out = item ? outB : outA;
+		int bs = 0, bi = 0, bj = 0x7fffffff;
+		for (int l = 0; l < 64; ++l) {
+			int s, i, j;
+			lane16_finish(st[l], g, item == 1, l, s, i, j);
+			if (better_end(s, j, i, bs, bj, bi)) { bs = s; bi = i; bj = j; }
+		}
+		memset(out, 0, sizeof(*out));
+		out->score = bs;
+		if (bs > 0) { out->q_end = bi + 1; out->s_end = bj + 1; }
+		if (TRACE && bs > 0 && bs < SW16_MAX_SCORE) {
+			const WalkResult r = traceback_walk((item ? traceB : traceA).data(), g, W, v, gap_open, gap_extend, bs, bi, bj, item ? trB : trA, cap);
+			out->q_begin = r.q_begin; out->s_begin = r.s_begin; out->length = r.length; out->identities = r.identities;
+			out->mismatches = r.mismatches; out->positives = r.positives; out->gap_openings = r.gap_openings; out->gaps = r.gaps;
+			out->transcript_len = r.transcript_len; out->status = r.status;
+		}
+	}
+}
+
+// trace != 0: traceback mode (coordinates, statistics and transcripts of both items); force_p: 0 = the pair's class
+extern "C" int emu_banded_swipe16(const Emu16Item* A, const Emu16Item* B, const int8_t* M, int gap_open, int gap_extend, int trace, int force_p,
+	Emu16Out* outA, Emu16Out* outB, uint8_t* trA, uint8_t* trB, int cap)
+{
+	int P = 1;
+	while (128 * P < A->d_end - A->d_begin || 128 * P < B->d_end - B->d_begin) P *= 2;
+	if (force_p > P) P = force_p;
+	switch (P) {
+	case 1: if (trace) run16<1, true>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); else run16<1, false>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); break;
+	case 2: if (trace) run16<2, true>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); else run16<2, false>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); break;
+	case 4: if (trace) run16<4, true>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); else run16<4, false>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); break;
+	default: return -4;
+	}
+	return 0;
+}

@@ -14,6 +14,9 @@ _SRC3 = os.path.join(_HERE, "emu", "gapped_emu.cpp")
 _CORE3 = os.path.join(_HERE, "..", "diamond_amd", "csrc", "gapped_core.h")
 _SRC4 = os.path.join(_HERE, "emu", "mask_emu.cpp")
 _CORE4 = os.path.join(_HERE, "..", "diamond_amd", "csrc", "mask_core.h")
+_SRC5 = os.path.join(_HERE, "emu", "bias_emu.cpp")
+_SRC6 = os.path.join(_HERE, "emu", "swipe16_emu.cpp")
+_CORE6 = os.path.join(_HERE, "..", "diamond_amd", "csrc", "swipe16_core.h")
 _SO = os.path.join(_HERE, "emu", "libswipe_emu.so")
 
 
@@ -29,10 +32,41 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_SO) or max(os.path.getmtime(f) for f in (_SRC, _SRC2, _SRC3, _SRC4, _CORE, _CORE2, _CORE3, _CORE4)) > os.path.getmtime(_SO):
-            subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-w", "-o", _SO, _SRC, _SRC2, _SRC3, _SRC4])
+        import glob
+        srcs = sorted(glob.glob(os.path.join(_HERE, "emu", "*.cpp")))
+        deps = srcs + glob.glob(os.path.join(_HERE, "..", "diamond_amd", "csrc", "*_core.h"))
+        if not os.path.exists(_SO) or max(os.path.getmtime(f) for f in deps) > os.path.getmtime(_SO):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-w", "-o", _SO] + srcs)
         _lib = ctypes.CDLL(_SO)
     return _lib
+
+
+class Emu16Item(ctypes.Structure):
+    _fields_ = [("q", ctypes.c_void_p), ("qlen", ctypes.c_int32), ("cbs", ctypes.c_void_p), ("t", ctypes.c_void_p), ("tlen", ctypes.c_int32),
+                ("d_begin", ctypes.c_int32), ("d_end", ctypes.c_int32)]
+
+
+def banded_swipe16(a, b, matrix8, gap_open, gap_extend, trace=True, force_p=0, cap=1 << 17):
+    """Two work items (dicts: query, cbs, target, d_begin, d_end) through the packed-int16 two-items-per-wavefront emulator."""
+    keep = []
+
+    def item(x):
+        q = np.ascontiguousarray(x["query"], dtype=np.int8)
+        t = np.ascontiguousarray(x["target"], dtype=np.int8)
+        c = np.ascontiguousarray(x["cbs"], dtype=np.int8) if x.get("cbs") is not None else None
+        keep.extend([q, t, c])
+        return Emu16Item(q.ctypes.data, len(q), c.ctypes.data if c is not None else None, t.ctypes.data, len(t), int(x["d_begin"]), int(x["d_end"]))
+
+    ia, ib = item(a), item(b)
+    m = np.ascontiguousarray(matrix8, dtype=np.int8)
+    oa, ob = EmuOut(), EmuOut()
+    tra, trb = np.zeros(cap, np.uint8), np.zeros(cap, np.uint8)
+    rc = lib().emu_banded_swipe16(ctypes.byref(ia), ctypes.byref(ib), m.ctypes.data_as(ctypes.c_void_p), int(gap_open), int(gap_extend),
+                                  int(bool(trace)), int(force_p), ctypes.byref(oa), ctypes.byref(ob),
+                                  tra.ctypes.data_as(ctypes.c_void_p), trb.ctypes.data_as(ctypes.c_void_p), cap)
+    da = {n: getattr(oa, n) for n, _ in EmuOut._fields_}
+    db = {n: getattr(ob, n) for n, _ in EmuOut._fields_}
+    return rc, (da, tra[:da["transcript_len"]].copy()), (db, trb[:db["transcript_len"]].copy())
 
 
 def banded_swipe(query, cbs, target, d_begin, d_end, matrix8, gap_open, gap_extend, mode, force_p=0, cap=1 << 17):

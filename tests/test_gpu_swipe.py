@@ -273,3 +273,35 @@ def test_stats_without_traceback_golden_and_oracle(ctx):
         if o["score"] > 0:          # a zero score never becomes an HSP; its coordinates are don't-care
             for key in STAT_KEYS:
                 assert out[k][key] == o[key], (key, k, out[k], o)
+
+
+def test_saturated_items_are_rerun_in_32_bits(ctx):
+    """Scores of 32767 and above saturate the packed 16-bit sweep: such items must come back from the 32-bit kernels with the
+    oracle's numbers in every mode, and must not disturb the item that shared their wavefront."""
+    M = hip.matrix_of(ctx.params)
+    rng = np.random.default_rng(77)
+    recs = _random_items(rng, 9, M)
+    big = np.full(3400, 17, np.int8)                     # W x W = 11 per column: 37400
+    recs.insert(3, {"query": big, "cbs": None, "targets": [{"seq": big.copy(), "d_begin": -20, "d_end": 21}]})
+    mid = rng.integers(0, 20, 3100).astype(np.int8)      # below and above the limit in one batch
+    recs.insert(6, {"query": mid, "cbs": None, "targets": [{"seq": mid.copy(), "d_begin": -30, "d_end": 31}]})
+    qb, tb, cbs, items, meta = pack_records(recs)
+    ctx.upload_block(hip.QUERY, qb)
+    ctx.upload_block(hip.TARGET, tb)
+    ctx.upload_cbs(cbs)
+    res = {mode: ctx.banded_swipe(items, mode) for mode in (hip.SWIPE_SCORE, hip.SWIPE_COORDS, hip.SWIPE_TRACEBACK)}
+    seen_big = False
+    for k, (rec, t) in enumerate(meta):
+        rc, o, otr = orc.banded_swipe(rec["query"], rec["cbs"], t["seq"], t["d_begin"], t["d_end"], M, 11, 1, orc.TRACEBACK)
+        assert rc == 0
+        seen_big |= o["score"] >= 32767
+        assert res[hip.SWIPE_SCORE][0][k]["score"] == o["score"]
+        c = res[hip.SWIPE_COORDS][0][k]
+        assert c["score"] == o["score"]
+        if o["score"] > 0:
+            assert (c["q_end"], c["s_end"]) == (o["q_end"], o["s_end"])
+            g, tr = res[hip.SWIPE_TRACEBACK][0][k], res[hip.SWIPE_TRACEBACK][1]
+            for key in KEYS:
+                assert g[key] == o[key], (key, k)
+            assert np.array_equal(_transcript(tr, g), otr)
+    assert seen_big
