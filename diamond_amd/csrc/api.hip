@@ -12,7 +12,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <numeric>
+#include <unordered_map>
 #include <string>
 #include <vector>
 #include "../../include/diamond_hip.h"
@@ -31,6 +33,44 @@ int dmnd::fail(int code, const std::string& msg)
 {
 	g_last_error = msg;
 	return code;
+}
+
+namespace {
+std::mutex g_sync_mutex;
+std::unordered_map<hipStream_t, hipEvent_t> g_sync_events;
+}
+
+hipError_t dmnd::sync_stream(hipStream_t s)
+{
+	if (spin_sync()) return hipStreamSynchronize(s);
+	hipEvent_t ev = nullptr;
+	{
+		std::lock_guard<std::mutex> g(g_sync_mutex);
+		auto it = g_sync_events.find(s);
+		if (it != g_sync_events.end()) ev = it->second;
+	}
+	if (!ev) {
+		// a stream is driven by one host thread at a time, so two threads never race to create its event
+		const hipError_t e = hipEventCreateWithFlags(&ev, hipEventBlockingSync | hipEventDisableTiming);
+		if (e != hipSuccess) return e;
+		std::lock_guard<std::mutex> g(g_sync_mutex);
+		g_sync_events[s] = ev;
+	}
+	const hipError_t e = hipEventRecord(ev, s);
+	return e != hipSuccess ? e : hipEventSynchronize(ev);
+}
+
+void dmnd::forget_stream(hipStream_t s)
+{
+	hipEvent_t ev = nullptr;
+	{
+		std::lock_guard<std::mutex> g(g_sync_mutex);
+		auto it = g_sync_events.find(s);
+		if (it == g_sync_events.end()) return;
+		ev = it->second;
+		g_sync_events.erase(it);
+	}
+	(void)hipEventDestroy(ev);
 }
 
 int dmnd::DevBuf::ensure(size_t bytes)
@@ -127,7 +167,7 @@ extern "C" void dmnd_destroy(dmnd_ctx* c)
 	if (c->ev0) (void)hipEventDestroy(c->ev0);
 	if (c->ev1) (void)hipEventDestroy(c->ev1);
 	if (c->ev2) (void)hipEventDestroy(c->ev2);
-	if (c->stream) (void)hipStreamDestroy(c->stream);
+	if (c->stream) { forget_stream(c->stream); (void)hipStreamDestroy(c->stream); }
 	delete c;
 }
 

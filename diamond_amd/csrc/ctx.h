@@ -32,23 +32,12 @@ inline bool spin_sync()
 	return v;
 }
 
-inline hipError_t sync_stream(hipStream_t s)
-{
-	if (spin_sync()) return hipStreamSynchronize(s);
-	static thread_local hipEvent_t ev = nullptr;
-	static thread_local int ev_device = -1;
-	int dev = 0;
-	hipError_t e = hipGetDevice(&dev);
-	if (e != hipSuccess) return e;
-	if (!ev || ev_device != dev) {
-		if (ev) (void)hipEventDestroy(ev);
-		e = hipEventCreateWithFlags(&ev, hipEventBlockingSync | hipEventDisableTiming);
-		if (e != hipSuccess) { ev = nullptr; return e; }
-		ev_device = dev;
-	}
-	e = hipEventRecord(ev, s);
-	return e != hipSuccess ? e : hipEventSynchronize(ev);
-}
+// One interrupt-driven event per STREAM (created on first use, released by forget_stream when the stream's owner goes away).
+// The event used to be thread-local: the extension stage's runner threads are short-lived, so every dmnd_extend call leaked a
+// handful of events and their interrupt signals, and after a few thousand calls the driver's finite pool of them ran out --
+// waits then returned early ("device not ready" from hipEventElapsedTime, stale results behind copy_now).
+hipError_t sync_stream(hipStream_t s);
+void forget_stream(hipStream_t s);
 
 inline hipError_t copy_now(hipStream_t s, void* dst, const void* src, size_t bytes, hipMemcpyKind kind)
 {

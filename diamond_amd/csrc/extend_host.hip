@@ -42,7 +42,7 @@
 #include <functional>
 #include <vector>
 #include "ctx.h"
-#include "chain_host.h"
+#include "chain_graph.h"
 #include "host_pool.h"
 #include "bias_kernels.h"
 
@@ -393,6 +393,10 @@ struct QueryState {
 // Steps 2.. of the extension stage for the queries qr[qr_begin, qr_end): c = the context that owns the blocks, limits, bias
 // and statistics parameters (read only), w = the context whose stream, device work buffers and counters this range uses
 // (w == c, or one of c's auxiliary contexts when the block is processed as concurrent sub-batches).
+// Host work is cut into `threads` fixed slices of the query range, slice t always handled by participant t of the calling
+// thread's pool (parallel_each): a query's state is built, updated and released by one thread, so it stays in that core's
+// caches across the phases and its memory goes back to the allocator arena it came from. The GPU phases in between are ONE
+// launch each over the items of all slices.
 static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const std::vector<Range>& qr, size_t qr_begin, size_t qr_end,
 	const dmnd_seed_hit* hits, const std::vector<uint8_t>& gf, const int8_t* qdata, const int8_t* tdata, const int8_t* cbs,
 	int threads, uint32_t hsp_values, std::vector<dmnd_match>& out_matches,
@@ -405,28 +409,43 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 	for (int i = 0; i < 12; ++i) if (i != 4 || w != c) w->ext_stats[i] = 0;      // [4] (bias + upload) of the caller's prelude is kept
 	for (double& x : w->host_ms) x = 0;
 	auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-	auto cells_of = [](const std::vector<dmnd_dp_target>& v) {
-		double s = 0;
-		for (const auto& d : v) s += (double)dmnd_banded_cols(d.query_len, d.target_len, d.d_begin, d.d_end) * (double)(d.d_end - d.d_begin);
-		return s;
-	};
+	auto cells_of = [](const dmnd_dp_target& d) { return (double)dmnd_banded_cols(d.query_len, d.target_len, d.d_begin, d.d_end) * (double)(d.d_end - d.d_begin); };
 	double t_mark = now();
 	const double t_enter = t_mark;
 	double fine[16] = { 0 }, at[16] = { 0 };          // DMND_TRACE=1: finer host timeline on stderr (at[]: end of each phase since dmnd_extend began, first pass)
 	auto lap = [&](int slot, int f = -1) { const double t = now(); w->ext_stats[slot] += t - t_mark; if (f >= 0) { fine[f] += t - t_mark; if (at[f] == 0) at[f] = t - g_extend_t0; } t_mark = t; };
 	lap(4, 1);
+	const size_t nq = qr_end - qr_begin;
+	const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(threads, 1), (nq + 63) / 64));
+	auto slice_begin = [&](int t) { return nq * (size_t)t / (size_t)T; };
+	struct Ref { size_t q, k; };
+	struct KeptGroup { std::vector<dmnd_dp_target> items; std::vector<int64_t> src; std::vector<Ref> ref; };
+	struct Slice {                       // what slice t contributes to the phase at hand
+		size_t n_items = 0, item_off = 0;
+		double cells = 0;
+		bool keepable = true, any = false;
+		std::vector<KeptGroup> kept;
+		std::vector<dmnd_dp_target> it_tb, it_st;
+		std::vector<Ref> ref_tb, ref_st;
+		size_t n_matches = 0, match_off = 0;
+	};
+	std::vector<Slice> sl((size_t)T);
 	// 2. load_hits for every query
-	std::vector<QueryState> qs(qr_end - qr_begin);
-	parallel_for(qs.size(), threads, [&](size_t i, int) {
-		const Range& r = qr[qr_begin + i];
-		load_query(h, qs[i].w, hits[r.b].query / (uint32_t)h.contexts, hits + r.b, hits + r.e, gf.empty() ? nullptr : gf.data() + r.b, tl.data(), (int64_t)tl.size() - 1, c->coarse[DMND_TARGET].empty() ? nullptr : c->coarse[DMND_TARGET].data());
-		if (qs[i].w.order.empty()) qs[i].done = true;
+	std::vector<QueryState> qs(nq);
+	std::vector<ChainWorkspace> ws((size_t)T);
+	const uint32_t* coarse = c->coarse[DMND_TARGET].empty() ? nullptr : c->coarse[DMND_TARGET].data();
+	parallel_each(T, [&](int t) {
+		for (size_t i = slice_begin(t); i < slice_begin(t + 1); ++i) {
+			const Range& r = qr[qr_begin + i];
+			load_query(h, qs[i].w, hits[r.b].query / (uint32_t)h.contexts, hits + r.b, hits + r.e, gf.empty() ? nullptr : gf.data() + r.b, tl.data(), (int64_t)tl.size() - 1, coarse);
+			if (qs[i].w.order.empty()) qs[i].done = true;
+		}
 	});
-	std::vector<ChainWorkspace> ws((size_t)threads);
 	lap(5, 3);
 	auto item_of = [&](uint32_t q, uint32_t t, int d0, int d1) {
 		return dmnd_dp_target{ ql[q], tl[t], h.use_cbs ? ql[q] : (int64_t)-1, (int32_t)(ql[q + 1] - ql[q] - 1), (int32_t)(tl[t + 1] - tl[t] - 1), d0, d1 };
 	};
+	auto dp_size = [](const dmnd_dp_target& d) { return (int64_t)dmnd_banded_cols(d.query_len, d.target_len, d.d_begin, d.d_end) * (int64_t)(d.d_end - d.d_begin); };
 	double sw1 = 0, sw2 = 0, tb2 = 0;
 	int64_t used = 0;
 	std::vector<dmnd_dp_target> items;
@@ -437,34 +456,52 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 	// the traceback path (those go through the statistics kernels), or past the context's trace budget: then round 2 sweeps again.
 	static const bool keep_traces = [] { const char* e = std::getenv("DMND_EXTEND_KEEP_TRACE"); return !e || e[0] != '0'; }();
 	std::vector<KeptTrace> kts(8);
+	std::vector<std::vector<dmnd_hsp>> r2(nq);
 	for (;;) {
 		int arena_iter = 0;
 		// ---- inner loop: ranking chunks, round 1 (score only, or traceback mode with kept traces) ----
 		for (;;) {
-			std::vector<size_t> active;
-			for (size_t i = 0; i < qs.size(); ++i) if (!qs[i].done && qs[i].in_inner) active.push_back(i);
-			if (active.empty()) break;
-			parallel_for(active.size(), threads, [&](size_t a, int t) {
-				QueryState& s = qs[active[a]];
-				s.plan.clear();
-				plan_groups(h, ws[(size_t)t], s.w, s.w.i0, s.w.i1, qdata, ql.data(), tdata, tl.data(), h.use_cbs ? cbs : nullptr, s.plan);
+			// plan the current chunk of every query that is still ranking
+			parallel_each(T, [&](int t) {
+				Slice& me = sl[(size_t)t];
+				me.n_items = 0; me.any = false;
+				for (size_t i = slice_begin(t); i < slice_begin(t + 1); ++i) {
+					QueryState& s = qs[i];
+					if (s.done || !s.in_inner) continue;
+					me.any = true;
+					s.plan.clear();
+					plan_groups(h, ws[(size_t)t], s.w, s.w.i0, s.w.i1, qdata, ql.data(), tdata, tl.data(), h.use_cbs ? cbs : nullptr, s.plan);
+					me.n_items += s.plan.size();
+				}
 			});
-			items.clear();
-			for (size_t i : active) {
-				QueryState& s = qs[i];
-				s.item_begin = items.size();
-				for (const PlanTarget& p : s.plan) items.push_back(item_of(p.query, p.target, p.d_begin, p.d_end));
-				s.item_end = items.size();
-			}
+			bool any = false;
+			size_t total = 0;
+			for (Slice& x : sl) { any |= x.any; x.item_off = total; total += x.n_items; }
+			if (!any) break;
+			items.resize(total);
+			parallel_each(T, [&](int t) {
+				Slice& me = sl[(size_t)t];
+				size_t o = me.item_off;
+				me.cells = 0; me.keepable = true;
+				for (size_t i = slice_begin(t); i < slice_begin(t + 1); ++i) {
+					QueryState& s = qs[i];
+					if (s.done || !s.in_inner) continue;
+					s.item_begin = o;
+					for (const PlanTarget& p : s.plan) {
+						const dmnd_dp_target d = item_of(p.query, p.target, p.d_begin, p.d_end);
+						me.cells += cells_of(d);
+						me.keepable &= dp_size(d) <= h.max_swipe_dp;
+						items[o++] = d;
+					}
+					s.item_end = o;
+				}
+			});
 			lap(5, 4);
 			res.assign(items.size(), dmnd_hsp());
 			int arena = -1;
 			if (!items.empty()) {
 				bool keep = keep_traces && !transcript && arena_iter < (int)kts.size();
-				for (size_t x = 0; x < items.size() && keep; ++x) {
-					const dmnd_dp_target& d = items[x];
-					keep = (int64_t)dmnd_banded_cols(d.query_len, d.target_len, d.d_begin, d.d_end) * (int64_t)(d.d_end - d.d_begin) <= h.max_swipe_dp;
-				}
+				for (const Slice& x : sl) keep &= x.keepable;
 				if (keep) {
 					if (int rc = dmnd_swipe_keep(w, c, items.data(), (int64_t)items.size(), arena_iter, res.data(), kts[(size_t)arena_iter])) return rc;
 					if (kts[(size_t)arena_iter].kept) arena = arena_iter;
@@ -472,81 +509,100 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 				}
 				else if (int rc = dmnd_swipe_shared(w, c, items.data(), (int64_t)items.size(), DMND_SWIPE_SCORE, 0, res.data(), nullptr, 0, nullptr)) return rc;
 				sw1 += w->swipe_ms;
-				w->ext_stats[0] += (double)items.size(); w->ext_stats[2] += cells_of(items);
+				w->ext_stats[0] += (double)items.size();
+				for (const Slice& x : sl) w->ext_stats[2] += x.cells;
 			}
 			lap(6, 5);
-			parallel_for(active.size(), threads, [&](size_t ai, int) {
-				QueryState& s = qs[active[ai]];
-				// extend_chunk -> align (gapped_score.cpp:182-268): report cutoff, best HSP per target
+			parallel_each(T, [&](int t) {
 				std::vector<Cand> v;
-				for (size_t x = s.item_begin; x < s.item_end; ++x) {
-					const PlanTarget& p = s.plan[x - s.item_begin];
-					const int score = res[x].score;
-					if (score <= 0) continue;
-					const double ev = c->evaluer.evalue(score, (unsigned)items[x].query_len, (unsigned)items[x].target_len);
-					if (ev > c->params.max_evalue) continue;
-					const int frame = (int)(p.query % C);
-					if (!v.empty() && v.back().target == p.target) {
-						// Target::add_hit(list, it) (target.h:105-113): the best context is the first one (contexts ascending) that
-						// reaches the maximum score; inner_culling then keeps that context's best HSP by (score desc, d_begin asc)
-						// (Hsp::operator<, match.h:199)
-						Cand& k = v.back();
-						if (score > k.score || (score == k.score && frame == k.frame && p.d_begin < k.d_begin)) {
-							k.score = score; k.evalue = ev; k.d_begin = p.d_begin; k.d_end = p.d_end; k.frame = frame; k.arena = arena; k.item = (int64_t)x;
+				for (size_t qi = slice_begin(t); qi < slice_begin(t + 1); ++qi) {
+					QueryState& s = qs[qi];
+					if (s.done || !s.in_inner) continue;
+					// extend_chunk -> align (gapped_score.cpp:182-268): report cutoff, best HSP per target
+					v.clear();
+					for (size_t x = s.item_begin; x < s.item_end; ++x) {
+						const PlanTarget& p = s.plan[x - s.item_begin];
+						const int score = res[x].score;
+						if (score <= 0) continue;
+						const double ev = c->evaluer.evalue(score, (unsigned)items[x].query_len, (unsigned)items[x].target_len);
+						if (ev > c->params.max_evalue) continue;
+						const int frame = (int)(p.query % C);
+						if (!v.empty() && v.back().target == p.target) {
+							// Target::add_hit(list, it) (target.h:105-113): the best context is the first one (contexts ascending) that
+							// reaches the maximum score; inner_culling then keeps that context's best HSP by (score desc, d_begin asc)
+							// (Hsp::operator<, match.h:199)
+							Cand& k = v.back();
+							if (score > k.score || (score == k.score && frame == k.frame && p.d_begin < k.d_begin)) {
+								k.score = score; k.evalue = ev; k.d_begin = p.d_begin; k.d_end = p.d_end; k.frame = frame; k.arena = arena; k.item = (int64_t)x;
+							}
 						}
+						else v.push_back(Cand{ p.target, score, p.d_begin, p.d_end, p.ungapped_score, frame, ev, arena, (int64_t)x });
 					}
-					else v.push_back(Cand{ p.target, score, p.d_begin, p.d_end, p.ungapped_score, frame, ev, arena, (int64_t)x });
+					const bool multi_chunk = (s.w.i1 - s.w.i0) < s.w.order.size();
+					bool new_hits = s.new_hits_ev = !v.empty();
+					if (multi_chunk) new_hits = append_hits(s.aligned, v, K);
+					else s.aligned = v;
+					// advance the chunk window (extend.cpp:325-329)
+					s.w.i0 = s.w.i1;
+					s.w.i1 += std::min((size_t)s.w.chunk_size, s.w.order.size() - s.w.i1);
+					s.previous_tail_score = s.tail_score;
+					const int next_tail = s.w.groups[s.w.order[s.w.i1 - 1]].score;
+					if (new_hits) s.tail_score = next_tail;
+					// ranking_terminate (extend.cpp:111-119) with default options
+					const bool terminate = !new_hits && (s.previous_tail_score == 0
+						|| (double)next_tail / (double)s.previous_tail_score <= 0.95
+						|| c->evaluer.bitscore(next_tail) < 25.0);
+					if (!(s.w.i0 < s.w.order.size() && !terminate)) s.in_inner = false;
 				}
-				const bool multi_chunk = (s.w.i1 - s.w.i0) < s.w.order.size();
-				bool new_hits = s.new_hits_ev = !v.empty();
-				if (multi_chunk) new_hits = append_hits(s.aligned, v, K);
-				else s.aligned = v;
-				// advance the chunk window (extend.cpp:325-329)
-				s.w.i0 = s.w.i1;
-				s.w.i1 += std::min((size_t)s.w.chunk_size, s.w.order.size() - s.w.i1);
-				s.previous_tail_score = s.tail_score;
-				const int next_tail = s.w.groups[s.w.order[s.w.i1 - 1]].score;
-				if (new_hits) s.tail_score = next_tail;
-				// ranking_terminate (extend.cpp:111-119) with default options
-				const bool terminate = !new_hits && (s.previous_tail_score == 0
-					|| (double)next_tail / (double)s.previous_tail_score <= 0.95
-					|| c->evaluer.bitscore(next_tail) < 25.0);
-				if (!(s.w.i0 < s.w.order.size() && !terminate)) s.in_inner = false;
 			});
 			lap(7, 6);
 		}
 		// ---- round 2 for every query that just left the inner loop ----
-		std::vector<size_t> batch;
-		for (size_t i = 0; i < qs.size(); ++i) if (!qs[i].done && !qs[i].in_inner) batch.push_back(i);
-		if (batch.empty()) break;
-		std::vector<dmnd_dp_target> it_tb, it_st;
-		struct Ref { size_t q, k; };
-		std::vector<Ref> ref_tb, ref_st;
-		struct KeptGroup { std::vector<dmnd_dp_target> items; std::vector<int64_t> src; std::vector<Ref> ref; };
-		std::vector<KeptGroup> kept(kts.size());
-		for (size_t i : batch) {
-			QueryState& s = qs[i];
-			cull(s.aligned, false, K);                                          // extend.cpp:331
-			for (size_t k = 0; k < s.aligned.size(); ++k) {
-				const Cand& cd = s.aligned[k];
-				const dmnd_dp_target d = item_of(s.w.query * C + (uint32_t)cd.frame, cd.target, cd.d_begin, cd.d_end);
-				const int64_t dp_size = (int64_t)dmnd_banded_cols(d.query_len, d.target_len, d.d_begin, d.d_end) * (int64_t)(d.d_end - d.d_begin);
-				if (dp_size > h.max_swipe_dp) { it_st.push_back(d); ref_st.push_back(Ref{ i, k }); }      // DP::BandedSwipe::bin
-				else if (cd.arena >= 0) { KeptGroup& g = kept[(size_t)cd.arena]; g.items.push_back(d); g.src.push_back(cd.item); g.ref.push_back(Ref{ i, k }); }
-				else { it_tb.push_back(d); ref_tb.push_back(Ref{ i, k }); }
+		parallel_each(T, [&](int t) {
+			Slice& me = sl[(size_t)t];
+			me.any = false;
+			me.kept.assign(kts.size(), KeptGroup());
+			me.it_tb.clear(); me.it_st.clear(); me.ref_tb.clear(); me.ref_st.clear();
+			for (size_t i = slice_begin(t); i < slice_begin(t + 1); ++i) {
+				QueryState& s = qs[i];
+				if (s.done || s.in_inner) continue;
+				me.any = true;
+				cull(s.aligned, false, K);                                          // extend.cpp:331
+				r2[i].assign(s.aligned.size(), dmnd_hsp());
+				for (size_t k = 0; k < s.aligned.size(); ++k) {
+					const Cand& cd = s.aligned[k];
+					const dmnd_dp_target d = item_of(s.w.query * C + (uint32_t)cd.frame, cd.target, cd.d_begin, cd.d_end);
+					if (dp_size(d) > h.max_swipe_dp) { me.it_st.push_back(d); me.ref_st.push_back(Ref{ i, k }); }      // DP::BandedSwipe::bin
+					else if (cd.arena >= 0) { KeptGroup& g = me.kept[(size_t)cd.arena]; g.items.push_back(d); g.src.push_back(cd.item); g.ref.push_back(Ref{ i, k }); }
+					else { me.it_tb.push_back(d); me.ref_tb.push_back(Ref{ i, k }); }
+				}
 			}
-		}
+		});
+		bool any_batch = false;
+		for (const Slice& x : sl) any_batch |= x.any;
+		if (!any_batch) break;
+		// the slices' lists, concatenated in slice order (= query order)
+		auto gather = [&](auto pick_items, auto pick_refs, std::vector<dmnd_dp_target>& its, std::vector<Ref>& refs) {
+			its.clear(); refs.clear();
+			for (Slice& x : sl) { its.insert(its.end(), pick_items(x).begin(), pick_items(x).end()); refs.insert(refs.end(), pick_refs(x).begin(), pick_refs(x).end()); }
+		};
+		std::vector<dmnd_dp_target> it_tb, it_st, it_k;
+		std::vector<Ref> ref_tb, ref_st, ref_k;
+		std::vector<int64_t> src_k;
+		gather([](Slice& x) -> std::vector<dmnd_dp_target>& { return x.it_tb; }, [](Slice& x) -> std::vector<Ref>& { return x.ref_tb; }, it_tb, ref_tb);
+		gather([](Slice& x) -> std::vector<dmnd_dp_target>& { return x.it_st; }, [](Slice& x) -> std::vector<Ref>& { return x.ref_st; }, it_st, ref_st);
 		lap(7, 7);
-		std::vector<std::vector<dmnd_hsp>> r2(qs.size());
-		for (size_t i : batch) r2[i].assign(qs[i].aligned.size(), dmnd_hsp());
-		for (size_t a = 0; a < kept.size(); ++a) {                               // walks over the traces kept by round 1
-			KeptGroup& g = kept[a];
-			if (g.items.empty()) continue;
-			res.assign(g.items.size(), dmnd_hsp());
-			if (int rc = dmnd_traceback_kept(w, c, g.items.data(), kts[a], g.src.data(), (int64_t)g.items.size(), res.data())) return rc;
-			for (size_t x = 0; x < g.ref.size(); ++x) r2[g.ref[x].q][g.ref[x].k] = res[x];
+		for (size_t a = 0; a < kts.size(); ++a) {                               // walks over the traces kept by round 1
+			gather([a](Slice& x) -> std::vector<dmnd_dp_target>& { return x.kept[a].items; }, [a](Slice& x) -> std::vector<Ref>& { return x.kept[a].ref; }, it_k, ref_k);
+			if (it_k.empty()) continue;
+			src_k.clear();
+			for (Slice& x : sl) src_k.insert(src_k.end(), x.kept[a].src.begin(), x.kept[a].src.end());
+			res.assign(it_k.size(), dmnd_hsp());
+			if (int rc = dmnd_traceback_kept(w, c, it_k.data(), kts[a], src_k.data(), (int64_t)it_k.size(), res.data())) return rc;
+			for (size_t x = 0; x < ref_k.size(); ++x) r2[ref_k[x].q][ref_k[x].k] = res[x];
 			tb2 += w->traceback_ms;
-			w->ext_stats[1] += (double)g.items.size(); w->ext_stats[3] += cells_of(g.items);      // the reference's round-2 targets and cells
+			w->ext_stats[1] += (double)it_k.size();                              // the reference's round-2 targets and cells
+			for (const dmnd_dp_target& d : it_k) w->ext_stats[3] += cells_of(d);
 		}
 		if (!it_tb.empty()) {
 			uint8_t* arena = transcript ? transcript + used : nullptr;           // NULL: statistics only, no transcripts copied back
@@ -567,71 +623,80 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 			for (size_t x = 0; x < ref_st.size(); ++x) { r2[ref_st[x].q][ref_st[x].k] = res[x]; r2[ref_st[x].q][ref_st[x].k].transcript_len = 0; r2[ref_st[x].q][ref_st[x].k].transcript_off = -1; }
 			sw2 += w->swipe_ms;
 		}
-		w->ext_stats[1] += (double)(it_tb.size() + it_st.size()); w->ext_stats[3] += cells_of(it_tb) + cells_of(it_st);
+		w->ext_stats[1] += (double)(it_tb.size() + it_st.size());
+		for (const dmnd_dp_target& d : it_tb) w->ext_stats[3] += cells_of(d);
+		for (const dmnd_dp_target& d : it_st) w->ext_stats[3] += cells_of(d);
 		lap(8, 8);
-		parallel_for(batch.size(), threads, [&](size_t bi, int) {
-			const size_t i = batch[bi];
-			QueryState& s = qs[i];
-			// align() round 2 (gapped_final.cpp:80-160): report cutoff again, culling of this round's matches
+		parallel_each(T, [&](int t) {
 			std::vector<dmnd_match> round;
-			const uint32_t q = s.w.query;
-			for (size_t k = 0; k < s.aligned.size(); ++k) {
-				const Cand& cd = s.aligned[k];
-				const dmnd_hsp& hsp = r2[i][k];
-				if (hsp.score <= 0) continue;
-				const int tlen = (int)(tl[cd.target + 1] - tl[cd.target] - 1);
-				const uint32_t qc = q * C + (uint32_t)cd.frame;
-				const int qlen = (int)(ql[qc + 1] - ql[qc] - 1);
-				const double ev = c->evaluer.evalue(hsp.score, (unsigned)qlen, (unsigned)tlen);
-				if (ev > c->params.max_evalue) continue;
-				dmnd_match m;
-				m.query = q; m.target = cd.target; m.evalue = ev; m.bit_score = c->evaluer.bitscore(hsp.score);
-				m.ungapped_score = cd.ungapped; m.d_begin = cd.d_begin; m.d_end = cd.d_end; m.frame = cd.frame; m.hsp = hsp;
-				round.push_back(m);
+			for (size_t i = slice_begin(t); i < slice_begin(t + 1); ++i) {
+				QueryState& s = qs[i];
+				if (s.done || s.in_inner) continue;
+				// align() round 2 (gapped_final.cpp:80-160): report cutoff again, culling of this round's matches
+				round.clear();
+				const uint32_t q = s.w.query;
+				for (size_t k = 0; k < s.aligned.size(); ++k) {
+					const Cand& cd = s.aligned[k];
+					const dmnd_hsp& hsp = r2[i][k];
+					if (hsp.score <= 0) continue;
+					const int tlen = (int)(tl[cd.target + 1] - tl[cd.target] - 1);
+					const uint32_t qc = q * C + (uint32_t)cd.frame;
+					const int qlen = (int)(ql[qc + 1] - ql[qc] - 1);
+					const double ev = c->evaluer.evalue(hsp.score, (unsigned)qlen, (unsigned)tlen);
+					if (ev > c->params.max_evalue) continue;
+					dmnd_match m;
+					m.query = q; m.target = cd.target; m.evalue = ev; m.bit_score = c->evaluer.bitscore(hsp.score);
+					m.ungapped_score = cd.ungapped; m.d_begin = cd.d_begin; m.d_end = cd.d_end; m.frame = cd.frame; m.hsp = hsp;
+					round.push_back(m);
+				}
+				std::sort(round.begin(), round.end(), match_less);
+				if ((int)round.size() > K) round.resize((size_t)K);
+				s.matches.insert(s.matches.end(), round.begin(), round.end());
+				s.aligned.clear();
+				// outer loop condition (extend.cpp:336)
+				if ((int)s.matches.size() < K && s.w.i0 < s.w.order.size() && s.new_hits_ev) s.in_inner = true;
+				else s.done = true;
 			}
-			std::sort(round.begin(), round.end(), match_less);
-			if ((int)round.size() > K) round.resize((size_t)K);
-			s.matches.insert(s.matches.end(), round.begin(), round.end());
-			s.aligned.clear();
-			// outer loop condition (extend.cpp:336)
-			if ((int)s.matches.size() < K && s.w.i0 < s.w.order.size() && s.new_hits_ev) s.in_inner = true;
-			else s.done = true;
 		});
 		lap(7, 9);
 	}
 	w->swipe_ms = sw1 + sw2; w->traceback_ms = tb2;
 	w->ext_stats[9] = sw1; w->ext_stats[10] = sw2; w->ext_stats[11] = tb2;
 	if (transcript_used) *transcript_used = transcript ? used : 0;
-	// final culling(matches, cfg) per query (extend.cpp:341) -> records in query order; sorting, copying out and releasing the
-	// per-query state (tens of thousands of small blocks: serial frees cost ~3 ms on C2) all run on the worker threads
-	std::vector<int64_t> out_off(qs.size() + 1, 0);
-	{
-		const size_t chunk = 64, n_chunks = (qs.size() + chunk - 1) / chunk;
-		parallel_for(n_chunks, threads, [&](size_t ci, int) {
-			for (size_t i = ci * chunk; i < std::min(qs.size(), (ci + 1) * chunk); ++i) {
-				QueryState& s = qs[i];
-				std::sort(s.matches.begin(), s.matches.end(), match_less);
-				if ((int)s.matches.size() > K) s.matches.resize((size_t)K);
-				out_off[i + 1] = (int64_t)s.matches.size();
-			}
-		});
-		for (size_t i = 0; i < qs.size(); ++i) out_off[i + 1] += out_off[i];
-		out_matches.resize((size_t)out_off[qs.size()]);
-		parallel_for(n_chunks, threads, [&](size_t ci, int) {
-			for (size_t i = ci * chunk; i < std::min(qs.size(), (ci + 1) * chunk); ++i) {
-				std::copy(qs[i].matches.begin(), qs[i].matches.end(), out_matches.begin() + out_off[i]);
-				QueryState empty;
-				std::swap(qs[i], empty);
-			}
-		});
-	}
+	// final culling(matches, cfg) per query (extend.cpp:341) -> records in query order; every slice sorts, copies out and releases
+	// the state of its own queries
+	parallel_each(T, [&](int t) {
+		Slice& me = sl[(size_t)t];
+		me.n_matches = 0;
+		for (size_t i = slice_begin(t); i < slice_begin(t + 1); ++i) {
+			QueryState& s = qs[i];
+			std::sort(s.matches.begin(), s.matches.end(), match_less);
+			if ((int)s.matches.size() > K) s.matches.resize((size_t)K);
+			me.n_matches += s.matches.size();
+		}
+	});
+	size_t total_matches = 0;
+	for (Slice& x : sl) { x.match_off = total_matches; total_matches += x.n_matches; }
+	out_matches.resize(total_matches);
+	parallel_each(T, [&](int t) {
+		size_t o = sl[(size_t)t].match_off;
+		for (size_t i = slice_begin(t); i < slice_begin(t + 1); ++i) {
+			std::copy(qs[i].matches.begin(), qs[i].matches.end(), out_matches.begin() + (ptrdiff_t)o);
+			o += qs[i].matches.size();
+			QueryState empty;
+			std::swap(qs[i], empty);
+			std::vector<dmnd_hsp>().swap(r2[i]);
+		}
+		Slice fresh;
+		std::swap(sl[(size_t)t], fresh);
+	});
 	lap(7, 10);
 	if (const char* tr = std::getenv("DMND_TRACE")) if (tr[0] == '2')
 		std::fprintf(stderr, "  timeline[%zu queries] enter %.2f | bias %.2f load %.2f plan %.2f swipe1 %.2f post1 %.2f build2 %.2f swipe2 %.2f post2 %.2f final %.2f\n",
 			qs.size(), t_enter - g_extend_t0, at[1], at[3], at[4], at[5], at[6], at[7], at[8], at[9], at[10]);
 	if (std::getenv("DMND_TRACE"))
-		std::fprintf(stderr, "dmnd_extend[%zu queries] ms: bias %.2f load %.2f plan %.2f swipe1 %.2f post1 %.2f build2 %.2f swipe2 %.2f post2 %.2f final %.2f | swipe host: prep %.2f run %.2f post %.2f\n",
-			qs.size(), fine[1], fine[3], fine[4], fine[5], fine[6], fine[7], fine[8], fine[9], fine[10], w->host_ms[0], w->host_ms[1], w->host_ms[2]);
+		std::fprintf(stderr, "dmnd_extend[%zu queries, %d slices] ms: bias %.2f load %.2f plan %.2f swipe1 %.2f post1 %.2f build2 %.2f swipe2 %.2f post2 %.2f final %.2f | swipe host: prep %.2f run %.2f post %.2f\n",
+			qs.size(), T, fine[1], fine[3], fine[4], fine[5], fine[6], fine[7], fine[8], fine[9], fine[10], w->host_ms[0], w->host_ms[1], w->host_ms[2]);
 	return DMND_OK;
 }
 

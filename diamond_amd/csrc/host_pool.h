@@ -33,14 +33,25 @@ public:
 		cv_.notify_all();
 		for (auto& t : th_) t.join();
 	}
+	// f(t) once on each of `threads` participants, participant t always being the same OS thread (the caller is 0): work that
+	// is cut into one fixed slice per participant stays in that core's caches from one parallel phase of a call to the next
 	template<typename F>
-	void run(size_t n, int threads, F& f)
+	void run_each(int threads, F& f)
+	{
+		auto g = [&f](size_t, int t) { f(t); };
+		run_impl((size_t)threads, threads, g, true);
+	}
+	template<typename F>
+	void run(size_t n, int threads, F& f) { run_impl(n, threads, f, false); }
+private:
+	template<typename F>
+	void run_impl(size_t n, int threads, F& f, bool each)
 	{
 		std::unique_lock<std::mutex> own(busy_, std::try_to_lock);
 		if (!own.owns_lock()) {                              // another context is using the pool: plain threads for this loop
 			std::vector<std::thread> th;
 			std::atomic<size_t> next(0);
-			for (int t = 0; t < threads; ++t) th.emplace_back([&, t] { size_t i; while ((i = next.fetch_add(1)) < n) f(i, t); });
+			for (int t = 0; t < threads; ++t) th.emplace_back([&, t] { if (each) { f((size_t)t, t); return; } size_t i; while ((i = next.fetch_add(1)) < n) f(i, t); });
 			for (auto& x : th) x.join();
 			return;
 		}
@@ -48,14 +59,14 @@ public:
 		std::function<void(size_t, int)> fn = [&f](size_t i, int t) { f(i, t); };
 		{
 			std::lock_guard<std::mutex> g(m_);
-			fn_ = &fn; n_ = n; next_.store(0); want_ = threads - 1; want_a_.store(threads - 1);
+			fn_ = &fn; n_ = n; each_ = each; next_.store(0); want_ = threads - 1; want_a_.store(threads - 1);
 			running_.store(threads - 1);
 			++gen_;
 			gen_a_.store(gen_, std::memory_order_release);      // publishes the job to the spinning workers
 		}
 		cv_.notify_all();
-		size_t i;
-		while ((i = next_.fetch_add(1)) < n) f(i, 0);
+		if (each) f(0, 0);
+		else { size_t i; while ((i = next_.fetch_add(1)) < n) f(i, 0); }
 		for (int s = 0, n = spins() * 8; s < n && running_.load(std::memory_order_acquire) != 0; ++s) cpu_relax();
 		if (running_.load(std::memory_order_acquire) != 0) {
 			std::unique_lock<std::mutex> g(m_);
@@ -63,7 +74,6 @@ public:
 		}
 		fn_ = nullptr;
 	}
-private:
 	// iterations of the spin phase (a pause instruction each, ~25 ns): long enough to catch the next of a run of back-to-back
 	// loops, short enough not to eat a CPU quota with dozens of idle spinning workers (DMND_POOL_SPINS overrides)
 	static int spins()
@@ -93,8 +103,8 @@ private:
 					seen = gen_a_.load(std::memory_order_acquire);
 					const std::function<void(size_t, int)>* fn = fn_;
 					const size_t n = n_;
-					size_t i;
-					while ((i = next_.fetch_add(1)) < n) (*fn)(i, id);
+					if (each_) (*fn)((size_t)id, id);
+					else { size_t i; while ((i = next_.fetch_add(1)) < n) (*fn)(i, id); }
 					if (running_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
 						std::lock_guard<std::mutex> g(m_);           // pairs with the predicate check of the waiting caller
 						done_.notify_one();
@@ -108,6 +118,7 @@ private:
 	std::condition_variable cv_, done_;
 	const std::function<void(size_t, int)>* fn_ = nullptr;
 	size_t n_ = 0;
+	bool each_ = false;
 	std::atomic<size_t> next_{ 0 };
 	int want_ = 0;
 	std::atomic<int> want_a_{ 0 }, running_{ 0 };
@@ -122,6 +133,14 @@ enum { MAX_POOLS = 16 };
 // their own pool with set_thread_pool(k) (k < MAX_POOLS); every other thread shares the default pool. Defined in extend_host.hip.
 WorkerPool& pool();
 void set_thread_pool(int k);
+
+// f(t) for t in [0, threads), participant t pinned to one thread of the calling thread's pool
+template<typename F>
+void parallel_each(int threads, F f)
+{
+	if (threads <= 1) { f(0); return; }
+	pool().run_each(threads, f);
+}
 
 template<typename F>
 void parallel_for(size_t n, int threads, F f)

@@ -1,4 +1,8 @@
-// chain_host.h -- host-side (CPU, per target) part of the extension stage that fixes the band geometry of the
+// oracle/chain_ref.h -- TEST INFRASTRUCTURE ONLY (the checker of diamond_amd/csrc/chain_graph.h; never compiled into the product).
+// Round 1's host-side chaining: a statement-by-statement restatement of the reference's functions listed below, which is why
+// it was retired from the product path. It stays here as the known-good answer for tests/test_chain_graph.py: it reproduced
+// the reference's DpTargets on every golden of round 1 (tests/test_extend_plan.py).
+// Original header: host-side (CPU, per target) part of the extension stage that fixes the band geometry of the
 // GPU Smith-Waterman: x-drop ungapped extension of the seed hits and greedy chaining of the resulting diagonal
 // segments into approximate HSPs. Branchy, tiny per target, stays on the host.
 //
@@ -18,13 +22,14 @@
 // thread-local graph object + std::map window + std::list outputs.
 #pragma once
 #include <stdint.h>
+#include <stddef.h>
 #include <algorithm>
 #include <climits>
 #include <cstdlib>
 #include <map>
 #include <vector>
 
-namespace dmnd {
+namespace dmnd_ref {
 
 struct ScoreTable {                // ScoreMatrix::operator()(a,b) = matrix32[a*32+b] on masked letters
 	int m[32 * 32];
@@ -459,4 +464,4 @@ struct ChainWorkspace {
 	}
 };
 
-}  // namespace dmnd
+}  // namespace dmnd_ref
