@@ -73,6 +73,16 @@ void dmnd::forget_stream(hipStream_t s)
 	(void)hipEventDestroy(ev);
 }
 
+int dmnd::PinBuf::ensure(size_t bytes)
+{
+	if (bytes <= cap) return DMND_OK;
+	release();
+	const size_t want = bytes + bytes / 2 + 4096;
+	if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; return fail(DMND_E_NOMEM, "hipHostMalloc of " + std::to_string(want) + " bytes failed"); }
+	cap = want;
+	return DMND_OK;
+}
+
 int dmnd::DevBuf::ensure(size_t bytes)
 {
 	if (bytes <= cap)
@@ -155,6 +165,8 @@ extern "C" void dmnd_destroy(dmnd_ctx* c)
 	if (c->sort_tmp) { (void)hipFree(c->sort_tmp); c->sort_tmp = nullptr; c->sort_tmp_bytes = 0; }
 	if (c->pinned_cbs) (void)hipHostFree(c->pinned_cbs);
 	for (DevBuf& kb : c->keep_trace) kb.release();
+	c->stage_h.release(); c->ends_h.release(); c->stage_d.release();
+	delete c->kts; c->kts = nullptr;
 	for (dmnd_ctx* a : c->aux) dmnd_destroy(a);
 	c->aux.clear();
 	(void)hipSetDevice(c->device);
@@ -291,26 +303,20 @@ bool force_swipe32()
 	return v;
 }
 
-// Launches the sweep of `slots` (grouped by class P ascending, longest first inside a class) on work's stream: per class
-// the packed-int16 kernel with two items per wavefront (neighbours in launch order = similar lengths) when the class is
-// eligible, else the 32-bit kernel with one item per wavefront. kmode: K_SCORE / K_COORDS / K_TRACE.
-// order_dev: slot -> item (device, as uploaded by the caller); trace_off_slot_dev: slot-indexed offsets for the 32-bit kernel;
-// trace_off_slot: the same on the host. force32: re-run of items that saturated 16 bits.
-int launch_sweeps(dmnd_ctx* work, const Bases& b, const dmnd_dp_target* d_items, int64_t n_items_total, const std::vector<Slot>& slots,
-	const int32_t* order_dev, const int64_t* trace_off_slot_dev, const std::vector<int64_t>* trace_off_slot, uint8_t* trace_dev, int kmode, bool force32)
+struct SweepLaunch { int64_t s0, s1; bool k16; int64_t pair0; };
+
+// One launch per band class of `slots` (grouped by class P ascending, longest first inside a class): the packed-int16 kernel
+// with two items per wavefront (neighbours in launch order = similar lengths) when the class is eligible, else the 32-bit kernel
+// with one item per wavefront. kmode: K_SCORE / K_COORDS / K_TRACE. pairs receives the item pairs of the 16-bit launches.
+void plan_sweeps(const std::vector<Slot>& slots, int kmode, bool force32, std::vector<SweepLaunch>& launches, std::vector<int32_t>& pairs)
 {
 	const int64_t n = (int64_t)slots.size();
-	const bool trace = kmode == K_TRACE;
-	// which classes go through the 16-bit kernel
-	std::vector<int32_t>& pairs = work->h_pairs;
-	pairs.clear();
-	struct Launch { int64_t s0, s1; bool k16; int64_t pair0; };
-	std::vector<Launch> launches;
+	launches.clear(); pairs.clear();
 	for (int64_t s0 = 0; s0 < n;) {
 		int64_t s1 = s0, max_steps = 0;
 		while (s1 < n && slots[(size_t)s1].P == slots[(size_t)s0].P) { max_steps = std::max(max_steps, slots[(size_t)s1].steps); ++s1; }
 		const bool k16 = !force32 && !force_swipe32() && kmode <= K_TRACE && slots[(size_t)s0].P <= SW16_MAX_P && max_steps <= 2 * (int64_t)SW16_MAX_PAIRS;
-		launches.push_back(Launch{ s0, s1, k16, (int64_t)pairs.size() / 2 });
+		launches.push_back(SweepLaunch{ s0, s1, k16, (int64_t)pairs.size() / 2 });
 		if (k16)
 			for (int64_t s = s0; s < s1; s += 2) {
 				pairs.push_back(slots[(size_t)s].item);
@@ -318,26 +324,21 @@ int launch_sweeps(dmnd_ctx* work, const Bases& b, const dmnd_dp_target* d_items,
 			}
 		s0 = s1;
 	}
-	if (!pairs.empty()) {
-		if (int rc = work->pairs.ensure(pairs.size() * sizeof(int32_t))) return rc;
-		HIP_TRY(hipMemcpyAsync(work->pairs.p, pairs.data(), pairs.size() * sizeof(int32_t), hipMemcpyHostToDevice, work->stream));
-		if (trace) {
-			// the 16-bit kernel addresses trace rows by item index
-			std::vector<int64_t>& by_item = work->h_trace_off_item;
-			by_item.assign((size_t)n_items_total, 0);
-			for (int64_t s = 0; s < n; ++s) by_item[(size_t)slots[(size_t)s].item] = (*trace_off_slot)[(size_t)s];
-			if (int rc = work->trace_off_item.ensure(by_item.size() * sizeof(int64_t))) return rc;
-			HIP_TRY(hipMemcpyAsync(work->trace_off_item.p, by_item.data(), by_item.size() * sizeof(int64_t), hipMemcpyHostToDevice, work->stream));
-		}
-	}
-	for (const Launch& l : launches) {
+}
+
+// order_dev / trace_off_slot_dev: slot-indexed (32-bit kernel); pairs_dev / trace_off_item_dev: for the 16-bit kernel
+int issue_sweeps(dmnd_ctx* work, const Bases& b, const dmnd_dp_target* d_items, const std::vector<Slot>& slots, const std::vector<SweepLaunch>& launches,
+	const int32_t* order_dev, const int64_t* trace_off_slot_dev, const int32_t* pairs_dev, const int64_t* trace_off_item_dev, uint8_t* trace_dev, int kmode)
+{
+	const bool trace = kmode == K_TRACE;
+	for (const SweepLaunch& l : launches) {
 		const int P = slots[(size_t)l.s0].P;
 		if (l.k16) {
 			Swipe16Args a;
 			a.qblock = b.q; a.tblock = b.t; a.cbs = b.cbs; a.matrix = work->matrix.as<int8_t>();
 			a.items = d_items;
-			a.pairs = work->pairs.as<int32_t>() + 2 * l.pair0;
-			a.trace_off = trace ? work->trace_off_item.as<int64_t>() : nullptr;
+			a.pairs = pairs_dev + 2 * l.pair0;
+			a.trace_off = trace ? trace_off_item_dev : nullptr;
 			a.trace = trace ? trace_dev : nullptr;
 			a.ends = work->ends.as<SwipeEnd>();
 			a.n_pairs = (l.s1 - l.s0 + 1) / 2;
@@ -358,6 +359,48 @@ int launch_sweeps(dmnd_ctx* work, const Bases& b, const dmnd_dp_target* d_items,
 		}
 	}
 	return DMND_OK;
+}
+
+// plan + upload of the 16-bit kernel's arrays + issue (the general path; dmnd_swipe_keep packs its own single upload)
+int launch_sweeps(dmnd_ctx* work, const Bases& b, const dmnd_dp_target* d_items, int64_t n_items_total, const std::vector<Slot>& slots,
+	const int32_t* order_dev, const int64_t* trace_off_slot_dev, const std::vector<int64_t>* trace_off_slot, uint8_t* trace_dev, int kmode, bool force32)
+{
+	const int64_t n = (int64_t)slots.size();
+	const bool trace = kmode == K_TRACE;
+	std::vector<SweepLaunch> launches;
+	std::vector<int32_t>& pairs = work->h_pairs;
+	plan_sweeps(slots, kmode, force32, launches, pairs);
+	if (!pairs.empty()) {
+		if (int rc = work->pairs.ensure(pairs.size() * sizeof(int32_t))) return rc;
+		HIP_TRY(hipMemcpyAsync(work->pairs.p, pairs.data(), pairs.size() * sizeof(int32_t), hipMemcpyHostToDevice, work->stream));
+		if (trace) {
+			// the 16-bit kernel addresses trace rows by item index
+			std::vector<int64_t>& by_item = work->h_trace_off_item;
+			by_item.assign((size_t)n_items_total, 0);
+			for (int64_t s = 0; s < n; ++s) by_item[(size_t)slots[(size_t)s].item] = (*trace_off_slot)[(size_t)s];
+			if (int rc = work->trace_off_item.ensure(by_item.size() * sizeof(int64_t))) return rc;
+			HIP_TRY(hipMemcpyAsync(work->trace_off_item.p, by_item.data(), by_item.size() * sizeof(int64_t), hipMemcpyHostToDevice, work->stream));
+		}
+	}
+	return issue_sweeps(work, b, d_items, slots, launches, order_dev, trace_off_slot_dev, work->pairs.as<int32_t>(), work->trace_off_item.as<int64_t>(), trace_dev, kmode);
+}
+
+// classes ascending, longest items first inside a class (load balance): a bucket sort on (P, steps / 16) is O(n) and enough --
+// the exact order inside a bucket does not matter (results are written by item index)
+void order_slots(std::vector<Slot>& v, std::vector<Slot>& tmp, std::vector<uint32_t>& count)
+{
+	if (v.size() < 2048) {
+		std::sort(v.begin(), v.end(), [](const Slot& x, const Slot& y) { return x.P < y.P || (x.P == y.P && x.steps > y.steps); });
+		return;
+	}
+	const int NB = 1024;
+	count.assign((size_t)33 * NB + 1, 0);
+	auto bucket = [&](const Slot& x) { return (size_t)x.P * NB + (size_t)(NB - 1 - std::min<int64_t>(x.steps >> 4, NB - 1)); };
+	for (const Slot& x : v) ++count[bucket(x) + 1];
+	for (size_t i = 1; i < count.size(); ++i) count[i] += count[i - 1];
+	tmp.resize(v.size());
+	for (const Slot& x : v) tmp[count[bucket(x)]++] = x;
+	v.swap(tmp);
 }
 
 // Runs one chunk of items [begin, end) (indices into `items`), all modes.
@@ -483,19 +526,9 @@ int swipe_impl(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, int64_t
 	std::vector<SwipeEnd> ends((size_t)n);
 	std::vector<dmnd_hsp> hsps;
 	auto by_class = [](const Slot& x, const Slot& y) { return x.P < y.P || (x.P == y.P && x.steps > y.steps); };
-	// launch order: classes ascending, inside a class longest items first (load balance). A bucket sort on (P, steps / 16) is
-	// enough for that and is O(n); exact order inside a bucket does not matter (results are written by item index).
-	auto order_slots = [&](std::vector<Slot>& v) {
-		if (v.size() < 2048) { std::sort(v.begin(), v.end(), by_class); return; }
-		const int NB = 1024;
-		std::vector<uint32_t> count((size_t)33 * NB + 1, 0);
-		auto bucket = [&](const Slot& x) { return (size_t)x.P * NB + (size_t)(NB - 1 - std::min<int64_t>(x.steps >> 4, NB - 1)); };
-		for (const Slot& x : v) ++count[bucket(x) + 1];
-		for (size_t i = 1; i < count.size(); ++i) count[i] += count[i - 1];
-		std::vector<Slot> out(v.size());
-		for (const Slot& x : v) out[count[bucket(x)]++] = x;
-		v.swap(out);
-	};
+	std::vector<Slot> sort_tmp;
+	std::vector<uint32_t> sort_count;
+	auto order_slots = [&](std::vector<Slot>& v) { ::order_slots(v, sort_tmp, sort_count); };
 	if (kmode != K_TRACE) {
 		order_slots(slots);
 		lap(0);
@@ -641,83 +674,98 @@ int dmnd_swipe_shared(dmnd_ctx* work, const dmnd_ctx* c, const dmnd_dp_target* i
 
 int dmnd_swipe_keep(dmnd_ctx* work, const dmnd_ctx* c, const dmnd_dp_target* items, int64_t n, int arena, dmnd_hsp* out, KeptTrace& kt)
 {
-	kt = KeptTrace();
-	kt.arena = arena;
+	kt.arena = arena; kt.kept = false;          // the vectors keep their capacity from call to call
 	if (!c || !work) return fail(DMND_E_ARG, "ctx is NULL");
 	if (n == 0) return DMND_OK;
-	// trace bytes of the whole call; past the budget (or with an unusable item) the plain score-only call does the job and reports errors
+	const Bases b{ c->block[DMND_QUERY].as<int8_t>(), c->block_len[DMND_QUERY], c->block[DMND_TARGET].as<int8_t>(), c->block_len[DMND_TARGET],
+		c->cbs_len > 0 ? c->cbs.as<int8_t>() : nullptr, c->cbs_len };
+	auto wall = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	const double t0 = wall();
+	// One pass over the items: geometry, class, trace rows, range checks. Past the trace budget (or with an item the traceback
+	// path cannot take) the plain score-only call does the job and reports the errors.
 	int64_t total = 0;
-	bool usable = arena >= 0 && arena < 16 && n <= 0x7fffffff;
-	std::vector<Slot> slots((size_t)n);
+	bool usable = arena >= 0 && arena < 16 && n <= 0x7fffffff, in_range = true;
+	static thread_local std::vector<Slot> slots, sort_tmp;
+	static thread_local std::vector<uint32_t> sort_count;
+	static thread_local std::vector<int64_t> rows_of;
+	slots.resize((size_t)n); rows_of.resize((size_t)n);
 	for (int64_t i = 0; i < n && usable; ++i) {
 		const dmnd_dp_target& it = items[i];
 		const int band = it.d_end - it.d_begin;
 		if (band <= 0 || it.query_len <= 0 || it.target_len <= 0 || band_class(band) > 32) { usable = false; break; }
+		in_range &= !(it.query_off < 0 || it.target_off < 0 || it.query_off + it.query_len > b.q_len || it.target_off + it.target_len > b.t_len
+			|| (it.cbs_off >= 0 && (!b.cbs || it.cbs_off + it.query_len > b.cbs_len)));
 		const Geom g = make_geom(it.query_len, it.target_len, it.d_begin, it.d_end);
-		slots[(size_t)i] = Slot{ (int32_t)i, band_class(band), n_steps(g) };
-		total += trace_rows(g) * 64 * slots[(size_t)i].P;
+		const int P = band_class(band);
+		slots[(size_t)i] = Slot{ (int32_t)i, P, n_steps(g) };
+		rows_of[(size_t)i] = trace_rows(g) * 64 * P;
+		total += rows_of[(size_t)i];
 	}
 	if (!usable || (size_t)total > work->trace_arena_max)
 		return dmnd_swipe_shared(work, c, items, n, DMND_SWIPE_SCORE, 0, out, nullptr, 0, nullptr);
-	const Bases b{ c->block[DMND_QUERY].as<int8_t>(), c->block_len[DMND_QUERY], c->block[DMND_TARGET].as<int8_t>(), c->block_len[DMND_TARGET],
-		c->cbs_len > 0 ? c->cbs.as<int8_t>() : nullptr, c->cbs_len };
-	for (int64_t i = 0; i < n; ++i) {
-		const dmnd_dp_target& it = items[i];
-		if (it.query_off < 0 || it.target_off < 0 || it.query_off + it.query_len > b.q_len || it.target_off + it.target_len > b.t_len
-			|| (it.cbs_off >= 0 && (!b.cbs || it.cbs_off + it.query_len > b.cbs_len)))
-			return fail(DMND_E_ARG, "dmnd_swipe_keep: item " + std::to_string(i) + " out of range");
-	}
+	if (!in_range) return fail(DMND_E_ARG, "dmnd_swipe_keep: an item lies outside the uploaded blocks");
 	if (work != c) {
 		work->matrix.p = c->matrix.p; work->matrix.cap = c->matrix.cap; work->matrix.own = false;
 		work->params = c->params; work->evaluer = c->evaluer;
 	}
 	HIP_TRY(hipSetDevice(work->device));
-	auto wall = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-	const double t0 = wall();
-	// classes ascending, longest first inside a class (as swipe_impl orders them)
-	std::sort(slots.begin(), slots.end(), [](const Slot& x, const Slot& y) { return x.P < y.P || (x.P == y.P && x.steps > y.steps); });
-	std::vector<int32_t> order((size_t)n);
-	std::vector<int64_t> trace_off((size_t)n + 1, 0);
-	kt.trace_off.assign((size_t)n, 0); kt.P.assign((size_t)n, 0);
+	order_slots(slots, sort_tmp, sort_count);
+	std::vector<SweepLaunch> launches;
+	plan_sweeps(slots, K_TRACE, false, launches, work->h_pairs);
+	// every array the launches read, in ONE page-locked buffer and one copy:
+	// [items n][order n][trace offset by slot n + 1][trace offset by item n][pairs]
+	const size_t o_items = 0, o_order = o_items + (size_t)n * sizeof(dmnd_dp_target), o_off_slot = (o_order + (size_t)n * sizeof(int32_t) + 7) & ~(size_t)7,
+		o_off_item = o_off_slot + ((size_t)n + 1) * sizeof(int64_t), o_pairs = o_off_item + (size_t)n * sizeof(int64_t),
+		bytes = o_pairs + work->h_pairs.size() * sizeof(int32_t);
+	if (int rc = work->stage_h.ensure(bytes)) return rc;
+	if (int rc = work->stage_d.ensure(bytes)) return rc;
+	char* hs = work->stage_h.as<char>();
+	std::memcpy(hs + o_items, items, (size_t)n * sizeof(dmnd_dp_target));
+	int32_t* order = reinterpret_cast<int32_t*>(hs + o_order);
+	int64_t* off_slot = reinterpret_cast<int64_t*>(hs + o_off_slot);
+	int64_t* off_item = reinterpret_cast<int64_t*>(hs + o_off_item);
+	kt.trace_off.resize((size_t)n); kt.P.resize((size_t)n);
+	off_slot[0] = 0;
 	for (int64_t s = 0; s < n; ++s) {
-		const dmnd_dp_target& it = items[slots[(size_t)s].item];
-		const Geom g = make_geom(it.query_len, it.target_len, it.d_begin, it.d_end);
-		order[(size_t)s] = slots[(size_t)s].item;
-		trace_off[(size_t)s + 1] = trace_off[(size_t)s] + trace_rows(g) * 64 * slots[(size_t)s].P;
-		kt.trace_off[(size_t)slots[(size_t)s].item] = trace_off[(size_t)s];
-		kt.P[(size_t)slots[(size_t)s].item] = slots[(size_t)s].P;
+		const int32_t item = slots[(size_t)s].item;
+		order[s] = item;
+		off_slot[s + 1] = off_slot[s] + rows_of[(size_t)item];
+		off_item[item] = off_slot[s];
+		kt.trace_off[(size_t)item] = off_slot[s];
+		kt.P[(size_t)item] = slots[(size_t)s].P;
 	}
+	if (!work->h_pairs.empty()) std::memcpy(hs + o_pairs, work->h_pairs.data(), work->h_pairs.size() * sizeof(int32_t));
 	if ((int)work->keep_trace.size() <= arena) work->keep_trace.resize((size_t)arena + 1);
 	DevBuf& tr = work->keep_trace[(size_t)arena];
 	if (int rc = tr.ensure((size_t)total + 64)) return rc;
-	if (int rc = work->items.ensure(n * sizeof(dmnd_dp_target))) return rc;
 	if (int rc = work->ends.ensure(n * sizeof(SwipeEnd))) return rc;
-	if (int rc = work->order.ensure(n * sizeof(int32_t))) return rc;
-	if (int rc = work->trace_off.ensure((n + 1) * sizeof(int64_t))) return rc;
-	HIP_TRY(hipMemcpyAsync(work->items.p, items, n * sizeof(dmnd_dp_target), hipMemcpyHostToDevice, work->stream));
-	HIP_TRY(hipMemcpyAsync(work->order.p, order.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, work->stream));
-	HIP_TRY(hipMemcpyAsync(work->trace_off.p, trace_off.data(), (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, work->stream));
+	if (int rc = work->ends_h.ensure(n * sizeof(SwipeEnd))) return rc;
+	HIP_TRY(hipMemcpyAsync(work->stage_d.p, hs, bytes, hipMemcpyHostToDevice, work->stream));
+	const char* ds = work->stage_d.as<char>();
+	const dmnd_dp_target* d_items = reinterpret_cast<const dmnd_dp_target*>(ds + o_items);
 	work->host_ms[0] += wall() - t0;
 	const double t1 = wall();
 	HIP_TRY(hipEventRecord(work->ev0, work->stream));
-	if (int rc = launch_sweeps(work, b, work->items.as<dmnd_dp_target>(), n, slots, work->order.as<int32_t>(), work->trace_off.as<int64_t>(), &trace_off,
-		tr.as<uint8_t>(), K_TRACE, false)) return rc;
+	if (int rc = issue_sweeps(work, b, d_items, slots, launches, reinterpret_cast<const int32_t*>(ds + o_order), reinterpret_cast<const int64_t*>(ds + o_off_slot),
+		reinterpret_cast<const int32_t*>(ds + o_pairs), reinterpret_cast<const int64_t*>(ds + o_off_item), tr.as<uint8_t>(), K_TRACE)) return rc;
 	HIP_TRY(hipEventRecord(work->ev1, work->stream));
-	std::vector<SwipeEnd> ends((size_t)n);
-	HIP_TRY(copy_now(work->stream, ends.data(), work->ends.p, n * sizeof(SwipeEnd), hipMemcpyDeviceToHost));
+	SwipeEnd* ends = work->ends_h.as<SwipeEnd>();
+	HIP_TRY(copy_now(work->stream, ends, work->ends.p, n * sizeof(SwipeEnd), hipMemcpyDeviceToHost));
 	{
 		// items that saturated the 16-bit sweep: once more in the 32-bit kernel, into the same trace rows
 		std::vector<Slot> again;
-		for (const Slot& x : slots) if (ends[(size_t)x.item].pad[0]) again.push_back(x);
+		for (const Slot& x : slots) if (ends[x.item].pad[0]) again.push_back(x);
 		if (!again.empty()) {
 			std::vector<int32_t> order2(again.size());
 			std::vector<int64_t> off2(again.size());
 			for (size_t k = 0; k < again.size(); ++k) { order2[k] = again[k].item; off2[k] = kt.trace_off[(size_t)again[k].item]; }
+			if (int rc = work->order.ensure(order2.size() * sizeof(int32_t))) return rc;
+			if (int rc = work->trace_off.ensure(off2.size() * sizeof(int64_t))) return rc;
 			HIP_TRY(hipMemcpyAsync(work->order.p, order2.data(), order2.size() * sizeof(int32_t), hipMemcpyHostToDevice, work->stream));
 			HIP_TRY(hipMemcpyAsync(work->trace_off.p, off2.data(), off2.size() * sizeof(int64_t), hipMemcpyHostToDevice, work->stream));
-			if (int rc = launch_sweeps(work, b, work->items.as<dmnd_dp_target>(), n, again, work->order.as<int32_t>(), work->trace_off.as<int64_t>(), &off2,
+			if (int rc = launch_sweeps(work, b, d_items, n, again, work->order.as<int32_t>(), work->trace_off.as<int64_t>(), &off2,
 				tr.as<uint8_t>(), K_TRACE, true)) return rc;
-			HIP_TRY(copy_now(work->stream, ends.data(), work->ends.p, n * sizeof(SwipeEnd), hipMemcpyDeviceToHost));
+			HIP_TRY(copy_now(work->stream, ends, work->ends.p, n * sizeof(SwipeEnd), hipMemcpyDeviceToHost));
 		}
 	}
 	float ms = 0.f;
@@ -728,11 +776,11 @@ int dmnd_swipe_keep(dmnd_ctx* work, const dmnd_ctx* c, const dmnd_dp_target* ite
 	for (int64_t i = 0; i < n; ++i) {
 		dmnd_hsp h;
 		std::memset(&h, 0, sizeof(h));
-		h.score = ends[(size_t)i].score;
-		if (h.score > 0) { h.q_end = ends[(size_t)i].end_i + 1; h.s_end = ends[(size_t)i].end_j + 1; }
+		h.score = ends[i].score;
+		if (h.score > 0) { h.q_end = ends[i].end_i + 1; h.s_end = ends[i].end_j + 1; }
 		h.transcript_off = -1;
 		out[i] = h;
-		kt.score[(size_t)i] = ends[(size_t)i].score; kt.end_i[(size_t)i] = ends[(size_t)i].end_i; kt.end_j[(size_t)i] = ends[(size_t)i].end_j;
+		kt.score[(size_t)i] = ends[i].score; kt.end_i[(size_t)i] = ends[i].end_i; kt.end_j[(size_t)i] = ends[i].end_j;
 	}
 	kt.kept = true;
 	return DMND_OK;
@@ -745,49 +793,54 @@ int dmnd_traceback_kept(dmnd_ctx* work, const dmnd_ctx* c, const dmnd_dp_target*
 	const Bases b{ c->block[DMND_QUERY].as<int8_t>(), c->block_len[DMND_QUERY], c->block[DMND_TARGET].as<int8_t>(), c->block_len[DMND_TARGET],
 		c->cbs_len > 0 ? c->cbs.as<int8_t>() : nullptr, c->cbs_len };
 	HIP_TRY(hipSetDevice(work->device));
-	std::vector<int32_t> order((size_t)n), p_of((size_t)n);
-	std::vector<int64_t> trace_off((size_t)n), tr_zero((size_t)n + 1, 0);
-	std::vector<SwipeEnd> ends((size_t)n);
+	// every array the walk reads, in one page-locked buffer and one copy:
+	// [items n][end cells n][trace offsets n][transcript offsets n + 1 (all 0: no transcripts)][order n][band class n][status 1]
+	const size_t o_items = 0, o_ends = o_items + (size_t)n * sizeof(dmnd_dp_target), o_off = o_ends + (size_t)n * sizeof(SwipeEnd),
+		o_tr = o_off + (size_t)n * sizeof(int64_t), o_order = o_tr + ((size_t)n + 1) * sizeof(int64_t), o_p = o_order + (size_t)n * sizeof(int32_t),
+		o_status = o_p + (size_t)n * sizeof(int32_t), bytes = o_status + sizeof(int32_t);
+	if (int rc = work->stage_h.ensure(bytes)) return rc;
+	if (int rc = work->stage_d.ensure(bytes)) return rc;
+	if (int rc = work->hsps.ensure(n * sizeof(dmnd_hsp))) return rc;
+	char* hs = work->stage_h.as<char>();
+	std::memcpy(hs + o_items, items, (size_t)n * sizeof(dmnd_dp_target));
+	SwipeEnd* ends = reinterpret_cast<SwipeEnd*>(hs + o_ends);
+	int64_t* trace_off = reinterpret_cast<int64_t*>(hs + o_off);
+	int32_t* order = reinterpret_cast<int32_t*>(hs + o_order);
+	int32_t* p_of = reinterpret_cast<int32_t*>(hs + o_p);
+	std::memset(hs + o_tr, 0, ((size_t)n + 1) * sizeof(int64_t));
+	*reinterpret_cast<int32_t*>(hs + o_status) = 0;
 	for (int64_t k = 0; k < n; ++k) {
 		const int64_t x = src[k];
 		if (x < 0 || x >= (int64_t)kt.P.size()) return fail(DMND_E_ARG, "dmnd_traceback_kept: item index out of range");
-		order[(size_t)k] = (int32_t)k; p_of[(size_t)k] = kt.P[(size_t)x]; trace_off[(size_t)k] = kt.trace_off[(size_t)x];
+		order[k] = (int32_t)k; p_of[k] = kt.P[(size_t)x]; trace_off[k] = kt.trace_off[(size_t)x];
 		SwipeEnd e;
 		std::memset(&e, 0, sizeof(e));
 		e.score = kt.score[(size_t)x]; e.end_i = kt.end_i[(size_t)x]; e.end_j = kt.end_j[(size_t)x];
-		ends[(size_t)k] = e;
+		ends[k] = e;
 	}
-	if (int rc = work->items.ensure(n * sizeof(dmnd_dp_target))) return rc;
-	if (int rc = work->ends.ensure(n * sizeof(SwipeEnd))) return rc;
-	if (int rc = work->hsps.ensure(n * sizeof(dmnd_hsp))) return rc;
-	if (int rc = work->order.ensure(n * sizeof(int32_t))) return rc;
-	if (int rc = work->p_of_slot.ensure(n * sizeof(int32_t))) return rc;
-	if (int rc = work->trace_off.ensure((n + 1) * sizeof(int64_t))) return rc;
-	if (int rc = work->transcript_off.ensure((n + 1) * sizeof(int64_t))) return rc;
-	if (int rc = work->status.ensure(sizeof(int32_t))) return rc;
-	HIP_TRY(hipMemcpyAsync(work->items.p, items, n * sizeof(dmnd_dp_target), hipMemcpyHostToDevice, work->stream));
-	HIP_TRY(hipMemcpyAsync(work->ends.p, ends.data(), n * sizeof(SwipeEnd), hipMemcpyHostToDevice, work->stream));
-	HIP_TRY(hipMemcpyAsync(work->order.p, order.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, work->stream));
-	HIP_TRY(hipMemcpyAsync(work->p_of_slot.p, p_of.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, work->stream));
-	HIP_TRY(hipMemcpyAsync(work->trace_off.p, trace_off.data(), n * sizeof(int64_t), hipMemcpyHostToDevice, work->stream));
-	HIP_TRY(hipMemcpyAsync(work->transcript_off.p, tr_zero.data(), (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, work->stream));
-	HIP_TRY(hipMemsetAsync(work->status.p, 0, sizeof(int32_t), work->stream));
+	HIP_TRY(hipMemcpyAsync(work->stage_d.p, hs, bytes, hipMemcpyHostToDevice, work->stream));
+	char* ds = work->stage_d.as<char>();
 	HIP_TRY(hipEventRecord(work->ev1, work->stream));
 	TracebackArgs t;
 	t.qblock = b.q; t.tblock = b.t; t.cbs = b.cbs; t.matrix = work->matrix.as<int8_t>();
-	t.items = work->items.as<dmnd_dp_target>(); t.order = work->order.as<int32_t>(); t.p_of_slot = work->p_of_slot.as<int32_t>();
-	t.trace_off = work->trace_off.as<int64_t>(); t.transcript_off = work->transcript_off.as<int64_t>();
+	t.items = reinterpret_cast<const dmnd_dp_target*>(ds + o_items); t.order = reinterpret_cast<const int32_t*>(ds + o_order);
+	t.p_of_slot = reinterpret_cast<const int32_t*>(ds + o_p);
+	t.trace_off = reinterpret_cast<const int64_t*>(ds + o_off); t.transcript_off = reinterpret_cast<const int64_t*>(ds + o_tr);
 	t.trace = work->keep_trace[(size_t)kt.arena].as<uint8_t>(); t.transcript = nullptr;
-	t.ends = work->ends.as<SwipeEnd>(); t.hsps = work->hsps.as<dmnd_hsp>(); t.status = work->status.as<int32_t>();
+	t.ends = reinterpret_cast<const SwipeEnd*>(ds + o_ends); t.hsps = work->hsps.as<dmnd_hsp>(); t.status = reinterpret_cast<int32_t*>(ds + o_status);
 	t.n = n; t.gap_open = work->params.gap_open; t.gap_extend = work->params.gap_extend;
 	HIP_TRY(launch_traceback(t, work->stream));
 	HIP_TRY(hipEventRecord(work->ev2, work->stream));
-	HIP_TRY(copy_now(work->stream, out, work->hsps.p, n * sizeof(dmnd_hsp), hipMemcpyDeviceToHost));
+	// results and status come back through the page-locked buffer, one wait for both
+	if (int rc = work->ends_h.ensure((size_t)n * sizeof(dmnd_hsp) + sizeof(int32_t))) return rc;
+	HIP_TRY(hipMemcpyAsync(work->ends_h.p, work->hsps.p, (size_t)n * sizeof(dmnd_hsp), hipMemcpyDeviceToHost, work->stream));
+	HIP_TRY(hipMemcpyAsync(work->ends_h.as<char>() + (size_t)n * sizeof(dmnd_hsp), ds + o_status, sizeof(int32_t), hipMemcpyDeviceToHost, work->stream));
+	HIP_TRY(sync_stream(work->stream));
+	std::memcpy(out, work->ends_h.p, (size_t)n * sizeof(dmnd_hsp));
 	float ms = 0.f;
 	HIP_TRY(hipEventElapsedTime(&ms, work->ev1, work->ev2));
 	work->swipe_ms = 0.0; work->traceback_ms = ms;
-	int32_t st = 0;
-	HIP_TRY(copy_now(work->stream, &st, work->status.p, sizeof(st), hipMemcpyDeviceToHost));
+	const int32_t st = *reinterpret_cast<const int32_t*>(work->ends_h.as<char>() + (size_t)n * sizeof(dmnd_hsp));
 	if (st != 0) return fail(st, st == DMND_E_TRACEBACK ? "Traceback error." : "transcript slot too small");
 	for (int64_t k = 0; k < n; ++k) out[k].transcript_off = -1;
 	return DMND_OK;

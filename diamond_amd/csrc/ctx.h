@@ -54,7 +54,19 @@ struct DevBuf {
 	template<typename T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// page-locked host staging (grows, never shrinks): asynchronous copies to and from it are real DMA transfers, and one buffer
+// holding several arrays goes to the device as ONE copy
+struct PinBuf {
+	void* p = nullptr;
+	size_t cap = 0;
+	int ensure(size_t bytes);
+	void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+	template<typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
 }  // namespace dmnd
+
+struct KeptTrace;
 
 struct dmnd_ctx {
 	int device = 0;
@@ -76,6 +88,9 @@ struct dmnd_ctx {
 	dmnd::DevBuf pairs, trace_off_item;        // packed-int16 sweep: item pairs per wavefront, trace offset by item index
 	std::vector<int32_t> h_pairs;              // their host staging (outlive the asynchronous copies of a call)
 	std::vector<int64_t> h_trace_off_item;
+	dmnd::PinBuf stage_h, ends_h;              // dmnd_swipe_keep: all launch arrays of a sweep in one upload; its results
+	dmnd::DevBuf stage_d;
+	std::vector<KeptTrace>* kts = nullptr;     // kept traces of the extension stage's ranking iterations (reused from call to call)
 	dmnd::DevBuf host_q, host_t, host_cbs;      // staging for dmnd_banded_swipe_host
 	double swipe_ms = 0.0, traceback_ms = 0.0;
 	size_t trace_arena_max = (size_t)8 << 30;

@@ -400,7 +400,7 @@ struct QueryState {
 static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const std::vector<Range>& qr, size_t qr_begin, size_t qr_end,
 	const dmnd_seed_hit* hits, const std::vector<uint8_t>& gf, const int8_t* qdata, const int8_t* tdata, const int8_t* cbs,
 	int threads, uint32_t hsp_values, std::vector<dmnd_match>& out_matches,
-	uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used)
+	uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used, hipStream_t bias_stream = nullptr)
 {
 	const std::vector<int64_t>& ql = c->limits[DMND_QUERY];
 	const std::vector<int64_t>& tl = c->limits[DMND_TARGET];
@@ -441,6 +441,7 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 			if (qs[i].w.order.empty()) qs[i].done = true;
 		}
 	});
+	if (bias_stream) HIP_TRY(sync_stream(bias_stream));      // the Hauser bias (kernel + copy to the host) ran beside load_hits
 	lap(5, 3);
 	auto item_of = [&](uint32_t q, uint32_t t, int d0, int d1) {
 		return dmnd_dp_target{ ql[q], tl[t], h.use_cbs ? ql[q] : (int64_t)-1, (int32_t)(ql[q + 1] - ql[q] - 1), (int32_t)(tl[t + 1] - tl[t] - 1), d0, d1 };
@@ -455,7 +456,9 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 	// round 2 only walks the kept traces. Not used when the caller wants transcripts, when a chunk holds a matrix too large for
 	// the traceback path (those go through the statistics kernels), or past the context's trace budget: then round 2 sweeps again.
 	static const bool keep_traces = [] { const char* e = std::getenv("DMND_EXTEND_KEEP_TRACE"); return !e || e[0] != '0'; }();
-	std::vector<KeptTrace> kts(8);
+	if (!w->kts) w->kts = new std::vector<KeptTrace>(8);
+	std::vector<KeptTrace>& kts = *w->kts;
+	for (KeptTrace& k : kts) { k.kept = false; k.arena = -1; }
 	std::vector<std::vector<dmnd_hsp>> r2(nq);
 	for (;;) {
 		int arena_iter = 0;
@@ -740,6 +743,7 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	// One launch over the whole query block (bias_kernels.hip: closed-form window per position), result kept in HBM next to
 	// the block for the swipe kernels and the gapped filter, and copied into a pinned host buffer for the host's x-drop stage.
 	const int8_t* cbs = nullptr;
+	bool bias_pending = false;
 	if (!h.use_cbs) {
 		c->cbs_len = 0;                                     // --comp-based-stats 0: no bias anywhere on the path
 	}
@@ -758,7 +762,7 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 		for (int i = 0; i < 20; ++i) ba.bg[i] = (float)h.background_scores[i];
 		HIP_TRY(launch_hauser_bias(ba, c->stream));
 		HIP_TRY(hipMemcpyAsync(c->pinned_cbs, c->cbs.p, (size_t)ql.back(), hipMemcpyDeviceToHost, c->stream));
-		HIP_TRY(sync_stream(c->stream));
+		bias_pending = true;                                // awaited after load_hits (extend_range) / before the runners start
 		c->cbs_len = ql.back();
 		cbs = c->pinned_cbs;
 	}
@@ -767,6 +771,7 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	std::vector<uint8_t> gf;
 	c->gf_ms = 0;
 	if (c->gapped_filter_evalue > 0.0 && n_hits > 0) {
+		if (bias_pending) { HIP_TRY(sync_stream(c->stream)); bias_pending = false; }      // the filter's profile reads the bias
 		gf.resize((size_t)n_hits);
 		if (int rc = dmnd_gapped_filter(c, hits, n_hits, h.use_cbs ? 1 : 0, gf.data(), nullptr)) return rc;
 	}
@@ -785,8 +790,9 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	// worker threads under them -- the host phases of a sub-batch are a few hundred microseconds, less than it costs to wake a
 	// pool -- and use a quarter of the CPU time, which matters on CPU-quota'd hosts. Worker threads are added per runner only
 	// when a runner's share of the seed hits is large enough to pay for them (--sensitive: 1.2e6 hits per block).
+	// Default: one range, host work in min(threads, 8) fixed slices, ONE launch per GPU phase (extend_range). DMND_EXTEND_SPLIT /
+	// DMND_EXTEND_RUNNERS > 1 select the older layout of independent runners with their own streams and small launches.
 	int split = 1, runners = 1;
-	if (!transcript && qr.size() >= 2048) { runners = std::max(1, std::min(8, threads)); split = runners; }
 	if (const char* e = std::getenv("DMND_EXTEND_SPLIT")) split = std::max(1, std::min(64, std::atoi(e)));
 	if (const char* e = std::getenv("DMND_EXTEND_RUNNERS")) runners = std::max(1, std::atoi(e));
 	if (transcript || qr.size() < (size_t)split * 2) split = 1;
@@ -794,10 +800,13 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	std::vector<std::vector<dmnd_match>> parts((size_t)split);
 	std::vector<int> rcs((size_t)split, DMND_OK);
 	std::vector<std::string> errs((size_t)split);
+	static const int team = [] { const char* e = std::getenv("DMND_EXTEND_TEAM"); return e ? std::max(1, std::atoi(e)) : 8; }();
 	if (split == 1) {
-		rcs[0] = extend_range(c, c, h, qr, 0, qr.size(), hits, gf, qdata, tdata, cbs, threads, hsp_values, parts[0], transcript, transcript_cap, transcript_used);
+		rcs[0] = extend_range(c, c, h, qr, 0, qr.size(), hits, gf, qdata, tdata, cbs, std::min(threads, team), hsp_values, parts[0], transcript, transcript_cap, transcript_used,
+			bias_pending ? c->stream : nullptr);
 	}
 	else {
+		if (bias_pending) HIP_TRY(sync_stream(c->stream));
 		const double stats4 = c->ext_stats[4];
 		std::vector<dmnd_ctx*> work((size_t)runners);
 		for (int r = 0; r < runners; ++r) {

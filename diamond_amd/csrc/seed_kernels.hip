@@ -118,7 +118,16 @@ __device__ __forceinline__ uint32_t reduce4(uint32_t letter, uint64_t map_lo, ui
 }
 // LEVEL2: consult the level-2 bitmap before the table. It pays when most level-1 positives are false (long seeds: --fast,
 // default); with short seeds (weight <= 9: a third of the reference positions really join) it is a wasted random access.
-template<bool LEVEL2>
+// PROBE: how the level-1 bitmap word is loaded (experiment, DMND_SEED_PROBE): 0 plain, 1 non-temporal, 2 device-scope (bypasses the vector L1)
+template<int PROBE>
+__device__ __forceinline__ uint32_t probe_word(const uint32_t* p)
+{
+	if (PROBE == 1) return __builtin_nontemporal_load(p);
+	if (PROBE == 2) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	return *p;
+}
+
+template<bool LEVEL2, int PROBE = 0>
 __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int sid, uint64_t map_lo, uint64_t map_hi, int64_t base, uint64_t care64)
 {
 	// Joined positions are staged in LDS and flushed with ONE atomic on the shared counter per workgroup: an atomicAdd per
@@ -168,7 +177,7 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 			const int w0 = 8 * half + i;
 			const bool ok = w0 >= first && w0 < last && (((delim >> w0) & span) | ((bad >> w0) & care)) == 0;
 			const uint32_t h = seed_hash_a(key[i]);                              // hash b is only needed past level 1
-			const uint32_t bw = ok ? a.bitmap1[(h >> 10) & a.bitmap1_mask] : 0u;
+			const uint32_t bw = ok ? probe_word<PROBE>(a.bitmap1 + ((h >> 10) & a.bitmap1_mask)) : 0u;
 			word[i] = (bw >> (h & 31)) & (bw >> ((h >> 5) & 31));
 		}
 #pragma unroll
@@ -524,7 +533,12 @@ hipError_t launch_seed_stream(const SeedArgs& a, int sid, hipStream_t st)
 		const int64_t threads = (a.t_end - base + 15) / 16;
 		uint64_t care64 = 0;
 		for (int k = 0; k < c.shape_weight[sid]; ++k) care64 |= (uint64_t)15 << (4 * c.shape_pos[sid][k]);
-		if (c.shape_weight[sid] >= 10)
+		static const int probe = [] { const char* e = getenv("DMND_SEED_PROBE"); return e ? atoi(e) : 0; }();
+		if (c.shape_weight[sid] >= 10 && probe == 1)
+			hipLaunchKernelGGL((seed_stream_fast_kernel<true, 1>), dim3(blocks_for(threads, 256)), dim3(256), 0, st, a, sid, lo, hi, base, care64);
+		else if (c.shape_weight[sid] >= 10 && probe == 2)
+			hipLaunchKernelGGL((seed_stream_fast_kernel<true, 2>), dim3(blocks_for(threads, 256)), dim3(256), 0, st, a, sid, lo, hi, base, care64);
+		else if (c.shape_weight[sid] >= 10)
 			hipLaunchKernelGGL(seed_stream_fast_kernel<true>, dim3(blocks_for(threads, 256)), dim3(256), 0, st, a, sid, lo, hi, base, care64);
 		else
 			hipLaunchKernelGGL(seed_stream_fast_kernel<false>, dim3(blocks_for(threads, 256)), dim3(256), 0, st, a, sid, lo, hi, base, care64);

@@ -31,7 +31,7 @@ ctx_seed = make()
 ctx_ext = [make() for _ in range(E)]
 sp = hip.seed_params_fast(threads=8)
 seed_pool = cf.ThreadPoolExecutor(1)
-ext_pool = cf.ThreadPoolExecutor(E)
+ext_pools = [cf.ThreadPoolExecutor(1) for _ in range(E)]      # one thread per extension context: a context runs one call at a time
 
 
 def seed():
@@ -48,7 +48,7 @@ def ext(k, fut):
 
 def run(n, primed):
     seeds = [primed] + [seed_pool.submit(seed) for _ in range(n)]      # n seed stages inside this call (the last one only awaited)
-    exts = [ext_pool.submit(ext, k, seeds[k]) for k in range(n)]
+    exts = [ext_pools[k % E].submit(ext, k, seeds[k]) for k in range(n)]
     r = [e.result() for e in exts]
     return seeds[n], r
 
