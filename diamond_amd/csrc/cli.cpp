@@ -232,6 +232,7 @@ struct Options {
 	double block_size = 0.0;        // -b, billions of letters (0 = the reference's default for the sensitivity)
 	int index_chunks = 0;           // -c (0 = the sensitivity's default)
 	std::string masking = "", motif_masking = "", sens = "";
+	int algo = -1;                  // --algo: -1 auto (the reference's default), 0 double-indexed, 1 query-indexed
 };
 
 Options parse(int argc, char** argv)
@@ -255,7 +256,13 @@ Options parse(int argc, char** argv)
 		else if (a == "--comp-based-stats") { o.cbs = std::atoi(need(i).c_str()); if (o.cbs != 0 && o.cbs != 1) throw std::runtime_error("Only --comp-based-stats 0 and 1 are implemented."); }
 		else if (a == "--masking") o.masking = need(i);
 		else if (a == "--motif-masking") o.motif_masking = need(i);
-		else if (a == "--algo") { if (need(i) != "0") throw std::runtime_error("Only --algo 0 (double-indexed) is implemented."); }
+		else if (a == "--algo") {
+			const std::string v = need(i);                      // Config::Algo: basic/config.cpp (0 | 1 | ctg, or the names)
+			if (v == "0" || v == "double-indexed") o.algo = 0;
+			else if (v == "1" || v == "query-indexed") o.algo = 1;
+			else if (v == "auto" || v == "") o.algo = -1;
+			else throw std::runtime_error("Invalid value for --algo: " + v + " (0 = double-indexed, 1 = query-indexed; ctg is not part of this build)");
+		}
 		else if (a == "-f" || a == "--outfmt") { if (need(i) != "6") throw std::runtime_error("Only output format 6 (BLAST tabular, default columns) is implemented."); }
 		else if (a == "--faster" || a == "--mid-sensitive" || a == "--sensitive" || a == "--more-sensitive" || a == "--very-sensitive" || a == "--ultra-sensitive")
 			o.sens = a;
@@ -366,6 +373,26 @@ int run_blastp(const Options& o)
 	if (o.index_chunks > 0) chk(dmnd_seed_params_set_index_chunks(&sp, o.index_chunks, threads));
 	chk(dmnd_set_gapped_filter(ctx, gf_evalue));
 	sp.query_translated = blastx ? 1 : 0;
+	// --algo (run/double_indexed.cpp:267-300): auto = query-indexed for a query block of at most 32 Mi letters against a
+	// database of 256 MiB and more (the size of the file on disk), decided on the first query block as the reference does
+	int algo = o.algo;
+	if (algo < 0) {
+		int64_t db_bytes = 0;
+		{ std::ifstream f(dbpath, std::ios::binary | std::ios::ate); if (f) db_bytes = (int64_t)f.tellg(); }
+		const Range& q0 = q_blocks.front();
+		std::vector<int64_t> lim(q_all.limits.begin() + (ptrdiff_t)(q0.begin * C), q_all.limits.begin() + (ptrdiff_t)(q0.end * C) + 1);
+		int qi = 0;
+		chk(dmnd_auto_query_indexed(&sp, q_all.data.data(), lim.data(), (int64_t)lim.size() - 1, db_bytes, &qi));
+		algo = qi;
+	}
+	std::cerr << "Algorithm: " << (algo == 1 ? "Query-indexed" : "Double-indexed") << "\n";
+	if (algo == 1) {
+		if (o.index_chunks > 1) throw std::runtime_error("The query-indexed algorithm of this build runs with one index chunk (-c1).");
+		chk(dmnd_seed_params_set_query_indexed(&sp, threads));
+	}
+	// query-indexed + masking: the reference masks a target only when the extension stage loads it (lazy masking,
+	// extend.cpp:168-181; run/double_indexed.cpp:300), i.e. the seed stage sees the unmasked reference block
+	const bool lazy_masking = algo == 1 && tantan;
 
 	FILE* out = o.out.empty() ? stdout : std::fopen(o.out.c_str(), "w");
 	if (!out) throw std::runtime_error("Error opening file " + o.out);
@@ -374,6 +401,7 @@ int run_blastp(const Options& o)
 	for (size_t i = 0; i < qid.size(); ++i) qid[i] = short_id(qtitles[i]);
 	for (size_t i = 0; i < tid.size(); ++i) tid[i] = short_id(t_all_seqs.ids[i]);
 	double ms_upload = 0, ms_mask = 0, ms_seed = 0, ms_ext = 0;
+	std::vector<int8_t> t_masked;         // lazily masked copy of the reference block at hand (query-indexed algorithm)
 	int64_t total_hits = 0, total_matches = 0, aligned = 0, mq_total = 0, mt_total = 0;
 	char line[8192];
 	for (const Range& qr : q_blocks) {
@@ -400,13 +428,22 @@ int run_blastp(const Options& o)
 			t0 = std::chrono::steady_clock::now();
 			chk(dmnd_upload_block(ctx, DMND_TARGET, t.data.data(), (int64_t)t.data.size(), t.limits.data(), (int64_t)(tr.end - tr.begin)));
 			ms_upload += ms_since(t0);
-			if (tantan && (t_blocks.size() > 1 || &qr == &q_blocks.front())) {     // a single reference block is masked once
+			const int8_t* t_host = t.data.data();            // the letters the extension stage's host part reads
+			auto mask_target = [&] {
 				t0 = std::chrono::steady_clock::now();
 				int64_t mt = 0;
-				chk(dmnd_mask_block(ctx, DMND_TARGET, t.data.data(), &mt));
+				if (lazy_masking) {                            // t.data stays unmasked: the next query block's seed stage needs it so
+					t_masked.resize(t.data.size());
+					chk(dmnd_mask_block(ctx, DMND_TARGET, t_masked.data(), &mt));
+					t_host = t_masked.data();
+				}
+				else chk(dmnd_mask_block(ctx, DMND_TARGET, t.data.data(), &mt));
 				if (&qr == &q_blocks.front()) mt_total += mt;
 				ms_mask += ms_since(t0);
-			}
+			};
+			// up-front masking: every block of a multi-block database for every query block; a single block only once (its host
+			// copy keeps the masked letters and is uploaded as it is from then on)
+			if (tantan && !lazy_masking && (t_blocks.size() > 1 || &qr == &q_blocks.front())) mask_target();
 			t0 = std::chrono::steady_clock::now();
 			int64_t n_hits = 0;
 			chk(dmnd_seed_search(ctx, &sp, &n_hits));
@@ -414,11 +451,12 @@ int run_blastp(const Options& o)
 			chk(dmnd_seed_hits(ctx, hits.data(), n_hits));
 			ms_seed += ms_since(t0);
 			total_hits += n_hits;
+			if (lazy_masking) mask_target();
 			t0 = std::chrono::steady_clock::now();
 			const size_t base = joined.size();
 			joined.resize(base + (size_t)std::max<int64_t>(n_hits, 1));
 			int64_t n_matches = 0;
-			chk(dmnd_extend(ctx, q.data.data(), t.data.data(), hits.data(), n_hits, threads, 0, joined.data() + base, (int64_t)(joined.size() - base), &n_matches, nullptr, 0, nullptr));
+			chk(dmnd_extend(ctx, q.data.data(), t_host, hits.data(), n_hits, threads, 0, joined.data() + base, (int64_t)(joined.size() - base), &n_matches, nullptr, 0, nullptr));
 			joined.resize(base + (size_t)n_matches);
 			for (size_t i = base; i < joined.size(); ++i) { joined[i].query += (uint32_t)qr.begin; joined[i].target += (uint32_t)tr.begin; }   // block ids -> file ordinals
 			ms_ext += ms_since(t0);

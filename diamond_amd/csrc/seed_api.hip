@@ -150,6 +150,48 @@ extern "C" int dmnd_seed_params_set_index_chunks(dmnd_seed_params* p, int index_
 	return DMND_OK;
 }
 
+extern "C" int dmnd_seed_params_set_query_indexed(dmnd_seed_params* p, int threads)
+{
+	if (!p || threads < 1 || p->n_shapes < 1) return fail(DMND_E_ARG, "dmnd_seed_params_set_query_indexed: bad argument");
+	if (p->reduction_size > 16) return fail(DMND_E_ARG, "dmnd_seed_params_set_query_indexed: the hashed seed encoding packs 4 bits per letter");
+	for (int i = 0; i < p->n_shapes; ++i)
+		if (p->shape_len[i] > 16) return fail(DMND_E_ARG, "dmnd_seed_params_set_query_indexed: shapes longer than 16 letters");
+	p->seed_encoding = SEED_HASHED;
+	return dmnd_seed_params_set_index_chunks(p, 1, threads);       // run/double_indexed.cpp:297: one index chunk unless -c is given
+}
+
+extern "C" int dmnd_auto_query_indexed(const dmnd_seed_params* params, const int8_t* qdata, const int64_t* qlimits, int64_t nq, int64_t db_bytes, int* query_indexed)
+{
+	if (!params || !qdata || !qlimits || nq < 0 || !query_indexed) return fail(DMND_E_ARG, "dmnd_auto_query_indexed: bad argument");
+	*query_indexed = 0;
+	const int64_t MiB = (int64_t)1 << 20;
+	const int64_t letters = nq > 0 ? qlimits[nq] - qlimits[0] - nq : 0;
+	if (letters > 32 * MiB || db_bytes < 256 * MiB) return DMND_OK;                    // MAX_INDEX_QUERY_SIZE, MIN_QUERY_INDEXED_DB_SIZE
+	if (params->reduction_size > 16) return DMND_OK;
+	for (int i = 0; i < params->n_shapes; ++i) if (params->shape_len[i] > 16) return DMND_OK;
+	auto next_pow2 = [](double x) { uint64_t n = (uint64_t)std::ceil(x), p = 1; while (p < n) p <<= 1; return p; };
+	// a shape has at most one seed per letter: only query blocks close to the 32 Mi limit need their seeds counted
+	if (next_pow2((double)letters * 1.25) <= (uint64_t)(32 * MiB)) { *query_indexed = 1; return DMND_OK; }
+	SeedParams sp;
+	std::memcpy(&sp, params, sizeof(sp));
+	sp.seed_encoding = SEED_HASHED;
+	std::vector<uint64_t> keys;
+	uint64_t largest = 0;
+	for (int sid = 0; sid < sp.n_shapes; ++sid) {
+		keys.clear();
+		for (int64_t i = 0; i < nq; ++i)
+			for (int64_t p = qlimits[i]; p + sp.shape_len[sid] < qlimits[i + 1]; ++p) {
+				uint64_t k;
+				if (seed_key_hashed(sp, sid, qdata + p, k)) keys.push_back(k);
+			}
+		std::sort(keys.begin(), keys.end());
+		const uint64_t distinct = (uint64_t)(std::unique(keys.begin(), keys.end()) - keys.begin());
+		largest = std::max(largest, next_pow2((double)distinct * 1.25));
+	}
+	*query_indexed = largest <= (uint64_t)(32 * MiB) ? 1 : 0;
+	return DMND_OK;
+}
+
 extern "C" int dmnd_seed_kernel_ms(const dmnd_ctx* c, double ms[5])
 {
 	if (!c || !ms) return fail(DMND_E_ARG, "dmnd_seed_kernel_ms: bad argument");
@@ -185,6 +227,12 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	for (int i = 0; i < sp.n_shapes; ++i)
 		if (sp.shape_len[i] < 1 || sp.shape_len[i] > 32 || sp.shape_weight[i] < 1 || sp.shape_weight[i] > SEED_MAX_WEIGHT)
 			return fail(DMND_E_ARG, "dmnd_seed_search: bad shape");
+	if (sp.seed_encoding != SEED_SPACED && sp.seed_encoding != SEED_HASHED) return fail(DMND_E_ARG, "dmnd_seed_search: unknown seed encoding");
+	if (sp.seed_encoding == SEED_HASHED) {
+		if (sp.index_chunks != 1 || sp.reduction_size > 16) return fail(DMND_E_ARG, "dmnd_seed_search: the query-indexed mode runs with one index chunk and a 4-bit reduction");
+		for (int i = 0; i < sp.n_shapes; ++i)
+			if (sp.shape_len[i] > 16) return fail(DMND_E_ARG, "dmnd_seed_search: query-indexed mode with a shape longer than 16 letters");
+	}
 	HIP_TRY(hipSetDevice(c->device));
 	hipStream_t st = c->stream;
 	const int64_t q_begin = ql.front(), q_end = ql.back(), t_begin = tl.front(), t_end = tl.back();
@@ -284,7 +332,8 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		if (attempt >= 2) return fail(DMND_E_NOMEM, "dmnd_seed_search: joined-position buffer overflow");
 		cap_total = off + off / 8 + 1024;
 	}
-	for (int sid = 0; sid < S; ++sid) {
+	// Search::mask_seeds (per joined group) only exists for spaced seeds; the query-indexed mode masked at enumeration
+	for (int sid = 0; sid < S && sp.seed_encoding == SEED_SPACED; ++sid) {
 		SeedArgs a = args_for(sid, (int64_t)counts[sid], m_off[sid]);
 		tm.start();
 		HIP_TRY(launch_seed_mask(a, sid, st));

@@ -22,6 +22,7 @@
 namespace dmnd {
 
 enum { SEED_MAX_SHAPES = 16, SEED_MAX_WEIGHT = 32, L_MASK = 23, L_STOP = 24, L_DELIM = 31, SEED_NEVER = 255 };
+enum { SEED_SPACED = 0, SEED_HASHED = 1 };
 
 // Seed-stage configuration: the globals the reference reads across the seam (shapes, Reduction::instance,
 // config.*, Search::Config), SURVEY 8b.
@@ -40,7 +41,7 @@ struct SeedParams {
 	int32_t cutoff_table[32];                                // CutoffTable::data_[bit_length(query_len)]
 	int32_t tile_size, simd_lanes;                           // config.tile_size (1024); int8 lanes of the reference build (AVX2: 32)
 	int32_t query_translated;                                // align_mode.query_translated (blastx): short-frame rules of stage2.h:51,58-63
-	int32_t pad_;
+	int32_t seed_encoding;                                   // SEED_SPACED (double-indexed algorithm) or SEED_HASHED (query-indexed)
 	int32_t cutoff_table_short[32];                          // CutoffTable(ungapped_evalue_short): translated frames of 61..85 letters (stage2.h:51)
 };
 
@@ -71,8 +72,41 @@ DMND_HD bool seed_at(const SeedParams& c, int sid, const int8_t* p, uint64_t& ou
 // recovered with seed_of_key where it matters (mask and pair kernels). Other shapes use the seed value itself as the key.
 DMND_HD bool seed_nibble_mode(const SeedParams& c, int sid) { return c.shape_len[sid] <= 16 && c.reduction_size <= 15; }
 
+// Seed of the query-indexed algorithm (HashedSeedIterator, search/seed_array/seed_iterator.h:161-198; the Murmur hash the
+// reference applies on top is a bijection and, with the single index chunk of this mode, its partition is never looked at):
+// the window's reduced letters under the shape mask, where
+//   * the iterator stops at the first window of a sequence and at every window whose LAST letter is an amino acid;
+//   * a mask / stop letter inside the window contributes 0 -- except among the first shape_len letters of the sequence, which
+//     the iterator's constructor reduces blindly: Reduction::map_[X] = 23 does not fit its 4 bits and spills into the letter
+//     before it.
+// Same nibble layout as the spaced-seed key (nibble j = letter j of the window), so a window of amino acids has the same key
+// in both modes. The position inside the sequence is found by looking back for the delimiter (at most shape_len bytes; blocks
+// start with padding delimiters).
+DMND_HD bool seed_key_hashed(const SeedParams& c, int sid, const int8_t* p, uint64_t& out)
+{
+	const int len = c.shape_len[sid];
+	for (int i = 0; i < len; ++i)
+		if ((p[i] & LETTER_MASK) == L_DELIM) return false;
+	int index = len;                                          // position of p in its sequence, capped at len
+	for (int k = 1; k <= len; ++k)
+		if ((p[-k] & LETTER_MASK) == L_DELIM) { index = k - 1; break; }
+	if (index != 0 && !is_amino_acid(p[len - 1] & LETTER_MASK)) return false;
+	uint64_t v = 0;
+	for (int j = 0; j < len; ++j) {
+		const int l = p[j] & LETTER_MASK;
+		const int r = (index + j < len || is_amino_acid(l)) ? c.reduction[l] : 0;
+		v |= (uint64_t)(r & 15) << (4 * j);
+		if ((r & 16) && j > 0) v |= (uint64_t)1 << (4 * (j - 1));
+	}
+	uint64_t care = 0;
+	for (int k = 0; k < c.shape_weight[sid]; ++k) care |= (uint64_t)15 << (4 * c.shape_pos[sid][k]);
+	out = v & care;
+	return true;
+}
+
 DMND_HD bool seed_key_at(const SeedParams& c, int sid, const int8_t* p, uint64_t& out)
 {
+	if (c.seed_encoding == SEED_HASHED) return seed_key_hashed(c, sid, p, out);
 	if (!seed_nibble_mode(c, sid)) return seed_at(c, sid, p, out);
 	const int len = c.shape_len[sid];
 	for (int i = 0; i < len; ++i)

@@ -40,6 +40,13 @@ __global__ void seed_index_kernel(SeedArgs a, int sid)
 	if (p >= a.q_end) return;
 	uint64_t seed;                                     // table key (seed_key_at)
 	if (!seed_key_at(a.params, sid, a.qdata + p, seed)) return;
+	if (a.params.seed_encoding == SEED_HASHED && !seed_is_complex(a.params, sid, a.qdata + p)) {
+		// query-indexed algorithm: a low-complexity query seed is dropped and masked when the query seeds are enumerated
+		// (enum_seeds_hashed, enum_seeds.h:141-145), whether or not it joins; one position per thread and shape: no race
+		const uint8_t t = (uint8_t)(sid * a.params.index_chunks);
+		if (t < a.mask_time[p]) a.mask_time[p] = t;
+		return;
+	}
 	const uint64_t h = seed_hash(seed);
 	atomicOr(&a.bitmap[(h >> 32) & a.bitmap_mask], 1u << (h >> 59));
 	atomicOr(&a.bitmap1[((uint32_t)h >> 10) & a.bitmap1_mask], (1u << (h & 31)) | (1u << ((h >> 5) & 31)));   // 2 bits, one word; bits of hash a only
@@ -118,16 +125,11 @@ __device__ __forceinline__ uint32_t reduce4(uint32_t letter, uint64_t map_lo, ui
 }
 // LEVEL2: consult the level-2 bitmap before the table. It pays when most level-1 positives are false (long seeds: --fast,
 // default); with short seeds (weight <= 9: a third of the reference positions really join) it is a wasted random access.
-// PROBE: how the level-1 bitmap word is loaded (experiment, DMND_SEED_PROBE): 0 plain, 1 non-temporal, 2 device-scope (bypasses the vector L1)
-template<int PROBE>
-__device__ __forceinline__ uint32_t probe_word(const uint32_t* p)
-{
-	if (PROBE == 1) return __builtin_nontemporal_load(p);
-	if (PROBE == 2) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	return *p;
-}
-
-template<bool LEVEL2, int PROBE = 0>
+// HASHED: seeds of the query-indexed algorithm (seed_key_hashed, seed_core.h). A window made of amino acids only has the same
+// key as in the spaced-seed mode and takes the same path; a window that holds a mask or stop letter (the spaced mode's
+// invalid windows) is keyed exactly by seed_key_hashed, which needs a look back for the start of the sequence -- a rare path
+// next to the table probes.
+template<bool LEVEL2, bool HASHED>
 __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int sid, uint64_t map_lo, uint64_t map_hi, int64_t base, uint64_t care64)
 {
 	// Joined positions are staged in LDS and flushed with ONE atomic on the shared counter per workgroup: an atomicAdd per
@@ -142,6 +144,28 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 	__syncthreads();
 	const int64_t p0 = base + ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
 	const bool in_range = p0 < a.t_end;
+	// level-2 bitmap -> table -> staging, for a window whose key passed (or skipped) level 1
+	auto probe_table = [&](uint64_t seed, int64_t pos) {
+		const uint64_t hh = seed_hash(seed);
+		uint64_t slot = hh & a.slot_mask;
+		bool found = false;
+		uint32_t fl = 0;
+		if (!LEVEL2 || ((a.bitmap[(uint32_t)(hh >> 32) & a.bitmap_mask] >> (uint32_t)(hh >> 59)) & 1u))
+			for (;;) {
+				const SeedSlot sl = a.slots[slot];
+				if (sl.key == SEED_EMPTY) break;
+				if (sl.key == seed) { found = true; fl = sl.flags; break; }
+				slot = (slot + 1) & a.slot_mask;
+			}
+		if (!found) return;
+		if ((fl & 0xffu) != SLOT_JOINED) a.slots[slot].flags = (fl & ~0xffu) | SLOT_JOINED;
+		const unsigned k = atomicAdd(&st_n, 1u);                 // LDS atomic
+		if (k < STAGE) { st_slot[k] = (uint32_t)slot; st_loc[k] = pos; }
+		else {                                                    // staging area full (dense matches): direct append
+			const unsigned long long idx = atomicAdd(a.matched_count, 1ull);
+			if (idx < (unsigned long long)a.matched_cap) { a.matched_slot[idx] = (uint32_t)slot; a.matched_loc[idx] = pos; }
+		}
+	};
 	if (in_range) {
 	const uint4 v0 = *reinterpret_cast<const uint4*>(a.tdata + p0);
 	const uint4 v1 = *reinterpret_cast<const uint4*>(a.tdata + p0 + 16);
@@ -152,7 +176,7 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 	for (int j = 0; j < 32; ++j) {
 		const uint32_t l = (w[j >> 2] >> ((j & 3) * 8)) & LETTER_MASK;
 		const uint32_t c = reduce4(l, map_lo, map_hi);
-		codes[j >> 4] |= (uint64_t)c << ((j & 15) * 4);
+		codes[j >> 4] |= (uint64_t)(HASHED && c == 15u ? 0u : c) << ((j & 15) * 4);
 		delim |= (l == L_DELIM ? 1u : 0u) << j;
 		bad |= (c == 15u ? 1u : 0u) << j;
 	}
@@ -162,6 +186,7 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 	// The 16 window starts are handled as two batches of 8 (register pressure). The table key of a window is its 16
 	// class nibbles ANDed with the care-position mask (seed_key_at): one funnel shift + one AND per window.
 	const int64_t first = a.t_begin - p0, last = a.t_end - p0;                 // valid window starts: first <= i < last
+	uint32_t special = 0;                                                        // HASHED: windows holding a mask / stop letter
 #pragma unroll 1
 	for (int half = 0; half < 2; ++half) {
 		uint64_t key[8];
@@ -175,9 +200,12 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 #pragma unroll
 		for (int i = 0; i < 8; ++i) {
 			const int w0 = 8 * half + i;
-			const bool ok = w0 >= first && w0 < last && (((delim >> w0) & span) | ((bad >> w0) & care)) == 0;
+			const bool inside = w0 >= first && w0 < last && ((delim >> w0) & span) == 0;
+			// spaced seeds: no mask / stop letter at a care position; hashed seeds: none anywhere in the window (else: special)
+			const bool ok = inside && ((bad >> w0) & (HASHED ? span : care)) == 0;
+			if (HASHED && inside && !ok) special |= 1u << w0;
 			const uint32_t h = seed_hash_a(key[i]);                              // hash b is only needed past level 1
-			const uint32_t bw = ok ? probe_word<PROBE>(a.bitmap1 + ((h >> 10) & a.bitmap1_mask)) : 0u;
+			const uint32_t bw = ok ? a.bitmap1[(h >> 10) & a.bitmap1_mask] : 0u;
 			word[i] = (bw >> (h & 31)) & (bw >> ((h >> 5) & 31));
 		}
 #pragma unroll
@@ -189,26 +217,17 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 			uint64_t seed = 0;
 #pragma unroll
 			for (int x = 0; x < 8; ++x) if (x == i) seed = key[x];
-			const uint64_t hh = seed_hash(seed);
-			uint64_t slot = hh & a.slot_mask;
-			bool found = false;
-			uint32_t fl = 0;
-			if (!LEVEL2 || ((a.bitmap[(uint32_t)(hh >> 32) & a.bitmap_mask] >> (uint32_t)(hh >> 59)) & 1u))
-				for (;;) {
-					const SeedSlot sl = a.slots[slot];
-					if (sl.key == SEED_EMPTY) break;
-					if (sl.key == seed) { found = true; fl = sl.flags; break; }
-					slot = (slot + 1) & a.slot_mask;
-				}
-			if (!found) continue;
-			if ((fl & 0xffu) != SLOT_JOINED) a.slots[slot].flags = (fl & ~0xffu) | SLOT_JOINED;
-			const unsigned k = atomicAdd(&st_n, 1u);                 // LDS atomic
-			if (k < STAGE) { st_slot[k] = (uint32_t)slot; st_loc[k] = p0 + 8 * half + i; }
-			else {                                                    // staging area full (dense matches): direct append
-				const unsigned long long idx = atomicAdd(a.matched_count, 1ull);
-				if (idx < (unsigned long long)a.matched_cap) { a.matched_slot[idx] = (uint32_t)slot; a.matched_loc[idx] = p0 + 8 * half + i; }
-			}
+			probe_table(seed, p0 + 8 * half + i);
 		}
+	}
+	while (HASHED && special) {
+		const int w0 = __builtin_ctz(special);
+		special &= special - 1;
+		uint64_t seed;
+		if (!seed_key_hashed(a.params, sid, a.tdata + p0 + w0, seed)) continue;
+		const uint32_t h = seed_hash_a(seed);
+		const uint32_t bw = a.bitmap1[(h >> 10) & a.bitmap1_mask];
+		if ((bw >> (h & 31)) & (bw >> ((h >> 5) & 31)) & 1u) probe_table(seed, p0 + w0);
 	}
 	}
 	__syncthreads();
@@ -533,15 +552,12 @@ hipError_t launch_seed_stream(const SeedArgs& a, int sid, hipStream_t st)
 		const int64_t threads = (a.t_end - base + 15) / 16;
 		uint64_t care64 = 0;
 		for (int k = 0; k < c.shape_weight[sid]; ++k) care64 |= (uint64_t)15 << (4 * c.shape_pos[sid][k]);
-		static const int probe = [] { const char* e = getenv("DMND_SEED_PROBE"); return e ? atoi(e) : 0; }();
-		if (c.shape_weight[sid] >= 10 && probe == 1)
-			hipLaunchKernelGGL((seed_stream_fast_kernel<true, 1>), dim3(blocks_for(threads, 256)), dim3(256), 0, st, a, sid, lo, hi, base, care64);
-		else if (c.shape_weight[sid] >= 10 && probe == 2)
-			hipLaunchKernelGGL((seed_stream_fast_kernel<true, 2>), dim3(blocks_for(threads, 256)), dim3(256), 0, st, a, sid, lo, hi, base, care64);
-		else if (c.shape_weight[sid] >= 10)
-			hipLaunchKernelGGL(seed_stream_fast_kernel<true>, dim3(blocks_for(threads, 256)), dim3(256), 0, st, a, sid, lo, hi, base, care64);
-		else
-			hipLaunchKernelGGL(seed_stream_fast_kernel<false>, dim3(blocks_for(threads, 256)), dim3(256), 0, st, a, sid, lo, hi, base, care64);
+		const bool level2 = c.shape_weight[sid] >= 10, hashed = c.seed_encoding == SEED_HASHED;
+		const dim3 grid(blocks_for(threads, 256)), block(256);
+		if (level2 && hashed) hipLaunchKernelGGL((seed_stream_fast_kernel<true, true>), grid, block, 0, st, a, sid, lo, hi, base, care64);
+		else if (level2) hipLaunchKernelGGL((seed_stream_fast_kernel<true, false>), grid, block, 0, st, a, sid, lo, hi, base, care64);
+		else if (hashed) hipLaunchKernelGGL((seed_stream_fast_kernel<false, true>), grid, block, 0, st, a, sid, lo, hi, base, care64);
+		else hipLaunchKernelGGL((seed_stream_fast_kernel<false, false>), grid, block, 0, st, a, sid, lo, hi, base, care64);
 		return hipGetLastError();
 	}
 	hipLaunchKernelGGL(seed_stream_kernel, dim3(blocks_for(a.t_end - a.t_begin, 256)), dim3(256), 0, st, a, sid);

@@ -36,7 +36,7 @@ class SeedParams(ctypes.Structure):
                 ("seed_complexity_cut", ctypes.c_double),
                 ("use_ungapped", ctypes.c_int32), ("short_query_max_len", ctypes.c_int32), ("short_query_cutoff", ctypes.c_int32),
                 ("cutoff_table", ctypes.c_int32 * 32), ("tile_size", ctypes.c_int32), ("simd_lanes", ctypes.c_int32),
-                ("query_translated", ctypes.c_int32), ("pad_", ctypes.c_int32), ("cutoff_table_short", ctypes.c_int32 * 32)]
+                ("query_translated", ctypes.c_int32), ("seed_encoding", ctypes.c_int32), ("cutoff_table_short", ctypes.c_int32 * 32)]
 
 
 SEED_HIT_DTYPE = np.dtype([("query", "<u4"), ("seed_offset", "<i4"), ("subject", "<i8"), ("score", "<i4"), ("pad", "<i4")])

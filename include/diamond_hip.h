@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DMND_ABI_VERSION 2      /* 2: dmnd_match.frame, seed parameters (ungapped filter, translated queries), dmnd_extend_plan(query_contexts) */
+#define DMND_ABI_VERSION 3      /* 2: dmnd_match.frame, seed parameters (ungapped filter, translated queries), dmnd_extend_plan(query_contexts); 3: seed_encoding */
 
 enum {
 	DMND_OK = 0,
@@ -177,7 +177,9 @@ typedef struct {
 	                                  that decides whether a stage-2 score saturates at 255 (src/dp/ungapped_simd.cpp:69-87) */
 	int32_t query_translated;      /* align_mode.query_translated: 1 for blastx blocks (six frames per read); enables the short-frame
 	                                  rules of src/search/stage2.h:51,58-63 (window = frame length for frames of <= 85 letters) */
-	int32_t pad_;
+	int32_t seed_encoding;         /* 0 = spaced-factor seeds of the double-indexed algorithm (--algo 0); 1 = the hashed seeds of the
+	                                  query-indexed algorithm (--algo 1, what AUTO picks for small query sets against databases of
+	                                  >= 256 MB: run/double_indexed.cpp:267-300), set by dmnd_seed_params_set_query_indexed */
 	int32_t cutoff_table_short[32]; /* CutoffTable(ungapped_evalue_short), used for translated frames of 61..85 letters (stage2.h:51) */
 } dmnd_seed_params;
 
@@ -264,6 +266,19 @@ int dmnd_seed_params_preset(dmnd_seed_params* p, int sensitivity, int threads, c
  * seedp_bits as Search::seedp_bits does (src/search/setup.cpp:306-309). The chunk of a seed decides which shape/chunk
  * pass sees it first, i.e. the left-most filter, so results depend on it exactly as in the reference. */
 int dmnd_seed_params_set_index_chunks(dmnd_seed_params* p, int index_chunks, int threads);
+/* Switches a preset to the reference's query-indexed algorithm (config.algo == QUERY_INDEXED: run/double_indexed.cpp:276-300,
+ * search/seed_array/seed_iterator.h:161-198, enum_seeds.h:125-153): hashed seed encoding -- every window that ends in an amino
+ * acid is a seed, mask and stop letters inside it read as class 0 --, low-complexity seeds dropped and masked on the query side
+ * when its seeds are enumerated instead of per joined group, one index chunk. The reference additionally masks the reference
+ * block lazily, i.e. AFTER the seed stage (extend.cpp:168-181): callers run dmnd_mask_block(DMND_TARGET) between
+ * dmnd_seed_search and dmnd_extend in this mode. */
+int dmnd_seed_params_set_query_indexed(dmnd_seed_params* p, int threads);
+/* The reference's choice under --algo auto (run/double_indexed.cpp:267-288) for a query block (host copy, SequenceSet layout)
+ * and a database of db_bytes (the size the reference looks at: the .dmnd file on disk): *query_indexed = 1 iff the query
+ * block has at most 32 Mi letters, the database at least 256 MiB, and the largest per-shape hash set of the query seeds
+ * (next_pow2(1.25 x distinct hashed seeds), HashedSeedSet, data/seed_set.cpp:91-119,144) stays within 32 Mi entries.
+ * Host arithmetic only. */
+int dmnd_auto_query_indexed(const dmnd_seed_params* p, const int8_t* qdata, const int64_t* qlimits, int64_t nq, int64_t db_bytes, int* query_indexed);
 /* Sensitive mode seed configuration (16 shapes of weight 8, search/setup.cpp:86-102; ungapped e-value 10000, seed cut 1.0) */
 int dmnd_seed_params_sensitive(dmnd_seed_params* p, int threads, const dmnd_params* scoring);
 

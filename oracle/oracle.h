@@ -70,6 +70,7 @@ typedef struct {
 	int8_t matrix[32 * 32];          /* ScoreMatrix::matrix8 (= matrix32 values) for ungapped_window */
 	int32_t query_translated;        /* align_mode.query_translated: short-frame rules of stage2.h:51,58-63 */
 	int32_t cutoff_table_short[32];  /* CutoffTable(ungapped_evalue_short), stage2.h:51 */
+	int32_t seed_encoding;           /* 0 = SeedEncoding::SPACED_FACTOR (double-indexed), 1 = HASHED (query-indexed algorithm) */
 } oracle_seed_cfg;
 
 typedef struct { uint32_t query; int32_t seed_offset; int64_t subject; int32_t score; int32_t pad; } oracle_hit;

@@ -105,7 +105,8 @@ class SeedCfg(ctypes.Structure):
                 ("seed_complexity_cut", ctypes.c_double),
                 ("use_ungapped", ctypes.c_int32), ("short_query_max_len", ctypes.c_int32), ("short_query_cutoff", ctypes.c_int32),
                 ("cutoff_table", ctypes.c_int32 * 32), ("tile_size", ctypes.c_int32), ("simd_lanes", ctypes.c_int32),
-                ("matrix", ctypes.c_int8 * 1024), ("query_translated", ctypes.c_int32), ("cutoff_table_short", ctypes.c_int32 * 32)]
+                ("matrix", ctypes.c_int8 * 1024), ("query_translated", ctypes.c_int32), ("cutoff_table_short", ctypes.c_int32 * 32),
+                ("seed_encoding", ctypes.c_int32)]
 
 
 def ungapped_cutoffs(ungapped_evalue, lambda_=0.267, K=0.041, short_bits=25.0):

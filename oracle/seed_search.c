@@ -23,6 +23,15 @@
  * inside one 1024x1024 tile, subjects in ascending location order) -- the AVX2 behaviour SURVEY.md section 7 fixes as canonical.
  * No self mode, no soft masking (run the reference with --masking 0 --motif-masking 0), no translated-query short rules.  Shapes and index chunks are processed in the reference's order so the
  * SEED_MASK bits written by mask_seeds are visible to later chunks exactly as in the reference.
+ * Query-indexed algorithm (--algo 1, and what AUTO picks for small query sets against databases of 256 MB and more;
+ * run/double_indexed.cpp:267-300), seed_encoding = 1:
+ *   HashedSeedIterator                                         src/search/seed_array/seed_iterator.h:161-198
+ *   enum_seeds_hashed (complexity filter + mask on the query)  src/search/seed_array/enum_seeds.h:125-153
+ *   one index chunk; Search::mask_seeds does nothing            src/search/seed_complexity.cpp:81-82
+ * A seed is the window's 4-bit reduced letters under Shape::long_mask (the Murmur hash on top is a bijection and, with one
+ * chunk, its partition is irrelevant). Every window ending in an amino acid is enumerated, plus the first window of a
+ * sequence; inside a window a mask / stop letter contributes 0, except among the first `length` letters of the sequence,
+ * which the iterator's constructor reduces without looking (map_[X] = 23 spills a bit into the letter before).
  * Pinned by tests/test_oracle_seed.py against tests/golden/ext_*.tap (hits tapped at Extension::extend).
  */
 #include <stdint.h>
@@ -75,6 +84,27 @@ static int seed_unreduced(const oracle_seed_cfg* c, int sid, const int8_t* p, ui
 		s = s * (uint64_t)c->reduction_size + (uint64_t)c->reduction[l];
 	}
 	*out = s;
+	return 1;
+}
+
+/* HashedSeedIterator: value of `last_ & long_mask` for the window starting at sequence index j (seq = first letter of the
+ * sequence, len its length), 0 if the iterator does not stop at this window */
+static int seed_hashed(const oracle_seed_cfg* c, int sid, const int8_t* seq, int64_t len, int64_t j, uint64_t* out)
+{
+	const int L = c->shape_len[sid];
+	if (j + L > len) return 0;
+	if (j > 0 && !is_amino_acid(seq[j + L - 1] & LETTER_MASK)) return 0;       /* operator++ only returns on an amino acid */
+	uint64_t last = 0, long_mask = 0;
+	/* the register holds the sequence from its start; letters before the window are shifted out or masked off, except
+	   for the spill of an out-of-range value, which only reaches the letter before it */
+	for (int64_t x = j; x < j + L; ++x) {
+		const int l = seq[x] & LETTER_MASK;
+		last <<= 4;
+		if (x < L) last |= (uint64_t)c->reduction[l];                            /* constructor: reduced blindly (X, '*' -> 23) */
+		else if (is_amino_acid(l)) last |= (uint64_t)c->reduction[l];
+	}
+	for (int k = 0; k < c->shape_weight[sid]; ++k) long_mask |= (uint64_t)15 << (4 * (L - 1 - c->shape_pos[sid][k]));
+	*out = last & long_mask;
 	return 1;
 }
 
@@ -230,12 +260,22 @@ static int ungapped_cutoff(const oracle_seed_cfg* c, int query_len)
 	return (c->query_translated && query_len <= 85) ? c->cutoff_table_short[b] : c->cutoff_table[b];
 }
 
-static int64_t enumerate(const oracle_seed_cfg* c, int sid, const int8_t* data, const int64_t* limits, int64_t n, range_t r, entry_t* out)
+/* query != 0 (hashed encoding only): the query side of enum_seeds_hashed drops low-complexity seeds and sets SEED_MASK on them */
+static int64_t enumerate(const oracle_seed_cfg* c, int sid, int8_t* data, const int64_t* limits, int64_t n, range_t r, entry_t* out, int query)
 {
 	int64_t m = 0;
 	const uint64_t pmask = (1ull << c->seedp_bits) - 1;
 	for (int64_t i = 0; i < n; ++i) {
 		const int64_t len = limits[i + 1] - limits[i] - 1;
+		if (c->seed_encoding == 1) {
+			for (int64_t j = 0; j + c->shape_len[sid] <= len; ++j) {
+				uint64_t seed;
+				if (!seed_hashed(c, sid, data + limits[i], len, j, &seed)) continue;
+				if (query && !seed_is_complex(c, sid, data + limits[i] + j)) { data[limits[i] + j] |= (int8_t)SEED_MASK_BIT; continue; }
+				out[m].seed = seed; out[m].loc = limits[i] + j; ++m;
+			}
+			continue;
+		}
 		for (int64_t j = 0; j + c->shape_len[sid] <= len; ++j) {
 			uint64_t seed;
 			if (!seed_at(c, sid, data + limits[i] + j, &seed)) continue;
@@ -265,7 +305,7 @@ int64_t oracle_seed_search(const oracle_seed_cfg* c, int8_t* qdata, const int64_
 			range_t r;
 			r.lo = b * (size + 1) + (chunk - b) * size;
 			r.hi = r.lo + (chunk < rem ? size + 1 : size);
-			const int64_t mq = enumerate(c, sid, qdata, qlimits, nq, r, qe), mt = enumerate(c, sid, tdata, tlimits, nt, r, te);
+			const int64_t mq = enumerate(c, sid, qdata, qlimits, nq, r, qe, 1), mt = enumerate(c, sid, (int8_t*)tdata, tlimits, nt, r, te, 0);
 			qsort(qe, (size_t)mq, sizeof(entry_t), cmp_entry);
 			qsort(te, (size_t)mt, sizeof(entry_t), cmp_entry);
 			/* pass 1: mask_seeds over every joined group of the chunk (before any search of the chunk, stage0.cpp:173) */
@@ -278,7 +318,7 @@ int64_t oracle_seed_search(const oracle_seed_cfg* c, int8_t* qdata, const int64_
 					while (i1 < mq && qe[i1].seed == qe[i].seed) ++i1;
 					while (j1 < mt && te[j1].seed == te[j].seed) ++j1;
 					if (pass == 0) {
-						if (!seed_is_complex(c, sid, qdata + qe[i].loc)) {
+						if (c->seed_encoding == 0 && !seed_is_complex(c, sid, qdata + qe[i].loc)) {
 							for (int64_t x = i; x < i1; ++x) qdata[qe[x].loc] |= (int8_t)SEED_MASK_BIT;
 							qe[i].seed = qe[i].seed;          /* group is erased: mark by negative loc on the first ref entry */
 							te[j].loc = -te[j].loc - 1;

@@ -27,15 +27,21 @@ extern "C" int64_t emu_seed_search(const SeedParams* cp, const int8_t* matrix, c
 	std::vector<std::unordered_map<uint64_t, Group>> tables(c.n_shapes);
 	std::vector<std::vector<std::pair<uint64_t, int64_t>>> matched(c.n_shapes);
 	// phase 1: index queries, stream the reference, complexity masks -- for every shape
+	const bool hashed = c.seed_encoding == SEED_HASHED;         // query-indexed algorithm: seed_index_kernel filters + masks, no seed_mask_kernel
 	for (int sid = 0; sid < c.n_shapes; ++sid) {
 		auto& tab = tables[sid];
 		for (int64_t p = qlimits[0]; p < qraw; ++p) {
 			uint64_t s;
-			if (seed_at(c, sid, qdata + p, s)) tab[s].q.push_back(p);
+			if (!(hashed ? seed_key_hashed(c, sid, qdata + p, s) : seed_at(c, sid, qdata + p, s))) continue;
+			if (hashed && !seed_is_complex(c, sid, qdata + p)) {
+				mask_time[(size_t)p] = (uint8_t)std::min<int>(mask_time[(size_t)p], sid * c.index_chunks);
+				continue;
+			}
+			tab[s].q.push_back(p);
 		}
 		for (int64_t p = tlimits[0]; p < traw; ++p) {
 			uint64_t s;
-			if (!seed_at(c, sid, tdata + p, s)) continue;
+			if (!(hashed ? seed_key_hashed(c, sid, tdata + p, s) : seed_at(c, sid, tdata + p, s))) continue;
 			auto it = tab.find(s);
 			if (it == tab.end()) continue;
 			it->second.present = true;
@@ -43,7 +49,7 @@ extern "C" int64_t emu_seed_search(const SeedParams* cp, const int8_t* matrix, c
 		}
 		for (auto& kv : tab) {
 			Group& g = kv.second;
-			if (!g.present) continue;
+			if (!g.present || hashed) continue;
 			const int64_t first = *std::min_element(g.q.begin(), g.q.end());
 			if (!seed_is_complex(c, sid, qdata + first)) {
 				g.erased = true;

@@ -109,7 +109,7 @@ class SeedParams(ctypes.Structure):
                 ("seed_complexity_cut", ctypes.c_double),
                 ("use_ungapped", ctypes.c_int32), ("short_query_max_len", ctypes.c_int32), ("short_query_cutoff", ctypes.c_int32),
                 ("cutoff_table", ctypes.c_int32 * 32), ("tile_size", ctypes.c_int32), ("simd_lanes", ctypes.c_int32),
-                ("query_translated", ctypes.c_int32), ("pad_", ctypes.c_int32), ("cutoff_table_short", ctypes.c_int32 * 32)]
+                ("query_translated", ctypes.c_int32), ("seed_encoding", ctypes.c_int32), ("cutoff_table_short", ctypes.c_int32 * 32)]
 
 
 HIT_DTYPE = np.dtype([("query", "<u4"), ("seed_offset", "<i4"), ("subject", "<i8"), ("score", "<i4"), ("pad", "<i4")])
@@ -137,6 +137,7 @@ def seed_params_from_tap(cfg):
         c.cutoff_table_short[i] = table[i]            # ungapped_evalue_short == ungapped_evalue in every golden mode
     c.tile_size, c.simd_lanes = 1024, 32
     c.query_translated = 1 if cfg.get("query_contexts", 1) > 1 else 0
+    c.seed_encoding = int(cfg.get("seed_encoding", 0))         # 1: taps minted with --algo 1 (the test sets it; the tap header has no such field)
     return c
 
 

@@ -160,3 +160,24 @@ def test_cli_blocked_matches_reference(tmp_path):
     ref = open(tmp_path / "ref_x.tsv").read()
     assert len(ref.splitlines()) > 150
     assert open(tmp_path / "hip_x.tsv").read() == ref
+
+
+def test_cli_query_indexed_matches_reference(tmp_path):
+    """--algo 1 on sequences with masked runs (also at sequence starts), stop codons and ambiguity letters, where the hashed
+    seeds of the query-indexed algorithm differ from the spaced seeds of --algo 0: three sensitivities without masking, and
+    default masking (tantan, applied lazily to the targets by the reference)."""
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/diamond not built")
+    g = os.path.join(ROOT, "tests", "golden")
+    for q, db in (("hashed_q.faa", "hashed_db.faa"), ("hashed_sens_q.faa", "hashed_sens_db.faa")):
+        for sens in (["--fast"], [], ["--sensitive"]):
+            for masking in ("0", "tantan"):
+                args = ["blastp"] + sens + ["--algo", "1", "--masking", masking, "-q", os.path.join(g, q), "-d", os.path.join(g, db), "-p", "4"]
+                _run([REF] + args + ["--motif-masking", "0", "-o", str(tmp_path / "ref.tsv")])
+                _run([CLI] + args + ["-o", str(tmp_path / "hip.tsv")])
+                ref = open(tmp_path / "ref.tsv").read()
+                assert len(ref.splitlines()) > 50
+                assert open(tmp_path / "hip.tsv").read() == ref, (q, sens, masking)
+    # the committed reference outputs of the golden runs (tests/golden/hashed*.tsv, minted with --masking 0)
+    _run([CLI, "blastp", "--sensitive", "--algo", "1", "--masking", "0", "-q", os.path.join(g, "hashed_sens_q.faa"), "-d", os.path.join(g, "hashed_sens_db.faa"), "-o", str(tmp_path / "s.tsv"), "-p", "2"])
+    assert open(tmp_path / "s.tsv").read() == open(os.path.join(g, "hashed_sens.tsv")).read()

@@ -49,6 +49,18 @@ def test_seed_hits_equal_reference(ctx, tap):
     assert (np.diff(hits["query"].astype(np.int64)) >= 0).all()
 
 
+@pytest.mark.parametrize("tap", ["ext_hashed.tap", "ext_hashed_default.tap", "ext_hashed_sens.tap"])
+def test_query_indexed_seed_hits_equal_reference(ctx, tap):
+    """--algo 1 (the reference's query-indexed algorithm, its AUTO choice at BASELINE's C2-C4 sizes): goldens minted with
+    --algo 1 on sequences with masked runs (also at sequence starts), stop codons and ambiguity letters."""
+    cfg, recs = read_ext_tap(os.path.join(GOLDEN, tap))
+    ctx.upload_block(hip.QUERY, cfg["query"]["data"], cfg["query"]["limits"])
+    ctx.upload_block(hip.TARGET, cfg["target"]["data"], cfg["target"]["limits"])
+    hits = ctx.seed_search(to_hip_params(dict(cfg, seed_encoding=1)))
+    ref = np.concatenate([r["hits"] for r in recs])
+    assert len(hits) == len(ref) and hit_multiset(hits) == hit_multiset(ref)
+
+
 def test_buffer_overflow_retry_paths_are_transparent(ctx, monkeypatch):
     """Joined-position and hit buffers that are too small (forced through the test hooks) must grow and give the same hits;
     with several shapes the shapes after the overflowing one run with zero remaining capacity."""

@@ -41,3 +41,21 @@ def test_seed_stage_hit_multiset_equals_reference(tap):
         assert (ref["score"] == 255).any() and (ref["score"] > 255).any() and (ref["score"] < 0xFFFF).all()
     for r in recs:                                                # extend() is called once per query with its own hits only
         assert (r["hits"]["query"] // cfg["query_contexts"] == r["query_id"]).all()
+
+
+@pytest.mark.parametrize("tap", ["ext_hashed.tap", "ext_hashed_default.tap", "ext_hashed_sens.tap"])
+def test_query_indexed_mode_equals_reference(tap):
+    """The reference's query-indexed algorithm (--algo 1; what --algo auto picks at BASELINE's C2-C4 sizes) on sequences with
+    masked runs (also at the start of sequences), stop codons and ambiguity letters: hashed seed encoding, complexity filter at
+    enumeration, one index chunk. Goldens: reference run with --algo 1 (tests/golden/hashed_{q,db}.faa)."""
+    cfg, recs = read_ext_tap(os.path.join(GOLDEN, tap))
+    assert cfg["index_chunks"] == 1
+    c = orc.seed_cfg_from_tap(cfg, blosum62_matrix8())
+    c.seed_encoding = 1
+    hits = orc.seed_search(c, cfg["query"]["data"], cfg["query"]["limits"], cfg["target"]["data"], cfg["target"]["limits"])
+    ref = np.concatenate([r["hits"] for r in recs])
+    assert len(ref) > 100
+    assert hit_multiset(hits) == hit_multiset(ref)
+    c.seed_encoding = 0
+    other = orc.seed_search(c, cfg["query"]["data"], cfg["query"]["limits"], cfg["target"]["data"], cfg["target"]["limits"])
+    print("spaced-seed rules on the same input differ in %d hits" % len(set(hit_multiset(other)) ^ set(hit_multiset(ref))))

@@ -37,3 +37,15 @@ def test_emulated_seed_stage_equals_oracle_other_partitionings(chunks, bits):
     a = orc.seed_search(oc, cfg["query"]["data"], cfg["query"]["limits"], cfg["target"]["data"], cfg["target"]["limits"])
     b = emu.seed_search(ec, cfg["query"]["data"], cfg["query"]["limits"], cfg["target"]["data"], cfg["target"]["limits"])
     assert len(a) == len(b) > 300 and hit_set(a) == hit_set(b)
+
+
+@pytest.mark.parametrize("tap", ["ext_hashed.tap", "ext_hashed_default.tap", "ext_hashed_sens.tap"])
+def test_emulated_query_indexed_mode_equals_reference_hits(tap):
+    """The reference's query-indexed algorithm (--algo 1): hashed seed keys (seed_key_hashed), complexity filter and mask when
+    the query seeds are indexed, no per-group mask pass -- on sequences with masked runs, stop codons and ambiguity letters."""
+    cfg, recs = read_ext_tap(os.path.join(GOLDEN, tap))
+    c = emu.seed_params_from_tap(dict(cfg, seed_encoding=1))
+    hits = emu.seed_search(c, cfg["query"]["data"], cfg["query"]["limits"], cfg["target"]["data"], cfg["target"]["limits"],
+                           matrix8=blosum62_matrix8())
+    ref = np.concatenate([r["hits"] for r in recs])
+    assert len(hits) == len(ref) and hit_multiset(hits) == hit_multiset(ref)
