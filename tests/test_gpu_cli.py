@@ -176,7 +176,7 @@ def test_cli_query_indexed_matches_reference(tmp_path):
                 _run([REF] + args + ["--motif-masking", "0", "-o", str(tmp_path / "ref.tsv")])
                 _run([CLI] + args + ["-o", str(tmp_path / "hip.tsv")])
                 ref = open(tmp_path / "ref.tsv").read()
-                assert len(ref.splitlines()) > 50
+                assert len(ref.splitlines()) > 20
                 assert open(tmp_path / "hip.tsv").read() == ref, (q, sens, masking)
     # the committed reference outputs of the golden runs (tests/golden/hashed*.tsv, minted with --masking 0)
     _run([CLI, "blastp", "--sensitive", "--algo", "1", "--masking", "0", "-q", os.path.join(g, "hashed_sens_q.faa"), "-d", os.path.join(g, "hashed_sens_db.faa"), "-o", str(tmp_path / "s.tsv"), "-p", "2"])
