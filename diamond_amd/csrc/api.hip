@@ -195,12 +195,22 @@ extern "C" int dmnd_upload_block(dmnd_ctx* c, int which, const int8_t* data, int
 {
 	if (!c || (which != DMND_QUERY && which != DMND_TARGET) || !data || data_len <= 0 || n_seqs < 0)
 		return fail(DMND_E_ARG, "dmnd_upload_block: bad argument");
+	// the limits are validated before any state of the context changes: the device kernels and load_hits index with them
+	if (limits) {
+		if (n_seqs < 1) return fail(DMND_E_ARG, "dmnd_upload_block: limits given for an empty block");
+		if (limits[0] < 0 || limits[n_seqs] > data_len) return fail(DMND_E_ARG, "dmnd_upload_block: limits outside [0, data_len]");
+		for (int64_t i = 0; i < n_seqs; ++i)
+			if (limits[i + 1] <= limits[i]) return fail(DMND_E_ARG, "dmnd_upload_block: limits must be strictly increasing (sequence " + std::to_string(i) + ")");
+	}
 	HIP_TRY(hipSetDevice(c->device));
 	if (int rc = c->block[which].ensure((size_t)data_len + 64)) return rc;
+	if (limits) if (int rc = c->d_limits[which].ensure((size_t)(n_seqs + 1) * sizeof(int64_t))) return rc;
 	HIP_TRY(hipMemcpyAsync(c->block[which].p, data, (size_t)data_len, hipMemcpyHostToDevice, c->stream));
+	if (limits) HIP_TRY(hipMemcpyAsync(c->d_limits[which].p, limits, (size_t)(n_seqs + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
 	HIP_TRY(sync_stream(c->stream));
 	c->block_len[which] = data_len;
 	c->limits[which].clear();
+	c->coarse[which].clear();
 	if (limits) {
 		c->limits[which].assign(limits, limits + n_seqs + 1);
 		std::vector<uint32_t>& co = c->coarse[which];
@@ -211,9 +221,6 @@ extern "C" int dmnd_upload_block(dmnd_ctx* c, int which, const int8_t* data, int
 			while (sidx + 1 <= n_seqs && limits[sidx + 1] <= pos) ++sidx;
 			co[b] = (uint32_t)std::min<int64_t>(sidx, n_seqs - 1);
 		}
-		if (limits[n_seqs] > data_len) return fail(DMND_E_ARG, "dmnd_upload_block: limits exceed data_len");
-		if (int rc = c->d_limits[which].ensure((size_t)(n_seqs + 1) * sizeof(int64_t))) return rc;
-		HIP_TRY(copy_now(c->stream, c->d_limits[which].p, limits, (size_t)(n_seqs + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
 	}
 	return DMND_OK;
 }

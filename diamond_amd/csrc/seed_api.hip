@@ -216,6 +216,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 {
 	if (!c || !params || !n_hits) return fail(DMND_E_ARG, "dmnd_seed_search: NULL argument");
 	*n_hits = 0;
+	c->n_seed_hits = 0;                                  // a failed or empty search must not leave the previous search's hits behind
 	const std::vector<int64_t>& ql = c->limits[DMND_QUERY];
 	const std::vector<int64_t>& tl = c->limits[DMND_TARGET];
 	if (ql.size() < 2 || tl.size() < 2) return fail(DMND_E_ARG, "dmnd_seed_search: both blocks must be uploaded with limits");
@@ -224,9 +225,21 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	if (sp.n_shapes < 1 || sp.n_shapes > SEED_MAX_SHAPES || sp.index_chunks < 1 || sp.seedp_bits < 1 || sp.seedp_bits > 24
 		|| sp.n_shapes * sp.index_chunks >= SEED_NEVER || sp.ungapped_window < 1 || sp.ungapped_window > 128 || sp.reduction_size < 2)
 		return fail(DMND_E_ARG, "dmnd_seed_search: unsupported seed configuration");
-	for (int i = 0; i < sp.n_shapes; ++i)
-		if (sp.shape_len[i] < 1 || sp.shape_len[i] > 32 || sp.shape_weight[i] < 1 || sp.shape_weight[i] > SEED_MAX_WEIGHT)
-			return fail(DMND_E_ARG, "dmnd_seed_search: bad shape");
+	// seed_is_complex counts reduced letters in count[20] and indexes LNFACT[20] by the counts (<= weight): weight <= 19, classes <= 20
+	if (sp.reduction_size > 20) return fail(DMND_E_ARG, "dmnd_seed_search: more than 20 reduced letter classes");
+	for (int l = 0; l < 32; ++l)
+		if (!((sp.reduction[l] >= 0 && sp.reduction[l] < sp.reduction_size) || sp.reduction[l] == L_MASK))
+			return fail(DMND_E_ARG, "dmnd_seed_search: reduction map entry outside [0, reduction_size) and not the mask letter");
+	for (int i = 0; i < sp.n_shapes; ++i) {
+		if (sp.shape_len[i] < 1 || sp.shape_len[i] > 32 || sp.shape_weight[i] < 1 || sp.shape_weight[i] > 19 || sp.shape_weight[i] > sp.shape_len[i])
+			return fail(DMND_E_ARG, "dmnd_seed_search: bad shape (length 1..32, weight 1..19)");
+		uint32_t mask = 0;
+		for (int k = 0; k < sp.shape_weight[i]; ++k) {
+			if (sp.shape_pos[i][k] < 0 || sp.shape_pos[i][k] >= sp.shape_len[i]) return fail(DMND_E_ARG, "dmnd_seed_search: shape position outside the shape");
+			mask |= 1u << sp.shape_pos[i][k];
+		}
+		if (mask != sp.shape_mask[i]) return fail(DMND_E_ARG, "dmnd_seed_search: shape mask and positions disagree");
+	}
 	if (sp.seed_encoding != SEED_SPACED && sp.seed_encoding != SEED_HASHED) return fail(DMND_E_ARG, "dmnd_seed_search: unknown seed encoding");
 	if (sp.seed_encoding == SEED_HASHED) {
 		if (sp.index_chunks != 1 || sp.reduction_size > 16) return fail(DMND_E_ARG, "dmnd_seed_search: the query-indexed mode runs with one index chunk and a 4-bit reduction");

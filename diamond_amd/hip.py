@@ -68,7 +68,8 @@ EXPORTS = ["dmnd_abi_version", "dmnd_last_error", "dmnd_default_params", "dmnd_c
            "dmnd_seed_hits", "dmnd_seed_kernel_ms", "dmnd_extend_plan", "dmnd_extend", "dmnd_extend_stats", "dmnd_format_tab", "dmnd_set_max_target_seqs",
            "dmnd_seed_params_sensitive", "dmnd_set_gapped_filter", "dmnd_gapped_filter", "dmnd_gapped_filter_ms",
            "dmnd_set_query_contexts", "dmnd_translate", "dmnd_format_tab_translated", "dmnd_mask_block", "dmnd_mask_kernel_ms", "dmnd_seed_params_preset", "dmnd_set_comp_based_stats",
-           "dmnd_seed_params_set_index_chunks", "dmnd_join_blocks", "dmnd_set_sensitivity", "dmnd_touch_streams"]
+           "dmnd_seed_params_set_index_chunks", "dmnd_join_blocks", "dmnd_set_sensitivity", "dmnd_touch_streams",
+           "dmnd_seed_params_set_query_indexed", "dmnd_auto_query_indexed"]
 
 
 def load():
@@ -229,6 +230,27 @@ def set_index_chunks(p, index_chunks, threads=1):
     if lib.dmnd_seed_params_set_index_chunks(ctypes.byref(p), int(index_chunks), int(threads)) != 0:
         raise DiamondHipError(lib.dmnd_last_error().decode())
     return p
+
+
+def set_query_indexed(p, threads=1):
+    """The reference's query-indexed algorithm (--algo 1): hashed seed encoding, one index chunk (dmnd_seed_params_set_query_indexed)."""
+    lib = load()
+    lib.dmnd_seed_params_set_query_indexed.argtypes = [ctypes.POINTER(SeedParams), ctypes.c_int]
+    if lib.dmnd_seed_params_set_query_indexed(ctypes.byref(p), int(threads)) != 0:
+        raise DiamondHipError(lib.dmnd_last_error().decode())
+    return p
+
+
+def auto_query_indexed(p, qdata, qlimits, db_bytes):
+    """The reference's --algo auto choice (dmnd_auto_query_indexed): True = query-indexed."""
+    lib = load()
+    qd = np.ascontiguousarray(qdata, dtype=np.int8)
+    ql = np.ascontiguousarray(qlimits, dtype=np.int64)
+    out = ctypes.c_int(0)
+    lib.dmnd_auto_query_indexed.argtypes = [ctypes.POINTER(SeedParams), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.POINTER(ctypes.c_int)]
+    if lib.dmnd_auto_query_indexed(ctypes.byref(p), qd.ctypes.data, ql.ctypes.data, len(ql) - 1, int(db_bytes), ctypes.byref(out)) != 0:
+        raise DiamondHipError(lib.dmnd_last_error().decode())
+    return bool(out.value)
 
 
 def join_blocks(records, max_target_seqs=25):
