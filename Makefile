@@ -11,7 +11,12 @@ HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-functio
 .PHONY: all product oracle emu clean
 all: product oracle emu
 
-product: diamond_amd/libdiamond_hip.so diamond_amd/libdmnd_synth.so diamond_amd/diamond-hip
+product: diamond_amd/libdiamond_hip.so diamond_amd/libdmnd_synth.so diamond_amd/diamond-hip motifs
+
+# the reference's motif table for soft masking: generated where /root/reference exists, not committed
+.PHONY: motifs
+motifs:
+	@python3 tools/make_motif_table.py >/dev/null || true
 
 diamond_amd/libdiamond_hip.so: $(HIPSRC) $(HIPHDR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIPSRC)

@@ -7,7 +7,7 @@
 // (pos u64, len u32, pad u32) records), SequenceSet layout (src/data/string_set.h:27-60), tabular output
 // (src/output/blast_tab_format.cpp, sequence ids cut at the first blank).
 // Supported: blastp / blastx (--fast, default sensitivity, --sensitive), tantan masking on the GPU (default) or --masking 0
-// (SEG and motif masking are not part of this build: --motif-masking 0 semantics, and the tool says so), -e, -k, -p, -f 6 default columns,
+// motif soft masking (default; table in motifs.bin next to the binary), --algo 0 / 1 / auto; SEG is not part of this build; -e, -k, -p, -f 6 default columns,
 // -b / -c: query and reference blocks cut as load_seqs cuts them, records of a query block merged over the reference blocks as
 // join_blocks does (output/join_blocks.cpp) -> same text as the reference run with the same -b.
 #include <algorithm>
@@ -21,6 +21,7 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+#include <unistd.h>
 #include "../../include/diamond_hip.h"
 
 namespace {
@@ -240,9 +241,20 @@ Options parse(int argc, char** argv)
 	Options o;
 	if (argc < 2) { o.command = "help"; return o; }
 	o.command = argv[1];
-	auto need = [&](int& i) -> std::string { if (i + 1 >= argc) throw std::runtime_error(std::string("Missing parameter for option ") + argv[i]); return argv[++i]; };
+	// short options may carry their value attached (-p4, -k3, -e10000, -b0.002, -c1), as the reference's parser accepts
+	std::vector<std::string> args;
 	for (int i = 2; i < argc; ++i) {
 		const std::string a = argv[i];
+		if (a.size() > 2 && a[0] == '-' && a[1] != '-' && std::string("pkebcqdof").find(a[1]) != std::string::npos) {
+			args.push_back(a.substr(0, 2));
+			args.push_back(a.substr(2));
+		}
+		else args.push_back(a);
+	}
+	const int n_args = (int)args.size();
+	auto need = [&](int& i) -> std::string { if (i + 1 >= n_args) throw std::runtime_error("Missing parameter for option " + args[(size_t)i]); return args[(size_t)++i]; };
+	for (int i = 0; i < n_args; ++i) {
+		const std::string a = args[(size_t)i];
 		if (a == "-q" || a == "--query") o.query = need(i);
 		else if (a == "-d" || a == "--db") o.db = need(i);
 		else if (a == "-o" || a == "--out") o.out = need(i);
@@ -251,8 +263,8 @@ Options parse(int argc, char** argv)
 		else if (a == "-k" || a == "--max-target-seqs") o.k = std::atoi(need(i).c_str());
 		else if (a == "-e" || a == "--evalue") o.evalue = std::atof(need(i).c_str());
 		else if (a == "--fast") o.fast = true;
-		else if (a == "-b" || a == "--block-size" || (a.size() > 2 && a.compare(0, 2, "-b") == 0)) { o.block_size = std::atof(a.size() > 2 && a[1] == 'b' ? a.c_str() + 2 : need(i).c_str()); if (o.block_size <= 0.0) throw std::runtime_error("Invalid block size."); }
-		else if (a == "-c" || a == "--index-chunks" || (a.size() > 2 && a.compare(0, 2, "-c") == 0)) { o.index_chunks = std::atoi(a.size() > 2 && a[1] == 'c' ? a.c_str() + 2 : need(i).c_str()); if (o.index_chunks < 1) throw std::runtime_error("Invalid number of index chunks."); }
+		else if (a == "-b" || a == "--block-size") { o.block_size = std::atof(need(i).c_str()); if (o.block_size <= 0.0) throw std::runtime_error("Invalid block size."); }
+		else if (a == "-c" || a == "--index-chunks") { o.index_chunks = std::atoi(need(i).c_str()); if (o.index_chunks < 1) throw std::runtime_error("Invalid number of index chunks."); }
 		else if (a == "--comp-based-stats") { o.cbs = std::atoi(need(i).c_str()); if (o.cbs != 0 && o.cbs != 1) throw std::runtime_error("Only --comp-based-stats 0 and 1 are implemented."); }
 		else if (a == "--masking") o.masking = need(i);
 		else if (a == "--motif-masking") o.motif_masking = need(i);
@@ -315,8 +327,7 @@ int run_blastp(const Options& o)
 	const bool tantan = o.masking.empty() || o.masking == "1" || o.masking == "tantan";
 	if (!tantan && o.masking != "0" && o.masking != "none")
 		throw std::runtime_error("Only --masking tantan (default) and --masking 0 are implemented.");
-	if (o.motif_masking != "0")
-		std::cerr << "Warning: motif masking is not implemented; running as --motif-masking 0.\n";
+	if (!o.motif_masking.empty() && o.motif_masking != "0" && o.motif_masking != "1") throw std::runtime_error("Permitted values for --motif-masking: 0, 1");
 	const auto t_all = std::chrono::steady_clock::now();
 	SeqBlock q_all, t_all_seqs;
 	const bool blastx = o.command == "blastx";
@@ -390,6 +401,20 @@ int run_blastp(const Options& o)
 		if (o.index_chunks > 1) throw std::runtime_error("The query-indexed algorithm of this build runs with one index chunk (-c1).");
 		chk(dmnd_seed_params_set_query_indexed(&sp, threads));
 	}
+	// motif soft masking (soft_masking_algo, search/setup.cpp:322-335): on by default up to --sensitive, needs masking enabled
+	// when forced on. The motif table is reference data (tools/make_motif_table.py -> motifs.bin next to this binary).
+	bool motifs = o.motif_masking.empty() ? sens <= DMND_SENS_SENSITIVE : o.motif_masking == "1";
+	if (o.motif_masking == "1" && !tantan) throw std::runtime_error("Soft masking requires masking.");
+	if (motifs) {
+		std::string dir = ".";
+		{ char buf[4096]; const ssize_t n = readlink("/proc/self/exe", buf, sizeof buf - 1); if (n > 0) { buf[n] = 0; dir = buf; dir = dir.substr(0, dir.find_last_of('/')); } }
+		std::ifstream f(dir + "/motifs.bin", std::ios::binary);
+		std::vector<uint64_t> codes;
+		uint64_t c;
+		while (f.read((char*)&c, 8)) codes.push_back(c);
+		if (codes.empty()) { std::cerr << "Warning: " << dir << "/motifs.bin not found (tools/make_motif_table.py); running as --motif-masking 0.\n"; motifs = false; }
+		else chk(dmnd_set_motif_table(codes.data(), (int64_t)codes.size()));
+	}
 	// query-indexed + masking: the reference masks a target only when the extension stage loads it (lazy masking,
 	// extend.cpp:168-181; run/double_indexed.cpp:300), i.e. the seed stage sees the unmasked reference block
 	const bool lazy_masking = algo == 1 && tantan;
@@ -401,6 +426,7 @@ int run_blastp(const Options& o)
 	for (size_t i = 0; i < qid.size(); ++i) qid[i] = short_id(qtitles[i]);
 	for (size_t i = 0; i < tid.size(); ++i) tid[i] = short_id(t_all_seqs.ids[i]);
 	double ms_upload = 0, ms_mask = 0, ms_seed = 0, ms_ext = 0;
+	int64_t motif_letters = 0;
 	std::vector<int8_t> t_masked;         // lazily masked copy of the reference block at hand (query-indexed algorithm)
 	int64_t total_hits = 0, total_matches = 0, aligned = 0, mq_total = 0, mt_total = 0;
 	char line[8192];
@@ -419,6 +445,7 @@ int run_blastp(const Options& o)
 			mq_total += mq;
 			ms_mask += ms_since(t0);
 		}
+		if (motifs) { int64_t n = 0; chk(dmnd_soft_mask_block(ctx, DMND_QUERY, &n)); motif_letters += n; }
 		std::vector<dmnd_match> joined;                       // the query block's records against all reference blocks
 		for (const Range& tr : t_blocks) {
 			// the reference re-reads and re-masks every reference block for every query block (run/double_indexed.cpp:404-470)
@@ -444,6 +471,7 @@ int run_blastp(const Options& o)
 			// up-front masking: every block of a multi-block database for every query block; a single block only once (its host
 			// copy keeps the masked letters and is uploaded as it is from then on)
 			if (tantan && !lazy_masking && (t_blocks.size() > 1 || &qr == &q_blocks.front())) mask_target();
+			if (motifs && algo == 0) { int64_t n = 0; chk(dmnd_soft_mask_block(ctx, DMND_TARGET, &n)); if (&qr == &q_blocks.front()) motif_letters += n; }
 			t0 = std::chrono::steady_clock::now();
 			int64_t n_hits = 0;
 			chk(dmnd_seed_search(ctx, &sp, &n_hits));
@@ -476,6 +504,7 @@ int run_blastp(const Options& o)
 	if (out != stdout) std::fclose(out);
 	dmnd_destroy(ctx);
 	std::cerr << "Uploading blocks to HBM...  [" << ms_upload / 1e3 << "s]\n";
+	if (motifs) std::cerr << "Soft-masked letters (motifs): " << motif_letters << "\n";
 	if (tantan) std::cerr << "Masking queries and reference (tantan)...  [" << ms_mask / 1e3 << "s]  masked letters: " << mq_total << " + " << mt_total << "\n";
 	std::cerr << "Searching alignments (seed stage)...  [" << ms_seed / 1e3 << "s]  hits=" << total_hits << "\n";
 	std::cerr << "Computing alignments (extension stage)...  [" << ms_ext / 1e3 << "s]\n";

@@ -103,6 +103,10 @@ struct dmnd_ctx {
 	double gapped_filter_evalue = 0.0, gf_ms = 0.0;
 	// tantan masking (mask_api.hip)
 	dmnd::DevBuf mask_lr, mask_pb, mask_scale;
+	// motif soft masking (dmnd_soft_mask_block): a copy of each block with the motif stretches masked, read by the seed
+	// stage for seed generation only; soft_valid is dropped whenever the block changes
+	dmnd::DevBuf soft[2], motif_hit, motif_table;
+	bool soft_valid[2] = { false, false };
 	double mask_ms = 0.0;
 	double seed_ms[5] = { 0, 0, 0, 0, 0 };
 	// extension-stage statistics of the last dmnd_extend (extend_host.hip)

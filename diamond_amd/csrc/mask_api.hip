@@ -2,6 +2,7 @@
 // Replaces mask_seqs(seqs, Masking::get(), true, MaskingAlgo::TANTAN) (src/masking/masking.cpp:225-251) as the reference
 // applies it to the reference block (run/double_indexed.cpp:122-127) and to the query block (:737-740).
 #pragma clang fp contract(off)
+#include <algorithm>
 #include <cmath>
 #include <vector>
 #include "ctx.h"
@@ -55,9 +56,54 @@ bool likelihood_ratios(const int8_t* m8, float* lr)
 
 }
 
+namespace { std::vector<uint64_t> g_motifs; }
+
+extern "C" int dmnd_set_motif_table(const uint64_t* codes, int64_t n)
+{
+	if (n < 0 || (n > 0 && !codes) || n > 8192) return fail(DMND_E_ARG, "dmnd_set_motif_table: at most 8192 motifs");
+	g_motifs.assign(codes, codes + n);
+	std::sort(g_motifs.begin(), g_motifs.end());
+	g_motifs.erase(std::unique(g_motifs.begin(), g_motifs.end()), g_motifs.end());
+	return DMND_OK;
+}
+
+extern "C" int64_t dmnd_motif_table_size(void) { return (int64_t)g_motifs.size(); }
+
+extern "C" int dmnd_soft_mask_block(dmnd_ctx* c, int which, int64_t* n_covered)
+{
+	if (!c || (which != DMND_QUERY && which != DMND_TARGET)) return fail(DMND_E_ARG, "dmnd_soft_mask_block: bad argument");
+	if (!c->block[which].p || c->limits[which].size() < 2) return fail(DMND_E_ARG, "dmnd_soft_mask_block: block must be uploaded with limits");
+	if (n_covered) *n_covered = 0;
+	c->soft_valid[which] = false;
+	if (g_motifs.empty()) return DMND_OK;                     // no table: nothing is soft-masked (as --motif-masking 0)
+	HIP_TRY(hipSetDevice(c->device));
+	hipStream_t st = c->stream;
+	const std::vector<int64_t>& lim = c->limits[which];
+	const int64_t raw = c->block_len[which];
+	if (int rc = c->soft[which].ensure((size_t)raw + 64)) return rc;
+	if (int rc = c->motif_hit.ensure((size_t)raw + 64)) return rc;
+	if (int rc = c->motif_table.ensure(g_motifs.size() * sizeof(uint64_t))) return rc;
+	if (int rc = c->counters.ensure(64 * sizeof(unsigned long long))) return rc;
+	HIP_TRY(hipMemcpyAsync(c->motif_table.p, g_motifs.data(), g_motifs.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(c->soft[which].p, c->block[which].p, (size_t)raw, hipMemcpyDeviceToDevice, st));
+	HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(unsigned long long), st));
+	MotifArgs a;
+	a.data = c->block[which].as<int8_t>(); a.soft = c->soft[which].as<int8_t>(); a.hit = c->motif_hit.as<uint8_t>();
+	a.limits = c->d_limits[which].as<int64_t>(); a.n_seqs = (int64_t)lim.size() - 1; a.begin = lim.front(); a.end = lim.back();
+	a.table = c->motif_table.as<uint64_t>(); a.n_table = (int)g_motifs.size(); a.max_range = MOTIF_MAX_RANGE;
+	a.n_covered = c->counters.as<unsigned long long>();
+	HIP_TRY(launch_motif_mask(a, st));
+	unsigned long long n = 0;
+	HIP_TRY(copy_now(st, &n, c->counters.p, sizeof(n), hipMemcpyDeviceToHost));
+	if (n_covered) *n_covered = (int64_t)n;
+	c->soft_valid[which] = true;
+	return DMND_OK;
+}
+
 extern "C" int dmnd_mask_block(dmnd_ctx* c, int which, int8_t* host_data, int64_t* n_masked)
 {
 	if (!c || (which != DMND_QUERY && which != DMND_TARGET)) return fail(DMND_E_ARG, "dmnd_mask_block: bad argument");
+	c->soft_valid[which] = false;
 	if (!c->block[which].p || c->limits[which].size() < 2) return fail(DMND_E_ARG, "dmnd_mask_block: block must be uploaded with limits");
 	HIP_TRY(hipSetDevice(c->device));
 	hipStream_t st = c->stream;

@@ -48,3 +48,72 @@ DMND_HD float tantan_group_sum(float v, Shfl shfl)
 }
 
 }  // namespace dmnd
+
+// ---- motif soft masking -------------------------------------------------------------------------------------------------
+// The reference soft-masks abundant 8-mer motifs while seeds are enumerated (mask_motifs, src/masking/masking.cpp:110-131;
+// table: src/masking/motifs.cpp, ~8000 8-mers; Block::soft_mask / remove_soft_masking, src/data/block/block.cpp:164-177;
+// enum_seeds, src/search/seed_array/enum_seeds.h:240-271): inside a sequence, every 8-mer of standard amino acids found
+// in the table covers its 8 letters; covered stretches (touching ones merge: Mask::Ranges::push_back, masking/def.h:72-78) are
+// replaced by the mask letter for the enumeration only -- unless the covered letters make up half of the sequence or more
+// (then nothing is masked), and only stretches of at most max_motif_len (30) letters. The letters are restored before the
+// filters and the extension run; on the query side the seed positions whose shape window touches a masked stretch keep
+// a SEED_MASK bit (MaskingTable::remove, masking.cpp:89-102).
+namespace dmnd {
+
+enum { MOTIF_LEN = 8, MOTIF_MAX_RANGE = 30 };
+
+// code of the 8-mer starting at p (Kmer<8>: base-20 polynomial of the letters), false if it holds a non-standard letter
+DMND_HD bool motif_code_at(const int8_t* p, uint64_t& code)
+{
+	uint64_t c = 0;
+	for (int i = 0; i < MOTIF_LEN; ++i) {
+		const int l = p[i] & 31;
+		if (l >= 20) return false;
+		c = c * 20 + (uint64_t)l;
+	}
+	code = c;
+	return true;
+}
+
+// sorted table lookup
+DMND_HD bool motif_in_table(const uint64_t* table, int n, uint64_t code)
+{
+	int lo = 0, hi = n;
+	while (lo < hi) {
+		const int mid = (lo + hi) >> 1;
+		if (table[mid] < code) lo = mid + 1; else hi = mid;
+	}
+	return lo < n && table[lo] == code;
+}
+
+// One sequence: hit[x] != 0 iff the 8-mer starting at x is a motif (x + 8 <= len). Writes the mask letter over the covered
+// stretches of `seq` that qualify; returns the number of covered letters (what the reference's statistics count).
+DMND_HD int motif_mask_sequence(int8_t* seq, const uint8_t* hit, int len, int max_range)
+{
+	if (len < MOTIF_LEN) return 0;
+	// covered[x] = a motif starts in [x - 7, x]
+	int covered = 0, since = MOTIF_LEN;                   // since: distance to the last motif start at or before x
+	for (int x = 0; x < len; ++x) {
+		since = (x + MOTIF_LEN <= len && hit[x]) ? 0 : since + 1;
+		covered += since < MOTIF_LEN;
+	}
+	if (2 * covered >= len) return 0;                      // (double) n / len >= 0.5
+	since = MOTIF_LEN;
+	int run_begin = -1;
+	for (int x = 0; x <= len; ++x) {
+		bool cov = false;
+		if (x < len) {
+			since = (x + MOTIF_LEN <= len && hit[x]) ? 0 : since + 1;
+			cov = since < MOTIF_LEN;
+		}
+		if (cov && run_begin < 0) run_begin = x;
+		if (!cov && run_begin >= 0) {
+			if (x - run_begin <= max_range)
+				for (int y = run_begin; y < x; ++y) seq[y] = 23;
+			run_begin = -1;
+		}
+	}
+	return covered;
+}
+
+}  // namespace dmnd

@@ -19,4 +19,19 @@ struct TantanArgs {
 
 hipError_t launch_tantan(const TantanArgs& a, hipStream_t st);
 
+// motif soft masking (mask_core.h): hit[p] = the 8-mer at block position p is in the sorted table; then per sequence the
+// qualifying covered stretches of `soft` (a copy of the block) are overwritten with the mask letter
+struct MotifArgs {
+	const int8_t* data;           // block letters
+	int8_t* soft;                 // copy of the block that receives the masks
+	uint8_t* hit;                 // scratch, indexed like data
+	const int64_t* limits;
+	int64_t n_seqs, begin, end;   // letter range [limits[0], limits[n_seqs])
+	const uint64_t* table;        // sorted 8-mer codes (HBM)
+	int n_table;
+	int max_range;
+	unsigned long long* n_covered;
+};
+hipError_t launch_motif_mask(const MotifArgs& a, hipStream_t st);
+
 }  // namespace dmnd

@@ -132,6 +132,41 @@ __global__ __launch_bounds__(256) void tantan_kernel(const TantanArgs a)
 
 }  // namespace
 
+// ---- motif soft masking ---------------------------------------------------------------------------------------------
+enum { MOTIF_TABLE_MAX = 8192, MOTIF_CHUNK = 1 << 15 };
+
+// a workgroup keeps the sorted table in LDS (64 KB) and tests the 8-mers of its 32 Ki block positions against it
+__global__ __launch_bounds__(256) void motif_hit_kernel(MotifArgs a)
+{
+	__shared__ uint64_t table[MOTIF_TABLE_MAX];
+	for (int i = threadIdx.x; i < a.n_table; i += blockDim.x) table[i] = a.table[i];
+	__syncthreads();
+	const int64_t p0 = a.begin + (int64_t)blockIdx.x * MOTIF_CHUNK;
+	for (int64_t p = p0 + threadIdx.x; p < p0 + MOTIF_CHUNK && p < a.end; p += blockDim.x) {
+		uint64_t code;
+		a.hit[p] = motif_code_at(a.data + p, code) && motif_in_table(table, a.n_table, code) ? 1 : 0;      // a window across a delimiter holds a letter >= 20
+	}
+}
+
+__global__ void motif_apply_kernel(MotifArgs a)
+{
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= a.n_seqs) return;
+	const int64_t b = a.limits[i];
+	const int len = (int)(a.limits[i + 1] - b - 1);
+	const int covered = motif_mask_sequence(a.soft + b, a.hit + b, len, a.max_range);
+	if (covered) atomicAdd(a.n_covered, (unsigned long long)covered);
+}
+
+hipError_t launch_motif_mask(const MotifArgs& a, hipStream_t st)
+{
+	if (a.n_seqs <= 0 || a.n_table <= 0 || a.n_table > MOTIF_TABLE_MAX) return a.n_table > MOTIF_TABLE_MAX ? hipErrorInvalidValue : hipSuccess;
+	const int64_t chunks = (a.end - a.begin + MOTIF_CHUNK - 1) / MOTIF_CHUNK;
+	motif_hit_kernel<<<dim3((unsigned)chunks), dim3(256), 0, st>>>(a);
+	motif_apply_kernel<<<dim3((unsigned)((a.n_seqs + 127) / 128)), dim3(128), 0, st>>>(a);
+	return hipGetLastError();
+}
+
 hipError_t launch_tantan(const TantanArgs& a, hipStream_t st)
 {
 	if (a.n_seqs <= 0) return hipSuccess;

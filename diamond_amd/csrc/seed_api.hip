@@ -283,6 +283,10 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		SeedArgs a;
 		a.params = sp;
 		a.qdata = c->block[DMND_QUERY].as<int8_t>(); a.tdata = c->block[DMND_TARGET].as<int8_t>();
+		// motif soft masking: seeds come from the masked views; the query-indexed algorithm does not soft-mask the reference
+		// block (search/stage0.cpp:125-127)
+		a.qseed = c->soft_valid[DMND_QUERY] ? c->soft[DMND_QUERY].as<int8_t>() : a.qdata;
+		a.tseed = (c->soft_valid[DMND_TARGET] && sp.seed_encoding == SEED_SPACED) ? c->soft[DMND_TARGET].as<int8_t>() : a.tdata;
 		a.qlimits = c->d_limits[DMND_QUERY].as<int64_t>();
 		a.q_begin = q_begin; a.q_end = q_end; a.t_begin = t_begin; a.t_end = t_end;
 		a.qid_of = c->qid_of.as<uint32_t>(); a.mask_time = c->mask_time.as<uint8_t>();
@@ -308,6 +312,10 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 
 	Timer tm(st);
 	for (int i = 0; i < 5; ++i) c->seed_ms[i] = 0;
+	if (c->soft_valid[DMND_QUERY]) {
+		SeedArgs a = args_for(0, 0, 0);
+		HIP_TRY(launch_seed_soft_time(a, st));
+	}
 	// phase 1: index + stream + mask, every shape. The joined-position lists of all shapes share one buffer.
 	std::vector<unsigned long long> counts((size_t)S + 1, 0);
 	std::vector<int64_t> m_off((size_t)S + 1, 0);

@@ -28,6 +28,7 @@ struct SeedSurvivor { uint32_t m, x; };
 struct SeedArgs {
 	SeedParams params;
 	const int8_t* qdata; const int8_t* tdata;     // block letters (HBM)
+	const int8_t* qseed; const int8_t* tseed;     // the letters seeds are generated from: the blocks, or their motif-soft-masked views
 	const int64_t* qlimits;                       // query block limits (HBM)
 	int64_t q_begin, q_end, t_begin, t_end;       // letter ranges [limits[0], limits[n])
 	const uint32_t* qid_of;                       // query position -> query id
@@ -55,6 +56,8 @@ struct SeedArgs {
 
 hipError_t launch_seed_qid(const int64_t* limits, int64_t n_seqs, uint32_t* qid_of, hipStream_t st);
 hipError_t launch_seed_index(const SeedArgs& a, int sid, hipStream_t st);
+// query seed positions whose shape window touches a soft-masked stretch get their mask time (MaskingTable::remove's bit mask)
+hipError_t launch_seed_soft_time(const SeedArgs& a, hipStream_t st);
 // groups the query positions by slot: stable radix sort of (qslot, position) into (sorted_slot, qlist_out), then the list
 // start/size of every occupied slot is written into the table
 hipError_t launch_seed_lists(const SeedArgs& a, uint32_t* sorted_slot, uint32_t* qlist_out, int slot_bits, void** tmp, size_t* tmp_bytes, hipStream_t st);

@@ -39,8 +39,8 @@ __global__ void seed_index_kernel(SeedArgs a, int sid)
 	const int64_t p = a.q_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (p >= a.q_end) return;
 	uint64_t seed;                                     // table key (seed_key_at)
-	if (!seed_key_at(a.params, sid, a.qdata + p, seed)) return;
-	if (a.params.seed_encoding == SEED_HASHED && !seed_is_complex(a.params, sid, a.qdata + p)) {
+	if (!seed_key_at(a.params, sid, a.qseed + p, seed)) return;
+	if (a.params.seed_encoding == SEED_HASHED && !seed_is_complex(a.params, sid, a.qseed + p)) {
 		// query-indexed algorithm: a low-complexity query seed is dropped and masked when the query seeds are enumerated
 		// (enum_seeds_hashed, enum_seeds.h:141-145), whether or not it joins; one position per thread and shape: no race
 		const uint8_t t = (uint8_t)(sid * a.params.index_chunks);
@@ -57,6 +57,26 @@ __global__ void seed_index_kernel(SeedArgs a, int sid)
 		slot = (slot + 1) & a.slot_mask;
 	}
 	a.qslot[p - a.q_begin] = (uint32_t)slot;            // the per-seed position lists are built by a sort on this (seed_lists_kernel)
+}
+
+// Motif soft masking on the query side: the seed positions whose window of shape sid (clipped at the end of the sequence)
+// touches a soft-masked letter carry the SEED_MASK bit from the first index chunk of that shape on (MaskingTable::remove with
+// template_len = the shape's length, after the query seeds of (shape, chunk 0) were enumerated: enum_seeds.h:255-260)
+__global__ void seed_soft_time_kernel(SeedArgs a)
+{
+	const int64_t p = a.q_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= a.q_end || (a.qdata[p] & LETTER_MASK) == L_DELIM) return;
+	int reach = 0;                                       // letters of the sequence from p on, up to the longest shape
+	int first_soft = 1 << 30;                            // distance to the first soft-masked letter
+	for (; reach < 32 && (a.qdata[p + reach] & LETTER_MASK) != L_DELIM; ++reach)
+		if (first_soft > reach && a.qseed[p + reach] != a.qdata[p + reach]) first_soft = reach;
+	if (first_soft >= 32) return;
+	for (int sid = 0; sid < a.params.n_shapes; ++sid)
+		if (first_soft < a.params.shape_len[sid]) {
+			const uint8_t t = (uint8_t)(sid * a.params.index_chunks);
+			if (t < a.mask_time[p]) a.mask_time[p] = t;
+			return;
+		}
 }
 
 // After the query positions have been sorted by slot (stable: ascending position inside a seed): the first element of every
@@ -93,7 +113,7 @@ __global__ void seed_stream_kernel(SeedArgs a, int sid)
 	uint64_t seed = 0, slot = 0;
 	uint32_t fl = 0;
 	bool found = false;
-	if (p < a.t_end && seed_key_at(a.params, sid, a.tdata + p, seed)) {
+	if (p < a.t_end && seed_key_at(a.params, sid, a.tseed + p, seed)) {
 		slot = seed_hash(seed) & a.slot_mask;
 		for (;;) {
 			const SeedSlot sl = a.slots[slot];
@@ -167,8 +187,8 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 		}
 	};
 	if (in_range) {
-	const uint4 v0 = *reinterpret_cast<const uint4*>(a.tdata + p0);
-	const uint4 v1 = *reinterpret_cast<const uint4*>(a.tdata + p0 + 16);
+	const uint4 v0 = *reinterpret_cast<const uint4*>(a.tseed + p0);
+	const uint4 v1 = *reinterpret_cast<const uint4*>(a.tseed + p0 + 16);
 	const uint32_t w[8] = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };
 	uint64_t codes[2] = { 0, 0 };
 	uint32_t delim = 0, bad = 0;
@@ -224,7 +244,7 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 		const int w0 = __builtin_ctz(special);
 		special &= special - 1;
 		uint64_t seed;
-		if (!seed_key_hashed(a.params, sid, a.tdata + p0 + w0, seed)) continue;
+		if (!seed_key_hashed(a.params, sid, a.tseed + p0 + w0, seed)) continue;
 		const uint32_t h = seed_hash_a(seed);
 		const uint32_t bw = a.bitmap1[(h >> 10) & a.bitmap1_mask];
 		if ((bw >> (h & 31)) & (bw >> ((h >> 5) & 31)) & 1u) probe_table(seed, p0 + w0);
@@ -507,6 +527,12 @@ hipError_t launch_seed_qid(const int64_t* limits, int64_t n_seqs, uint32_t* qid_
 {
 	if (n_seqs == 0) return hipSuccess;
 	hipLaunchKernelGGL(seed_qid_kernel, dim3(blocks_for(n_seqs * 64, 256)), dim3(256), 0, st, limits, n_seqs, qid_of);
+	return hipGetLastError();
+}
+
+hipError_t launch_seed_soft_time(const SeedArgs& a, hipStream_t st)
+{
+	hipLaunchKernelGGL(seed_soft_time_kernel, dim3(blocks_for(a.q_end - a.q_begin, 256)), dim3(256), 0, st, a);
 	return hipGetLastError();
 }
 

@@ -302,6 +302,18 @@ int dmnd_format_tab_translated(const dmnd_match* m, const char* qseqid, const ch
  * reads the same letters. *n_masked (may be NULL) = number of positions at or above the mask probability. */
 int dmnd_mask_block(dmnd_ctx* ctx, int which, int8_t* host_data, int64_t* n_masked);
 double dmnd_mask_kernel_ms(const dmnd_ctx* ctx);
+/* Motif soft masking (default on up to --sensitive: sensitivity_traits.motif_masking, search/setup.cpp:40-53,322-335): while seeds
+ * are enumerated the reference masks stretches covered by abundant 8-mer motifs (mask_motifs, masking/masking.cpp:110-131; the
+ * letters come back before the filters and the extension run, Block::soft_mask / remove_soft_masking, data/block/block.cpp:164-177),
+ * and query seed positions whose shape window touches such a stretch keep a SEED_MASK bit (MaskingTable::remove, masking.cpp:89-102).
+ * dmnd_set_motif_table: the process-wide motif table as Kmer<8> codes (base-20 polynomial of the 8 letters; the reference's
+ * table is src/masking/motifs.cpp -- tools/make_motif_table.py extracts it into diamond_amd/motifs.bin at build time, it is not
+ * part of this repository). dmnd_soft_mask_block: prepares the masked view of an uploaded (and, if wanted, tantan-masked) block
+ * in HBM; dmnd_seed_search then generates seeds from it -- query side always, reference side for spaced seeds only, as the
+ * reference does (search/stage0.cpp:125-127). Uploading or masking a block drops its view. *n_covered = letters under motifs. */
+int dmnd_set_motif_table(const uint64_t* codes, int64_t n);
+int64_t dmnd_motif_table_size(void);
+int dmnd_soft_mask_block(dmnd_ctx* ctx, int which, int64_t* n_covered);
 
 /* --comp-based-stats: 1 = Hauser composition bias (default; HauserCorrection, stats/hauser_correction.cpp), 0 = none.
  * The matrix-adjust modes 2-4 (stats/cbs.cpp) are not implemented. */

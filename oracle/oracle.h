@@ -54,6 +54,9 @@ int oracle_tantan_mask(int8_t* seq, int len, const float* lr, float p_repeat, fl
 double oracle_tantan_lambda(const int8_t* matrix8);
 void oracle_tantan_matrix(const int8_t* matrix8, float* lr);
 
+/* motif soft masking (motif_mask.c) */
+int oracle_motif_mask(int8_t* seq, int len, const uint64_t* table, int n_table, int max_motif_len);
+
 /* ---- seed stage (oracle/seed_search.c) ---- */
 typedef struct {
 	int32_t seedp_bits, index_chunks, hamming_filter_id, n_shapes;

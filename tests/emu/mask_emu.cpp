@@ -93,3 +93,15 @@ extern "C" int emu_tantan_mask(const TantanParams* p, const float* L, int8_t* se
 	for (int i = 0; i < len; ++i) if (mask[(std::size_t)i]) seq[i] = 23;
 	return n_masked;
 }
+
+// motif soft masking of one sequence through the product's per-thread code (mask_core.h): motif_hit_kernel's test per
+// position, motif_apply_kernel's per-sequence rule
+extern "C" int emu_motif_mask(int8_t* seq, int len, const uint64_t* table, int n_table, int max_range)
+{
+	std::vector<uint8_t> hit((size_t)len + 8, 0);
+	for (int p = 0; p + dmnd::MOTIF_LEN <= len; ++p) {
+		uint64_t code;
+		hit[(size_t)p] = dmnd::motif_code_at(seq + p, code) && dmnd::motif_in_table(table, n_table, code) ? 1 : 0;
+	}
+	return dmnd::motif_mask_sequence(seq, hit.data(), len, max_range);
+}

@@ -181,3 +181,80 @@ def test_cli_query_indexed_matches_reference(tmp_path):
     # the committed reference outputs of the golden runs (tests/golden/hashed*.tsv, minted with --masking 0)
     _run([CLI, "blastp", "--sensitive", "--algo", "1", "--masking", "0", "-q", os.path.join(g, "hashed_sens_q.faa"), "-d", os.path.join(g, "hashed_sens_db.faa"), "-o", str(tmp_path / "s.tsv"), "-p", "2"])
     assert open(tmp_path / "s.tsv").read() == open(os.path.join(g, "hashed_sens.tsv")).read()
+
+
+# the reference's own ctest cases on its 389-domain fixture (CMakeLists.txt:553-572: `diamond ARGS -o NAME.out`, then a plain
+# diff against src/test/NAME.out) that this build's options cover; fixtures copied to tests/golden/ref_ctest/
+CTEST = [
+    ("default", ["-p1"]),
+    ("multithreaded", ["-p4"]),
+    ("blocked", ["-c1", "-b0.00002", "-p4"]),
+    ("more-sensitive", ["--more-sensitive", "-c1", "-p4"]),
+    ("very-sensitive", ["--very-sensitive", "-c1", "-p4"]),
+    ("query-indexed", ["--more-sensitive", "-c1", "-p4", "--algo", "1"]),
+    ("comp-based-stats-0", ["--more-sensitive", "-c1", "-p4", "--comp-based-stats", "0"]),
+    ("target-seqs", ["-k3", "-c1", "-p4"]),
+    ("evalue", ["-e10000", "--more-sensitive", "-c1", "-p4"]),
+]
+
+
+@pytest.mark.parametrize("name,args", CTEST, ids=[c[0] for c in CTEST])
+def test_cli_reproduces_reference_ctest_golden(tmp_path, name, args):
+    """DEFAULT command lines: tantan masking, motif soft masking, --algo auto -- no parity flags on either side."""
+    g = os.path.join(ROOT, "tests", "golden", "ref_ctest")
+    assert os.path.exists(os.path.join(ROOT, "diamond_amd", "motifs.bin")), "motif table not generated (tools/make_motif_table.py)"
+    out = str(tmp_path / "out")
+    _run([CLI, "blastp", "-q", os.path.join(g, "data.faa"), "-d", os.path.join(g, "data.faa")] + args + ["-o", out])
+    want = open(os.path.join(g, "diamond-test-blastp-%s.out" % name)).read()
+    got = open(out).read()
+    if got != want:
+        a, b = set(want.splitlines()), set(got.splitlines())
+        raise AssertionError("%s: %d lines only in the golden, %d only in ours; e.g. %s | %s" % (name, len(a - b), len(b - a), sorted(a - b)[:3], sorted(b - a)[:3]))
+
+
+def test_cli_motif_masking_matches_reference_on_planted_motifs(tmp_path):
+    """Synthetic sequences with motifs of the reference's table planted in queries and targets (single, overlapping, chained
+    beyond max_motif_len, covering more than half of a short sequence): default flags on both sides, three sensitivities,
+    both algorithms."""
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/diamond not built")
+    import struct
+    raw = open(os.path.join(ROOT, "diamond_amd", "motifs.bin"), "rb").read()
+    codes = struct.unpack("<%dQ" % (len(raw) // 8), raw)
+    rng = np.random.default_rng(12)
+
+    def letters(code):
+        out = []
+        for _ in range(8):
+            out.append(code % 20)
+            code //= 20
+        return np.array(out[::-1], np.int8)
+
+    db, doff, q, qoff = synth.generate(300, members=8, queries=400, seed=21)
+
+    def plant(data, off):
+        data = data.copy()
+        for i in range(len(off) - 1):
+            b, e = int(off[i]), int(off[i + 1])
+            r = rng.random()
+            if r < 0.5:
+                for _ in range(int(rng.integers(1, 4))):
+                    p = int(rng.integers(b, max(b + 1, e - 8)))
+                    data[p:p + 8] = letters(codes[int(rng.integers(0, len(codes)))])[:max(0, min(8, e - p))]
+            elif r < 0.6 and e - b > 60:                        # 5 motifs back to back: a 40-letter range, too long to mask
+                p = int(rng.integers(b, e - 41))
+                for k in range(5):
+                    data[p + 8 * k:p + 8 * k + 8] = letters(codes[int(rng.integers(0, len(codes)))])
+        return data
+
+    synth.write_fasta(str(tmp_path / "db.faa"), "t", plant(db, doff), doff)
+    synth.write_fasta(str(tmp_path / "q.faa"), "q", plant(q, qoff), qoff)
+    for sens in (["--fast"], [], ["--sensitive"]):
+        for algo in ("0", "1"):
+            args = ["blastp"] + sens + ["--algo", algo, "-q", str(tmp_path / "q.faa"), "-d", str(tmp_path / "db.faa"), "-p", "4"]
+            _run([REF] + args + ["-o", str(tmp_path / "ref.tsv")])
+            log = _run([CLI] + args + ["-o", str(tmp_path / "hip.tsv")])
+            ref = open(tmp_path / "ref.tsv").read()
+            assert len(ref.splitlines()) > 300
+            assert open(tmp_path / "hip.tsv").read() == ref, (sens, algo)
+    assert "Soft-masked letters (motifs):" in log.stderr
