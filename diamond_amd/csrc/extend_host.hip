@@ -724,6 +724,7 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	make_cfg(c, h);
 	h.max_target_seqs = c->max_target_seqs;
 	h.ranking_block_letters = c->ranking_block_letters;
+	h.band_mode_fast = c->band_mode_fast;
 	h.contexts = c->query_contexts;
 	h.use_cbs = c->comp_based_stats != 0;
 	const uint32_t C = (uint32_t)h.contexts;
@@ -868,6 +869,7 @@ extern "C" int dmnd_set_sensitivity(dmnd_ctx* c, int sensitivity)
 {
 	if (!c || sensitivity < DMND_SENS_FAST || sensitivity > DMND_SENS_VERY_SENSITIVE) return fail(DMND_E_ARG, "dmnd_set_sensitivity: bad argument");
 	c->ranking_block_letters = sensitivity >= DMND_SENS_VERY_SENSITIVE ? 800e6 : 2e9;      // extend.cpp:87
+	c->band_mode_fast = sensitivity <= DMND_SENS_SENSITIVE ? 1 : 0;                          // default_ext_mode, extend.cpp:62-75
 	return DMND_OK;
 }
 

@@ -69,7 +69,24 @@ EXPORTS = ["dmnd_abi_version", "dmnd_last_error", "dmnd_default_params", "dmnd_c
            "dmnd_seed_params_sensitive", "dmnd_set_gapped_filter", "dmnd_gapped_filter", "dmnd_gapped_filter_ms",
            "dmnd_set_query_contexts", "dmnd_translate", "dmnd_format_tab_translated", "dmnd_mask_block", "dmnd_mask_kernel_ms", "dmnd_seed_params_preset", "dmnd_set_comp_based_stats",
            "dmnd_seed_params_set_index_chunks", "dmnd_join_blocks", "dmnd_set_sensitivity", "dmnd_touch_streams",
-           "dmnd_seed_params_set_query_indexed", "dmnd_auto_query_indexed"]
+           "dmnd_seed_params_set_query_indexed", "dmnd_auto_query_indexed", "dmnd_set_motif_table", "dmnd_motif_table_size",
+           "dmnd_soft_mask_block"]
+
+
+def set_motif_table(codes):
+    """Installs the process-wide motif table: uint64 codes of 8-letter motifs (base 20, first letter most significant); the
+    reference's table is extracted at build time by tools/make_motif_table.py into diamond_amd/motifs.bin."""
+    lib = load()
+    a = np.ascontiguousarray(codes, dtype=np.uint64)
+    lib.dmnd_set_motif_table.argtypes = [ctypes.c_void_p, ctypes.c_int64]
+    if lib.dmnd_set_motif_table(a.ctypes.data, len(a)) != 0:
+        raise DiamondHipError(lib.dmnd_last_error().decode())
+
+
+def load_motif_table(path=None):
+    """set_motif_table() from diamond_amd/motifs.bin (fails loudly if build() has not produced it)."""
+    path = path or os.path.join(os.path.dirname(os.path.abspath(__file__)), "motifs.bin")
+    set_motif_table(np.fromfile(path, dtype=np.uint64))
 
 
 def load():
@@ -399,6 +416,14 @@ class Context:
 
     def mask_kernel_ms(self):
         return float(self.lib.dmnd_mask_kernel_ms(self.h))
+
+    def soft_mask_block(self, which):
+        """Motif soft masking of the uploaded block (after mask_block): builds the view that seeds are generated from; the
+        block itself is unchanged. Needs set_motif_table() once per process. Returns the number of letters inside motif ranges."""
+        n = ctypes.c_int64(0)
+        self.lib.dmnd_soft_mask_block.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        self._check(self.lib.dmnd_soft_mask_block(self.h, int(which), ctypes.byref(n)))
+        return n.value
 
     def set_comp_based_stats(self, mode):
         """1 = Hauser composition bias (default), 0 = none."""

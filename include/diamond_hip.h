@@ -318,8 +318,9 @@ int dmnd_soft_mask_block(dmnd_ctx* ctx, int which, int64_t* n_covered);
 /* --comp-based-stats: 1 = Hauser composition bias (default; HauserCorrection, stats/hauser_correction.cpp), 0 = none.
  * The matrix-adjust modes 2-4 (stats/cbs.cpp) are not implemented. */
 int dmnd_set_comp_based_stats(dmnd_ctx* ctx, int mode);
-/* The part of the sensitivity that the extension stage reads: ranking_chunk_size counts reference-block letters in units of
- * 2e9, or of 8e8 from --very-sensitive up (src/align/extend.cpp:79-92). Only matters for reference blocks above 1.2e9 letters. */
+/* The part of the sensitivity that the extension stage reads: the band widths around a chain (Extension::Mode::BANDED_FAST up to
+ * --sensitive, BANDED_SLOW from --more-sensitive up: src/align/extend.cpp:62-75, gapped_score.cpp:41-73), and ranking_chunk_size's
+ * unit of reference-block letters (2e9, or 8e8 from --very-sensitive up: extend.cpp:79-92). */
 int dmnd_set_sensitivity(dmnd_ctx* ctx, int sensitivity);
 /* -k / --max-target-seqs (default 25, src/basic/config.h:55) */
 int dmnd_set_max_target_seqs(dmnd_ctx* ctx, int k);

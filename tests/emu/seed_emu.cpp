@@ -14,12 +14,35 @@ using namespace dmnd;
 
 struct EmuHit { uint32_t query; int32_t seed_offset; int64_t subject; int32_t score; int32_t pad; };
 
+// qseed / tseed (may be NULL): the motif-soft-masked views of the blocks that seeds are generated from (dmnd_soft_mask_block)
+extern "C" int64_t emu_seed_search_soft(const SeedParams* cp, const int8_t* matrix, const int8_t* qdata, const int64_t* qlimits, int64_t nq,
+	const int8_t* tdata, const int64_t* tlimits, int64_t nt, const int8_t* qseed, const int8_t* tseed, EmuHit* hits, int64_t cap);
+
 extern "C" int64_t emu_seed_search(const SeedParams* cp, const int8_t* matrix, const int8_t* qdata, const int64_t* qlimits, int64_t nq,
 	const int8_t* tdata, const int64_t* tlimits, int64_t nt, EmuHit* hits, int64_t cap)
+{
+	return emu_seed_search_soft(cp, matrix, qdata, qlimits, nq, tdata, tlimits, nt, nullptr, nullptr, hits, cap);
+}
+
+extern "C" int64_t emu_seed_search_soft(const SeedParams* cp, const int8_t* matrix, const int8_t* qdata, const int64_t* qlimits, int64_t nq,
+	const int8_t* tdata, const int64_t* tlimits, int64_t nt, const int8_t* qseed, const int8_t* tseed, EmuHit* hits, int64_t cap)
 {
 	const SeedParams& c = *cp;
 	const int64_t qraw = qlimits[nq], traw = tlimits[nt];
 	std::vector<uint8_t> mask_time((size_t)qraw + 256, SEED_NEVER);
+	if (!tseed || c.seed_encoding == SEED_HASHED) tseed = tdata;
+	if (qseed) {
+		// seed_soft_time_kernel
+		for (int64_t p = qlimits[0]; p < qraw; ++p) {
+			if ((qdata[p] & LETTER_MASK) == L_DELIM) continue;
+			int first_soft = 1 << 30;
+			for (int r = 0; r < 32 && (qdata[p + r] & LETTER_MASK) != L_DELIM; ++r)
+				if (qseed[p + r] != qdata[p + r]) { first_soft = r; break; }
+			for (int sid = 0; sid < c.n_shapes; ++sid)
+				if (first_soft < c.shape_len[sid]) { mask_time[(size_t)p] = (uint8_t)(sid * c.index_chunks); break; }
+		}
+	}
+	else qseed = qdata;
 	std::vector<uint32_t> qid_of((size_t)qraw, 0);
 	for (int64_t i = 0; i < nq; ++i)
 		for (int64_t p = qlimits[i]; p < qlimits[i + 1]; ++p) qid_of[(size_t)p] = (uint32_t)i;
@@ -32,8 +55,8 @@ extern "C" int64_t emu_seed_search(const SeedParams* cp, const int8_t* matrix, c
 		auto& tab = tables[sid];
 		for (int64_t p = qlimits[0]; p < qraw; ++p) {
 			uint64_t s;
-			if (!(hashed ? seed_key_hashed(c, sid, qdata + p, s) : seed_at(c, sid, qdata + p, s))) continue;
-			if (hashed && !seed_is_complex(c, sid, qdata + p)) {
+			if (!(hashed ? seed_key_hashed(c, sid, qseed + p, s) : seed_at(c, sid, qseed + p, s))) continue;
+			if (hashed && !seed_is_complex(c, sid, qseed + p)) {
 				mask_time[(size_t)p] = (uint8_t)std::min<int>(mask_time[(size_t)p], sid * c.index_chunks);
 				continue;
 			}
@@ -41,7 +64,7 @@ extern "C" int64_t emu_seed_search(const SeedParams* cp, const int8_t* matrix, c
 		}
 		for (int64_t p = tlimits[0]; p < traw; ++p) {
 			uint64_t s;
-			if (!(hashed ? seed_key_hashed(c, sid, tdata + p, s) : seed_at(c, sid, tdata + p, s))) continue;
+			if (!(hashed ? seed_key_hashed(c, sid, tseed + p, s) : seed_at(c, sid, tseed + p, s))) continue;
 			auto it = tab.find(s);
 			if (it == tab.end()) continue;
 			it->second.present = true;

@@ -258,3 +258,14 @@ def test_cli_motif_masking_matches_reference_on_planted_motifs(tmp_path):
             assert len(ref.splitlines()) > 300
             assert open(tmp_path / "hip.tsv").read() == ref, (sens, algo)
     assert "Soft-masked letters (motifs):" in log.stderr
+
+
+@pytest.mark.parametrize("flags,golden", [(["--algo", "0"], "motif.tsv"), (["--fast", "--algo", "1"], "motif_a1.tsv")])
+def test_cli_reproduces_motif_masking_golden(tmp_path, flags, golden):
+    """The committed output of the genuine reference with its default flags on sequences with planted motifs
+    (tests/golden/make_motif_golden.sh)."""
+    g = os.path.join(HERE, "golden")
+    out = str(tmp_path / "hip.tsv")
+    log = _run([CLI, "blastp"] + flags + ["-q", os.path.join(g, "motif_q.faa"), "-d", os.path.join(g, "motif_db.faa"), "-o", out, "-p", "2"])
+    assert "Soft-masked letters (motifs):" in log.stderr
+    assert open(out).read() == open(os.path.join(g, golden)).read()

@@ -18,7 +18,10 @@ if not os.path.exists(src):
     sys.exit(0)
 AA = "ARNDCQEGHILKMFPSTWYV"
 codes = set()
-for m in re.finditer(r'"([A-Z]{8})"', open(src).read()):
+text = open(src).read()
+text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)        # part of the array is commented out in the reference
+text = re.sub(r"//[^\n]*", "", text)
+for m in re.finditer(r'"([A-Z]{8})"', text):
     c = 0
     for ch in m.group(1):
         c = c * 20 + AA.index(ch)
