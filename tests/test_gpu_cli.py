@@ -264,7 +264,7 @@ def test_cli_motif_masking_matches_reference_on_planted_motifs(tmp_path):
 def test_cli_reproduces_motif_masking_golden(tmp_path, flags, golden):
     """The committed output of the genuine reference with its default flags on sequences with planted motifs
     (tests/golden/make_motif_golden.sh)."""
-    g = os.path.join(HERE, "golden")
+    g = os.path.join(ROOT, "tests", "golden")
     out = str(tmp_path / "hip.tsv")
     log = _run([CLI, "blastp"] + flags + ["-q", os.path.join(g, "motif_q.faa"), "-d", os.path.join(g, "motif_db.faa"), "-o", out, "-p", "2"])
     assert "Soft-masked letters (motifs):" in log.stderr
