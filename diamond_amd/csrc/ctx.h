@@ -95,7 +95,7 @@ struct dmnd_ctx {
 	double swipe_ms = 0.0, traceback_ms = 0.0;
 	size_t trace_arena_max = (size_t)8 << 30;
 	// seed-stage buffers (seed_api.hip)
-	dmnd::DevBuf qid_of, mask_time, seed_keys, seed_next, seed_qlist, seed_qkeys, seed_slot2, seed_loc2, seed_survivors, matched_slot, matched_loc, counters, seed_hits, seed_bitmap, seed_deferred, seed_eslot, seed_eloc, seed_hits_sorted, sort_keys[2], sort_idx[2];
+	dmnd::DevBuf qid_of, mask_time, seed_keys, seed_next, seed_qlist, seed_qkeys, seed_slot2, seed_loc2, seed_survivors, seed_need, matched_slot, matched_loc, counters, seed_hits, seed_bitmap, seed_deferred, seed_eslot, seed_eloc, seed_hits_sorted, sort_keys[2], sort_idx[2];
 	void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0;      // rocPRIM radix sort scratch
 	int64_t n_seed_hits = 0;
 	// gapped filter (gapped_api.hip)
@@ -119,6 +119,7 @@ struct dmnd_ctx {
 	int query_contexts = 1;                    // align_mode.query_contexts: 6 for blastx (basic/basic.cpp:40-60)
 	int max_target_seqs = 25;                  // config.max_target_seqs (-k), basic/config.h:55
 	int band_mode_fast = 1;                    // Extension::Mode::BANDED_FAST up to --sensitive, BANDED_SLOW from --more-sensitive up (align/extend.cpp:62-75)
+	std::vector<unsigned long long> seed_trace;   // DMND_TRACE: per shape Hamming survivors and deferred pairs of the last seed search
 	double ranking_block_letters = 2e9;        // default_letters of ranking_chunk_size (align/extend.cpp:87): 8e8 from --very-sensitive up
 };
 

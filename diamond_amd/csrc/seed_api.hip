@@ -270,6 +270,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	if (int rc = c->qid_of.ensure((size_t)q_end * sizeof(uint32_t))) return rc;
 	if (int rc = c->mask_time.ensure((size_t)c->block_len[DMND_QUERY] + 256)) return rc;
 	if (int rc = c->seed_keys.ensure((size_t)S * slots * sizeof(SeedSlot))) return rc;
+	if (int rc = c->seed_need.ensure((size_t)(slots / 32) * sizeof(uint32_t))) return rc;
 	if (int rc = c->seed_next.ensure((size_t)S * nq_pos * sizeof(uint32_t))) return rc;        // qslot
 	if (int rc = c->seed_qlist.ensure((size_t)S * nq_pos * sizeof(uint32_t))) return rc;
 	if (int rc = c->seed_qkeys.ensure((size_t)nq_pos * sizeof(uint32_t))) return rc;
@@ -304,6 +305,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		a.matched_cap = matched_cap;
 		a.deferred = nullptr; a.deferred_count = c->counters.as<unsigned long long>() + S + 1; a.deferred_cap = 0;
 		a.survivors = nullptr; a.survivor_count = c->counters.as<unsigned long long>() + S + 3; a.survivor_cap = 0;
+		a.need_bits = c->seed_need.as<uint32_t>();
 		a.e_key = nullptr; a.e_count = c->counters.as<unsigned long long>() + S + 2; a.e_n = 0;
 		a.matrix = c->matrix.as<int8_t>();
 		a.hits = c->seed_hits.as<dmnd_seed_hit>(); a.hit_count = c->counters.as<unsigned long long>() + S; a.hit_cap = 0;
@@ -316,8 +318,103 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		SeedArgs a = args_for(0, 0, 0);
 		HIP_TRY(launch_seed_soft_time(a, st));
 	}
-	// phase 1: index + stream + mask, every shape. The joined-position lists of all shapes share one buffer.
 	std::vector<unsigned long long> counts((size_t)S + 1, 0);
+	unsigned long long n_pairs = 0;
+	// Short seeds: one pass per shape -- index, stream with the Hamming filter fused in, mask, stage-2 scoring of the survivors,
+	// deferred pairs. A shape's masks only depend on this and earlier shapes, and so does the left-most rule (t_now).
+	bool fused = seed_stream_can_fuse(sp);
+	if (const char* e = getenv("DMND_SEED_FUSED")) fused = fused && atoi(e) != 0;
+	if (fused) {
+		unsigned long long* ctr = c->counters.as<unsigned long long>();
+		int64_t m_cap = std::max<int64_t>(std::max<int64_t>((int64_t)1 << 22, 4 * nq_pos), (int64_t)std::min(c->matched_loc.cap / sizeof(int64_t), c->matched_slot.cap / sizeof(uint32_t)));
+		if (const char* e = getenv("DMND_SEED_MATCHED_CAP")) m_cap = std::max<int64_t>(1, atoll(e));
+		int64_t surv_cap = std::max<int64_t>((int64_t)1 << 20, (int64_t)(c->seed_survivors.cap / sizeof(SeedSurvivor)));
+		if (const char* e = getenv("DMND_SEED_SURVIVOR_CAP")) surv_cap = std::max<int64_t>(1, atoll(e));
+		int64_t hit_cap = std::max<int64_t>((int64_t)1 << 20, (int64_t)(c->seed_hits.cap / sizeof(dmnd_seed_hit)));
+		if (const char* e = getenv("DMND_SEED_HIT_CAP")) hit_cap = std::max<int64_t>(1, atoll(e));
+		if (int rc = c->seed_hits.ensure((size_t)hit_cap * sizeof(dmnd_seed_hit))) return rc;
+		HIP_TRY(hipMemsetAsync(ctr, 0, (size_t)(S + 4) * sizeof(unsigned long long), st));
+		c->seed_trace.assign((size_t)2 * S, 0);
+		int64_t hits_bound = 0;                              // every survivor gives at most one hit
+		std::vector<unsigned long long> host_ctr((size_t)S + 4);
+		for (int sid = 0; sid < S; ++sid) {
+			SeedArgs a = args_for(sid, 0, 0);
+			tm.start();
+			HIP_TRY(launch_seed_index(a, sid, st));
+			HIP_TRY(launch_seed_lists(a, sid, c->seed_qkeys.as<uint32_t>(), c->seed_qlist.as<uint32_t>() + (size_t)sid * nq_pos, 32, &c->sort_tmp, &c->sort_tmp_bytes, st));
+			c->seed_ms[0] += tm.stop();
+			unsigned long long n = 0, ns = 0;
+			for (int attempt = 0;; ++attempt) {
+				if (int rc = c->matched_slot.ensure((size_t)m_cap * sizeof(uint32_t))) return rc;
+				if (int rc = c->matched_loc.ensure((size_t)m_cap * sizeof(int64_t))) return rc;
+				if (int rc = c->seed_survivors.ensure((size_t)surv_cap * sizeof(SeedSurvivor))) return rc;
+				a.matched_slot = c->matched_slot.as<uint32_t>(); a.matched_loc = c->matched_loc.as<int64_t>(); a.matched_cap = m_cap;
+				a.survivors = c->seed_survivors.as<SeedSurvivor>(); a.survivor_cap = surv_cap;
+				HIP_TRY(hipMemsetAsync(a.matched_count, 0, sizeof(unsigned long long), st));
+				HIP_TRY(hipMemsetAsync(a.survivor_count, 0, sizeof(unsigned long long), st));
+				tm.start();
+				HIP_TRY(launch_seed_stream(a, sid, st, true));
+				c->seed_ms[1] += tm.stop();
+				HIP_TRY(copy_now(c->stream, host_ctr.data(), ctr, host_ctr.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+				n = host_ctr[sid]; ns = host_ctr[S + 3];
+				if ((int64_t)n <= m_cap && (int64_t)ns <= surv_cap) break;
+				if (attempt >= 2) return fail(DMND_E_NOMEM, "dmnd_seed_search: joined-position / survivor buffer overflow");
+				if ((int64_t)n > m_cap) m_cap = (int64_t)n + (int64_t)n / 8 + 1024;
+				if ((int64_t)ns > surv_cap) surv_cap = (int64_t)ns + (int64_t)ns / 8 + 1024;
+			}
+			counts[sid] = n;
+			c->seed_trace[sid] = ns;
+			if (sp.seed_encoding == SEED_SPACED) {
+				tm.start();
+				HIP_TRY(launch_seed_mask(a, sid, st));
+				c->seed_ms[2] += tm.stop();
+			}
+			if (ns == 0) continue;
+			if (hits_bound + (int64_t)ns > hit_cap) {            // grow, keeping the hits of the earlier shapes
+				const int64_t new_cap = hits_bound + (int64_t)ns + (hits_bound + (int64_t)ns) / 2;
+				DevBuf nb;
+				if (int rc = nb.ensure((size_t)new_cap * sizeof(dmnd_seed_hit))) return rc;
+				HIP_TRY(hipMemcpyAsync(nb.p, c->seed_hits.p, (size_t)hit_cap * sizeof(dmnd_seed_hit), hipMemcpyDeviceToDevice, st));
+				HIP_TRY(sync_stream(st));
+				c->seed_hits.release();
+				c->seed_hits = nb;
+				hit_cap = new_cap;
+			}
+			hits_bound += (int64_t)ns;
+			if (int rc = c->seed_deferred.ensure((size_t)ns * sizeof(SeedDeferred))) return rc;      // deferred pairs <= survivors
+			a.hits = c->seed_hits.as<dmnd_seed_hit>(); a.hit_cap = hit_cap;
+			a.deferred = c->seed_deferred.as<SeedDeferred>(); a.deferred_cap = (int64_t)ns;
+			HIP_TRY(hipMemsetAsync(a.deferred_count, 0, 2 * sizeof(unsigned long long), st));
+			HIP_TRY(hipMemsetAsync(a.need_bits, 0, (size_t)(slots / 32) * sizeof(uint32_t), st));
+			tm.start();
+			HIP_TRY(launch_seed_post(a, sid, (int64_t)ns, st));
+			c->seed_ms[3] += tm.stop();
+			if (!sp.use_ungapped) continue;
+			unsigned long long nd = 0;
+			HIP_TRY(copy_now(c->stream, &nd, a.deferred_count, sizeof(nd), hipMemcpyDeviceToHost));
+			c->seed_trace[S + sid] = nd;
+			if (nd == 0) continue;
+			if (int rc = c->seed_eslot.ensure((size_t)n * sizeof(uint64_t))) return rc;
+			if (int rc = c->seed_eloc.ensure((size_t)n * sizeof(uint64_t))) return rc;
+			a.e_key = c->seed_eslot.as<uint64_t>();
+			tm.start();
+			HIP_TRY(launch_seed_collect(a, (int64_t)n, st));
+			unsigned long long ne = 0;
+			HIP_TRY(hipMemcpyAsync(&ne, a.e_count, sizeof(ne), hipMemcpyDeviceToHost, st));
+			HIP_TRY(sync_stream(st));
+			HIP_TRY(sort_keys_u64(c->seed_eslot.as<uint64_t>(), c->seed_eloc.as<uint64_t>(), (int64_t)ne, &c->sort_tmp, &c->sort_tmp_bytes, st));
+			a.e_key = c->seed_eloc.as<uint64_t>();
+			a.e_n = (int64_t)ne;
+			HIP_TRY(launch_seed_deferred(a, sid, (int64_t)nd, st));
+			c->seed_ms[3] += tm.stop();
+		}
+		unsigned long long nh = 0;
+		HIP_TRY(copy_now(c->stream, &nh, ctr + S, sizeof(nh), hipMemcpyDeviceToHost));
+		if ((int64_t)nh > hit_cap) return fail(DMND_E_NOMEM, "dmnd_seed_search: hit buffer overflow");
+		c->n_seed_hits = (int64_t)nh;
+	}
+	else {
+	// phase 1: index + stream + mask, every shape. The joined-position lists of all shapes share one buffer.
 	std::vector<int64_t> m_off((size_t)S + 1, 0);
 	// start from what earlier calls already grew the buffers to: a repeated search of the same scale never takes the overflow path
 	int64_t cap_total = std::max<int64_t>(std::max<int64_t>((int64_t)1 << 22, 4 * nq_pos), (int64_t)std::min(c->matched_loc.cap / sizeof(int64_t), c->matched_slot.cap / sizeof(uint32_t)));
@@ -339,7 +436,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 			SeedArgs a = args_for(sid, std::max<int64_t>(cap_total - off, 0), std::min(off, cap_total));
 			tm.start();
 			HIP_TRY(launch_seed_index(a, sid, st));
-			HIP_TRY(launch_seed_lists(a, c->seed_qkeys.as<uint32_t>(), c->seed_qlist.as<uint32_t>() + (size_t)sid * nq_pos, 32, &c->sort_tmp, &c->sort_tmp_bytes, st));
+			HIP_TRY(launch_seed_lists(a, sid, c->seed_qkeys.as<uint32_t>(), c->seed_qlist.as<uint32_t>() + (size_t)sid * nq_pos, 32, &c->sort_tmp, &c->sort_tmp_bytes, st));
 			c->seed_ms[0] += tm.stop();
 			tm.start();
 			HIP_TRY(launch_seed_stream(a, sid, st));
@@ -360,6 +457,14 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		HIP_TRY(launch_seed_mask(a, sid, st));
 		c->seed_ms[2] += tm.stop();
 	}
+	if (getenv("DMND_TRACE")) {
+		HIP_TRY(hipMemsetAsync(c->counters.as<unsigned long long>() + S + 3, 0, sizeof(unsigned long long), st));
+		for (int sid = 0; sid < S; ++sid) {
+			SeedArgs a = args_for(sid, (int64_t)counts[sid], m_off[sid]);
+			HIP_TRY(launch_seed_count_pairs(a, (int64_t)counts[sid], c->counters.as<unsigned long long>() + S + 3, st));
+		}
+		HIP_TRY(copy_now(c->stream, &n_pairs, c->counters.as<unsigned long long>() + S + 3, sizeof(n_pairs), hipMemcpyDeviceToHost));
+	}
 	// phase 2: pair filter per shape; hit and deferred-pair buffers grow on overflow
 	int64_t hit_cap = std::max<int64_t>(std::max<int64_t>((int64_t)1 << 20, m_off[S] / 8), (int64_t)(c->seed_hits.cap / sizeof(dmnd_seed_hit)));
 	if (const char* e = getenv("DMND_SEED_HIT_CAP")) hit_cap = std::max<int64_t>(1, atoll(e));
@@ -371,6 +476,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		HIP_TRY(hipMemsetAsync(c->counters.as<unsigned long long>() + S, 0, sizeof(unsigned long long), st));
 		double ms = 0;
 		bool def_overflow = false;
+		c->seed_trace.assign((size_t)2 * S, 0);
 		unsigned long long def_max = 0;
 		for (int sid = 0; sid < S; ++sid) {
 			SeedArgs a = args_for(sid, (int64_t)counts[sid], m_off[sid]);
@@ -378,6 +484,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 			a.hit_cap = hit_cap;
 			a.deferred = c->seed_deferred.as<SeedDeferred>(); a.deferred_cap = def_cap;
 			HIP_TRY(hipMemsetAsync(a.deferred_count, 0, 2 * sizeof(unsigned long long), st));
+			HIP_TRY(hipMemsetAsync(a.need_bits, 0, (size_t)(slots / 32) * sizeof(uint32_t), st));
 			tm.start();
 			// many joined positions (short seeds): sort them by seed and run the LDS-tiled filter; otherwise one thread per position
 			bool tiled = (int64_t)counts[sid] >= ((int64_t)1 << 22);
@@ -404,6 +511,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 					if (pass >= 2) return fail(DMND_E_NOMEM, "dmnd_seed_search: survivor buffer overflow");
 					surv_cap = (int64_t)ns + 1024;
 				}
+				c->seed_trace[sid] = ns;
 				HIP_TRY(launch_seed_post(a, sid, (int64_t)ns, st));
 			}
 			else
@@ -413,6 +521,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 			// pairs scoring above 255 (rare): resolve the reference's SIMD-batch saturation rule in a second pass
 			unsigned long long nd = 0;
 			HIP_TRY(copy_now(c->stream, &nd, a.deferred_count, sizeof(nd), hipMemcpyDeviceToHost));
+			c->seed_trace[S + sid] = nd;
 			if (nd == 0) continue;
 			def_max = std::max(def_max, nd);
 			if ((int64_t)nd > def_cap) { def_overflow = true; continue; }
@@ -438,6 +547,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		if ((int64_t)nh > hit_cap) hit_cap = (int64_t)nh + 1024;
 		if (def_overflow) def_cap = (int64_t)def_max + 1024;
 	}
+	}
 	// order the hits by (query, subject, seed_offset, score) on the device: what align_queries needs (hits grouped by query),
 	// made deterministic (the append order of the kernels is not)
 	if (c->n_seed_hits > 0) {
@@ -457,6 +567,10 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	if (getenv("DMND_TRACE")) {
 		std::fprintf(stderr, "dmnd_seed_search: %d shapes, %lld query positions, joined reference positions per shape:", S, (long long)nq_pos);
 		for (int sid = 0; sid < S; ++sid) std::fprintf(stderr, " %llu", counts[sid]);
+		std::fprintf(stderr, " | pairs %llu | Hamming survivors:", n_pairs);
+		for (int sid = 0; sid < S && (size_t)sid < c->seed_trace.size(); ++sid) std::fprintf(stderr, " %llu", c->seed_trace[sid]);
+		std::fprintf(stderr, " | deferred:");
+		for (int sid = 0; sid < S && (size_t)(S + sid) < c->seed_trace.size(); ++sid) std::fprintf(stderr, " %llu", c->seed_trace[S + sid]);
 		std::fprintf(stderr, " | hits %lld | ms index %.2f stream %.2f mask %.2f pairs %.2f\n", (long long)c->n_seed_hits, c->seed_ms[0], c->seed_ms[1], c->seed_ms[2], c->seed_ms[3]);
 	}
 	*n_hits = c->n_seed_hits;

@@ -9,21 +9,24 @@ namespace dmnd {
 
 static const uint64_t SEED_EMPTY = ~0ull;
 static const uint32_t LIST_END = 0xffffffffu;
-// head = start of the seed's query-position list in SeedArgs::qlist, flags = state (low byte) | list size << 8.
+// head = start of the seed's query-position list in SeedArgs::qlist -- or, for a list of ONE, the query position itself;
+// flags = state (low byte) | list size << 8.
 // A free slot is all ones (one memset initialises the table); the state of an occupied slot is written explicitly, and no
 // kernel bit-tests the state of a free slot.
-enum : uint32_t { SLOT_JOINED = 1, SLOT_ERASED = 2, SLOT_NEED = 4 };
+// LOWC: the seed of the group's first query position is not complex (written with the lists; spaced seeds only) -- if the seed
+// joins, seed_mask_kernel turns it into ERASED.
+enum : uint32_t { SLOT_JOINED = 1, SLOT_ERASED = 2, SLOT_LOWC = 8 };
 
 // One entry of the open-addressing query seed table: key, head of the list of query positions, join state -- 16 bytes, so
 // that the probe of the reference stream and the pair filter touch ONE cache line per seed instead of three arrays.
-struct SeedSlot { uint64_t key; uint32_t head; uint32_t flags; };      // NEED: the seed has a deferred pair (score > 255)
+struct SeedSlot { uint64_t key; uint32_t head; uint32_t flags; };
 
 // A (joined reference position, query position) pair whose stage-2 score exceeds 255: whether it saturates depends on the
 // reference's SIMD batch it would have been scored in (simd_batch_size_sorted), resolved in a second pass.
-struct SeedDeferred { int64_t m; uint32_t x; int32_t score; };
+struct SeedDeferred { int64_t sloc; uint32_t slot, x; int32_t score, pad; };
 
-// A (joined reference position m, query position x) pair that passed the Hamming filter of the tiled pair kernel
-struct SeedSurvivor { uint32_t m, x; };
+// A (joined reference position sloc of the seed in `slot`, query position x) pair that passed the Hamming filter
+struct SeedSurvivor { uint32_t slot, x; int64_t sloc; };
 
 struct SeedArgs {
 	SeedParams params;
@@ -47,7 +50,10 @@ struct SeedArgs {
 	uint32_t* matched_slot; int64_t* matched_loc; unsigned long long* matched_count; int64_t matched_cap;
 	SeedDeferred* deferred; unsigned long long* deferred_count; int64_t deferred_cap;
 	SeedSurvivor* survivors; unsigned long long* survivor_count; int64_t survivor_cap;
-	// joined positions of the seeds flagged SLOT_NEED, sorted by (slot, position) for the second pass
+	// need_bits: one bit per slot, set for the seeds that have a deferred pair (1 MB for the 10k-query table: the scan over the
+	// joined positions tests it in L2 instead of reading 16-byte slots all over the table); e_key: the joined positions of those
+	// seeds, sorted by (slot, position) for the second pass
+	uint32_t* need_bits;
 	uint64_t* e_key; unsigned long long* e_count; int64_t e_n;     // key = slot << 40 | position
 	const int8_t* matrix;                         // 32x32 int8 substitution matrix (HBM) for the stage-2 ungapped window score
 	// output
@@ -60,11 +66,15 @@ hipError_t launch_seed_index(const SeedArgs& a, int sid, hipStream_t st);
 hipError_t launch_seed_soft_time(const SeedArgs& a, hipStream_t st);
 // groups the query positions by slot: stable radix sort of (qslot, position) into (sorted_slot, qlist_out), then the list
 // start/size of every occupied slot is written into the table
-hipError_t launch_seed_lists(const SeedArgs& a, uint32_t* sorted_slot, uint32_t* qlist_out, int slot_bits, void** tmp, size_t* tmp_bytes, hipStream_t st);
-hipError_t launch_seed_stream(const SeedArgs& a, int sid, hipStream_t st);
+hipError_t launch_seed_lists(const SeedArgs& a, int sid, uint32_t* sorted_slot, uint32_t* qlist_out, int slot_bits, void** tmp, size_t* tmp_bytes, hipStream_t st);
+// fused = true (short seeds, where a third of the reference positions join): the stream kernel also runs the Hamming filter on
+// every joined pair while the reference letters are at hand, and fills a.survivors; a.matched_* then only serve the deferred pass
+hipError_t launch_seed_stream(const SeedArgs& a, int sid, hipStream_t st, bool fused = false);
+bool seed_stream_can_fuse(const SeedParams& c);
 hipError_t launch_seed_mask(const SeedArgs& a, int sid, hipStream_t st);
 hipError_t launch_seed_pairs(const SeedArgs& a, int sid, int64_t n_matched, hipStream_t st);
 hipError_t launch_seed_pairs_tiled(const SeedArgs& a, int sid, int64_t n_matched, hipStream_t st);      // a.matched_* sorted by slot; fills a.survivors
+hipError_t launch_seed_count_pairs(const SeedArgs& a, int64_t n_matched, unsigned long long* out, hipStream_t st);
 hipError_t launch_seed_post(const SeedArgs& a, int sid, int64_t n_survivors, hipStream_t st);
 hipError_t sort_matched_by_slot(const uint32_t* slot_in, uint32_t* slot_out, const int64_t* loc_in, int64_t* loc_out, int64_t n, int slot_bits,
 	void** tmp, size_t* tmp_bytes, hipStream_t st);

@@ -81,7 +81,7 @@ __global__ void seed_soft_time_kernel(SeedArgs a)
 
 // After the query positions have been sorted by slot (stable: ascending position inside a seed): the first element of every
 // group writes the group's start and size into its slot. state = 0 (occupied, not joined), count in bits 8..31.
-__global__ void seed_lists_kernel(SeedArgs a, const uint32_t* sorted_slot, int64_t n)
+__global__ void seed_lists_kernel(SeedArgs a, int sid, const uint32_t* sorted_slot, const uint32_t* qlist, int64_t n)
 {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
@@ -89,8 +89,13 @@ __global__ void seed_lists_kernel(SeedArgs a, const uint32_t* sorted_slot, int64
 	if (k == LIST_END || (i > 0 && sorted_slot[i - 1] == k)) return;
 	int64_t e = i + 1;
 	while (e < n && sorted_slot[e] == k) ++e;
-	a.slots[k].head = (uint32_t)i;
-	a.slots[k].flags = (uint32_t)(e - i) << 8;
+	// a list of one query position (most seeds): head IS the position -- the probe that finds the slot has it without a second
+	// dependent random read
+	a.slots[k].head = e - i == 1 ? qlist[i] : (uint32_t)i;
+	// Search::mask_seeds evaluates the first query position of a joined group (seed_complexity.cpp:97-99) -- the smallest
+	// position here: the sort is stable. Whether that seed is complex does not depend on the join, so it is decided once here.
+	const bool lowc = a.params.seed_encoding == SEED_SPACED && !seed_is_complex(a.params, sid, a.qdata + a.q_begin + qlist[i]);
+	a.slots[k].flags = ((uint32_t)(e - i) << 8) | (lowc ? SLOT_LOWC : 0u);
 }
 
 // Wave-aggregated append: the lanes of the wavefront that have an element reserve their slots with ONE atomic on the
@@ -124,11 +129,23 @@ __global__ void seed_stream_kernel(SeedArgs a, int sid)
 	}
 	const unsigned long long idx = wave_append(a.matched_count, found);
 	if (!found) return;
-	if ((fl & 0xffu) != SLOT_JOINED) a.slots[slot].flags = (fl & ~0xffu) | SLOT_JOINED;      // benign race: every writer stores the same value
+	if (!(fl & SLOT_JOINED)) a.slots[slot].flags = fl | SLOT_JOINED;      // benign race: every writer stores the same value
 	if (idx < (unsigned long long)a.matched_cap) {
 		a.matched_slot[idx] = (uint32_t)slot;
 		a.matched_loc[idx] = p;
 	}
+}
+
+// matches of two 48-letter windows held as 12 words each (fingerprint_id, four letters per 32-bit operation)
+__device__ __forceinline__ int window_identity(const uint32_t* a, const uint32_t* b)
+{
+	int n = 0;
+#pragma unroll
+	for (int w = 0; w < 12; ++w) {
+		const uint32_t d = (a[w] ^ b[w]) & 0x1f1f1f1fu;
+		n += 4 - __builtin_popcount((d + 0x7f7f7f7fu) & 0x80808080u);
+	}
+	return n;
 }
 
 // ---- fast reference stream: 16 positions per thread -------------------------------------------------------------
@@ -149,41 +166,83 @@ __device__ __forceinline__ uint32_t reduce4(uint32_t letter, uint64_t map_lo, ui
 // key as in the spaced-seed mode and takes the same path; a window that holds a mask or stop letter (the spaced mode's
 // invalid windows) is keyed exactly by seed_key_hashed, which needs a look back for the start of the sequence -- a rare path
 // next to the table probes.
-template<bool LEVEL2, bool HASHED>
+// FUSED (short seeds): the Hamming filter of every (joined reference position, query position) pair runs right here, while
+// the reference window is in L1 -- the pair filter that works from the list of joined positions re-reads a 48-byte window
+// at a random place of the reference block per joined position (80 M of them per shape and 1.7 pairs each in --sensitive:
+// ~14 GB of 128-byte line fills), after a radix sort of the list. The stream part only stages the joins (slot, position, list
+// start and size) in LDS; then every thread takes staged joins in turn and filters their lists -- all lanes busy and as many
+// independent loads in flight as there are lanes, instead of a chain of dependent loads in the few lanes that found a join.
+// Lists longer than LIGHT are filtered by the whole workgroup. Pairs of a non-complex seed (SLOT_LOWC) are dropped: the seed
+// only gets its JOINED mark for seed_mask_kernel.
+template<bool LEVEL2, bool HASHED, bool FUSED>
 __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int sid, uint64_t map_lo, uint64_t map_hi, int64_t base, uint64_t care64)
 {
 	// Joined positions are staged in LDS and flushed with ONE atomic on the shared counter per workgroup: an atomicAdd per
 	// match on a single address serialises at ~4.5 ns each (measured: 3.3 M matches = 14.8 ms per shape in default mode,
 	// 22 M = 98 ms per shape in --sensitive), which dwarfed the 1.6 ms stream itself.
-	constexpr unsigned STAGE = 1024;
+	// With short seeds (LEVEL2 off) a third of the positions join: the staging area then holds every position of the workgroup
+	// (the direct-append fallback cost more than the whole rest of the kernel); positions are staged as 16-bit offsets.
+	constexpr unsigned STAGE = LEVEL2 ? 1024 : (FUSED ? 2048 : 4096);
 	__shared__ uint32_t st_slot[STAGE];
-	__shared__ int64_t st_loc[STAGE];
+	__shared__ uint16_t st_loc[STAGE];
 	__shared__ unsigned st_n;
 	__shared__ unsigned long long st_base;
-	if (threadIdx.x == 0) st_n = 0;
+	constexpr uint32_t LIGHT = 8;
+	constexpr unsigned SURV = FUSED ? 512 : 1, HEAVY = FUSED ? 128 : 1, FSTAGE = FUSED ? STAGE : 1;
+	__shared__ uint32_t st_head[FSTAGE];
+	__shared__ uint16_t st_count[FSTAGE];                    // saturated: a list that long is read back from its slot
+	__shared__ uint32_t sv_slot[SURV], sv_x[SURV];
+	__shared__ uint16_t sv_loc[SURV], hv_k[HEAVY];
+	__shared__ unsigned sv_n, hv_n;
+	if (threadIdx.x == 0) { st_n = 0; sv_n = 0; hv_n = 0; }
 	__syncthreads();
-	const int64_t p0 = base + ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+	const int64_t wg_base = base + (int64_t)blockIdx.x * blockDim.x * 16;
+	const int64_t p0 = wg_base + (int64_t)threadIdx.x * 16;
 	const bool in_range = p0 < a.t_end;
+	auto survive = [&](uint32_t slot, uint32_t x, int64_t pos) {
+		const unsigned k = atomicAdd(&sv_n, 1u);
+		if (k < SURV) { sv_slot[k] = slot; sv_x[k] = x; sv_loc[k] = (uint16_t)(pos - wg_base); }
+		else {                                                    // staging area full: direct append
+			const unsigned long long idx = atomicAdd(a.survivor_count, 1ull);
+			if (idx < (unsigned long long)a.survivor_cap) a.survivors[idx] = SeedSurvivor{ slot, x, pos };
+		}
+	};
+	// Hamming filter of the reference window at pos against the entries first, first + step, ... of a list of query positions
+	auto filter_list = [&](uint32_t slot, uint32_t head, uint32_t count, int64_t pos, uint32_t first, uint32_t step) {
+		uint32_t tw[12];
+		__builtin_memcpy(tw, a.tdata + pos - 16, 48);
+		for (uint32_t i = first; i < count; i += step) {
+			const uint32_t x = count == 1 ? head : a.qlist[head + i];
+			uint32_t qw[12];
+			__builtin_memcpy(qw, a.qdata + a.q_begin + x - 16, 48);
+			if (window_identity(tw, qw) >= a.params.hamming_filter_id) survive(slot, x, pos);
+		}
+	};
 	// level-2 bitmap -> table -> staging, for a window whose key passed (or skipped) level 1
 	auto probe_table = [&](uint64_t seed, int64_t pos) {
 		const uint64_t hh = seed_hash(seed);
 		uint64_t slot = hh & a.slot_mask;
 		bool found = false;
-		uint32_t fl = 0;
+		uint32_t fl = 0, head = 0;
 		if (!LEVEL2 || ((a.bitmap[(uint32_t)(hh >> 32) & a.bitmap_mask] >> (uint32_t)(hh >> 59)) & 1u))
 			for (;;) {
 				const SeedSlot sl = a.slots[slot];
 				if (sl.key == SEED_EMPTY) break;
-				if (sl.key == seed) { found = true; fl = sl.flags; break; }
+				if (sl.key == seed) { found = true; fl = sl.flags; head = sl.head; break; }
 				slot = (slot + 1) & a.slot_mask;
 			}
 		if (!found) return;
-		if ((fl & 0xffu) != SLOT_JOINED) a.slots[slot].flags = (fl & ~0xffu) | SLOT_JOINED;
+		if (!(fl & SLOT_JOINED)) a.slots[slot].flags = fl | SLOT_JOINED;
+		if (FUSED && (fl & SLOT_LOWC)) return;
 		const unsigned k = atomicAdd(&st_n, 1u);                 // LDS atomic
-		if (k < STAGE) { st_slot[k] = (uint32_t)slot; st_loc[k] = pos; }
+		if (k < STAGE) {
+			st_slot[k] = (uint32_t)slot; st_loc[k] = (uint16_t)(pos - wg_base);
+			if (FUSED) { st_head[k] = head; st_count[k] = (uint16_t)((fl >> 8) < 0xffffu ? (fl >> 8) : 0xffffu); }
+		}
 		else {                                                    // staging area full (dense matches): direct append
 			const unsigned long long idx = atomicAdd(a.matched_count, 1ull);
 			if (idx < (unsigned long long)a.matched_cap) { a.matched_slot[idx] = (uint32_t)slot; a.matched_loc[idx] = pos; }
+			if (FUSED) filter_list((uint32_t)slot, head, fl >> 8, pos, 0, 1);
 		}
 	};
 	if (in_range) {
@@ -251,13 +310,44 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 	}
 	}
 	__syncthreads();
+	if (FUSED) {
+		const unsigned n_joined = st_n < STAGE ? st_n : STAGE;
+		for (unsigned k = threadIdx.x; k < n_joined; k += 256) {
+			uint32_t count = st_count[k];
+			if (count > LIGHT) {
+				const unsigned hk = atomicAdd(&hv_n, 1u);
+				if (hk < HEAVY) { hv_k[hk] = (uint16_t)k; continue; }
+				if (count == 0xffffu) count = a.slots[st_slot[k]].flags >> 8;
+			}
+			filter_list(st_slot[k], st_head[k], count, wg_base + st_loc[k], 0, 1);
+		}
+		__syncthreads();
+		const unsigned n_heavy = hv_n < HEAVY ? hv_n : HEAVY;       // block-uniform
+		for (unsigned h = 0; h < n_heavy; ++h) {
+			const unsigned k = hv_k[h];
+			uint32_t count = st_count[k];
+			if (count == 0xffffu) count = a.slots[st_slot[k]].flags >> 8;
+			filter_list(st_slot[k], st_head[k], count, wg_base + st_loc[k], threadIdx.x, 256);
+		}
+		__syncthreads();
+		const unsigned n_sv = sv_n < SURV ? sv_n : SURV;
+		if (n_sv) {
+			if (threadIdx.x == 0) st_base = atomicAdd(a.survivor_count, (unsigned long long)n_sv);
+			__syncthreads();
+			for (unsigned k = threadIdx.x; k < n_sv; k += blockDim.x) {
+				const unsigned long long idx = st_base + k;
+				if (idx < (unsigned long long)a.survivor_cap) a.survivors[idx] = SeedSurvivor{ sv_slot[k], sv_x[k], wg_base + sv_loc[k] };
+			}
+			__syncthreads();
+		}
+	}
 	const unsigned n_staged = st_n < STAGE ? st_n : STAGE;
 	if (n_staged == 0) return;
 	if (threadIdx.x == 0) st_base = atomicAdd(a.matched_count, (unsigned long long)n_staged);
 	__syncthreads();
 	for (unsigned k = threadIdx.x; k < n_staged; k += blockDim.x) {
 		const unsigned long long idx = st_base + k;
-		if (idx < (unsigned long long)a.matched_cap) { a.matched_slot[idx] = st_slot[k]; a.matched_loc[idx] = st_loc[k]; }
+		if (idx < (unsigned long long)a.matched_cap) { a.matched_slot[idx] = st_slot[k]; a.matched_loc[idx] = wg_base + st_loc[k]; }
 	}
 }
 
@@ -266,15 +356,12 @@ __global__ void seed_mask_kernel(SeedArgs a, int sid)
 	const uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (slot > a.slot_mask) return;
 	const SeedSlot sl = a.slots[slot];
-	if ((sl.flags & 0xffu) != SLOT_JOINED) return;
-	// Search::mask_seeds evaluates the first query position of the joined group (seed_complexity.cpp:97-99);
-	// "first" = smallest position here (and in the oracle): the lists are sorted by position
+	if (sl.key == SEED_EMPTY || (sl.flags & (SLOT_JOINED | SLOT_LOWC)) != (SLOT_JOINED | SLOT_LOWC)) return;      // joined and not complex (seed_lists_kernel); a free slot is all ones
 	const uint32_t count = sl.flags >> 8;
-	if (seed_is_complex(a.params, sid, a.qdata + a.q_begin + a.qlist[sl.head])) return;
-	a.slots[slot].flags = (sl.flags & ~0xffu) | SLOT_ERASED;
+	a.slots[slot].flags = sl.flags | SLOT_ERASED;
 	const int t = sid * a.params.index_chunks + seed_chunk(a.params, seed_of_key(a.params, sid, sl.key));
 	for (uint32_t i = 0; i < count; ++i) {
-		const uint32_t x = a.qlist[sl.head + i];
+		const uint32_t x = count == 1 ? sl.head : a.qlist[sl.head + i];
 		const uint8_t old = a.mask_time[a.q_begin + x];
 		if (t < old) a.mask_time[a.q_begin + x] = (uint8_t)t;       // one group per position and shape: no race within a launch
 	}
@@ -294,7 +381,7 @@ __device__ __forceinline__ void finish_pair(const SeedArgs& a, int sid, int chun
 }
 
 // everything after the Hamming filter for one (joined reference position m, query position x) pair
-__device__ __forceinline__ void post_hamming(const SeedArgs& a, int sid, int64_t m, uint32_t slot, uint32_t slot_flags, int chunk, int64_t sloc, uint32_t x)
+__device__ __forceinline__ void post_hamming(const SeedArgs& a, int sid, uint32_t slot, uint32_t slot_flags, int chunk, int64_t sloc, uint32_t x)
 {
 	const int8_t* s = a.tdata + sloc;
 	const int64_t qp = a.q_begin + x;
@@ -315,8 +402,8 @@ __device__ __forceinline__ void post_hamming(const SeedArgs& a, int sid, int64_t
 			if (score > 255) {
 				// saturation depends on the SIMD batch of the reference: second pass (seed_deferred_kernel)
 				const unsigned long long d = atomicAdd(a.deferred_count, 1ull);
-				if (d < (unsigned long long)a.deferred_cap) a.deferred[d] = SeedDeferred{ m, x, score };
-				a.slots[slot].flags = (slot_flags & ~0xffu) | SLOT_JOINED | SLOT_NEED;      // benign race: every writer stores the same value
+				if (d < (unsigned long long)a.deferred_cap) a.deferred[d] = SeedDeferred{ sloc, slot, x, score, 0 };
+				atomicOr(&a.need_bits[slot >> 5], 1u << (slot & 31));
 				return;
 			}
 			if (score <= cutoff) return;
@@ -325,10 +412,10 @@ __device__ __forceinline__ void post_hamming(const SeedArgs& a, int sid, int64_t
 	finish_pair(a, sid, chunk, qp, q, s, qid, seed_offset, query_len, sloc, score);
 }
 
-__device__ __forceinline__ void filter_pair(const SeedArgs& a, int sid, int64_t m, uint32_t slot, uint32_t slot_flags, int chunk, int64_t sloc, uint32_t x)
+__device__ __forceinline__ void filter_pair(const SeedArgs& a, int sid, uint32_t slot, uint32_t slot_flags, int chunk, int64_t sloc, uint32_t x)
 {
 	if (fingerprint_id(a.qdata + a.q_begin + x, a.tdata + sloc) < a.params.hamming_filter_id) return;
-	post_hamming(a, sid, m, slot, slot_flags, chunk, sloc, x);
+	post_hamming(a, sid, slot, slot_flags, chunk, sloc, x);
 }
 
 // One thread per joined reference position; the seed's query positions are a contiguous list. Work per position is the
@@ -353,7 +440,7 @@ __global__ void seed_pair_kernel(SeedArgs a, int sid, int64_t n_matched)
 		}
 	}
 	if (count <= LIGHT)
-		for (uint32_t i = 0; i < count; ++i) filter_pair(a, sid, m, slot, flags, chunk, sloc, a.qlist[head + i]);
+		for (uint32_t i = 0; i < count; ++i) filter_pair(a, sid, slot, flags, chunk, sloc, count == 1 ? head : a.qlist[head + i]);
 	unsigned long long heavy = __ballot(count > LIGHT);
 	while (heavy) {
 		const int src = __builtin_ctzll(heavy);
@@ -361,8 +448,8 @@ __global__ void seed_pair_kernel(SeedArgs a, int sid, int64_t n_matched)
 		const uint32_t h_slot = (uint32_t)__shfl((int)slot, src), h_head = (uint32_t)__shfl((int)head, src), h_count = (uint32_t)__shfl((int)count, src),
 			h_flags = (uint32_t)__shfl((int)flags, src);
 		const int h_chunk = __shfl(chunk, src);
-		const int64_t h_sloc = (int64_t)__shfl((long long)sloc, src), h_m = (int64_t)__shfl((long long)m, src);
-		for (uint32_t i = (uint32_t)lane; i < h_count; i += 64) filter_pair(a, sid, h_m, h_slot, h_flags, h_chunk, h_sloc, a.qlist[h_head + i]);
+		const int64_t h_sloc = (int64_t)__shfl((long long)sloc, src);
+		for (uint32_t i = (uint32_t)lane; i < h_count; i += 64) filter_pair(a, sid, h_slot, h_flags, h_chunk, h_sloc, a.qlist[h_head + i]);
 	}
 }
 
@@ -372,17 +459,6 @@ __global__ void seed_pair_kernel(SeedArgs a, int sid, int64_t n_matched)
 // a few seeds; per seed with a long query list the workgroup stages the 48-byte query windows in LDS, TQ at a time, and every
 // thread compares them (broadcast LDS reads) with its own reference window held in 12 registers: the query windows are read
 // from the cache hierarchy once per workgroup instead of once per pair.
-__device__ __forceinline__ int window_identity(const uint32_t* a, const uint32_t* b)
-{
-	int n = 0;
-#pragma unroll
-	for (int w = 0; w < 12; ++w) {
-		const uint32_t d = (a[w] ^ b[w]) & 0x1f1f1f1fu;
-		n += 4 - __builtin_popcount((d + 0x7f7f7f7fu) & 0x80808080u);
-	}
-	return n;
-}
-
 // Pairs that pass the Hamming filter are NOT scored in place: in a wavefront only the ~10 % passing lanes would run the long
 // stage-2 code while the others wait (measured: 3/4 of the kernel's time). They are staged in LDS, flushed to a compact
 // survivor list with one global atomic per flush, and scored by seed_post_kernel with all lanes busy.
@@ -390,7 +466,7 @@ __global__ __launch_bounds__(256) void seed_pair_tiled_kernel(SeedArgs a, int si
 {
 	constexpr uint32_t LIGHT = 8;
 	constexpr int TQ = 64;
-	constexpr unsigned STAGE = 2048;
+	constexpr unsigned STAGE = 1024;
 	__shared__ uint32_t q_tile[TQ * 12];
 	__shared__ uint32_t q_x[TQ];
 	__shared__ uint32_t sh_slot[256], sh_head[256], sh_count[256], run_of[256];
@@ -401,6 +477,7 @@ __global__ __launch_bounds__(256) void seed_pair_tiled_kernel(SeedArgs a, int si
 	const int tid = threadIdx.x;
 	const int64_t m = (int64_t)blockIdx.x * 256 + tid;
 	uint32_t slot = LIST_END, head = 0, count = 0;
+	int64_t sloc = 0;
 	uint32_t sw[12];
 #pragma unroll
 	for (int w = 0; w < 12; ++w) sw[w] = 0;
@@ -409,15 +486,16 @@ __global__ __launch_bounds__(256) void seed_pair_tiled_kernel(SeedArgs a, int si
 		const SeedSlot sl = a.slots[slot];
 		if (!(sl.flags & SLOT_ERASED)) {
 			head = sl.head; count = sl.flags >> 8;
-			__builtin_memcpy(sw, a.tdata + a.matched_loc[m] - 16, 48);
+			sloc = a.matched_loc[m];
+			__builtin_memcpy(sw, a.tdata + sloc - 16, 48);
 		}
 	}
 	auto survive = [&](uint32_t x) {
 		const unsigned k = atomicAdd(&st_n, 1u);
-		if (k < STAGE) stage[k] = SeedSurvivor{ (uint32_t)m, x };
+		if (k < STAGE) stage[k] = SeedSurvivor{ slot, x, sloc };
 		else {                                             // staging area full between two flushes: direct append
 			const unsigned long long idx = atomicAdd(a.survivor_count, 1ull);
-			if (idx < (unsigned long long)a.survivor_cap) a.survivors[idx] = SeedSurvivor{ (uint32_t)m, x };
+			if (idx < (unsigned long long)a.survivor_cap) a.survivors[idx] = SeedSurvivor{ slot, x, sloc };
 		}
 	};
 	auto flush = [&]() {                                   // block-uniform
@@ -443,7 +521,7 @@ __global__ __launch_bounds__(256) void seed_pair_tiled_kernel(SeedArgs a, int si
 	if (heavy && (tid == 0 || sh_slot[tid - 1] != slot)) run_of[atomicAdd(&n_runs, 1)] = (uint32_t)tid;      // first entry of a run of equal slots
 	if (count > 0 && count <= LIGHT)
 		for (uint32_t i = 0; i < count; ++i) {
-			const uint32_t x = a.qlist[head + i];
+			const uint32_t x = count == 1 ? head : a.qlist[head + i];
 			uint32_t qw[12];
 			__builtin_memcpy(qw, a.qdata + a.q_begin + x - 16, 48);
 			if (window_identity(sw, qw) >= a.params.hamming_filter_id) survive(x);
@@ -481,44 +559,100 @@ __global__ __launch_bounds__(256) void seed_post_kernel(SeedArgs a, int sid, int
 	if (i >= n_survivors) return;
 	a.matrix = matrix;                                    // flat pointer into LDS
 	const SeedSurvivor sv = a.survivors[i];
-	const uint32_t slot = a.matched_slot[sv.m];
-	const SeedSlot sl = a.slots[slot];
-	post_hamming(a, sid, (int64_t)sv.m, slot, sl.flags, seed_chunk(a.params, seed_of_key(a.params, sid, sl.key)), a.matched_loc[sv.m], sv.x);
+	const SeedSlot sl = a.slots[sv.slot];
+	if (sl.flags & SLOT_ERASED) return;                  // (the fused stream kernel never lets a pair of a non-complex seed through)
+	post_hamming(a, sid, sv.slot, sl.flags, seed_chunk(a.params, seed_of_key(a.params, sid, sl.key)), sv.sloc, sv.x);
 }
 
-// copies the joined positions of the seeds that have deferred pairs as sort keys slot << 40 | position
-__global__ void seed_collect_kernel(SeedArgs a, int64_t n_matched)
+// copies the joined positions of the seeds that have deferred pairs (need_bits) as sort keys slot << 40 | position.
+// 4096 list entries per workgroup and ONE atomic on the shared counter for them: with the joined positions in stream order the
+// wanted entries are spread over the whole list, and an atomic per wavefront that holds one (1.2 M of them per shape in
+// --sensitive, ~4.5 ns each on one address) was 5 ms of a 0.3 ms scan.
+__global__ __launch_bounds__(256) void seed_collect_kernel(SeedArgs a, int64_t n_matched)
 {
-	const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	bool have = false;
-	uint32_t slot = 0;
-	if (m < n_matched) { slot = a.matched_slot[m]; have = (a.slots[slot].flags & SLOT_NEED) != 0; }
-	const unsigned long long idx = wave_append(a.e_count, have);
-	if (have) a.e_key[idx] = ((uint64_t)slot << 40) | (uint64_t)a.matched_loc[m];
+	constexpr int PER = 16;
+	__shared__ unsigned n_local;
+	__shared__ unsigned long long base;
+	if (threadIdx.x == 0) n_local = 0;
+	__syncthreads();
+	const int64_t m0 = (int64_t)blockIdx.x * (256 * PER) + threadIdx.x;
+	uint32_t mine = 0;
+#pragma unroll
+	for (int j = 0; j < PER; ++j) {
+		const int64_t m = m0 + (int64_t)j * 256;
+		if (m < n_matched) {
+			const uint32_t slot = a.matched_slot[m];
+			mine |= ((a.need_bits[slot >> 5] >> (slot & 31)) & 1u) << j;
+		}
+	}
+	unsigned off = mine ? atomicAdd(&n_local, (unsigned)__builtin_popcount(mine)) : 0u;
+	__syncthreads();
+	if (n_local == 0) return;
+	if (threadIdx.x == 0) base = atomicAdd(a.e_count, (unsigned long long)n_local);
+	__syncthreads();
+	while (mine) {
+		const int j = __builtin_ctz(mine);
+		mine &= mine - 1;
+		const int64_t m = m0 + (int64_t)j * 256;
+		a.e_key[base + off++] = ((uint64_t)a.matched_slot[m] << 40) | (uint64_t)a.matched_loc[m];
+	}
 }
 
-__global__ void seed_deferred_kernel(SeedArgs a, int sid, int64_t n_deferred)
+// One wavefront per deferred pair: the lanes share the scan over the tile of the seed's joined positions (up to tile_size
+// Hamming comparisons at random places of the reference -- as one thread's loop that was a 0.7 ms tail per shape for 10^4 pairs).
+// Same arithmetic as simd_batch_size_sorted (seed_core.h), which the CPU emulation of this kernel uses.
+__global__ __launch_bounds__(256) void seed_deferred_kernel(SeedArgs a, int sid, int64_t n_deferred)
 {
-	const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (d >= n_deferred) return;
+	const int lane = threadIdx.x & 63;
+	const int64_t d = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	if (d >= n_deferred) return;                          // wave-uniform
 	const SeedDeferred r = a.deferred[d];
-	const uint32_t slot = a.matched_slot[r.m];
-	const int64_t sloc = a.matched_loc[r.m];
+	const uint32_t slot = r.slot;
+	const int64_t sloc = r.sloc;
 	// the seed's joined positions: range of `slot` in the sorted copy
 	int64_t lo = 0, hi = a.e_n;
 	while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((uint32_t)(a.e_key[mid] >> 40) < slot) lo = mid + 1; else hi = mid; }
 	const int64_t b = lo;
 	hi = a.e_n;
 	while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((uint32_t)(a.e_key[mid] >> 40) <= slot) lo = mid + 1; else hi = mid; }
+	const uint64_t* locs = a.e_key + b;
+	const int64_t n = lo - b;
+	const uint64_t LOC = ((uint64_t)1 << 40) - 1;
 	const int64_t qp = a.q_begin + r.x;
 	const int8_t* q = a.qdata + qp;
 	const int8_t* s = a.tdata + sloc;
+	int64_t rlo = 0, rhi = n;                             // rank = number of positions < sloc
+	while (rlo < rhi) { const int64_t mid = (rlo + rhi) >> 1; if ((int64_t)(locs[mid] & LOC) < sloc) rlo = mid + 1; else rhi = mid; }
+	const int64_t rank = rlo, T = a.params.tile_size;
+	int64_t t_lo = 0, t_hi = n;
+	if (T > 0 && n > T) { t_lo = rank / T * T; t_hi = t_lo + T < n ? t_lo + T : n; }
+	int L = 0, rr = 0;
+	for (int64_t k = t_lo + lane; k < t_hi; k += 64) {
+		if (fingerprint_id(q, a.tdata + (int64_t)(locs[k] & LOC)) < a.params.hamming_filter_id) continue;
+		++L; rr += k < rank;
+	}
+	for (int o = 32; o > 0; o >>= 1) { L += __shfl_xor(L, o); rr += __shfl_xor(rr, o); }
+	if (lane != 0) return;
+	const int lanes = a.params.simd_lanes, left = L - rr / lanes * lanes;
 	int score = r.score;
-	if (simd_batch_size_sorted(a.params, a.e_key + b, lo - b, a.tdata, q, sloc) >= 4) score = 255;
+	if ((left < lanes ? left : lanes) >= 4) score = 255;
 	const uint32_t qid = a.qid_of[qp];
 	const int query_len = (int)(a.qlimits[qid + 1] - a.qlimits[qid] - 1);
 	if (score <= ungapped_cutoff(a.params, query_len)) return;
 	finish_pair(a, sid, seed_chunk(a.params, seed_of_key(a.params, sid, a.slots[slot].key)), qp, q, s, qid, (int)(qp - a.qlimits[qid]), query_len, sloc, score);
+}
+
+// DMND_TRACE: number of (joined reference position, query position) pairs the Hamming filter sees
+__global__ void seed_count_pairs_kernel(SeedArgs a, int64_t n_matched, unsigned long long* out)
+{
+	const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	unsigned long long n = 0;
+	if (m < n_matched) {
+		const SeedSlot sl = a.slots[a.matched_slot[m]];
+		if (!(sl.flags & SLOT_ERASED)) n = sl.flags >> 8;
+	}
+	for (int o = 32; o > 0; o >>= 1) n += (unsigned long long)__shfl_down((long long)n, o);
+	if ((threadIdx.x & 63) == 0 && n) atomicAdd(out, n);
 }
 
 static unsigned blocks_for(int64_t n, int threads) { return (unsigned)((n + threads - 1) / threads); }
@@ -542,7 +676,7 @@ hipError_t launch_seed_index(const SeedArgs& a, int sid, hipStream_t st)
 	return hipGetLastError();
 }
 
-hipError_t launch_seed_lists(const SeedArgs& a, uint32_t* sorted_slot, uint32_t* qlist_out, int slot_bits, void** tmp, size_t* tmp_bytes, hipStream_t st)
+hipError_t launch_seed_lists(const SeedArgs& a, int sid, uint32_t* sorted_slot, uint32_t* qlist_out, int slot_bits, void** tmp, size_t* tmp_bytes, hipStream_t st)
 {
 	const int64_t n = a.q_end - a.q_begin;
 	if (n <= 0) return hipSuccess;
@@ -560,13 +694,21 @@ hipError_t launch_seed_lists(const SeedArgs& a, uint32_t* sorted_slot, uint32_t*
 	}
 	e = rocprim::radix_sort_pairs(*tmp, need, a.qslot, sorted_slot, iota, qlist_out, (size_t)n, 0, 32, st);
 	if (e != hipSuccess) return e;
-	hipLaunchKernelGGL(seed_lists_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, a, (const uint32_t*)sorted_slot, n);
+	hipLaunchKernelGGL(seed_lists_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, a, sid, (const uint32_t*)sorted_slot, (const uint32_t*)qlist_out, n);
 	return hipGetLastError();
 }
 
-hipError_t launch_seed_stream(const SeedArgs& a, int sid, hipStream_t st)
+bool seed_stream_can_fuse(const SeedParams& c)
+{
+	for (int sid = 0; sid < c.n_shapes; ++sid)
+		if (!seed_nibble_mode(c, sid) || c.shape_weight[sid] >= 10) return false;
+	return true;
+}
+
+hipError_t launch_seed_stream(const SeedArgs& a, int sid, hipStream_t st, bool fused)
 {
 	const SeedParams& c = a.params;
+	if (fused && !(seed_nibble_mode(c, sid) && c.shape_weight[sid] < 10)) return hipErrorInvalidValue;
 	if (seed_nibble_mode(c, sid)) {
 		// 4-bit class map: 15 = invalid (X, '*'); every other letter code -> its reduced class
 		uint64_t lo = 0, hi = 0;
@@ -580,10 +722,12 @@ hipError_t launch_seed_stream(const SeedArgs& a, int sid, hipStream_t st)
 		for (int k = 0; k < c.shape_weight[sid]; ++k) care64 |= (uint64_t)15 << (4 * c.shape_pos[sid][k]);
 		const bool level2 = c.shape_weight[sid] >= 10, hashed = c.seed_encoding == SEED_HASHED;
 		const dim3 grid(blocks_for(threads, 256)), block(256);
-		if (level2 && hashed) hipLaunchKernelGGL((seed_stream_fast_kernel<true, true>), grid, block, 0, st, a, sid, lo, hi, base, care64);
-		else if (level2) hipLaunchKernelGGL((seed_stream_fast_kernel<true, false>), grid, block, 0, st, a, sid, lo, hi, base, care64);
-		else if (hashed) hipLaunchKernelGGL((seed_stream_fast_kernel<false, true>), grid, block, 0, st, a, sid, lo, hi, base, care64);
-		else hipLaunchKernelGGL((seed_stream_fast_kernel<false, false>), grid, block, 0, st, a, sid, lo, hi, base, care64);
+		if (fused && hashed) hipLaunchKernelGGL((seed_stream_fast_kernel<false, true, true>), grid, block, 0, st, a, sid, lo, hi, base, care64);
+		else if (fused) hipLaunchKernelGGL((seed_stream_fast_kernel<false, false, true>), grid, block, 0, st, a, sid, lo, hi, base, care64);
+		else if (level2 && hashed) hipLaunchKernelGGL((seed_stream_fast_kernel<true, true, false>), grid, block, 0, st, a, sid, lo, hi, base, care64);
+		else if (level2) hipLaunchKernelGGL((seed_stream_fast_kernel<true, false, false>), grid, block, 0, st, a, sid, lo, hi, base, care64);
+		else if (hashed) hipLaunchKernelGGL((seed_stream_fast_kernel<false, true, false>), grid, block, 0, st, a, sid, lo, hi, base, care64);
+		else hipLaunchKernelGGL((seed_stream_fast_kernel<false, false, false>), grid, block, 0, st, a, sid, lo, hi, base, care64);
 		return hipGetLastError();
 	}
 	hipLaunchKernelGGL(seed_stream_kernel, dim3(blocks_for(a.t_end - a.t_begin, 256)), dim3(256), 0, st, a, sid);
@@ -607,6 +751,13 @@ hipError_t launch_seed_pairs_tiled(const SeedArgs& a, int sid, int64_t n_matched
 {
 	if (n_matched == 0) return hipSuccess;
 	hipLaunchKernelGGL(seed_pair_tiled_kernel, dim3(blocks_for(n_matched, 256)), dim3(256), 0, st, a, sid, n_matched);
+	return hipGetLastError();
+}
+
+hipError_t launch_seed_count_pairs(const SeedArgs& a, int64_t n_matched, unsigned long long* out, hipStream_t st)
+{
+	if (n_matched == 0) return hipSuccess;
+	hipLaunchKernelGGL(seed_count_pairs_kernel, dim3(blocks_for(n_matched, 256)), dim3(256), 0, st, a, n_matched, out);
 	return hipGetLastError();
 }
 
@@ -638,7 +789,7 @@ hipError_t sort_matched_by_slot(const uint32_t* slot_in, uint32_t* slot_out, con
 hipError_t launch_seed_collect(const SeedArgs& a, int64_t n_matched, hipStream_t st)
 {
 	if (n_matched == 0) return hipSuccess;
-	hipLaunchKernelGGL(seed_collect_kernel, dim3(blocks_for(n_matched, 256)), dim3(256), 0, st, a, n_matched);
+	hipLaunchKernelGGL(seed_collect_kernel, dim3(blocks_for(n_matched, 256 * 16)), dim3(256), 0, st, a, n_matched);
 	return hipGetLastError();
 }
 
@@ -713,7 +864,7 @@ hipError_t sort_seed_hits(const dmnd_seed_hit* hits, dmnd_seed_hit* out, int64_t
 hipError_t launch_seed_deferred(const SeedArgs& a, int sid, int64_t n_deferred, hipStream_t st)
 {
 	if (n_deferred == 0) return hipSuccess;
-	hipLaunchKernelGGL(seed_deferred_kernel, dim3(blocks_for(n_deferred, 64)), dim3(64), 0, st, a, sid, n_deferred);
+	hipLaunchKernelGGL(seed_deferred_kernel, dim3(blocks_for(n_deferred * 64, 256)), dim3(256), 0, st, a, sid, n_deferred);
 	return hipGetLastError();
 }
 
