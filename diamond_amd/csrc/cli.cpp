@@ -7,7 +7,8 @@
 // (pos u64, len u32, pad u32) records), SequenceSet layout (src/data/string_set.h:27-60), tabular output
 // (src/output/blast_tab_format.cpp, sequence ids cut at the first blank).
 // Supported: blastp / blastx (--fast, default sensitivity, --sensitive), tantan masking on the GPU (default) or --masking 0
-// motif soft masking (default; table in motifs.bin next to the binary), --algo 0 / 1 / auto; SEG is not part of this build; -e, -k, -p, -f 6 default columns,
+// motif soft masking (default; table in motifs.bin next to the binary), --algo 0 / 1 / auto; SEG is not part of this build; -e, -k, -p,
+// -f 6 [FIELD...] (BLAST tabular with the reference's field names) and -f 0 (BLAST pairwise),
 // -b / -c: query and reference blocks cut as load_seqs cuts them, records of a query block merged over the reference blocks as
 // join_blocks does (output/join_blocks.cpp) -> same text as the reference run with the same -b.
 #include <algorithm>
@@ -95,7 +96,7 @@ void read_fasta(const std::string& path, SeqBlock& b)
 
 // blastx query file: DNA reads -> six translated frames per read, consecutive in the block (Block::push_back,
 // data/block/block.cpp:82-100). source_len keeps the read lengths for the DNA coordinates of the output.
-void read_dna_fasta_translated(const std::string& path, SeqBlock& b, std::vector<int32_t>& source_len, std::vector<std::string>& read_ids)
+void read_dna_fasta_translated(const std::string& path, SeqBlock& b, std::vector<int32_t>& source_len, std::vector<std::string>& read_ids, std::vector<std::vector<int8_t>>& reads)
 {
 	std::ifstream f(path);
 	if (!f) throw std::runtime_error("Error opening file " + path);
@@ -122,6 +123,7 @@ void read_dna_fasta_translated(const std::string& path, SeqBlock& b, std::vector
 		for (int k = 0; k < 6; ++k) { frames[k].resize((size_t)lens[k]); b.push(frames[k], id); }
 		source_len.push_back((int32_t)seq.size());
 		read_ids.push_back(id);
+		reads.push_back(seq);
 		seq.clear();
 	};
 	while (std::getline(f, line)) {
@@ -234,6 +236,7 @@ struct Options {
 	int index_chunks = 0;           // -c (0 = the sensitivity's default)
 	std::string masking = "", motif_masking = "", sens = "";
 	int algo = -1;                  // --algo: -1 auto (the reference's default), 0 double-indexed, 1 query-indexed
+	std::vector<std::string> outfmt;   // -f / --outfmt: format, then field names
 };
 
 Options parse(int argc, char** argv)
@@ -275,7 +278,10 @@ Options parse(int argc, char** argv)
 			else if (v == "auto" || v == "") o.algo = -1;
 			else throw std::runtime_error("Invalid value for --algo: " + v + " (0 = double-indexed, 1 = query-indexed; ctg is not part of this build)");
 		}
-		else if (a == "-f" || a == "--outfmt") { if (need(i) != "6") throw std::runtime_error("Only output format 6 (BLAST tabular, default columns) is implemented."); }
+		else if (a == "-f" || a == "--outfmt") {
+			o.outfmt.assign(1, need(i));
+			while (i + 1 < n_args && !args[(size_t)i + 1].empty() && args[(size_t)i + 1][0] != '-') o.outfmt.push_back(args[(size_t)++i]);
+		}
 		else if (a == "--faster" || a == "--mid-sensitive" || a == "--sensitive" || a == "--more-sensitive" || a == "--very-sensitive" || a == "--ultra-sensitive")
 			o.sens = a;
 		else if (a == "--quiet" || a == "--log" || a == "-v" || a == "--verbose") {}
@@ -334,13 +340,44 @@ int run_blastp(const Options& o)
 	const size_t C = blastx ? 6 : 1;
 	std::vector<int32_t> source_len;
 	std::vector<std::string> read_ids;
+	std::vector<std::vector<int8_t>> reads;
+	// --outfmt (output/output_format.cpp:178-200): 6 / tab with optional field names, 0 / pairwise
+	enum { FMT_TAB, FMT_FIELDS, FMT_PAIRWISE, FMT_PAF } fmt = FMT_TAB;
+	std::vector<int32_t> field_ids;
+	int need_transcripts = 0;
+	if (!o.outfmt.empty()) {
+		const std::string& f0 = o.outfmt[0];
+		if (f0 == "6" || f0 == "tab") {
+			if (o.outfmt.size() > 1) {
+				std::vector<const char*> names;
+				for (size_t i = 1; i < o.outfmt.size(); ++i) names.push_back(o.outfmt[i].c_str());
+				field_ids.resize(names.size());
+				if (dmnd_output_fields(names.data(), (int)names.size(), field_ids.data(), &need_transcripts) != DMND_OK) throw std::runtime_error(dmnd_last_error());
+				fmt = FMT_FIELDS;
+			}
+		}
+		else if (f0 == "0" || f0 == "pairwise") {
+			if (o.outfmt.size() > 1) throw std::runtime_error("Invalid output format: the pairwise format takes no fields");
+			fmt = FMT_PAIRWISE;
+			need_transcripts = 1;
+		}
+		else if (f0 == "103" || f0 == "paf") {
+			if (o.outfmt.size() > 1) throw std::runtime_error("Invalid output format: the PAF format takes no fields");
+			fmt = FMT_PAF;
+		}
+		else throw std::runtime_error("Invalid output format: " + f0 + " (this build prints 6 = BLAST tabular, 0 = BLAST pairwise and 103 = PAF)");
+	}
+	bool want_full_sseq = false;
+	for (int32_t id : field_ids) want_full_sseq |= id == DMND_F_FULL_SSEQ;
 	auto t0 = std::chrono::steady_clock::now();
-	if (blastx) read_dna_fasta_translated(o.query, q_all, source_len, read_ids);
+	if (blastx) read_dna_fasta_translated(o.query, q_all, source_len, read_ids, reads);
 	else read_fasta(o.query, q_all);
 	std::string dbpath = o.db;
 	if (!std::ifstream(dbpath).good() && std::ifstream(dbpath + ".dmnd").good()) dbpath += ".dmnd";
 	if (is_dmnd(dbpath)) read_dmnd(dbpath, t_all_seqs); else read_fasta(dbpath, t_all_seqs);
 	const size_t n_queries = q_all.ids.size() / C, n_targets = t_all_seqs.ids.size();
+	std::vector<int8_t> t_unmasked;                        // full_sseq prints the target as it was loaded (Block::unmasked_seqs)
+	if (want_full_sseq) t_unmasked = t_all_seqs.data;
 	std::cerr << "Loading sequences...  [" << ms_since(t0) / 1e3 << "s]  queries=" << n_queries << " targets=" << n_targets << " letters=" << t_all_seqs.letters << "\n";
 	const int sens = o.fast ? DMND_SENS_FAST : o.sens == "--mid-sensitive" ? DMND_SENS_MID_SENSITIVE : o.sens == "--sensitive" ? DMND_SENS_SENSITIVE
 		: o.sens == "--more-sensitive" ? DMND_SENS_MORE_SENSITIVE : o.sens == "--very-sensitive" ? DMND_SENS_VERY_SENSITIVE : DMND_SENS_DEFAULT;
@@ -421,6 +458,7 @@ int run_blastp(const Options& o)
 
 	FILE* out = o.out.empty() ? stdout : std::fopen(o.out.c_str(), "w");
 	if (!out) throw std::runtime_error("Error opening file " + o.out);
+	if (fmt == FMT_PAIRWISE) std::fputs("BLASTP 2.3.0+\n\n\n", out);                   // PairwiseFormat::print_header
 	const std::vector<std::string>& qtitles = blastx ? read_ids : q_all.ids;
 	std::vector<std::string> qid(qtitles.size()), tid(n_targets);
 	for (size_t i = 0; i < qid.size(); ++i) qid[i] = short_id(qtitles[i]);
@@ -447,6 +485,8 @@ int run_blastp(const Options& o)
 		}
 		if (motifs) { int64_t n = 0; chk(dmnd_soft_mask_block(ctx, DMND_QUERY, &n)); motif_letters += n; }
 		std::vector<dmnd_match> joined;                       // the query block's records against all reference blocks
+		std::vector<uint8_t> arena;                           // ... and their transcripts, if the output format reads them
+		std::vector<char> seeded(qr.end - qr.begin, 0);       // queries with at least one seed hit (what the unaligned report depends on)
 		for (const Range& tr : t_blocks) {
 			// the reference re-reads and re-masks every reference block for every query block (run/double_indexed.cpp:404-470)
 			SeqBlock t_own;
@@ -479,24 +519,84 @@ int run_blastp(const Options& o)
 			chk(dmnd_seed_hits(ctx, hits.data(), n_hits));
 			ms_seed += ms_since(t0);
 			total_hits += n_hits;
+			for (const dmnd_seed_hit& h : hits) seeded[h.query / C] = 1;
 			if (lazy_masking) mask_target();
 			t0 = std::chrono::steady_clock::now();
 			const size_t base = joined.size();
 			joined.resize(base + (size_t)std::max<int64_t>(n_hits, 1));
 			int64_t n_matches = 0;
-			chk(dmnd_extend(ctx, q.data.data(), t_host, hits.data(), n_hits, threads, 0, joined.data() + base, (int64_t)(joined.size() - base), &n_matches, nullptr, 0, nullptr));
+			if (!need_transcripts)
+				chk(dmnd_extend(ctx, q.data.data(), t_host, hits.data(), n_hits, threads, 0, joined.data() + base, (int64_t)(joined.size() - base), &n_matches, nullptr, 0, nullptr));
+			else {
+				// the transcripts of this call are appended to the query block's arena; the records point into it
+				const size_t arena_base = arena.size();
+				int64_t cap = std::max<int64_t>((int64_t)1 << 20, 64 * n_hits), used = 0;
+				for (;;) {
+					arena.resize(arena_base + (size_t)cap);
+					const int rc = dmnd_extend(ctx, q.data.data(), t_host, hits.data(), n_hits, threads, 0, joined.data() + base, (int64_t)(joined.size() - base), &n_matches,
+						arena.data() + arena_base, cap, &used);
+					if (rc == DMND_E_CAP && cap < ((int64_t)1 << 36)) { cap *= 4; continue; }
+					chk(rc);
+					break;
+				}
+				arena.resize(arena_base + (size_t)used);
+				for (size_t i = base; i < base + (size_t)n_matches; ++i) joined[i].hsp.transcript_off += (int64_t)arena_base;
+			}
 			joined.resize(base + (size_t)n_matches);
 			for (size_t i = base; i < joined.size(); ++i) { joined[i].query += (uint32_t)qr.begin; joined[i].target += (uint32_t)tr.begin; }   // block ids -> file ordinals
 			ms_ext += ms_since(t0);
 		}
 		int64_t n_matches = (int64_t)joined.size();
 		if (t_blocks.size() > 1) chk(dmnd_join_blocks(joined.data(), (int64_t)joined.size(), o.k, &n_matches));
-		for (int64_t i = 0; i < n_matches; ++i) {
+		auto view_of = [&](const dmnd_match& m) {
+			dmnd_hsp_view v;
+			const size_t ctx_id = (size_t)m.query * C + (size_t)m.frame;            // the aligned query context in the file
+			v.match = &m;
+			v.transcript = need_transcripts ? arena.data() + m.hsp.transcript_off : nullptr;
+			v.qtitle = qtitles[m.query].c_str(); v.stitle = t_all_seqs.ids[m.target].c_str();
+			// the query block at hand holds the letters the extension stage saw (tantan-masked in place)
+			const size_t local = ctx_id - qr.begin * C;
+			v.qseq = q.data.data() + q.limits[local]; v.qlen = (int32_t)(q.limits[local + 1] - q.limits[local] - 1);
+			v.slen = (int32_t)(t_all_seqs.limits[m.target + 1] - t_all_seqs.limits[m.target] - 1);
+			v.full_sseq = want_full_sseq ? t_unmasked.data() + t_all_seqs.limits[m.target] : nullptr;
+			v.source_seq = blastx ? reads[m.query].data() : nullptr; v.source_len = blastx ? source_len[m.query] : 0;
+			v.qnum = (int64_t)m.query; v.snum = (int64_t)m.target;
+			return v;
+		};
+		std::vector<char> big;
+		auto put = [&](int64_t w, const char* p) { if (w < 0) throw std::runtime_error(dmnd_last_error()); std::fwrite(p, 1, (size_t)w, out); };
+		int64_t i = 0;
+		// The pairwise and PAF formats also report queries without alignments, in query order (DEFAULT_REPORT_UNALIGNED): with one
+		// reference block only those that had seed hits (a query without any is skipped before the output stage, align/align.cpp:173-176,
+		// align/output.cpp:35-53), with several blocks every one (output/join_blocks.cpp:302-308,365-372).
+		for (size_t qi = qr.begin; qi < qr.end && (fmt == FMT_PAIRWISE || fmt == FMT_PAF); ++qi) {
+			const bool has = i < n_matches && joined[(size_t)i].query == (uint32_t)qi;
+			if (!has && t_blocks.size() == 1 && !seeded[qi - qr.begin]) continue;
+			const int32_t qlen = blastx ? source_len[qi] : (int32_t)(q_all.limits[qi + 1] - q_all.limits[qi] - 1);
+			big.resize(qtitles[qi].size() + 256);
+			if (fmt == FMT_PAIRWISE) put(dmnd_format_pairwise_intro(qtitles[qi].c_str(), qlen, has ? 0 : 1, big.data(), (int64_t)big.size()), big.data());
+			else if (!has) put(dmnd_format_paf(nullptr, qtitles[qi].c_str(), big.data(), (int64_t)big.size()), big.data());
+			for (; i < n_matches && joined[(size_t)i].query == (uint32_t)qi; ++i) {
+				const dmnd_match& m = joined[(size_t)i];
+				const dmnd_hsp_view v = view_of(m);
+				big.resize((size_t)m.hsp.length * 8 + std::strlen(v.qtitle) + std::strlen(v.stitle) + 4096);
+				if (fmt == FMT_PAIRWISE) put(dmnd_format_pairwise(&v, p.matrix8, big.data(), (int64_t)big.size()), big.data());
+				else put(dmnd_format_paf(&v, nullptr, big.data(), (int64_t)big.size()), big.data());
+			}
+			if (has) ++aligned;
+		}
+		for (; i < n_matches && (fmt == FMT_TAB || fmt == FMT_FIELDS); ++i) {
 			const dmnd_match& m = joined[(size_t)i];
-			const int w = blastx ? dmnd_format_tab_translated(&m, qid[m.query].c_str(), tid[m.target].c_str(), source_len[m.query], line, sizeof line)
-				: dmnd_format_tab(&m, qid[m.query].c_str(), tid[m.target].c_str(), line, sizeof line);
-			if (w < 0) throw std::runtime_error(dmnd_last_error());
-			std::fwrite(line, 1, (size_t)w, out);
+			if (fmt == FMT_FIELDS) {
+				const dmnd_hsp_view v = view_of(m);
+				big.resize((size_t)m.hsp.length * 4 + (size_t)v.qlen * 3 + (size_t)v.slen + std::strlen(v.qtitle) + 2 * std::strlen(v.stitle) + (size_t)v.source_len * 2 + 4096);
+				put(dmnd_format_fields(&v, field_ids.data(), (int)field_ids.size(), big.data(), (int64_t)big.size()), big.data());
+			}
+			else {
+				const int w = blastx ? dmnd_format_tab_translated(&m, qid[m.query].c_str(), tid[m.target].c_str(), source_len[m.query], line, sizeof line)
+					: dmnd_format_tab(&m, qid[m.query].c_str(), tid[m.target].c_str(), line, sizeof line);
+				put(w, line);
+			}
 			if (i == 0 || joined[(size_t)i].query != joined[(size_t)i - 1].query) ++aligned;
 		}
 		total_matches += n_matches;

@@ -1,0 +1,356 @@
+// format_api.hip -- output formats of the hot path's records (host code only; part of libdiamond_hip.so so that the CLI, the
+// Python mirror and a reference-side binding print through the same code).
+// Mirrors: TabularFormat (src/output/blast_tab_format.cpp:46-620), PairwiseFormat (src/output/blast_pairwise_format.cpp:24-85),
+// print_cigar (src/output/sam_format.cpp:67-84), HspContext::Iterator (src/basic/match.h:300-370), TextBuffer number printing
+// (src/util/text_buffer.h:224-254), OutputFormat::print_title (src/output/output_format.cpp:150-168).
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/diamond_hip.h"
+#include "ctx.h"
+
+using namespace dmnd;
+
+namespace {
+
+const char* const AA = "ARNDCQEGHILKMFPSTWYVBJZX*_";      // amino_acid_traits.alphabet (basic/value.cpp:25)
+const char* const NT = "ACGTN";
+const char* const FIELD_NAMES[DMND_F_COUNT] = { "qseqid", "qlen", "sseqid", "sallseqid", "slen", "qstart", "qend", "sstart", "send", "qseq", "sseq",
+	"evalue", "bitscore", "score", "length", "pident", "nident", "mismatch", "positive", "gapopen", "gaps", "ppos", "qframe", "btop", "stitle",
+	"salltitles", "qcovhsp", "qtitle", "full_sseq", "qnum", "snum", "scovhsp", "full_qseq", "qseq_gapped", "sseq_gapped", "qstrand", "cigar",
+	"qseq_translated", "hspnum" };
+// fields of the reference that this build does not print
+const char* const UNAVAILABLE[] = { "staxids", "sscinames", "sskingdoms", "skingdoms", "sphylums", "slineages", "qqual", "full_qqual", "full_qseq_mate",
+	"normalized_bitscore", "normalized_bitscore_query", "normalized_nident", "approx_pident", "corrected_bitscore" };
+
+enum { OP_MATCH = 0, OP_INSERTION = 1, OP_DELETION = 2, OP_SUBSTITUTION = 3 };
+
+struct Out {
+	std::string s;
+	Out& operator<<(const char* x) { s += x; return *this; }
+	Out& operator<<(char x) { s += x; return *this; }
+	Out& operator<<(long long x) { s += std::to_string(x); return *this; }
+	Out& operator<<(int x) { return *this << (long long)x; }
+	Out& operator<<(unsigned x) { return *this << (long long)x; }
+	// Util::String::format_double (util/string/string.h:87-92)
+	Out& operator<<(double x)
+	{
+		char b[48];
+		if (x >= 100.0) std::snprintf(b, sizeof b, "%lli", (long long)std::floor(x));
+		else { const long long i = std::llround(x * 10.0); std::snprintf(b, sizeof b, "%lli.%lli", i / 10, i % 10); }
+		s += b;
+		return *this;
+	}
+	void print_e(double x)
+	{
+		char b[48];
+		if (x == 0.0) std::snprintf(b, sizeof b, "0.0"); else std::snprintf(b, sizeof b, "%.2e", x);
+		s += b;
+	}
+	// TextBuffer::print(unsigned, width): right-aligned, and only `width` characters are kept
+	void print_width(unsigned i, unsigned width)
+	{
+		char b[32];
+		std::snprintf(b, 16, "%*u", (int)width, i);
+		s.append(b, std::min<size_t>(width, std::strlen(b)));
+	}
+	void until(const char* t, const char* delims) { s.append(t, std::strcspn(t, delims)); }
+};
+
+const char* const ID_DELIMITERS = " \a\b\f\n\r\t\v\1";   // Util::Seq::id_delimiters
+
+// OutputFormat::print_title: the titles of a record are separated by \1 or " >"
+void print_title(Out& o, const char* id, bool full_titles, bool all_titles, const char* separator)
+{
+	const char* p = id;
+	int n = 0;
+	for (;;) {
+		const char* a = std::strchr(p, '\1');
+		const char* b = std::strstr(p, " >");
+		const char* e = a && b ? std::min(a, b) : a ? a : b;
+		const size_t len = e ? (size_t)(e - p) : std::strlen(p);
+		if (n++ > 0) o << separator;
+		const std::string tok(p, len);
+		if (full_titles) o.s += tok; else o.until(tok.c_str(), ID_DELIMITERS);
+		if (!e || !all_titles) break;
+		p = e + (*e == '\1' ? 1 : 2);
+	}
+}
+
+// HspContext::Iterator: one alignment column at a time
+struct Walk {
+	const dmnd_hsp_view& v;
+	const uint8_t* t;
+	int left, count = 0, op = 0, letter = 0;
+	int qpos, spos;
+	bool ok = false;
+	explicit Walk(const dmnd_hsp_view& view) : v(view), t(view.transcript), left(view.match->hsp.transcript_len), qpos(view.match->hsp.q_begin), spos(view.match->hsp.s_begin) { fetch(); }
+	void fetch()
+	{
+		ok = false;
+		while (left > 0) {
+			const uint8_t b = *t;
+			op = b >> 6;
+			if (op == OP_MATCH || op == OP_INSERTION) { count = b & 63; letter = 0; }
+			else { count = 1; letter = b & 63; }
+			++t; --left;
+			if (count > 0) { ok = true; return; }
+		}
+	}
+	bool good() const { return ok; }
+	void next()
+	{
+		if (op != OP_DELETION) ++qpos;
+		if (op != OP_INSERTION) ++spos;
+		if (--count == 0) fetch();
+	}
+	int query() const { return v.qseq[qpos] & 31; }
+	int subject() const { return (op == OP_MATCH || op == OP_INSERTION) ? query() : letter; }
+	char query_char() const { return op == OP_DELETION ? '-' : AA[query()]; }
+	char subject_char() const { return op == OP_INSERTION ? '-' : AA[subject()]; }
+};
+
+struct Frame {
+	bool translated; int offset; bool forward; int dna_len;
+	explicit Frame(const dmnd_hsp_view& v) : translated(v.source_seq != nullptr), offset(v.match->frame % 3), forward(v.match->frame < 3), dna_len(v.source_seq ? v.source_len : v.qlen) {}
+	int in_strand(int pos) const { return translated ? offset + 3 * pos : pos; }                 // TranslatedPosition::in_strand
+	int oriented(int p) const { return forward ? p : dna_len - 1 - p; }                           // oriented_position
+	int absolute(int pos) const { return oriented(in_strand(pos)); }
+	int blast_frame() const { return translated ? (forward ? offset + 1 : -(offset + 1)) : 0; }   // Hsp::blast_query_frame
+};
+
+// Hsp::query_source_range (basic/match.h, TranslatedPosition::absolute_interval): the DNA interval of the aligned codons
+void source_range(const dmnd_hsp_view& v, int& b, int& e)
+{
+	const Frame f(v);
+	const dmnd_hsp& h = v.match->hsp;
+	if (!f.translated) { b = h.q_begin; e = h.q_end; return; }
+	if (f.forward) { b = f.offset + 3 * h.q_begin; e = f.offset + 3 * h.q_end; }
+	else { e = f.dna_len - f.offset - 3 * h.q_begin; b = f.dna_len - f.offset - 3 * h.q_end; }
+}
+
+int need_transcript(int id)
+{
+	switch (id) {
+	case DMND_F_SSEQ: case DMND_F_BTOP: case DMND_F_QSEQ_GAPPED: case DMND_F_SSEQ_GAPPED: case DMND_F_CIGAR: return 1;
+	default: return 0;
+	}
+}
+
+int print_field(Out& o, const dmnd_hsp_view& v, int id)
+{
+	const dmnd_match& m = *v.match;
+	const dmnd_hsp& h = m.hsp;
+	const Frame f(v);
+	if (need_transcript(id) && !v.transcript) return fail(DMND_E_ARG, std::string("dmnd_format_fields: field ") + FIELD_NAMES[id] + " needs the transcript");
+	int sb, se;
+	source_range(v, sb, se);
+	switch (id) {
+	case DMND_F_QSEQID: o.until(v.qtitle, ID_DELIMITERS); break;
+	case DMND_F_QLEN: o << (f.translated ? v.source_len : v.qlen); break;
+	case DMND_F_SSEQID: print_title(o, v.stitle, false, false, ""); break;
+	case DMND_F_SALLSEQID: print_title(o, v.stitle, false, true, ";"); break;
+	case DMND_F_SLEN: o << v.slen; break;
+	// oriented_query_range: reverse frames print qstart > qend
+	case DMND_F_QSTART: o << (f.translated ? (f.forward ? sb + 1 : se) : h.q_begin + 1); break;
+	case DMND_F_QEND: o << (f.translated ? (f.forward ? se : sb + 1) : h.q_end); break;
+	case DMND_F_SSTART: o << h.s_begin + 1; break;
+	case DMND_F_SEND: o << h.s_end; break;
+	case DMND_F_QSEQ:                                       // the source sequence over query_source_range: DNA for a translated search
+		if (f.translated) for (int i = sb; i < se; ++i) o << NT[v.source_seq[i] & 7];
+		else for (int i = h.q_begin; i < h.q_end; ++i) o << AA[v.qseq[i] & 31];
+		break;
+	case DMND_F_SSEQ:
+		for (Walk w(v); w.good(); w.next()) if (w.op != OP_INSERTION) o << AA[w.subject()];
+		break;
+	case DMND_F_EVALUE: o.print_e(m.evalue); break;
+	case DMND_F_BITSCORE: o << m.bit_score; break;
+	case DMND_F_SCORE: o << h.score; break;
+	case DMND_F_LENGTH: o << h.length; break;
+	case DMND_F_PIDENT: o << (double)h.identities * 100.0 / (double)h.length; break;
+	case DMND_F_NIDENT: o << h.identities; break;
+	case DMND_F_MISMATCH: o << h.mismatches; break;
+	case DMND_F_POSITIVE: o << h.positives; break;
+	case DMND_F_GAPOPEN: o << h.gap_openings; break;
+	case DMND_F_GAPS: o << h.gaps; break;
+	case DMND_F_PPOS: o << (double)h.positives * 100.0 / h.length; break;
+	case DMND_F_QFRAME: o << f.blast_frame(); break;
+	case DMND_F_BTOP: {
+		unsigned n_matches = 0;
+		for (Walk w(v); w.good(); w.next()) {
+			if (w.op == OP_MATCH) { ++n_matches; continue; }
+			if (n_matches > 0) { o << n_matches; n_matches = 0; }
+			if (w.op == OP_SUBSTITUTION) o << w.query_char() << w.subject_char();
+			else if (w.op == OP_INSERTION) o << w.query_char() << '-';
+			else o << '-' << w.subject_char();
+		}
+		if (n_matches > 0) o << n_matches;
+		break;
+	}
+	case DMND_F_STITLE: print_title(o, v.stitle, true, false, "<>"); break;
+	case DMND_F_SALLTITLES: print_title(o, v.stitle, true, true, "<>"); break;
+	case DMND_F_QCOVHSP: o << (double)(se - sb) * 100.0 / (f.translated ? v.source_len : v.qlen); break;
+	case DMND_F_QTITLE: o << v.qtitle; break;
+	case DMND_F_FULL_SSEQ:
+		if (!v.full_sseq) return fail(DMND_E_ARG, "dmnd_format_fields: full_sseq needs the target letters");
+		for (int i = 0; i < v.slen; ++i) o << AA[v.full_sseq[i] & 31];
+		break;
+	case DMND_F_QNUM: o << (long long)v.qnum; break;
+	case DMND_F_SNUM: o << (long long)v.snum; break;
+	case DMND_F_SCOVHSP: o << (double)(h.s_end - h.s_begin) * 100.0 / v.slen; break;
+	case DMND_F_FULL_QSEQ:
+		if (f.translated) for (int i = 0; i < v.source_len; ++i) o << NT[v.source_seq[i] & 7];
+		else for (int i = 0; i < v.qlen; ++i) o << AA[v.qseq[i] & 31];
+		break;
+	case DMND_F_QSEQ_GAPPED: for (Walk w(v); w.good(); w.next()) o << w.query_char(); break;
+	case DMND_F_SSEQ_GAPPED: for (Walk w(v); w.good(); w.next()) o << w.subject_char(); break;
+	case DMND_F_QSTRAND: o << (f.translated ? (f.blast_frame() > 0 ? '+' : '-') : '+'); break;
+	case DMND_F_CIGAR: {
+		// print_cigar: runs of M (match + substitution), I, D
+		static const int map[4] = { 0, 1, 2, 0 };
+		static const char letter[3] = { 'M', 'I', 'D' };
+		unsigned n = 0;
+		int op = 0;
+		const uint8_t* t = v.transcript;
+		for (int i = 0; i < h.transcript_len; ++i) {
+			const int o2 = t[i] >> 6, cnt = (o2 == OP_MATCH || o2 == OP_INSERTION) ? (t[i] & 63) : 1;
+			if (map[o2] == op) n += (unsigned)cnt;
+			else { if (n > 0) { o << n << letter[op]; } n = (unsigned)cnt; op = map[o2]; }
+		}
+		if (n > 0) o << n << letter[op];
+		break;
+	}
+	case DMND_F_QSEQ_TRANSLATED: for (int i = h.q_begin; i < h.q_end; ++i) o << AA[v.qseq[i] & 31]; break;
+	case DMND_F_HSPNUM: o << 0; break;                      // max_hsps = 1
+	default: return fail(DMND_E_ARG, "dmnd_format_fields: unknown field id");
+	}
+	return DMND_OK;
+}
+
+int64_t emit(const Out& o, char* buf, int64_t cap, const char* who)
+{
+	if ((int64_t)o.s.size() >= cap) return fail(DMND_E_CAP, std::string(who) + ": buffer too small");
+	std::memcpy(buf, o.s.data(), o.s.size());
+	buf[o.s.size()] = 0;
+	return (int64_t)o.s.size();
+}
+
+bool view_ok(const dmnd_hsp_view* v)
+{
+	return v && v->match && v->qtitle && v->stitle && v->qseq && v->match->frame >= 0 && v->match->frame <= 5 && (!v->source_seq || v->source_len > 0)
+		&& v->match->hsp.q_begin >= 0 && v->match->hsp.q_end <= v->qlen && v->match->hsp.s_begin >= 0 && v->match->hsp.s_end <= v->slen && v->match->hsp.length > 0;
+}
+
+}  // namespace
+
+extern "C" int dmnd_output_fields(const char* const* names, int n, int32_t* ids, int* needs_transcript)
+{
+	if (!names || n < 1 || !ids) return fail(DMND_E_ARG, "dmnd_output_fields: bad argument");
+	if (needs_transcript) *needs_transcript = 0;
+	for (int i = 0; i < n; ++i) {
+		if (!names[i]) return fail(DMND_E_ARG, "dmnd_output_fields: NULL field name");
+		int id = -1;
+		for (int k = 0; k < DMND_F_COUNT; ++k) if (std::strcmp(names[i], FIELD_NAMES[k]) == 0) id = k;
+		if (id < 0) {
+			for (const char* u : UNAVAILABLE)
+				if (std::strcmp(names[i], u) == 0) return fail(DMND_E_ARG, std::string("Output field not available in this build: ") + names[i]);
+			return fail(DMND_E_ARG, std::string("Invalid output field: ") + names[i]);       // blast_tab_format.cpp:661
+		}
+		ids[i] = id;
+		if (needs_transcript && need_transcript(id)) *needs_transcript = 1;
+	}
+	return DMND_OK;
+}
+
+extern "C" int64_t dmnd_format_fields(const dmnd_hsp_view* v, const int32_t* ids, int n, char* buf, int64_t cap)
+{
+	if (!view_ok(v) || !ids || n < 1 || !buf) return fail(DMND_E_ARG, "dmnd_format_fields: bad argument");
+	Out o;
+	for (int i = 0; i < n; ++i) {
+		if (ids[i] < 0 || ids[i] >= DMND_F_COUNT) return fail(DMND_E_ARG, "dmnd_format_fields: unknown field id");
+		if (i) o << '\t';
+		if (int rc = print_field(o, *v, ids[i])) return rc;
+	}
+	o << '\n';
+	return emit(o, buf, cap, "dmnd_format_fields");
+}
+
+extern "C" int64_t dmnd_format_pairwise_intro(const char* qtitle, int32_t qlen, int unaligned, char* buf, int64_t cap)
+{
+	if (!qtitle || !buf) return fail(DMND_E_ARG, "dmnd_format_pairwise_intro: NULL argument");
+	Out o;
+	o << "Query= " << qtitle << "\n\nLength=" << qlen << "\n\n";
+	if (unaligned) o << "\n***** No hits found *****\n\n\n";
+	return emit(o, buf, cap, "dmnd_format_pairwise_intro");
+}
+
+extern "C" int64_t dmnd_format_pairwise(const dmnd_hsp_view* v, const int8_t* matrix8, char* buf, int64_t cap)
+{
+	if (!view_ok(v) || !matrix8 || !buf) return fail(DMND_E_ARG, "dmnd_format_pairwise: bad argument");
+	if (!v->transcript) return fail(DMND_E_ARG, "dmnd_format_pairwise: the pairwise format needs the transcript");
+	const dmnd_match& m = *v->match;
+	const dmnd_hsp& h = m.hsp;
+	const Frame f(*v);
+	const unsigned width = 60;
+	Out o;
+	o << '>';
+	print_title(o, v->stitle, true, true, " ");
+	o << "\nLength=" << v->slen << "\n\n";
+	o << " Score = " << m.bit_score << " bits (" << h.score << "),  Expect = ";
+	o.print_e(m.evalue);
+	o << '\n';
+	const unsigned len = (unsigned)h.length;
+	o << " Identities = " << h.identities << '/' << h.length << " (" << (unsigned)h.identities * 100u / len << "%), Positives = " << h.positives << '/' << h.length
+		<< " (" << (unsigned)h.positives * 100u / len << "%), Gaps = " << h.gaps << '/' << h.length << " (" << (unsigned)h.gaps * 100u / len << "%)\n";
+	if (f.translated) o << " Frame = " << f.blast_frame() << '\n';
+	o << '\n';
+	int sb, se;
+	source_range(*v, sb, se);
+	const unsigned digits = (unsigned)std::max(std::ceil(std::log10((double)h.s_end)), std::ceil(std::log10((double)se)));
+	Walk qi(*v), mi(*v), si(*v);
+	while (qi.good()) {
+		o << "Query  ";
+		o.print_width((unsigned)(f.absolute(qi.qpos) + 1), digits);
+		o << "  ";
+		for (unsigned i = 0; i < width && qi.good(); ++i, qi.next()) o << qi.query_char();
+		o << " " << f.oriented(f.in_strand(qi.qpos) - 1) + 1 << '\n';
+		for (unsigned i = 0; i < digits + 9; ++i) o << ' ';
+		for (unsigned i = 0; i < width && mi.good(); ++i, mi.next())
+			o << (mi.op == OP_MATCH ? AA[mi.query()] : mi.op == OP_SUBSTITUTION ? (matrix8[mi.query() * 32 + mi.subject()] > 0 ? '+' : ' ') : ' ');
+		o << '\n';
+		o << "Sbjct  ";
+		o.print_width((unsigned)(si.spos + 1), digits);
+		o << "  ";
+		for (unsigned i = 0; i < width && si.good(); ++i, si.next()) o << si.subject_char();
+		o << " " << si.spos << "\n\n";
+	}
+	return emit(o, buf, cap, "dmnd_format_pairwise");
+}
+
+extern "C" int64_t dmnd_format_paf(const dmnd_hsp_view* v, const char* unaligned_qtitle, char* buf, int64_t cap)
+{
+	if (!buf || (!v && !unaligned_qtitle)) return fail(DMND_E_ARG, "dmnd_format_paf: bad argument");
+	Out o;
+	if (!v) {
+		o.until(unaligned_qtitle, ID_DELIMITERS);
+		o << "\t4\t*\t0\t255\t*\t*\t0\t0\t*\t*\n";
+		return emit(o, buf, cap, "dmnd_format_paf");
+	}
+	if (!view_ok(v)) return fail(DMND_E_ARG, "dmnd_format_paf: bad argument");
+	const dmnd_match& m = *v->match;
+	const dmnd_hsp& h = m.hsp;
+	const Frame f(*v);
+	int sb, se;
+	source_range(*v, sb, se);
+	o.until(v->qtitle, ID_DELIMITERS);
+	o << '\t' << (f.translated ? v->source_len : v->qlen) << '\t' << sb << '\t' << se - 1 << '\t' << (f.forward ? '+' : '-') << '\t';
+	print_title(o, v->stitle, false, false, "<>");
+	// AS = (uint32_t)ScoreMatrix::bitscore(score): the record's bit score, truncated
+	o << '\t' << v->slen << '\t' << h.s_begin << '\t' << h.s_end - 1 << '\t' << h.identities << '\t' << h.length << '\t' << "255" << '\t'
+		<< "AS:i:" << (long long)(uint32_t)m.bit_score << '\t' << "ZR:i:" << h.score << '\t' << "ZE:f:";
+	o.print_e(m.evalue);
+	o << '\n';
+	return emit(o, buf, cap, "dmnd_format_paf");
+}

@@ -70,7 +70,8 @@ EXPORTS = ["dmnd_abi_version", "dmnd_last_error", "dmnd_default_params", "dmnd_c
            "dmnd_set_query_contexts", "dmnd_translate", "dmnd_format_tab_translated", "dmnd_mask_block", "dmnd_mask_kernel_ms", "dmnd_seed_params_preset", "dmnd_set_comp_based_stats",
            "dmnd_seed_params_set_index_chunks", "dmnd_join_blocks", "dmnd_set_sensitivity", "dmnd_touch_streams",
            "dmnd_seed_params_set_query_indexed", "dmnd_auto_query_indexed", "dmnd_set_motif_table", "dmnd_motif_table_size",
-           "dmnd_soft_mask_block"]
+           "dmnd_soft_mask_block", "dmnd_output_fields", "dmnd_format_fields", "dmnd_format_pairwise_intro", "dmnd_format_pairwise",
+           "dmnd_format_paf"]
 
 
 def set_motif_table(codes):
@@ -214,6 +215,83 @@ def format_tab(matches, qids, tids, source_lens=None):
             raise DiamondHipError(lib.dmnd_last_error().decode())
         out.append(buf.raw[:n].decode())
     return "".join(out)
+
+
+class HspView(ctypes.Structure):
+    """dmnd_hsp_view: one HSP with everything the output formats read."""
+    _fields_ = [("match", ctypes.c_void_p), ("transcript", ctypes.c_void_p), ("qtitle", ctypes.c_char_p), ("stitle", ctypes.c_char_p),
+                ("qseq", ctypes.c_void_p), ("qlen", ctypes.c_int32), ("slen", ctypes.c_int32), ("full_sseq", ctypes.c_void_p),
+                ("source_seq", ctypes.c_void_p), ("source_len", ctypes.c_int32), ("qnum", ctypes.c_int64), ("snum", ctypes.c_int64)]
+
+
+def output_fields(names):
+    """Field names of --outfmt 6 -> (ids, needs_transcript); raises with the reference's message for an unknown field."""
+    lib = load()
+    arr = (ctypes.c_char_p * len(names))(*[n.encode() for n in names])
+    ids = (ctypes.c_int32 * len(names))()
+    need = ctypes.c_int(0)
+    if lib.dmnd_output_fields(arr, len(names), ids, ctypes.byref(need)) != 0:
+        raise DiamondHipError(lib.dmnd_last_error().decode())
+    return list(ids), bool(need.value)
+
+
+class _View:
+    """Keeps the numpy buffers of an HspView alive."""
+
+    def __init__(self, match, transcript, qtitle, stitle, qseq, slen, full_sseq=None, source_seq=None, qnum=0, snum=0):
+        self.rec = np.ascontiguousarray(match, dtype=MATCH_DTYPE).reshape(1).copy()
+        self.tr = None if transcript is None else np.ascontiguousarray(transcript, dtype=np.uint8)
+        self.q = np.ascontiguousarray(qseq, dtype=np.int8)
+        self.fs = None if full_sseq is None else np.ascontiguousarray(full_sseq, dtype=np.int8)
+        self.src = None if source_seq is None else np.ascontiguousarray(source_seq, dtype=np.int8)
+        v = HspView()
+        v.match = self.rec.ctypes.data
+        v.transcript = None if self.tr is None else self.tr.ctypes.data
+        v.qtitle, v.stitle = qtitle.encode(), stitle.encode()
+        v.qseq, v.qlen, v.slen = self.q.ctypes.data, len(self.q), int(slen)
+        v.full_sseq = None if self.fs is None else self.fs.ctypes.data
+        v.source_seq = None if self.src is None else self.src.ctypes.data
+        v.source_len = 0 if self.src is None else len(self.src)
+        v.qnum, v.snum = int(qnum), int(snum)
+        self.v = v
+
+
+def _formatted(fn, *args):
+    lib = load()
+    cap = 1 << 16
+    while True:
+        buf = ctypes.create_string_buffer(cap)
+        fn.restype = ctypes.c_int64
+        n = fn(*args, buf, ctypes.c_int64(cap))
+        if n == -5 and cap < (1 << 30):       # DMND_E_CAP
+            cap *= 8
+            continue
+        if n < 0:
+            raise DiamondHipError(lib.dmnd_last_error().decode())
+        return buf.raw[:n].decode()
+
+
+def format_fields(ids, match, transcript, qtitle, stitle, qseq, slen, **kw):
+    """One `-f 6 FIELD...` line of a match record (transcript: its PackedOperation bytes; qseq: the aligned query context)."""
+    view = _View(match, transcript, qtitle, stitle, qseq, slen, **kw)
+    arr = (ctypes.c_int32 * len(ids))(*ids)
+    return _formatted(load().dmnd_format_fields, ctypes.byref(view.v), arr, len(ids))
+
+
+def format_pairwise(match, transcript, qtitle, stitle, qseq, slen, matrix8, **kw):
+    """The `-f 0` block of one match."""
+    view = _View(match, transcript, qtitle, stitle, qseq, slen, **kw)
+    m = np.ascontiguousarray(matrix8, dtype=np.int8)
+    return _formatted(load().dmnd_format_pairwise, ctypes.byref(view.v), m.ctypes.data_as(ctypes.c_void_p))
+
+
+def format_pairwise_intro(qtitle, qlen, unaligned=False):
+    return _formatted(load().dmnd_format_pairwise_intro, qtitle.encode(), ctypes.c_int32(int(qlen)), ctypes.c_int(1 if unaligned else 0))
+
+
+def format_paf(match, qtitle, stitle, qseq, slen, **kw):
+    view = _View(match, None, qtitle, stitle, qseq, slen, **kw)
+    return _formatted(load().dmnd_format_paf, ctypes.byref(view.v), None)
 
 
 def seed_params_default(scoring, threads=1):

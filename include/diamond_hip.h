@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DMND_ABI_VERSION 3      /* 2: dmnd_match.frame, seed parameters (ungapped filter, translated queries), dmnd_extend_plan(query_contexts); 3: seed_encoding */
+#define DMND_ABI_VERSION 4      /* 2: dmnd_match.frame, seed parameters (ungapped filter, translated queries), dmnd_extend_plan(query_contexts); 3: seed_encoding; 4: output formats */
 
 enum {
 	DMND_OK = 0,
@@ -342,6 +342,45 @@ int dmnd_touch_streams(dmnd_ctx* ctx);
 int dmnd_extend_stats(const dmnd_ctx* ctx, double out[12]);
 /* BLAST tabular (-f 6 default fields) line of one match, as the reference prints it; returns the length written. */
 int dmnd_format_tab(const dmnd_match* m, const char* qseqid, const char* sseqid, char* buf, int64_t cap);
+
+/* -- output formats over the records + packed transcripts (host only) ---------------------------------------------------
+ * `-f 6 FIELD...` (TabularFormat, src/output/blast_tab_format.cpp:46-620) and `-f 0` (PairwiseFormat,
+ * src/output/blast_pairwise_format.cpp:24-85) of the reference, printed from what dmnd_extend returns: the record, the HSP's
+ * PackedOperation bytes (basic/packed_transcript.h: op << 6 | count for matches / insertions, op << 6 | letter for deletions /
+ * substitutions) and the sequences. Fields that need the taxonomy or FASTQ qualities are not part of this build. */
+enum {
+	DMND_F_QSEQID = 0, DMND_F_QLEN, DMND_F_SSEQID, DMND_F_SALLSEQID, DMND_F_SLEN, DMND_F_QSTART, DMND_F_QEND, DMND_F_SSTART, DMND_F_SEND,
+	DMND_F_QSEQ, DMND_F_SSEQ, DMND_F_EVALUE, DMND_F_BITSCORE, DMND_F_SCORE, DMND_F_LENGTH, DMND_F_PIDENT, DMND_F_NIDENT, DMND_F_MISMATCH,
+	DMND_F_POSITIVE, DMND_F_GAPOPEN, DMND_F_GAPS, DMND_F_PPOS, DMND_F_QFRAME, DMND_F_BTOP, DMND_F_STITLE, DMND_F_SALLTITLES, DMND_F_QCOVHSP,
+	DMND_F_QTITLE, DMND_F_FULL_SSEQ, DMND_F_QNUM, DMND_F_SNUM, DMND_F_SCOVHSP, DMND_F_FULL_QSEQ, DMND_F_QSEQ_GAPPED, DMND_F_SSEQ_GAPPED,
+	DMND_F_QSTRAND, DMND_F_CIGAR, DMND_F_QSEQ_TRANSLATED, DMND_F_HSPNUM, DMND_F_COUNT
+};
+/* One HSP with everything a format reads (HspContext, src/basic/match.h:281-440) */
+typedef struct {
+	const dmnd_match* match;
+	const uint8_t* transcript;     /* the HSP's packed operations (match->hsp.transcript_len bytes), NULL if dmnd_extend ran without an arena */
+	const char* qtitle;            /* full FASTA titles */
+	const char* stitle;
+	const int8_t* qseq;            /* letters of the aligned query context (blastx: the frame match->frame), as the extension stage saw them */
+	int32_t qlen;
+	int32_t slen;                  /* target length */
+	const int8_t* full_sseq;       /* target letters before masking (full_sseq; may be NULL if the field is not printed) */
+	const int8_t* source_seq;      /* blastx: the DNA read (A C G T N = 0..4); blastp: NULL */
+	int32_t source_len;            /* blastx: its length; blastp: ignored */
+	int64_t qnum, snum;            /* ordinal ids in the query file / database */
+} dmnd_hsp_view;
+/* Field names of --outfmt 6 (blast_tab_format.cpp:46-102) -> DMND_F_*; DMND_E_ARG with the reference's message for an unknown
+ * or unavailable field. *needs_transcript = 1 if a field reads the transcript (HspValues::TRANSCRIPT). */
+int dmnd_output_fields(const char* const* names, int n, int32_t* ids, int* needs_transcript);
+/* One tabular line (fields separated by tabs, newline at the end); returns the length written or DMND_E_CAP. */
+int64_t dmnd_format_fields(const dmnd_hsp_view* v, const int32_t* ids, int n, char* buf, int64_t cap);
+/* BLAST pairwise: "Query= ..." block of a query (print_query_intro) and one alignment (print_match). matrix8 = the 32x32
+ * substitution matrix of the scoring parameters (midline '+'). */
+int64_t dmnd_format_pairwise_intro(const char* qtitle, int32_t qlen, int unaligned, char* buf, int64_t cap);
+int64_t dmnd_format_pairwise(const dmnd_hsp_view* v, const int8_t* matrix8, char* buf, int64_t cap);
+/* PAF (`-f paf` / 103, src/output/paf_format.cpp:24-66): one line per HSP; v == NULL prints the line of an unaligned query
+ * (qtitle given), which this format reports by default. */
+int64_t dmnd_format_paf(const dmnd_hsp_view* v, const char* unaligned_qtitle, char* buf, int64_t cap);
 
 /* -- timing hooks for bench.py: device time of the DP kernels of the last dmnd_banded_swipe call,
  *    measured with HIP events on the stream the kernels ran on ------------------------------------ */

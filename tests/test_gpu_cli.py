@@ -195,6 +195,8 @@ CTEST = [
     ("comp-based-stats-0", ["--more-sensitive", "-c1", "-p4", "--comp-based-stats", "0"]),
     ("target-seqs", ["-k3", "-c1", "-p4"]),
     ("evalue", ["-e10000", "--more-sensitive", "-c1", "-p4"]),
+    ("pairwise-format", ["-c1", "-f0", "-p4"]),
+    ("paf-format", ["-c1", "-f", "paf", "-p1"]),
 ]
 
 
@@ -205,7 +207,12 @@ def test_cli_reproduces_reference_ctest_golden(tmp_path, name, args):
     assert os.path.exists(os.path.join(ROOT, "diamond_amd", "motifs.bin")), "motif table not generated (tools/make_motif_table.py)"
     out = str(tmp_path / "out")
     _run([CLI, "blastp", "-q", os.path.join(g, "data.faa"), "-d", os.path.join(g, "data.faa")] + args + ["-o", out])
-    want = open(os.path.join(g, "diamond-test-blastp-%s.out" % name)).read()
+    path = os.path.join(g, "diamond-test-blastp-%s.out" % name)
+    if os.path.exists(path + ".gz"):
+        import gzip
+        want = gzip.open(path + ".gz", "rt").read()
+    else:
+        want = open(path).read()
     got = open(out).read()
     if got != want:
         a, b = set(want.splitlines()), set(got.splitlines())
@@ -269,3 +276,54 @@ def test_cli_reproduces_motif_masking_golden(tmp_path, flags, golden):
     log = _run([CLI, "blastp"] + flags + ["-q", os.path.join(g, "motif_q.faa"), "-d", os.path.join(g, "motif_db.faa"), "-o", out, "-p", "2"])
     assert "Soft-masked letters (motifs):" in log.stderr
     assert open(out).read() == open(os.path.join(g, golden)).read()
+
+
+ALL_FIELDS = ["qseqid", "qlen", "sseqid", "sallseqid", "slen", "qstart", "qend", "sstart", "send", "qseq", "sseq", "evalue", "bitscore", "score",
+              "length", "pident", "nident", "mismatch", "positive", "gapopen", "gaps", "ppos", "qframe", "btop", "stitle", "salltitles", "qcovhsp",
+              "qtitle", "full_sseq", "qnum", "snum", "scovhsp", "full_qseq", "qseq_gapped", "sseq_gapped", "qstrand", "cigar"]
+
+
+@pytest.mark.parametrize("mode", ["blastp", "blastp-sensitive-blocked", "blastx"])
+def test_cli_output_fields_and_pairwise_match_reference(tmp_path, mode):
+    """`-f 6 FIELD...` with every field this build prints, and `-f 0`, against the reference binary on the same files (default
+    flags: tantan-masked letters show up as X in qseq / sseq, full_sseq prints the unmasked target)."""
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/diamond not built")
+    db, doff, q, qoff = synth.generate(150, members=6, queries=200, seed=31)
+    rng = np.random.default_rng(4)
+    for a, off in ((db, doff), (q, qoff)):                       # low-complexity stretches that tantan masks
+        for i in range(0, len(off) - 1, 7):
+            b, e = int(off[i]), int(off[i + 1])
+            if e - b > 80:
+                p = int(rng.integers(b, e - 40))
+                a[p:p + 36] = np.tile(np.array([int(rng.integers(0, 20)), int(rng.integers(0, 20))], np.int8), 18)
+    synth.write_fasta(str(tmp_path / "db.faa"), "t", db, doff)
+    titles = str(tmp_path / "db2.faa")                            # titles with a description and a second \1-separated id
+    with open(tmp_path / "db.faa") as f, open(titles, "w") as g:
+        for n, line in enumerate(f):
+            g.write(line.rstrip("\n") + (" some protein [organism %d]\x01alt%d second title\n" % (n, n) if line.startswith(">") else "\n"))
+    if mode == "blastx":
+        dna, dna_off = synth.back_translate(q[:qoff[120]], qoff[:121], seed=5)
+        synth.write_dna_fasta(str(tmp_path / "q.fa"), "r", dna, dna_off)
+        base = ["blastx", "-q", str(tmp_path / "q.fa"), "-d", titles, "-p", "4"]
+        fields = ALL_FIELDS + ["qseq_translated"]
+    else:
+        synth.write_fasta(str(tmp_path / "q.faa"), "q", q, qoff)
+        base = ["blastp", "-q", str(tmp_path / "q.faa"), "-d", titles, "-p", "4"]
+        if mode == "blastp-sensitive-blocked":
+            base += ["--sensitive", "-b0.00003", "-c1"]
+        fields = ALL_FIELDS
+    for name, fmt in (("fields", ["-f", "6"] + fields), ("pairwise", ["-f", "0"]), ("paf", ["-f", "paf"])):
+        _run([REF] + base + fmt + ["-o", str(tmp_path / ("ref_" + name))])
+        _run([CLI] + base + fmt + ["-o", str(tmp_path / ("hip_" + name))])
+        want, got = open(tmp_path / ("ref_" + name)).read(), open(tmp_path / ("hip_" + name)).read()
+        assert len(want.splitlines()) > 200
+        if got != want:
+            w, g2 = want.splitlines(), got.splitlines()
+            k = next((i for i in range(min(len(w), len(g2))) if w[i] != g2[i]), min(len(w), len(g2)))
+            if name == "fields" and k < min(len(w), len(g2)):
+                a, b = w[k].split("\t"), g2[k].split("\t")
+                bad = [(fields[i], a[i][:60], b[i][:60]) for i in range(min(len(a), len(b))) if a[i] != b[i]]
+                raise AssertionError("%s %s line %d: %s" % (mode, name, k, bad[:4]))
+            raise AssertionError("%s %s: first difference at line %d of %d/%d:\n%r\n%r" % (mode, name, k, len(w), len(g2), w[k:k + 2], g2[k:k + 2]))
+    assert "X" in "".join(l.split("\t")[9] for l in open(tmp_path / "ref_fields")) or mode == "blastx"
