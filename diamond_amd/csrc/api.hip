@@ -116,6 +116,17 @@ extern "C" int dmnd_default_params(dmnd_params* p)
 	return DMND_OK;
 }
 
+extern "C" int dmnd_device_count(void)
+{
+	int count = 0, usable = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+	for (int d = 0; d < count; ++d) {
+		hipDeviceProp_t prop;
+		if (hipGetDeviceProperties(&prop, d) == hipSuccess && std::strncmp(prop.gcnArchName, "gfx950", 6) == 0) ++usable;
+	}
+	return usable;
+}
+
 extern "C" dmnd_ctx* dmnd_create(int device, const dmnd_params* params)
 {
 	if (!params) { fail(DMND_E_ARG, "dmnd_create: params is NULL"); return nullptr; }
@@ -137,6 +148,9 @@ extern "C" dmnd_ctx* dmnd_create(int device, const dmnd_params* params)
 	if (hipSetDevice(device) != hipSuccess) { fail(DMND_E_DEVICE, "hipSetDevice failed"); return nullptr; }
 	dmnd_ctx* c = new dmnd_ctx();
 	c->device = device;
+	// host worker pool of the context's extension calls: contexts driven by different host threads (one per GPU) do not share one
+	static std::atomic<int> n_created(0);
+	c->pool_id = MAX_POOLS / 2 + n_created.fetch_add(1) % (MAX_POOLS / 2);
 	c->params = *params;
 	c->evaluer.init(*params);
 	if (const char* mb = getenv("DMND_TRACE_ARENA_MB"))

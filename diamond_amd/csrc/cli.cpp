@@ -18,7 +18,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <iostream>
+#include <mutex>
+#include <thread>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -237,6 +240,7 @@ struct Options {
 	std::string masking = "", motif_masking = "", sens = "";
 	int algo = -1;                  // --algo: -1 auto (the reference's default), 0 double-indexed, 1 query-indexed
 	std::vector<std::string> outfmt;   // -f / --outfmt: format, then field names
+	int gpus = 1;                   // --gpus: the reference blocks are spread over this many MI355X of the node
 };
 
 Options parse(int argc, char** argv)
@@ -266,6 +270,7 @@ Options parse(int argc, char** argv)
 		else if (a == "-k" || a == "--max-target-seqs") o.k = std::atoi(need(i).c_str());
 		else if (a == "-e" || a == "--evalue") o.evalue = std::atof(need(i).c_str());
 		else if (a == "--fast") o.fast = true;
+		else if (a == "--gpus") { o.gpus = std::atoi(need(i).c_str()); if (o.gpus < 1) throw std::runtime_error("Invalid number of GPUs."); }
 		else if (a == "-b" || a == "--block-size") { o.block_size = std::atof(need(i).c_str()); if (o.block_size <= 0.0) throw std::runtime_error("Invalid block size."); }
 		else if (a == "-c" || a == "--index-chunks") { o.index_chunks = std::atoi(need(i).c_str()); if (o.index_chunks < 1) throw std::runtime_error("Invalid number of index chunks."); }
 		else if (a == "--comp-based-stats") { o.cbs = std::atoi(need(i).c_str()); if (o.cbs != 0 && o.cbs != 1) throw std::runtime_error("Only --comp-based-stats 0 and 1 are implemented."); }
@@ -399,7 +404,20 @@ int run_blastp(const Options& o)
 		}
 		q_units[i] = n;
 	}
-	const std::vector<Range> q_blocks = split_blocks(q_units, max_letters), t_blocks = split_blocks(t_units, max_letters);
+	// --gpus N: the reference blocks are the unit of distribution (a block's seed stage and extension are independent of the
+	// other blocks', and the records of a query are merged over the blocks as join_blocks does), so the database is cut into at
+	// least N of them -- the block size is lowered to total letters / N if -b would give fewer. The output is the reference's
+	// for the same block cut (-b).
+	const int n_gpus = o.gpus;
+	// test hook (a box with one GPU): DMND_CLI_SHARE_GPU=1 runs the N host threads and contexts of --gpus N on the current device
+	const bool share_gpu = std::getenv("DMND_CLI_SHARE_GPU") != nullptr && std::getenv("DMND_CLI_SHARE_GPU")[0] == '1';
+	if (!share_gpu) {
+		const int have = dmnd_device_count();
+		if (n_gpus > have) throw std::runtime_error("--gpus " + std::to_string(n_gpus) + ": only " + std::to_string(have) + " gfx950 device(s) visible");
+	}
+	int64_t t_max_letters = max_letters;
+	if (n_gpus > 1) t_max_letters = std::min<int64_t>(max_letters, (t_all_seqs.letters + n_gpus - 1) / n_gpus);
+	const std::vector<Range> q_blocks = split_blocks(q_units, max_letters), t_blocks = split_blocks(t_units, t_max_letters);
 	if (q_blocks.size() > 1 || t_blocks.size() > 1)
 		std::cerr << "Block size = " << max_letters << "  query blocks=" << q_blocks.size() << " reference blocks=" << t_blocks.size() << "\n";
 
@@ -407,19 +425,24 @@ int run_blastp(const Options& o)
 	dmnd_default_params(&p);
 	p.db_letters = (double)t_all_seqs.letters;
 	p.max_evalue = o.evalue;
-	dmnd_ctx* ctx = dmnd_create(-1, &p);
-	if (!ctx) throw std::runtime_error(dmnd_last_error());
 	auto chk = [&](int rc) { if (rc != DMND_OK) throw std::runtime_error(dmnd_last_error()); };
-	chk(dmnd_set_max_target_seqs(ctx, o.k));
-	chk(dmnd_set_comp_based_stats(ctx, o.cbs));
-	chk(dmnd_set_query_contexts(ctx, blastx ? 6 : 1));
-	chk(dmnd_set_sensitivity(ctx, sens));
 	const int threads = o.threads > 0 ? o.threads : 8;
 	dmnd_seed_params sp;
 	double gf_evalue = 0.0;
 	chk(dmnd_seed_params_preset(&sp, sens, threads, &p, &gf_evalue));
 	if (o.index_chunks > 0) chk(dmnd_seed_params_set_index_chunks(&sp, o.index_chunks, threads));
-	chk(dmnd_set_gapped_filter(ctx, gf_evalue));
+	// one context per GPU, driven by its own host thread
+	std::vector<dmnd_ctx*> ctxs((size_t)n_gpus, nullptr);
+	for (int g = 0; g < n_gpus; ++g) {
+		dmnd_ctx* c = dmnd_create(n_gpus > 1 && !share_gpu ? g : -1, &p);
+		if (!c) throw std::runtime_error(dmnd_last_error());
+		ctxs[(size_t)g] = c;
+		chk(dmnd_set_max_target_seqs(c, o.k));
+		chk(dmnd_set_comp_based_stats(c, o.cbs));
+		chk(dmnd_set_query_contexts(c, blastx ? 6 : 1));
+		chk(dmnd_set_sensitivity(c, sens));
+		chk(dmnd_set_gapped_filter(c, gf_evalue));
+	}
 	sp.query_translated = blastx ? 1 : 0;
 	// --algo (run/double_indexed.cpp:267-300): auto = query-indexed for a query block of at most 32 Mi letters against a
 	// database of 256 MiB and more (the size of the file on disk), decided on the first query block as the reference does
@@ -463,89 +486,113 @@ int run_blastp(const Options& o)
 	std::vector<std::string> qid(qtitles.size()), tid(n_targets);
 	for (size_t i = 0; i < qid.size(); ++i) qid[i] = short_id(qtitles[i]);
 	for (size_t i = 0; i < tid.size(); ++i) tid[i] = short_id(t_all_seqs.ids[i]);
-	double ms_upload = 0, ms_mask = 0, ms_seed = 0, ms_ext = 0;
+	double ms_upload = 0, ms_mask = 0, ms_seed = 0, ms_ext = 0;       // summed over the GPUs' host threads
 	int64_t motif_letters = 0;
-	std::vector<int8_t> t_masked;         // lazily masked copy of the reference block at hand (query-indexed algorithm)
 	int64_t total_hits = 0, total_matches = 0, aligned = 0, mq_total = 0, mt_total = 0;
 	char line[8192];
+	std::mutex merge_mutex;
+	std::vector<std::vector<int8_t>> t_masked((size_t)n_gpus);      // lazily masked copy of the reference block at hand (query-indexed algorithm)
+	// f(g) on one host thread per GPU; the first error is rethrown on the calling thread
+	auto on_each_gpu = [&](const std::function<void(int)>& f) {
+		if (n_gpus == 1) { f(0); return; }
+		std::vector<std::thread> th;
+		std::vector<std::string> err((size_t)n_gpus);
+		for (int g = 0; g < n_gpus; ++g)
+			th.emplace_back([&, g] { try { f(g); } catch (const std::exception& e) { err[(size_t)g] = e.what()[0] ? e.what() : "error"; } });
+		for (auto& t : th) t.join();
+		for (const std::string& e : err) if (!e.empty()) throw std::runtime_error(e);
+	};
 	for (const Range& qr : q_blocks) {
 		SeqBlock q_own;
 		if (q_blocks.size() > 1) q_own = slice(q_all, qr.begin * C, qr.end * C);
 		SeqBlock& q = q_blocks.size() > 1 ? q_own : q_all;
 		const int64_t nq = (int64_t)((qr.end - qr.begin) * C);
-		t0 = std::chrono::steady_clock::now();
-		chk(dmnd_upload_block(ctx, DMND_QUERY, q.data.data(), (int64_t)q.data.size(), q.limits.data(), nq));
-		ms_upload += ms_since(t0);
-		if (tantan) {
+		// every GPU gets the query block; GPU 0's masking run also writes the masked letters into the host copy that the host part
+		// of every extension call reads
+		on_each_gpu([&](int g) {
+			dmnd_ctx* ctx = ctxs[(size_t)g];
+			auto t0 = std::chrono::steady_clock::now();
+			chk(dmnd_upload_block(ctx, DMND_QUERY, q.data.data(), (int64_t)q.data.size(), q.limits.data(), nq));
+			const double up = ms_since(t0);
 			t0 = std::chrono::steady_clock::now();
-			int64_t mq = 0;
-			chk(dmnd_mask_block(ctx, DMND_QUERY, q.data.data(), &mq));        // the host copy gets the masked letters too
-			mq_total += mq;
-			ms_mask += ms_since(t0);
-		}
-		if (motifs) { int64_t n = 0; chk(dmnd_soft_mask_block(ctx, DMND_QUERY, &n)); motif_letters += n; }
+			int64_t mq = 0, ml = 0;
+			if (tantan) chk(dmnd_mask_block(ctx, DMND_QUERY, g == 0 ? q.data.data() : nullptr, &mq));
+			const double mk = ms_since(t0);
+			if (motifs) chk(dmnd_soft_mask_block(ctx, DMND_QUERY, &ml));
+			std::lock_guard<std::mutex> lock(merge_mutex);
+			ms_upload += up; ms_mask += mk;
+			if (g == 0) { mq_total += mq; motif_letters += ml; }
+		});
 		std::vector<dmnd_match> joined;                       // the query block's records against all reference blocks
 		std::vector<uint8_t> arena;                           // ... and their transcripts, if the output format reads them
 		std::vector<char> seeded(qr.end - qr.begin, 0);       // queries with at least one seed hit (what the unaligned report depends on)
-		for (const Range& tr : t_blocks) {
+		on_each_gpu([&](int g) {
+		dmnd_ctx* ctx = ctxs[(size_t)g];
+		for (size_t bi = (size_t)g; bi < t_blocks.size(); bi += (size_t)n_gpus) {
+			const Range& tr = t_blocks[bi];
 			// the reference re-reads and re-masks every reference block for every query block (run/double_indexed.cpp:404-470)
 			SeqBlock t_own;
 			if (t_blocks.size() > 1) t_own = slice(t_all_seqs, tr.begin, tr.end);
 			SeqBlock& t = t_blocks.size() > 1 ? t_own : t_all_seqs;
-			t0 = std::chrono::steady_clock::now();
+			auto t0 = std::chrono::steady_clock::now();
 			chk(dmnd_upload_block(ctx, DMND_TARGET, t.data.data(), (int64_t)t.data.size(), t.limits.data(), (int64_t)(tr.end - tr.begin)));
-			ms_upload += ms_since(t0);
+			double up = ms_since(t0), mk = 0;
 			const int8_t* t_host = t.data.data();            // the letters the extension stage's host part reads
+			int64_t mt = 0, ml = 0;
 			auto mask_target = [&] {
 				t0 = std::chrono::steady_clock::now();
-				int64_t mt = 0;
 				if (lazy_masking) {                            // t.data stays unmasked: the next query block's seed stage needs it so
-					t_masked.resize(t.data.size());
-					chk(dmnd_mask_block(ctx, DMND_TARGET, t_masked.data(), &mt));
-					t_host = t_masked.data();
+					t_masked[(size_t)g].resize(t.data.size());
+					chk(dmnd_mask_block(ctx, DMND_TARGET, t_masked[(size_t)g].data(), &mt));
+					t_host = t_masked[(size_t)g].data();
 				}
 				else chk(dmnd_mask_block(ctx, DMND_TARGET, t.data.data(), &mt));
-				if (&qr == &q_blocks.front()) mt_total += mt;
-				ms_mask += ms_since(t0);
+				mk += ms_since(t0);
 			};
 			// up-front masking: every block of a multi-block database for every query block; a single block only once (its host
 			// copy keeps the masked letters and is uploaded as it is from then on)
 			if (tantan && !lazy_masking && (t_blocks.size() > 1 || &qr == &q_blocks.front())) mask_target();
-			if (motifs && algo == 0) { int64_t n = 0; chk(dmnd_soft_mask_block(ctx, DMND_TARGET, &n)); if (&qr == &q_blocks.front()) motif_letters += n; }
+			if (motifs && algo == 0) chk(dmnd_soft_mask_block(ctx, DMND_TARGET, &ml));
 			t0 = std::chrono::steady_clock::now();
 			int64_t n_hits = 0;
 			chk(dmnd_seed_search(ctx, &sp, &n_hits));
 			std::vector<dmnd_seed_hit> hits((size_t)n_hits);
 			chk(dmnd_seed_hits(ctx, hits.data(), n_hits));
-			ms_seed += ms_since(t0);
-			total_hits += n_hits;
-			for (const dmnd_seed_hit& h : hits) seeded[h.query / C] = 1;
+			const double sd = ms_since(t0);
 			if (lazy_masking) mask_target();
 			t0 = std::chrono::steady_clock::now();
-			const size_t base = joined.size();
-			joined.resize(base + (size_t)std::max<int64_t>(n_hits, 1));
+			std::vector<dmnd_match> mine((size_t)std::max<int64_t>(n_hits, 1));
+			std::vector<uint8_t> my_arena;
 			int64_t n_matches = 0;
 			if (!need_transcripts)
-				chk(dmnd_extend(ctx, q.data.data(), t_host, hits.data(), n_hits, threads, 0, joined.data() + base, (int64_t)(joined.size() - base), &n_matches, nullptr, 0, nullptr));
+				chk(dmnd_extend(ctx, q.data.data(), t_host, hits.data(), n_hits, threads, 0, mine.data(), (int64_t)mine.size(), &n_matches, nullptr, 0, nullptr));
 			else {
-				// the transcripts of this call are appended to the query block's arena; the records point into it
-				const size_t arena_base = arena.size();
 				int64_t cap = std::max<int64_t>((int64_t)1 << 20, 64 * n_hits), used = 0;
 				for (;;) {
-					arena.resize(arena_base + (size_t)cap);
-					const int rc = dmnd_extend(ctx, q.data.data(), t_host, hits.data(), n_hits, threads, 0, joined.data() + base, (int64_t)(joined.size() - base), &n_matches,
-						arena.data() + arena_base, cap, &used);
+					my_arena.resize((size_t)cap);
+					const int rc = dmnd_extend(ctx, q.data.data(), t_host, hits.data(), n_hits, threads, 0, mine.data(), (int64_t)mine.size(), &n_matches, my_arena.data(), cap, &used);
 					if (rc == DMND_E_CAP && cap < ((int64_t)1 << 36)) { cap *= 4; continue; }
 					chk(rc);
 					break;
 				}
-				arena.resize(arena_base + (size_t)used);
-				for (size_t i = base; i < base + (size_t)n_matches; ++i) joined[i].hsp.transcript_off += (int64_t)arena_base;
+				my_arena.resize((size_t)used);
 			}
-			joined.resize(base + (size_t)n_matches);
-			for (size_t i = base; i < joined.size(); ++i) { joined[i].query += (uint32_t)qr.begin; joined[i].target += (uint32_t)tr.begin; }   // block ids -> file ordinals
-			ms_ext += ms_since(t0);
+			mine.resize((size_t)n_matches);
+			const double ex = ms_since(t0);
+			// into the query block's record list: block ids -> file ordinals, transcripts appended to the block's arena
+			std::lock_guard<std::mutex> lock(merge_mutex);
+			for (const dmnd_seed_hit& h : hits) seeded[h.query / C] = 1;
+			for (dmnd_match& m : mine) {
+				m.query += (uint32_t)qr.begin; m.target += (uint32_t)tr.begin;
+				if (need_transcripts) m.hsp.transcript_off += (int64_t)arena.size();
+			}
+			joined.insert(joined.end(), mine.begin(), mine.end());
+			arena.insert(arena.end(), my_arena.begin(), my_arena.end());
+			ms_upload += up; ms_mask += mk; ms_seed += sd; ms_ext += ex;
+			total_hits += n_hits;
+			if (&qr == &q_blocks.front()) { mt_total += mt; motif_letters += ml; }
 		}
+		});
 		int64_t n_matches = (int64_t)joined.size();
 		if (t_blocks.size() > 1) chk(dmnd_join_blocks(joined.data(), (int64_t)joined.size(), o.k, &n_matches));
 		auto view_of = [&](const dmnd_match& m) {
@@ -602,7 +649,7 @@ int run_blastp(const Options& o)
 		total_matches += n_matches;
 	}
 	if (out != stdout) std::fclose(out);
-	dmnd_destroy(ctx);
+	for (dmnd_ctx* c : ctxs) dmnd_destroy(c);
 	std::cerr << "Uploading blocks to HBM...  [" << ms_upload / 1e3 << "s]\n";
 	if (motifs) std::cerr << "Soft-masked letters (motifs): " << motif_letters << "\n";
 	if (tantan) std::cerr << "Masking queries and reference (tantan)...  [" << ms_mask / 1e3 << "s]  masked letters: " << mq_total << " + " << mt_total << "\n";
@@ -622,6 +669,7 @@ int main(int argc, char** argv)
 		if (o.command == "help" || o.command == "--help") {
 			std::cout << "Syntax: diamond-hip COMMAND [OPTIONS]\n  makedb --in FASTA -d DB        build a .dmnd database (no masking)\n"
 				"  blastp [--fast|--mid-sensitive|--sensitive|--more-sensitive|--very-sensitive] -q FASTA -d DB(.dmnd|FASTA) -o OUT [--masking 0] [-e EVALUE] [-k N] [-p THREADS] [-b BLOCK_SIZE] [-c INDEX_CHUNKS]\n"
+				"         [--algo 0|1] [--gpus N] [-f 6 [FIELD...] | -f 0 | -f paf]\n"
 				"  blastx [--fast|--sensitive] -q DNA_FASTA -d DB ...   (six-frame translation, standard genetic code)\n  version\n";
 			return 0;
 		}

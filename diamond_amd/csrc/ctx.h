@@ -70,6 +70,7 @@ struct KeptTrace;
 
 struct dmnd_ctx {
 	int device = 0;
+	int pool_id = -1;                           // host worker pool of this context's dmnd_extend calls (host_pool.h)
 	hipStream_t stream = nullptr;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
 	dmnd_params params;

@@ -50,6 +50,7 @@ namespace dmnd {
 static thread_local int tls_pool = -1;
 static double g_extend_t0 = 0;           // DMND_TRACE=2: start of the current dmnd_extend (absolute timeline of the runners)
 void set_thread_pool(int k) { tls_pool = k; }
+int thread_pool() { return tls_pool; }
 WorkerPool& pool()
 {
 	static WorkerPool pools[MAX_POOLS + 1];
@@ -717,6 +718,12 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	} total_clock;
 	*n_out = 0;
 	if (transcript_used) *transcript_used = 0;
+	// the calling thread works with the context's own worker pool for the length of the call (unless it already selected one)
+	struct PoolScope {
+		int old;
+		explicit PoolScope(int k) : old(thread_pool()) { if (old < 0) set_thread_pool(k); }
+		~PoolScope() { set_thread_pool(old); }
+	} pool_scope(c->pool_id);
 	const std::vector<int64_t>& ql = c->limits[DMND_QUERY];
 	const std::vector<int64_t>& tl = c->limits[DMND_TARGET];
 	if (ql.size() < 2 || tl.size() < 2) return fail(DMND_E_ARG, "dmnd_extend: blocks must be uploaded with limits");

@@ -133,6 +133,7 @@ enum { MAX_POOLS = 16 };
 // their own pool with set_thread_pool(k) (k < MAX_POOLS); every other thread shares the default pool. Defined in extend_host.hip.
 WorkerPool& pool();
 void set_thread_pool(int k);
+int thread_pool();
 
 // f(t) for t in [0, threads), participant t pinned to one thread of the calling thread's pool
 template<typename F>

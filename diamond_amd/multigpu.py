@@ -39,14 +39,34 @@ def topk_records(n_queries, query_idx, evalue, score, target_oid, k=TOPK, presor
 
 
 def gather_records(rec, device):
-    """ONE all_gather of the fixed-size record tensor; returns [world, n_queries, k, 3] on `device`."""
+    """ONE all_gather of the record tensors; returns [world, rows, k, 3] on `device`. Ranks may hold different numbers of query
+    rows (shard_range hands out slices that differ by one when the query count is not a multiple of the world size): the
+    tensors are padded with +inf rows to the largest count (one small all_gather of the counts), which read as "no record"."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return rec.unsqueeze(0)
     world = dist.get_world_size()
-    rec_d = rec.to(device).contiguous()
-    out = torch.empty((world * rec.shape[0],) + tuple(rec.shape[1:]), dtype=rec.dtype, device=device)
+    counts = torch.zeros(world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(counts, torch.tensor([rec.shape[0]], dtype=torch.int64, device=device))
+    rows = int(counts.max().item())
+    rec_d = rec.to(device)
+    if rec.shape[0] < rows:
+        pad = torch.full((rows - rec.shape[0],) + tuple(rec.shape[1:]), float("inf"), dtype=rec.dtype, device=device)
+        rec_d = torch.cat([rec_d, pad])
+    rec_d = rec_d.contiguous()
+    out = torch.empty((world * rows,) + tuple(rec.shape[1:]), dtype=rec.dtype, device=device)
     dist.all_gather_into_tensor(out, rec_d)          # concatenation along dim 0 (accepted by RCCL and gloo)
-    return out.view((world,) + tuple(rec.shape))
+    return out.view((world, rows) + tuple(rec.shape[1:]))
+
+
+def concat_query_shards(gathered, n_queries):
+    """Query sharding: rank r holds the rows of shard_range(n_queries, world, r); returns the [n_queries, k, 3] records in
+    query order, dropping the padding rows of the shorter shards."""
+    world = gathered.shape[0]
+    parts = []
+    for r in range(world):
+        lo, hi = shard_range(n_queries, world, r)
+        parts.append(gathered[r, : hi - lo])
+    return torch.cat(parts)
 
 
 def merge_topk(gathered, k=TOPK):

@@ -100,6 +100,8 @@ const char* dmnd_last_error(void);
 /* Fills params with the reference's defaults: BLOSUM62, gap open 11 / extend 1
  * (ScoreMatrix ctor, src/stats/score_matrix.cpp:49-72), max_evalue 0.001. */
 int dmnd_default_params(dmnd_params* params);
+/* Number of usable gfx950 devices (0 if none / HIP not available): what `--gpus N` is checked against. */
+int dmnd_device_count(void);
 /* device < 0: use the current HIP device. Fails (NULL) when no gfx950 device is present. */
 dmnd_ctx* dmnd_create(int device, const dmnd_params* params);
 void dmnd_destroy(dmnd_ctx* ctx);

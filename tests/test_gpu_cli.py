@@ -327,3 +327,34 @@ def test_cli_output_fields_and_pairwise_match_reference(tmp_path, mode):
                 raise AssertionError("%s %s line %d: %s" % (mode, name, k, bad[:4]))
             raise AssertionError("%s %s: first difference at line %d of %d/%d:\n%r\n%r" % (mode, name, k, len(w), len(g2), w[k:k + 2], g2[k:k + 2]))
     assert "X" in "".join(l.split("\t")[9] for l in open(tmp_path / "ref_fields")) or mode == "blastx"
+
+
+def test_cli_gpus_distributes_reference_blocks(tmp_path):
+    """`--gpus 2`: the reference blocks go to two host threads with a context each (here both on the one GPU of the box,
+    DMND_CLI_SHARE_GPU=1) and the records are joined as for a -b run. (a) with the -b of the reference's own `blocked` ctest the
+    output is that golden; (b) without -b the database is cut into two blocks: same text as the explicit cut on one GPU, and as
+    the reference run with that -b."""
+    g = os.path.join(ROOT, "tests", "golden", "ref_ctest")
+    env = dict(os.environ, DMND_CLI_SHARE_GPU="1")
+    out = str(tmp_path / "out")
+    r = subprocess.run([CLI, "blastp", "-q", os.path.join(g, "data.faa"), "-d", os.path.join(g, "data.faa"), "-c1", "-b0.00002", "-p4", "--gpus", "2", "-o", out],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert open(out).read() == open(os.path.join(g, "diamond-test-blastp-blocked.out")).read()
+    for fmt in ([], ["-f", "6", "qseqid", "sseqid", "evalue", "cigar", "btop"]):
+        r = subprocess.run([CLI, "blastp", "-q", os.path.join(g, "data.faa"), "-d", os.path.join(g, "data.faa"), "-p4", "--gpus", "2", "-o", out] + fmt,
+                           capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "reference blocks=2" in r.stderr
+        letters = sum(len(l.strip()) for l in open(os.path.join(g, "data.faa")) if not l.startswith(">"))
+        b = "%.12f" % (((letters + 1) // 2 + 0.5) / 1e9)
+        assert int(float(b) * 1e9) == (letters + 1) // 2
+        one = str(tmp_path / "one")
+        _run([CLI, "blastp", "-q", os.path.join(g, "data.faa"), "-d", os.path.join(g, "data.faa"), "-p4", "-b", b, "-o", one] + fmt)
+        assert open(out).read() == open(one).read()
+        if os.path.exists(REF):
+            ref = str(tmp_path / "ref")
+            _run([REF, "blastp", "-q", os.path.join(g, "data.faa"), "-d", os.path.join(g, "data.faa"), "-p4", "-b", b, "-o", ref] + fmt)
+            assert open(ref).read() == open(out).read()
+    r = subprocess.run([CLI, "blastp", "-q", os.path.join(g, "data.faa"), "-d", os.path.join(g, "data.faa"), "--gpus", "64", "-o", out], capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "gfx950 device(s) visible" in r.stderr

@@ -94,3 +94,33 @@ def test_two_rank_database_shard_join_equals_block_join():
     want = hip.join_blocks(np.concatenate(blocks), 25)
     assert ret[0] == ret[1] == want.tobytes()
     assert len(want) > 500
+
+
+def _uneven_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    from diamond_amd import multigpu
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    nq = 101                                                   # 51 + 50 queries
+    lo, hi = multigpu.shard_range(nq, world, rank)
+    q, ev, sc, oid = _records(7, nq, 900)                      # every rank draws the same records and keeps its own queries
+    keep = (q >= lo) & (q < hi)
+    rec = multigpu.topk_records(hi - lo, q[keep] - lo, ev[keep], sc[keep], oid[keep])
+    g = multigpu.gather_records(rec, torch.device("cpu"))
+    ret[rank] = multigpu.concat_query_shards(g, nq).numpy().copy()
+    dist.destroy_process_group()
+
+
+def test_query_shards_of_unequal_size_gather():
+    """101 queries over 2 ranks: the record tensors have 51 and 50 rows; the gather pads, the concatenation trims."""
+    sys.path.insert(0, ROOT)
+    from diamond_amd import multigpu
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_uneven_worker, args=(world, 29523, ret), nprocs=world, join=True)
+    q, ev, sc, oid = _records(7, 101, 900)
+    want = multigpu.topk_records(101, q, ev, sc, oid).numpy()
+    assert ret[0].shape == (101, multigpu.TOPK, 3)
+    assert np.array_equal(ret[0], ret[1]) and np.array_equal(ret[0], want)
