@@ -416,8 +416,9 @@ void order_slots(std::vector<Slot>& v, std::vector<Slot>& tmp, std::vector<uint3
 		return;
 	}
 	const int NB = 1024;
-	count.assign((size_t)33 * NB + 1, 0);
-	auto bucket = [&](const Slot& x) { return (size_t)x.P * NB + (size_t)(NB - 1 - std::min<int64_t>(x.steps >> 4, NB - 1)); };
+	count.assign((size_t)16 * NB + 1, 0);
+	auto cls = [](int P) { int c = 0; while ((1 << c) < P) ++c; return c; };      // P = 1, 2, 4, ... 512
+	auto bucket = [&](const Slot& x) { return (size_t)cls(x.P) * NB + (size_t)(NB - 1 - std::min<int64_t>(x.steps >> 4, NB - 1)); };
 	for (const Slot& x : v) ++count[bucket(x) + 1];
 	for (size_t i = 1; i < count.size(); ++i) count[i] += count[i - 1];
 	tmp.resize(v.size());
@@ -531,7 +532,8 @@ int swipe_impl(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, int64_t
 				|| it.query_off + it.query_len > b.q_len || it.target_off + it.target_len > b.t_len
 				|| (it.cbs_off >= 0 && (!b.cbs || it.cbs_off + it.query_len > b.cbs_len))) { bad_item.store(i); slots[i] = Slot{ (int32_t)i, 1, 0 }; continue; }
 			const int P = band_class(band);
-			if (P > 32 || (kmode == K_STATS_FWD && P > 16)) { bad_band.store(i); slots[i] = Slot{ (int32_t)i, 1, 0 }; continue; }
+			// up to 32 (16 with statistics) one wavefront sweeps the item; wider bands take up to 16 wavefronts (swipe_kernels.hip)
+			if (P > 32 * 16 || (kmode == K_STATS_FWD && P > 16 * 16)) { bad_band.store(i); slots[i] = Slot{ (int32_t)i, 1, 0 }; continue; }
 			const Geom g = make_geom(it.query_len, it.target_len, it.d_begin, it.d_end);
 			slots[i] = Slot{ (int32_t)i, P, n_steps(g) };
 		}

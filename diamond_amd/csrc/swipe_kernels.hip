@@ -17,6 +17,8 @@
 //     HBM arena; a second kernel walks it with one wavefront per item (64 columns per round trip).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdio>
+#include <cstdlib>
 #include "swipe_core.h"
 #include "swipe_kernels.h"
 
@@ -32,17 +34,28 @@ __device__ __forceinline__ int64_t uniform64(int64_t x)
 	return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
-template<int P, bool COORDS, bool TRACE, int STAT = STAT_NONE, bool REV = false>
-__global__ __launch_bounds__(WAVES_PER_BLOCK * 64)
+// MULTI (bands wider than one wavefront's 128 * P diagonals, P at its maximum): the item is swept by all the wavefronts of the
+// workgroup, wavefront w owning the diagonals of the virtual lanes 64 w .. 64 w + 63. The cross-lane shifts continue over the
+// wavefront boundaries through LDS with one workgroup barrier per anti-diagonal step -- slow next to the single-wavefront sweep,
+// and meant for the rare long repeat proteins whose merged band exceeds 4096 (2048 with statistics) diagonals; the reference
+// escalates its row counters the same way (RowCounter, banded_swipe.h:204). The trace row stride is 64 * P * wavefronts, i.e.
+// the item looks like one of band class P * wavefronts to the traceback kernel.
+constexpr int MULTI_MAX_WAVES = 16;
+
+template<int P, bool COORDS, bool TRACE, int STAT = STAT_NONE, bool REV = false, bool MULTI = false>
+__global__ __launch_bounds__(MULTI ? MULTI_MAX_WAVES * 64 : WAVES_PER_BLOCK * 64)
 void banded_swipe_kernel(SwipeArgs args)
 {
 	__shared__ int8_t matrix[32 * 32];
+	__shared__ int edge[2][3][MULTI ? MULTI_MAX_WAVES : 1];
+	__shared__ int red[MULTI ? MULTI_MAX_WAVES : 1][5];
 	for (int x = threadIdx.x; x < 32 * 32 / 4; x += blockDim.x)
 		reinterpret_cast<int32_t*>(matrix)[x] = reinterpret_cast<const int32_t*>(args.matrix)[x];
 	__syncthreads();
 
-	const int lane = threadIdx.x & 63;
-	const int64_t slot = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+	const int wave = threadIdx.x >> 6, n_waves = MULTI ? (int)(blockDim.x >> 6) : 1;
+	const int lane = MULTI ? (int)threadIdx.x : (int)(threadIdx.x & 63);          // MULTI: the virtual lane, 0 .. 64 * n_waves - 1
+	const int64_t slot = MULTI ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
 	if (slot >= args.n)
 		return;
 	const int32_t item_idx = args.order[slot];
@@ -53,7 +66,6 @@ void banded_swipe_kernel(SwipeArgs args)
 	SeqView v{ args.qblock + q_off, args.tblock + t_off, c_off >= 0 ? args.cbs + c_off : nullptr, matrix };
 	if (REV) { v.rev_q = it.query_len - 1; v.rev_t = it.target_len - 1; }
 	const int go = args.gap_open + args.gap_extend, ge = args.gap_extend;
-
 	int bs, bi, bj, ba = 0, bb = 0;
 	if constexpr (STAT == STAT_NONE) {
 		// register-window sweep (swipe_core.h): per step pair one query letter, one bias byte and one target letter are
@@ -64,16 +76,26 @@ void banded_swipe_kernel(SwipeArgs args)
 		uint8_t* row = nullptr;
 		if (TRACE)
 			row = args.trace + args.trace_off[slot] + lane * P;
-		constexpr int W = 64 * P;
+		const int W = 64 * P * n_waves;
 		const bool has_cbs = v.cbs != nullptr;
 		for (int a = g.a_first; a <= g.a_last; a += 2) {
 			const uint32_t xi = (uint32_t)clampi(st.iq, g.qlen - 1), xj = (uint32_t)clampi(st.jt, g.tlen - 1);
 			const int nq = v.q[xi], nt = v.t[xj], nc = has_cbs ? v.cbs[xi] : 0;      // consumed by win_advance at the end of the pair
 			int nb = wave_shr1(st.F[2 * P - 1]);
+			if (MULTI) {
+				if ((threadIdx.x & 63) == 63) edge[0][0][wave] = st.F[2 * P - 1];
+				__syncthreads();
+				if ((threadIdx.x & 63) == 0 && wave > 0) nb = edge[0][0][wave - 1];
+			}
 			win_step<P, COORDS, TRACE, 0>(st, matrix, nb, go, ge, a, d0, row);
 			if (TRACE) row += W;
 			// the odd step may lie past a_last: all its cells are then invalid, and its trace row is allocated
 			nb = wave_shl1(st.E[0]);
+			if (MULTI) {
+				if ((threadIdx.x & 63) == 0) edge[1][0][wave] = st.E[0];
+				__syncthreads();
+				if ((threadIdx.x & 63) == 63 && wave + 1 < n_waves) nb = edge[1][0][wave + 1];
+			}
 			win_step<P, COORDS, TRACE, 1>(st, matrix, nb, go, ge, a + 1, d0, row);
 			if (TRACE) row += W;
 			win_advance(st, nq, nc, nt);
@@ -86,8 +108,18 @@ void banded_swipe_kernel(SwipeArgs args)
 		st.init(g, lane);
 		for (int a = g.a_first; a <= g.a_last; a += 2) {
 			int nb = wave_shr1(st.F[2 * P - 1]), na = wave_shr1(st.st.Fa[2 * P - 1]), nbb = wave_shr1(st.st.Fb[2 * P - 1]);
+			if (MULTI) {
+				if ((threadIdx.x & 63) == 63) { edge[0][0][wave] = st.F[2 * P - 1]; edge[0][1][wave] = st.st.Fa[2 * P - 1]; edge[0][2][wave] = st.st.Fb[2 * P - 1]; }
+				__syncthreads();
+				if ((threadIdx.x & 63) == 0 && wave > 0) { nb = edge[0][0][wave - 1]; na = edge[0][1][wave - 1]; nbb = edge[0][2][wave - 1]; }
+			}
 			lane_step<P, COORDS, false, 0, STAT>(st, g, v, lane, a, nb, go, ge, nullptr, na, nbb);
 			nb = wave_shl1(st.E[0]); na = wave_shl1(st.st.Ea[0]); nbb = wave_shl1(st.st.Eb[0]);
+			if (MULTI) {
+				if ((threadIdx.x & 63) == 0) { edge[1][0][wave] = st.E[0]; edge[1][1][wave] = st.st.Ea[0]; edge[1][2][wave] = st.st.Eb[0]; }
+				__syncthreads();
+				if ((threadIdx.x & 63) == 63 && wave + 1 < n_waves) { nb = edge[1][0][wave + 1]; na = edge[1][1][wave + 1]; nbb = edge[1][2][wave + 1]; }
+			}
 			lane_step<P, COORDS, false, 1, STAT>(st, g, v, lane, a + 1, nb, go, ge, nullptr, na, nbb);
 		}
 		bs = st.best; bi = st.best_i; bj = st.best_j; ba = st.best_a; bb = st.best_b;
@@ -101,7 +133,16 @@ void banded_swipe_kernel(SwipeArgs args)
 		if constexpr (STAT != STAT_NONE) { oa = __shfl_xor(ba, off); ob = __shfl_xor(bb, off); }
 		if (COORDS ? better_end(os, oj, oi, bs, bj, bi) : os > bs) { bs = os; bi = oi; bj = oj; ba = oa; bb = ob; }
 	}
-	if (lane == 0) {
+	if (MULTI) {                                          // ... and over the wavefronts of the item
+		if ((threadIdx.x & 63) == 0) { red[wave][0] = bs; red[wave][1] = bi; red[wave][2] = bj; red[wave][3] = ba; red[wave][4] = bb; }
+		__syncthreads();
+		if (threadIdx.x != 0) return;
+		for (int w = 1; w < n_waves; ++w) {
+			const int os = red[w][0], oi = red[w][1], oj = red[w][2];
+			if (COORDS ? better_end(os, oj, oi, bs, bj, bi) : os > bs) { bs = os; bi = oi; bj = oj; ba = red[w][3]; bb = red[w][4]; }
+		}
+	}
+	if ((threadIdx.x & 63) == 0) {
 		SwipeEnd e;
 		e.score = bs; e.end_i = bi; e.end_j = bj; e.stat_a = ba; e.stat_b = bb; e.pad[0] = e.pad[1] = e.pad[2] = 0;
 		args.ends[item_idx] = e;
@@ -268,15 +309,37 @@ static hipError_t launch_p(int mode, const SwipeArgs& a, hipStream_t stream)
 	return hipGetLastError();
 }
 
+// band classes above the single-wavefront maximum: P = 32 * waves (16 * waves with statistics), waves = 2, 4, 8, 16
+static hipError_t launch_multi(int P, int mode, const SwipeArgs& a, hipStream_t stream)
+{
+	if (a.n == 0) return hipSuccess;
+	const bool stats = mode == K_STATS_FWD || mode == K_STATS_BWD_REV;
+	const int waves = P / (stats ? 16 : 32);
+	if (waves < 2 || waves > MULTI_MAX_WAVES || (waves & (waves - 1))) return hipErrorInvalidValue;
+	const dim3 grid((unsigned)a.n), block((unsigned)waves * 64);
+	if (std::getenv("DMND_TRACE")) std::fprintf(stderr, "banded swipe: %lld item(s) of band class %d on %d wavefronts each (mode %d)\n", (long long)a.n, P, waves, mode);
+	switch (mode) {
+	case K_SCORE: hipLaunchKernelGGL((banded_swipe_kernel<32, false, false, STAT_NONE, false, true>), grid, block, 0, stream, a); break;
+	case K_COORDS: hipLaunchKernelGGL((banded_swipe_kernel<32, true, false, STAT_NONE, false, true>), grid, block, 0, stream, a); break;
+	case K_TRACE: hipLaunchKernelGGL((banded_swipe_kernel<32, true, true, STAT_NONE, false, true>), grid, block, 0, stream, a); break;
+	case K_STATS_FWD: hipLaunchKernelGGL((banded_swipe_kernel<16, true, false, STAT_FWD, false, true>), grid, block, 0, stream, a); break;
+	case K_STATS_BWD_REV: hipLaunchKernelGGL((banded_swipe_kernel<16, true, false, STAT_BWD, true, true>), grid, block, 0, stream, a); break;
+	default: return hipErrorInvalidValue;
+	}
+	return hipGetLastError();
+}
+
 hipError_t launch_banded_swipe(int P, int mode, const SwipeArgs& a, hipStream_t stream)
 {
+	const bool stats = mode == K_STATS_FWD || mode == K_STATS_BWD_REV;
+	if (P > (stats ? 16 : 32)) return launch_multi(P, mode, a, stream);
 	switch (P) {
 	case 1: return launch_p<1>(mode, a, stream);
 	case 2: return launch_p<2>(mode, a, stream);
 	case 4: return launch_p<4>(mode, a, stream);
 	case 8: return launch_p<8>(mode, a, stream);
 	case 16: return launch_p<16>(mode, a, stream);
-	case 32: return launch_p<32>(mode, a, stream);   // statistics variants exist up to P = 16 (band <= 2048) only
+	case 32: return launch_p<32>(mode, a, stream);   // statistics variants exist up to P = 16 per wavefront
 	default: return hipErrorInvalidValue;
 	}
 }

@@ -34,7 +34,9 @@ enum {
 	DMND_E_TRACEBACK = -6   /* "Traceback error." (banded_swipe.h:168) */
 };
 
-#define DMND_MAX_BAND 4096
+/* Widest band of a work item: 65536 diagonals (the reference's 16-bit RowCounter limit is 65535); DMND_SWIPE_STATS: half of it.
+ * Up to 4096 (2048 with statistics) one wavefront sweeps an item, wider bands take up to 16 wavefronts. */
+#define DMND_MAX_BAND 65536
 
 /* which sequence block (reference: Search::Config::query / ::target Blocks, src/run/config.h) */
 enum { DMND_QUERY = 0, DMND_TARGET = 1 };

@@ -358,3 +358,53 @@ def test_cli_gpus_distributes_reference_blocks(tmp_path):
             assert open(ref).read() == open(out).read()
     r = subprocess.run([CLI, "blastp", "-q", os.path.join(g, "data.faa"), "-d", os.path.join(g, "data.faa"), "--gpus", "64", "-o", out], capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and "gfx950 device(s) visible" in r.stderr
+
+
+def test_cli_long_repeat_proteins_with_wide_bands(tmp_path):
+    """Long tandem-repeat proteins: the chains of a pair spread over thousands of diagonals and add_dp_targets merges them into
+    bands wider than one wavefront sweeps (round 1 aborted the block pair with DMND_E_BAND). Whole pipeline against the reference."""
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/diamond not built")
+    rng = np.random.default_rng(8)
+    db, doff, q, qoff = synth.generate(40, members=4, queries=40, seed=9)
+    seqs_t = [db[doff[i]:doff[i + 1]] for i in range(len(doff) - 1)]
+    seqs_q = [q[qoff[i]:qoff[i + 1]] for i in range(len(qoff) - 1)]
+
+    def repeat_protein(unit, n, rate):
+        s = np.tile(unit, n).copy()
+        mut = rng.random(len(s)) < rate
+        s[mut] = rng.integers(0, 20, int(mut.sum()))
+        return s
+
+    for k in range(3):
+        unit = rng.integers(0, 20, 61 + 10 * k).astype(np.int8)
+        seqs_t.append(repeat_protein(unit, 90, 0.15))
+        seqs_t.append(repeat_protein(unit, 70, 0.25))
+        seqs_q.append(repeat_protein(unit, 80, 0.2))
+    # domains in the same order with long unrelated insertions between them in the target: one chain that drifts over
+    # thousands of diagonals
+    for k in range(3):
+        doms = [rng.integers(0, 20, 350).astype(np.int8) for _ in range(5)]
+        seqs_q.append(np.concatenate(doms))
+        parts = []
+        for d in doms:
+            m = d.copy()
+            mut = rng.random(len(m)) < 0.1
+            m[mut] = rng.integers(0, 20, int(mut.sum()))
+            parts += [m, rng.integers(0, 20, 1100 + 150 * k).astype(np.int8)]
+        seqs_t.append(np.concatenate(parts[:-1]))
+    for name, seqs, prefix in (("db.faa", seqs_t, "t"), ("q.faa", seqs_q, "q")):
+        off = np.concatenate([[0], np.cumsum([len(s) for s in seqs])])
+        synth.write_fasta(str(tmp_path / name), prefix, np.concatenate(seqs), off)
+    traces = []
+    for sens in (["--fast"], ["--sensitive"]):
+        args = ["blastp"] + sens + ["-q", str(tmp_path / "q.faa"), "-d", str(tmp_path / "db.faa"), "-p", "4", "--masking", "0"]
+        _run([REF] + args + ["-o", str(tmp_path / "ref.tsv")])
+        r = subprocess.run([CLI] + args + ["-o", str(tmp_path / "hip.tsv")], capture_output=True, text=True, timeout=600, env=dict(os.environ, DMND_TRACE="1"))
+        assert r.returncode == 0, r.stderr[-2000:]
+        traces.append(r.stderr)
+        ref = open(tmp_path / "ref.tsv").read()
+        assert sum(1 for l in ref.splitlines() if int(l.split("\t")[3]) > 3000) >= 3      # the long repeat alignments are reported
+        assert open(tmp_path / "hip.tsv").read() == ref, sens
+    print("\n".join(l for t in traces for l in t.splitlines() if "wavefronts each" in l or "band" in l.lower()))
+    assert any("wavefronts each" in t for t in traces)        # some band was wider than one wavefront sweeps

@@ -109,7 +109,7 @@ def test_misuse_is_reported_not_crashed():
             c.mask_block(hip.QUERY)
         it = np.zeros(1, hip.DP_TARGET_DTYPE)
         it["query_off"], it["target_off"], it["cbs_off"], it["query_len"], it["target_len"] = 256, 256, -1, 50, 50
-        it["d_begin"], it["d_end"] = -5000, 5000                                 # band wider than the kernels support
+        it["d_begin"], it["d_end"] = -40000, 40000                               # band wider than DMND_MAX_BAND (65536)
         with pytest.raises(hip.DiamondHipError, match="Band size"):
             c.banded_swipe(it, hip.SWIPE_SCORE)
         it["d_begin"], it["d_end"] = 10, 10                                      # empty band

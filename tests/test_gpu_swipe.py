@@ -305,3 +305,52 @@ def test_saturated_items_are_rerun_in_32_bits(ctx):
                 assert g[key] == o[key], (key, k)
             assert np.array_equal(_transcript(tr, g), otr)
     assert seen_big
+
+
+def test_bands_wider_than_one_wavefront(ctx):
+    """Merged bands of long repeat proteins: above 4096 diagonals (2048 with statistics) an item is swept by several wavefronts
+    of one workgroup. Tandem-repeat pairs with bands from 2049 to 20000 in every mode against the oracle; they share the batch
+    with ordinary items, which must not be disturbed (round 1 failed the whole batch on the first over-wide band)."""
+    M = hip.matrix_of(ctx.params)
+    rng = np.random.default_rng(77)
+    recs = _random_items(rng, 24, M)
+    unit = rng.integers(0, 20, 37).astype(np.int8)
+    for width, qlen, tlen in ((2049, 2600, 2400), (3000, 1800, 3500), (4096, 4200, 4100), (4097, 4300, 4200), (6000, 5000, 3300),
+                              (9000, 5200, 5100), (20000, 10500, 10200)):
+        q = np.tile(unit, qlen // 37 + 1)[:qlen].copy()
+        t = np.tile(unit, tlen // 37 + 1)[:tlen].copy()
+        for a in (q, t):                                        # diverged copies of the repeat, a few indels
+            mut = rng.random(len(a)) < 0.2
+            a[mut] = rng.integers(0, 20, int(mut.sum()))
+        t = np.concatenate([t[:500], t[517:2000], rng.integers(0, 20, 9).astype(np.int8), t[2000:]])
+        d0 = int(rng.integers(-(len(t) - 1), qlen - width)) if qlen + len(t) - 1 > width else -(len(t) - 1)
+        d0 = max(-(len(t) - 1) - 3, min(d0, -width // 2))       # around the main diagonal
+        cbs = rng.integers(-2, 2, qlen).astype(np.int8)
+        recs.append({"query": q, "cbs": cbs, "targets": [{"seq": t, "d_begin": d0, "d_end": d0 + width}]})
+    qb, tb, cbs, items, meta = pack_records(recs)
+    ctx.upload_block(hip.QUERY, qb)
+    ctx.upload_block(hip.TARGET, tb)
+    ctx.upload_cbs(cbs)
+    res = {mode: ctx.banded_swipe(items, mode) for mode in (hip.SWIPE_SCORE, hip.SWIPE_COORDS, hip.SWIPE_TRACEBACK)}
+    stats, _ = ctx.banded_swipe(items, hip.SWIPE_STATS, 510)
+    n_wide = 0
+    for k, (rec, t) in enumerate(meta):
+        rc, o, otr = orc.banded_swipe(rec["query"], rec["cbs"], t["seq"], t["d_begin"], t["d_end"], M, 11, 1, orc.TRACEBACK)
+        assert rc == 0
+        assert res[hip.SWIPE_SCORE][0][k]["score"] == o["score"], k
+        c = res[hip.SWIPE_COORDS][0][k]
+        assert c["score"] == o["score"]
+        if o["score"] > 0:
+            assert (c["q_end"], c["s_end"]) == (o["q_end"], o["s_end"])
+            g, tr = res[hip.SWIPE_TRACEBACK][0][k], res[hip.SWIPE_TRACEBACK][1]
+            for key in KEYS:
+                assert g[key] == o[key], (key, k)
+            assert np.array_equal(_transcript(tr, g), otr)
+            rc, so = orc.swipe_stats(rec["query"], rec["cbs"], t["seq"], t["d_begin"], t["d_end"], M, 11, 1, 510)
+            assert rc == 0
+            for key in STAT_KEYS:
+                assert stats[k][key] == so[key], (key, k)
+        if t["d_end"] - t["d_begin"] > 2048:
+            n_wide += 1
+            assert o["score"] > 500                              # the repeat pair really aligns
+    assert n_wide == 7
