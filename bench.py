@@ -368,7 +368,7 @@ def main():
         out["roofline"] = {
             "bound": "hbm", "kernel": "seed_stream_fast_kernel (reference block streamed once per shape against the query seed table)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,      # PMC bytes are not collected inside a timed run; profiles/r02_pmc_summary.json holds the rocprofv3 --pmc passes
+            "traffic": None,      # PMC bytes cannot be collected inside a timed run: filled below from the committed rocprofv3 --pmc pass
             "measured_copy_gbs": copy_gbs, "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_unit": 17, "units_per_launch": ref_letters,
             "launches_per_step": seed_params.n_shapes, "kernel_ms": k_ms, "kernel_ms_alone": k_alone,
             "frac_alone": alg_bytes / (k_alone * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -377,6 +377,19 @@ def main():
                     "written and read back) / average launch duration in the timed region. The kernel reads every letter once (design_bytes = 1 B per "
                     "letter) and probes a query-side table instead of materialising reference seed entries; it is bound by one L2 request per reference "
                     "position, not by HBM bytes (DESIGN.md 5)"}
+        # HBM traffic of the dominant kernel per launch: FETCH_SIZE of a separate `rocprofv3 --pmc FETCH_SIZE` pass over this same
+        # command (tools/profile_r02.sh), doubled as MI355X_MICROARCH.md prescribes for gfx950, plus WRITE_SIZE; only quoted for the
+        # configuration and kernel variant it was measured on
+        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_summary_%s.json" % args.config)
+        if world == 1 and args.queries == 10_000 and args.families == 100_000 and os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path))
+            k = [v for name, v in pmc.items() if "seed_stream_fast_kernel" in name]
+            if len(k) == 1 and "FETCH_SIZE_x2_bytes_per_launch" in k[0]:
+                out["roofline"]["traffic"] = k[0]["FETCH_SIZE_x2_bytes_per_launch"] + k[0].get("WRITE_SIZE_bytes_per_launch", 0.0)
+                out["roofline"]["traffic_source"] = "profiles/r02_pmc_summary_%s.json: FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, bytes per launch" % args.config
+        if seed_params.n_shapes > 2:
+            out["roofline"]["note"] += ("; with short seeds (weight < 10) this kernel also runs the Hamming filter of every joined (query, reference) "
+                                        "position pair, so its launch time covers the join AND the stage-1 filter")
         if not args.no_cpu_baseline and world == 1:          # reported on rank 0 at N=1 only
             ref, ref_md5 = cpu_baseline_reference(w, cgroup_cpus())
             if ref is not None:
