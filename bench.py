@@ -50,6 +50,9 @@ CONFIGS = {
     "C2": dict(mode="blastp", sens="fast", flags=["--fast"], what="blastp --fast"),
     "C3": dict(mode="blastp", sens="sensitive", flags=["--sensitive"], what="blastp --sensitive"),
     "C4": dict(mode="blastx", sens="default", flags=[], what="blastx (default sensitivity), 5k reads of ~1 kb, six frames"),
+    # BASELINE config 5: 100k queries x 5M sequences cut into 8 database blocks; N GPUs take 8/N blocks each (one after the other
+    # on a rank), the records of all blocks are joined as the reference joins reference blocks
+    "C5": dict(mode="blastp", sens="fast", flags=["--fast"], what="blastp --fast, database in 8 blocks", blocks=8, queries=100_000, families=500_000),
 }
 
 
@@ -80,14 +83,35 @@ class Workload:
             self.source_lens = np.diff(self.dna_off)
         else:
             self.n_queries = queries
-        # this rank's part of the job
-        self.q_lo, self.q_hi, self.t_lo, self.t_hi = 0, self.n_queries, 0, self.n_db
-        if world > 1 and shard == "db":
-            self.t_lo, self.t_hi = multigpu.shard_range(self.n_db, world, rank)
-        elif world > 1:
+        # this rank's part of the job: its database blocks (one, unless the config names a block count) or its query slice
+        self.q_lo, self.q_hi = 0, self.n_queries
+        n_blocks = max(self.cfg.get("blocks", 1), world) if shard == "db" else 1
+        if world > 1 and shard != "db":
             self.q_lo, self.q_hi = multigpu.shard_range(self.n_queries, world, rank)
-        t_off = self.doff[self.t_lo:self.t_hi + 1] - self.doff[self.t_lo]
-        self.td, self.tl = workload.sequence_set(self.db[self.doff[self.t_lo]:self.doff[self.t_hi]], t_off)
+        self.blocks = []                                     # (first sequence, one past the last, letters, limits) of every block of this rank
+        # cut as the reference cuts reference blocks (SequenceFile::load_seqs: a block ends with the sequence that reaches the
+        # block size), block size = total letters / blocks: the job equals the reference run with that -b
+        lens = np.diff(self.doff)
+        self.block_letters = -(-self.db_letters // n_blocks)
+        cuts, acc = [0], 0
+        if n_blocks > 1:
+            csum = np.cumsum(lens)
+            while cuts[-1] < self.n_db:
+                nxt = int(np.searchsorted(csum, acc + self.block_letters, side="left")) + 1
+                nxt = min(max(nxt, cuts[-1] + 1), self.n_db)
+                cuts.append(nxt)
+                acc = int(csum[nxt - 1])
+        else:
+            cuts.append(self.n_db)
+        n_blocks = len(cuts) - 1
+        assert n_blocks >= world or shard != "db", "fewer database blocks than ranks"
+        for b in range(rank if shard == "db" else 0, n_blocks, world if shard == "db" else 1):
+            lo, hi = cuts[b], cuts[b + 1]
+            t_off = self.doff[lo:hi + 1] - self.doff[lo]
+            td, tl = workload.sequence_set(self.db[self.doff[lo]:self.doff[hi]], t_off)
+            self.blocks.append((lo, hi, td, tl))
+        self.n_blocks_total = n_blocks
+        self.t_lo, self.t_hi, self.td, self.tl = self.blocks[0]
         if self.cfg["mode"] == "blastx":
             off = self.dna_off[self.q_lo:self.q_hi + 1] - self.dna_off[self.q_lo]
             self.qd, self.ql = hip.translated_block(self.dna[self.dna_off[self.q_lo]:self.dna_off[self.q_hi]], off)
@@ -129,6 +153,8 @@ def cpu_baseline_reference(w, cores):
         env = dict(os.environ, DIAMOND_TAP_CELLS=os.path.join(tmp, "cells.json"))
         cmd = [exe, w.cfg["mode"]] + w.cfg["flags"] + ["--algo", "0", "--masking", "0", "--motif-masking", "0", "-q", qfile,
                                                          "-d", os.path.join(tmp, "db"), "-o", os.path.join(tmp, "out.tsv"), "-p", str(cores), "--log"]
+        if w.n_blocks_total > 1:                             # the same block cut as ours (-b in billions of letters; +0.5 letter against rounding)
+            cmd += ["-b", "%.12f" % ((w.block_letters + 0.5) / 1e9)]
         t0 = time.perf_counter()
         r = subprocess.run(cmd, check=True, capture_output=True, text=True, env=env, timeout=3000)
         wall = time.perf_counter() - t0
@@ -158,8 +184,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="C2")
-    ap.add_argument("--queries", type=int, default=10_000)
-    ap.add_argument("--families", type=int, default=100_000)
+    ap.add_argument("--queries", type=int, default=None, help="default: the config's (10000; C5: 100000)")
+    ap.add_argument("--families", type=int, default=None, help="protein families of 10 members in the database (default 100000; C5: 500000)")
     ap.add_argument("--host-threads", type=int, default=8)
     ap.add_argument("--shard", choices=["db", "query"], default="db")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -187,48 +213,68 @@ def main():
     assert world == args.gpus or world == 1
     threads = max(1, args.host_threads)
 
+    if args.queries is None:
+        args.queries = CONFIGS[args.config].get("queries", 10_000)
+    if args.families is None:
+        args.families = CONFIGS[args.config].get("families", 100_000)
     w = Workload(args.config, args.families, args.queries, world, rank, args.shard)
+    NB = len(w.blocks)
     params = hip.default_params()
     params.db_letters = float(w.db_letters)                  # e-values against the WHOLE database, whatever this rank holds
     seed_params, gf_evalue = w.seed_params(params)
 
-    def make_ctx():
+    def make_ctx(b=0):
         c = hip.Context(device=local_rank, params=params)
         c.upload_block(hip.QUERY, w.qd, w.ql)
-        c.upload_block(hip.TARGET, w.td, w.tl)
+        c.upload_block(hip.TARGET, w.blocks[b][2], w.blocks[b][3])
         c.set_query_contexts(w.contexts)
         c.set_gapped_filter(gf_evalue)
         return c
 
     torch.cuda.synchronize()
     t_up = time.perf_counter()
-    ctx = make_ctx()                                        # synchronous H2D of both blocks (pageable host memory)
+    ctxs = [make_ctx(b) for b in range(NB)]                 # synchronous H2D of the blocks (pageable host memory); all stay resident in HBM
     upload_ms = (time.perf_counter() - t_up) * 1e3          # outside the timed region: inputs are resident when a step starts
     pipeline = not args.no_pipeline
-    ctx_seed = make_ctx() if pipeline else ctx
+    ctxs_seed = [make_ctx(b) for b in range(NB)] if pipeline else ctxs
+    ctx, ctx_seed = ctxs[0], ctxs_seed[0]
     state = {"stream_ms": 0.0, "stream_launches": 0}
 
-    def seed_stage():
+    def seed_stage(b=0):
         torch.cuda.set_device(local_rank)
-        hits = ctx_seed.seed_search(seed_params)
-        ms = ctx_seed.seed_kernel_ms()
+        hits = ctxs_seed[b].seed_search(seed_params)
+        ms = ctxs_seed[b].seed_kernel_ms()
         state["stream_ms"] += ms[1]                         # every seed stage that ran since the counters were reset
         state["stream_launches"] += seed_params.n_shapes
         return hits, ms
 
-    def finish(matches):
-        """What happens to a batch's records: database shards are joined over RCCL as the reference joins reference blocks."""
-        if world > 1 and args.shard == "db":
-            return multigpu.db_shard_join(matches, coll_device, target_base=w.t_lo)
-        return matches
+    def finish(parts):
+        """What happens to a batch's records: database blocks are joined as the reference joins reference blocks -- the blocks of
+        this rank with the other ranks' over RCCL."""
+        if world > 1 and args.shard == "db" or NB > 1:
+            mine = []
+            for b, m in enumerate(parts):
+                r = np.ascontiguousarray(m, dtype=hip.MATCH_DTYPE).copy()
+                r["target"] += np.uint32(w.blocks[b][0])
+                mine.append(r)
+            return multigpu.db_shard_join(np.concatenate(mine), coll_device, target_base=0)
+        return parts[0]
 
-    def step(hits_and_ms=None):
-        hits, seed_ms = hits_and_ms if hits_and_ms is not None else seed_stage()
+    def step(prefetched=None):
+        """One batch = all database blocks of this rank, one after the other, then the join."""
         t_b = time.perf_counter()
-        matches, _ = ctx.extend(w.qd, w.td, hits, threads=threads)
+        parts, n_hits, seed_ms, ext_sum = [], 0, None, None
+        for b in range(NB):
+            hits, ms = prefetched[b] if prefetched is not None else seed_stage(b)
+            m, _ = ctxs[b].extend(w.qd, w.blocks[b][2], hits, threads=threads)
+            parts.append(m)
+            n_hits += int(hits.size)
+            seed_ms = list(ms) if seed_ms is None else [x + y for x, y in zip(seed_ms, ms)]
+            e = ctxs[b].extend_stats()
+            ext_sum = dict(e) if ext_sum is None else {k: ext_sum[k] + e[k] for k in e}
         t_c = time.perf_counter()
-        records = finish(matches)
-        state.update(hits=int(hits.size), matches=matches, records=records, seed_ms=seed_ms, ext=ctx.extend_stats(),
+        records = finish(parts)
+        state.update(hits=n_hits, matches=np.concatenate(parts) if NB > 1 else parts[0], records=records, seed_ms=seed_ms, ext=ext_sum,
                      ext_wall_ms=(t_c - t_b) * 1e3, finish_wall_ms=(time.perf_counter() - t_c) * 1e3)
 
     def sync():
@@ -251,23 +297,24 @@ def main():
         for s in range(n_steps):
             t_a = time.perf_counter()
             if pipeline:
-                got = queue.pop(0).result()
-                queue.append(seed_pool.submit(seed_stage))
+                got = [queue.pop(0).result() for _ in range(NB)]
+                for b in range(NB):
+                    queue.append(seed_pool.submit(seed_stage, b))
                 step(got)
             else:
                 step()
             each.append(round((time.perf_counter() - t_a) * 1e3, 2))
         return each, queue
 
-    queue = [seed_pool.submit(seed_stage) for _ in range(PREFETCH)] if pipeline else []
+    queue = [seed_pool.submit(seed_stage, b) for _ in range(PREFETCH) for b in range(NB)] if pipeline else []
     _, queue = run(args.warmup, queue)
     for f in queue:
         f.result()                                           # the first timed steps find their seed hits ready
     sync()
     # hipDeviceSynchronize lets the runtime release the hardware queues of idle streams; re-acquiring them costs the first
     # timed calls milliseconds (a streaming caller never synchronizes the whole device)
-    ctx.touch_streams()
-    ctx_seed.touch_streams()
+    for c in ctxs + (ctxs_seed if pipeline else []):
+        c.touch_streams()
     state["stream_ms"], state["stream_launches"] = 0.0, 0
     t0 = time.perf_counter()
     cpu0 = time.process_time()
@@ -283,7 +330,7 @@ def main():
     serial, alone = [], {}
     for _ in range(3):
         t_s = time.perf_counter()
-        hs = seed_stage()
+        hs = [seed_stage(b) for b in range(NB)]
         t_m = time.perf_counter()
         step(hs)
         serial.append(((time.perf_counter() - t_s) * 1e3, (t_m - t_s) * 1e3))
@@ -335,7 +382,7 @@ def main():
                                    "traceback_kernel_ms": ext["traceback_kernel_ms"]},
             "seed_kernel_ms": dict(zip(["index_queries", "stream_reference", "mask_groups", "pair_filter", "total"], state["seed_ms"])),
             # seed-stage Gletters/s = (L_q + L_r) x shapes / seed-stage seconds (device time of its kernels)
-            "seed_stage_gletters_per_s": (int(w.ql[-1] - w.ql[0]) + int(w.tl[-1] - w.tl[0])) * seed_params.n_shapes / max(state["seed_ms"][4], 1e-9) / 1e6,
+            "seed_stage_gletters_per_s": (NB * int(w.ql[-1] - w.ql[0]) + sum(int(b[3][-1] - b[3][0]) for b in w.blocks)) * seed_params.n_shapes / max(state["seed_ms"][4], 1e-9) / 1e6,
             "pipeline": "seed stages run on a second context (own low-priority stream), up to %d batches ahead of the extension stage" % PREFETCH if pipeline else "off",
             "ms_each_step": each,
             "alone": alone,
@@ -351,7 +398,7 @@ def main():
         # read back) per reference letter, N = L for the reference block. Our formulation never materialises the entries: it needs
         # 1 B per letter (design_bytes). Durations: HIP events around the launches on the seed stream (dmnd_seed_search).
         k_ms = stream_ms / max(stream_launches, 1)
-        ref_letters = int(w.tl[-1] - w.tl[0])
+        ref_letters = sum(int(b[3][-1] - b[3][0]) for b in w.blocks) // NB          # letters of one launch = one database block
         alg_bytes = 17 * ref_letters
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         k_alone = alone["seed_kernel_ms"][1] / seed_params.n_shapes
@@ -381,7 +428,7 @@ def main():
         # command (tools/profile_r02.sh), doubled as MI355X_MICROARCH.md prescribes for gfx950, plus WRITE_SIZE; only quoted for the
         # configuration and kernel variant it was measured on
         pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_summary_%s.json" % args.config)
-        if world == 1 and args.queries == 10_000 and args.families == 100_000 and os.path.exists(pmc_path):
+        if world == 1 and args.queries == 10_000 and args.families == 100_000 and NB == 1 and os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))
             k = [v for name, v in pmc.items() if "seed_stream_fast_kernel" in name]
             if len(k) == 1 and "FETCH_SIZE_x2_bytes_per_launch" in k[0]:
@@ -397,14 +444,13 @@ def main():
                 # parity of THIS run: the records of the last timed step, formatted as the reference's tabular output
                 qids = ["%s%d" % ("r" if w.contexts == 6 else "q", i) for i in range(w.n_queries)]
                 tids = ["t%d" % i for i in range(w.n_db)]
-                text = hip.format_tab(state["matches"], qids, tids, w.source_lens)
+                text = hip.format_tab(state["records"], qids, tids, w.source_lens)
                 ours = hashlib.md5(text.encode()).hexdigest()
                 out["parity_checked"] = ours == ref_md5
                 out["parity"] = {"records_md5": ours, "reference_output_md5": ref_md5, "lines": text.count("\n")}
         print(json.dumps(out))
-    ctx.close()
-    if pipeline:
-        ctx_seed.close()
+    for c in ctxs + (ctxs_seed if pipeline else []):
+        c.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -280,6 +280,8 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	HIP_TRY(hipMemsetAsync(c->seed_keys.p, 0xff, (size_t)S * slots * sizeof(SeedSlot), st));
 	HIP_TRY(launch_seed_qid(c->d_limits[DMND_QUERY].as<int64_t>(), (int64_t)ql.size() - 1, c->qid_of.as<uint32_t>(), st));
 
+	bool fused = seed_stream_can_fuse(sp);
+	if (const char* e = getenv("DMND_SEED_FUSED")) fused = fused && atoi(e) != 0;
 	auto args_for = [&](int sid, int64_t matched_cap, int64_t matched_off) {
 		SeedArgs a;
 		a.params = sp;
@@ -309,6 +311,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		a.e_key = nullptr; a.e_count = c->counters.as<unsigned long long>() + S + 2; a.e_n = 0;
 		a.matrix = c->matrix.as<int8_t>();
 		a.hits = c->seed_hits.as<dmnd_seed_hit>(); a.hit_count = c->counters.as<unsigned long long>() + S; a.hit_cap = 0;
+		a.fused = fused ? 1 : 0;
 		return a;
 	};
 
@@ -322,8 +325,6 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	unsigned long long n_pairs = 0;
 	// Short seeds: one pass per shape -- index, stream with the Hamming filter fused in, mask, stage-2 scoring of the survivors,
 	// deferred pairs. A shape's masks only depend on this and earlier shapes, and so does the left-most rule (t_now).
-	bool fused = seed_stream_can_fuse(sp);
-	if (const char* e = getenv("DMND_SEED_FUSED")) fused = fused && atoi(e) != 0;
 	if (fused) {
 		unsigned long long* ctr = c->counters.as<unsigned long long>();
 		int64_t m_cap = std::max<int64_t>(std::max<int64_t>((int64_t)1 << 22, 4 * nq_pos), (int64_t)std::min(c->matched_loc.cap / sizeof(int64_t), c->matched_slot.cap / sizeof(uint32_t)));

@@ -58,6 +58,7 @@ struct SeedArgs {
 	const int8_t* matrix;                         // 32x32 int8 substitution matrix (HBM) for the stage-2 ungapped window score
 	// output
 	dmnd_seed_hit* hits; unsigned long long* hit_count; int64_t hit_cap;
+	int fused;                                    // short-seed pipeline: seed_lists_kernel decides SLOT_LOWC for every group (the stream needs it)
 };
 
 hipError_t launch_seed_qid(const int64_t* limits, int64_t n_seqs, uint32_t* qid_of, hipStream_t st);

@@ -94,7 +94,8 @@ __global__ void seed_lists_kernel(SeedArgs a, int sid, const uint32_t* sorted_sl
 	a.slots[k].head = e - i == 1 ? qlist[i] : (uint32_t)i;
 	// Search::mask_seeds evaluates the first query position of a joined group (seed_complexity.cpp:97-99) -- the smallest
 	// position here: the sort is stable. Whether that seed is complex does not depend on the join, so it is decided once here.
-	const bool lowc = a.params.seed_encoding == SEED_SPACED && !seed_is_complex(a.params, sid, a.qdata + a.q_begin + qlist[i]);
+	// (only the fused stream needs the answer before the join is known; otherwise seed_mask_kernel asks for the few joined groups)
+	const bool lowc = a.fused && a.params.seed_encoding == SEED_SPACED && !seed_is_complex(a.params, sid, a.qdata + a.q_begin + qlist[i]);
 	a.slots[k].flags = ((uint32_t)(e - i) << 8) | (lowc ? SLOT_LOWC : 0u);
 }
 
@@ -356,8 +357,11 @@ __global__ void seed_mask_kernel(SeedArgs a, int sid)
 	const uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (slot > a.slot_mask) return;
 	const SeedSlot sl = a.slots[slot];
-	if (sl.key == SEED_EMPTY || (sl.flags & (SLOT_JOINED | SLOT_LOWC)) != (SLOT_JOINED | SLOT_LOWC)) return;      // joined and not complex (seed_lists_kernel); a free slot is all ones
+	if (sl.key == SEED_EMPTY || !(sl.flags & SLOT_JOINED)) return;          // a free slot is all ones
 	const uint32_t count = sl.flags >> 8;
+	// Search::mask_seeds evaluates the first query position of the joined group (seed_complexity.cpp:97-99) = the smallest one:
+	// the lists are sorted by position. The fused pipeline has the answer in the slot (seed_lists_kernel).
+	if (a.fused ? !(sl.flags & SLOT_LOWC) : seed_is_complex(a.params, sid, a.qdata + a.q_begin + (count == 1 ? sl.head : a.qlist[sl.head]))) return;
 	a.slots[slot].flags = sl.flags | SLOT_ERASED;
 	const int t = sid * a.params.index_chunks + seed_chunk(a.params, seed_of_key(a.params, sid, sl.key));
 	for (uint32_t i = 0; i < count; ++i) {

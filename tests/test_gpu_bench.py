@@ -1,0 +1,51 @@
+"""-m gpu: bench.py itself, at reduced size: the JSON contract (metric/value/roofline/cpu_baseline on one line), parity_checked
+against the reference binary inside the same run, the multi-block configuration (C5: database blocks processed one after the other
+and joined as the reference joins reference blocks) and the two-rank database-sharded path (both ranks on the one GPU of the box,
+records exchanged over gloo: DMND_BENCH_SHARE_GPU=1)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref", "diamond_tap")
+
+
+def _bench(args, env=None, launcher=None):
+    cmd = (launcher or [sys.executable]) + [os.path.join(ROOT, "bench.py")] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, **(env or {})), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                     # ONE json line
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("cfg", ["C2", "C3", "C4", "C5"])
+def test_bench_line_and_parity_at_reduced_size(cfg):
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/diamond_tap not built")
+    d = _bench(["--config", cfg, "--queries", "1500", "--families", "3000", "--steps", "2", "--warmup", "1"])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["unit"] == "GCUPS" and d["n_gpus"] == 1 and d["steps"] == 2 and d["vs_baseline"] is None and d["value"] > 0
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+    assert d["cpu_baseline"]["kind"] == "reference" and d["cpu_baseline"]["value"] > 0
+    assert d["parity_checked"] is True, d.get("parity")
+    assert d["parity"]["lines"] > 1000
+    if cfg == "C5":
+        assert "8 blocks" in d["config"]["workload"]
+
+
+def test_bench_two_ranks_database_sharded_on_one_gpu():
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29577"]
+    one = _bench(["--queries", "1500", "--families", "3000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    two = _bench(["--gpus", "2", "--queries", "1500", "--families", "3000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                 env={"DMND_BENCH_SHARE_GPU": "1"}, launcher=launcher)
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong"
+    # the same fixed job: same seed hits in total; alignments differ only by the per-block culling of the reference's block join
+    w1, w2 = one["config"]["workload"], two["config"]["workload"]
+    assert w1.split("per step")[1].split("seed hits")[0] == w2.split("per step")[1].split("seed hits")[0]
