@@ -273,9 +273,23 @@ def main():
             e = ctxs[b].extend_stats()
             ext_sum = dict(e) if ext_sum is None else {k: ext_sum[k] + e[k] for k in e}
         t_c = time.perf_counter()
-        records = finish(parts)
-        state.update(hits=n_hits, matches=np.concatenate(parts) if NB > 1 else parts[0], records=records, seed_ms=seed_ms, ext=ext_sum,
-                     ext_wall_ms=(t_c - t_b) * 1e3, finish_wall_ms=(time.perf_counter() - t_c) * 1e3)
+        state.update(hits=n_hits, matches=np.concatenate(parts) if NB > 1 else parts[0], seed_ms=seed_ms, ext=ext_sum, ext_wall_ms=(t_c - t_b) * 1e3)
+
+        def do_finish():
+            torch.cuda.set_device(local_rank)
+            t_f = time.perf_counter()
+            state["records"] = finish(parts)
+            state["finish_wall_ms"] = (time.perf_counter() - t_f) * 1e3
+        if pipeline and (world > 1 or NB > 1):
+            # the exchange + join of this batch's records runs on its own thread while the next batch is extended (the ranks'
+            # finish threads issue their collectives in batch order); every pending join is awaited before the clock stops
+            state.setdefault("finishing", []).append(finish_pool.submit(do_finish))
+        else:
+            do_finish()
+
+    def drain():
+        for f in state.pop("finishing", []):
+            f.result()
 
     def sync():
         torch.cuda.synchronize()
@@ -286,6 +300,7 @@ def main():
     if pipeline:
         import concurrent.futures
         seed_pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
+        finish_pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
 
     PREFETCH = 2        # seed stages in flight or finished ahead of the extension (a bounded prefetch queue, like a data loader's)
 
@@ -310,6 +325,7 @@ def main():
     _, queue = run(args.warmup, queue)
     for f in queue:
         f.result()                                           # the first timed steps find their seed hits ready
+    drain()
     sync()
     # hipDeviceSynchronize lets the runtime release the hardware queues of idle streams; re-acquiring them costs the first
     # timed calls milliseconds (a streaming caller never synchronizes the whole device)
@@ -321,6 +337,7 @@ def main():
     each, queue = run(args.steps, queue)
     for f in queue:
         f.result()
+    drain()
     sync()
     dt = time.perf_counter() - t0
     cpu_ms_per_step = (time.process_time() - cpu0) * 1e3 / args.steps      # CPU time of all threads of this process
@@ -333,6 +350,7 @@ def main():
         hs = [seed_stage(b) for b in range(NB)]
         t_m = time.perf_counter()
         step(hs)
+        drain()
         serial.append(((time.perf_counter() - t_s) * 1e3, (t_m - t_s) * 1e3))
     alone = {"batch_latency_ms": min(x[0] for x in serial), "seed_stage_call_ms": min(x[1] for x in serial),
              "extension_call_ms": state["ext_wall_ms"], "finish_ms": state["finish_wall_ms"], "seed_kernel_ms": list(state["seed_ms"]),

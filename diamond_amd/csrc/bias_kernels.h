@@ -8,7 +8,8 @@ namespace dmnd {
 struct BiasArgs {
 	const int8_t* block;         // query block letters (HBM)
 	const int64_t* limits;       // n_seqs + 1 sequence limits of the block (HBM)
-	int64_t n_seqs;
+	int64_t n_seqs;              // sequences to process
+	const int32_t* ids;          // their block sequence ids (HBM), or NULL = the first n_seqs sequences of the block
 	const int8_t* matrix;        // 32x32 int8 (HBM)
 	float bg[20];                // ScoreMatrix::background_scores as float
 	int window;                  // config.cbs_window

@@ -18,7 +18,8 @@ __global__ __launch_bounds__(256) void hauser_bias_kernel(BiasArgs a)
 		reinterpret_cast<int32_t*>(M)[x] = reinterpret_cast<const int32_t*>(a.matrix)[x];
 	if (threadIdx.x < 20) bg[threadIdx.x] = a.bg[threadIdx.x];
 	__syncthreads();
-	for (int64_t s = blockIdx.x; s < a.n_seqs; s += gridDim.x) {
+	for (int64_t k = blockIdx.x; k < a.n_seqs; k += gridDim.x) {
+		const int64_t s = a.ids ? a.ids[k] : k;
 		const int64_t begin = a.limits[s];
 		const int l = (int)(a.limits[s + 1] - begin - 1);
 		const int8_t* seq = a.block + begin;

@@ -75,7 +75,8 @@ struct dmnd_ctx {
 	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
 	dmnd_params params;
 	dmnd::Evaluer evaluer;
-	dmnd::DevBuf block[2], cbs, matrix;
+	dmnd::DevBuf block[2], cbs, matrix, bias_ids;
+	std::vector<int32_t> h_bias_ids;           // block sequence ids of the queries with seed hits (Hauser bias of one dmnd_extend call)
 	int64_t block_len[2] = { 0, 0 }, cbs_len = 0;
 	std::vector<int64_t> limits[2];
 	// coarse[which][p >> COARSE_SHIFT] = index of the last sequence starting at or before block offset (p >> COARSE_SHIFT) << COARSE_SHIFT:

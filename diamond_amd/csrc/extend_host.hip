@@ -764,8 +764,18 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 			HIP_TRY(hipHostMalloc((void**)&c->pinned_cbs, (size_t)ql.back() + 64, hipHostMallocDefault));
 			c->pinned_cbs_cap = (size_t)ql.back() + 64;
 		}
+		// only the queries that have seed hits (all their contexts): the others never reach a kernel or the host's x-drop stage
+		std::vector<int32_t>& ids = c->h_bias_ids;
+		ids.clear();
+		for (const Range& r : qr) {
+			const uint32_t q = hits[r.b].query / (uint32_t)h.contexts;
+			for (int f = 0; f < h.contexts; ++f) ids.push_back((int32_t)(q * (uint32_t)h.contexts + (uint32_t)f));
+		}
+		if (int rc = c->bias_ids.ensure(std::max<size_t>(ids.size(), 1) * sizeof(int32_t))) return rc;
+		if (!ids.empty()) HIP_TRY(hipMemcpyAsync(c->bias_ids.p, ids.data(), ids.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
 		BiasArgs ba;
-		ba.block = c->block[DMND_QUERY].as<int8_t>(); ba.limits = c->d_limits[DMND_QUERY].as<int64_t>(); ba.n_seqs = (int64_t)ql.size() - 1;
+		ba.block = c->block[DMND_QUERY].as<int8_t>(); ba.limits = c->d_limits[DMND_QUERY].as<int64_t>(); ba.n_seqs = (int64_t)ids.size();
+		ba.ids = c->bias_ids.as<int32_t>();
 		ba.matrix = c->matrix.as<int8_t>(); ba.window = h.cbs_window; ba.out = c->cbs.as<int8_t>();
 		for (int i = 0; i < 20; ++i) ba.bg[i] = (float)h.background_scores[i];
 		HIP_TRY(launch_hauser_bias(ba, c->stream));

@@ -455,7 +455,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	for (int sid = 0; sid < S && sp.seed_encoding == SEED_SPACED; ++sid) {
 		SeedArgs a = args_for(sid, (int64_t)counts[sid], m_off[sid]);
 		tm.start();
-		HIP_TRY(launch_seed_mask(a, sid, st));
+		HIP_TRY(launch_seed_mask(a, sid, st, (int64_t)counts[sid]));
 		c->seed_ms[2] += tm.stop();
 	}
 	if (getenv("DMND_TRACE")) {

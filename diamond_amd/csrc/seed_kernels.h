@@ -72,7 +72,8 @@ hipError_t launch_seed_lists(const SeedArgs& a, int sid, uint32_t* sorted_slot, 
 // every joined pair while the reference letters are at hand, and fills a.survivors; a.matched_* then only serve the deferred pass
 hipError_t launch_seed_stream(const SeedArgs& a, int sid, hipStream_t st, bool fused = false);
 bool seed_stream_can_fuse(const SeedParams& c);
-hipError_t launch_seed_mask(const SeedArgs& a, int sid, hipStream_t st);
+// n_matched >= 0: the number of joined positions in a.matched_* (few of them: the kernel walks that list instead of the table)
+hipError_t launch_seed_mask(const SeedArgs& a, int sid, hipStream_t st, int64_t n_matched = -1);
 hipError_t launch_seed_pairs(const SeedArgs& a, int sid, int64_t n_matched, hipStream_t st);
 hipError_t launch_seed_pairs_tiled(const SeedArgs& a, int sid, int64_t n_matched, hipStream_t st);      // a.matched_* sorted by slot; fills a.survivors
 hipError_t launch_seed_count_pairs(const SeedArgs& a, int64_t n_matched, unsigned long long* out, hipStream_t st);

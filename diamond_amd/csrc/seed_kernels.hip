@@ -371,6 +371,27 @@ __global__ void seed_mask_kernel(SeedArgs a, int sid)
 	}
 }
 
+// The same, driven by the list of joined reference positions instead of a scan over all table slots: with long seeds a block
+// pair joins a few 10^4 positions against 8 M slots. Every joined position of a seed finds the same slot; the first one to set
+// ERASED masks the seed's query positions.
+__global__ void seed_mask_joined_kernel(SeedArgs a, int sid, int64_t n_matched)
+{
+	const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (m >= n_matched) return;
+	const uint32_t slot = a.matched_slot[m];
+	const SeedSlot sl = a.slots[slot];
+	if (sl.flags & SLOT_ERASED) return;
+	const uint32_t count = sl.flags >> 8;
+	if (seed_is_complex(a.params, sid, a.qdata + a.q_begin + (count == 1 ? sl.head : a.qlist[sl.head]))) return;
+	if (atomicOr(&a.slots[slot].flags, (uint32_t)SLOT_ERASED) & SLOT_ERASED) return;
+	const int t = sid * a.params.index_chunks + seed_chunk(a.params, seed_of_key(a.params, sid, sl.key));
+	for (uint32_t i = 0; i < count; ++i) {
+		const uint32_t x = count == 1 ? sl.head : a.qlist[sl.head + i];
+		const uint8_t old = a.mask_time[a.q_begin + x];
+		if (t < old) a.mask_time[a.q_begin + x] = (uint8_t)t;
+	}
+}
+
 // left-most rule + emission of one pair that passed the Hamming and ungapped-score filters
 __device__ __forceinline__ void finish_pair(const SeedArgs& a, int sid, int chunk, int64_t qp, const int8_t* q, const int8_t* s,
 	uint32_t qid, int seed_offset, int query_len, int64_t sloc, int score)
@@ -738,8 +759,13 @@ hipError_t launch_seed_stream(const SeedArgs& a, int sid, hipStream_t st, bool f
 	return hipGetLastError();
 }
 
-hipError_t launch_seed_mask(const SeedArgs& a, int sid, hipStream_t st)
+hipError_t launch_seed_mask(const SeedArgs& a, int sid, hipStream_t st, int64_t n_matched)
 {
+	if (!a.fused && n_matched >= 0 && n_matched * 4 < (int64_t)a.slot_mask) {
+		if (n_matched == 0) return hipSuccess;
+		hipLaunchKernelGGL(seed_mask_joined_kernel, dim3(blocks_for(n_matched, 256)), dim3(256), 0, st, a, sid, n_matched);
+		return hipGetLastError();
+	}
 	hipLaunchKernelGGL(seed_mask_kernel, dim3(blocks_for((int64_t)a.slot_mask + 1, 256)), dim3(256), 0, st, a, sid);
 	return hipGetLastError();
 }
