@@ -275,7 +275,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	if (int rc = c->seed_qlist.ensure((size_t)S * nq_pos * sizeof(uint32_t))) return rc;
 	if (int rc = c->seed_qkeys.ensure((size_t)nq_pos * sizeof(uint32_t))) return rc;
 	HIP_TRY(hipMemsetAsync(c->seed_next.p, 0xff, (size_t)S * nq_pos * sizeof(uint32_t), st));
-	if (int rc = c->counters.ensure((size_t)(S + 4) * sizeof(unsigned long long))) return rc;      // [S] hits, [S+1] deferred pairs, [S+2] collected positions, [S+3] Hamming survivors
+	if (int rc = c->counters.ensure((size_t)(S + 5) * sizeof(unsigned long long))) return rc;      // [S] hits, [S+1] deferred pairs, [S+2] collected positions, [S+3] Hamming survivors, [S+4] scored survivors
 	HIP_TRY(hipMemsetAsync(c->mask_time.p, SEED_NEVER, (size_t)c->block_len[DMND_QUERY] + 256, st));
 	HIP_TRY(hipMemsetAsync(c->seed_keys.p, 0xff, (size_t)S * slots * sizeof(SeedSlot), st));
 	HIP_TRY(launch_seed_qid(c->d_limits[DMND_QUERY].as<int64_t>(), (int64_t)ql.size() - 1, c->qid_of.as<uint32_t>(), st));
@@ -307,6 +307,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		a.matched_cap = matched_cap;
 		a.deferred = nullptr; a.deferred_count = c->counters.as<unsigned long long>() + S + 1; a.deferred_cap = 0;
 		a.survivors = nullptr; a.survivor_count = c->counters.as<unsigned long long>() + S + 3; a.survivor_cap = 0;
+		a.scored = nullptr; a.scored_count = c->counters.as<unsigned long long>() + S + 4;
 		a.need_bits = c->seed_need.as<uint32_t>();
 		a.e_key = nullptr; a.e_count = c->counters.as<unsigned long long>() + S + 2; a.e_n = 0;
 		a.matrix = c->matrix.as<int8_t>();
@@ -334,7 +335,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		int64_t hit_cap = std::max<int64_t>((int64_t)1 << 20, (int64_t)(c->seed_hits.cap / sizeof(dmnd_seed_hit)));
 		if (const char* e = getenv("DMND_SEED_HIT_CAP")) hit_cap = std::max<int64_t>(1, atoll(e));
 		if (int rc = c->seed_hits.ensure((size_t)hit_cap * sizeof(dmnd_seed_hit))) return rc;
-		HIP_TRY(hipMemsetAsync(ctr, 0, (size_t)(S + 4) * sizeof(unsigned long long), st));
+		HIP_TRY(hipMemsetAsync(ctr, 0, (size_t)(S + 5) * sizeof(unsigned long long), st));
 		c->seed_trace.assign((size_t)2 * S, 0);
 		int64_t hits_bound = 0;                              // every survivor gives at most one hit
 		std::vector<unsigned long long> host_ctr((size_t)S + 4);
@@ -387,6 +388,8 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 			a.deferred = c->seed_deferred.as<SeedDeferred>(); a.deferred_cap = (int64_t)ns;
 			HIP_TRY(hipMemsetAsync(a.deferred_count, 0, 2 * sizeof(unsigned long long), st));
 			HIP_TRY(hipMemsetAsync(a.need_bits, 0, (size_t)(slots / 32) * sizeof(uint32_t), st));
+			if (int rc = c->seed_scored.ensure((size_t)ns * sizeof(SeedScored))) return rc;
+			a.scored = c->seed_scored.as<SeedScored>();
 			tm.start();
 			HIP_TRY(launch_seed_post(a, sid, (int64_t)ns, st));
 			c->seed_ms[3] += tm.stop();
@@ -423,7 +426,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	for (int attempt = 0;; ++attempt) {
 		if (int rc = c->matched_slot.ensure((size_t)cap_total * sizeof(uint32_t))) return rc;
 		if (int rc = c->matched_loc.ensure((size_t)cap_total * sizeof(int64_t))) return rc;
-		HIP_TRY(hipMemsetAsync(c->counters.p, 0, (size_t)(S + 4) * sizeof(unsigned long long), st));
+		HIP_TRY(hipMemsetAsync(c->counters.p, 0, (size_t)(S + 5) * sizeof(unsigned long long), st));
 		if (attempt > 0) {
 			HIP_TRY(hipMemsetAsync(c->seed_keys.p, 0xff, (size_t)S * slots * sizeof(SeedSlot), st));
 			HIP_TRY(hipMemsetAsync(c->seed_bitmap.p, 0, bm_total, st));
@@ -513,6 +516,8 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 					surv_cap = (int64_t)ns + 1024;
 				}
 				c->seed_trace[sid] = ns;
+				if (int rc = c->seed_scored.ensure((size_t)std::max<unsigned long long>(ns, 1) * sizeof(SeedScored))) return rc;
+				a.scored = c->seed_scored.as<SeedScored>();
 				HIP_TRY(launch_seed_post(a, sid, (int64_t)ns, st));
 			}
 			else

@@ -233,26 +233,27 @@ DMND_HD uint64_t reduced_match(const SeedParams& c, const int8_t* q, const int8_
 	return m;
 }
 
-// PatternMatcher::hit over the shape masks [0, n_patterns) (util/algo/pattern_matcher.h:23-63)
+// PatternMatcher::hit over the shape masks [0, n_patterns) (util/algo/pattern_matcher.h:23-63): bit i of the result is set iff
+// some pattern has all its care positions set in h >> i, for i < len - min_len + 1. Evaluated for all i at once: bit i of
+// AND_k (h >> pos_k) is exactly "every care position of the pattern is set at offset i" (h carries zeros above its length, as the
+// reference's running h >>= 1 does), so a pattern costs one shift + AND per care position instead of a 32-step scan.
 DMND_HD uint32_t pattern_hit(const SeedParams& c, int n_patterns, uint32_t h, uint32_t len)
 {
 	if (n_patterns == 0) return 0;
-	uint32_t min_len = 32, max_len = 0;
+	uint32_t min_len = 32;
 	for (int i = 0; i < n_patterns; ++i) {
 		const uint32_t l = (uint32_t)c.shape_len[i];          // = 32 - clz(mask): a shape code starts and ends with '1'
 		if (l < min_len) min_len = l;
-		if (l > max_len) max_len = l;
 	}
 	if (len < min_len) return 0;
-	const uint32_t suffix_mask = max_len >= 32 ? 0xffffffffu : ((1u << max_len) - 1), end = len - min_len + 1;
+	const uint32_t end = len - min_len + 1;
 	uint32_t r = 0;
-	for (uint32_t i = 0; i < end && i < 32; ++i) {
-		const uint32_t w = h & suffix_mask;
-		for (int p = 0; p < n_patterns; ++p)
-			if ((w & c.shape_mask[p]) == c.shape_mask[p]) { r |= 1u << i; break; }
-		h >>= 1;
+	for (int p = 0; p < n_patterns; ++p) {
+		uint32_t m = 0xffffffffu;
+		for (int k = 0; k < c.shape_weight[p]; ++k) m &= h >> c.shape_pos[p][k];
+		r |= m;
 	}
-	return r;
+	return end >= 32 ? r : r & ((1u << end) - 1);
 }
 
 DMND_HD bool verify_hit(const SeedParams& c, const int8_t* q, const int8_t* s, bool left, uint32_t match_mask, int sid, bool chunked, int lo, int hi)

@@ -28,6 +28,9 @@ struct SeedDeferred { int64_t sloc; uint32_t slot, x; int32_t score, pad; };
 // A (joined reference position sloc of the seed in `slot`, query position x) pair that passed the Hamming filter
 struct SeedSurvivor { uint32_t slot, x; int64_t sloc; };
 
+// A survivor whose stage-2 ungapped score passed the cutoff: input of the left-most rule (seed_leftmost_kernel)
+struct SeedScored { uint32_t slot, x; int64_t sloc; int32_t score, chunk; };
+
 struct SeedArgs {
 	SeedParams params;
 	const int8_t* qdata; const int8_t* tdata;     // block letters (HBM)
@@ -50,6 +53,7 @@ struct SeedArgs {
 	uint32_t* matched_slot; int64_t* matched_loc; unsigned long long* matched_count; int64_t matched_cap;
 	SeedDeferred* deferred; unsigned long long* deferred_count; int64_t deferred_cap;
 	SeedSurvivor* survivors; unsigned long long* survivor_count; int64_t survivor_cap;
+	SeedScored* scored; unsigned long long* scored_count;      // as many entries as survivors are scored (launch_seed_post)
 	// need_bits: one bit per slot, set for the seeds that have a deferred pair (1 MB for the 10k-query table: the scan over the
 	// joined positions tests it in L2 instead of reading 16-byte slots all over the table); e_key: the joined positions of those
 	// seeds, sorted by (slot, position) for the second pass

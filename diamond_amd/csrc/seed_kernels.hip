@@ -393,10 +393,10 @@ __global__ void seed_mask_joined_kernel(SeedArgs a, int sid, int64_t n_matched)
 }
 
 // left-most rule + emission of one pair that passed the Hamming and ungapped-score filters
-__device__ __forceinline__ void finish_pair(const SeedArgs& a, int sid, int chunk, int64_t qp, const int8_t* q, const int8_t* s,
+__device__ __forceinline__ void finish_pair(const SeedArgs& a, int sid, int chunk, const uint8_t* qmt, const int8_t* q, const int8_t* s,
 	uint32_t qid, int seed_offset, int query_len, int64_t sloc, int score)
 {
-	if (!left_most_pair(a.params, q, a.mask_time + qp, s, seed_offset, sid, chunk, query_len)) return;
+	if (!left_most_pair(a.params, q, qmt, s, seed_offset, sid, chunk, query_len)) return;
 	const unsigned long long idx = atomicAdd(a.hit_count, 1ull);
 	if (idx < (unsigned long long)a.hit_cap) {
 		dmnd_seed_hit h;
@@ -406,11 +406,37 @@ __device__ __forceinline__ void finish_pair(const SeedArgs& a, int sid, int chun
 }
 
 // everything after the Hamming filter for one (joined reference position m, query position x) pair
-__device__ __forceinline__ void post_hamming(const SeedArgs& a, int sid, uint32_t slot, uint32_t slot_flags, int chunk, int64_t sloc, uint32_t x)
+// q / s / qmt: the seed positions of the pair in the blocks and in mask_time[] -- or in staged copies of their surroundings
+// ([-48, +80) letters, [-48, +48) mask times: everything the stage-2 code reads)
+// stage-2 ungapped window score of one pair: -1 = dropped (below the cutoff, or deferred to the second pass), else the score that
+// goes into the hit if the pair also passes the left-most rule
+__device__ __forceinline__ int stage2_score(const SeedArgs& a, uint32_t slot, int64_t sloc, uint32_t x, const int8_t* q, const int8_t* s)
 {
-	const int8_t* s = a.tdata + sloc;
 	const int64_t qp = a.q_begin + x;
-	const int8_t* q = a.qdata + qp;
+	const uint32_t qid = a.qid_of[qp];
+	const int query_len = (int)(a.qlimits[qid + 1] - a.qlimits[qid] - 1);
+	if (!a.params.use_ungapped) return 0xFFFF;
+	const int cutoff = ungapped_cutoff(a.params, query_len);
+	if (!cutoff) return 0xFFFF;
+	const int window = stage2_window(a.params, query_len);
+	int cb, ce;
+	clip_window(q - window, 2 * window, window, cb, ce);
+	const int window_left = window - cb;
+	const int score = ungapped_window_score(a.matrix, q - window_left, s - window_left, ce - cb);
+	if (score > 255) {
+		// saturation depends on the SIMD batch of the reference: second pass (seed_deferred_kernel)
+		const unsigned long long d = atomicAdd(a.deferred_count, 1ull);
+		if (d < (unsigned long long)a.deferred_cap) a.deferred[d] = SeedDeferred{ sloc, slot, x, score, 0 };
+		atomicOr(&a.need_bits[slot >> 5], 1u << (slot & 31));
+		return -1;
+	}
+	return score <= cutoff ? -1 : score;
+}
+
+__device__ __forceinline__ void post_hamming(const SeedArgs& a, int sid, uint32_t slot, uint32_t slot_flags, int chunk, int64_t sloc, uint32_t x,
+	const int8_t* q, const int8_t* s, const uint8_t* qmt)
+{
+	const int64_t qp = a.q_begin + x;
 	const uint32_t qid = a.qid_of[qp];
 	const int seed_offset = (int)(qp - a.qlimits[qid]);
 	int score = 0xFFFF;
@@ -434,7 +460,12 @@ __device__ __forceinline__ void post_hamming(const SeedArgs& a, int sid, uint32_
 			if (score <= cutoff) return;
 		}
 	}
-	finish_pair(a, sid, chunk, qp, q, s, qid, seed_offset, query_len, sloc, score);
+	finish_pair(a, sid, chunk, qmt, q, s, qid, seed_offset, query_len, sloc, score);
+}
+
+__device__ __forceinline__ void post_hamming(const SeedArgs& a, int sid, uint32_t slot, uint32_t slot_flags, int chunk, int64_t sloc, uint32_t x)
+{
+	post_hamming(a, sid, slot, slot_flags, chunk, sloc, x, a.qdata + a.q_begin + x, a.tdata + sloc, a.mask_time + a.q_begin + x);
 }
 
 __device__ __forceinline__ void filter_pair(const SeedArgs& a, int sid, uint32_t slot, uint32_t slot_flags, int chunk, int64_t sloc, uint32_t x)
@@ -574,19 +605,92 @@ __global__ __launch_bounds__(256) void seed_pair_tiled_kernel(SeedArgs a, int si
 	}
 }
 
-// stage-2 scoring, left-most rule and emission for the compact list of pairs that passed the Hamming filter
-__global__ __launch_bounds__(256) void seed_post_kernel(SeedArgs a, int sid, int64_t n_survivors)
+// Stage 2 for the compact list of pairs that passed the Hamming filter, in two kernels: seed_score_kernel computes the ungapped
+// window score of every survivor and compacts those above the cutoff (~10 %) into a second list; seed_leftmost_kernel runs the
+// left-most rule on that list and emits the hits. In one kernel the long left-most code ran for whole wavefronts in which a
+// few lanes were still alive (the same divergence that the survivor list removed from the Hamming filter).
+// The score kernel reads ~100 letters of both sequences one byte at a time with data-dependent bounds: from the blocks that
+// was ~150 L2 requests per survivor; every thread first copies the [-48, +48) surroundings of its pair into LDS with 16-byte
+// loads and the byte-wise code runs on the copies (generic pointers into LDS).
+constexpr int POST_THREADS = 256, POST_BEFORE = 48, POST_LETTERS = 96, POST_STRIDE = 2 * POST_LETTERS + 16;
+__global__ __launch_bounds__(POST_THREADS) void seed_score_kernel(SeedArgs a, int sid, int64_t n_survivors)
 {
+	constexpr unsigned STAGE = POST_THREADS;
 	__shared__ int8_t matrix[32 * 32];
+	__shared__ __attribute__((aligned(16))) int8_t win[POST_THREADS * POST_STRIDE];
+	__shared__ SeedScored stage[STAGE];
+	__shared__ unsigned st_n;
+	__shared__ unsigned long long st_base;
 	for (int i = threadIdx.x; i < 1024; i += blockDim.x) matrix[i] = a.matrix[i];
+	if (threadIdx.x == 0) st_n = 0;
 	__syncthreads();
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n_survivors) return;
 	a.matrix = matrix;                                    // flat pointer into LDS
-	const SeedSurvivor sv = a.survivors[i];
-	const SeedSlot sl = a.slots[sv.slot];
-	if (sl.flags & SLOT_ERASED) return;                  // (the fused stream kernel never lets a pair of a non-complex seed through)
-	post_hamming(a, sid, sv.slot, sl.flags, seed_chunk(a.params, seed_of_key(a.params, sid, sl.key)), sv.sloc, sv.x);
+	if (i < n_survivors) {
+		const SeedSurvivor sv = a.survivors[i];
+		const SeedSlot sl = a.slots[sv.slot];
+		if (!(sl.flags & SLOT_ERASED)) {                  // (the fused stream kernel never lets a pair of a non-complex seed through)
+			const int64_t qp = a.q_begin + sv.x;
+			int score;
+			// windows wider than the staged stretch (--ungapped-window above 48; short translated frames use their whole length): from the blocks
+			if (a.params.query_translated || a.params.ungapped_window > POST_BEFORE) score = stage2_score(a, sv.slot, sv.sloc, sv.x, a.qdata + qp, a.tdata + sv.sloc);
+			else {
+				int8_t* lq = win + (size_t)threadIdx.x * POST_STRIDE;
+				int8_t* ls = lq + POST_LETTERS;
+#pragma unroll
+				for (int k = 0; k < POST_LETTERS / 16; ++k) {
+					uint4 v, w;
+					__builtin_memcpy(&v, a.qdata + qp - POST_BEFORE + 16 * k, 16);
+					__builtin_memcpy(&w, a.tdata + sv.sloc - POST_BEFORE + 16 * k, 16);
+					*reinterpret_cast<uint4*>(lq + 16 * k) = v;
+					*reinterpret_cast<uint4*>(ls + 16 * k) = w;
+				}
+				score = stage2_score(a, sv.slot, sv.sloc, sv.x, lq + POST_BEFORE, ls + POST_BEFORE);
+			}
+			if (score >= 0)
+				stage[atomicAdd(&st_n, 1u)] = SeedScored{ sv.slot, sv.x, sv.sloc, score, seed_chunk(a.params, seed_of_key(a.params, sid, sl.key)) };
+		}
+	}
+	__syncthreads();
+	const unsigned n = st_n;
+	if (n == 0) return;
+	if (threadIdx.x == 0) st_base = atomicAdd(a.scored_count, (unsigned long long)n);
+	__syncthreads();
+	if (threadIdx.x < n) a.scored[st_base + threadIdx.x] = stage[threadIdx.x];
+}
+
+// left-most rule + emission; launched over the upper bound of the list (the number of survivors), the real size is read on the device
+__global__ __launch_bounds__(256) void seed_leftmost_kernel(SeedArgs a, int sid)
+{
+	const int lane = threadIdx.x & 63;
+	const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x, n = *a.scored_count;
+	if ((i & ~63ull) >= n) return;                        // whole wavefront past the end
+	bool keep = false;
+	SeedScored sc{};
+	uint32_t qid = 0;
+	int seed_offset = 0;
+	if (i < n) {
+		sc = a.scored[i];
+		const int64_t qp = a.q_begin + sc.x;
+		qid = a.qid_of[qp];
+		seed_offset = (int)(qp - a.qlimits[qid]);
+		const int query_len = (int)(a.qlimits[qid + 1] - a.qlimits[qid] - 1);
+		keep = left_most_pair(a.params, a.qdata + qp, a.mask_time + qp, a.tdata + sc.sloc, seed_offset, sid, sc.chunk, query_len);
+	}
+	// one atomic on the hit counter per wavefront
+	const unsigned long long mask = __ballot(keep);
+	if (mask == 0) return;
+	unsigned long long base = 0;
+	const int leader = __builtin_ctzll(mask);
+	if (lane == leader) base = atomicAdd(a.hit_count, (unsigned long long)__builtin_popcountll(mask));
+	base = (unsigned long long)__shfl((long long)base, leader);
+	if (!keep) return;
+	const unsigned long long idx = base + (unsigned long long)__builtin_popcountll(mask & ((1ull << lane) - 1));
+	if (idx < (unsigned long long)a.hit_cap) {
+		dmnd_seed_hit h;
+		h.query = qid; h.seed_offset = seed_offset; h.subject = sc.sloc; h.score = sc.score; h.pad = 0;
+		a.hits[idx] = h;
+	}
 }
 
 // copies the joined positions of the seeds that have deferred pairs (need_bits) as sort keys slot << 40 | position.
@@ -664,7 +768,7 @@ __global__ __launch_bounds__(256) void seed_deferred_kernel(SeedArgs a, int sid,
 	const uint32_t qid = a.qid_of[qp];
 	const int query_len = (int)(a.qlimits[qid + 1] - a.qlimits[qid] - 1);
 	if (score <= ungapped_cutoff(a.params, query_len)) return;
-	finish_pair(a, sid, seed_chunk(a.params, seed_of_key(a.params, sid, a.slots[slot].key)), qp, q, s, qid, (int)(qp - a.qlimits[qid]), query_len, sloc, score);
+	finish_pair(a, sid, seed_chunk(a.params, seed_of_key(a.params, sid, a.slots[slot].key)), a.mask_time + qp, q, s, qid, (int)(qp - a.qlimits[qid]), query_len, sloc, score);
 }
 
 // DMND_TRACE: number of (joined reference position, query position) pairs the Hamming filter sees
@@ -794,7 +898,10 @@ hipError_t launch_seed_count_pairs(const SeedArgs& a, int64_t n_matched, unsigne
 hipError_t launch_seed_post(const SeedArgs& a, int sid, int64_t n_survivors, hipStream_t st)
 {
 	if (n_survivors == 0) return hipSuccess;
-	hipLaunchKernelGGL(seed_post_kernel, dim3(blocks_for(n_survivors, 256)), dim3(256), 0, st, a, sid, n_survivors);
+	hipError_t e = hipMemsetAsync(a.scored_count, 0, sizeof(unsigned long long), st);
+	if (e != hipSuccess) return e;
+	hipLaunchKernelGGL(seed_score_kernel, dim3(blocks_for(n_survivors, POST_THREADS)), dim3(POST_THREADS), 0, st, a, sid, n_survivors);
+	hipLaunchKernelGGL(seed_leftmost_kernel, dim3(blocks_for(n_survivors, 256)), dim3(256), 0, st, a, sid);
 	return hipGetLastError();
 }
 
