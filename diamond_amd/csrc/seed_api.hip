@@ -501,14 +501,18 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 				HIP_TRY(sort_matched_by_slot(a.matched_slot, c->seed_slot2.as<uint32_t>(), a.matched_loc, c->seed_loc2.as<int64_t>(), (int64_t)counts[sid], slot_bits,
 					&c->sort_tmp, &c->sort_tmp_bytes, st));
 				a.matched_slot = c->seed_slot2.as<uint32_t>(); a.matched_loc = c->seed_loc2.as<int64_t>();      // also for the deferred pass below
-				int64_t surv_cap = std::max<int64_t>(std::max<int64_t>((int64_t)1 << 22, 2 * (int64_t)counts[sid]), (int64_t)(c->seed_survivors.cap / sizeof(SeedSurvivor)));
+			}
+			// Hamming filter -> survivor list -> stage-2 kernels
+			{
+				int64_t surv_cap = std::max<int64_t>(std::max<int64_t>((int64_t)1 << 20, tiled ? 2 * (int64_t)counts[sid] : (int64_t)counts[sid]), (int64_t)(c->seed_survivors.cap / sizeof(SeedSurvivor)));
 				if (const char* e = getenv("DMND_SEED_SURVIVOR_CAP")) surv_cap = std::max<int64_t>(1, atoll(e));
 				unsigned long long ns = 0;
 				for (int pass = 0;; ++pass) {
 					if (int rc = c->seed_survivors.ensure((size_t)surv_cap * sizeof(SeedSurvivor))) return rc;
 					a.survivors = c->seed_survivors.as<SeedSurvivor>(); a.survivor_cap = surv_cap;
 					HIP_TRY(hipMemsetAsync(a.survivor_count, 0, sizeof(unsigned long long), st));
-					HIP_TRY(launch_seed_pairs_tiled(a, sid, (int64_t)counts[sid], st));
+					if (tiled) HIP_TRY(launch_seed_pairs_tiled(a, sid, (int64_t)counts[sid], st));
+					else HIP_TRY(launch_seed_pairs(a, sid, (int64_t)counts[sid], st));
 					HIP_TRY(hipMemcpyAsync(&ns, a.survivor_count, sizeof(ns), hipMemcpyDeviceToHost, st));
 					HIP_TRY(sync_stream(st));
 					if ((int64_t)ns <= surv_cap) break;
@@ -520,8 +524,6 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 				a.scored = c->seed_scored.as<SeedScored>();
 				HIP_TRY(launch_seed_post(a, sid, (int64_t)ns, st));
 			}
-			else
-				HIP_TRY(launch_seed_pairs(a, sid, (int64_t)counts[sid], st));
 			ms += tm.stop();
 			if (!sp.use_ungapped) continue;
 			// pairs scoring above 255 (rare): resolve the reference's SIMD-batch saturation rule in a second pass

@@ -478,34 +478,56 @@ __device__ __forceinline__ void filter_pair(const SeedArgs& a, int sid, uint32_t
 // list length, which is heavily skewed (a frequent seed has thousands of query positions and thousands of joined reference
 // positions): lists longer than LIGHT are processed by the whole wavefront, 64 query positions at a time, so that no lane
 // runs a 10^4-iteration loop while the rest of the machine idles.
-__global__ void seed_pair_kernel(SeedArgs a, int sid, int64_t n_matched)
+// The pairs that pass go to the survivor list (LDS-staged, one atomic per workgroup) for launch_seed_post -- scoring them in
+// place left most lanes of a wavefront waiting for the few that passed.
+__global__ __launch_bounds__(128) void seed_pair_kernel(SeedArgs a, int sid, int64_t n_matched)
 {
 	constexpr uint32_t LIGHT = 8;
+	constexpr unsigned STAGE = 1024;
+	__shared__ SeedSurvivor stage[STAGE];
+	__shared__ unsigned st_n;
+	__shared__ unsigned long long st_base;
+	if (threadIdx.x == 0) st_n = 0;
+	__syncthreads();
+	auto filter = [&](uint32_t slot, int64_t sloc, uint32_t x) {
+		if (fingerprint_id(a.qdata + a.q_begin + x, a.tdata + sloc) < a.params.hamming_filter_id) return;
+		const unsigned k = atomicAdd(&st_n, 1u);
+		if (k < STAGE) stage[k] = SeedSurvivor{ slot, x, sloc };
+		else {                                            // staging area full: direct append
+			const unsigned long long idx = atomicAdd(a.survivor_count, 1ull);
+			if (idx < (unsigned long long)a.survivor_cap) a.survivors[idx] = SeedSurvivor{ slot, x, sloc };
+		}
+	};
 	const int lane = threadIdx.x & 63;
 	const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	uint32_t slot = 0, head = 0, count = 0, flags = 0;
+	uint32_t slot = 0, head = 0, count = 0;
 	int64_t sloc = 0;
-	int chunk = 0;
 	if (m < n_matched) {
 		slot = a.matched_slot[m];
 		const SeedSlot sl = a.slots[slot];                // key, list start, size and state of the seed in one 16-byte read
 		if (!(sl.flags & SLOT_ERASED)) {
-			head = sl.head; count = sl.flags >> 8; flags = sl.flags;
+			head = sl.head; count = sl.flags >> 8;
 			sloc = a.matched_loc[m];
-			chunk = seed_chunk(a.params, seed_of_key(a.params, sid, sl.key));
 		}
 	}
 	if (count <= LIGHT)
-		for (uint32_t i = 0; i < count; ++i) filter_pair(a, sid, slot, flags, chunk, sloc, count == 1 ? head : a.qlist[head + i]);
+		for (uint32_t i = 0; i < count; ++i) filter(slot, sloc, count == 1 ? head : a.qlist[head + i]);
 	unsigned long long heavy = __ballot(count > LIGHT);
 	while (heavy) {
 		const int src = __builtin_ctzll(heavy);
 		heavy &= heavy - 1;
-		const uint32_t h_slot = (uint32_t)__shfl((int)slot, src), h_head = (uint32_t)__shfl((int)head, src), h_count = (uint32_t)__shfl((int)count, src),
-			h_flags = (uint32_t)__shfl((int)flags, src);
-		const int h_chunk = __shfl(chunk, src);
+		const uint32_t h_slot = (uint32_t)__shfl((int)slot, src), h_head = (uint32_t)__shfl((int)head, src), h_count = (uint32_t)__shfl((int)count, src);
 		const int64_t h_sloc = (int64_t)__shfl((long long)sloc, src);
-		for (uint32_t i = (uint32_t)lane; i < h_count; i += 64) filter_pair(a, sid, h_slot, h_flags, h_chunk, h_sloc, a.qlist[h_head + i]);
+		for (uint32_t i = (uint32_t)lane; i < h_count; i += 64) filter(h_slot, h_sloc, a.qlist[h_head + i]);
+	}
+	__syncthreads();
+	const unsigned n = st_n < STAGE ? st_n : STAGE;
+	if (n == 0) return;
+	if (threadIdx.x == 0) st_base = atomicAdd(a.survivor_count, (unsigned long long)n);
+	__syncthreads();
+	for (unsigned k = threadIdx.x; k < n; k += blockDim.x) {
+		const unsigned long long idx = st_base + k;
+		if (idx < (unsigned long long)a.survivor_cap) a.survivors[idx] = stage[k];
 	}
 }
 
