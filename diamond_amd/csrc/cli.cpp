@@ -241,6 +241,7 @@ struct Options {
 	int algo = -1;                  // --algo: -1 auto (the reference's default), 0 double-indexed, 1 query-indexed
 	std::vector<std::string> outfmt;   // -f / --outfmt: format, then field names
 	int gpus = 1;                   // --gpus: the reference blocks are spread over this many MI355X of the node
+	double top = -1.0;              // --top PERCENT
 };
 
 Options parse(int argc, char** argv)
@@ -270,6 +271,7 @@ Options parse(int argc, char** argv)
 		else if (a == "-k" || a == "--max-target-seqs") o.k = std::atoi(need(i).c_str());
 		else if (a == "-e" || a == "--evalue") o.evalue = std::atof(need(i).c_str());
 		else if (a == "--fast") o.fast = true;
+		else if (a == "--top") { o.top = std::atof(need(i).c_str()); if (o.top < 0.0 || o.top > 100.0) throw std::runtime_error("Invalid value for --top."); }
 		else if (a == "--gpus") { o.gpus = std::atoi(need(i).c_str()); if (o.gpus < 1) throw std::runtime_error("Invalid number of GPUs."); }
 		else if (a == "-b" || a == "--block-size") { o.block_size = std::atof(need(i).c_str()); if (o.block_size <= 0.0) throw std::runtime_error("Invalid block size."); }
 		else if (a == "-c" || a == "--index-chunks") { o.index_chunks = std::atoi(need(i).c_str()); if (o.index_chunks < 1) throw std::runtime_error("Invalid number of index chunks."); }
@@ -438,6 +440,7 @@ int run_blastp(const Options& o)
 		if (!c) throw std::runtime_error(dmnd_last_error());
 		ctxs[(size_t)g] = c;
 		chk(dmnd_set_max_target_seqs(c, o.k));
+		chk(dmnd_set_top_percent(c, o.top));
 		chk(dmnd_set_comp_based_stats(c, o.cbs));
 		chk(dmnd_set_query_contexts(c, blastx ? 6 : 1));
 		chk(dmnd_set_sensitivity(c, sens));
@@ -594,7 +597,8 @@ int run_blastp(const Options& o)
 		}
 		});
 		int64_t n_matches = (int64_t)joined.size();
-		if (t_blocks.size() > 1) chk(dmnd_join_blocks(joined.data(), (int64_t)joined.size(), o.k, &n_matches));
+		if (t_blocks.size() > 1) chk(o.top >= 0.0 ? dmnd_join_blocks_top(joined.data(), (int64_t)joined.size(), o.top, &n_matches)
+			: dmnd_join_blocks(joined.data(), (int64_t)joined.size(), o.k, &n_matches));
 		auto view_of = [&](const dmnd_match& m) {
 			dmnd_hsp_view v;
 			const size_t ctx_id = (size_t)m.query * C + (size_t)m.frame;            // the aligned query context in the file

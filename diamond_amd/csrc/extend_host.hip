@@ -82,6 +82,9 @@ struct HostCfg {
 	double ranking_block_letters = 2e9;
 	bool use_cbs = true;                 // config.comp_based_stats == 1 (Hauser bias); 0 = no composition correction
 	int contexts = 1;                    // align_mode.query_contexts: 1 (blastp) or 6 (blastx: the block holds 6 frames per read)
+	double top = -1.0;                   // config.toppercent (--top): >= 0 = report the targets within this percentage of the best bit score
+	const Evaluer* evaluer = nullptr;    // ScoreMatrix::evalue / bitscore of the context
+	double max_evalue = 0.001;
 };
 
 void make_cfg(const dmnd_ctx* c, HostCfg& h)
@@ -124,9 +127,10 @@ int band_for(int len, bool fast)                            // Extension::band, 
 	return len < 50 ? 15 : len < 100 ? 20 : len < 150 ? 30 : len < 200 ? 50 : len < 250 ? 60 : len < 350 ? 100 : len < 500 ? 120 : 150;
 }
 
-int64_t ranking_chunk_size(double ref_letters, int max_target_seqs, double default_letters)       // extend.cpp:79-92, default options
+int64_t ranking_chunk_size(double ref_letters, int max_target_seqs, double default_letters, bool toppercent)       // extend.cpp:79-92
 {
 	const int64_t block_mult = std::max((int64_t)std::llround(ref_letters / default_letters), (int64_t)1);
+	if (toppercent) return 128 * block_mult;             // MIN_CHUNK_SIZE
 	const int64_t m32 = ((int64_t)max_target_seqs + 31) / 32 * 32;
 	return std::max((int64_t)128, std::min(m32, (int64_t)400)) * block_mult;
 }
@@ -147,7 +151,7 @@ struct QueryWork {
 
 // load_hits (load_hits.h:44-127) + the target ranking of extend() (extend.cpp:403-414)
 void load_query(const HostCfg& h, QueryWork& w, uint32_t query, const dmnd_seed_hit* hb, const dmnd_seed_hit* he, const uint8_t* gf_flags,
-	const int64_t* tl, int64_t nt, const uint32_t* coarse = nullptr)
+	const int64_t* tl, int64_t nt, const uint32_t* coarse = nullptr, int query_len = 0)
 {
 	std::vector<dmnd_seed_hit> hits(hb, he);
 	for (size_t x = 0; x < hits.size(); ++x) hits[x].pad = gf_flags ? gf_flags[x] : 1;      // carried through the sort below
@@ -178,13 +182,18 @@ void load_query(const HostCfg& h, QueryWork& w, uint32_t query, const dmnd_seed_
 	}
 	w.order.resize(w.groups.size());
 	for (size_t i = 0; i < w.order.size(); ++i) w.order[i] = (uint32_t)i;
-	w.chunk_size = ranking_chunk_size(h.ref_letters, h.max_target_seqs, h.ranking_block_letters);
+	w.chunk_size = ranking_chunk_size(h.ref_letters, h.max_target_seqs, h.ranking_block_letters, h.top >= 0.0);
 	if (w.chunk_size < (int64_t)w.groups.size())      // TargetScore::operator<: score desc, target index asc (target.h:146-158)
 		std::sort(w.order.begin(), w.order.end(), [&](uint32_t a, uint32_t b) {
 			return w.groups[a].score > w.groups[b].score || (w.groups[a].score == w.groups[b].score && a < b);
 		});
 	w.i0 = 0;
 	w.i1 = std::min((size_t)w.chunk_size, w.order.size());
+	// a first chunk smaller than -k (k above MAX_CHUNK_SIZE) grows by 16 targets at a time while their seed-hit score would pass
+	// the e-value cutoff against a 50-letter target (extend.cpp:262-268, UNIFIED_TARGET_LEN)
+	if (h.top < 0.0 && (int64_t)(w.i1 - w.i0) < (int64_t)h.max_target_seqs && h.evaluer)
+		while (w.i1 < w.order.size() && h.evaluer->evalue(w.groups[w.order[w.i1]].score, (unsigned)query_len, 50u) <= h.max_evalue)
+			w.i1 += std::min<size_t>(16, w.order.size() - w.i1);
 }
 
 // ungapped_stage + chaining + add_dp_targets for the targets order[g0, g1) of one query (all its contexts)
@@ -350,29 +359,65 @@ bool cand_less(const Cand& a, const Cand& b)                 // Target::comp_eva
 	return a.evalue < b.evalue || (a.evalue == b.evalue && (a.score > b.score || (a.score == b.score && a.target < b.target)));
 }
 
+bool cand_less_score(const Cand& a, const Cand& b)           // Target::comp_score
+{
+	return a.score > b.score || (a.score == b.score && a.target < b.target);
+}
+
 bool match_less(const dmnd_match& a, const dmnd_match& b)    // Match::cmp_evalue, extend.h:51-56
 {
 	return a.evalue < b.evalue || (a.evalue == b.evalue && (a.hsp.score > b.hsp.score || (a.hsp.score == b.hsp.score && a.target < b.target)));
 }
 
-// culling(targets, sort_only, cfg) for first-round targets (culling.cpp:189-193, output_range :97-113)
-void cull(std::vector<Cand>& t, bool sort_only, int k)
+bool match_less_score(const dmnd_match& a, const dmnd_match& b)      // Match::cmp_score
 {
-	std::sort(t.begin(), t.end(), cand_less);
-	if (!sort_only && (int)t.size() > k) t.resize((size_t)k);
+	return a.hsp.score > b.hsp.score || (a.hsp.score == b.hsp.score && a.target < b.target);
+}
+
+// what is reported of a sorted list (output_range, culling.cpp:97-113): the first -k entries, or with --top the entries whose bit
+// score is within the percentage of the best one
+struct CullCfg { int k; double top; const Evaluer* ev; };
+
+template<typename Score>
+size_t output_range(size_t n, const CullCfg& cc, Score score_at)
+{
+	if (n == 0) return 0;
+	if (cc.top < 0.0) return std::min(n, (size_t)cc.k);
+	const double cutoff = std::max((1.0 - cc.top / 100.0) * cc.ev->bitscore(score_at(0)), 1.0);      // top_cutoff_score<double>
+	size_t i = 0;
+	while (i < n && cc.ev->bitscore(score_at(i)) >= cutoff) ++i;
+	return i;
+}
+
+// culling(targets, sort_only, cfg) for first-round targets (culling.cpp:189-193)
+void cull(std::vector<Cand>& t, bool sort_only, const CullCfg& cc)
+{
+	std::sort(t.begin(), t.end(), cc.top >= 0.0 ? cand_less_score : cand_less);
+	if (!sort_only) t.resize(output_range(t.size(), cc, [&](size_t i) { return t[i].score; }));
+}
+
+void cull(std::vector<dmnd_match>& t, const CullCfg& cc)      // culling(matches, cfg), culling.cpp:199-202
+{
+	std::sort(t.begin(), t.end(), cc.top >= 0.0 ? match_less_score : match_less);
+	t.resize(output_range(t.size(), cc, [&](size_t i) { return t[i].hsp.score; }));
 }
 
 // append_hits(targets, begin, end, with_culling = true, cfg), culling.cpp:115-145
-bool append_hits(std::vector<Cand>& targets, const std::vector<Cand>& v, int k)
+bool append_hits(std::vector<Cand>& targets, const std::vector<Cand>& v, const CullCfg& cc)
 {
 	if (v.empty()) return false;
-	bool new_hits = (int)targets.size() < k;
+	bool new_hits = cc.top < 0.0 && (int)targets.size() < cc.k;
 	bool append = new_hits;
-	cull(targets, append, k);
+	cull(targets, append, cc);
 	double min_evalue = DBL_MAX;
-	for (const Cand& c : v) min_evalue = std::min(min_evalue, c.evalue);
-	const size_t range_end = std::min(targets.size(), (size_t)k);
-	if (targets.empty() || min_evalue <= targets[range_end - 1].evalue) { append = true; new_hits = true; }
+	int max_score = 0;
+	for (const Cand& c : v) { min_evalue = std::min(min_evalue, c.evalue); max_score = std::max(max_score, c.score); }
+	const size_t range_end = output_range(targets.size(), cc, [&](size_t i) { return targets[i].score; });
+	if (targets.empty()
+		|| (cc.top < 0.0 && min_evalue <= targets[range_end - 1].evalue)
+		|| (cc.top >= 0.0 && max_score >= (int)((1.0 - cc.top / 100.0) * targets[range_end - 1].score))) {      // top_cutoff_score<int>
+		append = true; new_hits = true;
+	}
 	if (append) targets.insert(targets.end(), v.begin(), v.end());
 	return new_hits;
 }
@@ -407,6 +452,7 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 	const std::vector<int64_t>& tl = c->limits[DMND_TARGET];
 	const uint32_t C = (uint32_t)h.contexts;
 	const int K = h.max_target_seqs;
+	const CullCfg cc{ K, h.top, &c->evaluer };
 	for (int i = 0; i < 12; ++i) if (i != 4 || w != c) w->ext_stats[i] = 0;      // [4] (bias + upload) of the caller's prelude is kept
 	for (double& x : w->host_ms) x = 0;
 	auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -438,7 +484,9 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 	parallel_each(T, [&](int t) {
 		for (size_t i = slice_begin(t); i < slice_begin(t + 1); ++i) {
 			const Range& r = qr[qr_begin + i];
-			load_query(h, qs[i].w, hits[r.b].query / (uint32_t)h.contexts, hits + r.b, hits + r.e, gf.empty() ? nullptr : gf.data() + r.b, tl.data(), (int64_t)tl.size() - 1, coarse);
+			const uint32_t q0 = hits[r.b].query / (uint32_t)h.contexts * (uint32_t)h.contexts;       // first context of the query
+			load_query(h, qs[i].w, hits[r.b].query / (uint32_t)h.contexts, hits + r.b, hits + r.e, gf.empty() ? nullptr : gf.data() + r.b, tl.data(), (int64_t)tl.size() - 1, coarse,
+				(int)(ql[q0 + 1] - ql[q0] - 1));
 			if (qs[i].w.order.empty()) qs[i].done = true;
 		}
 	});
@@ -544,7 +592,7 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 					}
 					const bool multi_chunk = (s.w.i1 - s.w.i0) < s.w.order.size();
 					bool new_hits = s.new_hits_ev = !v.empty();
-					if (multi_chunk) new_hits = append_hits(s.aligned, v, K);
+					if (multi_chunk) new_hits = append_hits(s.aligned, v, cc);
 					else s.aligned = v;
 					// advance the chunk window (extend.cpp:325-329)
 					s.w.i0 = s.w.i1;
@@ -571,7 +619,7 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 				QueryState& s = qs[i];
 				if (s.done || s.in_inner) continue;
 				me.any = true;
-				cull(s.aligned, false, K);                                          // extend.cpp:331
+				cull(s.aligned, false, cc);                                         // extend.cpp:331
 				r2[i].assign(s.aligned.size(), dmnd_hsp());
 				for (size_t k = 0; k < s.aligned.size(); ++k) {
 					const Cand& cd = s.aligned[k];
@@ -653,12 +701,11 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 					m.ungapped_score = cd.ungapped; m.d_begin = cd.d_begin; m.d_end = cd.d_end; m.frame = cd.frame; m.hsp = hsp;
 					round.push_back(m);
 				}
-				std::sort(round.begin(), round.end(), match_less);
-				if ((int)round.size() > K) round.resize((size_t)K);
+				cull(round, cc);
 				s.matches.insert(s.matches.end(), round.begin(), round.end());
 				s.aligned.clear();
 				// outer loop condition (extend.cpp:336)
-				if ((int)s.matches.size() < K && s.w.i0 < s.w.order.size() && s.new_hits_ev) s.in_inner = true;
+				if (h.top < 0.0 && (int)s.matches.size() < K && s.w.i0 < s.w.order.size() && s.new_hits_ev) s.in_inner = true;
 				else s.done = true;
 			}
 		});
@@ -674,8 +721,7 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 		me.n_matches = 0;
 		for (size_t i = slice_begin(t); i < slice_begin(t + 1); ++i) {
 			QueryState& s = qs[i];
-			std::sort(s.matches.begin(), s.matches.end(), match_less);
-			if ((int)s.matches.size() > K) s.matches.resize((size_t)K);
+			cull(s.matches, cc);
 			me.n_matches += s.matches.size();
 		}
 	});
@@ -730,6 +776,9 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	HostCfg h;
 	make_cfg(c, h);
 	h.max_target_seqs = c->max_target_seqs;
+	h.top = c->top_percent;
+	h.evaluer = &c->evaluer;
+	h.max_evalue = c->params.max_evalue;
 	h.ranking_block_letters = c->ranking_block_letters;
 	h.band_mode_fast = c->band_mode_fast;
 	h.contexts = c->query_contexts;
@@ -900,6 +949,32 @@ extern "C" int dmnd_set_max_target_seqs(dmnd_ctx* c, int k)
 // join_query over the records of several reference blocks (output/join_blocks.cpp:180-256): every block's list of a query is
 // already in match_less order, so the reference's heap merge by JoinRecord::cmp_evalue (join_blocks.cpp:129-142) is the sort of
 // the union by (e-value, score descending, target ordinal); GlobalCulling keeps the first max_target_seqs (target_culling.h:70-88).
+extern "C" int dmnd_set_top_percent(dmnd_ctx* c, double percent)
+{
+	if (!c || percent > 100.0) return fail(DMND_E_ARG, "dmnd_set_top_percent: bad argument");
+	c->top_percent = percent < 0.0 ? -1.0 : percent;
+	return DMND_OK;
+}
+
+// join_query with --top: the heap merge runs on JoinRecord::cmp_score (score descending, target ordinal ascending) and GlobalCulling
+// keeps a target while (1 - bit score / best bit score) * 100 <= toppercent (output/target_culling.h:62-63)
+extern "C" int dmnd_join_blocks_top(dmnd_match* r, int64_t n, double top_percent, int64_t* n_out)
+{
+	if (!r || n < 0 || top_percent < 0.0 || !n_out) return fail(DMND_E_ARG, "dmnd_join_blocks_top: bad argument");
+	std::stable_sort(r, r + n, [](const dmnd_match& a, const dmnd_match& b) { return a.query < b.query || (a.query == b.query && match_less_score(a, b)); });
+	int64_t w = 0;
+	double top_score = 0.0;
+	bool finished = false;
+	for (int64_t i = 0; i < n; ++i) {
+		if (i == 0 || r[i].query != r[i - 1].query) { top_score = r[i].bit_score; finished = false; }
+		if (finished) continue;
+		if ((1.0 - r[i].bit_score / top_score) * 100.0 <= top_percent) { if (w != i) r[w] = r[i]; ++w; }
+		else finished = true;
+	}
+	*n_out = w;
+	return DMND_OK;
+}
+
 extern "C" int dmnd_join_blocks(dmnd_match* r, int64_t n, int max_target_seqs, int64_t* n_out)
 {
 	if (!r || n < 0 || max_target_seqs < 1 || !n_out) return fail(DMND_E_ARG, "dmnd_join_blocks: bad argument");

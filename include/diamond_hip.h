@@ -326,6 +326,12 @@ int dmnd_set_comp_based_stats(dmnd_ctx* ctx, int mode);
  * --sensitive, BANDED_SLOW from --more-sensitive up: src/align/extend.cpp:62-75, gapped_score.cpp:41-73), and ranking_chunk_size's
  * unit of reference-block letters (2e9, or 8e8 from --very-sensitive up: extend.cpp:79-92). */
 int dmnd_set_sensitivity(dmnd_ctx* ctx, int sensitivity);
+/* --top PERCENT (config.toppercent): report the targets whose bit score is within PERCENT of the best one instead of the first
+ * -k ones (output_range / append_hits / ranking_chunk_size with toppercent, align/culling.cpp:97-145, align/extend.cpp:88-89,336);
+ * percent < 0 switches it off. dmnd_join_blocks_top is the block join for such a run (JoinRecord::cmp_score + GlobalCulling,
+ * output/join_blocks.cpp:133-136, output/target_culling.h:62-63). */
+int dmnd_set_top_percent(dmnd_ctx* ctx, double percent);
+int dmnd_join_blocks_top(dmnd_match* records, int64_t n, double top_percent, int64_t* n_out);
 /* -k / --max-target-seqs (default 25, src/basic/config.h:55) */
 int dmnd_set_max_target_seqs(dmnd_ctx* ctx, int k);
 /* Multi-block databases (-b / --block-size): the records of one query block against several reference

@@ -195,6 +195,7 @@ CTEST = [
     ("comp-based-stats-0", ["--more-sensitive", "-c1", "-p4", "--comp-based-stats", "0"]),
     ("target-seqs", ["-k3", "-c1", "-p4"]),
     ("evalue", ["-e10000", "--more-sensitive", "-c1", "-p4"]),
+    ("top", ["--top", "10", "-p4"]),
     ("pairwise-format", ["-c1", "-f0", "-p4"]),
     ("paf-format", ["-c1", "-f", "paf", "-p1"]),
 ]
@@ -408,3 +409,20 @@ def test_cli_long_repeat_proteins_with_wide_bands(tmp_path):
         assert open(tmp_path / "hip.tsv").read() == ref, sens
     print("\n".join(l for t in traces for l in t.splitlines() if "wavefronts each" in l or "band" in l.lower()))
     assert any("wavefronts each" in t for t in traces)        # some band was wider than one wavefront sweeps
+
+
+def test_cli_top_percent_and_large_k_match_reference(tmp_path):
+    """--top N (bit-score window instead of -k, also over several reference blocks) and -k above MAX_CHUNK_SIZE (the first ranking
+    chunk grows by the seed-hit e-value rule, extend.cpp:262-268) against the reference binary."""
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/diamond not built")
+    db, doff, q, qoff = synth.generate(60, members=30, queries=120, seed=17)          # large families: many targets per query
+    synth.write_fasta(str(tmp_path / "db.faa"), "t", db, doff)
+    synth.write_fasta(str(tmp_path / "q.faa"), "q", q, qoff)
+    base = ["blastp", "-q", str(tmp_path / "q.faa"), "-d", str(tmp_path / "db.faa"), "-p", "4"]
+    for extra in (["--top", "5"], ["--top", "30", "--fast"], ["--top", "50", "-b0.0002", "-c1"], ["-k", "500", "--sensitive"], ["-k", "450", "-e", "10"]):
+        _run([REF] + base + extra + ["-o", str(tmp_path / "ref.tsv")])
+        _run([CLI] + base + extra + ["-o", str(tmp_path / "hip.tsv")])
+        ref = open(tmp_path / "ref.tsv").read()
+        assert len(ref.splitlines()) > 100, extra
+        assert open(tmp_path / "hip.tsv").read() == ref, extra
