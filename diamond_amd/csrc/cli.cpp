@@ -242,6 +242,7 @@ struct Options {
 	std::vector<std::string> outfmt;   // -f / --outfmt: format, then field names
 	int gpus = 1;                   // --gpus: the reference blocks are spread over this many MI355X of the node
 	double top = -1.0;              // --top PERCENT
+	double min_id = 0, query_cover = 0, subject_cover = 0, min_score = 0;      // --id, --query-cover, --subject-cover, --min-score
 };
 
 Options parse(int argc, char** argv)
@@ -271,6 +272,10 @@ Options parse(int argc, char** argv)
 		else if (a == "-k" || a == "--max-target-seqs") o.k = std::atoi(need(i).c_str());
 		else if (a == "-e" || a == "--evalue") o.evalue = std::atof(need(i).c_str());
 		else if (a == "--fast") o.fast = true;
+		else if (a == "--id") o.min_id = std::atof(need(i).c_str());
+		else if (a == "--query-cover") o.query_cover = std::atof(need(i).c_str());
+		else if (a == "--subject-cover") o.subject_cover = std::atof(need(i).c_str());
+		else if (a == "--min-score") o.min_score = std::atof(need(i).c_str());
 		else if (a == "--top") { o.top = std::atof(need(i).c_str()); if (o.top < 0.0 || o.top > 100.0) throw std::runtime_error("Invalid value for --top."); }
 		else if (a == "--gpus") { o.gpus = std::atoi(need(i).c_str()); if (o.gpus < 1) throw std::runtime_error("Invalid number of GPUs."); }
 		else if (a == "-b" || a == "--block-size") { o.block_size = std::atof(need(i).c_str()); if (o.block_size <= 0.0) throw std::runtime_error("Invalid block size."); }
@@ -341,6 +346,10 @@ int run_blastp(const Options& o)
 	if (!tantan && o.masking != "0" && o.masking != "none")
 		throw std::runtime_error("Only --masking tantan (default) and --masking 0 are implemented.");
 	if (!o.motif_masking.empty() && o.motif_masking != "0" && o.motif_masking != "1") throw std::runtime_error("Permitted values for --motif-masking: 0, 1");
+	// equal query and subject cover of 50 % and more switches the reference to its mutual-coverage search (length-sorted blocks, a
+	// length-ratio cutoff inside the seed stage: run/config.cpp:156-159) -- a clustering path that is not part of this build
+	if (o.command == "blastp" && o.query_cover >= 50 && o.query_cover == o.subject_cover)
+		throw std::runtime_error("--query-cover equal to --subject-cover (>= 50) selects the reference's mutual-coverage search, which is not part of this build; use different values");
 	const auto t_all = std::chrono::steady_clock::now();
 	SeqBlock q_all, t_all_seqs;
 	const bool blastx = o.command == "blastx";
@@ -441,6 +450,7 @@ int run_blastp(const Options& o)
 		ctxs[(size_t)g] = c;
 		chk(dmnd_set_max_target_seqs(c, o.k));
 		chk(dmnd_set_top_percent(c, o.top));
+		chk(dmnd_set_filters(c, o.min_id, o.query_cover, o.subject_cover, o.min_score));
 		chk(dmnd_set_comp_based_stats(c, o.cbs));
 		chk(dmnd_set_query_contexts(c, blastx ? 6 : 1));
 		chk(dmnd_set_sensitivity(c, sens));

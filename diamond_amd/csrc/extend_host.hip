@@ -85,6 +85,10 @@ struct HostCfg {
 	double top = -1.0;                   // config.toppercent (--top): >= 0 = report the targets within this percentage of the best bit score
 	const Evaluer* evaluer = nullptr;    // ScoreMatrix::evalue / bitscore of the context
 	double max_evalue = 0.001;
+	double min_bit_score = 0.0;          // config.min_bit_score (--min-score): replaces the e-value cutoff (ScoreMatrix::report_cutoff)
+	double min_id = 0.0, query_cover = 0.0, subject_cover = 0.0;      // --id, --query-cover, --subject-cover (filter_hsp, culling.cpp:147-170)
+	bool have_filters() const { return min_id > 0 || query_cover > 0 || subject_cover > 0; }
+	bool reported(int score, double evalue) const { return min_bit_score != 0.0 ? evaluer->bitscore(score) >= min_bit_score : evalue <= max_evalue; }
 };
 
 void make_cfg(const dmnd_ctx* c, HostCfg& h)
@@ -191,7 +195,7 @@ void load_query(const HostCfg& h, QueryWork& w, uint32_t query, const dmnd_seed_
 	w.i1 = std::min((size_t)w.chunk_size, w.order.size());
 	// a first chunk smaller than -k (k above MAX_CHUNK_SIZE) grows by 16 targets at a time while their seed-hit score would pass
 	// the e-value cutoff against a 50-letter target (extend.cpp:262-268, UNIFIED_TARGET_LEN)
-	if (h.top < 0.0 && (int64_t)(w.i1 - w.i0) < (int64_t)h.max_target_seqs && h.evaluer)
+	if (h.top < 0.0 && h.min_bit_score == 0.0 && (int64_t)(w.i1 - w.i0) < (int64_t)h.max_target_seqs && h.evaluer)
 		while (w.i1 < w.order.size() && h.evaluer->evalue(w.groups[w.order[w.i1]].score, (unsigned)query_len, 50u) <= h.max_evalue)
 			w.i1 += std::min<size_t>(16, w.order.size() - w.i1);
 }
@@ -396,18 +400,24 @@ void cull(std::vector<Cand>& t, bool sort_only, const CullCfg& cc)
 	if (!sort_only) t.resize(output_range(t.size(), cc, [&](size_t i) { return t[i].score; }));
 }
 
-void cull(std::vector<dmnd_match>& t, const CullCfg& cc)      // culling(matches, cfg), culling.cpp:199-202
+// culling(matches, cfg), culling.cpp:199-202. A match whose HSP was removed by a filter stays in the list as a placeholder with
+// filter_evalue = DBL_MAX, filter_score = 0 (Match::apply_filters): it sorts last, and output_range drops the placeholders at the
+// end of the reported range (and everything, if the best entry is one).
+void cull(std::vector<dmnd_match>& t, const CullCfg& cc)
 {
 	std::sort(t.begin(), t.end(), cc.top >= 0.0 ? match_less_score : match_less);
-	t.resize(output_range(t.size(), cc, [&](size_t i) { return t[i].hsp.score; }));
+	if (t.empty() || t[0].evalue == DBL_MAX) { t.clear(); return; }
+	size_t n = output_range(t.size(), cc, [&](size_t i) { return t[i].hsp.score; });
+	if (cc.top < 0.0) while (n > 1 && t[n - 1].evalue == DBL_MAX) --n;
+	t.resize(n);
 }
 
-// append_hits(targets, begin, end, with_culling = true, cfg), culling.cpp:115-145
-bool append_hits(std::vector<Cand>& targets, const std::vector<Cand>& v, const CullCfg& cc)
+// append_hits(targets, begin, end, with_culling, cfg), culling.cpp:115-145
+bool append_hits(std::vector<Cand>& targets, const std::vector<Cand>& v, const CullCfg& cc, bool with_culling)
 {
 	if (v.empty()) return false;
 	bool new_hits = cc.top < 0.0 && (int)targets.size() < cc.k;
-	bool append = new_hits;
+	bool append = !with_culling || new_hits;
 	cull(targets, append, cc);
 	double min_evalue = DBL_MAX;
 	int max_score = 0;
@@ -432,6 +442,10 @@ struct QueryState {
 	bool in_inner = true, done = false;
 	std::vector<PlanTarget> plan;       // DpTargets of the current chunk
 	size_t item_begin = 0, item_end = 0;
+	// round 2 (align(), gapped_final.cpp:80-160): the aligned targets are extended [r2_pos, r2_end) at a time
+	bool in_round2 = false;
+	size_t r2_pos = 0, r2_end = 0;
+	std::vector<dmnd_match> round;      // the round's matches so far
 };
 
 }
@@ -453,6 +467,7 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 	const uint32_t C = (uint32_t)h.contexts;
 	const int K = h.max_target_seqs;
 	const CullCfg cc{ K, h.top, &c->evaluer };
+	const bool first_round_culling = !h.have_filters() || h.top >= 0.0;      // extend.cpp:272
 	for (int i = 0; i < 12; ++i) if (i != 4 || w != c) w->ext_stats[i] = 0;      // [4] (bias + upload) of the caller's prelude is kept
 	for (double& x : w->host_ms) x = 0;
 	auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -577,7 +592,7 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 						const int score = res[x].score;
 						if (score <= 0) continue;
 						const double ev = c->evaluer.evalue(score, (unsigned)items[x].query_len, (unsigned)items[x].target_len);
-						if (ev > c->params.max_evalue) continue;
+						if (!h.reported(score, ev)) continue;
 						const int frame = (int)(p.query % C);
 						if (!v.empty() && v.back().target == p.target) {
 							// Target::add_hit(list, it) (target.h:105-113): the best context is the first one (contexts ascending) that
@@ -592,7 +607,7 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 					}
 					const bool multi_chunk = (s.w.i1 - s.w.i0) < s.w.order.size();
 					bool new_hits = s.new_hits_ev = !v.empty();
-					if (multi_chunk) new_hits = append_hits(s.aligned, v, cc);
+					if (multi_chunk) new_hits = append_hits(s.aligned, v, cc, first_round_culling);
 					else s.aligned = v;
 					// advance the chunk window (extend.cpp:325-329)
 					s.w.i0 = s.w.i1;
@@ -609,7 +624,10 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 			});
 			lap(7, 6);
 		}
-		// ---- round 2 for every query that just left the inner loop ----
+		// ---- round 2 for every query that just left the inner loop: all its aligned targets at once, or -- with --id / --query-cover /
+		// --subject-cover -- a step at a time until enough matches pass the filters (gapped_final.cpp:105-152) ----
+		bool any_round2 = false;
+		for (;;) {
 		parallel_each(T, [&](int t) {
 			Slice& me = sl[(size_t)t];
 			me.any = false;
@@ -619,9 +637,17 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 				QueryState& s = qs[i];
 				if (s.done || s.in_inner) continue;
 				me.any = true;
-				cull(s.aligned, false, cc);                                         // extend.cpp:331
+				if (!s.in_round2) {
+					cull(s.aligned, !first_round_culling, cc);                       // extend.cpp:331
+					s.in_round2 = true; s.r2_pos = 0; s.round.clear();
+				}
+				const size_t left = s.aligned.size() - s.r2_pos;
+				size_t step = left;
+				if (!first_round_culling && h.top < 0.0)
+					step = std::min<size_t>(((size_t)std::max<int64_t>((int64_t)K - (int64_t)s.round.size(), 16) + 15) / 16 * 16, left);
+				s.r2_end = s.r2_pos + step;
 				r2[i].assign(s.aligned.size(), dmnd_hsp());
-				for (size_t k = 0; k < s.aligned.size(); ++k) {
+				for (size_t k = s.r2_pos; k < s.r2_end; ++k) {
 					const Cand& cd = s.aligned[k];
 					const dmnd_dp_target d = item_of(s.w.query * C + (uint32_t)cd.frame, cd.target, cd.d_begin, cd.d_end);
 					if (dp_size(d) > h.max_swipe_dp) { me.it_st.push_back(d); me.ref_st.push_back(Ref{ i, k }); }      // DP::BandedSwipe::bin
@@ -633,6 +659,7 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 		bool any_batch = false;
 		for (const Slice& x : sl) any_batch |= x.any;
 		if (!any_batch) break;
+		any_round2 = true;
 		// the slices' lists, concatenated in slice order (= query order)
 		auto gather = [&](auto pick_items, auto pick_refs, std::vector<dmnd_dp_target>& its, std::vector<Ref>& refs) {
 			its.clear(); refs.clear();
@@ -680,14 +707,13 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 		for (const dmnd_dp_target& d : it_st) w->ext_stats[3] += cells_of(d);
 		lap(8, 8);
 		parallel_each(T, [&](int t) {
-			std::vector<dmnd_match> round;
 			for (size_t i = slice_begin(t); i < slice_begin(t + 1); ++i) {
 				QueryState& s = qs[i];
 				if (s.done || s.in_inner) continue;
-				// align() round 2 (gapped_final.cpp:80-160): report cutoff again, culling of this round's matches
-				round.clear();
+				// align() round 2 (gapped_final.cpp:80-160): report cutoff again, filters, culling of this round's matches
+				std::vector<dmnd_match>& round = s.round;
 				const uint32_t q = s.w.query;
-				for (size_t k = 0; k < s.aligned.size(); ++k) {
+				for (size_t k = s.r2_pos; k < s.r2_end; ++k) {
 					const Cand& cd = s.aligned[k];
 					const dmnd_hsp& hsp = r2[i][k];
 					if (hsp.score <= 0) continue;
@@ -695,20 +721,30 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 					const uint32_t qc = q * C + (uint32_t)cd.frame;
 					const int qlen = (int)(ql[qc + 1] - ql[qc] - 1);
 					const double ev = c->evaluer.evalue(hsp.score, (unsigned)qlen, (unsigned)tlen);
-					if (ev > c->params.max_evalue) continue;
+					if (!h.reported(hsp.score, ev)) continue;
 					dmnd_match m;
 					m.query = q; m.target = cd.target; m.evalue = ev; m.bit_score = c->evaluer.bitscore(hsp.score);
 					m.ungapped_score = cd.ungapped; m.d_begin = cd.d_begin; m.d_end = cd.d_end; m.frame = cd.frame; m.hsp = hsp;
+					// filter_hsp (culling.cpp:147-170): the HSP is removed, the match stays as a placeholder for the culling below
+					if (h.have_filters() && ((double)hsp.identities * 100.0 / (double)hsp.length < h.min_id
+						|| (double)(hsp.q_end - hsp.q_begin) * 100 / qlen < h.query_cover
+						|| (double)(hsp.s_end - hsp.s_begin) * 100 / tlen < h.subject_cover)) { m.evalue = DBL_MAX; m.hsp.score = 0; }
 					round.push_back(m);
 				}
 				cull(round, cc);
+				s.r2_pos = s.r2_end;
+				if (s.r2_pos < s.aligned.size() && (h.top >= 0.0 || (int)(round.size() + s.matches.size()) < K)) continue;      // next step (goon)
+				s.in_round2 = false;
 				s.matches.insert(s.matches.end(), round.begin(), round.end());
+				round.clear();
 				s.aligned.clear();
 				// outer loop condition (extend.cpp:336)
 				if (h.top < 0.0 && (int)s.matches.size() < K && s.w.i0 < s.w.order.size() && s.new_hits_ev) s.in_inner = true;
 				else s.done = true;
 			}
 		});
+		}
+		if (!any_round2) break;
 		lap(7, 9);
 	}
 	w->swipe_ms = sw1 + sw2; w->traceback_ms = tb2;
@@ -779,6 +815,9 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	h.top = c->top_percent;
 	h.evaluer = &c->evaluer;
 	h.max_evalue = c->params.max_evalue;
+	h.min_bit_score = c->min_bit_score; h.min_id = c->min_id; h.query_cover = c->query_cover; h.subject_cover = c->subject_cover;
+	if (h.query_cover > 0 && c->query_contexts != 1)
+		return fail(DMND_E_ARG, "dmnd_extend: --query-cover of translated queries needs the read lengths, which this entry point does not take");
 	h.ranking_block_letters = c->ranking_block_letters;
 	h.band_mode_fast = c->band_mode_fast;
 	h.contexts = c->query_contexts;
@@ -949,6 +988,14 @@ extern "C" int dmnd_set_max_target_seqs(dmnd_ctx* c, int k)
 // join_query over the records of several reference blocks (output/join_blocks.cpp:180-256): every block's list of a query is
 // already in match_less order, so the reference's heap merge by JoinRecord::cmp_evalue (join_blocks.cpp:129-142) is the sort of
 // the union by (e-value, score descending, target ordinal); GlobalCulling keeps the first max_target_seqs (target_culling.h:70-88).
+extern "C" int dmnd_set_filters(dmnd_ctx* c, double min_id, double query_cover, double subject_cover, double min_bit_score)
+{
+	if (!c || min_id < 0 || min_id > 100 || query_cover < 0 || query_cover > 100 || subject_cover < 0 || subject_cover > 100 || min_bit_score < 0)
+		return fail(DMND_E_ARG, "dmnd_set_filters: bad argument");
+	c->min_id = min_id; c->query_cover = query_cover; c->subject_cover = subject_cover; c->min_bit_score = min_bit_score;
+	return DMND_OK;
+}
+
 extern "C" int dmnd_set_top_percent(dmnd_ctx* c, double percent)
 {
 	if (!c || percent > 100.0) return fail(DMND_E_ARG, "dmnd_set_top_percent: bad argument");

@@ -331,6 +331,12 @@ int dmnd_set_sensitivity(dmnd_ctx* ctx, int sensitivity);
  * percent < 0 switches it off. dmnd_join_blocks_top is the block join for such a run (JoinRecord::cmp_score + GlobalCulling,
  * output/join_blocks.cpp:133-136, output/target_culling.h:62-63). */
 int dmnd_set_top_percent(dmnd_ctx* ctx, double percent);
+/* --id, --query-cover, --subject-cover (percentages; 0 = off): HSPs below are removed after round 2 and the extension takes more
+ * of the ranked targets, 16 or more at a time, until -k matches pass (filter_hsp, align/culling.cpp:147-170; the stepping of
+ * align(), align/gapped_final.cpp:105-152; first_round_culling = false, align/extend.cpp:272). --min-score BITS (0 = off)
+ * replaces the e-value cutoff (ScoreMatrix::report_cutoff, stats/score_matrix.cpp:234-239). Query cover is only available for
+ * untranslated queries. */
+int dmnd_set_filters(dmnd_ctx* ctx, double min_id, double query_cover, double subject_cover, double min_bit_score);
 int dmnd_join_blocks_top(dmnd_match* records, int64_t n, double top_percent, int64_t* n_out);
 /* -k / --max-target-seqs (default 25, src/basic/config.h:55) */
 int dmnd_set_max_target_seqs(dmnd_ctx* ctx, int k);

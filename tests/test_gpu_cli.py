@@ -426,3 +426,36 @@ def test_cli_top_percent_and_large_k_match_reference(tmp_path):
         ref = open(tmp_path / "ref.tsv").read()
         assert len(ref.splitlines()) > 100, extra
         assert open(tmp_path / "hip.tsv").read() == ref, extra
+
+
+def test_cli_identity_cover_and_min_score_filters_match_reference(tmp_path):
+    """--id / --query-cover / --subject-cover (HSPs removed after round 2; the extension then takes more of the ranked targets, a
+    step at a time, until -k matches pass) and --min-score (bit-score report cutoff) against the reference binary."""
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/diamond not built")
+    db, doff, q, qoff = synth.generate(60, members=40, queries=150, seed=23)
+    rng = np.random.default_rng(3)
+    seqs = [db[doff[i]:doff[i + 1]] for i in range(len(doff) - 1)]
+    for i in range(0, len(seqs), 3):                                     # truncated members: low query / subject cover
+        cut = int(rng.integers(len(seqs[i]) // 3, len(seqs[i])))
+        seqs[i] = seqs[i][:cut] if i % 2 else seqs[i][len(seqs[i]) - cut:]
+    off = np.concatenate([[0], np.cumsum([len(x) for x in seqs])])
+    synth.write_fasta(str(tmp_path / "db.faa"), "t", np.concatenate(seqs), off)
+    synth.write_fasta(str(tmp_path / "q.faa"), "q", q, qoff)
+    base = ["blastp", "-q", str(tmp_path / "q.faa"), "-d", str(tmp_path / "db.faa"), "-p", "4"]
+    plain = None
+    for extra in ([], ["--id", "55"], ["--query-cover", "80", "-k", "5"], ["--subject-cover", "90", "-k", "3", "--fast"], ["--id", "50", "--query-cover", "60", "--subject-cover", "65", "-k", "40"],
+                  ["--min-score", "150"], ["--id", "60", "--top", "20"], ["--query-cover", "75", "-b0.0003", "-c1", "--sensitive", "-k", "10"]):
+        _run([REF] + base + extra + ["-o", str(tmp_path / "ref.tsv")])
+        _run([CLI] + base + extra + ["-o", str(tmp_path / "hip.tsv")])
+        ref = open(tmp_path / "ref.tsv").read()
+        assert len(ref.splitlines()) > 100, extra
+        got = open(tmp_path / "hip.tsv").read()
+        if got != ref:
+            a, b = ref.splitlines(), got.splitlines()
+            k = next((i for i in range(min(len(a), len(b))) if a[i] != b[i]), min(len(a), len(b)))
+            raise AssertionError("%s: %d vs %d lines, first difference at %d: %r | %r; only ref %d, only ours %d" % (extra, len(a), len(b), k, a[k:k + 2], b[k:k + 2], len(set(a) - set(b)), len(set(b) - set(a))))
+        if not extra:
+            plain = ref
+        else:
+            assert ref != plain, extra                                    # the option matters on this input
