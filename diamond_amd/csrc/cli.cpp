@@ -338,8 +338,8 @@ SeqBlock slice(const SeqBlock& all, size_t begin, size_t end)
 int run_blastp(const Options& o)
 {
 	if (o.query.empty() || o.db.empty()) throw std::runtime_error("Missing parameter: query (--query/-q) and database (--db/-d) are required.");
-	if (!o.sens.empty() && o.sens != "--sensitive" && o.sens != "--mid-sensitive" && o.sens != "--more-sensitive" && o.sens != "--very-sensitive")
-		throw std::runtime_error("This build implements --fast, default, --mid-sensitive, --sensitive, --more-sensitive and --very-sensitive (" + o.sens + " is not available).");
+	if (!o.sens.empty() && o.sens != "--sensitive" && o.sens != "--mid-sensitive" && o.sens != "--more-sensitive" && o.sens != "--very-sensitive" && o.sens != "--ultra-sensitive")
+		throw std::runtime_error("This build implements --fast, default, --mid-sensitive, --sensitive, --more-sensitive, --very-sensitive and --ultra-sensitive (" + o.sens + " is not available).");
 	if (o.fast && !o.sens.empty()) throw std::runtime_error("Conflicting sensitivity options.");
 	// --masking: tantan = default (run/config.cpp:124-135); seg is not part of this build
 	const bool tantan = o.masking.empty() || o.masking == "1" || o.masking == "tantan";
@@ -396,7 +396,8 @@ int run_blastp(const Options& o)
 	if (want_full_sseq) t_unmasked = t_all_seqs.data;
 	std::cerr << "Loading sequences...  [" << ms_since(t0) / 1e3 << "s]  queries=" << n_queries << " targets=" << n_targets << " letters=" << t_all_seqs.letters << "\n";
 	const int sens = o.fast ? DMND_SENS_FAST : o.sens == "--mid-sensitive" ? DMND_SENS_MID_SENSITIVE : o.sens == "--sensitive" ? DMND_SENS_SENSITIVE
-		: o.sens == "--more-sensitive" ? DMND_SENS_MORE_SENSITIVE : o.sens == "--very-sensitive" ? DMND_SENS_VERY_SENSITIVE : DMND_SENS_DEFAULT;
+		: o.sens == "--more-sensitive" ? DMND_SENS_MORE_SENSITIVE : o.sens == "--very-sensitive" ? DMND_SENS_VERY_SENSITIVE
+		: o.sens == "--ultra-sensitive" ? DMND_SENS_ULTRA_SENSITIVE : DMND_SENS_DEFAULT;
 	// -b: 2.0 billion letters, 0.4 from --very-sensitive up (run/double_indexed.cpp:792-795); basic/config.h:434
 	const double b_opt = o.block_size > 0.0 ? o.block_size : (sens >= DMND_SENS_VERY_SENSITIVE ? 0.4 : 2.0);
 	const int64_t max_letters = (int64_t)(b_opt * 1e9);
@@ -682,7 +683,7 @@ int main(int argc, char** argv)
 		if (o.command == "version") { std::cout << "diamond-hip (MI355X back end of DIAMOND's seed-and-extend path), ABI " << dmnd_abi_version() << "\n"; return 0; }
 		if (o.command == "help" || o.command == "--help") {
 			std::cout << "Syntax: diamond-hip COMMAND [OPTIONS]\n  makedb --in FASTA -d DB        build a .dmnd database (no masking)\n"
-				"  blastp [--fast|--mid-sensitive|--sensitive|--more-sensitive|--very-sensitive] -q FASTA -d DB(.dmnd|FASTA) -o OUT [--masking 0] [-e EVALUE] [-k N] [-p THREADS] [-b BLOCK_SIZE] [-c INDEX_CHUNKS]\n"
+				"  blastp [--fast|--mid-sensitive|--sensitive|--more-sensitive|--very-sensitive|--ultra-sensitive] -q FASTA -d DB(.dmnd|FASTA) -o OUT [--masking 0] [-e EVALUE] [-k N] [-p THREADS] [-b BLOCK_SIZE] [-c INDEX_CHUNKS]\n"
 				"         [--algo 0|1] [--gpus N] [-f 6 [FIELD...] | -f 0 | -f paf]\n"
 				"  blastx [--fast|--sensitive] -q DNA_FASTA -d DB ...   (six-frame translation, standard genetic code)\n  version\n";
 			return 0;

@@ -972,7 +972,7 @@ extern "C" int dmnd_set_comp_based_stats(dmnd_ctx* c, int mode)
 
 extern "C" int dmnd_set_sensitivity(dmnd_ctx* c, int sensitivity)
 {
-	if (!c || sensitivity < DMND_SENS_FAST || sensitivity > DMND_SENS_VERY_SENSITIVE) return fail(DMND_E_ARG, "dmnd_set_sensitivity: bad argument");
+	if (!c || sensitivity < DMND_SENS_FAST || sensitivity > DMND_SENS_ULTRA_SENSITIVE) return fail(DMND_E_ARG, "dmnd_set_sensitivity: bad argument");
 	c->ranking_block_letters = sensitivity >= DMND_SENS_VERY_SENSITIVE ? 800e6 : 2e9;      // extend.cpp:87
 	c->band_mode_fast = sensitivity <= DMND_SENS_SENSITIVE ? 1 : 0;                          // default_ext_mode, extend.cpp:62-75
 	return DMND_OK;

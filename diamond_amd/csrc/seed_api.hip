@@ -134,6 +134,21 @@ extern "C" int dmnd_seed_params_preset(dmnd_seed_params* p, int sensitivity, int
 		// sensitivity_traits: min id 9, ungapped e-values 100000 / 30000 (short), one index chunk (setup.cpp:51)
 		return spaced_preset(p, threads, sc, codes, 14, 1.0, 100000.0, 30000.0, 9, 1);
 	}
+	case DMND_SENS_ULTRA_SENSITIVE: {
+		if (!sc) return fail(DMND_E_ARG, "dmnd_seed_params_preset: scoring parameters needed");
+		static const char* const codes[64] = { "1111111", "11101111", "110011111", "110110111", "111111001", "1010111011", "1011110101", "1111000111",
+			"10011110011", "10101101101", "10111010101", "11001010111", "11001100111", "11010101101", "11110001011", "100111010011", "101100110101",
+			"101110000111", "110100101011", "110110001101", "111000110011", "1010001011011", "1010101000111", "1010110100011", "1100100110011",
+			"1100101001011", "1101001100101", "1101010101001", "1110001010101", "1110010010011", "10100001101101", "11000100010111", "11010000100111",
+			"11010100110001", "11101000011001", "11110000001101", "11110100000011", "101001000001111", "110000100101011", "110010010000111",
+			"110101100001001", "110110000010011", "111001000100011", "111100000100101", "1000110010010101", "1001000100101101", "1001000110011001",
+			"1010001001001011", "1010001010010011", "1010010001010101", "1010010100010011", "1010010101001001", "1010100000101011", "1010100011000101",
+			"1011000010001011", "1100010000111001", "1100010010001011", "1100100001001011", "1100100100100011", "1100110000001101", "1101000100010011",
+			"1101000110000101", "1110000001010011", "1110100000010101" };                                   // 64x7, setup.cpp:135-200
+		if (gapped_filter_evalue) *gapped_filter_evalue = 1.0;
+		// sensitivity_traits: min id 9, ungapped e-values 300000 / 30000 (short), one index chunk (setup.cpp:53)
+		return spaced_preset(p, threads, sc, codes, 64, 1.0, 300000.0, 30000.0, 9, 1);
+	}
 	default:
 		return fail(DMND_E_ARG, "dmnd_seed_params_preset: unknown sensitivity");
 	}
@@ -264,25 +279,29 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	if (const char* e = getenv("DMND_SEED_BITMAP1_LOG2")) bm1_log2 = std::min(27, std::max(15, atoi(e)));      // word index = 22 bits of hash a
 	uint64_t bm1_words = ((uint64_t)1 << bm1_log2) / 32;
 	if (bm1_words > bm_words) bm1_words = bm_words;
-	const size_t bm_total = (size_t)S * (bm_words + bm1_words) * sizeof(uint32_t);
+	// The fused pipeline finishes a shape before it starts the next one: its table, lists and bitmaps are ONE shape's, reused
+	// (64 shapes of --ultra-sensitive would otherwise hold 8 GB of tables for a 10k-query block)
+	bool fused = seed_stream_can_fuse(sp);
+	if (const char* e = getenv("DMND_SEED_FUSED")) fused = fused && atoi(e) != 0;
+	const int SB = fused ? 1 : S;                        // shapes that own buffers at the same time
+	const size_t bm_total = (size_t)SB * (bm_words + bm1_words) * sizeof(uint32_t);
 	if (int rc = c->seed_bitmap.ensure(bm_total)) return rc;
 	HIP_TRY(hipMemsetAsync(c->seed_bitmap.p, 0, bm_total, st));
 	if (int rc = c->qid_of.ensure((size_t)q_end * sizeof(uint32_t))) return rc;
 	if (int rc = c->mask_time.ensure((size_t)c->block_len[DMND_QUERY] + 256)) return rc;
-	if (int rc = c->seed_keys.ensure((size_t)S * slots * sizeof(SeedSlot))) return rc;
+	if (int rc = c->seed_keys.ensure((size_t)SB * slots * sizeof(SeedSlot))) return rc;
 	if (int rc = c->seed_need.ensure((size_t)(slots / 32) * sizeof(uint32_t))) return rc;
-	if (int rc = c->seed_next.ensure((size_t)S * nq_pos * sizeof(uint32_t))) return rc;        // qslot
-	if (int rc = c->seed_qlist.ensure((size_t)S * nq_pos * sizeof(uint32_t))) return rc;
+	if (int rc = c->seed_next.ensure((size_t)SB * nq_pos * sizeof(uint32_t))) return rc;        // qslot
+	if (int rc = c->seed_qlist.ensure((size_t)SB * nq_pos * sizeof(uint32_t))) return rc;
 	if (int rc = c->seed_qkeys.ensure((size_t)nq_pos * sizeof(uint32_t))) return rc;
-	HIP_TRY(hipMemsetAsync(c->seed_next.p, 0xff, (size_t)S * nq_pos * sizeof(uint32_t), st));
+	HIP_TRY(hipMemsetAsync(c->seed_next.p, 0xff, (size_t)SB * nq_pos * sizeof(uint32_t), st));
 	if (int rc = c->counters.ensure((size_t)(S + 5) * sizeof(unsigned long long))) return rc;      // [S] hits, [S+1] deferred pairs, [S+2] collected positions, [S+3] Hamming survivors, [S+4] scored survivors
 	HIP_TRY(hipMemsetAsync(c->mask_time.p, SEED_NEVER, (size_t)c->block_len[DMND_QUERY] + 256, st));
-	HIP_TRY(hipMemsetAsync(c->seed_keys.p, 0xff, (size_t)S * slots * sizeof(SeedSlot), st));
+	HIP_TRY(hipMemsetAsync(c->seed_keys.p, 0xff, (size_t)SB * slots * sizeof(SeedSlot), st));
 	HIP_TRY(launch_seed_qid(c->d_limits[DMND_QUERY].as<int64_t>(), (int64_t)ql.size() - 1, c->qid_of.as<uint32_t>(), st));
 
-	bool fused = seed_stream_can_fuse(sp);
-	if (const char* e = getenv("DMND_SEED_FUSED")) fused = fused && atoi(e) != 0;
 	auto args_for = [&](int sid, int64_t matched_cap, int64_t matched_off) {
+		const int own = fused ? 0 : sid;                   // which of the SB buffer sets the shape uses
 		SeedArgs a;
 		a.params = sp;
 		a.qdata = c->block[DMND_QUERY].as<int8_t>(); a.tdata = c->block[DMND_TARGET].as<int8_t>();
@@ -293,11 +312,11 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		a.qlimits = c->d_limits[DMND_QUERY].as<int64_t>();
 		a.q_begin = q_begin; a.q_end = q_end; a.t_begin = t_begin; a.t_end = t_end;
 		a.qid_of = c->qid_of.as<uint32_t>(); a.mask_time = c->mask_time.as<uint8_t>();
-		a.slots = c->seed_keys.as<SeedSlot>() + (size_t)sid * slots;
-		a.qslot = c->seed_next.as<uint32_t>() + (size_t)sid * nq_pos;
-		a.qlist = c->seed_qlist.as<uint32_t>() + (size_t)sid * nq_pos;
+		a.slots = c->seed_keys.as<SeedSlot>() + (size_t)own * slots;
+		a.qslot = c->seed_next.as<uint32_t>() + (size_t)own * nq_pos;
+		a.qlist = c->seed_qlist.as<uint32_t>() + (size_t)own * nq_pos;
 		a.slot_mask = slots - 1;
-		a.bitmap = c->seed_bitmap.as<uint32_t>() + (size_t)sid * (bm_words + bm1_words);
+		a.bitmap = c->seed_bitmap.as<uint32_t>() + (size_t)own * (bm_words + bm1_words);
 		a.bitmap_mask = (uint32_t)(bm_words - 1);
 		a.bitmap1 = a.bitmap + bm_words;
 		a.bitmap1_mask = (uint32_t)(bm1_words - 1);
@@ -342,8 +361,13 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		for (int sid = 0; sid < S; ++sid) {
 			SeedArgs a = args_for(sid, 0, 0);
 			tm.start();
+			if (sid > 0) {                                   // the previous shape's table, slots-of-positions and bitmaps
+				HIP_TRY(hipMemsetAsync(c->seed_keys.p, 0xff, (size_t)slots * sizeof(SeedSlot), st));
+				HIP_TRY(hipMemsetAsync(c->seed_next.p, 0xff, (size_t)nq_pos * sizeof(uint32_t), st));
+				HIP_TRY(hipMemsetAsync(c->seed_bitmap.p, 0, bm_total, st));
+			}
 			HIP_TRY(launch_seed_index(a, sid, st));
-			HIP_TRY(launch_seed_lists(a, sid, c->seed_qkeys.as<uint32_t>(), c->seed_qlist.as<uint32_t>() + (size_t)sid * nq_pos, 32, &c->sort_tmp, &c->sort_tmp_bytes, st));
+			HIP_TRY(launch_seed_lists(a, sid, c->seed_qkeys.as<uint32_t>(), c->seed_qlist.as<uint32_t>(), 32, &c->sort_tmp, &c->sort_tmp_bytes, st));
 			c->seed_ms[0] += tm.stop();
 			unsigned long long n = 0, ns = 0;
 			for (int attempt = 0;; ++attempt) {

@@ -21,7 +21,7 @@
 
 namespace dmnd {
 
-enum { SEED_MAX_SHAPES = 16, SEED_MAX_WEIGHT = 32, L_MASK = 23, L_STOP = 24, L_DELIM = 31, SEED_NEVER = 255 };
+enum { SEED_MAX_SHAPES = 64, SEED_MAX_WEIGHT = 32, L_MASK = 23, L_STOP = 24, L_DELIM = 31, SEED_NEVER = 255 };
 enum { SEED_SPACED = 0, SEED_HASHED = 1 };
 
 // Seed-stage configuration: the globals the reference reads across the seam (shapes, Reduction::instance,

@@ -410,7 +410,7 @@ __device__ __forceinline__ void finish_pair(const SeedArgs& a, int sid, int chun
 // ([-48, +80) letters, [-48, +48) mask times: everything the stage-2 code reads)
 // stage-2 ungapped window score of one pair: -1 = dropped (below the cutoff, or deferred to the second pass), else the score that
 // goes into the hit if the pair also passes the left-most rule
-__device__ __forceinline__ int stage2_score(const SeedArgs& a, uint32_t slot, int64_t sloc, uint32_t x, const int8_t* q, const int8_t* s)
+__device__ __forceinline__ int stage2_score(const SeedArgs& a, const int8_t* matrix, uint32_t slot, int64_t sloc, uint32_t x, const int8_t* q, const int8_t* s)
 {
 	const int64_t qp = a.q_begin + x;
 	const uint32_t qid = a.qid_of[qp];
@@ -422,7 +422,7 @@ __device__ __forceinline__ int stage2_score(const SeedArgs& a, uint32_t slot, in
 	int cb, ce;
 	clip_window(q - window, 2 * window, window, cb, ce);
 	const int window_left = window - cb;
-	const int score = ungapped_window_score(a.matrix, q - window_left, s - window_left, ce - cb);
+	const int score = ungapped_window_score(matrix, q - window_left, s - window_left, ce - cb);
 	if (score > 255) {
 		// saturation depends on the SIMD batch of the reference: second pass (seed_deferred_kernel)
 		const unsigned long long d = atomicAdd(a.deferred_count, 1ull);
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(POST_THREADS) void seed_score_kernel(SeedArgs a, in
 	if (threadIdx.x == 0) st_n = 0;
 	__syncthreads();
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	a.matrix = matrix;                                    // flat pointer into LDS
+	// (the kernel argument is not modified: a private copy of the 3 KB struct would live in scratch memory)
 	if (i < n_survivors) {
 		const SeedSurvivor sv = a.survivors[i];
 		const SeedSlot sl = a.slots[sv.slot];
@@ -655,7 +655,7 @@ __global__ __launch_bounds__(POST_THREADS) void seed_score_kernel(SeedArgs a, in
 			const int64_t qp = a.q_begin + sv.x;
 			int score;
 			// windows wider than the staged stretch (--ungapped-window above 48; short translated frames use their whole length): from the blocks
-			if (a.params.query_translated || a.params.ungapped_window > POST_BEFORE) score = stage2_score(a, sv.slot, sv.sloc, sv.x, a.qdata + qp, a.tdata + sv.sloc);
+			if (a.params.query_translated || a.params.ungapped_window > POST_BEFORE) score = stage2_score(a, matrix, sv.slot, sv.sloc, sv.x, a.qdata + qp, a.tdata + sv.sloc);
 			else {
 				int8_t* lq = win + (size_t)threadIdx.x * POST_STRIDE;
 				int8_t* ls = lq + POST_LETTERS;
@@ -667,7 +667,7 @@ __global__ __launch_bounds__(POST_THREADS) void seed_score_kernel(SeedArgs a, in
 					*reinterpret_cast<uint4*>(lq + 16 * k) = v;
 					*reinterpret_cast<uint4*>(ls + 16 * k) = w;
 				}
-				score = stage2_score(a, sv.slot, sv.sloc, sv.x, lq + POST_BEFORE, ls + POST_BEFORE);
+				score = stage2_score(a, matrix, sv.slot, sv.sloc, sv.x, lq + POST_BEFORE, ls + POST_BEFORE);
 			}
 			if (score >= 0)
 				stage[atomicAdd(&st_n, 1u)] = SeedScored{ sv.slot, sv.x, sv.sloc, score, seed_chunk(a.params, seed_of_key(a.params, sid, sl.key)) };

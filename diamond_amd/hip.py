@@ -28,8 +28,8 @@ class Params(ctypes.Structure):
 
 class SeedParams(ctypes.Structure):
     """dmnd_seed_params (include/diamond_hip.h)."""
-    _fields_ = [("n_shapes", ctypes.c_int32), ("shape_len", ctypes.c_int32 * 16), ("shape_weight", ctypes.c_int32 * 16),
-                ("shape_mask", ctypes.c_uint32 * 16), ("shape_pos", (ctypes.c_int8 * 32) * 16),
+    _fields_ = [("n_shapes", ctypes.c_int32), ("shape_len", ctypes.c_int32 * 64), ("shape_weight", ctypes.c_int32 * 64),
+                ("shape_mask", ctypes.c_uint32 * 64), ("shape_pos", (ctypes.c_int8 * 32) * 64),
                 ("reduction", ctypes.c_int8 * 32), ("reduction_size", ctypes.c_int32),
                 ("seedp_bits", ctypes.c_int32), ("index_chunks", ctypes.c_int32), ("hamming_filter_id", ctypes.c_int32),
                 ("ungapped_window", ctypes.c_int32), ("left_most_interval", ctypes.c_int32),
@@ -303,7 +303,7 @@ def seed_params_default(scoring, threads=1):
     return p
 
 
-SENS = {"fast": 0, "default": 1, "mid-sensitive": 2, "sensitive": 3, "more-sensitive": 4, "very-sensitive": 5}
+SENS = {"fast": 0, "default": 1, "mid-sensitive": 2, "sensitive": 3, "more-sensitive": 4, "very-sensitive": 5, "ultra-sensitive": 6}
 
 
 def seed_params_preset(name, scoring, threads=1):

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DMND_ABI_VERSION 4      /* 2: dmnd_match.frame, seed parameters (ungapped filter, translated queries), dmnd_extend_plan(query_contexts); 3: seed_encoding; 4: output formats */
+#define DMND_ABI_VERSION 5      /* 2: dmnd_match.frame, seed parameters (ungapped filter, translated queries), dmnd_extend_plan(query_contexts); 3: seed_encoding; 4: output formats; 5: DMND_MAX_SHAPES 64 */
 
 enum {
 	DMND_OK = 0,
@@ -159,7 +159,7 @@ int dmnd_evalue_batch(const dmnd_params* params, const int32_t* raw_score, const
 
 /* -- seed stage: replaces Search::search_shape for all shapes and index chunks of one (query block, reference
  *    block) pair (src/search/search.h:83, src/search/stage0.cpp:101-228) -------------------------------------- */
-#define DMND_MAX_SHAPES 16
+#define DMND_MAX_SHAPES 64        /* --ultra-sensitive: 64 shapes of weight 7 (search/setup.cpp:135-200) */
 #define DMND_MAX_SHAPE_WEIGHT 32
 /* The globals the reference reads across the seam: `shapes` (basic/shape_config.h), Reduction::instance
  * (basic/reduction.h), Search::Config::{seedp_bits,index_chunks,hamming_filter_id,seed_complexity_cut}
@@ -264,7 +264,7 @@ double dmnd_gapped_filter_ms(const dmnd_ctx* ctx);
 /* Sensitivity presets (Sensitivity enum + sensitivity_traits, src/search/setup.cpp:40-53): shapes, seed cut, ungapped
  * e-value, and through *gapped_filter_evalue (may be NULL) the value to pass to dmnd_set_gapped_filter. */
 enum { DMND_SENS_FAST = 0, DMND_SENS_DEFAULT = 1, DMND_SENS_MID_SENSITIVE = 2, DMND_SENS_SENSITIVE = 3, DMND_SENS_MORE_SENSITIVE = 4,
-       DMND_SENS_VERY_SENSITIVE = 5 };
+       DMND_SENS_VERY_SENSITIVE = 5, DMND_SENS_ULTRA_SENSITIVE = 6 };
 int dmnd_seed_params_preset(dmnd_seed_params* p, int sensitivity, int threads, const dmnd_params* scoring, double* gapped_filter_evalue);
 /* -c / --index-chunks on a preset (config.lowmem_, src/run/double_indexed.cpp:297): sets index_chunks and recomputes
  * seedp_bits as Search::seedp_bits does (src/search/setup.cpp:306-309). The chunk of a seed decides which shape/chunk

@@ -101,8 +101,8 @@ def swipe_stats(query, cbs, target, d_begin, d_end, matrix8, gap_open, gap_exten
 # ---- seed stage ---------------------------------------------------------------------------------------------------
 class SeedParams(ctypes.Structure):
     """Mirror of dmnd::SeedParams (diamond_amd/csrc/seed_core.h) = dmnd_seed_params (include/diamond_hip.h)."""
-    _fields_ = [("n_shapes", ctypes.c_int32), ("shape_len", ctypes.c_int32 * 16), ("shape_weight", ctypes.c_int32 * 16),
-                ("shape_mask", ctypes.c_uint32 * 16), ("shape_pos", (ctypes.c_int8 * 32) * 16),
+    _fields_ = [("n_shapes", ctypes.c_int32), ("shape_len", ctypes.c_int32 * 64), ("shape_weight", ctypes.c_int32 * 64),
+                ("shape_mask", ctypes.c_uint32 * 64), ("shape_pos", (ctypes.c_int8 * 32) * 64),
                 ("reduction", ctypes.c_int8 * 32), ("reduction_size", ctypes.c_int32),
                 ("seedp_bits", ctypes.c_int32), ("index_chunks", ctypes.c_int32), ("hamming_filter_id", ctypes.c_int32),
                 ("ungapped_window", ctypes.c_int32), ("left_most_interval", ctypes.c_int32),

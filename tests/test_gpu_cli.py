@@ -119,7 +119,7 @@ def test_cli_default_masking_matches_reference(tmp_path):
 
 
 def test_cli_refuses_unimplemented_modes(tmp_path):
-    r = subprocess.run([CLI, "blastp", "--ultra-sensitive", "-q", "x", "-d", "y"], capture_output=True, text=True)
+    r = subprocess.run([CLI, "blastp", "--faster", "-q", "x", "-d", "y"], capture_output=True, text=True)
     assert r.returncode != 0 and "not available" in r.stderr
 
 
@@ -191,6 +191,7 @@ CTEST = [
     ("blocked", ["-c1", "-b0.00002", "-p4"]),
     ("more-sensitive", ["--more-sensitive", "-c1", "-p4"]),
     ("very-sensitive", ["--very-sensitive", "-c1", "-p4"]),
+    ("ultra-sensitive", ["--ultra-sensitive", "-c1", "-p4"]),
     ("query-indexed", ["--more-sensitive", "-c1", "-p4", "--algo", "1"]),
     ("comp-based-stats-0", ["--more-sensitive", "-c1", "-p4", "--comp-based-stats", "0"]),
     ("target-seqs", ["-k3", "-c1", "-p4"]),
