@@ -186,8 +186,9 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="C2")
     ap.add_argument("--queries", type=int, default=None, help="default: the config's (10000; C5: 100000)")
     ap.add_argument("--families", type=int, default=None, help="protein families of 10 members in the database (default 100000; C5: 500000)")
-    ap.add_argument("--host-threads", type=int, default=8)
+    ap.add_argument("--host-threads", type=int, default=12, help="host threads of the extension stage, divided among the extension contexts")
     ap.add_argument("--shard", choices=["db", "query"], default="db")
+    ap.add_argument("--ext-contexts", type=int, default=3, help="batches extended concurrently (each on its own context and host thread team)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="run seed stage and extension stage of a batch back to back on one context")
     args = ap.parse_args()
@@ -237,6 +238,11 @@ def main():
     upload_ms = (time.perf_counter() - t_up) * 1e3          # outside the timed region: inputs are resident when a step starts
     pipeline = not args.no_pipeline
     ctxs_seed = [make_ctx(b) for b in range(NB)] if pipeline else ctxs
+    # E batches are extended at the same time, each on its own context (own streams, buffers and host thread team): while one
+    # batch is in a host phase (chaining, culling) the other one's sweep or walk runs, which the seed stage alone did not fill
+    E = max(1, args.ext_contexts) if pipeline else 1
+    ext_ctxs = [ctxs] + [[make_ctx(b) for b in range(NB)] for _ in range(E - 1)]
+    ext_threads = max(1, threads // E)
     ctx, ctx_seed = ctxs[0], ctxs_seed[0]
     state = {"stream_ms": 0.0, "stream_launches": 0}
 
@@ -260,20 +266,28 @@ def main():
             return multigpu.db_shard_join(np.concatenate(mine), coll_device, target_base=0)
         return parts[0]
 
-    def step(prefetched=None):
-        """One batch = all database blocks of this rank, one after the other, then the join."""
+    def extend_batch(e, prefetched):
+        """The extension stage of one batch on extension context set e: all database blocks of this rank, one after the other.
+        prefetched: per block the future (or the result) of its seed stage."""
+        torch.cuda.set_device(local_rank)
         t_b = time.perf_counter()
         parts, n_hits, seed_ms, ext_sum = [], 0, None, None
         for b in range(NB):
-            hits, ms = prefetched[b] if prefetched is not None else seed_stage(b)
-            m, _ = ctxs[b].extend(w.qd, w.blocks[b][2], hits, threads=threads)
+            got = prefetched[b] if prefetched is not None else seed_stage(b)
+            hits, ms = got.result() if hasattr(got, "result") else got
+            m, _ = ext_ctxs[e][b].extend(w.qd, w.blocks[b][2], hits, threads=ext_threads)
             parts.append(m)
             n_hits += int(hits.size)
             seed_ms = list(ms) if seed_ms is None else [x + y for x, y in zip(seed_ms, ms)]
-            e = ctxs[b].extend_stats()
-            ext_sum = dict(e) if ext_sum is None else {k: ext_sum[k] + e[k] for k in e}
-        t_c = time.perf_counter()
-        state.update(hits=n_hits, matches=np.concatenate(parts) if NB > 1 else parts[0], seed_ms=seed_ms, ext=ext_sum, ext_wall_ms=(t_c - t_b) * 1e3)
+            st = ext_ctxs[e][b].extend_stats()
+            ext_sum = dict(st) if ext_sum is None else {k: ext_sum[k] + st[k] for k in st}
+        return dict(parts=parts, hits=n_hits, seed_ms=seed_ms, ext=ext_sum, ext_wall_ms=(time.perf_counter() - t_b) * 1e3)
+
+    def step(prefetched=None, done=None):
+        """One batch: its extension (here, or already done on an extension thread), then the join of its records."""
+        r = done if done is not None else extend_batch(0, prefetched)
+        parts = r["parts"]
+        state.update(hits=r["hits"], matches=np.concatenate(parts) if NB > 1 else parts[0], seed_ms=r["seed_ms"], ext=r["ext"], ext_wall_ms=r["ext_wall_ms"])
 
         def do_finish():
             torch.cuda.set_device(local_rank)
@@ -301,24 +315,38 @@ def main():
         import concurrent.futures
         seed_pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
         finish_pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
+        ext_pools = [concurrent.futures.ThreadPoolExecutor(max_workers=1) for _ in range(E)]      # a context runs one call at a time
 
-    PREFETCH = 2        # seed stages in flight or finished ahead of the extension (a bounded prefetch queue, like a data loader's)
+    PREFETCH = max(2, E + 1)        # seed stages in flight or finished ahead of the extension (a bounded prefetch queue, like a data loader's)
 
     def run(n_steps, queue):
         """n_steps batches: every step takes the oldest seed-stage result of the queue (computed during earlier steps; by the
         warm-up for the first timed ones), submits ONE new seed stage to the seed thread and extends its own batch. n steps
         execute n seed stages and n extensions; the seed stages still queued at the end are awaited before the clock stops."""
-        each = []
+        each, inflight = [], []
+        t_a = time.perf_counter()
+
+        def retire():                                        # batches complete in order: their records are joined in batch order on every rank
+            nonlocal t_a
+            step(done=inflight.pop(0).result())
+            t_n = time.perf_counter()
+            each.append(round((t_n - t_a) * 1e3, 2))
+            t_a = t_n
         for s in range(n_steps):
-            t_a = time.perf_counter()
             if pipeline:
-                got = [queue.pop(0).result() for _ in range(NB)]
+                got = [queue.pop(0) for _ in range(NB)]
                 for b in range(NB):
                     queue.append(seed_pool.submit(seed_stage, b))
-                step(got)
+                inflight.append(ext_pools[s % E].submit(extend_batch, s % E, got))
+                if len(inflight) >= E:
+                    retire()
             else:
                 step()
-            each.append(round((time.perf_counter() - t_a) * 1e3, 2))
+                t_n = time.perf_counter()
+                each.append(round((t_n - t_a) * 1e3, 2))
+                t_a = t_n
+        while inflight:
+            retire()
         return each, queue
 
     queue = [seed_pool.submit(seed_stage, b) for _ in range(PREFETCH) for b in range(NB)] if pipeline else []
@@ -329,7 +357,7 @@ def main():
     sync()
     # hipDeviceSynchronize lets the runtime release the hardware queues of idle streams; re-acquiring them costs the first
     # timed calls milliseconds (a streaming caller never synchronizes the whole device)
-    for c in ctxs + (ctxs_seed if pipeline else []):
+    for c in [x for cs in ext_ctxs for x in cs] + (ctxs_seed if pipeline else []):
         c.touch_streams()
     state["stream_ms"], state["stream_launches"] = 0.0, 0
     t0 = time.perf_counter()
@@ -349,7 +377,7 @@ def main():
         t_s = time.perf_counter()
         hs = [seed_stage(b) for b in range(NB)]
         t_m = time.perf_counter()
-        step(hs)
+        step(prefetched=hs)
         drain()
         serial.append(((time.perf_counter() - t_s) * 1e3, (t_m - t_s) * 1e3))
     alone = {"batch_latency_ms": min(x[0] for x in serial), "seed_stage_call_ms": min(x[1] for x in serial),
@@ -401,7 +429,8 @@ def main():
             "seed_kernel_ms": dict(zip(["index_queries", "stream_reference", "mask_groups", "pair_filter", "total"], state["seed_ms"])),
             # seed-stage Gletters/s = (L_q + L_r) x shapes / seed-stage seconds (device time of its kernels)
             "seed_stage_gletters_per_s": (NB * int(w.ql[-1] - w.ql[0]) + sum(int(b[3][-1] - b[3][0]) for b in w.blocks)) * seed_params.n_shapes / max(state["seed_ms"][4], 1e-9) / 1e6,
-            "pipeline": "seed stages run on a second context (own low-priority stream), up to %d batches ahead of the extension stage" % PREFETCH if pipeline else "off",
+            "pipeline": ("seed stages run on a second context (own low-priority stream), up to %d batches ahead of the extension stage; %d batches are extended at the same time "
+                         "(own context and a team of %d host threads each)" % (PREFETCH, E, ext_threads)) if pipeline else "off",
             "ms_each_step": each,
             "alone": alone,
             "host_cpu_ms_per_step": cpu_ms_per_step,
@@ -467,7 +496,7 @@ def main():
                 out["parity_checked"] = ours == ref_md5
                 out["parity"] = {"records_md5": ours, "reference_output_md5": ref_md5, "lines": text.count("\n")}
         print(json.dumps(out))
-    for c in ctxs + (ctxs_seed if pipeline else []):
+    for c in [x for cs in ext_ctxs for x in cs] + (ctxs_seed if pipeline else []):
         c.close()
     if world > 1:
         dist.destroy_process_group()
