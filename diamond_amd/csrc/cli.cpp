@@ -389,7 +389,7 @@ int run_blastp(const Options& o)
 	std::vector<std::string> read_ids;
 	std::vector<std::vector<int8_t>> reads;
 	// --outfmt (output/output_format.cpp:178-200): 6 / tab with optional field names, 0 / pairwise
-	enum { FMT_TAB, FMT_FIELDS, FMT_PAIRWISE, FMT_PAF } fmt = FMT_TAB;
+	enum { FMT_TAB, FMT_FIELDS, FMT_PAIRWISE, FMT_PAF, FMT_SAM } fmt = FMT_TAB;
 	std::vector<int32_t> field_ids;
 	int need_transcripts = 0;
 	if (!o.outfmt.empty()) {
@@ -412,7 +412,12 @@ int run_blastp(const Options& o)
 			if (o.outfmt.size() > 1) throw std::runtime_error("Invalid output format: the PAF format takes no fields");
 			fmt = FMT_PAF;
 		}
-		else throw std::runtime_error("Invalid output format: " + f0 + " (this build prints 6 = BLAST tabular, 0 = BLAST pairwise and 103 = PAF)");
+		else if (f0 == "101" || f0 == "sam") {
+			if (o.outfmt.size() > 1) throw std::runtime_error("Invalid output format: the SAM format takes no fields");
+			fmt = FMT_SAM;
+			need_transcripts = 1;
+		}
+		else throw std::runtime_error("Invalid output format: " + f0 + " (this build prints 6 = BLAST tabular, 0 = BLAST pairwise, 101 = SAM and 103 = PAF)");
 	}
 	bool want_full_sseq = false;
 	for (int32_t id : field_ids) want_full_sseq |= id == DMND_F_FULL_SSEQ;
@@ -527,6 +532,9 @@ int run_blastp(const Options& o)
 	FILE* out = o.out.empty() ? stdout : std::fopen(o.out.c_str(), "w");
 	if (!out) throw std::runtime_error("Error opening file " + o.out);
 	if (fmt == FMT_PAIRWISE) std::fputs("BLASTP 2.3.0+\n\n\n", out);                   // PairwiseFormat::print_header
+	if (fmt == FMT_SAM)                                                                // SamFormat::print_header (program name and version are ours)
+		std::fprintf(out, "@HD\tVN:1.5\tSO:query\n@PG\tPN:diamond-hip\tVN:ABI%d\n@mm\t%s\n@CO\t%s-like alignments\n@CO\tReporting AS: bitScore, ZR: rawScore, ZE: expected, ZI: percent identity, "
+			"ZL: reference length, ZF: frame, ZS: query start DNA coordinate\n", dmnd_abi_version(), blastx ? "BlastX" : "BlastP", blastx ? "BlastX" : "BlastP");
 	const std::vector<std::string>& qtitles = blastx ? read_ids : q_all.ids;
 	std::vector<std::string> qid(qtitles.size()), tid(n_targets);
 	for (size_t i = 0; i < qid.size(); ++i) qid[i] = short_id(qtitles[i]);
@@ -662,18 +670,20 @@ int run_blastp(const Options& o)
 		// The pairwise and PAF formats also report queries without alignments, in query order (DEFAULT_REPORT_UNALIGNED): with one
 		// reference block only those that had seed hits (a query without any is skipped before the output stage, align/align.cpp:173-176,
 		// align/output.cpp:35-53), with several blocks every one (output/join_blocks.cpp:302-308,365-372).
-		for (size_t qi = qr.begin; qi < qr.end && (fmt == FMT_PAIRWISE || fmt == FMT_PAF); ++qi) {
+		for (size_t qi = qr.begin; qi < qr.end && (fmt == FMT_PAIRWISE || fmt == FMT_PAF || fmt == FMT_SAM); ++qi) {
 			const bool has = i < n_matches && joined[(size_t)i].query == (uint32_t)qi;
 			if (!has && t_blocks.size() == 1 && !seeded[qi - qr.begin]) continue;
 			const int32_t qlen = blastx ? source_len[qi] : (int32_t)(q_all.limits[qi + 1] - q_all.limits[qi] - 1);
 			big.resize(qtitles[qi].size() + 256);
 			if (fmt == FMT_PAIRWISE) put(dmnd_format_pairwise_intro(qtitles[qi].c_str(), qlen, has ? 0 : 1, big.data(), (int64_t)big.size()), big.data());
-			else if (!has) put(dmnd_format_paf(nullptr, qtitles[qi].c_str(), big.data(), (int64_t)big.size()), big.data());
+			else if (!has) put(fmt == FMT_SAM ? dmnd_format_sam(nullptr, qtitles[qi].c_str(), big.data(), (int64_t)big.size())
+				: dmnd_format_paf(nullptr, qtitles[qi].c_str(), big.data(), (int64_t)big.size()), big.data());
 			for (; i < n_matches && joined[(size_t)i].query == (uint32_t)qi; ++i) {
 				const dmnd_match& m = joined[(size_t)i];
 				const dmnd_hsp_view v = view_of(m);
 				big.resize((size_t)m.hsp.length * 8 + std::strlen(v.qtitle) + std::strlen(v.stitle) + 4096);
 				if (fmt == FMT_PAIRWISE) put(dmnd_format_pairwise(&v, p.matrix8, big.data(), (int64_t)big.size()), big.data());
+				else if (fmt == FMT_SAM) put(dmnd_format_sam(&v, nullptr, big.data(), (int64_t)big.size()), big.data());
 				else put(dmnd_format_paf(&v, nullptr, big.data(), (int64_t)big.size()), big.data());
 			}
 			if (has) ++aligned;

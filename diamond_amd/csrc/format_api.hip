@@ -139,6 +139,22 @@ int need_transcript(int id)
 	}
 }
 
+// print_cigar (sam_format.cpp:67-84): runs of M (match + substitution), I, D
+void print_cigar(Out& o, const dmnd_hsp_view& v)
+{
+	static const int map[4] = { 0, 1, 2, 0 };
+	static const char letter[3] = { 'M', 'I', 'D' };
+	unsigned n = 0;
+	int op = 0;
+	const uint8_t* t = v.transcript;
+	for (int i = 0; i < v.match->hsp.transcript_len; ++i) {
+		const int o2 = t[i] >> 6, cnt = (o2 == OP_MATCH || o2 == OP_INSERTION) ? (t[i] & 63) : 1;
+		if (map[o2] == op) n += (unsigned)cnt;
+		else { if (n > 0) { o << n << letter[op]; } n = (unsigned)cnt; op = map[o2]; }
+	}
+	if (n > 0) o << n << letter[op];
+}
+
 int print_field(Out& o, const dmnd_hsp_view& v, int id)
 {
 	const dmnd_match& m = *v.match;
@@ -207,21 +223,7 @@ int print_field(Out& o, const dmnd_hsp_view& v, int id)
 	case DMND_F_QSEQ_GAPPED: for (Walk w(v); w.good(); w.next()) o << w.query_char(); break;
 	case DMND_F_SSEQ_GAPPED: for (Walk w(v); w.good(); w.next()) o << w.subject_char(); break;
 	case DMND_F_QSTRAND: o << (f.translated ? (f.blast_frame() > 0 ? '+' : '-') : '+'); break;
-	case DMND_F_CIGAR: {
-		// print_cigar: runs of M (match + substitution), I, D
-		static const int map[4] = { 0, 1, 2, 0 };
-		static const char letter[3] = { 'M', 'I', 'D' };
-		unsigned n = 0;
-		int op = 0;
-		const uint8_t* t = v.transcript;
-		for (int i = 0; i < h.transcript_len; ++i) {
-			const int o2 = t[i] >> 6, cnt = (o2 == OP_MATCH || o2 == OP_INSERTION) ? (t[i] & 63) : 1;
-			if (map[o2] == op) n += (unsigned)cnt;
-			else { if (n > 0) { o << n << letter[op]; } n = (unsigned)cnt; op = map[o2]; }
-		}
-		if (n > 0) o << n << letter[op];
-		break;
-	}
+	case DMND_F_CIGAR: print_cigar(o, v); break;
 	case DMND_F_QSEQ_TRANSLATED: for (int i = h.q_begin; i < h.q_end; ++i) o << AA[v.qseq[i] & 31]; break;
 	case DMND_F_HSPNUM: o << 0; break;                      // max_hsps = 1
 	default: return fail(DMND_E_ARG, "dmnd_format_fields: unknown field id");
@@ -353,4 +355,55 @@ extern "C" int64_t dmnd_format_paf(const dmnd_hsp_view* v, const char* unaligned
 	o.print_e(m.evalue);
 	o << '\n';
 	return emit(o, buf, cap, "dmnd_format_paf");
+}
+
+extern "C" int64_t dmnd_format_sam(const dmnd_hsp_view* v, const char* unaligned_qtitle, char* buf, int64_t cap)
+{
+	if (!buf || (!v && !unaligned_qtitle)) return fail(DMND_E_ARG, "dmnd_format_sam: bad argument");
+	Out o;
+	if (!v) {
+		o.until(unaligned_qtitle, ID_DELIMITERS);
+		o << "\t4\t*\t0\t255\t*\t*\t0\t0\t*\t*\n";
+		return emit(o, buf, cap, "dmnd_format_sam");
+	}
+	if (!view_ok(v)) return fail(DMND_E_ARG, "dmnd_format_sam: bad argument");
+	if (!v->transcript) return fail(DMND_E_ARG, "dmnd_format_sam: the SAM format needs the transcript");
+	const dmnd_match& m = *v->match;
+	const dmnd_hsp& h = m.hsp;
+	const Frame f(*v);
+	int sb, se;
+	source_range(*v, sb, se);
+	o.until(v->qtitle, ID_DELIMITERS);
+	o << '\t' << '0' << '\t';
+	print_title(o, v->stitle, false, false, "<>");
+	o << '\t' << h.s_begin + 1 << '\t' << "255" << '\t';
+	print_cigar(o, *v);
+	o << '\t' << '*' << '\t' << '0' << '\t' << '0' << '\t';
+	for (int i = h.q_begin; i < h.q_end; ++i) o << AA[v->qseq[i] & 31];
+	o << '\t' << '*' << '\t' << "AS:i:" << (long long)(uint32_t)m.bit_score << '\t' << "NM:i:" << h.length - h.identities << '\t' << "ZL:i:" << v->slen << '\t'
+		<< "ZR:i:" << h.score << '\t' << "ZE:f:";
+	o.print_e(m.evalue);
+	// ZF = Frame::signed_frame (1 for untranslated queries), ZS = oriented_query_range().begin_ + 1
+	o << '\t' << "ZI:i:" << h.identities * 100 / h.length << '\t' << "ZF:i:" << (f.forward ? f.offset + 1 : -(f.offset + 1)) << '\t'
+		<< "ZS:i:" << (f.translated ? (f.forward ? sb + 1 : se) : h.q_begin + 1) << '\t' << "MD:Z:";
+	// print_md (sam_format.cpp:30-65)
+	unsigned matches = 0, del = 0;
+	for (int i = 0; i < h.transcript_len; ++i) {
+		const int op = v->transcript[i] >> 6, arg = v->transcript[i] & 63;
+		if (op == OP_MATCH) { del = 0; matches += (unsigned)arg; }
+		else if (op == OP_SUBSTITUTION) {
+			if (matches > 0) { o << matches; matches = 0; }
+			else if (del > 0) { o << '0'; del = 0; }
+			o << AA[arg & 31];
+		}
+		else if (op == OP_DELETION) {
+			if (matches > 0) { o << matches; matches = 0; }
+			if (del == 0) o << '^';
+			o << AA[arg & 31];
+			++del;
+		}
+	}
+	if (matches > 0) o << matches;
+	o << '\n';
+	return emit(o, buf, cap, "dmnd_format_sam");
 }

@@ -397,6 +397,9 @@ int64_t dmnd_format_pairwise(const dmnd_hsp_view* v, const int8_t* matrix8, char
 /* PAF (`-f paf` / 103, src/output/paf_format.cpp:24-66): one line per HSP; v == NULL prints the line of an unaligned query
  * (qtitle given), which this format reports by default. */
 int64_t dmnd_format_paf(const dmnd_hsp_view* v, const char* unaligned_qtitle, char* buf, int64_t cap);
+/* SAM (`-f sam` / 101, src/output/sam_format.cpp:30-133): one alignment line per HSP (CIGAR, MD:Z and the reference's Z? tags);
+ * v == NULL prints the line of an unaligned query (flag 4), which this format reports by default. The @HD/@PG header is the caller's. */
+int64_t dmnd_format_sam(const dmnd_hsp_view* v, const char* unaligned_qtitle, char* buf, int64_t cap);
 
 /* -- timing hooks for bench.py: device time of the DP kernels of the last dmnd_banded_swipe call,
  *    measured with HIP events on the stream the kernels ran on ------------------------------------ */
