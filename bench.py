@@ -186,7 +186,7 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="C2")
     ap.add_argument("--queries", type=int, default=None, help="default: the config's (10000; C5: 100000)")
     ap.add_argument("--families", type=int, default=None, help="protein families of 10 members in the database (default 100000; C5: 500000)")
-    ap.add_argument("--host-threads", type=int, default=12, help="host threads of the extension stage, divided among the extension contexts")
+    ap.add_argument("--host-threads", type=int, default=None, help="host threads of the extension stage per rank, divided among the extension contexts (default 12, fewer per rank with several ranks)")
     ap.add_argument("--shard", choices=["db", "query"], default="db")
     ap.add_argument("--ext-contexts", type=int, default=3, help="batches extended concurrently (each on its own context and host thread team)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -212,7 +212,9 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     coll_device = torch.device("cpu") if share_gpu else device
     assert world == args.gpus or world == 1
-    threads = max(1, args.host_threads)
+    # every rank of a database-sharded run extends 1/N of the seed hits: its host part needs correspondingly fewer threads, and N
+    # ranks share the node's cores
+    threads = max(1, args.host_threads) if args.host_threads else (12 if world == 1 else max(3, 24 // world))
 
     if args.queries is None:
         args.queries = CONFIGS[args.config].get("queries", 10_000)
