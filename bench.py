@@ -351,6 +351,10 @@ def main():
             retire()
         return each, queue
 
+    # set-up, not warm-up: the first call of a context allocates its device buffers and trace arenas (tens to hundreds of ms);
+    # the W warm-up steps only reach the first W of the E extension contexts, so the others are primed here
+    for e in range(1, E):
+        extend_batch(e, [seed_stage(b) for b in range(NB)])
     queue = [seed_pool.submit(seed_stage, b) for _ in range(PREFETCH) for b in range(NB)] if pipeline else []
     _, queue = run(args.warmup, queue)
     for f in queue:
