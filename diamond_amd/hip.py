@@ -360,6 +360,22 @@ def join_blocks(records, max_target_seqs=25):
     return r[:n.value]
 
 
+def join_blocks_top(records, top_percent):
+    """The block join of a --top run (dmnd_join_blocks_top): score order, targets within top_percent of a query's best bit score."""
+    lib = load()
+    r = np.ascontiguousarray(records, dtype=MATCH_DTYPE).copy()
+    n = ctypes.c_int64(0)
+    lib.dmnd_join_blocks_top.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_double, ctypes.POINTER(ctypes.c_int64)]
+    if lib.dmnd_join_blocks_top(r.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(r.size), float(top_percent), ctypes.byref(n)) != 0:
+        raise DiamondHipError(lib.dmnd_last_error().decode())
+    return r[:n.value]
+
+
+def format_sam(match, transcript, qtitle, stitle, qseq, slen, **kw):
+    view = _View(match, transcript, qtitle, stitle, qseq, slen, **kw)
+    return _formatted(load().dmnd_format_sam, ctypes.byref(view.v), None)
+
+
 def seed_params_sensitive(scoring, threads=1):
     """--sensitive seed configuration (16 shapes of weight 8, ungapped e-value filter 10000); pair with set_gapped_filter(1.0)."""
     p = SeedParams()

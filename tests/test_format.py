@@ -77,10 +77,10 @@ def test_every_field_of_the_reference_output_is_reproduced():
     assert n > 600
 
 
-def test_pairwise_and_paf_files_are_reproduced():
+def test_pairwise_paf_and_sam_files_are_reproduced():
     p = hip.default_params()
     M = np.array(p.matrix8, dtype=np.int8)
-    pw, paf, last = ["BLASTP 2.3.0+\n\n\n"], [], None
+    pw, paf, sam, last = ["BLASTP 2.3.0+\n\n\n"], [], [], None
     for line, f, m, tr in records():
         if f["qtitle"] != last:
             pw.append(hip.format_pairwise_intro(f["qtitle"], int(f["qlen"])))
@@ -88,8 +88,10 @@ def test_pairwise_and_paf_files_are_reproduced():
         q = letters(f["full_qseq"])
         pw.append(hip.format_pairwise(m, tr, f["qtitle"], f["stitle"], q, int(f["slen"]), M))
         paf.append(hip.format_paf(m, f["qtitle"], f["stitle"], q, int(f["slen"])))
+        sam.append(hip.format_sam(m, tr, f["qtitle"], f["stitle"], q, int(f["slen"])))
     assert "".join(pw) == gzip.open(os.path.join(HERE, "golden", "pairwise_k4.out.gz"), "rt").read()
     assert "".join(paf) == gzip.open(os.path.join(HERE, "golden", "paf_k4.out.gz"), "rt").read()
+    assert "".join(sam) == gzip.open(os.path.join(HERE, "golden", "sam_k4.body.gz"), "rt").read()
 
 
 def test_field_names_are_checked_like_the_reference():

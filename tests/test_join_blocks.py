@@ -53,3 +53,27 @@ def test_join_blocks_edge_cases():
     r["hsp"]["score"] = [50, 40, 50]
     out = hip.join_blocks(r, 1)
     assert [(int(x["query"]), int(x["target"])) for x in out] == [(0, 9), (2, 1)]
+
+
+def test_join_blocks_top_keeps_the_bit_score_window():
+    """--top: records of a query over all blocks in (score descending, target ascending) order, kept while
+    (1 - bit score / best bit score) * 100 <= percent (GlobalCulling, output/target_culling.h:62-63)."""
+    rng = np.random.default_rng(12)
+    blocks = _block_records(rng, 40, 4, 300)
+    rec = np.concatenate(blocks)
+    rec["bit_score"] = 0.39 * rec["hsp"]["score"] + 3.1            # any increasing map of the score
+    for pct in (0.0, 5.0, 30.0, 100.0):
+        got = hip.join_blocks_top(rec[::-1], pct)
+        want = []
+        for q in range(40):
+            mine = sorted(((-int(r["hsp"]["score"]), int(r["target"]), float(r["bit_score"])) for r in rec[rec["query"] == q]))
+            if not mine:
+                continue
+            top = mine[0][2]
+            for negs, t, bits in mine:
+                if (1.0 - bits / top) * 100.0 <= pct:
+                    want.append((q, t, -negs))
+                else:
+                    break
+        assert [(int(r["query"]), int(r["target"]), int(r["hsp"]["score"])) for r in got] == want, pct
+    assert len(hip.join_blocks_top(rec, 100.0)) == len(rec)
