@@ -162,3 +162,29 @@ def test_seed_stage_c1_scale_against_oracle_and_properties(ctx):
     qloc = ql[hits["query"]] + hits["seed_offset"]
     assert (red[qd[qloc[:, None] + pos[None, :]] & 31] == red[td[hits["subject"][:, None] + pos[None, :]] & 31]).all()
     assert (qloc + 16 <= ql[hits["query"] + 1] - 1).all()
+
+
+@pytest.mark.parametrize("tap", ["ext_sensitive.tap", "ext_hashed_sens.tap"])
+def test_fused_short_seed_pipeline_equals_the_list_based_one_and_survives_small_buffers(ctx, tap, monkeypatch):
+    """Short seeds (weight < 10) take the per-shape pipeline with the Hamming filter fused into the reference stream. Same sorted
+    hit list as the list-based path (DMND_SEED_FUSED=0) and as the reference's hits; joined-position, survivor and hit buffers that
+    start too small (test hooks) grow -- the hit buffer keeping the hits of the earlier shapes."""
+    cfg, recs = read_ext_tap(os.path.join(GOLDEN, tap))
+    enc = 1 if "hashed" in tap else 0
+    ctx.upload_block(hip.QUERY, cfg["query"]["data"], cfg["query"]["limits"])
+    ctx.upload_block(hip.TARGET, cfg["target"]["data"], cfg["target"]["limits"])
+    p = to_hip_params(dict(cfg, seed_encoding=enc))
+    fused = ctx.seed_search(p)
+    ref = np.concatenate([r["hits"] for r in recs])
+    assert len(fused) == len(ref) and hit_multiset(fused) == hit_multiset(ref)
+    monkeypatch.setenv("DMND_SEED_FUSED", "0")
+    assert np.array_equal(ctx.seed_search(p), fused)
+    monkeypatch.delenv("DMND_SEED_FUSED")
+    for env in ({"DMND_SEED_MATCHED_CAP": "7"}, {"DMND_SEED_SURVIVOR_CAP": "3"}, {"DMND_SEED_HIT_CAP": "5"},
+                {"DMND_SEED_MATCHED_CAP": "100", "DMND_SEED_SURVIVOR_CAP": "10", "DMND_SEED_HIT_CAP": "40"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got = ctx.seed_search(p)
+        for k in env:
+            monkeypatch.delenv(k)
+        assert np.array_equal(got, fused), env
