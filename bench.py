@@ -414,7 +414,7 @@ def main():
         out = {
             "metric": "GCUPS + aligned queries/s, %s, %d queries vs %d-seq DB (seed stage + banded SW extension)" % (w.cfg["what"], w.n_queries, w.n_db),
             "value": cells_swept * args.steps / dt / 1e9, "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "int16", "data": "synthetic",
             "aligned_queries_per_s": aligned * args.steps / dt,
             "reference_equivalent_gcups": (r1_cells + r2_cells) * args.steps / dt / 1e9,
