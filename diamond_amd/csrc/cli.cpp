@@ -273,6 +273,8 @@ struct Options {
 	std::vector<std::string> outfmt;   // -f / --outfmt: format, then field names
 	int gpus = 1;                   // --gpus: the reference blocks are spread over this many MI355X of the node
 	double top = -1.0;              // --top PERCENT
+	int unal = -1;                  // --unal: report queries without alignments (-1 = the format's default)
+	std::string header;             // --header [simple|verbose|0]
 	double min_id = 0, query_cover = 0, subject_cover = 0, min_score = 0;      // --id, --query-cover, --subject-cover, --min-score
 };
 
@@ -307,6 +309,12 @@ Options parse(int argc, char** argv)
 		else if (a == "--query-cover") o.query_cover = std::atof(need(i).c_str());
 		else if (a == "--subject-cover") o.subject_cover = std::atof(need(i).c_str());
 		else if (a == "--min-score") o.min_score = std::atof(need(i).c_str());
+		else if (a == "--unal") { o.unal = std::atoi(need(i).c_str()); if (o.unal != 0 && o.unal != 1) throw std::runtime_error("Permitted values for --unal: 0, 1"); }
+		else if (a == "--header") {
+			o.header = "verbose";
+			if (i + 1 < n_args && !args[(size_t)i + 1].empty() && args[(size_t)i + 1][0] != '-') o.header = args[(size_t)++i];
+			if (o.header != "0" && o.header != "simple" && o.header != "verbose") throw std::runtime_error("Invalid header format: " + o.header);
+		}
 		else if (a == "--top") { o.top = std::atof(need(i).c_str()); if (o.top < 0.0 || o.top > 100.0) throw std::runtime_error("Invalid value for --top."); }
 		else if (a == "--gpus") { o.gpus = std::atoi(need(i).c_str()); if (o.gpus < 1) throw std::runtime_error("Invalid number of GPUs."); }
 		else if (a == "-b" || a == "--block-size") { o.block_size = std::atof(need(i).c_str()); if (o.block_size <= 0.0) throw std::runtime_error("Invalid block size."); }
@@ -419,6 +427,17 @@ int run_blastp(const Options& o)
 		}
 		else throw std::runtime_error("Invalid output format: " + f0 + " (this build prints 6 = BLAST tabular, 0 = BLAST pairwise, 101 = SAM and 103 = PAF)");
 	}
+	// --unal / --header work on the field list: the default columns are a field list too
+	const bool tab_extras = o.unal == 1 || (!o.header.empty() && o.header != "0");
+	if (fmt == FMT_TAB && tab_extras) {
+		static const char* const std_fields[12] = { "qseqid", "sseqid", "pident", "length", "mismatch", "gapopen", "qstart", "qend", "sstart", "send", "evalue", "bitscore" };
+		field_ids.resize(12);
+		if (dmnd_output_fields(std_fields, 12, field_ids.data(), &need_transcripts) != DMND_OK) throw std::runtime_error(dmnd_last_error());
+		fmt = FMT_FIELDS;
+	}
+	if (tab_extras && fmt != FMT_FIELDS && !o.header.empty() && o.header != "0") throw std::runtime_error("--header is only available for the tabular format");
+	// which formats report queries without alignments: pairwise, PAF and SAM by default (DEFAULT_REPORT_UNALIGNED), tabular with --unal 1
+	const bool report_unal = o.unal == 1 || (o.unal == -1 && (fmt == FMT_PAIRWISE || fmt == FMT_PAF || fmt == FMT_SAM));
 	bool want_full_sseq = false;
 	for (int32_t id : field_ids) want_full_sseq |= id == DMND_F_FULL_SSEQ;
 	auto t0 = std::chrono::steady_clock::now();
@@ -532,6 +551,18 @@ int run_blastp(const Options& o)
 	FILE* out = o.out.empty() ? stdout : std::fopen(o.out.c_str(), "w");
 	if (!out) throw std::runtime_error("Error opening file " + o.out);
 	if (fmt == FMT_PAIRWISE) std::fputs("BLASTP 2.3.0+\n\n\n", out);                   // PairwiseFormat::print_header
+	if (fmt == FMT_FIELDS && o.header == "simple") {
+		std::vector<char> hb(4096);
+		const int64_t w = dmnd_format_fields_header(field_ids.data(), (int)field_ids.size(), hb.data(), (int64_t)hb.size());
+		if (w < 0) throw std::runtime_error(dmnd_last_error());
+		std::fwrite(hb.data(), 1, (size_t)w, out);
+	}
+	if (fmt == FMT_FIELDS && o.header == "verbose") {       // TabularFormat::print_header (program name and command line are ours)
+		std::fprintf(out, "# diamond-hip (ABI %d). MI355X back end of DIAMOND's seed-and-extend path\n# Fields: ", dmnd_abi_version());
+		for (size_t i = 1; i < o.outfmt.size(); ++i) std::fprintf(out, "%s%s", i > 1 ? ", " : "", o.outfmt[i].c_str());
+		if (o.outfmt.size() <= 1) std::fputs("qseqid, sseqid, pident, length, mismatch, gapopen, qstart, qend, sstart, send, evalue, bitscore", out);
+		std::fputc('\n', out);
+	}
 	if (fmt == FMT_SAM)                                                                // SamFormat::print_header (program name and version are ours)
 		std::fprintf(out, "@HD\tVN:1.5\tSO:query\n@PG\tPN:diamond-hip\tVN:ABI%d\n@mm\t%s\n@CO\t%s-like alignments\n@CO\tReporting AS: bitScore, ZR: rawScore, ZE: expected, ZI: percent identity, "
 			"ZL: reference length, ZF: frame, ZS: query start DNA coordinate\n", dmnd_abi_version(), blastx ? "BlastX" : "BlastP", blastx ? "BlastX" : "BlastP");
@@ -572,6 +603,7 @@ int run_blastp(const Options& o)
 			if (tantan) chk(dmnd_mask_block(ctx, DMND_QUERY, g == 0 ? q.data.data() : nullptr, &mq));
 			const double mk = ms_since(t0);
 			if (motifs) chk(dmnd_soft_mask_block(ctx, DMND_QUERY, &ml));
+			if (blastx) chk(dmnd_set_query_source_lengths(ctx, source_len.data() + qr.begin, (int64_t)(qr.end - qr.begin)));
 			std::lock_guard<std::mutex> lock(merge_mutex);
 			ms_upload += up; ms_mask += mk;
 			if (g == 0) { mq_total += mq; motif_letters += ml; }
@@ -670,12 +702,20 @@ int run_blastp(const Options& o)
 		// The pairwise and PAF formats also report queries without alignments, in query order (DEFAULT_REPORT_UNALIGNED): with one
 		// reference block only those that had seed hits (a query without any is skipped before the output stage, align/align.cpp:173-176,
 		// align/output.cpp:35-53), with several blocks every one (output/join_blocks.cpp:302-308,365-372).
-		for (size_t qi = qr.begin; qi < qr.end && (fmt == FMT_PAIRWISE || fmt == FMT_PAF || fmt == FMT_SAM); ++qi) {
+		const bool per_query = fmt == FMT_PAIRWISE || fmt == FMT_PAF || fmt == FMT_SAM || (fmt == FMT_FIELDS && report_unal);
+		for (size_t qi = qr.begin; qi < qr.end && per_query; ++qi) {
 			const bool has = i < n_matches && joined[(size_t)i].query == (uint32_t)qi;
-			if (!has && t_blocks.size() == 1 && !seeded[qi - qr.begin]) continue;
+			if (!has && (!report_unal || (t_blocks.size() == 1 && !seeded[qi - qr.begin]))) continue;
 			const int32_t qlen = blastx ? source_len[qi] : (int32_t)(q_all.limits[qi + 1] - q_all.limits[qi] - 1);
 			big.resize(qtitles[qi].size() + 256);
 			if (fmt == FMT_PAIRWISE) put(dmnd_format_pairwise_intro(qtitles[qi].c_str(), qlen, has ? 0 : 1, big.data(), (int64_t)big.size()), big.data());
+			else if (!has && fmt == FMT_FIELDS) {
+				const size_t local = (qi - qr.begin) * C;
+				const int32_t l0 = (int32_t)(q.limits[local + 1] - q.limits[local] - 1);
+				big.resize(qtitles[qi].size() * 2 + (size_t)(blastx ? source_len[qi] : l0) + 4096);
+				put(dmnd_format_fields_unaligned(qtitles[qi].c_str(), q.data.data() + q.limits[local], l0, blastx ? reads[qi].data() : nullptr, blastx ? source_len[qi] : 0,
+					field_ids.data(), (int)field_ids.size(), big.data(), (int64_t)big.size()), big.data());
+			}
 			else if (!has) put(fmt == FMT_SAM ? dmnd_format_sam(nullptr, qtitles[qi].c_str(), big.data(), (int64_t)big.size())
 				: dmnd_format_paf(nullptr, qtitles[qi].c_str(), big.data(), (int64_t)big.size()), big.data());
 			for (; i < n_matches && joined[(size_t)i].query == (uint32_t)qi; ++i) {
@@ -683,12 +723,16 @@ int run_blastp(const Options& o)
 				const dmnd_hsp_view v = view_of(m);
 				big.resize((size_t)m.hsp.length * 8 + std::strlen(v.qtitle) + std::strlen(v.stitle) + 4096);
 				if (fmt == FMT_PAIRWISE) put(dmnd_format_pairwise(&v, p.matrix8, big.data(), (int64_t)big.size()), big.data());
+				else if (fmt == FMT_FIELDS) {
+					big.resize((size_t)m.hsp.length * 4 + (size_t)v.qlen * 3 + (size_t)v.slen + std::strlen(v.qtitle) + 2 * std::strlen(v.stitle) + (size_t)v.source_len * 2 + 4096);
+					put(dmnd_format_fields(&v, field_ids.data(), (int)field_ids.size(), big.data(), (int64_t)big.size()), big.data());
+				}
 				else if (fmt == FMT_SAM) put(dmnd_format_sam(&v, nullptr, big.data(), (int64_t)big.size()), big.data());
 				else put(dmnd_format_paf(&v, nullptr, big.data(), (int64_t)big.size()), big.data());
 			}
 			if (has) ++aligned;
 		}
-		for (; i < n_matches && (fmt == FMT_TAB || fmt == FMT_FIELDS); ++i) {
+		for (; i < n_matches && !per_query; ++i) {
 			const dmnd_match& m = joined[(size_t)i];
 			if (fmt == FMT_FIELDS) {
 				const dmnd_hsp_view v = view_of(m);

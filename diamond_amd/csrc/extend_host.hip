@@ -87,6 +87,7 @@ struct HostCfg {
 	double max_evalue = 0.001;
 	double min_bit_score = 0.0;          // config.min_bit_score (--min-score): replaces the e-value cutoff (ScoreMatrix::report_cutoff)
 	double min_id = 0.0, query_cover = 0.0, subject_cover = 0.0;      // --id, --query-cover, --subject-cover (filter_hsp, culling.cpp:147-170)
+	const int32_t* source_lens = nullptr; // translated queries: DNA read length per query
 	bool have_filters() const { return min_id > 0 || query_cover > 0 || subject_cover > 0; }
 	bool reported(int score, double evalue) const { return min_bit_score != 0.0 ? evaluer->bitscore(score) >= min_bit_score : evalue <= max_evalue; }
 };
@@ -727,7 +728,7 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 					m.ungapped_score = cd.ungapped; m.d_begin = cd.d_begin; m.d_end = cd.d_end; m.frame = cd.frame; m.hsp = hsp;
 					// filter_hsp (culling.cpp:147-170): the HSP is removed, the match stays as a placeholder for the culling below
 					if (h.have_filters() && ((double)hsp.identities * 100.0 / (double)hsp.length < h.min_id
-						|| (double)(hsp.q_end - hsp.q_begin) * 100 / qlen < h.query_cover
+						|| (C == 1 ? (double)(hsp.q_end - hsp.q_begin) * 100 / qlen : (double)(3 * (hsp.q_end - hsp.q_begin)) * 100 / (h.source_lens ? h.source_lens[q] : 1)) < h.query_cover
 						|| (double)(hsp.s_end - hsp.s_begin) * 100 / tlen < h.subject_cover)) { m.evalue = DBL_MAX; m.hsp.score = 0; }
 					round.push_back(m);
 				}
@@ -816,8 +817,9 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	h.evaluer = &c->evaluer;
 	h.max_evalue = c->params.max_evalue;
 	h.min_bit_score = c->min_bit_score; h.min_id = c->min_id; h.query_cover = c->query_cover; h.subject_cover = c->subject_cover;
-	if (h.query_cover > 0 && c->query_contexts != 1)
-		return fail(DMND_E_ARG, "dmnd_extend: --query-cover of translated queries needs the read lengths, which this entry point does not take");
+	if (h.query_cover > 0 && c->query_contexts != 1 && c->source_lens.size() != (ql.size() - 1) / (size_t)c->query_contexts)
+		return fail(DMND_E_ARG, "dmnd_extend: the query cover of translated queries needs the read lengths (dmnd_set_query_source_lengths)");
+	h.source_lens = c->source_lens.empty() ? nullptr : c->source_lens.data();
 	h.ranking_block_letters = c->ranking_block_letters;
 	h.band_mode_fast = c->band_mode_fast;
 	h.contexts = c->query_contexts;
@@ -993,6 +995,14 @@ extern "C" int dmnd_set_filters(dmnd_ctx* c, double min_id, double query_cover, 
 	if (!c || min_id < 0 || min_id > 100 || query_cover < 0 || query_cover > 100 || subject_cover < 0 || subject_cover > 100 || min_bit_score < 0)
 		return fail(DMND_E_ARG, "dmnd_set_filters: bad argument");
 	c->min_id = min_id; c->query_cover = query_cover; c->subject_cover = subject_cover; c->min_bit_score = min_bit_score;
+	return DMND_OK;
+}
+
+extern "C" int dmnd_set_query_source_lengths(dmnd_ctx* c, const int32_t* lengths, int64_t n_queries)
+{
+	if (!c || n_queries < 0 || (n_queries > 0 && !lengths)) return fail(DMND_E_ARG, "dmnd_set_query_source_lengths: bad argument");
+	for (int64_t i = 0; i < n_queries; ++i) if (lengths[i] < 1) return fail(DMND_E_ARG, "dmnd_set_query_source_lengths: a read length below 1");
+	c->source_lens.assign(lengths, lengths + n_queries);
 	return DMND_OK;
 }
 

@@ -407,3 +407,45 @@ extern "C" int64_t dmnd_format_sam(const dmnd_hsp_view* v, const char* unaligned
 	o << '\n';
 	return emit(o, buf, cap, "dmnd_format_sam");
 }
+
+extern "C" int64_t dmnd_format_fields_unaligned(const char* qtitle, const int8_t* qseq, int32_t qlen, const int8_t* source_seq, int32_t source_len,
+	const int32_t* ids, int n, char* buf, int64_t cap)
+{
+	if (!qtitle || !qseq || !ids || n < 1 || !buf) return fail(DMND_E_ARG, "dmnd_format_fields_unaligned: bad argument");
+	Out o;
+	for (int i = 0; i < n; ++i) {
+		if (i) o << '\t';
+		switch (ids[i]) {
+		case DMND_F_QSEQID: o.until(qtitle, ID_DELIMITERS); break;
+		case DMND_F_QLEN: o << (source_seq ? source_len : qlen); break;
+		case DMND_F_QTITLE: o << qtitle; break;
+		case DMND_F_FULL_QSEQ:
+			if (source_seq) for (int k = 0; k < source_len; ++k) o << NT[source_seq[k] & 7];
+			else for (int k = 0; k < qlen; ++k) o << AA[qseq[k] & 31];
+			break;
+		case DMND_F_QFRAME: o << '0'; break;
+		case DMND_F_SSEQID: case DMND_F_SALLSEQID: case DMND_F_QSEQ: case DMND_F_SSEQ: case DMND_F_BTOP: case DMND_F_STITLE: case DMND_F_SALLTITLES:
+		case DMND_F_FULL_SSEQ: case DMND_F_QSEQ_GAPPED: case DMND_F_SSEQ_GAPPED: case DMND_F_QSTRAND: case DMND_F_CIGAR: case DMND_F_QSEQ_TRANSLATED:
+			o << '*'; break;
+		case DMND_F_HSPNUM: return fail(DMND_E_ARG, "Invalid output field: hspnum");       // no handler for unaligned queries in the reference either
+		default:
+			if (ids[i] < 0 || ids[i] >= DMND_F_COUNT) return fail(DMND_E_ARG, "dmnd_format_fields_unaligned: unknown field id");
+			o << "-1";
+		}
+	}
+	o << '\n';
+	return emit(o, buf, cap, "dmnd_format_fields_unaligned");
+}
+
+extern "C" int64_t dmnd_format_fields_header(const int32_t* ids, int n, char* buf, int64_t cap)
+{
+	if (!ids || n < 1 || !buf) return fail(DMND_E_ARG, "dmnd_format_fields_header: bad argument");
+	Out o;
+	for (int i = 0; i < n; ++i) {
+		if (ids[i] < 0 || ids[i] >= DMND_F_COUNT) return fail(DMND_E_ARG, "dmnd_format_fields_header: unknown field id");
+		if (i) o << '\t';
+		o << FIELD_NAMES[ids[i]];
+	}
+	o << '\n';
+	return emit(o, buf, cap, "dmnd_format_fields_header");
+}

@@ -42,8 +42,11 @@ __device__ __forceinline__ int64_t uniform64(int64_t x)
 // the item looks like one of band class P * wavefronts to the traceback kernel.
 constexpr int MULTI_MAX_WAVES = 16;
 
-template<int P, bool COORDS, bool TRACE, int STAT = STAT_NONE, bool REV = false, bool MULTI = false>
-__global__ __launch_bounds__(MULTI ? MULTI_MAX_WAVES * 64 : WAVES_PER_BLOCK * 64)
+// MAXW: the largest workgroup the instantiation is launched with, in wavefronts. The register budget of a lane halves with every
+// doubling (512 VGPRs per SIMD lane slot / wavefronts per SIMD), so the common 2- and 4-wavefront cases get their own build that
+// keeps H/E/F in registers, and only the 8- and 16-wavefront build spills.
+template<int P, bool COORDS, bool TRACE, int STAT = STAT_NONE, bool REV = false, bool MULTI = false, int MAXW = MULTI_MAX_WAVES>
+__global__ __launch_bounds__(MULTI ? MAXW * 64 : WAVES_PER_BLOCK * 64)
 void banded_swipe_kernel(SwipeArgs args)
 {
 	__shared__ int8_t matrix[32 * 32];
@@ -318,14 +321,18 @@ static hipError_t launch_multi(int P, int mode, const SwipeArgs& a, hipStream_t 
 	if (waves < 2 || waves > MULTI_MAX_WAVES || (waves & (waves - 1))) return hipErrorInvalidValue;
 	const dim3 grid((unsigned)a.n), block((unsigned)waves * 64);
 	if (std::getenv("DMND_TRACE")) std::fprintf(stderr, "banded swipe: %lld item(s) of band class %d on %d wavefronts each (mode %d)\n", (long long)a.n, P, waves, mode);
-	switch (mode) {
-	case K_SCORE: hipLaunchKernelGGL((banded_swipe_kernel<32, false, false, STAT_NONE, false, true>), grid, block, 0, stream, a); break;
-	case K_COORDS: hipLaunchKernelGGL((banded_swipe_kernel<32, true, false, STAT_NONE, false, true>), grid, block, 0, stream, a); break;
-	case K_TRACE: hipLaunchKernelGGL((banded_swipe_kernel<32, true, true, STAT_NONE, false, true>), grid, block, 0, stream, a); break;
-	case K_STATS_FWD: hipLaunchKernelGGL((banded_swipe_kernel<16, true, false, STAT_FWD, false, true>), grid, block, 0, stream, a); break;
-	case K_STATS_BWD_REV: hipLaunchKernelGGL((banded_swipe_kernel<16, true, false, STAT_BWD, true, true>), grid, block, 0, stream, a); break;
-	default: return hipErrorInvalidValue;
+#define DMND_MULTI(MAXW)                                                                                                                        \
+	switch (mode) {                                                                                                                             \
+	case K_SCORE: hipLaunchKernelGGL((banded_swipe_kernel<32, false, false, STAT_NONE, false, true, MAXW>), grid, block, 0, stream, a); break;  \
+	case K_COORDS: hipLaunchKernelGGL((banded_swipe_kernel<32, true, false, STAT_NONE, false, true, MAXW>), grid, block, 0, stream, a); break;  \
+	case K_TRACE: hipLaunchKernelGGL((banded_swipe_kernel<32, true, true, STAT_NONE, false, true, MAXW>), grid, block, 0, stream, a); break;    \
+	case K_STATS_FWD: hipLaunchKernelGGL((banded_swipe_kernel<16, true, false, STAT_FWD, false, true, MAXW>), grid, block, 0, stream, a); break; \
+	case K_STATS_BWD_REV: hipLaunchKernelGGL((banded_swipe_kernel<16, true, false, STAT_BWD, true, true, MAXW>), grid, block, 0, stream, a); break; \
+	default: return hipErrorInvalidValue;                                                                                                       \
 	}
+	if (waves <= 4) { DMND_MULTI(4) }
+	else { DMND_MULTI(MULTI_MAX_WAVES) }
+#undef DMND_MULTI
 	return hipGetLastError();
 }
 

@@ -337,6 +337,10 @@ int dmnd_set_top_percent(dmnd_ctx* ctx, double percent);
  * replaces the e-value cutoff (ScoreMatrix::report_cutoff, stats/score_matrix.cpp:234-239). Query cover is only available for
  * untranslated queries. */
 int dmnd_set_filters(dmnd_ctx* ctx, double min_id, double query_cover, double subject_cover, double min_bit_score);
+/* Translated queries: the lengths of the DNA reads of the uploaded query block (one per query = per six contexts), which the
+ * query cover of an HSP is measured against (Hsp::query_cover_percent over query_source_range). Cleared by the next upload of
+ * the query block. */
+int dmnd_set_query_source_lengths(dmnd_ctx* ctx, const int32_t* lengths, int64_t n_queries);
 int dmnd_join_blocks_top(dmnd_match* records, int64_t n, double top_percent, int64_t* n_out);
 /* -k / --max-target-seqs (default 25, src/basic/config.h:55) */
 int dmnd_set_max_target_seqs(dmnd_ctx* ctx, int k);
@@ -390,6 +394,13 @@ typedef struct {
 int dmnd_output_fields(const char* const* names, int n, int32_t* ids, int* needs_transcript);
 /* One tabular line (fields separated by tabs, newline at the end); returns the length written or DMND_E_CAP. */
 int64_t dmnd_format_fields(const dmnd_hsp_view* v, const int32_t* ids, int n, char* buf, int64_t cap);
+/* The line of a query without alignments (`--unal 1`; TabularFormat::print_query_intro, blast_tab_format.cpp:776-787): its id,
+ * length, title and sequence where a field asks for them, '*' / -1 / 0 elsewhere. full_qseq: the query letters (blastp) or the
+ * read's nucleotides (source_seq != NULL). */
+int64_t dmnd_format_fields_unaligned(const char* qtitle, const int8_t* qseq, int32_t qlen, const int8_t* source_seq, int32_t source_len,
+	const int32_t* ids, int n, char* buf, int64_t cap);
+/* `--header simple`: the field keys, tab-separated (TabularFormat::output_header). */
+int64_t dmnd_format_fields_header(const int32_t* ids, int n, char* buf, int64_t cap);
 /* BLAST pairwise: "Query= ..." block of a query (print_query_intro) and one alignment (print_match). matrix8 = the 32x32
  * substitution matrix of the scoring parameters (midline '+'). */
 int64_t dmnd_format_pairwise_intro(const char* qtitle, int32_t qlen, int unaligned, char* buf, int64_t cap);

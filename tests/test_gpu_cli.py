@@ -463,3 +463,40 @@ def test_cli_identity_cover_and_min_score_filters_match_reference(tmp_path):
             plain = ref
         else:
             assert ref != plain, extra                                    # the option matters on this input
+
+
+def test_cli_unaligned_queries_header_and_translated_query_cover(tmp_path):
+    """--unal 1 (tabular lines of queries without alignments: those that had seed hits with one reference block, all of them
+    with several), --unal 0 for the formats that report them by default, --header simple, and --query-cover for blastx (measured
+    on the DNA read) against the reference binary."""
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/diamond not built")
+    rng = np.random.default_rng(41)
+    db, doff, q, qoff = synth.generate(120, members=6, queries=150, seed=41)
+    seqs = [q[qoff[i]:qoff[i + 1]] for i in range(len(qoff) - 1)]
+    for i in range(0, len(seqs), 4):                                       # unrelated queries: most get no alignment
+        seqs[i] = rng.integers(0, 20, len(seqs[i])).astype(np.int8)
+    off = np.concatenate([[0], np.cumsum([len(x) for x in seqs])])
+    qq = np.concatenate(seqs)
+    synth.write_fasta(str(tmp_path / "db.faa"), "t", db, doff)
+    synth.write_fasta(str(tmp_path / "q.faa"), "q", qq, off)
+    dna, dna_off = synth.back_translate(qq[:off[100]], off[:101], seed=5)
+    synth.write_dna_fasta(str(tmp_path / "q.fa"), "r", dna, dna_off)
+    p = ["-q", str(tmp_path / "q.faa"), "-d", str(tmp_path / "db.faa"), "-p", "4"]
+    x = ["-q", str(tmp_path / "q.fa"), "-d", str(tmp_path / "db.faa"), "-p", "4"]
+    cases = [(["blastp"] + p + ["--unal", "1"], 150), (["blastp"] + p + ["--unal", "1", "-b0.00002", "-c1"], 150),
+             (["blastp"] + p + ["--unal", "1", "-f", "6", "qseqid", "qlen", "sseqid", "evalue", "qtitle", "full_qseq", "cigar", "qframe", "slen"], 150),
+             (["blastp"] + p + ["--unal", "0", "-f", "0"], 100), (["blastp"] + p + ["--unal", "0", "-f", "sam"], 100), (["blastp"] + p + ["--header", "simple", "-f", "6", "qseqid", "sseqid", "bitscore"], 100),
+             (["blastx"] + x + ["--unal", "1", "-f", "6", "qseqid", "qlen", "sseqid", "qstart", "qend", "full_qseq"], 60),
+             (["blastx"] + x + ["--query-cover", "70"], 20), (["blastx"] + x + ["--query-cover", "85", "--id", "60", "-k", "3"], 5)]
+    for args, min_lines in cases:
+        _run([REF] + args + ["-o", str(tmp_path / "ref.out")])
+        _run([CLI] + args + ["-o", str(tmp_path / "hip.out")])
+        want, got = open(tmp_path / "ref.out").read(), open(tmp_path / "hip.out").read()
+        if "sam" in args:
+            want, got = ("\n".join(l for l in t.splitlines() if not l.startswith("@")) for t in (want, got))
+        assert len(want.splitlines()) >= min_lines, args
+        if got != want:
+            a, b = want.splitlines(), got.splitlines()
+            k = next((i for i in range(min(len(a), len(b))) if a[i] != b[i]), min(len(a), len(b)))
+            raise AssertionError("%s: %d vs %d lines, first difference at %d: %r | %r" % (args[5:], len(a), len(b), k, a[k:k + 1], b[k:k + 1]))
