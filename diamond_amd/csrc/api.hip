@@ -224,7 +224,7 @@ extern "C" int dmnd_upload_block(dmnd_ctx* c, int which, const int8_t* data, int
 	HIP_TRY(sync_stream(c->stream));
 	c->block_len[which] = data_len;
 	c->soft_valid[which] = false;
-	if (which == DMND_QUERY) c->source_lens.clear();
+	if (which == DMND_QUERY) { c->source_lens.clear(); ++c->query_generation; }
 	c->limits[which].clear();
 	c->coarse[which].clear();
 	if (limits) {

@@ -511,6 +511,8 @@ int run_blastp(const Options& o)
 		chk(dmnd_set_query_contexts(c, blastx ? 6 : 1));
 		chk(dmnd_set_sensitivity(c, sens));
 		chk(dmnd_set_gapped_filter(c, gf_evalue));
+		// several reference blocks per GPU: the query seed index of a query block is built once and kept for all of them
+		if (t_blocks.size() > (size_t)n_gpus) chk(dmnd_set_query_index_reuse(c, 1));
 	}
 	sp.query_translated = blastx ? 1 : 0;
 	// --algo (run/double_indexed.cpp:267-300): auto = query-indexed for a query block of at most 32 Mi letters against a

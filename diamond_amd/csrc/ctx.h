@@ -122,6 +122,9 @@ struct dmnd_ctx {
 	int max_target_seqs = 25;                  // config.max_target_seqs (-k), basic/config.h:55
 	double top_percent = -1.0;                 // config.toppercent (--top); < 0 = off
 	double min_id = 0, query_cover = 0, subject_cover = 0, min_bit_score = 0;      // --id, --query-cover, --subject-cover, --min-score
+	bool reuse_query_index = false;            // dmnd_set_query_index_reuse
+	uint64_t query_generation = 0;             // bumped whenever the query block or its masks change
+	std::string qindex_signature;              // what the resident query seed index was built for (empty: nothing resident)
 	std::vector<int32_t> source_lens;          // translated queries: DNA read lengths of the query block (query cover)
 	int band_mode_fast = 1;                    // Extension::Mode::BANDED_FAST up to --sensitive, BANDED_SLOW from --more-sensitive up (align/extend.cpp:62-75)
 	std::vector<unsigned long long> seed_trace;   // DMND_TRACE: per shape Hamming survivors and deferred pairs of the last seed search

@@ -75,6 +75,7 @@ extern "C" int dmnd_soft_mask_block(dmnd_ctx* c, int which, int64_t* n_covered)
 	if (!c->block[which].p || c->limits[which].size() < 2) return fail(DMND_E_ARG, "dmnd_soft_mask_block: block must be uploaded with limits");
 	if (n_covered) *n_covered = 0;
 	c->soft_valid[which] = false;
+	if (which == DMND_QUERY) ++c->query_generation;
 	if (g_motifs.empty()) return DMND_OK;                     // no table: nothing is soft-masked (as --motif-masking 0)
 	HIP_TRY(hipSetDevice(c->device));
 	hipStream_t st = c->stream;
@@ -104,6 +105,7 @@ extern "C" int dmnd_mask_block(dmnd_ctx* c, int which, int8_t* host_data, int64_
 {
 	if (!c || (which != DMND_QUERY && which != DMND_TARGET)) return fail(DMND_E_ARG, "dmnd_mask_block: bad argument");
 	c->soft_valid[which] = false;
+	if (which == DMND_QUERY) ++c->query_generation;
 	if (!c->block[which].p || c->limits[which].size() < 2) return fail(DMND_E_ARG, "dmnd_mask_block: block must be uploaded with limits");
 	HIP_TRY(hipSetDevice(c->device));
 	hipStream_t st = c->stream;

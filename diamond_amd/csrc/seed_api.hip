@@ -207,6 +207,14 @@ extern "C" int dmnd_auto_query_indexed(const dmnd_seed_params* params, const int
 	return DMND_OK;
 }
 
+extern "C" int dmnd_set_query_index_reuse(dmnd_ctx* c, int on)
+{
+	if (!c) return fail(DMND_E_ARG, "dmnd_set_query_index_reuse: ctx is NULL");
+	c->reuse_query_index = on != 0;
+	c->qindex_signature.clear();
+	return DMND_OK;
+}
+
 extern "C" int dmnd_seed_kernel_ms(const dmnd_ctx* c, double ms[5])
 {
 	if (!c || !ms) return fail(DMND_E_ARG, "dmnd_seed_kernel_ms: bad argument");
@@ -286,10 +294,23 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	// (64 shapes of --ultra-sensitive would otherwise hold 8 GB of tables for a 10k-query block)
 	bool fused = seed_stream_can_fuse(sp);
 	if (const char* e = getenv("DMND_SEED_FUSED")) fused = fused && atoi(e) != 0;
-	const int SB = fused ? 1 : S;                        // shapes that own buffers at the same time
+	// Query index reuse (dmnd_set_query_index_reuse; a query block against many reference blocks): the tables, lists and bitmaps of
+	// ALL shapes stay resident between calls and a call that finds them built for the same query block and parameters only resets
+	// the per-block state (join / erase marks) instead of rebuilding them. Needs S buffer sets; refused above 64 GiB.
+	const size_t set_bytes = slots * sizeof(SeedSlot) + 2 * (size_t)nq_pos * sizeof(uint32_t) + (size_t)(bm_words + bm1_words) * sizeof(uint32_t);
+	const bool reuse = c->reuse_query_index && set_bytes * (size_t)S <= ((size_t)64 << 30) && !getenv("DMND_SEED_MATCHED_CAP");
+	const int SB = (fused && !reuse) ? 1 : S;            // shapes that own buffers at the same time
 	const size_t bm_total = (size_t)SB * (bm_words + bm1_words) * sizeof(uint32_t);
+	std::string signature;
+	if (reuse) {
+		signature.assign(reinterpret_cast<const char*>(&sp), sizeof(sp));
+		const uint64_t extra[6] = { c->query_generation, (uint64_t)nq_pos, slots, bm_words, bm1_words, (uint64_t)fused };
+		signature.append(reinterpret_cast<const char*>(extra), sizeof(extra));
+	}
+	const bool index_ready = reuse && c->qindex_signature == signature && !signature.empty();
+	c->qindex_signature.clear();                         // set again when this call has built (or kept) a complete index
 	if (int rc = c->seed_bitmap.ensure(bm_total)) return rc;
-	HIP_TRY(hipMemsetAsync(c->seed_bitmap.p, 0, bm_total, st));
+	if (!index_ready) HIP_TRY(hipMemsetAsync(c->seed_bitmap.p, 0, bm_total, st));
 	if (int rc = c->qid_of.ensure((size_t)q_end * sizeof(uint32_t))) return rc;
 	if (int rc = c->mask_time.ensure((size_t)c->block_len[DMND_QUERY] + 256)) return rc;
 	if (int rc = c->seed_keys.ensure((size_t)SB * slots * sizeof(SeedSlot))) return rc;
@@ -297,14 +318,14 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	if (int rc = c->seed_next.ensure((size_t)SB * nq_pos * sizeof(uint32_t))) return rc;        // qslot
 	if (int rc = c->seed_qlist.ensure((size_t)SB * nq_pos * sizeof(uint32_t))) return rc;
 	if (int rc = c->seed_qkeys.ensure((size_t)nq_pos * sizeof(uint32_t))) return rc;
-	HIP_TRY(hipMemsetAsync(c->seed_next.p, 0xff, (size_t)SB * nq_pos * sizeof(uint32_t), st));
+	if (!index_ready) HIP_TRY(hipMemsetAsync(c->seed_next.p, 0xff, (size_t)SB * nq_pos * sizeof(uint32_t), st));
 	if (int rc = c->counters.ensure((size_t)(S + 5) * sizeof(unsigned long long))) return rc;      // [S] hits, [S+1] deferred pairs, [S+2] collected positions, [S+3] Hamming survivors, [S+4] scored survivors
 	HIP_TRY(hipMemsetAsync(c->mask_time.p, SEED_NEVER, (size_t)c->block_len[DMND_QUERY] + 256, st));
-	HIP_TRY(hipMemsetAsync(c->seed_keys.p, 0xff, (size_t)SB * slots * sizeof(SeedSlot), st));
+	if (!index_ready) HIP_TRY(hipMemsetAsync(c->seed_keys.p, 0xff, (size_t)SB * slots * sizeof(SeedSlot), st));
 	HIP_TRY(launch_seed_qid(c->d_limits[DMND_QUERY].as<int64_t>(), (int64_t)ql.size() - 1, c->qid_of.as<uint32_t>(), st));
 
 	auto args_for = [&](int sid, int64_t matched_cap, int64_t matched_off) {
-		const int own = fused ? 0 : sid;                   // which of the SB buffer sets the shape uses
+		const int own = SB == 1 ? 0 : sid;                 // which of the SB buffer sets the shape uses
 		SeedArgs a;
 		a.params = sp;
 		a.qdata = c->block[DMND_QUERY].as<int8_t>(); a.tdata = c->block[DMND_TARGET].as<int8_t>();
@@ -340,6 +361,15 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 
 	Timer tm(st);
 	for (int i = 0; i < 5; ++i) c->seed_ms[i] = 0;
+	// the query side of one shape: built (table, position lists, bitmaps), or -- kept from an earlier call -- its marks reset
+	auto query_side = [&](const SeedArgs& a, int sid, bool build) -> int {
+		if (build) {
+			HIP_TRY(launch_seed_index(a, sid, st));
+			HIP_TRY(launch_seed_lists(a, sid, c->seed_qkeys.as<uint32_t>(), c->seed_qlist.as<uint32_t>() + (size_t)(SB == 1 ? 0 : sid) * nq_pos, 32, &c->sort_tmp, &c->sort_tmp_bytes, st));
+		}
+		else HIP_TRY(launch_seed_reset(a, sid, st));
+		return DMND_OK;
+	};
 	if (c->soft_valid[DMND_QUERY]) {
 		SeedArgs a = args_for(0, 0, 0);
 		HIP_TRY(launch_seed_soft_time(a, st));
@@ -364,13 +394,12 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		for (int sid = 0; sid < S; ++sid) {
 			SeedArgs a = args_for(sid, 0, 0);
 			tm.start();
-			if (sid > 0) {                                   // the previous shape's table, slots-of-positions and bitmaps
+			if (sid > 0 && SB == 1) {                        // the previous shape's table, slots-of-positions and bitmaps
 				HIP_TRY(hipMemsetAsync(c->seed_keys.p, 0xff, (size_t)slots * sizeof(SeedSlot), st));
 				HIP_TRY(hipMemsetAsync(c->seed_next.p, 0xff, (size_t)nq_pos * sizeof(uint32_t), st));
 				HIP_TRY(hipMemsetAsync(c->seed_bitmap.p, 0, bm_total, st));
 			}
-			HIP_TRY(launch_seed_index(a, sid, st));
-			HIP_TRY(launch_seed_lists(a, sid, c->seed_qkeys.as<uint32_t>(), c->seed_qlist.as<uint32_t>(), 32, &c->sort_tmp, &c->sort_tmp_bytes, st));
+			if (int rc = query_side(a, sid, !index_ready)) return rc;
 			c->seed_ms[0] += tm.stop();
 			unsigned long long n = 0, ns = 0;
 			for (int attempt = 0;; ++attempt) {
@@ -466,8 +495,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 			// after an overflow the remaining shapes only count (capacity 0): a negative capacity would pass the kernels' unsigned bound test
 			SeedArgs a = args_for(sid, std::max<int64_t>(cap_total - off, 0), std::min(off, cap_total));
 			tm.start();
-			HIP_TRY(launch_seed_index(a, sid, st));
-			HIP_TRY(launch_seed_lists(a, sid, c->seed_qkeys.as<uint32_t>(), c->seed_qlist.as<uint32_t>() + (size_t)sid * nq_pos, 32, &c->sort_tmp, &c->sort_tmp_bytes, st));
+			if (int rc = query_side(a, sid, !index_ready || attempt > 0)) return rc;
 			c->seed_ms[0] += tm.stop();
 			tm.start();
 			HIP_TRY(launch_seed_stream(a, sid, st));
@@ -583,6 +611,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		if (def_overflow) def_cap = (int64_t)def_max + 1024;
 	}
 	}
+	if (reuse) c->qindex_signature = signature;          // every shape's query side is complete and resident
 	// order the hits by (query, subject, seed_offset, score) on the device: what align_queries needs (hits grouped by query),
 	// made deterministic (the append order of the kernels is not)
 	if (c->n_seed_hits > 0) {

@@ -74,6 +74,9 @@ hipError_t launch_seed_soft_time(const SeedArgs& a, hipStream_t st);
 hipError_t launch_seed_lists(const SeedArgs& a, int sid, uint32_t* sorted_slot, uint32_t* qlist_out, int slot_bits, void** tmp, size_t* tmp_bytes, hipStream_t st);
 // fused = true (short seeds, where a third of the reference positions join): the stream kernel also runs the Hamming filter on
 // every joined pair while the reference letters are at hand, and fills a.survivors; a.matched_* then only serve the deferred pass
+// a table kept from an earlier search of the same query block: clears the per-reference-block marks (joined, erased) of every slot
+// and, for hashed seeds, repeats the masking of the non-complex query seeds that the index kernel does at enumeration
+hipError_t launch_seed_reset(const SeedArgs& a, int sid, hipStream_t st);
 hipError_t launch_seed_stream(const SeedArgs& a, int sid, hipStream_t st, bool fused = false);
 bool seed_stream_can_fuse(const SeedParams& c);
 // n_matched >= 0: the number of joined positions in a.matched_* (few of them: the kernel walks that list instead of the table)

@@ -59,6 +59,26 @@ __global__ void seed_index_kernel(SeedArgs a, int sid)
 	a.qslot[p - a.q_begin] = (uint32_t)slot;            // the per-seed position lists are built by a sort on this (seed_lists_kernel)
 }
 
+__global__ void seed_reset_slots_kernel(SeedArgs a)
+{
+	const uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (slot > a.slot_mask) return;
+	const SeedSlot sl = a.slots[slot];
+	if (sl.key == SEED_EMPTY || !(sl.flags & (SLOT_JOINED | SLOT_ERASED))) return;
+	a.slots[slot].flags = sl.flags & ~(uint32_t)(SLOT_JOINED | SLOT_ERASED);
+}
+
+// hashed seeds: the part of seed_index_kernel that masks non-complex query seeds, without the insertion
+__global__ void seed_hashed_lowc_kernel(SeedArgs a, int sid)
+{
+	const int64_t p = a.q_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= a.q_end) return;
+	uint64_t seed;
+	if (!seed_key_at(a.params, sid, a.qseed + p, seed) || seed_is_complex(a.params, sid, a.qseed + p)) return;
+	const uint8_t t = (uint8_t)(sid * a.params.index_chunks);
+	if (t < a.mask_time[p]) a.mask_time[p] = t;
+}
+
 // Motif soft masking on the query side: the seed positions whose window of shape sid (clipped at the end of the sequence)
 // touches a soft-masked letter carry the SEED_MASK bit from the first index chunk of that shape on (MaskingTable::remove with
 // template_len = the shape's length, after the query seeds of (shape, chunk 0) were enumerated: enum_seeds.h:255-260)
@@ -818,6 +838,14 @@ hipError_t launch_seed_qid(const int64_t* limits, int64_t n_seqs, uint32_t* qid_
 hipError_t launch_seed_soft_time(const SeedArgs& a, hipStream_t st)
 {
 	hipLaunchKernelGGL(seed_soft_time_kernel, dim3(blocks_for(a.q_end - a.q_begin, 256)), dim3(256), 0, st, a);
+	return hipGetLastError();
+}
+
+hipError_t launch_seed_reset(const SeedArgs& a, int sid, hipStream_t st)
+{
+	hipLaunchKernelGGL(seed_reset_slots_kernel, dim3(blocks_for((int64_t)a.slot_mask + 1, 256)), dim3(256), 0, st, a);
+	if (a.params.seed_encoding == SEED_HASHED)
+		hipLaunchKernelGGL(seed_hashed_lowc_kernel, dim3(blocks_for(a.q_end - a.q_begin, 256)), dim3(256), 0, st, a, sid);
 	return hipGetLastError();
 }
 

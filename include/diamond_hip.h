@@ -209,6 +209,11 @@ int dmnd_seed_params_default(dmnd_seed_params* p, int threads, const dmnd_params
  * spaced seeds, ungapped e-value filter off (the --fast family). Hits stay in device memory;
  * *n_hits returns their number. */
 int dmnd_seed_search(dmnd_ctx* ctx, const dmnd_seed_params* params, int64_t* n_hits);
+/* One query block against many reference blocks: with reuse on, dmnd_seed_search keeps the query side of every shape (seed table,
+ * position lists, bitmaps) in HBM and a later call on the same query block and parameters only resets the per-reference-block
+ * marks instead of indexing the queries again (the reference rebuilds its query seed arrays for every block pair). Off by default;
+ * results are identical either way. */
+int dmnd_set_query_index_reuse(dmnd_ctx* ctx, int on);
 /* Copies the hits of the last dmnd_seed_search to the caller, sorted by (query, subject, seed_offset)
  * (the reference sorts by query before extension, align/align.cpp:233). cap < n -> DMND_E_CAP. */
 int dmnd_seed_hits(dmnd_ctx* ctx, dmnd_seed_hit* out, int64_t cap);

@@ -188,3 +188,64 @@ def test_fused_short_seed_pipeline_equals_the_list_based_one_and_survives_small_
         for k in env:
             monkeypatch.delenv(k)
         assert np.array_equal(got, fused), env
+
+
+@pytest.mark.parametrize("mode,hashed", [("fast", 0), ("default", 0), ("sensitive", 0), ("sensitive", 1), ("fast", 1)])
+def test_query_index_reuse_over_reference_blocks(mode, hashed):
+    """One query block against three reference blocks with dmnd_set_query_index_reuse: the kept index gives the same hits as a
+    fresh context per block pair; re-uploading or masking the query block, or other seed parameters, rebuild it."""
+    from diamond_amd import synth
+    db, doff, q, qoff = synth.generate(300, members=6, queries=200, seed=77)
+    rng = np.random.default_rng(5)
+    for a, off in ((db, doff), (q, qoff)):                         # low-complexity stretches: masked seeds, erased groups
+        for i in range(0, len(off) - 1, 9):
+            b, e = int(off[i]), int(off[i + 1])
+            if e - b > 60:
+                p = int(rng.integers(b, e - 30))
+                a[p:p + 24] = np.tile(np.array([int(rng.integers(0, 20)), int(rng.integers(0, 20))], np.int8), 12)
+    qd, ql = _blocks(q, qoff)
+    cuts = [0, 500, 1100, len(doff) - 1]
+    tblocks = [_blocks(db[doff[a]:doff[b]], doff[a:b + 1] - doff[a]) for a, b in zip(cuts, cuts[1:])]
+    params = hip.default_params()
+    sp, _ = hip.seed_params_preset(mode, params, threads=4)
+    if hashed:
+        hip.set_query_indexed(sp, threads=4)
+
+    def fresh(td, tl, qdata=qd):
+        c = hip.Context(params=params)
+        try:
+            c.upload_block(hip.QUERY, qdata, ql)
+            c.upload_block(hip.TARGET, td, tl)
+            return c.seed_search(sp)
+        finally:
+            c.close()
+
+    c = hip.Context(params=params)
+    try:
+        c.set_query_index_reuse(True)
+        c.upload_block(hip.QUERY, qd, ql)
+        n_hits = 0
+        for rep in range(2):                                        # second round: every call finds the index ready
+            for td, tl in tblocks:
+                c.upload_block(hip.TARGET, td, tl)
+                got = c.seed_search(sp)
+                assert np.array_equal(got, fresh(td, tl))
+                n_hits += len(got)
+        assert n_hits > 200
+        # the query block changes: the kept index must not be used
+        q2 = qd.copy()
+        q2[ql[3]:ql[3] + 40] = 23
+        c.upload_block(hip.QUERY, q2, ql)
+        c.upload_block(hip.TARGET, *tblocks[0])
+        assert np.array_equal(c.seed_search(sp), fresh(*tblocks[0], qdata=q2))
+        # other parameters
+        sp2, _ = hip.seed_params_preset("default" if mode != "default" else "fast", params, threads=4)
+        c2 = hip.Context(params=params)
+        c2.upload_block(hip.QUERY, q2, ql)
+        c2.upload_block(hip.TARGET, *tblocks[0])
+        want2 = c2.seed_search(sp2)
+        c2.close()
+        assert np.array_equal(c.seed_search(sp2), want2)
+        assert np.array_equal(c.seed_search(sp), fresh(*tblocks[0], qdata=q2))
+    finally:
+        c.close()
