@@ -19,6 +19,7 @@
 #include <cstring>
 #include <fstream>
 #include <functional>
+#include <future>
 #include <iostream>
 #include <mutex>
 #include <thread>
@@ -172,52 +173,106 @@ bool is_dmnd(const std::string& path)
 	return f && m == DMND_MAGIC;
 }
 
-// whole file into memory with one read (a seek + read per sequence made loading a 1M-sequence database 0.9 s of a 1.2 s run)
-std::vector<char> slurp(const std::string& path)
-{
-	std::ifstream f(path, std::ios::binary | std::ios::ate);
-	if (!f) throw std::runtime_error("Error opening file " + path);
-	const std::streamoff n = f.tellg();
-	std::vector<char> buf((size_t)n);
-	f.seekg(0);
-	if (n > 0 && !f.read(buf.data(), n)) throw std::runtime_error("Error reading file " + path);
-	return buf;
-}
+SeqBlock slice(const SeqBlock& all, size_t begin, size_t end);
 
-void read_dmnd(const std::string& path, SeqBlock& b)
-{
-	const std::vector<char> file = slurp(path);
-	auto rd = [&](size_t off, void* dst, size_t n) { if (off + n > file.size()) throw std::runtime_error("Truncated DIAMOND database."); std::memcpy(dst, file.data() + off, n); };
-	uint64_t magic, sequences, letters, pos_array_offset; uint32_t build, version;
-	rd(0, &magic, 8); rd(8, &build, 4); rd(12, &version, 4); rd(16, &sequences, 8); rd(24, &letters, 8); rd(32, &pos_array_offset, 8);
-	if (magic != DMND_MAGIC) throw std::runtime_error("Database file is not a DIAMOND database.");
-	if (version < 2 || version > 3) throw std::runtime_error("Unsupported DIAMOND database version (protein databases of format 2-3 only).");
-	if (pos_array_offset + (sequences + 1) * 16 > file.size()) throw std::runtime_error("Truncated DIAMOND database.");
-	b.begin();
-	b.data.reserve(256 + (size_t)letters + (size_t)sequences + 256);
-	b.limits.reserve((size_t)sequences + 1);
-	b.ids.reserve((size_t)sequences);
-	const char* pa = file.data() + pos_array_offset;
-	for (uint64_t i = 0; i < sequences; ++i) {
-		uint64_t pos; uint32_t len;
-		std::memcpy(&pos, pa + 16 * i, 8); std::memcpy(&len, pa + 16 * i + 8, 4);
-		// record: 0xFF letters 0xFF id 0
-		if (pos + (uint64_t)len + 3 > file.size()) throw std::runtime_error("Truncated DIAMOND database.");
-		const size_t at = b.data.size();
-		b.data.resize(at + len + 1);
-		int8_t* dst = b.data.data() + at;
-		const char* src = file.data() + pos + 1;
-		// the reference's makedb stores its SEG soft mask in bit 7 (src/legacy/dmnd/dmnd.cpp:262-265); with masking off
-		// the search ignores it (Sequence::operator[] & LETTER_MASK), so it is dropped at load time
-		for (uint32_t k = 0; k < len; ++k) dst[k] = (int8_t)(src[k] & 31);
-		dst[len] = 31;
-		b.limits.push_back((int64_t)b.data.size());
-		const char* id = file.data() + pos + len + 2;
-		b.ids.emplace_back(id, strnlen(id, file.size() - (pos + len + 2)));
-		b.letters += len;
+// The reference database as the block loop sees it. A .dmnd file is NOT read into memory as a whole: the header and the position
+// array give every sequence's length and file offset, a reference block is the byte range of its records (one read, parsed into the
+// SequenceSet layout), and the next block of a GPU's share is read by a helper thread while the current one is searched -- host
+// memory holds two blocks per GPU instead of the database (.dmnd streaming). Titles and unmasked sequences of the
+// reported targets are read on demand. A FASTA database is parsed once and sliced.
+struct Database {
+	bool dmnd = false;
+	std::string path;
+	SeqBlock all;                               // FASTA input
+	std::vector<uint64_t> pos;                  // .dmnd: record offsets, n + 1 (the last = position array offset)
+	std::vector<uint32_t> len;
+	size_t n = 0;
+	int64_t letters = 0;
+	mutable std::mutex mtx;
+	mutable std::vector<std::string> title_cache;
+	mutable std::vector<char> have_title;
+
+	void open(const std::string& p)
+	{
+		path = p;
+		dmnd = is_dmnd(p);
+		if (!dmnd) { read_fasta(p, all); n = all.ids.size(); letters = all.letters; return; }
+		std::ifstream f(p, std::ios::binary);
+		if (!f) throw std::runtime_error("Error opening file " + p);
+		uint64_t magic, sequences, let, pos_array_offset; uint32_t build, version;
+		f.read((char*)&magic, 8); f.read((char*)&build, 4); f.read((char*)&version, 4);
+		f.read((char*)&sequences, 8); f.read((char*)&let, 8); f.read((char*)&pos_array_offset, 8);
+		if (!f || magic != DMND_MAGIC) throw std::runtime_error("Database file is not a DIAMOND database.");
+		if (version < 2 || version > 3) throw std::runtime_error("Unsupported DIAMOND database version (protein databases of format 2-3 only).");
+		n = (size_t)sequences; letters = (int64_t)let;
+		std::vector<char> pa((n + 1) * 16);
+		f.seekg((std::streamoff)pos_array_offset);
+		if (!f.read(pa.data(), (std::streamsize)pa.size())) throw std::runtime_error("Truncated DIAMOND database.");
+		pos.resize(n + 1); len.resize(n + 1);
+		for (size_t i = 0; i <= n; ++i) { std::memcpy(&pos[i], pa.data() + 16 * i, 8); std::memcpy(&len[i], pa.data() + 16 * i + 8, 4); }
+		title_cache.resize(n); have_title.assign(n, 0);
 	}
-	b.finish();
-}
+	int64_t length(size_t i) const { return dmnd ? (int64_t)len[i] : all.limits[i + 1] - all.limits[i] - 1; }
+	// sequences [begin, end) as a block of their own (SequenceSet layout with its padding)
+	SeqBlock load(size_t begin, size_t end) const
+	{
+		if (!dmnd) return slice(all, begin, end);
+		std::ifstream f(path, std::ios::binary);
+		if (!f) throw std::runtime_error("Error opening file " + path);
+		const uint64_t b0 = pos[begin], b1 = pos[end];
+		std::vector<char> raw((size_t)(b1 - b0));
+		f.seekg((std::streamoff)b0);
+		if (b1 > b0 && !f.read(raw.data(), (std::streamsize)raw.size())) throw std::runtime_error("Truncated DIAMOND database.");
+		SeqBlock b;
+		b.begin();
+		int64_t total = 0;
+		for (size_t i = begin; i < end; ++i) total += len[i];
+		b.data.reserve(256 + (size_t)total + (end - begin) + 256);
+		b.limits.reserve(end - begin + 1);
+		for (size_t i = begin; i < end; ++i) {
+			const uint64_t at = pos[i] - b0;
+			if (at + len[i] + 3 > raw.size()) throw std::runtime_error("Truncated DIAMOND database.");
+			const size_t o = b.data.size();
+			b.data.resize(o + len[i] + 1);
+			int8_t* dst = b.data.data() + o;
+			const char* src = raw.data() + at + 1;             // record: 0xFF letters 0xFF id 0
+			// the reference's makedb stores its SEG soft mask in bit 7 (src/legacy/dmnd/dmnd.cpp:262-265); with masking off
+			// the search ignores it (Sequence::operator[] & LETTER_MASK), so it is dropped at load time
+			for (uint32_t k = 0; k < len[i]; ++k) dst[k] = (int8_t)(src[k] & 31);
+			dst[len[i]] = 31;
+			b.limits.push_back((int64_t)b.data.size());
+		}
+		b.letters = total;
+		b.finish();
+		return b;
+	}
+	const std::string& title(size_t i) const
+	{
+		if (!dmnd) return all.ids[i];
+		std::lock_guard<std::mutex> lock(mtx);
+		if (!have_title[i]) {
+			std::ifstream f(path, std::ios::binary);
+			const uint64_t at = pos[i] + (uint64_t)len[i] + 2, sz = pos[i + 1] - at;
+			std::string t((size_t)sz, 0);
+			f.seekg((std::streamoff)at);
+			if (sz && !f.read(&t[0], (std::streamsize)sz)) throw std::runtime_error("Truncated DIAMOND database.");
+			t.resize(std::strlen(t.c_str()));
+			title_cache[i] = t; have_title[i] = 1;
+		}
+		return title_cache[i];
+	}
+	// the letters of sequence i as stored (full_sseq)
+	std::vector<int8_t> sequence(size_t i) const
+	{
+		if (!dmnd) return std::vector<int8_t>(all.data.begin() + all.limits[i], all.data.begin() + all.limits[i + 1] - 1);
+		std::ifstream f(path, std::ios::binary);
+		std::vector<int8_t> s(len[i]);
+		f.seekg((std::streamoff)(pos[i] + 1));
+		if (len[i] && !f.read((char*)s.data(), (std::streamsize)len[i])) throw std::runtime_error("Truncated DIAMOND database.");
+		for (int8_t& l : s) l &= 31;
+		return s;
+	}
+};
 
 void write_dmnd(const std::string& path, const SeqBlock& b)
 {
@@ -390,7 +445,7 @@ int run_blastp(const Options& o)
 	if (o.command == "blastp" && o.query_cover >= 50 && o.query_cover == o.subject_cover)
 		throw std::runtime_error("--query-cover equal to --subject-cover (>= 50) selects the reference's mutual-coverage search, which is not part of this build; use different values");
 	const auto t_all = std::chrono::steady_clock::now();
-	SeqBlock q_all, t_all_seqs;
+	SeqBlock q_all;
 	const bool blastx = o.command == "blastx";
 	const size_t C = blastx ? 6 : 1;
 	std::vector<int32_t> source_len;
@@ -445,11 +500,10 @@ int run_blastp(const Options& o)
 	else read_fasta(o.query, q_all);
 	std::string dbpath = o.db;
 	if (!std::ifstream(dbpath).good() && std::ifstream(dbpath + ".dmnd").good()) dbpath += ".dmnd";
-	if (is_dmnd(dbpath)) read_dmnd(dbpath, t_all_seqs); else read_fasta(dbpath, t_all_seqs);
-	const size_t n_queries = q_all.ids.size() / C, n_targets = t_all_seqs.ids.size();
-	std::vector<int8_t> t_unmasked;                        // full_sseq prints the target as it was loaded (Block::unmasked_seqs)
-	if (want_full_sseq) t_unmasked = t_all_seqs.data;
-	std::cerr << "Loading sequences...  [" << ms_since(t0) / 1e3 << "s]  queries=" << n_queries << " targets=" << n_targets << " letters=" << t_all_seqs.letters << "\n";
+	Database db;
+	db.open(dbpath);
+	const size_t n_queries = q_all.ids.size() / C, n_targets = db.n;
+	std::cerr << "Loading sequences...  [" << ms_since(t0) / 1e3 << "s]  queries=" << n_queries << " targets=" << n_targets << " letters=" << db.letters << "\n";
 	const int sens = o.fast ? DMND_SENS_FAST : o.sens == "--mid-sensitive" ? DMND_SENS_MID_SENSITIVE : o.sens == "--sensitive" ? DMND_SENS_SENSITIVE
 		: o.sens == "--more-sensitive" ? DMND_SENS_MORE_SENSITIVE : o.sens == "--very-sensitive" ? DMND_SENS_VERY_SENSITIVE
 		: o.sens == "--ultra-sensitive" ? DMND_SENS_ULTRA_SENSITIVE : DMND_SENS_DEFAULT;
@@ -457,7 +511,7 @@ int run_blastp(const Options& o)
 	const double b_opt = o.block_size > 0.0 ? o.block_size : (sens >= DMND_SENS_VERY_SENSITIVE ? 0.4 : 2.0);
 	const int64_t max_letters = (int64_t)(b_opt * 1e9);
 	std::vector<int64_t> q_units(n_queries), t_units(n_targets);
-	for (size_t i = 0; i < n_targets; ++i) t_units[i] = t_all_seqs.limits[i + 1] - t_all_seqs.limits[i] - 1;
+	for (size_t i = 0; i < n_targets; ++i) t_units[i] = db.length(i);
 	for (size_t i = 0; i < n_queries; ++i) {
 		if (!blastx) { q_units[i] = q_all.limits[i + 1] - q_all.limits[i] - 1; continue; }
 		// Block::push_back counts the letters of the ORFs that survive find_orfs (data/block/block.cpp:88-100)
@@ -483,14 +537,14 @@ int run_blastp(const Options& o)
 		if (n_gpus > have) throw std::runtime_error("--gpus " + std::to_string(n_gpus) + ": only " + std::to_string(have) + " gfx950 device(s) visible");
 	}
 	int64_t t_max_letters = max_letters;
-	if (n_gpus > 1) t_max_letters = std::min<int64_t>(max_letters, (t_all_seqs.letters + n_gpus - 1) / n_gpus);
+	if (n_gpus > 1) t_max_letters = std::min<int64_t>(max_letters, (db.letters + n_gpus - 1) / n_gpus);
 	const std::vector<Range> q_blocks = split_blocks(q_units, max_letters), t_blocks = split_blocks(t_units, t_max_letters);
 	if (q_blocks.size() > 1 || t_blocks.size() > 1)
 		std::cerr << "Block size = " << max_letters << "  query blocks=" << q_blocks.size() << " reference blocks=" << t_blocks.size() << "\n";
 
 	dmnd_params p;
 	dmnd_default_params(&p);
-	p.db_letters = (double)t_all_seqs.letters;
+	p.db_letters = (double)db.letters;
 	p.max_evalue = o.evalue;
 	auto chk = [&](int rc) { if (rc != DMND_OK) throw std::runtime_error(dmnd_last_error()); };
 	const int threads = o.threads > 0 ? o.threads : 8;
@@ -569,15 +623,16 @@ int run_blastp(const Options& o)
 		std::fprintf(out, "@HD\tVN:1.5\tSO:query\n@PG\tPN:diamond-hip\tVN:ABI%d\n@mm\t%s\n@CO\t%s-like alignments\n@CO\tReporting AS: bitScore, ZR: rawScore, ZE: expected, ZI: percent identity, "
 			"ZL: reference length, ZF: frame, ZS: query start DNA coordinate\n", dmnd_abi_version(), blastx ? "BlastX" : "BlastP", blastx ? "BlastX" : "BlastP");
 	const std::vector<std::string>& qtitles = blastx ? read_ids : q_all.ids;
-	std::vector<std::string> qid(qtitles.size()), tid(n_targets);
+	std::vector<std::string> qid(qtitles.size());
 	for (size_t i = 0; i < qid.size(); ++i) qid[i] = short_id(qtitles[i]);
-	for (size_t i = 0; i < tid.size(); ++i) tid[i] = short_id(t_all_seqs.ids[i]);
 	double ms_upload = 0, ms_mask = 0, ms_seed = 0, ms_ext = 0;       // summed over the GPUs' host threads
 	int64_t motif_letters = 0;
 	int64_t total_hits = 0, total_matches = 0, aligned = 0, mq_total = 0, mt_total = 0;
 	char line[8192];
 	std::mutex merge_mutex;
 	std::vector<std::vector<int8_t>> t_masked((size_t)n_gpus);      // lazily masked copy of the reference block at hand (query-indexed algorithm)
+	struct Held { SeqBlock block; size_t index = (size_t)-1; };
+	std::vector<Held> held_blocks((size_t)n_gpus);                  // the reference block every GPU's thread holds in host memory
 	// f(g) on one host thread per GPU; the first error is rethrown on the calling thread
 	auto on_each_gpu = [&](const std::function<void(int)>& f) {
 		if (n_gpus == 1) { f(0); return; }
@@ -615,12 +670,20 @@ int run_blastp(const Options& o)
 		std::vector<char> seeded(qr.end - qr.begin, 0);       // queries with at least one seed hit (what the unaligned report depends on)
 		on_each_gpu([&](int g) {
 		dmnd_ctx* ctx = ctxs[(size_t)g];
+		Held& held = held_blocks[(size_t)g];
+		std::future<SeqBlock> next;                           // the GPU's next reference block, read while this one is searched
 		for (size_t bi = (size_t)g; bi < t_blocks.size(); bi += (size_t)n_gpus) {
 			const Range& tr = t_blocks[bi];
-			// the reference re-reads and re-masks every reference block for every query block (run/double_indexed.cpp:404-470)
-			SeqBlock t_own;
-			if (t_blocks.size() > 1) t_own = slice(t_all_seqs, tr.begin, tr.end);
-			SeqBlock& t = t_blocks.size() > 1 ? t_own : t_all_seqs;
+			// the reference re-reads and re-masks every reference block for every query block (run/double_indexed.cpp:404-470); a
+			// GPU that has one block keeps it (masked) from one query block to the next
+			const bool fresh = held.index != bi;             // just read: unmasked
+			if (fresh) {
+				held.block = next.valid() ? next.get() : db.load(tr.begin, tr.end);
+				held.index = bi;
+			}
+			const size_t bn = bi + (size_t)n_gpus;
+			if (bn < t_blocks.size()) next = std::async(std::launch::async, [&db, &t_blocks, bn] { return db.load(t_blocks[bn].begin, t_blocks[bn].end); });
+			SeqBlock& t = held.block;
 			auto t0 = std::chrono::steady_clock::now();
 			chk(dmnd_upload_block(ctx, DMND_TARGET, t.data.data(), (int64_t)t.data.size(), t.limits.data(), (int64_t)(tr.end - tr.begin)));
 			double up = ms_since(t0), mk = 0;
@@ -636,9 +699,9 @@ int run_blastp(const Options& o)
 				else chk(dmnd_mask_block(ctx, DMND_TARGET, t.data.data(), &mt));
 				mk += ms_since(t0);
 			};
-			// up-front masking: every block of a multi-block database for every query block; a single block only once (its host
-			// copy keeps the masked letters and is uploaded as it is from then on)
-			if (tantan && !lazy_masking && (t_blocks.size() > 1 || &qr == &q_blocks.front())) mask_target();
+			// up-front masking of a block that was just read; a block the GPU kept from the previous query block carries its masked
+			// letters already and is uploaded as it is
+			if (tantan && !lazy_masking && fresh) mask_target();
 			if (motifs && algo == 0) chk(dmnd_soft_mask_block(ctx, DMND_TARGET, &ml));
 			t0 = std::chrono::steady_clock::now();
 			int64_t n_hits = 0;
@@ -683,17 +746,18 @@ int run_blastp(const Options& o)
 		int64_t n_matches = (int64_t)joined.size();
 		if (t_blocks.size() > 1) chk(o.top >= 0.0 ? dmnd_join_blocks_top(joined.data(), (int64_t)joined.size(), o.top, &n_matches)
 			: dmnd_join_blocks(joined.data(), (int64_t)joined.size(), o.k, &n_matches));
+		std::vector<int8_t> full_sseq_buf;                    // the unmasked target of the line being printed (full_sseq)
 		auto view_of = [&](const dmnd_match& m) {
 			dmnd_hsp_view v;
 			const size_t ctx_id = (size_t)m.query * C + (size_t)m.frame;            // the aligned query context in the file
 			v.match = &m;
 			v.transcript = need_transcripts ? arena.data() + m.hsp.transcript_off : nullptr;
-			v.qtitle = qtitles[m.query].c_str(); v.stitle = t_all_seqs.ids[m.target].c_str();
+			v.qtitle = qtitles[m.query].c_str(); v.stitle = db.title(m.target).c_str();
 			// the query block at hand holds the letters the extension stage saw (tantan-masked in place)
 			const size_t local = ctx_id - qr.begin * C;
 			v.qseq = q.data.data() + q.limits[local]; v.qlen = (int32_t)(q.limits[local + 1] - q.limits[local] - 1);
-			v.slen = (int32_t)(t_all_seqs.limits[m.target + 1] - t_all_seqs.limits[m.target] - 1);
-			v.full_sseq = want_full_sseq ? t_unmasked.data() + t_all_seqs.limits[m.target] : nullptr;
+			v.slen = (int32_t)db.length(m.target);
+			if (want_full_sseq) { full_sseq_buf = db.sequence(m.target); v.full_sseq = full_sseq_buf.data(); } else v.full_sseq = nullptr;
 			v.source_seq = blastx ? reads[m.query].data() : nullptr; v.source_len = blastx ? source_len[m.query] : 0;
 			v.qnum = (int64_t)m.query; v.snum = (int64_t)m.target;
 			return v;
@@ -742,8 +806,8 @@ int run_blastp(const Options& o)
 				put(dmnd_format_fields(&v, field_ids.data(), (int)field_ids.size(), big.data(), (int64_t)big.size()), big.data());
 			}
 			else {
-				const int w = blastx ? dmnd_format_tab_translated(&m, qid[m.query].c_str(), tid[m.target].c_str(), source_len[m.query], line, sizeof line)
-					: dmnd_format_tab(&m, qid[m.query].c_str(), tid[m.target].c_str(), line, sizeof line);
+				const int w = blastx ? dmnd_format_tab_translated(&m, qid[m.query].c_str(), short_id(db.title(m.target)).c_str(), source_len[m.query], line, sizeof line)
+					: dmnd_format_tab(&m, qid[m.query].c_str(), short_id(db.title(m.target)).c_str(), line, sizeof line);
 				put(w, line);
 			}
 			if (i == 0 || joined[(size_t)i].query != joined[(size_t)i - 1].query) ++aligned;
