@@ -109,6 +109,11 @@ def test_cli_default_masking_matches_reference(tmp_path):
         ref = open(tmp_path / ("ref_%s.tsv" % tag)).read()
         assert len(ref.splitlines()) > 300
         assert open(tmp_path / ("hip_%s.tsv" % tag)).read() == ref, tag
+    # no parity flags at all (tantan + motif soft masking + --algo auto on both sides), every sensitivity
+    for mode in ([], ["--fast"], ["--mid-sensitive"], ["--sensitive"], ["--more-sensitive"], ["--very-sensitive"], ["--ultra-sensitive"]):
+        _run([REF, "blastp"] + mode + ["-q", str(tmp_path / "q.faa"), "-d", str(tmp_path / "db.faa"), "-o", str(tmp_path / "ref_plain.tsv"), "-p", "4"])
+        _run([CLI, "blastp"] + mode + ["-q", str(tmp_path / "q.faa"), "-d", str(tmp_path / "db.faa"), "-o", str(tmp_path / "hip_plain.tsv"), "-p", "4"])
+        assert open(tmp_path / "hip_plain.tsv").read() == open(tmp_path / "ref_plain.tsv").read(), mode
     # the reference's own choice of seed-index algorithm (AUTO picks the query-indexed path at these sizes) gives the same text
     _run([REF, "blastp", "--motif-masking", "0", "-q", str(tmp_path / "q.faa"), "-d", str(tmp_path / "db.faa"), "-o", str(tmp_path / "ref_auto.tsv"), "-p", "4"])
     assert open(tmp_path / "ref_auto.tsv").read() == open(tmp_path / "hip_default.tsv").read()
