@@ -505,3 +505,31 @@ def test_cli_unaligned_queries_header_and_translated_query_cover(tmp_path):
             a, b = want.splitlines(), got.splitlines()
             k = next((i for i in range(min(len(a), len(b))) if a[i] != b[i]), min(len(a), len(b)))
             raise AssertionError("%s: %d vs %d lines, first difference at %d: %r | %r" % (args[5:], len(a), len(b), k, a[k:k + 1], b[k:k + 1]))
+
+
+def test_cli_runs_without_any_hit_and_with_tiny_inputs(tmp_path):
+    """No seed hit at all, a query shorter than a seed, one sequence on each side: every output format finishes with the reference's
+    text (possibly empty)."""
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/diamond not built")
+    rng = np.random.default_rng(9)
+    with open(tmp_path / "q.faa", "w") as f:
+        f.write(">a first\n" + "".join("ARNDCQEGHILKMFPSTWYV"[int(x)] for x in rng.integers(0, 20, 90)) + "\n>b\nMKV\n>c\n" + "A" * 40 + "\n")
+    with open(tmp_path / "db.faa", "w") as f:
+        f.write(">t0 only target\n" + "".join("ARNDCQEGHILKMFPSTWYV"[int(x)] for x in rng.integers(0, 20, 120)) + "\n")
+    base = ["blastp", "-q", str(tmp_path / "q.faa"), "-d", str(tmp_path / "db.faa"), "-p", "2"]
+    for extra in ([], ["--unal", "1"], ["-f", "0"], ["-f", "paf"], ["-f", "sam"], ["--sensitive", "-f", "6", "qseqid", "sseqid", "cigar"], ["--top", "10"], ["--id", "30", "--unal", "1"],
+                  ["-b0.00000005", "--unal", "1"]):
+        _run([REF] + base + extra + ["-o", str(tmp_path / "ref.out")])
+        _run([CLI] + base + extra + ["-o", str(tmp_path / "hip.out")])
+        want, got = open(tmp_path / "ref.out").read(), open(tmp_path / "hip.out").read()
+        if "sam" in extra:
+            want, got = ("\n".join(l for l in t.splitlines() if not l.startswith("@")) for t in (want, got))
+        assert got == want, (extra, want[:300], got[:300])
+    # a self hit exists when the target is among the queries
+    with open(tmp_path / "db2.faa", "w") as f:
+        f.write(open(tmp_path / "q.faa").read())
+    args = ["blastp", "-q", str(tmp_path / "q.faa"), "-d", str(tmp_path / "db2.faa"), "-p", "2", "--unal", "1"]
+    _run([REF] + args + ["-o", str(tmp_path / "ref.out")])
+    _run([CLI] + args + ["-o", str(tmp_path / "hip.out")])
+    assert open(tmp_path / "hip.out").read() == open(tmp_path / "ref.out").read() != ""
