@@ -48,7 +48,7 @@ __global__ void seed_index_kernel(SeedArgs a, int sid)
 		return;
 	}
 	const uint64_t h = seed_hash(seed);
-	atomicOr(&a.bitmap[(h >> 32) & a.bitmap_mask], 1u << (h >> 59));
+	if (a.params.shape_weight[sid] >= 10) atomicOr(&a.bitmap[(h >> 32) & a.bitmap_mask], 1u << (h >> 59));      // level 2: only consulted for long seeds (launch_seed_stream)
 	atomicOr(&a.bitmap1[((uint32_t)h >> 10) & a.bitmap1_mask], (1u << (h & 31)) | (1u << ((h >> 5) & 31)));   // 2 bits, one word; bits of hash a only
 	uint64_t slot = h & a.slot_mask;
 	for (;;) {
