@@ -327,6 +327,8 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	if (!index_ready) HIP_TRY(hipMemsetAsync(c->seed_keys.p, 0xff, (size_t)SB * slots * sizeof(SeedSlot), st));
 	HIP_TRY(launch_seed_qid(c->d_limits[DMND_QUERY].as<int64_t>(), (int64_t)ql.size() - 1, c->qid_of.as<uint32_t>(), st));
 
+	static const int level2_env = [] { const char* e = getenv("DMND_SEED_LEVEL2"); return e ? atoi(e) : -1; }();
+	auto level2_of = [&](int sid) { return level2_env >= 0 ? level2_env : (sp.shape_weight[sid] >= 10 ? 1 : 0); };
 	auto args_for = [&](int sid, int64_t matched_cap, int64_t matched_off) {
 		const int own = SB == 1 ? 0 : sid;                 // which of the SB buffer sets the shape uses
 		SeedArgs a;
@@ -359,6 +361,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		a.matrix = c->matrix.as<int8_t>();
 		a.hits = c->seed_hits.as<dmnd_seed_hit>(); a.hit_count = c->counters.as<unsigned long long>() + S; a.hit_cap = 0;
 		a.fused = fused ? 1 : 0;
+		a.level2 = level2_of(sid);
 		return a;
 	};
 

@@ -62,6 +62,7 @@ struct SeedArgs {
 	const int8_t* matrix;                         // 32x32 int8 substitution matrix (HBM) for the stage-2 ungapped window score
 	// output
 	dmnd_seed_hit* hits; unsigned long long* hit_count; int64_t hit_cap;
+	int level2;                                   // the level-2 bitmap is filled and consulted (long seeds)
 	int fused;                                    // short-seed pipeline: seed_lists_kernel decides SLOT_LOWC for every group (the stream needs it)
 };
 

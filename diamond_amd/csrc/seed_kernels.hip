@@ -48,7 +48,7 @@ __global__ void seed_index_kernel(SeedArgs a, int sid)
 		return;
 	}
 	const uint64_t h = seed_hash(seed);
-	if (a.params.shape_weight[sid] >= 10) atomicOr(&a.bitmap[(h >> 32) & a.bitmap_mask], 1u << (h >> 59));      // level 2: only consulted for long seeds (launch_seed_stream)
+	if (a.level2) atomicOr(&a.bitmap[(h >> 32) & a.bitmap_mask], 1u << (h >> 59));      // level 2: only consulted for long seeds (launch_seed_stream)
 	atomicOr(&a.bitmap1[((uint32_t)h >> 10) & a.bitmap1_mask], (1u << (h & 31)) | (1u << ((h >> 5) & 31)));   // 2 bits, one word; bits of hash a only
 	uint64_t slot = h & a.slot_mask;
 	for (;;) {
@@ -899,7 +899,7 @@ hipError_t launch_seed_stream(const SeedArgs& a, int sid, hipStream_t st, bool f
 		const int64_t threads = (a.t_end - base + 15) / 16;
 		uint64_t care64 = 0;
 		for (int k = 0; k < c.shape_weight[sid]; ++k) care64 |= (uint64_t)15 << (4 * c.shape_pos[sid][k]);
-		const bool level2 = c.shape_weight[sid] >= 10, hashed = c.seed_encoding == SEED_HASHED;
+		const bool level2 = a.level2 != 0, hashed = c.seed_encoding == SEED_HASHED;
 		const dim3 grid(blocks_for(threads, 256)), block(256);
 		if (fused && hashed) hipLaunchKernelGGL((seed_stream_fast_kernel<false, true, true>), grid, block, 0, st, a, sid, lo, hi, base, care64);
 		else if (fused) hipLaunchKernelGGL((seed_stream_fast_kernel<false, false, true>), grid, block, 0, st, a, sid, lo, hi, base, care64);
