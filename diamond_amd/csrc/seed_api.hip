@@ -327,6 +327,14 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	if (!index_ready) HIP_TRY(hipMemsetAsync(c->seed_keys.p, 0xff, (size_t)SB * slots * sizeof(SeedSlot), st));
 	HIP_TRY(launch_seed_qid(c->d_limits[DMND_QUERY].as<int64_t>(), (int64_t)ql.size() - 1, c->qid_of.as<uint32_t>(), st));
 
+	// fused pipeline: 4-bit copy of the query block for the Hamming pre-filter (DMND_SEED_FOLD=0 switches it off)
+	static const bool fold_env = [] { const char* e = getenv("DMND_SEED_FOLD"); return !e || atoi(e) != 0; }();
+	const bool use_fold = fused && fold_env;
+	if (use_fold) {
+		const int64_t n = c->block_len[DMND_QUERY];
+		if (int rc = c->seed_qfold.ensure((size_t)(n + 1) / 2 + 64)) return rc;
+		HIP_TRY(launch_seed_fold(c->block[DMND_QUERY].as<int8_t>(), n, c->seed_qfold.as<uint8_t>(), st));
+	}
 	static const int level2_env = [] { const char* e = getenv("DMND_SEED_LEVEL2"); return e ? atoi(e) : -1; }();
 	auto level2_of = [&](int sid) { return level2_env >= 0 ? level2_env : (sp.shape_weight[sid] >= 10 ? 1 : 0); };
 	auto args_for = [&](int sid, int64_t matched_cap, int64_t matched_off) {
@@ -362,6 +370,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		a.hits = c->seed_hits.as<dmnd_seed_hit>(); a.hit_count = c->counters.as<unsigned long long>() + S; a.hit_cap = 0;
 		a.fused = fused ? 1 : 0;
 		a.level2 = level2_of(sid);
+		a.qfold = use_fold ? c->seed_qfold.as<uint8_t>() : nullptr;
 		return a;
 	};
 

@@ -62,6 +62,7 @@ struct SeedArgs {
 	const int8_t* matrix;                         // 32x32 int8 substitution matrix (HBM) for the stage-2 ungapped window score
 	// output
 	dmnd_seed_hit* hits; unsigned long long* hit_count; int64_t hit_cap;
+	const uint8_t* qfold;                         // fused pipeline: the query block with 4 bits per letter (letter & 15), or NULL: pre-filter of the Hamming test
 	int level2;                                   // the level-2 bitmap is filled and consulted (long seeds)
 	int fused;                                    // short-seed pipeline: seed_lists_kernel decides SLOT_LOWC for every group (the stream needs it)
 };
@@ -78,6 +79,8 @@ hipError_t launch_seed_lists(const SeedArgs& a, int sid, uint32_t* sorted_slot, 
 // a table kept from an earlier search of the same query block: clears the per-reference-block marks (joined, erased) of every slot
 // and, for hashed seeds, repeats the masking of the non-complex query seeds that the index kernel does at enumeration
 hipError_t launch_seed_reset(const SeedArgs& a, int sid, hipStream_t st);
+// letters [0, n) of a block folded to 4 bits each, two per byte (out: (n + 1) / 2 bytes)
+hipError_t launch_seed_fold(const int8_t* data, int64_t n, uint8_t* out, hipStream_t st);
 hipError_t launch_seed_stream(const SeedArgs& a, int sid, hipStream_t st, bool fused = false);
 bool seed_stream_can_fuse(const SeedParams& c);
 // n_matched >= 0: the number of joined positions in a.matched_* (few of them: the kernel walks that list instead of the table)

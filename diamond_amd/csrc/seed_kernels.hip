@@ -59,6 +59,14 @@ __global__ void seed_index_kernel(SeedArgs a, int sid)
 	a.qslot[p - a.q_begin] = (uint32_t)slot;            // the per-seed position lists are built by a sort on this (seed_lists_kernel)
 }
 
+__global__ void seed_fold_kernel(const int8_t* __restrict__ data, int64_t n, uint8_t* __restrict__ out)
+{
+	const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // output byte = letters 2j, 2j + 1
+	if (2 * j >= n) return;
+	const uint32_t a = (uint32_t)data[2 * j] & 15u, b = 2 * j + 1 < n ? (uint32_t)data[2 * j + 1] & 15u : 0u;
+	out[j] = (uint8_t)(a | (b << 4));
+}
+
 __global__ void seed_reset_slots_kernel(SeedArgs a)
 {
 	const uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -232,6 +240,39 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 	auto filter_list = [&](uint32_t slot, uint32_t head, uint32_t count, int64_t pos, uint32_t first, uint32_t step) {
 		uint32_t tw[12];
 		__builtin_memcpy(tw, a.tdata + pos - 16, 48);
+		if (a.qfold) {
+			// Pre-filter on letters folded to 4 bits (letter & 15: equal letters stay equal, so the folded identity count is an upper
+			// bound of the real one): the query side is read from a 1.5 MB array with two 16-byte requests per pair instead of three
+			// from the 3 MB block, which is what this kernel is short of (L2 capacity and fabric reads); the ~2 % that pass are
+			// counted exactly on the letters.
+			uint32_t tf[6];
+#pragma unroll
+			for (int w = 0; w < 6; ++w) {
+				uint32_t lo = tw[2 * w] & 0x0f0f0f0fu, hi = tw[2 * w + 1] & 0x0f0f0f0fu;
+				lo = (lo | (lo >> 4)) & 0x00ff00ffu; lo = (lo | (lo >> 8)) & 0xffffu;
+				hi = (hi | (hi >> 4)) & 0x00ff00ffu; hi = (hi | (hi >> 8)) & 0xffffu;
+				tf[w] = lo | (hi << 16);
+			}
+			for (uint32_t i = first; i < count; i += step) {
+				const uint32_t x = count == 1 ? head : a.qlist[head + i];
+				const int64_t x0 = a.q_begin + (int64_t)x - 16;
+				uint32_t raw[8];
+				__builtin_memcpy(raw, a.qfold + (x0 >> 1), 32);
+				const uint32_t sh = (uint32_t)(x0 & 1) * 4;
+				int mism = 0;
+#pragma unroll
+				for (int w = 0; w < 6; ++w) {
+					const uint32_t qf = __builtin_amdgcn_alignbit(raw[w + 1], raw[w], sh);
+					const uint32_t d = tf[w] ^ qf;
+					mism += __builtin_popcount((((d & 0x77777777u) + 0x77777777u) | d) & 0x88888888u);
+				}
+				if (48 - mism < a.params.hamming_filter_id) continue;
+				uint32_t qw[12];
+				__builtin_memcpy(qw, a.qdata + x0, 48);
+				if (window_identity(tw, qw) >= a.params.hamming_filter_id) survive(slot, x, pos);
+			}
+			return;
+		}
 		for (uint32_t i = first; i < count; i += step) {
 			const uint32_t x = count == 1 ? head : a.qlist[head + i];
 			uint32_t qw[12];
@@ -838,6 +879,13 @@ hipError_t launch_seed_qid(const int64_t* limits, int64_t n_seqs, uint32_t* qid_
 hipError_t launch_seed_soft_time(const SeedArgs& a, hipStream_t st)
 {
 	hipLaunchKernelGGL(seed_soft_time_kernel, dim3(blocks_for(a.q_end - a.q_begin, 256)), dim3(256), 0, st, a);
+	return hipGetLastError();
+}
+
+hipError_t launch_seed_fold(const int8_t* data, int64_t n, uint8_t* out, hipStream_t st)
+{
+	if (n <= 0) return hipSuccess;
+	hipLaunchKernelGGL(seed_fold_kernel, dim3(blocks_for((n + 1) / 2, 256)), dim3(256), 0, st, data, n, out);
 	return hipGetLastError();
 }
 
