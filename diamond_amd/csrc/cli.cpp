@@ -328,6 +328,7 @@ struct Options {
 	std::vector<std::string> outfmt;   // -f / --outfmt: format, then field names
 	int gpus = 1;                   // --gpus: the reference blocks are spread over this many MI355X of the node
 	double top = -1.0;              // --top PERCENT
+	bool no_self_hits = false;      // --no-self-hits
 	int unal = -1;                  // --unal: report queries without alignments (-1 = the format's default)
 	std::string header;             // --header [simple|verbose|0]
 	double min_id = 0, query_cover = 0, subject_cover = 0, min_score = 0;      // --id, --query-cover, --subject-cover, --min-score
@@ -364,6 +365,7 @@ Options parse(int argc, char** argv)
 		else if (a == "--query-cover") o.query_cover = std::atof(need(i).c_str());
 		else if (a == "--subject-cover") o.subject_cover = std::atof(need(i).c_str());
 		else if (a == "--min-score") o.min_score = std::atof(need(i).c_str());
+		else if (a == "--no-self-hits") o.no_self_hits = true;
 		else if (a == "--unal") { o.unal = std::atoi(need(i).c_str()); if (o.unal != 0 && o.unal != 1) throw std::runtime_error("Permitted values for --unal: 0, 1"); }
 		else if (a == "--header") {
 			o.header = "verbose";
@@ -631,6 +633,9 @@ int run_blastp(const Options& o)
 	char line[8192];
 	std::mutex merge_mutex;
 	std::vector<std::vector<int8_t>> t_masked((size_t)n_gpus);      // lazily masked copy of the reference block at hand (query-indexed algorithm)
+	// --no-self-hits: the library finds query / target pairs with the same letters and asks here whether the titles agree too
+	struct SelfCtx { const std::vector<std::string>* qtitles; const Database* db; size_t q0 = 0, t0 = 0; };
+	std::vector<SelfCtx> self_ctx((size_t)n_gpus);
 	struct Held { SeqBlock block; size_t index = (size_t)-1; };
 	std::vector<Held> held_blocks((size_t)n_gpus);                  // the reference block every GPU's thread holds in host memory
 	// f(g) on one host thread per GPU; the first error is rethrown on the calling thread
@@ -711,6 +716,14 @@ int run_blastp(const Options& o)
 			const double sd = ms_since(t0);
 			if (lazy_masking) mask_target();
 			t0 = std::chrono::steady_clock::now();
+			if (o.no_self_hits) {
+				if (blastx) throw std::runtime_error("--no-self-hits is not supported for blastx");      // basic/config.cpp:677
+				self_ctx[(size_t)g] = SelfCtx{ &qtitles, &db, qr.begin, tr.begin };
+				chk(dmnd_set_no_self_hits(ctx, [](void* u, uint32_t q, uint32_t t) -> int {
+					const SelfCtx& s = *static_cast<const SelfCtx*>(u);
+					return (*s.qtitles)[s.q0 + q] == s.db->title(s.t0 + t) ? 1 : 0;
+				}, &self_ctx[(size_t)g]));
+			}
 			std::vector<dmnd_match> mine((size_t)std::max<int64_t>(n_hits, 1));
 			std::vector<uint8_t> my_arena;
 			int64_t n_matches = 0;

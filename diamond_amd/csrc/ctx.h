@@ -122,6 +122,8 @@ struct dmnd_ctx {
 	int max_target_seqs = 25;                  // config.max_target_seqs (-k), basic/config.h:55
 	double top_percent = -1.0;                 // config.toppercent (--top); < 0 = off
 	double min_id = 0, query_cover = 0, subject_cover = 0, min_bit_score = 0;      // --id, --query-cover, --subject-cover, --min-score
+	dmnd_same_title_fn same_title = nullptr;   // --no-self-hits: title comparison of the caller (dmnd_set_no_self_hits)
+	void* same_title_user = nullptr;
 	bool reuse_query_index = false;            // dmnd_set_query_index_reuse
 	uint64_t query_generation = 0;             // bumped whenever the query block or its masks change
 	std::string qindex_signature;              // what the resident query seed index was built for (empty: nothing resident)

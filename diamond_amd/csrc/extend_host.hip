@@ -730,6 +730,14 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 					if (h.have_filters() && ((double)hsp.identities * 100.0 / (double)hsp.length < h.min_id
 						|| (C == 1 ? (double)(hsp.q_end - hsp.q_begin) * 100 / qlen : (double)(3 * (hsp.q_end - hsp.q_begin)) * 100 / (h.source_lens ? h.source_lens[q] : 1)) < h.query_cover
 						|| (double)(hsp.s_end - hsp.s_begin) * 100 / tlen < h.subject_cover)) { m.evalue = DBL_MAX; m.hsp.score = 0; }
+					// --no-self-hits: same letters (Sequence::operator==, the query's first context) and same title
+					if (c->same_title && C == 1 && qlen == tlen) {
+						const int8_t* a = qdata + ql[qc];
+						const int8_t* b = tdata + tl[cd.target];
+						bool same = true;
+						for (int x = 0; x < qlen && same; ++x) same = ((a[x] ^ b[x]) & 31) == 0;
+						if (same && c->same_title(c->same_title_user, q, cd.target)) { m.evalue = DBL_MAX; m.hsp.score = 0; }
+					}
 					round.push_back(m);
 				}
 				cull(round, cc);
@@ -1003,6 +1011,13 @@ extern "C" int dmnd_set_query_source_lengths(dmnd_ctx* c, const int32_t* lengths
 	if (!c || n_queries < 0 || (n_queries > 0 && !lengths)) return fail(DMND_E_ARG, "dmnd_set_query_source_lengths: bad argument");
 	for (int64_t i = 0; i < n_queries; ++i) if (lengths[i] < 1) return fail(DMND_E_ARG, "dmnd_set_query_source_lengths: a read length below 1");
 	c->source_lens.assign(lengths, lengths + n_queries);
+	return DMND_OK;
+}
+
+extern "C" int dmnd_set_no_self_hits(dmnd_ctx* c, dmnd_same_title_fn same_title, void* user)
+{
+	if (!c) return fail(DMND_E_ARG, "dmnd_set_no_self_hits: ctx is NULL");
+	c->same_title = same_title; c->same_title_user = user;
 	return DMND_OK;
 }
 

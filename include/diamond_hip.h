@@ -346,6 +346,11 @@ int dmnd_set_filters(dmnd_ctx* ctx, double min_id, double query_cover, double su
  * query cover of an HSP is measured against (Hsp::query_cover_percent over query_source_range). Cleared by the next upload of
  * the query block. */
 int dmnd_set_query_source_lengths(dmnd_ctx* ctx, const int32_t* lengths, int64_t n_queries);
+/* --no-self-hits (filter_hsp, align/culling.cpp:166-169): an HSP is removed when the query and the target have the same letters
+ * AND the same title. The library compares the letters; `same_title` (called only for such pairs, with the block-local query and
+ * target ids of the uploaded blocks) answers for the titles. NULL switches the filter off. */
+typedef int (*dmnd_same_title_fn)(void* user, uint32_t query, uint32_t target);
+int dmnd_set_no_self_hits(dmnd_ctx* ctx, dmnd_same_title_fn same_title, void* user);
 int dmnd_join_blocks_top(dmnd_match* records, int64_t n, double top_percent, int64_t* n_out);
 /* -k / --max-target-seqs (default 25, src/basic/config.h:55) */
 int dmnd_set_max_target_seqs(dmnd_ctx* ctx, int k);

@@ -533,3 +533,31 @@ def test_cli_runs_without_any_hit_and_with_tiny_inputs(tmp_path):
     _run([REF] + args + ["-o", str(tmp_path / "ref.out")])
     _run([CLI] + args + ["-o", str(tmp_path / "hip.out")])
     assert open(tmp_path / "hip.out").read() == open(tmp_path / "ref.out").read() != ""
+
+
+def test_cli_no_self_hits_matches_reference(tmp_path):
+    """--no-self-hits on an all-against-all search of the reference's own fixture (every query is in the database under its own
+    title), also with several reference blocks and another output format; duplicates under a different title stay."""
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/diamond not built")
+    g = os.path.join(ROOT, "tests", "golden", "ref_ctest", "data.faa")
+    lines = open(g).read().splitlines()
+    with open(tmp_path / "db.faa", "w") as f:                       # + copies of the first sequences under other titles
+        f.write("\n".join(lines) + "\n")
+        k = 0
+        for i, l in enumerate(lines[:40]):
+            if l.startswith(">"):
+                f.write(">copy%d of %s\n%s\n" % (k, l[1:], lines[i + 1]))
+                k += 1
+    base = ["blastp", "-q", g, "-d", str(tmp_path / "db.faa"), "-p", "4", "--no-self-hits"]
+    plain = None
+    for extra in ([], ["-k", "3"], ["-b0.00002", "-c1"], ["-f", "6", "qseqid", "sseqid", "pident", "stitle"], ["--id", "40"]):
+        _run([REF] + base + extra + ["-o", str(tmp_path / "ref.tsv")])
+        _run([CLI] + base + extra + ["-o", str(tmp_path / "hip.tsv")])
+        ref = open(tmp_path / "ref.tsv").read()
+        assert len(ref.splitlines()) > 30, extra
+        assert open(tmp_path / "hip.tsv").read() == ref, extra
+        if not extra:
+            plain = ref
+    assert not any(l.split("\t")[0] == l.split("\t")[1] for l in plain.splitlines())       # no self hit
+    assert any(l.split("\t")[1].startswith("copy") and l.split("\t")[2] == "100" for l in plain.splitlines())      # the renamed copies are reported
