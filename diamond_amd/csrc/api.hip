@@ -23,7 +23,7 @@
 #include "host_pool.h"
 #include "swipe_kernels.h"
 #include "ctx.h"
-#include "blosum62.h"
+#include "score_matrices.h"
 
 using namespace dmnd;
 
@@ -102,18 +102,41 @@ extern "C" int dmnd_abi_version(void) { return DMND_ABI_VERSION; }
 
 extern "C" const char* dmnd_last_error(void) { return g_last_error.c_str(); }
 
+extern "C" int dmnd_matrix_params(const char* name, int gap_open, int gap_extend, dmnd_params* p)
+{
+	if (!p || !name) return fail(DMND_E_ARG, "dmnd_matrix_params: NULL argument");
+	std::string n(name);
+	for (char& ch : n) ch = (char)std::tolower((unsigned char)ch);
+	const StandardMatrixTable* m = nullptr;
+	for (int i = 0; i < N_STANDARD_MATRICES; ++i)
+		if (n == STANDARD_MATRICES[i].name) m = &STANDARD_MATRICES[i];
+	if (!m) return fail(DMND_E_ARG, std::string("Unknown scoring matrix: ") + name);
+	if (gap_open == -1) gap_open = m->default_gap_open;
+	if (gap_extend == -1) gap_extend = m->default_gap_extend;
+	const GumbelRow* g = nullptr;
+	for (int i = 1; i < m->n_rows; ++i)
+		if (m->rows[i].gap_open == gap_open && m->rows[i].gap_extend == gap_extend) g = &m->rows[i];
+	if (!g) return fail(DMND_E_ARG, "Gap penalty settings are outside the supported range for this scoring matrix.");
+	// Scores<int8_t>: the 26 letters of the table, everything else (delimiter, padding) the lowest score (score_matrix.h:35-50)
+	for (int i = 0; i < 32; ++i)
+		for (int j = 0; j < 32; ++j) {
+			int8_t v = -128;
+			if (i < 26 && j < 26) { const char ch = m->scores[i * 26 + j]; v = (int8_t)(ch >= 'a' ? ch - 'a' : -(ch - 'A' + 1)); }
+			p->matrix8[i * 32 + j] = v;
+		}
+	p->gap_open = gap_open; p->gap_extend = gap_extend;
+	p->lambda = g->lambda; p->K = g->K; p->alpha = g->alpha; p->alpha_v = g->alpha_v; p->sigma = g->sigma;
+	p->u_alpha = m->rows[0].alpha; p->u_alpha_v = m->rows[0].alpha_v;
+	return DMND_OK;
+}
+
 extern "C" int dmnd_default_params(dmnd_params* p)
 {
-	// BLOSUM62, gap open 11 / extend 1 (the reference's defaults, src/stats/score_matrix.cpp:51-52),
-	// Gumbel constants of the published NCBI table for that matrix and penalty pair.
+	// BLOSUM62, gap open 11 / extend 1 (the reference's defaults, src/stats/score_matrix.cpp:51-52)
 	if (!p) return fail(DMND_E_ARG, "params is NULL");
-	blosum62_matrix8(p->matrix8);
-	p->gap_open = 11; p->gap_extend = 1;
-	p->lambda = 0.267; p->K = 0.041; p->alpha = 1.9; p->alpha_v = 42.6028; p->sigma = 43.6362;
-	p->u_alpha = 0.7916; p->u_alpha_v = 4.96466;
 	p->db_letters = 0.0;
 	p->max_evalue = 0.001;      // config.max_evalue default, src/basic/config.cpp
-	return DMND_OK;
+	return dmnd_matrix_params("blosum62", -1, -1, p);
 }
 
 extern "C" int dmnd_device_count(void)

@@ -59,7 +59,6 @@ struct HostSeedHit { int i, j, score, frame; };
 
 // chaining constants = the reference's config defaults (basic/config.cpp:549-603)
 struct ChainCfg {
-	int xdrop = 20;                       // config.raw_ungapped_xdrop = rawscore(12.3 bits), config.cpp:428,853
 	int max_shift = 2000;                 // chaining_maxgap
 	size_t range_cover = 8;               // chaining_range_cover
 	size_t maxnodes = 0;                  // chaining_maxnodes

@@ -329,6 +329,8 @@ struct Options {
 	int gpus = 1;                   // --gpus: the reference blocks are spread over this many MI355X of the node
 	double top = -1.0;              // --top PERCENT
 	bool no_self_hits = false;      // --no-self-hits
+	std::string matrix = "blosum62";        // --matrix / --gapopen / --gapextend (-1 = the matrix's default), basic/config.cpp:256-258
+	int gap_open = -1, gap_extend = -1;
 	int unal = -1;                  // --unal: report queries without alignments (-1 = the format's default)
 	std::string header;             // --header [simple|verbose|0]
 	double min_id = 0, query_cover = 0, subject_cover = 0, min_score = 0;      // --id, --query-cover, --subject-cover, --min-score
@@ -366,6 +368,9 @@ Options parse(int argc, char** argv)
 		else if (a == "--subject-cover") o.subject_cover = std::atof(need(i).c_str());
 		else if (a == "--min-score") o.min_score = std::atof(need(i).c_str());
 		else if (a == "--no-self-hits") o.no_self_hits = true;
+		else if (a == "--matrix") o.matrix = need(i);
+		else if (a == "--gapopen") o.gap_open = std::atoi(need(i).c_str());
+		else if (a == "--gapextend") o.gap_extend = std::atoi(need(i).c_str());
 		else if (a == "--unal") { o.unal = std::atoi(need(i).c_str()); if (o.unal != 0 && o.unal != 1) throw std::runtime_error("Permitted values for --unal: 0, 1"); }
 		else if (a == "--header") {
 			o.header = "verbose";
@@ -546,6 +551,7 @@ int run_blastp(const Options& o)
 
 	dmnd_params p;
 	dmnd_default_params(&p);
+	if (dmnd_matrix_params(o.matrix.c_str(), o.gap_open, o.gap_extend, &p) != DMND_OK) throw std::runtime_error(dmnd_last_error());
 	p.db_letters = (double)db.letters;
 	p.max_evalue = o.evalue;
 	auto chk = [&](int rc) { if (rc != DMND_OK) throw std::runtime_error(dmnd_last_error()); };

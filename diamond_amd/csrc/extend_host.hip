@@ -73,6 +73,7 @@ const double BLOSUM62_BG[20] = { 7.4216205067993410e-02, 5.1614486141284638e-02,
 struct HostCfg {
 	ScoreTable S;
 	double background_scores[20];
+	int xdrop = 20;                      // config.raw_ungapped_xdrop = score_matrix.rawscore(12.3 bits), config.cpp:428,853
 	alignas(32) int16_t rows[32][24];    // score matrix rows (row = letter, 20 residue columns padded to 24) for the vectorised window sums
 	int cbs_window = 40;                 // config.cbs_window
 	int max_target_seqs = 25;
@@ -96,6 +97,7 @@ void make_cfg(const dmnd_ctx* c, HostCfg& h)
 {
 	for (int i = 0; i < 32 * 32; ++i) { h.S.m[i] = c->params.matrix8[i]; if ((i & 31) < 24) h.rows[i >> 5][i & 31] = (i & 31) < 20 ? c->params.matrix8[i] : 0; }
 	h.S.gap_open = c->params.gap_open; h.S.gap_extend = c->params.gap_extend;
+	h.xdrop = (int)std::ceil((12.3 * 0.69314718055994530941723212145818 + std::log(c->params.K)) / c->params.lambda);
 	for (int i = 0; i < 20; ++i) {                     // ScoreMatrix::init_background_scores, score_matrix.cpp:241-248
 		h.background_scores[i] = 0;
 		for (int j = 0; j < 20; ++j) h.background_scores[i] += BLOSUM62_BG[j] * h.S.at(i, j);
@@ -237,7 +239,7 @@ void plan_groups(const HostCfg& h, ChainWorkspace& ws, QueryWork& w, size_t g0, 
 				const int f = sh[x].frame;
 				ungapped[f] = std::max(ungapped[f], sh[x].score);
 				if (!segs[f].empty() && segs[f].back().diag() == sh[x].i - sh[x].j && segs[f].back().j_end() >= sh[x].j) continue;
-				const Seg d = xdrop_ungapped(h.S, q[f], cbs[f], t, sh[x].i, sh[x].j, ws.cfg.xdrop);
+				const Seg d = xdrop_ungapped(h.S, q[f], cbs[f], t, sh[x].i, sh[x].j, h.xdrop);
 				if (d.score > 0) segs[f].push_back(d);
 			}
 		}

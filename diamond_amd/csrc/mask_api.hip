@@ -12,8 +12,10 @@ using namespace dmnd;
 
 namespace {
 
-// f(lambda) = sum(inverse(exp(lambda * S))) - 1 over the 20 standard residues (cbrc::LambdaCalculator, masking/lambda.cpp)
-bool inv_sum(const int8_t* m8, double lambda, double& f)
+// f(lambda) = sum(inverse(exp(lambda * S))) - 1 over the 20 standard residues (cbrc::LambdaCalculator, lib/tantan/LambdaCalculator.cc).
+// valid (optional): the row and column sums of the inverse -- the letter probabilities the matrix implies -- all lie in [0, 1]
+// (LambdaCalculator::check_lambda).
+bool inv_sum(const int8_t* m8, double lambda, double& f, bool* valid = nullptr)
 {
 	const int n = 20;
 	double A[20][40];
@@ -35,28 +37,85 @@ bool inv_sum(const int8_t* m8, double lambda, double& f)
 	long double acc = 0;
 	for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) acc += A[i][n + j];
 	f = (double)(acc - 1.0L);
-	return true;
+	if (valid) {
+		*valid = true;
+		for (int i = 0; i < n; ++i) {
+			double row = 0, col = 0;
+			for (int j = 0; j < n; ++j) { row += A[i][n + j]; col += A[j][n + i]; }
+			if (!(row >= 0.0 && row <= 1.0) || !(col >= 0.0 && col <= 1.0)) *valid = false;
+		}
+	}
+	return std::isfinite(f);
 }
 
-bool likelihood_ratios(const int8_t* m8, float* lr)
+// The scale of the matrix as the reference's masking derives it (Masking::Masking, masking/masking.cpp:132-143): the lambda in
+// (ub * 1e-6, ub] with sum(inverse(exp(lambda * S))) = 1 whose implied letter probabilities are valid, ub from the smallest row /
+// column maximum (LambdaCalculator::find_ub). The reference brackets the root with random pairs until one bisection ends on a valid
+// lambda and gives up with lambda = -1 after 1000 attempts; this scan over the same interval visits every sign change in
+// ascending order instead. A matrix without a valid root (PAM250) gets the reference's fallback: -1, i.e. likelihood ratios
+// exp(-score) -- which masks nearly everything, exactly as the reference then does.
+double masking_lambda(const int8_t* m8)
 {
-	double lo = 1e-3, hi = 1.0, flo, fhi, fm;
-	if (!inv_sum(m8, lo, flo) || !inv_sum(m8, hi, fhi) || flo * fhi > 0) return false;
-	for (int it = 0; it < 200 && hi - lo >= 1e-15; ++it) {
-		const double mid = 0.5 * (lo + hi);
-		if (!inv_sum(m8, mid, fm)) return false;
-		if ((fm < 0) == (flo < 0)) { lo = mid; flo = fm; } else { hi = mid; fhi = fm; }
+	const int n = 20;
+	double r_max_min = 1e300, c_max_min = 1e300;
+	int zero_rows = 0, zero_cols = 0;
+	for (int i = 0; i < n; ++i) {
+		int rmax = -128, rmin = 127, cmax = -128, cmin = 127;
+		for (int j = 0; j < n; ++j) {
+			rmax = std::max(rmax, (int)m8[i * 32 + j]); rmin = std::min(rmin, (int)m8[i * 32 + j]);
+			cmax = std::max(cmax, (int)m8[j * 32 + i]); cmin = std::min(cmin, (int)m8[j * 32 + i]);
+		}
+		if (rmax == 0 && rmin == 0) ++zero_rows; else if (rmax <= 0 || rmin >= 0) return -1.0; else r_max_min = std::min(r_max_min, (double)rmax);
+		if (cmax == 0 && cmin == 0) ++zero_cols; else if (cmax <= 0 || cmin >= 0) return -1.0; else c_max_min = std::min(c_max_min, (double)cmax);
 	}
-	const double lambda = 0.5 * (lo + hi);
+	if (zero_rows == n) return -1.0;
+	const double ub = r_max_min > c_max_min ? 1.1 * std::log(1.0 * (n - zero_rows)) / r_max_min : 1.1 * std::log(1.0 * (n - zero_cols)) / c_max_min;
+	const double lb = ub * 1e-6;
+	const int GRID = 4096;
+	double x0 = lb, f0 = 0;
+	bool have0 = inv_sum(m8, x0, f0);
+	for (int g = 1; g <= GRID; ++g) {
+		const double x1 = lb + (ub - lb) * g / GRID;
+		double f1 = 0;
+		const bool have1 = inv_sum(m8, x1, f1);
+		if (have0 && have1 && (f0 < 0) != (f1 < 0)) {
+			double lo = x0, hi = x1, flo = f0, fm = 0;
+			bool ok = true;
+			for (int it = 0; it < 200 && ok; ++it) {
+				const double mid = 0.5 * (lo + hi);
+				if (mid == lo || mid == hi) break;
+				ok = inv_sum(m8, mid, fm);
+				if (ok) { if ((fm < 0) == (flo < 0)) { lo = mid; flo = fm; } else hi = mid; }
+			}
+			bool valid = false;
+			double fl = 0, fh = 0;
+			if (ok && inv_sum(m8, lo, fl) && inv_sum(m8, hi, fh)) {
+				const double lambda = std::fabs(fl) < std::fabs(fh) ? lo : hi;       // the end closer to the root, LambdaCalculator::binary_search
+				if (inv_sum(m8, lambda, fm, &valid) && valid && std::fabs(fm) < 1e-3) return lambda;
+			}
+		}
+		x0 = x1; f0 = f1; have0 = have1;
+	}
+	return -1.0;
+}
+
+void likelihood_ratios(const int8_t* m8, float* lr)
+{
+	const double lambda = masking_lambda(m8);
 	for (int i = 0; i < 32; ++i)
 		for (int j = 0; j < 32; ++j)      // Masking::Masking, masking.cpp:147-153: the 26 alphabet letters, 0 elsewhere
 			lr[i * 32 + j] = (i < 26 && j < 26) ? (float)std::exp(lambda * (double)m8[i * 32 + j]) : 0.0f;
-	return true;
 }
 
 }
 
 namespace { std::vector<uint64_t> g_motifs; }
+
+extern "C" double dmnd_masking_lambda(const dmnd_params* p)
+{
+	if (!p) { fail(DMND_E_ARG, "dmnd_masking_lambda: params is NULL"); return 0.0; }
+	return masking_lambda(p->matrix8);
+}
 
 extern "C" int dmnd_set_motif_table(const uint64_t* codes, int64_t n)
 {
@@ -112,7 +171,7 @@ extern "C" int dmnd_mask_block(dmnd_ctx* c, int which, int8_t* host_data, int64_
 	const std::vector<int64_t>& lim = c->limits[which];
 	const int64_t n = (int64_t)lim.size() - 1, raw = c->block_len[which];
 	std::vector<float> lr(32 * 32);
-	if (!likelihood_ratios(c->params.matrix8, lr.data())) return fail(DMND_E_ARG, "dmnd_mask_block: no lambda for this scoring matrix");
+	likelihood_ratios(c->params.matrix8, lr.data());
 	TantanArgs a;
 	// Masking::operator() (masking.cpp:176): p_repeat 0.005, p_repeat_end 0.05, growth 1/0.9, minMaskProb 0.9 (config.cpp:402)
 	const float p_repeat = 0.005f, p_repeat_end = 0.05f, growth = 1.0f / 0.9f;

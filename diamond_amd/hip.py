@@ -71,7 +71,7 @@ EXPORTS = ["dmnd_abi_version", "dmnd_last_error", "dmnd_default_params", "dmnd_c
            "dmnd_seed_params_set_index_chunks", "dmnd_join_blocks", "dmnd_set_sensitivity", "dmnd_touch_streams",
            "dmnd_seed_params_set_query_indexed", "dmnd_auto_query_indexed", "dmnd_set_motif_table", "dmnd_motif_table_size",
            "dmnd_soft_mask_block", "dmnd_output_fields", "dmnd_format_fields", "dmnd_format_pairwise_intro", "dmnd_format_pairwise",
-           "dmnd_format_paf", "dmnd_device_count", "dmnd_set_top_percent", "dmnd_join_blocks_top", "dmnd_set_filters", "dmnd_format_sam", "dmnd_set_query_source_lengths", "dmnd_format_fields_unaligned", "dmnd_format_fields_header", "dmnd_set_query_index_reuse", "dmnd_set_no_self_hits"]
+           "dmnd_format_paf", "dmnd_device_count", "dmnd_set_top_percent", "dmnd_join_blocks_top", "dmnd_set_filters", "dmnd_format_sam", "dmnd_set_query_source_lengths", "dmnd_format_fields_unaligned", "dmnd_format_fields_header", "dmnd_set_query_index_reuse", "dmnd_set_no_self_hits", "dmnd_matrix_params", "dmnd_masking_lambda"]
 
 
 def set_motif_table(codes):
@@ -138,6 +138,8 @@ def load():
         lib.dmnd_mask_block.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)]
         lib.dmnd_mask_kernel_ms.argtypes = [ctypes.c_void_p]
         lib.dmnd_mask_kernel_ms.restype = ctypes.c_double
+        lib.dmnd_masking_lambda.restype = ctypes.c_double
+        lib.dmnd_masking_lambda.argtypes = [ctypes.c_void_p]
         lib.dmnd_translate.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
         lib.dmnd_last_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
         _lib = lib
@@ -147,6 +149,15 @@ def load():
 def default_params():
     p = Params()
     rc = load().dmnd_default_params(ctypes.byref(p))
+    if rc != 0:
+        raise DiamondHipError(load().dmnd_last_error().decode())
+    return p
+
+
+def matrix_params(name, gap_open=-1, gap_extend=-1, params=None):
+    """--matrix NAME --gapopen O --gapextend E (-1 = the matrix's defaults) -> Params (ScoreMatrix ctor, score_matrix.cpp:49-72)."""
+    p = params if params is not None else default_params()
+    rc = load().dmnd_matrix_params(name.encode(), int(gap_open), int(gap_extend), ctypes.byref(p))
     if rc != 0:
         raise DiamondHipError(load().dmnd_last_error().decode())
     return p

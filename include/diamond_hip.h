@@ -102,6 +102,12 @@ const char* dmnd_last_error(void);
 /* Fills params with the reference's defaults: BLOSUM62, gap open 11 / extend 1
  * (ScoreMatrix ctor, src/stats/score_matrix.cpp:49-72), max_evalue 0.001. */
 int dmnd_default_params(dmnd_params* params);
+/* Scoring of `--matrix NAME --gapopen O --gapextend E`: one of the reference's standard matrices (blosum45, blosum50, blosum62,
+ * blosum80, blosum90, pam30, pam70, pam250; any case), gap penalties -1 = the matrix's defaults. Fills matrix8, the penalties and
+ * the Gumbel constants of that pair and leaves db_letters / max_evalue as they are. Replaces ScoreMatrix::ScoreMatrix
+ * (src/stats/score_matrix.cpp:49-72) + StandardMatrix::get / constants (src/stats/stats.cpp:59-75), with their errors:
+ * DMND_E_ARG "Unknown scoring matrix" / "Gap penalty settings are outside the supported range for this scoring matrix." */
+int dmnd_matrix_params(const char* name, int gap_open, int gap_extend, dmnd_params* params);
 /* Number of usable gfx950 devices (0 if none / HIP not available): what `--gpus N` is checked against. */
 int dmnd_device_count(void);
 /* device < 0: use the current HIP device. Fails (NULL) when no gfx950 device is present. */
@@ -311,6 +317,10 @@ int dmnd_format_tab_translated(const dmnd_match* m, const char* qseqid, const ch
  * reads the same letters. *n_masked (may be NULL) = number of positions at or above the mask probability. */
 int dmnd_mask_block(dmnd_ctx* ctx, int which, int8_t* host_data, int64_t* n_masked);
 double dmnd_mask_kernel_ms(const dmnd_ctx* ctx);
+/* The lambda of those likelihood ratios (host only): the scale at which the matrix's implied letter probabilities are valid
+ * (cbrc::LambdaCalculator::calculate, src/lib/tantan/LambdaCalculator.cc), or -1 where the matrix has none (PAM250) -- the value
+ * the reference then uses too. */
+double dmnd_masking_lambda(const dmnd_params* params);
 /* Motif soft masking (default on up to --sensitive: sensitivity_traits.motif_masking, search/setup.cpp:40-53,322-335): while seeds
  * are enumerated the reference masks stretches covered by abundant 8-mer motifs (mask_motifs, masking/masking.cpp:110-131; the
  * letters come back before the filters and the extension run, Block::soft_mask / remove_soft_masking, data/block/block.cpp:164-177),

@@ -561,3 +561,40 @@ def test_cli_no_self_hits_matches_reference(tmp_path):
             plain = ref
     assert not any(l.split("\t")[0] == l.split("\t")[1] for l in plain.splitlines())       # no self hit
     assert any(l.split("\t")[1].startswith("copy") and l.split("\t")[2] == "100" for l in plain.splitlines())      # the renamed copies are reported
+
+
+def test_cli_scoring_matrices_and_gap_penalties_match_reference(tmp_path):
+    """--matrix (the eight standard matrices) / --gapopen / --gapextend: default flags (tantan + motif masking use the matrix too) on
+    the reference's ctest fixture, the filters of --sensitive and a translated search on synthetic families, the positives of the
+    output formats."""
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/diamond not built")
+    g = os.path.join(ROOT, "tests", "golden", "ref_ctest", "data.faa")
+    db, doff, q, qoff = synth.generate(300, members=10, queries=300, seed=23)
+    dna, off = synth.back_translate(q[: qoff[120]], qoff[:121], seed=24)
+    synth.write_fasta(str(tmp_path / "db.faa"), "t", db, doff)
+    synth.write_fasta(str(tmp_path / "q.faa"), "q", q, qoff)
+    synth.write_dna_fasta(str(tmp_path / "reads.fna"), "r", dna, off)
+    fixture = ["blastp", "-q", g, "-d", g, "-p", "4"]
+    fam = ["blastp", "-q", str(tmp_path / "q.faa"), "-d", str(tmp_path / "db.faa"), "-p", "4"]
+    runs = [(fixture + ["--matrix", m], 5 if m == "pam250" else 500) for m in ("blosum45", "BLOSUM50", "blosum80", "blosum90", "pam30", "PAM70", "pam250")]
+    runs += [(fixture + ["--gapopen", "9", "--gapextend", "2"], 500), (fixture + ["--matrix", "blosum45", "--gapopen", "19", "--gapextend", "1", "--masking", "0"], 500),
+             (fam + ["--matrix", "pam30", "--sensitive"], 100), (fam + ["--matrix", "blosum45", "--sensitive"], 300),
+             (fam + ["--matrix", "blosum90", "--fast", "--comp-based-stats", "0"], 100), (fam + ["--gapopen", "6", "--gapextend", "2", "--very-sensitive"], 300),
+             (fam + ["--matrix", "blosum50", "-f", "6", "qseqid", "sseqid", "positive", "ppos", "score", "bitscore", "evalue", "cigar"], 300),
+             (fam + ["--matrix", "pam70", "-f", "0"], 1000),
+             (["blastx", "-q", str(tmp_path / "reads.fna"), "-d", str(tmp_path / "db.faa"), "-p", "4", "--matrix", "blosum80"], 100)]
+    bad = []
+    for args, least in runs:
+        _run([REF] + args + ["-o", str(tmp_path / "ref.out")])
+        _run([CLI] + args + ["-o", str(tmp_path / "hip.out")])
+        ref, hip_ = open(tmp_path / "ref.out").read(), open(tmp_path / "hip.out").read()
+        if len(ref.splitlines()) < least or ref != hip_:
+            r, h = ref.splitlines(), hip_.splitlines()
+            first = next((i for i in range(min(len(r), len(h))) if r[i] != h[i]), min(len(r), len(h)))
+            bad.append("%s: ref %d lines, hip %d lines, first difference at %d\n  ref: %s\n  hip: %s" % (
+                " ".join(args[5:]), len(r), len(h), first, r[first] if first < len(r) else "-", h[first] if first < len(h) else "-"))
+    assert not bad, "\n".join(bad)
+    for args, msg in ((fixture + ["--matrix", "blosum61"], "Unknown scoring matrix"), (fixture + ["--gapopen", "3"], "outside the supported range")):
+        r = subprocess.run([CLI] + args + ["-o", str(tmp_path / "x.out")], capture_output=True, text=True, timeout=600)
+        assert r.returncode != 0 and msg in r.stderr
