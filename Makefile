@@ -23,7 +23,7 @@ diamond_amd/libdiamond_hip.so: $(HIPSRC) $(HIPHDR)
 
 # the CLI (makedb / blastp) over the C ABI; finds the library next to itself
 diamond_amd/diamond-hip: $(CSRC)/cli.cpp include/diamond_hip.h diamond_amd/libdiamond_hip.so
-	g++ -O2 -std=c++17 -Wall -o $@ $(CSRC)/cli.cpp -Ldiamond_amd -ldiamond_hip -Wl,-rpath,'$$ORIGIN'
+	g++ -O2 -std=c++17 -Wall -o $@ $(CSRC)/cli.cpp -Ldiamond_amd -ldiamond_hip -lz -Wl,-rpath,'$$ORIGIN'
 
 diamond_amd/libdmnd_synth.so: $(CSRC)/synth.c
 	gcc -O2 -fPIC -shared -std=c11 -Wall -o $@ $< -lm

@@ -26,6 +26,7 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+#include <zlib.h>
 #include <unistd.h>
 #include "../../include/diamond_hip.h"
 
@@ -68,14 +69,82 @@ std::string short_id(const std::string& title)
 	return e == std::string::npos ? title : title.substr(0, e);
 }
 
+// Sequence file -> text in memory. Compressed input is detected by the gzip magic as the reference's InputFile does
+// (File::Flags::DETECT_COMPRESSION, data/fasta/fasta_file.cpp:68; zlib inflates it, also concatenated members); FASTQ
+// (first character '@', guess_format fasta_file.cpp:43-52) is rewritten as FASTA text -- title, letters up to the '+' line, as many
+// quality characters as letters skipped (FastqTokenizer::read_record, data/fasta/parser.h:238-270).
+std::vector<char> read_sequence_text(const std::string& path)
+{
+	std::vector<char> file;
+	unsigned char magic[2] = { 0, 0 };
+	{
+		std::ifstream f(path, std::ios::binary | std::ios::ate);
+		if (!f) throw std::runtime_error("Error opening file " + path);
+		const std::streamoff n = f.tellg();
+		f.seekg(0);
+		if (n >= 2) { f.read((char*)magic, 2); f.seekg(0); }
+		if (!(magic[0] == 0x1f && magic[1] == 0x8b)) {
+			file.resize((size_t)n);
+			if (n > 0 && !f.read(file.data(), n)) throw std::runtime_error("Error reading file " + path);
+		}
+	}
+	if (magic[0] == 0x1f && magic[1] == 0x8b) {
+		gzFile g = gzopen(path.c_str(), "rb");
+		if (!g) throw std::runtime_error("Error opening file " + path);
+		gzbuffer(g, 1 << 20);
+		size_t have = 0;
+		for (;;) {
+			if (file.size() < have + (1 << 22)) file.resize(std::max<size_t>(file.size() * 2, have + (1 << 22)));
+			const int got = gzread(g, file.data() + have, 1 << 22);
+			if (got < 0) { gzclose(g); throw std::runtime_error("Error reading compressed file " + path); }
+			if (got == 0) break;
+			have += (size_t)got;
+		}
+		gzclose(g);
+		file.resize(have);
+	}
+	if (file.empty()) throw std::runtime_error("Error detecting input file format. Input file seems to be empty.");
+	if (file[0] != '>' && file[0] != '@')
+		throw std::runtime_error("Error detecting input file format (when treating as text file). First line must begin with '>' (FASTA) or '@' (FASTQ).");
+	if (file[0] == '>') return file;
+	std::vector<char> fasta;
+	fasta.reserve(file.size() / 2 + 16);
+	const char* p = file.data();
+	const char* const end = p + file.size();
+	int64_t lineno = 0;
+	auto line = [&](const char*& b, const char*& e) -> bool {            // next line without its terminator; false at the end of the file
+		if (p >= end) return false;
+		const char* nl = (const char*)std::memchr(p, '\n', (size_t)(end - p));
+		b = p; e = nl ? nl : end; p = nl ? nl + 1 : end;
+		if (e > b && e[-1] == '\r') --e;
+		++lineno;
+		return true;
+	};
+	const char *b, *e;
+	while (line(b, e)) {
+		if (b == e && p >= end) break;
+		const int64_t at = lineno;
+		auto bad = [&] { return std::runtime_error("Malformed FASTQ record at line " + std::to_string(at)); };
+		if (b == e || *b != '@') throw bad();
+		fasta.push_back('>');
+		fasta.insert(fasta.end(), b + 1, e);
+		fasta.push_back('\n');
+		int64_t len = 0, qlen = 0;
+		for (;;) {
+			if (!line(b, e) || b == e) throw bad();
+			if (*b == '+') break;
+			len += e - b;
+			fasta.insert(fasta.end(), b, e);
+		}
+		fasta.push_back('\n');
+		while (qlen < len && line(b, e)) qlen += e - b;
+	}
+	return fasta;
+}
+
 void read_fasta(const std::string& path, SeqBlock& b)
 {
-	std::ifstream f(path, std::ios::binary | std::ios::ate);
-	if (!f) throw std::runtime_error("Error opening file " + path);
-	const std::streamoff n = f.tellg();
-	std::vector<char> file((size_t)n);
-	f.seekg(0);
-	if (n > 0 && !f.read(file.data(), n)) throw std::runtime_error("Error reading file " + path);
+	const std::vector<char> file = read_sequence_text(path);
 	b.begin();
 	b.data.reserve(256 + file.size() + 256);
 	letter_of('A');                                        // builds the letter map
@@ -117,10 +186,10 @@ void read_fasta(const std::string& path, SeqBlock& b)
 
 // blastx query file: DNA reads -> six translated frames per read, consecutive in the block (Block::push_back,
 // data/block/block.cpp:82-100). source_len keeps the read lengths for the DNA coordinates of the output.
-void read_dna_fasta_translated(const std::string& path, SeqBlock& b, std::vector<int32_t>& source_len, std::vector<std::string>& read_ids, std::vector<std::vector<int8_t>>& reads)
+void read_dna_fasta_translated(const std::string& path, SeqBlock& b, std::vector<int32_t>& source_len, std::vector<std::string>& read_ids, std::vector<std::vector<int8_t>>& reads,
+	int gencode, int strands, int min_orf)
 {
-	std::ifstream f(path);
-	if (!f) throw std::runtime_error("Error opening file " + path);
+	const std::vector<char> file = read_sequence_text(path);
 	static int8_t map[256];
 	static bool init = false;
 	if (!init) {                                                     // nucleotide_traits("ACGTN", 4, "MRWSYKVHDBX"), stats/stats.cpp:42
@@ -140,14 +209,20 @@ void read_dna_fasta_translated(const std::string& path, SeqBlock& b, std::vector
 		int8_t* out[6];
 		int32_t lens[6];
 		for (int k = 0; k < 6; ++k) { frames[k].assign(seq.size() / 3 + 1, 0); out[k] = frames[k].data(); }
-		if (dmnd_translate(seq.data(), (int32_t)seq.size(), out, lens) != DMND_OK) throw std::runtime_error(dmnd_last_error());
+		if (dmnd_translate_opts(seq.data(), (int32_t)seq.size(), gencode, strands, min_orf, out, lens) != DMND_OK) throw std::runtime_error(dmnd_last_error());
 		for (int k = 0; k < 6; ++k) { frames[k].resize((size_t)lens[k]); b.push(frames[k], id); }
 		source_len.push_back((int32_t)seq.size());
 		read_ids.push_back(id);
 		reads.push_back(seq);
 		seq.clear();
 	};
-	while (std::getline(f, line)) {
+	const char* p = file.data();
+	const char* const end = p + file.size();
+	while (p < end) {
+		const char* nl = (const char*)std::memchr(p, '\n', (size_t)(end - p));
+		const char* le = nl ? nl : end;
+		line.assign(p, le);
+		p = nl ? nl + 1 : end;
 		if (!line.empty() && line.back() == '\r') line.pop_back();
 		if (line.empty()) continue;
 		if (line[0] == '>') { flush(); id = line.substr(1); have = true; continue; }
@@ -331,6 +406,7 @@ struct Options {
 	bool no_self_hits = false;      // --no-self-hits
 	std::string matrix = "blosum62";        // --matrix / --gapopen / --gapextend (-1 = the matrix's default), basic/config.cpp:256-258
 	int gap_open = -1, gap_extend = -1;
+	int strands = 3, gencode = 1, min_orf = 0;      // --strand (mask: 1 plus, 2 minus), --query-gencode, --min-orf: translated searches
 	int unal = -1;                  // --unal: report queries without alignments (-1 = the format's default)
 	std::string header;             // --header [simple|verbose|0]
 	double min_id = 0, query_cover = 0, subject_cover = 0, min_score = 0;      // --id, --query-cover, --subject-cover, --min-score
@@ -369,6 +445,13 @@ Options parse(int argc, char** argv)
 		else if (a == "--min-score") o.min_score = std::atof(need(i).c_str());
 		else if (a == "--no-self-hits") o.no_self_hits = true;
 		else if (a == "--matrix") o.matrix = need(i);
+		else if (a == "--strand") {
+			const std::string v = need(i);                      // config.query_strands, basic/config.cpp:290,879
+			if (v == "both") o.strands = 3; else if (v == "plus") o.strands = 1; else if (v == "minus") o.strands = 2;
+			else throw std::runtime_error("Invalid value for parameter --strand");
+		}
+		else if (a == "--query-gencode") o.gencode = std::atoi(need(i).c_str());
+		else if (a == "-l" || a == "--min-orf") o.min_orf = std::atoi(need(i).c_str());
 		else if (a == "--gapopen") o.gap_open = std::atoi(need(i).c_str());
 		else if (a == "--gapextend") o.gap_extend = std::atoi(need(i).c_str());
 		else if (a == "--unal") { o.unal = std::atoi(need(i).c_str()); if (o.unal != 0 && o.unal != 1) throw std::runtime_error("Permitted values for --unal: 0, 1"); }
@@ -503,7 +586,7 @@ int run_blastp(const Options& o)
 	bool want_full_sseq = false;
 	for (int32_t id : field_ids) want_full_sseq |= id == DMND_F_FULL_SSEQ;
 	auto t0 = std::chrono::steady_clock::now();
-	if (blastx) read_dna_fasta_translated(o.query, q_all, source_len, read_ids, reads);
+	if (blastx) read_dna_fasta_translated(o.query, q_all, source_len, read_ids, reads, o.gencode, o.strands, o.min_orf);
 	else read_fasta(o.query, q_all);
 	std::string dbpath = o.db;
 	if (!std::ifstream(dbpath).good() && std::ifstream(dbpath + ".dmnd").good()) dbpath += ".dmnd";

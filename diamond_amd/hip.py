@@ -71,7 +71,7 @@ EXPORTS = ["dmnd_abi_version", "dmnd_last_error", "dmnd_default_params", "dmnd_c
            "dmnd_seed_params_set_index_chunks", "dmnd_join_blocks", "dmnd_set_sensitivity", "dmnd_touch_streams",
            "dmnd_seed_params_set_query_indexed", "dmnd_auto_query_indexed", "dmnd_set_motif_table", "dmnd_motif_table_size",
            "dmnd_soft_mask_block", "dmnd_output_fields", "dmnd_format_fields", "dmnd_format_pairwise_intro", "dmnd_format_pairwise",
-           "dmnd_format_paf", "dmnd_device_count", "dmnd_set_top_percent", "dmnd_join_blocks_top", "dmnd_set_filters", "dmnd_format_sam", "dmnd_set_query_source_lengths", "dmnd_format_fields_unaligned", "dmnd_format_fields_header", "dmnd_set_query_index_reuse", "dmnd_set_no_self_hits", "dmnd_matrix_params", "dmnd_masking_lambda"]
+           "dmnd_format_paf", "dmnd_device_count", "dmnd_set_top_percent", "dmnd_join_blocks_top", "dmnd_set_filters", "dmnd_format_sam", "dmnd_set_query_source_lengths", "dmnd_format_fields_unaligned", "dmnd_format_fields_header", "dmnd_set_query_index_reuse", "dmnd_set_no_self_hits", "dmnd_matrix_params", "dmnd_masking_lambda", "dmnd_translate_opts"]
 
 
 def set_motif_table(codes):
@@ -396,16 +396,17 @@ def seed_params_sensitive(scoring, threads=1):
     return p
 
 
-def translate(dna):
-    """Six-frame translation of one DNA read (int8 letters 0-4 = ACGTN) as the reference loads a blastx query.
-    Returns a list of six int8 arrays (frames 0-2 forward, 3-5 reverse)."""
+def translate(dna, gencode=1, strands=3, min_orf=0):
+    """Six-frame translation of one DNA read (int8 letters 0-4 = ACGTN) as the reference loads a blastx query
+    (--query-gencode, --strand as a mask 1 plus / 2 minus / 3 both, --min-orf). Returns a list of six int8 arrays (frames 0-2
+    forward, 3-5 reverse)."""
     lib = load()
     dna = np.ascontiguousarray(dna, dtype=np.int8)
     n = dna.size // 3
     bufs = [np.zeros(max(n, 1), np.int8) for _ in range(6)]
     ptrs = (ctypes.c_void_p * 6)(*[b.ctypes.data for b in bufs])
     lens = (ctypes.c_int32 * 6)()
-    rc = lib.dmnd_translate(dna.ctypes.data_as(ctypes.c_void_p), ctypes.c_int32(dna.size), ptrs, lens)
+    rc = lib.dmnd_translate_opts(dna.ctypes.data_as(ctypes.c_void_p), ctypes.c_int32(dna.size), int(gencode), int(strands), int(min_orf), ptrs, lens)
     if rc != 0:
         raise DiamondHipError(lib.dmnd_last_error().decode())
     return [bufs[f][:lens[f]].copy() for f in range(6)]

@@ -305,6 +305,11 @@ int dmnd_set_query_contexts(dmnd_ctx* ctx, int contexts);
  * standard genetic code, stop codons = letter 24, ORFs shorter than config.min_orf_len masked to 23 (find_orfs,
  * src/util/sequence/sequence.cpp:180-197). out[f] must hold len/3 letters each; lens[f] receives the frame lengths. */
 int dmnd_translate(const int8_t* dna, int32_t len, int8_t* out[6], int32_t lens[6]);
+/* The same with the options of a translated search: gencode = --query-gencode (NCBI table number; Translator::init,
+ * src/basic/basic.cpp:116-139, "Invalid genetic code id." for a number it does not have), strands = --strand as a mask (1 plus,
+ * 2 minus, 3 both: the frames of a strand that is not searched are filled with mask letters, frame_mask
+ * src/data/sequence_file.cpp:286-294), min_orf = --min-orf (0 = by read length). dmnd_translate = (1, 3, 0). */
+int dmnd_translate_opts(const int8_t* dna, int32_t len, int gencode, int strands, int min_orf, int8_t* out[6], int32_t lens[6]);
 /* BLAST tabular line of a translated match: qstart/qend in DNA coordinates of the read (TranslatedPosition,
  * src/basic/translated_position.h:125-175; reverse frames print qstart > qend). */
 int dmnd_format_tab_translated(const dmnd_match* m, const char* qseqid, const char* sseqid, int32_t source_len, char* buf, int64_t cap);

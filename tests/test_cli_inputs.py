@@ -1,0 +1,55 @@
+"""Input side of the command line that needs no device: `diamond-hip makedb` from FASTA, gzip-compressed FASTA, FASTQ and
+gzip-compressed FASTQ writes the same .dmnd; malformed inputs fail with the reference's messages (data/fasta/fasta_file.cpp:43-52,
+data/fasta/parser.h:238-270)."""
+import gzip
+import os
+import subprocess
+
+import pytest
+
+from diamond_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "diamond_amd", "diamond-hip")
+
+
+def _makedb(src, dst):
+    return subprocess.run([CLI, "makedb", "--in", str(src), "-d", str(dst)], capture_output=True, text=True, timeout=120)
+
+
+def test_makedb_reads_gzip_and_fastq(tmp_path):
+    assert os.path.exists(CLI), "diamond-hip not built (make product)"
+    db, doff, _, _ = synth.generate(20, members=5, queries=1, seed=3)
+    synth.write_fasta(str(tmp_path / "a.faa"), "t", db, doff)
+    recs = open(tmp_path / "a.faa").read().split(">")[1:]
+    with open(tmp_path / "a.fastq", "w") as f:
+        for i, r in enumerate(recs):
+            h, *s = r.strip().split("\n")
+            s = "".join(s)
+            half = len(s) // 2
+            if i % 3 == 0:            # sequence and quality wrapped over two lines, '+' line repeating the title, CRLF line ends
+                f.write("@%s\r\n%s\r\n%s\r\n+%s\r\n%s\r\n%s\r\n" % (h, s[:half], s[half:], h, "@" * half, "@" * (len(s) - half)))
+            else:
+                f.write("@%s\n%s\n+\n%s\n" % (h, s, "@" * len(s)))      # quality lines that start with '@'
+    for name in ("a.faa", "a.fastq"):
+        with open(tmp_path / name, "rb") as f, gzip.open(str(tmp_path / name) + ".gz", "wb") as g:
+            g.write(f.read())
+    out = []
+    for name in ("a.faa", "a.faa.gz", "a.fastq", "a.fastq.gz"):
+        r = _makedb(tmp_path / name, tmp_path / ("db_" + name))
+        assert r.returncode == 0, r.stderr
+        out.append(open(str(tmp_path / ("db_" + name)) + ".dmnd", "rb").read())
+    assert len(out[0]) > 1000 and all(o == out[0] for o in out)
+
+
+@pytest.mark.parametrize("content, message", [
+    (b"", "Input file seems to be empty"),
+    (b"ACDEFG\n", "First line must begin with '>' (FASTA) or '@' (FASTQ)"),
+    (b"@r1\nACDE\n", "Malformed FASTQ record at line 1"),
+    (b"@r1\nACDE\n+\nIIII\nr2\nACDE\n+\nIIII\n", "Malformed FASTQ record at line 5"),
+    (b">s1\nAC1DE\n", "Invalid character (1) in sequence s1"),
+])
+def test_makedb_rejects_malformed_input(tmp_path, content, message):
+    open(tmp_path / "bad", "wb").write(content)
+    r = _makedb(tmp_path / "bad", tmp_path / "bad_db")
+    assert r.returncode != 0 and message in r.stderr, r.stderr

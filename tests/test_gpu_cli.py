@@ -598,3 +598,56 @@ def test_cli_scoring_matrices_and_gap_penalties_match_reference(tmp_path):
     for args, msg in ((fixture + ["--matrix", "blosum61"], "Unknown scoring matrix"), (fixture + ["--gapopen", "3"], "outside the supported range")):
         r = subprocess.run([CLI] + args + ["-o", str(tmp_path / "x.out")], capture_output=True, text=True, timeout=600)
         assert r.returncode != 0 and msg in r.stderr
+
+
+def test_cli_input_formats_and_translation_options_match_reference(tmp_path):
+    """gzip-compressed FASTA and FASTQ inputs (query, database, makedb), and the options of a translated search: --strand,
+    --query-gencode, --min-orf. (A gzip-compressed FASTQ is read here too; the reference build loads no query from one.)"""
+    import gzip
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/diamond not built")
+    db, doff, q, qoff = synth.generate(300, members=10, queries=200, seed=31)
+    dna, off = synth.back_translate(q[: qoff[150]], qoff[:151], seed=32)
+    synth.write_fasta(str(tmp_path / "db.faa"), "t", db, doff)
+    synth.write_fasta(str(tmp_path / "q.faa"), "q", q, qoff)
+    synth.write_dna_fasta(str(tmp_path / "reads.fna"), "r", dna, off)
+
+    def fastq(src, dst):
+        recs = open(src).read().split(">")[1:]
+        with open(dst, "w") as f:
+            for r in recs:
+                h, *s = r.strip().split("\n")
+                s = "".join(s)
+                f.write("@%s\n%s\n+%s\n%s\n" % (h, s, h if len(s) % 2 else "", "F" * len(s)))
+
+    def gz(src):
+        with open(src, "rb") as f, gzip.open(src + ".gz", "wb") as g:
+            g.write(f.read())
+        return src + ".gz"
+
+    fastq(tmp_path / "q.faa", tmp_path / "q.fastq")
+    fastq(tmp_path / "reads.fna", tmp_path / "reads.fastq")
+    d = str(tmp_path / "db.faa")
+    _run([REF, "blastp", "-q", str(tmp_path / "q.faa"), "-d", d, "-p", "4", "-o", str(tmp_path / "ref_p.tsv")])
+    _run([REF, "blastx", "-q", str(tmp_path / "reads.fna"), "-d", d, "-p", "4", "-o", str(tmp_path / "ref_x.tsv")])
+    ref_p, ref_x = open(tmp_path / "ref_p.tsv").read(), open(tmp_path / "ref_x.tsv").read()
+    assert len(ref_p.splitlines()) > 300 and len(ref_x.splitlines()) > 100
+    _run([CLI, "makedb", "--in", gz(d), "-d", str(tmp_path / "dbz")])
+    for mode, query, database, want in (("blastp", gz(str(tmp_path / "q.faa")), d, ref_p), ("blastp", str(tmp_path / "q.fastq"), gz(d), ref_p),
+                                        ("blastp", gz(str(tmp_path / "q.fastq")), str(tmp_path / "dbz.dmnd"), ref_p),
+                                        ("blastx", gz(str(tmp_path / "reads.fna")), d, ref_x), ("blastx", str(tmp_path / "reads.fastq"), str(tmp_path / "dbz.dmnd"), ref_x)):
+        _run([CLI, mode, "-q", query, "-d", database, "-p", "4", "-o", str(tmp_path / "hip.tsv")])
+        assert open(tmp_path / "hip.tsv").read() == want, (mode, query, database)
+    seen = set()
+    for extra in (["--strand", "plus"], ["--strand", "minus"], ["--query-gencode", "4"], ["--min-orf", "10"], ["--query-gencode", "11", "--strand", "minus", "-l", "60"],
+                  ["--query-gencode", "2", "--sensitive"]):
+        args = ["blastx", "-q", str(tmp_path / "reads.fastq"), "-d", d, "-p", "4"] + extra
+        _run([REF] + args + ["-o", str(tmp_path / "ref.tsv")])
+        _run([CLI] + args + ["-o", str(tmp_path / "hip.tsv")])
+        ref = open(tmp_path / "ref.tsv").read()
+        assert len(ref.splitlines()) > 50, extra
+        assert open(tmp_path / "hip.tsv").read() == ref, extra
+        seen.add(ref)
+    assert len(seen) >= 5 and ref_x not in seen                        # the options change the result
+    r = subprocess.run([CLI, "blastx", "-q", str(tmp_path / "reads.fna"), "-d", d, "--query-gencode", "7", "-o", str(tmp_path / "x.tsv")], capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "Invalid genetic code id" in r.stderr
