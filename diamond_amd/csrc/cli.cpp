@@ -406,6 +406,9 @@ struct Options {
 	bool no_self_hits = false;      // --no-self-hits
 	std::string matrix = "blosum62";        // --matrix / --gapopen / --gapextend (-1 = the matrix's default), basic/config.cpp:256-258
 	int gap_open = -1, gap_extend = -1;
+	std::string un, al;             // --un / --al: FASTA files of the queries without / with alignments
+	int shapes = 0;                 // --shapes: the first N shapes of the sensitivity mode (ShapeConfig, basic/shape_config.h:34-44); 0 = all
+	bool compress = false;          // --compress 1: gzip output, ".gz" appended to the file name
 	int strands = 3, gencode = 1, min_orf = 0;      // --strand (mask: 1 plus, 2 minus), --query-gencode, --min-orf: translated searches
 	int unal = -1;                  // --unal: report queries without alignments (-1 = the format's default)
 	std::string header;             // --header [simple|verbose|0]
@@ -421,7 +424,7 @@ Options parse(int argc, char** argv)
 	std::vector<std::string> args;
 	for (int i = 2; i < argc; ++i) {
 		const std::string a = argv[i];
-		if (a.size() > 2 && a[0] == '-' && a[1] != '-' && std::string("pkebcqdof").find(a[1]) != std::string::npos) {
+		if (a.size() > 2 && a[0] == '-' && a[1] != '-' && std::string("pkebcqdofsl").find(a[1]) != std::string::npos) {
 			args.push_back(a.substr(0, 2));
 			args.push_back(a.substr(2));
 		}
@@ -445,6 +448,15 @@ Options parse(int argc, char** argv)
 		else if (a == "--min-score") o.min_score = std::atof(need(i).c_str());
 		else if (a == "--no-self-hits") o.no_self_hits = true;
 		else if (a == "--matrix") o.matrix = need(i);
+		else if (a == "-s" || a == "--shapes") { o.shapes = std::atoi(need(i).c_str()); if (o.shapes < 0) throw std::runtime_error("Invalid number of seed shapes."); }
+		else if (a == "--un") o.un = need(i);
+		else if (a == "--al") o.al = need(i);
+		else if (a == "--unfmt" || a == "--alfmt") { if (need(i) != "fasta") throw std::runtime_error("Only the fasta format of --un / --al is part of this build."); }
+		else if (a == "--compress") {
+			const std::string v = need(i);                      // Config::compressor, basic/config.cpp:149-159
+			if (v == "0") o.compress = false; else if (v == "1") o.compress = true;
+			else throw std::runtime_error(v == "zstd" ? "Executable was not compiled with ZStd support." : "Invalid compression algorithm: " + v);
+		}
 		else if (a == "--strand") {
 			const std::string v = need(i);                      // config.query_strands, basic/config.cpp:290,879
 			if (v == "both") o.strands = 3; else if (v == "plus") o.strands = 1; else if (v == "minus") o.strands = 2;
@@ -485,6 +497,38 @@ Options parse(int argc, char** argv)
 	}
 	return o;
 }
+
+// Output file: plain, or gzip-compressed with --compress 1 (OutputFile + ZlibSink, util/io/output_file.cpp:52-60)
+struct Sink {
+	FILE* f = nullptr;
+	gzFile g = nullptr;
+	void open(const std::string& path, bool gzip)
+	{
+		if (gzip) {
+			if (path.empty()) throw std::runtime_error("--compress needs an output file (-o)");
+			g = gzopen(path.c_str(), "wb");
+			if (!g) throw std::runtime_error("Error opening file " + path);
+			gzbuffer(g, 1 << 20);
+		}
+		else {
+			f = path.empty() ? stdout : std::fopen(path.c_str(), "w");
+			if (!f) throw std::runtime_error("Error opening file " + path);
+		}
+	}
+	void write(const char* p, size_t n)
+	{
+		if (n == 0) return;
+		if (g) { if (gzwrite(g, p, (unsigned)n) != (int)n) throw std::runtime_error("Error writing compressed output file"); }
+		else if (std::fwrite(p, 1, n, f) != n) throw std::runtime_error("Error writing output file");
+	}
+	void write(const std::string& t) { write(t.data(), t.size()); }
+	void close()
+	{
+		if (g) { if (gzclose(g) != Z_OK) throw std::runtime_error("Error closing compressed output file"); g = nullptr; }
+		if (f && f != stdout) std::fclose(f);
+		f = nullptr;
+	}
+};
 
 double ms_since(std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); }
 
@@ -643,6 +687,7 @@ int run_blastp(const Options& o)
 	double gf_evalue = 0.0;
 	chk(dmnd_seed_params_preset(&sp, sens, threads, &p, &gf_evalue));
 	if (o.index_chunks > 0) chk(dmnd_seed_params_set_index_chunks(&sp, o.index_chunks, threads));
+	if (o.shapes > 0 && o.shapes < sp.n_shapes) sp.n_shapes = o.shapes;
 	// one context per GPU, driven by its own host thread
 	std::vector<dmnd_ctx*> ctxs((size_t)n_gpus, nullptr);
 	for (int g = 0; g < n_gpus; ++g) {
@@ -695,24 +740,33 @@ int run_blastp(const Options& o)
 	// extend.cpp:168-181; run/double_indexed.cpp:300), i.e. the seed stage sees the unmasked reference block
 	const bool lazy_masking = algo == 1 && tantan;
 
-	FILE* out = o.out.empty() ? stdout : std::fopen(o.out.c_str(), "w");
-	if (!out) throw std::runtime_error("Error opening file " + o.out);
-	if (fmt == FMT_PAIRWISE) std::fputs("BLASTP 2.3.0+\n\n\n", out);                   // PairwiseFormat::print_header
+	Sink out;
+	{
+		std::string path = o.out;                // auto_append_extension(output_file, ".gz"), basic/config.cpp:771-772
+		if (o.compress && (path.size() < 3 || path.substr(path.size() - 3) != ".gz")) path += ".gz";
+		out.open(path, o.compress);
+	}
+	if (fmt == FMT_PAIRWISE) out.write("BLASTP 2.3.0+\n\n\n");                   // PairwiseFormat::print_header
 	if (fmt == FMT_FIELDS && o.header == "simple") {
 		std::vector<char> hb(4096);
 		const int64_t w = dmnd_format_fields_header(field_ids.data(), (int)field_ids.size(), hb.data(), (int64_t)hb.size());
 		if (w < 0) throw std::runtime_error(dmnd_last_error());
-		std::fwrite(hb.data(), 1, (size_t)w, out);
+		out.write(hb.data(), (size_t)w);
 	}
 	if (fmt == FMT_FIELDS && o.header == "verbose") {       // TabularFormat::print_header (program name and command line are ours)
-		std::fprintf(out, "# diamond-hip (ABI %d). MI355X back end of DIAMOND's seed-and-extend path\n# Fields: ", dmnd_abi_version());
-		for (size_t i = 1; i < o.outfmt.size(); ++i) std::fprintf(out, "%s%s", i > 1 ? ", " : "", o.outfmt[i].c_str());
-		if (o.outfmt.size() <= 1) std::fputs("qseqid, sseqid, pident, length, mismatch, gapopen, qstart, qend, sstart, send, evalue, bitscore", out);
-		std::fputc('\n', out);
+		std::string h = "# diamond-hip (ABI " + std::to_string(dmnd_abi_version()) + "). MI355X back end of DIAMOND's seed-and-extend path\n# Fields: ";
+		for (size_t i = 1; i < o.outfmt.size(); ++i) h += (i > 1 ? ", " : "") + o.outfmt[i];
+		if (o.outfmt.size() <= 1) h += "qseqid, sseqid, pident, length, mismatch, gapopen, qstart, qend, sstart, send, evalue, bitscore";
+		out.write(h + "\n");
 	}
-	if (fmt == FMT_SAM)                                                                // SamFormat::print_header (program name and version are ours)
-		std::fprintf(out, "@HD\tVN:1.5\tSO:query\n@PG\tPN:diamond-hip\tVN:ABI%d\n@mm\t%s\n@CO\t%s-like alignments\n@CO\tReporting AS: bitScore, ZR: rawScore, ZE: expected, ZI: percent identity, "
-			"ZL: reference length, ZF: frame, ZS: query start DNA coordinate\n", dmnd_abi_version(), blastx ? "BlastX" : "BlastP", blastx ? "BlastX" : "BlastP");
+	if (fmt == FMT_SAM) {                                                              // SamFormat::print_header (program name and version are ours)
+		const std::string prog = blastx ? "BlastX" : "BlastP";
+		out.write("@HD\tVN:1.5\tSO:query\n@PG\tPN:diamond-hip\tVN:ABI" + std::to_string(dmnd_abi_version()) + "\n@mm\t" + prog + "\n@CO\t" + prog
+			+ "-like alignments\n@CO\tReporting AS: bitScore, ZR: rawScore, ZE: expected, ZI: percent identity, ZL: reference length, ZF: frame, ZS: query start DNA coordinate\n");
+	}
+	FILE* un_file = nullptr; FILE* al_file = nullptr;          // --un / --al: config.unaligned / aligned_file, run/double_indexed.cpp:689-693
+	if (!o.un.empty() && !(un_file = std::fopen(o.un.c_str(), "w"))) throw std::runtime_error("Error opening file " + o.un);
+	if (!o.al.empty() && !(al_file = std::fopen(o.al.c_str(), "w"))) throw std::runtime_error("Error opening file " + o.al);
 	const std::vector<std::string>& qtitles = blastx ? read_ids : q_all.ids;
 	std::vector<std::string> qid(qtitles.size());
 	for (size_t i = 0; i < qid.size(); ++i) qid[i] = short_id(qtitles[i]);
@@ -865,7 +919,7 @@ int run_blastp(const Options& o)
 			return v;
 		};
 		std::vector<char> big;
-		auto put = [&](int64_t w, const char* p) { if (w < 0) throw std::runtime_error(dmnd_last_error()); std::fwrite(p, 1, (size_t)w, out); };
+		auto put = [&](int64_t w, const char* p) { if (w < 0) throw std::runtime_error(dmnd_last_error()); out.write(p, (size_t)w); };
 		int64_t i = 0;
 		// The pairwise and PAF formats also report queries without alignments, in query order (DEFAULT_REPORT_UNALIGNED): with one
 		// reference block only those that had seed hits (a query without any is skipped before the output stage, align/align.cpp:173-176,
@@ -915,8 +969,32 @@ int run_blastp(const Options& o)
 			if (i == 0 || joined[(size_t)i].query != joined[(size_t)i - 1].query) ++aligned;
 		}
 		total_matches += n_matches;
+		// --un / --al: the block's queries without / with a reported alignment, in file order, as FASTA wrapped at 160 letters with
+		// the letters of the block as it stands after masking (write_unaligned / write_aligned, data/queries.cpp:32-66; a read of a
+		// translated search as its DNA)
+		if (un_file || al_file) {
+			std::vector<uint8_t> has((size_t)(qr.end - qr.begin), 0);
+			for (int64_t k = 0; k < n_matches; ++k) has[(size_t)joined[(size_t)k].query - qr.begin] = 1;
+			std::string rec;
+			for (size_t qi = qr.begin; qi < qr.end; ++qi) {
+				FILE* f = has[qi - qr.begin] ? al_file : un_file;
+				if (!f) continue;
+				rec.assign(1, '>'); rec += qtitles[qi]; rec += '\n';
+				const size_t local = (qi - qr.begin) * C;
+				const int8_t* letters = blastx ? reads[qi].data() : q.data.data() + q.limits[local];
+				const int64_t n = blastx ? (int64_t)source_len[qi] : q.limits[local + 1] - q.limits[local] - 1;
+				const char* alphabet = blastx ? "ACGTN" : "ARNDCQEGHILKMFPSTWYVBJZX*_";
+				for (int64_t x = 0; x < n; x += 160) {
+					for (int64_t y = x; y < std::min(x + 160, n); ++y) rec += alphabet[letters[y] & 31];
+					rec += '\n';
+				}
+				if (std::fwrite(rec.data(), 1, rec.size(), f) != rec.size()) throw std::runtime_error("Error writing file");
+			}
+		}
 	}
-	if (out != stdout) std::fclose(out);
+	out.close();
+	if (un_file) std::fclose(un_file);
+	if (al_file) std::fclose(al_file);
 	for (dmnd_ctx* c : ctxs) dmnd_destroy(c);
 	std::cerr << "Uploading blocks to HBM...  [" << ms_upload / 1e3 << "s]\n";
 	if (motifs) std::cerr << "Soft-masked letters (motifs): " << motif_letters << "\n";

@@ -651,3 +651,41 @@ def test_cli_input_formats_and_translation_options_match_reference(tmp_path):
     assert len(seen) >= 5 and ref_x not in seen                        # the options change the result
     r = subprocess.run([CLI, "blastx", "-q", str(tmp_path / "reads.fna"), "-d", d, "--query-gencode", "7", "-o", str(tmp_path / "x.tsv")], capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and "Invalid genetic code id" in r.stderr
+
+
+def test_cli_unaligned_aligned_files_compressed_output_and_shape_count(tmp_path):
+    """--un / --al (FASTA of the queries without / with alignments, masked letters as the block holds them, DNA reads for blastx),
+    --compress 1 (gzip, ".gz" appended) and --shapes N against the reference."""
+    import gzip
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/diamond not built")
+    db, doff, q, qoff = synth.generate(200, members=10, queries=300, seed=41, decoy_frac=0.3)
+    rng = np.random.default_rng(5)
+    q = _plant_repeats(q, qoff, rng)                  # tantan masks these stretches: the --un / --al records show them as X
+    dna, off = synth.back_translate(q[: qoff[120]], qoff[:121], seed=42)
+    synth.write_fasta(str(tmp_path / "db.faa"), "t", db, doff)
+    synth.write_fasta(str(tmp_path / "q.faa"), "q", q, qoff)
+    synth.write_dna_fasta(str(tmp_path / "reads.fna"), "r", dna, off)
+    for mode, query, extra in (("blastp", "q.faa", []), ("blastp", "q.faa", ["-b0.00003", "--id", "50"]), ("blastx", "reads.fna", ["--fast"])):
+        outs = {}
+        for tag, exe in (("ref", REF), ("hip", CLI)):
+            _run([exe, mode, "-q", str(tmp_path / query), "-d", str(tmp_path / "db.faa"), "-p", "4", "-o", str(tmp_path / (tag + ".tsv")),
+                  "--un", str(tmp_path / (tag + ".un")), "--al", str(tmp_path / (tag + ".al"))] + extra)
+            outs[tag] = [open(tmp_path / (tag + e)).read() for e in (".tsv", ".un", ".al")]
+        assert outs["hip"] == outs["ref"], (mode, extra)
+        assert all(len(t) > 1000 for t in outs["ref"]), (mode, extra)
+        if mode == "blastp":
+            assert sum(l.count("XXXX") for l in outs["ref"][1].splitlines() + outs["ref"][2].splitlines() if not l.startswith(">")) > 5
+    args = ["blastp", "-q", str(tmp_path / "q.faa"), "-d", str(tmp_path / "db.faa"), "-p", "4", "--compress", "1"]
+    _run([REF] + args + ["-o", str(tmp_path / "refz.tsv")])
+    _run([CLI] + args + ["-o", str(tmp_path / "hipz.tsv")])
+    _run([CLI] + args + ["-o", str(tmp_path / "hipz2.tsv.gz"), "-f", "0"])
+    ref = gzip.open(str(tmp_path / "refz.tsv.gz"), "rt").read()
+    assert gzip.open(str(tmp_path / "hipz.tsv.gz"), "rt").read() == ref and len(ref) > 1000
+    assert gzip.open(str(tmp_path / "hipz2.tsv.gz"), "rt").read().startswith("BLASTP 2.3.0+")
+    for sens, n in (("--sensitive", "4"), ("--very-sensitive", "1"), ("--mid-sensitive", "40"), ("--fast", "1")):
+        args = ["blastp", sens, "-s", n, "-q", str(tmp_path / "q.faa"), "-d", str(tmp_path / "db.faa"), "-p", "4"]
+        _run([REF] + args + ["-o", str(tmp_path / "refs.tsv")])
+        _run([CLI] + args + ["-o", str(tmp_path / "hips.tsv")])
+        ref = open(tmp_path / "refs.tsv").read()
+        assert len(ref.splitlines()) > 200 and open(tmp_path / "hips.tsv").read() == ref, (sens, n)
