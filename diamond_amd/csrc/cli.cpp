@@ -408,6 +408,7 @@ struct Options {
 	int gap_open = -1, gap_extend = -1;
 	std::string un, al;             // --un / --al: FASTA files of the queries without / with alignments
 	int shapes = 0;                 // --shapes: the first N shapes of the sensitivity mode (ShapeConfig, basic/shape_config.h:34-44); 0 = all
+	int ext = DMND_EXT_DEFAULT;     // --ext
 	bool compress = false;          // --compress 1: gzip output, ".gz" appended to the file name
 	int strands = 3, gencode = 1, min_orf = 0;      // --strand (mask: 1 plus, 2 minus), --query-gencode, --min-orf: translated searches
 	int unal = -1;                  // --unal: report queries without alignments (-1 = the format's default)
@@ -449,6 +450,11 @@ Options parse(int argc, char** argv)
 		else if (a == "--no-self-hits") o.no_self_hits = true;
 		else if (a == "--matrix") o.matrix = need(i);
 		else if (a == "-s" || a == "--shapes") { o.shapes = std::atoi(need(i).c_str()); if (o.shapes < 0) throw std::runtime_error("Invalid number of seed shapes."); }
+		else if (a == "--ext") {
+			const std::string v = need(i);                      // Extension::Mode, align/extend.cpp:51-58
+			if (v == "banded-fast") o.ext = DMND_EXT_BANDED_FAST; else if (v == "banded-slow") o.ext = DMND_EXT_BANDED_SLOW; else if (v == "full") o.ext = DMND_EXT_FULL;
+			else throw std::runtime_error("--ext " + v + " is not part of this build (banded-fast, banded-slow, full)");
+		}
 		else if (a == "--un") o.un = need(i);
 		else if (a == "--al") o.al = need(i);
 		else if (a == "--unfmt" || a == "--alfmt") { if (need(i) != "fasta") throw std::runtime_error("Only the fasta format of --un / --al is part of this build."); }
@@ -700,6 +706,7 @@ int run_blastp(const Options& o)
 		chk(dmnd_set_comp_based_stats(c, o.cbs));
 		chk(dmnd_set_query_contexts(c, blastx ? 6 : 1));
 		chk(dmnd_set_sensitivity(c, sens));
+		chk(dmnd_set_extension_mode(c, o.ext));
 		chk(dmnd_set_gapped_filter(c, gf_evalue));
 		// several reference blocks per GPU: the query seed index of a query block is built once and kept for all of them
 		if (t_blocks.size() > (size_t)n_gpus) chk(dmnd_set_query_index_reuse(c, 1));

@@ -128,6 +128,7 @@ struct dmnd_ctx {
 	uint64_t query_generation = 0;             // bumped whenever the query block or its masks change
 	std::string qindex_signature;              // what the resident query seed index was built for (empty: nothing resident)
 	std::vector<int32_t> source_lens;          // translated queries: DNA read lengths of the query block (query cover)
+	int ext_mode = -1;                         // --ext: DMND_EXT_DEFAULT = what the sensitivity selects
 	int band_mode_fast = 1;                    // Extension::Mode::BANDED_FAST up to --sensitive, BANDED_SLOW from --more-sensitive up (align/extend.cpp:62-75)
 	std::vector<unsigned long long> seed_trace;   // DMND_TRACE: per shape Hamming survivors and deferred pairs of the last seed search
 	double ranking_block_letters = 2e9;        // default_letters of ranking_chunk_size (align/extend.cpp:87): 8e8 from --very-sensitive up

@@ -79,6 +79,7 @@ struct HostCfg {
 	int max_target_seqs = 25;
 	int64_t max_swipe_dp = 1000000;      // config.max_swipe_dp
 	int band_mode_fast = 1;              // Extension::Mode::BANDED_FAST for every sensitivity up to --sensitive
+	bool ext_full = false;               // Extension::Mode::FULL (--ext full): no chaining, one full-matrix DpTarget per target and context
 	double ref_letters = 0;
 	double ranking_block_letters = 2e9;
 	bool use_cbs = true;                 // config.comp_based_stats == 1 (Hauser bias); 0 = no composition correction
@@ -225,6 +226,13 @@ void plan_groups(const HostCfg& h, ChainWorkspace& ws, QueryWork& w, size_t g0, 
 		const SeqRef t{ tdata + tl[g.target], (int)(tl[g.target + 1] - tl[g.target] - 1) };
 		int ungapped[6] = { 0, 0, 0, 0, 0, 0 };
 		for (int f = 0; f < C; ++f) segs[f].clear();
+		if (h.ext_full) {
+			// Mode::FULL (ungapped.cpp:70-75, gapped_score.cpp:123-130): the contexts that have a seed hit, whole matrix each
+			for (size_t x = g.begin; x < g.end; ++x) ungapped[sh[x].frame] = std::max(ungapped[sh[x].frame], sh[x].score);
+			for (int f = 0; f < C; ++f)
+				if (ungapped[f] != 0) out.push_back(PlanTarget{ q0 + (uint32_t)f, g.target, -(t.len - 1), q[f].len, ungapped[0] });
+			continue;
+		}
 		const bool single_translated = C > 1 && g.end - g.begin == 1;      // ungapped.cpp:76-80: one seed hit of a translated query
 		if (single_translated) {                                           // becomes a one-diagonal ApproxHsp without extension
 			const HostSeedHit& x = sh[g.begin];
@@ -513,7 +521,11 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 	auto item_of = [&](uint32_t q, uint32_t t, int d0, int d1) {
 		return dmnd_dp_target{ ql[q], tl[t], h.use_cbs ? ql[q] : (int64_t)-1, (int32_t)(ql[q + 1] - ql[q] - 1), (int32_t)(tl[t + 1] - tl[t] - 1), d0, d1 };
 	};
-	auto dp_size = [](const dmnd_dp_target& d) { return (int64_t)dmnd_banded_cols(d.query_len, d.target_len, d.d_begin, d.d_end) * (int64_t)(d.d_end - d.d_begin); };
+	const bool full_matrix = h.ext_full;               // DP::Flags::FULL_MATRIX: DpTarget::cells = query length x target length, dp/dp.h:121-124
+	auto dp_size = [full_matrix](const dmnd_dp_target& d) {
+		return full_matrix ? (int64_t)d.query_len * (int64_t)d.target_len
+			: (int64_t)dmnd_banded_cols(d.query_len, d.target_len, d.d_begin, d.d_end) * (int64_t)(d.d_end - d.d_begin);
+	};
 	double sw1 = 0, sw2 = 0, tb2 = 0;
 	int64_t used = 0;
 	std::vector<dmnd_dp_target> items;
@@ -653,7 +665,9 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 				for (size_t k = s.r2_pos; k < s.r2_end; ++k) {
 					const Cand& cd = s.aligned[k];
 					const dmnd_dp_target d = item_of(s.w.query * C + (uint32_t)cd.frame, cd.target, cd.d_begin, cd.d_end);
-					if (dp_size(d) > h.max_swipe_dp) { me.it_st.push_back(d); me.ref_st.push_back(Ref{ i, k }); }      // DP::BandedSwipe::bin
+					// DP::BandedSwipe::bin (swipe_wrapper.cpp:75-102): above max_swipe_dp cells the statistics cells replace the traceback,
+					// unless the output needs the transcript -- then the matrix is traced whatever its size
+					if (dp_size(d) > h.max_swipe_dp && !transcript) { me.it_st.push_back(d); me.ref_st.push_back(Ref{ i, k }); }
 					else if (cd.arena >= 0) { KeptGroup& g = me.kept[(size_t)cd.arena]; g.items.push_back(d); g.src.push_back(cd.item); g.ref.push_back(Ref{ i, k }); }
 					else { me.it_tb.push_back(d); me.ref_tb.push_back(Ref{ i, k }); }
 				}
@@ -832,6 +846,8 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	h.source_lens = c->source_lens.empty() ? nullptr : c->source_lens.data();
 	h.ranking_block_letters = c->ranking_block_letters;
 	h.band_mode_fast = c->band_mode_fast;
+	h.ext_full = c->ext_mode == DMND_EXT_FULL;
+	if (c->ext_mode == DMND_EXT_BANDED_FAST) h.band_mode_fast = 1; else if (c->ext_mode == DMND_EXT_BANDED_SLOW) h.band_mode_fast = 0;
 	h.contexts = c->query_contexts;
 	h.use_cbs = c->comp_based_stats != 0;
 	const uint32_t C = (uint32_t)h.contexts;
@@ -987,6 +1003,13 @@ extern "C" int dmnd_set_sensitivity(dmnd_ctx* c, int sensitivity)
 	if (!c || sensitivity < DMND_SENS_FAST || sensitivity > DMND_SENS_ULTRA_SENSITIVE) return fail(DMND_E_ARG, "dmnd_set_sensitivity: bad argument");
 	c->ranking_block_letters = sensitivity >= DMND_SENS_VERY_SENSITIVE ? 800e6 : 2e9;      // extend.cpp:87
 	c->band_mode_fast = sensitivity <= DMND_SENS_SENSITIVE ? 1 : 0;                          // default_ext_mode, extend.cpp:62-75
+	return DMND_OK;
+}
+
+extern "C" int dmnd_set_extension_mode(dmnd_ctx* c, int mode)
+{
+	if (!c || mode < DMND_EXT_DEFAULT || mode > DMND_EXT_FULL) return fail(DMND_E_ARG, "dmnd_set_extension_mode: bad argument");
+	c->ext_mode = mode;
 	return DMND_OK;
 }
 

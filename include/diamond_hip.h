@@ -346,6 +346,11 @@ int dmnd_set_comp_based_stats(dmnd_ctx* ctx, int mode);
  * --sensitive, BANDED_SLOW from --more-sensitive up: src/align/extend.cpp:62-75, gapped_score.cpp:41-73), and ranking_chunk_size's
  * unit of reference-block letters (2e9, or 8e8 from --very-sensitive up: extend.cpp:79-92). */
 int dmnd_set_sensitivity(dmnd_ctx* ctx, int sensitivity);
+/* --ext banded-fast | banded-slow | full (Extension::Mode, src/align/extend.cpp:51-58): overrides the band mode of the sensitivity;
+ * FULL skips chaining and aligns every target that has a seed hit over its whole matrix in both rounds (align/ungapped.cpp:70-75,
+ * gapped_score.cpp:123-130,204-205, gapped_final.cpp:97-98) -- query length + target length must stay below DMND_MAX_BAND. */
+enum { DMND_EXT_DEFAULT = -1, DMND_EXT_BANDED_FAST = 0, DMND_EXT_BANDED_SLOW = 1, DMND_EXT_FULL = 2 };
+int dmnd_set_extension_mode(dmnd_ctx* ctx, int mode);
 /* --top PERCENT (config.toppercent): report the targets whose bit score is within PERCENT of the best one instead of the first
  * -k ones (output_range / append_hits / ranking_chunk_size with toppercent, align/culling.cpp:97-145, align/extend.cpp:88-89,336);
  * percent < 0 switches it off. dmnd_join_blocks_top is the block join for such a run (JoinRecord::cmp_score + GlobalCulling,

@@ -370,13 +370,10 @@ def test_cli_gpus_distributes_reference_blocks(tmp_path):
     assert r.returncode != 0 and "gfx950 device(s) visible" in r.stderr
 
 
-def test_cli_long_repeat_proteins_with_wide_bands(tmp_path):
-    """Long tandem-repeat proteins: the chains of a pair spread over thousands of diagonals and add_dp_targets merges them into
-    bands wider than one wavefront sweeps (round 1 aborted the block pair with DMND_E_BAND). Whole pipeline against the reference."""
-    if not os.path.exists(REF):
-        pytest.skip("oracle/_ref/diamond not built")
+def _write_repeat_protein_files(tmp_path, indel=0.02):
+    """Families plus long tandem-repeat proteins and multi-domain proteins with long unrelated insertions (db.faa, q.faa)."""
     rng = np.random.default_rng(8)
-    db, doff, q, qoff = synth.generate(40, members=4, queries=40, seed=9)
+    db, doff, q, qoff = synth.generate(40, members=4, queries=40, seed=9, indel=indel)
     seqs_t = [db[doff[i]:doff[i + 1]] for i in range(len(doff) - 1)]
     seqs_q = [q[qoff[i]:qoff[i + 1]] for i in range(len(qoff) - 1)]
 
@@ -406,6 +403,14 @@ def test_cli_long_repeat_proteins_with_wide_bands(tmp_path):
     for name, seqs, prefix in (("db.faa", seqs_t, "t"), ("q.faa", seqs_q, "q")):
         off = np.concatenate([[0], np.cumsum([len(s) for s in seqs])])
         synth.write_fasta(str(tmp_path / name), prefix, np.concatenate(seqs), off)
+
+
+def test_cli_long_repeat_proteins_with_wide_bands(tmp_path):
+    """Long tandem-repeat proteins: the chains of a pair spread over thousands of diagonals and add_dp_targets merges them into
+    bands wider than one wavefront sweeps (round 1 aborted the block pair with DMND_E_BAND). Whole pipeline against the reference."""
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/diamond not built")
+    _write_repeat_protein_files(tmp_path)
     traces = []
     for sens in (["--fast"], ["--sensitive"]):
         args = ["blastp"] + sens + ["-q", str(tmp_path / "q.faa"), "-d", str(tmp_path / "db.faa"), "-p", "4", "--masking", "0"]
@@ -418,6 +423,14 @@ def test_cli_long_repeat_proteins_with_wide_bands(tmp_path):
         assert open(tmp_path / "hip.tsv").read() == ref, sens
     print("\n".join(l for t in traces for l in t.splitlines() if "wavefronts each" in l or "band" in l.lower()))
     assert any("wavefronts each" in t for t in traces)        # some band was wider than one wavefront sweeps
+    # output that needs the transcript: matrices above max_swipe_dp cells are traced too (the statistics cells only replace the
+    # traceback when no transcript is asked for, swipe_wrapper.cpp:91-96)
+    for fmt in (["-f", "6", "qseqid", "sseqid", "length", "gapopen", "gaps", "btop", "cigar"], ["-f", "0"]):
+        args = ["blastp", "-q", str(tmp_path / "q.faa"), "-d", str(tmp_path / "db.faa"), "-p", "4", "--masking", "0"] + fmt
+        _run([REF] + args + ["-o", str(tmp_path / "ref.out")])
+        _run([CLI] + args + ["-o", str(tmp_path / "hip.out")])
+        ref = open(tmp_path / "ref.out").read()
+        assert len(ref) > 50000 and open(tmp_path / "hip.out").read() == ref, fmt
 
 
 def test_cli_top_percent_and_large_k_match_reference(tmp_path):
@@ -689,3 +702,22 @@ def test_cli_unaligned_aligned_files_compressed_output_and_shape_count(tmp_path)
         _run([CLI] + args + ["-o", str(tmp_path / "hips.tsv")])
         ref = open(tmp_path / "refs.tsv").read()
         assert len(ref.splitlines()) > 200 and open(tmp_path / "hips.tsv").read() == ref, (sens, n)
+
+
+def test_cli_extension_modes_match_reference(tmp_path):
+    """--ext banded-fast / banded-slow / full (whole-matrix alignment of every target with a seed hit, no chaining) on families with
+    many indels, tandem-repeat and multi-domain proteins -- data on which the three modes give different alignments."""
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/diamond not built")
+    _write_repeat_protein_files(tmp_path, indel=0.08)
+    seen = {}
+    for extra in (["--ext", "banded-fast"], ["--ext", "banded-slow"], ["--ext", "full"], ["--ext", "full", "--sensitive", "-f", "6", "qseqid", "sseqid", "length", "gapopen", "gaps", "btop"],
+                  ["--ext", "banded-fast", "--more-sensitive"], ["--ext", "full", "--fast", "--comp-based-stats", "0", "-k", "3"], ["--ext", "full", "--id", "30", "--query-cover", "40"]):
+        args = ["blastp", "-q", str(tmp_path / "q.faa"), "-d", str(tmp_path / "db.faa"), "-p", "4"] + extra
+        _run([REF] + args + ["-o", str(tmp_path / "ref.tsv")])
+        _run([CLI] + args + ["-o", str(tmp_path / "hip.tsv")])
+        ref = open(tmp_path / "ref.tsv").read()
+        assert len(ref.splitlines()) > 10, extra
+        assert open(tmp_path / "hip.tsv").read() == ref, extra
+        seen[" ".join(extra)] = ref
+    assert len({seen["--ext banded-fast"], seen["--ext banded-slow"], seen["--ext full"]}) == 3
