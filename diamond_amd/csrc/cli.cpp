@@ -592,7 +592,7 @@ int run_blastp(const Options& o)
 	std::vector<std::string> read_ids;
 	std::vector<std::vector<int8_t>> reads;
 	// --outfmt (output/output_format.cpp:178-200): 6 / tab with optional field names, 0 / pairwise
-	enum { FMT_TAB, FMT_FIELDS, FMT_PAIRWISE, FMT_PAF, FMT_SAM } fmt = FMT_TAB;
+	enum { FMT_TAB, FMT_FIELDS, FMT_PAIRWISE, FMT_PAF, FMT_SAM, FMT_XML } fmt = FMT_TAB;
 	std::vector<int32_t> field_ids;
 	int need_transcripts = 0;
 	if (!o.outfmt.empty()) {
@@ -620,7 +620,12 @@ int run_blastp(const Options& o)
 			fmt = FMT_SAM;
 			need_transcripts = 1;
 		}
-		else throw std::runtime_error("Invalid output format: " + f0 + " (this build prints 6 = BLAST tabular, 0 = BLAST pairwise, 101 = SAM and 103 = PAF)");
+		else if (f0 == "5" || f0 == "xml") {
+			if (o.outfmt.size() > 1) throw std::runtime_error("Invalid output format: the XML format takes no fields");
+			fmt = FMT_XML;
+			need_transcripts = 1;
+		}
+		else throw std::runtime_error("Invalid output format: " + f0 + " (this build prints 6 = BLAST tabular, 0 = BLAST pairwise, 5 = BLAST XML, 101 = SAM and 103 = PAF)");
 	}
 	// --unal / --header work on the field list: the default columns are a field list too
 	const bool tab_extras = o.unal == 1 || (!o.header.empty() && o.header != "0");
@@ -632,7 +637,7 @@ int run_blastp(const Options& o)
 	}
 	if (tab_extras && fmt != FMT_FIELDS && !o.header.empty() && o.header != "0") throw std::runtime_error("--header is only available for the tabular format");
 	// which formats report queries without alignments: pairwise, PAF and SAM by default (DEFAULT_REPORT_UNALIGNED), tabular with --unal 1
-	const bool report_unal = o.unal == 1 || (o.unal == -1 && (fmt == FMT_PAIRWISE || fmt == FMT_PAF || fmt == FMT_SAM));
+	const bool report_unal = o.unal == 1 || (o.unal == -1 && (fmt == FMT_PAIRWISE || fmt == FMT_PAF || fmt == FMT_SAM || fmt == FMT_XML));
 	bool want_full_sseq = false;
 	for (int32_t id : field_ids) want_full_sseq |= id == DMND_F_FULL_SSEQ;
 	auto t0 = std::chrono::steady_clock::now();
@@ -770,6 +775,17 @@ int run_blastp(const Options& o)
 		const std::string prog = blastx ? "BlastX" : "BlastP";
 		out.write("@HD\tVN:1.5\tSO:query\n@PG\tPN:diamond-hip\tVN:ABI" + std::to_string(dmnd_abi_version()) + "\n@mm\t" + prog + "\n@CO\t" + prog
 			+ "-like alignments\n@CO\tReporting AS: bitScore, ZR: rawScore, ZE: expected, ZI: percent identity, ZL: reference length, ZF: frame, ZS: query start DNA coordinate\n");
+	}
+	if (fmt == FMT_XML) {                                                              // XMLFormat::print_header (version string is ours)
+		const std::vector<std::string>& titles = blastx ? read_ids : q_all.ids;
+		if (!titles.empty()) {
+			const int32_t len0 = blastx ? source_len[0] : (int32_t)(q_all.limits[1] - q_all.limits[0] - 1);
+			std::vector<char> hb(titles[0].size() * 6 + o.db.size() + 4096);
+			const int64_t w = dmnd_format_xml_header(blastx ? "blastx" : "blastp", ("diamond-hip ABI " + std::to_string(dmnd_abi_version())).c_str(), o.db.c_str(), titles[0].c_str(), len0,
+				o.matrix.c_str(), p.gap_open, p.gap_extend, o.evalue, hb.data(), (int64_t)hb.size());
+			if (w < 0) throw std::runtime_error(dmnd_last_error());
+			out.write(hb.data(), (size_t)w);
+		}
 	}
 	FILE* un_file = nullptr; FILE* al_file = nullptr;          // --un / --al: config.unaligned / aligned_file, run/double_indexed.cpp:689-693
 	if (!o.un.empty() && !(un_file = std::fopen(o.un.c_str(), "w"))) throw std::runtime_error("Error opening file " + o.un);
@@ -931,13 +947,14 @@ int run_blastp(const Options& o)
 		// The pairwise and PAF formats also report queries without alignments, in query order (DEFAULT_REPORT_UNALIGNED): with one
 		// reference block only those that had seed hits (a query without any is skipped before the output stage, align/align.cpp:173-176,
 		// align/output.cpp:35-53), with several blocks every one (output/join_blocks.cpp:302-308,365-372).
-		const bool per_query = fmt == FMT_PAIRWISE || fmt == FMT_PAF || fmt == FMT_SAM || (fmt == FMT_FIELDS && report_unal);
+		const bool per_query = fmt == FMT_PAIRWISE || fmt == FMT_PAF || fmt == FMT_SAM || fmt == FMT_XML || (fmt == FMT_FIELDS && report_unal);
 		for (size_t qi = qr.begin; qi < qr.end && per_query; ++qi) {
 			const bool has = i < n_matches && joined[(size_t)i].query == (uint32_t)qi;
 			if (!has && (!report_unal || (t_blocks.size() == 1 && !seeded[qi - qr.begin]))) continue;
 			const int32_t qlen = blastx ? source_len[qi] : (int32_t)(q_all.limits[qi + 1] - q_all.limits[qi] - 1);
 			big.resize(qtitles[qi].size() + 256);
 			if (fmt == FMT_PAIRWISE) put(dmnd_format_pairwise_intro(qtitles[qi].c_str(), qlen, has ? 0 : 1, big.data(), (int64_t)big.size()), big.data());
+			else if (fmt == FMT_XML) { big.resize(qtitles[qi].size() * 6 + 512); put(dmnd_format_xml_query_intro(qtitles[qi].c_str(), (int64_t)qi, qlen, big.data(), (int64_t)big.size()), big.data()); }
 			else if (!has && fmt == FMT_FIELDS) {
 				const size_t local = (qi - qr.begin) * C;
 				const int32_t l0 = (int32_t)(q.limits[local + 1] - q.limits[local] - 1);
@@ -947,11 +964,16 @@ int run_blastp(const Options& o)
 			}
 			else if (!has) put(fmt == FMT_SAM ? dmnd_format_sam(nullptr, qtitles[qi].c_str(), big.data(), (int64_t)big.size())
 				: dmnd_format_paf(nullptr, qtitles[qi].c_str(), big.data(), (int64_t)big.size()), big.data());
+			int32_t xml_hit = 0;
 			for (; i < n_matches && joined[(size_t)i].query == (uint32_t)qi; ++i) {
 				const dmnd_match& m = joined[(size_t)i];
 				const dmnd_hsp_view v = view_of(m);
 				big.resize((size_t)m.hsp.length * 8 + std::strlen(v.qtitle) + std::strlen(v.stitle) + 4096);
 				if (fmt == FMT_PAIRWISE) put(dmnd_format_pairwise(&v, p.matrix8, big.data(), (int64_t)big.size()), big.data());
+				else if (fmt == FMT_XML) {
+					big.resize((size_t)m.hsp.length * 4 + 6 * std::strlen(v.stitle) + 4096);
+					put(dmnd_format_xml(&v, xml_hit++, 0, p.matrix8, big.data(), (int64_t)big.size()), big.data());
+				}
 				else if (fmt == FMT_FIELDS) {
 					big.resize((size_t)m.hsp.length * 4 + (size_t)v.qlen * 3 + (size_t)v.slen + std::strlen(v.qtitle) + 2 * std::strlen(v.stitle) + (size_t)v.source_len * 2 + 4096);
 					put(dmnd_format_fields(&v, field_ids.data(), (int)field_ids.size(), big.data(), (int64_t)big.size()), big.data());
@@ -959,6 +981,7 @@ int run_blastp(const Options& o)
 				else if (fmt == FMT_SAM) put(dmnd_format_sam(&v, nullptr, big.data(), (int64_t)big.size()), big.data());
 				else put(dmnd_format_paf(&v, nullptr, big.data(), (int64_t)big.size()), big.data());
 			}
+			if (fmt == FMT_XML) put(dmnd_format_xml_query_epilog(has ? 0 : 1, (int64_t)db.n, db.letters, p.K, p.lambda, big.data(), (int64_t)big.size()), big.data());
 			if (has) ++aligned;
 		}
 		for (; i < n_matches && !per_query; ++i) {
@@ -999,6 +1022,7 @@ int run_blastp(const Options& o)
 			}
 		}
 	}
+	if (fmt == FMT_XML) out.write("</BlastOutput_iterations>\n</BlastOutput>");        // XMLFormat::print_footer
 	out.close();
 	if (un_file) std::fclose(un_file);
 	if (al_file) std::fclose(al_file);

@@ -408,6 +408,156 @@ extern "C" int64_t dmnd_format_sam(const dmnd_hsp_view* v, const char* unaligned
 	return emit(o, buf, cap, "dmnd_format_sam");
 }
 
+// ---- BLAST XML (-f 5 / xml): src/output/xml_format.cpp ------------------------------------------------------------------------
+namespace {
+
+// EscapeSequences::XML (util/util.cpp:80-88)
+void xml_escaped(Out& o, const char* p, size_t n)
+{
+	for (size_t i = 0; i < n; ++i) {
+		switch (p[i]) {
+		case '"': o.s += "&quot;"; break;
+		case '\'': o.s += "&apos;"; break;
+		case '<': o.s += "&lt;"; break;
+		case '>': o.s += "&gt;"; break;
+		case '&': o.s += "&amp;"; break;
+		default: o.s += p[i];
+		}
+	}
+}
+
+// OutputFormat::print_title(buf, id, true, all_titles, separator, &EscapeSequences::XML): the titles of a record, escaped
+void xml_title(Out& o, const char* id, bool all_titles, const char* separator)
+{
+	const char* p = id;
+	int n = 0;
+	for (;;) {
+		const char* a = std::strchr(p, '\1');
+		const char* b = std::strstr(p, " >");
+		const char* e = a && b ? std::min(a, b) : a ? a : b;
+		const size_t len = e ? (size_t)(e - p) : std::strlen(p);
+		if (n++ > 0) o << separator;
+		xml_escaped(o, p, len);
+		if (!e || !all_titles) break;
+		p = e + (*e == '\1' ? 1 : 2);
+	}
+}
+
+// Util::Seq::get_accession (util/sequence/sequence.cpp:76-103): UniRef prefix, gi|N|db|acc|, db|acc|name and the version suffix
+std::string accession_of(std::string t)
+{
+	size_t i;
+	if (t.compare(0, 6, "UniRef") == 0) t.erase(0, t.find('_', 0) + 1);
+	else if ((i = t.find_first_of('|', 0)) != std::string::npos) {
+		if (t.compare(0, 3, "gi|") == 0) {
+			t.erase(0, t.find_first_of('|', i + 1) + 1);
+			i = t.find_first_of('|', 0);
+		}
+		t.erase(0, i + 1);
+		i = t.find_first_of('|', 0);
+		if (i != std::string::npos) t.erase(i);
+	}
+	i = t.find_last_of('.');
+	if (i != std::string::npos) t.erase(i);
+	return t;
+}
+
+void print_lf(Out& o, double x) { char b[48]; std::snprintf(b, sizeof b, "%lf", x); o.s += b; }      // TextBuffer::print_d
+
+}  // namespace
+
+extern "C" int64_t dmnd_format_xml_header(const char* program, const char* version, const char* database, const char* first_qtitle, int32_t first_qlen,
+	const char* matrix, int gap_open, int gap_extend, double max_evalue, char* buf, int64_t cap)
+{
+	if (!program || !version || !database || !first_qtitle || !matrix || !buf) return fail(DMND_E_ARG, "dmnd_format_xml_header: NULL argument");
+	Out o;
+	o << "<?xml version=\"1.0\"?>\n<!DOCTYPE BlastOutput PUBLIC \"-//NCBI//NCBI BlastOutput/EN\" \"http://www.ncbi.nlm.nih.gov/dtd/NCBI_BlastOutput.dtd\">\n<BlastOutput>\n"
+		<< "  <BlastOutput_program>" << program << "</BlastOutput_program>\n  <BlastOutput_version>" << version << "</BlastOutput_version>\n"
+		<< "  <BlastOutput_reference>Benjamin Buchfink, Xie Chao, and Daniel Huson (2015), &quot;Fast and sensitive protein alignment using DIAMOND&quot;, Nature Methods 12:59-60.</BlastOutput_reference>\n"
+		<< "  <BlastOutput_db>" << database << "</BlastOutput_db>\n  <BlastOutput_query-ID>Query_1</BlastOutput_query-ID>\n  <BlastOutput_query-def>";
+	// the escaped title, cut where the unescaped one has its first \1 (xml_format.cpp:120-123)
+	Out esc;
+	xml_escaped(esc, first_qtitle, std::strlen(first_qtitle));
+	const char* sep = std::strchr(first_qtitle, '\1');
+	o.s += sep ? esc.s.substr(0, (size_t)(sep - first_qtitle)) : esc.s;
+	char ev[48];
+	std::snprintf(ev, sizeof ev, "%g", max_evalue);                 // stringstream << double
+	o << "</BlastOutput_query-def>\n  <BlastOutput_query-len>" << first_qlen << "</BlastOutput_query-len>\n  <BlastOutput_param>\n    <Parameters>\n"
+		<< "      <Parameters_matrix>" << matrix << "</Parameters_matrix>\n      <Parameters_expect>" << ev << "</Parameters_expect>\n"
+		<< "      <Parameters_gap-open>" << gap_open << "</Parameters_gap-open>\n      <Parameters_gap-extend>" << gap_extend << "</Parameters_gap-extend>\n"
+		<< "      <Parameters_filter>F</Parameters_filter>\n    </Parameters>\n  </BlastOutput_param>\n<BlastOutput_iterations>\n";
+	return emit(o, buf, cap, "dmnd_format_xml_header");
+}
+
+extern "C" int64_t dmnd_format_xml_query_intro(const char* qtitle, int64_t qnum, int32_t qlen, char* buf, int64_t cap)
+{
+	if (!qtitle || !buf) return fail(DMND_E_ARG, "dmnd_format_xml_query_intro: NULL argument");
+	Out o;
+	o << "<Iteration>\n  <Iteration_iter-num>" << (long long)(qnum + 1) << "</Iteration_iter-num>\n  <Iteration_query-ID>Query_" << (long long)(qnum + 1)
+		<< "</Iteration_query-ID>\n  <Iteration_query-def>";
+	xml_title(o, qtitle, false, "");
+	o << "</Iteration_query-def>\n  <Iteration_query-len>" << qlen << "</Iteration_query-len>\n<Iteration_hits>\n";
+	return emit(o, buf, cap, "dmnd_format_xml_query_intro");
+}
+
+extern "C" int64_t dmnd_format_xml(const dmnd_hsp_view* v, int32_t hit_num, int32_t hsp_num, const int8_t* matrix8, char* buf, int64_t cap)
+{
+	if (!view_ok(v) || !matrix8 || !buf || hit_num < 0 || hsp_num < 0) return fail(DMND_E_ARG, "dmnd_format_xml: bad argument");
+	if (!v->transcript) return fail(DMND_E_ARG, "dmnd_format_xml: the XML format needs the transcript");
+	const dmnd_match& m = *v->match;
+	const dmnd_hsp& h = m.hsp;
+	Out o;
+	if (hsp_num == 0) {
+		if (hit_num > 0) o << "  </Hit_hsps>\n</Hit>\n";
+		o << "<Hit>\n  <Hit_num>" << hit_num + 1 << "</Hit_num>\n";
+		// Util::Seq::get_title_def: the id up to the first delimiter, the rest is the definition
+		const size_t cut = std::strcspn(v->stitle, ID_DELIMITERS), total = std::strlen(v->stitle);
+		const std::string id(v->stitle, cut), def = cut >= total ? std::string() : std::string(v->stitle + cut + 1);
+		o << "  <Hit_id>";
+		xml_escaped(o, id.data(), id.size());
+		o << "</Hit_id>\n  <Hit_def>";
+		xml_title(o, def.c_str(), true, " &gt;");
+		o << "</Hit_def>\n  <Hit_accession>";
+		const std::string acc = accession_of(id);
+		xml_escaped(o, acc.data(), acc.size());
+		o << "</Hit_accession>\n  <Hit_len>" << v->slen << "</Hit_len>\n  <Hit_hsps>\n";
+	}
+	int sb, se;
+	source_range(*v, sb, se);
+	const Frame f(*v);
+	o << "    <Hsp>\n      <Hsp_num>" << hsp_num + 1 << "</Hsp_num>\n      <Hsp_bit-score>" << m.bit_score << "</Hsp_bit-score>\n      <Hsp_score>" << h.score
+		<< "</Hsp_score>\n      <Hsp_evalue>";
+	o.print_e(m.evalue);
+	o << "</Hsp_evalue>\n      <Hsp_query-from>" << sb + 1 << "</Hsp_query-from>\n      <Hsp_query-to>" << se << "</Hsp_query-to>\n      <Hsp_hit-from>" << h.s_begin + 1
+		<< "</Hsp_hit-from>\n      <Hsp_hit-to>" << h.s_end << "</Hsp_hit-to>\n      <Hsp_query-frame>" << f.blast_frame() << "</Hsp_query-frame>\n"
+		<< "      <Hsp_hit-frame>0</Hsp_hit-frame>\n      <Hsp_identity>" << h.identities << "</Hsp_identity>\n      <Hsp_positive>" << h.positives
+		<< "</Hsp_positive>\n      <Hsp_gaps>" << h.gaps << "</Hsp_gaps>\n      <Hsp_align-len>" << h.length << "</Hsp_align-len>\n         <Hsp_qseq>";
+	for (Walk w(*v); w.good(); w.next()) o << w.query_char();
+	o << "</Hsp_qseq>\n         <Hsp_hseq>";
+	for (Walk w(*v); w.good(); w.next()) o << w.subject_char();
+	o << "</Hsp_hseq>\n      <Hsp_midline>";
+	for (Walk w(*v); w.good(); w.next())
+		o << (w.op == OP_MATCH ? AA[w.query()] : w.op == OP_SUBSTITUTION ? (matrix8[w.query() * 32 + w.subject()] > 0 ? '+' : ' ') : ' ');
+	o << "</Hsp_midline>\n    </Hsp>\n";
+	return emit(o, buf, cap, "dmnd_format_xml");
+}
+
+extern "C" int64_t dmnd_format_xml_query_epilog(int unaligned, int64_t db_seqs, int64_t db_letters, double K, double lambda, char* buf, int64_t cap)
+{
+	if (!buf) return fail(DMND_E_ARG, "dmnd_format_xml_query_epilog: NULL argument");
+	Out o;
+	if (!unaligned) o << "  </Hit_hsps>\n</Hit>\n";
+	o << "</Iteration_hits>\n  <Iteration_stat>\n    <Statistics>\n";
+	if (db_seqs >= 0) o << "      <Statistics_db-num>" << (long long)db_seqs << "</Statistics_db-num>\n";
+	if (db_letters >= 0) o << "      <Statistics_db-len>" << (long long)db_letters << "</Statistics_db-len>\n";
+	o << "      <Statistics_hsp-len>0</Statistics_hsp-len>\n      <Statistics_eff-space>0</Statistics_eff-space>\n      <Statistics_kappa>";
+	print_lf(o, K);
+	o << "</Statistics_kappa>\n      <Statistics_lambda>";
+	print_lf(o, lambda);
+	o << "</Statistics_lambda>\n      <Statistics_entropy>0</Statistics_entropy>\n    </Statistics>\n  </Iteration_stat>\n</Iteration>\n";
+	return emit(o, buf, cap, "dmnd_format_xml_query_epilog");
+}
+
 extern "C" int64_t dmnd_format_fields_unaligned(const char* qtitle, const int8_t* qseq, int32_t qlen, const int8_t* source_seq, int32_t source_len,
 	const int32_t* ids, int n, char* buf, int64_t cap)
 {

@@ -71,7 +71,7 @@ EXPORTS = ["dmnd_abi_version", "dmnd_last_error", "dmnd_default_params", "dmnd_c
            "dmnd_seed_params_set_index_chunks", "dmnd_join_blocks", "dmnd_set_sensitivity", "dmnd_touch_streams",
            "dmnd_seed_params_set_query_indexed", "dmnd_auto_query_indexed", "dmnd_set_motif_table", "dmnd_motif_table_size",
            "dmnd_soft_mask_block", "dmnd_output_fields", "dmnd_format_fields", "dmnd_format_pairwise_intro", "dmnd_format_pairwise",
-           "dmnd_format_paf", "dmnd_device_count", "dmnd_set_top_percent", "dmnd_join_blocks_top", "dmnd_set_filters", "dmnd_format_sam", "dmnd_set_query_source_lengths", "dmnd_format_fields_unaligned", "dmnd_format_fields_header", "dmnd_set_query_index_reuse", "dmnd_set_no_self_hits", "dmnd_matrix_params", "dmnd_masking_lambda", "dmnd_translate_opts", "dmnd_set_extension_mode"]
+           "dmnd_format_paf", "dmnd_device_count", "dmnd_set_top_percent", "dmnd_join_blocks_top", "dmnd_set_filters", "dmnd_format_sam", "dmnd_set_query_source_lengths", "dmnd_format_fields_unaligned", "dmnd_format_fields_header", "dmnd_set_query_index_reuse", "dmnd_set_no_self_hits", "dmnd_matrix_params", "dmnd_masking_lambda", "dmnd_translate_opts", "dmnd_set_extension_mode", "dmnd_format_xml_header", "dmnd_format_xml_query_intro", "dmnd_format_xml", "dmnd_format_xml_query_epilog"]
 
 
 def set_motif_table(codes):
@@ -385,6 +385,31 @@ def join_blocks_top(records, top_percent):
 def format_sam(match, transcript, qtitle, stitle, qseq, slen, **kw):
     view = _View(match, transcript, qtitle, stitle, qseq, slen, **kw)
     return _formatted(load().dmnd_format_sam, ctypes.byref(view.v), None)
+
+
+def format_xml_header(program, version, database, first_qtitle, first_qlen, matrix="blosum62", gap_open=11, gap_extend=1, max_evalue=0.001):
+    """`-f 5`: the file header (XMLFormat::print_header)."""
+    return _formatted(load().dmnd_format_xml_header, program.encode(), version.encode(), database.encode(), first_qtitle.encode(), ctypes.c_int32(int(first_qlen)),
+                      matrix.encode(), ctypes.c_int(int(gap_open)), ctypes.c_int(int(gap_extend)), ctypes.c_double(float(max_evalue)))
+
+
+def format_xml_query_intro(qtitle, qnum, qlen):
+    return _formatted(load().dmnd_format_xml_query_intro, qtitle.encode(), ctypes.c_int64(int(qnum)), ctypes.c_int32(int(qlen)))
+
+
+def format_xml(match, transcript, qtitle, stitle, qseq, slen, hit_num, hsp_num, matrix8, **kw):
+    """One <Hsp> of the XML format (hsp_num 0 opens the <Hit>)."""
+    view = _View(match, transcript, qtitle, stitle, qseq, slen, **kw)
+    m = np.ascontiguousarray(matrix8, dtype=np.int8)
+    return _formatted(load().dmnd_format_xml, ctypes.byref(view.v), ctypes.c_int32(int(hit_num)), ctypes.c_int32(int(hsp_num)), m.ctypes.data_as(ctypes.c_void_p))
+
+
+def format_xml_query_epilog(unaligned, db_seqs, db_letters, K, lambda_):
+    return _formatted(load().dmnd_format_xml_query_epilog, ctypes.c_int(1 if unaligned else 0), ctypes.c_int64(int(db_seqs)), ctypes.c_int64(int(db_letters)),
+                      ctypes.c_double(float(K)), ctypes.c_double(float(lambda_)))
+
+
+XML_FOOTER = "</BlastOutput_iterations>\n</BlastOutput>"
 
 
 def seed_params_sensitive(scoring, threads=1):

@@ -441,6 +441,16 @@ int64_t dmnd_format_paf(const dmnd_hsp_view* v, const char* unaligned_qtitle, ch
 /* SAM (`-f sam` / 101, src/output/sam_format.cpp:30-133): one alignment line per HSP (CIGAR, MD:Z and the reference's Z? tags);
  * v == NULL prints the line of an unaligned query (flag 4), which this format reports by default. The @HD/@PG header is the caller's. */
 int64_t dmnd_format_sam(const dmnd_hsp_view* v, const char* unaligned_qtitle, char* buf, int64_t cap);
+/* BLAST XML (`-f 5` / xml, src/output/xml_format.cpp): header of the file (print_header; program = "blastp" / "blastx", version and
+ * database name are the caller's), the <Iteration> opening of a query (print_query_intro; qnum = ordinal of the query in the file),
+ * one <Hsp> (print_match: hsp_num == 0 also opens the <Hit> and, for hit_num > 0, closes the one before), the closing of a query
+ * (print_query_epilog; db_seqs / db_letters < 0 = not printed) -- the footer is "</BlastOutput_iterations>\n</BlastOutput>". The format
+ * reports unaligned queries by default (intro + epilog with unaligned = 1). */
+int64_t dmnd_format_xml_header(const char* program, const char* version, const char* database, const char* first_qtitle, int32_t first_qlen,
+	const char* matrix, int gap_open, int gap_extend, double max_evalue, char* buf, int64_t cap);
+int64_t dmnd_format_xml_query_intro(const char* qtitle, int64_t qnum, int32_t qlen, char* buf, int64_t cap);
+int64_t dmnd_format_xml(const dmnd_hsp_view* v, int32_t hit_num, int32_t hsp_num, const int8_t* matrix8, char* buf, int64_t cap);
+int64_t dmnd_format_xml_query_epilog(int unaligned, int64_t db_seqs, int64_t db_letters, double K, double lambda, char* buf, int64_t cap);
 
 /* -- timing hooks for bench.py: device time of the DP kernels of the last dmnd_banded_swipe call,
  *    measured with HIP events on the stream the kernels ran on ------------------------------------ */

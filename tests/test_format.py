@@ -94,6 +94,45 @@ def test_pairwise_paf_and_sam_files_are_reproduced():
     assert "".join(sam) == gzip.open(os.path.join(HERE, "golden", "sam_k4.body.gz"), "rt").read()
 
 
+def test_xml_file_is_reproduced():
+    """`-f 5` (tests/golden/xml_k4.out.gz): header, one <Iteration> per query with its <Hit> / <Hsp> elements, statistics block, footer."""
+    p = hip.default_params()
+    M = np.array(p.matrix8, dtype=np.int8)
+    recs = list(records())
+    n_db = len({f["stitle"] for _, f, _, _ in recs} | {f["qtitle"] for _, f, _, _ in recs})
+    fasta = open(os.path.join(HERE, "golden", "ref_ctest", "data.faa")).read().split(">")[1:]
+    db_letters = sum(len("".join(r.split("\n")[1:])) for r in fasta)
+    assert n_db <= len(fasta)
+    first = fasta[0].split("\n")
+    out = [hip.format_xml_header("blastp", "diamond 2.2.2", "data.faa", first[0], len("".join(first[1:])))]
+    last, hit = None, 0
+    for line, f, m, tr in recs:
+        if f["qtitle"] != last:
+            if last is not None:
+                out.append(hip.format_xml_query_epilog(False, len(fasta), db_letters, p.K, p.lambda_))
+            out.append(hip.format_xml_query_intro(f["qtitle"], int(f["qnum"]), int(f["qlen"])))
+            last, hit = f["qtitle"], 0
+        out.append(hip.format_xml(m, tr, f["qtitle"], f["stitle"], letters(f["full_qseq"]), int(f["slen"]), hit, 0, M))
+        hit += 1
+    out.append(hip.format_xml_query_epilog(False, len(fasta), db_letters, p.K, p.lambda_))
+    out.append(hip.XML_FOOTER)
+    want = gzip.open(os.path.join(HERE, "golden", "xml_k4.out.gz"), "rt").read()
+    got = "".join(out)
+    if got != want:
+        g, w = got.splitlines(), want.splitlines()
+        bad = next(i for i in range(min(len(g), len(w))) if g[i] != w[i])
+        raise AssertionError("line %d:\n  got  %s\n  want %s" % (bad + 1, g[bad][:200], w[bad][:200]))
+    # titles: escapes, several titles of one record, accession parsing (Util::Seq::get_accession)
+    line, f, m, tr = recs[0]
+    x = hip.format_xml(m, tr, "q", 'gi|123|ref|NP_000001.2| first <protein> & "more"\x01sp|P12345|NAME_HUMAN second', letters(f["full_qseq"]), int(f["slen"]), 2, 0, M)
+    assert x.startswith("  </Hit_hsps>\n</Hit>\n<Hit>\n  <Hit_num>3</Hit_num>\n  <Hit_id>gi|123|ref|NP_000001.2|</Hit_id>\n"
+                        "  <Hit_def>first &lt;protein&gt; &amp; &quot;more&quot; &gt;sp|P12345|NAME_HUMAN second</Hit_def>\n  <Hit_accession>NP_000001</Hit_accession>\n")
+    assert "<Hit_accession>Q6GZX4</Hit_accession>" in hip.format_xml(m, tr, "q", "UniRef90_Q6GZX4 x", letters(f["full_qseq"]), int(f["slen"]), 0, 0, M)
+    assert hip.format_xml(m, tr, "q", "t", letters(f["full_qseq"]), int(f["slen"]), 0, 1, M).startswith("    <Hsp>\n      <Hsp_num>2</Hsp_num>")
+    assert "<Iteration_query-def>a &apos;b&apos;</Iteration_query-def>" in hip.format_xml_query_intro("a 'b'\x01second title", 4, 10)
+    assert hip.format_xml_query_epilog(True, -1, -1, 0.041, 0.267).startswith("</Iteration_hits>\n  <Iteration_stat>\n    <Statistics>\n      <Statistics_hsp-len>")
+
+
 def test_field_names_are_checked_like_the_reference():
     with pytest.raises(hip.DiamondHipError, match="Invalid output field: nosuchfield"):
         hip.output_fields(["qseqid", "nosuchfield"])

@@ -721,3 +721,25 @@ def test_cli_extension_modes_match_reference(tmp_path):
         assert open(tmp_path / "hip.tsv").read() == ref, extra
         seen[" ".join(extra)] = ref
     assert len({seen["--ext banded-fast"], seen["--ext banded-slow"], seen["--ext full"]}) == 3
+
+
+def test_cli_xml_format_matches_reference(tmp_path):
+    """-f 5 (BLAST XML) for blastp (one and several reference blocks, queries without alignments) and blastx; the version line of the
+    header names the program that wrote the file and is excluded."""
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/diamond not built")
+    db, doff, q, qoff = synth.generate(200, members=10, queries=150, seed=51, decoy_frac=0.3)
+    dna, off = synth.back_translate(q[: qoff[60]], qoff[:61], seed=52)
+    synth.write_fasta(str(tmp_path / "db.faa"), "t", db, doff)
+    synth.write_fasta(str(tmp_path / "q.faa"), "q", q, qoff)
+    synth.write_dna_fasta(str(tmp_path / "reads.fna"), "r", dna, off)
+    g = os.path.join(ROOT, "tests", "golden", "ref_ctest", "data.faa")
+    strip = lambda t: "\n".join(l for l in t.splitlines() if "<BlastOutput_version>" not in l)
+    for mode, query, database, extra in (("blastp", str(tmp_path / "q.faa"), str(tmp_path / "db.faa"), []), ("blastp", str(tmp_path / "q.faa"), str(tmp_path / "db.faa"), ["-b0.00003", "-k", "5"]),
+                                         ("blastp", g, g, ["-k", "3", "--matrix", "blosum45"]), ("blastx", str(tmp_path / "reads.fna"), str(tmp_path / "db.faa"), ["-e", "1e-5"])):
+        args = [mode, "-q", query, "-d", database, "-p", "4", "-f", "5"] + extra
+        _run([REF] + args + ["-o", str(tmp_path / "ref.xml")])
+        _run([CLI] + args + ["-o", str(tmp_path / "hip.xml")])
+        ref = open(tmp_path / "ref.xml").read()
+        assert ref.count("<Hsp>") > 100 and ref.count("<Iteration>") > 20 and ref.endswith("</BlastOutput>"), (mode, extra)
+        assert strip(open(tmp_path / "hip.xml").read()) == strip(ref), (mode, extra)
