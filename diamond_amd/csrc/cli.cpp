@@ -409,6 +409,7 @@ struct Options {
 	std::string un, al;             // --un / --al: FASTA files of the queries without / with alignments
 	int shapes = 0;                 // --shapes: the first N shapes of the sensitivity mode (ShapeConfig, basic/shape_config.h:34-44); 0 = all
 	int ext = DMND_EXT_DEFAULT;     // --ext
+	bool salltitles = false, sallseqid = false;      // DAA: full subject titles / all subject ids in the dictionary (DAAFormat, legacy/daa/daa_record.cpp:26-28)
 	bool compress = false;          // --compress 1: gzip output, ".gz" appended to the file name
 	int strands = 3, gencode = 1, min_orf = 0;      // --strand (mask: 1 plus, 2 minus), --query-gencode, --min-orf: translated searches
 	int unal = -1;                  // --unal: report queries without alignments (-1 = the format's default)
@@ -455,6 +456,8 @@ Options parse(int argc, char** argv)
 			if (v == "banded-fast") o.ext = DMND_EXT_BANDED_FAST; else if (v == "banded-slow") o.ext = DMND_EXT_BANDED_SLOW; else if (v == "full") o.ext = DMND_EXT_FULL;
 			else throw std::runtime_error("--ext " + v + " is not part of this build (banded-fast, banded-slow, full)");
 		}
+		else if (a == "--salltitles") o.salltitles = true;
+		else if (a == "--sallseqid") o.sallseqid = true;
 		else if (a == "--un") o.un = need(i);
 		else if (a == "--al") o.al = need(i);
 		else if (a == "--unfmt" || a == "--alfmt") { if (need(i) != "fasta") throw std::runtime_error("Only the fasta format of --un / --al is part of this build."); }
@@ -592,7 +595,7 @@ int run_blastp(const Options& o)
 	std::vector<std::string> read_ids;
 	std::vector<std::vector<int8_t>> reads;
 	// --outfmt (output/output_format.cpp:178-200): 6 / tab with optional field names, 0 / pairwise
-	enum { FMT_TAB, FMT_FIELDS, FMT_PAIRWISE, FMT_PAF, FMT_SAM, FMT_XML } fmt = FMT_TAB;
+	enum { FMT_TAB, FMT_FIELDS, FMT_PAIRWISE, FMT_PAF, FMT_SAM, FMT_XML, FMT_DAA } fmt = FMT_TAB;
 	std::vector<int32_t> field_ids;
 	int need_transcripts = 0;
 	if (!o.outfmt.empty()) {
@@ -620,12 +623,19 @@ int run_blastp(const Options& o)
 			fmt = FMT_SAM;
 			need_transcripts = 1;
 		}
+		else if (f0 == "100" || f0 == "daa") {
+			if (o.outfmt.size() > 1) throw std::runtime_error("Invalid output format: the DAA format takes no fields");
+			if (o.out.empty()) throw std::runtime_error("The DAA format needs an output file (-o)");
+			if (o.compress) throw std::runtime_error("Compression is not supported for DAA format.");
+			fmt = FMT_DAA;
+			need_transcripts = 1;
+		}
 		else if (f0 == "5" || f0 == "xml") {
 			if (o.outfmt.size() > 1) throw std::runtime_error("Invalid output format: the XML format takes no fields");
 			fmt = FMT_XML;
 			need_transcripts = 1;
 		}
-		else throw std::runtime_error("Invalid output format: " + f0 + " (this build prints 6 = BLAST tabular, 0 = BLAST pairwise, 5 = BLAST XML, 101 = SAM and 103 = PAF)");
+		else throw std::runtime_error("Invalid output format: " + f0 + " (this build prints 6 = BLAST tabular, 0 = BLAST pairwise, 5 = BLAST XML, 100 = DAA, 101 = SAM and 103 = PAF)");
 	}
 	// --unal / --header work on the field list: the default columns are a field list too
 	const bool tab_extras = o.unal == 1 || (!o.header.empty() && o.header != "0");
@@ -756,7 +766,24 @@ int run_blastp(const Options& o)
 	{
 		std::string path = o.out;                // auto_append_extension(output_file, ".gz"), basic/config.cpp:771-772
 		if (o.compress && (path.size() < 3 || path.substr(path.size() - 3) != ".gz")) path += ".gz";
+		if (fmt == FMT_DAA && (path.size() < 4 || path.substr(path.size() - 4) != ".daa")) path += ".daa";      // auto_append_extension, config.cpp:728
 		out.open(path, o.compress);
+	}
+	// DAA (legacy/daa/daa_write.cpp): header placeholder now, query records as they come, dictionary + final header at the end
+	dmnd_daa_header daa;
+	std::vector<uint32_t> daa_dict_id;                 // target ordinal -> dictionary id (order of first appearance in the output)
+	std::vector<uint32_t> daa_dict;                    // dictionary id -> target ordinal
+	int64_t daa_bytes = 0, daa_queries = 0;
+	if (fmt == FMT_DAA) {
+		daa.build = 182;                                // the build number of the reference version whose format this is (basic/const.h:25)
+		daa.db_seqs = (int64_t)db.n; daa.db_letters = db.letters; daa.db_seqs_used = 0; daa.query_records = 0;
+		daa.mode = blastx ? 3 : 2; daa.gap_open = p.gap_open; daa.gap_extend = p.gap_extend; daa.K = p.K; daa.lambda = p.lambda; daa.max_evalue = o.evalue;
+		daa.matrix = o.matrix.c_str(); daa.finished = 0; daa.alignment_bytes = 0; daa.ref_name_bytes = 0;
+		std::vector<char> hb(4096);
+		const int64_t w = dmnd_format_daa_header(&daa, hb.data(), (int64_t)hb.size());
+		if (w < 0) throw std::runtime_error(dmnd_last_error());
+		out.write(hb.data(), (size_t)w);
+		daa_dict_id.assign(db.n, UINT32_MAX);
 	}
 	if (fmt == FMT_PAIRWISE) out.write("BLASTP 2.3.0+\n\n\n");                   // PairwiseFormat::print_header
 	if (fmt == FMT_FIELDS && o.header == "simple") {
@@ -947,7 +974,7 @@ int run_blastp(const Options& o)
 		// The pairwise and PAF formats also report queries without alignments, in query order (DEFAULT_REPORT_UNALIGNED): with one
 		// reference block only those that had seed hits (a query without any is skipped before the output stage, align/align.cpp:173-176,
 		// align/output.cpp:35-53), with several blocks every one (output/join_blocks.cpp:302-308,365-372).
-		const bool per_query = fmt == FMT_PAIRWISE || fmt == FMT_PAF || fmt == FMT_SAM || fmt == FMT_XML || (fmt == FMT_FIELDS && report_unal);
+		const bool per_query = fmt == FMT_PAIRWISE || fmt == FMT_PAF || fmt == FMT_SAM || fmt == FMT_XML || fmt == FMT_DAA || (fmt == FMT_FIELDS && report_unal);
 		for (size_t qi = qr.begin; qi < qr.end && per_query; ++qi) {
 			const bool has = i < n_matches && joined[(size_t)i].query == (uint32_t)qi;
 			if (!has && (!report_unal || (t_blocks.size() == 1 && !seeded[qi - qr.begin]))) continue;
@@ -965,11 +992,28 @@ int run_blastp(const Options& o)
 			else if (!has) put(fmt == FMT_SAM ? dmnd_format_sam(nullptr, qtitles[qi].c_str(), big.data(), (int64_t)big.size())
 				: dmnd_format_paf(nullptr, qtitles[qi].c_str(), big.data(), (int64_t)big.size()), big.data());
 			int32_t xml_hit = 0;
+			std::string daa_rec;
+			if (fmt == FMT_DAA) {
+				const size_t local = (qi - qr.begin) * C;
+				const int8_t* letters = blastx ? reads[qi].data() : q.data.data() + q.limits[local];
+				const int32_t n = blastx ? source_len[qi] : (int32_t)(q.limits[local + 1] - q.limits[local] - 1);
+				big.resize(qtitles[qi].size() + (size_t)n + 64);
+				const int64_t w = dmnd_format_daa_query(qtitles[qi].c_str(), letters, n, blastx ? 1 : 0, big.data(), (int64_t)big.size());
+				if (w < 0) throw std::runtime_error(dmnd_last_error());
+				daa_rec.assign(big.data(), (size_t)w);
+			}
 			for (; i < n_matches && joined[(size_t)i].query == (uint32_t)qi; ++i) {
 				const dmnd_match& m = joined[(size_t)i];
 				const dmnd_hsp_view v = view_of(m);
 				big.resize((size_t)m.hsp.length * 8 + std::strlen(v.qtitle) + std::strlen(v.stitle) + 4096);
 				if (fmt == FMT_PAIRWISE) put(dmnd_format_pairwise(&v, p.matrix8, big.data(), (int64_t)big.size()), big.data());
+				else if (fmt == FMT_DAA) {
+					if (daa_dict_id[m.target] == UINT32_MAX) { daa_dict_id[m.target] = (uint32_t)daa_dict.size(); daa_dict.push_back(m.target); }
+					big.resize((size_t)m.hsp.transcript_len + 64);
+					const int64_t w = dmnd_format_daa_match(&v, daa_dict_id[m.target], big.data(), (int64_t)big.size());
+					if (w < 0) throw std::runtime_error(dmnd_last_error());
+					daa_rec.append(big.data(), (size_t)w);
+				}
 				else if (fmt == FMT_XML) {
 					big.resize((size_t)m.hsp.length * 4 + 6 * std::strlen(v.stitle) + 4096);
 					put(dmnd_format_xml(&v, xml_hit++, 0, p.matrix8, big.data(), (int64_t)big.size()), big.data());
@@ -980,6 +1024,13 @@ int run_blastp(const Options& o)
 				}
 				else if (fmt == FMT_SAM) put(dmnd_format_sam(&v, nullptr, big.data(), (int64_t)big.size()), big.data());
 				else put(dmnd_format_paf(&v, nullptr, big.data(), (int64_t)big.size()), big.data());
+			}
+			if (fmt == FMT_DAA) {                                               // finish_daa_query_record: byte count after the size field
+				const uint32_t size = (uint32_t)(daa_rec.size() - 4);
+				std::memcpy(&daa_rec[0], &size, 4);
+				out.write(daa_rec);
+				daa_bytes += (int64_t)daa_rec.size();
+				++daa_queries;
 			}
 			if (fmt == FMT_XML) put(dmnd_format_xml_query_epilog(has ? 0 : 1, (int64_t)db.n, db.letters, p.K, p.lambda, big.data(), (int64_t)big.size()), big.data());
 			if (has) ++aligned;
@@ -1023,6 +1074,37 @@ int run_blastp(const Options& o)
 		}
 	}
 	if (fmt == FMT_XML) out.write("</BlastOutput_iterations>\n</BlastOutput>");        // XMLFormat::print_footer
+	if (fmt == FMT_DAA) {                                                              // finish_daa, daa_write.cpp:75-123
+		const uint32_t zero = 0;
+		out.write((const char*)&zero, 4);
+		daa_bytes += 4;
+		int64_t name_bytes = 0;
+		for (uint32_t t : daa_dict) {
+			const std::string& title = db.title(t);
+			std::string name;
+			if (o.salltitles) name = title;
+			else if (o.sallseqid) {                                                     // Util::Seq::all_seqids: the id of every title of the record
+				size_t b = 0;
+				for (;;) {
+					const size_t e = title.find('\1', b);
+					if (b > 0) name += '\1';
+					name += short_id(title.substr(b, e == std::string::npos ? std::string::npos : e - b));
+					if (e == std::string::npos) break;
+					b = e + 1;
+				}
+			}
+			else name = title.substr(0, std::strcspn(title.c_str(), " \a\b\f\n\r\t\v\1"));
+			out.write(name.c_str(), name.size() + 1);
+			name_bytes += (int64_t)name.size() + 1;
+		}
+		for (uint32_t t : daa_dict) { const uint32_t len = (uint32_t)db.length(t); out.write((const char*)&len, 4); }
+		daa.db_seqs_used = (int64_t)daa_dict.size(); daa.query_records = daa_queries; daa.finished = 1; daa.alignment_bytes = daa_bytes; daa.ref_name_bytes = name_bytes;
+		std::vector<char> hb(4096);
+		const int64_t w = dmnd_format_daa_header(&daa, hb.data(), (int64_t)hb.size());
+		if (w < 0) throw std::runtime_error(dmnd_last_error());
+		if (std::fseek(out.f, 0, SEEK_SET) != 0) throw std::runtime_error("Error writing the DAA header");
+		out.write(hb.data(), (size_t)w);
+	}
 	out.close();
 	if (un_file) std::fclose(un_file);
 	if (al_file) std::fclose(al_file);

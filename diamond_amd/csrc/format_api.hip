@@ -558,6 +558,96 @@ extern "C" int64_t dmnd_format_xml_query_epilog(int unaligned, int64_t db_seqs, 
 	return emit(o, buf, cap, "dmnd_format_xml_query_epilog");
 }
 
+// ---- DAA (-f 100 / daa): src/legacy/daa/daa_write.cpp, daa_file.h ------------------------------------------------------------------
+namespace {
+
+struct Bin {
+	std::string s;
+	template<typename T> void put(T x) { s.append((const char*)&x, sizeof x); }
+	void packed(unsigned x)            // TextBuffer::write_packed: the narrowest of 1 / 2 / 4 bytes
+	{
+		if (x <= 0xffu) put((uint8_t)x); else if (x <= 0xffffu) put((uint16_t)x); else put((uint32_t)x);
+	}
+};
+
+unsigned length_flag(unsigned x) { return x <= 0xffu ? 0 : x <= 0xffffu ? 1 : 2; }       // get_length_flag, output/output.h:33-40
+
+int64_t emit_bin(const Bin& b, char* buf, int64_t cap, const char* who)
+{
+	if ((int64_t)b.s.size() > cap) return fail(DMND_E_CAP, std::string(who) + ": output buffer too small");
+	std::memcpy(buf, b.s.data(), b.s.size());
+	return (int64_t)b.s.size();
+}
+
+}  // namespace
+
+extern "C" int64_t dmnd_format_daa_header(const dmnd_daa_header* h, char* buf, int64_t cap)
+{
+	if (!h || !buf || !h->matrix || std::strlen(h->matrix) > 15 || (h->mode != 2 && h->mode != 3)) return fail(DMND_E_ARG, "dmnd_format_daa_header: bad argument");
+	Bin b;
+	b.put((uint64_t)0x3c0e53476d3ee36bULL); b.put((uint64_t)1);                         // DAA_header1: magic number, version
+	b.put((uint64_t)h->build); b.put((uint64_t)h->db_seqs); b.put((uint64_t)h->db_seqs_used); b.put((uint64_t)h->db_letters);
+	b.put((uint64_t)0); b.put((uint64_t)h->query_records);                               // flags, query_records
+	b.put((int32_t)h->mode); b.put((int32_t)h->gap_open); b.put((int32_t)h->gap_extend);
+	b.put((int32_t)0); b.put((int32_t)0); b.put((int32_t)0); b.put((int32_t)0); b.put((int32_t)0);    // reward, penalty, reserved1-3
+	b.put(h->K); b.put(h->lambda); b.put(h->max_evalue); b.put((double)0);
+	char name[16] = { 0 };
+	for (size_t i = 0; h->matrix[i]; ++i) name[i] = (char)std::tolower((unsigned char)h->matrix[i]);
+	b.s.append(name, 16);
+	uint64_t block_size[256] = { 0 };
+	char block_type[256] = { 0 };
+	if (h->finished) {
+		block_size[0] = (uint64_t)h->alignment_bytes; block_size[1] = (uint64_t)h->ref_name_bytes; block_size[2] = (uint64_t)h->db_seqs_used * 4;
+		block_type[0] = 1; block_type[1] = 2; block_type[2] = 3;                          // alignments, ref_names, ref_lengths
+	}
+	b.s.append((const char*)block_size, sizeof block_size);
+	b.s.append(block_type, sizeof block_type);
+	return emit_bin(b, buf, cap, "dmnd_format_daa_header");
+}
+
+extern "C" int64_t dmnd_format_daa_query(const char* qtitle, const int8_t* seq, int32_t len, int dna, char* buf, int64_t cap)
+{
+	if (!qtitle || !seq || len < 0 || !buf) return fail(DMND_E_ARG, "dmnd_format_daa_query: bad argument");
+	Bin b;
+	b.put((uint32_t)0);                                       // record size: the caller fills it in when the query's matches are written
+	b.put((uint32_t)len);
+	b.s.append(qtitle, std::strcspn(qtitle, ID_DELIMITERS));
+	b.s += '\0';
+	// PackedSequence (basic/packed_sequence.h:34-105): 5 bits per amino acid; DNA 2 bits per base, 3 when the read has an N
+	bool has_n = false;
+	if (dna) for (int32_t i = 0; i < len; ++i) has_n |= seq[i] == 4;
+	b.put((uint8_t)(has_n ? 1 : 0));
+	const unsigned bits = dna ? (has_n ? 3 : 2) : 5;
+	unsigned x = 0, n = 0;
+	for (int32_t i = 0; i < len; ++i) {
+		x |= (unsigned)(seq[i] & 31) << n;
+		n += bits;
+		if (n >= 8) { b.s += (char)(x & 0xff); n -= 8; x >>= 8; }
+	}
+	if (n > 0) b.s += (char)(x & 0xff);
+	return emit_bin(b, buf, cap, "dmnd_format_daa_query");
+}
+
+extern "C" int64_t dmnd_format_daa_match(const dmnd_hsp_view* v, uint32_t dict_id, char* buf, int64_t cap)
+{
+	if (!view_ok(v) || !buf) return fail(DMND_E_ARG, "dmnd_format_daa_match: bad argument");
+	if (!v->transcript) return fail(DMND_E_ARG, "dmnd_format_daa_match: the DAA format needs the transcript");
+	const dmnd_hsp& h = v->match->hsp;
+	int sb, se;
+	source_range(*v, sb, se);
+	const bool rev = v->match->frame > 2;
+	const unsigned qb = (unsigned)(rev ? se - 1 : sb);                   // Hsp::oriented_range().begin_, basic/match.h:168-174
+	Bin b;
+	b.put((uint32_t)dict_id);
+	b.put((uint8_t)(length_flag((unsigned)h.score) | (length_flag(qb) << 2) | (length_flag((unsigned)h.s_begin) << 4) | ((rev ? 1u : 0u) << 6)));
+	b.packed((unsigned)h.score);
+	b.packed(qb);
+	b.packed((unsigned)h.s_begin);
+	b.s.append((const char*)v->transcript, (size_t)h.transcript_len);
+	b.s += '\0';                                                        // PackedOperation::terminator
+	return emit_bin(b, buf, cap, "dmnd_format_daa_match");
+}
+
 extern "C" int64_t dmnd_format_fields_unaligned(const char* qtitle, const int8_t* qseq, int32_t qlen, const int8_t* source_seq, int32_t source_len,
 	const int32_t* ids, int n, char* buf, int64_t cap)
 {

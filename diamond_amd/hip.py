@@ -71,7 +71,7 @@ EXPORTS = ["dmnd_abi_version", "dmnd_last_error", "dmnd_default_params", "dmnd_c
            "dmnd_seed_params_set_index_chunks", "dmnd_join_blocks", "dmnd_set_sensitivity", "dmnd_touch_streams",
            "dmnd_seed_params_set_query_indexed", "dmnd_auto_query_indexed", "dmnd_set_motif_table", "dmnd_motif_table_size",
            "dmnd_soft_mask_block", "dmnd_output_fields", "dmnd_format_fields", "dmnd_format_pairwise_intro", "dmnd_format_pairwise",
-           "dmnd_format_paf", "dmnd_device_count", "dmnd_set_top_percent", "dmnd_join_blocks_top", "dmnd_set_filters", "dmnd_format_sam", "dmnd_set_query_source_lengths", "dmnd_format_fields_unaligned", "dmnd_format_fields_header", "dmnd_set_query_index_reuse", "dmnd_set_no_self_hits", "dmnd_matrix_params", "dmnd_masking_lambda", "dmnd_translate_opts", "dmnd_set_extension_mode", "dmnd_format_xml_header", "dmnd_format_xml_query_intro", "dmnd_format_xml", "dmnd_format_xml_query_epilog"]
+           "dmnd_format_paf", "dmnd_device_count", "dmnd_set_top_percent", "dmnd_join_blocks_top", "dmnd_set_filters", "dmnd_format_sam", "dmnd_set_query_source_lengths", "dmnd_format_fields_unaligned", "dmnd_format_fields_header", "dmnd_set_query_index_reuse", "dmnd_set_no_self_hits", "dmnd_matrix_params", "dmnd_masking_lambda", "dmnd_translate_opts", "dmnd_set_extension_mode", "dmnd_format_xml_header", "dmnd_format_xml_query_intro", "dmnd_format_xml", "dmnd_format_xml_query_epilog", "dmnd_format_daa_header", "dmnd_format_daa_query", "dmnd_format_daa_match"]
 
 
 def set_motif_table(codes):
@@ -410,6 +410,46 @@ def format_xml_query_epilog(unaligned, db_seqs, db_letters, K, lambda_):
 
 
 XML_FOOTER = "</BlastOutput_iterations>\n</BlastOutput>"
+
+
+class DaaHeader(ctypes.Structure):
+    """dmnd_daa_header (include/diamond_hip.h)."""
+    _fields_ = [("build", ctypes.c_int64), ("db_seqs", ctypes.c_int64), ("db_letters", ctypes.c_int64), ("db_seqs_used", ctypes.c_int64),
+                ("query_records", ctypes.c_int64), ("mode", ctypes.c_int32), ("gap_open", ctypes.c_int32), ("gap_extend", ctypes.c_int32),
+                ("K", ctypes.c_double), ("lambda_", ctypes.c_double), ("max_evalue", ctypes.c_double), ("matrix", ctypes.c_char_p),
+                ("finished", ctypes.c_int32), ("alignment_bytes", ctypes.c_int64), ("ref_name_bytes", ctypes.c_int64)]
+
+
+def _binary(fn, *args):
+    lib = load()
+    cap = 1 << 16
+    while True:
+        buf = ctypes.create_string_buffer(cap)
+        fn.restype = ctypes.c_int64
+        n = fn(*args, buf, ctypes.c_int64(cap))
+        if n == -5 and cap < (1 << 30):       # DMND_E_CAP
+            cap *= 8
+            continue
+        if n < 0:
+            raise DiamondHipError(lib.dmnd_last_error().decode())
+        return buf.raw[:n]
+
+
+def format_daa_header(**kw):
+    h = DaaHeader()
+    for k, v in kw.items():
+        setattr(h, k, v.encode() if k == "matrix" else v)
+    return _binary(load().dmnd_format_daa_header, ctypes.byref(h))
+
+
+def format_daa_query(qtitle, seq, dna=False):
+    s = np.ascontiguousarray(seq, dtype=np.int8)
+    return _binary(load().dmnd_format_daa_query, qtitle.encode(), s.ctypes.data_as(ctypes.c_void_p), ctypes.c_int32(s.size), ctypes.c_int(1 if dna else 0))
+
+
+def format_daa_match(match, transcript, qtitle, stitle, qseq, slen, dict_id, **kw):
+    view = _View(match, transcript, qtitle, stitle, qseq, slen, **kw)
+    return _binary(load().dmnd_format_daa_match, ctypes.byref(view.v), ctypes.c_uint32(int(dict_id)))
 
 
 def seed_params_sensitive(scoring, threads=1):

@@ -451,6 +451,28 @@ int64_t dmnd_format_xml_header(const char* program, const char* version, const c
 int64_t dmnd_format_xml_query_intro(const char* qtitle, int64_t qnum, int32_t qlen, char* buf, int64_t cap);
 int64_t dmnd_format_xml(const dmnd_hsp_view* v, int32_t hit_num, int32_t hsp_num, const int8_t* matrix8, char* buf, int64_t cap);
 int64_t dmnd_format_xml_query_epilog(int unaligned, int64_t db_seqs, int64_t db_letters, double K, double lambda, char* buf, int64_t cap);
+/* DAA (`-f 100` / daa: DIAMOND's alignment archive, src/legacy/daa/daa_write.cpp + daa_file.h:30-90). File layout: header
+ * (dmnd_format_daa_header: DAA_header1 + DAA_header2, 2448 bytes -- written first with finished = 0 and rewritten at the end), one
+ * record per aligned query (dmnd_format_daa_query: size placeholder, length, id, packed sequence -- the block's letters, a read as its
+ * DNA -- followed by its dmnd_format_daa_match records; the caller stores the record's byte count after the placeholder in its first 4
+ * bytes), a zero uint32, the titles of the targets used (one C string each, in dictionary order: the order of first appearance),
+ * their lengths as uint32. dict_id = index of the target in that dictionary. */
+typedef struct {
+	int64_t build;                 /* DAA_header2::diamond_build */
+	int64_t db_seqs, db_letters;   /* of the whole database */
+	int64_t db_seqs_used;          /* dictionary size */
+	int64_t query_records;
+	int32_t mode;                  /* AlignMode: 2 = blastp, 3 = blastx */
+	int32_t gap_open, gap_extend;
+	double K, lambda, max_evalue;
+	const char* matrix;            /* written in lower case */
+	int32_t finished;              /* 1: block sizes / types are filled in */
+	int64_t alignment_bytes;       /* bytes between the header and the reference names (records + the zero uint32) */
+	int64_t ref_name_bytes;
+} dmnd_daa_header;
+int64_t dmnd_format_daa_header(const dmnd_daa_header* h, char* buf, int64_t cap);
+int64_t dmnd_format_daa_query(const char* qtitle, const int8_t* seq, int32_t len, int dna, char* buf, int64_t cap);
+int64_t dmnd_format_daa_match(const dmnd_hsp_view* v, uint32_t dict_id, char* buf, int64_t cap);
 
 /* -- timing hooks for bench.py: device time of the DP kernels of the last dmnd_banded_swipe call,
  *    measured with HIP events on the stream the kernels ran on ------------------------------------ */

@@ -17,4 +17,6 @@ gzip -9nc "$tmp/pairwise.out" > "$here/pairwise_k4.out.gz"
 gzip -9nc "$tmp/paf.out" > "$here/paf_k4.out.gz"
 grep -v '^@' "$tmp/sam.out" | gzip -9nc > "$here/sam_k4.body.gz"
 gzip -9nc "$tmp/xml.out" > "$here/xml_k4.out.gz"
+"$ref" blastp -q data.faa -d data.faa -p 1 -k 4 -f 100 -o "$tmp/aln" --quiet
+gzip -9nc "$tmp/aln.daa" > "$here/daa_k4.daa.gz"
 rm -r "$tmp"

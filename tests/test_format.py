@@ -45,6 +45,28 @@ def transcript_of(qg, sg):
     return np.array(out, dtype=np.uint8)
 
 
+def transcript_as_traced(qg, sg):
+    """The transcript bytes as the traceback leaves them (Hsp::push_match / push_gap, basic/hssp.cpp:260-290): one byte per match
+    column, an insertion as runs of at most 63 pushed from the alignment's end (so the remainder comes first after the reversal)."""
+    out, i = [], 0
+    while i < len(qg):
+        a, b = qg[i], sg[i]
+        if b == "-":
+            j = i
+            while j < len(qg) and sg[j] == "-":
+                j += 1
+            n, runs = j - i, []
+            while n > 0:
+                runs.append(min(n, 63))
+                n -= runs[-1]
+            out.extend((1 << 6) | r for r in reversed(runs))
+            i = j
+            continue
+        out.append((2 << 6) | CODE[b] if a == "-" else 1 if a == b else (3 << 6) | CODE[b])
+        i += 1
+    return np.array(out, dtype=np.uint8)
+
+
 def records():
     lib = hip.load()
     lib.dmnd_bitscore_p.restype = ctypes.c_double
@@ -131,6 +153,53 @@ def test_xml_file_is_reproduced():
     assert hip.format_xml(m, tr, "q", "t", letters(f["full_qseq"]), int(f["slen"]), 0, 1, M).startswith("    <Hsp>\n      <Hsp_num>2</Hsp_num>")
     assert "<Iteration_query-def>a &apos;b&apos;</Iteration_query-def>" in hip.format_xml_query_intro("a 'b'\x01second title", 4, 10)
     assert hip.format_xml_query_epilog(True, -1, -1, 0.041, 0.267).startswith("</Iteration_hits>\n  <Iteration_stat>\n    <Statistics>\n      <Statistics_hsp-len>")
+
+
+def test_daa_file_is_reproduced():
+    """`-f 100` (tests/golden/daa_k4.daa.gz, reference run with -p 1): headers, query records with packed sequences, match records with
+    their packed coordinates and transcripts, dictionary of the targets in order of first appearance, lengths -- byte for byte."""
+    import struct
+    p = hip.default_params()
+    recs = list(records())
+    fasta = open(os.path.join(HERE, "golden", "ref_ctest", "data.faa")).read().split(">")[1:]
+    db_letters = sum(len("".join(r.split("\n")[1:])) for r in fasta)
+    head = dict(build=182, db_seqs=len(fasta), db_letters=db_letters, mode=2, gap_open=11, gap_extend=1, K=p.K, lambda_=p.lambda_, max_evalue=0.001, matrix="BLOSUM62")
+    body, dict_ids, names, lens = [], {}, [], []
+    last, rec, n_queries = None, None, 0
+
+    def close(r):
+        if r is not None:
+            body.append(struct.pack("<I", len(r) - 4) + r[4:])
+
+    for line, f, m, tr in recs:
+        if f["qtitle"] != last:
+            close(rec)
+            rec = hip.format_daa_query(f["qtitle"], letters(f["full_qseq"]))
+            last = f["qtitle"]
+            n_queries += 1
+        key = f["stitle"]
+        if key not in dict_ids:
+            dict_ids[key] = len(names)
+            names.append(f["sseqid"])
+            lens.append(int(f["slen"]))
+        raw = transcript_as_traced(f["qseq_gapped"], f["sseq_gapped"])
+        m = m.copy()
+        m["hsp"]["transcript_len"] = len(raw)
+        rec += hip.format_daa_match(m, raw, f["qtitle"], f["stitle"], letters(f["full_qseq"]), int(f["slen"]), dict_ids[key])
+    close(rec)
+    body.append(struct.pack("<I", 0))
+    aln = b"".join(body)
+    ref_names = b"".join(n.encode() + b"\0" for n in names)
+    header = hip.format_daa_header(db_seqs_used=len(names), query_records=n_queries, finished=1, alignment_bytes=len(aln), ref_name_bytes=len(ref_names), **head)
+    assert len(header) == 2448 and len(hip.format_daa_header(**head)) == 2448
+    got = header + aln + ref_names + b"".join(struct.pack("<I", x) for x in lens)
+    want = gzip.open(os.path.join(HERE, "golden", "daa_k4.daa.gz"), "rb").read()
+    if got != want:
+        bad = next(i for i in range(min(len(got), len(want))) if got[i] != want[i])
+        raise AssertionError("first difference at byte %d of %d / %d: got %r want %r" % (bad, len(got), len(want), got[bad:bad + 24], want[bad:bad + 24]))
+    # a translated query: DNA packed with 2 bits per base, 3 when it holds an N; reverse frames set bit 6 of the match flag
+    assert hip.format_daa_query("r1 x", np.array([0, 1, 2, 3, 3, 2, 1, 0], np.int8), dna=True) == struct.pack("<II", 0, 8) + b"r1\0" + bytes([0]) + bytes([0xE4, 0x1B])
+    assert hip.format_daa_query("r1", np.array([0, 4, 2], np.int8), dna=True)[11] == 1
 
 
 def test_field_names_are_checked_like_the_reference():

@@ -743,3 +743,32 @@ def test_cli_xml_format_matches_reference(tmp_path):
         ref = open(tmp_path / "ref.xml").read()
         assert ref.count("<Hsp>") > 100 and ref.count("<Iteration>") > 20 and ref.endswith("</BlastOutput>"), (mode, extra)
         assert strip(open(tmp_path / "hip.xml").read()) == strip(ref), (mode, extra)
+
+
+def test_cli_daa_format_matches_reference(tmp_path):
+    """-f 100 (DAA): byte-identical archives for blastp and blastx on one reference block (the header's build number is the reference
+    version's); with several reference blocks the dictionary order is an artefact of the block loop, so there the reference's own
+    `view` must print from our archive what it prints from its own; --salltitles / --sallseqid change the dictionary."""
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/diamond not built")
+    db, doff, q, qoff = synth.generate(200, members=10, queries=150, seed=61, decoy_frac=0.3)
+    dna, off = synth.back_translate(q[: qoff[60]], qoff[:61], seed=62)
+    synth.write_fasta(str(tmp_path / "db.faa"), "t", db, doff)
+    synth.write_fasta(str(tmp_path / "q.faa"), "q", q, qoff)
+    synth.write_dna_fasta(str(tmp_path / "reads.fna"), "r", dna, off)
+    g = os.path.join(ROOT, "tests", "golden", "ref_ctest", "data.faa")
+    for mode, query, database, extra in (("blastp", str(tmp_path / "q.faa"), str(tmp_path / "db.faa"), []), ("blastx", str(tmp_path / "reads.fna"), str(tmp_path / "db.faa"), ["--sensitive"]),
+                                         ("blastp", g, g, ["-k", "5", "--salltitles"]), ("blastp", g, g, ["-k", "2", "--sallseqid", "--matrix", "pam70"])):
+        args = [mode, "-q", query, "-d", database, "-p", "1", "-f", "100"] + extra
+        _run([REF] + args + ["-o", str(tmp_path / "ref")])
+        _run([CLI] + args + ["-o", str(tmp_path / "hip")])
+        ref, hip_ = open(tmp_path / "ref.daa", "rb").read(), open(tmp_path / "hip.daa", "rb").read()
+        assert len(ref) > 20000, (mode, extra)
+        assert hip_ == ref, (mode, extra, next(i for i in range(min(len(ref), len(hip_))) if ref[i] != hip_[i]) if ref[:len(hip_)] != hip_ else "length")
+    args = ["blastp", "-q", str(tmp_path / "q.faa"), "-d", str(tmp_path / "db.faa"), "-p", "4", "-b0.00003", "-k", "7"]
+    _run([CLI] + args + ["-f", "100", "-o", str(tmp_path / "blocks.daa")])
+    _run([REF] + args + ["-o", str(tmp_path / "direct.tsv")])
+    for fmt, name in ((["-f", "6"], "direct.tsv"),):
+        _run([REF, "view", "--daa", str(tmp_path / "blocks.daa"), "-o", str(tmp_path / "view.tsv")] + fmt)
+        want = open(tmp_path / name).read()
+        assert len(want.splitlines()) > 300 and open(tmp_path / "view.tsv").read() == want
