@@ -578,10 +578,12 @@ int run_blastp(const Options& o)
 	if (!o.sens.empty() && o.sens != "--sensitive" && o.sens != "--mid-sensitive" && o.sens != "--more-sensitive" && o.sens != "--very-sensitive" && o.sens != "--ultra-sensitive")
 		throw std::runtime_error("This build implements --fast, default, --mid-sensitive, --sensitive, --more-sensitive, --very-sensitive and --ultra-sensitive (" + o.sens + " is not available).");
 	if (o.fast && !o.sens.empty()) throw std::runtime_error("Conflicting sensitivity options.");
-	// --masking: tantan = default (run/config.cpp:124-135); seg is not part of this build
+	// --masking (MaskingMode, run/config.cpp:124-135): tantan = default, on both blocks and on the GPU; seg = NCBI's SEG over the
+	// reference block only, on the host as in the reference (dmnd_seg_mask_block); 0 / none
 	const bool tantan = o.masking.empty() || o.masking == "1" || o.masking == "tantan";
-	if (!tantan && o.masking != "0" && o.masking != "none")
-		throw std::runtime_error("Only --masking tantan (default) and --masking 0 are implemented.");
+	const bool seg = o.masking == "seg";
+	if (!tantan && !seg && o.masking != "0" && o.masking != "none")
+		throw std::runtime_error("Invalid value for --masking: " + o.masking + " (none / 0, seg, tantan / 1)");
 	if (!o.motif_masking.empty() && o.motif_masking != "0" && o.motif_masking != "1") throw std::runtime_error("Permitted values for --motif-masking: 0, 1");
 	// equal query and subject cover of 50 % and more switches the reference to its mutual-coverage search (length-sorted blocks, a
 	// length-ratio cutoff inside the seed stage: run/config.cpp:156-159) -- a clustering path that is not part of this build
@@ -747,7 +749,7 @@ int run_blastp(const Options& o)
 	// motif soft masking (soft_masking_algo, search/setup.cpp:322-335): on by default up to --sensitive, needs masking enabled
 	// when forced on. The motif table is reference data (tools/make_motif_table.py -> motifs.bin next to this binary).
 	bool motifs = o.motif_masking.empty() ? sens <= DMND_SENS_SENSITIVE : o.motif_masking == "1";
-	if (o.motif_masking == "1" && !tantan) throw std::runtime_error("Soft masking requires masking.");
+	if (o.motif_masking == "1" && !tantan && !seg) throw std::runtime_error("Soft masking requires masking.");
 	if (motifs) {
 		std::string dir = ".";
 		{ char buf[4096]; const ssize_t n = readlink("/proc/self/exe", buf, sizeof buf - 1); if (n > 0) { buf[n] = 0; dir = buf; dir = dir.substr(0, dir.find_last_of('/')); } }
@@ -760,7 +762,7 @@ int run_blastp(const Options& o)
 	}
 	// query-indexed + masking: the reference masks a target only when the extension stage loads it (lazy masking,
 	// extend.cpp:168-181; run/double_indexed.cpp:300), i.e. the seed stage sees the unmasked reference block
-	const bool lazy_masking = algo == 1 && tantan;
+	const bool lazy_masking = algo == 1 && (tantan || seg);
 
 	Sink out;
 	{
@@ -883,15 +885,24 @@ int run_blastp(const Options& o)
 			if (bn < t_blocks.size()) next = std::async(std::launch::async, [&db, &t_blocks, bn] { return db.load(t_blocks[bn].begin, t_blocks[bn].end); });
 			SeqBlock& t = held.block;
 			auto t0 = std::chrono::steady_clock::now();
-			chk(dmnd_upload_block(ctx, DMND_TARGET, t.data.data(), (int64_t)t.data.size(), t.limits.data(), (int64_t)(tr.end - tr.begin)));
-			double up = ms_since(t0), mk = 0;
-			const int8_t* t_host = t.data.data();            // the letters the extension stage's host part reads
+			double up = 0, mk = 0;
 			int64_t mt = 0, ml = 0;
+			const int64_t t_seqs = (int64_t)(tr.end - tr.begin);
+			// SEG runs on the host copy: a block that was just read is masked before it goes to HBM (up-front masking)
+			if (seg && !lazy_masking && fresh) { chk(dmnd_seg_mask_block(t.data.data(), t.limits.data(), t_seqs, threads, &mt)); mk += ms_since(t0); t0 = std::chrono::steady_clock::now(); }
+			chk(dmnd_upload_block(ctx, DMND_TARGET, t.data.data(), (int64_t)t.data.size(), t.limits.data(), t_seqs));
+			up += ms_since(t0);
+			const int8_t* t_host = t.data.data();            // the letters the extension stage's host part reads
 			auto mask_target = [&] {
 				t0 = std::chrono::steady_clock::now();
 				if (lazy_masking) {                            // t.data stays unmasked: the next query block's seed stage needs it so
 					t_masked[(size_t)g].resize(t.data.size());
-					chk(dmnd_mask_block(ctx, DMND_TARGET, t_masked[(size_t)g].data(), &mt));
+					if (seg) {                                   // masked copy on the host, then the block in HBM is replaced by it
+						std::memcpy(t_masked[(size_t)g].data(), t.data.data(), t.data.size());
+						chk(dmnd_seg_mask_block(t_masked[(size_t)g].data(), t.limits.data(), t_seqs, threads, &mt));
+						chk(dmnd_upload_block(ctx, DMND_TARGET, t_masked[(size_t)g].data(), (int64_t)t.data.size(), t.limits.data(), t_seqs));
+					}
+					else chk(dmnd_mask_block(ctx, DMND_TARGET, t_masked[(size_t)g].data(), &mt));
 					t_host = t_masked[(size_t)g].data();
 				}
 				else chk(dmnd_mask_block(ctx, DMND_TARGET, t.data.data(), &mt));
@@ -1111,6 +1122,7 @@ int run_blastp(const Options& o)
 	for (dmnd_ctx* c : ctxs) dmnd_destroy(c);
 	std::cerr << "Uploading blocks to HBM...  [" << ms_upload / 1e3 << "s]\n";
 	if (motifs) std::cerr << "Soft-masked letters (motifs): " << motif_letters << "\n";
+	if (seg) std::cerr << "Masking reference (seg)...  [" << ms_mask / 1e3 << "s]  masked letters: " << mt_total << "\n";
 	if (tantan) std::cerr << "Masking queries and reference (tantan)...  [" << ms_mask / 1e3 << "s]  masked letters: " << mq_total << " + " << mt_total << "\n";
 	std::cerr << "Searching alignments (seed stage)...  [" << ms_seed / 1e3 << "s]  hits=" << total_hits << "\n";
 	std::cerr << "Computing alignments (extension stage)...  [" << ms_ext / 1e3 << "s]\n";

@@ -7,6 +7,9 @@
 #include <vector>
 #include "ctx.h"
 #include "mask_kernels.h"
+#include "seg_mask.h"
+#include <atomic>
+#include <thread>
 
 using namespace dmnd;
 
@@ -116,6 +119,49 @@ extern "C" double dmnd_masking_lambda(const dmnd_params* p)
 	if (!p) { fail(DMND_E_ARG, "dmnd_masking_lambda: params is NULL"); return 0.0; }
 	return masking_lambda(p->matrix8);
 }
+
+// ---- SEG (--masking seg): host side, as in the reference ------------------------------------------------------------------------
+extern "C" int dmnd_seg_ranges(const int8_t* seq, int32_t len, int32_t* ranges, int32_t cap, int32_t* n)
+{
+	if (!seq || len < 0 || !n || cap < 0 || (cap > 0 && !ranges)) return fail(DMND_E_ARG, "dmnd_seg_ranges: bad argument");
+	const std::vector<seg::Range> r = seg::segments(seq, len);
+	*n = (int32_t)r.size();
+	if ((int32_t)r.size() > cap) return fail(DMND_E_CAP, "dmnd_seg_ranges: more segments than the output holds");
+	for (size_t i = 0; i < r.size(); ++i) { ranges[2 * i] = r[i].begin; ranges[2 * i + 1] = r[i].end; }
+	return DMND_OK;
+}
+
+extern "C" int dmnd_seg_mask_block(int8_t* data, const int64_t* limits, int64_t n_seqs, int threads, int64_t* n_masked)
+{
+	if (!data || !limits || n_seqs < 0) return fail(DMND_E_ARG, "dmnd_seg_mask_block: bad argument");
+	for (int64_t i = 0; i < n_seqs; ++i)
+		if (limits[i + 1] <= limits[i] || limits[i + 1] - limits[i] - 1 > INT32_MAX) return fail(DMND_E_ARG, "dmnd_seg_mask_block: limits are not a SequenceSet layout");
+	(void)seg::lnfact();                                    // built once, before the workers start
+	std::atomic<int64_t> next(0), masked(0);
+	auto worker = [&] {
+		int64_t mine = 0;
+		for (;;) {
+			const int64_t i0 = next.fetch_add(64, std::memory_order_relaxed);
+			if (i0 >= n_seqs) break;
+			for (int64_t i = i0; i < std::min(i0 + 64, n_seqs); ++i) {
+				int8_t* s = data + limits[i];
+				const int len = (int)(limits[i + 1] - limits[i] - 1);
+				for (const seg::Range& r : seg::segments(s, len))       // Masking::operator(), masking.cpp:186-190: the mask letter over [left, right]
+					for (int x = r.begin; x <= r.end; ++x) { s[x] = 23; ++mine; }
+			}
+		}
+		masked += mine;
+	};
+	const int T = (int)std::max<int64_t>(1, std::min<int64_t>(threads, (n_seqs + 63) / 64));
+	std::vector<std::thread> pool;
+	for (int t = 1; t < T; ++t) pool.emplace_back(worker);
+	worker();
+	for (std::thread& t : pool) t.join();
+	if (n_masked) *n_masked = masked.load();
+	return DMND_OK;
+}
+
+extern "C" double dmnd_seg_lnfact(uint32_t n) { return seg::lnfact()(n); }
 
 extern "C" int dmnd_set_motif_table(const uint64_t* codes, int64_t n)
 {

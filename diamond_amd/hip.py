@@ -71,7 +71,7 @@ EXPORTS = ["dmnd_abi_version", "dmnd_last_error", "dmnd_default_params", "dmnd_c
            "dmnd_seed_params_set_index_chunks", "dmnd_join_blocks", "dmnd_set_sensitivity", "dmnd_touch_streams",
            "dmnd_seed_params_set_query_indexed", "dmnd_auto_query_indexed", "dmnd_set_motif_table", "dmnd_motif_table_size",
            "dmnd_soft_mask_block", "dmnd_output_fields", "dmnd_format_fields", "dmnd_format_pairwise_intro", "dmnd_format_pairwise",
-           "dmnd_format_paf", "dmnd_device_count", "dmnd_set_top_percent", "dmnd_join_blocks_top", "dmnd_set_filters", "dmnd_format_sam", "dmnd_set_query_source_lengths", "dmnd_format_fields_unaligned", "dmnd_format_fields_header", "dmnd_set_query_index_reuse", "dmnd_set_no_self_hits", "dmnd_matrix_params", "dmnd_masking_lambda", "dmnd_translate_opts", "dmnd_set_extension_mode", "dmnd_format_xml_header", "dmnd_format_xml_query_intro", "dmnd_format_xml", "dmnd_format_xml_query_epilog", "dmnd_format_daa_header", "dmnd_format_daa_query", "dmnd_format_daa_match"]
+           "dmnd_format_paf", "dmnd_device_count", "dmnd_set_top_percent", "dmnd_join_blocks_top", "dmnd_set_filters", "dmnd_format_sam", "dmnd_set_query_source_lengths", "dmnd_format_fields_unaligned", "dmnd_format_fields_header", "dmnd_set_query_index_reuse", "dmnd_set_no_self_hits", "dmnd_matrix_params", "dmnd_masking_lambda", "dmnd_translate_opts", "dmnd_set_extension_mode", "dmnd_format_xml_header", "dmnd_format_xml_query_intro", "dmnd_format_xml", "dmnd_format_xml_query_epilog", "dmnd_format_daa_header", "dmnd_format_daa_query", "dmnd_format_daa_match", "dmnd_seg_ranges", "dmnd_seg_mask_block", "dmnd_seg_lnfact"]
 
 
 def set_motif_table(codes):
@@ -450,6 +450,31 @@ def format_daa_query(qtitle, seq, dna=False):
 def format_daa_match(match, transcript, qtitle, stitle, qseq, slen, dict_id, **kw):
     view = _View(match, transcript, qtitle, stitle, qseq, slen, **kw)
     return _binary(load().dmnd_format_daa_match, ctypes.byref(view.v), ctypes.c_uint32(int(dict_id)))
+
+
+def seg_ranges(seq):
+    """SEG segments of one sequence (int8 letters) as [(begin, end)] inclusive (dmnd_seg_ranges)."""
+    lib = load()
+    s = np.ascontiguousarray(seq, dtype=np.int8)
+    cap = max(16, s.size // 4)
+    out = np.zeros(2 * cap, np.int32)
+    n = ctypes.c_int32(0)
+    lib.dmnd_seg_ranges.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32)]
+    if lib.dmnd_seg_ranges(s.ctypes.data, s.size, out.ctypes.data, cap, ctypes.byref(n)) != 0:
+        raise DiamondHipError(lib.dmnd_last_error().decode())
+    return [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(n.value)]
+
+
+def seg_mask_block(data, limits, threads=1):
+    """Hard-masks a SequenceSet block in place with SEG (dmnd_seg_mask_block); returns the number of masked letters."""
+    lib = load()
+    assert data.dtype == np.int8 and data.flags["C_CONTIGUOUS"]
+    lim = np.ascontiguousarray(limits, dtype=np.int64)
+    n = ctypes.c_int64(0)
+    lib.dmnd_seg_mask_block.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_int64)]
+    if lib.dmnd_seg_mask_block(data.ctypes.data, lim.ctypes.data, len(lim) - 1, int(threads), ctypes.byref(n)) != 0:
+        raise DiamondHipError(lib.dmnd_last_error().decode())
+    return n.value
 
 
 def seed_params_sensitive(scoring, threads=1):

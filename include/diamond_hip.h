@@ -326,6 +326,15 @@ double dmnd_mask_kernel_ms(const dmnd_ctx* ctx);
  * (cbrc::LambdaCalculator::calculate, src/lib/tantan/LambdaCalculator.cc), or -1 where the matrix has none (PAM250) -- the value
  * the reference then uses too. */
 double dmnd_masking_lambda(const dmnd_params* params);
+/* SEG low-complexity masking (`--masking seg`: the reference then hard-masks the reference block with NCBI's SEG and leaves the queries
+ * alone, src/run/config.cpp:125-134, src/masking/masking.cpp:172-192, src/lib/blast/blast_seg.cpp). Host code, as in the reference:
+ * the driver masks the block it is about to upload. dmnd_seg_ranges: the segments [begin, end] (inclusive) of one sequence (letters
+ * 0-25), ascending; *n = their number (DMND_E_CAP if above cap). dmnd_seg_mask_block: letter 23 over every segment of every sequence
+ * of a SequenceSet block (data, limits as for dmnd_upload_block), `threads` host threads. dmnd_seg_lnfact: the ln(n!) SEG computes
+ * with (six-decimal table up to 10000, Stirling above). */
+int dmnd_seg_ranges(const int8_t* seq, int32_t len, int32_t* ranges, int32_t cap, int32_t* n);
+int dmnd_seg_mask_block(int8_t* data, const int64_t* limits, int64_t n_seqs, int threads, int64_t* n_masked);
+double dmnd_seg_lnfact(uint32_t n);
 /* Motif soft masking (default on up to --sensitive: sensitivity_traits.motif_masking, search/setup.cpp:40-53,322-335): while seeds
  * are enumerated the reference masks stretches covered by abundant 8-mer motifs (mask_motifs, masking/masking.cpp:110-131; the
  * letters come back before the filters and the extension run, Block::soft_mask / remove_soft_masking, data/block/block.cpp:164-177),

@@ -772,3 +772,33 @@ def test_cli_daa_format_matches_reference(tmp_path):
         _run([REF, "view", "--daa", str(tmp_path / "blocks.daa"), "-o", str(tmp_path / "view.tsv")] + fmt)
         want = open(tmp_path / name).read()
         assert len(want.splitlines()) > 300 and open(tmp_path / "view.tsv").read() == want
+
+
+def test_cli_seg_masking_matches_reference(tmp_path):
+    """--masking seg: the reference block hard-masked by SEG on the host (up front with the double-indexed algorithm, after the seed
+    stage with the query-indexed one), queries untouched; with and without motif soft masking, several reference blocks, blastx."""
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/diamond not built")
+    rng = np.random.default_rng(71)
+    db, doff, q, qoff = synth.generate(300, members=10, queries=300, seed=71)
+    db, q = _plant_repeats(db, doff, rng, frac=0.5), _plant_repeats(q, qoff, rng)
+    dna, off = synth.back_translate(q[: qoff[80]], qoff[:81], seed=72)
+    synth.write_fasta(str(tmp_path / "db.faa"), "t", db, doff)
+    synth.write_fasta(str(tmp_path / "q.faa"), "q", q, qoff)
+    synth.write_dna_fasta(str(tmp_path / "reads.fna"), "r", dna, off)
+    seen = set()
+    for mode, query, extra in (("blastp", "q.faa", []), ("blastp", "q.faa", ["--algo", "0"]), ("blastp", "q.faa", ["--algo", "1", "--motif-masking", "0"]),
+                               ("blastp", "q.faa", ["--sensitive", "--algo", "0", "-b0.00004"]), ("blastp", "q.faa", ["--fast", "-b0.00004"]), ("blastx", "reads.fna", [])):
+        args = [mode, "-q", str(tmp_path / query), "-d", str(tmp_path / "db.faa"), "-p", "4", "--masking", "seg"] + extra
+        _run([REF] + args + ["-o", str(tmp_path / "ref.tsv")])
+        r = _run([CLI] + args + ["-o", str(tmp_path / "hip.tsv")])
+        assert "Masking reference (seg)" in r.stderr
+        ref = open(tmp_path / "ref.tsv").read()
+        assert len(ref.splitlines()) > 100, (mode, extra)
+        assert open(tmp_path / "hip.tsv").read() == ref, (mode, extra)
+        seen.add(ref)
+    # SEG changes this workload: neither the unmasked nor the tantan-masked run gives the same lines
+    base = ["blastp", "-q", str(tmp_path / "q.faa"), "-d", str(tmp_path / "db.faa"), "-p", "4", "--algo", "0"]
+    for other in (["--masking", "0"], []):
+        _run([REF] + base + other + ["-o", str(tmp_path / "other.tsv")])
+        assert open(tmp_path / "other.tsv").read() not in seen
