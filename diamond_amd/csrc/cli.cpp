@@ -1138,10 +1138,20 @@ int main(int argc, char** argv)
 		const Options o = parse(argc, argv);
 		if (o.command == "version") { std::cout << "diamond-hip (MI355X back end of DIAMOND's seed-and-extend path), ABI " << dmnd_abi_version() << "\n"; return 0; }
 		if (o.command == "help" || o.command == "--help") {
-			std::cout << "Syntax: diamond-hip COMMAND [OPTIONS]\n  makedb --in FASTA -d DB        build a .dmnd database (no masking)\n"
-				"  blastp [--fast|--mid-sensitive|--sensitive|--more-sensitive|--very-sensitive|--ultra-sensitive] -q FASTA -d DB(.dmnd|FASTA) -o OUT [--masking 0] [-e EVALUE] [-k N] [-p THREADS] [-b BLOCK_SIZE] [-c INDEX_CHUNKS]\n"
-				"         [--algo 0|1] [--gpus N] [-f 6 [FIELD...] | -f 0 | -f paf]\n"
-				"  blastx [--fast|--sensitive] -q DNA_FASTA -d DB ...   (six-frame translation, standard genetic code)\n  version\n";
+			std::cout << "Syntax: diamond-hip COMMAND [OPTIONS]\n"
+				"  makedb --in FASTA -d DB              build a .dmnd database\n"
+				"  blastp -q PROTEINS -d DB -o OUT      protein search;  blastx -q READS -d DB -o OUT   translated search\n"
+				"  version\n\n"
+				"input        -q / -d: FASTA or FASTQ, gzip-compressed or not; -d also a .dmnd file\n"
+				"sensitivity  --fast | (none: default mode) | --mid-sensitive | --sensitive | --more-sensitive | --very-sensitive | --ultra-sensitive; --shapes N\n"
+				"scoring      --matrix BLOSUM45|50|62|80|90|PAM30|70|250  --gapopen N  --gapextend N  --comp-based-stats 0|1\n"
+				"masking      --masking tantan|seg|none  --motif-masking 0|1\n"
+				"extension    --ext banded-fast|banded-slow|full\n"
+				"reporting    -k N  --top PCT  -e EVALUE  --min-score BITS  --id PCT  --query-cover PCT  --subject-cover PCT  --no-self-hits\n"
+				"             --unal 0|1  --un FILE  --al FILE  --header [simple|verbose]  --compress 1  --salltitles  --sallseqid\n"
+				"formats      -f 6 [FIELD...] | 0 (pairwise) | 5 (XML) | 100 (DAA) | 101 (SAM) | 103 (PAF)\n"
+				"translated   --strand both|plus|minus  --query-gencode N  --min-orf N\n"
+				"resources    -p THREADS  --gpus N  -b BLOCK_SIZE  -c INDEX_CHUNKS  --algo 0|1|auto\n";
 			return 0;
 		}
 		if (o.command == "makedb") {
