@@ -410,6 +410,8 @@ struct Options {
 	int shapes = 0;                 // --shapes: the first N shapes of the sensitivity mode (ShapeConfig, basic/shape_config.h:34-44); 0 = all
 	int ext = DMND_EXT_DEFAULT;     // --ext
 	bool salltitles = false, sallseqid = false;      // DAA: full subject titles / all subject ids in the dictionary (DAAFormat, legacy/daa/daa_record.cpp:26-28)
+	std::string daa;                // -a / --daa: the archive `view` reads; for blastp / blastx the legacy way to ask for DAA output into this file
+	bool forwardonly = false;       // view: only alignments on the forward strand
 	bool compress = false;          // --compress 1: gzip output, ".gz" appended to the file name
 	int strands = 3, gencode = 1, min_orf = 0;      // --strand (mask: 1 plus, 2 minus), --query-gencode, --min-orf: translated searches
 	int unal = -1;                  // --unal: report queries without alignments (-1 = the format's default)
@@ -426,7 +428,7 @@ Options parse(int argc, char** argv)
 	std::vector<std::string> args;
 	for (int i = 2; i < argc; ++i) {
 		const std::string a = argv[i];
-		if (a.size() > 2 && a[0] == '-' && a[1] != '-' && std::string("pkebcqdofsl").find(a[1]) != std::string::npos) {
+		if (a.size() > 2 && a[0] == '-' && a[1] != '-' && std::string("pkebcqdofsla").find(a[1]) != std::string::npos) {
 			args.push_back(a.substr(0, 2));
 			args.push_back(a.substr(2));
 		}
@@ -458,6 +460,8 @@ Options parse(int argc, char** argv)
 		}
 		else if (a == "--salltitles") o.salltitles = true;
 		else if (a == "--sallseqid") o.sallseqid = true;
+		else if (a == "-a" || a == "--daa") o.daa = need(i);
+		else if (a == "--forwardonly") o.forwardonly = true;
 		else if (a == "--un") o.un = need(i);
 		else if (a == "--al") o.al = need(i);
 		else if (a == "--unfmt" || a == "--alfmt") { if (need(i) != "fasta") throw std::runtime_error("Only the fasta format of --un / --al is part of this build."); }
@@ -672,9 +676,10 @@ int run_blastp(const Options& o)
 	for (size_t i = 0; i < n_queries; ++i) {
 		if (!blastx) { q_units[i] = q_all.limits[i + 1] - q_all.limits[i] - 1; continue; }
 		// Block::push_back counts the letters of the ORFs that survive find_orfs (data/block/block.cpp:88-100)
-		const int l0 = (int)(q_all.limits[i * 6 + 1] - q_all.limits[i * 6] - 1), min_len = l0 < 30 ? 1 : l0 < 100 ? 20 : 40;
+		const int l0 = (int)(q_all.limits[i * 6 + 1] - q_all.limits[i * 6] - 1), min_len = o.min_orf > 0 ? o.min_orf : l0 < 30 ? 1 : l0 < 100 ? 20 : 40;
 		int64_t n = 0;
 		for (size_t f = 0; f < 6; ++f) {
+			if (!(o.strands & (f < 3 ? 1 : 2))) continue;             // frames of a strand that is not searched hold no ORF letters (block.cpp:92-99)
 			const int8_t* s = q_all.data.data() + q_all.limits[i * 6 + f];
 			const int len = (int)(q_all.limits[i * 6 + f + 1] - q_all.limits[i * 6 + f] - 1);
 			for (int x = 0, begin = 0; x <= len; ++x)
@@ -1130,6 +1135,184 @@ int run_blastp(const Options& o)
 	return 0;
 }
 
+// `view`: prints a DAA archive in another format (view_daa / view_query, src/legacy/daa/view.cpp:88-186). Host only: the records hold
+// score, begin coordinates and transcript; everything else is recomputed from them (dmnd_hsp_from_transcript).
+int run_view(const Options& o)
+{
+	if (o.daa.empty()) throw std::runtime_error("The view command requires a DAA (option -a) input file.");
+	std::string path = o.daa;
+	if (!std::ifstream(path).good() && std::ifstream(path + ".daa").good()) path += ".daa";
+	std::ifstream f(path, std::ios::binary | std::ios::ate);
+	if (!f) throw std::runtime_error("Error opening file " + path);
+	std::vector<uint8_t> file((size_t)f.tellg());
+	f.seekg(0);
+	if (!file.empty() && !f.read((char*)file.data(), (std::streamsize)file.size())) throw std::runtime_error("Error reading file " + path);
+	const size_t H1 = 16, H2 = 2432, HEAD = H1 + H2;
+	auto rd64 = [&](size_t off) { uint64_t x; std::memcpy(&x, file.data() + off, 8); return x; };
+	auto rd32 = [&](size_t off) { int32_t x; std::memcpy(&x, file.data() + off, 4); return x; };
+	auto rdd = [&](size_t off) { double x; std::memcpy(&x, file.data() + off, 8); return x; };
+	if (file.size() < HEAD || rd64(0) != 0x3c0e53476d3ee36bULL) throw std::runtime_error("Input file is not a DAA file.");
+	if (rd64(8) > 1) throw std::runtime_error("DAA version requires later version of DIAMOND.");
+	// DAA_header2 (legacy/daa/daa_file.h:41-90): build, db_seqs, db_seqs_used, db_letters, flags, query_records; mode, gap_open, gap_extend, ...
+	const uint64_t db_seqs = rd64(H1 + 8), used = rd64(H1 + 16), db_letters = rd64(H1 + 24);
+	const int32_t mode = rd32(H1 + 48), gap_open = rd32(H1 + 52), gap_extend = rd32(H1 + 56);
+	const double max_evalue = rdd(H1 + 96);
+	char matrix[17] = { 0 };
+	std::memcpy(matrix, file.data() + H1 + 112, 16);
+	const uint64_t aln_bytes = rd64(H1 + 128), name_bytes = rd64(H1 + 136);
+	if (aln_bytes == 0) throw std::runtime_error("Invalid DAA file. DIAMOND run has probably not completed successfully.");
+	if (mode != 2 && mode != 3) throw std::runtime_error("This build reads blastp and blastx archives.");
+	const bool blastx = mode == 3;
+	if (HEAD + aln_bytes + name_bytes + used * 4 > file.size()) throw std::runtime_error("Truncated DAA file.");
+	std::vector<const char*> ref_name((size_t)used);
+	{
+		const char* p = (const char*)file.data() + HEAD + aln_bytes;
+		const char* const end = p + name_bytes;
+		for (uint64_t i = 0; i < used; ++i) {
+			if (p >= end) throw std::runtime_error("Truncated DAA file.");
+			ref_name[(size_t)i] = p;
+			p += std::strlen(p) + 1;
+		}
+	}
+	const uint8_t* ref_len = file.data() + HEAD + aln_bytes + name_bytes;
+	dmnd_params p;
+	dmnd_default_params(&p);
+	if (dmnd_matrix_params(matrix, gap_open, gap_extend, &p) != DMND_OK) throw std::runtime_error(dmnd_last_error());
+	p.db_letters = (double)db_letters;
+	p.max_evalue = max_evalue;
+	std::cerr << "Scoring parameters: (Matrix=" << matrix << " Lambda=" << p.lambda << " K=" << p.K << " Penalties=" << gap_open << "/" << gap_extend << ")\nDB sequences = " << db_seqs
+		<< "\nDB sequences used = " << used << "\nDB letters = " << db_letters << "\n";
+
+	enum { V_FIELDS, V_PAIRWISE, V_XML, V_SAM, V_PAF } fmt = V_FIELDS;
+	std::vector<int32_t> field_ids;
+	int need_tr = 0;
+	std::vector<const char*> names;
+	const std::string f0 = o.outfmt.empty() ? "6" : o.outfmt[0];
+	if (f0 == "6" || f0 == "tab") {
+		static const char* const std_fields[12] = { "qseqid", "sseqid", "pident", "length", "mismatch", "gapopen", "qstart", "qend", "sstart", "send", "evalue", "bitscore" };
+		if (o.outfmt.size() > 1) for (size_t i = 1; i < o.outfmt.size(); ++i) names.push_back(o.outfmt[i].c_str());
+		else names.assign(std_fields, std_fields + 12);
+		field_ids.resize(names.size());
+		if (dmnd_output_fields(names.data(), (int)names.size(), field_ids.data(), &need_tr) != DMND_OK) throw std::runtime_error(dmnd_last_error());
+		for (int32_t id : field_ids)
+			if (id == DMND_F_FULL_SSEQ) throw std::runtime_error("full_sseq is not stored in a DAA file");
+	}
+	else if (f0 == "0" || f0 == "pairwise") fmt = V_PAIRWISE;
+	else if (f0 == "5" || f0 == "xml") fmt = V_XML;
+	else if (f0 == "101" || f0 == "sam") fmt = V_SAM;
+	else if (f0 == "103" || f0 == "paf") fmt = V_PAF;
+	else throw std::runtime_error("Invalid output format: " + f0 + " (view prints 6, 0, 5, 101 and 103)");
+	if (fmt != V_FIELDS && o.outfmt.size() > 1) throw std::runtime_error("Invalid output format: only the tabular format takes fields");
+
+	Sink out;
+	{
+		std::string op = o.out;
+		if (o.compress && (op.size() < 3 || op.substr(op.size() - 3) != ".gz")) op += ".gz";
+		out.open(op, o.compress);
+	}
+	std::vector<char> big(1 << 16);
+	auto put = [&](int64_t w) { if (w < 0) throw std::runtime_error(dmnd_last_error()); out.write(big.data(), (size_t)w); };
+	if (fmt == V_PAIRWISE) out.write("BLASTP 2.3.0+\n\n\n");
+	if (fmt == V_SAM) {
+		const std::string prog = blastx ? "BlastX" : "BlastP";
+		out.write("@HD\tVN:1.5\tSO:query\n@PG\tPN:diamond-hip\tVN:ABI" + std::to_string(dmnd_abi_version()) + "\n@mm\t" + prog + "\n@CO\t" + prog
+			+ "-like alignments\n@CO\tReporting AS: bitScore, ZR: rawScore, ZE: expected, ZI: percent identity, ZL: reference length, ZF: frame, ZS: query start DNA coordinate\n");
+	}
+	const int64_t K = o.k > 0 ? o.k : 25;
+	size_t pos = HEAD;
+	const size_t aln_end = HEAD + (size_t)aln_bytes;
+	int64_t qnum = 0, n_hsps = 0;
+	std::vector<int8_t> seq, frames[6];
+	for (;; ++qnum) {
+		if (pos + 4 > aln_end) throw std::runtime_error("Truncated DAA file.");
+		uint32_t size;
+		std::memcpy(&size, file.data() + pos, 4);
+		pos += 4;
+		if (size == 0) break;
+		if (pos + size > aln_end) throw std::runtime_error("Truncated DAA file.");
+		const uint8_t* r = file.data() + pos;
+		const uint8_t* const rend = r + size;
+		pos += size;
+		// DAA_query_record::init (daa_record.cpp:30-50): length, name, flags, packed letters
+		uint32_t qlen;
+		std::memcpy(&qlen, r, 4);
+		const char* qname = (const char*)r + 4;
+		const size_t name_len = strnlen(qname, (size_t)(rend - r) - 4);
+		const uint8_t* q = r + 4 + name_len + 1;
+		if (q >= rend) throw std::runtime_error("Malformed DAA query record.");
+		const unsigned bits = blastx ? ((*q & 1) ? 3 : 2) : 5;
+		++q;
+		const size_t packed = ((size_t)qlen * bits + 7) / 8;
+		if (q + packed > rend) throw std::runtime_error("Malformed DAA query record.");
+		seq.assign(qlen, 0);
+		{
+			unsigned x = 0, n = 0;
+			size_t l = 0;
+			for (size_t i = 0; i < packed; ++i) {
+				x |= (unsigned)q[i] << n;
+				n += 8;
+				while (n >= bits && l < qlen) { seq[l++] = (int8_t)(x & ((1u << bits) - 1)); n -= bits; x >>= bits; }
+			}
+		}
+		q += packed;
+		int32_t flen[6] = { (int32_t)qlen, 0, 0, 0, 0, 0 };
+		if (blastx) {
+			int8_t* outp[6];
+			for (int k = 0; k < 6; ++k) { frames[k].assign(qlen / 3 + 1, 0); outp[k] = frames[k].data(); }
+			// Translator::translate: the plain six-frame translation, no ORF masking (min_orf 1)
+			if (dmnd_translate_opts(seq.data(), (int32_t)qlen, o.gencode, 3, 1, outp, flen) != DMND_OK) throw std::runtime_error(dmnd_last_error());
+		}
+		const std::string qtitle(qname, name_len);
+		bool intro = false;
+		uint32_t last_subject = UINT32_MAX;
+		int32_t hit_num = -1, hsp_num = 0, top_score = 0;
+		while (q < rend) {
+			uint32_t dict = 0;
+			dmnd_match m;
+			int64_t tr_off = 0, usedb = 0;
+			if (dmnd_daa_match_read(q, (int64_t)(rend - q), blastx ? 1 : 0, (int32_t)qlen, &dict, &m, &tr_off, &usedb) != DMND_OK) throw std::runtime_error(dmnd_last_error());
+			const uint8_t* tr = q + tr_off;
+			q += usedb;
+			if (dict >= used) throw std::runtime_error("Malformed DAA match record.");
+			if (dict == last_subject) ++hsp_num; else { hsp_num = 0; ++hit_num; last_subject = dict; }
+			if (hit_num == 0 && hsp_num == 0) top_score = m.hsp.score;
+			if (m.frame > 2 && o.forwardonly) continue;
+			// Config::output_range (basic/config.h:426-432)
+			if (o.top >= 0.0 ? !((1.0 - (double)m.hsp.score / top_score) * 100 <= o.top) : !(hit_num < K)) break;
+			uint32_t slen;
+			std::memcpy(&slen, ref_len + (size_t)dict * 4, 4);
+			const int8_t* ctx = blastx ? frames[m.frame].data() : seq.data();
+			const int32_t ctx_len = blastx ? flen[m.frame] : (int32_t)qlen;
+			m.query = (uint32_t)qnum; m.target = dict;
+			m.hsp.transcript_off = 0;
+			if (dmnd_hsp_from_transcript(&p, ctx, ctx_len, flen[0], (int32_t)slen, tr, &m) != DMND_OK) throw std::runtime_error(dmnd_last_error());
+			dmnd_hsp_view v;
+			v.match = &m; v.transcript = tr; v.qtitle = qtitle.c_str(); v.stitle = ref_name[dict]; v.qseq = ctx; v.qlen = ctx_len; v.slen = (int32_t)slen; v.full_sseq = nullptr;
+			v.source_seq = blastx ? seq.data() : nullptr; v.source_len = blastx ? (int32_t)qlen : 0; v.qnum = 0; v.snum = (int64_t)dict;      // the reference's view hands 0 to every record as the query's ordinal (daa_record.h:46-52)
+			big.resize((size_t)m.hsp.length * 8 + (size_t)qlen * 3 + qtitle.size() * 6 + std::strlen(v.stitle) * 6 + 4096);
+			if (!intro) {
+				intro = true;
+				if (fmt == V_XML && qnum == 0)
+					put(dmnd_format_xml_header(blastx ? "blastx" : "blastp", ("diamond-hip ABI " + std::to_string(dmnd_abi_version())).c_str(), "", qtitle.c_str(), (int32_t)qlen, matrix,
+						gap_open, gap_extend, max_evalue, big.data(), (int64_t)big.size()));
+				if (fmt == V_PAIRWISE) put(dmnd_format_pairwise_intro(qtitle.c_str(), (int32_t)qlen, 0, big.data(), (int64_t)big.size()));
+				if (fmt == V_XML) put(dmnd_format_xml_query_intro(qtitle.c_str(), qnum, (int32_t)qlen, big.data(), (int64_t)big.size()));
+			}
+			if (fmt == V_FIELDS) put(dmnd_format_fields(&v, field_ids.data(), (int)field_ids.size(), big.data(), (int64_t)big.size()));
+			else if (fmt == V_PAIRWISE) put(dmnd_format_pairwise(&v, p.matrix8, big.data(), (int64_t)big.size()));
+			else if (fmt == V_XML) put(dmnd_format_xml(&v, hit_num, hsp_num, p.matrix8, big.data(), (int64_t)big.size()));
+			else if (fmt == V_SAM) put(dmnd_format_sam(&v, nullptr, big.data(), (int64_t)big.size()));
+			else put(dmnd_format_paf(&v, nullptr, big.data(), (int64_t)big.size()));
+			++n_hsps;
+		}
+		if (fmt == V_XML && intro) put(dmnd_format_xml_query_epilog(0, (int64_t)db_seqs, (int64_t)db_letters, p.K, p.lambda, big.data(), (int64_t)big.size()));
+	}
+	if (fmt == V_XML) out.write("</BlastOutput_iterations>\n</BlastOutput>");
+	out.close();
+	std::cerr << "Printed " << n_hsps << " HSPs of " << qnum << " queries.\n";
+	return 0;
+}
+
 }  // namespace
 
 int main(int argc, char** argv)
@@ -1141,7 +1324,7 @@ int main(int argc, char** argv)
 			std::cout << "Syntax: diamond-hip COMMAND [OPTIONS]\n"
 				"  makedb --in FASTA -d DB              build a .dmnd database\n"
 				"  blastp -q PROTEINS -d DB -o OUT      protein search;  blastx -q READS -d DB -o OUT   translated search\n"
-				"  version\n\n"
+				"  view -a ARCHIVE.daa -o OUT [-f ...]    print a DAA archive in another format\n  version\n\n"
 				"input        -q / -d: FASTA or FASTQ, gzip-compressed or not; -d also a .dmnd file\n"
 				"sensitivity  --fast | (none: default mode) | --mid-sensitive | --sensitive | --more-sensitive | --very-sensitive | --ultra-sensitive; --shapes N\n"
 				"scoring      --matrix BLOSUM45|50|62|80|90|PAM30|70|250  --gapopen N  --gapextend N  --comp-based-stats 0|1\n"
@@ -1161,8 +1344,17 @@ int main(int argc, char** argv)
 			write_dmnd(o.db, b);
 			return 0;
 		}
+		if (o.command == "view") return run_view(o);
+		if ((o.command == "blastp" || o.command == "blastx") && !o.daa.empty()) {       // -a FILE: the legacy spelling of -f 100 -o FILE (basic/config.cpp:716-724)
+			if (!o.out.empty()) throw std::runtime_error("Options --daa and --out cannot be used together.");
+			if (!o.outfmt.empty() && o.outfmt[0] != "daa" && o.outfmt[0] != "100") throw std::runtime_error("Invalid parameter: --daa/-a. Output file is specified with the --out/-o parameter.");
+			Options legacy = o;
+			legacy.outfmt.assign(1, "100");
+			legacy.out = o.daa;
+			return run_blastp(legacy);
+		}
 		if (o.command == "blastp" || o.command == "blastx") return run_blastp(o);
-		throw std::runtime_error("Invalid command: " + o.command + " (only makedb, blastp and blastx are part of this build)");
+		throw std::runtime_error("Invalid command: " + o.command + " (makedb, blastp, blastx and view are part of this build)");
 	}
 	catch (const std::exception& e) {
 		std::cerr << "Error: " << e.what() << std::endl;          // main.cpp:211-232

@@ -648,6 +648,78 @@ extern "C" int64_t dmnd_format_daa_match(const dmnd_hsp_view* v, uint32_t dict_i
 	return emit_bin(b, buf, cap, "dmnd_format_daa_match");
 }
 
+// ---- reading a DAA record back (the `view` command): DAA_query_record::Match::read, legacy/daa/daa_record.cpp:52-83 -------------
+extern "C" int dmnd_daa_match_read(const uint8_t* p, int64_t avail, int translated, int32_t source_len, uint32_t* dict_id, dmnd_match* m, int64_t* transcript_off,
+	int64_t* used)
+{
+	if (!p || avail < 0 || !dict_id || !m || !transcript_off || !used) return fail(DMND_E_ARG, "dmnd_daa_match_read: NULL argument");
+	int64_t o = 0;
+	auto need = [&](int64_t n) { return o + n <= avail; };
+	auto packed = [&](unsigned flag, uint32_t& x) -> bool {           // read_packed: 0 = one byte, 1 = two, 2 = four
+		const int n = flag == 0 ? 1 : flag == 1 ? 2 : 4;
+		if (flag > 2 || !need(n)) return false;
+		x = 0;
+		std::memcpy(&x, p + o, (size_t)n);
+		o += n;
+		return true;
+	};
+	if (!need(5)) return fail(DMND_E_ARG, "dmnd_daa_match_read: truncated record");
+	std::memcpy(dict_id, p, 4);
+	const uint8_t flag = p[4];
+	o = 5;
+	uint32_t score = 0, qb = 0, sb = 0;
+	if (!packed(flag & 3, score) || !packed((flag >> 2) & 3, qb) || !packed((flag >> 4) & 3, sb)) return fail(DMND_E_ARG, "dmnd_daa_match_read: truncated record");
+	*transcript_off = o;
+	while (o < avail && p[o] != 0) ++o;                                 // PackedOperation::terminator
+	if (o >= avail) return fail(DMND_E_ARG, "dmnd_daa_match_read: transcript without terminator");
+	std::memset(m, 0, sizeof *m);
+	m->hsp.transcript_len = (int32_t)(o - *transcript_off);
+	m->hsp.transcript_off = *transcript_off;
+	m->hsp.score = (int32_t)score;
+	m->hsp.s_begin = (int32_t)sb;
+	if (translated) {
+		const bool rev = (flag & (1 << 6)) != 0;
+		m->frame = rev ? 3 + (int32_t)(((uint32_t)source_len - 1 - qb) % 3) : (int32_t)(qb % 3);
+		// Hsp::set_translated_query_begin, basic/match.h:176-183
+		m->hsp.q_begin = rev ? (int32_t)(((uint32_t)source_len - 1 - (uint32_t)(m->frame - 3) - qb) / 3) : (int32_t)((qb - (uint32_t)m->frame) / 3);
+	}
+	else { m->frame = 0; m->hsp.q_begin = (int32_t)qb; }
+	*used = o + 1;
+	return DMND_OK;
+}
+
+// HspContext::parse (basic/hssp.cpp:48-105): ends, length, identities, mismatches, positives, gaps and gap openings (a run of
+// insertions and deletions is one opening) from the transcript; e-value and bit score from the score.
+extern "C" int dmnd_hsp_from_transcript(const dmnd_params* params, const int8_t* qseq, int32_t qlen, int32_t evalue_qlen, int32_t slen, const uint8_t* transcript, dmnd_match* m)
+{
+	if (!params || !qseq || !transcript || !m || qlen < 0) return fail(DMND_E_ARG, "dmnd_hsp_from_transcript: bad argument");
+	dmnd_hsp& h = m->hsp;
+	h.length = h.identities = h.mismatches = h.positives = h.gap_openings = h.gaps = 0;
+	int qpos = h.q_begin, spos = h.s_begin, run = 0;
+	for (int32_t k = 0; k < h.transcript_len; ++k) {
+		const uint8_t b = transcript[k];
+		const int op = b >> 6;
+		const int count = (op == OP_MATCH || op == OP_INSERTION) ? (b & 63) : 1;
+		for (int c = 0; c < count; ++c) {
+			if (op != OP_DELETION && qpos >= qlen) return fail(DMND_E_ARG, "Query sequence index out of bounds.");
+			++h.length;
+			if (op == OP_MATCH) { ++h.identities; ++h.positives; run = 0; }
+			else if (op == OP_SUBSTITUTION) {
+				++h.mismatches;
+				if (params->matrix8[(qseq[qpos] & 31) * 32 + (b & 31)] > 0) ++h.positives;
+				run = 0;
+			}
+			else { if (run == 0) ++h.gap_openings; ++run; ++h.gaps; }
+			if (op != OP_DELETION) ++qpos;
+			if (op != OP_INSERTION) ++spos;
+		}
+	}
+	h.q_end = qpos; h.s_end = spos;
+	m->evalue = dmnd_evalue_p(params, h.score, evalue_qlen, slen);
+	m->bit_score = dmnd_bitscore_p(params, (double)h.score);
+	return DMND_OK;
+}
+
 extern "C" int64_t dmnd_format_fields_unaligned(const char* qtitle, const int8_t* qseq, int32_t qlen, const int8_t* source_seq, int32_t source_len,
 	const int32_t* ids, int n, char* buf, int64_t cap)
 {

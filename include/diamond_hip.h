@@ -482,6 +482,14 @@ typedef struct {
 int64_t dmnd_format_daa_header(const dmnd_daa_header* h, char* buf, int64_t cap);
 int64_t dmnd_format_daa_query(const char* qtitle, const int8_t* seq, int32_t len, int dna, char* buf, int64_t cap);
 int64_t dmnd_format_daa_match(const dmnd_hsp_view* v, uint32_t dict_id, char* buf, int64_t cap);
+/* Reading an archive back (`view`): dmnd_daa_match_read parses one match record at p (DAA_query_record::Match::read,
+ * src/legacy/daa/daa_record.cpp:52-83: dictionary id, score, frame, begin coordinates -- of a translated query from its DNA position
+ * and the read length source_len --, the transcript's offset inside p and its length in hsp.transcript_len; *used = bytes consumed);
+ * dmnd_hsp_from_transcript fills the rest of the record as HspContext::parse does (src/basic/hssp.cpp:48-105) from the aligned query
+ * context qseq and the transcript, with the e-value of a query of evalue_qlen letters (the reference's view passes the length of
+ * frame 0 there) and the scoring parameters of the archive's header (params->db_letters = its database letters). */
+int dmnd_daa_match_read(const uint8_t* p, int64_t avail, int translated, int32_t source_len, uint32_t* dict_id, dmnd_match* m, int64_t* transcript_off, int64_t* used);
+int dmnd_hsp_from_transcript(const dmnd_params* params, const int8_t* qseq, int32_t qlen, int32_t evalue_qlen, int32_t slen, const uint8_t* transcript, dmnd_match* m);
 
 /* -- timing hooks for bench.py: device time of the DP kernels of the last dmnd_banded_swipe call,
  *    measured with HIP events on the stream the kernels ran on ------------------------------------ */

@@ -1,0 +1,66 @@
+"""`diamond-hip view` (host only): a DAA archive printed in the other formats must read as the reference's own `view` prints it
+(tests/golden/view_golden.txt.gz, minted by tests/golden/make_view_golden.sh) -- a blastx archive written by the reference (DNA
+coordinates, frames, the e-value rule of view) and the blastp archive of the ctest fixture; plus the legacy `-a` option and damaged
+files."""
+import gzip
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "diamond_amd", "diamond-hip")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def _sections():
+    out, name = {}, None
+    for line in gzip.open(os.path.join(GOLDEN, "view_golden.txt.gz"), "rt"):
+        if line.startswith("#### "):
+            name = line[5:].rstrip("\n")
+            out[name] = []
+        else:
+            out[name].append(line)
+    return {k: "".join(v) for k, v in out.items()}
+
+
+@pytest.fixture(scope="module")
+def archives(tmp_path_factory):
+    d = tmp_path_factory.mktemp("daa")
+    for a, src in (("bx", "daa_blastx.daa.gz"), ("k4", "daa_k4.daa.gz")):
+        open(d / (a + ".daa"), "wb").write(gzip.open(os.path.join(GOLDEN, src), "rb").read())
+    return d
+
+
+def test_view_prints_what_the_reference_view_prints(archives):
+    assert os.path.exists(CLI), "diamond-hip not built (make product)"
+    sections = _sections()
+    assert len(sections) == 12
+    for name, want in sections.items():
+        a, *args = name.split()
+        r = subprocess.run([CLI, "view", "-a", str(archives / (a + ".daa")), "-o", str(archives / "out")] + args, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, (name, r.stderr)
+        got = open(archives / "out").read()
+        if args[:2] == ["-f", "5"]:
+            got, want = "".join(l for l in got.splitlines(True) if "<BlastOutput_version>" not in l).rstrip("\n"), want.rstrip("\n")
+        if args[:2] == ["-f", "101"]:
+            got = "".join(l for l in got.splitlines(True) if not l.startswith("@PG"))
+        assert got == want, name
+        assert len(want) > 1000, name
+
+
+def test_view_options_and_damaged_files(archives):
+    r = subprocess.run([CLI, "view", "-a", str(archives / "bx"), "-f", "6", "qseqid", "full_sseq"], capture_output=True, text=True)      # ".daa" is appended
+    assert r.returncode != 0 and "not stored in a DAA file" in r.stderr
+    r = subprocess.run([CLI, "view", "-o", "x"], capture_output=True, text=True)
+    assert r.returncode != 0 and "requires a DAA" in r.stderr
+    raw = open(archives / "k4.daa", "rb").read()
+    open(archives / "bad1.daa", "wb").write(b"\0" * 8 + raw[8:])
+    open(archives / "bad2.daa", "wb").write(raw[: len(raw) // 2])
+    open(archives / "bad3.daa", "wb").write(raw[:16 + 128] + b"\0" * 8 + raw[16 + 136:])          # block size 0: run did not finish
+    for name, msg in (("bad1", "not a DAA file"), ("bad2", "Truncated DAA file"), ("bad3", "has probably not completed")):
+        r = subprocess.run([CLI, "view", "-a", str(archives / (name + ".daa")), "-o", str(archives / "x")], capture_output=True, text=True)
+        assert r.returncode != 0 and msg in r.stderr, (name, r.stderr)
+    # gzip output of view
+    r = subprocess.run([CLI, "view", "-a", str(archives / "bx.daa"), "--compress", "1", "-o", str(archives / "z.tsv")], capture_output=True, text=True)
+    assert r.returncode == 0 and gzip.open(str(archives / "z.tsv.gz"), "rt").read() == _sections()["bx -f 6"]
