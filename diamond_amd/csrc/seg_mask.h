@@ -79,6 +79,19 @@ inline double entropy(const int* sv)
 	return std::fabs(ent / (double)total);
 }
 
+// The entropy of a trigger window only depends on its state vector, and a window of 10 letters has 139 of them: the values are
+// kept per thread (same function of the same input, so the numbers are the ones entropy() returns).
+inline double window_entropy(const int* sv)
+{
+	struct Entry { uint64_t key; double value; };
+	thread_local Entry cache[512] = {};
+	uint64_t key = 1;                                   // counts are at most WINDOW = 10: four bits each, at most ten of them
+	for (int i = 0; sv[i] != 0; ++i) key = (key << 4) | (uint64_t)sv[i];
+	Entry& e = cache[(key * 0x9E3779B97F4A7C15ULL) >> 55];
+	if (e.key != key) { e.key = key; e.value = entropy(sv); }
+	return e.value;
+}
+
 // ln of the number of compositions of a complexity state (s_LnAss, :1871-1911): 20! / (product over the groups of equal counts
 // of their multiplicity!, the zero counts being one group)
 inline double ln_ass(const int* sv)
@@ -148,7 +161,7 @@ inline void seg_seq(const int8_t* s, int len, int offset, std::vector<Range>& ou
 		Window w;
 		w.open(s, WINDOW);
 		for (int i = first; i <= last; ++i) {
-			if (w.bogus <= MAX_BOGUS) H[(size_t)i] = entropy(w.state);
+			if (w.bogus <= MAX_BOGUS) H[(size_t)i] = window_entropy(w.state);
 			if (i < last) w.shift(s[i - first], s[i - first + WINDOW]);
 		}
 	}
