@@ -428,7 +428,7 @@ Options parse(int argc, char** argv)
 	std::vector<std::string> args;
 	for (int i = 2; i < argc; ++i) {
 		const std::string a = argv[i];
-		if (a.size() > 2 && a[0] == '-' && a[1] != '-' && std::string("pkebcqdofsla").find(a[1]) != std::string::npos) {
+		if (a.size() > 2 && a[0] == '-' && a[1] != '-' && std::string("pkebcqdofslat").find(a[1]) != std::string::npos) {
 			args.push_back(a.substr(0, 2));
 			args.push_back(a.substr(2));
 		}
@@ -506,6 +506,14 @@ Options parse(int argc, char** argv)
 		else if (a == "--faster" || a == "--mid-sensitive" || a == "--sensitive" || a == "--more-sensitive" || a == "--very-sensitive" || a == "--ultra-sensitive")
 			o.sens = a;
 		else if (a == "--quiet" || a == "--log" || a == "-v" || a == "--verbose") {}
+		else if (a == "-t" || a == "--tmpdir") (void)need(i);                // no temporary files: hits and records stay in memory / HBM
+		else if (a == "--ignore-warnings" || a == "--no-auto-append" || a == "--keep-temp-files") {}
+		else if (a == "--max-hsps") { if (std::atoi(need(i).c_str()) != 1) throw std::runtime_error("--max-hsps other than 1 is not part of this build (one HSP per target is reported)."); }
+		else if (a == "-F" || a == "--frameshift" || a == "--long-reads" || a == "--range-culling")
+			throw std::runtime_error(a + " (frameshift alignment / range culling) is not part of this build.");
+		else if (a == "--custom-matrix") throw std::runtime_error("--custom-matrix is not part of this build (the standard matrices of --matrix are).");
+		else if (a == "-g" || a == "--global-ranking" || a == "--swipe" || a == "--iterate" || a == "--approx-id" || a == "--taxonlist" || a == "--taxon-exclude" || a == "--seqidlist")
+			throw std::runtime_error(a + " is not part of this build.");
 		else throw std::runtime_error("Invalid option: " + a);
 	}
 	return o;

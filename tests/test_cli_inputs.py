@@ -53,3 +53,19 @@ def test_makedb_rejects_malformed_input(tmp_path, content, message):
     open(tmp_path / "bad", "wb").write(content)
     r = _makedb(tmp_path / "bad", tmp_path / "bad_db")
     assert r.returncode != 0 and message in r.stderr, r.stderr
+
+
+@pytest.mark.parametrize("args, message", [
+    (["--max-hsps", "2"], "--max-hsps other than 1 is not part of this build"),
+    (["-F", "15"], "frameshift alignment"),
+    (["--custom-matrix", "m.txt"], "--custom-matrix is not part of this build"),
+    (["--iterate"], "--iterate is not part of this build"),
+    (["--bogus-option"], "Invalid option: --bogus-option"),
+    (["--strand", "sideways"], "Invalid value for parameter --strand"),
+    (["--compress", "zstd"], "not compiled with ZStd"),
+    (["--ext", "global"], "is not part of this build"),
+    (["--unfmt", "fastq"], "Only the fasta format"),
+])
+def test_unsupported_options_fail_with_a_message(args, message):
+    r = subprocess.run([CLI, "blastp", "-q", "x", "-d", "y", "--tmpdir", "/tmp", "--max-hsps", "1", "--ignore-warnings"] + args, capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and message in r.stderr, r.stderr
