@@ -443,7 +443,11 @@ Options parse(int argc, char** argv)
 		else if (a == "-o" || a == "--out") o.out = need(i);
 		else if (a == "--in") o.in = need(i);
 		else if (a == "-p" || a == "--threads") o.threads = std::atoi(need(i).c_str());
-		else if (a == "-k" || a == "--max-target-seqs") o.k = std::atoi(need(i).c_str());
+		else if (a == "-k" || a == "--max-target-seqs") {
+			o.k = std::atoi(need(i).c_str());
+			if (o.k < 0) throw std::runtime_error("Invalid value for --max-target-seqs.");
+			if (o.k == 0) o.k = 1 << 30;                           // 0 = report every target (init_output, output/output_format.cpp:242-244)
+		}
 		else if (a == "-e" || a == "--evalue") o.evalue = std::atof(need(i).c_str());
 		else if (a == "--fast") o.fast = true;
 		else if (a == "--id") o.min_id = std::atof(need(i).c_str());

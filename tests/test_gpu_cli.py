@@ -802,3 +802,22 @@ def test_cli_seg_masking_matches_reference(tmp_path):
     for other in (["--masking", "0"], []):
         _run([REF] + base + other + ["-o", str(tmp_path / "other.tsv")])
         assert open(tmp_path / "other.tsv").read() not in seen
+
+
+def test_cli_unlimited_target_seqs_matches_reference(tmp_path):
+    """-k 0 = every target is reported (init_output: max_target_seqs = INT64_MAX), also over several reference blocks and with a filter."""
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/diamond not built")
+    db, doff, q, qoff = synth.generate(60, members=60, queries=120, seed=81)          # families of 60: far more than 25 targets per query
+    synth.write_fasta(str(tmp_path / "db.faa"), "t", db, doff)
+    synth.write_fasta(str(tmp_path / "q.faa"), "q", q, qoff)
+    for extra in (["-k", "0"], ["-k0", "-b0.0002", "--sensitive"], ["--max-target-seqs", "0", "--id", "35", "--fast"]):
+        args = ["blastp", "-q", str(tmp_path / "q.faa"), "-d", str(tmp_path / "db.faa"), "-p", "4"] + extra
+        _run([REF] + args + ["-o", str(tmp_path / "ref.tsv")])
+        _run([CLI] + args + ["-o", str(tmp_path / "hip.tsv")])
+        ref = open(tmp_path / "ref.tsv").read()
+        per_query = {}
+        for l in ref.splitlines():
+            per_query[l.split("\t")[0]] = per_query.get(l.split("\t")[0], 0) + 1
+        assert max(per_query.values()) > 25, extra
+        assert open(tmp_path / "hip.tsv").read() == ref, extra
