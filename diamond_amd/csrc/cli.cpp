@@ -412,6 +412,11 @@ struct Options {
 	bool salltitles = false, sallseqid = false;      // DAA: full subject titles / all subject ids in the dictionary (DAAFormat, legacy/daa/daa_record.cpp:26-28)
 	std::string daa;                // -a / --daa: the archive `view` reads; for blastp / blastx the legacy way to ask for DAA output into this file
 	bool forwardonly = false;       // view: only alignments on the forward strand
+	double dbsize = 0.0;            // --dbsize: effective database size in letters for the e-values (run/double_indexed.cpp:900); 0 = the database's
+	int id2 = 0;                    // --id2: Hamming identities of a stage-1 hit (config.min_identities_, search/setup.cpp:343); 0 = the mode's
+	double seed_cut = 0.0;          // --seed-cut: seed complexity cut (setup.cpp:368-369); 0 = the mode's
+	double gapped_filter_evalue = -1.0;      // --gapped-filter-evalue (setup.cpp:346); -1 = the mode's, 0 = filter off
+	int stop_match_score = 1;       // --stop-match-score: score of a stop codon against a stop codon (Scores ctor, stats/score_matrix.h:42-43)
 	bool compress = false;          // --compress 1: gzip output, ".gz" appended to the file name
 	int strands = 3, gencode = 1, min_orf = 0;      // --strand (mask: 1 plus, 2 minus), --query-gencode, --min-orf: translated searches
 	int unal = -1;                  // --unal: report queries without alignments (-1 = the format's default)
@@ -466,6 +471,11 @@ Options parse(int argc, char** argv)
 		else if (a == "--sallseqid") o.sallseqid = true;
 		else if (a == "-a" || a == "--daa") o.daa = need(i);
 		else if (a == "--forwardonly") o.forwardonly = true;
+		else if (a == "--dbsize") { o.dbsize = std::atof(need(i).c_str()); if (o.dbsize < 0) throw std::runtime_error("Invalid value for --dbsize."); }
+		else if (a == "--id2") o.id2 = std::atoi(need(i).c_str());
+		else if (a == "--seed-cut") o.seed_cut = std::atof(need(i).c_str());
+		else if (a == "--gapped-filter-evalue") o.gapped_filter_evalue = std::atof(need(i).c_str());
+		else if (a == "--stop-match-score") o.stop_match_score = std::atoi(need(i).c_str());
 		else if (a == "--un") o.un = need(i);
 		else if (a == "--al") o.al = need(i);
 		else if (a == "--unfmt" || a == "--alfmt") { if (need(i) != "fasta") throw std::runtime_error("Only the fasta format of --un / --al is part of this build."); }
@@ -719,13 +729,17 @@ int run_blastp(const Options& o)
 	dmnd_params p;
 	dmnd_default_params(&p);
 	if (dmnd_matrix_params(o.matrix.c_str(), o.gap_open, o.gap_extend, &p) != DMND_OK) throw std::runtime_error(dmnd_last_error());
-	p.db_letters = (double)db.letters;
+	p.db_letters = o.dbsize > 0.0 ? o.dbsize : (double)db.letters;
+	if (o.stop_match_score != 1) p.matrix8[24 * 32 + 24] = (int8_t)o.stop_match_score;
 	p.max_evalue = o.evalue;
 	auto chk = [&](int rc) { if (rc != DMND_OK) throw std::runtime_error(dmnd_last_error()); };
 	const int threads = o.threads > 0 ? o.threads : 8;
 	dmnd_seed_params sp;
 	double gf_evalue = 0.0;
 	chk(dmnd_seed_params_preset(&sp, sens, threads, &p, &gf_evalue));
+	if (o.gapped_filter_evalue >= 0.0) gf_evalue = o.gapped_filter_evalue;
+	if (o.id2 > 0) sp.hamming_filter_id = o.id2;
+	if (o.seed_cut != 0.0) sp.seed_complexity_cut = o.seed_cut * 0.69314718055994530942 * sp.shape_weight[0];
 	if (o.index_chunks > 0) chk(dmnd_seed_params_set_index_chunks(&sp, o.index_chunks, threads));
 	if (o.shapes > 0 && o.shapes < sp.n_shapes) sp.n_shapes = o.shapes;
 	// one context per GPU, driven by its own host thread
@@ -795,7 +809,7 @@ int run_blastp(const Options& o)
 	int64_t daa_bytes = 0, daa_queries = 0;
 	if (fmt == FMT_DAA) {
 		daa.build = 182;                                // the build number of the reference version whose format this is (basic/const.h:25)
-		daa.db_seqs = (int64_t)db.n; daa.db_letters = db.letters; daa.db_seqs_used = 0; daa.query_records = 0;
+		daa.db_seqs = (int64_t)db.n; daa.db_letters = (int64_t)p.db_letters; daa.db_seqs_used = 0; daa.query_records = 0;
 		daa.mode = blastx ? 3 : 2; daa.gap_open = p.gap_open; daa.gap_extend = p.gap_extend; daa.K = p.K; daa.lambda = p.lambda; daa.max_evalue = o.evalue;
 		daa.matrix = o.matrix.c_str(); daa.finished = 0; daa.alignment_bytes = 0; daa.ref_name_bytes = 0;
 		std::vector<char> hb(4096);
@@ -1346,6 +1360,7 @@ int main(int argc, char** argv)
 				"             --unal 0|1  --un FILE  --al FILE  --header [simple|verbose]  --compress 1  --salltitles  --sallseqid\n"
 				"formats      -f 6 [FIELD...] | 0 (pairwise) | 5 (XML) | 100 (DAA) | 101 (SAM) | 103 (PAF)\n"
 				"translated   --strand both|plus|minus  --query-gencode N  --min-orf N\n"
+				"expert       --dbsize LETTERS  --id2 N  --seed-cut X  --gapped-filter-evalue E  --stop-match-score N\n"
 				"resources    -p THREADS  --gpus N  -b BLOCK_SIZE  -c INDEX_CHUNKS  --algo 0|1|auto\n";
 			return 0;
 		}

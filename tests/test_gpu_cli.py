@@ -821,3 +821,33 @@ def test_cli_unlimited_target_seqs_matches_reference(tmp_path):
             per_query[l.split("\t")[0]] = per_query.get(l.split("\t")[0], 0) + 1
         assert max(per_query.values()) > 25, extra
         assert open(tmp_path / "hip.tsv").read() == ref, extra
+
+
+def test_cli_expert_options_match_reference(tmp_path):
+    """--dbsize (effective database size of the e-values), --id2, --seed-cut, --gapped-filter-evalue, --stop-match-score: each against the
+    reference, and each changes the default result of this workload."""
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/diamond not built")
+    rng = np.random.default_rng(91)
+    db, doff, q, qoff = synth.generate(300, members=10, queries=300, seed=91)
+    db, q = _plant_repeats(db, doff, rng), _plant_repeats(q, qoff, rng)
+    dna, off = synth.back_translate(q[: qoff[100]], qoff[:101], seed=92)
+    synth.write_fasta(str(tmp_path / "db.faa"), "t", db, doff)
+    synth.write_fasta(str(tmp_path / "q.faa"), "q", q, qoff)
+    synth.write_dna_fasta(str(tmp_path / "reads.fna"), "r", dna, off)
+    out = {}
+    for name, mode, query, extra in (("plain", "blastp", "q.faa", []), ("dbsize", "blastp", "q.faa", ["--dbsize", "1000000000"]),
+                                     ("id2", "blastp", "q.faa", ["--id2", "14"]), ("seed-cut", "blastp", "q.faa", ["--seed-cut", "0.5", "--masking", "0"]),
+                                     ("plain sensitive", "blastp", "q.faa", ["--sensitive"]), ("gf off", "blastp", "q.faa", ["--sensitive", "--gapped-filter-evalue", "0"]),
+                                     ("gf strict", "blastp", "q.faa", ["--sensitive", "--gapped-filter-evalue", "0.000001"]),
+                                     ("plain x", "blastx", "reads.fna", []), ("stop score", "blastx", "reads.fna", ["--stop-match-score", "-4", "--min-orf", "1"])):
+        args = [mode, "-q", str(tmp_path / query), "-d", str(tmp_path / "db.faa"), "-p", "1"] + extra
+        daa = "-f" in extra
+        _run([REF] + args + ["-o", str(tmp_path / ("ref" if daa else "ref.tsv"))])
+        _run([CLI] + args + ["-o", str(tmp_path / ("hip" if daa else "hip.tsv"))])
+        ref = open(tmp_path / ("ref.daa" if daa else "ref.tsv"), "rb").read()
+        assert len(ref) > 5000, name
+        assert open(tmp_path / ("hip.daa" if daa else "hip.tsv"), "rb").read() == ref, name
+        out[name] = ref
+    assert out["dbsize"] != out["plain"] and out["id2"] != out["plain"] and out["seed-cut"] != out["plain"]
+    assert len({out["plain sensitive"], out["gf off"], out["gf strict"]}) >= 2
