@@ -77,7 +77,9 @@ std::vector<char> read_sequence_text(const std::string& path)
 {
 	std::vector<char> file;
 	unsigned char magic[2] = { 0, 0 };
-	{
+	const bool from_stdin = path.empty() || path == "-";       // File::Flags::TREAT_BLANK_AS_STDIN: zlib reads plain and gzip data alike
+	if (from_stdin) { magic[0] = 0x1f; magic[1] = 0x8b; }
+	else {
 		std::ifstream f(path, std::ios::binary | std::ios::ate);
 		if (!f) throw std::runtime_error("Error opening file " + path);
 		const std::streamoff n = f.tellg();
@@ -89,8 +91,8 @@ std::vector<char> read_sequence_text(const std::string& path)
 		}
 	}
 	if (magic[0] == 0x1f && magic[1] == 0x8b) {
-		gzFile g = gzopen(path.c_str(), "rb");
-		if (!g) throw std::runtime_error("Error opening file " + path);
+		gzFile g = from_stdin ? gzdopen(dup(0), "rb") : gzopen(path.c_str(), "rb");
+		if (!g) throw std::runtime_error("Error opening file " + (from_stdin ? std::string("(standard input)") : path));
 		gzbuffer(g, 1 << 20);
 		size_t have = 0;
 		for (;;) {
@@ -600,7 +602,7 @@ SeqBlock slice(const SeqBlock& all, size_t begin, size_t end)
 
 int run_blastp(const Options& o)
 {
-	if (o.query.empty() || o.db.empty()) throw std::runtime_error("Missing parameter: query (--query/-q) and database (--db/-d) are required.");
+	if (o.db.empty()) throw std::runtime_error("Missing parameter: database file (--db/-d)");          // no -q: the queries come from standard input
 	if (!o.sens.empty() && o.sens != "--sensitive" && o.sens != "--mid-sensitive" && o.sens != "--more-sensitive" && o.sens != "--very-sensitive" && o.sens != "--ultra-sensitive")
 		throw std::runtime_error("This build implements --fast, default, --mid-sensitive, --sensitive, --more-sensitive, --very-sensitive and --ultra-sensitive (" + o.sens + " is not available).");
 	if (o.fast && !o.sens.empty()) throw std::runtime_error("Conflicting sensitivity options.");
@@ -1365,7 +1367,7 @@ int main(int argc, char** argv)
 			return 0;
 		}
 		if (o.command == "makedb") {
-			if (o.in.empty() || o.db.empty()) throw std::runtime_error("makedb needs --in and -d");
+			if (o.db.empty()) throw std::runtime_error("Missing parameter: database file (--db/-d)");        // no --in: the sequences come from standard input
 			SeqBlock b;
 			read_fasta(o.in, b);
 			write_dmnd(o.db, b);

@@ -69,3 +69,18 @@ def test_makedb_rejects_malformed_input(tmp_path, content, message):
 def test_unsupported_options_fail_with_a_message(args, message):
     r = subprocess.run([CLI, "blastp", "-q", "x", "-d", "y", "--tmpdir", "/tmp", "--max-hsps", "1", "--ignore-warnings"] + args, capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and message in r.stderr, r.stderr
+
+
+def test_makedb_reads_standard_input(tmp_path):
+    """No --in (or "-"): the sequences come from standard input, plain or gzip-compressed (File::Flags::TREAT_BLANK_AS_STDIN)."""
+    db, doff, _, _ = synth.generate(10, members=5, queries=1, seed=4)
+    synth.write_fasta(str(tmp_path / "a.faa"), "t", db, doff)
+    raw = open(tmp_path / "a.faa", "rb").read()
+    assert _makedb(tmp_path / "a.faa", tmp_path / "file").returncode == 0
+    want = open(tmp_path / "file.dmnd", "rb").read()
+    for name, data, args in (("plain", raw, []), ("gz", gzip.compress(raw), []), ("dash", raw, ["--in", "-"])):
+        r = subprocess.run([CLI, "makedb", "-d", str(tmp_path / name)] + args, input=data, capture_output=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        assert open(str(tmp_path / name) + ".dmnd", "rb").read() == want, name
+    r = subprocess.run([CLI, "makedb", "-d", str(tmp_path / "none")], input=b"", capture_output=True, timeout=120)
+    assert r.returncode != 0 and b"seems to be empty" in r.stderr
