@@ -851,3 +851,24 @@ def test_cli_expert_options_match_reference(tmp_path):
         out[name] = ref
     assert out["dbsize"] != out["plain"] and out["id2"] != out["plain"] and out["seed-cut"] != out["plain"]
     assert len({out["plain sensitive"], out["gf off"], out["gf strict"]}) >= 2
+
+
+def test_cli_queries_from_standard_input(tmp_path):
+    """No -q: the queries are read from standard input (gzip-compressed or not), blastp and blastx."""
+    import gzip
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/diamond not built")
+    db, doff, q, qoff = synth.generate(100, members=10, queries=80, seed=95)
+    dna, off = synth.back_translate(q[: qoff[40]], qoff[:41], seed=96)
+    synth.write_fasta(str(tmp_path / "db.faa"), "t", db, doff)
+    synth.write_fasta(str(tmp_path / "q.faa"), "q", q, qoff)
+    synth.write_dna_fasta(str(tmp_path / "reads.fna"), "r", dna, off)
+    for mode, query in (("blastp", "q.faa"), ("blastx", "reads.fna")):
+        _run([REF, mode, "-q", str(tmp_path / query), "-d", str(tmp_path / "db.faa"), "-p", "4", "-o", str(tmp_path / "ref.tsv")])
+        ref = open(tmp_path / "ref.tsv").read()
+        assert len(ref.splitlines()) > 50
+        raw = open(tmp_path / query, "rb").read()
+        for data in (raw, gzip.compress(raw)):
+            r = subprocess.run([CLI, mode, "-d", str(tmp_path / "db.faa"), "-p", "4"], input=data, capture_output=True, timeout=300)
+            assert r.returncode == 0, r.stderr[-1000:]
+            assert r.stdout.decode() == ref, mode                    # no -o either: the alignments go to standard output
