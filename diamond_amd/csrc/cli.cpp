@@ -419,6 +419,7 @@ struct Options {
 	double seed_cut = 0.0;          // --seed-cut: seed complexity cut (setup.cpp:368-369); 0 = the mode's
 	double gapped_filter_evalue = -1.0;      // --gapped-filter-evalue (setup.cpp:346); -1 = the mode's, 0 = filter off
 	int stop_match_score = 1;       // --stop-match-score: score of a stop codon against a stop codon (Scores ctor, stats/score_matrix.h:42-43)
+	uint32_t format_flags = 0;      // --xml-blord-format, --no-parse-seqids, --sam-query-len
 	bool compress = false;          // --compress 1: gzip output, ".gz" appended to the file name
 	int strands = 3, gencode = 1, min_orf = 0;      // --strand (mask: 1 plus, 2 minus), --query-gencode, --min-orf: translated searches
 	int unal = -1;                  // --unal: report queries without alignments (-1 = the format's default)
@@ -478,6 +479,9 @@ Options parse(int argc, char** argv)
 		else if (a == "--seed-cut") o.seed_cut = std::atof(need(i).c_str());
 		else if (a == "--gapped-filter-evalue") o.gapped_filter_evalue = std::atof(need(i).c_str());
 		else if (a == "--stop-match-score") o.stop_match_score = std::atoi(need(i).c_str());
+		else if (a == "--xml-blord-format") o.format_flags |= DMND_FMT_XML_BLORD;
+		else if (a == "--no-parse-seqids") o.format_flags |= DMND_FMT_NO_PARSE_SEQIDS;
+		else if (a == "--sam-query-len") o.format_flags |= DMND_FMT_SAM_QUERY_LEN;
 		else if (a == "--un") o.un = need(i);
 		else if (a == "--al") o.al = need(i);
 		else if (a == "--unfmt" || a == "--alfmt") { if (need(i) != "fasta") throw std::runtime_error("Only the fasta format of --un / --al is part of this build."); }
@@ -1373,6 +1377,7 @@ int main(int argc, char** argv)
 			write_dmnd(o.db, b);
 			return 0;
 		}
+		if (dmnd_set_format_flags(o.format_flags) != DMND_OK) throw std::runtime_error(dmnd_last_error());
 		if (o.command == "view") return run_view(o);
 		if ((o.command == "blastp" || o.command == "blastx") && !o.daa.empty()) {       // -a FILE: the legacy spelling of -f 100 -o FILE (basic/config.cpp:716-724)
 			if (!o.out.empty()) throw std::runtime_error("Options --daa and --out cannot be used together.");

@@ -3,6 +3,7 @@
 // Mirrors: TabularFormat (src/output/blast_tab_format.cpp:46-620), PairwiseFormat (src/output/blast_pairwise_format.cpp:24-85),
 // print_cigar (src/output/sam_format.cpp:67-84), HspContext::Iterator (src/basic/match.h:300-370), TextBuffer number printing
 // (src/util/text_buffer.h:224-254), OutputFormat::print_title (src/output/output_format.cpp:150-168).
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -26,6 +27,8 @@ const char* const UNAVAILABLE[] = { "staxids", "sscinames", "sskingdoms", "sking
 	"normalized_bitscore", "normalized_bitscore_query", "normalized_nident", "approx_pident", "corrected_bitscore" };
 
 enum { OP_MATCH = 0, OP_INSERTION = 1, OP_DELETION = 2, OP_SUBSTITUTION = 3 };
+
+std::atomic<uint32_t> g_format_flags(0);        // dmnd_set_format_flags: the reference reads these from its global config
 
 struct Out {
 	std::string s;
@@ -404,6 +407,7 @@ extern "C" int64_t dmnd_format_sam(const dmnd_hsp_view* v, const char* unaligned
 		}
 	}
 	if (matches > 0) o << matches;
+	if (g_format_flags.load() & DMND_FMT_SAM_QUERY_LEN) o << '\t' << "ZQ:i:" << (f.translated ? v->source_len : v->qlen);      // --sam-query-len, sam_format.cpp:129-130
 	o << '\n';
 	return emit(o, buf, cap, "dmnd_format_sam");
 }
@@ -466,6 +470,13 @@ void print_lf(Out& o, double x) { char b[48]; std::snprintf(b, sizeof b, "%lf", 
 
 }  // namespace
 
+extern "C" int dmnd_set_format_flags(uint32_t flags)
+{
+	if (flags & ~(uint32_t)(DMND_FMT_XML_BLORD | DMND_FMT_NO_PARSE_SEQIDS | DMND_FMT_SAM_QUERY_LEN)) return fail(DMND_E_ARG, "dmnd_set_format_flags: unknown flag");
+	g_format_flags.store(flags);
+	return DMND_OK;
+}
+
 extern "C" int64_t dmnd_format_xml_header(const char* program, const char* version, const char* database, const char* first_qtitle, int32_t first_qlen,
 	const char* matrix, int gap_open, int gap_extend, double max_evalue, char* buf, int64_t cap)
 {
@@ -513,12 +524,19 @@ extern "C" int64_t dmnd_format_xml(const dmnd_hsp_view* v, int32_t hit_num, int3
 		// Util::Seq::get_title_def: the id up to the first delimiter, the rest is the definition
 		const size_t cut = std::strcspn(v->stitle, ID_DELIMITERS), total = std::strlen(v->stitle);
 		const std::string id(v->stitle, cut), def = cut >= total ? std::string() : std::string(v->stitle + cut + 1);
-		o << "  <Hit_id>";
-		xml_escaped(o, id.data(), id.size());
-		o << "</Hit_id>\n  <Hit_def>";
-		xml_title(o, def.c_str(), true, " &gt;");
+		const uint32_t flags = g_format_flags.load();
+		if (flags & DMND_FMT_XML_BLORD) {                      // --xml-blord-format, xml_format.cpp:43-48
+			o << "  <Hit_id>gnl|BL_ORD_ID|" << (long long)v->snum << "</Hit_id>\n  <Hit_def>";
+			xml_title(o, v->stitle, true, " &gt;");
+		}
+		else {
+			o << "  <Hit_id>";
+			xml_escaped(o, id.data(), id.size());
+			o << "</Hit_id>\n  <Hit_def>";
+			xml_title(o, def.c_str(), true, " &gt;");
+		}
 		o << "</Hit_def>\n  <Hit_accession>";
-		const std::string acc = accession_of(id);
+		const std::string acc = (flags & DMND_FMT_NO_PARSE_SEQIDS) ? id : accession_of(id);
 		xml_escaped(o, acc.data(), acc.size());
 		o << "</Hit_accession>\n  <Hit_len>" << v->slen << "</Hit_len>\n  <Hit_hsps>\n";
 	}

@@ -455,6 +455,10 @@ int64_t dmnd_format_sam(const dmnd_hsp_view* v, const char* unaligned_qtitle, ch
  * one <Hsp> (print_match: hsp_num == 0 also opens the <Hit> and, for hit_num > 0, closes the one before), the closing of a query
  * (print_query_epilog; db_seqs / db_letters < 0 = not printed) -- the footer is "</BlastOutput_iterations>\n</BlastOutput>". The format
  * reports unaligned queries by default (intro + epilog with unaligned = 1). */
+/* Process-wide switches of the writers, as the reference reads them from its global config: --xml-blord-format (Hit_id = gnl|BL_ORD_ID|<snum>,
+ * Hit_def = all titles; xml_format.cpp:43-48), --no-parse-seqids (Hit_accession = the id as it is), --sam-query-len (ZQ:i: tag). */
+enum { DMND_FMT_XML_BLORD = 1, DMND_FMT_NO_PARSE_SEQIDS = 2, DMND_FMT_SAM_QUERY_LEN = 4 };
+int dmnd_set_format_flags(uint32_t flags);
 int64_t dmnd_format_xml_header(const char* program, const char* version, const char* database, const char* first_qtitle, int32_t first_qlen,
 	const char* matrix, int gap_open, int gap_extend, double max_evalue, char* buf, int64_t cap);
 int64_t dmnd_format_xml_query_intro(const char* qtitle, int64_t qnum, int32_t qlen, char* buf, int64_t cap);

@@ -202,6 +202,33 @@ def test_daa_file_is_reproduced():
     assert hip.format_daa_query("r1", np.array([0, 4, 2], np.int8), dna=True)[11] == 1
 
 
+def test_format_switches_of_the_xml_and_sam_writers():
+    """--xml-blord-format, --no-parse-seqids, --sam-query-len (dmnd_set_format_flags; checked against the reference binary's output for
+    the same options while they were written: tests/golden/make_format_golden.sh documents the commands)."""
+    p = hip.default_params()
+    M = np.array(p.matrix8, dtype=np.int8)
+    line, f, m, tr = next(records())
+    q = letters(f["full_qseq"])
+    title = "gi|123|ref|NP_000001.2| first protein\x01sp|P12345|NAME_HUMAN second"
+    try:
+        plain = hip.format_xml(m, tr, "q", title, q, int(f["slen"]), 0, 0, M, snum=7)
+        assert "<Hit_id>gi|123|ref|NP_000001.2|</Hit_id>" in plain and "<Hit_accession>NP_000001</Hit_accession>" in plain
+        hip.set_format_flags(hip.FMT_XML_BLORD)
+        x = hip.format_xml(m, tr, "q", title, q, int(f["slen"]), 0, 0, M, snum=7)
+        assert "  <Hit_id>gnl|BL_ORD_ID|7</Hit_id>\n  <Hit_def>gi|123|ref|NP_000001.2| first protein &gt;sp|P12345|NAME_HUMAN second</Hit_def>\n  <Hit_accession>NP_000001</Hit_accession>" in x
+        hip.set_format_flags(hip.FMT_NO_PARSE_SEQIDS)
+        x = hip.format_xml(m, tr, "q", title, q, int(f["slen"]), 0, 0, M, snum=7)
+        assert "<Hit_id>gi|123|ref|NP_000001.2|</Hit_id>" in x and "<Hit_accession>gi|123|ref|NP_000001.2|</Hit_accession>" in x
+        sam = hip.format_sam(m, tr, f["qtitle"], f["stitle"], q, int(f["slen"]))
+        assert "ZQ:i:" not in sam
+        hip.set_format_flags(hip.FMT_SAM_QUERY_LEN)
+        assert hip.format_sam(m, tr, f["qtitle"], f["stitle"], q, int(f["slen"])) == sam[:-1] + "\tZQ:i:%d\n" % len(q)
+        with pytest.raises(hip.DiamondHipError, match="unknown flag"):
+            hip.set_format_flags(64)
+    finally:
+        hip.set_format_flags(0)
+
+
 def test_field_names_are_checked_like_the_reference():
     with pytest.raises(hip.DiamondHipError, match="Invalid output field: nosuchfield"):
         hip.output_fields(["qseqid", "nosuchfield"])
