@@ -1356,7 +1356,7 @@ int main(int argc, char** argv)
 			std::cout << "Syntax: diamond-hip COMMAND [OPTIONS]\n"
 				"  makedb --in FASTA -d DB              build a .dmnd database\n"
 				"  blastp -q PROTEINS -d DB -o OUT      protein search;  blastx -q READS -d DB -o OUT   translated search\n"
-				"  view -a ARCHIVE.daa -o OUT [-f ...]    print a DAA archive in another format\n  version\n\n"
+				"  view -a ARCHIVE.daa -o OUT [-f ...]    print a DAA archive in another format\n  dbinfo -d DB                         sequences, letters and format of a .dmnd file\n  version\n\n"
 				"input        -q / -d: FASTA or FASTQ, gzip-compressed or not; -d also a .dmnd file\n"
 				"sensitivity  --fast | (none: default mode) | --mid-sensitive | --sensitive | --more-sensitive | --very-sensitive | --ultra-sensitive; --shapes N\n"
 				"scoring      --matrix BLOSUM45|50|62|80|90|PAM30|70|250  --gapopen N  --gapextend N  --comp-based-stats 0|1\n"
@@ -1378,6 +1378,19 @@ int main(int argc, char** argv)
 			return 0;
 		}
 		if (dmnd_set_format_flags(o.format_flags) != DMND_OK) throw std::runtime_error(dmnd_last_error());
+		if (o.command == "dbinfo") {                                                   // db_info, data/sequence_file.cpp:876-890
+			if (o.db.empty()) throw std::runtime_error("Missing parameter: database file (--db/-d)");
+			std::string path = o.db;
+			if (!std::ifstream(path).good() && std::ifstream(path + ".dmnd").good()) path += ".dmnd";
+			std::ifstream f(path, std::ios::binary);
+			if (!f) throw std::runtime_error("Error opening file " + path);
+			uint64_t magic = 0, sequences = 0, letters = 0; uint32_t build = 0, version = 0;
+			f.read((char*)&magic, 8); f.read((char*)&build, 4); f.read((char*)&version, 4); f.read((char*)&sequences, 8); f.read((char*)&letters, 8);
+			if (!f || magic != DMND_MAGIC) throw std::runtime_error("Database file is not a DIAMOND database.");
+			std::printf("%23s  %s\n%23s  %u\n%23s  %u\n%23s  %llu\n%23s  %llu\n", "Database type", "Diamond database", "Database format version", version, "Diamond build", build,
+				"Sequences", (unsigned long long)sequences, "Letters", (unsigned long long)letters);
+			return 0;
+		}
 		if (o.command == "view") return run_view(o);
 		if ((o.command == "blastp" || o.command == "blastx") && !o.daa.empty()) {       // -a FILE: the legacy spelling of -f 100 -o FILE (basic/config.cpp:716-724)
 			if (!o.out.empty()) throw std::runtime_error("Options --daa and --out cannot be used together.");
@@ -1388,7 +1401,7 @@ int main(int argc, char** argv)
 			return run_blastp(legacy);
 		}
 		if (o.command == "blastp" || o.command == "blastx") return run_blastp(o);
-		throw std::runtime_error("Invalid command: " + o.command + " (makedb, blastp, blastx and view are part of this build)");
+		throw std::runtime_error("Invalid command: " + o.command + " (makedb, blastp, blastx, view and dbinfo are part of this build)");
 	}
 	catch (const std::exception& e) {
 		std::cerr << "Error: " << e.what() << std::endl;          // main.cpp:211-232

@@ -84,3 +84,18 @@ def test_makedb_reads_standard_input(tmp_path):
         assert open(str(tmp_path / name) + ".dmnd", "rb").read() == want, name
     r = subprocess.run([CLI, "makedb", "-d", str(tmp_path / "none")], input=b"", capture_output=True, timeout=120)
     assert r.returncode != 0 and b"seems to be empty" in r.stderr
+
+
+def test_dbinfo_prints_the_header_like_the_reference(tmp_path):
+    db, doff, _, _ = synth.generate(12, members=5, queries=1, seed=6)
+    synth.write_fasta(str(tmp_path / "a.faa"), "t", db, doff)
+    assert _makedb(tmp_path / "a.faa", tmp_path / "a").returncode == 0
+    r = subprocess.run([CLI, "dbinfo", "-d", str(tmp_path / "a")], capture_output=True, text=True, timeout=60)
+    want = ("          Database type  Diamond database\nDatabase format version  3\n          Diamond build  182\n"
+            "              Sequences  %d\n                Letters  %d\n" % (len(doff) - 1, int(doff[-1])))
+    assert r.returncode == 0 and r.stdout == want
+    ref = os.path.join(ROOT, "oracle", "_ref", "diamond")
+    if os.path.exists(ref):
+        assert subprocess.run([ref, "dbinfo", "-d", str(tmp_path / "a.dmnd"), "--quiet"], capture_output=True, text=True, timeout=60).stdout == want
+    r = subprocess.run([CLI, "dbinfo", "-d", str(tmp_path / "a.faa")], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "not a DIAMOND database" in r.stderr
