@@ -18,8 +18,14 @@ product: diamond_amd/libdiamond_hip.so diamond_amd/libdmnd_synth.so diamond_amd/
 motifs:
 	@python3 tools/make_motif_table.py >/dev/null || true
 
-diamond_amd/libdiamond_hip.so: $(HIPSRC) $(HIPHDR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIPSRC)
+# one object per translation unit (no device code crosses a unit), so that a change to one kernel file rebuilds that file only
+HIPOBJ  := $(patsubst $(CSRC)/%.hip,build/%.o,$(HIPSRC))
+build/%.o: $(CSRC)/%.hip $(HIPHDR)
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+
+diamond_amd/libdiamond_hip.so: $(HIPOBJ)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIPOBJ)
 
 # the CLI (makedb / blastp) over the C ABI; finds the library next to itself
 diamond_amd/diamond-hip: $(CSRC)/cli.cpp include/diamond_hip.h diamond_amd/libdiamond_hip.so

@@ -138,42 +138,97 @@ class Workload:
         return os.path.join(d, "q.faa")
 
 
-def cpu_baseline_reference(w, cores):
+# the task timers of the reference's --log output that make up the hot path (what dmnd_seed_search + dmnd_extend replace): the seed
+# stage of every shape x index chunk and the extension stage; everything else (open, load, masking, output) is outside it
+HOT_TIMERS = ("Building reference histograms", "Building query histograms", "Allocating buffers", "Building reference seed array",
+              "Building query seed array", "Computing hash join", "Masking low complexity seeds", "Searching alignments", "Deallocating memory",
+              "Deallocating buffers", "Sorting trace points", "Computing partition", "Computing alignments", "Building seed filter",
+              "Building query seed set", "Building reference index", "Building query index")
+
+
+def _timers(log):
+    t = {}
+    for name, sec in re.findall(r"^([A-Za-z][^\[\n]*?)\.\.\.\s+\[([0-9.eE+-]+)s\]", log, re.M):
+        t[name] = t.get(name, 0.0) + float(sec)
+    return t
+
+
+def cpu_baseline_reference(w, cores, e2e=True):
     """The GENUINE reference (oracle/_ref/diamond_tap: /root/reference compiled in place; the tap only counts DP cells) on
-    this box's host cores, on the FULL workload of the config, with as many threads as the cgroup allows. Returns the
-    cpu_baseline object and the md5 of the reference's tabular output (for parity_checked), or (None, None)."""
+    this box's host cores, on the FULL workload of the config, with as many threads as the cgroup allows.
+      hot path  `--algo 0 --masking 0 --motif-masking 0 --log`: cells / (sum of the seed-stage and extension-stage task timers) --
+                what bench.py's `value` (blocks resident, seed stage + extension) may be compared with; md5 of its output = parity_checked
+      e2e       `diamond blastp ...` against `diamond-hip blastp ...` on the same files, whole processes (open + load the .dmnd,
+                upload, mask, search, write the output file), wall clock around the process; default masking, masking off, and the
+                stock command line (no --algo); outputs md5-compared (SURVEY.md 8d GCUPS_e2e; target >= 10x)
+    Returns (cpu_baseline object, md5 of the hot-path run's output, e2e object | None), or (None, None, None)."""
     exe = os.path.join(ROOT, "oracle", "_ref", "diamond_tap")
+    ours_exe = os.path.join(ROOT, "diamond_amd", "diamond-hip")
     if not os.path.exists(exe):
-        return None, None
+        return None, None, None
     tmp = tempfile.mkdtemp(prefix="dmnd_cpu_")
     try:
         qfile = w.write_fasta(tmp)
         subprocess.run([exe, "makedb", "--in", os.path.join(tmp, "db.faa"), "-d", os.path.join(tmp, "db"), "-p", str(cores)],
                        check=True, capture_output=True, timeout=900)
         env = dict(os.environ, DIAMOND_TAP_CELLS=os.path.join(tmp, "cells.json"))
-        cmd = [exe, w.cfg["mode"]] + w.cfg["flags"] + ["--algo", "0", "--masking", "0", "--motif-masking", "0", "-q", qfile,
-                                                         "-d", os.path.join(tmp, "db"), "-o", os.path.join(tmp, "out.tsv"), "-p", str(cores), "--log"]
+        blocks = []
         if w.n_blocks_total > 1:                             # the same block cut as ours (-b in billions of letters; +0.5 letter against rounding)
-            cmd += ["-b", "%.12f" % ((w.block_letters + 0.5) / 1e9)]
-        t0 = time.perf_counter()
-        r = subprocess.run(cmd, check=True, capture_output=True, text=True, env=env, timeout=3000)
-        wall = time.perf_counter() - t0
+            blocks = ["-b", "%.12f" % ((w.block_letters + 0.5) / 1e9)]
+
+        def run(binary, flags, out, threads=True):
+            cmd = [binary, w.cfg["mode"]] + w.cfg["flags"] + flags + ["-q", qfile, "-d", os.path.join(tmp, "db"), "-o", os.path.join(tmp, out)] + blocks
+            if threads:
+                cmd += ["-p", str(cores)]
+            t0 = time.perf_counter()
+            r = subprocess.run(cmd, check=True, capture_output=True, text=True, env=env, timeout=3000)
+            wall = time.perf_counter() - t0
+            return wall, r.stdout + r.stderr, hashlib.md5(open(os.path.join(tmp, out), "rb").read()).hexdigest()
+
+        hot_flags = ["--algo", "0", "--masking", "0", "--motif-masking", "0"]
+        wall, log, md5 = run(exe, hot_flags + ["--log"], "out.tsv")
         cells = json.load(open(os.path.join(tmp, "cells.json")))
-        log = r.stdout + r.stderr
+        timers = _timers(log)
+        hot_s = sum(v for k, v in timers.items() if k in HOT_TIMERS)
         sw = re.search(r"Time \(Smith Waterman\)\s*= ([0-9.eE+-]+)s", log)
         aligned = re.search(r"(\d+) queries aligned", log)
         total = re.search(r"Total time = ([0-9.eE+-]+)s", log)
         sw_s = float(sw.group(1)) if sw else float("nan")
         model = open("/proc/cpuinfo").read().split("model name")[1].split("\n")[0].strip(": \t") if os.path.exists("/proc/cpuinfo") else "?"
-        md5 = hashlib.md5(open(os.path.join(tmp, "out.tsv"), "rb").read()).hexdigest()
         n_aligned = int(aligned.group(1)) if aligned else 0
-        return {"value": cells["cells"] / wall / 1e9, "unit": "GCUPS", "cores": cores, "kind": "reference",
-                "aligned_queries_per_s": n_aligned / wall,
+        base = {"value": cells["cells"] / hot_s / 1e9, "unit": "GCUPS", "cores": cores, "kind": "reference",
+                "aligned_queries_per_s": n_aligned / hot_s,
+                "hot_path": {"seconds": hot_s, "gcups": cells["cells"] / hot_s / 1e9,
+                             "what": "sum of the reference's --log task timers of the seed stage (histograms, seed arrays, hash join, stage-1/2 filters) and the "
+                                     "extension stage (sort, partition, 'Computing alignments'): the part of its run that dmnd_seed_search + dmnd_extend replace",
+                             "timers_s": {k: round(v, 4) for k, v in timers.items() if k in HOT_TIMERS and v > 0}},
+                "whole_process": {"seconds": wall, "gcups": cells["cells"] / wall / 1e9, "own_total_time_s": float(total.group(1)) if total else None},
                 "sample": "reference diamond v2.2.2 `%s %s --algo 0 --masking 0 --motif-masking 0 -p %d` on the FULL workload (%d queries x %d seqs), "
-                          "%d = the cgroup's CPU quota of this box (%d hardware threads visible), CPU %s: %.2f s wall end to end (its own 'Total time' %s s), "
+                          "%d = the cgroup's CPU quota of this box (%d hardware threads visible), CPU %s; value = cells / hot-path seconds (%.3f s of %.2f s wall); "
                           "%d DpTargets / %d cells (both rounds), %d queries aligned; SW stage alone: %.3f CPU-s => %.2f GCUPS per core"
-                          % (w.cfg["mode"], " ".join(w.cfg["flags"]), cores, w.n_queries, w.n_db, cores, os.cpu_count() or 0, model, wall,
-                             total.group(1) if total else "?", cells["targets"], cells["cells"], n_aligned, sw_s, cells["cells"] / sw_s / 1e9)}, md5
+                          % (w.cfg["mode"], " ".join(w.cfg["flags"]), cores, w.n_queries, w.n_db, cores, os.cpu_count() or 0, model, hot_s, wall,
+                             cells["targets"], cells["cells"], n_aligned, sw_s, cells["cells"] / sw_s / 1e9)}
+        e2e_obj = None
+        if e2e and os.path.exists(ours_exe):
+            runs = {}
+            plain = os.path.join(ROOT, "oracle", "_ref", "diamond")      # the unmodified reference binary (no tap) for the process timings
+            if os.path.exists(plain):
+                exe = plain
+            for name, flags in (("default_masking", ["--algo", "0"]), ("masking_off", hot_flags), ("stock_command_line", [])):
+                ref_wall, ref_log, ref_md5 = run(exe, flags, "ref_%s.tsv" % name)
+                ours = [run(ours_exe, flags, "ours_%s.tsv" % name, threads=False) for _ in range(3)]
+                ours_wall = sorted(x[0] for x in ours)[1]
+                ref_total = re.search(r"Total time = ([0-9.eE+-]+)s", ref_log)
+                runs[name] = {"flags": " ".join(w.cfg["flags"] + flags), "reference_s": ref_wall, "reference_own_total_time_s": float(ref_total.group(1)) if ref_total else None,
+                              "ours_s": ours_wall, "ours_runs_s": [round(x[0], 4) for x in ours], "speedup": ref_wall / ours_wall, "parity": all(x[2] == ref_md5 for x in ours),
+                              "ours_log": [l for l in ours[1][1].splitlines() if "[" in l or "Total time" in l]}
+            e2e_obj = {"what": "whole processes on the same files (page cache warm): `diamond %s` on %d host threads against `diamond-hip %s` on one MI355X -- open and load the "
+                               ".dmnd, upload, masking, seed stage, extension, output file; wall clock around the process (ours: median of 3, HIP start-up included)"
+                               % (w.cfg["mode"], cores, w.cfg["mode"]),
+                       "runs": runs, "speedup": runs["default_masking"]["speedup"], "parity": all(r["parity"] for r in runs.values()),
+                       "gcups_e2e": {"ours": cells["cells"] / runs["masking_off"]["ours_s"] / 1e9, "reference": cells["cells"] / runs["masking_off"]["reference_s"] / 1e9,
+                                     "note": "SURVEY 8(d) GCUPS_e2e = the reference's cell count (both rounds) of the masking-off run / whole-process wall seconds"}}
+        return base, md5, e2e_obj
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -190,18 +245,36 @@ def main():
     ap.add_argument("--shard", choices=["db", "query"], default="db")
     ap.add_argument("--ext-contexts", type=int, default=3, help="batches extended concurrently (each on its own context and host thread team)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the whole-process comparison (diamond-hip against the reference binary on files)")
     ap.add_argument("--no-pipeline", action="store_true", help="run seed stage and extension stage of a batch back to back on one context")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` launches its own N ranks (one process per GPU over RCCL); under torchrun / torch.distributed.run
+    # the ranks exist already. Either way the number of ranks that run must be the number asked for.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))).returncode)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d ranks were launched; refusing to report a rank count that did not run" % (args.gpus, world))
+    if os.environ.get("DMND_BENCH_LAUNCH_ONLY") == "1":      # tests/test_multigpu_gloo.py: the launcher alone, no GPU needed
+        print("launch-only rank %d of %d local %d gpus %d" % (rank, world, local_rank, args.gpus), flush=True)
+        return
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
     # test hook: several ranks on ONE GPU (RCCL refuses that), used to exercise the multi-rank code path on a 1-GPU box:
     # DMND_BENCH_SHARE_GPU=1 maps every rank to cuda:0 and gathers the records over gloo instead of RCCL
     share_gpu = os.environ.get("DMND_BENCH_SHARE_GPU") == "1"
     if share_gpu:
         local_rank = 0
+    elif torch.cuda.device_count() < world:
+        sys.exit("bench.py: %d ranks but %d GPU(s) visible" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
@@ -211,7 +284,6 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     coll_device = torch.device("cpu") if share_gpu else device
-    assert world == args.gpus or world == 1
     # every rank of a database-sharded run extends 1/N of the seed hits: its host part needs correspondingly fewer threads, and N
     # ranks share the node's cores
     threads = max(1, args.host_threads) if args.host_threads else (12 if world == 1 else max(3, 24 // world))
@@ -229,7 +301,8 @@ def main():
     def make_ctx(b=0):
         c = hip.Context(device=local_rank, params=params)
         c.upload_block(hip.QUERY, w.qd, w.ql)
-        c.upload_block(hip.TARGET, w.blocks[b][2], w.blocks[b][3])
+        if b is not None:
+            c.upload_block(hip.TARGET, w.blocks[b][2], w.blocks[b][3])
         c.set_query_contexts(w.contexts)
         c.set_gapped_filter(gf_evalue)
         return c
@@ -239,7 +312,11 @@ def main():
     ctxs = [make_ctx(b) for b in range(NB)]                 # synchronous H2D of the blocks (pageable host memory); all stay resident in HBM
     upload_ms = (time.perf_counter() - t_up) * 1e3          # outside the timed region: inputs are resident when a step starts
     pipeline = not args.no_pipeline
-    ctxs_seed = [make_ctx(b) for b in range(NB)] if pipeline else ctxs
+    # Several database blocks on this rank (C5): ONE seed context searches them in turn -- every block stays resident in the
+    # context that extends it and is aliased (dmnd_share_block), and the query seed index built for the first block of a batch
+    # is kept for its other blocks (dmnd_set_query_index_reuse; reset at the start of every batch, so that every step still
+    # indexes its query block once, as a run over many query blocks does)
+    ctxs_seed = [make_ctx(None)] if NB > 1 else ([make_ctx(0)] if pipeline else ctxs)
     # E batches are extended at the same time, each on its own context (own streams, buffers and host thread team): while one
     # batch is in a host phase (chaining, culling) the other one's sweep or walk runs, which the seed stage alone did not fill
     E = max(1, args.ext_contexts) if pipeline else 1
@@ -250,8 +327,15 @@ def main():
 
     def seed_stage(b=0):
         torch.cuda.set_device(local_rank)
-        hits = ctxs_seed[b].seed_search(seed_params)
-        ms = ctxs_seed[b].seed_kernel_ms()
+        c = ctxs_seed[0]
+        if NB > 1:
+            if b == 0:
+                c.set_query_index_reuse(True)               # drops the index of the previous batch
+            c.share_block(hip.TARGET, ctxs[b])
+        t_s = time.perf_counter()
+        hits = c.seed_search(seed_params)
+        state.setdefault("seed_wall", []).append((time.perf_counter() - t_s) * 1e3)
+        ms = c.seed_kernel_ms()
         state["stream_ms"] += ms[1]                         # every seed stage that ran since the counters were reset
         state["stream_launches"] += seed_params.n_shapes
         return hits, ms
@@ -265,7 +349,10 @@ def main():
                 r = np.ascontiguousarray(m, dtype=hip.MATCH_DTYPE).copy()
                 r["target"] += np.uint32(w.blocks[b][0])
                 mine.append(r)
-            return multigpu.db_shard_join(np.concatenate(mine), coll_device, target_base=0)
+            # all-to-all keyed by query range, rank g joins queries [g Q/G, (g+1) Q/G), one gather to rank 0
+            part, full = multigpu.query_range_join(np.concatenate(mine), w.n_queries, coll_device)
+            state["joined_queries"] = int(np.unique(part["query"]).size)
+            return full if rank == 0 else part
         return parts[0]
 
     def extend_batch(e, prefetched):
@@ -283,6 +370,7 @@ def main():
             seed_ms = list(ms) if seed_ms is None else [x + y for x, y in zip(seed_ms, ms)]
             st = ext_ctxs[e][b].extend_stats()
             ext_sum = dict(st) if ext_sum is None else {k: ext_sum[k] + st[k] for k in st}
+        state.setdefault("ext_wall", []).append((time.perf_counter() - t_b) * 1e3)
         return dict(parts=parts, hits=n_hits, seed_ms=seed_ms, ext=ext_sum, ext_wall_ms=(time.perf_counter() - t_b) * 1e3)
 
     def step(prefetched=None, done=None):
@@ -363,9 +451,10 @@ def main():
     sync()
     # hipDeviceSynchronize lets the runtime release the hardware queues of idle streams; re-acquiring them costs the first
     # timed calls milliseconds (a streaming caller never synchronizes the whole device)
-    for c in [x for cs in ext_ctxs for x in cs] + (ctxs_seed if pipeline else []):
+    for c in [x for cs in ext_ctxs for x in cs] + (ctxs_seed if ctxs_seed is not ctxs else []):
         c.touch_streams()
     state["stream_ms"], state["stream_launches"] = 0.0, 0
+    state["seed_wall"], state["ext_wall"] = [], []
     t0 = time.perf_counter()
     cpu0 = time.process_time()
     each, queue = run(args.steps, queue)
@@ -376,6 +465,14 @@ def main():
     dt = time.perf_counter() - t0
     cpu_ms_per_step = (time.process_time() - cpu0) * 1e3 / args.steps      # CPU time of all threads of this process
     stream_ms, stream_launches = state["stream_ms"], state["stream_launches"]
+
+    def pct(v, q):
+        v = sorted(v)
+        return v[min(len(v) - 1, int(q * len(v)))] if v else None
+    lat = {"seed_stage_call_ms": {"p50": pct(state["seed_wall"], 0.5), "p95": pct(state["seed_wall"], 0.95)},
+           "extension_of_a_batch_ms": {"p50": pct(state["ext_wall"], 0.5), "p95": pct(state["ext_wall"], 0.95)},
+           "note": "wall time of the calls inside the timed, pipelined region (per database block for the seed stage, per batch for the extension): with "
+                   "several batches in flight a batch's latency is several steps long; ms_per_step is the throughput figure"}
     pipe_ext = dict(state["ext"])
     # stage latencies of one batch on an otherwise idle GPU, after the timed region
     serial, alone = [], {}
@@ -403,8 +500,8 @@ def main():
     r1_cells, r2_swept, r2_cells, n_matches_all, r1_targets, r2_targets, n_hits_all = [float(x) for x in cells.tolist()]
     cells_swept = r1_cells + r2_swept
     records = state["records"]
-    if world > 1 and args.shard == "query":
-        n_aligned = torch.tensor([float(np.unique(records["query"]).size)], dtype=torch.float64, device=coll_device)
+    if world > 1:         # every rank holds the records of its own queries (its query shard, or the query range it joined)
+        n_aligned = torch.tensor([float(state["joined_queries"] if args.shard == "db" else np.unique(records["query"]).size)], dtype=torch.float64, device=coll_device)
         dist.all_reduce(n_aligned, op=dist.ReduceOp.SUM)
         aligned = int(n_aligned.item())
     else:
@@ -428,7 +525,7 @@ def main():
                                      "definition cpu_baseline is quoted on",
                        "dp_arithmetic": "packed int16 (two work items per wavefront), items that saturate re-run in int32",
                        "host_threads": threads,
-                       "parallelism": ("%s-shard x%d (strong scaling of the fixed job)%s" % (args.shard, world, " + RCCL all_gather of match records + block join" if args.shard == "db" else "")) if world > 1 else "single GPU"},
+                       "parallelism": ("%s-shard x%d (strong scaling of the fixed job)%s" % (args.shard, world, " + RCCL all-to-all of match records keyed by query range, rank g joins 1/N of the queries, gather to rank 0" if args.shard == "db" else "")) if world > 1 else "single GPU"},
             "extension": ext,
             "swipe_kernel_gcups": {"round1": ext["round1_cells"] / max(ext["round1_swipe_kernel_ms"], 1e-9) / 1e6,
                                    "traceback_kernel_ms": ext["traceback_kernel_ms"]},
@@ -438,6 +535,7 @@ def main():
             "pipeline": ("seed stages run on a second context (own low-priority stream), up to %d batches ahead of the extension stage; %d batches are extended at the same time "
                          "(own context and a team of %d host threads each)" % (PREFETCH, E, ext_threads)) if pipeline else "off",
             "ms_each_step": each,
+            "latency_in_pipeline": lat,
             "alone": alone,
             "host_cpu_ms_per_step": cpu_ms_per_step,
             "host_cpu_quota": cgroup_cpus(),
@@ -480,20 +578,44 @@ def main():
         # HBM traffic of the dominant kernel per launch: FETCH_SIZE of a separate `rocprofv3 --pmc FETCH_SIZE` pass over this same
         # command (tools/profile_r02.sh), doubled as MI355X_MICROARCH.md prescribes for gfx950, plus WRITE_SIZE; only quoted for the
         # configuration and kernel variant it was measured on
-        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_summary_%s.json" % args.config)
-        if world == 1 and args.queries == 10_000 and args.families == 100_000 and NB == 1 and os.path.exists(pmc_path):
+        pmc_path = next((q for q in (os.path.join(ROOT, "profiles", "r%02d_pmc_summary_%s.json" % (r, args.config)) for r in (3, 2)) if os.path.exists(q)), None)
+        if world == 1 and args.queries == 10_000 and args.families == 100_000 and NB == 1 and pmc_path:
             pmc = json.load(open(pmc_path))
             k = [v for name, v in pmc.items() if "seed_stream_fast_kernel" in name]
             if len(k) == 1 and "FETCH_SIZE_x2_bytes_per_launch" in k[0]:
-                out["roofline"]["traffic"] = k[0]["FETCH_SIZE_x2_bytes_per_launch"] + k[0].get("WRITE_SIZE_bytes_per_launch", 0.0)
-                out["roofline"]["traffic_source"] = "profiles/r02_pmc_summary_%s.json: FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, bytes per launch" % args.config
+                rl = out["roofline"]
+                rl["traffic"] = k[0]["FETCH_SIZE_x2_bytes_per_launch"] + k[0].get("WRITE_SIZE_bytes_per_launch", 0.0)
+                rl["traffic_source"] = "%s: FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, bytes per launch" % os.path.relpath(pmc_path, ROOT)
+                # three different HBM figures, named for what they are
+                rl["hbm_measured"] = {"bytes_per_launch": rl["traffic"], "gbs": rl["traffic"] / (k_alone * 1e-3) / 1e9, "frac": rl["traffic"] / (k_alone * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      "note": "what the kernel really moves over the fabric (PMC) / its launch time alone; `achieved` above is the SURVEY 8(d) MODEL of the "
+                                              "reference's seed-array traffic (17 B per letter), which this kernel never moves"}
+                if "TCC_REQ_sum_per_launch" in k[0]:
+                    L2_REQ_PEAK = 2.7e11      # 34.5 TB/s of L2 bandwidth (MI355X_MICROARCH.md) / 128-byte lines
+                    rl["l2_requests"] = {"bound": "l2 request rate", "requests_per_launch": k[0]["TCC_REQ_sum_per_launch"],
+                                         "hits": k[0].get("TCC_HIT_sum_per_launch"), "misses": k[0].get("TCC_MISS_sum_per_launch"),
+                                         "achieved": k[0]["TCC_REQ_sum_per_launch"] / (k_alone * 1e-3), "peak": L2_REQ_PEAK, "unit": "requests/s",
+                                         "frac": k[0]["TCC_REQ_sum_per_launch"] / (k_alone * 1e-3) / L2_REQ_PEAK,
+                                         "note": "the kernel's real limit: one 4-byte probe of the L2-resident query-seed bitmap per reference position = one L2 "
+                                                 "request per letter (TCC_REQ of the committed PMC pass / launch time alone)"}
+        # SURVEY 8(d)'s whole-pipeline figure: bytes_total = bytes_seed + bytes_sw over the step's wall time
+        S = seed_params.n_shapes
+        L = ref_letters * NB + int(w.ql[-1] - w.ql[0]) * NB
+        bytes_seed = S * (L * 1 + L * 16 + int(n_hits_all) * 15)
+        bytes_sw = int((r1_targets + r2_targets) * w.db_letters / w.n_db) + int(w.ql[-1] - w.ql[0]) * 32 + int(r1_targets + r2_targets) * 72      # T ~ DpTargets x mean target length
+        out["roofline"]["pipeline_hbm_model"] = {"bytes_per_step": bytes_seed + bytes_sw, "gbs": (bytes_seed + bytes_sw) / (dt / args.steps) / 1e9,
+                                                 "frac": (bytes_seed + bytes_sw) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS / max(world, 1),
+                                                 "note": "SURVEY 8(d): (bytes_seed + bytes_sw of the reference's data layout) / wall time of a step / (N x 8 TB/s); the joined-position "
+                                                         "fingerprint term (P x 48 B) is left out (P is not counted on the device in --fast)"}
         if seed_params.n_shapes > 2:
             out["roofline"]["note"] += ("; with short seeds (weight < 10) this kernel also runs the Hamming filter of every joined (query, reference) "
                                         "position pair, so its launch time covers the join AND the stage-1 filter")
         if not args.no_cpu_baseline and world == 1:          # reported on rank 0 at N=1 only
-            ref, ref_md5 = cpu_baseline_reference(w, cgroup_cpus())
+            ref, ref_md5, e2e = cpu_baseline_reference(w, cgroup_cpus(), e2e=not args.no_e2e)
             if ref is not None:
                 out["cpu_baseline"] = ref
+                if e2e is not None:
+                    out["e2e"] = e2e
                 # parity of THIS run: the records of the last timed step, formatted as the reference's tabular output
                 qids = ["%s%d" % ("r" if w.contexts == 6 else "q", i) for i in range(w.n_queries)]
                 tids = ["t%d" % i for i in range(w.n_db)]
@@ -502,7 +624,7 @@ def main():
                 out["parity_checked"] = ours == ref_md5
                 out["parity"] = {"records_md5": ours, "reference_output_md5": ref_md5, "lines": text.count("\n")}
         print(json.dumps(out))
-    for c in [x for cs in ext_ctxs for x in cs] + (ctxs_seed if pipeline else []):
+    for c in (ctxs_seed if ctxs_seed is not ctxs else []) + [x for cs in ext_ctxs for x in cs]:
         c.close()
     if world > 1:
         dist.destroy_process_group()

@@ -28,12 +28,26 @@
 #include <vector>
 #include <zlib.h>
 #include <unistd.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include "../../include/diamond_hip.h"
 
 namespace {
 
+// vector storage that is not zero-filled on resize: a reference block of hundreds of MB is written exactly once, by the loader's
+// threads (the fill would be one more single-threaded pass over it, and the first touch of every page)
+template<typename T> struct NoInitAlloc : std::allocator<T> {
+	template<typename U> struct rebind { using other = NoInitAlloc<U>; };
+	NoInitAlloc() = default;
+	template<typename U> NoInitAlloc(const NoInitAlloc<U>&) {}
+	template<typename U> void construct(U* p) { ::new ((void*)p) U; }
+	template<typename U, typename... A> void construct(U* p, A&&... a) { ::new ((void*)p) U(std::forward<A>(a)...); }
+};
+using Letters = std::vector<int8_t, NoInitAlloc<int8_t>>;
+
 struct SeqBlock {
-	std::vector<int8_t> data;        // SequenceSet layout
+	Letters data;                    // SequenceSet layout
 	std::vector<int64_t> limits;
 	std::vector<std::string> ids;
 	int64_t letters = 0;
@@ -268,59 +282,84 @@ struct Database {
 	mutable std::mutex mtx;
 	mutable std::vector<std::string> title_cache;
 	mutable std::vector<char> have_title;
+	const char* map = nullptr;                  // .dmnd: the file, mapped read-only (the page cache is the only copy on the host
+	size_t map_size = 0;                        // until a block's letters are written out in the SequenceSet layout)
 
+	Database() = default;
+	Database(const Database&) = delete;
+	~Database() { if (map) ::munmap(const_cast<char*>(map), map_size); }
+
+	void need(uint64_t at, uint64_t bytes) const { if (at > map_size || bytes > map_size - at) throw std::runtime_error("Truncated DIAMOND database."); }
 	void open(const std::string& p)
 	{
 		path = p;
 		dmnd = is_dmnd(p);
 		if (!dmnd) { read_fasta(p, all); n = all.ids.size(); letters = all.letters; return; }
-		std::ifstream f(p, std::ios::binary);
-		if (!f) throw std::runtime_error("Error opening file " + p);
+		const int fd = ::open(p.c_str(), O_RDONLY);
+		if (fd < 0) throw std::runtime_error("Error opening file " + p);
+		struct stat st;
+		if (::fstat(fd, &st) != 0 || st.st_size < 40) { ::close(fd); throw std::runtime_error("Database file is not a DIAMOND database."); }
+		map_size = (size_t)st.st_size;
+		void* m = ::mmap(nullptr, map_size, PROT_READ, MAP_PRIVATE, fd, 0);
+		::close(fd);
+		if (m == MAP_FAILED) { map_size = 0; throw std::runtime_error("Error mapping file " + p); }
+		map = static_cast<const char*>(m);
 		uint64_t magic, sequences, let, pos_array_offset; uint32_t build, version;
-		f.read((char*)&magic, 8); f.read((char*)&build, 4); f.read((char*)&version, 4);
-		f.read((char*)&sequences, 8); f.read((char*)&let, 8); f.read((char*)&pos_array_offset, 8);
-		if (!f || magic != DMND_MAGIC) throw std::runtime_error("Database file is not a DIAMOND database.");
+		std::memcpy(&magic, map, 8); std::memcpy(&build, map + 8, 4); std::memcpy(&version, map + 12, 4);
+		std::memcpy(&sequences, map + 16, 8); std::memcpy(&let, map + 24, 8); std::memcpy(&pos_array_offset, map + 32, 8);
+		(void)build;
+		if (magic != DMND_MAGIC) throw std::runtime_error("Database file is not a DIAMOND database.");
 		if (version < 2 || version > 3) throw std::runtime_error("Unsupported DIAMOND database version (protein databases of format 2-3 only).");
 		n = (size_t)sequences; letters = (int64_t)let;
-		std::vector<char> pa((n + 1) * 16);
-		f.seekg((std::streamoff)pos_array_offset);
-		if (!f.read(pa.data(), (std::streamsize)pa.size())) throw std::runtime_error("Truncated DIAMOND database.");
+		need(pos_array_offset, (uint64_t)(n + 1) * 16);
+		const char* pa = map + pos_array_offset;
 		pos.resize(n + 1); len.resize(n + 1);
-		for (size_t i = 0; i <= n; ++i) { std::memcpy(&pos[i], pa.data() + 16 * i, 8); std::memcpy(&len[i], pa.data() + 16 * i + 8, 4); }
+		for (size_t i = 0; i <= n; ++i) { std::memcpy(&pos[i], pa + 16 * i, 8); std::memcpy(&len[i], pa + 16 * i + 8, 4); }
+		for (size_t i = 0; i < n; ++i)               // every record inside the file, in order: the loader's threads index with these
+			if (pos[i + 1] < pos[i] || pos[i + 1] > map_size || (uint64_t)len[i] + 3 > pos[i + 1] - pos[i]) throw std::runtime_error("Truncated DIAMOND database.");
 		title_cache.resize(n); have_title.assign(n, 0);
 	}
 	int64_t length(size_t i) const { return dmnd ? (int64_t)len[i] : all.limits[i + 1] - all.limits[i] - 1; }
-	// sequences [begin, end) as a block of their own (SequenceSet layout with its padding)
-	SeqBlock load(size_t begin, size_t end) const
+	// sequences [begin, end) as a block of their own (SequenceSet layout with its padding). The reference reads the records of a
+	// block one after the other on one thread (load_seqs, data/sequence_file.cpp:113-150 over legacy/dmnd/dmnd.cpp:224-340); here
+	// the position array gives every sequence's place in the block up front, so `threads` threads each write their share of the
+	// block straight from the mapped file -- one pass over the letters, no intermediate copy.
+	SeqBlock load(size_t begin, size_t end, int threads = 8) const
 	{
 		if (!dmnd) return slice(all, begin, end);
-		std::ifstream f(path, std::ios::binary);
-		if (!f) throw std::runtime_error("Error opening file " + path);
-		const uint64_t b0 = pos[begin], b1 = pos[end];
-		std::vector<char> raw((size_t)(b1 - b0));
-		f.seekg((std::streamoff)b0);
-		if (b1 > b0 && !f.read(raw.data(), (std::streamsize)raw.size())) throw std::runtime_error("Truncated DIAMOND database.");
 		SeqBlock b;
-		b.begin();
-		int64_t total = 0;
-		for (size_t i = begin; i < end; ++i) total += len[i];
-		b.data.reserve(256 + (size_t)total + (end - begin) + 256);
-		b.limits.reserve(end - begin + 1);
-		for (size_t i = begin; i < end; ++i) {
-			const uint64_t at = pos[i] - b0;
-			if (at + len[i] + 3 > raw.size()) throw std::runtime_error("Truncated DIAMOND database.");
-			const size_t o = b.data.size();
-			b.data.resize(o + len[i] + 1);
-			int8_t* dst = b.data.data() + o;
-			const char* src = raw.data() + at + 1;             // record: 0xFF letters 0xFF id 0
-			// the reference's makedb stores its SEG soft mask in bit 7 (src/legacy/dmnd/dmnd.cpp:262-265); with masking off
-			// the search ignores it (Sequence::operator[] & LETTER_MASK), so it is dropped at load time
-			for (uint32_t k = 0; k < len[i]; ++k) dst[k] = (int8_t)(src[k] & 31);
-			dst[len[i]] = 31;
-			b.limits.push_back((int64_t)b.data.size());
+		const size_t count = end - begin;
+		b.limits.resize(count + 1);
+		b.limits[0] = 256;
+		for (size_t k = 0; k < count; ++k) b.limits[k + 1] = b.limits[k] + (int64_t)len[begin + k] + 1;
+		const int64_t total = b.limits[count] - 256 - (int64_t)count;
+		b.data.resize((size_t)b.limits[count] + 256);
+		int8_t* const data = b.data.data();
+		std::memset(data, 31, 256);
+		std::memset(data + b.limits[count], 31, 256);
+		const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, threads), count / 4096 + 1));
+		auto work = [&](int t) {
+			// shares of about equal letters: the sequence whose offset passes t / T of the block starts share t
+			const int64_t lo_off = 256 + (b.limits[count] - 256) * t / T, hi_off = 256 + (b.limits[count] - 256) * (t + 1) / T;
+			size_t k0 = (size_t)(std::lower_bound(b.limits.begin(), b.limits.end() - 1, lo_off) - b.limits.begin());
+			size_t k1 = t + 1 == T ? count : (size_t)(std::lower_bound(b.limits.begin(), b.limits.end() - 1, hi_off) - b.limits.begin());
+			for (size_t k = k0; k < k1; ++k) {
+				const uint32_t l = len[begin + k];
+				int8_t* dst = data + b.limits[k];
+				const char* src = map + pos[begin + k] + 1;       // record: 0xFF letters 0xFF id 0
+				// the reference's makedb stores its SEG soft mask in bit 7 (src/legacy/dmnd/dmnd.cpp:262-265); with masking off
+				// the search ignores it (Sequence::operator[] & LETTER_MASK), so it is dropped at load time
+				for (uint32_t x = 0; x < l; ++x) dst[x] = (int8_t)(src[x] & 31);
+				dst[l] = 31;
+			}
+		};
+		if (T == 1) work(0);
+		else {
+			std::vector<std::thread> th;
+			for (int t = 0; t < T; ++t) th.emplace_back(work, t);
+			for (auto& x : th) x.join();
 		}
 		b.letters = total;
-		b.finish();
 		return b;
 	}
 	const std::string& title(size_t i) const
@@ -328,13 +367,9 @@ struct Database {
 		if (!dmnd) return all.ids[i];
 		std::lock_guard<std::mutex> lock(mtx);
 		if (!have_title[i]) {
-			std::ifstream f(path, std::ios::binary);
 			const uint64_t at = pos[i] + (uint64_t)len[i] + 2, sz = pos[i + 1] - at;
-			std::string t((size_t)sz, 0);
-			f.seekg((std::streamoff)at);
-			if (sz && !f.read(&t[0], (std::streamsize)sz)) throw std::runtime_error("Truncated DIAMOND database.");
-			t.resize(std::strlen(t.c_str()));
-			title_cache[i] = t; have_title[i] = 1;
+			title_cache[i].assign(map + at, strnlen(map + at, (size_t)sz));
+			have_title[i] = 1;
 		}
 		return title_cache[i];
 	}
@@ -342,10 +377,7 @@ struct Database {
 	std::vector<int8_t> sequence(size_t i) const
 	{
 		if (!dmnd) return std::vector<int8_t>(all.data.begin() + all.limits[i], all.data.begin() + all.limits[i + 1] - 1);
-		std::ifstream f(path, std::ios::binary);
-		std::vector<int8_t> s(len[i]);
-		f.seekg((std::streamoff)(pos[i] + 1));
-		if (len[i] && !f.read((char*)s.data(), (std::streamsize)len[i])) throw std::runtime_error("Truncated DIAMOND database.");
+		std::vector<int8_t> s(map + pos[i] + 1, map + pos[i] + 1 + len[i]);
 		for (int8_t& l : s) l &= 31;
 		return s;
 	}
@@ -886,13 +918,18 @@ int run_blastp(const Options& o)
 		SeqBlock& q = q_blocks.size() > 1 ? q_own : q_all;
 		const int64_t nq = (int64_t)((qr.end - qr.begin) * C);
 		// every GPU gets the query block; GPU 0's masking run also writes the masked letters into the host copy that the host part
-		// of every extension call reads
+		// of every extension call reads. Two phases with a join between them: no GPU's upload may still be reading the host copy
+		// when GPU 0 writes the masked letters back into it (a late GPU would upload a partly masked block and mask it again).
+		std::vector<double> up_ms((size_t)n_gpus, 0.0);
+		on_each_gpu([&](int g) {
+			auto t0 = std::chrono::steady_clock::now();
+			chk(dmnd_upload_block(ctxs[(size_t)g], DMND_QUERY, q.data.data(), (int64_t)q.data.size(), q.limits.data(), nq));
+			up_ms[(size_t)g] = ms_since(t0);
+		});
 		on_each_gpu([&](int g) {
 			dmnd_ctx* ctx = ctxs[(size_t)g];
+			const double up = up_ms[(size_t)g];
 			auto t0 = std::chrono::steady_clock::now();
-			chk(dmnd_upload_block(ctx, DMND_QUERY, q.data.data(), (int64_t)q.data.size(), q.limits.data(), nq));
-			const double up = ms_since(t0);
-			t0 = std::chrono::steady_clock::now();
 			int64_t mq = 0, ml = 0;
 			if (tantan) chk(dmnd_mask_block(ctx, DMND_QUERY, g == 0 ? q.data.data() : nullptr, &mq));
 			const double mk = ms_since(t0);
@@ -915,11 +952,11 @@ int run_blastp(const Options& o)
 			// GPU that has one block keeps it (masked) from one query block to the next
 			const bool fresh = held.index != bi;             // just read: unmasked
 			if (fresh) {
-				held.block = next.valid() ? next.get() : db.load(tr.begin, tr.end);
+				held.block = next.valid() ? next.get() : db.load(tr.begin, tr.end, threads);
 				held.index = bi;
 			}
 			const size_t bn = bi + (size_t)n_gpus;
-			if (bn < t_blocks.size()) next = std::async(std::launch::async, [&db, &t_blocks, bn] { return db.load(t_blocks[bn].begin, t_blocks[bn].end); });
+			if (bn < t_blocks.size()) next = std::async(std::launch::async, [&db, &t_blocks, bn, threads] { return db.load(t_blocks[bn].begin, t_blocks[bn].end, threads); });
 			SeqBlock& t = held.block;
 			auto t0 = std::chrono::steady_clock::now();
 			double up = 0, mk = 0;

@@ -90,6 +90,9 @@ struct dmnd_ctx {
 	dmnd::DevBuf pairs, trace_off_item;        // packed-int16 sweep: item pairs per wavefront, trace offset by item index
 	std::vector<int32_t> h_pairs;              // their host staging (outlive the asynchronous copies of a call)
 	std::vector<int64_t> h_trace_off_item;
+	dmnd::PinBuf up_stage[2];                  // dmnd_upload_block: page-locked double buffer of a pageable source
+	hipEvent_t up_ev[2] = { nullptr, nullptr };
+	bool up_busy[2] = { false, false };
 	dmnd::PinBuf stage_h, ends_h;              // dmnd_swipe_keep: all launch arrays of a sweep in one upload; its results
 	dmnd::DevBuf stage_d;
 	std::vector<KeptTrace>* kts = nullptr;     // kept traces of the extension stage's ranking iterations (reused from call to call)

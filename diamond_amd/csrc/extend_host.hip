@@ -1020,9 +1020,6 @@ extern "C" int dmnd_set_max_target_seqs(dmnd_ctx* c, int k)
 	return DMND_OK;
 }
 
-// join_query over the records of several reference blocks (output/join_blocks.cpp:180-256): every block's list of a query is
-// already in match_less order, so the reference's heap merge by JoinRecord::cmp_evalue (join_blocks.cpp:129-142) is the sort of
-// the union by (e-value, score descending, target ordinal); GlobalCulling keeps the first max_target_seqs (target_culling.h:70-88).
 extern "C" int dmnd_set_filters(dmnd_ctx* c, double min_id, double query_cover, double subject_cover, double min_bit_score)
 {
 	if (!c || min_id < 0 || min_id > 100 || query_cover < 0 || query_cover > 100 || subject_cover < 0 || subject_cover > 100 || min_bit_score < 0)
@@ -1072,6 +1069,9 @@ extern "C" int dmnd_join_blocks_top(dmnd_match* r, int64_t n, double top_percent
 	return DMND_OK;
 }
 
+// join_query over the records of several reference blocks (output/join_blocks.cpp:180-256): every block's list of a query is
+// already in match_less order, so the reference's heap merge by JoinRecord::cmp_evalue (join_blocks.cpp:129-142) is the sort of
+// the union by (e-value, score descending, target ordinal); GlobalCulling keeps the first max_target_seqs (target_culling.h:70-88).
 extern "C" int dmnd_join_blocks(dmnd_match* r, int64_t n, int max_target_seqs, int64_t* n_out)
 {
 	if (!r || n < 0 || max_target_seqs < 1 || !n_out) return fail(DMND_E_ARG, "dmnd_join_blocks: bad argument");

@@ -212,6 +212,7 @@ extern "C" int dmnd_mask_block(dmnd_ctx* c, int which, int8_t* host_data, int64_
 	c->soft_valid[which] = false;
 	if (which == DMND_QUERY) ++c->query_generation;
 	if (!c->block[which].p || c->limits[which].size() < 2) return fail(DMND_E_ARG, "dmnd_mask_block: block must be uploaded with limits");
+	if (!c->block[which].own) return fail(DMND_E_ARG, "dmnd_mask_block: the block is shared from another context (dmnd_share_block); mask it there");
 	HIP_TRY(hipSetDevice(c->device));
 	hipStream_t st = c->stream;
 	const std::vector<int64_t>& lim = c->limits[which];

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DMND_ABI_VERSION 5      /* 2: dmnd_match.frame, seed parameters (ungapped filter, translated queries), dmnd_extend_plan(query_contexts); 3: seed_encoding; 4: output formats; 5: DMND_MAX_SHAPES 64 */
+#define DMND_ABI_VERSION 6      /* 2: dmnd_match.frame, seed parameters (ungapped filter, translated queries), dmnd_extend_plan(query_contexts); 3: seed_encoding; 4: output formats; 5: DMND_MAX_SHAPES 64; 6: dmnd_host_alloc, dmnd_share_block */
 
 enum {
 	DMND_OK = 0,
@@ -122,6 +122,17 @@ int dmnd_set_db_letters(dmnd_ctx* ctx, double db_letters);
  * limits may be NULL when only the DP entry points are used. */
 int dmnd_upload_block(dmnd_ctx* ctx, int which, const int8_t* data, int64_t data_len,
 	const int64_t* limits, int64_t n_seqs);
+/* Page-locked host memory for a block's letters: dmnd_upload_block hands such a buffer to the DMA engine as it is, any other
+ * (pageable) source is staged through two page-locked chunks of the context while the previous chunk is in flight. A driver that
+ * reads a database block from disk into this memory (the reference's loader: data/sequence_file.cpp:113-150 load_seqs,
+ * legacy/dmnd/dmnd.cpp:224-340) uploads it at the PCIe rate. NULL on failure. */
+void* dmnd_host_alloc(size_t bytes);
+void dmnd_host_free(void* p);
+/* Makes block `which` of ctx an alias of the block `src` holds (same device): no copy, no second resident copy. For a driver that
+ * keeps several reference blocks resident (one context each) and lets ONE context search them in turn, e.g. to keep that context's
+ * query seed index over the blocks (dmnd_set_query_index_reuse). `src` must outlive every use; the alias is read-only
+ * (dmnd_mask_block on it is refused) and is dropped by the next dmnd_upload_block / dmnd_share_block of that block. */
+int dmnd_share_block(dmnd_ctx* ctx, int which, const dmnd_ctx* src);
 /* Uploads the per-query Hauser composition-bias vectors (HauserCorrection::int8,
  * src/stats/hauser_correction.cpp:107), concatenated; dmnd_dp_target::cbs_off indexes this buffer. */
 int dmnd_upload_cbs(dmnd_ctx* ctx, const int8_t* cbs, int64_t len);

@@ -1,6 +1,13 @@
-"""world_size-2 CPU test (gloo) of the N>1 path: query sharding + the single all_gather of per-query top-k
-records, and the database-sharded merge ordering (JoinRecord::cmp_evalue, output/join_blocks.cpp:129-137)."""
+"""world_size-2 / 3 CPU tests (gloo) of the N > 1 path:
+  * database shards: `multigpu.query_range_join` -- all-to-all of match records keyed by query range, rank g joining the
+    queries [g Q/G, (g+1) Q/G) with dmnd_join_blocks, one gather to rank 0 -- equals the sequential join of the same blocks
+    (dmnd_join_blocks itself is pinned on the reference's heap merge, JoinRecord::cmp_evalue output/join_blocks.cpp:129-137,
+    in test_join_blocks); uneven query ranges, several blocks per rank, a rank without records, a query count below the world size;
+  * query shards: the ordered gather to rank 0;
+  * bench.py's launcher: `--gpus N` without torchrun re-executes itself under torch.distributed.run with N ranks, and a rank
+    count that differs from --gpus is a hard failure."""
 import os
+import subprocess
 import sys
 import numpy as np
 import torch
@@ -10,117 +17,105 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _records(seed, nq, n):
-    rng = np.random.default_rng(seed)
-    q = np.sort(rng.integers(0, nq, n))
-    ev = rng.choice([1e-30, 1e-10, 1e-5, 2e-5], n)          # ties on purpose
-    sc = rng.integers(40, 60, n)
-    oid = rng.permutation(n) + seed * 100000
-    return q, ev, sc, oid
-
-
-def _worker(rank, world, port, ret):
+def _init(rank, world, port):
     sys.path.insert(0, ROOT)
-    from diamond_amd import multigpu
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    nq = 50
-    q, ev, sc, oid = _records(rank + 1, nq, 400)
-    rec = multigpu.topk_records(nq, q, ev, sc, oid)
-    g = multigpu.gather_records(rec, torch.device("cpu"))
-    merged = multigpu.merge_topk(g)
-    lo, hi = multigpu.shard_range(101, world, rank)
-    ret[rank] = (g.numpy().copy(), merged.numpy().copy(), (lo, hi))
-    dist.destroy_process_group()
 
 
-def test_two_rank_gather_and_merge():
-    world = 2
-    mgr = mp.Manager()
-    ret = mgr.dict()
-    mp.spawn(_worker, args=(world, 29517, ret), nprocs=world, join=True)
-    g0, m0, r0 = ret[0]
-    g1, m1, r1 = ret[1]
-    assert np.array_equal(g0, g1) and np.array_equal(m0, m1)          # every rank holds the same gathered view
-    assert r0 == (0, 51) and r1 == (51, 101)                            # contiguous, covering, ordered slices
-    # reference ordering, brute force
-    nq = 50
-    rows = []
-    for rank in range(world):
-        q, ev, sc, oid = _records(rank + 1, nq, 400)
-        rows += list(zip(q, ev, -sc.astype(float), oid.astype(float)))
-    for qi in range(nq):
-        mine = sorted((r[1:] for r in rows if r[0] == qi))
-        # each rank first culls to its own top-25, then the merge keeps the global top-25 of those
-        per_rank = []
-        for rank in range(world):
-            q, ev, sc, oid = _records(rank + 1, nq, 400)
-            rr = sorted((e, -float(s), float(o)) for qq, e, s, o in zip(q, ev, sc, oid) if qq == qi)[:25]
-            per_rank += rr
-        want = sorted(per_rank)[:25]
-        got = [tuple(x) for x in m0[qi] if np.isfinite(x[0])]
-        assert got == want
-        assert len(mine) >= len(got)
-
-
-def _shard_worker(rank, world, port, ret):
-    sys.path.insert(0, ROOT)
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
+def _shard_worker(rank, world, port, case, ret):
+    _init(rank, world, port)
     from diamond_amd import multigpu
     from test_join_blocks import _block_records
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    blocks = _block_records(np.random.default_rng(5), 40, world, 300)          # every rank draws the same set and keeps its own shard
-    mine = blocks[rank].copy()
-    mine["target"] -= np.uint32(rank * 300)                                     # shard-local target ids, as dmnd_extend returns them
-    joined = multigpu.db_shard_join(mine, torch.device("cpu"), target_base=rank * 300, k=25)
-    ret[rank] = joined.tobytes()
+    nq, n_blocks, tpb, k = case
+    blocks = _block_records(np.random.default_rng(5), nq, n_blocks, tpb)        # every rank draws the same set ...
+    mine = [blocks[b] for b in range(rank, n_blocks, world)]                      # ... and keeps blocks rank, rank + world, ...
+    if case == CASES[2] and rank == 1:
+        mine = []                                                                 # a rank whose shard produced no alignment
+    rec = np.concatenate(mine) if mine else np.zeros(0, blocks[0].dtype)
+    part, full = multigpu.query_range_join(rec, nq, torch.device("cpu"), k=k)
+    lo, hi = multigpu.shard_range(nq, world, rank)
+    assert part.size == 0 or (part["query"].min() >= lo and part["query"].max() < hi)
+    assert (full is None) == (rank != 0)
+    ret[rank] = (part.tobytes(), None if full is None else full.tobytes())
     dist.destroy_process_group()
 
 
-def test_two_rank_database_shard_join_equals_block_join():
-    """Database sharding (SURVEY.md 8e option 2): two ranks, one shard each, all queries; the gathered + joined records equal
-    the sequential join of the same two blocks (dmnd_join_blocks, pinned on the reference's heap merge in test_join_blocks)."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
+#          queries, blocks, targets per block, k
+CASES = [(41, 2, 300, 25), (40, 5, 200, 25), (33, 2, 300, 25), (1, 2, 300, 3)]
+
+
+def _run_case(ci, world, port):
     from diamond_amd import hip
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     from test_join_blocks import _block_records
-    world = 2
+    case = CASES[ci]
+    nq, n_blocks, tpb, k = case
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_shard_worker, args=(world, 29519, ret), nprocs=world, join=True)
-    blocks = _block_records(np.random.default_rng(5), 40, world, 300)
-    want = hip.join_blocks(np.concatenate(blocks), 25)
-    assert ret[0] == ret[1] == want.tobytes()
+    mp.spawn(_shard_worker, args=(world, port, case, ret), nprocs=world, join=True)
+    blocks = _block_records(np.random.default_rng(5), nq, n_blocks, tpb)
+    if ci == 2:
+        blocks = [b for i, b in enumerate(blocks) if i % world != 1]
+    want = hip.join_blocks(np.concatenate(blocks), k)
+    assert ret[0][1] == want.tobytes()                                  # rank 0 holds the whole job's records, in query order
+    assert b"".join(ret[r][0] for r in range(world)) == want.tobytes()  # and the ranks' query ranges tile it
+    return want
+
+
+def test_two_rank_query_range_join_equals_block_join():
+    want = _run_case(0, 2, 29519)                                        # 41 queries: ranges of 21 and 20
     assert len(want) > 500
 
 
-def _uneven_worker(rank, world, port, ret):
-    sys.path.insert(0, ROOT)
-    from diamond_amd import multigpu
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    nq = 101                                                   # 51 + 50 queries
+def test_three_ranks_five_blocks():
+    _run_case(1, 3, 29521)                                               # ranks hold 2, 2 and 1 blocks
+
+
+def test_rank_without_records_and_fewer_queries_than_ranks():
+    _run_case(2, 2, 29523)
+    _run_case(3, 2, 29525)                                               # one query: rank 1's range is empty
+
+
+def _gather_worker(rank, world, port, ret):
+    _init(rank, world, port)
+    from diamond_amd import hip, multigpu
+    from test_join_blocks import _block_records
+    nq = 101                                                             # 51 + 50 queries
+    rec = hip.join_blocks(_block_records(np.random.default_rng(9), nq, 1, 400)[0], 25)
     lo, hi = multigpu.shard_range(nq, world, rank)
-    q, ev, sc, oid = _records(7, nq, 900)                      # every rank draws the same records and keeps its own queries
-    keep = (q >= lo) & (q < hi)
-    rec = multigpu.topk_records(hi - lo, q[keep] - lo, ev[keep], sc[keep], oid[keep])
-    g = multigpu.gather_records(rec, torch.device("cpu"))
-    ret[rank] = multigpu.concat_query_shards(g, nq).numpy().copy()
+    mine = rec[(rec["query"] >= lo) & (rec["query"] < hi)]
+    full = multigpu.gather_to_root(mine, torch.device("cpu"))
+    ret[rank] = None if full is None else full.tobytes()
     dist.destroy_process_group()
 
 
-def test_query_shards_of_unequal_size_gather():
-    """101 queries over 2 ranks: the record tensors have 51 and 50 rows; the gather pads, the concatenation trims."""
-    sys.path.insert(0, ROOT)
-    from diamond_amd import multigpu
-    world = 2
+def test_query_shards_of_unequal_size_gather_in_query_order():
+    from diamond_amd import hip, multigpu
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_join_blocks import _block_records
+    assert multigpu.shard_range(101, 2, 0) == (0, 51) and multigpu.shard_range(101, 2, 1) == (51, 101)
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_uneven_worker, args=(world, 29523, ret), nprocs=world, join=True)
-    q, ev, sc, oid = _records(7, 101, 900)
-    want = multigpu.topk_records(101, q, ev, sc, oid).numpy()
-    assert ret[0].shape == (101, multigpu.TOPK, 3)
-    assert np.array_equal(ret[0], ret[1]) and np.array_equal(ret[0], want)
+    mp.spawn(_gather_worker, args=(2, 29527, ret), nprocs=2, join=True)
+    want = hip.join_blocks(_block_records(np.random.default_rng(9), 101, 1, 400)[0], 25)
+    assert ret[1] is None and ret[0] == want.tobytes()
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` (no torchrun): the launcher half of bench.py runs before anything touches the GPU, so it is
+    testable here -- DMND_BENCH_LAUNCH_ONLY makes every spawned rank print its rendezvous environment and exit."""
+    env = dict(os.environ, DMND_BENCH_LAUNCH_ONLY="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = sorted(l for l in r.stdout.splitlines() if l.startswith("launch-only"))
+    assert lines == ["launch-only rank 0 of 2 local 0 gpus 2", "launch-only rank 1 of 2 local 1 gpus 2"], r.stdout + r.stderr[-2000:]
+    # a rank count that differs from --gpus is refused, not silently run on fewer GPUs
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env2, cwd=ROOT)
+    assert r.returncode != 0 and "--gpus 2" in r.stderr and "WORLD_SIZE=1" in r.stderr
