@@ -41,11 +41,34 @@ def test_bench_line_and_parity_at_reduced_size(cfg):
 
 
 def test_bench_two_ranks_database_sharded_on_one_gpu():
-    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29577"]
+    """`python bench.py --gpus 2` with NO torchrun: bench.py launches its two ranks itself (both on the one GPU of the box:
+    DMND_BENCH_SHARE_GPU=1 maps them to cuda:0 and runs the record exchange over gloo)."""
     one = _bench(["--queries", "1500", "--families", "3000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
-    two = _bench(["--gpus", "2", "--queries", "1500", "--families", "3000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
-                 env={"DMND_BENCH_SHARE_GPU": "1"}, launcher=launcher)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--queries", "1500", "--families", "3000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(env, DMND_BENCH_SHARE_GPU="1"), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    two = json.loads(lines[0])
     assert two["n_gpus"] == 2 and two["scaling"] == "strong"
+    assert "all-to-all" in two["config"]["parallelism"]
     # the same fixed job: same seed hits in total; alignments differ only by the per-block culling of the reference's block join
     w1, w2 = one["config"]["workload"], two["config"]["workload"]
     assert w1.split("per step")[1].split("seed hits")[0] == w2.split("per step")[1].split("seed hits")[0]
+    # one GPU but --gpus 2 without the sharing hook: refused, not silently run on fewer GPUs
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode != 0
+
+
+def test_bench_e2e_and_hot_path_baselines():
+    """The whole-process comparison (diamond-hip against the reference binary on the same files) and the hot-path baseline
+    (the reference's seed-stage + extension task timers) are on the bench line, md5-equal outputs for all three command lines."""
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/diamond_tap not built")
+    d = _bench(["--queries", "1500", "--families", "3000", "--steps", "2", "--warmup", "1"])
+    assert d["cpu_baseline"]["hot_path"]["seconds"] > 0 and d["cpu_baseline"]["whole_process"]["seconds"] > d["cpu_baseline"]["hot_path"]["seconds"]
+    e = d["e2e"]
+    assert set(e["runs"]) == {"default_masking", "masking_off", "stock_command_line"}
+    assert e["parity"] is True, {k: v["parity"] for k, v in e["runs"].items()}
+    assert all(v["ours_s"] > 0 and v["reference_s"] > 0 for v in e["runs"].values())

@@ -1,6 +1,6 @@
 """-m gpu: database sharding (SURVEY.md 8e option 2 / BASELINE config C5) end to end with two ranks on ONE GPU (gloo for the
 record exchange, as bench.py's DMND_BENCH_SHARE_GPU hook does): every rank searches ALL queries against its own shard on
-the MI355X, the ranks gather their match records and join them as the reference joins the blocks of a `-b` run. Must equal
+the MI355X, the ranks exchange their match records by query range (multigpu.query_range_join) and join them as the reference joins the blocks of a `-b` run. Must equal
 the same two blocks processed one after the other in a single process (whose text tests/test_gpu_cli.py pins against the
 reference binary run with the same block boundaries)."""
 import os
@@ -48,10 +48,12 @@ def _rank(rank, world, port, ret):
     try:
         base, td, tl = shards[rank]
         m = _search(ctx, hip, qd, ql, td, tl, hip.seed_params_fast(threads=4))
-        joined = multigpu.db_shard_join(m, torch.device("cpu"), target_base=base, k=25)
+        m = m.copy()
+        m["target"] += np.uint32(base)
+        _, joined = multigpu.query_range_join(m, len(ql) - 1, torch.device("cpu"), k=25)
     finally:
         ctx.close()
-    ret[rank] = joined.tobytes()
+    ret[rank] = None if joined is None else joined.tobytes()
     dist.destroy_process_group()
 
 
@@ -77,4 +79,4 @@ def test_two_rank_database_shards_equal_sequential_blocks():
         ctx.close()
     want = hip.join_blocks(np.concatenate(parts), 25)
     assert len(want) > 300 and len(set(want["target"].tolist())) > 300
-    assert ret[0] == ret[1] == want.tobytes()
+    assert ret[1] is None and ret[0] == want.tobytes()
