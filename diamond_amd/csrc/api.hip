@@ -523,7 +523,7 @@ int run_chunk(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, int64_t 
 		if (trace) {
 			const dmnd_dp_target& it = items[slots[s].item];
 			const Geom g = make_geom(it.query_len, it.target_len, it.d_begin, it.d_end);
-			trace_off[s + 1] = trace_off[s] + trace_rows(g) * 64 * slots[s].P;
+			trace_off[s + 1] = trace_off[s] + trace_bytes(g, slots[s].P);
 			tr_off[s + 1] = tr_off[s] + (int64_t)it.query_len + it.target_len + 2;
 		}
 	}
@@ -712,7 +712,7 @@ int swipe_impl(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, int64_t
 		while (c1 < n) {
 			const dmnd_dp_target& it = items[c1];
 			const Geom g = make_geom(it.query_len, it.target_len, it.d_begin, it.d_end);
-			const size_t need = (size_t)trace_rows(g) * 64 * slots[c1].P;
+			const size_t need = (size_t)trace_bytes(g, slots[c1].P);
 			if (c1 > c0 && bytes + need > c->trace_arena_max) break;
 			bytes += need;
 			++c1;
@@ -804,7 +804,7 @@ int dmnd_swipe_keep(dmnd_ctx* work, const dmnd_ctx* c, const dmnd_dp_target* ite
 		const Geom g = make_geom(it.query_len, it.target_len, it.d_begin, it.d_end);
 		const int P = band_class(band);
 		slots[(size_t)i] = Slot{ (int32_t)i, P, n_steps(g) };
-		rows_of[(size_t)i] = trace_rows(g) * 64 * P;
+		rows_of[(size_t)i] = trace_bytes(g, P);
 		total += rows_of[(size_t)i];
 	}
 	if (!usable || (size_t)total > work->trace_arena_max)

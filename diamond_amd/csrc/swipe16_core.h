@@ -29,6 +29,8 @@ namespace dmnd {
 
 typedef uint32_t pk16;                       // two int16 halves: low = item A, high = item B
 enum { SW16_MAX_SCORE = 32767, SW16_MAX_PAIRS = 65535, SW16_SENTINEL = 31, SW16_MAX_P = 4, SW16_Q_SHIFT = 1, SW16_T_SHIFT = 6 };
+// pair-steps of one trace record = trace_group(P) of swipe_core.h for the classes of this kernel (P <= 4): the sweep runs in groups
+template<int P> struct Sw16Group { enum { G = 16 / P }; };
 
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef short sw16_s2 __attribute__((ext_vector_type(2)));
@@ -62,6 +64,18 @@ inline pk16 pk_subus(pk16 a, pk16 b)
 inline pk16 pk_max(pk16 a, pk16 b) { return sw16_mk(imax(sw16_lo(a), sw16_lo(b)), imax(sw16_hi(a), sw16_hi(b))); }
 inline pk16 pk_twice_plus(pk16 a, pk16 b) { return sw16_mk(2 * (int)(a & 0xffff) + (int)(b & 0xffff), 2 * (int)(a >> 16) + (int)(b >> 16)); }
 #endif
+
+// keeps a value where it is computed (device). The traceback sweep ends a group of pair-steps with conditional stores, and the
+// compiler sinks whatever is only needed after them -- the packing of the trace nibbles, the updates of the end-cell keys -- past
+// the branch, keeping every step's cell values alive until then (+60 registers at P = 1)
+DMND_HD void pin_here(uint32_t& x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	asm volatile("" : "+v"(x));
+#else
+	(void)x;
+#endif
+}
 
 DMND_HD pk16 pk_both(int x) { return ((uint32_t)(uint16_t)x) | ((uint32_t)(uint16_t)x << 16); }
 DMND_HD pk16 pk_make(int lo, int hi) { return ((uint32_t)(uint16_t)lo) | ((uint32_t)(uint16_t)hi << 16); }
@@ -210,8 +224,60 @@ DMND_HD void lane16_step(Lane16<P>& st, const pk16* S, pk16 nb, pk16 go, pk16 ge
 		const uint32_t ka = (c << 16) | revt, kb = (c & 0xffff0000u) | revt;
 		st.keyA[k] = st.keyA[k] > ka ? st.keyA[k] : ka;
 		st.keyB[k] = st.keyB[k] > kb ? st.keyB[k] : kb;
+		if (TRACE) { pin_here(st.keyA[k]); pin_here(st.keyB[k]); }      // see pin_here: else every cell value of a group stays alive to its end
 	}
 }
+
+// ---- trace records (layout: swipe_core.h, trace_byte_index) --------------------------------------------------------------
+// v_perm_b32: byte x of the result = byte sel[x] (0-7) of the 8 bytes { hi : lo }
+DMND_HD uint32_t byte_perm(uint32_t hi, uint32_t lo, uint32_t sel)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	return __builtin_amdgcn_perm(hi, lo, sel);
+#else
+	const uint64_t v = ((uint64_t)hi << 32) | lo;
+	uint32_t r = 0;
+	for (int x = 0; x < 4; ++x) r |= (uint32_t)((v >> (8 * ((sel >> (8 * x)) & 7))) & 0xffu) << (8 * x);
+	return r;
+#endif
+}
+
+// A lane's 16-byte trace records of both items over one group of G = 16 / P pair-steps, collected in registers and written
+// with one 16-byte store per item and group. put<R>() takes pair-step R of the group (a compile-time position: the kernel
+// unrolls a group): tb0 / tb1 = the P trace nibbles of the even / odd step as lane16_step returns them (item A in bits 0-3,
+// item B in bits 16-19). Byte (R * P + p) of an item's record = tb0[p] | tb1[p] << 4.
+template<int P>
+struct Trace16Group {
+	uint32_t a[4], b[4];                    // the records of item A / item B
+	uint32_t h0, h1;                        // partly filled words: [A A B B] byte pairs waiting for their other half
+	template<int R>
+	DMND_HD void put(const pk16* tb0, const pk16* tb1)
+	{
+		constexpr uint32_t ZIP = 0x06020400u;            // { hi, lo } -> [lo.b0, hi.b0, lo.b2, hi.b2]
+		constexpr uint32_t LOW = 0x05040100u, HIGH = 0x07060302u;      // { hi, lo } -> [lo.h0, hi.h0] / [lo.h1, hi.h1]
+		uint32_t w[P];
+#pragma unroll
+		for (int p = 0; p < P; ++p) w[p] = tb0[p] | (tb1[p] << 4);      // A's byte in bits 0-7, B's in bits 16-23
+		if (P == 4) {
+			const uint32_t x01 = byte_perm(w[1], w[0], ZIP), x23 = byte_perm(w[P - 1], w[P == 4 ? 2 : 0], ZIP);
+			a[R] = byte_perm(x23, x01, LOW); b[R] = byte_perm(x23, x01, HIGH);
+			pin_here(a[R]); pin_here(b[R]);
+		}
+		else if (P == 2) {
+			const uint32_t x = byte_perm(w[P - 1], w[0], ZIP);         // [A0 A1 B0 B1] of this pair-step
+			if (R % 2 == 0) { h0 = x; pin_here(h0); }
+			else { a[R / 2] = byte_perm(x, h0, LOW); b[R / 2] = byte_perm(x, h0, HIGH); pin_here(a[R / 2]); pin_here(b[R / 2]); }
+		}
+		else {
+			if (R % 2 == 0) { h0 = w[0]; pin_here(h0); }
+			else {
+				uint32_t x = byte_perm(w[0], h0, ZIP);                   // [A(R-1) A(R) B(R-1) B(R)]
+				if (R % 4 == 1) { h1 = x; pin_here(h1); }
+				else { a[R / 4] = byte_perm(x, h1, LOW); b[R / 4] = byte_perm(x, h1, HIGH); pin_here(a[R / 4]); pin_here(b[R / 4]); }
+			}
+		}
+	}
+};
 
 // after the sweep: the lane's end cell of one item from its per-diagonal keys
 template<int P>

@@ -12,11 +12,14 @@
 //   * the scores of pair-step t + 1 are looked up in LDS (32x32 table of 16-bit entries with the sentinel's row and column
 //     at -128) BEFORE the cells of pair-step t are computed, so LDS latency hides behind ~40 packed VALU instructions
 //     instead of stalling the first cell of every step;
-//   * trace rows (TRACE) in the layout of the 32-bit kernel -- one byte per cell, 64*P bytes per step and item -- so the
-//     wave-cooperative walk of swipe_kernels.hip (traceback_kernel) decodes them unchanged.
+//   * trace (TRACE): one nibble per cell, collected in registers over a group of 16 / P pair-steps and written as ONE 16-byte
+//     record per lane, item and group (swipe_core.h, trace_byte_index) -- half the bytes and a sixteenth of the store
+//     instructions of a row per anti-diagonal step, and the walk (traceback_kernel) finds 16 / P consecutive columns of a
+//     diagonal in one record instead of one 128-byte line per column.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
+#include <utility>
 #include "swipe16_core.h"
 #include "swipe_kernels.h"
 
@@ -53,19 +56,9 @@ __device__ __forceinline__ Item16 load_item(const dmnd_dp_target* items, int idx
 	return r;
 }
 
-// the P trace bytes of one lane, step and item (item B: the high halves)
-template<int P, bool SECOND>
-__device__ __forceinline__ void store_trace(uint8_t* row, const pk16* tb)
-{
-	const int sh = SECOND ? 16 : 0;
-	if (P == 1) row[0] = (uint8_t)(tb[0] >> sh);
-	else if (P == 2) *reinterpret_cast<uint16_t*>(row) = (uint16_t)(((tb[0] >> sh) & 0xffu) | (((tb[1] >> sh) & 0xffu) << 8));
-	else {
-#pragma unroll
-		for (int p = 0; p < P; p += 4)
-			*reinterpret_cast<uint32_t*>(row + p) = ((tb[p] >> sh) & 0xffu) | (((tb[p + 1] >> sh) & 0xffu) << 8) | (((tb[p + 2] >> sh) & 0xffu) << 16) | (((tb[p + 3] >> sh) & 0xffu) << 24);
-	}
-}
+// f(integral_constant<0>) ... f(integral_constant<N-1>): a loop whose index is a compile-time constant in every iteration
+template<int... R, typename F>
+__device__ __forceinline__ void unrolled(std::integer_sequence<int, R...>, F&& f) { (f(std::integral_constant<int, R>()), ...); }
 
 enum { EDGE_CHUNK = 256 };            // pair-steps per refill of a wavefront's edge records (4 records per lane)
 
@@ -94,68 +87,70 @@ void banded_swipe16_kernel(const int8_t* __restrict__ qblock, const int8_t* __re
 
 	Lane16<P> st;
 	lane16_init(st, A.g, A.v, B.g, B.v, lane);
-	constexpr int W = 64 * P;
-	uint8_t *baseA = nullptr, *baseB = nullptr;
+	constexpr int G = Sw16Group<P>::G;                 // pair-steps per trace record (16 bytes per lane and item)
+	uint8_t *recA = nullptr, *recB = nullptr;          // this lane's record of the current group
 	if (TRACE) {
-		baseA = trace + rfl64(trace_off[idxA]);
-		baseB = trace + rfl64(trace_off[idxB]);
+		recA = trace + rfl64(trace_off[idxA]) + lane * 16;
+		recB = trace + rfl64(trace_off[idxB]) + lane * 16;
 	}
-	const uint32_t lane_off = (uint32_t)(lane * P);
 	uint4* const my_edges = edges[wave];
 
 	pk16 S0[P], S1[P];
 	lane16_scores(st, table, S0, S1);
 	Edge16 e = sw16_edge(A.g, A.v, B.g, B.v, P, 0);        // enters at the end of pair-step 0
+	Trace16Group<P> acc;
 
-	// pair-steps [t0, t1): SA / SB = item A / B still has trace rows to write there
-	auto sweep = [&](auto sa, auto sb, int t0, int t1) {
-		constexpr bool SA = decltype(sa)::value, SB = decltype(sb)::value;
-		auto pair_step = [&](int t, int tc) {
-			// edge record of the NEXT pair-step (LDS broadcast read, in flight during this one)
-			const uint4 nx = my_edges[t - tc];
-			// windows of pair-step t + 1 and its scores: the LDS reads are in flight while the cells of pair-step t are computed
-			lane16_advance(st, shl1_in(e.qq, st.QQ[1]), shl1_in(e.cc, st.CC[1]), shr1_in(e.tt, st.TT[P - 1]));
-			pk16 N0[P], N1[P];
-			lane16_scores(st, table, N0, N1);
-			const uint32_t revt = 0xffffu - (uint32_t)t;
-			const uint32_t row = lane_off + (uint32_t)t * (2 * W);
-			pk16 tb[P];
-			lane16_step<P, TRACE, 0>(st, S0, shr1_z(st.F[2 * P - 1]), go, ge, revt, tb);
-			if (TRACE && SA) store_trace<P, false>(baseA + row, tb);
-			if (TRACE && SB) store_trace<P, true>(baseB + row, tb);
-			lane16_step<P, TRACE, 1>(st, S1, shl1_z(st.E[0]), go, ge, revt, tb);
-			if (TRACE && SA) store_trace<P, false>(baseA + row + W, tb);
-			if (TRACE && SB) store_trace<P, true>(baseB + row + W, tb);
+	// One pair-step; R = its position inside the group of G (compile time: the trace bytes go to fixed places of the record)
+	auto pair_step = [&](auto r, int t, int tc) {
+		constexpr int R = decltype(r)::value;
+		// edge record of the NEXT pair-step (LDS broadcast read, in flight during this one)
+		const uint4 nx = my_edges[t - tc];
+		// windows of pair-step t + 1 and its scores: the LDS reads are in flight while the cells of pair-step t are computed
+		lane16_advance(st, shl1_in(e.qq, st.QQ[1]), shl1_in(e.cc, st.CC[1]), shr1_in(e.tt, st.TT[P - 1]));
+		pk16 N0[P], N1[P];
+		lane16_scores(st, table, N0, N1);
+		const uint32_t revt = 0xffffu - (uint32_t)t;
+		pk16 tb0[P], tb1[P];
+		lane16_step<P, TRACE, 0>(st, S0, shr1_z(st.F[2 * P - 1]), go, ge, revt, tb0);
+		lane16_step<P, TRACE, 1>(st, S1, shl1_z(st.E[0]), go, ge, revt, tb1);
+		if (TRACE) acc.template put<R>(tb0, tb1);
 #pragma unroll
-			for (int p = 0; p < P; ++p) { S0[p] = N0[p]; S1[p] = N1[p]; }
-			e.qq = nx.x; e.tt = nx.y; e.cc = nx.z;
-		};
-		for (int tc = t0; tc < t1; tc += EDGE_CHUNK) {
-			// records of pair-steps tc + 1 .. tc + EDGE_CHUNK (slot r holds pair-step tc + 1 + r), built by the lanes in parallel
-			// (adjacent lanes read adjacent letters); only this wavefront reads them back, so a wave-level barrier orders the
-			// writes before the reads
-			__builtin_amdgcn_wave_barrier();
-#pragma unroll
-			for (int r = lane; r < EDGE_CHUNK; r += 64) {
-				const Edge16 x = sw16_edge(A.g, A.v, B.g, B.v, P, tc + 1 + r);
-				my_edges[r] = make_uint4(x.qq, x.tt, x.cc, 0u);
-			}
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-			__builtin_amdgcn_wave_barrier();
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-			const int te = tc + EDGE_CHUNK < t1 ? tc + EDGE_CHUNK : t1;
-			// two pair-steps per trip: the window registers rotate with period P + 1 (2 at P = 1) and the score registers with
-			// period 2, so the copies at the end of a pair-step become renames (the DPP moves are convergent operations, which
-			// keeps the compiler from unrolling a loop with a run-time trip count by itself)
-			int t = tc;
-			for (; t + 1 < te; t += 2) { pair_step(t, tc); pair_step(t + 1, tc); }
-			if (t < te) pair_step(t, tc);
-		}
+		for (int p = 0; p < P; ++p) { S0[p] = N0[p]; S1[p] = N1[p]; }
+		e.qq = nx.x; e.tt = nx.y; e.cc = nx.z;
+		// the group is unrolled: without a fence the scheduler hoists the LDS reads of all its pair-steps to the top (16 edge
+		// records = 64 registers at P = 1) and halves the occupancy
+		if (R % 2 == 1) __builtin_amdgcn_sched_barrier(0);
 	};
-	const int n_both = nA < nB ? nA : nB;
-	sweep(std::true_type(), std::true_type(), 0, n_both);
-	if (nA > n_both) sweep(std::true_type(), std::false_type(), n_both, nA);
-	if (nB > n_both) sweep(std::false_type(), std::true_type(), n_both, nB);
+	// The sweep runs in whole groups of G pair-steps, fully unrolled (the window registers rotate with period P + 1 and the
+	// score registers with period 2, so the copies at the end of a pair-step become renames; the DPP moves are convergent
+	// operations, which keeps the compiler from unrolling a loop with a run-time trip count by itself). The last group of an
+	// item may run past its last pair-step: those cells lie behind the matrix, where nothing can reach the best-score record
+	// (swipe16_core.h), and their trace bytes land in the padding of the item's last record.
+	const int nMax = nA > nB ? nA : nB, T = (nMax + G - 1) / G * G;
+	for (int tc = 0; tc < T; tc += EDGE_CHUNK) {
+		// records of pair-steps tc + 1 .. tc + EDGE_CHUNK (slot r holds pair-step tc + 1 + r), built by the lanes in parallel
+		// (adjacent lanes read adjacent letters); only this wavefront reads them back, so a wave-level barrier orders the
+		// writes before the reads
+		__builtin_amdgcn_wave_barrier();
+#pragma unroll
+		for (int r = lane; r < EDGE_CHUNK; r += 64) {
+			const Edge16 x = sw16_edge(A.g, A.v, B.g, B.v, P, tc + 1 + r);
+			my_edges[r] = make_uint4(x.qq, x.tt, x.cc, 0u);
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		const int te = tc + EDGE_CHUNK < T ? tc + EDGE_CHUNK : T;      // EDGE_CHUNK is a multiple of every G
+		for (int t = tc; t < te; t += G) {
+			unrolled(std::make_integer_sequence<int, G>(), [&](auto r) { pair_step(r, t + decltype(r)::value, tc); });
+			if (TRACE) {
+				// one 16-byte store per lane and item: the 64 lanes write 1 KiB of consecutive bytes
+				if (t < nA) *reinterpret_cast<uint4*>(recA) = make_uint4(acc.a[0], acc.a[1], acc.a[2], acc.a[3]);
+				if (t < nB) *reinterpret_cast<uint4*>(recB) = make_uint4(acc.b[0], acc.b[1], acc.b[2], acc.b[3]);
+				recA += 1024; recB += 1024;
+			}
+		}
+	}
 
 	// end cells of both items: per lane from its diagonal keys, then a wave reduction
 #pragma unroll

@@ -70,6 +70,28 @@ DMND_HD int64_t trace_rows(const Geom& g) { return (n_steps(g) + 1) / 2 * 2; }
 // lanes own 2*P diagonals each: smallest power of two with 128*P >= band
 DMND_HD int band_class(int band) { int P = 1; while (128 * P < band) P *= 2; return P; }
 
+// ---- trace layout (traceback-mode sweeps -> traceback walk) --------------------------------------------------------------
+// A PAIR-STEP t is the two anti-diagonal steps a_first + 2t (even: the cells of the even band diagonals) and a_first + 2t + 1
+// (odd diagonals). One trace BYTE holds the two cells of band diagonals 2x and 2x + 1 of one pair-step: low nibble = the even
+// diagonal's cell, high nibble = the odd one's (4 trace bits each, TB_*). x = 0 .. 64 P - 1 for an item of band class P (the
+// lane-local pair p of lane l is x = l P + p). The bytes of one lane over G = trace_group(P) consecutive pair-steps are
+// contiguous -- a 16-byte record for P <= 16 -- and the 64 P / P records of a group follow each other lane by lane:
+//     index(t, x) = (t / G) * (64 P G) + (x / P) * (G P) + (t % G) * P + x % P          (P >= 16: G = 1, index = t * 64 P + x)
+// Why: the walk follows an alignment along a diagonal, i.e. through the SAME x over consecutive pair-steps. With one row per
+// anti-diagonal step (the first layout: 64 P bytes per step, 4 bits used per byte) every column of the alignment was a
+// different 128-byte line; here 16 / P consecutive columns of a diagonal are one record and a gap's neighbour diagonal is the
+// neighbouring record or the same one. The sweep writes a record with ONE 16-byte store per lane and group (64 lanes = 1 KiB
+// contiguous), half the bytes of before.
+DMND_HD int trace_group(int P) { return P >= 16 ? 1 : 16 / P; }
+DMND_HD int64_t trace_pairs(const Geom& g) { return (n_steps(g) + 1) / 2; }
+DMND_HD int64_t trace_bytes(const Geom& g, int P) { const int G = trace_group(P); return (trace_pairs(g) + G - 1) / G * G * 64 * P; }
+DMND_HD int64_t trace_byte_index(int P, int t, int x)
+{
+	if (P >= 16) return (int64_t)t * (64 * P) + x;
+	const int G = 16 / P, lane = x / P;
+	return (int64_t)(t / G) * 1024 + lane * 16 + (t % G) * P + (x - lane * P);
+}
+
 // validity window of diagonal k (global index) on anti-diagonal a:  a_lo <= a <= a_hi
 //   i >= 0 <=> a >= -d ; j >= 0 <=> a >= d ; i < qlen <=> a <= 2*qlen-2-d ; j < tlen <=> a <= 2*tlen-2+d
 DMND_HD void diag_window(const Geom& g, int k, int& a_lo, int& a_span)
@@ -322,9 +344,9 @@ DMND_HD void win_finish(WinLane<P, COORDS>& st, int d0)
 }
 
 // One anti-diagonal step (PAR as in lane_step; `a` = its anti-diagonal, d0 = the lane's first diagonal: only read when a new
-// end cell is recorded). trace: this lane's P bytes of the step's trace row (aligned to min(P, 4): written as one 1-, 2- or 4-byte store per up to 4 cells).
+// end cell is recorded). tb4 (TRACE): receives the step's P trace bytes (one cell each, 4 bits used), four to a dword.
 template<int P, bool COORDS, bool TRACE, int PAR>
-DMND_HD void win_step(WinLane<P, COORDS>& st, const int8_t* M, int nb, int go, int ge, int a, int d0, uint8_t* trace)
+DMND_HD void win_step(WinLane<P, COORDS>& st, const int8_t* M, int nb, int go, int ge, int a, int d0, uint32_t* tb4)
 {
 	uint32_t packed = 0;
 #pragma unroll
@@ -342,7 +364,7 @@ DMND_HD void win_step(WinLane<P, COORDS>& st, const int8_t* M, int nb, int go, i
 		if (TRACE) {
 			const uint32_t tb = (c == F_in ? TB_GAP_V : 0) | (c == E_in ? TB_GAP_H : 0) | (f == open ? TB_OPEN_V : 0) | (e == open ? TB_OPEN_H : 0);
 			packed |= tb << (8 * (p & 3));
-			if (P >= 4 && (p & 3) == 3) { *reinterpret_cast<uint32_t*>(trace + p - 3) = packed; packed = 0; }
+			if (P >= 4 && (p & 3) == 3) { tb4[p >> 2] = packed; packed = 0; }
 		}
 		c = valid ? c : 0;
 		st.H[k] = c; st.E[k] = valid ? e : 0; st.F[k] = valid ? f : 0;
@@ -360,8 +382,20 @@ DMND_HD void win_step(WinLane<P, COORDS>& st, const int8_t* M, int nb, int go, i
 		else
 			st.best = imax(st.best, c);
 	}
-	if (TRACE && P == 1) trace[0] = (uint8_t)packed;
-	if (TRACE && P == 2) *reinterpret_cast<uint16_t*>(trace) = (uint16_t)packed;
+	if (TRACE && P < 4) tb4[0] = packed;
+}
+
+// The lane's P bytes of one pair-step from the two steps' cells (tb_even / tb_odd as win_step returns them), stored at `rec` =
+// the lane's record position of that pair-step: trace + trace_byte_index(P_class, t, lane * P)
+template<int P>
+DMND_HD void win_store_trace(uint8_t* rec, const uint32_t* tb_even, const uint32_t* tb_odd)
+{
+	if (P == 1) rec[0] = (uint8_t)(tb_even[0] | (tb_odd[0] << 4));
+	else if (P == 2) *reinterpret_cast<uint16_t*>(rec) = (uint16_t)(tb_even[0] | (tb_odd[0] << 4));
+	else {
+#pragma unroll
+		for (int x = 0; x < P / 4; ++x) reinterpret_cast<uint32_t*>(rec)[x] = tb_even[x] | (tb_odd[x] << 4);
+	}
 }
 
 // end of a step pair: the window moves one row down and one column right; nq / nc / nt are the letters of row st.iq and
@@ -391,22 +425,24 @@ DMND_HD void reversed_band(int qlen, int s_end, int d_begin, int d_end, int& r_t
 // ---- traceback walk over the anti-diagonal trace (one thread per item) -------------------------
 // Follows banded_swipe.h:128-183 + TracebackVectorMatrix::TracebackIterator (banded_matrix.h:359-408)
 // and the accounting of Hsp::push_match / push_gap (basic/hssp.cpp:260-290).
-// trace layout: byte [(a - a_first) * W + (k >> 1)], W = 64*P (row stride), k = i - j - d_begin.
+// trace layout: trace_byte_index above; P = the item's band class (for an item swept by several wavefronts: P per lane x wavefronts).
 struct WalkResult {
 	int q_begin, s_begin, length, identities, mismatches, positives, gap_openings, gaps, transcript_len, status;
 };
 
-DMND_HD uint8_t trace_at(const uint8_t* trace, const Geom& g, int W, int i, int j)
+DMND_HD uint8_t trace_at(const uint8_t* trace, const Geom& g, int P, int i, int j)
 {
 	const int a = i + j, k = i - j - g.d_begin;
 	if (k < 0 || k >= g.band || a < g.a_first)       // cannot happen on a valid path; keeps the walk memory-safe
 		return TB_OPEN_V | TB_OPEN_H;
-	return trace[(int64_t)(a - g.a_first) * W + (k >> 1)];
+	// a_first + d_begin is even (make_geom), so the parity of the step inside its pair is the parity of the diagonal
+	const uint8_t b = trace[trace_byte_index(P, (a - g.a_first) >> 1, k >> 1)];
+	return (k & 1) ? (uint8_t)(b >> 4) : (uint8_t)(b & 15);
 }
 
 // transcript receives the packed operations in forward order followed by a 0 terminator;
 // cap is the number of bytes available (including the terminator).
-DMND_HD WalkResult traceback_walk(const uint8_t* trace, const Geom& g, int W, const SeqView& v, int gap_open, int gap_extend,
+DMND_HD WalkResult traceback_walk(const uint8_t* trace, const Geom& g, int P, const SeqView& v, int gap_open, int gap_extend,
 	int best, int end_i, int end_j, uint8_t* transcript, int cap)
 {
 	WalkResult r;
@@ -415,7 +451,7 @@ DMND_HD WalkResult traceback_walk(const uint8_t* trace, const Geom& g, int W, co
 	int i = end_i, j = end_j, sc = 0, n = 0;
 	// written backwards from the end of the slot, then moved to the front
 	while (i >= 0 && j >= 0 && sc < best) {
-		const uint8_t m = trace_at(trace, g, W, i, j);
+		const uint8_t m = trace_at(trace, g, P, i, j);
 		if ((m & (TB_GAP_V | TB_GAP_H)) == 0) {
 			const int ql = v.q[i] & LETTER_MASK, tl = v.t[j] & LETTER_MASK;
 			int s = v.M[tl * 32 + ql];
@@ -432,7 +468,7 @@ DMND_HD WalkResult traceback_walk(const uint8_t* trace, const Geom& g, int W, co
 		else {
 			int l = 0;
 			if (m & TB_GAP_V) {
-				do { ++l; --i; } while (i > 0 && (trace_at(trace, g, W, i, j) & TB_OPEN_V) == 0);
+				do { ++l; --i; } while (i > 0 && (trace_at(trace, g, P, i, j) & TB_OPEN_V) == 0);
 				// reference loop: do { ++l; --i; --mask; } while (!(mask->open & v) && i > 0)
 				int c = l;
 				while (c > 0) {
@@ -443,7 +479,7 @@ DMND_HD WalkResult traceback_walk(const uint8_t* trace, const Geom& g, int W, co
 			}
 			else {
 				const int j_before = j;
-				do { ++l; --j; } while (j > 0 && (trace_at(trace, g, W, i, j) & TB_OPEN_H) == 0);
+				do { ++l; --j; } while (j > 0 && (trace_at(trace, g, P, i, j) & TB_OPEN_H) == 0);
 				for (int x = 0; x < l; ++x) {
 					if (n < cap - 1) transcript[cap - 2 - n] = (uint8_t)((OP_DELETION << OP_COUNT_BITS) | (v.t[j_before - x] & LETTER_MASK));
 					++n;

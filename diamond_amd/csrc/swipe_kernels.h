@@ -37,7 +37,7 @@ struct TracebackArgs {
 	const int8_t* matrix;
 	const dmnd_dp_target* items;
 	const int32_t* order;        // slot -> item index (all TRACEBACK slots of the chunk)
-	const int32_t* p_of_slot;    // slot -> P (trace row stride = 64*P)
+	const int32_t* p_of_slot;    // slot -> band class P of the item (its trace layout, swipe_core.h trace_byte_index)
 	const int64_t* trace_off;    // slot -> trace byte offset
 	const int64_t* transcript_off; // slot -> transcript byte offset, n+1 entries
 	const uint8_t* trace;

@@ -13,8 +13,9 @@
 //     query letter, ONE bias byte and ONE target letter per lane (scalar base + lane offset, adjacent lanes adjacent bytes),
 //     issued a whole pair before their first use; cells are branch-free (invalid cells are zeroed by v_cndmask), the end
 //     cell is kept as one (best score, first anti-diagonal) record per diagonal and turned into coordinates after the sweep;
-//   * TRACEBACK mode streams one trace byte per cell, one coalesced 64*P-byte row per step, to an
-//     HBM arena; a second kernel walks it with one wavefront per item (64 columns per round trip).
+//   * TRACEBACK mode streams one trace nibble per cell to an HBM arena in the layout of swipe_core.h (trace_byte_index:
+//     a lane's bytes of 16 / P consecutive pair-steps are one 16-byte record); a second kernel walks it with one wavefront
+//     per item (64 columns per round trip).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <cstdio>
@@ -38,8 +39,8 @@ __device__ __forceinline__ int64_t uniform64(int64_t x)
 // workgroup, wavefront w owning the diagonals of the virtual lanes 64 w .. 64 w + 63. The cross-lane shifts continue over the
 // wavefront boundaries through LDS with one workgroup barrier per anti-diagonal step -- slow next to the single-wavefront sweep,
 // and meant for the rare long repeat proteins whose merged band exceeds 4096 (2048 with statistics) diagonals; the reference
-// escalates its row counters the same way (RowCounter, banded_swipe.h:204). The trace row stride is 64 * P * wavefronts, i.e.
-// the item looks like one of band class P * wavefronts to the traceback kernel.
+// escalates its row counters the same way (RowCounter, banded_swipe.h:204). The trace is that of an item of band class
+// P * wavefronts (one row of 64 * P * wavefronts bytes per pair-step).
 constexpr int MULTI_MAX_WAVES = 16;
 
 // MAXW: the largest workgroup the instantiation is launched with, in wavefronts. The register budget of a lane halves with every
@@ -76,12 +77,14 @@ void banded_swipe_kernel(SwipeArgs args)
 		WinLane<P, COORDS> st;
 		win_init(st, g, v, lane);
 		const int d0 = g.d_begin + 2 * P * lane;
-		uint8_t* row = nullptr;
+		uint8_t* tbase = nullptr;
 		if (TRACE)
-			row = args.trace + args.trace_off[slot] + lane * P;
-		const int W = 64 * P * n_waves;
+			tbase = args.trace + args.trace_off[slot];
+		const int PC = P * n_waves;                           // the item's band class: its trace layout (trace_byte_index)
 		const bool has_cbs = v.cbs != nullptr;
-		for (int a = g.a_first; a <= g.a_last; a += 2) {
+		uint32_t tb_even[(P + 3) / 4], tb_odd[(P + 3) / 4];
+		int t = 0;
+		for (int a = g.a_first; a <= g.a_last; a += 2, ++t) {
 			const uint32_t xi = (uint32_t)clampi(st.iq, g.qlen - 1), xj = (uint32_t)clampi(st.jt, g.tlen - 1);
 			const int nq = v.q[xi], nt = v.t[xj], nc = has_cbs ? v.cbs[xi] : 0;      // consumed by win_advance at the end of the pair
 			int nb = wave_shr1(st.F[2 * P - 1]);
@@ -90,8 +93,7 @@ void banded_swipe_kernel(SwipeArgs args)
 				__syncthreads();
 				if ((threadIdx.x & 63) == 0 && wave > 0) nb = edge[0][0][wave - 1];
 			}
-			win_step<P, COORDS, TRACE, 0>(st, matrix, nb, go, ge, a, d0, row);
-			if (TRACE) row += W;
+			win_step<P, COORDS, TRACE, 0>(st, matrix, nb, go, ge, a, d0, tb_even);
 			// the odd step may lie past a_last: all its cells are then invalid, and its trace row is allocated
 			nb = wave_shl1(st.E[0]);
 			if (MULTI) {
@@ -99,8 +101,8 @@ void banded_swipe_kernel(SwipeArgs args)
 				__syncthreads();
 				if ((threadIdx.x & 63) == 63 && wave + 1 < n_waves) nb = edge[1][0][wave + 1];
 			}
-			win_step<P, COORDS, TRACE, 1>(st, matrix, nb, go, ge, a + 1, d0, row);
-			if (TRACE) row += W;
+			win_step<P, COORDS, TRACE, 1>(st, matrix, nb, go, ge, a + 1, d0, tb_odd);
+			if (TRACE) win_store_trace<P>(tbase + trace_byte_index(PC, t, lane * P), tb_even, tb_odd);
 			win_advance(st, nq, nc, nt);
 		}
 		win_finish(st, d0);
@@ -171,7 +173,7 @@ __device__ __forceinline__ int wave_prefix_sum(int x, int lane)
 
 __device__ __forceinline__ int popc64(unsigned long long x) { return __popcll(x); }
 
-__device__ WalkResult traceback_walk_wave(const uint8_t* trace, const Geom& g, int W, const SeqView& v, int gap_open, int gap_extend,
+__device__ WalkResult traceback_walk_wave(const uint8_t* trace, const Geom& g, int P, const SeqView& v, int gap_open, int gap_extend,
 	int best, int end_i, int end_j, uint8_t* transcript, int cap, int lane)
 {
 	WalkResult r;
@@ -181,7 +183,7 @@ __device__ WalkResult traceback_walk_wave(const uint8_t* trace, const Geom& g, i
 	while (i >= 0 && j >= 0 && sc < best) {
 		const int ii = i - lane, jj = j - lane;
 		const bool valid = ii >= 0 && jj >= 0;
-		const uint8_t m = valid ? trace_at(trace, g, W, ii, jj) : (uint8_t)TB_GAP_V;
+		const uint8_t m = valid ? trace_at(trace, g, P, ii, jj) : (uint8_t)TB_GAP_V;
 		const bool is_match = valid && (m & (TB_GAP_V | TB_GAP_H)) == 0;
 		int s = 0, ql = 0, tl = 1;
 		bool positive = false;
@@ -212,7 +214,7 @@ __device__ WalkResult traceback_walk_wave(const uint8_t* trace, const Geom& g, i
 		const uint8_t m0 = (uint8_t)__shfl((int)m, 0);
 		int l = 0;
 		if (m0 & TB_GAP_V) {
-			do { ++l; --i; } while (i > 0 && (trace_at(trace, g, W, i, j) & TB_OPEN_V) == 0);
+			do { ++l; --i; } while (i > 0 && (trace_at(trace, g, P, i, j) & TB_OPEN_V) == 0);
 			int c = l;
 			while (c > 0) {
 				const int kk = imin(c, (int)OP_MAX_COUNT);
@@ -222,7 +224,7 @@ __device__ WalkResult traceback_walk_wave(const uint8_t* trace, const Geom& g, i
 		}
 		else {
 			const int j_before = j;
-			do { ++l; --j; } while (j > 0 && (trace_at(trace, g, W, i, j) & TB_OPEN_H) == 0);
+			do { ++l; --j; } while (j > 0 && (trace_at(trace, g, P, i, j) & TB_OPEN_H) == 0);
 			for (int x = lane; transcript && x < l; x += 64)
 				if (n + x < cap - 1) transcript[cap - 2 - (n + x)] = (uint8_t)((OP_DELETION << OP_COUNT_BITS) | (v.t[j_before - x] & LETTER_MASK));
 			n += l;
@@ -273,9 +275,9 @@ __global__ __launch_bounds__(256) void traceback_kernel(TracebackArgs args)
 		const Geom g = make_geom(it.query_len, it.target_len, it.d_begin, it.d_end);
 		const SeqView v{ args.qblock + it.query_off, args.tblock + it.target_off,
 			it.cbs_off >= 0 ? args.cbs + it.cbs_off : nullptr, matrix };
-		const int W = 64 * args.p_of_slot[slot];
+		const int PC = args.p_of_slot[slot];
 		const int cap = (int)(args.transcript_off[slot + 1] - args.transcript_off[slot]);
-		const WalkResult r = traceback_walk_wave(args.trace + args.trace_off[slot], g, W, v, args.gap_open, args.gap_extend,
+		const WalkResult r = traceback_walk_wave(args.trace + args.trace_off[slot], g, PC, v, args.gap_open, args.gap_extend,
 			e.score, e.end_i, e.end_j, args.transcript ? args.transcript + args.transcript_off[slot] : nullptr, cap, lane);
 		h.q_begin = r.q_begin; h.s_begin = r.s_begin; h.q_end = e.end_i + 1; h.s_end = e.end_j + 1;
 		h.length = r.length; h.identities = r.identities; h.mismatches = r.mismatches; h.positives = r.positives;

@@ -21,7 +21,7 @@ int run_one(const int8_t* q, int qlen, const int8_t* cbs, const int8_t* t, int t
 	// ungapped_stage: hits sorted by (diagonal, j); a hit inside the previous segment of its diagonal is skipped
 	for (int x = 0; x < n_hits; ++x) {
 		if (!segs.empty() && segs.back().diag() == hi[x] - hj[x] && segs.back().j_end() >= hj[x]) continue;
-		const SegT d = xdrop(S, qs, cbs, ts, hi[x], hj[x], ws.cfg.xdrop);
+		const SegT d = xdrop(S, qs, cbs, ts, hi[x], hj[x], 20);      // config.raw_ungapped_xdrop = rawscore(12.3 bits) for BLOSUM62 11/1, config.cpp:428,853
 		if (d.score > 0) segs.push_back(d);
 	}
 	*n_segs = (int)segs.size();

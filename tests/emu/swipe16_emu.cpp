@@ -2,7 +2,8 @@
 // CPU lane-emulator of the packed-int16 two-items-per-wavefront sweep (diamond_amd/csrc/swipe16_kernels.hip): runs the SAME
 // per-lane code (diamond_amd/csrc/swipe16_core.h) for 64 emulated lanes in lock-step, DPP shifts replaced by array indexing,
 // including the systolic letter flow (rows come down from lane l+1, columns from lane l-1, edge lanes read memory). The trace
-// it writes has the layout of the 32-bit kernel, so the reference walk (traceback_walk, swipe_core.h) decodes it.
+// is collected and stored as the kernel does it (Trace16Group, one 16-byte record per lane, item and group of pair-steps) in
+// the layout of swipe_core.h, so the reference walk (traceback_walk) decodes it.
 #include <vector>
 #include <cstring>
 #include "../../diamond_amd/csrc/swipe16_core.h"
@@ -17,6 +18,16 @@ struct Emu16Item {
 	const int8_t* q; int32_t qlen; const int8_t* cbs; const int8_t* t; int32_t tlen; int32_t d_begin, d_end;
 };
 
+// Trace16Group::put<R> with a run-time R (the kernel unrolls the group and knows R at compile time)
+template<int P, int R = 0>
+static void put_r(Trace16Group<P>& acc, int r, const pk16* tb0, const pk16* tb1)
+{
+	if constexpr (R < Sw16Group<P>::G) {
+		if (r == R) acc.template put<R>(tb0, tb1);
+		else put_r<P, R + 1>(acc, r, tb0, tb1);
+	}
+}
+
 template<int P, bool TRACE>
 static void run16(const Emu16Item& A, const Emu16Item& B, const int8_t* M, int gap_open, int gap_extend, Emu16Out* outA, Emu16Out* outB,
 	uint8_t* trA, uint8_t* trB, int cap)
@@ -25,13 +36,15 @@ static void run16(const Emu16Item& A, const Emu16Item& B, const int8_t* M, int g
 	for (int x = 0; x < 1024; ++x) table[x] = sw16_table_entry(M, x);
 	const Geom gA = make_geom(A.qlen, A.tlen, A.d_begin, A.d_end), gB = make_geom(B.qlen, B.tlen, B.d_begin, B.d_end);
 	const SeqView vA{ A.q, A.t, A.cbs, M }, vB{ B.q, B.t, B.cbs, M };
-	const int nA = sw16_pairs(gA), nB = sw16_pairs(gB), T = nA > nB ? nA : nB, W = 64 * P;
+	constexpr int G = Sw16Group<P>::G;
+	const int nA = sw16_pairs(gA), nB = sw16_pairs(gB), T = ((nA > nB ? nA : nB) + G - 1) / G * G;      // whole groups, as the kernel
 	const pk16 go = pk_both(gap_open + gap_extend), ge = pk_both(gap_extend);
 	std::vector<Lane16<P>> st(64);
 	for (int l = 0; l < 64; ++l) lane16_init(st[l], gA, vA, gB, vB, l);
 	std::vector<uint8_t> traceA, traceB;
-	if (TRACE) { traceA.assign((size_t)2 * nA * W + 8, 0xee); traceB.assign((size_t)2 * nB * W + 8, 0xee); }
-	pk16 S0[64][P], S1[64][P], tb[64][P], nb[64];
+	if (TRACE) { traceA.assign((size_t)trace_bytes(gA, P) + 8, 0xee); traceB.assign((size_t)trace_bytes(gB, P) + 8, 0xee); }
+	pk16 S0[64][P], S1[64][P], tb[64][P], tbe[64][P], nb[64];
+	std::vector<Trace16Group<P>> acc(64);
 	for (int t = 0; t < T; ++t) {
 		const uint32_t revt = 0xffffu - (uint32_t)t;
 		for (int l = 0; l < 64; ++l) lane16_scores(st[l], table, S0[l], S1[l]);
@@ -42,12 +55,19 @@ static void run16(const Emu16Item& A, const Emu16Item& B, const int8_t* M, int g
 				if (par == 0) lane16_step<P, TRACE, 0>(st[l], S0[l], nb[l], go, ge, revt, tb[l]);
 				else lane16_step<P, TRACE, 1>(st[l], S1[l], nb[l], go, ge, revt, tb[l]);
 			}
-			if (TRACE)
-				for (int l = 0; l < 64; ++l)
-					for (int p = 0; p < P; ++p) {
-						if (t < nA) traceA[(size_t)(2 * t + par) * W + l * P + p] = (uint8_t)(tb[l][p] & 0xff);
-						if (t < nB) traceB[(size_t)(2 * t + par) * W + l * P + p] = (uint8_t)((tb[l][p] >> 16) & 0xff);
-					}
+			if (TRACE && par == 0)
+				for (int l = 0; l < 64; ++l) for (int p = 0; p < P; ++p) tbe[l][p] = tb[l][p];
+		}
+		if (TRACE) {
+			// the kernel's register accumulation (Trace16Group::put<R>, R = position inside the group) and its one store per group
+			for (int l = 0; l < 64; ++l) put_r<P>(acc[l], t % G, tbe[l], tb[l]);
+			if (t % G == G - 1) {
+				const int g0 = t - (G - 1);
+				for (int l = 0; l < 64; ++l) {
+					if (g0 < nA) memcpy(traceA.data() + trace_byte_index(P, g0, l * P), acc[l].a, 16);
+					if (g0 < nB) memcpy(traceB.data() + trace_byte_index(P, g0, l * P), acc[l].b, 16);
+				}
+			}
 		}
 		// systolic letter flow
 		const Edge16 e = sw16_edge(gA, vA, gB, vB, P, t);
@@ -73,7 +93,7 @@ static void run16(const Emu16Item& A, const Emu16Item& B, const int8_t* M, int g
 		out->score = bs;
 		if (bs > 0) { out->q_end = bi + 1; out->s_end = bj + 1; }
 		if (TRACE && bs > 0 && bs < SW16_MAX_SCORE) {
-			const WalkResult r = traceback_walk((item ? traceB : traceA).data(), g, W, v, gap_open, gap_extend, bs, bi, bj, item ? trB : trA, cap);
+			const WalkResult r = traceback_walk((item ? traceB : traceA).data(), g, P, v, gap_open, gap_extend, bs, bi, bj, item ? trB : trA, cap);
 			out->q_begin = r.q_begin; out->s_begin = r.s_begin; out->length = r.length; out->identities = r.identities;
 			out->mismatches = r.mismatches; out->positives = r.positives; out->gap_openings = r.gap_openings; out->gaps = r.gaps;
 			out->transcript_len = r.transcript_len; out->status = r.status;

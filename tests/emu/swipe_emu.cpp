@@ -18,25 +18,27 @@ template<int P, bool COORDS, bool TRACE>
 static void run(const SeqView& v, int qlen, int tlen, int d_begin, int d_end, int gap_open, int gap_extend, EmuOut* out, uint8_t* transcript, int cap)
 {
 	const Geom g = make_geom(qlen, tlen, d_begin, d_end);
-	const int go = gap_open + gap_extend, ge = gap_extend, W = 64 * P;
+	const int go = gap_open + gap_extend, ge = gap_extend;
 	// the register-window lanes of the score / coordinates / traceback kernels (WinLane, swipe_core.h), driven exactly as
 	// banded_swipe_kernel drives them: fetch the pair's new letters, even step, odd step, advance the windows
 	std::vector<WinLane<P, COORDS>> st(64);
 	for (int l = 0; l < 64; ++l) win_init(st[l], g, v, l);
 	std::vector<uint8_t> trace;
-	if (TRACE) trace.assign((size_t)trace_rows(g) * W + 8, 0xee);
+	if (TRACE) trace.assign((size_t)trace_bytes(g, P) + 8, 0xee);
 	int nb[64], nq[64], nc[64], nt[64];
-	for (int a = g.a_first; a <= g.a_last; a += 2) {
+	std::vector<uint32_t> tbe(64 * ((P + 3) / 4)), tbo(64 * ((P + 3) / 4));
+	constexpr int D = (P + 3) / 4;
+	int t = 0;
+	for (int a = g.a_first; a <= g.a_last; a += 2, ++t) {
 		for (int l = 0; l < 64; ++l) {
 			const int xi = clampi(st[l].iq, g.qlen - 1), xj = clampi(st[l].jt, g.tlen - 1);
 			nq[l] = v.q[xi]; nt[l] = v.t[xj]; nc[l] = v.cbs ? v.cbs[xi] : 0;
 		}
-		uint8_t* row = TRACE ? trace.data() + (size_t)(a - g.a_first) * W : nullptr;
 		for (int l = 0; l < 64; ++l) nb[l] = l == 0 ? 0 : st[l - 1].F[2 * P - 1];       // wave_shr:1, lane 0 reads 0
-		for (int l = 0; l < 64; ++l) win_step<P, COORDS, TRACE, 0>(st[l], v.M, nb[l], go, ge, a, g.d_begin + 2 * P * l, row ? row + l * P : nullptr);
-		row = TRACE ? trace.data() + (size_t)(a + 1 - g.a_first) * W : nullptr;
+		for (int l = 0; l < 64; ++l) win_step<P, COORDS, TRACE, 0>(st[l], v.M, nb[l], go, ge, a, g.d_begin + 2 * P * l, &tbe[l * D]);
 		for (int l = 0; l < 64; ++l) nb[l] = l == 63 ? 0 : st[l + 1].E[0];               // wave_shl:1, lane 63 reads 0
-		for (int l = 0; l < 64; ++l) win_step<P, COORDS, TRACE, 1>(st[l], v.M, nb[l], go, ge, a + 1, g.d_begin + 2 * P * l, row ? row + l * P : nullptr);
+		for (int l = 0; l < 64; ++l) win_step<P, COORDS, TRACE, 1>(st[l], v.M, nb[l], go, ge, a + 1, g.d_begin + 2 * P * l, &tbo[l * D]);
+		if (TRACE) for (int l = 0; l < 64; ++l) win_store_trace<P>(trace.data() + trace_byte_index(P, t, l * P), &tbe[l * D], &tbo[l * D]);
 		for (int l = 0; l < 64; ++l) win_advance(st[l], nq[l], nc[l], nt[l]);
 	}
 	for (int l = 0; l < 64; ++l) win_finish(st[l], g.d_begin + 2 * P * l);
@@ -50,7 +52,7 @@ static void run(const SeqView& v, int qlen, int tlen, int d_begin, int d_end, in
 	out->score = bs;
 	if (COORDS && bs > 0) { out->q_end = bi + 1; out->s_end = bj + 1; }
 	if (TRACE && bs > 0) {
-		const WalkResult r = traceback_walk(trace.data(), g, W, v, gap_open, gap_extend, bs, bi, bj, transcript, cap);
+		const WalkResult r = traceback_walk(trace.data(), g, P, v, gap_open, gap_extend, bs, bi, bj, transcript, cap);
 		out->q_begin = r.q_begin; out->s_begin = r.s_begin; out->length = r.length; out->identities = r.identities;
 		out->mismatches = r.mismatches; out->positives = r.positives; out->gap_openings = r.gap_openings; out->gaps = r.gaps;
 		out->transcript_len = r.transcript_len; out->status = r.status;
