@@ -149,6 +149,22 @@ extern "C" int dmnd_device_count(void)
 	return usable;
 }
 
+namespace { __global__ void init_marker_kernel(int* p) { if (p) *p = 1; } }
+
+extern "C" int dmnd_init(int device)
+{
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return fail(DMND_E_DEVICE, "dmnd_init: no HIP device visible (this library has no CPU fallback)");
+	if (device < 0) device = 0;
+	if (device >= count) return fail(DMND_E_ARG, "dmnd_init: device index out of range");
+	HIP_TRY(hipSetDevice(device));
+	// the first launch of any kernel of this library loads its code object onto the device
+	hipLaunchKernelGGL(init_marker_kernel, dim3(1), dim3(1), 0, nullptr, (int*)nullptr);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipDeviceSynchronize());
+	return DMND_OK;
+}
+
 extern "C" dmnd_ctx* dmnd_create(int device, const dmnd_params* params)
 {
 	if (!params) { fail(DMND_E_ARG, "dmnd_create: params is NULL"); return nullptr; }
@@ -211,7 +227,7 @@ extern "C" void dmnd_destroy(dmnd_ctx* c)
 	for (DevBuf* b : { &c->block[0], &c->block[1], &c->cbs, &c->matrix, &c->bias_ids, &c->items, &c->order, &c->p_of_slot, &c->trace_off,
 		&c->transcript_off, &c->ends, &c->hsps, &c->trace, &c->transcript, &c->status, &c->pairs, &c->trace_off_item, &c->host_q, &c->host_t, &c->host_cbs,
 		&c->d_limits[0], &c->d_limits[1], &c->qid_of, &c->mask_time, &c->seed_keys, &c->seed_next, &c->seed_qlist, &c->seed_qkeys, &c->seed_slot2, &c->seed_loc2, &c->seed_survivors, &c->seed_scored, &c->seed_need, &c->seed_qfold,
-		&c->matched_slot, &c->matched_loc, &c->counters, &c->seed_hits, &c->seed_bitmap, &c->seed_deferred, &c->seed_eslot, &c->seed_eloc, &c->seed_hits_sorted, &c->sort_keys[0], &c->sort_keys[1], &c->sort_idx[0], &c->sort_idx[1], &c->gf_tables, &c->gf_hits, &c->gf_flags, &c->gf_scores, &c->mask_lr, &c->mask_pb, &c->mask_scale, &c->soft[0], &c->soft[1], &c->motif_hit, &c->motif_table })
+		&c->matched_slot, &c->matched_loc, &c->counters, &c->seed_hits, &c->seed_bitmap, &c->seed_deferred, &c->seed_eslot, &c->seed_eloc, &c->seed_hits_sorted, &c->sort_keys[0], &c->sort_keys[1], &c->sort_idx[0], &c->sort_idx[1], &c->gf_tables, &c->gf_hits, &c->gf_flags, &c->gf_scores, &c->mask_lr, &c->mask_pb, &c->mask_scale, &c->mask_pos, &c->soft[0], &c->soft[1], &c->motif_hit, &c->motif_table })
 		b->release();
 	if (c->ev0) (void)hipEventDestroy(c->ev0);
 	if (c->ev1) (void)hipEventDestroy(c->ev1);

@@ -26,6 +26,7 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+#include <future>
 #include <zlib.h>
 #include <unistd.h>
 #include <fcntl.h>
@@ -605,6 +606,16 @@ struct Sink {
 
 double ms_since(std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); }
 
+// DMND_CLI_TIMELINE=1: when every phase of a run ended, in ms since the process entered main (threads interleave; printed at the end)
+struct Timeline {
+	std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+	std::mutex m;
+	std::vector<std::pair<double, std::string>> ev;
+	const bool on = std::getenv("DMND_CLI_TIMELINE") != nullptr;
+	void mark(const std::string& what) { if (!on) return; const double t = ms_since(t0); std::lock_guard<std::mutex> g(m); ev.emplace_back(t, what); }
+	void print() { if (!on) return; std::sort(ev.begin(), ev.end()); for (auto& e : ev) std::fprintf(stderr, "timeline %9.2f ms  %s\n", e.first, e.second.c_str()); }
+} g_timeline;
+
 // Block boundaries of SequenceFile::load_seqs (src/data/sequence_file.cpp:215-222 for a .dmnd, :311-330 for FASTA):
 // units (sequences, or reads with their six frames) are added while letters < max_letters, so a block ends with the unit
 // that reaches the limit.
@@ -654,6 +665,9 @@ int run_blastp(const Options& o)
 	if (o.command == "blastp" && o.query_cover >= 50 && o.query_cover == o.subject_cover)
 		throw std::runtime_error("--query-cover equal to --subject-cover (>= 50) selects the reference's mutual-coverage search, which is not part of this build; use different values");
 	const auto t_all = std::chrono::steady_clock::now();
+	// the HIP runtime and the library's code object take their time to start (a quarter of a second on the MI355X boxes of this
+	// project): that runs beside reading the queries, opening the database and loading the first reference block
+	std::future<int> gpu_ready = std::async(std::launch::async, [] { const int rc = dmnd_init(-1); g_timeline.mark("dmnd_init"); return rc; });
 	SeqBlock q_all;
 	const bool blastx = o.command == "blastx";
 	const size_t C = blastx ? 6 : 1;
@@ -725,6 +739,7 @@ int run_blastp(const Options& o)
 	db.open(dbpath);
 	const size_t n_queries = q_all.ids.size() / C, n_targets = db.n;
 	std::cerr << "Loading sequences...  [" << ms_since(t0) / 1e3 << "s]  queries=" << n_queries << " targets=" << n_targets << " letters=" << db.letters << "\n";
+	g_timeline.mark("queries read, database opened");
 	const int sens = o.fast ? DMND_SENS_FAST : o.sens == "--mid-sensitive" ? DMND_SENS_MID_SENSITIVE : o.sens == "--sensitive" ? DMND_SENS_SENSITIVE
 		: o.sens == "--more-sensitive" ? DMND_SENS_MORE_SENSITIVE : o.sens == "--very-sensitive" ? DMND_SENS_VERY_SENSITIVE
 		: o.sens == "--ultra-sensitive" ? DMND_SENS_ULTRA_SENSITIVE : DMND_SENS_DEFAULT;
@@ -763,6 +778,15 @@ int run_blastp(const Options& o)
 	const std::vector<Range> q_blocks = split_blocks(q_units, max_letters), t_blocks = split_blocks(t_units, t_max_letters);
 	if (q_blocks.size() > 1 || t_blocks.size() > 1)
 		std::cerr << "Block size = " << max_letters << "  query blocks=" << q_blocks.size() << " reference blocks=" << t_blocks.size() << "\n";
+	const int load_threads = o.threads > 0 ? o.threads : 8;
+	// every GPU's first reference block is read (mapped file -> SequenceSet layout) while the contexts are being created
+	std::vector<std::future<SeqBlock>> first_block((size_t)n_gpus);
+	for (int g = 0; g < n_gpus && (size_t)g < t_blocks.size(); ++g)
+		first_block[(size_t)g] = std::async(std::launch::async, [&db, &t_blocks, g, load_threads] {
+			SeqBlock b = db.load(t_blocks[(size_t)g].begin, t_blocks[(size_t)g].end, load_threads);
+			g_timeline.mark("first reference block of GPU " + std::to_string(g) + " loaded");
+			return b;
+		});
 
 	dmnd_params p;
 	dmnd_default_params(&p);
@@ -781,6 +805,7 @@ int run_blastp(const Options& o)
 	if (o.index_chunks > 0) chk(dmnd_seed_params_set_index_chunks(&sp, o.index_chunks, threads));
 	if (o.shapes > 0 && o.shapes < sp.n_shapes) sp.n_shapes = o.shapes;
 	// one context per GPU, driven by its own host thread
+	if (gpu_ready.get() != DMND_OK) throw std::runtime_error(dmnd_last_error());
 	std::vector<dmnd_ctx*> ctxs((size_t)n_gpus, nullptr);
 	for (int g = 0; g < n_gpus; ++g) {
 		dmnd_ctx* c = dmnd_create(n_gpus > 1 && !share_gpu ? g : -1, &p);
@@ -939,6 +964,7 @@ int run_blastp(const Options& o)
 			ms_upload += up; ms_mask += mk;
 			if (g == 0) { mq_total += mq; motif_letters += ml; }
 		});
+		g_timeline.mark("query block uploaded and masked");
 		std::vector<dmnd_match> joined;                       // the query block's records against all reference blocks
 		std::vector<uint8_t> arena;                           // ... and their transcripts, if the output format reads them
 		std::vector<char> seeded(qr.end - qr.begin, 0);       // queries with at least one seed hit (what the unaligned report depends on)
@@ -952,8 +978,9 @@ int run_blastp(const Options& o)
 			// GPU that has one block keeps it (masked) from one query block to the next
 			const bool fresh = held.index != bi;             // just read: unmasked
 			if (fresh) {
-				held.block = next.valid() ? next.get() : db.load(tr.begin, tr.end, threads);
+				held.block = bi == (size_t)g && first_block[(size_t)g].valid() ? first_block[(size_t)g].get() : next.valid() ? next.get() : db.load(tr.begin, tr.end, threads);
 				held.index = bi;
+				g_timeline.mark("reference block " + std::to_string(bi) + " in host memory");
 			}
 			const size_t bn = bi + (size_t)n_gpus;
 			if (bn < t_blocks.size()) next = std::async(std::launch::async, [&db, &t_blocks, bn, threads] { return db.load(t_blocks[bn].begin, t_blocks[bn].end, threads); });
@@ -966,6 +993,7 @@ int run_blastp(const Options& o)
 			if (seg && !lazy_masking && fresh) { chk(dmnd_seg_mask_block(t.data.data(), t.limits.data(), t_seqs, threads, &mt)); mk += ms_since(t0); t0 = std::chrono::steady_clock::now(); }
 			chk(dmnd_upload_block(ctx, DMND_TARGET, t.data.data(), (int64_t)t.data.size(), t.limits.data(), t_seqs));
 			up += ms_since(t0);
+			g_timeline.mark("reference block " + std::to_string(bi) + " uploaded");
 			const int8_t* t_host = t.data.data();            // the letters the extension stage's host part reads
 			auto mask_target = [&] {
 				t0 = std::chrono::steady_clock::now();
@@ -984,15 +1012,16 @@ int run_blastp(const Options& o)
 			};
 			// up-front masking of a block that was just read; a block the GPU kept from the previous query block carries its masked
 			// letters already and is uploaded as it is
-			if (tantan && !lazy_masking && fresh) mask_target();
-			if (motifs && algo == 0) chk(dmnd_soft_mask_block(ctx, DMND_TARGET, &ml));
+			if (tantan && !lazy_masking && fresh) { mask_target(); g_timeline.mark("reference block " + std::to_string(bi) + " masked (tantan)"); }
+			if (motifs && algo == 0) { chk(dmnd_soft_mask_block(ctx, DMND_TARGET, &ml)); g_timeline.mark("reference block " + std::to_string(bi) + " soft-masked (motifs)"); }
 			t0 = std::chrono::steady_clock::now();
 			int64_t n_hits = 0;
 			chk(dmnd_seed_search(ctx, &sp, &n_hits));
 			std::vector<dmnd_seed_hit> hits((size_t)n_hits);
 			chk(dmnd_seed_hits(ctx, hits.data(), n_hits));
 			const double sd = ms_since(t0);
-			if (lazy_masking) mask_target();
+			g_timeline.mark("seed stage of block " + std::to_string(bi) + " done");
+			if (lazy_masking) { mask_target(); g_timeline.mark("reference block " + std::to_string(bi) + " masked lazily"); }
 			t0 = std::chrono::steady_clock::now();
 			if (o.no_self_hits) {
 				if (blastx) throw std::runtime_error("--no-self-hits is not supported for blastx");      // basic/config.cpp:677
@@ -1020,6 +1049,7 @@ int run_blastp(const Options& o)
 			}
 			mine.resize((size_t)n_matches);
 			const double ex = ms_since(t0);
+			g_timeline.mark("extension of block " + std::to_string(bi) + " done");
 			// into the query block's record list: block ids -> file ordinals, transcripts appended to the block's arena
 			std::lock_guard<std::mutex> lock(merge_mutex);
 			for (const dmnd_seed_hit& h : hits) seeded[h.query / C] = 1;
@@ -1193,7 +1223,12 @@ int run_blastp(const Options& o)
 	out.close();
 	if (un_file) std::fclose(un_file);
 	if (al_file) std::fclose(al_file);
-	for (dmnd_ctx* c : ctxs) dmnd_destroy(c);
+	g_timeline.mark("output written");
+	// The results are on disk. Tearing the contexts down buffer by buffer and unloading the HIP runtime costs tens of
+	// milliseconds that buy nothing -- the driver reclaims a process's HBM when it exits -- so the process leaves through _exit
+	// after the report below (DMND_CLI_CLEAN_EXIT=1: full teardown, for leak checkers).
+	const bool clean_exit = std::getenv("DMND_CLI_CLEAN_EXIT") != nullptr;
+	if (clean_exit) for (dmnd_ctx* c : ctxs) dmnd_destroy(c);
 	std::cerr << "Uploading blocks to HBM...  [" << ms_upload / 1e3 << "s]\n";
 	if (motifs) std::cerr << "Soft-masked letters (motifs): " << motif_letters << "\n";
 	if (seg) std::cerr << "Masking reference (seg)...  [" << ms_mask / 1e3 << "s]  masked letters: " << mt_total << "\n";
@@ -1201,6 +1236,8 @@ int run_blastp(const Options& o)
 	std::cerr << "Searching alignments (seed stage)...  [" << ms_seed / 1e3 << "s]  hits=" << total_hits << "\n";
 	std::cerr << "Computing alignments (extension stage)...  [" << ms_ext / 1e3 << "s]\n";
 	std::cerr << "Total time = " << ms_since(t_all) / 1e3 << "s\nReported " << total_matches << " pairwise alignments, " << total_matches << " HSPs.\n" << aligned << " queries aligned.\n";
+	g_timeline.print();
+	if (!clean_exit) { std::cerr.flush(); std::cout.flush(); std::fflush(nullptr); ::_exit(0); }
 	return 0;
 }
 

@@ -234,7 +234,11 @@ extern "C" int dmnd_mask_block(dmnd_ctx* c, int which, int8_t* host_data, int64_
 	if (int rc = c->mask_scale.ensure((size_t)(raw / 16 + n + 16) * sizeof(float))) return rc;
 	if (int rc = c->counters.ensure(64 * sizeof(unsigned long long))) return rc;
 	HIP_TRY(hipMemcpyAsync(c->mask_lr.p, lr.data(), lr.size() * sizeof(float), hipMemcpyHostToDevice, st));
-	HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(unsigned long long), st));
+	HIP_TRY(hipMemsetAsync(c->counters.p, 0, 2 * sizeof(unsigned long long), st));
+	// the host copy is patched from a list of the masked positions (a few per mille of the letters) instead of copying the
+	// whole block back over PCIe; a block with more than 1/16 of its letters masked takes the full copy
+	const unsigned long long pos_cap = host_data && raw < ((int64_t)1 << 32) ? (unsigned long long)raw / 16 + 1024 : 0;
+	if (pos_cap) if (int rc = c->mask_pos.ensure((size_t)pos_cap * sizeof(uint32_t))) return rc;
 	a.data = c->block[which].as<int8_t>();
 	a.limits = c->d_limits[which].as<int64_t>();
 	a.n_seqs = n;
@@ -242,13 +246,22 @@ extern "C" int dmnd_mask_block(dmnd_ctx* c, int which, int8_t* host_data, int64_
 	a.pb = c->mask_pb.as<float>();
 	a.scale = c->mask_scale.as<float>();
 	a.n_masked = c->counters.as<unsigned long long>();
+	a.masked_pos = pos_cap ? c->mask_pos.as<uint32_t>() : nullptr;
+	a.n_pos = c->counters.as<unsigned long long>() + 1;
+	a.pos_cap = pos_cap;
 	HIP_TRY(hipEventRecord(c->ev0, st));
 	HIP_TRY(launch_tantan(a, st));
 	HIP_TRY(hipEventRecord(c->ev1, st));
-	unsigned long long nm = 0;
-	HIP_TRY(hipMemcpyAsync(&nm, c->counters.p, sizeof(nm), hipMemcpyDeviceToHost, st));
-	if (host_data) HIP_TRY(hipMemcpyAsync(host_data, c->block[which].p, (size_t)raw, hipMemcpyDeviceToHost, st));
+	unsigned long long cnt[2] = { 0, 0 };
+	HIP_TRY(hipMemcpyAsync(cnt, c->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, st));
 	HIP_TRY(sync_stream(st));
+	const unsigned long long nm = cnt[0];
+	if (host_data && pos_cap && cnt[1] <= pos_cap) {
+		std::vector<uint32_t> pos((size_t)cnt[1]);
+		if (cnt[1]) HIP_TRY(copy_now(st, pos.data(), c->mask_pos.p, pos.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+		for (uint32_t x : pos) host_data[x] = 23;
+	}
+	else if (host_data) HIP_TRY(copy_now(st, host_data, c->block[which].p, (size_t)raw, hipMemcpyDeviceToHost));
 	float ms = 0;
 	HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
 	c->mask_ms = ms;
@@ -256,6 +269,7 @@ extern "C" int dmnd_mask_block(dmnd_ctx* c, int which, int8_t* host_data, int64_
 	// the scratch (4 B per letter) is only needed during the call
 	c->mask_pb.release();
 	c->mask_scale.release();
+	c->mask_pos.release();
 	return DMND_OK;
 }
 

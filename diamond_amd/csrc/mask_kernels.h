@@ -15,6 +15,9 @@ struct TantanArgs {
 	float* pb;                    // scratch: one float per block letter (indexed like data)
 	float* scale;                 // scratch: limits[i] / 16 + i is the first slot of sequence i
 	unsigned long long* n_masked; // out: number of letters masked
+	uint32_t* masked_pos;         // out (optional): block offsets of the letters that were overwritten, in no particular order
+	unsigned long long* n_pos;    //   their number (may exceed pos_cap: then the list is incomplete)
+	unsigned long long pos_cap;
 };
 
 hipError_t launch_tantan(const TantanArgs& a, hipStream_t st);

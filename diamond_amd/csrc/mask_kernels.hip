@@ -125,6 +125,15 @@ __global__ __launch_bounds__(256) void tantan_kernel(const TantanArgs a)
 		if (pf >= a.p.p_mask) { if (lane == (i & 63)) mask_me = true; ++n_masked; }
 		if ((i & 63) == 0) {                                   // positions [i, i + 64) are final: no later step reads them
 			if (mask_me) seq[i + lane] = 23;
+			if (a.masked_pos) {                                  // the host copy of the block is patched from this list instead of a full copy back
+				const unsigned long long mm = __ballot(mask_me);
+				if (mm) {
+					unsigned long long at = 0;
+					if (lane == 0) at = atomicAdd(a.n_pos, (unsigned long long)__popcll(mm));
+					at = (unsigned long long)__shfl((long long)at, 0) + (unsigned long long)__popcll(mm & ((1ull << lane) - 1));
+					if (mask_me && at < a.pos_cap) a.masked_pos[at] = (uint32_t)(base + i + lane);
+				}
+			}
 		}
 	}
 	if (lane == 0 && n_masked) atomicAdd(a.n_masked, (unsigned long long)n_masked);

@@ -412,4 +412,14 @@ DMND_HD uint32_t seed_hash_b(uint64_t x)
 
 DMND_HD uint64_t seed_hash(uint64_t x) { return ((uint64_t)seed_hash_b(x) << 32) | seed_hash_a(x); }
 
+// Level-1 filter of the reference stream: a blocked Bloom filter over the query seeds, every seed's K bits inside ONE 32-bit word
+// (one L2 request per probe). word = high bits of hash a scaled to the word count (any count, not only powers of two: the filter
+// is sized to what an XCD's L2 holds next to the stream); bits = three 5-bit fields of a's low half (K = 2: the first two).
+DMND_HD uint32_t bm1_word(uint32_t h, uint32_t words) { return (uint32_t)(((uint64_t)h * words) >> 32); }
+DMND_HD uint32_t bm1_bits(uint32_t h, uint32_t k3)
+{
+	const uint32_t two = (1u << (h & 31)) | (1u << ((h >> 5) & 31));
+	return k3 ? two | (1u << ((h >> 10) & 31)) : two;
+}
+
 }  // namespace dmnd

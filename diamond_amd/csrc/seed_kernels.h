@@ -47,7 +47,8 @@ struct SeedArgs {
 	// two one-hash bitmaps of the query seeds: level 1 is sized to stay resident in every XCD's 4 MB L2 (the reference
 	// stream probes it once per position), level 2 (>= 16 bits per query seed) filters level-1 false positives before
 	// the open-addressing table is touched
-	uint32_t* bitmap1; uint32_t bitmap1_mask;
+	uint32_t* bitmap1; uint32_t bitmap1_words, bitmap1_k3;      // level-1 filter (seed_core.h bm1_word / bm1_bits)
+	int stream_nt;                                              // reference letters are loaded non-temporally (they are read once)
 	uint32_t* bitmap; uint32_t bitmap_mask;
 	// joined reference positions of this shape
 	uint32_t* matched_slot; int64_t* matched_loc; unsigned long long* matched_count; int64_t matched_cap;

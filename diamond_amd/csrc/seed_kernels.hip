@@ -49,7 +49,7 @@ __global__ void seed_index_kernel(SeedArgs a, int sid)
 	}
 	const uint64_t h = seed_hash(seed);
 	if (a.level2) atomicOr(&a.bitmap[(h >> 32) & a.bitmap_mask], 1u << (h >> 59));      // level 2: only consulted for long seeds (launch_seed_stream)
-	atomicOr(&a.bitmap1[((uint32_t)h >> 10) & a.bitmap1_mask], (1u << (h & 31)) | (1u << ((h >> 5) & 31)));   // 2 bits, one word; bits of hash a only
+	atomicOr(&a.bitmap1[bm1_word((uint32_t)h, a.bitmap1_words)], bm1_bits((uint32_t)h, a.bitmap1_k3));        // K bits, one word; bits of hash a only
 	uint64_t slot = h & a.slot_mask;
 	for (;;) {
 		const unsigned long long old = atomicCAS((unsigned long long*)&a.slots[slot].key, (unsigned long long)SEED_EMPTY, (unsigned long long)seed);
@@ -308,8 +308,15 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 		}
 	};
 	if (in_range) {
-	const uint4 v0 = *reinterpret_cast<const uint4*>(a.tseed + p0);
-	const uint4 v1 = *reinterpret_cast<const uint4*>(a.tseed + p0 + 16);
+	uint4 v0, v1;
+	if (a.stream_nt) {
+		v0 = __builtin_nontemporal_load(reinterpret_cast<const uint4*>(a.tseed + p0));
+		v1 = __builtin_nontemporal_load(reinterpret_cast<const uint4*>(a.tseed + p0 + 16));
+	}
+	else {
+		v0 = *reinterpret_cast<const uint4*>(a.tseed + p0);
+		v1 = *reinterpret_cast<const uint4*>(a.tseed + p0 + 16);
+	}
 	const uint32_t w[8] = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };
 	uint64_t codes[2] = { 0, 0 };
 	uint32_t delim = 0, bad = 0;
@@ -346,11 +353,12 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 			const bool ok = inside && ((bad >> w0) & (HASHED ? span : care)) == 0;
 			if (HASHED && inside && !ok) special |= 1u << w0;
 			const uint32_t h = seed_hash_a(key[i]);                              // hash b is only needed past level 1
-			const uint32_t bw = ok ? a.bitmap1[(h >> 10) & a.bitmap1_mask] : 0u;
-			word[i] = (bw >> (h & 31)) & (bw >> ((h >> 5) & 31));
+			const uint32_t bw = ok ? a.bitmap1[bm1_word(h, a.bitmap1_words)] : 0u;
+			const uint32_t need = bm1_bits(h, a.bitmap1_k3);
+			word[i] = (bw & need) == need ? 1u : 0u;
 		}
 #pragma unroll
-		for (int i = 0; i < 8; ++i) pos_mask |= (word[i] & 1u) << i;
+		for (int i = 0; i < 8; ++i) pos_mask |= word[i] << i;
 		// rare path: level-1 positives -> level-2 bitmap -> table
 		while (pos_mask) {
 			const int i = __builtin_ctz(pos_mask);
@@ -367,8 +375,8 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 		uint64_t seed;
 		if (!seed_key_hashed(a.params, sid, a.tseed + p0 + w0, seed)) continue;
 		const uint32_t h = seed_hash_a(seed);
-		const uint32_t bw = a.bitmap1[(h >> 10) & a.bitmap1_mask];
-		if ((bw >> (h & 31)) & (bw >> ((h >> 5) & 31)) & 1u) probe_table(seed, p0 + w0);
+		const uint32_t bw = a.bitmap1[bm1_word(h, a.bitmap1_words)], need = bm1_bits(h, a.bitmap1_k3);
+		if ((bw & need) == need) probe_table(seed, p0 + w0);
 	}
 	}
 	__syncthreads();

@@ -122,6 +122,9 @@ int dmnd_set_db_letters(dmnd_ctx* ctx, double db_letters);
  * limits may be NULL when only the DP entry points are used. */
 int dmnd_upload_block(dmnd_ctx* ctx, int which, const int8_t* data, int64_t data_len,
 	const int64_t* limits, int64_t n_seqs);
+/* Optional: starts the HIP runtime and loads this library's kernels onto `device` (-1: device 0). Every entry point does so on
+ * first use; a driver calls it on a helper thread to overlap the start-up with its own file I/O. */
+int dmnd_init(int device);
 /* Page-locked host memory for a block's letters: dmnd_upload_block hands such a buffer to the DMA engine as it is, any other
  * (pageable) source is staged through two page-locked chunks of the context while the previous chunk is in flight. A driver that
  * reads a database block from disk into this memory (the reference's loader: data/sequence_file.cpp:113-150 load_seqs,
