@@ -298,6 +298,8 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	if (const char* e = getenv("DMND_SEED_BM1_KB")) bm1_words = (uint64_t)std::min(65536, std::max(4, atoi(e))) * 256;       // experiment knobs
 	if (const char* e = getenv("DMND_SEED_BM1_K")) bm1_k3 = atoi(e) == 3 ? 1u : 0u;
 	if (const char* e = getenv("DMND_SEED_STREAM_NT")) stream_nt = atoi(e) != 0;
+	int probe_policy = 0;
+	if (const char* e = getenv("DMND_SEED_PROBE_POLICY")) probe_policy = atoi(e);
 	// The fused pipeline finishes a shape before it starts the next one: its table, lists and bitmaps are ONE shape's, reused
 	// (64 shapes of --ultra-sensitive would otherwise hold 8 GB of tables for a 10k-query block)
 	bool fused = seed_stream_can_fuse(sp);
@@ -361,7 +363,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		a.bitmap = c->seed_bitmap.as<uint32_t>() + (size_t)own * (bm_words + bm1_words);
 		a.bitmap_mask = (uint32_t)(bm_words - 1);
 		a.bitmap1 = a.bitmap + bm_words;
-		a.bitmap1_words = (uint32_t)bm1_words; a.bitmap1_k3 = bm1_k3; a.stream_nt = stream_nt;
+		a.bitmap1_words = (uint32_t)bm1_words; a.bitmap1_k3 = bm1_k3; a.stream_nt = stream_nt; a.probe_policy = probe_policy;
 		a.matched_slot = c->matched_slot.as<uint32_t>() + matched_off;
 		a.matched_loc = c->matched_loc.as<int64_t>() + matched_off;
 		a.matched_count = c->counters.as<unsigned long long>() + sid;

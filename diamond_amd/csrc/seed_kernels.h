@@ -48,6 +48,7 @@ struct SeedArgs {
 	// stream probes it once per position), level 2 (>= 16 bits per query seed) filters level-1 false positives before
 	// the open-addressing table is touched
 	uint32_t* bitmap1; uint32_t bitmap1_words, bitmap1_k3;      // level-1 filter (seed_core.h bm1_word / bm1_bits)
+	int probe_policy;                                           // cache policy of the level-1 probes (seed_kernels.hip bm1_probe)
 	int stream_nt;                                              // reference letters are loaded non-temporally (they are read once)
 	uint32_t* bitmap; uint32_t bitmap_mask;
 	// joined reference positions of this shape

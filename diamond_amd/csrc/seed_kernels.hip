@@ -203,6 +203,29 @@ __device__ __forceinline__ uint32_t reduce4(uint32_t letter, uint64_t map_lo, ui
 // independent loads in flight as there are lanes, instead of a chain of dependent loads in the few lanes that found a join.
 // Lists longer than LIGHT are filtered by the whole workgroup. Pairs of a non-complex seed (SLOT_LOWC) are dropped: the seed
 // only gets its JOINED mark for seed_mask_kernel.
+// One probe of the level-1 filter. What bounds the stream is not the number of probes but the bytes they pull out of L2: a
+// plain load of a 4-byte word fills a whole 128-byte line of the CU's vector L1 (3e8 probes = 38 GB per launch, 3/4 of what
+// the L2s can deliver), and the line is never used again. POLICY selects the cache policy of the buffer load (aux bits:
+// 1 = sc0, 2 = nt, 16 = sc1; sc1 / nt loads are served by L2 without an L1 fill).
+template<int POLICY>
+__device__ __forceinline__ uint32_t bm1_probe(__amdgpu_buffer_rsrc_t rsrc, const uint32_t* base, uint32_t word)
+{
+	if (POLICY == 0) return base[word];
+	return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, word * 4u, 0, POLICY);
+}
+__device__ __forceinline__ uint32_t bm1_probe_any(int policy, __amdgpu_buffer_rsrc_t rsrc, const uint32_t* base, uint32_t word)
+{
+	switch (policy) {
+	case 1: return bm1_probe<1>(rsrc, base, word);
+	case 2: return bm1_probe<2>(rsrc, base, word);
+	case 3: return bm1_probe<3>(rsrc, base, word);
+	case 16: return bm1_probe<16>(rsrc, base, word);
+	case 17: return bm1_probe<17>(rsrc, base, word);
+	case 18: return bm1_probe<18>(rsrc, base, word);
+	default: return bm1_probe<0>(rsrc, base, word);
+	}
+}
+
 template<bool LEVEL2, bool HASHED, bool FUSED>
 __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int sid, uint64_t map_lo, uint64_t map_hi, int64_t base, uint64_t care64)
 {
@@ -225,6 +248,7 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 	__shared__ unsigned sv_n, hv_n;
 	if (threadIdx.x == 0) { st_n = 0; sv_n = 0; hv_n = 0; }
 	__syncthreads();
+	const __amdgpu_buffer_rsrc_t bm1_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.bitmap1, 0, (int)(a.bitmap1_words * 4u), 0x00020000);
 	const int64_t wg_base = base + (int64_t)blockIdx.x * blockDim.x * 16;
 	const int64_t p0 = wg_base + (int64_t)threadIdx.x * 16;
 	const bool in_range = p0 < a.t_end;
@@ -308,14 +332,15 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 		}
 	};
 	if (in_range) {
-	uint4 v0, v1;
+	typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+	u32x4 v0, v1;
 	if (a.stream_nt) {
-		v0 = __builtin_nontemporal_load(reinterpret_cast<const uint4*>(a.tseed + p0));
-		v1 = __builtin_nontemporal_load(reinterpret_cast<const uint4*>(a.tseed + p0 + 16));
+		v0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.tseed + p0));
+		v1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.tseed + p0 + 16));
 	}
 	else {
-		v0 = *reinterpret_cast<const uint4*>(a.tseed + p0);
-		v1 = *reinterpret_cast<const uint4*>(a.tseed + p0 + 16);
+		v0 = *reinterpret_cast<const u32x4*>(a.tseed + p0);
+		v1 = *reinterpret_cast<const u32x4*>(a.tseed + p0 + 16);
 	}
 	const uint32_t w[8] = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };
 	uint64_t codes[2] = { 0, 0 };
@@ -353,7 +378,7 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 			const bool ok = inside && ((bad >> w0) & (HASHED ? span : care)) == 0;
 			if (HASHED && inside && !ok) special |= 1u << w0;
 			const uint32_t h = seed_hash_a(key[i]);                              // hash b is only needed past level 1
-			const uint32_t bw = ok ? a.bitmap1[bm1_word(h, a.bitmap1_words)] : 0u;
+			const uint32_t bw = ok ? bm1_probe_any(a.probe_policy, bm1_rsrc, a.bitmap1, bm1_word(h, a.bitmap1_words)) : 0u;
 			const uint32_t need = bm1_bits(h, a.bitmap1_k3);
 			word[i] = (bw & need) == need ? 1u : 0u;
 		}

@@ -332,8 +332,10 @@ int dmnd_format_tab_translated(const dmnd_match* m, const char* qseqid, const ch
  * reference block and the query block with its default --masking tantan (mask_seqs, src/masking/masking.cpp:225-251;
  * Util::tantan::mask, src/masking/tantan.cpp:112; likelihood ratios exp(lambda * score), masking.cpp:134-155).
  * Results are bit-identical to the reference's AVX2 build (float operation order restated, see csrc/mask_core.h).
- * host_data (may be NULL) receives the masked block letters (block raw length bytes): the extension stage's host part
- * reads the same letters. *n_masked (may be NULL) = number of positions at or above the mask probability. */
+ * host_data (may be NULL): the caller's host copy of the block as it stands in HBM (the bytes it was uploaded from, block raw
+ * length); the mask letter is written over the masked positions -- from a list of those positions, not by copying the block
+ * back -- so that the extension stage's host part reads the same letters. *n_masked (may be NULL) = number of positions at or
+ * above the mask probability. */
 int dmnd_mask_block(dmnd_ctx* ctx, int which, int8_t* host_data, int64_t* n_masked);
 double dmnd_mask_kernel_ms(const dmnd_ctx* ctx);
 /* The lambda of those likelihood ratios (host only): the scale at which the matrix's implied letter probabilities are valid

@@ -45,7 +45,7 @@ def test_masked_block_equals_reference(ctx):
     for i in range(len(limits) - 1):
         a, b = int(limits[i]), int(limits[i + 1]) - 1
         twice[a:b] = orc.tantan_mask(want[a:b], lr)[0]
-    host2 = np.zeros_like(host)
+    host2 = host.copy()                 # host_data is the caller's copy of the block as it stands in HBM: the masked positions are patched into it
     ctx.mask_block(hip.TARGET, host2)
     assert np.array_equal(host2, twice)
 

@@ -22,10 +22,11 @@ ctx.upload_block(hip.QUERY, w.qd, w.ql)
 ctx.upload_block(hip.TARGET, w.td, w.tl)
 ctx.set_query_contexts(w.contexts)
 base = None
-variants = [dict()] + [dict(DMND_SEED_BM1_KB=str(kb), DMND_SEED_BM1_K=str(k), DMND_SEED_STREAM_NT=str(nt))
-                       for kb in (2048, 2560, 3072, 3584, 4096, 6144) for k in (2, 3) for nt in (0, 1)]
+variants = [dict()] + [dict(DMND_SEED_PROBE_POLICY=str(pol)) for pol in (1, 2, 3, 16, 17, 18)] \
+    + [dict(DMND_SEED_BM1_KB=str(kb), DMND_SEED_BM1_K=str(k), DMND_SEED_STREAM_NT=str(nt), DMND_SEED_PROBE_POLICY=str(pol))
+       for kb in (2048, 3072, 4096, 8192) for k in (2, 3) for pol in (0, 2, 16) for nt in (0, 1)]
 for v in variants:
-    for k in ("DMND_SEED_BM1_KB", "DMND_SEED_BM1_K", "DMND_SEED_STREAM_NT"):
+    for k in ("DMND_SEED_BM1_KB", "DMND_SEED_BM1_K", "DMND_SEED_STREAM_NT", "DMND_SEED_PROBE_POLICY"):
         os.environ.pop(k, None)
     os.environ.update(v)
     best, hits = None, None
@@ -41,7 +42,7 @@ for v in variants:
     if base is None:
         base = key
     same = key.shape == base.shape and (key == base).all()
-    print("%-60s stream %.3f ms  index %.3f  total %.3f  call %.2f  hits %d  %s" % (v or "default", best[1], best[0], best[4], best[5], hits.size, "same" if same else "DIFFERENT"), flush=True)
+    print("%-110s stream %.3f ms  index %.3f  total %.3f  call %.2f  hits %d  %s" % (v or "default", best[1], best[0], best[4], best[5], hits.size, "same" if same else "DIFFERENT"), flush=True)
 ctx.close()
 # band geometry of the round-1 DpTargets of this workload (what the sweep kernels get): widths and lane use per band class
 os.environ.pop("DMND_SEED_BM1_KB", None)
