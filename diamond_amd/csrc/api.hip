@@ -192,7 +192,7 @@ extern "C" dmnd_ctx* dmnd_create(int device, const dmnd_params* params)
 	c->params = *params;
 	c->evaluer.init(*params);
 	if (const char* mb = getenv("DMND_TRACE_ARENA_MB"))
-		c->trace_arena_max = (size_t)std::max(64L, atol(mb)) << 20;
+		c->trace_arena_max = (size_t)std::max(8L, atol(mb)) << 20;
 	// The context's own stream (seed stage, masking, uploads) runs at the lowest priority and the streams of the extension
 	// stage's runners (aux_context) at the highest: when a driver overlaps the seed stage of the next batch with the extension
 	// of the current one, the swipe kernels -- which sit on the extension's critical path between host phases -- get the CUs

@@ -295,6 +295,16 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	if (bm1_words > bm_words) bm1_words = bm_words;
 	uint32_t bm1_k3 = 0;
 	int stream_nt = 0;
+	// Long seeds (level-2 path: nearly every level-1 positive is a false one) with a query block that the default size serves:
+	// 3 MB and three bits per seed. Measured on C2 (3e6 query seeds, tools/stream_sweep.py): the stream kernel takes the same
+	// 1.45 ms as with 2 MB / two bits -- its bound is the rate at which the L2s serve 4-byte probes, not the misses behind
+	// them -- but the false positives drop from 9.7 % to 3.1 %, and with them the level-2 / table lines fetched over the fabric
+	// (4 MB: 1.53 ms, 8 MB: 2.56 ms -- the filter has to fit an XCD's 4 MB L2 beside the stream)
+	const bool long_seeds = !seed_stream_can_fuse(sp);
+	if (long_seeds && bm1_log2 == 24 && bm_words >= 3 * bm1_words / 2) {
+		bm1_words = 3 * bm1_words / 2;
+		bm1_k3 = (uint64_t)nq_pos * 4 <= bm1_words * 32 ? 1u : 0u;      // a third bit pays from ~4.3 filter bits per seed up (optimum k = ln 2 x bits per seed)
+	}
 	if (const char* e = getenv("DMND_SEED_BM1_KB")) bm1_words = (uint64_t)std::min(65536, std::max(4, atoi(e))) * 256;       // experiment knobs
 	if (const char* e = getenv("DMND_SEED_BM1_K")) bm1_k3 = atoi(e) == 3 ? 1u : 0u;
 	if (const char* e = getenv("DMND_SEED_STREAM_NT")) stream_nt = atoi(e) != 0;

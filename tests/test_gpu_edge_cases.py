@@ -127,7 +127,7 @@ def test_misuse_is_reported_not_crashed():
 def test_extension_without_kept_traces_gives_the_same_records(monkeypatch):
     """Round 1 normally sweeps in traceback mode and keeps its trace rows (dmnd_swipe_keep). When the rows of a call do not fit
     the context's trace budget the call falls back to a score-only sweep and round 2 sweeps again: same records either way
-    (the budget is read from DMND_TRACE_ARENA_MB when the context is created; 64 MB is less than this batch needs)."""
+    (the budget is read from DMND_TRACE_ARENA_MB when the context is created; 16 MB is less than this batch needs)."""
     from diamond_amd import synth, workload
     db, doff, q, qoff = synth.generate(300, members=10, queries=1500, seed=4)
     qd, ql = workload.sequence_set(q, qoff)
@@ -135,7 +135,7 @@ def test_extension_without_kept_traces_gives_the_same_records(monkeypatch):
     params = hip.default_params()
     params.db_letters = float(doff[-1])
     out = []
-    for mb in (None, "64"):
+    for mb in (None, "16"):
         if mb is None:
             monkeypatch.delenv("DMND_TRACE_ARENA_MB", raising=False)
         else:
@@ -165,4 +165,4 @@ def test_extension_without_kept_traces_gives_the_same_records(monkeypatch):
             bad = np.nonzero(m_keep[name] != m_again[name])[0]
             assert bad.size == 0, (name, bad[:5], m_keep[name][bad[:5]], m_again[name][bad[:5]])
     assert st_keep["round2_swipe_kernel_ms"] == 0.0 and st_again["round2_swipe_kernel_ms"] > 0.0      # the two paths really differ
-    assert st_keep["round1_targets"] * 40_000 > 64 << 20                                                 # ... because the trace rows exceed 64 MB
+    assert st_keep["round1_targets"] * 15_000 > 16 << 20                                                 # ... because the trace records (half a byte per cell) exceed 16 MB

@@ -1,7 +1,9 @@
-"""-m gpu A/B test at the reference's own operator seam: oracle/_ref/diamond_hip is the GENUINE reference
+"""-m gpu A/B test at the reference's own operator seams: oracle/_ref/diamond_hip is the GENUINE reference
 (compiled in place from /root/reference by oracle/Makefile) whose DP::BandedSwipe::swipe is answered by our
-C ABI on the MI355X (oracle/ref_hip_bridge.cpp). Its output must be byte-identical to the unmodified
-reference binary on the same inputs -- hit sets, scores, coordinates, identities, CIGARs, e-values."""
+C ABI on the MI355X (oracle/ref_hip_bridge.cpp) -- and, with DMND_BRIDGE_SEED=1, whose Search::search_shape
+(the seed stage's dispatch point) is answered by dmnd_seed_search as well, the hits going into the
+reference's own HitBuffer. Its output must be byte-identical to the unmodified reference binary on the same
+inputs -- hit sets, scores, coordinates, identities, CIGARs, e-values."""
 import os
 import subprocess
 import pytest
@@ -26,12 +28,15 @@ def data(tmp_path_factory):
     return d
 
 
-def _run(binary, d, name, extra):
+def _run(binary, d, name, extra, seed_seam=False, algo=("--algo", "0")):
     env = dict(os.environ, DMND_HIP_LIB=os.path.join(ROOT, "diamond_amd", "libdiamond_hip.so"))
+    if seed_seam:
+        env["DMND_BRIDGE_SEED"] = "1"
     out = d / name
-    cmd = [binary, "blastp", "-q", str(d / "q.faa"), "-d", str(d / "db.faa"), "-o", str(out), "-p", "4", "--algo", "0"] + extra
+    cmd = [binary, "blastp", "-q", str(d / "q.faa"), "-d", str(d / "db.faa"), "-o", str(out), "-p", "4"] + list(algo) + extra
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
+    assert "outside the bridge" not in r.stderr, r.stderr[-2000:]      # the seed seam really answered (no silent fall-back to the reference's own seed stage)
     return open(out).read()
 
 
@@ -44,5 +49,22 @@ def _run(binary, d, name, extra):
 def test_reference_with_hip_swipe_is_byte_identical(data, name, extra):
     ref = _run(REF, data, name + ".ref.tsv", extra)
     got = _run(BRIDGE, data, name + ".hip.tsv", extra)
+    assert len(ref.splitlines()) > 200
+    assert got == ref
+
+
+@pytest.mark.parametrize("name,extra,algo", [
+    ("fast", ["--fast"], ("--algo", "0")),
+    ("fast_nomask", ["--fast", "--masking", "0", "--motif-masking", "0"], ("--algo", "0")),
+    ("default", [], ("--algo", "0")),
+    ("sensitive", ["--sensitive"], ("--algo", "0")),
+    ("default_c1", ["-c", "1"], ("--algo", "0")),
+    ("fast_query_indexed", ["--fast"], ("--algo", "1")),
+])
+def test_reference_with_both_seams_is_byte_identical(data, name, extra, algo):
+    """Search::search_shape AND DP::BandedSwipe::swipe inside the genuine reference answered by libdiamond_hip.so: default
+    masking (tantan on both blocks before the seed stage, motif soft masking during seed enumeration) unless switched off."""
+    ref = _run(REF, data, name + ".ref2.tsv", extra, algo=algo)
+    got = _run(BRIDGE, data, name + ".hip2.tsv", extra, seed_seam=True, algo=algo)
     assert len(ref.splitlines()) > 200
     assert got == ref
