@@ -151,17 +151,34 @@ extern "C" int dmnd_device_count(void)
 
 namespace { __global__ void init_marker_kernel(int* p) { if (p) *p = 1; } }
 
+extern "C" hipError_t dmnd_touch_bias(hipStream_t), dmnd_touch_gapped(hipStream_t), dmnd_touch_mask(hipStream_t), dmnd_touch_seed(hipStream_t),
+	dmnd_touch_swipe16(hipStream_t), dmnd_touch_swipe(hipStream_t);
+
 extern "C" int dmnd_init(int device)
 {
+	const auto t0 = std::chrono::steady_clock::now();
+	const bool trace = getenv("DMND_TRACE") != nullptr;
+	auto lap = [&](const char* what) { if (trace) std::fprintf(stderr, "dmnd_init %8.2f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what); };
 	int count = 0;
 	if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return fail(DMND_E_DEVICE, "dmnd_init: no HIP device visible (this library has no CPU fallback)");
+	lap("runtime up, devices counted");
 	if (device < 0) device = 0;
 	if (device >= count) return fail(DMND_E_ARG, "dmnd_init: device index out of range");
 	HIP_TRY(hipSetDevice(device));
-	// the first launch of any kernel of this library loads its code object onto the device
+	// the first launch of a kernel of a translation unit loads that unit's code object onto the device: all of them now, so that
+	// no stage of the search pays for it later
 	hipLaunchKernelGGL(init_marker_kernel, dim3(1), dim3(1), 0, nullptr, (int*)nullptr);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipDeviceSynchronize());
+	lap("first kernel (api)");
+	struct { const char* name; hipError_t (*fn)(hipStream_t); } units[] = { { "mask", dmnd_touch_mask }, { "seed", dmnd_touch_seed }, { "bias", dmnd_touch_bias },
+		{ "swipe16", dmnd_touch_swipe16 }, { "swipe", dmnd_touch_swipe }, { "gapped", dmnd_touch_gapped } };
+	for (auto& u : units) {
+		HIP_TRY(u.fn(nullptr));
+		if (trace) { HIP_TRY(hipDeviceSynchronize()); lap(u.name); }
+	}
+	HIP_TRY(hipDeviceSynchronize());
+	lap("all code objects loaded");
 	return DMND_OK;
 }
 

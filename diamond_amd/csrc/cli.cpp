@@ -971,6 +971,11 @@ int run_blastp(const Options& o)
 			if (g == 0) { mq_total += mq; motif_letters += ml; }
 		});
 		g_timeline.mark("query block uploaded and masked");
+		// the seed stage's device buffers are allocated beside the upload and the masking of the first reference block
+		std::vector<std::future<int>> reserved;
+		if (&qr == &q_blocks.front())
+			for (int g = 0; g < n_gpus; ++g)
+				reserved.push_back(std::async(std::launch::async, [&, g] { const int rc = dmnd_seed_reserve(ctxs[(size_t)g], &sp, (int64_t)q.data.size()); g_timeline.mark("seed buffers reserved"); return rc; }));
 		std::vector<dmnd_match> joined;                       // the query block's records against all reference blocks
 		std::vector<uint8_t> arena;                           // ... and their transcripts, if the output format reads them
 		std::vector<char> seeded(qr.end - qr.begin, 0);       // queries with at least one seed hit (what the unaligned report depends on)
@@ -1024,6 +1029,7 @@ int run_blastp(const Options& o)
 			// letters already and is uploaded as it is
 			if (tantan && !lazy_masking && fresh) { mask_target(); g_timeline.mark("reference block " + std::to_string(bi) + " masked (tantan)"); }
 			if (motifs && algo == 0) { chk(dmnd_soft_mask_block(ctx, DMND_TARGET, &ml)); g_timeline.mark("reference block " + std::to_string(bi) + " soft-masked (motifs)"); }
+			if ((size_t)g < reserved.size() && reserved[(size_t)g].valid()) (void)reserved[(size_t)g].get();      // an optimisation only: the search allocates what is missing
 			t0 = std::chrono::steady_clock::now();
 			int64_t n_hits = 0;
 			chk(dmnd_seed_search(ctx, &sp, &n_hits));

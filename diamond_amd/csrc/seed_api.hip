@@ -235,6 +235,110 @@ struct Timer {
 
 }
 
+// Buffer geometry of a seed search: a function of the seed parameters and the number of query positions only, so that the buffers
+// can be reserved (dmnd_seed_reserve) before the blocks are resident
+struct SeedSizes {
+	uint64_t slots, bm_words, bm1_words;
+	uint32_t bm1_k3;
+	int stream_nt, probe_policy, SB, slot_shift;
+	bool fused, reuse;
+	size_t bm_total;
+};
+
+static SeedSizes seed_sizes(const dmnd_ctx* c, const SeedParams& sp, int64_t nq_pos)
+{
+	SeedSizes z;
+	const int S = sp.n_shapes;
+	z.slots = 1024;
+	while (z.slots < (uint64_t)nq_pos * 2) z.slots <<= 1;
+
+	// bitmap: >= 16 bits per query position, at most 2^27 bits (16 MB); word mask for 32-bit words
+	uint64_t bm_words = 1 << 15;
+	while (bm_words * 32 < (uint64_t)nq_pos * 16 && bm_words < ((uint64_t)1 << 22)) bm_words <<= 1;
+	// level-1 bitmap: 2^24 bits = 2 MB by default (half an XCD's L2), never larger than level 2
+	// ... unless the query block is so large that 2 MB saturate (above 16 M positions more than 85 % of the bits are set and nearly
+	// every probe is positive): then 4 bits per position, up to 2^27 -- a filter that works from the Infinity Cache beats one in
+	// L2 that does not filter (100k queries: stream 34 -> 24 ms per 8 blocks). Below that the L2-resident size wins even at 70 %
+	// density (blastx, 10 M positions: 3.7 against 5.8 ms).
+	int bm1_log2 = 24;
+	if (nq_pos > ((int64_t)1 << 24))
+		while (bm1_log2 < 27 && ((uint64_t)1 << bm1_log2) < (uint64_t)nq_pos * 4) ++bm1_log2;
+	if (const char* e = getenv("DMND_SEED_BITMAP1_LOG2")) bm1_log2 = std::min(27, std::max(15, atoi(e)));      // word index = 22 bits of hash a
+	uint64_t bm1_words = ((uint64_t)1 << bm1_log2) / 32;
+	if (bm1_words > bm_words) bm1_words = bm_words;
+	uint32_t bm1_k3 = 0;
+	int stream_nt = 0;
+	// Long seeds (level-2 path: nearly every level-1 positive is a false one) with a query block that the default size serves:
+	// 3 MB and three bits per seed. Measured on C2 (3e6 query seeds, tools/stream_sweep.py): the stream kernel takes the same
+	// 1.45 ms as with 2 MB / two bits -- its bound is the rate at which the L2s serve 4-byte probes, not the misses behind
+	// them -- but the false positives drop from 9.7 % to 3.1 %, and with them the level-2 / table lines fetched over the fabric
+	// (4 MB: 1.53 ms, 8 MB: 2.56 ms -- the filter has to fit an XCD's 4 MB L2 beside the stream)
+	const bool long_seeds = !seed_stream_can_fuse(sp);
+	if (long_seeds && bm1_log2 == 24 && bm_words >= 3 * bm1_words / 2) {
+		bm1_words = 3 * bm1_words / 2;
+		bm1_k3 = (uint64_t)nq_pos * 4 <= bm1_words * 32 ? 1u : 0u;      // a third bit pays from ~4.3 filter bits per seed up (optimum k = ln 2 x bits per seed)
+	}
+	if (const char* e = getenv("DMND_SEED_BM1_KB")) bm1_words = (uint64_t)std::min(65536, std::max(4, atoi(e))) * 256;       // experiment knobs
+	if (const char* e = getenv("DMND_SEED_BM1_K")) bm1_k3 = atoi(e) == 3 ? 1u : 0u;
+	if (const char* e = getenv("DMND_SEED_STREAM_NT")) stream_nt = atoi(e) != 0;
+	int probe_policy = 0;
+	if (const char* e = getenv("DMND_SEED_PROBE_POLICY")) probe_policy = atoi(e);
+	// The fused pipeline finishes a shape before it starts the next one: its table, lists and bitmaps are ONE shape's, reused
+	// (64 shapes of --ultra-sensitive would otherwise hold 8 GB of tables for a 10k-query block)
+	bool fused = seed_stream_can_fuse(sp);
+	if (const char* e = getenv("DMND_SEED_FUSED")) fused = fused && atoi(e) != 0;
+	// Query index reuse (dmnd_set_query_index_reuse; a query block against many reference blocks): the tables, lists and bitmaps of
+	// ALL shapes stay resident between calls and a call that finds them built for the same query block and parameters only resets
+	// the per-block state (join / erase marks) instead of rebuilding them. Needs S buffer sets; refused above 64 GiB.
+	// fused pipeline: 64-byte slots that carry the folded query window of single-position seeds (DMND_SEED_WIDE_SLOTS=0: 16-byte slots)
+	static const bool wide_env = [] { const char* e = getenv("DMND_SEED_WIDE_SLOTS"); return !e || atoi(e) != 0; }();
+	z.slot_shift = fused && wide_env ? 6 : 4;
+	const size_t set_bytes = (z.slots << z.slot_shift) + 2 * (size_t)nq_pos * sizeof(uint32_t) + (size_t)(bm_words + bm1_words) * sizeof(uint32_t);
+	const bool reuse = c->reuse_query_index && set_bytes * (size_t)S <= ((size_t)64 << 30) && !getenv("DMND_SEED_MATCHED_CAP");
+	const int SB = (fused && !reuse) ? 1 : S;            // shapes that own buffers at the same time
+	const size_t bm_total = (size_t)SB * (bm_words + bm1_words) * sizeof(uint32_t);
+	z.bm_words = bm_words; z.bm1_words = bm1_words; z.bm1_k3 = bm1_k3; z.stream_nt = stream_nt; z.probe_policy = probe_policy;
+	z.fused = fused; z.reuse = reuse; z.SB = SB; z.bm_total = bm_total;
+	return z;
+}
+
+// The buffers a search of this geometry needs before its first kernel. generous: also the buffers whose size depends on what the
+// search finds, at their starting capacities (dmnd_seed_reserve; the search itself grows them where they overflow)
+static int seed_reserve(dmnd_ctx* c, const SeedParams& sp, const SeedSizes& z, int64_t nq_pos, int64_t q_end, int64_t q_block_len, bool generous)
+{
+	if (int rc = c->seed_bitmap.ensure(z.bm_total)) return rc;
+	if (int rc = c->qid_of.ensure((size_t)q_end * sizeof(uint32_t))) return rc;
+	if (int rc = c->mask_time.ensure((size_t)q_block_len + 256)) return rc;
+	if (int rc = c->seed_keys.ensure((size_t)z.SB * (z.slots << z.slot_shift))) return rc;
+	if (int rc = c->seed_need.ensure((size_t)(z.slots / 32) * sizeof(uint32_t))) return rc;
+	if (int rc = c->seed_next.ensure((size_t)z.SB * nq_pos * sizeof(uint32_t))) return rc;        // qslot
+	if (int rc = c->seed_qlist.ensure((size_t)z.SB * nq_pos * sizeof(uint32_t))) return rc;
+	if (int rc = c->seed_qkeys.ensure((size_t)nq_pos * sizeof(uint32_t))) return rc;
+	// (c->counters is shared with the masking calls that may run beside a reservation: the search allocates it itself)
+	if (!generous) return DMND_OK;
+	const int64_t m_cap = std::max<int64_t>((int64_t)1 << 22, 4 * nq_pos);
+	if (int rc = c->matched_slot.ensure((size_t)m_cap * sizeof(uint32_t))) return rc;
+	if (int rc = c->matched_loc.ensure((size_t)m_cap * sizeof(int64_t))) return rc;
+	if (int rc = c->seed_hits.ensure(((size_t)1 << 20) * sizeof(dmnd_seed_hit))) return rc;
+	if (int rc = c->seed_deferred.ensure(((size_t)1 << 18) * sizeof(SeedDeferred))) return rc;
+	if (z.fused) {
+		if (int rc = c->seed_survivors.ensure(((size_t)1 << 20) * sizeof(SeedSurvivor))) return rc;
+		if (int rc = c->seed_qfold.ensure((size_t)(q_block_len + 1) / 2 + 64)) return rc;
+	}
+	return DMND_OK;
+}
+
+extern "C" int dmnd_seed_reserve(dmnd_ctx* c, const dmnd_seed_params* params, int64_t query_block_len)
+{
+	if (!c || !params || query_block_len <= 512) return fail(DMND_E_ARG, "dmnd_seed_reserve: bad argument");
+	SeedParams sp;
+	std::memcpy(&sp, params, sizeof(sp));
+	if (sp.n_shapes < 1 || sp.n_shapes > SEED_MAX_SHAPES) return fail(DMND_E_ARG, "dmnd_seed_reserve: unsupported seed configuration");
+	HIP_TRY(hipSetDevice(c->device));
+	const int64_t nq_pos = query_block_len - 512;             // a SequenceSet block: 256 padding letters on either side
+	return seed_reserve(c, sp, seed_sizes(c, sp, nq_pos), nq_pos, query_block_len - 256, query_block_len, true);
+}
+
 extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int64_t* n_hits)
 {
 	if (!c || !params || !n_hits) return fail(DMND_E_ARG, "dmnd_seed_search: NULL argument");
@@ -276,72 +380,27 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	if (nq_pos <= 0 || t_end <= t_begin) return DMND_OK;
 	if (nq_pos >= 0xffffffffLL) return fail(DMND_E_ARG, "dmnd_seed_search: query block larger than 4G letters");
 	const int S = sp.n_shapes;
-	uint64_t slots = 1024;
-	while (slots < (uint64_t)nq_pos * 2) slots <<= 1;
-
-	// bitmap: >= 16 bits per query position, at most 2^27 bits (16 MB); word mask for 32-bit words
-	uint64_t bm_words = 1 << 15;
-	while (bm_words * 32 < (uint64_t)nq_pos * 16 && bm_words < ((uint64_t)1 << 22)) bm_words <<= 1;
-	// level-1 bitmap: 2^24 bits = 2 MB by default (half an XCD's L2), never larger than level 2
-	// ... unless the query block is so large that 2 MB saturate (above 16 M positions more than 85 % of the bits are set and nearly
-	// every probe is positive): then 4 bits per position, up to 2^27 -- a filter that works from the Infinity Cache beats one in
-	// L2 that does not filter (100k queries: stream 34 -> 24 ms per 8 blocks). Below that the L2-resident size wins even at 70 %
-	// density (blastx, 10 M positions: 3.7 against 5.8 ms).
-	int bm1_log2 = 24;
-	if (nq_pos > ((int64_t)1 << 24))
-		while (bm1_log2 < 27 && ((uint64_t)1 << bm1_log2) < (uint64_t)nq_pos * 4) ++bm1_log2;
-	if (const char* e = getenv("DMND_SEED_BITMAP1_LOG2")) bm1_log2 = std::min(27, std::max(15, atoi(e)));      // word index = 22 bits of hash a
-	uint64_t bm1_words = ((uint64_t)1 << bm1_log2) / 32;
-	if (bm1_words > bm_words) bm1_words = bm_words;
-	uint32_t bm1_k3 = 0;
-	int stream_nt = 0;
-	// Long seeds (level-2 path: nearly every level-1 positive is a false one) with a query block that the default size serves:
-	// 3 MB and three bits per seed. Measured on C2 (3e6 query seeds, tools/stream_sweep.py): the stream kernel takes the same
-	// 1.45 ms as with 2 MB / two bits -- its bound is the rate at which the L2s serve 4-byte probes, not the misses behind
-	// them -- but the false positives drop from 9.7 % to 3.1 %, and with them the level-2 / table lines fetched over the fabric
-	// (4 MB: 1.53 ms, 8 MB: 2.56 ms -- the filter has to fit an XCD's 4 MB L2 beside the stream)
-	const bool long_seeds = !seed_stream_can_fuse(sp);
-	if (long_seeds && bm1_log2 == 24 && bm_words >= 3 * bm1_words / 2) {
-		bm1_words = 3 * bm1_words / 2;
-		bm1_k3 = (uint64_t)nq_pos * 4 <= bm1_words * 32 ? 1u : 0u;      // a third bit pays from ~4.3 filter bits per seed up (optimum k = ln 2 x bits per seed)
-	}
-	if (const char* e = getenv("DMND_SEED_BM1_KB")) bm1_words = (uint64_t)std::min(65536, std::max(4, atoi(e))) * 256;       // experiment knobs
-	if (const char* e = getenv("DMND_SEED_BM1_K")) bm1_k3 = atoi(e) == 3 ? 1u : 0u;
-	if (const char* e = getenv("DMND_SEED_STREAM_NT")) stream_nt = atoi(e) != 0;
-	int probe_policy = 0;
-	if (const char* e = getenv("DMND_SEED_PROBE_POLICY")) probe_policy = atoi(e);
-	// The fused pipeline finishes a shape before it starts the next one: its table, lists and bitmaps are ONE shape's, reused
-	// (64 shapes of --ultra-sensitive would otherwise hold 8 GB of tables for a 10k-query block)
-	bool fused = seed_stream_can_fuse(sp);
-	if (const char* e = getenv("DMND_SEED_FUSED")) fused = fused && atoi(e) != 0;
-	// Query index reuse (dmnd_set_query_index_reuse; a query block against many reference blocks): the tables, lists and bitmaps of
-	// ALL shapes stay resident between calls and a call that finds them built for the same query block and parameters only resets
-	// the per-block state (join / erase marks) instead of rebuilding them. Needs S buffer sets; refused above 64 GiB.
-	const size_t set_bytes = slots * sizeof(SeedSlot) + 2 * (size_t)nq_pos * sizeof(uint32_t) + (size_t)(bm_words + bm1_words) * sizeof(uint32_t);
-	const bool reuse = c->reuse_query_index && set_bytes * (size_t)S <= ((size_t)64 << 30) && !getenv("DMND_SEED_MATCHED_CAP");
-	const int SB = (fused && !reuse) ? 1 : S;            // shapes that own buffers at the same time
-	const size_t bm_total = (size_t)SB * (bm_words + bm1_words) * sizeof(uint32_t);
+	const SeedSizes z = seed_sizes(c, sp, nq_pos);
+	const uint64_t slots = z.slots, bm_words = z.bm_words, bm1_words = z.bm1_words;
+	const uint32_t bm1_k3 = z.bm1_k3;
+	const int stream_nt = z.stream_nt, probe_policy = z.probe_policy, SB = z.SB;
+	const size_t slot_bytes = (size_t)slots << z.slot_shift;      // one shape's table
+	const bool fused = z.fused, reuse = z.reuse;
+	const size_t bm_total = z.bm_total;
 	std::string signature;
 	if (reuse) {
 		signature.assign(reinterpret_cast<const char*>(&sp), sizeof(sp));
-		const uint64_t extra[6] = { c->query_generation, (uint64_t)nq_pos, slots, bm_words, bm1_words, (uint64_t)fused };
+		const uint64_t extra[7] = { c->query_generation, (uint64_t)nq_pos, slots, bm_words, bm1_words, (uint64_t)fused, (uint64_t)z.slot_shift * 2 + bm1_k3 };
 		signature.append(reinterpret_cast<const char*>(extra), sizeof(extra));
 	}
 	const bool index_ready = reuse && c->qindex_signature == signature && !signature.empty();
 	c->qindex_signature.clear();                         // set again when this call has built (or kept) a complete index
-	if (int rc = c->seed_bitmap.ensure(bm_total)) return rc;
-	if (!index_ready) HIP_TRY(hipMemsetAsync(c->seed_bitmap.p, 0, bm_total, st));
-	if (int rc = c->qid_of.ensure((size_t)q_end * sizeof(uint32_t))) return rc;
-	if (int rc = c->mask_time.ensure((size_t)c->block_len[DMND_QUERY] + 256)) return rc;
-	if (int rc = c->seed_keys.ensure((size_t)SB * slots * sizeof(SeedSlot))) return rc;
-	if (int rc = c->seed_need.ensure((size_t)(slots / 32) * sizeof(uint32_t))) return rc;
-	if (int rc = c->seed_next.ensure((size_t)SB * nq_pos * sizeof(uint32_t))) return rc;        // qslot
-	if (int rc = c->seed_qlist.ensure((size_t)SB * nq_pos * sizeof(uint32_t))) return rc;
-	if (int rc = c->seed_qkeys.ensure((size_t)nq_pos * sizeof(uint32_t))) return rc;
-	if (!index_ready) HIP_TRY(hipMemsetAsync(c->seed_next.p, 0xff, (size_t)SB * nq_pos * sizeof(uint32_t), st));
+	if (int rc = seed_reserve(c, sp, z, nq_pos, q_end, c->block_len[DMND_QUERY], false)) return rc;
 	if (int rc = c->counters.ensure((size_t)(S + 5) * sizeof(unsigned long long))) return rc;      // [S] hits, [S+1] deferred pairs, [S+2] collected positions, [S+3] Hamming survivors, [S+4] scored survivors
+	if (!index_ready) HIP_TRY(hipMemsetAsync(c->seed_bitmap.p, 0, bm_total, st));
+	if (!index_ready) HIP_TRY(hipMemsetAsync(c->seed_next.p, 0xff, (size_t)SB * nq_pos * sizeof(uint32_t), st));
 	HIP_TRY(hipMemsetAsync(c->mask_time.p, SEED_NEVER, (size_t)c->block_len[DMND_QUERY] + 256, st));
-	if (!index_ready) HIP_TRY(hipMemsetAsync(c->seed_keys.p, 0xff, (size_t)SB * slots * sizeof(SeedSlot), st));
+	if (!index_ready) HIP_TRY(hipMemsetAsync(c->seed_keys.p, 0xff, (size_t)SB * slot_bytes, st));
 	HIP_TRY(launch_seed_qid(c->d_limits[DMND_QUERY].as<int64_t>(), (int64_t)ql.size() - 1, c->qid_of.as<uint32_t>(), st));
 
 	// fused pipeline: 4-bit copy of the query block for the Hamming pre-filter (DMND_SEED_FOLD=0 switches it off)
@@ -366,7 +425,8 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		a.qlimits = c->d_limits[DMND_QUERY].as<int64_t>();
 		a.q_begin = q_begin; a.q_end = q_end; a.t_begin = t_begin; a.t_end = t_end;
 		a.qid_of = c->qid_of.as<uint32_t>(); a.mask_time = c->mask_time.as<uint8_t>();
-		a.slots = c->seed_keys.as<SeedSlot>() + (size_t)own * slots;
+		a.slots = reinterpret_cast<SeedSlot*>(c->seed_keys.as<char>() + (size_t)own * slot_bytes);
+		a.slot_shift = z.slot_shift;
 		a.qslot = c->seed_next.as<uint32_t>() + (size_t)own * nq_pos;
 		a.qlist = c->seed_qlist.as<uint32_t>() + (size_t)own * nq_pos;
 		a.slot_mask = slots - 1;
@@ -427,7 +487,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 			SeedArgs a = args_for(sid, 0, 0);
 			tm.start();
 			if (sid > 0 && SB == 1) {                        // the previous shape's table, slots-of-positions and bitmaps
-				HIP_TRY(hipMemsetAsync(c->seed_keys.p, 0xff, (size_t)slots * sizeof(SeedSlot), st));
+				HIP_TRY(hipMemsetAsync(c->seed_keys.p, 0xff, slot_bytes, st));
 				HIP_TRY(hipMemsetAsync(c->seed_next.p, 0xff, (size_t)nq_pos * sizeof(uint32_t), st));
 				HIP_TRY(hipMemsetAsync(c->seed_bitmap.p, 0, bm_total, st));
 			}
@@ -516,7 +576,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		if (int rc = c->matched_loc.ensure((size_t)cap_total * sizeof(int64_t))) return rc;
 		HIP_TRY(hipMemsetAsync(c->counters.p, 0, (size_t)(S + 5) * sizeof(unsigned long long), st));
 		if (attempt > 0) {
-			HIP_TRY(hipMemsetAsync(c->seed_keys.p, 0xff, (size_t)S * slots * sizeof(SeedSlot), st));
+			HIP_TRY(hipMemsetAsync(c->seed_keys.p, 0xff, (size_t)S * slot_bytes, st));
 			HIP_TRY(hipMemsetAsync(c->seed_bitmap.p, 0, bm_total, st));
 			HIP_TRY(hipMemsetAsync(c->seed_next.p, 0xff, (size_t)S * nq_pos * sizeof(uint32_t), st));
 		}

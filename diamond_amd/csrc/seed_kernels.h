@@ -40,7 +40,10 @@ struct SeedArgs {
 	const uint32_t* qid_of;                       // query position -> query id
 	uint8_t* mask_time;                           // per query letter: (shape, chunk) time of its SEED_MASK bit
 	// per-shape query seed table
-	SeedSlot* slots;
+	SeedSlot* slots;              // slot i lives at byte offset i << slot_shift: 16-byte slots, or (fused short-seed pipeline) 64-byte
+	int slot_shift;               // slots whose bytes 16..39 hold the folded window of the seed's one query position (slot_win)
+	__host__ __device__ SeedSlot& slot(uint64_t i) const { return *reinterpret_cast<SeedSlot*>(reinterpret_cast<char*>(slots) + (i << slot_shift)); }
+	__host__ __device__ uint32_t* slot_win(uint64_t i) const { return reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(slots) + (i << slot_shift) + 16); }
 	uint32_t* qslot;                              // per query position: slot of its seed (LIST_END: no seed); input of the list sort
 	const uint32_t* qlist;                        // query positions grouped by slot (SeedSlot::head = start, count in flags >> 8)
 	uint64_t slot_mask;

@@ -52,7 +52,7 @@ __global__ void seed_index_kernel(SeedArgs a, int sid)
 	atomicOr(&a.bitmap1[bm1_word((uint32_t)h, a.bitmap1_words)], bm1_bits((uint32_t)h, a.bitmap1_k3));        // K bits, one word; bits of hash a only
 	uint64_t slot = h & a.slot_mask;
 	for (;;) {
-		const unsigned long long old = atomicCAS((unsigned long long*)&a.slots[slot].key, (unsigned long long)SEED_EMPTY, (unsigned long long)seed);
+		const unsigned long long old = atomicCAS((unsigned long long*)&a.slot(slot).key, (unsigned long long)SEED_EMPTY, (unsigned long long)seed);
 		if (old == SEED_EMPTY || old == seed) break;
 		slot = (slot + 1) & a.slot_mask;
 	}
@@ -71,9 +71,9 @@ __global__ void seed_reset_slots_kernel(SeedArgs a)
 {
 	const uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (slot > a.slot_mask) return;
-	const SeedSlot sl = a.slots[slot];
+	const SeedSlot sl = a.slot(slot);
 	if (sl.key == SEED_EMPTY || !(sl.flags & (SLOT_JOINED | SLOT_ERASED))) return;
-	a.slots[slot].flags = sl.flags & ~(uint32_t)(SLOT_JOINED | SLOT_ERASED);
+	a.slot(slot).flags = sl.flags & ~(uint32_t)(SLOT_JOINED | SLOT_ERASED);
 }
 
 // hashed seeds: the part of seed_index_kernel that masks non-complex query seeds, without the insertion
@@ -119,12 +119,25 @@ __global__ void seed_lists_kernel(SeedArgs a, int sid, const uint32_t* sorted_sl
 	while (e < n && sorted_slot[e] == k) ++e;
 	// a list of one query position (most seeds): head IS the position -- the probe that finds the slot has it without a second
 	// dependent random read
-	a.slots[k].head = e - i == 1 ? qlist[i] : (uint32_t)i;
+	a.slot(k).head = e - i == 1 ? qlist[i] : (uint32_t)i;
+	if (a.slot_shift == 6 && e - i == 1) {
+		// 64-byte slots (fused short-seed pipeline): the 48 letters around the seed's one query position, folded to 4 bits, ride in
+		// the slot's own line -- the stream's Hamming pre-filter of such a join then needs no second random read (seed_stream_fast_kernel)
+		const int8_t* w = a.qdata + a.q_begin + (int64_t)qlist[i] - 16;
+		uint32_t* out = a.slot_win(k);
+#pragma unroll
+		for (int x = 0; x < 6; ++x) {
+			uint32_t v = 0;
+#pragma unroll
+			for (int n = 0; n < 8; ++n) v |= ((uint32_t)w[8 * x + n] & 15u) << (4 * n);
+			out[x] = v;
+		}
+	}
 	// Search::mask_seeds evaluates the first query position of a joined group (seed_complexity.cpp:97-99) -- the smallest
 	// position here: the sort is stable. Whether that seed is complex does not depend on the join, so it is decided once here.
 	// (only the fused stream needs the answer before the join is known; otherwise seed_mask_kernel asks for the few joined groups)
 	const bool lowc = a.fused && a.params.seed_encoding == SEED_SPACED && !seed_is_complex(a.params, sid, a.qdata + a.q_begin + qlist[i]);
-	a.slots[k].flags = ((uint32_t)(e - i) << 8) | (lowc ? SLOT_LOWC : 0u);
+	a.slot(k).flags = ((uint32_t)(e - i) << 8) | (lowc ? SLOT_LOWC : 0u);
 }
 
 // Wave-aggregated append: the lanes of the wavefront that have an element reserve their slots with ONE atomic on the
@@ -150,7 +163,7 @@ __global__ void seed_stream_kernel(SeedArgs a, int sid)
 	if (p < a.t_end && seed_key_at(a.params, sid, a.tseed + p, seed)) {
 		slot = seed_hash(seed) & a.slot_mask;
 		for (;;) {
-			const SeedSlot sl = a.slots[slot];
+			const SeedSlot sl = a.slot(slot);
 			if (sl.key == SEED_EMPTY) break;
 			if (sl.key == seed) { found = true; fl = sl.flags; break; }
 			slot = (slot + 1) & a.slot_mask;
@@ -158,7 +171,7 @@ __global__ void seed_stream_kernel(SeedArgs a, int sid)
 	}
 	const unsigned long long idx = wave_append(a.matched_count, found);
 	if (!found) return;
-	if (!(fl & SLOT_JOINED)) a.slots[slot].flags = fl | SLOT_JOINED;      // benign race: every writer stores the same value
+	if (!(fl & SLOT_JOINED)) a.slot(slot).flags = fl | SLOT_JOINED;      // benign race: every writer stores the same value
 	if (idx < (unsigned long long)a.matched_cap) {
 		a.matched_slot[idx] = (uint32_t)slot;
 		a.matched_loc[idx] = p;
@@ -264,6 +277,25 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 	auto filter_list = [&](uint32_t slot, uint32_t head, uint32_t count, int64_t pos, uint32_t first, uint32_t step) {
 		uint32_t tw[12];
 		__builtin_memcpy(tw, a.tdata + pos - 16, 48);
+		if (a.slot_shift == 6 && count == 1) {
+			// the folded query window came with the slot's line: same pre-filter as below without touching the query block
+			uint32_t qf[6];
+			__builtin_memcpy(qf, a.slot_win(slot), 24);
+			int mism = 0;
+#pragma unroll
+			for (int w = 0; w < 6; ++w) {
+				uint32_t lo = tw[2 * w] & 0x0f0f0f0fu, hi = tw[2 * w + 1] & 0x0f0f0f0fu;
+				lo = (lo | (lo >> 4)) & 0x00ff00ffu; lo = (lo | (lo >> 8)) & 0xffffu;
+				hi = (hi | (hi >> 4)) & 0x00ff00ffu; hi = (hi | (hi >> 8)) & 0xffffu;
+				const uint32_t d = (lo | (hi << 16)) ^ qf[w];
+				mism += __builtin_popcount((((d & 0x77777777u) + 0x77777777u) | d) & 0x88888888u);
+			}
+			if (48 - mism < a.params.hamming_filter_id) return;
+			uint32_t qw[12];
+			__builtin_memcpy(qw, a.qdata + a.q_begin + (int64_t)head - 16, 48);
+			if (window_identity(tw, qw) >= a.params.hamming_filter_id) survive(slot, head, pos);
+			return;
+		}
 		if (a.qfold) {
 			// Pre-filter on letters folded to 4 bits (letter & 15: equal letters stay equal, so the folded identity count is an upper
 			// bound of the real one): the query side is read from a 1.5 MB array with two 16-byte requests per pair instead of three
@@ -312,13 +344,13 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 		uint32_t fl = 0, head = 0;
 		if (!LEVEL2 || ((a.bitmap[(uint32_t)(hh >> 32) & a.bitmap_mask] >> (uint32_t)(hh >> 59)) & 1u))
 			for (;;) {
-				const SeedSlot sl = a.slots[slot];
+				const SeedSlot sl = a.slot(slot);
 				if (sl.key == SEED_EMPTY) break;
 				if (sl.key == seed) { found = true; fl = sl.flags; head = sl.head; break; }
 				slot = (slot + 1) & a.slot_mask;
 			}
 		if (!found) return;
-		if (!(fl & SLOT_JOINED)) a.slots[slot].flags = fl | SLOT_JOINED;
+		if (!(fl & SLOT_JOINED)) a.slot(slot).flags = fl | SLOT_JOINED;
 		if (FUSED && (fl & SLOT_LOWC)) return;
 		const unsigned k = atomicAdd(&st_n, 1u);                 // LDS atomic
 		if (k < STAGE) {
@@ -412,7 +444,7 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 			if (count > LIGHT) {
 				const unsigned hk = atomicAdd(&hv_n, 1u);
 				if (hk < HEAVY) { hv_k[hk] = (uint16_t)k; continue; }
-				if (count == 0xffffu) count = a.slots[st_slot[k]].flags >> 8;
+				if (count == 0xffffu) count = a.slot(st_slot[k]).flags >> 8;
 			}
 			filter_list(st_slot[k], st_head[k], count, wg_base + st_loc[k], 0, 1);
 		}
@@ -421,7 +453,7 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 		for (unsigned h = 0; h < n_heavy; ++h) {
 			const unsigned k = hv_k[h];
 			uint32_t count = st_count[k];
-			if (count == 0xffffu) count = a.slots[st_slot[k]].flags >> 8;
+			if (count == 0xffffu) count = a.slot(st_slot[k]).flags >> 8;
 			filter_list(st_slot[k], st_head[k], count, wg_base + st_loc[k], threadIdx.x, 256);
 		}
 		__syncthreads();
@@ -450,13 +482,13 @@ __global__ void seed_mask_kernel(SeedArgs a, int sid)
 {
 	const uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (slot > a.slot_mask) return;
-	const SeedSlot sl = a.slots[slot];
+	const SeedSlot sl = a.slot(slot);
 	if (sl.key == SEED_EMPTY || !(sl.flags & SLOT_JOINED)) return;          // a free slot is all ones
 	const uint32_t count = sl.flags >> 8;
 	// Search::mask_seeds evaluates the first query position of the joined group (seed_complexity.cpp:97-99) = the smallest one:
 	// the lists are sorted by position. The fused pipeline has the answer in the slot (seed_lists_kernel).
 	if (a.fused ? !(sl.flags & SLOT_LOWC) : seed_is_complex(a.params, sid, a.qdata + a.q_begin + (count == 1 ? sl.head : a.qlist[sl.head]))) return;
-	a.slots[slot].flags = sl.flags | SLOT_ERASED;
+	a.slot(slot).flags = sl.flags | SLOT_ERASED;
 	const int t = sid * a.params.index_chunks + seed_chunk(a.params, seed_of_key(a.params, sid, sl.key));
 	for (uint32_t i = 0; i < count; ++i) {
 		const uint32_t x = count == 1 ? sl.head : a.qlist[sl.head + i];
@@ -473,11 +505,11 @@ __global__ void seed_mask_joined_kernel(SeedArgs a, int sid, int64_t n_matched)
 	const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (m >= n_matched) return;
 	const uint32_t slot = a.matched_slot[m];
-	const SeedSlot sl = a.slots[slot];
+	const SeedSlot sl = a.slot(slot);
 	if (sl.flags & SLOT_ERASED) return;
 	const uint32_t count = sl.flags >> 8;
 	if (seed_is_complex(a.params, sid, a.qdata + a.q_begin + (count == 1 ? sl.head : a.qlist[sl.head]))) return;
-	if (atomicOr(&a.slots[slot].flags, (uint32_t)SLOT_ERASED) & SLOT_ERASED) return;
+	if (atomicOr(&a.slot(slot).flags, (uint32_t)SLOT_ERASED) & SLOT_ERASED) return;
 	const int t = sid * a.params.index_chunks + seed_chunk(a.params, seed_of_key(a.params, sid, sl.key));
 	for (uint32_t i = 0; i < count; ++i) {
 		const uint32_t x = count == 1 ? sl.head : a.qlist[sl.head + i];
@@ -598,7 +630,7 @@ __global__ __launch_bounds__(128) void seed_pair_kernel(SeedArgs a, int sid, int
 	int64_t sloc = 0;
 	if (m < n_matched) {
 		slot = a.matched_slot[m];
-		const SeedSlot sl = a.slots[slot];                // key, list start, size and state of the seed in one 16-byte read
+		const SeedSlot sl = a.slot(slot);                // key, list start, size and state of the seed in one 16-byte read
 		if (!(sl.flags & SLOT_ERASED)) {
 			head = sl.head; count = sl.flags >> 8;
 			sloc = a.matched_loc[m];
@@ -655,7 +687,7 @@ __global__ __launch_bounds__(256) void seed_pair_tiled_kernel(SeedArgs a, int si
 	for (int w = 0; w < 12; ++w) sw[w] = 0;
 	if (m < n_matched) {
 		slot = a.matched_slot[m];
-		const SeedSlot sl = a.slots[slot];
+		const SeedSlot sl = a.slot(slot);
 		if (!(sl.flags & SLOT_ERASED)) {
 			head = sl.head; count = sl.flags >> 8;
 			sloc = a.matched_loc[m];
@@ -744,7 +776,7 @@ __global__ __launch_bounds__(POST_THREADS) void seed_score_kernel(SeedArgs a, in
 	// (the kernel argument is not modified: a private copy of the 3 KB struct would live in scratch memory)
 	if (i < n_survivors) {
 		const SeedSurvivor sv = a.survivors[i];
-		const SeedSlot sl = a.slots[sv.slot];
+		const SeedSlot sl = a.slot(sv.slot);
 		if (!(sl.flags & SLOT_ERASED)) {                  // (the fused stream kernel never lets a pair of a non-complex seed through)
 			const int64_t qp = a.q_begin + sv.x;
 			int score;
@@ -884,7 +916,7 @@ __global__ __launch_bounds__(256) void seed_deferred_kernel(SeedArgs a, int sid,
 	const uint32_t qid = a.qid_of[qp];
 	const int query_len = (int)(a.qlimits[qid + 1] - a.qlimits[qid] - 1);
 	if (score <= ungapped_cutoff(a.params, query_len)) return;
-	finish_pair(a, sid, seed_chunk(a.params, seed_of_key(a.params, sid, a.slots[slot].key)), a.mask_time + qp, q, s, qid, (int)(qp - a.qlimits[qid]), query_len, sloc, score);
+	finish_pair(a, sid, seed_chunk(a.params, seed_of_key(a.params, sid, a.slot(slot).key)), a.mask_time + qp, q, s, qid, (int)(qp - a.qlimits[qid]), query_len, sloc, score);
 }
 
 // DMND_TRACE: number of (joined reference position, query position) pairs the Hamming filter sees
@@ -893,7 +925,7 @@ __global__ void seed_count_pairs_kernel(SeedArgs a, int64_t n_matched, unsigned 
 	const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	unsigned long long n = 0;
 	if (m < n_matched) {
-		const SeedSlot sl = a.slots[a.matched_slot[m]];
+		const SeedSlot sl = a.slot(a.matched_slot[m]);
 		if (!(sl.flags & SLOT_ERASED)) n = sl.flags >> 8;
 	}
 	for (int o = 32; o > 0; o >>= 1) n += (unsigned long long)__shfl_down((long long)n, o);
@@ -1137,3 +1169,7 @@ hipError_t launch_seed_deferred(const SeedArgs& a, int sid, int64_t n_deferred, 
 }
 
 }  // namespace dmnd
+
+// dmnd_init: the first launch of a kernel of this translation unit loads its code object onto the device
+namespace { __global__ void touch_seed_kernel() {} }
+extern "C" hipError_t dmnd_touch_seed(hipStream_t st) { hipLaunchKernelGGL(touch_seed_kernel, dim3(1), dim3(64), 0, st); return hipGetLastError(); }

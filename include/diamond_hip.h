@@ -229,6 +229,10 @@ int dmnd_seed_params_default(dmnd_seed_params* p, int threads, const dmnd_params
  * spaced seeds, ungapped e-value filter off (the --fast family). Hits stay in device memory;
  * *n_hits returns their number. */
 int dmnd_seed_search(dmnd_ctx* ctx, const dmnd_seed_params* params, int64_t* n_hits);
+/* Optional: allocates the device buffers of a seed search with these parameters for a query block of query_block_len bytes
+ * (SequenceSet layout) ahead of time. May run on another host thread while the caller uploads and masks the blocks of the same
+ * context: the first search then starts without tens of milliseconds of allocations. Changes no result. */
+int dmnd_seed_reserve(dmnd_ctx* ctx, const dmnd_seed_params* params, int64_t query_block_len);
 /* One query block against many reference blocks: with reuse on, dmnd_seed_search keeps the query side of every shape (seed table,
  * position lists, bitmaps) in HBM and a later call on the same query block and parameters only resets the per-reference-block
  * marks instead of indexing the queries again (the reference rebuilds its query seed arrays for every block pair). Off by default;
