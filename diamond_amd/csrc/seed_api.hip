@@ -290,9 +290,7 @@ static SeedSizes seed_sizes(const dmnd_ctx* c, const SeedParams& sp, int64_t nq_
 	// Query index reuse (dmnd_set_query_index_reuse; a query block against many reference blocks): the tables, lists and bitmaps of
 	// ALL shapes stay resident between calls and a call that finds them built for the same query block and parameters only resets
 	// the per-block state (join / erase marks) instead of rebuilding them. Needs S buffer sets; refused above 64 GiB.
-	// fused pipeline: 64-byte slots that carry the folded query window of single-position seeds (DMND_SEED_WIDE_SLOTS=0: 16-byte slots)
-	static const bool wide_env = [] { const char* e = getenv("DMND_SEED_WIDE_SLOTS"); return !e || atoi(e) != 0; }();
-	z.slot_shift = fused && wide_env ? 6 : 4;
+	z.slot_shift = 4;
 	const size_t set_bytes = (z.slots << z.slot_shift) + 2 * (size_t)nq_pos * sizeof(uint32_t) + (size_t)(bm_words + bm1_words) * sizeof(uint32_t);
 	const bool reuse = c->reuse_query_index && set_bytes * (size_t)S <= ((size_t)64 << 30) && !getenv("DMND_SEED_MATCHED_CAP");
 	const int SB = (fused && !reuse) ? 1 : S;            // shapes that own buffers at the same time

@@ -40,10 +40,12 @@ struct SeedArgs {
 	const uint32_t* qid_of;                       // query position -> query id
 	uint8_t* mask_time;                           // per query letter: (shape, chunk) time of its SEED_MASK bit
 	// per-shape query seed table
-	SeedSlot* slots;              // slot i lives at byte offset i << slot_shift: 16-byte slots, or (fused short-seed pipeline) 64-byte
-	int slot_shift;               // slots whose bytes 16..39 hold the folded window of the seed's one query position (slot_win)
+	SeedSlot* slots;              // 16-byte slots: key, list start (or the seed's one query position), state | list size
+	int slot_shift;               // log2 of the slot stride in bytes (4). Tried and dropped in round 3: 64-byte slots carrying the folded
+	                              // 48-letter window of single-position seeds, so that the fused Hamming pre-filter needs no second random
+	                              // read -- the 512 MB table no longer fits the 256 MB Infinity Cache and the stream + filter kernel of C3
+	                              // went from 124 to 137 ms per 16 shapes (L2 misses 3.15e8 -> 4.05e8 per launch)
 	__host__ __device__ SeedSlot& slot(uint64_t i) const { return *reinterpret_cast<SeedSlot*>(reinterpret_cast<char*>(slots) + (i << slot_shift)); }
-	__host__ __device__ uint32_t* slot_win(uint64_t i) const { return reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(slots) + (i << slot_shift) + 16); }
 	uint32_t* qslot;                              // per query position: slot of its seed (LIST_END: no seed); input of the list sort
 	const uint32_t* qlist;                        // query positions grouped by slot (SeedSlot::head = start, count in flags >> 8)
 	uint64_t slot_mask;

@@ -120,19 +120,6 @@ __global__ void seed_lists_kernel(SeedArgs a, int sid, const uint32_t* sorted_sl
 	// a list of one query position (most seeds): head IS the position -- the probe that finds the slot has it without a second
 	// dependent random read
 	a.slot(k).head = e - i == 1 ? qlist[i] : (uint32_t)i;
-	if (a.slot_shift == 6 && e - i == 1) {
-		// 64-byte slots (fused short-seed pipeline): the 48 letters around the seed's one query position, folded to 4 bits, ride in
-		// the slot's own line -- the stream's Hamming pre-filter of such a join then needs no second random read (seed_stream_fast_kernel)
-		const int8_t* w = a.qdata + a.q_begin + (int64_t)qlist[i] - 16;
-		uint32_t* out = a.slot_win(k);
-#pragma unroll
-		for (int x = 0; x < 6; ++x) {
-			uint32_t v = 0;
-#pragma unroll
-			for (int n = 0; n < 8; ++n) v |= ((uint32_t)w[8 * x + n] & 15u) << (4 * n);
-			out[x] = v;
-		}
-	}
 	// Search::mask_seeds evaluates the first query position of a joined group (seed_complexity.cpp:97-99) -- the smallest
 	// position here: the sort is stable. Whether that seed is complex does not depend on the join, so it is decided once here.
 	// (only the fused stream needs the answer before the join is known; otherwise seed_mask_kernel asks for the few joined groups)
@@ -277,25 +264,6 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 	auto filter_list = [&](uint32_t slot, uint32_t head, uint32_t count, int64_t pos, uint32_t first, uint32_t step) {
 		uint32_t tw[12];
 		__builtin_memcpy(tw, a.tdata + pos - 16, 48);
-		if (a.slot_shift == 6 && count == 1) {
-			// the folded query window came with the slot's line: same pre-filter as below without touching the query block
-			uint32_t qf[6];
-			__builtin_memcpy(qf, a.slot_win(slot), 24);
-			int mism = 0;
-#pragma unroll
-			for (int w = 0; w < 6; ++w) {
-				uint32_t lo = tw[2 * w] & 0x0f0f0f0fu, hi = tw[2 * w + 1] & 0x0f0f0f0fu;
-				lo = (lo | (lo >> 4)) & 0x00ff00ffu; lo = (lo | (lo >> 8)) & 0xffffu;
-				hi = (hi | (hi >> 4)) & 0x00ff00ffu; hi = (hi | (hi >> 8)) & 0xffffu;
-				const uint32_t d = (lo | (hi << 16)) ^ qf[w];
-				mism += __builtin_popcount((((d & 0x77777777u) + 0x77777777u) | d) & 0x88888888u);
-			}
-			if (48 - mism < a.params.hamming_filter_id) return;
-			uint32_t qw[12];
-			__builtin_memcpy(qw, a.qdata + a.q_begin + (int64_t)head - 16, 48);
-			if (window_identity(tw, qw) >= a.params.hamming_filter_id) survive(slot, head, pos);
-			return;
-		}
 		if (a.qfold) {
 			// Pre-filter on letters folded to 4 bits (letter & 15: equal letters stay equal, so the folded identity count is an upper
 			// bound of the real one): the query side is read from a 1.5 MB array with two 16-byte requests per pair instead of three
