@@ -817,6 +817,7 @@ int run_blastp(const Options& o)
 		dmnd_ctx* c = dmnd_create(n_gpus > 1 && !share_gpu ? g : -1, &p);
 		if (!c) throw std::runtime_error(dmnd_last_error());
 		ctxs[(size_t)g] = c;
+		g_timeline.mark("context " + std::to_string(g) + " created");
 		chk(dmnd_set_max_target_seqs(c, o.k));
 		chk(dmnd_set_top_percent(c, o.top));
 		chk(dmnd_set_filters(c, o.min_id, o.query_cover, o.subject_cover, o.min_score));
@@ -962,8 +963,10 @@ int run_blastp(const Options& o)
 			const double up = up_ms[(size_t)g];
 			auto t0 = std::chrono::steady_clock::now();
 			int64_t mq = 0, ml = 0;
+			g_timeline.mark("query block uploaded");
 			if (tantan) chk(dmnd_mask_block(ctx, DMND_QUERY, g == 0 ? q.data.data() : nullptr, &mq));
 			const double mk = ms_since(t0);
+			if (tantan) g_timeline.mark("query block masked (tantan)");
 			if (motifs) chk(dmnd_soft_mask_block(ctx, DMND_QUERY, &ml));
 			if (blastx) chk(dmnd_set_query_source_lengths(ctx, source_len.data() + qr.begin, (int64_t)(qr.end - qr.begin)));
 			std::lock_guard<std::mutex> lock(merge_mutex);
@@ -1036,7 +1039,13 @@ int run_blastp(const Options& o)
 			std::vector<dmnd_seed_hit> hits((size_t)n_hits);
 			chk(dmnd_seed_hits(ctx, hits.data(), n_hits));
 			const double sd = ms_since(t0);
-			g_timeline.mark("seed stage of block " + std::to_string(bi) + " done");
+			if (g_timeline.on) {
+				double ms[5] = { 0, 0, 0, 0, 0 };
+				(void)dmnd_seed_kernel_ms(ctx, ms);
+				char b[160];
+				std::snprintf(b, sizeof b, " (kernels: index %.2f, stream %.2f, mask %.2f, pairs %.2f, all %.2f ms)", ms[0], ms[1], ms[2], ms[3], ms[4]);
+				g_timeline.mark("seed stage of block " + std::to_string(bi) + " done" + b);
+			}
 			if (lazy_masking) { mask_target(); g_timeline.mark("reference block " + std::to_string(bi) + " masked lazily"); }
 			t0 = std::chrono::steady_clock::now();
 			if (o.no_self_hits) {

@@ -53,6 +53,16 @@ int oracle_banded_cols(int qlen, int tlen, int d_begin, int d_end)
 	return j1 - pos;
 }
 
+/* Optional model of ONE CHANNEL of the reference's 8-bit vector pass whose own band is narrower than the vector's band
+ * (banded_swipe.h:211-224,277-297, RangePartition: the rows of the vector band are cut into parts, and on a part that lies outside
+ * a channel's own band the lane mask is ADDED, saturating, to vgap (once per part), hgap and the match scores (every cell)). For
+ * the biased int8 vectors the mask is -128, not minus infinity, so a gap value of 128 or more survives as value - 128 in a cell
+ * outside the band. oracle_set_channel_band(own_d_begin, own_d_end, 128) makes oracle_banded_swipe treat its d_begin / d_end as
+ * the VECTOR band and the given band as the channel's own; penalty 0 switches the model off. Only tests/test_oracle_swipe.py uses
+ * it, to show that the leak never reaches a result. */
+static int g_own_b = 0, g_own_e = 0, g_pen = 0;
+void oracle_set_channel_band(int own_d_begin, int own_d_end, int penalty) { g_own_b = own_d_begin; g_own_e = own_d_end; g_pen = penalty; }
+
 /* One target through the banded sweep.
  * mode: ORACLE_SCORE_ONLY  -> score (DummyRowCounter: max_band_row stays 0)        swipe_wrapper.cpp:187-190
  *       ORACLE_COORDS      -> + end coordinates (VectorRowCounter)                 swipe_wrapper.cpp:196-200
@@ -103,6 +113,8 @@ int oracle_banded_swipe(const int8_t* query, int qlen, const int8_t* cbs,
 		const int t_raw = target[pos];                                /* VectorIdMask compares the raw target byte, stat_cell.h:41-44 */
 		const int8_t* mrow = matrix8 + 32 * t;
 		int vgap = 0, va = 0, vb = 0, col_best = 0, i_max = 0;
+		int prev_own = g_pen ? 0 : 1;                               /* the part above the own band, if any, is entered first */
+		if (g_pen && g_own_b > d_begin) vgap = imax(vgap - g_pen, 0);
 		for (int i = i0_; i < i1_; ++i) {
 			const int r = i - i0;
 			const int q = query[i] & LETTER_MASK;
@@ -110,6 +122,12 @@ int oracle_banded_swipe(const int8_t* query, int qlen, const int8_t* cbs,
 			int m = mrow[q];
 			if (cbs)
 				m += cbs[i];
+			if (g_pen) {                                             /* channel model: lane mask on the parts outside the own band */
+				const int d = i - pos, own = d >= g_own_b && d < g_own_e;
+				if (!own && prev_own && d >= g_own_e) vgap = imax(vgap - g_pen, 0);      /* vgap += target_mask at the start of the part below */
+				if (!own) { hg = imax(hg - g_pen, 0); m -= g_pen; }
+				prev_own = own;
+			}
 			int cur = score[r] + m;                                 /* cell_update.h:116-117 */
 			int ca = 0, cb = 0, hga = 0, hgb = 0;
 			if (fwd) {                                              /* stat_cell.h:225-231 */

@@ -19,6 +19,8 @@ typedef struct {
 
 int oracle_banded_cols(int qlen, int tlen, int d_begin, int d_end);
 
+/* channel model of the reference's 8-bit vector pass, see banded_swipe.c; penalty 0 = off (the default) */
+void oracle_set_channel_band(int own_d_begin, int own_d_end, int penalty);
 int oracle_banded_swipe(const int8_t* query, int qlen, const int8_t* cbs,
 	const int8_t* target, int tlen, int d_begin, int d_end,
 	const int8_t* matrix8, int gap_open, int gap_extend, int mode,

@@ -63,6 +63,11 @@ def banded_swipe(query, cbs, target, d_begin, d_end, matrix8, gap_open, gap_exte
     return rc, out.asdict(), tr[:out.transcript_len].copy()
 
 
+def set_channel_band(own_d_begin=0, own_d_end=0, penalty=0):
+    """Model of one channel of the reference's 8-bit vector pass inside a wider vector band (oracle/banded_swipe.c); penalty 0 = off."""
+    lib().oracle_set_channel_band(int(own_d_begin), int(own_d_end), int(penalty))
+
+
 def swipe_stats(query, cbs, target, d_begin, d_end, matrix8, gap_open, gap_extend, hsp_values):
     q = np.ascontiguousarray(query, dtype=np.int8)
     t = np.ascontiguousarray(target, dtype=np.int8)

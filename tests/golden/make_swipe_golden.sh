@@ -96,5 +96,33 @@ DIAMOND_TAP_EXT="$HERE/ext_blastx.tap" \
 # 10. the long proteins of step 3 end to end (round 2 takes the statistics-without-traceback path: DP size > 1e6 cells)
 DIAMOND_TAP_EXT="$HERE/ext_long.tap" \
   "$TAP" blastp --masking 0 --motif-masking 0 --algo 0 -q "$TMP/long_q.faa" -d "$TMP/long_db.faa" -o "$HERE/long.tsv" -p1 2>/dev/null
+# 11. duplicate query seeds with ambiguity letters: 16-letter windows that differ only by A vs B / J / Z at a
+#     care position of the --fast shape (same reduced seed, but seed_is_complex rejects the window with the ambiguity letter),
+#     as query pairs in both file orders; targets hold the A window. Queries / database are kept as bjz_q.faa / bjz_db.faa.
+python3 - "$HERE" <<'PY'
+import sys
+import numpy as np
+rng = np.random.default_rng(42)
+AA = "ARNDCQEGHILKMFPSTWYV"
+rnd = lambda n: "".join(AA[i] for i in rng.integers(0, 20, n))
+care = [0, 1, 3, 4, 5, 7, 9, 10, 12, 13, 14, 15]
+qs, ts, n = [], [], 0
+for amb in "BJZ":
+    for typ in (1, 2):
+        for rep in range(20):
+            cp = care[rng.integers(0, len(care))]
+            w = list(rnd(16)); w[cp] = "A"; W = "".join(w)
+            w2 = list(W); w2[cp] = amb; W2 = "".join(w2)
+            a, b = rnd(40) + W + rnd(40), rnd(40) + W2 + rnd(40)
+            for s in ((a, b) if typ == 1 else (b, a)):
+                qs.append((">q%d_%s_t%d" % (n, amb, typ), s)); n += 1
+            ts.append((">t%d" % len(ts), rnd(60) + W + rnd(60)))
+for i in range(300):
+    ts.append((">r%d" % i, rnd(int(rng.integers(100, 400)))))
+open(sys.argv[1] + "/bjz_q.faa", "w").write("".join("%s\n%s\n" % x for x in qs))
+open(sys.argv[1] + "/bjz_db.faa", "w").write("".join("%s\n%s\n" % x for x in ts))
+PY
+DIAMOND_TAP_EXT="$HERE/ext_bjz.tap" \
+  "$TAP" blastp --fast --masking 0 --motif-masking 0 --algo 0 -q "$HERE/bjz_q.faa" -d "$HERE/bjz_db.faa" -o "$TMP/bjz.out" -p1 2>/dev/null
 ls -la "$HERE"/*.tap
 rm -rf "$TMP"

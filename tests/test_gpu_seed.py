@@ -37,8 +37,9 @@ def to_hip_params(cfg):
     return p
 
 
-@pytest.mark.parametrize("tap", ["ext_fast.tap", "ext_fast_synth.tap", "ext_6x10.tap", "ext_default.tap", "ext_default_synth.tap", "ext_sensitive.tap", "ext_blastx.tap"])
+@pytest.mark.parametrize("tap", ["ext_fast.tap", "ext_fast_synth.tap", "ext_6x10.tap", "ext_default.tap", "ext_default_synth.tap", "ext_sensitive.tap", "ext_blastx.tap", "ext_bjz.tap"])
 def test_seed_hits_equal_reference(ctx, tap):
+    # ext_bjz.tap: query windows that share a seed while one of them holds B / J / Z at a care position (see test_oracle_seed.py)
     cfg, recs = read_ext_tap(os.path.join(GOLDEN, tap))
     ctx.upload_block(hip.QUERY, cfg["query"]["data"], cfg["query"]["limits"])
     ctx.upload_block(hip.TARGET, cfg["target"]["data"], cfg["target"]["limits"])

@@ -59,3 +59,24 @@ def test_query_indexed_mode_equals_reference(tap):
     c.seed_encoding = 0
     other = orc.seed_search(c, cfg["query"]["data"], cfg["query"]["limits"], cfg["target"]["data"], cfg["target"]["limits"])
     print("spaced-seed rules on the same input differ in %d hits" % len(set(hit_multiset(other)) ^ set(hit_multiset(ref))))
+
+
+def test_duplicate_query_seeds_with_ambiguity_letters():
+    """SURVEY 8 row a5, the corner DESIGN.md used to list as a deviation. B, J and Z reduce to class 0 like A (Reduction's map_ is
+    zero-filled, basic.cpp:269), so a window with B at a care position carries the SAME seed as the window with A there -- but
+    seed_is_complex answers "not complex" for it (letter >= TRUE_AA, seed_complexity.cpp:43-44). mask_seeds tests the FIRST query
+    position of a joined group; the seed stage here tests the SMALLEST. They are the same position: the query seed array of a
+    partition is filled in block order (BufferedWriter, seed_array_impl.h:43-93), radix_cluster scatters in input order
+    (radix_cluster.h:62-101) and both join variants write a group's values in input order (hash_join.h:98-104,159-165).
+    tests/golden/ext_bjz.tap provokes it from the reference itself: 120 query pairs whose 16-letter windows differ only by A vs
+    B / J / Z at one care position, in both file orders -- ambiguity letter second: the group is kept and both queries get their
+    hit; ambiguity letter first: the whole group is erased (golden minted by make_swipe_golden.sh step 11)."""
+    cfg, recs = read_ext_tap(os.path.join(GOLDEN, "ext_bjz.tap"))
+    c = orc.seed_cfg_from_tap(cfg, blosum62_matrix8())
+    hits = orc.seed_search(c, cfg["query"]["data"], cfg["query"]["limits"], cfg["target"]["data"], cfg["target"]["limits"])
+    ref = np.concatenate([r["hits"] for r in recs])
+    assert hit_multiset(hits) == hit_multiset(ref) and len(ref) > 100
+    # the two arrangements really behave differently in the reference: queries 0..39 (B, complex window first) all have hits,
+    # of queries 40..79 (B first) only the few that another seed reaches
+    with_hits = {int(r["query_id"]) for r in recs if len(r["hits"])}
+    assert all(q in with_hits for q in range(40)) and sum(q in with_hits for q in range(40, 80)) < 12

@@ -68,3 +68,43 @@ def test_golden_covers_all_modes():
             for h in rec["hsps"]:
                 seen.add((rec["hsp_values"] != 0, h["swipe_bin"] >= 3))
     assert {(False, False), (True, False), (True, True)} <= seen
+
+
+def test_int8_lane_mask_leak_never_reaches_a_result():
+    """SURVEY 8 row a15, the corner DESIGN.md section 2 lists: in the reference's 8-bit vector pass a channel whose band is narrower
+    than the vector's band has the lane mask -128 (not minus infinity) ADDED to vgap, hgap and the match scores of the out-of-band
+    parts (banded_swipe.h:277-297), so a gap value E >= 128 at a band edge survives as E - 128 in an out-of-band cell. The device
+    kernels give every target exactly its own band. That is the same result: the leaked value can only re-enter the band through
+    the gap of the cell next to it, where it is at least 128 + gap_open + 2 gap_extend - (largest mismatch penalty) below the diagonal
+    predecessor's contribution to that very cell. Here the claim is checked on the reference's own work items: every golden target
+    with a score in the range where the 8-bit pass is the final one and gaps of 128 and more exist (139..254) is swept as one
+    channel of a wider vector band, mask -128 (oracle_set_channel_band), in several placements -- score, coordinates, statistics
+    and transcript stay what the reference reported."""
+    rng = np.random.default_rng(5)
+    checked = 0
+    for tap in TAPS[:2] + ["swipe_fast_synth.tap"]:
+        hdr, recs = read_tap(os.path.join(GOLDEN, tap))
+        M, go, ge = hdr["matrix8"], hdr["gap_open"], hdr["gap_extend"]
+        for rec in recs:
+            q, cbs = rec["query"], rec["cbs"]
+            for t, hsps in _targets_with_hsps(rec):
+                if len(hsps) != 1 or not (128 + go + ge <= hsps[0]["score"] < 255):
+                    continue
+                h = hsps[0]
+                mode = orc.TRACEBACK if (rec["hsp_values"] != 0 and h["swipe_bin"] < 3) else orc.SCORE_ONLY
+                for _ in range(3):
+                    lo, hi = int(rng.integers(0, 48)), int(rng.integers(0, 48))
+                    if lo + hi == 0:
+                        lo = 7
+                    try:
+                        orc.set_channel_band(t["d_begin"], t["d_end"], 128)
+                        rc, o, tr = orc.banded_swipe(q, cbs, t["seq"], t["d_begin"] - lo, t["d_end"] + hi, M, go, ge, mode)
+                    finally:
+                        orc.set_channel_band(0, 0, 0)
+                    assert rc == 0 and o["score"] == h["score"], (tap, lo, hi, o["score"], h["score"])
+                    if mode == orc.TRACEBACK:
+                        for k in COORD_KEYS + ["positives"]:
+                            assert o[k] == h[k], (k, lo, hi, o, h)
+                        assert np.array_equal(h["transcript"][:-1], tr)
+                    checked += 1
+    assert checked > 100
