@@ -249,6 +249,7 @@ def main():
     ap.add_argument("--host-threads", type=int, default=None, help="host threads of the extension stage per rank, divided among the extension contexts (default 12, fewer per rank with several ranks)")
     ap.add_argument("--shard", choices=["db", "query"], default="db")
     ap.add_argument("--ext-contexts", type=int, default=3, help="batches extended concurrently (each on its own context and host thread team)")
+    ap.add_argument("--seed-contexts", type=int, default=2, help="seed stages in flight at the same time (own context and stream each; one with several database blocks per rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the whole-process comparison (diamond-hip against the reference binary on files)")
     ap.add_argument("--no-pipeline", action="store_true", help="run seed stage and extension stage of a batch back to back on one context")
@@ -321,7 +322,17 @@ def main():
     # context that extends it and is aliased (dmnd_share_block), and the query seed index built for the first block of a batch
     # is kept for its other blocks (dmnd_set_query_index_reuse; reset at the start of every batch, so that every step still
     # indexes its query block once, as a run over many query blocks does)
-    ctxs_seed = [make_ctx(None)] if NB > 1 else ([make_ctx(0)] if pipeline else ctxs)
+    # One database block: SC seed stages run at the same time, each on its own context -- the reference stream of one batch fills
+    # the chip, but the small kernels around it (query index, list sort, mask, pair filter, left-most rule) and the host's waits
+    # between them do not, and another batch's stream runs in those gaps.
+    SC = 1 if (NB > 1 or not pipeline) else max(1, args.seed_contexts)
+    ctxs_seed = [make_ctx(None)] if NB > 1 else ([make_ctx(0) for _ in range(SC)] if pipeline else ctxs)
+    import queue as queue_mod
+    import threading
+    seed_free = queue_mod.Queue()
+    for c in ctxs_seed:
+        seed_free.put(c)
+    seed_lock = threading.Lock()
     # E batches are extended at the same time, each on its own context (own streams, buffers and host thread team): while one
     # batch is in a host phase (chaining, culling) the other one's sweep or walk runs, which the seed stage alone did not fill
     E = max(1, args.ext_contexts) if pipeline else 1
@@ -332,17 +343,22 @@ def main():
 
     def seed_stage(b=0):
         torch.cuda.set_device(local_rank)
-        c = ctxs_seed[0]
-        if NB > 1:
-            if b == 0:
-                c.set_query_index_reuse(True)               # drops the index of the previous batch
-            c.share_block(hip.TARGET, ctxs[b])
-        t_s = time.perf_counter()
-        hits = c.seed_search(seed_params)
-        state.setdefault("seed_wall", []).append((time.perf_counter() - t_s) * 1e3)
-        ms = c.seed_kernel_ms()
-        state["stream_ms"] += ms[1]                         # every seed stage that ran since the counters were reset
-        state["stream_launches"] += seed_params.n_shapes
+        c = seed_free.get()
+        try:
+            if NB > 1:
+                if b == 0:
+                    c.set_query_index_reuse(True)               # drops the index of the previous batch
+                c.share_block(hip.TARGET, ctxs[b])
+            t_s = time.perf_counter()
+            hits = c.seed_search(seed_params)
+            wall = (time.perf_counter() - t_s) * 1e3
+            ms = c.seed_kernel_ms()
+        finally:
+            seed_free.put(c)
+        with seed_lock:
+            state.setdefault("seed_wall", []).append(wall)
+            state["stream_ms"] += ms[1]                         # every seed stage that ran since the counters were reset
+            state["stream_launches"] += seed_params.n_shapes
         return hits, ms
 
     def finish(parts):
@@ -408,11 +424,11 @@ def main():
 
     if pipeline:
         import concurrent.futures
-        seed_pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
+        seed_pool = concurrent.futures.ThreadPoolExecutor(max_workers=SC)
         finish_pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
         ext_pools = [concurrent.futures.ThreadPoolExecutor(max_workers=1) for _ in range(E)]      # a context runs one call at a time
 
-    PREFETCH = max(2, E + 1)        # seed stages in flight or finished ahead of the extension (a bounded prefetch queue, like a data loader's)
+    PREFETCH = max(2, E + 1, 2 * SC)        # seed stages in flight or finished ahead of the extension (a bounded prefetch queue, like a data loader's)
 
     def run(n_steps, queue):
         """n_steps batches: every step takes the oldest seed-stage result of the queue (computed during earlier steps; by the
@@ -538,8 +554,8 @@ def main():
             "seed_kernel_ms": dict(zip(["index_queries", "stream_reference", "mask_groups", "pair_filter", "total"], state["seed_ms"])),
             # seed-stage Gletters/s = (L_q + L_r) x shapes / seed-stage seconds (device time of its kernels)
             "seed_stage_gletters_per_s": (NB * int(w.ql[-1] - w.ql[0]) + sum(int(b[3][-1] - b[3][0]) for b in w.blocks)) * seed_params.n_shapes / max(state["seed_ms"][4], 1e-9) / 1e6,
-            "pipeline": ("seed stages run on a second context (own low-priority stream), up to %d batches ahead of the extension stage; %d batches are extended at the same time "
-                         "(own context and a team of %d host threads each)" % (PREFETCH, E, ext_threads)) if pipeline else "off",
+            "pipeline": ("%d seed stage(s) at a time on their own contexts (low-priority streams), up to %d batches ahead of the extension stage; %d batches are extended at the same time "
+                         "(own context and a team of %d host threads each)" % (SC, PREFETCH, E, ext_threads)) if pipeline else "off",
             "ms_each_step": each,
             "latency_in_pipeline": lat,
             "alone": alone,
