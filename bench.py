@@ -248,8 +248,8 @@ def main():
     ap.add_argument("--families", type=int, default=None, help="protein families of 10 members in the database (default 100000; C5: 500000)")
     ap.add_argument("--host-threads", type=int, default=None, help="host threads of the extension stage per rank, divided among the extension contexts (default 12, fewer per rank with several ranks)")
     ap.add_argument("--shard", choices=["db", "query"], default="db")
-    ap.add_argument("--ext-contexts", type=int, default=3, help="batches extended concurrently (each on its own context and host thread team)")
-    ap.add_argument("--seed-contexts", type=int, default=2, help="seed stages in flight at the same time (own context and stream each; one with several database blocks per rank)")
+    ap.add_argument("--ext-contexts", type=int, default=None, help="batches extended concurrently, each on its own context and host thread team (default 3; 2 with several database blocks per rank)")
+    ap.add_argument("--seed-contexts", type=int, default=1, help="seed stages in flight at the same time (own context and stream each; one with several database blocks per rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the whole-process comparison (diamond-hip against the reference binary on files)")
     ap.add_argument("--no-pipeline", action="store_true", help="run seed stage and extension stage of a batch back to back on one context")
@@ -293,6 +293,11 @@ def main():
     # every rank of a database-sharded run extends 1/N of the seed hits: its host part needs correspondingly fewer threads, and N
     # ranks share the node's cores
     threads = max(1, args.host_threads) if args.host_threads else (12 if world == 1 else max(3, 24 // world))
+    many_blocks = CONFIGS[args.config].get("blocks", 1) > world
+    if many_blocks and not args.host_threads:
+        threads = max(threads, min(16, cgroup_cpus()) // max(world, 1))      # the host part of 8 blocks per batch is the bound of C5 (measured: 86 -> 66 ms per step)
+    if args.ext_contexts is None:
+        args.ext_contexts = 2 if many_blocks else 3
 
     if args.queries is None:
         args.queries = CONFIGS[args.config].get("queries", 10_000)
@@ -322,9 +327,9 @@ def main():
     # context that extends it and is aliased (dmnd_share_block), and the query seed index built for the first block of a batch
     # is kept for its other blocks (dmnd_set_query_index_reuse; reset at the start of every batch, so that every step still
     # indexes its query block once, as a run over many query blocks does)
-    # One database block: SC seed stages run at the same time, each on its own context -- the reference stream of one batch fills
-    # the chip, but the small kernels around it (query index, list sort, mask, pair filter, left-most rule) and the host's waits
-    # between them do not, and another batch's stream runs in those gaps.
+    # --seed-contexts N: N seed stages at the same time, each on its own context. Measured on C2 (round 3): 3.38 / 3.33 / 3.46 ms per
+    # step with 1 / 2 / 3 -- the device is the bound (the stream kernels of two batches share the L2 request rate, each takes twice
+    # as long), so the default stays 1.
     SC = 1 if (NB > 1 or not pipeline) else max(1, args.seed_contexts)
     ctxs_seed = [make_ctx(None)] if NB > 1 else ([make_ctx(0) for _ in range(SC)] if pipeline else ctxs)
     import queue as queue_mod
