@@ -579,7 +579,7 @@ def main():
         ref_letters = sum(int(b[3][-1] - b[3][0]) for b in w.blocks) // NB          # letters of one launch = one database block
         alg_bytes = 17 * ref_letters
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        k_alone = alone["seed_kernel_ms"][1] / seed_params.n_shapes
+        k_alone = alone["seed_kernel_ms"][1] / (seed_params.n_shapes * NB)       # the serial step runs one launch per shape and database block
         buf_a = torch.empty(1 << 30, dtype=torch.uint8, device=device)
         buf_b = torch.empty_like(buf_a)
         buf_b.copy_(buf_a)
@@ -603,7 +603,7 @@ def main():
                     "letter) and probes a query-side table instead of materialising reference seed entries; it is bound by one L2 request per reference "
                     "position, not by HBM bytes (DESIGN.md 5)"}
         # HBM traffic of the dominant kernel per launch: FETCH_SIZE of a separate `rocprofv3 --pmc FETCH_SIZE` pass over this same
-        # command (tools/profile_r02.sh), doubled as MI355X_MICROARCH.md prescribes for gfx950, plus WRITE_SIZE; only quoted for the
+        # command (tools/profile_r03.sh), doubled as MI355X_MICROARCH.md prescribes for gfx950, plus WRITE_SIZE; only quoted for the
         # configuration and kernel variant it was measured on
         pmc_path = next((q for q in (os.path.join(ROOT, "profiles", "r%02d_pmc_summary_%s.json" % (r, args.config)) for r in (3, 2)) if os.path.exists(q)), None)
         if world == 1 and args.queries == 10_000 and args.families == 100_000 and NB == 1 and pmc_path:
