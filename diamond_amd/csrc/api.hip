@@ -302,6 +302,40 @@ static int upload_bytes(dmnd_ctx* c, void* dst, const void* src, size_t bytes)
 	return DMND_OK;
 }
 
+// HBM -> host, synchronous, through the same page-locked chunks: the runtime's own path for a pageable destination took 10-30 ms
+// for half a megabyte of seed hits right after large allocations or frees (round 3 timeline), a DMA into page-locked memory
+// plus a memcpy does not
+int dmnd::download_bytes(dmnd_ctx* c, void* dst, const void* src, size_t bytes)
+{
+	constexpr size_t CHUNK = (size_t)8 << 20;
+	if (bytes == 0) return DMND_OK;
+	for (int i = 0; i < 2; ++i) {
+		if (int rc = c->up_stage[i].ensure(CHUNK)) return rc;
+		if (!c->up_ev[i]) HIP_TRY(hipEventCreateWithFlags(&c->up_ev[i], hipEventDisableTiming));
+		if (c->up_busy[i]) { HIP_TRY(hipEventSynchronize(c->up_ev[i])); c->up_busy[i] = false; }
+	}
+	size_t issued = 0, copied = 0;
+	int i = 0;
+	// chunk k + 1 is in flight while chunk k is copied out of its staging buffer
+	HIP_TRY(hipMemcpyAsync(c->up_stage[0].p, src, std::min(CHUNK, bytes), hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipEventRecord(c->up_ev[0], c->stream));
+	issued = std::min(CHUNK, bytes);
+	while (copied < bytes) {
+		const size_t n = std::min(CHUNK, bytes - copied);
+		if (issued < bytes) {
+			const size_t m = std::min(CHUNK, bytes - issued);
+			HIP_TRY(hipMemcpyAsync(c->up_stage[i ^ 1].p, static_cast<const char*>(src) + issued, m, hipMemcpyDeviceToHost, c->stream));
+			HIP_TRY(hipEventRecord(c->up_ev[i ^ 1], c->stream));
+			issued += m;
+		}
+		HIP_TRY(hipEventSynchronize(c->up_ev[i]));
+		std::memcpy(static_cast<char*>(dst) + copied, c->up_stage[i].p, n);
+		copied += n;
+		i ^= 1;
+	}
+	return DMND_OK;
+}
+
 extern "C" int dmnd_share_block(dmnd_ctx* c, int which, const dmnd_ctx* src)
 {
 	if (!c || !src || c == src || (which != DMND_QUERY && which != DMND_TARGET) || !src->block[which].p || c->device != src->device)

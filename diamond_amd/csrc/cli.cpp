@@ -1033,9 +1033,11 @@ int run_blastp(const Options& o)
 			if (tantan && !lazy_masking && fresh) { mask_target(); g_timeline.mark("reference block " + std::to_string(bi) + " masked (tantan)"); }
 			if (motifs && algo == 0) { chk(dmnd_soft_mask_block(ctx, DMND_TARGET, &ml)); g_timeline.mark("reference block " + std::to_string(bi) + " soft-masked (motifs)"); }
 			if ((size_t)g < reserved.size() && reserved[(size_t)g].valid()) (void)reserved[(size_t)g].get();      // an optimisation only: the search allocates what is missing
+			g_timeline.mark("seed stage of block " + std::to_string(bi) + " starts");
 			t0 = std::chrono::steady_clock::now();
 			int64_t n_hits = 0;
 			chk(dmnd_seed_search(ctx, &sp, &n_hits));
+			g_timeline.mark("dmnd_seed_search returned");
 			std::vector<dmnd_seed_hit> hits((size_t)n_hits);
 			chk(dmnd_seed_hits(ctx, hits.data(), n_hits));
 			const double sd = ms_since(t0);
@@ -1448,6 +1450,10 @@ int run_view(const Options& o)
 
 int main(int argc, char** argv)
 {
+	// Copies through blit kernels, not the SDMA engines (unless the caller chose otherwise): the driver also runs its page-table
+	// updates on SDMA, and after the GBs of scratch a masking call maps and unmaps, a half-megabyte copy of seed hits queued behind
+	// them for 10-27 ms (round 3 timeline); block uploads run at the same 18 GB/s either way. Must be set before the runtime starts.
+	::setenv("HSA_ENABLE_SDMA", "0", 0);
 	try {
 		const Options o = parse(argc, argv);
 		if (o.command == "version") { std::cout << "diamond-hip (MI355X back end of DIAMOND's seed-and-extend path), ABI " << dmnd_abi_version() << "\n"; return 0; }

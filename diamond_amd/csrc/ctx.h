@@ -66,6 +66,9 @@ struct PinBuf {
 
 }  // namespace dmnd
 
+struct dmnd_ctx;
+namespace dmnd { int download_bytes(dmnd_ctx* c, void* dst, const void* src, size_t bytes); }      // api.hip: HBM -> pageable host memory through the context's page-locked chunks
+
 struct KeptTrace;
 
 struct dmnd_ctx {

@@ -258,7 +258,7 @@ extern "C" int dmnd_mask_block(dmnd_ctx* c, int which, int8_t* host_data, int64_
 	const unsigned long long nm = cnt[0];
 	if (host_data && pos_cap && cnt[1] <= pos_cap) {
 		std::vector<uint32_t> pos((size_t)cnt[1]);
-		if (cnt[1]) HIP_TRY(copy_now(st, pos.data(), c->mask_pos.p, pos.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+		if (cnt[1]) if (int rc = download_bytes(c, pos.data(), c->mask_pos.p, pos.size() * sizeof(uint32_t))) return rc;
 		for (uint32_t x : pos) host_data[x] = 23;
 	}
 	else if (host_data) HIP_TRY(copy_now(st, host_data, c->block[which].p, (size_t)raw, hipMemcpyDeviceToHost));

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <chrono>
 #include "ctx.h"
 #include "seed_core.h"
 #include "seed_kernels.h"
@@ -340,6 +341,12 @@ extern "C" int dmnd_seed_reserve(dmnd_ctx* c, const dmnd_seed_params* params, in
 extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int64_t* n_hits)
 {
 	if (!c || !params || !n_hits) return fail(DMND_E_ARG, "dmnd_seed_search: NULL argument");
+	// DMND_TRACE: host wall time of the call's parts (the kernel times do not show allocations, copies and waits)
+	const bool lap_on = getenv("DMND_TRACE") != nullptr;
+	const auto lap_t0 = std::chrono::steady_clock::now();
+	auto lap = [&](const char* what) {
+		if (lap_on) std::fprintf(stderr, "dmnd_seed_search %8.2f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - lap_t0).count(), what);
+	};
 	*n_hits = 0;
 	c->n_seed_hits = 0;                                  // a failed or empty search must not leave the previous search's hits behind
 	const std::vector<int64_t>& ql = c->limits[DMND_QUERY];
@@ -393,7 +400,9 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	}
 	const bool index_ready = reuse && c->qindex_signature == signature && !signature.empty();
 	c->qindex_signature.clear();                         // set again when this call has built (or kept) a complete index
+	lap("parameters checked");
 	if (int rc = seed_reserve(c, sp, z, nq_pos, q_end, c->block_len[DMND_QUERY], false)) return rc;
+	lap("buffers ensured");
 	if (int rc = c->counters.ensure((size_t)(S + 5) * sizeof(unsigned long long))) return rc;      // [S] hits, [S+1] deferred pairs, [S+2] collected positions, [S+3] Hamming survivors, [S+4] scored survivors
 	if (!index_ready) HIP_TRY(hipMemsetAsync(c->seed_bitmap.p, 0, bm_total, st));
 	if (!index_ready) HIP_TRY(hipMemsetAsync(c->seed_next.p, 0xff, (size_t)SB * nq_pos * sizeof(uint32_t), st));
@@ -409,7 +418,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		if (int rc = c->seed_qfold.ensure((size_t)(n + 1) / 2 + 64)) return rc;
 		HIP_TRY(launch_seed_fold(c->block[DMND_QUERY].as<int8_t>(), n, c->seed_qfold.as<uint8_t>(), st));
 	}
-	static const int level2_env = [] { const char* e = getenv("DMND_SEED_LEVEL2"); return e ? atoi(e) : -1; }();
+	const int level2_env = [] { const char* e = getenv("DMND_SEED_LEVEL2"); return e ? atoi(e) : -1; }();
 	auto level2_of = [&](int sid) { return level2_env >= 0 ? level2_env : (sp.shape_weight[sid] >= 10 ? 1 : 0); };
 	auto args_for = [&](int sid, int64_t matched_cap, int64_t matched_off) {
 		const int own = SB == 1 ? 0 : sid;                 // which of the SB buffer sets the shape uses
@@ -451,6 +460,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 
 	Timer tm(st);
 	for (int i = 0; i < 5; ++i) c->seed_ms[i] = 0;
+	lap("clears and query ids enqueued");
 	// the query side of one shape: built (table, position lists, bitmaps), or -- kept from an earlier call -- its marks reset
 	auto query_side = [&](const SeedArgs& a, int sid, bool build) -> int {
 		if (build) {
@@ -614,6 +624,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		}
 		HIP_TRY(copy_now(c->stream, &n_pairs, c->counters.as<unsigned long long>() + S + 3, sizeof(n_pairs), hipMemcpyDeviceToHost));
 	}
+	lap("phase 1 done (index, stream, mask of every shape)");
 	// phase 2: pair filter per shape; hit and deferred-pair buffers grow on overflow
 	int64_t hit_cap = std::max<int64_t>(std::max<int64_t>((int64_t)1 << 20, m_off[S] / 8), (int64_t)(c->seed_hits.cap / sizeof(dmnd_seed_hit)));
 	if (const char* e = getenv("DMND_SEED_HIT_CAP")) hit_cap = std::max<int64_t>(1, atoll(e));
@@ -701,6 +712,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		if (def_overflow) def_cap = (int64_t)def_max + 1024;
 	}
 	}
+	lap("filters done");
 	if (reuse) c->qindex_signature = signature;          // every shape's query side is complete and resident
 	// order the hits by (query, subject, seed_offset, score) on the device: what align_queries needs (hits grouped by query),
 	// made deterministic (the append order of the kernels is not)
@@ -717,6 +729,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		HIP_TRY(sort_seed_hits(c->seed_hits.as<dmnd_seed_hit>(), c->seed_hits_sorted.as<dmnd_seed_hit>(), n, keys, idx, &c->sort_tmp, &c->sort_tmp_bytes, st));
 		HIP_TRY(sync_stream(st));
 	}
+	lap("hits sorted");
 	c->seed_ms[4] = c->seed_ms[0] + c->seed_ms[1] + c->seed_ms[2] + c->seed_ms[3];
 	if (getenv("DMND_TRACE")) {
 		std::fprintf(stderr, "dmnd_seed_search: %d shapes, %lld query positions, joined reference positions per shape:", S, (long long)nq_pos);
@@ -737,6 +750,6 @@ extern "C" int dmnd_seed_hits(dmnd_ctx* c, dmnd_seed_hit* out, int64_t cap)
 	if (cap < c->n_seed_hits) return fail(DMND_E_CAP, "dmnd_seed_hits: buffer too small");
 	if (c->n_seed_hits == 0) return DMND_OK;
 	HIP_TRY(hipSetDevice(c->device));
-	HIP_TRY(copy_now(c->stream, out, c->seed_hits_sorted.p, (size_t)c->n_seed_hits * sizeof(dmnd_seed_hit), hipMemcpyDeviceToHost));      // sorted by dmnd_seed_search
+	if (int rc = download_bytes(c, out, c->seed_hits_sorted.p, (size_t)c->n_seed_hits * sizeof(dmnd_seed_hit))) return rc;      // sorted by dmnd_seed_search
 	return DMND_OK;
 }

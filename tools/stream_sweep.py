@@ -22,11 +22,11 @@ ctx.upload_block(hip.QUERY, w.qd, w.ql)
 ctx.upload_block(hip.TARGET, w.td, w.tl)
 ctx.set_query_contexts(w.contexts)
 base = None
-variants = [dict()] + [dict(DMND_SEED_PROBE_POLICY=str(pol)) for pol in (1, 2, 3, 16, 17, 18)] \
+variants = [dict(), dict(DMND_SEED_LEVEL2="0")] + [dict(DMND_SEED_PROBE_POLICY=str(pol)) for pol in (1, 2, 3, 16, 17, 18)] \
     + [dict(DMND_SEED_BM1_KB=str(kb), DMND_SEED_BM1_K=str(k), DMND_SEED_STREAM_NT=str(nt), DMND_SEED_PROBE_POLICY=str(pol))
        for kb in (2048, 3072, 4096, 8192) for k in (2, 3) for pol in (0, 2, 16) for nt in (0, 1)]
 for v in variants:
-    for k in ("DMND_SEED_BM1_KB", "DMND_SEED_BM1_K", "DMND_SEED_STREAM_NT", "DMND_SEED_PROBE_POLICY"):
+    for k in ("DMND_SEED_BM1_KB", "DMND_SEED_BM1_K", "DMND_SEED_STREAM_NT", "DMND_SEED_PROBE_POLICY", "DMND_SEED_LEVEL2"):
         os.environ.pop(k, None)
     os.environ.update(v)
     best, hits = None, None
