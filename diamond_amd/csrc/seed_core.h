@@ -297,11 +297,23 @@ DMND_HD int stage2_window(const SeedParams& c, int query_len)
 // Hamming filter (stage2.h:74-154, left_most.h:62-108). q/s point at the seed positions inside the blocks,
 // qmt at the query position's entry of mask_time[]. Returns true if the pair is kept (it is the left-most
 // seed hit of its diagonal in index-chunk order).
-DMND_HD bool left_most_pair(const SeedParams& c, const int8_t* q, const uint8_t* qmt, const int8_t* s, int seed_offset, int sid, int chunk, int query_len)
+// How the rule reads its letter windows: byte by byte (this form; the CPU emulator, the oracle-sized cases), or with a few wide
+// loads and register arithmetic (seed_kernels.hip, LmWide) -- same values either way.
+struct LmBytewise {
+	DMND_HD void clip(const int8_t* seq, int len, int anchor, int& b, int& e) const { clip_window(seq, len, anchor, b, e); }
+	DMND_HD void masks(const SeedParams& c, const int8_t* qq, const int8_t* ss, const uint8_t* mm, int w, int t_now, uint64_t& match, uint64_t& masked) const
+	{
+		match = reduced_match(c, qq, ss, w);
+		masked = seed_mask_bits(mm, w, t_now);
+	}
+};
+
+template<typename Windows>
+DMND_HD bool left_most_pair_t(const Windows& win, const SeedParams& c, const int8_t* q, const uint8_t* qmt, const int8_t* s, int seed_offset, int sid, int chunk, int query_len)
 {
 	const int window = stage2_window(c, query_len);
 	int cb, ce;
-	clip_window(q - window, 2 * window, window, cb, ce);           // query_clipped, stage2.h:94
+	win.clip(q - window, 2 * window, window, cb, ce);              // query_clipped, stage2.h:94
 	const int window_left0 = window - cb, clipped_len = ce - cb;
 	const int interval_mod = c.left_most_interval > 0 ? seed_offset % c.left_most_interval : window_left0;
 	const int overhang = imax(window_left0 - interval_mod, 0);
@@ -322,11 +334,13 @@ DMND_HD bool left_most_pair(const SeedParams& c, const int8_t* q, const uint8_t*
 	const uint8_t* mm = md + d;
 	int w = imin(qlen - d, window_left + 1 + 32);
 	int sb, se;
-	clip_window(ss, w, window_left, sb, se);                         // subject_clipped
+	win.clip(ss, w, window_left, sb, se);                            // subject_clipped
 	w -= w - se;
 	qq += sb; ss += sb; mm += sb; window_left -= sb; w -= sb;
 
-	const uint64_t match_mask = reduced_match(c, qq, ss, w), query_seed_mask = ~seed_mask_bits(mm, w, t_now);
+	uint64_t match_mask, masked_bits;
+	win.masks(c, qq, ss, mm, w, t_now, match_mask, masked_bits);
+	const uint64_t query_seed_mask = ~masked_bits;
 	const uint32_t len_left = (uint32_t)(window_left + seed_len - 1);
 	const uint32_t match_mask_left = (uint32_t)(((1ull << len_left) - 1) & match_mask),
 		query_mask_left = (uint32_t)(((1ull << len_left) - 1) & query_seed_mask);
@@ -338,6 +352,11 @@ DMND_HD bool left_most_pair(const SeedParams& c, const int8_t* q, const uint8_t*
 	const uint32_t right_hit = pattern_hit(c, chunked ? sid + 1 : sid, match_mask_right, len_right) & query_mask_right;
 	return (left_hit == 0 || !verify_hits(c, left_hit, qq, ss, true, match_mask_left, sid, chunked, lo, hi))
 		&& (right_hit == 0 || !verify_hits(c, right_hit, qq + window_left + 1, ss + window_left + 1, false, match_mask_right, sid, chunked, lo, hi));
+}
+
+DMND_HD bool left_most_pair(const SeedParams& c, const int8_t* q, const uint8_t* qmt, const int8_t* s, int seed_offset, int sid, int chunk, int query_len)
+{
+	return left_most_pair_t(LmBytewise(), c, q, qmt, s, seed_offset, sid, chunk, query_len);
 }
 
 // Stage-2 ungapped window score: best running local score over `window` aligned letters

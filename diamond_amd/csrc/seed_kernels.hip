@@ -775,8 +775,67 @@ __global__ __launch_bounds__(POST_THREADS) void seed_score_kernel(SeedArgs a, in
 	if (threadIdx.x < n) a.scored[st_base + threadIdx.x] = stage[threadIdx.x];
 }
 
+// The left-most rule's windows with wide loads (LmBytewise's counterpart, seed_core.h). The byte-wise form walks up to 96 + 49 + 49
+// + 49 letters with one dependent load each, and looks every letter's class up in the parameter block: ~150 us of latency per
+// survivor however few there are (0.16 ms of every C2 step for 20 k survivors). Here a window is six or four 16-byte loads issued
+// together, delimiters are found with a zero-byte test per dword, classes come from the two 64-bit nibble maps of the stream kernel.
+struct LmWide {
+	uint64_t map_lo, map_hi;
+	int reduction_ok;                                              // classes fit a nibble (else the byte-wise form)
+	// bit x of the result: byte x of the dword equals v (exact, no carries between bytes)
+	static __device__ __forceinline__ uint32_t eq_bytes(uint32_t x, uint32_t v)
+	{
+		const uint32_t t = x ^ (v * 0x01010101u);
+		const uint32_t y = ~(((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t) & 0x80808080u;
+		return ((y >> 7) & 1u) | ((y >> 14) & 2u) | ((y >> 21) & 4u) | ((y >> 28) & 8u);
+	}
+	__device__ void clip(const int8_t* seq, int len, int anchor, int& b, int& e) const
+	{
+		if (len > 96 || anchor > 63) { clip_window(seq, len, anchor, b, e); return; }
+		uint32_t w[24];
+		__builtin_memcpy(w, seq, 96);                                // the blocks carry 256 padding letters: reading past len is safe
+		uint64_t lo = 0;
+		uint32_t hi = 0;
+#pragma unroll
+		for (int x = 0; x < 16; ++x) lo |= (uint64_t)eq_bytes(w[x], (uint32_t)L_DELIM) << (4 * x);
+#pragma unroll
+		for (int x = 16; x < 24; ++x) hi |= eq_bytes(w[x], (uint32_t)L_DELIM) << (4 * (x - 16));
+		if (len < 64) { lo &= (1ull << len) - 1; hi = 0; }
+		else if (len < 96) hi &= (1u << (len - 64)) - 1;
+		b = 0; e = len;
+		const uint64_t below = lo & ((1ull << anchor) - 1), above = lo >> anchor;
+		if (below) b = 64 - __builtin_clzll(below);
+		if (above) e = anchor + __builtin_ctzll(above);
+		else if (hi) e = 64 + __builtin_ctz(hi);
+	}
+	__device__ void masks(const SeedParams& c, const int8_t* qq, const int8_t* ss, const uint8_t* mm, int w, int t_now, uint64_t& match, uint64_t& masked) const
+	{
+		if (!reduction_ok) { match = reduced_match(c, qq, ss, w); masked = seed_mask_bits(mm, w, t_now); return; }
+		uint32_t qw[16], sw[16], mw[16];
+		__builtin_memcpy(qw, qq, 64); __builtin_memcpy(sw, ss, 64); __builtin_memcpy(mw, mm, 64);
+		uint64_t m = 0, k = 0;
+#pragma unroll
+		for (int x = 0; x < 16; ++x) {
+			uint32_t eq = 0, ms = 0;
+#pragma unroll
+			for (int y = 0; y < 4; ++y) {
+				const uint32_t lq = (qw[x] >> (8 * y)) & LETTER_MASK, ls = (sw[x] >> (8 * y)) & LETTER_MASK;
+				const bool bad = lq == L_MASK || lq == L_STOP || lq == L_DELIM || ls == L_MASK || ls == L_STOP || ls == L_DELIM;
+				const uint32_t cq = (uint32_t)(((lq & 16) ? map_hi : map_lo) >> ((lq & 15) * 4)) & 15u, cs = (uint32_t)(((ls & 16) ? map_hi : map_lo) >> ((ls & 15) * 4)) & 15u;
+				eq |= (uint32_t)(!bad && cq == cs) << y;
+				ms |= (uint32_t)((int)((mw[x] >> (8 * y)) & 0xffu) <= t_now) << y;
+			}
+			m |= (uint64_t)eq << (4 * x);
+			k |= (uint64_t)ms << (4 * x);
+		}
+		const uint64_t keep = w >= 64 ? ~0ull : (1ull << (w < 0 ? 0 : w)) - 1;
+		match = m & keep;
+		masked = k & keep;
+	}
+};
+
 // left-most rule + emission; launched over the upper bound of the list (the number of survivors), the real size is read on the device
-__global__ __launch_bounds__(256) void seed_leftmost_kernel(SeedArgs a, int sid)
+__global__ __launch_bounds__(256) void seed_leftmost_kernel(SeedArgs a, int sid, uint64_t map_lo, uint64_t map_hi, int reduction_ok)
 {
 	const int lane = threadIdx.x & 63;
 	const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x, n = *a.scored_count;
@@ -791,7 +850,7 @@ __global__ __launch_bounds__(256) void seed_leftmost_kernel(SeedArgs a, int sid)
 		qid = a.qid_of[qp];
 		seed_offset = (int)(qp - a.qlimits[qid]);
 		const int query_len = (int)(a.qlimits[qid + 1] - a.qlimits[qid] - 1);
-		keep = left_most_pair(a.params, a.qdata + qp, a.mask_time + qp, a.tdata + sc.sloc, seed_offset, sid, sc.chunk, query_len);
+		keep = left_most_pair_t(LmWide{ map_lo, map_hi, reduction_ok }, a.params, a.qdata + qp, a.mask_time + qp, a.tdata + sc.sloc, seed_offset, sid, sc.chunk, query_len);
 	}
 	// one atomic on the hit counter per wavefront
 	const unsigned long long mask = __ballot(keep);
@@ -1032,7 +1091,14 @@ hipError_t launch_seed_post(const SeedArgs& a, int sid, int64_t n_survivors, hip
 	hipError_t e = hipMemsetAsync(a.scored_count, 0, sizeof(unsigned long long), st);
 	if (e != hipSuccess) return e;
 	hipLaunchKernelGGL(seed_score_kernel, dim3(blocks_for(n_survivors, POST_THREADS)), dim3(POST_THREADS), 0, st, a, sid, n_survivors);
-	hipLaunchKernelGGL(seed_leftmost_kernel, dim3(blocks_for(n_survivors, 256)), dim3(256), 0, st, a, sid);
+	// 4-bit class map of the letters (as launch_seed_stream builds it); reductions with more than 15 classes keep the byte-wise windows
+	uint64_t lo = 0, hi = 0;
+	const SeedParams& c = a.params;
+	for (int l = 0; l < 32; ++l) {
+		const uint64_t code = c.reduction[l] == L_MASK ? 15u : (uint64_t)(c.reduction[l] & 15);
+		(l < 16 ? lo : hi) |= code << ((l & 15) * 4);
+	}
+	hipLaunchKernelGGL(seed_leftmost_kernel, dim3(blocks_for(n_survivors, 256)), dim3(256), 0, st, a, sid, lo, hi, c.reduction_size <= 15 ? 1 : 0);
 	return hipGetLastError();
 }
 
