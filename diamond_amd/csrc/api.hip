@@ -236,6 +236,8 @@ extern "C" void dmnd_destroy(dmnd_ctx* c)
 	for (DevBuf& kb : c->keep_trace) kb.release();
 	c->stage_h.release(); c->ends_h.release(); c->stage_d.release();
 	for (int i = 0; i < 2; ++i) { c->up_stage[i].release(); if (c->up_ev[i]) (void)hipEventDestroy(c->up_ev[i]); c->up_ev[i] = nullptr; }
+	for (int i = 0; i < 2; ++i) { c->t_stage[i].release(); if (c->t_ev[i]) (void)hipEventDestroy(c->t_ev[i]); c->t_ev[i] = nullptr; }
+	if (c->t_stream) { (void)hipStreamSynchronize(c->t_stream); forget_stream(c->t_stream); (void)hipStreamDestroy(c->t_stream); c->t_stream = nullptr; }
 	delete c->kts; c->kts = nullptr;
 	for (dmnd_ctx* a : c->aux) dmnd_destroy(a);
 	c->aux.clear();
@@ -275,28 +277,32 @@ extern "C" void dmnd_host_free(void* p) { if (p) (void)hipHostFree(p); }
 // bytes are staged instead through TWO page-locked buffers of the context -- while the DMA engine moves one chunk the host
 // fills the other -- so the transfer runs at the host's memcpy rate. A source that is page-locked already (dmnd_host_alloc,
 // hipHostMalloc, hipHostRegister) is handed to the DMA engine as it is.
-static int upload_bytes(dmnd_ctx* c, void* dst, const void* src, size_t bytes)
+static int upload_bytes(dmnd_ctx* c, void* dst, const void* src, size_t bytes, bool target_lane = false)
 {
 	constexpr size_t CHUNK = (size_t)8 << 20;
+	hipStream_t stream = target_lane ? c->t_stream : c->stream;
+	dmnd::PinBuf* stage = target_lane ? c->t_stage : c->up_stage;
+	hipEvent_t* ev = target_lane ? c->t_ev : c->up_ev;
+	bool* busy = target_lane ? c->t_busy : c->up_busy;
 	hipPointerAttribute_t attr;
 	const bool pinned = hipPointerGetAttributes(&attr, src) == hipSuccess && (attr.type == hipMemoryTypeHost || attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged);
 	if (!pinned) (void)hipGetLastError();              // an unregistered pointer is an "invalid value", not a failure
 	if (pinned || bytes <= ((size_t)256 << 10)) {
-		HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, c->stream));
+		HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, stream));
 		return DMND_OK;
 	}
 	for (int i = 0; i < 2; ++i) {
-		if (int rc = c->up_stage[i].ensure(CHUNK)) return rc;
-		if (!c->up_ev[i]) HIP_TRY(hipEventCreateWithFlags(&c->up_ev[i], hipEventDisableTiming));
+		if (int rc = stage[i].ensure(CHUNK)) return rc;
+		if (!ev[i]) HIP_TRY(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
 	}
 	size_t done = 0;
 	for (int i = 0; done < bytes; i ^= 1) {
 		const size_t n = std::min(CHUNK, bytes - done);
-		if (c->up_busy[i]) HIP_TRY(hipEventSynchronize(c->up_ev[i]));
-		std::memcpy(c->up_stage[i].p, static_cast<const char*>(src) + done, n);
-		HIP_TRY(hipMemcpyAsync(static_cast<char*>(dst) + done, c->up_stage[i].p, n, hipMemcpyHostToDevice, c->stream));
-		HIP_TRY(hipEventRecord(c->up_ev[i], c->stream));
-		c->up_busy[i] = true;
+		if (busy[i]) HIP_TRY(hipEventSynchronize(ev[i]));
+		std::memcpy(stage[i].p, static_cast<const char*>(src) + done, n);
+		HIP_TRY(hipMemcpyAsync(static_cast<char*>(dst) + done, stage[i].p, n, hipMemcpyHostToDevice, stream));
+		HIP_TRY(hipEventRecord(ev[i], stream));
+		busy[i] = true;
 		done += n;
 	}
 	return DMND_OK;
@@ -367,9 +373,14 @@ extern "C" int dmnd_upload_block(dmnd_ctx* c, int which, const int8_t* data, int
 	HIP_TRY(hipSetDevice(c->device));
 	if (int rc = c->block[which].ensure((size_t)data_len + 64)) return rc;
 	if (limits) if (int rc = c->d_limits[which].ensure((size_t)(n_seqs + 1) * sizeof(int64_t))) return rc;
-	if (int rc = upload_bytes(c, c->block[which].p, data, (size_t)data_len)) return rc;
-	if (limits) if (int rc = upload_bytes(c, c->d_limits[which].p, limits, (size_t)(n_seqs + 1) * sizeof(int64_t))) return rc;
-	HIP_TRY(sync_stream(c->stream));
+	// the reference block travels on its own lane: nothing this call touches is shared with calls on the QUERY block of the same
+	// context, so a driver may run it on a helper thread beside them (diamond-hip does, for the first block of a run)
+	const bool lane = which == DMND_TARGET;
+	if (lane && !c->t_stream) HIP_TRY(hipStreamCreateWithFlags(&c->t_stream, hipStreamNonBlocking));
+	if (lane && c->block_len[which] > 0) HIP_TRY(sync_stream(c->stream));      // whatever still reads the block that is replaced
+	if (int rc = upload_bytes(c, c->block[which].p, data, (size_t)data_len, lane)) return rc;
+	if (limits) if (int rc = upload_bytes(c, c->d_limits[which].p, limits, (size_t)(n_seqs + 1) * sizeof(int64_t), lane)) return rc;
+	HIP_TRY(sync_stream(lane ? c->t_stream : c->stream));
 	c->block_len[which] = data_len;
 	c->soft_valid[which] = false;
 	if (which == DMND_QUERY) { c->source_lens.clear(); ++c->query_generation; }

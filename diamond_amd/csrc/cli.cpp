@@ -932,7 +932,7 @@ int run_blastp(const Options& o)
 	// --no-self-hits: the library finds query / target pairs with the same letters and asks here whether the titles agree too
 	struct SelfCtx { const std::vector<std::string>* qtitles; const Database* db; size_t q0 = 0, t0 = 0; };
 	std::vector<SelfCtx> self_ctx((size_t)n_gpus);
-	struct Held { SeqBlock block; size_t index = (size_t)-1; };
+	struct Held { SeqBlock block; size_t index = (size_t)-1; bool ahead = false; };      // ahead: read AND uploaded before the query phase, not yet masked
 	std::vector<Held> held_blocks((size_t)n_gpus);                  // the reference block every GPU's thread holds in host memory
 	// f(g) on one host thread per GPU; the first error is rethrown on the calling thread
 	auto on_each_gpu = [&](const std::function<void(int)>& f) {
@@ -953,6 +953,24 @@ int run_blastp(const Options& o)
 		// of every extension call reads. Two phases with a join between them: no GPU's upload may still be reading the host copy
 		// when GPU 0 writes the masked letters back into it (a late GPU would upload a partly masked block and mask it again).
 		std::vector<double> up_ms((size_t)n_gpus, 0.0);
+		// first query block: every GPU's first reference block goes to HBM on a helper thread meanwhile (the reference block has its
+		// own transfer lane in the library); SEG masks the host copy before the upload, so not then
+		std::vector<std::future<double>> ahead((size_t)n_gpus);
+		if (&qr == &q_blocks.front() && !seg && !std::getenv("DMND_CLI_NO_AHEAD"))
+			for (int g = 0; g < n_gpus && (size_t)g < t_blocks.size(); ++g)
+				ahead[(size_t)g] = std::async(std::launch::async, [&, g]() -> double {
+					Held& h = held_blocks[(size_t)g];
+					h.block = first_block[(size_t)g].get();
+					h.index = (size_t)g;
+					g_timeline.mark("reference block " + std::to_string(g) + " in host memory");
+					const auto t0 = std::chrono::steady_clock::now();
+					const Range& tr = t_blocks[(size_t)g];
+					if (dmnd_upload_block(ctxs[(size_t)g], DMND_TARGET, h.block.data.data(), (int64_t)h.block.data.size(), h.block.limits.data(), (int64_t)(tr.end - tr.begin)) != DMND_OK)
+						throw std::runtime_error(dmnd_last_error());
+					h.ahead = true;
+					g_timeline.mark("reference block " + std::to_string(g) + " uploaded (beside the query phase)");
+					return ms_since(t0);
+				});
 		on_each_gpu([&](int g) {
 			auto t0 = std::chrono::steady_clock::now();
 			chk(dmnd_upload_block(ctxs[(size_t)g], DMND_QUERY, q.data.data(), (int64_t)q.data.size(), q.limits.data(), nq));
@@ -990,8 +1008,12 @@ int run_blastp(const Options& o)
 			const Range& tr = t_blocks[bi];
 			// the reference re-reads and re-masks every reference block for every query block (run/double_indexed.cpp:404-470); a
 			// GPU that has one block keeps it (masked) from one query block to the next
-			const bool fresh = held.index != bi;             // just read: unmasked
-			if (fresh) {
+			double ahead_ms = 0;
+			if ((size_t)g < ahead.size() && ahead[(size_t)g].valid()) ahead_ms = ahead[(size_t)g].get();      // rethrows the helper's error
+			const bool in_hbm = held.ahead && held.index == bi;
+			held.ahead = false;
+			const bool fresh = held.index != bi || in_hbm;   // just read: unmasked
+			if (fresh && !in_hbm) {
 				held.block = bi == (size_t)g && first_block[(size_t)g].valid() ? first_block[(size_t)g].get() : next.valid() ? next.get() : db.load(tr.begin, tr.end, threads);
 				held.index = bi;
 				g_timeline.mark("reference block " + std::to_string(bi) + " in host memory");
@@ -1005,9 +1027,12 @@ int run_blastp(const Options& o)
 			const int64_t t_seqs = (int64_t)(tr.end - tr.begin);
 			// SEG runs on the host copy: a block that was just read is masked before it goes to HBM (up-front masking)
 			if (seg && !lazy_masking && fresh) { chk(dmnd_seg_mask_block(t.data.data(), t.limits.data(), t_seqs, threads, &mt)); mk += ms_since(t0); t0 = std::chrono::steady_clock::now(); }
-			chk(dmnd_upload_block(ctx, DMND_TARGET, t.data.data(), (int64_t)t.data.size(), t.limits.data(), t_seqs));
-			up += ms_since(t0);
-			g_timeline.mark("reference block " + std::to_string(bi) + " uploaded");
+			if (in_hbm) up += ahead_ms;
+			else {
+				chk(dmnd_upload_block(ctx, DMND_TARGET, t.data.data(), (int64_t)t.data.size(), t.limits.data(), t_seqs));
+				up += ms_since(t0);
+				g_timeline.mark("reference block " + std::to_string(bi) + " uploaded");
+			}
 			const int8_t* t_host = t.data.data();            // the letters the extension stage's host part reads
 			auto mask_target = [&] {
 				t0 = std::chrono::steady_clock::now();

@@ -96,6 +96,12 @@ struct dmnd_ctx {
 	dmnd::PinBuf up_stage[2];                  // dmnd_upload_block: page-locked double buffer of a pageable source
 	hipEvent_t up_ev[2] = { nullptr, nullptr };
 	bool up_busy[2] = { false, false };
+	// a second transfer lane for the reference block alone (own stream, own staging): a driver may upload the reference block on a
+	// helper thread while the query block of the same context is uploaded and masked on its main stream
+	hipStream_t t_stream = nullptr;
+	dmnd::PinBuf t_stage[2];
+	hipEvent_t t_ev[2] = { nullptr, nullptr };
+	bool t_busy[2] = { false, false };
 	dmnd::PinBuf stage_h, ends_h;              // dmnd_swipe_keep: all launch arrays of a sweep in one upload; its results
 	dmnd::DevBuf stage_d;
 	std::vector<KeptTrace>* kts = nullptr;     // kept traces of the extension stage's ranking iterations (reused from call to call)
