@@ -235,6 +235,7 @@ extern "C" void dmnd_destroy(dmnd_ctx* c)
 	if (c->pinned_cbs) (void)hipHostFree(c->pinned_cbs);
 	for (DevBuf& kb : c->keep_trace) kb.release();
 	c->stage_h.release(); c->ends_h.release(); c->stage_d.release();
+	c->xd_hits.release(); c->xd_out.release(); c->xd_host.release();
 	for (int i = 0; i < 2; ++i) { c->up_stage[i].release(); if (c->up_ev[i]) (void)hipEventDestroy(c->up_ev[i]); c->up_ev[i] = nullptr; }
 	for (int i = 0; i < 2; ++i) { c->t_stage[i].release(); if (c->t_ev[i]) (void)hipEventDestroy(c->t_ev[i]); c->t_ev[i] = nullptr; }
 	if (c->t_stream) { (void)hipStreamSynchronize(c->t_stream); forget_stream(c->t_stream); (void)hipStreamDestroy(c->t_stream); c->t_stream = nullptr; }

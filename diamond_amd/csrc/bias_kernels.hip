@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include "bias_core.h"
 #include "bias_kernels.h"
+#include "xdrop_core.h"
 
 namespace dmnd {
 
@@ -26,6 +27,36 @@ __global__ __launch_bounds__(256) void hauser_bias_kernel(BiasArgs a)
 		for (int m = threadIdx.x; m < l; m += blockDim.x)
 			a.out[begin + m] = hauser_at(seq, l, m, M, bg, a.window);
 	}
+}
+
+// x-drop ungapped extension of every seed hit of a block pair (ungapped_stage's inner call, align/ungapped.cpp:62-126): one thread
+// per hit, both directions along the hit's diagonal; letters and bias come from the resident blocks, the matrix from LDS. The host's
+// chaining stage did this per hit with two dependent reads per step into a target block of hundreds of MB (about half of its ~1 us
+// per hit); here the walks of all hits of the block run at once while the host is still grouping the hits by target.
+__global__ __launch_bounds__(256) void xdrop_seg_kernel(XdropArgs a)
+{
+	__shared__ int8_t M[32 * 32];
+	for (int x = threadIdx.x; x < 32 * 32 / 4; x += blockDim.x)
+		reinterpret_cast<int32_t*>(M)[x] = reinterpret_cast<const int32_t*>(a.matrix)[x];
+	__syncthreads();
+	const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= a.n_hits) return;
+	const dmnd_seed_hit h = a.hits[k];
+	const int64_t qoff = a.qlimits[h.query] + h.seed_offset;
+	const int8_t* q = a.qblock + qoff;
+	const int8_t* t = a.tblock + h.subject;
+	const int8_t* cbs = a.cbs ? a.cbs + qoff : nullptr;
+	int left, right;
+	const int s_left = xdrop_walk_core(M, q - 1, cbs ? cbs - 1 : nullptr, t - 1, -1, 0, a.xdrop, left);
+	const int s_both = xdrop_walk_core(M, q, cbs, t, +1, s_left, a.xdrop, right);
+	a.out[k] = XdropSeg{ left, right, s_both };
+}
+
+hipError_t launch_xdrop_segs(const XdropArgs& a, hipStream_t st)
+{
+	if (a.n_hits <= 0) return hipSuccess;
+	hipLaunchKernelGGL(xdrop_seg_kernel, dim3((unsigned)((a.n_hits + 255) / 256)), dim3(256), 0, st, a);
+	return hipGetLastError();
 }
 
 hipError_t launch_hauser_bias(const BiasArgs& a, hipStream_t st)

@@ -27,6 +27,8 @@
 #include <cstdlib>
 #include <vector>
 
+#include "xdrop_core.h"
+
 namespace dmnd {
 
 struct ScoreTable {                // ScoreMatrix::operator()(a,b) = matrix32[a*32+b] on masked letters
@@ -55,7 +57,7 @@ struct Chain {                     // the fields of an approximate HSP the exten
 	int q0, q1, s0, s1;            // query / subject range, end exclusive
 };
 
-struct HostSeedHit { int i, j, score, frame; };
+struct HostSeedHit { int i, j, score, frame; int src = -1; };      // src: index of the hit in the block pair's hit list (device x-drop results)
 
 // chaining constants = the reference's config defaults (basic/config.cpp:549-603)
 struct ChainCfg {
@@ -76,15 +78,7 @@ struct ChainCfg {
 // how many letters it took to get there. Reads one position beyond either end: the blocks carry delimiters there.
 inline int xdrop_walk(const ScoreTable& S, const SeqRef& q, const int8_t* cbs, const SeqRef& t, int qi, int tj, int dir, int best, int xdrop, int& reach)
 {
-	reach = 0;
-	int sum = best;
-	for (int n = 1; best - sum < xdrop; ++n, qi += dir, tj += dir) {
-		const int a = q[qi], b = t[tj];
-		if (a == 31 || b == 31) break;
-		sum += S.at(a, b) + (cbs ? cbs[qi] : 0);
-		if (sum > best) { best = sum; reach = n; }
-	}
-	return best;
+	return xdrop_walk_core(S.m, q.p + qi, cbs ? cbs + qi : nullptr, t.p + tj, dir, best, xdrop, reach);
 }
 
 inline Seg xdrop_ungapped(const ScoreTable& S, const SeqRef& q, const int8_t* cbs, const SeqRef& t, int qa, int sa, int xdrop)

@@ -79,6 +79,8 @@ struct dmnd_ctx {
 	dmnd_params params;
 	dmnd::Evaluer evaluer;
 	dmnd::DevBuf block[2], cbs, matrix, bias_ids;
+	dmnd::DevBuf xd_hits, xd_out;             // device x-drop stage of dmnd_extend: the call's seed hits, one XdropSeg per hit
+	dmnd::PinBuf xd_host;
 	std::vector<int32_t> h_bias_ids;           // block sequence ids of the queries with seed hits (Hauser bias of one dmnd_extend call)
 	int64_t block_len[2] = { 0, 0 }, cbs_len = 0;
 	std::vector<int64_t> limits[2];

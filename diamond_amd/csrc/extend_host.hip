@@ -159,10 +159,11 @@ struct QueryWork {
 
 // load_hits (load_hits.h:44-127) + the target ranking of extend() (extend.cpp:403-414)
 void load_query(const HostCfg& h, QueryWork& w, uint32_t query, const dmnd_seed_hit* hb, const dmnd_seed_hit* he, const uint8_t* gf_flags,
-	const int64_t* tl, int64_t nt, const uint32_t* coarse = nullptr, int query_len = 0)
+	const int64_t* tl, int64_t nt, const uint32_t* coarse = nullptr, int query_len = 0, int64_t first_index = -1)
 {
 	std::vector<dmnd_seed_hit> hits(hb, he);
-	for (size_t x = 0; x < hits.size(); ++x) hits[x].pad = gf_flags ? gf_flags[x] : 1;      // carried through the sort below
+	// carried through the sort below: bit 0 = the hit's gapped-filter flag, the rest = its position in [hb, he)
+	for (size_t x = 0; x < hits.size(); ++x) hits[x].pad = (int32_t)((gf_flags ? (gf_flags[x] ? 1u : 0u) : 1u) | ((uint32_t)x << 1));
 	std::sort(hits.begin(), hits.end(), [](const dmnd_seed_hit& a, const dmnd_seed_hit& b) {       // Hit::CmpSubject
 		return a.subject < b.subject || (a.subject == b.subject && (a.query < b.query || (a.query == b.query && a.seed_offset < b.seed_offset)));
 	});
@@ -183,10 +184,11 @@ void load_query(const HostCfg& h, QueryWork& w, uint32_t query, const dmnd_seed_
 		const uint32_t t = (uint32_t)(it - tl) - 1;
 		--it;
 		if (w.groups.empty() || w.groups.back().target != t) w.groups.push_back(TargetGroup{ t, x, x, 0, false });
-		w.sh[x] = HostSeedHit{ hits[x].seed_offset, (int)(s - tl[t]), hits[x].score, (int)(hits[x].query % (uint32_t)h.contexts) };
+		w.sh[x] = HostSeedHit{ hits[x].seed_offset, (int)(s - tl[t]), hits[x].score, (int)(hits[x].query % (uint32_t)h.contexts),
+			first_index >= 0 ? (int)(first_index + (int64_t)((uint32_t)hits[x].pad >> 1)) : -1 };
 		w.groups.back().end = x + 1;
 		w.groups.back().score = std::max(w.groups.back().score, (int)(uint16_t)hits[x].score);
-		w.groups.back().pass |= hits[x].pad != 0;        // gapped-filter flag of the hit (1 everywhere when the filter is off)
+		w.groups.back().pass |= (hits[x].pad & 1) != 0;  // gapped-filter flag of the hit (1 everywhere when the filter is off)
 	}
 	w.order.resize(w.groups.size());
 	for (size_t i = 0; i < w.order.size(); ++i) w.order[i] = (uint32_t)i;
@@ -206,7 +208,8 @@ void load_query(const HostCfg& h, QueryWork& w, uint32_t query, const dmnd_seed_
 
 // ungapped_stage + chaining + add_dp_targets for the targets order[g0, g1) of one query (all its contexts)
 void plan_groups(const HostCfg& h, ChainWorkspace& ws, QueryWork& w, size_t g0, size_t g1,
-	const int8_t* qdata, const int64_t* ql, const int8_t* tdata, const int64_t* tl, const int8_t* cbs_all, std::vector<PlanTarget>& out)
+	const int8_t* qdata, const int64_t* ql, const int8_t* tdata, const int64_t* tl, const int8_t* cbs_all, std::vector<PlanTarget>& out,
+	const XdropSeg* xd = nullptr)      // xd: the x-drop extension of every hit as the device computed it (xdrop_seg_kernel); NULL: walked here
 {
 	const int C = h.contexts;
 	const uint32_t q0 = w.query * (uint32_t)C;                  // block id of context 0
@@ -247,7 +250,9 @@ void plan_groups(const HostCfg& h, ChainWorkspace& ws, QueryWork& w, size_t g0, 
 				const int f = sh[x].frame;
 				ungapped[f] = std::max(ungapped[f], sh[x].score);
 				if (!segs[f].empty() && segs[f].back().diag() == sh[x].i - sh[x].j && segs[f].back().j_end() >= sh[x].j) continue;
-				const Seg d = xdrop_ungapped(h.S, q[f], cbs[f], t, sh[x].i, sh[x].j, h.xdrop);
+				const Seg d = xd && sh[x].src >= 0
+					? Seg{ sh[x].i - xd[sh[x].src].left, sh[x].j - xd[sh[x].src].left, xd[sh[x].src].left + xd[sh[x].src].right, xd[sh[x].src].score }
+					: xdrop_ungapped(h.S, q[f], cbs[f], t, sh[x].i, sh[x].j, h.xdrop);
 				if (d.score > 0) segs[f].push_back(d);
 			}
 		}
@@ -471,7 +476,7 @@ struct QueryState {
 static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const std::vector<Range>& qr, size_t qr_begin, size_t qr_end,
 	const dmnd_seed_hit* hits, const std::vector<uint8_t>& gf, const int8_t* qdata, const int8_t* tdata, const int8_t* cbs,
 	int threads, uint32_t hsp_values, std::vector<dmnd_match>& out_matches,
-	uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used, hipStream_t bias_stream = nullptr)
+	uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used, hipStream_t bias_stream = nullptr, const XdropSeg* xd = nullptr)
 {
 	const std::vector<int64_t>& ql = c->limits[DMND_QUERY];
 	const std::vector<int64_t>& tl = c->limits[DMND_TARGET];
@@ -512,7 +517,7 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 			const Range& r = qr[qr_begin + i];
 			const uint32_t q0 = hits[r.b].query / (uint32_t)h.contexts * (uint32_t)h.contexts;       // first context of the query
 			load_query(h, qs[i].w, hits[r.b].query / (uint32_t)h.contexts, hits + r.b, hits + r.e, gf.empty() ? nullptr : gf.data() + r.b, tl.data(), (int64_t)tl.size() - 1, coarse,
-				(int)(ql[q0 + 1] - ql[q0] - 1));
+				(int)(ql[q0 + 1] - ql[q0] - 1), (int64_t)r.b);
 			if (qs[i].w.order.empty()) qs[i].done = true;
 		}
 	});
@@ -552,7 +557,7 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 					if (s.done || !s.in_inner) continue;
 					me.any = true;
 					s.plan.clear();
-					plan_groups(h, ws[(size_t)t], s.w, s.w.i0, s.w.i1, qdata, ql.data(), tdata, tl.data(), h.use_cbs ? cbs : nullptr, s.plan);
+					plan_groups(h, ws[(size_t)t], s.w, s.w.i0, s.w.i1, qdata, ql.data(), tdata, tl.data(), h.use_cbs ? cbs : nullptr, s.plan, xd);
 					me.n_items += s.plan.size();
 				}
 			});
@@ -900,6 +905,26 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 		c->cbs_len = ql.back();
 		cbs = c->pinned_cbs;
 	}
+	// 1a. x-drop ungapped extension of every seed hit on the device (xdrop_seg_kernel), behind the bias kernel on the same stream;
+	// the host's chaining stage picks the segments up instead of walking the letters itself (DMND_EXTEND_XDROP_GPU=0: host walks)
+	const XdropSeg* xd = nullptr;
+	static const bool xdrop_gpu = [] { const char* e = std::getenv("DMND_EXTEND_XDROP_GPU"); return !e || e[0] != '0'; }();
+	if (xdrop_gpu && !h.ext_full && n_hits > 0) {
+		HIP_TRY(hipSetDevice(c->device));
+		if (int rc = c->xd_hits.ensure((size_t)n_hits * sizeof(dmnd_seed_hit))) return rc;
+		if (int rc = c->xd_out.ensure((size_t)n_hits * sizeof(XdropSeg))) return rc;
+		if (int rc = c->xd_host.ensure((size_t)n_hits * sizeof(XdropSeg))) return rc;
+		HIP_TRY(hipMemcpyAsync(c->xd_hits.p, hits, (size_t)n_hits * sizeof(dmnd_seed_hit), hipMemcpyHostToDevice, c->stream));
+		XdropArgs xa;
+		xa.qblock = c->block[DMND_QUERY].as<int8_t>(); xa.tblock = c->block[DMND_TARGET].as<int8_t>();
+		xa.cbs = h.use_cbs ? c->cbs.as<int8_t>() : nullptr;
+		xa.qlimits = c->d_limits[DMND_QUERY].as<int64_t>(); xa.matrix = c->matrix.as<int8_t>();
+		xa.hits = c->xd_hits.as<dmnd_seed_hit>(); xa.n_hits = n_hits; xa.xdrop = h.xdrop; xa.out = c->xd_out.as<XdropSeg>();
+		HIP_TRY(launch_xdrop_segs(xa, c->stream));
+		HIP_TRY(hipMemcpyAsync(c->xd_host.p, c->xd_out.p, (size_t)n_hits * sizeof(XdropSeg), hipMemcpyDeviceToHost, c->stream));
+		bias_pending = true;                                // the same wait covers it
+		xd = c->xd_host.as<XdropSeg>();
+	}
 	lap(4, 1);
 	// 1b. gapped filter of every seed hit in one launch (only --sensitive and above; extend.cpp:205-213)
 	std::vector<uint8_t> gf;
@@ -937,7 +962,7 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	static const int team = [] { const char* e = std::getenv("DMND_EXTEND_TEAM"); return e ? std::max(1, std::atoi(e)) : 8; }();
 	if (split == 1) {
 		rcs[0] = extend_range(c, c, h, qr, 0, qr.size(), hits, gf, qdata, tdata, cbs, std::min(threads, team), hsp_values, parts[0], transcript, transcript_cap, transcript_used,
-			bias_pending ? c->stream : nullptr);
+			bias_pending ? c->stream : nullptr, xd);
 	}
 	else {
 		if (bias_pending) HIP_TRY(sync_stream(c->stream));
@@ -960,7 +985,7 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 				dmnd_ctx* w = work[(size_t)r];
 				for (int k; (k = next_sub.fetch_add(1)) < split;) {
 					const size_t b = qr.size() * (size_t)k / (size_t)split, e = qr.size() * (size_t)(k + 1) / (size_t)split;
-					rcs[(size_t)k] = extend_range(c, w, h, qr, b, e, hits, gf, qdata, tdata, cbs, sub_threads, hsp_values, parts[(size_t)k], nullptr, 0, nullptr);
+					rcs[(size_t)k] = extend_range(c, w, h, qr, b, e, hits, gf, qdata, tdata, cbs, sub_threads, hsp_values, parts[(size_t)k], nullptr, 0, nullptr, nullptr, xd);
 					if (rcs[(size_t)k] != DMND_OK) { errs[(size_t)k] = dmnd_last_error(); break; }
 					for (int i = 0; i < 12; ++i) acc[(size_t)r][(size_t)i] += w->ext_stats[i];
 				}
