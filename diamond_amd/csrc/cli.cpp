@@ -1034,11 +1034,13 @@ int run_blastp(const Options& o)
 				g_timeline.mark("reference block " + std::to_string(bi) + " uploaded");
 			}
 			const int8_t* t_host = t.data.data();            // the letters the extension stage's host part reads
+			std::vector<int32_t> lazy_ids;                   // lazy masking: the targets that have seed hits (block sequence ids)
 			auto mask_target = [&] {
 				t0 = std::chrono::steady_clock::now();
 				if (lazy_masking && q_blocks.size() == 1 && !seg) {
-					// the only query block: nobody needs the unmasked letters again, the host copy is masked in place
-					chk(dmnd_mask_block(ctx, DMND_TARGET, t.data.data(), &mt));
+					// the only query block: nobody needs the unmasked letters again, the host copy is masked in place -- and, as in
+					// the reference (extend.cpp:168-181), only the targets the extension stage will load
+					chk(dmnd_mask_sequences(ctx, DMND_TARGET, t.data.data(), lazy_ids.data(), (int64_t)lazy_ids.size(), &mt));
 				}
 				else if (lazy_masking) {                       // t.data stays unmasked: the next query block's seed stage needs it so
 					t_masked[(size_t)g].resize(t.data.size());
@@ -1047,7 +1049,7 @@ int run_blastp(const Options& o)
 						chk(dmnd_seg_mask_block(t_masked[(size_t)g].data(), t.limits.data(), t_seqs, threads, &mt));
 						chk(dmnd_upload_block(ctx, DMND_TARGET, t_masked[(size_t)g].data(), (int64_t)t.data.size(), t.limits.data(), t_seqs));
 					}
-					else chk(dmnd_mask_block(ctx, DMND_TARGET, t_masked[(size_t)g].data(), &mt));      // patches the masked positions into the copy
+					else chk(dmnd_mask_sequences(ctx, DMND_TARGET, t_masked[(size_t)g].data(), lazy_ids.data(), (int64_t)lazy_ids.size(), &mt));      // patches the masked positions into the copy
 					t_host = t_masked[(size_t)g].data();
 				}
 				else chk(dmnd_mask_block(ctx, DMND_TARGET, t.data.data(), &mt));
@@ -1073,7 +1075,17 @@ int run_blastp(const Options& o)
 				std::snprintf(b, sizeof b, " (kernels: index %.2f, stream %.2f, mask %.2f, pairs %.2f, all %.2f ms)", ms[0], ms[1], ms[2], ms[3], ms[4]);
 				g_timeline.mark("seed stage of block " + std::to_string(bi) + " done" + b);
 			}
-			if (lazy_masking) { mask_target(); g_timeline.mark("reference block " + std::to_string(bi) + " masked lazily"); }
+			if (lazy_masking) {
+				if (!seg) {                                      // which targets: the sequence that holds each hit's reference position
+					lazy_ids.reserve(hits.size());
+					for (const dmnd_seed_hit& h : hits)
+						lazy_ids.push_back((int32_t)(std::upper_bound(t.limits.begin(), t.limits.end(), h.subject) - t.limits.begin() - 1));
+					std::sort(lazy_ids.begin(), lazy_ids.end());
+					lazy_ids.erase(std::unique(lazy_ids.begin(), lazy_ids.end()), lazy_ids.end());
+				}
+				mask_target();
+				g_timeline.mark("reference block " + std::to_string(bi) + " masked lazily (" + std::to_string(lazy_ids.size()) + " targets)");
+			}
 			t0 = std::chrono::steady_clock::now();
 			if (o.no_self_hits) {
 				if (blastx) throw std::runtime_error("--no-self-hits is not supported for blastx");      // basic/config.cpp:677

@@ -118,7 +118,7 @@ struct dmnd_ctx {
 	dmnd::DevBuf gf_tables, gf_hits, gf_flags, gf_scores;
 	double gapped_filter_evalue = 0.0, gf_ms = 0.0;
 	// tantan masking (mask_api.hip)
-	dmnd::DevBuf mask_lr, mask_pb, mask_scale, mask_pos;
+	dmnd::DevBuf mask_lr, mask_pb, mask_scale, mask_pos, mask_ids, mask_soff;
 	// motif soft masking (dmnd_soft_mask_block): a copy of each block with the motif stretches masked, read by the seed
 	// stage for seed generation only; soft_valid is dropped whenever the block changes
 	dmnd::DevBuf soft[2], motif_hit, motif_table;

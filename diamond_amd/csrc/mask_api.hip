@@ -206,7 +206,22 @@ extern "C" int dmnd_soft_mask_block(dmnd_ctx* c, int which, int64_t* n_covered)
 	return DMND_OK;
 }
 
+static int mask_impl(dmnd_ctx* c, int which, int8_t* host_data, const int32_t* ids, int64_t n_ids, int64_t* n_masked);
+
 extern "C" int dmnd_mask_block(dmnd_ctx* c, int which, int8_t* host_data, int64_t* n_masked)
+{
+	return mask_impl(c, which, host_data, nullptr, 0, n_masked);
+}
+
+extern "C" int dmnd_mask_sequences(dmnd_ctx* c, int which, int8_t* host_data, const int32_t* seq_ids, int64_t n, int64_t* n_masked)
+{
+	if (n < 0 || (n > 0 && !seq_ids)) return fail(DMND_E_ARG, "dmnd_mask_sequences: bad argument");
+	if (n_masked) *n_masked = 0;
+	if (n == 0) return c && (which == DMND_QUERY || which == DMND_TARGET) ? DMND_OK : fail(DMND_E_ARG, "dmnd_mask_sequences: bad argument");
+	return mask_impl(c, which, host_data, seq_ids, n, n_masked);
+}
+
+static int mask_impl(dmnd_ctx* c, int which, int8_t* host_data, const int32_t* ids, int64_t n_ids, int64_t* n_masked)
 {
 	if (!c || (which != DMND_QUERY && which != DMND_TARGET)) return fail(DMND_E_ARG, "dmnd_mask_block: bad argument");
 	c->soft_valid[which] = false;
@@ -230,8 +245,26 @@ extern "C" int dmnd_mask_block(dmnd_ctx* c, int which, int8_t* host_data, int64_
 	a.p.d[TANTAN_WINDOW - 1] = b2f0;
 	for (int i = TANTAN_WINDOW - 2; i >= 0; --i) a.p.d[i] = a.p.d[i + 1] * growth;
 	if (int rc = c->mask_lr.ensure(lr.size() * sizeof(float))) return rc;
-	if (int rc = c->mask_pb.ensure((size_t)raw * sizeof(float))) return rc;
-	if (int rc = c->mask_scale.ensure((size_t)(raw / 16 + n + 16) * sizeof(float))) return rc;
+	// a subset of the sequences (lazy masking: only the targets that reach the extension stage): compact scratch, ids and scratch
+	// offsets uploaded
+	std::vector<int64_t> soff;
+	int64_t scratch_letters = raw, n_work = n;
+	if (ids) {
+		soff.resize((size_t)n_ids);
+		int64_t acc = 0;
+		for (int64_t k = 0; k < n_ids; ++k) {
+			if (ids[k] < 0 || ids[k] >= n) return fail(DMND_E_ARG, "dmnd_mask_sequences: sequence id outside the block");
+			soff[(size_t)k] = acc;
+			acc += lim[(size_t)ids[k] + 1] - lim[(size_t)ids[k]];
+		}
+		scratch_letters = acc + 64; n_work = n_ids;
+		if (int rc = c->mask_ids.ensure((size_t)n_ids * sizeof(int32_t))) return rc;
+		if (int rc = c->mask_soff.ensure((size_t)n_ids * sizeof(int64_t))) return rc;
+		HIP_TRY(hipMemcpyAsync(c->mask_ids.p, ids, (size_t)n_ids * sizeof(int32_t), hipMemcpyHostToDevice, st));
+		HIP_TRY(hipMemcpyAsync(c->mask_soff.p, soff.data(), (size_t)n_ids * sizeof(int64_t), hipMemcpyHostToDevice, st));
+	}
+	if (int rc = c->mask_pb.ensure((size_t)scratch_letters * sizeof(float))) return rc;
+	if (int rc = c->mask_scale.ensure((size_t)(scratch_letters / 16 + n_work + 16) * sizeof(float))) return rc;
 	if (int rc = c->counters.ensure(64 * sizeof(unsigned long long))) return rc;
 	HIP_TRY(hipMemcpyAsync(c->mask_lr.p, lr.data(), lr.size() * sizeof(float), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemsetAsync(c->counters.p, 0, 2 * sizeof(unsigned long long), st));
@@ -241,7 +274,9 @@ extern "C" int dmnd_mask_block(dmnd_ctx* c, int which, int8_t* host_data, int64_
 	if (pos_cap) if (int rc = c->mask_pos.ensure((size_t)pos_cap * sizeof(uint32_t))) return rc;
 	a.data = c->block[which].as<int8_t>();
 	a.limits = c->d_limits[which].as<int64_t>();
-	a.n_seqs = n;
+	a.n_seqs = n_work;
+	a.ids = ids ? c->mask_ids.as<int32_t>() : nullptr;
+	a.scratch_off = ids ? c->mask_soff.as<int64_t>() : nullptr;
 	a.lr = c->mask_lr.as<float>();
 	a.pb = c->mask_pb.as<float>();
 	a.scale = c->mask_scale.as<float>();

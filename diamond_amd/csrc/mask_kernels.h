@@ -15,6 +15,8 @@ struct TantanArgs {
 	float* pb;                    // scratch: one float per block letter (indexed like data)
 	float* scale;                 // scratch: limits[i] / 16 + i is the first slot of sequence i
 	unsigned long long* n_masked; // out: number of letters masked
+	const int32_t* ids;           // optional: only these sequences (block sequence ids), n_seqs of them; scratch_off[k] = where sequence
+	const int64_t* scratch_off;   //   ids[k] keeps its floats in pb / scale (cumulative letters + 1 of the sequences before it)
 	uint32_t* masked_pos;         // out (optional): block offsets of the letters that were overwritten, in no particular order
 	unsigned long long* n_pos;    //   their number (may exceed pos_cap: then the list is incomplete)
 	unsigned long long pos_cap;

@@ -43,14 +43,16 @@ __global__ __launch_bounds__(256) void tantan_kernel(const TantanArgs a)
 	for (int i = threadIdx.x; i < 1024; i += blockDim.x) L[i] = a.lr[i];
 	__syncthreads();
 	const int lane = threadIdx.x & 63;
-	const int64_t seq_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-	if (seq_id >= a.n_seqs) return;
+	const int64_t work = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	if (work >= a.n_seqs) return;
+	const int64_t seq_id = a.ids ? (int64_t)a.ids[work] : work;
 	const int64_t base = a.limits[seq_id];
 	const int len = (int)(a.limits[seq_id + 1] - base - 1);
 	if (len <= 0) return;
 	int8_t* seq = a.data + base;
-	float* pb = a.pb + base;
-	float* scale = a.scale + base / 16 + seq_id;
+	const int64_t sbase = a.ids ? a.scratch_off[work] : base;          // a subset keeps its scratch compact
+	float* pb = a.pb + sbase;
+	float* scale = a.scale + sbase / 16 + work;
 	const bool own = lane < TANTAN_WINDOW;
 	const float d = own ? a.p.d[lane] : 0.0f;
 	const float f2f = a.p.f2f, b2b = a.p.b2b, pre = a.p.p_repeat_end;

@@ -71,7 +71,7 @@ EXPORTS = ["dmnd_abi_version", "dmnd_last_error", "dmnd_default_params", "dmnd_c
            "dmnd_seed_params_set_index_chunks", "dmnd_join_blocks", "dmnd_set_sensitivity", "dmnd_touch_streams",
            "dmnd_seed_params_set_query_indexed", "dmnd_auto_query_indexed", "dmnd_set_motif_table", "dmnd_motif_table_size",
            "dmnd_soft_mask_block", "dmnd_output_fields", "dmnd_format_fields", "dmnd_format_pairwise_intro", "dmnd_format_pairwise",
-           "dmnd_format_paf", "dmnd_device_count", "dmnd_set_top_percent", "dmnd_join_blocks_top", "dmnd_set_filters", "dmnd_format_sam", "dmnd_set_query_source_lengths", "dmnd_format_fields_unaligned", "dmnd_format_fields_header", "dmnd_set_query_index_reuse", "dmnd_set_no_self_hits", "dmnd_matrix_params", "dmnd_masking_lambda", "dmnd_translate_opts", "dmnd_set_extension_mode", "dmnd_format_xml_header", "dmnd_format_xml_query_intro", "dmnd_format_xml", "dmnd_format_xml_query_epilog", "dmnd_format_daa_header", "dmnd_format_daa_query", "dmnd_format_daa_match", "dmnd_seg_ranges", "dmnd_seg_mask_block", "dmnd_seg_lnfact", "dmnd_daa_match_read", "dmnd_hsp_from_transcript", "dmnd_set_format_flags", "dmnd_host_alloc", "dmnd_host_free", "dmnd_share_block", "dmnd_init", "dmnd_seed_reserve"]
+           "dmnd_format_paf", "dmnd_device_count", "dmnd_set_top_percent", "dmnd_join_blocks_top", "dmnd_set_filters", "dmnd_format_sam", "dmnd_set_query_source_lengths", "dmnd_format_fields_unaligned", "dmnd_format_fields_header", "dmnd_set_query_index_reuse", "dmnd_set_no_self_hits", "dmnd_matrix_params", "dmnd_masking_lambda", "dmnd_translate_opts", "dmnd_set_extension_mode", "dmnd_format_xml_header", "dmnd_format_xml_query_intro", "dmnd_format_xml", "dmnd_format_xml_query_epilog", "dmnd_format_daa_header", "dmnd_format_daa_query", "dmnd_format_daa_match", "dmnd_seg_ranges", "dmnd_seg_mask_block", "dmnd_seg_lnfact", "dmnd_daa_match_read", "dmnd_hsp_from_transcript", "dmnd_set_format_flags", "dmnd_host_alloc", "dmnd_host_free", "dmnd_share_block", "dmnd_init", "dmnd_seed_reserve", "dmnd_mask_sequences"]
 
 
 def set_motif_table(codes):
@@ -624,6 +624,18 @@ class Context:
             assert host_data.dtype == np.int8 and host_data.flags["C_CONTIGUOUS"]
             ptr = host_data.ctypes.data
         self._check(self.lib.dmnd_mask_block(self.h, int(which), ptr, ctypes.byref(n)))
+        return n.value
+
+    def mask_sequences(self, which, host_data, seq_ids):
+        """tantan on the given sequences of the block only (lazy masking); host_data as for mask_block. Returns the masked positions."""
+        ids = np.ascontiguousarray(seq_ids, dtype=np.int32)
+        n = ctypes.c_int64(0)
+        ptr = None
+        if host_data is not None:
+            assert host_data.dtype == np.int8 and host_data.flags["C_CONTIGUOUS"]
+            ptr = host_data.ctypes.data
+        self.lib.dmnd_mask_sequences.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
+        self._check(self.lib.dmnd_mask_sequences(self.h, int(which), ptr, ids.ctypes.data, ctypes.c_int64(ids.size), ctypes.byref(n)))
         return n.value
 
     def mask_kernel_ms(self):

@@ -341,6 +341,11 @@ int dmnd_format_tab_translated(const dmnd_match* m, const char* qseqid, const ch
  * back -- so that the extension stage's host part reads the same letters. *n_masked (may be NULL) = number of positions at or
  * above the mask probability. */
 int dmnd_mask_block(dmnd_ctx* ctx, int which, int8_t* host_data, int64_t* n_masked);
+/* The same for a subset of the block's sequences (block sequence ids, any order, no duplicates): what the reference's LAZY masking
+ * does -- with the query-indexed algorithm it masks a target only when the extension stage loads it (align/extend.cpp:168-181), i.e.
+ * the targets that have seed hits. tantan works sequence by sequence, so the letters of those targets come out as dmnd_mask_block
+ * leaves them; the scratch and the kernel shrink with the subset (C2: 15 k of 10^6 sequences). */
+int dmnd_mask_sequences(dmnd_ctx* ctx, int which, int8_t* host_data, const int32_t* seq_ids, int64_t n, int64_t* n_masked);
 double dmnd_mask_kernel_ms(const dmnd_ctx* ctx);
 /* The lambda of those likelihood ratios (host only): the scale at which the matrix's implied letter probabilities are valid
  * (cbrc::LambdaCalculator::calculate, src/lib/tantan/LambdaCalculator.cc), or -1 where the matrix has none (PAM250) -- the value

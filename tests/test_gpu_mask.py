@@ -76,3 +76,31 @@ def test_planted_repeats_and_boundary_lengths_against_oracle(ctx):
         total += k
     assert n == total > 2000
     assert (host[:256] == 31).all() and (host[limits[1:] - 1] == 31).all()          # delimiters and padding untouched
+
+
+def test_masking_a_subset_of_sequences_leaves_the_others_alone(ctx):
+    """dmnd_mask_sequences (lazy masking: only the targets that have seed hits): the chosen sequences come out as dmnd_mask_block
+    leaves them, every other letter -- in HBM and in the host copy -- is untouched."""
+    hdr, recs = read_tantan_tap(os.path.join(GOLDEN, "tantan.tap"))
+    data, limits = _block([r["before"] for r in recs])
+    want, _ = _block([r["after"] for r in recs])
+    n_seq = len(recs)
+    rng = np.random.default_rng(5)
+    for ids in (rng.permutation(n_seq)[: n_seq // 3], np.array([n_seq - 1, 0], np.int64), np.arange(n_seq)[::-1], np.zeros(0, np.int64)):
+        ctx.upload_block(hip.TARGET, data, limits)
+        host = data.copy()
+        n = ctx.mask_sequences(hip.TARGET, host, ids)
+        expect = data.copy()
+        changed = 0
+        for i in ids:
+            a, b = int(limits[i]), int(limits[i + 1])
+            expect[a:b] = want[a:b]
+            changed += int((want[a:b] != data[a:b]).sum())
+        assert np.array_equal(host, expect)
+        assert n >= changed
+        # the device copy holds the same letters: a second pass over the REST now completes the block
+        rest = np.setdiff1d(np.arange(n_seq), ids)
+        ctx.mask_sequences(hip.TARGET, host, rest)
+        assert np.array_equal(host, want)
+    with pytest.raises(Exception):
+        ctx.mask_sequences(hip.TARGET, None, np.array([n_seq], np.int64))            # id outside the block
