@@ -112,11 +112,6 @@ struct dmnd_ctx {
 	size_t trace_arena_max = (size_t)8 << 30;
 	// seed-stage buffers (seed_api.hip)
 	dmnd::DevBuf qid_of, mask_time, seed_keys, seed_next, seed_qlist, seed_qkeys, seed_slot2, seed_loc2, seed_survivors, seed_scored, seed_need, seed_qfold, matched_slot, matched_loc, counters, seed_hits, seed_bitmap, seed_deferred, seed_eslot, seed_eloc, seed_hits_sorted, sort_keys[2], sort_idx[2];
-	// partitioned join of the short-seed pipeline (SeedPart, seed_kernels.h): sorted slots, folded windows and partition offsets of the
-	// query side (per shape when the index is kept), the partitions' cursors and entry buffers; part_fill = entries per reference
-	// position seen so far (sizes the entry buffers of the next shape / call)
-	dmnd::DevBuf part_sorted, part_fold, part_off, part_cursor, part_entries;
-	double part_fill = 0.40;
 	void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0;      // rocPRIM radix sort scratch
 	int64_t n_seed_hits = 0;
 	// gapped filter (gapped_api.hip)

@@ -250,9 +250,12 @@ static SeedSizes seed_sizes(const dmnd_ctx* c, const SeedParams& sp, int64_t nq_
 {
 	SeedSizes z;
 	const int S = sp.n_shapes;
+	// Table slots per query position: two for long seeds, FOUR for the short seeds of the fused pipeline, where a third of the
+	// reference positions probe the table and the probe chains are what costs (most query seeds are distinct: two slots per
+	// position = 36 % load). Measured on C3 (16 shapes): stream + filter 189 / 124 / 116 / 115 ms at 1 / 2 / 4 / 8 slots per position
+	// (DMND_SEED_SLOTS_X8 = 8 / 16 / 32 / 64, slots per position in eighths).
+	const uint64_t slots_x8 = [&] { const char* e = getenv("DMND_SEED_SLOTS_X8"); return (uint64_t)(e ? std::min(64, std::max(8, atoi(e))) : (seed_stream_can_fuse(sp) ? 32 : 16)); }();
 	z.slots = 1024;
-	// experiment knob: table slots per query position in eighths (default 16 = two slots per position; 8 halves the table)
-	const uint64_t slots_x8 = [] { const char* e = getenv("DMND_SEED_SLOTS_X8"); return (uint64_t)(e ? std::min(64, std::max(8, atoi(e))) : 16); }();
 	while (z.slots * 8 < (uint64_t)nq_pos * slots_x8) z.slots <<= 1;
 
 	// bitmap: >= 16 bits per query position, at most 2^27 bits (16 MB); word mask for 32-bit words
@@ -394,18 +397,10 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	const size_t slot_bytes = (size_t)slots << z.slot_shift;      // one shape's table
 	const bool fused = z.fused, reuse = z.reuse;
 	const size_t bm_total = z.bm_total;
-	// Partitioned join (SeedPart, seed_kernels.h): spaced short seeds, entry positions as 32-bit offsets. DMND_SEED_PART=0: the fused
-	// stream kernel alone (round 2's path, kept for the A/B comparison and for what the partitions do not take).
-	const bool part_env = [] { const char* e = getenv("DMND_SEED_PART"); return !e || atoi(e) != 0; }();      // (read per call: the tests switch it)
-	const int64_t part_base = t_begin & ~(int64_t)15;
-	const bool part = fused && part_env && sp.seed_encoding == SEED_SPACED && slots >= 2 * PART_SLOTS && slots <= ((uint64_t)1 << 31)
-		&& t_end - part_base < ((int64_t)1 << 32);
-	const uint32_t n_parts = part ? (uint32_t)(slots >> PART_SHIFT) : 0;
-	const int part_scope = [] { const char* e = getenv("DMND_SEED_PART_SCOPE"); return e ? atoi(e) : 0; }();
 	std::string signature;
 	if (reuse) {
 		signature.assign(reinterpret_cast<const char*>(&sp), sizeof(sp));
-		const uint64_t extra[7] = { c->query_generation, (uint64_t)nq_pos, slots, bm_words, bm1_words, (uint64_t)fused + 2 * (uint64_t)part, (uint64_t)z.slot_shift * 2 + bm1_k3 };
+		const uint64_t extra[7] = { c->query_generation, (uint64_t)nq_pos, slots, bm_words, bm1_words, (uint64_t)fused, (uint64_t)z.slot_shift * 2 + bm1_k3 };
 		signature.append(reinterpret_cast<const char*>(extra), sizeof(extra));
 	}
 	const bool index_ready = reuse && c->qindex_signature == signature && !signature.empty();
@@ -413,13 +408,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	lap("parameters checked");
 	if (int rc = seed_reserve(c, sp, z, nq_pos, q_end, c->block_len[DMND_QUERY], false)) return rc;
 	lap("buffers ensured");
-	if (int rc = c->counters.ensure((size_t)(S + 8) * sizeof(unsigned long long))) return rc;      // [S] hits, [S+1] deferred pairs, [S+2] collected positions, [S+3] Hamming survivors, [S+4] scored survivors, [S+5], [S+6] partitioned join: entries joined / spilled
-	if (part) {
-		if (int rc = c->part_sorted.ensure((size_t)SB * nq_pos * sizeof(uint32_t))) return rc;
-		if (int rc = c->part_fold.ensure((size_t)SB * nq_pos * PART_FOLD_WORDS * sizeof(uint32_t))) return rc;
-		if (int rc = c->part_off.ensure((size_t)SB * ((size_t)n_parts + 1) * sizeof(uint32_t))) return rc;
-		if (int rc = c->part_cursor.ensure((size_t)PART_XCDS * n_parts * sizeof(uint32_t))) return rc;
-	}
+	if (int rc = c->counters.ensure((size_t)(S + 5) * sizeof(unsigned long long))) return rc;      // [S] hits, [S+1] deferred pairs, [S+2] collected positions, [S+3] Hamming survivors, [S+4] scored survivors
 	if (!index_ready) HIP_TRY(hipMemsetAsync(c->seed_bitmap.p, 0, bm_total, st));
 	if (!index_ready) HIP_TRY(hipMemsetAsync(c->seed_next.p, 0xff, (size_t)SB * nq_pos * sizeof(uint32_t), st));
 	HIP_TRY(hipMemsetAsync(c->mask_time.p, SEED_NEVER, (size_t)c->block_len[DMND_QUERY] + 256, st));
@@ -471,17 +460,6 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		a.fused = fused ? 1 : 0;
 		a.level2 = level2_of(sid);
 		a.qfold = use_fold ? c->seed_qfold.as<uint8_t>() : nullptr;
-		std::memset(&a.part, 0, sizeof(a.part));
-		if (part) {                                        // (entries and cap are set per shape by the fused loop)
-			a.part.cursor = c->part_cursor.as<uint32_t>();
-			a.part.n_parts = n_parts;
-			a.part.sorted_slot = c->part_sorted.as<uint32_t>() + (size_t)own * nq_pos;
-			a.part.part_off = c->part_off.as<uint32_t>() + (size_t)own * ((size_t)n_parts + 1);
-			a.part.fold = c->part_fold.as<uint32_t>() + (size_t)own * nq_pos * PART_FOLD_WORDS;
-			a.part.base = part_base;
-			a.part.stats = c->counters.as<unsigned long long>() + S + 5;
-			a.part.device_scope = part_scope;
-		}
 		return a;
 	};
 
@@ -492,9 +470,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	auto query_side = [&](const SeedArgs& a, int sid, bool build) -> int {
 		if (build) {
 			HIP_TRY(launch_seed_index(a, sid, st));
-			uint32_t* sorted_slot = part ? const_cast<uint32_t*>(a.part.sorted_slot) : c->seed_qkeys.as<uint32_t>();
-			HIP_TRY(launch_seed_lists(a, sid, sorted_slot, c->seed_qlist.as<uint32_t>() + (size_t)(SB == 1 ? 0 : sid) * nq_pos, 32, &c->sort_tmp, &c->sort_tmp_bytes, st));
-			if (part) HIP_TRY(launch_seed_part_build(a, st));
+			HIP_TRY(launch_seed_lists(a, sid, c->seed_qkeys.as<uint32_t>(), c->seed_qlist.as<uint32_t>() + (size_t)(SB == 1 ? 0 : sid) * nq_pos, 32, &c->sort_tmp, &c->sort_tmp_bytes, st));
 		}
 		else HIP_TRY(launch_seed_reset(a, sid, st));
 		return DMND_OK;
@@ -516,11 +492,10 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		int64_t hit_cap = std::max<int64_t>((int64_t)1 << 20, (int64_t)(c->seed_hits.cap / sizeof(dmnd_seed_hit)));
 		if (const char* e = getenv("DMND_SEED_HIT_CAP")) hit_cap = std::max<int64_t>(1, atoll(e));
 		if (int rc = c->seed_hits.ensure((size_t)hit_cap * sizeof(dmnd_seed_hit))) return rc;
-		HIP_TRY(hipMemsetAsync(ctr, 0, (size_t)(S + 8) * sizeof(unsigned long long), st));
+		HIP_TRY(hipMemsetAsync(ctr, 0, (size_t)(S + 5) * sizeof(unsigned long long), st));
 		c->seed_trace.assign((size_t)2 * S, 0);
 		int64_t hits_bound = 0;                              // every survivor gives at most one hit
-		std::vector<unsigned long long> host_ctr((size_t)S + 7);
-		const int64_t part_cap_env = [] { const char* e = getenv("DMND_SEED_PART_CAP"); return e ? atoll(e) : (int64_t)0; }();
+		std::vector<unsigned long long> host_ctr((size_t)S + 4);
 		for (int sid = 0; sid < S; ++sid) {
 			SeedArgs a = args_for(sid, 0, 0);
 			tm.start();
@@ -540,30 +515,11 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 				a.survivors = c->seed_survivors.as<SeedSurvivor>(); a.survivor_cap = surv_cap;
 				HIP_TRY(hipMemsetAsync(a.matched_count, 0, sizeof(unsigned long long), st));
 				HIP_TRY(hipMemsetAsync(a.survivor_count, 0, sizeof(unsigned long long), st));
-				if (part) {
-					// entry buffers: 1.3 x what the last shape (or call) put into a partition on average; what does not fit takes the old
-					// path inside the stream kernel, so a low estimate costs time, not results
-					const int64_t subs = (int64_t)n_parts * PART_XCDS;                              // one sub-buffer per partition and XCD
-					int64_t cap = (int64_t)(1.3 * c->part_fill * (double)(t_end - t_begin) / (double)subs) + 64;
-					if (part_cap_env > 0) cap = part_cap_env;
-					cap = std::min<int64_t>(cap, ((int64_t)48 << 30) / 32 / subs);                  // at most 48 GB of entries
-					if (int rc = c->part_entries.ensure((size_t)subs * (size_t)cap * 32)) return rc;
-					a.part.entries = c->part_entries.as<uint4>();
-					a.part.cap = (uint32_t)cap;
-					HIP_TRY(hipMemsetAsync(a.part.cursor, 0, (size_t)subs * sizeof(uint32_t), st));
-					HIP_TRY(hipMemsetAsync(a.part.stats, 0, 2 * sizeof(unsigned long long), st));
-				}
 				tm.start();
 				HIP_TRY(launch_seed_stream(a, sid, st, true));
-				if (part) HIP_TRY(launch_seed_part_join(a, sid, st));
 				c->seed_ms[1] += tm.stop();
 				HIP_TRY(copy_now(c->stream, host_ctr.data(), ctr, host_ctr.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
 				n = host_ctr[sid]; ns = host_ctr[S + 3];
-				if (part && host_ctr[S + 5] + host_ctr[S + 6] > 0) {
-					c->part_fill = (double)(host_ctr[S + 5] + host_ctr[S + 6]) / (double)(t_end - t_begin);
-					if (lap_on) std::fprintf(stderr, "dmnd_seed_search shape %d: partitioned join %llu entries, %llu took the old path (cap %u x %u partitions x %u XCDs)\n",
-						sid, host_ctr[S + 5], host_ctr[S + 6], a.part.cap, n_parts, (unsigned)PART_XCDS);
-				}
 				if ((int64_t)n <= m_cap && (int64_t)ns <= surv_cap) break;
 				if (attempt >= 2) return fail(DMND_E_NOMEM, "dmnd_seed_search: joined-position / survivor buffer overflow");
 				if ((int64_t)n > m_cap) m_cap = (int64_t)n + (int64_t)n / 8 + 1024;
@@ -631,7 +587,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	for (int attempt = 0;; ++attempt) {
 		if (int rc = c->matched_slot.ensure((size_t)cap_total * sizeof(uint32_t))) return rc;
 		if (int rc = c->matched_loc.ensure((size_t)cap_total * sizeof(int64_t))) return rc;
-		HIP_TRY(hipMemsetAsync(c->counters.p, 0, (size_t)(S + 8) * sizeof(unsigned long long), st));
+		HIP_TRY(hipMemsetAsync(c->counters.p, 0, (size_t)(S + 5) * sizeof(unsigned long long), st));
 		if (attempt > 0) {
 			HIP_TRY(hipMemsetAsync(c->seed_keys.p, 0xff, (size_t)S * slot_bytes, st));
 			HIP_TRY(hipMemsetAsync(c->seed_bitmap.p, 0, bm_total, st));

@@ -31,30 +31,6 @@ struct SeedSurvivor { uint32_t slot, x; int64_t sloc; };
 // A survivor whose stage-2 ungapped score passed the cutoff: input of the left-most rule (seed_leftmost_kernel)
 struct SeedScored { uint32_t slot, x; int64_t sloc; int32_t score, chunk; };
 
-// Partitioned join of the short-seed pipeline (round 3). The fused stream kernel loses its time on random reads of the query
-// side (slot, list, folded windows: 3e8 L2 misses per shape on C3). Here the stream only SCATTERS a level-1 positive -- key,
-// position and the folded window of the reference -- into the buffer of the partition its home slot lies in (a partition = PART_SLOTS
-// consecutive slots of the table), and a second kernel joins one partition per workgroup with that partition's query side -- slots,
-// position lists, folded query windows, contiguous in HBM because the lists are sorted by slot -- held in LDS. Random reads become
-// one scattered 32-byte write and two streaming reads. Entries that do not fit a partition's buffer take the old path in the
-// stream kernel itself.
-// XCD-aware: every partition has one sub-buffer and one cursor PER XCD (HW_REG_XCC_ID of the writing workgroup). The cursor is then
-// only ever touched through one XCD's L2, so its atomic runs there (workgroup scope: no sc1, no fabric round trip -- a device-scope
-// atomic per entry, 1e8 per shape, cost more than the random reads it replaced), and the 128-byte lines of a sub-buffer fill up
-// in that L2 and leave it once, whole (entries of one partition written through eight L2s left as 16-byte partial writes).
-enum : uint32_t { PART_SHIFT = 11, PART_SLOTS = 1u << PART_SHIFT, PART_OVER = 64, PART_ENTRIES = 1024, PART_FOLD_WORDS = 5, PART_XCDS = 8 };
-struct SeedPart {
-	uint32_t* cursor;             // [PART_XCDS][n_parts] entries appended to each sub-buffer (may run past cap: the excess took the old path)
-	uint4* entries;               // [PART_XCDS][n_parts][cap] x 32 bytes: key (2 words), position - base, folded letters pos - 8 .. pos + 31 (5 words)
-	uint32_t cap, n_parts;
-	const uint32_t* sorted_slot;  // the query positions' slots, ascending (launch_seed_lists); LIST_END at the end
-	const uint32_t* part_off;     // [n_parts + 1] first index into sorted_slot / qlist / fold of every partition
-	uint32_t* fold;               // [n query positions][5] folded query windows (letters x - 8 .. x + 31), in list order
-	int64_t base;                 // reference position that entry positions count from
-	unsigned long long* stats;    // [0] entries joined by the partition kernel, [1] entries that did not fit (old path)
-	int device_scope;             // cursor atomics at device scope (DMND_SEED_PART_SCOPE=1: the A/B switch)
-};
-
 struct SeedArgs {
 	SeedParams params;
 	const int8_t* qdata; const int8_t* tdata;     // block letters (HBM)
@@ -96,7 +72,6 @@ struct SeedArgs {
 	const uint8_t* qfold;                         // fused pipeline: the query block with 4 bits per letter (letter & 15), or NULL: pre-filter of the Hamming test
 	int level2;                                   // the level-2 bitmap is filled and consulted (long seeds)
 	int fused;                                    // short-seed pipeline: seed_lists_kernel decides SLOT_LOWC for every group (the stream needs it)
-	SeedPart part;                                // part.entries != NULL: partitioned join (spaced short seeds)
 };
 
 hipError_t launch_seed_qid(const int64_t* limits, int64_t n_seqs, uint32_t* qid_of, hipStream_t st);
@@ -114,10 +89,6 @@ hipError_t launch_seed_reset(const SeedArgs& a, int sid, hipStream_t st);
 // letters [0, n) of a block folded to 4 bits each, two per byte (out: (n + 1) / 2 bytes)
 hipError_t launch_seed_fold(const int8_t* data, int64_t n, uint8_t* out, hipStream_t st);
 hipError_t launch_seed_stream(const SeedArgs& a, int sid, hipStream_t st, bool fused = false);
-// partitioned join: offsets and folded windows of the query side (after launch_seed_lists); the join of the scattered entries (after
-// launch_seed_stream with a.part set)
-hipError_t launch_seed_part_build(const SeedArgs& a, hipStream_t st);
-hipError_t launch_seed_part_join(const SeedArgs& a, int sid, hipStream_t st);
 bool seed_stream_can_fuse(const SeedParams& c);
 // n_matched >= 0: the number of joined positions in a.matched_* (few of them: the kernel walks that list instead of the table)
 hipError_t launch_seed_mask(const SeedArgs& a, int sid, hipStream_t st, int64_t n_matched = -1);

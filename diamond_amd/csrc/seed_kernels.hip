@@ -17,7 +17,6 @@
 #include <stdint.h>
 #include "seed_core.h"
 #include <cstring>
-#include <algorithm>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
 #include "seed_kernels.h"
@@ -227,22 +226,7 @@ __device__ __forceinline__ uint32_t bm1_probe_any(int policy, __amdgpu_buffer_rs
 	}
 }
 
-// eight letters (two words) folded to 4 bits each: letter k -> nibble k
-__device__ __forceinline__ uint32_t fold_letters8(uint32_t lo, uint32_t hi)
-{
-	lo &= 0x0f0f0f0fu; hi &= 0x0f0f0f0fu;
-	lo = (lo | (lo >> 4)) & 0x00ff00ffu; lo = (lo | (lo >> 8)) & 0xffffu;
-	hi = (hi | (hi >> 4)) & 0x00ff00ffu; hi = (hi | (hi >> 8)) & 0xffffu;
-	return lo | (hi << 16);
-}
-// nibbles that differ between two folded words
-__device__ __forceinline__ int fold_mismatches(uint32_t x, uint32_t y)
-{
-	const uint32_t d = x ^ y;
-	return __builtin_popcount((((d & 0x77777777u) + 0x77777777u) | d) & 0x88888888u);
-}
-
-template<bool LEVEL2, bool HASHED, bool FUSED, bool PART = false>
+template<bool LEVEL2, bool HASHED, bool FUSED>
 __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int sid, uint64_t map_lo, uint64_t map_hi, int64_t base, uint64_t care64)
 {
 	// Joined positions are staged in LDS and flushed with ONE atomic on the shared counter per workgroup: an atomicAdd per
@@ -265,7 +249,6 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 	if (threadIdx.x == 0) { st_n = 0; sv_n = 0; hv_n = 0; }
 	__syncthreads();
 	const __amdgpu_buffer_rsrc_t bm1_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.bitmap1, 0, (int)(a.bitmap1_words * 4u), 0x00020000);
-	const uint32_t xcc = PART ? (__builtin_amdgcn_s_getreg(20 | (3 << 11)) & (PART_XCDS - 1)) : 0u;      // HW_REG_XCC_ID[3:0]: the XCD this workgroup runs on
 	const int64_t wg_base = base + (int64_t)blockIdx.x * blockDim.x * 16;
 	const int64_t p0 = wg_base + (int64_t)threadIdx.x * 16;
 	const bool in_range = p0 < a.t_end;
@@ -401,39 +384,6 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 		}
 #pragma unroll
 		for (int i = 0; i < 8; ++i) pos_mask |= word[i] << i;
-		if (PART) {
-			// partitioned join: a level-1 positive is appended to the buffer of its home slot's partition. The eight cursor atomics of
-			// a thread are issued back to back (independent round trips), then the entries are written.
-			uint32_t at[8], pt[8];
-			const uint32_t sub0 = xcc * a.part.n_parts;              // this XCD's cursors and sub-buffers
-#pragma unroll
-			for (int i = 0; i < 8; ++i) {
-				at[i] = 0; pt[i] = 0;
-				if ((pos_mask >> i) & 1u) {
-					pt[i] = sub0 + ((seed_hash_a(key[i]) & (uint32_t)a.slot_mask) >> PART_SHIFT);
-					at[i] = a.part.device_scope ? atomicAdd(&a.part.cursor[pt[i]], 1u)
-						: __hip_atomic_fetch_add(&a.part.cursor[pt[i]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-				}
-			}
-#pragma unroll
-			for (int i = 0; i < 8; ++i) {
-				if (!((pos_mask >> i) & 1u)) continue;
-				const int64_t pos = p0 + 8 * half + i;
-				if (at[i] < a.part.cap) {
-					uint32_t lw[10];
-					__builtin_memcpy(lw, a.tdata + pos - 8, 40);
-					uint4 e0, e1;
-					e0.x = (uint32_t)key[i]; e0.y = (uint32_t)(key[i] >> 32); e0.z = (uint32_t)(pos - a.part.base);
-					e0.w = fold_letters8(lw[0], lw[1]);
-					e1.x = fold_letters8(lw[2], lw[3]); e1.y = fold_letters8(lw[4], lw[5]);
-					e1.z = fold_letters8(lw[6], lw[7]); e1.w = fold_letters8(lw[8], lw[9]);
-					uint4* dst = a.part.entries + ((size_t)pt[i] * a.part.cap + at[i]) * 2;
-					dst[0] = e0; dst[1] = e1;
-				}
-				else probe_table(key[i], pos);                       // the partition's buffer is full: the old path
-			}
-			pos_mask = 0;
-		}
 		// rare path: level-1 positives -> level-2 bitmap -> table
 		while (pos_mask) {
 			const int i = __builtin_ctz(pos_mask);
@@ -493,210 +443,6 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 	for (unsigned k = threadIdx.x; k < n_staged; k += blockDim.x) {
 		const unsigned long long idx = st_base + k;
 		if (idx < (unsigned long long)a.matched_cap) { a.matched_slot[idx] = st_slot[k]; a.matched_loc[idx] = wg_base + st_loc[k]; }
-	}
-}
-
-// ---- partitioned join (SeedPart, seed_kernels.h) ---------------------------------------------------------------------------
-// Query side: where every partition's run of the slot-sorted position lists starts, and the folded windows in list order.
-__global__ void seed_part_build_kernel(SeedArgs a, int64_t n, uint32_t* part_off)
-{
-	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i <= (int64_t)a.part.n_parts) {
-		const uint64_t want = (uint64_t)i << PART_SHIFT;          // first list entry whose slot is >= the partition's first slot
-		int64_t lo = 0, hi = n;
-		while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((uint64_t)a.part.sorted_slot[mid] < want) lo = mid + 1; else hi = mid; }
-		part_off[i] = (uint32_t)lo;
-	}
-	if (i >= n || a.part.sorted_slot[i] == LIST_END) return;
-	uint32_t lw[10];
-	__builtin_memcpy(lw, a.qdata + a.q_begin + (int64_t)a.qlist[i] - 8, 40);
-#pragma unroll
-	for (int w = 0; w < 5; ++w) a.part.fold[i * 5 + w] = fold_letters8(lw[2 * w], lw[2 * w + 1]);
-}
-
-// One workgroup per partition: the partition's slots (+ PART_OVER of the next one: probe chains that run over the boundary), its
-// list entries and their folded windows are loaded into LDS once; the scattered reference entries of the partition's eight
-// sub-buffers stream through. Everything the fused stream kernel produces is produced here: JOINED marks, the joined-position
-// list, the Hamming survivors.
-constexpr int PJ_THREADS = 512;
-__global__ __launch_bounds__(PJ_THREADS) void seed_part_join_kernel(SeedArgs a, int sid)
-{
-	constexpr unsigned NS = PART_SLOTS + PART_OVER, STAGE = 2048, SURV = 512, HEAVY = 64, LIGHT = 48, T = PJ_THREADS;
-	__shared__ uint64_t l_key[NS];
-	__shared__ uint32_t l_flags[NS];
-	__shared__ uint16_t l_first[PART_SLOTS];
-	__shared__ uint32_t l_x[PART_ENTRIES];
-	__shared__ uint32_t l_fold[PART_ENTRIES * 5];
-	__shared__ uint32_t st_slot[STAGE], st_pos[STAGE];
-	__shared__ uint32_t sv_slot[SURV], sv_x[SURV], sv_pos[SURV];
-	// a long list is filtered by the whole workgroup: everything that needs is staged here, so that the loop over the staged
-	// joins issues no dependent global load for a list held in LDS (with the slot and the reference window re-read per join the
-	// loop cost more than the rest of the kernel)
-	__shared__ uint32_t hv_slot[HEAVY], hv_pos[HEAVY], hv_at[HEAVY], hv_count[HEAVY], hv_tf[HEAVY * 5];
-	__shared__ unsigned st_n, sv_n, hv_n;
-	__shared__ unsigned long long st_base;
-	const uint32_t p = blockIdx.x, tid = threadIdx.x;
-	const uint32_t b = p << PART_SHIFT, smask = (uint32_t)a.slot_mask;
-	uint32_t total = 0, spilled = 0;
-#pragma unroll
-	for (int x = 0; x < (int)PART_XCDS; ++x) {
-		const uint32_t cur = a.part.cursor[(size_t)x * a.part.n_parts + p];
-		const uint32_t fit = cur < a.part.cap ? cur : a.part.cap;
-		total += fit; spilled += cur - fit;
-	}
-	if (tid == 0) {
-		st_n = 0; sv_n = 0; hv_n = 0;
-		if (total) atomicAdd(a.part.stats, (unsigned long long)total);
-		if (spilled) atomicAdd(a.part.stats + 1, (unsigned long long)spilled);
-	}
-	if (total == 0) return;                                        // (spilled entries were joined by the stream kernel)
-	for (uint32_t s = tid; s < NS; s += T) {
-		const SeedSlot sl = a.slot((b + s) & smask);
-		l_key[s] = sl.key; l_flags[s] = sl.flags;
-		if (s < PART_SLOTS) l_first[s] = 0xffffu;
-	}
-	const uint32_t lo = a.part.part_off[p], hi = a.part.part_off[p + 1];
-	const uint32_t n_ent = hi - lo < PART_ENTRIES ? hi - lo : PART_ENTRIES;
-	__syncthreads();
-	for (uint32_t e = tid; e < n_ent; e += T) {
-		const uint32_t g = lo + e, sl = a.part.sorted_slot[g];
-		l_x[e] = a.qlist[g];
-#pragma unroll
-		for (int w = 0; w < 5; ++w) l_fold[e * 5 + w] = a.part.fold[(size_t)g * 5 + w];
-		if (g == 0 || a.part.sorted_slot[g - 1] != sl) l_first[sl - b] = (uint16_t)e;
-	}
-	__syncthreads();
-	const int id_min = a.params.hamming_filter_id;
-	auto survive = [&](uint32_t slot, uint32_t x, uint32_t pos32) {
-		const unsigned k = atomicAdd(&sv_n, 1u);
-		if (k < SURV) { sv_slot[k] = slot; sv_x[k] = x; sv_pos[k] = pos32; }
-		else {
-			const unsigned long long idx = atomicAdd(a.survivor_count, 1ull);
-			if (idx < (unsigned long long)a.survivor_cap) a.survivors[idx] = SeedSurvivor{ slot, x, a.part.base + (int64_t)pos32 };
-		}
-	};
-	// the exact test of a pair that passed the folded pre-filter (fingerprint_id on the letters)
-	auto exact = [&](uint32_t slot, uint32_t x, uint32_t pos32) {
-		uint32_t tw[12], qw[12];
-		__builtin_memcpy(tw, a.tdata + a.part.base + (int64_t)pos32 - 16, 48);
-		__builtin_memcpy(qw, a.qdata + a.q_begin + (int64_t)x - 16, 48);
-		if (window_identity(tw, qw) >= id_min) survive(slot, x, pos32);
-	};
-	// entries first, first + step, ... of a list held in LDS from entry `at` on
-	auto filter_lds = [&](uint32_t slot, uint32_t at, uint32_t count, uint32_t pos32, const uint32_t* tf, uint32_t first, uint32_t step) {
-		for (uint32_t i = first; i < count; i += step) {
-			const uint32_t* qf = l_fold + (at + i) * 5;
-			int mism = 0;
-#pragma unroll
-			for (int w = 0; w < 5; ++w) mism += fold_mismatches(tf[w], qf[w]);
-			if (48 - mism >= id_min) exact(slot, l_x[at + i], pos32);
-		}
-	};
-	// the same for a list that is not (completely) in LDS: positions and folded windows from HBM
-	auto filter_hbm = [&](uint32_t slot, uint32_t head, uint32_t count, uint32_t pos32, const uint32_t* tf, uint32_t first, uint32_t step) {
-		for (uint32_t i = first; i < count; i += step) {
-			uint32_t x;
-			int mism = 0;
-			if (count == 1) {                                         // head is the query position itself: fold its letters here
-				x = head;
-				uint32_t lw[10];
-				__builtin_memcpy(lw, a.qdata + a.q_begin + (int64_t)x - 8, 40);
-#pragma unroll
-				for (int w = 0; w < 5; ++w) mism += fold_mismatches(tf[w], fold_letters8(lw[2 * w], lw[2 * w + 1]));
-			}
-			else {
-				x = a.qlist[head + i];
-#pragma unroll
-				for (int w = 0; w < 5; ++w) mism += fold_mismatches(tf[w], a.part.fold[(size_t)(head + i) * 5 + w]);
-			}
-			if (48 - mism >= id_min) exact(slot, x, pos32);
-		}
-	};
-	auto flush_matched = [&]() {                                  // block-uniform
-		const unsigned n = st_n;
-		if (n) {
-			if (tid == 0) st_base = atomicAdd(a.matched_count, (unsigned long long)n);
-			__syncthreads();
-			for (unsigned k = tid; k < n; k += T) {
-				const unsigned long long idx = st_base + k;
-				if (idx < (unsigned long long)a.matched_cap) { a.matched_slot[idx] = st_slot[k]; a.matched_loc[idx] = a.part.base + (int64_t)st_pos[k]; }
-			}
-		}
-		__syncthreads();
-		if (tid == 0) st_n = 0;
-		__syncthreads();
-	};
-#pragma unroll 1
-	for (int x = 0; x < (int)PART_XCDS; ++x) {
-		const uint32_t cur = a.part.cursor[(size_t)x * a.part.n_parts + p];
-		const uint32_t n_in = cur < a.part.cap ? cur : a.part.cap;
-		const uint4* ent = a.part.entries + ((size_t)x * a.part.n_parts + p) * a.part.cap * 2;
-#pragma unroll 1
-		for (uint32_t c0 = 0; c0 < n_in; c0 += T) {
-			const uint32_t idx = c0 + tid;
-			if (idx < n_in) {
-				const uint4 e0 = ent[(size_t)idx * 2], e1 = ent[(size_t)idx * 2 + 1];
-				const uint64_t key = (uint64_t)e0.x | ((uint64_t)e0.y << 32);
-				const uint32_t pos32 = e0.z;
-				const uint32_t tf[5] = { e0.w, e1.x, e1.y, e1.z, e1.w };
-				uint32_t s = (seed_hash_a(key) & smask) - b;        // the home slot lies in this partition
-				bool found = false;
-				uint32_t fl = 0;
-				for (;;) {
-					const uint64_t k = s < NS ? l_key[s] : a.slot((b + s) & smask).key;
-					if (k == SEED_EMPTY) break;
-					if (k == key) { found = true; fl = s < NS ? l_flags[s] : a.slot((b + s) & smask).flags; break; }
-					++s;
-				}
-				if (found) {
-					const uint32_t slot = (b + s) & smask;
-					if (!(fl & SLOT_JOINED)) {
-						a.slot(slot).flags = fl | SLOT_JOINED;
-						if (s < NS) l_flags[s] = fl | SLOT_JOINED;
-					}
-					if (!(fl & SLOT_LOWC)) {
-						const unsigned k = atomicAdd(&st_n, 1u);      // < STAGE: flushed below whenever fewer than T places are left
-						st_slot[k] = slot; st_pos[k] = pos32;
-						const uint32_t count = fl >> 8;
-						const uint32_t at = s < PART_SLOTS ? l_first[s] : 0xffffu;
-						const bool in_lds = at != 0xffffu && at + count <= n_ent;
-						unsigned hk = HEAVY;
-						if (count > LIGHT) hk = atomicAdd(&hv_n, 1u);
-						if (hk < HEAVY) {
-							hv_slot[hk] = slot; hv_pos[hk] = pos32; hv_count[hk] = count;
-							hv_at[hk] = in_lds ? at : (0x80000000u | a.slot(slot).head);       // (list starts are < 2^31: query blocks < 4G letters / 2)
-#pragma unroll
-							for (int w = 0; w < 5; ++w) hv_tf[hk * 5 + w] = tf[w];
-						}
-						else if (in_lds) filter_lds(slot, at, count, pos32, tf, 0, 1);
-						else filter_hbm(slot, a.slot(slot).head, count, pos32, tf, 0, 1);
-					}
-				}
-			}
-			__syncthreads();
-			const unsigned n_heavy = hv_n < HEAVY ? hv_n : HEAVY;   // block-uniform: long lists are filtered by the whole workgroup
-			for (unsigned h = 0; h < n_heavy; ++h) {
-				uint32_t tf[5];
-#pragma unroll
-				for (int w = 0; w < 5; ++w) tf[w] = hv_tf[h * 5 + w];
-				if (!(hv_at[h] & 0x80000000u)) filter_lds(hv_slot[h], hv_at[h], hv_count[h], hv_pos[h], tf, tid, T);
-				else filter_hbm(hv_slot[h], hv_at[h] & 0x7fffffffu, hv_count[h], hv_pos[h], tf, tid, T);
-			}
-			__syncthreads();
-			if (tid == 0) hv_n = 0;
-			if (st_n + T > STAGE) flush_matched();                  // st_n: block-uniform after the barrier above
-			else __syncthreads();
-		}
-	}
-	flush_matched();
-	const unsigned n_sv = sv_n < SURV ? sv_n : SURV;
-	if (n_sv) {
-		if (tid == 0) st_base = atomicAdd(a.survivor_count, (unsigned long long)n_sv);
-		__syncthreads();
-		for (unsigned k = tid; k < n_sv; k += T) {
-			const unsigned long long idx = st_base + k;
-			if (idx < (unsigned long long)a.survivor_cap) a.survivors[idx] = SeedSurvivor{ sv_slot[k], sv_x[k], a.part.base + (int64_t)sv_pos[k] };
-		}
 	}
 }
 
@@ -1295,11 +1041,7 @@ hipError_t launch_seed_stream(const SeedArgs& a, int sid, hipStream_t st, bool f
 		for (int k = 0; k < c.shape_weight[sid]; ++k) care64 |= (uint64_t)15 << (4 * c.shape_pos[sid][k]);
 		const bool level2 = a.level2 != 0, hashed = c.seed_encoding == SEED_HASHED;
 		const dim3 grid(blocks_for(threads, 256)), block(256);
-		if (fused && a.part.entries) {
-			if (hashed || base != a.part.base) return hipErrorInvalidValue;
-			hipLaunchKernelGGL((seed_stream_fast_kernel<false, false, true, true>), grid, block, 0, st, a, sid, lo, hi, base, care64);
-		}
-		else if (fused && hashed) hipLaunchKernelGGL((seed_stream_fast_kernel<false, true, true>), grid, block, 0, st, a, sid, lo, hi, base, care64);
+		if (fused && hashed) hipLaunchKernelGGL((seed_stream_fast_kernel<false, true, true>), grid, block, 0, st, a, sid, lo, hi, base, care64);
 		else if (fused) hipLaunchKernelGGL((seed_stream_fast_kernel<false, false, true>), grid, block, 0, st, a, sid, lo, hi, base, care64);
 		else if (level2 && hashed) hipLaunchKernelGGL((seed_stream_fast_kernel<true, true, false>), grid, block, 0, st, a, sid, lo, hi, base, care64);
 		else if (level2) hipLaunchKernelGGL((seed_stream_fast_kernel<true, false, false>), grid, block, 0, st, a, sid, lo, hi, base, care64);
@@ -1308,20 +1050,6 @@ hipError_t launch_seed_stream(const SeedArgs& a, int sid, hipStream_t st, bool f
 		return hipGetLastError();
 	}
 	hipLaunchKernelGGL(seed_stream_kernel, dim3(blocks_for(a.t_end - a.t_begin, 256)), dim3(256), 0, st, a, sid);
-	return hipGetLastError();
-}
-
-hipError_t launch_seed_part_build(const SeedArgs& a, hipStream_t st)
-{
-	const int64_t n = a.q_end - a.q_begin;
-	const int64_t threads = std::max<int64_t>(n, (int64_t)a.part.n_parts + 1);
-	hipLaunchKernelGGL(seed_part_build_kernel, dim3(blocks_for(threads, 256)), dim3(256), 0, st, a, n, const_cast<uint32_t*>(a.part.part_off));
-	return hipGetLastError();
-}
-
-hipError_t launch_seed_part_join(const SeedArgs& a, int sid, hipStream_t st)
-{
-	hipLaunchKernelGGL(seed_part_join_kernel, dim3(a.part.n_parts), dim3(PJ_THREADS), 0, st, a, sid);
 	return hipGetLastError();
 }
 

@@ -181,12 +181,8 @@ def test_fused_short_seed_pipeline_equals_the_list_based_one_and_survives_small_
     monkeypatch.setenv("DMND_SEED_FUSED", "0")
     assert np.array_equal(ctx.seed_search(p), fused)
     monkeypatch.delenv("DMND_SEED_FUSED")
-    # DMND_SEED_PART=0: the fused stream kernel alone instead of scatter + partitioned join (spaced seeds; the default since round 3);
-    # DMND_SEED_PART_CAP: partition buffers of 1 / 5 entries -- most level-1 positives then take the old path inside the stream kernel
     for env in ({"DMND_SEED_MATCHED_CAP": "7"}, {"DMND_SEED_SURVIVOR_CAP": "3"}, {"DMND_SEED_HIT_CAP": "5"},
-                {"DMND_SEED_MATCHED_CAP": "100", "DMND_SEED_SURVIVOR_CAP": "10", "DMND_SEED_HIT_CAP": "40"},
-                {"DMND_SEED_PART": "0"}, {"DMND_SEED_PART_CAP": "1"}, {"DMND_SEED_PART_CAP": "5", "DMND_SEED_SURVIVOR_CAP": "3"},
-                {"DMND_SEED_PART": "0", "DMND_SEED_MATCHED_CAP": "7"}):
+                {"DMND_SEED_MATCHED_CAP": "100", "DMND_SEED_SURVIVOR_CAP": "10", "DMND_SEED_HIT_CAP": "40"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         got = ctx.seed_search(p)
