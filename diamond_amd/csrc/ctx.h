@@ -115,7 +115,7 @@ struct dmnd_ctx {
 	void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0;      // rocPRIM radix sort scratch
 	int64_t n_seed_hits = 0;
 	// gapped filter (gapped_api.hip)
-	dmnd::DevBuf gf_tables, gf_hits, gf_flags, gf_scores;
+	dmnd::DevBuf gf_tables, gf_hits, gf_flags, gf_scores, gf_units;
 	double gapped_filter_evalue = 0.0, gf_ms = 0.0;
 	// tantan masking (mask_api.hip)
 	dmnd::DevBuf mask_lr, mask_pb, mask_scale, mask_pos, mask_ids, mask_soff;

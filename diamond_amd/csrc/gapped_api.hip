@@ -1,6 +1,7 @@
 // gapped_api.hip -- C ABI of the gapped filter: dmnd_set_gapped_filter, dmnd_gapped_filter.
 // Replaces Extension::gapped_filter (src/align/gapped_filter.cpp:80-109) for a whole batch of seed hits.
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 #include "ctx.h"
 #include "gapped_kernels.h"
@@ -73,8 +74,44 @@ extern "C" int dmnd_gapped_filter(dmnd_ctx* c, const dmnd_seed_hit* hits, int64_
 	a.hits = c->gf_hits.as<dmnd_seed_hit>(); a.n_hits = n_hits;
 	a.flags = c->gf_flags.as<uint8_t>();
 	a.scores = scores ? c->gf_scores.as<int32_t>() : nullptr;
+	// Units: runs of consecutive hits of one query (the seed stage hands its hits over sorted by query), at most GF_UNIT_HITS each,
+	// sorted into classes by the LDS their query's profile needs -- 32 rows of (query length + 2 * GF_PAD) bytes: 24 / 40 / 64 KB --
+	// and one class of queries too long for that (matrix path). DMND_GF_PROFILE=0: round 2's one-wavefront-per-hit launch.
+	static const bool profile_env = [] { const char* e = getenv("DMND_GF_PROFILE"); return !e || atoi(e) != 0; }();
+	const char* off = getenv("DMND_GF_PROFILE_TEST");                // test hook, read per call
+	const bool use_profile = profile_env && !(off && off[0] == '0');
+	const int widths[4] = { 768, 1280, 2048, 0 };
+	std::vector<int2> units[4];
+	if (use_profile) {
+		const std::vector<int64_t>& ql = c->limits[DMND_QUERY];
+		for (int64_t b = 0; b < n_hits;) {
+			const uint32_t q = hits[b].query;
+			if ((size_t)q + 1 >= ql.size()) return fail(DMND_E_ARG, "dmnd_gapped_filter: hit with a query id outside the block");
+			int64_t e = b + 1;
+			while (e < n_hits && e - b < GF_UNIT_HITS && hits[e].query == q) ++e;
+			const int64_t w = ql[q + 1] - ql[q] - 1 + 2 * GF_PAD;
+			const int cls = w <= widths[0] ? 0 : w <= widths[1] ? 1 : w <= widths[2] ? 2 : 3;
+			units[cls].push_back(make_int2((int)b, (int)e));
+			b = e;
+		}
+		if (n_hits > 0x7fffffff) return fail(DMND_E_ARG, "dmnd_gapped_filter: more than 2^31 hits in one call");
+		const size_t total = units[0].size() + units[1].size() + units[2].size() + units[3].size();
+		if (int rc = c->gf_units.ensure(total * sizeof(int2))) return rc;
+		size_t off = 0;
+		for (int k = 0; k < 4; ++k) {
+			if (!units[k].empty()) HIP_TRY(hipMemcpyAsync(c->gf_units.as<int2>() + off, units[k].data(), units[k].size() * sizeof(int2), hipMemcpyHostToDevice, st));
+			off += units[k].size();
+		}
+	}
 	HIP_TRY(hipEventRecord(c->ev0, st));
-	HIP_TRY(launch_gapped_filter(a, st));
+	if (use_profile) {
+		size_t off = 0;
+		for (int k = 0; k < 4; ++k) {
+			HIP_TRY(launch_gapped_filter_units(a, c->gf_units.as<int2>() + off, (int)units[k].size(), widths[k], st));
+			off += units[k].size();
+		}
+	}
+	else HIP_TRY(launch_gapped_filter(a, st));
 	HIP_TRY(hipEventRecord(c->ev1, st));
 	HIP_TRY(hipMemcpyAsync(flags, c->gf_flags.p, (size_t)n_hits, hipMemcpyDeviceToHost, st));
 	if (scores) HIP_TRY(hipMemcpyAsync(scores, c->gf_scores.p, (size_t)n_hits * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));

@@ -19,5 +19,10 @@ struct GfArgs {
 };
 
 hipError_t launch_gapped_filter(const GfArgs& a, hipStream_t st);
+// The hits cut into units of consecutive hits of one query (units[u] = { first hit, end }): one workgroup per unit. width > 0: the
+// query's score profile is built in LDS, 32 rows of `width` bytes (>= the longest query of these units + 2 * GF_PAD); width = 0:
+// the matrix path of launch_gapped_filter.
+enum { GF_PAD = 128, GF_UNIT_HITS = 64 };
+hipError_t launch_gapped_filter_units(const GfArgs& a, const int2* units, int n_units, int width, hipStream_t st);
 
 }  // namespace dmnd
