@@ -247,7 +247,7 @@ extern "C" void dmnd_destroy(dmnd_ctx* c)
 	for (DevBuf* b : { &c->block[0], &c->block[1], &c->cbs, &c->matrix, &c->bias_ids, &c->items, &c->order, &c->p_of_slot, &c->trace_off,
 		&c->transcript_off, &c->ends, &c->hsps, &c->trace, &c->transcript, &c->status, &c->pairs, &c->trace_off_item, &c->host_q, &c->host_t, &c->host_cbs,
 		&c->d_limits[0], &c->d_limits[1], &c->qid_of, &c->mask_time, &c->seed_keys, &c->seed_next, &c->seed_qlist, &c->seed_qkeys, &c->seed_slot2, &c->seed_loc2, &c->seed_survivors, &c->seed_scored, &c->seed_need, &c->seed_qfold,
-		&c->matched_slot, &c->matched_loc, &c->counters, &c->seed_hits, &c->seed_bitmap, &c->seed_deferred, &c->seed_eslot, &c->seed_eloc, &c->seed_hits_sorted, &c->sort_keys[0], &c->sort_keys[1], &c->sort_idx[0], &c->sort_idx[1], &c->gf_tables, &c->gf_hits, &c->gf_flags, &c->gf_scores, &c->gf_units, &c->mask_lr, &c->mask_pb, &c->mask_scale, &c->mask_pos, &c->mask_ids, &c->mask_soff, &c->soft[0], &c->soft[1], &c->motif_hit, &c->motif_table })
+		&c->matched_slot, &c->matched_loc, &c->counters, &c->seed_hits, &c->seed_bitmap, &c->seed_deferred, &c->seed_eslot, &c->seed_eloc, &c->seed_hits_sorted, &c->sort_keys[0], &c->sort_keys[1], &c->sort_idx[0], &c->sort_idx[1], &c->gf_tables, &c->gf_hits, &c->gf_flags, &c->gf_scores, &c->gf_units, &c->alt_targets, &c->mask_lr, &c->mask_pb, &c->mask_scale, &c->mask_pos, &c->mask_ids, &c->mask_soff, &c->soft[0], &c->soft[1], &c->motif_hit, &c->motif_table })
 		b->release();
 	if (c->ev0) (void)hipEventDestroy(c->ev0);
 	if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -851,6 +851,20 @@ int dmnd_swipe_shared(dmnd_ctx* work, const dmnd_ctx* c, const dmnd_dp_target* i
 	const Bases b{ c->block[DMND_QUERY].as<int8_t>(), c->block_len[DMND_QUERY], c->block[DMND_TARGET].as<int8_t>(), c->block_len[DMND_TARGET],
 		c->cbs_len > 0 ? c->cbs.as<int8_t>() : nullptr, c->cbs_len };
 	if (work != c) {                                       // scoring state of the owner, by reference
+		work->matrix.p = c->matrix.p; work->matrix.cap = c->matrix.cap; work->matrix.own = false;
+		work->params = c->params; work->evaluer = c->evaluer;
+	}
+	return swipe_impl(work, b, items, n, mode, hsp_values, out, transcript, transcript_cap, transcript_used);
+}
+
+// The same with the target letters in a device buffer of the caller instead of the resident target block (items[].target_off
+// counts from t): the masked target copies of the alternative-HSP rounds (--max-hsps, extend_host.hip)
+int dmnd_swipe_targets(dmnd_ctx* work, const dmnd_ctx* c, const int8_t* t, int64_t t_len, const dmnd_dp_target* items, int64_t n, int mode, uint32_t hsp_values,
+	dmnd_hsp* out, uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used)
+{
+	if (!c || !work || !t) return fail(DMND_E_ARG, "ctx is NULL");
+	const Bases b{ c->block[DMND_QUERY].as<int8_t>(), c->block_len[DMND_QUERY], t, t_len, c->cbs_len > 0 ? c->cbs.as<int8_t>() : nullptr, c->cbs_len };
+	if (work != c) {
 		work->matrix.p = c->matrix.p; work->matrix.cap = c->matrix.cap; work->matrix.own = false;
 		work->params = c->params; work->evaluer = c->evaluer;
 	}

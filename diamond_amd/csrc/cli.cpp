@@ -444,6 +444,7 @@ struct Options {
 	std::vector<std::string> outfmt;   // -f / --outfmt: format, then field names
 	int gpus = 1;                   // --gpus: the reference blocks are spread over this many MI355X of the node
 	double top = -1.0;              // --top PERCENT
+	int max_hsps = 1;               // --max-hsps N: HSPs per target (0 = all)
 	bool no_self_hits = false;      // --no-self-hits
 	std::string matrix = "blosum62";        // --matrix / --gapopen / --gapextend (-1 = the matrix's default), basic/config.cpp:256-258
 	int gap_open = -1, gap_extend = -1;
@@ -567,7 +568,7 @@ Options parse(int argc, char** argv)
 		else if (a == "--quiet" || a == "--log" || a == "-v" || a == "--verbose") {}
 		else if (a == "-t" || a == "--tmpdir") (void)need(i);                // no temporary files: hits and records stay in memory / HBM
 		else if (a == "--ignore-warnings" || a == "--no-auto-append" || a == "--keep-temp-files") {}
-		else if (a == "--max-hsps") { if (std::atoi(need(i).c_str()) != 1) throw std::runtime_error("--max-hsps other than 1 is not part of this build (one HSP per target is reported)."); }
+		else if (a == "--max-hsps") { o.max_hsps = std::atoi(need(i).c_str()); if (o.max_hsps < 0) throw std::runtime_error("Invalid value for --max-hsps."); }
 		else if (a == "-F" || a == "--frameshift" || a == "--long-reads" || a == "--range-culling")
 			throw std::runtime_error(a + " (frameshift alignment / range culling) is not part of this build.");
 		else if (a == "--custom-matrix") throw std::runtime_error("--custom-matrix is not part of this build (the standard matrices of --matrix are).");
@@ -819,6 +820,7 @@ int run_blastp(const Options& o)
 		ctxs[(size_t)g] = c;
 		g_timeline.mark("context " + std::to_string(g) + " created");
 		chk(dmnd_set_max_target_seqs(c, o.k));
+		chk(dmnd_set_max_hsps(c, o.max_hsps));
 		chk(dmnd_set_top_percent(c, o.top));
 		chk(dmnd_set_filters(c, o.min_id, o.query_cover, o.subject_cover, o.min_score));
 		chk(dmnd_set_comp_based_stats(c, o.cbs));
@@ -1098,13 +1100,21 @@ int run_blastp(const Options& o)
 			std::vector<dmnd_match> mine((size_t)std::max<int64_t>(n_hits, 1));
 			std::vector<uint8_t> my_arena;
 			int64_t n_matches = 0;
-			if (!need_transcripts)
-				chk(dmnd_extend(ctx, q.data.data(), t_host, hits.data(), n_hits, threads, 0, mine.data(), (int64_t)mine.size(), &n_matches, nullptr, 0, nullptr));
+			// (with --max-hsps a target can have more HSP records than seed hits: the call reports the number it needs)
+			if (!need_transcripts) {
+				int rc = dmnd_extend(ctx, q.data.data(), t_host, hits.data(), n_hits, threads, 0, mine.data(), (int64_t)mine.size(), &n_matches, nullptr, 0, nullptr);
+				if (rc == DMND_E_CAP && n_matches > (int64_t)mine.size()) {
+					mine.resize((size_t)n_matches);
+					rc = dmnd_extend(ctx, q.data.data(), t_host, hits.data(), n_hits, threads, 0, mine.data(), (int64_t)mine.size(), &n_matches, nullptr, 0, nullptr);
+				}
+				chk(rc);
+			}
 			else {
 				int64_t cap = std::max<int64_t>((int64_t)1 << 20, 64 * n_hits), used = 0;
 				for (;;) {
 					my_arena.resize((size_t)cap);
 					const int rc = dmnd_extend(ctx, q.data.data(), t_host, hits.data(), n_hits, threads, 0, mine.data(), (int64_t)mine.size(), &n_matches, my_arena.data(), cap, &used);
+					if (rc == DMND_E_CAP && n_matches > (int64_t)mine.size()) { mine.resize((size_t)n_matches); continue; }
 					if (rc == DMND_E_CAP && cap < ((int64_t)1 << 36)) { cap *= 4; continue; }
 					chk(rc);
 					break;
@@ -1170,7 +1180,8 @@ int run_blastp(const Options& o)
 			}
 			else if (!has) put(fmt == FMT_SAM ? dmnd_format_sam(nullptr, qtitles[qi].c_str(), big.data(), (int64_t)big.size())
 				: dmnd_format_paf(nullptr, qtitles[qi].c_str(), big.data(), (int64_t)big.size()), big.data());
-			int32_t xml_hit = 0;
+			int32_t xml_hit = -1, xml_hsp = 0;                   // records of one target follow each other (--max-hsps): Hit_num / Hsp_num
+			uint32_t xml_target = UINT32_MAX;
 			std::string daa_rec;
 			if (fmt == FMT_DAA) {
 				const size_t local = (qi - qr.begin) * C;
@@ -1195,7 +1206,8 @@ int run_blastp(const Options& o)
 				}
 				else if (fmt == FMT_XML) {
 					big.resize((size_t)m.hsp.length * 4 + 6 * std::strlen(v.stitle) + 4096);
-					put(dmnd_format_xml(&v, xml_hit++, 0, p.matrix8, big.data(), (int64_t)big.size()), big.data());
+					if (m.target == xml_target) ++xml_hsp; else { ++xml_hit; xml_hsp = 0; xml_target = m.target; }
+					put(dmnd_format_xml(&v, xml_hit, xml_hsp, p.matrix8, big.data(), (int64_t)big.size()), big.data());
 				}
 				else if (fmt == FMT_FIELDS) {
 					big.resize((size_t)m.hsp.length * 4 + (size_t)v.qlen * 3 + (size_t)v.slen + std::strlen(v.qtitle) + 2 * std::strlen(v.stitle) + (size_t)v.source_len * 2 + 4096);

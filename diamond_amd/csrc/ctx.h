@@ -134,6 +134,8 @@ struct dmnd_ctx {
 	int comp_based_stats = 1;                  // config.comp_based_stats: 1 = Hauser bias (default), 0 = off
 	int query_contexts = 1;                    // align_mode.query_contexts: 6 for blastx (basic/basic.cpp:40-60)
 	int max_target_seqs = 25;                  // config.max_target_seqs (-k), basic/config.h:55
+	int max_hsps = 1;                          // config.max_hsps (--max-hsps): HSPs reported per target, 0 = all (dmnd_set_max_hsps)
+	dmnd::DevBuf alt_targets;                  // masked target copies of the alternative-HSP rounds (extend_host.hip)
 	double top_percent = -1.0;                 // config.toppercent (--top); < 0 = off
 	double min_id = 0, query_cover = 0, subject_cover = 0, min_bit_score = 0;      // --id, --query-cover, --subject-cover, --min-score
 	dmnd_same_title_fn same_title = nullptr;   // --no-self-hits: title comparison of the caller (dmnd_set_no_self_hits)
@@ -166,6 +168,8 @@ int dmnd_swipe_keep(dmnd_ctx* work, const dmnd_ctx* blocks, const dmnd_dp_target
 // items[k] with its KeptTrace entry src[k] (index into kt's vectors): statistics and coordinates from the kept trace, no transcripts
 int dmnd_traceback_kept(dmnd_ctx* work, const dmnd_ctx* blocks, const dmnd_dp_target* items, const KeptTrace& kt, const int64_t* src, int64_t n, dmnd_hsp* out);
 int dmnd_swipe_shared(dmnd_ctx* work, const dmnd_ctx* blocks, const dmnd_dp_target* items, int64_t n, int mode, uint32_t hsp_values,
+	dmnd_hsp* out, uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used);
+int dmnd_swipe_targets(dmnd_ctx* work, const dmnd_ctx* blocks, const int8_t* t, int64_t t_len, const dmnd_dp_target* items, int64_t n, int mode, uint32_t hsp_values,
 	dmnd_hsp* out, uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used);
 // k-th of `split` auxiliary contexts of c (created on first use; owned and destroyed by c)
 dmnd_ctx* aux_context(dmnd_ctx* c, int k, int split);

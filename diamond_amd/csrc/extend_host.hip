@@ -77,6 +77,7 @@ struct HostCfg {
 	alignas(32) int16_t rows[32][24];    // score matrix rows (row = letter, 20 residue columns padded to 24) for the vectorised window sums
 	int cbs_window = 40;                 // config.cbs_window
 	int max_target_seqs = 25;
+	int max_hsps = 1;                    // config.max_hsps: HSPs reported per target; 0 = all of them
 	int64_t max_swipe_dp = 1000000;      // config.max_swipe_dp
 	int band_mode_fast = 1;              // Extension::Mode::BANDED_FAST for every sensitivity up to --sensitive
 	bool ext_full = false;               // Extension::Mode::FULL (--ext full): no chaining, one full-matrix DpTarget per target and context
@@ -366,13 +367,22 @@ extern "C" int dmnd_extend_plan(const dmnd_params* params, const int8_t* qdata, 
 
 namespace {
 
-struct Cand {              // one target of one query after round 1 (Extension::Target with max_hsps = 1)
+struct Cand {              // one target of one query after round 1 (Extension::Target; with max_hsps = 1 its one HSP)
 	uint32_t target;
 	int score, d_begin, d_end, ungapped, frame;
 	double evalue;
 	int arena = -1;            // >= 0: the round-1 sweep kept this DpTarget's trace (KeptTrace kts[arena], entry `item`)
 	int64_t item = -1;
+	int band_off = -1, band_n = 0;      // max_hsps != 1: ALL reported round-1 DpTargets of the target, QueryState::bands[band_off, band_off + band_n)
 };
+
+// max_hsps != 1: a round-1 DpTarget whose score passed the report cutoff. Round 1 runs without coordinates, so Target::inner_culling
+// is not applied to them (gapped_score.cpp:240) and every one of them is a DpTarget of round 2 (add_dp_targets, gapped_final.cpp:62-76).
+struct Band { int d_begin, d_end, frame, arena; int64_t item; };
+
+// A reported target of a query = Extension::Match: its first HSP in m (m.evalue / m.hsp.score double as Match::filter_evalue /
+// filter_score) and, with max_hsps != 1, the further HSPs of its list in QueryState::extra[extra] (Hsp::operator< order)
+struct MatchG { dmnd_match m; int extra = -1; };
 
 bool cand_less(const Cand& a, const Cand& b)                 // Target::comp_evalue, target.h:123-129
 {
@@ -419,13 +429,56 @@ void cull(std::vector<Cand>& t, bool sort_only, const CullCfg& cc)
 // culling(matches, cfg), culling.cpp:199-202. A match whose HSP was removed by a filter stays in the list as a placeholder with
 // filter_evalue = DBL_MAX, filter_score = 0 (Match::apply_filters): it sorts last, and output_range drops the placeholders at the
 // end of the reported range (and everything, if the best entry is one).
-void cull(std::vector<dmnd_match>& t, const CullCfg& cc)
+void cull(std::vector<MatchG>& t, const CullCfg& cc)
 {
-	std::sort(t.begin(), t.end(), cc.top >= 0.0 ? match_less_score : match_less);
-	if (t.empty() || t[0].evalue == DBL_MAX) { t.clear(); return; }
-	size_t n = output_range(t.size(), cc, [&](size_t i) { return t[i].hsp.score; });
-	if (cc.top < 0.0) while (n > 1 && t[n - 1].evalue == DBL_MAX) --n;
+	if (cc.top >= 0.0) std::sort(t.begin(), t.end(), [](const MatchG& a, const MatchG& b) { return match_less_score(a.m, b.m); });
+	else std::sort(t.begin(), t.end(), [](const MatchG& a, const MatchG& b) { return match_less(a.m, b.m); });
+	if (t.empty() || t[0].m.evalue == DBL_MAX) { t.clear(); return; }
+	size_t n = output_range(t.size(), cc, [&](size_t i) { return t[i].m.hsp.score; });
+	if (cc.top < 0.0) while (n > 1 && t[n - 1].m.evalue == DBL_MAX) --n;
 	t.resize(n);
+}
+
+// Hsp::query_source_range (TranslatedPosition::absolute_interval, basic/translated_position.h:130-136): the query interval of an HSP
+// in the coordinates of the source sequence -- the DNA read for a translated query
+void source_interval(const dmnd_match& m, int contexts, int dna_len, int& b, int& e)
+{
+	if (contexts == 1) { b = m.hsp.q_begin; e = m.hsp.q_end; return; }
+	const int offset = m.frame % 3;
+	if (m.frame < 3) { b = offset + 3 * m.hsp.q_begin; e = offset + 3 * m.hsp.q_end; }
+	else { e = dna_len - offset - 3 * m.hsp.q_begin; b = dna_len - offset - 3 * m.hsp.q_end; }
+}
+
+// Match::inner_culling for max_hsps != 1 (culling.cpp:40-57): the HSPs of a target in Hsp::operator< order (score descending, band
+// start, query start: basic/match.h:199-202; list::sort is stable), an HSP dropped when half of its query or subject range lies
+// inside a better one that was kept (Hsp::is_enveloped_by, hssp.cpp:233-244; --culling-overlap 50), the list cut at max_hsps
+void inner_culling(std::vector<dmnd_match>& l, int contexts, int dna_len, int max_hsps)
+{
+	if (l.size() <= 1) return;
+	struct Key { int qb, qe; };
+	std::vector<Key> k(l.size());
+	std::vector<size_t> ord(l.size());
+	for (size_t i = 0; i < l.size(); ++i) { source_interval(l[i], contexts, dna_len, k[i].qb, k[i].qe); ord[i] = i; }
+	std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) {
+		return l[a].hsp.score > l[b].hsp.score || (l[a].hsp.score == l[b].hsp.score && (l[a].d_begin < l[b].d_begin || (l[a].d_begin == l[b].d_begin && k[a].qb < k[b].qb)));
+	});
+	auto overlap_factor = [](int b0, int e0, int b1, int e1) {      // Interval::overlap_factor: overlap / own length
+		const int o = std::max(0, std::min(e0, e1) - std::max(b0, b1));
+		return (double)o / (double)(e0 - b0);
+	};
+	std::vector<size_t> kept;
+	for (size_t i : ord) {
+		bool enveloped = false;
+		for (size_t j : kept)
+			if (overlap_factor(k[i].qb, k[i].qe, k[j].qb, k[j].qe) >= 0.5
+				|| overlap_factor(l[i].hsp.s_begin, l[i].hsp.s_end, l[j].hsp.s_begin, l[j].hsp.s_end) >= 0.5) { enveloped = true; break; }
+		if (!enveloped) kept.push_back(i);
+	}
+	if (max_hsps > 0 && kept.size() > (size_t)max_hsps) kept.resize((size_t)max_hsps);
+	std::vector<dmnd_match> out;
+	out.reserve(kept.size());
+	for (size_t i : kept) out.push_back(l[i]);
+	l.swap(out);
 }
 
 // append_hits(targets, begin, end, with_culling, cfg), culling.cpp:115-145
@@ -452,7 +505,11 @@ bool append_hits(std::vector<Cand>& targets, const std::vector<Cand>& v, const C
 struct QueryState {
 	QueryWork w;
 	std::vector<Cand> aligned;          // aligned_targets of the current outer iteration
-	std::vector<dmnd_match> matches;
+	std::vector<Band> bands;            // max_hsps != 1: the reported DpTargets of the aligned targets (Cand::band_off)
+	std::vector<MatchG> matches;
+	std::vector<std::vector<dmnd_match>> extra;      // max_hsps != 1: HSP lists beyond the first (MatchG::extra)
+	std::vector<size_t> r2_slot;        // max_hsps != 1: first result slot of every target of the current round-2 step
+	bool alt_pending = false;           // round 2 done, alternative HSPs (recompute_alt_hsps) still to be searched
 	int tail_score = 0, previous_tail_score = 0;
 	bool new_hits_ev = false;
 	bool in_inner = true, done = false;
@@ -461,7 +518,7 @@ struct QueryState {
 	// round 2 (align(), gapped_final.cpp:80-160): the aligned targets are extended [r2_pos, r2_end) at a time
 	bool in_round2 = false;
 	size_t r2_pos = 0, r2_end = 0;
-	std::vector<dmnd_match> round;      // the round's matches so far
+	std::vector<MatchG> round;          // the round's matches so far
 };
 
 }
@@ -484,6 +541,7 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 	const int K = h.max_target_seqs;
 	const CullCfg cc{ K, h.top, &c->evaluer };
 	const bool first_round_culling = !h.have_filters() || h.top >= 0.0;      // extend.cpp:272
+	const bool multi = h.max_hsps != 1;                                       // several HSPs per target: every reported band goes through round 2
 	for (int i = 0; i < 12; ++i) if (i != 4 || w != c) w->ext_stats[i] = 0;      // [4] (bias + upload) of the caller's prelude is kept
 	for (double& x : w->host_ms) x = 0;
 	auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -622,8 +680,12 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 							if (score > k.score || (score == k.score && frame == k.frame && p.d_begin < k.d_begin)) {
 								k.score = score; k.evalue = ev; k.d_begin = p.d_begin; k.d_end = p.d_end; k.frame = frame; k.arena = arena; k.item = (int64_t)x;
 							}
+							if (multi) { s.bands.push_back(Band{ p.d_begin, p.d_end, frame, arena, (int64_t)x }); ++k.band_n; }
 						}
-						else v.push_back(Cand{ p.target, score, p.d_begin, p.d_end, p.ungapped_score, frame, ev, arena, (int64_t)x });
+						else {
+							v.push_back(Cand{ p.target, score, p.d_begin, p.d_end, p.ungapped_score, frame, ev, arena, (int64_t)x });
+							if (multi) { v.back().band_off = (int)s.bands.size(); v.back().band_n = 1; s.bands.push_back(Band{ p.d_begin, p.d_end, frame, arena, (int64_t)x }); }
+						}
 					}
 					const bool multi_chunk = (s.w.i1 - s.w.i0) < s.w.order.size();
 					bool new_hits = s.new_hits_ev = !v.empty();
@@ -666,15 +728,36 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 				if (!first_round_culling && h.top < 0.0)
 					step = std::min<size_t>(((size_t)std::max<int64_t>((int64_t)K - (int64_t)s.round.size(), 16) + 15) / 16 * 16, left);
 				s.r2_end = s.r2_pos + step;
-				r2[i].assign(s.aligned.size(), dmnd_hsp());
-				for (size_t k = s.r2_pos; k < s.r2_end; ++k) {
-					const Cand& cd = s.aligned[k];
-					const dmnd_dp_target d = item_of(s.w.query * C + (uint32_t)cd.frame, cd.target, cd.d_begin, cd.d_end);
+				// one DpTarget per aligned target (its best band), or -- max_hsps != 1 -- one per reported band of the target
+				// (add_dp_targets, gapped_final.cpp:62-76): result slot k, or r2_slot[k - r2_pos] + band
+				auto add_item = [&](uint32_t target, int frame, int d0, int d1, int arena, int64_t item, size_t slot) {
+					const dmnd_dp_target d = item_of(s.w.query * C + (uint32_t)frame, target, d0, d1);
 					// DP::BandedSwipe::bin (swipe_wrapper.cpp:75-102): above max_swipe_dp cells the statistics cells replace the traceback,
 					// unless the output needs the transcript -- then the matrix is traced whatever its size
-					if (dp_size(d) > h.max_swipe_dp && !transcript) { me.it_st.push_back(d); me.ref_st.push_back(Ref{ i, k }); }
-					else if (cd.arena >= 0) { KeptGroup& g = me.kept[(size_t)cd.arena]; g.items.push_back(d); g.src.push_back(cd.item); g.ref.push_back(Ref{ i, k }); }
-					else { me.it_tb.push_back(d); me.ref_tb.push_back(Ref{ i, k }); }
+					if (dp_size(d) > h.max_swipe_dp && !transcript) { me.it_st.push_back(d); me.ref_st.push_back(Ref{ i, slot }); }
+					else if (arena >= 0) { KeptGroup& g = me.kept[(size_t)arena]; g.items.push_back(d); g.src.push_back(item); g.ref.push_back(Ref{ i, slot }); }
+					else { me.it_tb.push_back(d); me.ref_tb.push_back(Ref{ i, slot }); }
+				};
+				if (!multi) {
+					r2[i].assign(s.aligned.size(), dmnd_hsp());
+					for (size_t k = s.r2_pos; k < s.r2_end; ++k) {
+						const Cand& cd = s.aligned[k];
+						add_item(cd.target, cd.frame, cd.d_begin, cd.d_end, cd.arena, cd.item, k);
+					}
+				}
+				else {
+					s.r2_slot.clear();
+					size_t slot = 0;
+					for (size_t k = s.r2_pos; k < s.r2_end; ++k) { s.r2_slot.push_back(slot); slot += (size_t)s.aligned[k].band_n; }
+					s.r2_slot.push_back(slot);
+					r2[i].assign(slot, dmnd_hsp());
+					for (size_t k = s.r2_pos; k < s.r2_end; ++k) {
+						const Cand& cd = s.aligned[k];
+						for (int j = 0; j < cd.band_n; ++j) {
+							const Band& b = s.bands[(size_t)(cd.band_off + j)];
+							add_item(cd.target, b.frame, b.d_begin, b.d_end, b.arena, b.item, s.r2_slot[k - s.r2_pos] + (size_t)j);
+						}
+					}
 				}
 			}
 		});
@@ -733,37 +816,71 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 				QueryState& s = qs[i];
 				if (s.done || s.in_inner) continue;
 				// align() round 2 (gapped_final.cpp:80-160): report cutoff again, filters, culling of this round's matches
-				std::vector<dmnd_match>& round = s.round;
+				std::vector<MatchG>& round = s.round;
 				const uint32_t q = s.w.query;
-				for (size_t k = s.r2_pos; k < s.r2_end; ++k) {
-					const Cand& cd = s.aligned[k];
-					const dmnd_hsp& hsp = r2[i][k];
-					if (hsp.score <= 0) continue;
+				// one HSP of target cd in context `frame` as a match record; false: no score, or below the report cutoff
+				auto make = [&](const Cand& cd, int frame, int d0, int d1, const dmnd_hsp& hsp, dmnd_match& m) {
+					if (hsp.score <= 0) return false;
 					const int tlen = (int)(tl[cd.target + 1] - tl[cd.target] - 1);
-					const uint32_t qc = q * C + (uint32_t)cd.frame;
+					const uint32_t qc = q * C + (uint32_t)frame;
 					const int qlen = (int)(ql[qc + 1] - ql[qc] - 1);
 					const double ev = c->evaluer.evalue(hsp.score, (unsigned)qlen, (unsigned)tlen);
-					if (!h.reported(hsp.score, ev)) continue;
-					dmnd_match m;
+					if (!h.reported(hsp.score, ev)) return false;
 					m.query = q; m.target = cd.target; m.evalue = ev; m.bit_score = c->evaluer.bitscore(hsp.score);
-					m.ungapped_score = cd.ungapped; m.d_begin = cd.d_begin; m.d_end = cd.d_end; m.frame = cd.frame; m.hsp = hsp;
-					// filter_hsp (culling.cpp:147-170): the HSP is removed, the match stays as a placeholder for the culling below
+					m.ungapped_score = cd.ungapped; m.d_begin = d0; m.d_end = d1; m.frame = frame; m.hsp = hsp;
+					if (multi && h.ext_full) m.d_begin = m.d_end = 0;       // Hsp::d_begin of a full-matrix sweep (tie-break of Hsp::operator<)
+					return true;
+				};
+				// filter_hsp (culling.cpp:147-170): --id, --query-cover, --subject-cover, --no-self-hits
+				auto filtered = [&](const dmnd_match& m) {
+					const dmnd_hsp& hsp = m.hsp;
+					const int tlen = (int)(tl[m.target + 1] - tl[m.target] - 1);
+					const uint32_t qc = q * C + (uint32_t)m.frame;
+					const int qlen = (int)(ql[qc + 1] - ql[qc] - 1);
 					if (h.have_filters() && ((double)hsp.identities * 100.0 / (double)hsp.length < h.min_id
 						|| (C == 1 ? (double)(hsp.q_end - hsp.q_begin) * 100 / qlen : (double)(3 * (hsp.q_end - hsp.q_begin)) * 100 / (h.source_lens ? h.source_lens[q] : 1)) < h.query_cover
-						|| (double)(hsp.s_end - hsp.s_begin) * 100 / tlen < h.subject_cover)) { m.evalue = DBL_MAX; m.hsp.score = 0; }
+						|| (double)(hsp.s_end - hsp.s_begin) * 100 / tlen < h.subject_cover)) return true;
 					// --no-self-hits: same letters (Sequence::operator==, the query's first context) and same title
 					if (c->same_title && C == 1 && qlen == tlen) {
 						const int8_t* a = qdata + ql[qc];
-						const int8_t* b = tdata + tl[cd.target];
+						const int8_t* b = tdata + tl[m.target];
 						bool same = true;
 						for (int x = 0; x < qlen && same; ++x) same = ((a[x] ^ b[x]) & 31) == 0;
-						if (same && c->same_title(c->same_title_user, q, cd.target)) { m.evalue = DBL_MAX; m.hsp.score = 0; }
+						if (same && c->same_title(c->same_title_user, q, m.target)) return true;
 					}
-					round.push_back(m);
+					return false;
+				};
+				std::vector<dmnd_match> L;
+				for (size_t k = s.r2_pos; k < s.r2_end; ++k) {
+					const Cand& cd = s.aligned[k];
+					dmnd_match m;
+					if (!multi) {
+						if (!make(cd, cd.frame, cd.d_begin, cd.d_end, r2[i][k], m)) continue;
+						// the HSP is removed, the match stays as a placeholder for the culling below
+						if (filtered(m)) { m.evalue = DBL_MAX; m.hsp.score = 0; }
+						round.push_back(MatchG{ m, -1 });
+						continue;
+					}
+					// max_hsps != 1: the HSPs of all the target's bands; Match::inner_culling, then the filters HSP by HSP
+					// (Match::apply_filters: filter values = those of the first HSP left)
+					L.clear();
+					for (int j = 0; j < cd.band_n; ++j) {
+						const Band& b = s.bands[(size_t)(cd.band_off + j)];
+						if (make(cd, b.frame, b.d_begin, b.d_end, r2[i][s.r2_slot[k - s.r2_pos] + (size_t)j], m)) L.push_back(m);
+					}
+					if (L.empty()) continue;
+					inner_culling(L, (int)C, h.source_lens ? h.source_lens[q] : 0, h.max_hsps);
+					const dmnd_match first = L[0];
+					L.erase(std::remove_if(L.begin(), L.end(), filtered), L.end());
+					if (L.empty()) { m = first; m.evalue = DBL_MAX; m.hsp.score = 0; round.push_back(MatchG{ m, -1 }); continue; }
+					MatchG g{ L[0], -1 };
+					if (L.size() > 1) { g.extra = (int)s.extra.size(); s.extra.emplace_back(L.begin() + 1, L.end()); }
+					round.push_back(g);
 				}
 				cull(round, cc);
 				s.r2_pos = s.r2_end;
 				if (s.r2_pos < s.aligned.size() && (h.top >= 0.0 || (int)(round.size() + s.matches.size()) < K)) continue;      // next step (goon)
+				if (multi) { s.alt_pending = true; continue; }                 // recompute_alt_hsps (gapped_final.cpp:156) comes first
 				s.in_round2 = false;
 				s.matches.insert(s.matches.end(), round.begin(), round.end());
 				round.clear();
@@ -773,6 +890,147 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 				else s.done = true;
 			}
 		});
+		// recompute_alt_hsps (alt_hsp.cpp:86-142) for the queries whose round 2 is complete: every reported target is copied per
+		// context with the subject ranges of its HSPs overwritten by SUPER_HARD_MASK (letter 25, scored like the matrix minimum)
+		// and swept over the WHOLE matrix; an HSP found is added, masked, and the target goes round again until a sweep finds
+		// nothing, its copy is masked through, or it has max_hsps HSPs. One launch per round for all queries of the batch.
+		if (multi) {
+			struct Alt { size_t qi, mi; uint32_t target; int tlen; int64_t off[6]; uint32_t have, sweep; std::vector<dmnd_match> hs; };
+			std::vector<Alt> alts;
+			std::vector<int8_t> scratch(256, (int8_t)31);
+			auto mask_range = [&](Alt& a, const dmnd_match& m) {
+				std::fill(scratch.begin() + (ptrdiff_t)(a.off[m.frame] + m.hsp.s_begin), scratch.begin() + (ptrdiff_t)(a.off[m.frame] + m.hsp.s_end), (int8_t)25);
+			};
+			for (size_t i = 0; i < nq; ++i) {
+				QueryState& s = qs[i];
+				if (!s.alt_pending) continue;
+				for (size_t mi = 0; mi < s.round.size(); ++mi) {
+					const MatchG& g = s.round[mi];
+					if (g.m.evalue == DBL_MAX) continue;                  // every HSP filtered: nothing to mask, no context
+					Alt a;
+					a.qi = i; a.mi = mi; a.target = g.m.target; a.tlen = (int)(tl[a.target + 1] - tl[a.target] - 1); a.have = 0; a.sweep = 0;
+					a.hs.push_back(g.m);
+					if (g.extra >= 0) a.hs.insert(a.hs.end(), s.extra[(size_t)g.extra].begin(), s.extra[(size_t)g.extra].end());
+					for (const dmnd_match& m : a.hs) {                   // ActiveTarget::copy_seq: one copy per context that has an HSP
+						if (!((a.have >> m.frame) & 1u)) {
+							a.off[m.frame] = (int64_t)scratch.size();
+							scratch.insert(scratch.end(), tdata + tl[a.target], tdata + tl[a.target] + a.tlen);
+							scratch.push_back((int8_t)31);
+							a.have |= 1u << m.frame;
+						}
+						mask_range(a, m);
+					}
+					a.sweep = a.have;
+					alts.push_back(std::move(a));
+				}
+			}
+			std::vector<dmnd_dp_target> it_alt[2];                      // [0] traceback, [1] statistics cells (matrix above max_swipe_dp)
+			struct ARef { size_t a; int frame; };
+			std::vector<ARef> ref_alt[2];
+			while (!alts.empty()) {
+				for (int k = 0; k < 2; ++k) { it_alt[k].clear(); ref_alt[k].clear(); }
+				for (size_t x = 0; x < alts.size(); ++x) {
+					const Alt& a = alts[x];
+					const uint32_t q = qs[a.qi].w.query;
+					for (int f = 0; f < (int)C; ++f) {
+						if (!((a.sweep >> f) & 1u)) continue;
+						const uint32_t qc = q * C + (uint32_t)f;
+						const int qlen = (int)(ql[qc + 1] - ql[qc] - 1);
+						const dmnd_dp_target d{ ql[qc], a.off[f], h.use_cbs ? ql[qc] : (int64_t)-1, qlen, a.tlen, -(a.tlen - 1), qlen };
+						const int k = ((int64_t)qlen * (int64_t)a.tlen > h.max_swipe_dp && !transcript) ? 1 : 0;
+						it_alt[k].push_back(d); ref_alt[k].push_back(ARef{ x, f });
+					}
+				}
+				const size_t bytes = scratch.size() + 256;
+				if (int rc = w->alt_targets.ensure(bytes)) return rc;
+				HIP_TRY(hipMemsetAsync(w->alt_targets.as<int8_t>() + scratch.size(), 31, 256, w->stream));
+				HIP_TRY(hipMemcpyAsync(w->alt_targets.p, scratch.data(), scratch.size(), hipMemcpyHostToDevice, w->stream));
+				std::vector<uint32_t> found(alts.size(), 0);
+				for (int k = 0; k < 2; ++k) {
+					if (it_alt[k].empty()) continue;
+					res.assign(it_alt[k].size(), dmnd_hsp());
+					uint8_t* arena = transcript && k == 0 ? transcript + used : nullptr;
+					const int64_t arena_cap = transcript && k == 0 ? transcript_cap - used : 0;
+					int64_t u = 0;
+					if (int rc = dmnd_swipe_targets(w, c, w->alt_targets.as<int8_t>(), (int64_t)bytes, it_alt[k].data(), (int64_t)it_alt[k].size(),
+						k == 0 ? DMND_SWIPE_TRACEBACK : DMND_SWIPE_STATS, hsp_values, res.data(), arena, arena_cap, &u)) return rc;
+					sw2 += w->swipe_ms; if (k == 0) tb2 += w->traceback_ms;
+					w->ext_stats[1] += (double)it_alt[k].size();
+					for (const dmnd_dp_target& d : it_alt[k]) w->ext_stats[3] += (double)d.query_len * (double)d.target_len;
+					for (size_t x = 0; x < ref_alt[k].size(); ++x) {
+						Alt& a = alts[ref_alt[k][x].a];
+						const int f = ref_alt[k][x].frame;
+						dmnd_hsp hsp = res[x];
+						if (hsp.score <= 0) continue;
+						const double ev = c->evaluer.evalue(hsp.score, (unsigned)it_alt[k][x].query_len, (unsigned)a.tlen);
+						if (!h.reported(hsp.score, ev)) continue;
+						if (k == 0 && transcript) hsp.transcript_off += used; else { hsp.transcript_off = -1; if (k == 1) hsp.transcript_len = 0; }
+						dmnd_match m;
+						m.query = a.hs[0].query; m.target = a.target; m.evalue = ev; m.bit_score = c->evaluer.bitscore(hsp.score);
+						m.ungapped_score = a.hs[0].ungapped_score; m.d_begin = 0; m.d_end = 0; m.frame = f; m.hsp = hsp;      // (the full-matrix sweep leaves Hsp::d_begin / d_end at 0)
+						a.hs.push_back(m);
+						mask_range(a, m);
+						found[ref_alt[k][x].a] |= 1u << f;
+					}
+					if (transcript && k == 0) used += u;
+				}
+				std::vector<Alt> next;
+				for (size_t x = 0; x < alts.size(); ++x) {
+					Alt& a = alts[x];
+					if (!found[x]) continue;                              // nothing new: the target is finished (its record is up to date)
+					QueryState& s = qs[a.qi];
+					inner_culling(a.hs, (int)C, h.source_lens ? h.source_lens[s.w.query] : 0, h.max_hsps);
+					MatchG& g = s.round[a.mi];
+					g.m = a.hs[0];
+					if (a.hs.size() > 1) {
+						if (g.extra < 0) { g.extra = (int)s.extra.size(); s.extra.emplace_back(); }
+						s.extra[(size_t)g.extra].assign(a.hs.begin() + 1, a.hs.end());
+					}
+					else if (g.extra >= 0) s.extra[(size_t)g.extra].clear();
+					// check_fully_masked: a context goes on while its copy still has a residue (Util::Seq::is_fully_masked: all letters >= 20)
+					uint32_t active = found[x];
+					for (int f = 0; f < (int)C; ++f) {
+						if (!((active >> f) & 1u)) continue;
+						bool residue = false;
+						for (int p = 0; p < a.tlen && !residue; ++p) residue = (scratch[(size_t)(a.off[f] + p)] & 31) < 20;
+						if (!residue) active &= ~(1u << f);
+					}
+					if (active && (h.max_hsps == 0 || (int)a.hs.size() < h.max_hsps)) { a.sweep = active; next.push_back(std::move(a)); }
+				}
+				// Which of them really go round again. The reference collects them with `out.emplace_back(t)` into a growing
+				// std::vector<ActiveTarget> (alt_hsp.cpp:116-121), and ActiveTarget's copy constructor -- which is what a reallocation
+				// of that vector relocates its elements with -- drops the masked copy of every context that is not in `active`, of an
+				// element already in `out` (active = 0) all of them (alt_hsp.cpp:47-56). With the doubling growth of the vector only the
+				// elements appended since its last reallocation keep their copies: of a query's n continuing targets those from index
+				// 2^floor(log2(n - 1)) on. The others are swept no more. Restated as it stands: the outputs are compared byte for byte.
+				{
+					std::vector<Alt> go;
+					for (size_t b = 0; b < next.size();) {
+						size_t e = b;
+						while (e < next.size() && next[e].qi == next[b].qi) ++e;
+						const size_t n = e - b;
+						size_t first = 0;
+						if (n >= 2) { first = 1; while (first * 2 <= n - 1) first *= 2; }
+						for (size_t x = b + first; x < e; ++x) go.push_back(std::move(next[x]));
+						b = e;
+					}
+					next.swap(go);
+				}
+				alts.swap(next);
+			}
+			for (size_t i = 0; i < nq; ++i) {
+				QueryState& s = qs[i];
+				if (!s.alt_pending) continue;
+				s.alt_pending = false;
+				s.in_round2 = false;
+				s.matches.insert(s.matches.end(), s.round.begin(), s.round.end());
+				s.round.clear();
+				s.aligned.clear();
+				s.bands.clear();
+				if (h.top < 0.0 && (int)s.matches.size() < K && s.w.i0 < s.w.order.size() && s.new_hits_ev) s.in_inner = true;
+				else s.done = true;
+			}
+		}
 		}
 		if (!any_round2) break;
 		lap(7, 9);
@@ -788,7 +1046,7 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 		for (size_t i = slice_begin(t); i < slice_begin(t + 1); ++i) {
 			QueryState& s = qs[i];
 			cull(s.matches, cc);
-			me.n_matches += s.matches.size();
+			for (const MatchG& g : s.matches) me.n_matches += 1 + (g.extra >= 0 ? s.extra[(size_t)g.extra].size() : 0);
 		}
 	});
 	size_t total_matches = 0;
@@ -797,8 +1055,10 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 	parallel_each(T, [&](int t) {
 		size_t o = sl[(size_t)t].match_off;
 		for (size_t i = slice_begin(t); i < slice_begin(t + 1); ++i) {
-			std::copy(qs[i].matches.begin(), qs[i].matches.end(), out_matches.begin() + (ptrdiff_t)o);
-			o += qs[i].matches.size();
+			for (const MatchG& g : qs[i].matches) {            // a target's HSPs follow each other (Hsp::operator< order)
+				out_matches[o++] = g.m;
+				if (g.extra >= 0) for (const dmnd_match& m : qs[i].extra[(size_t)g.extra]) out_matches[o++] = m;
+			}
 			QueryState empty;
 			std::swap(qs[i], empty);
 			std::vector<dmnd_hsp>().swap(r2[i]);
@@ -842,12 +1102,15 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	HostCfg h;
 	make_cfg(c, h);
 	h.max_target_seqs = c->max_target_seqs;
+	h.max_hsps = c->max_hsps;
 	h.top = c->top_percent;
 	h.evaluer = &c->evaluer;
 	h.max_evalue = c->params.max_evalue;
 	h.min_bit_score = c->min_bit_score; h.min_id = c->min_id; h.query_cover = c->query_cover; h.subject_cover = c->subject_cover;
 	if (h.query_cover > 0 && c->query_contexts != 1 && c->source_lens.size() != (ql.size() - 1) / (size_t)c->query_contexts)
 		return fail(DMND_E_ARG, "dmnd_extend: the query cover of translated queries needs the read lengths (dmnd_set_query_source_lengths)");
+	if (h.max_hsps != 1 && c->query_contexts != 1 && c->source_lens.size() != (ql.size() - 1) / (size_t)c->query_contexts)
+		return fail(DMND_E_ARG, "dmnd_extend: several HSPs per target of translated queries need the read lengths (dmnd_set_query_source_lengths)");
 	h.source_lens = c->source_lens.empty() ? nullptr : c->source_lens.data();
 	h.ranking_block_letters = c->ranking_block_letters;
 	h.band_mode_fast = c->band_mode_fast;
@@ -1038,6 +1301,13 @@ extern "C" int dmnd_set_extension_mode(dmnd_ctx* c, int mode)
 	return DMND_OK;
 }
 
+extern "C" int dmnd_set_max_hsps(dmnd_ctx* c, int n)
+{
+	if (!c || n < 0) return fail(DMND_E_ARG, "dmnd_set_max_hsps: bad argument");
+	c->max_hsps = n;
+	return DMND_OK;
+}
+
 extern "C" int dmnd_set_max_target_seqs(dmnd_ctx* c, int k)
 {
 	if (!c || k < 1) return fail(DMND_E_ARG, "dmnd_set_max_target_seqs: bad argument");
@@ -1077,20 +1347,51 @@ extern "C" int dmnd_set_top_percent(dmnd_ctx* c, double percent)
 
 // join_query with --top: the heap merge runs on JoinRecord::cmp_score (score descending, target ordinal ascending) and GlobalCulling
 // keeps a target while (1 - bit score / best bit score) * 100 <= toppercent (output/target_culling.h:62-63)
+namespace {
+
+// The records of a join: consecutive records of one (query, target) pair are the HSPs of one match (dmnd_set_max_hsps) and move
+// together, ranked by the first one. Returns the matches as (first record, count), ordered by query and `less` of the first records.
+template<typename Less>
+std::vector<std::pair<int64_t, int64_t>> join_groups(const dmnd_match* r, int64_t n, Less less)
+{
+	std::vector<std::pair<int64_t, int64_t>> g;
+	for (int64_t i = 0; i < n;) {
+		int64_t j = i + 1;
+		while (j < n && r[j].query == r[i].query && r[j].target == r[i].target) ++j;
+		g.emplace_back(i, j - i);
+		i = j;
+	}
+	std::stable_sort(g.begin(), g.end(), [&](const std::pair<int64_t, int64_t>& a, const std::pair<int64_t, int64_t>& b) {
+		return r[a.first].query < r[b.first].query || (r[a.first].query == r[b.first].query && less(r[a.first], r[b.first]));
+	});
+	return g;
+}
+
+void write_groups(dmnd_match* r, const std::vector<dmnd_match>& src, const std::vector<std::pair<int64_t, int64_t>>& keep, int64_t* n_out)
+{
+	int64_t w = 0;
+	for (const auto& g : keep) for (int64_t k = 0; k < g.second; ++k) r[w++] = src[(size_t)(g.first + k)];
+	*n_out = w;
+}
+
+}
+
 extern "C" int dmnd_join_blocks_top(dmnd_match* r, int64_t n, double top_percent, int64_t* n_out)
 {
 	if (!r || n < 0 || top_percent < 0.0 || !n_out) return fail(DMND_E_ARG, "dmnd_join_blocks_top: bad argument");
-	std::stable_sort(r, r + n, [](const dmnd_match& a, const dmnd_match& b) { return a.query < b.query || (a.query == b.query && match_less_score(a, b)); });
-	int64_t w = 0;
+	const std::vector<dmnd_match> src(r, r + n);
+	const auto groups = join_groups(src.data(), n, match_less_score);
+	std::vector<std::pair<int64_t, int64_t>> keep;
 	double top_score = 0.0;
 	bool finished = false;
-	for (int64_t i = 0; i < n; ++i) {
-		if (i == 0 || r[i].query != r[i - 1].query) { top_score = r[i].bit_score; finished = false; }
+	for (size_t i = 0; i < groups.size(); ++i) {
+		const dmnd_match& m = src[(size_t)groups[i].first];
+		if (i == 0 || m.query != src[(size_t)groups[i - 1].first].query) { top_score = m.bit_score; finished = false; }
 		if (finished) continue;
-		if ((1.0 - r[i].bit_score / top_score) * 100.0 <= top_percent) { if (w != i) r[w] = r[i]; ++w; }
+		if ((1.0 - m.bit_score / top_score) * 100.0 <= top_percent) keep.push_back(groups[i]);
 		else finished = true;
 	}
-	*n_out = w;
+	write_groups(r, src, keep, n_out);
 	return DMND_OK;
 }
 
@@ -1100,13 +1401,15 @@ extern "C" int dmnd_join_blocks_top(dmnd_match* r, int64_t n, double top_percent
 extern "C" int dmnd_join_blocks(dmnd_match* r, int64_t n, int max_target_seqs, int64_t* n_out)
 {
 	if (!r || n < 0 || max_target_seqs < 1 || !n_out) return fail(DMND_E_ARG, "dmnd_join_blocks: bad argument");
-	std::stable_sort(r, r + n, [](const dmnd_match& a, const dmnd_match& b) { return a.query < b.query || (a.query == b.query && match_less(a, b)); });
-	int64_t w = 0, run = 0;
-	for (int64_t i = 0; i < n; ++i) {
-		run = (i > 0 && r[i].query == r[i - 1].query) ? run + 1 : 0;
-		if (run < max_target_seqs) { if (w != i) r[w] = r[i]; ++w; }
+	const std::vector<dmnd_match> src(r, r + n);
+	const auto groups = join_groups(src.data(), n, match_less);
+	std::vector<std::pair<int64_t, int64_t>> keep;
+	int64_t run = 0;
+	for (size_t i = 0; i < groups.size(); ++i) {
+		run = (i > 0 && src[(size_t)groups[i].first].query == src[(size_t)groups[i - 1].first].query) ? run + 1 : 0;
+		if (run < max_target_seqs) keep.push_back(groups[i]);
 	}
-	*n_out = w;
+	write_groups(r, src, keep, n_out);
 	return DMND_OK;
 }
 

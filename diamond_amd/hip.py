@@ -71,7 +71,7 @@ EXPORTS = ["dmnd_abi_version", "dmnd_last_error", "dmnd_default_params", "dmnd_c
            "dmnd_seed_params_set_index_chunks", "dmnd_join_blocks", "dmnd_set_sensitivity", "dmnd_touch_streams",
            "dmnd_seed_params_set_query_indexed", "dmnd_auto_query_indexed", "dmnd_set_motif_table", "dmnd_motif_table_size",
            "dmnd_soft_mask_block", "dmnd_output_fields", "dmnd_format_fields", "dmnd_format_pairwise_intro", "dmnd_format_pairwise",
-           "dmnd_format_paf", "dmnd_device_count", "dmnd_set_top_percent", "dmnd_join_blocks_top", "dmnd_set_filters", "dmnd_format_sam", "dmnd_set_query_source_lengths", "dmnd_format_fields_unaligned", "dmnd_format_fields_header", "dmnd_set_query_index_reuse", "dmnd_set_no_self_hits", "dmnd_matrix_params", "dmnd_masking_lambda", "dmnd_translate_opts", "dmnd_set_extension_mode", "dmnd_format_xml_header", "dmnd_format_xml_query_intro", "dmnd_format_xml", "dmnd_format_xml_query_epilog", "dmnd_format_daa_header", "dmnd_format_daa_query", "dmnd_format_daa_match", "dmnd_seg_ranges", "dmnd_seg_mask_block", "dmnd_seg_lnfact", "dmnd_daa_match_read", "dmnd_hsp_from_transcript", "dmnd_set_format_flags", "dmnd_host_alloc", "dmnd_host_free", "dmnd_share_block", "dmnd_init", "dmnd_seed_reserve", "dmnd_mask_sequences"]
+           "dmnd_format_paf", "dmnd_device_count", "dmnd_set_top_percent", "dmnd_join_blocks_top", "dmnd_set_filters", "dmnd_format_sam", "dmnd_set_query_source_lengths", "dmnd_format_fields_unaligned", "dmnd_format_fields_header", "dmnd_set_query_index_reuse", "dmnd_set_no_self_hits", "dmnd_matrix_params", "dmnd_masking_lambda", "dmnd_translate_opts", "dmnd_set_extension_mode", "dmnd_format_xml_header", "dmnd_format_xml_query_intro", "dmnd_format_xml", "dmnd_format_xml_query_epilog", "dmnd_format_daa_header", "dmnd_format_daa_query", "dmnd_format_daa_match", "dmnd_seg_ranges", "dmnd_seg_mask_block", "dmnd_seg_lnfact", "dmnd_daa_match_read", "dmnd_hsp_from_transcript", "dmnd_set_format_flags", "dmnd_host_alloc", "dmnd_host_free", "dmnd_share_block", "dmnd_init", "dmnd_seed_reserve", "dmnd_mask_sequences", "dmnd_set_max_hsps"]
 
 
 def set_motif_table(codes):
@@ -696,16 +696,25 @@ class Context:
         td = np.ascontiguousarray(tdata, dtype=np.int8)
         hits = np.ascontiguousarray(hits, dtype=SEED_HIT_DTYPE)
         cap = max(1024, hits.size)
-        out = np.empty(cap, dtype=MATCH_DTYPE)
-        n, used = ctypes.c_int64(0), ctypes.c_int64(0)
-        tr = np.zeros(max(1 << 20, 64 * hits.size) if with_transcripts else 0, np.uint8)
         v = ctypes.c_void_p
-        self._check(self.lib.dmnd_extend(self.h, qd.ctypes.data_as(v), td.ctypes.data_as(v), hits.ctypes.data_as(v),
-                                         ctypes.c_int64(hits.size), int(threads), ctypes.c_uint32(hsp_values),
-                                         out.ctypes.data_as(v), ctypes.c_int64(cap), ctypes.byref(n),
-                                         tr.ctypes.data_as(v) if with_transcripts else None, ctypes.c_int64(tr.size),
-                                         ctypes.byref(used)))
-        return out[:n.value], (tr[:used.value] if with_transcripts else None)
+        tr = np.zeros(max(1 << 20, 64 * hits.size) if with_transcripts else 0, np.uint8)
+        while True:
+            out = np.empty(cap, dtype=MATCH_DTYPE)
+            n, used = ctypes.c_int64(0), ctypes.c_int64(0)
+            rc = self.lib.dmnd_extend(self.h, qd.ctypes.data_as(v), td.ctypes.data_as(v), hits.ctypes.data_as(v),
+                                      ctypes.c_int64(hits.size), int(threads), ctypes.c_uint32(hsp_values),
+                                      out.ctypes.data_as(v), ctypes.c_int64(cap), ctypes.byref(n),
+                                      tr.ctypes.data_as(v) if with_transcripts else None, ctypes.c_int64(tr.size),
+                                      ctypes.byref(used))
+            if rc != 0 and n.value > cap:          # several HSPs per target (set_max_hsps): more records than seed hits
+                cap = n.value
+                continue
+            self._check(rc)
+            return out[:n.value], (tr[:used.value] if with_transcripts else None)
+
+    def set_max_hsps(self, n):
+        """--max-hsps: HSPs reported per target (default 1; 0 = all). The records of a target then follow each other."""
+        self._check(self.lib.dmnd_set_max_hsps(self.h, int(n)))
 
     def touch_streams(self):
         """Re-acquires the hardware queues of the context's streams after a device-wide synchronize (see diamond_hip.h)."""

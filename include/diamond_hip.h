@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DMND_ABI_VERSION 6      /* 2: dmnd_match.frame, seed parameters (ungapped filter, translated queries), dmnd_extend_plan(query_contexts); 3: seed_encoding; 4: output formats; 5: DMND_MAX_SHAPES 64; 6: dmnd_host_alloc, dmnd_share_block */
+#define DMND_ABI_VERSION 7      /* 2: dmnd_match.frame, seed parameters (ungapped filter, translated queries), dmnd_extend_plan(query_contexts); 3: seed_encoding; 4: output formats; 5: DMND_MAX_SHAPES 64; 6: dmnd_host_alloc, dmnd_share_block; 7: dmnd_set_max_hsps, several dmnd_match records per target */
 
 enum {
 	DMND_OK = 0,
@@ -254,7 +254,8 @@ typedef struct {
 	int32_t ungapped_score;       /* WorkTarget::ungapped_score = max stage-1 score of the target's seed hits */
 } dmnd_plan_target;
 
-/* One reported alignment = Extension::Match with its single Hsp (max_hsps = 1), src/align/extend.h:34-66 */
+/* One reported alignment = one Hsp of an Extension::Match (src/align/extend.h:34-66); with max_hsps = 1 (the default) a match has
+ * one record, else its HSPs are consecutive records (dmnd_set_max_hsps) */
 typedef struct {
 	uint32_t query, target;       /* query id (= block sequence id / query_contexts), target block id */
 	int32_t ungapped_score, d_begin, d_end;
@@ -408,6 +409,17 @@ int dmnd_set_no_self_hits(dmnd_ctx* ctx, dmnd_same_title_fn same_title, void* us
 int dmnd_join_blocks_top(dmnd_match* records, int64_t n, double top_percent, int64_t* n_out);
 /* -k / --max-target-seqs (default 25, src/basic/config.h:55) */
 int dmnd_set_max_target_seqs(dmnd_ctx* ctx, int k);
+/* --max-hsps N (config.max_hsps, default 1; 0 = no limit): HSPs reported per target. With N != 1 dmnd_extend
+ *  - sends EVERY reported round-1 band of a target through round 2 (add_dp_targets, align/gapped_final.cpp:62-76) and culls the
+ *    target's HSP list as Match::inner_culling does (align/culling.cpp:40-57: Hsp::operator< order, an HSP dropped when half of
+ *    its query or subject range lies inside a better one, the list cut at N);
+ *  - then searches alternative HSPs (recompute_alt_hsps, align/alt_hsp.cpp:86-142): every reported target is copied per query
+ *    context with the subject ranges of its HSPs overwritten by letter 25 and swept over the whole matrix, round after round,
+ *    until a sweep finds nothing above the report cutoff, the copy is masked through, or the target has N HSPs;
+ *  - returns one dmnd_match record per HSP, the records of a (query, target) pair consecutive and in the list's order: the first
+ *    one carries the target's place among the query's targets (Match::filter_evalue / filter_score).
+ * Translated queries need dmnd_set_query_source_lengths (the envelope test works on the read's coordinates). */
+int dmnd_set_max_hsps(dmnd_ctx* ctx, int n);
 /* Multi-block databases (-b / --block-size): the records of one query block against several reference
  * blocks (dmnd_match::target already offset to database ordinals by the caller, blocks in any order) are merged per query
  * the way join_query does it: ascending by (e-value, score descending, target ordinal) = JoinRecord::cmp_evalue

@@ -56,7 +56,7 @@ def test_makedb_rejects_malformed_input(tmp_path, content, message):
 
 
 @pytest.mark.parametrize("args, message", [
-    (["--max-hsps", "2"], "--max-hsps other than 1 is not part of this build"),
+    (["--max-hsps", "-2"], "Invalid value for --max-hsps"),
     (["-F", "15"], "frameshift alignment"),
     (["--custom-matrix", "m.txt"], "--custom-matrix is not part of this build"),
     (["--iterate"], "--iterate is not part of this build"),

@@ -723,6 +723,76 @@ def test_cli_extension_modes_match_reference(tmp_path):
     assert len({seen["--ext banded-fast"], seen["--ext banded-slow"], seen["--ext full"]}) == 3
 
 
+def _write_multi_hsp_files(d, seed=21):
+    """Multi-domain queries (four domains) against targets with the domains in another order, in reverse order, one domain
+    three times, two domains far apart, a single domain -- plus ordinary families: targets with one to four HSPs."""
+    rng = np.random.default_rng(seed)
+    db, doff, q, qoff = synth.generate(60, members=5, queries=60, seed=seed + 1, indel=0.03)
+    seqs_t = [db[doff[i]:doff[i + 1]] for i in range(len(doff) - 1)]
+    seqs_q = [q[qoff[i]:qoff[i + 1]] for i in range(len(qoff) - 1)]
+
+    def mutate(s, rate):
+        m = s.copy()
+        mut = rng.random(len(m)) < rate
+        m[mut] = rng.integers(0, 20, int(mut.sum()))
+        return m
+
+    def spacer():
+        return rng.integers(0, 20, int(rng.integers(5, 90))).astype(np.int8)
+
+    for k in range(40):
+        doms = [rng.integers(0, 20, int(rng.integers(70, 160))).astype(np.int8) for _ in range(4)]
+        seqs_q.append(np.concatenate([doms[0], spacer(), doms[1], spacer(), doms[2], spacer(), doms[3]]))
+        seqs_t.append(np.concatenate([mutate(doms[2], 0.15), spacer(), mutate(doms[0], 0.2), spacer(), mutate(doms[1], 0.1)]))
+        seqs_t.append(np.concatenate([mutate(doms[3], 0.1), spacer(), mutate(doms[2], 0.25), spacer(), mutate(doms[1], 0.2), spacer(), mutate(doms[0], 0.15)]))
+        seqs_t.append(np.concatenate([mutate(doms[0], 0.1), spacer(), mutate(doms[0], 0.25), spacer(), mutate(doms[0], 0.3)]))
+        seqs_t.append(np.concatenate([mutate(doms[1], 0.2), rng.integers(0, 20, 400).astype(np.int8), mutate(doms[3], 0.2)]))
+        seqs_t.append(np.concatenate([spacer(), mutate(doms[1], 0.3)]))
+    for name, seqs, prefix in (("db.faa", seqs_t, "t"), ("q.faa", seqs_q, "q")):
+        off = np.concatenate([[0], np.cumsum([len(s) for s in seqs])])
+        synth.write_fasta(os.path.join(str(d), name), prefix, np.concatenate(seqs), off)
+    qs = np.concatenate(seqs_q[60:80])
+    qo = np.concatenate([[0], np.cumsum([len(s) for s in seqs_q[60:80]])])
+    dna, off = synth.back_translate(qs, qo, seed=seed + 2)
+    synth.write_dna_fasta(os.path.join(str(d), "reads.fna"), "r", dna, off)
+
+
+def test_cli_max_hsps_matches_reference(tmp_path):
+    """--max-hsps N (0 = all): every reported band of a target goes through round 2, the target's HSP list is culled by range
+    overlap (Match::inner_culling), then alternative HSPs are searched on copies of the target with the found ranges masked
+    (recompute_alt_hsps) -- per sensitivity, with the list cut at 2 / 3, with transcripts, in XML (Hit_num / Hsp_num), with the
+    filters, over several reference blocks (an HSP list moves as one record group through the join), for translated queries."""
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/diamond not built")
+    _write_multi_hsp_files(tmp_path)
+    base = ["-q", str(tmp_path / "q.faa"), "-d", str(tmp_path / "db.faa"), "-p", "4"]
+    per_target = {}
+    strip = lambda t: "\n".join(l for l in t.splitlines() if "<BlastOutput_version>" not in l)
+    for extra in (["--max-hsps", "0"], ["--max-hsps", "2"], ["--max-hsps", "3", "--fast"], ["--max-hsps", "0", "--sensitive"],
+                  ["--max-hsps", "0", "-f", "6", "qseqid", "sseqid", "qstart", "qend", "sstart", "send", "evalue", "bitscore", "length", "gapopen", "btop"],
+                  ["--max-hsps", "0", "-f", "5"], ["--max-hsps", "2", "-f", "0"],
+                  ["--max-hsps", "0", "--id", "80"], ["--max-hsps", "0", "--query-cover", "20", "-k", "3"], ["--max-hsps", "0", "--comp-based-stats", "0"],
+                  ["--max-hsps", "0", "-b0.00002"], ["--max-hsps", "0", "--top", "10"], ["--max-hsps", "0", "--ext", "full"],
+                  ["--max-hsps", "0", "--masking", "0", "--algo", "1"]):
+        _run([REF, "blastp"] + base + extra + ["-o", str(tmp_path / "ref.out")])
+        _run([CLI, "blastp"] + base + extra + ["-o", str(tmp_path / "hip.out")])
+        ref = open(tmp_path / "ref.out").read()
+        assert len(ref) > 5000, extra
+        assert strip(open(tmp_path / "hip.out").read()) == strip(ref), extra
+        if "-f" not in extra:
+            pairs = [tuple(l.split("\t")[:2]) for l in ref.splitlines()]
+            per_target[" ".join(extra)] = max(pairs.count(p) for p in set(pairs))
+    assert per_target["--max-hsps 0"] >= 4 and per_target["--max-hsps 2"] == 2 and per_target["--max-hsps 3 --fast"] == 3
+    xargs = ["blastx", "-q", str(tmp_path / "reads.fna"), "-d", str(tmp_path / "db.faa"), "-p", "4", "--max-hsps", "0"]
+    for extra in ([], ["--sensitive", "-f", "6", "qseqid", "sseqid", "qstart", "qend", "qframe", "sstart", "send", "evalue", "btop"]):
+        _run([REF] + xargs + extra + ["-o", str(tmp_path / "ref.out")])
+        _run([CLI] + xargs + extra + ["-o", str(tmp_path / "hip.out")])
+        ref = open(tmp_path / "ref.out").read()
+        pairs = [tuple(l.split("\t")[:2]) for l in ref.splitlines()]
+        assert max(pairs.count(p) for p in set(pairs)) >= 3, extra
+        assert open(tmp_path / "hip.out").read() == ref, extra
+
+
 def test_cli_xml_format_matches_reference(tmp_path):
     """-f 5 (BLAST XML) for blastp (one and several reference blocks, queries without alignments) and blastx; the version line of the
     header names the program that wrote the file and is excluded."""
