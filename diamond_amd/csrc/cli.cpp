@@ -1516,7 +1516,7 @@ int main(int argc, char** argv)
 				"scoring      --matrix BLOSUM45|50|62|80|90|PAM30|70|250  --gapopen N  --gapextend N  --comp-based-stats 0|1\n"
 				"masking      --masking tantan|seg|none  --motif-masking 0|1\n"
 				"extension    --ext banded-fast|banded-slow|full\n"
-				"reporting    -k N  --top PCT  -e EVALUE  --min-score BITS  --id PCT  --query-cover PCT  --subject-cover PCT  --no-self-hits\n"
+				"reporting    -k N  --max-hsps N  --top PCT  -e EVALUE  --min-score BITS  --id PCT  --query-cover PCT  --subject-cover PCT  --no-self-hits\n"
 				"             --unal 0|1  --un FILE  --al FILE  --header [simple|verbose]  --compress 1  --salltitles  --sallseqid\n"
 				"formats      -f 6 [FIELD...] | 0 (pairwise) | 5 (XML) | 100 (DAA) | 101 (SAM) | 103 (PAF)\n"
 				"translated   --strand both|plus|minus  --query-gencode N  --min-orf N\n"
