@@ -445,6 +445,7 @@ struct Options {
 	int gpus = 1;                   // --gpus: the reference blocks are spread over this many MI355X of the node
 	double top = -1.0;              // --top PERCENT
 	int max_hsps = 1;               // --max-hsps N: HSPs per target (0 = all)
+	int global_ranking = 0;         // --global-ranking N: extend only the N targets per query with the best ungapped scores over the whole database
 	bool no_self_hits = false;      // --no-self-hits
 	std::string matrix = "blosum62";        // --matrix / --gapopen / --gapextend (-1 = the matrix's default), basic/config.cpp:256-258
 	int gap_open = -1, gap_extend = -1;
@@ -568,6 +569,7 @@ Options parse(int argc, char** argv)
 		else if (a == "--quiet" || a == "--log" || a == "-v" || a == "--verbose") {}
 		else if (a == "-t" || a == "--tmpdir") (void)need(i);                // no temporary files: hits and records stay in memory / HBM
 		else if (a == "--ignore-warnings" || a == "--no-auto-append" || a == "--keep-temp-files") {}
+		else if (a == "--global-ranking" || a == "-g") { o.global_ranking = std::atoi(need(i).c_str()); if (o.global_ranking < 0) throw std::runtime_error("Invalid value for --global-ranking."); }
 		else if (a == "--max-hsps") { o.max_hsps = std::atoi(need(i).c_str()); if (o.max_hsps < 0) throw std::runtime_error("Invalid value for --max-hsps."); }
 		else if (a == "-F" || a == "--frameshift" || a == "--long-reads" || a == "--range-culling")
 			throw std::runtime_error(a + " (frameshift alignment / range culling) is not part of this build.");
@@ -826,7 +828,10 @@ int run_blastp(const Options& o)
 		chk(dmnd_set_comp_based_stats(c, o.cbs));
 		chk(dmnd_set_query_contexts(c, blastx ? 6 : 1));
 		chk(dmnd_set_sensitivity(c, sens));
-		chk(dmnd_set_extension_mode(c, o.ext));
+		// global ranking extends its targets over the full matrix (search/setup.cpp:377-389)
+		if (o.global_ranking > 0 && o.ext != DMND_EXT_DEFAULT && o.ext != DMND_EXT_FULL) throw std::runtime_error("Global ranking only supports full matrix extension.");
+		chk(dmnd_set_extension_mode(c, o.global_ranking > 0 ? DMND_EXT_FULL : o.ext));
+		chk(dmnd_set_global_ranking(c, o.global_ranking));
 		chk(dmnd_set_gapped_filter(c, gf_evalue));
 		// several reference blocks per GPU: the query seed index of a query block is built once and kept for all of them
 		if (t_blocks.size() > (size_t)n_gpus) chk(dmnd_set_query_index_reuse(c, 1));
@@ -932,7 +937,7 @@ int run_blastp(const Options& o)
 	std::mutex merge_mutex;
 	std::vector<std::vector<int8_t>> t_masked((size_t)n_gpus);      // lazily masked copy of the reference block at hand (query-indexed algorithm)
 	// --no-self-hits: the library finds query / target pairs with the same letters and asks here whether the titles agree too
-	struct SelfCtx { const std::vector<std::string>* qtitles; const Database* db; size_t q0 = 0, t0 = 0; };
+	struct SelfCtx { const std::vector<std::string>* qtitles; const Database* db; size_t q0 = 0, t0 = 0; const std::vector<uint32_t>* ordinals = nullptr; };      // ordinals: block id -> database ordinal (globally ranked targets)
 	std::vector<SelfCtx> self_ctx((size_t)n_gpus);
 	struct Held { SeqBlock block; size_t index = (size_t)-1; bool ahead = false; };      // ahead: read AND uploaded before the query phase, not yet masked
 	std::vector<Held> held_blocks((size_t)n_gpus);                  // the reference block every GPU's thread holds in host memory
@@ -999,6 +1004,8 @@ int run_blastp(const Options& o)
 		if (&qr == &q_blocks.front())
 			for (int g = 0; g < n_gpus; ++g)
 				reserved.push_back(std::async(std::launch::async, [&, g] { const int rc = dmnd_seed_reserve(ctxs[(size_t)g], &sp, (int64_t)q.data.size()); g_timeline.mark("seed buffers reserved"); return rc; }));
+		// --global-ranking: per query the N best targets of the whole database by ungapped score (align/global_ranking/table.cpp)
+		std::vector<dmnd_ranked_target> rank_table(o.global_ranking > 0 ? (qr.end - qr.begin) * (size_t)o.global_ranking : 0, dmnd_ranked_target{ 0, 0, 0, 0, 0 });
 		std::vector<dmnd_match> joined;                       // the query block's records against all reference blocks
 		std::vector<uint8_t> arena;                           // ... and their transcripts, if the output format reads them
 		std::vector<char> seeded(qr.end - qr.begin, 0);       // queries with at least one seed hit (what the unaligned report depends on)
@@ -1077,6 +1084,22 @@ int run_blastp(const Options& o)
 				std::snprintf(b, sizeof b, " (kernels: index %.2f, stream %.2f, mask %.2f, pairs %.2f, all %.2f ms)", ms[0], ms[1], ms[2], ms[3], ms[4]);
 				g_timeline.mark("seed stage of block " + std::to_string(bi) + " done" + b);
 			}
+			if (o.global_ranking > 0) {
+				// no extension here: the block pair's seed hits only update the ranking table (search/stage2.h:138, table.cpp:153-190);
+				// the targets are neither masked lazily (extend.cpp:202) nor extended before the last block
+				std::vector<dmnd_ranked_target> recs((size_t)std::max<int64_t>(n_hits, 1));
+				int64_t n_recs = 0;
+				chk(dmnd_rank_targets(ctx, q.data.data(), t.data.data(), hits.data(), n_hits, threads, recs.data(), (int64_t)recs.size(), &n_recs));
+				for (int64_t k = 0; k < n_recs; ++k) recs[(size_t)k].target += (uint32_t)tr.begin;
+				std::lock_guard<std::mutex> lock(merge_mutex);
+				chk(dmnd_rank_update(rank_table.data(), (int64_t)(qr.end - qr.begin), o.global_ranking, recs.data(), n_recs));
+				for (const dmnd_seed_hit& h : hits) seeded[h.query / C] = 1;
+				ms_upload += up; ms_mask += mk; ms_seed += sd;
+				total_hits += n_hits;
+				if (&qr == &q_blocks.front()) { mt_total += mt; motif_letters += ml; }
+				g_timeline.mark("ranking table updated with block " + std::to_string(bi));
+				continue;
+			}
 			if (lazy_masking) {
 				if (!seg) {                                      // which targets: the sequence that holds each hit's reference position
 					lazy_ids.reserve(hits.size());
@@ -1094,7 +1117,7 @@ int run_blastp(const Options& o)
 				self_ctx[(size_t)g] = SelfCtx{ &qtitles, &db, qr.begin, tr.begin };
 				chk(dmnd_set_no_self_hits(ctx, [](void* u, uint32_t q, uint32_t t) -> int {
 					const SelfCtx& s = *static_cast<const SelfCtx*>(u);
-					return (*s.qtitles)[s.q0 + q] == s.db->title(s.t0 + t) ? 1 : 0;
+					return (*s.qtitles)[s.q0 + q] == s.db->title(s.ordinals ? (size_t)(*s.ordinals)[t] : s.t0 + t) ? 1 : 0;
 				}, &self_ctx[(size_t)g]));
 			}
 			std::vector<dmnd_match> mine((size_t)std::max<int64_t>(n_hits, 1));
@@ -1138,8 +1161,68 @@ int run_blastp(const Options& o)
 			if (&qr == &q_blocks.front()) { mt_total += mt; motif_letters += ml; }
 		}
 		});
+		if (o.global_ranking > 0) {
+			// Extension::GlobalRanking::extend (global_ranking/extend.cpp:171-233): the ranked targets of this query block as ONE reference
+			// block (database order), masked as the option says, then Extension::extend per query over the table's entries -- one seed
+			// hit per entry carrying its score and context -- full matrix, no ranking chunks, no gapped filter
+			auto t0 = std::chrono::steady_clock::now();
+			std::vector<uint32_t> ordinals;
+			for (const dmnd_ranked_target& e : rank_table) if (e.score) ordinals.push_back(e.target);
+			std::sort(ordinals.begin(), ordinals.end());
+			ordinals.erase(std::unique(ordinals.begin(), ordinals.end()), ordinals.end());
+			std::cerr << "#Ranked database sequences: " << ordinals.size() << "\n";
+			if (!ordinals.empty()) {
+				dmnd_ctx* ctx = ctxs[0];
+				SeqBlock rb;
+				rb.begin();
+				for (uint32_t oid : ordinals) rb.push(db.sequence(oid), std::string());
+				rb.finish();
+				int64_t mt = 0;
+				if (seg) chk(dmnd_seg_mask_block(rb.data.data(), rb.limits.data(), (int64_t)ordinals.size(), threads, &mt));
+				chk(dmnd_upload_block(ctx, DMND_TARGET, rb.data.data(), (int64_t)rb.data.size(), rb.limits.data(), (int64_t)ordinals.size()));
+				if (tantan) chk(dmnd_mask_block(ctx, DMND_TARGET, rb.data.data(), &mt));
+				held_blocks[0].index = (size_t)-1; held_blocks[0].ahead = false;      // the reference block this GPU held is no longer in HBM
+				std::vector<dmnd_seed_hit> hits;
+				for (size_t qi = 0; qi < qr.end - qr.begin; ++qi)
+					for (int k = 0; k < o.global_ranking; ++k) {
+						const dmnd_ranked_target& e = rank_table[qi * (size_t)o.global_ranking + (size_t)k];
+						if (!e.score) break;
+						const size_t local = (size_t)(std::lower_bound(ordinals.begin(), ordinals.end(), e.target) - ordinals.begin());
+						dmnd_seed_hit h;
+						std::memset(&h, 0, sizeof h);
+						h.query = (uint32_t)(qi * C + e.context); h.seed_offset = 0; h.subject = rb.limits[local]; h.score = e.score;
+						hits.push_back(h);
+					}
+				const int64_t n_hits = (int64_t)hits.size();
+				if (o.no_self_hits) {
+					if (blastx) throw std::runtime_error("--no-self-hits is not supported for blastx");
+					self_ctx[0] = SelfCtx{ &qtitles, &db, qr.begin, 0, &ordinals };
+					chk(dmnd_set_no_self_hits(ctx, [](void* u, uint32_t q, uint32_t t) -> int {
+						const SelfCtx& s = *static_cast<const SelfCtx*>(u);
+						return (*s.qtitles)[s.q0 + q] == s.db->title((size_t)(*s.ordinals)[t]) ? 1 : 0;
+					}, &self_ctx[0]));
+				}
+				joined.assign((size_t)std::max<int64_t>(n_hits, 1), dmnd_match());
+				int64_t n_m = 0, cap = std::max<int64_t>((int64_t)1 << 20, 64 * n_hits), used = 0;
+				for (;;) {
+					if (need_transcripts) arena.resize((size_t)cap);
+					const int rc = dmnd_extend(ctx, q.data.data(), rb.data.data(), hits.data(), n_hits, threads, 0, joined.data(), (int64_t)joined.size(), &n_m,
+						need_transcripts ? arena.data() : nullptr, need_transcripts ? cap : 0, need_transcripts ? &used : nullptr);
+					if (rc == DMND_E_CAP && n_m > (int64_t)joined.size()) { joined.resize((size_t)n_m); continue; }
+					if (rc == DMND_E_CAP && need_transcripts && cap < ((int64_t)1 << 36)) { cap *= 4; continue; }
+					chk(rc);
+					break;
+				}
+				joined.resize((size_t)n_m);
+				arena.resize(need_transcripts ? (size_t)used : 0);
+				for (dmnd_match& m : joined) { m.query += (uint32_t)qr.begin; m.target = ordinals[m.target]; }
+				mt_total += mt;
+			}
+			ms_ext += ms_since(t0);
+			g_timeline.mark("globally ranked targets extended");
+		}
 		int64_t n_matches = (int64_t)joined.size();
-		if (t_blocks.size() > 1) chk(o.top >= 0.0 ? dmnd_join_blocks_top(joined.data(), (int64_t)joined.size(), o.top, &n_matches)
+		if (t_blocks.size() > 1 && o.global_ranking == 0) chk(o.top >= 0.0 ? dmnd_join_blocks_top(joined.data(), (int64_t)joined.size(), o.top, &n_matches)
 			: dmnd_join_blocks(joined.data(), (int64_t)joined.size(), o.k, &n_matches));
 		std::vector<int8_t> full_sseq_buf;                    // the unmasked target of the line being printed (full_sseq)
 		auto view_of = [&](const dmnd_match& m) {
@@ -1516,7 +1599,7 @@ int main(int argc, char** argv)
 				"scoring      --matrix BLOSUM45|50|62|80|90|PAM30|70|250  --gapopen N  --gapextend N  --comp-based-stats 0|1\n"
 				"masking      --masking tantan|seg|none  --motif-masking 0|1\n"
 				"extension    --ext banded-fast|banded-slow|full\n"
-				"reporting    -k N  --max-hsps N  --top PCT  -e EVALUE  --min-score BITS  --id PCT  --query-cover PCT  --subject-cover PCT  --no-self-hits\n"
+				"reporting    -k N  --max-hsps N  --global-ranking N  --top PCT  -e EVALUE  --min-score BITS  --id PCT  --query-cover PCT  --subject-cover PCT  --no-self-hits\n"
 				"             --unal 0|1  --un FILE  --al FILE  --header [simple|verbose]  --compress 1  --salltitles  --sallseqid\n"
 				"formats      -f 6 [FIELD...] | 0 (pairwise) | 5 (XML) | 100 (DAA) | 101 (SAM) | 103 (PAF)\n"
 				"translated   --strand both|plus|minus  --query-gencode N  --min-orf N\n"

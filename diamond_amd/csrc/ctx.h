@@ -135,6 +135,7 @@ struct dmnd_ctx {
 	int query_contexts = 1;                    // align_mode.query_contexts: 6 for blastx (basic/basic.cpp:40-60)
 	int max_target_seqs = 25;                  // config.max_target_seqs (-k), basic/config.h:55
 	int max_hsps = 1;                          // config.max_hsps (--max-hsps): HSPs reported per target, 0 = all (dmnd_set_max_hsps)
+	int global_ranking = 0;                    // config.global_ranking_targets (--global-ranking): dmnd_set_global_ranking
 	dmnd::DevBuf alt_targets;                  // masked target copies of the alternative-HSP rounds (extend_host.hip)
 	double top_percent = -1.0;                 // config.toppercent (--top); < 0 = off
 	double min_id = 0, query_cover = 0, subject_cover = 0, min_bit_score = 0;      // --id, --query-cover, --subject-cover, --min-score

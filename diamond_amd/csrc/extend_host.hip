@@ -78,6 +78,7 @@ struct HostCfg {
 	int cbs_window = 40;                 // config.cbs_window
 	int max_target_seqs = 25;
 	int max_hsps = 1;                    // config.max_hsps: HSPs reported per target; 0 = all of them
+	int global_ranking = 0;              // config.global_ranking_targets > 0: the hits are one record per ranked target, no ranking chunks
 	int64_t max_swipe_dp = 1000000;      // config.max_swipe_dp
 	int band_mode_fast = 1;              // Extension::Mode::BANDED_FAST for every sensitivity up to --sensitive
 	bool ext_full = false;               // Extension::Mode::FULL (--ext full): no chaining, one full-matrix DpTarget per target and context
@@ -194,6 +195,7 @@ void load_query(const HostCfg& h, QueryWork& w, uint32_t query, const dmnd_seed_
 	w.order.resize(w.groups.size());
 	for (size_t i = 0; i < w.order.size(); ++i) w.order[i] = (uint32_t)i;
 	w.chunk_size = ranking_chunk_size(h.ref_letters, h.max_target_seqs, h.ranking_block_letters, h.top >= 0.0);
+	if (h.global_ranking > 0) w.chunk_size = std::max<int64_t>((int64_t)w.groups.size(), 1);      // extend.cpp:80: one chunk = all ranked targets
 	if (w.chunk_size < (int64_t)w.groups.size())      // TargetScore::operator<: score desc, target index asc (target.h:146-158)
 		std::sort(w.order.begin(), w.order.end(), [&](uint32_t a, uint32_t b) {
 			return w.groups[a].score > w.groups[b].score || (w.groups[a].score == w.groups[b].score && a < b);
@@ -1103,6 +1105,8 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	make_cfg(c, h);
 	h.max_target_seqs = c->max_target_seqs;
 	h.max_hsps = c->max_hsps;
+	h.global_ranking = c->global_ranking;
+	if (h.global_ranking > 0 && c->ext_mode != DMND_EXT_FULL) return fail(DMND_E_ARG, "dmnd_extend: globally ranked targets are extended over the full matrix (dmnd_set_extension_mode(DMND_EXT_FULL))");
 	h.top = c->top_percent;
 	h.evaluer = &c->evaluer;
 	h.max_evalue = c->params.max_evalue;
@@ -1192,7 +1196,7 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	// 1b. gapped filter of every seed hit in one launch (only --sensitive and above; extend.cpp:205-213)
 	std::vector<uint8_t> gf;
 	c->gf_ms = 0;
-	if (c->gapped_filter_evalue > 0.0 && n_hits > 0) {
+	if (c->gapped_filter_evalue > 0.0 && n_hits > 0 && h.global_ranking == 0) {      // (extend.cpp:206: not for globally ranked targets)
 		if (bias_pending) { HIP_TRY(sync_stream(c->stream)); bias_pending = false; }      // the filter's profile reads the bias
 		gf.resize((size_t)n_hits);
 		if (int rc = dmnd_gapped_filter(c, hits, n_hits, h.use_cbs ? 1 : 0, gf.data(), nullptr)) return rc;
@@ -1298,6 +1302,95 @@ extern "C" int dmnd_set_extension_mode(dmnd_ctx* c, int mode)
 {
 	if (!c || mode < DMND_EXT_DEFAULT || mode > DMND_EXT_FULL) return fail(DMND_E_ARG, "dmnd_set_extension_mode: bad argument");
 	c->ext_mode = mode;
+	return DMND_OK;
+}
+
+// ---- global ranking (align/global_ranking/table.cpp) ------------------------------------------------------------------
+// get_query_hits_reextend + target_score (table.cpp:88-133): per (query, target) of a block pair's seed hits the best x-drop
+// ungapped score over the target's hits -- no composition bias; hits in (diagonal, column) order, a hit skipped when the segment
+// computed LAST on its diagonal already reaches it -- and the context it was found in.
+extern "C" int dmnd_rank_targets(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata, const dmnd_seed_hit* hits, int64_t n_hits, int threads,
+	dmnd_ranked_target* out, int64_t cap, int64_t* n_out)
+{
+	if (!c || !qdata || !tdata || (!hits && n_hits) || !n_out || (!out && cap)) return fail(DMND_E_ARG, "dmnd_rank_targets: NULL argument");
+	*n_out = 0;
+	const std::vector<int64_t>& ql = c->limits[DMND_QUERY];
+	const std::vector<int64_t>& tl = c->limits[DMND_TARGET];
+	if (ql.size() < 2 || tl.size() < 2) return fail(DMND_E_ARG, "dmnd_rank_targets: blocks must be uploaded with limits");
+	HostCfg h;
+	make_cfg(c, h);
+	h.contexts = c->query_contexts;
+	h.evaluer = nullptr;
+	const uint32_t C = (uint32_t)h.contexts;
+	const std::vector<Range> qr = split_by_query(hits, n_hits, h.contexts);
+	std::vector<std::vector<dmnd_ranked_target>> per(qr.size());
+	threads = std::max(1, threads);
+	const uint32_t* coarse = c->coarse[DMND_TARGET].empty() ? nullptr : c->coarse[DMND_TARGET].data();
+	parallel_for(qr.size(), threads, [&](size_t i, int) {
+		QueryWork w;
+		const uint32_t query = hits[qr[i].b].query / C;
+		load_query(h, w, query, hits + qr[i].b, hits + qr[i].e, nullptr, tl.data(), (int64_t)tl.size() - 1, coarse);
+		std::vector<HostSeedHit>& sh = w.sh;
+		for (const TargetGroup& g : w.groups) {
+			std::sort(sh.begin() + (ptrdiff_t)g.begin, sh.begin() + (ptrdiff_t)g.end, [](const HostSeedHit& a, const HostSeedHit& b) {
+				const int d1 = a.i - a.j, d2 = b.i - b.j;
+				return d1 < d2 || (d1 == d2 && a.j < b.j);
+			});
+			const SeqRef t{ tdata + tl[g.target], (int)(tl[g.target + 1] - tl[g.target] - 1) };
+			auto walk = [&](const HostSeedHit& x) {
+				const uint32_t qc = query * C + (uint32_t)x.frame;
+				return xdrop_ungapped(h.S, SeqRef{ qdata + ql[qc], (int)(ql[qc + 1] - ql[qc] - 1) }, nullptr, t, x.i, x.j, h.xdrop);
+			};
+			Seg d = walk(sh[g.begin]);
+			int score = d.score, context = sh[g.begin].frame;
+			for (size_t x = g.begin + 1; x < g.end; ++x) {
+				if (d.diag() == sh[x].i - sh[x].j && d.j_end() >= sh[x].j) continue;
+				d = walk(sh[x]);
+				if (d.score > score) { score = d.score; context = sh[x].frame; }
+			}
+			per[i].push_back(dmnd_ranked_target{ query, g.target, (uint16_t)score, (uint8_t)context, 0 });
+		}
+	});
+	int64_t n = 0;
+	for (const auto& v : per) n += (int64_t)v.size();
+	*n_out = n;
+	if (n > cap) return fail(DMND_E_CAP, "dmnd_rank_targets: record buffer too small");
+	int64_t o = 0;
+	for (const auto& v : per) { std::copy(v.begin(), v.end(), out + o); o += (int64_t)v.size(); }
+	return DMND_OK;
+}
+
+// merge_hits (table.cpp:135-151): the records of one block pair into the table of the best n targets of every query -- per target its
+// best score, the table in (score descending, target ascending) order (Hit::operator<), empty entries have score 0
+extern "C" int dmnd_rank_update(dmnd_ranked_target* table, int64_t n_queries, int n, const dmnd_ranked_target* recs, int64_t n_recs)
+{
+	if (!table || n_queries < 0 || n < 1 || (!recs && n_recs) || n_recs < 0) return fail(DMND_E_ARG, "dmnd_rank_update: bad argument");
+	std::vector<dmnd_ranked_target> hits, merged;
+	for (int64_t b = 0; b < n_recs;) {
+		int64_t e = b;
+		while (e < n_recs && recs[e].query == recs[b].query) ++e;
+		const uint32_t q = recs[b].query;
+		if ((int64_t)q >= n_queries) return fail(DMND_E_ARG, "dmnd_rank_update: query id outside the table");
+		dmnd_ranked_target* row = table + (size_t)q * (size_t)n;
+		int count = n;
+		while (count > 0 && row[count - 1].score == 0) --count;
+		hits.assign(recs + b, recs + e);
+		hits.insert(hits.end(), row, row + count);
+		std::sort(hits.begin(), hits.end(), [](const dmnd_ranked_target& x, const dmnd_ranked_target& y) { return x.target < y.target || (x.target == y.target && x.score > y.score); });
+		merged.clear();
+		for (const dmnd_ranked_target& x : hits) if (merged.empty() || merged.back().target != x.target) merged.push_back(x);
+		std::sort(merged.begin(), merged.end(), [](const dmnd_ranked_target& x, const dmnd_ranked_target& y) { return x.score > y.score || (x.score == y.score && x.target < y.target); });
+		const size_t keep = std::min((size_t)n, merged.size());
+		for (size_t k = 0; k < keep; ++k) { row[k] = merged[k]; row[k].query = q; }
+		b = e;
+	}
+	return DMND_OK;
+}
+
+extern "C" int dmnd_set_global_ranking(dmnd_ctx* c, int n)
+{
+	if (!c || n < 0) return fail(DMND_E_ARG, "dmnd_set_global_ranking: bad argument");
+	c->global_ranking = n;
 	return DMND_OK;
 }
 

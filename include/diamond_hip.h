@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DMND_ABI_VERSION 7      /* 2: dmnd_match.frame, seed parameters (ungapped filter, translated queries), dmnd_extend_plan(query_contexts); 3: seed_encoding; 4: output formats; 5: DMND_MAX_SHAPES 64; 6: dmnd_host_alloc, dmnd_share_block; 7: dmnd_set_max_hsps, several dmnd_match records per target */
+#define DMND_ABI_VERSION 7      /* 2: dmnd_match.frame, seed parameters (ungapped filter, translated queries), dmnd_extend_plan(query_contexts); 3: seed_encoding; 4: output formats; 5: DMND_MAX_SHAPES 64; 6: dmnd_host_alloc, dmnd_share_block; 7: dmnd_set_max_hsps, several dmnd_match records per target, global ranking */
 
 enum {
 	DMND_OK = 0,
@@ -420,6 +420,24 @@ int dmnd_set_max_target_seqs(dmnd_ctx* ctx, int k);
  *    one carries the target's place among the query's targets (Match::filter_evalue / filter_score).
  * Translated queries need dmnd_set_query_source_lengths (the envelope test works on the read's coordinates). */
 int dmnd_set_max_hsps(dmnd_ctx* ctx, int n);
+/* --global-ranking N (config.global_ranking_targets; align/global_ranking/): instead of extending every reference block's seed
+ * hits, the search keeps per query the N targets of the WHOLE database with the best ungapped score and extends only those, over
+ * the full matrix, after the last block. Three calls:
+ *  - dmnd_rank_targets after dmnd_seed_search / dmnd_seed_hits of a block pair (get_query_hits_reextend, table.cpp:108-121): one
+ *    record per (query, target) of the hits = the best x-drop ungapped score over the target's seed hits (no composition bias) and
+ *    the query context it was found in (target_score, table.cpp:88-106); target = block sequence id. Host code, as in the reference.
+ *  - dmnd_rank_update (merge_hits, table.cpp:135-151): merges such records (target already turned into a database ordinal by the
+ *    caller, records grouped by query) into a table of n entries per query, zero-initialised by the caller: per target its best
+ *    score, rows ordered by (score descending, target ascending); an entry with score 0 is empty.
+ *  - the final extension (global_ranking/extend.cpp:133-233): the caller loads the targets the table names as ONE reference block,
+ *    masks and uploads it, calls dmnd_set_global_ranking(ctx, N) and dmnd_set_extension_mode(ctx, DMND_EXT_FULL), and hands
+ *    dmnd_extend one seed hit per table entry { query = query id * contexts + context, seed_offset 0, subject = first letter of the
+ *    target, score }: no ranking chunks (extend.cpp:80) and no gapped filter (extend.cpp:206) then. */
+typedef struct { uint32_t query, target; uint16_t score; uint8_t context, pad; } dmnd_ranked_target;
+int dmnd_rank_targets(dmnd_ctx* ctx, const int8_t* qdata, const int8_t* tdata, const dmnd_seed_hit* hits, int64_t n_hits, int threads,
+	dmnd_ranked_target* out, int64_t cap, int64_t* n_out);
+int dmnd_rank_update(dmnd_ranked_target* table, int64_t n_queries, int n, const dmnd_ranked_target* records, int64_t n_records);
+int dmnd_set_global_ranking(dmnd_ctx* ctx, int n);
 /* Multi-block databases (-b / --block-size): the records of one query block against several reference
  * blocks (dmnd_match::target already offset to database ordinals by the caller, blocks in any order) are merged per query
  * the way join_query does it: ascending by (e-value, score descending, target ordinal) = JoinRecord::cmp_evalue

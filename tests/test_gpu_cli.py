@@ -793,6 +793,38 @@ def test_cli_max_hsps_matches_reference(tmp_path):
         assert open(tmp_path / "hip.out").read() == ref, extra
 
 
+def test_cli_global_ranking_matches_reference(tmp_path):
+    """--global-ranking N: the seed hits of every reference block only update a table of the N best targets per query (x-drop
+    ungapped score over a target's seed hits); after the last block those targets are loaded as one block and extended over the
+    full matrix. One and several reference blocks, three sensitivities, both algorithms, SEG, transcripts, --max-hsps, blastx."""
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/diamond not built")
+    db, doff, q, qoff = synth.generate(150, members=12, queries=200, seed=31, decoy_frac=0.3)
+    db, q = _plant_repeats(db, doff, np.random.default_rng(3)), _plant_repeats(q, qoff, np.random.default_rng(4))
+    dna, off = synth.back_translate(q[: qoff[60]], qoff[:61], seed=32)
+    synth.write_fasta(str(tmp_path / "db.faa"), "t", db, doff)
+    synth.write_fasta(str(tmp_path / "q.faa"), "q", q, qoff)
+    synth.write_dna_fasta(str(tmp_path / "reads.fna"), "r", dna, off)
+    lines = {}
+    for mode, query, extra in (("blastp", "q.faa", ["-g", "3"]), ("blastp", "q.faa", ["--global-ranking", "8", "-b0.00002"]), ("blastp", "q.faa", ["-g", "100"]),
+                               ("blastp", "q.faa", ["-g", "4", "--fast", "-b0.00004", "-c1"]), ("blastp", "q.faa", ["-g", "5", "--sensitive", "-b0.00003"]),
+                               ("blastp", "q.faa", ["-g", "3", "--algo", "1", "-b0.00003"]), ("blastp", "q.faa", ["-g", "3", "--masking", "seg", "-b0.00003"]),
+                               ("blastp", "q.faa", ["-g", "3", "--masking", "0", "-b0.00003", "-f", "6", "qseqid", "sseqid", "qstart", "qend", "sstart", "send", "evalue", "bitscore", "btop"]),
+                               ("blastp", "q.faa", ["-g", "2", "--max-hsps", "0", "-k", "1", "-b0.00003"]), ("blastp", "q.faa", ["-g", "6", "--ext", "full", "--top", "20", "-b0.00003"]),
+                               ("blastx", "reads.fna", ["-g", "3", "-b0.00003"]), ("blastx", "reads.fna", ["-g", "2", "--sensitive"])):
+        args = [mode, "-q", str(tmp_path / query), "-d", str(tmp_path / "db.faa"), "-p", "4"] + extra
+        _run([REF] + args + ["-o", str(tmp_path / "ref.out")])
+        _run([CLI] + args + ["-o", str(tmp_path / "hip.out")])
+        ref = open(tmp_path / "ref.out").read()
+        assert len(ref.splitlines()) > 50, extra
+        assert open(tmp_path / "hip.out").read() == ref, (mode, extra)
+        lines[" ".join([mode] + extra)] = len(ref.splitlines())
+    assert lines["blastp -g 3"] < lines["blastp --global-ranking 8 -b0.00002"] < lines["blastp -g 100"]        # the table size limits what is extended
+    r = subprocess.run([CLI, "blastp", "-q", str(tmp_path / "q.faa"), "-d", str(tmp_path / "db.faa"), "-o", str(tmp_path / "x.out"), "-g", "3", "--ext", "banded-fast"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "Global ranking only supports full matrix extension" in r.stderr
+
+
 def test_cli_xml_format_matches_reference(tmp_path):
     """-f 5 (BLAST XML) for blastp (one and several reference blocks, queries without alignments) and blastx; the version line of the
     header names the program that wrote the file and is excluded."""
