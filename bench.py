@@ -241,8 +241,8 @@ def cpu_baseline_reference(w, cores, e2e=True):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="C2")
     ap.add_argument("--queries", type=int, default=None, help="default: the config's (10000; C5: 100000)")
     ap.add_argument("--families", type=int, default=None, help="protein families of 10 members in the database (default 100000; C5: 500000)")
@@ -562,6 +562,9 @@ def main():
             "pipeline": ("%d seed stage(s) at a time on their own contexts (low-priority streams), up to %d batches ahead of the extension stage; %d batches are extended at the same time "
                          "(own context and a team of %d host threads each)" % (SC, PREFETCH, E, ext_threads)) if pipeline else "off",
             "ms_each_step": each,
+            # batches retire in clumps (three are extended at a time): the completion intervals as windows of three steps -- the
+            # median window / 3 shows what a host hiccup (one long step) does to the mean that `value` is defined on
+            "ms_per_step_median_of_3_step_windows": (sorted(sum(each[i:i + 3]) for i in range(0, len(each) - 2, 3))[len(range(0, len(each) - 2, 3)) // 2] / 3.0) if len(each) >= 3 else None,
             "latency_in_pipeline": lat,
             "alone": alone,
             "host_cpu_ms_per_step": cpu_ms_per_step,

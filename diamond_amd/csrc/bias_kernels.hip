@@ -33,6 +33,36 @@ __global__ __launch_bounds__(256) void hauser_bias_kernel(BiasArgs a)
 // per hit, both directions along the hit's diagonal; letters and bias come from the resident blocks, the matrix from LDS. The host's
 // chaining stage did this per hit with two dependent reads per step into a target block of hundreds of MB (about half of its ~1 us
 // per hit); here the walks of all hits of the block run at once while the host is still grouping the hits by target.
+// xdrop_walk_core (xdrop_core.h) with the letters fetched sixteen at a time: the byte-by-byte walk is a chain of dependent L2 reads
+// (three per step: query letter, target letter, bias), 0.37 ms for the 20 k seed hits of a C2 batch with every wavefront waiting for its
+// longest walk. Same sums in the same order; the chunk may reach past the delimiter that ends the walk, never past the block's
+// 256-byte perimeter.
+__device__ __forceinline__ int xdrop_walk_chunked(const int8_t* M, const int8_t* q, const int8_t* cbs, const int8_t* t, int dir, int best, int xdrop, int& reach)
+{
+	reach = 0;
+	int sum = best, n = 1;
+	for (;;) {
+		uint32_t qw[4], tw[4], cw[4] = { 0, 0, 0, 0 };
+		// the sixteen letters from the current one on in walking direction: memory [p, p + 16) forward, [p - 15, p] backward
+		const int back = dir < 0 ? 15 : 0;
+		__builtin_memcpy(qw, q - back, 16);
+		__builtin_memcpy(tw, t - back, 16);
+		if (cbs) __builtin_memcpy(cw, cbs - back, 16);
+#pragma unroll
+		for (int j = 0; j < 16; ++j) {
+			if (!(best - sum < xdrop)) return best;
+			const int k = dir < 0 ? 15 - j : j;
+			const int a = (int)((qw[k >> 2] >> (8 * (k & 3))) & 31u), b = (int)((tw[k >> 2] >> (8 * (k & 3))) & 31u);
+			if (a == 31 || b == 31) return best;
+			sum += (int)M[(a << 5) + b] + (int)(int8_t)(cw[k >> 2] >> (8 * (k & 3)));
+			if (sum > best) { best = sum; reach = n; }
+			++n;
+		}
+		q += 16 * dir; t += 16 * dir;
+		if (cbs) cbs += 16 * dir;
+	}
+}
+
 __global__ __launch_bounds__(256) void xdrop_seg_kernel(XdropArgs a)
 {
 	__shared__ int8_t M[32 * 32];
@@ -47,8 +77,8 @@ __global__ __launch_bounds__(256) void xdrop_seg_kernel(XdropArgs a)
 	const int8_t* t = a.tblock + h.subject;
 	const int8_t* cbs = a.cbs ? a.cbs + qoff : nullptr;
 	int left, right;
-	const int s_left = xdrop_walk_core(M, q - 1, cbs ? cbs - 1 : nullptr, t - 1, -1, 0, a.xdrop, left);
-	const int s_both = xdrop_walk_core(M, q, cbs, t, +1, s_left, a.xdrop, right);
+	const int s_left = xdrop_walk_chunked(M, q - 1, cbs ? cbs - 1 : nullptr, t - 1, -1, 0, a.xdrop, left);
+	const int s_both = xdrop_walk_chunked(M, q, cbs, t, +1, s_left, a.xdrop, right);
 	a.out[k] = XdropSeg{ left, right, s_both };
 }
 

@@ -10,8 +10,8 @@ cd "$ROOT"
 if [ "${1:-}" = tests ]; then timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -6; fi
 cd /tmp && export TMPDIR=/tmp
 for cfg in C2 C4 C5 C3; do
-  steps=20; [ $cfg = C3 ] && steps=5; [ $cfg = C5 ] && steps=6
-  timeout 900 python "$ROOT/bench.py" --config $cfg --steps $steps --warmup 3 > "$OUT/bench_$cfg.json" 2> "$OUT/bench_$cfg.err"
+  steps=50; [ $cfg = C3 ] && steps=10; [ $cfg = C5 ] && steps=20
+  timeout 900 python "$ROOT/bench.py" --config $cfg --steps $steps --warmup 10 > "$OUT/bench_$cfg.json" 2> "$OUT/bench_$cfg.err"
   tail -c 300 "$OUT/bench_$cfg.err"
 done
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c2" -o s -- python "$ROOT/bench.py" --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/stats_c2.log" 2>&1
