@@ -444,6 +444,7 @@ struct Options {
 	std::vector<std::string> outfmt;   // -f / --outfmt: format, then field names
 	int gpus = 1;                   // --gpus: the reference blocks are spread over this many MI355X of the node
 	double top = -1.0;              // --top PERCENT
+	bool k_given = false;           // -k on the command line (--top excludes it, basic/config.cpp:674)
 	int max_hsps = 1;               // --max-hsps N: HSPs per target (0 = all)
 	int global_ranking = 0;         // --global-ranking N: extend only the N targets per query with the best ungapped scores over the whole database
 	bool no_self_hits = false;      // --no-self-hits
@@ -494,6 +495,7 @@ Options parse(int argc, char** argv)
 		else if (a == "-p" || a == "--threads") o.threads = std::atoi(need(i).c_str());
 		else if (a == "-k" || a == "--max-target-seqs") {
 			o.k = std::atoi(need(i).c_str());
+			o.k_given = true;
 			if (o.k < 0) throw std::runtime_error("Invalid value for --max-target-seqs.");
 			if (o.k == 0) o.k = 1 << 30;                           // 0 = report every target (init_output, output/output_format.cpp:242-244)
 		}
@@ -578,6 +580,7 @@ Options parse(int argc, char** argv)
 			throw std::runtime_error(a + " is not part of this build.");
 		else throw std::runtime_error("Invalid option: " + a);
 	}
+	if (o.top >= 0.0 && o.k_given) throw std::runtime_error("--top and -k/--max-target-seqs are mutually exclusive.");      // basic/config.cpp:674-675
 	return o;
 }
 
@@ -736,7 +739,8 @@ int run_blastp(const Options& o)
 	}
 	if (tab_extras && fmt != FMT_FIELDS && !o.header.empty() && o.header != "0") throw std::runtime_error("--header is only available for the tabular format");
 	// which formats report queries without alignments: pairwise, PAF and SAM by default (DEFAULT_REPORT_UNALIGNED), tabular with --unal 1
-	const bool report_unal = o.unal == 1 || (o.unal == -1 && (fmt == FMT_PAIRWISE || fmt == FMT_PAF || fmt == FMT_SAM || fmt == FMT_XML));
+	// (DAA files never list unaligned queries, whatever --unal says: output/join_blocks.cpp:302,365)
+	const bool report_unal = fmt != FMT_DAA && (o.unal == 1 || (o.unal == -1 && (fmt == FMT_PAIRWISE || fmt == FMT_PAF || fmt == FMT_SAM || fmt == FMT_XML)));
 	bool want_full_sseq = false;
 	for (int32_t id : field_ids) want_full_sseq |= id == DMND_F_FULL_SSEQ;
 	auto t0 = std::chrono::steady_clock::now();
@@ -886,7 +890,7 @@ int run_blastp(const Options& o)
 	int64_t daa_bytes = 0, daa_queries = 0;
 	if (fmt == FMT_DAA) {
 		daa.build = 182;                                // the build number of the reference version whose format this is (basic/const.h:25)
-		daa.db_seqs = (int64_t)db.n; daa.db_letters = (int64_t)p.db_letters; daa.db_seqs_used = 0; daa.query_records = 0;
+		daa.db_seqs = (int64_t)db.n; daa.db_letters = db.letters;      /* the database's letters, not --dbsize */ daa.db_seqs_used = 0; daa.query_records = 0;
 		daa.mode = blastx ? 3 : 2; daa.gap_open = p.gap_open; daa.gap_extend = p.gap_extend; daa.K = p.K; daa.lambda = p.lambda; daa.max_evalue = o.evalue;
 		daa.matrix = o.matrix.c_str(); daa.finished = 0; daa.alignment_bytes = 0; daa.ref_name_bytes = 0;
 		std::vector<char> hb(4096);

@@ -57,6 +57,7 @@ def test_makedb_rejects_malformed_input(tmp_path, content, message):
 
 @pytest.mark.parametrize("args, message", [
     (["--max-hsps", "-2"], "Invalid value for --max-hsps"),
+    (["--top", "10", "-k", "5"], "--top and -k/--max-target-seqs are mutually exclusive"),
     (["-F", "15"], "frameshift alignment"),
     (["--custom-matrix", "m.txt"], "--custom-matrix is not part of this build"),
     (["--iterate"], "--iterate is not part of this build"),
