@@ -371,6 +371,22 @@ def join_blocks(records, max_target_seqs=25):
     return r[:n.value]
 
 
+RANKED_DTYPE = np.dtype([("query", "<u4"), ("target", "<u4"), ("score", "<u2"), ("context", "u1"), ("pad", "u1")])
+assert RANKED_DTYPE.itemsize == 12
+
+
+def rank_update(table, n, records):
+    """--global-ranking: merges the records of one block pair (RANKED_DTYPE, grouped by query, targets as database ordinals) into the
+    table of the n best targets per query (dmnd_rank_update = merge_hits). table: RANKED_DTYPE[n_queries * n], modified in place."""
+    lib = load()
+    assert table.dtype == RANKED_DTYPE and table.flags["C_CONTIGUOUS"] and table.size % n == 0
+    r = np.ascontiguousarray(records, dtype=RANKED_DTYPE)
+    lib.dmnd_rank_update.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64]
+    if lib.dmnd_rank_update(table.ctypes.data, ctypes.c_int64(table.size // n), int(n), r.ctypes.data, ctypes.c_int64(r.size)) != 0:
+        raise DiamondHipError(lib.dmnd_last_error().decode())
+    return table
+
+
 def join_blocks_top(records, top_percent):
     """The block join of a --top run (dmnd_join_blocks_top): score order, targets within top_percent of a query's best bit score."""
     lib = load()
@@ -711,6 +727,22 @@ class Context:
                 continue
             self._check(rc)
             return out[:n.value], (tr[:used.value] if with_transcripts else None)
+
+    def rank_targets(self, qdata, tdata, hits, threads=4):
+        """--global-ranking: per (query, target) of the seed hits the best x-drop ungapped score and its context (dmnd_rank_targets)."""
+        qd = np.ascontiguousarray(qdata, dtype=np.int8)
+        td = np.ascontiguousarray(tdata, dtype=np.int8)
+        hits = np.ascontiguousarray(hits, dtype=SEED_HIT_DTYPE)
+        out = np.zeros(max(1, hits.size), RANKED_DTYPE)
+        n = ctypes.c_int64(0)
+        v = ctypes.c_void_p
+        self.lib.dmnd_rank_targets.argtypes = [v, v, v, v, ctypes.c_int64, ctypes.c_int, v, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
+        self._check(self.lib.dmnd_rank_targets(self.h, qd.ctypes.data, td.ctypes.data, hits.ctypes.data, ctypes.c_int64(hits.size), int(threads),
+                                               out.ctypes.data, ctypes.c_int64(out.size), ctypes.byref(n)))
+        return out[:n.value]
+
+    def set_global_ranking(self, n):
+        self._check(self.lib.dmnd_set_global_ranking(self.h, int(n)))
 
     def set_max_hsps(self, n):
         """--max-hsps: HSPs reported per target (default 1; 0 = all). The records of a target then follow each other."""
