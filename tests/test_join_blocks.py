@@ -29,6 +29,22 @@ def _block_records(rng, n_queries, n_blocks, targets_per_block):
     return blocks
 
 
+def _expand_runs(blocks, rng):
+    """--max-hsps: every record becomes a run of 1-4 records of its (query, target) pair; hsp.q_begin = position inside the run."""
+    multi = []
+    for b in blocks:
+        rows = []
+        for r in b:
+            n = int(rng.integers(1, 5))
+            g = np.repeat(r[None], n)
+            g["hsp"]["score"][1:] = np.sort(rng.integers(10, int(r["hsp"]["score"]) + 1, n - 1))[::-1]
+            g["evalue"][1:] = 1.0                                  # worse than any first record: must not re-rank the run
+            g["hsp"]["q_begin"] = np.arange(n)
+            rows.append(g)
+        multi.append(np.concatenate(rows) if rows else np.zeros(0, hip.MATCH_DTYPE))
+    return multi
+
+
 def test_join_blocks_equals_reference_heap_merge():
     rng = np.random.default_rng(11)
     for n_blocks, k in ((1, 25), (2, 25), (5, 25), (7, 3), (4, 100)):
@@ -85,17 +101,7 @@ def test_hsp_records_of_a_target_move_through_the_join_together():
     against -k (the heap rule JoinRecord::same_subject_, output/join_blocks.cpp:129-137,180-206)."""
     rng = np.random.default_rng(13)
     blocks = _block_records(rng, 50, 4, 400)
-    multi = []
-    for b in blocks:
-        rows = []
-        for r in b:
-            n = int(rng.integers(1, 5))
-            g = np.repeat(r[None], n)
-            g["hsp"]["score"][1:] = np.sort(rng.integers(10, int(r["hsp"]["score"]) + 1, n - 1))[::-1]
-            g["evalue"][1:] = 1.0                                  # worse than any first record: must not re-rank the run
-            g["hsp"]["q_begin"] = np.arange(n)                     # position inside the run
-            rows.append(g)
-        multi.append(np.concatenate(rows) if rows else np.zeros(0, hip.MATCH_DTYPE))
+    multi = _expand_runs(blocks, rng)
     for k in (25, 2):
         got = hip.join_blocks(np.concatenate(multi[::-1]), k)
         want = hip.join_blocks(np.concatenate(blocks[::-1]), k)      # the same join on the first records alone

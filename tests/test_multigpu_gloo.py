@@ -28,9 +28,11 @@ def _init(rank, world, port):
 def _shard_worker(rank, world, port, case, ret):
     _init(rank, world, port)
     from diamond_amd import multigpu
-    from test_join_blocks import _block_records
+    from test_join_blocks import _block_records, _expand_runs
     nq, n_blocks, tpb, k = case
     blocks = _block_records(np.random.default_rng(5), nq, n_blocks, tpb)        # every rank draws the same set ...
+    if case == CASES[4]:
+        blocks = _expand_runs(blocks, np.random.default_rng(6))                   # --max-hsps: runs of records per (query, target)
     mine = [blocks[b] for b in range(rank, n_blocks, world)]                      # ... and keeps blocks rank, rank + world, ...
     if case == CASES[2] and rank == 1:
         mine = []                                                                 # a rank whose shard produced no alignment
@@ -44,19 +46,21 @@ def _shard_worker(rank, world, port, case, ret):
 
 
 #          queries, blocks, targets per block, k
-CASES = [(41, 2, 300, 25), (40, 5, 200, 25), (33, 2, 300, 25), (1, 2, 300, 3)]
+CASES = [(41, 2, 300, 25), (40, 5, 200, 25), (33, 2, 300, 25), (1, 2, 300, 3), (37, 4, 250, 5)]
 
 
 def _run_case(ci, world, port):
     from diamond_amd import hip
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from test_join_blocks import _block_records
+    from test_join_blocks import _block_records, _expand_runs
     case = CASES[ci]
     nq, n_blocks, tpb, k = case
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_shard_worker, args=(world, port, case, ret), nprocs=world, join=True)
     blocks = _block_records(np.random.default_rng(5), nq, n_blocks, tpb)
+    if ci == 4:
+        blocks = _expand_runs(blocks, np.random.default_rng(6))
     if ci == 2:
         blocks = [b for i, b in enumerate(blocks) if i % world != 1]
     want = hip.join_blocks(np.concatenate(blocks), k)
@@ -77,6 +81,12 @@ def test_three_ranks_five_blocks():
 def test_rank_without_records_and_fewer_queries_than_ranks():
     _run_case(2, 2, 29523)
     _run_case(3, 2, 29525)                                               # one query: rank 1's range is empty
+
+
+def test_hsp_runs_stay_together_over_the_ranks():
+    """--max-hsps: the records of a (query, target) pair travel as one run through the all-to-all and the per-rank join."""
+    want = _run_case(4, 2, 29529)
+    assert (want["hsp"]["q_begin"] > 0).sum() > 100
 
 
 def _gather_worker(rank, world, port, ret):
