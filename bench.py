@@ -370,14 +370,16 @@ def main():
         """What happens to a batch's records: database blocks are joined as the reference joins reference blocks -- the blocks of
         this rank with the other ranks' over RCCL."""
         if world > 1 and args.shard == "db" or NB > 1:
-            mine = []
+            # one copy of the records (the concatenation); block ids -> database ordinals in place
+            mine = np.concatenate([np.ascontiguousarray(m, dtype=hip.MATCH_DTYPE) for m in parts])
+            at = 0
             for b, m in enumerate(parts):
-                r = np.ascontiguousarray(m, dtype=hip.MATCH_DTYPE).copy()
-                r["target"] += np.uint32(w.blocks[b][0])
-                mine.append(r)
+                mine["target"][at:at + len(m)] += np.uint32(w.blocks[b][0])
+                at += len(m)
             # SURVEY 8(e).2: all-to-all keyed by query range, rank g joins queries [g Q/G, (g+1) Q/G), one gather to rank 0
-            part, full = multigpu.query_range_join(np.concatenate(mine), w.n_queries, coll_device)
-            state["joined_queries"] = int(np.unique(part["query"]).size)
+            part, full = multigpu.query_range_join(mine, w.n_queries, coll_device, own=True)
+            q = part["query"]
+            state["joined_queries"] = int((q[1:] != q[:-1]).sum() + 1) if q.size else 0      # (the join returns query order)
             return full if rank == 0 else part
         return parts[0]
 

@@ -359,11 +359,14 @@ def auto_query_indexed(p, qdata, qlimits, db_bytes):
     return bool(out.value)
 
 
-def join_blocks(records, max_target_seqs=25):
+def join_blocks(records, max_target_seqs=25, copy=True):
     """Merge of one query block's records against several reference blocks (dmnd_join_blocks: join_query of the reference):
-    `records` = concatenation of the per-block MATCH_DTYPE arrays with database-wide target ordinals."""
+    `records` = concatenation of the per-block MATCH_DTYPE arrays with database-wide target ordinals. copy=False: the caller's
+    array is reordered in place (it must be a contiguous MATCH_DTYPE array the caller owns)."""
     lib = load()
-    r = np.ascontiguousarray(records, dtype=MATCH_DTYPE).copy()
+    r = np.ascontiguousarray(records, dtype=MATCH_DTYPE)
+    if copy or r is not records or not r.flags["WRITEABLE"]:
+        r = r.copy()
     n = ctypes.c_int64(0)
     lib.dmnd_join_blocks.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_int64)]
     if lib.dmnd_join_blocks(r.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(r.size), int(max_target_seqs), ctypes.byref(n)) != 0:
