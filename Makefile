@@ -24,8 +24,15 @@ build/%.o: $(CSRC)/%.hip $(HIPHDR)
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 
-diamond_amd/libdiamond_hip.so: $(HIPOBJ)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIPOBJ)
+# host-only double-precision code whose results must be bit-identical to the reference's (composition-based matrix adjustment):
+# plain g++, no contraction of a * b + c into fused multiply-adds
+HOSTOBJ := build/cbs_adjust.o
+build/cbs_adjust.o: $(CSRC)/cbs_adjust.cpp $(HIPHDR)
+	@mkdir -p build
+	g++ -O2 -std=c++17 -ffp-contract=off -fPIC -Wall -c -o $@ $<
+
+diamond_amd/libdiamond_hip.so: $(HIPOBJ) $(HOSTOBJ)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIPOBJ) $(HOSTOBJ)
 
 # the CLI (makedb / blastp) over the C ABI; finds the library next to itself
 diamond_amd/diamond-hip: $(CSRC)/cli.cpp include/diamond_hip.h diamond_amd/libdiamond_hip.so

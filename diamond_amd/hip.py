@@ -71,7 +71,8 @@ EXPORTS = ["dmnd_abi_version", "dmnd_last_error", "dmnd_default_params", "dmnd_c
            "dmnd_seed_params_set_index_chunks", "dmnd_join_blocks", "dmnd_set_sensitivity", "dmnd_touch_streams",
            "dmnd_seed_params_set_query_indexed", "dmnd_auto_query_indexed", "dmnd_set_motif_table", "dmnd_motif_table_size",
            "dmnd_soft_mask_block", "dmnd_output_fields", "dmnd_format_fields", "dmnd_format_pairwise_intro", "dmnd_format_pairwise",
-           "dmnd_format_paf", "dmnd_device_count", "dmnd_set_top_percent", "dmnd_join_blocks_top", "dmnd_set_filters", "dmnd_format_sam", "dmnd_set_query_source_lengths", "dmnd_format_fields_unaligned", "dmnd_format_fields_header", "dmnd_set_query_index_reuse", "dmnd_set_no_self_hits", "dmnd_matrix_params", "dmnd_masking_lambda", "dmnd_translate_opts", "dmnd_set_extension_mode", "dmnd_format_xml_header", "dmnd_format_xml_query_intro", "dmnd_format_xml", "dmnd_format_xml_query_epilog", "dmnd_format_daa_header", "dmnd_format_daa_query", "dmnd_format_daa_match", "dmnd_seg_ranges", "dmnd_seg_mask_block", "dmnd_seg_lnfact", "dmnd_daa_match_read", "dmnd_hsp_from_transcript", "dmnd_set_format_flags", "dmnd_host_alloc", "dmnd_host_free", "dmnd_share_block", "dmnd_init", "dmnd_seed_reserve", "dmnd_mask_sequences", "dmnd_set_max_hsps", "dmnd_rank_targets", "dmnd_rank_update", "dmnd_set_global_ranking"]
+           "dmnd_format_paf", "dmnd_device_count", "dmnd_set_top_percent", "dmnd_join_blocks_top", "dmnd_set_filters", "dmnd_format_sam", "dmnd_set_query_source_lengths", "dmnd_format_fields_unaligned", "dmnd_format_fields_header", "dmnd_set_query_index_reuse", "dmnd_set_no_self_hits", "dmnd_matrix_params", "dmnd_masking_lambda", "dmnd_translate_opts", "dmnd_set_extension_mode", "dmnd_format_xml_header", "dmnd_format_xml_query_intro", "dmnd_format_xml", "dmnd_format_xml_query_epilog", "dmnd_format_daa_header", "dmnd_format_daa_query", "dmnd_format_daa_match", "dmnd_seg_ranges", "dmnd_seg_mask_block", "dmnd_seg_lnfact", "dmnd_daa_match_read", "dmnd_hsp_from_transcript", "dmnd_set_format_flags", "dmnd_host_alloc", "dmnd_host_free", "dmnd_share_block", "dmnd_init", "dmnd_seed_reserve", "dmnd_mask_sequences", "dmnd_set_max_hsps", "dmnd_rank_targets", "dmnd_rank_update", "dmnd_set_global_ranking",
+           "dmnd_cbs_composition", "dmnd_cbs_rule", "dmnd_cbs_target_matrix", "dmnd_cbs_ideal_lambda"]
 
 
 def set_motif_table(codes):
@@ -142,8 +143,42 @@ def load():
         lib.dmnd_masking_lambda.argtypes = [ctypes.c_void_p]
         lib.dmnd_translate.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
         lib.dmnd_last_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+        lib.dmnd_cbs_ideal_lambda.restype = ctypes.c_double
+        lib.dmnd_cbs_ideal_lambda.argtypes = [ctypes.POINTER(Params)]
+        lib.dmnd_cbs_composition.argtypes = [v, ctypes.c_int32, v, ctypes.POINTER(ctypes.c_int32)]
+        lib.dmnd_cbs_rule.argtypes = [ctypes.POINTER(Params), ctypes.c_int, v, ctypes.c_int32, v, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32)]
+        lib.dmnd_cbs_target_matrix.argtypes = [ctypes.POINTER(Params), ctypes.c_int, v, ctypes.c_int32, v, ctypes.c_int32, v]
         _lib = lib
     return _lib
+
+
+def cbs_composition(seq):
+    """Stats::composition + count_true_aa (stats/cbs.cpp:52-77) -> (frequencies[20], residues)."""
+    seq = np.ascontiguousarray(seq, dtype=np.int8)
+    comp, n = np.zeros(20, np.float64), ctypes.c_int32(0)
+    rc = load().dmnd_cbs_composition(seq.ctypes.data, len(seq), comp.ctypes.data, ctypes.byref(n))
+    if rc != 0:
+        raise DiamondHipError("dmnd_cbs_composition: %d" % rc)
+    return comp, n.value
+
+
+def cbs_rule(params, mode, query_comp, query_true_aa, target):
+    """Stats::adjust_matrix (stats/cbs.cpp:94-112) -> -1 / 0 / 4."""
+    qc, t, r = np.ascontiguousarray(query_comp, dtype=np.float64), np.ascontiguousarray(target, dtype=np.int8), ctypes.c_int32(99)
+    rc = load().dmnd_cbs_rule(ctypes.byref(params), int(mode), qc.ctypes.data, int(query_true_aa), t.ctypes.data, len(t), ctypes.byref(r))
+    if rc != 0:
+        raise DiamondHipError("dmnd_cbs_rule: %d" % rc)
+    return r.value
+
+
+def cbs_target_matrix(params, rule, query_comp, query_true_aa, target):
+    """Stats::TargetMatrix::TargetMatrix (stats/cbs.cpp:114-173) -> int8[32, 32], [target letter][query letter]."""
+    qc, t = np.ascontiguousarray(query_comp, dtype=np.float64), np.ascontiguousarray(target, dtype=np.int8)
+    out = np.zeros((32, 32), np.int8)
+    rc = load().dmnd_cbs_target_matrix(ctypes.byref(params), int(rule), qc.ctypes.data, int(query_true_aa), t.ctypes.data, len(t), out.ctypes.data)
+    if rc != 0:
+        raise DiamondHipError("dmnd_cbs_target_matrix: %d" % rc)
+    return out
 
 
 def default_params():

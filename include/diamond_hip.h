@@ -374,9 +374,27 @@ int dmnd_set_motif_table(const uint64_t* codes, int64_t n);
 int64_t dmnd_motif_table_size(void);
 int dmnd_soft_mask_block(dmnd_ctx* ctx, int which, int64_t* n_covered);
 
-/* --comp-based-stats: 1 = Hauser composition bias (default; HauserCorrection, stats/hauser_correction.cpp), 0 = none.
- * The matrix-adjust modes 2-4 (stats/cbs.cpp) are not implemented. */
+/* --comp-based-stats (Stats::CBS, stats/cbs.h:112-196): 0 = none; 1 = Hauser composition bias (default; HauserCorrection,
+ * stats/hauser_correction.cpp); 2 / 3 = Hauser bias, and a composition-adjusted scoring matrix for every target that NCBI's
+ * conditional test selects; 4 = no bias, every target gets an adjusted matrix; 5 = no bias, every target gets either the full
+ * adjustment or the standard matrix rescaled to the pair's lambda. An adjusted target is swept with ITS matrix and without
+ * the bias (dp/swipe/target_iterator.h:124-134, swipe.h:43-54); seed stage, gapped filter, x-drop stage and chaining keep the
+ * standard matrix. Modes above 1 need one of the eight standard matrices (basic/config.cpp:837) and untranslated queries
+ * (config.cpp:700): DMND_E_ARG otherwise, from dmnd_extend. */
 int dmnd_set_comp_based_stats(dmnd_ctx* ctx, int mode);
+/* Composition-based matrix adjustment of one (query, target) pair on the host (double precision, no device): what
+ * WorkTarget::WorkTarget computes per target (align/ungapped.cpp:44-58). dmnd_extend calls the same code for every target it
+ * plans; the entry points exist so that a caller -- and the CPU tests -- can reproduce a single matrix.
+ *   dmnd_cbs_composition   Stats::composition + count_true_aa (stats/cbs.cpp:52-77): frequencies of the 20 residues
+ *   dmnd_cbs_rule          Stats::adjust_matrix (cbs.cpp:94-112): *rule = -1 (keep the standard matrix), 0 (rescale it to the
+ *                          pair's lambda, mode 5 only) or 4 (relative-entropy adjustment); query_true_aa = residues of the query
+ *   dmnd_cbs_target_matrix Stats::TargetMatrix::TargetMatrix (cbs.cpp:114-173): matrix_out[target letter * 32 + query letter],
+ *                          32 x 32 int8 (rows / columns above letter 25 at -128), for rule 0 or 4
+ *   dmnd_cbs_ideal_lambda  ScoreMatrix::ideal_lambda (score_matrix.cpp:61): < 0 if params does not hold a standard matrix */
+int dmnd_cbs_composition(const int8_t* seq, int32_t len, double* comp20, int32_t* true_aa);
+int dmnd_cbs_rule(const dmnd_params* params, int mode, const double* query_comp20, int32_t query_true_aa, const int8_t* target, int32_t target_len, int32_t* rule);
+int dmnd_cbs_target_matrix(const dmnd_params* params, int rule, const double* query_comp20, int32_t query_true_aa, const int8_t* target, int32_t target_len, int8_t* matrix_out);
+double dmnd_cbs_ideal_lambda(const dmnd_params* params);
 /* The part of the sensitivity that the extension stage reads: the band widths around a chain (Extension::Mode::BANDED_FAST up to
  * --sensitive, BANDED_SLOW from --more-sensitive up: src/align/extend.cpp:62-75, gapped_score.cpp:41-73), and ranking_chunk_size's
  * unit of reference-block letters (2e9, or 8e8 from --very-sensitive up: extend.cpp:79-92). */

@@ -14,6 +14,8 @@
 //   magic 'SWP1' | flags | hsp_values | frame | query_source_len | qlen | has_cbs
 //   | query[qlen] (int8, raw letters incl. mask bit) | cbs[qlen] (int8, if has_cbs)
 //   | n_targets | n_targets x { bin, target_idx, d_begin, d_end, cols, true_target_len, tlen, seq[tlen] }
+//     ($DIAMOND_TAP_MATRICES set: magic 'SWP2' and every target is followed by has_matrix | int8 scores[32*26] if has_matrix:
+//      the target's composition-adjusted matrix, DpTarget::matrix, --comp-based-stats 2..5)
 //   | n_hsps   | n_hsps x { swipe_target, swipe_bin, score, frame, d_begin, d_end,
 //                           q_begin, q_end, s_begin, s_end, length, identities, mismatches,
 //                           positives, gap_openings, gaps, backtraced, f64 evalue, f64 bit_score,
@@ -91,8 +93,9 @@ std::list<Hsp> wrap_swipe(const DP::Targets& targets, DP::Params& params)
 	}
 	Buf b;
 	FILE* f = tap_file();
+	static const bool with_matrices = getenv("DIAMOND_TAP_MATRICES") != nullptr;      // 'SWP2': every DpTarget followed by its adjusted matrix
 	if (f) {
-		b.i32(0x31505753);
+		b.i32(with_matrices ? 0x32505753 : 0x31505753);
 		b.i32((int32_t)params.flags);
 		b.i32((int32_t)params.v);
 		b.i32(params.frame.index());
@@ -117,6 +120,10 @@ std::list<Hsp> wrap_swipe(const DP::Targets& targets, DP::Params& params)
 				b.i32(t.true_target_len);
 				b.i32(t.seq.length());
 				b.bytes(t.seq.data(), t.seq.length());
+				if (with_matrices) {
+					b.i32(t.adjusted_matrix() ? 1 : 0);
+					if (t.adjusted_matrix()) b.bytes(t.matrix->scores.data(), 32 * AMINO_ACID_COUNT);
+				}
 			}
 	}
 	std::list<Hsp> out = real_swipe(targets, params);
@@ -357,4 +364,73 @@ Mask::Ranges wrap_tantan(Letter* seq, int len, const float** lr, float p_repeat,
 	fwrite(b.d.data(), 1, b.d.size(), f);
 	fflush(f);
 	return r;
+}
+
+// ---- fifth seam: composition-based matrix adjustment (--comp-based-stats 2..5). Two wrapped symbols, both defined in
+// stats/cbs.cpp and called per (query, target) from WorkTarget::WorkTarget (align/ungapped.cpp:44-58):
+//   Stats::adjust_matrix (cbs.cpp:94-112)            -> which rule, or eDontAdjustMatrix
+//   Stats::TargetMatrix::TargetMatrix (cbs.cpp:114-173) -> the target's 32 x 26 int8 score table
+// $DIAMOND_TAP_CBS=file. Header 'CBH1' once: cbs mode | cbs_matrix_scale | f64 ideal_lambda | f64 ungapped_lambda | f64 cbs_angle
+//   | f64 joint_probs[400] | f64 background[20] | int8 matrix8[32*32]
+// then 'ADJ1': f64 query_comp[20] | query_len | cbs | tlen | target[tlen] | rule
+// and  'TMX1': f64 query_comp[20] | query_len | cbs | rule | tlen | target[tlen] | int8 scores[32*26] | score_min | score_max
+#include "stats/cbs.h"
+#define ADJ_SYM "_ZN5Stats13adjust_matrixERKSt5arrayIdLm20EEijRK8Sequence"
+#define TMX_SYM "_ZN5Stats12TargetMatrixC1ERKSt5arrayIdLm20EEijRK8SequenceR10StatisticsRNSt3pmr25monotonic_buffer_resourceENS_17EMatrixAdjustRuleE"
+namespace {
+std::mutex cbs_mtx;
+FILE* cbs_file() {
+	static FILE* f = getenv("DIAMOND_TAP_CBS") ? fopen(getenv("DIAMOND_TAP_CBS"), "wb") : nullptr;
+	return f;
+}
+std::atomic<int64_t> cbs_budget(getenv("DIAMOND_TAP_CBS_MAX") ? atoll(getenv("DIAMOND_TAP_CBS_MAX")) : (int64_t)1 << 62);
+void cbs_write(const Buf& b) {
+	FILE* f = cbs_file();
+	std::lock_guard<std::mutex> lock(cbs_mtx);
+	static bool header = false;
+	if (!header) {
+		header = true;
+		Buf h;
+		h.i32(0x31484243); h.i32((int32_t)config.comp_based_stats); h.i32((int32_t)config.cbs_matrix_scale);
+		h.f64(score_matrix.ideal_lambda()); h.f64(score_matrix.ungapped_lambda()); h.f64(Stats::comp_based_stats.angle);
+		h.bytes(score_matrix.joint_probs(), 400 * sizeof(double));
+		h.bytes(score_matrix.background_freqs(), 20 * sizeof(double));
+		h.bytes(score_matrix.matrix8(), 32 * 32);
+		fwrite(h.d.data(), 1, h.d.size(), f);
+	}
+	fwrite(b.d.data(), 1, b.d.size(), f);
+	fflush(f);
+}
+}
+Stats::EMatrixAdjustRule real_adjust(const Stats::Composition& query_comp, int query_len, unsigned cbs, const Sequence& target) asm("__real_" ADJ_SYM);
+Stats::EMatrixAdjustRule wrap_adjust(const Stats::Composition& query_comp, int query_len, unsigned cbs, const Sequence& target) asm("__wrap_" ADJ_SYM);
+Stats::EMatrixAdjustRule wrap_adjust(const Stats::Composition& query_comp, int query_len, unsigned cbs, const Sequence& target)
+{
+	const Stats::EMatrixAdjustRule r = real_adjust(query_comp, query_len, cbs, target);
+	if (cbs_file() && Stats::CBS::matrix_adjust(cbs) && cbs_budget.fetch_sub(1) > 0) {
+		Buf b;
+		b.i32(0x314a4441);
+		b.bytes(query_comp.data(), 20 * sizeof(double));
+		b.i32(query_len); b.i32((int32_t)cbs); b.i32((int32_t)target.length());
+		b.bytes(target.data(), (size_t)target.length());
+		b.i32((int32_t)r);
+		cbs_write(b);
+	}
+	return r;
+}
+void real_tmx(Stats::TargetMatrix* self, const Stats::Composition& query_comp, int query_len, unsigned cbs, const Sequence& target, Statistics& stats, std::pmr::monotonic_buffer_resource& pool, Stats::EMatrixAdjustRule rule) asm("__real_" TMX_SYM);
+void wrap_tmx(Stats::TargetMatrix* self, const Stats::Composition& query_comp, int query_len, unsigned cbs, const Sequence& target, Statistics& stats, std::pmr::monotonic_buffer_resource& pool, Stats::EMatrixAdjustRule rule) asm("__wrap_" TMX_SYM);
+void wrap_tmx(Stats::TargetMatrix* self, const Stats::Composition& query_comp, int query_len, unsigned cbs, const Sequence& target, Statistics& stats, std::pmr::monotonic_buffer_resource& pool, Stats::EMatrixAdjustRule rule)
+{
+	real_tmx(self, query_comp, query_len, cbs, target, stats, pool, rule);
+	if (cbs_file() && cbs_budget.fetch_sub(1) > 0) {
+		Buf b;
+		b.i32(0x31584d54);
+		b.bytes(query_comp.data(), 20 * sizeof(double));
+		b.i32(query_len); b.i32((int32_t)cbs); b.i32((int32_t)rule); b.i32((int32_t)target.length());
+		b.bytes(target.data(), (size_t)target.length());
+		b.bytes(self->scores.data(), 32 * AMINO_ACID_COUNT);
+		b.i32(self->score_min); b.i32(self->score_max);
+		cbs_write(b);
+	}
 }

@@ -6,6 +6,7 @@ import numpy as np
 
 MAGIC = 0x31505753
 MAGIC_MTX = 0x3158544D
+MAGIC2 = 0x32505753          # 'SWP2': DpTargets carry their adjusted matrix
 
 HSP_FIELDS = ("swipe_target", "swipe_bin", "score", "frame", "d_begin", "d_end", "q_begin", "q_end",
               "s_begin", "s_end", "length", "identities", "mismatches", "positives", "gap_openings",
@@ -44,7 +45,7 @@ def read_tap(path, max_records=None):
                       "db_letters": f64(), "max_evalue": f64()}
             header["matrix8"] = raw(1024, np.int8).reshape(32, 32)
             continue
-        assert magic == MAGIC, "bad tap record magic at %d" % (pos - 4)
+        assert magic in (MAGIC, MAGIC2), "bad tap record magic at %d" % (pos - 4)
         rec = {"flags": i32(), "hsp_values": i32(), "frame": i32(), "query_source_len": i32()}
         qlen = i32()
         has_cbs = i32()
@@ -55,6 +56,9 @@ def read_tap(path, max_records=None):
             t = {"bin": i32(), "target_idx": i32(), "d_begin": i32(), "d_end": i32(), "cols": i32(),
                  "true_target_len": i32()}
             t["seq"] = raw(i32(), np.int8)
+            t["matrix"] = None
+            if magic == MAGIC2 and i32():
+                t["matrix"] = raw(32 * 26, np.int8).reshape(26, 32)       # [target letter][query letter]
             targets.append(t)
         rec["targets"] = targets
         hsps = []
@@ -205,3 +209,36 @@ def read_tantan_tap(path, max_records=None):
         pos += 8 * nr
         recs.append(dict(mask_mode=mode, before=before, after=after, ranges=ranges))
     return hdr, recs
+
+
+def read_cbs_tap(path, max_records=None):
+    """Reader for $DIAMOND_TAP_CBS files (oracle/ref_tap.cpp, fifth seam: Stats::adjust_matrix and Stats::TargetMatrix).
+    Returns (hdr, adj, tmx): hdr = {cbs, scale, ideal_lambda, ungapped_lambda, angle, joint_probs (20x20), background (20), matrix8};
+    adj[i] = {query_comp, query_len, cbs, target, rule}; tmx[i] = {query_comp, query_len, cbs, rule, target, scores (26x32), score_min, score_max}."""
+    buf = open(path, "rb").read()
+    pos, hdr, adj, tmx = 0, None, [], []
+    while pos < len(buf) and (max_records is None or len(adj) + len(tmx) < max_records):
+        magic, = struct.unpack_from("<i", buf, pos)
+        pos += 4
+        if magic == 0x31484243:
+            cbs, scale, il, ul, angle = struct.unpack_from("<iiddd", buf, pos)
+            pos += 32
+            jp = np.frombuffer(buf, "<f8", 400, pos).reshape(20, 20).copy(); pos += 3200
+            bg = np.frombuffer(buf, "<f8", 20, pos).copy(); pos += 160
+            m8 = np.frombuffer(buf, np.int8, 1024, pos).reshape(32, 32).copy(); pos += 1024
+            hdr = dict(cbs=cbs, scale=scale, ideal_lambda=il, ungapped_lambda=ul, angle=angle, joint_probs=jp, background=bg, matrix8=m8)
+            continue
+        comp = np.frombuffer(buf, "<f8", 20, pos).copy(); pos += 160
+        if magic == 0x314a4441:
+            qlen, cbs, tlen = struct.unpack_from("<iii", buf, pos); pos += 12
+            t = np.frombuffer(buf, np.int8, tlen, pos).copy(); pos += tlen
+            rule, = struct.unpack_from("<i", buf, pos); pos += 4
+            adj.append(dict(query_comp=comp, query_len=qlen, cbs=cbs, target=t, rule=rule))
+        else:
+            assert magic == 0x31584d54, hex(magic)
+            qlen, cbs, rule, tlen = struct.unpack_from("<iiii", buf, pos); pos += 16
+            t = np.frombuffer(buf, np.int8, tlen, pos).copy(); pos += tlen
+            sc = np.frombuffer(buf, np.int8, 32 * 26, pos).reshape(26, 32).copy(); pos += 32 * 26
+            smin, smax = struct.unpack_from("<ii", buf, pos); pos += 8
+            tmx.append(dict(query_comp=comp, query_len=qlen, cbs=cbs, rule=rule, target=t, scores=sc, score_min=smin, score_max=smax))
+    return hdr, adj, tmx
