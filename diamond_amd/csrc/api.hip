@@ -247,7 +247,7 @@ extern "C" void dmnd_destroy(dmnd_ctx* c)
 	for (DevBuf* b : { &c->block[0], &c->block[1], &c->cbs, &c->matrix, &c->bias_ids, &c->items, &c->order, &c->p_of_slot, &c->trace_off,
 		&c->transcript_off, &c->ends, &c->hsps, &c->trace, &c->transcript, &c->status, &c->pairs, &c->trace_off_item, &c->host_q, &c->host_t, &c->host_cbs,
 		&c->d_limits[0], &c->d_limits[1], &c->qid_of, &c->mask_time, &c->seed_keys, &c->seed_next, &c->seed_qlist, &c->seed_qkeys, &c->seed_slot2, &c->seed_loc2, &c->seed_survivors, &c->seed_scored, &c->seed_need, &c->seed_qfold,
-		&c->matched_slot, &c->matched_loc, &c->counters, &c->seed_hits, &c->seed_bitmap, &c->seed_deferred, &c->seed_eslot, &c->seed_eloc, &c->seed_hits_sorted, &c->sort_keys[0], &c->sort_keys[1], &c->sort_idx[0], &c->sort_idx[1], &c->gf_tables, &c->gf_hits, &c->gf_flags, &c->gf_scores, &c->gf_units, &c->alt_targets, &c->mask_lr, &c->mask_pb, &c->mask_scale, &c->mask_pos, &c->mask_ids, &c->mask_soff, &c->soft[0], &c->soft[1], &c->motif_hit, &c->motif_table })
+		&c->matched_slot, &c->matched_loc, &c->counters, &c->seed_hits, &c->seed_bitmap, &c->seed_deferred, &c->seed_eslot, &c->seed_eloc, &c->seed_hits_sorted, &c->sort_keys[0], &c->sort_keys[1], &c->sort_idx[0], &c->sort_idx[1], &c->gf_tables, &c->gf_hits, &c->gf_flags, &c->gf_scores, &c->gf_units, &c->alt_targets, &c->mask_lr, &c->mask_pb, &c->mask_scale, &c->mask_pos, &c->mask_ids, &c->mask_soff, &c->soft[0], &c->soft[1], &c->motif_hit, &c->motif_table, &c->adj_matrices })
 		b->release();
 	if (c->ev0) (void)hipEventDestroy(c->ev0);
 	if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -474,9 +474,15 @@ struct Bases {
 	const int8_t* q; int64_t q_len;
 	const int8_t* t; int64_t t_len;
 	const int8_t* cbs; int64_t cbs_len;
+	const int8_t* matrices = nullptr; int64_t n_matrices = 0;      // adjusted matrices of the work context (dmnd_upload_matrices)
 };
 
+// P: band class, + ADJ_CLASS for an item that is scored with an adjusted matrix of its own (a launch class of its own: those
+// items go to the 32-bit kernels, which stage one matrix per wavefront)
+enum { ADJ_CLASS = 1 << 20 };
 struct Slot { int32_t item; int32_t P; int64_t steps; };
+inline int band_p(const Slot& s) { return s.P & (ADJ_CLASS - 1); }
+inline bool own_matrix(const Slot& s) { return (s.P & ADJ_CLASS) != 0; }
 
 // DMND_SWIPE32=1: every sweep in the 32-bit kernels (A/B runs; the packed 16-bit kernels are the default for band classes
 // up to SW16_MAX_P)
@@ -498,7 +504,7 @@ void plan_sweeps(const std::vector<Slot>& slots, int kmode, bool force32, std::v
 	for (int64_t s0 = 0; s0 < n;) {
 		int64_t s1 = s0, max_steps = 0;
 		while (s1 < n && slots[(size_t)s1].P == slots[(size_t)s0].P) { max_steps = std::max(max_steps, slots[(size_t)s1].steps); ++s1; }
-		const bool k16 = !force32 && !force_swipe32() && kmode <= K_TRACE && slots[(size_t)s0].P <= SW16_MAX_P && max_steps <= 2 * (int64_t)SW16_MAX_PAIRS;
+		const bool k16 = !force32 && !force_swipe32() && kmode <= K_TRACE && !own_matrix(slots[(size_t)s0]) && slots[(size_t)s0].P <= SW16_MAX_P && max_steps <= 2 * (int64_t)SW16_MAX_PAIRS;
 		launches.push_back(SweepLaunch{ s0, s1, k16, (int64_t)pairs.size() / 2 });
 		if (k16)
 			for (int64_t s = s0; s < s1; s += 2) {
@@ -515,7 +521,7 @@ int issue_sweeps(dmnd_ctx* work, const Bases& b, const dmnd_dp_target* d_items, 
 {
 	const bool trace = kmode == K_TRACE;
 	for (const SweepLaunch& l : launches) {
-		const int P = slots[(size_t)l.s0].P;
+		const int P = band_p(slots[(size_t)l.s0]);
 		if (l.k16) {
 			Swipe16Args a;
 			a.qblock = b.q; a.tblock = b.t; a.cbs = b.cbs; a.matrix = work->matrix.as<int8_t>();
@@ -530,7 +536,7 @@ int issue_sweeps(dmnd_ctx* work, const Bases& b, const dmnd_dp_target* d_items, 
 		}
 		else {
 			SwipeArgs a;
-			a.qblock = b.q; a.tblock = b.t; a.cbs = b.cbs; a.matrix = work->matrix.as<int8_t>();
+			a.qblock = b.q; a.tblock = b.t; a.cbs = b.cbs; a.matrix = work->matrix.as<int8_t>(); a.matrices = b.matrices;
 			a.items = d_items;
 			a.order = order_dev + l.s0;
 			a.trace_off = trace ? trace_off_slot_dev + l.s0 : nullptr;
@@ -577,9 +583,9 @@ void order_slots(std::vector<Slot>& v, std::vector<Slot>& tmp, std::vector<uint3
 		return;
 	}
 	const int NB = 1024;
-	count.assign((size_t)16 * NB + 1, 0);
-	auto cls = [](int P) { int c = 0; while ((1 << c) < P) ++c; return c; };      // P = 1, 2, 4, ... 512
-	auto bucket = [&](const Slot& x) { return (size_t)cls(x.P) * NB + (size_t)(NB - 1 - std::min<int64_t>(x.steps >> 4, NB - 1)); };
+	count.assign((size_t)32 * NB + 1, 0);
+	auto cls = [](const Slot& x) { int c = 0; while ((1 << c) < band_p(x)) ++c; return c + (own_matrix(x) ? 16 : 0); };      // P = 1, 2, 4, ... 512; then the same with own matrices
+	auto bucket = [&](const Slot& x) { return (size_t)cls(x) * NB + (size_t)(NB - 1 - std::min<int64_t>(x.steps >> 4, NB - 1)); };
 	for (const Slot& x : v) ++count[bucket(x) + 1];
 	for (size_t i = 1; i < count.size(); ++i) count[i] += count[i - 1];
 	tmp.resize(v.size());
@@ -598,11 +604,11 @@ int run_chunk(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, int64_t 
 	std::vector<int64_t> trace_off(n + 1, 0), tr_off(n + 1, 0);
 	for (int64_t s = 0; s < n; ++s) {
 		order[s] = slots[s].item;
-		p_of[s] = slots[s].P;
+		p_of[s] = band_p(slots[s]);
 		if (trace) {
 			const dmnd_dp_target& it = items[slots[s].item];
 			const Geom g = make_geom(it.query_len, it.target_len, it.d_begin, it.d_end);
-			trace_off[s + 1] = trace_off[s] + trace_bytes(g, slots[s].P);
+			trace_off[s + 1] = trace_off[s] + trace_bytes(g, band_p(slots[s]));
 			tr_off[s + 1] = tr_off[s] + (int64_t)it.query_len + it.target_len + 2;
 		}
 	}
@@ -628,7 +634,7 @@ int run_chunk(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, int64_t 
 	HIP_TRY(hipEventRecord(c->ev1, c->stream));
 	if (trace) {
 		TracebackArgs t;
-		t.qblock = b.q; t.tblock = b.t; t.cbs = b.cbs; t.matrix = c->matrix.as<int8_t>();
+		t.qblock = b.q; t.tblock = b.t; t.cbs = b.cbs; t.matrix = c->matrix.as<int8_t>(); t.matrices = b.matrices;
 		t.items = d_items; t.order = c->order.as<int32_t>(); t.p_of_slot = c->p_of_slot.as<int32_t>();
 		t.trace_off = c->trace_off.as<int64_t>(); t.transcript_off = c->transcript_off.as<int64_t>();
 		t.trace = c->trace.as<uint8_t>(); t.transcript = chunk_transcripts ? c->transcript.as<uint8_t>() : nullptr;
@@ -691,12 +697,13 @@ int swipe_impl(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, int64_t
 			const int band = it.d_end - it.d_begin;
 			if (band <= 0 || it.query_len <= 0 || it.target_len <= 0 || it.query_off < 0 || it.target_off < 0
 				|| it.query_off + it.query_len > b.q_len || it.target_off + it.target_len > b.t_len
-				|| (it.cbs_off >= 0 && (!b.cbs || it.cbs_off + it.query_len > b.cbs_len))) { bad_item.store(i); slots[i] = Slot{ (int32_t)i, 1, 0 }; continue; }
+				|| (it.cbs_off >= 0 && (!b.cbs || it.cbs_off + it.query_len > b.cbs_len))
+				|| (it.cbs_off <= -2 && (own_matrix_number(it.cbs_off) >= b.n_matrices || (own_matrix_biased(it.cbs_off) && (!b.cbs || it.query_off + it.query_len > b.cbs_len))))) { bad_item.store(i); slots[i] = Slot{ (int32_t)i, 1, 0 }; continue; }
 			const int P = band_class(band);
 			// up to 32 (16 with statistics) one wavefront sweeps the item; wider bands take up to 16 wavefronts (swipe_kernels.hip)
 			if (P > 32 * 16 || (kmode == K_STATS_FWD && P > 16 * 16)) { bad_band.store(i); slots[i] = Slot{ (int32_t)i, 1, 0 }; continue; }
 			const Geom g = make_geom(it.query_len, it.target_len, it.d_begin, it.d_end);
-			slots[i] = Slot{ (int32_t)i, P, n_steps(g) };
+			slots[i] = Slot{ (int32_t)i, P | (it.cbs_off <= -2 ? (int)ADJ_CLASS : 0), n_steps(g) };
 		}
 	});
 	if (bad_item.load() >= 0) return fail(DMND_E_ARG, "dmnd_banded_swipe: item " + std::to_string(bad_item.load()) + " out of range");
@@ -762,7 +769,7 @@ int swipe_impl(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, int64_t
 		std::vector<Slot> rslots((size_t)m);
 		for (int64_t k = 0; k < m; ++k) {
 			const Geom g = make_geom(rev[k].query_len, rev[k].target_len, rev[k].d_begin, rev[k].d_end);
-			rslots[k] = Slot{ (int32_t)k, band_class(rev[k].d_end - rev[k].d_begin), n_steps(g) };
+			rslots[k] = Slot{ (int32_t)k, band_class(rev[k].d_end - rev[k].d_begin) | (rev[k].cbs_off <= -2 ? (int)ADJ_CLASS : 0), n_steps(g) };
 		}
 		std::sort(rslots.begin(), rslots.end(), by_class);
 		HIP_TRY(hipMemcpyAsync(c->items.p, rev.data(), m * sizeof(dmnd_dp_target), hipMemcpyHostToDevice, c->stream));
@@ -791,7 +798,7 @@ int swipe_impl(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, int64_t
 		while (c1 < n) {
 			const dmnd_dp_target& it = items[c1];
 			const Geom g = make_geom(it.query_len, it.target_len, it.d_begin, it.d_end);
-			const size_t need = (size_t)trace_bytes(g, slots[c1].P);
+			const size_t need = (size_t)trace_bytes(g, band_p(slots[c1]));
 			if (c1 > c0 && bytes + need > c->trace_arena_max) break;
 			bytes += need;
 			++c1;
@@ -849,7 +856,7 @@ int dmnd_swipe_shared(dmnd_ctx* work, const dmnd_ctx* c, const dmnd_dp_target* i
 {
 	if (!c || !work) return fail(DMND_E_ARG, "ctx is NULL");
 	const Bases b{ c->block[DMND_QUERY].as<int8_t>(), c->block_len[DMND_QUERY], c->block[DMND_TARGET].as<int8_t>(), c->block_len[DMND_TARGET],
-		c->cbs_len > 0 ? c->cbs.as<int8_t>() : nullptr, c->cbs_len };
+		c->cbs_len > 0 ? c->cbs.as<int8_t>() : nullptr, c->cbs_len, work->adj_matrices.as<int8_t>(), work->n_adj_matrices };
 	if (work != c) {                                       // scoring state of the owner, by reference
 		work->matrix.p = c->matrix.p; work->matrix.cap = c->matrix.cap; work->matrix.own = false;
 		work->params = c->params; work->evaluer = c->evaluer;
@@ -863,7 +870,8 @@ int dmnd_swipe_targets(dmnd_ctx* work, const dmnd_ctx* c, const int8_t* t, int64
 	dmnd_hsp* out, uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used)
 {
 	if (!c || !work || !t) return fail(DMND_E_ARG, "ctx is NULL");
-	const Bases b{ c->block[DMND_QUERY].as<int8_t>(), c->block_len[DMND_QUERY], t, t_len, c->cbs_len > 0 ? c->cbs.as<int8_t>() : nullptr, c->cbs_len };
+	const Bases b{ c->block[DMND_QUERY].as<int8_t>(), c->block_len[DMND_QUERY], t, t_len, c->cbs_len > 0 ? c->cbs.as<int8_t>() : nullptr, c->cbs_len,
+		work->adj_matrices.as<int8_t>(), work->n_adj_matrices };
 	if (work != c) {
 		work->matrix.p = c->matrix.p; work->matrix.cap = c->matrix.cap; work->matrix.own = false;
 		work->params = c->params; work->evaluer = c->evaluer;
@@ -877,7 +885,7 @@ int dmnd_swipe_keep(dmnd_ctx* work, const dmnd_ctx* c, const dmnd_dp_target* ite
 	if (!c || !work) return fail(DMND_E_ARG, "ctx is NULL");
 	if (n == 0) return DMND_OK;
 	const Bases b{ c->block[DMND_QUERY].as<int8_t>(), c->block_len[DMND_QUERY], c->block[DMND_TARGET].as<int8_t>(), c->block_len[DMND_TARGET],
-		c->cbs_len > 0 ? c->cbs.as<int8_t>() : nullptr, c->cbs_len };
+		c->cbs_len > 0 ? c->cbs.as<int8_t>() : nullptr, c->cbs_len, work->adj_matrices.as<int8_t>(), work->n_adj_matrices };
 	auto wall = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	const double t0 = wall();
 	// One pass over the items: geometry, class, trace rows, range checks. Past the trace budget (or with an item the traceback
@@ -893,10 +901,10 @@ int dmnd_swipe_keep(dmnd_ctx* work, const dmnd_ctx* c, const dmnd_dp_target* ite
 		const int band = it.d_end - it.d_begin;
 		if (band <= 0 || it.query_len <= 0 || it.target_len <= 0 || band_class(band) > 32) { usable = false; break; }
 		in_range &= !(it.query_off < 0 || it.target_off < 0 || it.query_off + it.query_len > b.q_len || it.target_off + it.target_len > b.t_len
-			|| (it.cbs_off >= 0 && (!b.cbs || it.cbs_off + it.query_len > b.cbs_len)));
+			|| (it.cbs_off >= 0 && (!b.cbs || it.cbs_off + it.query_len > b.cbs_len)) || (it.cbs_off <= -2 && (own_matrix_number(it.cbs_off) >= b.n_matrices || (own_matrix_biased(it.cbs_off) && (!b.cbs || it.query_off + it.query_len > b.cbs_len)))));
 		const Geom g = make_geom(it.query_len, it.target_len, it.d_begin, it.d_end);
 		const int P = band_class(band);
-		slots[(size_t)i] = Slot{ (int32_t)i, P, n_steps(g) };
+		slots[(size_t)i] = Slot{ (int32_t)i, P | (it.cbs_off <= -2 ? (int)ADJ_CLASS : 0), n_steps(g) };
 		rows_of[(size_t)i] = trace_bytes(g, P);
 		total += rows_of[(size_t)i];
 	}
@@ -931,7 +939,7 @@ int dmnd_swipe_keep(dmnd_ctx* work, const dmnd_ctx* c, const dmnd_dp_target* ite
 		off_slot[s + 1] = off_slot[s] + rows_of[(size_t)item];
 		off_item[item] = off_slot[s];
 		kt.trace_off[(size_t)item] = off_slot[s];
-		kt.P[(size_t)item] = slots[(size_t)s].P;
+		kt.P[(size_t)item] = band_p(slots[(size_t)s]);
 	}
 	if (!work->h_pairs.empty()) std::memcpy(hs + o_pairs, work->h_pairs.data(), work->h_pairs.size() * sizeof(int32_t));
 	if ((int)work->keep_trace.size() <= arena) work->keep_trace.resize((size_t)arena + 1);
@@ -990,7 +998,7 @@ int dmnd_traceback_kept(dmnd_ctx* work, const dmnd_ctx* c, const dmnd_dp_target*
 	if (!c || !work || !kt.kept || kt.arena < 0 || kt.arena >= (int)work->keep_trace.size()) return fail(DMND_E_ARG, "dmnd_traceback_kept: no kept trace");
 	if (n == 0) return DMND_OK;
 	const Bases b{ c->block[DMND_QUERY].as<int8_t>(), c->block_len[DMND_QUERY], c->block[DMND_TARGET].as<int8_t>(), c->block_len[DMND_TARGET],
-		c->cbs_len > 0 ? c->cbs.as<int8_t>() : nullptr, c->cbs_len };
+		c->cbs_len > 0 ? c->cbs.as<int8_t>() : nullptr, c->cbs_len, work->adj_matrices.as<int8_t>(), work->n_adj_matrices };
 	HIP_TRY(hipSetDevice(work->device));
 	// every array the walk reads, in one page-locked buffer and one copy:
 	// [items n][end cells n][trace offsets n][transcript offsets n + 1 (all 0: no transcripts)][order n][band class n][status 1]
@@ -1021,7 +1029,7 @@ int dmnd_traceback_kept(dmnd_ctx* work, const dmnd_ctx* c, const dmnd_dp_target*
 	char* ds = work->stage_d.as<char>();
 	HIP_TRY(hipEventRecord(work->ev1, work->stream));
 	TracebackArgs t;
-	t.qblock = b.q; t.tblock = b.t; t.cbs = b.cbs; t.matrix = work->matrix.as<int8_t>();
+	t.qblock = b.q; t.tblock = b.t; t.cbs = b.cbs; t.matrix = work->matrix.as<int8_t>(); t.matrices = b.matrices;
 	t.items = reinterpret_cast<const dmnd_dp_target*>(ds + o_items); t.order = reinterpret_cast<const int32_t*>(ds + o_order);
 	t.p_of_slot = reinterpret_cast<const int32_t*>(ds + o_p);
 	t.trace_off = reinterpret_cast<const int64_t*>(ds + o_off); t.transcript_off = reinterpret_cast<const int64_t*>(ds + o_tr);
@@ -1089,6 +1097,32 @@ dmnd_ctx* aux_context(dmnd_ctx* c, int k, int split)
 	return a;
 }
 
+// Replaces (n_keep == 0) or extends the context's adjusted matrices: the first n_keep stay, `n` are appended behind them.
+int dmnd_append_matrices(dmnd_ctx* c, int64_t n_keep, const int8_t* matrices, int64_t n)
+{
+	if (n == 0 && n_keep == 0 && c) { c->n_adj_matrices = 0; return DMND_OK; }
+	if (!c || n_keep < 0 || n < 0 || n_keep > c->n_adj_matrices || (n > 0 && !matrices)) return fail(DMND_E_ARG, "dmnd_upload_matrices: bad argument");
+	HIP_TRY(hipSetDevice(c->device));
+	const size_t M = 32 * 32, need = (size_t)(n_keep + n) * M;
+	if (need > c->adj_matrices.cap) {                     // grow: the kept matrices move to the new buffer on the device
+		dmnd::DevBuf bigger;
+		if (int rc = bigger.ensure(std::max(need * 2, (size_t)64 << 10))) return rc;
+		if (n_keep > 0) HIP_TRY(hipMemcpyAsync(bigger.p, c->adj_matrices.p, (size_t)n_keep * M, hipMemcpyDeviceToDevice, c->stream));
+		HIP_TRY(sync_stream(c->stream));
+		c->adj_matrices.release();
+		c->adj_matrices = bigger;
+	}
+	if (n > 0) HIP_TRY(copy_now(c->stream, c->adj_matrices.as<int8_t>() + (size_t)n_keep * M, matrices, (size_t)n * M, hipMemcpyHostToDevice));
+	c->n_adj_matrices = n_keep + n;
+	return DMND_OK;
+}
+
+extern "C" int dmnd_upload_matrices(dmnd_ctx* c, const int8_t* matrices, int64_t n)
+{
+	if (!c) return fail(DMND_E_ARG, "ctx is NULL");
+	return dmnd_append_matrices(c, 0, matrices, n);
+}
+
 extern "C" int dmnd_banded_swipe(dmnd_ctx* c, const dmnd_dp_target* items, int64_t n, int mode, uint32_t hsp_values,
 	dmnd_hsp* out, uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used)
 {
@@ -1105,12 +1139,19 @@ extern "C" int dmnd_banded_swipe_host(dmnd_ctx* c, const int8_t* query, int32_t 
 	if (!query || query_len <= 0 || !targets || n < 0) return fail(DMND_E_ARG, "dmnd_banded_swipe_host: bad argument");
 	HIP_TRY(hipSetDevice(c->device));
 	std::vector<dmnd_dp_target> items((size_t)n);
+	std::vector<int8_t> mats;
 	int64_t total = 0;
 	for (int64_t i = 0; i < n; ++i) {
 		if (!targets[i].seq || targets[i].len <= 0) return fail(DMND_E_ARG, "dmnd_banded_swipe_host: empty target");
 		items[i] = dmnd_dp_target{ 0, total, cbs ? 0 : -1, query_len, targets[i].len, targets[i].d_begin, targets[i].d_end };
+		if (targets[i].matrix) {                          // the target's own matrix: 26 letter rows as the reference holds them, the rest never scores
+			items[i].cbs_off = -2 - (int64_t)(mats.size() / (32 * 32));
+			mats.resize(mats.size() + 32 * 32, (int8_t)-128);
+			std::memcpy(mats.data() + mats.size() - 32 * 32, targets[i].matrix, 26 * 32);
+		}
 		total += targets[i].len;
 	}
+	if (int rc = dmnd_append_matrices(c, 0, mats.data(), (int64_t)(mats.size() / (32 * 32)))) return rc;
 	std::vector<int8_t> tbuf((size_t)total);
 	for (int64_t i = 0; i < n; ++i)
 		std::memcpy(tbuf.data() + items[i].target_off, targets[i].seq, (size_t)targets[i].len);
@@ -1123,6 +1164,6 @@ extern "C" int dmnd_banded_swipe_host(dmnd_ctx* c, const int8_t* query, int32_t 
 		HIP_TRY(hipMemcpyAsync(c->host_cbs.p, cbs, (size_t)query_len, hipMemcpyHostToDevice, c->stream));
 	}
 	HIP_TRY(sync_stream(c->stream));
-	const Bases b{ c->host_q.as<int8_t>(), query_len, c->host_t.as<int8_t>(), total, cbs ? c->host_cbs.as<int8_t>() : nullptr, cbs ? query_len : 0 };
+	const Bases b{ c->host_q.as<int8_t>(), query_len, c->host_t.as<int8_t>(), total, cbs ? c->host_cbs.as<int8_t>() : nullptr, cbs ? query_len : 0, c->adj_matrices.as<int8_t>(), c->n_adj_matrices };
 	return swipe_impl(c, b, items.data(), n, mode, hsp_values, out, transcript, transcript_cap, transcript_used);
 }

@@ -552,7 +552,7 @@ Options parse(int argc, char** argv)
 		else if (a == "--gpus") { o.gpus = std::atoi(need(i).c_str()); if (o.gpus < 1) throw std::runtime_error("Invalid number of GPUs."); }
 		else if (a == "-b" || a == "--block-size") { o.block_size = std::atof(need(i).c_str()); if (o.block_size <= 0.0) throw std::runtime_error("Invalid block size."); }
 		else if (a == "-c" || a == "--index-chunks") { o.index_chunks = std::atoi(need(i).c_str()); if (o.index_chunks < 1) throw std::runtime_error("Invalid number of index chunks."); }
-		else if (a == "--comp-based-stats") { o.cbs = std::atoi(need(i).c_str()); if (o.cbs != 0 && o.cbs != 1) throw std::runtime_error("Only --comp-based-stats 0 and 1 are implemented."); }
+		else if (a == "--comp-based-stats") { o.cbs = std::atoi(need(i).c_str()); if (o.cbs < 0 || o.cbs > 5) throw std::runtime_error("Invalid value for --comp-based-stats. Permitted values: 0, 1, 2, 3, 4, 5."); }
 		else if (a == "--masking") o.masking = need(i);
 		else if (a == "--motif-masking") o.motif_masking = need(i);
 		else if (a == "--algo") {
@@ -676,6 +676,9 @@ int run_blastp(const Options& o)
 	// length-ratio cutoff inside the seed stage: run/config.cpp:156-159) -- a clustering path that is not part of this build
 	if (o.command == "blastp" && o.query_cover >= 50 && o.query_cover == o.subject_cover)
 		throw std::runtime_error("--query-cover equal to --subject-cover (>= 50) selects the reference's mutual-coverage search, which is not part of this build; use different values");
+	// basic/config.cpp:688, :700: what the matrix-adjust modes of --comp-based-stats exclude
+	if (o.cbs >= 2 && o.global_ranking > 0) throw std::runtime_error("Global ranking is not supported in this mode.");
+	if (o.cbs >= 2 && o.command == "blastx") throw std::runtime_error("This mode of composition based stats is not supported for translated searches.");
 	const auto t_all = std::chrono::steady_clock::now();
 	// the HIP runtime and the library's code object take their time to start (a quarter of a second on the MI355X boxes of this
 	// project): that runs beside reading the queries, opening the database and loading the first reference block

@@ -79,6 +79,8 @@ struct dmnd_ctx {
 	dmnd_params params;
 	dmnd::Evaluer evaluer;
 	dmnd::DevBuf block[2], cbs, matrix, bias_ids;
+	dmnd::DevBuf adj_matrices;                 // composition-adjusted scoring matrices of the items this context sweeps (dmnd_upload_matrices;
+	int64_t n_adj_matrices = 0;                // dmnd_extend: those of the targets planned so far), 32 x 32 int8 each
 	dmnd::DevBuf xd_hits, xd_out;             // device x-drop stage of dmnd_extend: the call's seed hits, one XdropSeg per hit
 	dmnd::PinBuf xd_host;
 	std::vector<int32_t> h_bias_ids;           // block sequence ids of the queries with seed hits (Hauser bias of one dmnd_extend call)
@@ -172,5 +174,7 @@ int dmnd_swipe_shared(dmnd_ctx* work, const dmnd_ctx* blocks, const dmnd_dp_targ
 	dmnd_hsp* out, uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used);
 int dmnd_swipe_targets(dmnd_ctx* work, const dmnd_ctx* blocks, const int8_t* t, int64_t t_len, const dmnd_dp_target* items, int64_t n, int mode, uint32_t hsp_values,
 	dmnd_hsp* out, uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used);
+// the first n_keep adjusted matrices of c stay, n more are appended (dmnd_upload_matrices = the same with n_keep = 0)
+int dmnd_append_matrices(dmnd_ctx* c, int64_t n_keep, const int8_t* matrices, int64_t n);
 // k-th of `split` auxiliary contexts of c (created on first use; owned and destroyed by c)
 dmnd_ctx* aux_context(dmnd_ctx* c, int k, int split);

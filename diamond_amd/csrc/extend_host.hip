@@ -24,8 +24,9 @@
 //   round-2 add_dp_targets / align          src/align/gapped_final.cpp:66-160
 //   join of reference blocks                src/output/join_blocks.cpp:129-256
 //   six-frame translation, blast tab fields src/util/sequence/translate.h, src/output/blast_tab_format.cpp
-// Scope: blastp and blastx (1 or 6 query contexts), max_hsps = 1, comp-based-stats 0 / 1, gapped filter, ranking chunks;
-// no id/coverage filters, no frameshift alignment.
+//   composition-based matrix adjustment     src/align/ungapped.cpp:44-58 -> cbs_adjust.cpp (--comp-based-stats 2 - 5)
+// Scope: blastp and blastx (1 or 6 query contexts), any max_hsps, comp-based-stats 0 - 5, gapped filter, ranking chunks,
+// id / coverage filters; no frameshift alignment.
 #include <algorithm>
 #include <array>
 #include <cfloat>
@@ -45,6 +46,8 @@
 #include "chain_graph.h"
 #include "host_pool.h"
 #include "bias_kernels.h"
+#include "cbs_adjust.h"
+#include <unordered_map>
 
 namespace dmnd {
 static thread_local int tls_pool = -1;
@@ -84,7 +87,9 @@ struct HostCfg {
 	bool ext_full = false;               // Extension::Mode::FULL (--ext full): no chaining, one full-matrix DpTarget per target and context
 	double ref_letters = 0;
 	double ranking_block_letters = 2e9;
-	bool use_cbs = true;                 // config.comp_based_stats == 1 (Hauser bias); 0 = no composition correction
+	bool use_cbs = true;                 // Stats::CBS::hauser(config.comp_based_stats): the Hauser bias of modes 1 - 3; modes 0, 4, 5 have none
+	int cbs_mode = 1;                    // config.comp_based_stats
+	const CbsModel* cbs_model = nullptr; // modes 2 - 5: what the per-target matrix adjustment reads of the scoring matrix (cbs_adjust.h)
 	int contexts = 1;                    // align_mode.query_contexts: 1 (blastp) or 6 (blastx: the block holds 6 frames per read)
 	double top = -1.0;                   // config.toppercent (--top): >= 0 = report the targets within this percentage of the best bit score
 	const Evaluer* evaluer = nullptr;    // ScoreMatrix::evalue / bitscore of the context
@@ -521,6 +526,13 @@ struct QueryState {
 	bool in_round2 = false;
 	size_t r2_pos = 0, r2_end = 0;
 	std::vector<MatchG> round;          // the round's matches so far
+	// --comp-based-stats 2 - 5 (WorkTarget::WorkTarget, ungapped.cpp:44-58): the query's composition, and per planned target the
+	// number of its adjusted matrix among the work context's (dmnd_append_matrices), -1 = the target keeps the standard matrix;
+	// values <= -2 between the two halves of a planning step: -2 - (number among the slice's new matrices)
+	double comp[20];
+	int true_aa = -1;                   // -1: composition not computed yet
+	std::unordered_map<uint32_t, int32_t> mat_of;
+	int32_t matrix_of(uint32_t target) const { const auto it = mat_of.find(target); return it == mat_of.end() ? -1 : it->second; }
 };
 
 }
@@ -558,7 +570,10 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 	auto slice_begin = [&](int t) { return nq * (size_t)t / (size_t)T; };
 	struct Ref { size_t q, k; };
 	struct KeptGroup { std::vector<dmnd_dp_target> items; std::vector<int64_t> src; std::vector<Ref> ref; };
+	struct NewMatrix { size_t q; uint32_t target; };
 	struct Slice {                       // what slice t contributes to the phase at hand
+		std::vector<int8_t> new_mats;    // adjusted matrices made in this planning step (32 x 32 each) and whose they are
+		std::vector<NewMatrix> new_refs;
 		size_t n_items = 0, item_off = 0;
 		double cells = 0;
 		bool keepable = true, any = false;
@@ -583,9 +598,19 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 	});
 	if (bias_stream) HIP_TRY(sync_stream(bias_stream));      // the Hauser bias (kernel + copy to the host) ran beside load_hits
 	lap(5, 3);
-	auto item_of = [&](uint32_t q, uint32_t t, int d0, int d1) {
-		return dmnd_dp_target{ ql[q], tl[t], h.use_cbs ? ql[q] : (int64_t)-1, (int32_t)(ql[q + 1] - ql[q] - 1), (int32_t)(tl[t + 1] - tl[t] - 1), d0, d1 };
+	// mat: number of the target's adjusted matrix (it is then swept with that matrix and without the bias), -1 = standard matrix
+	// (the reference's full-matrix sweep -- --ext full, alternative HSPs -- keeps the bias for adjusted targets: full_swipe.h:164)
+	auto matrix_code = [&](int32_t mat) { return (int64_t)-2 - mat - (h.use_cbs ? DMND_CBS_MATRIX_WITH_BIAS : (int64_t)0); };
+	auto item_of = [&](uint32_t q, uint32_t t, int d0, int d1, int32_t mat) {
+		return dmnd_dp_target{ ql[q], tl[t], mat >= 0 ? (h.ext_full ? matrix_code(mat) : (int64_t)-2 - mat) : h.use_cbs ? ql[q] : (int64_t)-1, (int32_t)(ql[q + 1] - ql[q] - 1), (int32_t)(tl[t + 1] - tl[t] - 1), d0, d1 };
 	};
+	const bool adjust = cbs_matrix_adjust(h.cbs_mode);
+	// The reference's full-matrix sweep cannot trace an alignment back on an adjusted matrix: Hsp traceback(...) of
+	// dp/swipe/full_swipe.h:97-102 throws as soon as such a target has an HSP to report (--ext full, and the alternative HSPs of
+	// --max-hsps != 1). Same refusal here, with its message.
+	std::atomic<bool> adjusted_full_traceback(false);
+	std::vector<int8_t> upload_mats;
+	w->n_adj_matrices = 0;
 	const bool full_matrix = h.ext_full;               // DP::Flags::FULL_MATRIX: DpTarget::cells = query length x target length, dp/dp.h:121-124
 	auto dp_size = [full_matrix](const dmnd_dp_target& d) {
 		return full_matrix ? (int64_t)d.query_len * (int64_t)d.target_len
@@ -619,12 +644,41 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 					s.plan.clear();
 					plan_groups(h, ws[(size_t)t], s.w, s.w.i0, s.w.i1, qdata, ql.data(), tdata, tl.data(), h.use_cbs ? cbs : nullptr, s.plan, xd);
 					me.n_items += s.plan.size();
+					if (!adjust) continue;
+					// the adjusted matrix of every target that got a DpTarget (the reference makes one for every target of the chunk,
+					// WorkTarget::WorkTarget; only the sweeps read it)
+					const uint32_t q0 = s.w.query * C;
+					if (s.true_aa < 0) cbs_composition(qdata + ql[q0], (int)(ql[q0 + 1] - ql[q0] - 1), s.comp, &s.true_aa);
+					for (const PlanTarget& p : s.plan) {
+						if (s.mat_of.count(p.target)) continue;
+						const int8_t* tseq = tdata + tl[p.target];
+						const int tlen = (int)(tl[p.target + 1] - tl[p.target] - 1);
+						const int rule = cbs_rule(*h.cbs_model, h.cbs_mode, s.comp, s.true_aa, tseq, tlen);
+						if (rule == CBS_RULE_NONE) { s.mat_of[p.target] = -1; continue; }
+						s.mat_of[p.target] = -2 - (int32_t)me.new_refs.size();
+						me.new_refs.push_back(NewMatrix{ i, p.target });
+						me.new_mats.resize(me.new_mats.size() + 32 * 32);
+						cbs_target_matrix(*h.cbs_model, rule, s.comp, s.true_aa, tseq, tlen, me.new_mats.data() + me.new_mats.size() - 32 * 32);
+					}
 				}
 			});
 			bool any = false;
 			size_t total = 0;
 			for (Slice& x : sl) { any |= x.any; x.item_off = total; total += x.n_items; }
 			if (!any) break;
+			if (adjust) {
+				// the step's new matrices get their numbers (slice order) and go to the device behind the ones already there
+				const int64_t before = w->n_adj_matrices;
+				int64_t next = before;
+				upload_mats.clear();
+				for (Slice& x : sl) {
+					for (const NewMatrix& r : x.new_refs) qs[r.q].mat_of[r.target] = (int32_t)next++;
+					upload_mats.insert(upload_mats.end(), x.new_mats.begin(), x.new_mats.end());
+					x.new_refs.clear(); x.new_mats.clear();
+				}
+				if (next > 0x7fffffff) return fail(DMND_E_CAP, "dmnd_extend: more than 2^31 adjusted matrices in one call");
+				if (next > before) { if (int rc = dmnd_append_matrices(w, before, upload_mats.data(), next - before)) return rc; }
+			}
 			items.resize(total);
 			parallel_each(T, [&](int t) {
 				Slice& me = sl[(size_t)t];
@@ -635,7 +689,7 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 					if (s.done || !s.in_inner) continue;
 					s.item_begin = o;
 					for (const PlanTarget& p : s.plan) {
-						const dmnd_dp_target d = item_of(p.query, p.target, p.d_begin, p.d_end);
+						const dmnd_dp_target d = item_of(p.query, p.target, p.d_begin, p.d_end, adjust ? s.matrix_of(p.target) : -1);
 						me.cells += cells_of(d);
 						me.keepable &= dp_size(d) <= h.max_swipe_dp;
 						items[o++] = d;
@@ -733,7 +787,7 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 				// one DpTarget per aligned target (its best band), or -- max_hsps != 1 -- one per reported band of the target
 				// (add_dp_targets, gapped_final.cpp:62-76): result slot k, or r2_slot[k - r2_pos] + band
 				auto add_item = [&](uint32_t target, int frame, int d0, int d1, int arena, int64_t item, size_t slot) {
-					const dmnd_dp_target d = item_of(s.w.query * C + (uint32_t)frame, target, d0, d1);
+					const dmnd_dp_target d = item_of(s.w.query * C + (uint32_t)frame, target, d0, d1, adjust ? s.matrix_of(target) : -1);
 					// DP::BandedSwipe::bin (swipe_wrapper.cpp:75-102): above max_swipe_dp cells the statistics cells replace the traceback,
 					// unless the output needs the transcript -- then the matrix is traced whatever its size
 					if (dp_size(d) > h.max_swipe_dp && !transcript) { me.it_st.push_back(d); me.ref_st.push_back(Ref{ i, slot }); }
@@ -828,6 +882,7 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 					const int qlen = (int)(ql[qc + 1] - ql[qc] - 1);
 					const double ev = c->evaluer.evalue(hsp.score, (unsigned)qlen, (unsigned)tlen);
 					if (!h.reported(hsp.score, ev)) return false;
+					if (adjust && h.ext_full && s.matrix_of(cd.target) >= 0 && ((int64_t)qlen * (int64_t)tlen <= h.max_swipe_dp || transcript)) adjusted_full_traceback = true;
 					m.query = q; m.target = cd.target; m.evalue = ev; m.bit_score = c->evaluer.bitscore(hsp.score);
 					m.ungapped_score = cd.ungapped; m.d_begin = d0; m.d_end = d1; m.frame = frame; m.hsp = hsp;
 					if (multi && h.ext_full) m.d_begin = m.d_end = 0;       // Hsp::d_begin of a full-matrix sweep (tie-break of Hsp::operator<)
@@ -892,6 +947,7 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 				else s.done = true;
 			}
 		});
+		if (adjusted_full_traceback) return fail(DMND_E_ARG, "Traceback with adjusted matrix not supported");
 		// recompute_alt_hsps (alt_hsp.cpp:86-142) for the queries whose round 2 is complete: every reported target is copied per
 		// context with the subject ranges of its HSPs overwritten by SUPER_HARD_MASK (letter 25, scored like the matrix minimum)
 		// and swept over the WHOLE matrix; an HSP found is added, masked, and the target goes round again until a sweep finds
@@ -938,7 +994,9 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 						if (!((a.sweep >> f) & 1u)) continue;
 						const uint32_t qc = q * C + (uint32_t)f;
 						const int qlen = (int)(ql[qc + 1] - ql[qc] - 1);
-						const dmnd_dp_target d{ ql[qc], a.off[f], h.use_cbs ? ql[qc] : (int64_t)-1, qlen, a.tlen, -(a.tlen - 1), qlen };
+						// (the alternative HSPs are searched with the match's own matrix: alt_hsp.cpp:91)
+						const int32_t mat = adjust ? qs[a.qi].matrix_of(a.target) : -1;
+						const dmnd_dp_target d{ ql[qc], a.off[f], mat >= 0 ? matrix_code(mat) : h.use_cbs ? ql[qc] : (int64_t)-1, qlen, a.tlen, -(a.tlen - 1), qlen };
 						const int k = ((int64_t)qlen * (int64_t)a.tlen > h.max_swipe_dp && !transcript) ? 1 : 0;
 						it_alt[k].push_back(d); ref_alt[k].push_back(ARef{ x, f });
 					}
@@ -966,6 +1024,7 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 						if (hsp.score <= 0) continue;
 						const double ev = c->evaluer.evalue(hsp.score, (unsigned)it_alt[k][x].query_len, (unsigned)a.tlen);
 						if (!h.reported(hsp.score, ev)) continue;
+						if (k == 0 && it_alt[k][x].cbs_off <= -2) return fail(DMND_E_ARG, "Traceback with adjusted matrix not supported");
 						if (k == 0 && transcript) hsp.transcript_off += used; else { hsp.transcript_off = -1; if (k == 1) hsp.transcript_len = 0; }
 						dmnd_match m;
 						m.query = a.hs[0].query; m.target = a.target; m.evalue = ev; m.bit_score = c->evaluer.bitscore(hsp.score);
@@ -1121,7 +1180,17 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	h.ext_full = c->ext_mode == DMND_EXT_FULL;
 	if (c->ext_mode == DMND_EXT_BANDED_FAST) h.band_mode_fast = 1; else if (c->ext_mode == DMND_EXT_BANDED_SLOW) h.band_mode_fast = 0;
 	h.contexts = c->query_contexts;
-	h.use_cbs = c->comp_based_stats != 0;
+	h.cbs_mode = c->comp_based_stats;
+	h.use_cbs = cbs_hauser(h.cbs_mode);
+	CbsModel cbs_model;
+	if (cbs_matrix_adjust(h.cbs_mode)) {
+		// basic/config.cpp:700, :837, :688
+		if (c->query_contexts != 1) return fail(DMND_E_ARG, "This mode of composition based stats is not supported for translated searches.");
+		if (h.global_ranking > 0) return fail(DMND_E_ARG, "Global ranking is not supported in this mode.");
+		cbs_model_init(cbs_model, c->params);
+		if (!cbs_model.valid) return fail(DMND_E_ARG, "This value for --comp-based-stats is not supported when using a custom scoring matrix.");
+		h.cbs_model = &cbs_model;
+	}
 	const uint32_t C = (uint32_t)h.contexts;
 	if ((ql.size() - 1) % C != 0) return fail(DMND_E_ARG, "dmnd_extend: query block size is not a multiple of the query contexts");
 	h.ref_letters = (double)(tl.back() - tl.front() - ((int64_t)tl.size() - 1));
@@ -1285,7 +1354,7 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 
 extern "C" int dmnd_set_comp_based_stats(dmnd_ctx* c, int mode)
 {
-	if (!c || (mode != 0 && mode != 1)) return fail(DMND_E_ARG, "dmnd_set_comp_based_stats: only modes 0 (off) and 1 (Hauser, the default) are implemented");
+	if (!c || mode < 0 || mode > 5) return fail(DMND_E_ARG, "Invalid value for --comp-based-stats. Permitted values: 0, 1, 2, 3, 4, 5.");
 	c->comp_based_stats = mode;
 	return DMND_OK;
 }

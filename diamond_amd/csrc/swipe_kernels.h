@@ -13,6 +13,10 @@ struct SwipeEnd {            // per item: best score, its end cell (row i, colum
 	int32_t score, end_i, end_j, stat_a, stat_b, pad[3];
 };
 
+// dmnd_dp_target::cbs_off <= -2: the item's own matrix and whether it is biased as well (diamond_hip.h)
+__host__ __device__ inline int64_t own_matrix_number(int64_t cbs_off) { return (-2 - cbs_off) & (DMND_CBS_MATRIX_WITH_BIAS - 1); }
+__host__ __device__ inline bool own_matrix_biased(int64_t cbs_off) { return cbs_off <= -2 && ((-2 - cbs_off) & DMND_CBS_MATRIX_WITH_BIAS) != 0; }
+
 // kernel variants (launch_banded_swipe's kmode)
 enum { K_SCORE = 0, K_COORDS = 1, K_TRACE = 2, K_STATS_FWD = 3, K_STATS_BWD_REV = 4 };
 
@@ -20,7 +24,9 @@ struct SwipeArgs {
 	const int8_t* qblock;        // DMND_QUERY block letters (HBM)
 	const int8_t* tblock;        // DMND_TARGET block letters (HBM)
 	const int8_t* cbs;           // concatenated composition-bias vectors or nullptr
-	const int8_t* matrix;        // 32x32 int8 (HBM; staged to LDS per workgroup)
+	const int8_t* matrix;        // 32x32 int8 (HBM; staged to LDS per wavefront)
+	const int8_t* matrices;      // composition-adjusted matrices, 32x32 int8 each (HBM): an item with cbs_off <= -2 is scored with
+	                             // number -2 - cbs_off instead of `matrix`, and without bias (dmnd_upload_matrices)
 	const dmnd_dp_target* items; // all items of the call (HBM)
 	const int32_t* order;        // slot -> item index, this launch's items (one P class)
 	const int64_t* trace_off;    // slot -> byte offset into trace (TRACEBACK only)
@@ -35,6 +41,7 @@ struct TracebackArgs {
 	const int8_t* tblock;
 	const int8_t* cbs;
 	const int8_t* matrix;
+	const int8_t* matrices;      // as in SwipeArgs
 	const dmnd_dp_target* items;
 	const int32_t* order;        // slot -> item index (all TRACEBACK slots of the chunk)
 	const int32_t* p_of_slot;    // slot -> band class P of the item (its trace layout, swipe_core.h trace_byte_index)
@@ -49,7 +56,9 @@ struct TracebackArgs {
 	int32_t gap_open, gap_extend;
 };
 
-// packed-int16 sweep, two items per wavefront (swipe16_kernels.hip): band classes P <= 4, at most 65535 pair-steps per item
+// packed-int16 sweep, two items per wavefront (swipe16_kernels.hip): band classes P <= 4, at most 65535 pair-steps per item,
+// items scored with the context's standard matrix only (one LDS table per workgroup; the host sends items with an adjusted matrix
+// of their own to the 32-bit kernels)
 struct Swipe16Args {
 	const int8_t* qblock;
 	const int8_t* tblock;

@@ -7,7 +7,9 @@
 //     consecutive band diagonals, P chosen per item so that 128*P >= band;
 //   * H/E/F live in VGPRs; the only cross-lane traffic is ONE DPP wave shift per step
 //     (v_mov_b32_dpp wave_shr:1 / wave_shl:1 -- no LDS, no ds_bpermute);
-//   * the 32x32 int8 substitution matrix is staged in LDS once per workgroup;
+//   * the item's 32x32 int8 substitution matrix -- the context's, or the item's own composition-adjusted one
+//     (--comp-based-stats 2..5: dp/swipe/target_iterator.h:124-134 hands every SIMD channel its target's matrix) -- is staged in
+//     LDS by the item's wavefront;
 //   * letters: a lane's cells of one (even, odd) step pair need P + 1 consecutive query letters and P consecutive target
 //     letters, and the next pair the same windows moved by one, so the windows live in VGPRs and every pair fetches ONE
 //     query letter, ONE bias byte and ONE target letter per lane (scalar base + lane offset, adjacent lanes adjacent bytes),
@@ -50,24 +52,31 @@ template<int P, bool COORDS, bool TRACE, int STAT = STAT_NONE, bool REV = false,
 __global__ __launch_bounds__(MULTI ? MAXW * 64 : WAVES_PER_BLOCK * 64)
 void banded_swipe_kernel(SwipeArgs args)
 {
-	__shared__ int8_t matrix[32 * 32];
+	// one scoring matrix per item: the context's, or the item's own composition-adjusted one (cbs_off <= -2), staged by the
+	// item's wavefront(s)
+	__shared__ int8_t matrices[MULTI ? 1 : WAVES_PER_BLOCK][32 * 32];
 	__shared__ int edge[2][3][MULTI ? MULTI_MAX_WAVES : 1];
 	__shared__ int red[MULTI ? MULTI_MAX_WAVES : 1][5];
-	for (int x = threadIdx.x; x < 32 * 32 / 4; x += blockDim.x)
-		reinterpret_cast<int32_t*>(matrix)[x] = reinterpret_cast<const int32_t*>(args.matrix)[x];
-	__syncthreads();
 
 	const int wave = threadIdx.x >> 6, n_waves = MULTI ? (int)(blockDim.x >> 6) : 1;
 	const int lane = MULTI ? (int)threadIdx.x : (int)(threadIdx.x & 63);          // MULTI: the virtual lane, 0 .. 64 * n_waves - 1
 	const int64_t slot = MULTI ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
-	if (slot >= args.n)
-		return;
-	const int32_t item_idx = args.order[slot];
-	const dmnd_dp_target it = args.items[item_idx];
-	const Geom g = make_geom(it.query_len, it.target_len, it.d_begin, it.d_end);
-	// the item is the same for all 64 lanes: keeping its offsets in SGPRs lets the letter loads use scalar base + lane offset
+	const bool live = slot < args.n;
+	int32_t item_idx = 0;
+	dmnd_dp_target it = { 0, 0, -1, 1, 1, 0, 1 };
+	if (live) { item_idx = args.order[slot]; it = args.items[item_idx]; }
 	const int64_t q_off = uniform64(it.query_off), t_off = uniform64(it.target_off), c_off = uniform64(it.cbs_off);
-	SeqView v{ args.qblock + q_off, args.tblock + t_off, c_off >= 0 ? args.cbs + c_off : nullptr, matrix };
+	int8_t* const matrix = matrices[MULTI ? 0 : wave];
+	{
+		const int32_t* src = reinterpret_cast<const int32_t*>(c_off <= -2 ? args.matrices + own_matrix_number(c_off) * (32 * 32) : args.matrix);
+		for (int x = lane; x < 32 * 32 / 4; x += MULTI ? (int)blockDim.x : 64)
+			reinterpret_cast<int32_t*>(matrix)[x] = src[x];
+	}
+	__syncthreads();
+	if (!live)
+		return;
+	const Geom g = make_geom(it.query_len, it.target_len, it.d_begin, it.d_end);
+	SeqView v{ args.qblock + q_off, args.tblock + t_off, c_off >= 0 ? args.cbs + c_off : own_matrix_biased(c_off) ? args.cbs + q_off : nullptr, matrix };
 	if (REV) { v.rev_q = it.query_len - 1; v.rev_t = it.target_len - 1; }
 	const int go = args.gap_open + args.gap_extend, ge = args.gap_extend;
 	int bs, bi, bj, ba = 0, bb = 0;
@@ -273,8 +282,10 @@ __global__ __launch_bounds__(256) void traceback_kernel(TracebackArgs args)
 	if (e.pad[0]) h.transcript_len = -1;          // saturated 16-bit sweep: nothing to walk, the host re-runs the item
 	if (e.score > 0 && !e.pad[0]) {
 		const Geom g = make_geom(it.query_len, it.target_len, it.d_begin, it.d_end);
+		// an item with its own adjusted matrix is walked on that matrix, read where it lies in HBM (a few hundred look-ups)
 		const SeqView v{ args.qblock + it.query_off, args.tblock + it.target_off,
-			it.cbs_off >= 0 ? args.cbs + it.cbs_off : nullptr, matrix };
+			it.cbs_off >= 0 ? args.cbs + it.cbs_off : own_matrix_biased(it.cbs_off) ? args.cbs + it.query_off : nullptr,
+			it.cbs_off <= -2 ? args.matrices + own_matrix_number(it.cbs_off) * (32 * 32) : matrix };
 		const int PC = args.p_of_slot[slot];
 		const int cap = (int)(args.transcript_off[slot + 1] - args.transcript_off[slot]);
 		const WalkResult r = traceback_walk_wave(args.trace + args.trace_off[slot], g, PC, v, args.gap_open, args.gap_extend,

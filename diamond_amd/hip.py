@@ -56,8 +56,8 @@ HSP_DTYPE = np.dtype([("score", "<i4"), ("q_begin", "<i4"), ("q_end", "<i4"), ("
                       ("length", "<i4"), ("identities", "<i4"), ("mismatches", "<i4"), ("positives", "<i4"),
                       ("gap_openings", "<i4"), ("gaps", "<i4"), ("transcript_len", "<i4"), ("transcript_off", "<i8")],
                      align=True)
-HOST_TARGET_DTYPE = np.dtype([("seq", "<u8"), ("len", "<i4"), ("d_begin", "<i4"), ("d_end", "<i4")], align=True)
-assert DP_TARGET_DTYPE.itemsize == 40 and HSP_DTYPE.itemsize == 56 and HOST_TARGET_DTYPE.itemsize == 24
+HOST_TARGET_DTYPE = np.dtype([("seq", "<u8"), ("len", "<i4"), ("d_begin", "<i4"), ("d_end", "<i4"), ("matrix", "<u8")], align=True)
+assert DP_TARGET_DTYPE.itemsize == 40 and HSP_DTYPE.itemsize == 56 and HOST_TARGET_DTYPE.itemsize == 32
 
 _lib = None
 
@@ -72,7 +72,7 @@ EXPORTS = ["dmnd_abi_version", "dmnd_last_error", "dmnd_default_params", "dmnd_c
            "dmnd_seed_params_set_query_indexed", "dmnd_auto_query_indexed", "dmnd_set_motif_table", "dmnd_motif_table_size",
            "dmnd_soft_mask_block", "dmnd_output_fields", "dmnd_format_fields", "dmnd_format_pairwise_intro", "dmnd_format_pairwise",
            "dmnd_format_paf", "dmnd_device_count", "dmnd_set_top_percent", "dmnd_join_blocks_top", "dmnd_set_filters", "dmnd_format_sam", "dmnd_set_query_source_lengths", "dmnd_format_fields_unaligned", "dmnd_format_fields_header", "dmnd_set_query_index_reuse", "dmnd_set_no_self_hits", "dmnd_matrix_params", "dmnd_masking_lambda", "dmnd_translate_opts", "dmnd_set_extension_mode", "dmnd_format_xml_header", "dmnd_format_xml_query_intro", "dmnd_format_xml", "dmnd_format_xml_query_epilog", "dmnd_format_daa_header", "dmnd_format_daa_query", "dmnd_format_daa_match", "dmnd_seg_ranges", "dmnd_seg_mask_block", "dmnd_seg_lnfact", "dmnd_daa_match_read", "dmnd_hsp_from_transcript", "dmnd_set_format_flags", "dmnd_host_alloc", "dmnd_host_free", "dmnd_share_block", "dmnd_init", "dmnd_seed_reserve", "dmnd_mask_sequences", "dmnd_set_max_hsps", "dmnd_rank_targets", "dmnd_rank_update", "dmnd_set_global_ranking",
-           "dmnd_cbs_composition", "dmnd_cbs_rule", "dmnd_cbs_target_matrix", "dmnd_cbs_ideal_lambda"]
+           "dmnd_upload_matrices", "dmnd_cbs_composition", "dmnd_cbs_rule", "dmnd_cbs_target_matrix", "dmnd_cbs_ideal_lambda"]
 
 
 def set_motif_table(codes):
@@ -143,6 +143,7 @@ def load():
         lib.dmnd_masking_lambda.argtypes = [ctypes.c_void_p]
         lib.dmnd_translate.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
         lib.dmnd_last_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+        lib.dmnd_upload_matrices.argtypes = [v, v, ctypes.c_int64]
         lib.dmnd_cbs_ideal_lambda.restype = ctypes.c_double
         lib.dmnd_cbs_ideal_lambda.argtypes = [ctypes.POINTER(Params)]
         lib.dmnd_cbs_composition.argtypes = [v, ctypes.c_int32, v, ctypes.POINTER(ctypes.c_int32)]
@@ -623,6 +624,11 @@ class Context:
         self.lib.dmnd_share_block.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         self._check(self.lib.dmnd_share_block(self.h, int(which), src.h))
 
+    def upload_matrices(self, matrices):
+        """n composition-adjusted matrices (int8[n, 32, 32]) for the items whose cbs_off is -2 - number."""
+        m = np.ascontiguousarray(matrices, dtype=np.int8).reshape(-1, 32, 32)
+        self._check(self.lib.dmnd_upload_matrices(self.h, m.ctypes.data if len(m) else None, len(m)))
+
     def upload_cbs(self, cbs):
         cbs = np.ascontiguousarray(cbs, dtype=np.int8)
         self._check(self.lib.dmnd_upload_cbs(self.h, cbs.ctypes.data if cbs.size else None, cbs.size))
@@ -643,13 +649,15 @@ class Context:
         return out, (tr[:used.value] if tr is not None else None)
 
     def banded_swipe_host(self, query, cbs, targets, mode, hsp_values=0):
-        """targets: list of (seq int8[], d_begin, d_end): the literal reference call shape (one query)."""
+        """targets: list of (seq int8[], d_begin, d_end[, matrix int8[26, 32] or None]): the literal reference call shape (one query)."""
         q = np.ascontiguousarray(query, dtype=np.int8)
         c = np.ascontiguousarray(cbs, dtype=np.int8) if cbs is not None else None
         seqs = [np.ascontiguousarray(t[0], dtype=np.int8) for t in targets]
+        mats = [np.ascontiguousarray(t[3], dtype=np.int8) if len(t) > 3 and t[3] is not None else None for t in targets]
         ht = np.zeros(len(targets), dtype=HOST_TARGET_DTYPE)
         for k, (s, t) in enumerate(zip(seqs, targets)):
-            ht[k] = (s.ctypes.data, s.size, t[1], t[2])
+            assert mats[k] is None or mats[k].size >= 26 * 32
+            ht[k] = (s.ctypes.data, s.size, t[1], t[2], mats[k].ctypes.data if mats[k] is not None else 0)
         out = np.zeros(len(targets), dtype=HSP_DTYPE)
         tr = None
         used = ctypes.c_int64(0)

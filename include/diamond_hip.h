@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DMND_ABI_VERSION 7      /* 2: dmnd_match.frame, seed parameters (ungapped filter, translated queries), dmnd_extend_plan(query_contexts); 3: seed_encoding; 4: output formats; 5: DMND_MAX_SHAPES 64; 6: dmnd_host_alloc, dmnd_share_block; 7: dmnd_set_max_hsps, several dmnd_match records per target, global ranking */
+#define DMND_ABI_VERSION 8      /* 2: dmnd_match.frame, seed parameters (ungapped filter, translated queries), dmnd_extend_plan(query_contexts); 3: seed_encoding; 4: output formats; 5: DMND_MAX_SHAPES 64; 6: dmnd_host_alloc, dmnd_share_block; 7: dmnd_set_max_hsps, several dmnd_match records per target, global ranking; 8: --comp-based-stats 2..5 (dmnd_cbs_*, dmnd_upload_matrices, dmnd_dp_target::cbs_off <= -2); dmnd_mask_block patches host_data in place (the full copy-back of ABI <= 6 only above 1/16 masked letters) */
 
 enum {
 	DMND_OK = 0,
@@ -73,13 +73,18 @@ typedef struct {
 	double max_evalue;         /* config.max_evalue (report_cutoff, score_matrix.cpp:234) */
 } dmnd_params;
 
+#define DMND_CBS_MATRIX_WITH_BIAS ((int64_t)1 << 40)
 /* One banded-DP work item = one DpTarget of the reference (src/dp/dp.h:34-157) together with the
  * query it is aligned against (DP::Params::query / composition_bias, src/dp/dp.h:171-184).
  * Offsets address letters inside the blocks uploaded with dmnd_upload_block(). */
 typedef struct {
 	int64_t query_off;    /* first query letter, offset into the DMND_QUERY block data */
 	int64_t target_off;   /* first target letter, offset into the DMND_TARGET block data */
-	int64_t cbs_off;      /* offset of the query's int8 composition bias inside the uploaded bias buffer, or -1 (NoCBS) */
+	int64_t cbs_off;      /* offset of the query's int8 composition bias inside the uploaded bias buffer, or -1 (NoCBS);
+	                         <= -2: the item has a composition-adjusted matrix of its own (DpTarget::matrix, dp/dp.h:143): number
+	                         -2 - cbs_off of the matrices uploaded with dmnd_upload_matrices, and no bias (swipe.h:43-54); with
+	                         DMND_CBS_MATRIX_WITH_BIAS subtracted as well, the item is biased too, by the bias bytes at offset query_off
+	                         (the reference's FULL-MATRIX sweep keeps the bias in every channel: full_swipe.h:164) */
 	int32_t query_len;
 	int32_t target_len;   /* DpTarget::seq.length() (a prefix length in reversed passes) */
 	int32_t d_begin;      /* diagonal band [d_begin, d_end), diagonal = i - j */
@@ -140,6 +145,11 @@ int dmnd_share_block(dmnd_ctx* ctx, int which, const dmnd_ctx* src);
  * src/stats/hauser_correction.cpp:107), concatenated; dmnd_dp_target::cbs_off indexes this buffer. */
 int dmnd_upload_cbs(dmnd_ctx* ctx, const int8_t* cbs, int64_t len);
 
+/* Uploads n composition-adjusted scoring matrices (32 x 32 int8 each, [target letter * 32 + query letter], as
+ * dmnd_cbs_target_matrix writes them = Stats::TargetMatrix::scores, stats/cbs.h:50-62) for the work items that name one in
+ * dmnd_dp_target::cbs_off; replaces what was uploaded before. --comp-based-stats 2..5 only. */
+int dmnd_upload_matrices(dmnd_ctx* ctx, const int8_t* matrices, int64_t n);
+
 /* -- banded Smith-Waterman: replaces DP::BandedSwipe::swipe (src/dp/dp.h:287;
  *    dispatcher src/dp/swipe/swipe_wrapper.cpp:446-470,487) -------------------------------------- */
 /* Computes n work items in one batched launch (any mix of queries).  mode is DMND_SWIPE_*;
@@ -159,6 +169,8 @@ typedef struct {
 	const int8_t* seq;     /* DpTarget::seq.data() */
 	int32_t len;           /* DpTarget::seq.length() */
 	int32_t d_begin, d_end;
+	const int8_t* matrix;  /* DpTarget::matrix->scores.data() (26 rows of 32 int8, [target letter][query letter]: Stats::TargetMatrix,
+	                          stats/cbs.h:50-62) for a target with a composition-adjusted matrix -- it is then scored without cbs --, else NULL */
 } dmnd_host_target;
 int dmnd_banded_swipe_host(dmnd_ctx* ctx, const int8_t* query, int32_t query_len, const int8_t* cbs,
 	const dmnd_host_target* targets, int64_t n, int mode, uint32_t hsp_values,

@@ -114,7 +114,7 @@ std::list<Hsp> wrap_swipe(const DP::Targets& targets, DP::Params& p)
 	for (int bin = 0; bin < DP::BINS; ++bin)
 		for (const DpTarget& t : targets[bin]) {
 			const bool stats_bin = p.v != HspValues::NONE && bin >= DP::SCORE_BINS;
-			if (plain && !t.adjusted_matrix() && t.carry_over.i1 == 0 && (!stats_bin || bridge_stats))
+			if (plain && t.carry_over.i1 == 0 && (!stats_bin || bridge_stats))
 				gpu.push_back(Item{ bin, &t });
 			else {
 				rest[bin].push_back(t);
@@ -144,7 +144,7 @@ std::list<Hsp> wrap_swipe(const DP::Targets& targets, DP::Params& p)
 		int64_t cap = 16;
 		for (size_t k = 0; k < sel.size(); ++k) {
 			const DpTarget& t = *sel[k]->t;
-			ht[k] = dmnd_host_target{ (const int8_t*)t.seq.data(), t.seq.length(), t.d_begin, t.d_end };
+			ht[k] = dmnd_host_target{ (const int8_t*)t.seq.data(), t.seq.length(), t.d_begin, t.d_end, t.adjusted_matrix() ? t.matrix->scores.data() : nullptr };
 			cap += (int64_t)qlen + t.seq.length() + 2;
 		}
 		std::vector<dmnd_hsp> res(sel.size());

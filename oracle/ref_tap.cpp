@@ -126,7 +126,19 @@ std::list<Hsp> wrap_swipe(const DP::Targets& targets, DP::Params& params)
 				}
 			}
 	}
-	std::list<Hsp> out = real_swipe(targets, params);
+	std::list<Hsp> out;
+	try { out = real_swipe(targets, params); }
+	catch (...) {
+		// a call the reference itself refuses (e.g. "Traceback with adjusted matrix not supported", full_swipe.h:102): its inputs
+		// are still written, with -1 for the number of HSPs
+		if (f) {
+			b.i32(-1);
+			std::lock_guard<std::mutex> lock(tap_mtx);
+			fwrite(b.d.data(), 1, b.d.size(), f);
+			fflush(f);
+		}
+		throw;
+	}
 	if (f) {
 		b.i32((int32_t)out.size());
 		for (const Hsp& h : out) {

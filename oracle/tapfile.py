@@ -62,7 +62,9 @@ def read_tap(path, max_records=None):
             targets.append(t)
         rec["targets"] = targets
         hsps = []
-        for _ in range(i32()):
+        n_hsps = i32()
+        rec["refused"] = n_hsps < 0                 # the reference threw inside this call
+        for _ in range(max(n_hsps, 0)):
             h = {k: i32() for k in HSP_FIELDS}
             h["evalue"] = f64()
             h["bit_score"] = f64()

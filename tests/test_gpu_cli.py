@@ -199,6 +199,9 @@ CTEST = [
     ("ultra-sensitive", ["--ultra-sensitive", "-c1", "-p4"]),
     ("query-indexed", ["--more-sensitive", "-c1", "-p4", "--algo", "1"]),
     ("comp-based-stats-0", ["--more-sensitive", "-c1", "-p4", "--comp-based-stats", "0"]),
+    ("comp-based-stats-2", ["--more-sensitive", "-c1", "-p4", "--comp-based-stats", "2"]),
+    ("comp-based-stats-3", ["--more-sensitive", "-c1", "-p4", "--comp-based-stats", "3"]),
+    ("comp-based-stats-4", ["--more-sensitive", "-c1", "-p4", "--comp-based-stats", "4"]),
     ("target-seqs", ["-k3", "-c1", "-p4"]),
     ("evalue", ["-e10000", "--more-sensitive", "-c1", "-p4"]),
     ("top", ["--top", "10", "-p4"]),
@@ -974,3 +977,89 @@ def test_cli_queries_from_standard_input(tmp_path):
             r = subprocess.run([CLI, mode, "-d", str(tmp_path / "db.faa"), "-p", "4"], input=data, capture_output=True, timeout=300)
             assert r.returncode == 0, r.stderr[-1000:]
             assert r.stdout.decode() == ref, mode                    # no -o either: the alignments go to standard output
+
+
+def _write_biased_files(d, seed=33):
+    """Ordinary families plus families whose compositions are far from the matrix background -- two letters above 40 % of the
+    sequence, hydrophobic-only and charged-only stretches, short queries -- so that NCBI's conditional test (the angle between the
+    two compositions' deviations, the high-pair rule) takes both of its branches and the adjusted matrices differ from BLOSUM62."""
+    rng = np.random.default_rng(seed)
+    db, doff, q, qoff = synth.generate(150, members=6, queries=160, seed=seed + 1)
+    seqs_t = [db[doff[i]:doff[i + 1]] for i in range(len(doff) - 1)]
+    seqs_q = [q[qoff[i]:qoff[i + 1]] for i in range(len(qoff) - 1)]
+
+    def mutate(s, rate, alphabet):
+        m = s.copy()
+        mut = rng.random(len(m)) < rate
+        m[mut] = rng.choice(alphabet, int(mut.sum()))
+        return m
+
+    full = np.arange(20, dtype=np.int8)
+    pools = [np.array([0, 10, 19, 9, 12, 13], np.int8),        # A L V I M F
+             np.array([3, 6, 11, 1, 15, 5], np.int8),          # D E K R S Q
+             np.array([7, 14, 15, 16, 2], np.int8)]            # G P S T N
+    for k in range(90):
+        n = int(rng.integers(40, 420))
+        pool = pools[k % 3]
+        weights = rng.dirichlet(np.ones(len(pool)) * (0.4 if k % 2 else 3.0))
+        anc = np.where(rng.random(n) < 0.75, rng.choice(pool, n, p=weights), rng.choice(full, n)).astype(np.int8)
+        seqs_q.append(mutate(anc, 0.2, full))
+        for _ in range(3):
+            seqs_t.append(mutate(anc, float(rng.uniform(0.1, 0.45)), pool if rng.random() < 0.5 else full))
+        seqs_t.append(np.concatenate([rng.choice(full, int(rng.integers(10, 200))).astype(np.int8), mutate(anc, 0.25, full)]))
+    for name, seqs, prefix in (("db.faa", seqs_t, "t"), ("q.faa", seqs_q, "q")):
+        off = np.concatenate([[0], np.cumsum([len(s) for s in seqs])])
+        synth.write_fasta(os.path.join(str(d), name), prefix, np.concatenate(seqs), off)
+
+
+def test_cli_comp_based_stats_matrix_adjust_matches_reference(tmp_path):
+    """--comp-based-stats 2 .. 5 (row f4): per (query, target) a composition-adjusted scoring matrix (host double precision,
+    cbs_adjust.cpp) and sweeps that score every DpTarget with its own matrix; byte-identical to the reference binary per mode,
+    sensitivity, algorithm, with transcripts, several HSPs per target, several reference blocks, another standard matrix, --top and
+    the filters. The reference's refusals are reproduced too."""
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/diamond not built")
+    _write_biased_files(tmp_path)
+    base = ["-q", str(tmp_path / "q.faa"), "-d", str(tmp_path / "db.faa"), "-p", "4"]
+    outs = {}
+    cases = [[m] + x for m in ("2", "3", "4", "5") for x in ([], ["--sensitive"], ["--fast"])]
+    cases += [["4", "--masking", "0", "--algo", "0"], ["3", "--algo", "1"], ["5", "--max-hsps", "0"], ["4", "-b0.00004"],
+              ["3", "-f", "6", "qseqid", "sseqid", "score", "qstart", "qend", "sstart", "send", "evalue", "bitscore", "length", "gapopen", "btop", "cigar"],
+              ["4", "-f", "0"], ["5", "--matrix", "BLOSUM45"], ["4", "--matrix", "PAM70", "--top", "20"], ["2", "--id", "40", "-k", "5"],
+              ["4", "--ext", "full"], ["5", "--more-sensitive", "-e", "10"],
+              # Hauser bias AND adjusted matrices in full-matrix sweeps (the reference keeps the bias in every channel there)
+              ["3", "--ext", "full"], ["2", "--max-hsps", "0"], ["3", "--max-hsps", "2", "-k", "3"]]
+    refused = 0
+    for extra in cases:
+        args = ["--comp-based-stats"] + extra
+        r = subprocess.run([REF, "blastp"] + base + args + ["-o", str(tmp_path / "ref.out")], capture_output=True, text=True, timeout=600)
+        if r.returncode != 0:
+            # the reference's full-matrix sweep cannot trace back on an adjusted matrix (dp/swipe/full_swipe.h:101-102): --ext full and
+            # the alternative HSPs of --max-hsps end with this error as soon as such a target has an HSP to report -- so does this build
+            assert "Traceback with adjusted matrix not supported" in r.stderr + r.stdout, (extra, r.stderr[-500:])
+            r2 = subprocess.run([CLI, "blastp"] + base + args + ["-o", str(tmp_path / "hip.out")], capture_output=True, text=True, timeout=600)
+            assert r2.returncode != 0 and "Traceback with adjusted matrix not supported" in r2.stderr + r2.stdout, (extra, r2.stderr[-500:])
+            refused += 1
+            continue
+        _run([CLI, "blastp"] + base + args + ["-o", str(tmp_path / "hip.out")])
+        ref = open(tmp_path / "ref.out").read()
+        assert len(ref) > 5000, extra
+        got = open(tmp_path / "hip.out").read()
+        if got != ref:
+            a, b = set(ref.splitlines()), set(got.splitlines())
+            raise AssertionError("%s: %d lines only in the reference's output, %d only in ours; e.g. %s | %s" % (extra, len(a - b), len(b - a), sorted(a - b)[:2], sorted(b - a)[:2]))
+        outs[" ".join(extra)] = ref
+    assert refused >= 2                                      # --max-hsps 0 and --ext full
+    # the modes are not the same computation: the adjusted matrices change scores
+    _run([REF, "blastp"] + base + ["-o", str(tmp_path / "m1.out")])
+    m1 = open(tmp_path / "m1.out").read()
+    assert outs["4"] != m1 and outs["3"] != m1 and outs["5"] != outs["4"] and outs["3"] != outs["4"]
+    # what the reference refuses (basic/config.cpp:688-700)
+    for cmd in (["blastp", "--global-ranking", "5"], ):
+        r1 = subprocess.run([REF] + cmd + base + ["--comp-based-stats", "3", "-o", str(tmp_path / "x.out")], capture_output=True, text=True)
+        r2 = subprocess.run([CLI] + cmd + base + ["--comp-based-stats", "3", "-o", str(tmp_path / "y.out")], capture_output=True, text=True)
+        assert r1.returncode != 0 and r2.returncode != 0
+        assert "Global ranking is not supported in this mode." in r1.stderr + r1.stdout and "Global ranking is not supported in this mode." in r2.stderr + r2.stdout
+    for val in ("6", "9"):
+        r2 = subprocess.run([CLI, "blastp"] + base + ["--comp-based-stats", val, "-o", str(tmp_path / "y.out")], capture_output=True, text=True)
+        assert r2.returncode != 0 and "Permitted values" in r2.stderr + r2.stdout

@@ -45,6 +45,11 @@ def _run(binary, d, name, extra, seed_seam=False, algo=("--algo", "0")):
     ("fast_cigar", ["--fast", "-f", "6", "qseqid", "sseqid", "score", "qstart", "qend", "sstart", "send", "cigar", "evalue", "bitscore"]),
     ("default", []),
     ("sensitive_k5", ["--sensitive", "-k", "5"]),
+    # --comp-based-stats 3 / 4 / 5: the reference makes the per-target adjusted matrices, DpTarget::matrix crosses the seam
+    # (dmnd_host_target::matrix) and the device sweeps every target with its own
+    ("cbs3", ["--comp-based-stats", "3"]),
+    ("cbs4_cigar", ["--comp-based-stats", "4", "-f", "6", "qseqid", "sseqid", "score", "qstart", "qend", "sstart", "send", "cigar", "evalue", "bitscore"]),
+    ("cbs5_sensitive", ["--comp-based-stats", "5", "--sensitive"]),
 ])
 def test_reference_with_hip_swipe_is_byte_identical(data, name, extra):
     ref = _run(REF, data, name + ".ref.tsv", extra)

@@ -13,7 +13,7 @@ import torch
 import oracle_py as orc
 from tapfile import read_tap
 from diamond_amd import hip, synth
-from gpu_util import pack_records
+from gpu_util import pack_records, pack_records_m
 
 pytestmark = pytest.mark.gpu
 
@@ -64,6 +64,99 @@ def test_golden_reference_calls(ctx, tap):
                 assert tr[o["transcript_off"] + o["transcript_len"]] == 0
             n_checked += 1
         assert n_checked > 0
+
+
+@pytest.mark.parametrize("tap", ["swipe_cbs3.tap", "swipe_cbs4.tap"])
+def test_golden_reference_calls_with_adjusted_matrices(ctx, tap):
+    """--comp-based-stats 3 / 4 (row f4): DpTargets with a composition-adjusted matrix of their own, as the reference swept them
+    (tests/golden/make_cbs_golden.sh). Both call shapes: resident blocks + dmnd_upload_matrices, and the reference's own
+    (dmnd_banded_swipe_host with DpTarget::matrix pointers)."""
+    hdr, recs = read_tap(os.path.join(GOLDEN, tap))
+    p = hip.default_params()
+    p.db_letters = hdr["db_letters"]
+    n_adj = 0
+    for v, mode in ((0, hip.SWIPE_SCORE), (510, hip.SWIPE_TRACEBACK)):
+        sel = [r for r in recs if r["hsp_values"] == v]
+        assert sel
+        qb, tb, cbs, items, meta, mats = pack_records_m(sel)
+        assert len(mats) > 20 and (items["cbs_off"] <= -2).sum() == len(mats)
+        ctx.upload_block(hip.QUERY, qb)
+        ctx.upload_block(hip.TARGET, tb)
+        ctx.upload_cbs(cbs)
+        ctx.upload_matrices(mats)
+        out, tr = ctx.banded_swipe(items, mode, v)
+        for k, (rec, t) in enumerate(meta):
+            hs = [h for h in rec["hsps"] if (h["swipe_target"], h["d_begin"], h["d_end"]) == (t["target_idx"], t["d_begin"], t["d_end"])]
+            o = out[k]
+            if not hs:
+                ev = ctx.lib.dmnd_evalue_p(p, int(o["score"]), len(rec["query"]), t["true_target_len"]) if o["score"] > 0 else 1e9
+                assert o["score"] <= 0 or ev > hdr["max_evalue"]
+                continue
+            h = hs[0]
+            assert o["score"] == h["score"], (k, t["matrix"] is not None)
+            if mode == hip.SWIPE_TRACEBACK and h["swipe_bin"] < 3:
+                for key in KEYS:
+                    assert o[key] == h[key], (key, k)
+                assert np.array_equal(_transcript(tr, o), h["transcript"][:-1])
+            n_adj += t["matrix"] is not None
+        # the reference's call shape, one query at a time
+        for rec in sel[:25]:
+            targets = [(t["seq"], t["d_begin"], t["d_end"], t["matrix"]) for t in rec["targets"]]
+            ho, htr = ctx.banded_swipe_host(rec["query"], rec["cbs"], targets, mode, v)
+            for j, t in enumerate(rec["targets"]):
+                hs = [h for h in rec["hsps"] if (h["swipe_target"], h["d_begin"], h["d_end"]) == (t["target_idx"], t["d_begin"], t["d_end"])]
+                if hs:
+                    assert ho[j]["score"] == hs[0]["score"]
+                    if mode == hip.SWIPE_TRACEBACK and hs[0]["swipe_bin"] < 3:
+                        assert np.array_equal(_transcript(htr, ho[j]), hs[0]["transcript"][:-1])
+    assert n_adj > 50
+    ctx.upload_matrices(np.zeros((0, 32, 32), np.int8))
+
+
+def test_random_matrices_against_oracle(ctx):
+    """Every item with a random matrix of its own (or the context's, one in four), every band class up to the multi-wavefront
+    sweep, all modes incl. the statistics cells: equal to the oracle run on that matrix."""
+    M = hip.matrix_of(ctx.params)
+    rng = np.random.default_rng(2024)
+    recs = _random_items(rng, 240, M) + _random_items(rng, 60, M, wide=True)
+    for k, rec in enumerate(recs):
+        t = rec["targets"][0]
+        if k % 4:
+            m = M.copy()
+            m[:24, :24] = np.clip(m[:24, :24].astype(int) + rng.integers(-2, 3, (24, 24)), -128, 127).astype(np.int8)
+            t["matrix"] = m
+            rec["cbs_used"] = None
+        else:
+            t["matrix"] = None
+            rec["cbs_used"] = rec["cbs"]
+    qb, tb, cbs, items, meta, mats = pack_records_m(recs)
+    ctx.upload_block(hip.QUERY, qb)
+    ctx.upload_block(hip.TARGET, tb)
+    ctx.upload_cbs(cbs)
+    ctx.upload_matrices(mats)
+    res = {mode: ctx.banded_swipe(items, mode) for mode in (hip.SWIPE_SCORE, hip.SWIPE_COORDS, hip.SWIPE_TRACEBACK)}
+    st, _ = ctx.banded_swipe(items, hip.SWIPE_STATS, 510)
+    for k, (rec, t) in enumerate(meta):
+        m = t["matrix"] if t["matrix"] is not None else M
+        rc, o, otr = orc.banded_swipe(rec["query"], rec["cbs_used"], t["seq"], t["d_begin"], t["d_end"], m, 11, 1, orc.TRACEBACK)
+        assert rc == 0
+        assert res[hip.SWIPE_SCORE][0][k]["score"] == o["score"], k
+        assert res[hip.SWIPE_COORDS][0][k]["score"] == o["score"]
+        if o["score"] > 0:
+            g, tr = res[hip.SWIPE_TRACEBACK][0][k], res[hip.SWIPE_TRACEBACK][1]
+            for key in KEYS:
+                assert g[key] == o[key], (key, k)
+            assert np.array_equal(_transcript(tr, g), otr)
+            rc, so = orc.swipe_stats(rec["query"], rec["cbs_used"], t["seq"], t["d_begin"], t["d_end"], m, 11, 1, 510)
+            assert rc == 0
+            for key in "score q_begin q_end s_begin s_end length identities mismatches gap_openings gaps".split():
+                assert st[k][key] == so[key], (key, k)
+    # an item that names a matrix that was not uploaded is refused
+    bad = items[:1].copy()
+    bad["cbs_off"] = -2 - len(mats)
+    with pytest.raises(hip.DiamondHipError):
+        ctx.banded_swipe(bad, hip.SWIPE_SCORE)
+    ctx.upload_matrices(np.zeros((0, 32, 32), np.int8))
 
 
 def _random_items(rng, n, M, wide=False):

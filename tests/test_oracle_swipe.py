@@ -60,6 +60,40 @@ def test_restated_swipe_matches_reference(tap):
     assert n_hsp > 0
 
 
+@pytest.mark.parametrize("tap", ["swipe_cbs3.tap", "swipe_cbs4.tap"])
+def test_restated_swipe_with_adjusted_matrices(tap):
+    """--comp-based-stats 3 / 4: a DpTarget that carries a composition-adjusted matrix is swept with it and WITHOUT the query's
+    Hauser bias (banded_swipe.h:157-165, swipe.h:43-54: the bias vector is blended to zero in the target's channel)."""
+    hdr, recs = read_tap(os.path.join(GOLDEN, tap))
+    M, go, ge = hdr["matrix8"], hdr["gap_open"], hdr["gap_extend"]
+    ev = orc.evaluer(hdr["db_letters"], go, ge)
+    n_adj = n_plain = 0
+    for rec in recs:
+        q, v = rec["query"], rec["hsp_values"]
+        for t, hsps in _targets_with_hsps(rec):
+            own = t["matrix"] is not None
+            m = M
+            if own:
+                m = np.full((32, 32), -128, np.int8)
+                m[:26] = t["matrix"]
+            cbs = None if own else rec["cbs"]
+            mode = orc.SCORE_ONLY if v == 0 else orc.TRACEBACK
+            rc, o, tr = orc.banded_swipe(q, cbs, t["seq"], t["d_begin"], t["d_end"], m, go, ge, mode)
+            assert rc == 0
+            if not hsps:
+                assert o["score"] <= 0 or orc.evalue(ev, o["score"], len(q), t["true_target_len"]) > hdr["max_evalue"]
+                continue
+            h = hsps[0]
+            assert o["score"] == h["score"]
+            if v != 0 and h["swipe_bin"] < 3:
+                for k in COORD_KEYS + ["positives"]:
+                    assert o[k] == h[k], (k, o, h)
+                assert np.array_equal(h["transcript"][:-1], tr)
+            n_adj += own
+            n_plain += not own
+    assert n_adj > 50 and (n_plain > 50 or tap == "swipe_cbs4.tap")
+
+
 def test_golden_covers_all_modes():
     seen = set()
     for tap in TAPS:
