@@ -110,6 +110,30 @@ def back_translate(q, q_off, seed=1, flank=(0, 60), reverse_frac=0.5):
     return out, off
 
 
+def indel_reads(dna, off, seed=1, deletion=0.003, insertion=0.003, substitution=0.01):
+    """Reads with sequencing errors that break the reading frame (what blastx -F is for): every base is dropped with probability
+    `deletion`, preceded by a random base with probability `insertion`, replaced with probability `substitution`.
+    Returns (dna, offsets)."""
+    rng = np.random.default_rng(seed)
+    reads = []
+    for i in range(len(off) - 1):
+        r = dna[off[i]:off[i + 1]]
+        x = rng.random(len(r))
+        keep = x >= deletion
+        ins = (x >= deletion) & (x < deletion + insertion)
+        sub = rng.random(len(r)) < substitution
+        r = np.where(sub, rng.integers(0, 4, len(r)).astype(r.dtype), r)
+        parts = np.empty(2 * len(r), r.dtype)
+        parts[0::2] = rng.integers(0, 4, len(r))
+        parts[1::2] = r
+        mask = np.empty(2 * len(r), bool)
+        mask[0::2] = ins
+        mask[1::2] = keep
+        reads.append(parts[mask])
+    o = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.int64)
+    return np.concatenate(reads), o
+
+
 def write_dna_fasta(path, prefix, dna, off):
     lut = np.frombuffer(_NT.encode(), np.uint8)
     with open(path, "wb") as f:

@@ -41,6 +41,18 @@ double oracle_area(const oracle_evaluer* e, double y, double seqlen1, double seq
 double oracle_evalue(const oracle_evaluer* e, int raw_score, unsigned query_len, unsigned subject_len);
 double oracle_bitscore(const oracle_evaluer* e, double raw_score);
 
+/* three-frame banded sweep of frameshift alignment, blastx -F (frameshift_swipe.c) */
+typedef struct {
+	int32_t score, frame, q_begin, q_end, s_begin, s_end, qs_begin, qs_end;
+	int32_t length, identities, mismatches, positives, gap_openings, gaps, transcript_len;
+} oracle_hsp3;
+int oracle_3frame_score(const int8_t* const frames[3], const int32_t lens[3], const int8_t* target, int tlen,
+	int band, int i0, int i1, int pos0, const int8_t* matrix8, int gap_open, int gap_extend, int frame_shift, int* max_col, int* overflow);
+void oracle_3frame_score_range(int strand, int dna_len, int qlen, int band, int i0, int pos0, int max_col, oracle_hsp3* out);
+int oracle_3frame_traceback(const int8_t* const frames[3], const int32_t lens[3], int strand, int dna_len, const int8_t* target, int tlen,
+	int d_begin, int d_end, const int8_t* matrix8, int gap_open, int gap_extend, int frame_shift,
+	oracle_hsp3* out, uint8_t* transcript, int transcript_cap);
+
 /* gapped filter (gapped_filter.c) */
 void oracle_scan_diags(const int8_t* matrix8, const int8_t* query, int qlen, const int8_t* cbs, const int8_t* target,
 	int d_begin, int j_begin, int j_end, int band, int* out);

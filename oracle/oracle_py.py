@@ -258,3 +258,71 @@ def join_blocks(per_block, max_target_seqs=25):
         if pos < len(per_block[bi]):
             heads.append([per_block[bi][pos], bi, pos])
     return out
+
+
+class Hsp3(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in
+                "score frame q_begin q_end s_begin s_end qs_begin qs_end length identities mismatches positives gap_openings gaps "
+                "transcript_len".split()]
+
+    def asdict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+def _frames(frames):
+    fr = [np.ascontiguousarray(f, dtype=np.int8) for f in frames]
+    ptrs = (ctypes.POINTER(ctypes.c_int8) * 3)(*[_p8(f) if len(f) else ctypes.cast(0, ctypes.POINTER(ctypes.c_int8)) for f in fr])
+    lens = (ctypes.c_int32 * 3)(*[len(f) for f in fr])
+    return fr, ptrs, lens
+
+
+def frameshift_batches(targets, channels=16, band_bin=24, col_bin=400):
+    """The vector batches of the reference's score-only three-frame sweep: the DpTargets of one strand in the order
+    std::stable_sort(DpTarget::operator<) leaves them (dp/dp.h:105-111: band / band_bin, cols / col_bin, left_i1), `channels` at a
+    time (banded_3frame_swipe.cpp:533-551; 16 int16 channels with AVX2). targets: dicts with d_begin, d_end, cols.
+    Yields lists of (index into targets, band, i0, i1, pos0)."""
+    key = lambda t: ((t["d_end"] - t["d_begin"]) // band_bin, _floordiv_c(t["cols"], col_bin), max(t["d_end"] - 1, 0))
+    order = sorted(range(len(targets)), key=lambda k: key(targets[k]))
+    for b in range(0, len(order), channels):
+        idx = order[b:b + channels]
+        band = max(targets[k]["d_end"] - targets[k]["d_begin"] for k in idx)
+        i1 = min(max(targets[k]["d_end"] - 1, 0) for k in idx)
+        i0 = i1 + 1 - band
+        yield [(k, band, i0, i1, i1 - (targets[k]["d_end"] - 1)) for k in idx]
+
+
+def _floordiv_c(a, b):
+    """C integer division (truncation toward zero): DpTarget::cols may be negative here."""
+    q = abs(a) // abs(b)
+    return q if (a >= 0) == (b >= 0) else -q
+
+
+def frameshift_score(frames, target, band, i0, i1, pos0, matrix8, gap_open, gap_extend, frame_shift):
+    """-> (score, max_col, overflow) of one channel of a score-only batch."""
+    fr, ptrs, lens = _frames(frames)
+    t = np.ascontiguousarray(target, dtype=np.int8)
+    m = np.ascontiguousarray(matrix8, dtype=np.int8)
+    mc, ov = ctypes.c_int(0), ctypes.c_int(0)
+    s = lib().oracle_3frame_score(ptrs, lens, _p8(t), len(t), int(band), int(i0), int(i1), int(pos0), _p8(m), int(gap_open), int(gap_extend),
+                                  int(frame_shift), ctypes.byref(mc), ctypes.byref(ov))
+    return s, mc.value, ov.value
+
+
+def frameshift_score_range(strand, dna_len, qlen, band, i0, pos0, max_col):
+    out = Hsp3()
+    lib().oracle_3frame_score_range(int(strand), int(dna_len), int(qlen), int(band), int(i0), int(pos0), int(max_col), ctypes.byref(out))
+    return out.asdict()
+
+
+def frameshift_traceback(frames, strand, dna_len, target, d_begin, d_end, matrix8, gap_open, gap_extend, frame_shift):
+    """-> (rc, Hsp3 dict, transcript uint8[]) of one target on its own band."""
+    fr, ptrs, lens = _frames(frames)
+    t = np.ascontiguousarray(target, dtype=np.int8)
+    m = np.ascontiguousarray(matrix8, dtype=np.int8)
+    out = Hsp3()
+    cap = 4 * (len(t) + len(fr[0])) + 64
+    tr = np.zeros(cap, np.uint8)
+    rc = lib().oracle_3frame_traceback(ptrs, lens, int(strand), int(dna_len), _p8(t), len(t), int(d_begin), int(d_end), _p8(m),
+                                       int(gap_open), int(gap_extend), int(frame_shift), ctypes.byref(out),
+                                       tr.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), cap)
+    return rc, out.asdict(), tr[:out.transcript_len].copy()

@@ -446,3 +446,58 @@ void wrap_tmx(Stats::TargetMatrix* self, const Stats::Composition& query_comp, i
 		cbs_write(b);
 	}
 }
+
+// ---- sixth seam: the three-frame banded sweep of frameshift alignment (blastx -F), dispatch point banded_3frame_swipe
+// (dp/dp.h:296, dp/swipe/banded_3frame_swipe.cpp:647; called twice per query -- forward and reverse strand -- from
+// ExtensionPipeline::BandedSwipe::Pipeline::run_swipe, align/legacy/banded_swipe_pipeline.cpp:157-171).
+// $DIAMOND_TAP_3F=file. Header 'F3H1' once: gap_open gap_extend frame_shift | f64 db_letters | f64 max_evalue | int8 matrix8[32*32],
+// then per call 'F3S1': strand score_only dna_len | 3 x { len, letters[len] } (the strand's three frames)
+//   | n_targets x { target_idx d_begin d_end cols tlen seq[tlen] }   (in the order the caller passed them: the sweep sorts them itself)
+//   | n_hsps x { swipe_target score frame q_begin q_end s_begin s_end qs_begin qs_end length identities mismatches positives
+//                gap_openings gaps f64 evalue f64 bit_score n_transcript transcript[] }
+#define F3_SYM "_Z19banded_3frame_swipeB5cxx11RK18TranslatedSequence6StrandN9__gnu_cxx17__normal_iteratorIP8DpTargetSt6vectorIS5_SaIS5_EEEESA_R6DpStatbb"
+std::list<Hsp> real_3f(const TranslatedSequence& query, Strand strand, std::vector<DpTarget>::iterator target_begin, std::vector<DpTarget>::iterator target_end, DpStat& stat, bool score_only, bool parallel) asm("__real_" F3_SYM);
+std::list<Hsp> wrap_3f(const TranslatedSequence& query, Strand strand, std::vector<DpTarget>::iterator target_begin, std::vector<DpTarget>::iterator target_end, DpStat& stat, bool score_only, bool parallel) asm("__wrap_" F3_SYM);
+std::list<Hsp> wrap_3f(const TranslatedSequence& query, Strand strand, std::vector<DpTarget>::iterator target_begin, std::vector<DpTarget>::iterator target_end, DpStat& stat, bool score_only, bool parallel)
+{
+	static FILE* f = getenv("DIAMOND_TAP_3F") ? fopen(getenv("DIAMOND_TAP_3F"), "wb") : nullptr;
+	static std::mutex mtx;
+	static bool header = false;
+	static std::atomic<int64_t> budget(getenv("DIAMOND_TAP_3F_MAX") ? atoll(getenv("DIAMOND_TAP_3F_MAX")) : (int64_t)1 << 62);
+	if (!f || target_begin == target_end || budget.fetch_sub(1) <= 0)
+		return real_3f(query, strand, target_begin, target_end, stat, score_only, parallel);
+	Buf b;
+	b.i32(0x31533346); b.i32((int32_t)strand); b.i32(score_only ? 1 : 0); b.i32((int32_t)query.source().length());
+	Sequence q[3];
+	query.get_strand(strand, q);
+	for (int k = 0; k < 3; ++k) { b.i32((int32_t)q[k].length()); b.bytes(q[k].data(), (size_t)q[k].length()); }
+	b.i32((int32_t)(target_end - target_begin));
+	for (auto t = target_begin; t != target_end; ++t) {
+		b.i32((int32_t)t->target_idx); b.i32(t->d_begin); b.i32(t->d_end); b.i32(t->cols); b.i32((int32_t)t->seq.length());
+		b.bytes(t->seq.data(), (size_t)t->seq.length());
+	}
+	std::list<Hsp> out = real_3f(query, strand, target_begin, target_end, stat, score_only, parallel);
+	b.i32((int32_t)out.size());
+	for (const Hsp& h : out) {
+		b.i32(h.swipe_target); b.i32(h.score); b.i32(h.frame);
+		b.i32(h.query_range.begin_); b.i32(h.query_range.end_); b.i32(h.subject_range.begin_); b.i32(h.subject_range.end_);
+		b.i32(h.query_source_range.begin_); b.i32(h.query_source_range.end_);
+		b.i32(h.length); b.i32(h.identities); b.i32(h.mismatches); b.i32(h.positives); b.i32(h.gap_openings); b.i32(h.gaps);
+		b.f64(h.evalue); b.f64(h.bit_score);
+		const auto& tr = h.transcript.data();
+		b.i32((int32_t)tr.size());
+		for (const PackedOperation& op : tr) { const uint8_t c = op.code; b.bytes(&c, 1); }
+	}
+	std::lock_guard<std::mutex> lock(mtx);
+	if (!header) {
+		header = true;
+		Buf h;
+		h.i32(0x31483346); h.i32(score_matrix.gap_open()); h.i32(score_matrix.gap_extend()); h.i32(score_matrix.frame_shift());
+		h.f64(score_matrix.db_letters()); h.f64(config.max_evalue);
+		h.bytes(score_matrix.matrix8(), 32 * 32);
+		fwrite(h.d.data(), 1, h.d.size(), f);
+	}
+	fwrite(b.d.data(), 1, b.d.size(), f);
+	fflush(f);
+	return out;
+}

@@ -244,3 +244,56 @@ def read_cbs_tap(path, max_records=None):
             smin, smax = struct.unpack_from("<ii", buf, pos); pos += 8
             tmx.append(dict(query_comp=comp, query_len=qlen, cbs=cbs, rule=rule, target=t, scores=sc, score_min=smin, score_max=smax))
     return hdr, adj, tmx
+
+
+F3_HSP_FIELDS = ("swipe_target", "score", "frame", "q_begin", "q_end", "s_begin", "s_end", "qs_begin", "qs_end", "length", "identities",
+                 "mismatches", "positives", "gap_openings", "gaps")
+
+
+def read_3frame_tap(path, max_records=None):
+    """Reader for $DIAMOND_TAP_3F files (oracle/ref_tap.cpp, sixth seam: banded_3frame_swipe, blastx -F).
+    Returns (hdr, records): hdr = {gap_open, gap_extend, frame_shift, db_letters, max_evalue, matrix8};
+    records[i] = {strand, score_only, dna_len, frames [3 x int8[]], targets [{target_idx, d_begin, d_end, cols, seq}], hsps [dict]}."""
+    buf = open(path, "rb").read()
+    pos, hdr, recs = 0, None, []
+
+    def i32():
+        nonlocal pos
+        v = struct.unpack_from("<i", buf, pos)[0]
+        pos += 4
+        return v
+
+    def f64():
+        nonlocal pos
+        v = struct.unpack_from("<d", buf, pos)[0]
+        pos += 8
+        return v
+
+    def raw(n, dtype):
+        nonlocal pos
+        a = np.frombuffer(buf, dtype=dtype, count=n, offset=pos).copy()
+        pos += n
+        return a
+
+    while pos < len(buf) and (max_records is None or len(recs) < max_records):
+        magic = i32()
+        if magic == 0x31483346:
+            hdr = {"gap_open": i32(), "gap_extend": i32(), "frame_shift": i32(), "db_letters": f64(), "max_evalue": f64()}
+            hdr["matrix8"] = raw(1024, np.int8).reshape(32, 32)
+            continue
+        assert magic == 0x31533346, hex(magic)
+        rec = {"strand": i32(), "score_only": i32(), "dna_len": i32()}
+        rec["frames"] = [raw(i32(), np.int8) for _ in range(3)]
+        rec["targets"] = []
+        for _ in range(i32()):
+            t = {"target_idx": i32(), "d_begin": i32(), "d_end": i32(), "cols": i32()}
+            t["seq"] = raw(i32(), np.int8)
+            rec["targets"].append(t)
+        rec["hsps"] = []
+        for _ in range(i32()):
+            h = {k: i32() for k in F3_HSP_FIELDS}
+            h["evalue"], h["bit_score"] = f64(), f64()
+            h["transcript"] = raw(i32(), np.uint8)
+            rec["hsps"].append(h)
+        recs.append(rec)
+    return hdr, recs
