@@ -152,7 +152,7 @@ extern "C" int dmnd_device_count(void)
 namespace { __global__ void init_marker_kernel(int* p) { if (p) *p = 1; } }
 
 extern "C" hipError_t dmnd_touch_bias(hipStream_t), dmnd_touch_gapped(hipStream_t), dmnd_touch_mask(hipStream_t), dmnd_touch_seed(hipStream_t),
-	dmnd_touch_swipe16(hipStream_t), dmnd_touch_swipe(hipStream_t);
+	dmnd_touch_swipe16(hipStream_t), dmnd_touch_swipe(hipStream_t), dmnd_touch_frameshift(hipStream_t);
 
 extern "C" int dmnd_init(int device)
 {
@@ -172,7 +172,7 @@ extern "C" int dmnd_init(int device)
 	HIP_TRY(hipDeviceSynchronize());
 	lap("first kernel (api)");
 	struct { const char* name; hipError_t (*fn)(hipStream_t); } units[] = { { "mask", dmnd_touch_mask }, { "seed", dmnd_touch_seed }, { "bias", dmnd_touch_bias },
-		{ "swipe16", dmnd_touch_swipe16 }, { "swipe", dmnd_touch_swipe }, { "gapped", dmnd_touch_gapped } };
+		{ "swipe16", dmnd_touch_swipe16 }, { "swipe", dmnd_touch_swipe }, { "gapped", dmnd_touch_gapped }, { "frameshift", dmnd_touch_frameshift } };
 	for (auto& u : units) {
 		HIP_TRY(u.fn(nullptr));
 		if (trace) { HIP_TRY(hipDeviceSynchronize()); lap(u.name); }

@@ -56,6 +56,11 @@ HSP_DTYPE = np.dtype([("score", "<i4"), ("q_begin", "<i4"), ("q_end", "<i4"), ("
                       ("length", "<i4"), ("identities", "<i4"), ("mismatches", "<i4"), ("positives", "<i4"),
                       ("gap_openings", "<i4"), ("gaps", "<i4"), ("transcript_len", "<i4"), ("transcript_off", "<i8")],
                      align=True)
+FS_TARGET_DTYPE = np.dtype([("frame_off", "<i8", (3,)), ("target_off", "<i8"), ("frame_len", "<i4", (3,)), ("target_len", "<i4"), ("d_begin", "<i4"),
+                            ("d_end", "<i4"), ("cols", "<i4"), ("strand", "<i4"), ("dna_len", "<i4"), ("group", "<i4")], align=True)
+FS_HSP_DTYPE = np.dtype([(n, "<i4") for n in "score frame q_begin q_end s_begin s_end read_begin read_end length identities mismatches positives "
+                         "gap_openings gaps transcript_len max_col".split()] + [("transcript_off", "<i8")], align=True)
+assert FS_TARGET_DTYPE.itemsize == 72 and FS_HSP_DTYPE.itemsize == 72
 HOST_TARGET_DTYPE = np.dtype([("seq", "<u8"), ("len", "<i4"), ("d_begin", "<i4"), ("d_end", "<i4"), ("matrix", "<u8")], align=True)
 assert DP_TARGET_DTYPE.itemsize == 40 and HSP_DTYPE.itemsize == 56 and HOST_TARGET_DTYPE.itemsize == 32
 
@@ -72,7 +77,7 @@ EXPORTS = ["dmnd_abi_version", "dmnd_last_error", "dmnd_default_params", "dmnd_c
            "dmnd_seed_params_set_query_indexed", "dmnd_auto_query_indexed", "dmnd_set_motif_table", "dmnd_motif_table_size",
            "dmnd_soft_mask_block", "dmnd_output_fields", "dmnd_format_fields", "dmnd_format_pairwise_intro", "dmnd_format_pairwise",
            "dmnd_format_paf", "dmnd_device_count", "dmnd_set_top_percent", "dmnd_join_blocks_top", "dmnd_set_filters", "dmnd_format_sam", "dmnd_set_query_source_lengths", "dmnd_format_fields_unaligned", "dmnd_format_fields_header", "dmnd_set_query_index_reuse", "dmnd_set_no_self_hits", "dmnd_matrix_params", "dmnd_masking_lambda", "dmnd_translate_opts", "dmnd_set_extension_mode", "dmnd_format_xml_header", "dmnd_format_xml_query_intro", "dmnd_format_xml", "dmnd_format_xml_query_epilog", "dmnd_format_daa_header", "dmnd_format_daa_query", "dmnd_format_daa_match", "dmnd_seg_ranges", "dmnd_seg_mask_block", "dmnd_seg_lnfact", "dmnd_daa_match_read", "dmnd_hsp_from_transcript", "dmnd_set_format_flags", "dmnd_host_alloc", "dmnd_host_free", "dmnd_share_block", "dmnd_init", "dmnd_seed_reserve", "dmnd_mask_sequences", "dmnd_set_max_hsps", "dmnd_rank_targets", "dmnd_rank_update", "dmnd_set_global_ranking",
-           "dmnd_upload_matrices", "dmnd_cbs_composition", "dmnd_cbs_rule", "dmnd_cbs_target_matrix", "dmnd_cbs_ideal_lambda"]
+           "dmnd_upload_matrices", "dmnd_frameshift_swipe", "dmnd_cbs_composition", "dmnd_cbs_rule", "dmnd_cbs_target_matrix", "dmnd_cbs_ideal_lambda"]
 
 
 def set_motif_table(codes):
@@ -144,6 +149,7 @@ def load():
         lib.dmnd_translate.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
         lib.dmnd_last_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
         lib.dmnd_upload_matrices.argtypes = [v, v, ctypes.c_int64]
+        lib.dmnd_frameshift_swipe.argtypes = [v, v, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, v, v, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
         lib.dmnd_cbs_ideal_lambda.restype = ctypes.c_double
         lib.dmnd_cbs_ideal_lambda.argtypes = [ctypes.POINTER(Params)]
         lib.dmnd_cbs_composition.argtypes = [v, ctypes.c_int32, v, ctypes.POINTER(ctypes.c_int32)]
@@ -623,6 +629,18 @@ class Context:
         """Alias block `which` of the context `src` (no copy; `src` must stay alive): dmnd_share_block."""
         self.lib.dmnd_share_block.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         self._check(self.lib.dmnd_share_block(self.h, int(which), src.h))
+
+    def frameshift_swipe(self, items, score_only, frame_shift=15, channels=16, with_transcripts=True):
+        """banded_3frame_swipe for many (query strand, target) items (FS_TARGET_DTYPE) -> (FS_HSP_DTYPE[], transcript bytes or None)."""
+        items = np.ascontiguousarray(items, dtype=FS_TARGET_DTYPE)
+        out = np.zeros(len(items), dtype=FS_HSP_DTYPE)
+        tr, used = None, ctypes.c_int64(0)
+        if not score_only and with_transcripts:
+            tr = np.zeros(int((2 * items["target_len"].astype(np.int64) + items["frame_len"][:, 0] + 65).sum()) + 16, np.uint8)
+        self._check(self.lib.dmnd_frameshift_swipe(self.h, items.ctypes.data, len(items), int(bool(score_only)), int(frame_shift), int(channels),
+                                                   out.ctypes.data, tr.ctypes.data if tr is not None else None, tr.size if tr is not None else 0,
+                                                   ctypes.byref(used)))
+        return out, (tr[:used.value] if tr is not None else None)
 
     def upload_matrices(self, matrices):
         """n composition-adjusted matrices (int8[n, 32, 32]) for the items whose cbs_off is -2 - number."""

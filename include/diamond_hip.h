@@ -163,6 +163,39 @@ int dmnd_upload_matrices(dmnd_ctx* ctx, const int8_t* matrices, int64_t n);
 int dmnd_banded_swipe(dmnd_ctx* ctx, const dmnd_dp_target* items, int64_t n, int mode, uint32_t hsp_values,
 	dmnd_hsp* out, uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used);
 
+/* -- three-frame banded sweep of frameshift alignment (blastx -F): replaces the dispatch point banded_3frame_swipe
+ *    (src/dp/dp.h:296, src/dp/swipe/banded_3frame_swipe.cpp:597-647) ------------------------------------------------ */
+/* One work item = one DpTarget of a banded_3frame_swipe call together with the query strand of that call. */
+typedef struct {
+	int64_t frame_off[3];   /* the strand's frames 0, 1, 2 (TranslatedSequence::get_strand): offsets into the DMND_QUERY block */
+	int64_t target_off;     /* first target letter, offset into the DMND_TARGET block */
+	int32_t frame_len[3];
+	int32_t target_len;
+	int32_t d_begin, d_end; /* the target's band [d_begin, d_end) in query positions, diagonal = i - j */
+	int32_t cols;           /* DpTarget::cols as the caller's constructor left it (the legacy pipeline passes qlen = 0: dp.h:47-52,
+	                           legacy/banded_swipe_pipeline.cpp:70-76): only the batching order of the score-only pass reads it */
+	int32_t strand;         /* 0 = forward, 1 = reverse */
+	int32_t dna_len;        /* length of the read (coordinates of the results) */
+	int32_t group;          /* items of one banded_3frame_swipe call (one query strand) carry one id and are consecutive */
+} dmnd_fs_target;
+/* The Hsp fields a call fills (banded_3frame_swipe.cpp:345-414). Score-only: score, frame (0 / 3), q_begin, q_end, read_begin,
+ * read_end (the reference's estimate from the end column), max_col. Traceback: everything; transcript = PackedOperation codes with
+ * the frameshift operations (basic/packed_transcript.h:26,81-88), 0-terminated, at transcript_off of the caller's arena. */
+typedef struct {
+	int32_t score, frame;                        /* frame 0 - 5: strand * 3 + frame of the first aligned query position */
+	int32_t q_begin, q_end, s_begin, s_end;      /* query_range (positions in their frames) / subject_range, end exclusive */
+	int32_t read_begin, read_end;                /* query_source_range: the alignment's interval of the read */
+	int32_t length, identities, mismatches, positives, gap_openings, gaps;
+	int32_t transcript_len, max_col;
+	int64_t transcript_off;                      /* -1: none */
+} dmnd_fs_hsp;
+/* Sweeps n items. score_only != 0: the items of a group are ordered and swept `channels` at a time on one band geometry, as the
+ * reference's int16 vectors do (16 channels with AVX2, 8 with SSE4.1: its results depend on that width; pass what the reference
+ * build you compare with uses); a score of 65535 or more is repeated alone. score_only == 0: every item on its own band, with the
+ * walk back. frame_shift = the -F penalty. Results in input order; no e-value cut is applied (the caller's report_cutoff). */
+int dmnd_frameshift_swipe(dmnd_ctx* ctx, const dmnd_fs_target* items, int64_t n, int score_only, int frame_shift, int channels,
+	dmnd_fs_hsp* out, uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used);
+
 /* Same computation on caller-owned HOST sequences -- the literal shape of the reference call
  * (one query, its DpTargets as pointer+length): stages the letters into HBM, then runs the batch. */
 typedef struct {
