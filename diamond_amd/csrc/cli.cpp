@@ -463,6 +463,10 @@ struct Options {
 	int stop_match_score = 1;       // --stop-match-score: score of a stop codon against a stop codon (Scores ctor, stats/score_matrix.h:42-43)
 	uint32_t format_flags = 0;      // --xml-blord-format, --no-parse-seqids, --sam-query-len
 	bool compress = false;          // --compress 1: gzip output, ".gz" appended to the file name
+	int frameshift = 0;             // -F / --frameshift: frame shift penalty, 0 = disabled (config.frame_shift)
+	bool range_culling = false;     // --range-culling (config.query_range_culling); --long-reads = --range-culling --top 10 -F 15
+	double range_cover = 50.0;      // --range-cover
+	bool long_reads = false;
 	int strands = 3, gencode = 1, min_orf = 0;      // --strand (mask: 1 plus, 2 minus), --query-gencode, --min-orf: translated searches
 	int unal = -1;                  // --unal: report queries without alignments (-1 = the format's default)
 	std::string header;             // --header [simple|verbose|0]
@@ -540,6 +544,10 @@ Options parse(int argc, char** argv)
 		}
 		else if (a == "--query-gencode") o.gencode = std::atoi(need(i).c_str());
 		else if (a == "-l" || a == "--min-orf") o.min_orf = std::atoi(need(i).c_str());
+		else if (a == "-F" || a == "--frameshift") { o.frameshift = std::atoi(need(i).c_str()); if (o.frameshift < 0) throw std::runtime_error("Invalid value for --frameshift."); }
+		else if (a == "--range-culling") o.range_culling = true;
+		else if (a == "--range-cover") o.range_cover = std::atof(need(i).c_str());
+		else if (a == "--long-reads") o.long_reads = true;
 		else if (a == "--gapopen") o.gap_open = std::atoi(need(i).c_str());
 		else if (a == "--gapextend") o.gap_extend = std::atoi(need(i).c_str());
 		else if (a == "--unal") { o.unal = std::atoi(need(i).c_str()); if (o.unal != 0 && o.unal != 1) throw std::runtime_error("Permitted values for --unal: 0, 1"); }
@@ -581,6 +589,11 @@ Options parse(int argc, char** argv)
 		else throw std::runtime_error("Invalid option: " + a);
 	}
 	if (o.top >= 0.0 && o.k_given) throw std::runtime_error("--top and -k/--max-target-seqs are mutually exclusive.");      // basic/config.cpp:674-675
+	if (o.long_reads) {                                       // basic/config.cpp:680-686
+		o.range_culling = true;
+		if (o.top < 0.0) o.top = 10.0;
+		if (o.frameshift == 0) o.frameshift = 15;
+	}
 	return o;
 }
 
@@ -676,6 +689,10 @@ int run_blastp(const Options& o)
 	// length-ratio cutoff inside the seed stage: run/config.cpp:156-159) -- a clustering path that is not part of this build
 	if (o.command == "blastp" && o.query_cover >= 50 && o.query_cover == o.subject_cover)
 		throw std::runtime_error("--query-cover equal to --subject-cover (>= 50) selects the reference's mutual-coverage search, which is not part of this build; use different values");
+	// basic/config.cpp:688, :822-825: frameshift alignment is for translated queries, range culling for frameshift alignment
+	if (o.global_ranking > 0 && (o.range_culling || o.frameshift > 0)) throw std::runtime_error("Global ranking is not supported in this mode.");
+	if (o.frameshift != 0 && o.command == "blastp") throw std::runtime_error("Frameshift alignments are only supported for translated searches.");
+	if (o.range_culling && o.frameshift == 0) throw std::runtime_error("Query range culling is only supported in frameshift alignment mode (option -F).");
 	// basic/config.cpp:688, :700: what the matrix-adjust modes of --comp-based-stats exclude
 	if (o.cbs >= 2 && o.global_ranking > 0) throw std::runtime_error("Global ranking is not supported in this mode.");
 	if (o.cbs >= 2 && o.command == "blastx") throw std::runtime_error("This mode of composition based stats is not supported for translated searches.");
@@ -741,13 +758,23 @@ int run_blastp(const Options& o)
 		fmt = FMT_FIELDS;
 	}
 	if (tab_extras && fmt != FMT_FIELDS && !o.header.empty() && o.header != "0") throw std::runtime_error("--header is only available for the tabular format");
+	if (o.frameshift > 0) {
+		// A frameshift alignment changes frame: the formats and fields of this build that walk the query letters along the transcript
+		// read ONE frame. What is printed: the tabular format with the fields that come from the record.
+		if (fmt != FMT_TAB && fmt != FMT_FIELDS) throw std::runtime_error("Frameshift alignments (-F) are printed in the tabular format (-f 6) only in this build.");
+		for (int32_t id : field_ids)
+			if (id == DMND_F_SSEQ || id == DMND_F_BTOP || id == DMND_F_QSEQ_GAPPED || id == DMND_F_SSEQ_GAPPED || id == DMND_F_CIGAR || id == DMND_F_QSEQ_TRANSLATED)
+				throw std::runtime_error("Frameshift alignments (-F): the fields sseq, btop, qseq_gapped, sseq_gapped, cigar and qseq_translated are not available in this build.");
+	}
 	// which formats report queries without alignments: pairwise, PAF and SAM by default (DEFAULT_REPORT_UNALIGNED), tabular with --unal 1
 	// (DAA files never list unaligned queries, whatever --unal says: output/join_blocks.cpp:302,365)
 	const bool report_unal = fmt != FMT_DAA && (o.unal == 1 || (o.unal == -1 && (fmt == FMT_PAIRWISE || fmt == FMT_PAF || fmt == FMT_SAM || fmt == FMT_XML)));
 	bool want_full_sseq = false;
 	for (int32_t id : field_ids) want_full_sseq |= id == DMND_F_FULL_SSEQ;
 	auto t0 = std::chrono::steady_clock::now();
-	if (blastx) read_dna_fasta_translated(o.query, q_all, source_len, read_ids, reads, o.gencode, o.strands, o.min_orf);
+	// with a frameshift penalty every open reading frame counts, however short (Config::min_orf_len, basic/config.h:413-421)
+	const int min_orf = o.min_orf > 0 ? o.min_orf : o.frameshift != 0 ? 1 : 0;
+	if (blastx) read_dna_fasta_translated(o.query, q_all, source_len, read_ids, reads, o.gencode, o.strands, min_orf);
 	else read_fasta(o.query, q_all);
 	std::string dbpath = o.db;
 	if (!std::ifstream(dbpath).good() && std::ifstream(dbpath + ".dmnd").good()) dbpath += ".dmnd";
@@ -767,7 +794,7 @@ int run_blastp(const Options& o)
 	for (size_t i = 0; i < n_queries; ++i) {
 		if (!blastx) { q_units[i] = q_all.limits[i + 1] - q_all.limits[i] - 1; continue; }
 		// Block::push_back counts the letters of the ORFs that survive find_orfs (data/block/block.cpp:88-100)
-		const int l0 = (int)(q_all.limits[i * 6 + 1] - q_all.limits[i * 6] - 1), min_len = o.min_orf > 0 ? o.min_orf : l0 < 30 ? 1 : l0 < 100 ? 20 : 40;
+		const int l0 = (int)(q_all.limits[i * 6 + 1] - q_all.limits[i * 6] - 1), min_len = min_orf > 0 ? min_orf : l0 < 30 ? 1 : l0 < 100 ? 20 : 40;
 		int64_t n = 0;
 		for (size_t f = 0; f < 6; ++f) {
 			if (!(o.strands & (f < 3 ? 1 : 2))) continue;             // frames of a strand that is not searched hold no ORF letters (block.cpp:92-99)
@@ -834,6 +861,7 @@ int run_blastp(const Options& o)
 		chk(dmnd_set_filters(c, o.min_id, o.query_cover, o.subject_cover, o.min_score));
 		chk(dmnd_set_comp_based_stats(c, o.cbs));
 		chk(dmnd_set_query_contexts(c, blastx ? 6 : 1));
+		chk(dmnd_set_frameshift(c, o.frameshift, o.range_culling ? 1 : 0, o.range_cover, 16));
 		chk(dmnd_set_sensitivity(c, sens));
 		// global ranking extends its targets over the full matrix (search/setup.cpp:377-389)
 		if (o.global_ranking > 0 && o.ext != DMND_EXT_DEFAULT && o.ext != DMND_EXT_FULL) throw std::runtime_error("Global ranking only supports full matrix extension.");
@@ -877,7 +905,7 @@ int run_blastp(const Options& o)
 	}
 	// query-indexed + masking: the reference masks a target only when the extension stage loads it (lazy masking,
 	// extend.cpp:168-181; run/double_indexed.cpp:300), i.e. the seed stage sees the unmasked reference block
-	const bool lazy_masking = algo == 1 && (tantan || seg);
+	const bool lazy_masking = algo == 1 && (tantan || seg) && o.frameshift == 0;
 
 	Sink out;
 	{

@@ -136,6 +136,10 @@ struct dmnd_ctx {
 	int comp_based_stats = 1;                  // config.comp_based_stats: 1 = Hauser bias (default), 0 = off
 	int query_contexts = 1;                    // align_mode.query_contexts: 6 for blastx (basic/basic.cpp:40-60)
 	int max_target_seqs = 25;                  // config.max_target_seqs (-k), basic/config.h:55
+	int frame_shift = 0;                       // config.frame_shift (-F): > 0 = frameshift alignment through the legacy pipeline (frameshift_host.hip)
+	bool range_culling = false;                // config.query_range_culling
+	double range_cover = 50.0;                 // config.query_range_cover
+	int fs_channels = 16;                      // int16 channels of the reference's three-frame score-only vectors (AVX2)
 	int max_hsps = 1;                          // config.max_hsps (--max-hsps): HSPs reported per target, 0 = all (dmnd_set_max_hsps)
 	int global_ranking = 0;                    // config.global_ranking_targets (--global-ranking): dmnd_set_global_ranking
 	dmnd::DevBuf alt_targets;                  // masked target copies of the alternative-HSP rounds (extend_host.hip)
@@ -174,6 +178,9 @@ int dmnd_swipe_shared(dmnd_ctx* work, const dmnd_ctx* blocks, const dmnd_dp_targ
 	dmnd_hsp* out, uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used);
 int dmnd_swipe_targets(dmnd_ctx* work, const dmnd_ctx* blocks, const int8_t* t, int64_t t_len, const dmnd_dp_target* items, int64_t n, int mode, uint32_t hsp_values,
 	dmnd_hsp* out, uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used);
+// frameshift_host.hip: the extension stage of blastx -F for the seed hits of a block pair (sorted by query)
+int dmnd_extend_frameshift(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata, const dmnd_seed_hit* hits, int64_t n_hits, int threads,
+	std::vector<dmnd_match>& out, uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used);
 // the first n_keep adjusted matrices of c stay, n more are appended (dmnd_upload_matrices = the same with n_keep = 0)
 int dmnd_append_matrices(dmnd_ctx* c, int64_t n_keep, const int8_t* matrices, int64_t n);
 // k-th of `split` auxiliary contexts of c (created on first use; owned and destroyed by c)

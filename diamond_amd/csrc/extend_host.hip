@@ -883,7 +883,7 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 					const double ev = c->evaluer.evalue(hsp.score, (unsigned)qlen, (unsigned)tlen);
 					if (!h.reported(hsp.score, ev)) return false;
 					if (adjust && h.ext_full && s.matrix_of(cd.target) >= 0 && ((int64_t)qlen * (int64_t)tlen <= h.max_swipe_dp || transcript)) adjusted_full_traceback = true;
-					m.query = q; m.target = cd.target; m.evalue = ev; m.bit_score = c->evaluer.bitscore(hsp.score);
+					m.query = q; m.target = cd.target; m.evalue = ev; m.bit_score = c->evaluer.bitscore(hsp.score); m.read_begin = m.read_end = 0;
 					m.ungapped_score = cd.ungapped; m.d_begin = d0; m.d_end = d1; m.frame = frame; m.hsp = hsp;
 					if (multi && h.ext_full) m.d_begin = m.d_end = 0;       // Hsp::d_begin of a full-matrix sweep (tie-break of Hsp::operator<)
 					return true;
@@ -1027,7 +1027,7 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 						if (k == 0 && it_alt[k][x].cbs_off <= -2) return fail(DMND_E_ARG, "Traceback with adjusted matrix not supported");
 						if (k == 0 && transcript) hsp.transcript_off += used; else { hsp.transcript_off = -1; if (k == 1) hsp.transcript_len = 0; }
 						dmnd_match m;
-						m.query = a.hs[0].query; m.target = a.target; m.evalue = ev; m.bit_score = c->evaluer.bitscore(hsp.score);
+						m.query = a.hs[0].query; m.target = a.target; m.evalue = ev; m.bit_score = c->evaluer.bitscore(hsp.score); m.read_begin = m.read_end = 0;
 						m.ungapped_score = a.hs[0].ungapped_score; m.d_begin = 0; m.d_end = 0; m.frame = f; m.hsp = hsp;      // (the full-matrix sweep leaves Hsp::d_begin / d_end at 0)
 						a.hs.push_back(m);
 						mask_range(a, m);
@@ -1160,6 +1160,17 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	const std::vector<int64_t>& ql = c->limits[DMND_QUERY];
 	const std::vector<int64_t>& tl = c->limits[DMND_TARGET];
 	if (ql.size() < 2 || tl.size() < 2) return fail(DMND_E_ARG, "dmnd_extend: blocks must be uploaded with limits");
+	if (c->frame_shift > 0) {
+		// frameshift alignment: the reference's legacy pipeline instead of Extension::extend (align/align.cpp:168-172)
+		if (c->global_ranking > 0) return fail(DMND_E_ARG, "Global ranking is not supported in this mode.");
+		if (cbs_matrix_adjust(c->comp_based_stats)) return fail(DMND_E_ARG, "This mode of composition based stats is not supported for translated searches.");
+		std::vector<dmnd_match> v;
+		if (int rc = dmnd_extend_frameshift(c, qdata, tdata, hits, n_hits, threads, v, transcript, transcript_cap, transcript_used)) return rc;
+		*n_out = (int64_t)v.size();
+		if ((int64_t)v.size() > cap) return fail(DMND_E_CAP, "dmnd_extend: output buffer too small");
+		if (!v.empty()) std::memcpy(out, v.data(), v.size() * sizeof(dmnd_match));
+		return DMND_OK;
+	}
 	HostCfg h;
 	make_cfg(c, h);
 	h.max_target_seqs = c->max_target_seqs;
@@ -1349,6 +1360,14 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 		int64_t off = 0;
 		for (const auto& v : parts) { std::copy(v.begin(), v.end(), out + off); off += (int64_t)v.size(); }
 	}
+	return DMND_OK;
+}
+
+extern "C" int dmnd_set_frameshift(dmnd_ctx* c, int penalty, int range_culling, double range_cover, int channels)
+{
+	if (!c || penalty < 0 || channels < 1 || range_cover < 0) return fail(DMND_E_ARG, "dmnd_set_frameshift: bad argument");
+	if (range_culling && penalty == 0) return fail(DMND_E_ARG, "Query range culling is only supported in frameshift alignment mode (option -F).");
+	c->frame_shift = penalty; c->range_culling = range_culling != 0; c->range_cover = range_cover; c->fs_channels = channels;
 	return DMND_OK;
 }
 
@@ -1649,7 +1668,11 @@ extern "C" int dmnd_format_tab_translated(const dmnd_match* m, const char* qseqi
 	if (m->frame < 0 || m->frame > 5) return fail(DMND_E_ARG, "dmnd_format_tab_translated: frame out of range");
 	const int b = m->hsp.q_begin, e = m->hsp.q_end;
 	int qstart, qend;
-	if (m->frame < 3) { qstart = m->frame + 3 * b + 1; qend = m->frame + 3 * e; }
+	if (m->read_end > m->read_begin) {                         // frameshift alignment: Hsp::query_source_range, oriented by the strand
+		if (m->frame < 3) { qstart = m->read_begin + 1; qend = m->read_end; }
+		else { qstart = m->read_end; qend = m->read_begin + 1; }
+	}
+	else if (m->frame < 3) { qstart = m->frame + 3 * b + 1; qend = m->frame + 3 * e; }
 	else { const int off = m->frame - 3; qstart = source_len - off - 3 * b; qend = source_len - off - 3 * e + 1; }
 	return format_tab_impl(m, qseqid, sseqid, qstart, qend, buf, cap);
 }

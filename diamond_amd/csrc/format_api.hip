@@ -130,6 +130,7 @@ void source_range(const dmnd_hsp_view& v, int& b, int& e)
 	const Frame f(v);
 	const dmnd_hsp& h = v.match->hsp;
 	if (!f.translated) { b = h.q_begin; e = h.q_end; return; }
+	if (v.match->read_end > v.match->read_begin) { b = v.match->read_begin; e = v.match->read_end; return; }      // frameshift alignment: the range is part of the record
 	if (f.forward) { b = f.offset + 3 * h.q_begin; e = f.offset + 3 * h.q_end; }
 	else { e = f.dna_len - f.offset - 3 * h.q_begin; b = f.dna_len - f.offset - 3 * h.q_end; }
 }
@@ -245,7 +246,7 @@ int64_t emit(const Out& o, char* buf, int64_t cap, const char* who)
 bool view_ok(const dmnd_hsp_view* v)
 {
 	return v && v->match && v->qtitle && v->stitle && v->qseq && v->match->frame >= 0 && v->match->frame <= 5 && (!v->source_seq || v->source_len > 0)
-		&& v->match->hsp.q_begin >= 0 && v->match->hsp.q_end <= v->qlen && v->match->hsp.s_begin >= 0 && v->match->hsp.s_end <= v->slen && v->match->hsp.length > 0;
+		&& v->match->hsp.q_begin >= 0 && (v->match->hsp.q_end <= v->qlen || v->match->read_end > v->match->read_begin /* frameshift alignment: q_end is a position of another frame */) && v->match->hsp.s_begin >= 0 && v->match->hsp.s_end <= v->slen && v->match->hsp.length > 0;
 }
 
 }  // namespace
@@ -682,6 +683,7 @@ extern "C" int dmnd_daa_match_read(const uint8_t* p, int64_t avail, int translat
 		return true;
 	};
 	if (!need(5)) return fail(DMND_E_ARG, "dmnd_daa_match_read: truncated record");
+	m->read_begin = m->read_end = 0;
 	std::memcpy(dict_id, p, 4);
 	const uint8_t flag = p[4];
 	o = 5;

@@ -42,11 +42,11 @@ class SeedParams(ctypes.Structure):
 SEED_HIT_DTYPE = np.dtype([("query", "<u4"), ("seed_offset", "<i4"), ("subject", "<i8"), ("score", "<i4"), ("pad", "<i4")])
 
 MATCH_DTYPE = np.dtype([("query", "<u4"), ("target", "<u4"), ("ungapped_score", "<i4"), ("d_begin", "<i4"), ("d_end", "<i4"),
-                        ("frame", "<i4"), ("evalue", "<f8"), ("bit_score", "<f8"),
+                        ("frame", "<i4"), ("read_begin", "<i4"), ("read_end", "<i4"), ("evalue", "<f8"), ("bit_score", "<f8"),
                         ("hsp", [("score", "<i4"), ("q_begin", "<i4"), ("q_end", "<i4"), ("s_begin", "<i4"), ("s_end", "<i4"),
                                  ("length", "<i4"), ("identities", "<i4"), ("mismatches", "<i4"), ("positives", "<i4"),
                                  ("gap_openings", "<i4"), ("gaps", "<i4"), ("transcript_len", "<i4"), ("transcript_off", "<i8")])])
-assert MATCH_DTYPE.itemsize == 96
+assert MATCH_DTYPE.itemsize == 104
 
 PLAN_DTYPE = np.dtype([("query", "<u4"), ("target", "<u4"), ("d_begin", "<i4"), ("d_end", "<i4"), ("ungapped_score", "<i4")])
 
@@ -77,7 +77,7 @@ EXPORTS = ["dmnd_abi_version", "dmnd_last_error", "dmnd_default_params", "dmnd_c
            "dmnd_seed_params_set_query_indexed", "dmnd_auto_query_indexed", "dmnd_set_motif_table", "dmnd_motif_table_size",
            "dmnd_soft_mask_block", "dmnd_output_fields", "dmnd_format_fields", "dmnd_format_pairwise_intro", "dmnd_format_pairwise",
            "dmnd_format_paf", "dmnd_device_count", "dmnd_set_top_percent", "dmnd_join_blocks_top", "dmnd_set_filters", "dmnd_format_sam", "dmnd_set_query_source_lengths", "dmnd_format_fields_unaligned", "dmnd_format_fields_header", "dmnd_set_query_index_reuse", "dmnd_set_no_self_hits", "dmnd_matrix_params", "dmnd_masking_lambda", "dmnd_translate_opts", "dmnd_set_extension_mode", "dmnd_format_xml_header", "dmnd_format_xml_query_intro", "dmnd_format_xml", "dmnd_format_xml_query_epilog", "dmnd_format_daa_header", "dmnd_format_daa_query", "dmnd_format_daa_match", "dmnd_seg_ranges", "dmnd_seg_mask_block", "dmnd_seg_lnfact", "dmnd_daa_match_read", "dmnd_hsp_from_transcript", "dmnd_set_format_flags", "dmnd_host_alloc", "dmnd_host_free", "dmnd_share_block", "dmnd_init", "dmnd_seed_reserve", "dmnd_mask_sequences", "dmnd_set_max_hsps", "dmnd_rank_targets", "dmnd_rank_update", "dmnd_set_global_ranking",
-           "dmnd_upload_matrices", "dmnd_frameshift_swipe", "dmnd_cbs_composition", "dmnd_cbs_rule", "dmnd_cbs_target_matrix", "dmnd_cbs_ideal_lambda"]
+           "dmnd_upload_matrices", "dmnd_frameshift_swipe", "dmnd_set_frameshift", "dmnd_cbs_composition", "dmnd_cbs_rule", "dmnd_cbs_target_matrix", "dmnd_cbs_ideal_lambda"]
 
 
 def set_motif_table(codes):

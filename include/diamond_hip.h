@@ -305,6 +305,8 @@ typedef struct {
 	uint32_t query, target;       /* query id (= block sequence id / query_contexts), target block id */
 	int32_t ungapped_score, d_begin, d_end;
 	int32_t frame;                /* query context of the HSP: 0 for blastp; 0-2 forward, 3-5 reverse frames for blastx (Hsp::frame) */
+	int32_t read_begin, read_end; /* frameshift alignment (blastx -F): Hsp::query_source_range, the alignment's interval of the read -- the HSP
+	                                 changes frame, so frame (that of its first position) and q_begin / q_end alone do not give it; else 0, 0 */
 	double evalue, bit_score;
 	dmnd_hsp hsp;
 } dmnd_match;
@@ -419,6 +421,14 @@ int dmnd_set_motif_table(const uint64_t* codes, int64_t n);
 int64_t dmnd_motif_table_size(void);
 int dmnd_soft_mask_block(dmnd_ctx* ctx, int which, int64_t* n_covered);
 
+/* Frameshift alignment of translated queries (-F PENALTY, config.frame_shift; --range-culling, --range-cover): dmnd_extend then runs
+ * the reference's legacy pipeline (align/legacy/banded_swipe_pipeline.cpp, query_mapper.cpp; entered at align/align.cpp:168) over
+ * the three-frame sweep (dmnd_frameshift_swipe) instead of Extension::extend. penalty 0 = off (the default). range_culling != 0:
+ * targets are culled per read range (RangeCulling, output/target_culling.h:112-160: a target is dropped when range_cover per cent
+ * of its alignments' read range is covered by -k better ones, or by better-scoring ones with --top) instead of per query.
+ * channels = the int16 vector width of the reference build whose score-only pass is to be reproduced (16: AVX2). Needs
+ * dmnd_set_query_contexts(6) and the read lengths (dmnd_set_query_source_lengths). */
+int dmnd_set_frameshift(dmnd_ctx* ctx, int penalty, int range_culling, double range_cover, int channels);
 /* --comp-based-stats (Stats::CBS, stats/cbs.h:112-196): 0 = none; 1 = Hauser composition bias (default; HauserCorrection,
  * stats/hauser_correction.cpp); 2 / 3 = Hauser bias, and a composition-adjusted scoring matrix for every target that NCBI's
  * conditional test selects; 4 = no bias, every target gets an adjusted matrix; 5 = no bias, every target gets either the full

@@ -1063,3 +1063,44 @@ def test_cli_comp_based_stats_matrix_adjust_matches_reference(tmp_path):
     for val in ("6", "9"):
         r2 = subprocess.run([CLI, "blastp"] + base + ["--comp-based-stats", val, "-o", str(tmp_path / "y.out")], capture_output=True, text=True)
         assert r2.returncode != 0 and "Permitted values" in r2.stderr + r2.stdout
+
+
+def test_cli_frameshift_matches_reference(tmp_path):
+    """blastx -F 15 (row f4): reads with single-base insertions and deletions; the reference's legacy pipeline (ungapped ranking,
+    score-only three-frame sweep + culling, traceback sweep, inner culling, global or range culling) over the three-frame sweep
+    kernels. Byte-identical to the reference binary: the committed goldens and fresh runs in several sensitivities, -k, --top,
+    --range-culling, --long-reads, filters, -F 5 / 30, one strand."""
+    g = os.path.join(ROOT, "tests", "golden")
+    base = ["blastx", "-q", os.path.join(g, "fs_reads.fna"), "-d", os.path.join(g, "fs_db.faa"), "-p", "4"]
+    for extra, name in ((["-F", "15"], "fs_f15.tsv"), (["-F", "15", "-k", "3"], "fs_k3.tsv"), (["-F", "15", "--range-culling", "--top", "10"], "fs_f15_rc.tsv")):
+        _run([CLI] + base + extra + ["-o", str(tmp_path / "hip.out")])
+        want, got = open(os.path.join(g, name)).read(), open(tmp_path / "hip.out").read()
+        if got != want:
+            a, b = set(want.splitlines()), set(got.splitlines())
+            raise AssertionError("%s: %d lines only in the golden, %d only in ours; e.g. %s | %s" % (name, len(a - b), len(b - a), sorted(a - b)[:2], sorted(b - a)[:2]))
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/diamond not built")
+    db, doff, q, qoff = synth.generate(150, members=8, queries=220, seed=81)
+    synth.write_fasta(str(tmp_path / "db.faa"), "t", db, doff)
+    dna, off = synth.back_translate(q, qoff, seed=82)
+    synth.write_dna_fasta(str(tmp_path / "reads.fna"), "r", *synth.indel_reads(dna, off, seed=83, deletion=0.004, insertion=0.004))
+    base = ["blastx", "-q", str(tmp_path / "reads.fna"), "-d", str(tmp_path / "db.faa"), "-p", "4"]
+    n_shift = 0
+    for extra in (["-F", "15"], ["-F", "15", "-k", "2"], ["-F", "15", "-k", "1", "--sensitive"], ["-F", "15", "--top", "5"], ["--long-reads"],
+                  ["-F", "15", "--range-culling", "-k", "2"], ["-F", "15", "--range-culling", "--range-cover", "20", "--top", "30"],
+                  ["-F", "5", "--fast"], ["-F", "30", "--max-hsps", "0"], ["-F", "15", "--strand", "minus"], ["-F", "15", "--id", "60", "--query-cover", "30"],
+                  ["-F", "15", "--masking", "0", "--algo", "1"], ["-F", "15", "-e", "1e-20", "--min-orf", "30"],
+                  ["-F", "15", "-f", "6", "qseqid", "sseqid", "qstart", "qend", "qframe", "sstart", "send", "score", "length", "nident", "gaps", "qcovhsp", "qstrand", "qlen"]):
+        _run([REF] + base + extra + ["-o", str(tmp_path / "ref.out")])
+        _run([CLI] + base + extra + ["-o", str(tmp_path / "hip.out")])
+        ref, got = open(tmp_path / "ref.out").read(), open(tmp_path / "hip.out").read()
+        assert len(ref) > 1000, extra
+        if got != ref:
+            a, b = set(ref.splitlines()), set(got.splitlines())
+            raise AssertionError("%s: %d lines only in the reference's output, %d only in ours; e.g. %s | %s" % (extra, len(a - b), len(b - a), sorted(a - b)[:2], sorted(b - a)[:2]))
+    # the refusals (basic/config.cpp:822-825)
+    for cmd, msg in ((["blastp", "-q", str(tmp_path / "db.faa"), "-d", str(tmp_path / "db.faa"), "-F", "15"], "Frameshift alignments are only supported for translated searches."),
+                     (base + ["--range-culling"], "Query range culling is only supported in frameshift alignment mode (option -F).")):
+        for binary in (REF, CLI):
+            r = subprocess.run([binary] + cmd + ["-o", str(tmp_path / "x.out")], capture_output=True, text=True)
+            assert r.returncode != 0 and msg in r.stderr + r.stdout, (binary, cmd)
