@@ -639,6 +639,27 @@ def main():
                                                  "frac": (bytes_seed + bytes_sw) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS / max(world, 1),
                                                  "note": "SURVEY 8(d): (bytes_seed + bytes_sw of the reference's data layout) / wall time of a step / (N x 8 TB/s); the joined-position "
                                                          "fingerprint term (P x 48 B) is left out (P is not counted on the device in --fast)"}
+        if world == 1 and NB == 1:
+            # What N database shards can and cannot shrink (strong scaling of the fixed job, one shard per rank): per step every rank
+            # indexes ALL queries and pays the launch floors of its stages whatever its shard's size, the reference stream, the
+            # pair filter and the extension shrink with the shard, and the ranks exchange their records (two all-to-alls of the
+            # per-query top-k, then the gather). Printed before any multi-GPU run so that the first SCALE file is a check.
+            sk = out["seed_kernel_ms"]
+            fixed = sk["index_queries"] + sk["mask_groups"] + 0.30      # + memsets / copies / launch floors of a step (profiles/r03_kernel_stats_C2.csv)
+            shrink = max(dt / args.steps * 1e3 - fixed, 0.0)
+            n_matches_step = int(n_matches_all)
+            def coll_ms(n):      # 2 x all_to_all_single (counts + records, then the gather): ~25 us latency each over xGMI + payload at ~50 GB/s per link
+                payload = 104.0 * int(n_matches_step) / n
+                return 4 * 0.025 + 2 * payload / 50e9 * 1e3
+            out["scaling_model"] = {
+                "what": "predicted ms per step of the database-sharded job on N GPUs = fixed + shrinking / N + collectives(N); measured at N = 1, to be checked against SCALE",
+                "fixed_ms": fixed, "shrinking_ms": shrink,
+                "fixed_parts": {"index_queries": sk["index_queries"], "mask_groups": sk["mask_groups"], "memsets_copies_launch_floors": 0.30},
+                "predicted_ms_per_step": {str(n): fixed + shrink / n + (coll_ms(n) if n > 1 else 0.0) for n in (1, 2, 4, 8)},
+                "predicted_speedup": {str(n): (dt / args.steps * 1e3) / (fixed + shrink / n + (coll_ms(n) if n > 1 else 0.0)) for n in (2, 4, 8)},
+                "host_cpu_ms_per_step": out.get("host_cpu_ms_per_step"),
+                "note": "Amdahl: the query index is built on every rank; with 16 host CPUs for 8 ranks the extension's host part (host_cpu_ms_per_step, "
+                        "mostly chaining and culling) is the other term that does not shrink per box"}
         if seed_params.n_shapes > 2:
             out["roofline"]["note"] += ("; with short seeds (weight < 10) this kernel also runs the Hamming filter of every joined (query, reference) "
                                         "position pair, so its launch time covers the join AND the stage-1 filter")

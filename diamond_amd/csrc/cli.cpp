@@ -581,8 +581,6 @@ Options parse(int argc, char** argv)
 		else if (a == "--ignore-warnings" || a == "--no-auto-append" || a == "--keep-temp-files") {}
 		else if (a == "--global-ranking" || a == "-g") { o.global_ranking = std::atoi(need(i).c_str()); if (o.global_ranking < 0) throw std::runtime_error("Invalid value for --global-ranking."); }
 		else if (a == "--max-hsps") { o.max_hsps = std::atoi(need(i).c_str()); if (o.max_hsps < 0) throw std::runtime_error("Invalid value for --max-hsps."); }
-		else if (a == "-F" || a == "--frameshift" || a == "--long-reads" || a == "--range-culling")
-			throw std::runtime_error(a + " (frameshift alignment / range culling) is not part of this build.");
 		else if (a == "--custom-matrix") throw std::runtime_error("--custom-matrix is not part of this build (the standard matrices of --matrix are).");
 		else if (a == "-g" || a == "--global-ranking" || a == "--swipe" || a == "--iterate" || a == "--approx-id" || a == "--taxonlist" || a == "--taxon-exclude" || a == "--seqidlist")
 			throw std::runtime_error(a + " is not part of this build.");
@@ -900,8 +898,9 @@ int run_blastp(const Options& o)
 		std::vector<uint64_t> codes;
 		uint64_t c;
 		while (f.read((char*)&c, 8)) codes.push_back(c);
-		if (codes.empty()) { std::cerr << "Warning: " << dir << "/motifs.bin not found (tools/make_motif_table.py); running as --motif-masking 0.\n"; motifs = false; }
-		else chk(dmnd_set_motif_table(codes.data(), (int64_t)codes.size()));
+		// without the table the default command line would silently differ from the reference's: that is an error, not a warning
+		if (codes.empty()) throw std::runtime_error("Motif masking is on (the default up to --sensitive) but " + dir + "/motifs.bin was not found: generate it with tools/make_motif_table.py, or pass --motif-masking 0.");
+		chk(dmnd_set_motif_table(codes.data(), (int64_t)codes.size()));
 	}
 	// query-indexed + masking: the reference masks a target only when the extension stage loads it (lazy masking,
 	// extend.cpp:168-181; run/double_indexed.cpp:300), i.e. the seed stage sees the unmasked reference block

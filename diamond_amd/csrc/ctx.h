@@ -125,6 +125,8 @@ struct dmnd_ctx {
 	// stage for seed generation only; soft_valid is dropped whenever the block changes
 	dmnd::DevBuf soft[2], motif_hit, motif_table;
 	bool soft_valid[2] = { false, false };
+	std::vector<uint64_t> motifs;              // dmnd_set_context_motif_table: this context's motif table instead of the process-wide one
+	bool own_motifs = false;
 	double mask_ms = 0.0;
 	double seed_ms[5] = { 0, 0, 0, 0, 0 };
 	// extension-stage statistics of the last dmnd_extend (extend_host.hip)

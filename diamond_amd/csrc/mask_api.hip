@@ -4,6 +4,7 @@
 #pragma clang fp contract(off)
 #include <algorithm>
 #include <cmath>
+#include <mutex>
 #include <vector>
 #include "ctx.h"
 #include "mask_kernels.h"
@@ -112,7 +113,9 @@ void likelihood_ratios(const int8_t* m8, float* lr)
 
 }
 
-namespace { std::vector<uint64_t> g_motifs; }
+// the process-wide motif table and the lock that makes a context's use of it a snapshot (dmnd_set_context_motif_table gives a
+// context a table of its own)
+namespace { std::vector<uint64_t> g_motifs; std::mutex g_motifs_mutex; }
 
 extern "C" double dmnd_masking_lambda(const dmnd_params* p)
 {
@@ -166,13 +169,28 @@ extern "C" double dmnd_seg_lnfact(uint32_t n) { return seg::lnfact()(n); }
 extern "C" int dmnd_set_motif_table(const uint64_t* codes, int64_t n)
 {
 	if (n < 0 || (n > 0 && !codes) || n > 8192) return fail(DMND_E_ARG, "dmnd_set_motif_table: at most 8192 motifs");
-	g_motifs.assign(codes, codes + n);
-	std::sort(g_motifs.begin(), g_motifs.end());
-	g_motifs.erase(std::unique(g_motifs.begin(), g_motifs.end()), g_motifs.end());
+	std::vector<uint64_t> v(codes, codes + n);
+	std::sort(v.begin(), v.end());
+	v.erase(std::unique(v.begin(), v.end()), v.end());
+	std::lock_guard<std::mutex> lock(g_motifs_mutex);
+	g_motifs.swap(v);
 	return DMND_OK;
 }
 
-extern "C" int64_t dmnd_motif_table_size(void) { return (int64_t)g_motifs.size(); }
+extern "C" int dmnd_set_context_motif_table(dmnd_ctx* c, const uint64_t* codes, int64_t n)
+{
+	if (!c || n < -1 || (n > 0 && !codes) || n > 8192) return fail(DMND_E_ARG, "dmnd_set_context_motif_table: at most 8192 motifs");
+	c->own_motifs = n >= 0;
+	c->motifs.clear();
+	if (n > 0) {
+		c->motifs.assign(codes, codes + n);
+		std::sort(c->motifs.begin(), c->motifs.end());
+		c->motifs.erase(std::unique(c->motifs.begin(), c->motifs.end()), c->motifs.end());
+	}
+	return DMND_OK;
+}
+
+extern "C" int64_t dmnd_motif_table_size(void) { std::lock_guard<std::mutex> lock(g_motifs_mutex); return (int64_t)g_motifs.size(); }
 
 extern "C" int dmnd_soft_mask_block(dmnd_ctx* c, int which, int64_t* n_covered)
 {
@@ -181,6 +199,10 @@ extern "C" int dmnd_soft_mask_block(dmnd_ctx* c, int which, int64_t* n_covered)
 	if (n_covered) *n_covered = 0;
 	c->soft_valid[which] = false;
 	if (which == DMND_QUERY) ++c->query_generation;
+	// the table of this call: the context's own, or a snapshot of the process-wide one
+	std::vector<uint64_t> snapshot;
+	if (!c->own_motifs) { std::lock_guard<std::mutex> lock(g_motifs_mutex); snapshot = g_motifs; }
+	const std::vector<uint64_t>& g_motifs = c->own_motifs ? c->motifs : snapshot;
 	if (g_motifs.empty()) return DMND_OK;                     // no table: nothing is soft-masked (as --motif-masking 0)
 	HIP_TRY(hipSetDevice(c->device));
 	hipStream_t st = c->stream;

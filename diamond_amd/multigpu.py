@@ -36,17 +36,18 @@ def _a2a_bytes(parts, device):
     return [recv[cuts[r]:cuts[r + 1]] for r in range(world)]
 
 
-def query_range_join(matches, n_queries, device, k=TOPK, root=0, own=False):
+def query_range_join(matches, n_queries, device, k=TOPK, root=0, own=False, force_exchange=False):
     """SURVEY.md 8(e).2's exchange for database shards. `matches`: this rank's records (all queries against its own shard(s),
     database-wide target ordinals). Step 1: all-to-all keyed by query range -- the records of queries [g Q/G, (g+1) Q/G)
     (`shard_range`) go to rank g, <= k x 96 B per query and shard. Step 2: rank g merges its 1/G of the queries with
     dmnd_join_blocks (the reference's join_query heap merge by JoinRecord::cmp_evalue + GlobalCulling,
     output/join_blocks.cpp:129-137,180-256). Step 3: the joined records travel once more, to `root`, whose concatenation in
     rank order is in query order. Returns (records of this rank's query range, all records on root | None elsewhere).
-    own=True: `matches` is a contiguous record array the caller hands over (it may be reordered in place: no defensive copy)."""
+    own=True: `matches` is a contiguous record array the caller hands over (it may be reordered in place: no defensive copy).
+    force_exchange=True: the collectives run even in a group of one rank (the RCCL path of a 1-GPU box, tests)."""
     from . import hip
     rec = np.ascontiguousarray(matches, dtype=hip.MATCH_DTYPE)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force_exchange):
         joined = hip.join_blocks(rec, k, copy=own is False)
         return joined, joined
     world, rank = dist.get_world_size(), dist.get_rank()

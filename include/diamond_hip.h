@@ -419,6 +419,10 @@ double dmnd_seg_lnfact(uint32_t n);
  * reference does (search/stage0.cpp:125-127). Uploading or masking a block drops its view. *n_covered = letters under motifs. */
 int dmnd_set_motif_table(const uint64_t* codes, int64_t n);
 int64_t dmnd_motif_table_size(void);
+/* dmnd_set_motif_table is process-wide (the reference's table is a global too); a context takes a snapshot of it, under a lock, when
+ * it soft-masks a block. A process that runs contexts with DIFFERENT tables gives each its own: n motifs for this context alone
+ * (n = 0: none, i.e. no soft masking on this context; n = -1: back to the process-wide table). */
+int dmnd_set_context_motif_table(dmnd_ctx* ctx, const uint64_t* codes, int64_t n);
 int dmnd_soft_mask_block(dmnd_ctx* ctx, int which, int64_t* n_covered);
 
 /* Frameshift alignment of translated queries (-F PENALTY, config.frame_shift; --range-culling, --range-cover): dmnd_extend then runs

@@ -58,7 +58,8 @@ def test_makedb_rejects_malformed_input(tmp_path, content, message):
 @pytest.mark.parametrize("args, message", [
     (["--max-hsps", "-2"], "Invalid value for --max-hsps"),
     (["--top", "10", "-k", "5"], "--top and -k/--max-target-seqs are mutually exclusive"),
-    (["-F", "15"], "frameshift alignment"),
+    (["-F", "15"], "Frameshift alignments are only supported for translated searches."),
+    (["--comp-based-stats", "7"], "Invalid value for --comp-based-stats. Permitted values: 0, 1, 2, 3, 4, 5."),
     (["--custom-matrix", "m.txt"], "--custom-matrix is not part of this build"),
     (["--iterate"], "--iterate is not part of this build"),
     (["--bogus-option"], "Invalid option: --bogus-option"),

@@ -40,6 +40,18 @@ def test_bench_line_and_parity_at_reduced_size(cfg):
         assert "8 blocks" in d["config"]["workload"]
 
 
+def test_c5_full_size_parity():
+    """BASELINE config C5 at its full size (100 000 queries, 5 000 000 sequences in 8 database blocks): the joined records of the
+    timed run equal the reference binary's output for the same files and the same block size, line for line (md5), inside the
+    bench run itself. The other full-size configurations are byte-compared in test_gpu_fullscale.py."""
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/diamond_tap not built")
+    d = _bench(["--config", "C5", "--steps", "2", "--warmup", "1", "--no-e2e"])
+    assert d["config"]["queries"] == 100000 and d["config"]["db_seqs"] == 5000000
+    assert d["parity_checked"] is True, d.get("parity")
+    assert d["parity"]["lines"] > 100000 and d["parity"]["records_md5"] == d["parity"]["reference_output_md5"]
+
+
 def test_bench_two_ranks_database_sharded_on_one_gpu():
     """`python bench.py --gpus 2` with NO torchrun: bench.py launches its two ranks itself (both on the one GPU of the box:
     DMND_BENCH_SHARE_GPU=1 maps them to cuda:0 and runs the record exchange over gloo)."""

@@ -80,3 +80,41 @@ def test_two_rank_database_shards_equal_sequential_blocks():
     want = hip.join_blocks(np.concatenate(parts), 25)
     assert len(want) > 300 and len(set(want["target"].tolist())) > 300
     assert ret[1] is None and ret[0] == want.tobytes()
+
+
+def test_query_range_join_over_rccl_world_size_1(tmp_path):
+    """The RCCL branch of multigpu.query_range_join on the box's one GPU: backend "nccl" (= RCCL on ROCm), a process group of one
+    rank, device tensors, all_to_all_single with split sizes -- forced to run although a single rank has nothing to exchange --
+    and the same records as the local join (and as a gloo group doing the same). Runs in a child process so that the process
+    group does not outlive the test."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from diamond_amd import hip, multigpu
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+rng = np.random.default_rng(3)
+rec = np.zeros(4000, hip.MATCH_DTYPE)
+rec["query"] = np.sort(rng.integers(0, 300, len(rec)))
+rec["target"] = rng.integers(0, 100000, len(rec))
+rec["evalue"] = 10.0 ** rng.integers(-80, -3, len(rec))
+rec["hsp"]["score"] = rng.integers(30, 900, len(rec))
+rec["bit_score"] = rec["hsp"]["score"] * 0.38
+local = hip.join_blocks(rec.copy(), 25)
+device = torch.device("cuda:0")
+torch.cuda.set_device(device)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+mine, full = multigpu.query_range_join(rec.copy(), 300, device, force_exchange=True)
+dist.barrier()
+dist.destroy_process_group()
+assert len(local) > 1000 and np.array_equal(mine, local) and np.array_equal(full, local), (len(mine), len(local))
+dist.init_process_group("gloo", rank=0, world_size=1)
+mine2, full2 = multigpu.query_range_join(rec.copy(), 300, torch.device("cpu"), force_exchange=True)
+dist.destroy_process_group()
+assert np.array_equal(mine2, local) and np.array_equal(full2, local)
+print("RCCL_OK", len(local))
+''' % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])

@@ -104,3 +104,56 @@ def test_masking_a_subset_of_sequences_leaves_the_others_alone(ctx):
         assert np.array_equal(host, want)
     with pytest.raises(Exception):
         ctx.mask_sequences(hip.TARGET, None, np.array([n_seq], np.int64))            # id outside the block
+
+
+def test_two_contexts_with_different_motif_tables():
+    """The motif table is process-wide by default (as the reference's is), read as a snapshot under a lock; a context can carry its
+    own (dmnd_set_context_motif_table). Two contexts with different tables, soft-masking the same block from two threads at
+    once, each cover exactly their own motifs."""
+    import threading
+    from diamond_amd import workload
+    rng = np.random.default_rng(9)
+
+    def code(letters):
+        c = 0
+        for x in letters:
+            c = c * 20 + int(x)
+        return c
+
+    motif_a, motif_b = rng.integers(0, 20, 8), rng.integers(0, 20, 8)
+    seqs = []
+    for k in range(400):
+        s = rng.integers(0, 20, int(rng.integers(60, 300))).astype(np.int8)
+        p = int(rng.integers(0, len(s) - 8))
+        s[p:p + 8] = motif_a if k % 2 == 0 else motif_b
+        seqs.append(s)
+    off = np.concatenate([[0], np.cumsum([len(s) for s in seqs])])
+    data, lim = workload.sequence_set(np.concatenate(seqs), off)
+    ca, cb, cg = hip.Context(), hip.Context(), hip.Context()
+    try:
+        for c in (ca, cb, cg):
+            c.upload_block(hip.QUERY, data, lim)
+        hip.set_motif_table([code(motif_a), code(motif_b)])          # process-wide: both
+        ca.set_motif_table([code(motif_a)])
+        cb.set_motif_table([code(motif_b)])
+        out = {}
+
+        def run(name, c):
+            out[name] = [c.soft_mask_block(hip.QUERY) for _ in range(20)]
+
+        th = [threading.Thread(target=run, args=(n, c)) for n, c in (("a", ca), ("b", cb), ("g", cg))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert len(set(out["a"])) == 1 and len(set(out["b"])) == 1 and len(set(out["g"])) == 1
+        na, nb, ng = out["a"][0], out["b"][0], out["g"][0]
+        assert na >= 200 * 8 and nb >= 200 * 8 and ng >= na + nb - 64 and na < ng and nb < ng      # (chance occurrences of a motif elsewhere: a handful at most)
+        ca.set_motif_table(None)
+        assert ca.soft_mask_block(hip.QUERY) == ng
+        cb.set_motif_table([])
+        assert cb.soft_mask_block(hip.QUERY) == 0
+    finally:
+        for c in (ca, cb, cg):
+            c.close()
+        hip.load_motif_table()
