@@ -285,8 +285,26 @@ static int mask_impl(dmnd_ctx* c, int which, int8_t* host_data, const int32_t* i
 		HIP_TRY(hipMemcpyAsync(c->mask_ids.p, ids, (size_t)n_ids * sizeof(int32_t), hipMemcpyHostToDevice, st));
 		HIP_TRY(hipMemcpyAsync(c->mask_soff.p, soff.data(), (size_t)n_ids * sizeof(int64_t), hipMemcpyHostToDevice, st));
 	}
-	if (int rc = c->mask_pb.ensure((size_t)scratch_letters * sizeof(float))) return rc;
-	if (int rc = c->mask_scale.ensure((size_t)(scratch_letters / 16 + n_work + 16) * sizeof(float))) return rc;
+	// DMND_TANTAN_WAVE=1: the round-2 kernel (one wavefront per sequence, one lane per repeat offset) instead of one lane per sequence
+	static const bool wave_kernel = [] { const char* e = std::getenv("DMND_TANTAN_WAVE"); return e && e[0] == '1'; }();
+	int64_t max_len = 0, total_len = 0;
+	if (!wave_kernel) {
+		if (ids) for (int64_t k = 0; k < n_ids; ++k) { const int64_t l = lim[(size_t)ids[k] + 1] - lim[(size_t)ids[k]] - 1; max_len = std::max(max_len, l); total_len += l; }
+		else { for (int64_t k = 0; k < n; ++k) max_len = std::max(max_len, lim[(size_t)k + 1] - lim[(size_t)k] - 1); total_len = raw; }
+	}
+	const int64_t lanes_floats = wave_kernel ? 0 : tantan_lanes_scratch(n_work, total_len, max_len), n_waves = (n_work + 63) / 64;
+	if (wave_kernel) {
+		if (int rc = c->mask_pb.ensure((size_t)scratch_letters * sizeof(float))) return rc;
+		if (int rc = c->mask_scale.ensure((size_t)(scratch_letters / 16 + n_work + 16) * sizeof(float))) return rc;
+	}
+	else {
+		if (n_work >= ((int64_t)1 << 32)) return fail(DMND_E_ARG, "dmnd_mask_block: more than 2^32 sequences");
+		if (int rc = c->mask_pb.ensure((size_t)lanes_floats * sizeof(float))) return rc;
+		if (int rc = c->sort_keys[0].ensure((size_t)n_work * sizeof(uint32_t))) return rc;
+		if (int rc = c->sort_keys[1].ensure((size_t)n_work * sizeof(uint32_t))) return rc;
+		if (int rc = c->sort_idx[0].ensure((size_t)n_work * sizeof(uint32_t))) return rc;
+		if (int rc = c->mask_scale.ensure((size_t)(2 * (n_waves + 1) + 1) * sizeof(int64_t))) return rc;
+	}
 	if (int rc = c->counters.ensure(64 * sizeof(unsigned long long))) return rc;
 	HIP_TRY(hipMemcpyAsync(c->mask_lr.p, lr.data(), lr.size() * sizeof(float), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemsetAsync(c->counters.p, 0, 2 * sizeof(unsigned long long), st));
@@ -306,7 +324,19 @@ static int mask_impl(dmnd_ctx* c, int which, int8_t* host_data, const int32_t* i
 	a.masked_pos = pos_cap ? c->mask_pos.as<uint32_t>() : nullptr;
 	a.n_pos = c->counters.as<unsigned long long>() + 1;
 	a.pos_cap = pos_cap;
+	TantanLanesArgs la;
+	if (!wave_kernel) {
+		la.t = a;
+		la.keys[0] = c->sort_keys[0].as<uint32_t>(); la.keys[1] = c->sort_keys[1].as<uint32_t>(); la.order = c->sort_idx[0].as<uint32_t>();
+		la.wave_off = c->mask_scale.as<int64_t>(); la.scratch = c->mask_pb.as<float>(); la.scratch_floats = lanes_floats;
+		la.sort_tmp = &c->sort_tmp; la.sort_tmp_bytes = &c->sort_tmp_bytes;
+		HIP_TRY(prepare_tantan_lanes(la, st));
+	}
 	HIP_TRY(hipEventRecord(c->ev0, st));
+	if (!wave_kernel) {
+		HIP_TRY(launch_tantan_lanes(la, st));
+	}
+	else
 	HIP_TRY(launch_tantan(a, st));
 	HIP_TRY(hipEventRecord(c->ev1, st));
 	unsigned long long cnt[2] = { 0, 0 };

@@ -24,6 +24,24 @@ struct TantanArgs {
 
 hipError_t launch_tantan(const TantanArgs& a, hipStream_t st);
 
+// Lane-per-sequence variant (round 4; mask_kernels.hip, tantan_lanes_kernel): the sequences are ordered by length on the device, a
+// wavefront takes 64 neighbours of that order and every lane runs the whole recurrence of its own sequence -- the 50 repeat-offset
+// states in registers, the sums in the lane -- so that no step crosses lanes. Work buffers are the caller's.
+struct TantanLanesArgs {
+	TantanArgs t;                 // p, data, limits, n_seqs, lr, n_masked, ids, masked_pos, n_pos, pos_cap as above; pb / scale / scratch_off unused
+	uint32_t* keys[2];            // n_seqs entries each: sequence lengths, unsorted and sorted (descending)
+	uint32_t* order;              // n_seqs entries: work index (into ids, or the sequence id itself) by descending length
+	int64_t* wave_off;            // 2 (n_waves + 1) + 1 entries: where a wavefront keeps its floats inside `scratch`; behind them the wavefronts' sizes, then a counter
+	float* scratch;               // scratch_floats entries
+	int64_t scratch_floats;
+	void** sort_tmp;              // rocPRIM scratch of the context (grown here when too small)
+	size_t* sort_tmp_bytes;
+};
+// floats of scratch that any order of the sequences needs: total_len = sum of the lengths, max_len = the longest
+inline int64_t tantan_lanes_scratch(int64_t n_seqs, int64_t total_len, int64_t max_len) { return (total_len + 64 * max_len) / 16 * 17 + 128 * ((n_seqs + 63) / 64) + 4096; }
+hipError_t prepare_tantan_lanes(const TantanLanesArgs& a, hipStream_t st);   // sizes rocPRIM's work space (launch_ does it too; this one runs no kernel)
+hipError_t launch_tantan_lanes(const TantanLanesArgs& a, hipStream_t st);
+
 // motif soft masking (mask_core.h): hit[p] = the 8-mer at block position p is in the sorted table; then per sequence the
 // qualifying covered stretches of `soft` (a copy of the block) are overwritten with the mask letter
 struct MotifArgs {

@@ -6,6 +6,11 @@
 // back 64 positions at a time. Float operation order = the reference's (mask_core.h); no contraction in this file.
 #pragma clang fp contract(off)      // before every definition of this translation unit, mask_core.h included
 #include "mask_kernels.h"
+#include <algorithm>
+#include <utility>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 
 namespace dmnd {
 
@@ -141,6 +146,361 @@ __global__ __launch_bounds__(256) void tantan_kernel(const TantanArgs a)
 	if (lane == 0 && n_masked) atomicAdd(a.n_masked, (unsigned long long)n_masked);
 }
 
+// ---- lane per sequence (round 4) ------------------------------------------------------------------------------------------
+// The kernel above spends its time between lanes: per letter and pass three ds_swizzle butterflies and eight v_readlane feed a chain
+// of scalar-fed adds, ~350 cycles of latency per step. Here a lane owns a whole sequence: its 50 offset states are 50 VGPRs and the
+// ordered sums are plain adds inside the lane, in the same order. What is left per step is 50 likelihood look-ups
+// L[own letter][history letter] and the arithmetic:
+//   * the history -- the last 52 letters of the lane's sequence -- lives in 14 VGPRs, four letters to a register. All lanes of a
+//     wavefront stand at the same position i, so which register and byte hold the letter of repeat offset K depends on i alone:
+//     the steps are unrolled four at a time and every (register, shift) pair is a compile-time constant; a new letter is one
+//     v_lshl_or, and every fourth step the 14 registers move up by one;
+//   * the table exists 32 times in LDS, copy c in bank c (entry (a, b) at float (a * 32 + b) * 32 + c; lane l reads copy l mod 32):
+//     64 lanes with arbitrary letters never collide in a bank, a ds_read_b32 costs its 2 cycles. 128 KiB of the CU's 160 KiB: one
+//     workgroup of 8 wavefronts per CU (the register budget allows 2 per SIMD) owns it and walks over the sequences;
+//   * the look-ups of step i + 1 depend on letters only, not on the recurrence: they are issued at the top of step i, so LDS latency
+//     lies behind the ~300 VALU instructions of a step instead of in front of them (with 2 wavefronts per SIMD nothing else hides it).
+// A history position that holds no letter (before the sequence, or past a shorter lane's end) holds letter 31, whose table column is
+// 0 here: the offset's state becomes 0, as `hp < 0` makes it above. Lengths differ, so the sequences are sorted by length first
+// (rocPRIM radix sort of 10^6 keys: ~0.1 ms) and a wavefront takes 64 neighbours; its scratch -- the background probability of every
+// position, the rescaling factors -- is interleaved over the lanes (one 256-byte line per wavefront access).
+enum { LANES_WAVES = 8, TABLE_COPIES = 32, WINDOW_REGS = 14, LISTED = 23 | 0x40 };      // LISTED: a masked letter whose position is not in the list yet (& 31 = the mask letter)
+
+// column (byte offset inside the lane's table copy) of the history letter of repeat offset K: position i - 1 - K, where the window
+// registers W[0], W[1], ... hold the letters newest dword first and position i - 1 sits in byte PH = (i - 1) & 3 of W[0]
+template<int PH, int K>
+__device__ __forceinline__ uint32_t history_col(const uint32_t* W)
+{
+	constexpr int q = K / 4, r = K % 4;
+	constexpr int reg = PH - r >= 0 ? q : q + 1, byte = PH - r >= 0 ? PH - r : PH - r + 4;
+	return __builtin_amdgcn_ubfe(W[reg], 8 * byte, 5) << 7;
+}
+__device__ __forceinline__ float lookup(const char* row, uint32_t col) { return *reinterpret_cast<const float*>(row + col); }
+
+// The 50 states, their look-ups and the transition constants are 25 register pairs each: (2 j, 2 j + 1) in one v_pk_mul_f32 /
+// v_pk_add_f32 (two IEEE single operations per instruction, each rounded like the scalar one). Written out as vectors: left to
+// itself the compiler pairs the scalar form too, but offset by one, and spends as many v_mov as arithmetic on re-pairing.
+typedef float pair_t __attribute__((ext_vector_type(2)));
+enum { PAIRS = TANTAN_WINDOW / 2 };
+
+// a group of 8 values x0 .. x7 = pairs v[0 .. 3]: ((x0 + x4) + (x1 + x5)) + ((x2 + x6) + (x3 + x7)), the order of ordered_sum()
+__device__ __forceinline__ float group_sum(const pair_t* v)
+{
+	const pair_t p = v[0] + v[2], q = v[1] + v[3];
+	return (p.x + p.y) + (q.x + q.y);
+}
+// the lane's sum of its 50 values in the order of ordered_sum()
+__device__ __forceinline__ float lane_ordered_sum(const pair_t* v)
+{
+	float s = 0.0f;
+#pragma unroll
+	for (int g = 0; g < 6; ++g) s = s + group_sum(v + 4 * g);
+	s = s + v[24].x;
+	s = s + v[24].y;
+	return s;
+}
+
+struct LaneConst { pair_t d[PAIRS]; float f2f, b2b, pre, p_mask; };
+
+// forward: look-ups of the NEXT step (position i + 1: its offset 0 is the letter of position i, its offsets 1 .. 49 are this step's
+// offsets 0 .. 48), W = the window of this step
+template<int PH, int... K>
+__device__ __forceinline__ void fwd_prefetch(pair_t* e_next, const uint32_t* W, const char* row_next, uint32_t letter_col, std::integer_sequence<int, K...>)
+{
+	e_next[0].x = lookup(row_next, letter_col);
+	((e_next[(K + 1) / 2][(K + 1) % 2] = lookup(row_next, history_col<PH, K>(W))), ...);
+}
+// (both write every e_next[k] exactly once and read none: they may reuse the registers of the step's own look-ups once those are consumed)
+// backward: look-ups of the step of position i - 1: its offsets 0 .. 48 are this step's offsets 1 .. 49, its offset 49 the entering letter
+template<int PH, int... K>
+__device__ __forceinline__ void bwd_prefetch(pair_t* e_next, const uint32_t* W, const char* row_next, uint32_t enter_col, std::integer_sequence<int, K...>)
+{
+	((e_next[K / 2][K % 2] = lookup(row_next, history_col<PH, K + 1>(W))), ...);
+	e_next[PAIRS - 1].y = lookup(row_next, enter_col);
+}
+
+__global__ void tantan_lengths_kernel(TantanLanesArgs a)
+{
+	const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= a.t.n_seqs) return;
+	const int64_t id = a.t.ids ? (int64_t)a.t.ids[k] : k;
+	const int64_t len = a.t.limits[id + 1] - a.t.limits[id] - 1;
+	a.keys[0][k] = (uint32_t)(len > 0 ? len : 0);
+}
+
+// a wavefront's scratch: (positions + rescaling points of its longest sequence) x 64 floats
+__global__ void tantan_wave_sizes_kernel(TantanLanesArgs a, int64_t n_waves)
+{
+	const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (w > n_waves) return;
+	const int64_t len = w < n_waves ? (int64_t)a.keys[1][w * 64] : 0;
+	a.wave_off[n_waves + 1 + w] = (len + (len + 15) / 16) * 64;      // sizes behind the offsets: the scan reads these, writes those
+	if (w == 0) a.wave_off[2 * (n_waves + 1)] = 0;                    // the ticket counter of tantan_lanes_kernel
+}
+
+// One wavefront = 64 sequences. The per-step state of a lane.
+struct Lanes {
+	pair_t f[PAIRS];
+	uint32_t W[WINDOW_REGS];
+	float b, f_sum;
+};
+
+// forward step of position i (phase PH = (i - 1) & 3): e_cur = its look-ups (issued a step ago), e_next receives those of i + 1
+template<int PH>
+__device__ __forceinline__ void fwd_step(Lanes& s, const LaneConst& c, pair_t* e, int i, int len, int ltr, int ltr_next, const float* L, int lane,
+	float* pb, float* scale)
+{
+	const auto first49 = std::make_integer_sequence<int, TANTAN_WINDOW - 1>();
+	const bool on = i < len;
+	const float b_old = s.b;
+	if (on) {
+		// tantan_fwd_cell for two offsets at a time: f' = (f * f2f + b_old * d) * e
+#pragma unroll
+		for (int k = 0; k < PAIRS; ++k) { const pair_t t1 = s.f[k] * c.f2f, t2 = c.d[k] * b_old; const pair_t tmp = t1 + t2; s.f[k] = tmp * e[k]; }
+	}
+	// the look-ups of position i + 1, into the registers the cells above have just read: their latency lies behind the sums below
+	fwd_prefetch<PH>(e, s.W, reinterpret_cast<const char*>(L + ltr_next * (32 * TABLE_COPIES) + (lane & 31)), (uint32_t)ltr << 7, first49);
+	if (on) {
+		const float f_sum_new = lane_ordered_sum(s.f);
+		{ const float t1 = b_old * c.b2b, t2 = s.f_sum * c.pre; s.b = t1 + t2; }
+		s.f_sum = f_sum_new;
+		if ((i & 15) == 15) {
+			const float r = __fdiv_rn(1.0f, s.b);
+			scale[(int64_t)(i >> 4) * 64] = r;
+			s.b = s.b * r;
+#pragma unroll
+			for (int k = 0; k < PAIRS; ++k) s.f[k] = s.f[k] * r;
+			s.f_sum = s.f_sum * r;
+		}
+		pb[(int64_t)i * 64] = s.b;
+	}
+	// the letter of position i joins the window: next byte of W[0], or a new register in front
+	if (PH == 3) {
+#pragma unroll
+		for (int j = WINDOW_REGS - 1; j > 0; --j) s.W[j] = s.W[j - 1];
+		s.W[0] = (uint32_t)ltr;
+	}
+	else s.W[0] |= (uint32_t)ltr << (8 * (PH + 1));
+}
+
+// backward step of position i; `enter` = the letter of position i - 51, which the window of position i - 1 gains
+template<int PH>
+__device__ __forceinline__ bool bwd_step(Lanes& s, const LaneConst& c, pair_t* e, int i, int len, int ltr_prev, int enter, const float* L, int lane,
+	float pbi, float scale_i, float zinv)
+{
+	const auto first49 = std::make_integer_sequence<int, TANTAN_WINDOW - 1>();
+	bool mask = false;
+	float C = 0.0f;
+	const bool on = i < len;
+	if (on) {
+		float pf;
+		{ const float x = pbi * s.b; const float u = x * zinv; pf = 1.0f - u; }
+		if ((i & 15) == 15) {
+			const float r = scale_i;
+			s.b = s.b * r;
+#pragma unroll
+			for (int k = 0; k < PAIRS; ++k) s.f[k] = s.f[k] * r;
+		}
+		C = c.pre * s.b;
+		mask = pf >= c.p_mask;
+		// vf = f * e first, kept in the state's own registers: it is all the cells need of the look-ups, whose registers then take
+		// the next step's
+#pragma unroll
+		for (int k = 0; k < PAIRS; ++k) s.f[k] = s.f[k] * e[k];
+	}
+	bwd_prefetch<PH>(e, s.W, reinterpret_cast<const char*>(L + ltr_prev * (32 * TABLE_COPIES) + (lane & 31)), (uint32_t)enter << 7, first49);
+	if (on) {
+		// tantan_bwd_cell for two offsets at a time: vt = vf * d, f' = vf * f2f + C
+		float tsum = 0.0f;
+#pragma unroll
+		for (int g = 0; g < 6; ++g) {
+			pair_t t[4];
+#pragma unroll
+			for (int x = 0; x < 4; ++x) { const pair_t vf = s.f[4 * g + x]; t[x] = vf * c.d[4 * g + x]; const pair_t t1 = vf * c.f2f; s.f[4 * g + x] = t1 + C; }
+			tsum = tsum + group_sum(t);
+		}
+		{ const pair_t vf = s.f[24]; const pair_t t = vf * c.d[24]; const pair_t t1 = vf * c.f2f; s.f[24] = t1 + C; tsum = tsum + t.x; tsum = tsum + t.y; }
+		{ const float t1 = c.b2b * s.b; s.b = t1 + tsum; }
+	}
+	// The window of position i - 1 (phase PH - 1): position i - 1 leaves at the front (phase 0: its whole register does), position
+	// i - 51 enters at the back as offset 49 -- history_col<PH - 1, 49>: register 13 byte 3 at phase 0, register 12 byte PH - 2 else.
+	// A register of the back fills from byte 3 down: it starts as W[13] and is W[12] after the next move.
+	if (PH == 0) {
+#pragma unroll
+		for (int j = 0; j < WINDOW_REGS - 1; ++j) s.W[j] = s.W[j + 1];
+		s.W[12] |= (uint32_t)enter << 16;
+	}
+	else if (PH == 1) s.W[13] = (uint32_t)enter << 24;
+	else s.W[12] |= (uint32_t)enter << (8 * (PH - 2));
+	return mask;
+}
+
+__global__ __launch_bounds__(LANES_WAVES * 64) void tantan_lanes_kernel(const TantanLanesArgs a)
+{
+	__shared__ float L[32 * 32 * TABLE_COPIES];
+	for (int i = threadIdx.x; i < 1024 * TABLE_COPIES; i += blockDim.x) { const int e = i >> 5; L[i] = (e & 31) == 31 ? 0.0f : a.t.lr[e]; }
+	__syncthreads();
+	const int lane = threadIdx.x & 63;
+	const int64_t n_waves = (a.t.n_seqs + 63) / 64;
+	LaneConst c;
+#pragma unroll
+	for (int k = 0; k < PAIRS; ++k) { c.d[k].x = a.t.p.d[2 * k]; c.d[k].y = a.t.p.d[2 * k + 1]; }
+	c.f2f = a.t.p.f2f; c.b2b = a.t.p.b2b; c.pre = a.t.p.p_repeat_end; c.p_mask = a.t.p.p_mask;
+	// Wavefronts draw tickets: the groups are ordered from the longest sequences down, so whoever is free takes the longest group
+	// left (longest-processing-time-first; 0.5 ms of 11.5 on a 3.0e8-letter block against a fixed stride).
+	unsigned long long* const ticket = reinterpret_cast<unsigned long long*>(a.wave_off + 2 * (n_waves + 1));
+	for (;;) {
+		unsigned long long drawn = 0;
+		if (lane == 0) drawn = atomicAdd(ticket, 1ull);
+		const int64_t wave = (int64_t)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(drawn >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)drawn));
+		if (wave >= n_waves) break;
+		const int64_t slot = wave * 64 + lane;
+		const bool have = slot < a.t.n_seqs;
+		const int64_t work = have ? (int64_t)a.order[slot] : 0;
+		const int64_t seq_id = a.t.ids ? (int64_t)a.t.ids[work] : work;
+		const int64_t base = a.t.limits[seq_id];
+		const int len = have ? (int)a.keys[1][slot] : 0;
+		const int max_len = __builtin_amdgcn_readfirstlane((int)a.keys[1][wave * 64]);      // sorted: lane 0 holds the wavefront's longest
+		if (max_len <= 0) continue;
+		int8_t* const seq = a.t.data + base;
+		float* const pb = a.scratch + a.wave_off[wave] + lane;                               // position i at pb[i * 64]
+		float* const scale = pb + (int64_t)max_len * 64;                                     // rescaling point i >> 4 at scale[(i >> 4) * 64]
+		// (always a load, from a clamped position, then a select: a load under a branch is waited for on the spot -- measured: 60 % of
+		// the wavefronts' cycles at s_waitcnt with the conditional form -- while these are requested a group of steps ahead of their use)
+		auto letter_at = [&](int p) { const int q = p < 0 ? 0 : p > len ? len : p; const int l = seq[q] & 31; return (p >= 0 && p < len) ? l : 31; };
+		Lanes s;
+		pair_t e[PAIRS];
+
+		// ---- forward: steps 4 g .. 4 g + 3 have the phases 3, 0, 1, 2 ----
+#pragma unroll
+		for (int j = 0; j < WINDOW_REGS; ++j) s.W[j] = 0x1f1f1f1fu;
+#pragma unroll
+		for (int k = 0; k < PAIRS; ++k) { s.f[k] = 0.0f; e[k] = 0.0f; }                // nothing before position 0: every look-up of step 0 is the empty column
+		s.b = 1.0f; s.f_sum = 0.0f;
+		// a lane's letters come through the vector cache one byte per step (64 different lines per wavefront load), each requested
+		// four steps before its use
+		// four letters per load (any alignment), positions p .. p + 3 clamped into the lane's sequence; byte x of the result = letter of
+		// position p + x or 31. The block has 256 bytes of padding on both sides, so a dword that starts up to 3 bytes before the
+		// sequence or ends behind its delimiter still lies inside the buffer.
+		auto letters4 = [&](int p) {
+			const int q = p < -3 ? -3 : p > len ? len : p;
+			uint32_t x;
+			__builtin_memcpy(&x, seq + q, 4);
+			x &= 0x1f1f1f1fu;
+			uint32_t r = 0;
+#pragma unroll
+			for (int y = 0; y < 4; ++y) r |= ((q == p && p + y >= 0 && p + y < len) ? (x >> (8 * y)) & 31u : 31u) << (8 * y);
+			return r;
+		};
+		uint32_t lw = letters4(0);
+		int l0 = (int)(lw & 31), l1 = (int)((lw >> 8) & 31), l2 = (int)((lw >> 16) & 31), l3 = (int)(lw >> 24);
+		for (int i = 0; i < max_len; i += 4) {
+			const uint32_t lw2 = letters4(i + 4);
+			const int l4 = (int)(lw2 & 31), l5 = (int)((lw2 >> 8) & 31), l6 = (int)((lw2 >> 16) & 31), l7 = (int)(lw2 >> 24);
+			fwd_step<3>(s, c, e, i, len, l0, l1, L, lane, pb, scale);
+			if (i + 1 < max_len) fwd_step<0>(s, c, e, i + 1, len, l1, l2, L, lane, pb, scale);
+			if (i + 2 < max_len) fwd_step<1>(s, c, e, i + 2, len, l2, l3, L, lane, pb, scale);
+			if (i + 3 < max_len) fwd_step<2>(s, c, e, i + 3, len, l3, l4, L, lane, pb, scale);
+			l0 = l4; l1 = l5; l2 = l6; l3 = l7;
+		}
+		// z = b * b2b + sum(f, 50) * p_repeat_end (SIMD::sum: the six groups accumulated lane-wise, then the tree, then 48, 49)
+		float zinv;
+		{
+			float acc[8];
+#pragma unroll
+			for (int j = 0; j < 8; ++j) {
+				float x = 0.0f;
+#pragma unroll
+				for (int g = 0; g < 6; ++g) x = x + s.f[4 * g + j / 2][j % 2];
+				acc[j] = x;
+			}
+			float total = ((acc[0] + acc[4]) + (acc[1] + acc[5])) + ((acc[2] + acc[6]) + (acc[3] + acc[7]));
+			total = total + s.f[24].x;
+			total = total + s.f[24].y;
+			const float t1 = s.b * c.b2b, t2 = total * c.pre;
+			zinv = __fdiv_rn(1.0f, t1 + t2);
+		}
+
+		// ---- backward: steps 4 g + 3 .. 4 g have the phases 2, 1, 0, 3; a lane joins when the common position reaches its last letter ----
+		const int top = (max_len - 1) | 3;
+		// window of position `top` (phase 2): positions top - 1 (byte 2 of W[0]) down to top - 50; the bytes of older positions enter later
+#pragma unroll
+		for (int j = 0; j < WINDOW_REGS; ++j) {
+			uint32_t x = 0;
+#pragma unroll
+			for (int y = 0; y < 4; ++y) {
+				const int p = top - 1 - (4 * j + 2 - y);                    // byte y of W[j]: position 4 (T - j) + y with position top - 1 at 4 T + 2
+				if (4 * j + 2 - y >= 0 && 4 * j + 2 - y < TANTAN_WINDOW) x |= (uint32_t)letter_at(p) << (8 * y);
+			}
+			s.W[j] = x;
+		}
+#pragma unroll
+		for (int k = 0; k < PAIRS; ++k) s.f[k] = c.pre;
+		s.b = c.b2b;
+		{
+			// look-ups of the first step, straight from the window
+			const char* row = reinterpret_cast<const char*>(L + letter_at(top) * (32 * TABLE_COPIES) + (lane & 31));
+			const auto all50 = std::make_integer_sequence<int, TANTAN_WINDOW>();
+			[&]<int... K>(std::integer_sequence<int, K...>) { ((e[K / 2][K % 2] = lookup(row, history_col<2, K>(s.W))), ...); }(all50);
+		}
+		int n_masked = 0;
+		const int8_t mark = a.t.masked_pos ? (int8_t)LISTED : (int8_t)23;
+		uint32_t pw = letters4(top - 4), nw = letters4(top - 54);
+		int p0 = (int)(pw >> 24), p1 = (int)((pw >> 16) & 31), p2 = (int)((pw >> 8) & 31), p3 = (int)(pw & 31);          // letters of the next steps' own positions: top - 1 .. top - 4
+		int n0 = (int)(nw >> 24), n1 = (int)((nw >> 16) & 31), n2 = (int)((nw >> 8) & 31), n3 = (int)(nw & 31);          // letters entering the window: top - 51 .. top - 54
+		// the forward pass' background probabilities (and the rescaling factor, needed by position 4 g + 3 when it is a multiple of 16
+		// less one) come from HBM: requested a whole group of four steps ahead, like the letters
+		auto pb_at = [&](int p) { const int q = p < 0 ? 0 : p >= max_len ? max_len - 1 : p; const float x = pb[(int64_t)q * 64]; return (p >= 0 && p < len) ? x : 0.0f; };
+		auto scale_at = [&](int p) { const int q = p < 0 ? 0 : p >= max_len ? max_len - 1 : p; const float x = scale[(int64_t)(q >> 4) * 64]; return (p >= 0 && p < len && (p & 15) == 15) ? x : 1.0f; };
+		float q0 = pb_at(top), q1 = pb_at(top - 1), q2 = pb_at(top - 2), q3 = pb_at(top - 3), sc = scale_at(top);
+		for (int i = top; i >= 0; i -= 4) {
+			pw = letters4(i - 8); nw = letters4(i - 58);
+			const int p4 = (int)(pw >> 24), p5 = (int)((pw >> 16) & 31), p6 = (int)((pw >> 8) & 31), p7 = (int)(pw & 31);
+			const int n4 = (int)(nw >> 24), n5 = (int)((nw >> 16) & 31), n6 = (int)((nw >> 8) & 31), n7 = (int)(nw & 31);
+			const float q4 = pb_at(i - 4), q5 = pb_at(i - 5), q6 = pb_at(i - 6), q7 = pb_at(i - 7), sc_next = scale_at(i - 4);
+			const bool m0 = bwd_step<2>(s, c, e, i, len, p0, n0, L, lane, q0, sc, zinv);
+			const bool m1 = bwd_step<1>(s, c, e, i - 1, len, p1, n1, L, lane, q1, 1.0f, zinv);
+			const bool m2 = bwd_step<0>(s, c, e, i - 2, len, p2, n2, L, lane, q2, 1.0f, zinv);
+			const bool m3 = bwd_step<3>(s, c, e, i - 3, len, p3, n3, L, lane, q3, 1.0f, zinv);
+			q0 = q4; q1 = q5; q2 = q6; q3 = q7; sc = sc_next;
+			// the four positions are final: the steps to come read positions below them only, from the window
+			// (with a list of the masked positions wanted, the letter carries LISTED until the wavefront writes its part of the list below)
+			if (m0 | m1 | m2 | m3) {
+				const bool mm[4] = { m0, m1, m2, m3 };
+#pragma unroll
+				for (int x = 0; x < 4; ++x)
+					if (mm[x]) { seq[i - x] = mark; ++n_masked; }
+			}
+			p0 = p4; p1 = p5; p2 = p6; p3 = p7; n0 = n4; n1 = n5; n2 = n6; n3 = n7;
+		}
+		// The list of masked positions: one reservation per wavefront -- a returning atomicAdd per masked letter on the one counter
+		// (~90 per microsecond on this chip) took 4.5 of the kernel's 10.8 ms on a block with 9.5e5 masked letters.
+		int incl = n_masked;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+		const int wave_masked = __builtin_amdgcn_readlane(incl, 63);
+		if (wave_masked == 0) continue;
+		if (lane == 0) atomicAdd(a.t.n_masked, (unsigned long long)wave_masked);
+		if (!a.t.masked_pos) continue;
+		unsigned long long first = 0;
+		if (lane == 0) first = atomicAdd(a.t.n_pos, (unsigned long long)wave_masked);
+		first = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(first >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+		unsigned long long at = first + (unsigned long long)(incl - n_masked);
+		if (n_masked)
+			for (int p = 0; p < len; p += 4) {
+				uint32_t x;
+				__builtin_memcpy(&x, seq + p, 4);
+#pragma unroll
+				for (int y = 0; y < 4; ++y)
+					if (p + y < len && ((x >> (8 * y)) & 0xffu) == (uint32_t)LISTED) {
+						seq[p + y] = 23;
+						if (at < a.t.pos_cap) a.t.masked_pos[at] = (uint32_t)(base + p + y);
+						++at;
+					}
+			}
+	}
+}
+
 }  // namespace
 
 // ---- motif soft masking ---------------------------------------------------------------------------------------------
@@ -178,6 +538,52 @@ hipError_t launch_motif_mask(const MotifArgs& a, hipStream_t st)
 	return hipGetLastError();
 }
 
+// rocPRIM's work space for the sort and the scan of launch_tantan_lanes (grown when too small: a hipMalloc, so before any timing)
+hipError_t prepare_tantan_lanes(const TantanLanesArgs& a, hipStream_t st)
+{
+	const int64_t n = a.t.n_seqs;
+	if (n <= 0) return hipSuccess;
+	const int64_t n_waves = (n + 63) / 64;
+	size_t need = 0, need2 = 0;
+	rocprim::counting_iterator<uint32_t> iota(0);
+	hipError_t e = rocprim::radix_sort_pairs_desc(nullptr, need, a.keys[0], a.keys[1], iota, a.order, (size_t)n, 0, 32, st);
+	if (e != hipSuccess) return e;
+	e = rocprim::exclusive_scan(nullptr, need2, a.wave_off + n_waves + 1, a.wave_off, (int64_t)0, (size_t)(n_waves + 1), rocprim::plus<int64_t>(), st);
+	if (e != hipSuccess) return e;
+	need = need > need2 ? need : need2;
+	if (need > *a.sort_tmp_bytes) {
+		if (*a.sort_tmp) (void)hipFree(*a.sort_tmp);
+		*a.sort_tmp = nullptr; *a.sort_tmp_bytes = 0;
+		e = hipMalloc(a.sort_tmp, need);
+		if (e != hipSuccess) return e;
+		*a.sort_tmp_bytes = need;
+	}
+	return hipSuccess;
+}
+
+hipError_t launch_tantan_lanes(const TantanLanesArgs& a, hipStream_t st)
+{
+	const int64_t n = a.t.n_seqs;
+	if (n <= 0) return hipSuccess;
+	const int64_t n_waves = (n + 63) / 64;
+	hipError_t e = prepare_tantan_lanes(a, st);
+	if (e != hipSuccess) return e;
+	tantan_lengths_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(a);
+	rocprim::counting_iterator<uint32_t> iota(0);
+	size_t n1 = *a.sort_tmp_bytes, n2 = *a.sort_tmp_bytes;
+	e = rocprim::radix_sort_pairs_desc(*a.sort_tmp, n1, a.keys[0], a.keys[1], iota, a.order, (size_t)n, 0, 32, st);
+	if (e != hipSuccess) return e;
+	tantan_wave_sizes_kernel<<<dim3((unsigned)((n_waves + 1 + 255) / 256)), dim3(256), 0, st>>>(a, n_waves);
+	e = rocprim::exclusive_scan(*a.sort_tmp, n2, a.wave_off + n_waves + 1, a.wave_off, (int64_t)0, (size_t)(n_waves + 1), rocprim::plus<int64_t>(), st);
+	if (e != hipSuccess) return e;
+	// one workgroup per CU (it takes the CU's LDS), each walking over the wavefront-sized groups from the longest sequences down
+	int dev = 0, cus = 256;
+	if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+	const int64_t groups = (n_waves + LANES_WAVES - 1) / LANES_WAVES;
+	tantan_lanes_kernel<<<dim3((unsigned)std::min<int64_t>(groups, cus)), dim3(LANES_WAVES * 64), 0, st>>>(a);
+	return hipGetLastError();
+}
+
 hipError_t launch_tantan(const TantanArgs& a, hipStream_t st)
 {
 	if (a.n_seqs <= 0) return hipSuccess;
@@ -189,5 +595,34 @@ hipError_t launch_tantan(const TantanArgs& a, hipStream_t st)
 }  // namespace dmnd
 
 // dmnd_init: the first launch of a kernel of this translation unit loads its code object onto the device
+// -- and the first launch of each kernel (rocPRIM's sort and scan stages among them) costs the host 0.5 - 1 ms more, 6 ms over the
+// chain of launch_tantan_lanes: run that chain once here, on one sequence of four letters.
 namespace { __global__ void touch_mask_kernel() {} }
-extern "C" hipError_t dmnd_touch_mask(hipStream_t st) { hipLaunchKernelGGL(touch_mask_kernel, dim3(1), dim3(64), 0, st); return hipGetLastError(); }
+extern "C" hipError_t dmnd_touch_mask(hipStream_t st)
+{
+	hipLaunchKernelGGL(touch_mask_kernel, dim3(1), dim3(64), 0, st);
+	using namespace dmnd;
+	enum { DATA = 0, LIMITS = 1024, LR = 2048, KEYS = LR + 4096, ORDER = KEYS + 64, OFF = ORDER + 64, COUNT = OFF + 64, SCRATCH = COUNT + 64 };
+	const int64_t floats = tantan_lanes_scratch(1, 4, 4);
+	char* buf = nullptr;
+	hipError_t e = hipMalloc(&buf, SCRATCH + (size_t)floats * sizeof(float));
+	if (e != hipSuccess) return e;
+	void* tmp = nullptr; size_t tmp_bytes = 0;
+	const int64_t lim[2] = { 256, 261 };
+	e = hipMemsetAsync(buf, 0, SCRATCH, st);
+	if (e == hipSuccess) e = hipMemcpyAsync(buf + LIMITS, lim, sizeof(lim), hipMemcpyHostToDevice, st);
+	if (e == hipSuccess) {
+		TantanLanesArgs a;
+		a.t = TantanArgs();
+		a.t.data = reinterpret_cast<int8_t*>(buf + DATA); a.t.limits = reinterpret_cast<const int64_t*>(buf + LIMITS); a.t.n_seqs = 1;
+		a.t.lr = reinterpret_cast<const float*>(buf + LR); a.t.n_masked = reinterpret_cast<unsigned long long*>(buf + COUNT);
+		a.keys[0] = reinterpret_cast<uint32_t*>(buf + KEYS); a.keys[1] = a.keys[0] + 8; a.order = reinterpret_cast<uint32_t*>(buf + ORDER);
+		a.wave_off = reinterpret_cast<int64_t*>(buf + OFF); a.scratch = reinterpret_cast<float*>(buf + SCRATCH); a.scratch_floats = floats;
+		a.sort_tmp = &tmp; a.sort_tmp_bytes = &tmp_bytes;
+		e = launch_tantan_lanes(a, st);
+	}
+	const hipError_t e2 = hipStreamSynchronize(st);
+	if (tmp) (void)hipFree(tmp);
+	(void)hipFree(buf);
+	return e != hipSuccess ? e : e2;
+}

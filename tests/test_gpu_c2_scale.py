@@ -169,6 +169,7 @@ def test_c2_tantan_masking_at_scale(capsys):
         a, L = int(rng.integers(0, n - 70)), int(rng.integers(25, 70))
         db[doff[i] + a: doff[i] + a + L] = np.resize(rng.integers(0, 20, int(rng.integers(1, 6))).astype(np.int8), L)
     td, tl = workload.sequence_set(db, doff)
+    assert hip.load().dmnd_init(0) == 0            # as the command line does: code objects on the device, every kernel launched once
     ctx = hip.Context()
     try:
         ctx.upload_block(hip.TARGET, td, tl)
