@@ -224,7 +224,7 @@ def cpu_baseline_reference(w, cores, e2e=True):
                 ours = [run(ours_exe, flags, "ours_%s.tsv" % name, threads=False) for _ in range(3)]
                 ours_wall = sorted(x[0] for x in ours)[1]
                 ref_total = re.search(r"Total time = ([0-9.eE+-]+)s", ref_log)
-                runs[name] = {"flags": " ".join(w.cfg["flags"] + flags), "reference_s": ref_wall, "reference_own_total_time_s": float(ref_total.group(1)) if ref_total else None,
+                runs[name] = {"flags": " ".join(w.cfg["flags"] + flags), "reference_md5": ref_md5, "reference_s": ref_wall, "reference_own_total_time_s": float(ref_total.group(1)) if ref_total else None,
                               "ours_s": ours_wall, "ours_runs_s": [round(x[0], 4) for x in ours], "speedup": ref_wall / ours_wall, "parity": all(x[2] == ref_md5 for x in ours),
                               "ours_log": [l for l in ours[1][1].splitlines() if "[" in l or "Total time" in l]}
             e2e_obj = {"what": "whole processes on the same files (page cache warm): `diamond %s` on %d host threads against `diamond-hip %s` on one MI355X -- open and load the "
@@ -252,6 +252,8 @@ def main():
     ap.add_argument("--seed-contexts", type=int, default=1, help="seed stages in flight at the same time (own context and stream each; one with several database blocks per rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the whole-process comparison (diamond-hip against the reference binary on files)")
+    ap.add_argument("--with-masking", action="store_true", help="after the timed steps, also time the step of the default command line (N=1, one database block): block copies as "
+                    "loaded -> tantan + motif masking of both blocks on the device -> seed stage -> extension, back to back on one context; reported as `masked_step`")
     ap.add_argument("--no-pipeline", action="store_true", help="run seed stage and extension stage of a batch back to back on one context")
     args = ap.parse_args()
 
@@ -519,6 +521,50 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    masked_step, masked_records = None, None
+    if args.with_masking and world == 1 and NB == 1 and w.contexts == 1:
+        # The step of `diamond blastp --algo 0` with masking at its default (tantan on both blocks, motif soft masking for seed
+        # generation; cli.cpp does the same calls per block pair). dmnd_mask_block works in place, so every step starts from the
+        # letters as loaded: a device-to-device copy from a context that keeps them (it stands in for the block upload -- inputs
+        # are resident in HBM when a step starts -- and is inside the timed region). One context, stages back to back.
+        hip.load_motif_table()
+        raw, mc = make_ctx(0), make_ctx(0)
+        qd_m, td_m = w.qd.copy(), w.blocks[0][2].copy()       # the host copies the extension reads: patched with the masked positions
+        parts = {k: [] for k in ("copy", "mask_query", "mask_target", "tantan_target_kernel", "seed_stage", "extension", "step")}
+        n_masked = None
+        for s in range(args.warmup + args.steps):
+            torch.cuda.synchronize()
+            t_0 = time.perf_counter()
+            mc.copy_block(hip.QUERY, raw)
+            mc.copy_block(hip.TARGET, raw)
+            t_1 = time.perf_counter()
+            nq = mc.mask_block(hip.QUERY, qd_m)
+            mc.soft_mask_block(hip.QUERY)
+            t_2 = time.perf_counter()
+            nt = mc.mask_block(hip.TARGET, td_m)
+            k_ms = mc.mask_kernel_ms()
+            mc.soft_mask_block(hip.TARGET)
+            t_3 = time.perf_counter()
+            hits = mc.seed_search(seed_params)
+            t_4 = time.perf_counter()
+            masked_records, _ = mc.extend(qd_m, td_m, hits, threads=threads)
+            t_5 = time.perf_counter()
+            if s >= args.warmup:
+                for k, v in zip(("copy", "mask_query", "mask_target", "seed_stage", "extension", "step"), (t_1 - t_0, t_2 - t_1, t_3 - t_2, t_4 - t_3, t_5 - t_4, t_5 - t_0)):
+                    parts[k].append(v * 1e3)
+                parts["tantan_target_kernel"].append(k_ms)
+            n_masked = (int(nq), int(nt))
+        st = mc.extend_stats()
+        m_cells = st["round1_cells"] + (st["round2_cells"] if st["round2_swipe_kernel_ms"] > 0 else 0.0)
+        mean = {k: sum(v) / len(v) for k, v in parts.items()}
+        masked_step = {"what": "one context, stages back to back (no pipelining): block letters as loaded copied device-to-device, tantan + motif masking of the "
+                               "query block and of the database block, seed stage, extension -- the work of `diamond blastp --algo 0` per block pair with masking at its default",
+                       "ms_per_step": mean["step"], "gcups": m_cells / mean["step"] / 1e6, "cells_swept_per_step": m_cells,
+                       "parts_ms": {k: round(v, 3) for k, v in mean.items() if k != "step"},
+                       "masked_letters": {"query": n_masked[0], "database": n_masked[1]}, "records": int(len(masked_records)), "steps": args.steps}
+        raw.close()
+        mc.close()
+
     ext = pipe_ext
     # the job's DP cells: with database shards every rank sweeps its own targets, with query shards its own queries
     cells = torch.tensor([ext["round1_cells"], ext["round2_cells"] if ext["round2_swipe_kernel_ms"] > 0 else 0.0, ext["round2_cells"],
@@ -556,6 +602,7 @@ def main():
                        "host_threads": threads,
                        "parallelism": ("%s-shard x%d (strong scaling of the fixed job)%s" % (args.shard, world, " + RCCL all-to-all of match records keyed by query range, rank g joins 1/N of the queries, gather to rank 0" if args.shard == "db" else "")) if world > 1 else "single GPU"},
             "extension": ext,
+            **({"masked_step": masked_step} if masked_step is not None else {}),
             "swipe_kernel_gcups": {"round1": ext["round1_cells"] / max(ext["round1_swipe_kernel_ms"], 1e-9) / 1e6,
                                    "traceback_kernel_ms": ext["traceback_kernel_ms"]},
             "seed_kernel_ms": dict(zip(["index_queries", "stream_reference", "mask_groups", "pair_filter", "total"], state["seed_ms"])),
@@ -668,6 +715,7 @@ def main():
             qids = ["%s%d" % ("r" if w.contexts == 6 else "q", i) for i in range(w.n_queries)]
             tids = ["t%d" % i for i in range(w.n_db)]
             text = hip.format_tab(state["records"], qids, tids, w.source_lens)
+            masked_text = hip.format_tab(masked_records, qids, tids, w.source_lens) if masked_records is not None else None
             for c in (ctxs_seed if ctxs_seed is not ctxs else []) + [x for cs in ext_ctxs for x in cs]:
                 c.close()
             closed = True
@@ -681,6 +729,10 @@ def main():
                 ours = hashlib.md5(text.encode()).hexdigest()
                 out["parity_checked"] = ours == ref_md5
                 out["parity"] = {"records_md5": ours, "reference_output_md5": ref_md5, "lines": text.count("\n")}
+                if masked_text is not None and e2e is not None:
+                    want = e2e["runs"]["default_masking"]["reference_md5"]
+                    got = hashlib.md5(masked_text.encode()).hexdigest()
+                    out["masked_step"]["parity"] = {"records_md5": got, "reference_output_md5": want, "matches": got == want}
         print(json.dumps(out))
     if not closed:
         for c in (ctxs_seed if ctxs_seed is not ctxs else []) + [x for cs in ext_ctxs for x in cs]:

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <numeric>
 #include <unordered_map>
 #include <string>
@@ -89,10 +90,13 @@ int dmnd::DevBuf::ensure(size_t bytes)
 		return DMND_OK;
 	release();                                         // an alias of another context's buffer (own == false) is dropped, not freed
 	const size_t want = bytes + bytes / 4 + 256;
+	static const bool trace = std::getenv("DMND_TRACE_ALLOC") != nullptr;
+	const auto t0 = std::chrono::steady_clock::now();
 	if (hipMalloc(&p, want) != hipSuccess) {
 		p = nullptr;
 		return fail(DMND_E_NOMEM, "hipMalloc of " + std::to_string(want) + " bytes failed");
 	}
+	if (trace) std::fprintf(stderr, "hipMalloc %zu bytes: %.3f ms\n", want, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
 	cap = want;
 	return DMND_OK;
 }
@@ -151,6 +155,27 @@ extern "C" int dmnd_device_count(void)
 
 namespace { __global__ void init_marker_kernel(int* p) { if (p) *p = 1; } }
 
+// streams made ahead of their use by dmnd_init (a stream of the right priority is taken from here before a new one is created)
+namespace {
+struct PooledStream { int device; int priority; hipStream_t s; };
+std::mutex g_stream_pool_mutex;
+std::vector<PooledStream> g_stream_pool;
+
+hipError_t take_stream(hipStream_t* s, int device, int priority)
+{
+	{
+		std::lock_guard<std::mutex> g(g_stream_pool_mutex);
+		for (size_t i = 0; i < g_stream_pool.size(); ++i)
+			if (g_stream_pool[i].device == device && g_stream_pool[i].priority == priority) {
+				*s = g_stream_pool[i].s;
+				g_stream_pool.erase(g_stream_pool.begin() + (ptrdiff_t)i);
+				return hipSuccess;
+			}
+	}
+	return hipStreamCreateWithPriority(s, hipStreamNonBlocking, priority);
+}
+}
+
 extern "C" hipError_t dmnd_touch_bias(hipStream_t), dmnd_touch_gapped(hipStream_t), dmnd_touch_mask(hipStream_t), dmnd_touch_seed(hipStream_t),
 	dmnd_touch_swipe16(hipStream_t), dmnd_touch_swipe(hipStream_t), dmnd_touch_frameshift(hipStream_t);
 
@@ -165,18 +190,38 @@ extern "C" int dmnd_init(int device)
 	if (device < 0) device = 0;
 	if (device >= count) return fail(DMND_E_ARG, "dmnd_init: device index out of range");
 	HIP_TRY(hipSetDevice(device));
-	// the first launch of a kernel of a translation unit loads that unit's code object onto the device: all of them now, so that
-	// no stage of the search pays for it later
+	// The first launch of a kernel of a translation unit loads that unit's code object onto the device: all of them now, so that
+	// no stage of the search pays for it later. The runtime loads two code objects from two threads at the same time (measured:
+	// 18 + 5 ms one after the other, 16 ms together), and a stream costs 7.6 ms to create on these boxes -- so the two large units
+	// (seed stage 18 ms, masking 8 ms) and the streams of the first context each get a thread of their own beside this one.
+	hipError_t side_rc[3] = { hipSuccess, hipSuccess, hipSuccess };
+	std::thread side[3];
+	side[0] = std::thread([&] { side_rc[0] = hipSetDevice(device); if (side_rc[0] == hipSuccess) side_rc[0] = dmnd_touch_seed(nullptr); lap("seed"); });
+	side[1] = std::thread([&] { side_rc[1] = hipSetDevice(device); if (side_rc[1] == hipSuccess) side_rc[1] = dmnd_touch_mask(nullptr); lap("mask"); });
+	side[2] = std::thread([&] {
+		side_rc[2] = hipSetDevice(device);
+		int least = 0, greatest = 0;
+		(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+		if (std::getenv("DMND_NO_STREAM_PRIORITY")) least = 0;
+		for (int prio : { least, 0 }) {                   // dmnd_create's stream, and the reference block's upload lane
+			hipStream_t s = nullptr;
+			if (side_rc[2] == hipSuccess) side_rc[2] = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio);
+			if (side_rc[2] == hipSuccess) { std::lock_guard<std::mutex> g(g_stream_pool_mutex); g_stream_pool.push_back(PooledStream{ device, prio, s }); }
+		}
+		lap("streams");
+	});
 	hipLaunchKernelGGL(init_marker_kernel, dim3(1), dim3(1), 0, nullptr, (int*)nullptr);
-	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipDeviceSynchronize());
+	hipError_t rc = hipGetLastError();
 	lap("first kernel (api)");
-	struct { const char* name; hipError_t (*fn)(hipStream_t); } units[] = { { "mask", dmnd_touch_mask }, { "seed", dmnd_touch_seed }, { "bias", dmnd_touch_bias },
+	struct { const char* name; hipError_t (*fn)(hipStream_t); } units[] = { { "bias", dmnd_touch_bias },
 		{ "swipe16", dmnd_touch_swipe16 }, { "swipe", dmnd_touch_swipe }, { "gapped", dmnd_touch_gapped }, { "frameshift", dmnd_touch_frameshift } };
 	for (auto& u : units) {
-		HIP_TRY(u.fn(nullptr));
-		if (trace) { HIP_TRY(hipDeviceSynchronize()); lap(u.name); }
+		if (rc == hipSuccess) rc = u.fn(nullptr);
+		lap(u.name);
 	}
+	for (std::thread& t : side) t.join();
+	for (hipError_t e : side_rc) if (rc == hipSuccess) rc = e;
+	HIP_TRY(rc);
 	HIP_TRY(hipDeviceSynchronize());
 	lap("all code objects loaded");
 	return DMND_OK;
@@ -217,7 +262,7 @@ extern "C" dmnd_ctx* dmnd_create(int device, const dmnd_params* params)
 	int prio_least = 0, prio_greatest = 0;
 	(void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
 	if (std::getenv("DMND_NO_STREAM_PRIORITY")) prio_least = prio_greatest = 0;
-	if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_least) != hipSuccess
+	if (take_stream(&c->stream, device, prio_least) != hipSuccess
 		|| hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev2) != hipSuccess
 		|| c->matrix.ensure(32 * 32) != DMND_OK
 		|| hipMemcpy(c->matrix.p, params->matrix8, 32 * 32, hipMemcpyHostToDevice) != hipSuccess) {
@@ -247,7 +292,7 @@ extern "C" void dmnd_destroy(dmnd_ctx* c)
 	for (DevBuf* b : { &c->block[0], &c->block[1], &c->cbs, &c->matrix, &c->bias_ids, &c->items, &c->order, &c->p_of_slot, &c->trace_off,
 		&c->transcript_off, &c->ends, &c->hsps, &c->trace, &c->transcript, &c->status, &c->pairs, &c->trace_off_item, &c->host_q, &c->host_t, &c->host_cbs,
 		&c->d_limits[0], &c->d_limits[1], &c->qid_of, &c->mask_time, &c->seed_keys, &c->seed_next, &c->seed_qlist, &c->seed_qkeys, &c->seed_slot2, &c->seed_loc2, &c->seed_survivors, &c->seed_scored, &c->seed_need, &c->seed_qfold,
-		&c->matched_slot, &c->matched_loc, &c->counters, &c->seed_hits, &c->seed_bitmap, &c->seed_deferred, &c->seed_eslot, &c->seed_eloc, &c->seed_hits_sorted, &c->sort_keys[0], &c->sort_keys[1], &c->sort_idx[0], &c->sort_idx[1], &c->gf_tables, &c->gf_hits, &c->gf_flags, &c->gf_scores, &c->gf_units, &c->alt_targets, &c->mask_lr, &c->mask_pb, &c->mask_scale, &c->mask_pos, &c->mask_ids, &c->mask_soff, &c->soft[0], &c->soft[1], &c->motif_hit, &c->motif_table, &c->adj_matrices })
+		&c->matched_slot, &c->matched_loc, &c->counters, &c->seed_hits, &c->seed_bitmap, &c->seed_deferred, &c->seed_eslot, &c->seed_eloc, &c->seed_hits_sorted, &c->sort_keys[0], &c->sort_keys[1], &c->sort_idx[0], &c->sort_idx[1], &c->gf_tables, &c->gf_hits, &c->gf_flags, &c->gf_scores, &c->gf_units, &c->alt_targets, &c->mask_lr, &c->mask_pb, &c->mask_scale, &c->mask_pos, &c->mask_ids, &c->mask_soff, &c->mask_long_ids, &c->mask_long_soff, &c->mask_long_pb, &c->mask_long_scale, &c->soft[0], &c->soft[1], &c->motif_hit, &c->motif_table, &c->adj_matrices })
 		b->release();
 	if (c->ev0) (void)hipEventDestroy(c->ev0);
 	if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -291,6 +336,19 @@ static int upload_bytes(dmnd_ctx* c, void* dst, const void* src, size_t bytes, b
 	if (pinned || bytes <= ((size_t)256 << 10)) {
 		HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, stream));
 		return DMND_OK;
+	}
+	// A large pageable source is page-locked where it lies for the duration of the copy: registering 300 MB takes 5 ms on these
+	// boxes (hipHostMalloc of as much: 46 ms), after which the DMA engine reads it at the PCIe rate -- 33 ms through the staging
+	// chunks below (one host thread's memcpy rate) against 12 ms this way. The registration ends with the copy (synchronous here).
+	if (bytes >= ((size_t)32 << 20)) {
+		if (hipHostRegister(const_cast<void*>(src), bytes, hipHostRegisterDefault) == hipSuccess) {
+			const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream);
+			const hipError_t e2 = e == hipSuccess ? sync_stream(stream) : e;
+			(void)hipHostUnregister(const_cast<void*>(src));
+			HIP_TRY(e2);
+			return DMND_OK;
+		}
+		(void)hipGetLastError();                         // e.g. a read-only mapping: staged below
 	}
 	for (int i = 0; i < 2; ++i) {
 		if (int rc = stage[i].ensure(CHUNK)) return rc;
@@ -360,6 +418,21 @@ extern "C" int dmnd_share_block(dmnd_ctx* c, int which, const dmnd_ctx* src)
 	return DMND_OK;
 }
 
+extern "C" int dmnd_copy_block(dmnd_ctx* c, int which, const dmnd_ctx* src)
+{
+	if (!c || !src || c == src || (which != DMND_QUERY && which != DMND_TARGET) || !src->block[which].p || !c->block[which].p || c->device != src->device)
+		return fail(DMND_E_ARG, "dmnd_copy_block: bad argument (both contexts must hold the block, on the same device)");
+	if (!c->block[which].own) return fail(DMND_E_ARG, "dmnd_copy_block: the block is an alias (dmnd_share_block) and read-only");
+	if (c->block_len[which] != src->block_len[which] || c->limits[which] != src->limits[which])
+		return fail(DMND_E_ARG, "dmnd_copy_block: the two blocks differ in shape");
+	HIP_TRY(hipSetDevice(c->device));
+	HIP_TRY(sync_stream(src->stream));                 // whatever wrote the source block has finished
+	HIP_TRY(hipMemcpyAsync(c->block[which].p, src->block[which].p, (size_t)c->block_len[which], hipMemcpyDeviceToDevice, c->stream));
+	c->soft_valid[which] = false;
+	if (which == DMND_QUERY) ++c->query_generation;
+	return DMND_OK;
+}
+
 extern "C" int dmnd_upload_block(dmnd_ctx* c, int which, const int8_t* data, int64_t data_len, const int64_t* limits, int64_t n_seqs)
 {
 	if (!c || (which != DMND_QUERY && which != DMND_TARGET) || !data || data_len <= 0 || n_seqs < 0)
@@ -377,7 +450,7 @@ extern "C" int dmnd_upload_block(dmnd_ctx* c, int which, const int8_t* data, int
 	// the reference block travels on its own lane: nothing this call touches is shared with calls on the QUERY block of the same
 	// context, so a driver may run it on a helper thread beside them (diamond-hip does, for the first block of a run)
 	const bool lane = which == DMND_TARGET;
-	if (lane && !c->t_stream) HIP_TRY(hipStreamCreateWithFlags(&c->t_stream, hipStreamNonBlocking));
+	if (lane && !c->t_stream) HIP_TRY(take_stream(&c->t_stream, c->device, 0));
 	if (lane && c->block_len[which] > 0) HIP_TRY(sync_stream(c->stream));      // whatever still reads the block that is replaced
 	if (int rc = upload_bytes(c, c->block[which].p, data, (size_t)data_len, lane)) return rc;
 	if (limits) if (int rc = upload_bytes(c, c->d_limits[which].p, limits, (size_t)(n_seqs + 1) * sizeof(int64_t), lane)) return rc;

@@ -1,6 +1,8 @@
 // ctx.h -- shared internals of libdiamond_hip.so: error plumbing, device buffers, the context object.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <stdint.h>
 #include <string>
@@ -66,6 +68,21 @@ struct PinBuf {
 
 }  // namespace dmnd
 
+// DMND_TRACE=1: wall-clock laps of a call on stderr (what the host waits for inside an entry point)
+struct TraceLaps {
+	const char* call;
+	bool on;
+	std::chrono::steady_clock::time_point t0, last;
+	explicit TraceLaps(const char* name) : call(name) { static const bool env = std::getenv("DMND_TRACE") != nullptr; on = env; if (on) t0 = last = std::chrono::steady_clock::now(); }
+	void lap(const char* what)
+	{
+		if (!on) return;
+		const auto now = std::chrono::steady_clock::now();
+		std::fprintf(stderr, "%s %8.2f ms (+%.2f)  %s\n", call, std::chrono::duration<double, std::milli>(now - t0).count(), std::chrono::duration<double, std::milli>(now - last).count(), what);
+		last = now;
+	}
+};
+
 struct dmnd_ctx;
 namespace dmnd { int download_bytes(dmnd_ctx* c, void* dst, const void* src, size_t bytes); }      // api.hip: HBM -> pageable host memory through the context's page-locked chunks
 
@@ -120,7 +137,7 @@ struct dmnd_ctx {
 	dmnd::DevBuf gf_tables, gf_hits, gf_flags, gf_scores, gf_units;
 	double gapped_filter_evalue = 0.0, gf_ms = 0.0;
 	// tantan masking (mask_api.hip)
-	dmnd::DevBuf mask_lr, mask_pb, mask_scale, mask_pos, mask_ids, mask_soff;
+	dmnd::DevBuf mask_lr, mask_pb, mask_scale, mask_pos, mask_ids, mask_soff, mask_long_ids, mask_long_soff, mask_long_pb, mask_long_scale;
 	// motif soft masking (dmnd_soft_mask_block): a copy of each block with the motif stretches masked, read by the seed
 	// stage for seed generation only; soft_valid is dropped whenever the block changes
 	dmnd::DevBuf soft[2], motif_hit, motif_table;

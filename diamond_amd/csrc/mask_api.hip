@@ -4,7 +4,9 @@
 #pragma clang fp contract(off)
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <mutex>
+#include <utility>
 #include <vector>
 #include "ctx.h"
 #include "mask_kernels.h"
@@ -103,9 +105,22 @@ double masking_lambda(const int8_t* m8)
 	return -1.0;
 }
 
+// (the root search above is 4096 inversions of a 20 x 20 matrix, 6 ms: the reference does it once per run, in Masking's constructor
+// -- here once per scoring matrix and process, whatever context asks)
+double cached_masking_lambda(const int8_t* m8)
+{
+	static std::mutex mutex;
+	static std::vector<std::pair<std::vector<int8_t>, double>> known;
+	std::lock_guard<std::mutex> lock(mutex);
+	for (const auto& k : known)
+		if (std::memcmp(k.first.data(), m8, 1024) == 0) return k.second;
+	known.emplace_back(std::vector<int8_t>(m8, m8 + 1024), masking_lambda(m8));
+	return known.back().second;
+}
+
 void likelihood_ratios(const int8_t* m8, float* lr)
 {
-	const double lambda = masking_lambda(m8);
+	const double lambda = cached_masking_lambda(m8);
 	for (int i = 0; i < 32; ++i)
 		for (int j = 0; j < 32; ++j)      // Masking::Masking, masking.cpp:147-153: the 26 alphabet letters, 0 elsewhere
 			lr[i * 32 + j] = (i < 26 && j < 26) ? (float)std::exp(lambda * (double)m8[i * 32 + j]) : 0.0f;
@@ -120,7 +135,7 @@ namespace { std::vector<uint64_t> g_motifs; std::mutex g_motifs_mutex; }
 extern "C" double dmnd_masking_lambda(const dmnd_params* p)
 {
 	if (!p) { fail(DMND_E_ARG, "dmnd_masking_lambda: params is NULL"); return 0.0; }
-	return masking_lambda(p->matrix8);
+	return cached_masking_lambda(p->matrix8);
 }
 
 // ---- SEG (--masking seg): host side, as in the reference ------------------------------------------------------------------------
@@ -254,8 +269,10 @@ static int mask_impl(dmnd_ctx* c, int which, int8_t* host_data, const int32_t* i
 	hipStream_t st = c->stream;
 	const std::vector<int64_t>& lim = c->limits[which];
 	const int64_t n = (int64_t)lim.size() - 1, raw = c->block_len[which];
+	TraceLaps tr(ids ? "dmnd_mask_sequences" : "dmnd_mask_block");
 	std::vector<float> lr(32 * 32);
 	likelihood_ratios(c->params.matrix8, lr.data());
+	tr.lap("likelihood ratios");
 	TantanArgs a;
 	// Masking::operator() (masking.cpp:176): p_repeat 0.005, p_repeat_end 0.05, growth 1/0.9, minMaskProb 0.9 (config.cpp:402)
 	const float p_repeat = 0.005f, p_repeat_end = 0.05f, growth = 1.0f / 0.9f;
@@ -287,12 +304,37 @@ static int mask_impl(dmnd_ctx* c, int which, int8_t* host_data, const int32_t* i
 	}
 	// DMND_TANTAN_WAVE=1: the round-2 kernel (one wavefront per sequence, one lane per repeat offset) instead of one lane per sequence
 	static const bool wave_kernel = [] { const char* e = std::getenv("DMND_TANTAN_WAVE"); return e && e[0] == '1'; }();
-	int64_t max_len = 0, total_len = 0;
+	// The lane-per-sequence kernel runs a wavefront's 64 sequences in lock step: 2 len steps of ~0.5 - 0.9 us each for the
+	// longest of them, whatever else the device has to do -- 6 ms for a 3.0e8-letter block, but 6 ms too for a block of 10 000
+	// queries with a 7 000-letter one among them, and 70 ms for a titin. The wavefront-per-sequence kernel is 7 times slower per
+	// letter on a full device and 3 times faster on a single sequence. So: sequences longer than `long_len` -- the length whose
+	// lock-step time equals what the lanes kernel needs for the block's letters anyway -- go to the wavefront kernel (their ids
+	// and scratch offsets listed here), the lanes kernel leaves them out (its length keys of them are 0).
+	int64_t max_len = 0, total_len = 0, long_len = 0, n_long = 0, long_letters = 0;
+	std::vector<int32_t> long_ids;
+	std::vector<int64_t> long_soff;
+	auto work_id = [&](int64_t k) { return ids ? (int64_t)ids[k] : k; };
 	if (!wave_kernel) {
-		if (ids) for (int64_t k = 0; k < n_ids; ++k) { const int64_t l = lim[(size_t)ids[k] + 1] - lim[(size_t)ids[k]] - 1; max_len = std::max(max_len, l); total_len += l; }
-		else { for (int64_t k = 0; k < n; ++k) max_len = std::max(max_len, lim[(size_t)k + 1] - lim[(size_t)k] - 1); total_len = raw; }
+		if (ids) for (int64_t k = 0; k < n_ids; ++k) total_len += lim[(size_t)ids[k] + 1] - lim[(size_t)ids[k]] - 1;
+		else total_len = raw;
+		static const int64_t long_env = [] { const char* e = std::getenv("DMND_TANTAN_LONG"); return e ? std::atoll(e) : (long long)0; }();
+		long_len = long_env > 0 ? long_env : std::max<int64_t>(256, total_len / 90000);
+		for (int64_t k = 0; k < n_work; ++k) {
+			const int64_t id = work_id(k), l = lim[(size_t)id + 1] - lim[(size_t)id] - 1;
+			if (l > long_len) { long_ids.push_back((int32_t)id); long_soff.push_back(long_letters); long_letters += l + 1; }
+			else max_len = std::max(max_len, l);
+		}
+		n_long = (int64_t)long_ids.size();
 	}
-	const int64_t lanes_floats = wave_kernel ? 0 : tantan_lanes_scratch(n_work, total_len, max_len), n_waves = (n_work + 63) / 64;
+	const int64_t lanes_floats = wave_kernel ? 0 : tantan_lanes_scratch(n_work, total_len - (long_letters - n_long), max_len), n_waves = (n_work + 63) / 64;
+	if (n_long > 0) {
+		if (int rc = c->mask_long_ids.ensure((size_t)n_long * sizeof(int32_t))) return rc;
+		if (int rc = c->mask_long_soff.ensure((size_t)n_long * sizeof(int64_t))) return rc;
+		if (int rc = c->mask_long_pb.ensure((size_t)(long_letters + 64) * sizeof(float))) return rc;
+		if (int rc = c->mask_long_scale.ensure((size_t)(long_letters / 16 + n_long + 16) * sizeof(float))) return rc;
+		HIP_TRY(hipMemcpyAsync(c->mask_long_ids.p, long_ids.data(), (size_t)n_long * sizeof(int32_t), hipMemcpyHostToDevice, st));
+		HIP_TRY(hipMemcpyAsync(c->mask_long_soff.p, long_soff.data(), (size_t)n_long * sizeof(int64_t), hipMemcpyHostToDevice, st));
+	}
 	if (wave_kernel) {
 		if (int rc = c->mask_pb.ensure((size_t)scratch_letters * sizeof(float))) return rc;
 		if (int rc = c->mask_scale.ensure((size_t)(scratch_letters / 16 + n_work + 16) * sizeof(float))) return rc;
@@ -306,6 +348,7 @@ static int mask_impl(dmnd_ctx* c, int which, int8_t* host_data, const int32_t* i
 		if (int rc = c->mask_scale.ensure((size_t)(2 * (n_waves + 1) + 1) * sizeof(int64_t))) return rc;
 	}
 	if (int rc = c->counters.ensure(64 * sizeof(unsigned long long))) return rc;
+	tr.lap("lengths, buffers");
 	HIP_TRY(hipMemcpyAsync(c->mask_lr.p, lr.data(), lr.size() * sizeof(float), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemsetAsync(c->counters.p, 0, 2 * sizeof(unsigned long long), st));
 	// the host copy is patched from a list of the masked positions (a few per mille of the letters) instead of copying the
@@ -330,18 +373,29 @@ static int mask_impl(dmnd_ctx* c, int which, int8_t* host_data, const int32_t* i
 		la.keys[0] = c->sort_keys[0].as<uint32_t>(); la.keys[1] = c->sort_keys[1].as<uint32_t>(); la.order = c->sort_idx[0].as<uint32_t>();
 		la.wave_off = c->mask_scale.as<int64_t>(); la.scratch = c->mask_pb.as<float>(); la.scratch_floats = lanes_floats;
 		la.sort_tmp = &c->sort_tmp; la.sort_tmp_bytes = &c->sort_tmp_bytes;
+		la.long_len = long_len;
 		HIP_TRY(prepare_tantan_lanes(la, st));
 	}
+	tr.lap("work space");
 	HIP_TRY(hipEventRecord(c->ev0, st));
 	if (!wave_kernel) {
-		HIP_TRY(launch_tantan_lanes(la, st));
+		if (n_long < n_work) HIP_TRY(launch_tantan_lanes(la, st));
+		if (n_long > 0) {
+			TantanArgs w = a;
+			w.n_seqs = n_long;
+			w.ids = c->mask_long_ids.as<int32_t>(); w.scratch_off = c->mask_long_soff.as<int64_t>();
+			w.pb = c->mask_long_pb.as<float>(); w.scale = c->mask_long_scale.as<float>();
+			HIP_TRY(launch_tantan(w, st));
+		}
 	}
 	else
 	HIP_TRY(launch_tantan(a, st));
 	HIP_TRY(hipEventRecord(c->ev1, st));
 	unsigned long long cnt[2] = { 0, 0 };
 	HIP_TRY(hipMemcpyAsync(cnt, c->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, st));
+	tr.lap("launched");
 	HIP_TRY(sync_stream(st));
+	tr.lap("kernels done");
 	const unsigned long long nm = cnt[0];
 	if (host_data && pos_cap && cnt[1] <= pos_cap) {
 		std::vector<uint32_t> pos((size_t)cnt[1]);
@@ -349,6 +403,7 @@ static int mask_impl(dmnd_ctx* c, int which, int8_t* host_data, const int32_t* i
 		for (uint32_t x : pos) host_data[x] = 23;
 	}
 	else if (host_data) HIP_TRY(copy_now(st, host_data, c->block[which].p, (size_t)raw, hipMemcpyDeviceToHost));
+	tr.lap("host copy patched");
 	float ms = 0;
 	HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
 	c->mask_ms = ms;
@@ -357,6 +412,9 @@ static int mask_impl(dmnd_ctx* c, int which, int8_t* host_data, const int32_t* i
 	c->mask_pb.release();
 	c->mask_scale.release();
 	c->mask_pos.release();
+	c->mask_long_pb.release();
+	c->mask_long_scale.release();
+	tr.lap("scratch released");
 	return DMND_OK;
 }
 

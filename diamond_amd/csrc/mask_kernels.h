@@ -34,6 +34,7 @@ struct TantanLanesArgs {
 	int64_t* wave_off;            // 2 (n_waves + 1) + 1 entries: where a wavefront keeps its floats inside `scratch`; behind them the wavefronts' sizes, then a counter
 	float* scratch;               // scratch_floats entries
 	int64_t scratch_floats;
+	int64_t long_len;             // sequences longer than this are left out (their length key is 0): the caller gives them to launch_tantan
 	void** sort_tmp;              // rocPRIM scratch of the context (grown here when too small)
 	size_t* sort_tmp_bytes;
 };

@@ -225,7 +225,7 @@ __global__ void tantan_lengths_kernel(TantanLanesArgs a)
 	if (k >= a.t.n_seqs) return;
 	const int64_t id = a.t.ids ? (int64_t)a.t.ids[k] : k;
 	const int64_t len = a.t.limits[id + 1] - a.t.limits[id] - 1;
-	a.keys[0][k] = (uint32_t)(len > 0 ? len : 0);
+	a.keys[0][k] = (uint32_t)(len > 0 && len <= a.long_len ? len : 0);
 }
 
 // a wavefront's scratch: (positions + rescaling points of its longest sequence) x 64 floats
@@ -618,7 +618,7 @@ extern "C" hipError_t dmnd_touch_mask(hipStream_t st)
 		a.t.lr = reinterpret_cast<const float*>(buf + LR); a.t.n_masked = reinterpret_cast<unsigned long long*>(buf + COUNT);
 		a.keys[0] = reinterpret_cast<uint32_t*>(buf + KEYS); a.keys[1] = a.keys[0] + 8; a.order = reinterpret_cast<uint32_t*>(buf + ORDER);
 		a.wave_off = reinterpret_cast<int64_t*>(buf + OFF); a.scratch = reinterpret_cast<float*>(buf + SCRATCH); a.scratch_floats = floats;
-		a.sort_tmp = &tmp; a.sort_tmp_bytes = &tmp_bytes;
+		a.sort_tmp = &tmp; a.sort_tmp_bytes = &tmp_bytes; a.long_len = 4;
 		e = launch_tantan_lanes(a, st);
 	}
 	const hipError_t e2 = hipStreamSynchronize(st);

@@ -17,6 +17,7 @@
  */
 #ifndef DIAMOND_HIP_H
 #define DIAMOND_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -141,6 +142,11 @@ void dmnd_host_free(void* p);
  * query seed index over the blocks (dmnd_set_query_index_reuse). `src` must outlive every use; the alias is read-only
  * (dmnd_mask_block on it is refused) and is dropped by the next dmnd_upload_block / dmnd_share_block of that block. */
 int dmnd_share_block(dmnd_ctx* ctx, int which, const dmnd_ctx* src);
+/* Overwrites the letters of block `which` of ctx with those of the block of the same shape (same sequence limits) that `src` holds
+ * on the same device: a device-to-device copy on ctx's stream. For a driver that keeps a block as loaded in one context and masks
+ * a working copy in another (dmnd_mask_block works in place) -- the reference re-reads or keeps unmasked letters the same way when
+ * a block is searched by several query blocks (Block::soft_mask / remove_soft_masking, src/data/block/block.cpp:164-177). */
+int dmnd_copy_block(dmnd_ctx* ctx, int which, const dmnd_ctx* src);
 /* Uploads the per-query Hauser composition-bias vectors (HauserCorrection::int8,
  * src/stats/hauser_correction.cpp:107), concatenated; dmnd_dp_target::cbs_off indexes this buffer. */
 int dmnd_upload_cbs(dmnd_ctx* ctx, const int8_t* cbs, int64_t len);

@@ -78,7 +78,11 @@ def test_bench_e2e_and_hot_path_baselines():
     (the reference's seed-stage + extension task timers) are on the bench line, md5-equal outputs for all three command lines."""
     if not os.path.exists(REF):
         pytest.skip("oracle/_ref/diamond_tap not built")
-    d = _bench(["--queries", "1500", "--families", "3000", "--steps", "2", "--warmup", "1"])
+    d = _bench(["--queries", "1500", "--families", "3000", "--steps", "2", "--warmup", "1", "--with-masking"])
+    # --with-masking: the step of the default command line (masking on the device inside the step); its records = the reference's default output
+    m = d["masked_step"]
+    assert m["ms_per_step"] > 0 and m["parts_ms"]["mask_target"] > 0 and m["masked_letters"]["database"] > 0
+    assert m["parity"]["matches"] is True, m["parity"]
     assert d["cpu_baseline"]["hot_path"]["seconds"] > 0 and d["cpu_baseline"]["whole_process"]["seconds"] > d["cpu_baseline"]["hot_path"]["seconds"]
     e = d["e2e"]
     assert set(e["runs"]) == {"default_masking", "masking_off", "stock_command_line"}
