@@ -380,6 +380,7 @@ static int mask_impl(dmnd_ctx* c, int which, int8_t* host_data, const int32_t* i
 	HIP_TRY(hipEventRecord(c->ev0, st));
 	if (!wave_kernel) {
 		if (n_long < n_work) HIP_TRY(launch_tantan_lanes(la, st));
+		tr.lap("lanes chain enqueued");
 		if (n_long > 0) {
 			TantanArgs w = a;
 			w.n_seqs = n_long;
@@ -391,11 +392,11 @@ static int mask_impl(dmnd_ctx* c, int which, int8_t* host_data, const int32_t* i
 	else
 	HIP_TRY(launch_tantan(a, st));
 	HIP_TRY(hipEventRecord(c->ev1, st));
+	tr.lap("all enqueued");
+	// (through the context's page-locked chunk: the runtime's own path to a pageable destination took 6 ms here for these 16 bytes)
 	unsigned long long cnt[2] = { 0, 0 };
-	HIP_TRY(hipMemcpyAsync(cnt, c->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, st));
-	tr.lap("launched");
-	HIP_TRY(sync_stream(st));
-	tr.lap("kernels done");
+	if (int rc = download_bytes(c, cnt, c->counters.p, sizeof(cnt))) return rc;
+	tr.lap("kernels done, counters read");
 	const unsigned long long nm = cnt[0];
 	if (host_data && pos_cap && cnt[1] <= pos_cap) {
 		std::vector<uint32_t> pos((size_t)cnt[1]);
@@ -407,13 +408,12 @@ static int mask_impl(dmnd_ctx* c, int which, int8_t* host_data, const int32_t* i
 	float ms = 0;
 	HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
 	c->mask_ms = ms;
+	if (tr.on) std::fprintf(stderr, "%s: %lld sequences (%lld long, > %lld letters), kernels %.3f ms between the events\n", tr.call, (long long)n_work, (long long)n_long, (long long)long_len, (double)ms);
 	if (n_masked) *n_masked = (int64_t)nm;
-	// the scratch (4 B per letter) is only needed during the call
-	c->mask_pb.release();
-	c->mask_scale.release();
-	c->mask_pos.release();
-	c->mask_long_pb.release();
-	c->mask_long_scale.release();
+	// the scratch (4 B per letter) is only needed during the call -- but hipFree waits for everything the device is doing (a block
+	// upload on the context's other lane, say: 4.5 ms here), so a small one stays for the next call
+	for (DevBuf* b : { &c->mask_pb, &c->mask_scale, &c->mask_pos, &c->mask_long_pb, &c->mask_long_scale })
+		if (b->cap > ((size_t)256 << 20)) b->release();
 	tr.lap("scratch released");
 	return DMND_OK;
 }
