@@ -397,10 +397,13 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	const size_t slot_bytes = (size_t)slots << z.slot_shift;      // one shape's table
 	const bool fused = z.fused, reuse = z.reuse;
 	const size_t bm_total = z.bm_total;
+	// key classes (seed_core.h seed_class): the short-seed pipeline, when the geometry allows eighths (DMND_SEED_CLASSES=0: one range)
+	static const bool classes_env = [] { const char* e = getenv("DMND_SEED_CLASSES"); return !e || atoi(e) != 0; }();
+	const int classes = fused && classes_env && slots >= 64 && bm1_words % 8 == 0 && bm1_words >= 64 ? 8 : 0;
 	std::string signature;
 	if (reuse) {
 		signature.assign(reinterpret_cast<const char*>(&sp), sizeof(sp));
-		const uint64_t extra[7] = { c->query_generation, (uint64_t)nq_pos, slots, bm_words, bm1_words, (uint64_t)fused, (uint64_t)z.slot_shift * 2 + bm1_k3 };
+		const uint64_t extra[7] = { c->query_generation, (uint64_t)nq_pos, slots, bm_words, bm1_words, (uint64_t)fused + 2 * (uint64_t)classes, (uint64_t)z.slot_shift * 2 + bm1_k3 };
 		signature.append(reinterpret_cast<const char*>(extra), sizeof(extra));
 	}
 	const bool index_ready = reuse && c->qindex_signature == signature && !signature.empty();
@@ -408,7 +411,10 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	lap("parameters checked");
 	if (int rc = seed_reserve(c, sp, z, nq_pos, q_end, c->block_len[DMND_QUERY], false)) return rc;
 	lap("buffers ensured");
-	if (int rc = c->counters.ensure((size_t)(S + 5) * sizeof(unsigned long long))) return rc;      // [S] hits, [S+1] deferred pairs, [S+2] collected positions, [S+3] Hamming survivors, [S+4] scored survivors
+	static const bool phases = getenv("DMND_SEED_PHASES") != nullptr;
+	const bool counters_new = c->counters.cap < (size_t)(S + 16) * sizeof(unsigned long long);
+	if (int rc = c->counters.ensure((size_t)(S + 16) * sizeof(unsigned long long))) return rc;      // [S] hits, [S+1] deferred pairs, [S+2] collected positions, [S+3] Hamming survivors, [S+4] scored survivors
+	if (phases || counters_new) HIP_TRY(hipMemsetAsync(c->counters.as<unsigned long long>() + S + 5, 0, 11 * sizeof(unsigned long long), st));
 	if (!index_ready) HIP_TRY(hipMemsetAsync(c->seed_bitmap.p, 0, bm_total, st));
 	if (!index_ready) HIP_TRY(hipMemsetAsync(c->seed_next.p, 0xff, (size_t)SB * nq_pos * sizeof(uint32_t), st));
 	HIP_TRY(hipMemsetAsync(c->mask_time.p, SEED_NEVER, (size_t)c->block_len[DMND_QUERY] + 256, st));
@@ -422,6 +428,14 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		const int64_t n = c->block_len[DMND_QUERY];
 		if (int rc = c->seed_qfold.ensure((size_t)(n + 1) / 2 + 64)) return rc;
 		HIP_TRY(launch_seed_fold(c->block[DMND_QUERY].as<int8_t>(), n, c->seed_qfold.as<uint8_t>(), st));
+	}
+	if (classes) {
+		const int8_t* tseed = (c->soft_valid[DMND_TARGET] && sp.seed_encoding == SEED_SPACED) ? c->soft[DMND_TARGET].as<int8_t>() : c->block[DMND_TARGET].as<int8_t>();
+		const int64_t n = seed_code_groups(t_begin, t_end);
+		if (int rc = c->seed_tcodes.ensure((size_t)n * sizeof(uint64_t))) return rc;
+		if (int rc = c->seed_tflags.ensure((size_t)n * sizeof(uint32_t))) return rc;
+		if (int rc = c->seed_tclass.ensure((size_t)9 * n * sizeof(uint16_t))) return rc;
+		HIP_TRY(launch_seed_codes(sp, tseed, t_begin, t_end, c->seed_tcodes.as<uint64_t>(), c->seed_tflags.as<uint32_t>(), st));
 	}
 	const int level2_env = [] { const char* e = getenv("DMND_SEED_LEVEL2"); return e ? atoi(e) : -1; }();
 	auto level2_of = [&](int sid) { return level2_env >= 0 ? level2_env : (sp.shape_weight[sid] >= 10 ? 1 : 0); };
@@ -442,6 +456,10 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		a.qslot = c->seed_next.as<uint32_t>() + (size_t)own * nq_pos;
 		a.qlist = c->seed_qlist.as<uint32_t>() + (size_t)own * nq_pos;
 		a.slot_mask = slots - 1;
+		a.classes = classes;
+		a.phase_ticks = phases ? c->counters.as<unsigned long long>() + S + 8 : nullptr;
+		a.tclass = classes ? c->seed_tclass.as<uint16_t>() : nullptr; a.tclass_stride = seed_code_groups(t_begin, t_end);
+		a.tcodes = classes ? c->seed_tcodes.as<uint64_t>() : nullptr; a.tflags = classes ? c->seed_tflags.as<uint32_t>() : nullptr;
 		a.bitmap = c->seed_bitmap.as<uint32_t>() + (size_t)own * (bm_words + bm1_words);
 		a.bitmap_mask = (uint32_t)(bm_words - 1);
 		a.bitmap1 = a.bitmap + bm_words;
@@ -731,10 +749,24 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		if (int rc = c->sort_idx[1].ensure((size_t)n * sizeof(uint32_t))) return rc;
 		uint64_t* keys[2] = { c->sort_keys[0].as<uint64_t>(), c->sort_keys[1].as<uint64_t>() };
 		uint32_t* idx[2] = { c->sort_idx[0].as<uint32_t>(), c->sort_idx[1].as<uint32_t>() };
-		HIP_TRY(sort_seed_hits(c->seed_hits.as<dmnd_seed_hit>(), c->seed_hits_sorted.as<dmnd_seed_hit>(), n, keys, idx, &c->sort_tmp, &c->sort_tmp_bytes, st));
+		auto bits_of = [](uint64_t v) { int b = 1; while (b < 64 && (v >> b) != 0) ++b; return b; };
+		const std::vector<int64_t>& qlim = c->limits[DMND_QUERY];
+		if (c->max_query_len_generation != c->query_generation || c->max_query_len <= 0) {
+			int64_t m = 1;
+			for (size_t i = 0; i + 1 < qlim.size(); ++i) m = std::max(m, qlim[i + 1] - qlim[i]);
+			c->max_query_len = m; c->max_query_len_generation = c->query_generation;
+		}
+		HIP_TRY(sort_seed_hits(c->seed_hits.as<dmnd_seed_hit>(), c->seed_hits_sorted.as<dmnd_seed_hit>(), n, keys, idx, &c->sort_tmp, &c->sort_tmp_bytes, st,
+			bits_of((uint64_t)std::max<size_t>(qlim.size(), 2) - 1), bits_of((uint64_t)c->block_len[DMND_TARGET]), bits_of((uint64_t)c->max_query_len)));
 		HIP_TRY(sync_stream(st));
 	}
 	lap("hits sorted");
+	if (phases) {
+		unsigned long long t[8];
+		HIP_TRY(copy_now(c->stream, t, c->counters.as<unsigned long long>() + S + 8, sizeof(t), hipMemcpyDeviceToHost));
+		std::fprintf(stderr, "SEED_PHASES (ms of workgroup time, summed): start %.1f | windows %.1f | level 1 %.1f | table %.1f | light lists %.1f | heavy lists %.1f\n",
+			t[0] / 1e5, t[1] / 1e5, t[2] / 1e5, t[3] / 1e5, t[4] / 1e5, t[5] / 1e5);
+	}
 	c->seed_ms[4] = c->seed_ms[0] + c->seed_ms[1] + c->seed_ms[2] + c->seed_ms[3];
 	if (getenv("DMND_TRACE")) {
 		std::fprintf(stderr, "dmnd_seed_search: %d shapes, %lld query positions, joined reference positions per shape:", S, (long long)nq_pos);

@@ -435,6 +435,19 @@ DMND_HD uint64_t seed_hash(uint64_t x) { return ((uint64_t)seed_hash_b(x) << 32)
 // (one L2 request per probe). word = high bits of hash a scaled to the word count (any count, not only powers of two: the filter
 // is sized to what an XCD's L2 holds next to the stream); bits = three 5-bit fields of a's low half (K = 2: the first two).
 DMND_HD uint32_t bm1_word(uint32_t h, uint32_t words) { return (uint32_t)(((uint64_t)h * words) >> 32); }
+// Key classes of the short-seed pipeline (round 4): one of eight, a cheap function of the table key alone. Class c owns the c-th
+// eighth of the level-1 filter's words and of the table's slots, and the fused stream kernel runs one workgroup per (tile, class)
+// with workgroup w taking class w mod 8 -- the XCD the hardware dispatches it to -- so that an XCD's L2 only ever sees its own eighth
+// of the query side (seed_kernels.hip, seed_stream_fast_kernel).
+// (an XOR fold of the key's 16 nibbles to three bits: full-rate integer operations only -- the stream evaluates it for every window and class)
+DMND_HD uint32_t seed_class(uint64_t key)
+{
+	uint32_t x = (uint32_t)key ^ (uint32_t)(key >> 32);
+	x ^= x >> 16;
+	x ^= x >> 8;
+	x ^= x >> 4;
+	return (x ^ (x >> 3)) & 7u;
+}
 DMND_HD uint32_t bm1_bits(uint32_t h, uint32_t k3)
 {
 	const uint32_t two = (1u << (h & 31)) | (1u << ((h >> 5) & 31));

@@ -49,6 +49,25 @@ struct SeedArgs {
 	uint32_t* qslot;                              // per query position: slot of its seed (LIST_END: no seed); input of the list sort
 	const uint32_t* qlist;                        // query positions grouped by slot (SeedSlot::head = start, count in flags >> 8)
 	uint64_t slot_mask;
+	int classes;                                  // 8: slots and level-1 words are partitioned by seed_class(key) (short-seed pipeline); 0: one range
+	// ... and then the reference letters as the stream wants them, made once per search by seed_codes_kernel: per group of 16
+	// letters (from t_begin rounded down to 16) their class nibbles, and delimiter / no-class maps (low / high 16 bits)
+	const uint64_t* tcodes; const uint32_t* tflags;
+	const uint16_t* tclass; int64_t tclass_stride;  // per shape (seed_classify_kernel): plane c = the valid windows of class c, 16 per entry; plane 8 (hashed seeds): the special ones
+	unsigned long long* phase_ticks;              // DMND_SEED_PHASES=1: 8 counters (seed_stream_fast_kernel PHASE_MARK), else NULL
+	// home slot of a key (hh = seed_hash(key)) and word of its level-1 bits (h = seed_hash_a(key))
+	__host__ __device__ uint64_t home(uint64_t hh, uint64_t key) const
+	{
+		if (!classes) return hh & slot_mask;
+		const uint64_t low = slot_mask >> 3;
+		return (uint64_t)seed_class(key) * (low + 1) | (hh & low);
+	}
+	__host__ __device__ uint32_t bm1_index(uint32_t h, uint64_t key) const
+	{
+		if (!classes) return bm1_word(h, bitmap1_words);
+		const uint32_t w8 = bitmap1_words >> 3;
+		return seed_class(key) * w8 + bm1_word(h, w8);
+	}
 	// two one-hash bitmaps of the query seeds: level 1 is sized to stay resident in every XCD's 4 MB L2 (the reference
 	// stream probes it once per position), level 2 (>= 16 bits per query seed) filters level-1 false positives before
 	// the open-addressing table is touched
@@ -88,6 +107,9 @@ hipError_t launch_seed_lists(const SeedArgs& a, int sid, uint32_t* sorted_slot, 
 hipError_t launch_seed_reset(const SeedArgs& a, int sid, hipStream_t st);
 // letters [0, n) of a block folded to 4 bits each, two per byte (out: (n + 1) / 2 bytes)
 hipError_t launch_seed_fold(const int8_t* data, int64_t n, uint8_t* out, hipStream_t st);
+// class nibbles + flag maps of the reference letters [t_begin & ~15, t_end + 32) (SeedArgs::tcodes / tflags); n_groups entries each
+inline int64_t seed_code_groups(int64_t t_begin, int64_t t_end) { return (t_end - (t_begin & ~(int64_t)15) + 15) / 16 + 2; }
+hipError_t launch_seed_codes(const SeedParams& c, const int8_t* tseed, int64_t t_begin, int64_t t_end, uint64_t* codes, uint32_t* flags, hipStream_t st);
 hipError_t launch_seed_stream(const SeedArgs& a, int sid, hipStream_t st, bool fused = false);
 bool seed_stream_can_fuse(const SeedParams& c);
 // n_matched >= 0: the number of joined positions in a.matched_* (few of them: the kernel walks that list instead of the table)
@@ -105,6 +127,6 @@ hipError_t sort_keys_u64(const uint64_t* in, uint64_t* out, int64_t n, void** tm
 // Orders the n seed hits by (query, subject, seed_offset, score) on the device: three stable radix-sort passes over an index
 // permutation (keys/idx: two buffers of n uint64 / uint32 each), then one gather into `out`.
 hipError_t sort_seed_hits(const dmnd_seed_hit* hits, dmnd_seed_hit* out, int64_t n, uint64_t* keys[2], uint32_t* idx[2],
-	void** tmp, size_t* tmp_bytes, hipStream_t st);
+	void** tmp, size_t* tmp_bytes, hipStream_t st, int query_bits, int subject_bits, int off_bits);      // bits of the largest query id / subject position / seed offset
 
 }  // namespace dmnd

@@ -49,8 +49,8 @@ __global__ void seed_index_kernel(SeedArgs a, int sid)
 	}
 	const uint64_t h = seed_hash(seed);
 	if (a.level2) atomicOr(&a.bitmap[(h >> 32) & a.bitmap_mask], 1u << (h >> 59));      // level 2: only consulted for long seeds (launch_seed_stream)
-	atomicOr(&a.bitmap1[bm1_word((uint32_t)h, a.bitmap1_words)], bm1_bits((uint32_t)h, a.bitmap1_k3));        // K bits, one word; bits of hash a only
-	uint64_t slot = h & a.slot_mask;
+	atomicOr(&a.bitmap1[a.bm1_index((uint32_t)h, seed)], bm1_bits((uint32_t)h, a.bitmap1_k3));        // K bits, one word; bits of hash a only
+	uint64_t slot = a.home(h, seed);
 	for (;;) {
 		const unsigned long long old = atomicCAS((unsigned long long*)&a.slot(slot).key, (unsigned long long)SEED_EMPTY, (unsigned long long)seed);
 		if (old == SEED_EMPTY || old == seed) break;
@@ -148,7 +148,7 @@ __global__ void seed_stream_kernel(SeedArgs a, int sid)
 	uint32_t fl = 0;
 	bool found = false;
 	if (p < a.t_end && seed_key_at(a.params, sid, a.tseed + p, seed)) {
-		slot = seed_hash(seed) & a.slot_mask;
+		slot = a.home(seed_hash(seed), seed);
 		for (;;) {
 			const SeedSlot sl = a.slot(slot);
 			if (sl.key == SEED_EMPTY) break;
@@ -226,7 +226,10 @@ __device__ __forceinline__ uint32_t bm1_probe_any(int policy, __amdgpu_buffer_rs
 	}
 }
 
-template<bool LEVEL2, bool HASHED, bool FUSED>
+enum { SEED_CLASS_TILES = 4 };      // tiles of 4096 window starts per class workgroup (kernel and launch)
+// DMND_SEED_PHASES=1 (SeedArgs::phase_ticks): thread 0 of every workgroup adds the 100 MHz ticks between its phase boundaries
+#define PHASE_MARK(i) do { if (a.phase_ticks && threadIdx.x == 0) { const uint64_t now_ = wall_clock64(); atomicAdd(&a.phase_ticks[i], (unsigned long long)(now_ - phase_t_)); phase_t_ = now_; } } while (0)
+template<bool LEVEL2, bool HASHED, bool FUSED, bool BYCLASS = false>
 __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int sid, uint64_t map_lo, uint64_t map_hi, int64_t base, uint64_t care64)
 {
 	// Joined positions are staged in LDS and flushed with ONE atomic on the shared counter per workgroup: an atomicAdd per
@@ -234,22 +237,40 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 	// 22 M = 98 ms per shape in --sensitive), which dwarfed the 1.6 ms stream itself.
 	// With short seeds (LEVEL2 off) a third of the positions join: the staging area then holds every position of the workgroup
 	// (the direct-append fallback cost more than the whole rest of the kernel); positions are staged as 16-bit offsets.
-	constexpr unsigned STAGE = LEVEL2 ? 1024 : (FUSED ? 2048 : 4096);
+	// (BYCLASS: a workgroup time is spent waiting for memory, phase after phase, and the kernel's time is the sum of the workgroup times
+	// over the workgroups a CU holds -- which LDS decides: 58 KB allowed 2, these sizes allow 8, as many as the 62 VGPRs do)
+	constexpr unsigned STAGE = BYCLASS ? 768 : LEVEL2 ? 1024 : (FUSED ? 2048 : 4096);
 	__shared__ uint32_t st_slot[STAGE];
 	__shared__ uint16_t st_loc[STAGE];
 	__shared__ unsigned st_n;
 	__shared__ unsigned long long st_base;
 	constexpr uint32_t LIGHT = 8;
-	constexpr unsigned SURV = FUSED ? 512 : 1, HEAVY = FUSED ? 128 : 1, FSTAGE = FUSED ? STAGE : 1;
+	constexpr unsigned SURV = FUSED ? (BYCLASS ? 128 : 512) : 1, HEAVY = FUSED ? (BYCLASS ? 64 : 128) : 1, FSTAGE = FUSED ? STAGE : 1;
 	__shared__ uint32_t st_head[FSTAGE];
 	__shared__ uint16_t st_count[FSTAGE];                    // saturated: a list that long is read back from its slot
 	__shared__ uint32_t sv_slot[SURV], sv_x[SURV];
 	__shared__ uint16_t sv_loc[SURV], hv_k[HEAVY];
 	__shared__ unsigned sv_n, hv_n;
-	if (threadIdx.x == 0) { st_n = 0; sv_n = 0; hv_n = 0; }
+	constexpr unsigned CQ = BYCLASS ? 2560 : 1, PQ = BYCLASS ? 1024 : 1;
+	__shared__ uint16_t cq[CQ], pq[PQ];                      // BYCLASS: the workgroup's windows of its class (2048 expected); those that passed level 1
+	__shared__ unsigned cq_n, pq_n;
+	constexpr unsigned PAIRS = BYCLASS ? 1536 : 1;           // (join, list element) pairs of the light lists: in cq's place, which is done with by then
+	uint16_t* const pr = cq;
+	static_assert(PAIRS <= CQ, "the pair list lives in the class queue");
+	__shared__ unsigned pr_n;
+	uint64_t phase_t_ = a.phase_ticks ? wall_clock64() : 0;
+	if (threadIdx.x == 0) { st_n = 0; sv_n = 0; hv_n = 0; cq_n = 0; pq_n = 0; pr_n = 0; }
 	__syncthreads();
+	PHASE_MARK(0);
 	const __amdgpu_buffer_rsrc_t bm1_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.bitmap1, 0, (int)(a.bitmap1_words * 4u), 0x00020000);
-	const int64_t wg_base = base + (int64_t)blockIdx.x * blockDim.x * 16;
+	// (FUSED, a.classes: eight workgroups per tile of 4096 positions, each looking at the windows of one key class only -- its own:
+	// workgroup w is dispatched to XCD w mod 8, which is all the affinity there is; the result does not depend on it)
+	constexpr bool by_class = BYCLASS;
+	const uint32_t my_class = by_class ? blockIdx.x & 7u : 0u;
+	// (a class workgroup covers CLASS_TILES tiles: it finds an eighth of a tile's joins, and the filter phase below wants as many
+	// staged joins per workgroup as without classes -- measured with one tile per class workgroup: 11.5 ms per shape against 7.3)
+	constexpr int CLASS_TILES = SEED_CLASS_TILES;
+	const int64_t wg_base = base + (int64_t)(by_class ? (blockIdx.x >> 3) * CLASS_TILES : blockIdx.x) * blockDim.x * 16;
 	const int64_t p0 = wg_base + (int64_t)threadIdx.x * 16;
 	const bool in_range = p0 < a.t_end;
 	auto survive = [&](uint32_t slot, uint32_t x, int64_t pos) {
@@ -305,18 +326,16 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 		}
 	};
 	// level-2 bitmap -> table -> staging, for a window whose key passed (or skipped) level 1
-	auto probe_table = [&](uint64_t seed, int64_t pos) {
-		const uint64_t hh = seed_hash(seed);
-		uint64_t slot = hh & a.slot_mask;
+	// the probe chain of a key from `slot` on, whose content `sl` the caller has read already; a join is staged
+	auto table_chain = [&](uint64_t seed, int64_t pos, uint64_t slot, SeedSlot sl) {
 		bool found = false;
 		uint32_t fl = 0, head = 0;
-		if (!LEVEL2 || ((a.bitmap[(uint32_t)(hh >> 32) & a.bitmap_mask] >> (uint32_t)(hh >> 59)) & 1u))
-			for (;;) {
-				const SeedSlot sl = a.slot(slot);
-				if (sl.key == SEED_EMPTY) break;
-				if (sl.key == seed) { found = true; fl = sl.flags; head = sl.head; break; }
-				slot = (slot + 1) & a.slot_mask;
-			}
+		for (;;) {
+			if (sl.key == SEED_EMPTY) break;
+			if (sl.key == seed) { found = true; fl = sl.flags; head = sl.head; break; }
+			slot = (slot + 1) & a.slot_mask;
+			sl = a.slot(slot);
+		}
 		if (!found) return;
 		if (!(fl & SLOT_JOINED)) a.slot(slot).flags = fl | SLOT_JOINED;
 		if (FUSED && (fl & SLOT_LOWC)) return;
@@ -331,7 +350,117 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 			if (FUSED) filter_list((uint32_t)slot, head, fl >> 8, pos, 0, 1);
 		}
 	};
-	if (in_range) {
+	auto probe_table = [&](uint64_t seed, int64_t pos) {
+		const uint64_t hh = seed_hash(seed);
+		if (LEVEL2 && !((a.bitmap[(uint32_t)(hh >> 32) & a.bitmap_mask] >> (uint32_t)(hh >> 59)) & 1u)) return;
+		const uint64_t slot = a.home(hh, seed);
+		table_chain(seed, pos, slot, a.slot(slot));
+	};
+	if (by_class) {
+		// Eight workgroups look at every window, each at one class: what is done for all of them is kept to the key, its class and
+		// the validity maps (the letters come decoded: seed_codes_kernel). A thread's own windows -- 2 of 16 on average, 7 for the
+		// unluckiest lane of a wavefront -- are not probed where they are found: a lane's probes are a chain of dependent reads
+		// (filter word -> slot -> next slot), and 8 x 7 such rounds per wavefront with most lanes idle took 9.3 ms per shape. They
+		// are queued in LDS as 16-bit offsets; then all threads take queue entries in turn, first through the level-1 filter (four
+		// independent probes per thread in flight), the survivors through the table.
+		auto key_at = [&](uint32_t off) {
+			const int64_t p = wg_base + off;
+			const int64_t g = (p - base) >> 4;
+			const int sh = (int)(p & 15) * 4;                             // base and wg_base are multiples of 16
+			const uint64_t c0 = a.tcodes[g], c1 = a.tcodes[g + 1];
+			return (sh == 0 ? c0 : (c0 >> sh) | (c1 << (64 - sh))) & care64;
+		};
+		// which of a group's 16 windows are valid and of this class: seed_classify_kernel's answer for this shape (one bit per window);
+		// the maps of all the thread's groups are requested together
+		uint32_t maps[CLASS_TILES], specials[CLASS_TILES];
+#pragma unroll
+		for (int sub = 0; sub < CLASS_TILES; ++sub) {
+			const int64_t p0 = wg_base + ((int64_t)sub * 256 + threadIdx.x) * 16;
+			const int64_t g = (p0 - base) >> 4;
+			maps[sub] = p0 < a.t_end ? a.tclass[(int64_t)my_class * a.tclass_stride + g] : 0u;
+			specials[sub] = HASHED && p0 < a.t_end && ((uint32_t)g & 7u) == my_class ? a.tclass[8 * a.tclass_stride + g] : 0u;
+		}
+#pragma unroll
+		for (int sub = 0; sub < CLASS_TILES; ++sub) {
+			const int64_t p0 = wg_base + ((int64_t)sub * 256 + threadIdx.x) * 16;
+			uint32_t mine = maps[sub];
+			if (mine) {
+				const unsigned n_mine = (unsigned)__builtin_popcount(mine);
+				unsigned k = atomicAdd(&cq_n, n_mine);
+				while (mine) {
+					const int w0 = __builtin_ctz(mine);
+					mine &= mine - 1;
+					if (k < CQ) cq[k] = (uint16_t)(p0 + w0 - wg_base);
+					else {                                                    // queue full (never seen: 4096 expected, room for 6144): on the spot
+						const uint64_t key = key_at((uint32_t)(p0 + w0 - wg_base));
+						const uint32_t h = seed_hash_a(key);
+						const uint32_t bw = a.bitmap1[a.bm1_index(h, key)], need = bm1_bits(h, a.bitmap1_k3);
+						if ((bw & need) == need) probe_table(key, p0 + w0);
+					}
+					++k;
+				}
+			}
+			// HASHED: windows holding a mask / stop letter are keyed by seed_key_hashed -- plane 8; each is looked at by ONE of the
+			// eight workgroups (any will do: the classes are an affinity, not a partition of the work's correctness)
+			uint32_t special = specials[sub];
+			while (HASHED && special) {
+				const int w0 = __builtin_ctz(special);
+				special &= special - 1;
+				uint64_t seed;
+				if (!seed_key_hashed(a.params, sid, a.tseed + p0 + w0, seed)) continue;
+				const uint32_t h = seed_hash_a(seed);
+				const uint32_t bw = a.bitmap1[a.bm1_index(h, seed)], need = bm1_bits(h, a.bitmap1_k3);
+				if ((bw & need) == need) probe_table(seed, p0 + w0);
+			}
+		}
+		__syncthreads();
+		PHASE_MARK(1);
+		const unsigned n_cq = cq_n < CQ ? cq_n : CQ;
+		constexpr int L1B = 8, TB = 4;                                // entries a thread has in flight: level-1 probes, first slot reads
+		for (unsigned k0 = threadIdx.x; k0 < n_cq; k0 += L1B * 256) {
+			uint32_t off[L1B], bw[L1B], need[L1B];
+#pragma unroll
+			for (int j = 0; j < L1B; ++j) {
+				const unsigned k = k0 + (unsigned)j * 256;
+				off[j] = k < n_cq ? cq[k] : 0xffffffffu;
+				bw[j] = 0; need[j] = 1;
+				if (k < n_cq) {
+					const uint64_t key = key_at(off[j]);
+					const uint32_t h = seed_hash_a(key);
+					bw[j] = bm1_probe_any(a.probe_policy, bm1_rsrc, a.bitmap1, a.bm1_index(h, key));
+					need[j] = bm1_bits(h, a.bitmap1_k3);
+				}
+			}
+#pragma unroll
+			for (int j = 0; j < L1B; ++j)
+				if ((bw[j] & need[j]) == need[j]) {
+					const unsigned k = atomicAdd(&pq_n, 1u);
+					if (k < PQ) pq[k] = (uint16_t)off[j];
+					else probe_table(key_at(off[j]), wg_base + off[j]);
+				}
+		}
+		__syncthreads();
+		PHASE_MARK(2);
+		const unsigned n_pq = pq_n < PQ ? pq_n : PQ;
+		for (unsigned k0 = threadIdx.x; k0 < n_pq; k0 += TB * 256) {
+			uint64_t key[TB], slot[TB];
+			uint32_t off[TB];
+			SeedSlot sl[TB];
+#pragma unroll
+			for (int j = 0; j < TB; ++j) {
+				const unsigned k = k0 + (unsigned)j * 256;
+				off[j] = k < n_pq ? pq[k] : 0xffffffffu;
+				key[j] = k < n_pq ? key_at(off[j]) : 0;
+			}
+#pragma unroll
+			for (int j = 0; j < TB; ++j)
+				if (off[j] != 0xffffffffu) { slot[j] = a.home(seed_hash(key[j]), key[j]); sl[j] = a.slot(slot[j]); }
+#pragma unroll
+			for (int j = 0; j < TB; ++j)
+				if (off[j] != 0xffffffffu) table_chain(key[j], wg_base + off[j], slot[j], sl[j]);
+		}
+	}
+	else if (in_range) {
 	typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 	u32x4 v0, v1;
 	if (a.stream_nt) {
@@ -378,7 +507,7 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 			const bool ok = inside && ((bad >> w0) & (HASHED ? span : care)) == 0;
 			if (HASHED && inside && !ok) special |= 1u << w0;
 			const uint32_t h = seed_hash_a(key[i]);                              // hash b is only needed past level 1
-			const uint32_t bw = ok ? bm1_probe_any(a.probe_policy, bm1_rsrc, a.bitmap1, bm1_word(h, a.bitmap1_words)) : 0u;
+			const uint32_t bw = ok ? bm1_probe_any(a.probe_policy, bm1_rsrc, a.bitmap1, a.bm1_index(h, key[i])) : 0u;
 			const uint32_t need = bm1_bits(h, a.bitmap1_k3);
 			word[i] = (bw & need) == need ? 1u : 0u;
 		}
@@ -400,12 +529,16 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 		uint64_t seed;
 		if (!seed_key_hashed(a.params, sid, a.tseed + p0 + w0, seed)) continue;
 		const uint32_t h = seed_hash_a(seed);
-		const uint32_t bw = a.bitmap1[bm1_word(h, a.bitmap1_words)], need = bm1_bits(h, a.bitmap1_k3);
+		const uint32_t bw = a.bitmap1[a.bm1_index(h, seed)], need = bm1_bits(h, a.bitmap1_k3);
 		if ((bw & need) == need) probe_table(seed, p0 + w0);
 	}
 	}
 	__syncthreads();
+	PHASE_MARK(3);
 	if (FUSED) {
+		// Light lists (up to LIGHT query positions), one (join, list element) PAIR per thread and turn: a thread that walked its join's
+		// whole list made the wavefront wait for the longest list of 64 -- two dependent reads per element (measured, DMND_SEED_PHASES:
+		// 50 of 139 s of workgroup time over the 16 shapes of C3). The pairs are listed in LDS first (join << 3 | element).
 		const unsigned n_joined = st_n < STAGE ? st_n : STAGE;
 		for (unsigned k = threadIdx.x; k < n_joined; k += 256) {
 			uint32_t count = st_count[k];
@@ -413,10 +546,26 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 				const unsigned hk = atomicAdd(&hv_n, 1u);
 				if (hk < HEAVY) { hv_k[hk] = (uint16_t)k; continue; }
 				if (count == 0xffffu) count = a.slot(st_slot[k]).flags >> 8;
+				filter_list(st_slot[k], st_head[k], count, wg_base + st_loc[k], 0, 1);
+				continue;
 			}
-			filter_list(st_slot[k], st_head[k], count, wg_base + st_loc[k], 0, 1);
+			if (!BYCLASS) { filter_list(st_slot[k], st_head[k], count, wg_base + st_loc[k], 0, 1); continue; }
+			const unsigned at = atomicAdd(&pr_n, count);
+			if (at + count <= PAIRS) for (uint32_t i = 0; i < count; ++i) pr[at + i] = (uint16_t)((k << 3) | i);
+			else {                                                    // no room: on the spot (the slots of the reservation that exist are voided)
+				for (unsigned i = at; i < PAIRS; ++i) pr[i] = 0xffffu;
+				filter_list(st_slot[k], st_head[k], count, wg_base + st_loc[k], 0, 1);
+			}
 		}
 		__syncthreads();
+		const unsigned n_pairs = pr_n < PAIRS ? pr_n : PAIRS;
+		for (unsigned e = threadIdx.x; e < n_pairs; e += 256) {       // (two pairs per thread in flight, their loads issued together: 108 -> 124 ms
+			if (pr[e] == 0xffffu) continue;                            //  per 16 shapes -- the registers cost more wavefronts than the overlap returns)
+			const unsigned k = pr[e] >> 3;
+			filter_list(st_slot[k], st_head[k], st_count[k], wg_base + st_loc[k], pr[e] & 7u, 0x40000000u);
+		}
+		__syncthreads();
+		PHASE_MARK(4);
 		const unsigned n_heavy = hv_n < HEAVY ? hv_n : HEAVY;       // block-uniform
 		for (unsigned h = 0; h < n_heavy; ++h) {
 			const unsigned k = hv_k[h];
@@ -425,6 +574,7 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 			filter_list(st_slot[k], st_head[k], count, wg_base + st_loc[k], threadIdx.x, 256);
 		}
 		__syncthreads();
+		PHASE_MARK(5);
 		const unsigned n_sv = sv_n < SURV ? sv_n : SURV;
 		if (n_sv) {
 			if (threadIdx.x == 0) st_base = atomicAdd(a.survivor_count, (unsigned long long)n_sv);
@@ -974,6 +1124,71 @@ hipError_t launch_seed_soft_time(const SeedArgs& a, hipStream_t st)
 	return hipGetLastError();
 }
 
+// class nibbles and flag maps of 16 reference letters (the decode of seed_stream_fast_kernel, once per search instead of once per
+// shape and class)
+__global__ void seed_codes_kernel(const int8_t* __restrict__ tseed, int64_t base, int64_t n_groups, uint64_t map_lo, uint64_t map_hi, int hashed, uint64_t* __restrict__ codes, uint32_t* __restrict__ flags)
+{
+	const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= n_groups) return;
+	typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+	const u32x4 v = *reinterpret_cast<const u32x4*>(tseed + base + 16 * g);
+	const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+	uint64_t code = 0;
+	uint32_t delim = 0, bad = 0;
+#pragma unroll
+	for (int j = 0; j < 16; ++j) {
+		const uint32_t l = (w[j >> 2] >> ((j & 3) * 8)) & LETTER_MASK;
+		const uint32_t c = reduce4(l, map_lo, map_hi);
+		code |= (uint64_t)(hashed && c == 15u ? 0u : c) << (j * 4);
+		delim |= (l == L_DELIM ? 1u : 0u) << j;
+		bad |= (c == 15u ? 1u : 0u) << j;
+	}
+	codes[g] = code;
+	flags[g] = delim | (bad << 16);
+}
+
+hipError_t launch_seed_codes(const SeedParams& c, const int8_t* tseed, int64_t t_begin, int64_t t_end, uint64_t* codes, uint32_t* flags, hipStream_t st)
+{
+	uint64_t lo = 0, hi = 0;
+	for (int l = 0; l < 32; ++l) {
+		const uint64_t code = c.reduction[l] == L_MASK ? 15u : (uint64_t)c.reduction[l];
+		(l < 16 ? lo : hi) |= code << ((l & 15) * 4);
+	}
+	const int64_t n = seed_code_groups(t_begin, t_end);
+	hipLaunchKernelGGL(seed_codes_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, tseed, t_begin & ~(int64_t)15, n, lo, hi, c.seed_encoding == SEED_HASHED ? 1 : 0, codes, flags);
+	return hipGetLastError();
+}
+
+// Per shape: which windows are valid seeds, and of which key class -- one 16-bit map per group of 16 window starts and class (plane c
+// of `out`; plane 8: the HASHED mode's windows with a mask / stop letter). The eight class workgroups of the stream then read a map
+// instead of each evaluating every window (that alone was 46 of 124 s of workgroup time over the 16 shapes of C3).
+__global__ void seed_classify_kernel(SeedArgs a, int sid, int64_t base, int64_t n_groups, uint64_t care64, int hashed, uint16_t* __restrict__ out)
+{
+	const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= n_groups) return;
+	const int64_t p0 = base + 16 * g;
+	const uint64_t c0 = a.tcodes[g], c1 = g + 1 < n_groups ? a.tcodes[g + 1] : 0;
+	const uint32_t f0 = a.tflags[g], f1 = g + 1 < n_groups ? a.tflags[g + 1] : 0xffffu;
+	const uint32_t delim = (f0 & 0xffffu) | (f1 << 16), bad = (f0 >> 16) | (f1 & 0xffff0000u);
+	const int len = a.params.shape_len[sid];
+	const uint32_t care = a.params.shape_mask[sid], span = (1u << len) - 1;
+	const int64_t first = a.t_begin - p0, last = a.t_end - p0;
+	uint32_t m[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+#pragma unroll
+	for (int w0 = 0; w0 < 16; ++w0) {
+		const bool inside = w0 >= first && w0 < last && ((delim >> w0) & span) == 0;
+		const bool ok = inside && ((bad >> w0) & (hashed ? span : care)) == 0;
+		const int sh = w0 * 4;
+		const uint64_t key = (sh == 0 ? c0 : (c0 >> sh) | (c1 << (64 - sh))) & care64;
+		const uint32_t cls = seed_class(key);
+#pragma unroll
+		for (int c = 0; c < 8; ++c) m[c] |= (ok && cls == (uint32_t)c ? 1u : 0u) << w0;
+		m[8] |= (hashed && inside && !ok ? 1u : 0u) << w0;
+	}
+#pragma unroll
+	for (int c = 0; c < 9; ++c) if (c < 8 || hashed) out[(int64_t)c * n_groups + g] = (uint16_t)m[c];
+}
+
 hipError_t launch_seed_fold(const int8_t* data, int64_t n, uint8_t* out, hipStream_t st)
 {
 	if (n <= 0) return hipSuccess;
@@ -1040,8 +1255,14 @@ hipError_t launch_seed_stream(const SeedArgs& a, int sid, hipStream_t st, bool f
 		uint64_t care64 = 0;
 		for (int k = 0; k < c.shape_weight[sid]; ++k) care64 |= (uint64_t)15 << (4 * c.shape_pos[sid][k]);
 		const bool level2 = a.level2 != 0, hashed = c.seed_encoding == SEED_HASHED;
-		const dim3 grid(blocks_for(threads, 256)), block(256);
-		if (fused && hashed) hipLaunchKernelGGL((seed_stream_fast_kernel<false, true, true>), grid, block, 0, st, a, sid, lo, hi, base, care64);
+		const dim3 grid(fused && a.classes ? blocks_for(threads, 256 * SEED_CLASS_TILES) * 8u : blocks_for(threads, 256)), block(256);
+		if (fused && a.classes) {
+			const int64_t n_groups = seed_code_groups(a.t_begin, a.t_end);
+			hipLaunchKernelGGL(seed_classify_kernel, dim3(blocks_for(n_groups, 256)), dim3(256), 0, st, a, sid, base, n_groups, care64, hashed ? 1 : 0, const_cast<uint16_t*>(a.tclass));
+		}
+		if (fused && a.classes && hashed) hipLaunchKernelGGL((seed_stream_fast_kernel<false, true, true, true>), grid, block, 0, st, a, sid, lo, hi, base, care64);
+		else if (fused && a.classes) hipLaunchKernelGGL((seed_stream_fast_kernel<false, false, true, true>), grid, block, 0, st, a, sid, lo, hi, base, care64);
+		else if (fused && hashed) hipLaunchKernelGGL((seed_stream_fast_kernel<false, true, true>), grid, block, 0, st, a, sid, lo, hi, base, care64);
 		else if (fused) hipLaunchKernelGGL((seed_stream_fast_kernel<false, false, true>), grid, block, 0, st, a, sid, lo, hi, base, care64);
 		else if (level2 && hashed) hipLaunchKernelGGL((seed_stream_fast_kernel<true, true, false>), grid, block, 0, st, a, sid, lo, hi, base, care64);
 		else if (level2) hipLaunchKernelGGL((seed_stream_fast_kernel<true, false, false>), grid, block, 0, st, a, sid, lo, hi, base, care64);
@@ -1144,14 +1365,16 @@ hipError_t sort_keys_u64(const uint64_t* in, uint64_t* out, int64_t n, void** tm
 
 namespace {
 
-// pass 0: key = score, identity permutation; pass 1: key = subject << 24 | seed_offset; pass 2: key = query
-__global__ void hit_keys_kernel(const dmnd_seed_hit* hits, const uint32_t* perm, int64_t n, int pass, uint64_t* keys, uint32_t* idx_out)
+// pass 0: key = score, identity permutation; pass 1: key = subject << 24 | seed_offset; pass 2: key = query.
+// pass 3 = passes 1 and 2 in one key, query | subject | seed_offset in subject_bits and off_bits wide fields (when the three fit 64 bits)
+__global__ void hit_keys_kernel(const dmnd_seed_hit* hits, const uint32_t* perm, int64_t n, int pass, uint64_t* keys, uint32_t* idx_out, int subject_bits, int off_bits)
 {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	const uint32_t src = perm ? perm[i] : (uint32_t)i;
 	const dmnd_seed_hit h = hits[src];
-	keys[i] = pass == 0 ? (uint64_t)(uint32_t)h.score : pass == 1 ? ((uint64_t)h.subject << 24) | ((uint64_t)h.seed_offset & 0xffffffu) : (uint64_t)h.query;
+	keys[i] = pass == 0 ? (uint64_t)(uint32_t)h.score : pass == 1 ? ((uint64_t)h.subject << 24) | ((uint64_t)h.seed_offset & 0xffffffu) : pass == 2 ? (uint64_t)h.query
+		: ((((uint64_t)h.query << subject_bits) | (uint64_t)h.subject) << off_bits) | ((uint64_t)h.seed_offset & 0xffffffu);
 	if (idx_out) idx_out[i] = src;
 }
 
@@ -1179,17 +1402,24 @@ hipError_t sort_pairs(const uint64_t* kin, uint64_t* kout, const uint32_t* vin, 
 }  // namespace
 
 hipError_t sort_seed_hits(const dmnd_seed_hit* hits, dmnd_seed_hit* out, int64_t n, uint64_t* keys[2], uint32_t* idx[2],
-	void** tmp, size_t* tmp_bytes, hipStream_t st)
+	void** tmp, size_t* tmp_bytes, hipStream_t st, int query_bits, int subject_bits, int off_bits)
 {
 	if (n <= 0) return hipSuccess;
 	const dim3 grid(blocks_for(n, 256)), block(256);
 	hipError_t e;
 	// least significant criterion first; every pass is stable
-	hipLaunchKernelGGL(hit_keys_kernel, grid, block, 0, st, hits, (const uint32_t*)nullptr, n, 0, keys[0], idx[0]);
+	hipLaunchKernelGGL(hit_keys_kernel, grid, block, 0, st, hits, (const uint32_t*)nullptr, n, 0, keys[0], idx[0], 0, 0);
 	if ((e = sort_pairs(keys[0], keys[1], idx[0], idx[1], n, 32, tmp, tmp_bytes, st)) != hipSuccess) return e;
-	hipLaunchKernelGGL(hit_keys_kernel, grid, block, 0, st, hits, (const uint32_t*)idx[1], n, 1, keys[0], (uint32_t*)nullptr);
+	if (off_bits >= 1 && off_bits <= 24 && query_bits + subject_bits + off_bits <= 64) {
+		// (query, subject, seed_offset) as ONE key: a sort less (80 of 250 us for the 2e4 hits of a C2 step)
+		hipLaunchKernelGGL(hit_keys_kernel, grid, block, 0, st, hits, (const uint32_t*)idx[1], n, 3, keys[0], (uint32_t*)nullptr, subject_bits, off_bits);
+		if ((e = sort_pairs(keys[0], keys[1], idx[1], idx[0], n, query_bits + subject_bits + off_bits, tmp, tmp_bytes, st)) != hipSuccess) return e;
+		hipLaunchKernelGGL(hit_gather_kernel, grid, block, 0, st, hits, (const uint32_t*)idx[0], n, out);
+		return hipGetLastError();
+	}
+	hipLaunchKernelGGL(hit_keys_kernel, grid, block, 0, st, hits, (const uint32_t*)idx[1], n, 1, keys[0], (uint32_t*)nullptr, 0, 0);
 	if ((e = sort_pairs(keys[0], keys[1], idx[1], idx[0], n, 64, tmp, tmp_bytes, st)) != hipSuccess) return e;
-	hipLaunchKernelGGL(hit_keys_kernel, grid, block, 0, st, hits, (const uint32_t*)idx[0], n, 2, keys[0], (uint32_t*)nullptr);
+	hipLaunchKernelGGL(hit_keys_kernel, grid, block, 0, st, hits, (const uint32_t*)idx[0], n, 2, keys[0], (uint32_t*)nullptr, 0, 0);
 	if ((e = sort_pairs(keys[0], keys[1], idx[0], idx[1], n, 32, tmp, tmp_bytes, st)) != hipSuccess) return e;
 	hipLaunchKernelGGL(hit_gather_kernel, grid, block, 0, st, hits, (const uint32_t*)idx[1], n, out);
 	return hipGetLastError();
