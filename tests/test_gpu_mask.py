@@ -157,3 +157,29 @@ def test_two_contexts_with_different_motif_tables():
         for c in (ca, cb, cg):
             c.close()
         hip.load_motif_table()
+
+
+def test_copy_block_restores_the_letters_as_loaded():
+    """dmnd_copy_block: a context that masks in place takes the letters as loaded from a context that keeps them (device to
+    device), so that a second masking pass reproduces the first; blocks of different shape are refused."""
+    hdr, recs = read_tantan_tap(os.path.join(GOLDEN, "tantan.tap"))
+    data, limits = _block([r["before"] for r in recs])
+    want, _ = _block([r["after"] for r in recs])
+    keep, work = hip.Context(), hip.Context()
+    try:
+        keep.upload_block(hip.TARGET, data, limits)
+        work.upload_block(hip.TARGET, data, limits)
+        for _ in range(2):
+            host = data.copy()
+            work.mask_block(hip.TARGET, host)
+            assert np.array_equal(host, want)
+            work.copy_block(hip.TARGET, keep)               # back to the unmasked letters
+        other, olim = _block([r["before"] for r in recs[:10]])
+        keep.upload_block(hip.TARGET, other, olim)
+        with pytest.raises(Exception):
+            work.copy_block(hip.TARGET, keep)
+        with pytest.raises(Exception):
+            work.copy_block(hip.QUERY, keep)                # no query block in either
+    finally:
+        keep.close()
+        work.close()
