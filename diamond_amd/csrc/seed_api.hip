@@ -193,28 +193,44 @@ extern "C" int dmnd_auto_query_indexed(const dmnd_seed_params* params, const int
 	std::memcpy(&sp, params, sizeof(sp));
 	sp.seed_encoding = SEED_HASHED;
 	// (3e7 keys per shape for a block at the limit: sorted on one thread that was 2.3 s per shape, more than the whole search of
-	// such a block takes on the device -- eight threads each collect, sort and count the keys of their eighth of the key space)
+	// such a block takes on the device. Eight threads: each hashes the seeds of its eighth of the sequences into eight buckets by key,
+	// then each sorts and counts one bucket of all eight)
 	uint64_t largest = 0;
 	constexpr int T = 8;
 	for (int sid = 0; sid < sp.n_shapes; ++sid) {
+		std::vector<uint64_t> bucket[T][T];                  // [producer][key class]
 		uint64_t distinct[T] = { 0 };
-		std::vector<std::thread> team;
-		for (int t = 0; t < T; ++t)
-			team.emplace_back([&, t] {
-				std::vector<uint64_t> keys;
-				keys.reserve((size_t)letters / T + 1024);
-				for (int64_t i = 0; i < nq; ++i)
-					for (int64_t p = qlimits[i]; p + sp.shape_len[sid] < qlimits[i + 1]; ++p) {
-						uint64_t k;
-						if (seed_key_hashed(sp, sid, qdata + p, k) && (int)((k * 0x9E3779B97F4A7C15ull) >> 61) == t) keys.push_back(k);
-					}
-				std::sort(keys.begin(), keys.end());
-				distinct[t] = (uint64_t)(std::unique(keys.begin(), keys.end()) - keys.begin());
-			});
-		for (std::thread& th : team) th.join();
+		{
+			std::vector<std::thread> team;
+			for (int t = 0; t < T; ++t)
+				team.emplace_back([&, t] {
+					for (int c = 0; c < T; ++c) bucket[t][c].reserve((size_t)letters / (T * T) + 1024);
+					for (int64_t i = nq * t / T; i < nq * (t + 1) / T; ++i)
+						for (int64_t p = qlimits[i]; p + sp.shape_len[sid] < qlimits[i + 1]; ++p) {
+							uint64_t k;
+							if (seed_key_hashed(sp, sid, qdata + p, k)) bucket[t][(int)((k * 0x9E3779B97F4A7C15ull) >> 61)].push_back(k);
+						}
+				});
+			for (std::thread& th : team) th.join();
+		}
+		{
+			std::vector<std::thread> team;
+			for (int c = 0; c < T; ++c)
+				team.emplace_back([&, c] {
+					std::vector<uint64_t> keys;
+					size_t n = 0;
+					for (int t = 0; t < T; ++t) n += bucket[t][c].size();
+					keys.reserve(n);
+					for (int t = 0; t < T; ++t) { keys.insert(keys.end(), bucket[t][c].begin(), bucket[t][c].end()); std::vector<uint64_t>().swap(bucket[t][c]); }
+					std::sort(keys.begin(), keys.end());
+					distinct[c] = (uint64_t)(std::unique(keys.begin(), keys.end()) - keys.begin());
+				});
+			for (std::thread& th : team) th.join();
+		}
 		uint64_t all = 0;
-		for (int t = 0; t < T; ++t) all += distinct[t];
+		for (int c = 0; c < T; ++c) all += distinct[c];
 		largest = std::max(largest, next_pow2((double)all * 1.25));
+		if (largest > (uint64_t)(32 * MiB)) break;          // the answer is no whatever the other shapes say
 	}
 	*query_indexed = largest <= (uint64_t)(32 * MiB) ? 1 : 0;
 	return DMND_OK;
