@@ -657,7 +657,7 @@ def main():
         # HBM traffic of the dominant kernel per launch: FETCH_SIZE of a separate `rocprofv3 --pmc FETCH_SIZE` pass over this same
         # command (tools/profile_r03.sh), doubled as MI355X_MICROARCH.md prescribes for gfx950, plus WRITE_SIZE; only quoted for the
         # configuration and kernel variant it was measured on
-        pmc_path = next((q for q in (os.path.join(ROOT, "profiles", "r%02d_pmc_summary_%s.json" % (r, args.config)) for r in (3, 2)) if os.path.exists(q)), None)
+        pmc_path = next((q for q in (os.path.join(ROOT, "profiles", "r%02d_pmc_summary_%s.json" % (r, args.config)) for r in (4, 3, 2)) if os.path.exists(q)), None)
         if world == 1 and args.queries == 10_000 and args.families == 100_000 and NB == 1 and pmc_path:
             pmc = json.load(open(pmc_path))
             k = [v for name, v in pmc.items() if "seed_stream_fast_kernel" in name]
@@ -677,6 +677,10 @@ def main():
                                          "frac": k[0]["TCC_REQ_sum_per_launch"] / (k_alone * 1e-3) / L2_REQ_PEAK,
                                          "note": "the kernel's real limit: one 4-byte probe of the L2-resident query-seed bitmap per reference position = one L2 "
                                                  "request per letter (TCC_REQ of the committed PMC pass / launch time alone)"}
+                # ... and as plain fields of the roofline object, for readers that do not descend into the sub-objects
+                rl["hbm_measured_frac"] = rl["hbm_measured"]["frac"]
+                if "l2_requests" in rl:
+                    rl["l2_requests_frac"] = rl["l2_requests"]["frac"]
         # SURVEY 8(d)'s whole-pipeline figure: bytes_total = bytes_seed + bytes_sw over the step's wall time
         S = seed_params.n_shapes
         L = ref_letters * NB + int(w.ql[-1] - w.ql[0]) * NB

@@ -46,16 +46,16 @@ hipError_t dmnd::sync_stream(hipStream_t s)
 	if (spin_sync()) return hipStreamSynchronize(s);
 	hipEvent_t ev = nullptr;
 	{
+		// (looked up and created under the lock: the reference block's upload lane lets a second host thread wait on a context's
+		// main stream, so "one host thread per stream" does not hold for the first wait)
 		std::lock_guard<std::mutex> g(g_sync_mutex);
 		auto it = g_sync_events.find(s);
 		if (it != g_sync_events.end()) ev = it->second;
-	}
-	if (!ev) {
-		// a stream is driven by one host thread at a time, so two threads never race to create its event
-		const hipError_t e = hipEventCreateWithFlags(&ev, hipEventBlockingSync | hipEventDisableTiming);
-		if (e != hipSuccess) return e;
-		std::lock_guard<std::mutex> g(g_sync_mutex);
-		g_sync_events[s] = ev;
+		else {
+			const hipError_t e = hipEventCreateWithFlags(&ev, hipEventBlockingSync | hipEventDisableTiming);
+			if (e != hipSuccess) return e;
+			g_sync_events[s] = ev;
+		}
 	}
 	const hipError_t e = hipEventRecord(ev, s);
 	return e != hipSuccess ? e : hipEventSynchronize(ev);

@@ -705,7 +705,12 @@ int run_blastp(const Options& o)
 	const auto t_all = std::chrono::steady_clock::now();
 	// the HIP runtime and the library's code object take their time to start (a quarter of a second on the MI355X boxes of this
 	// project): that runs beside reading the queries, opening the database and loading the first reference block
-	std::future<int> gpu_ready = std::async(std::launch::async, [] { const int rc = dmnd_init(-1); g_timeline.mark("dmnd_init"); return rc; });
+	// (the error text is thread-local in the library: it travels back with the code)
+	std::future<std::pair<int, std::string>> gpu_ready = std::async(std::launch::async, [] {
+		const int rc = dmnd_init(-1);
+		g_timeline.mark("dmnd_init");
+		return std::make_pair(rc, std::string(rc == DMND_OK ? "" : dmnd_last_error()));
+	});
 	// tantan's likelihood ratios need the scoring matrix' lambda, a 6 ms root search (kept per matrix by the library): beside the file reads too
 	std::future<void> lambda_ready = std::async(std::launch::async, [&o, tantan] {
 		dmnd_params mp;
@@ -862,7 +867,7 @@ int run_blastp(const Options& o)
 	// one context per GPU, driven by its own host thread (measured, round 4: creating the context and starting the first block's upload
 	// while dmnd_init still loads code objects stretches that load from 95 to 123 ms -- page-locking 300 MB and the loader contend --
 	// and the seed stage starts 6 ms later than with the wait here)
-	if (gpu_ready.get() != DMND_OK) throw std::runtime_error(dmnd_last_error());
+	{ const std::pair<int, std::string> r = gpu_ready.get(); if (r.first != DMND_OK) throw std::runtime_error(r.second.empty() ? "dmnd_init failed" : r.second); }
 	std::vector<dmnd_ctx*> ctxs((size_t)n_gpus, nullptr);
 	for (int g = 0; g < n_gpus; ++g) {
 		dmnd_ctx* c = dmnd_create(n_gpus > 1 && !share_gpu ? g : -1, &p);
@@ -1489,7 +1494,12 @@ int run_blastp(const Options& o)
 	// The results are on disk. Tearing the contexts down buffer by buffer and unloading the HIP runtime costs tens of
 	// milliseconds that buy nothing -- the driver reclaims a process's HBM when it exits -- so the process leaves through _exit
 	// after the report below (DMND_CLI_CLEAN_EXIT=1: full teardown, for leak checkers).
-	const bool clean_exit = std::getenv("DMND_CLI_CLEAN_EXIT") != nullptr;
+	// A process that a profiler, tracer, sanitizer or coverage tool looks into leaves the normal way on its own: those do their
+	// end-of-run work in exit handlers (a rocprofv3 run of this binary that left through _exit never finished).
+	bool clean_exit = std::getenv("DMND_CLI_CLEAN_EXIT") != nullptr;
+	for (const char* v : { "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "ROCPROF_OUTPUT_PATH", "ROCPROFILER_METRICS_PATH", "HSA_TOOLS_LIB", "ROCTRACER_DOMAIN", "ASAN_OPTIONS", "TSAN_OPTIONS", "GCOV_PREFIX", "LLVM_PROFILE_FILE" })
+		if (std::getenv(v)) clean_exit = true;
+	if (const char* pre = std::getenv("LD_PRELOAD")) if (std::strstr(pre, "rocprof") || std::strstr(pre, "roctracer") || std::strstr(pre, "asan")) clean_exit = true;
 	if (clean_exit) for (dmnd_ctx* c : ctxs) dmnd_destroy(c);
 	std::cerr << "Uploading blocks to HBM...  [" << ms_upload / 1e3 << "s]\n";
 	if (motifs) std::cerr << "Soft-masked letters (motifs): " << motif_letters << "\n";

@@ -285,6 +285,9 @@ static SeedSizes seed_sizes(const dmnd_ctx* c, const SeedParams& sp, int64_t nq_
 	const uint64_t slots_x8 = [&] { const char* e = getenv("DMND_SEED_SLOTS_X8"); return (uint64_t)(e ? std::min(64, std::max(8, atoi(e))) : (seed_stream_can_fuse(sp) ? 32 : 16)); }();
 	z.slots = 1024;
 	while (z.slots * 8 < (uint64_t)nq_pos * slots_x8) z.slots <<= 1;
+	// slot numbers are 32-bit in the position lists and the joined-position records (LIST_END = all ones): a query block above 2^30
+	// positions keeps the table at 2^31 slots, i.e. fewer slots per position (the query-block limit of 4 G letters is checked by the caller)
+	while (z.slots > ((uint64_t)1 << 31) && z.slots / 2 >= (uint64_t)nq_pos + (uint64_t)nq_pos / 4) z.slots >>= 1;
 
 	// bitmap: >= 16 bits per query position, at most 2^27 bits (16 MB); word mask for 32-bit words
 	uint64_t bm_words = 1 << 15;
@@ -419,6 +422,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	if (nq_pos >= 0xffffffffLL) return fail(DMND_E_ARG, "dmnd_seed_search: query block larger than 4G letters");
 	const int S = sp.n_shapes;
 	const SeedSizes z = seed_sizes(c, sp, nq_pos);
+	if (z.slots > ((uint64_t)1 << 31)) return fail(DMND_E_ARG, "dmnd_seed_search: query block too large for 32-bit slot numbers (more than 1.7 G seed positions): cut it into smaller blocks");
 	const uint64_t slots = z.slots, bm_words = z.bm_words, bm1_words = z.bm1_words;
 	const uint32_t bm1_k3 = z.bm1_k3;
 	const int stream_nt = z.stream_nt, probe_policy = z.probe_policy, SB = z.SB;
