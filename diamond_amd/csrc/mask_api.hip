@@ -308,7 +308,9 @@ static int mask_impl(dmnd_ctx* c, int which, int8_t* host_data, const int32_t* i
 	// longest of them, whatever else the device has to do -- 6 ms for a 3.0e8-letter block, but 6 ms too for a block of 10 000
 	// queries with a 7 000-letter one among them, and 70 ms for a titin. The wavefront-per-sequence kernel is 7 times slower per
 	// letter on a full device and 3 times faster on a single sequence. So: sequences longer than `long_len` -- the length whose
-	// lock-step time equals what the lanes kernel needs for the block's letters anyway -- go to the wavefront kernel (their ids
+	// lock-step time (0.9 us per step on a full device) equals what the lanes kernel needs for the block's letters anyway (20 ps per
+	// letter), and never below 1024 letters (measured on 51 000 targets of 15e6 letters, the lazy masking of C2's stock run: all
+	// in the lanes kernel 1.2 ms, those above 256 letters in the wavefront kernel 3.0 ms) -- go to the wavefront kernel (their ids
 	// and scratch offsets listed here), the lanes kernel leaves them out (its length keys of them are 0).
 	int64_t max_len = 0, total_len = 0, long_len = 0, n_long = 0, long_letters = 0;
 	std::vector<int32_t> long_ids;
@@ -318,7 +320,7 @@ static int mask_impl(dmnd_ctx* c, int which, int8_t* host_data, const int32_t* i
 		if (ids) for (int64_t k = 0; k < n_ids; ++k) total_len += lim[(size_t)ids[k] + 1] - lim[(size_t)ids[k]] - 1;
 		else total_len = raw;
 		static const int64_t long_env = [] { const char* e = std::getenv("DMND_TANTAN_LONG"); return e ? std::atoll(e) : (long long)0; }();
-		long_len = long_env > 0 ? long_env : std::max<int64_t>(256, total_len / 90000);
+		long_len = long_env > 0 ? long_env : std::max<int64_t>(1024, total_len / 45000);
 		for (int64_t k = 0; k < n_work; ++k) {
 			const int64_t id = work_id(k), l = lim[(size_t)id + 1] - lim[(size_t)id] - 1;
 			if (l > long_len) { long_ids.push_back((int32_t)id); long_soff.push_back(long_letters); long_letters += l + 1; }
