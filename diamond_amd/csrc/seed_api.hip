@@ -429,6 +429,8 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	const size_t slot_bytes = (size_t)slots << z.slot_shift;      // one shape's table
 	const bool fused = z.fused, reuse = z.reuse;
 	const size_t bm_total = z.bm_total;
+	int list_key_bits = 1;                                // of the list sort's keys: log2(slots) + 1 (launch_seed_lists)
+	while (((uint64_t)1 << list_key_bits) <= slots) ++list_key_bits;
 	// key classes (seed_core.h seed_class): the short-seed pipeline, when the geometry allows eighths (DMND_SEED_CLASSES=0: one range)
 	static const bool classes_env = [] { const char* e = getenv("DMND_SEED_CLASSES"); return !e || atoi(e) != 0; }();
 	const int classes = fused && classes_env && slots >= 64 && bm1_words % 8 == 0 && bm1_words >= 64 ? 8 : 0;
@@ -520,7 +522,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	auto query_side = [&](const SeedArgs& a, int sid, bool build) -> int {
 		if (build) {
 			HIP_TRY(launch_seed_index(a, sid, st));
-			HIP_TRY(launch_seed_lists(a, sid, c->seed_qkeys.as<uint32_t>(), c->seed_qlist.as<uint32_t>() + (size_t)(SB == 1 ? 0 : sid) * nq_pos, 32, &c->sort_tmp, &c->sort_tmp_bytes, st));
+			HIP_TRY(launch_seed_lists(a, sid, c->seed_qkeys.as<uint32_t>(), c->seed_qlist.as<uint32_t>() + (size_t)(SB == 1 ? 0 : sid) * nq_pos, list_key_bits, &c->sort_tmp, &c->sort_tmp_bytes, st));
 		}
 		else HIP_TRY(launch_seed_reset(a, sid, st));
 		return DMND_OK;

@@ -1214,10 +1214,12 @@ hipError_t launch_seed_lists(const SeedArgs& a, int sid, uint32_t* sorted_slot, 
 {
 	const int64_t n = a.q_end - a.q_begin;
 	if (n <= 0) return hipSuccess;
-	(void)slot_bits;                                      // LIST_END (all ones) must sort last: all 32 key bits
+	// LIST_END (all ones) must sort last. slot_bits = log2(slots) + 1: every slot number has bit log2(slots) clear, LIST_END has it
+	// set, so the sort may stop there (C2: 24 key bits = three radix passes instead of four)
+	const unsigned end_bit = (unsigned)std::min(32, std::max(1, slot_bits));
 	size_t need = 0;
 	rocprim::counting_iterator<uint32_t> iota(0);
-	hipError_t e = rocprim::radix_sort_pairs(nullptr, need, a.qslot, sorted_slot, iota, qlist_out, (size_t)n, 0, 32, st);
+	hipError_t e = rocprim::radix_sort_pairs(nullptr, need, a.qslot, sorted_slot, iota, qlist_out, (size_t)n, 0, end_bit, st);
 	if (e != hipSuccess) return e;
 	if (need > *tmp_bytes) {
 		if (*tmp) (void)hipFree(*tmp);
@@ -1226,7 +1228,7 @@ hipError_t launch_seed_lists(const SeedArgs& a, int sid, uint32_t* sorted_slot, 
 		if (e != hipSuccess) return e;
 		*tmp_bytes = need;
 	}
-	e = rocprim::radix_sort_pairs(*tmp, need, a.qslot, sorted_slot, iota, qlist_out, (size_t)n, 0, 32, st);
+	e = rocprim::radix_sort_pairs(*tmp, need, a.qslot, sorted_slot, iota, qlist_out, (size_t)n, 0, end_bit, st);
 	if (e != hipSuccess) return e;
 	hipLaunchKernelGGL(seed_lists_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, a, sid, (const uint32_t*)sorted_slot, (const uint32_t*)qlist_out, n);
 	return hipGetLastError();
