@@ -139,3 +139,18 @@ extern "C" int64_t emu_seed_search_soft(const SeedParams* cp, const int8_t* matr
 	}
 	return n;
 }
+
+// round 4: key classes of the short-seed pipeline (seed_core.h seed_class) and the partitioned indexing built on them
+// (SeedArgs::home / bm1_index, seed_kernels.h, restated here: that header needs the HIP runtime)
+extern "C" void emu_seed_classes(const uint64_t* keys, int64_t n, uint64_t slot_mask, uint32_t bm1_words, uint32_t* cls, uint64_t* home, uint32_t* word)
+{
+	for (int64_t i = 0; i < n; ++i) {
+		const uint64_t hh = seed_hash(keys[i]);
+		const uint32_t c = seed_class(keys[i]);
+		const uint64_t low = slot_mask >> 3;
+		cls[i] = c;
+		home[i] = (uint64_t)c * (low + 1) | (hh & low);
+		const uint32_t w8 = bm1_words >> 3;
+		word[i] = c * w8 + bm1_word(seed_hash_a(keys[i]), w8);
+	}
+}
