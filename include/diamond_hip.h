@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DMND_ABI_VERSION 8      /* 2: dmnd_match.frame, seed parameters (ungapped filter, translated queries), dmnd_extend_plan(query_contexts); 3: seed_encoding; 4: output formats; 5: DMND_MAX_SHAPES 64; 6: dmnd_host_alloc, dmnd_share_block; 7: dmnd_set_max_hsps, several dmnd_match records per target, global ranking; 8: --comp-based-stats 2..5 (dmnd_cbs_*, dmnd_upload_matrices, dmnd_dp_target::cbs_off <= -2); dmnd_mask_block patches host_data in place (the full copy-back of ABI <= 6 only above 1/16 masked letters) */
+#define DMND_ABI_VERSION 9      /* 2: dmnd_match.frame, seed parameters (ungapped filter, translated queries), dmnd_extend_plan(query_contexts); 3: seed_encoding; 4: output formats; 5: DMND_MAX_SHAPES 64; 6: dmnd_host_alloc, dmnd_share_block; 7: dmnd_set_max_hsps, several dmnd_match records per target, global ranking; 8: --comp-based-stats 2..5 (dmnd_cbs_*, dmnd_upload_matrices, dmnd_dp_target::cbs_off <= -2); dmnd_mask_block patches host_data in place (the full copy-back of ABI <= 6 only above 1/16 masked letters); 9: frameshift alignment (dmnd_set_frameshift, dmnd_frameshift_swipe, dmnd_match.read_begin / read_end: the record is 104 bytes), dmnd_set_context_motif_table, dmnd_copy_block */
 
 enum {
 	DMND_OK = 0,
