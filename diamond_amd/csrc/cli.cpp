@@ -776,12 +776,10 @@ int run_blastp(const Options& o)
 	}
 	if (tab_extras && fmt != FMT_FIELDS && !o.header.empty() && o.header != "0") throw std::runtime_error("--header is only available for the tabular format");
 	if (o.frameshift > 0) {
-		// A frameshift alignment changes frame: the formats and fields of this build that walk the query letters along the transcript
-		// read ONE frame. What is printed: the tabular format with the fields that come from the record.
+		// A frameshift alignment changes frame along its transcript. The tabular format prints it with every field (the cursor of
+		// format_api.hip follows the frames); the pairwise, XML, SAM, PAF and DAA writers of this build read ONE frame.
 		if (fmt != FMT_TAB && fmt != FMT_FIELDS) throw std::runtime_error("Frameshift alignments (-F) are printed in the tabular format (-f 6) only in this build.");
-		for (int32_t id : field_ids)
-			if (id == DMND_F_SSEQ || id == DMND_F_BTOP || id == DMND_F_QSEQ_GAPPED || id == DMND_F_SSEQ_GAPPED || id == DMND_F_CIGAR || id == DMND_F_QSEQ_TRANSLATED)
-				throw std::runtime_error("Frameshift alignments (-F): the fields sseq, btop, qseq_gapped, sseq_gapped, cigar and qseq_translated are not available in this build.");
+		if (dmnd_set_format_flags(o.format_flags | DMND_FMT_FRAMESHIFT) != DMND_OK) throw std::runtime_error(dmnd_last_error());      // qseq_translated follows the alignment (config.frame_shift != 0)
 	}
 	// which formats report queries without alignments: pairwise, PAF and SAM by default (DEFAULT_REPORT_UNALIGNED), tabular with --unal 1
 	// (DAA files never list unaligned queries, whatever --unal says: output/join_blocks.cpp:302,365)
@@ -1301,6 +1299,11 @@ int run_blastp(const Options& o)
 			if (want_full_sseq) { full_sseq_buf = db.sequence(m.target); v.full_sseq = full_sseq_buf.data(); } else v.full_sseq = nullptr;
 			v.source_seq = blastx ? reads[m.query].data() : nullptr; v.source_len = blastx ? source_len[m.query] : 0;
 			v.qnum = (int64_t)m.query; v.snum = (int64_t)m.target;
+			// the three reading frames of the alignment's strand: a frameshift alignment walks through them (contexts 0-2 / 3-5 of the read)
+			for (int k = 0; k < 3; ++k) {
+				const size_t c3 = (size_t)m.query * C + (size_t)(m.frame / 3) * 3 + (size_t)k - qr.begin * C;
+				v.qframes[k] = blastx && o.frameshift > 0 ? q.data.data() + q.limits[c3] : nullptr;
+			}
 			return v;
 		};
 		std::vector<char> big;
@@ -1663,10 +1666,17 @@ int run_view(const Options& o)
 			const int32_t ctx_len = blastx ? flen[m.frame] : (int32_t)qlen;
 			m.query = (uint32_t)qnum; m.target = dict;
 			m.hsp.transcript_off = 0;
-			if (dmnd_hsp_from_transcript(&p, ctx, ctx_len, flen[0], (int32_t)slen, tr, &m) != DMND_OK) throw std::runtime_error(dmnd_last_error());
+			if (blastx) {
+				const int strand = m.frame / 3;
+				const int8_t* f3[3] = { frames[strand * 3].data(), frames[strand * 3 + 1].data(), frames[strand * 3 + 2].data() };
+				const int32_t l3[3] = { flen[strand * 3], flen[strand * 3 + 1], flen[strand * 3 + 2] };
+				if (dmnd_hsp_from_transcript_frames(&p, f3, l3, (int32_t)qlen, flen[0], (int32_t)slen, tr, &m) != DMND_OK) throw std::runtime_error(dmnd_last_error());
+			}
+			else if (dmnd_hsp_from_transcript(&p, ctx, ctx_len, flen[0], (int32_t)slen, tr, &m) != DMND_OK) throw std::runtime_error(dmnd_last_error());
 			dmnd_hsp_view v;
 			v.match = &m; v.transcript = tr; v.qtitle = qtitle.c_str(); v.stitle = ref_name[dict]; v.qseq = ctx; v.qlen = ctx_len; v.slen = (int32_t)slen; v.full_sseq = nullptr;
 			v.source_seq = blastx ? seq.data() : nullptr; v.source_len = blastx ? (int32_t)qlen : 0; v.qnum = 0; v.snum = (int64_t)dict;      // the reference's view hands 0 to every record as the query's ordinal (daa_record.h:46-52)
+			for (int k = 0; k < 3; ++k) v.qframes[k] = blastx ? frames[(m.frame / 3) * 3 + k].data() : nullptr;
 			big.resize((size_t)m.hsp.length * 8 + (size_t)qlen * 3 + qtitle.size() * 6 + std::strlen(v.stitle) * 6 + 4096);
 			if (!intro) {
 				intro = true;

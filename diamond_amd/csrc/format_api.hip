@@ -83,13 +83,19 @@ void print_title(Out& o, const char* id, bool full_titles, bool all_titles, cons
 }
 
 // HspContext::Iterator: one alignment column at a time
+// (frameshift alignments, blastx -F: a substitution whose letter is 26 / 27 is a frame shift back / forward, packed_transcript.h:44-58.
+// The cursor then leaves its frame -- TranslatedPosition::shift_forward / shift_back, translated_position.h:97-113 -- and reads the
+// query letters from the view's three frames of the strand)
+enum { FS_REVERSE = 26, FS_FORWARD = 27 };
 struct Walk {
 	const dmnd_hsp_view& v;
 	const uint8_t* t;
 	int left, count = 0, op = 0, letter = 0;
-	int qpos, spos;
+	int qpos, spos, foff;
 	bool ok = false;
-	explicit Walk(const dmnd_hsp_view& view) : v(view), t(view.transcript), left(view.match->hsp.transcript_len), qpos(view.match->hsp.q_begin), spos(view.match->hsp.s_begin) { fetch(); }
+	explicit Walk(const dmnd_hsp_view& view) : v(view), t(view.transcript), left(view.match->hsp.transcript_len), qpos(view.match->hsp.q_begin), spos(view.match->hsp.s_begin),
+		foff(view.match->frame % 3) { fetch(); }
+	int shift() const { return op == OP_SUBSTITUTION ? (letter == FS_FORWARD ? 1 : letter == FS_REVERSE ? -1 : 0) : 0; }
 	void fetch()
 	{
 		ok = false;
@@ -105,14 +111,19 @@ struct Walk {
 	bool good() const { return ok; }
 	void next()
 	{
-		if (op != OP_DELETION) ++qpos;
-		if (op != OP_INSERTION) ++spos;
+		const int s = shift();
+		if (s > 0) { if (++foff == 3) { foff = 0; ++qpos; } }
+		else if (s < 0) { if (--foff < 0) { foff = 2; --qpos; } }
+		else {
+			if (op != OP_DELETION) ++qpos;
+			if (op != OP_INSERTION) ++spos;
+		}
 		if (--count == 0) fetch();
 	}
-	int query() const { return v.qseq[qpos] & 31; }
+	int query() const { return (v.qframes[foff] ? v.qframes[foff][qpos] : v.qseq[qpos]) & 31; }
 	int subject() const { return (op == OP_MATCH || op == OP_INSERTION) ? query() : letter; }
-	char query_char() const { return op == OP_DELETION ? '-' : AA[query()]; }
-	char subject_char() const { return op == OP_INSERTION ? '-' : AA[subject()]; }
+	char query_char() const { const int s = shift(); return s > 0 ? '\\' : s < 0 ? '/' : op == OP_DELETION ? '-' : AA[query()]; }
+	char subject_char() const { return op == OP_INSERTION || shift() ? '-' : AA[subject()]; }
 };
 
 struct Frame {
@@ -143,16 +154,19 @@ int need_transcript(int id)
 	}
 }
 
-// print_cigar (sam_format.cpp:67-84): runs of M (match + substitution), I, D
+// print_cigar (sam_format.cpp:67-84): runs of M (match + substitution), I, D, \ (frame shift forward), / (back)
 void print_cigar(Out& o, const dmnd_hsp_view& v)
 {
-	static const int map[4] = { 0, 1, 2, 0 };
-	static const char letter[3] = { 'M', 'I', 'D' };
+	static const int map[6] = { 0, 1, 2, 0, 3, 4 };
+	static const char letter[5] = { 'M', 'I', 'D', '\\', '/' };
 	unsigned n = 0;
 	int op = 0;
 	const uint8_t* t = v.transcript;
 	for (int i = 0; i < v.match->hsp.transcript_len; ++i) {
-		const int o2 = t[i] >> 6, cnt = (o2 == OP_MATCH || o2 == OP_INSERTION) ? (t[i] & 63) : 1;
+		int o2 = t[i] >> 6;
+		const int cnt = (o2 == OP_MATCH || o2 == OP_INSERTION) ? (t[i] & 63) : 1;
+		if (o2 == OP_SUBSTITUTION && (t[i] & 63) == FS_FORWARD) o2 = 4;
+		else if (o2 == OP_SUBSTITUTION && (t[i] & 63) == FS_REVERSE) o2 = 5;
 		if (map[o2] == op) n += (unsigned)cnt;
 		else { if (n > 0) { o << n << letter[op]; } n = (unsigned)cnt; op = map[o2]; }
 	}
@@ -183,7 +197,9 @@ int print_field(Out& o, const dmnd_hsp_view& v, int id)
 		else for (int i = h.q_begin; i < h.q_end; ++i) o << AA[v.qseq[i] & 31];
 		break;
 	case DMND_F_SSEQ:
-		for (Walk w(v); w.good(); w.next()) if (w.op != OP_INSERTION) o << AA[w.subject()];
+		// (a frame-shift column is not skipped: the reference's iterator answers its subject() with the query letter it stands on,
+		// blast_tab_format.cpp:269-276 with match.h:325-335)
+		for (Walk w(v); w.good(); w.next()) if (w.op != OP_INSERTION) o << AA[w.shift() ? w.query() : w.subject()];
 		break;
 	case DMND_F_EVALUE: o.print_e(m.evalue); break;
 	case DMND_F_BITSCORE: o << m.bit_score; break;
@@ -202,7 +218,7 @@ int print_field(Out& o, const dmnd_hsp_view& v, int id)
 		for (Walk w(v); w.good(); w.next()) {
 			if (w.op == OP_MATCH) { ++n_matches; continue; }
 			if (n_matches > 0) { o << n_matches; n_matches = 0; }
-			if (w.op == OP_SUBSTITUTION) o << w.query_char() << w.subject_char();
+			if (w.op == OP_SUBSTITUTION) o << w.query_char() << w.subject_char();      // (a frame shift prints as \\- or /-: blast_tab_format.cpp:372-380)
 			else if (w.op == OP_INSERTION) o << w.query_char() << '-';
 			else o << '-' << w.subject_char();
 		}
@@ -228,7 +244,11 @@ int print_field(Out& o, const dmnd_hsp_view& v, int id)
 	case DMND_F_SSEQ_GAPPED: for (Walk w(v); w.good(); w.next()) o << w.subject_char(); break;
 	case DMND_F_QSTRAND: o << (f.translated ? (f.blast_frame() > 0 ? '+' : '-') : '+'); break;
 	case DMND_F_CIGAR: print_cigar(o, v); break;
-	case DMND_F_QSEQ_TRANSLATED: for (int i = h.q_begin; i < h.q_end; ++i) o << AA[v.qseq[i] & 31]; break;
+	case DMND_F_QSEQ_TRANSLATED:
+		// with a frameshift penalty set the reference reads the translated query along the alignment (blast_tab_format.cpp:565-574)
+		if ((g_format_flags.load() & DMND_FMT_FRAMESHIFT) && v.transcript) { for (Walk w(v); w.good(); w.next()) if (w.op != OP_DELETION && !w.shift()) o << AA[w.query()]; }
+		else for (int i = h.q_begin; i < h.q_end; ++i) o << AA[v.qseq[i] & 31];
+		break;
 	case DMND_F_HSPNUM: o << 0; break;                      // max_hsps = 1
 	default: return fail(DMND_E_ARG, "dmnd_format_fields: unknown field id");
 	}
@@ -473,7 +493,7 @@ void print_lf(Out& o, double x) { char b[48]; std::snprintf(b, sizeof b, "%lf", 
 
 extern "C" int dmnd_set_format_flags(uint32_t flags)
 {
-	if (flags & ~(uint32_t)(DMND_FMT_XML_BLORD | DMND_FMT_NO_PARSE_SEQIDS | DMND_FMT_SAM_QUERY_LEN)) return fail(DMND_E_ARG, "dmnd_set_format_flags: unknown flag");
+	if (flags & ~(uint32_t)(DMND_FMT_XML_BLORD | DMND_FMT_NO_PARSE_SEQIDS | DMND_FMT_SAM_QUERY_LEN | DMND_FMT_FRAMESHIFT)) return fail(DMND_E_ARG, "dmnd_set_format_flags: unknown flag");
 	g_format_flags.store(flags);
 	return DMND_OK;
 }
@@ -710,23 +730,33 @@ extern "C" int dmnd_daa_match_read(const uint8_t* p, int64_t avail, int translat
 
 // HspContext::parse (basic/hssp.cpp:48-105): ends, length, identities, mismatches, positives, gaps and gap openings (a run of
 // insertions and deletions is one opening) from the transcript; e-value and bit score from the score.
-extern "C" int dmnd_hsp_from_transcript(const dmnd_params* params, const int8_t* qseq, int32_t qlen, int32_t evalue_qlen, int32_t slen, const uint8_t* transcript, dmnd_match* m)
+static int hsp_from_transcript(const dmnd_params* params, const int8_t* const* qframes, const int32_t* qframe_len, int32_t source_len, int32_t evalue_qlen, int32_t slen,
+	const uint8_t* transcript, dmnd_match* m)
 {
-	if (!params || !qseq || !transcript || !m || qlen < 0) return fail(DMND_E_ARG, "dmnd_hsp_from_transcript: bad argument");
 	dmnd_hsp& h = m->hsp;
 	h.length = h.identities = h.mismatches = h.positives = h.gap_openings = h.gaps = 0;
-	int qpos = h.q_begin, spos = h.s_begin, run = 0;
+	const int off0 = qframes[1] ? m->frame % 3 : 0;         // one frame given: it is the alignment's
+	int qpos = h.q_begin, spos = h.s_begin, run = 0, foff = off0;
+	bool shifted = false;
 	for (int32_t k = 0; k < h.transcript_len; ++k) {
 		const uint8_t b = transcript[k];
 		const int op = b >> 6;
 		const int count = (op == OP_MATCH || op == OP_INSERTION) ? (b & 63) : 1;
+		const int shift = op == OP_SUBSTITUTION ? ((b & 63) == FS_FORWARD ? 1 : (b & 63) == FS_REVERSE ? -1 : 0) : 0;
+		if (shift && !qframes[1]) return fail(DMND_E_ARG, "dmnd_hsp_from_transcript: a frameshift alignment needs the three frames of its strand");
 		for (int c = 0; c < count; ++c) {
-			if (op != OP_DELETION && qpos >= qlen) return fail(DMND_E_ARG, "Query sequence index out of bounds.");
+			if (op != OP_DELETION && (qpos < 0 || qpos >= qframe_len[foff])) return fail(DMND_E_ARG, "Query sequence index out of bounds.");
 			++h.length;
+			if (shift) {                                          // counted as a column, nothing else (HspContext::parse, hssp.cpp:67-91)
+				shifted = true;
+				if (shift > 0) { if (++foff == 3) { foff = 0; ++qpos; } }
+				else if (--foff < 0) { foff = 2; --qpos; }
+				continue;
+			}
 			if (op == OP_MATCH) { ++h.identities; ++h.positives; run = 0; }
 			else if (op == OP_SUBSTITUTION) {
 				++h.mismatches;
-				if (params->matrix8[(qseq[qpos] & 31) * 32 + (b & 31)] > 0) ++h.positives;
+				if (params->matrix8[(qframes[foff][qpos] & 31) * 32 + (b & 31)] > 0) ++h.positives;
 				run = 0;
 			}
 			else { if (run == 0) ++h.gap_openings; ++run; ++h.gaps; }
@@ -735,9 +765,30 @@ extern "C" int dmnd_hsp_from_transcript(const dmnd_params* params, const int8_t*
 		}
 	}
 	h.q_end = qpos; h.s_end = spos;
+	if (shifted) {
+		// TranslatedPosition::absolute_interval over the walk's first and last position (translated_position.h:129-135)
+		const int b_in = off0 + 3 * h.q_begin, e_in = foff + 3 * qpos;
+		if (m->frame < 3) { m->read_begin = b_in; m->read_end = e_in; }
+		else { m->read_begin = source_len - e_in; m->read_end = source_len - b_in; }
+	}
 	m->evalue = dmnd_evalue_p(params, h.score, evalue_qlen, slen);
 	m->bit_score = dmnd_bitscore_p(params, (double)h.score);
 	return DMND_OK;
+}
+
+extern "C" int dmnd_hsp_from_transcript(const dmnd_params* params, const int8_t* qseq, int32_t qlen, int32_t evalue_qlen, int32_t slen, const uint8_t* transcript, dmnd_match* m)
+{
+	if (!params || !qseq || !transcript || !m || qlen < 0) return fail(DMND_E_ARG, "dmnd_hsp_from_transcript: bad argument");
+	const int8_t* frames[3] = { qseq, nullptr, nullptr };
+	const int32_t lens[3] = { qlen, 0, 0 };
+	return hsp_from_transcript(params, frames, lens, 0, evalue_qlen, slen, transcript, m);
+}
+
+extern "C" int dmnd_hsp_from_transcript_frames(const dmnd_params* params, const int8_t* const qframes[3], const int32_t qframe_len[3], int32_t source_len, int32_t evalue_qlen,
+	int32_t slen, const uint8_t* transcript, dmnd_match* m)
+{
+	if (!params || !qframes || !qframe_len || !qframes[0] || !qframes[1] || !qframes[2] || !transcript || !m || source_len < 0) return fail(DMND_E_ARG, "dmnd_hsp_from_transcript_frames: bad argument");
+	return hsp_from_transcript(params, qframes, qframe_len, source_len, evalue_qlen, slen, transcript, m);
 }
 
 extern "C" int64_t dmnd_format_fields_unaligned(const char* qtitle, const int8_t* qseq, int32_t qlen, const int8_t* source_seq, int32_t source_len,

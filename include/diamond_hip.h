@@ -565,6 +565,9 @@ typedef struct {
 	const int8_t* source_seq;      /* blastx: the DNA read (A C G T N = 0..4); blastp: NULL */
 	int32_t source_len;            /* blastx: its length; blastp: ignored */
 	int64_t qnum, snum;            /* ordinal ids in the query file / database */
+	const int8_t* qframes[3];      /* blastx: the letters of the three reading frames (offset 0, 1, 2) of the alignment's strand -- a frameshift
+	                                  alignment (-F) leaves the frame of qseq, and the fields that walk the alignment (btop, cigar, sseq, qseq_gapped,
+	                                  sseq_gapped, qseq_translated) then read these; all NULL: one frame (qseq) */
 } dmnd_hsp_view;
 /* Field names of --outfmt 6 (blast_tab_format.cpp:46-102) -> DMND_F_*; DMND_E_ARG with the reference's message for an unknown
  * or unavailable field. *needs_transcript = 1 if a field reads the transcript (HspValues::TRANSCRIPT). */
@@ -595,7 +598,8 @@ int64_t dmnd_format_sam(const dmnd_hsp_view* v, const char* unaligned_qtitle, ch
  * reports unaligned queries by default (intro + epilog with unaligned = 1). */
 /* Process-wide switches of the writers, as the reference reads them from its global config: --xml-blord-format (Hit_id = gnl|BL_ORD_ID|<snum>,
  * Hit_def = all titles; xml_format.cpp:43-48), --no-parse-seqids (Hit_accession = the id as it is), --sam-query-len (ZQ:i: tag). */
-enum { DMND_FMT_XML_BLORD = 1, DMND_FMT_NO_PARSE_SEQIDS = 2, DMND_FMT_SAM_QUERY_LEN = 4 };
+enum { DMND_FMT_XML_BLORD = 1, DMND_FMT_NO_PARSE_SEQIDS = 2, DMND_FMT_SAM_QUERY_LEN = 4,
+	DMND_FMT_FRAMESHIFT = 8 };     /* config.frame_shift != 0: qseq_translated follows the alignment (blast_tab_format.cpp:565-574) */
 int dmnd_set_format_flags(uint32_t flags);
 int64_t dmnd_format_xml_header(const char* program, const char* version, const char* database, const char* first_qtitle, int32_t first_qlen,
 	const char* matrix, int gap_open, int gap_extend, double max_evalue, char* buf, int64_t cap);
@@ -632,6 +636,11 @@ int64_t dmnd_format_daa_match(const dmnd_hsp_view* v, uint32_t dict_id, char* bu
  * frame 0 there) and the scoring parameters of the archive's header (params->db_letters = its database letters). */
 int dmnd_daa_match_read(const uint8_t* p, int64_t avail, int translated, int32_t source_len, uint32_t* dict_id, dmnd_match* m, int64_t* transcript_off, int64_t* used);
 int dmnd_hsp_from_transcript(const dmnd_params* params, const int8_t* qseq, int32_t qlen, int32_t evalue_qlen, int32_t slen, const uint8_t* transcript, dmnd_match* m);
+/* The same for a translated query given as the three reading frames of the alignment's strand (frame offsets 0, 1, 2; m->frame names the
+ * first column's): a frameshift alignment (blastx -F) changes frame along its transcript, and its range on the read
+ * (m->read_begin / read_end) is that of its first and last column (TranslatedPosition::absolute_interval). */
+int dmnd_hsp_from_transcript_frames(const dmnd_params* params, const int8_t* const qframes[3], const int32_t qframe_len[3], int32_t source_len, int32_t evalue_qlen,
+	int32_t slen, const uint8_t* transcript, dmnd_match* m);
 
 /* -- timing hooks for bench.py: device time of the DP kernels of the last dmnd_banded_swipe call,
  *    measured with HIP events on the stream the kernels ran on ------------------------------------ */

@@ -26,3 +26,8 @@ DIAMOND_TAP_3F="$HERE/f3_k1.tap" "$TAP" blastx -q "$HERE/fs_reads.fna" -d "$HERE
 "$ROOT/oracle/_ref/diamond" blastx -q "$HERE/fs_reads.fna" -d "$HERE/fs_db.faa" -F 15 --range-culling --top 10 -o "$HERE/fs_f15_rc.tsv" -p1 2>/dev/null
 ls -la "$HERE"/f3_k3.tap "$HERE"/fs_*
 rm -rf "$TMP"
+# the archive of the same run and what the reference's own `view` prints of it (tests/test_view.py::test_view_of_frameshift_alignments)
+TMP2="$(mktemp -d)"
+"$ROOT/oracle/_ref/diamond" blastx -q "$HERE/fs_reads.fna" -d "$HERE/fs_db.faa" -F 15 -f 100 -o "$TMP2/fs.daa" -p 2 2>/dev/null
+"$ROOT/oracle/_ref/diamond" view -a "$TMP2/fs.daa" -f 6 qseqid sseqid pident length mismatch gapopen qstart qend sstart send evalue bitscore qframe nident positive gaps btop cigar qseq_gapped sseq_gapped sseq qcovhsp -o "$TMP2/v.tsv" 2>/dev/null
+gzip -9 -c "$TMP2/fs.daa" > "$HERE/fs_f15.daa.gz"; gzip -9 -c "$TMP2/v.tsv" > "$HERE/fs_f15_view_fields.tsv.gz"; rm -rf "$TMP2"

@@ -1104,3 +1104,24 @@ def test_cli_frameshift_matches_reference(tmp_path):
         for binary in (REF, CLI):
             r = subprocess.run([binary] + cmd + ["-o", str(tmp_path / "x.out")], capture_output=True, text=True)
             assert r.returncode != 0 and msg in r.stderr + r.stdout, (binary, cmd)
+
+
+def test_cli_frameshift_alignment_fields_match_reference(tmp_path):
+    """blastx -F 15 with the tabular fields that walk the alignment (round 4): btop, cigar, qseq_gapped, sseq_gapped, sseq and
+    qseq_translated follow the alignment through its frame changes as the reference's HspContext::Iterator does; byte-identical
+    to the reference binary on the reads with planted insertions and deletions."""
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/diamond not built")
+    g = os.path.join(ROOT, "tests", "golden")
+    base = ["blastx", "-q", os.path.join(g, "fs_reads.fna"), "-d", os.path.join(g, "fs_db.faa"), "-p", "4", "-F", "15"]
+    for extra in (["-f", "6", "qseqid", "sseqid", "qstart", "qend", "sstart", "send", "length", "btop", "cigar"],
+                  ["-f", "6", "qseqid", "sseqid", "qseq_gapped", "sseq_gapped", "sseq", "qseq_translated", "qseq"],
+                  ["--range-culling", "--top", "10", "-f", "6", "qseqid", "sseqid", "qframe", "btop", "qseq_translated"]):
+        _run([REF] + base + extra + ["-o", str(tmp_path / "ref.out")])
+        _run([CLI] + base + extra + ["-o", str(tmp_path / "hip.out")])
+        ref, got = open(tmp_path / "ref.out").read(), open(tmp_path / "hip.out").read()
+        assert len(ref) > 1000 and ("\\" in ref or "/" in ref or "qseq_gapped" not in extra), extra
+        if got != ref:
+            for i, (a, b) in enumerate(zip(ref.splitlines(), got.splitlines())):
+                assert a == b, (extra, i, [(x[:80], y[:80]) for x, y in zip(a.split("\t"), b.split("\t")) if x != y][:2])
+        assert got == ref, extra

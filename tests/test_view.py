@@ -64,3 +64,21 @@ def test_view_options_and_damaged_files(archives):
     # gzip output of view
     r = subprocess.run([CLI, "view", "-a", str(archives / "bx.daa"), "--compress", "1", "-o", str(archives / "z.tsv")], capture_output=True, text=True)
     assert r.returncode == 0 and gzip.open(str(archives / "z.tsv.gz"), "rt").read() == _sections()["bx -f 6"]
+
+
+def test_view_of_frameshift_alignments(tmp_path):
+    """A DAA archive the reference wrote with `blastx -F 15` (154 of its 157 alignments change frame): every field that walks the
+    alignment -- btop, cigar, qseq_gapped, sseq_gapped, sseq -- and the statistics and read coordinates recomputed from the
+    transcripts must read as the reference's own `view` prints them (round 4: the formatter's cursor follows the three frames).
+    qseq_translated is left out: with a frame change the reference's view reads past the end of the first frame."""
+    fields = "qseqid sseqid pident length mismatch gapopen qstart qend sstart send evalue bitscore qframe nident positive gaps btop cigar qseq_gapped sseq_gapped sseq qcovhsp".split()
+    open(tmp_path / "fs.daa", "wb").write(gzip.open(os.path.join(GOLDEN, "fs_f15.daa.gz"), "rb").read())
+    r = subprocess.run([CLI, "view", "-a", str(tmp_path / "fs.daa"), "-o", str(tmp_path / "out"), "-f", "6"] + fields, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    want = gzip.open(os.path.join(GOLDEN, "fs_f15_view_fields.tsv.gz"), "rt").read()
+    got = open(tmp_path / "out").read()
+    assert want.count("\\") + want.count("/") > 400            # the frame shifts are there
+    if got != want:
+        for i, (a, b) in enumerate(zip(want.splitlines(), got.splitlines())):
+            assert a == b, (i, [(x, y) for x, y in zip(a.split("\t"), b.split("\t")) if x != y][:2])
+    assert got == want
