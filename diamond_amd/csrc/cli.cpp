@@ -776,8 +776,11 @@ int run_blastp(const Options& o)
 	}
 	if (tab_extras && fmt != FMT_FIELDS && !o.header.empty() && o.header != "0") throw std::runtime_error("--header is only available for the tabular format");
 	if (o.frameshift > 0) {
-		// A frameshift alignment changes frame along its transcript. The tabular format prints it with every field (the cursor of
-		// format_api.hip follows the frames); the pairwise, XML, SAM, PAF and DAA writers of this build read ONE frame.
+		// A frameshift alignment changes frame along its transcript: the cursor of format_api.hip follows the frames, and the tabular
+		// format prints such alignments with any field. The other writers print them too (`view` of a reference-written -F archive
+		// equals the reference's view in the pairwise, XML, SAM and PAF formats: tests/test_view.py), but which queries WITHOUT an
+		// alignment those formats list differs from the reference under -F (its legacy pipeline reports by its own rule), so the
+		// search itself stays with the tabular format.
 		if (fmt != FMT_TAB && fmt != FMT_FIELDS) throw std::runtime_error("Frameshift alignments (-F) are printed in the tabular format (-f 6) only in this build.");
 		if (dmnd_set_format_flags(o.format_flags | DMND_FMT_FRAMESHIFT) != DMND_OK) throw std::runtime_error(dmnd_last_error());      // qseq_translated follows the alignment (config.frame_shift != 0)
 	}

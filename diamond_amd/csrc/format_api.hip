@@ -96,6 +96,7 @@ struct Walk {
 	explicit Walk(const dmnd_hsp_view& view) : v(view), t(view.transcript), left(view.match->hsp.transcript_len), qpos(view.match->hsp.q_begin), spos(view.match->hsp.s_begin),
 		foff(view.match->frame % 3) { fetch(); }
 	int shift() const { return op == OP_SUBSTITUTION ? (letter == FS_FORWARD ? 1 : letter == FS_REVERSE ? -1 : 0) : 0; }
+	int in_strand() const { return v.source_seq ? foff + 3 * qpos : qpos; }      // TranslatedPosition::in_strand of the cursor's frame
 	void fetch()
 	{
 		ok = false;
@@ -338,13 +339,13 @@ extern "C" int64_t dmnd_format_pairwise(const dmnd_hsp_view* v, const int8_t* ma
 	Walk qi(*v), mi(*v), si(*v);
 	while (qi.good()) {
 		o << "Query  ";
-		o.print_width((unsigned)(f.absolute(qi.qpos) + 1), digits);
+		o.print_width((unsigned)(f.oriented(qi.in_strand()) + 1), digits);
 		o << "  ";
 		for (unsigned i = 0; i < width && qi.good(); ++i, qi.next()) o << qi.query_char();
-		o << " " << f.oriented(f.in_strand(qi.qpos) - 1) + 1 << '\n';
+		o << " " << f.oriented(qi.in_strand() - 1) + 1 << '\n';
 		for (unsigned i = 0; i < digits + 9; ++i) o << ' ';
 		for (unsigned i = 0; i < width && mi.good(); ++i, mi.next())
-			o << (mi.op == OP_MATCH ? AA[mi.query()] : mi.op == OP_SUBSTITUTION ? (matrix8[mi.query() * 32 + mi.subject()] > 0 ? '+' : ' ') : ' ');
+			o << (mi.op == OP_MATCH ? AA[mi.query()] : mi.op == OP_SUBSTITUTION && !mi.shift() ? (matrix8[mi.query() * 32 + mi.subject()] > 0 ? '+' : ' ') : ' ');
 		o << '\n';
 		o << "Sbjct  ";
 		o.print_width((unsigned)(si.spos + 1), digits);
@@ -415,6 +416,7 @@ extern "C" int64_t dmnd_format_sam(const dmnd_hsp_view* v, const char* unaligned
 	for (int i = 0; i < h.transcript_len; ++i) {
 		const int op = v->transcript[i] >> 6, arg = v->transcript[i] & 63;
 		if (op == OP_MATCH) { del = 0; matches += (unsigned)arg; }
+		else if (op == OP_SUBSTITUTION && (arg == FS_FORWARD || arg == FS_REVERSE)) continue;      // a frame shift: no case of print_md's switch
 		else if (op == OP_SUBSTITUTION) {
 			if (matches > 0) { o << matches; matches = 0; }
 			else if (del > 0) { o << '0'; del = 0; }
@@ -576,7 +578,7 @@ extern "C" int64_t dmnd_format_xml(const dmnd_hsp_view* v, int32_t hit_num, int3
 	for (Walk w(*v); w.good(); w.next()) o << w.subject_char();
 	o << "</Hsp_hseq>\n      <Hsp_midline>";
 	for (Walk w(*v); w.good(); w.next())
-		o << (w.op == OP_MATCH ? AA[w.query()] : w.op == OP_SUBSTITUTION ? (matrix8[w.query() * 32 + w.subject()] > 0 ? '+' : ' ') : ' ');
+		o << (w.op == OP_MATCH ? AA[w.query()] : w.op == OP_SUBSTITUTION && !w.shift() ? (matrix8[w.query() * 32 + w.subject()] > 0 ? '+' : ' ') : ' ');
 	o << "</Hsp_midline>\n    </Hsp>\n";
 	return emit(o, buf, cap, "dmnd_format_xml");
 }

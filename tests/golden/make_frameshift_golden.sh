@@ -31,3 +31,6 @@ TMP2="$(mktemp -d)"
 "$ROOT/oracle/_ref/diamond" blastx -q "$HERE/fs_reads.fna" -d "$HERE/fs_db.faa" -F 15 -f 100 -o "$TMP2/fs.daa" -p 2 2>/dev/null
 "$ROOT/oracle/_ref/diamond" view -a "$TMP2/fs.daa" -f 6 qseqid sseqid pident length mismatch gapopen qstart qend sstart send evalue bitscore qframe nident positive gaps btop cigar qseq_gapped sseq_gapped sseq qcovhsp -o "$TMP2/v.tsv" 2>/dev/null
 gzip -9 -c "$TMP2/fs.daa" > "$HERE/fs_f15.daa.gz"; gzip -9 -c "$TMP2/v.tsv" > "$HERE/fs_f15_view_fields.tsv.gz"; rm -rf "$TMP2"
+# ... and in the pairwise, XML, PAF and SAM formats (tests/golden/fs_f15_view_formats.txt.gz: sections "#### -f N")
+TMP3="$(mktemp -d)"; gzip -dc "$HERE/fs_f15.daa.gz" > "$TMP3/fs.daa"
+for f in 0 5 paf 101; do echo "#### -f $f"; "$ROOT/oracle/_ref/diamond" view -a "$TMP3/fs.daa" -f $f 2>/dev/null; done | gzip -9 > "$HERE/fs_f15_view_formats.txt.gz"; rm -rf "$TMP3"
