@@ -781,7 +781,9 @@ int run_blastp(const Options& o)
 		// equals the reference's view in the pairwise, XML, SAM and PAF formats: tests/test_view.py), but which queries WITHOUT an
 		// alignment those formats list differs from the reference under -F (its legacy pipeline reports by its own rule), so the
 		// search itself stays with the tabular format.
-		if (fmt != FMT_TAB && fmt != FMT_FIELDS) throw std::runtime_error("Frameshift alignments (-F) are printed in the tabular format (-f 6) only in this build.");
+		// A DAA archive never lists unaligned queries, and its records are written from the first column's frame and position
+		// (`view` of a reference-written -F archive writes every record back byte for byte: tests/test_view.py), so -f 100 is fine.
+		if (fmt != FMT_TAB && fmt != FMT_FIELDS && fmt != FMT_DAA) throw std::runtime_error("Frameshift alignments (-F) are printed in the tabular format (-f 6) or as a DAA archive (-f 100) only in this build.");
 		if (dmnd_set_format_flags(o.format_flags | DMND_FMT_FRAMESHIFT) != DMND_OK) throw std::runtime_error(dmnd_last_error());      // qseq_translated follows the alignment (config.frame_shift != 0)
 	}
 	// which formats report queries without alignments: pairwise, PAF and SAM by default (DEFAULT_REPORT_UNALIGNED), tabular with --unal 1
@@ -1606,6 +1608,8 @@ int run_view(const Options& o)
 	size_t pos = HEAD;
 	const size_t aln_end = HEAD + (size_t)aln_bytes;
 	int64_t qnum = 0, n_hsps = 0;
+	const bool check_daa = std::getenv("DMND_VIEW_CHECK_DAA") != nullptr;
+	int64_t daa_mismatches = 0;
 	std::vector<int8_t> seq, frames[6];
 	for (;; ++qnum) {
 		if (pos + 4 > aln_end) throw std::runtime_error("Truncated DAA file.");
@@ -1680,6 +1684,12 @@ int run_view(const Options& o)
 			v.match = &m; v.transcript = tr; v.qtitle = qtitle.c_str(); v.stitle = ref_name[dict]; v.qseq = ctx; v.qlen = ctx_len; v.slen = (int32_t)slen; v.full_sseq = nullptr;
 			v.source_seq = blastx ? seq.data() : nullptr; v.source_len = blastx ? (int32_t)qlen : 0; v.qnum = 0; v.snum = (int64_t)dict;      // the reference's view hands 0 to every record as the query's ordinal (daa_record.h:46-52)
 			for (int k = 0; k < 3; ++k) v.qframes[k] = blastx ? frames[(m.frame / 3) * 3 + k].data() : nullptr;
+			if (check_daa) {
+				// DMND_VIEW_CHECK_DAA=1 (tests): the record written again from what was read must be the bytes that were read
+				std::vector<char> again((size_t)usedb + 64);
+				const int64_t w = dmnd_format_daa_match(&v, dict, again.data(), (int64_t)again.size());
+				if (w != usedb || std::memcmp(again.data(), q - usedb, (size_t)usedb) != 0) ++daa_mismatches;
+			}
 			big.resize((size_t)m.hsp.length * 8 + (size_t)qlen * 3 + qtitle.size() * 6 + std::strlen(v.stitle) * 6 + 4096);
 			if (!intro) {
 				intro = true;
@@ -1701,6 +1711,7 @@ int run_view(const Options& o)
 	if (fmt == V_XML) out.write("</BlastOutput_iterations>\n</BlastOutput>");
 	out.close();
 	std::cerr << "Printed " << n_hsps << " HSPs of " << qnum << " queries.\n";
+	if (check_daa) { std::cerr << "DAA records written back: " << daa_mismatches << " differ.\n"; if (daa_mismatches) return 1; }
 	return 0;
 }
 

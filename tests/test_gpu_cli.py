@@ -1125,3 +1125,10 @@ def test_cli_frameshift_alignment_fields_match_reference(tmp_path):
             for i, (a, b) in enumerate(zip(ref.splitlines(), got.splitlines())):
                 assert a == b, (extra, i, [(x[:80], y[:80]) for x, y in zip(a.split("\t"), b.split("\t")) if x != y][:2])
         assert got == ref, extra
+    # -f 100: the archive of a -F run, byte for byte (one thread on both sides: the dictionary order follows the output order)
+    args = ["blastx", "-q", os.path.join(g, "fs_reads.fna"), "-d", os.path.join(g, "fs_db.faa"), "-p", "1", "-F", "15", "-f", "100"]
+    _run([REF] + args + ["-o", str(tmp_path / "ref")])
+    _run([CLI] + args + ["-o", str(tmp_path / "hip")])
+    ref, hip_ = open(tmp_path / "ref.daa", "rb").read(), open(tmp_path / "hip.daa", "rb").read()
+    assert len(ref) > 20000
+    assert hip_ == ref, next(i for i in range(min(len(ref), len(hip_))) if ref[i] != hip_[i]) if ref[:len(hip_)] != hip_[:len(ref)] else ("length", len(ref), len(hip_))

@@ -107,3 +107,13 @@ def test_view_of_frameshift_alignments_in_the_other_formats(tmp_path):
             for i, (a, b) in enumerate(zip(want.splitlines(), got.splitlines())):
                 assert a == b, (name, i, a[:200], b[:200])
         assert got == want, name
+
+
+def test_view_writes_every_daa_record_back(tmp_path, archives):
+    """DMND_VIEW_CHECK_DAA=1: every match record that `view` reads is written again from the rebuilt record (dmnd_format_daa_match) and
+    must be the bytes that were read -- for the blastp and blastx archives and for the archive of a frameshift run (the record of a
+    frameshift alignment is written from its first column's frame and position)."""
+    open(tmp_path / "fs.daa", "wb").write(gzip.open(os.path.join(GOLDEN, "fs_f15.daa.gz"), "rb").read())
+    for path in (tmp_path / "fs.daa", archives / "bx.daa", archives / "k4.daa"):
+        r = subprocess.run([CLI, "view", "-a", str(path), "-o", str(tmp_path / "out")], capture_output=True, text=True, timeout=120, env=dict(os.environ, DMND_VIEW_CHECK_DAA="1"))
+        assert r.returncode == 0 and "written back: 0 differ" in r.stderr, (path, r.stderr[-300:])
