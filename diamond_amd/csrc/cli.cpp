@@ -783,7 +783,7 @@ int run_blastp(const Options& o)
 		// search itself stays with the tabular format.
 		// A DAA archive never lists unaligned queries, and its records are written from the first column's frame and position
 		// (`view` of a reference-written -F archive writes every record back byte for byte: tests/test_view.py), so -f 100 is fine.
-		if (fmt != FMT_TAB && fmt != FMT_FIELDS && fmt != FMT_DAA) throw std::runtime_error("Frameshift alignments (-F) are printed in the tabular format (-f 6) or as a DAA archive (-f 100) only in this build.");
+		if (fmt == FMT_SAM) throw std::runtime_error("Frameshift alignments (-F): the SAM format is not available in this build (its query column reads the alignment's range from one frame, past that frame's end in the reference); use -f 100 and view.");
 		if (dmnd_set_format_flags(o.format_flags | DMND_FMT_FRAMESHIFT) != DMND_OK) throw std::runtime_error(dmnd_last_error());      // qseq_translated follows the alignment (config.frame_shift != 0)
 	}
 	// which formats report queries without alignments: pairwise, PAF and SAM by default (DEFAULT_REPORT_UNALIGNED), tabular with --unal 1
@@ -1320,7 +1320,9 @@ int run_blastp(const Options& o)
 		const bool per_query = fmt == FMT_PAIRWISE || fmt == FMT_PAF || fmt == FMT_SAM || fmt == FMT_XML || fmt == FMT_DAA || (fmt == FMT_FIELDS && report_unal);
 		for (size_t qi = qr.begin; qi < qr.end && per_query; ++qi) {
 			const bool has = i < n_matches && joined[(size_t)i].query == (uint32_t)qi;
-			if (!has && (!report_unal || (t_blocks.size() == 1 && !seeded[qi - qr.begin]))) continue;
+			// (with a frameshift penalty the legacy pipeline is entered for every query, a query without seed hits gets its intro there:
+			// align/align.cpp:167-171,119-129)
+			if (!has && (!report_unal || (t_blocks.size() == 1 && !seeded[qi - qr.begin] && o.frameshift == 0))) continue;
 			const int32_t qlen = blastx ? source_len[qi] : (int32_t)(q_all.limits[qi + 1] - q_all.limits[qi] - 1);
 			big.resize(qtitles[qi].size() + 256);
 			if (fmt == FMT_PAIRWISE) put(dmnd_format_pairwise_intro(qtitles[qi].c_str(), qlen, has ? 0 : 1, big.data(), (int64_t)big.size()), big.data());

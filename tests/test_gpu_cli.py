@@ -1132,3 +1132,15 @@ def test_cli_frameshift_alignment_fields_match_reference(tmp_path):
     ref, hip_ = open(tmp_path / "ref.daa", "rb").read(), open(tmp_path / "hip.daa", "rb").read()
     assert len(ref) > 20000
     assert hip_ == ref, next(i for i in range(min(len(ref), len(hip_))) if ref[i] != hip_[i]) if ref[:len(hip_)] != hip_[:len(ref)] else ("length", len(ref), len(hip_))
+    # the pairwise format (coordinates move by single bases at a shift; every query without an alignment is listed: the legacy
+    # pipeline is entered for each, align/align.cpp:167-171), XML and PAF
+    strip = lambda t: "\n".join(l for l in t.splitlines() if "<BlastOutput_version>" not in l)
+    for extra in (["-f", "0"], ["-f", "5"], ["-f", "paf"]):
+        _run([REF] + base + extra + ["-o", str(tmp_path / "ref.out")])
+        _run([CLI] + base + extra + ["-o", str(tmp_path / "hip.out")])
+        ref, got = strip(open(tmp_path / "ref.out").read()), strip(open(tmp_path / "hip.out").read())
+        assert len(ref) > 1000, extra
+        if got != ref:
+            for i, (a, b) in enumerate(zip(ref.splitlines(), got.splitlines())):
+                assert a == b, (extra, i, a[:200], b[:200])
+        assert got == ref, extra
