@@ -225,12 +225,12 @@ def cpu_baseline_reference(w, cores, e2e=True):
                 ours_wall = sorted(x[0] for x in ours)[1]
                 ref_total = re.search(r"Total time = ([0-9.eE+-]+)s", ref_log)
                 runs[name] = {"flags": " ".join(w.cfg["flags"] + flags), "reference_md5": ref_md5, "reference_s": ref_wall, "reference_own_total_time_s": float(ref_total.group(1)) if ref_total else None,
-                              "ours_s": ours_wall, "ours_runs_s": [round(x[0], 4) for x in ours], "speedup": ref_wall / ours_wall, "parity": all(x[2] == ref_md5 for x in ours),
+                              "ours_s": ours_wall, "ours_runs_s": [round(x[0], 4) for x in ours], "speedup": ref_wall / ours_wall, "speedup_min": ref_wall / max(x[0] for x in ours), "parity": all(x[2] == ref_md5 for x in ours),
                               "ours_log": [l for l in ours[1][1].splitlines() if "[" in l or "Total time" in l]}
             e2e_obj = {"what": "whole processes on the same files (page cache warm): `diamond %s` on %d host threads against `diamond-hip %s` on one MI355X -- open and load the "
                                ".dmnd, upload, masking, seed stage, extension, output file; wall clock around the process (ours: median of 3, HIP start-up included, each run started 1 s after the previous process left the GPU)"
                                % (w.cfg["mode"], cores, w.cfg["mode"]),
-                       "runs": runs, "speedup": runs["default_masking"]["speedup"], "parity": all(r["parity"] for r in runs.values()),
+                       "runs": runs, "speedup": runs["default_masking"]["speedup"], "speedup_min": min(r["speedup_min"] for r in runs.values()), "parity": all(r["parity"] for r in runs.values()),
                        "gcups_e2e": {"ours": cells["cells"] / runs["masking_off"]["ours_s"] / 1e9, "reference": cells["cells"] / runs["masking_off"]["reference_s"] / 1e9,
                                      "note": "SURVEY 8(d) GCUPS_e2e = the reference's cell count (both rounds) of the masking-off run / whole-process wall seconds"}}
         return base, md5, e2e_obj
@@ -252,8 +252,12 @@ def main():
     ap.add_argument("--seed-contexts", type=int, default=1, help="seed stages in flight at the same time (own context and stream each; one with several database blocks per rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the whole-process comparison (diamond-hip against the reference binary on files)")
-    ap.add_argument("--with-masking", action="store_true", help="after the timed steps, also time the step of the default command line (N=1, one database block): block copies as "
-                    "loaded -> tantan + motif masking of both blocks on the device -> seed stage -> extension, back to back on one context; reported as `masked_step`")
+    ap.add_argument("--with-masking", action="store_true", help="(default since round 5; kept for old command lines) time the step of the default command line too")
+    ap.add_argument("--no-masked-step", action="store_true", help="skip `masked_step`: after the timed steps the step of the default command line is timed as well (N=1, one database "
+                    "block, blastp): block copies as loaded -> tantan + motif masking of both blocks on the device -> seed stage -> extension, back to back on one context")
+    ap.add_argument("--same-block", action="store_true", help="search the SAME database block in every step. Default (N=1, one block per rank): two database blocks at different "
+                    "places of HBM alternate between steps -- the block of the config and the same sequences in reverse order -- so that no step finds its 301 MB of "
+                    "letters in the 256 MiB Infinity Cache from the step before")
     ap.add_argument("--no-pipeline", action="store_true", help="run seed stage and extension stage of a batch back to back on one context")
     args = ap.parse_args()
 
@@ -347,10 +351,37 @@ def main():
     ext_threads = max(1, threads // E)
     ctx, ctx_seed = ctxs[0], ctxs_seed[0]
     state = {"stream_ms": 0.0, "stream_launches": 0}
+    # Two database blocks alternate between the steps (round 5): block B holds the sequences of block A in reverse order, at its own
+    # place in HBM -- the same work per step (same hits, cells and records up to the target numbers), but a step never streams the
+    # letters the step before it has just pulled through the Infinity Cache. Block B has its own seed context and its own extension
+    # context per extension team.
+    alternate = world == 1 and NB == 1 and pipeline and SC == 1 and not args.same_block
+    alt_host = None
+    if alternate:
+        lens = np.diff(w.doff)
+        r_lens = lens[::-1]
+        r_off = np.concatenate([[0], np.cumsum(r_lens)]).astype(np.int64)
+        idx = np.repeat(w.doff[:-1][::-1] - r_off[:-1], r_lens) + np.arange(int(r_off[-1]), dtype=np.int64)
+        alt_host = workload.sequence_set(w.db[idx], r_off)
+        del idx
 
-    def seed_stage(b=0):
+        def make_alt_ctx():
+            c = hip.Context(device=local_rank, params=params)
+            c.upload_block(hip.QUERY, w.qd, w.ql)
+            c.upload_block(hip.TARGET, alt_host[0], alt_host[1])
+            c.set_query_contexts(w.contexts)
+            c.set_gapped_filter(gf_evalue)
+            return c
+        alt_ext_ctxs = [make_alt_ctx() for _ in range(E)]
+        seed_ctx_alt = make_alt_ctx()
+        seed_counter = [0]
+
+    def seed_stage(b=0, alt=False):
         torch.cuda.set_device(local_rank)
         c = seed_free.get()
+        if alt:                                              # block B has its own seed context (one seed stage runs at a time: SC = 1)
+            seed_free.put(c)
+            c = seed_ctx_alt
         try:
             if NB > 1:
                 if b == 0:
@@ -361,12 +392,13 @@ def main():
             wall = (time.perf_counter() - t_s) * 1e3
             ms = c.seed_kernel_ms()
         finally:
-            seed_free.put(c)
+            if not alt:
+                seed_free.put(c)
         with seed_lock:
             state.setdefault("seed_wall", []).append(wall)
             state["stream_ms"] += ms[1]                         # every seed stage that ran since the counters were reset
             state["stream_launches"] += seed_params.n_shapes
-        return hits, ms
+        return hits, ms, alt
 
     def finish(parts):
         """What happens to a batch's records: database blocks are joined as the reference joins reference blocks -- the blocks of
@@ -393,12 +425,13 @@ def main():
         parts, n_hits, seed_ms, ext_sum = [], 0, None, None
         for b in range(NB):
             got = prefetched[b] if prefetched is not None else seed_stage(b)
-            hits, ms = got.result() if hasattr(got, "result") else got
-            m, _ = ext_ctxs[e][b].extend(w.qd, w.blocks[b][2], hits, threads=ext_threads)
+            hits, ms, alt = got.result() if hasattr(got, "result") else got
+            ec = alt_ext_ctxs[e] if alt else ext_ctxs[e][b]
+            m, _ = ec.extend(w.qd, alt_host[0] if alt else w.blocks[b][2], hits, threads=ext_threads)
             parts.append(m)
             n_hits += int(hits.size)
             seed_ms = list(ms) if seed_ms is None else [x + y for x, y in zip(seed_ms, ms)]
-            st = ext_ctxs[e][b].extend_stats()
+            st = ec.extend_stats()
             ext_sum = dict(st) if ext_sum is None else {k: ext_sum[k] + st[k] for k in st}
         state.setdefault("ext_wall", []).append((time.perf_counter() - t_b) * 1e3)
         return dict(parts=parts, hits=n_hits, seed_ms=seed_ms, ext=ext_sum, ext_wall_ms=(time.perf_counter() - t_b) * 1e3)
@@ -437,6 +470,13 @@ def main():
         finish_pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
         ext_pools = [concurrent.futures.ThreadPoolExecutor(max_workers=1) for _ in range(E)]      # a context runs one call at a time
 
+    def submit_seed(b):
+        alt = False
+        if alternate:
+            alt = seed_counter[0] % 2 == 1
+            seed_counter[0] += 1
+        return seed_pool.submit(seed_stage, b, alt)
+
     PREFETCH = max(2, E + 1, 2 * SC)        # seed stages in flight or finished ahead of the extension (a bounded prefetch queue, like a data loader's)
 
     def run(n_steps, queue):
@@ -456,7 +496,7 @@ def main():
             if pipeline:
                 got = [queue.pop(0) for _ in range(NB)]
                 for b in range(NB):
-                    queue.append(seed_pool.submit(seed_stage, b))
+                    queue.append(submit_seed(b))
                 inflight.append(ext_pools[s % E].submit(extend_batch, s % E, got))
                 if len(inflight) >= E:
                     retire()
@@ -473,7 +513,10 @@ def main():
     # the W warm-up steps only reach the first W of the E extension contexts, so the others are primed here
     for e in range(1, E):
         extend_batch(e, [seed_stage(b) for b in range(NB)])
-    queue = [seed_pool.submit(seed_stage, b) for _ in range(PREFETCH) for b in range(NB)] if pipeline else []
+    if alternate:
+        for e in range(E):
+            extend_batch(e, [seed_stage(0, True)])
+    queue = [submit_seed(b) for _ in range(PREFETCH) for b in range(NB)] if pipeline else []
     _, queue = run(args.warmup, queue)
     for f in queue:
         f.result()                                           # the first timed steps find their seed hits ready
@@ -481,7 +524,7 @@ def main():
     sync()
     # hipDeviceSynchronize lets the runtime release the hardware queues of idle streams; re-acquiring them costs the first
     # timed calls milliseconds (a streaming caller never synchronizes the whole device)
-    for c in [x for cs in ext_ctxs for x in cs] + (ctxs_seed if ctxs_seed is not ctxs else []):
+    for c in [x for cs in ext_ctxs for x in cs] + (ctxs_seed if ctxs_seed is not ctxs else []) + (alt_ext_ctxs + [seed_ctx_alt] if alternate else []):
         c.touch_streams()
     state["stream_ms"], state["stream_launches"] = 0.0, 0
     state["seed_wall"], state["ext_wall"] = [], []
@@ -522,7 +565,7 @@ def main():
         dt = float(t.item())
 
     masked_step, masked_records = None, None
-    if args.with_masking and world == 1 and NB == 1 and w.contexts == 1:
+    if not args.no_masked_step and world == 1 and NB == 1 and w.contexts == 1:
         # The step of `diamond blastp --algo 0` with masking at its default (tantan on both blocks, motif soft masking for seed
         # generation; cli.cpp does the same calls per block pair). dmnd_mask_block works in place, so every step starts from the
         # letters as loaded: a device-to-device copy from a context that keeps them (it stands in for the block upload -- inputs
@@ -565,6 +608,12 @@ def main():
         raw.close()
         mc.close()
 
+    # completion intervals as windows: at least five of them when the run has the steps for it, each a multiple of E steps
+    WIN = E
+    while len(each) // (2 * WIN) >= 5 and WIN < 4 * E:
+        WIN += E
+    win_ms = [sum(each[i:i + WIN]) / WIN for i in range(0, len(each) - WIN + 1, WIN)]
+    win_median = sorted(win_ms)[len(win_ms) // 2] if win_ms else None
     ext = pipe_ext
     # the job's DP cells: with database shards every rank sweeps its own targets, with query shards its own queries
     cells = torch.tensor([ext["round1_cells"], ext["round2_cells"] if ext["round2_swipe_kernel_ms"] > 0 else 0.0, ext["round2_cells"],
@@ -614,6 +663,11 @@ def main():
             # batches retire in clumps (three are extended at a time): the completion intervals as windows of three steps -- the
             # median window / 3 shows what a host hiccup (one long step) does to the mean that `value` is defined on
             "ms_per_step_median_of_3_step_windows": (sorted(sum(each[i:i + 3]) for i in range(0, len(each) - 2, 3))[len(range(0, len(each) - 2, 3)) // 2] / 3.0) if len(each) >= 3 else None,
+            "ms_per_step_median": win_median,
+            "ms_per_step_windows": {"window_steps": WIN, "ms_per_step_of_each_window": [round(x, 4) for x in win_ms], "median": win_median,
+                                    "note": "the timed steps cut into windows of %d (a multiple of the %d batches that retire together); `ms_per_step` above is the MEAN over the whole "
+                                            "timed region (what `value` is defined on), this is the median window" % (WIN, E)},
+            "database_blocks_alternated": bool(alternate),
             "latency_in_pipeline": lat,
             "alone": alone,
             "host_cpu_ms_per_step": cpu_ms_per_step,
@@ -720,7 +774,7 @@ def main():
             tids = ["t%d" % i for i in range(w.n_db)]
             text = hip.format_tab(state["records"], qids, tids, w.source_lens)
             masked_text = hip.format_tab(masked_records, qids, tids, w.source_lens) if masked_records is not None else None
-            for c in (ctxs_seed if ctxs_seed is not ctxs else []) + [x for cs in ext_ctxs for x in cs]:
+            for c in (ctxs_seed if ctxs_seed is not ctxs else []) + [x for cs in ext_ctxs for x in cs] + (alt_ext_ctxs + [seed_ctx_alt] if alternate else []):
                 c.close()
             closed = True
             torch.cuda.empty_cache()
@@ -739,7 +793,7 @@ def main():
                     out["masked_step"]["parity"] = {"records_md5": got, "reference_output_md5": want, "matches": got == want}
         print(json.dumps(out))
     if not closed:
-        for c in (ctxs_seed if ctxs_seed is not ctxs else []) + [x for cs in ext_ctxs for x in cs]:
+        for c in (ctxs_seed if ctxs_seed is not ctxs else []) + [x for cs in ext_ctxs for x in cs] + (alt_ext_ctxs + [seed_ctx_alt] if alternate else []):
             c.close()
     if world > 1:
         dist.destroy_process_group()

@@ -1288,7 +1288,9 @@ int run_blastp(const Options& o)
 		}
 		g_timeline.mark("block pairs of the query block done");
 		int64_t n_matches = (int64_t)joined.size();
-		if (t_blocks.size() > 1 && o.global_ranking == 0) chk(o.top >= 0.0 ? dmnd_join_blocks_top(joined.data(), (int64_t)joined.size(), o.top, &n_matches)
+		// the join's culler is the one TargetCulling::get picks (output/target_culling.cpp:22-28): RangeCulling with --range-culling
+		if (t_blocks.size() > 1 && o.global_ranking == 0) chk(o.range_culling ? dmnd_join_blocks_range(joined.data(), (int64_t)joined.size(), o.k, o.top, o.range_cover, &n_matches)
+			: o.top >= 0.0 ? dmnd_join_blocks_top(joined.data(), (int64_t)joined.size(), o.top, &n_matches)
 			: dmnd_join_blocks(joined.data(), (int64_t)joined.size(), o.k, &n_matches));
 		std::vector<int8_t> full_sseq_buf;                    // the unmasked target of the line being printed (full_sseq)
 		auto view_of = [&](const dmnd_match& m) {

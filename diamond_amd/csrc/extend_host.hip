@@ -47,6 +47,7 @@
 #include "host_pool.h"
 #include "bias_kernels.h"
 #include "cbs_adjust.h"
+#include "read_coverage.h"
 #include <unordered_map>
 
 namespace dmnd {
@@ -1615,6 +1616,41 @@ extern "C" int dmnd_join_blocks(dmnd_match* r, int64_t n, int max_target_seqs, i
 	for (size_t i = 0; i < groups.size(); ++i) {
 		run = (i > 0 && r[groups[i].first].query == r[groups[i - 1].first].query) ? run + 1 : 0;
 		if (run < max_target_seqs) keep.push_back(groups[i]);
+	}
+	write_groups(r, keep, n_out);
+	return DMND_OK;
+}
+
+// join_query with --range-culling (blastx -F n --range-culling / --long-reads over a database of several reference blocks): the
+// reference builds its join culler with TargetCulling::get (output/target_culling.cpp:22-28), which is RangeCulling then -- a
+// target of the merged order (JoinRecord::cmp_evalue, or cmp_score with --top) is dropped (NEXT, never FINISHED) when
+// range_cover per cent of its HSPs' read intervals are already covered: by max_target_seqs kept alignments
+// (IntervalPartition::covered), or with --top by one kept alignment of at least score / (1 - top / 100)
+// (covered(..., MaxScore), output/target_culling.h:123-150). Kept targets add their intervals (IntermediateRecord::
+// absolute_query_range = dmnd_match::read_begin / read_end). Rounds 3-4 applied GlobalCulling here whatever the mode: every
+// target outside the top per cent of the read's single best score was lost, also when it covers another part of the read.
+extern "C" int dmnd_join_blocks_range(dmnd_match* r, int64_t n, int max_target_seqs, double top_percent, double range_cover, int64_t* n_out)
+{
+	if (!r || n < 0 || max_target_seqs < 1 || top_percent >= 100.0 || !n_out) return fail(DMND_E_ARG, "dmnd_join_blocks_range: bad argument");
+	const auto groups = top_percent >= 0.0 ? join_groups(r, n, match_less_score) : join_groups(r, n, match_less);
+	std::vector<std::pair<int64_t, int64_t>> keep;
+	Coverage cover(max_target_seqs);
+	for (size_t i = 0; i < groups.size(); ++i) {
+		if (i == 0 || r[groups[i].first].query != r[groups[i - 1].first].query) cover = Coverage(max_target_seqs);
+		int cv = 0, len = 0;
+		for (int64_t k = 0; k < groups[i].second; ++k) {
+			const dmnd_match& m = r[groups[i].first + k];
+			if (m.read_end <= m.read_begin) return fail(DMND_E_ARG, "dmnd_join_blocks_range: a record without its interval of the read (read_begin / read_end are set by frameshift alignment)");
+			const Interval iv{ m.read_begin, m.read_end };
+			cv += top_percent < 0.0 ? cover.covered(iv) : cover.covered_max(iv, (int)((double)m.hsp.score / (1.0 - top_percent / 100.0)));
+			len += iv.length();
+		}
+		if (!((double)cv / len * 100.0 < range_cover)) continue;
+		for (int64_t k = 0; k < groups[i].second; ++k) {
+			const dmnd_match& m = r[groups[i].first + k];
+			cover.insert(Interval{ m.read_begin, m.read_end }, m.hsp.score);
+		}
+		keep.push_back(groups[i]);
 	}
 	write_groups(r, keep, n_out);
 	return DMND_OK;

@@ -412,11 +412,14 @@ static int mask_impl(dmnd_ctx* c, int which, int8_t* host_data, const int32_t* i
 	c->mask_ms = ms;
 	if (tr.on) std::fprintf(stderr, "%s: %lld sequences (%lld long, > %lld letters), kernels %.3f ms between the events\n", tr.call, (long long)n_work, (long long)n_long, (long long)long_len, (double)ms);
 	if (n_masked) *n_masked = (int64_t)nm;
-	// the scratch (4 B per letter) is only needed during the call -- but hipFree waits for everything the device is doing (a block
-	// upload on the context's other lane, say: 4.5 ms here), so a small one stays for the next call
+	// The scratch (4.25 B per letter: 1.3 GB for a 3.0e8-letter block) stays with the context for the next block. Rounds 3-4 gave it
+	// back above 256 MB: the hipMalloc / hipFree pair per call (hipFree = a device-wide wait plus page-table work) was 12.9 of the
+	// 19 ms a block's masking took in the pipelined step, twice the kernel's own 6.1 ms. 288 GB of HBM hold it easily; the bound
+	// (DMND_MASK_SCRATCH_KEEP_MB, default 16 GiB) only exists so that one pathological block does not pin its scratch for good.
+	static const size_t keep_bytes = [] { const char* e = std::getenv("DMND_MASK_SCRATCH_KEEP_MB"); return (size_t)(e ? std::max(0ll, std::atoll(e)) : 16384ll) << 20; }();
 	for (DevBuf* b : { &c->mask_pb, &c->mask_scale, &c->mask_pos, &c->mask_long_pb, &c->mask_long_scale })
-		if (b->cap > ((size_t)256 << 20)) b->release();
-	tr.lap("scratch released");
+		if (b->cap > keep_bytes) b->release();
+	tr.lap("scratch kept");
 	return DMND_OK;
 }
 

@@ -451,11 +451,21 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	static const bool phases = getenv("DMND_SEED_PHASES") != nullptr;
 	const bool counters_new = c->counters.cap < (size_t)(S + 16) * sizeof(unsigned long long);
 	if (int rc = c->counters.ensure((size_t)(S + 16) * sizeof(unsigned long long))) return rc;      // [S] hits, [S+1] deferred pairs, [S+2] collected positions, [S+3] Hamming survivors, [S+4] scored survivors
-	if (phases || counters_new) HIP_TRY(hipMemsetAsync(c->counters.as<unsigned long long>() + S + 5, 0, 11 * sizeof(unsigned long long), st));
-	if (!index_ready) HIP_TRY(hipMemsetAsync(c->seed_bitmap.p, 0, bm_total, st));
-	if (!index_ready) HIP_TRY(hipMemsetAsync(c->seed_next.p, 0xff, (size_t)SB * nq_pos * sizeof(uint32_t), st));
-	HIP_TRY(hipMemsetAsync(c->mask_time.p, SEED_NEVER, (size_t)c->block_len[DMND_QUERY] + 256, st));
-	if (!index_ready) HIP_TRY(hipMemsetAsync(c->seed_keys.p, 0xff, (size_t)SB * slot_bytes, st));
+	// everything a search starts from, in ONE launch (launch_seed_clear): the counters, the mask times, the need map and -- unless the
+	// query side is kept from the last call -- bitmaps, slots-of-positions and table
+	{
+		SeedClear z;
+		z.add(c->counters.p, (size_t)((phases || counters_new) ? S + 16 : S + 5) * sizeof(unsigned long long), 0);
+		z.add(c->mask_time.p, (size_t)c->block_len[DMND_QUERY] + 256, SEED_NEVER);
+		z.add(c->seed_need.p, (size_t)(slots / 32) * sizeof(uint32_t), 0);
+		if (!index_ready) {
+			z.add(c->seed_bitmap.p, bm_total, 0);
+			z.add(c->seed_next.p, (size_t)SB * nq_pos * sizeof(uint32_t), 0xff);
+			z.add(c->seed_keys.p, (size_t)SB * slot_bytes, 0xff);
+		}
+		HIP_TRY(launch_seed_clear(z, st));
+	}
+	bool pristine = true;                                // the counters and the need map are as the clear above left them
 	HIP_TRY(launch_seed_qid(c->d_limits[DMND_QUERY].as<int64_t>(), (int64_t)ql.size() - 1, c->qid_of.as<uint32_t>(), st));
 
 	// fused pipeline: 4-bit copy of the query block for the Hamming pre-filter (DMND_SEED_FOLD=0 switches it off)
@@ -547,17 +557,24 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		int64_t hit_cap = std::max<int64_t>((int64_t)1 << 20, (int64_t)(c->seed_hits.cap / sizeof(dmnd_seed_hit)));
 		if (const char* e = getenv("DMND_SEED_HIT_CAP")) hit_cap = std::max<int64_t>(1, atoll(e));
 		if (int rc = c->seed_hits.ensure((size_t)hit_cap * sizeof(dmnd_seed_hit))) return rc;
-		HIP_TRY(hipMemsetAsync(ctr, 0, (size_t)(S + 5) * sizeof(unsigned long long), st));
 		c->seed_trace.assign((size_t)2 * S, 0);
 		int64_t hits_bound = 0;                              // every survivor gives at most one hit
 		std::vector<unsigned long long> host_ctr((size_t)S + 4);
 		for (int sid = 0; sid < S; ++sid) {
 			SeedArgs a = args_for(sid, 0, 0);
 			tm.start();
-			if (sid > 0 && SB == 1) {                        // the previous shape's table, slots-of-positions and bitmaps
-				HIP_TRY(hipMemsetAsync(c->seed_keys.p, 0xff, slot_bytes, st));
-				HIP_TRY(hipMemsetAsync(c->seed_next.p, 0xff, (size_t)nq_pos * sizeof(uint32_t), st));
-				HIP_TRY(hipMemsetAsync(c->seed_bitmap.p, 0, bm_total, st));
+			if (sid > 0) {
+				// the per-shape counters (deferred pairs, collected positions, survivors, scored) and the need map; with one buffer set
+				// for all shapes also the previous shape's table, slots-of-positions and bitmaps -- one launch
+				SeedClear z;
+				z.add(ctr + S + 1, 4 * sizeof(unsigned long long), 0);
+				z.add(c->seed_need.p, (size_t)(slots / 32) * sizeof(uint32_t), 0);
+				if (SB == 1) {
+					z.add(c->seed_keys.p, slot_bytes, 0xff);
+					z.add(c->seed_next.p, (size_t)nq_pos * sizeof(uint32_t), 0xff);
+					z.add(c->seed_bitmap.p, bm_total, 0);
+				}
+				HIP_TRY(launch_seed_clear(z, st));
 			}
 			if (int rc = query_side(a, sid, !index_ready)) return rc;
 			c->seed_ms[0] += tm.stop();
@@ -568,8 +585,10 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 				if (int rc = c->seed_survivors.ensure((size_t)surv_cap * sizeof(SeedSurvivor))) return rc;
 				a.matched_slot = c->matched_slot.as<uint32_t>(); a.matched_loc = c->matched_loc.as<int64_t>(); a.matched_cap = m_cap;
 				a.survivors = c->seed_survivors.as<SeedSurvivor>(); a.survivor_cap = surv_cap;
-				HIP_TRY(hipMemsetAsync(a.matched_count, 0, sizeof(unsigned long long), st));
-				HIP_TRY(hipMemsetAsync(a.survivor_count, 0, sizeof(unsigned long long), st));
+				if (attempt > 0) {                               // (the first attempt finds them zero: the clears above)
+					HIP_TRY(hipMemsetAsync(a.matched_count, 0, sizeof(unsigned long long), st));
+					HIP_TRY(hipMemsetAsync(a.survivor_count, 0, sizeof(unsigned long long), st));
+				}
 				tm.start();
 				HIP_TRY(launch_seed_stream(a, sid, st, true));
 				c->seed_ms[1] += tm.stop();
@@ -602,12 +621,10 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 			if (int rc = c->seed_deferred.ensure((size_t)ns * sizeof(SeedDeferred))) return rc;      // deferred pairs <= survivors
 			a.hits = c->seed_hits.as<dmnd_seed_hit>(); a.hit_cap = hit_cap;
 			a.deferred = c->seed_deferred.as<SeedDeferred>(); a.deferred_cap = (int64_t)ns;
-			HIP_TRY(hipMemsetAsync(a.deferred_count, 0, 2 * sizeof(unsigned long long), st));
-			HIP_TRY(hipMemsetAsync(a.need_bits, 0, (size_t)(slots / 32) * sizeof(uint32_t), st));
 			if (int rc = c->seed_scored.ensure((size_t)ns * sizeof(SeedScored))) return rc;
 			a.scored = c->seed_scored.as<SeedScored>();
 			tm.start();
-			HIP_TRY(launch_seed_post(a, sid, (int64_t)ns, st));
+			HIP_TRY(launch_seed_post(a, sid, (int64_t)ns, st, false));
 			c->seed_ms[3] += tm.stop();
 			if (!sp.use_ungapped) continue;
 			unsigned long long nd = 0;
@@ -642,8 +659,8 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	for (int attempt = 0;; ++attempt) {
 		if (int rc = c->matched_slot.ensure((size_t)cap_total * sizeof(uint32_t))) return rc;
 		if (int rc = c->matched_loc.ensure((size_t)cap_total * sizeof(int64_t))) return rc;
-		HIP_TRY(hipMemsetAsync(c->counters.p, 0, (size_t)(S + 5) * sizeof(unsigned long long), st));
 		if (attempt > 0) {
+			HIP_TRY(hipMemsetAsync(c->counters.p, 0, (size_t)(S + 5) * sizeof(unsigned long long), st));
 			HIP_TRY(hipMemsetAsync(c->seed_keys.p, 0xff, (size_t)S * slot_bytes, st));
 			HIP_TRY(hipMemsetAsync(c->seed_bitmap.p, 0, bm_total, st));
 			HIP_TRY(hipMemsetAsync(c->seed_next.p, 0xff, (size_t)S * nq_pos * sizeof(uint32_t), st));
@@ -677,6 +694,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		c->seed_ms[2] += tm.stop();
 	}
 	if (getenv("DMND_TRACE")) {
+		pristine = false;
 		HIP_TRY(hipMemsetAsync(c->counters.as<unsigned long long>() + S + 3, 0, sizeof(unsigned long long), st));
 		for (int sid = 0; sid < S; ++sid) {
 			SeedArgs a = args_for(sid, (int64_t)counts[sid], m_off[sid]);
@@ -693,7 +711,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	for (int attempt = 0;; ++attempt) {
 		if (int rc = c->seed_hits.ensure((size_t)hit_cap * sizeof(dmnd_seed_hit))) return rc;
 		if (int rc = c->seed_deferred.ensure((size_t)def_cap * sizeof(SeedDeferred))) return rc;
-		HIP_TRY(hipMemsetAsync(c->counters.as<unsigned long long>() + S, 0, sizeof(unsigned long long), st));
+		if (!pristine) HIP_TRY(hipMemsetAsync(c->counters.as<unsigned long long>() + S, 0, sizeof(unsigned long long), st));
 		double ms = 0;
 		bool def_overflow = false;
 		c->seed_trace.assign((size_t)2 * S, 0);
@@ -703,8 +721,12 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 			a.hits = c->seed_hits.as<dmnd_seed_hit>();
 			a.hit_cap = hit_cap;
 			a.deferred = c->seed_deferred.as<SeedDeferred>(); a.deferred_cap = def_cap;
-			HIP_TRY(hipMemsetAsync(a.deferred_count, 0, 2 * sizeof(unsigned long long), st));
-			HIP_TRY(hipMemsetAsync(a.need_bits, 0, (size_t)(slots / 32) * sizeof(uint32_t), st));
+			if (!pristine) {
+				SeedClear z;
+				z.add(a.deferred_count, 2 * sizeof(unsigned long long), 0);
+				z.add(a.need_bits, (size_t)(slots / 32) * sizeof(uint32_t), 0);
+				HIP_TRY(launch_seed_clear(z, st));
+			}
 			tm.start();
 			// many joined positions (short seeds): sort them by seed and run the LDS-tiled filter; otherwise one thread per position
 			bool tiled = (int64_t)counts[sid] >= ((int64_t)1 << 22);
@@ -726,7 +748,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 				for (int pass = 0;; ++pass) {
 					if (int rc = c->seed_survivors.ensure((size_t)surv_cap * sizeof(SeedSurvivor))) return rc;
 					a.survivors = c->seed_survivors.as<SeedSurvivor>(); a.survivor_cap = surv_cap;
-					HIP_TRY(hipMemsetAsync(a.survivor_count, 0, sizeof(unsigned long long), st));
+					if (!pristine || pass > 0) HIP_TRY(hipMemsetAsync(a.survivor_count, 0, sizeof(unsigned long long), st));
 					if (tiled) HIP_TRY(launch_seed_pairs_tiled(a, sid, (int64_t)counts[sid], st));
 					else HIP_TRY(launch_seed_pairs(a, sid, (int64_t)counts[sid], st));
 					HIP_TRY(hipMemcpyAsync(&ns, a.survivor_count, sizeof(ns), hipMemcpyDeviceToHost, st));
@@ -738,7 +760,8 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 				c->seed_trace[sid] = ns;
 				if (int rc = c->seed_scored.ensure((size_t)std::max<unsigned long long>(ns, 1) * sizeof(SeedScored))) return rc;
 				a.scored = c->seed_scored.as<SeedScored>();
-				HIP_TRY(launch_seed_post(a, sid, (int64_t)ns, st));
+				HIP_TRY(launch_seed_post(a, sid, (int64_t)ns, st, !pristine));
+				pristine = false;                                // from here on the counters hold this shape's numbers
 			}
 			ms += tm.stop();
 			if (!sp.use_ungapped) continue;

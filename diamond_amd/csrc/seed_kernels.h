@@ -93,6 +93,16 @@ struct SeedArgs {
 	int fused;                                    // short-seed pipeline: seed_lists_kernel decides SLOT_LOWC for every group (the stream needs it)
 };
 
+// Up to 8 byte ranges set to a byte value each by ONE kernel launch. A search used to start with six hipMemsetAsync calls and add
+// four to eight per shape (table, slots-of-positions, bitmaps, mask times, need map, five counters): every one is its own
+// fillBufferAligned launch on the stream, ~5 us of launch floor each even for 8 bytes (profiles/r04_kernel_stats_C2.csv: 21 fills
+// per C2 step, a tenth of it).
+struct SeedClear {
+	void* p[8]; uint64_t bytes[8]; uint32_t value[8];
+	int n = 0;
+	void add(void* ptr, uint64_t nbytes, uint32_t byte_value) { if (ptr && nbytes && n < 8) { p[n] = ptr; bytes[n] = nbytes; value[n] = byte_value; ++n; } }
+};
+hipError_t launch_seed_clear(const SeedClear& z, hipStream_t st);
 hipError_t launch_seed_qid(const int64_t* limits, int64_t n_seqs, uint32_t* qid_of, hipStream_t st);
 hipError_t launch_seed_index(const SeedArgs& a, int sid, hipStream_t st);
 // query seed positions whose shape window touches a soft-masked stretch get their mask time (MaskingTable::remove's bit mask)
@@ -117,7 +127,8 @@ hipError_t launch_seed_mask(const SeedArgs& a, int sid, hipStream_t st, int64_t 
 hipError_t launch_seed_pairs(const SeedArgs& a, int sid, int64_t n_matched, hipStream_t st);
 hipError_t launch_seed_pairs_tiled(const SeedArgs& a, int sid, int64_t n_matched, hipStream_t st);      // a.matched_* sorted by slot; fills a.survivors
 hipError_t launch_seed_count_pairs(const SeedArgs& a, int64_t n_matched, unsigned long long* out, hipStream_t st);
-hipError_t launch_seed_post(const SeedArgs& a, int sid, int64_t n_survivors, hipStream_t st);
+// clear_scored = false: the caller has zeroed a.scored_count on the stream already (launch_seed_clear)
+hipError_t launch_seed_post(const SeedArgs& a, int sid, int64_t n_survivors, hipStream_t st, bool clear_scored = true);
 hipError_t sort_matched_by_slot(const uint32_t* slot_in, uint32_t* slot_out, const int64_t* loc_in, int64_t* loc_out, int64_t n, int slot_bits,
 	void** tmp, size_t* tmp_bytes, hipStream_t st);
 hipError_t launch_seed_collect(const SeedArgs& a, int64_t n_matched, hipStream_t st);

@@ -23,6 +23,42 @@
 
 namespace dmnd {
 
+// launch_seed_clear: thread t owns the t-th 16-byte chunk of the concatenated ranges
+struct SeedClearArgs { char* p[8]; uint64_t bytes[8]; uint64_t first_chunk[9]; uint32_t word[8]; int n; };
+__global__ __launch_bounds__(256) void seed_clear_kernel(SeedClearArgs z)
+{
+	const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= z.first_chunk[8]) return;
+	// (selects over constant indices: a dynamically indexed kernel argument would be copied to scratch memory)
+	char* base = z.p[0];
+	uint64_t bytes = z.bytes[0], first = 0;
+	uint32_t w = z.word[0];
+#pragma unroll
+	for (int i = 1; i < 8; ++i)
+		if (i < z.n && t >= z.first_chunk[i]) { base = z.p[i]; bytes = z.bytes[i]; first = z.first_chunk[i]; w = z.word[i]; }
+	const uint64_t off = (t - first) * 16, left = bytes - off;
+	char* q = base + off;
+	if (left >= 16 && ((uintptr_t)q & 15) == 0) { *reinterpret_cast<uint4*>(q) = make_uint4(w, w, w, w); return; }
+	for (uint64_t i = 0; i < (left < 16 ? left : 16); ++i) q[i] = (char)w;
+}
+
+hipError_t launch_seed_clear(const SeedClear& z, hipStream_t st)
+{
+	if (z.n == 0) return hipSuccess;
+	SeedClearArgs a;
+	uint64_t chunks = 0;
+	for (int i = 0; i < 8; ++i) {
+		a.p[i] = i < z.n ? static_cast<char*>(z.p[i]) : nullptr; a.bytes[i] = i < z.n ? z.bytes[i] : 0;
+		a.word[i] = i < z.n ? (z.value[i] & 0xffu) * 0x01010101u : 0u;
+		a.first_chunk[i] = chunks;
+		if (i < z.n) chunks += (z.bytes[i] + 15) / 16;
+	}
+	for (int i = z.n; i <= 8; ++i) a.first_chunk[i] = chunks;
+	a.n = z.n;
+	hipLaunchKernelGGL(seed_clear_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, a);
+	return hipGetLastError();
+}
+
 __global__ void seed_qid_kernel(const int64_t* __restrict__ limits, int64_t n_seqs, uint32_t* __restrict__ qid_of)
 {
 	// one wavefront per sequence
@@ -1308,11 +1344,13 @@ hipError_t launch_seed_count_pairs(const SeedArgs& a, int64_t n_matched, unsigne
 	return hipGetLastError();
 }
 
-hipError_t launch_seed_post(const SeedArgs& a, int sid, int64_t n_survivors, hipStream_t st)
+hipError_t launch_seed_post(const SeedArgs& a, int sid, int64_t n_survivors, hipStream_t st, bool clear_scored)
 {
 	if (n_survivors == 0) return hipSuccess;
-	hipError_t e = hipMemsetAsync(a.scored_count, 0, sizeof(unsigned long long), st);
-	if (e != hipSuccess) return e;
+	if (clear_scored) {
+		const hipError_t e = hipMemsetAsync(a.scored_count, 0, sizeof(unsigned long long), st);
+		if (e != hipSuccess) return e;
+	}
 	hipLaunchKernelGGL(seed_score_kernel, dim3(blocks_for(n_survivors, POST_THREADS)), dim3(POST_THREADS), 0, st, a, sid, n_survivors);
 	// 4-bit class map of the letters (as launch_seed_stream builds it); reductions with more than 15 classes keep the byte-wise windows
 	uint64_t lo = 0, hi = 0;

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DMND_ABI_VERSION 9      /* 2: dmnd_match.frame, seed parameters (ungapped filter, translated queries), dmnd_extend_plan(query_contexts); 3: seed_encoding; 4: output formats; 5: DMND_MAX_SHAPES 64; 6: dmnd_host_alloc, dmnd_share_block; 7: dmnd_set_max_hsps, several dmnd_match records per target, global ranking; 8: --comp-based-stats 2..5 (dmnd_cbs_*, dmnd_upload_matrices, dmnd_dp_target::cbs_off <= -2); dmnd_mask_block patches host_data in place (the full copy-back of ABI <= 6 only above 1/16 masked letters); 9: frameshift alignment (dmnd_set_frameshift, dmnd_frameshift_swipe, dmnd_match.read_begin / read_end: the record is 104 bytes), dmnd_set_context_motif_table, dmnd_copy_block */
+#define DMND_ABI_VERSION 10      /* 2: dmnd_match.frame, seed parameters (ungapped filter, translated queries), dmnd_extend_plan(query_contexts); 3: seed_encoding; 4: output formats; 5: DMND_MAX_SHAPES 64; 6: dmnd_host_alloc, dmnd_share_block; 7: dmnd_set_max_hsps, several dmnd_match records per target, global ranking; 8: --comp-based-stats 2..5 (dmnd_cbs_*, dmnd_upload_matrices, dmnd_dp_target::cbs_off <= -2); dmnd_mask_block patches host_data in place (the full copy-back of ABI <= 6 only above 1/16 masked letters); 9: frameshift alignment (dmnd_set_frameshift, dmnd_frameshift_swipe, dmnd_match.read_begin / read_end: the record is 104 bytes), dmnd_set_context_motif_table, dmnd_copy_block; 10: dmnd_join_blocks_range (round 5) */
 
 enum {
 	DMND_OK = 0,
@@ -528,6 +528,12 @@ int dmnd_set_global_ranking(dmnd_ctx* ctx, int n);
  * src/output/target_culling.h:70-88). In place; records stay grouped by ascending query. The outcome equals the
  * reference run with the same block boundaries, not the single-block run (ranking and culling happen per block). */
 int dmnd_join_blocks(dmnd_match* records, int64_t n, int max_target_seqs, int64_t* n_out);
+/* The same join with --range-culling (blastx -F n --range-culling / --long-reads): the reference's join culler is RangeCulling
+ * then (TargetCulling::get, src/output/target_culling.cpp:22-28; src/output/target_culling.h:107-163): in the merged order
+ * (cmp_evalue, or cmp_score when top_percent >= 0) a target is skipped when range_cover per cent of its HSPs' intervals of the
+ * read (dmnd_match::read_begin / read_end) are covered already -- by max_target_seqs kept alignments, or with --top by one kept
+ * alignment scoring at least score / (1 - top / 100) -- and every kept target adds its intervals. top_percent < 0: no --top. */
+int dmnd_join_blocks_range(dmnd_match* records, int64_t n, int max_target_seqs, double top_percent, double range_cover, int64_t* n_out);
 /* Touches every HIP stream the context owns (its own and those of the extension stage's runners) with an empty marker and
  * waits for them. A driver that calls hipDeviceSynchronize between batches (bench.py must, by its timing contract) lets the
  * runtime release idle hardware queues; re-acquiring them costs the next dmnd_extend several milliseconds (measured: +6.5 ms

@@ -26,7 +26,7 @@ def _bench(args, env=None, launcher=None):
 @pytest.mark.parametrize("cfg", ["C2", "C3", "C4", "C5"])
 def test_bench_line_and_parity_at_reduced_size(cfg):
     if not os.path.exists(REF):
-        pytest.skip("oracle/_ref/diamond_tap not built")
+        pytest.fail("oracle/_ref/diamond_tap is missing: under -m gpu the reference binary is the checker, its absence is a failure")
     d = _bench(["--config", cfg, "--queries", "1500", "--families", "3000", "--steps", "2", "--warmup", "1"])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
                 "roofline", "cpu_baseline"):
@@ -36,6 +36,9 @@ def test_bench_line_and_parity_at_reduced_size(cfg):
     assert d["cpu_baseline"]["kind"] == "reference" and d["cpu_baseline"]["value"] > 0
     assert d["parity_checked"] is True, d.get("parity")
     assert d["parity"]["lines"] > 1000
+    # round 5: median over windows beside the mean, and (one block per rank) two database blocks alternating between the steps
+    assert "ms_per_step_median" in d and "ms_per_step_windows" in d
+    assert d["database_blocks_alternated"] is (cfg != "C5")
     if cfg == "C5":
         assert "8 blocks" in d["config"]["workload"]
 
@@ -45,7 +48,7 @@ def test_c5_full_size_parity():
     timed run equal the reference binary's output for the same files and the same block size, line for line (md5), inside the
     bench run itself. The other full-size configurations are byte-compared in test_gpu_fullscale.py."""
     if not os.path.exists(REF):
-        pytest.skip("oracle/_ref/diamond_tap not built")
+        pytest.fail("oracle/_ref/diamond_tap is missing: under -m gpu the reference binary is the checker, its absence is a failure")
     d = _bench(["--config", "C5", "--steps", "2", "--warmup", "1", "--no-e2e"])
     assert d["config"]["queries"] == 100000 and d["config"]["db_seqs"] == 5000000
     assert d["parity_checked"] is True, d.get("parity")
@@ -77,7 +80,7 @@ def test_bench_e2e_and_hot_path_baselines():
     """The whole-process comparison (diamond-hip against the reference binary on the same files) and the hot-path baseline
     (the reference's seed-stage + extension task timers) are on the bench line, md5-equal outputs for all three command lines."""
     if not os.path.exists(REF):
-        pytest.skip("oracle/_ref/diamond_tap not built")
+        pytest.fail("oracle/_ref/diamond_tap is missing: under -m gpu the reference binary is the checker, its absence is a failure")
     d = _bench(["--queries", "1500", "--families", "3000", "--steps", "2", "--warmup", "1", "--with-masking"])
     # --with-masking: the step of the default command line (masking on the device inside the step); its records = the reference's default output
     m = d["masked_step"]
@@ -88,3 +91,4 @@ def test_bench_e2e_and_hot_path_baselines():
     assert set(e["runs"]) == {"default_masking", "masking_off", "stock_command_line"}
     assert e["parity"] is True, {k: v["parity"] for k, v in e["runs"].items()}
     assert all(v["ours_s"] > 0 and v["reference_s"] > 0 for v in e["runs"].values())
+    assert all(0 < v["speedup_min"] <= v["speedup"] for v in e["runs"].values()) and e["speedup_min"] > 0

@@ -22,7 +22,7 @@ def _run(cmd):
 
 def test_cli_makedb_blastp_matches_reference(tmp_path):
     if not os.path.exists(REF):
-        pytest.skip("oracle/_ref/diamond not built")
+        pytest.fail("oracle/_ref/diamond is missing: under -m gpu the reference binary is the checker, its absence is a failure (run __graft_entry__.build() where /root/reference exists; oracle/_ref travels with gpurun)")
     assert os.path.exists(CLI), "diamond-hip not built (make product)"
     db, doff, q, qoff = synth.generate(400, members=10, queries=500, seed=5)
     synth.write_fasta(str(tmp_path / "db.faa"), "t", db, doff)
@@ -57,7 +57,7 @@ def test_cli_makedb_blastp_matches_reference(tmp_path):
 
 def test_cli_blastx_matches_reference(tmp_path):
     if not os.path.exists(REF):
-        pytest.skip("oracle/_ref/diamond not built")
+        pytest.fail("oracle/_ref/diamond is missing: under -m gpu the reference binary is the checker, its absence is a failure (run __graft_entry__.build() where /root/reference exists; oracle/_ref travels with gpurun)")
     db, doff, q, qoff = synth.generate(300, members=10, queries=250, seed=11)
     dna, off = synth.back_translate(q, qoff, seed=12)
     synth.write_fasta(str(tmp_path / "db.faa"), "t", db, doff)
@@ -93,7 +93,7 @@ def _plant_repeats(data, off, rng, frac=0.3):
 def test_cli_default_masking_matches_reference(tmp_path):
     """Default --masking (tantan on both blocks, on the GPU) against the reference's default masking; motif masking off."""
     if not os.path.exists(REF):
-        pytest.skip("oracle/_ref/diamond not built")
+        pytest.fail("oracle/_ref/diamond is missing: under -m gpu the reference binary is the checker, its absence is a failure (run __graft_entry__.build() where /root/reference exists; oracle/_ref travels with gpurun)")
     rng = np.random.default_rng(21)
     db, doff, q, qoff = synth.generate(300, members=10, queries=400, seed=21)
     db, q = _plant_repeats(db, doff, rng), _plant_repeats(q, qoff, rng)
@@ -132,7 +132,7 @@ def test_cli_blocked_matches_reference(tmp_path):
     """-b: several query and reference blocks (reference ctest diamond-test-blastp-blocked: -c1 -b0.00002), joined as
     join_blocks does. Same text as the reference with the same block size."""
     if not os.path.exists(REF):
-        pytest.skip("oracle/_ref/diamond not built")
+        pytest.fail("oracle/_ref/diamond is missing: under -m gpu the reference binary is the checker, its absence is a failure (run __graft_entry__.build() where /root/reference exists; oracle/_ref travels with gpurun)")
     rng = np.random.default_rng(33)
     db, doff, q, qoff = synth.generate(400, members=10, queries=500, seed=33)
     db, q = _plant_repeats(db, doff, rng), _plant_repeats(q, qoff, rng)
@@ -172,7 +172,7 @@ def test_cli_query_indexed_matches_reference(tmp_path):
     seeds of the query-indexed algorithm differ from the spaced seeds of --algo 0: three sensitivities without masking, and
     default masking (tantan, applied lazily to the targets by the reference)."""
     if not os.path.exists(REF):
-        pytest.skip("oracle/_ref/diamond not built")
+        pytest.fail("oracle/_ref/diamond is missing: under -m gpu the reference binary is the checker, its absence is a failure (run __graft_entry__.build() where /root/reference exists; oracle/_ref travels with gpurun)")
     g = os.path.join(ROOT, "tests", "golden")
     for q, db in (("hashed_q.faa", "hashed_db.faa"), ("hashed_sens_q.faa", "hashed_sens_db.faa")):
         for sens in (["--fast"], [], ["--sensitive"]):
@@ -234,7 +234,7 @@ def test_cli_motif_masking_matches_reference_on_planted_motifs(tmp_path):
     beyond max_motif_len, covering more than half of a short sequence): default flags on both sides, three sensitivities,
     both algorithms."""
     if not os.path.exists(REF):
-        pytest.skip("oracle/_ref/diamond not built")
+        pytest.fail("oracle/_ref/diamond is missing: under -m gpu the reference binary is the checker, its absence is a failure (run __graft_entry__.build() where /root/reference exists; oracle/_ref travels with gpurun)")
     import struct
     raw = open(os.path.join(ROOT, "diamond_amd", "motifs.bin"), "rb").read()
     codes = struct.unpack("<%dQ" % (len(raw) // 8), raw)
@@ -298,7 +298,7 @@ def test_cli_output_fields_and_pairwise_match_reference(tmp_path, mode):
     """`-f 6 FIELD...` with every field this build prints, and `-f 0`, against the reference binary on the same files (default
     flags: tantan-masked letters show up as X in qseq / sseq, full_sseq prints the unmasked target)."""
     if not os.path.exists(REF):
-        pytest.skip("oracle/_ref/diamond not built")
+        pytest.fail("oracle/_ref/diamond is missing: under -m gpu the reference binary is the checker, its absence is a failure (run __graft_entry__.build() where /root/reference exists; oracle/_ref travels with gpurun)")
     db, doff, q, qoff = synth.generate(150, members=6, queries=200, seed=31)
     rng = np.random.default_rng(4)
     for a, off in ((db, doff), (q, qoff)):                       # low-complexity stretches that tantan masks
@@ -412,7 +412,7 @@ def test_cli_long_repeat_proteins_with_wide_bands(tmp_path):
     """Long tandem-repeat proteins: the chains of a pair spread over thousands of diagonals and add_dp_targets merges them into
     bands wider than one wavefront sweeps (round 1 aborted the block pair with DMND_E_BAND). Whole pipeline against the reference."""
     if not os.path.exists(REF):
-        pytest.skip("oracle/_ref/diamond not built")
+        pytest.fail("oracle/_ref/diamond is missing: under -m gpu the reference binary is the checker, its absence is a failure (run __graft_entry__.build() where /root/reference exists; oracle/_ref travels with gpurun)")
     _write_repeat_protein_files(tmp_path)
     traces = []
     for sens in (["--fast"], ["--sensitive"]):
@@ -440,7 +440,7 @@ def test_cli_top_percent_and_large_k_match_reference(tmp_path):
     """--top N (bit-score window instead of -k, also over several reference blocks) and -k above MAX_CHUNK_SIZE (the first ranking
     chunk grows by the seed-hit e-value rule, extend.cpp:262-268) against the reference binary."""
     if not os.path.exists(REF):
-        pytest.skip("oracle/_ref/diamond not built")
+        pytest.fail("oracle/_ref/diamond is missing: under -m gpu the reference binary is the checker, its absence is a failure (run __graft_entry__.build() where /root/reference exists; oracle/_ref travels with gpurun)")
     db, doff, q, qoff = synth.generate(60, members=30, queries=120, seed=17)          # large families: many targets per query
     synth.write_fasta(str(tmp_path / "db.faa"), "t", db, doff)
     synth.write_fasta(str(tmp_path / "q.faa"), "q", q, qoff)
@@ -457,7 +457,7 @@ def test_cli_identity_cover_and_min_score_filters_match_reference(tmp_path):
     """--id / --query-cover / --subject-cover (HSPs removed after round 2; the extension then takes more of the ranked targets, a
     step at a time, until -k matches pass) and --min-score (bit-score report cutoff) against the reference binary."""
     if not os.path.exists(REF):
-        pytest.skip("oracle/_ref/diamond not built")
+        pytest.fail("oracle/_ref/diamond is missing: under -m gpu the reference binary is the checker, its absence is a failure (run __graft_entry__.build() where /root/reference exists; oracle/_ref travels with gpurun)")
     db, doff, q, qoff = synth.generate(60, members=40, queries=150, seed=23)
     rng = np.random.default_rng(3)
     seqs = [db[doff[i]:doff[i + 1]] for i in range(len(doff) - 1)]
@@ -491,7 +491,7 @@ def test_cli_unaligned_queries_header_and_translated_query_cover(tmp_path):
     with several), --unal 0 for the formats that report them by default, --header simple, and --query-cover for blastx (measured
     on the DNA read) against the reference binary."""
     if not os.path.exists(REF):
-        pytest.skip("oracle/_ref/diamond not built")
+        pytest.fail("oracle/_ref/diamond is missing: under -m gpu the reference binary is the checker, its absence is a failure (run __graft_entry__.build() where /root/reference exists; oracle/_ref travels with gpurun)")
     rng = np.random.default_rng(41)
     db, doff, q, qoff = synth.generate(120, members=6, queries=150, seed=41)
     seqs = [q[qoff[i]:qoff[i + 1]] for i in range(len(qoff) - 1)]
@@ -527,7 +527,7 @@ def test_cli_runs_without_any_hit_and_with_tiny_inputs(tmp_path):
     """No seed hit at all, a query shorter than a seed, one sequence on each side: every output format finishes with the reference's
     text (possibly empty)."""
     if not os.path.exists(REF):
-        pytest.skip("oracle/_ref/diamond not built")
+        pytest.fail("oracle/_ref/diamond is missing: under -m gpu the reference binary is the checker, its absence is a failure (run __graft_entry__.build() where /root/reference exists; oracle/_ref travels with gpurun)")
     rng = np.random.default_rng(9)
     with open(tmp_path / "q.faa", "w") as f:
         f.write(">a first\n" + "".join("ARNDCQEGHILKMFPSTWYV"[int(x)] for x in rng.integers(0, 20, 90)) + "\n>b\nMKV\n>c\n" + "A" * 40 + "\n")
@@ -555,7 +555,7 @@ def test_cli_no_self_hits_matches_reference(tmp_path):
     """--no-self-hits on an all-against-all search of the reference's own fixture (every query is in the database under its own
     title), also with several reference blocks and another output format; duplicates under a different title stay."""
     if not os.path.exists(REF):
-        pytest.skip("oracle/_ref/diamond not built")
+        pytest.fail("oracle/_ref/diamond is missing: under -m gpu the reference binary is the checker, its absence is a failure (run __graft_entry__.build() where /root/reference exists; oracle/_ref travels with gpurun)")
     g = os.path.join(ROOT, "tests", "golden", "ref_ctest", "data.faa")
     lines = open(g).read().splitlines()
     with open(tmp_path / "db.faa", "w") as f:                       # + copies of the first sequences under other titles
@@ -584,7 +584,7 @@ def test_cli_scoring_matrices_and_gap_penalties_match_reference(tmp_path):
     the reference's ctest fixture, the filters of --sensitive and a translated search on synthetic families, the positives of the
     output formats."""
     if not os.path.exists(REF):
-        pytest.skip("oracle/_ref/diamond not built")
+        pytest.fail("oracle/_ref/diamond is missing: under -m gpu the reference binary is the checker, its absence is a failure (run __graft_entry__.build() where /root/reference exists; oracle/_ref travels with gpurun)")
     g = os.path.join(ROOT, "tests", "golden", "ref_ctest", "data.faa")
     db, doff, q, qoff = synth.generate(300, members=10, queries=300, seed=23)
     dna, off = synth.back_translate(q[: qoff[120]], qoff[:121], seed=24)
@@ -621,7 +621,7 @@ def test_cli_input_formats_and_translation_options_match_reference(tmp_path):
     --query-gencode, --min-orf. (A gzip-compressed FASTQ is read here too; the reference build loads no query from one.)"""
     import gzip
     if not os.path.exists(REF):
-        pytest.skip("oracle/_ref/diamond not built")
+        pytest.fail("oracle/_ref/diamond is missing: under -m gpu the reference binary is the checker, its absence is a failure (run __graft_entry__.build() where /root/reference exists; oracle/_ref travels with gpurun)")
     db, doff, q, qoff = synth.generate(300, members=10, queries=200, seed=31)
     dna, off = synth.back_translate(q[: qoff[150]], qoff[:151], seed=32)
     synth.write_fasta(str(tmp_path / "db.faa"), "t", db, doff)
@@ -674,7 +674,7 @@ def test_cli_unaligned_aligned_files_compressed_output_and_shape_count(tmp_path)
     --compress 1 (gzip, ".gz" appended) and --shapes N against the reference."""
     import gzip
     if not os.path.exists(REF):
-        pytest.skip("oracle/_ref/diamond not built")
+        pytest.fail("oracle/_ref/diamond is missing: under -m gpu the reference binary is the checker, its absence is a failure (run __graft_entry__.build() where /root/reference exists; oracle/_ref travels with gpurun)")
     db, doff, q, qoff = synth.generate(200, members=10, queries=300, seed=41, decoy_frac=0.3)
     rng = np.random.default_rng(5)
     q = _plant_repeats(q, qoff, rng)                  # tantan masks these stretches: the --un / --al records show them as X
@@ -711,7 +711,7 @@ def test_cli_extension_modes_match_reference(tmp_path):
     """--ext banded-fast / banded-slow / full (whole-matrix alignment of every target with a seed hit, no chaining) on families with
     many indels, tandem-repeat and multi-domain proteins -- data on which the three modes give different alignments."""
     if not os.path.exists(REF):
-        pytest.skip("oracle/_ref/diamond not built")
+        pytest.fail("oracle/_ref/diamond is missing: under -m gpu the reference binary is the checker, its absence is a failure (run __graft_entry__.build() where /root/reference exists; oracle/_ref travels with gpurun)")
     _write_repeat_protein_files(tmp_path, indel=0.08)
     seen = {}
     for extra in (["--ext", "banded-fast"], ["--ext", "banded-slow"], ["--ext", "full"], ["--ext", "full", "--sensitive", "-f", "6", "qseqid", "sseqid", "length", "gapopen", "gaps", "btop"],
@@ -766,7 +766,7 @@ def test_cli_max_hsps_matches_reference(tmp_path):
     (recompute_alt_hsps) -- per sensitivity, with the list cut at 2 / 3, with transcripts, in XML (Hit_num / Hsp_num), with the
     filters, over several reference blocks (an HSP list moves as one record group through the join), for translated queries."""
     if not os.path.exists(REF):
-        pytest.skip("oracle/_ref/diamond not built")
+        pytest.fail("oracle/_ref/diamond is missing: under -m gpu the reference binary is the checker, its absence is a failure (run __graft_entry__.build() where /root/reference exists; oracle/_ref travels with gpurun)")
     _write_multi_hsp_files(tmp_path)
     base = ["-q", str(tmp_path / "q.faa"), "-d", str(tmp_path / "db.faa"), "-p", "4"]
     per_target = {}
@@ -801,7 +801,7 @@ def test_cli_global_ranking_matches_reference(tmp_path):
     ungapped score over a target's seed hits); after the last block those targets are loaded as one block and extended over the
     full matrix. One and several reference blocks, three sensitivities, both algorithms, SEG, transcripts, --max-hsps, blastx."""
     if not os.path.exists(REF):
-        pytest.skip("oracle/_ref/diamond not built")
+        pytest.fail("oracle/_ref/diamond is missing: under -m gpu the reference binary is the checker, its absence is a failure (run __graft_entry__.build() where /root/reference exists; oracle/_ref travels with gpurun)")
     db, doff, q, qoff = synth.generate(150, members=12, queries=200, seed=31, decoy_frac=0.3)
     db, q = _plant_repeats(db, doff, np.random.default_rng(3)), _plant_repeats(q, qoff, np.random.default_rng(4))
     dna, off = synth.back_translate(q[: qoff[60]], qoff[:61], seed=32)
@@ -832,7 +832,7 @@ def test_cli_xml_format_matches_reference(tmp_path):
     """-f 5 (BLAST XML) for blastp (one and several reference blocks, queries without alignments) and blastx; the version line of the
     header names the program that wrote the file and is excluded."""
     if not os.path.exists(REF):
-        pytest.skip("oracle/_ref/diamond not built")
+        pytest.fail("oracle/_ref/diamond is missing: under -m gpu the reference binary is the checker, its absence is a failure (run __graft_entry__.build() where /root/reference exists; oracle/_ref travels with gpurun)")
     db, doff, q, qoff = synth.generate(200, members=10, queries=150, seed=51, decoy_frac=0.3)
     dna, off = synth.back_translate(q[: qoff[60]], qoff[:61], seed=52)
     synth.write_fasta(str(tmp_path / "db.faa"), "t", db, doff)
@@ -855,7 +855,7 @@ def test_cli_daa_format_matches_reference(tmp_path):
     version's); with several reference blocks the dictionary order is an artefact of the block loop, so there the reference's own
     `view` must print from our archive what it prints from its own; --salltitles / --sallseqid change the dictionary."""
     if not os.path.exists(REF):
-        pytest.skip("oracle/_ref/diamond not built")
+        pytest.fail("oracle/_ref/diamond is missing: under -m gpu the reference binary is the checker, its absence is a failure (run __graft_entry__.build() where /root/reference exists; oracle/_ref travels with gpurun)")
     db, doff, q, qoff = synth.generate(200, members=10, queries=150, seed=61, decoy_frac=0.3)
     dna, off = synth.back_translate(q[: qoff[60]], qoff[:61], seed=62)
     synth.write_fasta(str(tmp_path / "db.faa"), "t", db, doff)
@@ -883,7 +883,7 @@ def test_cli_seg_masking_matches_reference(tmp_path):
     """--masking seg: the reference block hard-masked by SEG on the host (up front with the double-indexed algorithm, after the seed
     stage with the query-indexed one), queries untouched; with and without motif soft masking, several reference blocks, blastx."""
     if not os.path.exists(REF):
-        pytest.skip("oracle/_ref/diamond not built")
+        pytest.fail("oracle/_ref/diamond is missing: under -m gpu the reference binary is the checker, its absence is a failure (run __graft_entry__.build() where /root/reference exists; oracle/_ref travels with gpurun)")
     rng = np.random.default_rng(71)
     db, doff, q, qoff = synth.generate(300, members=10, queries=300, seed=71)
     db, q = _plant_repeats(db, doff, rng, frac=0.5), _plant_repeats(q, qoff, rng)
@@ -912,7 +912,7 @@ def test_cli_seg_masking_matches_reference(tmp_path):
 def test_cli_unlimited_target_seqs_matches_reference(tmp_path):
     """-k 0 = every target is reported (init_output: max_target_seqs = INT64_MAX), also over several reference blocks and with a filter."""
     if not os.path.exists(REF):
-        pytest.skip("oracle/_ref/diamond not built")
+        pytest.fail("oracle/_ref/diamond is missing: under -m gpu the reference binary is the checker, its absence is a failure (run __graft_entry__.build() where /root/reference exists; oracle/_ref travels with gpurun)")
     db, doff, q, qoff = synth.generate(60, members=60, queries=120, seed=81)          # families of 60: far more than 25 targets per query
     synth.write_fasta(str(tmp_path / "db.faa"), "t", db, doff)
     synth.write_fasta(str(tmp_path / "q.faa"), "q", q, qoff)
@@ -932,7 +932,7 @@ def test_cli_expert_options_match_reference(tmp_path):
     """--dbsize (effective database size of the e-values), --id2, --seed-cut, --gapped-filter-evalue, --stop-match-score: each against the
     reference, and each changes the default result of this workload."""
     if not os.path.exists(REF):
-        pytest.skip("oracle/_ref/diamond not built")
+        pytest.fail("oracle/_ref/diamond is missing: under -m gpu the reference binary is the checker, its absence is a failure (run __graft_entry__.build() where /root/reference exists; oracle/_ref travels with gpurun)")
     rng = np.random.default_rng(91)
     db, doff, q, qoff = synth.generate(300, members=10, queries=300, seed=91)
     db, q = _plant_repeats(db, doff, rng), _plant_repeats(q, qoff, rng)
@@ -962,7 +962,7 @@ def test_cli_queries_from_standard_input(tmp_path):
     """No -q: the queries are read from standard input (gzip-compressed or not), blastp and blastx."""
     import gzip
     if not os.path.exists(REF):
-        pytest.skip("oracle/_ref/diamond not built")
+        pytest.fail("oracle/_ref/diamond is missing: under -m gpu the reference binary is the checker, its absence is a failure (run __graft_entry__.build() where /root/reference exists; oracle/_ref travels with gpurun)")
     db, doff, q, qoff = synth.generate(100, members=10, queries=80, seed=95)
     dna, off = synth.back_translate(q[: qoff[40]], qoff[:41], seed=96)
     synth.write_fasta(str(tmp_path / "db.faa"), "t", db, doff)
@@ -1018,7 +1018,7 @@ def test_cli_comp_based_stats_matrix_adjust_matches_reference(tmp_path):
     sensitivity, algorithm, with transcripts, several HSPs per target, several reference blocks, another standard matrix, --top and
     the filters. The reference's refusals are reproduced too."""
     if not os.path.exists(REF):
-        pytest.skip("oracle/_ref/diamond not built")
+        pytest.fail("oracle/_ref/diamond is missing: under -m gpu the reference binary is the checker, its absence is a failure (run __graft_entry__.build() where /root/reference exists; oracle/_ref travels with gpurun)")
     _write_biased_files(tmp_path)
     base = ["-q", str(tmp_path / "q.faa"), "-d", str(tmp_path / "db.faa"), "-p", "4"]
     outs = {}
@@ -1079,7 +1079,7 @@ def test_cli_frameshift_matches_reference(tmp_path):
             a, b = set(want.splitlines()), set(got.splitlines())
             raise AssertionError("%s: %d lines only in the golden, %d only in ours; e.g. %s | %s" % (name, len(a - b), len(b - a), sorted(a - b)[:2], sorted(b - a)[:2]))
     if not os.path.exists(REF):
-        pytest.skip("oracle/_ref/diamond not built")
+        pytest.fail("oracle/_ref/diamond is missing: under -m gpu the reference binary is the checker, its absence is a failure (run __graft_entry__.build() where /root/reference exists; oracle/_ref travels with gpurun)")
     db, doff, q, qoff = synth.generate(150, members=8, queries=220, seed=81)
     synth.write_fasta(str(tmp_path / "db.faa"), "t", db, doff)
     dna, off = synth.back_translate(q, qoff, seed=82)
@@ -1106,12 +1106,41 @@ def test_cli_frameshift_matches_reference(tmp_path):
             assert r.returncode != 0 and msg in r.stderr + r.stdout, (binary, cmd)
 
 
+def test_cli_frameshift_blocked_range_culling_matches_reference(tmp_path):
+    """blastx -F with a database of several reference blocks (round 5, dmnd_join_blocks_range): the join of the per-block records
+    uses the culler TargetCulling::get picks -- RangeCulling with --range-culling / --long-reads (a target is kept unless the part
+    of the read it covers is covered already), GlobalCulling otherwise. Byte-identical to the reference binary with the same -b."""
+    if not os.path.exists(REF):
+        pytest.fail("oracle/_ref/diamond is missing: under -m gpu the reference binary is the checker, its absence is a failure (run __graft_entry__.build() where /root/reference exists; oracle/_ref travels with gpurun)")
+    db, doff, q, qoff = synth.generate(150, members=8, queries=220, seed=81)
+    synth.write_fasta(str(tmp_path / "db.faa"), "t", db, doff)
+    dna, off = synth.back_translate(q, qoff, seed=82)
+    synth.write_dna_fasta(str(tmp_path / "reads.fna"), "r", *synth.indel_reads(dna, off, seed=83, deletion=0.004, insertion=0.004))
+    base = ["blastx", "-q", str(tmp_path / "reads.fna"), "-d", str(tmp_path / "db.faa"), "-p", "4", "-b0.0001", "-c1"]
+    differs = 0
+    for extra in (["-F", "15", "--range-culling", "-k", "2"], ["--long-reads"], ["-F", "15", "--range-culling", "--range-cover", "20", "--top", "30"],
+                  ["-F", "15", "--range-culling", "-k", "1", "--range-cover", "80"], ["-F", "15", "-k", "3"], ["-F", "15", "--top", "5"]):
+        _run([REF] + base + extra + ["-o", str(tmp_path / "ref.out")])
+        r = _run([CLI] + base + extra + ["-o", str(tmp_path / "hip.out")])
+        assert "reference blocks=" in r.stderr
+        ref, got = open(tmp_path / "ref.out").read(), open(tmp_path / "hip.out").read()
+        assert len(ref) > 1000, extra
+        if got != ref:
+            a, b = set(ref.splitlines()), set(got.splitlines())
+            raise AssertionError("%s: %d lines only in the reference's output, %d only in ours; e.g. %s | %s" % (extra, len(a - b), len(b - a), sorted(a - b)[:2], sorted(b - a)[:2]))
+        if "--range-culling" in extra or "--long-reads" in extra:
+            # the case is only a test of the range join if global culling of the same records would give another text
+            _run([CLI] + base + [x for x in extra if x not in ("--range-culling", "--long-reads")] + (["-F", "15", "--top", "10"] if "--long-reads" in extra else []) + ["-o", str(tmp_path / "glob.out")])
+            differs += open(tmp_path / "glob.out").read() != got
+    assert differs >= 1
+
+
 def test_cli_frameshift_alignment_fields_match_reference(tmp_path):
     """blastx -F 15 with the tabular fields that walk the alignment (round 4): btop, cigar, qseq_gapped, sseq_gapped, sseq and
     qseq_translated follow the alignment through its frame changes as the reference's HspContext::Iterator does; byte-identical
     to the reference binary on the reads with planted insertions and deletions."""
     if not os.path.exists(REF):
-        pytest.skip("oracle/_ref/diamond not built")
+        pytest.fail("oracle/_ref/diamond is missing: under -m gpu the reference binary is the checker, its absence is a failure (run __graft_entry__.build() where /root/reference exists; oracle/_ref travels with gpurun)")
     g = os.path.join(ROOT, "tests", "golden")
     base = ["blastx", "-q", os.path.join(g, "fs_reads.fna"), "-d", os.path.join(g, "fs_db.faa"), "-p", "4", "-F", "15"]
     for extra in (["-f", "6", "qseqid", "sseqid", "qstart", "qend", "sstart", "send", "length", "btop", "cigar"],
