@@ -711,8 +711,9 @@ def main():
         # HBM traffic of the dominant kernel per launch: FETCH_SIZE of a separate `rocprofv3 --pmc FETCH_SIZE` pass over this same
         # command (tools/profile_r03.sh), doubled as MI355X_MICROARCH.md prescribes for gfx950, plus WRITE_SIZE; only quoted for the
         # configuration and kernel variant it was measured on
-        pmc_path = next((q for q in (os.path.join(ROOT, "profiles", "r%02d_pmc_summary_%s.json" % (r, args.config)) for r in (4, 3, 2)) if os.path.exists(q)), None)
-        if world == 1 and args.queries == 10_000 and args.families == 100_000 and NB == 1 and pmc_path:
+        pmc_path = next((q for q in (os.path.join(ROOT, "profiles", "r%02d_pmc_summary_%s.json" % (r, args.config)) for r in (5, 4, 3, 2)) if os.path.exists(q)), None)
+        full_size = args.queries == CONFIGS[args.config].get("queries", 10_000) and args.families == CONFIGS[args.config].get("families", 100_000)
+        if world == 1 and full_size and pmc_path:
             pmc = json.load(open(pmc_path))
             k = [v for name, v in pmc.items() if "seed_stream_fast_kernel" in name]
             if len(k) == 1 and "FETCH_SIZE_x2_bytes_per_launch" in k[0]:

@@ -1308,7 +1308,34 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	std::vector<int> rcs((size_t)split, DMND_OK);
 	std::vector<std::string> errs((size_t)split);
 	static const int team = [] { const char* e = std::getenv("DMND_EXTEND_TEAM"); return e ? std::max(1, std::atoi(e)) : 8; }();
-	if (split == 1) {
+	if (split == 1 && cbs_matrix_adjust(h.cbs_mode)) {
+		// --comp-based-stats 2-5: every planned (query, target) pair owns a 1 KB adjusted matrix for the whole extend_range call
+		// (QueryState::mat_of, dmnd_ctx::adj_matrices), where the reference holds a TargetMatrix for the queries of one chunk only.
+		// A block pair of 1e5-1e6 queries would ask for tens of GB of matrices in one call. So the queries go through in passes
+		// of at most DMND_CBS_PASS_HITS seed hits (default 2 M: a pair needs a seed hit, so <= 2 GB of matrices, in practice a tenth);
+		// a pass frees its matrices (extend_range starts from none). The result does not depend on the cut: queries are independent.
+		static const int64_t pass_hits = [] { const char* e = std::getenv("DMND_CBS_PASS_HITS"); return e ? std::max<int64_t>(1, std::atoll(e)) : (int64_t)2 << 20; }();
+		int64_t t_used = 0;
+		double stats[12] = { 0 };
+		for (size_t b = 0; b < qr.size() && rcs[0] == DMND_OK;) {
+			size_t e = b + 1;
+			while (e < qr.size() && (int64_t)(qr[e].e - qr[b].b) <= pass_hits) ++e;
+			std::vector<dmnd_match> part;
+			int64_t used = 0;
+			rcs[0] = extend_range(c, c, h, qr, b, e, hits, gf, qdata, tdata, cbs, std::min(threads, team), hsp_values, part, transcript ? transcript + t_used : nullptr,
+				transcript ? transcript_cap - t_used : 0, &used, b == 0 && bias_pending ? c->stream : nullptr, xd);
+			if (rcs[0] != DMND_OK) break;
+			if (t_used > 0) for (dmnd_match& m : part) if (m.hsp.transcript_off >= 0) m.hsp.transcript_off += t_used;
+			t_used += used;
+			parts[0].insert(parts[0].end(), part.begin(), part.end());
+			for (int i = 0; i < 12; ++i) stats[i] += c->ext_stats[i];
+			c->ext_stats[4] = 0;                             // (extend_range keeps slot 4 of its caller: the prelude's time, counted with the first pass)
+			b = e;
+		}
+		for (int i = 0; i < 12; ++i) c->ext_stats[i] = stats[i];
+		if (transcript_used) *transcript_used = t_used;
+	}
+	else if (split == 1) {
 		rcs[0] = extend_range(c, c, h, qr, 0, qr.size(), hits, gf, qdata, tdata, cbs, std::min(threads, team), hsp_values, parts[0], transcript, transcript_cap, transcript_used,
 			bias_pending ? c->stream : nullptr, xd);
 	}

@@ -262,6 +262,22 @@ __device__ __forceinline__ uint32_t bm1_probe_any(int policy, __amdgpu_buffer_rs
 	}
 }
 
+// Loads of data that a workgroup reads once (the reference letters, their class nibbles and window maps) with the non-temporal
+// hint: the lines are still filled, but first in line for eviction -- the L2's capacity is wanted for the query side, which every
+// workgroup of an XCD comes back to (SeedArgs::stream_nt, DMND_SEED_STREAM_NT)
+template<typename T>
+__device__ __forceinline__ T stream_load(const T* p, int nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ void window_load(uint32_t (&tw)[12], const int8_t* p, int nt)
+{
+	if (!nt) { __builtin_memcpy(tw, p, 48); return; }
+	typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(1)));
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+		const u32x4_u v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_u*>(p + 16 * k));
+		tw[4 * k] = v.x; tw[4 * k + 1] = v.y; tw[4 * k + 2] = v.z; tw[4 * k + 3] = v.w;
+	}
+}
+
 enum { SEED_CLASS_TILES = 4 };      // tiles of 4096 window starts per class workgroup (kernel and launch)
 // DMND_SEED_PHASES=1 (SeedArgs::phase_ticks): thread 0 of every workgroup adds the 100 MHz ticks between its phase boundaries
 #define PHASE_MARK(i) do { if (a.phase_ticks && threadIdx.x == 0) { const uint64_t now_ = wall_clock64(); atomicAdd(&a.phase_ticks[i], (unsigned long long)(now_ - phase_t_)); phase_t_ = now_; } } while (0)
@@ -320,7 +336,7 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 	// Hamming filter of the reference window at pos against the entries first, first + step, ... of a list of query positions
 	auto filter_list = [&](uint32_t slot, uint32_t head, uint32_t count, int64_t pos, uint32_t first, uint32_t step) {
 		uint32_t tw[12];
-		__builtin_memcpy(tw, a.tdata + pos - 16, 48);
+		window_load(tw, a.tdata + pos - 16, BYCLASS ? a.stream_nt : 0);
 		if (a.qfold) {
 			// Pre-filter on letters folded to 4 bits (letter & 15: equal letters stay equal, so the folded identity count is an upper
 			// bound of the real one): the query side is read from a 1.5 MB array with two 16-byte requests per pair instead of three
@@ -403,7 +419,7 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 			const int64_t p = wg_base + off;
 			const int64_t g = (p - base) >> 4;
 			const int sh = (int)(p & 15) * 4;                             // base and wg_base are multiples of 16
-			const uint64_t c0 = a.tcodes[g], c1 = a.tcodes[g + 1];
+			const uint64_t c0 = stream_load(a.tcodes + g, a.stream_nt), c1 = stream_load(a.tcodes + g + 1, a.stream_nt);
 			return (sh == 0 ? c0 : (c0 >> sh) | (c1 << (64 - sh))) & care64;
 		};
 		// which of a group's 16 windows are valid and of this class: seed_classify_kernel's answer for this shape (one bit per window);
@@ -413,7 +429,7 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 		for (int sub = 0; sub < CLASS_TILES; ++sub) {
 			const int64_t p0 = wg_base + ((int64_t)sub * 256 + threadIdx.x) * 16;
 			const int64_t g = (p0 - base) >> 4;
-			maps[sub] = p0 < a.t_end ? a.tclass[(int64_t)my_class * a.tclass_stride + g] : 0u;
+			maps[sub] = p0 < a.t_end ? stream_load(a.tclass + (int64_t)my_class * a.tclass_stride + g, a.stream_nt) : 0u;
 			specials[sub] = HASHED && p0 < a.t_end && ((uint32_t)g & 7u) == my_class ? a.tclass[8 * a.tclass_stride + g] : 0u;
 		}
 #pragma unroll

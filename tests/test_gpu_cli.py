@@ -1050,6 +1050,12 @@ def test_cli_comp_based_stats_matrix_adjust_matches_reference(tmp_path):
             raise AssertionError("%s: %d lines only in the reference's output, %d only in ours; e.g. %s | %s" % (extra, len(a - b), len(b - a), sorted(a - b)[:2], sorted(b - a)[:2]))
         outs[" ".join(extra)] = ref
     assert refused >= 2                                      # --max-hsps 0 and --ext full
+    # round 5: the matrices live for one pass over at most DMND_CBS_PASS_HITS seed hits; many small passes give the same text
+    for extra in (["4"], ["3", "-f", "6", "qseqid", "sseqid", "score", "qstart", "qend", "sstart", "send", "evalue", "bitscore", "length", "gapopen", "btop", "cigar"]):
+        r = subprocess.run([CLI, "blastp"] + base + ["--comp-based-stats"] + extra + ["-o", str(tmp_path / "passes.out")], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, DMND_CBS_PASS_HITS="300"))
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert open(tmp_path / "passes.out").read() == outs[" ".join(extra)], extra
     # the modes are not the same computation: the adjusted matrices change scores
     _run([REF, "blastp"] + base + ["-o", str(tmp_path / "m1.out")])
     m1 = open(tmp_path / "m1.out").read()
