@@ -776,6 +776,7 @@ int run_blastp(const Options& o)
 	}
 	if (tab_extras && fmt != FMT_FIELDS && !o.header.empty() && o.header != "0") throw std::runtime_error("--header is only available for the tabular format");
 	if (o.frameshift > 0) {
+		need_transcripts = 1;      // config.frame_shift != 0 => output_format->hsp_values = TRANSCRIPT (output/output_format.cpp:256-257); the block join re-counts from them
 		// A frameshift alignment changes frame along its transcript: the cursor of format_api.hip follows the frames, and the tabular
 		// format prints such alignments with any field. The other writers print them too (`view` of a reference-written -F archive
 		// equals the reference's view in the pairwise, XML, SAM and PAF formats: tests/test_view.py), but which queries WITHOUT an
@@ -1292,6 +1293,22 @@ int run_blastp(const Options& o)
 		if (t_blocks.size() > 1 && o.global_ranking == 0) chk(o.range_culling ? dmnd_join_blocks_range(joined.data(), (int64_t)joined.size(), o.k, o.top, o.range_cover, &n_matches)
 			: o.top >= 0.0 ? dmnd_join_blocks_top(joined.data(), (int64_t)joined.size(), o.top, &n_matches)
 			: dmnd_join_blocks(joined.data(), (int64_t)joined.size(), o.k, &n_matches));
+		if (t_blocks.size() > 1 && o.frameshift > 0 && need_transcripts) {
+			// Several reference blocks: the reference prints from the joined IntermediateRecords, and with a frameshift penalty those
+			// carry transcripts (output_format.cpp:256-257), so every printed Hsp is re-counted from its transcript by HspContext::parse
+			// (basic/hssp.cpp:64-100) -- where a frameshift operation is a column of the alignment: `length` (and pident with it) counts
+			// it, which the traceback's own statistics of a single-block run do not. E-value and bit score stay the record's.
+			for (int64_t k = 0; k < n_matches; ++k) {
+				dmnd_match& m = joined[(size_t)k];
+				const size_t base = (size_t)m.query * C + (size_t)(m.frame / 3) * 3 - qr.begin * C;
+				const int8_t* f3[3];
+				int32_t l3[3];
+				for (int j = 0; j < 3; ++j) { f3[j] = q.data.data() + q.limits[base + (size_t)j]; l3[j] = (int32_t)(q.limits[base + (size_t)j + 1] - q.limits[base + (size_t)j] - 1); }
+				const double ev = m.evalue, bs = m.bit_score;
+				chk(dmnd_hsp_from_transcript_frames(&p, f3, l3, source_len[m.query], l3[0], (int32_t)db.length(m.target), arena.data() + m.hsp.transcript_off, &m));
+				m.evalue = ev; m.bit_score = bs;
+			}
+		}
 		std::vector<int8_t> full_sseq_buf;                    // the unmasked target of the line being printed (full_sseq)
 		auto view_of = [&](const dmnd_match& m) {
 			dmnd_hsp_view v;

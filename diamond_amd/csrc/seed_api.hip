@@ -19,6 +19,8 @@
 
 using namespace dmnd;
 
+enum { SEED_CLASSES_LONG_DEFAULT = 0 };      // (off until measured: tools/gpu_r05b.sh)
+
 static_assert(sizeof(dmnd_seed_params) == sizeof(SeedParams), "dmnd_seed_params must mirror dmnd::SeedParams");
 static_assert(sizeof(dmnd_seed_hit) == 24, "dmnd_seed_hit layout");
 
@@ -436,7 +438,13 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	while (((uint64_t)1 << list_key_bits) <= slots) ++list_key_bits;
 	// key classes (seed_core.h seed_class): the short-seed pipeline, when the geometry allows eighths (DMND_SEED_CLASSES=0: one range)
 	static const bool classes_env = [] { const char* e = getenv("DMND_SEED_CLASSES"); return !e || atoi(e) != 0; }();
-	const int classes = fused && classes_env && slots >= 64 && bm1_words % 8 == 0 && bm1_words >= 64 ? 8 : 0;
+	// ... and (round 5) long seeds against a query block whose level-1 filter has outgrown an XCD's L2 (above 2^24 query positions the
+	// filter is 4-16 MB: C5's 100 000 queries): by class every XCD probes its own eighth of it. DMND_SEED_CLASSES_LONG=0/1 forces it.
+	static const int classes_long_env = [] { const char* e = getenv("DMND_SEED_CLASSES_LONG"); return e ? atoi(e) : -1; }();
+	bool nibble_shapes = true;
+	for (int i = 0; i < S; ++i) nibble_shapes = nibble_shapes && seed_nibble_mode(sp, i);
+	const bool classes_long = !fused && nibble_shapes && (classes_long_env >= 0 ? classes_long_env != 0 : SEED_CLASSES_LONG_DEFAULT && bm1_words * 32 > ((uint64_t)1 << 24));
+	const int classes = (fused ? classes_env : classes_long) && slots >= 64 && bm1_words % 8 == 0 && bm1_words >= 64 ? 8 : 0;
 	std::string signature;
 	if (reuse) {
 		signature.assign(reinterpret_cast<const char*>(&sp), sizeof(sp));
@@ -475,6 +483,15 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		const int64_t n = c->block_len[DMND_QUERY];
 		if (int rc = c->seed_qfold.ensure((size_t)(n + 1) / 2 + 64)) return rc;
 		HIP_TRY(launch_seed_fold(c->block[DMND_QUERY].as<int8_t>(), n, c->seed_qfold.as<uint8_t>(), st));
+	}
+	// ... and of the reference block for the by-class stream (round 5): eight workgroups on eight XCDs read the letters around the
+	// joins of every tile, each through its own L2 -- from the folded copy that is half the lines (DMND_SEED_TFOLD=0: from the letters)
+	static const bool tfold_env = [] { const char* e = getenv("DMND_SEED_TFOLD"); return !e || atoi(e) != 0; }();
+	const bool use_tfold = use_fold && classes && tfold_env;
+	if (use_tfold) {
+		const int64_t n = c->block_len[DMND_TARGET];
+		if (int rc = c->seed_tfold.ensure((size_t)(n + 1) / 2 + 64)) return rc;
+		HIP_TRY(launch_seed_fold(c->block[DMND_TARGET].as<int8_t>(), n, c->seed_tfold.as<uint8_t>(), st));
 	}
 	if (classes) {
 		const int8_t* tseed = (c->soft_valid[DMND_TARGET] && sp.seed_encoding == SEED_SPACED) ? c->soft[DMND_TARGET].as<int8_t>() : c->block[DMND_TARGET].as<int8_t>();
@@ -525,6 +542,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		a.fused = fused ? 1 : 0;
 		a.level2 = level2_of(sid);
 		a.qfold = use_fold ? c->seed_qfold.as<uint8_t>() : nullptr;
+		a.tfold = use_tfold ? c->seed_tfold.as<uint8_t>() : nullptr;
 		return a;
 	};
 

@@ -89,6 +89,7 @@ struct SeedArgs {
 	// output
 	dmnd_seed_hit* hits; unsigned long long* hit_count; int64_t hit_cap;
 	const uint8_t* qfold;                         // fused pipeline: the query block with 4 bits per letter (letter & 15), or NULL: pre-filter of the Hamming test
+	const uint8_t* tfold;                         // by-class stream: the reference block folded the same way, or NULL (the window is folded from the letters)
 	int level2;                                   // the level-2 bitmap is filled and consulted (long seeds)
 	int fused;                                    // short-seed pipeline: seed_lists_kernel decides SLOT_LOWC for every group (the stream needs it)
 };

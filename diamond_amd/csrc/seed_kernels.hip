@@ -336,19 +336,32 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 	// Hamming filter of the reference window at pos against the entries first, first + step, ... of a list of query positions
 	auto filter_list = [&](uint32_t slot, uint32_t head, uint32_t count, int64_t pos, uint32_t first, uint32_t step) {
 		uint32_t tw[12];
-		window_load(tw, a.tdata + pos - 16, BYCLASS ? a.stream_nt : 0);
+		const bool folded_ref = BYCLASS && a.qfold && a.tfold;      // the letters themselves are only read for the pairs that pass the pre-filter
+		if (!folded_ref) window_load(tw, a.tdata + pos - 16, BYCLASS ? a.stream_nt : 0);
 		if (a.qfold) {
 			// Pre-filter on letters folded to 4 bits (letter & 15: equal letters stay equal, so the folded identity count is an upper
 			// bound of the real one): the query side is read from a 1.5 MB array with two 16-byte requests per pair instead of three
 			// from the 3 MB block, which is what this kernel is short of (L2 capacity and fabric reads); the ~2 % that pass are
 			// counted exactly on the letters.
 			uint32_t tf[6];
+			if (folded_ref) {
+				const int64_t t0 = pos - 16;
+				typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(1)));
+				const u32x4_u* src = reinterpret_cast<const u32x4_u*>(a.tfold + (t0 >> 1));
+				const u32x4_u r0 = a.stream_nt ? __builtin_nontemporal_load(src) : src[0], r1 = a.stream_nt ? __builtin_nontemporal_load(src + 1) : src[1];
+				const uint32_t raw[8] = { r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w };
+				const uint32_t sh = (uint32_t)(t0 & 1) * 4;
 #pragma unroll
-			for (int w = 0; w < 6; ++w) {
-				uint32_t lo = tw[2 * w] & 0x0f0f0f0fu, hi = tw[2 * w + 1] & 0x0f0f0f0fu;
-				lo = (lo | (lo >> 4)) & 0x00ff00ffu; lo = (lo | (lo >> 8)) & 0xffffu;
-				hi = (hi | (hi >> 4)) & 0x00ff00ffu; hi = (hi | (hi >> 8)) & 0xffffu;
-				tf[w] = lo | (hi << 16);
+				for (int w = 0; w < 6; ++w) tf[w] = __builtin_amdgcn_alignbit(raw[w + 1], raw[w], sh);
+			}
+			else {
+#pragma unroll
+				for (int w = 0; w < 6; ++w) {
+					uint32_t lo = tw[2 * w] & 0x0f0f0f0fu, hi = tw[2 * w + 1] & 0x0f0f0f0fu;
+					lo = (lo | (lo >> 4)) & 0x00ff00ffu; lo = (lo | (lo >> 8)) & 0xffffu;
+					hi = (hi | (hi >> 4)) & 0x00ff00ffu; hi = (hi | (hi >> 8)) & 0xffffu;
+					tf[w] = lo | (hi << 16);
+				}
 			}
 			for (uint32_t i = first; i < count; i += step) {
 				const uint32_t x = count == 1 ? head : a.qlist[head + i];
@@ -366,6 +379,7 @@ __global__ __launch_bounds__(256) void seed_stream_fast_kernel(SeedArgs a, int s
 				if (48 - mism < a.params.hamming_filter_id) continue;
 				uint32_t qw[12];
 				__builtin_memcpy(qw, a.qdata + x0, 48);
+				if (folded_ref) __builtin_memcpy(tw, a.tdata + pos - 16, 48);
 				if (window_identity(tw, qw) >= a.params.hamming_filter_id) survive(slot, x, pos);
 			}
 			return;
@@ -1309,8 +1323,17 @@ hipError_t launch_seed_stream(const SeedArgs& a, int sid, hipStream_t st, bool f
 		uint64_t care64 = 0;
 		for (int k = 0; k < c.shape_weight[sid]; ++k) care64 |= (uint64_t)15 << (4 * c.shape_pos[sid][k]);
 		const bool level2 = a.level2 != 0, hashed = c.seed_encoding == SEED_HASHED;
-		const dim3 grid(fused && a.classes ? blocks_for(threads, 256 * SEED_CLASS_TILES) * 8u : blocks_for(threads, 256)), block(256);
-		if (fused && a.classes) {
+		const dim3 grid(a.classes ? blocks_for(threads, 256 * SEED_CLASS_TILES) * 8u : blocks_for(threads, 256)), block(256);
+		// Residency cap of the long-seed stream (round 5): the kernel is bound by the L2s' request rate, which a fraction of the
+		// wavefront slots saturates (8 probes x 64 lanes in flight per wavefront; at ~1 us of latency 2e11 requests/s need ~400
+		// wavefronts, the device holds 8192) -- but launched bare it takes every slot, and the kernels of the other batches in flight
+		// (the next query index, the sweeps and walks of the extension: VALU-bound, nothing to do with the L2s) queue behind its
+		// 73 000 workgroups instead of running beside them. DMND_SEED_STREAM_WGS = workgroups (of four wavefronts) per CU, enforced
+		// with dynamic LDS the kernel never touches (160 KB per CU / n); 0 = no cap.
+		static const int wgs_per_cu = [] { const char* e = getenv("DMND_SEED_STREAM_WGS"); return e ? std::max(0, atoi(e)) : 0; }();
+		const unsigned cap_lds = (!fused && !a.classes && wgs_per_cu > 0) ? (unsigned)std::min(56 * 1024, std::max(0, 160 * 1024 / wgs_per_cu - 8 * 1024)) & ~255u : 0u;      // (<= 64 KB per workgroup with the kernel's own 6 KB: two per CU at the least)
+		const bool by_class = a.classes != 0;               // the fused pipeline, or long seeds against a large query block (seed_api.hip)
+		if (by_class) {
 			const int64_t n_groups = seed_code_groups(a.t_begin, a.t_end);
 			hipLaunchKernelGGL(seed_classify_kernel, dim3(blocks_for(n_groups, 256)), dim3(256), 0, st, a, sid, base, n_groups, care64, hashed ? 1 : 0, const_cast<uint16_t*>(a.tclass));
 		}
@@ -1318,10 +1341,14 @@ hipError_t launch_seed_stream(const SeedArgs& a, int sid, hipStream_t st, bool f
 		else if (fused && a.classes) hipLaunchKernelGGL((seed_stream_fast_kernel<false, false, true, true>), grid, block, 0, st, a, sid, lo, hi, base, care64);
 		else if (fused && hashed) hipLaunchKernelGGL((seed_stream_fast_kernel<false, true, true>), grid, block, 0, st, a, sid, lo, hi, base, care64);
 		else if (fused) hipLaunchKernelGGL((seed_stream_fast_kernel<false, false, true>), grid, block, 0, st, a, sid, lo, hi, base, care64);
-		else if (level2 && hashed) hipLaunchKernelGGL((seed_stream_fast_kernel<true, true, false>), grid, block, 0, st, a, sid, lo, hi, base, care64);
-		else if (level2) hipLaunchKernelGGL((seed_stream_fast_kernel<true, false, false>), grid, block, 0, st, a, sid, lo, hi, base, care64);
-		else if (hashed) hipLaunchKernelGGL((seed_stream_fast_kernel<false, true, false>), grid, block, 0, st, a, sid, lo, hi, base, care64);
-		else hipLaunchKernelGGL((seed_stream_fast_kernel<false, false, false>), grid, block, 0, st, a, sid, lo, hi, base, care64);
+		else if (by_class && level2 && hashed) hipLaunchKernelGGL((seed_stream_fast_kernel<true, true, false, true>), grid, block, 0, st, a, sid, lo, hi, base, care64);
+		else if (by_class && level2) hipLaunchKernelGGL((seed_stream_fast_kernel<true, false, false, true>), grid, block, 0, st, a, sid, lo, hi, base, care64);
+		else if (by_class && hashed) hipLaunchKernelGGL((seed_stream_fast_kernel<false, true, false, true>), grid, block, 0, st, a, sid, lo, hi, base, care64);
+		else if (by_class) hipLaunchKernelGGL((seed_stream_fast_kernel<false, false, false, true>), grid, block, 0, st, a, sid, lo, hi, base, care64);
+		else if (level2 && hashed) hipLaunchKernelGGL((seed_stream_fast_kernel<true, true, false>), grid, block, cap_lds, st, a, sid, lo, hi, base, care64);
+		else if (level2) hipLaunchKernelGGL((seed_stream_fast_kernel<true, false, false>), grid, block, cap_lds, st, a, sid, lo, hi, base, care64);
+		else if (hashed) hipLaunchKernelGGL((seed_stream_fast_kernel<false, true, false>), grid, block, cap_lds, st, a, sid, lo, hi, base, care64);
+		else hipLaunchKernelGGL((seed_stream_fast_kernel<false, false, false>), grid, block, cap_lds, st, a, sid, lo, hi, base, care64);
 		return hipGetLastError();
 	}
 	hipLaunchKernelGGL(seed_stream_kernel, dim3(blocks_for(a.t_end - a.t_begin, 256)), dim3(256), 0, st, a, sid);
