@@ -573,7 +573,7 @@ def main():
         hip.load_motif_table()
         raw, mc = make_ctx(0), make_ctx(0)
         qd_m, td_m = w.qd.copy(), w.blocks[0][2].copy()       # the host copies the extension reads: patched with the masked positions
-        parts = {k: [] for k in ("copy", "mask_query", "mask_target", "tantan_target_kernel", "seed_stage", "extension", "step")}
+        parts = {k: [] for k in ("copy", "mask_query", "mask_target", "tantan_target_kernel", "tantan_target_call", "motif_target_call", "seed_stage", "extension", "step")}
         n_masked = None
         for s in range(args.warmup + args.steps):
             torch.cuda.synchronize()
@@ -586,6 +586,7 @@ def main():
             t_2 = time.perf_counter()
             nt = mc.mask_block(hip.TARGET, td_m)
             k_ms = mc.mask_kernel_ms()
+            t_2b = time.perf_counter()
             mc.soft_mask_block(hip.TARGET)
             t_3 = time.perf_counter()
             hits = mc.seed_search(seed_params)
@@ -596,6 +597,8 @@ def main():
                 for k, v in zip(("copy", "mask_query", "mask_target", "seed_stage", "extension", "step"), (t_1 - t_0, t_2 - t_1, t_3 - t_2, t_4 - t_3, t_5 - t_4, t_5 - t_0)):
                     parts[k].append(v * 1e3)
                 parts["tantan_target_kernel"].append(k_ms)
+                parts["tantan_target_call"].append((t_2b - t_2) * 1e3)
+                parts["motif_target_call"].append((t_3 - t_2b) * 1e3)
             n_masked = (int(nq), int(nt))
         st = mc.extend_stats()
         m_cells = st["round1_cells"] + (st["round2_cells"] if st["round2_swipe_kernel_ms"] > 0 else 0.0)

@@ -506,25 +506,60 @@ __global__ __launch_bounds__(LANES_WAVES * 64) void tantan_lanes_kernel(const Ta
 // ---- motif soft masking ---------------------------------------------------------------------------------------------
 enum { MOTIF_TABLE_MAX = 8192, MOTIF_CHUNK = 1 << 15 };
 
-// a workgroup keeps the sorted table in LDS (64 KB) and tests the 8-mers of its 32 Ki block positions against it
+// A workgroup keeps the sorted table in LDS (64 KB) and tests the 8-mers of its 32 Ki block positions against it.
+// Round 5 (the masked step of bench.py spent 12 ms per 3.0e8-letter block in the two motif kernels, twice tantan's 6 ms): a thread
+// takes EIGHT consecutive window starts from one 16-byte load, rolls the base-20 code from start to start, asks a 64 Kbit
+// one-hash filter of the table (8 KB of LDS, one read; 1000 motifs set 1.5 % of it) before the 10-step binary search, and writes
+// its eight hit bytes with one store. (Before: one start per thread and iteration, eight byte loads and a full search each.)
 __global__ __launch_bounds__(256) void motif_hit_kernel(MotifArgs a)
 {
 	__shared__ uint64_t table[MOTIF_TABLE_MAX];
+	__shared__ uint32_t filter[2048];
+	for (int i = threadIdx.x; i < 2048; i += blockDim.x) filter[i] = 0;
 	for (int i = threadIdx.x; i < a.n_table; i += blockDim.x) table[i] = a.table[i];
 	__syncthreads();
+	auto slot_of = [](uint64_t code) { return (uint32_t)((code * 0x9E3779B97F4A7C15ull) >> 48); };
+	for (int i = threadIdx.x; i < a.n_table; i += blockDim.x) { const uint32_t h = slot_of(table[i]); atomicOr(&filter[h >> 5], 1u << (h & 31)); }
+	__syncthreads();
 	const int64_t p0 = a.begin + (int64_t)blockIdx.x * MOTIF_CHUNK;
-	for (int64_t p = p0 + threadIdx.x; p < p0 + MOTIF_CHUNK && p < a.end; p += blockDim.x) {
-		uint64_t code;
-		a.hit[p] = motif_code_at(a.data + p, code) && motif_in_table(table, a.n_table, code) ? 1 : 0;      // a window across a delimiter holds a letter >= 20
+	constexpr uint64_t TOP = 1280000000ull;                  // 20^7: the weight of a window's first letter
+	for (int64_t p = p0 + 8 * (int64_t)threadIdx.x; p < p0 + MOTIF_CHUNK && p < a.end; p += 8 * (int64_t)blockDim.x) {
+		uint8_t l[16];
+		__builtin_memcpy(l, a.data + p, 16);                   // starts p .. p + 7 read letters p .. p + 14 (blocks end with 256 padding letters)
+		uint64_t code = 0, hits = 0;
+		int bad = 0;                                           // non-standard letters among the window's eight
+#pragma unroll
+		for (int i = 0; i < 8; ++i) { const int x = l[i] & 31; bad += x >= 20; code = code * 20 + (uint64_t)(x >= 20 ? 0 : x); }
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			if (k > 0) {                                          // roll: drop letter k - 1, take letter k + 7
+				const int out = l[k - 1] & 31, in = l[k + 7] & 31;
+				bad += (in >= 20) - (out >= 20);
+				code = (code - (uint64_t)(out >= 20 ? 0 : out) * TOP) * 20 + (uint64_t)(in >= 20 ? 0 : in);
+			}
+			if (bad == 0 && p + k < a.end) {                      // (a window across a delimiter holds a letter >= 20)
+				const uint32_t h = slot_of(code);
+				if (((filter[h >> 5] >> (h & 31)) & 1u) && motif_in_table(table, a.n_table, code)) hits |= (uint64_t)1 << (8 * k);
+			}
+		}
+		if (p + 8 <= a.end) __builtin_memcpy(a.hit + p, &hits, 8);
+		else for (int k = 0; p + k < a.end; ++k) a.hit[p + k] = (uint8_t)(hits >> (8 * k));
 	}
 }
 
-__global__ void motif_apply_kernel(MotifArgs a)
+// One WAVEFRONT per sequence (round 5; one thread per sequence read hit[] and soft[] with a stride of a sequence length between the
+// lanes, 64 cache lines per load): the lanes look through the sequence's hit bytes 64 at a time; a sequence without a motif start
+// -- nearly all of them -- is done there, the others are masked by lane 0 with the serial code the CPU emulation shares.
+__global__ __launch_bounds__(256) void motif_apply_kernel(MotifArgs a)
 {
-	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const int lane = threadIdx.x & 63;
 	if (i >= a.n_seqs) return;
 	const int64_t b = a.limits[i];
 	const int len = (int)(a.limits[i + 1] - b - 1);
+	bool any = false;
+	for (int x = lane; x < len; x += 64) any |= a.hit[b + x] != 0;
+	if (__ballot(any) == 0 || lane != 0) return;
 	const int covered = motif_mask_sequence(a.soft + b, a.hit + b, len, a.max_range);
 	if (covered) atomicAdd(a.n_covered, (unsigned long long)covered);
 }
@@ -534,7 +569,7 @@ hipError_t launch_motif_mask(const MotifArgs& a, hipStream_t st)
 	if (a.n_seqs <= 0 || a.n_table <= 0 || a.n_table > MOTIF_TABLE_MAX) return a.n_table > MOTIF_TABLE_MAX ? hipErrorInvalidValue : hipSuccess;
 	const int64_t chunks = (a.end - a.begin + MOTIF_CHUNK - 1) / MOTIF_CHUNK;
 	motif_hit_kernel<<<dim3((unsigned)chunks), dim3(256), 0, st>>>(a);
-	motif_apply_kernel<<<dim3((unsigned)((a.n_seqs + 127) / 128)), dim3(128), 0, st>>>(a);
+	motif_apply_kernel<<<dim3((unsigned)((a.n_seqs * 64 + 255) / 256)), dim3(256), 0, st>>>(a);
 	return hipGetLastError();
 }
 
