@@ -4,6 +4,8 @@
   --config C2 (default)  blastp --fast,      10k synthetic queries x 1M-sequence synthetic database (the headline config)
   --config C3            blastp --sensitive, same blocks (16 shapes, ungapped + gapped filters)
   --config C4            blastx, 5k synthetic DNA reads of ~1 kb (six frames each) x the same database, default sensitivity
+  --config C5            blastp --fast, 100k queries x 5M sequences in 8 database blocks (BASELINE config 5)
+  --config C2skew        blastp --fast, 10k queries x 1M sequences in 1000 families of 1000 (the seed stage's overflow / tiled paths)
 
 A "step" = one full pass of the hot path over the query block and the reference block, both resident in HBM before the timed
 region: seed stage on the GPU (dmnd_seed_search) and extension stage (dmnd_extend: Hauser bias on the GPU, host chaining in
@@ -53,6 +55,9 @@ CONFIGS = {
     # BASELINE config 5: 100k queries x 5M sequences cut into 8 database blocks; N GPUs take 8/N blocks each (one after the other
     # on a rank), the records of all blocks are joined as the reference joins reference blocks
     "C5": dict(mode="blastp", sens="fast", flags=["--fast"], what="blastp --fast, database in 8 blocks", blocks=8, queries=100_000, families=500_000),
+    # round 5: the same sizes as C2, but 1000 families of 1000 members -- a query's seeds join thousands of reference positions, the
+    # joined-position lists outgrow their first buffer, the pair filter runs in its sorted, LDS-tiled form (tests/test_gpu_skew.py)
+    "C2skew": dict(mode="blastp", sens="fast", flags=["--fast"], what="blastp --fast, 1000 families of 1000 members", families=1000, members=1000),
 }
 
 
@@ -73,7 +78,7 @@ class Workload:
 
     def __init__(self, cfg, families, queries, world, rank, shard):
         self.cfg = CONFIGS[cfg]
-        self.db, self.doff, self.q, self.qoff = synth.generate(families, members=10, queries=queries, seed=20260923)
+        self.db, self.doff, self.q, self.qoff = synth.generate(families, members=self.cfg.get("members", 10), queries=queries, seed=20260923)
         self.n_db, self.db_letters = len(self.doff) - 1, int(self.doff[-1])
         self.source_lens = None
         if self.cfg["mode"] == "blastx":

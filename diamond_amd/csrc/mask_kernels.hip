@@ -513,8 +513,8 @@ enum { MOTIF_TABLE_MAX = 8192, MOTIF_CHUNK = 1 << 15 };
 // its eight hit bytes with one store. (Before: one start per thread and iteration, eight byte loads and a full search each.)
 __global__ __launch_bounds__(256) void motif_hit_kernel(MotifArgs a)
 {
-	__shared__ uint64_t table[MOTIF_TABLE_MAX];
-	__shared__ uint32_t filter[2048];
+	extern __shared__ uint64_t table[];                      // n_table entries (1000 motifs = 8 KB; sized by the launch: at the table's maximum of
+	__shared__ uint32_t filter[2048];                        // 64 KB two workgroups fit a CU and the kernel waited for its loads: 1.6 ms per 3.0e8 letters)
 	for (int i = threadIdx.x; i < 2048; i += blockDim.x) filter[i] = 0;
 	for (int i = threadIdx.x; i < a.n_table; i += blockDim.x) table[i] = a.table[i];
 	__syncthreads();
@@ -568,7 +568,7 @@ hipError_t launch_motif_mask(const MotifArgs& a, hipStream_t st)
 {
 	if (a.n_seqs <= 0 || a.n_table <= 0 || a.n_table > MOTIF_TABLE_MAX) return a.n_table > MOTIF_TABLE_MAX ? hipErrorInvalidValue : hipSuccess;
 	const int64_t chunks = (a.end - a.begin + MOTIF_CHUNK - 1) / MOTIF_CHUNK;
-	motif_hit_kernel<<<dim3((unsigned)chunks), dim3(256), 0, st>>>(a);
+	motif_hit_kernel<<<dim3((unsigned)chunks), dim3(256), (size_t)a.n_table * sizeof(uint64_t), st>>>(a);
 	motif_apply_kernel<<<dim3((unsigned)((a.n_seqs * 64 + 255) / 256)), dim3(256), 0, st>>>(a);
 	return hipGetLastError();
 }

@@ -19,7 +19,7 @@
 
 using namespace dmnd;
 
-enum { SEED_CLASSES_LONG_DEFAULT = 0 };      // (off until measured: tools/gpu_r05b.sh)
+enum { SEED_CLASSES_LONG_DEFAULT = 1 };      // C5 (100 000 queries, 16 MB level-1 filter): stream 3.0 -> 2.06 ms per 1.9e8-letter block, seed stage 33.2 -> 25.4 ms per 8 blocks (tools/gpu_r05b.sh)
 
 static_assert(sizeof(dmnd_seed_params) == sizeof(SeedParams), "dmnd_seed_params must mirror dmnd::SeedParams");
 static_assert(sizeof(dmnd_seed_hit) == 24, "dmnd_seed_hit layout");
@@ -320,6 +320,9 @@ static SeedSizes seed_sizes(const dmnd_ctx* c, const SeedParams& sp, int64_t nq_
 		bm1_words = 3 * bm1_words / 2;
 		bm1_k3 = (uint64_t)nq_pos * 4 <= bm1_words * 32 ? 1u : 0u;      // a third bit pays from ~4.3 filter bits per seed up (optimum k = ln 2 x bits per seed)
 	}
+	// Short seeds by class (round 5 sweep on C3, tools/gpu_r05b.sh): 4 MB / three bits -- half a megabyte per XCD -- instead of 2 MB / two:
+	// stream + filter 103.9 -> 102.6 ms per 16 shapes (8 MB: 103.4; fewer false positives = fewer slot lines fetched over the fabric)
+	if (!long_seeds && bm1_log2 == 24 && !getenv("DMND_SEED_BITMAP1_LOG2") && bm_words >= 2 * bm1_words) { bm1_words *= 2; bm1_k3 = 1u; }
 	if (const char* e = getenv("DMND_SEED_BM1_KB")) bm1_words = (uint64_t)std::min(65536, std::max(4, atoi(e))) * 256;       // experiment knobs
 	if (const char* e = getenv("DMND_SEED_BM1_K")) bm1_k3 = atoi(e) == 3 ? 1u : 0u;
 	if (const char* e = getenv("DMND_SEED_STREAM_NT")) stream_nt = atoi(e) != 0;
@@ -440,7 +443,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	static const bool classes_env = [] { const char* e = getenv("DMND_SEED_CLASSES"); return !e || atoi(e) != 0; }();
 	// ... and (round 5) long seeds against a query block whose level-1 filter has outgrown an XCD's L2 (above 2^24 query positions the
 	// filter is 4-16 MB: C5's 100 000 queries): by class every XCD probes its own eighth of it. DMND_SEED_CLASSES_LONG=0/1 forces it.
-	static const int classes_long_env = [] { const char* e = getenv("DMND_SEED_CLASSES_LONG"); return e ? atoi(e) : -1; }();
+	const int classes_long_env = [] { const char* e = getenv("DMND_SEED_CLASSES_LONG"); return e ? atoi(e) : -1; }();      // (read per call: the tests switch it)
 	bool nibble_shapes = true;
 	for (int i = 0; i < S; ++i) nibble_shapes = nibble_shapes && seed_nibble_mode(sp, i);
 	const bool classes_long = !fused && nibble_shapes && (classes_long_env >= 0 ? classes_long_env != 0 : SEED_CLASSES_LONG_DEFAULT && bm1_words * 32 > ((uint64_t)1 << 24));
@@ -702,6 +705,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		m_off[S] = off;
 		if (!overflow) break;
 		if (attempt >= 2) return fail(DMND_E_NOMEM, "dmnd_seed_search: joined-position buffer overflow");
+		if (lap_on) std::fprintf(stderr, "dmnd_seed_search: joined-position buffer overflow, %lld positions against a capacity of %lld: phase 1 runs again\n", (long long)off, (long long)cap_total);
 		cap_total = off + off / 8 + 1024;
 	}
 	// Search::mask_seeds (per joined group) only exists for spaced seeds; the query-indexed mode masked at enumeration
@@ -749,6 +753,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 			// many joined positions (short seeds): sort them by seed and run the LDS-tiled filter; otherwise one thread per position
 			bool tiled = (int64_t)counts[sid] >= ((int64_t)1 << 22);
 			if (const char* e = getenv("DMND_SEED_TILED")) tiled = atoi(e) != 0;
+			if (lap_on && tiled) std::fprintf(stderr, "dmnd_seed_search: shape %d, %llu joined positions: sorted by seed, tiled pair filter\n", sid, counts[sid]);
 			if (tiled) {
 				if (int rc = c->seed_slot2.ensure((size_t)counts[sid] * sizeof(uint32_t))) return rc;
 				if (int rc = c->seed_loc2.ensure((size_t)counts[sid] * sizeof(int64_t))) return rc;

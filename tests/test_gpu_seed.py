@@ -112,6 +112,26 @@ def test_tiled_pair_filter_equals_reference(ctx, tap, monkeypatch):
     assert np.array_equal(hits, plain)
 
 
+@pytest.mark.parametrize("tap,enc", [("ext_fast_synth.tap", 0), ("ext_default.tap", 0), ("ext_6x10.tap", 0), ("ext_blastx.tap", 0), ("ext_rank.tap", 0), ("ext_bjz.tap", 0),
+                                     ("ext_hashed.tap", 1), ("ext_hashed_default.tap", 1)])
+def test_by_class_stream_for_long_seeds_equals_reference(ctx, tap, enc, monkeypatch):
+    """Round 5: the reference stream by key class -- eight workgroups per tile group, each probing its XCD's eighth of the level-1
+    filter and of the table -- for LONG seeds (the path a query block above 2^24 positions takes by itself: C5), forced on the goldens:
+    the hit multiset is the reference's, and the hits equal the plain stream's."""
+    cfg, recs = read_ext_tap(os.path.join(GOLDEN, tap))
+    ctx.upload_block(hip.QUERY, cfg["query"]["data"], cfg["query"]["limits"])
+    ctx.upload_block(hip.TARGET, cfg["target"]["data"], cfg["target"]["limits"])
+    params = to_hip_params(dict(cfg, seed_encoding=1) if enc else cfg)
+    monkeypatch.setenv("DMND_SEED_CLASSES_LONG", "0")
+    plain = ctx.seed_search(params)
+    monkeypatch.setenv("DMND_SEED_CLASSES_LONG", "1")
+    hits = ctx.seed_search(params)
+    monkeypatch.delenv("DMND_SEED_CLASSES_LONG")
+    ref = np.concatenate([r["hits"] for r in recs])
+    assert len(hits) == len(ref) and hit_multiset(hits) == hit_multiset(ref)
+    assert np.array_equal(hits, plain)
+
+
 @pytest.mark.parametrize("chunks,bits", [(1, 8), (3, 9), (7, 10)])
 def test_seed_hits_equal_oracle_other_partitionings(ctx, chunks, bits):
     cfg, _ = read_ext_tap(os.path.join(GOLDEN, "ext_fast_synth.tap"), max_records=1)
