@@ -263,6 +263,7 @@ def main():
     ap.add_argument("--same-block", action="store_true", help="search the SAME database block in every step. Default (N=1, one block per rank): two database blocks at different "
                     "places of HBM alternate between steps -- the block of the config and the same sequences in reverse order -- so that no step finds its 301 MB of "
                     "letters in the 256 MiB Infinity Cache from the step before")
+    ap.add_argument("--host-join", action="store_true", help="join the records of several database blocks / ranks on the host (dmnd_join_blocks) instead of on the device")
     ap.add_argument("--no-pipeline", action="store_true", help="run seed stage and extension stage of a batch back to back on one context")
     args = ap.parse_args()
 
@@ -355,6 +356,7 @@ def main():
     ext_ctxs = [ctxs] + [[make_ctx(b) for b in range(NB)] for _ in range(E - 1)]
     ext_threads = max(1, threads // E)
     ctx, ctx_seed = ctxs[0], ctxs_seed[0]
+    join_ctx = hip.Context(device=local_rank, params=params) if (world > 1 or NB > 1) else None      # stream + scratch of the device-side block join
     state = {"stream_ms": 0.0, "stream_launches": 0}
     # Two database blocks alternate between the steps (round 5): block B holds the sequences of block A in reverse order, at its own
     # place in HBM -- the same work per step (same hits, cells and records up to the target numbers), but a step never streams the
@@ -415,8 +417,15 @@ def main():
             for b, m in enumerate(parts):
                 mine["target"][at:at + len(m)] += np.uint32(w.blocks[b][0])
                 at += len(m)
-            # all-to-all keyed by query range, rank g joins queries [g Q/G, (g+1) Q/G), one gather to rank 0
-            part, full = multigpu.query_range_join(mine, w.n_queries, coll_device, own=True)
+            # all-to-all keyed by query range, rank g joins queries [g Q/G, (g+1) Q/G), one gather to rank 0.
+            # Round 5: over RCCL the records stay in HBM from the first all-to-all to the gather and are merged there
+            # (dmnd_join_blocks_device); one GPU with several blocks joins them on the device too. (gloo / --host-join: the host join.)
+            if world > 1 and coll_device.type == "cuda" and not args.host_join:
+                part, full = multigpu.query_range_join_device(mine, w.n_queries, coll_device, join_ctx)
+            elif world == 1 and not args.host_join:
+                part = full = join_ctx.join_blocks_device(mine, multigpu.TOPK)
+            else:
+                part, full = multigpu.query_range_join(mine, w.n_queries, coll_device, own=True)
             q = part["query"]
             state["joined_queries"] = int((q[1:] != q[:-1]).sum() + 1) if q.size else 0      # (the join returns query order)
             return full if rank == 0 else part
@@ -783,7 +792,7 @@ def main():
             tids = ["t%d" % i for i in range(w.n_db)]
             text = hip.format_tab(state["records"], qids, tids, w.source_lens)
             masked_text = hip.format_tab(masked_records, qids, tids, w.source_lens) if masked_records is not None else None
-            for c in (ctxs_seed if ctxs_seed is not ctxs else []) + [x for cs in ext_ctxs for x in cs] + (alt_ext_ctxs + [seed_ctx_alt] if alternate else []):
+            for c in (ctxs_seed if ctxs_seed is not ctxs else []) + [x for cs in ext_ctxs for x in cs] + (alt_ext_ctxs + [seed_ctx_alt] if alternate else []) + ([join_ctx] if join_ctx else []):
                 c.close()
             closed = True
             torch.cuda.empty_cache()
@@ -802,7 +811,7 @@ def main():
                     out["masked_step"]["parity"] = {"records_md5": got, "reference_output_md5": want, "matches": got == want}
         print(json.dumps(out))
     if not closed:
-        for c in (ctxs_seed if ctxs_seed is not ctxs else []) + [x for cs in ext_ctxs for x in cs] + (alt_ext_ctxs + [seed_ctx_alt] if alternate else []):
+        for c in (ctxs_seed if ctxs_seed is not ctxs else []) + [x for cs in ext_ctxs for x in cs] + (alt_ext_ctxs + [seed_ctx_alt] if alternate else []) + ([join_ctx] if join_ctx else []):
             c.close()
     if world > 1:
         dist.destroy_process_group()

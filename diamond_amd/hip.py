@@ -77,7 +77,7 @@ EXPORTS = ["dmnd_abi_version", "dmnd_last_error", "dmnd_default_params", "dmnd_c
            "dmnd_seed_params_set_query_indexed", "dmnd_auto_query_indexed", "dmnd_set_motif_table", "dmnd_motif_table_size",
            "dmnd_soft_mask_block", "dmnd_output_fields", "dmnd_format_fields", "dmnd_format_pairwise_intro", "dmnd_format_pairwise",
            "dmnd_format_paf", "dmnd_device_count", "dmnd_set_top_percent", "dmnd_join_blocks_top", "dmnd_set_filters", "dmnd_format_sam", "dmnd_set_query_source_lengths", "dmnd_format_fields_unaligned", "dmnd_format_fields_header", "dmnd_set_query_index_reuse", "dmnd_set_no_self_hits", "dmnd_matrix_params", "dmnd_masking_lambda", "dmnd_translate_opts", "dmnd_set_extension_mode", "dmnd_format_xml_header", "dmnd_format_xml_query_intro", "dmnd_format_xml", "dmnd_format_xml_query_epilog", "dmnd_format_daa_header", "dmnd_format_daa_query", "dmnd_format_daa_match", "dmnd_seg_ranges", "dmnd_seg_mask_block", "dmnd_seg_lnfact", "dmnd_daa_match_read", "dmnd_hsp_from_transcript", "dmnd_hsp_from_transcript_frames", "dmnd_set_format_flags", "dmnd_host_alloc", "dmnd_host_free", "dmnd_share_block", "dmnd_copy_block", "dmnd_init", "dmnd_seed_reserve", "dmnd_mask_sequences", "dmnd_set_max_hsps", "dmnd_rank_targets", "dmnd_rank_update", "dmnd_set_global_ranking",
-           "dmnd_upload_matrices", "dmnd_frameshift_swipe", "dmnd_set_frameshift", "dmnd_set_context_motif_table", "dmnd_cbs_composition", "dmnd_cbs_rule", "dmnd_cbs_target_matrix", "dmnd_cbs_ideal_lambda", "dmnd_join_blocks_range"]
+           "dmnd_upload_matrices", "dmnd_frameshift_swipe", "dmnd_set_frameshift", "dmnd_set_context_motif_table", "dmnd_cbs_composition", "dmnd_cbs_rule", "dmnd_cbs_target_matrix", "dmnd_cbs_ideal_lambda", "dmnd_join_blocks_range", "dmnd_join_blocks_device", "dmnd_join_blocks_device_host"]
 
 
 def set_motif_table(codes):
@@ -637,6 +637,25 @@ class Context:
         self._check(self.lib.dmnd_upload_block(self.h, which, data.ctypes.data, data.size,
                                                lim.ctypes.data if lim is not None else None,
                                                (lim.size - 1) if lim is not None else 0))
+
+    def join_blocks_device(self, records, max_target_seqs=25, top_percent=-1.0):
+        """The block join on the device for records in host memory (dmnd_join_blocks_device_host: upload, three radix sorts of a
+        permutation, top-k per query, download of the survivors). `records`: concatenated per-block MATCH_DTYPE arrays with
+        database-wide target ordinals, one record per (query, target). Returns the joined records (a new array)."""
+        r = np.ascontiguousarray(records, dtype=MATCH_DTYPE).copy()
+        n = ctypes.c_int64(0)
+        self.lib.dmnd_join_blocks_device_host.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_int64)]
+        self._check(self.lib.dmnd_join_blocks_device_host(self.h, r.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(r.size), int(max_target_seqs), float(top_percent), ctypes.byref(n)))
+        return r[:n.value]
+
+    def join_blocks_device_ptr(self, records_ptr, n, out_ptr, max_target_seqs=25, top_percent=-1.0, max_query=0):
+        """dmnd_join_blocks_device on device pointers (e.g. torch tensors' data_ptr() on this context's device): n records at
+        records_ptr are joined into out_ptr (room for n records); returns the number of survivors."""
+        n_out = ctypes.c_int64(0)
+        self.lib.dmnd_join_blocks_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.c_uint32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)]
+        self._check(self.lib.dmnd_join_blocks_device(self.h, ctypes.c_void_p(int(records_ptr)), ctypes.c_int64(int(n)), int(max_target_seqs), float(top_percent), ctypes.c_uint32(int(max_query)),
+                                                     ctypes.c_void_p(int(out_ptr)), ctypes.byref(n_out)))
+        return n_out.value
 
     def share_block(self, which, src):
         """Alias block `which` of the context `src` (no copy; `src` must stay alive): dmnd_share_block."""

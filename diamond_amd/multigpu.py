@@ -36,6 +36,47 @@ def _a2a_bytes(parts, device):
     return [recv[cuts[r]:cuts[r + 1]] for r in range(world)]
 
 
+def _a2a_device(send, in_counts, device):
+    """all_to_all of device-resident bytes: `send` (uint8 tensor on `device`) holds the parts for ranks 0..G-1 back to back,
+    in_counts[g] bytes each. Returns (recv tensor on the device, per-source byte counts). The counts travel first (one small
+    collective whose result the host needs for the split sizes), then the payload, device to device over xGMI."""
+    world = dist.get_world_size()
+    n_in = torch.tensor([int(x) for x in in_counts], dtype=torch.int64, device=device)
+    n_out = torch.zeros(world, dtype=torch.int64, device=device)
+    dist.all_to_all_single(n_out, n_in)
+    n_out = [int(x) for x in n_out.cpu().tolist()]
+    recv = torch.empty(sum(n_out), dtype=torch.uint8, device=device)
+    dist.all_to_all_single(recv, send, output_split_sizes=n_out, input_split_sizes=[int(x) for x in in_counts])
+    return recv, n_out
+
+
+def query_range_join_device(matches, n_queries, device, ctx, k=TOPK, root=0):
+    """query_range_join with the records DEVICE-RESIDENT from the first all-to-all to the gather (round 5): one upload of this rank's
+    records (ordered by destination on the host, where dmnd_extend leaves them), all_to_all_single on device tensors (RCCL: grouped
+    sends over xGMI), the merge of this rank's query range ON THE DEVICE (dmnd_join_blocks_device: radix sorts of a permutation
+    + top-k per query), the survivors sent on to `root` from where they lie, ONE download there. `ctx`: a hip.Context on `device`
+    (its stream and scratch run the join). One record per (query, target): --max-hsps 1, no range culling (else: query_range_join)."""
+    from . import hip
+    rec = np.ascontiguousarray(matches, dtype=hip.MATCH_DTYPE)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    item = hip.MATCH_DTYPE.itemsize
+    hi = np.array([shard_range(n_queries, world, g)[1] for g in range(world)], dtype=np.int64)
+    dest = np.searchsorted(hi, rec["query"].astype(np.int64), side="right")
+    assert dest.size == 0 or dest.max() < world, "a record's query lies outside [0, n_queries)"
+    order = np.argsort(dest, kind="stable")
+    cuts = np.searchsorted(dest[order], np.arange(world + 1))
+    send = torch.from_numpy(rec[order].view(np.uint8).reshape(-1)).to(device)                 # the one upload
+    recv, n_from = _a2a_device(send, [(cuts[g + 1] - cuts[g]) * item for g in range(world)], device)
+    n = recv.numel() // item
+    out = torch.empty(max(n, 1) * item, dtype=torch.uint8, device=device)
+    torch.cuda.current_stream(device).synchronize()                                            # the join runs on the context's own stream
+    n_kept = ctx.join_blocks_device_ptr(recv.data_ptr(), n, out.data_ptr(), max_target_seqs=k, max_query=max(n_queries - 1, 1)) if n else 0
+    mine_dev = out[:n_kept * item]
+    full_dev, _ = _a2a_device(mine_dev, [mine_dev.numel() if g == root else 0 for g in range(world)], device)      # every rank's survivors go to root
+    mine = mine_dev.cpu().numpy().view(hip.MATCH_DTYPE)
+    return mine, (full_dev.cpu().numpy().view(hip.MATCH_DTYPE) if rank == root else None)
+
+
 def query_range_join(matches, n_queries, device, k=TOPK, root=0, own=False, force_exchange=False):
     """SURVEY.md 8(e).2's exchange for database shards. `matches`: this rank's records (all queries against its own shard(s),
     database-wide target ordinals). Step 1: all-to-all keyed by query range -- the records of queries [g Q/G, (g+1) Q/G)

@@ -534,6 +534,17 @@ int dmnd_join_blocks(dmnd_match* records, int64_t n, int max_target_seqs, int64_
  * read (dmnd_match::read_begin / read_end) are covered already -- by max_target_seqs kept alignments, or with --top by one kept
  * alignment scoring at least score / (1 - top / 100) -- and every kept target adds its intervals. top_percent < 0: no --top. */
 int dmnd_join_blocks_range(dmnd_match* records, int64_t n, int max_target_seqs, double top_percent, double range_cover, int64_t* n_out);
+/* The block join ON THE DEVICE (round 5; SURVEY.md 8(e): the final top-k merge), for records that are in HBM already -- received
+ * from the other ranks over RCCL, or produced block after block on this GPU: the union of the per-block lists sorted into
+ * join_query's order (three stable radix sorts of a permutation: (score descending, target), e-value, query =
+ * JoinRecord::cmp_evalue, src/output/join_blocks.cpp:129-142; top_percent >= 0: cmp_score and GlobalCulling's top-per-cent rule,
+ * src/output/target_culling.h:56-64), the first max_target_seqs of every query kept and written to out_dev (HBM, >= n records, no
+ * overlap with records_dev); *n_out = their number. Every (query, target) pair must have ONE record (--max-hsps 1, the default;
+ * the host forms above carry HSP groups and range culling). max_query: largest query id among the records, 0 = unknown.
+ * dmnd_join_blocks_device_host: the same for records in host memory (upload, join, download of the survivors), in place. */
+int dmnd_join_blocks_device(dmnd_ctx* ctx, const dmnd_match* records_dev, int64_t n, int max_target_seqs, double top_percent, uint32_t max_query,
+	dmnd_match* out_dev, int64_t* n_out);
+int dmnd_join_blocks_device_host(dmnd_ctx* ctx, dmnd_match* records, int64_t n, int max_target_seqs, double top_percent, int64_t* n_out);
 /* Touches every HIP stream the context owns (its own and those of the extension stage's runners) with an empty marker and
  * waits for them. A driver that calls hipDeviceSynchronize between batches (bench.py must, by its timing contract) lets the
  * runtime release idle hardware queues; re-acquiring them costs the next dmnd_extend several milliseconds (measured: +6.5 ms
