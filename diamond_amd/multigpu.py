@@ -77,7 +77,7 @@ def query_range_join_device(matches, n_queries, device, ctx, k=TOPK, root=0):
     return mine, (full_dev.cpu().numpy().view(hip.MATCH_DTYPE) if rank == root else None)
 
 
-def query_range_join(matches, n_queries, device, k=TOPK, root=0, own=False, force_exchange=False):
+def query_range_join(matches, n_queries, device, k=TOPK, root=0, own=False, force_exchange=False, ctx=None):
     """SURVEY.md 8(e).2's exchange for database shards. `matches`: this rank's records (all queries against its own shard(s),
     database-wide target ordinals). Step 1: all-to-all keyed by query range -- the records of queries [g Q/G, (g+1) Q/G)
     (`shard_range`) go to rank g, <= k x 96 B per query and shard. Step 2: rank g merges its 1/G of the queries with
@@ -85,7 +85,8 @@ def query_range_join(matches, n_queries, device, k=TOPK, root=0, own=False, forc
     output/join_blocks.cpp:129-137,180-256). Step 3: the joined records travel once more, to `root`, whose concatenation in
     rank order is in query order. Returns (records of this rank's query range, all records on root | None elsewhere).
     own=True: `matches` is a contiguous record array the caller hands over (it may be reordered in place: no defensive copy).
-    force_exchange=True: the collectives run even in a group of one rank (the RCCL path of a 1-GPU box, tests)."""
+    force_exchange=True: the collectives run even in a group of one rank (the RCCL path of a 1-GPU box, tests).
+    See query_range_join_device for the form that keeps the records in HBM between the collectives."""
     from . import hip
     rec = np.ascontiguousarray(matches, dtype=hip.MATCH_DTYPE)
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force_exchange):
@@ -100,7 +101,10 @@ def query_range_join(matches, n_queries, device, k=TOPK, root=0, own=False, forc
     cuts = np.searchsorted(dest[order], np.arange(world + 1))
     raw = rec[order].view(np.uint8).reshape(-1)
     got = _a2a_bytes([raw[cuts[g] * item:cuts[g + 1] * item] for g in range(world)], device)
-    mine = hip.join_blocks(np.concatenate(got).view(hip.MATCH_DTYPE), k, copy=False)
+    # ctx (a hip.Context): the merge runs on its device (dmnd_join_blocks_device_host) although the exchange went through host
+    # memory -- two ranks that share one GPU over gloo (tests/test_gpu_db_shard.py)
+    union = np.concatenate(got).view(hip.MATCH_DTYPE)
+    mine = ctx.join_blocks_device(union, k) if ctx is not None else hip.join_blocks(union, k, copy=False)
     empty = np.zeros(0, np.uint8)
     out = _a2a_bytes([mine.view(np.uint8).reshape(-1) if g == root else empty for g in range(world)], device)
     return mine, (np.concatenate(out).view(hip.MATCH_DTYPE) if rank == root else None)

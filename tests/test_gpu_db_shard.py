@@ -50,7 +50,8 @@ def _rank(rank, world, port, ret):
         m = _search(ctx, hip, qd, ql, td, tl, hip.seed_params_fast(threads=4))
         m = m.copy()
         m["target"] += np.uint32(base)
-        _, joined = multigpu.query_range_join(m, len(ql) - 1, torch.device("cpu"), k=25)
+        # rank 1 merges its query range on the device (dmnd_join_blocks_device), rank 0 on the host: the same records either way
+        _, joined = multigpu.query_range_join(m, len(ql) - 1, torch.device("cpu"), k=25, ctx=ctx if rank == 1 else None)
     finally:
         ctx.close()
     ret[rank] = None if joined is None else joined.tobytes()

@@ -108,16 +108,37 @@ def test_device_join_on_real_block_records(ctx, block_records):
     assert n == len(want) and out[:n * hip.MATCH_DTYPE.itemsize].cpu().numpy().tobytes() == want.tobytes()
 
 
-def test_query_range_join_device_over_rccl_world_size_1(ctx, block_records):
-    import torch.distributed as dist
-    rec, nq = block_records
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29561")
-    dev = torch.device("cuda", 0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-    try:
-        mine, full = multigpu.query_range_join_device(rec, nq, dev, ctx, k=25)
-    finally:
-        dist.destroy_process_group()
-    want = hip.join_blocks(rec, 25)
-    assert mine.tobytes() == want.tobytes() and full.tobytes() == want.tobytes()
+def test_query_range_join_device_over_rccl_world_size_1():
+    """multigpu.query_range_join_device with the one rank a 1-GPU box has: backend "nccl" (= RCCL), the records uploaded once,
+    all_to_all_single on device tensors, the merge on the device, the gather from device memory. In a child process so that the
+    process group does not outlive the test."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from diamond_amd import hip, multigpu
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29561", RANK="0", WORLD_SIZE="1")
+rng = np.random.default_rng(5)
+rec = np.zeros(60000, hip.MATCH_DTYPE)
+rec["query"] = np.sort(rng.integers(0, 900, len(rec)))
+rec["target"] = rng.permutation(1 << 20)[:len(rec)]
+rec["evalue"] = np.choose(rng.integers(0, 3, len(rec)), [0.0, 1e-12, 0.5])
+rec["hsp"]["score"] = rng.integers(30, 40, len(rec))
+rec["bit_score"] = rec["hsp"]["score"] * 0.38
+want = hip.join_blocks(rec.copy(), 25)
+device = torch.device("cuda:0")
+torch.cuda.set_device(device)
+ctx = hip.Context(params=hip.default_params())
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+mine, full = multigpu.query_range_join_device(rec, 900, device, ctx, k=25)
+dist.barrier()
+dist.destroy_process_group()
+ctx.close()
+assert len(want) > 10000 and mine.tobytes() == want.tobytes() and full.tobytes() == want.tobytes(), (len(mine), len(want))
+print("RCCL_DEVICE_JOIN_OK", len(want))
+''' % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_DEVICE_JOIN_OK" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
