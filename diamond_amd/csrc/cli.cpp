@@ -1066,6 +1066,7 @@ int run_blastp(const Options& o)
 		// --global-ranking: per query the N best targets of the whole database by ungapped score (align/global_ranking/table.cpp)
 		std::vector<dmnd_ranked_target> rank_table(o.global_ranking > 0 ? (qr.end - qr.begin) * (size_t)o.global_ranking : 0, dmnd_ranked_target{ 0, 0, 0, 0, 0 });
 		std::vector<dmnd_match> joined;                       // the query block's records against all reference blocks
+		std::vector<uint8_t> joined_gpu;                      // ... and the GPU that produced each of them (the RCCL merge sends from there)
 		std::vector<uint8_t> arena;                           // ... and their transcripts, if the output format reads them
 		std::vector<char> seeded(qr.end - qr.begin, 0);       // queries with at least one seed hit (what the unaligned report depends on)
 		on_each_gpu([&](int g) {
@@ -1221,6 +1222,7 @@ int run_blastp(const Options& o)
 				if (need_transcripts) m.hsp.transcript_off += (int64_t)arena.size();
 			}
 			joined.insert(joined.end(), mine.begin(), mine.end());
+			joined_gpu.insert(joined_gpu.end(), mine.size(), (uint8_t)g);
 			arena.insert(arena.end(), my_arena.begin(), my_arena.end());
 			ms_upload += up; ms_mask += mk; ms_seed += sd; ms_ext += ex;
 			total_hits += n_hits;
@@ -1289,6 +1291,29 @@ int run_blastp(const Options& o)
 		}
 		g_timeline.mark("block pairs of the query block done");
 		int64_t n_matches = (int64_t)joined.size();
+		// Several GPUs: the final merge runs over RCCL and on the devices (dmnd_join_ranks: the records of every GPU go to the owner of
+		// their query range in one grouped ncclSend / ncclRecv exchange and are merged there); one record per (query, target) only.
+		// DMND_CLI_RCCL=1 takes that path with one GPU too (RCCL with itself), =0 keeps the host join.
+		static const int rccl_env = [] { const char* e = std::getenv("DMND_CLI_RCCL"); return e ? std::atoi(e) : -1; }();
+		const bool rank_join = t_blocks.size() > 1 && o.global_ranking == 0 && o.max_hsps == 1 && !o.range_culling && !joined.empty()
+			&& (rccl_env >= 0 ? rccl_env != 0 : n_gpus > 1);
+		if (rank_join) {
+			std::vector<std::vector<dmnd_match>> per_gpu((size_t)n_gpus);
+			for (size_t k = 0; k < joined.size(); ++k) {
+				dmnd_match m = joined[k];
+				m.query -= (uint32_t)qr.begin;                      // owners by the query block's own range
+				per_gpu[joined_gpu[k]].push_back(m);
+			}
+			std::vector<const dmnd_match*> ptrs((size_t)n_gpus);
+			std::vector<int64_t> counts((size_t)n_gpus);
+			for (int g = 0; g < n_gpus; ++g) { ptrs[(size_t)g] = per_gpu[(size_t)g].data(); counts[(size_t)g] = (int64_t)per_gpu[(size_t)g].size(); }
+			int transport = 0;
+			chk(dmnd_join_ranks(ctxs.data(), n_gpus, ptrs.data(), counts.data(), (int64_t)(qr.end - qr.begin), o.k, o.top, joined.data(), (int64_t)joined.size(), &n_matches, &transport));
+			for (int64_t k = 0; k < n_matches; ++k) joined[(size_t)k].query += (uint32_t)qr.begin;
+			if (&qr == &q_blocks.front()) std::cerr << "Block join: " << (transport == 1 ? "RCCL exchange (ncclSend/ncclRecv) between " : "device-to-device copies between ") << n_gpus
+				<< " context(s), merged on the device(s)\n";
+		}
+		else
 		// the join's culler is the one TargetCulling::get picks (output/target_culling.cpp:22-28): RangeCulling with --range-culling
 		if (t_blocks.size() > 1 && o.global_ranking == 0) chk(o.range_culling ? dmnd_join_blocks_range(joined.data(), (int64_t)joined.size(), o.k, o.top, o.range_cover, &n_matches)
 			: o.top >= 0.0 ? dmnd_join_blocks_top(joined.data(), (int64_t)joined.size(), o.top, &n_matches)

@@ -77,7 +77,7 @@ EXPORTS = ["dmnd_abi_version", "dmnd_last_error", "dmnd_default_params", "dmnd_c
            "dmnd_seed_params_set_query_indexed", "dmnd_auto_query_indexed", "dmnd_set_motif_table", "dmnd_motif_table_size",
            "dmnd_soft_mask_block", "dmnd_output_fields", "dmnd_format_fields", "dmnd_format_pairwise_intro", "dmnd_format_pairwise",
            "dmnd_format_paf", "dmnd_device_count", "dmnd_set_top_percent", "dmnd_join_blocks_top", "dmnd_set_filters", "dmnd_format_sam", "dmnd_set_query_source_lengths", "dmnd_format_fields_unaligned", "dmnd_format_fields_header", "dmnd_set_query_index_reuse", "dmnd_set_no_self_hits", "dmnd_matrix_params", "dmnd_masking_lambda", "dmnd_translate_opts", "dmnd_set_extension_mode", "dmnd_format_xml_header", "dmnd_format_xml_query_intro", "dmnd_format_xml", "dmnd_format_xml_query_epilog", "dmnd_format_daa_header", "dmnd_format_daa_query", "dmnd_format_daa_match", "dmnd_seg_ranges", "dmnd_seg_mask_block", "dmnd_seg_lnfact", "dmnd_daa_match_read", "dmnd_hsp_from_transcript", "dmnd_hsp_from_transcript_frames", "dmnd_set_format_flags", "dmnd_host_alloc", "dmnd_host_free", "dmnd_share_block", "dmnd_copy_block", "dmnd_init", "dmnd_seed_reserve", "dmnd_mask_sequences", "dmnd_set_max_hsps", "dmnd_rank_targets", "dmnd_rank_update", "dmnd_set_global_ranking",
-           "dmnd_upload_matrices", "dmnd_frameshift_swipe", "dmnd_set_frameshift", "dmnd_set_context_motif_table", "dmnd_cbs_composition", "dmnd_cbs_rule", "dmnd_cbs_target_matrix", "dmnd_cbs_ideal_lambda", "dmnd_join_blocks_range", "dmnd_join_blocks_device", "dmnd_join_blocks_device_host"]
+           "dmnd_upload_matrices", "dmnd_frameshift_swipe", "dmnd_set_frameshift", "dmnd_set_context_motif_table", "dmnd_cbs_composition", "dmnd_cbs_rule", "dmnd_cbs_target_matrix", "dmnd_cbs_ideal_lambda", "dmnd_join_blocks_range", "dmnd_join_blocks_device", "dmnd_join_blocks_device_host", "dmnd_join_ranks"]
 
 
 def set_motif_table(codes):
@@ -442,6 +442,25 @@ def join_blocks_top(records, top_percent):
     if lib.dmnd_join_blocks_top(r.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(r.size), float(top_percent), ctypes.byref(n)) != 0:
         raise DiamondHipError(lib.dmnd_last_error().decode())
     return r[:n.value]
+
+
+def join_ranks(contexts, records, n_queries, max_target_seqs=25, top_percent=-1.0):
+    """dmnd_join_ranks: the RCCL merge of the records of several GPUs driven by one process. contexts: one hip.Context per GPU
+    (or several on one device: copies instead of RCCL); records: one MATCH_DTYPE array per context. Returns (joined, transport)."""
+    lib = load()
+    recs = [np.ascontiguousarray(r, dtype=MATCH_DTYPE) for r in records]
+    n = len(contexts)
+    out = np.empty(max(1, sum(len(r) for r in recs)), dtype=MATCH_DTYPE)
+    n_out, transport = ctypes.c_int64(0), ctypes.c_int(0)
+    lib.dmnd_join_ranks.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double,
+                                    ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int)]
+    hs = (ctypes.c_void_p * n)(*[c.h for c in contexts])
+    ps = (ctypes.c_void_p * n)(*[r.ctypes.data for r in recs])
+    cs = (ctypes.c_int64 * n)(*[len(r) for r in recs])
+    if lib.dmnd_join_ranks(hs, n, ps, cs, ctypes.c_int64(int(n_queries)), int(max_target_seqs), float(top_percent), out.ctypes.data_as(ctypes.c_void_p),
+                           ctypes.c_int64(out.size), ctypes.byref(n_out), ctypes.byref(transport)) != 0:
+        raise DiamondHipError(lib.dmnd_last_error().decode())
+    return out[:n_out.value], transport.value
 
 
 def join_blocks_range(records, max_target_seqs=25, top_percent=-1.0, range_cover=50.0):

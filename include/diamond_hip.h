@@ -545,6 +545,17 @@ int dmnd_join_blocks_range(dmnd_match* records, int64_t n, int max_target_seqs, 
 int dmnd_join_blocks_device(dmnd_ctx* ctx, const dmnd_match* records_dev, int64_t n, int max_target_seqs, double top_percent, uint32_t max_query,
 	dmnd_match* out_dev, int64_t* n_out);
 int dmnd_join_blocks_device_host(dmnd_ctx* ctx, dmnd_match* records, int64_t n, int max_target_seqs, double top_percent, int64_t* n_out);
+/* The final merge of a search that ran on several GPUs of one node, over RCCL (what `diamond-hip --gpus N` calls
+ * per query block): n_ctx contexts, one per GPU, each with the records its GPU produced (host memory, database-wide target ordinals,
+ * every (query, target) once). GPU j becomes the owner of the query range [j Q/N, (j + 1) Q/N), Q = n_queries: the records are
+ * ordered by owner and uploaded, ONE grouped RCCL exchange (ncclGroupStart; ncclSend / ncclRecv per (source, owner); ncclGroupEnd)
+ * moves them to their owners device to device, every owner merges its range with dmnd_join_blocks_device, the survivors are
+ * written to `out` owner after owner = in query order: the records dmnd_join_blocks (top_percent < 0) / dmnd_join_blocks_top give for
+ * the concatenated input. RCCL is loaded at run time (librccl.so). Contexts that all share one device exchange with device-to-device
+ * copies instead (RCCL refuses two ranks on a device; the test hook of a 1-GPU box); one context alone goes through RCCL with itself.
+ * *transport_used (may be NULL): 1 = RCCL, 2 = copies. */
+int dmnd_join_ranks(dmnd_ctx* const* ctx, int n_ctx, const dmnd_match* const* records, const int64_t* counts, int64_t n_queries, int max_target_seqs,
+	double top_percent, dmnd_match* out, int64_t cap, int64_t* n_out, int* transport_used);
 /* Touches every HIP stream the context owns (its own and those of the extension stage's runners) with an empty marker and
  * waits for them. A driver that calls hipDeviceSynchronize between batches (bench.py must, by its timing contract) lets the
  * runtime release idle hardware queues; re-acquiring them costs the next dmnd_extend several milliseconds (measured: +6.5 ms

@@ -354,6 +354,24 @@ def test_cli_gpus_distributes_reference_blocks(tmp_path):
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     assert open(out).read() == open(os.path.join(g, "diamond-test-blastp-blocked.out")).read()
+    # round 5: with several contexts the records are merged by dmnd_join_ranks -- owners by query range, exchange, merge on the device.
+    # Two contexts on the box's one GPU exchange with device copies (RCCL refuses two ranks on a device) ...
+    assert "Block join: device-to-device copies between 2 context(s), merged on the device(s)" in r.stderr, r.stderr[-1500:]
+    # ... and ONE context goes through RCCL itself (ncclCommInitAll, a grouped ncclSend / ncclRecv to itself): same golden; so does --top
+    for extra, golden in (([], "diamond-test-blastp-blocked.out"), ):
+        r1 = subprocess.run([CLI, "blastp", "-q", os.path.join(g, "data.faa"), "-d", os.path.join(g, "data.faa"), "-c1", "-b0.00002", "-p4", "-o", out] + extra,
+                            capture_output=True, text=True, timeout=600, env=dict(os.environ, DMND_CLI_RCCL="1"))
+        assert r1.returncode == 0, r1.stderr[-2000:]
+        assert "Block join: RCCL exchange (ncclSend/ncclRecv) between 1 context(s)" in r1.stderr, r1.stderr[-1500:]
+        assert open(out).read() == open(os.path.join(g, golden)).read()
+    for top_flags in (["--top", "10"], ["-k", "3"]):
+        outs = []
+        for e in (dict(DMND_CLI_RCCL="1"), dict(DMND_CLI_RCCL="0"), dict(DMND_CLI_SHARE_GPU="1", GPUS="2")):
+            cmd = [CLI, "blastp", "-q", os.path.join(g, "data.faa"), "-d", os.path.join(g, "data.faa"), "-c1", "-b0.00002", "-p4", "-o", out] + top_flags + (["--gpus", e.pop("GPUS")] if "GPUS" in e else [])
+            rr = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, **e))
+            assert rr.returncode == 0, rr.stderr[-2000:]
+            outs.append(open(out).read())
+        assert outs[0] == outs[1] == outs[2] and len(outs[0]) > 1000, top_flags
     for fmt in ([], ["-f", "6", "qseqid", "sseqid", "evalue", "cigar", "btop"]):
         r = subprocess.run([CLI, "blastp", "-q", os.path.join(g, "data.faa"), "-d", os.path.join(g, "data.faa"), "-p4", "--gpus", "2", "-o", out] + fmt,
                            capture_output=True, text=True, timeout=600, env=env)

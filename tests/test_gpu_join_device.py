@@ -142,3 +142,27 @@ print("RCCL_DEVICE_JOIN_OK", len(want))
 ''' % root
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL_DEVICE_JOIN_OK" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+
+
+def test_join_ranks_one_process_several_contexts(ctx, block_records):
+    """dmnd_join_ranks (csrc/rank_join.hip): what `diamond-hip --gpus N` calls per query block. One context: the exchange is RCCL's
+    (ncclCommInitAll for the device, ncclSend / ncclRecv to itself inside one group), the merge is the device's. Three contexts on
+    the box's one GPU: owners by query range, device-to-device copies in RCCL's place (it refuses several ranks on a device), three
+    merges, the concatenation in query order. Both equal the host join of the same records, with -k and with --top."""
+    rec, nq = block_records
+    want = hip.join_blocks(rec, 25)
+    got, transport = hip.join_ranks([ctx], [rec], nq, 25)
+    assert transport == 1 and got.tobytes() == want.tobytes()
+    others = [hip.Context(params=hip.default_params()) for _ in range(2)]
+    try:
+        thirds = np.array_split(np.arange(len(rec)), 3)
+        parts = [rec[i] for i in thirds]                       # any split of the records over the sources gives the same join
+        got, transport = hip.join_ranks([ctx] + others, parts, nq, 25)
+        assert transport == 2 and got.tobytes() == want.tobytes()
+        got, _ = hip.join_ranks([ctx] + others, [parts[0], parts[1][:0], np.concatenate(parts[1:])], nq, 4)      # a source without records
+        assert got.tobytes() == hip.join_blocks(rec, 4).tobytes()
+        got, _ = hip.join_ranks([ctx] + others, parts, nq, 25, top_percent=15.0)
+        assert got.tobytes() == hip.join_blocks_top(rec, 15.0).tobytes()
+    finally:
+        for c in others:
+            c.close()
