@@ -783,6 +783,30 @@ def main():
                 "host_cpu_ms_per_step": out.get("host_cpu_ms_per_step"),
                 "note": "Amdahl: the query index is built on every rank; with 16 host CPUs for 8 ranks the extension's host part (host_cpu_ms_per_step, "
                         "mostly chaining and culling) is the other term that does not shrink per box"}
+        if world == 1 and NB > 1:
+            # The same question for a job of several database blocks (C5: 8 blocks, N GPUs take 8 / N each). Per step a rank indexes
+            # the query block once (kept over its blocks), streams and extends its blocks; the host part of the extension (chaining,
+            # culling, packing: host_cpu_ms_per_step of CPU time, the same total however many ranks share it) runs on the box's CPU
+            # quota; the ranks exchange their records once (device-resident all-to-all + device merge).
+            sk = out["seed_kernel_ms"]
+            gpu_fixed = sk["index_queries"]
+            gpu_shrink = (sk["total"] - sk["index_queries"]) + ext["round1_swipe_kernel_ms"] + ext["round2_swipe_kernel_ms"] + ext["traceback_kernel_ms"]
+            cpus = cgroup_cpus()
+            host_floor = cpu_ms_per_step / max(cpus, 1)
+            step_now = dt / args.steps * 1e3
+            def pred(n, host_cpus):
+                host = cpu_ms_per_step / max(host_cpus, 1)
+                coll = 4 * 0.025 + 2 * 104.0 * len(records) / n / 50e9 * 1e3 if n > 1 else 0.0
+                return max(gpu_fixed + gpu_shrink / n, host, step_now / n if n == 1 else 0.0) + coll
+            out["scaling_model"] = {
+                "what": "predicted ms per step of the %d-block job on N GPUs = max(GPU: fixed + shrinking / N, host: CPU-ms per step / CPUs of the box) + collectives; measured at N = 1" % w.n_blocks_total,
+                "gpu_fixed_ms": gpu_fixed, "gpu_shrinking_ms": gpu_shrink, "host_cpu_ms_per_step": cpu_ms_per_step, "host_cpus": cpus, "host_floor_ms": host_floor,
+                "measured_ms_per_step": step_now,
+                "predicted_ms_per_step": {str(n): pred(n, cpus) for n in (1, 2, 4, 8)},
+                "predicted_speedup": {str(n): step_now / pred(n, cpus) for n in (2, 4, 8)},
+                "predicted_speedup_with_8_cpus_per_rank": {str(n): step_now / pred(n, 8 * n) for n in (2, 4, 8)},
+                "note": "under this box's CPU quota the extension's host part bounds the 8-GPU run (the same CPU-ms per step shared by all ranks); with 8 host cores per rank the "
+                        "GPU term (the query index every rank builds + its share of the stream and the sweeps) is the bound"}
         if seed_params.n_shapes > 2:
             out["roofline"]["note"] += ("; with short seeds (weight < 10) this kernel also runs the Hamming filter of every joined (query, reference) "
                                         "position pair, so its launch time covers the join AND the stage-1 filter")

@@ -97,7 +97,7 @@ def test_device_join_on_real_block_records(ctx, block_records):
     rec, nq = block_records
     for k in (25, 3):
         want = hip.join_blocks(rec, k)
-        assert len(want) > 2000
+        assert len(want) > 300, len(want)
         assert ctx.join_blocks_device(rec, k).tobytes() == want.tobytes()
     want = hip.join_blocks(rec, 25)
     # device pointers: records and result as torch tensors on the context's device
