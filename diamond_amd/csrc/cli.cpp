@@ -1456,7 +1456,7 @@ int run_blastp(const Options& o)
 								: dmnd_format_tab(&m, qid[m.query].c_str(), short_id(db.title(m.target)).c_str(), one, sizeof one);
 							from = one;
 						}
-						if (w < 0) { errors[(size_t)t] = dmnd_last_error(); return; }
+						if (w < 0) { const char* why = dmnd_last_error(); errors[(size_t)t] = why && why[0] ? why : "formatting a match record failed"; return; }      // (never empty: the main thread tests for it)
 						s.append(from, (size_t)w);
 					}
 				});

@@ -1391,6 +1391,51 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	return DMND_OK;
 }
 
+// xdrop_ungapped for every seed hit of a block pair at once (SURVEY 8(b)'s optional entry; /root/reference/src/dp/ungapped_align.cpp:
+// 151-199: from the seed position (qa, sa) the diagonal is walked to the left and to the right, each walk ending at a sequence end
+// or once the running score has fallen `xdrop` below the best; DiagonalSegment(qa - delta, sa - delta, len + delta, score)). The kernel
+// is dmnd_extend's own first device stage (xdrop_seg_kernel, bias_kernels.hip; arithmetic shared with the host in xdrop_core.h).
+// use_bias: the Hauser composition bias of the queries is added to every letter score (Extension::extend's call shape); 0 = none
+// (the reference's legacy mapper and global ranking call it that way). xdrop <= 0: config.raw_ungapped_xdrop of the context's matrix.
+extern "C" int dmnd_xdrop_ungapped(dmnd_ctx* c, const dmnd_seed_hit* hits, int64_t n_hits, int use_bias, int xdrop, dmnd_diagonal_segment* out)
+{
+	if (!c || n_hits < 0 || (n_hits > 0 && (!hits || !out))) return fail(DMND_E_ARG, "dmnd_xdrop_ungapped: bad argument");
+	const std::vector<int64_t>& ql = c->limits[DMND_QUERY];
+	const std::vector<int64_t>& tl = c->limits[DMND_TARGET];
+	if (ql.size() < 2 || tl.size() < 2) return fail(DMND_E_ARG, "dmnd_xdrop_ungapped: both blocks must be uploaded with limits");
+	if (n_hits == 0) return DMND_OK;
+	for (int64_t k = 0; k < n_hits; ++k) {
+		const dmnd_seed_hit& h = hits[k];
+		if ((size_t)h.query + 1 >= ql.size() || h.seed_offset < 0 || ql[h.query] + h.seed_offset >= ql[h.query + 1] - 1 || h.subject < tl.front() || h.subject >= tl.back())
+			return fail(DMND_E_ARG, "dmnd_xdrop_ungapped: seed hit " + std::to_string(k) + " outside the blocks");
+	}
+	HIP_TRY(hipSetDevice(c->device));
+	HostCfg h;
+	make_cfg(c, h);
+	if (use_bias) {
+		if (int rc = c->cbs.ensure((size_t)ql.back() + 256)) return rc;
+		BiasArgs ba;
+		ba.block = c->block[DMND_QUERY].as<int8_t>(); ba.limits = c->d_limits[DMND_QUERY].as<int64_t>(); ba.n_seqs = (int64_t)ql.size() - 1; ba.ids = nullptr;
+		ba.matrix = c->matrix.as<int8_t>(); ba.window = h.cbs_window; ba.out = c->cbs.as<int8_t>();
+		for (int i = 0; i < 20; ++i) ba.bg[i] = (float)h.background_scores[i];
+		HIP_TRY(launch_hauser_bias(ba, c->stream));
+	}
+	if (int rc = c->xd_hits.ensure((size_t)n_hits * sizeof(dmnd_seed_hit))) return rc;
+	if (int rc = c->xd_out.ensure((size_t)n_hits * sizeof(XdropSeg))) return rc;
+	HIP_TRY(hipMemcpyAsync(c->xd_hits.p, hits, (size_t)n_hits * sizeof(dmnd_seed_hit), hipMemcpyHostToDevice, c->stream));
+	XdropArgs xa;
+	xa.qblock = c->block[DMND_QUERY].as<int8_t>(); xa.tblock = c->block[DMND_TARGET].as<int8_t>();
+	xa.cbs = use_bias ? c->cbs.as<int8_t>() : nullptr;
+	xa.qlimits = c->d_limits[DMND_QUERY].as<int64_t>(); xa.matrix = c->matrix.as<int8_t>();
+	xa.hits = c->xd_hits.as<dmnd_seed_hit>(); xa.n_hits = n_hits; xa.xdrop = xdrop > 0 ? xdrop : h.xdrop; xa.out = c->xd_out.as<XdropSeg>();
+	HIP_TRY(launch_xdrop_segs(xa, c->stream));
+	std::vector<XdropSeg> seg((size_t)n_hits);
+	if (int rc = download_bytes(c, seg.data(), c->xd_out.p, (size_t)n_hits * sizeof(XdropSeg))) return rc;
+	for (int64_t k = 0; k < n_hits; ++k)
+		out[k] = dmnd_diagonal_segment{ hits[k].seed_offset - seg[(size_t)k].left, hits[k].subject - (int64_t)seg[(size_t)k].left, seg[(size_t)k].left + seg[(size_t)k].right, seg[(size_t)k].score };
+	return DMND_OK;
+}
+
 extern "C" int dmnd_set_frameshift(dmnd_ctx* c, int penalty, int range_culling, double range_cover, int channels)
 {
 	if (!c || penalty < 0 || channels < 1 || range_cover < 0) return fail(DMND_E_ARG, "dmnd_set_frameshift: bad argument");

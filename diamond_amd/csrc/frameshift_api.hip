@@ -62,6 +62,9 @@ int run_launch(dmnd_ctx* c, bool traceback, int frame_shift, const dmnd_fs_targe
 				}
 			}
 			if (c1 > c0 && (size_t)(trace + t_add) * sizeof(int32_t) > trace_budget) break;
+			// ... and (score-only passes keep no trace, so the budget above never ends a chunk) at 1 GB of interleaved DP state or 4 M
+			// items: the state and item arrays of a large read block are not sized for all of it at once
+			if (c1 > c0 && ((size_t)state * sizeof(int32_t) > ((size_t)1 << 30) || c1 - c0 >= ((int64_t)4 << 20))) break;
 			for (int64_t k = c1; k < w1; ++k) {
 				const Pending& p = work[(size_t)k];
 				const dmnd_fs_target& it = items[p.item];

@@ -393,7 +393,10 @@ int dmnd_format_tab_translated(const dmnd_match* m, const char* qseqid, const ch
  * host_data (may be NULL): the caller's host copy of the block as it stands in HBM (the bytes it was uploaded from, block raw
  * length); the mask letter is written over the masked positions -- from a list of those positions, not by copying the block
  * back -- so that the extension stage's host part reads the same letters. *n_masked (may be NULL) = number of positions at or
- * above the mask probability. */
+ * above the mask probability.
+ * Calls on ONE context are serialized by the caller: the masking calls, dmnd_seed_search and the block joins share the context's
+ * sort scratch (a helper thread may run dmnd_upload_block of the other block beside them, nothing else). The tantan work space
+ * (4.25 B per letter) stays with the context for the next block; DMND_MASK_SCRATCH_KEEP_MB (default 16384) bounds what is kept. */
 int dmnd_mask_block(dmnd_ctx* ctx, int which, int8_t* host_data, int64_t* n_masked);
 /* The same for a subset of the block's sequences (block sequence ids, any order, no duplicates): what the reference's LAZY masking
  * does -- with the query-indexed algorithm it masks a target only when the extension stage loads it (align/extend.cpp:168-181), i.e.
@@ -503,6 +506,13 @@ int dmnd_set_max_target_seqs(dmnd_ctx* ctx, int k);
  *    one carries the target's place among the query's targets (Match::filter_evalue / filter_score).
  * Translated queries need dmnd_set_query_source_lengths (the envelope test works on the read's coordinates). */
 int dmnd_set_max_hsps(dmnd_ctx* ctx, int n);
+/* xdrop_ungapped for every seed hit of the resident block pair in one launch (the optional entry;
+ * src/dp/ungapped_align.cpp:151-199): from the hit's position the diagonal is walked left and right until a sequence end or until
+ * the running score has fallen xdrop below the best. out[k] = DiagonalSegment(qa - delta, sa - delta, len + delta, score) of hit k:
+ * i = position in the query sequence, j = block offset in the reference block. use_bias != 0: the queries' Hauser bias is added to
+ * every letter score (Extension::extend's call); xdrop <= 0: config.raw_ungapped_xdrop of the context's matrix (12.3 bits). */
+typedef struct { int32_t i; int64_t j; int32_t len, score; } dmnd_diagonal_segment;
+int dmnd_xdrop_ungapped(dmnd_ctx* ctx, const dmnd_seed_hit* hits, int64_t n_hits, int use_bias, int xdrop, dmnd_diagonal_segment* out);
 /* --global-ranking N (config.global_ranking_targets; align/global_ranking/): instead of extending every reference block's seed
  * hits, the search keeps per query the N targets of the WHOLE database with the best ungapped score and extends only those, over
  * the full matrix, after the last block. Three calls:
