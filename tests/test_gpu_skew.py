@@ -3,7 +3,7 @@ members with i.i.d. background letters; here the database is 40 families of 3000
 reference positions: the joined-position lists outgrow their first buffer and phase 1 runs again, the lists are sorted by seed and
 filtered by the LDS-tiled kernel -- the situation the reference's 1024 x 1024 stage-1 tiles exist for, search/hamming/kernel.h:29-50,
 basic/config.cpp:423), with tandem repeats planted into a third of the sequences. Byte-identical A/B against the reference binary for
---fast and the default sensitivity, tantan on and off; that the slow paths were really taken is read from the library's DMND_TRACE lines."""
+--fast without masking and the default sensitivity with tantan; that the slow paths were really taken is read from the library's DMND_TRACE lines."""
 import os
 import re
 import subprocess
@@ -40,7 +40,9 @@ def files(tmp_path_factory):
         pytest.fail("oracle/_ref/diamond is missing: under -m gpu the reference binary is the checker, its absence is a failure")
     d = tmp_path_factory.mktemp("skew")
     rng = np.random.default_rng(7)
-    db, doff, q, qoff = synth.generate(40, members=3000, queries=4000, seed=20260924)
+    # (measured while calibrating: at the generator's default divergence 4000 queries join 1.7e6 positions of this database, not enough;
+    #  members 10-30 % from their ancestor and queries 10-30 % from a member join ~14 reference positions per query position)
+    db, doff, q, qoff = synth.generate(40, members=3000, queries=1500, seed=20260924, sub=(0.1, 0.3), qsub=(0.1, 0.3))
     assert len(doff) - 1 >= 100_000
     synth.write_fasta(str(d / "db.faa"), "t", _plant_repeats(db, doff, rng), doff)
     synth.write_fasta(str(d / "q.faa"), "q", _plant_repeats(q, qoff, rng), qoff)
@@ -49,7 +51,7 @@ def files(tmp_path_factory):
     return d
 
 
-@pytest.mark.parametrize("flags", [["--fast", "--masking", "0"], ["--fast"], ["--masking", "0"], []], ids=["fast_unmasked", "fast_tantan", "default_unmasked", "default_tantan"])
+@pytest.mark.parametrize("flags", [["--fast", "--masking", "0"], []], ids=["fast_unmasked", "default_tantan"])
 def test_skewed_families_are_byte_identical_and_take_the_slow_paths(files, flags):
     d = files
     tag = "_".join(x.strip("-") for x in flags) or "default"
@@ -59,12 +61,12 @@ def test_skewed_families_are_byte_identical_and_take_the_slow_paths(files, flags
     h = subprocess.run([CLI] + common + ["-o", str(d / (tag + "_hip.tsv"))], capture_output=True, text=True, timeout=1400, env=dict(os.environ, DMND_TRACE="1"))
     assert h.returncode == 0, h.stderr[-2000:]
     a, b = open(d / (tag + "_ref.tsv"), "rb").read(), open(d / (tag + "_hip.tsv"), "rb").read()
-    assert a.count(b"\n") > 80_000
+    assert a.count(b"\n") > 30_000
     if a != b:
         sa, sb = set(a.decode().splitlines()), set(b.decode().splitlines())
         raise AssertionError("%s: %d lines only in the reference, %d only in diamond-hip, e.g. %s | %s" % (tag, len(sa - sb), len(sb - sa), sorted(sa - sb)[:3], sorted(sb - sa)[:3]))
     # the slow paths, taken because of the data and not because an environment variable forced them
     joined = [int(x) for m in re.finditer(r"joined reference positions per shape:((?: \d+)+)", h.stderr) for x in m.group(1).split()]
     assert joined and max(joined) >= 1 << 22, joined[:8]
-    assert "tiled pair filter" in h.stderr
-    assert "phase 1 runs again" in h.stderr
+    assert "tiled pair filter" in h.stderr, joined[:8]
+    assert "phase 1 runs again" in h.stderr, joined[:8]

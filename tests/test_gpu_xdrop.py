@@ -37,9 +37,12 @@ def _reference_xdrop(M, q, cbs, t, qa, sa, xdrop):
 def test_xdrop_ungapped_equals_the_reference_function(tap):
     cfg, recs = read_ext_tap(os.path.join(GOLDEN, tap))
     qd, ql, td, tl = cfg["query"]["data"], cfg["query"]["limits"], cfg["target"]["data"], cfg["target"]["limits"]
-    hits = np.concatenate([r["hits"] for r in recs]).astype(hip.SEED_HIT_DTYPE)
+    src = np.concatenate([r["hits"] for r in recs])
     rng = np.random.default_rng(1)
-    hits = hits[rng.permutation(len(hits))[:600]]
+    src = src[rng.permutation(len(src))[:600]]
+    hits = np.zeros(len(src), dtype=hip.SEED_HIT_DTYPE)
+    for f in ("query", "seed_offset", "subject", "score"):
+        hits[f] = src[f]
     params = hip.default_params()
     M = hip.matrix_of(params)
     cbs, _ = hip.extend_plan(params, qd, ql, td, tl, np.zeros(0, hip.SEED_HIT_DTYPE))
