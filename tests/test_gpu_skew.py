@@ -1,5 +1,5 @@
 """-m gpu: a workload that takes the seed stage's slow paths by itself (round 5). Every other full-size run is on families of 10
-members with i.i.d. background letters; here the database is 40 families of 3000 members (a query's seeds join thousands of
+members with i.i.d. background letters; here the database is 40 families of 6000 members (a query's seeds join thousands of
 reference positions: the joined-position lists outgrow their first buffer and phase 1 runs again, the lists are sorted by seed and
 filtered by the LDS-tiled kernel -- the situation the reference's 1024 x 1024 stage-1 tiles exist for, search/hamming/kernel.h:29-50,
 basic/config.cpp:423), with tandem repeats planted into a third of the sequences. Byte-identical A/B against the reference binary for
@@ -42,8 +42,8 @@ def files(tmp_path_factory):
     rng = np.random.default_rng(7)
     # (measured while calibrating: at the generator's default divergence 4000 queries join 1.7e6 positions of this database, not enough;
     #  members 10-30 % from their ancestor and queries 10-30 % from a member join ~14 reference positions per query position)
-    db, doff, q, qoff = synth.generate(40, members=3000, queries=3000, seed=20260924, sub=(0.1, 0.3), qsub=(0.1, 0.3))
-    assert len(doff) - 1 >= 100_000
+    db, doff, q, qoff = synth.generate(40, members=6000, queries=3000, seed=20260924, sub=(0.1, 0.3), qsub=(0.1, 0.3))
+    assert len(doff) - 1 >= 200_000
     synth.write_fasta(str(d / "db.faa"), "t", _plant_repeats(db, doff, rng), doff)
     synth.write_fasta(str(d / "q.faa"), "q", _plant_repeats(q, qoff, rng), qoff)
     r = subprocess.run([REF, "makedb", "--in", str(d / "db.faa"), "-d", str(d / "db"), "-p", THREADS], capture_output=True, text=True, timeout=600)
