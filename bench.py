@@ -309,7 +309,12 @@ def main():
     if many_blocks and not args.host_threads:
         threads = max(threads, min(16, cgroup_cpus()) // max(world, 1))      # the host part of 8 blocks per batch is the bound of C5 (measured: 86 -> 66 ms per step)
     if args.ext_contexts is None:
-        args.ext_contexts = 2 if many_blocks else 3
+        # several blocks per batch (C5): the extension of a block is a chain of short host and device phases; four batches in flight
+        # with 24 host threads among them (more than the 16-CPU quota: most of the time they wait for the device) gave 50 ms per step
+        # against 59 with two batches and 16 threads (profiles/r05_extension_contexts_sweep.txt) -- at the price of a third more CPU time
+        args.ext_contexts = (4 if world == 1 else 2) if many_blocks else 3
+        if many_blocks and world == 1 and not args.host_threads:
+            threads = max(threads, 24)
 
     if args.queries is None:
         args.queries = CONFIGS[args.config].get("queries", 10_000)

@@ -277,6 +277,8 @@ extern "C" void dmnd_destroy(dmnd_ctx* c)
 {
 	if (!c) return;
 	if (c->sort_tmp) { (void)hipFree(c->sort_tmp); c->sort_tmp = nullptr; c->sort_tmp_bytes = 0; }
+	if (c->sort_tmp_b) { (void)hipFree(c->sort_tmp_b); c->sort_tmp_b = nullptr; c->sort_tmp_b_bytes = 0; }
+	if (c->seed_stream_b) { (void)hipStreamSynchronize(c->seed_stream_b); forget_stream(c->seed_stream_b); (void)hipStreamDestroy(c->seed_stream_b); c->seed_stream_b = nullptr; }
 	if (c->pinned_cbs) (void)hipHostFree(c->pinned_cbs);
 	for (DevBuf& kb : c->keep_trace) kb.release();
 	c->stage_h.release(); c->ends_h.release(); c->stage_d.release();

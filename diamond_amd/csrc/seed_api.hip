@@ -275,7 +275,7 @@ struct SeedSizes {
 	uint64_t slots, bm_words, bm1_words;
 	uint32_t bm1_k3;
 	int stream_nt, probe_policy, SB, slot_shift;
-	bool fused, reuse;
+	bool fused, reuse, overlap;
 	size_t bm_total;
 };
 
@@ -338,7 +338,12 @@ static SeedSizes seed_sizes(const dmnd_ctx* c, const SeedParams& sp, int64_t nq_
 	z.slot_shift = 4;
 	const size_t set_bytes = (z.slots << z.slot_shift) + 2 * (size_t)nq_pos * sizeof(uint32_t) + (size_t)(bm_words + bm1_words) * sizeof(uint32_t);
 	const bool reuse = c->reuse_query_index && set_bytes * (size_t)S <= ((size_t)64 << 30) && !getenv("DMND_SEED_MATCHED_CAP");
-	const int SB = (fused && !reuse) ? 1 : S;            // shapes that own buffers at the same time
+	// Two lanes (round 5, DMND_SEED_OVERLAP=0 switches it off): stage 2 of shape s -- ungapped scores, left-most rule, deferred pairs --
+	// runs on a second stream beside the index and the stream of shape s + 1, so consecutive shapes must not share a table: two
+	// buffer sets, used alternately.
+	static const bool overlap_env = [] { const char* e = getenv("DMND_SEED_OVERLAP"); return !e || atoi(e) != 0; }();
+	z.overlap = fused && overlap_env && S > 1;
+	const int SB = (fused && !reuse) ? (z.overlap ? 2 : 1) : S;            // shapes that own buffers at the same time
 	const size_t bm_total = (size_t)SB * (bm_words + bm1_words) * sizeof(uint32_t);
 	z.bm_words = bm_words; z.bm1_words = bm1_words; z.bm1_k3 = bm1_k3; z.stream_nt = stream_nt; z.probe_policy = probe_policy;
 	z.fused = fused; z.reuse = reuse; z.SB = SB; z.bm_total = bm_total;
@@ -507,7 +512,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	const int level2_env = [] { const char* e = getenv("DMND_SEED_LEVEL2"); return e ? atoi(e) : -1; }();
 	auto level2_of = [&](int sid) { return level2_env >= 0 ? level2_env : (sp.shape_weight[sid] >= 10 ? 1 : 0); };
 	auto args_for = [&](int sid, int64_t matched_cap, int64_t matched_off) {
-		const int own = SB == 1 ? 0 : sid;                 // which of the SB buffer sets the shape uses
+		const int own = sid % SB;                          // which of the SB buffer sets the shape uses
 		SeedArgs a;
 		a.params = sp;
 		a.qdata = c->block[DMND_QUERY].as<int8_t>(); a.tdata = c->block[DMND_TARGET].as<int8_t>();
@@ -556,7 +561,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	auto query_side = [&](const SeedArgs& a, int sid, bool build) -> int {
 		if (build) {
 			HIP_TRY(launch_seed_index(a, sid, st));
-			HIP_TRY(launch_seed_lists(a, sid, c->seed_qkeys.as<uint32_t>(), c->seed_qlist.as<uint32_t>() + (size_t)(SB == 1 ? 0 : sid) * nq_pos, list_key_bits, &c->sort_tmp, &c->sort_tmp_bytes, st));
+			HIP_TRY(launch_seed_lists(a, sid, c->seed_qkeys.as<uint32_t>(), c->seed_qlist.as<uint32_t>() + (size_t)(sid % SB) * nq_pos, list_key_bits, &c->sort_tmp, &c->sort_tmp_bytes, st));
 		}
 		else HIP_TRY(launch_seed_reset(a, sid, st));
 		return DMND_OK;
@@ -571,9 +576,10 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	// deferred pairs. A shape's masks only depend on this and earlier shapes, and so does the left-most rule (t_now).
 	if (fused) {
 		unsigned long long* ctr = c->counters.as<unsigned long long>();
-		int64_t m_cap = std::max<int64_t>(std::max<int64_t>((int64_t)1 << 22, 4 * nq_pos), (int64_t)std::min(c->matched_loc.cap / sizeof(int64_t), c->matched_slot.cap / sizeof(uint32_t)));
+		const size_t lanes = z.overlap ? 2 : 1;               // the joined-position and survivor buffers hold one half per lane (shape parity)
+		int64_t m_cap = std::max<int64_t>(std::max<int64_t>((int64_t)1 << 22, 4 * nq_pos), (int64_t)(std::min(c->matched_loc.cap / sizeof(int64_t), c->matched_slot.cap / sizeof(uint32_t)) / lanes));
 		if (const char* e = getenv("DMND_SEED_MATCHED_CAP")) m_cap = std::max<int64_t>(1, atoll(e));
-		int64_t surv_cap = std::max<int64_t>((int64_t)1 << 20, (int64_t)(c->seed_survivors.cap / sizeof(SeedSurvivor)));
+		int64_t surv_cap = std::max<int64_t>((int64_t)1 << 20, (int64_t)(c->seed_survivors.cap / sizeof(SeedSurvivor) / lanes));
 		if (const char* e = getenv("DMND_SEED_SURVIVOR_CAP")) surv_cap = std::max<int64_t>(1, atoll(e));
 		int64_t hit_cap = std::max<int64_t>((int64_t)1 << 20, (int64_t)(c->seed_hits.cap / sizeof(dmnd_seed_hit)));
 		if (const char* e = getenv("DMND_SEED_HIT_CAP")) hit_cap = std::max<int64_t>(1, atoll(e));
@@ -581,19 +587,99 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		c->seed_trace.assign((size_t)2 * S, 0);
 		int64_t hits_bound = 0;                              // every survivor gives at most one hit
 		std::vector<unsigned long long> host_ctr((size_t)S + 4);
+		// ---- lane B: everything behind a shape's Hamming filter (stage-2 scores, left-most rule, deferred pairs). With the lanes
+		// overlapped it runs on its own stream, driven by a helper thread (it waits for two counts of its own), while the main thread
+		// indexes and streams the next shape on the context's stream. What the lanes share: the shape's table set (read by B; the next
+		// shape builds the OTHER set), its halves of the joined-position and survivor buffers (by shape parity), mask_time (B only reads it,
+		// "<= t_now": what the next shape's kernels write there is later than any t_now of this shape), the hit list (B only).
+		const bool overlap = z.overlap;
+		hipStream_t sb = st;
+		if (overlap) {
+			if (!c->seed_stream_b) {
+				int prio = 0;
+				HIP_TRY(hipStreamGetPriority(st, &prio));
+				HIP_TRY(hipStreamCreateWithPriority(&c->seed_stream_b, hipStreamNonBlocking, prio));
+			}
+			sb = c->seed_stream_b;
+		}
+		Timer tmb(sb);
+		hipEvent_t lane_a_done = nullptr;
+		if (overlap) HIP_TRY(hipEventCreateWithFlags(&lane_a_done, hipEventDisableTiming));
+		struct EventGuard { hipEvent_t& e; ~EventGuard() { if (e) (void)hipEventDestroy(e); } } event_guard{ lane_a_done };
+		std::string lane_b_error;
+		auto lane_b = [&](SeedArgs a, int sid, unsigned long long n, unsigned long long ns) -> int {
+			HIP_TRY(hipSetDevice(c->device));
+			if (overlap) HIP_TRY(hipStreamWaitEvent(sb, lane_a_done, 0));       // recorded behind the shape's mask kernel
+			if (hits_bound + (int64_t)ns > hit_cap) {            // grow, keeping the hits of the earlier shapes
+				const int64_t new_cap = hits_bound + (int64_t)ns + (hits_bound + (int64_t)ns) / 2;
+				DevBuf nb;
+				if (int rc = nb.ensure((size_t)new_cap * sizeof(dmnd_seed_hit))) return rc;
+				HIP_TRY(hipMemcpyAsync(nb.p, c->seed_hits.p, (size_t)hit_cap * sizeof(dmnd_seed_hit), hipMemcpyDeviceToDevice, sb));
+				HIP_TRY(sync_stream(sb));
+				c->seed_hits.release();
+				c->seed_hits = nb;
+				hit_cap = new_cap;
+			}
+			hits_bound += (int64_t)ns;
+			if (int rc = c->seed_deferred.ensure((size_t)ns * sizeof(SeedDeferred))) return rc;      // deferred pairs <= survivors
+			a.hits = c->seed_hits.as<dmnd_seed_hit>(); a.hit_cap = hit_cap;
+			a.deferred = c->seed_deferred.as<SeedDeferred>(); a.deferred_cap = (int64_t)ns;
+			if (int rc = c->seed_scored.ensure((size_t)ns * sizeof(SeedScored))) return rc;
+			a.scored = c->seed_scored.as<SeedScored>();
+			tmb.start();
+			{
+				// this lane's own counters (deferred pairs, collected positions, scored) and the need map
+				SeedClear zb;
+				zb.add(ctr + S + 1, 2 * sizeof(unsigned long long), 0);
+				zb.add(ctr + S + 4, sizeof(unsigned long long), 0);
+				zb.add(c->seed_need.p, (size_t)(slots / 32) * sizeof(uint32_t), 0);
+				HIP_TRY(launch_seed_clear(zb, sb));
+			}
+			HIP_TRY(launch_seed_post(a, sid, (int64_t)ns, sb, false));
+			c->seed_ms[3] += tmb.stop();
+			if (!sp.use_ungapped) return DMND_OK;
+			unsigned long long nd = 0;
+			HIP_TRY(copy_now(sb, &nd, a.deferred_count, sizeof(nd), hipMemcpyDeviceToHost));
+			c->seed_trace[S + sid] = nd;
+			if (nd == 0) return DMND_OK;
+			if (int rc = c->seed_eslot.ensure((size_t)n * sizeof(uint64_t))) return rc;
+			if (int rc = c->seed_eloc.ensure((size_t)n * sizeof(uint64_t))) return rc;
+			a.e_key = c->seed_eslot.as<uint64_t>();
+			tmb.start();
+			HIP_TRY(launch_seed_collect(a, (int64_t)n, sb));
+			unsigned long long ne = 0;
+			HIP_TRY(hipMemcpyAsync(&ne, a.e_count, sizeof(ne), hipMemcpyDeviceToHost, sb));
+			HIP_TRY(sync_stream(sb));
+			HIP_TRY(sort_keys_u64(c->seed_eslot.as<uint64_t>(), c->seed_eloc.as<uint64_t>(), (int64_t)ne, overlap ? &c->sort_tmp_b : &c->sort_tmp, overlap ? &c->sort_tmp_b_bytes : &c->sort_tmp_bytes, sb));
+			a.e_key = c->seed_eloc.as<uint64_t>();
+			a.e_n = (int64_t)ne;
+			HIP_TRY(launch_seed_deferred(a, sid, (int64_t)nd, sb));
+			c->seed_ms[3] += tmb.stop();
+			return DMND_OK;
+		};
+		std::thread lane_b_thread;
+		int lane_b_rc = DMND_OK;
+		auto wait_b = [&]() -> int {                            // lane B idle (its last shape finished on the device too)
+			if (lane_b_thread.joinable()) lane_b_thread.join();
+			if (lane_b_rc != DMND_OK) { const int rc = lane_b_rc; lane_b_rc = DMND_OK; return fail(rc, lane_b_error); }
+			return DMND_OK;
+		};
+		struct ThreadGuard { std::thread& t; ~ThreadGuard() { if (t.joinable()) t.join(); } } thread_guard{ lane_b_thread };
+		const bool recycle = SB < S;                          // a buffer set serves several shapes: cleared before its next one
 		for (int sid = 0; sid < S; ++sid) {
 			SeedArgs a = args_for(sid, 0, 0);
+			const int half = overlap ? sid & 1 : 0;            // this shape's half of the joined-position / survivor buffers
 			tm.start();
 			if (sid > 0) {
-				// the per-shape counters (deferred pairs, collected positions, survivors, scored) and the need map; with one buffer set
-				// for all shapes also the previous shape's table, slots-of-positions and bitmaps -- one launch
+				// the survivor counter and, where a buffer set is used again, its table, slots-of-positions and bitmaps -- one launch
+				// (lane B was last seen idle before the PREVIOUS shape went to it: the set of shape sid - SB is free)
 				SeedClear z;
-				z.add(ctr + S + 1, 4 * sizeof(unsigned long long), 0);
-				z.add(c->seed_need.p, (size_t)(slots / 32) * sizeof(uint32_t), 0);
-				if (SB == 1) {
-					z.add(c->seed_keys.p, slot_bytes, 0xff);
-					z.add(c->seed_next.p, (size_t)nq_pos * sizeof(uint32_t), 0xff);
-					z.add(c->seed_bitmap.p, bm_total, 0);
+				z.add(ctr + S + 3, sizeof(unsigned long long), 0);
+				if (recycle && sid >= SB) {
+					const size_t own = (size_t)(sid % SB);
+					z.add(c->seed_keys.as<char>() + own * slot_bytes, slot_bytes, 0xff);
+					z.add(c->seed_next.as<char>() + own * (size_t)nq_pos * sizeof(uint32_t), (size_t)nq_pos * sizeof(uint32_t), 0xff);
+					z.add(c->seed_bitmap.as<char>() + own * (size_t)(bm_words + bm1_words) * sizeof(uint32_t), (size_t)(bm_words + bm1_words) * sizeof(uint32_t), 0);
 				}
 				HIP_TRY(launch_seed_clear(z, st));
 			}
@@ -601,11 +687,16 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 			c->seed_ms[0] += tm.stop();
 			unsigned long long n = 0, ns = 0;
 			for (int attempt = 0;; ++attempt) {
-				if (int rc = c->matched_slot.ensure((size_t)m_cap * sizeof(uint32_t))) return rc;
-				if (int rc = c->matched_loc.ensure((size_t)m_cap * sizeof(int64_t))) return rc;
-				if (int rc = c->seed_survivors.ensure((size_t)surv_cap * sizeof(SeedSurvivor))) return rc;
-				a.matched_slot = c->matched_slot.as<uint32_t>(); a.matched_loc = c->matched_loc.as<int64_t>(); a.matched_cap = m_cap;
-				a.survivors = c->seed_survivors.as<SeedSurvivor>(); a.survivor_cap = surv_cap;
+				const size_t halves = lanes;
+				// (a buffer that has to grow is freed first: not while lane B reads the other half)
+				if (halves * (size_t)m_cap * sizeof(uint32_t) > c->matched_slot.cap || halves * (size_t)m_cap * sizeof(int64_t) > c->matched_loc.cap
+					|| halves * (size_t)surv_cap * sizeof(SeedSurvivor) > c->seed_survivors.cap)
+					if (int rc = wait_b()) return rc;
+				if (int rc = c->matched_slot.ensure(halves * (size_t)m_cap * sizeof(uint32_t))) return rc;
+				if (int rc = c->matched_loc.ensure(halves * (size_t)m_cap * sizeof(int64_t))) return rc;
+				if (int rc = c->seed_survivors.ensure(halves * (size_t)surv_cap * sizeof(SeedSurvivor))) return rc;
+				a.matched_slot = c->matched_slot.as<uint32_t>() + (size_t)half * (size_t)m_cap; a.matched_loc = c->matched_loc.as<int64_t>() + (size_t)half * (size_t)m_cap; a.matched_cap = m_cap;
+				a.survivors = c->seed_survivors.as<SeedSurvivor>() + (size_t)half * (size_t)surv_cap; a.survivor_cap = surv_cap;
 				if (attempt > 0) {                               // (the first attempt finds them zero: the clears above)
 					HIP_TRY(hipMemsetAsync(a.matched_count, 0, sizeof(unsigned long long), st));
 					HIP_TRY(hipMemsetAsync(a.survivor_count, 0, sizeof(unsigned long long), st));
@@ -627,45 +718,15 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 				HIP_TRY(launch_seed_mask(a, sid, st));
 				c->seed_ms[2] += tm.stop();
 			}
+			// lane B takes the shape over; it is idle first (so the table set and the buffer halves of shape sid - 1 are free for
+			// shape sid + 1, and lane B's own buffers for this shape)
+			if (int rc = wait_b()) return rc;
 			if (ns == 0) continue;
-			if (hits_bound + (int64_t)ns > hit_cap) {            // grow, keeping the hits of the earlier shapes
-				const int64_t new_cap = hits_bound + (int64_t)ns + (hits_bound + (int64_t)ns) / 2;
-				DevBuf nb;
-				if (int rc = nb.ensure((size_t)new_cap * sizeof(dmnd_seed_hit))) return rc;
-				HIP_TRY(hipMemcpyAsync(nb.p, c->seed_hits.p, (size_t)hit_cap * sizeof(dmnd_seed_hit), hipMemcpyDeviceToDevice, st));
-				HIP_TRY(sync_stream(st));
-				c->seed_hits.release();
-				c->seed_hits = nb;
-				hit_cap = new_cap;
-			}
-			hits_bound += (int64_t)ns;
-			if (int rc = c->seed_deferred.ensure((size_t)ns * sizeof(SeedDeferred))) return rc;      // deferred pairs <= survivors
-			a.hits = c->seed_hits.as<dmnd_seed_hit>(); a.hit_cap = hit_cap;
-			a.deferred = c->seed_deferred.as<SeedDeferred>(); a.deferred_cap = (int64_t)ns;
-			if (int rc = c->seed_scored.ensure((size_t)ns * sizeof(SeedScored))) return rc;
-			a.scored = c->seed_scored.as<SeedScored>();
-			tm.start();
-			HIP_TRY(launch_seed_post(a, sid, (int64_t)ns, st, false));
-			c->seed_ms[3] += tm.stop();
-			if (!sp.use_ungapped) continue;
-			unsigned long long nd = 0;
-			HIP_TRY(copy_now(c->stream, &nd, a.deferred_count, sizeof(nd), hipMemcpyDeviceToHost));
-			c->seed_trace[S + sid] = nd;
-			if (nd == 0) continue;
-			if (int rc = c->seed_eslot.ensure((size_t)n * sizeof(uint64_t))) return rc;
-			if (int rc = c->seed_eloc.ensure((size_t)n * sizeof(uint64_t))) return rc;
-			a.e_key = c->seed_eslot.as<uint64_t>();
-			tm.start();
-			HIP_TRY(launch_seed_collect(a, (int64_t)n, st));
-			unsigned long long ne = 0;
-			HIP_TRY(hipMemcpyAsync(&ne, a.e_count, sizeof(ne), hipMemcpyDeviceToHost, st));
-			HIP_TRY(sync_stream(st));
-			HIP_TRY(sort_keys_u64(c->seed_eslot.as<uint64_t>(), c->seed_eloc.as<uint64_t>(), (int64_t)ne, &c->sort_tmp, &c->sort_tmp_bytes, st));
-			a.e_key = c->seed_eloc.as<uint64_t>();
-			a.e_n = (int64_t)ne;
-			HIP_TRY(launch_seed_deferred(a, sid, (int64_t)nd, st));
-			c->seed_ms[3] += tm.stop();
+			if (!overlap) { if (int rc = lane_b(a, sid, n, ns)) return rc; continue; }
+			HIP_TRY(hipEventRecord(lane_a_done, st));
+			lane_b_thread = std::thread([&, a, sid, n, ns] { lane_b_rc = lane_b(a, sid, n, ns); if (lane_b_rc != DMND_OK) lane_b_error = dmnd_last_error(); else if (sync_stream(sb) != hipSuccess) { lane_b_rc = DMND_E_DEVICE; lane_b_error = "dmnd_seed_search: lane B failed"; } });
 		}
+		if (int rc = wait_b()) return rc;
 		unsigned long long nh = 0;
 		HIP_TRY(copy_now(c->stream, &nh, ctr + S, sizeof(nh), hipMemcpyDeviceToHost));
 		if ((int64_t)nh > hit_cap) return fail(DMND_E_NOMEM, "dmnd_seed_search: hit buffer overflow");
