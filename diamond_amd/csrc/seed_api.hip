@@ -338,10 +338,14 @@ static SeedSizes seed_sizes(const dmnd_ctx* c, const SeedParams& sp, int64_t nq_
 	z.slot_shift = 4;
 	const size_t set_bytes = (z.slots << z.slot_shift) + 2 * (size_t)nq_pos * sizeof(uint32_t) + (size_t)(bm_words + bm1_words) * sizeof(uint32_t);
 	const bool reuse = c->reuse_query_index && set_bytes * (size_t)S <= ((size_t)64 << 30) && !getenv("DMND_SEED_MATCHED_CAP");
-	// Two lanes (round 5, DMND_SEED_OVERLAP=0 switches it off): stage 2 of shape s -- ungapped scores, left-most rule, deferred pairs --
+	// Two lanes (round 5, DMND_SEED_OVERLAP=1 switches it ON): stage 2 of shape s -- ungapped scores, left-most rule, deferred pairs --
 	// runs on a second stream beside the index and the stream of shape s + 1, so consecutive shapes must not share a table: two
-	// buffer sets, used alternately.
-	static const bool overlap_env = [] { const char* e = getenv("DMND_SEED_OVERLAP"); return !e || atoi(e) != 0; }();
+	// buffer sets, used alternately. Measured on C3 (tools/gpu_r05g.sh, profiles/r05_two_lane_pipeline.txt): the seed stage alone
+	// 139.1 -> 133.0 ms (16 shapes; 29 ms of index + stage-2 kernels were there to hide: the by-class stream holds the CUs' LDS and
+	// wavefront slots, the other lane's kernels mostly wait for them), the pipelined bench step 150.4 -> 150.1 ms (the device is
+	// busy with the other batches' kernels anyway). Same hits in every mode (61 seed / full-size C3 / CLI tests with it on). Not
+	// worth a helper thread per shape by default: off.
+	static const bool overlap_env = [] { const char* e = getenv("DMND_SEED_OVERLAP"); return e && atoi(e) != 0; }();
 	z.overlap = fused && overlap_env && S > 1;
 	const int SB = (fused && !reuse) ? (z.overlap ? 2 : 1) : S;            // shapes that own buffers at the same time
 	const size_t bm_total = (size_t)SB * (bm_words + bm1_words) * sizeof(uint32_t);
