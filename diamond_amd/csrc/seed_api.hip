@@ -345,7 +345,7 @@ static SeedSizes seed_sizes(const dmnd_ctx* c, const SeedParams& sp, int64_t nq_
 	// wavefront slots, the other lane's kernels mostly wait for them), the pipelined bench step 150.4 -> 150.1 ms (the device is
 	// busy with the other batches' kernels anyway). Same hits in every mode (61 seed / full-size C3 / CLI tests with it on). Not
 	// worth a helper thread per shape by default: off.
-	static const bool overlap_env = [] { const char* e = getenv("DMND_SEED_OVERLAP"); return e && atoi(e) != 0; }();
+	const bool overlap_env = [] { const char* e = getenv("DMND_SEED_OVERLAP"); return e && atoi(e) != 0; }();      // (read per call: the tests switch it)
 	z.overlap = fused && overlap_env && S > 1;
 	const int SB = (fused && !reuse) ? (z.overlap ? 2 : 1) : S;            // shapes that own buffers at the same time
 	const size_t bm_total = (size_t)SB * (bm_words + bm1_words) * sizeof(uint32_t);

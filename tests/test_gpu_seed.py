@@ -132,6 +132,29 @@ def test_by_class_stream_for_long_seeds_equals_reference(ctx, tap, enc, monkeypa
     assert np.array_equal(hits, plain)
 
 
+@pytest.mark.parametrize("tap,enc", [("ext_sensitive.tap", 0), ("ext_hashed_sens.tap", 1)])
+def test_two_lane_short_seed_pipeline_equals_reference(ctx, tap, enc, monkeypatch):
+    """Round 5, off by default: stage 2 of shape s (ungapped scores, left-most rule, deferred pairs) on a second stream and a helper
+    thread beside the index and the stream of shape s + 1 -- two table sets, buffer halves by shape parity. Same hits as the reference
+    and as the one-lane order, also when the joined-position / survivor buffers overflow and grow while the other lane is busy."""
+    cfg, recs = read_ext_tap(os.path.join(GOLDEN, tap))
+    ctx.upload_block(hip.QUERY, cfg["query"]["data"], cfg["query"]["limits"])
+    ctx.upload_block(hip.TARGET, cfg["target"]["data"], cfg["target"]["limits"])
+    params = to_hip_params(dict(cfg, seed_encoding=1) if enc else cfg)
+    one_lane = ctx.seed_search(params)
+    monkeypatch.setenv("DMND_SEED_OVERLAP", "1")
+    for _ in range(3):
+        assert np.array_equal(ctx.seed_search(params), one_lane)
+    monkeypatch.setenv("DMND_SEED_MATCHED_CAP", "700")
+    monkeypatch.setenv("DMND_SEED_SURVIVOR_CAP", "40")
+    assert np.array_equal(ctx.seed_search(params), one_lane)
+    monkeypatch.delenv("DMND_SEED_MATCHED_CAP")
+    monkeypatch.delenv("DMND_SEED_SURVIVOR_CAP")
+    monkeypatch.delenv("DMND_SEED_OVERLAP")
+    ref = np.concatenate([r["hits"] for r in recs])
+    assert len(one_lane) == len(ref) and hit_multiset(one_lane) == hit_multiset(ref)
+
+
 @pytest.mark.parametrize("chunks,bits", [(1, 8), (3, 9), (7, 10)])
 def test_seed_hits_equal_oracle_other_partitionings(ctx, chunks, bits):
     cfg, _ = read_ext_tap(os.path.join(GOLDEN, "ext_fast_synth.tap"), max_records=1)
