@@ -905,7 +905,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 			c->max_query_len = m; c->max_query_len_generation = c->query_generation;
 		}
 		HIP_TRY(sort_seed_hits(c->seed_hits.as<dmnd_seed_hit>(), c->seed_hits_sorted.as<dmnd_seed_hit>(), n, keys, idx, &c->sort_tmp, &c->sort_tmp_bytes, st,
-			bits_of((uint64_t)std::max<size_t>(qlim.size(), 2) - 1), bits_of((uint64_t)c->block_len[DMND_TARGET]), bits_of((uint64_t)c->max_query_len)));
+			bits_of((uint64_t)std::max<size_t>(qlim.size(), 2) - 1), bits_of((uint64_t)c->block_len[DMND_TARGET]), bits_of((uint64_t)c->max_query_len), !sp.use_ungapped));
 		HIP_TRY(sync_stream(st));
 	}
 	lap("hits sorted");

@@ -139,6 +139,6 @@ hipError_t sort_keys_u64(const uint64_t* in, uint64_t* out, int64_t n, void** tm
 // Orders the n seed hits by (query, subject, seed_offset, score) on the device: three stable radix-sort passes over an index
 // permutation (keys/idx: two buffers of n uint64 / uint32 each), then one gather into `out`.
 hipError_t sort_seed_hits(const dmnd_seed_hit* hits, dmnd_seed_hit* out, int64_t n, uint64_t* keys[2], uint32_t* idx[2],
-	void** tmp, size_t* tmp_bytes, hipStream_t st, int query_bits, int subject_bits, int off_bits);      // bits of the largest query id / subject position / seed offset
+	void** tmp, size_t* tmp_bytes, hipStream_t st, int query_bits, int subject_bits, int off_bits, bool equal_scores = false);      // bits of the largest query id / subject position / seed offset; equal_scores: every hit carries the same score (no ungapped filter: --fast), the pass over the scores is left out
 
 }  // namespace dmnd

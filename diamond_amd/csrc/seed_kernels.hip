@@ -1485,15 +1485,24 @@ hipError_t sort_pairs(const uint64_t* kin, uint64_t* kout, const uint32_t* vin, 
 }  // namespace
 
 hipError_t sort_seed_hits(const dmnd_seed_hit* hits, dmnd_seed_hit* out, int64_t n, uint64_t* keys[2], uint32_t* idx[2],
-	void** tmp, size_t* tmp_bytes, hipStream_t st, int query_bits, int subject_bits, int off_bits)
+	void** tmp, size_t* tmp_bytes, hipStream_t st, int query_bits, int subject_bits, int off_bits, bool equal_scores)
 {
 	if (n <= 0) return hipSuccess;
 	const dim3 grid(blocks_for(n, 256)), block(256);
 	hipError_t e;
+	const bool one_key = off_bits >= 1 && off_bits <= 24 && query_bits + subject_bits + off_bits <= 64;
+	if (equal_scores && one_key) {
+		// round 5: without the ungapped filter every hit carries the same score (0xFFFF), the stable pass over the scores orders
+		// nothing: ONE sort of the (query, subject, seed_offset) key from the identity permutation (C2: a key kernel and a sort less)
+		hipLaunchKernelGGL(hit_keys_kernel, grid, block, 0, st, hits, (const uint32_t*)nullptr, n, 3, keys[0], idx[1], subject_bits, off_bits);
+		if ((e = sort_pairs(keys[0], keys[1], idx[1], idx[0], n, query_bits + subject_bits + off_bits, tmp, tmp_bytes, st)) != hipSuccess) return e;
+		hipLaunchKernelGGL(hit_gather_kernel, grid, block, 0, st, hits, (const uint32_t*)idx[0], n, out);
+		return hipGetLastError();
+	}
 	// least significant criterion first; every pass is stable
 	hipLaunchKernelGGL(hit_keys_kernel, grid, block, 0, st, hits, (const uint32_t*)nullptr, n, 0, keys[0], idx[0], 0, 0);
 	if ((e = sort_pairs(keys[0], keys[1], idx[0], idx[1], n, 32, tmp, tmp_bytes, st)) != hipSuccess) return e;
-	if (off_bits >= 1 && off_bits <= 24 && query_bits + subject_bits + off_bits <= 64) {
+	if (one_key) {
 		// (query, subject, seed_offset) as ONE key: a sort less (80 of 250 us for the 2e4 hits of a C2 step)
 		hipLaunchKernelGGL(hit_keys_kernel, grid, block, 0, st, hits, (const uint32_t*)idx[1], n, 3, keys[0], (uint32_t*)nullptr, subject_bits, off_bits);
 		if ((e = sort_pairs(keys[0], keys[1], idx[1], idx[0], n, query_bits + subject_bits + off_bits, tmp, tmp_bytes, st)) != hipSuccess) return e;
