@@ -811,7 +811,9 @@ def main():
                 "predicted_speedup": {str(n): step_now / pred(n, cpus) for n in (2, 4, 8)},
                 "predicted_speedup_with_8_cpus_per_rank": {str(n): step_now / pred(n, 8 * n) for n in (2, 4, 8)},
                 "note": "under this box's CPU quota the extension's host part bounds the 8-GPU run (the same CPU-ms per step shared by all ranks); with 8 host cores per rank the "
-                        "GPU term (the query index every rank builds + its share of the stream and the sweeps) is the bound"}
+                        "GPU term (the query index every rank builds + its share of the stream and the sweeps) is the bound. host_cpu_ms_per_step is that of THIS run's configuration "
+                        "(%d extension contexts, %d host threads); a rank of a multi-rank run extends two batches at a time with its share of the cores and spends less CPU time per step "
+                        "(381 against 470 CPU-ms measured at N = 1, profiles/r05_bench_C5*.json)" % (E, threads)}
         if seed_params.n_shapes > 2:
             out["roofline"]["note"] += ("; with short seeds (weight < 10) this kernel also runs the Hamming filter of every joined (query, reference) "
                                         "position pair, so its launch time covers the join AND the stage-1 filter")
