@@ -17,14 +17,21 @@ below compares this run's records with the reference output produced for `cpu_ba
 
 Batches are pipelined (default; --no-pipeline runs them back to back): the seed stage of batch s+1 runs on a second context
 (own low-priority stream) while batch s is extended -- every batch still passes through the whole path in the timed region.
+Since round 5 consecutive steps search DIFFERENT memory (N = 1, one block per rank): the config's database block and a second one
+holding the same sequences in reverse order alternate, so that no step finds its letters in the 256 MiB Infinity Cache from the step
+before (--same-block: the old behaviour); `ms_per_step` is the mean over the timed region, `ms_per_step_median` the median over
+windows of steps. After the timed steps the step of the DEFAULT command line (tantan + motif masking of both blocks inside the step)
+is timed too and reported as `masked_step`, with its own parity check (--no-masked-step skips it).
 
 value   = GCUPS on the DP cells the device SWEEPS (DpTarget::cells, dp/dp.h:121-124, of every round-1 target; round 2 walks
           the kept traces and sweeps nothing) / wall seconds of the K timed steps, whole job. The reference's own count (both
           rounds swept: what cpu_baseline is quoted on) is reported beside it as `reference_equivalent_gcups`.
 N > 1   : STRONG scaling of the fixed job, database-sharded (SURVEY.md 8e option 2, what BASELINE config C5 names): rank g holds
-          1/N of the reference block and all queries; e-values against the whole database; per step one RCCL all_gather of the
-          ranks' match records and the reference's block join (dmnd_join_blocks) on every rank. --shard query: every rank holds
-          the whole block and 1/N of the queries, no collective on the data path (records are concatenated).
+          1/N of the reference block and all queries; e-values against the whole database; per step the ranks' match records go to
+          the owners of their query ranges in one all-to-all over RCCL, device memory to device memory, are merged there on the device
+          (dmnd_join_blocks_device = the reference's block join) and gathered on rank 0 (multigpu.query_range_join_device; --host-join:
+          the host merge of rounds 3-4). --shard query: every rank holds the whole block and 1/N of the queries, no collective on the
+          data path (records are concatenated).
 
 Prints ONE JSON line on rank 0.
 """
