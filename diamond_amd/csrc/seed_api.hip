@@ -505,6 +505,21 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		if (int rc = c->seed_tfold.ensure((size_t)(n + 1) / 2 + 64)) return rc;
 		HIP_TRY(launch_seed_fold(c->block[DMND_TARGET].as<int8_t>(), n, c->seed_tfold.as<uint8_t>(), st));
 	}
+	// scatter + join instead of the fused by-class kernel (seed_sj_kernels.hip): an experiment, DMND_SEED_SJ=1
+	const bool sj_env = [] { const char* e = getenv("DMND_SEED_SJ"); return e && atoi(e) != 0; }();
+	const bool sj = sj_env && fused && classes && use_tfold && seed_sj_supported(sp) && slots >= 64;
+	SeedSjArgs sja{};
+	if (sj) {
+		sja.n_wg = seed_sj_workgroups(t_begin, t_end);
+		if (int rc = c->seed_sj_slabs.ensure((size_t)sja.n_wg * SEED_SJ_PARTS * SEED_SJ_SLAB * sizeof(SeedSjEntry))) return rc;
+		if (int rc = c->seed_sj_counts.ensure((size_t)sja.n_wg * SEED_SJ_PARTS * sizeof(uint32_t))) return rc;
+		sja.overflow_cap = (int64_t)1 << 22;
+		if (int rc = c->seed_sj_overflow.ensure((size_t)sja.overflow_cap * 2 * sizeof(uint64_t))) return rc;
+		sja.slabs = c->seed_sj_slabs.as<SeedSjEntry>(); sja.counts = c->seed_sj_counts.as<uint32_t>(); sja.overflow = c->seed_sj_overflow.as<uint64_t>();
+		sja.overflow_count = c->counters.as<unsigned long long>() + S + 5;
+		sja.slab_limit = SEED_SJ_SLAB;
+		if (const char* e = getenv("DMND_SEED_SJ_SLAB_LIMIT")) sja.slab_limit = (uint32_t)std::min<long long>(SEED_SJ_SLAB, std::max<long long>(0, atoll(e)));
+	}
 	if (classes) {
 		const int8_t* tseed = (c->soft_valid[DMND_TARGET] && sp.seed_encoding == SEED_SPACED) ? c->soft[DMND_TARGET].as<int8_t>() : c->block[DMND_TARGET].as<int8_t>();
 		const int64_t n = seed_code_groups(t_begin, t_end);
@@ -533,6 +548,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		a.qlist = c->seed_qlist.as<uint32_t>() + (size_t)own * nq_pos;
 		a.slot_mask = slots - 1;
 		a.classes = classes;
+		a.parts = sj ? SEED_SJ_PARTS : 0;
 		a.phase_ticks = phases ? c->counters.as<unsigned long long>() + S + 8 : nullptr;
 		a.tclass = classes ? c->seed_tclass.as<uint16_t>() : nullptr; a.tclass_stride = seed_code_groups(t_begin, t_end);
 		a.tcodes = classes ? c->seed_tcodes.as<uint64_t>() : nullptr; a.tflags = classes ? c->seed_tflags.as<uint32_t>() : nullptr;
@@ -706,7 +722,17 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 					HIP_TRY(hipMemsetAsync(a.survivor_count, 0, sizeof(unsigned long long), st));
 				}
 				tm.start();
-				HIP_TRY(launch_seed_stream(a, sid, st, true));
+				if (sj) {
+					HIP_TRY(hipMemsetAsync(sja.overflow_count, 0, sizeof(unsigned long long), st));
+					HIP_TRY(launch_seed_sj_scatter(a, sja, sid, st));
+					HIP_TRY(launch_seed_sj_join(a, sja, sid, st));
+					unsigned long long spilled = 0;
+					HIP_TRY(copy_now(c->stream, &spilled, sja.overflow_count, sizeof(spilled), hipMemcpyDeviceToHost));
+					if ((int64_t)spilled > sja.overflow_cap) return fail(DMND_E_NOMEM, "dmnd_seed_search: scatter overflow list too small");
+					HIP_TRY(launch_seed_sj_overflow(a, sja, sid, (int64_t)spilled, st));
+					if (lap_on && spilled) std::fprintf(stderr, "dmnd_seed_search: shape %d, %llu windows spilled from full slabs\n", sid, spilled);
+				}
+				else HIP_TRY(launch_seed_stream(a, sid, st, true));
 				c->seed_ms[1] += tm.stop();
 				HIP_TRY(copy_now(c->stream, host_ctr.data(), ctr, host_ctr.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
 				n = host_ctr[sid]; ns = host_ctr[S + 3];

@@ -155,6 +155,30 @@ def test_two_lane_short_seed_pipeline_equals_reference(ctx, tap, enc, monkeypatc
     assert len(one_lane) == len(ref) and hit_multiset(one_lane) == hit_multiset(ref)
 
 
+@pytest.mark.parametrize("tap", ["ext_sensitive.tap", "ext_bjz.tap"])
+def test_scatter_join_short_seed_path_equals_reference(ctx, tap, monkeypatch):
+    """Round 5 experiment, off by default (DMND_SEED_SJ=1, csrc/seed_sj_kernels.hip): the short-seed stream as scatter (level-1
+    positives into per-workgroup slabs of 64 key partitions, no global atomics) + join (a partition's table range at a time).
+    Same hits as the reference and as the fused kernel, also when every slab is too small and all windows take the overflow path."""
+    cfg, recs = read_ext_tap(os.path.join(GOLDEN, tap))
+    ctx.upload_block(hip.QUERY, cfg["query"]["data"], cfg["query"]["limits"])
+    ctx.upload_block(hip.TARGET, cfg["target"]["data"], cfg["target"]["limits"])
+    params = to_hip_params(cfg)
+    fused = ctx.seed_search(params)
+    monkeypatch.setenv("DMND_SEED_SJ", "1")
+    got = ctx.seed_search(params)
+    monkeypatch.setenv("DMND_SEED_SLOTS_X8", "16")
+    monkeypatch.setenv("DMND_SEED_BM1_K", "3")
+    got2 = ctx.seed_search(params)
+    monkeypatch.setenv("DMND_SEED_SJ_SLAB_LIMIT", "2")        # nearly every window spills to the overflow list
+    got3 = ctx.seed_search(params)
+    for k in ("DMND_SEED_SJ", "DMND_SEED_SLOTS_X8", "DMND_SEED_BM1_K", "DMND_SEED_SJ_SLAB_LIMIT"):
+        monkeypatch.delenv(k)
+    ref = np.concatenate([r["hits"] for r in recs])
+    assert len(fused) == len(ref) and hit_multiset(fused) == hit_multiset(ref)
+    assert np.array_equal(got, fused) and np.array_equal(got2, fused) and np.array_equal(got3, fused)
+
+
 @pytest.mark.parametrize("chunks,bits", [(1, 8), (3, 9), (7, 10)])
 def test_seed_hits_equal_oracle_other_partitionings(ctx, chunks, bits):
     cfg, _ = read_ext_tap(os.path.join(GOLDEN, "ext_fast_synth.tap"), max_records=1)
