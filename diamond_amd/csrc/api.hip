@@ -58,7 +58,19 @@ hipError_t dmnd::sync_stream(hipStream_t s)
 		}
 	}
 	const hipError_t e = hipEventRecord(ev, s);
-	return e != hipSuccess ? e : hipEventSynchronize(ev);
+	if (e != hipSuccess) return e;
+	// DMND_SYNC_SPIN_US=n: poll for up to n microseconds before the interrupt-driven wait (a short kernel's count is back before
+	// a sleeping thread would have been woken; the CPU time this can burn is bounded per wait, unlike DMND_SPIN_SYNC)
+	static const int spin_us = [] { const char* v = std::getenv("DMND_SYNC_SPIN_US"); return v ? std::max(0, atoi(v)) : 0; }();
+	if (spin_us > 0) {
+		const auto t0 = std::chrono::steady_clock::now();
+		do {
+			const hipError_t q = hipEventQuery(ev);
+			if (q == hipSuccess) return hipSuccess;
+			if (q != hipErrorNotReady) return q;
+		} while (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() < spin_us);
+	}
+	return hipEventSynchronize(ev);
 }
 
 void dmnd::forget_stream(hipStream_t s)

@@ -258,13 +258,53 @@ extern "C" int dmnd_seed_kernel_ms(const dmnd_ctx* c, double ms[5])
 
 namespace {
 
+// Device time of the phases of a search (dmnd_seed_kernel_ms), WITHOUT a host wait per phase: start / stop only record events on
+// the stream, collect() reads every pair once the search has been waited for anyway. (Until round 5 stop() waited for its event:
+// four host round trips per shape that served nothing but the clock -- an interrupt-driven wake-up and an idle device each,
+// ~0.13 ms of the 2.46 ms a C2 seed stage takes.)
 struct Timer {
-	hipEvent_t a, b;
 	hipStream_t st;
-	Timer(hipStream_t s) : st(s) { (void)hipEventCreate(&a); (void)hipEventCreateWithFlags(&b, spin_sync() ? hipEventDefault : hipEventBlockingSync); }
-	~Timer() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
-	void start() { (void)hipEventRecord(a, st); }
-	double stop() { (void)hipEventRecord(b, st); (void)hipEventSynchronize(b); float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms; }
+	hipEvent_t open = nullptr;
+	struct Span { hipEvent_t a, b; double* into; };
+	std::vector<Span> spans;
+	Timer(hipStream_t s) : st(s) {}
+	~Timer() { if (open) (void)hipEventDestroy(open); for (const Span& x : spans) { (void)hipEventDestroy(x.a); (void)hipEventDestroy(x.b); } }
+	void start()
+	{
+		if (!open) (void)hipEventCreate(&open);
+		(void)hipEventRecord(open, st);
+	}
+	void stop(double& into)
+	{
+		if (!open) return;
+		hipEvent_t b = nullptr;
+		(void)hipEventCreateWithFlags(&b, spin_sync() ? hipEventDefault : hipEventBlockingSync);
+		(void)hipEventRecord(b, st);
+		spans.push_back(Span{ open, b, &into });
+		open = nullptr;
+		if (waits()) collect();
+	}
+	// DMND_SEED_TIMER_WAITS=1: the clock of rounds 1-4 (a host wait behind every phase), for A/B runs
+	static bool waits() { static const bool v = [] { const char* e = std::getenv("DMND_SEED_TIMER_WAITS"); return e && e[0] == '1'; }(); return v; }
+	// a phase that runs again after an overflow: the spans of the abandoned attempt do not count
+	void discard(const double* into)
+	{
+		size_t k = 0;
+		for (const Span& x : spans)
+			if (x.into == into) { (void)hipEventDestroy(x.a); (void)hipEventDestroy(x.b); }
+			else spans[k++] = x;
+		spans.resize(k);
+	}
+	void collect()
+	{
+		if (!spans.empty()) (void)hipEventSynchronize(spans.back().b);
+		for (const Span& x : spans) {
+			float ms = 0;
+			if (hipEventElapsedTime(&ms, x.a, x.b) == hipSuccess) *x.into += ms;
+			(void)hipEventDestroy(x.a); (void)hipEventDestroy(x.b);
+		}
+		spans.clear();
+	}
 };
 
 }
@@ -627,6 +667,8 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		if (overlap) HIP_TRY(hipEventCreateWithFlags(&lane_a_done, hipEventDisableTiming));
 		struct EventGuard { hipEvent_t& e; ~EventGuard() { if (e) (void)hipEventDestroy(e); } } event_guard{ lane_a_done };
 		std::string lane_b_error;
+		unsigned long long hits_seen = 0;                     // the hit counter as lane B last read it; fresh: nothing appended since
+		bool hits_fresh = false;
 		auto lane_b = [&](SeedArgs a, int sid, unsigned long long n, unsigned long long ns) -> int {
 			HIP_TRY(hipSetDevice(c->device));
 			if (overlap) HIP_TRY(hipStreamWaitEvent(sb, lane_a_done, 0));       // recorded behind the shape's mask kernel
@@ -656,12 +698,16 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 				HIP_TRY(launch_seed_clear(zb, sb));
 			}
 			HIP_TRY(launch_seed_post(a, sid, (int64_t)ns, sb, false));
-			c->seed_ms[3] += tmb.stop();
+			tmb.stop(c->seed_ms[3]);
+			hits_fresh = false;
 			if (!sp.use_ungapped) return DMND_OK;
-			unsigned long long nd = 0;
-			HIP_TRY(copy_now(sb, &nd, a.deferred_count, sizeof(nd), hipMemcpyDeviceToHost));
+			// (hits so far, deferred pairs of this shape): neighbours in the counter block, one copy -- and if nothing was deferred, the
+			// hit count of the search's last shape is already the final one
+			unsigned long long both[2] = { 0, 0 };
+			HIP_TRY(copy_now(sb, both, a.hit_count, sizeof(both), hipMemcpyDeviceToHost));
+			const unsigned long long nd = both[1];
 			c->seed_trace[S + sid] = nd;
-			if (nd == 0) return DMND_OK;
+			if (nd == 0) { hits_seen = both[0]; hits_fresh = true; return DMND_OK; }
 			if (int rc = c->seed_eslot.ensure((size_t)n * sizeof(uint64_t))) return rc;
 			if (int rc = c->seed_eloc.ensure((size_t)n * sizeof(uint64_t))) return rc;
 			a.e_key = c->seed_eslot.as<uint64_t>();
@@ -674,7 +720,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 			a.e_key = c->seed_eloc.as<uint64_t>();
 			a.e_n = (int64_t)ne;
 			HIP_TRY(launch_seed_deferred(a, sid, (int64_t)nd, sb));
-			c->seed_ms[3] += tmb.stop();
+			tmb.stop(c->seed_ms[3]);
 			return DMND_OK;
 		};
 		std::thread lane_b_thread;
@@ -704,7 +750,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 				HIP_TRY(launch_seed_clear(z, st));
 			}
 			if (int rc = query_side(a, sid, !index_ready)) return rc;
-			c->seed_ms[0] += tm.stop();
+			tm.stop(c->seed_ms[0]);
 			unsigned long long n = 0, ns = 0;
 			for (int attempt = 0;; ++attempt) {
 				const size_t halves = lanes;
@@ -733,7 +779,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 					if (lap_on && spilled) std::fprintf(stderr, "dmnd_seed_search: shape %d, %llu windows spilled from full slabs\n", sid, spilled);
 				}
 				else HIP_TRY(launch_seed_stream(a, sid, st, true));
-				c->seed_ms[1] += tm.stop();
+				tm.stop(c->seed_ms[1]);
 				HIP_TRY(copy_now(c->stream, host_ctr.data(), ctr, host_ctr.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
 				n = host_ctr[sid]; ns = host_ctr[S + 3];
 				if ((int64_t)n <= m_cap && (int64_t)ns <= surv_cap) break;
@@ -746,7 +792,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 			if (sp.seed_encoding == SEED_SPACED) {
 				tm.start();
 				HIP_TRY(launch_seed_mask(a, sid, st));
-				c->seed_ms[2] += tm.stop();
+				tm.stop(c->seed_ms[2]);
 			}
 			// lane B takes the shape over; it is idle first (so the table set and the buffer halves of shape sid - 1 are free for
 			// shape sid + 1, and lane B's own buffers for this shape)
@@ -757,10 +803,11 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 			lane_b_thread = std::thread([&, a, sid, n, ns] { lane_b_rc = lane_b(a, sid, n, ns); if (lane_b_rc != DMND_OK) lane_b_error = dmnd_last_error(); else if (sync_stream(sb) != hipSuccess) { lane_b_rc = DMND_E_DEVICE; lane_b_error = "dmnd_seed_search: lane B failed"; } });
 		}
 		if (int rc = wait_b()) return rc;
-		unsigned long long nh = 0;
-		HIP_TRY(copy_now(c->stream, &nh, ctr + S, sizeof(nh), hipMemcpyDeviceToHost));
+		unsigned long long nh = hits_seen;
+		if (!hits_fresh) HIP_TRY(copy_now(c->stream, &nh, ctr + S, sizeof(nh), hipMemcpyDeviceToHost));
 		if ((int64_t)nh > hit_cap) return fail(DMND_E_NOMEM, "dmnd_seed_search: hit buffer overflow");
 		c->n_seed_hits = (int64_t)nh;
+		tmb.collect();
 	}
 	else {
 	// phase 1: index + stream + mask, every shape. The joined-position lists of all shapes share one buffer.
@@ -785,10 +832,10 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 			SeedArgs a = args_for(sid, std::max<int64_t>(cap_total - off, 0), std::min(off, cap_total));
 			tm.start();
 			if (int rc = query_side(a, sid, !index_ready || attempt > 0)) return rc;
-			c->seed_ms[0] += tm.stop();
+			tm.stop(c->seed_ms[0]);
 			tm.start();
 			HIP_TRY(launch_seed_stream(a, sid, st));
-			c->seed_ms[1] += tm.stop();
+			tm.stop(c->seed_ms[1]);
 			HIP_TRY(copy_now(c->stream, &counts[sid], a.matched_count, sizeof(unsigned long long), hipMemcpyDeviceToHost));
 			if ((int64_t)counts[sid] > cap_total - off) { overflow = true; off += (int64_t)counts[sid]; continue; }
 			off += (int64_t)counts[sid];
@@ -804,7 +851,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		SeedArgs a = args_for(sid, (int64_t)counts[sid], m_off[sid]);
 		tm.start();
 		HIP_TRY(launch_seed_mask(a, sid, st, (int64_t)counts[sid]));
-		c->seed_ms[2] += tm.stop();
+		tm.stop(c->seed_ms[2]);
 	}
 	if (getenv("DMND_TRACE")) {
 		pristine = false;
@@ -825,8 +872,10 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		if (int rc = c->seed_hits.ensure((size_t)hit_cap * sizeof(dmnd_seed_hit))) return rc;
 		if (int rc = c->seed_deferred.ensure((size_t)def_cap * sizeof(SeedDeferred))) return rc;
 		if (!pristine) HIP_TRY(hipMemsetAsync(c->counters.as<unsigned long long>() + S, 0, sizeof(unsigned long long), st));
-		double ms = 0;
+		if (attempt > 0) tm.discard(&c->seed_ms[3]);
 		bool def_overflow = false;
+		unsigned long long hits_seen = 0;                     // the hit counter as last read with a shape's deferred count; fresh: nothing appended since
+		bool hits_fresh = false;
 		c->seed_trace.assign((size_t)2 * S, 0);
 		unsigned long long def_max = 0;
 		for (int sid = 0; sid < S; ++sid) {
@@ -877,13 +926,17 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 				HIP_TRY(launch_seed_post(a, sid, (int64_t)ns, st, !pristine));
 				pristine = false;                                // from here on the counters hold this shape's numbers
 			}
-			ms += tm.stop();
+			tm.stop(c->seed_ms[3]);
+			hits_fresh = false;
 			if (!sp.use_ungapped) continue;
-			// pairs scoring above 255 (rare): resolve the reference's SIMD-batch saturation rule in a second pass
-			unsigned long long nd = 0;
-			HIP_TRY(copy_now(c->stream, &nd, a.deferred_count, sizeof(nd), hipMemcpyDeviceToHost));
+			// pairs scoring above 255 (rare): resolve the reference's SIMD-batch saturation rule in a second pass.
+			// (hits so far, deferred pairs of this shape) are neighbours in the counter block: one copy, and with nothing deferred
+			// behind the last shape the hit count is final
+			unsigned long long both[2] = { 0, 0 };
+			HIP_TRY(copy_now(c->stream, both, a.hit_count, sizeof(both), hipMemcpyDeviceToHost));
+			const unsigned long long nd = both[1];
 			c->seed_trace[S + sid] = nd;
-			if (nd == 0) continue;
+			if (nd == 0) { hits_seen = both[0]; hits_fresh = true; continue; }
 			def_max = std::max(def_max, nd);
 			if ((int64_t)nd > def_cap) { def_overflow = true; continue; }
 			if (int rc = c->seed_eslot.ensure((size_t)counts[sid] * sizeof(uint64_t))) return rc;      // unsorted keys
@@ -898,11 +951,10 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 			a.e_key = c->seed_eloc.as<uint64_t>();
 			a.e_n = (int64_t)ne;
 			HIP_TRY(launch_seed_deferred(a, sid, (int64_t)nd, st));
-			ms += tm.stop();
+			tm.stop(c->seed_ms[3]);
 		}
-		unsigned long long nh = 0;
-		HIP_TRY(copy_now(c->stream, &nh, c->counters.as<unsigned long long>() + S, sizeof(nh), hipMemcpyDeviceToHost));
-		c->seed_ms[3] = ms;
+		unsigned long long nh = hits_seen;
+		if (!hits_fresh) HIP_TRY(copy_now(c->stream, &nh, c->counters.as<unsigned long long>() + S, sizeof(nh), hipMemcpyDeviceToHost));
 		if ((int64_t)nh <= hit_cap && !def_overflow) { c->n_seed_hits = (int64_t)nh; break; }
 		if (attempt >= 3) return fail(DMND_E_NOMEM, "dmnd_seed_search: hit buffer overflow");
 		if ((int64_t)nh > hit_cap) hit_cap = (int64_t)nh + 1024;
@@ -941,6 +993,7 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		std::fprintf(stderr, "SEED_PHASES (ms of workgroup time, summed): start %.1f | windows %.1f | level 1 %.1f | table %.1f | light lists %.1f | heavy lists %.1f\n",
 			t[0] / 1e5, t[1] / 1e5, t[2] / 1e5, t[3] / 1e5, t[4] / 1e5, t[5] / 1e5);
 	}
+	tm.collect();
 	c->seed_ms[4] = c->seed_ms[0] + c->seed_ms[1] + c->seed_ms[2] + c->seed_ms[3];
 	if (getenv("DMND_TRACE")) {
 		std::fprintf(stderr, "dmnd_seed_search: %d shapes, %lld query positions, joined reference positions per shape:", S, (long long)nq_pos);

@@ -228,11 +228,11 @@ __global__ __launch_bounds__(256) void seed_sj_scatter_kernel(SeedArgs a, SeedSj
 // walking a list (the wavefront waits for its longest: the by-class kernel's lesson) and never a list at a time (the
 // first version filtered the long lists one after the other with the whole workgroup: ~2 us each, 16 per workgroup, most of the
 // kernel's 4.7 ms). A pair reads its reference window from the entry again (L2: the workgroup has just read it).
-__global__ __launch_bounds__(256) void seed_sj_join_kernel(SeedArgs a, SeedSjArgs j, int sid, int64_t base, int units_per_part)
+__global__ __launch_bounds__(256, 8) void seed_sj_join_kernel(SeedArgs a, SeedSjArgs j, int sid, int64_t base, int units_per_part)
 {
 	// (the kernel's time is its workgroups' chains of memory round trips over the workgroups a CU holds: small LDS -- the staging area
 	// is sized to the EXPECTED joins of a unit, 600, with a slow path behind it -- and several independent loads per thread in flight)
-	constexpr unsigned G = SEED_SJ_GROUP, STAGE = 1024, SURV = 256, HEAVY = 128, LIGHT = 8, PAIRS = 2048;
+	constexpr unsigned G = SEED_SJ_GROUP, STAGE = 768, SURV = 192, HEAVY = 96, LIGHT = 8, PAIRS = 1536;
 	__shared__ unsigned pre[G + 1];
 	__shared__ uint32_t st_slot[STAGE], st_pos[STAGE], st_head[STAGE];
 	__shared__ uint16_t st_ent[STAGE], st_count[STAGE];      // entry number in the unit; list size, saturated (a list that long is read back from its slot)
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void seed_sj_join_kernel(SeedArgs a, SeedSjArg
 			if (sj_pair_passes(a, tf, x, base + (int64_t)rel)) survive(slot, x, rel);
 		}
 	};
-	constexpr int B1 = 4;
+	constexpr int B1 = 2;
 	for (unsigned e0 = threadIdx.x; e0 < E; e0 += B1 * 256) {
 		uint2 kp[B1];
 		uint64_t key[B1], slot[B1];
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256) void seed_sj_join_kernel(SeedArgs a, SeedSjArg
 		k = hv_k[lo]; i = q - hv_pre[lo];
 		return true;
 	};
-	constexpr int B3 = 2;
+	constexpr int B3 = 1;
 	for (unsigned p0 = threadIdx.x; p0 < n_all; p0 += B3 * 256) {
 		unsigned k[B3], i[B3];
 		bool on[B3];
