@@ -402,7 +402,7 @@ static int seed_reserve(dmnd_ctx* c, const SeedParams& sp, const SeedSizes& z, i
 	if (int rc = c->qid_of.ensure((size_t)q_end * sizeof(uint32_t))) return rc;
 	if (int rc = c->mask_time.ensure((size_t)q_block_len + 256)) return rc;
 	if (int rc = c->seed_keys.ensure((size_t)z.SB * (z.slots << z.slot_shift))) return rc;
-	if (int rc = c->seed_need.ensure((size_t)(z.slots / 32) * sizeof(uint32_t))) return rc;
+	if (int rc = c->seed_need.ensure((size_t)(z.slots / 32 + SEED_NEED_FOLD_WORDS) * sizeof(uint32_t))) return rc;      // the map and, behind it, its folded copy (launch_seed_collect)
 	if (int rc = c->seed_next.ensure((size_t)z.SB * nq_pos * sizeof(uint32_t))) return rc;        // qslot
 	if (int rc = c->seed_qlist.ensure((size_t)z.SB * nq_pos * sizeof(uint32_t))) return rc;
 	if (int rc = c->seed_qkeys.ensure((size_t)nq_pos * sizeof(uint32_t))) return rc;
@@ -565,8 +565,9 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		const int64_t n = seed_code_groups(t_begin, t_end);
 		if (int rc = c->seed_tcodes.ensure((size_t)n * sizeof(uint64_t))) return rc;
 		if (int rc = c->seed_tflags.ensure((size_t)n * sizeof(uint32_t))) return rc;
-		if (int rc = c->seed_tclass.ensure((size_t)9 * n * sizeof(uint16_t))) return rc;
-		HIP_TRY(launch_seed_codes(sp, tseed, t_begin, t_end, c->seed_tcodes.as<uint64_t>(), c->seed_tflags.as<uint32_t>(), st));
+		if (int rc = c->seed_tplanes.ensure((size_t)n * sizeof(uint64_t))) return rc;
+		if (int rc = c->seed_tclass.ensure((size_t)9 * (size_t)((n + 3) & ~(int64_t)3) * sizeof(uint16_t))) return rc;      // planes of a stride that is a multiple of four groups: 8-byte stores
+		HIP_TRY(launch_seed_codes(sp, tseed, t_begin, t_end, c->seed_tcodes.as<uint64_t>(), c->seed_tflags.as<uint32_t>(), c->seed_tplanes.as<uint64_t>(), st));
 	}
 	const int level2_env = [] { const char* e = getenv("DMND_SEED_LEVEL2"); return e ? atoi(e) : -1; }();
 	auto level2_of = [&](int sid) { return level2_env >= 0 ? level2_env : (sp.shape_weight[sid] >= 10 ? 1 : 0); };
@@ -590,8 +591,8 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		a.classes = classes;
 		a.parts = sj ? SEED_SJ_PARTS : 0;
 		a.phase_ticks = phases ? c->counters.as<unsigned long long>() + S + 8 : nullptr;
-		a.tclass = classes ? c->seed_tclass.as<uint16_t>() : nullptr; a.tclass_stride = seed_code_groups(t_begin, t_end);
-		a.tcodes = classes ? c->seed_tcodes.as<uint64_t>() : nullptr; a.tflags = classes ? c->seed_tflags.as<uint32_t>() : nullptr;
+		a.tclass = classes ? c->seed_tclass.as<uint16_t>() : nullptr; a.tclass_stride = (seed_code_groups(t_begin, t_end) + 3) & ~(int64_t)3;
+		a.tcodes = classes ? c->seed_tcodes.as<uint64_t>() : nullptr; a.tflags = classes ? c->seed_tflags.as<uint32_t>() : nullptr; a.tplanes = classes ? c->seed_tplanes.as<uint64_t>() : nullptr;
 		a.bitmap = c->seed_bitmap.as<uint32_t>() + (size_t)own * (bm_words + bm1_words);
 		a.bitmap_mask = (uint32_t)(bm_words - 1);
 		a.bitmap1 = a.bitmap + bm_words;

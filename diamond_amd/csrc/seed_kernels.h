@@ -54,6 +54,7 @@ struct SeedArgs {
 	// ... and then the reference letters as the stream wants them, made once per search by seed_codes_kernel: per group of 16
 	// letters (from t_begin rounded down to 16) their class nibbles, and delimiter / no-class maps (low / high 16 bits)
 	const uint64_t* tcodes; const uint32_t* tflags;
+	const uint64_t* tplanes;                      // the same class nibbles bit-sliced: bits [16 b, 16 b + 16) = bit b of the group's 16 nibbles (seed_classify_kernel)
 	const uint16_t* tclass; int64_t tclass_stride;  // per shape (seed_classify_kernel): plane c = the valid windows of class c, 16 per entry; plane 8 (hashed seeds): the special ones
 	unsigned long long* phase_ticks;              // DMND_SEED_PHASES=1: 8 counters (seed_stream_fast_kernel PHASE_MARK), else NULL
 	// home slot of a key (hh = seed_hash(key)) and word of its level-1 bits (h = seed_hash_a(key))
@@ -112,6 +113,9 @@ struct SeedClear {
 hipError_t launch_seed_clear(const SeedClear& z, hipStream_t st);
 hipError_t launch_seed_qid(const int64_t* limits, int64_t n_seqs, uint32_t* qid_of, hipStream_t st);
 // scatter + join of the short-seed stream (seed_sj_kernels.hip; DMND_SEED_SJ=1)
+// room for the folded need map that seed_collect's workgroups keep in LDS (2^13 words = 32 KB by default, up to 2^15); it lies behind
+// SeedArgs::need_bits
+enum { SEED_NEED_FOLD_WORDS = 32768 };
 enum { SEED_SJ_PARTS = 64, SEED_SJ_TILES = 4, SEED_SJ_SLAB = 192, SEED_SJ_GROUP = 8 };
 struct SeedSjEntry { uint32_t key32, pos; uint32_t fold[6]; };       // compact key, position relative to the stream's base, 48 folded letters
 struct SeedSjArgs {
@@ -141,7 +145,7 @@ hipError_t launch_seed_reset(const SeedArgs& a, int sid, hipStream_t st);
 hipError_t launch_seed_fold(const int8_t* data, int64_t n, uint8_t* out, hipStream_t st);
 // class nibbles + flag maps of the reference letters [t_begin & ~15, t_end + 32) (SeedArgs::tcodes / tflags); n_groups entries each
 inline int64_t seed_code_groups(int64_t t_begin, int64_t t_end) { return (t_end - (t_begin & ~(int64_t)15) + 15) / 16 + 2; }
-hipError_t launch_seed_codes(const SeedParams& c, const int8_t* tseed, int64_t t_begin, int64_t t_end, uint64_t* codes, uint32_t* flags, hipStream_t st);
+hipError_t launch_seed_codes(const SeedParams& c, const int8_t* tseed, int64_t t_begin, int64_t t_end, uint64_t* codes, uint32_t* flags, uint64_t* planes, hipStream_t st);
 hipError_t launch_seed_stream(const SeedArgs& a, int sid, hipStream_t st, bool fused = false);
 bool seed_stream_can_fuse(const SeedParams& c);
 // n_matched >= 0: the number of joined positions in a.matched_* (few of them: the kernel walks that list instead of the table)

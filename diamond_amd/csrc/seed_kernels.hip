@@ -944,12 +944,58 @@ __global__ __launch_bounds__(256) void seed_pair_tiled_kernel(SeedArgs a, int si
 // The score kernel reads ~100 letters of both sequences one byte at a time with data-dependent bounds: from the blocks that
 // was ~150 L2 requests per survivor; every thread first copies the [-48, +48) surroundings of its pair into LDS with 16-byte
 // loads and the byte-wise code runs on the copies (generic pointers into LDS).
-constexpr int POST_THREADS = 256, POST_BEFORE = 48, POST_LETTERS = 96, POST_STRIDE = 2 * POST_LETTERS + 16;
+constexpr int POST_THREADS = 256, POST_BEFORE = 48, POST_LETTERS = 96;
+
+// stage2_score for windows of at most POST_BEFORE letters to either side, on the 96 letters around the pair held in REGISTERS
+// (qw / sw: 24 dwords each, letter -48 first). Until round 5 the windows were staged in LDS (53 KB per workgroup: three wavefronts
+// per SIMD) and clip_window / ungapped_window_score walked them byte by byte -- three dependent LDS reads per letter, ~14 us of a
+// wavefront's 28 us (profiles/r05_pmc_summary_C3.json: 15 000 x 4 cycles per wavefront for 3 000 instructions). Here the delimiter
+// search is a 96-bit mask, and the score loop is unrolled over all 96 letters with the letters outside [begin, end) neutralised
+// (before the window: +0 keeps the running score at its initial 0; behind it: a large negative resets it without touching the
+// maximum) -- the matrix reads of a thread no longer wait for one another.
+__device__ __forceinline__ int stage2_score_regs(const SeedArgs& a, const int8_t* matrix, uint32_t slot, int64_t sloc, uint32_t x, const uint32_t (&qw)[24], const uint32_t (&sw)[24])
+{
+	const int64_t qp = a.q_begin + x;
+	const uint32_t qid = a.qid_of[qp];
+	const int query_len = (int)(a.qlimits[qid + 1] - a.qlimits[qid] - 1);
+	if (!a.params.use_ungapped) return 0xFFFF;
+	const int cutoff = ungapped_cutoff(a.params, query_len);
+	if (!cutoff) return 0xFFFF;
+	const int window = stage2_window(a.params, query_len);               // <= POST_BEFORE (the caller's test)
+	// clip_window(q - window, 2 window, window): delimiters of the query letters [48 - window, 48 + window) as bits
+	uint64_t lo = 0, hi = 0;
+#pragma unroll
+	for (int i = 0; i < 96; ++i) {
+		const uint64_t d = ((qw[i >> 2] >> (8 * (i & 3))) & 0xffu) == (uint32_t)L_DELIM ? 1u : 0u;
+		if (i < 64) lo |= d << i; else hi |= d << (i - 64);
+	}
+	const uint64_t before = lo & (((uint64_t)1 << 48) - 1) & ~(((uint64_t)1 << (48 - window)) - 1);
+	const int begin = before ? 64 - __builtin_clzll(before) : 48 - window;
+	const uint64_t behind = ((lo >> 48) | (hi << 16)) & (window >= 48 ? ((uint64_t)1 << 48) - 1 : ((uint64_t)1 << window) - 1);
+	const int end = behind ? 48 + __builtin_ctzll(behind) : 48 + window;
+	int score = 0, st = 0;
+#pragma unroll
+	for (int n = 0; n < 96; ++n) {
+		const uint32_t ql = (qw[n >> 2] >> (8 * (n & 3))) & LETTER_MASK, sl = (sw[n >> 2] >> (8 * (n & 3))) & LETTER_MASK;
+		const int m = matrix[ql * 32 + sl];
+		st += n < begin ? 0 : n < end ? m : -(1 << 20);
+		st = imax(st, 0);
+		score = imax(score, st);
+	}
+	if (score > 255) {
+		// saturation depends on the SIMD batch of the reference: second pass (seed_deferred_kernel)
+		const unsigned long long d = atomicAdd(a.deferred_count, 1ull);
+		if (d < (unsigned long long)a.deferred_cap) a.deferred[d] = SeedDeferred{ sloc, slot, x, score, 0 };
+		atomicOr(&a.need_bits[slot >> 5], 1u << (slot & 31));
+		return -1;
+	}
+	return score <= cutoff ? -1 : score;
+}
+
 __global__ __launch_bounds__(POST_THREADS) void seed_score_kernel(SeedArgs a, int sid, int64_t n_survivors)
 {
 	constexpr unsigned STAGE = POST_THREADS;
 	__shared__ int8_t matrix[32 * 32];
-	__shared__ __attribute__((aligned(16))) int8_t win[POST_THREADS * POST_STRIDE];
 	__shared__ SeedScored stage[STAGE];
 	__shared__ unsigned st_n;
 	__shared__ unsigned long long st_base;
@@ -967,17 +1013,16 @@ __global__ __launch_bounds__(POST_THREADS) void seed_score_kernel(SeedArgs a, in
 			// windows wider than the staged stretch (--ungapped-window above 48; short translated frames use their whole length): from the blocks
 			if (a.params.query_translated || a.params.ungapped_window > POST_BEFORE) score = stage2_score(a, matrix, sv.slot, sv.sloc, sv.x, a.qdata + qp, a.tdata + sv.sloc);
 			else {
-				int8_t* lq = win + (size_t)threadIdx.x * POST_STRIDE;
-				int8_t* ls = lq + POST_LETTERS;
+				uint32_t qw[24], sw[24];
 #pragma unroll
 				for (int k = 0; k < POST_LETTERS / 16; ++k) {
 					uint4 v, w;
 					__builtin_memcpy(&v, a.qdata + qp - POST_BEFORE + 16 * k, 16);
 					__builtin_memcpy(&w, a.tdata + sv.sloc - POST_BEFORE + 16 * k, 16);
-					*reinterpret_cast<uint4*>(lq + 16 * k) = v;
-					*reinterpret_cast<uint4*>(ls + 16 * k) = w;
+					qw[4 * k] = v.x; qw[4 * k + 1] = v.y; qw[4 * k + 2] = v.z; qw[4 * k + 3] = v.w;
+					sw[4 * k] = w.x; sw[4 * k + 1] = w.y; sw[4 * k + 2] = w.z; sw[4 * k + 3] = w.w;
 				}
-				score = stage2_score(a, matrix, sv.slot, sv.sloc, sv.x, lq + POST_BEFORE, ls + POST_BEFORE);
+				score = stage2_score_regs(a, matrix, sv.slot, sv.sloc, sv.x, qw, sw);
 			}
 			if (score >= 0)
 				stage[atomicAdd(&st_n, 1u)] = SeedScored{ sv.slot, sv.x, sv.sloc, score, seed_chunk(a.params, seed_of_key(a.params, sid, sl.key)) };
@@ -1118,6 +1163,95 @@ __global__ __launch_bounds__(256) void seed_collect_kernel(SeedArgs a, int64_t n
 	}
 }
 
+// The same for the 10^7-10^8 joined positions of a short-seed shape (C3: 8.1e7 per shape, of which the ~10^4 seeds with a deferred
+// pair own a few thousand). One need_bits test per joined position is one L2 request per position -- the request rate of the L2s,
+// not the 4 bytes per position, set the 0.42 ms the kernel above took there. Here the need map is first folded to 2^18 bits
+// (seed_need_fold_kernel: bit b = OR of the map's bits b + k 2^18), every workgroup keeps the folded map in LDS and walks many
+// tiles; only positions whose folded bit is set (a few per cent) go on to the exact test.
+__global__ void seed_need_fold_kernel(const uint32_t* __restrict__ need_bits, uint64_t words, uint32_t* __restrict__ fold, uint32_t fold_words)
+{
+	const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+	if (w >= fold_words) return;
+	uint32_t x = 0;
+	for (uint64_t i = w; i < words; i += fold_words) x |= need_bits[i];
+	fold[w] = x;
+}
+
+__global__ __launch_bounds__(256) void seed_collect_folded_kernel(SeedArgs a, int64_t n_matched, const uint32_t* __restrict__ fold, uint32_t fold_words)
+{
+	constexpr int PER = 16;
+	constexpr unsigned HOLD = 1024;                        // wanted entries a workgroup keeps before it claims room in the output
+	extern __shared__ uint32_t filt[];                     // fold_words (a power of two) words
+	__shared__ uint64_t held[HOLD];
+	__shared__ unsigned n_local, n_held;
+	__shared__ unsigned long long base;
+	for (uint32_t i = threadIdx.x * 4; i < fold_words; i += 256 * 4)
+		*reinterpret_cast<uint4*>(&filt[i]) = *reinterpret_cast<const uint4*>(&fold[i]);
+	if (threadIdx.x == 0) n_held = 0;
+	// the held entries go out: ONE returning atomic on the shared counter (a memory-side round trip the whole workgroup waits for --
+	// per tile, as the kernel above does it, that wait was most of a tile's time here: nearly every tile of a short-seed shape holds
+	// a wanted position)
+	auto flush = [&]() {                                   // (called by all threads)
+		__syncthreads();
+		const unsigned n = n_held;
+		if (n == 0) return;
+		if (threadIdx.x == 0) base = atomicAdd(a.e_count, (unsigned long long)n);
+		__syncthreads();
+		for (unsigned i = threadIdx.x; i < n; i += 256) a.e_key[base + i] = held[i];
+		__syncthreads();
+		if (threadIdx.x == 0) n_held = 0;
+		__syncthreads();
+	};
+	const int64_t tiles = (n_matched + 256 * PER - 1) / (256 * PER);
+	for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+		__syncthreads();                                   // the filter is filled; the previous tile's counters have been read
+		if (threadIdx.x == 0) n_local = 0;
+		__syncthreads();
+		const int64_t m0 = tile * (256 * PER) + threadIdx.x;
+		uint32_t slot[PER];
+#pragma unroll
+		for (int j = 0; j < PER; ++j) {
+			const int64_t m = m0 + (int64_t)j * 256;
+			slot[j] = m < n_matched ? a.matched_slot[m] : 0xffffffffu;
+		}
+		// folded test of all sixteen first, then the exact words of the few candidates as independent loads behind one wait
+		uint32_t cand = 0;
+#pragma unroll
+		for (int j = 0; j < PER; ++j)
+			cand |= (slot[j] != 0xffffffffu ? (filt[(slot[j] >> 5) & (fold_words - 1)] >> (slot[j] & 31)) & 1u : 0u) << j;
+		uint32_t exact[PER];
+#pragma unroll
+		for (int j = 0; j < PER; ++j) exact[j] = (cand >> j) & 1u ? a.need_bits[slot[j] >> 5] : 0u;
+		uint32_t mine = 0;
+#pragma unroll
+		for (int j = 0; j < PER; ++j) mine |= ((exact[j] >> (slot[j] & 31)) & 1u) << j;
+		unsigned off = mine ? atomicAdd(&n_local, (unsigned)__builtin_popcount(mine)) : 0u;
+		__syncthreads();
+		const unsigned n = n_local;
+		if (n == 0) continue;
+		if (n > HOLD) {                                       // a tile of wanted positions only: straight to the output
+			if (threadIdx.x == 0) base = atomicAdd(a.e_count, (unsigned long long)n);
+			__syncthreads();
+			while (mine) {
+				const int j = __builtin_ctz(mine);
+				mine &= mine - 1;
+				a.e_key[base + off++] = ((uint64_t)slot[j] << 40) | (uint64_t)a.matched_loc[m0 + (int64_t)j * 256];
+			}
+			continue;
+		}
+		if (n_held + n > HOLD) flush();                     // (uniform: n_held only changes between barriers)
+		const unsigned at = n_held;
+		while (mine) {
+			const int j = __builtin_ctz(mine);
+			mine &= mine - 1;
+			held[at + off++] = ((uint64_t)slot[j] << 40) | (uint64_t)a.matched_loc[m0 + (int64_t)j * 256];
+		}
+		__syncthreads();
+		if (threadIdx.x == 0) n_held = at + n;
+	}
+	flush();
+}
+
 // One wavefront per deferred pair: the lanes share the scan over the tile of the seed's joined positions (up to tile_size
 // Hamming comparisons at random places of the reference -- as one thread's loop that was a 0.7 ms tail per shape for 10^4 pairs).
 // Same arithmetic as simd_batch_size_sorted (seed_core.h), which the CPU emulation of this kernel uses.
@@ -1129,21 +1263,28 @@ __global__ __launch_bounds__(256) void seed_deferred_kernel(SeedArgs a, int sid,
 	const SeedDeferred r = a.deferred[d];
 	const uint32_t slot = r.slot;
 	const int64_t sloc = r.sloc;
-	// the seed's joined positions: range of `slot` in the sorted copy
-	int64_t lo = 0, hi = a.e_n;
-	while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((uint32_t)(a.e_key[mid] >> 40) < slot) lo = mid + 1; else hi = mid; }
-	const int64_t b = lo;
-	hi = a.e_n;
-	while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((uint32_t)(a.e_key[mid] >> 40) <= slot) lo = mid + 1; else hi = mid; }
-	const uint64_t* locs = a.e_key + b;
-	const int64_t n = lo - b;
+	// the seed's joined positions: range of `slot` in the sorted copy. The keys are sorted by (slot, position), so all three searches
+	// are lower bounds of a 64-bit key; the 64 lanes probe 64 places of the range at a time (three rounds for 2.5e5 keys where the
+	// one-probe-per-round search, which every lane used to repeat for itself, made eighteen dependent reads)
 	const uint64_t LOC = ((uint64_t)1 << 40) - 1;
+	auto lower_bound64 = [&](int64_t lo, int64_t hi, uint64_t key) -> int64_t {       // first index in [lo, hi) whose key is >= `key`
+		while (hi - lo > 64) {
+			const int64_t chunk = (hi - lo + 63) >> 6, at = lo + (int64_t)lane * chunk;
+			const int c = __builtin_popcountll(__ballot(at < hi && a.e_key[at] < key));      // the first c probes lie below the key
+			const int64_t new_hi = c < 64 ? (lo + (int64_t)c * chunk < hi ? lo + (int64_t)c * chunk : hi) : hi;
+			lo = c > 0 ? lo + (int64_t)(c - 1) * chunk + 1 : lo;
+			hi = c > 0 ? new_hi : lo;
+		}
+		return lo + __builtin_popcountll(__ballot(lo + lane < hi && a.e_key[lo + lane] < key));
+	};
+	const int64_t b = lower_bound64(0, a.e_n, (uint64_t)slot << 40);
+	const int64_t e = lower_bound64(b, a.e_n, ((uint64_t)slot + 1) << 40);
+	const uint64_t* locs = a.e_key + b;
+	const int64_t n = e - b;
 	const int64_t qp = a.q_begin + r.x;
 	const int8_t* q = a.qdata + qp;
 	const int8_t* s = a.tdata + sloc;
-	int64_t rlo = 0, rhi = n;                             // rank = number of positions < sloc
-	while (rlo < rhi) { const int64_t mid = (rlo + rhi) >> 1; if ((int64_t)(locs[mid] & LOC) < sloc) rlo = mid + 1; else rhi = mid; }
-	const int64_t rank = rlo, T = a.params.tile_size;
+	const int64_t rank = lower_bound64(b, e, ((uint64_t)slot << 40) | (uint64_t)sloc) - b, T = a.params.tile_size;      // rank = number of positions < sloc
 	int64_t t_lo = 0, t_hi = n;
 	if (T > 0 && n > T) { t_lo = rank / T * T; t_hi = t_lo + T < n ? t_lo + T : n; }
 	int L = 0, rr = 0;
@@ -1192,7 +1333,8 @@ hipError_t launch_seed_soft_time(const SeedArgs& a, hipStream_t st)
 
 // class nibbles and flag maps of 16 reference letters (the decode of seed_stream_fast_kernel, once per search instead of once per
 // shape and class)
-__global__ void seed_codes_kernel(const int8_t* __restrict__ tseed, int64_t base, int64_t n_groups, uint64_t map_lo, uint64_t map_hi, int hashed, uint64_t* __restrict__ codes, uint32_t* __restrict__ flags)
+__global__ void seed_codes_kernel(const int8_t* __restrict__ tseed, int64_t base, int64_t n_groups, uint64_t map_lo, uint64_t map_hi, int hashed, uint64_t* __restrict__ codes, uint32_t* __restrict__ flags,
+	uint64_t* __restrict__ planes)
 {
 	const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (g >= n_groups) return;
@@ -1200,20 +1342,24 @@ __global__ void seed_codes_kernel(const int8_t* __restrict__ tseed, int64_t base
 	const u32x4 v = *reinterpret_cast<const u32x4*>(tseed + base + 16 * g);
 	const uint32_t w[4] = { v.x, v.y, v.z, v.w };
 	uint64_t code = 0;
-	uint32_t delim = 0, bad = 0;
+	uint32_t delim = 0, bad = 0, p01 = 0, p23 = 0;          // bit planes 0 | 1 << 16 and 2 | 3 << 16 of the nibbles
 #pragma unroll
 	for (int j = 0; j < 16; ++j) {
 		const uint32_t l = (w[j >> 2] >> ((j & 3) * 8)) & LETTER_MASK;
 		const uint32_t c = reduce4(l, map_lo, map_hi);
-		code |= (uint64_t)(hashed && c == 15u ? 0u : c) << (j * 4);
+		const uint32_t stored = hashed && c == 15u ? 0u : c;
+		code |= (uint64_t)stored << (j * 4);
+		p01 |= ((stored & 1u) | ((stored & 2u) << 15)) << j;
+		p23 |= (((stored >> 2) & 1u) | ((stored & 8u) << 13)) << j;
 		delim |= (l == L_DELIM ? 1u : 0u) << j;
 		bad |= (c == 15u ? 1u : 0u) << j;
 	}
 	codes[g] = code;
 	flags[g] = delim | (bad << 16);
+	planes[g] = (uint64_t)p01 | ((uint64_t)p23 << 32);
 }
 
-hipError_t launch_seed_codes(const SeedParams& c, const int8_t* tseed, int64_t t_begin, int64_t t_end, uint64_t* codes, uint32_t* flags, hipStream_t st)
+hipError_t launch_seed_codes(const SeedParams& c, const int8_t* tseed, int64_t t_begin, int64_t t_end, uint64_t* codes, uint32_t* flags, uint64_t* planes, hipStream_t st)
 {
 	uint64_t lo = 0, hi = 0;
 	for (int l = 0; l < 32; ++l) {
@@ -1221,38 +1367,89 @@ hipError_t launch_seed_codes(const SeedParams& c, const int8_t* tseed, int64_t t
 		(l < 16 ? lo : hi) |= code << ((l & 15) * 4);
 	}
 	const int64_t n = seed_code_groups(t_begin, t_end);
-	hipLaunchKernelGGL(seed_codes_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, tseed, t_begin & ~(int64_t)15, n, lo, hi, c.seed_encoding == SEED_HASHED ? 1 : 0, codes, flags);
+	hipLaunchKernelGGL(seed_codes_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, tseed, t_begin & ~(int64_t)15, n, lo, hi, c.seed_encoding == SEED_HASHED ? 1 : 0, codes, flags, planes);
 	return hipGetLastError();
 }
 
 // Per shape: which windows are valid seeds, and of which key class -- one 16-bit map per group of 16 window starts and class (plane c
 // of `out`; plane 8: the HASHED mode's windows with a mask / stop letter). The eight class workgroups of the stream then read a map
 // instead of each evaluating every window (that alone was 46 of 124 s of workgroup time over the 16 shapes of C3).
-__global__ void seed_classify_kernel(SeedArgs a, int sid, int64_t base, int64_t n_groups, uint64_t care64, int hashed, uint16_t* __restrict__ out)
+// Round 5: all 16 windows of a group at once, on bit planes. seed_class is GF(2)-linear in the key (shifts and XORs only), so the
+// class of the window at w is the XOR over the shape's care positions i and the four nibble bits b of
+// [bit b of letter w + i] * seed_class(1 << (4 i + b)): with the letters' nibbles bit-sliced (SeedArgs::tplanes), bit j of the class
+// of all 16 windows is an XOR of shifted planes, and the "valid window" tests are ORs of shifted delimiter / bad-letter maps.
+// ~150 integer operations per group where the window-by-window form spent ~1000; with the 8-byte stores below 0.335 -> 0.28 ms per
+// shape and 3e8 letters (C3; neither change alone moved it by more than 0.03 ms).
+struct SeedClassCoef { int n; int8_t pos[16]; uint16_t coef[16]; };       // per care position: its offset, and seed_class(1 << (4 pos + b)) << (3 b), b = 0..3
+// Four consecutive groups per thread: a plane is written as one 8-byte store per thread (the planes' stride is a multiple of four
+// groups, seed_api.hip) -- with the arithmetic gone the kernel is its stores, 16 B out against 12 B in per group.
+__global__ __launch_bounds__(256) void seed_classify_kernel(SeedArgs a, int sid, int64_t base, int64_t n_groups, SeedClassCoef cc, int hashed, uint16_t* __restrict__ out)
 {
-	const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (g >= n_groups) return;
-	const int64_t p0 = base + 16 * g;
-	const uint64_t c0 = a.tcodes[g], c1 = g + 1 < n_groups ? a.tcodes[g + 1] : 0;
-	const uint32_t f0 = a.tflags[g], f1 = g + 1 < n_groups ? a.tflags[g + 1] : 0xffffu;
-	const uint32_t delim = (f0 & 0xffffu) | (f1 << 16), bad = (f0 >> 16) | (f1 & 0xffff0000u);
-	const int len = a.params.shape_len[sid];
-	const uint32_t care = a.params.shape_mask[sid], span = (1u << len) - 1;
-	const int64_t first = a.t_begin - p0, last = a.t_end - p0;
-	uint32_t m[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-#pragma unroll
-	for (int w0 = 0; w0 < 16; ++w0) {
-		const bool inside = w0 >= first && w0 < last && ((delim >> w0) & span) == 0;
-		const bool ok = inside && ((bad >> w0) & (hashed ? span : care)) == 0;
-		const int sh = w0 * 4;
-		const uint64_t key = (sh == 0 ? c0 : (c0 >> sh) | (c1 << (64 - sh))) & care64;
-		const uint32_t cls = seed_class(key);
-#pragma unroll
-		for (int c = 0; c < 8; ++c) m[c] |= (ok && cls == (uint32_t)c ? 1u : 0u) << w0;
-		m[8] |= (hashed && inside && !ok ? 1u : 0u) << w0;
+	const int64_t g0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+	if (g0 >= n_groups) return;
+	// the thread's four groups and the one behind them (their windows reach into it)
+	uint64_t q[5];
+	uint32_t f[5];
+	if (g0 + 4 <= n_groups) {
+		typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+		typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+		const u64x2 x = *reinterpret_cast<const u64x2*>(a.tplanes + g0), y = *reinterpret_cast<const u64x2*>(a.tplanes + g0 + 2);
+		const u32x4 z = *reinterpret_cast<const u32x4*>(a.tflags + g0);
+		q[0] = x.x; q[1] = x.y; q[2] = y.x; q[3] = y.y;
+		f[0] = z.x; f[1] = z.y; f[2] = z.z; f[3] = z.w;
+		q[4] = g0 + 4 < n_groups ? a.tplanes[g0 + 4] : 0;
+		f[4] = g0 + 4 < n_groups ? a.tflags[g0 + 4] : 0xffffu;
 	}
+	else {
 #pragma unroll
-	for (int c = 0; c < 9; ++c) if (c < 8 || hashed) out[(int64_t)c * n_groups + g] = (uint16_t)m[c];
+		for (int k = 0; k < 5; ++k) { q[k] = g0 + k < n_groups ? a.tplanes[g0 + k] : 0; f[k] = g0 + k < n_groups ? a.tflags[g0 + k] : 0xffffu; }
+	}
+	const int len = a.params.shape_len[sid];
+	uint64_t m[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+#pragma unroll
+	for (int t = 0; t < 4; ++t) {
+		const int64_t p0 = base + 16 * (g0 + t);
+		const uint64_t q0 = q[t], q1 = q[t + 1];
+		const uint32_t f0 = f[t], f1 = f[t + 1];
+		const uint32_t delim = (f0 & 0xffffu) | (f1 << 16), bad = (f0 >> 16) | (f1 & 0xffff0000u);
+		uint32_t plane[4];                                  // bit u = bit b of the nibble of letter p0 + u, u < 32
+#pragma unroll
+		for (int b = 0; b < 4; ++b) plane[b] = (uint32_t)((q0 >> (16 * b)) & 0xffffu) | ((uint32_t)((q1 >> (16 * b)) & 0xffffu) << 16);
+		uint32_t cls[3] = { 0, 0, 0 };
+		uint32_t bad_any = 0;                               // bit w: a mask / stop letter at a care position of window w
+		for (int k = 0; k < cc.n; ++k) {                    // (uniform: scalar branches)
+			const int i = cc.pos[k];
+			const uint32_t coef = cc.coef[k];
+#pragma unroll
+			for (int b = 0; b < 4; ++b) {
+				const uint32_t x = plane[b] >> i;
+#pragma unroll
+				for (int j = 0; j < 3; ++j) if ((coef >> (3 * b + j)) & 1u) cls[j] ^= x;
+			}
+			bad_any |= bad >> i;
+		}
+		uint32_t delim_any = 0, bad_span = 0;               // bit w: a delimiter / a bad letter among the window's len letters
+		for (int i = 0; i < len; ++i) { delim_any |= delim >> i; bad_span |= bad >> i; }
+		const int64_t first = a.t_begin - p0, last = a.t_end - p0;
+		const uint32_t from = first <= 0 ? 0xffffu : first >= 16 ? 0u : (0xffffu << first) & 0xffffu;
+		const uint32_t to = last >= 16 ? 0xffffu : last <= 0 ? 0u : (1u << last) - 1;
+		const uint32_t inside = g0 + t < n_groups ? from & to & ~delim_any & 0xffffu : 0u;
+		const uint32_t ok = inside & ~(hashed ? bad_span : bad_any);
+#pragma unroll
+		for (int c = 0; c < 8; ++c) {
+			const uint32_t eq = (c & 1 ? cls[0] : ~cls[0]) & (c & 2 ? cls[1] : ~cls[1]) & (c & 4 ? cls[2] : ~cls[2]);
+			m[c] |= (uint64_t)(ok & eq) << (16 * t);
+		}
+		m[8] |= (uint64_t)(inside & ~ok) << (16 * t);
+	}
+	const bool whole = g0 + 4 <= n_groups && (a.tclass_stride & 3) == 0;
+#pragma unroll
+	for (int c = 0; c < 9; ++c) {
+		if (c == 8 && !hashed) break;
+		uint16_t* o = out + (int64_t)c * a.tclass_stride + g0;
+		if (whole) *reinterpret_cast<uint64_t*>(o) = m[c];
+		else for (int t = 0; t < 4 && g0 + t < n_groups; ++t) o[t] = (uint16_t)(m[c] >> (16 * t));
+	}
 }
 
 hipError_t launch_seed_fold(const int8_t* data, int64_t n, uint8_t* out, hipStream_t st)
@@ -1335,7 +1532,16 @@ hipError_t launch_seed_stream(const SeedArgs& a, int sid, hipStream_t st, bool f
 		const bool by_class = a.classes != 0;               // the fused pipeline, or long seeds against a large query block (seed_api.hip)
 		if (by_class) {
 			const int64_t n_groups = seed_code_groups(a.t_begin, a.t_end);
-			hipLaunchKernelGGL(seed_classify_kernel, dim3(blocks_for(n_groups, 256)), dim3(256), 0, st, a, sid, base, n_groups, care64, hashed ? 1 : 0, const_cast<uint16_t*>(a.tclass));
+			SeedClassCoef cc;
+			cc.n = 0;
+			for (int k = 0; k < 16; ++k) { cc.pos[k] = 0; cc.coef[k] = 0; }
+			for (int i = 0; i < 16; ++i) {
+				if (!((care64 >> (4 * i)) & 15u)) continue;
+				cc.pos[cc.n] = (int8_t)i;
+				for (int b = 0; b < 4; ++b) cc.coef[cc.n] |= (uint16_t)(seed_class((uint64_t)1 << (4 * i + b)) << (3 * b));
+				++cc.n;
+			}
+			hipLaunchKernelGGL(seed_classify_kernel, dim3(blocks_for((n_groups + 3) / 4, 256)), dim3(256), 0, st, a, sid, base, n_groups, cc, hashed ? 1 : 0, const_cast<uint16_t*>(a.tclass));
 		}
 		if (fused && a.classes && hashed) hipLaunchKernelGGL((seed_stream_fast_kernel<false, true, true, true>), grid, block, 0, st, a, sid, lo, hi, base, care64);
 		else if (fused && a.classes) hipLaunchKernelGGL((seed_stream_fast_kernel<false, false, true, true>), grid, block, 0, st, a, sid, lo, hi, base, care64);
@@ -1427,6 +1633,23 @@ hipError_t sort_matched_by_slot(const uint32_t* slot_in, uint32_t* slot_out, con
 hipError_t launch_seed_collect(const SeedArgs& a, int64_t n_matched, hipStream_t st)
 {
 	if (n_matched == 0) return hipSuccess;
+	const char* folded_env = getenv("DMND_SEED_COLLECT_FOLDED_FROM");                  // (tests: 1 = always)
+	const int64_t folded_from = folded_env ? (int64_t)atoll(folded_env) : (int64_t)1 << 22;
+	if (n_matched >= folded_from) {
+		const uint64_t words = (a.slot_mask + 1) / 32;
+		uint32_t* fold = a.need_bits + words;              // (seed_api.hip sizes the map's buffer for it)
+		const char* fold_env = getenv("DMND_SEED_NEED_FOLD_LOG2");
+		const uint32_t fold_words = 1u << std::min(15, std::max(8, fold_env ? atoi(fold_env) : 13));      // <= SEED_NEED_FOLD_WORDS
+		hipLaunchKernelGGL(seed_need_fold_kernel, dim3(fold_words / 256), dim3(256), 0, st, (const uint32_t*)a.need_bits, words, fold, fold_words);
+		const unsigned tiles = blocks_for(n_matched, 256 * 16);
+		const unsigned per_cu = std::max(1u, std::min(4u, (150u * 1024u) / (fold_words * 4u + 64u)));
+		if (fold_words * sizeof(uint32_t) > 48 * 1024) {
+			const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(seed_collect_folded_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(fold_words * sizeof(uint32_t)));
+			if (e != hipSuccess) return e;
+		}
+		hipLaunchKernelGGL(seed_collect_folded_kernel, dim3(std::min(tiles, 256u * per_cu)), dim3(256), fold_words * sizeof(uint32_t), st, a, n_matched, (const uint32_t*)fold, fold_words);
+		return hipGetLastError();
+	}
 	hipLaunchKernelGGL(seed_collect_kernel, dim3(blocks_for(n_matched, 256 * 16)), dim3(256), 0, st, a, n_matched);
 	return hipGetLastError();
 }

@@ -92,6 +92,27 @@ def test_buffer_overflow_retry_paths_are_transparent(ctx, monkeypatch):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("tap,tiled", [("ext_default.tap", "0"), ("ext_default.tap", "1"), ("ext_sensitive.tap", "0")])
+def test_folded_need_map_of_the_deferred_pass_equals_reference(ctx, tap, tiled, monkeypatch):
+    """Round 5: the deferred pass gathers the joined positions of the seeds that have a deferred pair through a folded copy of the
+    need map kept in LDS (taken by itself from 4 M joined positions per shape: C3) -- forced on the goldens that have deferred
+    pairs, long seeds (plain and tiled pair filter) and short: the hits equal the plain gather's and the reference's."""
+    cfg, recs = read_ext_tap(os.path.join(GOLDEN, tap))
+    ctx.upload_block(hip.QUERY, cfg["query"]["data"], cfg["query"]["limits"])
+    ctx.upload_block(hip.TARGET, cfg["target"]["data"], cfg["target"]["limits"])
+    monkeypatch.setenv("DMND_SEED_TILED", tiled)
+    monkeypatch.setenv("DMND_SEED_COLLECT_FOLDED_FROM", str(1 << 60))
+    plain = ctx.seed_search(to_hip_params(cfg))
+    monkeypatch.setenv("DMND_SEED_COLLECT_FOLDED_FROM", "1")
+    hits = ctx.seed_search(to_hip_params(cfg))
+    monkeypatch.delenv("DMND_SEED_COLLECT_FOLDED_FROM")
+    monkeypatch.delenv("DMND_SEED_TILED")
+    assert (plain["score"] >= 255).any()                       # the deferred pass ran
+    ref = np.concatenate([r["hits"] for r in recs])
+    assert len(hits) == len(ref) and hit_multiset(hits) == hit_multiset(ref)
+    assert np.array_equal(hits, plain)
+
+
 @pytest.mark.parametrize("tap", ["ext_fast_synth.tap", "ext_default.tap", "ext_sensitive.tap", "ext_blastx.tap", "ext_rank.tap"])
 def test_tiled_pair_filter_equals_reference(ctx, tap, monkeypatch):
     """The LDS-tiled pair filter (joined positions sorted by seed; normally chosen for >= 4 M joined positions per shape)
