@@ -1380,7 +1380,9 @@ hipError_t launch_seed_codes(const SeedParams& c, const int8_t* tseed, int64_t t
 // of all 16 windows is an XOR of shifted planes, and the "valid window" tests are ORs of shifted delimiter / bad-letter maps.
 // ~150 integer operations per group where the window-by-window form spent ~1000; with the 8-byte stores below 0.335 -> 0.28 ms per
 // shape and 3e8 letters (C3; neither change alone moved it by more than 0.03 ms).
-struct SeedClassCoef { int n; int8_t pos[16]; uint16_t coef[16]; };       // per care position: its offset, and seed_class(1 << (4 pos + b)) << (3 b), b = 0..3
+// The care positions grouped by their coefficient word coef = seed_class(1 << (4 pos + b)) << (3 b), b = 0..3 (seed_class has two: nibbles
+// 0 and 8 of the key, and the rest): the planes of a group's positions are XORed first, the coefficients applied once per group.
+struct SeedClassCoef { int n, n_groups; int8_t pos[16]; int8_t start[17]; uint16_t coef[16]; };       // group t = pos[start[t] .. start[t + 1])
 // Four consecutive groups per thread: a plane is written as one 8-byte store per thread (the planes' stride is a multiple of four
 // groups, seed_api.hip) -- with the arithmetic gone the kernel is its stores, 16 B out against 12 B in per group.
 __global__ __launch_bounds__(256) void seed_classify_kernel(SeedArgs a, int sid, int64_t base, int64_t n_groups, SeedClassCoef cc, int hashed, uint16_t* __restrict__ out)
@@ -1417,19 +1419,26 @@ __global__ __launch_bounds__(256) void seed_classify_kernel(SeedArgs a, int sid,
 		for (int b = 0; b < 4; ++b) plane[b] = (uint32_t)((q0 >> (16 * b)) & 0xffffu) | ((uint32_t)((q1 >> (16 * b)) & 0xffffu) << 16);
 		uint32_t cls[3] = { 0, 0, 0 };
 		uint32_t bad_any = 0;                               // bit w: a mask / stop letter at a care position of window w
-		for (int k = 0; k < cc.n; ++k) {                    // (uniform: scalar branches)
-			const int i = cc.pos[k];
-			const uint32_t coef = cc.coef[k];
+		for (int grp = 0; grp < cc.n_groups; ++grp) {       // (uniform: scalar loop control and branches)
+			uint32_t sum[4] = { 0, 0, 0, 0 };
+			for (int k = cc.start[grp]; k < cc.start[grp + 1]; ++k) {
+				const int i = cc.pos[k];
 #pragma unroll
-			for (int b = 0; b < 4; ++b) {
-				const uint32_t x = plane[b] >> i;
-#pragma unroll
-				for (int j = 0; j < 3; ++j) if ((coef >> (3 * b + j)) & 1u) cls[j] ^= x;
+				for (int b = 0; b < 4; ++b) sum[b] ^= plane[b] >> i;
+				bad_any |= bad >> i;
 			}
-			bad_any |= bad >> i;
+			const uint32_t coef = cc.coef[grp];
+#pragma unroll
+			for (int b = 0; b < 4; ++b)
+#pragma unroll
+				for (int j = 0; j < 3; ++j) if ((coef >> (3 * b + j)) & 1u) cls[j] ^= sum[b];
 		}
-		uint32_t delim_any = 0, bad_span = 0;               // bit w: a delimiter / a bad letter among the window's len letters
-		for (int i = 0; i < len; ++i) { delim_any |= delim >> i; bad_span |= bad >> i; }
+		// bit w: a delimiter / a bad letter among the window's len letters: [w, w + len) = [w, w + p) u [w + len - p, w + len), p = the
+		// largest power of two <= len, and runs of p by doubling
+		uint32_t delim_any = delim, bad_span = bad;
+		int p = 1;
+		while (2 * p <= len) { delim_any |= delim_any >> p; bad_span |= bad_span >> p; p *= 2; }
+		delim_any |= delim_any >> (len - p); bad_span |= bad_span >> (len - p);
 		const int64_t first = a.t_begin - p0, last = a.t_end - p0;
 		const uint32_t from = first <= 0 ? 0xffffu : first >= 16 ? 0u : (0xffffu << first) & 0xffffu;
 		const uint32_t to = last >= 16 ? 0xffffu : last <= 0 ? 0u : (1u << last) - 1;
@@ -1533,13 +1542,24 @@ hipError_t launch_seed_stream(const SeedArgs& a, int sid, hipStream_t st, bool f
 		if (by_class) {
 			const int64_t n_groups = seed_code_groups(a.t_begin, a.t_end);
 			SeedClassCoef cc;
-			cc.n = 0;
-			for (int k = 0; k < 16; ++k) { cc.pos[k] = 0; cc.coef[k] = 0; }
+			cc.n = 0; cc.n_groups = 0;
+			for (int k = 0; k < 16; ++k) { cc.pos[k] = 0; cc.coef[k] = 0; cc.start[k] = 0; }
+			cc.start[16] = 0;
+			uint16_t coef_of[16];
 			for (int i = 0; i < 16; ++i) {
+				coef_of[i] = 0;
+				for (int b = 0; b < 4; ++b) coef_of[i] |= (uint16_t)(seed_class((uint64_t)1 << (4 * i + b)) << (3 * b));
+			}
+			for (int i = 0; i < 16; ++i) {                      // a group per distinct coefficient word, in order of first appearance
 				if (!((care64 >> (4 * i)) & 15u)) continue;
-				cc.pos[cc.n] = (int8_t)i;
-				for (int b = 0; b < 4; ++b) cc.coef[cc.n] |= (uint16_t)(seed_class((uint64_t)1 << (4 * i + b)) << (3 * b));
-				++cc.n;
+				bool seen = false;
+				for (int t = 0; t < cc.n_groups; ++t) seen = seen || cc.coef[t] == coef_of[i];
+				if (seen) continue;
+				cc.coef[cc.n_groups] = coef_of[i];
+				cc.start[cc.n_groups] = (int8_t)cc.n;
+				for (int i2 = i; i2 < 16; ++i2)
+					if (((care64 >> (4 * i2)) & 15u) && coef_of[i2] == coef_of[i]) cc.pos[cc.n++] = (int8_t)i2;
+				cc.start[++cc.n_groups] = (int8_t)cc.n;
 			}
 			hipLaunchKernelGGL(seed_classify_kernel, dim3(blocks_for((n_groups + 3) / 4, 256)), dim3(256), 0, st, a, sid, base, n_groups, cc, hashed ? 1 : 0, const_cast<uint16_t*>(a.tclass));
 		}
