@@ -17,6 +17,7 @@
 #include <stdint.h>
 #include "seed_core.h"
 #include <cstring>
+#include <cstdio>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
 #include "seed_kernels.h"
@@ -1541,6 +1542,18 @@ hipError_t launch_seed_stream(const SeedArgs& a, int sid, hipStream_t st, bool f
 		const bool by_class = a.classes != 0;               // the fused pipeline, or long seeds against a large query block (seed_api.hip)
 		if (by_class) {
 			const int64_t n_groups = seed_code_groups(a.t_begin, a.t_end);
+			// seed_classify_kernel computes classes as XORs of shifted bit planes: only right while seed_class is GF(2)-linear in the key
+			static const bool class_is_linear = [] {
+				uint64_t x = 0x9e3779b97f4a7c15ull;
+				for (int t = 0; t < 256; ++t) {
+					x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+					uint32_t sum = 0;
+					for (int bit = 0; bit < 64; ++bit) if ((x >> bit) & 1u) sum ^= seed_class((uint64_t)1 << bit);
+					if (sum != seed_class(x)) return false;
+				}
+				return seed_class(0) == 0;
+			}();
+			if (!class_is_linear) { std::fprintf(stderr, "seed_classify_kernel: seed_class is no longer linear over GF(2); the bit-plane classifier does not apply\n"); return hipErrorInvalidValue; }
 			SeedClassCoef cc;
 			cc.n = 0; cc.n_groups = 0;
 			for (int k = 0; k < 16; ++k) { cc.pos[k] = 0; cc.coef[k] = 0; cc.start[k] = 0; }
