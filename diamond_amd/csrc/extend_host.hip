@@ -169,17 +169,29 @@ struct QueryWork {
 void load_query(const HostCfg& h, QueryWork& w, uint32_t query, const dmnd_seed_hit* hb, const dmnd_seed_hit* he, const uint8_t* gf_flags,
 	const int64_t* tl, int64_t nt, const uint32_t* coarse = nullptr, int query_len = 0, int64_t first_index = -1)
 {
-	std::vector<dmnd_seed_hit> hits(hb, he);
-	// carried through the sort below: bit 0 = the hit's gapped-filter flag, the rest = its position in [hb, he)
-	for (size_t x = 0; x < hits.size(); ++x) hits[x].pad = (int32_t)((gf_flags ? (gf_flags[x] ? 1u : 0u) : 1u) | ((uint32_t)x << 1));
-	std::sort(hits.begin(), hits.end(), [](const dmnd_seed_hit& a, const dmnd_seed_hit& b) {       // Hit::CmpSubject
+	auto by_subject = [](const dmnd_seed_hit& a, const dmnd_seed_hit& b) {       // Hit::CmpSubject
 		return a.subject < b.subject || (a.subject == b.subject && (a.query < b.query || (a.query == b.query && a.seed_offset < b.seed_offset)));
-	});
+	};
+	// dmnd_seed_search hands the hits over sorted by (query, subject, seed offset): for an untranslated query that IS the order wanted
+	// here, and the copy + sort (a third of this function's time, itself a third of the host time of a --sensitive step) is skipped.
+	// A translated query's hits come frame after frame and are merged by the sort.
+	const size_t n_hits = (size_t)(he - hb);
+	const bool in_order = std::is_sorted(hb, he, by_subject);
+	std::vector<dmnd_seed_hit> sorted_copy;
+	const dmnd_seed_hit* hits = hb;
+	if (!in_order) {
+		sorted_copy.assign(hb, he);
+		// carried through the sort: bit 0 = the hit's gapped-filter flag, the rest = its position in [hb, he)
+		for (size_t x = 0; x < n_hits; ++x) sorted_copy[x].pad = (int32_t)((gf_flags ? (gf_flags[x] ? 1u : 0u) : 1u) | ((uint32_t)x << 1));
+		std::sort(sorted_copy.begin(), sorted_copy.end(), by_subject);
+		hits = sorted_copy.data();
+	}
+	auto carried = [&](size_t x) -> uint32_t { return in_order ? (gf_flags ? (gf_flags[x] ? 1u : 0u) : 1u) | ((uint32_t)x << 1) : (uint32_t)hits[x].pad; };
 	w.query = query;
-	w.sh.resize(hits.size());
+	w.sh.resize(n_hits);
 	w.groups.clear();
 	const int64_t* it = tl;
-	for (size_t x = 0; x < hits.size(); ++x) {
+	for (size_t x = 0; x < n_hits; ++x) {
 		const int64_t s = hits[x].subject;
 		if (coarse) {                                        // sequences starting inside the hit's 4 KiB stretch, from the table's entry on
 			const int64_t* lo = tl + coarse[s >> dmnd_ctx::COARSE_SHIFT];
@@ -193,10 +205,10 @@ void load_query(const HostCfg& h, QueryWork& w, uint32_t query, const dmnd_seed_
 		--it;
 		if (w.groups.empty() || w.groups.back().target != t) w.groups.push_back(TargetGroup{ t, x, x, 0, false });
 		w.sh[x] = HostSeedHit{ hits[x].seed_offset, (int)(s - tl[t]), hits[x].score, (int)(hits[x].query % (uint32_t)h.contexts),
-			first_index >= 0 ? (int)(first_index + (int64_t)((uint32_t)hits[x].pad >> 1)) : -1 };
+			first_index >= 0 ? (int)(first_index + (int64_t)(carried(x) >> 1)) : -1 };
 		w.groups.back().end = x + 1;
 		w.groups.back().score = std::max(w.groups.back().score, (int)(uint16_t)hits[x].score);
-		w.groups.back().pass |= (hits[x].pad & 1) != 0;  // gapped-filter flag of the hit (1 everywhere when the filter is off)
+		w.groups.back().pass |= (carried(x) & 1u) != 0;  // gapped-filter flag of the hit (1 everywhere when the filter is off)
 	}
 	w.order.resize(w.groups.size());
 	for (size_t i = 0; i < w.order.size(); ++i) w.order[i] = (uint32_t)i;
@@ -321,9 +333,20 @@ int plan_all(const HostCfg& h, int threads, const dmnd_seed_hit* hits, int64_t n
 	std::vector<std::vector<PlanTarget>> per(qr.size());
 	threads = std::max(1, threads);
 	std::vector<ChainWorkspace> ws((size_t)threads);
+	// the table dmnd_upload_block keeps for load_query (ctx.h coarse[]), so that this entry runs the code the extension stage runs
+	const int64_t n_seqs = (int64_t)tl.size() - 1;
+	std::vector<uint32_t> coarse((size_t)(tl[(size_t)n_seqs] >> dmnd_ctx::COARSE_SHIFT) + 2, 0);
+	{
+		int64_t sidx = 0;
+		for (size_t b = 0; b < coarse.size(); ++b) {
+			const int64_t pos = (int64_t)b << dmnd_ctx::COARSE_SHIFT;
+			while (sidx + 1 <= n_seqs && tl[(size_t)sidx + 1] <= pos) ++sidx;
+			coarse[b] = (uint32_t)std::min<int64_t>(sidx, n_seqs - 1);
+		}
+	}
 	parallel_for(qr.size(), threads, [&](size_t i, int t) {
 		QueryWork w;
-		load_query(h, w, hits[qr[i].b].query / (uint32_t)h.contexts, hits + qr[i].b, hits + qr[i].e, nullptr, tl.data(), (int64_t)tl.size() - 1);
+		load_query(h, w, hits[qr[i].b].query / (uint32_t)h.contexts, hits + qr[i].b, hits + qr[i].e, nullptr, tl.data(), n_seqs, n_seqs > 0 ? coarse.data() : nullptr);
 		plan_groups(h, ws[(size_t)t], w, 0, w.order.size(), qdata, ql.data(), tdata, tl.data(), cbs_all, per[i]);
 	});
 	size_t total = 0;
