@@ -286,9 +286,10 @@ void plan_groups(const HostCfg& h, ChainWorkspace& ws, QueryWork& w, size_t g0, 
 			}
 			else {
 				if (segs[f].empty()) continue;
-				std::stable_sort(segs[f].begin(), segs[f].end(), [](const Seg& a, const Seg& b) { return a.diag() < b.diag() || (a.diag() == b.diag() && a.j < b.j); });
+				// (std::stable_sort takes a temporary buffer from the heap even for one element: most targets have one segment and one chain)
+				if (segs[f].size() > 1) std::stable_sort(segs[f].begin(), segs[f].end(), [](const Seg& a, const Seg& b) { return a.diag() < b.diag() || (a.diag() == b.diag() && a.j < b.j); });
 				ws.run(h.S, q[f], t, segs[f], chains);
-				std::stable_sort(chains.begin(), chains.end(), [](const Chain& a, const Chain& b) { return a.d_min < b.d_min; });
+				if (chains.size() > 1) std::stable_sort(chains.begin(), chains.end(), [](const Chain& a, const Chain& b) { return a.d_min < b.d_min; });
 			}
 			// add_dp_targets (gapped_score.cpp:107-180): merge overlapping bands of the context's chains
 			int d0 = INT_MAX, d1 = INT_MIN;
