@@ -189,7 +189,7 @@ hipError_t take_stream(hipStream_t* s, int device, int priority)
 }
 
 extern "C" hipError_t dmnd_touch_bias(hipStream_t), dmnd_touch_gapped(hipStream_t), dmnd_touch_mask(hipStream_t), dmnd_touch_seed(hipStream_t),
-	dmnd_touch_swipe16(hipStream_t), dmnd_touch_swipe(hipStream_t), dmnd_touch_frameshift(hipStream_t);
+	dmnd_touch_swipe16(hipStream_t), dmnd_touch_swipe(hipStream_t), dmnd_touch_frameshift(hipStream_t), dmnd_touch_plan(hipStream_t);
 
 extern "C" int dmnd_init(int device)
 {
@@ -226,7 +226,7 @@ extern "C" int dmnd_init(int device)
 	hipError_t rc = hipGetLastError();
 	lap("first kernel (api)");
 	struct { const char* name; hipError_t (*fn)(hipStream_t); } units[] = { { "bias", dmnd_touch_bias },
-		{ "swipe16", dmnd_touch_swipe16 }, { "swipe", dmnd_touch_swipe }, { "gapped", dmnd_touch_gapped }, { "frameshift", dmnd_touch_frameshift } };
+		{ "swipe16", dmnd_touch_swipe16 }, { "swipe", dmnd_touch_swipe }, { "gapped", dmnd_touch_gapped }, { "plan", dmnd_touch_plan }, { "frameshift", dmnd_touch_frameshift } };
 	for (auto& u : units) {
 		if (rc == hipSuccess) rc = u.fn(nullptr);
 		lap(u.name);
@@ -295,6 +295,8 @@ extern "C" void dmnd_destroy(dmnd_ctx* c)
 	for (DevBuf& kb : c->keep_trace) kb.release();
 	c->stage_h.release(); c->ends_h.release(); c->stage_d.release();
 	c->xd_hits.release(); c->xd_out.release(); c->xd_host.release();
+	c->plan_dev.release(); c->plan_host.release();
+	if (c->plan_tmp) { (void)hipFree(c->plan_tmp); c->plan_tmp = nullptr; c->plan_tmp_bytes = 0; }
 	for (int i = 0; i < 2; ++i) { c->up_stage[i].release(); if (c->up_ev[i]) (void)hipEventDestroy(c->up_ev[i]); c->up_ev[i] = nullptr; }
 	for (int i = 0; i < 2; ++i) { c->t_stage[i].release(); if (c->t_ev[i]) (void)hipEventDestroy(c->t_ev[i]); c->t_ev[i] = nullptr; }
 	if (c->t_stream) { (void)hipStreamSynchronize(c->t_stream); forget_stream(c->t_stream); (void)hipStreamDestroy(c->t_stream); c->t_stream = nullptr; }

@@ -29,27 +29,92 @@
 
 #include "xdrop_core.h"
 
+// DMND_XD (xdrop_core.h): __host__ __device__ under hipcc. The chaining below is ONE source for both sides: the host instantiates
+// it over std::vector (ChainWorkspace), the device planner (plan_kernels.hip, round 6) over fixed-capacity arrays in a lane's
+// private memory (ChainWorkspaceT<FixedChainPolicy>); a target that does not fit those arrays is chained on the host.
 namespace dmnd {
+
+// std::vector's interface as far as the chaining uses it, over a fixed array; running out of room sets `overflow` (the caller
+// then discards the result) instead of growing
+template<typename T, int CAP>
+struct FixedVec {
+	T a[CAP];
+	int n = 0;
+	bool overflow = false;
+	DMND_XD size_t size() const { return (size_t)n; }
+	DMND_XD bool empty() const { return n == 0; }
+	DMND_XD void clear() { n = 0; }
+	DMND_XD void reserve(size_t) {}
+	DMND_XD T* begin() { return a; }
+	DMND_XD T* end() { return a + n; }
+	DMND_XD const T* begin() const { return a; }
+	DMND_XD const T* end() const { return a + n; }
+	DMND_XD T& operator[](size_t i) { return a[i]; }
+	DMND_XD const T& operator[](size_t i) const { return a[i]; }
+	DMND_XD T& back() { return a[n - 1]; }
+	DMND_XD const T& back() const { return a[n - 1]; }
+	DMND_XD void push_back(const T& x) { if (n < CAP) a[n++] = x; else overflow = true; }
+	DMND_XD void pop_back() { --n; }
+	DMND_XD void resize(size_t m) { if ((int)m <= CAP) n = (int)m; else overflow = true; }      // (only ever shrinks in the chaining)
+	DMND_XD void insert(T* at, const T& x)
+	{
+		if (n >= CAP) { overflow = true; return; }
+		for (T* p = a + n; p > at; --p) *p = *(p - 1);
+		*at = x; ++n;
+	}
+	DMND_XD void erase(T* at) { for (T* p = at; p + 1 < a + n; ++p) *p = *(p + 1); --n; }
+	DMND_XD void swap(FixedVec& o) { const FixedVec t = *this; *this = o; o = t; }
+	template<typename It> DMND_XD void append(It b, It e) { for (; b != e; ++b) push_back(*b); }
+};
+
+// what std::sort does for up to 16 elements (libstdc++: introsort leaves ranges of <= _S_threshold = 16 elements to ONE insertion
+// sort, which keeps equal elements in their order) -- the device's sort; longer ranges do not occur there (FixedChainPolicy caps)
+template<typename T, typename Cmp>
+DMND_XD void insertion_sort(T* b, T* e, Cmp less)
+{
+	for (T* i = b == e ? e : b + 1; i < e; ++i) {
+		const T v = *i;
+		T* p = i;
+		while (p > b && less(v, *(p - 1))) { *p = *(p - 1); --p; }
+		*p = v;
+	}
+}
+
+struct HostChainPolicy {
+	template<typename T, int CAP> struct Vec : std::vector<T> {
+		template<typename It> void append(It b, It e) { this->insert(this->end(), b, e); }
+		bool overflowed() const { return false; }
+	};
+	template<typename It, typename Cmp> static void sort(It b, It e, Cmp c) { std::sort(b, e, c); }
+	template<typename V> static bool overflowed(const V&) { return false; }
+};
+
+struct FixedChainPolicy {
+	enum { SORT_MAX = 16 };
+	template<typename T, int CAP> using Vec = FixedVec<T, CAP>;
+	template<typename T, typename Cmp> DMND_XD static void sort(T* b, T* e, Cmp c) { insertion_sort(b, e, c); }
+	template<typename V> DMND_XD static bool overflowed(const V& v) { return v.overflow; }
+};
 
 struct ScoreTable {                // ScoreMatrix::operator()(a,b) = matrix32[a*32+b] on masked letters
 	int m[32 * 32];
 	int gap_open, gap_extend;
-	int at(int a, int b) const { return m[(a << 5) + b]; }
+	DMND_XD int at(int a, int b) const { return m[(a << 5) + b]; }
 };
 
 struct SeqRef {                    // Sequence: letters are read through & 31 (basic/sequence.h:80-87)
 	const int8_t* p;
 	int len;
-	int operator[](int i) const { return p[i] & 31; }
+	DMND_XD int operator[](int i) const { return p[i] & 31; }
 };
 
 struct Seg {                       // one ungapped diagonal segment: cells (i + k, j + k), k < len
 	int i, j, len, score;
-	int diag() const { return i - j; }
-	int j_end() const { return j + len; }
-	int j_last() const { return j + len - 1; }
-	int i_end() const { return i + len; }
-	int i_last() const { return i + len - 1; }
+	DMND_XD int diag() const { return i - j; }
+	DMND_XD int j_end() const { return j + len; }
+	DMND_XD int j_last() const { return j + len - 1; }
+	DMND_XD int i_end() const { return i + len; }
+	DMND_XD int i_last() const { return i + len - 1; }
 };
 
 struct Chain {                     // the fields of an approximate HSP the extension reads
@@ -72,6 +137,12 @@ struct ChainCfg {
 	int link_padding = 10, reverse_overhang = 10;
 };
 
+DMND_XD int chain_min(int a, int b) { return b < a ? b : a; }
+DMND_XD int chain_max(int a, int b) { return a < b ? b : a; }
+DMND_XD double chain_min(double a, double b) { return b < a ? b : a; }      // std::min / std::max: the second argument only when it is strictly smaller / larger
+DMND_XD double chain_max(double a, double b) { return a < b ? b : a; }
+DMND_XD int chain_abs(int a) { return a < 0 ? -a : a; }
+
 // ---- x-drop ungapped extension ------------------------------------------------------------------------------------
 // One direction of the extension: from (qi, tj) in steps of `dir`, adding letter scores (+ bias) to a running sum that starts
 // at `best`; stops at a delimiter or when the sum has dropped xdrop below the best. Returns the best sum and, in `reach`,
@@ -90,11 +161,13 @@ inline Seg xdrop_ungapped(const ScoreTable& S, const SeqRef& q, const int8_t* cb
 }
 
 // ---- chaining -----------------------------------------------------------------------------------------------------
-struct ChainWorkspace {
+// P: HostChainPolicy (std::vector, std::sort) or FixedChainPolicy (arrays of NODES segments, LINKS links, CHAINS chains; insertion sort)
+template<typename P, int NODES = 16, int LINKS = 96, int CHAINS = 16>
+struct ChainWorkspaceT {
 	struct Node : Seg {
 		int best, peak, dip;          // best chain score ending here; the highest and lowest running score on that chain's way
 		int newest;                   // most recent incoming link (index into links), -1 = none
-		int rel() const { return best == peak ? best : best - dip; }
+		DMND_XD int rel() const { return best == peak ? best : best - dip; }
 	};
 	struct InLink {                   // an admissible way into `to` from `from`
 		int best, peak, dip, begin;   // chain score through it (and its peak / dip); score at which the downstream part begins
@@ -105,27 +178,36 @@ struct ChainWorkspace {
 	struct Junction { int total, s1, q1, s2, q2, up, down; };      // up / down: re-cut scores of the two parts
 	struct Front { int diag; unsigned node; };
 	struct Frame { unsigned node; int link, dip; };
+	typedef typename P::template Vec<Node, NODES> NodeVec;
+	typedef typename P::template Vec<Chain, CHAINS> ChainVec;
 
-	std::vector<Node> nodes;
-	std::vector<InLink> links;
-	std::vector<Front> front;
-	std::vector<Frame> frames;
-	std::vector<unsigned> tops;
+	NodeVec nodes, closed_, open_;
+	typename P::template Vec<InLink, LINKS> links;
+	typename P::template Vec<Front, NODES> front;
+	typename P::template Vec<Frame, NODES + 1> frames;
+	typename P::template Vec<unsigned, NODES> tops;
 	const ScoreTable* S = nullptr;
 	SeqRef query, subject;
 	ChainCfg cfg;
 
-	static Node node_of(const Seg& s) { Node n; (Seg&)n = s; n.best = n.peak = n.dip = s.score; n.newest = -1; return n; }
+	DMND_XD static Node node_of(const Seg& s) { Node n; n.i = s.i; n.j = s.j; n.len = s.len; n.score = s.score; n.best = n.peak = n.dip = s.score; n.newest = -1; return n; }
+
+	// true: some array of a fixed-capacity instance was too small -- the result is void (never with HostChainPolicy)
+	DMND_XD bool overflowed() const
+	{
+		return P::overflowed(nodes) || P::overflowed(closed_) || P::overflowed(open_) || P::overflowed(links) || P::overflowed(front) || P::overflowed(frames) || P::overflowed(tops);
+	}
 
 	// Segments arrive sorted by (diagonal, j): a segment that begins inside the stretch already covered on its diagonal is dropped
-	void load(const std::vector<Seg>& segs)
+	DMND_XD void load(const Seg* segs, size_t n_segs)
 	{
 		nodes.clear(); links.clear();
 		bool have = false;
 		int d = 0, covered = 0;
-		for (const Seg& s : segs) {
+		for (size_t x = 0; x < n_segs; ++x) {
+			const Seg& s = segs[x];
 			if (have && s.diag() == d && s.j <= covered) continue;
-			covered = have && s.diag() == d ? std::max(covered, s.j_end()) : s.j_end();
+			covered = have && s.diag() == d ? chain_max(covered, s.j_end()) : s.j_end();
 			d = s.diag(); have = true;
 			nodes.push_back(node_of(s));
 		}
@@ -133,14 +215,17 @@ struct ChainWorkspace {
 
 	// Drops a segment when more than range_cover still-open segments (in subject order) score at least as much and cover its
 	// whole subject range. The survivors come out in the order in which they stop being open.
-	void thin_out()
+	DMND_XD void thin_out()
 	{
-		std::vector<Node> closed, open;
+		NodeVec& closed = closed_;
+		NodeVec& open = open_;
+		closed.clear(); open.clear();
 		closed.reserve(nodes.size());
-		for (const Node& d : nodes) {
+		for (size_t k = 0; k < nodes.size(); ++k) {
+			const Node d = nodes[k];
 			size_t covering = 0, keep = 0;
 			for (size_t x = 0; x < open.size(); ++x) {
-				const Node& w = open[x];
+				const Node w = open[x];
 				if (w.j_end() <= d.j) { closed.push_back(w); continue; }
 				covering += w.score >= d.score && w.j <= d.j && w.j_end() >= d.j_end();
 				if (keep != x) open[keep] = w;
@@ -149,13 +234,13 @@ struct ChainWorkspace {
 			open.resize(keep);
 			if (covering <= cfg.range_cover) open.push_back(d);
 		}
-		closed.insert(closed.end(), open.begin(), open.end());
+		closed.append(open.begin(), open.end());
 		nodes.swap(closed);
 	}
 
 	// Best incoming link of `node` among those whose downstream part begins before column j and that beat the bare
 	// segment; of equally good ones the newest. -1 = none.
-	int best_in(unsigned node, int j) const
+	DMND_XD int best_in(unsigned node, int j) const
 	{
 		int pick = -1, top = nodes[node].score;
 		for (int l = nodes[node].newest; l >= 0; l = links[(size_t)l].older)
@@ -163,13 +248,15 @@ struct ChainWorkspace {
 		return pick;
 	}
 
-	void add_link(unsigned to, const InLink& l)
+	DMND_XD void add_link(unsigned to, const InLink& l)
 	{
 		Node& d = nodes[to];
 		if (l.best > d.best) { d.best = l.best; d.peak = l.peak; d.dip = l.dip; }
+		const int at = (int)links.size();
 		links.push_back(l);
+		if (P::overflowed(links)) return;
 		links.back().older = d.newest;
-		d.newest = (int)links.size() - 1;
+		d.newest = at;
 	}
 
 	// Where to leave segment `up` (the one further left / higher) for segment `down` on a diagonal g >= 0 lower, in
@@ -181,48 +268,48 @@ struct ChainWorkspace {
 	// segments do not reach each other, else `pad` cells before the first possible junction) while the entry point stays within
 	// `pad` cells behind the first cell either segment offers, and inside `down`. The first candidate with the largest
 	// T(c + 1) + R(c + g + 1) wins; since T(c + 1) = T(c0 + 1) + sum W(up.off, (c0, c]), the search runs on that partial sum.
-	struct Axis { int x, off, len, score; int end() const { return x + len; } int last() const { return x + len - 1; } };
+	struct Axis { int x, off, len, score; DMND_XD int end() const { return x + len; } DMND_XD int last() const { return x + len - 1; } };
 
 	template<typename Cell>
-	static bool junction_on(const Axis& up, const Axis& down, int pad, Cell W, int& c_best, int& t_best, int& r_best, int& total)
+	DMND_XD static bool junction_on(const Axis& up, const Axis& down, int pad, Cell W, int& c_best, int& t_best, int& r_best, int& total)
 	{
 		const int g = up.off - down.off;
 		const bool apart = up.last() < down.x - g - 1;
-		const int c0 = apart ? up.last() : std::max(down.x - g - 1 - pad, up.x);
-		const int entry_max = std::min(std::max(down.x, up.last() + g + 1 + pad), down.last());
+		const int c0 = apart ? up.last() : chain_max(down.x - g - 1 - pad, up.x);
+		const int entry_max = chain_min(chain_max(down.x, up.last() + g + 1 + pad), down.last());
 		if (c0 + g + 1 > down.last()) return false;
 		auto span = [&](int off, int a, int b) { int s = 0; for (int x = a; x < b; ++x) s += W(off, x); return s; };
 		int run = 0;                                                                              // sum W(up.off, (c0, c])
 		int r = down.score + span(down.off, c0 + g + 1, down.x) - span(down.off, down.x, c0 + g + 1);      // R(c + g + 1)
-		int run_best = 0;
 		total = INT_MIN;
 		for (int c = c0;; ++c) {
-			if (run + r > total) { total = run + r; c_best = c; r_best = r; run_best = run; }
+			if (run + r > total) { total = run + r; c_best = c; r_best = r; }
 			if (c + g + 1 >= entry_max) break;
 			r -= W(down.off, c + g + 1);
 			run += W(up.off, c + 1);
 		}
 		// T(c_best + 1)
 		t_best = up.score + span(up.off, up.end(), c_best + 1) - span(up.off, c_best + 1, up.end());
-		(void)run_best;
 		return true;
 	}
 
 	// Junction from segment e into segment d (e is the upstream one). Lower or equal diagonal of d: the segments advance
 	// along the subject; higher diagonal: along the query (same computation with the roles of the sequences swapped).
-	bool junction(const Seg& e, const Seg& d, Junction& out) const
+	DMND_XD bool junction(const Seg& e, const Seg& d, Junction& out) const
 	{
 		int c = 0, t = 0, r = 0, total = 0;
+		const ScoreTable* st = S;
+		const SeqRef qs = query, ss = subject;
 		if (e.diag() < d.diag()) {
 			const Axis up{ e.i, -e.diag(), e.len, e.score }, down{ d.i, -d.diag(), d.len, d.score };
-			auto cell = [&](int off, int x) { return S->at(subject[x + off], query[x]); };
+			auto cell = [&](int off, int x) { return st->at(ss[x + off], qs[x]); };
 			if (!junction_on(up, down, cfg.link_padding, cell, c, t, r, total)) return false;
 			const int g = up.off - down.off;
 			out = Junction{ total, c + up.off, c, c + g + 1 + down.off, c + g + 1, t, r };
 		}
 		else {
 			const Axis up{ e.j, e.diag(), e.len, e.score }, down{ d.j, d.diag(), d.len, d.score };
-			auto cell = [&](int off, int x) { return S->at(query[x + off], subject[x]); };
+			auto cell = [&](int off, int x) { return st->at(qs[x + off], ss[x]); };
 			if (!junction_on(up, down, cfg.link_padding, cell, c, t, r, total)) return false;
 			const int g = up.off - down.off;
 			out = Junction{ total, c, c + up.off, c + g + 1, c + g + 1 + down.off, t, r };
@@ -231,12 +318,12 @@ struct ChainWorkspace {
 	}
 
 	// Considers continuing the best chain of `from` with segment `to`, and records the link if it improves on the bare segment.
-	void try_link(unsigned to, unsigned from)
+	DMND_XD void try_link(unsigned to, unsigned from)
 	{
-		const Node& d = nodes[to];
-		const Node& e = nodes[from];
+		const Node d = nodes[to];
+		const Node e = nodes[from];
 		const int shift = d.diag() - e.diag();
-		const int gap = shift ? -(S->gap_open + std::abs(shift) * S->gap_extend) : 0;
+		const int gap = shift ? -(S->gap_open + chain_abs(shift) * S->gap_extend) : 0;
 		const int apart = shift > 0 ? d.j - e.j_last() : d.i - e.i_last();
 		InLink l;
 		l.from = from; l.older = -1;
@@ -249,54 +336,60 @@ struct ChainWorkspace {
 			const int cut = e.score - jn.up;                       // what `from` loses by ending at the junction
 			const int in = best_in(from, jn.s1);
 			const int e_score = e.score;
-			const int e_best = in < 0 ? e_score : std::max(e_score, links[(size_t)in].best);
-			int peak = in < 0 ? e_score : std::max(e_score, links[(size_t)in].peak);
+			const int e_best = in < 0 ? e_score : chain_max(e_score, links[(size_t)in].best);
+			int peak = in < 0 ? e_score : chain_max(e_score, links[(size_t)in].peak);
 			int dip = in < 0 ? e_score : links[(size_t)in].dip;
 			l.best = e_best - cut + gap + jn.down;
 			const int have2 = best_in(to, jn.s2);
 			if (have2 >= 0 && links[(size_t)have2].best > l.best) return;
 			l.begin = l.best - jn.down;
-			dip = std::min(dip, l.begin);
+			dip = chain_min(dip, l.begin);
 			if (e_best == peak) peak -= cut;
 			l.peak = peak; l.dip = dip; l.j = jn.s2;
 		}
 		else {
 			// free space between the segments: a flat penalty per skipped position
-			l.best = e.best + gap - int(cfg.space_penalty * std::max(apart - 1, 0)) + d.score;
+			l.best = e.best + gap - int(cfg.space_penalty * chain_max(apart - 1, 0)) + d.score;
 			const int have = best_in(to, d.j);
 			if (have >= 0 && links[(size_t)have].best > l.best) return;
 			l.begin = l.best - d.score;
 			l.peak = e.peak;
-			l.dip = std::min(e.dip, l.begin);
+			l.dip = chain_min(e.dip, l.begin);
 			l.j = d.j;
 		}
 		if (l.best <= d.score) return;
-		l.peak = std::max(l.peak, l.best);
+		l.peak = chain_max(l.peak, l.best);
 		if (l.best == l.peak) l.dip = l.best;
 		add_link(to, l);
 	}
 
-	bool faded(const Node& e, const Node& d) const { return e.best - int(cfg.space_penalty * std::max(d.j - e.j_end(), 0)) <= 0; }
-	bool overhangs(const Node& e, const Node& d) const { return e.j_end() - (d.j_end() - std::min(e.diag() - d.diag(), 0)) >= cfg.reverse_overhang; }
+	DMND_XD bool faded(const Node& e, const Node& d) const { return e.best - int(cfg.space_penalty * chain_max(d.j - e.j_end(), 0)) <= 0; }
+	DMND_XD bool overhangs(const Node& e, const Node& d) const { return e.j_end() - (d.j_end() - chain_min(e.diag() - d.diag(), 0)) >= cfg.reverse_overhang; }
 
 	// Segments in (j, i) order; `front` holds for every diagonal the latest segment seen on it while that segment can still
 	// contribute (its chain score has not faded over the distance). A new segment is linked to the frontier segments below
 	// it (nearest diagonal first), then to those at and above it.
-	void sweep()
+	DMND_XD void sweep()
 	{
 		front.clear();
 		for (unsigned n = 0; n < nodes.size(); ++n) {
 			const int dd = nodes[n].diag();
-			size_t pos = (size_t)(std::lower_bound(front.begin(), front.end(), dd, [](const Front& f, int v) { return f.diag < v; }) - front.begin());
+			size_t pos = 0;
+			{       // first frontier entry whose diagonal is not below dd (std::lower_bound)
+				size_t lo = 0, hi = front.size();
+				while (lo < hi) { const size_t mid = (lo + hi) / 2; if (front[mid].diag < dd) lo = mid + 1; else hi = mid; }
+				pos = lo;
+			}
 			const bool fresh = pos == front.size() || front[pos].diag != dd;
 			if (fresh) front.insert(front.begin() + (ptrdiff_t)pos, Front{ dd, n });
+			if (P::overflowed(front)) return;
 			int reach_j = 0;
 			for (size_t k = pos; k-- > 0;) {
 				const unsigned en = front[k].node;
 				if (faded(nodes[en], nodes[n])) { front.erase(front.begin() + (ptrdiff_t)k); --pos; continue; }
 				if (nodes[en].j_end() < reach_j) continue;
 				try_link(n, en);
-				reach_j = std::max(reach_j, std::min(nodes[n].j, nodes[en].j_end()));
+				reach_j = chain_max(reach_j, chain_min(nodes[n].j, nodes[en].j_end()));
 				if (overhangs(nodes[en], nodes[n])) try_link(en, n);
 			}
 			int reach_i = 0;
@@ -305,7 +398,7 @@ struct ChainWorkspace {
 				if (k != pos && faded(nodes[en], nodes[n])) { front.erase(front.begin() + (ptrdiff_t)k); continue; }
 				if (nodes[en].i_end() >= reach_i) {
 					try_link(n, en);
-					if (nodes[en].i < nodes[n].i) reach_i = std::max(reach_i, std::min(nodes[en].i_end(), nodes[n].i));
+					if (nodes[en].i < nodes[n].i) reach_i = chain_max(reach_i, chain_min(nodes[en].i_end(), nodes[n].i));
 					if (overhangs(nodes[en], nodes[n])) try_link(en, n);
 				}
 				++k;
@@ -314,21 +407,22 @@ struct ChainWorkspace {
 		}
 	}
 
-	static double share(int a0, int a1, int b0, int b1)            // part of [a0, a1) that lies in [b0, b1)
+	DMND_XD static double share(int a0, int a1, int b0, int b1)            // part of [a0, a1) that lies in [b0, b1)
 	{
-		const int lo = std::max(a0, b0), hi = std::min(a1, b1);
+		const int lo = chain_max(a0, b0), hi = chain_min(a1, b1);
 		return (double)(unsigned)(hi > lo ? hi - lo : 0) / (double)(a1 > a0 ? a1 - a0 : 0);
 	}
 
 	// May a candidate (ranges + score) coexist with the chains ts[first..)? A chain that the candidate mostly stacks on (in
 	// either sequence) without being dwarfed by it does not count; otherwise what remains of the candidate outside that chain
 	// must still be worth the cutoff.
-	bool compatible(const std::vector<Chain>& ts, size_t first, int q0, int q1, int s0, int s1, int score) const
+	template<typename CV>
+	DMND_XD bool compatible(const CV& ts, size_t first, int q0, int q1, int s0, int s1, int score) const
 	{
 		for (size_t x = first; x < ts.size(); ++x) {
 			const double in_s = share(s0, s1, ts[x].s0, ts[x].s1), in_q = share(q0, q1, ts[x].q0, ts[x].q1);
-			if ((1.0 - std::min(in_s, in_q)) * score / ts[x].score >= cfg.stacked_hsp_ratio) continue;
-			if ((1.0 - std::max(in_s, in_q)) * score < cfg.cutoff) return false;
+			if ((1.0 - chain_min(in_s, in_q)) * score / ts[x].score >= cfg.stacked_hsp_ratio) continue;
+			if ((1.0 - chain_max(in_s, in_q)) * score < cfg.cutoff) return false;
 		}
 		return true;
 	}
@@ -337,7 +431,7 @@ struct ChainWorkspace {
 	// running score exceeds the chain's final score; a part reached through such a link is cut off if the chain is still worth
 	// more from there on. `jump` receives the segment behind a link that crosses more than max_shift diagonals (the walk stops
 	// in front of it and the caller continues from there), else UINT_MAX. Returns false if nothing could be followed.
-	bool follow(unsigned top, int j_bound, Chain& t, unsigned& jump)
+	DMND_XD bool follow(unsigned top, int j_bound, Chain& t, unsigned& jump)
 	{
 		const int final_score = nodes[top].best;
 		frames.clear();
@@ -348,12 +442,13 @@ struct ChainWorkspace {
 		for (;;) {
 			const int l = best_in(cur, j_bound);
 			if ((l < 0 ? nodes[cur].score : links[(size_t)l].best) > final_score) { rejected = true; break; }
-			dip = std::min(dip, l < 0 ? 0 : links[(size_t)l].begin);
+			dip = chain_min(dip, l < 0 ? 0 : links[(size_t)l].begin);
 			frames.push_back(Frame{ cur, l, dip });
+			if (P::overflowed(frames)) return false;
 			if (l < 0) break;
 			const InLink& in = links[(size_t)l];
 			const int shift = nodes[cur].diag() - nodes[in.from].diag();
-			if (std::abs(shift) > cfg.max_shift) { jump = in.from; break; }
+			if (chain_abs(shift) > cfg.max_shift) { jump = in.from; break; }
 			j_bound = shift > 0 ? in.j : in.j + shift;
 			cur = in.from;
 		}
@@ -362,33 +457,36 @@ struct ChainWorkspace {
 		if (frames.empty()) return false;
 		const Node& first = nodes[frames.back().node];
 		t.q0 = first.i; t.s0 = first.j; t.score = final_score - frames.back().dip;
-		for (const Frame& f : frames) {
-			const int dd = nodes[f.node].diag();
-			t.d_min = std::min(t.d_min, dd);
-			t.d_max = std::max(t.d_max, dd);
+		for (size_t k = 0; k < frames.size(); ++k) {
+			const int dd = nodes[frames[k].node].diag();
+			t.d_min = chain_min(t.d_min, dd);
+			t.d_max = chain_max(t.d_max, dd);
 		}
 		return true;
 	}
 
-	void collect(std::vector<Chain>& ts)
+	template<typename CV>
+	DMND_XD void collect(CV& ts)
 	{
 		tops.clear();
 		for (unsigned n = 0; n < nodes.size(); ++n)
 			if (nodes[n].rel() >= cfg.cutoff) tops.push_back(n);
 		// same comparison sequence as the reference's sort of its candidate list, so equal scores end up in the same order
-		std::sort(tops.begin(), tops.end(), [this](unsigned x, unsigned y) { return nodes[x].rel() > nodes[y].rel(); });
+		const NodeVec& nd = nodes;
+		P::sort(tops.begin(), tops.end(), [&nd](unsigned x, unsigned y) { return nd[x].rel() > nd[y].rel(); });
 		const size_t none = (size_t)-1;
 		size_t first = none;                              // first chain of this call in ts
-		for (unsigned n : tops) {
-			const Node& d = nodes[n];
+		for (size_t k = 0; k < tops.size(); ++k) {
+			const unsigned n = tops[k];
+			const Node d = nodes[n];
 			if (!compatible(ts, first == none ? ts.size() : first, d.i, d.i_end(), d.j, d.j_end(), d.score)) continue;
 			unsigned from = n;
 			int j_bound = subject.len;
 			while (from != UINT_MAX) {
-				const Node& top = nodes[from];
+				const Node top = nodes[from];
 				Chain t{ INT_MAX, INT_MIN, 0, 0, top.i_end(), 0, top.j_end() };
 				unsigned jump;
-				follow(from, std::min(top.j_end(), j_bound), t, jump);
+				follow(from, chain_min(top.j_end(), j_bound), t, jump);
 				if (t.score > 0) j_bound = t.s0;
 				if (t.score >= cfg.cutoff && compatible(ts, first == none ? ts.size() : first, t.q0, t.q1, t.s0, t.s1, t.score)) {
 					if (first == none) first = ts.size();
@@ -400,59 +498,70 @@ struct ChainWorkspace {
 	}
 
 	// Two chains in sequence (a before b in both sequences) join when the sum minus gap costs beats both
-	static int joined_score(const Chain& a, const Chain& b)
+	DMND_XD static int joined_score(const Chain& a, const Chain& b)
 	{
 		const int dq = b.q0 - a.q1, ds = b.s0 - a.s1;
 		if (dq < 0 || ds < 0) return 0;
-		const int longer = std::max(dq, ds), shorter = std::min(dq, ds);
+		const int longer = chain_max(dq, ds), shorter = chain_min(dq, ds);
 		// the reference subtracts the two costs in this order (double arithmetic, truncated)
 		return int((a.score + b.score) - longer * 0.5 - shorter * 0.1);
 	}
 
-	static void join_chains(std::vector<Chain>& h)
+	template<typename CV>
+	DMND_XD static void join_chains(CV& h)
 	{
 		for (size_t a = 0; a < h.size(); ++a)
 			for (size_t b = a + 1; b < h.size();) {
-				const int limit = std::max(h[a].score, h[b].score);
+				const int limit = chain_max(h[a].score, h[b].score);
 				const bool ab = joined_score(h[a], h[b]) > limit, ba = !ab && joined_score(h[b], h[a]) > limit;
 				if (!ab && !ba) { ++b; continue; }
 				const Chain x = ab ? h[a] : h[b], y = ab ? h[b] : h[a];
-				h[a] = Chain{ std::min(x.d_min, y.d_min), std::max(x.d_max, y.d_max), joined_score(x, y), x.q0, y.q1, x.s0, y.s1 };
+				h[a] = Chain{ chain_min(x.d_min, y.d_min), chain_max(x.d_max, y.d_max), joined_score(x, y), x.q0, y.q1, x.s0, y.s1 };
 				h.erase(h.begin() + (ptrdiff_t)b);
 			}
 	}
 
-	// segments sorted by (diagonal, j) in, chains out (unsorted)
-	void run(const ScoreTable& st, const SeqRef& q, const SeqRef& s, const std::vector<Seg>& segs, std::vector<Chain>& out)
+	// segments sorted by (diagonal, j) in, chains out (unsorted). With FixedChainPolicy the caller checks overflowed() and
+	// P::overflowed(out) afterwards.
+	template<typename CV>
+	DMND_XD void run_segs(const ScoreTable& st, const SeqRef& q, const SeqRef& s, const Seg* segs, size_t n_segs, CV& out)
 	{
 		out.clear();
-		if (segs.size() == 1) {
+		if (n_segs == 1) {
 			const Seg& g = segs[0];
 			out.push_back(Chain{ g.diag(), g.diag(), g.score, g.i, g.i_end(), g.j, g.j_end() });
 			return;
 		}
 		S = &st; query = q; subject = s;
-		load(segs);
+		load(segs, n_segs);
 		auto by_score = [](const Seg& x, const Seg& y) { return x.score > y.score; };
 		if (cfg.maxnodes > 0) {
-			std::sort(nodes.begin(), nodes.end(), by_score);
+			P::sort(nodes.begin(), nodes.end(), by_score);
 			if (nodes.size() > cfg.maxnodes) nodes.resize(cfg.maxnodes);
 		}
 		if (cfg.len_cap > 0.0 && nodes.size() > cfg.min_nodes) {
 			// many segments: the best-scoring ones until their lengths add up to len_cap query lengths, at least min_nodes
-			std::sort(nodes.begin(), nodes.end(), by_score);
+			P::sort(nodes.begin(), nodes.end(), by_score);
 			const double cap = q.len * cfg.len_cap;
 			double total = 0.0;
 			size_t n = 0;
 			while (n < nodes.size() && total < cap) total += nodes[n++].len;
-			nodes.resize(std::max(cfg.min_nodes, n));
+			nodes.resize(min_nodes_or(n));
 		}
-		std::sort(nodes.begin(), nodes.end(), [](const Seg& x, const Seg& y) { return x.j < y.j || (x.j == y.j && x.i < y.i); });
+		P::sort(nodes.begin(), nodes.end(), [](const Seg& x, const Seg& y) { return x.j < y.j || (x.j == y.j && x.i < y.i); });
 		thin_out();
 		sweep();
 		collect(out);
 		join_chains(out);
 	}
+	DMND_XD size_t min_nodes_or(size_t n) const { return cfg.min_nodes < n ? n : cfg.min_nodes; }
+
+	void run(const ScoreTable& st, const SeqRef& q, const SeqRef& s, const std::vector<Seg>& segs, std::vector<Chain>& out)
+	{
+		run_segs(st, q, s, segs.data(), segs.size(), out);
+	}
 };
+
+typedef ChainWorkspaceT<HostChainPolicy> ChainWorkspace;
 
 }  // namespace dmnd

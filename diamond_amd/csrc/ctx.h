@@ -100,6 +100,9 @@ struct dmnd_ctx {
 	int64_t n_adj_matrices = 0;                // dmnd_extend: those of the targets planned so far), 32 x 32 int8 each
 	dmnd::DevBuf xd_hits, xd_out;             // device x-drop stage of dmnd_extend: the call's seed hits, one XdropSeg per hit
 	dmnd::PinBuf xd_host;
+	dmnd::DevBuf plan_dev;                    // device planner of dmnd_extend (plan_kernels.hip): its work arrays ...
+	dmnd::PinBuf plan_host;                   // ... and the group / query / band lists it hands to the host
+	void* plan_tmp = nullptr; size_t plan_tmp_bytes = 0;      // rocPRIM scan scratch of the planner
 	std::vector<int32_t> h_bias_ids;           // block sequence ids of the queries with seed hits (Hauser bias of one dmnd_extend call)
 	int64_t block_len[2] = { 0, 0 }, cbs_len = 0;
 	std::vector<int64_t> limits[2];
@@ -156,6 +159,7 @@ struct dmnd_ctx {
 	std::vector<dmnd_ctx*> aux;                // auxiliary contexts (own stream + work buffers) for concurrent sub-batches of dmnd_extend
 	int8_t* pinned_cbs = nullptr; size_t pinned_cbs_cap = 0;      // Hauser bias of the query block, pinned host copy (parallel to the block letters)
 	double ext_stats[12] = { 0 };
+	double ext_plan_stats[3] = { 0, 0, 0 };    // device planner of the last dmnd_extend: groups, groups left to the host, bands (0: the host planned)
 	double host_ms[3] = { 0, 0, 0 };           // host wall time inside dmnd_banded_swipe: prepare, launch+wait, unpack (DMND_TRACE)
 	int comp_based_stats = 1;                  // config.comp_based_stats: 1 = Hauser bias (default), 0 = off
 	int query_contexts = 1;                    // align_mode.query_contexts: 6 for blastx (basic/basic.cpp:40-60)
@@ -202,6 +206,8 @@ int dmnd_swipe_shared(dmnd_ctx* work, const dmnd_ctx* blocks, const dmnd_dp_targ
 	dmnd_hsp* out, uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used);
 int dmnd_swipe_targets(dmnd_ctx* work, const dmnd_ctx* blocks, const int8_t* t, int64_t t_len, const dmnd_dp_target* items, int64_t n, int mode, uint32_t hsp_values,
 	dmnd_hsp* out, uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used);
+// gapped_api.hip: dmnd_gapped_filter on hits that may be in HBM already (hits_dev) and whose flags may stay there (flags == NULL)
+int dmnd_gapped_filter_on(dmnd_ctx* c, const dmnd_seed_hit* hits, const dmnd_seed_hit* hits_dev, int64_t n_hits, int use_cbs_flag, uint8_t* flags, int32_t* scores);
 // frameshift_host.hip: the extension stage of blastx -F for the seed hits of a block pair (sorted by query)
 int dmnd_extend_frameshift(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata, const dmnd_seed_hit* hits, int64_t n_hits, int threads,
 	std::vector<dmnd_match>& out, uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used);

@@ -48,6 +48,7 @@
 #include "bias_kernels.h"
 #include "cbs_adjust.h"
 #include "read_coverage.h"
+#include "plan_kernels.h"
 #include <unordered_map>
 
 namespace dmnd {
@@ -163,7 +164,46 @@ struct QueryWork {
 	std::vector<uint32_t> order;            // ranking order: indices into groups (l.target_scores)
 	int64_t chunk_size = 0;
 	size_t i0 = 0, i1 = 0;                  // current ranking chunk [i0, i1) of `order`
+	// planned on the device (plan_kernels.hip): the query's group records (parallel to `groups`) and the call's band list; sh stays
+	// empty until a group that the device left to the host (PLAN_ON_HOST) is planned
+	const PlanGroup* dev = nullptr;
+	const PlanBand* dev_bands = nullptr;
+	const dmnd_seed_hit* hb = nullptr;      // the query's hits and the index of the first one in the call's hit list
+	int64_t first_index = -1;
 };
+
+// the target ranking of extend() (extend.cpp:403-414) over the loaded groups: the order in which ranking chunks take them
+void rank_groups(const HostCfg& h, QueryWork& w, int query_len)
+{
+	w.order.resize(w.groups.size());
+	for (size_t i = 0; i < w.order.size(); ++i) w.order[i] = (uint32_t)i;
+	w.chunk_size = ranking_chunk_size(h.ref_letters, h.max_target_seqs, h.ranking_block_letters, h.top >= 0.0);
+	if (h.global_ranking > 0) w.chunk_size = std::max<int64_t>((int64_t)w.groups.size(), 1);      // extend.cpp:80: one chunk = all ranked targets
+	if (w.chunk_size < (int64_t)w.groups.size())      // TargetScore::operator<: score desc, target index asc (target.h:146-158)
+		std::sort(w.order.begin(), w.order.end(), [&](uint32_t a, uint32_t b) {
+			return w.groups[a].score > w.groups[b].score || (w.groups[a].score == w.groups[b].score && a < b);
+		});
+	w.i0 = 0;
+	w.i1 = std::min((size_t)w.chunk_size, w.order.size());
+	// a first chunk smaller than -k (k above MAX_CHUNK_SIZE) grows by 16 targets at a time while their seed-hit score would pass
+	// the e-value cutoff against a 50-letter target (extend.cpp:262-268, UNIFIED_TARGET_LEN)
+	if (h.top < 0.0 && h.min_bit_score == 0.0 && (int64_t)(w.i1 - w.i0) < (int64_t)h.max_target_seqs && h.evaluer)
+		while (w.i1 < w.order.size() && h.evaluer->evalue(w.groups[w.order[w.i1]].score, (unsigned)query_len, 50u) <= h.max_evalue)
+			w.i1 += std::min<size_t>(16, w.order.size() - w.i1);
+}
+
+// load_hits as the device did it (plan_kernels.hip): the query's groups are copied from its PlanGroup records, no hit is touched
+void load_query_planned(const HostCfg& h, QueryWork& w, uint32_t query, const PlanGroup* g, size_t n_groups, const PlanBand* bands,
+	const dmnd_seed_hit* hb, int64_t first_index, int query_len)
+{
+	w.query = query;
+	w.sh.clear();
+	w.dev = g; w.dev_bands = bands; w.hb = hb; w.first_index = first_index;
+	w.groups.resize(n_groups);
+	for (size_t k = 0; k < n_groups; ++k)
+		w.groups[k] = TargetGroup{ g[k].target, (size_t)(g[k].hit_begin - (uint32_t)first_index), (size_t)(g[k].hit_begin - (uint32_t)first_index) + g[k].n_hits, (int)g[k].score, g[k].pass != 0 };
+	rank_groups(h, w, query_len);
+}
 
 // load_hits (load_hits.h:44-127) + the target ranking of extend() (extend.cpp:403-414)
 void load_query(const HostCfg& h, QueryWork& w, uint32_t query, const dmnd_seed_hit* hb, const dmnd_seed_hit* he, const uint8_t* gf_flags,
@@ -210,21 +250,7 @@ void load_query(const HostCfg& h, QueryWork& w, uint32_t query, const dmnd_seed_
 		w.groups.back().score = std::max(w.groups.back().score, (int)(uint16_t)hits[x].score);
 		w.groups.back().pass |= (carried(x) & 1u) != 0;  // gapped-filter flag of the hit (1 everywhere when the filter is off)
 	}
-	w.order.resize(w.groups.size());
-	for (size_t i = 0; i < w.order.size(); ++i) w.order[i] = (uint32_t)i;
-	w.chunk_size = ranking_chunk_size(h.ref_letters, h.max_target_seqs, h.ranking_block_letters, h.top >= 0.0);
-	if (h.global_ranking > 0) w.chunk_size = std::max<int64_t>((int64_t)w.groups.size(), 1);      // extend.cpp:80: one chunk = all ranked targets
-	if (w.chunk_size < (int64_t)w.groups.size())      // TargetScore::operator<: score desc, target index asc (target.h:146-158)
-		std::sort(w.order.begin(), w.order.end(), [&](uint32_t a, uint32_t b) {
-			return w.groups[a].score > w.groups[b].score || (w.groups[a].score == w.groups[b].score && a < b);
-		});
-	w.i0 = 0;
-	w.i1 = std::min((size_t)w.chunk_size, w.order.size());
-	// a first chunk smaller than -k (k above MAX_CHUNK_SIZE) grows by 16 targets at a time while their seed-hit score would pass
-	// the e-value cutoff against a 50-letter target (extend.cpp:262-268, UNIFIED_TARGET_LEN)
-	if (h.top < 0.0 && h.min_bit_score == 0.0 && (int64_t)(w.i1 - w.i0) < (int64_t)h.max_target_seqs && h.evaluer)
-		while (w.i1 < w.order.size() && h.evaluer->evalue(w.groups[w.order[w.i1]].score, (unsigned)query_len, 50u) <= h.max_evalue)
-			w.i1 += std::min<size_t>(16, w.order.size() - w.i1);
+	rank_groups(h, w, query_len);
 }
 
 // ungapped_stage + chaining + add_dp_targets for the targets order[g0, g1) of one query (all its contexts)
@@ -247,6 +273,22 @@ void plan_groups(const HostCfg& h, ChainWorkspace& ws, QueryWork& w, size_t g0, 
 	for (size_t gi = g0; gi < g1; ++gi) {
 		const TargetGroup& g = w.groups[w.order[gi]];
 		if (!g.pass) continue;                               // gapped filter (extend.cpp:205-213): dropped before chaining
+		if (w.dev) {
+			// planned on the device: the bands are looked up. A group the device left to the host goes through the code below, on
+			// the query's seed hits (built here, once, when the first such group turns up)
+			const PlanGroup& pg = w.dev[w.order[gi]];
+			if (pg.n_bands != PLAN_ON_HOST) {
+				for (uint32_t k = 0; k < pg.n_bands; ++k)
+					out.push_back(PlanTarget{ q0, g.target, w.dev_bands[pg.band_begin + k].d_begin, w.dev_bands[pg.band_begin + k].d_end, g.score });
+				continue;
+			}
+			if (sh.empty()) {
+				sh.resize(w.groups.back().end);
+				for (const TargetGroup& tg : w.groups)
+					for (size_t x = tg.begin; x < tg.end; ++x)
+						sh[x] = HostSeedHit{ w.hb[x].seed_offset, (int)(w.hb[x].subject - tl[tg.target]), w.hb[x].score, 0, (int)(w.first_index + (int64_t)x) };
+			}
+		}
 		const SeqRef t{ tdata + tl[g.target], (int)(tl[g.target + 1] - tl[g.target] - 1) };
 		int ungapped[6] = { 0, 0, 0, 0, 0, 0 };
 		for (int f = 0; f < C; ++f) segs[f].clear();
@@ -562,6 +604,66 @@ struct QueryState {
 
 }
 
+// What the device planner hands over (page-locked host copies of its lists; valid until the context's next dmnd_extend)
+struct DevPlan {
+	const PlanGroup* groups = nullptr;
+	const PlanQuery* queries = nullptr;       // n_queries + 1 entries
+	const PlanBand* bands = nullptr;
+	uint32_t n_groups = 0, n_queries = 0, n_bands = 0, n_on_host = 0;
+};
+
+// Runs the planner over the call's hits (in c->xd_hits, with their x-drop extensions in c->xd_out and -- gf_on -- their gapped
+// filter flags in c->gf_flags), waits for it and copies its lists to the host. planned = false: the hits are not in
+// (query, location, seed offset) order, the host has to plan.
+static int plan_on_device(dmnd_ctx* c, const HostCfg& h, int64_t n_hits, bool gf_on, DevPlan& plan, bool& planned)
+{
+	planned = false;
+	const size_t n = (size_t)n_hits;
+	auto align = [](size_t x) { return (x + 63) & ~(size_t)63; };
+	const size_t o_tgt = 0, o_heads = align(o_tgt + n * sizeof(uint32_t)), o_scan = align(o_heads + n * sizeof(uint64_t)),
+		o_groups = align(o_scan + n * sizeof(uint64_t)), o_queries = align(o_groups + (n + 1) * sizeof(PlanGroup)),
+		o_segs = align(o_queries + (n + 1) * sizeof(PlanQuery)), o_slots = align(o_segs + n * 4 * sizeof(int32_t)),
+		o_count = align(o_slots + n * sizeof(PlanBand)), o_off = align(o_count + (n + 1) * sizeof(uint32_t)),
+		o_bands = align(o_off + (n + 1) * sizeof(uint32_t)), o_counters = align(o_bands + n * sizeof(PlanBand)),
+		bytes = o_counters + sizeof(PlanCounters);
+	if (int rc = c->plan_dev.ensure(bytes)) return rc;
+	char* d = c->plan_dev.as<char>();
+	PlanArgs a;
+	a.qblock = c->block[DMND_QUERY].as<int8_t>(); a.tblock = c->block[DMND_TARGET].as<int8_t>();
+	a.qlimits = c->d_limits[DMND_QUERY].as<int64_t>(); a.tlimits = c->d_limits[DMND_TARGET].as<int64_t>();
+	a.n_targets = (int64_t)c->limits[DMND_TARGET].size() - 1;
+	a.matrix = c->matrix.as<int8_t>();
+	a.hits = c->xd_hits.as<dmnd_seed_hit>(); a.n_hits = n_hits;
+	a.gf_flags = gf_on ? c->gf_flags.as<uint8_t>() : nullptr;
+	a.xd = c->xd_out.as<XdropSeg>();
+	a.gap_open = h.S.gap_open; a.gap_extend = h.S.gap_extend; a.band_fast = h.band_mode_fast;
+	a.tgt = reinterpret_cast<uint32_t*>(d + o_tgt); a.heads = reinterpret_cast<uint64_t*>(d + o_heads); a.head_scan = reinterpret_cast<uint64_t*>(d + o_scan);
+	a.groups = reinterpret_cast<PlanGroup*>(d + o_groups); a.queries = reinterpret_cast<PlanQuery*>(d + o_queries);
+	a.segs = reinterpret_cast<int32_t*>(d + o_segs); a.band_slots = reinterpret_cast<PlanBand*>(d + o_slots);
+	a.band_count = reinterpret_cast<uint32_t*>(d + o_count); a.band_off = reinterpret_cast<uint32_t*>(d + o_off);
+	a.bands = reinterpret_cast<PlanBand*>(d + o_bands); a.counters = reinterpret_cast<PlanCounters*>(d + o_counters);
+	a.scan_tmp = &c->plan_tmp; a.scan_tmp_bytes = &c->plan_tmp_bytes;
+	HIP_TRY(launch_plan(a, c->stream));
+	if (int rc = c->plan_host.ensure(sizeof(PlanCounters))) return rc;
+	HIP_TRY(copy_now(c->stream, c->plan_host.p, a.counters, sizeof(PlanCounters), hipMemcpyDeviceToHost));
+	const PlanCounters cn = *c->plan_host.as<PlanCounters>();
+	if (cn.unsorted || cn.n_groups == 0) return DMND_OK;
+	const size_t h_groups = align(sizeof(PlanCounters)), h_queries = align(h_groups + (size_t)cn.n_groups * sizeof(PlanGroup)),
+		h_bands = align(h_queries + ((size_t)cn.n_queries + 1) * sizeof(PlanQuery)), h_bytes = h_bands + (size_t)cn.n_bands * sizeof(PlanBand);
+	if (int rc = c->plan_host.ensure(h_bytes)) return rc;
+	char* hp = c->plan_host.as<char>();
+	HIP_TRY(hipMemcpyAsync(hp + h_groups, a.groups, (size_t)cn.n_groups * sizeof(PlanGroup), hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipMemcpyAsync(hp + h_queries, a.queries, ((size_t)cn.n_queries + 1) * sizeof(PlanQuery), hipMemcpyDeviceToHost, c->stream));
+	if (cn.n_bands) HIP_TRY(hipMemcpyAsync(hp + h_bands, a.bands, (size_t)cn.n_bands * sizeof(PlanBand), hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(sync_stream(c->stream));
+	plan.groups = reinterpret_cast<const PlanGroup*>(hp + h_groups);
+	plan.queries = reinterpret_cast<const PlanQuery*>(hp + h_queries);
+	plan.bands = reinterpret_cast<const PlanBand*>(hp + h_bands);
+	plan.n_groups = cn.n_groups; plan.n_queries = cn.n_queries; plan.n_bands = cn.n_bands; plan.n_on_host = cn.n_on_host;
+	planned = true;
+	return DMND_OK;
+}
+
 // Steps 2.. of the extension stage for the queries qr[qr_begin, qr_end): c = the context that owns the blocks, limits, bias
 // and statistics parameters (read only), w = the context whose stream, device work buffers and counters this range uses
 // (w == c, or one of c's auxiliary contexts when the block is processed as concurrent sub-batches).
@@ -572,7 +674,8 @@ struct QueryState {
 static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const std::vector<Range>& qr, size_t qr_begin, size_t qr_end,
 	const dmnd_seed_hit* hits, const std::vector<uint8_t>& gf, const int8_t* qdata, const int8_t* tdata, const int8_t* cbs,
 	int threads, uint32_t hsp_values, std::vector<dmnd_match>& out_matches,
-	uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used, hipStream_t bias_stream = nullptr, const XdropSeg* xd = nullptr)
+	uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used, hipStream_t bias_stream = nullptr, const XdropSeg* xd = nullptr,
+	const DevPlan* dp = nullptr)      // dp: the call's groups and bands as the device planned them (entry k of dp->queries = query range qr[k])
 {
 	const std::vector<int64_t>& ql = c->limits[DMND_QUERY];
 	const std::vector<int64_t>& tl = c->limits[DMND_TARGET];
@@ -616,6 +719,12 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 		for (size_t i = slice_begin(t); i < slice_begin(t + 1); ++i) {
 			const Range& r = qr[qr_begin + i];
 			const uint32_t q0 = hits[r.b].query / (uint32_t)h.contexts * (uint32_t)h.contexts;       // first context of the query
+			if (dp) {
+				const PlanQuery& pq = dp->queries[qr_begin + i];
+				load_query_planned(h, qs[i].w, hits[r.b].query, dp->groups + pq.group_begin, (size_t)(dp->queries[qr_begin + i + 1].group_begin - pq.group_begin), dp->bands,
+					hits + r.b, (int64_t)r.b, (int)(ql[q0 + 1] - ql[q0] - 1));
+			}
+			else
 			load_query(h, qs[i].w, hits[r.b].query / (uint32_t)h.contexts, hits + r.b, hits + r.e, gf.empty() ? nullptr : gf.data() + r.b, tl.data(), (int64_t)tl.size() - 1, coarse,
 				(int)(ql[q0 + 1] - ql[q0] - 1), (int64_t)r.b);
 			if (qs[i].w.order.empty()) qs[i].done = true;
@@ -1293,19 +1402,42 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 		xa.qlimits = c->d_limits[DMND_QUERY].as<int64_t>(); xa.matrix = c->matrix.as<int8_t>();
 		xa.hits = c->xd_hits.as<dmnd_seed_hit>(); xa.n_hits = n_hits; xa.xdrop = h.xdrop; xa.out = c->xd_out.as<XdropSeg>();
 		HIP_TRY(launch_xdrop_segs(xa, c->stream));
-		HIP_TRY(hipMemcpyAsync(c->xd_host.p, c->xd_out.p, (size_t)n_hits * sizeof(XdropSeg), hipMemcpyDeviceToHost, c->stream));
 		bias_pending = true;                                // the same wait covers it
-		xd = c->xd_host.as<XdropSeg>();
+		xd = c->xd_host.as<XdropSeg>();                     // (copied back below, once it is known whether the host needs it)
 	}
 	lap(4, 1);
+	// The groups, segments, chains and bands of every (query, target) pair on the device (plan_kernels.hip; one query context, banded
+	// extension). DMND_EXTEND_PLAN_GPU=0: the host plans, as up to round 5.
+	static const bool plan_gpu = [] { const char* e = std::getenv("DMND_EXTEND_PLAN_GPU"); return !e || e[0] != '0'; }();
+	const bool try_plan = plan_gpu && xd && h.contexts == 1 && n_hits < ((int64_t)1 << 31);
 	// 1b. gapped filter of every seed hit in one launch (only --sensitive and above; extend.cpp:205-213)
 	std::vector<uint8_t> gf;
 	c->gf_ms = 0;
-	if (c->gapped_filter_evalue > 0.0 && n_hits > 0 && h.global_ranking == 0) {      // (extend.cpp:206: not for globally ranked targets)
+	const bool gf_on = c->gapped_filter_evalue > 0.0 && n_hits > 0 && h.global_ranking == 0;      // (extend.cpp:206: not for globally ranked targets)
+	if (gf_on) {
 		if (bias_pending) { HIP_TRY(sync_stream(c->stream)); bias_pending = false; }      // the filter's profile reads the bias
-		gf.resize((size_t)n_hits);
-		if (int rc = dmnd_gapped_filter(c, hits, n_hits, h.use_cbs ? 1 : 0, gf.data(), nullptr)) return rc;
+		if (!try_plan) gf.resize((size_t)n_hits);
+		// (with the device planner the hits are in HBM already and the flags stay there)
+		if (int rc = dmnd_gapped_filter_on(c, hits, try_plan ? c->xd_hits.as<dmnd_seed_hit>() : nullptr, n_hits, h.use_cbs ? 1 : 0, try_plan ? nullptr : gf.data(), nullptr)) return rc;
 	}
+	lap(4, 2);
+	DevPlan plan;
+	bool planned = false;
+	if (try_plan) {
+		if (int rc = plan_on_device(c, h, n_hits, gf_on, plan, planned)) return rc;
+		if (planned && plan.n_queries != qr.size()) planned = false;
+		if (!planned && gf_on) {                            // hits out of order (a caller's own list): the host plans, and needs the flags
+			gf.resize((size_t)n_hits);
+			HIP_TRY(copy_now(c->stream, gf.data(), c->gf_flags.p, (size_t)n_hits, hipMemcpyDeviceToHost));
+		}
+		bias_pending = false;                               // plan_on_device has waited for the stream
+	}
+	if (xd && (!planned || plan.n_on_host > 0)) {
+		HIP_TRY(hipMemcpyAsync(c->xd_host.p, c->xd_out.p, (size_t)n_hits * sizeof(XdropSeg), hipMemcpyDeviceToHost, c->stream));
+		bias_pending = true;
+	}
+	const DevPlan* dp = planned ? &plan : nullptr;
+	c->ext_plan_stats[0] = planned ? (double)plan.n_groups : 0; c->ext_plan_stats[1] = planned ? (double)plan.n_on_host : 0; c->ext_plan_stats[2] = planned ? (double)plan.n_bands : 0;
 	lap(4, 2);
 	if (const char* tr = std::getenv("DMND_TRACE")) if (tr[0] == '3') {
 		const double t0 = now();
@@ -1347,7 +1479,7 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 			std::vector<dmnd_match> part;
 			int64_t used = 0;
 			rcs[0] = extend_range(c, c, h, qr, b, e, hits, gf, qdata, tdata, cbs, std::min(threads, team), hsp_values, part, transcript ? transcript + t_used : nullptr,
-				transcript ? transcript_cap - t_used : 0, &used, b == 0 && bias_pending ? c->stream : nullptr, xd);
+				transcript ? transcript_cap - t_used : 0, &used, b == 0 && bias_pending ? c->stream : nullptr, xd, dp);
 			if (rcs[0] != DMND_OK) break;
 			if (t_used > 0) for (dmnd_match& m : part) if (m.hsp.transcript_off >= 0) m.hsp.transcript_off += t_used;
 			t_used += used;
@@ -1361,7 +1493,7 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	}
 	else if (split == 1) {
 		rcs[0] = extend_range(c, c, h, qr, 0, qr.size(), hits, gf, qdata, tdata, cbs, std::min(threads, team), hsp_values, parts[0], transcript, transcript_cap, transcript_used,
-			bias_pending ? c->stream : nullptr, xd);
+			bias_pending ? c->stream : nullptr, xd, dp);
 	}
 	else {
 		if (bias_pending) HIP_TRY(sync_stream(c->stream));
@@ -1384,7 +1516,7 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 				dmnd_ctx* w = work[(size_t)r];
 				for (int k; (k = next_sub.fetch_add(1)) < split;) {
 					const size_t b = qr.size() * (size_t)k / (size_t)split, e = qr.size() * (size_t)(k + 1) / (size_t)split;
-					rcs[(size_t)k] = extend_range(c, w, h, qr, b, e, hits, gf, qdata, tdata, cbs, sub_threads, hsp_values, parts[(size_t)k], nullptr, 0, nullptr, nullptr, xd);
+					rcs[(size_t)k] = extend_range(c, w, h, qr, b, e, hits, gf, qdata, tdata, cbs, sub_threads, hsp_values, parts[(size_t)k], nullptr, 0, nullptr, nullptr, xd, dp);
 					if (rcs[(size_t)k] != DMND_OK) { errs[(size_t)k] = dmnd_last_error(); break; }
 					for (int i = 0; i < 12; ++i) acc[(size_t)r][(size_t)i] += w->ext_stats[i];
 				}
@@ -1759,6 +1891,13 @@ extern "C" int dmnd_extend_stats(const dmnd_ctx* c, double out[12])
 {
 	if (!c || !out) return fail(DMND_E_ARG, "dmnd_extend_stats: NULL argument");
 	for (int i = 0; i < 12; ++i) out[i] = c->ext_stats[i];
+	return DMND_OK;
+}
+
+extern "C" int dmnd_extend_plan_stats(const dmnd_ctx* c, double out[3])
+{
+	if (!c || !out) return fail(DMND_E_ARG, "dmnd_extend_plan_stats: NULL argument");
+	for (int i = 0; i < 3; ++i) out[i] = c->ext_plan_stats[i];
 	return DMND_OK;
 }
 

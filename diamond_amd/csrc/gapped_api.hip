@@ -44,7 +44,15 @@ extern "C" int dmnd_set_gapped_filter(dmnd_ctx* c, double evalue)
 
 extern "C" int dmnd_gapped_filter(dmnd_ctx* c, const dmnd_seed_hit* hits, int64_t n_hits, int use_cbs_flag, uint8_t* flags, int32_t* scores)
 {
-	if (!c || (!hits && n_hits) || (!flags && n_hits)) return fail(DMND_E_ARG, "dmnd_gapped_filter: NULL argument");
+	if (!flags && n_hits) return fail(DMND_E_ARG, "dmnd_gapped_filter: NULL argument");
+	return dmnd_gapped_filter_on(c, hits, nullptr, n_hits, use_cbs_flag, flags, scores);
+}
+
+// hits_dev != NULL: the same hits are in HBM already (dmnd_extend's x-drop stage uploaded them) -- no second upload;
+// flags == NULL: the flags stay in ctx->gf_flags for the device planner, nothing is copied back
+int dmnd_gapped_filter_on(dmnd_ctx* c, const dmnd_seed_hit* hits, const dmnd_seed_hit* hits_dev, int64_t n_hits, int use_cbs_flag, uint8_t* flags, int32_t* scores)
+{
+	if (!c || (!hits && n_hits)) return fail(DMND_E_ARG, "dmnd_gapped_filter: NULL argument");
 	if (n_hits < 0) return fail(DMND_E_ARG, "dmnd_gapped_filter: negative count");
 	if (c->gapped_filter_evalue <= 0.0) return fail(DMND_E_ARG, "dmnd_gapped_filter: filter is off (dmnd_set_gapped_filter)");
 	if (!c->block[DMND_QUERY].p || !c->block[DMND_TARGET].p || c->limits[DMND_QUERY].size() < 2 || c->limits[DMND_TARGET].size() < 2)
@@ -55,10 +63,10 @@ extern "C" int dmnd_gapped_filter(dmnd_ctx* c, const dmnd_seed_hit* hits, int64_
 	if (n_hits == 0) return DMND_OK;
 	HIP_TRY(hipSetDevice(c->device));
 	hipStream_t st = c->stream;
-	if (int rc = c->gf_hits.ensure((size_t)n_hits * sizeof(dmnd_seed_hit))) return rc;
+	if (!hits_dev) if (int rc = c->gf_hits.ensure((size_t)n_hits * sizeof(dmnd_seed_hit))) return rc;
 	if (int rc = c->gf_flags.ensure((size_t)n_hits)) return rc;
 	if (scores) if (int rc = c->gf_scores.ensure((size_t)n_hits * 2 * sizeof(int32_t))) return rc;
-	HIP_TRY(hipMemcpyAsync(c->gf_hits.p, hits, (size_t)n_hits * sizeof(dmnd_seed_hit), hipMemcpyHostToDevice, st));
+	if (!hits_dev) HIP_TRY(hipMemcpyAsync(c->gf_hits.p, hits, (size_t)n_hits * sizeof(dmnd_seed_hit), hipMemcpyHostToDevice, st));
 	GfArgs a;
 	const double LN2 = 0.69314718055994530941723212145818;
 	a.p.diag_score = (int32_t)std::ceil((12.0 * LN2 + std::log(c->params.K)) / c->params.lambda);    // rawscore(gapped_filter_diag_bit_score), setup.cpp:368
@@ -71,7 +79,7 @@ extern "C" int dmnd_gapped_filter(dmnd_ctx* c, const dmnd_seed_hit* hits, int64_
 	a.n_targets = (int64_t)c->limits[DMND_TARGET].size() - 1;
 	a.matrix = c->matrix.as<int8_t>();
 	a.cutoff1 = c->gf_tables.as<int32_t>(); a.cutoff2 = a.cutoff1 + 32 * 32;
-	a.hits = c->gf_hits.as<dmnd_seed_hit>(); a.n_hits = n_hits;
+	a.hits = hits_dev ? hits_dev : c->gf_hits.as<dmnd_seed_hit>(); a.n_hits = n_hits;
 	a.flags = c->gf_flags.as<uint8_t>();
 	a.scores = scores ? c->gf_scores.as<int32_t>() : nullptr;
 	// Units: runs of consecutive hits of one query (the seed stage hands its hits over sorted by query), at most GF_UNIT_HITS each,
@@ -113,7 +121,7 @@ extern "C" int dmnd_gapped_filter(dmnd_ctx* c, const dmnd_seed_hit* hits, int64_
 	}
 	else HIP_TRY(launch_gapped_filter(a, st));
 	HIP_TRY(hipEventRecord(c->ev1, st));
-	HIP_TRY(hipMemcpyAsync(flags, c->gf_flags.p, (size_t)n_hits, hipMemcpyDeviceToHost, st));
+	if (flags) HIP_TRY(hipMemcpyAsync(flags, c->gf_flags.p, (size_t)n_hits, hipMemcpyDeviceToHost, st));
 	if (scores) HIP_TRY(hipMemcpyAsync(scores, c->gf_scores.p, (size_t)n_hits * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
 	HIP_TRY(sync_stream(st));
 	float ms = 0;

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DMND_ABI_VERSION 10      /* 2: dmnd_match.frame, seed parameters (ungapped filter, translated queries), dmnd_extend_plan(query_contexts); 3: seed_encoding; 4: output formats; 5: DMND_MAX_SHAPES 64; 6: dmnd_host_alloc, dmnd_share_block; 7: dmnd_set_max_hsps, several dmnd_match records per target, global ranking; 8: --comp-based-stats 2..5 (dmnd_cbs_*, dmnd_upload_matrices, dmnd_dp_target::cbs_off <= -2); dmnd_mask_block patches host_data in place (the full copy-back of ABI <= 6 only above 1/16 masked letters); 9: frameshift alignment (dmnd_set_frameshift, dmnd_frameshift_swipe, dmnd_match.read_begin / read_end: the record is 104 bytes), dmnd_set_context_motif_table, dmnd_copy_block; 10: dmnd_join_blocks_range (round 5) */
+#define DMND_ABI_VERSION 11      /* 2: dmnd_match.frame, seed parameters (ungapped filter, translated queries), dmnd_extend_plan(query_contexts); 3: seed_encoding; 4: output formats; 5: DMND_MAX_SHAPES 64; 6: dmnd_host_alloc, dmnd_share_block; 7: dmnd_set_max_hsps, several dmnd_match records per target, global ranking; 8: --comp-based-stats 2..5 (dmnd_cbs_*, dmnd_upload_matrices, dmnd_dp_target::cbs_off <= -2); dmnd_mask_block patches host_data in place (the full copy-back of ABI <= 6 only above 1/16 masked letters); 9: frameshift alignment (dmnd_set_frameshift, dmnd_frameshift_swipe, dmnd_match.read_begin / read_end: the record is 104 bytes), dmnd_set_context_motif_table, dmnd_copy_block; 10: dmnd_join_blocks_range (round 5); 11: dmnd_extend_plan_stats (round 6: device planner) */
 
 enum {
 	DMND_OK = 0,
@@ -575,6 +575,13 @@ int dmnd_touch_streams(dmnd_ctx* ctx);
  * (DpTarget::cells, src/dp/dp.h:121-124: the GCUPS denominator); host wall ms [4] Hauser+upload [5] chaining [6] round-1
  * call [7] culling [8] round-2 call; device ms [9] round-1 swipe [10] round-2 swipe [11] traceback. */
 int dmnd_extend_stats(const dmnd_ctx* ctx, double out[12]);
+/* Round 6: the extension stage plans on the device -- grouping the seed hits by target (load_hits, src/align/load_hits.h:44),
+ * diagonal segments (src/align/ungapped.cpp:62-126), chaining (src/chaining/greedy_align.cpp:482-497) and band construction
+ * (src/align/gapped_score.cpp:107-180) of ALL (query, target) pairs of a block pair in a few launches (one query context, banded
+ * modes). Of the last dmnd_extend: [0] (query, target) groups the device found, [1] groups it left to the host (more than 32 hits
+ * or 16 segments), [2] round-1 bands it planned; all 0 = the host planned (several contexts, --ext full, hits not in
+ * (query, location) order). Lets a test tell which path produced the records. */
+int dmnd_extend_plan_stats(const dmnd_ctx* ctx, double out[3]);
 /* BLAST tabular (-f 6 default fields) line of one match, as the reference prints it; returns the length written. */
 int dmnd_format_tab(const dmnd_match* m, const char* qseqid, const char* sseqid, char* buf, int64_t cap);
 

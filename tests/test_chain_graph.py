@@ -30,6 +30,8 @@ def _run(which, q, cbs, t, M, hits, go=11, ge=1):
                             ctypes.c_void_p(tb.ctypes.data + pad), len(t), m.ctypes.data_as(ctypes.c_void_p), go, ge,
                             hi.ctypes.data_as(ctypes.c_void_p), hj.ctypes.data_as(ctypes.c_void_p), len(hits),
                             segs.ctypes.data_as(ctypes.c_void_p), 8192, ctypes.byref(nseg), chains.ctypes.data_as(ctypes.c_void_p), 1024)
+    if n < 0:                                   # which == 2 only: the target does not fit the fixed-capacity instance
+        return segs[:4 * nseg.value].reshape(-1, 4).copy(), None
     return segs[:4 * nseg.value].reshape(-1, 4).copy(), chains[:7 * n].reshape(-1, 7).copy()
 
 
@@ -116,3 +118,30 @@ def test_many_segments_take_the_length_cap_path():
         assert np.array_equal(s0, s1) and np.array_equal(c0, c1), it
         seen += len(s0) > 200
     assert seen >= 3
+
+
+def test_fixed_capacity_instance_equals_the_host_instance():
+    """The device planner's instance of the same source (ChainWorkspaceT<FixedChainPolicy>: arrays of 16 segments / 96 links in a
+    lane's private memory, insertion sort) against the host's std::vector instance: identical chains whenever the target fits,
+    and most multi-segment targets do fit (the others are chained on the host)."""
+    hdr, _ = read_tap(os.path.join(GOLDEN, "swipe_fast.tap"), max_records=1)
+    M = hdr["matrix8"]
+    rng = np.random.default_rng(606)
+    fit = multi = 0
+    for it in range(3000):
+        q, t = _pair(rng, it % 4)
+        cbs = rng.integers(-2, 2, len(q)).astype(np.int8) if it % 3 == 0 else None
+        hits = _hits(rng, q, t, w=(4, 5, 6)[it % 3])
+        if it % 2:                              # fewer hits: the sizes the seed stage really produces per target
+            hits = hits[::max(1, len(hits) // int(rng.integers(2, 14)))]
+        s0, c0 = _run(0, q, cbs, t, M, hits)
+        s2, c2 = _run(2, q, cbs, t, M, hits)
+        assert np.array_equal(s0, s2), it
+        if len(s0) > 1:
+            multi += 1
+        if c2 is None:
+            assert len(s0) > 1
+            continue
+        fit += len(s0) > 1
+        assert np.array_equal(c0, c2), (it, c0, c2)
+    assert multi > 1500 and fit > 0.5 * multi, (fit, multi)
