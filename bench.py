@@ -68,6 +68,29 @@ CONFIGS = {
 }
 
 
+def name_thread(name):
+    """OS name of the calling thread (what /proc/<pid>/task/<tid>/comm shows): host_cpu_by_thread below groups by it"""
+    try:
+        import ctypes
+        ctypes.CDLL(None).prctl(15, name.encode()[:15], 0, 0, 0)      # PR_SET_NAME
+    except Exception:
+        pass
+
+
+def thread_cpu_ms():
+    """CPU time (user + system, ms) of every thread of this process by OS thread name"""
+    out, tick = {}, os.sysconf("SC_CLK_TCK")
+    for tid in os.listdir("/proc/self/task"):
+        try:
+            st = open("/proc/self/task/%s/stat" % tid).read()
+        except OSError:
+            continue
+        comm = st[st.index("(") + 1:st.rindex(")")]
+        f = st[st.rindex(")") + 2:].split()
+        out[comm] = out.get(comm, 0.0) + (int(f[11]) + int(f[12])) * 1e3 / tick
+    return out
+
+
 def cgroup_cpus():
     """CPUs of time this process may use: the cgroup quota when there is one (the GPU boxes run the container under
     cpu.max = 16 CPUs for 256 hardware threads), else the visible cores."""
@@ -492,9 +515,9 @@ def main():
 
     if pipeline:
         import concurrent.futures
-        seed_pool = concurrent.futures.ThreadPoolExecutor(max_workers=SC)
-        finish_pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
-        ext_pools = [concurrent.futures.ThreadPoolExecutor(max_workers=1) for _ in range(E)]      # a context runs one call at a time
+        seed_pool = concurrent.futures.ThreadPoolExecutor(max_workers=SC, initializer=name_thread, initargs=("bench-seed",))
+        finish_pool = concurrent.futures.ThreadPoolExecutor(max_workers=1, initializer=name_thread, initargs=("bench-finish",))
+        ext_pools = [concurrent.futures.ThreadPoolExecutor(max_workers=1, initializer=name_thread, initargs=("bench-extend",)) for _ in range(E)]      # a context runs one call at a time
 
     def submit_seed(b):
         alt = False
@@ -556,6 +579,7 @@ def main():
     state["seed_wall"], state["ext_wall"] = [], []
     t0 = time.perf_counter()
     cpu0 = time.process_time()
+    thr0 = thread_cpu_ms()
     each, queue = run(args.steps, queue)
     for f in queue:
         f.result()
@@ -563,6 +587,8 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     cpu_ms_per_step = (time.process_time() - cpu0) * 1e3 / args.steps      # CPU time of all threads of this process
+    thr1 = thread_cpu_ms()
+    cpu_by_thread = {k: round((v - thr0.get(k, 0.0)) / args.steps, 2) for k, v in sorted(thr1.items()) if v - thr0.get(k, 0.0) > 0}
     stream_ms, stream_launches = state["stream_ms"], state["stream_launches"]
 
     def pct(v, q):
@@ -700,6 +726,7 @@ def main():
             "latency_in_pipeline": lat,
             "alone": alone,
             "host_cpu_ms_per_step": cpu_ms_per_step,
+            "host_cpu_ms_per_step_by_thread": cpu_by_thread,      # by OS thread name (10 ms clock ticks): bench-* = this script's stage threads incl. the library calls they make, dmnd-pool = the library's host workers
             "host_cpu_quota": cgroup_cpus(),
             # not part of `value`: one-time PCIe upload of both blocks, and the rate if it were paid on every step
             "block_upload_ms": upload_ms,

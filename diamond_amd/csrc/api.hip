@@ -41,6 +41,28 @@ std::mutex g_sync_mutex;
 std::unordered_map<hipStream_t, hipEvent_t> g_sync_events;
 }
 
+static int sync_spin_us()
+{
+	// Poll for up to DMND_SYNC_SPIN_US microseconds (default 150) before the interrupt-driven wait: a short kernel's count is back
+	// before a sleeping thread would have been woken; the CPU time this can burn is bounded per wait, unlike DMND_SPIN_SYNC
+	static const int v = [] { const char* e = std::getenv("DMND_SYNC_SPIN_US"); return e ? std::max(0, atoi(e)) : 150; }();
+	return v;
+}
+
+hipError_t dmnd::wait_event(hipEvent_t ev)
+{
+	const int spin_us = sync_spin_us();
+	if (spin_us > 0 && !spin_sync()) {
+		const auto t0 = std::chrono::steady_clock::now();
+		do {
+			const hipError_t q = hipEventQuery(ev);
+			if (q == hipSuccess) return hipSuccess;
+			if (q != hipErrorNotReady) return q;
+		} while (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() < spin_us);
+	}
+	return hipEventSynchronize(ev);
+}
+
 hipError_t dmnd::sync_stream(hipStream_t s)
 {
 	if (spin_sync()) return hipStreamSynchronize(s);
@@ -59,18 +81,7 @@ hipError_t dmnd::sync_stream(hipStream_t s)
 	}
 	const hipError_t e = hipEventRecord(ev, s);
 	if (e != hipSuccess) return e;
-	// DMND_SYNC_SPIN_US=n: poll for up to n microseconds before the interrupt-driven wait (a short kernel's count is back before
-	// a sleeping thread would have been woken; the CPU time this can burn is bounded per wait, unlike DMND_SPIN_SYNC)
-	static const int spin_us = [] { const char* v = std::getenv("DMND_SYNC_SPIN_US"); return v ? std::max(0, atoi(v)) : 0; }();
-	if (spin_us > 0) {
-		const auto t0 = std::chrono::steady_clock::now();
-		do {
-			const hipError_t q = hipEventQuery(ev);
-			if (q == hipSuccess) return hipSuccess;
-			if (q != hipErrorNotReady) return q;
-		} while (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() < spin_us);
-	}
-	return hipEventSynchronize(ev);
+	return wait_event(ev);
 }
 
 void dmnd::forget_stream(hipStream_t s)
@@ -191,6 +202,23 @@ hipError_t take_stream(hipStream_t* s, int device, int priority)
 extern "C" hipError_t dmnd_touch_bias(hipStream_t), dmnd_touch_gapped(hipStream_t), dmnd_touch_mask(hipStream_t), dmnd_touch_seed(hipStream_t),
 	dmnd_touch_swipe16(hipStream_t), dmnd_touch_swipe(hipStream_t), dmnd_touch_frameshift(hipStream_t), dmnd_touch_plan(hipStream_t);
 
+// Host waits sleep on the completion interrupt. Measured on ROCm 7.2 (tools/probes/wait_probe.hip, round 6): the event flag
+// hipEventBlockingSync alone changes nothing -- hipEventSynchronize and hipStreamSynchronize spin, 50.0 CPU-ms per 50 ms of
+// kernel -- while with the DEVICE flag hipDeviceScheduleBlockingSync every wait of the process on this device costs 0.5 CPU-ms
+// per 50 ms and returns 30 - 60 us later. sync_stream polls for a bounded time first, so short kernels do not pay that latency.
+// The seed stage's thread burnt 142 of C3's 239 host CPU-ms per step this way. DMND_SPIN_SYNC=1 keeps the spinning waits.
+// Called with `device` current, by dmnd_init and by every dmnd_create (once per device).
+static void blocking_waits(int device)
+{
+	static std::mutex m;
+	static std::vector<int> done;
+	std::lock_guard<std::mutex> g(m);
+	if (spin_sync() || std::find(done.begin(), done.end(), device) != done.end()) return;
+	(void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
+	(void)hipGetLastError();
+	done.push_back(device);
+}
+
 extern "C" int dmnd_init(int device)
 {
 	const auto t0 = std::chrono::steady_clock::now();
@@ -202,6 +230,7 @@ extern "C" int dmnd_init(int device)
 	if (device < 0) device = 0;
 	if (device >= count) return fail(DMND_E_ARG, "dmnd_init: device index out of range");
 	HIP_TRY(hipSetDevice(device));
+	blocking_waits(device);
 	// The first launch of a kernel of a translation unit loads that unit's code object onto the device: all of them now, so that
 	// no stage of the search pays for it later. The runtime loads two code objects from two threads at the same time (measured:
 	// 18 + 5 ms one after the other, 16 ms together), and a stream costs 7.6 ms to create on these boxes -- so the two large units
@@ -258,6 +287,7 @@ extern "C" dmnd_ctx* dmnd_create(int device, const dmnd_params* params)
 		return nullptr;
 	}
 	if (hipSetDevice(device) != hipSuccess) { fail(DMND_E_DEVICE, "hipSetDevice failed"); return nullptr; }
+	blocking_waits(device);
 	dmnd_ctx* c = new dmnd_ctx();
 	c->device = device;
 	// host worker pool of the context's extension calls: contexts driven by different host threads (one per GPU) do not share one
@@ -373,7 +403,7 @@ static int upload_bytes(dmnd_ctx* c, void* dst, const void* src, size_t bytes, b
 	size_t done = 0;
 	for (int i = 0; done < bytes; i ^= 1) {
 		const size_t n = std::min(CHUNK, bytes - done);
-		if (busy[i]) HIP_TRY(hipEventSynchronize(ev[i]));
+		if (busy[i]) HIP_TRY(wait_event(ev[i]));
 		std::memcpy(stage[i].p, static_cast<const char*>(src) + done, n);
 		HIP_TRY(hipMemcpyAsync(static_cast<char*>(dst) + done, stage[i].p, n, hipMemcpyHostToDevice, stream));
 		HIP_TRY(hipEventRecord(ev[i], stream));
@@ -393,7 +423,7 @@ int dmnd::download_bytes(dmnd_ctx* c, void* dst, const void* src, size_t bytes)
 	for (int i = 0; i < 2; ++i) {
 		if (int rc = c->up_stage[i].ensure(CHUNK)) return rc;
 		if (!c->up_ev[i]) HIP_TRY(hipEventCreateWithFlags(&c->up_ev[i], hipEventDisableTiming));
-		if (c->up_busy[i]) { HIP_TRY(hipEventSynchronize(c->up_ev[i])); c->up_busy[i] = false; }
+		if (c->up_busy[i]) { HIP_TRY(wait_event(c->up_ev[i])); c->up_busy[i] = false; }
 	}
 	size_t issued = 0, copied = 0;
 	int i = 0;
@@ -409,7 +439,7 @@ int dmnd::download_bytes(dmnd_ctx* c, void* dst, const void* src, size_t bytes)
 			HIP_TRY(hipEventRecord(c->up_ev[i ^ 1], c->stream));
 			issued += m;
 		}
-		HIP_TRY(hipEventSynchronize(c->up_ev[i]));
+		HIP_TRY(wait_event(c->up_ev[i]));
 		std::memcpy(static_cast<char*>(dst) + copied, c->up_stage[i].p, n);
 		copied += n;
 		i ^= 1;

@@ -27,7 +27,8 @@ int fail(int code, const std::string& msg);      // sets dmnd_last_error(), retu
 // thread then burns a whole core for as long as the GPU works, which is what a CPU-quota'd container (cgroup cpu.max; the
 // MI355X boxes of this project give 16 CPUs to 256 hardware threads) can least afford -- the quota runs out and every thread
 // of the process is frozen for the rest of the 100 ms period. So by default the wait is an interrupt-driven one on a
-// hipEventBlockingSync event (one per thread); DMND_SPIN_SYNC=1 restores the spinning wait (lowest latency on an idle host).
+// hipEventBlockingSync event on a device that dmnd_init put into hipDeviceScheduleBlockingSync mode (round 6: the event flag
+// alone does not stop the runtime from spinning); DMND_SPIN_SYNC=1 restores the spinning wait (lowest latency on an idle host).
 inline bool spin_sync()
 {
 	static const bool v = [] { const char* e = std::getenv("DMND_SPIN_SYNC"); return e && e[0] == '1'; }();
@@ -39,6 +40,7 @@ inline bool spin_sync()
 // handful of events and their interrupt signals, and after a few thousand calls the driver's finite pool of them ran out --
 // waits then returned early ("device not ready" from hipEventElapsedTime, stale results behind copy_now).
 hipError_t sync_stream(hipStream_t s);
+hipError_t wait_event(hipEvent_t ev);      // the wait of sync_stream on an event of the caller's: polls DMND_SYNC_SPIN_US microseconds, then sleeps
 void forget_stream(hipStream_t s);
 
 inline hipError_t copy_now(hipStream_t s, void* dst, const void* src, size_t bytes, hipMemcpyKind kind)

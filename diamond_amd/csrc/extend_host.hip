@@ -691,7 +691,16 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 	double t_mark = now();
 	const double t_enter = t_mark;
 	double fine[16] = { 0 }, at[16] = { 0 };          // DMND_TRACE=1: finer host timeline on stderr (at[]: end of each phase since dmnd_extend began, first pass)
-	auto lap = [&](int slot, int f = -1) { const double t = now(); w->ext_stats[slot] += t - t_mark; if (f >= 0) { fine[f] += t - t_mark; if (at[f] == 0) at[f] = t - g_extend_t0; } t_mark = t; };
+	// DMND_TRACE: CPU time of the whole process per phase beside the wall time (only meaningful when nothing else runs, as in the
+	// serial steps bench.py appends to its timed region)
+	static const bool trace_cpu = std::getenv("DMND_TRACE") != nullptr;
+	auto cpu_now = [] { timespec ts; clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+	double cpu[16] = { 0 }, cpu_mark = trace_cpu ? cpu_now() : 0;
+	auto lap = [&](int slot, int f = -1) {
+		const double t = now(); w->ext_stats[slot] += t - t_mark;
+		if (f >= 0) { fine[f] += t - t_mark; if (at[f] == 0) at[f] = t - g_extend_t0; if (trace_cpu) { const double cn = cpu_now(); cpu[f] += cn - cpu_mark; cpu_mark = cn; } }
+		t_mark = t;
+	};
 	lap(4, 1);
 	const size_t nq = qr_end - qr_begin;
 	const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(threads, 1), (nq + 63) / 64));
@@ -1268,6 +1277,9 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 	if (std::getenv("DMND_TRACE"))
 		std::fprintf(stderr, "dmnd_extend[%zu queries, %d slices] ms: bias %.2f load %.2f plan %.2f swipe1 %.2f post1 %.2f build2 %.2f swipe2 %.2f post2 %.2f final %.2f | swipe host: prep %.2f run %.2f post %.2f\n",
 			qs.size(), T, fine[1], fine[3], fine[4], fine[5], fine[6], fine[7], fine[8], fine[9], fine[10], w->host_ms[0], w->host_ms[1], w->host_ms[2]);
+	if (trace_cpu)
+		std::fprintf(stderr, "dmnd_extend process CPU ms: bias %.2f load %.2f plan %.2f swipe1 %.2f post1 %.2f build2 %.2f swipe2 %.2f post2 %.2f final %.2f\n",
+			cpu[1], cpu[3], cpu[4], cpu[5], cpu[6], cpu[7], cpu[8], cpu[9], cpu[10]);
 	return DMND_OK;
 }
 

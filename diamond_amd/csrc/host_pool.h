@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <functional>
 #include <mutex>
+#include <pthread.h>
 #include <thread>
 #include <vector>
 
@@ -86,6 +87,7 @@ private:
 		while ((int)th_.size() < workers) {
 			const int id = (int)th_.size() + 1;
 			th_.emplace_back([this, id] {
+				pthread_setname_np(pthread_self(), "dmnd-pool");      // (per-thread CPU accounting by name: bench.py host_cpu_ms_per_step_by_thread)
 				uint64_t seen = 0;
 				for (;;) {
 					bool got = false;

@@ -297,7 +297,7 @@ struct Timer {
 	}
 	void collect()
 	{
-		if (!spans.empty()) (void)hipEventSynchronize(spans.back().b);
+		if (!spans.empty()) (void)wait_event(spans.back().b);
 		for (const Span& x : spans) {
 			float ms = 0;
 			if (hipEventElapsedTime(&ms, x.a, x.b) == hipSuccess) *x.into += ms;
