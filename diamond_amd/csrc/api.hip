@@ -200,7 +200,7 @@ hipError_t take_stream(hipStream_t* s, int device, int priority)
 }
 
 extern "C" hipError_t dmnd_touch_bias(hipStream_t), dmnd_touch_gapped(hipStream_t), dmnd_touch_mask(hipStream_t), dmnd_touch_seed(hipStream_t),
-	dmnd_touch_swipe16(hipStream_t), dmnd_touch_swipe(hipStream_t), dmnd_touch_frameshift(hipStream_t), dmnd_touch_plan(hipStream_t);
+	dmnd_touch_swipe16(hipStream_t), dmnd_touch_swipe(hipStream_t), dmnd_touch_frameshift(hipStream_t), dmnd_touch_plan(hipStream_t), dmnd_touch_extend(hipStream_t);
 
 // Host waits sleep on the completion interrupt. Measured on ROCm 7.2 (tools/probes/wait_probe.hip, round 6): the event flag
 // hipEventBlockingSync alone changes nothing -- hipEventSynchronize and hipStreamSynchronize spin, 50.0 CPU-ms per 50 ms of
@@ -255,7 +255,7 @@ extern "C" int dmnd_init(int device)
 	hipError_t rc = hipGetLastError();
 	lap("first kernel (api)");
 	struct { const char* name; hipError_t (*fn)(hipStream_t); } units[] = { { "bias", dmnd_touch_bias },
-		{ "swipe16", dmnd_touch_swipe16 }, { "swipe", dmnd_touch_swipe }, { "gapped", dmnd_touch_gapped }, { "plan", dmnd_touch_plan }, { "frameshift", dmnd_touch_frameshift } };
+		{ "swipe16", dmnd_touch_swipe16 }, { "swipe", dmnd_touch_swipe }, { "gapped", dmnd_touch_gapped }, { "plan", dmnd_touch_plan }, { "extend", dmnd_touch_extend }, { "frameshift", dmnd_touch_frameshift } };
 	for (auto& u : units) {
 		if (rc == hipSuccess) rc = u.fn(nullptr);
 		lap(u.name);
@@ -326,6 +326,7 @@ extern "C" void dmnd_destroy(dmnd_ctx* c)
 	c->stage_h.release(); c->ends_h.release(); c->stage_d.release();
 	c->xd_hits.release(); c->xd_out.release(); c->xd_host.release();
 	c->plan_dev.release(); c->plan_host.release();
+	c->ext_dev.release(); c->ext_trace.release(); c->ext_host.release();
 	if (c->plan_tmp) { (void)hipFree(c->plan_tmp); c->plan_tmp = nullptr; c->plan_tmp_bytes = 0; }
 	for (int i = 0; i < 2; ++i) { c->up_stage[i].release(); if (c->up_ev[i]) (void)hipEventDestroy(c->up_ev[i]); c->up_ev[i] = nullptr; }
 	for (int i = 0; i < 2; ++i) { c->t_stage[i].release(); if (c->t_ev[i]) (void)hipEventDestroy(c->t_ev[i]); c->t_ev[i] = nullptr; }
@@ -969,6 +970,42 @@ int swipe_impl(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, int64_t
 }
 
 }  // namespace
+
+// The traceback-mode sweeps of items that were prepared ON THE DEVICE (extend_kernels.hip): the launch order, trace offsets and
+// item pairs are in HBM already, the host only knows how many items every band class has (class c: P = 1 << c) and the longest
+// one's step count. One launch per class, as plan_sweeps / issue_sweeps do for a host-prepared list; pairs of class c start at
+// pair sum((count + 1) / 2) of the classes before it.
+int dmnd_sweep_classes(dmnd_ctx* work, const dmnd_ctx* c, const dmnd_dp_target* d_items, const uint32_t* class_count, const uint32_t* class_max_steps, int n_classes,
+	const int32_t* order_dev, const int64_t* off_slot_dev, const int32_t* pairs_dev, const int64_t* off_item_dev, uint8_t* trace_dev, SwipeEnd* ends_dev)
+{
+	if (!c || !work) return fail(DMND_E_ARG, "ctx is NULL");
+	const int8_t* cbs = c->cbs_len > 0 ? c->cbs.as<int8_t>() : nullptr;
+	int64_t s0 = 0, pair0 = 0;
+	for (int k = 0; k < n_classes; ++k) {
+		const int64_t count = class_count[k];
+		if (count == 0) continue;
+		const int P = 1 << k;
+		const bool k16 = !force_swipe32() && P <= SW16_MAX_P && (int64_t)class_max_steps[k] <= 2 * (int64_t)SW16_MAX_PAIRS;
+		if (k16) {
+			Swipe16Args a;
+			a.qblock = c->block[DMND_QUERY].as<int8_t>(); a.tblock = c->block[DMND_TARGET].as<int8_t>(); a.cbs = cbs; a.matrix = c->matrix.as<int8_t>();
+			a.items = d_items; a.pairs = pairs_dev + 2 * pair0; a.trace_off = off_item_dev; a.trace = trace_dev; a.ends = ends_dev;
+			a.n_pairs = (count + 1) / 2;
+			a.gap_open = c->params.gap_open; a.gap_extend = c->params.gap_extend;
+			HIP_TRY(launch_banded_swipe16(P, true, a, work->stream));
+		}
+		else {
+			SwipeArgs a;
+			a.qblock = c->block[DMND_QUERY].as<int8_t>(); a.tblock = c->block[DMND_TARGET].as<int8_t>(); a.cbs = cbs; a.matrix = c->matrix.as<int8_t>(); a.matrices = nullptr;
+			a.items = d_items; a.order = order_dev + s0; a.trace_off = off_slot_dev + s0; a.trace = trace_dev; a.ends = ends_dev;
+			a.n = count;
+			a.gap_open = c->params.gap_open; a.gap_extend = c->params.gap_extend;
+			HIP_TRY(launch_banded_swipe(P, K_TRACE, a, work->stream));
+		}
+		s0 += count; pair0 += (count + 1) / 2;
+	}
+	return DMND_OK;
+}
 
 int dmnd_swipe_shared(dmnd_ctx* work, const dmnd_ctx* c, const dmnd_dp_target* items, int64_t n, int mode, uint32_t hsp_values,
 	dmnd_hsp* out, uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used)

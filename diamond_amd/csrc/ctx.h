@@ -105,6 +105,9 @@ struct dmnd_ctx {
 	dmnd::DevBuf plan_dev;                    // device planner of dmnd_extend (plan_kernels.hip): its work arrays ...
 	dmnd::PinBuf plan_host;                   // ... and the group / query / band lists it hands to the host
 	void* plan_tmp = nullptr; size_t plan_tmp_bytes = 0;      // rocPRIM scan scratch of the planner
+	dmnd::DevBuf ext_dev, ext_trace;          // device half of dmnd_extend behind the planner (extend_kernels.hip): work arrays, kept traces
+	dmnd::PinBuf ext_host;                    // ... its counters, records and query states on the host
+	double ext_dev_stats[4] = { 0, 0, 0, 0 }; // of the last dmnd_extend: queries extended on the device, of them redone by the host (ambiguous e-value order / 16-bit saturation), items, records
 	std::vector<int32_t> h_bias_ids;           // block sequence ids of the queries with seed hits (Hauser bias of one dmnd_extend call)
 	int64_t block_len[2] = { 0, 0 }, cbs_len = 0;
 	std::vector<int64_t> limits[2];
@@ -204,6 +207,9 @@ struct KeptTrace {
 int dmnd_swipe_keep(dmnd_ctx* work, const dmnd_ctx* blocks, const dmnd_dp_target* items, int64_t n, int arena, dmnd_hsp* out, KeptTrace& kt);
 // items[k] with its KeptTrace entry src[k] (index into kt's vectors): statistics and coordinates from the kept trace, no transcripts
 int dmnd_traceback_kept(dmnd_ctx* work, const dmnd_ctx* blocks, const dmnd_dp_target* items, const KeptTrace& kt, const int64_t* src, int64_t n, dmnd_hsp* out);
+namespace dmnd { struct SwipeEnd; }
+int dmnd_sweep_classes(dmnd_ctx* work, const dmnd_ctx* blocks, const dmnd_dp_target* d_items, const uint32_t* class_count, const uint32_t* class_max_steps, int n_classes,
+	const int32_t* order_dev, const int64_t* off_slot_dev, const int32_t* pairs_dev, const int64_t* off_item_dev, uint8_t* trace_dev, dmnd::SwipeEnd* ends_dev);
 int dmnd_swipe_shared(dmnd_ctx* work, const dmnd_ctx* blocks, const dmnd_dp_target* items, int64_t n, int mode, uint32_t hsp_values,
 	dmnd_hsp* out, uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used);
 int dmnd_swipe_targets(dmnd_ctx* work, const dmnd_ctx* blocks, const int8_t* t, int64_t t_len, const dmnd_dp_target* items, int64_t n, int mode, uint32_t hsp_values,

@@ -49,6 +49,7 @@
 #include "cbs_adjust.h"
 #include "read_coverage.h"
 #include "plan_kernels.h"
+#include "extend_kernels.h"
 #include <unordered_map>
 
 namespace dmnd {
@@ -610,6 +611,7 @@ struct DevPlan {
 	const PlanQuery* queries = nullptr;       // n_queries + 1 entries
 	const PlanBand* bands = nullptr;
 	uint32_t n_groups = 0, n_queries = 0, n_bands = 0, n_on_host = 0;
+	PlanArgs dev;                             // the same lists (and the planner's inputs) where they lie in HBM
 };
 
 // Runs the planner over the call's hits (in c->xd_hits, with their x-drop extensions in c->xd_out and -- gf_on -- their gapped
@@ -660,7 +662,125 @@ static int plan_on_device(dmnd_ctx* c, const HostCfg& h, int64_t n_hits, bool gf
 	plan.queries = reinterpret_cast<const PlanQuery*>(hp + h_queries);
 	plan.bands = reinterpret_cast<const PlanBand*>(hp + h_bands);
 	plan.n_groups = cn.n_groups; plan.n_queries = cn.n_queries; plan.n_bands = cn.n_bands; plan.n_on_host = cn.n_on_host;
+	plan.dev = a;
 	planned = true;
+	return DMND_OK;
+}
+
+// The extension of the queries whose targets fit one ranking chunk, in HBM from the planner's bands to the match records
+// (extend_kernels.h). records: those queries' matches in output order (query ascending; e-value, score, target inside a query) with
+// the HOST's e-value and bit score; qstate[k] (k = index into plan.queries): EXT_Q_DEVICE = done here, anything else = the host path
+// has to extend the query. done = false: nothing was done here (no eligible query, or the kept traces would not fit the context's
+// trace budget), every query goes to the host path.
+static int extend_on_device(dmnd_ctx* c, const HostCfg& h, const DevPlan& plan, int threads, std::vector<dmnd_match>& records, std::vector<uint8_t>& qstate, bool& done)
+{
+	done = false;
+	const int64_t chunk = ranking_chunk_size(h.ref_letters, h.max_target_seqs, h.ranking_block_letters, false);
+	if (chunk > EXT_MAX_CHUNK || plan.n_bands == 0) return DMND_OK;
+	const size_t nG = plan.n_groups, nQ = plan.n_queries, nB = plan.n_bands, nR = std::min(nG, nQ * (size_t)std::max(h.max_target_seqs, 1));
+	size_t at = 0;
+	auto take = [&](size_t bytes) { const size_t o = at; at = (at + bytes + 63) & ~(size_t)63; return o; };
+	const size_t o_gq = take(nG * 4), o_qstate = take(nQ), o_cnt = take((nG + 1) * 4), o_item_off = take((nG + 1) * 4), o_items = take(nB * sizeof(dmnd_dp_target)),
+		o_item_group = take(nB * 4), o_keys = take(nB * 4), o_keys_sorted = take(nB * 4), o_idx = take(nB * 4), o_order = take(nB * 4),
+		o_rows = take(nB * 8), o_rows_slot = take((nB + 1) * 8), o_off_slot = take((nB + 1) * 8), o_off_item = take(nB * 8), o_p = take(nB * 4),
+		o_pairs = take((nB + 2 * EXT_CLASSES) * 4), o_ends = take(nB * sizeof(SwipeEnd)), o_kept = take((nG + 1) * 4), o_kept_pos = take((nG + 1) * 4),
+		o_cand_item = take(nG * 4), o_cand_ev = take(nG * 8), o_r2_order = take(nB * 4), o_r2_p = take(nB * 4), o_r2_off = take(nB * 8), o_r2_tr = take((nB + 1) * 8),
+		o_hsps = take(nB * sizeof(dmnd_hsp)), o_records = take(nR * sizeof(dmnd_match)), o_ctr = take(sizeof(ExtCounters));
+	if (int rc = c->ext_dev.ensure(at)) return rc;
+	char* d = c->ext_dev.as<char>();
+	ExtArgs a;
+	a.groups = plan.dev.groups; a.queries = plan.dev.queries; a.bands = plan.dev.bands;
+	a.n_groups = plan.n_groups; a.n_queries = plan.n_queries; a.n_bands = plan.n_bands;
+	a.hits = plan.dev.hits; a.qlimits = plan.dev.qlimits; a.tlimits = plan.dev.tlimits;
+	a.use_cbs = h.use_cbs ? 1 : 0; a.chunk_size = (uint32_t)chunk; a.k = h.max_target_seqs; a.max_swipe_dp = h.max_swipe_dp;
+	const Evaluer& E = c->evaluer;
+	a.ev = ExtEvalue{ E.lambda, E.K, E.db_letters, E.a, E.b, E.alpha, E.beta, E.sigma, E.tau, E.v_thr, E.c_thr, h.max_evalue };
+	a.gq = reinterpret_cast<uint32_t*>(d + o_gq); a.qstate = reinterpret_cast<uint8_t*>(d + o_qstate);
+	a.cnt = reinterpret_cast<uint32_t*>(d + o_cnt); a.item_off = reinterpret_cast<uint32_t*>(d + o_item_off);
+	a.items = reinterpret_cast<dmnd_dp_target*>(d + o_items); a.item_group = reinterpret_cast<uint32_t*>(d + o_item_group);
+	a.keys = reinterpret_cast<uint32_t*>(d + o_keys); a.keys_sorted = reinterpret_cast<uint32_t*>(d + o_keys_sorted);
+	a.idx = reinterpret_cast<uint32_t*>(d + o_idx); a.order = reinterpret_cast<uint32_t*>(d + o_order);
+	a.rows = reinterpret_cast<int64_t*>(d + o_rows); a.rows_slot = reinterpret_cast<int64_t*>(d + o_rows_slot);
+	a.off_slot = reinterpret_cast<int64_t*>(d + o_off_slot); a.off_item = reinterpret_cast<int64_t*>(d + o_off_item);
+	a.p_of_item = reinterpret_cast<int32_t*>(d + o_p); a.pairs = reinterpret_cast<int32_t*>(d + o_pairs);
+	a.ends = reinterpret_cast<SwipeEnd*>(d + o_ends);
+	a.kept = reinterpret_cast<uint32_t*>(d + o_kept); a.kept_pos = reinterpret_cast<uint32_t*>(d + o_kept_pos);
+	a.cand_item = reinterpret_cast<uint32_t*>(d + o_cand_item); a.cand_ev = reinterpret_cast<double*>(d + o_cand_ev);
+	a.r2_order = reinterpret_cast<int32_t*>(d + o_r2_order); a.r2_p = reinterpret_cast<int32_t*>(d + o_r2_p);
+	a.r2_off = reinterpret_cast<int64_t*>(d + o_r2_off); a.r2_tr = reinterpret_cast<int64_t*>(d + o_r2_tr);
+	a.hsps = reinterpret_cast<dmnd_hsp*>(d + o_hsps); a.records = reinterpret_cast<dmnd_match*>(d + o_records);
+	a.ctr = reinterpret_cast<ExtCounters*>(d + o_ctr);
+	a.scan_tmp = &c->plan_tmp; a.scan_tmp_bytes = &c->plan_tmp_bytes;
+	hipStream_t st = c->stream;
+	// 1. items, launch order, trace offsets, pairs
+	HIP_TRY(launch_ext_prepare(a, st));
+	if (int rc = c->ext_host.ensure(sizeof(ExtCounters))) return rc;
+	HIP_TRY(copy_now(st, c->ext_host.p, a.ctr, sizeof(ExtCounters), hipMemcpyDeviceToHost));
+	ExtCounters ctr = *c->ext_host.as<ExtCounters>();
+	if (ctr.n_eligible == 0 || ctr.n_items == 0) return DMND_OK;
+	if ((size_t)ctr.total_rows > c->trace_arena_max) return DMND_OK;
+	if (int rc = c->ext_trace.ensure((size_t)ctr.total_rows + 64)) return rc;
+	// 2. round 1 in traceback mode (one launch per band class), then best HSP per target, culling, the round-2 list
+	HIP_TRY(hipEventRecord(c->ev0, st));
+	if (int rc = dmnd_sweep_classes(c, c, a.items, ctr.class_count, ctr.class_max_steps, EXT_CLASSES, reinterpret_cast<const int32_t*>(a.order), a.off_slot, a.pairs, a.off_item,
+		c->ext_trace.as<uint8_t>(), a.ends)) return rc;
+	HIP_TRY(hipEventRecord(c->ev1, st));
+	HIP_TRY(launch_ext_select(a, st));
+	HIP_TRY(copy_now(st, c->ext_host.p, a.ctr, sizeof(ExtCounters), hipMemcpyDeviceToHost));
+	ctr = *c->ext_host.as<ExtCounters>();
+	// 3. round 2 = a walk of the survivors' kept traces, then the records
+	if (ctr.n_kept > nR) return fail(DMND_E_CAP, "dmnd_extend: more device records than -k allows");
+	if (ctr.n_kept > 0) {
+		TracebackArgs t;
+		t.qblock = c->block[DMND_QUERY].as<int8_t>(); t.tblock = c->block[DMND_TARGET].as<int8_t>(); t.cbs = c->cbs_len > 0 ? c->cbs.as<int8_t>() : nullptr;
+		t.matrix = c->matrix.as<int8_t>(); t.matrices = nullptr;
+		t.items = a.items; t.order = a.r2_order; t.p_of_slot = a.r2_p; t.trace_off = a.r2_off; t.transcript_off = a.r2_tr;
+		t.trace = c->ext_trace.as<uint8_t>(); t.transcript = nullptr; t.ends = a.ends; t.hsps = a.hsps; t.status = &a.ctr->tb_status;
+		t.n = ctr.n_kept; t.gap_open = c->params.gap_open; t.gap_extend = c->params.gap_extend;
+		HIP_TRY(launch_traceback(t, st));
+	}
+	HIP_TRY(hipEventRecord(c->ev2, st));
+	HIP_TRY(launch_ext_records(a, ctr.n_kept, st));
+	const size_t h_ctr = 0, h_qstate = (sizeof(ExtCounters) + 63) & ~(size_t)63, h_records = (h_qstate + nQ + 63) & ~(size_t)63,
+		h_bytes = h_records + (size_t)ctr.n_kept * sizeof(dmnd_match);
+	if (int rc = c->ext_host.ensure(h_bytes)) return rc;
+	char* hp = c->ext_host.as<char>();
+	HIP_TRY(hipMemcpyAsync(hp + h_ctr, a.ctr, sizeof(ExtCounters), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(hp + h_qstate, a.qstate, nQ, hipMemcpyDeviceToHost, st));
+	if (ctr.n_kept) HIP_TRY(hipMemcpyAsync(hp + h_records, a.records, (size_t)ctr.n_kept * sizeof(dmnd_match), hipMemcpyDeviceToHost, st));
+	HIP_TRY(sync_stream(st));
+	ctr = *reinterpret_cast<const ExtCounters*>(hp + h_ctr);
+	if (ctr.tb_status != 0) return fail(ctr.tb_status, ctr.tb_status == DMND_E_TRACEBACK ? "Traceback error." : "transcript slot too small");
+	float ms1 = 0.f, ms2 = 0.f;
+	HIP_TRY(hipEventElapsedTime(&ms1, c->ev0, c->ev1));
+	HIP_TRY(hipEventElapsedTime(&ms2, c->ev1, c->ev2));
+	qstate.assign(hp + h_qstate, hp + h_qstate + nQ);
+	// 4. the host's own e-value and bit score in every record; the device ordered a query's records by ITS e-values -- checked,
+	// and put right where the two disagree
+	const dmnd_match* rec = reinterpret_cast<const dmnd_match*>(hp + h_records);
+	records.assign(rec, rec + ctr.n_kept);
+	const std::vector<int64_t>& ql = c->limits[DMND_QUERY];
+	const std::vector<int64_t>& tl = c->limits[DMND_TARGET];
+	const size_t n = records.size(), per = 4096, n_chunks = (n + per - 1) / per;
+	parallel_for(n_chunks, std::max(1, std::min(threads, (int)((n + 16383) / 16384))), [&](size_t ci, int) {
+		for (size_t i = ci * per; i < std::min(n, (ci + 1) * per); ++i) {
+			dmnd_match& m = records[i];
+			m.evalue = E.evalue(m.hsp.score, (unsigned)(ql[m.query + 1] - ql[m.query] - 1), (unsigned)(tl[m.target + 1] - tl[m.target] - 1));
+			m.bit_score = E.bitscore(m.hsp.score);
+		}
+	});
+	for (size_t b = 0; b < n;) {
+		size_t e = b + 1;
+		bool sorted = true;
+		while (e < n && records[e].query == records[b].query) { sorted &= !match_less(records[e], records[e - 1]); ++e; }
+		if (!sorted) std::sort(records.begin() + (ptrdiff_t)b, records.begin() + (ptrdiff_t)e, match_less);
+		b = e;
+	}
+	c->ext_stats[0] += (double)ctr.n_items; c->ext_stats[1] += (double)ctr.n_kept;
+	c->ext_stats[2] += (double)ctr.cells1; c->ext_stats[3] += (double)ctr.cells2;
+	c->ext_stats[9] += ms1; c->ext_stats[11] += ms2;
+	c->ext_dev_stats[0] = (double)ctr.n_eligible; c->ext_dev_stats[1] = (double)(ctr.n_ambiguous + ctr.n_saturated); c->ext_dev_stats[2] = (double)ctr.n_items; c->ext_dev_stats[3] = (double)ctr.n_kept;
+	done = true;
 	return DMND_OK;
 }
 
@@ -675,7 +795,8 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 	const dmnd_seed_hit* hits, const std::vector<uint8_t>& gf, const int8_t* qdata, const int8_t* tdata, const int8_t* cbs,
 	int threads, uint32_t hsp_values, std::vector<dmnd_match>& out_matches,
 	uint8_t* transcript, int64_t transcript_cap, int64_t* transcript_used, hipStream_t bias_stream = nullptr, const XdropSeg* xd = nullptr,
-	const DevPlan* dp = nullptr)      // dp: the call's groups and bands as the device planned them (entry k of dp->queries = query range qr[k])
+	const DevPlan* dp = nullptr,      // dp: the call's groups and bands as the device planned them (entry k of dp->queries = query range qr[k] ...
+	const uint32_t* pq_index = nullptr)      // ... or, when qr is a subset of the call's queries, entry pq_index[k])
 {
 	const std::vector<int64_t>& ql = c->limits[DMND_QUERY];
 	const std::vector<int64_t>& tl = c->limits[DMND_TARGET];
@@ -729,8 +850,9 @@ static int extend_range(const dmnd_ctx* c, dmnd_ctx* w, const HostCfg& h, const 
 			const Range& r = qr[qr_begin + i];
 			const uint32_t q0 = hits[r.b].query / (uint32_t)h.contexts * (uint32_t)h.contexts;       // first context of the query
 			if (dp) {
-				const PlanQuery& pq = dp->queries[qr_begin + i];
-				load_query_planned(h, qs[i].w, hits[r.b].query, dp->groups + pq.group_begin, (size_t)(dp->queries[qr_begin + i + 1].group_begin - pq.group_begin), dp->bands,
+				const size_t pqi = pq_index ? pq_index[qr_begin + i] : qr_begin + i;
+				const PlanQuery& pq = dp->queries[pqi];
+				load_query_planned(h, qs[i].w, hits[r.b].query, dp->groups + pq.group_begin, (size_t)(dp->queries[pqi + 1].group_begin - pq.group_begin), dp->bands,
 					hits + r.b, (int64_t)r.b, (int)(ql[q0 + 1] - ql[q0] - 1));
 			}
 			else
@@ -1449,6 +1571,34 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 		bias_pending = true;
 	}
 	const DevPlan* dp = planned ? &plan : nullptr;
+	// The queries whose targets fit one ranking chunk are extended in HBM from here on (extend_kernels.hip): the default search of a
+	// protein query block -- one HSP per target, -k culling by e-value, Hauser bias or none, no --id / cover filters, no transcripts
+	// (the caller formats from the statistics). The others, and every query of any other mode, take the host path below.
+	// DMND_EXTEND_DEVICE=0: all queries on the host path, as up to round 5.
+	static const bool ext_gpu = [] { const char* e = std::getenv("DMND_EXTEND_DEVICE"); return !e || e[0] != '0'; }();
+	std::vector<dmnd_match> dev_records;
+	std::vector<Range> qr_host;
+	std::vector<uint32_t> pq_host;
+	bool on_device = false;
+	for (double& x : c->ext_dev_stats) x = 0;
+	if (ext_gpu && planned && h.max_hsps == 1 && !h.have_filters() && h.top < 0.0 && h.min_bit_score == 0.0 && !cbs_matrix_adjust(h.cbs_mode) && !h.ext_full && !transcript
+		&& h.global_ranking == 0 && !c->same_title && h.max_target_seqs > 0) {
+		std::vector<uint8_t> qstate;
+		double kept[12];
+		for (int i = 0; i < 12; ++i) kept[i] = c->ext_stats[i];
+		if (int rc = extend_on_device(c, h, plan, threads, dev_records, qstate, on_device)) return rc;
+		bias_pending = false;                               // (it has waited for the stream)
+		if (on_device) {
+			for (size_t k = 0; k < qr.size(); ++k)
+				if (qstate[k] != EXT_Q_DEVICE) { qr_host.push_back(qr[k]); pq_host.push_back((uint32_t)k); }
+		}
+		else for (int i = 0; i < 12; ++i) c->ext_stats[i] = kept[i];
+	}
+	const std::vector<Range>& qr_all = qr;
+	const std::vector<Range>& qr_run = on_device ? qr_host : qr_all;
+	const uint32_t* pq_index = on_device ? pq_host.data() : nullptr;
+	double dev_stats[12];
+	for (int i = 0; i < 12; ++i) dev_stats[i] = on_device ? c->ext_stats[i] : 0.0;
 	c->ext_plan_stats[0] = planned ? (double)plan.n_groups : 0; c->ext_plan_stats[1] = planned ? (double)plan.n_on_host : 0; c->ext_plan_stats[2] = planned ? (double)plan.n_bands : 0;
 	lap(4, 2);
 	if (const char* tr = std::getenv("DMND_TRACE")) if (tr[0] == '3') {
@@ -1470,13 +1620,16 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	int split = 1, runners = 1;
 	if (const char* e = std::getenv("DMND_EXTEND_SPLIT")) split = std::max(1, std::min(64, std::atoi(e)));
 	if (const char* e = std::getenv("DMND_EXTEND_RUNNERS")) runners = std::max(1, std::atoi(e));
-	if (transcript || qr.size() < (size_t)split * 2) split = 1;
+	if (transcript || qr_run.size() < (size_t)split * 2) split = 1;
 	runners = std::min(std::min(runners, split), (int)MAX_POOLS);
 	std::vector<std::vector<dmnd_match>> parts((size_t)split);
 	std::vector<int> rcs((size_t)split, DMND_OK);
 	std::vector<std::string> errs((size_t)split);
 	static const int team = [] { const char* e = std::getenv("DMND_EXTEND_TEAM"); return e ? std::max(1, std::atoi(e)) : 8; }();
-	if (split == 1 && cbs_matrix_adjust(h.cbs_mode)) {
+	if (on_device && qr_run.empty()) {
+		if (bias_pending) HIP_TRY(sync_stream(c->stream));      // every query was extended on the device
+	}
+	else if (split == 1 && cbs_matrix_adjust(h.cbs_mode)) {
 		// --comp-based-stats 2-5: every planned (query, target) pair owns a 1 KB adjusted matrix for the whole extend_range call
 		// (QueryState::mat_of, dmnd_ctx::adj_matrices), where the reference holds a TargetMatrix for the queries of one chunk only.
 		// A block pair of 1e5-1e6 queries would ask for tens of GB of matrices in one call. So the queries go through in passes
@@ -1485,13 +1638,13 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 		static const int64_t pass_hits = [] { const char* e = std::getenv("DMND_CBS_PASS_HITS"); return e ? std::max<int64_t>(1, std::atoll(e)) : (int64_t)2 << 20; }();
 		int64_t t_used = 0;
 		double stats[12] = { 0 };
-		for (size_t b = 0; b < qr.size() && rcs[0] == DMND_OK;) {
+		for (size_t b = 0; b < qr_run.size() && rcs[0] == DMND_OK;) {
 			size_t e = b + 1;
-			while (e < qr.size() && (int64_t)(qr[e].e - qr[b].b) <= pass_hits) ++e;
+			while (e < qr_run.size() && (int64_t)(qr_run[e].e - qr_run[b].b) <= pass_hits) ++e;
 			std::vector<dmnd_match> part;
 			int64_t used = 0;
-			rcs[0] = extend_range(c, c, h, qr, b, e, hits, gf, qdata, tdata, cbs, std::min(threads, team), hsp_values, part, transcript ? transcript + t_used : nullptr,
-				transcript ? transcript_cap - t_used : 0, &used, b == 0 && bias_pending ? c->stream : nullptr, xd, dp);
+			rcs[0] = extend_range(c, c, h, qr_run, b, e, hits, gf, qdata, tdata, cbs, std::min(threads, team), hsp_values, part, transcript ? transcript + t_used : nullptr,
+				transcript ? transcript_cap - t_used : 0, &used, b == 0 && bias_pending ? c->stream : nullptr, xd, dp, pq_index);
 			if (rcs[0] != DMND_OK) break;
 			if (t_used > 0) for (dmnd_match& m : part) if (m.hsp.transcript_off >= 0) m.hsp.transcript_off += t_used;
 			t_used += used;
@@ -1504,8 +1657,8 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 		if (transcript_used) *transcript_used = t_used;
 	}
 	else if (split == 1) {
-		rcs[0] = extend_range(c, c, h, qr, 0, qr.size(), hits, gf, qdata, tdata, cbs, std::min(threads, team), hsp_values, parts[0], transcript, transcript_cap, transcript_used,
-			bias_pending ? c->stream : nullptr, xd, dp);
+		rcs[0] = extend_range(c, c, h, qr_run, 0, qr_run.size(), hits, gf, qdata, tdata, cbs, std::min(threads, team), hsp_values, parts[0], transcript, transcript_cap, transcript_used,
+			bias_pending ? c->stream : nullptr, xd, dp, pq_index);
 	}
 	else {
 		if (bias_pending) HIP_TRY(sync_stream(c->stream));
@@ -1527,8 +1680,8 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 				(void)hipSetDevice(c->device);
 				dmnd_ctx* w = work[(size_t)r];
 				for (int k; (k = next_sub.fetch_add(1)) < split;) {
-					const size_t b = qr.size() * (size_t)k / (size_t)split, e = qr.size() * (size_t)(k + 1) / (size_t)split;
-					rcs[(size_t)k] = extend_range(c, w, h, qr, b, e, hits, gf, qdata, tdata, cbs, sub_threads, hsp_values, parts[(size_t)k], nullptr, 0, nullptr, nullptr, xd, dp);
+					const size_t b = qr_run.size() * (size_t)k / (size_t)split, e = qr_run.size() * (size_t)(k + 1) / (size_t)split;
+					rcs[(size_t)k] = extend_range(c, w, h, qr_run, b, e, hits, gf, qdata, tdata, cbs, sub_threads, hsp_values, parts[(size_t)k], nullptr, 0, nullptr, nullptr, xd, dp, pq_index);
 					if (rcs[(size_t)k] != DMND_OK) { errs[(size_t)k] = dmnd_last_error(); break; }
 					for (int i = 0; i < 12; ++i) acc[(size_t)r][(size_t)i] += w->ext_stats[i];
 				}
@@ -1548,13 +1701,30 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	}
 	for (int k = 0; k < split; ++k)
 		if (rcs[(size_t)k] != DMND_OK) return split == 1 ? rcs[0] : fail(rcs[(size_t)k], errs[(size_t)k]);
-	int64_t n = 0;
+	int64_t n = (int64_t)dev_records.size();
 	for (const auto& v : parts) n += (int64_t)v.size();
 	*n_out = n;
 	if (n > cap) return fail(DMND_E_CAP, "dmnd_extend: match buffer too small");
-	if (out) {
+	if (on_device) {
+		// counts, cells and device times of the two halves add up; the host times are those of the host path
+		if (!qr_run.empty()) for (int i : { 0, 1, 2, 3, 9, 11 }) c->ext_stats[i] += dev_stats[i];      // (no host path: the context's counters are the device's)
+		c->swipe_ms = c->ext_stats[9] + c->ext_stats[10]; c->traceback_ms = c->ext_stats[11];
+	}
+	if (out && !on_device) {
 		int64_t off = 0;
 		for (const auto& v : parts) { std::copy(v.begin(), v.end(), out + off); off += (int64_t)v.size(); }
+	}
+	else if (out) {
+		// the records of the device's queries and of the host's, both in query order, merged (a query is in one of them)
+		std::vector<dmnd_match> host_records;
+		if (split > 1) for (const auto& v : parts) host_records.insert(host_records.end(), v.begin(), v.end());
+		const std::vector<dmnd_match>& hr = split > 1 ? host_records : parts[0];
+		size_t x = 0, y = 0;
+		int64_t off = 0;
+		while (x < dev_records.size() || y < hr.size()) {
+			const bool take_dev = y == hr.size() || (x < dev_records.size() && dev_records[x].query < hr[y].query);
+			out[off++] = take_dev ? dev_records[x++] : hr[y++];
+		}
 	}
 	return DMND_OK;
 }
@@ -1903,6 +2073,13 @@ extern "C" int dmnd_extend_stats(const dmnd_ctx* c, double out[12])
 {
 	if (!c || !out) return fail(DMND_E_ARG, "dmnd_extend_stats: NULL argument");
 	for (int i = 0; i < 12; ++i) out[i] = c->ext_stats[i];
+	return DMND_OK;
+}
+
+extern "C" int dmnd_extend_device_stats(const dmnd_ctx* c, double out[4])
+{
+	if (!c || !out) return fail(DMND_E_ARG, "dmnd_extend_device_stats: NULL argument");
+	for (int i = 0; i < 4; ++i) out[i] = c->ext_dev_stats[i];
 	return DMND_OK;
 }
 

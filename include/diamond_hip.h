@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DMND_ABI_VERSION 11      /* 2: dmnd_match.frame, seed parameters (ungapped filter, translated queries), dmnd_extend_plan(query_contexts); 3: seed_encoding; 4: output formats; 5: DMND_MAX_SHAPES 64; 6: dmnd_host_alloc, dmnd_share_block; 7: dmnd_set_max_hsps, several dmnd_match records per target, global ranking; 8: --comp-based-stats 2..5 (dmnd_cbs_*, dmnd_upload_matrices, dmnd_dp_target::cbs_off <= -2); dmnd_mask_block patches host_data in place (the full copy-back of ABI <= 6 only above 1/16 masked letters); 9: frameshift alignment (dmnd_set_frameshift, dmnd_frameshift_swipe, dmnd_match.read_begin / read_end: the record is 104 bytes), dmnd_set_context_motif_table, dmnd_copy_block; 10: dmnd_join_blocks_range (round 5); 11: dmnd_extend_plan_stats (round 6: device planner) */
+#define DMND_ABI_VERSION 12      /* 2: dmnd_match.frame, seed parameters (ungapped filter, translated queries), dmnd_extend_plan(query_contexts); 3: seed_encoding; 4: output formats; 5: DMND_MAX_SHAPES 64; 6: dmnd_host_alloc, dmnd_share_block; 7: dmnd_set_max_hsps, several dmnd_match records per target, global ranking; 8: --comp-based-stats 2..5 (dmnd_cbs_*, dmnd_upload_matrices, dmnd_dp_target::cbs_off <= -2); dmnd_mask_block patches host_data in place (the full copy-back of ABI <= 6 only above 1/16 masked letters); 9: frameshift alignment (dmnd_set_frameshift, dmnd_frameshift_swipe, dmnd_match.read_begin / read_end: the record is 104 bytes), dmnd_set_context_motif_table, dmnd_copy_block; 10: dmnd_join_blocks_range (round 5); 11: dmnd_extend_plan_stats (round 6: device planner); 12: dmnd_extend_device_stats (round 6: culling, round 2 and records on the device) */
 
 enum {
 	DMND_OK = 0,
@@ -582,6 +582,15 @@ int dmnd_extend_stats(const dmnd_ctx* ctx, double out[12]);
  * or 16 segments), [2] round-1 bands it planned; all 0 = the host planned (several contexts, --ext full, hits not in
  * (query, location) order). Lets a test tell which path produced the records. */
 int dmnd_extend_plan_stats(const dmnd_ctx* ctx, double out[3]);
+/* Round 6: for the queries whose targets fit one ranking chunk (src/align/extend.cpp:79-92) the rest of the extension stage runs in
+ * HBM as well -- DpTargets and their launch order from the bands (DP::BandedSwipe::bin, src/dp/swipe/swipe_wrapper.cpp:75-102), best
+ * HSP per target and report cutoff (src/align/gapped_score.cpp:182-268), culling (src/align/culling.cpp:97-113,189-203), round 2 as a
+ * walk of the kept traces (src/align/gapped_final.cpp:66-160), match records in output order (src/align/extend.h:51-56). The host
+ * writes its own e-value and bit score into the records. Of the last dmnd_extend: [0] queries extended that way, [1] of them handed
+ * back to the host path (two device e-values too close to order safely, or a saturated 16-bit sweep), [2] round-1 DpTargets,
+ * [3] records; all 0 = every query took the host path (other modes: --max-hsps != 1, --top, filters, matrix adjustment, --ext full,
+ * transcripts wanted, translated queries). */
+int dmnd_extend_device_stats(const dmnd_ctx* ctx, double out[4]);
 /* BLAST tabular (-f 6 default fields) line of one match, as the reference prints it; returns the length written. */
 int dmnd_format_tab(const dmnd_match* m, const char* qseqid, const char* sseqid, char* buf, int64_t cap);
 
