@@ -529,6 +529,7 @@ extern "C" int dmnd_upload_cbs(dmnd_ctx* c, const int8_t* cbs, int64_t len)
 	c->cbs_len = len;
 	if (len == 0)
 		return DMND_OK;
+	c->cbs_generation = ~(uint64_t)0;                  // the caller's own bias: not dmnd_extend's cached one
 	if (int rc = c->cbs.ensure((size_t)len + 256)) return rc;      // slack: the gapped filter reads up to 130 bytes past a query (values unused)
 	HIP_TRY(hipMemcpyAsync(c->cbs.p, cbs, (size_t)len, hipMemcpyHostToDevice, c->stream));
 	HIP_TRY(sync_stream(c->stream));

@@ -182,6 +182,7 @@ struct dmnd_ctx {
 	void* same_title_user = nullptr;
 	bool reuse_query_index = false;            // dmnd_set_query_index_reuse
 	uint64_t query_generation = 0;             // bumped whenever the query block or its masks change
+	uint64_t cbs_generation = ~(uint64_t)0;    // query_generation the Hauser bias in `cbs` was computed for by dmnd_extend (all sequences); ~0: none / someone else's
 	std::string qindex_signature;              // what the resident query seed index was built for (empty: nothing resident)
 	std::vector<int32_t> source_lens;          // translated queries: DNA read lengths of the query block (query cover)
 	int ext_mode = -1;                         // --ext: DMND_EXT_DEFAULT = what the sensitivity selects

@@ -650,20 +650,28 @@ static int plan_on_device(dmnd_ctx* c, const HostCfg& h, int64_t n_hits, bool gf
 	HIP_TRY(copy_now(c->stream, c->plan_host.p, a.counters, sizeof(PlanCounters), hipMemcpyDeviceToHost));
 	const PlanCounters cn = *c->plan_host.as<PlanCounters>();
 	if (cn.unsorted || cn.n_groups == 0) return DMND_OK;
-	const size_t h_groups = align(sizeof(PlanCounters)), h_queries = align(h_groups + (size_t)cn.n_groups * sizeof(PlanGroup)),
-		h_bands = align(h_queries + ((size_t)cn.n_queries + 1) * sizeof(PlanQuery)), h_bytes = h_bands + (size_t)cn.n_bands * sizeof(PlanBand);
+	plan.n_groups = cn.n_groups; plan.n_queries = cn.n_queries; plan.n_bands = cn.n_bands; plan.n_on_host = cn.n_on_host;
+	plan.dev = a;
+	planned = true;
+	return DMND_OK;
+}
+
+// The planner's lists on the host (page-locked copies, valid until the context's next dmnd_extend): only the host path reads them
+static int plan_fetch_lists(dmnd_ctx* c, DevPlan& plan)
+{
+	if (plan.groups) return DMND_OK;
+	auto align = [](size_t x) { return (x + 63) & ~(size_t)63; };
+	const size_t h_groups = align(sizeof(PlanCounters)), h_queries = align(h_groups + (size_t)plan.n_groups * sizeof(PlanGroup)),
+		h_bands = align(h_queries + ((size_t)plan.n_queries + 1) * sizeof(PlanQuery)), h_bytes = h_bands + (size_t)plan.n_bands * sizeof(PlanBand);
 	if (int rc = c->plan_host.ensure(h_bytes)) return rc;
 	char* hp = c->plan_host.as<char>();
-	HIP_TRY(hipMemcpyAsync(hp + h_groups, a.groups, (size_t)cn.n_groups * sizeof(PlanGroup), hipMemcpyDeviceToHost, c->stream));
-	HIP_TRY(hipMemcpyAsync(hp + h_queries, a.queries, ((size_t)cn.n_queries + 1) * sizeof(PlanQuery), hipMemcpyDeviceToHost, c->stream));
-	if (cn.n_bands) HIP_TRY(hipMemcpyAsync(hp + h_bands, a.bands, (size_t)cn.n_bands * sizeof(PlanBand), hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipMemcpyAsync(hp + h_groups, plan.dev.groups, (size_t)plan.n_groups * sizeof(PlanGroup), hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipMemcpyAsync(hp + h_queries, plan.dev.queries, ((size_t)plan.n_queries + 1) * sizeof(PlanQuery), hipMemcpyDeviceToHost, c->stream));
+	if (plan.n_bands) HIP_TRY(hipMemcpyAsync(hp + h_bands, plan.dev.bands, (size_t)plan.n_bands * sizeof(PlanBand), hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(sync_stream(c->stream));
 	plan.groups = reinterpret_cast<const PlanGroup*>(hp + h_groups);
 	plan.queries = reinterpret_cast<const PlanQuery*>(hp + h_queries);
 	plan.bands = reinterpret_cast<const PlanBand*>(hp + h_bands);
-	plan.n_groups = cn.n_groups; plan.n_queries = cn.n_queries; plan.n_bands = cn.n_bands; plan.n_on_host = cn.n_on_host;
-	plan.dev = a;
-	planned = true;
 	return DMND_OK;
 }
 
@@ -717,7 +725,7 @@ static int extend_on_device(dmnd_ctx* c, const HostCfg& h, const DevPlan& plan, 
 	if (int rc = c->ext_host.ensure(sizeof(ExtCounters))) return rc;
 	HIP_TRY(copy_now(st, c->ext_host.p, a.ctr, sizeof(ExtCounters), hipMemcpyDeviceToHost));
 	ExtCounters ctr = *c->ext_host.as<ExtCounters>();
-	if (ctr.n_eligible == 0 || ctr.n_items == 0) return DMND_OK;
+	if (ctr.n_items == 0) return DMND_OK;
 	if ((size_t)ctr.total_rows > c->trace_arena_max) return DMND_OK;
 	if (int rc = c->ext_trace.ensure((size_t)ctr.total_rows + 64)) return rc;
 	// 2. round 1 in traceback mode (one launch per band class), then best HSP per target, culling, the round-2 list
@@ -779,7 +787,9 @@ static int extend_on_device(dmnd_ctx* c, const HostCfg& h, const DevPlan& plan, 
 	c->ext_stats[0] += (double)ctr.n_items; c->ext_stats[1] += (double)ctr.n_kept;
 	c->ext_stats[2] += (double)ctr.cells1; c->ext_stats[3] += (double)ctr.cells2;
 	c->ext_stats[9] += ms1; c->ext_stats[11] += ms2;
-	c->ext_dev_stats[0] = (double)ctr.n_eligible; c->ext_dev_stats[1] = (double)(ctr.n_ambiguous + ctr.n_saturated); c->ext_dev_stats[2] = (double)ctr.n_items; c->ext_dev_stats[3] = (double)ctr.n_kept;
+	size_t n_eligible = 0;
+	for (uint8_t x : qstate) n_eligible += x != EXT_Q_HOST;
+	c->ext_dev_stats[0] = (double)n_eligible; c->ext_dev_stats[1] = (double)(ctr.n_ambiguous + ctr.n_saturated); c->ext_dev_stats[2] = (double)ctr.n_items; c->ext_dev_stats[3] = (double)ctr.n_kept;
 	done = true;
 	return DMND_OK;
 }
@@ -1488,42 +1498,44 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	// the block for the swipe kernels and the gapped filter, and copied into a pinned host buffer for the host's x-drop stage.
 	const int8_t* cbs = nullptr;
 	bool bias_pending = false;
+	static const bool xdrop_gpu = [] { const char* e = std::getenv("DMND_EXTEND_XDROP_GPU"); return !e || e[0] != '0'; }();
 	if (!h.use_cbs) {
 		c->cbs_len = 0;                                     // --comp-based-stats 0: no bias anywhere on the path
 	}
 	else {
 		HIP_TRY(hipSetDevice(c->device));
+		const bool host_walks = !(xdrop_gpu && !h.ext_full && n_hits > 0);
+		if (c->cbs.cap < (size_t)ql.back() + 256) c->cbs_generation = ~(uint64_t)0;      // (the buffer is about to be replaced)
 		if (int rc = c->cbs.ensure((size_t)ql.back() + 256)) return rc;
-		if (c->pinned_cbs_cap < (size_t)ql.back() + 64) {
+		if (host_walks && c->pinned_cbs_cap < (size_t)ql.back() + 64) {
 			if (c->pinned_cbs) (void)hipHostFree(c->pinned_cbs);
 			c->pinned_cbs = nullptr; c->pinned_cbs_cap = 0;
 			HIP_TRY(hipHostMalloc((void**)&c->pinned_cbs, (size_t)ql.back() + 64, hipHostMallocDefault));
 			c->pinned_cbs_cap = (size_t)ql.back() + 64;
 		}
-		// only the queries that have seed hits (all their contexts): the others never reach a kernel or the host's x-drop stage
-		std::vector<int32_t>& ids = c->h_bias_ids;
-		ids.clear();
-		for (const Range& r : qr) {
-			const uint32_t q = hits[r.b].query / (uint32_t)h.contexts;
-			for (int f = 0; f < h.contexts; ++f) ids.push_back((int32_t)(q * (uint32_t)h.contexts + (uint32_t)f));
+		// Computed once per query block (dmnd_ctx::query_generation changes whenever the block's letters do) for ALL its sequences and
+		// kept in HBM next to the block: every later call against another database block finds it there. The host copy is only made
+		// when the host is going to walk letters itself (DMND_EXTEND_XDROP_GPU=0).
+		if (c->cbs_generation != c->query_generation || c->cbs_len != ql.back()) {
+			BiasArgs ba;
+			ba.block = c->block[DMND_QUERY].as<int8_t>(); ba.limits = c->d_limits[DMND_QUERY].as<int64_t>(); ba.n_seqs = (int64_t)ql.size() - 1;
+			ba.ids = nullptr;
+			ba.matrix = c->matrix.as<int8_t>(); ba.window = h.cbs_window; ba.out = c->cbs.as<int8_t>();
+			for (int i = 0; i < 20; ++i) ba.bg[i] = (float)h.background_scores[i];
+			HIP_TRY(launch_hauser_bias(ba, c->stream));
+			c->cbs_generation = c->query_generation;
+			bias_pending = true;                            // awaited after load_hits (extend_range) / before the runners start
 		}
-		if (int rc = c->bias_ids.ensure(std::max<size_t>(ids.size(), 1) * sizeof(int32_t))) return rc;
-		if (!ids.empty()) HIP_TRY(hipMemcpyAsync(c->bias_ids.p, ids.data(), ids.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-		BiasArgs ba;
-		ba.block = c->block[DMND_QUERY].as<int8_t>(); ba.limits = c->d_limits[DMND_QUERY].as<int64_t>(); ba.n_seqs = (int64_t)ids.size();
-		ba.ids = c->bias_ids.as<int32_t>();
-		ba.matrix = c->matrix.as<int8_t>(); ba.window = h.cbs_window; ba.out = c->cbs.as<int8_t>();
-		for (int i = 0; i < 20; ++i) ba.bg[i] = (float)h.background_scores[i];
-		HIP_TRY(launch_hauser_bias(ba, c->stream));
-		HIP_TRY(hipMemcpyAsync(c->pinned_cbs, c->cbs.p, (size_t)ql.back(), hipMemcpyDeviceToHost, c->stream));
-		bias_pending = true;                                // awaited after load_hits (extend_range) / before the runners start
 		c->cbs_len = ql.back();
-		cbs = c->pinned_cbs;
+		if (host_walks) {
+			HIP_TRY(hipMemcpyAsync(c->pinned_cbs, c->cbs.p, (size_t)ql.back(), hipMemcpyDeviceToHost, c->stream));
+			bias_pending = true;
+			cbs = c->pinned_cbs;
+		}
 	}
 	// 1a. x-drop ungapped extension of every seed hit on the device (xdrop_seg_kernel), behind the bias kernel on the same stream;
 	// the host's chaining stage picks the segments up instead of walking the letters itself (DMND_EXTEND_XDROP_GPU=0: host walks)
 	const XdropSeg* xd = nullptr;
-	static const bool xdrop_gpu = [] { const char* e = std::getenv("DMND_EXTEND_XDROP_GPU"); return !e || e[0] != '0'; }();
 	if (xdrop_gpu && !h.ext_full && n_hits > 0) {
 		HIP_TRY(hipSetDevice(c->device));
 		if (int rc = c->xd_hits.ensure((size_t)n_hits * sizeof(dmnd_seed_hit))) return rc;
@@ -1596,6 +1608,7 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	}
 	const std::vector<Range>& qr_all = qr;
 	const std::vector<Range>& qr_run = on_device ? qr_host : qr_all;
+	if (planned && !qr_run.empty()) { if (int rc = plan_fetch_lists(c, plan)) return rc; bias_pending = false; }
 	const uint32_t* pq_index = on_device ? pq_host.data() : nullptr;
 	double dev_stats[12];
 	for (int i = 0; i < 12; ++i) dev_stats[i] = on_device ? c->ext_stats[i] : 0.0;
@@ -1751,6 +1764,7 @@ extern "C" int dmnd_xdrop_ungapped(dmnd_ctx* c, const dmnd_seed_hit* hits, int64
 	HostCfg h;
 	make_cfg(c, h);
 	if (use_bias) {
+		c->cbs_generation = ~(uint64_t)0;
 		if (int rc = c->cbs.ensure((size_t)ql.back() + 256)) return rc;
 		BiasArgs ba;
 		ba.block = c->block[DMND_QUERY].as<int8_t>(); ba.limits = c->d_limits[DMND_QUERY].as<int64_t>(); ba.n_seqs = (int64_t)ql.size() - 1; ba.ids = nullptr;

@@ -83,8 +83,7 @@ __global__ __launch_bounds__(64) void ext_mark_kernel(ExtArgs a)
 		a.cnt[g] = ok && grp.pass ? grp.n_bands : 0u;
 	}
 	if (lane == 0) {
-		a.qstate[q] = ok ? EXT_Q_DEVICE : EXT_Q_HOST;
-		if (ok) atomicAdd(&a.ctr->n_eligible, 1u);
+		a.qstate[q] = ok ? EXT_Q_DEVICE : EXT_Q_HOST;      // (no counter here: thousands of atomics on one address cost this kernel 70 us)
 		if (q == 0) a.cnt[a.n_groups] = 0;
 	}
 }
