@@ -319,8 +319,6 @@ extern "C" void dmnd_destroy(dmnd_ctx* c)
 {
 	if (!c) return;
 	if (c->sort_tmp) { (void)hipFree(c->sort_tmp); c->sort_tmp = nullptr; c->sort_tmp_bytes = 0; }
-	if (c->sort_tmp_b) { (void)hipFree(c->sort_tmp_b); c->sort_tmp_b = nullptr; c->sort_tmp_b_bytes = 0; }
-	if (c->seed_stream_b) { (void)hipStreamSynchronize(c->seed_stream_b); forget_stream(c->seed_stream_b); (void)hipStreamDestroy(c->seed_stream_b); c->seed_stream_b = nullptr; }
 	if (c->pinned_cbs) (void)hipHostFree(c->pinned_cbs);
 	for (DevBuf& kb : c->keep_trace) kb.release();
 	c->stage_h.release(); c->ends_h.release(); c->stage_d.release();
@@ -338,7 +336,7 @@ extern "C" void dmnd_destroy(dmnd_ctx* c)
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	for (DevBuf* b : { &c->block[0], &c->block[1], &c->cbs, &c->matrix, &c->bias_ids, &c->items, &c->order, &c->p_of_slot, &c->trace_off,
 		&c->transcript_off, &c->ends, &c->hsps, &c->trace, &c->transcript, &c->status, &c->pairs, &c->trace_off_item, &c->host_q, &c->host_t, &c->host_cbs,
-		&c->d_limits[0], &c->d_limits[1], &c->qid_of, &c->mask_time, &c->seed_keys, &c->seed_next, &c->seed_qlist, &c->seed_qkeys, &c->seed_slot2, &c->seed_loc2, &c->seed_survivors, &c->seed_scored, &c->seed_need, &c->seed_qfold, &c->seed_tfold, &c->seed_sj_slabs, &c->seed_sj_counts, &c->seed_sj_overflow, &c->seed_tcodes, &c->seed_tflags, &c->seed_tplanes, &c->seed_tclass,
+		&c->d_limits[0], &c->d_limits[1], &c->qid_of, &c->mask_time, &c->seed_keys, &c->seed_next, &c->seed_qlist, &c->seed_qkeys, &c->seed_slot2, &c->seed_loc2, &c->seed_survivors, &c->seed_scored, &c->seed_need, &c->seed_qfold, &c->seed_tfold, &c->seed_tcodes, &c->seed_tflags, &c->seed_tplanes, &c->seed_tclass,
 		&c->matched_slot, &c->matched_loc, &c->counters, &c->seed_hits, &c->seed_bitmap, &c->seed_deferred, &c->seed_eslot, &c->seed_eloc, &c->seed_hits_sorted, &c->sort_keys[0], &c->sort_keys[1], &c->sort_idx[0], &c->sort_idx[1], &c->gf_tables, &c->gf_hits, &c->gf_flags, &c->gf_scores, &c->gf_units, &c->alt_targets, &c->mask_lr, &c->mask_pb, &c->mask_scale, &c->mask_pos, &c->mask_ids, &c->mask_soff, &c->mask_long_ids, &c->mask_long_soff, &c->mask_long_pb, &c->mask_long_scale, &c->soft[0], &c->soft[1], &c->motif_hit, &c->motif_table, &c->adj_matrices, &c->join_keep, &c->join_pos, &c->join_in, &c->join_out, &c->join_recv })
 		b->release();
 	if (c->ev0) (void)hipEventDestroy(c->ev0);

@@ -140,10 +140,8 @@ struct dmnd_ctx {
 	double swipe_ms = 0.0, traceback_ms = 0.0;
 	size_t trace_arena_max = (size_t)8 << 30;
 	// seed-stage buffers (seed_api.hip)
-	dmnd::DevBuf qid_of, mask_time, seed_keys, seed_next, seed_qlist, seed_qkeys, seed_slot2, seed_loc2, seed_survivors, seed_scored, seed_need, seed_qfold, seed_tfold, seed_sj_slabs, seed_sj_counts, seed_sj_overflow, seed_tcodes, seed_tflags, seed_tplanes, seed_tclass, matched_slot, matched_loc, counters, seed_hits, seed_bitmap, seed_deferred, seed_eslot, seed_eloc, seed_hits_sorted, sort_keys[2], sort_idx[2];
+	dmnd::DevBuf qid_of, mask_time, seed_keys, seed_next, seed_qlist, seed_qkeys, seed_slot2, seed_loc2, seed_survivors, seed_scored, seed_need, seed_qfold, seed_tfold, seed_tcodes, seed_tflags, seed_tplanes, seed_tclass, matched_slot, matched_loc, counters, seed_hits, seed_bitmap, seed_deferred, seed_eslot, seed_eloc, seed_hits_sorted, sort_keys[2], sort_idx[2];
 	void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0;      // rocPRIM radix sort scratch
-	void* sort_tmp_b = nullptr; size_t sort_tmp_b_bytes = 0;  // ... of the short-seed pipeline's second lane (seed_api.hip: stage 2 of shape s beside the stream of shape s + 1)
-	hipStream_t seed_stream_b = nullptr;                      // that lane's stream
 	dmnd::DevBuf join_keep, join_pos, join_in, join_out, join_recv;      // dmnd_join_blocks_device: survivor flags and their numbers; staging of the host form
 	int64_t n_seed_hits = 0;
 	// gapped filter (gapped_api.hip)

@@ -315,7 +315,7 @@ struct SeedSizes {
 	uint64_t slots, bm_words, bm1_words;
 	uint32_t bm1_k3;
 	int stream_nt, probe_policy, SB, slot_shift;
-	bool fused, reuse, overlap;
+	bool fused, reuse;
 	size_t bm_total;
 };
 
@@ -378,16 +378,7 @@ static SeedSizes seed_sizes(const dmnd_ctx* c, const SeedParams& sp, int64_t nq_
 	z.slot_shift = 4;
 	const size_t set_bytes = (z.slots << z.slot_shift) + 2 * (size_t)nq_pos * sizeof(uint32_t) + (size_t)(bm_words + bm1_words) * sizeof(uint32_t);
 	const bool reuse = c->reuse_query_index && set_bytes * (size_t)S <= ((size_t)64 << 30) && !getenv("DMND_SEED_MATCHED_CAP");
-	// Two lanes (round 5, DMND_SEED_OVERLAP=1 switches it ON): stage 2 of shape s -- ungapped scores, left-most rule, deferred pairs --
-	// runs on a second stream beside the index and the stream of shape s + 1, so consecutive shapes must not share a table: two
-	// buffer sets, used alternately. Measured on C3 (tools/gpu_r05g.sh, profiles/r05_two_lane_pipeline.txt): the seed stage alone
-	// 139.1 -> 133.0 ms (16 shapes; 29 ms of index + stage-2 kernels were there to hide: the by-class stream holds the CUs' LDS and
-	// wavefront slots, the other lane's kernels mostly wait for them), the pipelined bench step 150.4 -> 150.1 ms (the device is
-	// busy with the other batches' kernels anyway). Same hits in every mode (61 seed / full-size C3 / CLI tests with it on). Not
-	// worth a helper thread per shape by default: off.
-	const bool overlap_env = [] { const char* e = getenv("DMND_SEED_OVERLAP"); return e && atoi(e) != 0; }();      // (read per call: the tests switch it)
-	z.overlap = fused && overlap_env && S > 1;
-	const int SB = (fused && !reuse) ? (z.overlap ? 2 : 1) : S;            // shapes that own buffers at the same time
+	const int SB = (fused && !reuse) ? 1 : S;            // shapes that own buffers at the same time
 	const size_t bm_total = (size_t)SB * (bm_words + bm1_words) * sizeof(uint32_t);
 	z.bm_words = bm_words; z.bm1_words = bm1_words; z.bm1_k3 = bm1_k3; z.stream_nt = stream_nt; z.probe_policy = probe_policy;
 	z.fused = fused; z.reuse = reuse; z.SB = SB; z.bm_total = bm_total;
@@ -545,21 +536,6 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		if (int rc = c->seed_tfold.ensure((size_t)(n + 1) / 2 + 64)) return rc;
 		HIP_TRY(launch_seed_fold(c->block[DMND_TARGET].as<int8_t>(), n, c->seed_tfold.as<uint8_t>(), st));
 	}
-	// scatter + join instead of the fused by-class kernel (seed_sj_kernels.hip): an experiment, DMND_SEED_SJ=1
-	const bool sj_env = [] { const char* e = getenv("DMND_SEED_SJ"); return e && atoi(e) != 0; }();
-	const bool sj = sj_env && fused && classes && use_tfold && seed_sj_supported(sp) && slots >= 64;
-	SeedSjArgs sja{};
-	if (sj) {
-		sja.n_wg = seed_sj_workgroups(t_begin, t_end);
-		if (int rc = c->seed_sj_slabs.ensure((size_t)sja.n_wg * SEED_SJ_PARTS * SEED_SJ_SLAB * sizeof(SeedSjEntry))) return rc;
-		if (int rc = c->seed_sj_counts.ensure((size_t)sja.n_wg * SEED_SJ_PARTS * sizeof(uint32_t))) return rc;
-		sja.overflow_cap = (int64_t)1 << 22;
-		if (int rc = c->seed_sj_overflow.ensure((size_t)sja.overflow_cap * 2 * sizeof(uint64_t))) return rc;
-		sja.slabs = c->seed_sj_slabs.as<SeedSjEntry>(); sja.counts = c->seed_sj_counts.as<uint32_t>(); sja.overflow = c->seed_sj_overflow.as<uint64_t>();
-		sja.overflow_count = c->counters.as<unsigned long long>() + S + 5;
-		sja.slab_limit = SEED_SJ_SLAB;
-		if (const char* e = getenv("DMND_SEED_SJ_SLAB_LIMIT")) sja.slab_limit = (uint32_t)std::min<long long>(SEED_SJ_SLAB, std::max<long long>(0, atoll(e)));
-	}
 	if (classes) {
 		const int8_t* tseed = (c->soft_valid[DMND_TARGET] && sp.seed_encoding == SEED_SPACED) ? c->soft[DMND_TARGET].as<int8_t>() : c->block[DMND_TARGET].as<int8_t>();
 		const int64_t n = seed_code_groups(t_begin, t_end);
@@ -589,7 +565,6 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		a.qlist = c->seed_qlist.as<uint32_t>() + (size_t)own * nq_pos;
 		a.slot_mask = slots - 1;
 		a.classes = classes;
-		a.parts = sj ? SEED_SJ_PARTS : 0;
 		a.phase_ticks = phases ? c->counters.as<unsigned long long>() + S + 8 : nullptr;
 		a.tclass = classes ? c->seed_tclass.as<uint16_t>() : nullptr; a.tclass_stride = (seed_code_groups(t_begin, t_end) + 3) & ~(int64_t)3;
 		a.tcodes = classes ? c->seed_tcodes.as<uint64_t>() : nullptr; a.tflags = classes ? c->seed_tflags.as<uint32_t>() : nullptr; a.tplanes = classes ? c->seed_tplanes.as<uint64_t>() : nullptr;
@@ -637,10 +612,9 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 	// deferred pairs. A shape's masks only depend on this and earlier shapes, and so does the left-most rule (t_now).
 	if (fused) {
 		unsigned long long* ctr = c->counters.as<unsigned long long>();
-		const size_t lanes = z.overlap ? 2 : 1;               // the joined-position and survivor buffers hold one half per lane (shape parity)
-		int64_t m_cap = std::max<int64_t>(std::max<int64_t>((int64_t)1 << 22, 4 * nq_pos), (int64_t)(std::min(c->matched_loc.cap / sizeof(int64_t), c->matched_slot.cap / sizeof(uint32_t)) / lanes));
+		int64_t m_cap = std::max<int64_t>(std::max<int64_t>((int64_t)1 << 22, 4 * nq_pos), (int64_t)(std::min(c->matched_loc.cap / sizeof(int64_t), c->matched_slot.cap / sizeof(uint32_t))));
 		if (const char* e = getenv("DMND_SEED_MATCHED_CAP")) m_cap = std::max<int64_t>(1, atoll(e));
-		int64_t surv_cap = std::max<int64_t>((int64_t)1 << 20, (int64_t)(c->seed_survivors.cap / sizeof(SeedSurvivor) / lanes));
+		int64_t surv_cap = std::max<int64_t>((int64_t)1 << 20, (int64_t)(c->seed_survivors.cap / sizeof(SeedSurvivor)));
 		if (const char* e = getenv("DMND_SEED_SURVIVOR_CAP")) surv_cap = std::max<int64_t>(1, atoll(e));
 		int64_t hit_cap = std::max<int64_t>((int64_t)1 << 20, (int64_t)(c->seed_hits.cap / sizeof(dmnd_seed_hit)));
 		if (const char* e = getenv("DMND_SEED_HIT_CAP")) hit_cap = std::max<int64_t>(1, atoll(e));
@@ -648,31 +622,13 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 		c->seed_trace.assign((size_t)2 * S, 0);
 		int64_t hits_bound = 0;                              // every survivor gives at most one hit
 		std::vector<unsigned long long> host_ctr((size_t)S + 4);
-		// ---- lane B: everything behind a shape's Hamming filter (stage-2 scores, left-most rule, deferred pairs). With the lanes
-		// overlapped it runs on its own stream, driven by a helper thread (it waits for two counts of its own), while the main thread
-		// indexes and streams the next shape on the context's stream. What the lanes share: the shape's table set (read by B; the next
-		// shape builds the OTHER set), its halves of the joined-position and survivor buffers (by shape parity), mask_time (B only reads it,
-		// "<= t_now": what the next shape's kernels write there is later than any t_now of this shape), the hit list (B only).
-		const bool overlap = z.overlap;
+		// ---- stage 2: everything behind a shape's Hamming filter (stage-2 scores, left-most rule, deferred pairs), on the same stream
 		hipStream_t sb = st;
-		if (overlap) {
-			if (!c->seed_stream_b) {
-				int prio = 0;
-				HIP_TRY(hipStreamGetPriority(st, &prio));
-				HIP_TRY(hipStreamCreateWithPriority(&c->seed_stream_b, hipStreamNonBlocking, prio));
-			}
-			sb = c->seed_stream_b;
-		}
 		Timer tmb(sb);
-		hipEvent_t lane_a_done = nullptr;
-		if (overlap) HIP_TRY(hipEventCreateWithFlags(&lane_a_done, hipEventDisableTiming));
-		struct EventGuard { hipEvent_t& e; ~EventGuard() { if (e) (void)hipEventDestroy(e); } } event_guard{ lane_a_done };
-		std::string lane_b_error;
-		unsigned long long hits_seen = 0;                     // the hit counter as lane B last read it; fresh: nothing appended since
+		unsigned long long hits_seen = 0;                     // the hit counter as stage 2 last read it; fresh: nothing appended since
 		bool hits_fresh = false;
-		auto lane_b = [&](SeedArgs a, int sid, unsigned long long n, unsigned long long ns) -> int {
+		auto stage2 = [&](SeedArgs a, int sid, unsigned long long n, unsigned long long ns) -> int {
 			HIP_TRY(hipSetDevice(c->device));
-			if (overlap) HIP_TRY(hipStreamWaitEvent(sb, lane_a_done, 0));       // recorded behind the shape's mask kernel
 			if (hits_bound + (int64_t)ns > hit_cap) {            // grow, keeping the hits of the earlier shapes
 				const int64_t new_cap = hits_bound + (int64_t)ns + (hits_bound + (int64_t)ns) / 2;
 				DevBuf nb;
@@ -717,29 +673,19 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 			unsigned long long ne = 0;
 			HIP_TRY(hipMemcpyAsync(&ne, a.e_count, sizeof(ne), hipMemcpyDeviceToHost, sb));
 			HIP_TRY(sync_stream(sb));
-			HIP_TRY(sort_keys_u64(c->seed_eslot.as<uint64_t>(), c->seed_eloc.as<uint64_t>(), (int64_t)ne, overlap ? &c->sort_tmp_b : &c->sort_tmp, overlap ? &c->sort_tmp_b_bytes : &c->sort_tmp_bytes, sb));
+			HIP_TRY(sort_keys_u64(c->seed_eslot.as<uint64_t>(), c->seed_eloc.as<uint64_t>(), (int64_t)ne, &c->sort_tmp, &c->sort_tmp_bytes, sb));
 			a.e_key = c->seed_eloc.as<uint64_t>();
 			a.e_n = (int64_t)ne;
 			HIP_TRY(launch_seed_deferred(a, sid, (int64_t)nd, sb));
 			tmb.stop(c->seed_ms[3]);
 			return DMND_OK;
 		};
-		std::thread lane_b_thread;
-		int lane_b_rc = DMND_OK;
-		auto wait_b = [&]() -> int {                            // lane B idle (its last shape finished on the device too)
-			if (lane_b_thread.joinable()) lane_b_thread.join();
-			if (lane_b_rc != DMND_OK) { const int rc = lane_b_rc; lane_b_rc = DMND_OK; return fail(rc, lane_b_error); }
-			return DMND_OK;
-		};
-		struct ThreadGuard { std::thread& t; ~ThreadGuard() { if (t.joinable()) t.join(); } } thread_guard{ lane_b_thread };
 		const bool recycle = SB < S;                          // a buffer set serves several shapes: cleared before its next one
 		for (int sid = 0; sid < S; ++sid) {
 			SeedArgs a = args_for(sid, 0, 0);
-			const int half = overlap ? sid & 1 : 0;            // this shape's half of the joined-position / survivor buffers
 			tm.start();
 			if (sid > 0) {
 				// the survivor counter and, where a buffer set is used again, its table, slots-of-positions and bitmaps -- one launch
-				// (lane B was last seen idle before the PREVIOUS shape went to it: the set of shape sid - SB is free)
 				SeedClear z;
 				z.add(ctr + S + 3, sizeof(unsigned long long), 0);
 				if (recycle && sid >= SB) {
@@ -754,32 +700,17 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 			tm.stop(c->seed_ms[0]);
 			unsigned long long n = 0, ns = 0;
 			for (int attempt = 0;; ++attempt) {
-				const size_t halves = lanes;
-				// (a buffer that has to grow is freed first: not while lane B reads the other half)
-				if (halves * (size_t)m_cap * sizeof(uint32_t) > c->matched_slot.cap || halves * (size_t)m_cap * sizeof(int64_t) > c->matched_loc.cap
-					|| halves * (size_t)surv_cap * sizeof(SeedSurvivor) > c->seed_survivors.cap)
-					if (int rc = wait_b()) return rc;
-				if (int rc = c->matched_slot.ensure(halves * (size_t)m_cap * sizeof(uint32_t))) return rc;
-				if (int rc = c->matched_loc.ensure(halves * (size_t)m_cap * sizeof(int64_t))) return rc;
-				if (int rc = c->seed_survivors.ensure(halves * (size_t)surv_cap * sizeof(SeedSurvivor))) return rc;
-				a.matched_slot = c->matched_slot.as<uint32_t>() + (size_t)half * (size_t)m_cap; a.matched_loc = c->matched_loc.as<int64_t>() + (size_t)half * (size_t)m_cap; a.matched_cap = m_cap;
-				a.survivors = c->seed_survivors.as<SeedSurvivor>() + (size_t)half * (size_t)surv_cap; a.survivor_cap = surv_cap;
+				if (int rc = c->matched_slot.ensure((size_t)m_cap * sizeof(uint32_t))) return rc;
+				if (int rc = c->matched_loc.ensure((size_t)m_cap * sizeof(int64_t))) return rc;
+				if (int rc = c->seed_survivors.ensure((size_t)surv_cap * sizeof(SeedSurvivor))) return rc;
+				a.matched_slot = c->matched_slot.as<uint32_t>(); a.matched_loc = c->matched_loc.as<int64_t>(); a.matched_cap = m_cap;
+				a.survivors = c->seed_survivors.as<SeedSurvivor>(); a.survivor_cap = surv_cap;
 				if (attempt > 0) {                               // (the first attempt finds them zero: the clears above)
 					HIP_TRY(hipMemsetAsync(a.matched_count, 0, sizeof(unsigned long long), st));
 					HIP_TRY(hipMemsetAsync(a.survivor_count, 0, sizeof(unsigned long long), st));
 				}
 				tm.start();
-				if (sj) {
-					HIP_TRY(hipMemsetAsync(sja.overflow_count, 0, sizeof(unsigned long long), st));
-					HIP_TRY(launch_seed_sj_scatter(a, sja, sid, st));
-					HIP_TRY(launch_seed_sj_join(a, sja, sid, st));
-					unsigned long long spilled = 0;
-					HIP_TRY(copy_now(c->stream, &spilled, sja.overflow_count, sizeof(spilled), hipMemcpyDeviceToHost));
-					if ((int64_t)spilled > sja.overflow_cap) return fail(DMND_E_NOMEM, "dmnd_seed_search: scatter overflow list too small");
-					HIP_TRY(launch_seed_sj_overflow(a, sja, sid, (int64_t)spilled, st));
-					if (lap_on && spilled) std::fprintf(stderr, "dmnd_seed_search: shape %d, %llu windows spilled from full slabs\n", sid, spilled);
-				}
-				else HIP_TRY(launch_seed_stream(a, sid, st, true));
+				HIP_TRY(launch_seed_stream(a, sid, st, true));
 				tm.stop(c->seed_ms[1]);
 				HIP_TRY(copy_now(c->stream, host_ctr.data(), ctr, host_ctr.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
 				n = host_ctr[sid]; ns = host_ctr[S + 3];
@@ -795,15 +726,9 @@ extern "C" int dmnd_seed_search(dmnd_ctx* c, const dmnd_seed_params* params, int
 				HIP_TRY(launch_seed_mask(a, sid, st));
 				tm.stop(c->seed_ms[2]);
 			}
-			// lane B takes the shape over; it is idle first (so the table set and the buffer halves of shape sid - 1 are free for
-			// shape sid + 1, and lane B's own buffers for this shape)
-			if (int rc = wait_b()) return rc;
 			if (ns == 0) continue;
-			if (!overlap) { if (int rc = lane_b(a, sid, n, ns)) return rc; continue; }
-			HIP_TRY(hipEventRecord(lane_a_done, st));
-			lane_b_thread = std::thread([&, a, sid, n, ns] { lane_b_rc = lane_b(a, sid, n, ns); if (lane_b_rc != DMND_OK) lane_b_error = dmnd_last_error(); else if (sync_stream(sb) != hipSuccess) { lane_b_rc = DMND_E_DEVICE; lane_b_error = "dmnd_seed_search: lane B failed"; } });
+			if (int rc = stage2(a, sid, n, ns)) return rc;
 		}
-		if (int rc = wait_b()) return rc;
 		unsigned long long nh = hits_seen;
 		if (!hits_fresh) HIP_TRY(copy_now(c->stream, &nh, ctr + S, sizeof(nh), hipMemcpyDeviceToHost));
 		if ((int64_t)nh > hit_cap) return fail(DMND_E_NOMEM, "dmnd_seed_search: hit buffer overflow");

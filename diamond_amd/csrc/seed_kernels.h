@@ -50,7 +50,6 @@ struct SeedArgs {
 	const uint32_t* qlist;                        // query positions grouped by slot (SeedSlot::head = start, count in flags >> 8)
 	uint64_t slot_mask;
 	int classes;                                  // 8: slots and level-1 words are partitioned by seed_class(key) (short-seed pipeline); 0: one range
-	int parts;                                    // 64: the table in 64 contiguous partitions (scatter + join, seed_sj_kernels.hip); else 0
 	// ... and then the reference letters as the stream wants them, made once per search by seed_codes_kernel: per group of 16
 	// letters (from t_begin rounded down to 16) their class nibbles, and delimiter / no-class maps (low / high 16 bits)
 	const uint64_t* tcodes; const uint32_t* tflags;
@@ -61,11 +60,6 @@ struct SeedArgs {
 	__host__ __device__ uint64_t home(uint64_t hh, uint64_t key) const
 	{
 		if (!classes) return hh & slot_mask;
-		if (parts) {
-			// 64 partitions = (key class, top three bits of hash a), each a contiguous 1/64 of the table (seed_sj_kernels.hip)
-			const uint64_t per = (slot_mask + 1) >> 6;
-			return (uint64_t)((seed_class(key) << 3) | ((uint32_t)hh >> 29)) * per | (hh & (per - 1));
-		}
 		const uint64_t low = slot_mask >> 3;
 		return (uint64_t)seed_class(key) * (low + 1) | (hh & low);
 	}
@@ -112,24 +106,9 @@ struct SeedClear {
 };
 hipError_t launch_seed_clear(const SeedClear& z, hipStream_t st);
 hipError_t launch_seed_qid(const int64_t* limits, int64_t n_seqs, uint32_t* qid_of, hipStream_t st);
-// scatter + join of the short-seed stream (seed_sj_kernels.hip; DMND_SEED_SJ=1)
 // room for the folded need map that seed_collect's workgroups keep in LDS (2^13 words = 32 KB by default, up to 2^15); it lies behind
 // SeedArgs::need_bits
 enum { SEED_NEED_FOLD_WORDS = 32768 };
-enum { SEED_SJ_PARTS = 64, SEED_SJ_TILES = 4, SEED_SJ_SLAB = 192, SEED_SJ_GROUP = 8 };
-struct SeedSjEntry { uint32_t key32, pos; uint32_t fold[6]; };       // compact key, position relative to the stream's base, 48 folded letters
-struct SeedSjArgs {
-	SeedSjEntry* slabs;                           // [n_wg][SEED_SJ_PARTS][SEED_SJ_SLAB]
-	uint32_t* counts;                             // [n_wg][SEED_SJ_PARTS] entries in each slab
-	uint64_t* overflow; unsigned long long* overflow_count; int64_t overflow_cap;      // (key, position) of the windows whose slab was full
-	int64_t n_wg;                                 // scatter workgroups (SEED_SJ_TILES tiles of 4096 window starts each)
-	uint32_t slab_limit;                          // entries a slab takes before it spills (<= SEED_SJ_SLAB; the tests lower it)
-};
-bool seed_sj_supported(const SeedParams& c);
-int64_t seed_sj_workgroups(int64_t t_begin, int64_t t_end);
-hipError_t launch_seed_sj_scatter(const SeedArgs& a, const SeedSjArgs& j, int sid, hipStream_t st);
-hipError_t launch_seed_sj_join(const SeedArgs& a, const SeedSjArgs& j, int sid, hipStream_t st);
-hipError_t launch_seed_sj_overflow(const SeedArgs& a, const SeedSjArgs& j, int sid, int64_t n, hipStream_t st);
 hipError_t launch_seed_index(const SeedArgs& a, int sid, hipStream_t st);
 // query seed positions whose shape window touches a soft-masked stretch get their mask time (MaskingTable::remove's bit mask)
 hipError_t launch_seed_soft_time(const SeedArgs& a, hipStream_t st);

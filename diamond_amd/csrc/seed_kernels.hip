@@ -1531,14 +1531,6 @@ hipError_t launch_seed_stream(const SeedArgs& a, int sid, hipStream_t st, bool f
 		for (int k = 0; k < c.shape_weight[sid]; ++k) care64 |= (uint64_t)15 << (4 * c.shape_pos[sid][k]);
 		const bool level2 = a.level2 != 0, hashed = c.seed_encoding == SEED_HASHED;
 		const dim3 grid(a.classes ? blocks_for(threads, 256 * SEED_CLASS_TILES) * 8u : blocks_for(threads, 256)), block(256);
-		// Residency cap of the long-seed stream (round 5): the kernel is bound by the L2s' request rate, which a fraction of the
-		// wavefront slots saturates (8 probes x 64 lanes in flight per wavefront; at ~1 us of latency 2e11 requests/s need ~400
-		// wavefronts, the device holds 8192) -- but launched bare it takes every slot, and the kernels of the other batches in flight
-		// (the next query index, the sweeps and walks of the extension: VALU-bound, nothing to do with the L2s) queue behind its
-		// 73 000 workgroups instead of running beside them. DMND_SEED_STREAM_WGS = workgroups (of four wavefronts) per CU, enforced
-		// with dynamic LDS the kernel never touches (160 KB per CU / n); 0 = no cap.
-		static const int wgs_per_cu = [] { const char* e = getenv("DMND_SEED_STREAM_WGS"); return e ? std::max(0, atoi(e)) : 0; }();
-		const unsigned cap_lds = (!fused && !a.classes && wgs_per_cu > 0) ? (unsigned)std::min(56 * 1024, std::max(0, 160 * 1024 / wgs_per_cu - 8 * 1024)) & ~255u : 0u;      // (<= 64 KB per workgroup with the kernel's own 6 KB: two per CU at the least)
 		const bool by_class = a.classes != 0;               // the fused pipeline, or long seeds against a large query block (seed_api.hip)
 		if (by_class) {
 			const int64_t n_groups = seed_code_groups(a.t_begin, a.t_end);
@@ -1584,10 +1576,10 @@ hipError_t launch_seed_stream(const SeedArgs& a, int sid, hipStream_t st, bool f
 		else if (by_class && level2) hipLaunchKernelGGL((seed_stream_fast_kernel<true, false, false, true>), grid, block, 0, st, a, sid, lo, hi, base, care64);
 		else if (by_class && hashed) hipLaunchKernelGGL((seed_stream_fast_kernel<false, true, false, true>), grid, block, 0, st, a, sid, lo, hi, base, care64);
 		else if (by_class) hipLaunchKernelGGL((seed_stream_fast_kernel<false, false, false, true>), grid, block, 0, st, a, sid, lo, hi, base, care64);
-		else if (level2 && hashed) hipLaunchKernelGGL((seed_stream_fast_kernel<true, true, false>), grid, block, cap_lds, st, a, sid, lo, hi, base, care64);
-		else if (level2) hipLaunchKernelGGL((seed_stream_fast_kernel<true, false, false>), grid, block, cap_lds, st, a, sid, lo, hi, base, care64);
-		else if (hashed) hipLaunchKernelGGL((seed_stream_fast_kernel<false, true, false>), grid, block, cap_lds, st, a, sid, lo, hi, base, care64);
-		else hipLaunchKernelGGL((seed_stream_fast_kernel<false, false, false>), grid, block, cap_lds, st, a, sid, lo, hi, base, care64);
+		else if (level2 && hashed) hipLaunchKernelGGL((seed_stream_fast_kernel<true, true, false>), grid, block, 0, st, a, sid, lo, hi, base, care64);
+		else if (level2) hipLaunchKernelGGL((seed_stream_fast_kernel<true, false, false>), grid, block, 0, st, a, sid, lo, hi, base, care64);
+		else if (hashed) hipLaunchKernelGGL((seed_stream_fast_kernel<false, true, false>), grid, block, 0, st, a, sid, lo, hi, base, care64);
+		else hipLaunchKernelGGL((seed_stream_fast_kernel<false, false, false>), grid, block, 0, st, a, sid, lo, hi, base, care64);
 		return hipGetLastError();
 	}
 	hipLaunchKernelGGL(seed_stream_kernel, dim3(blocks_for(a.t_end - a.t_begin, 256)), dim3(256), 0, st, a, sid);
