@@ -91,6 +91,61 @@ def thread_cpu_ms():
     return out
 
 
+def scaling_model(out, ext, cpu_ms_per_step, cpus, step_ms, n_records, n_blocks, ext_contexts, threads):
+    """ONE formula for every config and decomposition, evaluated from this N = 1 run; the first SCALE file is a check of it.
+    A rank's step = max(GPU term, host term) + exchange:
+      GPU term  = overlap x (index + stream + pairs + extension kernels of the rank's share); overlap = this run's step / the same sum at
+                  N = 1 (how much of the kernel time the pipeline hides or the launch gaps add), kept for every N
+      host term = host CPU-ms per step of the whole job / CPUs of the box (the cgroup quota all ranks share)
+      exchange  = 2 x 25 us per collective + this rank's records at 50 GB/s per xGMI link
+    Decompositions (the reference's own multi-process mode hands out (query chunk x reference chunk) units,
+    /root/reference/src/run/double_indexed.cpp:346-396):
+      db     every rank: ALL queries x 1/N of the database -- index whole, stream / pairs / extension by N, records exchanged by query range
+      query  every rank: 1/N of the queries x ALL the database -- index and pairs and extension by N, the per-letter stream whole, one gather
+      2xN/2  two query halves x N/2 database shards -- index by 2, stream by N/2, pairs and extension by N, exchange inside a half
+    """
+    sk = out["seed_kernel_ms"]
+    index = sk["index_queries"] + sk["mask_groups"]
+    stream = sk["stream_reference"]
+    pairs = max(sk["total"] - index - stream, 0.0)
+    ext_k = ext["round1_swipe_kernel_ms"] + ext["round2_swipe_kernel_ms"] + ext["traceback_kernel_ms"]
+    gpu1 = index + stream + pairs + ext_k
+    overlap = step_ms / max(gpu1, 1e-9)
+    host = cpu_ms_per_step / max(cpus, 1)
+
+    def coll(n, kind):
+        if n == 1:
+            return 0.0
+        payload = 104.0 * n_records / n
+        return {"db": 4 * 0.025 + 2 * payload / 50e9 * 1e3, "query": 2 * 0.025 + payload / 50e9 * 1e3, "2d": 4 * 0.025 + 2 * payload / 50e9 * 1e3}[kind]
+
+    def gpu(n, kind):
+        if kind == "db":
+            return index + (stream + pairs + ext_k) / n
+        if kind == "query":
+            return index / n + stream + (pairs + ext_k) / n
+        return index / 2 + stream / max(n // 2, 1) + (pairs + ext_k) / n          # 2 x n/2
+
+    model = {"what": "predicted ms per step on N GPUs = max(overlap x GPU kernels of a rank's share, host CPU-ms per step / CPUs of the box) + exchange; one formula for "
+                     "every config, evaluated for three decompositions from this N = 1 run -- to be checked against SCALE",
+             "measured_ms_per_step": step_ms, "kernel_ms_per_step": {"index_queries": index, "stream_reference": stream, "pair_filter_and_stage2": pairs, "extension": ext_k},
+             "overlap_factor": overlap, "host_cpu_ms_per_step": cpu_ms_per_step, "host_cpus": cpus, "host_floor_ms": host, "database_blocks": n_blocks,
+             "decompositions": {}}
+    best = {}
+    for kind, label in (("db", "db"), ("query", "query"), ("2d", "2xN/2")):
+        pred = {str(n): max(overlap * gpu(n, kind), host if n > 1 else 0.0) + coll(n, kind) for n in (1, 2, 4, 8) if kind != "2d" or n >= 4}
+        model["decompositions"][label] = {"predicted_ms_per_step": pred, "predicted_speedup": {n: step_ms / v for n, v in pred.items() if n != "1"},
+                                          "bound_at_8": "host" if host > overlap * gpu(8, kind) else "gpu"}
+        for n, v in pred.items():
+            if n != "1" and (n not in best or v < best[n][1]):
+                best[n] = (label, v)
+    model["best"] = {n: {"decomposition": k, "predicted_ms_per_step": v, "predicted_speedup": step_ms / v} for n, (k, v) in best.items()}
+    model["predicted_speedup"] = {n: step_ms / v for n, (k, v) in best.items()}
+    model["note"] = ("host_cpu_ms_per_step is this run's (%d extension contexts, %d host threads); `bench.py --gpus N` shards by --shard (default db: the only one of the "
+                     "three whose N-rank exchange is implemented together with query; the 2 x N/2 split is priced here, not built)" % (ext_contexts, threads))
+    return model
+
+
 def cgroup_cpus():
     """CPUs of time this process may use: the cgroup quota when there is one (the GPU boxes run the container under
     cpu.max = 16 CPUs for 256 hardware threads), else the visible cores."""
@@ -188,7 +243,7 @@ def _timers(log):
     return t
 
 
-def cpu_baseline_reference(w, cores, e2e=True):
+def cpu_baseline_reference(w, cores, e2e=True, parity_only=False):
     """The GENUINE reference (oracle/_ref/diamond_tap: /root/reference compiled in place; the tap only counts DP cells) on
     this box's host cores, on the FULL workload of the config, with as many threads as the cgroup allows.
       hot path  `--algo 0 --masking 0 --motif-masking 0 --log`: cells / (sum of the seed-stage and extension-stage task timers) --
@@ -227,6 +282,8 @@ def cpu_baseline_reference(w, cores, e2e=True):
 
         hot_flags = ["--algo", "0", "--masking", "0", "--motif-masking", "0"]
         wall, log, md5 = run(exe, hot_flags + ["--log"], "out.tsv")
+        if parity_only:                                      # N > 1: only what the records are compared with (the same block cut: -b above)
+            return None, md5, None
         cells = json.load(open(os.path.join(tmp, "cells.json")))
         timers = _timers(log)
         hot_s = sum(v for k, v in timers.items() if k in HOT_TIMERS)
@@ -577,6 +634,7 @@ def main():
         c.touch_streams()
     state["stream_ms"], state["stream_launches"] = 0.0, 0
     state["seed_wall"], state["ext_wall"] = [], []
+    multigpu.reset_stats()
     t0 = time.perf_counter()
     cpu0 = time.process_time()
     thr0 = thread_cpu_ms()
@@ -588,6 +646,7 @@ def main():
     dt = time.perf_counter() - t0
     cpu_ms_per_step = (time.process_time() - cpu0) * 1e3 / args.steps      # CPU time of all threads of this process
     thr1 = thread_cpu_ms()
+    xstats = dict(multigpu.STATS)                          # the exchanges of the timed steps (the serial steps below exchange again)
     cpu_by_thread = {k: round((v - thr0.get(k, 0.0)) / args.steps, 2) for k, v in sorted(thr1.items()) if v - thr0.get(k, 0.0) > 0}
     stream_ms, stream_launches = state["stream_ms"], state["stream_launches"]
 
@@ -668,7 +727,7 @@ def main():
     while len(each) // (2 * WIN) >= 5 and WIN < 4 * E:
         WIN += E
     win_ms = [sum(each[i:i + WIN]) / WIN for i in range(0, len(each) - WIN + 1, WIN)]
-    win_median = sorted(win_ms)[len(win_ms) // 2] if win_ms else None
+    win_median = sorted(win_ms)[len(win_ms) // 2] if len(win_ms) >= 8 else None      # (fewer windows: a median of clumped completions says nothing -- the mean is the figure)
     ext = pipe_ext
     # the job's DP cells: with database shards every rank sweeps its own targets, with query shards its own queries
     cells = torch.tensor([ext["round1_cells"], ext["round2_cells"] if ext["round2_swipe_kernel_ms"] > 0 else 0.0, ext["round2_cells"],
@@ -717,7 +776,7 @@ def main():
             "ms_each_step": each,
             # batches retire in clumps (three are extended at a time): the completion intervals as windows of three steps -- the
             # median window / 3 shows what a host hiccup (one long step) does to the mean that `value` is defined on
-            "ms_per_step_median_of_3_step_windows": (sorted(sum(each[i:i + 3]) for i in range(0, len(each) - 2, 3))[len(range(0, len(each) - 2, 3)) // 2] / 3.0) if len(each) >= 3 else None,
+            "ms_per_step_median_of_3_step_windows": (sorted(sum(each[i:i + 3]) for i in range(0, len(each) - 2, 3))[len(range(0, len(each) - 2, 3)) // 2] / 3.0) if len(each) >= 24 else None,
             "ms_per_step_median": win_median,
             "ms_per_step_windows": {"window_steps": WIN, "ms_per_step_of_each_window": [round(x, 4) for x in win_ms], "median": win_median,
                                     "note": "the timed steps cut into windows of %d (a multiple of the %d batches that retire together); `ms_per_step` above is the MEAN over the whole "
@@ -728,6 +787,15 @@ def main():
             "host_cpu_ms_per_step": cpu_ms_per_step,
             "host_cpu_ms_per_step_by_thread": cpu_by_thread,      # by OS thread name (10 ms clock ticks): bench-* = this script's stage threads incl. the library calls they make, dmnd-pool = the library's host workers
             "host_cpu_quota": cgroup_cpus(),
+            # what the exchange of the match records was (per step and rank 0's share; N = 1: no exchange, the fields say so): the
+            # SCALE record's own evidence that the collective ran over N ranks
+            "rccl": {"world_size": (dist.get_world_size() if world > 1 else 1), "backend": (dist.get_backend() if world > 1 else None),
+                     "transport": (xstats["transport"] if world > 1 else "none (one rank: the blocks are joined on the device, dmnd_join_blocks_device)"),
+                     "collectives_per_step": xstats["collectives"] / max(args.steps, 1),
+                     "bytes_exchanged_per_step": (xstats["bytes_sent"] + xstats["bytes_received"]) / max(args.steps, 1),
+                     "exchange_ms": xstats["exchange_s"] * 1e3 / max(args.steps, 1),
+                     "shard": args.shard if world > 1 else None,
+                     "note": "counted inside diamond_amd/multigpu.py around its all_to_all_single calls during the timed steps (rank 0's sends + receives; exchange_ms runs on the finish thread beside the next batch)"},
             # not part of `value`: one-time PCIe upload of both blocks, and the rate if it were paid on every step
             "block_upload_ms": upload_ms,
             "pcie_inclusive_gcups": cells_swept / ((dt / args.steps + upload_ms * 1e-3)) / 1e9,
@@ -767,11 +835,14 @@ def main():
         # HBM traffic of the dominant kernel per launch: FETCH_SIZE of a separate `rocprofv3 --pmc FETCH_SIZE` pass over this same
         # command (tools/profile_r03.sh), doubled as MI355X_MICROARCH.md prescribes for gfx950, plus WRITE_SIZE; only quoted for the
         # configuration and kernel variant it was measured on
-        pmc_path = next((q for q in (os.path.join(ROOT, "profiles", "r%02d_pmc_summary_%s.json" % (r, args.config)) for r in (5, 4, 3, 2)) if os.path.exists(q)), None)
+        pmc_path = next((q for q in (os.path.join(ROOT, "profiles", "r%02d_pmc_summary_%s.json" % (r, args.config)) for r in (6, 5, 4, 3, 2)) if os.path.exists(q)), None)
         full_size = args.queries == CONFIGS[args.config].get("queries", 10_000) and args.families == CONFIGS[args.config].get("families", 100_000)
+        if not (world == 1 and full_size and pmc_path):
+            out["roofline"]["traffic_source"] = "no committed PMC pass applies (N = %d, full size: %s, file: %s)" % (world, full_size, pmc_path)
         if world == 1 and full_size and pmc_path:
             pmc = json.load(open(pmc_path))
-            k = [v for name, v in pmc.items() if "seed_stream_fast_kernel" in name]
+            # the stream kernel's entry: of several instantiations the one with the most launches (the config's own)
+            k = sorted([v for name, v in pmc.items() if "seed_stream_fast_kernel" in name and "FETCH_SIZE_x2_bytes_per_launch" in v], key=lambda v: -v.get("launches", 0))[:1]
             if len(k) == 1 and "FETCH_SIZE_x2_bytes_per_launch" in k[0]:
                 rl = out["roofline"]
                 rl["traffic"] = k[0]["FETCH_SIZE_x2_bytes_per_launch"] + k[0].get("WRITE_SIZE_bytes_per_launch", 0.0)
@@ -801,53 +872,8 @@ def main():
                                                  "frac": (bytes_seed + bytes_sw) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS / max(world, 1),
                                                  "note": "SURVEY 8(d): (bytes_seed + bytes_sw of the reference's data layout) / wall time of a step / (N x 8 TB/s); the joined-position "
                                                          "fingerprint term (P x 48 B) is left out (P is not counted on the device in --fast)"}
-        if world == 1 and NB == 1:
-            # What N database shards can and cannot shrink (strong scaling of the fixed job, one shard per rank): per step every rank
-            # indexes ALL queries and pays the launch floors of its stages whatever its shard's size, the reference stream, the
-            # pair filter and the extension shrink with the shard, and the ranks exchange their records (two all-to-alls of the
-            # per-query top-k, then the gather). Printed before any multi-GPU run so that the first SCALE file is a check.
-            sk = out["seed_kernel_ms"]
-            fixed = sk["index_queries"] + sk["mask_groups"] + 0.30      # + memsets / copies / launch floors of a step (profiles/r03_kernel_stats_C2.csv)
-            shrink = max(dt / args.steps * 1e3 - fixed, 0.0)
-            n_matches_step = int(n_matches_all)
-            def coll_ms(n):      # 2 x all_to_all_single (counts + records, then the gather): ~25 us latency each over xGMI + payload at ~50 GB/s per link
-                payload = 104.0 * int(n_matches_step) / n
-                return 4 * 0.025 + 2 * payload / 50e9 * 1e3
-            out["scaling_model"] = {
-                "what": "predicted ms per step of the database-sharded job on N GPUs = fixed + shrinking / N + collectives(N); measured at N = 1, to be checked against SCALE",
-                "fixed_ms": fixed, "shrinking_ms": shrink,
-                "fixed_parts": {"index_queries": sk["index_queries"], "mask_groups": sk["mask_groups"], "memsets_copies_launch_floors": 0.30},
-                "predicted_ms_per_step": {str(n): fixed + shrink / n + (coll_ms(n) if n > 1 else 0.0) for n in (1, 2, 4, 8)},
-                "predicted_speedup": {str(n): (dt / args.steps * 1e3) / (fixed + shrink / n + (coll_ms(n) if n > 1 else 0.0)) for n in (2, 4, 8)},
-                "host_cpu_ms_per_step": out.get("host_cpu_ms_per_step"),
-                "note": "Amdahl: the query index is built on every rank; with 16 host CPUs for 8 ranks the extension's host part (host_cpu_ms_per_step, "
-                        "mostly chaining and culling) is the other term that does not shrink per box"}
-        if world == 1 and NB > 1:
-            # The same question for a job of several database blocks (C5: 8 blocks, N GPUs take 8 / N each). Per step a rank indexes
-            # the query block once (kept over its blocks), streams and extends its blocks; the host part of the extension (chaining,
-            # culling, packing: host_cpu_ms_per_step of CPU time, the same total however many ranks share it) runs on the box's CPU
-            # quota; the ranks exchange their records once (device-resident all-to-all + device merge).
-            sk = out["seed_kernel_ms"]
-            gpu_fixed = sk["index_queries"]
-            gpu_shrink = (sk["total"] - sk["index_queries"]) + ext["round1_swipe_kernel_ms"] + ext["round2_swipe_kernel_ms"] + ext["traceback_kernel_ms"]
-            cpus = cgroup_cpus()
-            host_floor = cpu_ms_per_step / max(cpus, 1)
-            step_now = dt / args.steps * 1e3
-            def pred(n, host_cpus):
-                host = cpu_ms_per_step / max(host_cpus, 1)
-                coll = 4 * 0.025 + 2 * 104.0 * len(records) / n / 50e9 * 1e3 if n > 1 else 0.0
-                return max(gpu_fixed + gpu_shrink / n, host, step_now / n if n == 1 else 0.0) + coll
-            out["scaling_model"] = {
-                "what": "predicted ms per step of the %d-block job on N GPUs = max(GPU: fixed + shrinking / N, host: CPU-ms per step / CPUs of the box) + collectives; measured at N = 1" % w.n_blocks_total,
-                "gpu_fixed_ms": gpu_fixed, "gpu_shrinking_ms": gpu_shrink, "host_cpu_ms_per_step": cpu_ms_per_step, "host_cpus": cpus, "host_floor_ms": host_floor,
-                "measured_ms_per_step": step_now,
-                "predicted_ms_per_step": {str(n): pred(n, cpus) for n in (1, 2, 4, 8)},
-                "predicted_speedup": {str(n): step_now / pred(n, cpus) for n in (2, 4, 8)},
-                "predicted_speedup_with_8_cpus_per_rank": {str(n): step_now / pred(n, 8 * n) for n in (2, 4, 8)},
-                "note": "under this box's CPU quota the extension's host part bounds the 8-GPU run (the same CPU-ms per step shared by all ranks); with 8 host cores per rank the "
-                        "GPU term (the query index every rank builds + its share of the stream and the sweeps) is the bound. host_cpu_ms_per_step is that of THIS run's configuration "
-                        "(%d extension contexts, %d host threads); a rank of a multi-rank run extends two batches at a time with its share of the cores and spends less CPU time per step "
-                        "(381 against 470 CPU-ms measured at N = 1, profiles/r05_bench_C5*.json)" % (E, threads)}
+        if world == 1:
+            out["scaling_model"] = scaling_model(out, ext, cpu_ms_per_step, cgroup_cpus(), dt / args.steps * 1e3, int(n_matches_all), w.n_blocks_total, E, threads)
         if seed_params.n_shapes > 2:
             out["roofline"]["note"] += ("; with short seeds (weight < 10) this kernel also runs the Hamming filter of every joined (query, reference) "
                                         "position pair, so its launch time covers the join AND the stage-1 filter")
@@ -874,6 +900,18 @@ def main():
                     want = e2e["runs"]["default_masking"]["reference_md5"]
                     got = hashlib.md5(masked_text.encode()).hexdigest()
                     out["masked_step"]["parity"] = {"records_md5": got, "reference_output_md5": want, "matches": got == want}
+        if not args.no_cpu_baseline and world > 1 and state.get("records") is not None:
+            # N > 1: the job's records (rank 0 holds them all) against the reference run with the same database block cut (-b as the
+            # workload cut its blocks); the reference's own timing is an N = 1 matter and not taken here
+            qids = ["%s%d" % ("r" if w.contexts == 6 else "q", i) for i in range(w.n_queries)]
+            tids = ["t%d" % i for i in range(w.n_db)]
+            text = hip.format_tab(state["records"], qids, tids, w.source_lens)
+            _, ref_md5, _ = cpu_baseline_reference(w, cgroup_cpus(), e2e=False, parity_only=True)
+            if ref_md5 is not None:
+                ours = hashlib.md5(text.encode()).hexdigest()
+                out["parity_checked"] = ours == ref_md5
+                out["parity"] = {"records_md5": ours, "reference_output_md5": ref_md5, "lines": text.count("\n"),
+                                 "note": "reference run on rank 0 with the database cut into the same %d blocks (-b)" % w.n_blocks_total}
         print(json.dumps(out))
     if not closed:
         for c in (ctxs_seed if ctxs_seed is not ctxs else []) + [x for cs in ext_ctxs for x in cs] + (alt_ext_ctxs + [seed_ctx_alt] if alternate else []) + ([join_ctx] if join_ctx else []):

@@ -1297,6 +1297,7 @@ int run_blastp(const Options& o)
 		static const int rccl_env = [] { const char* e = std::getenv("DMND_CLI_RCCL"); return e ? std::atoi(e) : -1; }();
 		const bool rank_join = t_blocks.size() > 1 && o.global_ranking == 0 && o.max_hsps == 1 && !o.range_culling && !joined.empty()
 			&& (rccl_env >= 0 ? rccl_env != 0 : n_gpus > 1);
+		bool rank_joined = false;
 		if (rank_join) {
 			std::vector<std::vector<dmnd_match>> per_gpu((size_t)n_gpus);
 			for (size_t k = 0; k < joined.size(); ++k) {
@@ -1308,12 +1309,22 @@ int run_blastp(const Options& o)
 			std::vector<int64_t> counts((size_t)n_gpus);
 			for (int g = 0; g < n_gpus; ++g) { ptrs[(size_t)g] = per_gpu[(size_t)g].data(); counts[(size_t)g] = (int64_t)per_gpu[(size_t)g].size(); }
 			int transport = 0;
-			chk(dmnd_join_ranks(ctxs.data(), n_gpus, ptrs.data(), counts.data(), (int64_t)(qr.end - qr.begin), o.k, o.top, joined.data(), (int64_t)joined.size(), &n_matches, &transport));
-			for (int64_t k = 0; k < n_matches; ++k) joined[(size_t)k].query += (uint32_t)qr.begin;
-			if (&qr == &q_blocks.front()) std::cerr << "Block join: " << (transport == 1 ? "RCCL exchange (ncclSend/ncclRecv) between " : "device-to-device copies between ") << n_gpus
-				<< " context(s), merged on the device(s)\n";
+			std::vector<dmnd_match> merged(joined.size());
+			const int jrc = dmnd_join_ranks(ctxs.data(), n_gpus, ptrs.data(), counts.data(), (int64_t)(qr.end - qr.begin), o.k, o.top, merged.data(), (int64_t)merged.size(), &n_matches, &transport);
+			if (jrc == DMND_OK) {
+				for (int64_t k = 0; k < n_matches; ++k) { joined[(size_t)k] = merged[(size_t)k]; joined[(size_t)k].query += (uint32_t)qr.begin; }
+				if (&qr == &q_blocks.front()) std::cerr << "Block join: transport_used = " << (transport == 1 ? "RCCL exchange (ncclSend/ncclRecv) between " : "device-to-device copies between ") << n_gpus
+					<< " context(s), merged on the device(s)\n";
+				rank_joined = true;
+			}
+			else if (jrc == DMND_E_DEVICE || jrc == DMND_E_CAP || jrc == DMND_E_NOMEM) {
+				// no RCCL library, no peer access, ncclCommInitAll refused by the container ...: the host join gives the same records
+				std::cerr << "Block join: the device exchange is not available (" << dmnd_last_error() << "); transport_used = host join\n";
+				n_matches = (int64_t)joined.size();
+			}
+			else chk(jrc);
 		}
-		else
+		if (!rank_joined)
 		// the join's culler is the one TargetCulling::get picks (output/target_culling.cpp:22-28): RangeCulling with --range-culling
 		if (t_blocks.size() > 1 && o.global_ranking == 0) chk(o.range_culling ? dmnd_join_blocks_range(joined.data(), (int64_t)joined.size(), o.k, o.top, o.range_cover, &n_matches)
 			: o.top >= 0.0 ? dmnd_join_blocks_top(joined.data(), (int64_t)joined.size(), o.top, &n_matches)

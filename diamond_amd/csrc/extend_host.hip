@@ -2055,7 +2055,8 @@ extern "C" int dmnd_join_blocks(dmnd_match* r, int64_t n, int max_target_seqs, i
 // target outside the top per cent of the read's single best score was lost, also when it covers another part of the read.
 extern "C" int dmnd_join_blocks_range(dmnd_match* r, int64_t n, int max_target_seqs, double top_percent, double range_cover, int64_t* n_out)
 {
-	if (!r || n < 0 || max_target_seqs < 1 || top_percent >= 100.0 || !n_out) return fail(DMND_E_ARG, "dmnd_join_blocks_range: bad argument");
+	if (!r || n < 0 || max_target_seqs < 1 || top_percent > 100.0 || !n_out) return fail(DMND_E_ARG, "dmnd_join_blocks_range: bad argument");
+	if (top_percent >= 100.0) top_percent = -1.0;       // RangeCulling: toppercent == 100.0 means "no --top" (the count-based coverage test, cmp_evalue order)
 	const auto groups = top_percent >= 0.0 ? join_groups(r, n, match_less_score) : join_groups(r, n, match_less);
 	std::vector<std::pair<int64_t, int64_t>> keep;
 	Coverage cover(max_target_seqs);

@@ -568,7 +568,12 @@ hipError_t launch_motif_mask(const MotifArgs& a, hipStream_t st)
 {
 	if (a.n_seqs <= 0 || a.n_table <= 0 || a.n_table > MOTIF_TABLE_MAX) return a.n_table > MOTIF_TABLE_MAX ? hipErrorInvalidValue : hipSuccess;
 	const int64_t chunks = (a.end - a.begin + MOTIF_CHUNK - 1) / MOTIF_CHUNK;
+	// the table (up to 64 KB) + the kernel's 8 KB filter: more dynamic LDS than a kernel gets without asking (gfx950 has 160 KB per CU)
+	static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(motif_hit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MOTIF_TABLE_MAX * (int)sizeof(uint64_t));
+	if (attr != hipSuccess) return attr;
 	motif_hit_kernel<<<dim3((unsigned)chunks), dim3(256), (size_t)a.n_table * sizeof(uint64_t), st>>>(a);
+	const hipError_t e_hit = hipGetLastError();
+	if (e_hit != hipSuccess) return e_hit;                // (so that a refused launch is reported as this kernel's)
 	motif_apply_kernel<<<dim3((unsigned)((a.n_seqs * 64 + 255) / 256)), dim3(256), 0, st>>>(a);
 	return hipGetLastError();
 }

@@ -16,7 +16,20 @@
 // through RCCL (send and receive to itself inside the group), which is how the RCCL calls are exercised on a 1-GPU box.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
-#include <rccl/rccl.h>
+// The few RCCL declarations this file uses, stated here: the library is dlopen'ed (a ROCm install without RCCL still builds and
+// runs -- dmnd_join_ranks then reports that the library is missing and the caller joins on the host). Values as in rccl.h.
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclUint8 = 1 } ncclDataType_t;
+ncclResult_t ncclCommInitAll(ncclComm_t* comms, int ndev, const int* devlist);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclGroupStart(void);
+ncclResult_t ncclGroupEnd(void);
+ncclResult_t ncclSend(const void* sendbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclRecv(void* recvbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
+const char* ncclGetErrorString(ncclResult_t result);
+}
 #include <cstdint>
 #include <cstring>
 #include <mutex>
@@ -96,6 +109,39 @@ int owner_of(int64_t q, int64_t Q, int n)
 	return base > 0 ? (int)(rem + (q - big) / base) : n - 1;
 }
 
+// The exchange of dmnd_join_ranks as plain arithmetic (no device; dmnd_join_ranks_plan exposes it to the CPU tests): source g holds
+// counts[g] records; cnt[g][j] of them belong to owner j and are sent from offset send_off(g, j) = sum_{j' < j} cnt[g][j'] of g's
+// owner-ordered copy to offset recv_off(j, g) = sum_{g' < g} cnt[g'][j] of owner j's receive buffer, which holds n_recv[j] records.
+struct ExchangePlan {
+	int n = 0;
+	std::vector<int64_t> cnt, n_recv;                   // cnt[g * n + j]
+	int64_t count(int g, int j) const { return cnt[(size_t)g * (size_t)n + (size_t)j]; }
+	int64_t send_off(int g, int j) const { int64_t o = 0; for (int x = 0; x < j; ++x) o += count(g, x); return o; }
+	int64_t recv_off(int j, int g) const { int64_t o = 0; for (int x = 0; x < g; ++x) o += count(x, j); return o; }
+};
+
+// query_of(g, i) = query of record i of source g; place(g, i, k): record i of source g is entry k of g's owner-ordered copy (stable:
+// block and query order inside an owner's share survive). Returns the first record whose query lies outside [0, n_queries), or -1.
+template<typename QueryOf, typename Place>
+int64_t plan_exchange(int n, const int64_t* counts, int64_t n_queries, QueryOf query_of, Place place, ExchangePlan& p)
+{
+	p.n = n;
+	p.cnt.assign((size_t)n * (size_t)n, 0);
+	p.n_recv.assign((size_t)n, 0);
+	for (int g = 0; g < n; ++g) {
+		for (int64_t i = 0; i < counts[g]; ++i) {
+			const int64_t q = query_of(g, i);
+			if (q < 0 || q >= n_queries) return i;
+			++p.cnt[(size_t)g * (size_t)n + (size_t)owner_of(q, n_queries, n)];
+		}
+		std::vector<int64_t> at((size_t)n, 0);
+		for (int j = 1; j < n; ++j) at[(size_t)j] = at[(size_t)j - 1] + p.count(g, j - 1);
+		for (int64_t i = 0; i < counts[g]; ++i) place(g, i, at[(size_t)owner_of(query_of(g, i), n_queries, n)]++);
+	}
+	for (int g = 0; g < n; ++g) for (int j = 0; j < n; ++j) p.n_recv[(size_t)j] += p.count(g, j);
+	return -1;
+}
+
 }  // namespace
 
 // transport_used (may be NULL): 1 = RCCL (ncclSend / ncclRecv), 2 = device-to-device copies (contexts sharing a device)
@@ -113,26 +159,22 @@ extern "C" int dmnd_join_ranks(dmnd_ctx* const* ctx, int n_ctx, const dmnd_match
 		devices[(size_t)g] = ctx[g]->device;
 		for (int j = 0; j < g; ++j) distinct = distinct && devices[(size_t)j] != devices[(size_t)g] && ctx[j] != ctx[g];
 	}
+	for (int g = 0; g < N; ++g) for (int j = 0; j < g; ++j) if (ctx[j] == ctx[g]) return fail(DMND_E_ARG, "dmnd_join_ranks: the same context twice (its join buffers would be shared by two sources)");
 	const bool use_rccl = distinct;                       // (one context: RCCL with itself)
 	if (!use_rccl) for (int g = 1; g < N; ++g) if (devices[(size_t)g] != devices[0]) return fail(DMND_E_ARG, "dmnd_join_ranks: contexts either on distinct devices (RCCL) or all on one (copies)");
 	if (transport_used) *transport_used = use_rccl ? 1 : 2;
 	const size_t item = sizeof(dmnd_match);
 	// 1. per source: records ordered by owner (stable: block and query order inside an owner's share survive), counts per owner
-	std::vector<std::vector<int64_t>> cnt((size_t)N, std::vector<int64_t>((size_t)N, 0));
+	ExchangePlan plan;
 	std::vector<std::vector<dmnd_match>> sorted((size_t)N);
-	for (int g = 0; g < N; ++g) {
-		const dmnd_match* r = records[g];
-		for (int64_t i = 0; i < counts[g]; ++i) {
-			if ((int64_t)r[i].query >= n_queries) return fail(DMND_E_ARG, "dmnd_join_ranks: a record's query lies outside [0, n_queries)");
-			++cnt[(size_t)g][(size_t)owner_of((int64_t)r[i].query, n_queries, N)];
-		}
-		std::vector<int64_t> at((size_t)N, 0);
-		for (int j = 1; j < N; ++j) at[(size_t)j] = at[(size_t)j - 1] + cnt[(size_t)g][(size_t)j - 1];
-		sorted[(size_t)g].resize((size_t)counts[g]);
-		for (int64_t i = 0; i < counts[g]; ++i) sorted[(size_t)g][(size_t)at[(size_t)owner_of((int64_t)r[i].query, n_queries, N)]++] = r[i];
-	}
-	std::vector<int64_t> n_recv((size_t)N, 0);
-	for (int g = 0; g < N; ++g) for (int j = 0; j < N; ++j) n_recv[(size_t)j] += cnt[(size_t)g][(size_t)j];
+	for (int g = 0; g < N; ++g) sorted[(size_t)g].resize((size_t)counts[g]);
+	if (plan_exchange(N, counts, n_queries, [&](int g, int64_t i) { return (int64_t)records[g][i].query; },
+		[&](int g, int64_t i, int64_t k) { sorted[(size_t)g][(size_t)k] = records[g][i]; }, plan) >= 0)
+		return fail(DMND_E_ARG, "dmnd_join_ranks: a record's query lies outside [0, n_queries)");
+	const std::vector<int64_t>& n_recv = plan.n_recv;
+	auto cnt_of = [&](int g, int j) { return plan.count(g, j); };
+	// the page-locked-less `sorted` copies are the sources of asynchronous uploads: no exit before every stream has drained
+	struct Drain { dmnd_ctx* const* ctx; int n; ~Drain() { for (int g = 0; g < n; ++g) if (ctx[g] && ctx[g]->stream) { (void)hipSetDevice(ctx[g]->device); (void)sync_stream(ctx[g]->stream); } } } drain{ ctx, N };
 	// 2. upload, buffers
 	for (int g = 0; g < N; ++g) {
 		dmnd_ctx* c = ctx[g];
@@ -144,8 +186,8 @@ extern "C" int dmnd_join_ranks(dmnd_ctx* const* ctx, int n_ctx, const dmnd_match
 	}
 	// 3. the exchange: source g's share for owner j lies at send offset S(g, j) = sum_{j' < j} cnt[g][j'], and lands at receive offset
 	// R(j, g) = sum_{g' < g} cnt[g'][j] of owner j
-	auto send_off = [&](int g, int j) { int64_t o = 0; for (int x = 0; x < j; ++x) o += cnt[(size_t)g][(size_t)x]; return o; };
-	auto recv_off = [&](int j, int g) { int64_t o = 0; for (int x = 0; x < g; ++x) o += cnt[(size_t)x][(size_t)j]; return o; };
+	auto send_off = [&](int g, int j) { return plan.send_off(g, j); };
+	auto recv_off = [&](int j, int g) { return plan.recv_off(j, g); };
 	if (use_rccl) {
 		std::vector<ncclComm_t> comms;
 		if (int rc = comms_for(devices, comms)) return rc;
@@ -154,10 +196,10 @@ extern "C" int dmnd_join_ranks(dmnd_ctx* const* ctx, int n_ctx, const dmnd_match
 		for (int g = 0; g < N && e == ncclSuccess; ++g) {
 			dmnd_ctx* c = ctx[g];
 			for (int j = 0; j < N && e == ncclSuccess; ++j) {
-				if (cnt[(size_t)g][(size_t)j] > 0)
-					e = r.send(c->join_in.as<char>() + (size_t)send_off(g, j) * item, (size_t)cnt[(size_t)g][(size_t)j] * item, ncclUint8, j, comms[(size_t)g], c->stream);
-				if (e == ncclSuccess && cnt[(size_t)j][(size_t)g] > 0)
-					e = r.recv(c->join_recv.as<char>() + (size_t)recv_off(g, j) * item, (size_t)cnt[(size_t)j][(size_t)g] * item, ncclUint8, j, comms[(size_t)g], c->stream);
+				if (cnt_of(g, j) > 0)
+					e = r.send(c->join_in.as<char>() + (size_t)send_off(g, j) * item, (size_t)cnt_of(g, j) * item, ncclUint8, j, comms[(size_t)g], c->stream);
+				if (e == ncclSuccess && cnt_of(j, g) > 0)
+					e = r.recv(c->join_recv.as<char>() + (size_t)recv_off(g, j) * item, (size_t)cnt_of(j, g) * item, ncclUint8, j, comms[(size_t)g], c->stream);
 			}
 		}
 		const ncclResult_t e2 = r.group_end();
@@ -168,9 +210,9 @@ extern "C" int dmnd_join_ranks(dmnd_ctx* const* ctx, int n_ctx, const dmnd_match
 			dmnd_ctx* c = ctx[g];
 			HIP_TRY(hipSetDevice(c->device));
 			for (int j = 0; j < N; ++j)
-				if (cnt[(size_t)g][(size_t)j] > 0)
+				if (cnt_of(g, j) > 0)
 					HIP_TRY(hipMemcpyAsync(ctx[j]->join_recv.as<char>() + (size_t)recv_off(j, g) * item, c->join_in.as<char>() + (size_t)send_off(g, j) * item,
-						(size_t)cnt[(size_t)g][(size_t)j] * item, hipMemcpyDeviceToDevice, c->stream));
+						(size_t)cnt_of(g, j) * item, hipMemcpyDeviceToDevice, c->stream));
 		}
 		for (int g = 0; g < N; ++g) HIP_TRY(sync_stream(ctx[g]->stream));      // an owner's merge reads what every source's stream wrote
 	}
@@ -205,5 +247,28 @@ extern "C" int dmnd_join_ranks(dmnd_ctx* const* ctx, int n_ctx, const dmnd_match
 		if (int rc = download_bytes(ctx[g], out + at, ctx[g]->join_out.p, (size_t)kept[(size_t)g] * item)) return rc;
 		at += kept[(size_t)g];
 	}
+	return DMND_OK;
+}
+
+// The exchange plan of dmnd_join_ranks without a device (tests/test_multigpu_gloo.py feeds it uneven counts for 2 - 8 ranks and moves
+// bytes by it): queries[g][i] = query of record i of source g. Outputs, all n x n row-major unless noted: cnt[g][j] records source g
+// sends to owner j, send_off[g][j], recv_off[j][g], n_recv[j] (n entries), place[g][i] (counts[g] entries per source, may be NULL) =
+// position of record i in g's owner-ordered copy.
+extern "C" int dmnd_join_ranks_plan(int n, const int64_t* counts, const uint32_t* const* queries, int64_t n_queries, int64_t* cnt, int64_t* send_off, int64_t* recv_off,
+	int64_t* n_recv, int64_t* const* place)
+{
+	if (n < 1 || n > 64 || !counts || !queries || n_queries < 1 || !cnt || !send_off || !recv_off || !n_recv) return fail(DMND_E_ARG, "dmnd_join_ranks_plan: bad argument");
+	for (int g = 0; g < n; ++g) if (counts[g] < 0 || (counts[g] > 0 && !queries[g])) return fail(DMND_E_ARG, "dmnd_join_ranks_plan: bad argument");
+	ExchangePlan p;
+	if (plan_exchange(n, counts, n_queries, [&](int g, int64_t i) { return (int64_t)queries[g][i]; },
+		[&](int g, int64_t i, int64_t k) { if (place && place[g]) place[g][i] = k; }, p) >= 0)
+		return fail(DMND_E_ARG, "dmnd_join_ranks_plan: a query lies outside [0, n_queries)");
+	for (int g = 0; g < n; ++g)
+		for (int j = 0; j < n; ++j) {
+			cnt[(size_t)g * n + j] = p.count(g, j);
+			send_off[(size_t)g * n + j] = p.send_off(g, j);
+			recv_off[(size_t)j * n + g] = p.recv_off(j, g);
+		}
+	for (int j = 0; j < n; ++j) n_recv[j] = p.n_recv[(size_t)j];
 	return DMND_OK;
 }

@@ -77,7 +77,7 @@ EXPORTS = ["dmnd_abi_version", "dmnd_last_error", "dmnd_default_params", "dmnd_c
            "dmnd_seed_params_set_query_indexed", "dmnd_auto_query_indexed", "dmnd_set_motif_table", "dmnd_motif_table_size",
            "dmnd_soft_mask_block", "dmnd_output_fields", "dmnd_format_fields", "dmnd_format_pairwise_intro", "dmnd_format_pairwise",
            "dmnd_format_paf", "dmnd_device_count", "dmnd_set_top_percent", "dmnd_join_blocks_top", "dmnd_set_filters", "dmnd_format_sam", "dmnd_set_query_source_lengths", "dmnd_format_fields_unaligned", "dmnd_format_fields_header", "dmnd_set_query_index_reuse", "dmnd_set_no_self_hits", "dmnd_matrix_params", "dmnd_masking_lambda", "dmnd_translate_opts", "dmnd_set_extension_mode", "dmnd_format_xml_header", "dmnd_format_xml_query_intro", "dmnd_format_xml", "dmnd_format_xml_query_epilog", "dmnd_format_daa_header", "dmnd_format_daa_query", "dmnd_format_daa_match", "dmnd_seg_ranges", "dmnd_seg_mask_block", "dmnd_seg_lnfact", "dmnd_daa_match_read", "dmnd_hsp_from_transcript", "dmnd_hsp_from_transcript_frames", "dmnd_set_format_flags", "dmnd_host_alloc", "dmnd_host_free", "dmnd_share_block", "dmnd_copy_block", "dmnd_init", "dmnd_seed_reserve", "dmnd_mask_sequences", "dmnd_set_max_hsps", "dmnd_rank_targets", "dmnd_rank_update", "dmnd_set_global_ranking",
-           "dmnd_upload_matrices", "dmnd_frameshift_swipe", "dmnd_set_frameshift", "dmnd_set_context_motif_table", "dmnd_cbs_composition", "dmnd_cbs_rule", "dmnd_cbs_target_matrix", "dmnd_cbs_ideal_lambda", "dmnd_join_blocks_range", "dmnd_join_blocks_device", "dmnd_join_blocks_device_host", "dmnd_join_ranks", "dmnd_xdrop_ungapped"]
+           "dmnd_upload_matrices", "dmnd_frameshift_swipe", "dmnd_set_frameshift", "dmnd_set_context_motif_table", "dmnd_cbs_composition", "dmnd_cbs_rule", "dmnd_cbs_target_matrix", "dmnd_cbs_ideal_lambda", "dmnd_join_blocks_range", "dmnd_join_blocks_device", "dmnd_join_blocks_device_host", "dmnd_join_ranks", "dmnd_join_ranks_plan", "dmnd_xdrop_ungapped"]
 
 
 def set_motif_table(codes):

@@ -5,6 +5,8 @@ there is NO collective on the data path. The one exchange is `query_range_join`:
 query range, rank g merging the queries [g Q/G, (g+1) Q/G) as the reference joins reference blocks
 (JoinRecord::cmp_evalue: evalue asc, score desc, target oid asc; output/join_blocks.cpp:129-137), then one gather of the
 joined records to rank 0. Query sharding (8e option 1) needs only the ordered gather."""
+import time
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -19,6 +21,20 @@ def shard_range(n, world, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+# what the exchanges of this process moved so far (bench.py reports it per step: the SCALE record's proof that the collective ran
+# over `world_size` ranks): bytes this rank sent / received in payload collectives, their wall time, the calls
+STATS = {"bytes_sent": 0, "bytes_received": 0, "exchange_s": 0.0, "collectives": 0, "transport": None}
+
+
+def _note(sent, received, seconds, transport):
+    STATS["bytes_sent"] += int(sent); STATS["bytes_received"] += int(received); STATS["exchange_s"] += float(seconds)
+    STATS["collectives"] += 1; STATS["transport"] = transport
+
+
+def reset_stats():
+    STATS.update(bytes_sent=0, bytes_received=0, exchange_s=0.0, collectives=0, transport=None)
+
+
 def _a2a_bytes(parts, device):
     """all_to_all of variable-length byte strings: parts[g] (uint8 ndarray) goes to rank g; returns the list of the world's
     contributions to this rank, in rank order. Two collectives: the counts, then the payload (all_to_all_single with split
@@ -30,8 +46,10 @@ def _a2a_bytes(parts, device):
     n_out = [int(x) for x in n_out.cpu().tolist()]
     send = torch.from_numpy(np.concatenate(parts) if sum(p.size for p in parts) else np.zeros(0, np.uint8)).to(device)
     recv = torch.empty(sum(n_out), dtype=torch.uint8, device=device)
+    t0 = time.perf_counter()
     dist.all_to_all_single(recv, send, output_split_sizes=n_out, input_split_sizes=[int(p.size) for p in parts])
     recv = recv.cpu().numpy()
+    _note(send.numel(), recv.size, time.perf_counter() - t0, "all_to_all_single (%s, through host memory)" % dist.get_backend())
     cuts = np.cumsum([0] + n_out)
     return [recv[cuts[r]:cuts[r + 1]] for r in range(world)]
 
@@ -46,7 +64,11 @@ def _a2a_device(send, in_counts, device):
     dist.all_to_all_single(n_out, n_in)
     n_out = [int(x) for x in n_out.cpu().tolist()]
     recv = torch.empty(sum(n_out), dtype=torch.uint8, device=device)
+    t0 = time.perf_counter()
     dist.all_to_all_single(recv, send, output_split_sizes=n_out, input_split_sizes=[int(x) for x in in_counts])
+    if recv.is_cuda:
+        torch.cuda.current_stream(device).synchronize()
+    _note(send.numel(), recv.numel(), time.perf_counter() - t0, "all_to_all_single (%s, device tensors)" % dist.get_backend())
     return recv, n_out
 
 

@@ -566,6 +566,12 @@ int dmnd_join_blocks_device_host(dmnd_ctx* ctx, dmnd_match* records, int64_t n, 
  * *transport_used (may be NULL): 1 = RCCL, 2 = copies. */
 int dmnd_join_ranks(dmnd_ctx* const* ctx, int n_ctx, const dmnd_match* const* records, const int64_t* counts, int64_t n_queries, int max_target_seqs,
 	double top_percent, dmnd_match* out, int64_t cap, int64_t* n_out, int* transport_used);
+/* The exchange plan of dmnd_join_ranks as plain arithmetic, no device needed (the code the RCCL path runs; tests/test_rank_join_plan.py
+ * moves bytes by it for 2 - 8 ranks): queries[g][i] = query of record i of source g. Outputs (n x n, row-major): cnt[g][j] = records
+ * source g sends to owner j, send_off[g][j] = their offset in g's owner-ordered copy, recv_off[j][g] = their offset in owner j's
+ * receive buffer; n_recv[j] (n entries); place[g][i] (may be NULL) = position of record i in g's owner-ordered copy. */
+int dmnd_join_ranks_plan(int n, const int64_t* counts, const uint32_t* const* queries, int64_t n_queries, int64_t* cnt, int64_t* send_off, int64_t* recv_off,
+	int64_t* n_recv, int64_t* const* place);
 /* Touches every HIP stream the context owns (its own and those of the extension stage's runners) with an empty marker and
  * waits for them. A driver that calls hipDeviceSynchronize between batches (bench.py must, by its timing contract) lets the
  * runtime release idle hardware queues; re-acquiring them costs the next dmnd_extend several milliseconds (measured: +6.5 ms
