@@ -341,7 +341,7 @@ def main():
     ap.add_argument("--host-threads", type=int, default=None, help="host threads of the extension stage per rank, divided among the extension contexts (default 12, fewer per rank with several ranks)")
     ap.add_argument("--shard", choices=["db", "query"], default="db")
     ap.add_argument("--ext-contexts", type=int, default=None, help="batches extended concurrently, each on its own context and host thread team (default 3; 2 with several database blocks per rank)")
-    ap.add_argument("--seed-contexts", type=int, default=1, help="seed stages in flight at the same time (own context and stream each; one with several database blocks per rank)")
+    ap.add_argument("--seed-contexts", type=int, default=None, help="seed stages in flight at the same time (own context and stream each; one with several database blocks per rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the whole-process comparison (diamond-hip against the reference binary on files)")
     ap.add_argument("--with-masking", action="store_true", help="(default since round 5; kept for old command lines) time the step of the default command line too")
@@ -434,8 +434,13 @@ def main():
     # --seed-contexts N: N seed stages at the same time, each on its own context. Measured on C2 (round 3): 3.38 / 3.33 / 3.46 ms per
     # step with 1 / 2 / 3 -- the device is the bound (the stream kernels of two batches share the L2 request rate, each takes twice
     # as long), so the default stays 1.
-    SC = 1 if (NB > 1 or not pipeline) else max(1, args.seed_contexts)
-    ctxs_seed = [make_ctx(None)] if NB > 1 else ([make_ctx(0) for _ in range(SC)] if pipeline else ctxs)
+    # Several blocks (round 6): the seed stages of a BATCH (all its blocks, one query index) are one task on one context, and two such
+    # tasks run at the same time on two contexts -- a seed stage of a 1.9e8-letter block is ~45 dependent launches and half a dozen
+    # host waits around 2 ms of kernels, so one context alone left the device idle half of the time (C5: 54 -> see DESIGN 5.0).
+    if args.seed_contexts is None:
+        args.seed_contexts = 2 if NB > 1 else 1
+    SC = 1 if not pipeline else max(1, args.seed_contexts)
+    ctxs_seed = [make_ctx(None) for _ in range(SC)] if NB > 1 else ([make_ctx(0) for _ in range(SC)] if pipeline else ctxs)
     import queue as queue_mod
     import threading
     seed_free = queue_mod.Queue()
@@ -475,9 +480,11 @@ def main():
         seed_ctx_alt = make_alt_ctx()
         seed_counter = [0]
 
-    def seed_stage(b=0, alt=False):
+    def seed_stage(b=0, alt=False, c=None):
         torch.cuda.set_device(local_rank)
-        c = seed_free.get()
+        held = c is not None                                 # a batch task brings the context it holds for all its blocks
+        if c is None:
+            c = seed_free.get()
         if alt:                                              # block B has its own seed context (one seed stage runs at a time: SC = 1)
             seed_free.put(c)
             c = seed_ctx_alt
@@ -491,7 +498,7 @@ def main():
             wall = (time.perf_counter() - t_s) * 1e3
             ms = c.seed_kernel_ms()
         finally:
-            if not alt:
+            if not alt and not held:
                 seed_free.put(c)
         with seed_lock:
             state.setdefault("seed_wall", []).append(wall)
@@ -576,6 +583,26 @@ def main():
         finish_pool = concurrent.futures.ThreadPoolExecutor(max_workers=1, initializer=name_thread, initargs=("bench-finish",))
         ext_pools = [concurrent.futures.ThreadPoolExecutor(max_workers=1, initializer=name_thread, initargs=("bench-extend",)) for _ in range(E)]      # a context runs one call at a time
 
+    def seed_batch():
+        """the seed stages of all blocks of one batch, on ONE seed context (its query index serves every block)"""
+        c = seed_free.get()
+        try:
+            return [seed_stage(b, c=c) for b in range(NB)]
+        finally:
+            seed_free.put(c)
+
+    class BatchPart:
+        """block b's share of a batch task, with a future's face"""
+        def __init__(self, fut, b):
+            self.fut, self.b = fut, b
+
+        def result(self):
+            return self.fut.result()[self.b]
+
+    def submit_seed_batch():
+        fut = seed_pool.submit(seed_batch)
+        return [BatchPart(fut, b) for b in range(NB)]
+
     def submit_seed(b):
         alt = False
         if alternate:
@@ -601,8 +628,10 @@ def main():
         for s in range(n_steps):
             if pipeline:
                 got = [queue.pop(0) for _ in range(NB)]
-                for b in range(NB):
-                    queue.append(submit_seed(b))
+                if NB > 1:
+                    queue.extend(submit_seed_batch())
+                else:
+                    queue.append(submit_seed(0))
                 inflight.append(ext_pools[s % E].submit(extend_batch, s % E, got))
                 if len(inflight) >= E:
                     retire()
@@ -622,7 +651,7 @@ def main():
     if alternate:
         for e in range(E):
             extend_batch(e, [seed_stage(0, True)])
-    queue = [submit_seed(b) for _ in range(PREFETCH) for b in range(NB)] if pipeline else []
+    queue = ([p for _ in range(PREFETCH) for p in submit_seed_batch()] if NB > 1 else [submit_seed(0) for _ in range(PREFETCH)]) if pipeline else []
     _, queue = run(args.warmup, queue)
     for f in queue:
         f.result()                                           # the first timed steps find their seed hits ready
