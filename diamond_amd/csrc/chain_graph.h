@@ -63,7 +63,14 @@ struct FixedVec {
 		*at = x; ++n;
 	}
 	DMND_XD void erase(T* at) { for (T* p = at; p + 1 < a + n; ++p) *p = *(p + 1); --n; }
-	DMND_XD void swap(FixedVec& o) { const FixedVec t = *this; *this = o; o = t; }
+	DMND_XD void reset() { n = 0; overflow = false; }      // an instance in memory no constructor ran on (LDS)
+	DMND_XD void swap(FixedVec& o)                      // element by element: a whole-array temporary would be 0.5 KB of private memory on the device
+	{
+		const int m = n > o.n ? n : o.n;
+		for (int i = 0; i < m; ++i) { const T t = a[i]; a[i] = o.a[i]; o.a[i] = t; }
+		const int tn = n; n = o.n; o.n = tn;
+		const bool tv = overflow; overflow = o.overflow; o.overflow = tv;
+	}
 	template<typename It> DMND_XD void append(It b, It e) { for (; b != e; ++b) push_back(*b); }
 };
 
@@ -191,6 +198,13 @@ struct ChainWorkspaceT {
 	ChainCfg cfg;
 
 	DMND_XD static Node node_of(const Seg& s) { Node n; n.i = s.i; n.j = s.j; n.len = s.len; n.score = s.score; n.best = n.peak = n.dip = s.score; n.newest = -1; return n; }
+
+	// FixedChainPolicy only: puts an instance that lives in raw memory (the device planner's LDS) into its constructed state
+	DMND_XD void reset_fixed()
+	{
+		nodes.reset(); closed_.reset(); open_.reset(); links.reset(); front.reset(); frames.reset(); tops.reset();
+		S = nullptr; cfg = ChainCfg();
+	}
 
 	// true: some array of a fixed-capacity instance was too small -- the result is void (never with HostChainPolicy)
 	DMND_XD bool overflowed() const

@@ -1062,7 +1062,7 @@ int run_blastp(const Options& o)
 		std::vector<std::future<int>> reserved;
 		if (&qr == &q_blocks.front())
 			for (int g = 0; g < n_gpus; ++g)
-				reserved.push_back(std::async(std::launch::async, [&, g] { const int rc = dmnd_seed_reserve(ctxs[(size_t)g], &sp, (int64_t)q.data.size()); g_timeline.mark("seed buffers reserved"); return rc; }));
+				reserved.push_back(std::async(std::launch::async, [&, g] { int rc = dmnd_seed_reserve(ctxs[(size_t)g], &sp, (int64_t)q.data.size()); if (rc == DMND_OK) rc = dmnd_extend_reserve(ctxs[(size_t)g], (int64_t)(4 * (qr.end - qr.begin))); g_timeline.mark("seed + extension buffers reserved"); return rc; }));
 		// --global-ranking: per query the N best targets of the whole database by ungapped score (align/global_ranking/table.cpp)
 		std::vector<dmnd_ranked_target> rank_table(o.global_ranking > 0 ? (qr.end - qr.begin) * (size_t)o.global_ranking : 0, dmnd_ranked_target{ 0, 0, 0, 0, 0 });
 		std::vector<dmnd_match> joined;                       // the query block's records against all reference blocks

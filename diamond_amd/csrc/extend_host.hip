@@ -627,8 +627,10 @@ static int plan_on_device(dmnd_ctx* c, const HostCfg& h, int64_t n_hits, bool gf
 		o_segs = align(o_queries + (n + 1) * sizeof(PlanQuery)), o_slots = align(o_segs + n * 4 * sizeof(int32_t)),
 		o_count = align(o_slots + n * sizeof(PlanBand)), o_off = align(o_count + (n + 1) * sizeof(uint32_t)),
 		o_bands = align(o_off + (n + 1) * sizeof(uint32_t)), o_counters = align(o_bands + n * sizeof(PlanBand)),
-		bytes = o_counters + sizeof(PlanCounters);
+		o_chain = align(o_counters + sizeof(PlanCounters)), bytes = o_chain + (n / 2 + 1) * sizeof(uint32_t);
+	TraceLaps tr("dmnd_extend (planner)");
 	if (int rc = c->plan_dev.ensure(bytes)) return rc;
+	tr.lap("work arrays");
 	char* d = c->plan_dev.as<char>();
 	PlanArgs a;
 	a.qblock = c->block[DMND_QUERY].as<int8_t>(); a.tblock = c->block[DMND_TARGET].as<int8_t>();
@@ -644,10 +646,14 @@ static int plan_on_device(dmnd_ctx* c, const HostCfg& h, int64_t n_hits, bool gf
 	a.segs = reinterpret_cast<int32_t*>(d + o_segs); a.band_slots = reinterpret_cast<PlanBand*>(d + o_slots);
 	a.band_count = reinterpret_cast<uint32_t*>(d + o_count); a.band_off = reinterpret_cast<uint32_t*>(d + o_off);
 	a.bands = reinterpret_cast<PlanBand*>(d + o_bands); a.counters = reinterpret_cast<PlanCounters*>(d + o_counters);
+	a.chain_list = reinterpret_cast<uint32_t*>(d + o_chain);
 	a.scan_tmp = &c->plan_tmp; a.scan_tmp_bytes = &c->plan_tmp_bytes;
 	HIP_TRY(launch_plan(a, c->stream));
+	tr.lap("launched");
 	if (int rc = c->plan_host.ensure(sizeof(PlanCounters))) return rc;
+	tr.lap("host buffer");
 	HIP_TRY(copy_now(c->stream, c->plan_host.p, a.counters, sizeof(PlanCounters), hipMemcpyDeviceToHost));
+	tr.lap("counters back");
 	const PlanCounters cn = *c->plan_host.as<PlanCounters>();
 	if (cn.unsorted || cn.n_groups == 0) return DMND_OK;
 	plan.n_groups = cn.n_groups; plan.n_queries = cn.n_queries; plan.n_bands = cn.n_bands; plan.n_on_host = cn.n_on_host;
@@ -683,6 +689,7 @@ static int plan_fetch_lists(dmnd_ctx* c, DevPlan& plan)
 static int extend_on_device(dmnd_ctx* c, const HostCfg& h, const DevPlan& plan, int threads, std::vector<dmnd_match>& records, std::vector<uint8_t>& qstate, bool& done)
 {
 	done = false;
+	TraceLaps tr("dmnd_extend (device half)");
 	const int64_t chunk = ranking_chunk_size(h.ref_letters, h.max_target_seqs, h.ranking_block_letters, false);
 	if (chunk > EXT_MAX_CHUNK || plan.n_bands == 0) return DMND_OK;
 	const size_t nG = plan.n_groups, nQ = plan.n_queries, nB = plan.n_bands, nR = std::min(nG, nQ * (size_t)std::max(h.max_target_seqs, 1));
@@ -695,6 +702,7 @@ static int extend_on_device(dmnd_ctx* c, const HostCfg& h, const DevPlan& plan, 
 		o_cand_item = take(nG * 4), o_cand_ev = take(nG * 8), o_r2_order = take(nB * 4), o_r2_p = take(nB * 4), o_r2_off = take(nB * 8), o_r2_tr = take((nB + 1) * 8),
 		o_hsps = take(nB * sizeof(dmnd_hsp)), o_records = take(nR * sizeof(dmnd_match)), o_ctr = take(sizeof(ExtCounters));
 	if (int rc = c->ext_dev.ensure(at)) return rc;
+	tr.lap("work arrays");
 	char* d = c->ext_dev.as<char>();
 	ExtArgs a;
 	a.groups = plan.dev.groups; a.queries = plan.dev.queries; a.bands = plan.dev.bands;
@@ -725,9 +733,11 @@ static int extend_on_device(dmnd_ctx* c, const HostCfg& h, const DevPlan& plan, 
 	if (int rc = c->ext_host.ensure(sizeof(ExtCounters))) return rc;
 	HIP_TRY(copy_now(st, c->ext_host.p, a.ctr, sizeof(ExtCounters), hipMemcpyDeviceToHost));
 	ExtCounters ctr = *c->ext_host.as<ExtCounters>();
+	tr.lap("items, launch order, trace offsets");
 	if (ctr.n_items == 0) return DMND_OK;
 	if ((size_t)ctr.total_rows > c->trace_arena_max) return DMND_OK;
 	if (int rc = c->ext_trace.ensure((size_t)ctr.total_rows + 64)) return rc;
+	tr.lap("trace arena");
 	// 2. round 1 in traceback mode (one launch per band class), then best HSP per target, culling, the round-2 list
 	HIP_TRY(hipEventRecord(c->ev0, st));
 	if (int rc = dmnd_sweep_classes(c, c, a.items, ctr.class_count, ctr.class_max_steps, EXT_CLASSES, reinterpret_cast<const int32_t*>(a.order), a.off_slot, a.pairs, a.off_item,
@@ -736,6 +746,7 @@ static int extend_on_device(dmnd_ctx* c, const HostCfg& h, const DevPlan& plan, 
 	HIP_TRY(launch_ext_select(a, st));
 	HIP_TRY(copy_now(st, c->ext_host.p, a.ctr, sizeof(ExtCounters), hipMemcpyDeviceToHost));
 	ctr = *c->ext_host.as<ExtCounters>();
+	tr.lap("sweeps, culling");
 	// 3. round 2 = a walk of the survivors' kept traces, then the records
 	if (ctr.n_kept > nR) return fail(DMND_E_CAP, "dmnd_extend: more device records than -k allows");
 	if (ctr.n_kept > 0) {
@@ -758,6 +769,7 @@ static int extend_on_device(dmnd_ctx* c, const HostCfg& h, const DevPlan& plan, 
 	if (ctr.n_kept) HIP_TRY(hipMemcpyAsync(hp + h_records, a.records, (size_t)ctr.n_kept * sizeof(dmnd_match), hipMemcpyDeviceToHost, st));
 	HIP_TRY(sync_stream(st));
 	ctr = *reinterpret_cast<const ExtCounters*>(hp + h_ctr);
+	tr.lap("walk, records, copy");
 	if (ctr.tb_status != 0) return fail(ctr.tb_status, ctr.tb_status == DMND_E_TRACEBACK ? "Traceback error." : "transcript slot too small");
 	float ms1 = 0.f, ms2 = 0.f;
 	HIP_TRY(hipEventElapsedTime(&ms1, c->ev0, c->ev1));
@@ -784,6 +796,7 @@ static int extend_on_device(dmnd_ctx* c, const HostCfg& h, const DevPlan& plan, 
 		if (!sorted) std::sort(records.begin() + (ptrdiff_t)b, records.begin() + (ptrdiff_t)e, match_less);
 		b = e;
 	}
+	tr.lap("host e-values, order check");
 	c->ext_stats[0] += (double)ctr.n_items; c->ext_stats[1] += (double)ctr.n_kept;
 	c->ext_stats[2] += (double)ctr.cells1; c->ext_stats[3] += (double)ctr.cells2;
 	c->ext_stats[9] += ms1; c->ext_stats[11] += ms2;
@@ -1492,8 +1505,10 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	g_extend_t0 = t_mark;
 	double fine[16] = { 0 };          // DMND_TRACE=1: finer host timeline on stderr
 	auto lap = [&](int slot, int f = -1) { const double t = now(); c->ext_stats[slot] += t - t_mark; if (f >= 0) fine[f] += t - t_mark; t_mark = t; };
+	TraceLaps trp("dmnd_extend (prelude)");
 	// 1. Hauser bias for every query, resident next to the query block
 	const std::vector<Range> qr = split_by_query(hits, n_hits, h.contexts);
+	trp.lap("queries split");
 	// One launch over the whole query block (bias_kernels.hip: closed-form window per position), result kept in HBM next to
 	// the block for the swipe kernels and the gapped filter, and copied into a pinned host buffer for the host's x-drop stage.
 	const int8_t* cbs = nullptr;
@@ -1533,6 +1548,7 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 			cbs = c->pinned_cbs;
 		}
 	}
+	trp.lap("bias");
 	// 1a. x-drop ungapped extension of every seed hit on the device (xdrop_seg_kernel), behind the bias kernel on the same stream;
 	// the host's chaining stage picks the segments up instead of walking the letters itself (DMND_EXTEND_XDROP_GPU=0: host walks)
 	const XdropSeg* xd = nullptr;
@@ -1540,7 +1556,6 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 		HIP_TRY(hipSetDevice(c->device));
 		if (int rc = c->xd_hits.ensure((size_t)n_hits * sizeof(dmnd_seed_hit))) return rc;
 		if (int rc = c->xd_out.ensure((size_t)n_hits * sizeof(XdropSeg))) return rc;
-		if (int rc = c->xd_host.ensure((size_t)n_hits * sizeof(XdropSeg))) return rc;
 		HIP_TRY(hipMemcpyAsync(c->xd_hits.p, hits, (size_t)n_hits * sizeof(dmnd_seed_hit), hipMemcpyHostToDevice, c->stream));
 		XdropArgs xa;
 		xa.qblock = c->block[DMND_QUERY].as<int8_t>(); xa.tblock = c->block[DMND_TARGET].as<int8_t>();
@@ -1549,7 +1564,7 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 		xa.hits = c->xd_hits.as<dmnd_seed_hit>(); xa.n_hits = n_hits; xa.xdrop = h.xdrop; xa.out = c->xd_out.as<XdropSeg>();
 		HIP_TRY(launch_xdrop_segs(xa, c->stream));
 		bias_pending = true;                                // the same wait covers it
-		xd = c->xd_host.as<XdropSeg>();                     // (copied back below, once it is known whether the host needs it)
+		xd = reinterpret_cast<const XdropSeg*>(1);          // (set below, once it is known whether the host needs the copy)
 	}
 	lap(4, 1);
 	// The groups, segments, chains and bands of every (query, target) pair on the device (plan_kernels.hip; one query context, banded
@@ -1567,10 +1582,12 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 		if (int rc = dmnd_gapped_filter_on(c, hits, try_plan ? c->xd_hits.as<dmnd_seed_hit>() : nullptr, n_hits, h.use_cbs ? 1 : 0, try_plan ? nullptr : gf.data(), nullptr)) return rc;
 	}
 	lap(4, 2);
+	trp.lap("x-drop enqueued, gapped filter");
 	DevPlan plan;
 	bool planned = false;
 	if (try_plan) {
 		if (int rc = plan_on_device(c, h, n_hits, gf_on, plan, planned)) return rc;
+		trp.lap("planned");
 		if (planned && plan.n_queries != qr.size()) planned = false;
 		if (!planned && gf_on) {                            // hits out of order (a caller's own list): the host plans, and needs the flags
 			gf.resize((size_t)n_hits);
@@ -1579,9 +1596,11 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 		bias_pending = false;                               // plan_on_device has waited for the stream
 	}
 	if (xd && (!planned || plan.n_on_host > 0)) {
+		if (int rc = c->xd_host.ensure((size_t)n_hits * sizeof(XdropSeg))) return rc;      // (page-locked: allocated when first needed)
 		HIP_TRY(hipMemcpyAsync(c->xd_host.p, c->xd_out.p, (size_t)n_hits * sizeof(XdropSeg), hipMemcpyDeviceToHost, c->stream));
 		bias_pending = true;
 	}
+	if (xd) xd = c->xd_host.as<XdropSeg>();              // (NULL while no group was left to the host: nothing reads it then)
 	const DevPlan* dp = planned ? &plan : nullptr;
 	// The queries whose targets fit one ranking chunk are extended in HBM from here on (extend_kernels.hip): the default search of a
 	// protein query block -- one HSP per target, -k culling by e-value, Hauser bias or none, no --id / cover filters, no transcripts
@@ -2088,6 +2107,25 @@ extern "C" int dmnd_extend_stats(const dmnd_ctx* c, double out[12])
 {
 	if (!c || !out) return fail(DMND_E_ARG, "dmnd_extend_stats: NULL argument");
 	for (int i = 0; i < 12; ++i) out[i] = c->ext_stats[i];
+	return DMND_OK;
+}
+
+// First-call allocations of dmnd_extend made ahead of it (a driver calls this beside its upload / masking phase): the device work
+// arrays of the x-drop stage, the planner and the device half for about n_hits_hint seed hits, and the page-locked result buffer.
+// A hint that turns out too small only means the call itself grows the buffers, as it would have without this.
+extern "C" int dmnd_extend_reserve(dmnd_ctx* c, int64_t n_hits_hint)
+{
+	if (!c || n_hits_hint < 0) return fail(DMND_E_ARG, "dmnd_extend_reserve: bad argument");
+	if (n_hits_hint == 0) return DMND_OK;
+	HIP_TRY(hipSetDevice(c->device));
+	const size_t n = (size_t)n_hits_hint, nq = c->limits[DMND_QUERY].size() > 1 ? c->limits[DMND_QUERY].size() - 1 : n;
+	const size_t n_rec = std::min(n, nq * (size_t)std::max(c->max_target_seqs, 1));
+	if (int rc = c->xd_hits.ensure(n * sizeof(dmnd_seed_hit))) return rc;
+	if (int rc = c->xd_out.ensure(n * sizeof(XdropSeg))) return rc;
+	if (int rc = c->plan_dev.ensure(n * 112 + 8192)) return rc;            // (the planner's arrays: ~100 bytes per hit, plan_on_device)
+	if (int rc = c->plan_host.ensure(sizeof(PlanCounters))) return rc;
+	if (int rc = c->ext_dev.ensure(n * 440 + nq + n_rec * sizeof(dmnd_match) + 16384)) return rc;      // (~420 bytes per band, extend_on_device)
+	if (int rc = c->ext_host.ensure(sizeof(ExtCounters) + nq + n_rec * sizeof(dmnd_match) + 256)) return rc;
 	return DMND_OK;
 }
 

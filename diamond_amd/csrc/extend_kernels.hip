@@ -281,14 +281,16 @@ __global__ __launch_bounds__(64) void ext_records_kernel(ExtArgs a)
 		for (uint32_t gj = 0; gj < ng; ++gj) rank += sel[gj].valid && gj != gi && sel_less(sel[gj], me) ? 1u : 0u;
 		const uint32_t g = g0 + gi, item = a.cand_item[g];
 		const dmnd_dp_target d = a.items[item];
-		dmnd_match m;
+		dmnd_match& m = a.records[first + rank];             // (field by field into HBM: a local record would live in scratch memory)
 		m.query = query; m.target = me.target;
 		m.ungapped_score = (int32_t)a.groups[g].score; m.d_begin = d.d_begin; m.d_end = d.d_end;
 		m.frame = 0; m.read_begin = 0; m.read_end = 0;
 		m.evalue = me.ev; m.bit_score = 0.0;                  // the host writes its own e-value and the bit score
-		m.hsp = a.hsps[item];
+		const dmnd_hsp hsp = a.hsps[item];
+		m.hsp.score = hsp.score; m.hsp.q_begin = hsp.q_begin; m.hsp.q_end = hsp.q_end; m.hsp.s_begin = hsp.s_begin; m.hsp.s_end = hsp.s_end;
+		m.hsp.length = hsp.length; m.hsp.identities = hsp.identities; m.hsp.mismatches = hsp.mismatches; m.hsp.positives = hsp.positives;
+		m.hsp.gap_openings = hsp.gap_openings; m.hsp.gaps = hsp.gaps; m.hsp.transcript_len = hsp.transcript_len;
 		m.hsp.transcript_off = -1;
-		a.records[first + rank] = m;
 	}
 }
 

@@ -31,7 +31,7 @@ struct PlanGroup {             // the seed hits of one (query, target) pair = Se
 };
 struct PlanBand { int32_t d_begin, d_end; };
 struct PlanQuery { uint32_t query, group_begin, hit_begin; };      // one per query that has hits, in hit order; one sentinel entry behind the last
-struct PlanCounters { uint32_t n_groups, n_queries, n_bands, unsorted, n_on_host, pad[3]; };
+struct PlanCounters { uint32_t n_groups, n_queries, n_bands, unsorted, n_on_host, n_chain, pad[2]; };      // n_chain: groups with more than one segment (plan_chain_list_kernel)
 
 struct PlanArgs {
 	const int8_t* qblock; const int8_t* tblock;
@@ -50,6 +50,7 @@ struct PlanArgs {
 	PlanQuery* queries;
 	int32_t* segs;                 // 4 ints per hit slot: the sorted segments of a multi-segment group, from its first hit slot on
 	PlanBand* band_slots;          // bands of a group, from its first hit slot on
+	uint32_t* chain_list;          // the groups that need chaining (at most one per two hits)
 	uint32_t* band_count;          // per group, then its exclusive scan in band_off
 	uint32_t* band_off;
 	PlanBand* bands;               // dense

@@ -95,8 +95,18 @@ __device__ inline void merge_bands(const CV& chains, int n_chains, int base_band
 	if (d0 != INT_MAX) out.emit(d0, d1);
 }
 
+// per-lane arrays of plan_segments_kernel, in LDS (entry [x][lane]: a lane's accesses never conflict with its neighbours'). In
+// private memory they were 528 bytes of scratch per lane behind 240 registers -- and the first kernel of a process that needs
+// scratch makes the runtime set the scratch arena of its queue up, milliseconds on the first dmnd_extend of a run.
+// The segments take the hits' places: segment ns is written when hit x >= ns has been read, (i, j, source) -> (i, j, length), + score.
+struct SegLds {
+	int hi[PLAN_MAX_HITS][64], hj[PLAN_MAX_HITS][64], hs[PLAN_MAX_HITS][64], ss[PLAN_MAX_HITS][64];
+};
+
 __global__ __launch_bounds__(64) void plan_segments_kernel(PlanArgs a)
 {
+	__shared__ SegLds L;
+	const int lane = threadIdx.x;
 	const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
 	if (g >= a.counters->n_groups) return;
 	PlanGroup grp = a.groups[g];
@@ -115,25 +125,27 @@ __global__ __launch_bounds__(64) void plan_segments_kernel(PlanArgs a)
 	const uint32_t query = a.hits[b].query;
 	const int qlen = (int)(a.qlimits[query + 1] - a.qlimits[query] - 1);
 	// the group's hits sorted by (diagonal, j) -- they arrive sorted by (j, i)
-	int hi[PLAN_MAX_HITS], hj[PLAN_MAX_HITS], hs[PLAN_MAX_HITS];
 	for (uint32_t x = 0; x < n; ++x) {
 		const dmnd_seed_hit h = a.hits[b + x];
 		const int i = h.seed_offset, j = (int)(h.subject - t0), d = i - j;
 		int p = (int)x;
-		while (p > 0 && (hi[p - 1] - hj[p - 1] > d || (hi[p - 1] - hj[p - 1] == d && hj[p - 1] > j))) { hi[p] = hi[p - 1]; hj[p] = hj[p - 1]; hs[p] = hs[p - 1]; --p; }
-		hi[p] = i; hj[p] = j; hs[p] = (int)(b + x);
+		while (p > 0 && (L.hi[p - 1][lane] - L.hj[p - 1][lane] > d || (L.hi[p - 1][lane] - L.hj[p - 1][lane] == d && L.hj[p - 1][lane] > j))) {
+			L.hi[p][lane] = L.hi[p - 1][lane]; L.hj[p][lane] = L.hj[p - 1][lane]; L.hs[p][lane] = L.hs[p - 1][lane]; --p;
+		}
+		L.hi[p][lane] = i; L.hj[p][lane] = j; L.hs[p][lane] = (int)(b + x);
 	}
 	// a hit inside the last kept segment of its diagonal is skipped; segments need a positive score (ungapped.cpp:96-113)
-	Seg sg[PLAN_MAX_HITS];
 	int ns = 0;
 	for (uint32_t x = 0; x < n; ++x) {
-		if (ns > 0 && sg[ns - 1].diag() == hi[x] - hj[x] && sg[ns - 1].j_end() >= hj[x]) continue;
-		const XdropSeg xs = a.xd[hs[x]];
-		if (xs.score > 0) sg[ns++] = Seg{ hi[x] - xs.left, hj[x] - xs.left, xs.left + xs.right, xs.score };
+		const int i = L.hi[x][lane], j = L.hj[x][lane];
+		if (ns > 0 && L.hi[ns - 1][lane] - L.hj[ns - 1][lane] == i - j && L.hj[ns - 1][lane] + L.hs[ns - 1][lane] >= j) continue;
+		const XdropSeg xs = a.xd[L.hs[x][lane]];
+		if (xs.score > 0) { L.hi[ns][lane] = i - xs.left; L.hj[ns][lane] = j - xs.left; L.hs[ns][lane] = xs.left + xs.right; L.ss[ns][lane] = xs.score; ++ns; }
 	}
 	if (ns == 0) { a.groups[g] = grp; return; }
 	if (ns == 1) {
-		const Chain c{ sg[0].diag(), sg[0].diag(), sg[0].score, 0, 0, 0, 0 };
+		const int d = L.hi[0][lane] - L.hj[0][lane];
+		const Chain c{ d, d, L.ss[0][lane], 0, 0, 0, 0 };
 		BandOut out{ a.band_slots + b, (int)n, 0, false };
 		merge_bands(&c, 1, band_for_dev(qlen, a.band_fast != 0), qlen, tlen, out);
 		grp.n_bands = (uint8_t)out.n;
@@ -143,13 +155,15 @@ __global__ __launch_bounds__(64) void plan_segments_kernel(PlanArgs a)
 	if (ns > PLAN_MAX_SEGS) { grp.n_bands = PLAN_ON_HOST; a.groups[g] = grp; return; }
 	// stable by (diagonal, segment start): the x-drop walk to the left may carry a later hit's segment in front of an earlier one's
 	for (int x = 1; x < ns; ++x) {
-		const Seg v = sg[x];
+		const int vi = L.hi[x][lane], vj = L.hj[x][lane], vl = L.hs[x][lane], vs = L.ss[x][lane];
 		int p = x;
-		while (p > 0 && (sg[p - 1].diag() > v.diag() || (sg[p - 1].diag() == v.diag() && sg[p - 1].j > v.j))) { sg[p] = sg[p - 1]; --p; }
-		sg[p] = v;
+		while (p > 0 && (L.hi[p - 1][lane] - L.hj[p - 1][lane] > vi - vj || (L.hi[p - 1][lane] - L.hj[p - 1][lane] == vi - vj && L.hj[p - 1][lane] > vj))) {
+			L.hi[p][lane] = L.hi[p - 1][lane]; L.hj[p][lane] = L.hj[p - 1][lane]; L.hs[p][lane] = L.hs[p - 1][lane]; L.ss[p][lane] = L.ss[p - 1][lane]; --p;
+		}
+		L.hi[p][lane] = vi; L.hj[p][lane] = vj; L.hs[p][lane] = vl; L.ss[p][lane] = vs;
 	}
 	int32_t* dst = a.segs + 4 * (size_t)b;
-	for (int x = 0; x < ns; ++x) { dst[4 * x] = sg[x].i; dst[4 * x + 1] = sg[x].j; dst[4 * x + 2] = sg[x].len; dst[4 * x + 3] = sg[x].score; }
+	for (int x = 0; x < ns; ++x) { dst[4 * x] = L.hi[x][lane]; dst[4 * x + 1] = L.hj[x][lane]; dst[4 * x + 2] = L.hs[x][lane]; dst[4 * x + 3] = L.ss[x][lane]; }
 	grp.n_bands = PLAN_NEED_CHAIN;
 	grp.band_begin = (uint32_t)ns;
 	a.groups[g] = grp;
@@ -157,16 +171,43 @@ __global__ __launch_bounds__(64) void plan_segments_kernel(PlanArgs a)
 
 typedef ChainWorkspaceT<FixedChainPolicy, PLAN_MAX_SEGS, 96, 16> DevChain;
 
+// Everything a lane's chaining works on, in LDS: in private memory this was 6 KB of scratch per lane (one lane per group, 64 groups a
+// wavefront, most of them with nothing to chain). Now plan_chain_list_kernel lists the groups that need chaining and
+// plan_chain_kernel takes PLAN_CHAIN_LANES of them per workgroup.
+enum { PLAN_CHAIN_LANES = 8 };
+struct ChainLds {
+	DevChain ws;
+	Seg sg[PLAN_MAX_SEGS];
+	FixedVec<Chain, 16> chains;
+};
+
+__global__ __launch_bounds__(256) void plan_chain_list_kernel(PlanArgs a)
+{
+	const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+	const bool need = g < a.counters->n_groups && a.groups[g].n_bands == PLAN_NEED_CHAIN;
+	// one atomic per wavefront that has any
+	const unsigned long long m = __ballot(need);
+	if (m == 0) return;
+	const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+	uint32_t base = 0;
+	if (lane == leader) base = atomicAdd(&a.counters->n_chain, (uint32_t)__popcll(m));
+	base = __shfl(base, leader);
+	if (need) a.chain_list[base + (uint32_t)__popcll(m & (((unsigned long long)1 << lane) - 1))] = g;
+}
+
 __global__ __launch_bounds__(64) void plan_chain_kernel(PlanArgs a)
 {
 	__shared__ ScoreTable S;
+	__shared__ __align__(16) char raw[PLAN_CHAIN_LANES * sizeof(ChainLds)];
 	for (int x = threadIdx.x; x < 32 * 32; x += blockDim.x) S.m[x] = a.matrix[x];
 	if (threadIdx.x == 0) { S.gap_open = a.gap_open; S.gap_extend = a.gap_extend; }
 	__syncthreads();
-	const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-	if (g >= a.counters->n_groups) return;
+	if (threadIdx.x >= PLAN_CHAIN_LANES) return;
+	const uint32_t k = blockIdx.x * PLAN_CHAIN_LANES + threadIdx.x;
+	if (k >= a.counters->n_chain) return;
+	const uint32_t g = a.chain_list[k];
+	ChainLds& L = *reinterpret_cast<ChainLds*>(raw + threadIdx.x * sizeof(ChainLds));
 	PlanGroup grp = a.groups[g];
-	if (grp.n_bands != PLAN_NEED_CHAIN) return;
 	const int ns = (int)grp.band_begin;
 	const uint32_t b = grp.hit_begin;
 	const int64_t t0 = a.tlimits[grp.target];
@@ -174,17 +215,16 @@ __global__ __launch_bounds__(64) void plan_chain_kernel(PlanArgs a)
 	const uint32_t query = a.hits[b].query;
 	const int64_t q0 = a.qlimits[query];
 	const int qlen = (int)(a.qlimits[query + 1] - q0 - 1);
-	Seg sg[PLAN_MAX_SEGS];
 	const int32_t* src = a.segs + 4 * (size_t)b;
-	for (int x = 0; x < ns; ++x) sg[x] = Seg{ src[4 * x], src[4 * x + 1], src[4 * x + 2], src[4 * x + 3] };
-	DevChain ws;
-	FixedVec<Chain, 16> chains;
-	ws.run_segs(S, SeqRef{ a.qblock + q0, qlen }, SeqRef{ a.tblock + t0, tlen }, sg, (size_t)ns, chains);
+	for (int x = 0; x < ns; ++x) L.sg[x] = Seg{ src[4 * x], src[4 * x + 1], src[4 * x + 2], src[4 * x + 3] };
+	L.ws.reset_fixed();
+	L.chains.reset();
+	L.ws.run_segs(S, SeqRef{ a.qblock + q0, qlen }, SeqRef{ a.tblock + t0, tlen }, L.sg, (size_t)ns, L.chains);
 	grp.band_begin = 0;
-	if (ws.overflowed() || chains.overflow) { grp.n_bands = PLAN_ON_HOST; a.groups[g] = grp; return; }
-	insertion_sort(chains.begin(), chains.end(), [](const Chain& x, const Chain& y) { return x.d_min < y.d_min; });      // std::stable_sort by d_min
+	if (L.ws.overflowed() || L.chains.overflow) { grp.n_bands = PLAN_ON_HOST; a.groups[g] = grp; return; }
+	insertion_sort(L.chains.begin(), L.chains.end(), [](const Chain& x, const Chain& y) { return x.d_min < y.d_min; });      // std::stable_sort by d_min
 	BandOut out{ a.band_slots + b, (int)grp.n_hits, 0, false };
-	merge_bands(chains, (int)chains.size(), band_for_dev(qlen, a.band_fast != 0), qlen, tlen, out);
+	merge_bands(L.chains, (int)L.chains.size(), band_for_dev(qlen, a.band_fast != 0), qlen, tlen, out);
 	grp.n_bands = out.overflow || out.n >= PLAN_NEED_CHAIN ? (uint8_t)PLAN_ON_HOST : (uint8_t)out.n;
 	a.groups[g] = grp;
 }
@@ -247,7 +287,10 @@ hipError_t launch_plan(const PlanArgs& a, hipStream_t st)
 	hipLaunchKernelGGL(plan_fill_kernel, dim3(b256), dim3(256), 0, st, a);
 	// groups <= hits: the per-group kernels are launched over the hit count and return beyond the group count (read on the device)
 	hipLaunchKernelGGL(plan_segments_kernel, dim3(b64), dim3(64), 0, st, a);
-	hipLaunchKernelGGL(plan_chain_kernel, dim3(b64), dim3(64), 0, st, a);
+	// (the chaining kernel is launched over the upper bound of one group per two hits -- a group that needs chaining has at least two
+	// -- and reads the count of the list on the device)
+	hipLaunchKernelGGL(plan_chain_list_kernel, dim3(b256), dim3(256), 0, st, a);
+	hipLaunchKernelGGL(plan_chain_kernel, dim3((unsigned)((n / 2 + PLAN_CHAIN_LANES) / PLAN_CHAIN_LANES)), dim3(64), 0, st, a);
 	hipLaunchKernelGGL(plan_count_kernel, dim3(b256g), dim3(256), 0, st, a);
 	// (the scan runs over n + 1 entries whatever the group count: entries beyond it are never read)
 	e = rocprim::exclusive_scan(*a.scan_tmp, need2, a.band_count, a.band_off, 0u, n + 1, rocprim::plus<uint32_t>(), st);

@@ -597,6 +597,10 @@ int dmnd_extend_plan_stats(const dmnd_ctx* ctx, double out[3]);
  * [3] records; all 0 = every query took the host path (other modes: --max-hsps != 1, --top, filters, matrix adjustment, --ext full,
  * transcripts wanted, translated queries). */
 int dmnd_extend_device_stats(const dmnd_ctx* ctx, double out[4]);
+/* Optional: the first-call allocations of dmnd_extend made ahead of it, for about n_hits_hint seed hits (device work arrays of the
+ * x-drop stage, planner and device half; the page-locked result buffer). A driver calls it beside its upload / masking phase, as
+ * dmnd_seed_reserve; a hint that is too small costs nothing but the growth inside the call. The query block must be uploaded. */
+int dmnd_extend_reserve(dmnd_ctx* ctx, int64_t n_hits_hint);
 /* BLAST tabular (-f 6 default fields) line of one match, as the reference prints it; returns the length written. */
 int dmnd_format_tab(const dmnd_match* m, const char* qseqid, const char* sseqid, char* buf, int64_t cap);
 
