@@ -330,6 +330,7 @@ extern "C" void dmnd_destroy(dmnd_ctx* c)
 	c->xd_hits.release(); c->xd_out.release(); c->xd_host.release();
 	c->plan_dev.release(); c->plan_host.release();
 	c->ext_dev.release(); c->ext_trace.release(); c->ext_host.release();
+	for (DevBuf& b : c->ext_trace_more) b.release();
 	if (c->plan_tmp) { (void)hipFree(c->plan_tmp); c->plan_tmp = nullptr; c->plan_tmp_bytes = 0; }
 	for (int i = 0; i < 2; ++i) { c->up_stage[i].release(); if (c->up_ev[i]) (void)hipEventDestroy(c->up_ev[i]); c->up_ev[i] = nullptr; }
 	for (int i = 0; i < 2; ++i) { c->t_stage[i].release(); if (c->t_ev[i]) (void)hipEventDestroy(c->t_ev[i]); c->t_ev[i] = nullptr; }
@@ -975,7 +976,7 @@ int swipe_impl(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, int64_t
 
 }  // namespace
 
-// The traceback-mode sweeps of items that were prepared ON THE DEVICE (extend_kernels.hip): the launch order, trace offsets and
+// The sweeps (traceback mode, or scores only with trace_dev == NULL) of items that were prepared ON THE DEVICE (extend_kernels.hip): the launch order, trace offsets and
 // item pairs are in HBM already, the host only knows how many items every band class has (class c: P = 1 << c) and the longest
 // one's step count. One launch per class, as plan_sweeps / issue_sweeps do for a host-prepared list; pairs of class c start at
 // pair sum((count + 1) / 2) of the classes before it.
@@ -993,18 +994,18 @@ int dmnd_sweep_classes(dmnd_ctx* work, const dmnd_ctx* c, const dmnd_dp_target* 
 		if (k16) {
 			Swipe16Args a;
 			a.qblock = c->block[DMND_QUERY].as<int8_t>(); a.tblock = c->block[DMND_TARGET].as<int8_t>(); a.cbs = cbs; a.matrix = c->matrix.as<int8_t>();
-			a.items = d_items; a.pairs = pairs_dev + 2 * pair0; a.trace_off = off_item_dev; a.trace = trace_dev; a.ends = ends_dev;
+			a.items = d_items; a.pairs = pairs_dev + 2 * pair0; a.trace_off = trace_dev ? off_item_dev : nullptr; a.trace = trace_dev; a.ends = ends_dev;
 			a.n_pairs = (count + 1) / 2;
 			a.gap_open = c->params.gap_open; a.gap_extend = c->params.gap_extend;
-			HIP_TRY(launch_banded_swipe16(P, true, a, work->stream));
+			HIP_TRY(launch_banded_swipe16(P, trace_dev != nullptr, a, work->stream));
 		}
 		else {
 			SwipeArgs a;
 			a.qblock = c->block[DMND_QUERY].as<int8_t>(); a.tblock = c->block[DMND_TARGET].as<int8_t>(); a.cbs = cbs; a.matrix = c->matrix.as<int8_t>(); a.matrices = nullptr;
-			a.items = d_items; a.order = order_dev + s0; a.trace_off = off_slot_dev + s0; a.trace = trace_dev; a.ends = ends_dev;
+			a.items = d_items; a.order = order_dev + s0; a.trace_off = trace_dev ? off_slot_dev + s0 : nullptr; a.trace = trace_dev; a.ends = ends_dev;
 			a.n = count;
 			a.gap_open = c->params.gap_open; a.gap_extend = c->params.gap_extend;
-			HIP_TRY(launch_banded_swipe(P, K_TRACE, a, work->stream));
+			HIP_TRY(launch_banded_swipe(P, trace_dev ? K_TRACE : K_SCORE, a, work->stream));
 		}
 		s0 += count; pair0 += (count + 1) / 2;
 	}

@@ -681,6 +681,8 @@ static int plan_fetch_lists(dmnd_ctx* c, DevPlan& plan)
 	return DMND_OK;
 }
 
+static bool keep_traces_dev() { static const bool v = [] { const char* e = std::getenv("DMND_EXTEND_KEEP_TRACE"); return !e || e[0] != '0'; }(); return v; }
+
 // The extension of the queries whose targets fit one ranking chunk, in HBM from the planner's bands to the match records
 // (extend_kernels.h). records: those queries' matches in output order (query ascending; e-value, score, target inside a query) with
 // the HOST's e-value and bit score; qstate[k] (k = index into plan.queries): EXT_Q_DEVICE = done here, anything else = the host path
@@ -692,15 +694,18 @@ static int extend_on_device(dmnd_ctx* c, const HostCfg& h, const DevPlan& plan, 
 	TraceLaps tr("dmnd_extend (device half)");
 	const int64_t chunk = ranking_chunk_size(h.ref_letters, h.max_target_seqs, h.ranking_block_letters, false);
 	if (chunk > EXT_MAX_CHUNK || plan.n_bands == 0) return DMND_OK;
+	if (((size_t)h.max_target_seqs + 2 * (size_t)chunk) * 24 > ((size_t)60 << 10)) return DMND_OK;      // (the LDS lists of ext_append_kernel)
 	const size_t nG = plan.n_groups, nQ = plan.n_queries, nB = plan.n_bands, nR = std::min(nG, nQ * (size_t)std::max(h.max_target_seqs, 1));
+	const size_t nI = nB + nR;                            // items: every band once + a copy of every survivor (round 2 without kept traces)
 	size_t at = 0;
 	auto take = [&](size_t bytes) { const size_t o = at; at = (at + bytes + 63) & ~(size_t)63; return o; };
-	const size_t o_gq = take(nG * 4), o_qstate = take(nQ), o_cnt = take((nG + 1) * 4), o_item_off = take((nG + 1) * 4), o_items = take(nB * sizeof(dmnd_dp_target)),
-		o_item_group = take(nB * 4), o_keys = take(nB * 4), o_keys_sorted = take(nB * 4), o_idx = take(nB * 4), o_order = take(nB * 4),
-		o_rows = take(nB * 8), o_rows_slot = take((nB + 1) * 8), o_off_slot = take((nB + 1) * 8), o_off_item = take(nB * 8), o_p = take(nB * 4),
-		o_pairs = take((nB + 2 * EXT_CLASSES) * 4), o_ends = take(nB * sizeof(SwipeEnd)), o_kept = take((nG + 1) * 4), o_kept_pos = take((nG + 1) * 4),
-		o_cand_item = take(nG * 4), o_cand_ev = take(nG * 8), o_r2_order = take(nB * 4), o_r2_p = take(nB * 4), o_r2_off = take(nB * 8), o_r2_tr = take((nB + 1) * 8),
-		o_hsps = take(nB * sizeof(dmnd_hsp)), o_records = take(nR * sizeof(dmnd_match)), o_ctr = take(sizeof(ExtCounters));
+	const size_t o_qstate = take(nQ), o_qactive = take(nQ), o_qi0 = take(nQ * 4), o_qi1 = take(nQ * 4), o_qtail = take(nQ * 4), o_qprev = take(nQ * 4),
+		o_okeys = take(nG * 8), o_okeys2 = take(nG * 8), o_oidx = take(nG * 4), o_gorder = take(nG * 4), o_aligned = take(nG), o_gfirst = take(nG * 4), o_gcnt = take(nG * 4),
+		o_cnt = take((nG + 1) * 4), o_item_off = take((nG + 1) * 4), o_kept = take((nG + 1) * 4), o_kept_pos = take((nG + 1) * 4), o_cand_item = take(nG * 4), o_cand_ev = take(nG * 8),
+		o_items = take(nI * sizeof(dmnd_dp_target)), o_off_item = take(nI * 8), o_p = take(nI * 4), o_ends = take(nI * sizeof(SwipeEnd)), o_hsps = take(nI * sizeof(dmnd_hsp)),
+		o_keys = take(nI * 4), o_keys_sorted = take(nI * 4), o_idx = take(nI * 4), o_order = take(nI * 4), o_rows = take(nI * 8), o_rows_slot = take((nI + 1) * 8), o_off_slot = take((nI + 1) * 8),
+		o_pairs = take((nI + 2 * EXT_CLASSES) * 4), o_r2_order = take(nR * 4), o_r2_p = take(nR * 4), o_r2_off = take(nR * 8), o_r2_tr = take((nR + 1) * 8), o_r2_group = take(nR * 4),
+		o_records = take(nR * sizeof(dmnd_match)), o_ctr = take(sizeof(ExtCounters));
 	if (int rc = c->ext_dev.ensure(at)) return rc;
 	tr.lap("work arrays");
 	char* d = c->ext_dev.as<char>();
@@ -710,45 +715,110 @@ static int extend_on_device(dmnd_ctx* c, const HostCfg& h, const DevPlan& plan, 
 	a.hits = plan.dev.hits; a.qlimits = plan.dev.qlimits; a.tlimits = plan.dev.tlimits;
 	a.use_cbs = h.use_cbs ? 1 : 0; a.chunk_size = (uint32_t)chunk; a.k = h.max_target_seqs; a.max_swipe_dp = h.max_swipe_dp;
 	const Evaluer& E = c->evaluer;
-	a.ev = ExtEvalue{ E.lambda, E.K, E.db_letters, E.a, E.b, E.alpha, E.beta, E.sigma, E.tau, E.v_thr, E.c_thr, h.max_evalue };
-	a.gq = reinterpret_cast<uint32_t*>(d + o_gq); a.qstate = reinterpret_cast<uint8_t*>(d + o_qstate);
+	a.ev = ExtEvalue{ E.lambda, E.K, E.ln_k, E.db_letters, E.a, E.b, E.alpha, E.beta, E.sigma, E.tau, E.v_thr, E.c_thr, h.max_evalue };
+	a.qstate = reinterpret_cast<uint8_t*>(d + o_qstate); a.q_active = reinterpret_cast<uint8_t*>(d + o_qactive);
+	a.q_i0 = reinterpret_cast<uint32_t*>(d + o_qi0); a.q_i1 = reinterpret_cast<uint32_t*>(d + o_qi1);
+	a.q_tail = reinterpret_cast<int32_t*>(d + o_qtail); a.q_prev = reinterpret_cast<int32_t*>(d + o_qprev);
+	a.okeys = reinterpret_cast<uint64_t*>(d + o_okeys); a.okeys_sorted = reinterpret_cast<uint64_t*>(d + o_okeys2);
+	a.oidx = reinterpret_cast<uint32_t*>(d + o_oidx); a.gorder = reinterpret_cast<uint32_t*>(d + o_gorder);
+	a.aligned = reinterpret_cast<uint8_t*>(d + o_aligned); a.g_first = reinterpret_cast<uint32_t*>(d + o_gfirst); a.g_cnt = reinterpret_cast<uint32_t*>(d + o_gcnt);
 	a.cnt = reinterpret_cast<uint32_t*>(d + o_cnt); a.item_off = reinterpret_cast<uint32_t*>(d + o_item_off);
-	a.items = reinterpret_cast<dmnd_dp_target*>(d + o_items); a.item_group = reinterpret_cast<uint32_t*>(d + o_item_group);
-	a.keys = reinterpret_cast<uint32_t*>(d + o_keys); a.keys_sorted = reinterpret_cast<uint32_t*>(d + o_keys_sorted);
-	a.idx = reinterpret_cast<uint32_t*>(d + o_idx); a.order = reinterpret_cast<uint32_t*>(d + o_order);
-	a.rows = reinterpret_cast<int64_t*>(d + o_rows); a.rows_slot = reinterpret_cast<int64_t*>(d + o_rows_slot);
-	a.off_slot = reinterpret_cast<int64_t*>(d + o_off_slot); a.off_item = reinterpret_cast<int64_t*>(d + o_off_item);
-	a.p_of_item = reinterpret_cast<int32_t*>(d + o_p); a.pairs = reinterpret_cast<int32_t*>(d + o_pairs);
-	a.ends = reinterpret_cast<SwipeEnd*>(d + o_ends);
 	a.kept = reinterpret_cast<uint32_t*>(d + o_kept); a.kept_pos = reinterpret_cast<uint32_t*>(d + o_kept_pos);
 	a.cand_item = reinterpret_cast<uint32_t*>(d + o_cand_item); a.cand_ev = reinterpret_cast<double*>(d + o_cand_ev);
+	a.item_base = 0; a.item_cap = (uint32_t)nI;
+	a.items = reinterpret_cast<dmnd_dp_target*>(d + o_items); a.off_item = reinterpret_cast<int64_t*>(d + o_off_item);
+	a.p_of_item = reinterpret_cast<int32_t*>(d + o_p); a.ends = reinterpret_cast<SwipeEnd*>(d + o_ends); a.hsps = reinterpret_cast<dmnd_hsp*>(d + o_hsps);
+	a.keys = reinterpret_cast<uint32_t*>(d + o_keys); a.keys_sorted = reinterpret_cast<uint32_t*>(d + o_keys_sorted);
+	a.idx = reinterpret_cast<uint32_t*>(d + o_idx); a.order = reinterpret_cast<uint32_t*>(d + o_order);
+	a.rows = reinterpret_cast<int64_t*>(d + o_rows); a.rows_slot = reinterpret_cast<int64_t*>(d + o_rows_slot); a.off_slot = reinterpret_cast<int64_t*>(d + o_off_slot);
+	a.pairs = reinterpret_cast<int32_t*>(d + o_pairs);
 	a.r2_order = reinterpret_cast<int32_t*>(d + o_r2_order); a.r2_p = reinterpret_cast<int32_t*>(d + o_r2_p);
-	a.r2_off = reinterpret_cast<int64_t*>(d + o_r2_off); a.r2_tr = reinterpret_cast<int64_t*>(d + o_r2_tr);
-	a.hsps = reinterpret_cast<dmnd_hsp*>(d + o_hsps); a.records = reinterpret_cast<dmnd_match*>(d + o_records);
+	a.r2_off = reinterpret_cast<int64_t*>(d + o_r2_off); a.r2_tr = reinterpret_cast<int64_t*>(d + o_r2_tr); a.r2_group = reinterpret_cast<uint32_t*>(d + o_r2_group);
+	a.records = reinterpret_cast<dmnd_match*>(d + o_records);
 	a.ctr = reinterpret_cast<ExtCounters*>(d + o_ctr);
 	a.scan_tmp = &c->plan_tmp; a.scan_tmp_bytes = &c->plan_tmp_bytes;
 	hipStream_t st = c->stream;
-	// 1. items, launch order, trace offsets, pairs
-	HIP_TRY(launch_ext_prepare(a, st));
 	if (int rc = c->ext_host.ensure(sizeof(ExtCounters))) return rc;
-	HIP_TRY(copy_now(st, c->ext_host.p, a.ctr, sizeof(ExtCounters), hipMemcpyDeviceToHost));
-	ExtCounters ctr = *c->ext_host.as<ExtCounters>();
-	tr.lap("items, launch order, trace offsets");
-	if (ctr.n_items == 0) return DMND_OK;
-	if ((size_t)ctr.total_rows > c->trace_arena_max) return DMND_OK;
-	if (int rc = c->ext_trace.ensure((size_t)ctr.total_rows + 64)) return rc;
-	tr.lap("trace arena");
-	// 2. round 1 in traceback mode (one launch per band class), then best HSP per target, culling, the round-2 list
-	HIP_TRY(hipEventRecord(c->ev0, st));
-	if (int rc = dmnd_sweep_classes(c, c, a.items, ctr.class_count, ctr.class_max_steps, EXT_CLASSES, reinterpret_cast<const int32_t*>(a.order), a.off_slot, a.pairs, a.off_item,
-		c->ext_trace.as<uint8_t>(), a.ends)) return rc;
-	HIP_TRY(hipEventRecord(c->ev1, st));
-	HIP_TRY(launch_ext_select(a, st));
-	HIP_TRY(copy_now(st, c->ext_host.p, a.ctr, sizeof(ExtCounters), hipMemcpyDeviceToHost));
-	ctr = *c->ext_host.as<ExtCounters>();
+	// Round 1 sweeps in traceback mode and keeps the trace rows (round 2 then only walks them) while the iterations' rows fit the
+	// context's trace budget: the first iteration's in ext_trace, every later one's in an arena of its own, all addressed from
+	// ext_trace's base (64-bit offsets). An iteration that does not fit is swept for scores only, and round 2 sweeps its survivors
+	// again with traceback -- what the reference's round 2 does for every survivor.
+	const size_t trace_budget = c->trace_arena_max;
+	size_t trace_used = 0, n_more = 0;
+	auto arena_for = [&](size_t bytes, DevBuf*& arena, int64_t& rel) -> int {
+		arena = &c->ext_trace;
+		if (trace_used > 0) {
+			if (c->ext_trace_more.size() <= n_more) c->ext_trace_more.resize(n_more + 1);
+			arena = &c->ext_trace_more[n_more++];
+		}
+		if (int rc = arena->ensure(bytes + 64)) return rc;
+		if (!c->ext_trace.p) { if (int rc = c->ext_trace.ensure(64)) return rc; }
+		rel = (int64_t)(arena->as<char>() - c->ext_trace.as<char>());
+		trace_used += bytes;
+		return DMND_OK;
+	};
+	HIP_TRY(launch_ext_begin(a, st));
+	ExtCounters ctr;
+	double ms_sweeps = 0, ms_sweeps2 = 0, ms_walk = 0;
+	uint64_t items_total = 0;
+	for (int iter = 0;; ++iter) {
+		if (iter >= EXT_MAX_ITERATIONS) return fail(DMND_E_CAP, "dmnd_extend: a query's ranking did not end within the supported number of chunks");
+		// 1. the chunk's items, launch order, trace offsets, pairs
+		HIP_TRY(launch_ext_prepare(a, st));
+		HIP_TRY(copy_now(st, c->ext_host.p, a.ctr, sizeof(ExtCounters), hipMemcpyDeviceToHost));
+		ctr = *c->ext_host.as<ExtCounters>();
+		if (iter == 0) tr.lap("items, launch order, trace offsets");
+		if (iter == 0 && ctr.n_items == 0) return DMND_OK;
+		// 2. round 1 (one launch per band class)
+		int64_t rel = 0;
+		bool kept = false;
+		if (ctr.n_items > 0) {
+			kept = keep_traces_dev() && trace_used + (size_t)ctr.total_rows <= trace_budget;
+			DevBuf* arena = nullptr;
+			if (kept) if (int rc = arena_for((size_t)ctr.total_rows, arena, rel)) return rc;
+			if (iter == 0) tr.lap("trace arena");
+			HIP_TRY(hipEventRecord(c->ev0, st));
+			if (int rc = dmnd_sweep_classes(c, c, a.items + a.item_base, ctr.class_count, ctr.class_max_steps, EXT_CLASSES, reinterpret_cast<const int32_t*>(a.order), a.off_slot, a.pairs,
+				a.off_item + a.item_base, kept ? arena->as<uint8_t>() : nullptr, a.ends + a.item_base)) return rc;
+			HIP_TRY(hipEventRecord(c->ev1, st));
+		}
+		// 3. best HSP per target, append_hits, next window; and -- in case that was the last chunk of every query -- final culling + round-2 list
+		HIP_TRY(launch_ext_append(a, ctr.n_items, kept, rel, st));
+		const uint32_t n_items_iter = ctr.n_items;
+		HIP_TRY(copy_now(st, c->ext_host.p, a.ctr, sizeof(ExtCounters), hipMemcpyDeviceToHost));
+		ctr = *c->ext_host.as<ExtCounters>();
+		if (n_items_iter > 0) { float ms = 0.f; HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1)); ms_sweeps += ms; }
+		items_total += n_items_iter;
+		a.item_base += n_items_iter;
+		if (tr.on && (iter > 0 || ctr.n_active > 0)) std::fprintf(stderr, "dmnd_extend (device half): chunk %d: %u DpTargets%s, %.1f MB of trace rows kept so far, %u queries go on\n", iter, n_items_iter, kept ? "" : " (scores only)", (double)trace_used / 1048576.0, ctr.n_active);
+		if (ctr.n_active == 0) break;
+	}
 	tr.lap("sweeps, culling");
-	// 3. round 2 = a walk of the survivors' kept traces, then the records
+	// 4. round 2: the survivors whose trace rows were not kept are swept again with traceback (copies of their items, one more
+	// iteration), then one walk over all survivors' traces, then the records
 	if (ctr.n_kept > nR) return fail(DMND_E_CAP, "dmnd_extend: more device records than -k allows");
+	const uint32_t n_kept = ctr.n_kept;
+	if (ctr.n_resweep > 0) {
+		HIP_TRY(launch_ext_resweep(a, n_kept, st));
+		HIP_TRY(copy_now(st, c->ext_host.p, a.ctr, sizeof(ExtCounters), hipMemcpyDeviceToHost));
+		ctr = *c->ext_host.as<ExtCounters>();
+		if ((size_t)ctr.total_rows > c->trace_arena_max * 4) return fail(DMND_E_NOMEM, "dmnd_extend: the trace rows of round 2 exceed the trace budget (DMND_TRACE_ARENA_MB)");
+		DevBuf* arena = nullptr;
+		int64_t rel = 0;
+		if (int rc = arena_for((size_t)ctr.total_rows, arena, rel)) return rc;
+		HIP_TRY(hipEventRecord(c->ev0, st));
+		if (int rc = dmnd_sweep_classes(c, c, a.items + a.item_base, ctr.class_count, ctr.class_max_steps, EXT_CLASSES, reinterpret_cast<const int32_t*>(a.order), a.off_slot, a.pairs,
+			a.off_item + a.item_base, arena->as<uint8_t>(), a.ends + a.item_base)) return rc;
+		HIP_TRY(hipEventRecord(c->ev1, st));
+		HIP_TRY(launch_ext_rewalk(a, ctr.n_items, n_kept, rel, st));
+		HIP_TRY(sync_stream(st));
+		float ms = 0.f;
+		HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+		ms_sweeps2 += ms;
+		tr.lap("round-2 sweeps");
+	}
+	ctr.n_kept = n_kept;
+	HIP_TRY(hipEventRecord(c->ev1, st));
 	if (ctr.n_kept > 0) {
 		TracebackArgs t;
 		t.qblock = c->block[DMND_QUERY].as<int8_t>(); t.tblock = c->block[DMND_TARGET].as<int8_t>(); t.cbs = c->cbs_len > 0 ? c->cbs.as<int8_t>() : nullptr;
@@ -771,9 +841,9 @@ static int extend_on_device(dmnd_ctx* c, const HostCfg& h, const DevPlan& plan, 
 	ctr = *reinterpret_cast<const ExtCounters*>(hp + h_ctr);
 	tr.lap("walk, records, copy");
 	if (ctr.tb_status != 0) return fail(ctr.tb_status, ctr.tb_status == DMND_E_TRACEBACK ? "Traceback error." : "transcript slot too small");
-	float ms1 = 0.f, ms2 = 0.f;
-	HIP_TRY(hipEventElapsedTime(&ms1, c->ev0, c->ev1));
+	float ms2 = 0.f;
 	HIP_TRY(hipEventElapsedTime(&ms2, c->ev1, c->ev2));
+	ms_walk = ms2;
 	qstate.assign(hp + h_qstate, hp + h_qstate + nQ);
 	// 4. the host's own e-value and bit score in every record; the device ordered a query's records by ITS e-values -- checked,
 	// and put right where the two disagree
@@ -797,12 +867,12 @@ static int extend_on_device(dmnd_ctx* c, const HostCfg& h, const DevPlan& plan, 
 		b = e;
 	}
 	tr.lap("host e-values, order check");
-	c->ext_stats[0] += (double)ctr.n_items; c->ext_stats[1] += (double)ctr.n_kept;
+	c->ext_stats[0] += (double)items_total; c->ext_stats[1] += (double)ctr.n_kept;
 	c->ext_stats[2] += (double)ctr.cells1; c->ext_stats[3] += (double)ctr.cells2;
-	c->ext_stats[9] += ms1; c->ext_stats[11] += ms2;
+	c->ext_stats[9] += ms_sweeps; c->ext_stats[10] += ms_sweeps2; c->ext_stats[11] += ms_walk;
 	size_t n_eligible = 0;
 	for (uint8_t x : qstate) n_eligible += x != EXT_Q_HOST;
-	c->ext_dev_stats[0] = (double)n_eligible; c->ext_dev_stats[1] = (double)(ctr.n_ambiguous + ctr.n_saturated); c->ext_dev_stats[2] = (double)ctr.n_items; c->ext_dev_stats[3] = (double)ctr.n_kept;
+	c->ext_dev_stats[0] = (double)n_eligible; c->ext_dev_stats[1] = (double)(ctr.n_ambiguous + ctr.n_saturated); c->ext_dev_stats[2] = (double)items_total; c->ext_dev_stats[3] = (double)ctr.n_kept;
 	done = true;
 	return DMND_OK;
 }

@@ -3,7 +3,7 @@
 # host CPU per step and the step time of C3 / C2skew / C5 / C2 with it on and off (DMND_EXTEND_DEVICE=0) on one box
 set -u
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
-OUT="$ROOT/gpurun_out/r06d"
+OUT="$ROOT/gpurun_out/${R06D_OUT:-r06d}"
 mkdir -p "$OUT"
 cd "$ROOT"
 timeout 1500 python -m pytest tests/test_gpu_extend.py tests/test_gpu_gapped.py tests/test_gpu_skew.py tests/test_gpu_fullscale.py tests/test_gpu_xdrop.py tests/test_gpu_edge_cases.py -m gpu -x -q 2>&1 | tail -15 | tee "$OUT/tests.log"
