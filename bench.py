@@ -146,6 +146,44 @@ def scaling_model(out, ext, cpu_ms_per_step, cpus, step_ms, n_records, n_blocks,
     return model
 
 
+def sweep_roofline(config, ext):
+    """north_star's second kernel, the banded Smith-Waterman sweep (/root/reference/src/dp/swipe/banded_swipe.h:189-351), against the
+    roofline that bounds it: VALU issue. Per kernel: VALU wave-instructions per launch (committed PMC pass) / its average launch
+    time (committed rocprofv3 kernel statistics of the same configuration) / the device's issue peak: 256 CUs x 4 SIMDs x 2.4 GHz / 2
+    = 1229 G wave-instructions/s (a 64-lane wavefront's VALU instruction occupies its SIMD for two cycles). Live from this run: the sweeps' device time and cells, and the lane
+    use of the device path's round-1 DpTargets (band diagonals / the 128 P diagonals their wavefront holds, weighted by steps)."""
+    import csv
+    PEAK = 256 * 4 * 2.4 / 2
+    o = {"bound": "valu_issue", "peak": PEAK, "unit": "G wave-instructions/s", "kernels": {}, "achieved": None, "frac": None,
+         "lane_use": (ext["band_diagonal_steps"] / ext["wavefront_diagonal_steps"]) if ext.get("wavefront_diagonal_steps") else None,
+         "live": {"round1_sweep_kernel_ms": ext["round1_swipe_kernel_ms"], "round2_sweep_kernel_ms": ext["round2_swipe_kernel_ms"],
+                  "round1_gcups": ext["round1_cells"] / max(ext["round1_swipe_kernel_ms"], 1e-9) / 1e6}}
+    pmc = next((q for q in (os.path.join(ROOT, "profiles", "r%02d_pmc_summary_%s.json" % (r, config)) for r in (6, 5)) if os.path.exists(q)), None)
+    st = next((q for q in (os.path.join(ROOT, "profiles", "r%02d_kernel_stats_%s.csv" % (r, config)) for r in (6, 5)) if os.path.exists(q)), None)
+    if not pmc or not st:
+        o["source"] = "no committed PMC pass + kernel statistics for this configuration"
+        return o
+    avg_ns = {r["Name"]: (float(r["AverageNs"]), int(r["TotalDurationNs"])) for r in csv.DictReader(open(st)) if "banded_swipe" in r["Name"]}
+    best = None
+    for name, v in json.load(open(pmc)).items():
+        if "banded_swipe" not in name or "SQ_INSTS_VALU_per_launch" not in v or name not in avg_ns:
+            continue
+        ach = v["SQ_INSTS_VALU_per_launch"] / avg_ns[name][0]          # wave-instructions per ns = G/s
+        short = name[name.index("banded_swipe"):name.index("(")] if "(" in name else name
+        o["kernels"][short] = {"valu_wave_instructions_per_launch": v["SQ_INSTS_VALU_per_launch"], "avg_launch_ms": avg_ns[name][0] / 1e6,
+                               "share_of_sweep_time": None, "achieved": ach, "frac": ach / PEAK, "_total_ns": avg_ns[name][1]}
+        if best is None or avg_ns[name][1] > best[1]:
+            best = (short, avg_ns[name][1])
+    total = sum(k["_total_ns"] for k in o["kernels"].values()) or 1
+    for k in o["kernels"].values():
+        k["share_of_sweep_time"] = k.pop("_total_ns") / total
+    if best:
+        o["dominant"] = best[0]
+        o["achieved"], o["frac"] = o["kernels"][best[0]]["achieved"], o["kernels"][best[0]]["frac"]
+    o["source"] = "%s (SQ_INSTS_VALU per launch) / %s (average launch time)" % (os.path.relpath(pmc, ROOT), os.path.relpath(st, ROOT))
+    return o
+
+
 def cgroup_cpus():
     """CPUs of time this process may use: the cgroup quota when there is one (the GPU boxes run the container under
     cpu.max = 16 CPUs for 256 hardware threads), else the visible cores."""
@@ -545,6 +583,9 @@ def main():
             n_hits += int(hits.size)
             seed_ms = list(ms) if seed_ms is None else [x + y for x, y in zip(seed_ms, ms)]
             st = ec.extend_stats()
+            dv = ec.extend_device_stats()                       # how much of the batch the device half extended, and its sweeps' lane use
+            st.update(device_queries=float(dv["queries"]), device_queries_back_to_host=float(dv["queries_back_to_host"]), device_items=float(dv["items"]),
+                      band_diagonal_steps=dv["band_diagonal_steps"], wavefront_diagonal_steps=dv["wavefront_diagonal_steps"])
             ext_sum = dict(st) if ext_sum is None else {k: ext_sum[k] + st[k] for k in st}
         state.setdefault("ext_wall", []).append((time.perf_counter() - t_b) * 1e3)
         return dict(parts=parts, hits=n_hits, seed_ms=seed_ms, ext=ext_sum, ext_wall_ms=(time.perf_counter() - t_b) * 1e3)
@@ -892,6 +933,7 @@ def main():
                 rl["hbm_measured_frac"] = rl["hbm_measured"]["frac"]
                 if "l2_requests" in rl:
                     rl["l2_requests_frac"] = rl["l2_requests"]["frac"]
+        out["sweep_roofline"] = sweep_roofline(args.config, ext)
         # SURVEY 8(d)'s whole-pipeline figure: bytes_total = bytes_seed + bytes_sw over the step's wall time
         S = seed_params.n_shapes
         L = ref_letters * NB + int(w.ql[-1] - w.ql[0]) * NB

@@ -38,6 +38,7 @@ struct ExtCounters {
 	uint32_t class_max_steps[EXT_CLASSES];
 	unsigned long long total_rows;           // trace bytes of the current iteration's items
 	unsigned long long cells1, cells2;       // DP cells of all round-1 items / of the items walked in round 2
+	unsigned long long diag_steps, lane_steps;   // over the round-1 items: band diagonals x anti-diagonal steps, and the 128 P diagonals the item's wavefront holds x steps (lane use of the sweeps)
 };
 
 struct ExtArgs {

@@ -122,9 +122,9 @@ __global__ __launch_bounds__(256) void ext_init_kernel(ExtArgs a)
 __global__ __launch_bounds__(256) void ext_items_kernel(ExtArgs a)
 {
 	__shared__ uint32_t h_count[EXT_CLASSES], h_steps[EXT_CLASSES];
-	__shared__ unsigned long long h_cells;
+	__shared__ unsigned long long h_cells, h_diag, h_lane;
 	if (threadIdx.x < EXT_CLASSES) { h_count[threadIdx.x] = 0; h_steps[threadIdx.x] = 0; }
-	if (threadIdx.x == 0) h_cells = 0;
+	if (threadIdx.x == 0) { h_cells = 0; h_diag = 0; h_lane = 0; }
 	__syncthreads();
 	const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
 	if (g < a.n_groups) {
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void ext_items_kernel(ExtArgs a)
 			const int qlen = (int)(a.qlimits[query + 1] - q0 - 1), tlen = (int)(a.tlimits[grp.target + 1] - t0 - 1);
 			const uint32_t local = a.item_off[g], first = a.item_base + local;
 			a.g_first[g] = first; a.g_cnt[g] = n;
-			unsigned long long cells = 0;
+			unsigned long long cells = 0, diag = 0, lanes = 0;
 			for (uint32_t k = 0; k < n; ++k) {
 				const PlanBand b = a.bands[grp.band_begin + k];
 				const dmnd_dp_target d{ q0, t0, a.use_cbs ? q0 : (int64_t)-1, qlen, tlen, b.d_begin, b.d_end };
@@ -152,8 +152,10 @@ __global__ __launch_bounds__(256) void ext_items_kernel(ExtArgs a)
 				atomicAdd(&h_count[c], 1u);
 				atomicMax(&h_steps[c], (uint32_t)(steps < 0x7fffffff ? steps : 0x7fffffff));
 				cells += (unsigned long long)ext_cells(d);
+				diag += (unsigned long long)(b.d_end - b.d_begin) * (unsigned long long)steps;
+				lanes += (unsigned long long)(128 * P) * (unsigned long long)steps;
 			}
-			atomicAdd(&h_cells, cells);
+			atomicAdd(&h_cells, cells); atomicAdd(&h_diag, diag); atomicAdd(&h_lane, lanes);
 		}
 		if (g == 0) a.ctr->n_items = a.item_off[a.n_groups];
 	}
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(256) void ext_items_kernel(ExtArgs a)
 		atomicAdd(&a.ctr->class_count[threadIdx.x], h_count[threadIdx.x]);
 		atomicMax(&a.ctr->class_max_steps[threadIdx.x], h_steps[threadIdx.x]);
 	}
-	if (threadIdx.x == 0 && h_cells) atomicAdd(&a.ctr->cells1, h_cells);
+	if (threadIdx.x == 0 && h_cells) { atomicAdd(&a.ctr->cells1, h_cells); atomicAdd(&a.ctr->diag_steps, h_diag); atomicAdd(&a.ctr->lane_steps, h_lane); }
 }
 
 __global__ __launch_bounds__(256) void ext_slots_kernel(ExtArgs a)

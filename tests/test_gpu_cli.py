@@ -356,13 +356,13 @@ def test_cli_gpus_distributes_reference_blocks(tmp_path):
     assert open(out).read() == open(os.path.join(g, "diamond-test-blastp-blocked.out")).read()
     # round 5: with several contexts the records are merged by dmnd_join_ranks -- owners by query range, exchange, merge on the device.
     # Two contexts on the box's one GPU exchange with device copies (RCCL refuses two ranks on a device) ...
-    assert "Block join: device-to-device copies between 2 context(s), merged on the device(s)" in r.stderr, r.stderr[-1500:]
+    assert "Block join: transport_used = device-to-device copies between 2 context(s), merged on the device(s)" in r.stderr, r.stderr[-1500:]
     # ... and ONE context goes through RCCL itself (ncclCommInitAll, a grouped ncclSend / ncclRecv to itself): same golden; so does --top
     for extra, golden in (([], "diamond-test-blastp-blocked.out"), ):
         r1 = subprocess.run([CLI, "blastp", "-q", os.path.join(g, "data.faa"), "-d", os.path.join(g, "data.faa"), "-c1", "-b0.00002", "-p4", "-o", out] + extra,
                             capture_output=True, text=True, timeout=600, env=dict(os.environ, DMND_CLI_RCCL="1"))
         assert r1.returncode == 0, r1.stderr[-2000:]
-        assert "Block join: RCCL exchange (ncclSend/ncclRecv) between 1 context(s)" in r1.stderr, r1.stderr[-1500:]
+        assert "Block join: transport_used = RCCL exchange (ncclSend/ncclRecv) between 1 context(s)" in r1.stderr, r1.stderr[-1500:]
         assert open(out).read() == open(os.path.join(g, golden)).read()
     for top_flags in (["--top", "10"], ["-k", "3"]):
         outs = []
