@@ -802,7 +802,8 @@ static int extend_on_device(dmnd_ctx* c, const HostCfg& h, const DevPlan& plan, 
 		HIP_TRY(launch_ext_resweep(a, n_kept, st));
 		HIP_TRY(copy_now(st, c->ext_host.p, a.ctr, sizeof(ExtCounters), hipMemcpyDeviceToHost));
 		ctr = *c->ext_host.as<ExtCounters>();
-		if ((size_t)ctr.total_rows > c->trace_arena_max * 4) return fail(DMND_E_NOMEM, "dmnd_extend: the trace rows of round 2 exceed the trace budget (DMND_TRACE_ARENA_MB)");
+		// (at most -k survivors per query: their rows are not held against the budget of round 1, only against a hard limit)
+		if ((size_t)ctr.total_rows > std::max(c->trace_arena_max * 4, (size_t)4 << 30)) return fail(DMND_E_NOMEM, "dmnd_extend: the trace rows of round 2 exceed the trace limit (4 x DMND_TRACE_ARENA_MB, at least 4 GB)");
 		DevBuf* arena = nullptr;
 		int64_t rel = 0;
 		if (int rc = arena_for((size_t)ctr.total_rows, arena, rel)) return rc;
