@@ -9,12 +9,15 @@ mkdir -p "$OUT"
 cd "$ROOT"
 if [[ " $* " == *" tests "* ]]; then timeout 1700 python -m pytest tests -m gpu -q 2>&1 | tail -30 > "$OUT/pytest.txt"; tail -4 "$OUT/pytest.txt"; fi
 cd /tmp && export TMPDIR=/tmp
+if [[ " $* " == *" bench "* ]]; then
 for cfg in C2 C4 C5 C3 C2skew; do
   steps=50; [ $cfg = C3 ] && steps=30; [ $cfg = C5 ] && steps=32; [ $cfg = C2skew ] && steps=30
   extra=""; [ $cfg = C2skew ] && extra="--no-e2e"
   timeout 900 python "$ROOT/bench.py" --config $cfg --steps $steps --warmup 10 $extra > "$OUT/bench_$cfg.json" 2> "$OUT/bench_$cfg.err"
   tail -c 300 "$OUT/bench_$cfg.err"
 done
+fi
+if [[ " $* " == *" counters "* ]]; then
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c2" -o s -- python "$ROOT/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-masked-step > "$OUT/stats_c2.log" 2>&1
 find "$OUT/stats_c2" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/kernel_stats_C2.csv"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c3" -o s -- python "$ROOT/bench.py" --config C3 --steps 3 --warmup 1 --no-cpu-baseline --no-masked-step > "$OUT/stats_c3.log" 2>&1
@@ -24,7 +27,8 @@ find "$OUT/stats_c5" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OU
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_skew" -o s -- python "$ROOT/bench.py" --config C2skew --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-masked-step > "$OUT/stats_skew.log" 2>&1
 find "$OUT/stats_skew" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/kernel_stats_C2skew.csv"
 rm -rf "$OUT"/stats_c2 "$OUT"/stats_c3 "$OUT"/stats_c5 "$OUT"/stats_skew
-if [[ " $* " != *" nopmc "* ]]; then
+fi
+if [[ " $* " == *" counters "* && " $* " != *" nopmc "* ]]; then
   timeout 600 "$ROOT/tools/pmc_passes.sh" C2 "$OUT/pmc_summary_C2.json" 2>&1 | tail -1
   timeout 900 "$ROOT/tools/pmc_passes.sh" C3 "$OUT/pmc_summary_C3.json" 2>&1 | tail -1
   PMC_SHORT=1 timeout 600 "$ROOT/tools/pmc_passes.sh" C5 "$OUT/pmc_summary_C5.json" 2>&1 | tail -1
