@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <time.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -51,16 +52,23 @@ static int sync_spin_us()
 
 hipError_t dmnd::wait_event(hipEvent_t ev)
 {
+	if (spin_sync()) return hipEventSynchronize(ev);
+	// Poll, then sleep between polls: 0.7 CPU-ms per 50 ms of kernel (tools/probes/wait_probe.hip), as cheap as the runtime's
+	// interrupt-driven wait (hipDeviceScheduleBlockingSync: 0.5 ms) and without its rare long stalls -- with the blocking wait one
+	// step in ~100 of the C2 bench took 10 - 50 ms (a wait that slept through its completion until a timeout), with the sleeping
+	// poll none. The sleeps grow from 20 to 200 us: a short kernel is picked up within microseconds, a long one costs a poll per 0.2 ms.
 	const int spin_us = sync_spin_us();
-	if (spin_us > 0 && !spin_sync()) {
-		const auto t0 = std::chrono::steady_clock::now();
-		do {
-			const hipError_t q = hipEventQuery(ev);
-			if (q == hipSuccess) return hipSuccess;
-			if (q != hipErrorNotReady) return q;
-		} while (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() < spin_us);
+	const auto t0 = std::chrono::steady_clock::now();
+	long sleep_ns = 20000;
+	for (;;) {
+		const hipError_t q = hipEventQuery(ev);
+		if (q == hipSuccess) return hipSuccess;
+		if (q != hipErrorNotReady) return q;
+		if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() < spin_us) continue;
+		timespec ts{ 0, sleep_ns };
+		nanosleep(&ts, nullptr);
+		if (sleep_ns < 200000) sleep_ns += sleep_ns / 2;
 	}
-	return hipEventSynchronize(ev);
 }
 
 hipError_t dmnd::sync_stream(hipStream_t s)
@@ -202,12 +210,12 @@ hipError_t take_stream(hipStream_t* s, int device, int priority)
 extern "C" hipError_t dmnd_touch_bias(hipStream_t), dmnd_touch_gapped(hipStream_t), dmnd_touch_mask(hipStream_t), dmnd_touch_seed(hipStream_t),
 	dmnd_touch_swipe16(hipStream_t), dmnd_touch_swipe(hipStream_t), dmnd_touch_frameshift(hipStream_t), dmnd_touch_plan(hipStream_t), dmnd_touch_extend(hipStream_t);
 
-// Host waits sleep on the completion interrupt. Measured on ROCm 7.2 (tools/probes/wait_probe.hip, round 6): the event flag
-// hipEventBlockingSync alone changes nothing -- hipEventSynchronize and hipStreamSynchronize spin, 50.0 CPU-ms per 50 ms of
-// kernel -- while with the DEVICE flag hipDeviceScheduleBlockingSync every wait of the process on this device costs 0.5 CPU-ms
-// per 50 ms and returns 30 - 60 us later. sync_stream polls for a bounded time first, so short kernels do not pay that latency.
-// The seed stage's thread burnt 142 of C3's 239 host CPU-ms per step this way. DMND_SPIN_SYNC=1 keeps the spinning waits.
-// Called with `device` current, by dmnd_init and by every dmnd_create (once per device).
+// Host waits must not spin: measured on ROCm 7.2 (tools/probes/wait_probe.hip, round 6) hipEventSynchronize and hipStreamSynchronize
+// burn 50.0 CPU-ms per 50 ms of kernel whatever the event's flags (hipEventBlockingSync alone changes nothing) -- the seed stage's
+// thread spent 142 of C3's 239 host CPU-ms per step that way. Only the DEVICE flag hipDeviceScheduleBlockingSync makes the runtime
+// sleep (0.5 CPU-ms per 50 ms), for every wait of the process; the library's own waits (sync_stream / wait_event) poll and sleep
+// instead and do not depend on it. The flag is still set once per device, for the few runtime waits left (hipMemcpy of a parameter
+// table, stream destruction) and for a host program's own synchronisations. DMND_SPIN_SYNC=1: spinning waits, no flag.
 static void blocking_waits(int device)
 {
 	static std::mutex m;
