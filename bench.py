@@ -586,6 +586,10 @@ def main():
             dv = ec.extend_device_stats()                       # how much of the batch the device half extended, and its sweeps' lane use
             st.update(device_queries=float(dv["queries"]), device_queries_back_to_host=float(dv["queries_back_to_host"]), device_items=float(dv["items"]),
                       band_diagonal_steps=dv["band_diagonal_steps"], wavefront_diagonal_steps=dv["wavefront_diagonal_steps"])
+            # DP cells that round 2 SWEEPS (again): the device half's survivors without kept trace rows, and all round-2 targets of the
+            # host half when it ran without kept traces (its own round-2 sweep time is what is left of slot [10])
+            host_r2_ms = st["round2_swipe_kernel_ms"] - dv["round2_sweep_kernel_ms"]
+            st["round2_cells_swept"] = dv["round2_cells_swept_again"] + ((st["round2_cells"] - dv["round2_cells"]) if host_r2_ms > 1e-6 else 0.0)
             ext_sum = dict(st) if ext_sum is None else {k: ext_sum[k] + st[k] for k in st}
         state.setdefault("ext_wall", []).append((time.perf_counter() - t_b) * 1e3)
         return dict(parts=parts, hits=n_hits, seed_ms=seed_ms, ext=ext_sum, ext_wall_ms=(time.perf_counter() - t_b) * 1e3)
@@ -782,7 +786,9 @@ def main():
                 parts["motif_target_call"].append((t_3 - t_2b) * 1e3)
             n_masked = (int(nq), int(nt))
         st = mc.extend_stats()
-        m_cells = st["round1_cells"] + (st["round2_cells"] if st["round2_swipe_kernel_ms"] > 0 else 0.0)
+        dvm = mc.extend_device_stats()
+        m_host_r2 = (st["round2_cells"] - dvm["round2_cells"]) if st["round2_swipe_kernel_ms"] - dvm["round2_sweep_kernel_ms"] > 1e-6 else 0.0
+        m_cells = st["round1_cells"] + dvm["round2_cells_swept_again"] + m_host_r2
         mean = {k: sum(v) / len(v) for k, v in parts.items()}
         masked_step = {"what": "one context, stages back to back (no pipelining): block letters as loaded copied device-to-device, tantan + motif masking of the "
                                "query block and of the database block, seed stage, extension -- the work of `diamond blastp --algo 0` per block pair with masking at its default",
@@ -800,7 +806,7 @@ def main():
     win_median = sorted(win_ms)[len(win_ms) // 2] if len(win_ms) >= 8 else None      # (fewer windows: a median of clumped completions says nothing -- the mean is the figure)
     ext = pipe_ext
     # the job's DP cells: with database shards every rank sweeps its own targets, with query shards its own queries
-    cells = torch.tensor([ext["round1_cells"], ext["round2_cells"] if ext["round2_swipe_kernel_ms"] > 0 else 0.0, ext["round2_cells"],
+    cells = torch.tensor([ext["round1_cells"], ext["round2_cells_swept"], ext["round2_cells"],
                           float(len(state["matches"])), ext["round1_targets"], ext["round2_targets"], float(state["hits"])], dtype=torch.float64, device=coll_device)
     if world > 1:
         dist.all_reduce(cells, op=dist.ReduceOp.SUM)

@@ -108,7 +108,7 @@ struct dmnd_ctx {
 	dmnd::DevBuf ext_dev, ext_trace;          // device half of dmnd_extend behind the planner (extend_kernels.hip): work arrays, kept traces
 	std::vector<dmnd::DevBuf> ext_trace_more; // ... the kept traces of the ranking chunks behind the first
 	dmnd::PinBuf ext_host;                    // ... its counters, records and query states on the host
-	double ext_dev_stats[6] = { 0, 0, 0, 0, 0, 0 };      // of the last dmnd_extend: queries extended on the device, of them redone by the host (ambiguous e-value order / 16-bit saturation), items, records, band diagonals x steps, wavefront diagonals x steps
+	double ext_dev_stats[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };      // of the last dmnd_extend: queries extended on the device, of them redone by the host (ambiguous e-value order / 16-bit saturation), items, records, band diagonals x steps, wavefront diagonals x steps
 	std::vector<int32_t> h_bias_ids;           // block sequence ids of the queries with seed hits (Hauser bias of one dmnd_extend call)
 	int64_t block_len[2] = { 0, 0 }, cbs_len = 0;
 	std::vector<int64_t> limits[2];

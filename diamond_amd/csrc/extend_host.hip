@@ -875,6 +875,7 @@ static int extend_on_device(dmnd_ctx* c, const HostCfg& h, const DevPlan& plan, 
 	for (uint8_t x : qstate) n_eligible += x != EXT_Q_HOST;
 	c->ext_dev_stats[0] = (double)n_eligible; c->ext_dev_stats[1] = (double)(ctr.n_ambiguous + ctr.n_saturated); c->ext_dev_stats[2] = (double)items_total; c->ext_dev_stats[3] = (double)ctr.n_kept;
 	c->ext_dev_stats[4] = (double)ctr.diag_steps; c->ext_dev_stats[5] = (double)ctr.lane_steps;
+	c->ext_dev_stats[6] = (double)ctr.cells2; c->ext_dev_stats[7] = (double)ctr.cells_again; c->ext_dev_stats[8] = ms_sweeps2;
 	done = true;
 	return DMND_OK;
 }
@@ -2201,10 +2202,10 @@ extern "C" int dmnd_extend_reserve(dmnd_ctx* c, int64_t n_hits_hint)
 	return DMND_OK;
 }
 
-extern "C" int dmnd_extend_device_stats(const dmnd_ctx* c, double out[6])
+extern "C" int dmnd_extend_device_stats(const dmnd_ctx* c, double out[10])
 {
 	if (!c || !out) return fail(DMND_E_ARG, "dmnd_extend_device_stats: NULL argument");
-	for (int i = 0; i < 6; ++i) out[i] = c->ext_dev_stats[i];
+	for (int i = 0; i < 10; ++i) out[i] = c->ext_dev_stats[i];
 	return DMND_OK;
 }
 

@@ -37,7 +37,8 @@ struct ExtCounters {
 	uint32_t class_count[EXT_CLASSES];       // items of the current iteration per band class P = 1 << c
 	uint32_t class_max_steps[EXT_CLASSES];
 	unsigned long long total_rows;           // trace bytes of the current iteration's items
-	unsigned long long cells1, cells2;       // DP cells of all round-1 items / of the items walked in round 2
+	unsigned long long cells1, cells2;       // DP cells of all round-1 items / of the items walked in round 2 (the reference's round-2 targets)
+	unsigned long long cells_again;          // ... of those of them that round 2 swept again (their round-1 sweep kept no trace rows)
 	unsigned long long diag_steps, lane_steps;   // over the round-1 items: band diagonals x anti-diagonal steps, and the 128 P diagonals the item's wavefront holds x steps (lane use of the sweeps)
 };
 

@@ -388,7 +388,9 @@ __global__ __launch_bounds__(256) void ext_round2_kernel(ExtArgs a)
 __global__ __launch_bounds__(256) void ext_resweep_kernel(ExtArgs a, uint32_t n_kept)
 {
 	__shared__ uint32_t h_count[EXT_CLASSES], h_steps[EXT_CLASSES];
+	__shared__ unsigned long long h_cells;
 	if (threadIdx.x < EXT_CLASSES) { h_count[threadIdx.x] = 0; h_steps[threadIdx.x] = 0; }
+	if (threadIdx.x == 0) h_cells = 0;
 	__syncthreads();
 	const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
 	if (k < n_kept && a.r2_off[k] < 0) {
@@ -407,12 +409,14 @@ __global__ __launch_bounds__(256) void ext_resweep_kernel(ExtArgs a, uint32_t n_
 		atomicMax(&h_steps[c], (uint32_t)(steps < 0x7fffffff ? steps : 0x7fffffff));
 		a.r2_order[k] = (int32_t)copy;
 		a.cand_item[a.r2_group[k]] = copy;
+		atomicAdd(&h_cells, (unsigned long long)ext_cells(d));
 	}
 	__syncthreads();
 	if (threadIdx.x < EXT_CLASSES && h_count[threadIdx.x]) {
 		atomicAdd(&a.ctr->class_count[threadIdx.x], h_count[threadIdx.x]);
 		atomicMax(&a.ctr->class_max_steps[threadIdx.x], h_steps[threadIdx.x]);
 	}
+	if (threadIdx.x == 0 && h_cells) atomicAdd(&a.ctr->cells_again, h_cells);
 }
 
 // ... and behind the sweeps of the copies: the walk's trace offsets of those slots
@@ -545,6 +549,8 @@ hipError_t launch_ext_append(const ExtArgs& a, uint32_t n_items, bool kept, int6
 	hipError_t e = hipMemsetAsync(&a.ctr->n_active, 0, sizeof(uint32_t), st);
 	if (e != hipSuccess) return e;
 	e = hipMemsetAsync(&a.ctr->n_resweep, 0, sizeof(uint32_t), st);
+	if (e != hipSuccess) return e;
+	e = hipMemsetAsync(&a.ctr->cells2, 0, sizeof(unsigned long long), st);      // (the round-2 list below is rebuilt behind every iteration)
 	if (e != hipSuccess) return e;
 	const size_t lds_append = ((size_t)a.k + 2 * (size_t)a.chunk_size) * sizeof(SelSlot), lds_final = ((size_t)a.k + (size_t)a.chunk_size) * sizeof(SelSlot);
 	hipLaunchKernelGGL(ext_append_kernel, dim3(a.n_queries), dim3(64), lds_append, st, a);

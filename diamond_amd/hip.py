@@ -909,10 +909,11 @@ class Context:
 
     def extend_device_stats(self):
         """(queries extended on the device, of them handed back to the host, round-1 DpTargets, records) of the last extend()"""
-        st = (ctypes.c_double * 6)()
+        st = (ctypes.c_double * 10)()
         self.lib.dmnd_extend_device_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
         self._check(self.lib.dmnd_extend_device_stats(self.h, st))
-        return dict(queries=int(st[0]), queries_back_to_host=int(st[1]), items=int(st[2]), records=int(st[3]), band_diagonal_steps=st[4], wavefront_diagonal_steps=st[5])
+        return dict(queries=int(st[0]), queries_back_to_host=int(st[1]), items=int(st[2]), records=int(st[3]), band_diagonal_steps=st[4], wavefront_diagonal_steps=st[5],
+                    round2_cells=st[6], round2_cells_swept_again=st[7], round2_sweep_kernel_ms=st[8])
 
     def last_kernel_ms(self):
         a, b = ctypes.c_double(0), ctypes.c_double(0)

@@ -595,9 +595,10 @@ int dmnd_extend_plan_stats(const dmnd_ctx* ctx, double out[3]);
  * writes its own e-value and bit score into the records. Of the last dmnd_extend: [0] queries extended that way, [1] of them handed
  * back to the host path (two device e-values too close to order safely, or a saturated 16-bit sweep), [2] round-1 DpTargets,
  * [3] records, [4] sum over the round-1 DpTargets of band diagonals x anti-diagonal steps and [5] of the 128 P diagonals their wavefront
- * holds x steps ([4] / [5] = lane use of the sweeps); all 0 = every query took the host path (other modes: --max-hsps != 1, --top,
+ * holds x steps ([4] / [5] = lane use of the sweeps), [6] DP cells of the device half's round-2 targets, [7] of those swept again in
+ * round 2 (their round-1 sweep kept no trace rows), [8] device ms of those sweeps, [9] reserved; all 0 = every query took the host path (other modes: --max-hsps != 1, --top,
  * filters, matrix adjustment, --ext full, transcripts wanted, translated queries). */
-int dmnd_extend_device_stats(const dmnd_ctx* ctx, double out[6]);
+int dmnd_extend_device_stats(const dmnd_ctx* ctx, double out[10]);
 /* Optional: the first-call allocations of dmnd_extend made ahead of it, for about n_hits_hint seed hits (device work arrays of the
  * x-drop stage, planner and device half; the page-locked result buffer). A driver calls it beside its upload / masking phase, as
  * dmnd_seed_reserve; a hint that is too small costs nothing but the growth inside the call. The query block must be uploaded. */
