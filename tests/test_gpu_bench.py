@@ -84,7 +84,8 @@ def test_bench_e2e_and_hot_path_baselines():
     d = _bench(["--queries", "1500", "--families", "3000", "--steps", "2", "--warmup", "1", "--with-masking"])
     # --with-masking: the step of the default command line (masking on the device inside the step); its records = the reference's default output
     m = d["masked_step"]
-    assert m["ms_per_step"] > 0 and m["parts_ms"]["mask_target"] > 0 and m["masked_letters"]["database"] > 0
+    assert m["ms_per_step"] > 0 and m["stages_back_to_back"]["parts_ms"]["mask_target"] > 0 and m["masked_letters"]["database"] > 0
+    assert m["records_equal_back_to_back"] is True          # the pipelined form and the stages one after the other: the same records
     assert m["parity"]["matches"] is True, m["parity"]
     assert d["cpu_baseline"]["hot_path"]["seconds"] > 0 and d["cpu_baseline"]["whole_process"]["seconds"] > d["cpu_baseline"]["hot_path"]["seconds"]
     e = d["e2e"]

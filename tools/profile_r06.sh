@@ -43,7 +43,7 @@ for c in ("C2","C4","C5","C3","C2skew"):
         e=d.get("e2e",{})
         print(c, "ms/step %.3f median %s value %.1f parity %s | cpu hot %.3f s %.2f GCUPS | host_cpu %.1f | e2e %s" % (d["ms_per_step"], d.get("ms_per_step_median"), d["value"], d.get("parity_checked"), d["cpu_baseline"]["hot_path"]["seconds"], d["cpu_baseline"]["value"], d["host_cpu_ms_per_step"],
               {k:(round(v["reference_s"],2), round(v["ours_s"],3), round(v["speedup"],1), round(v["speedup_min"],1), v["parity"]) for k,v in e.get("runs",{}).items()}))
-        if "masked_step" in d: print("   masked", round(d["masked_step"]["ms_per_step"],2), d["masked_step"]["parts_ms"], d["masked_step"].get("parity",{}).get("matches"))
+        if "masked_step" in d: print("   masked", round(d["masked_step"]["ms_per_step"],2), round(d["masked_step"]["stages_back_to_back"]["ms_per_step"],2), d["masked_step"]["stages_back_to_back"]["parts_ms"], d["masked_step"].get("records_equal_back_to_back"), d["masked_step"].get("parity",{}).get("matches"))
         if "scaling_model" in d: print("   scaling", {k:(v["decomposition"], round(v["predicted_speedup"],2)) for k,v in d["scaling_model"]["best"].items()})
         print("   roofline", {k: d["roofline"].get(k) for k in ("frac", "traffic", "hbm_measured_frac", "l2_requests_frac")}, "| sweep", d.get("sweep_roofline", {}).get("frac"))
     except Exception as ex: print(c, "failed", ex)
