@@ -492,6 +492,9 @@ def main():
     ext_threads = max(1, threads // E)
     ctx, ctx_seed = ctxs[0], ctxs_seed[0]
     join_ctx = hip.Context(device=local_rank, params=params) if (world > 1 or NB > 1) else None      # stream + scratch of the device-side block join
+    # (round 6) one GPU, several blocks: the records of a batch's blocks are joined where dmnd_extend left them in HBM
+    # (dmnd_join_contexts_device), by the extension thread of the batch, on a join context of its context set
+    set_join_ctxs = [hip.Context(device=local_rank, params=params) for _ in range(max(1, args.ext_contexts))] if (world == 1 and NB > 1 and not args.host_join) else None
     state = {"stream_ms": 0.0, "stream_launches": 0}
     # Two database blocks alternate between the steps (round 5): block B holds the sequences of block A in reverse order, at its own
     # place in HBM -- the same work per step (same hits, cells and records up to the target numbers), but a step never streams the
@@ -547,6 +550,12 @@ def main():
     def finish(parts):
         """What happens to a batch's records: database blocks are joined as the reference joins reference blocks -- the blocks of
         this rank with the other ranks' over RCCL."""
+        if isinstance(parts, dict):                          # joined in HBM by the batch's extension thread
+            full = parts["joined"]
+            q = full["query"]
+            state["joined_queries"] = int((q[1:] != q[:-1]).sum() + 1) if q.size else 0
+            state["join_form"] = "records joined where dmnd_extend left them in HBM (dmnd_join_contexts_device)"
+            return full
         if world > 1 and args.shard == "db" or NB > 1:
             # one copy of the records (the concatenation); block ids -> database ordinals in place
             mine = np.concatenate([np.ascontiguousarray(m, dtype=hip.MATCH_DTYPE) for m in parts])
@@ -561,6 +570,7 @@ def main():
                 part, full = multigpu.query_range_join_device(mine, w.n_queries, coll_device, join_ctx)
             elif world == 1 and not args.host_join:
                 part = full = join_ctx.join_blocks_device(mine, multigpu.TOPK)
+                state["join_form"] = "host records uploaded (dmnd_join_blocks_device_host)"
             else:
                 part, full = multigpu.query_range_join(mine, w.n_queries, coll_device, own=True)
             q = part["query"]
@@ -573,10 +583,11 @@ def main():
         prefetched: per block the future (or the result) of its seed stage."""
         torch.cuda.set_device(local_rank)
         t_b = time.perf_counter()
-        parts, n_hits, seed_ms, ext_sum = [], 0, None, None
+        parts, n_hits, seed_ms, ext_sum, alt_flags = [], 0, None, None, []
         for b in range(NB):
             got = prefetched[b] if prefetched is not None else seed_stage(b)
             hits, ms, alt = got.result() if hasattr(got, "result") else got
+            alt_flags.append(bool(alt))
             ec = alt_ext_ctxs[e] if alt else ext_ctxs[e][b]
             m, _ = ec.extend(w.qd, alt_host[0] if alt else w.blocks[b][2], hits, threads=ext_threads)
             parts.append(m)
@@ -591,19 +602,23 @@ def main():
             host_r2_ms = st["round2_swipe_kernel_ms"] - dv["round2_sweep_kernel_ms"]
             st["round2_cells_swept"] = dv["round2_cells_swept_again"] + ((st["round2_cells"] - dv["round2_cells"]) if host_r2_ms > 1e-6 else 0.0)
             ext_sum = dict(st) if ext_sum is None else {k: ext_sum[k] + st[k] for k in st}
+        joined = None
+        if set_join_ctxs is not None and not any(alt_flags) and all(ext_ctxs[e][b].extend_records_device()[1] >= 0 for b in range(NB)):
+            joined = set_join_ctxs[e].join_contexts_device([ext_ctxs[e][b] for b in range(NB)], [w.blocks[b][0] for b in range(NB)], multigpu.TOPK, max_query=max(w.n_queries - 1, 1))
         state.setdefault("ext_wall", []).append((time.perf_counter() - t_b) * 1e3)
-        return dict(parts=parts, hits=n_hits, seed_ms=seed_ms, ext=ext_sum, ext_wall_ms=(time.perf_counter() - t_b) * 1e3)
+        return dict(parts=parts, joined=joined, hits=n_hits, seed_ms=seed_ms, ext=ext_sum, ext_wall_ms=(time.perf_counter() - t_b) * 1e3)
 
     def step(prefetched=None, done=None):
         """One batch: its extension (here, or already done on an extension thread), then the join of its records."""
         r = done if done is not None else extend_batch(0, prefetched)
         parts = r["parts"]
+        joined_in_hbm = r.get("joined")
         state.update(hits=r["hits"], matches=np.concatenate(parts) if NB > 1 else parts[0], seed_ms=r["seed_ms"], ext=r["ext"], ext_wall_ms=r["ext_wall_ms"])
 
         def do_finish():
             torch.cuda.set_device(local_rank)
             t_f = time.perf_counter()
-            state["records"] = finish(parts)
+            state["records"] = finish(dict(joined=joined_in_hbm) if joined_in_hbm is not None else parts)
             state["finish_wall_ms"] = (time.perf_counter() - t_f) * 1e3
         if pipeline and (world > 1 or NB > 1):
             # the exchange + join of this batch's records runs on its own thread while the next batch is extended (the ranks'
@@ -930,7 +945,7 @@ def main():
             # what the exchange of the match records was (per step and rank 0's share; N = 1: no exchange, the fields say so): the
             # SCALE record's own evidence that the collective ran over N ranks
             "rccl": {"world_size": (dist.get_world_size() if world > 1 else 1), "backend": (dist.get_backend() if world > 1 else None),
-                     "transport": (xstats["transport"] if world > 1 else "none (one rank: the blocks are joined on the device, dmnd_join_blocks_device)"),
+                     "transport": (xstats["transport"] if world > 1 else "none (one rank; the blocks' records: %s)" % state.get("join_form", "one block, no join")),
                      "collectives_per_step": xstats["collectives"] / max(args.steps, 1),
                      "bytes_exchanged_per_step": (xstats["bytes_sent"] + xstats["bytes_received"]) / max(args.steps, 1),
                      "exchange_ms": xstats["exchange_s"] * 1e3 / max(args.steps, 1),
@@ -1024,7 +1039,7 @@ def main():
             tids = ["t%d" % i for i in range(w.n_db)]
             text = hip.format_tab(state["records"], qids, tids, w.source_lens)
             masked_text = hip.format_tab(masked_records, qids, tids, w.source_lens) if masked_records is not None else None
-            for c in (ctxs_seed if ctxs_seed is not ctxs else []) + [x for cs in ext_ctxs for x in cs] + (alt_ext_ctxs + [seed_ctx_alt] if alternate else []) + ([join_ctx] if join_ctx else []):
+            for c in (ctxs_seed if ctxs_seed is not ctxs else []) + [x for cs in ext_ctxs for x in cs] + (alt_ext_ctxs + [seed_ctx_alt] if alternate else []) + ([join_ctx] if join_ctx else []) + (set_join_ctxs or []):
                 c.close()
             closed = True
             torch.cuda.empty_cache()
@@ -1053,9 +1068,15 @@ def main():
                 out["parity_checked"] = ours == ref_md5
                 out["parity"] = {"records_md5": ours, "reference_output_md5": ref_md5, "lines": text.count("\n"),
                                  "note": "reference run on rank 0 with the database cut into the same %d blocks (-b)" % w.n_blocks_total}
+        # the last thing on the line (what a tail of the output shows): the figures of this run in one place
+        out["summary"] = {"ms_per_step": out["ms_per_step"], "value": out["value"], "unit": out["unit"], "parity_checked": out.get("parity_checked"),
+                          "masked_step_ms_per_step": (out.get("masked_step") or {}).get("ms_per_step"), "host_cpu_ms_per_step": out["host_cpu_ms_per_step"],
+                          "roofline_frac": out["roofline"]["frac"], "roofline_traffic_bytes": out["roofline"].get("traffic"),
+                          "sweep_valu_issue_frac": out["sweep_roofline"].get("frac"), "sweep_lane_use": out["sweep_roofline"].get("lane_use"),
+                          "e2e_speedup_min": (out.get("e2e") or {}).get("speedup_min"), "rccl_world_size": out["rccl"]["world_size"]}
         print(json.dumps(out))
     if not closed:
-        for c in (ctxs_seed if ctxs_seed is not ctxs else []) + [x for cs in ext_ctxs for x in cs] + (alt_ext_ctxs + [seed_ctx_alt] if alternate else []) + ([join_ctx] if join_ctx else []):
+        for c in (ctxs_seed if ctxs_seed is not ctxs else []) + [x for cs in ext_ctxs for x in cs] + (alt_ext_ctxs + [seed_ctx_alt] if alternate else []) + ([join_ctx] if join_ctx else []) + (set_join_ctxs or []):
             c.close()
     if world > 1:
         dist.destroy_process_group()

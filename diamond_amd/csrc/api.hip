@@ -337,7 +337,7 @@ extern "C" void dmnd_destroy(dmnd_ctx* c)
 	c->stage_h.release(); c->ends_h.release(); c->stage_d.release();
 	c->xd_hits.release(); c->xd_out.release(); c->xd_host.release();
 	c->plan_dev.release(); c->plan_host.release();
-	c->ext_dev.release(); c->ext_trace.release(); c->ext_host.release();
+	c->ext_dev.release(); c->ext_trace.release(); c->ext_host.release(); c->ext_ev.release();
 	for (DevBuf& b : c->ext_trace_more) b.release();
 	if (c->plan_tmp) { (void)hipFree(c->plan_tmp); c->plan_tmp = nullptr; c->plan_tmp_bytes = 0; }
 	for (int i = 0; i < 2; ++i) { c->up_stage[i].release(); if (c->up_ev[i]) (void)hipEventDestroy(c->up_ev[i]); c->up_ev[i] = nullptr; }

@@ -107,6 +107,8 @@ struct dmnd_ctx {
 	void* plan_tmp = nullptr; size_t plan_tmp_bytes = 0;      // rocPRIM scan scratch of the planner
 	dmnd::DevBuf ext_dev, ext_trace;          // device half of dmnd_extend behind the planner (extend_kernels.hip): work arrays, kept traces
 	std::vector<dmnd::DevBuf> ext_trace_more; // ... the kept traces of the ranking chunks behind the first
+	dmnd::DevBuf ext_ev;                      // the host's (e-value, bit score) pairs on their way into the device copy of the records
+	const dmnd_match* ext_records_dev = nullptr; int64_t ext_records_n = -1;      // the records of the last dmnd_extend where they lie in HBM (complete: host e-values in); n = -1: part of them only exists on the host
 	dmnd::PinBuf ext_host;                    // ... its counters, records and query states on the host
 	double ext_dev_stats[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };      // of the last dmnd_extend: queries extended on the device, of them redone by the host (ambiguous e-value order / 16-bit saturation), items, records, band diagonals x steps, wavefront diagonals x steps
 	std::vector<int32_t> h_bias_ids;           // block sequence ids of the queries with seed hits (Hauser bias of one dmnd_extend call)

@@ -106,4 +106,9 @@ hipError_t launch_ext_rewalk(const ExtArgs& a, uint32_t n_items, uint32_t n_kept
 // after the walk: the records
 hipError_t launch_ext_records(const ExtArgs& a, uint32_t n_kept, hipStream_t st);
 
+// the host's (e-value, bit score) pairs into the records where they lie in HBM; records of a context gathered for a join with
+// their block-local target ids turned into database-wide ordinals
+hipError_t launch_ext_patch(dmnd_match* records, const double* ev_bits, uint32_t n, hipStream_t st);
+hipError_t launch_ext_gather(dmnd_match* dst, const dmnd_match* src, uint32_t n, uint32_t target_offset, hipStream_t st);
+
 }  // namespace dmnd

@@ -586,6 +586,39 @@ hipError_t launch_ext_rewalk(const ExtArgs& a, uint32_t n_items, uint32_t n_kept
 	return hipGetLastError();
 }
 
+namespace {
+// the host's e-value and bit score into the device copy of the records (two doubles per record, in record order)
+__global__ __launch_bounds__(256) void ext_patch_kernel(dmnd_match* records, const double* ev_bits, uint32_t n)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	records[i].evalue = ev_bits[2 * i]; records[i].bit_score = ev_bits[2 * i + 1];
+}
+// block-local target ids -> database-wide ordinals while the records are gathered for a join
+__global__ __launch_bounds__(256) void ext_gather_kernel(dmnd_match* dst, const dmnd_match* src, uint32_t n, uint32_t target_offset)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	dmnd_match m = src[i];
+	m.target += target_offset;
+	dst[i] = m;
+}
+}
+
+hipError_t launch_ext_patch(dmnd_match* records, const double* ev_bits, uint32_t n, hipStream_t st)
+{
+	if (n == 0) return hipSuccess;
+	hipLaunchKernelGGL(ext_patch_kernel, dim3((n + 255) / 256), dim3(256), 0, st, records, ev_bits, n);
+	return hipGetLastError();
+}
+
+hipError_t launch_ext_gather(dmnd_match* dst, const dmnd_match* src, uint32_t n, uint32_t target_offset, hipStream_t st)
+{
+	if (n == 0) return hipSuccess;
+	hipLaunchKernelGGL(ext_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dst, src, n, target_offset);
+	return hipGetLastError();
+}
+
 hipError_t launch_ext_records(const ExtArgs& a, uint32_t n_kept, hipStream_t st)
 {
 	if (n_kept == 0) return hipSuccess;

@@ -70,7 +70,7 @@ EXPORTS = ["dmnd_abi_version", "dmnd_last_error", "dmnd_default_params", "dmnd_c
            "dmnd_set_db_letters", "dmnd_upload_block", "dmnd_upload_cbs", "dmnd_banded_swipe",
            "dmnd_banded_swipe_host", "dmnd_banded_cols", "dmnd_evalue", "dmnd_bitscore", "dmnd_evalue_p",
            "dmnd_bitscore_p", "dmnd_evalue_batch", "dmnd_last_kernel_ms", "dmnd_seed_params_fast", "dmnd_seed_params_default", "dmnd_seed_search",
-           "dmnd_seed_hits", "dmnd_seed_kernel_ms", "dmnd_extend_plan", "dmnd_extend", "dmnd_extend_stats", "dmnd_extend_plan_stats", "dmnd_extend_device_stats", "dmnd_extend_reserve", "dmnd_format_tab", "dmnd_set_max_target_seqs",
+           "dmnd_seed_hits", "dmnd_seed_kernel_ms", "dmnd_extend_plan", "dmnd_extend", "dmnd_extend_stats", "dmnd_extend_plan_stats", "dmnd_extend_device_stats", "dmnd_extend_reserve", "dmnd_extend_records_device", "dmnd_join_contexts_device", "dmnd_format_tab", "dmnd_set_max_target_seqs",
            "dmnd_seed_params_sensitive", "dmnd_set_gapped_filter", "dmnd_gapped_filter", "dmnd_gapped_filter_ms",
            "dmnd_set_query_contexts", "dmnd_translate", "dmnd_format_tab_translated", "dmnd_mask_block", "dmnd_mask_kernel_ms", "dmnd_seed_params_preset", "dmnd_set_comp_based_stats",
            "dmnd_seed_params_set_index_chunks", "dmnd_join_blocks", "dmnd_set_sensitivity", "dmnd_touch_streams",
@@ -676,6 +676,28 @@ class Context:
         self.lib.dmnd_join_blocks_device_host.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_int64)]
         self._check(self.lib.dmnd_join_blocks_device_host(self.h, r.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(r.size), int(max_target_seqs), float(top_percent), ctypes.byref(n)))
         return r[:n.value]
+
+    def extend_records_device(self):
+        """(device pointer, n) of the last extend()'s records where they lie in HBM, or (0, -1) when part of them exists on the host only"""
+        ptr, n = ctypes.c_void_p(0), ctypes.c_int64(0)
+        self.lib.dmnd_extend_records_device.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64)]
+        self._check(self.lib.dmnd_extend_records_device(self.h, ctypes.byref(ptr), ctypes.byref(n)))
+        return (ptr.value or 0), n.value
+
+    def join_contexts_device(self, contexts, target_offsets, max_target_seqs=25, top_percent=-1.0, max_query=0):
+        """dmnd_join_contexts_device: the block join over the device-resident records of the contexts' last extend() (one context per
+        reference block, on this context's device); returns the joined records."""
+        n_ctx = len(contexts)
+        hs = (ctypes.c_void_p * n_ctx)(*[c.h for c in contexts])
+        offs = (ctypes.c_uint32 * n_ctx)(*[int(x) for x in target_offsets])
+        total = sum(max(c.extend_records_device()[1], 0) for c in contexts)
+        out = np.zeros(max(total, 1), dtype=MATCH_DTYPE)
+        n = ctypes.c_int64(0)
+        self.lib.dmnd_join_contexts_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_uint32, ctypes.c_void_p,
+                                                       ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
+        self._check(self.lib.dmnd_join_contexts_device(self.h, hs, offs, n_ctx, int(max_target_seqs), float(top_percent), ctypes.c_uint32(int(max_query)),
+                                                       out.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(out.size), ctypes.byref(n)))
+        return out[:n.value]
 
     def join_blocks_device_ptr(self, records_ptr, n, out_ptr, max_target_seqs=25, top_percent=-1.0, max_query=0):
         """dmnd_join_blocks_device on device pointers (e.g. torch tensors' data_ptr() on this context's device): n records at

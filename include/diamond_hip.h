@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DMND_ABI_VERSION 12      /* 2: dmnd_match.frame, seed parameters (ungapped filter, translated queries), dmnd_extend_plan(query_contexts); 3: seed_encoding; 4: output formats; 5: DMND_MAX_SHAPES 64; 6: dmnd_host_alloc, dmnd_share_block; 7: dmnd_set_max_hsps, several dmnd_match records per target, global ranking; 8: --comp-based-stats 2..5 (dmnd_cbs_*, dmnd_upload_matrices, dmnd_dp_target::cbs_off <= -2); dmnd_mask_block patches host_data in place (the full copy-back of ABI <= 6 only above 1/16 masked letters); 9: frameshift alignment (dmnd_set_frameshift, dmnd_frameshift_swipe, dmnd_match.read_begin / read_end: the record is 104 bytes), dmnd_set_context_motif_table, dmnd_copy_block; 10: dmnd_join_blocks_range (round 5); 11: dmnd_extend_plan_stats (round 6: device planner); 12: dmnd_extend_device_stats (round 6: culling, round 2 and records on the device) */
+#define DMND_ABI_VERSION 13      /* 2: dmnd_match.frame, seed parameters (ungapped filter, translated queries), dmnd_extend_plan(query_contexts); 3: seed_encoding; 4: output formats; 5: DMND_MAX_SHAPES 64; 6: dmnd_host_alloc, dmnd_share_block; 7: dmnd_set_max_hsps, several dmnd_match records per target, global ranking; 8: --comp-based-stats 2..5 (dmnd_cbs_*, dmnd_upload_matrices, dmnd_dp_target::cbs_off <= -2); dmnd_mask_block patches host_data in place (the full copy-back of ABI <= 6 only above 1/16 masked letters); 9: frameshift alignment (dmnd_set_frameshift, dmnd_frameshift_swipe, dmnd_match.read_begin / read_end: the record is 104 bytes), dmnd_set_context_motif_table, dmnd_copy_block; 10: dmnd_join_blocks_range (round 5); 11: dmnd_extend_plan_stats (round 6: device planner); 12: dmnd_extend_device_stats (round 6: culling, round 2 and records on the device); 13: dmnd_extend_reserve, dmnd_extend_records_device, dmnd_join_contexts_device, dmnd_join_ranks_plan */
 
 enum {
 	DMND_OK = 0,
@@ -599,6 +599,17 @@ int dmnd_extend_plan_stats(const dmnd_ctx* ctx, double out[3]);
  * round 2 (their round-1 sweep kept no trace rows), [8] device ms of those sweeps, [9] reserved; all 0 = every query took the host path (other modes: --max-hsps != 1, --top,
  * filters, matrix adjustment, --ext full, transcripts wanted, translated queries). */
 int dmnd_extend_device_stats(const dmnd_ctx* ctx, double out[10]);
+/* Round 6: the records of the last dmnd_extend where they lie in HBM, complete (the host's e-values and bit scores are written back
+ * into them): *records_dev is valid until the context's next dmnd_extend; *n = -1 (and NULL) when part of the records only exists on the
+ * host (queries that took the host path: other modes, or a query handed back). The records dmnd_extend returned are the same. */
+int dmnd_extend_records_device(const dmnd_ctx* ctx, const dmnd_match** records_dev, int64_t* n);
+/* The block join (dmnd_join_blocks_device: join_query of src/output/join_blocks.cpp:129-256, one record per (query, target)) over the
+ * device-resident records of several contexts' last dmnd_extend -- one context per reference block, all on join_ctx's device; the
+ * block-local target ids become database ordinals on the way (target_offset[k] = first sequence of context k's block). The
+ * records never leave HBM between round 2 and the join; the survivors come back in `out` (query order). A context without a complete
+ * device copy (dmnd_extend_records_device: n = -1) is refused: join the host records then (dmnd_join_blocks_device_host). */
+int dmnd_join_contexts_device(dmnd_ctx* join_ctx, dmnd_ctx* const* ctx, const uint32_t* target_offset, int n_ctx, int max_target_seqs, double top_percent,
+	uint32_t max_query, dmnd_match* out, int64_t cap, int64_t* n_out);
 /* Optional: the first-call allocations of dmnd_extend made ahead of it, for about n_hits_hint seed hits (device work arrays of the
  * x-drop stage, planner and device half; the page-locked result buffer). A driver calls it beside its upload / masking phase, as
  * dmnd_seed_reserve; a hint that is too small costs nothing but the growth inside the call. The query block must be uploaded. */

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), name
     assert declared == set(hip.EXPORTS)
-    assert lib.dmnd_abi_version() == 12
+    assert lib.dmnd_abi_version() == 13
 
 
 def test_struct_layouts_match_header():
