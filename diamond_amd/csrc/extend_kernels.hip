@@ -99,16 +99,26 @@ __global__ __launch_bounds__(64) void ext_mark_kernel(ExtArgs a)
 	}
 }
 
-// the items of the current iteration: the bands of the passing groups of every active query's window
+// the items of the current iteration: the bands of the passing groups of every active query's window. Every group gets its count
+// (0 outside the windows) and a cleared `kept` flag here, and workgroup 0 resets the iteration's counters -- seven memset launches per
+// iteration otherwise (each a kernel of its own on the stream)
 __global__ __launch_bounds__(64) void ext_window_kernel(ExtArgs a)
 {
 	const uint32_t q = blockIdx.x, lane = threadIdx.x;
-	if (!a.q_active[q]) return;
-	const uint32_t g0 = a.queries[q].group_begin, i0 = a.q_i0[q], i1 = a.q_i1[q];
-	for (uint32_t w = i0 + lane; w < i1; w += 64) {
+	const uint32_t g0 = a.queries[q].group_begin, g1 = a.queries[q + 1].group_begin;
+	const bool active = a.q_active[q] != 0;
+	const uint32_t i0 = active ? a.q_i0[q] : 0, i1 = active ? a.q_i1[q] : 0;
+	for (uint32_t w = lane; w < g1 - g0; w += 64) {
 		const uint32_t g = a.gorder[g0 + w];
-		const PlanGroup grp = a.groups[g];
-		a.cnt[g] = grp.pass ? grp.n_bands : 0u;
+		uint32_t n = 0;
+		if (w >= i0 && w < i1) { const PlanGroup grp = a.groups[g]; n = grp.pass ? grp.n_bands : 0u; }
+		a.cnt[g] = n;
+		a.kept[g] = 0;
+	}
+	if (q == 0 && lane < EXT_CLASSES) { a.ctr->class_count[lane] = 0; a.ctr->class_max_steps[lane] = 0; }
+	if (q == 0 && lane == 0) {
+		a.cnt[a.n_groups] = 0; a.kept[a.n_groups] = 0;
+		a.ctr->n_items = 0; a.ctr->n_active = 0; a.ctr->n_resweep = 0; a.ctr->total_rows = 0; a.ctr->cells2 = 0;
 	}
 }
 
@@ -525,13 +535,9 @@ hipError_t order_items(const ExtArgs& a, hipStream_t st)
 
 hipError_t launch_ext_prepare(const ExtArgs& a, hipStream_t st)
 {
-	hipError_t e = reset_iteration(a, st);
-	if (e != hipSuccess) return e;
-	e = hipMemsetAsync(a.cnt, 0, ((size_t)a.n_groups + 1) * sizeof(uint32_t), st);
-	if (e != hipSuccess) return e;
 	const uint32_t n_left = a.item_cap - a.item_base;
 	size_t need_a = 0;
-	e = rocprim::exclusive_scan(nullptr, need_a, a.cnt, a.item_off, 0u, (size_t)a.n_groups + 1, rocprim::plus<uint32_t>(), st);
+	hipError_t e = rocprim::exclusive_scan(nullptr, need_a, a.cnt, a.item_off, 0u, (size_t)a.n_groups + 1, rocprim::plus<uint32_t>(), st);
 	if (e != hipSuccess) return e;
 	e = ensure_tmp(a.scan_tmp, a.scan_tmp_bytes, need_a);
 	if (e != hipSuccess) return e;
@@ -546,17 +552,12 @@ hipError_t launch_ext_prepare(const ExtArgs& a, hipStream_t st)
 hipError_t launch_ext_append(const ExtArgs& a, uint32_t n_items, bool kept, int64_t rel, hipStream_t st)
 {
 	if (n_items > 0 && (!kept || rel != 0)) hipLaunchKernelGGL(ext_rebase_kernel, dim3((n_items + 255) / 256), dim3(256), 0, st, a, n_items, rel, kept ? 1 : 0);
-	hipError_t e = hipMemsetAsync(&a.ctr->n_active, 0, sizeof(uint32_t), st);
-	if (e != hipSuccess) return e;
-	e = hipMemsetAsync(&a.ctr->n_resweep, 0, sizeof(uint32_t), st);
-	if (e != hipSuccess) return e;
-	e = hipMemsetAsync(&a.ctr->cells2, 0, sizeof(unsigned long long), st);      // (the round-2 list below is rebuilt behind every iteration)
-	if (e != hipSuccess) return e;
+	// (n_active, n_resweep, cells2 and the kept flags were cleared by this iteration's ext_window_kernel: the round-2 list below is
+	// rebuilt behind every iteration)
+	hipError_t e = hipSuccess;
 	const size_t lds_append = ((size_t)a.k + 2 * (size_t)a.chunk_size) * sizeof(SelSlot), lds_final = ((size_t)a.k + (size_t)a.chunk_size) * sizeof(SelSlot);
 	hipLaunchKernelGGL(ext_append_kernel, dim3(a.n_queries), dim3(64), lds_append, st, a);
 	// speculatively (the host only uses it when no query is left ranking): final culling, record slots, the round-2 list
-	e = hipMemsetAsync(a.kept, 0, ((size_t)a.n_groups + 1) * sizeof(uint32_t), st);
-	if (e != hipSuccess) return e;
 	size_t need = 0;
 	e = rocprim::exclusive_scan(nullptr, need, a.kept, a.kept_pos, 0u, (size_t)a.n_groups + 1, rocprim::plus<uint32_t>(), st);
 	if (e != hipSuccess) return e;

@@ -94,3 +94,27 @@ def test_queries_ranked_in_chunks_equal_the_reference_binary(tmp_path, arena_mb)
         assert any("scores only" in l for l in chunks)
     assert open(tmp_path / "hip.tsv", "rb").read() == open(tmp_path / "ref.tsv", "rb").read()
     assert os.path.getsize(tmp_path / "ref.tsv") > 10000
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref/diamond missing")
+@pytest.mark.parametrize("extra", [["-k", "1"], ["-k", "5"], ["-k", "200"], ["--comp-based-stats", "0"], ["-e", "1e-20"], ["--sensitive"]],
+                         ids=["k1", "k5", "k200", "cbs0", "e1e-20", "sensitive"])
+def test_device_extension_options_equal_the_reference_binary(tmp_path, extra):
+    """The options that change what the device half decides -- -k below and above the ranking chunk (with -k 200 the chunk is 224 and
+    a first chunk may have to grow: those queries stay on the host), no composition bias, a strict e-value cutoff, the gapped filter of
+    --sensitive -- on queries with several ranking chunks and on queries with none: byte-identical to the reference binary."""
+    db, doff, q, qoff = synth.generate(40, members=60, queries=300, seed=23, sub=(0.1, 0.4), qsub=(0.1, 0.4))
+    synth.write_fasta(str(tmp_path / "db.faa"), "t", db, doff)
+    synth.write_fasta(str(tmp_path / "q.faa"), "q", q, qoff)
+    assert subprocess.run([REF, "makedb", "--in", str(tmp_path / "db.faa"), "-d", str(tmp_path / "db")], capture_output=True).returncode == 0
+    common = ["blastp", "--algo", "0", "--masking", "0", "--motif-masking", "0", "-q", str(tmp_path / "q.faa"), "-d", str(tmp_path / "db.dmnd")] + extra
+    if "--sensitive" not in extra:
+        common.append("--fast")
+    r = subprocess.run([REF] + common + ["-o", str(tmp_path / "ref.tsv"), "-p", "4"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1000:]
+    cli = os.path.join(os.path.dirname(HERE), "diamond_amd", "diamond-hip")
+    h = subprocess.run([cli] + common + ["-o", str(tmp_path / "hip.tsv")], capture_output=True, text=True, timeout=600, env=dict(os.environ, DMND_TRACE="1"))
+    assert h.returncode == 0, h.stderr[-1000:]
+    assert "dmnd_extend (device half)" in h.stderr
+    assert open(tmp_path / "hip.tsv", "rb").read() == open(tmp_path / "ref.tsv", "rb").read()
+    assert os.path.getsize(tmp_path / "ref.tsv") > 1000
