@@ -46,8 +46,7 @@ static int sync_spin_us()
 {
 	// Poll for up to DMND_SYNC_SPIN_US microseconds (default 150) before the interrupt-driven wait: a short kernel's count is back
 	// before a sleeping thread would have been woken; the CPU time this can burn is bounded per wait, unlike DMND_SPIN_SYNC
-	static const int v = [] { const char* e = std::getenv("DMND_SYNC_SPIN_US"); return e ? std::max(0, atoi(e)) : 150; }();
-	return v;
+	return tuning().sync_spin_us;
 }
 
 hipError_t dmnd::wait_event(hipEvent_t ev)
@@ -254,7 +253,7 @@ extern "C" int dmnd_init(int device)
 		side_rc[2] = hipSetDevice(device);
 		int least = 0, greatest = 0;
 		(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-		if (std::getenv("DMND_NO_STREAM_PRIORITY")) least = 0;
+		if (tuning().no_stream_priority) least = 0;
 		for (int prio : { least, 0 }) {                   // dmnd_create's stream, and the reference block's upload lane
 			hipStream_t s = nullptr;
 			if (side_rc[2] == hipSuccess) side_rc[2] = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio);
@@ -316,7 +315,7 @@ extern "C" dmnd_ctx* dmnd_create(int device, const dmnd_params* params)
 	// first and the seed kernels fill the gaps.
 	int prio_least = 0, prio_greatest = 0;
 	(void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-	if (std::getenv("DMND_NO_STREAM_PRIORITY")) prio_least = prio_greatest = 0;
+	if (tuning().no_stream_priority) prio_least = prio_greatest = 0;
 	if (take_stream(&c->stream, device, prio_least) != hipSuccess
 		|| hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev2) != hipSuccess
 		|| c->matrix.ensure(32 * 32) != DMND_OK
@@ -1248,7 +1247,7 @@ static int aux_priority()
 {
 	int least = 0, greatest = 0;
 	(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-	return std::getenv("DMND_NO_STREAM_PRIORITY") ? 0 : greatest;
+	return tuning().no_stream_priority ? 0 : greatest;
 }
 
 dmnd_ctx* aux_context(dmnd_ctx* c, int k, int split)

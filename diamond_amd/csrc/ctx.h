@@ -1,5 +1,6 @@
 // ctx.h -- shared internals of libdiamond_hip.so: error plumbing, device buffers, the context object.
 #pragma once
+#include "tuning.h"
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
@@ -31,8 +32,7 @@ int fail(int code, const std::string& msg);      // sets dmnd_last_error(), retu
 // alone does not stop the runtime from spinning); DMND_SPIN_SYNC=1 restores the spinning wait (lowest latency on an idle host).
 inline bool spin_sync()
 {
-	static const bool v = [] { const char* e = std::getenv("DMND_SPIN_SYNC"); return e && e[0] == '1'; }();
-	return v;
+	return dmnd::tuning().spin_sync;
 }
 
 // One interrupt-driven event per STREAM (created on first use, released by forget_stream when the stream's owner goes away).

@@ -1740,14 +1740,13 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 	// Default: one range, host work in min(threads, 8) fixed slices, ONE launch per GPU phase (extend_range). DMND_EXTEND_SPLIT /
 	// DMND_EXTEND_RUNNERS > 1 select the older layout of independent runners with their own streams and small launches.
 	int split = 1, runners = 1;
-	if (const char* e = std::getenv("DMND_EXTEND_SPLIT")) split = std::max(1, std::min(64, std::atoi(e)));
-	if (const char* e = std::getenv("DMND_EXTEND_RUNNERS")) runners = std::max(1, std::atoi(e));
+	split = tuning().extend_split; runners = tuning().extend_runners;
 	if (transcript || qr_run.size() < (size_t)split * 2) split = 1;
 	runners = std::min(std::min(runners, split), (int)MAX_POOLS);
 	std::vector<std::vector<dmnd_match>> parts((size_t)split);
 	std::vector<int> rcs((size_t)split, DMND_OK);
 	std::vector<std::string> errs((size_t)split);
-	static const int team = [] { const char* e = std::getenv("DMND_EXTEND_TEAM"); return e ? std::max(1, std::atoi(e)) : 8; }();
+	const int team = tuning().extend_team;
 	if (on_device && qr_run.empty()) {
 		if (bias_pending) HIP_TRY(sync_stream(c->stream));      // every query was extended on the device
 	}
@@ -1792,7 +1791,7 @@ extern "C" int dmnd_extend(dmnd_ctx* c, const int8_t* qdata, const int8_t* tdata
 		}
 		std::vector<std::thread> th;
 		int sub_threads = std::max(1, std::min(threads / runners, (int)(n_hits / runners / 8192)));
-		if (const char* e = std::getenv("DMND_EXTEND_SUB_THREADS")) sub_threads = std::max(1, std::atoi(e));
+		if (tuning().extend_sub_threads > 0) sub_threads = tuning().extend_sub_threads;
 		std::atomic<int> next_sub(0);
 		std::vector<std::array<double, 12>> acc((size_t)runners);
 		for (auto& x : acc) x.fill(0.0);

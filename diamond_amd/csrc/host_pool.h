@@ -12,6 +12,7 @@
 #include <pthread.h>
 #include <thread>
 #include <vector>
+#include "tuning.h"
 
 namespace dmnd {
 
@@ -79,8 +80,7 @@ private:
 	// loops, short enough not to eat a CPU quota with dozens of idle spinning workers (DMND_POOL_SPINS overrides)
 	static int spins()
 	{
-		static const int v = [] { const char* e = std::getenv("DMND_POOL_SPINS"); return e ? std::max(0, std::atoi(e)) : 600; }();
-		return v;
+		return tuning().pool_spins;
 	}
 	void grow(int workers)
 	{

@@ -327,7 +327,7 @@ static SeedSizes seed_sizes(const dmnd_ctx* c, const SeedParams& sp, int64_t nq_
 	// reference positions probe the table and the probe chains are what costs (most query seeds are distinct: two slots per
 	// position = 36 % load). Measured on C3 (16 shapes): stream + filter 189 / 124 / 116 / 115 ms at 1 / 2 / 4 / 8 slots per position
 	// (DMND_SEED_SLOTS_X8 = 8 / 16 / 32 / 64, slots per position in eighths).
-	const uint64_t slots_x8 = [&] { const char* e = getenv("DMND_SEED_SLOTS_X8"); return (uint64_t)(e ? std::min(64, std::max(8, atoi(e))) : (seed_stream_can_fuse(sp) ? 32 : 16)); }();
+	const uint64_t slots_x8 = (uint64_t)(tuning().seed_slots_x8 ? tuning().seed_slots_x8 : (seed_stream_can_fuse(sp) ? 32 : 16));
 	z.slots = 1024;
 	while (z.slots * 8 < (uint64_t)nq_pos * slots_x8) z.slots <<= 1;
 	// slot numbers are 32-bit in the position lists and the joined-position records (LIST_END = all ones): a query block above 2^30
@@ -345,7 +345,7 @@ static SeedSizes seed_sizes(const dmnd_ctx* c, const SeedParams& sp, int64_t nq_
 	int bm1_log2 = 24;
 	if (nq_pos > ((int64_t)1 << 24))
 		while (bm1_log2 < 27 && ((uint64_t)1 << bm1_log2) < (uint64_t)nq_pos * 4) ++bm1_log2;
-	if (const char* e = getenv("DMND_SEED_BITMAP1_LOG2")) bm1_log2 = std::min(27, std::max(15, atoi(e)));      // word index = 22 bits of hash a
+	if (tuning().seed_bitmap1_log2) bm1_log2 = tuning().seed_bitmap1_log2;      // word index = 22 bits of hash a
 	uint64_t bm1_words = ((uint64_t)1 << bm1_log2) / 32;
 	if (bm1_words > bm_words) bm1_words = bm_words;
 	uint32_t bm1_k3 = 0;
@@ -362,12 +362,12 @@ static SeedSizes seed_sizes(const dmnd_ctx* c, const SeedParams& sp, int64_t nq_
 	}
 	// Short seeds by class (round 5 sweep on C3, tools/gpu_r05b.sh): 4 MB / three bits -- half a megabyte per XCD -- instead of 2 MB / two:
 	// stream + filter 103.9 -> 102.6 ms per 16 shapes (8 MB: 103.4; fewer false positives = fewer slot lines fetched over the fabric)
-	if (!long_seeds && bm1_log2 == 24 && !getenv("DMND_SEED_BITMAP1_LOG2") && bm_words >= 2 * bm1_words) { bm1_words *= 2; bm1_k3 = 1u; }
-	if (const char* e = getenv("DMND_SEED_BM1_KB")) bm1_words = (uint64_t)std::min(65536, std::max(4, atoi(e))) * 256;       // experiment knobs
-	if (const char* e = getenv("DMND_SEED_BM1_K")) bm1_k3 = atoi(e) == 3 ? 1u : 0u;
-	if (const char* e = getenv("DMND_SEED_STREAM_NT")) stream_nt = atoi(e) != 0;
+	if (!long_seeds && bm1_log2 == 24 && !tuning().seed_bitmap1_log2 && bm_words >= 2 * bm1_words) { bm1_words *= 2; bm1_k3 = 1u; }
+	if (tuning().seed_bm1_kb) bm1_words = (uint64_t)tuning().seed_bm1_kb * 256;       // (tuning.h: the sweeps' overrides)
+	if (tuning().seed_bm1_k) bm1_k3 = tuning().seed_bm1_k == 3 ? 1u : 0u;
+	if (tuning().seed_stream_nt >= 0) stream_nt = tuning().seed_stream_nt != 0;
 	int probe_policy = 0;
-	if (const char* e = getenv("DMND_SEED_PROBE_POLICY")) probe_policy = atoi(e);
+	if (tuning().seed_probe_policy >= 0) probe_policy = tuning().seed_probe_policy;
 	// The fused pipeline finishes a shape before it starts the next one: its table, lists and bitmaps are ONE shape's, reused
 	// (64 shapes of --ultra-sensitive would otherwise hold 8 GB of tables for a 10k-query block)
 	bool fused = seed_stream_can_fuse(sp);

@@ -21,6 +21,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
 #include "seed_kernels.h"
+#include "tuning.h"
 
 namespace dmnd {
 
@@ -1663,8 +1664,7 @@ hipError_t launch_seed_collect(const SeedArgs& a, int64_t n_matched, hipStream_t
 	if (n_matched >= folded_from) {
 		const uint64_t words = (a.slot_mask + 1) / 32;
 		uint32_t* fold = a.need_bits + words;              // (seed_api.hip sizes the map's buffer for it)
-		const char* fold_env = getenv("DMND_SEED_NEED_FOLD_LOG2");
-		const uint32_t fold_words = 1u << std::min(15, std::max(8, fold_env ? atoi(fold_env) : 13));      // <= SEED_NEED_FOLD_WORDS
+		const uint32_t fold_words = 1u << std::min(15, std::max(8, tuning().seed_need_fold_log2 ? tuning().seed_need_fold_log2 : 13));      // <= SEED_NEED_FOLD_WORDS
 		hipLaunchKernelGGL(seed_need_fold_kernel, dim3(fold_words / 256), dim3(256), 0, st, (const uint32_t*)a.need_bits, words, fold, fold_words);
 		const unsigned tiles = blocks_for(n_matched, 256 * 16);
 		const unsigned per_cu = std::max(1u, std::min(4u, (150u * 1024u) / (fold_words * 4u + 64u)));
