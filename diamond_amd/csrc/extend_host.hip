@@ -627,7 +627,7 @@ static int plan_on_device(dmnd_ctx* c, const HostCfg& h, int64_t n_hits, bool gf
 		o_segs = align(o_queries + (n + 1) * sizeof(PlanQuery)), o_slots = align(o_segs + n * 4 * sizeof(int32_t)),
 		o_count = align(o_slots + n * sizeof(PlanBand)), o_off = align(o_count + (n + 1) * sizeof(uint32_t)),
 		o_bands = align(o_off + (n + 1) * sizeof(uint32_t)), o_counters = align(o_bands + n * sizeof(PlanBand)),
-		o_chain = align(o_counters + sizeof(PlanCounters)), bytes = o_chain + (n / 2 + 1) * sizeof(uint32_t);
+		o_chain = align(o_counters + sizeof(PlanCounters)), bytes = o_chain + (n + 2) * sizeof(uint32_t);      // (both chaining lists, and a small group listed again)
 	TraceLaps tr("dmnd_extend (planner)");
 	if (int rc = c->plan_dev.ensure(bytes)) return rc;
 	tr.lap("work arrays");
@@ -641,12 +641,13 @@ static int plan_on_device(dmnd_ctx* c, const HostCfg& h, int64_t n_hits, bool gf
 	a.gf_flags = gf_on ? c->gf_flags.as<uint8_t>() : nullptr;
 	a.xd = c->xd_out.as<XdropSeg>();
 	a.gap_open = h.S.gap_open; a.gap_extend = h.S.gap_extend; a.band_fast = h.band_mode_fast;
+	a.small_segs = n_hits >= ((int64_t)1 << 18) ? 4 : 0;
 	a.tgt = reinterpret_cast<uint32_t*>(d + o_tgt); a.heads = reinterpret_cast<uint64_t*>(d + o_heads); a.head_scan = reinterpret_cast<uint64_t*>(d + o_scan);
 	a.groups = reinterpret_cast<PlanGroup*>(d + o_groups); a.queries = reinterpret_cast<PlanQuery*>(d + o_queries);
 	a.segs = reinterpret_cast<int32_t*>(d + o_segs); a.band_slots = reinterpret_cast<PlanBand*>(d + o_slots);
 	a.band_count = reinterpret_cast<uint32_t*>(d + o_count); a.band_off = reinterpret_cast<uint32_t*>(d + o_off);
 	a.bands = reinterpret_cast<PlanBand*>(d + o_bands); a.counters = reinterpret_cast<PlanCounters*>(d + o_counters);
-	a.chain_list = reinterpret_cast<uint32_t*>(d + o_chain);
+	a.chain_list = reinterpret_cast<uint32_t*>(d + o_chain); a.chain_cap = (uint32_t)(n + 2);
 	a.scan_tmp = &c->plan_tmp; a.scan_tmp_bytes = &c->plan_tmp_bytes;
 	HIP_TRY(launch_plan(a, c->stream));
 	tr.lap("launched");

@@ -31,7 +31,7 @@ struct PlanGroup {             // the seed hits of one (query, target) pair = Se
 };
 struct PlanBand { int32_t d_begin, d_end; };
 struct PlanQuery { uint32_t query, group_begin, hit_begin; };      // one per query that has hits, in hit order; one sentinel entry behind the last
-struct PlanCounters { uint32_t n_groups, n_queries, n_bands, unsorted, n_on_host, n_chain, pad[2]; };      // n_chain: groups with more than one segment (plan_chain_list_kernel)
+struct PlanCounters { uint32_t n_groups, n_queries, n_bands, unsorted, n_on_host, n_chain, n_chain_big, pad; };      // n_chain / n_chain_big: groups with two to PLAN_SMALL_SEGS / more segments (plan_chain_list_kernel)
 
 struct PlanArgs {
 	const int8_t* qblock; const int8_t* tblock;
@@ -42,6 +42,7 @@ struct PlanArgs {
 	const uint8_t* gf_flags;       // gapped filter flag per hit, or NULL (filter off)
 	const XdropSeg* xd;            // x-drop extension of every hit (xdrop_seg_kernel)
 	int gap_open, gap_extend, band_fast;
+	int small_segs;                // groups with at most this many segments are chained with the small workspace (0: none; plan_kernels.hip)
 	// work and output arrays, all in HBM, sized for n_hits entries (+ 1 where a sentinel follows)
 	uint32_t* tgt;                 // target of every hit
 	uint64_t* heads;               // group head flag | query head flag << 32, then their inclusive scan
@@ -50,7 +51,7 @@ struct PlanArgs {
 	PlanQuery* queries;
 	int32_t* segs;                 // 4 ints per hit slot: the sorted segments of a multi-segment group, from its first hit slot on
 	PlanBand* band_slots;          // bands of a group, from its first hit slot on
-	uint32_t* chain_list;          // the groups that need chaining (at most one per two hits)
+	uint32_t* chain_list; uint32_t chain_cap;      // the groups that need chaining (at most one per two hits): small ones from the front, the others from the back
 	uint32_t* band_count;          // per group, then its exclusive scan in band_off
 	uint32_t* band_off;
 	PlanBand* bands;               // dense

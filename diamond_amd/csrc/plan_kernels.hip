@@ -169,44 +169,61 @@ __global__ __launch_bounds__(64) void plan_segments_kernel(PlanArgs a)
 	a.groups[g] = grp;
 }
 
-typedef ChainWorkspaceT<FixedChainPolicy, PLAN_MAX_SEGS, 96, 16> DevChain;
-
 // Everything a lane's chaining works on, in LDS: in private memory this was 6 KB of scratch per lane (one lane per group, 64 groups a
-// wavefront, most of them with nothing to chain). Now plan_chain_list_kernel lists the groups that need chaining and
-// plan_chain_kernel takes PLAN_CHAIN_LANES of them per workgroup.
-enum { PLAN_CHAIN_LANES = 8 };
-struct ChainLds {
-	DevChain ws;
-	Seg sg[PLAN_MAX_SEGS];
-	FixedVec<Chain, 16> chains;
+// wavefront, most of them with nothing to chain). plan_chain_list_kernel lists the groups that need chaining -- those with at most
+// PLAN_SMALL_SEGS segments from the front of the list, the others from its back -- and two instantiations of plan_chain_kernel take
+// them: a 1 KB workspace for the small ones (most: two or three segments; as many lanes of a workgroup as 48 KB hold), the
+// 6 KB workspace for the rest and for a small one whose links did not fit (it is appended to the other list). A call with few
+// hits (PlanArgs::small_segs = 0) uses the large form only: each kernel's time is the one longest chain in it (~0.1 ms: the junction
+// search reads letters one dependent load at a time), and two kernels would pay that twice.
+enum { PLAN_SMALL_SEGS = 4 };
+template<int NODES, int LINKS, int CHAINS>
+struct ChainLdsT {
+	ChainWorkspaceT<FixedChainPolicy, NODES, LINKS, CHAINS> ws;
+	Seg sg[NODES];
+	FixedVec<Chain, CHAINS> chains;
 };
+template<int NODES, int LINKS, int CHAINS>
+struct ChainLanes { enum { bytes = (int)sizeof(ChainLdsT<NODES, LINKS, CHAINS>), fit = 48 * 1024 / bytes, value = fit > 64 ? 64 : fit }; };
 
 __global__ __launch_bounds__(256) void plan_chain_list_kernel(PlanArgs a)
 {
+	__shared__ uint32_t n_small, n_big, base_small, base_big;
+	if (threadIdx.x == 0) { n_small = 0; n_big = 0; }
+	__syncthreads();
 	const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-	const bool need = g < a.counters->n_groups && a.groups[g].n_bands == PLAN_NEED_CHAIN;
-	// one atomic per wavefront that has any
-	const unsigned long long m = __ballot(need);
-	if (m == 0) return;
-	const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
-	uint32_t base = 0;
-	if (lane == leader) base = atomicAdd(&a.counters->n_chain, (uint32_t)__popcll(m));
-	base = __shfl(base, leader);
-	if (need) a.chain_list[base + (uint32_t)__popcll(m & (((unsigned long long)1 << lane) - 1))] = g;
+	const bool in = g < a.counters->n_groups;
+	const PlanGroup grp = in ? a.groups[g] : PlanGroup{ 0, 0, 0, 0, 0, 0, 0 };
+	const bool need = in && grp.n_bands == PLAN_NEED_CHAIN, small = need && (int)grp.band_begin <= a.small_segs, big = need && !small;
+	// places inside the workgroup from LDS counters, one global atomic per workgroup and list (one per wavefront cost 0.2 ms at 10^6 groups)
+	uint32_t at = 0;
+	if (small) at = atomicAdd(&n_small, 1u);
+	if (big) at = atomicAdd(&n_big, 1u);
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		if (n_small) base_small = atomicAdd(&a.counters->n_chain, n_small);
+		if (n_big) base_big = atomicAdd(&a.counters->n_chain_big, n_big);
+	}
+	__syncthreads();
+	if (small) a.chain_list[base_small + at] = g;
+	if (big) a.chain_list[a.chain_cap - 1 - (base_big + at)] = g;
 }
 
+template<int NODES, int LINKS, int CHAINS, bool SMALL>
 __global__ __launch_bounds__(64) void plan_chain_kernel(PlanArgs a)
 {
+	typedef ChainLdsT<NODES, LINKS, CHAINS> Lds;
+	constexpr int LANES = ChainLanes<NODES, LINKS, CHAINS>::value;
 	__shared__ ScoreTable S;
-	__shared__ __align__(16) char raw[PLAN_CHAIN_LANES * sizeof(ChainLds)];
+	__shared__ __align__(16) char raw[LANES * sizeof(Lds)];
 	for (int x = threadIdx.x; x < 32 * 32; x += blockDim.x) S.m[x] = a.matrix[x];
 	if (threadIdx.x == 0) { S.gap_open = a.gap_open; S.gap_extend = a.gap_extend; }
 	__syncthreads();
-	if (threadIdx.x >= PLAN_CHAIN_LANES) return;
-	const uint32_t k = blockIdx.x * PLAN_CHAIN_LANES + threadIdx.x;
-	if (k >= a.counters->n_chain) return;
-	const uint32_t g = a.chain_list[k];
-	ChainLds& L = *reinterpret_cast<ChainLds*>(raw + threadIdx.x * sizeof(ChainLds));
+	if ((int)threadIdx.x >= LANES) return;
+	const uint32_t k = blockIdx.x * LANES + threadIdx.x;
+	if (k >= (SMALL ? a.counters->n_chain : a.counters->n_chain_big)) return;
+	const uint32_t g = SMALL ? a.chain_list[k] : a.chain_list[a.chain_cap - 1 - k];
+	Lds& L = *reinterpret_cast<Lds*>(raw + threadIdx.x * sizeof(Lds));
 	PlanGroup grp = a.groups[g];
 	const int ns = (int)grp.band_begin;
 	const uint32_t b = grp.hit_begin;
@@ -220,8 +237,15 @@ __global__ __launch_bounds__(64) void plan_chain_kernel(PlanArgs a)
 	L.ws.reset_fixed();
 	L.chains.reset();
 	L.ws.run_segs(S, SeqRef{ a.qblock + q0, qlen }, SeqRef{ a.tblock + t0, tlen }, L.sg, (size_t)ns, L.chains);
+	if (L.ws.overflowed() || L.chains.overflow) {
+		if (SMALL) {      // once more with the large workspace (the group keeps its PLAN_NEED_CHAIN state)
+			a.chain_list[a.chain_cap - 1 - atomicAdd(&a.counters->n_chain_big, 1u)] = g;
+			return;
+		}
+		grp.band_begin = 0; grp.n_bands = PLAN_ON_HOST; a.groups[g] = grp;
+		return;
+	}
 	grp.band_begin = 0;
-	if (L.ws.overflowed() || L.chains.overflow) { grp.n_bands = PLAN_ON_HOST; a.groups[g] = grp; return; }
 	insertion_sort(L.chains.begin(), L.chains.end(), [](const Chain& x, const Chain& y) { return x.d_min < y.d_min; });      // std::stable_sort by d_min
 	BandOut out{ a.band_slots + b, (int)grp.n_hits, 0, false };
 	merge_bands(L.chains, (int)L.chains.size(), band_for_dev(qlen, a.band_fast != 0), qlen, tlen, out);
@@ -270,7 +294,7 @@ hipError_t ensure_tmp(void** tmp, size_t* have, size_t need)
 void plan_kernel_table(const void** out, int* n)
 {
 	const void* k[] = { (const void*)plan_mark_kernel, (const void*)plan_fill_kernel, (const void*)plan_segments_kernel, (const void*)plan_chain_list_kernel,
-		(const void*)plan_chain_kernel, (const void*)plan_count_kernel, (const void*)plan_gather_kernel };
+		(const void*)plan_chain_kernel<PLAN_SMALL_SEGS, 16, 4, true>, (const void*)plan_chain_kernel<PLAN_MAX_SEGS, 96, 16, false>, (const void*)plan_count_kernel, (const void*)plan_gather_kernel };
 	*n = (int)(sizeof(k) / sizeof(k[0]));
 	for (int i = 0; i < *n; ++i) out[i] = k[i];
 }
@@ -295,10 +319,14 @@ hipError_t launch_plan(const PlanArgs& a, hipStream_t st)
 	hipLaunchKernelGGL(plan_fill_kernel, dim3(b256), dim3(256), 0, st, a);
 	// groups <= hits: the per-group kernels are launched over the hit count and return beyond the group count (read on the device)
 	hipLaunchKernelGGL(plan_segments_kernel, dim3(b64), dim3(64), 0, st, a);
-	// (the chaining kernel is launched over the upper bound of one group per two hits -- a group that needs chaining has at least two
-	// -- and reads the count of the list on the device)
+	// (the chaining kernels are launched over the upper bound of one group per two hits -- a group that needs chaining has at least
+	// two -- and read the counts of their lists on the device)
 	hipLaunchKernelGGL(plan_chain_list_kernel, dim3(b256), dim3(256), 0, st, a);
-	hipLaunchKernelGGL(plan_chain_kernel, dim3((unsigned)((n / 2 + PLAN_CHAIN_LANES) / PLAN_CHAIN_LANES)), dim3(64), 0, st, a);
+	{
+		constexpr int LS = ChainLanes<PLAN_SMALL_SEGS, 16, 4>::value, LB = ChainLanes<PLAN_MAX_SEGS, 96, 16>::value;
+		if (a.small_segs > 0) hipLaunchKernelGGL((plan_chain_kernel<PLAN_SMALL_SEGS, 16, 4, true>), dim3((unsigned)((n / 2 + LS) / LS)), dim3(64), 0, st, a);
+		hipLaunchKernelGGL((plan_chain_kernel<PLAN_MAX_SEGS, 96, 16, false>), dim3((unsigned)((n / 2 + LB) / LB)), dim3(64), 0, st, a);
+	}
 	hipLaunchKernelGGL(plan_count_kernel, dim3(b256g), dim3(256), 0, st, a);
 	// (the scan runs over n + 1 entries whatever the group count: entries beyond it are never read)
 	e = rocprim::exclusive_scan(*a.scan_tmp, need2, a.band_count, a.band_off, 0u, n + 1, rocprim::plus<uint32_t>(), st);
