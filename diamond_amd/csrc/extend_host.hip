@@ -1,19 +1,23 @@
 // extend_host.hip -- the extension stage above the GPU Smith-Waterman: what Extension::extend does per query
-// (/root/reference/src/align/extend.cpp:226-420), re-organised for the GPU as block-wide batches. The queries with seed hits are
-// cut into sub-batches that a few single-threaded runners (own HIP stream and device buffers each) pull from a queue; a runner
-// takes its sub-batch through
+// (/root/reference/src/align/extend.cpp:226-420), re-organised for the GPU as block-wide batches.
+// Since round 6 dmnd_extend has TWO halves behind one entry. The default protein search (one query context, one HSP per target,
+// -k culling by e-value, Hauser bias or none, banded extension, no transcripts) is planned (plan_kernels.hip) and extended
+// (extend_kernels.hip; extend_on_device below drives it) entirely in HBM: the host reads a few counters per ranking iteration, writes
+// its own e-value and bit score into the records and leaves them on the device for the join. Every other mode, and the queries the
+// device half hands back, take the HOST PATH described next (extend_range) -- same records either way; the two outputs are merged by query.
+// The host path: the queries with seed hits go through
 //   prelude     :  Hauser bias of the whole query block                              (GPU, bias_kernels.hip; once per call)
 //                  gapped filter of every seed hit, --sensitive and above             (GPU, gapped_kernels.hip; once per call)
-//   all queries :  load_hits -> x-drop ungapped -> chaining -> band construction      (host)
+//   all queries :  load_hits -> x-drop ungapped -> chaining -> band construction      (host; looked up from the device planner's lists when it ran)
 //   ONE call    :  round-1 banded swipe over every DpTarget of the ranking chunk, in traceback mode with kept trace rows
 //                  (score-only when the caller wants transcripts or the rows exceed the trace budget)      (GPU)
 //   all queries :  e-value cutoff, per-target best HSP, ranking-chunk logic, top-k culling                 (host)
 //   ONE call    :  round 2 = traceback walk over the kept traces of the surviving targets (or a second sweep with traceback;
 //                  statistics kernels for matrices above max_swipe_dp)                                     (GPU)
 //   all queries :  final culling -> match records                                                          (host)
-// instead of the reference's per-query calls of DP::BandedSwipe::swipe from a thread pool. While one runner waits for the GPU
-// the others work on the host, and the GPU serialises their launches.
-// Reference pieces restated here (chaining itself is in chain_host.h):
+// instead of the reference's per-query calls of DP::BandedSwipe::swipe from a thread pool (host work in fixed slices of the query
+// range on the context's worker pool; tuning.h: extend_team / extend_split).
+// Reference pieces restated here (chaining itself is in chain_graph.h, one source for host and device):
 //   HauserCorrection                        src/stats/hauser_correction.cpp:53-109   (host copy: dmnd_extend_plan; GPU: bias_core.h)
 //   load_hits                               src/align/load_hits.h:44-127
 //   ranking_chunk_size, ranking loop        src/align/extend.cpp:79-119, 289-336

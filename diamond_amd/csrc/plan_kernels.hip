@@ -8,17 +8,17 @@
 //   ungapped_stage       hits sorted by (diagonal, j); a hit inside the previous segment of its diagonal is skipped; segments
 //                        with a positive x-drop score are kept (align/ungapped.cpp:62-126)
 //   Chaining::run        one segment = one chain; more: the segment graph of chain_graph.h (chaining/greedy_align.cpp:362-497),
-//                        instantiated here over fixed arrays in the lane's private memory
+//                        instantiated here over fixed arrays in LDS (two workspace sizes, see plan_chain_kernel)
 //   add_dp_targets       band = [d_min - b, d_max + 1 + b) clipped to the matrix, overlapping bands merged (align/gapped_score.cpp:107-180)
 // Kernels (all one thread per hit or per group; the work per group is a few hundred scalar operations, the launch is latency-bound):
 //   plan_mark_kernel     target of every hit (binary search in the block's limits), group / query head flags, order check
 //   rocPRIM inclusive scan of the packed head flags  -> group and query numbers
 //   plan_fill_kernel     group and query records
 //   plan_segments_kernel per group: score, filter flag, sorted segments; single-segment groups are finished here
-//   plan_chain_kernel    per multi-segment group: chaining + band merge
+//   plan_chain_list_kernel, plan_chain_kernel<small> / <large>    per multi-segment group: chaining + band merge
 //   rocPRIM exclusive scan of the band counts, plan_gather_kernel: dense band list
 // A group with more than PLAN_MAX_HITS hits or PLAN_MAX_SEGS segments, or whose chaining outgrows the fixed arrays, is marked
-// PLAN_ON_HOST and planned by the host as before (extend_host.hip plan_one_group): same result either way.
+// PLAN_ON_HOST and planned by the host as before (extend_host.hip plan_groups): same result either way.
 // Compiled with -ffp-contract=off: the chaining truncates double expressions to int (joined_score, faded) exactly as the host does.
 #include <hip/hip_runtime.h>
 #include <climits>
