@@ -900,6 +900,7 @@ def main():
         aligned = int(np.unique(records["query"]).size)
 
     closed = False
+    pending_line = None
     if rank == 0:
         out = {
             "metric": "GCUPS + aligned queries/s, %s, %d queries vs %d-seq DB (seed stage + banded SW extension)" % (w.cfg["what"], w.n_queries, w.n_db),
@@ -1056,7 +1057,19 @@ def main():
                     want = e2e["runs"]["default_masking"]["reference_md5"]
                     got = hashlib.md5(masked_text.encode()).hexdigest()
                     out["masked_step"]["parity"] = {"records_md5": got, "reference_output_md5": want, "matches": got == want}
-        if not args.no_cpu_baseline and world > 1 and state.get("records") is not None:
+        if world > 1:
+            pending_line = out                               # printed below, behind the teardown of the process group
+        else:
+            print_line(out)
+    if not closed:
+        for c in (ctxs_seed if ctxs_seed is not ctxs else []) + [x for cs in ext_ctxs for x in cs] + (alt_ext_ctxs + [seed_ctx_alt] if alternate else []) + ([join_ctx] if join_ctx else []) + (set_join_ctxs or []):
+            c.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()                         # all ranks together: rank 0 is about to spend seconds on the reference run
+    if pending_line is not None:
+        out = pending_line
+        if not args.no_cpu_baseline and state.get("records") is not None:
             # N > 1: the job's records (rank 0 holds them all) against the reference run with the same database block cut (-b as the
             # workload cut its blocks); the reference's own timing is an N = 1 matter and not taken here
             qids = ["%s%d" % ("r" if w.contexts == 6 else "q", i) for i in range(w.n_queries)]
@@ -1068,18 +1081,17 @@ def main():
                 out["parity_checked"] = ours == ref_md5
                 out["parity"] = {"records_md5": ours, "reference_output_md5": ref_md5, "lines": text.count("\n"),
                                  "note": "reference run on rank 0 with the database cut into the same %d blocks (-b)" % w.n_blocks_total}
-        # the last thing on the line (what a tail of the output shows): the figures of this run in one place
-        out["summary"] = {"ms_per_step": out["ms_per_step"], "value": out["value"], "unit": out["unit"], "parity_checked": out.get("parity_checked"),
-                          "masked_step_ms_per_step": (out.get("masked_step") or {}).get("ms_per_step"), "host_cpu_ms_per_step": out["host_cpu_ms_per_step"],
-                          "roofline_frac": out["roofline"]["frac"], "roofline_traffic_bytes": out["roofline"].get("traffic"),
-                          "sweep_valu_issue_frac": out["sweep_roofline"].get("frac"), "sweep_lane_use": out["sweep_roofline"].get("lane_use"),
-                          "e2e_speedup_min": (out.get("e2e") or {}).get("speedup_min"), "rccl_world_size": out["rccl"]["world_size"]}
-        print(json.dumps(out))
-    if not closed:
-        for c in (ctxs_seed if ctxs_seed is not ctxs else []) + [x for cs in ext_ctxs for x in cs] + (alt_ext_ctxs + [seed_ctx_alt] if alternate else []) + ([join_ctx] if join_ctx else []) + (set_join_ctxs or []):
-            c.close()
-    if world > 1:
-        dist.destroy_process_group()
+        print_line(out)
+
+
+def print_line(out):
+    """the last thing on the line (what a tail of the output shows): the figures of this run in one place"""
+    out["summary"] = {"ms_per_step": out["ms_per_step"], "value": out["value"], "unit": out["unit"], "parity_checked": out.get("parity_checked"),
+                      "masked_step_ms_per_step": (out.get("masked_step") or {}).get("ms_per_step"), "host_cpu_ms_per_step": out["host_cpu_ms_per_step"],
+                      "roofline_frac": out["roofline"]["frac"], "roofline_traffic_bytes": out["roofline"].get("traffic"),
+                      "sweep_valu_issue_frac": out["sweep_roofline"].get("frac"), "sweep_lane_use": out["sweep_roofline"].get("lane_use"),
+                      "e2e_speedup_min": (out.get("e2e") or {}).get("speedup_min"), "rccl_world_size": out["rccl"]["world_size"]}
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
