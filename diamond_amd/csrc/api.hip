@@ -624,11 +624,37 @@ bool force_swipe32()
 	return v;
 }
 
-struct SweepLaunch { int64_t s0, s1; bool k16; int64_t pair0; };
+}  // namespace
+
+// The row classes pay when a launch fills the chip: a wavefront of eight items issues three to five times the instructions of a
+// wavefront of two per anti-diagonal step, so a launch of a few thousand items (C2: 15 600 per batch, under one wavefront per SIMD
+// in the row form) is done sooner as many thin wavefronts, and a launch of 10^5 and more (C2skew, C3) sooner with 1.4 x fewer
+// instructions. Items of one call (host path) / one ranking iteration (device half) from which on the row classes are used.
+// DMND_SWEEP_ROWS (read per call: an A/B switch of the tests): 0 = never, 1 = always.
+int64_t dmnd::sweep_rows_min_items()
+{
+	if (force_swipe32()) return INT64_MAX;
+	const char* e = std::getenv("DMND_SWEEP_ROWS");
+	if (e && e[0] == '0') return INT64_MAX;
+	if (e && e[0] == '1') return 0;
+	return tuning().sweep_rows_min_items;
+}
+
+namespace {
+
+// launch class of an item: its band class, or -- for what the packed 16-bit kernels take (score / coordinates / traceback sweeps
+// on the context's matrix, at most 65535 pair-steps) -- the row class its band fits (swipe_core.h band_class_rows)
+inline int sweep_class(int band, int64_t steps, bool own, int kmode, bool rows)
+{
+	if (rows && !own && kmode <= K_TRACE && steps <= 2 * (int64_t)SW16_MAX_PAIRS) return band_class_rows(band);
+	return band_class(band);
+}
+
+struct SweepLaunch { int64_t s0, s1; bool k16; int64_t pair_off; };      // pair_off: first entry of the launch in `pairs`
 
 // One launch per band class of `slots` (grouped by class P ascending, longest first inside a class): the packed-int16 kernel
-// with two items per wavefront (neighbours in launch order = similar lengths) when the class is eligible, else the 32-bit kernel
-// with one item per wavefront. kmode: K_SCORE / K_COORDS / K_TRACE. pairs receives the item pairs of the 16-bit launches.
+// with two items per wavefront -- eight for a row class -- (neighbours in launch order = similar lengths) when the class is eligible,
+// else the 32-bit kernel with one item per wavefront. kmode: K_SCORE / K_COORDS / K_TRACE. pairs receives the item pairs of the 16-bit launches.
 void plan_sweeps(const std::vector<Slot>& slots, int kmode, bool force32, std::vector<SweepLaunch>& launches, std::vector<int32_t>& pairs)
 {
 	const int64_t n = (int64_t)slots.size();
@@ -636,13 +662,13 @@ void plan_sweeps(const std::vector<Slot>& slots, int kmode, bool force32, std::v
 	for (int64_t s0 = 0; s0 < n;) {
 		int64_t s1 = s0, max_steps = 0;
 		while (s1 < n && slots[(size_t)s1].P == slots[(size_t)s0].P) { max_steps = std::max(max_steps, slots[(size_t)s1].steps); ++s1; }
-		const bool k16 = !force32 && !force_swipe32() && kmode <= K_TRACE && !own_matrix(slots[(size_t)s0]) && slots[(size_t)s0].P <= SW16_MAX_P && max_steps <= 2 * (int64_t)SW16_MAX_PAIRS;
-		launches.push_back(SweepLaunch{ s0, s1, k16, (int64_t)pairs.size() / 2 });
-		if (k16)
-			for (int64_t s = s0; s < s1; s += 2) {
-				pairs.push_back(slots[(size_t)s].item);
-				pairs.push_back(s + 1 < s1 ? slots[(size_t)s + 1].item : -1);
-			}
+		const bool k16 = !force32 && !force_swipe32() && kmode <= K_TRACE && !own_matrix(slots[(size_t)s0]) && sw16_class(slots[(size_t)s0].P) && max_steps <= 2 * (int64_t)SW16_MAX_PAIRS;
+		launches.push_back(SweepLaunch{ s0, s1, k16, (int64_t)pairs.size() });
+		if (k16) {
+			const int64_t per = class_items_per_wave16(slots[(size_t)s0].P);
+			for (int64_t s = s0; s < (s1 - s0 + per - 1) / per * per + s0; ++s)
+				pairs.push_back(s < s1 ? slots[(size_t)s].item : -1);
+		}
 		s0 = s1;
 	}
 }
@@ -658,11 +684,11 @@ int issue_sweeps(dmnd_ctx* work, const Bases& b, const dmnd_dp_target* d_items, 
 			Swipe16Args a;
 			a.qblock = b.q; a.tblock = b.t; a.cbs = b.cbs; a.matrix = work->matrix.as<int8_t>();
 			a.items = d_items;
-			a.pairs = pairs_dev + 2 * l.pair0;
+			a.pairs = pairs_dev + l.pair_off;
 			a.trace_off = trace ? trace_off_item_dev : nullptr;
 			a.trace = trace ? trace_dev : nullptr;
 			a.ends = work->ends.as<SwipeEnd>();
-			a.n_pairs = (l.s1 - l.s0 + 1) / 2;
+			a.n_pairs = (l.s1 - l.s0 + class_items_per_wave16(P) - 1) / class_items_per_wave16(P);
 			a.gap_open = work->params.gap_open; a.gap_extend = work->params.gap_extend;
 			HIP_TRY(launch_banded_swipe16(P, trace, a, work->stream));
 		}
@@ -716,7 +742,7 @@ void order_slots(std::vector<Slot>& v, std::vector<Slot>& tmp, std::vector<uint3
 	}
 	const int NB = 1024;
 	count.assign((size_t)32 * NB + 1, 0);
-	auto cls = [](const Slot& x) { int c = 0; while ((1 << c) < band_p(x)) ++c; return c + (own_matrix(x) ? 16 : 0); };      // P = 1, 2, 4, ... 512; then the same with own matrices
+	auto cls = [](const Slot& x) { return class_index(band_p(x)) + (own_matrix(x) ? 16 : 0); };      // P = 1, 2, 4, ... 512, the rows; then the same with own matrices
 	auto bucket = [&](const Slot& x) { return (size_t)cls(x) * NB + (size_t)(NB - 1 - std::min<int64_t>(x.steps >> 4, NB - 1)); };
 	for (const Slot& x : v) ++count[bucket(x) + 1];
 	for (size_t i = 1; i < count.size(); ++i) count[i] += count[i - 1];
@@ -820,6 +846,9 @@ int swipe_impl(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, int64_t
 	auto lap = [&](int slot) { const double t = wall(); c->host_ms[slot] += t - t_mark; t_mark = t; };
 
 	std::vector<Slot> slots((size_t)n);
+	const bool rows = n >= sweep_rows_min_items();
+	// a saturated item goes to the 32-bit kernels in its power-of-two class
+	auto for_32_bits = [&](Slot x) { const dmnd_dp_target& it = items[x.item]; x.P = band_class(it.d_end - it.d_begin) | (x.P & (int)ADJ_CLASS); return x; };
 	std::atomic<int64_t> bad_item(-1), bad_band(-1);
 	const int host_threads = n >= 4096 ? 8 : 1;
 	const int64_t chunk = 2048, n_chunks = (n + chunk - 1) / chunk;
@@ -831,10 +860,10 @@ int swipe_impl(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, int64_t
 				|| it.query_off + it.query_len > b.q_len || it.target_off + it.target_len > b.t_len
 				|| (it.cbs_off >= 0 && (!b.cbs || it.cbs_off + it.query_len > b.cbs_len))
 				|| (it.cbs_off <= -2 && (own_matrix_number(it.cbs_off) >= b.n_matrices || (own_matrix_biased(it.cbs_off) && (!b.cbs || it.query_off + it.query_len > b.cbs_len))))) { bad_item.store(i); slots[i] = Slot{ (int32_t)i, 1, 0 }; continue; }
-			const int P = band_class(band);
 			// up to 32 (16 with statistics) one wavefront sweeps the item; wider bands take up to 16 wavefronts (swipe_kernels.hip)
-			if (P > 32 * 16 || (kmode == K_STATS_FWD && P > 16 * 16)) { bad_band.store(i); slots[i] = Slot{ (int32_t)i, 1, 0 }; continue; }
+			if (band_class(band) > 32 * 16 || (kmode == K_STATS_FWD && band_class(band) > 16 * 16)) { bad_band.store(i); slots[i] = Slot{ (int32_t)i, 1, 0 }; continue; }
 			const Geom g = make_geom(it.query_len, it.target_len, it.d_begin, it.d_end);
+			const int P = sweep_class(band, n_steps(g), it.cbs_off <= -2, kmode, rows);
 			slots[i] = Slot{ (int32_t)i, P | (it.cbs_off <= -2 ? (int)ADJ_CLASS : 0), n_steps(g) };
 		}
 	});
@@ -863,8 +892,9 @@ int swipe_impl(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, int64_t
 			// items that saturated the 16-bit sweep (score >= 32767): once more in the 32-bit kernels, as the reference escalates
 			// its score vectors (swipe_wrapper.cpp:317-360)
 			std::vector<Slot> again;
-			for (const Slot& x : slots) if (ends[(size_t)x.item].pad[0]) again.push_back(x);
+			for (const Slot& x : slots) if (ends[(size_t)x.item].pad[0]) again.push_back(for_32_bits(x));
 			if (!again.empty()) {
+				std::sort(again.begin(), again.end(), by_class);
 				if (int rc = run_chunk(c, b, items, n, c->items.as<dmnd_dp_target>(), again, kmode, out, nullptr, nullptr, true)) return rc;
 				HIP_TRY(copy_now(c->stream, ends.data(), c->ends.p, n * sizeof(SwipeEnd), hipMemcpyDeviceToHost));
 			}
@@ -947,8 +977,9 @@ int swipe_impl(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, int64_t
 		std::vector<Slot> again;
 		std::vector<uint8_t> tr2;
 		std::vector<int64_t> tr_off2;
-		for (const Slot& x : chunk) if (hsps[(size_t)x.item].transcript_len < 0) again.push_back(x);
+		for (const Slot& x : chunk) if (hsps[(size_t)x.item].transcript_len < 0) again.push_back(for_32_bits(x));
 		if (!again.empty()) {
+			std::sort(again.begin(), again.end(), by_class);
 			if (int rc = run_chunk(c, b, items, n, c->items.as<dmnd_dp_target>(), again, K_TRACE, out, transcript ? &tr2 : nullptr, transcript ? &tr_off2 : nullptr, true)) return rc;
 			for (const Slot& x : again)
 				HIP_TRY(copy_now(c->stream, &hsps[(size_t)x.item], c->hsps.as<dmnd_hsp>() + x.item, sizeof(dmnd_hsp), hipMemcpyDeviceToHost));
@@ -984,9 +1015,9 @@ int swipe_impl(dmnd_ctx* c, const Bases& b, const dmnd_dp_target* items, int64_t
 }  // namespace
 
 // The sweeps (traceback mode, or scores only with trace_dev == NULL) of items that were prepared ON THE DEVICE (extend_kernels.hip): the launch order, trace offsets and
-// item pairs are in HBM already, the host only knows how many items every band class has (class c: P = 1 << c) and the longest
-// one's step count. One launch per class, as plan_sweeps / issue_sweeps do for a host-prepared list; pairs of class c start at
-// pair sum((count + 1) / 2) of the classes before it.
+// item pairs are in HBM already, the host only knows how many items every launch class has (class c: P = class_of_index(c)) and the
+// longest one's step count. One launch per class, as plan_sweeps / issue_sweeps do for a host-prepared list; the `pairs` entries of
+// class c (class_items_per_wave16 per wavefront, the last wavefront filled up with -1) follow those of the classes before it.
 int dmnd_sweep_classes(dmnd_ctx* work, const dmnd_ctx* c, const dmnd_dp_target* d_items, const uint32_t* class_count, const uint32_t* class_max_steps, int n_classes,
 	const int32_t* order_dev, const int64_t* off_slot_dev, const int32_t* pairs_dev, const int64_t* off_item_dev, uint8_t* trace_dev, SwipeEnd* ends_dev)
 {
@@ -996,13 +1027,15 @@ int dmnd_sweep_classes(dmnd_ctx* work, const dmnd_ctx* c, const dmnd_dp_target* 
 	for (int k = 0; k < n_classes; ++k) {
 		const int64_t count = class_count[k];
 		if (count == 0) continue;
-		const int P = 1 << k;
-		const bool k16 = !force_swipe32() && P <= SW16_MAX_P && (int64_t)class_max_steps[k] <= 2 * (int64_t)SW16_MAX_PAIRS;
+		const int P = class_of_index(k);
+		const int64_t per = class_items_per_wave16(P), waves = (count + per - 1) / per;
+		const bool k16 = !force_swipe32() && sw16_class(P) && (int64_t)class_max_steps[k] <= 2 * (int64_t)SW16_MAX_PAIRS;
+		if (row_class(P) && !k16) return fail(DMND_E_ARG, "dmnd_sweep_classes: a row class outside the 16-bit kernels");
 		if (k16) {
 			Swipe16Args a;
 			a.qblock = c->block[DMND_QUERY].as<int8_t>(); a.tblock = c->block[DMND_TARGET].as<int8_t>(); a.cbs = cbs; a.matrix = c->matrix.as<int8_t>();
-			a.items = d_items; a.pairs = pairs_dev + 2 * pair0; a.trace_off = trace_dev ? off_item_dev : nullptr; a.trace = trace_dev; a.ends = ends_dev;
-			a.n_pairs = (count + 1) / 2;
+			a.items = d_items; a.pairs = pairs_dev + pair0; a.trace_off = trace_dev ? off_item_dev : nullptr; a.trace = trace_dev; a.ends = ends_dev;
+			a.n_pairs = waves;
 			a.gap_open = c->params.gap_open; a.gap_extend = c->params.gap_extend;
 			HIP_TRY(launch_banded_swipe16(P, trace_dev != nullptr, a, work->stream));
 		}
@@ -1014,7 +1047,7 @@ int dmnd_sweep_classes(dmnd_ctx* work, const dmnd_ctx* c, const dmnd_dp_target* 
 			a.gap_open = c->params.gap_open; a.gap_extend = c->params.gap_extend;
 			HIP_TRY(launch_banded_swipe(P, trace_dev ? K_TRACE : K_SCORE, a, work->stream));
 		}
-		s0 += count; pair0 += (count + 1) / 2;
+		s0 += count; pair0 += waves * per;
 	}
 	return DMND_OK;
 }
@@ -1060,6 +1093,7 @@ int dmnd_swipe_keep(dmnd_ctx* work, const dmnd_ctx* c, const dmnd_dp_target* ite
 	// path cannot take) the plain score-only call does the job and reports the errors.
 	int64_t total = 0;
 	bool usable = arena >= 0 && arena < 16 && n <= 0x7fffffff, in_range = true;
+	const bool rows = n >= sweep_rows_min_items();
 	static thread_local std::vector<Slot> slots, sort_tmp;
 	static thread_local std::vector<uint32_t> sort_count;
 	static thread_local std::vector<int64_t> rows_of;
@@ -1071,7 +1105,7 @@ int dmnd_swipe_keep(dmnd_ctx* work, const dmnd_ctx* c, const dmnd_dp_target* ite
 		in_range &= !(it.query_off < 0 || it.target_off < 0 || it.query_off + it.query_len > b.q_len || it.target_off + it.target_len > b.t_len
 			|| (it.cbs_off >= 0 && (!b.cbs || it.cbs_off + it.query_len > b.cbs_len)) || (it.cbs_off <= -2 && (own_matrix_number(it.cbs_off) >= b.n_matrices || (own_matrix_biased(it.cbs_off) && (!b.cbs || it.query_off + it.query_len > b.cbs_len)))));
 		const Geom g = make_geom(it.query_len, it.target_len, it.d_begin, it.d_end);
-		const int P = band_class(band);
+		const int P = sweep_class(band, n_steps(g), it.cbs_off <= -2, K_TRACE, rows);
 		slots[(size_t)i] = Slot{ (int32_t)i, P | (it.cbs_off <= -2 ? (int)ADJ_CLASS : 0), n_steps(g) };
 		rows_of[(size_t)i] = trace_bytes(g, P);
 		total += rows_of[(size_t)i];
@@ -1130,6 +1164,10 @@ int dmnd_swipe_keep(dmnd_ctx* work, const dmnd_ctx* c, const dmnd_dp_target* ite
 		// items that saturated the 16-bit sweep: once more in the 32-bit kernel, into the same trace rows
 		std::vector<Slot> again;
 		for (const Slot& x : slots) if (ends[x.item].pad[0]) again.push_back(x);
+		// (an item of a row class has trace rows of that class, which the 32-bit kernels do not write: scores only then -- the
+		// caller's round 2 sweeps its survivors again)
+		for (const Slot& x : again)
+			if (row_class(band_p(x))) return dmnd_swipe_shared(work, c, items, n, DMND_SWIPE_SCORE, 0, out, nullptr, 0, nullptr);
 		if (!again.empty()) {
 			std::vector<int32_t> order2(again.size());
 			std::vector<int64_t> off2(again.size());

@@ -210,6 +210,7 @@ int dmnd_swipe_keep(dmnd_ctx* work, const dmnd_ctx* blocks, const dmnd_dp_target
 // items[k] with its KeptTrace entry src[k] (index into kt's vectors): statistics and coordinates from the kept trace, no transcripts
 int dmnd_traceback_kept(dmnd_ctx* work, const dmnd_ctx* blocks, const dmnd_dp_target* items, const KeptTrace& kt, const int64_t* src, int64_t n, dmnd_hsp* out);
 namespace dmnd { struct SwipeEnd; }
+namespace dmnd { int64_t sweep_rows_min_items(); }      // items of a call / ranking iteration from which on the row classes of the packed 16-bit sweeps are used (api.hip)
 int dmnd_sweep_classes(dmnd_ctx* work, const dmnd_ctx* blocks, const dmnd_dp_target* d_items, const uint32_t* class_count, const uint32_t* class_max_steps, int n_classes,
 	const int32_t* order_dev, const int64_t* off_slot_dev, const int32_t* pairs_dev, const int64_t* off_item_dev, uint8_t* trace_dev, dmnd::SwipeEnd* ends_dev);
 int dmnd_swipe_shared(dmnd_ctx* work, const dmnd_ctx* blocks, const dmnd_dp_target* items, int64_t n, int mode, uint32_t hsp_values,

@@ -709,7 +709,7 @@ static int extend_on_device(dmnd_ctx* c, const HostCfg& h, const DevPlan& plan, 
 		o_cnt = take((nG + 1) * 4), o_item_off = take((nG + 1) * 4), o_kept = take((nG + 1) * 4), o_kept_pos = take((nG + 1) * 4), o_cand_item = take(nG * 4), o_cand_ev = take(nG * 8),
 		o_items = take(nI * sizeof(dmnd_dp_target)), o_off_item = take(nI * 8), o_p = take(nI * 4), o_ends = take(nI * sizeof(SwipeEnd)), o_hsps = take(nI * sizeof(dmnd_hsp)),
 		o_keys = take(nI * 4), o_keys_sorted = take(nI * 4), o_idx = take(nI * 4), o_order = take(nI * 4), o_rows = take(nI * 8), o_rows_slot = take((nI + 1) * 8), o_off_slot = take((nI + 1) * 8),
-		o_pairs = take((nI + 2 * EXT_CLASSES) * 4), o_r2_order = take(nR * 4), o_r2_p = take(nR * 4), o_r2_off = take(nR * 8), o_r2_tr = take((nR + 1) * 8), o_r2_group = take(nR * 4),
+		o_pairs = take((nI + 8 * EXT_CLASSES) * 4), o_r2_order = take(nR * 4), o_r2_p = take(nR * 4), o_r2_off = take(nR * 8), o_r2_tr = take((nR + 1) * 8), o_r2_group = take(nR * 4),
 		o_records = take(nR * sizeof(dmnd_match)), o_ctr = take(sizeof(ExtCounters));
 	if (int rc = c->ext_dev.ensure(at)) return rc;
 	tr.lap("work arrays");
@@ -718,7 +718,7 @@ static int extend_on_device(dmnd_ctx* c, const HostCfg& h, const DevPlan& plan, 
 	a.groups = plan.dev.groups; a.queries = plan.dev.queries; a.bands = plan.dev.bands;
 	a.n_groups = plan.n_groups; a.n_queries = plan.n_queries; a.n_bands = plan.n_bands;
 	a.hits = plan.dev.hits; a.qlimits = plan.dev.qlimits; a.tlimits = plan.dev.tlimits;
-	a.use_cbs = h.use_cbs ? 1 : 0; a.chunk_size = (uint32_t)chunk; a.k = h.max_target_seqs; a.max_swipe_dp = h.max_swipe_dp;
+	a.use_cbs = h.use_cbs ? 1 : 0; a.row_min_items = (uint32_t)std::min<int64_t>(sweep_rows_min_items(), 0xffffffffll); a.chunk_size = (uint32_t)chunk; a.k = h.max_target_seqs; a.max_swipe_dp = h.max_swipe_dp;
 	const Evaluer& E = c->evaluer;
 	a.ev = ExtEvalue{ E.lambda, E.K, E.ln_k, E.db_letters, E.a, E.b, E.alpha, E.beta, E.sigma, E.tau, E.v_thr, E.c_thr, h.max_evalue };
 	a.qstate = reinterpret_cast<uint8_t*>(d + o_qstate); a.q_active = reinterpret_cast<uint8_t*>(d + o_qactive);

@@ -34,7 +34,7 @@ struct ExtCounters {
 	uint32_t n_saturated, n_kept, n_ambiguous, n_resweep;      // n_resweep: survivors whose round-1 sweep kept no trace
 	int32_t tb_status;                       // traceback_kernel's status word (0 = every walk ended at a cell with score 0)
 	uint32_t pad;                            // (the arrays and the 64-bit counters below lie back to back: reset_iteration clears them in one go)
-	uint32_t class_count[EXT_CLASSES];       // items of the current iteration per band class P = 1 << c
+	uint32_t class_count[EXT_CLASSES];       // items of the current iteration per launch class c (P = class_of_index(c), swipe_core.h)
 	uint32_t class_max_steps[EXT_CLASSES];
 	unsigned long long total_rows;           // trace bytes of the current iteration's items
 	unsigned long long cells1, cells2;       // DP cells of all round-1 items / of the items walked in round 2 (the reference's round-2 targets)
@@ -49,6 +49,7 @@ struct ExtArgs {
 	const dmnd_seed_hit* hits;
 	const int64_t* qlimits; const int64_t* tlimits;
 	int use_cbs;
+	uint32_t row_min_items;        // items of an iteration from which on the row classes of the packed 16-bit sweeps are used (sweep_rows_min_items)
 	uint32_t chunk_size;           // ranking_chunk_size
 	int k;                         // max_target_seqs
 	int64_t max_swipe_dp;

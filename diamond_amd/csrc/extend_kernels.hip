@@ -24,6 +24,7 @@
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/device/device_radix_sort.hpp>
 #include "extend_kernels.h"
+#include "swipe16_core.h"
 #include "swipe_core.h"
 
 namespace dmnd {
@@ -129,6 +130,12 @@ __global__ __launch_bounds__(256) void ext_init_kernel(ExtArgs a)
 	a.idx[i] = i; a.keys[i] = 0x7fffu; a.rows[i] = 0;
 }
 
+// launch class of an item (api.hip sweep_class: the row classes take what the packed 16-bit kernels take)
+__device__ inline int ext_class(bool rows, int band, int64_t steps)
+{
+	return rows && steps <= 2 * (int64_t)SW16_MAX_PAIRS ? band_class_rows(band) : band_class(band);
+}
+
 __global__ __launch_bounds__(256) void ext_items_kernel(ExtArgs a)
 {
 	__shared__ uint32_t h_count[EXT_CLASSES], h_steps[EXT_CLASSES];
@@ -137,6 +144,7 @@ __global__ __launch_bounds__(256) void ext_items_kernel(ExtArgs a)
 	if (threadIdx.x == 0) { h_cells = 0; h_diag = 0; h_lane = 0; }
 	__syncthreads();
 	const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+	const bool rows = a.item_off[a.n_groups] >= a.row_min_items;      // by the items of the whole iteration
 	if (g < a.n_groups) {
 		const uint32_t n = a.cnt[g];
 		if (n) {
@@ -151,10 +159,10 @@ __global__ __launch_bounds__(256) void ext_items_kernel(ExtArgs a)
 				const PlanBand b = a.bands[grp.band_begin + k];
 				const dmnd_dp_target d{ q0, t0, a.use_cbs ? q0 : (int64_t)-1, qlen, tlen, b.d_begin, b.d_end };
 				a.items[first + k] = d;
-				const int P = band_class(b.d_end - b.d_begin);
 				const Geom geom = make_geom(qlen, tlen, b.d_begin, b.d_end);
 				const int64_t steps = n_steps(geom);
-				const int c = 31 - __clz(P);
+				const int P = ext_class(rows, b.d_end - b.d_begin, steps);
+				const int c = class_index(P);
 				a.p_of_item[first + k] = P;
 				a.rows[local + k] = trace_bytes(geom, P);
 				const int64_t s16 = steps >> 4;
@@ -163,7 +171,7 @@ __global__ __launch_bounds__(256) void ext_items_kernel(ExtArgs a)
 				atomicMax(&h_steps[c], (uint32_t)(steps < 0x7fffffff ? steps : 0x7fffffff));
 				cells += (unsigned long long)ext_cells(d);
 				diag += (unsigned long long)(b.d_end - b.d_begin) * (unsigned long long)steps;
-				lanes += (unsigned long long)(128 * P) * (unsigned long long)steps;
+				lanes += (unsigned long long)(2 * P * class_lanes(P)) * (unsigned long long)steps;
 			}
 			atomicAdd(&h_cells, cells); atomicAdd(&h_diag, diag); atomicAdd(&h_lane, lanes);
 		}
@@ -192,13 +200,18 @@ __global__ __launch_bounds__(256) void ext_offsets_kernel(ExtArgs a)
 	if (s >= n) return;
 	const uint32_t item = a.order[s];                   // (relative to item_base, as the sweeps see the item arrays)
 	a.off_item[a.item_base + item] = a.off_slot[s];
-	// the packed 16-bit launches take their items in pairs of neighbours of the launch order; every class starts a new pair
+	// the packed 16-bit launches take their items in pairs (eights for a row class) of neighbours of the launch order; every class
+	// starts a new wavefront, and the last wavefront of a class is filled up with -1 (dmnd_sweep_classes reads the same layout)
 	const uint32_t c = a.keys_sorted[s] >> 10;
 	uint32_t s0 = 0, pair0 = 0;
-	for (uint32_t x = 0; x < c; ++x) { s0 += a.ctr->class_count[x]; pair0 += (a.ctr->class_count[x] + 1) / 2; }
-	const uint32_t count = a.ctr->class_count[c];
-	a.pairs[2 * pair0 + (s - s0)] = (int32_t)item;
-	if (s - s0 == count - 1 && (count & 1u)) a.pairs[2 * pair0 + count] = -1;
+	for (uint32_t x = 0; x < c; ++x) {
+		const uint32_t per = (uint32_t)class_items_per_wave16(class_of_index((int)x));
+		s0 += a.ctr->class_count[x]; pair0 += (a.ctr->class_count[x] + per - 1) / per * per;
+	}
+	const uint32_t count = a.ctr->class_count[c], per = (uint32_t)class_items_per_wave16(class_of_index((int)c));
+	a.pairs[pair0 + (s - s0)] = (int32_t)item;
+	if (s - s0 == count - 1)
+		for (uint32_t x = count; x < (count + per - 1) / per * per; ++x) a.pairs[pair0 + x] = -1;
 }
 
 // behind an iteration's sweeps: its items' trace offsets from the first arena on (the walk of round 2 reads all arenas from one
@@ -407,10 +420,10 @@ __global__ __launch_bounds__(256) void ext_resweep_kernel(ExtArgs a, uint32_t n_
 		const uint32_t local = atomicAdd(&a.ctr->n_items, 1u), copy = a.item_base + local;
 		const dmnd_dp_target d = a.items[a.r2_order[k]];
 		a.items[copy] = d;
-		const int P = band_class(d.d_end - d.d_begin);
 		const Geom geom = make_geom(d.query_len, d.target_len, d.d_begin, d.d_end);
 		const int64_t steps = n_steps(geom);
-		const int c = 31 - __clz(P);
+		const int P = ext_class(a.ctr->n_resweep >= a.row_min_items, d.d_end - d.d_begin, steps);
+		const int c = class_index(P);
 		a.p_of_item[copy] = P;
 		a.rows[local] = trace_bytes(geom, P);
 		const int64_t s16 = steps >> 4;
@@ -418,6 +431,7 @@ __global__ __launch_bounds__(256) void ext_resweep_kernel(ExtArgs a, uint32_t n_
 		atomicAdd(&h_count[c], 1u);
 		atomicMax(&h_steps[c], (uint32_t)(steps < 0x7fffffff ? steps : 0x7fffffff));
 		a.r2_order[k] = (int32_t)copy;
+		a.r2_p[k] = P;                            // (the copy's class: the first sweep may have been in another one, ext_class)
 		a.cand_item[a.r2_group[k]] = copy;
 		atomicAdd(&h_cells, (unsigned long long)ext_cells(d));
 	}

@@ -29,7 +29,10 @@ namespace dmnd {
 
 typedef uint32_t pk16;                       // two int16 halves: low = item A, high = item B
 enum { SW16_MAX_SCORE = 32767, SW16_MAX_PAIRS = 65535, SW16_SENTINEL = 31, SW16_MAX_P = 4, SW16_Q_SHIFT = 1, SW16_T_SHIFT = 6 };
-// pair-steps of one trace record = trace_group(P) of swipe_core.h for the classes of this kernel (P <= 4): the sweep runs in groups
+// the classes of these kernels: P = 1, 2, 4 on the 64 lanes of a wavefront (two items per wavefront), the row classes P = 3, 5 on the
+// 16 lanes of a DPP row (eight items per wavefront: swipe_core.h row_class)
+DMND_HD bool sw16_class(int P) { return P <= SW16_MAX_P || P == 5; }
+// pair-steps of one trace record = trace_group(P) of swipe_core.h for the classes of this kernel: the sweep runs in groups
 template<int P> struct Sw16Group { enum { G = 16 / P }; };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -128,12 +131,13 @@ DMND_HD pk16 sw16_tt(const Geom& gA, const SeqView& vA, const Geom& gB, const Se
 	return pk_make(sw16_letter(vA.t, jA, gA.tlen) << SW16_T_SHIFT, sw16_letter(vB.t, jB, gB.tlen) << SW16_T_SHIFT);
 }
 
-// What enters the wave's edge lanes at the end of pair-step t: the row that becomes lane 63's top row and the column that
-// becomes lane 0's newest column (wave-uniform; the kernel keeps a chunk of these records in LDS)
+// What enters the edge lanes of an item pair at the end of pair-step t: the row that becomes the last lane's (63; 15 for a row
+// class) top row and the column that becomes lane 0's newest column (the same for all lanes of the pair; the kernel keeps a chunk
+// of these records in LDS)
 struct Edge16 { pk16 qq, tt, cc; };
-DMND_HD Edge16 sw16_edge(const Geom& gA, const SeqView& vA, const Geom& gB, const SeqView& vB, int P, int t)
+DMND_HD Edge16 sw16_edge(const Geom& gA, const SeqView& vA, const Geom& gB, const SeqView& vB, int P, int t, int last_lane = 63)
 {
-	const int iA = sw16_row0(gA, P, 63) + P + 1 + t, iB = sw16_row0(gB, P, 63) + P + 1 + t;
+	const int iA = sw16_row0(gA, P, last_lane) + P + 1 + t, iB = sw16_row0(gB, P, last_lane) + P + 1 + t;
 	const int jA = sw16_col0(gA, P, 0) + 1 + t, jB = sw16_col0(gB, P, 0) + 1 + t;
 	Edge16 e;
 	e.qq = sw16_qq(gA, vA, gB, vB, iA, iB);
@@ -268,12 +272,26 @@ struct Trace16Group {
 			if (R % 2 == 0) { h0 = x; pin_here(h0); }
 			else { a[R / 2] = byte_perm(x, h0, LOW); b[R / 2] = byte_perm(x, h0, HIGH); pin_here(a[R / 2]); pin_here(b[R / 2]); }
 		}
-		else {
+		else if (P == 1) {
 			if (R % 2 == 0) { h0 = w[0]; pin_here(h0); }
 			else {
 				uint32_t x = byte_perm(w[0], h0, ZIP);                   // [A(R-1) A(R) B(R-1) B(R)]
 				if (R % 4 == 1) { h1 = x; pin_here(h1); }
 				else { a[R / 4] = byte_perm(x, h1, LOW); b[R / 4] = byte_perm(x, h1, HIGH); pin_here(a[R / 4]); pin_here(b[R / 4]); }
+			}
+		}
+		else {
+			// the row classes (P = 3, 5: G P = 15 bytes, the 16th is not used): byte n = R P + p of the record, taken as they come --
+			// two bytes zip into [A A B B], two such halves make a word of either record
+#pragma unroll
+			for (int p = 0; p < P; ++p) {
+				const int n = R * P + p;
+				if (n % 2 == 0 && n != 14) { h0 = w[p]; pin_here(h0); }
+				else {
+					const uint32_t x = n == 14 ? byte_perm(0u, w[p], ZIP) : byte_perm(w[p], h0, ZIP);      // [A(n-1) A(n) B(n-1) B(n)]; the last: [A14 0 B14 0]
+					if (n % 4 == 1) { h1 = x; pin_here(h1); }
+					else { a[n / 4] = byte_perm(x, h1, LOW); b[n / 4] = byte_perm(x, h1, HIGH); pin_here(a[n / 4]); pin_here(b[n / 4]); }
+				}
 			}
 		}
 	}

@@ -69,14 +69,28 @@ DMND_HD int64_t n_steps(const Geom& g) { return g.a_last >= g.a_first ? (int64_t
 DMND_HD int64_t trace_rows(const Geom& g) { return (n_steps(g) + 1) / 2 * 2; }
 // lanes own 2*P diagonals each: smallest power of two with 128*P >= band
 DMND_HD int band_class(int band) { int P = 1; while (128 * P < band) P *= 2; return P; }
+// ROW classes (packed 16-bit sweeps only, swipe16_kernels.hip): P = 3 / 5 -- the item is swept by ONE 16-lane DPP row of a wavefront
+// instead of all 64 lanes, 2 P = 6 / 10 diagonals per lane: 96 / 160 diagonals. Four rows x two register halves = eight items per
+// wavefront. They sit between the power-of-two classes: most bands of an alignment run are 61-81 or 131-161 diagonals wide, which
+// leaves 37-52 % of the lanes of the classes 1 / 2 (128 / 256 diagonals) on diagonals outside the band.
+DMND_HD bool row_class(int P) { return P == 3 || P == 5; }
+DMND_HD int class_lanes(int P) { return row_class(P) ? 16 : 64; }
+DMND_HD int band_class_rows(int band) { return band <= 96 ? 3 : band <= 128 ? 1 : band <= 160 ? 5 : band_class(band); }
+// launch classes as small numbers (counters per class, sort buckets): P = 1 << c for c = 0 .. 9 (512 = 16 wavefronts of 32), then the rows
+enum { CLASS_INDEX_ROW3 = 10, CLASS_INDEX_ROW5 = 11, CLASS_INDICES = 12 };
+DMND_HD int class_index(int P) { if (P == 3) return CLASS_INDEX_ROW3; if (P == 5) return CLASS_INDEX_ROW5; int c = 0; while ((1 << c) < P) ++c; return c; }
+DMND_HD int class_of_index(int c) { return c == CLASS_INDEX_ROW3 ? 3 : c == CLASS_INDEX_ROW5 ? 5 : 1 << c; }
+// work items that share a wavefront of the packed 16-bit sweep
+DMND_HD int class_items_per_wave16(int P) { return row_class(P) ? 8 : 2; }
 
 // ---- trace layout (traceback-mode sweeps -> traceback walk) --------------------------------------------------------------
 // A PAIR-STEP t is the two anti-diagonal steps a_first + 2t (even: the cells of the even band diagonals) and a_first + 2t + 1
 // (odd diagonals). One trace BYTE holds the two cells of band diagonals 2x and 2x + 1 of one pair-step: low nibble = the even
-// diagonal's cell, high nibble = the odd one's (4 trace bits each, TB_*). x = 0 .. 64 P - 1 for an item of band class P (the
-// lane-local pair p of lane l is x = l P + p). The bytes of one lane over G = trace_group(P) consecutive pair-steps are
-// contiguous -- a 16-byte record for P <= 16 -- and the 64 P / P records of a group follow each other lane by lane:
-//     index(t, x) = (t / G) * (64 P G) + (x / P) * (G P) + (t % G) * P + x % P          (P >= 16: G = 1, index = t * 64 P + x)
+// diagonal's cell, high nibble = the odd one's (4 trace bits each, TB_*). x = 0 .. L P - 1 for an item of band class P swept by
+// L = class_lanes(P) lanes (the lane-local pair p of lane l is x = l P + p). The bytes of one lane over G = trace_group(P)
+// consecutive pair-steps are contiguous -- a 16-byte record for P <= 16 (G P = 16 bytes; 15 + one unused for the row classes
+// P = 3 / 5) -- and the L records of a group follow each other lane by lane:
+//     index(t, x) = (t / G) * (16 L) + (x / P) * 16 + (t % G) * P + x % P          (P >= 16: G = 1, index = t * 64 P + x)
 // Why: the walk follows an alignment along a diagonal, i.e. through the SAME x over consecutive pair-steps. With one row per
 // anti-diagonal step (the first layout: 64 P bytes per step, 4 bits used per byte) every column of the alignment was a
 // different 128-byte line; here 16 / P consecutive columns of a diagonal are one record and a gap's neighbour diagonal is the
@@ -84,12 +98,17 @@ DMND_HD int band_class(int band) { int P = 1; while (128 * P < band) P *= 2; ret
 // contiguous), half the bytes of before.
 DMND_HD int trace_group(int P) { return P >= 16 ? 1 : 16 / P; }
 DMND_HD int64_t trace_pairs(const Geom& g) { return (n_steps(g) + 1) / 2; }
-DMND_HD int64_t trace_bytes(const Geom& g, int P) { const int G = trace_group(P); return (trace_pairs(g) + G - 1) / G * G * 64 * P; }
+DMND_HD int64_t trace_bytes(const Geom& g, int P)
+{
+	if (P >= 16) return trace_pairs(g) * 64 * P;
+	const int G = 16 / P;
+	return (trace_pairs(g) + G - 1) / G * (16 * class_lanes(P));
+}
 DMND_HD int64_t trace_byte_index(int P, int t, int x)
 {
 	if (P >= 16) return (int64_t)t * (64 * P) + x;
 	const int G = 16 / P, lane = x / P;
-	return (int64_t)(t / G) * 1024 + lane * 16 + (t % G) * P + (x - lane * P);
+	return (int64_t)(t / G) * (16 * class_lanes(P)) + lane * 16 + (t % G) * P + (x - lane * P);
 }
 
 // validity window of diagonal k (global index) on anti-diagonal a:  a_lo <= a <= a_hi

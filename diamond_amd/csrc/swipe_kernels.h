@@ -56,7 +56,7 @@ struct TracebackArgs {
 	int32_t gap_open, gap_extend;
 };
 
-// packed-int16 sweep, two items per wavefront (swipe16_kernels.hip): band classes P <= 4, at most 65535 pair-steps per item,
+// packed-int16 sweep, two items per wavefront (swipe16_kernels.hip; eight for the row classes P = 3, 5): band classes P <= 5, at most 65535 pair-steps per item,
 // items scored with the context's standard matrix only (one LDS table per workgroup; the host sends items with an adjusted matrix
 // of their own to the 32-bit kernels)
 struct Swipe16Args {
@@ -65,11 +65,11 @@ struct Swipe16Args {
 	const int8_t* cbs;
 	const int8_t* matrix;
 	const dmnd_dp_target* items;
-	const int32_t* pairs;        // 2 item indices per wavefront of this launch (one P class); second = -1: single item
+	const int32_t* pairs;        // class_items_per_wave16(P) = 2 (8 for a row class) item indices per wavefront of this launch (one P class); -1: no item (only the first is always there)
 	const int64_t* trace_off;    // item index -> byte offset into trace (traceback mode)
 	uint8_t* trace;
 	SwipeEnd* ends;              // indexed by item; score == 32767: saturated, to be re-run in the 32-bit kernel
-	int64_t n_pairs;
+	int64_t n_pairs;             // wavefronts
 	int32_t gap_open, gap_extend;
 };
 

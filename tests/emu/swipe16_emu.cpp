@@ -1,6 +1,6 @@
 // tests/emu/swipe16_emu.cpp -- TEST INFRASTRUCTURE ONLY.
 // CPU lane-emulator of the packed-int16 two-items-per-wavefront sweep (diamond_amd/csrc/swipe16_kernels.hip): runs the SAME
-// per-lane code (diamond_amd/csrc/swipe16_core.h) for 64 emulated lanes in lock-step, DPP shifts replaced by array indexing,
+// per-lane code (diamond_amd/csrc/swipe16_core.h) for 64 emulated lanes (16 for the row classes P = 3, 5: one DPP row) in lock-step, DPP shifts replaced by array indexing,
 // including the systolic letter flow (rows come down from lane l+1, columns from lane l-1, edge lanes read memory). The trace
 // is collected and stored as the kernel does it (Trace16Group, one 16-byte record per lane, item and group of pair-steps) in
 // the layout of swipe_core.h, so the reference walk (traceback_walk) decodes it.
@@ -36,55 +36,55 @@ static void run16(const Emu16Item& A, const Emu16Item& B, const int8_t* M, int g
 	for (int x = 0; x < 1024; ++x) table[x] = sw16_table_entry(M, x);
 	const Geom gA = make_geom(A.qlen, A.tlen, A.d_begin, A.d_end), gB = make_geom(B.qlen, B.tlen, B.d_begin, B.d_end);
 	const SeqView vA{ A.q, A.t, A.cbs, M }, vB{ B.q, B.t, B.cbs, M };
-	constexpr int G = Sw16Group<P>::G;
+	constexpr int G = Sw16Group<P>::G, L = (P == 3 || P == 5) ? 16 : 64;      // lanes of an item pair
 	const int nA = sw16_pairs(gA), nB = sw16_pairs(gB), T = ((nA > nB ? nA : nB) + G - 1) / G * G;      // whole groups, as the kernel
 	const pk16 go = pk_both(gap_open + gap_extend), ge = pk_both(gap_extend);
-	std::vector<Lane16<P>> st(64);
-	for (int l = 0; l < 64; ++l) lane16_init(st[l], gA, vA, gB, vB, l);
+	std::vector<Lane16<P>> st(L);
+	for (int l = 0; l < L; ++l) lane16_init(st[l], gA, vA, gB, vB, l);
 	std::vector<uint8_t> traceA, traceB;
 	if (TRACE) { traceA.assign((size_t)trace_bytes(gA, P) + 8, 0xee); traceB.assign((size_t)trace_bytes(gB, P) + 8, 0xee); }
-	pk16 S0[64][P], S1[64][P], tb[64][P], tbe[64][P], nb[64];
-	std::vector<Trace16Group<P>> acc(64);
+	pk16 S0[L][P], S1[L][P], tb[L][P], tbe[L][P], nb[L];
+	std::vector<Trace16Group<P>> acc(L);
 	for (int t = 0; t < T; ++t) {
 		const uint32_t revt = 0xffffu - (uint32_t)t;
-		for (int l = 0; l < 64; ++l) lane16_scores(st[l], table, S0[l], S1[l]);
+		for (int l = 0; l < L; ++l) lane16_scores(st[l], table, S0[l], S1[l]);
 		for (int par = 0; par < 2; ++par) {
-			if (par == 0) for (int l = 0; l < 64; ++l) nb[l] = l == 0 ? 0 : st[l - 1].F[2 * P - 1];
-			else for (int l = 0; l < 64; ++l) nb[l] = l == 63 ? 0 : st[l + 1].E[0];
-			for (int l = 0; l < 64; ++l) {
+			if (par == 0) for (int l = 0; l < L; ++l) nb[l] = l == 0 ? 0 : st[l - 1].F[2 * P - 1];
+			else for (int l = 0; l < L; ++l) nb[l] = l == L - 1 ? 0 : st[l + 1].E[0];
+			for (int l = 0; l < L; ++l) {
 				if (par == 0) lane16_step<P, TRACE, 0>(st[l], S0[l], nb[l], go, ge, revt, tb[l]);
 				else lane16_step<P, TRACE, 1>(st[l], S1[l], nb[l], go, ge, revt, tb[l]);
 			}
 			if (TRACE && par == 0)
-				for (int l = 0; l < 64; ++l) for (int p = 0; p < P; ++p) tbe[l][p] = tb[l][p];
+				for (int l = 0; l < L; ++l) for (int p = 0; p < P; ++p) tbe[l][p] = tb[l][p];
 		}
 		if (TRACE) {
 			// the kernel's register accumulation (Trace16Group::put<R>, R = position inside the group) and its one store per group
-			for (int l = 0; l < 64; ++l) put_r<P>(acc[l], t % G, tbe[l], tb[l]);
+			for (int l = 0; l < L; ++l) put_r<P>(acc[l], t % G, tbe[l], tb[l]);
 			if (t % G == G - 1) {
 				const int g0 = t - (G - 1);
-				for (int l = 0; l < 64; ++l) {
+				for (int l = 0; l < L; ++l) {
 					if (g0 < nA) memcpy(traceA.data() + trace_byte_index(P, g0, l * P), acc[l].a, 16);
 					if (g0 < nB) memcpy(traceB.data() + trace_byte_index(P, g0, l * P), acc[l].b, 16);
 				}
 			}
 		}
 		// systolic letter flow
-		const Edge16 e = sw16_edge(gA, vA, gB, vB, P, t);
-		pk16 nqq[64], ncc[64], ntt[64];
-		for (int l = 0; l < 64; ++l) {
-			nqq[l] = l < 63 ? st[l + 1].QQ[1] : e.qq;
-			ncc[l] = l < 63 ? st[l + 1].CC[1] : e.cc;
+		const Edge16 e = sw16_edge(gA, vA, gB, vB, P, t, L - 1);
+		pk16 nqq[L], ncc[L], ntt[L];
+		for (int l = 0; l < L; ++l) {
+			nqq[l] = l < L - 1 ? st[l + 1].QQ[1] : e.qq;
+			ncc[l] = l < L - 1 ? st[l + 1].CC[1] : e.cc;
 			ntt[l] = l > 0 ? st[l - 1].TT[P - 1] : e.tt;
 		}
-		for (int l = 0; l < 64; ++l) lane16_advance(st[l], nqq[l], ncc[l], ntt[l]);
+		for (int l = 0; l < L; ++l) lane16_advance(st[l], nqq[l], ncc[l], ntt[l]);
 	}
 	for (int item = 0; item < 2; ++item) {
 		const Geom& g = item ? gB : gA;
 		const SeqView& v = item ? vB : vA;
 		Emu16Out* out = item ? outB : outA;
 		int bs = 0, bi = 0, bj = 0x7fffffff;
-		for (int l = 0; l < 64; ++l) {
+		for (int l = 0; l < L; ++l) {
 			int s, i, j;
 			lane16_finish(st[l], g, item == 1, l, s, i, j);
 			if (better_end(s, j, i, bs, bj, bi)) { bs = s; bi = i; bj = j; }
@@ -101,14 +101,21 @@ static void run16(const Emu16Item& A, const Emu16Item& B, const int8_t* M, int g
 	}
 }
 
-// trace != 0: traceback mode (coordinates, statistics and transcripts of both items); force_p: 0 = the pair's class
+// trace != 0: traceback mode (coordinates, statistics and transcripts of both items); force_p: 0 = the pair's class; 3 / 5: the row
+// class, if both bands fit its 96 / 160 diagonals
 extern "C" int emu_banded_swipe16(const Emu16Item* A, const Emu16Item* B, const int8_t* M, int gap_open, int gap_extend, int trace, int force_p,
 	Emu16Out* outA, Emu16Out* outB, uint8_t* trA, uint8_t* trB, int cap)
 {
 	int P = 1;
 	while (128 * P < A->d_end - A->d_begin || 128 * P < B->d_end - B->d_begin) P *= 2;
-	if (force_p > P) P = force_p;
+	if (force_p == 3 || force_p == 5) {
+		if (32 * force_p < A->d_end - A->d_begin || 32 * force_p < B->d_end - B->d_begin) return -4;
+		P = force_p;
+	}
+	else if (force_p > P) P = force_p;
 	switch (P) {
+	case 3: if (trace) run16<3, true>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); else run16<3, false>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); break;
+	case 5: if (trace) run16<5, true>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); else run16<5, false>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); break;
 	case 1: if (trace) run16<1, true>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); else run16<1, false>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); break;
 	case 2: if (trace) run16<2, true>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); else run16<2, false>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); break;
 	case 4: if (trace) run16<4, true>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); else run16<4, false>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); break;

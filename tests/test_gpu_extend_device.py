@@ -3,6 +3,7 @@ the genuine reference's Extension::extend returned (tests/golden/ext_*.tap), wit
  * the default search of a protein block is planned and extended in HBM (dmnd_extend_plan_stats / dmnd_extend_device_stats);
  * with a trace budget of 8 MB (DMND_TRACE_ARENA_MB, read when the context is made) round 1 sweeps for scores only and round 2
    sweeps the survivors again with traceback -- same records;
+ * the same with the row classes of the sweeps forced on (DMND_SWEEP_ROWS=1: small blocks would not take them);
  * a skewed block whose queries have more targets than a ranking chunk (/root/reference/src/align/extend.cpp:79-92: 128 with -k 25)
    is ranked in chunks on the device -- same records as the reference binary on the same files (tests/test_gpu_skew.py holds the
    big case; here a small one that also runs with a tiny budget)."""
@@ -50,11 +51,15 @@ def _check(m, recs):
 
 
 @pytest.mark.parametrize("tap", ["ext_fast_synth.tap", "ext_default_synth.tap", "ext_sensitive.tap", "ext_long.tap"])
-@pytest.mark.parametrize("arena_mb", [None, "8"])
-def test_protein_search_is_extended_in_hbm_and_equals_the_reference(tap, arena_mb, monkeypatch):
+@pytest.mark.parametrize("arena_mb,rows", [(None, None), ("8", None), (None, "1"), ("8", "1")])
+def test_protein_search_is_extended_in_hbm_and_equals_the_reference(tap, arena_mb, rows, monkeypatch):
+    """rows = "1": the row classes of the packed 16-bit sweeps (eight items per wavefront, swipe16_kernels.hip) whatever the number
+    of items -- by default only iterations of 32 768 items and more take them (tests/test_gpu_skew.py has such a block)."""
     assert torch.cuda.is_available()
     if arena_mb:
         monkeypatch.setenv("DMND_TRACE_ARENA_MB", arena_mb)
+    if rows:
+        monkeypatch.setenv("DMND_SWEEP_ROWS", rows)
     ctx = hip.Context()
     try:
         cfg, recs = read_ext_tap(os.path.join(GOLDEN, tap))

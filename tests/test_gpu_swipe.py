@@ -187,8 +187,9 @@ def _random_items(rng, n, M, wide=False):
     return recs
 
 
-@pytest.mark.parametrize("wide", [False, True])
-def test_random_geometry_against_oracle(ctx, wide):
+@pytest.mark.parametrize("wide,rows", [(False, "0"), (False, "1"), (True, "1")])
+def test_random_geometry_against_oracle(ctx, wide, rows, monkeypatch):
+    monkeypatch.setenv("DMND_SWEEP_ROWS", rows)      # the row classes (bands of <= 96 / 160 diagonals) off / on whatever the item count
     M = hip.matrix_of(ctx.params)
     rng = np.random.default_rng(11 + wide)
     recs = _random_items(rng, 400 if not wide else 120, M, wide)
@@ -199,6 +200,48 @@ def test_random_geometry_against_oracle(ctx, wide):
     res = {}
     for mode in (hip.SWIPE_SCORE, hip.SWIPE_COORDS, hip.SWIPE_TRACEBACK):
         res[mode] = ctx.banded_swipe(items, mode)
+    for k, (rec, t) in enumerate(meta):
+        rc, o, otr = orc.banded_swipe(rec["query"], rec["cbs"], t["seq"], t["d_begin"], t["d_end"], M, 11, 1, orc.TRACEBACK)
+        assert rc == 0
+        assert res[hip.SWIPE_SCORE][0][k]["score"] == o["score"]
+        c = res[hip.SWIPE_COORDS][0][k]
+        assert c["score"] == o["score"]
+        if o["score"] > 0:
+            assert (c["q_end"], c["s_end"]) == (o["q_end"], o["s_end"])
+            g, tr = res[hip.SWIPE_TRACEBACK][0][k], res[hip.SWIPE_TRACEBACK][1]
+            for key in KEYS:
+                assert g[key] == o[key], (key, k)
+            assert np.array_equal(_transcript(tr, g), otr)
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 17, 150])
+def test_row_classes_take_any_number_of_items(ctx, n, monkeypatch):
+    """Bands of up to 96 / 160 diagonals are swept by the row classes (eight items per wavefront, one pair per 16-lane DPP row): any
+    item count (wavefronts filled up with copies that store nothing), items of very different lengths in one wavefront, and the
+    same numbers as the wavefront classes (DMND_SWEEP_ROWS=0) and the oracle."""
+    M = hip.matrix_of(ctx.params)
+    rng = np.random.default_rng(100 + n)
+    recs = _random_items(rng, n, M)
+    for k, r in enumerate(recs):                                       # one class per call: 3 for odd n, 5 for even n
+        t = r["targets"][0]
+        width = int(rng.integers(1, 97)) if n % 2 else int(rng.integers(129, 161))
+        t["d_begin"] = -min(len(t["seq"]) - 1, width // 2 + int(rng.integers(0, 5)))
+        t["d_end"] = t["d_begin"] + width
+        if k == 1:                                                     # a long item next to short ones
+            q = rng.integers(0, 20, 2500).astype(np.int8)
+            r["query"], r["cbs"] = q, None
+            t["seq"] = q.copy()
+    qb, tb, cbs, items, meta = pack_records(recs)
+    ctx.upload_block(hip.QUERY, qb)
+    ctx.upload_block(hip.TARGET, tb)
+    ctx.upload_cbs(cbs)
+    monkeypatch.setenv("DMND_SWEEP_ROWS", "1")        # (by default only calls of 32 768 items and more take the row classes)
+    res = {mode: ctx.banded_swipe(items, mode) for mode in (hip.SWIPE_SCORE, hip.SWIPE_COORDS, hip.SWIPE_TRACEBACK)}
+    monkeypatch.setenv("DMND_SWEEP_ROWS", "0")
+    off = {mode: ctx.banded_swipe(items, mode) for mode in (hip.SWIPE_SCORE, hip.SWIPE_COORDS, hip.SWIPE_TRACEBACK)}
+    monkeypatch.delenv("DMND_SWEEP_ROWS")
+    for mode in res:
+        assert np.array_equal(res[mode][0], off[mode][0]) and np.array_equal(res[mode][1], off[mode][1])
     for k, (rec, t) in enumerate(meta):
         rc, o, otr = orc.banded_swipe(rec["query"], rec["cbs"], t["seq"], t["d_begin"], t["d_end"], M, 11, 1, orc.TRACEBACK)
         assert rc == 0
@@ -368,9 +411,12 @@ def test_stats_without_traceback_golden_and_oracle(ctx):
                 assert out[k][key] == o[key], (key, k, out[k], o)
 
 
-def test_saturated_items_are_rerun_in_32_bits(ctx):
+@pytest.mark.parametrize("rows", ["0", "1"])
+def test_saturated_items_are_rerun_in_32_bits(ctx, rows, monkeypatch):
     """Scores of 32767 and above saturate the packed 16-bit sweep: such items must come back from the 32-bit kernels with the
-    oracle's numbers in every mode, and must not disturb the item that shared their wavefront."""
+    oracle's numbers in every mode, and must not disturb the items that shared their wavefront (rows = "1": the row classes, where
+    the re-run is in another class than the first sweep)."""
+    monkeypatch.setenv("DMND_SWEEP_ROWS", rows)
     M = hip.matrix_of(ctx.params)
     rng = np.random.default_rng(77)
     recs = _random_items(rng, 9, M)

@@ -92,6 +92,34 @@ def test_random_pairs_every_class():
     _check_pair(a, a, M)
 
 
+def test_row_classes():
+    """The row classes P = 3 / 5 (an item pair on the 16 lanes of a DPP row, 6 / 10 diagonals per lane, 15-byte trace records):
+    bands of up to 96 / 160 diagonals, everything else as in the wavefront classes."""
+    hdr, _ = read_tap(os.path.join(GOLDEN, "swipe_fast.tap"), max_records=1)
+    M = hdr["matrix8"]
+    rng = np.random.default_rng(35)
+    n = {3: 0, 5: 0}
+    for it in range(400):
+        a, b = _random_item(rng, it, wide=it % 4 == 3), _random_item(rng, it + 1, wide=it % 8 == 7)
+        width = max(a["d_end"] - a["d_begin"], b["d_end"] - b["d_begin"])
+        P = 3 if width <= 96 and it % 3 else 5 if width <= 160 else 0
+        if P:
+            _check_pair(a, b, M, force_p=P)
+            n[P] += 1
+    assert n[3] >= 60 and n[5] >= 60
+    # bands at the classes' limits, items of very different lengths in one row, an item paired with itself
+    for width, P in ((96, 3), (95, 3), (160, 5), (159, 5), (1, 3), (2, 5)):
+        a = _random_item(rng, 0); b = _random_item(rng, 2)
+        a["d_begin"] = -min(len(a["target"]) - 1, width // 2); a["d_end"] = a["d_begin"] + width
+        _check_pair(a, b if b["d_end"] - b["d_begin"] <= 32 * P else a, M, force_p=P)
+    hdr, items = _items_of("swipe_default.tap", 4)
+    narrow = [x for x in items if x["d_end"] - x["d_begin"] <= 160]
+    assert len(narrow) >= 6
+    for i in range(0, len(narrow) - 1, 2):
+        w = max(narrow[i]["d_end"] - narrow[i]["d_begin"], narrow[i + 1]["d_end"] - narrow[i + 1]["d_begin"])
+        _check_pair(narrow[i], narrow[i + 1], hdr["matrix8"], hdr["gap_open"], hdr["gap_extend"], force_p=3 if w <= 96 else 5)
+
+
 def test_ties_and_repeats():
     hdr, _ = read_tap(os.path.join(GOLDEN, "swipe_fast.tap"), max_records=1)
     M = hdr["matrix8"]
