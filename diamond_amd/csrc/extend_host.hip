@@ -704,7 +704,7 @@ static int extend_on_device(dmnd_ctx* c, const HostCfg& h, const DevPlan& plan, 
 	const size_t nI = nB + nR;                            // items: every band once + a copy of every survivor (round 2 without kept traces)
 	size_t at = 0;
 	auto take = [&](size_t bytes) { const size_t o = at; at = (at + bytes + 63) & ~(size_t)63; return o; };
-	const size_t o_qstate = take(nQ), o_qactive = take(nQ), o_qi0 = take(nQ * 4), o_qi1 = take(nQ * 4), o_qtail = take(nQ * 4), o_qprev = take(nQ * 4),
+	const size_t o_qstate = take(nQ), o_qactive = take(nQ), o_qi0 = take(nQ * 4), o_qi1 = take(nQ * 4), o_qtail = take(nQ * 4), o_qprev = take(nQ * 4), o_qswept = take(nQ * 4),
 		o_okeys = take(nG * 8), o_okeys2 = take(nG * 8), o_oidx = take(nG * 4), o_gorder = take(nG * 4), o_aligned = take(nG), o_gfirst = take(nG * 4), o_gcnt = take(nG * 4),
 		o_cnt = take((nG + 1) * 4), o_item_off = take((nG + 1) * 4), o_kept = take((nG + 1) * 4), o_kept_pos = take((nG + 1) * 4), o_cand_item = take(nG * 4), o_cand_ev = take(nG * 8),
 		o_items = take(nI * sizeof(dmnd_dp_target)), o_off_item = take(nI * 8), o_p = take(nI * 4), o_ends = take(nI * sizeof(SwipeEnd)), o_hsps = take(nI * sizeof(dmnd_hsp)),
@@ -723,7 +723,7 @@ static int extend_on_device(dmnd_ctx* c, const HostCfg& h, const DevPlan& plan, 
 	a.ev = ExtEvalue{ E.lambda, E.K, E.ln_k, E.db_letters, E.a, E.b, E.alpha, E.beta, E.sigma, E.tau, E.v_thr, E.c_thr, h.max_evalue };
 	a.qstate = reinterpret_cast<uint8_t*>(d + o_qstate); a.q_active = reinterpret_cast<uint8_t*>(d + o_qactive);
 	a.q_i0 = reinterpret_cast<uint32_t*>(d + o_qi0); a.q_i1 = reinterpret_cast<uint32_t*>(d + o_qi1);
-	a.q_tail = reinterpret_cast<int32_t*>(d + o_qtail); a.q_prev = reinterpret_cast<int32_t*>(d + o_qprev);
+	a.q_tail = reinterpret_cast<int32_t*>(d + o_qtail); a.q_prev = reinterpret_cast<int32_t*>(d + o_qprev); a.q_swept = reinterpret_cast<uint32_t*>(d + o_qswept);
 	a.okeys = reinterpret_cast<uint64_t*>(d + o_okeys); a.okeys_sorted = reinterpret_cast<uint64_t*>(d + o_okeys2);
 	a.oidx = reinterpret_cast<uint32_t*>(d + o_oidx); a.gorder = reinterpret_cast<uint32_t*>(d + o_gorder);
 	a.aligned = reinterpret_cast<uint8_t*>(d + o_aligned); a.g_first = reinterpret_cast<uint32_t*>(d + o_gfirst); a.g_cnt = reinterpret_cast<uint32_t*>(d + o_gcnt);
@@ -778,7 +778,12 @@ static int extend_on_device(dmnd_ctx* c, const HostCfg& h, const DevPlan& plan, 
 		int64_t rel = 0;
 		bool kept = false;
 		if (ctr.n_items > 0) {
-			kept = keep_traces_dev() && trace_used + (size_t)ctr.total_rows <= trace_budget;
+			// Trace rows are kept for the walk of round 2 -- unless they do not fit, or so few of the targets can survive the
+			// culling (at most -k per query) that sweeping all of them for scores only (18 VALU instructions per packed cell
+			// against 31 with trace bits) and the survivors a second time is less work: 18 + 31 f < 31 for a surviving fraction
+			// f < 0.42 (C2skew: 125 targets per query, f <= 0.2; C2, C3: f = 0.8 / 0.56, rows kept)
+			const bool few_survive = ctr.window_bound * 100 < ctr.window_targets * (unsigned long long)tuning().extend_resweep_below_pct;
+			kept = keep_traces_dev() && !few_survive && trace_used + (size_t)ctr.total_rows <= trace_budget;
 			DevBuf* arena = nullptr;
 			if (kept) if (int rc = arena_for((size_t)ctr.total_rows, arena, rel)) return rc;
 			if (iter == 0) tr.lap("trace arena");

@@ -39,6 +39,7 @@ struct ExtCounters {
 	unsigned long long total_rows;           // trace bytes of the current iteration's items
 	unsigned long long cells1, cells2;       // DP cells of all round-1 items / of the items walked in round 2 (the reference's round-2 targets)
 	unsigned long long cells_again;          // ... of those of them that round 2 swept again (their round-1 sweep kept no trace rows)
+	unsigned long long window_targets, window_bound;      // of the current iteration: targets in the active queries' windows, and sum over the queries of min(-k, targets): what can survive the culling
 	unsigned long long diag_steps, lane_steps;   // over the round-1 items: band diagonals x anti-diagonal steps, and the 128 P diagonals the item's wavefront holds x steps (lane use of the sweeps)
 };
 
@@ -59,6 +60,7 @@ struct ExtArgs {
 	uint8_t* q_active;             // still ranking: its window [q_i0, q_i1) of the order below is the next chunk
 	uint32_t* q_i0; uint32_t* q_i1;
 	int32_t* q_tail; int32_t* q_prev;        // tail_score / previous_tail_score of the ranking loop
+	uint32_t* q_swept;             // targets of its current window that are swept (0: none, or not active)
 	// per group
 	uint64_t* okeys; uint64_t* okeys_sorted; uint32_t* oidx;      // ranking order: sort keys (query, 0xffff - score), group numbers
 	uint32_t* gorder;              // groups of a query in ranking order (TargetScore::operator<: score descending, then load order)

@@ -109,17 +109,22 @@ __global__ __launch_bounds__(64) void ext_window_kernel(ExtArgs a)
 	const uint32_t g0 = a.queries[q].group_begin, g1 = a.queries[q + 1].group_begin;
 	const bool active = a.q_active[q] != 0;
 	const uint32_t i0 = active ? a.q_i0[q] : 0, i1 = active ? a.q_i1[q] : 0;
+	uint32_t swept = 0;                        // targets of the window that are swept (they passed the filters before)
 	for (uint32_t w = lane; w < g1 - g0; w += 64) {
 		const uint32_t g = a.gorder[g0 + w];
 		uint32_t n = 0;
 		if (w >= i0 && w < i1) { const PlanGroup grp = a.groups[g]; n = grp.pass ? grp.n_bands : 0u; }
 		a.cnt[g] = n;
 		a.kept[g] = 0;
+		swept += n ? 1u : 0u;
 	}
+	for (int off = 32; off >= 1; off >>= 1) swept += __shfl_xor(swept, off);
+	if (lane == 0) a.q_swept[q] = swept;       // summed by ext_items_kernel (an atomic per query here is 10 ns each, one after the other)
 	if (q == 0 && lane < EXT_CLASSES) { a.ctr->class_count[lane] = 0; a.ctr->class_max_steps[lane] = 0; }
 	if (q == 0 && lane == 0) {
 		a.cnt[a.n_groups] = 0; a.kept[a.n_groups] = 0;
 		a.ctr->n_items = 0; a.ctr->n_active = 0; a.ctr->n_resweep = 0; a.ctr->total_rows = 0; a.ctr->cells2 = 0;
+		a.ctr->window_targets = 0; a.ctr->window_bound = 0;
 	}
 }
 
@@ -140,10 +145,15 @@ __global__ __launch_bounds__(256) void ext_items_kernel(ExtArgs a)
 {
 	__shared__ uint32_t h_count[EXT_CLASSES], h_steps[EXT_CLASSES];
 	__shared__ unsigned long long h_cells, h_diag, h_lane;
+	__shared__ uint32_t h_targets, h_bound;
 	if (threadIdx.x < EXT_CLASSES) { h_count[threadIdx.x] = 0; h_steps[threadIdx.x] = 0; }
-	if (threadIdx.x == 0) { h_cells = 0; h_diag = 0; h_lane = 0; }
+	if (threadIdx.x == 0) { h_cells = 0; h_diag = 0; h_lane = 0; h_targets = 0; h_bound = 0; }
 	__syncthreads();
 	const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+	for (uint32_t q = g; q < a.n_queries; q += gridDim.x * blockDim.x) {      // the windows' swept targets, and how many of them can survive the culling
+		const uint32_t swept = a.q_swept[q];
+		if (swept) { atomicAdd(&h_targets, swept); atomicAdd(&h_bound, swept < (uint32_t)a.k ? swept : (uint32_t)a.k); }
+	}
 	const bool rows = a.item_off[a.n_groups] >= a.row_min_items;      // by the items of the whole iteration
 	if (g < a.n_groups) {
 		const uint32_t n = a.cnt[g];
@@ -183,6 +193,7 @@ __global__ __launch_bounds__(256) void ext_items_kernel(ExtArgs a)
 		atomicMax(&a.ctr->class_max_steps[threadIdx.x], h_steps[threadIdx.x]);
 	}
 	if (threadIdx.x == 0 && h_cells) { atomicAdd(&a.ctr->cells1, h_cells); atomicAdd(&a.ctr->diag_steps, h_diag); atomicAdd(&a.ctr->lane_steps, h_lane); }
+	if (threadIdx.x == 0 && h_targets) { atomicAdd(&a.ctr->window_targets, (unsigned long long)h_targets); atomicAdd(&a.ctr->window_bound, (unsigned long long)h_bound); }
 }
 
 __global__ __launch_bounds__(256) void ext_slots_kernel(ExtArgs a)

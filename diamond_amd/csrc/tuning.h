@@ -24,6 +24,7 @@ struct Tuning {
 	int extend_sub_threads = 0;        // DMND_EXTEND_SUB_THREADS: 0 = by the hits per runner
 	// ---- sweeps (api.hip sweep_rows_min_items)
 	int sweep_rows_min_items = 1 << 15; // DMND_SWEEP_ROWS_MIN: items of a launch set from which on bands of <= 96 / 160 diagonals take the row classes
+	int extend_resweep_below_pct = 40; // DMND_EXTEND_RESWEEP_BELOW_PCT: device half: an iteration of which at most this share of the targets can survive the culling is swept for scores only, its survivors again with traceback (0 = always keep trace rows)
 	// ---- streams
 	bool no_stream_priority = false;   // DMND_NO_STREAM_PRIORITY: every stream at the default priority
 	// ---- seed stage geometry (seed_api.hip seed_sizes; 0 / -1 = the size-dependent default chosen there)
@@ -49,6 +50,7 @@ inline const Tuning& tuning()
 		x.extend_runners = std::max(1, num("DMND_EXTEND_RUNNERS", x.extend_runners));
 		x.extend_sub_threads = std::max(0, num("DMND_EXTEND_SUB_THREADS", x.extend_sub_threads));
 		x.sweep_rows_min_items = std::max(0, num("DMND_SWEEP_ROWS_MIN", x.sweep_rows_min_items));
+		x.extend_resweep_below_pct = std::max(0, std::min(100, num("DMND_EXTEND_RESWEEP_BELOW_PCT", x.extend_resweep_below_pct)));
 		x.no_stream_priority = std::getenv("DMND_NO_STREAM_PRIORITY") != nullptr;
 		if (std::getenv("DMND_SEED_SLOTS_X8")) x.seed_slots_x8 = std::min(64, std::max(8, num("DMND_SEED_SLOTS_X8", 0)));
 		if (std::getenv("DMND_SEED_BITMAP1_LOG2")) x.seed_bitmap1_log2 = std::min(27, std::max(15, num("DMND_SEED_BITMAP1_LOG2", 0)));
