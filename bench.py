@@ -150,11 +150,16 @@ def sweep_roofline(config, ext):
     """north_star's second kernel, the banded Smith-Waterman sweep (/root/reference/src/dp/swipe/banded_swipe.h:189-351), against the
     roofline that bounds it: VALU issue. Per kernel: VALU wave-instructions per launch (committed PMC pass) / its average launch
     time (committed rocprofv3 kernel statistics of the same configuration) / the device's issue peak: 256 CUs x 4 SIMDs x 2.4 GHz / 2
-    = 1229 G wave-instructions/s (a 64-lane wavefront's VALU instruction occupies its SIMD for two cycles). Live from this run: the sweeps' device time and cells, and the lane
-    use of the device path's round-1 DpTargets (band diagonals / the 128 P diagonals their wavefront holds, weighted by steps)."""
+    = 1229 G wave-instructions/s (a 64-lane wavefront's VALU instruction occupies its SIMD for two cycles) -- `frac`. That peak holds
+    for the plain 32-bit VOP2 operations only: tools/probes/valu_probe.hip (profiles/r06_valu_probe.txt) measures 2.4 cycles per
+    instruction and SIMD for v_add_u32 / v_and_b32 and 4.2-4.5 for the operations these sweeps are made of (v_pk_*_i16, v_perm_b32,
+    DPP moves, v_max, v_lshl_or_b32: 550-590 G/s), so `frac_of_packed_issue_peak` (achieved / 565) is the distance to what this
+    instruction mix can issue. Live from this run: the sweeps' device time and cells, and the lane use of the device path's round-1
+    DpTargets (band diagonals / the 2 P x lanes diagonals their wavefront or DPP row holds, weighted by steps)."""
     import csv
-    PEAK = 256 * 4 * 2.4 / 2
-    o = {"bound": "valu_issue", "peak": PEAK, "unit": "G wave-instructions/s", "kernels": {}, "achieved": None, "frac": None,
+    PEAK, PACKED_PEAK = 256 * 4 * 2.4 / 2, 565.0
+    o = {"bound": "valu_issue", "peak": PEAK, "packed_issue_peak": PACKED_PEAK, "unit": "G wave-instructions/s", "kernels": {}, "achieved": None, "frac": None,
+         "frac_of_packed_issue_peak": None,
          "lane_use": (ext["band_diagonal_steps"] / ext["wavefront_diagonal_steps"]) if ext.get("wavefront_diagonal_steps") else None,
          "live": {"round1_sweep_kernel_ms": ext["round1_swipe_kernel_ms"], "round2_sweep_kernel_ms": ext["round2_swipe_kernel_ms"],
                   "round1_gcups": ext["round1_cells"] / max(ext["round1_swipe_kernel_ms"], 1e-9) / 1e6}}
@@ -171,7 +176,7 @@ def sweep_roofline(config, ext):
         ach = v["SQ_INSTS_VALU_per_launch"] / avg_ns[name][0]          # wave-instructions per ns = G/s
         short = name[name.index("banded_swipe"):name.index("(")] if "(" in name else name
         o["kernels"][short] = {"valu_wave_instructions_per_launch": v["SQ_INSTS_VALU_per_launch"], "avg_launch_ms": avg_ns[name][0] / 1e6,
-                               "share_of_sweep_time": None, "achieved": ach, "frac": ach / PEAK, "_total_ns": avg_ns[name][1]}
+                               "share_of_sweep_time": None, "achieved": ach, "frac": ach / PEAK, "frac_of_packed_issue_peak": ach / PACKED_PEAK, "_total_ns": avg_ns[name][1]}
         if best is None or avg_ns[name][1] > best[1]:
             best = (short, avg_ns[name][1])
     total = sum(k["_total_ns"] for k in o["kernels"].values()) or 1
@@ -180,6 +185,7 @@ def sweep_roofline(config, ext):
     if best:
         o["dominant"] = best[0]
         o["achieved"], o["frac"] = o["kernels"][best[0]]["achieved"], o["kernels"][best[0]]["frac"]
+        o["frac_of_packed_issue_peak"] = o["kernels"][best[0]]["frac_of_packed_issue_peak"]
     o["source"] = "%s (SQ_INSTS_VALU per launch) / %s (average launch time)" % (os.path.relpath(pmc, ROOT), os.path.relpath(st, ROOT))
     return o
 
@@ -1089,7 +1095,7 @@ def print_line(out):
     out["summary"] = {"ms_per_step": out["ms_per_step"], "value": out["value"], "unit": out["unit"], "parity_checked": out.get("parity_checked"),
                       "masked_step_ms_per_step": (out.get("masked_step") or {}).get("ms_per_step"), "host_cpu_ms_per_step": out["host_cpu_ms_per_step"],
                       "roofline_frac": out["roofline"]["frac"], "roofline_traffic_bytes": out["roofline"].get("traffic"),
-                      "sweep_valu_issue_frac": out["sweep_roofline"].get("frac"), "sweep_lane_use": out["sweep_roofline"].get("lane_use"),
+                      "sweep_valu_issue_frac": out["sweep_roofline"].get("frac"), "sweep_frac_of_packed_issue_peak": out["sweep_roofline"].get("frac_of_packed_issue_peak"), "sweep_lane_use": out["sweep_roofline"].get("lane_use"),
                       "e2e_speedup_min": (out.get("e2e") or {}).get("speedup_min"), "rccl_world_size": out["rccl"]["world_size"]}
     print(json.dumps(out), flush=True)
 

@@ -690,6 +690,7 @@ int issue_sweeps(dmnd_ctx* work, const Bases& b, const dmnd_dp_target* d_items, 
 			a.ends = work->ends.as<SwipeEnd>();
 			a.n_pairs = (l.s1 - l.s0 + class_items_per_wave16(P) - 1) / class_items_per_wave16(P);
 			a.gap_open = work->params.gap_open; a.gap_extend = work->params.gap_extend;
+			a.score_only = kmode == K_SCORE;
 			HIP_TRY(launch_banded_swipe16(P, trace, a, work->stream));
 		}
 		else {
@@ -1037,6 +1038,7 @@ int dmnd_sweep_classes(dmnd_ctx* work, const dmnd_ctx* c, const dmnd_dp_target* 
 			a.items = d_items; a.pairs = pairs_dev + pair0; a.trace_off = trace_dev ? off_item_dev : nullptr; a.trace = trace_dev; a.ends = ends_dev;
 			a.n_pairs = waves;
 			a.gap_open = c->params.gap_open; a.gap_extend = c->params.gap_extend;
+			a.score_only = trace_dev == nullptr;          // the device half reads end cells only behind traceback-mode sweeps
 			HIP_TRY(launch_banded_swipe16(P, trace_dev != nullptr, a, work->stream));
 		}
 		else {

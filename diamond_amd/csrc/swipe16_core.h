@@ -105,6 +105,7 @@ struct Lane16 {
 	pk16 H[2 * P], E[2 * P], F[2 * P];
 	pk16 m[2 * P];                          // 0xffff in an item's half iff the diagonal lies inside that item's band
 	uint32_t keyA[2 * P], keyB[2 * P];      // max over the sweep of (H << 16 | 0xffff - pair-step), per diagonal and item
+	pk16 best;                              // score-only sweeps (COORDS = false in lane16_step) keep this instead: the lane's best score of either item
 	// letter windows, packed like the DP registers (A low, B high):
 	pk16 QQ[P + 1];                         // (query letter << 1) of rows I0 + t .. I0 + t + P
 	pk16 CC[P + 1];                         // their composition bias
@@ -153,6 +154,7 @@ DMND_HD void lane16_init(Lane16<P>& st, const Geom& gA, const SeqView& vA, const
 	for (int k = 0; k < 2 * P; ++k) {
 		st.H[k] = st.E[k] = st.F[k] = 0;
 		st.keyA[k] = st.keyB[k] = 0;
+		st.best = 0;
 		const int kk = 2 * P * lane + k;
 		st.m[k] = (kk < gA.band ? 0xffffu : 0u) | (kk < gB.band ? 0xffff0000u : 0u);
 	}
@@ -204,7 +206,9 @@ DMND_HD void lane16_advance(Lane16<P>& st, pk16 nqq, pk16 ncc, pk16 ntt)
 // diagonals, nb = E of lane+1's bottom diagonal (as lane_step / win_step in swipe_core.h). S = the P packed scores of this
 // step, go = gap_open + gap_extend and ge = gap_extend in both halves, revt = 0xffff - pair-step.
 // tb[p] (TRACE) receives the cell's four trace bits of item A in bits 0-3 and of item B in bits 16-19.
-template<int P, bool TRACE, int PAR>
+// COORDS = false: only the best score is wanted (the first pass of an extension whose survivors are swept again, DMND_SWIPE_SCORE):
+// one packed max per cell instead of the two 32-bit keys (4 of a cell's 18 instructions).
+template<int P, bool TRACE, int PAR, bool COORDS = true>
 DMND_HD void lane16_step(Lane16<P>& st, const pk16* S, pk16 nb, pk16 go, pk16 ge, uint32_t revt, pk16* tb)
 {
 	const pk16 one = pk_both(1);
@@ -225,6 +229,7 @@ DMND_HD void lane16_step(Lane16<P>& st, const pk16* S, pk16 nb, pk16 go, pk16 ge
 			tb[p] = pk_twice_plus(pk_twice_plus(pk_twice_plus(oh, ov), gh), gv);      // TB_OPEN_H 8 | TB_OPEN_V 4 | TB_GAP_H 2 | TB_GAP_V 1
 		}
 		st.H[k] = c; st.E[k] = e; st.F[k] = f;
+		if (!COORDS) { st.best = pk_max(st.best, c); continue; }
 		const uint32_t ka = (c << 16) | revt, kb = (c & 0xffff0000u) | revt;
 		st.keyA[k] = st.keyA[k] > ka ? st.keyA[k] : ka;
 		st.keyB[k] = st.keyB[k] > kb ? st.keyB[k] : kb;
@@ -297,11 +302,12 @@ struct Trace16Group {
 	}
 };
 
-// after the sweep: the lane's end cell of one item from its per-diagonal keys
-template<int P>
+// after the sweep: the lane's end cell of one item from its per-diagonal keys (COORDS = false: its best score, no cell)
+template<int P, bool COORDS = true>
 DMND_HD void lane16_finish(const Lane16<P>& st, const Geom& g, bool second, int lane, int& bs, int& bi, int& bj)
 {
 	bs = 0; bi = 0; bj = 0x7fffffff;
+	if (!COORDS) { bs = (int)(int16_t)(second ? st.best >> 16 : st.best & 0xffffu); return; }
 #pragma unroll
 	for (int k = 0; k < 2 * P; ++k) {
 		const uint32_t key = second ? st.keyB[k] : st.keyA[k];

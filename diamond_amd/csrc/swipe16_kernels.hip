@@ -85,7 +85,7 @@ __device__ __forceinline__ void unrolled(std::integer_sequence<int, R...>, F&& f
 
 enum { EDGE_CHUNK = 256 };            // pair-steps per refill of a wavefront's edge records (4 records per lane)
 
-template<int P, bool TRACE>
+template<int P, bool TRACE, bool COORDS = true>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * 64)
 void banded_swipe16_kernel(const int8_t* __restrict__ qblock, const int8_t* __restrict__ tblock, const int8_t* __restrict__ cbs,
 	const int8_t* __restrict__ matrix, const dmnd_dp_target* __restrict__ items, const int32_t* __restrict__ pairs,
@@ -134,8 +134,8 @@ void banded_swipe16_kernel(const int8_t* __restrict__ qblock, const int8_t* __re
 		lane16_scores(st, table, N0, N1);
 		const uint32_t revt = 0xffffu - (uint32_t)t;
 		pk16 tb0[P], tb1[P];
-		lane16_step<P, TRACE, 0>(st, S0, shr1_z(st.F[2 * P - 1]), go, ge, revt, tb0);
-		lane16_step<P, TRACE, 1>(st, S1, shl1_z(st.E[0]), go, ge, revt, tb1);
+		lane16_step<P, TRACE, 0, COORDS>(st, S0, shr1_z(st.F[2 * P - 1]), go, ge, revt, tb0);
+		lane16_step<P, TRACE, 1, COORDS>(st, S1, shl1_z(st.E[0]), go, ge, revt, tb1);
 		if (TRACE) acc.template put<R>(tb0, tb1);
 #pragma unroll
 		for (int p = 0; p < P; ++p) { S0[p] = N0[p]; S1[p] = N1[p]; }
@@ -180,7 +180,7 @@ void banded_swipe16_kernel(const int8_t* __restrict__ qblock, const int8_t* __re
 	for (int item = 0; item < 2; ++item) {
 		if (item == 1 && !hasB) break;
 		int bs, bi, bj;
-		lane16_finish(st, item ? B.g : A.g, item == 1, lane, bs, bi, bj);
+		lane16_finish<P, COORDS>(st, item ? B.g : A.g, item == 1, lane, bs, bi, bj);
 #pragma unroll
 		for (int off = 32; off >= 1; off >>= 1) {
 			const int os = __shfl_xor(bs, off), oi = __shfl_xor(bi, off), oj = __shfl_xor(bj, off);
@@ -201,7 +201,7 @@ void banded_swipe16_kernel(const int8_t* __restrict__ qblock, const int8_t* __re
 // always there). A row without an item sweeps a copy of another one and stores nothing.
 enum { ROW_EDGE_CHUNK = 120 };        // pair-steps per refill of a row's edge records: a multiple of both G = 5 and G = 3
 
-template<int P, bool TRACE>
+template<int P, bool TRACE, bool COORDS = true>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * 64)
 void banded_swipe16_rows_kernel(const int8_t* __restrict__ qblock, const int8_t* __restrict__ tblock, const int8_t* __restrict__ cbs,
 	const int8_t* __restrict__ matrix, const dmnd_dp_target* __restrict__ items, const int32_t* __restrict__ pairs,
@@ -256,8 +256,8 @@ void banded_swipe16_rows_kernel(const int8_t* __restrict__ qblock, const int8_t*
 		lane16_scores(st, table, N0, N1);
 		const uint32_t revt = 0xffffu - (uint32_t)t;
 		pk16 tb0[P], tb1[P];
-		lane16_step<P, TRACE, 0>(st, S0, rshr1_z(st.F[2 * P - 1]), go, ge, revt, tb0);
-		lane16_step<P, TRACE, 1>(st, S1, rshl1_z(st.E[0]), go, ge, revt, tb1);
+		lane16_step<P, TRACE, 0, COORDS>(st, S0, rshr1_z(st.F[2 * P - 1]), go, ge, revt, tb0);
+		lane16_step<P, TRACE, 1, COORDS>(st, S1, rshl1_z(st.E[0]), go, ge, revt, tb1);
 		if (TRACE) acc.template put<R>(tb0, tb1);
 #pragma unroll
 		for (int p = 0; p < P; ++p) { S0[p] = N0[p]; S1[p] = N1[p]; }
@@ -298,7 +298,7 @@ void banded_swipe16_rows_kernel(const int8_t* __restrict__ qblock, const int8_t*
 		const dmnd_dp_target it = items[again(item ? idxB : idxA)];
 		const Geom g = make_geom(it.query_len, it.target_len, it.d_begin, it.d_end);
 		int bs, bi, bj;
-		lane16_finish(st, g, item == 1, rl, bs, bi, bj);
+		lane16_finish<P, COORDS>(st, g, item == 1, rl, bs, bi, bj);
 #pragma unroll
 		for (int off = 8; off >= 1; off >>= 1) {
 			const int os = __shfl_xor(bs, off), oi = __shfl_xor(bi, off), oj = __shfl_xor(bj, off);
@@ -322,6 +322,7 @@ static hipError_t launch16_rows(bool trace, const Swipe16Args& a, hipStream_t st
 		return hipSuccess;
 	const dim3 grid(blocks), block(WAVES_PER_BLOCK * 64);
 	if (trace) hipLaunchKernelGGL((banded_swipe16_rows_kernel<P, true>), grid, block, 0, stream, a.qblock, a.tblock, a.cbs, a.matrix, a.items, a.pairs, a.trace_off, a.trace, a.ends, a.n_pairs, a.gap_open, a.gap_extend);
+	else if (a.score_only) hipLaunchKernelGGL((banded_swipe16_rows_kernel<P, false, false>), grid, block, 0, stream, a.qblock, a.tblock, a.cbs, a.matrix, a.items, a.pairs, a.trace_off, a.trace, a.ends, a.n_pairs, a.gap_open, a.gap_extend);
 	else hipLaunchKernelGGL((banded_swipe16_rows_kernel<P, false>), grid, block, 0, stream, a.qblock, a.tblock, a.cbs, a.matrix, a.items, a.pairs, a.trace_off, a.trace, a.ends, a.n_pairs, a.gap_open, a.gap_extend);
 	return hipGetLastError();
 }
@@ -334,6 +335,7 @@ static hipError_t launch16_p(bool trace, const Swipe16Args& a, hipStream_t strea
 		return hipSuccess;
 	const dim3 grid(blocks), block(WAVES_PER_BLOCK * 64);
 	if (trace) hipLaunchKernelGGL((banded_swipe16_kernel<P, true>), grid, block, 0, stream, a.qblock, a.tblock, a.cbs, a.matrix, a.items, a.pairs, a.trace_off, a.trace, a.ends, a.n_pairs, a.gap_open, a.gap_extend);
+	else if (a.score_only) hipLaunchKernelGGL((banded_swipe16_kernel<P, false, false>), grid, block, 0, stream, a.qblock, a.tblock, a.cbs, a.matrix, a.items, a.pairs, a.trace_off, a.trace, a.ends, a.n_pairs, a.gap_open, a.gap_extend);
 	else hipLaunchKernelGGL((banded_swipe16_kernel<P, false>), grid, block, 0, stream, a.qblock, a.tblock, a.cbs, a.matrix, a.items, a.pairs, a.trace_off, a.trace, a.ends, a.n_pairs, a.gap_open, a.gap_extend);
 	return hipGetLastError();
 }

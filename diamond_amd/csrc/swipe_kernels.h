@@ -71,6 +71,7 @@ struct Swipe16Args {
 	SwipeEnd* ends;              // indexed by item; score == 32767: saturated, to be re-run in the 32-bit kernel
 	int64_t n_pairs;             // wavefronts
 	int32_t gap_open, gap_extend;
+	bool score_only = false;     // (without trace) only ends[].score and the saturation flag are wanted: no end cells
 };
 
 hipError_t launch_banded_swipe(int P, int mode, const SwipeArgs& a, hipStream_t stream);

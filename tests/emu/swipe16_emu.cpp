@@ -28,7 +28,7 @@ static void put_r(Trace16Group<P>& acc, int r, const pk16* tb0, const pk16* tb1)
 	}
 }
 
-template<int P, bool TRACE>
+template<int P, bool TRACE, bool COORDS = true>
 static void run16(const Emu16Item& A, const Emu16Item& B, const int8_t* M, int gap_open, int gap_extend, Emu16Out* outA, Emu16Out* outB,
 	uint8_t* trA, uint8_t* trB, int cap)
 {
@@ -52,8 +52,8 @@ static void run16(const Emu16Item& A, const Emu16Item& B, const int8_t* M, int g
 			if (par == 0) for (int l = 0; l < L; ++l) nb[l] = l == 0 ? 0 : st[l - 1].F[2 * P - 1];
 			else for (int l = 0; l < L; ++l) nb[l] = l == L - 1 ? 0 : st[l + 1].E[0];
 			for (int l = 0; l < L; ++l) {
-				if (par == 0) lane16_step<P, TRACE, 0>(st[l], S0[l], nb[l], go, ge, revt, tb[l]);
-				else lane16_step<P, TRACE, 1>(st[l], S1[l], nb[l], go, ge, revt, tb[l]);
+				if (par == 0) lane16_step<P, TRACE, 0, COORDS>(st[l], S0[l], nb[l], go, ge, revt, tb[l]);
+				else lane16_step<P, TRACE, 1, COORDS>(st[l], S1[l], nb[l], go, ge, revt, tb[l]);
 			}
 			if (TRACE && par == 0)
 				for (int l = 0; l < L; ++l) for (int p = 0; p < P; ++p) tbe[l][p] = tb[l][p];
@@ -86,12 +86,12 @@ static void run16(const Emu16Item& A, const Emu16Item& B, const int8_t* M, int g
 		int bs = 0, bi = 0, bj = 0x7fffffff;
 		for (int l = 0; l < L; ++l) {
 			int s, i, j;
-			lane16_finish(st[l], g, item == 1, l, s, i, j);
+			lane16_finish<P, COORDS>(st[l], g, item == 1, l, s, i, j);
 			if (better_end(s, j, i, bs, bj, bi)) { bs = s; bi = i; bj = j; }
 		}
 		memset(out, 0, sizeof(*out));
 		out->score = bs;
-		if (bs > 0) { out->q_end = bi + 1; out->s_end = bj + 1; }
+		if (bs > 0 && COORDS) { out->q_end = bi + 1; out->s_end = bj + 1; }
 		if (TRACE && bs > 0 && bs < SW16_MAX_SCORE) {
 			const WalkResult r = traceback_walk((item ? traceB : traceA).data(), g, P, v, gap_open, gap_extend, bs, bi, bj, item ? trB : trA, cap);
 			out->q_begin = r.q_begin; out->s_begin = r.s_begin; out->length = r.length; out->identities = r.identities;
@@ -101,7 +101,7 @@ static void run16(const Emu16Item& A, const Emu16Item& B, const int8_t* M, int g
 	}
 }
 
-// trace != 0: traceback mode (coordinates, statistics and transcripts of both items); force_p: 0 = the pair's class; 3 / 5: the row
+// trace = 1: traceback mode (coordinates, statistics and transcripts of both items), 0: end cells, 2: scores only; force_p: 0 = the pair's class; 3 / 5: the row
 // class, if both bands fit its 96 / 160 diagonals
 extern "C" int emu_banded_swipe16(const Emu16Item* A, const Emu16Item* B, const int8_t* M, int gap_open, int gap_extend, int trace, int force_p,
 	Emu16Out* outA, Emu16Out* outB, uint8_t* trA, uint8_t* trB, int cap)
@@ -114,11 +114,11 @@ extern "C" int emu_banded_swipe16(const Emu16Item* A, const Emu16Item* B, const 
 	}
 	else if (force_p > P) P = force_p;
 	switch (P) {
-	case 3: if (trace) run16<3, true>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); else run16<3, false>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); break;
-	case 5: if (trace) run16<5, true>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); else run16<5, false>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); break;
-	case 1: if (trace) run16<1, true>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); else run16<1, false>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); break;
-	case 2: if (trace) run16<2, true>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); else run16<2, false>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); break;
-	case 4: if (trace) run16<4, true>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); else run16<4, false>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); break;
+	case 3: if (trace == 1) run16<3, true>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); else if (trace == 2) run16<3, false, false>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); else run16<3, false>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); break;
+	case 5: if (trace == 1) run16<5, true>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); else if (trace == 2) run16<5, false, false>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); else run16<5, false>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); break;
+	case 1: if (trace == 1) run16<1, true>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); else if (trace == 2) run16<1, false, false>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); else run16<1, false>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); break;
+	case 2: if (trace == 1) run16<2, true>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); else if (trace == 2) run16<2, false, false>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); else run16<2, false>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); break;
+	case 4: if (trace == 1) run16<4, true>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); else if (trace == 2) run16<4, false, false>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); else run16<4, false>(*A, *B, M, gap_open, gap_extend, outA, outB, trA, trB, cap); break;
 	default: return -4;
 	}
 	return 0;

@@ -47,7 +47,8 @@ class Emu16Item(ctypes.Structure):
 
 
 def banded_swipe16(a, b, matrix8, gap_open, gap_extend, trace=True, force_p=0, cap=1 << 17):
-    """Two work items (dicts: query, cbs, target, d_begin, d_end) through the packed-int16 two-items-per-wavefront emulator."""
+    """Two work items (dicts: query, cbs, target, d_begin, d_end) through the packed-int16 two-items-per-wavefront emulator.
+    trace: True = traceback mode, False = end cells, "score" = scores only (one packed max per cell instead of the end-cell keys)."""
     keep = []
 
     def item(x):
@@ -62,7 +63,7 @@ def banded_swipe16(a, b, matrix8, gap_open, gap_extend, trace=True, force_p=0, c
     oa, ob = EmuOut(), EmuOut()
     tra, trb = np.zeros(cap, np.uint8), np.zeros(cap, np.uint8)
     rc = lib().emu_banded_swipe16(ctypes.byref(ia), ctypes.byref(ib), m.ctypes.data_as(ctypes.c_void_p), int(gap_open), int(gap_extend),
-                                  int(bool(trace)), int(force_p), ctypes.byref(oa), ctypes.byref(ob),
+                                  2 if trace == "score" else int(bool(trace)), int(force_p), ctypes.byref(oa), ctypes.byref(ob),
                                   tra.ctypes.data_as(ctypes.c_void_p), trb.ctypes.data_as(ctypes.c_void_p), cap)
     da = {n: getattr(oa, n) for n, _ in EmuOut._fields_}
     db = {n: getattr(ob, n) for n, _ in EmuOut._fields_}

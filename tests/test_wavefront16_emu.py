@@ -19,6 +19,8 @@ def _check_pair(a, b, M, go=11, ge=1, force_p=0):
     assert rc == 0
     rc, sa, sb = emu.banded_swipe16(a, b, M, go, ge, False, force_p)
     assert rc == 0
+    rc, ca, cb = emu.banded_swipe16(a, b, M, go, ge, "score", force_p)
+    assert rc == 0 and ca[0]["score"] == sa[0]["score"] and cb[0]["score"] == sb[0]["score"]
     for x, (e, etr), (s, _) in ((a, ra, sa), (b, rb, sb)):
         rc, o, otr = orc.banded_swipe(x["query"], x.get("cbs"), x["target"], x["d_begin"], x["d_end"], M, go, ge, orc.TRACEBACK)
         assert rc == 0
