@@ -199,7 +199,7 @@ void banded_swipe16_kernel(const int8_t* __restrict__ qblock, const int8_t* __re
 // ---- row classes ----------------------------------------------------------------------------------------------------------
 // pairs[8 w + 2 r], pairs[8 w + 2 r + 1]: the items A / B of row r of wavefront w (-1: none -- the tail of a class; the first is
 // always there). A row without an item sweeps a copy of another one and stores nothing.
-enum { ROW_EDGE_CHUNK = 120 };        // pair-steps per refill of a row's edge records: a multiple of both G = 5 and G = 3
+enum { ROW_EDGE_CHUNK = 60 };         // pair-steps per refill of a row's edge records: a multiple of both G = 5 and G = 3 (16 KB per workgroup: the registers, not the LDS, bound the wavefronts per SIMD)
 
 template<int P, bool TRACE, bool COORDS = true>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * 64)
