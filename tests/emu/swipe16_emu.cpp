@@ -123,3 +123,13 @@ extern "C" int emu_banded_swipe16(const Emu16Item* A, const Emu16Item* B, const 
 	}
 	return 0;
 }
+
+// ---- the launch classes and the trace layout as plain numbers (tests/test_wavefront16_emu.py checks them without a sweep) ----
+extern "C" int emu_band_class(int band, int rows) { return rows ? band_class_rows(band) : band_class(band); }
+extern "C" int emu_class_index(int P) { return class_index(P); }
+extern "C" int emu_class_of_index(int c) { return class_of_index(c); }
+extern "C" int emu_class_lanes(int P) { return class_lanes(P); }
+extern "C" int emu_items_per_wave16(int P) { return class_items_per_wave16(P); }
+extern "C" long long emu_trace_bytes(int qlen, int tlen, int d_begin, int d_end, int P) { return (long long)trace_bytes(make_geom(qlen, tlen, d_begin, d_end), P); }
+extern "C" long long emu_trace_byte_index(int P, int t, int x) { return (long long)trace_byte_index(P, t, x); }
+extern "C" int emu_trace_pairs(int qlen, int tlen, int d_begin, int d_end) { return (int)trace_pairs(make_geom(qlen, tlen, d_begin, d_end)); }

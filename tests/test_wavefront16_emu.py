@@ -122,6 +122,43 @@ def test_row_classes():
         _check_pair(narrow[i], narrow[i + 1], hdr["matrix8"], hdr["gap_open"], hdr["gap_extend"], force_p=3 if w <= 96 else 5)
 
 
+def test_launch_classes_and_trace_layout_arithmetic():
+    """Band -> class (with and without the row classes), class <-> class number, and the trace layout of every class the packed
+    kernels take: every (pair-step, diagonal pair) of an item has a byte of its own inside the item's trace_bytes."""
+    import ctypes
+    L = emu.lib()
+    L.emu_trace_bytes.restype = ctypes.c_longlong
+    L.emu_trace_byte_index.restype = ctypes.c_longlong
+    for band in range(1, 700):
+        p2 = L.emu_band_class(band, 0)
+        assert p2 & (p2 - 1) == 0 and 128 * p2 >= band and (p2 == 1 or 64 * p2 < band)
+        pr = L.emu_band_class(band, 1)
+        assert pr == (3 if band <= 96 else 1 if band <= 128 else 5 if band <= 160 else p2)
+        assert 2 * pr * L.emu_class_lanes(pr) >= band
+    seen = set()
+    for P in (1, 2, 3, 4, 5, 8, 16, 32, 64, 128, 256, 512):
+        c = L.emu_class_index(P)
+        assert 0 <= c < 16 and c not in seen and L.emu_class_of_index(c) == P
+        seen.add(c)
+        assert L.emu_items_per_wave16(P) == (8 if P in (3, 5) else 2) and L.emu_class_lanes(P) == (16 if P in (3, 5) else 64)
+    rng = np.random.default_rng(4)
+    for P in (1, 2, 3, 4, 5, 16):
+        lanes = L.emu_class_lanes(P)
+        for _ in range(6):
+            qlen, tlen = int(rng.integers(1, 300)), int(rng.integers(1, 300))
+            width = int(rng.integers(1, 2 * P * lanes + 1))
+            d0 = int(rng.integers(-(tlen - 1), qlen))
+            pairs = L.emu_trace_pairs(qlen, tlen, d0, d0 + width)
+            size = L.emu_trace_bytes(qlen, tlen, d0, d0 + width, P)
+            idx = np.array([[L.emu_trace_byte_index(P, t, x) for x in range(lanes * P)] for t in range(pairs)], dtype=np.int64)
+            assert idx.size == 0 or (idx.min() >= 0 and idx.max() < size)
+            assert len(np.unique(idx)) == idx.size
+            if P < 16 and pairs:      # a lane's bytes of one group of pair-steps are one 16-byte record
+                G = 16 // P
+                rec = idx[:G, :P] // 16
+                assert len(np.unique(rec)) == 1
+
+
 def test_ties_and_repeats():
     hdr, _ = read_tap(os.path.join(GOLDEN, "swipe_fast.tap"), max_records=1)
     M = hdr["matrix8"]
