@@ -26,8 +26,8 @@
 //   DP::BandedSwipe::bin                    src/dp/swipe/swipe_wrapper.cpp:75-102
 //   Target::add_hit / inner_culling, culling, output_range   src/align/target.h:97-113, culling.cpp:37-113,189-203
 //   round-2 add_dp_targets / align          src/align/gapped_final.cpp:66-160
-//   join of reference blocks                src/output/join_blocks.cpp:129-256
-//   six-frame translation, blast tab fields src/util/sequence/translate.h, src/output/blast_tab_format.cpp
+//   (the join of reference blocks, the blast tab line and the six-frame translation lived here until round 6:
+//    join_blocks.hip, format_tab.hip, translate.hip)
 //   composition-based matrix adjustment     src/align/ungapped.cpp:44-58 -> cbs_adjust.cpp (--comp-based-stats 2 - 5)
 // Scope: blastp and blastx (1 or 6 query contexts), any max_hsps, comp-based-stats 0 - 5, gapped filter, ranking chunks,
 // id / coverage filters; no frameshift alignment.
@@ -54,6 +54,7 @@
 #include "read_coverage.h"
 #include "plan_kernels.h"
 #include "extend_kernels.h"
+#include "match_order.h"
 #include <unordered_map>
 
 namespace dmnd {
@@ -471,16 +472,6 @@ bool cand_less(const Cand& a, const Cand& b)                 // Target::comp_eva
 bool cand_less_score(const Cand& a, const Cand& b)           // Target::comp_score
 {
 	return a.score > b.score || (a.score == b.score && a.target < b.target);
-}
-
-bool match_less(const dmnd_match& a, const dmnd_match& b)    // Match::cmp_evalue, extend.h:51-56
-{
-	return a.evalue < b.evalue || (a.evalue == b.evalue && (a.hsp.score > b.hsp.score || (a.hsp.score == b.hsp.score && a.target < b.target)));
-}
-
-bool match_less_score(const dmnd_match& a, const dmnd_match& b)      // Match::cmp_score
-{
-	return a.hsp.score > b.hsp.score || (a.hsp.score == b.hsp.score && a.target < b.target);
 }
 
 // what is reported of a sorted list (output_range, culling.cpp:97-113): the first -k entries, or with --top the entries whose bit
@@ -2070,136 +2061,6 @@ extern "C" int dmnd_set_top_percent(dmnd_ctx* c, double percent)
 	return DMND_OK;
 }
 
-// join_query with --top: the heap merge runs on JoinRecord::cmp_score (score descending, target ordinal ascending) and GlobalCulling
-// keeps a target while (1 - bit score / best bit score) * 100 <= toppercent (output/target_culling.h:62-63)
-namespace {
-
-// The records of a join: consecutive records of one (query, target) pair are the HSPs of one match (dmnd_set_max_hsps) and move
-// together, ranked by the first one. Returns the matches as (first record, count), ordered by query and `less` of the first records.
-// Every block's list arrives in (query, rank) order and query ids are dense, so the order is made by a counting sort of the matches
-// by query (stable: block order) and a small sort per query -- not one comparison sort over everything (C5: 116 k records of 8
-// blocks, 20 ms of every 62 ms step went into std::stable_sort here).
-template<typename Less>
-std::vector<std::pair<int64_t, int64_t>> join_groups(const dmnd_match* r, int64_t n, Less less)
-{
-	std::vector<std::pair<int64_t, int64_t>> g;
-	g.reserve((size_t)n);
-	uint32_t max_query = 0;
-	for (int64_t i = 0; i < n;) {
-		int64_t j = i + 1;
-		while (j < n && r[j].query == r[i].query && r[j].target == r[i].target) ++j;
-		g.emplace_back(i, j - i);
-		max_query = std::max(max_query, r[i].query);
-		i = j;
-	}
-	auto by_rank = [&](const std::pair<int64_t, int64_t>& a, const std::pair<int64_t, int64_t>& b) { return less(r[a.first], r[b.first]); };
-	if (g.empty()) return g;
-	if ((uint64_t)max_query > 4 * (uint64_t)g.size() + 1024) {          // sparse query ids: one sort
-		std::stable_sort(g.begin(), g.end(), [&](const std::pair<int64_t, int64_t>& a, const std::pair<int64_t, int64_t>& b) {
-			return r[a.first].query < r[b.first].query || (r[a.first].query == r[b.first].query && less(r[a.first], r[b.first]));
-		});
-		return g;
-	}
-	std::vector<int64_t> start((size_t)max_query + 2, 0);
-	for (const auto& x : g) ++start[(size_t)r[x.first].query + 1];
-	for (size_t q = 1; q < start.size(); ++q) start[q] += start[q - 1];
-	std::vector<std::pair<int64_t, int64_t>> out(g.size());
-	{
-		std::vector<int64_t> at(start.begin(), start.end() - 1);
-		for (const auto& x : g) out[(size_t)at[r[x.first].query]++] = x;
-	}
-	for (size_t q = 0; q + 1 < start.size(); ++q)
-		if (start[q + 1] - start[q] > 1) std::stable_sort(out.begin() + (ptrdiff_t)start[q], out.begin() + (ptrdiff_t)start[q + 1], by_rank);
-	return out;
-}
-
-// the kept matches in their new order: gathered into a scratch array (independent reads, sequential writes), copied back. (An
-// in-place permutation along the chains of the mapping moves every record once instead of twice and was slower: its reads depend
-// on each other.)
-void write_groups(dmnd_match* r, const std::vector<std::pair<int64_t, int64_t>>& keep, int64_t* n_out)
-{
-	int64_t total = 0;
-	for (const auto& g : keep) total += g.second;
-	std::vector<dmnd_match> out((size_t)total);
-	int64_t w = 0;
-	for (const auto& g : keep) for (int64_t k = 0; k < g.second; ++k) out[(size_t)w++] = r[g.first + k];
-	std::copy(out.begin(), out.end(), r);
-	*n_out = total;
-}
-
-}
-
-extern "C" int dmnd_join_blocks_top(dmnd_match* r, int64_t n, double top_percent, int64_t* n_out)
-{
-	if (!r || n < 0 || top_percent < 0.0 || !n_out) return fail(DMND_E_ARG, "dmnd_join_blocks_top: bad argument");
-	const auto groups = join_groups(r, n, match_less_score);
-	std::vector<std::pair<int64_t, int64_t>> keep;
-	double top_score = 0.0;
-	bool finished = false;
-	for (size_t i = 0; i < groups.size(); ++i) {
-		const dmnd_match& m = r[groups[i].first];
-		if (i == 0 || m.query != r[groups[i - 1].first].query) { top_score = m.bit_score; finished = false; }
-		if (finished) continue;
-		if ((1.0 - m.bit_score / top_score) * 100.0 <= top_percent) keep.push_back(groups[i]);
-		else finished = true;
-	}
-	write_groups(r, keep, n_out);
-	return DMND_OK;
-}
-
-// join_query over the records of several reference blocks (output/join_blocks.cpp:180-256): every block's list of a query is
-// already in match_less order, so the reference's heap merge by JoinRecord::cmp_evalue (join_blocks.cpp:129-142) is the sort of
-// the union by (e-value, score descending, target ordinal); GlobalCulling keeps the first max_target_seqs (target_culling.h:70-88).
-extern "C" int dmnd_join_blocks(dmnd_match* r, int64_t n, int max_target_seqs, int64_t* n_out)
-{
-	if (!r || n < 0 || max_target_seqs < 1 || !n_out) return fail(DMND_E_ARG, "dmnd_join_blocks: bad argument");
-	const auto groups = join_groups(r, n, match_less);
-	std::vector<std::pair<int64_t, int64_t>> keep;
-	int64_t run = 0;
-	for (size_t i = 0; i < groups.size(); ++i) {
-		run = (i > 0 && r[groups[i].first].query == r[groups[i - 1].first].query) ? run + 1 : 0;
-		if (run < max_target_seqs) keep.push_back(groups[i]);
-	}
-	write_groups(r, keep, n_out);
-	return DMND_OK;
-}
-
-// join_query with --range-culling (blastx -F n --range-culling / --long-reads over a database of several reference blocks): the
-// reference builds its join culler with TargetCulling::get (output/target_culling.cpp:22-28), which is RangeCulling then -- a
-// target of the merged order (JoinRecord::cmp_evalue, or cmp_score with --top) is dropped (NEXT, never FINISHED) when
-// range_cover per cent of its HSPs' read intervals are already covered: by max_target_seqs kept alignments
-// (IntervalPartition::covered), or with --top by one kept alignment of at least score / (1 - top / 100)
-// (covered(..., MaxScore), output/target_culling.h:123-150). Kept targets add their intervals (IntermediateRecord::
-// absolute_query_range = dmnd_match::read_begin / read_end). Rounds 3-4 applied GlobalCulling here whatever the mode: every
-// target outside the top per cent of the read's single best score was lost, also when it covers another part of the read.
-extern "C" int dmnd_join_blocks_range(dmnd_match* r, int64_t n, int max_target_seqs, double top_percent, double range_cover, int64_t* n_out)
-{
-	if (!r || n < 0 || max_target_seqs < 1 || top_percent > 100.0 || !n_out) return fail(DMND_E_ARG, "dmnd_join_blocks_range: bad argument");
-	if (top_percent >= 100.0) top_percent = -1.0;       // RangeCulling: toppercent == 100.0 means "no --top" (the count-based coverage test, cmp_evalue order)
-	const auto groups = top_percent >= 0.0 ? join_groups(r, n, match_less_score) : join_groups(r, n, match_less);
-	std::vector<std::pair<int64_t, int64_t>> keep;
-	Coverage cover(max_target_seqs);
-	for (size_t i = 0; i < groups.size(); ++i) {
-		if (i == 0 || r[groups[i].first].query != r[groups[i - 1].first].query) cover = Coverage(max_target_seqs);
-		int cv = 0, len = 0;
-		for (int64_t k = 0; k < groups[i].second; ++k) {
-			const dmnd_match& m = r[groups[i].first + k];
-			if (m.read_end <= m.read_begin) return fail(DMND_E_ARG, "dmnd_join_blocks_range: a record without its interval of the read (read_begin / read_end are set by frameshift alignment)");
-			const Interval iv{ m.read_begin, m.read_end };
-			cv += top_percent < 0.0 ? cover.covered(iv) : cover.covered_max(iv, (int)((double)m.hsp.score / (1.0 - top_percent / 100.0)));
-			len += iv.length();
-		}
-		if (!((double)cv / len * 100.0 < range_cover)) continue;
-		for (int64_t k = 0; k < groups[i].second; ++k) {
-			const dmnd_match& m = r[groups[i].first + k];
-			cover.insert(Interval{ m.read_begin, m.read_end }, m.hsp.score);
-		}
-		keep.push_back(groups[i]);
-	}
-	write_groups(r, keep, n_out);
-	return DMND_OK;
-}
-
 // [0] round-1 DpTargets [1] round-2 DpTargets [2] round-1 cells [3] round-2 cells (DpTarget::cells, dp/dp.h:121-124)
 // host wall ms: [4] Hauser+upload [5] chaining/plan [6] round-1 call [7] culling [8] round-2 call
 // device ms: [9] round-1 swipe kernels [10] round-2 swipe kernels [11] traceback kernel
@@ -2237,38 +2098,6 @@ extern "C" int dmnd_extend_records_device(const dmnd_ctx* c, const dmnd_match** 
 	return DMND_OK;
 }
 
-extern "C" int dmnd_join_blocks_device(dmnd_ctx* c, const dmnd_match* records_dev, int64_t n, int max_target_seqs, double top_percent, uint32_t max_query,
-	dmnd_match* out_dev, int64_t* n_out);
-
-extern "C" int dmnd_join_contexts_device(dmnd_ctx* join_ctx, dmnd_ctx* const* ctx, const uint32_t* target_offset, int n_ctx, int max_target_seqs, double top_percent,
-	uint32_t max_query, dmnd_match* out, int64_t cap, int64_t* n_out)
-{
-	if (!join_ctx || !ctx || !target_offset || n_ctx < 1 || !n_out || cap < 0 || (cap > 0 && !out)) return fail(DMND_E_ARG, "dmnd_join_contexts_device: bad argument");
-	*n_out = 0;
-	int64_t total = 0;
-	for (int k = 0; k < n_ctx; ++k) {
-		if (!ctx[k] || ctx[k]->device != join_ctx->device) return fail(DMND_E_ARG, "dmnd_join_contexts_device: the contexts must be on the join context's device");
-		if (ctx[k]->ext_records_n < 0) return fail(DMND_E_ARG, "dmnd_join_contexts_device: context " + std::to_string(k) + " holds no complete device copy of its last dmnd_extend's records (dmnd_extend_records_device)");
-		total += ctx[k]->ext_records_n;
-	}
-	if (total == 0) return DMND_OK;
-	if (total > 0xffffffffLL) return fail(DMND_E_CAP, "dmnd_join_contexts_device: more than 2^32 records");
-	HIP_TRY(hipSetDevice(join_ctx->device));
-	if (int rc = join_ctx->join_in.ensure((size_t)total * sizeof(dmnd_match))) return rc;
-	if (int rc = join_ctx->join_out.ensure((size_t)total * sizeof(dmnd_match))) return rc;
-	int64_t at = 0;
-	for (int k = 0; k < n_ctx; ++k) {      // (dmnd_extend left every source's stream idle: the records are final)
-		HIP_TRY(launch_ext_gather(join_ctx->join_in.as<dmnd_match>() + at, ctx[k]->ext_records_dev, (uint32_t)ctx[k]->ext_records_n, target_offset[k], join_ctx->stream));
-		at += ctx[k]->ext_records_n;
-	}
-	int64_t kept = 0;
-	if (int rc = dmnd_join_blocks_device(join_ctx, join_ctx->join_in.as<dmnd_match>(), total, max_target_seqs, top_percent, max_query, join_ctx->join_out.as<dmnd_match>(), &kept)) return rc;
-	*n_out = kept;
-	if (kept > cap) return fail(DMND_E_CAP, "dmnd_join_contexts_device: record buffer too small");
-	if (kept > 0) if (int rc = download_bytes(join_ctx, out, join_ctx->join_out.p, (size_t)kept * sizeof(dmnd_match))) return rc;
-	return DMND_OK;
-}
-
 extern "C" int dmnd_extend_device_stats(const dmnd_ctx* c, double out[10])
 {
 	if (!c || !out) return fail(DMND_E_ARG, "dmnd_extend_device_stats: NULL argument");
@@ -2283,53 +2112,6 @@ extern "C" int dmnd_extend_plan_stats(const dmnd_ctx* c, double out[3])
 	return DMND_OK;
 }
 
-// BLAST tabular line of one match (qseqid sseqid pident length mismatch gapopen qstart qend sstart send evalue bitscore),
-// formatted as the reference prints it (src/output/blast_tab_format.cpp; util/text_buffer.h:238-260).
-namespace {
-
-int format_tab_impl(const dmnd_match* m, const char* qseqid, const char* sseqid, int qstart, int qend, char* buf, int64_t cap)
-{
-	const dmnd_hsp& h = m->hsp;
-	// Util::String::format_double (util/string/string.h:87-92): >= 100 -> floor, else one rounded decimal
-	auto fd = [](double x, char* p, size_t n) {
-		if (x >= 100.0) std::snprintf(p, n, "%lli", (long long)std::floor(x));
-		else { const long long i = std::llround(x * 10.0); std::snprintf(p, n, "%lli.%lli", i / 10, i % 10); }
-	};
-	char pid[64], ev[64], bs[64];
-	fd((double)h.identities * 100.0 / (double)h.length, pid, sizeof pid);     // Hsp::id_percent
-	if (m->evalue == 0.0) std::snprintf(ev, sizeof ev, "0.0");                 // TextBuffer::print_e
-	else std::snprintf(ev, sizeof ev, "%.2e", m->evalue);
-	fd(m->bit_score, bs, sizeof bs);
-	const int w = std::snprintf(buf, (size_t)cap, "%s\t%s\t%s\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%s\t%s\n", qseqid, sseqid, pid, h.length,
-		h.mismatches, h.gap_openings, qstart, qend, h.s_begin + 1, h.s_end, ev, bs);
-	return w < cap ? w : DMND_E_CAP;
-}
-
-}
-
-extern "C" int dmnd_format_tab(const dmnd_match* m, const char* qseqid, const char* sseqid, char* buf, int64_t cap)
-{
-	if (!m || !qseqid || !sseqid || !buf) return fail(DMND_E_ARG, "dmnd_format_tab: NULL argument");
-	return format_tab_impl(m, qseqid, sseqid, m->hsp.q_begin + 1, m->hsp.q_end, buf, cap);
-}
-
-// Hsp::oriented_query_range over query_source_range (basic/match.h:168-174; TranslatedPosition::absolute_interval,
-// basic/translated_position.h:131-137): forward frame f reads DNA [f + 3 b, f + 3 e), reverse frames count from the 3' end
-extern "C" int dmnd_format_tab_translated(const dmnd_match* m, const char* qseqid, const char* sseqid, int32_t source_len, char* buf, int64_t cap)
-{
-	if (!m || !qseqid || !sseqid || !buf) return fail(DMND_E_ARG, "dmnd_format_tab_translated: NULL argument");
-	if (m->frame < 0 || m->frame > 5) return fail(DMND_E_ARG, "dmnd_format_tab_translated: frame out of range");
-	const int b = m->hsp.q_begin, e = m->hsp.q_end;
-	int qstart, qend;
-	if (m->read_end > m->read_begin) {                         // frameshift alignment: Hsp::query_source_range, oriented by the strand
-		if (m->frame < 3) { qstart = m->read_begin + 1; qend = m->read_end; }
-		else { qstart = m->read_end; qend = m->read_begin + 1; }
-	}
-	else if (m->frame < 3) { qstart = m->frame + 3 * b + 1; qend = m->frame + 3 * e; }
-	else { const int off = m->frame - 3; qstart = source_len - off - 3 * b; qend = source_len - off - 3 * e + 1; }
-	return format_tab_impl(m, qseqid, sseqid, qstart, qend, buf, cap);
-}
-
 extern "C" int dmnd_set_query_contexts(dmnd_ctx* c, int contexts)
 {
 	if (!c || (contexts != 1 && contexts != 6)) return fail(DMND_E_ARG, "dmnd_set_query_contexts: contexts must be 1 (blastp) or 6 (blastx)");
@@ -2337,112 +2119,3 @@ extern "C" int dmnd_set_query_contexts(dmnd_ctx* c, int contexts)
 	return DMND_OK;
 }
 
-// ---- six-frame translation (blastx query loading) ---------------------------------------------------------------------
-namespace {
-
-// NCBI genetic codes (the published translation tables, base order TCAG) that Translator::codes holds (basic/basic.cpp:86-113)
-struct GeneticCode { int id; const char* aa; };
-const GeneticCode GENETIC_CODES[] = {
-	{ 1,  "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG" },     // standard
-	{ 2,  "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIMMTTTTNNKKSS**VVVVAAAADDEEGGGG" },     // vertebrate mitochondrial
-	{ 3,  "FFLLSSSSYY**CCWWTTTTPPPPHHQQRRRRIIMMTTTTNNKKSSRRVVVVAAAADDEEGGGG" },     // yeast mitochondrial
-	{ 4,  "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG" },     // mold / protozoan mitochondrial, mycoplasma
-	{ 5,  "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIMMTTTTNNKKSSSSVVVVAAAADDEEGGGG" },     // invertebrate mitochondrial
-	{ 6,  "FFLLSSSSYYQQCC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG" },     // ciliate nuclear
-	{ 9,  "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIIMTTTTNNNKSSSSVVVVAAAADDEEGGGG" },     // echinoderm mitochondrial
-	{ 10, "FFLLSSSSYY**CCCWLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG" },     // euplotid nuclear
-	{ 11, "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG" },     // bacterial, archaeal, plant plastid
-	{ 12, "FFLLSSSSYY**CC*WLLLSPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG" },     // alternative yeast nuclear
-	{ 13, "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIMMTTTTNNKKSSGGVVVVAAAADDEEGGGG" },     // ascidian mitochondrial
-	{ 14, "FFLLSSSSYYY*CCWWLLLLPPPPHHQQRRRRIIIMTTTTNNNKSSSSVVVVAAAADDEEGGGG" },     // alternative flatworm mitochondrial
-	{ 16, "FFLLSSSSYY*LCC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG" },     // chlorophycean mitochondrial
-	{ 21, "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIMMTTTTNNNKSSSSVVVVAAAADDEEGGGG" },     // trematode mitochondrial
-	{ 22, "FFLLSS*SYY*LCC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG" },     // scenedesmus obliquus mitochondrial
-	{ 23, "FF*LSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG" },     // thraustochytrium mitochondrial
-	{ 24, "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSSKVVVVAAAADDEEGGGG" },     // rhabdopleuridae mitochondrial
-	{ 25, "FFLLSSSSYY**CCGWLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG" },     // candidate division SR1, gracilibacteria
-	{ 26, "FFLLSSSSYY**CC*WLLLAPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG" },     // pachysolen tannophilus nuclear
-};
-
-const char* genetic_code(int id)
-{
-	for (const GeneticCode& g : GENETIC_CODES) if (g.id == id) return g.aa;
-	return nullptr;
-}
-
-struct CodonTable {
-	int8_t fwd[5][5][5], rev[5][5][5];
-	explicit CodonTable(const char* code)
-	{
-		// Translator::init (basic/basic.cpp:116-139): base order TCAG; DNA letters A C G T N = 0..4
-		static const char* aa = "ARNDCQEGHILKMFPSTWYVBJZX*_";
-		static const int idx[4] = { 2, 1, 3, 0 }, comp[5] = { 3, 2, 1, 0, 4 };
-		auto letter = [&](char ch) { return (int8_t)(std::strchr(aa, ch) - aa); };
-		for (int i = 0; i < 5; ++i)
-			for (int j = 0; j < 5; ++j)
-				for (int k = 0; k < 5; ++k) {
-					if (i == 4 || j == 4 || k == 4) { fwd[i][j][k] = rev[i][j][k] = 23; continue; }
-					fwd[i][j][k] = letter(code[idx[i] * 16 + idx[j] * 4 + idx[k]]);
-					rev[i][j][k] = letter(code[idx[comp[i]] * 16 + idx[comp[j]] * 4 + idx[comp[k]]]);
-				}
-		for (int i = 0; i < 4; ++i)            // an N in the wobble position that cannot change the amino acid
-			for (int j = 0; j < 4; ++j) {
-				bool f = true, r = true;
-				for (int k = 1; k < 4; ++k) { f &= fwd[i][j][k] == fwd[i][j][0]; r &= rev[i][j][k] == rev[i][j][0]; }
-				if (f) fwd[i][j][4] = fwd[i][j][0];
-				if (r) rev[i][j][4] = rev[i][j][0];
-			}
-	}
-};
-
-// Util::Seq::find_orfs (util/sequence/sequence.cpp:180-197): stretches between stop codons shorter than min_len -> X
-void mask_short_orfs(int8_t* s, int n, int min_len)
-{
-	int begin = 0;
-	for (int i = 0; i <= n; ++i)
-		if (i == n || s[i] == 24) {
-			if (i - begin < min_len) for (int x = begin; x < i; ++x) s[x] = 23;
-			begin = i + 1;
-		}
-}
-
-}
-
-extern "C" int dmnd_translate_opts(const int8_t* dna, int32_t len, int gencode, int strands, int min_orf, int8_t* out[6], int32_t lens[6])
-{
-	if (!dna || !out || !lens || len < 0) return fail(DMND_E_ARG, "dmnd_translate: bad argument");
-	if (strands < 1 || strands > 3) return fail(DMND_E_ARG, "dmnd_translate: strands must be 1 (plus), 2 (minus) or 3 (both)");
-	const char* code = genetic_code(gencode);
-	if (!code) return fail(DMND_E_ARG, "Invalid genetic code id.");
-	static const CodonTable STANDARD(genetic_code(1));
-	CodonTable other_storage = STANDARD;
-	if (gencode != 1) other_storage = CodonTable(code);
-	const CodonTable& T = gencode == 1 ? STANDARD : other_storage;
-	for (int f = 0; f < 6; ++f) lens[f] = 0;
-	if (len < 3) return DMND_OK;
-	for (int32_t i = 0; i < len; ++i)
-		if (dna[i] < 0 || dna[i] > 4) return fail(DMND_E_ARG, "dmnd_translate: DNA letters must be 0-4 (ACGTN)");
-	for (int f = 0; f < 3; ++f) {
-		const int n = (len - f) / 3;
-		lens[f] = lens[f + 3] = n;
-		for (int i = 0; i < n; ++i) {
-			const int p = 3 * i + f;                                    // Translator::getAminoAcid
-			out[f][i] = T.fwd[dna[p]][dna[p + 1]][dna[p + 2]];
-			const int r = len - 3 - f - 3 * i;                           // Translator::getAminoAcidReverse(dna, r): letters r+2, r+1, r
-			out[f + 3][i] = T.rev[dna[r + 2]][dna[r + 1]][dna[r]];
-		}
-	}
-	// config.min_orf_len(frame 0 length): --min-orf, or by read length when it is 0 (basic/config.h:413-424)
-	const int l0 = lens[0], min_len = min_orf > 0 ? min_orf : l0 < 30 ? 1 : l0 < 100 ? 20 : 40;
-	for (int f = 0; f < 6; ++f) {
-		// frames of a strand that is not searched are all mask letters (frame_mask, data/sequence_file.cpp:286-294; Block::push_back, block.cpp:92-99)
-		if (strands & (f < 3 ? 1 : 2)) mask_short_orfs(out[f], lens[f], min_len);
-		else std::fill(out[f], out[f] + lens[f], (int8_t)23);
-	}
-	return DMND_OK;
-}
-
-extern "C" int dmnd_translate(const int8_t* dna, int32_t len, int8_t* out[6], int32_t lens[6])
-{
-	return dmnd_translate_opts(dna, len, 1, 3, 0, out, lens);
-}
