@@ -4,7 +4,7 @@
 # and the test-only helpers: oracle/_ref/* (CPU restatement + reference build), tests/emu/libswipe_emu.so
 HIPCC   ?= /opt/rocm/bin/hipcc
 CSRC    := diamond_amd/csrc
-HIPSRC  := $(CSRC)/api.hip $(CSRC)/swipe_kernels.hip $(CSRC)/swipe16_kernels.hip $(CSRC)/seed_api.hip $(CSRC)/seed_kernels.hip $(CSRC)/extend_host.hip $(CSRC)/gapped_api.hip $(CSRC)/gapped_kernels.hip $(CSRC)/mask_api.hip $(CSRC)/mask_kernels.hip $(CSRC)/bias_kernels.hip $(CSRC)/format_api.hip $(CSRC)/frameshift_api.hip $(CSRC)/frameshift_kernels.hip $(CSRC)/frameshift_host.hip $(CSRC)/join_device.hip $(CSRC)/rank_join.hip $(CSRC)/plan_kernels.hip $(CSRC)/extend_kernels.hip $(CSRC)/join_blocks.hip $(CSRC)/format_tab.hip $(CSRC)/translate.hip
+HIPSRC  := $(CSRC)/api.hip $(CSRC)/swipe_kernels.hip $(CSRC)/swipe16_kernels.hip $(CSRC)/seed_api.hip $(CSRC)/seed_kernels.hip $(CSRC)/extend_host.hip $(CSRC)/gapped_api.hip $(CSRC)/gapped_kernels.hip $(CSRC)/mask_api.hip $(CSRC)/mask_kernels.hip $(CSRC)/bias_kernels.hip $(CSRC)/format_api.hip $(CSRC)/frameshift_api.hip $(CSRC)/frameshift_kernels.hip $(CSRC)/frameshift_host.hip $(CSRC)/join_device.hip $(CSRC)/rank_join.hip $(CSRC)/plan_kernels.hip $(CSRC)/extend_kernels.hip $(CSRC)/extend_device.hip $(CSRC)/join_blocks.hip $(CSRC)/format_tab.hip $(CSRC)/translate.hip
 HIPHDR  := $(wildcard $(CSRC)/*.h) include/diamond_hip.h
 HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function
 
