@@ -443,7 +443,10 @@ def main():
         # several blocks per batch (C5): the extension of a block is a chain of short host and device phases; four batches in flight
         # with 24 host threads among them (more than the 16-CPU quota: most of the time they wait for the device) gave 50 ms per step
         # against 59 with two batches and 16 threads (profiles/r05_extension_contexts_sweep.txt) -- at the price of a third more CPU time
-        args.ext_contexts = (4 if world == 1 else 2) if many_blocks else 3
+        # one block per batch: 4 batches in flight with two seed stages at a time (round 6, tools/gpu_r06v.sh / gpu_r06w.sh, the two
+        # database blocks alternating in every variant: C3 145 -> 136 ms per step, C2 3.09 -> 3.00, C4 and C2skew unchanged against
+        # three batches and one seed stage)
+        args.ext_contexts = (4 if world == 1 else 2) if many_blocks else (4 if world == 1 else 3)
         if many_blocks and world == 1 and not args.host_threads:
             threads = max(threads, 24)
 
@@ -481,8 +484,12 @@ def main():
     # Several blocks (round 6): the seed stages of a BATCH (all its blocks, one query index) are one task on one context, and two such
     # tasks run at the same time on two contexts -- a seed stage of a 1.9e8-letter block is ~45 dependent launches and half a dozen
     # host waits around 2 ms of kernels, so one context alone left the device idle half of the time (C5: 54 -> see DESIGN 5.0).
+    # One block (round 6, after the extension left the host): with FOUR batches in the extension two seed stages at a time pay a
+    # little (C2: 3.09 / 3.16 ms per step with one seed stage and 3 / 4 extension contexts, 3.08 / 3.00 with two, 3.46 / 3.02 with
+    # three; C3: 145 -> 136). A first measurement of this without the alternating blocks showed 7-12 %: the second seed context
+    # switched the alternation off, and the block stayed in the Infinity Cache.
     if args.seed_contexts is None:
-        args.seed_contexts = 2 if NB > 1 else 1
+        args.seed_contexts = 2 if (NB > 1 or world == 1) else 1
     SC = 1 if not pipeline else max(1, args.seed_contexts)
     ctxs_seed = [make_ctx(None) for _ in range(SC)] if NB > 1 else ([make_ctx(0) for _ in range(SC)] if pipeline else ctxs)
     import queue as queue_mod
@@ -504,9 +511,9 @@ def main():
     state = {"stream_ms": 0.0, "stream_launches": 0}
     # Two database blocks alternate between the steps (round 5): block B holds the sequences of block A in reverse order, at its own
     # place in HBM -- the same work per step (same hits, cells and records up to the target numbers), but a step never streams the
-    # letters the step before it has just pulled through the Infinity Cache. Block B has its own seed context and its own extension
-    # context per extension team.
-    alternate = world == 1 and NB == 1 and pipeline and SC == 1 and not args.same_block
+    # letters the step before it has just pulled through the Infinity Cache. Block B has its own seed contexts (as many as block A:
+    # SC seed stages run at the same time, of either block) and its own extension context per extension team.
+    alternate = world == 1 and NB == 1 and pipeline and not args.same_block
     alt_host = None
     if alternate:
         lens = np.diff(w.doff)
@@ -524,17 +531,17 @@ def main():
             c.set_gapped_filter(gf_evalue)
             return c
         alt_ext_ctxs = [make_alt_ctx() for _ in range(E)]
-        seed_ctx_alt = make_alt_ctx()
+        seed_ctxs_alt = [make_alt_ctx() for _ in range(SC)]
+        seed_free_alt = queue_mod.Queue()
+        for c in seed_ctxs_alt:
+            seed_free_alt.put(c)
         seed_counter = [0]
 
     def seed_stage(b=0, alt=False, c=None):
         torch.cuda.set_device(local_rank)
         held = c is not None                                 # a batch task brings the context it holds for all its blocks
         if c is None:
-            c = seed_free.get()
-        if alt:                                              # block B has its own seed context (one seed stage runs at a time: SC = 1)
-            seed_free.put(c)
-            c = seed_ctx_alt
+            c = (seed_free_alt if alt else seed_free).get()      # block B has its own seed contexts
         try:
             if NB > 1:
                 if b == 0:
@@ -545,7 +552,9 @@ def main():
             wall = (time.perf_counter() - t_s) * 1e3
             ms = c.seed_kernel_ms()
         finally:
-            if not alt and not held:
+            if alt:
+                seed_free_alt.put(c)
+            elif not held:
                 seed_free.put(c)
         with seed_lock:
             state.setdefault("seed_wall", []).append(wall)
@@ -725,7 +734,7 @@ def main():
     sync()
     # hipDeviceSynchronize lets the runtime release the hardware queues of idle streams; re-acquiring them costs the first
     # timed calls milliseconds (a streaming caller never synchronizes the whole device)
-    for c in [x for cs in ext_ctxs for x in cs] + (ctxs_seed if ctxs_seed is not ctxs else []) + (alt_ext_ctxs + [seed_ctx_alt] if alternate else []):
+    for c in [x for cs in ext_ctxs for x in cs] + (ctxs_seed if ctxs_seed is not ctxs else []) + (alt_ext_ctxs + seed_ctxs_alt if alternate else []):
         c.touch_streams()
     state["stream_ms"], state["stream_launches"] = 0.0, 0
     state["seed_wall"], state["ext_wall"] = [], []
@@ -1046,7 +1055,7 @@ def main():
             tids = ["t%d" % i for i in range(w.n_db)]
             text = hip.format_tab(state["records"], qids, tids, w.source_lens)
             masked_text = hip.format_tab(masked_records, qids, tids, w.source_lens) if masked_records is not None else None
-            for c in (ctxs_seed if ctxs_seed is not ctxs else []) + [x for cs in ext_ctxs for x in cs] + (alt_ext_ctxs + [seed_ctx_alt] if alternate else []) + ([join_ctx] if join_ctx else []) + (set_join_ctxs or []):
+            for c in (ctxs_seed if ctxs_seed is not ctxs else []) + [x for cs in ext_ctxs for x in cs] + (alt_ext_ctxs + seed_ctxs_alt if alternate else []) + ([join_ctx] if join_ctx else []) + (set_join_ctxs or []):
                 c.close()
             closed = True
             torch.cuda.empty_cache()
@@ -1068,7 +1077,7 @@ def main():
         else:
             print_line(out)
     if not closed:
-        for c in (ctxs_seed if ctxs_seed is not ctxs else []) + [x for cs in ext_ctxs for x in cs] + (alt_ext_ctxs + [seed_ctx_alt] if alternate else []) + ([join_ctx] if join_ctx else []) + (set_join_ctxs or []):
+        for c in (ctxs_seed if ctxs_seed is not ctxs else []) + [x for cs in ext_ctxs for x in cs] + (alt_ext_ctxs + seed_ctxs_alt if alternate else []) + ([join_ctx] if join_ctx else []) + (set_join_ctxs or []):
             c.close()
     if world > 1:
         dist.barrier()
