@@ -439,14 +439,17 @@ def main():
     many_blocks = CONFIGS[args.config].get("blocks", 1) > world
     if many_blocks and not args.host_threads:
         threads = max(threads, min(16, cgroup_cpus()) // max(world, 1))      # the host part of 8 blocks per batch is the bound of C5 (measured: 86 -> 66 ms per step)
+    long_seed_stage = CONFIGS[args.config]["sens"] not in ("fast", "default")
     if args.ext_contexts is None:
         # several blocks per batch (C5): the extension of a block is a chain of short host and device phases; four batches in flight
         # with 24 host threads among them (more than the 16-CPU quota: most of the time they wait for the device) gave 50 ms per step
         # against 59 with two batches and 16 threads (profiles/r05_extension_contexts_sweep.txt) -- at the price of a third more CPU time
-        # one block per batch: 4 batches in flight with two seed stages at a time (round 6, tools/gpu_r06v.sh / gpu_r06w.sh, the two
-        # database blocks alternating in every variant: C3 145 -> 136 ms per step, C2 3.09 -> 3.00, C4 and C2skew unchanged against
-        # three batches and one seed stage)
-        args.ext_contexts = (4 if world == 1 else 2) if many_blocks else (4 if world == 1 else 3)
+        # one block per batch: three batches in flight, one seed stage at a time -- except for the sensitive modes, whose seed stage is
+        # 16 shapes long: two seed stages at a time and four batches (round 6, tools/gpu_r06v.sh / gpu_r06w.sh, the two database blocks
+        # alternating in every variant: C3 145 -> 136 ms per step; C2 3.09 -> 3.00 -- inside the noise, and two stream kernels that
+        # share the L2 request rate take twice as long each, which halves `roofline.frac` as it is defined on a launch's duration --;
+        # C4 and C2skew unchanged)
+        args.ext_contexts = (4 if world == 1 else 2) if many_blocks else (4 if world == 1 and long_seed_stage else 3)
         if many_blocks and world == 1 and not args.host_threads:
             threads = max(threads, 24)
 
@@ -484,12 +487,12 @@ def main():
     # Several blocks (round 6): the seed stages of a BATCH (all its blocks, one query index) are one task on one context, and two such
     # tasks run at the same time on two contexts -- a seed stage of a 1.9e8-letter block is ~45 dependent launches and half a dozen
     # host waits around 2 ms of kernels, so one context alone left the device idle half of the time (C5: 54 -> see DESIGN 5.0).
-    # One block (round 6, after the extension left the host): with FOUR batches in the extension two seed stages at a time pay a
-    # little (C2: 3.09 / 3.16 ms per step with one seed stage and 3 / 4 extension contexts, 3.08 / 3.00 with two, 3.46 / 3.02 with
-    # three; C3: 145 -> 136). A first measurement of this without the alternating blocks showed 7-12 %: the second seed context
-    # switched the alternation off, and the block stayed in the Infinity Cache.
+    # One block (round 6, after the extension left the host): two seed stages at a time pay for the sensitive modes only (C3:
+    # 145 -> 136 ms per step with four batches in the extension; C2: 3.09 / 3.16 ms per step with one seed stage and 3 / 4 extension
+    # contexts, 3.08 / 3.00 with two, 3.46 / 3.02 with three). A first measurement of this without the alternating blocks showed
+    # 7-12 % for every config: the second seed context switched the alternation off, and the block stayed in the Infinity Cache.
     if args.seed_contexts is None:
-        args.seed_contexts = 2 if (NB > 1 or world == 1) else 1
+        args.seed_contexts = 2 if (NB > 1 or (world == 1 and long_seed_stage)) else 1
     SC = 1 if not pipeline else max(1, args.seed_contexts)
     ctxs_seed = [make_ctx(None) for _ in range(SC)] if NB > 1 else ([make_ctx(0) for _ in range(SC)] if pipeline else ctxs)
     import queue as queue_mod

@@ -628,8 +628,8 @@ bool force_swipe32()
 
 // The row classes pay when a launch fills the chip: a wavefront of eight items issues three to five times the instructions of a
 // wavefront of two per anti-diagonal step, so a launch of a few thousand items (C2: 15 600 per batch, under one wavefront per SIMD
-// in the row form) is done sooner as many thin wavefronts, and a launch of 10^5 and more (C2skew, C3) sooner with 1.4 x fewer
-// instructions. Items of one call (host path) / one ranking iteration (device half) from which on the row classes are used.
+// in the row form; C5: 38 600 per call, measured 10 % slower in the row classes) is done sooner as many thin wavefronts, and a launch
+// of 10^5 and more (C2skew, C3) sooner with 1.4 x fewer instructions. Items of one call (host path) / one ranking iteration (device half) from which on the row classes are used.
 // DMND_SWEEP_ROWS (read per call: an A/B switch of the tests): 0 = never, 1 = always.
 int64_t dmnd::sweep_rows_min_items()
 {

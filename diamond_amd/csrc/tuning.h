@@ -23,7 +23,7 @@ struct Tuning {
 	int extend_runners = 1;            // DMND_EXTEND_RUNNERS
 	int extend_sub_threads = 0;        // DMND_EXTEND_SUB_THREADS: 0 = by the hits per runner
 	// ---- sweeps (api.hip sweep_rows_min_items)
-	int sweep_rows_min_items = 1 << 15; // DMND_SWEEP_ROWS_MIN: items of a launch set from which on bands of <= 96 / 160 diagonals take the row classes
+	int sweep_rows_min_items = 1 << 17; // DMND_SWEEP_ROWS_MIN: items of a launch set from which on bands of <= 96 / 160 diagonals take the row classes
 	int extend_resweep_below_pct = 40; // DMND_EXTEND_RESWEEP_BELOW_PCT: device half: an iteration of which at most this share of the targets can survive the culling is swept for scores only, its survivors again with traceback (0 = always keep trace rows)
 	// ---- streams
 	bool no_stream_priority = false;   // DMND_NO_STREAM_PRIORITY: every stream at the default priority

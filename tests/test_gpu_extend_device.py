@@ -54,7 +54,7 @@ def _check(m, recs):
 @pytest.mark.parametrize("arena_mb,rows", [(None, None), ("8", None), (None, "1"), ("8", "1")])
 def test_protein_search_is_extended_in_hbm_and_equals_the_reference(tap, arena_mb, rows, monkeypatch):
     """rows = "1": the row classes of the packed 16-bit sweeps (eight items per wavefront, swipe16_kernels.hip) whatever the number
-    of items -- by default only iterations of 32 768 items and more take them (tests/test_gpu_skew.py has such a block)."""
+    of items -- by default only iterations of 131 072 items and more take them (tests/test_gpu_skew.py has such a block)."""
     assert torch.cuda.is_available()
     if arena_mb:
         monkeypatch.setenv("DMND_TRACE_ARENA_MB", arena_mb)

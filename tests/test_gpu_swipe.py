@@ -235,7 +235,7 @@ def test_row_classes_take_any_number_of_items(ctx, n, monkeypatch):
     ctx.upload_block(hip.QUERY, qb)
     ctx.upload_block(hip.TARGET, tb)
     ctx.upload_cbs(cbs)
-    monkeypatch.setenv("DMND_SWEEP_ROWS", "1")        # (by default only calls of 32 768 items and more take the row classes)
+    monkeypatch.setenv("DMND_SWEEP_ROWS", "1")        # (by default only calls of 131 072 items and more take the row classes)
     res = {mode: ctx.banded_swipe(items, mode) for mode in (hip.SWIPE_SCORE, hip.SWIPE_COORDS, hip.SWIPE_TRACEBACK)}
     monkeypatch.setenv("DMND_SWEEP_ROWS", "0")
     off = {mode: ctx.banded_swipe(items, mode) for mode in (hip.SWIPE_SCORE, hip.SWIPE_COORDS, hip.SWIPE_TRACEBACK)}
