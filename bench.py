@@ -142,7 +142,7 @@ def scaling_model(out, ext, cpu_ms_per_step, cpus, step_ms, n_records, n_blocks,
     model["best"] = {n: {"decomposition": k, "predicted_ms_per_step": v, "predicted_speedup": step_ms / v} for n, (k, v) in best.items()}
     model["predicted_speedup"] = {n: step_ms / v for n, (k, v) in best.items()}
     model["note"] = ("host_cpu_ms_per_step is this run's (%d extension contexts, %d host threads); `bench.py --gpus N` shards by --shard (default db: the only one of the "
-                     "three whose N-rank exchange is implemented together with query; the 2 x N/2 split is priced here, not built)" % (ext_contexts, threads))
+                     "three a rank count below 4 allows besides query); the default at N > 1 is this model's best decomposition of the config's committed N = 1 line)" % (ext_contexts, threads))
     return model
 
 
@@ -218,10 +218,16 @@ class Workload:
         else:
             self.n_queries = queries
         # this rank's part of the job: its database blocks (one, unless the config names a block count) or its query slice
+        # "2d" (round 6): two query halves x world / 2 database shards -- rank r searches half r % 2 of the queries against shard r // 2
+        # (the reference's own multi-process mode hands out (query chunk x reference chunk) units: run/double_indexed.cpp:346-396)
         self.q_lo, self.q_hi = 0, self.n_queries
-        n_blocks = max(self.cfg.get("blocks", 1), world) if shard == "db" else 1
-        if world > 1 and shard != "db":
+        db_ranks, db_rank = (world, rank) if shard == "db" else (world // 2, rank // 2) if shard == "2d" else (1, 0)
+        n_blocks = max(self.cfg.get("blocks", 1), db_ranks) if shard in ("db", "2d") else 1
+        if world > 1 and shard == "query":
             self.q_lo, self.q_hi = multigpu.shard_range(self.n_queries, world, rank)
+        if world > 1 and shard == "2d":
+            assert world % 2 == 0 and world >= 4, "--shard 2d needs an even number of at least 4 ranks"
+            self.q_lo, self.q_hi = multigpu.shard_range(self.n_queries, 2, rank % 2)
         self.blocks = []                                     # (first sequence, one past the last, letters, limits) of every block of this rank
         # cut as the reference cuts reference blocks (SequenceFile::load_seqs: a block ends with the sequence that reaches the
         # block size), block size = total letters / blocks: the job equals the reference run with that -b
@@ -238,8 +244,8 @@ class Workload:
         else:
             cuts.append(self.n_db)
         n_blocks = len(cuts) - 1
-        assert n_blocks >= world or shard != "db", "fewer database blocks than ranks"
-        for b in range(rank if shard == "db" else 0, n_blocks, world if shard == "db" else 1):
+        assert n_blocks >= db_ranks, "fewer database blocks than ranks"
+        for b in range(db_rank, n_blocks, db_ranks):
             lo, hi = cuts[b], cuts[b + 1]
             t_off = self.doff[lo:hi + 1] - self.doff[lo]
             td, tl = workload.sequence_set(self.db[self.doff[lo]:self.doff[hi]], t_off)
@@ -383,7 +389,8 @@ def main():
     ap.add_argument("--queries", type=int, default=None, help="default: the config's (10000; C5: 100000)")
     ap.add_argument("--families", type=int, default=None, help="protein families of 10 members in the database (default 100000; C5: 500000)")
     ap.add_argument("--host-threads", type=int, default=None, help="host threads of the extension stage per rank, divided among the extension contexts (default 12, fewer per rank with several ranks)")
-    ap.add_argument("--shard", choices=["db", "query"], default="db")
+    ap.add_argument("--shard", choices=["db", "query", "2d"], default=None, help="N > 1: database shards (all queries each), query shards (the whole database each), or 2d = two query halves x N/2 "
+                    "database shards. Default: what the scaling model of the config's committed N = 1 line predicts to be fastest at this N (profiles/r06_bench_<config>.json scaling_model.best), db without one")
     ap.add_argument("--ext-contexts", type=int, default=None, help="batches extended concurrently, each on its own context and host thread team (default 3; 2 with several database blocks per rank)")
     ap.add_argument("--seed-contexts", type=int, default=None, help="seed stages in flight at the same time (own context and stream each; one with several database blocks per rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -433,10 +440,22 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     coll_device = torch.device("cpu") if share_gpu else device
+    if args.shard is None:
+        # the decomposition the scaling model of this config's committed N = 1 line predicts to be fastest at this rank count (the
+        # same choice on every rank: it is read from the repository, not measured here)
+        args.shard = "db"
+        try:
+            best = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_%s.json" % args.config)))["scaling_model"]["best"].get(str(world))
+            if world > 1 and best:
+                args.shard = {"db": "db", "query": "query", "2xN/2": "2d"}[best["decomposition"]]
+        except (OSError, KeyError, ValueError):
+            pass
+        if args.shard == "2d" and (world < 4 or world % 2):
+            args.shard = "db"
     # every rank of a database-sharded run extends 1/N of the seed hits: its host part needs correspondingly fewer threads, and N
     # ranks share the node's cores
     threads = max(1, args.host_threads) if args.host_threads else (12 if world == 1 else max(3, 24 // world))
-    many_blocks = CONFIGS[args.config].get("blocks", 1) > world
+    many_blocks = CONFIGS[args.config].get("blocks", 1) > (world // 2 if args.shard == "2d" else world)
     if many_blocks and not args.host_threads:
         threads = max(threads, min(16, cgroup_cpus()) // max(world, 1))      # the host part of 8 blocks per batch is the bound of C5 (measured: 86 -> 66 ms per step)
     long_seed_stage = CONFIGS[args.config]["sens"] not in ("fast", "default")
@@ -574,9 +593,12 @@ def main():
             state["joined_queries"] = int((q[1:] != q[:-1]).sum() + 1) if q.size else 0
             state["join_form"] = "records joined where dmnd_extend left them in HBM (dmnd_join_contexts_device)"
             return full
-        if world > 1 and args.shard == "db" or NB > 1:
-            # one copy of the records (the concatenation); block ids -> database ordinals in place
+        if world > 1 and args.shard in ("db", "2d") or NB > 1:
+            # one copy of the records (the concatenation); block ids -> database ordinals in place (2d: and the half's query numbers
+            # -> the job's: the exchange below is keyed by the job's query ranges whatever rank searched a query)
             mine = np.concatenate([np.ascontiguousarray(m, dtype=hip.MATCH_DTYPE) for m in parts])
+            if args.shard == "2d":
+                mine["query"] += np.uint32(w.q_lo)
             at = 0
             for b, m in enumerate(parts):
                 mine["target"][at:at + len(m)] += np.uint32(w.blocks[b][0])
@@ -911,7 +933,7 @@ def main():
     cells_swept = r1_cells + r2_swept
     records = state["records"]
     if world > 1:         # every rank holds the records of its own queries (its query shard, or the query range it joined)
-        n_aligned = torch.tensor([float(state["joined_queries"] if args.shard == "db" else np.unique(records["query"]).size)], dtype=torch.float64, device=coll_device)
+        n_aligned = torch.tensor([float(state["joined_queries"] if args.shard in ("db", "2d") else np.unique(records["query"]).size)], dtype=torch.float64, device=coll_device)
         dist.all_reduce(n_aligned, op=dist.ReduceOp.SUM)
         aligned = int(n_aligned.item())
     else:
@@ -937,7 +959,7 @@ def main():
                                      "definition cpu_baseline is quoted on",
                        "dp_arithmetic": "packed int16 (two work items per wavefront), items that saturate re-run in int32",
                        "host_threads": threads,
-                       "parallelism": ("%s-shard x%d (strong scaling of the fixed job)%s" % (args.shard, world, " + RCCL all-to-all of match records keyed by query range, rank g joins 1/N of the queries, gather to rank 0" if args.shard == "db" else "")) if world > 1 else "single GPU"},
+                       "parallelism": ("%s-shard x%d (strong scaling of the fixed job)%s" % (args.shard, world, " + RCCL all-to-all of match records keyed by query range, rank g joins 1/N of the queries, gather to rank 0" if args.shard in ("db", "2d") else "")) if world > 1 else "single GPU"},
             "extension": ext,
             **({"masked_step": masked_step} if masked_step is not None else {}),
             "swipe_kernel_gcups": {"round1": ext["round1_cells"] / max(ext["round1_swipe_kernel_ms"], 1e-9) / 1e6,
