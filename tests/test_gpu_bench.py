@@ -76,6 +76,25 @@ def test_bench_two_ranks_database_sharded_on_one_gpu():
     assert r.returncode != 0
 
 
+def test_bench_four_ranks_two_query_halves_times_two_database_shards():
+    """`--shard 2d` (round 6): rank r searches query half r % 2 against database shard r // 2; the records go through the same
+    query-range exchange as the database-sharded run. Four ranks on the one GPU (gloo), the job's records against the reference run
+    with the database cut into the same two blocks (`parity_checked`, made on rank 0 behind the teardown of the process group)."""
+    if not os.path.exists(REF):
+        pytest.fail("oracle/_ref/diamond_tap is missing: under -m gpu the reference binary is the checker, its absence is a failure")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--shard", "2d", "--queries", "1500", "--families", "3000", "--steps", "2", "--warmup", "1",
+           "--no-e2e", "--no-masked-step"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(env, DMND_BENCH_SHARE_GPU="1"), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["rccl"]["world_size"] == 4 and d["rccl"]["shard"] == "2d"
+    assert d["parity_checked"] is True, d.get("parity")
+    assert "2 blocks" in d["parity"]["note"]
+
+
 def test_bench_e2e_and_hot_path_baselines():
     """The whole-process comparison (diamond-hip against the reference binary on the same files) and the hot-path baseline
     (the reference's seed-stage + extension task timers) are on the bench line, md5-equal outputs for all three command lines."""
