@@ -20,8 +20,11 @@
 //     diagonals per lane, 96 / 160 per item, EIGHT items per wavefront. The shifts are row shifts (row_shr:1 / row_shl:1 stop at
 //     the row's ends, which are the bands' edges), the items' geometry and the edge records are per row, and the wavefront runs
 //     until its longest item is done. Bands of 61-81 / 131-161 diagonals -- most of them -- fill 0.63-0.84 / 0.82-1.0 of their lanes
-//     there against 0.48-0.63 / 0.51-0.63 in the classes 1 / 2, and the per-pair-step work that does not depend on P (five shifts,
-//     the edge record, the window moves) is shared by eight items instead of two.
+//     there against 0.48-0.63 / 0.51-0.63 in the classes 1 / 2. That is the whole gain: a cell costs the same 31 (18, 15.9 without
+//     end cells) VALU instructions in every class -- the shifts and window moves are a few per cent of a pair-step --, so the sweeps'
+//     instructions fall by the lane use (measured 1.42 x on C2skew). A wavefront of eight items is a longer dependency chain per
+//     anti-diagonal step, though: the row classes are taken when a launch set fills the chip (api.hip sweep_rows_min_items).
+//   * COORDS = false (DMND_SWIPE_SCORE, the device half's scores-first pass): one packed max per cell instead of the two end-cell keys.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
