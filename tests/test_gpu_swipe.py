@@ -113,9 +113,12 @@ def test_golden_reference_calls_with_adjusted_matrices(ctx, tap):
     ctx.upload_matrices(np.zeros((0, 32, 32), np.int8))
 
 
-def test_random_matrices_against_oracle(ctx):
+@pytest.mark.parametrize("rows", ["0", "1"])
+def test_random_matrices_against_oracle(ctx, rows, monkeypatch):
     """Every item with a random matrix of its own (or the context's, one in four), every band class up to the multi-wavefront
-    sweep, all modes incl. the statistics cells: equal to the oracle run on that matrix."""
+    sweep, all modes incl. the statistics cells: equal to the oracle run on that matrix. rows = "1": the items on the context's
+    matrix take the row classes of the packed sweeps where their bands fit, the others (32-bit kernels) never do."""
+    monkeypatch.setenv("DMND_SWEEP_ROWS", rows)
     M = hip.matrix_of(ctx.params)
     rng = np.random.default_rng(2024)
     recs = _random_items(rng, 240, M) + _random_items(rng, 60, M, wide=True)
