@@ -325,9 +325,13 @@ def _rescore(q, cbs, t, h, tr, M):
     return s, i, j
 
 
-def test_baseline_scale_properties(ctx):
+@pytest.mark.parametrize("rows", [None, "1"])
+def test_baseline_scale_properties(ctx, rows, monkeypatch):
     """C1-shaped synthetic workload (1k queries x 10k-seq DB, SURVEY.md 8d generator), ~20k DpTargets:
-    size-independent invariants instead of a per-item oracle."""
+    size-independent invariants instead of a per-item oracle. rows = "1": in the row classes of the packed sweeps (20 000 items
+    are below the count from which they are taken by default)."""
+    if rows:
+        monkeypatch.setenv("DMND_SWEEP_ROWS", rows)
     db, doff, q, qoff = synth.generate(1000, members=10, queries=1000, seed=1)
     rng = np.random.default_rng(2)
     # every query against 20 members: its own family is unknown here, so pair with random targets plus
