@@ -1098,8 +1098,9 @@ struct LmWide {
 };
 
 // left-most rule + emission over the scored list, whose size is only known on the device (~10 % of the survivors): a bounded grid
-// walks it in strides. (Up to round 6 the grid covered the upper bound, the number of survivors: on C3 70 000 workgroups per shape of
-// which nine in ten read the count and left -- 0.73 ms per launch, nearly all of it dispatch.)
+// walks it in strides (up to round 6 the grid covered the upper bound, the number of survivors: on C3 70 000 workgroups per shape of
+// which nine in ten read the count and left). 0.12-0.14 ms per C3 shape by itself; the 0.70 ms average of the committed C3 statistics
+// is what a small kernel shows when it shares the chip with the other seed stage's stream kernel, not work (tools/gpu_r06ab.sh).
 __global__ __launch_bounds__(256) void seed_leftmost_kernel(SeedArgs a, int sid, uint64_t map_lo, uint64_t map_hi, int reduction_ok)
 {
 	const int lane = threadIdx.x & 63;
