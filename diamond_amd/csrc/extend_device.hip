@@ -175,6 +175,9 @@ int dmnd::extend_on_device(dmnd_ctx* c, const DeviceCfg& h, const DevPlan& plan,
 		ctr = *c->ext_host.as<ExtCounters>();
 		if (iter == 0) tr.lap("items, launch order, trace offsets");
 		if (iter == 0 && ctr.n_items == 0) return DMND_OK;
+		// a call whose first ranking iteration took the row classes keeps them for its later, smaller iterations and for the copies
+		// of round 2 (they are short next to the first one, and a row launch of 10^5 items still beats the wavefront classes)
+		if (iter == 0 && ctr.n_items >= a.row_min_items && a.row_min_items > 4096) a.row_min_items = 4096;
 		// 2. round 1 (one launch per band class)
 		int64_t rel = 0;
 		bool kept = false;
